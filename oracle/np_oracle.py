@@ -1,0 +1,279 @@
+"""NumPy oracle: CPU restatement of desilike's theory -> observable -> Gaussian-likelihood hot path.
+
+TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module; the product path (``desilike_amd``) never does.
+
+Every function cites the reference file:line (relative to /root/reference/desilike) it restates.
+Parity pin: checked against golden vectors captured from the reference's own numpy path
+(``tests/golden/*.npz``, produced by ``tests/golden/make_golden.py``) in ``tests/test_oracle.py``
+for rows a1-a9, a14 of SURVEY.md section 8.  Rows that the reference cannot run here are marked
+"parity unpinned" where they are defined (FFTLog: third-party cosmoprimo absent; analytic
+marginalisation: needs jax; emulator forward: third-party) and are pinned by closed-form /
+brute-force identities instead.
+
+Everything is float64.
+"""
+import numpy as np
+from scipy import interpolate, special
+
+
+# ----------------------------------------------------------------------------------------------
+# a4: mu-quadrature                                            utils.py:625-643, tgc/base.py:201-208
+# ----------------------------------------------------------------------------------------------
+def weights_leggauss_sym(nmu):
+    """Gauss-Legendre nodes on (0, 1): leggauss(2n), positive half, symmetrised weights (sum = 1).
+
+    utils.py:625-630 (``weights_leggauss(nx, sym=True)``), used by ``weights_mu`` utils.py:633-643.
+    """
+    x, w = np.polynomial.legendre.leggauss(2 * nmu)
+    return x[nmu:], (w[nmu:] + w[nmu - 1::-1]) / 2.
+
+
+def multipole_weights(mu, wmu, ells):
+    """``wmu[ell, m] = w_m (2 ell + 1) L_ell(mu_m)``; tgc/base.py:201-204."""
+    return np.array([wmu * (2 * ell + 1) * special.legendre(ell)(mu) for ell in ells])
+
+
+# ----------------------------------------------------------------------------------------------
+# a1: Alcock-Paczynski                                               tgc/base.py:211-223, 325-353
+# ----------------------------------------------------------------------------------------------
+def ap_qparqper(mode, eta, **params):
+    """(qpar, qper) from the AP parameterisation; tgc/base.py:341-350."""
+    if mode == 'qiso':
+        return params['qiso'], params['qiso']
+    if mode == 'qap':
+        qap = params['qap']
+        return qap**(1 - eta), qap**(-eta)
+    if mode == 'qisoqap':
+        qiso, qap = params['qiso'], params['qap']
+        return qiso * qap**(1 - eta), qiso * qap**(-eta)
+    return params['qpar'], params['qper']
+
+
+def ap_k_mu(k, mu, qpar=1., qper=1.):
+    """tgc/base.py:211-223: returns jac, kap[k, mu], muap[k, mu]."""
+    qap = qpar / qper
+    jac = 1. / (qpar * qper**2)
+    factorap = np.sqrt(1 + mu**2 * (1. / qap**2 - 1))
+    kap = k[:, None] / qper * factorap
+    muap = mu / qap / factorap
+    return jac, kap, muap * np.ones_like(kap)
+
+
+# ----------------------------------------------------------------------------------------------
+# a2: templates                                 power_template.py:747-761, 592-596, 372-376, 198-202
+# ----------------------------------------------------------------------------------------------
+def shapefit_factor(k, kp, a, dm=0., dn=0.):
+    """power_template.py:749: exp(dm / a tanh(a ln(k / kp)) + dn ln(k / kp))."""
+    return np.exp(dm / a * np.tanh(a * np.log(k / kp)) + dn * np.log(k / kp))
+
+
+# ----------------------------------------------------------------------------------------------
+# a3: interp1d                                                                    jax.py:211-265
+# ----------------------------------------------------------------------------------------------
+def interp1d(xq, x, f, method='cubic'):
+    """numpy-backend branch jax.py:263-265: scipy not-a-knot cubic (or linear) with extrapolation."""
+    method = {1: 'linear', 3: 'cubic'}.get(method, method)
+    return interpolate.interp1d(x, f, kind=method, fill_value='extrapolate', axis=0)(xq)
+
+
+def notaknot_moments(x, y):
+    """Second derivatives M of the not-a-knot cubic spline through (x, y) (independent formulation).
+
+    This is NOT how scipy computes it (B-spline collocation); the interpolant is unique, so the
+    piecewise-cubic "moment" form used by the device kernel must agree to rounding.  Used to check
+    the kernel's spline formulation on CPU (``notaknot_eval`` vs ``interp1d``).
+    """
+    n = len(x)
+    h = np.diff(x)
+    A = np.zeros((n, n))
+    r = np.zeros(n)
+    for i in range(1, n - 1):
+        A[i, i - 1], A[i, i], A[i, i + 1] = h[i - 1], 2. * (h[i - 1] + h[i]), h[i]
+        r[i] = 6. * ((y[i + 1] - y[i]) / h[i] - (y[i] - y[i - 1]) / h[i - 1])
+    A[0, 0], A[0, 1], A[0, 2] = h[1], -(h[0] + h[1]), h[0]
+    A[-1, -3], A[-1, -2], A[-1, -1] = h[-1], -(h[-2] + h[-1]), h[-2]
+    return np.linalg.solve(A, r)
+
+
+def notaknot_eval(xq, x, y, M):
+    i = np.clip(np.searchsorted(x, xq, side='right') - 1, 0, len(x) - 2)
+    h = x[i + 1] - x[i]
+    a = (x[i + 1] - xq) / h
+    b = (xq - x[i]) / h
+    return a * y[i] + b * y[i + 1] + ((a**3 - a) * M[i] + (b**3 - b) * M[i + 1]) * h**2 / 6.
+
+
+# ----------------------------------------------------------------------------------------------
+# a4: Kaiser P(k, mu) -> multipole tables                          full_shape.py:488-500
+# ----------------------------------------------------------------------------------------------
+def kaiser_pktable(k, mu, wmu_ell, k11, pk11, f, qpar=1., qper=1., sigmapar=0., sigmaper=0.):
+    """Returns pk_dd, pk_dt, pk_tt, each [n_ell, n_k]; full_shape.py:488-500, to_poles tgc/base.py:206-208."""
+    jac, kap, muap = ap_k_mu(k, mu, qpar=qpar, qper=qper)
+    sigmanl2 = kap**2 * (sigmapar**2 * muap**2 + sigmaper**2 * (1. - muap**2))
+    damping = np.exp(-sigmanl2 / 2.)
+    pktable = jac * damping * interp1d(np.log10(kap), np.log10(k11), pk11, method='cubic')
+
+    def to_poles(pkmu):
+        return np.sum(pkmu * wmu_ell[:, None, :], axis=-1)
+
+    return to_poles(pktable), to_poles(f * muap**2 * pktable), to_poles(f**2 * muap**4 * pktable)
+
+
+# ----------------------------------------------------------------------------------------------
+# a5: tracer combine                                          full_shape.py:545-550, 628-634
+# ----------------------------------------------------------------------------------------------
+def kaiser_tracer_power(ells, pk_dd, pk_dt, pk_tt, nd, b1X, b1Y, sn0):
+    """full_shape.py:545-550 (cross-correlation aware: b1X b1Y dd + (b1X + b1Y) dt + tt + delta_l0 sn0 / nd)."""
+    sn = np.array([(ell == 0) for ell in ells], dtype='f8')[:, None] * sn0 / nd
+    return b1X * b1Y * pk_dd + (b1X + b1Y) * pk_dt + pk_tt + sn
+
+
+def eftlike_addon(power, ells, pk_dd, ct_matrix, ct_values, sn_matrix, sn_values, nd):
+    """full_shape.py:628-634: ``+ ct_matrix . (0.5 sum ct) * pk11[ell = 0] + sn_matrix . (sn / nd)``.
+
+    ct_matrix, sn_matrix: [n_ell, n_k, n_par]; ct_values already summed over the two tracers.
+    """
+    power = power.copy()
+    if ct_matrix.size:
+        power += ct_matrix.dot(0.5 * np.asarray(ct_values)) * pk_dd[list(ells).index(0)]
+    if sn_matrix.size:
+        power += sn_matrix.dot(np.asarray(sn_values) / nd)
+    return power
+
+
+# ----------------------------------------------------------------------------------------------
+# a6: window matrix                                                 window.py:14-68, 445-473
+# ----------------------------------------------------------------------------------------------
+def matrix_lininterp(xin, xout):
+    """utils.py:646-657."""
+    toret = np.zeros((len(xin), len(xout)), dtype='f8')
+    for iout, xo in enumerate(xout):
+        iin = np.searchsorted(xin, xo, side='right') - 1
+        if 0 <= iin < len(xin) - 1:
+            frac = (xo - xin[iin]) / (xin[iin + 1] - xin[iin])
+            toret[iin, iout] = 1. - frac
+            toret[iin + 1, iout] = frac
+        elif np.isclose(xo, xin[-1]):
+            toret[iin, iout] = 1.
+    return toret
+
+
+def window_matrix_bininteg(list_edges, resolution=1):
+    """window.py:14-68: binning matrix in the continuous limit; returns xin, matrix [n_in_total, n_out_total]."""
+    resolution = int(resolution)
+    step = min((edges[..., 1] - edges[..., 0]).min() for edges in list_edges) / resolution
+    start, stop = min(np.min(edges) for edges in list_edges), max(np.max(edges) for edges in list_edges)
+    edgesin = np.arange(start, stop + step / 2., step)
+    xin = 3. / 4. * (edgesin[1:]**4 - edgesin[:-1]**4) / (edgesin[1:]**3 - edgesin[:-1]**3)
+    matrices = []
+    for edges in list_edges:
+        x, w = [], []
+        for ibin, edge in enumerate(edges):
+            edge = np.linspace(*edge, resolution + 1)
+            x.append(3. / 4. * (edge[1:]**4 - edge[:-1]**4) / (edge[1:]**3 - edge[:-1]**3))
+            line = np.zeros(len(edges) * resolution, dtype='f8')
+            tmp = edge[1:]**3 - edge[:-1]**3
+            line[ibin * resolution:(ibin + 1) * resolution] = tmp / tmp.sum()
+            w.append(line)
+        matrices.append(matrix_lininterp(xin, np.concatenate(x)).dot(np.column_stack(w)))
+    n = len(matrices)
+    full = np.block([[matrices[i] if i == j else np.zeros_like(matrices[j]) for j in range(n)] for i in range(n)])
+    return xin, full
+
+
+def window_apply(power, matrix_full=None, offset=None, kmask=None, shotnoisein=None, shotnoiseout=None):
+    """window.py:459-473: ``W . ravel(power + sn_in[:, None]) (+ offset) [kmask] - sn_out``."""
+    theory = power
+    if shotnoisein is not None:
+        theory = theory + np.asarray(shotnoisein)[:, None]
+    theory = np.ravel(theory)
+    if matrix_full is not None:
+        theory = np.dot(matrix_full, theory)
+    if offset is not None:
+        theory = theory + offset
+    if kmask is not None:
+        theory = theory[kmask]
+    if shotnoiseout is not None:
+        theory = theory - shotnoiseout
+    return theory
+
+
+# ----------------------------------------------------------------------------------------------
+# a7: observable                                                   power_spectrum.py:400-404
+# ----------------------------------------------------------------------------------------------
+def observable_transform(flattheory, flatdata, transform=None):
+    if transform == 'cubic':
+        return (3. * (flattheory / flatdata)**(1. / 3.) - 2.) * flatdata
+    return flattheory
+
+
+# ----------------------------------------------------------------------------------------------
+# a8: Gaussian chi2                                         likelihoods/base.py:13-17, 658-660
+# ----------------------------------------------------------------------------------------------
+def chi2(flatdiff, precision):
+    if precision.ndim == 1:
+        return (flatdiff * precision).dot(flatdiff.T)
+    return flatdiff.dot(precision).dot(flatdiff.T)
+
+
+def gaussian_loglikelihood(flattheory, flatdata, precision):
+    """flatdiff = theory - data (likelihoods/base.py:659); logL = -chi2/2."""
+    flatdiff = flattheory - flatdata
+    return -0.5 * chi2(flatdiff, precision), flatdiff
+
+
+# ----------------------------------------------------------------------------------------------
+# a9: priors                                                parameter.py:1889-1897, 1994-2017
+# ----------------------------------------------------------------------------------------------
+def prior_logpdf(x, dist='uniform', limits=(-np.inf, np.inf), loc=0., scale=1.):
+    """Zero-lag-removed log-pdf, closed limits; parameter.py:1994-2007 (uniform and norm fast paths)."""
+    isin = (limits[0] <= x) & (x <= limits[1])
+    if dist == 'uniform':
+        return np.where(isin, 0., -np.inf)
+    if dist == 'norm':
+        return np.where(isin, -0.5 * (x - loc)**2 / scale**2, -np.inf)
+    raise NotImplementedError(dist)
+
+
+def logprior(theta, priors):
+    """Sum over varied, non-solved parameters; parameter.py:1889-1897. theta[..., P]; priors: list of dict."""
+    theta = np.asarray(theta, dtype='f8')
+    toret = np.zeros(theta.shape[:-1])
+    for i, prior in enumerate(priors):
+        toret = toret + prior_logpdf(theta[..., i], **prior)
+    return toret
+
+
+# ----------------------------------------------------------------------------------------------
+# Whole full-shape evaluation for one point (rows a1-a9 chained as in SURVEY.md section 3.1)
+# ----------------------------------------------------------------------------------------------
+def fullshape_observable(c, p):
+    """One observable of a full-shape likelihood at one parameter point.
+
+    ``c``: dict of constants (see ``tests/golden/make_golden.py`` for the layout), ``p``: dict of
+    model inputs (qpar, qper, df, dm, dn, b1 (tuple of 2), sn0, sigmapar, sigmaper, + EFT terms).
+    Returns dict of every intermediate.
+    """
+    out = {}
+    k11 = c['k11']
+    if c['template'] == 'shapefit':
+        factor = shapefit_factor(k11, c['kp'], c['a'], dm=p.get('dm', 0.), dn=p.get('dn', 0.))
+        pk11 = c['pk_dd_fid'] * factor
+    else:  # fixed / standard / bao: power_template.py:107-108
+        pk11 = c['pk_dd_fid']
+    f = c['f_fid'] * p.get('df', 1.)
+    out['pk_dd_template'], out['f'] = pk11, f
+    dd, dt, tt = kaiser_pktable(c['kin'], c['mu'], c['wmu_ell'], k11, pk11, f, qpar=p.get('qpar', 1.), qper=p.get('qper', 1.),
+                                sigmapar=p.get('sigmapar', 0.), sigmaper=p.get('sigmaper', 0.))
+    out['pk_dd'], out['pk_dt'], out['pk_tt'] = dd, dt, tt
+    b1X, b1Y = p['b1']
+    power = kaiser_tracer_power(c['ellsin'], dd, dt, tt, c['nd'], b1X, b1Y, p.get('sn0', 0.))
+    if c.get('ct_matrix', None) is not None:
+        power = eftlike_addon(power, c['ellsin'], dd, c['ct_matrix'], p['ct'], c['sn_matrix'], p['sn'], c['nd'])
+    out['power'] = power
+    flat = window_apply(power, matrix_full=c.get('matrix_full', None), offset=c.get('offset', None), kmask=c.get('kmask', None),
+                        shotnoisein=c.get('shotnoisein', None), shotnoiseout=c.get('shotnoiseout', None))
+    out['flatpower'] = flat
+    out['flattheory'] = observable_transform(flat, c['flatdata'], c.get('transform', None))
+    return out

@@ -1,0 +1,229 @@
+"""Generate golden vectors by running the *reference* (cosmodesi/desilike at /root/reference) here.
+
+Run from the repo root, in the build container only (the reference never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+The reference is imported through ``tests/golden/refstub`` (our own stand-in for its missing
+third-party deps cosmoprimo / lsstypes: a synthetic analytic cosmology).
+desilike's own arithmetic downstream of ``pk_dd_fid[k]``, ``f_fid`` runs unmodified (numpy backend:
+scipy not-a-knot cubic ``interp1d``).  Outputs: small ``.npz`` fixtures in this directory holding
+inputs (constants extracted from the *initialised reference calculators*), the theta batch, and every
+intermediate + loglikelihood / logprior returned by the reference.
+"""
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(here, 'refstub'))
+sys.path.insert(0, '/root/reference')
+sys.path.insert(0, os.path.dirname(os.path.dirname(here)))
+warnings.filterwarnings('ignore')
+
+from desilike.theories.galaxy_clustering import (ShapeFitPowerSpectrumTemplate, FixedPowerSpectrumTemplate, StandardPowerSpectrumTemplate,
+                                                 KaiserTracerPowerSpectrumMultipoles, EFTLikeKaiserTracerPowerSpectrumMultipoles)
+from desilike.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+from desilike.likelihoods import ObservablesGaussianLikelihood
+from desilike.base import vmap
+
+
+def prior_spec(param):
+    prior = param.prior
+    spec = dict(dist=prior.dist, lo=float(prior.limits[0]), hi=float(prior.limits[1]), loc=0., scale=1.)
+    if prior.dist == 'norm':
+        spec.update(loc=float(prior.attrs['loc']), scale=float(prior.attrs['scale']))
+    return spec
+
+
+def extract_observable(obs):
+    """Constants of one TracerPowerSpectrumMultipolesObservable, read off the initialised reference objects."""
+    wm = obs.wmatrix
+    theory = wm.theory
+    pt = theory.pt
+    template = pt.template
+    c = {}
+    c['ells'] = np.array(wm.ells)
+    c['ellsin'] = np.array(wm.ellsin)
+    c['kin'] = np.asarray(pt.k)
+    c['kout'] = np.concatenate(wm.k)
+    c['mu'], c['wmu_ell'] = np.asarray(pt.mu), np.asarray(pt.wmu)
+    c['k11'] = np.asarray(template.k)
+    c['pk_dd_fid'] = np.asarray(template.pk_dd_fid)
+    if getattr(template, 'with_now', False):
+        c['pknow_dd_fid'] = np.asarray(template.pknow_dd_fid)
+    c['f_fid'] = float(template.f_fid)
+    c['template'] = template.__class__.__name__
+    if hasattr(template, 'kp'):
+        c['kp'], c['a'] = template.kp, template.a
+    c['nd'] = theory.nd
+    if wm.matrix_full is not None: c['matrix_full'] = np.asarray(wm.matrix_full)
+    if wm.offset is not None: c['offset'] = np.asarray(wm.offset)
+    if wm.kmask is not None: c['kmask'] = np.asarray(wm.kmask)
+    c['shotnoisein'], c['shotnoiseout'] = np.asarray(wm.shotnoisein), np.asarray(wm.shotnoiseout)
+    c['flatdata'] = np.asarray(obs.flatdata)
+    if hasattr(theory, 'counterterm_matrix'):
+        c['ct_matrix'] = np.asarray(theory.counterterm_matrix)
+        c['sn_matrix'] = np.asarray(theory.stochastic_matrix)
+        c['ct_params'] = np.array(theory.counterterm_params)
+        c['sn_params'] = np.array(theory.stochastic_params)
+    return c
+
+
+def run_batch(likelihood, observables, theta, names, nint=8):
+    """Reference evaluation: vmap over the batch (base.py:232-258) + per-point intermediates for the first nint rows."""
+    vlike = vmap(likelihood, backend=None, errors='return', return_derived=True)
+    t0 = time.time()
+    (logpost, derived), errors = vlike({name: theta[:, i] for i, name in enumerate(names)})
+    dt = time.time() - t0
+    out = {'logposterior': np.asarray(logpost),
+           'loglikelihood': np.asarray(derived[likelihood._param_loglikelihood]),
+           'logprior': np.asarray(derived[likelihood._param_logprior]),
+           'ref_seconds_per_eval': dt / len(theta), 'nerrors': len(errors)}
+    inter = {name: [] for name in ['pk_dd_template', 'pk_dd', 'pk_dt', 'pk_tt', 'power', 'flatpower', 'flatdiff']}
+    flattheory = []
+    for row in theta:
+        likelihood(**dict(zip(names, row)))
+        flattheory.append(np.asarray(likelihood.flattheory))
+    for row in theta[:nint]:
+        likelihood(**dict(zip(names, row)))
+        for iobs, obs in enumerate(observables):
+            pt = obs.wmatrix.theory.pt
+            inter['pk_dd_template'].append(np.asarray(pt.template.pk_dd))
+            for name in ['pk_dd', 'pk_dt', 'pk_tt']:
+                inter[name].append(np.asarray(pt.pktable[name]))
+            inter['power'].append(np.asarray(obs.wmatrix.theory.power))
+            inter['flatpower'].append(np.asarray(obs.wmatrix.flatpower))
+        inter['flatdiff'].append(np.asarray(likelihood.flatdiff))
+    out['flattheory'] = np.array(flattheory)
+    nobs = len(observables)
+    for name, value in inter.items():
+        value = np.array(value)
+        if name != 'flatdiff':
+            value = value.reshape((min(nint, len(theta)), nobs) + value.shape[1:])
+        out['int_' + name] = value
+    return out
+
+
+def sample_theta(likelihood, size, seed):
+    """theta ~ Parameter.ref (samplers/base.py:222-230), RandomState(seed)."""
+    rng = np.random.RandomState(seed)
+    cols = []
+    for param in likelihood.varied_params:
+        if param.ref.is_proper():
+            cols.append(param.ref.sample(size=size, random_state=rng))
+        else:
+            cols.append(np.full(size, param.value))
+    return np.column_stack(cols)
+
+
+def save(name, **arrays):
+    flat = {}
+    for key, value in arrays.items():
+        if isinstance(value, dict):
+            for k, v in value.items():
+                flat['{}.{}'.format(key, k)] = v
+        else:
+            flat[key] = value
+    fn = os.path.join(here, name + '.npz')
+    np.savez_compressed(fn, **flat)
+    print('saved', fn, '{:.1f} kB'.format(os.path.getsize(fn) / 1e3))
+
+
+def dense_window(kedges, ells, resolution=10, seed=7):
+    """Synthetic survey-like dense window: bininteg (x) smooth Gaussian mixing kernel + 5 % ell-leakage (SURVEY 8d cfg 2)."""
+    from oracle.np_oracle import window_matrix_bininteg
+    edges = np.column_stack([kedges[:-1], kedges[1:]])
+    kin, binmat = window_matrix_bininteg([edges] * len(ells), resolution=resolution)
+    binmat = binmat.T  # [n_out, n_in]
+    nin = kin.size
+    dk = kin[:, None] - kin[None, :]
+    smooth = np.exp(-0.5 * (dk / 0.004)**2)
+    smooth /= smooth.sum(axis=1)[:, None]
+    nl = len(ells)
+    mix = np.zeros((nl * nin, nl * nin))
+    for i in range(nl):
+        for j in range(nl):
+            mix[i * nin:(i + 1) * nin, j * nin:(j + 1) * nin] = smooth * (1. if i == j else 0.05 / (1 + abs(i - j)))
+    rng = np.random.RandomState(seed)
+    wmat = binmat.dot(mix) * (1. + 0.01 * rng.standard_normal((binmat.shape[0], mix.shape[1])))
+    return kin, wmat
+
+
+def spd_covariance(n, seed=0, diag=1e4, amp=30.):
+    rng = np.random.RandomState(seed)
+    A = rng.standard_normal((n, n)) * amp
+    return A.dot(A.T) + diag * np.eye(n)
+
+
+def special_rows(theta, names):
+    """Append rows outside the prior and with NaN (SURVEY 8a row a14 conventions)."""
+    theta = theta.copy()
+    iq, ib = names.index('qpar'), names.index('b1')
+    theta[-1, iq] = 1.3       # outside uniform prior [0.8, 1.2] -> logprior = -inf
+    theta[-2, ib] = -0.5      # outside [0, 4]
+    theta[-3, ib] = 4.        # exactly on the (closed) upper limit -> finite
+    return theta
+
+
+def cfg1():
+    """BASELINE config 1: Kaiser ell=(0, 2), 40 k-bins, no window, Gaussian likelihood, single evals."""
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    theory = KaiserTracerPowerSpectrumMultipoles(template=template)
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2.}, kedges=np.linspace(0., 0.2, 41), ells=(0, 2), theory=theory, shotnoise=1e4)
+    cov = spd_covariance(80, seed=0)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+    assert abs(like(b1=2.)) < 1e-20
+    names = like.varied_params.names()
+    theta = special_rows(sample_theta(like, 16, seed=42), names)
+    out = run_batch(like, [obs], theta, names)
+    save('cfg1_kaiser_nowindow', names=np.array(names), theta=theta, obs0=extract_observable(obs), precision=np.asarray(like.precision), covariance=cov,
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]), **out)
+
+
+def cfg2(dense=False):
+    """BASELINE config 2: ShapeFit + Kaiser ell=(0, 2, 4), 40 k-bins, window (binning res=10, or dense synthetic), 64 points."""
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    theory = KaiserTracerPowerSpectrumMultipoles(template=template)
+    kedges = np.linspace(0., 0.2, 41)
+    if dense:
+        kin, wmat = dense_window(kedges, (0, 2, 4))
+        obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2.}, kedges=kedges, ells=(0, 2, 4), wmatrix=wmat, kin=kin, ellsin=(0, 2, 4), theory=theory, shotnoise=1e4)
+    else:
+        obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2.}, kedges=kedges, ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=1e4)
+    cov = spd_covariance(120, seed=1)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+    assert abs(like(b1=2.)) < 1e-18, like(b1=2.)
+    names = like.varied_params.names()
+    theta = special_rows(sample_theta(like, 64, seed=42), names)
+    out = run_batch(like, [obs], theta, names)
+    print('cfg2 dense={} reference: {:.1f} evals/s'.format(dense, 1. / out['ref_seconds_per_eval']))
+    save('cfg2_shapefit_window' + ('_dense' if dense else ''), names=np.array(names), theta=theta, obs0=extract_observable(obs), precision=np.asarray(like.precision), covariance=cov,
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]), **out)
+
+
+def cfg2_variants():
+    """Damping on (sigmapar, sigmaper varied), dn varied, diagonal precision, qisoqap AP mode, EFT-like terms."""
+    template = ShapeFitPowerSpectrumTemplate(z=0.5, apmode='qisoqap')
+    template.init.params['dn'].update(fixed=False)
+    theory = EFTLikeKaiserTracerPowerSpectrumMultipoles(template=template)
+    for name in ['sigmapar', 'sigmaper']:
+        theory.init.params[name].update(fixed=False, ref=dict(dist='norm', loc=4., scale=0.5))
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'sigmapar': 4., 'sigmaper': 3.}, kedges=np.linspace(0.01, 0.2, 39), ells=(0, 2, 4), wmatrix={'resolution': 3}, theory=theory, shotnoise=1e4)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=np.diag(1. / np.linspace(1e-4, 3e-4, 114)))
+    like()
+    names = like.varied_params.names()
+    theta = sample_theta(like, 24, seed=3)
+    out = run_batch(like, [obs], theta, names)
+    save('cfg2v_eft_damping_qisoqap', names=np.array(names), theta=theta, obs0=extract_observable(obs), precision=np.asarray(like.precision),
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]), **out)
+
+
+if __name__ == '__main__':
+    cfg1()
+    cfg2(dense=False)
+    cfg2(dense=True)
+    cfg2_variants()
