@@ -1,0 +1,183 @@
+"""ctypes binding of the C ABI declared in ``include/desilike_amd.h`` (thin: plain pointers and sizes).
+
+The shared library holds the hand-written HIP kernels for gfx950.  There is NO CPU fallback:
+if the library is missing, or no GPU is visible, evaluation raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libdesilike_amd.so')
+_lib = None
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+# every symbol include/desilike_amd.h declares: (restype, argtypes)
+SYMBOLS = {
+    'dl_config_new': (ctypes.c_void_p, []),
+    'dl_config_set_f64': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_double_p, ctypes.c_int64]),
+    'dl_config_set_i32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_int32_p, ctypes.c_int64]),
+    'dl_config_free': (None, [ctypes.c_void_p]),
+    'dl_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
+    'dl_destroy': (None, [ctypes.c_void_p]),
+    'dl_last_error': (ctypes.c_char_p, [ctypes.c_void_p]),
+    'dl_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
+    'dl_eval_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_eval_theory': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_eval_batch_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_int32_p]),
+    'dl_eval_theory_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, ctypes.c_int32, _c_double_p, _c_double_p]),
+    'dl_profile_enable': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'dl_profile_read': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int32]),
+}
+
+
+class LibraryError(RuntimeError):
+    """Raised when the HIP library is missing or a C-ABI call fails."""
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load ``libdesilike_amd.so`` (built by ``__graft_entry__.build()`` / ``make -C desilike_amd/csrc``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_LIB_PATH):
+            raise LibraryError('HIP library {} not found: build it with `python -c "import __graft_entry__ as g; g.build()"`; there is no CPU fallback'.format(_LIB_PATH))
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (restype, argtypes) in SYMBOLS.items():
+            func = getattr(lib, name)
+            func.restype, func.argtypes = restype, argtypes
+        _lib = lib
+    return _lib
+
+
+def _f64_ptr(array):
+    return None if array is None else array.ctypes.data_as(_c_double_p)
+
+
+def _i32_ptr(array):
+    return None if array is None else array.ctypes.data_as(_c_int32_p)
+
+
+def fill_config(spec, set_f64, set_i32):
+    """Flatten a likelihood ``spec`` (nested dict, see ``desilike_amd.compile``) into config keys (include/desilike_amd.h).
+
+    ``set_f64(key, float64 array)`` and ``set_i32(key, int32 array)`` receive contiguous 1-D arrays.
+    """
+    def put(key, value):
+        value = np.asarray(value)
+        if value.dtype.kind in 'iub':
+            set_i32(key, np.ascontiguousarray(value.ravel(), dtype=np.int32))
+        else:
+            set_f64(key, np.ascontiguousarray(value.ravel(), dtype=np.float64))
+
+    for key, value in spec.items():
+        if key == 'observables':
+            for iobs, obs in enumerate(value):
+                for okey, ovalue in obs.items():
+                    if okey == 'inputs':
+                        for name, (col, const) in ovalue.items():
+                            if name in ('ct', 'sn'):
+                                put('obs{:d}.in.{}'.format(iobs, name), np.array([[c, v] for c, v in zip(np.ravel(col), np.ravel(const))], dtype='f8'))
+                            else:
+                                put('obs{:d}.in.{}'.format(iobs, name), np.array([col, const], dtype='f8'))
+                    elif ovalue is not None:
+                        put('obs{:d}.{}'.format(iobs, okey), ovalue)
+            put('n_obs', np.array([len(value)], dtype='i4'))
+        elif value is not None:
+            put(key, value)
+
+
+class Context(object):
+    """Owner of one ``dl_ctx`` (device constants + workspaces) on one GPU."""
+
+    def __init__(self, spec, device=0):
+        lib = load()
+        cfg = lib.dl_config_new()
+        keep = []
+
+        def set_f64(key, array):
+            keep.append(array)
+            if lib.dl_config_set_f64(cfg, key.encode(), _f64_ptr(array), array.size): raise LibraryError(lib.dl_last_error(None).decode())
+
+        def set_i32(key, array):
+            keep.append(array)
+            if lib.dl_config_set_i32(cfg, key.encode(), _i32_ptr(array), array.size): raise LibraryError(lib.dl_last_error(None).decode())
+
+        try:
+            fill_config(spec, set_f64, set_i32)
+            handle = ctypes.c_void_p()
+            rc = lib.dl_create(ctypes.byref(handle), int(device), cfg)
+        finally:
+            lib.dl_config_free(cfg)
+        if rc != 0:
+            raise LibraryError(lib.dl_last_error(None).decode())
+        self._lib, self._handle, self.device = lib, handle, int(device)
+        self.n_params, self.n_data, self.n_obs = (self.info(name) for name in ['n_params', 'n_data', 'n_obs'])
+
+    def info(self, key):
+        return int(self._lib.dl_info(self._handle, key.encode()))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise LibraryError(self._lib.dl_last_error(self._handle).decode())
+
+    def close(self):
+        if getattr(self, '_handle', None):
+            self._lib.dl_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-pointer entry points (numpy in / numpy out) ----
+    def eval_batch_host(self, theta, return_flattheory=False):
+        theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
+        if theta.shape[1] != self.n_params:
+            raise ValueError('theta must have shape (B, {:d}), found {}'.format(self.n_params, theta.shape))
+        B = theta.shape[0]
+        loglike, logprior, status = np.empty(B, dtype='f8'), np.empty(B, dtype='f8'), np.empty(B, dtype='i4')
+        flat = np.empty((B, self.n_data), dtype='f8') if return_flattheory else None
+        self._check(self._lib.dl_eval_batch_host(self._handle, _f64_ptr(theta), B, _f64_ptr(loglike), _f64_ptr(logprior), _f64_ptr(flat), _i32_ptr(status)))
+        return (loglike, logprior, status, flat) if return_flattheory else (loglike, logprior, status)
+
+    def eval_theory_host(self, theta, iobs=0, return_tables=False):
+        theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
+        B = theta.shape[0]
+        n_ell, n_kin = self.info('n_ell_obs{:d}'.format(iobs)), self.info('n_kin_obs{:d}'.format(iobs))
+        power = np.empty((B, n_ell, n_kin), dtype='f8')
+        tables = np.empty((B, 3, n_ell, n_kin), dtype='f8') if return_tables else None
+        self._check(self._lib.dl_eval_theory_host(self._handle, _f64_ptr(theta), B, int(iobs), _f64_ptr(power), _f64_ptr(tables)))
+        return (power, tables) if return_tables else power
+
+    # ---- device-pointer entry points (torch tensors as the array container) ----
+    def eval_batch(self, theta, loglike=None, logprior=None, flattheory=None, status=None, stream=None):
+        """All arguments are CUDA(ROCm) torch tensors on this context's device; asynchronous on ``stream``."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(theta.device).cuda_stream
+        B = theta.shape[0]
+        assert theta.is_contiguous() and theta.dtype == torch.float64 and theta.shape[1] == self.n_params
+
+        def ptr(tensor, dtype, shape):
+            if tensor is None: return None
+            assert tensor.is_contiguous() and tensor.dtype == dtype and tuple(tensor.shape) == shape, (tensor.shape, shape)
+            return ctypes.c_void_p(tensor.data_ptr())
+
+        self._check(self._lib.dl_eval_batch(self._handle, ctypes.c_void_p(theta.data_ptr()), B, ptr(loglike, torch.float64, (B,)), ptr(logprior, torch.float64, (B,)),
+                                            ptr(flattheory, torch.float64, (B, self.n_data)), ptr(status, torch.int32, (B,)), ctypes.c_void_p(stream)))
+
+    def profile_enable(self, enable=True):
+        self._check(self._lib.dl_profile_enable(self._handle, int(bool(enable))))
+
+    def profile_read(self):
+        ms = np.zeros(4, dtype='f8')
+        self._check(self._lib.dl_profile_read(self._handle, _f64_ptr(ms), 4))
+        return dict(theory=ms[0], window_gemm=ms[1], finalize=ms[2], total=ms[3])

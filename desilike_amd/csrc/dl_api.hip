@@ -1,0 +1,386 @@
+// dl_api.hip -- C ABI (include/desilike_amd.h) over the gfx950 kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/desilike_amd.h"
+#include "dl_host.hpp"
+#include "dl_kernels.h"
+
+static thread_local std::string g_last_error;
+
+struct dl_ctx {
+    int device = 0;
+    int n_params = 0, n_obs = 0, n_data = 0;
+    int N_pad = 0, K_pad = 0, max_n_t = 0;
+    bool any_transform = false;
+    std::vector<DlObsHost> obs;
+    std::vector<int> obs_row0;       // first data row of each observable
+    // device constants
+    double* arena_dev = nullptr;     // per-observable theory constants
+    DlObsDev* obs_dev = nullptr;
+    double* priors_dev = nullptr;    // [P, 5]
+    double* wt_white_dev = nullptr;  // [N_pad, K_pad]  L^T . blockdiag(W_obs)          (chi2 path)
+    double* bias_white_dev = nullptr;// [N_pad]         L^T . (bias - flatdata)
+    double* wt_full_dev = nullptr;   // [N_pad, K_pad]  blockdiag(W_obs)                 (flattheory path)
+    double* bias_full_dev = nullptr; // [N_pad]
+    double* wh_dev = nullptr;        // [N_pad, N_pad]  L^T                              (transform path)
+    double* bias_wh_dev = nullptr;   // [N_pad]        -L^T . flatdata
+    double* flatdata_dev = nullptr;  // [N_pad]
+    int32_t* transform_dev = nullptr;// [N_pad]
+    // workspaces (grown on demand, never inside dl_eval_* once large enough)
+    int64_t cap = 0;
+    double* power_ws = nullptr;      // [cap, K_pad]
+    double* delta_ws = nullptr;      // [cap, N_pad]
+    double* flat_ws = nullptr;       // [cap, N_pad]  (transform path / flattheory staging)
+    // host staging for the *_host entry points
+    int64_t stage_cap = 0;
+    double* theta_stage = nullptr;   // device
+    double* out_stage = nullptr;     // device: loglike[cap] | logprior[cap]
+    int32_t* status_stage = nullptr; // device
+    // profiling
+    bool profile = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::string last_error;
+};
+
+#define DL_HIP_CHECK(ctx, call)                                                                                  \
+    do {                                                                                                         \
+        hipError_t err__ = (call);                                                                               \
+        if (err__ != hipSuccess) {                                                                               \
+            std::string msg__ = std::string(#call) + ": " + hipGetErrorString(err__);                            \
+            if (ctx) (ctx)->last_error = msg__;                                                                  \
+            g_last_error = msg__;                                                                                \
+            return 1;                                                                                            \
+        }                                                                                                        \
+    } while (0)
+
+static int dl_fail(dl_ctx* ctx, const std::string& msg) {
+    if (ctx) ctx->last_error = msg;
+    g_last_error = msg;
+    return 1;
+}
+
+template <typename T>
+static int dl_upload(dl_ctx* ctx, T** dst, const std::vector<T>& src) {
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    DL_HIP_CHECK(ctx, hipMalloc((void**)dst, bytes));
+    if (!src.empty()) DL_HIP_CHECK(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" {
+
+dl_config* dl_config_new(void) { return new dl_config(); }
+
+int dl_config_set_f64(dl_config* cfg, const char* key, const double* data, int64_t n) {
+    if (!cfg || !key || (n > 0 && !data) || n < 0) { g_last_error = "dl_config_set_f64: invalid argument"; return 1; }
+    cfg->f64[key] = std::vector<double>(data, data + n);
+    return 0;
+}
+
+int dl_config_set_i32(dl_config* cfg, const char* key, const int32_t* data, int64_t n) {
+    if (!cfg || !key || (n > 0 && !data) || n < 0) { g_last_error = "dl_config_set_i32: invalid argument"; return 1; }
+    cfg->i32[key] = std::vector<int32_t>(data, data + n);
+    return 0;
+}
+
+void dl_config_free(dl_config* cfg) { delete cfg; }
+
+const char* dl_last_error(const dl_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
+    if (!out || !cfg) { g_last_error = "dl_create: null argument"; return 1; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_last_error = "dl_create: no HIP device available (this library has no CPU fallback)";
+        return 1;
+    }
+    if (device < 0 || device >= ndev) { g_last_error = "dl_create: device ordinal out of range"; return 1; }
+    dl_ctx* ctx = new dl_ctx();
+    ctx->device = device;
+    auto bail = [&](const std::string& msg) { g_last_error = msg; dl_destroy(ctx); return 1; };
+    if (hipSetDevice(device) != hipSuccess) return bail("dl_create: hipSetDevice failed");
+    ctx->n_params = cfg->i("n_params", -1);
+    ctx->n_obs = cfg->i("n_obs", -1);
+    if (ctx->n_params < 1 || ctx->n_obs < 1) return bail("dl_create: n_params and n_obs must be set (>= 1)");
+    const auto& priors = cfg->F("priors");
+    if ((int)priors.size() != 5 * ctx->n_params) return bail("dl_create: priors must have 5 entries per parameter");
+    // ---- observables ----
+    DlArena arena;
+    ctx->obs.resize(ctx->n_obs);
+    std::string err;
+    int64_t col = 0;
+    int row = 0;
+    for (int i = 0; i < ctx->n_obs; ++i) {
+        if (!dl_build_obs(*cfg, i, ctx->n_params, ctx->obs[i], arena, err)) return bail("dl_create: " + err);
+        ctx->obs[i].dev.col_offset = col;
+        col += ctx->obs[i].dev.n_in;
+        ctx->obs_row0.push_back(row);
+        row += ctx->obs[i].n_out;
+        ctx->max_n_t = std::max(ctx->max_n_t, ctx->obs[i].dev.n_t);
+        if (ctx->obs[i].dev.transform != 0) ctx->any_transform = true;
+    }
+    if (dl_fs_shared_doubles(ctx->max_n_t) * sizeof(double) > 160 * 1024) return bail("dl_create: template too large for LDS (n_t <= 6800)");
+    ctx->n_data = row;
+    int n = ctx->n_data;
+    int K = (int)col;
+    ctx->K_pad = round_up(K, 32);
+    ctx->N_pad = round_up(n, 32);
+    // ---- precision -> Cholesky factor (likelihoods/base.py:13-17: chi2 = d P d = |L^T d|^2) ----
+    const auto& prec = cfg->F("precision");
+    std::vector<double> L((size_t)n * n, 0.);
+    if ((int64_t)prec.size() == (int64_t)n * n) {
+        L = prec;
+        // symmetrise (the reference uses the matrix as given in d.P.d, which only sees the symmetric part)
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j) { double v = 0.5 * (L[(size_t)i * n + j] + L[(size_t)j * n + i]); L[(size_t)i * n + j] = L[(size_t)j * n + i] = v; }
+        if (!dl_cholesky(L, n)) return bail("dl_create: precision matrix is not positive definite");
+    } else if ((int)prec.size() == n) {
+        for (int i = 0; i < n; ++i) {
+            if (!(prec[i] > 0.)) return bail("dl_create: diagonal precision must be positive");
+            L[(size_t)i * n + i] = std::sqrt(prec[i]);
+        }
+    } else return bail("dl_create: precision must have n_data^2 or n_data entries");
+    // ---- assemble GEMM operands ----
+    size_t NK = (size_t)ctx->N_pad * ctx->K_pad;
+    std::vector<double> wt_full(NK, 0.), wt_white(NK, 0.), bias_full(ctx->N_pad, 0.), bias_white(ctx->N_pad, 0.), flatdata(ctx->N_pad, 0.);
+    std::vector<double> wh((size_t)ctx->N_pad * ctx->N_pad, 0.), bias_wh(ctx->N_pad, 0.);
+    std::vector<int32_t> transform(ctx->N_pad, 0);
+    for (int i = 0; i < ctx->n_obs; ++i) {
+        const DlObsHost& oh = ctx->obs[i];
+        for (int r = 0; r < oh.n_out; ++r) {
+            int gr = ctx->obs_row0[i] + r;
+            std::memcpy(&wt_full[(size_t)gr * ctx->K_pad + oh.dev.col_offset], &oh.weff[(size_t)r * oh.dev.n_in], sizeof(double) * oh.dev.n_in);
+            bias_full[gr] = oh.bias[r];
+            flatdata[gr] = oh.flatdata[r];
+            transform[gr] = oh.dev.transform;
+        }
+    }
+    // whitened: row i of (L^T . X) = sum_{j >= i} L[j][i] X[j]
+    for (int i = 0; i < n; ++i) {
+        double* dst = &wt_white[(size_t)i * ctx->K_pad];
+        double bsum = 0., dsum = 0.;
+        for (int j = i; j < n; ++j) {
+            double lji = L[(size_t)j * n + i];
+            if (lji == 0.) continue;
+            const double* src = &wt_full[(size_t)j * ctx->K_pad];
+            for (int k = 0; k < K; ++k) dst[k] += lji * src[k];
+            bsum += lji * (bias_full[j] - flatdata[j]);
+            dsum += lji * flatdata[j];
+            wh[(size_t)i * ctx->N_pad + j] = lji;
+        }
+        bias_white[i] = bsum;
+        bias_wh[i] = -dsum;
+    }
+    // ---- upload ----
+    if (dl_upload(ctx, &ctx->arena_dev, arena.data)) { dl_destroy(ctx); return 1; }
+    std::vector<DlObsDev> devs(ctx->n_obs);
+    for (int i = 0; i < ctx->n_obs; ++i) { ctx->obs[i].rebase(ctx->arena_dev); devs[i] = ctx->obs[i].dev; }
+    if (dl_upload(ctx, &ctx->obs_dev, devs) || dl_upload(ctx, &ctx->priors_dev, priors) || dl_upload(ctx, &ctx->wt_white_dev, wt_white) ||
+        dl_upload(ctx, &ctx->bias_white_dev, bias_white) || dl_upload(ctx, &ctx->wt_full_dev, wt_full) || dl_upload(ctx, &ctx->bias_full_dev, bias_full) ||
+        dl_upload(ctx, &ctx->wh_dev, wh) || dl_upload(ctx, &ctx->bias_wh_dev, bias_wh) || dl_upload(ctx, &ctx->flatdata_dev, flatdata) ||
+        dl_upload(ctx, &ctx->transform_dev, transform)) {
+        dl_destroy(ctx);
+        return 1;
+    }
+    for (int i = 0; i < 4; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return bail("dl_create: hipEventCreate failed");
+    *out = ctx;
+    return 0;
+}
+
+void dl_destroy(dl_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    void* ptrs[] = {ctx->arena_dev, ctx->obs_dev, ctx->priors_dev, ctx->wt_white_dev, ctx->bias_white_dev, ctx->wt_full_dev, ctx->bias_full_dev, ctx->wh_dev,
+                    ctx->bias_wh_dev, ctx->flatdata_dev, ctx->transform_dev, ctx->power_ws, ctx->delta_ws, ctx->flat_ws, ctx->theta_stage, ctx->out_stage,
+                    ctx->status_stage};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    delete ctx;
+}
+
+int64_t dl_info(const dl_ctx* ctx, const char* key) {
+    if (!ctx || !key) return -1;
+    std::string k(key);
+    if (k == "n_params") return ctx->n_params;
+    if (k == "n_data") return ctx->n_data;
+    if (k == "n_obs") return ctx->n_obs;
+    if (k == "n_in_total") { int64_t t = 0; for (auto& o : ctx->obs) t += o.dev.n_in; return t; }
+    if (k == "K_pad") return ctx->K_pad;
+    if (k == "N_pad") return ctx->N_pad;
+    if (k == "n_solved") return 0;
+    for (int i = 0; i < ctx->n_obs; ++i) {
+        if (k == "n_in_obs" + std::to_string(i)) return ctx->obs[i].dev.n_in;
+        if (k == "n_out_obs" + std::to_string(i)) return ctx->obs[i].n_out;
+        if (k == "n_ell_obs" + std::to_string(i)) return ctx->obs[i].dev.n_ell;
+        if (k == "n_kin_obs" + std::to_string(i)) return ctx->obs[i].dev.n_kin;
+    }
+    return -1;
+}
+
+static const int64_t DL_CHUNK = 32768;  // points per internal pass: bounds the workspaces to ~0.4 GB at K_pad ~ 1200
+
+static int dl_reserve(dl_ctx* ctx, int64_t B) {
+    int64_t need = std::min<int64_t>(B, DL_CHUNK);
+    if (need <= ctx->cap) return 0;
+    need = std::min<int64_t>(std::max<int64_t>(need, 1024), DL_CHUNK);
+    for (double** p : {&ctx->power_ws, &ctx->delta_ws, &ctx->flat_ws}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    ctx->cap = 0;
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->power_ws, (size_t)need * ctx->K_pad * sizeof(double)));
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->delta_ws, (size_t)need * ctx->N_pad * sizeof(double)));
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->flat_ws, (size_t)need * ctx->N_pad * sizeof(double)));
+    // the K padding columns of the power buffer are never written by the theory kernel and must be finite
+    DL_HIP_CHECK(ctx, hipMemset(ctx->power_ws, 0, (size_t)need * ctx->K_pad * sizeof(double)));
+    ctx->cap = need;
+    return 0;
+}
+
+int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* loglike_dev, double* logprior_dev, double* flattheory_dev, int32_t* status_dev,
+                  void* hip_stream) {
+    if (!ctx) { g_last_error = "dl_eval_batch: null context"; return 1; }
+    if (B < 0 || (B > 0 && !theta_dev)) return dl_fail(ctx, "dl_eval_batch: invalid batch");
+    if (B == 0) return 0;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (dl_reserve(ctx, B)) return 1;
+    const int n = ctx->n_data, P = ctx->n_params;
+    for (int64_t b0 = 0; b0 < B; b0 += DL_CHUNK) {
+        int64_t nb = std::min<int64_t>(DL_CHUNK, B - b0);
+        const double* th = theta_dev + (size_t)b0 * P;
+        bool prof = ctx->profile && b0 == 0;
+        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], stream));
+        dl_launch_fullshape(ctx->obs_dev, ctx->n_obs, ctx->max_n_t, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream);
+        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], stream));
+        bool need_flat = ctx->any_transform || flattheory_dev != nullptr;
+        if (need_flat) {
+            // flattheory = W . power + bias (window.py:459-473), then optional cubic transform (power_spectrum.py:402-404)
+            dl_launch_window_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_full_dev, ctx->K_pad, ctx->bias_full_dev, ctx->flat_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad,
+                                  ctx->K_pad, stream);
+            if (ctx->any_transform) dl_launch_transform(ctx->flat_ws, ctx->N_pad, ctx->flatdata_dev, ctx->transform_dev, n, nb, stream);
+            if (flattheory_dev)
+                DL_HIP_CHECK(ctx, hipMemcpy2DAsync(flattheory_dev + (size_t)b0 * n, (size_t)n * sizeof(double), ctx->flat_ws, (size_t)ctx->N_pad * sizeof(double),
+                                                   (size_t)n * sizeof(double), (size_t)nb, hipMemcpyDeviceToDevice, stream));
+        }
+        if (ctx->any_transform) {
+            // dtilde = L^T (flattheory - flatdata)
+            dl_launch_window_gemm(ctx->flat_ws, ctx->N_pad, ctx->wh_dev, ctx->N_pad, ctx->bias_wh_dev, ctx->delta_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad, ctx->N_pad,
+                                  stream);
+        } else {
+            // dtilde = (L^T W) . power + L^T (bias - flatdata): window convolution and precision folded in one fp64 MFMA GEMM
+            dl_launch_window_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad,
+                                  ctx->K_pad, stream);
+        }
+        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], stream));
+        dl_launch_finalize(ctx->delta_ws, ctx->N_pad, n, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
+                           status_dev ? status_dev + b0 : nullptr, stream);
+        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ctx->ev[3], stream));
+    }
+    DL_HIP_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+int dl_eval_theory(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs, double* power_dev, double* tables_dev, void* hip_stream) {
+    if (!ctx) { g_last_error = "dl_eval_theory: null context"; return 1; }
+    if (iobs < 0 || iobs >= ctx->n_obs) return dl_fail(ctx, "dl_eval_theory: observable index out of range");
+    if (B < 0 || (B > 0 && (!theta_dev || !power_dev))) return dl_fail(ctx, "dl_eval_theory: invalid argument");
+    if (B == 0) return 0;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // launch only observable iobs, writing rows of n_in doubles directly into the caller's buffers
+    DlObsDev tmp = ctx->obs[iobs].dev;
+    tmp.col_offset = 0;
+    DlObsDev* tmp_dev = nullptr;
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&tmp_dev, sizeof(DlObsDev)));
+    DL_HIP_CHECK(ctx, hipMemcpyAsync(tmp_dev, &tmp, sizeof(DlObsDev), hipMemcpyHostToDevice, stream));
+    DL_HIP_CHECK(ctx, hipStreamSynchronize(stream));
+    dl_launch_fullshape(tmp_dev, 1, tmp.n_t, theta_dev, ctx->n_params, B, power_dev, tmp.n_in, tables_dev, 3 * (int64_t)tmp.n_in, stream);
+    DL_HIP_CHECK(ctx, hipStreamSynchronize(stream));
+    DL_HIP_CHECK(ctx, hipFree(tmp_dev));
+    DL_HIP_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+static int dl_stage_reserve(dl_ctx* ctx, int64_t B) {
+    if (B <= ctx->stage_cap) return 0;
+    for (void* p : {(void*)ctx->theta_stage, (void*)ctx->out_stage, (void*)ctx->status_stage}) if (p) (void)hipFree(p);
+    ctx->theta_stage = ctx->out_stage = nullptr; ctx->status_stage = nullptr; ctx->stage_cap = 0;
+    int64_t cap = std::max<int64_t>(B, 64);
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->theta_stage, (size_t)cap * ctx->n_params * sizeof(double)));
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->out_stage, (size_t)cap * 2 * sizeof(double)));
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->status_stage, (size_t)cap * sizeof(int32_t)));
+    ctx->stage_cap = cap;
+    return 0;
+}
+
+int dl_eval_batch_host(dl_ctx* ctx, const double* theta, int64_t B, double* loglike, double* logprior, double* flattheory, int32_t* status) {
+    if (!ctx) { g_last_error = "dl_eval_batch_host: null context"; return 1; }
+    if (B < 0 || (B > 0 && !theta)) return dl_fail(ctx, "dl_eval_batch_host: invalid batch");
+    if (B == 0) return 0;
+    DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (dl_stage_reserve(ctx, B)) return 1;
+    double* flat_dev = nullptr;
+    if (flattheory) DL_HIP_CHECK(ctx, hipMalloc((void**)&flat_dev, (size_t)B * ctx->n_data * sizeof(double)));
+    DL_HIP_CHECK(ctx, hipMemcpy(ctx->theta_stage, theta, (size_t)B * ctx->n_params * sizeof(double), hipMemcpyHostToDevice));
+    int rc = dl_eval_batch(ctx, ctx->theta_stage, B, ctx->out_stage, ctx->out_stage + ctx->stage_cap, flat_dev, ctx->status_stage, nullptr);
+    if (rc == 0) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) rc = dl_fail(ctx, std::string("dl_eval_batch_host: ") + hipGetErrorString(e));
+    }
+    if (rc == 0) {
+        if (loglike) (void)hipMemcpy(loglike, ctx->out_stage, (size_t)B * sizeof(double), hipMemcpyDeviceToHost);
+        if (logprior) (void)hipMemcpy(logprior, ctx->out_stage + ctx->stage_cap, (size_t)B * sizeof(double), hipMemcpyDeviceToHost);
+        if (status) (void)hipMemcpy(status, ctx->status_stage, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (flattheory) (void)hipMemcpy(flattheory, flat_dev, (size_t)B * ctx->n_data * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    if (flat_dev) (void)hipFree(flat_dev);
+    return rc;
+}
+
+int dl_eval_theory_host(dl_ctx* ctx, const double* theta, int64_t B, int32_t iobs, double* power, double* tables) {
+    if (!ctx) { g_last_error = "dl_eval_theory_host: null context"; return 1; }
+    if (iobs < 0 || iobs >= ctx->n_obs) return dl_fail(ctx, "dl_eval_theory_host: observable index out of range");
+    if (B <= 0 || !theta || !power) return dl_fail(ctx, "dl_eval_theory_host: invalid argument");
+    DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (dl_stage_reserve(ctx, B)) return 1;
+    int n_in = ctx->obs[iobs].dev.n_in;
+    double *pdev = nullptr, *tdev = nullptr;
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&pdev, (size_t)B * n_in * sizeof(double)));
+    if (tables) DL_HIP_CHECK(ctx, hipMalloc((void**)&tdev, (size_t)B * 3 * n_in * sizeof(double)));
+    DL_HIP_CHECK(ctx, hipMemcpy(ctx->theta_stage, theta, (size_t)B * ctx->n_params * sizeof(double), hipMemcpyHostToDevice));
+    int rc = dl_eval_theory(ctx, ctx->theta_stage, B, iobs, pdev, tdev, nullptr);
+    if (rc == 0) {
+        (void)hipMemcpy(power, pdev, (size_t)B * n_in * sizeof(double), hipMemcpyDeviceToHost);
+        if (tables) (void)hipMemcpy(tables, tdev, (size_t)B * 3 * n_in * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(pdev);
+    if (tdev) (void)hipFree(tdev);
+    return rc;
+}
+
+int dl_profile_enable(dl_ctx* ctx, int enable) {
+    if (!ctx) { g_last_error = "dl_profile_enable: null context"; return 1; }
+    ctx->profile = enable != 0;
+    return 0;
+}
+
+int dl_profile_read(dl_ctx* ctx, double* ms, int32_t n) {
+    if (!ctx || !ms || n < 4) return dl_fail(ctx, "dl_profile_read: need room for 4 values");
+    DL_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[3]));
+    float t01 = 0, t12 = 0, t23 = 0, t03 = 0;
+    DL_HIP_CHECK(ctx, hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]));
+    DL_HIP_CHECK(ctx, hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));
+    DL_HIP_CHECK(ctx, hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]));
+    DL_HIP_CHECK(ctx, hipEventElapsedTime(&t03, ctx->ev[0], ctx->ev[3]));
+    ms[0] = t01; ms[1] = t12; ms[2] = t23; ms[3] = t03;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+// dl_host.hpp -- host-side (init-time) preparation of the constants the kernels consume.
+// Plain C++ (no HIP): shared by the C-ABI library (dl_api.hip) and by the CPU emulation harness of
+// the `not gpu` tests.  Everything here runs once per dl_create, never per evaluation.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "dl_fullshape.h"
+
+struct dl_config {
+    std::map<std::string, std::vector<double>> f64;
+    std::map<std::string, std::vector<int32_t>> i32;
+
+    bool has_f64(const std::string& k) const { return f64.count(k) > 0; }
+    bool has_i32(const std::string& k) const { return i32.count(k) > 0; }
+    const std::vector<double>& F(const std::string& k) const {
+        static const std::vector<double> empty;
+        auto it = f64.find(k);
+        return it == f64.end() ? empty : it->second;
+    }
+    const std::vector<int32_t>& I(const std::string& k) const {
+        static const std::vector<int32_t> empty;
+        auto it = i32.find(k);
+        return it == i32.end() ? empty : it->second;
+    }
+    double f(const std::string& k, double def) const { auto& v = F(k); return v.empty() ? def : v[0]; }
+    int32_t i(const std::string& k, int32_t def) const { auto& v = I(k); return v.empty() ? def : v[0]; }
+};
+
+// Arena of doubles: constants are laid out contiguously on the host, uploaded with one copy, and the
+// DlObsDev pointers are rebased onto the device (or left on the host arena for the CPU emulation).
+struct DlArena {
+    std::vector<double> data;
+    size_t push(const double* src, size_t n) {
+        size_t off = data.size();
+        // keep every array 16-byte aligned for vector loads
+        data.insert(data.end(), src, src + n);
+        if (data.size() % 2) data.push_back(0.);
+        return off;
+    }
+    size_t push(const std::vector<double>& v) { return push(v.data(), v.size()); }
+};
+
+struct DlObsHost {
+    DlObsDev dev;   // pointers are OFFSETS into arena (in doubles) until rebase()
+    int n_out = 0;  // data size of this observable
+    std::vector<double> weff;     // [n_out, n_in] effective window (matrix / identity / row selection)
+    std::vector<double> bias;     // [n_out]: W . (sn_in (x) 1) + offset[mask] - sn_out        (window.py:459-473)
+    std::vector<double> flatdata; // [n_out]
+    size_t off_kin, off_lkin, off_mu, off_wmu, off_xt, off_pk, off_th, off_lg, off_ih, off_A, off_nC, off_inv, off_Mfix, off_ct, off_sn;
+
+    void rebase(const double* base) {
+        dev.kin = base + off_kin; dev.lkin = base + off_lkin; dev.mu = base + off_mu; dev.wmu = base + off_wmu;
+        dev.x_t = base + off_xt; dev.pk_fid = base + off_pk; dev.sf_th = base + off_th; dev.sf_lg = base + off_lg;
+        dev.ih = base + off_ih; dev.sp_A = base + off_A; dev.sp_nC = base + off_nC; dev.sp_inv = base + off_inv;
+        dev.M_fixed = base + off_Mfix; dev.ct_matrix = base + off_ct; dev.sn_matrix = base + off_sn;
+    }
+};
+
+// Not-a-knot cubic spline in moment form on knots x[n]: reduced tridiagonal system for M[1..n-2]
+// (the two not-a-knot conditions substituted into the first / last interior rows), factorised once.
+// Per evaluation only the right-hand side changes (dl_fs_phase2a-c).
+struct DlSplineSetup {
+    std::vector<double> ih, A, nC, inv;
+    double end0a, end0b, end1a, end1b;
+    int warm;  // warm-up length after which a truncated sweep is exact to < 1e-22 relative
+};
+
+inline bool dl_spline_setup(const std::vector<double>& x, DlSplineSetup& s, std::string& err) {
+    int n = (int)x.size();
+    if (n < 5) { err = "spline needs at least 5 knots"; return false; }
+    std::vector<double> h(n - 1);
+    s.ih.resize(n - 1);
+    for (int j = 0; j < n - 1; ++j) {
+        h[j] = x[j + 1] - x[j];
+        if (!(h[j] > 0.)) { err = "template knots must be strictly increasing"; return false; }
+        s.ih[j] = 1. / h[j];
+    }
+    int m = n - 2;
+    std::vector<double> lo(m), di(m), up(m);
+    for (int i = 0; i < m; ++i) {  // reduced row i <-> original interior row i + 1
+        lo[i] = h[i];
+        di[i] = 2. * (h[i] + h[i + 1]);
+        up[i] = h[i + 1];
+    }
+    // M[0] = (1 + h0/h1) M[1] - (h0/h1) M[2]
+    s.end0a = 1. + h[0] / h[1];
+    s.end0b = -h[0] / h[1];
+    di[0] += h[0] * s.end0a;
+    up[0] += h[0] * s.end0b;
+    lo[0] = 0.;
+    // M[n-1] = (1 + h[n-2]/h[n-3]) M[n-2] - (h[n-2]/h[n-3]) M[n-3]
+    s.end1a = 1. + h[n - 2] / h[n - 3];
+    s.end1b = -h[n - 2] / h[n - 3];
+    di[m - 1] += h[n - 2] * s.end1a;
+    lo[m - 1] += h[n - 2] * s.end1b;
+    up[m - 1] = 0.;
+    s.A.resize(m); s.nC.resize(m); s.inv.resize(m);
+    double cprev = 0.;
+    double amax = 0.;
+    for (int i = 0; i < m; ++i) {
+        double den = di[i] - lo[i] * cprev;
+        if (!(std::fabs(den) > 0.)) { err = "singular spline system"; return false; }
+        s.inv[i] = 1. / den;
+        s.A[i] = -lo[i] * s.inv[i];
+        cprev = up[i] * s.inv[i];
+        s.nC[i] = -cprev;
+        amax = std::fmax(amax, std::fmax(std::fabs(s.A[i]), std::fabs(cprev)));
+    }
+    if (amax < 0.9 && amax > 0.) s.warm = (int)std::ceil(std::log(1e-22) / std::log(amax)) + 1;
+    else s.warm = m;  // no exploitable decay: every segment sweeps from the boundary (serial)
+    if (s.warm > m) s.warm = m;
+    return true;
+}
+
+inline void dl_spline_moments_serial(const std::vector<double>& y, const DlSplineSetup& s, std::vector<double>& M) {
+    int n = (int)y.size(), m = n - 2;
+    std::vector<double> z(m);
+    M.assign(n, 0.);
+    double zz = 0.;
+    for (int i = 0; i < m; ++i) {
+        double r = 6. * ((y[i + 2] - y[i + 1]) * s.ih[i + 1] - (y[i + 1] - y[i]) * s.ih[i]);
+        zz = std::fma(s.A[i], zz, r * s.inv[i]);
+        z[i] = zz;
+    }
+    double uu = 0.;
+    for (int i = m - 1; i >= 0; --i) {
+        uu = std::fma(s.nC[i], uu, z[i]);
+        M[i + 1] = uu;
+    }
+    M[0] = s.end0a * M[1] + s.end0b * M[2];
+    M[n - 1] = s.end1a * M[n - 2] + s.end1b * M[n - 3];
+}
+
+inline DlInput dl_input_from(const dl_config& cfg, const std::string& key, double def) {
+    DlInput in;
+    in.col = -1; in.pad = 0; in.value = def;
+    const auto& v = cfg.F(key);
+    if (v.size() >= 2) { in.col = (int32_t)std::lround(v[0]); in.value = v[1]; }
+    return in;
+}
+
+// Cholesky factor of a symmetric positive-definite matrix: P = L L^T (lower), in place (upper part zeroed)
+inline bool dl_cholesky(std::vector<double>& P, int n) {
+    for (int j = 0; j < n; ++j) {
+        double d = P[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= P[(size_t)j * n + k] * P[(size_t)j * n + k];
+        if (!(d > 0.)) return false;
+        d = std::sqrt(d);
+        P[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double sum = P[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) sum -= P[(size_t)i * n + k] * P[(size_t)j * n + k];
+            P[(size_t)i * n + j] = sum / d;
+        }
+        for (int i = 0; i < j; ++i) P[(size_t)i * n + j] = 0.;
+    }
+    return true;
+}
+
+// Build the constants of observable `iobs` from the key/value store.
+inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost& oh, DlArena& arena, std::string& err) {
+    std::string p = "obs" + std::to_string(iobs) + ".";
+    DlObsDev& d = oh.dev;
+    std::memset(&d, 0, sizeof(d));
+    d.theory = cfg.i(p + "theory", 0);
+    d.templ = cfg.i(p + "template", 0);
+    d.apmode = cfg.i(p + "apmode", 0);
+    d.transform = cfg.i(p + "transform", 0);
+    const auto& ells = cfg.I(p + "ells_in");
+    const auto& kin = cfg.F(p + "kin");
+    const auto& mu = cfg.F(p + "mu");
+    const auto& wmu = cfg.F(p + "wmu_ell");
+    const auto& k_t = cfg.F(p + "k_t");
+    const auto& pk = cfg.F(p + "pk_dd_fid");
+    d.n_ell = (int)ells.size(); d.n_kin = (int)kin.size(); d.n_mu = (int)mu.size(); d.n_t = (int)k_t.size();
+    d.n_in = d.n_ell * d.n_kin;
+    if (d.n_ell < 1 || d.n_ell > DL_MAX_ELL) { err = p + "ells_in: between 1 and 5 multipoles supported"; return false; }
+    if (d.n_mu < 1 || d.n_mu > DL_MAX_MU) { err = p + "mu: between 1 and 32 nodes supported"; return false; }
+    if (d.n_kin < 1) { err = p + "kin missing"; return false; }
+    if ((int)wmu.size() != d.n_ell * d.n_mu) { err = p + "wmu_ell must have n_ell * n_mu entries"; return false; }
+    if ((int)pk.size() != d.n_t) { err = p + "pk_dd_fid and k_t sizes differ"; return false; }
+    d.ell0 = -1;
+    for (int l = 0; l < d.n_ell; ++l) if (ells[l] == 0) d.ell0 = l;
+    d.eta = cfg.f(p + "eta", 1. / 3.);
+    d.f_fid = cfg.f(p + "f_fid", 1.);
+    d.a = cfg.f(p + "a", 0.6);
+    double kp = cfg.f(p + "kp", 0.03);
+    d.nd = cfg.f(p + "nd", 1e-4);
+    struct { const char* name; DlInput* in; double def; } inputs[] = {
+        {"qpar", &d.qpar, 1.}, {"qper", &d.qper, 1.}, {"qiso", &d.qiso, 1.}, {"qap", &d.qap, 1.}, {"df", &d.df, 1.}, {"dm", &d.dm, 0.}, {"dn", &d.dn, 0.},
+        {"sigmapar", &d.sigpar, 0.}, {"sigmaper", &d.sigper, 0.}, {"b1X", &d.b1X, 1.}, {"b1Y", &d.b1Y, 1.}, {"sn0", &d.sn0, 0.}};
+    for (auto& it : inputs) {
+        *it.in = dl_input_from(cfg, p + "in." + it.name, it.def);
+        if (it.in->col >= n_params) { err = p + "in." + it.name + ": theta column out of range"; return false; }
+    }
+    // template knots in log10 k (full_shape.py:498: interp1d(log10(kap), log10(k11), pk11))
+    std::vector<double> x_t(d.n_t), sf_th(d.n_t), sf_lg(d.n_t), lkin(d.n_kin);
+    for (int j = 0; j < d.n_t; ++j) {
+        x_t[j] = std::log10(k_t[j]);
+        sf_lg[j] = std::log(k_t[j] / kp);               // power_template.py:749
+        sf_th[j] = std::tanh(d.a * std::log(k_t[j] / kp));
+    }
+    for (int i = 0; i < d.n_kin; ++i) lkin[i] = std::log10(kin[i]);
+    DlSplineSetup sp;
+    if (!dl_spline_setup(x_t, sp, err)) { err = p + err; return false; }
+    d.end0a = sp.end0a; d.end0b = sp.end0b; d.end1a = sp.end1a; d.end1b = sp.end1b;
+    d.x0 = x_t[0];
+    d.inv_hx = (d.n_t - 1) / (x_t[d.n_t - 1] - x_t[0]);
+    d.fixed_spline = (d.templ == 0);
+    int m = d.n_t - 2;
+    d.seg_warm = sp.warm;
+    d.n_seg = 64;
+    if (sp.warm >= m) d.n_seg = 1;
+    d.seg_len = (m + d.n_seg - 1) / d.n_seg;
+    std::vector<double> Mfix;
+    dl_spline_moments_serial(pk, sp, Mfix);
+    // EFT-like terms
+    const auto& ctm = cfg.F(p + "ct_matrix");
+    const auto& snm = cfg.F(p + "sn_matrix");
+    d.n_ct = ctm.empty() ? 0 : (int)(ctm.size() / d.n_in);
+    d.n_sn = snm.empty() ? 0 : (int)(snm.size() / d.n_in);
+    if (d.n_ct > DL_MAX_EFT || d.n_sn > DL_MAX_EFT) { err = p + "at most 8 counter / stochastic terms supported"; return false; }
+    if (d.n_ct > 0 && d.ell0 < 0) { err = p + "counter terms need the monopole in ells_in (full_shape.py:633)"; return false; }
+    const auto& ctin = cfg.F(p + "in.ct");
+    const auto& snin = cfg.F(p + "in.sn");
+    if ((int)ctin.size() != d.n_ct * 4 || (int)snin.size() != d.n_sn * 2) { err = p + "in.ct / in.sn sizes do not match the matrices"; return false; }
+    for (int c = 0; c < d.n_ct; ++c)
+        for (int t = 0; t < 2; ++t) {
+            d.ct_in[c][t].col = (int32_t)std::lround(ctin[(c * 2 + t) * 2]);
+            d.ct_in[c][t].value = ctin[(c * 2 + t) * 2 + 1];
+        }
+    for (int c = 0; c < d.n_sn; ++c) {
+        d.sn_in[c].col = (int32_t)std::lround(snin[c * 2]);
+        d.sn_in[c].value = snin[c * 2 + 1];
+    }
+    oh.off_kin = arena.push(kin); oh.off_lkin = arena.push(lkin); oh.off_mu = arena.push(mu); oh.off_wmu = arena.push(wmu);
+    oh.off_xt = arena.push(x_t); oh.off_pk = arena.push(pk); oh.off_th = arena.push(sf_th); oh.off_lg = arena.push(sf_lg);
+    oh.off_ih = arena.push(sp.ih); oh.off_A = arena.push(sp.A); oh.off_nC = arena.push(sp.nC); oh.off_inv = arena.push(sp.inv);
+    oh.off_Mfix = arena.push(Mfix); oh.off_ct = arena.push(ctm); oh.off_sn = arena.push(snm);
+
+    // ---- window: effective matrix and additive bias (window.py:445-473) ----
+    const auto& wm = cfg.F(p + "wmatrix");
+    const auto& kmask = cfg.I(p + "kmask");
+    const auto& offset = cfg.F(p + "offset");
+    const auto& snin_w = cfg.F(p + "shotnoise_in");
+    const auto& snout_w = cfg.F(p + "shotnoise_out");
+    const auto& flatdata = cfg.F(p + "flatdata");
+    int n_rows = wm.empty() ? d.n_in : (int)(wm.size() / d.n_in);
+    if (!wm.empty() && (size_t)n_rows * d.n_in != wm.size()) { err = p + "wmatrix size is not a multiple of n_ell * n_kin"; return false; }
+    oh.n_out = kmask.empty() ? n_rows : (int)kmask.size();
+    if ((int)flatdata.size() != oh.n_out) { err = p + "flatdata size does not match the window output size"; return false; }
+    if (!offset.empty() && (int)offset.size() != n_rows) { err = p + "offset size mismatch"; return false; }
+    if (!snout_w.empty() && (int)snout_w.size() != oh.n_out) { err = p + "shotnoise_out size mismatch"; return false; }
+    if (!snin_w.empty() && (int)snin_w.size() != d.n_ell) { err = p + "shotnoise_in size mismatch"; return false; }
+    oh.weff.assign((size_t)oh.n_out * d.n_in, 0.);
+    oh.bias.assign(oh.n_out, 0.);
+    oh.flatdata = flatdata;
+    for (int r = 0; r < oh.n_out; ++r) {
+        int src = kmask.empty() ? r : kmask[r];
+        if (src < 0 || src >= n_rows) { err = p + "kmask entry out of range"; return false; }
+        double* row = &oh.weff[(size_t)r * d.n_in];
+        if (wm.empty()) row[src] = 1.;
+        else std::memcpy(row, &wm[(size_t)src * d.n_in], sizeof(double) * d.n_in);
+        double b = 0.;
+        if (!snin_w.empty())
+            for (int l = 0; l < d.n_ell; ++l) {
+                if (snin_w[l] == 0.) continue;
+                double sum = 0.;
+                for (int i = 0; i < d.n_kin; ++i) sum += row[(size_t)l * d.n_kin + i];
+                b += sum * snin_w[l];
+            }
+        if (!offset.empty()) b += offset[src];
+        if (!snout_w.empty()) b -= snout_w[r];
+        oh.bias[r] = b;
+    }
+    return true;
+}

@@ -1,0 +1,132 @@
+/*
+ * desilike_amd.h -- C ABI of the MI355X (gfx950) implementation of desilike's
+ * theory -> observable -> Gaussian-likelihood hot path.
+ *
+ * The reference (cosmodesi/desilike) is pure Python: there is no FFI to mirror symbol by symbol.
+ * What this library replaces is the chain of ``calculate()`` bodies that
+ * ``BasePipeline.calculate`` (desilike/base.py:510-572) runs for one parameter point, evaluated
+ * here for a whole batch of points per call (what ``vmap`` desilike/base.py:232-383 and
+ * ``BasePosteriorSampler.logposterior`` desilike/samplers/base.py:144-200 loop over):
+ *
+ *   dl_eval_batch   <->  APEffect.calculate                      theories/galaxy_clustering/base.py:325-353
+ *                        ShapeFitPowerSpectrumTemplate.calculate theories/galaxy_clustering/power_template.py:747-761
+ *                        KaiserPowerSpectrumMultipoles.calculate theories/galaxy_clustering/full_shape.py:488-500
+ *                        KaiserTracerPowerSpectrumMultipoles.calculate            full_shape.py:545-550 (+628-634 EFT-like)
+ *                        WindowedPowerSpectrumMultipoles.calculate   observables/galaxy_clustering/window.py:459-473
+ *                        TracerPowerSpectrumMultipolesObservable.calculate        power_spectrum.py:400-404
+ *                        ObservablesGaussianLikelihood.calculate     likelihoods/base.py:13-17, 658-664
+ *                        BaseLikelihood.get / ParameterCollection.prior           likelihoods/base.py:242-245, parameter.py:1889-1897
+ *                        BaseLikelihood._solve (analytic marginalisation)         likelihoods/base.py:314-413
+ *   dl_eval_theory  <->  the ``power`` / ``pktable`` state of the theory calculators (``__getstate__`` full_shape.py:502-510)
+ *
+ * Conventions
+ *  - plain pointers and sizes only; float64 throughout (the reference forces x64: desilike/jax.py:18).
+ *  - ``*_dev`` pointers are device (HBM) addresses on the context's GPU; the caller allocates and
+ *    owns every in/out buffer, the library never frees caller memory.
+ *  - return code 0 = success; non-zero = error, message via dl_last_error(ctx) (or dl_last_error(NULL)
+ *    for errors before a context exists).  Per-point numerical failures are NOT errors: they are
+ *    reported in ``status`` (the Python host maps them to -inf exactly like samplers/base.py:185-191).
+ *  - calls on one dl_ctx are serialised on the HIP stream passed in (NULL = default stream);
+ *    different contexts (devices) are independent; no global mutable state except the last-error string.
+ *  - the library FAILS (non-zero) when no GPU is present: there is no CPU fallback.
+ */
+#ifndef DESILIKE_AMD_H
+#define DESILIKE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dl_config dl_config;   /* host-side key -> array store describing one likelihood */
+typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device constants and workspaces */
+
+/* per-point status written by dl_eval_batch */
+#define DL_STATUS_OK            0
+#define DL_STATUS_OUT_OF_PRIOR  1   /* logprior = -inf (parameter.py:1994-2007) */
+#define DL_STATUS_NONFINITE     2   /* loglikelihood is NaN/inf */
+#define DL_STATUS_NAN_INPUT     3   /* a theta entry is NaN (samplers/base.py:57-61) */
+
+/* enumerations used as values of integer config keys */
+#define DL_TEMPLATE_FIXED     0   /* Fixed / Standard / BAO templates: fiducial table, only f = f_fid * df varies (power_template.py:198-202, 592-596, 372-376) */
+#define DL_TEMPLATE_SHAPEFIT  1   /* power_template.py:747-761 */
+#define DL_THEORY_KAISER      0   /* full_shape.py:488-500, 545-550 */
+#define DL_THEORY_EFT_KAISER  1   /* + counter / stochastic terms full_shape.py:628-634 */
+#define DL_APMODE_QPARQPER    0   /* theories/galaxy_clustering/base.py:341-350 */
+#define DL_APMODE_QISO        1
+#define DL_APMODE_QAP         2
+#define DL_APMODE_QISOQAP     3
+#define DL_PRIOR_UNIFORM      0
+#define DL_PRIOR_NORM         1
+#define DL_TRANSFORM_NONE     0
+#define DL_TRANSFORM_CUBIC    1   /* power_spectrum.py:402-404 */
+
+/* ---- configuration store ---------------------------------------------------------------------
+ * Keys (all arrays are copied; "obs<i>." prefix = i-th observable of ObservablesGaussianLikelihood):
+ *   n_params        i32[1]   number of sampled parameters P (= columns of theta)
+ *   priors          f64[P*5] rows (kind, lo, hi, loc, scale)                   parameter.py:1994-2007
+ *   n_obs           i32[1]
+ *   precision       f64[n*n] or f64[n]  precision matrix (or its diagonal), n = total data size
+ *                                        (Hartlap / Percival factors already applied by the host: likelihoods/base.py:623-656)
+ *   obs<i>.theory, .template, .apmode, .transform   i32[1]
+ *   obs<i>.eta, .f_fid, .a, .kp, .nd                f64[1]
+ *   obs<i>.ells_in  i32[n_ell]      theory multipoles
+ *   obs<i>.kin      f64[n_kin]      theory wavenumbers (same for every multipole)
+ *   obs<i>.mu, obs<i>.wmu_ell       f64[n_mu], f64[n_ell*n_mu]   GL nodes and (2l+1) L_l(mu) w   (tgc/base.py:201-204)
+ *   obs<i>.k_t, obs<i>.pk_dd_fid    f64[n_t]   template knots and fiducial linear power
+ *   obs<i>.in.<name>  f64[2] = (theta column or -1, constant value) for
+ *                     qpar qper qiso qap df dm dn sigmapar sigmaper b1X b1Y sn0
+ *   obs<i>.ct_matrix f64[n_ell*n_kin*n_ct], obs<i>.in.ct f64[n_ct*2*2] (X and Y tracer inputs per term)
+ *   obs<i>.sn_matrix f64[n_ell*n_kin*n_sn], obs<i>.in.sn f64[n_sn*2]
+ *   obs<i>.wmatrix  f64[n_out*n_in] row-major (n_in = n_ell*n_kin); absent = identity      window.py:459-468
+ *   obs<i>.kmask    i32[n_out]      row selection applied after the matrix / identity
+ *   obs<i>.offset   f64[n_out_before_mask], obs<i>.shotnoise_in f64[n_ell], obs<i>.shotnoise_out f64[n_out]
+ *   obs<i>.flatdata f64[n_out]
+ *   marg.*          analytic marginalisation spec
+ */
+dl_config* dl_config_new(void);
+int  dl_config_set_f64(dl_config* cfg, const char* key, const double* data, int64_t n);
+int  dl_config_set_i32(dl_config* cfg, const char* key, const int32_t* data, int64_t n);
+void dl_config_free(dl_config* cfg);
+
+/* ---- context ---------------------------------------------------------------------------------*/
+/* Uploads every constant once (window matrix folded with the Cholesky factor of the precision,
+ * spline elimination coefficients, quadrature weights, ...).  device = HIP device ordinal. */
+int  dl_create(dl_ctx** out, int device, const dl_config* cfg);
+void dl_destroy(dl_ctx* ctx);
+const char* dl_last_error(const dl_ctx* ctx);
+
+/* integer properties: "n_params", "n_data", "n_obs", "n_in_total", "n_in_obs<i>", "n_out_obs<i>", "n_solved" */
+int64_t dl_info(const dl_ctx* ctx, const char* key);
+
+/* ---- evaluation ------------------------------------------------------------------------------*/
+/* theta_dev [B, P] row-major.  Outputs (any may be NULL): loglike_dev[B], logprior_dev[B],
+ * flattheory_dev[B, n_data], status_dev[B].  Asynchronous on ``hip_stream``. */
+int  dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B,
+                   double* loglike_dev, double* logprior_dev, double* flattheory_dev,
+                   int32_t* status_dev, void* hip_stream);
+
+/* Theory state of observable ``iobs`` for parity / plots / emulation:
+ * power_dev [B, n_ell, n_kin] and (optional) tables_dev [B, 3, n_ell, n_kin] = pk_dd, pk_dt, pk_tt. */
+int  dl_eval_theory(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs,
+                    double* power_dev, double* tables_dev, void* hip_stream);
+
+/* Host-pointer conveniences (copy in, evaluate on the default stream, copy out, synchronise):
+ * used by the scalar ``likelihood(**params)`` call surface (desilike/base.py:1194-1196). */
+int  dl_eval_batch_host(dl_ctx* ctx, const double* theta, int64_t B,
+                        double* loglike, double* logprior, double* flattheory, int32_t* status);
+int  dl_eval_theory_host(dl_ctx* ctx, const double* theta, int64_t B, int32_t iobs,
+                         double* power, double* tables);
+
+/* ---- measurement -----------------------------------------------------------------------------*/
+/* When enabled, dl_eval_batch brackets each kernel with HIP events on the launch stream;
+ * dl_profile_read synchronises and returns the per-kernel milliseconds of the LAST call:
+ * ms[0] theory kernel, ms[1] window GEMM, ms[2] chi2/prior finalize, ms[3] whole call. */
+int  dl_profile_enable(dl_ctx* ctx, int enable);
+int  dl_profile_read(dl_ctx* ctx, double* ms, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DESILIKE_AMD_H */

@@ -1,0 +1,91 @@
+// emulate.cpp -- TEST INFRASTRUCTURE: runs the theory kernel's phase functions (desilike_amd/csrc/dl_fullshape.h)
+// and the host-side constant folding (dl_host.hpp) on the CPU, emulating one workgroup by looping tid over
+// [0, 256) for each barrier-separated phase.  Lets the `not gpu` test-suite catch logic errors in the device
+// arithmetic without a GPU.  It is NOT a fallback: nothing in desilike_amd/ links or loads it.
+#include <algorithm>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../desilike_amd/csrc/dl_host.hpp"
+
+static std::string g_err;
+
+extern "C" {
+
+dl_config* emu_config_new(void) { return new dl_config(); }
+void emu_config_free(dl_config* cfg) { delete cfg; }
+int emu_config_set_f64(dl_config* cfg, const char* key, const double* data, int64_t n) { cfg->f64[key] = std::vector<double>(data, data + n); return 0; }
+int emu_config_set_i32(dl_config* cfg, const char* key, const int32_t* data, int64_t n) { cfg->i32[key] = std::vector<int32_t>(data, data + n); return 0; }
+const char* emu_last_error(void) { return g_err.c_str(); }
+
+static void run_point(const DlObsDev& o, const double* th, double* prow, double* trow) {
+    std::vector<double> lds(dl_fs_shared_doubles(o.n_t));
+    DlFsShared s;
+    s.y = lds.data(); s.M = s.y + o.n_t; s.z = s.M + o.n_t; s.pt = s.z + o.n_t;
+    const int nthr = DL_FS_THREADS;
+    for (int tid = 0; tid < nthr; ++tid) dl_fs_phase01(tid, nthr, o, th, s);
+    if (!o.fixed_spline) {
+        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2a(tid, nthr, o, s);
+        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2b(tid, nthr, o, s);
+        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2c(tid, nthr, o, s);
+    }
+    for (int tid = 0; tid < nthr; ++tid) dl_fs_phase3(tid, nthr, o, s, prow, trow);
+}
+
+// power [B, n_in], tables [B, 3, n_in] (may be null)
+int emu_eval_theory(const dl_config* cfg, const double* theta, int64_t B, int iobs, double* power, double* tables) {
+    int P = cfg->i("n_params", -1);
+    DlArena arena;
+    DlObsHost oh;
+    if (!dl_build_obs(*cfg, iobs, P, oh, arena, g_err)) return 1;
+    oh.rebase(arena.data.data());
+    oh.dev.col_offset = 0;
+    for (int64_t b = 0; b < B; ++b)
+        run_point(oh.dev, theta + b * P, power + b * oh.dev.n_in, tables ? tables + b * 3 * oh.dev.n_in : nullptr);
+    return 0;
+}
+
+// whole pipeline with the same folding as dl_create: dtilde = (L^T W) power + L^T (bias - data); loglike = -1/2 |dtilde|^2
+int emu_eval_batch(const dl_config* cfg, const double* theta, int64_t B, double* loglike, double* flattheory) {
+    int P = cfg->i("n_params", -1), nobs = cfg->i("n_obs", -1);
+    DlArena arena;
+    std::vector<DlObsHost> obs(nobs);
+    int n = 0, K = 0;
+    std::vector<int> row0, col0;
+    for (int i = 0; i < nobs; ++i) {
+        if (!dl_build_obs(*cfg, i, P, obs[i], arena, g_err)) return 1;
+        row0.push_back(n); col0.push_back(K);
+        n += obs[i].n_out; K += obs[i].dev.n_in;
+    }
+    for (int i = 0; i < nobs; ++i) { obs[i].rebase(arena.data.data()); obs[i].dev.col_offset = col0[i]; }
+    const auto& prec = cfg->F("precision");
+    std::vector<double> L((size_t)n * n, 0.);
+    if ((int64_t)prec.size() == (int64_t)n * n) { L = prec; if (!dl_cholesky(L, n)) { g_err = "not positive definite"; return 1; } }
+    else for (int i = 0; i < n; ++i) L[(size_t)i * n + i] = std::sqrt(prec[i]);
+    std::vector<double> power(K), flat(n);
+    for (int64_t b = 0; b < B; ++b) {
+        for (int i = 0; i < nobs; ++i) run_point(obs[i].dev, theta + b * P, power.data(), nullptr);
+        for (int i = 0; i < nobs; ++i)
+            for (int r = 0; r < obs[i].n_out; ++r) {
+                double sum = 0.;
+                for (int k = 0; k < obs[i].dev.n_in; ++k) sum += obs[i].weff[(size_t)r * obs[i].dev.n_in + k] * power[col0[i] + k];
+                flat[row0[i] + r] = sum + obs[i].bias[r];
+            }
+        if (flattheory) std::copy(flat.begin(), flat.end(), flattheory + b * n);
+        double chi2 = 0.;
+        for (int i = 0; i < n; ++i) {
+            double d = 0.;
+            int oi = 0;
+            for (int j = i; j < n; ++j) {
+                while (oi + 1 < nobs && j >= row0[oi + 1]) ++oi;
+                d += L[(size_t)j * n + i] * (flat[j] - obs[oi].flatdata[j - row0[oi]]);
+            }
+            chi2 += d * d;
+        }
+        loglike[b] = -0.5 * chi2;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+"""Build + ctypes-load the CPU emulation of the theory kernel phases (tests/csrc/emulate.cpp): test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_emu = None
+
+
+def load_emulation():
+    global _emu
+    if _emu is None:
+        build = os.path.join(HERE, 'csrc', '_build')
+        os.makedirs(build, exist_ok=True)
+        so = os.path.join(build, 'libdl_emulate.so')
+        src = os.path.join(HERE, 'csrc', 'emulate.cpp')
+        deps = [src] + [os.path.join(HERE, '..', 'desilike_amd', 'csrc', name) for name in ['dl_fullshape.h', 'dl_host.hpp']]
+        if not os.path.isfile(so) or any(os.path.getmtime(dep) > os.path.getmtime(so) for dep in deps):
+            subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-o', so, src])
+        lib = ctypes.CDLL(so)
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
+        lib.emu_config_new.restype = ctypes.c_void_p
+        lib.emu_config_free.argtypes = [ctypes.c_void_p]
+        lib.emu_config_set_f64.argtypes = [ctypes.c_void_p, ctypes.c_char_p, dp, ctypes.c_int64]
+        lib.emu_config_set_i32.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ip, ctypes.c_int64]
+        lib.emu_last_error.restype = ctypes.c_char_p
+        lib.emu_eval_theory.argtypes = [ctypes.c_void_p, dp, ctypes.c_int64, ctypes.c_int, dp, dp]
+        lib.emu_eval_batch.argtypes = [ctypes.c_void_p, dp, ctypes.c_int64, dp, dp]
+        _emu = lib
+    return _emu
+
+
+class Emulation(object):
+
+    def __init__(self, spec):
+        from desilike_amd._lib import fill_config
+        self.lib = load_emulation()
+        self.cfg = self.lib.emu_config_new()
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
+        fill_config(spec, lambda key, a: self.lib.emu_config_set_f64(self.cfg, key.encode(), a.ctypes.data_as(dp), a.size),
+                    lambda key, a: self.lib.emu_config_set_i32(self.cfg, key.encode(), a.ctypes.data_as(ip), a.size))
+        self.spec = spec
+
+    def eval_theory(self, theta, iobs=0):
+        theta = np.ascontiguousarray(theta, dtype='f8')
+        obs = self.spec['observables'][iobs]
+        n_ell, n_kin = len(obs['ells_in']), len(obs['kin'])
+        power, tables = np.empty((len(theta), n_ell, n_kin)), np.empty((len(theta), 3, n_ell, n_kin))
+        dp = ctypes.POINTER(ctypes.c_double)
+        if self.lib.emu_eval_theory(self.cfg, theta.ctypes.data_as(dp), len(theta), iobs, power.ctypes.data_as(dp), tables.ctypes.data_as(dp)):
+            raise RuntimeError(self.lib.emu_last_error().decode())
+        return power, tables
+
+    def eval_batch(self, theta):
+        theta = np.ascontiguousarray(theta, dtype='f8')
+        n = sum(len(obs['flatdata']) for obs in self.spec['observables'])
+        loglike, flat = np.empty(len(theta)), np.empty((len(theta), n))
+        dp = ctypes.POINTER(ctypes.c_double)
+        if self.lib.emu_eval_batch(self.cfg, theta.ctypes.data_as(dp), len(theta), loglike.ctypes.data_as(dp), flat.ctypes.data_as(dp)):
+            raise RuntimeError(self.lib.emu_last_error().decode())
+        return loglike, flat
+
+    def __del__(self):
+        self.lib.emu_config_free(self.cfg)

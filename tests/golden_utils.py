@@ -34,3 +34,34 @@ def observable_constants(g, iobs=0):
 
 def prior_list(g):
     return [dict(dist=['uniform', 'norm'][int(row[0])], limits=(row[1], row[2]), loc=row[3], scale=row[4]) for row in g['priors']]
+
+
+def spec_from_golden(g):
+    """Likelihood spec (the nested dict ``desilike_amd._lib.fill_config`` flattens into C-ABI config keys) from a golden fixture."""
+    names = [str(n) for n in g['names']]
+    observables = []
+    iobs = 0
+    while 'obs{:d}'.format(iobs) in g:
+        c = g['obs{:d}'.format(iobs)]
+
+        def inp(name, default):
+            return (names.index(name), default) if name in names else (-1, default)
+
+        inputs = {'qpar': inp('qpar', 1.), 'qper': inp('qper', 1.), 'qiso': inp('qiso', 1.), 'qap': inp('qap', 1.), 'df': inp('df', 1.), 'dm': inp('dm', 0.), 'dn': inp('dn', 0.),
+                  'sigmapar': inp('sigmapar', 0.), 'sigmaper': inp('sigmaper', 0.), 'b1X': inp('b1', 1.), 'b1Y': inp('b1', 1.), 'sn0': inp('sn0', 0.)}
+        apmode = 3 if 'qiso' in names and 'qap' in names else 0
+        obs = dict(theory=np.array([1 if 'ct_matrix' in c else 0]), template=np.array([1 if str(c['template']).startswith('ShapeFit') else 0]),
+                   apmode=np.array([apmode]), transform=np.array([0]), eta=[1. / 3.], f_fid=[c['f_fid']], a=[c.get('a', 0.6)], kp=[c.get('kp', 0.03)], nd=[c['nd']],
+                   ells_in=np.asarray(c['ellsin'], dtype='i4'), kin=c['kin'], mu=c['mu'], wmu_ell=c['wmu_ell'], k_t=c['k11'], pk_dd_fid=c['pk_dd_fid'],
+                   wmatrix=c.get('matrix_full', None), kmask=c.get('kmask', None), offset=c.get('offset', None),
+                   shotnoise_in=c['shotnoisein'], shotnoise_out=c['shotnoiseout'], flatdata=c['flatdata'])
+        if 'ct_matrix' in c:
+            obs['ct_matrix'], obs['sn_matrix'] = c['ct_matrix'], c['sn_matrix']
+            ct = [[inp(str(n), 0.)] * 2 for n in c['ct_params']]
+            sn = [inp(str(n), 0.) for n in c['sn_params']]
+            inputs['ct'] = ([[t[0] for t in row] for row in ct], [[t[1] for t in row] for row in ct])
+            inputs['sn'] = ([t[0] for t in sn], [t[1] for t in sn])
+        obs['inputs'] = inputs
+        observables.append(obs)
+        iobs += 1
+    return dict(n_params=np.array([len(names)]), priors=g['priors'], precision=g['precision'], observables=observables)

@@ -1,0 +1,25 @@
+"""CPU: the device arithmetic (desilike_amd/csrc/dl_fullshape.h phases + dl_host.hpp constant folding), emulated
+workgroup by workgroup on the host, against golden vectors from the reference.  Catches kernel logic errors without a GPU."""
+import numpy as np
+import pytest
+
+from golden_utils import load_golden, spec_from_golden
+from emulation import Emulation
+
+
+@pytest.mark.parametrize('name', ['cfg1_kaiser_nowindow', 'cfg2_shapefit_window', 'cfg2_shapefit_window_dense', 'cfg2v_eft_damping_qisoqap'])
+def test_emulated_kernel_vs_reference(name):
+    g = load_golden(name)
+    emu = Emulation(spec_from_golden(g))
+    theta = g['theta']
+    nint = g['int_power'].shape[0]
+    power, tables = emu.eval_theory(theta[:nint])
+    for i, key in enumerate(['pk_dd', 'pk_dt', 'pk_tt']):
+        ref = g['int_' + key][:, 0]
+        assert np.allclose(tables[:, i], ref, rtol=1e-11, atol=1e-12 * np.abs(ref).max()), key
+    ref = g['int_power'][:, 0]
+    assert np.allclose(power, ref, rtol=1e-11, atol=1e-12 * np.abs(ref).max())
+    loglike, flat = emu.eval_batch(theta)
+    assert np.allclose(flat, g['flattheory'], rtol=1e-11, atol=1e-8)
+    tol = 1e-10 * np.maximum(1., np.abs(g['loglikelihood']))
+    assert (np.abs(loglike - g['loglikelihood']) <= tol).all(), np.abs(loglike - g['loglikelihood']).max()

@@ -1,0 +1,94 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against golden vectors captured from the reference
+and against the NumPy oracle on seeded inputs.  Tolerances: 1e-10 on logL (north star; relative above |logL| = 1),
+1e-11 relative on intermediates."""
+import numpy as np
+import pytest
+
+from golden_utils import load_golden, spec_from_golden, observable_constants, prior_list
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = ['cfg1_kaiser_nowindow', 'cfg2_shapefit_window', 'cfg2_shapefit_window_dense', 'cfg2v_eft_damping_qisoqap']
+
+
+@pytest.fixture(scope='module')
+def contexts():
+    from desilike_amd._lib import Context
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            g = load_golden(name)
+            cache[name] = (g, Context(spec_from_golden(g), device=0))
+        return cache[name]
+
+    yield get
+    for g, ctx in cache.values():
+        ctx.close()
+
+
+@pytest.mark.parametrize('name', GOLDEN)
+def test_theory_tables_vs_reference(contexts, name):
+    g, ctx = contexts(name)
+    nint = g['int_power'].shape[0]
+    power, tables = ctx.eval_theory_host(g['theta'][:nint], iobs=0, return_tables=True)
+    for i, key in enumerate(['pk_dd', 'pk_dt', 'pk_tt']):
+        ref = g['int_' + key][:, 0]
+        assert np.allclose(tables[:, i], ref, rtol=1e-11, atol=1e-12 * np.abs(ref).max()), key
+    ref = g['int_power'][:, 0]
+    assert np.allclose(power, ref, rtol=1e-11, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('name', GOLDEN)
+def test_loglikelihood_vs_reference(contexts, name):
+    g, ctx = contexts(name)
+    loglike, logprior, status, flat = ctx.eval_batch_host(g['theta'], return_flattheory=True)
+    assert np.allclose(flat, g['flattheory'], rtol=1e-11, atol=1e-8)
+    tol = 1e-10 * np.maximum(1., np.abs(g['loglikelihood']))
+    assert (np.abs(loglike - g['loglikelihood']) <= tol).all(), np.abs(loglike - g['loglikelihood']).max()
+    finite = np.isfinite(g['logprior'])
+    assert np.allclose(logprior[finite], g['logprior'][finite], rtol=1e-13, atol=1e-13)
+    assert np.array_equal(np.isneginf(logprior), np.isneginf(g['logprior']))
+    assert np.array_equal(status == 1, np.isneginf(g['logprior']))
+    assert (status[finite] == 0).all()
+
+
+def test_vs_oracle_seeded_batch(contexts):
+    """Same seeded inputs through the HIP path and the NumPy oracle, at a size the oracle finishes in seconds (B = 257: ragged tile)."""
+    from oracle import np_oracle as orc
+    g, ctx = contexts('cfg2_shapefit_window_dense')
+    c, priors = observable_constants(g), prior_list(g)
+    rng = np.random.RandomState(123)
+    lo = np.array([0.9, 0.9, -0.5, 0.5, 0.5, -3.])
+    hi = np.array([1.1, 1.1, 0.5, 1.5, 3.5, 3.])
+    theta = rng.uniform(lo, hi, size=(257, 6))
+    loglike, logprior, status = ctx.eval_batch_host(theta)
+    names = [str(n) for n in g['names']]
+    ref = []
+    for row in theta:
+        p = dict(zip(names, row)); p['b1'] = (p['b1'], p['b1'])
+        out = orc.fullshape_observable(c, p)
+        ref.append(orc.gaussian_loglikelihood(out['flattheory'], c['flatdata'], g['precision'])[0])
+    ref = np.array(ref)
+    assert (np.abs(loglike - ref) <= 1e-10 * np.maximum(1., np.abs(ref))).all(), np.abs((loglike - ref) / ref).max()
+    assert np.allclose(logprior, orc.logprior(theta, priors), rtol=1e-13, atol=1e-13)
+    assert (status == 0).all()
+
+
+def test_edge_cases(contexts):
+    g, ctx = contexts('cfg2_shapefit_window')
+    theta = g['theta'][:5].copy()
+    theta[1, 2] = np.nan
+    loglike, logprior, status = ctx.eval_batch_host(theta)
+    assert status[1] == 3 and status[0] == 0
+    # B = 1 (scalar likelihood() call surface) and empty batch
+    l1, p1, s1 = ctx.eval_batch_host(g['theta'][:1])
+    assert np.isclose(l1[0], g['loglikelihood'][0], rtol=1e-12, atol=1e-10)
+    l0, p0, s0 = ctx.eval_batch_host(np.zeros((0, ctx.n_params)))
+    assert l0.size == 0
+    # data generated from theory => logL(fiducial) = 0 (likelihoods/tests/test_galaxy_clustering.py:6-16)
+    names = [str(n) for n in g['names']]
+    fid = np.array([[1., 1., 0., 1., 2., 0.]])
+    assert names == ['qpar', 'qper', 'dm', 'df', 'b1', 'sn0']
+    lf, _, _ = ctx.eval_batch_host(fid)
+    assert abs(lf[0]) < 1e-12
