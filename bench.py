@@ -1,0 +1,185 @@
+"""Benchmark of the hot path: log-likelihood evaluations / second (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): ShapeFit + Kaiser P_ell, ell = (0, 2, 4), 40 k-bins, dense synthetic
+survey-like window (120 x 1200), full 120 x 120 precision; one *step* = one pass of the hot path over a batch of
+1024 parameter points per GPU (theta already resident in HBM).  N > 1: one process per GPU (torchrun), walkers
+sharded contiguously (weak scaling: 1024 points per rank), one RCCL all-gather of the log-posteriors per step.
+Prints ONE JSON line (rank 0).  Synthetic inputs only; nothing here reads /root/reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 1024
+# Algorithmic FLOP per evaluation (DESIGN.md "Measurement"), fp64 add/mul = 1, transcendental = 20
+FLOP_THEORY = 23e3 + 5e3 + 288e3 + 57.6e3 + 7e3    # template factor, spline coefficients, AP + spline eval, GL projection, tracer combine
+FLOP_GEMM = 288e3 + 29e3                            # window GEMM 2 n n_in + chi2 2 n^2 + 2 n (precision folded into the window matrix)
+FLOP_FINAL = 2 * 120 + 5 * 6
+PEAK_FP64_TFLOPS = 78.6                             # MI355X public spec, FP64 vector = FP64 matrix (the CDNA4 guide lists no fp64 row)
+
+
+def dense_window(kedges, ells, resolution=10, seed=7):
+    """Synthetic survey-like window: binning matrix (x) Gaussian k-mixing + 5 % multipole leakage + 1 % noise (SURVEY.md 8d cfg 2)."""
+    from desilike_amd.utils import window_matrix_bininteg
+    edges = np.column_stack([kedges[:-1], kedges[1:]])
+    kin, binmat = window_matrix_bininteg([edges] * len(ells), resolution=resolution)
+    binmat = binmat.T
+    nin = kin.size
+    smooth = np.exp(-0.5 * ((kin[:, None] - kin[None, :]) / 0.004)**2)
+    smooth /= smooth.sum(axis=1)[:, None]
+    nl = len(ells)
+    mix = np.zeros((nl * nin, nl * nin))
+    for i in range(nl):
+        for j in range(nl):
+            mix[i * nin:(i + 1) * nin, j * nin:(j + 1) * nin] = smooth * (1. if i == j else 0.05 / (1 + abs(i - j)))
+    rng = np.random.RandomState(seed)
+    return kin, binmat.dot(mix) * (1. + 0.01 * rng.standard_normal((binmat.shape[0], mix.shape[1])))
+
+
+def make_likelihood(device):
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    kedges = np.linspace(0., 0.2, 41)
+    kin, wmat = dense_window(kedges, (0, 2, 4))
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    theory = KaiserTracerPowerSpectrumMultipoles(template=template)
+    observable = TracerPowerSpectrumMultipolesObservable(data={'b1': 2.}, kedges=kedges, ells=(0, 2, 4), wmatrix=wmat, kin=kin, ellsin=(0, 2, 4), theory=theory, shotnoise=1e4)
+    rng = np.random.RandomState(1)
+    A = rng.standard_normal((120, 120)) * 30.
+    likelihood = ObservablesGaussianLikelihood(observables=[observable], covariance=A.dot(A.T) + 1e4 * np.eye(120), device=device)
+    likelihood.initialize()
+    return likelihood
+
+
+def sample_theta(likelihood, size, seed):
+    """theta ~ Parameter.ref, as samplers draw their start (samplers/base.py:222-230)."""
+    rng = np.random.RandomState(seed)
+    return np.column_stack([param.ref.sample(size=size, random_state=rng) for param in likelihood.varied_params])
+
+
+def oracle_constants(likelihood):
+    """Constants for the NumPy oracle (cpu_baseline leg only), read off the host-side calculators."""
+    obs = likelihood.observables[0]
+    wm, theory = obs.wmatrix, obs.wmatrix.theory
+    template = theory.template
+    return dict(template='shapefit', k11=template.k, pk_dd_fid=template.pk_dd_fid, f_fid=template.f_fid, kp=template.kp, a=template.a, kin=theory.k, mu=theory.mu,
+                wmu_ell=theory.wmu, ellsin=theory.ells, nd=theory.nd, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout, flatdata=obs.flatdata)
+
+
+def cpu_baseline(likelihood, theta, budget=12.):
+    """The NumPy oracle (restatement of the reference's numpy path, pinned to its golden vectors) on 1 host core, bounded sample."""
+    from oracle import np_oracle as orc
+    c = oracle_constants(likelihood)
+    names = likelihood.varied_params.names()
+    precision = likelihood.precision
+    t0, n, check = time.perf_counter(), 0, []
+    while time.perf_counter() - t0 < budget and n < len(theta):
+        p = dict(zip(names, theta[n]))
+        p['b1'] = (p['b1'], p['b1'])
+        out = orc.fullshape_observable(c, p)
+        check.append(orc.gaussian_loglikelihood(out['flattheory'], c['flatdata'], precision)[0])
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit='evals/s', cores=1, kind='port', sample='{:d} of the {:d} points of one step, {:.1f} s, NumPy oracle, 1 thread'.format(n, len(theta), dt)), np.array(check)
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--gpus', type=int, default=1)
+    parser.add_argument('--steps', type=int, default=200)
+    parser.add_argument('--warmup', type=int, default=20)
+    parser.add_argument('--batch', type=int, default=BATCH)
+    parser.add_argument('--no-cpu-baseline', action='store_true')
+    args = parser.parse_args()
+
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise RuntimeError('bench.py needs a GPU: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group(backend='nccl', device_id=device)
+
+    likelihood = make_likelihood(local_rank)
+    ctx = likelihood._get_context()
+    B = args.batch
+    theta_host = sample_theta(likelihood, B, seed=42 + rank)
+    theta = torch.as_tensor(theta_host, dtype=torch.float64, device=device).contiguous()
+    loglike = torch.empty(B, dtype=torch.float64, device=device)
+    logprior = torch.empty(B, dtype=torch.float64, device=device)
+    status = torch.empty(B, dtype=torch.int32, device=device)
+    logpost = torch.empty(B, dtype=torch.float64, device=device)
+    gathered = torch.empty(world * B, dtype=torch.float64, device=device) if distributed else None
+    stream = torch.cuda.current_stream(device)
+
+    def step():
+        ctx.eval_batch(theta, loglike=loglike, logprior=logprior, status=status, stream=stream.cuda_stream)
+        if distributed:
+            # the path's one real exchange: every rank needs every walker's log-posterior (samplers/base.py:200)
+            torch.add(loglike, logprior, out=logpost)
+            dist.all_gather_into_tensor(gathered, logpost)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_enable(True)   # HIP events on the launch stream around each kernel of the timed steps
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ctx.profile_read()
+    ctx.profile_enable(False)
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    assert int((status != 0).sum().item()) == 0, 'non-OK status in the benchmark batch'
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        flops = {'theory': FLOP_THEORY, 'window_gemm': FLOP_GEMM, 'finalize': FLOP_FINAL}
+        dominant = max(['theory', 'window_gemm', 'finalize'], key=lambda name: kernel_ms[name])
+        achieved = flops[dominant] * B / (kernel_ms[dominant] * 1e-3) / 1e12
+        result = {'metric': 'log-likelihood evals/sec (full-shape P_ell, 3x40 bins)', 'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
+                  'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+                  'data': 'synthetic',
+                  'config': {'workload': 'BASELINE configs[1]: ShapeFit+Kaiser P_ell ell=(0,2,4) x 40 k-bins, dense window 120x1200 (n_kin=400/ell), 120x120 precision, '
+                                         '{:d} batched param points per GPU per step'.format(B), 'batch_per_gpu': B, 'n_params': 6, 'parallelism': 'walkers x{:d}'.format(world)},
+                  'roofline': {'bound': 'mfma', 'kernel': {'theory': 'dl_fullshape_kernel', 'window_gemm': 'dl_window_gemm_kernel', 'finalize': 'dl_finalize_kernel'}[dominant],
+                               'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS, 'traffic': None,
+                               'flop_per_launch': flops[dominant] * B, 'avg_launch_ms': kernel_ms[dominant]},
+                  'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize', 'total']}}
+        if world == 1 and not args.no_cpu_baseline:
+            base, check = cpu_baseline(likelihood, theta_host)
+            gpu = loglike[:len(check)].cpu().numpy()
+            assert (np.abs(gpu - check) <= 1e-10 * np.maximum(1., np.abs(check))).all(), 'GPU / oracle mismatch in bench'
+            result['cpu_baseline'] = base
+        print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,165 @@
+"""Calculator plugin surface kept from desilike (reference: desilike/base.py -- ``BaseCalculator`` 1119-1323,
+``InitConfig`` 30-121, ``vmap`` 232-383), re-designed for a batched GPU back-end.
+
+In the reference every calculator runs its own ``calculate()`` per point inside ``BasePipeline.calculate``
+(base.py:510-572).  Here calculators are *declarative*: they keep the reference's constructor arguments,
+parameter names / priors and attributes, and contribute constants to one likelihood ``spec`` that is
+uploaded once (``dl_create``); evaluation of any batch is a single ``dl_eval_batch`` call.
+"""
+import numpy as np
+
+from .parameter import Parameter, ParameterCollection, Samples
+
+
+class PipelineError(Exception):
+    """Error raised when a calculator cannot be set up (name kept from desilike/base.py)."""
+
+
+class InitConfig(dict):
+    """Constructor arguments + parameters of a calculator; updating it invalidates compiled state (base.py:30-121)."""
+
+    def __init__(self, owner, kwargs, params):
+        super(InitConfig, self).__init__(kwargs)
+        self._owner = owner
+        self._params = params
+
+    @property
+    def params(self):
+        return self._params
+
+    @params.setter
+    def params(self, params):
+        self._params = params if isinstance(params, ParameterCollection) else ParameterCollection(params)
+        self._owner._invalidate()
+
+    @staticmethod
+    def _same(a, b):
+        if a is b: return True
+        try:
+            return bool(np.array_equal(np.asarray(a, dtype='f8'), np.asarray(b, dtype='f8')))
+        except (TypeError, ValueError):
+            return False
+
+    def update(self, *args, **kwargs):
+        new = dict(*args, **kwargs)
+        changed = any(key not in self or not self._same(self[key], value) for key, value in new.items())
+        super(InitConfig, self).update(new)
+        if changed: self._owner._invalidate()
+
+    def __setitem__(self, key, value):
+        changed = key not in self or not self._same(self[key], value)
+        super(InitConfig, self).__setitem__(key, value)
+        if changed: self._owner._invalidate()
+
+    def setdefault(self, key, value):
+        if key not in self:
+            self[key] = value
+        return self[key]
+
+
+class _TrackedCollection(ParameterCollection):
+    """ParameterCollection whose parameters report updates to the owning calculator."""
+
+
+class BaseCalculator(object):
+    """Base calculator: ``init`` (arguments + params), ``params``, lazy ``initialize`` (base.py:1119-1323)."""
+
+    _params = {}
+
+    def __init__(self, *args, **kwargs):
+        if args:
+            raise TypeError('{} takes keyword arguments only'.format(self.__class__.__name__))
+        self._dependents = []
+        self._initialized = False
+        self.init = InitConfig(self, kwargs, ParameterCollection(self._default_params(**kwargs)))
+
+    @classmethod
+    def _default_params(cls, **kwargs):
+        import copy
+        return copy.deepcopy(cls._params)
+
+    @property
+    def params(self):
+        return self.init.params
+
+    @params.setter
+    def params(self, params):
+        self.init.params = params
+
+    def _invalidate(self):
+        self._initialized = False
+        for dep in getattr(self, '_dependents', []):
+            dep._invalidate()
+
+    def _require(self, calculator):
+        """Register ``calculator`` as a requirement: its updates invalidate ``self`` (base.py:1024-1029)."""
+        if self not in calculator._dependents:
+            calculator._dependents.append(self)
+        return calculator
+
+    def _param_signature(self):
+        return tuple(sorted((name, repr(param.__getstate__())) for name, param in ((p.name, p) for p in self.init.params)))
+
+
+def _check_params(params):
+    """dict name -> array: broadcast scalars, return (dict of 1-D arrays, batch shape) (base.py:124-159)."""
+    shapes = [np.shape(value) for value in params.values()]
+    shape = ()
+    for s in shapes:
+        if s != () and shape not in ((), s):
+            raise ValueError('input shapes are different: {}'.format(dict(zip(params, shapes))))
+        if s != ():
+            shape = s
+    size = int(np.prod(shape, dtype='i8')) if shape else 1
+    flat = {name: np.broadcast_to(np.asarray(value, dtype='f8'), shape).reshape(size) if shape else np.full(1, value, dtype='f8') for name, value in params.items()}
+    return flat, shape
+
+
+def vmap(calculate, backend=None, errors='raise', mpicomm=None, mpi_max_chunk_size=100, **kwargs):
+    """Vectorise ``calculate`` over a dict of parameter arrays (reference: base.py:232-383).
+
+    For the likelihoods of this package the whole batch is ONE GPU evaluation, whatever ``backend`` says
+    ('jax' / 'mpi' / None are accepted for drop-in compatibility); ``errors`` keeps its meaning:
+    per-point failures (non-finite results) are reported, never raised, when errors != 'raise'.
+    Any other callable falls back to the reference's plain Python loop (backend=None semantics).
+    """
+    errors = str(errors)
+    batched = getattr(calculate, '_evaluate_dict', None)
+
+    if batched is not None:
+        def wrapper(params, **kw):
+            kw = {**kwargs, **kw}
+            kw.pop('mpicomm', None)
+            flat, shape = _check_params(params)
+            results, errs = batched(flat, shape, errors=errors, **kw)
+            if errors == 'return':
+                return results, errs
+            return results
+        wrapper.__wrapped__vmap__ = calculate
+        return wrapper
+
+    def wrapper(params, **kw):
+        kw = {**kwargs, **kw}
+        kw.pop('mpicomm', None)
+        flat, shape = _check_params(params)
+        size = len(next(iter(flat.values()))) if flat else 0
+        results, errs = [], {}
+        for i in range(size):
+            try:
+                results.append(calculate({name: value[i] for name, value in flat.items()}, **kw))
+            except Exception as exc:
+                if errors == 'raise':
+                    raise
+                import traceback
+                errs[i] = (exc, traceback.format_exc())
+                results.append(None)
+        ref = next((res for res in results if res is not None), None)
+        if ref is not None:
+            fill = np.nan * np.asarray(ref) if errors == 'nan' else ref
+            results = [fill if res is None else res for res in results]
+            results = np.asarray(results).reshape(shape + np.shape(ref))
+        if errors == 'return':
+            return results, errs
+        return results
+
+    return wrapper

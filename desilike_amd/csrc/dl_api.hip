@@ -44,7 +44,9 @@ struct dl_ctx {
     int32_t* status_stage = nullptr; // device
     // profiling
     bool profile = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    static const int NPOOL = 256;            // event sets kept: dl_profile_read averages over the calls recorded since dl_profile_enable
+    std::vector<hipEvent_t> ev;              // [NPOOL * 4]
+    int64_t prof_calls = 0;
     std::string last_error;
 };
 
@@ -191,7 +193,6 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
         dl_destroy(ctx);
         return 1;
     }
-    for (int i = 0; i < 4; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return bail("dl_create: hipEventCreate failed");
     *out = ctx;
     return 0;
 }
@@ -203,7 +204,7 @@ void dl_destroy(dl_ctx* ctx) {
                     ctx->bias_wh_dev, ctx->flatdata_dev, ctx->transform_dev, ctx->power_ws, ctx->delta_ws, ctx->flat_ws, ctx->theta_stage, ctx->out_stage,
                     ctx->status_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -256,9 +257,10 @@ int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logli
         int64_t nb = std::min<int64_t>(DL_CHUNK, B - b0);
         const double* th = theta_dev + (size_t)b0 * P;
         bool prof = ctx->profile && b0 == 0;
-        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], stream));
+        hipEvent_t* ev = prof ? &ctx->ev[(size_t)(ctx->prof_calls % dl_ctx::NPOOL) * 4] : nullptr;
+        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[0], stream));
         dl_launch_fullshape(ctx->obs_dev, ctx->n_obs, ctx->max_n_t, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream);
-        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], stream));
+        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[1], stream));
         bool need_flat = ctx->any_transform || flattheory_dev != nullptr;
         if (need_flat) {
             // flattheory = W . power + bias (window.py:459-473), then optional cubic transform (power_spectrum.py:402-404)
@@ -278,10 +280,10 @@ int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logli
             dl_launch_window_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad,
                                   ctx->K_pad, stream);
         }
-        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], stream));
+        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
         dl_launch_finalize(ctx->delta_ws, ctx->N_pad, n, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
                            status_dev ? status_dev + b0 : nullptr, stream);
-        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ctx->ev[3], stream));
+        if (prof) { DL_HIP_CHECK(ctx, hipEventRecord(ev[3], stream)); ctx->prof_calls++; }
     }
     DL_HIP_CHECK(ctx, hipGetLastError());
     return 0;
@@ -367,19 +369,31 @@ int dl_eval_theory_host(dl_ctx* ctx, const double* theta, int64_t B, int32_t iob
 
 int dl_profile_enable(dl_ctx* ctx, int enable) {
     if (!ctx) { g_last_error = "dl_profile_enable: null context"; return 1; }
+    if (enable && ctx->ev.empty()) {
+        ctx->ev.assign((size_t)dl_ctx::NPOOL * 4, nullptr);
+        for (auto& e : ctx->ev) DL_HIP_CHECK(ctx, hipEventCreate(&e));
+    }
     ctx->profile = enable != 0;
+    ctx->prof_calls = 0;
     return 0;
 }
 
 int dl_profile_read(dl_ctx* ctx, double* ms, int32_t n) {
     if (!ctx || !ms || n < 4) return dl_fail(ctx, "dl_profile_read: need room for 4 values");
-    DL_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[3]));
-    float t01 = 0, t12 = 0, t23 = 0, t03 = 0;
-    DL_HIP_CHECK(ctx, hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]));
-    DL_HIP_CHECK(ctx, hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));
-    DL_HIP_CHECK(ctx, hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]));
-    DL_HIP_CHECK(ctx, hipEventElapsedTime(&t03, ctx->ev[0], ctx->ev[3]));
-    ms[0] = t01; ms[1] = t12; ms[2] = t23; ms[3] = t03;
+    if (ctx->ev.empty() || ctx->prof_calls == 0) return dl_fail(ctx, "dl_profile_read: no profiled call recorded");
+    int64_t ncalls = std::min<int64_t>(ctx->prof_calls, dl_ctx::NPOOL);
+    ms[0] = ms[1] = ms[2] = ms[3] = 0.;
+    for (int64_t c = 0; c < ncalls; ++c) {
+        hipEvent_t* ev = &ctx->ev[(size_t)c * 4];
+        DL_HIP_CHECK(ctx, hipEventSynchronize(ev[3]));
+        float t01 = 0, t12 = 0, t23 = 0, t03 = 0;
+        DL_HIP_CHECK(ctx, hipEventElapsedTime(&t01, ev[0], ev[1]));
+        DL_HIP_CHECK(ctx, hipEventElapsedTime(&t12, ev[1], ev[2]));
+        DL_HIP_CHECK(ctx, hipEventElapsedTime(&t23, ev[2], ev[3]));
+        DL_HIP_CHECK(ctx, hipEventElapsedTime(&t03, ev[0], ev[3]));
+        ms[0] += t01; ms[1] += t12; ms[2] += t23; ms[3] += t03;
+    }
+    for (int i = 0; i < 4; ++i) ms[i] /= (double)ncalls;
     return 0;
 }
 

@@ -1,0 +1,63 @@
+"""Fiducial-cosmology providers for the power-spectrum templates.
+
+The reference takes its fiducial linear power spectrum from the third-party Boltzmann wrapper ``cosmoprimo``
+(power_template.py:49-66), which is out of scope (CPU, external).  The hot path only
+needs the fiducial *tables*: ``pk_dd(k)``, optionally the no-wiggle ``pknow_dd(k)``, and the growth rate ``f``.
+"""
+import numpy as np
+
+
+class TabulatedFiducial(object):
+    """Fiducial given as tables (e.g. exported once from cosmoprimo / CLASS / CAMB on a CPU node)."""
+
+    def __init__(self, k, pk_dd, f, pknow_dd=None, sigma8=None):
+        self.k = np.asarray(k, dtype='f8')
+        self._logpk = np.log(np.asarray(pk_dd, dtype='f8'))
+        self._logpknow = None if pknow_dd is None else np.log(np.asarray(pknow_dd, dtype='f8'))
+        self.f = float(f)
+        self.sigma8 = sigma8
+
+    def _interp(self, k, table):
+        from scipy import interpolate
+        k = np.asarray(k, dtype='f8')
+        if k.shape == self.k.shape and np.array_equal(k, self.k):
+            return np.exp(table)
+        return np.exp(interpolate.CubicSpline(np.log(self.k), table)(np.log(k)))
+
+    def pk_dd(self, k):
+        return self._interp(k, self._logpk)
+
+    def pknow_dd(self, k):
+        if self._logpknow is None:
+            raise ValueError('no-wiggle table not provided')
+        return self._interp(k, self._logpknow)
+
+
+class SyntheticFiducial(object):
+    r"""Analytic synthetic cosmology used for benchmarks and fixtures:
+    :math:`P(k) = A (k / 0.05)^{n_s} T_\mathrm{BBKS}(k / k_\mathrm{eq})^2 (1 + w \sin(k r_s) e^{-(8 k)^2})`, ``f = 0.8``."""
+
+    def __init__(self, A=2.5e4, n_s=0.965, keq=0.015, rs=100., wiggle=0.05, f=0.8):
+        self.A, self.n_s, self.keq, self.rs, self.wiggle, self.f = A, n_s, keq, rs, wiggle, f
+
+    def _pk(self, k, wiggle):
+        k = np.asarray(k, dtype='f8')
+        q = k / self.keq
+        T = np.log(1. + 2.34 * q) / (2.34 * q) * (1. + 3.89 * q + (16.1 * q)**2 + (5.46 * q)**3 + (6.71 * q)**4)**(-0.25)
+        return self.A * (k / 0.05)**self.n_s * T**2 * (1. + wiggle * np.sin(k * self.rs) * np.exp(-(8. * k)**2))
+
+    def pk_dd(self, k):
+        return self._pk(k, self.wiggle)
+
+    def pknow_dd(self, k):
+        return self._pk(k, 0.)
+
+
+def get_fiducial(fiducial):
+    if fiducial is None or (isinstance(fiducial, str) and fiducial.lower() in ('synthetic', 'desi')):
+        # 'DESI' is the reference's default (a cosmoprimo.fiducial entry): not available without cosmoprimo,
+        # so the synthetic analytic cosmology stands in; pass a TabulatedFiducial for a real analysis.
+        return SyntheticFiducial()
+    if isinstance(fiducial, dict):
+        return TabulatedFiducial(**fiducial)
+    return fiducial

@@ -1,0 +1,373 @@
+"""Gaussian likelihoods (reference: desilike/likelihoods/base.py -- ``BaseLikelihood`` 203-462,
+``ObservablesGaussianLikelihood`` 504-712, ``SumLikelihood`` 715-732).
+
+Host side: collects the observables' constants and parameters into one likelihood ``spec``, builds the
+precision matrix exactly like the reference (block-wise inverse 617-619, scale_covariance 606-621, Hartlap 623-629,
+Percival 633-656) and hands everything to ``dl_create``.  Evaluation (``__call__``, ``vmap``) is one
+``dl_eval_batch`` call on the GPU; there is no CPU path.
+"""
+import numpy as np
+
+from ..base import BaseCalculator, PipelineError
+from ..parameter import Parameter, ParameterCollection, Samples
+from .. import utils
+
+
+class BaseLikelihood(BaseCalculator):
+    """Base likelihood: ``loglikelihood`` / ``logprior`` derived parameters, ``__call__`` surface (likelihoods/base.py:203-245)."""
+    name = None
+    solved_default = '.marg'
+    _attrs = ['loglikelihood', 'logprior']
+
+    def _set_derived_params(self):
+        self.name = self.init.get('name', self.name)
+        for name in self._attrs:
+            setattr(self, '_param_{}'.format(name), Parameter(basename=name, namespace=self.name or '', derived=True))
+
+    # ---- parameters -------------------------------------------------------------------------------
+    @property
+    def all_params(self):
+        self.initialize()
+        return self._all_params
+
+    @property
+    def varied_params(self):
+        """Sampled parameters: varied, not derived, not solved (base.py:1273-1281)."""
+        return ParameterCollection([param for param in self.all_params if param.varied and not param.solved and param.derived is False])
+
+    # ---- evaluation -------------------------------------------------------------------------------
+    def __call__(self, *args, return_derived=False, **kwargs):
+        """``likelihood(**params)`` or ``likelihood(dict)`` -> loglikelihood + logprior (base.py:1194-1196, likelihoods/base.py:242-245)."""
+        params = {}
+        for arg in args:
+            params.update(arg)
+        params.update(kwargs)
+        (logposterior, derived), errs = self._evaluate_dict({name: np.asarray(value, dtype='f8') for name, value in params.items()}, (), errors='return',
+                                                            return_derived=True)
+        self.loglikelihood = float(derived[self._param_loglikelihood][()])
+        self.logprior = float(derived[self._param_logprior][()])
+        toret = self.loglikelihood + self.logprior
+        if return_derived:
+            return toret, derived
+        return toret
+
+    def _evaluate_dict(self, flat, shape, errors='raise', return_derived=False):
+        """Batched evaluation for :func:`desilike_amd.base.vmap`: dict name -> array[B] in, logposterior[shape] out."""
+        raise NotImplementedError
+
+    def __add__(self, other):
+        return SumLikelihood(likelihoods=[self, other])
+
+    def __radd__(self, other):
+        if other == 0:
+            return SumLikelihood(likelihoods=[self])
+        return self.__add__(other)
+
+
+class BaseGaussianLikelihood(BaseLikelihood):
+    """Gaussian likelihood of a flat theory vector (likelihoods/base.py:465-501); concrete classes define the observables."""
+
+
+def _collect_varied(observables):
+    all_params = ParameterCollection()
+    for obs in observables:
+        for param in obs.wmatrix.theory._all_params():
+            if param.name in all_params:
+                if all_params[param.name] != param:
+                    # same name used with different settings by two calculators: the first definition wins, like one shared pipeline parameter
+                    continue
+            else:
+                all_params.set(param)
+    return all_params
+
+
+class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
+    """
+    Gaussian likelihood of observables (likelihoods/base.py:504-712).
+
+    Parameters
+    ----------
+    observables : list, BaseCalculator
+    covariance : array, default=None
+        Covariance (2D) of the concatenated observables; if ``None``, block-diagonal from each observable's own.
+    scale_covariance : float, default=1.
+    correct_covariance : str, dict, default='hartlap-percival2014'
+        Applied only when the number of observations ``nobs`` is known (``{'nobs': nobs, 'correction': ...}``).
+    precision : array, default=None
+        Precision matrix (2D) or its diagonal (1D), used instead of the inverse covariance.
+    device : int, default=None
+        GPU ordinal (default: ``LOCAL_RANK`` env variable, else 0).
+    """
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        init = self.init
+        self._set_derived_params()
+        observables = init['observables']
+        if not isinstance(observables, (list, tuple)):
+            observables = [observables]
+        self.observables = list(observables)
+        for obs in self.observables:
+            self._require(obs)
+            obs.initialize()
+        covariance, precision = init.get('covariance', None), init.get('precision', None)
+        scale_covariance = init.get('scale_covariance', 1.)
+        correct_covariance = init.get('correct_covariance', 'hartlap-percival2014')
+        self.nobs = init.get('nobs', None)
+        if isinstance(correct_covariance, dict):
+            self.nobs = correct_covariance.get('nobs', self.nobs)
+            correct_covariance = correct_covariance['correction']
+        self.correct_covariance = correct_covariance
+        sizes = [obs.wmatrix.size for obs in self.observables]
+        size = sum(sizes)
+        if covariance is None and precision is None:
+            if all(getattr(obs, 'covariance', None) is not None for obs in self.observables):  # likelihoods/base.py:552-566
+                covariance = np.zeros((size, size), dtype='f8')
+                start = 0
+                for obs, n in zip(self.observables, sizes):
+                    covariance[start:start + n, start:start + n] = obs.covariance
+                    start += n
+                if self.nobs is None:
+                    nobs = [getattr(obs, 'nobs', None) for obs in self.observables]
+                    if all(nobs): self.nobs = int(np.mean(nobs))
+            else:
+                raise ValueError('Observables must have their own covariance if global covariance or precision matrix not provided')
+
+        def check_matrix(matrix, name, allow_1d=False):
+            if matrix is None:
+                return None
+            matrix = np.array(matrix, dtype='f8')
+            if allow_1d and matrix.ndim == 1:
+                if matrix.size != size: raise ValueError('{} diagonal must have size {:d}'.format(name, size))
+                return matrix
+            matrix = np.atleast_2d(matrix)
+            if matrix.shape != (size, size):
+                raise ValueError('based on provided observables, {} expected to be a matrix of shape ({:d}, {:d}), but found {}'.format(name, size, size, matrix.shape))
+            return matrix
+
+        self.precision = check_matrix(precision, 'precision', allow_1d=True)
+        self.covariance = check_matrix(covariance, 'covariance')
+        if self.covariance is not None:
+            self.covariance = self.covariance * scale_covariance
+            slices, start = [], 0
+            for obs, n in zip(self.observables, sizes):
+                slices.append(slice(start, start + n))
+                obs.covariance = self.covariance[slices[-1], slices[-1]]
+                start += n
+            if self.precision is None:
+                # block-inversion, as the reference (likelihoods/base.py:617-619, utils.py:561-599)
+                self.precision = utils.blockinv([[self.covariance[sl1, sl2] for sl2 in slices] for sl1 in slices])
+        else:
+            self.precision = self.precision / scale_covariance
+        if self.nobs is not None and 'hartlap' in self.correct_covariance:  # likelihoods/base.py:623-629
+            nbins = self.precision.shape[0]
+            self.hartlap2007_factor = (self.nobs - nbins - 2.) / (self.nobs - 1.)
+            self.precision = self.precision * self.hartlap2007_factor
+        self.precision_hartlap2007 = self.precision.copy()
+        self._all_params = _collect_varied(self.observables)
+        if self.nobs is not None and 'percival' in self.correct_covariance:  # likelihoods/base.py:633-656
+            nbins = self.precision_hartlap2007.shape[0]
+            A = 2. / (self.nobs - nbins - 1.) / (self.nobs - nbins - 4.)
+            B = (self.nobs - nbins - 2.) / (self.nobs - nbins - 1.) / (self.nobs - nbins - 4.)
+            nparams = len([param for param in self._all_params if param.varied and param.derived is False or param.solved])
+            self.percival2014_factor = (1 + B * (nbins - nparams)) / (1 + A + B * (nparams + 1))
+            self.precision = self.precision_hartlap2007 / self.percival2014_factor
+        self._contexts = {}
+        self._flatdata = None
+        self._initialized = True
+        self._generate_data()
+        return self
+
+    # ---- compile ------------------------------------------------------------------------------------
+    @property
+    def device(self):
+        import os
+        device = self.init.get('device', None)
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', 0))
+        return int(device)
+
+    def _spec(self, fixed_values, flatdata_list, precision):
+        """Nested likelihood spec flattened by ``_lib.fill_config`` into the C-ABI config keys (include/desilike_amd.h)."""
+        varied = self.varied_params
+        names = varied.names()
+        observables = []
+        for obs, flatdata in zip(self.observables, flatdata_list):
+            theory = obs.wmatrix.theory
+            spec = obs._observable_spec(flatdata=flatdata)
+
+            def resolve(pname, default):
+                if pname in names:
+                    return (names.index(pname), default)
+                if pname in fixed_values:
+                    return (-1, float(fixed_values[pname]))
+                if pname in self._all_params:
+                    return (-1, float(self._all_params[pname].value))
+                return (-1, default)
+
+            defaults = dict(qpar=1., qper=1., qiso=1., qap=1., df=1., dm=0., dn=0., sigmapar=0., sigmaper=0., b1X=1., b1Y=1., sn0=0.)
+            inputs = {}
+            for iname, pname in theory._input_map().items():
+                if iname == 'ct':
+                    res = [[resolve(pn, 0.) for pn in pair] for pair in pname]
+                    if res: inputs['ct'] = ([[r[0] for r in pair] for pair in res], [[r[1] for r in pair] for pair in res])
+                elif iname == 'sn':
+                    res = [resolve(pn, 0.) for pn in pname]
+                    if res: inputs['sn'] = ([r[0] for r in res], [r[1] for r in res])
+                else:
+                    inputs[iname] = resolve(pname, defaults[iname])
+            spec['inputs'] = inputs
+            observables.append(spec)
+        priors = np.array([param.prior.spec() for param in varied], dtype='f8').reshape(len(names), 5)
+        return dict(n_params=np.array([len(names)], dtype='i4'), priors=priors, precision=precision, observables=observables)
+
+    def _get_context(self, fixed_values=None):
+        from .._lib import Context
+        self.initialize()
+        fixed_values = dict(fixed_values or {})
+        key = tuple(sorted(fixed_values.items()))
+        if key not in self._contexts:
+            if len(self._contexts) > 8:
+                self._contexts.pop(next(iter(self._contexts))).close()
+            flatdata = self._flatdata_list()
+            self._contexts[key] = Context(self._spec(fixed_values, flatdata, self.precision), device=self.device)
+        return self._contexts[key]
+
+    def _flatdata_list(self):
+        return [obs.flatdata for obs in self.observables]
+
+    def _generate_data(self):
+        """Observables given ``data=dict(params)`` take the theory evaluated at these parameters as data (power_spectrum.py:86-88)."""
+        if not any(obs.flatdata is None for obs in self.observables):
+            self.flatdata = np.concatenate(self._flatdata_list())
+            return
+        from .._lib import Context
+        varied = self.varied_params
+        sizes = [obs.wmatrix.size for obs in self.observables]
+        zeros = [np.zeros(n) if obs.flatdata is None else obs.flatdata for obs, n in zip(self.observables, sizes)]
+        for iobs, obs in enumerate(self.observables):
+            if obs.flatdata is not None: continue
+            data_params = obs._data_params
+            fixed = {name: value for name, value in data_params.items() if name not in varied}
+            ctx = Context(self._spec(fixed, zeros, np.ones(sum(sizes))), device=self.device)
+            theta = np.array([[data_params.get(param.name, param.value) for param in varied]], dtype='f8')
+            flat = ctx.eval_batch_host(theta, return_flattheory=True)[3][0]
+            ctx.close()
+            start = sum(sizes[:iobs])
+            obs.flatdata = flat[start:start + sizes[iobs]].copy()
+        self.flatdata = np.concatenate(self._flatdata_list())
+
+    # ---- evaluation -------------------------------------------------------------------------------------
+    def _split_params(self, flat):
+        """Separate the values of varied parameters (theta columns) from overrides of fixed parameters."""
+        varied = self.varied_params
+        unknown = [name for name in flat if name not in self._all_params]
+        if unknown:
+            raise PipelineError('Input parameter {} is not one of parameters: {}'.format(unknown[0], self._all_params.names()))
+        size = max([np.size(value) for value in flat.values()] + [1])
+        theta = np.empty((size, len(varied)), dtype='f8')
+        for i, param in enumerate(varied):
+            theta[:, i] = flat.get(param.name, param.value)
+        fixed = {}
+        for name, value in flat.items():
+            if name not in varied:
+                value = np.unique(value)
+                if value.size != 1:
+                    raise PipelineError('parameter {} is fixed: it takes one value per batch'.format(name))
+                if float(value[0]) != self._all_params[name].value:
+                    fixed[name] = float(value[0])
+        return theta, fixed
+
+    def _evaluate_dict(self, flat, shape, errors='raise', return_derived=False, return_flattheory=False):
+        self.initialize()
+        theta, fixed = self._split_params(flat)
+        ctx = self._get_context(fixed)
+        out = ctx.eval_batch_host(theta, return_flattheory=return_flattheory)
+        loglike, logprior, status = out[:3]
+        if return_flattheory:
+            self.flattheory = out[3].reshape(shape + (ctx.n_data,))
+            self.flatdiff = self.flattheory - self.flatdata
+        errs = {}
+        bad = np.flatnonzero(status >= 2)
+        if bad.size:
+            if errors == 'raise':
+                raise PipelineError('non-finite loglikelihood / NaN input for points {}'.format(bad.tolist()))
+            errs = {int(i): (FloatingPointError('non-finite likelihood (status {:d})'.format(int(status[i]))), '') for i in bad}
+        logposterior = (loglike + logprior).reshape(shape)
+        if return_derived:
+            derived = Samples()
+            derived[self._param_loglikelihood] = loglike.reshape(shape)
+            derived[self._param_logprior] = logprior.reshape(shape)
+            return (logposterior, derived), errs
+        return logposterior, errs
+
+    def evaluate_batch(self, theta, loglike=None, logprior=None, status=None, flattheory=None, stream=None):
+        """Fast path: ``theta`` is a float64 torch tensor [B, n_varied] resident on this likelihood's GPU
+        (columns ordered as ``varied_params``); outputs are written asynchronously to the given tensors (allocated if ``None``).
+        Returns (loglike, logprior, status)."""
+        import torch
+        ctx = self._get_context()
+        B = theta.shape[0]
+        if loglike is None: loglike = torch.empty(B, dtype=torch.float64, device=theta.device)
+        if logprior is None: logprior = torch.empty(B, dtype=torch.float64, device=theta.device)
+        if status is None: status = torch.empty(B, dtype=torch.int32, device=theta.device)
+        ctx.eval_batch(theta, loglike=loglike, logprior=logprior, flattheory=flattheory, status=status, stream=stream)
+        return loglike, logprior, status
+
+    @property
+    def size(self):
+        return len(self.flatdata)
+
+    @property
+    def nvaried(self):
+        return len(self.varied_params) + len(self.all_params.select(solved=True))
+
+    @property
+    def ndof(self):
+        return self.size - self.nvaried
+
+
+class SumLikelihood(BaseLikelihood):
+    """Sum of independent likelihoods (likelihoods/base.py:715-732): Gaussian members are fused into ONE device context
+    with a block-diagonal precision, so a batch is still a single GPU evaluation."""
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        self._set_derived_params()
+        likelihoods = self.init['likelihoods']
+        if not isinstance(likelihoods, (list, tuple)): likelihoods = [likelihoods]
+        flat = []
+        for like in likelihoods:
+            like.initialize()
+            flat += like.likelihoods if isinstance(like, SumLikelihood) else [like]
+        self.likelihoods = flat
+        if not all(isinstance(like, ObservablesGaussianLikelihood) for like in flat):
+            raise NotImplementedError('only sums of ObservablesGaussianLikelihood are supported on the GPU path')
+        observables, blocks = [], []
+        for like in flat:
+            self._require(like)
+            observables += like.observables
+            prec = like.precision
+            blocks.append(np.diag(prec) if prec.ndim == 1 else prec)
+        from scipy import linalg
+        self._fused = ObservablesGaussianLikelihood(observables=observables, precision=linalg.block_diag(*blocks), device=self.init.get('device', None),
+                                                    correct_covariance='none', name=self.init.get('name', None))
+        self._fused.initialize()
+        self._all_params = self._fused._all_params
+        self.flatdata = self._fused.flatdata
+        self._initialized = True
+        return self
+
+    def _evaluate_dict(self, flat, shape, **kwargs):
+        self.initialize()
+        return self._fused._evaluate_dict(flat, shape, **kwargs)
+
+    def evaluate_batch(self, *args, **kwargs):
+        self.initialize()
+        return self._fused.evaluate_batch(*args, **kwargs)
+
+    @property
+    def size(self):
+        return self._fused.size

@@ -1,0 +1,76 @@
+"""Tracer power spectrum multipoles observable (reference: desilike/observables/galaxy_clustering/power_spectrum.py:20-121, 400-404)."""
+import numpy as np
+
+from ...base import BaseCalculator
+from .window import WindowedPowerSpectrumMultipoles
+
+
+class TracerPowerSpectrumMultipolesObservable(BaseCalculator):
+    """
+    Compare a power spectrum measurement to theory.
+
+    Parameters
+    ----------
+    data : array, dict
+        Flat data vector (all multipoles concatenated), or dict of parameter values used to generate a
+        mock measurement from the theory itself (power_spectrum.py:86-88).
+    covariance : array, default=None
+        Covariance of this observable (used when the likelihood is not given a global one).
+    klim, kedges, k, ells, wmatrix, shotnoise, theory, ... :
+        Forwarded to :class:`WindowedPowerSpectrumMultipoles`.
+    transform : str, default=None
+        ``None`` or 'cubic' (power_spectrum.py:400-404).
+    Loading measurements from files / lsstypes objects is out of scope.
+    """
+    name = 'spectrum2poles'
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        init = dict(self.init)
+        data, covariance = init.pop('data', None), init.pop('covariance', None)
+        wmatrix, transform = init.pop('wmatrix', None), init.pop('transform', None)
+        self.name = init.pop('name', self.name)
+        self.covariance = None if covariance is None else np.asarray(covariance, dtype='f8')
+        self.nobs = init.pop('nobs', None)
+        if isinstance(wmatrix, WindowedPowerSpectrumMultipoles):
+            self.wmatrix = wmatrix
+        else:
+            self.wmatrix = WindowedPowerSpectrumMultipoles()
+            if wmatrix is not None:
+                self.wmatrix.init.update(wmatrix=wmatrix)
+        self._require(self.wmatrix)
+        self.wmatrix.init.update(init)
+        self.wmatrix.initialize()
+        for name in ['k', 'ells', 'kedges']:
+            setattr(self, name, getattr(self.wmatrix, name))
+        self.shotnoise = self.wmatrix.shotnoise
+        self.transform = transform
+        if self.transform not in [None, 'cubic']:
+            raise ValueError('transform must be one of {}'.format([None, 'cubic']))
+        self._data_params = None
+        if isinstance(data, dict):
+            self._data_params = dict(data)
+            self.flatdata = None  # generated from the theory at compile time
+        elif data is None:
+            raise ValueError('provide data (flat array or dict of parameters to generate it from theory)')
+        else:
+            self.flatdata = np.ravel(np.asarray(data, dtype='f8'))
+            if self.flatdata.size != self.wmatrix.size:
+                raise ValueError('data size {:d} does not match the window output size {:d}'.format(self.flatdata.size, self.wmatrix.size))
+        self._initialized = True
+        return self
+
+    @property
+    def theory_calculator(self):
+        self.initialize()
+        return self.wmatrix.theory
+
+    def _observable_spec(self, flatdata=None):
+        self.initialize()
+        theory = self.wmatrix.theory
+        spec = theory._theory_spec()
+        spec.update(self.wmatrix._window_spec())
+        spec['transform'] = np.array([1 if self.transform == 'cubic' else 0], dtype='i4')
+        spec['flatdata'] = flatdata if flatdata is not None else self.flatdata
+        return spec

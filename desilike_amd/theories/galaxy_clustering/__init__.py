@@ -1,0 +1,3 @@
+from .power_template import (BasePowerSpectrumTemplate, FixedPowerSpectrumTemplate, StandardPowerSpectrumTemplate,
+                             ShapeFitPowerSpectrumTemplate, BAOPowerSpectrumTemplate)
+from .full_shape import KaiserTracerPowerSpectrumMultipoles, EFTLikeKaiserTracerPowerSpectrumMultipoles

@@ -121,8 +121,9 @@ int  dl_eval_theory_host(dl_ctx* ctx, const double* theta, int64_t B, int32_t io
 
 /* ---- measurement -----------------------------------------------------------------------------*/
 /* When enabled, dl_eval_batch brackets each kernel with HIP events on the launch stream;
- * dl_profile_read synchronises and returns the per-kernel milliseconds of the LAST call:
- * ms[0] theory kernel, ms[1] window GEMM, ms[2] chi2/prior finalize, ms[3] whole call. */
+ * dl_profile_read synchronises and returns the per-kernel milliseconds:
+ * ms[0] theory kernel, ms[1] window GEMM, ms[2] chi2/prior finalize, ms[3] whole call,
+ * averaged over the (up to 256) calls recorded since dl_profile_enable. */
 int  dl_profile_enable(dl_ctx* ctx, int enable);
 int  dl_profile_read(dl_ctx* ctx, double* ms, int32_t n);
 
