@@ -174,10 +174,11 @@ class Context(object):
         self._check(self._lib.dl_eval_batch(self._handle, ctypes.c_void_p(theta.data_ptr()), B, ptr(loglike, torch.float64, (B,)), ptr(logprior, torch.float64, (B,)),
                                             ptr(flattheory, torch.float64, (B, self.n_data)), ptr(status, torch.int32, (B,)), ctypes.c_void_p(stream)))
 
-    def profile_enable(self, enable=True):
-        self._check(self._lib.dl_profile_enable(self._handle, int(bool(enable))))
+    def profile_enable(self, every=1):
+        """Bracket kernels with HIP events on one ``eval_batch`` call out of ``every`` (0 / False: off)."""
+        self._check(self._lib.dl_profile_enable(self._handle, int(every)))
 
     def profile_read(self):
-        ms = np.zeros(4, dtype='f8')
-        self._check(self._lib.dl_profile_read(self._handle, _f64_ptr(ms), 4))
-        return dict(theory=ms[0], window_gemm=ms[1], finalize=ms[2], total=ms[3])
+        ms = np.zeros(5, dtype='f8')
+        self._check(self._lib.dl_profile_read(self._handle, _f64_ptr(ms), 5))
+        return dict(theory=ms[0], window_gemm=ms[1], finalize=ms[2], total=ms[3], event_overhead=ms[4])

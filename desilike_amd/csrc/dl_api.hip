@@ -22,7 +22,7 @@ struct dl_ctx {
     std::vector<int> obs_row0;       // first data row of each observable
     // device constants
     double* arena_dev = nullptr;     // per-observable theory constants
-    DlObsDev* obs_dev = nullptr;
+    std::vector<DlObsDev> obs_kernarg; // observables with device pointers, passed by value to the theory kernel
     double* priors_dev = nullptr;    // [P, 5]
     double* wt_white_dev = nullptr;  // [N_pad, K_pad]  L^T . blockdiag(W_obs)          (chi2 path)
     double* bias_white_dev = nullptr;// [N_pad]         L^T . (bias - flatdata)
@@ -46,7 +46,10 @@ struct dl_ctx {
     bool profile = false;
     static const int NPOOL = 256;            // event sets kept: dl_profile_read averages over the calls recorded since dl_profile_enable
     std::vector<hipEvent_t> ev;              // [NPOOL * 4]
-    int64_t prof_calls = 0;
+    int64_t prof_calls = 0;                  // profiled calls recorded
+    int64_t eval_calls = 0;                  // dl_eval_batch calls since dl_profile_enable
+    int prof_every = 1;                      // record events on one call out of prof_every (sampling keeps the event overhead out of the throughput)
+    double ev_overhead_ms = 0.;              // calibrated cost of an empty event-to-event interval, subtracted from every interval
     std::string last_error;
 };
 
@@ -130,7 +133,8 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
         ctx->max_n_t = std::max(ctx->max_n_t, ctx->obs[i].dev.n_t);
         if (ctx->obs[i].dev.transform != 0) ctx->any_transform = true;
     }
-    if (dl_fs_shared_doubles(ctx->max_n_t) * sizeof(double) > 160 * 1024) return bail("dl_create: template too large for LDS (n_t <= 6800)");
+    for (auto& ob : ctx->obs)
+        if (dl_fs_shared_doubles(ob.dev.n_t, ob.dev.n_in) * sizeof(double) > 160 * 1024) return bail("dl_create: template / theory grid too large for the 160 KiB LDS");
     ctx->n_data = row;
     int n = ctx->n_data;
     int K = (int)col;
@@ -184,9 +188,9 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     }
     // ---- upload ----
     if (dl_upload(ctx, &ctx->arena_dev, arena.data)) { dl_destroy(ctx); return 1; }
-    std::vector<DlObsDev> devs(ctx->n_obs);
-    for (int i = 0; i < ctx->n_obs; ++i) { ctx->obs[i].rebase(ctx->arena_dev); devs[i] = ctx->obs[i].dev; }
-    if (dl_upload(ctx, &ctx->obs_dev, devs) || dl_upload(ctx, &ctx->priors_dev, priors) || dl_upload(ctx, &ctx->wt_white_dev, wt_white) ||
+    ctx->obs_kernarg.resize(ctx->n_obs);
+    for (int i = 0; i < ctx->n_obs; ++i) { ctx->obs[i].rebase(ctx->arena_dev); ctx->obs_kernarg[i] = ctx->obs[i].dev; }
+    if (dl_upload(ctx, &ctx->priors_dev, priors) || dl_upload(ctx, &ctx->wt_white_dev, wt_white) ||
         dl_upload(ctx, &ctx->bias_white_dev, bias_white) || dl_upload(ctx, &ctx->wt_full_dev, wt_full) || dl_upload(ctx, &ctx->bias_full_dev, bias_full) ||
         dl_upload(ctx, &ctx->wh_dev, wh) || dl_upload(ctx, &ctx->bias_wh_dev, bias_wh) || dl_upload(ctx, &ctx->flatdata_dev, flatdata) ||
         dl_upload(ctx, &ctx->transform_dev, transform)) {
@@ -200,7 +204,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
 void dl_destroy(dl_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    void* ptrs[] = {ctx->arena_dev, ctx->obs_dev, ctx->priors_dev, ctx->wt_white_dev, ctx->bias_white_dev, ctx->wt_full_dev, ctx->bias_full_dev, ctx->wh_dev,
+    void* ptrs[] = {ctx->arena_dev, ctx->priors_dev, ctx->wt_white_dev, ctx->bias_white_dev, ctx->wt_full_dev, ctx->bias_full_dev, ctx->wh_dev,
                     ctx->bias_wh_dev, ctx->flatdata_dev, ctx->transform_dev, ctx->power_ws, ctx->delta_ws, ctx->flat_ws, ctx->theta_stage, ctx->out_stage,
                     ctx->status_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -256,10 +260,10 @@ int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logli
     for (int64_t b0 = 0; b0 < B; b0 += DL_CHUNK) {
         int64_t nb = std::min<int64_t>(DL_CHUNK, B - b0);
         const double* th = theta_dev + (size_t)b0 * P;
-        bool prof = ctx->profile && b0 == 0;
+        bool prof = ctx->profile && b0 == 0 && (ctx->eval_calls % ctx->prof_every == 0);
         hipEvent_t* ev = prof ? &ctx->ev[(size_t)(ctx->prof_calls % dl_ctx::NPOOL) * 4] : nullptr;
         if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[0], stream));
-        dl_launch_fullshape(ctx->obs_dev, ctx->n_obs, ctx->max_n_t, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream);
+        dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream);
         if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[1], stream));
         bool need_flat = ctx->any_transform || flattheory_dev != nullptr;
         if (need_flat) {
@@ -285,6 +289,7 @@ int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logli
                            status_dev ? status_dev + b0 : nullptr, stream);
         if (prof) { DL_HIP_CHECK(ctx, hipEventRecord(ev[3], stream)); ctx->prof_calls++; }
     }
+    if (ctx->profile) ctx->eval_calls++;
     DL_HIP_CHECK(ctx, hipGetLastError());
     return 0;
 }
@@ -297,15 +302,9 @@ int dl_eval_theory(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs
     hipStream_t stream = (hipStream_t)hip_stream;
     DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     // launch only observable iobs, writing rows of n_in doubles directly into the caller's buffers
-    DlObsDev tmp = ctx->obs[iobs].dev;
+    DlObsDev tmp = ctx->obs_kernarg[iobs];
     tmp.col_offset = 0;
-    DlObsDev* tmp_dev = nullptr;
-    DL_HIP_CHECK(ctx, hipMalloc((void**)&tmp_dev, sizeof(DlObsDev)));
-    DL_HIP_CHECK(ctx, hipMemcpyAsync(tmp_dev, &tmp, sizeof(DlObsDev), hipMemcpyHostToDevice, stream));
-    DL_HIP_CHECK(ctx, hipStreamSynchronize(stream));
-    dl_launch_fullshape(tmp_dev, 1, tmp.n_t, theta_dev, ctx->n_params, B, power_dev, tmp.n_in, tables_dev, 3 * (int64_t)tmp.n_in, stream);
-    DL_HIP_CHECK(ctx, hipStreamSynchronize(stream));
-    DL_HIP_CHECK(ctx, hipFree(tmp_dev));
+    dl_launch_fullshape(&tmp, 1, theta_dev, ctx->n_params, B, power_dev, tmp.n_in, tables_dev, 3 * (int64_t)tmp.n_in, stream);
     DL_HIP_CHECK(ctx, hipGetLastError());
     return 0;
 }
@@ -369,12 +368,29 @@ int dl_eval_theory_host(dl_ctx* ctx, const double* theta, int64_t B, int32_t iob
 
 int dl_profile_enable(dl_ctx* ctx, int enable) {
     if (!ctx) { g_last_error = "dl_profile_enable: null context"; return 1; }
+    DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (enable && ctx->ev.empty()) {
         ctx->ev.assign((size_t)dl_ctx::NPOOL * 4, nullptr);
         for (auto& e : ctx->ev) DL_HIP_CHECK(ctx, hipEventCreate(&e));
     }
+    if (enable) {
+        // calibrate the cost of an event-to-event interval with nothing in between (median of 32), on the default stream
+        std::vector<float> gaps;
+        for (int i = 0; i < 32; ++i) {
+            DL_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], nullptr));
+            DL_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], nullptr));
+            DL_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[1]));
+            float t = 0;
+            DL_HIP_CHECK(ctx, hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
+            gaps.push_back(t);
+        }
+        std::sort(gaps.begin(), gaps.end());
+        ctx->ev_overhead_ms = gaps[gaps.size() / 2];
+    }
     ctx->profile = enable != 0;
+    ctx->prof_every = enable > 1 ? enable : 1;
     ctx->prof_calls = 0;
+    ctx->eval_calls = 0;
     return 0;
 }
 
@@ -391,9 +407,11 @@ int dl_profile_read(dl_ctx* ctx, double* ms, int32_t n) {
         DL_HIP_CHECK(ctx, hipEventElapsedTime(&t12, ev[1], ev[2]));
         DL_HIP_CHECK(ctx, hipEventElapsedTime(&t23, ev[2], ev[3]));
         DL_HIP_CHECK(ctx, hipEventElapsedTime(&t03, ev[0], ev[3]));
-        ms[0] += t01; ms[1] += t12; ms[2] += t23; ms[3] += t03;
+        double oh = ctx->ev_overhead_ms;
+        ms[0] += std::max(0., t01 - oh); ms[1] += std::max(0., t12 - oh); ms[2] += std::max(0., t23 - oh); ms[3] += std::max(0., t03 - oh);
     }
     for (int i = 0; i < 4; ++i) ms[i] /= (double)ncalls;
+    if (n >= 5) ms[4] = ctx->ev_overhead_ms;
     return 0;
 }
 

@@ -1,11 +1,20 @@
 // dl_fullshape.h -- per-point arithmetic of the full-shape theory kernel.
 //
-// One workgroup evaluates one (parameter point, observable): ShapeFit template rescaling at the
-// N_t knots, not-a-knot cubic-spline moments by a segmented Thomas sweep, AP remap + spline evaluation
-// at (k, mu'), Gauss-Legendre projection onto multipoles, tracer bias combination.
+// One workgroup evaluates one (parameter point, observable): ShapeFit template rescaling at the N_t knots,
+// not-a-knot cubic-spline moments by a segmented Thomas sweep, conversion to per-interval polynomials,
+// AP remap + spline evaluation at (k, mu'), Gauss-Legendre projection onto multipoles, tracer bias combination.
 // The body is written as barrier-separated *phases*, each a function of (tid, nthreads) acting on
 // workgroup-shared arrays, so that the HIP kernel (dl_kernels.hip) and the CPU emulation used by the
-// `not gpu` tests (tests/csrc/emulate_fullshape.cpp) run literally the same code.
+// `not gpu` tests (tests/csrc/emulate.cpp) run literally the same code.
+//
+// Design notes (measured on MI355X with tools/mfma_f64_probe.hip: a dependent fp64 FMA costs 40 cycles, one wave
+// issues an fp64 FMA every 8.5 cycles, a SIMD every 4.4):
+//  * the tridiagonal sweeps are split into 64 segments; the state entering a segment is a 30-40 term DOT PRODUCT
+//    with precomputed weights (independent FMAs) instead of a warm-up recurrence (dependent FMAs): the sweep
+//    multipliers decay like (2 - sqrt 3)^d, so truncating at < 1e-19 is exact in fp64;
+//  * the (k, mu) loop evaluates S(u) = ((d3 u + d2) u + d1) u + d0 with u the fractional knot index, the four
+//    coefficients of an interval being one 32-byte LDS read; the multipole weights, the Jacobian and (when the
+//    separate tables are not requested) the bias factors (b1X + f mu'^2)(b1Y + f mu'^2) are folded per mu node.
 //
 // Reference arithmetic restated here (paths relative to /root/reference/desilike):
 //   phase0: APEffect.calculate + ap_k_mu          theories/galaxy_clustering/base.py:211-223, 341-353
@@ -27,6 +36,9 @@
 #define DL_MAX_MU 32
 #define DL_MAX_EFT 8
 #define DL_FS_THREADS 256
+#define DL_MAX_SEG 64
+#define DL_SEG_PARTS 4      // threads cooperating on the warm-up dot product of one segment (DL_MAX_SEG * DL_SEG_PARTS = DL_FS_THREADS)
+#define DL_SEG_QMAX 12     // dot-product terms per thread: warm-up length <= DL_SEG_PARTS * DL_SEG_QMAX = 48
 
 struct DlInput {
     int32_t col;    // >= 0: column of theta; < 0: use `value`
@@ -41,6 +53,7 @@ struct DlObsDev {
     int32_t n_ell, n_kin, n_mu, n_t;
     int32_t n_in, ell0, n_ct, n_sn;
     int32_t seg_len, seg_warm, n_seg, fixed_spline;
+    int32_t uniform_knots, pad0;     // knots uniform in log10 k (to < 1e-6 of the spacing): interval index = floor of the scaled abscissa
     int64_t col_offset;  // first column of this observable in a row of the (concatenated) power buffer
     double eta, f_fid, a, nd, x0, inv_hx;
     double end0a, end0b, end1a, end1b;  // not-a-knot end relations: M[0] = end0a M[1] + end0b M[2]; M[n-1] = end1a M[n-2] + end1b M[n-3]
@@ -49,32 +62,48 @@ struct DlObsDev {
     DlInput sn_in[DL_MAX_EFT];
     const double *kin, *lkin, *mu, *wmu;          // [n_kin], log10(kin) [n_kin], [n_mu], [n_ell * n_mu]
     const double *x_t, *pk_fid, *sf_th, *sf_lg;   // log10(k_t), fiducial P, tanh(a ln(k/kp)), ln(k/kp): all [n_t]
-    const double *ih;                              // 1 / (x_t[j+1] - x_t[j]) [n_t - 1]
-    const double *sp_A, *sp_nC, *sp_inv;           // Thomas sweep coefficients of the reduced system [n_t - 2]
-    const double *M_fixed;                         // moments of the fiducial table (fixed templates) [n_t]
+    const double *ih, *dlt;                        // 1 / (x_t[j+1] - x_t[j]); x_t[j] - (x0 + j / inv_hx): [n_t]
+    const double *sp_A, *sp_nC, *sp_inv;           // Thomas sweep multipliers / pivots of the reduced system [n_t - 2]
+    const double *sp_gf, *sp_gb;                   // [DL_SEG_QMAX, DL_FS_THREADS] warm-up weights of the forward / backward sweeps: term d = 4 q + part of
+                                                   // segment seg sits at [q][4 seg + part] (zero beyond the warm-up length / the ends of the system)
+    const double *coef_fixed;                      // [n_t, 4] interval polynomials of the fiducial table (fixed templates)
     const double *ct_matrix, *sn_matrix;           // [n_ell, n_kin, n_ct], [n_ell, n_kin, n_sn]
 };
 
 // Layout of the small per-point scratch `pt` (doubles) in workgroup-shared memory
 enum {
     DL_PT_QPAR = 0, DL_PT_QPER, DL_PT_JAC, DL_PT_F, DL_PT_B1X, DL_PT_B1Y, DL_PT_SN0ND, DL_PT_DAMP,
-    DL_PT_LQ = 8,                        // log10(F_m / qper)
-    DL_PT_MUP2 = DL_PT_LQ + DL_MAX_MU,   // mu'^2
-    DL_PT_FAC = DL_PT_MUP2 + DL_MAX_MU,  // F_m
-    DL_PT_SD = DL_PT_FAC + DL_MAX_MU,    // sigmapar^2 mu'^2 + sigmaper^2 (1 - mu'^2)
-    DL_PT_CT = DL_PT_SD + DL_MAX_MU,     // 0.5 (ctX + ctY)
-    DL_PT_SN = DL_PT_CT + DL_MAX_EFT,    // sn / nd
-    DL_PT_SIZE = DL_PT_SN + DL_MAX_EFT
+    DL_PT_LQ = 8,                                   // log10(F_m / qper)
+    DL_PT_FAC = DL_PT_LQ + DL_MAX_MU,               // F_m
+    DL_PT_SD = DL_PT_FAC + DL_MAX_MU,               // sigmapar^2 mu'^2 + sigmaper^2 (1 - mu'^2)
+    DL_PT_CT = DL_PT_SD + DL_MAX_MU,                // 0.5 (ctX + ctY)
+    DL_PT_SN = DL_PT_CT + DL_MAX_EFT,               // sn / nd
+    DL_PT_OM = DL_PT_SN + DL_MAX_EFT,               // [n_mu][8]: jac w_l(mu) (b1X + f mu'^2)(b1Y + f mu'^2) for l < 5, [5] = jac w_{l=0}: fused weights
+    DL_PT_W3 = DL_PT_OM + 8 * DL_MAX_MU,            // [n_mu][5][3]: jac w_l(mu) (1, f mu'^2, (f mu'^2)^2): separate-table weights
+    DL_PT_PART = DL_PT_W3 + 15 * DL_MAX_MU,         // [DL_FS_THREADS] partial dot products of the segmented sweeps
+    DL_PT_SIZE = DL_PT_PART + DL_FS_THREADS
 };
 
 struct DlFsShared {
-    double* y;   // [n_t] template power at the knots
-    double* M;   // [n_t] spline moments (second derivatives); M[0], M[n_t-1] are formed on the fly
-    double* z;   // [n_t] forward-sweep scratch
-    double* pt;  // [DL_PT_SIZE]
+    double* y;     // [n_t] template power at the knots
+    double* M;     // [n_t] pivot-scaled right-hand side, then spline moments (second derivatives) M[1 .. n_t-2]
+    double* z;     // [n_t] forward-sweep result
+    double* coef;  // [n_t][4] per-interval polynomial in the fractional knot index
+    double* out;   // [n_in] output multipoles, staged for one coalesced store (ALIASES y, M, z: dead once coef is built)
+    double* pt;    // [DL_PT_SIZE]
 };
 
-DL_HD size_t dl_fs_shared_doubles(int n_t) { return 3 * (size_t)n_t + DL_PT_SIZE; }
+DL_HD size_t dl_fs_work_doubles(int n_t, int n_in) { size_t w = 3 * (size_t)n_t; if ((size_t)n_in > w) w = (size_t)n_in; return (w + 1) & ~(size_t)1; }
+DL_HD size_t dl_fs_shared_doubles(int n_t, int n_in) { return 4 * (size_t)n_t + dl_fs_work_doubles(n_t, n_in) + DL_PT_SIZE; }
+
+DL_HD DlFsShared dl_fs_shared_carve(double* base, int n_t, int n_in) {
+    DlFsShared s;
+    s.coef = base;                       // first: keeps the 32-byte coefficient groups 16-byte aligned
+    s.y = base + 4 * (size_t)n_t; s.M = base + 5 * (size_t)n_t; s.z = base + 6 * (size_t)n_t;
+    s.out = s.y;
+    s.pt = s.y + dl_fs_work_doubles(n_t, n_in);
+    return s;
+}
 
 DL_HD void dl_ap_qparqper(const DlObsDev& o, const double* th, double& qpar, double& qper) {
     // theories/galaxy_clustering/base.py:341-350
@@ -86,31 +115,51 @@ DL_HD void dl_ap_qparqper(const DlObsDev& o, const double* th, double& qpar, dou
     }
 }
 
-// phase 0 + 1 (no barrier needed between them): per-point scalars, per-mu AP factors, template at the knots
+// phase 0 + 1 (no barrier needed between them): per-point scalars, per-mu AP factors and weights, template at the knots
 DL_HD void dl_fs_phase01(int tid, int nthr, const DlObsDev& o, const double* th, const DlFsShared& s) {
     if (tid < o.n_mu || tid == 0) {
         double qpar, qper;
         dl_ap_qparqper(o, th, qpar, qper);
         double sigpar = dl_get(o.sigpar, th), sigper = dl_get(o.sigper, th);
+        double jac = 1. / (qpar * qper * qper);                    // tgc/base.py:217
+        double f = o.f_fid * dl_get(o.df, th);                     // power_template.py:757
+        double b1X = dl_get(o.b1X, th), b1Y = dl_get(o.b1Y, th);
         if (tid < o.n_mu) {
             // ap_k_mu, tgc/base.py:216-222: factorap = sqrt(1 + mu^2 (1/qap^2 - 1)); muap = mu / qap / factorap
             double qap = qpar / qper;
             double mu = o.mu[tid];
             double fac = sqrt(1. + mu * mu * (1. / (qap * qap) - 1.));
             double mup = mu / qap / fac;
+            double mup2 = mup * mup;
             s.pt[DL_PT_FAC + tid] = fac;
             s.pt[DL_PT_LQ + tid] = log10(fac / qper);  // log10(kap) = log10(k) + log10(factorap / qper)
-            s.pt[DL_PT_MUP2 + tid] = mup * mup;
             // full_shape.py:492: sigmapar^2 muap^2 + sigmaper^2 (1 - muap^2)
-            s.pt[DL_PT_SD + tid] = sigpar * sigpar * (mup * mup) + sigper * sigper * (1. - mup * mup);
+            s.pt[DL_PT_SD + tid] = sigpar * sigpar * mup2 + sigper * sigper * (1. - mup2);
+            double fm2 = f * mup2;
+            double bias = (b1X + fm2) * (b1Y + fm2);               // = b1X b1Y + (b1X + b1Y) f mu'^2 + f^2 mu'^4, full_shape.py:550
+            for (int l = 0; l < DL_MAX_ELL; ++l) {
+                double w = (l < o.n_ell) ? jac * o.wmu[l * o.n_mu + tid] : 0.;
+                s.pt[DL_PT_OM + tid * 8 + l] = w * bias;
+                s.pt[DL_PT_W3 + (tid * 5 + l) * 3 + 0] = w;
+                s.pt[DL_PT_W3 + (tid * 5 + l) * 3 + 1] = w * fm2;
+                s.pt[DL_PT_W3 + (tid * 5 + l) * 3 + 2] = w * (fm2 * fm2);
+            }
+            s.pt[DL_PT_OM + tid * 8 + 5] = (o.ell0 >= 0) ? jac * o.wmu[o.ell0 * o.n_mu + tid] : 0.;
+            s.pt[DL_PT_OM + tid * 8 + 6] = 0.;
+            s.pt[DL_PT_OM + tid * 8 + 7] = 0.;
         }
         if (tid == 0) {
+            for (int mm = o.n_mu; mm < ((o.n_mu + 3) & ~3); ++mm) {   // pad the mu nodes to a multiple of 4 with zero weights (unrolled loops)
+                s.pt[DL_PT_LQ + mm] = 0.; s.pt[DL_PT_FAC + mm] = 0.; s.pt[DL_PT_SD + mm] = 0.;
+                for (int c = 0; c < 8; ++c) s.pt[DL_PT_OM + mm * 8 + c] = 0.;
+                for (int c = 0; c < 15; ++c) s.pt[DL_PT_W3 + mm * 15 + c] = 0.;
+            }
             s.pt[DL_PT_QPAR] = qpar;
             s.pt[DL_PT_QPER] = qper;
-            s.pt[DL_PT_JAC] = 1. / (qpar * qper * qper);           // tgc/base.py:217
-            s.pt[DL_PT_F] = o.f_fid * dl_get(o.df, th);            // power_template.py:757
-            s.pt[DL_PT_B1X] = dl_get(o.b1X, th);
-            s.pt[DL_PT_B1Y] = dl_get(o.b1Y, th);
+            s.pt[DL_PT_JAC] = jac;
+            s.pt[DL_PT_F] = f;
+            s.pt[DL_PT_B1X] = b1X;
+            s.pt[DL_PT_B1Y] = b1Y;
             s.pt[DL_PT_SN0ND] = dl_get(o.sn0, th) / o.nd;          // full_shape.py:549
             s.pt[DL_PT_DAMP] = (sigpar != 0. || sigper != 0.) ? 1. : 0.;
             for (int c = 0; c < o.n_ct; ++c)                       // full_shape.py:630
@@ -119,18 +168,20 @@ DL_HD void dl_fs_phase01(int tid, int nthr, const DlObsDev& o, const double* th,
                 s.pt[DL_PT_SN + c] = dl_get(o.sn_in[c], th) / o.nd;
         }
     }
-    if (o.templ == 1) {
+    const int n_t = o.n_t;
+    if (o.fixed_spline) {
+        for (int j = tid; j < 4 * n_t; j += nthr) s.coef[j] = o.coef_fixed[j];
+    } else if (o.templ == 1) {
         // power_template.py:749: exp(dm / a * tanh(a * log(k / kp)) + dn * log(k / kp))
         double dm_a = dl_get(o.dm, th) / o.a, dn = dl_get(o.dn, th);
-        for (int j = tid; j < o.n_t; j += nthr) s.y[j] = o.pk_fid[j] * exp(dm_a * o.sf_th[j] + dn * o.sf_lg[j]);
+        for (int j = tid; j < n_t; j += nthr) s.y[j] = o.pk_fid[j] * exp(dm_a * o.sf_th[j] + dn * o.sf_lg[j]);
     } else {
-        for (int j = tid; j < o.n_t; j += nthr) { s.y[j] = o.pk_fid[j]; s.M[j] = o.M_fixed[j]; }
+        for (int j = tid; j < n_t; j += nthr) s.y[j] = o.pk_fid[j];
     }
 }
 
 // phase 2a: right-hand side of the reduced (n_t - 2 unknowns) not-a-knot system, pre-multiplied by the pivots
 DL_HD void dl_fs_phase2a(int tid, int nthr, const DlObsDev& o, const DlFsShared& s) {
-    if (o.fixed_spline) return;
     int m = o.n_t - 2;
     for (int i = tid; i < m; i += nthr) {
         double r = 6. * ((s.y[i + 2] - s.y[i + 1]) * o.ih[i + 1] - (s.y[i + 1] - s.y[i]) * o.ih[i]);
@@ -138,110 +189,228 @@ DL_HD void dl_fs_phase2a(int tid, int nthr, const DlObsDev& o, const DlFsShared&
     }
 }
 
-// phase 2b: forward sweep z_i = A_i z_{i-1} + B_i, segmented with an exponentially-decaying warm-up
+// phase 2b (two steps): forward sweep z_i = A_i z_{i-1} + B_i.  Segment `seg` covers [start, end); the state entering it,
+// z_{start-1} = sum_d gf[d] B_{start-1-d}, is a dot product with precomputed products of the multipliers, computed
+// cooperatively by DL_SEG_PARTS threads (independent, fully unrolled loads and FMAs).
+DL_HD void dl_fs_phase2b_dot(int tid, int nthr, const DlObsDev& o, const DlFsShared& s) {
+    const int m = o.n_t - 2;
+    int seg = tid / DL_SEG_PARTS, part = tid % DL_SEG_PARTS;
+    int start = seg * o.seg_len;
+    double acc = 0.;
+    if (start < m) {
+#pragma unroll
+        for (int q = 0; q < DL_SEG_QMAX; ++q) {
+            int idx = start - (DL_SEG_PARTS * q + part);                  // B_{start-1-d} is stored at M[start-d]
+            double g = o.sp_gf[q * DL_FS_THREADS + tid];
+            double b = (idx >= 1) ? s.M[idx] : 0.;
+            acc = fma(g, b, acc);
+        }
+    }
+    s.pt[DL_PT_PART + tid] = acc;
+}
+
 DL_HD void dl_fs_phase2b(int tid, int nthr, const DlObsDev& o, const DlFsShared& s) {
-    if (o.fixed_spline || tid >= o.n_seg) return;
-    int m = o.n_t - 2;
+    if (tid >= o.n_seg) return;
+    const int m = o.n_t - 2;
     int start = tid * o.seg_len, end = start + o.seg_len;
     if (end > m) end = m;
     if (start >= m) return;
-    int i0 = start - o.seg_warm;
-    if (i0 < 0) i0 = 0;
-    double zz = 0.;
-    for (int i = i0; i < end; ++i) {
+    const double* part = s.pt + DL_PT_PART + tid * DL_SEG_PARTS;
+    double zz = (part[0] + part[1]) + (part[2] + part[3]);
+#pragma unroll 8
+    for (int i = start; i < end; ++i) {
         zz = fma(o.sp_A[i], zz, s.M[i + 1]);
-        if (i >= start) s.z[i] = zz;
+        s.z[i] = zz;
     }
 }
 
-// phase 2c: backward sweep u_i = z_i - c'_i u_{i+1}; u_i = M[i + 1]
+// phase 2c (two steps): backward sweep u_i = z_i - c'_i u_{i+1}; u_i = M[i + 1]; u_end = sum_d gb[d] z_{end+d}
+DL_HD void dl_fs_phase2c_dot(int tid, int nthr, const DlObsDev& o, const DlFsShared& s) {
+    const int m = o.n_t - 2;
+    int seg = tid / DL_SEG_PARTS, part = tid % DL_SEG_PARTS;
+    int start = seg * o.seg_len, end = start + o.seg_len;
+    if (end > m) end = m;
+    double acc = 0.;
+    if (start < m) {
+#pragma unroll
+        for (int q = 0; q < DL_SEG_QMAX; ++q) {
+            int idx = end + DL_SEG_PARTS * q + part;
+            double g = o.sp_gb[q * DL_FS_THREADS + tid];
+            double zv = (idx < m) ? s.z[idx] : 0.;
+            acc = fma(g, zv, acc);
+        }
+    }
+    s.pt[DL_PT_PART + tid] = acc;
+}
+
 DL_HD void dl_fs_phase2c(int tid, int nthr, const DlObsDev& o, const DlFsShared& s) {
-    if (o.fixed_spline || tid >= o.n_seg) return;
-    int m = o.n_t - 2;
+    if (tid >= o.n_seg) return;
+    const int m = o.n_t - 2;
     int start = tid * o.seg_len, end = start + o.seg_len;
     if (end > m) end = m;
     if (start >= m) return;
-    int i1 = end - 1 + o.seg_warm;
-    if (i1 > m - 1) i1 = m - 1;
-    double uu = 0.;
-    for (int i = i1; i >= start; --i) {
+    const double* part = s.pt + DL_PT_PART + tid * DL_SEG_PARTS;
+    double uu = (part[0] + part[1]) + (part[2] + part[3]);
+#pragma unroll 8
+    for (int i = end - 1; i >= start; --i) {
         uu = fma(o.sp_nC[i], uu, s.z[i]);
-        if (i < end) s.M[i + 1] = uu;
+        s.M[i + 1] = uu;
     }
 }
 
-// spline value at abscissa x (log10 k'), extrapolating with the end pieces like scipy's fill_value='extrapolate'
-DL_HD double dl_spline_eval(const DlObsDev& o, const DlFsShared& s, double x) {
-    int n = o.n_t;
-    int j = (int)floor((x - o.x0) * o.inv_hx);
-    if (j < 0) j = 0;
-    if (j > n - 2) j = n - 2;
-    while (j > 0 && x < o.x_t[j]) --j;
-    while (j < n - 2 && x >= o.x_t[j + 1]) ++j;
-    double xl = o.x_t[j], xr = o.x_t[j + 1];
-    double ihj = o.ih[j];
-    double h = xr - xl;
-    double a = (xr - x) * ihj, b = (x - xl) * ihj;
-    double Ml = (j == 0) ? (o.end0a * s.M[1] + o.end0b * s.M[2]) : s.M[j];
-    double Mr = (j == n - 2) ? (o.end1a * s.M[n - 2] + o.end1b * s.M[n - 3]) : s.M[j + 1];
-    return a * s.y[j] + b * s.y[j + 1] + ((a * a * a - a) * Ml + (b * b * b - b) * Mr) * (h * h * (1. / 6.));
+// phase 2d: moments -> polynomial of each interval j in u = (x - x0) inv_hx - j (uniform knots) or u = (x - x_j) / h_j
+DL_HD void dl_fs_phase2d(int tid, int nthr, const DlObsDev& o, const DlFsShared& s) {
+    const int n = o.n_t;
+    const double hx = 1. / o.inv_hx;
+    for (int j = tid; j < n - 1; j += nthr) {
+        double Ml = (j == 0) ? (o.end0a * s.M[1] + o.end0b * s.M[2]) : s.M[j];
+        double Mr = (j == n - 2) ? (o.end1a * s.M[n - 2] + o.end1b * s.M[n - 3]) : s.M[j + 1];
+        double ihj = o.ih[j];
+        double h = o.x_t[j + 1] - o.x_t[j];
+        double yl = s.y[j], yr = s.y[j + 1];
+        // S(t) = c0 + c1 t + c2 t^2 + c3 t^3, t = x - x_j
+        double c0 = yl;
+        double c1 = (yr - yl) * ihj - h * (2. * Ml + Mr) * (1. / 6.);
+        double c2 = 0.5 * Ml;
+        double c3 = (Mr - Ml) * ihj * (1. / 6.);
+        double d0, d1, d2, d3;
+        if (o.uniform_knots) {
+            // t = u hx + dlt_j with dlt_j = x_j - (x0 + j hx) (rounding of the knot table, ~1e-16): exact re-expansion in u
+            double dl = -o.dlt[j];
+            d0 = c0 + dl * (c1 + dl * (c2 + dl * c3));
+            d1 = hx * (c1 + dl * (2. * c2 + 3. * dl * c3));
+            d2 = hx * hx * (c2 + 3. * dl * c3);
+            d3 = hx * hx * hx * c3;
+        } else {
+            d0 = c0; d1 = c1 * h; d2 = c2 * h * h; d3 = c3 * h * h * h;
+        }
+        s.coef[4 * j + 0] = d0; s.coef[4 * j + 1] = d1; s.coef[4 * j + 2] = d2; s.coef[4 * j + 3] = d3;
+    }
 }
 
-// phase 3: (k, mu) evaluation, multipole projection, tracer combination; writes power (and tables)
-DL_HD void dl_fs_phase3(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, double* power_row, double* tables_row) {
-    const double jac = s.pt[DL_PT_JAC], f = s.pt[DL_PT_F], qper = s.pt[DL_PT_QPER];
-    const double b1X = s.pt[DL_PT_B1X], b1Y = s.pt[DL_PT_B1Y], sn0nd = s.pt[DL_PT_SN0ND];
+// interval index j and local coordinate u of abscissa x (log10 k'); extrapolation continues the end pieces like
+// scipy's fill_value='extrapolate'
+template <bool UNIF>
+DL_HD void dl_spline_locate(const DlObsDev& o, double x, int& j, double& u) {
+    const int n = o.n_t;
+    if (UNIF || o.uniform_knots) {
+        // adjacent pieces of a C2 spline agree to O(eps^3) within eps of a knot: no fix-up of the index is needed
+        double t = (x - o.x0) * o.inv_hx;
+        double tc = t > 0. ? t : 0.;
+        j = (int)tc;
+        if (j > n - 2) j = n - 2;
+        u = t - (double)j;
+    } else {
+        int lo = 0, hi = n - 1;   // x_t[lo] <= x < x_t[hi] (clamped)
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (x >= o.x_t[mid]) lo = mid; else hi = mid;
+        }
+        j = lo;
+        u = (x - o.x_t[j]) * o.ih[j];
+    }
+}
+
+template <bool UNIF>
+DL_HD double dl_spline_eval(const DlObsDev& o, const DlFsShared& s, double x) {
+    int j;
+    double u;
+    dl_spline_locate<UNIF>(o, x, j, u);
+    const double* c = s.coef + 4 * j;
+    return fma(fma(fma(c[3], u, c[2]), u, c[1]), u, c[0]);
+}
+
+// phase 3: (k, mu) evaluation, multipole projection, tracer combination; writes power (and tables).
+// NL = number of multipole accumulators compiled in (3 or 5; weights of absent multipoles are zero); the mu loop is
+// unrolled by 4 (nodes padded with zero weights) so that four independent evaluation chains are in flight per thread.
+// FAST: uniform knots, no separate tables (straight-line inner loop); EFT: counter terms present (needs P_dd,l=0).
+// The generic instantiation <false, 5, true> decides everything at run time.
+// Results go to the LDS tile s.out (dl_fs_phase4 stores it): no global store, hence no store-completion wait, in the loop.
+template <bool FAST, int NL, bool EFT>
+DL_HD void dl_fs_phase3(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, double* tables_row) {
+    const double qper = s.pt[DL_PT_QPER], sn0nd = s.pt[DL_PT_SN0ND];
+    const double b1X = s.pt[DL_PT_B1X], b1Y = s.pt[DL_PT_B1Y];
     const bool damp = s.pt[DL_PT_DAMP] != 0.;
-    const int n_ell = o.n_ell, n_mu = o.n_mu, n_kin = o.n_kin;
+    const bool need_dd0 = EFT && o.n_ct > 0;
+    const bool TABLES = !FAST && tables_row != nullptr;
+    const int n_ell = o.n_ell, n_kin = o.n_kin;
+    const int n_mu4 = (o.n_mu + 3) & ~3;
     for (int i = tid; i < n_kin; i += nthr) {
-        double lk = o.lkin[i], kk = o.kin[i];
-        double dd[DL_MAX_ELL], dt[DL_MAX_ELL], tt[DL_MAX_ELL];
+        const double lk = o.lkin[i];
+        const double kq = damp ? o.kin[i] / qper : 0.;   // tgc/base.py:220: kap = k / qper * factorap
+        double p[NL];
+        double dd[FAST ? 1 : NL], dt[FAST ? 1 : NL], tt[FAST ? 1 : NL];
+        double dd0 = 0.;
 #pragma unroll
-        for (int l = 0; l < DL_MAX_ELL; ++l) dd[l] = dt[l] = tt[l] = 0.;
-        for (int m = 0; m < n_mu; ++m) {
-            double T = jac * dl_spline_eval(o, s, lk + s.pt[DL_PT_LQ + m]);
+        for (int l = 0; l < NL; ++l) p[l] = 0.;
+#pragma unroll
+        for (int l = 0; l < (FAST ? 1 : NL); ++l) dd[l] = dt[l] = tt[l] = 0.;
+        for (int m0 = 0; m0 < n_mu4; m0 += 4) {
+            double T[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[q] = dl_spline_eval<FAST>(o, s, lk + s.pt[DL_PT_LQ + m0 + q]);
             if (damp) {
-                double kap = kk / qper * s.pt[DL_PT_FAC + m];   // tgc/base.py:220
-                T *= exp(-(kap * kap * s.pt[DL_PT_SD + m]) / 2.);  // full_shape.py:492-493
-            }
-            double fm2 = f * s.pt[DL_PT_MUP2 + m];
-            double Tdt = fm2 * T, Ttt = fm2 * fm2 * T;
 #pragma unroll
-            for (int l = 0; l < DL_MAX_ELL; ++l) {
-                if (l < n_ell) {
-                    double w = o.wmu[l * n_mu + m];
-                    dd[l] = fma(w, T, dd[l]);
-                    dt[l] = fma(w, Tdt, dt[l]);
-                    tt[l] = fma(w, Ttt, tt[l]);
+                for (int q = 0; q < 4; ++q) {
+                    double kap = kq * s.pt[DL_PT_FAC + m0 + q];
+                    T[q] *= exp(-(kap * kap * s.pt[DL_PT_SD + m0 + q]) / 2.);  // full_shape.py:492-493
+                }
+            }
+            if (FAST || !TABLES) {
+                // fused weights: P_l = sum_m Omega_l(m) S(k'_m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double* om = s.pt + DL_PT_OM + (m0 + q) * 8;
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) p[l] = fma(om[l], T[q], p[l]);
+                    if (need_dd0) dd0 = fma(om[5], T[q], dd0);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double* w3 = s.pt + DL_PT_W3 + (m0 + q) * 15;
+#pragma unroll
+                    for (int l = 0; l < (FAST ? 1 : NL); ++l) {
+                        dd[l] = fma(w3[3 * l + 0], T[q], dd[l]);
+                        dt[l] = fma(w3[3 * l + 1], T[q], dt[l]);
+                        tt[l] = fma(w3[3 * l + 2], T[q], tt[l]);
+                    }
                 }
             }
         }
-        double dd0 = 0.;
+        if (!FAST && TABLES) {
 #pragma unroll
-        for (int l = 0; l < DL_MAX_ELL; ++l)
-            if (l == o.ell0) dd0 = dd[l];
-#pragma unroll
-        for (int l = 0; l < DL_MAX_ELL; ++l) {
-            if (l < n_ell) {
-                // full_shape.py:550
-                double p = b1X * b1Y * dd[l] + (b1X + b1Y) * dt[l] + tt[l] + (l == o.ell0 ? sn0nd : 0.);
-                if (o.n_ct > 0) {  // full_shape.py:633
-                    double acc = 0.;
-                    for (int c = 0; c < o.n_ct; ++c) acc += o.ct_matrix[((size_t)l * n_kin + i) * o.n_ct + c] * s.pt[DL_PT_CT + c];
-                    p += acc * dd0;
-                }
-                if (o.n_sn > 0) {  // full_shape.py:634
-                    double acc = 0.;
-                    for (int c = 0; c < o.n_sn; ++c) acc += o.sn_matrix[((size_t)l * n_kin + i) * o.n_sn + c] * s.pt[DL_PT_SN + c];
-                    p += acc;
-                }
-                power_row[(size_t)l * n_kin + i] = p;
-                if (tables_row) {
+            for (int l = 0; l < (FAST ? 1 : NL); ++l) {
+                if (l < n_ell) {
+                    p[l] = b1X * b1Y * dd[l] + (b1X + b1Y) * dt[l] + tt[l];   // full_shape.py:550
+                    if (l == o.ell0) dd0 = dd[l];
                     tables_row[(size_t)(0 * n_ell + l) * n_kin + i] = dd[l];
                     tables_row[(size_t)(1 * n_ell + l) * n_kin + i] = dt[l];
                     tables_row[(size_t)(2 * n_ell + l) * n_kin + i] = tt[l];
                 }
             }
         }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (l < n_ell) {
+                double pl = p[l] + (l == o.ell0 ? sn0nd : 0.);
+                if (EFT && o.n_ct > 0) {  // full_shape.py:633
+                    double acc = 0.;
+                    for (int c = 0; c < o.n_ct; ++c) acc += o.ct_matrix[((size_t)l * n_kin + i) * o.n_ct + c] * s.pt[DL_PT_CT + c];
+                    pl += acc * dd0;
+                }
+                if (EFT && o.n_sn > 0) {  // full_shape.py:634
+                    double acc = 0.;
+                    for (int c = 0; c < o.n_sn; ++c) acc += o.sn_matrix[((size_t)l * n_kin + i) * o.n_sn + c] * s.pt[DL_PT_SN + c];
+                    pl += acc;
+                }
+                s.out[(size_t)l * n_kin + i] = pl;
+            }
+        }
     }
+}
+
+// phase 4: coalesced store of the staged multipoles
+DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, double* power_row) {
+    for (int idx = tid; idx < o.n_in; idx += nthr) power_row[idx] = s.out[idx];
 }

@@ -2,6 +2,7 @@
 // Plain C++ (no HIP): shared by the C-ABI library (dl_api.hip) and by the CPU emulation harness of
 // the `not gpu` tests.  Everything here runs once per dl_create, never per evaluation.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -51,13 +52,14 @@ struct DlObsHost {
     std::vector<double> weff;     // [n_out, n_in] effective window (matrix / identity / row selection)
     std::vector<double> bias;     // [n_out]: W . (sn_in (x) 1) + offset[mask] - sn_out        (window.py:459-473)
     std::vector<double> flatdata; // [n_out]
-    size_t off_kin, off_lkin, off_mu, off_wmu, off_xt, off_pk, off_th, off_lg, off_ih, off_A, off_nC, off_inv, off_Mfix, off_ct, off_sn;
+    size_t off_kin, off_lkin, off_mu, off_wmu, off_xt, off_pk, off_th, off_lg, off_ih, off_dlt, off_A, off_nC, off_inv, off_gf, off_gb, off_coef, off_ct, off_sn;
 
     void rebase(const double* base) {
         dev.kin = base + off_kin; dev.lkin = base + off_lkin; dev.mu = base + off_mu; dev.wmu = base + off_wmu;
         dev.x_t = base + off_xt; dev.pk_fid = base + off_pk; dev.sf_th = base + off_th; dev.sf_lg = base + off_lg;
-        dev.ih = base + off_ih; dev.sp_A = base + off_A; dev.sp_nC = base + off_nC; dev.sp_inv = base + off_inv;
-        dev.M_fixed = base + off_Mfix; dev.ct_matrix = base + off_ct; dev.sn_matrix = base + off_sn;
+        dev.ih = base + off_ih; dev.dlt = base + off_dlt; dev.sp_A = base + off_A; dev.sp_nC = base + off_nC; dev.sp_inv = base + off_inv;
+        dev.sp_gf = base + off_gf; dev.sp_gb = base + off_gb; dev.coef_fixed = base + off_coef;
+        dev.ct_matrix = base + off_ct; dev.sn_matrix = base + off_sn;
     }
 };
 
@@ -67,7 +69,7 @@ struct DlObsHost {
 struct DlSplineSetup {
     std::vector<double> ih, A, nC, inv;
     double end0a, end0b, end1a, end1b;
-    int warm;  // warm-up length after which a truncated sweep is exact to < 1e-22 relative
+    int warm;  // warm-up length after which a truncated sweep is exact to < 1e-19 relative (fp64 eps = 1.1e-16)
 };
 
 inline bool dl_spline_setup(const std::vector<double>& x, DlSplineSetup& s, std::string& err) {
@@ -111,7 +113,7 @@ inline bool dl_spline_setup(const std::vector<double>& x, DlSplineSetup& s, std:
         s.nC[i] = -cprev;
         amax = std::fmax(amax, std::fmax(std::fabs(s.A[i]), std::fabs(cprev)));
     }
-    if (amax < 0.9 && amax > 0.) s.warm = (int)std::ceil(std::log(1e-22) / std::log(amax)) + 1;
+    if (amax < 0.9 && amax > 0.) s.warm = (int)std::ceil(std::log(1e-19) / std::log(amax)) + 1;
     else s.warm = m;  // no exploitable decay: every segment sweeps from the boundary (serial)
     if (s.warm > m) s.warm = m;
     return true;
@@ -212,13 +214,47 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     d.x0 = x_t[0];
     d.inv_hx = (d.n_t - 1) / (x_t[d.n_t - 1] - x_t[0]);
     d.fixed_spline = (d.templ == 0);
+    // deviation of the knot table from an exactly uniform grid in log10 k (geomspace knots: rounding only)
+    std::vector<double> dlt(d.n_t);
+    d.uniform_knots = 1;
+    for (int j = 0; j < d.n_t; ++j) {
+        dlt[j] = x_t[j] - (d.x0 + j / d.inv_hx);
+        if (std::fabs(dlt[j] * d.inv_hx) > 1e-6) d.uniform_knots = 0;
+    }
+    // segmented sweeps: 64 segments, the state entering each is a dot product with products of the multipliers
     int m = d.n_t - 2;
     d.seg_warm = sp.warm;
-    d.n_seg = 64;
-    if (sp.warm >= m) d.n_seg = 1;
+    d.n_seg = DL_MAX_SEG;
     d.seg_len = (m + d.n_seg - 1) / d.n_seg;
-    std::vector<double> Mfix;
+    if (d.seg_warm > DL_SEG_PARTS * DL_SEG_QMAX) { err = p + "template knots too irregular for the segmented spline solve (sweep multipliers decay too slowly)"; return false; }
+    std::vector<double> gf((size_t)DL_SEG_QMAX * DL_FS_THREADS, 0.), gb((size_t)DL_SEG_QMAX * DL_FS_THREADS, 0.);
+    auto slot = [](int dd, int sgm) { return (size_t)(dd / DL_SEG_PARTS) * DL_FS_THREADS + (size_t)sgm * DL_SEG_PARTS + (dd % DL_SEG_PARTS); };
+    for (int sgm = 0; sgm < d.n_seg; ++sgm) {
+        int start = sgm * d.seg_len, end = std::min(start + d.seg_len, m);
+        if (start >= m) continue;
+        double g = 1.;
+        for (int dd = 0; dd < d.seg_warm && start - 1 - dd >= 0; ++dd) {   // weight of B_{start-1-dd} in z_{start-1}
+            gf[slot(dd, sgm)] = g;
+            g *= sp.A[start - 1 - dd];
+        }
+        g = 1.;
+        for (int dd = 0; dd < d.seg_warm && end + dd < m; ++dd) {           // weight of z_{end+dd} in u_end
+            gb[slot(dd, sgm)] = g;
+            g *= sp.nC[end + dd];
+        }
+    }
+    // interval polynomials of the fiducial table itself (fixed templates skip the per-point spline build)
+    std::vector<double> Mfix, coef((size_t)4 * d.n_t, 0.);
     dl_spline_moments_serial(pk, sp, Mfix);
+    {
+        std::vector<double> lds(dl_fs_shared_doubles(d.n_t, d.n_in), 0.);
+        DlFsShared sh = dl_fs_shared_carve(lds.data(), d.n_t, d.n_in);
+        for (int j = 0; j < d.n_t; ++j) { sh.y[j] = pk[j]; sh.M[j] = Mfix[j]; }
+        DlObsDev tmp = d;
+        tmp.ih = sp.ih.data(); tmp.x_t = x_t.data(); tmp.dlt = dlt.data();
+        dl_fs_phase2d(0, 1, tmp, sh);
+        for (size_t c = 0; c < coef.size(); ++c) coef[c] = sh.coef[c];
+    }
     // EFT-like terms
     const auto& ctm = cfg.F(p + "ct_matrix");
     const auto& snm = cfg.F(p + "sn_matrix");
@@ -240,8 +276,9 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     }
     oh.off_kin = arena.push(kin); oh.off_lkin = arena.push(lkin); oh.off_mu = arena.push(mu); oh.off_wmu = arena.push(wmu);
     oh.off_xt = arena.push(x_t); oh.off_pk = arena.push(pk); oh.off_th = arena.push(sf_th); oh.off_lg = arena.push(sf_lg);
-    oh.off_ih = arena.push(sp.ih); oh.off_A = arena.push(sp.A); oh.off_nC = arena.push(sp.nC); oh.off_inv = arena.push(sp.inv);
-    oh.off_Mfix = arena.push(Mfix); oh.off_ct = arena.push(ctm); oh.off_sn = arena.push(snm);
+    oh.off_ih = arena.push(sp.ih); oh.off_dlt = arena.push(dlt); oh.off_A = arena.push(sp.A); oh.off_nC = arena.push(sp.nC); oh.off_inv = arena.push(sp.inv);
+    oh.off_gf = arena.push(gf); oh.off_gb = arena.push(gb); oh.off_coef = arena.push(coef);
+    oh.off_ct = arena.push(ctm); oh.off_sn = arena.push(snm);
 
     // ---- window: effective matrix and additive bias (window.py:445-473) ----
     const auto& wm = cfg.F(p + "wmatrix");

@@ -10,8 +10,9 @@
 #define DL_ST_NONFINITE 2
 #define DL_ST_NAN_INPUT 3
 
-void dl_launch_fullshape(const DlObsDev* obs_dev, int n_obs, int max_n_t, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power,
-                         double* tables, int64_t ld_tables, hipStream_t stream);
+// obs_host: HOST array of observables whose pointers already point into device memory (passed by value to the kernel)
+void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
+                         int64_t ld_tables, hipStream_t stream);
 void dl_launch_window_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* C, int64_t ldc, int64_t M, int N_valid, int N_pad,
                            int K_pad, hipStream_t stream);
 void dl_launch_transform(double* flat, int64_t ld, const double* data, const int32_t* transform, int n, int64_t B, hipStream_t stream);

@@ -7,50 +7,70 @@
 //   dl_finalize_kernel  : chi2 = |whitened residual|^2 by wavefront shuffles, priors, status (rows a8 + a9).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "dl_fullshape.h"
 #include "dl_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
 // theory kernel
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DL_FS_THREADS) void dl_fullshape_kernel(const DlObsDev* __restrict__ obs, int n_obs, const double* __restrict__ theta,
-                                                                     int n_params, double* __restrict__ power, int64_t ld_power,
-                                                                     double* __restrict__ tables, int64_t ld_tables) {
+// The observable's constants travel BY VALUE in the kernarg segment: every pointer in it is then known to be a
+// global-memory pointer (global_load, not flat_load) and every scalar field is an SGPR, never re-read in a loop.
+template <bool FAST, int NL, bool EFT>
+__global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power,
+                                                                     int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int b = blockIdx.x, iobs = blockIdx.y;
-    const DlObsDev& o = obs[iobs];
-    DlFsShared s;
-    s.y = lds;
-    s.M = lds + o.n_t;
-    s.z = lds + 2 * (size_t)o.n_t;
-    s.pt = lds + 3 * (size_t)o.n_t;
+    const int b = blockIdx.x;
+    const DlFsShared s = dl_fs_shared_carve(lds, o.n_t, o.n_in);
     const double* th = theta + (size_t)b * n_params;
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = threadIdx.x, nthr = DL_FS_THREADS;
+    if (stop_after == -1) return;  // stop_after != 0: timing diagnostics only (DL_FS_STOP), outputs are then incomplete
     dl_fs_phase01(tid, nthr, o, th, s);
     __syncthreads();
+    if (stop_after == 1) return;
     if (!o.fixed_spline) {
         dl_fs_phase2a(tid, nthr, o, s);
         __syncthreads();
+        if (stop_after == 2) return;
+        dl_fs_phase2b_dot(tid, nthr, o, s);
+        __syncthreads();
         dl_fs_phase2b(tid, nthr, o, s);
+        __syncthreads();
+        if (stop_after == 3) return;
+        dl_fs_phase2c_dot(tid, nthr, o, s);
         __syncthreads();
         dl_fs_phase2c(tid, nthr, o, s);
         __syncthreads();
+        if (stop_after == 4) return;
+        dl_fs_phase2d(tid, nthr, o, s);
+        __syncthreads();
+        if (stop_after == 5) return;
     }
     double* prow = power + (size_t)b * ld_power + o.col_offset;
     double* trow = tables ? tables + (size_t)b * ld_tables : nullptr;
-    dl_fs_phase3(tid, nthr, o, s, prow, trow);
+    dl_fs_phase3<FAST, NL, EFT>(tid, nthr, o, s, trow);
+    __syncthreads();
+    dl_fs_phase4(tid, nthr, o, s, prow);
 }
 
-void dl_launch_fullshape(const DlObsDev* obs_dev, int n_obs, int max_n_t, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power,
-                         double* tables, int64_t ld_tables, hipStream_t stream) {
-    dim3 grid((unsigned)B, (unsigned)n_obs);
-    size_t shmem = dl_fs_shared_doubles(max_n_t) * sizeof(double);
-    static size_t shmem_optin = 0;
-    if (shmem > 48 * 1024 && shmem > shmem_optin) {  // large templates (e.g. 2000-knot BAO tables) need the dynamic-LDS opt-in
-        (void)hipFuncSetAttribute((const void*)dl_fullshape_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        shmem_optin = shmem;
+void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
+                         int64_t ld_tables, hipStream_t stream) {
+    static const int stop_after = getenv("DL_FS_STOP") ? atoi(getenv("DL_FS_STOP")) : 0;   // per-phase timing diagnostics
+    for (int i = 0; i < n_obs; ++i) {  // one launch per observable (1-2 in practice)
+        size_t shmem = dl_fs_shared_doubles(obs_host[i].n_t, obs_host[i].n_in) * sizeof(double);
+        auto launch = [&](auto kernel) {
+            if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  // e.g. 2000-knot BAO tables
+            hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shmem, stream, obs_host[i], theta, n_params, power, ld_power, tables, ld_tables, stop_after);
+        };
+        const DlObsDev& oh = obs_host[i];
+        bool nl3 = oh.n_ell <= 3, eft = oh.n_ct > 0 || oh.n_sn > 0;
+        if (tables || !oh.uniform_knots) launch(dl_fullshape_kernel<false, 5, true>);   // generic: run-time decisions
+        else if (nl3 && !eft) launch(dl_fullshape_kernel<true, 3, false>);
+        else if (nl3) launch(dl_fullshape_kernel<true, 3, true>);
+        else if (!eft) launch(dl_fullshape_kernel<true, 5, false>);
+        else launch(dl_fullshape_kernel<true, 5, true>);
     }
-    hipLaunchKernelGGL(dl_fullshape_kernel, grid, dim3(DL_FS_THREADS), shmem, stream, obs_dev, n_obs, theta, n_params, power, ld_power, tables, ld_tables);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -61,38 +81,64 @@ void dl_launch_fullshape(const DlObsDev* obs_dev, int n_obs, int max_n_t, const 
 //   (round-robin) and are summed through LDS.  v_mfma_f64_16x16x4_f64 operand layout (guide section 3):
 //   A operand lane l = A[row l&15][k l>>4], B operand lane l = B[k l>>4][col l&15],
 //   C/D reg r of lane l = C[row (l>>4) + 4 r][col l&15].
-//   Inside a 32-chunk lane group g = l>>4 owns k = 8 g .. 8 g + 7 (contiguous 64 B per lane), i.e. the
-//   k -> (mfma step, lane group) assignment is permuted identically for A and Wt: the sum is unchanged.
+//   Inside a 32-chunk lane group g = l>>4 owns k = 8 q + 2 g + {0, 1}, q = 0..3 (16 B per lane per load, the four lane
+//   groups of a row contiguous: 64 B per row per load instruction), i.e. the k -> (mfma step, lane group) assignment
+//   is permuted identically for A and Wt: the sum is unchanged.
 // ------------------------------------------------------------------------------------------------
 typedef double dl_double4 __attribute__((ext_vector_type(4)));
 typedef double dl_double2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void dl_window_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
-                                                             const double* __restrict__ bias, double* __restrict__ C, int64_t ldc, int M, int N_valid, int K_pad) {
-    __shared__ __attribute__((aligned(16))) double red[3][2][4][64];
+#define DL_GEMM_WAVES 8   // waves per workgroup = K-split factor
+
+struct DlGemmFrag {
+    dl_double2 a[4], b0[4], b1[4];   // 8 consecutive k per lane for one A row and two Wt rows
+};
+
+__device__ __forceinline__ void dl_gemm_load(DlGemmFrag& f, const double* ap, const double* b0p, const double* b1p, int kc) {
+    const dl_double2* a2 = reinterpret_cast<const dl_double2*>(ap + (size_t)kc * 32);
+    const dl_double2* b02 = reinterpret_cast<const dl_double2*>(b0p + (size_t)kc * 32);
+    const dl_double2* b12 = reinterpret_cast<const dl_double2*>(b1p + (size_t)kc * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { f.a[q] = a2[4 * q]; f.b0[q] = b02[4 * q]; f.b1[q] = b12[4 * q]; }
+}
+
+__device__ __forceinline__ void dl_gemm_mma(const DlGemmFrag& f, dl_double4& acc0, dl_double4& acc1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[q].x, f.b0[q].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[q].x, f.b1[q].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[q].y, f.b0[q].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[q].y, f.b1[q].y, acc1, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(64 * DL_GEMM_WAVES) void dl_window_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
+                                                                            const double* __restrict__ bias, double* __restrict__ C, int64_t ldc, int M, int N_valid,
+                                                                            int K_pad) {
+    __shared__ __attribute__((aligned(16))) double red[DL_GEMM_WAVES - 1][2][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 32;
     int arow = m0 + r16;
     if (arow > M - 1) arow = M - 1;
-    const double* ap = A + (size_t)arow * lda + g * 8;
-    const double* b0p = Wt + (size_t)(n0 + r16) * ldw + g * 8;
-    const double* b1p = Wt + (size_t)(n0 + 16 + r16) * ldw + g * 8;
+    // lane (r16, g) reads k = 8 q + 2 g + {0, 1} of each 32-chunk: one load instruction = 16 rows x 64 contiguous bytes
+    const double* ap = A + (size_t)arow * lda + g * 2;
+    const double* b0p = Wt + (size_t)(n0 + r16) * ldw + g * 2;
+    const double* b1p = Wt + (size_t)(n0 + 16 + r16) * ldw + g * 2;
     dl_double4 acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
     const int nchunks = K_pad / 32;
-    for (int kc = wave; kc < nchunks; kc += 4) {
-        const dl_double2* a2 = reinterpret_cast<const dl_double2*>(ap + (size_t)kc * 32);
-        const dl_double2* b02 = reinterpret_cast<const dl_double2*>(b0p + (size_t)kc * 32);
-        const dl_double2* b12 = reinterpret_cast<const dl_double2*>(b1p + (size_t)kc * 32);
-        dl_double2 av[4], bv0[4], bv1[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { av[q] = a2[q]; bv0[q] = b02[q]; bv1[q] = b12[q]; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q].x, bv0[q].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q].x, bv1[q].x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q].y, bv0[q].y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q].y, bv1[q].y, acc1, 0, 0, 0);
+    // software pipeline: the loads of chunk kc + 2 W are in flight while chunk kc is multiplied (two register buffers)
+    DlGemmFrag f0, f1;
+    int kc = wave;
+    if (kc < nchunks) dl_gemm_load(f0, ap, b0p, b1p, kc);
+    for (; kc < nchunks; kc += 2 * DL_GEMM_WAVES) {
+        int kn = kc + DL_GEMM_WAVES;
+        if (kn < nchunks) dl_gemm_load(f1, ap, b0p, b1p, kn);
+        dl_gemm_mma(f0, acc0, acc1);
+        if (kn < nchunks) {
+            int kn2 = kn + DL_GEMM_WAVES;
+            if (kn2 < nchunks) dl_gemm_load(f0, ap, b0p, b1p, kn2);
+            dl_gemm_mma(f1, acc0, acc1);
         }
     }
     if (wave > 0) {
@@ -105,7 +151,7 @@ __global__ __launch_bounds__(256) void dl_window_gemm_kernel(const double* __res
         for (int r = 0; r < 4; ++r) {
             double s0 = acc0[r], s1 = acc1[r];
 #pragma unroll
-            for (int w = 0; w < 3; ++w) { s0 += red[w][0][r][lane]; s1 += red[w][1][r][lane]; }
+            for (int w = 0; w < DL_GEMM_WAVES - 1; ++w) { s0 += red[w][0][r][lane]; s1 += red[w][1][r][lane]; }
             int row = m0 + g + 4 * r;
             if (row < M) {
                 if (n0 + r16 < N_valid) C[(size_t)row * ldc + n0 + r16] = s0 + bias[n0 + r16];
@@ -118,7 +164,7 @@ __global__ __launch_bounds__(256) void dl_window_gemm_kernel(const double* __res
 void dl_launch_window_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* C, int64_t ldc, int64_t M, int N_valid, int N_pad,
                            int K_pad, hipStream_t stream) {
     dim3 grid((unsigned)((M + 15) / 16), (unsigned)(N_pad / 32));
-    hipLaunchKernelGGL(dl_window_gemm_kernel, grid, dim3(256), 0, stream, A, lda, Wt, ldw, bias, C, ldc, (int)M, N_valid, K_pad);
+    hipLaunchKernelGGL(dl_window_gemm_kernel, grid, dim3(64 * DL_GEMM_WAVES), 0, stream, A, lda, Wt, ldw, bias, C, ldc, (int)M, N_valid, K_pad);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -120,10 +120,11 @@ int  dl_eval_theory_host(dl_ctx* ctx, const double* theta, int64_t B, int32_t io
                          double* power, double* tables);
 
 /* ---- measurement -----------------------------------------------------------------------------*/
-/* When enabled, dl_eval_batch brackets each kernel with HIP events on the launch stream;
- * dl_profile_read synchronises and returns the per-kernel milliseconds:
- * ms[0] theory kernel, ms[1] window GEMM, ms[2] chi2/prior finalize, ms[3] whole call,
- * averaged over the (up to 256) calls recorded since dl_profile_enable. */
+/* enable > 0: dl_eval_batch brackets each kernel with HIP events on the launch stream, on one call out of
+ * ``enable`` (sampling keeps the cost of the event records, ~3.5 us each, out of the measured throughput).
+ * dl_profile_read synchronises and returns per-kernel milliseconds averaged over the (up to 256) sampled calls,
+ * after subtracting the calibrated cost of an empty event-to-event interval:
+ * ms[0] theory kernel, ms[1] window GEMM, ms[2] chi2/prior finalize, ms[3] whole call, ms[4] (if n >= 5) the overhead subtracted. */
 int  dl_profile_enable(dl_ctx* ctx, int enable);
 int  dl_profile_read(dl_ctx* ctx, double* ms, int32_t n);
 

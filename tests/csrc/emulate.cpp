@@ -20,17 +20,27 @@ int emu_config_set_i32(dl_config* cfg, const char* key, const int32_t* data, int
 const char* emu_last_error(void) { return g_err.c_str(); }
 
 static void run_point(const DlObsDev& o, const double* th, double* prow, double* trow) {
-    std::vector<double> lds(dl_fs_shared_doubles(o.n_t));
-    DlFsShared s;
-    s.y = lds.data(); s.M = s.y + o.n_t; s.z = s.M + o.n_t; s.pt = s.z + o.n_t;
+    std::vector<double> lds(dl_fs_shared_doubles(o.n_t, o.n_in));
+    DlFsShared s = dl_fs_shared_carve(lds.data(), o.n_t, o.n_in);
     const int nthr = DL_FS_THREADS;
     for (int tid = 0; tid < nthr; ++tid) dl_fs_phase01(tid, nthr, o, th, s);
     if (!o.fixed_spline) {
         for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2a(tid, nthr, o, s);
+        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2b_dot(tid, nthr, o, s);
         for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2b(tid, nthr, o, s);
+        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2c_dot(tid, nthr, o, s);
         for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2c(tid, nthr, o, s);
+        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2d(tid, nthr, o, s);
     }
-    for (int tid = 0; tid < nthr; ++tid) dl_fs_phase3(tid, nthr, o, s, prow, trow);
+    for (int tid = 0; tid < nthr; ++tid) {
+        bool nl3 = o.n_ell <= 3, eft = o.n_ct > 0 || o.n_sn > 0;   // same dispatch as dl_launch_fullshape
+        if (trow || !o.uniform_knots) dl_fs_phase3<false, 5, true>(tid, nthr, o, s, trow);
+        else if (nl3 && !eft) dl_fs_phase3<true, 3, false>(tid, nthr, o, s, trow);
+        else if (nl3) dl_fs_phase3<true, 3, true>(tid, nthr, o, s, trow);
+        else if (!eft) dl_fs_phase3<true, 5, false>(tid, nthr, o, s, trow);
+        else dl_fs_phase3<true, 5, true>(tid, nthr, o, s, trow);
+    }
+    for (int tid = 0; tid < nthr; ++tid) dl_fs_phase4(tid, nthr, o, s, prow);
 }
 
 // power [B, n_in], tables [B, 3, n_in] (may be null)
