@@ -24,9 +24,9 @@ SYMBOLS = {
     'dl_destroy': (None, [ctypes.c_void_p]),
     'dl_last_error': (ctypes.c_char_p, [ctypes.c_void_p]),
     'dl_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
-    'dl_eval_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_eval_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_theory': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-    'dl_eval_batch_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_int32_p]),
+    'dl_eval_batch_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
     'dl_eval_theory_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, ctypes.c_int32, _c_double_p, _c_double_p]),
     'dl_profile_enable': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'dl_profile_read': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int32]),
@@ -85,9 +85,15 @@ def fill_config(spec, set_f64, set_i32):
                                 put('obs{:d}.in.{}'.format(iobs, name), np.array([[c, v] for c, v in zip(np.ravel(col), np.ravel(const))], dtype='f8'))
                             else:
                                 put('obs{:d}.in.{}'.format(iobs, name), np.array([col, const], dtype='f8'))
+                    elif okey == 'marg':
+                        for name, index in ovalue.items():
+                            put('obs{:d}.marg.{}'.format(iobs, name), np.asarray(index, dtype='i4'))
                     elif ovalue is not None:
                         put('obs{:d}.{}'.format(iobs, okey), ovalue)
             put('n_obs', np.array([len(value)], dtype='i4'))
+        elif key == 'marg':
+            for name, array in value.items():
+                put('marg.{}'.format(name), array)
         elif value is not None:
             put(key, value)
 
@@ -117,7 +123,7 @@ class Context(object):
         if rc != 0:
             raise LibraryError(lib.dl_last_error(None).decode())
         self._lib, self._handle, self.device = lib, handle, int(device)
-        self.n_params, self.n_data, self.n_obs = (self.info(name) for name in ['n_params', 'n_data', 'n_obs'])
+        self.n_params, self.n_data, self.n_obs, self.n_solved = (self.info(name) for name in ['n_params', 'n_data', 'n_obs', 'n_solved'])
 
     def info(self, key):
         return int(self._lib.dl_info(self._handle, key.encode()))
@@ -138,15 +144,21 @@ class Context(object):
             pass
 
     # ---- host-pointer entry points (numpy in / numpy out) ----
-    def eval_batch_host(self, theta, return_flattheory=False):
+    def eval_batch_host(self, theta, return_flattheory=False, return_solved=False):
+        """numpy in / numpy out: (loglike, logprior, status[, flattheory][, solved])."""
         theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
         if theta.shape[1] != self.n_params:
             raise ValueError('theta must have shape (B, {:d}), found {}'.format(self.n_params, theta.shape))
         B = theta.shape[0]
         loglike, logprior, status = np.empty(B, dtype='f8'), np.empty(B, dtype='f8'), np.empty(B, dtype='i4')
         flat = np.empty((B, self.n_data), dtype='f8') if return_flattheory else None
-        self._check(self._lib.dl_eval_batch_host(self._handle, _f64_ptr(theta), B, _f64_ptr(loglike), _f64_ptr(logprior), _f64_ptr(flat), _i32_ptr(status)))
-        return (loglike, logprior, status, flat) if return_flattheory else (loglike, logprior, status)
+        solved = np.empty((B, self.n_solved), dtype='f8') if return_solved else None
+        self._check(self._lib.dl_eval_batch_host(self._handle, _f64_ptr(theta), B, _f64_ptr(loglike), _f64_ptr(logprior), _f64_ptr(flat), _i32_ptr(status),
+                                                 _f64_ptr(solved) if self.n_solved else None))
+        toret = (loglike, logprior, status)
+        if return_flattheory: toret += (flat,)
+        if return_solved: toret += (solved,)
+        return toret
 
     def eval_theory_host(self, theta, iobs=0, return_tables=False):
         theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
@@ -158,7 +170,7 @@ class Context(object):
         return (power, tables) if return_tables else power
 
     # ---- device-pointer entry points (torch tensors as the array container) ----
-    def eval_batch(self, theta, loglike=None, logprior=None, flattheory=None, status=None, stream=None):
+    def eval_batch(self, theta, loglike=None, logprior=None, flattheory=None, status=None, solved=None, stream=None):
         """All arguments are CUDA(ROCm) torch tensors on this context's device; asynchronous on ``stream``."""
         import torch
         if stream is None:
@@ -172,7 +184,8 @@ class Context(object):
             return ctypes.c_void_p(tensor.data_ptr())
 
         self._check(self._lib.dl_eval_batch(self._handle, ctypes.c_void_p(theta.data_ptr()), B, ptr(loglike, torch.float64, (B,)), ptr(logprior, torch.float64, (B,)),
-                                            ptr(flattheory, torch.float64, (B, self.n_data)), ptr(status, torch.int32, (B,)), ctypes.c_void_p(stream)))
+                                            ptr(flattheory, torch.float64, (B, self.n_data)), ptr(status, torch.int32, (B,)),
+                                            ptr(solved, torch.float64, (B, self.n_solved)), ctypes.c_void_p(stream)))
 
     def profile_enable(self, every=1):
         """Bracket kernels with HIP events on one ``eval_batch`` call out of ``every`` (0 / False: off)."""

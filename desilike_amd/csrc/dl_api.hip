@@ -18,6 +18,10 @@ struct dl_ctx {
     int n_params = 0, n_obs = 0, n_data = 0;
     int N_pad = 0, K_pad = 0, max_n_t = 0;
     bool any_transform = false;
+    // analytic marginalisation
+    int n_solved = 0, n_var = 0;
+    DlMargDev marg;
+    double* tconst_dev = nullptr;    // [n_solved, N_pad]
     std::vector<DlObsHost> obs;
     std::vector<int> obs_row0;       // first data row of each observable
     // device constants
@@ -186,6 +190,65 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
         bias_white[i] = bsum;
         bias_wh[i] = -dsum;
     }
+    // ---- analytic marginalisation (likelihoods/base.py:314-413): solved parameters, constant / point-dependent derivative columns ----
+    {
+        const auto& kind = cfg->I("marg.kind");
+        const auto& mprior = cfg->F("marg.prior");
+        const auto& mx0 = cfg->F("marg.x0");
+        int ns = (int)kind.size();
+        if (ns > DL_MAX_SOLVED) return bail("dl_create: at most 16 analytically solved parameters");
+        if ((int)mprior.size() != 2 * ns || (int)mx0.size() != ns) return bail("dl_create: marg.prior / marg.x0 sizes do not match marg.kind");
+        if (ns > 0 && ctx->any_transform) return bail("dl_create: analytic marginalisation needs a theory linear in the solved parameters (no observable transform)");
+        if (ns > 0 && n > 64 * DL_MARG_NJ) return bail("dl_create: analytic marginalisation supports up to 512 data points");
+        ctx->n_solved = ns;
+        std::memset(&ctx->marg, 0, sizeof(ctx->marg));
+        ctx->marg.n_s = ns;
+        for (int s_ = 0; s_ < ns; ++s_) {
+            ctx->marg.is_marg[s_] = kind[s_] != 0;
+            ctx->marg.n_marg += kind[s_] != 0;
+            ctx->marg.loc[s_] = mprior[2 * s_];
+            ctx->marg.prec[s_] = mprior[2 * s_ + 1];
+            ctx->marg.x0[s_] = mx0[s_];
+            ctx->marg.var_slot[s_] = -1;
+        }
+        // point-dependent columns: counter terms (derivative proportional to P_dd,l=0 of the point)
+        for (auto& ob : ctx->obs)
+            for (int c = 0; c < ob.dev.n_ct; ++c)
+                for (int t = 0; t < 2; ++t) {
+                    int sidx = ob.marg_ct[c][t];
+                    if (sidx < 0) continue;
+                    if (sidx >= ns) return bail("dl_create: marg index out of range");
+                    if (ctx->marg.var_slot[sidx] < 0) ctx->marg.var_slot[sidx] = ctx->n_var++;
+                }
+        for (auto& ob : ctx->obs) {
+            ob.dev.n_var = ctx->n_var;
+            for (int c = 0; c < ob.dev.n_ct; ++c)
+                for (int t = 0; t < 2; ++t) ob.dev.marg_ct_slot[c][t] = ob.marg_ct[c][t] >= 0 ? ctx->marg.var_slot[ob.marg_ct[c][t]] : -1;
+        }
+        // constant columns: Tt_s = (L^T W) dpower/dx_s with dpower/dsn0 = delta_{l0} / nd (full_shape.py:549), dpower/dsn_c = sn_matrix[:, c] / nd (634)
+        std::vector<double> tconst((size_t)std::max(ns, 1) * ctx->N_pad, 0.);
+        for (int s_ = 0; s_ < ns; ++s_) {
+            std::vector<double> dvec(K, 0.);
+            for (auto& ob : ctx->obs) {
+                const DlObsDev& od = ob.dev;
+                double* dst = &dvec[od.col_offset];
+                if (ob.marg_sn0 == s_ && od.ell0 >= 0)
+                    for (int i = 0; i < od.n_kin; ++i) dst[(size_t)od.ell0 * od.n_kin + i] += 1. / od.nd;
+                const auto& snm = cfg->F("obs" + std::to_string(&ob - &ctx->obs[0]) + ".sn_matrix");
+                for (int c = 0; c < od.n_sn; ++c)
+                    if (ob.marg_sn[c] == s_)
+                        for (int idx = 0; idx < od.n_in; ++idx) dst[idx] += snm[(size_t)idx * od.n_sn + c] / od.nd;
+            }
+            for (int i = 0; i < n; ++i) {
+                double sum = 0.;
+                const double* wrow = &wt_white[(size_t)i * ctx->K_pad];
+                for (int k = 0; k < K; ++k) sum += wrow[k] * dvec[k];
+                tconst[(size_t)s_ * ctx->N_pad + i] = sum;
+            }
+        }
+        if (dl_upload(ctx, &ctx->tconst_dev, tconst)) { dl_destroy(ctx); return 1; }
+        ctx->marg.tconst = ctx->tconst_dev;
+    }
     // ---- upload ----
     if (dl_upload(ctx, &ctx->arena_dev, arena.data)) { dl_destroy(ctx); return 1; }
     ctx->obs_kernarg.resize(ctx->n_obs);
@@ -205,7 +268,7 @@ void dl_destroy(dl_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     void* ptrs[] = {ctx->arena_dev, ctx->priors_dev, ctx->wt_white_dev, ctx->bias_white_dev, ctx->wt_full_dev, ctx->bias_full_dev, ctx->wh_dev,
-                    ctx->bias_wh_dev, ctx->flatdata_dev, ctx->transform_dev, ctx->power_ws, ctx->delta_ws, ctx->flat_ws, ctx->theta_stage, ctx->out_stage,
+                    ctx->bias_wh_dev, ctx->flatdata_dev, ctx->transform_dev, ctx->tconst_dev, ctx->power_ws, ctx->delta_ws, ctx->flat_ws, ctx->theta_stage, ctx->out_stage,
                     ctx->status_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -221,7 +284,7 @@ int64_t dl_info(const dl_ctx* ctx, const char* key) {
     if (k == "n_in_total") { int64_t t = 0; for (auto& o : ctx->obs) t += o.dev.n_in; return t; }
     if (k == "K_pad") return ctx->K_pad;
     if (k == "N_pad") return ctx->N_pad;
-    if (k == "n_solved") return 0;
+    if (k == "n_solved") return ctx->n_solved;
     for (int i = 0; i < ctx->n_obs; ++i) {
         if (k == "n_in_obs" + std::to_string(i)) return ctx->obs[i].dev.n_in;
         if (k == "n_out_obs" + std::to_string(i)) return ctx->obs[i].n_out;
@@ -239,24 +302,25 @@ static int dl_reserve(dl_ctx* ctx, int64_t B) {
     need = std::min<int64_t>(std::max<int64_t>(need, 1024), DL_CHUNK);
     for (double** p : {&ctx->power_ws, &ctx->delta_ws, &ctx->flat_ws}) if (*p) { (void)hipFree(*p); *p = nullptr; }
     ctx->cap = 0;
-    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->power_ws, (size_t)need * ctx->K_pad * sizeof(double)));
-    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->delta_ws, (size_t)need * ctx->N_pad * sizeof(double)));
+    const size_t R = 1 + ctx->n_var;   // rows per point: power + point-dependent derivative rows (analytic marginalisation)
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->power_ws, (size_t)need * R * ctx->K_pad * sizeof(double)));
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->delta_ws, (size_t)need * R * ctx->N_pad * sizeof(double)));
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->flat_ws, (size_t)need * ctx->N_pad * sizeof(double)));
     // the K padding columns of the power buffer are never written by the theory kernel and must be finite
-    DL_HIP_CHECK(ctx, hipMemset(ctx->power_ws, 0, (size_t)need * ctx->K_pad * sizeof(double)));
+    DL_HIP_CHECK(ctx, hipMemset(ctx->power_ws, 0, (size_t)need * R * ctx->K_pad * sizeof(double)));
     ctx->cap = need;
     return 0;
 }
 
 int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* loglike_dev, double* logprior_dev, double* flattheory_dev, int32_t* status_dev,
-                  void* hip_stream) {
+                  double* solved_dev, void* hip_stream) {
     if (!ctx) { g_last_error = "dl_eval_batch: null context"; return 1; }
     if (B < 0 || (B > 0 && !theta_dev)) return dl_fail(ctx, "dl_eval_batch: invalid batch");
     if (B == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
     DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (dl_reserve(ctx, B)) return 1;
-    const int n = ctx->n_data, P = ctx->n_params;
+    const int n = ctx->n_data, P = ctx->n_params, R = 1 + ctx->n_var;
     for (int64_t b0 = 0; b0 < B; b0 += DL_CHUNK) {
         int64_t nb = std::min<int64_t>(DL_CHUNK, B - b0);
         const double* th = theta_dev + (size_t)b0 * P;
@@ -268,8 +332,8 @@ int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logli
         bool need_flat = ctx->any_transform || flattheory_dev != nullptr;
         if (need_flat) {
             // flattheory = W . power + bias (window.py:459-473), then optional cubic transform (power_spectrum.py:402-404)
-            dl_launch_window_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_full_dev, ctx->K_pad, ctx->bias_full_dev, ctx->flat_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad,
-                                  ctx->K_pad, stream);
+            dl_launch_window_gemm(ctx->power_ws, (int64_t)R * ctx->K_pad, ctx->wt_full_dev, ctx->K_pad, ctx->bias_full_dev, ctx->flat_ws, ctx->N_pad, nb, ctx->N_pad,
+                                  ctx->N_pad, ctx->K_pad, 1, stream);   // row 0 of each point only (lda skips the derivative rows)
             if (ctx->any_transform) dl_launch_transform(ctx->flat_ws, ctx->N_pad, ctx->flatdata_dev, ctx->transform_dev, n, nb, stream);
             if (flattheory_dev)
                 DL_HIP_CHECK(ctx, hipMemcpy2DAsync(flattheory_dev + (size_t)b0 * n, (size_t)n * sizeof(double), ctx->flat_ws, (size_t)ctx->N_pad * sizeof(double),
@@ -278,15 +342,20 @@ int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logli
         if (ctx->any_transform) {
             // dtilde = L^T (flattheory - flatdata)
             dl_launch_window_gemm(ctx->flat_ws, ctx->N_pad, ctx->wh_dev, ctx->N_pad, ctx->bias_wh_dev, ctx->delta_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad, ctx->N_pad,
-                                  stream);
+                                  1, stream);
         } else {
             // dtilde = (L^T W) . power + L^T (bias - flatdata): window convolution and precision folded in one fp64 MFMA GEMM
-            dl_launch_window_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad,
-                                  ctx->K_pad, stream);
+            dl_launch_window_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, ctx->N_pad, nb * R, ctx->N_pad, ctx->N_pad,
+                                  ctx->K_pad, R, stream);
         }
         if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
-        dl_launch_finalize(ctx->delta_ws, ctx->N_pad, n, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
-                           status_dev ? status_dev + b0 : nullptr, stream);
+        if (ctx->n_solved > 0)
+            dl_launch_finalize_marg(ctx->delta_ws, ctx->N_pad, n, R, ctx->marg, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr,
+                                    logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr,
+                                    solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr, stream);
+        else
+            dl_launch_finalize(ctx->delta_ws, ctx->N_pad, n, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
+                               status_dev ? status_dev + b0 : nullptr, stream);
         if (prof) { DL_HIP_CHECK(ctx, hipEventRecord(ev[3], stream)); ctx->prof_calls++; }
     }
     if (ctx->profile) ctx->eval_calls++;
@@ -321,16 +390,17 @@ static int dl_stage_reserve(dl_ctx* ctx, int64_t B) {
     return 0;
 }
 
-int dl_eval_batch_host(dl_ctx* ctx, const double* theta, int64_t B, double* loglike, double* logprior, double* flattheory, int32_t* status) {
+int dl_eval_batch_host(dl_ctx* ctx, const double* theta, int64_t B, double* loglike, double* logprior, double* flattheory, int32_t* status, double* solved) {
     if (!ctx) { g_last_error = "dl_eval_batch_host: null context"; return 1; }
     if (B < 0 || (B > 0 && !theta)) return dl_fail(ctx, "dl_eval_batch_host: invalid batch");
     if (B == 0) return 0;
     DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (dl_stage_reserve(ctx, B)) return 1;
-    double* flat_dev = nullptr;
+    double *flat_dev = nullptr, *solved_dev = nullptr;
     if (flattheory) DL_HIP_CHECK(ctx, hipMalloc((void**)&flat_dev, (size_t)B * ctx->n_data * sizeof(double)));
+    if (solved && ctx->n_solved > 0) DL_HIP_CHECK(ctx, hipMalloc((void**)&solved_dev, (size_t)B * ctx->n_solved * sizeof(double)));
     DL_HIP_CHECK(ctx, hipMemcpy(ctx->theta_stage, theta, (size_t)B * ctx->n_params * sizeof(double), hipMemcpyHostToDevice));
-    int rc = dl_eval_batch(ctx, ctx->theta_stage, B, ctx->out_stage, ctx->out_stage + ctx->stage_cap, flat_dev, ctx->status_stage, nullptr);
+    int rc = dl_eval_batch(ctx, ctx->theta_stage, B, ctx->out_stage, ctx->out_stage + ctx->stage_cap, flat_dev, ctx->status_stage, solved_dev, nullptr);
     if (rc == 0) {
         hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) rc = dl_fail(ctx, std::string("dl_eval_batch_host: ") + hipGetErrorString(e));
@@ -340,8 +410,10 @@ int dl_eval_batch_host(dl_ctx* ctx, const double* theta, int64_t B, double* logl
         if (logprior) (void)hipMemcpy(logprior, ctx->out_stage + ctx->stage_cap, (size_t)B * sizeof(double), hipMemcpyDeviceToHost);
         if (status) (void)hipMemcpy(status, ctx->status_stage, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost);
         if (flattheory) (void)hipMemcpy(flattheory, flat_dev, (size_t)B * ctx->n_data * sizeof(double), hipMemcpyDeviceToHost);
+        if (solved_dev) (void)hipMemcpy(solved, solved_dev, (size_t)B * ctx->n_solved * sizeof(double), hipMemcpyDeviceToHost);
     }
     if (flat_dev) (void)hipFree(flat_dev);
+    if (solved_dev) (void)hipFree(solved_dev);
     return rc;
 }
 

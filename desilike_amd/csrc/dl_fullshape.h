@@ -38,6 +38,7 @@
 #define DL_FS_THREADS 256
 #define DL_MAX_SEG 64
 #define DL_SEG_PARTS 4      // threads cooperating on the warm-up dot product of one segment (DL_MAX_SEG * DL_SEG_PARTS = DL_FS_THREADS)
+#define DL_MAX_SOLVED 16   // analytically solved (marginalised / best-fit) linear parameters
 #define DL_SEG_QMAX 12     // dot-product terms per thread: warm-up length <= DL_SEG_PARTS * DL_SEG_QMAX = 48
 
 struct DlInput {
@@ -55,6 +56,10 @@ struct DlObsDev {
     int32_t seg_len, seg_warm, n_seg, fixed_spline;
     int32_t uniform_knots, pad0;     // knots uniform in log10 k (to < 1e-6 of the spacing): interval index = floor of the scaled abscissa
     int64_t col_offset;  // first column of this observable in a row of the (concatenated) power buffer
+    // analytic marginalisation: each point owns 1 + n_var consecutive rows of the power buffer; row 1 + v holds
+    // d(power) / d(solved parameter of variable slot v) (counter terms: the derivative depends on the point through P_dd,l=0)
+    int32_t n_var, pad1;
+    int32_t marg_ct_slot[DL_MAX_EFT][2];   // variable slot fed by counter term c through tracer X / Y, or -1
     double eta, f_fid, a, nd, x0, inv_hx;
     double end0a, end0b, end1a, end1b;  // not-a-knot end relations: M[0] = end0a M[1] + end0b M[2]; M[n-1] = end1a M[n-2] + end1b M[n-3]
     DlInput qpar, qper, qiso, qap, df, dm, dn, sigpar, sigper, b1X, b1Y, sn0;
@@ -93,7 +98,8 @@ struct DlFsShared {
     double* pt;    // [DL_PT_SIZE]
 };
 
-DL_HD size_t dl_fs_work_doubles(int n_t, int n_in) { size_t w = 3 * (size_t)n_t; if ((size_t)n_in > w) w = (size_t)n_in; return (w + 1) & ~(size_t)1; }
+// out [n_in] + dd0 [n_kin <= n_in] alias y, M, z
+DL_HD size_t dl_fs_work_doubles(int n_t, int n_in) { size_t w = 3 * (size_t)n_t; if (2 * (size_t)n_in > w) w = 2 * (size_t)n_in; return (w + 1) & ~(size_t)1; }
 DL_HD size_t dl_fs_shared_doubles(int n_t, int n_in) { return 4 * (size_t)n_t + dl_fs_work_doubles(n_t, n_in) + DL_PT_SIZE; }
 
 DL_HD DlFsShared dl_fs_shared_carve(double* base, int n_t, int n_in) {
@@ -407,10 +413,28 @@ DL_HD void dl_fs_phase3(int tid, int nthr, const DlObsDev& o, const DlFsShared& 
                 s.out[(size_t)l * n_kin + i] = pl;
             }
         }
+        if (EFT && o.n_var > 0) s.out[o.n_in + i] = dd0;   // needed by the derivative rows (phase 4)
     }
 }
 
 // phase 4: coalesced store of the staged multipoles
-DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, double* power_row) {
+// power_row: row 0 of this point (already offset by col_offset); ld: leading dimension of the power buffer
+DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, double* power_row, int64_t ld) {
     for (int idx = tid; idx < o.n_in; idx += nthr) power_row[idx] = s.out[idx];
+    if (o.n_var > 0 && o.n_ct > 0) {
+        // d(power)/d(ct) = 0.5 ct_matrix[:, c] P_dd,l=0 per tracer (full_shape.py:630, 633): rows 1 + slot of this point
+        for (int c = 0; c < o.n_ct; ++c) {
+            for (int t = 0; t < 2; ++t) {
+                int slot = o.marg_ct_slot[c][t];
+                if (slot < 0) continue;
+                if (t == 1 && o.marg_ct_slot[c][0] == slot) continue;   // both tracers feed the same parameter: handled at t = 0 with weight 1
+                double wgt = (o.marg_ct_slot[c][0] == o.marg_ct_slot[c][1]) ? 1. : 0.5;
+                double* drow = power_row + (size_t)(1 + slot) * ld;
+                for (int idx = tid; idx < o.n_in; idx += nthr) {
+                    int i = idx % o.n_kin;
+                    drow[idx] = wgt * o.ct_matrix[(size_t)idx * o.n_ct + c] * s.out[o.n_in + i];
+                }
+            }
+        }
+    }
 }

@@ -49,6 +49,10 @@ struct DlArena {
 struct DlObsHost {
     DlObsDev dev;   // pointers are OFFSETS into arena (in doubles) until rebase()
     int n_out = 0;  // data size of this observable
+    // analytic marginalisation: index of the solved parameter fed by each linear input of this observable (-1: not solved)
+    int marg_sn0 = -1;
+    int marg_sn[DL_MAX_EFT];
+    int marg_ct[DL_MAX_EFT][2];
     std::vector<double> weff;     // [n_out, n_in] effective window (matrix / identity / row selection)
     std::vector<double> bias;     // [n_out]: W . (sn_in (x) 1) + offset[mask] - sn_out        (window.py:459-473)
     std::vector<double> flatdata; // [n_out]
@@ -273,6 +277,17 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     for (int c = 0; c < d.n_sn; ++c) {
         d.sn_in[c].col = (int32_t)std::lround(snin[c * 2]);
         d.sn_in[c].value = snin[c * 2 + 1];
+    }
+    {
+        const auto& msn0 = cfg.I(p + "marg.sn0");
+        const auto& msn = cfg.I(p + "marg.sn");
+        const auto& mct = cfg.I(p + "marg.ct");
+        oh.marg_sn0 = msn0.empty() ? -1 : msn0[0];
+        for (int c = 0; c < DL_MAX_EFT; ++c) {
+            oh.marg_sn[c] = (c < (int)msn.size()) ? msn[c] : -1;
+            for (int t = 0; t < 2; ++t) { oh.marg_ct[c][t] = (2 * c + t < (int)mct.size()) ? mct[2 * c + t] : -1; d.marg_ct_slot[c][t] = -1; }
+        }
+        d.n_var = 0;
     }
     oh.off_kin = arena.push(kin); oh.off_lkin = arena.push(lkin); oh.off_mu = arena.push(mu); oh.off_wmu = arena.push(wmu);
     oh.off_xt = arena.push(x_t); oh.off_pk = arena.push(pk); oh.off_th = arena.push(sf_th); oh.off_lg = arena.push(sf_lg);

@@ -13,8 +13,20 @@
 // obs_host: HOST array of observables whose pointers already point into device memory (passed by value to the kernel)
 void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
                          int64_t ld_tables, hipStream_t stream);
+// bias is added to rows r with r % bias_period == 0 only (bias_period = 1: every row)
 void dl_launch_window_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* C, int64_t ldc, int64_t M, int N_valid, int N_pad,
-                           int K_pad, hipStream_t stream);
+                           int K_pad, int bias_period, hipStream_t stream);
+
+#define DL_MARG_NJ 8   // finalize-marg keeps n / 64 <= 8 residual entries per lane: n_data <= 512
+struct DlMargDev {
+    int32_t n_s, n_marg;
+    int32_t is_marg[DL_MAX_SOLVED];
+    int32_t var_slot[DL_MAX_SOLVED];     // row (1 + slot) of the point holds the point-dependent part of Tt_s, or -1
+    double x0[DL_MAX_SOLVED], loc[DL_MAX_SOLVED], prec[DL_MAX_SOLVED];
+    const double* tconst;                // [n_s, N_pad] point-independent part of Tt_s = L^T W dpower/dx_s
+};
+void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, const DlMargDev& mg, const double* theta, int n_params, const double* priors,
+                             int64_t B, double* loglike, double* logprior, int32_t* status, double* solved, hipStream_t stream);
 void dl_launch_transform(double* flat, int64_t ld, const double* data, const int32_t* transform, int n, int64_t B, hipStream_t stream);
 void dl_launch_finalize(const double* dtilde, int64_t ld, int n, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
                         int32_t* status, hipStream_t stream);

@@ -47,11 +47,11 @@ __global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_kernel(const Dl
         __syncthreads();
         if (stop_after == 5) return;
     }
-    double* prow = power + (size_t)b * ld_power + o.col_offset;
+    double* prow = power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset;
     double* trow = tables ? tables + (size_t)b * ld_tables : nullptr;
     dl_fs_phase3<FAST, NL, EFT>(tid, nthr, o, s, trow);
     __syncthreads();
-    dl_fs_phase4(tid, nthr, o, s, prow);
+    dl_fs_phase4(tid, nthr, o, s, prow, ld_power);
 }
 
 void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
@@ -114,7 +114,7 @@ __device__ __forceinline__ void dl_gemm_mma(const DlGemmFrag& f, dl_double4& acc
 
 __global__ __launch_bounds__(64 * DL_GEMM_WAVES) void dl_window_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
                                                                             const double* __restrict__ bias, double* __restrict__ C, int64_t ldc, int M, int N_valid,
-                                                                            int K_pad) {
+                                                                            int K_pad, int bias_period) {
     __shared__ __attribute__((aligned(16))) double red[DL_GEMM_WAVES - 1][2][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -154,17 +154,18 @@ __global__ __launch_bounds__(64 * DL_GEMM_WAVES) void dl_window_gemm_kernel(cons
             for (int w = 0; w < DL_GEMM_WAVES - 1; ++w) { s0 += red[w][0][r][lane]; s1 += red[w][1][r][lane]; }
             int row = m0 + g + 4 * r;
             if (row < M) {
-                if (n0 + r16 < N_valid) C[(size_t)row * ldc + n0 + r16] = s0 + bias[n0 + r16];
-                if (n0 + 16 + r16 < N_valid) C[(size_t)row * ldc + n0 + 16 + r16] = s1 + bias[n0 + 16 + r16];
+                bool wb = (row % bias_period) == 0;   // derivative rows (analytic marginalisation) carry no bias
+                if (n0 + r16 < N_valid) C[(size_t)row * ldc + n0 + r16] = wb ? s0 + bias[n0 + r16] : s0;
+                if (n0 + 16 + r16 < N_valid) C[(size_t)row * ldc + n0 + 16 + r16] = wb ? s1 + bias[n0 + 16 + r16] : s1;
             }
         }
     }
 }
 
 void dl_launch_window_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* C, int64_t ldc, int64_t M, int N_valid, int N_pad,
-                           int K_pad, hipStream_t stream) {
+                           int K_pad, int bias_period, hipStream_t stream) {
     dim3 grid((unsigned)((M + 15) / 16), (unsigned)(N_pad / 32));
-    hipLaunchKernelGGL(dl_window_gemm_kernel, grid, dim3(64 * DL_GEMM_WAVES), 0, stream, A, lda, Wt, ldw, bias, C, ldc, (int)M, N_valid, K_pad);
+    hipLaunchKernelGGL(dl_window_gemm_kernel, grid, dim3(64 * DL_GEMM_WAVES), 0, stream, A, lda, Wt, ldw, bias, C, ldc, (int)M, N_valid, K_pad, bias_period);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,4 +237,168 @@ __global__ __launch_bounds__(256) void dl_finalize_kernel(const double* __restri
 void dl_launch_finalize(const double* dtilde, int64_t ld, int n, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
                         int32_t* status, hipStream_t stream) {
     hipLaunchKernelGGL(dl_finalize_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, theta, n_params, priors, B, loglike, logprior, status);
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize with analytic marginalisation / best fit of n_s linear parameters (likelihoods/base.py:129-200, 314-413),
+// one wavefront per point.  In whitened variables (dt = L^T Delta, Tt_s = L^T dDelta/dx_s):
+//   H_L = -Tt Tt^T, g_L = -Tt dt, H = H_L - diag(prec), g = g_L - (x0 - loc) prec, dx = -H^-1 g,
+//   loglike = -1/2 |dt|^2 + 1/2 dx H_L dx + g_L dx - 1/2 logdet(-H[marg, marg]),  logprior += sum -1/2 (x0 + dx - loc)^2 prec.
+// Tt_s = tconst[s] (+ row 1 + var_slot[s] of the point when the derivative depends on the point).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __restrict__ dtilde, int64_t ld, int n, int rows_per_point, DlMargDev mg,
+                                                               const double* __restrict__ theta, int n_params, const double* __restrict__ priors, int64_t B,
+                                                               double* __restrict__ loglike, double* __restrict__ logprior, int32_t* __restrict__ status,
+                                                               double* __restrict__ solved) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int ns = mg.n_s;
+    const double* row0 = dtilde + (size_t)b * rows_per_point * ld;
+    // per-lane slices of dt and of every Tt_s (n <= 64 * DL_MARG_NJ)
+    double dj[DL_MARG_NJ];
+    double chi2 = 0.;
+#pragma unroll
+    for (int q = 0; q < DL_MARG_NJ; ++q) {
+        int j = lane + 64 * q;
+        dj[q] = (j < n) ? row0[j] : 0.;
+        chi2 = fma(dj[q], dj[q], chi2);
+    }
+    chi2 = dl_wave_sum(chi2);
+    double HL[DL_MAX_SOLVED * (DL_MAX_SOLVED + 1) / 2];   // lower triangle of -H_L = Tt Tt^T (lane-uniform after the reductions)
+    double gL[DL_MAX_SOLVED];                              // Tt dt = -g_L
+    for (int s = 0; s < ns; ++s) {
+        double ts[DL_MARG_NJ];
+#pragma unroll
+        for (int q = 0; q < DL_MARG_NJ; ++q) {
+            int j = lane + 64 * q;
+            double v = 0.;
+            if (j < n) {
+                v = mg.tconst[(size_t)s * ld + j];
+                if (mg.var_slot[s] >= 0) v += row0[(size_t)(1 + mg.var_slot[s]) * ld + j];
+            }
+            ts[q] = v;
+        }
+        double acc = 0.;
+#pragma unroll
+        for (int q = 0; q < DL_MARG_NJ; ++q) acc = fma(ts[q], dj[q], acc);
+        gL[s] = dl_wave_sum(acc);
+        for (int t = 0; t <= s; ++t) {
+            double a2 = 0.;
+#pragma unroll
+            for (int q = 0; q < DL_MARG_NJ; ++q) {
+                int j = lane + 64 * q;
+                double v = 0.;
+                if (j < n) {
+                    v = mg.tconst[(size_t)t * ld + j];
+                    if (mg.var_slot[t] >= 0) v += row0[(size_t)(1 + mg.var_slot[t]) * ld + j];
+                }
+                a2 = fma(ts[q], v, a2);
+            }
+            HL[s * (s + 1) / 2 + t] = dl_wave_sum(a2);
+        }
+    }
+    // priors of the sampled parameters
+    double lp = 0.;
+    int nan_in = 0;
+    const double inf = __builtin_huge_val();
+    for (int p = lane; p < n_params; p += 64) {
+        double x = theta[(size_t)b * n_params + p];
+        const double* pr = priors + 5 * p;
+        if (x != x) nan_in = 1;
+        bool isin = (pr[1] <= x) && (x <= pr[2]);
+        double v = 0.;
+        if (pr[0] == 1.) { double t = x - pr[3]; v = -0.5 * (t * t) / (pr[4] * pr[4]); }
+        lp += isin ? v : -inf;
+    }
+    lp = dl_wave_sum(lp);
+    nan_in = __any(nan_in);
+    if (lane == 0) {
+        // A = -H = Tt Tt^T + diag(prec) (SPD); rhs = g = -(Tt dt) - (x0 - loc) prec; dx = A^-1 g
+        double A[DL_MAX_SOLVED][DL_MAX_SOLVED], g[DL_MAX_SOLVED], dx[DL_MAX_SOLVED];
+        for (int s = 0; s < ns; ++s) {
+            for (int t = 0; t <= s; ++t) A[s][t] = A[t][s] = HL[s * (s + 1) / 2 + t];
+            A[s][s] += mg.prec[s];
+            g[s] = -gL[s] - (mg.x0[s] - mg.loc[s]) * mg.prec[s];
+        }
+        bool ok = true;
+        double logdet_all = 0.;
+        // Cholesky A = C C^T (in place, lower)
+        for (int j = 0; j < ns; ++j) {
+            double d = A[j][j];
+            for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+            if (!(d > 0.)) { ok = false; d = 1.; }
+            d = sqrt(d);
+            A[j][j] = d;
+            logdet_all += 2. * log(d);
+            for (int i = j + 1; i < ns; ++i) {
+                double sum = A[i][j];
+                for (int k = 0; k < j; ++k) sum -= A[i][k] * A[j][k];
+                A[i][j] = sum / d;
+            }
+        }
+        for (int i = 0; i < ns; ++i) {   // forward, backward substitution
+            double sum = g[i];
+            for (int k = 0; k < i; ++k) sum -= A[i][k] * dx[k];
+            dx[i] = sum / A[i][i];
+        }
+        for (int i = ns - 1; i >= 0; --i) {
+            double sum = dx[i];
+            for (int k = i + 1; k < ns; ++k) sum -= A[k][i] * dx[k];
+            dx[i] = sum / A[i][i];
+        }
+        // 1/2 dx H_L dx + g_L dx  (likelihoods/base.py:385-386), H_L = -HL, g_L = -gL
+        double quad = 0., lin = 0., lps = 0.;
+        for (int s = 0; s < ns; ++s) {
+            double rowsum = 0.;
+            for (int t = 0; t < ns; ++t) rowsum += HL[(s >= t) ? s * (s + 1) / 2 + t : t * (t + 1) / 2 + s] * dx[t];
+            quad += dx[s] * rowsum;
+            lin += gL[s] * dx[s];
+            double xs = mg.x0[s] + dx[s];
+            lps += -0.5 * (xs - mg.loc[s]) * (xs - mg.loc[s]) * mg.prec[s];   // 363-364 with parameter.py:2007 (0 for flat priors: prec = 0)
+            if (solved) solved[(size_t)b * ns + s] = xs;
+        }
+        double ll = -0.5 * chi2 - 0.5 * quad - lin;
+        // -1/2 logdet(-H[marg, marg]) (394-404); all-marg: reuse the Cholesky above, else factor the sub-block
+        if (mg.n_marg == ns) ll -= 0.5 * logdet_all;
+        else if (mg.n_marg > 0) {
+            double S[DL_MAX_SOLVED][DL_MAX_SOLVED];
+            int idx[DL_MAX_SOLVED], nm = 0;
+            for (int s = 0; s < ns; ++s) if (mg.is_marg[s]) idx[nm++] = s;
+            for (int a = 0; a < nm; ++a)
+                for (int c = 0; c <= a; ++c) {
+                    int s = idx[a], t = idx[c];
+                    S[a][c] = HL[(s >= t) ? s * (s + 1) / 2 + t : t * (t + 1) / 2 + s] + (a == c ? mg.prec[s] : 0.);
+                }
+            double ld2 = 0.;
+            for (int j = 0; j < nm; ++j) {
+                double d = S[j][j];
+                for (int k = 0; k < j; ++k) d -= S[j][k] * S[j][k];
+                if (!(d > 0.)) { ok = false; d = 1.; }
+                d = sqrt(d);
+                S[j][j] = d;
+                ld2 += 2. * log(d);
+                for (int i = j + 1; i < nm; ++i) {
+                    double sum = S[i][j];
+                    for (int k = 0; k < j; ++k) sum -= S[i][k] * S[j][k];
+                    S[i][j] = sum / d;
+                }
+            }
+            ll -= 0.5 * ld2;
+        }
+        double lptot = lp + lps;
+        int st = DL_ST_OK;
+        if (nan_in) st = DL_ST_NAN_INPUT;
+        else if (lp == -inf) st = DL_ST_OUT_OF_PRIOR;
+        else if (!ok || !(ll == ll) || ll == inf || ll == -inf) st = DL_ST_NONFINITE;
+        if (loglike) loglike[b] = ll;
+        if (logprior) logprior[b] = lptot;
+        if (status) status[b] = st;
+    }
+}
+
+void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, const DlMargDev& mg, const double* theta, int n_params, const double* priors,
+                             int64_t B, double* loglike, double* logprior, int32_t* status, double* solved, hipStream_t stream) {
+    hipLaunchKernelGGL(dl_finalize_marg_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, mg, theta, n_params, priors, B, loglike,
+                       logprior, status, solved);
 }

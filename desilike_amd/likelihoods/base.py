@@ -35,6 +35,11 @@ class BaseLikelihood(BaseCalculator):
         """Sampled parameters: varied, not derived, not solved (base.py:1273-1281)."""
         return ParameterCollection([param for param in self.all_params if param.varied and not param.solved and param.derived is False])
 
+    @property
+    def solved_params(self):
+        """Parameters solved analytically ('.marg', '.best', '.auto'): likelihoods/base.py:262-271."""
+        return ParameterCollection([param for param in self.all_params if param.solved])
+
     # ---- evaluation -------------------------------------------------------------------------------
     def __call__(self, *args, return_derived=False, **kwargs):
         """``likelihood(**params)`` or ``likelihood(dict)`` -> loglikelihood + logprior (base.py:1194-1196, likelihoods/base.py:242-245)."""
@@ -192,6 +197,8 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         """Nested likelihood spec flattened by ``_lib.fill_config`` into the C-ABI config keys (include/desilike_amd.h)."""
         varied = self.varied_params
         names = varied.names()
+        solved = self.solved_params
+        solved_names = solved.names()
         observables = []
         for obs, flatdata in zip(self.observables, flatdata_list):
             theory = obs.wmatrix.theory
@@ -218,9 +225,38 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
                 else:
                     inputs[iname] = resolve(pname, defaults[iname])
             spec['inputs'] = inputs
+            if solved_names:
+                # analytically solved parameters must enter the theory linearly: shot-noise like and counter terms (full_shape.py:545-550, 628-634)
+                imap = theory._input_map()
+
+                def sindex(pname):
+                    return solved_names.index(pname) if pname in solved_names else -1
+
+                marg = {'sn0': [sindex(imap['sn0'])]}
+                if 'sn' in imap and imap['sn']: marg['sn'] = [sindex(pn) for pn in imap['sn']]
+                if 'ct' in imap and imap['ct']: marg['ct'] = [[sindex(pn) for pn in pair] for pair in imap['ct']]
+                linear = {imap['sn0']} | set(imap.get('sn', [])) | {pn for pair in imap.get('ct', []) for pn in pair}
+                for iname, pname in imap.items():
+                    if iname not in ('sn0', 'sn', 'ct') and pname in solved_names:
+                        raise PipelineError('parameter {} cannot be solved analytically: the theory is not linear in it'.format(pname))
+                spec['marg'] = marg
             observables.append(spec)
         priors = np.array([param.prior.spec() for param in varied], dtype='f8').reshape(len(names), 5)
-        return dict(n_params=np.array([len(names)], dtype='i4'), priors=priors, precision=precision, observables=observables)
+        spec = dict(n_params=np.array([len(names)], dtype='i4'), priors=priors, precision=precision, observables=observables)
+        if solved_names:
+            kind, mprior, x0 = [], [], []
+            for param in solved:
+                derived = param.derived
+                if derived.startswith('.prec'):
+                    raise NotImplementedError("'.prec' (one-off precision marginalisation) is not implemented: use '.marg'")
+                if derived.startswith('.auto'):
+                    derived = derived.replace('.auto', self.solved_default)                     # likelihoods/base.py:336-337
+                kind.append(1 if derived.startswith('.marg') else 0)
+                loc, scale = (param.prior.loc, param.prior.scale) if param.prior.dist == 'norm' else (0., np.inf)   # likelihoods/base.py:180-181
+                mprior.append([loc, scale**(-2)])
+                x0.append(float(fixed_values.get(param.name, param.value)))                  # likelihoods/base.py:355
+            spec['marg'] = dict(kind=np.array(kind, dtype='i4'), prior=np.array(mprior, dtype='f8'), x0=np.array(x0, dtype='f8'))
+        return spec
 
     def _get_context(self, fixed_values=None):
         from .._lib import Context
@@ -283,7 +319,7 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         self.initialize()
         theta, fixed = self._split_params(flat)
         ctx = self._get_context(fixed)
-        out = ctx.eval_batch_host(theta, return_flattheory=return_flattheory)
+        out = ctx.eval_batch_host(theta, return_flattheory=return_flattheory, return_solved=ctx.n_solved > 0)
         loglike, logprior, status = out[:3]
         if return_flattheory:
             self.flattheory = out[3].reshape(shape + (ctx.n_data,))
@@ -299,6 +335,9 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             derived = Samples()
             derived[self._param_loglikelihood] = loglike.reshape(shape)
             derived[self._param_logprior] = logprior.reshape(shape)
+            if ctx.n_solved:   # solution of the analytically solved parameters (likelihoods/base.py:361-368)
+                for param, column in zip(self.solved_params, out[-1].T):
+                    derived[param] = column.reshape(shape)
             return (logposterior, derived), errs
         return logposterior, errs
 

@@ -83,7 +83,10 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
  *   obs<i>.kmask    i32[n_out]      row selection applied after the matrix / identity
  *   obs<i>.offset   f64[n_out_before_mask], obs<i>.shotnoise_in f64[n_ell], obs<i>.shotnoise_out f64[n_out]
  *   obs<i>.flatdata f64[n_out]
- *   marg.*          analytic marginalisation spec
+ *   marg.kind       i32[n_s]    analytically solved linear parameters (likelihoods/base.py:314-413): 1 = marginalised ('.marg'), 0 = best fit ('.best')
+ *   marg.prior      f64[n_s*2]  (loc, 1 / scale^2) of their Gaussian priors (0 precision = flat prior)
+ *   marg.x0         f64[n_s]    values at which the theory is evaluated (the parameters' default values, likelihoods/base.py:355)
+ *   obs<i>.marg.sn0 i32[1], obs<i>.marg.sn i32[n_sn], obs<i>.marg.ct i32[n_ct*2]: index of the solved parameter each linear input feeds, or -1
  */
 dl_config* dl_config_new(void);
 int  dl_config_set_f64(dl_config* cfg, const char* key, const double* data, int64_t n);
@@ -102,10 +105,11 @@ int64_t dl_info(const dl_ctx* ctx, const char* key);
 
 /* ---- evaluation ------------------------------------------------------------------------------*/
 /* theta_dev [B, P] row-major.  Outputs (any may be NULL): loglike_dev[B], logprior_dev[B],
- * flattheory_dev[B, n_data], status_dev[B].  Asynchronous on ``hip_stream``. */
+ * flattheory_dev[B, n_data] (theory at the default values of the solved parameters), status_dev[B],
+ * solved_dev[B, n_solved] (solution of the analytically solved parameters).  Asynchronous on ``hip_stream``. */
 int  dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B,
                    double* loglike_dev, double* logprior_dev, double* flattheory_dev,
-                   int32_t* status_dev, void* hip_stream);
+                   int32_t* status_dev, double* solved_dev, void* hip_stream);
 
 /* Theory state of observable ``iobs`` for parity / plots / emulation:
  * power_dev [B, n_ell, n_kin] and (optional) tables_dev [B, 3, n_ell, n_kin] = pk_dd, pk_dt, pk_tt. */
@@ -115,7 +119,7 @@ int  dl_eval_theory(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iob
 /* Host-pointer conveniences (copy in, evaluate on the default stream, copy out, synchronise):
  * used by the scalar ``likelihood(**params)`` call surface (desilike/base.py:1194-1196). */
 int  dl_eval_batch_host(dl_ctx* ctx, const double* theta, int64_t B,
-                        double* loglike, double* logprior, double* flattheory, int32_t* status);
+                        double* loglike, double* logprior, double* flattheory, int32_t* status, double* solved);
 int  dl_eval_theory_host(dl_ctx* ctx, const double* theta, int64_t B, int32_t iobs,
                          double* power, double* tables);
 

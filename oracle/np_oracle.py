@@ -277,3 +277,54 @@ def fullshape_observable(c, p):
     out['flatpower'] = flat
     out['flattheory'] = observable_transform(flat, c['flatdata'], c.get('transform', None))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# a10: analytic marginalisation / best-fit of linear nuisance parameters
+#      likelihoods/base.py:129-200 (FastFisher.__call__), 314-413 (BaseLikelihood._solve)
+# PARITY UNPINNED by the reference itself: the reference needs jax (likelihoods/base.py:130) which is absent here, and its
+# tests only run/plot (samplers/tests/test_base.py:380-408).  Pinned instead by (i) the Gaussian-integral identity against
+# the reference's own NON-marginalised likelihood evaluated on a grid of the solved parameter (golden fixture
+# tests/golden/marg_sn0_grid.npz) and (ii) closed forms, in tests/test_oracle_marg.py.
+# ----------------------------------------------------------------------------------------------
+def solve_marginalized(flatdiff, flatderiv, precision, x0, prior_loc, prior_scale, marg_mask):
+    """One parameter point.
+
+    flatdiff: Delta = theory(x0) - data [n]; flatderiv: T = dDelta/dx [n_s, n] (rows = solved parameters, as
+    likelihoods/base.py:162); precision [n, n] or [n]; x0: values at which Delta was evaluated (likelihoods/base.py:355);
+    prior_loc / prior_scale: Gaussian prior of each solved parameter (scale = inf for flat priors, likelihoods/base.py:180-183);
+    marg_mask: True where the parameter is marginalised ('.marg'), False where it is set to its best fit ('.best').
+    Returns dict(loglikelihood, logprior_solved, x, dx, posterior_hessian, likelihood_hessian, likelihood_gradient).
+    """
+    flatdiff, flatderiv = np.asarray(flatdiff, dtype='f8'), np.atleast_2d(np.asarray(flatderiv, dtype='f8'))
+    x0, prior_loc, prior_scale = (np.asarray(a, dtype='f8') for a in (x0, prior_loc, prior_scale))
+    derivp = flatderiv * precision if precision.ndim == 1 else flatderiv.dot(precision)   # 169-172
+    likelihood_gradient = -derivp.dot(flatdiff.T)                                          # 173
+    likelihood_hessian = -derivp.dot(flatderiv.T)                                          # 174
+    prec = prior_scale**(-2)                                                               # 181
+    prior_gradient = -(x0 - prior_loc) * prec                                              # 182
+    prior_hessian = np.diag(-prec)                                                         # 183-185
+    posterior_gradient = prior_gradient + likelihood_gradient
+    posterior_hessian = prior_hessian + likelihood_hessian
+    dx = -np.linalg.solve(posterior_hessian, posterior_gradient)                           # 188
+    x = x0 + dx                                                                            # 189
+    loglikelihood = -0.5 * chi2(flatdiff, precision)
+    loglikelihood += 0.5 * dx.dot(likelihood_hessian).dot(dx) + likelihood_gradient.dot(dx)   # 385-386
+    # prior of the solved parameters at their solution, zero-lag removed (363-364, parameter.py:2003-2010)
+    logprior = np.sum(np.where(np.isinf(prior_scale), 0., -0.5 * (x - prior_loc)**2 * prec))
+    marg_mask = np.asarray(marg_mask, dtype='?')
+    if marg_mask.any():                                                                    # 394-404: no (2 pi)^(n/2)
+        loglikelihood += -0.5 * np.linalg.slogdet(-posterior_hessian[np.ix_(marg_mask, marg_mask)])[1]
+    return dict(loglikelihood=loglikelihood, logprior_solved=logprior, x=x, dx=dx, posterior_hessian=posterior_hessian,
+                likelihood_hessian=likelihood_hessian, likelihood_gradient=likelihood_gradient)
+
+
+def marginalize_precision(precision, flatderiv, prior_scale):
+    """'.prec' solved parameters: one-off precision marginalisation, likelihoods/base.py:280-309:
+    P <- P - P T^T (-H)^-1 T P with H the posterior Hessian (T: [n_s, n])."""
+    precision = np.asarray(precision, dtype='f8')
+    flatderiv = np.atleast_2d(flatderiv)
+    derivp = flatderiv * precision if precision.ndim == 1 else flatderiv.dot(precision)
+    posterior_hessian = -derivp.dot(flatderiv.T) - np.diag(np.asarray(prior_scale, dtype='f8')**(-2))
+    full = np.diag(precision) if precision.ndim == 1 else precision
+    return full - derivp.T.dot(np.linalg.solve(-posterior_hessian, derivp))

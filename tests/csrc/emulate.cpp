@@ -40,7 +40,7 @@ static void run_point(const DlObsDev& o, const double* th, double* prow, double*
         else if (!eft) dl_fs_phase3<true, 5, false>(tid, nthr, o, s, trow);
         else dl_fs_phase3<true, 5, true>(tid, nthr, o, s, trow);
     }
-    for (int tid = 0; tid < nthr; ++tid) dl_fs_phase4(tid, nthr, o, s, prow);
+    for (int tid = 0; tid < nthr; ++tid) dl_fs_phase4(tid, nthr, o, s, prow, o.n_in);
 }
 
 // power [B, n_in], tables [B, 3, n_in] (may be null)

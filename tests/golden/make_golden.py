@@ -222,8 +222,47 @@ def cfg2_variants():
          priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]), **out)
 
 
+
+
+def marg_grid():
+    """Pin for analytic marginalisation (the reference's own implementation needs jax: not runnable here).
+
+    The reference's NON-marginalised likelihood + prior is evaluated on a fine grid of the linear parameter sn0
+    (all other parameters fixed at a few points): the Gaussian integral over sn0 must equal the analytically
+    marginalised posterior up to the (2 pi)^(1/2) the reference drops (likelihoods/base.py:396-401).
+    Also stores d(flattheory)/d(sn0) by finite difference of the reference (exactly linear in sn0)."""
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    theory = KaiserTracerPowerSpectrumMultipoles(template=template)
+    theory.init.params['sn0'].update(prior=dict(dist='norm', loc=0.2, scale=1.5))
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'sn0': 0.4}, kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=1e4)
+    cov = spd_covariance(120, seed=1)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+    like()
+    names = like.varied_params.names()
+    theta = sample_theta(like, 6, seed=11)
+    isn0 = names.index('sn0')
+    grid = np.linspace(-4., 4.8, 881)
+    logpost = np.empty((len(theta), grid.size))
+    flat0, flat1 = [], []
+    for ip, row in enumerate(theta):
+        for ig, sn0 in enumerate(grid):
+            row2 = row.copy(); row2[isn0] = sn0
+            logpost[ip, ig] = like(**dict(zip(names, row2)))
+        row2 = row.copy(); row2[isn0] = 0.
+        like(**dict(zip(names, row2))); flat0.append(np.asarray(like.flattheory).copy())
+        row2[isn0] = 1.
+        like(**dict(zip(names, row2))); flat1.append(np.asarray(like.flattheory).copy())
+    # logprior of the non-solved parameters only (to compare with the marginalised likelihood's own logprior)
+    logprior_others = np.array([like.all_params.prior(**{name: value for name, value in zip(names, row) if name != 'sn0'}) for row in theta])
+    save('marg_sn0_grid', names=np.array(names), theta=theta, grid=grid, logposterior_grid=logpost, flattheory_sn0_0=np.array(flat0), flattheory_sn0_1=np.array(flat1),
+         logprior_others=logprior_others, sn0_prior=np.array([0.2, 1.5]), obs0=extract_observable(obs), precision=np.asarray(like.precision), covariance=cov,
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]))
+
+
 if __name__ == '__main__':
-    cfg1()
-    cfg2(dense=False)
-    cfg2(dense=True)
-    cfg2_variants()
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid']
+    if 'cfg1' in todo: cfg1()
+    if 'cfg2' in todo: cfg2(dense=False)
+    if 'cfg2_dense' in todo: cfg2(dense=True)
+    if 'cfg2_variants' in todo: cfg2_variants()
+    if 'marg_grid' in todo: marg_grid()

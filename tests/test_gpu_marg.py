@@ -1,0 +1,86 @@
+"""GPU (-m gpu): analytic marginalisation / best fit of linear nuisance parameters on the HIP path (dl_finalize_marg_kernel)
+against (i) the reference's own non-marginalised posterior on a grid (fixture from the reference) and (ii) the NumPy oracle
+restatement of likelihoods/base.py:129-200, 314-413 on seeded inputs, including point-dependent derivative columns (counter terms)."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as orc
+from golden_utils import load_golden, observable_constants
+from test_oracle_marg import reference_parabola
+
+pytestmark = pytest.mark.gpu
+
+
+def make_marg_likelihood(g, solved='.marg'):
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    theory = KaiserTracerPowerSpectrumMultipoles(template=template)
+    theory.init.params['sn0'].update(prior=dict(dist='norm', loc=0.2, scale=1.5), derived=solved)
+    obs = TracerPowerSpectrumMultipolesObservable(data=g['obs0']['flatdata'], kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=1e4)
+    return ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
+
+
+@pytest.mark.parametrize('solved', ['.marg', '.best', '.auto'])
+def test_sn0_marginalisation_vs_reference_grid(solved):
+    from desilike_amd import vmap
+    g = load_golden('marg_sn0_grid')
+    like = make_marg_likelihood(g, solved=solved)
+    names = [str(n) for n in g['names']]
+    assert like.varied_params.names() == [name for name in names if name != 'sn0'] and like.solved_params.names() == ['sn0']
+    theta = {name: g['theta'][:, i] for i, name in enumerate(names) if name != 'sn0'}
+    (logpost, derived), errors = vmap(like, errors='return', return_derived=True)(theta)
+    assert errors == {}
+    for ip in range(len(g['theta'])):
+        a, smax, cmax, resid = reference_parabola(g, ip)
+        expected = cmax - (0.5 * np.log(a) if solved != '.best' else 0.)
+        assert abs(logpost[ip] - expected) < 1e-6 * max(1., abs(expected)), (ip, logpost[ip], expected)
+        assert np.isclose(derived['sn0'][ip], smax, rtol=1e-6, atol=1e-8)
+
+
+def test_marg_vs_oracle_with_counterterms():
+    """EFT-like Kaiser: ct (point-dependent derivative) and sn terms solved; two of them marginalised, one at best fit, flat and Gaussian priors."""
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, EFTLikeKaiserTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    g = load_golden('cfg2_shapefit_window_dense')
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    theory = EFTLikeKaiserTracerPowerSpectrumMultipoles(template=template)
+    theory.init.params['ct0_2'].update(derived='.marg', prior=dict(dist='norm', loc=0., scale=30.))
+    theory.init.params['ct2_2'].update(derived='.best', prior=dict(dist='norm', loc=1., scale=50.))
+    theory.init.params['sn0_2'].update(derived='.marg', prior=dict(dist='uniform'))
+    for name in ['ct4_2', 'sn2_2', 'sn4_2']:
+        theory.init.params[name].update(fixed=True, value=0.)
+    obs = TracerPowerSpectrumMultipolesObservable(data=g['obs0']['flatdata'], kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix=g['obs0']['matrix_full'], kin=g['obs0']['kin'],
+                                                  ellsin=(0, 2, 4), theory=theory, shotnoise=1e4)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
+    names = like.varied_params.names()
+    assert like.solved_params.names() == ['ct0_2', 'ct2_2', 'sn0_2']
+    rng = np.random.RandomState(5)
+    theta = np.column_stack([param.ref.sample(size=33, random_state=rng) for param in like.varied_params])
+    ctx = like._get_context()
+    loglike, logprior, status, solved = ctx.eval_batch_host(theta, return_solved=True)
+    assert (status == 0).all()
+    # oracle: theory at x0 and derivative columns by unit steps of the (exactly linear) solved parameters
+    c = observable_constants(g)
+    theory.initialize()
+    c.update(ct_matrix=theory.counterterm_matrix, sn_matrix=theory.stochastic_matrix)
+    ctn, snn = theory.counterterm_params, theory.stochastic_params
+    x0 = np.array([param.value for param in like.solved_params])
+
+    def flat(row, x):
+        p = dict(zip(names, row)); p['b1'] = (p['b1'], p['b1'])
+        vals = dict(zip(['ct0_2', 'ct2_2', 'sn0_2'], x))
+        p['ct'] = [2. * vals.get(n, 0.) for n in ctn]
+        p['sn'] = [vals.get(n, p.get(n, 0.)) if n != 'sn0' else p['sn0'] for n in snn]
+        return orc.fullshape_observable(c, p)['flattheory']
+
+    for i, row in enumerate(theta):
+        f0 = flat(row, x0)
+        T = np.array([flat(row, x0 + np.eye(3)[s]) - f0 for s in range(3)])
+        sol = orc.solve_marginalized(f0 - c['flatdata'], T, like.precision, x0=x0, prior_loc=[0., 1., 0.], prior_scale=[30., 50., np.inf], marg_mask=[True, False, True])
+        assert abs(loglike[i] - sol['loglikelihood']) <= 1e-9 * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
+        assert np.allclose(solved[i], sol['x'], rtol=1e-8, atol=1e-10)
+        lp_ref = orc.logprior(row, [dict(dist=['uniform', 'norm'][int(pr[0])], limits=(pr[1], pr[2]), loc=pr[3], scale=pr[4]) for pr in [p.prior.spec() for p in like.varied_params]]) + sol['logprior_solved']
+        assert np.isclose(logprior[i], lp_ref, rtol=1e-10, atol=1e-10)
