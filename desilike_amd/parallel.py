@@ -1,0 +1,69 @@
+"""Walker / parameter-point sharding across the GPUs of a node.
+
+The reference's only parallelism is data-parallel over points (``vmap(..., backend='mpi')`` desilike/base.py:291-378:
+``Scatterv`` of the points, local loop, gather; ``mpi.local_size`` desilike/mpi.py:145-149).  Here: one process per GPU,
+rank r evaluates the contiguous slice ``[r B // G, (r + 1) B // G)`` and the only exchange is ONE all-gather of the per-point
+results (log-posteriors: B / G doubles per rank) through ``torch.distributed`` -- backend "nccl" (= RCCL over xGMI) on GPUs,
+"gloo" in the CPU tests.  Payloads are kilobytes: the exchange is latency-bound, so it is never split or bucketed.
+"""
+import numpy as np
+
+
+def local_slice(size, rank, world):
+    """Contiguous share of ``size`` items for ``rank`` out of ``world`` (same rule as desilike/mpi.py:145-149)."""
+    return slice(rank * size // world, (rank + 1) * size // world)
+
+
+class WalkerSharding(object):
+    """Evaluate a batch function on the local share of the rows and all-gather the results on every rank."""
+
+    def __init__(self, group=None, device=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.device = device
+
+    def slice(self, size):
+        return local_slice(size, self.rank, self.world)
+
+    def allgather_rows(self, local, size):
+        """``local``: array / tensor with the rows of this rank's slice of ``size`` rows -> all ``size`` rows, on every rank."""
+        import torch
+        if not self.active or self.world == 1:
+            return local
+        is_numpy = isinstance(local, np.ndarray)
+        tensor = torch.as_tensor(local) if is_numpy else local
+        if self.device is not None:
+            tensor = tensor.to(self.device)
+        counts = [local_slice(size, rank, self.world) for rank in range(self.world)]
+        counts = [sl.stop - sl.start for sl in counts]
+        nmax = max(counts)
+        trailing = tuple(tensor.shape[1:])
+        padded = torch.zeros((nmax,) + trailing, dtype=tensor.dtype, device=tensor.device)
+        padded[:tensor.shape[0]] = tensor
+        gathered = torch.empty((self.world * nmax,) + trailing, dtype=tensor.dtype, device=tensor.device)
+        self.dist.all_gather_into_tensor(gathered, padded, group=self.group)   # the single collective of the path
+        gathered = gathered.reshape((self.world, nmax) + trailing)
+        out = torch.cat([gathered[rank, :count] for rank, count in enumerate(counts)], dim=0)
+        return out.cpu().numpy() if is_numpy else out
+
+    def map(self, func, values):
+        """``func(values_local) -> array[len(values_local), ...]`` applied to this rank's slice; returns the full result everywhere."""
+        values = np.asarray(values)
+        sl = self.slice(len(values))
+        local = np.asarray(func(values[sl]))
+        return self.allgather_rows(np.ascontiguousarray(local), len(values))
+
+    def broadcast(self, array, src=0):
+        """Broadcast a numpy array from ``src`` (walker positions must be identical on all ranks: samplers/base.py:45-54)."""
+        import torch
+        if not self.active or self.world == 1:
+            return array
+        tensor = torch.as_tensor(np.ascontiguousarray(array))
+        if self.device is not None:
+            tensor = tensor.to(self.device)
+        self.dist.broadcast(tensor, src=src, group=self.group)
+        return tensor.cpu().numpy()

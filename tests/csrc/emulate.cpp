@@ -75,7 +75,7 @@ int emu_eval_batch(const dl_config* cfg, const double* theta, int64_t B, double*
     else for (int i = 0; i < n; ++i) L[(size_t)i * n + i] = std::sqrt(prec[i]);
     std::vector<double> power(K), flat(n);
     for (int64_t b = 0; b < B; ++b) {
-        for (int i = 0; i < nobs; ++i) run_point(obs[i].dev, theta + b * P, power.data(), nullptr);
+        for (int i = 0; i < nobs; ++i) run_point(obs[i].dev, theta + b * P, power.data() + col0[i], nullptr);
         for (int i = 0; i < nobs; ++i)
             for (int r = 0; r < obs[i].n_out; ++r) {
                 double sum = 0.;

@@ -102,6 +102,7 @@ def run_batch(likelihood, observables, theta, names, nint=8):
     nobs = len(observables)
     for name, value in inter.items():
         value = np.array(value)
+        if nint == 0: continue
         if name != 'flatdiff':
             value = value.reshape((min(nint, len(theta)), nobs) + value.shape[1:])
         out['int_' + name] = value
@@ -259,10 +260,34 @@ def marg_grid():
          priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]))
 
 
+def cfg5():
+    """BASELINE config 5 (one walker batch): two tracers, one ObservablesGaussianLikelihood with a joint covariance, shared ShapeFit template,
+    per-tracer b1 / sn0 namespaces (full_shape.py:59-133; likelihoods/base.py:567, 662-664)."""
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    observables = []
+    for tracer, b1, kmax in [('LRG', 2., 0.2), ('ELG', 1.3, 0.15)]:
+        theory = KaiserTracerPowerSpectrumMultipoles(template=template, tracers=tracer)
+        nk = int(round(kmax / 0.005))
+        observables.append(TracerPowerSpectrumMultipolesObservable(data={tracer + '.b1': b1}, kedges=np.linspace(0., kmax, nk + 1), ells=(0, 2, 4), wmatrix={'resolution': 4},
+                                                                   theory=theory, shotnoise=1e4 if tracer == 'LRG' else 4e3))
+    sizes = [3 * 40, 3 * 30]
+    cov = spd_covariance(sum(sizes), seed=5)
+    like = ObservablesGaussianLikelihood(observables=observables, covariance=cov)
+    like()
+    names = like.varied_params.names()
+    theta = sample_theta(like, 32, seed=21)
+    out = run_batch(like, observables, theta, names, nint=0)
+    obs = {'obs{:d}'.format(i): {**extract_observable(o), 'tracer': ['LRG', 'ELG'][i]} for i, o in enumerate(observables)}
+    save('cfg5_two_tracers', names=np.array(names), theta=theta, precision=np.asarray(like.precision), covariance=cov,
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]),
+         **obs, **{k: v for k, v in out.items() if not k.startswith('int_')})
+
+
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
     if 'cfg2_variants' in todo: cfg2_variants()
     if 'marg_grid' in todo: marg_grid()
+    if 'cfg5' in todo: cfg5()

@@ -44,7 +44,10 @@ def spec_from_golden(g):
     while 'obs{:d}'.format(iobs) in g:
         c = g['obs{:d}'.format(iobs)]
 
+        tracer = str(c.get('tracer', ''))
+
         def inp(name, default):
+            if name in ('b1', 'sn0') and tracer: name = tracer + '.' + name
             return (names.index(name), default) if name in names else (-1, default)
 
         inputs = {'qpar': inp('qpar', 1.), 'qper': inp('qper', 1.), 'qiso': inp('qiso', 1.), 'qap': inp('qap', 1.), 'df': inp('df', 1.), 'dm': inp('dm', 0.), 'dn': inp('dn', 0.),

@@ -23,3 +23,13 @@ def test_emulated_kernel_vs_reference(name):
     assert np.allclose(flat, g['flattheory'], rtol=1e-11, atol=1e-8)
     tol = 1e-10 * np.maximum(1., np.abs(g['loglikelihood']))
     assert (np.abs(loglike - g['loglikelihood']) <= tol).all(), np.abs(loglike - g['loglikelihood']).max()
+
+
+def test_emulated_two_tracers():
+    """Two observables with a joint covariance, shared template parameters, per-tracer b1 / sn0 (config 5 geometry)."""
+    g = load_golden('cfg5_two_tracers')
+    emu = Emulation(spec_from_golden(g))
+    loglike, flat = emu.eval_batch(g['theta'])
+    assert np.allclose(flat, g['flattheory'], rtol=1e-11, atol=1e-8)
+    tol = 1e-10 * np.maximum(1., np.abs(g['loglikelihood']))
+    assert (np.abs(loglike - g['loglikelihood']) <= tol).all()

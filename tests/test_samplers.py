@@ -1,0 +1,102 @@
+"""CPU: sampler call surface and walker sharding (gloo, world_size 2) -- no GPU needed: a toy Gaussian likelihood object stands in.
+Mirrors the reference's tests/test_samplers.py:9-52 (2-D Gaussian sampled with emcee; mean / std vs analytic)."""
+import os
+
+import numpy as np
+import pytest
+
+from desilike_amd import Parameter, ParameterCollection, Samples
+
+
+class ToyGaussianLikelihood(object):
+    """Minimal object with the likelihood surface the samplers use (varied_params, _param_*, _evaluate_dict)."""
+
+    def __init__(self):
+        self.varied_params = ParameterCollection([Parameter('a', prior=dict(limits=[-5., 5.]), ref=dict(limits=[-1., 1.])),
+                                                  Parameter('b', prior=dict(dist='norm', loc=0., scale=10.), ref=dict(dist='norm', loc=0., scale=1.))])
+        self.mean, self.cov = np.array([0.5, -0.3]), np.array([[0.04, 0.01], [0.01, 0.09]])
+        self.precision = np.linalg.inv(self.cov)
+        self._param_loglikelihood, self._param_logprior = Parameter('loglikelihood', derived=True), Parameter('logprior', derived=True)
+        self.ncalls = 0
+
+    def _evaluate_dict(self, flat, shape, errors='raise', return_derived=False):
+        self.ncalls += 1
+        x = np.column_stack([flat['a'], flat['b']]) - self.mean
+        loglike = -0.5 * np.einsum('ij,jk,ik->i', x, self.precision, x)
+        loglike[flat['a'] > 4.9] = np.nan                            # a NaN region, to exercise the NaN -> -inf convention
+        logprior = sum(param.prior(flat[param.name]) for param in self.varied_params)
+        derived = Samples()
+        derived[self._param_loglikelihood], derived[self._param_logprior] = loglike.reshape(shape), logprior.reshape(shape)
+        return ((loglike + logprior).reshape(shape), derived), {}
+
+
+def test_logposterior_conventions():
+    from desilike_amd.samplers import BasePosteriorSampler
+    like = ToyGaussianLikelihood()
+    sampler = BasePosteriorSampler(like, seed=1)
+    values = np.array([[0.5, -0.3], [np.nan, 0.], [6., 0.], [4.95, 0.], [0., 0.]])
+    lp = sampler.logposterior(values)
+    assert np.isclose(lp[0], -0.5 * (0.3 / 10.)**2)          # likelihood maximum + Gaussian prior of b
+    assert np.isneginf(lp[1]) and np.isneginf(lp[2]) and np.isneginf(lp[3]) and np.isfinite(lp[4])
+    assert np.isclose(sampler.logposterior(values[0]), lp[0])   # 1-D input -> scalar
+    calls = like.ncalls
+    sampler.logposterior(np.array([[6., 0.], [-7., 1.]]))      # all rows outside the prior: the likelihood is not evaluated
+    assert like.ncalls == calls
+
+
+def test_stretch_move_recovers_gaussian():
+    from desilike_amd.samplers import EmceeSampler
+    like = ToyGaussianLikelihood()
+    sampler = EmceeSampler(like, nwalkers=20, seed=42, use_emcee=False)
+    sampler.run(niterations=400)
+    chain = sampler.run(niterations=1600)
+    assert chain['a'].shape == (2000, 20)
+    samples = np.column_stack([chain[name][500:].ravel() for name in ['a', 'b']])
+    assert np.allclose(samples.mean(axis=0), like.mean, atol=0.03)
+    assert np.allclose(samples.std(axis=0), np.diag(like.cov)**0.5, rtol=0.1)
+    assert 0.2 < sampler.acceptance_fraction.mean() < 0.9
+
+
+def test_local_slice():
+    from desilike_amd.parallel import local_slice
+    for size in [0, 1, 7, 256, 1000]:
+        for world in [1, 2, 3, 8]:
+            slices = [local_slice(size, rank, world) for rank in range(world)]
+            assert slices[0].start == 0 and slices[-1].stop == size
+            assert all(a.stop == b.start for a, b in zip(slices[:-1], slices[1:]))
+
+
+def _worker(rank, world, port, results):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from desilike_amd.samplers import EmceeSampler
+    from desilike_amd.parallel import WalkerSharding
+    like = ToyGaussianLikelihood()
+    sharding = WalkerSharding()
+    assert sharding.world == world and sharding.rank == rank
+    rng = np.random.RandomState(3)
+    values = rng.uniform(-1., 1., size=(13, 2))                  # ragged: 13 rows over 2 ranks
+    values[4, 0] = np.nan
+    sampler = EmceeSampler(like, nwalkers=12, seed=7, use_emcee=False, sharding=sharding)
+    lp = sampler.logposterior(values)
+    sampler.run(niterations=30)
+    results[rank] = (lp, like.ncalls, sampler.chain['a'][-1].copy())
+    dist.destroy_process_group()
+
+
+def test_walker_sharding_gloo_world2():
+    import torch.multiprocessing as mp
+    manager = mp.Manager()
+    results = manager.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, results), nprocs=2, join=True)
+    from desilike_amd.samplers import BasePosteriorSampler
+    single = BasePosteriorSampler(ToyGaussianLikelihood())
+    rng = np.random.RandomState(3)
+    values = rng.uniform(-1., 1., size=(13, 2))
+    values[4, 0] = np.nan
+    expected = single.logposterior(values)
+    for rank in range(2):
+        assert np.allclose(results[rank][0], expected, equal_nan=True)     # every rank holds every walker's log-posterior
+    assert np.allclose(results[0][2], results[1][2])                       # identical chains on all ranks
