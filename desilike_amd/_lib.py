@@ -47,6 +47,12 @@ def load():
     if _lib is None:
         if not os.path.isfile(_LIB_PATH):
             raise LibraryError('HIP library {} not found: build it with `python -c "import __graft_entry__ as g; g.build()"`; there is no CPU fallback'.format(_LIB_PATH))
+        try:
+            # PyTorch-ROCm wheels bundle their own libamdhip64: load it FIRST so that this library binds to the same HIP runtime
+            # (two HIP runtimes in one process do not see each other's devices: "No HIP GPUs are available")
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(_LIB_PATH)
         for name, (restype, argtypes) in SYMBOLS.items():
             func = getattr(lib, name)
