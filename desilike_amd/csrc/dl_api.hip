@@ -131,14 +131,15 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     for (int i = 0; i < ctx->n_obs; ++i) {
         if (!dl_build_obs(*cfg, i, ctx->n_params, ctx->obs[i], arena, err)) return bail("dl_create: " + err);
         ctx->obs[i].dev.col_offset = col;
-        col += ctx->obs[i].dev.n_in;
+        col += ctx->obs[i].n_cols();
         ctx->obs_row0.push_back(row);
         row += ctx->obs[i].n_out;
         ctx->max_n_t = std::max(ctx->max_n_t, ctx->obs[i].dev.n_t);
         if (ctx->obs[i].dev.transform != 0) ctx->any_transform = true;
     }
     for (auto& ob : ctx->obs)
-        if (dl_fs_shared_doubles(ob.dev.n_t, ob.dev.n_in) * sizeof(double) > 160 * 1024) return bail("dl_create: template / theory grid too large for the 160 KiB LDS");
+        if ((ob.dev.theory == 2 ? dl_bao_shared_doubles(ob.dev.n_in) : dl_fs_shared_doubles(ob.dev.n_t, ob.dev.n_in)) * sizeof(double) > 160 * 1024)
+            return bail("dl_create: template / theory grid too large for the 160 KiB LDS");
     ctx->n_data = row;
     int n = ctx->n_data;
     int K = (int)col;
@@ -168,7 +169,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
         const DlObsHost& oh = ctx->obs[i];
         for (int r = 0; r < oh.n_out; ++r) {
             int gr = ctx->obs_row0[i] + r;
-            std::memcpy(&wt_full[(size_t)gr * ctx->K_pad + oh.dev.col_offset], &oh.weff[(size_t)r * oh.dev.n_in], sizeof(double) * oh.dev.n_in);
+            std::memcpy(&wt_full[(size_t)gr * ctx->K_pad + oh.dev.col_offset], &oh.weff[(size_t)r * oh.n_cols()], sizeof(double) * oh.n_cols());
             bias_full[gr] = oh.bias[r];
             flatdata[gr] = oh.flatdata[r];
             transform[gr] = oh.dev.transform;
@@ -234,6 +235,8 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
                 double* dst = &dvec[od.col_offset];
                 if (ob.marg_sn0 == s_ && od.ell0 >= 0)
                     for (int i = 0; i < od.n_kin; ++i) dst[(size_t)od.ell0 * od.n_kin + i] += 1. / od.nd;
+                for (int c = 0; c < od.n_pass; ++c)
+                    if (ob.marg_pass[c] == s_) dst[od.n_in + c] += 1.;   // pass-through column: derivative = unit vector
                 const auto& snm = cfg->F("obs" + std::to_string(&ob - &ctx->obs[0]) + ".sn_matrix");
                 for (int c = 0; c < od.n_sn; ++c)
                     if (ob.marg_sn[c] == s_)
@@ -281,7 +284,7 @@ int64_t dl_info(const dl_ctx* ctx, const char* key) {
     if (k == "n_params") return ctx->n_params;
     if (k == "n_data") return ctx->n_data;
     if (k == "n_obs") return ctx->n_obs;
-    if (k == "n_in_total") { int64_t t = 0; for (auto& o : ctx->obs) t += o.dev.n_in; return t; }
+    if (k == "n_in_total") { int64_t t = 0; for (auto& o : ctx->obs) t += o.n_cols(); return t; }
     if (k == "K_pad") return ctx->K_pad;
     if (k == "N_pad") return ctx->N_pad;
     if (k == "n_solved") return ctx->n_solved;
@@ -373,6 +376,8 @@ int dl_eval_theory(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs
     // launch only observable iobs, writing rows of n_in doubles directly into the caller's buffers
     DlObsDev tmp = ctx->obs_kernarg[iobs];
     tmp.col_offset = 0;
+    tmp.n_pass = 0;   // rows of exactly n_in doubles
+    tmp.n_var = 0;
     dl_launch_fullshape(&tmp, 1, theta_dev, ctx->n_params, B, power_dev, tmp.n_in, tables_dev, 3 * (int64_t)tmp.n_in, stream);
     DL_HIP_CHECK(ctx, hipGetLastError());
     return 0;

@@ -38,6 +38,7 @@
 #define DL_FS_THREADS 256
 #define DL_MAX_SEG 64
 #define DL_SEG_PARTS 4      // threads cooperating on the warm-up dot product of one segment (DL_MAX_SEG * DL_SEG_PARTS = DL_FS_THREADS)
+#define DL_MAX_PASS 16     // pass-through columns: linear (broadband) parameters appended to the theory vector
 #define DL_MAX_SOLVED 16   // analytically solved (marginalised / best-fit) linear parameters
 #define DL_SEG_QMAX 12     // dot-product terms per thread: warm-up length <= DL_SEG_PARTS * DL_SEG_QMAX = 48
 
@@ -65,6 +66,14 @@ struct DlObsDev {
     DlInput qpar, qper, qiso, qap, df, dm, dn, sigpar, sigper, b1X, b1Y, sn0;
     DlInput ct_in[DL_MAX_EFT][2];
     DlInput sn_in[DL_MAX_EFT];
+    // pass-through columns n_in .. n_in + n_pass - 1 of the theory vector: parameters the observable is linear in through a constant
+    // matrix folded into the window (BAO broadband terms bao.py:495-534, 881-905)
+    int32_t n_pass, bao_mode;              // bao_mode: 0 = '' / 'recsym', 1 = 'reciso' (bao.py:131)
+    DlInput pass_in[DL_MAX_PASS];
+    DlInput dbeta, sigmas;                 // BAO wiggle model (bao.py:117)
+    double smoothing_radius;
+    const double *coef_w, *coef_n;         // [n_t, 4] interval polynomials of the wiggle P_dd - P_now and of P_now (fixed BAO template)
+    const double *pknow_k;                 // [n_kin] P_now at the fiducial k (bao.py:137)
     const double *kin, *lkin, *mu, *wmu;          // [n_kin], log10(kin) [n_kin], [n_mu], [n_ell * n_mu]
     const double *x_t, *pk_fid, *sf_th, *sf_lg;   // log10(k_t), fiducial P, tanh(a ln(k/kp)), ln(k/kp): all [n_t]
     const double *ih, *dlt;                        // 1 / (x_t[j+1] - x_t[j]); x_t[j] - (x0 + j / inv_hx): [n_t]
@@ -419,8 +428,9 @@ DL_HD void dl_fs_phase3(int tid, int nthr, const DlObsDev& o, const DlFsShared& 
 
 // phase 4: coalesced store of the staged multipoles
 // power_row: row 0 of this point (already offset by col_offset); ld: leading dimension of the power buffer
-DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, double* power_row, int64_t ld) {
+DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, const double* th, double* power_row, int64_t ld) {
     for (int idx = tid; idx < o.n_in; idx += nthr) power_row[idx] = s.out[idx];
+    for (int c = tid; c < o.n_pass; c += nthr) power_row[o.n_in + c] = dl_get(o.pass_in[c], th);
     if (o.n_var > 0 && o.n_ct > 0) {
         // d(power)/d(ct) = 0.5 ct_matrix[:, c] P_dd,l=0 per tracer (full_shape.py:630, 633): rows 1 + slot of this point
         for (int c = 0; c < o.n_ct; ++c) {
@@ -437,4 +447,96 @@ DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& 
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// BAO wiggle model, 'standard' (Chen 2023): DampedBAOWigglesPowerSpectrumMultipoles.calculate bao.py:117-140.
+//   P(k, mu) = B(k, mu) P_now(k) + C(k', mu') [P_dd - P_now](k'),  P_ell = sum_mu w_ell(mu) P(k, mu)   (no Jacobian in this model)
+// The BAO template does not change P(k) (power_template.py:372-376): both splines are constants, held as interval polynomials in global
+// memory (L1 / L2 resident).  Phase A: per-mu AP factors; phase B: one k per thread, mu loop unrolled by 4; output staged in LDS.
+// ------------------------------------------------------------------------------------------------------------------------
+enum { DL_BAO_QPER = 0, DL_BAO_F, DL_BAO_B1, DL_BAO_SIGS, DL_BAO_LQ = 8, DL_BAO_FAC = DL_BAO_LQ + DL_MAX_MU, DL_BAO_MUP2 = DL_BAO_FAC + DL_MAX_MU,
+       DL_BAO_SD = DL_BAO_MUP2 + DL_MAX_MU, DL_BAO_PT = DL_BAO_SD + DL_MAX_MU };
+
+DL_HD size_t dl_bao_shared_doubles(int n_in) { return DL_BAO_PT + (size_t)n_in; }
+
+DL_HD void dl_bao_phaseA(int tid, int nthr, const DlObsDev& o, const double* th, double* lds) {
+    if (tid < ((o.n_mu + 3) & ~3) || tid == 0) {
+        double qpar, qper;
+        dl_ap_qparqper(o, th, qpar, qper);
+        if (tid < o.n_mu) {
+            double sigpar = dl_get(o.sigpar, th), sigper = dl_get(o.sigper, th);
+            double qap = qpar / qper;
+            double mu = o.mu[tid];
+            double fac = sqrt(1. + mu * mu * (1. / (qap * qap) - 1.));   // tgc/base.py:218
+            double mup = mu / qap / fac;
+            lds[DL_BAO_FAC + tid] = fac;
+            lds[DL_BAO_LQ + tid] = log10(fac / qper);
+            lds[DL_BAO_MUP2 + tid] = mup * mup;
+            lds[DL_BAO_SD + tid] = sigpar * sigpar * (mup * mup) + sigper * sigper * (1. - mup * mup);   // bao.py:129
+        } else if (tid < ((o.n_mu + 3) & ~3)) {
+            lds[DL_BAO_FAC + tid] = 0.; lds[DL_BAO_LQ + tid] = 0.; lds[DL_BAO_MUP2 + tid] = 0.; lds[DL_BAO_SD + tid] = 0.;
+        }
+        if (tid == 0) {
+            lds[DL_BAO_QPER] = qper;
+            lds[DL_BAO_F] = dl_get(o.dbeta, th) * (o.f_fid * dl_get(o.df, th));   // bao.py:119 with power_template.py:374
+            lds[DL_BAO_B1] = dl_get(o.b1X, th);
+            lds[DL_BAO_SIGS] = dl_get(o.sigmas, th);
+        }
+    }
+}
+
+DL_HD void dl_bao_phaseB(int tid, int nthr, const DlObsDev& o, double* lds) {
+    const double qper = lds[DL_BAO_QPER], f = lds[DL_BAO_F], b1 = lds[DL_BAO_B1], sigmas = lds[DL_BAO_SIGS];
+    const int n_ell = o.n_ell, n_mu = o.n_mu, n_kin = o.n_kin, n_mu4 = (o.n_mu + 3) & ~3;
+    double* out = lds + DL_BAO_PT;
+    for (int i = tid; i < n_kin; i += nthr) {
+        const double kk = o.kin[i], lk = o.lkin[i], pknow = o.pknow_k[i];
+        const double kq = kk / qper;
+        double sk = 0.;
+        if (o.bao_mode == 1) { double kr = kk * o.smoothing_radius; sk = exp(-0.5 * (kr * kr)); }   // bao.py:131, fiducial coordinates
+        double p[DL_MAX_ELL];
+#pragma unroll
+        for (int l = 0; l < DL_MAX_ELL; ++l) p[l] = 0.;
+        for (int m0 = 0; m0 < n_mu4; m0 += 4) {
+            double pkmu[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int m = m0 + q;
+                int j;
+                double u;
+                dl_spline_locate<false>(o, lk + lds[DL_BAO_LQ + m], j, u);
+                const double* c = o.coef_w + 4 * (size_t)j;
+                double pkw = fma(fma(fma(c[3], u, c[2]), u, c[1]), u, c[0]);                    // [P_dd - P_now](k')
+                double kap = kq * lds[DL_BAO_FAC + m];
+                double mup2 = lds[DL_BAO_MUP2 + m];
+                double ca = b1 + f * mup2 * (1. - sk);
+                double Cap = ca * ca * exp(-(kap * kap * lds[DL_BAO_SD + m]) / 2.);             // bao.py:129-132
+                double mu = (m < n_mu) ? o.mu[m] : 0.;
+                double sm = sigmas * kk * mu;
+                double den = 1. + sm * sm / 2.;
+                double fog = 1. / (den * den);                                                   // bao.py:133
+                double cb = b1 + f * mu * mu * (1. - sk);
+                pkmu[q] = cb * cb * fog * pknow + Cap * pkw;                                     // bao.py:134-136
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int m = m0 + q;
+                if (m < n_mu) {
+#pragma unroll
+                    for (int l = 0; l < DL_MAX_ELL; ++l)
+                        if (l < n_ell) p[l] = fma(o.wmu[l * n_mu + m], pkmu[q], p[l]);
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < DL_MAX_ELL; ++l)
+            if (l < n_ell) out[(size_t)l * n_kin + i] = p[l];
+    }
+}
+
+// coalesced store of the multipoles + pass-through columns
+DL_HD void dl_store_with_pass(int tid, int nthr, const DlObsDev& o, const double* th, const double* out, double* power_row) {
+    for (int idx = tid; idx < o.n_in; idx += nthr) power_row[idx] = out[idx];
+    for (int c = tid; c < o.n_pass; c += nthr) power_row[o.n_in + c] = dl_get(o.pass_in[c], th);
 }

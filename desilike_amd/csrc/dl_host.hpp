@@ -57,6 +57,9 @@ struct DlObsHost {
     std::vector<double> bias;     // [n_out]: W . (sn_in (x) 1) + offset[mask] - sn_out        (window.py:459-473)
     std::vector<double> flatdata; // [n_out]
     size_t off_kin, off_lkin, off_mu, off_wmu, off_xt, off_pk, off_th, off_lg, off_ih, off_dlt, off_A, off_nC, off_inv, off_gf, off_gb, off_coef, off_ct, off_sn;
+    size_t off_cw, off_cn, off_pknowk;
+    int marg_pass[DL_MAX_PASS];
+    int n_cols() const { return dev.n_in + dev.n_pass; }   // columns of this observable in the theory vector / window matrix
 
     void rebase(const double* base) {
         dev.kin = base + off_kin; dev.lkin = base + off_lkin; dev.mu = base + off_mu; dev.wmu = base + off_wmu;
@@ -64,6 +67,7 @@ struct DlObsHost {
         dev.ih = base + off_ih; dev.dlt = base + off_dlt; dev.sp_A = base + off_A; dev.sp_nC = base + off_nC; dev.sp_inv = base + off_inv;
         dev.sp_gf = base + off_gf; dev.sp_gb = base + off_gb; dev.coef_fixed = base + off_coef;
         dev.ct_matrix = base + off_ct; dev.sn_matrix = base + off_sn;
+        dev.coef_w = base + off_cw; dev.coef_n = base + off_cn; dev.pknow_k = base + off_pknowk;
     }
 };
 
@@ -199,10 +203,24 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     d.nd = cfg.f(p + "nd", 1e-4);
     struct { const char* name; DlInput* in; double def; } inputs[] = {
         {"qpar", &d.qpar, 1.}, {"qper", &d.qper, 1.}, {"qiso", &d.qiso, 1.}, {"qap", &d.qap, 1.}, {"df", &d.df, 1.}, {"dm", &d.dm, 0.}, {"dn", &d.dn, 0.},
-        {"sigmapar", &d.sigpar, 0.}, {"sigmaper", &d.sigper, 0.}, {"b1X", &d.b1X, 1.}, {"b1Y", &d.b1Y, 1.}, {"sn0", &d.sn0, 0.}};
+        {"sigmapar", &d.sigpar, 0.}, {"sigmaper", &d.sigper, 0.}, {"b1X", &d.b1X, 1.}, {"b1Y", &d.b1Y, 1.}, {"sn0", &d.sn0, 0.},
+        {"dbeta", &d.dbeta, 1.}, {"sigmas", &d.sigmas, 0.}};
     for (auto& it : inputs) {
         *it.in = dl_input_from(cfg, p + "in." + it.name, it.def);
         if (it.in->col >= n_params) { err = p + "in." + it.name + ": theta column out of range"; return false; }
+    }
+    {
+        const auto& pin = cfg.F(p + "in.pass");
+        d.n_pass = (int)(pin.size() / 2);
+        if (d.n_pass > DL_MAX_PASS) { err = p + "at most 16 pass-through (broadband) parameters supported"; return false; }
+        const auto& mpass = cfg.I(p + "marg.pass");
+        for (int c = 0; c < DL_MAX_PASS; ++c) oh.marg_pass[c] = (c < (int)mpass.size()) ? mpass[c] : -1;
+        for (int c = 0; c < d.n_pass; ++c) {
+            d.pass_in[c].col = (int32_t)std::lround(pin[2 * c]); d.pass_in[c].pad = 0; d.pass_in[c].value = pin[2 * c + 1];
+            if (d.pass_in[c].col >= n_params) { err = p + "in.pass: theta column out of range"; return false; }
+        }
+        d.bao_mode = cfg.i(p + "bao_mode", 0);
+        d.smoothing_radius = cfg.f(p + "smoothing_radius", 15.);
     }
     // template knots in log10 k (full_shape.py:498: interp1d(log10(kap), log10(k11), pk11))
     std::vector<double> x_t(d.n_t), sf_th(d.n_t), sf_lg(d.n_t), lkin(d.n_kin);
@@ -259,6 +277,36 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         dl_fs_phase2d(0, 1, tmp, sh);
         for (size_t c = 0; c < coef.size(); ++c) coef[c] = sh.coef[c];
     }
+    // BAO wiggle model (bao.py:117-140): constant splines of P_now and of the wiggle P_dd - P_now, P_now at the fiducial k
+    std::vector<double> coef_w(4, 0.), coef_n(4, 0.), pknow_k(2, 0.);
+    if (d.theory == 2) {
+        const auto& pknow = cfg.F(p + "pknow_dd_fid");
+        if ((int)pknow.size() != d.n_t) { err = p + "pknow_dd_fid (no-wiggle table) is required by the BAO model"; return false; }
+        auto interval_polynomials = [&](const std::vector<double>& y, std::vector<double>& out) {
+            std::vector<double> Mv;
+            dl_spline_moments_serial(y, sp, Mv);
+            std::vector<double> lds(dl_fs_shared_doubles(d.n_t, d.n_in), 0.);
+            DlFsShared sh = dl_fs_shared_carve(lds.data(), d.n_t, d.n_in);
+            for (int j = 0; j < d.n_t; ++j) { sh.y[j] = y[j]; sh.M[j] = Mv[j]; }
+            DlObsDev tmp = d;
+            tmp.ih = sp.ih.data(); tmp.x_t = x_t.data(); tmp.dlt = dlt.data();
+            dl_fs_phase2d(0, 1, tmp, sh);
+            out.assign(sh.coef, sh.coef + (size_t)4 * d.n_t);
+        };
+        std::vector<double> wig(d.n_t);
+        for (int j = 0; j < d.n_t; ++j) wig[j] = pk[j] - pknow[j];
+        interval_polynomials(wig, coef_w);
+        interval_polynomials(pknow, coef_n);
+        pknow_k.assign(d.n_kin, 0.);
+        DlObsDev tmp = d;
+        tmp.ih = sp.ih.data(); tmp.x_t = x_t.data();
+        for (int i = 0; i < d.n_kin; ++i) {
+            int j; double u;
+            dl_spline_locate<false>(tmp, lkin[i], j, u);
+            const double* c = &coef_n[(size_t)4 * j];
+            pknow_k[i] = std::fma(std::fma(std::fma(c[3], u, c[2]), u, c[1]), u, c[0]);
+        }
+    }
     // EFT-like terms
     const auto& ctm = cfg.F(p + "ct_matrix");
     const auto& snm = cfg.F(p + "sn_matrix");
@@ -294,6 +342,7 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     oh.off_ih = arena.push(sp.ih); oh.off_dlt = arena.push(dlt); oh.off_A = arena.push(sp.A); oh.off_nC = arena.push(sp.nC); oh.off_inv = arena.push(sp.inv);
     oh.off_gf = arena.push(gf); oh.off_gb = arena.push(gb); oh.off_coef = arena.push(coef);
     oh.off_ct = arena.push(ctm); oh.off_sn = arena.push(snm);
+    oh.off_cw = arena.push(coef_w); oh.off_cn = arena.push(coef_n); oh.off_pknowk = arena.push(pknow_k);
 
     // ---- window: effective matrix and additive bias (window.py:445-473) ----
     const auto& wm = cfg.F(p + "wmatrix");
@@ -302,22 +351,24 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     const auto& snin_w = cfg.F(p + "shotnoise_in");
     const auto& snout_w = cfg.F(p + "shotnoise_out");
     const auto& flatdata = cfg.F(p + "flatdata");
-    int n_rows = wm.empty() ? d.n_in : (int)(wm.size() / d.n_in);
-    if (!wm.empty() && (size_t)n_rows * d.n_in != wm.size()) { err = p + "wmatrix size is not a multiple of n_ell * n_kin"; return false; }
+    const int n_cols = d.n_in + d.n_pass;
+    if (wm.empty() && d.n_pass > 0) { err = p + "pass-through parameters need an explicit wmatrix with n_in + n_pass columns"; return false; }
+    int n_rows = wm.empty() ? d.n_in : (int)(wm.size() / n_cols);
+    if (!wm.empty() && (size_t)n_rows * n_cols != wm.size()) { err = p + "wmatrix size is not a multiple of n_ell * n_kin (+ n_pass)"; return false; }
     oh.n_out = kmask.empty() ? n_rows : (int)kmask.size();
     if ((int)flatdata.size() != oh.n_out) { err = p + "flatdata size does not match the window output size"; return false; }
     if (!offset.empty() && (int)offset.size() != n_rows) { err = p + "offset size mismatch"; return false; }
     if (!snout_w.empty() && (int)snout_w.size() != oh.n_out) { err = p + "shotnoise_out size mismatch"; return false; }
     if (!snin_w.empty() && (int)snin_w.size() != d.n_ell) { err = p + "shotnoise_in size mismatch"; return false; }
-    oh.weff.assign((size_t)oh.n_out * d.n_in, 0.);
+    oh.weff.assign((size_t)oh.n_out * n_cols, 0.);
     oh.bias.assign(oh.n_out, 0.);
     oh.flatdata = flatdata;
     for (int r = 0; r < oh.n_out; ++r) {
         int src = kmask.empty() ? r : kmask[r];
         if (src < 0 || src >= n_rows) { err = p + "kmask entry out of range"; return false; }
-        double* row = &oh.weff[(size_t)r * d.n_in];
+        double* row = &oh.weff[(size_t)r * n_cols];
         if (wm.empty()) row[src] = 1.;
-        else std::memcpy(row, &wm[(size_t)src * d.n_in], sizeof(double) * d.n_in);
+        else std::memcpy(row, &wm[(size_t)src * n_cols], sizeof(double) * n_cols);
         double b = 0.;
         if (!snin_w.empty())
             for (int l = 0; l < d.n_ell; ++l) {

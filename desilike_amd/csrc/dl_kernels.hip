@@ -51,13 +51,31 @@ __global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_kernel(const Dl
     double* trow = tables ? tables + (size_t)b * ld_tables : nullptr;
     dl_fs_phase3<FAST, NL, EFT>(tid, nthr, o, s, trow);
     __syncthreads();
-    dl_fs_phase4(tid, nthr, o, s, prow, ld_power);
+    dl_fs_phase4(tid, nthr, o, s, th, prow, ld_power);
+}
+
+// BAO wiggle model: one workgroup per point; constant splines read from global memory, no per-point spline build
+__global__ __launch_bounds__(DL_FS_THREADS) void dl_bao_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power, int64_t ld_power) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double* th = theta + (size_t)b * n_params;
+    dl_bao_phaseA(tid, DL_FS_THREADS, o, th, lds);
+    __syncthreads();
+    dl_bao_phaseB(tid, DL_FS_THREADS, o, lds);
+    __syncthreads();
+    dl_store_with_pass(tid, DL_FS_THREADS, o, th, lds + DL_BAO_PT, power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset);
 }
 
 void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
                          int64_t ld_tables, hipStream_t stream) {
     static const int stop_after = getenv("DL_FS_STOP") ? atoi(getenv("DL_FS_STOP")) : 0;   // per-phase timing diagnostics
     for (int i = 0; i < n_obs; ++i) {  // one launch per observable (1-2 in practice)
+        if (obs_host[i].theory == 2) {   // DL_THEORY_BAO_DAMPED
+            size_t shm = dl_bao_shared_doubles(obs_host[i].n_in) * sizeof(double);
+            if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_bao_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            hipLaunchKernelGGL(dl_bao_kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power);
+            continue;
+        }
         size_t shmem = dl_fs_shared_doubles(obs_host[i].n_t, obs_host[i].n_in) * sizeof(double);
         auto launch = [&](auto kernel) {
             if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  // e.g. 2000-knot BAO tables

@@ -1,0 +1,110 @@
+r"""FFTLog Hankel transform P_\ell(k) -> \xi_\ell(s), init-time host code.
+
+In the reference this is the third-party ``cosmoprimo.PowerToCorrelation(k, ell, q=0, lowring=True)`` (call sites
+theories/galaxy_clustering/base.py:76-77, 135), absent here and not pinned by any reference test ("parity unpinned"): this module is
+our own implementation of the public algorithm (Hamilton 2000, "FFTLog"), checked against ``scipy.fft.fht`` (oracle) and against the
+brute-force integral the reference itself uses as a cross-check (theories/galaxy_clustering/base.py:163-168).
+
+    \xi_\ell(s) = (-1)^{\ell/2} / (2 \pi^2) \int dk k^2 P_\ell(k) j_\ell(k s)
+                = (-1)^{\ell/2} (2 \pi)^{-3/2} s^{-3/2} \int d\ln k [k^{3/2} P_\ell(k)] (k s) J_{\ell + 1/2}(k s)
+
+Because every step of the reference's ``get_corr`` (theories/galaxy_clustering/base.py:127-136: linear interpolation of P_\ell in log k onto
+the FFTLog grid, linear-in-log high-k tail with Gaussian damping, FFTLog, linear interpolation to the data separations) is LINEAR in
+P_\ell(k_in), the whole map is one constant matrix per multipole (``hankel_operator``) which the GPU path folds into the window matrix:
+the FFT never runs in the hot loop.
+"""
+import numpy as np
+from scipy import special
+
+LN_2 = np.log(2.)
+
+
+def fftlog_offset(dln, mu, initial=0., bias=0.):
+    """Low-ringing offset ln(k_c s_c) closest to ``initial`` (Hamilton 2000, eq. 186): makes the Nyquist coefficient real."""
+    xp, xm = (mu + 1. + bias) / 2., (mu + 1. - bias) / 2.
+    y = np.pi / (2. * dln)
+    zp, zm = special.loggamma(xp + 1j * y), special.loggamma(xm + 1j * y)
+    arg = (LN_2 - initial) / dln + (zp.imag + zm.imag) / np.pi
+    return initial + (arg - np.round(arg)) * dln
+
+
+def fftlog_coefficients(n, dln, mu, offset=0.):
+    """u_m, m = 0 .. n/2: Mellin transform of z J_mu(z) on the imaginary axis times the phase of the output-grid offset (unbiased, q = 0)."""
+    y = np.pi * np.arange(n // 2 + 1) / (n * dln)
+    xh = (mu + 1.) / 2.
+    phase = 2. * special.loggamma(xh + 1j * y).imag + 2. * y * (LN_2 - offset)
+    u = np.exp(1j * phase)
+    u.imag[-1] = 0.   # Nyquist term real
+    return u
+
+
+class PowerToCorrelation(object):
+    """Drop-in for the call surface ``PowerToCorrelation(k, ell=ells, q=0, lowring=True)(pk[n_ell, N]) -> (s[n_ell, N], xi[n_ell, N])``.
+
+    ``k`` must be log-spaced; the input is zero-padded to ``minfolds * N`` points (half on each side) before the transform.
+    """
+
+    def __init__(self, k, ell=0, q=0, lowring=True, minfolds=2):
+        self.k = np.asarray(k, dtype='f8')
+        self.ells = np.atleast_1d(ell)
+        if q != 0:
+            raise NotImplementedError('only the unbiased transform q = 0 is implemented')
+        n = self.k.size
+        self.dln = np.log(self.k[-1] / self.k[0]) / (n - 1)
+        if not np.allclose(np.diff(np.log(self.k)), self.dln, rtol=1e-8):
+            raise ValueError('k must be log-spaced')
+        self.npad = int(2**np.ceil(np.log2(minfolds * n)))
+        self.pad = (self.npad - n) // 2
+        self.kpad = self.k[0] * np.exp(self.dln * (np.arange(self.npad) - self.pad))
+        self.offsets, self.u, self.s = [], [], []
+        for ell in self.ells:
+            mu = ell + 0.5
+            offset = fftlog_offset(self.dln, mu) if lowring else 0.
+            self.offsets.append(offset)
+            self.u.append(fftlog_coefficients(self.npad, self.dln, mu, offset=offset))
+            # output grid: s_j k_{npad - 1 - j} = exp(offset)
+            self.s.append(np.exp(offset) / self.kpad[::-1])
+        self.prefactor = [(-1.)**(ell // 2) / (2. * np.pi)**1.5 for ell in self.ells]
+
+    def __call__(self, fun):
+        fun = np.atleast_2d(np.asarray(fun, dtype='f8'))
+        s, xi = [], []
+        for ill in range(len(self.ells)):
+            a = np.zeros(self.npad, dtype='f8')
+            a[self.pad:self.pad + self.k.size] = fun[ill] * self.k**1.5
+            A = np.fft.irfft(np.fft.rfft(a) * self.u[ill], self.npad)[::-1]
+            sl = slice(self.pad, self.pad + self.k.size)
+            s.append(self.s[ill][sl])
+            xi.append(self.prefactor[ill] * A[sl] * self.s[ill][sl]**(-1.5))
+        return np.array(s), np.array(xi)
+
+
+def correlation_from_power(power, kin, k, logk_high, damp_high, kmask_mid, fftlog, s):
+    """``get_corr`` of the reference (theories/galaxy_clustering/base.py:127-136) for interp_order = 1."""
+    tmp = []
+    logkin = np.log10(kin)
+    for pk in power:
+        slope_high = (pk[-1] - pk[-2]) / np.log10(kin[-1] / kin[-2])
+        interp = np.interp(np.log10(k[kmask_mid]), logkin, pk)
+        tmp.append(np.concatenate([interp, (pk[-1] + slope_high * logk_high) * damp_high], axis=-1))
+    ss, corr = fftlog(np.vstack(tmp))
+    return np.array([np.interp(s, sss, cc) for sss, cc in zip(ss, corr)])
+
+
+def hankel_operator(kin, s, ells, k=None):
+    r"""Matrices H_\ell [len(s), len(kin)] with \xi_\ell(s) = H_\ell P_\ell(k_in), reproducing the reference's ``get_corr`` grids
+    (theories/galaxy_clustering/base.py:62-77: k = logspace(-4, 3, 2048), tail beyond kin[-1])."""
+    kin = np.asarray(kin, dtype='f8')
+    if k is None: k = np.logspace(-4., 3., 2048)
+    mask = k > kin[-1]
+    logk_high = np.log10(k[mask] / kin[-1])
+    damp_high = np.exp(-(k[mask] / kin[-1] - 1.)**2 / (2. * (10.)**2))
+    fftlog = PowerToCorrelation(k, ell=ells, q=0, lowring=True)
+    nell = len(ells)
+    H = np.zeros((nell, len(s), kin.size), dtype='f8')
+    basis = np.zeros((nell, kin.size), dtype='f8')
+    for i in range(kin.size):
+        basis[:, i] = 1.
+        H[:, :, i] = correlation_from_power(basis, kin, k, logk_high, damp_high, ~mask, fftlog, s)
+        basis[:, i] = 0.
+    return H

@@ -10,12 +10,13 @@ import numpy as np
 class TabulatedFiducial(object):
     """Fiducial given as tables (e.g. exported once from cosmoprimo / CLASS / CAMB on a CPU node)."""
 
-    def __init__(self, k, pk_dd, f, pknow_dd=None, sigma8=None):
+    def __init__(self, k, pk_dd, f, pknow_dd=None, sigma8=None, rs_drag=None):
         self.k = np.asarray(k, dtype='f8')
         self._logpk = np.log(np.asarray(pk_dd, dtype='f8'))
         self._logpknow = None if pknow_dd is None else np.log(np.asarray(pknow_dd, dtype='f8'))
         self.f = float(f)
         self.sigma8 = sigma8
+        self.rs_drag = rs_drag   # sound horizon of the fiducial cosmology [Mpc/h]: sets the default broadband pivot 2 pi / r_d (bao.py:488)
 
     def _interp(self, k, table):
         from scipy import interpolate
@@ -39,6 +40,7 @@ class SyntheticFiducial(object):
 
     def __init__(self, A=2.5e4, n_s=0.965, keq=0.015, rs=100., wiggle=0.05, f=0.8):
         self.A, self.n_s, self.keq, self.rs, self.wiggle, self.f = A, n_s, keq, rs, wiggle, f
+        self.rs_drag = rs
 
     def _pk(self, k, wiggle):
         k = np.asarray(k, dtype='f8')

@@ -213,15 +213,15 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
                     return (-1, float(self._all_params[pname].value))
                 return (-1, default)
 
-            defaults = dict(qpar=1., qper=1., qiso=1., qap=1., df=1., dm=0., dn=0., sigmapar=0., sigmaper=0., b1X=1., b1Y=1., sn0=0.)
+            defaults = dict(qpar=1., qper=1., qiso=1., qap=1., df=1., dm=0., dn=0., sigmapar=0., sigmaper=0., b1X=1., b1Y=1., sn0=0., dbeta=1., sigmas=0.)
             inputs = {}
             for iname, pname in theory._input_map().items():
                 if iname == 'ct':
                     res = [[resolve(pn, 0.) for pn in pair] for pair in pname]
                     if res: inputs['ct'] = ([[r[0] for r in pair] for pair in res], [[r[1] for r in pair] for pair in res])
-                elif iname == 'sn':
+                elif iname in ('sn', 'pass'):
                     res = [resolve(pn, 0.) for pn in pname]
-                    if res: inputs['sn'] = ([r[0] for r in res], [r[1] for r in res])
+                    if res: inputs[iname] = ([r[0] for r in res], [r[1] for r in res])
                 else:
                     inputs[iname] = resolve(pname, defaults[iname])
             spec['inputs'] = inputs
@@ -232,12 +232,13 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
                 def sindex(pname):
                     return solved_names.index(pname) if pname in solved_names else -1
 
-                marg = {'sn0': [sindex(imap['sn0'])]}
+                marg = {}
+                if 'sn0' in imap: marg['sn0'] = [sindex(imap['sn0'])]
                 if 'sn' in imap and imap['sn']: marg['sn'] = [sindex(pn) for pn in imap['sn']]
+                if 'pass' in imap and imap['pass']: marg['pass'] = [sindex(pn) for pn in imap['pass']]
                 if 'ct' in imap and imap['ct']: marg['ct'] = [[sindex(pn) for pn in pair] for pair in imap['ct']]
-                linear = {imap['sn0']} | set(imap.get('sn', [])) | {pn for pair in imap.get('ct', []) for pn in pair}
                 for iname, pname in imap.items():
-                    if iname not in ('sn0', 'sn', 'ct') and pname in solved_names:
+                    if iname not in ('sn0', 'sn', 'ct', 'pass') and pname in solved_names:
                         raise PipelineError('parameter {} cannot be solved analytically: the theory is not linear in it'.format(pname))
                 spec['marg'] = marg
             observables.append(spec)

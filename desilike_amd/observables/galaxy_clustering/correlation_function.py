@@ -1,0 +1,158 @@
+"""Correlation function multipoles observable and its window (reference: desilike/observables/galaxy_clustering/window.py:536-793,
+correlation_function.py:20-120, 380-381)."""
+import numpy as np
+
+from ...base import BaseCalculator
+from ... import utils
+from ...utils import window_matrix_bininteg
+
+
+class WindowedCorrelationFunctionMultipoles(BaseCalculator):
+    """Window (binning) effect on correlation function multipoles: ``slim``, ``s``, ``sedges``, ``ells``,
+    ``wmatrix`` (None, ``{'resolution': n}`` or 2D array with ``sin``, ``ellsin``), ``theory`` -- same meaning as the reference's."""
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        init = self.init
+        _default_step = 5.
+        slim, s, sedges, ells = init.get('slim', None), init.get('s', None), init.get('sedges', None), init.get('ells', None)
+        wmatrix, sin, ellsin = init.get('wmatrix', None), init.get('sin', None), init.get('ellsin', None)
+        if ells is None:
+            ells = list(slim) if slim is not None else (0, 2, 4)
+        self.ells = tuple(ells)
+        self.s = self.sedges = None
+        if s is not None:
+            if np.ndim(s[0]) == 0: s = [s] * len(self.ells)
+            self.s = [np.array(ss, dtype='f8') for ss in s]
+        if sedges is not None:
+            if np.ndim(sedges[0]) == 0: sedges = [sedges] * len(self.ells)
+            self.sedges = [np.array(ss, dtype='f8') for ss in sedges]
+            self.sedges = [np.column_stack([edges[:-1], edges[1:]]) if edges.ndim <= 1 else edges for edges in self.sedges]
+            if slim is None:
+                slim = {ell: (edges[0, 0], edges[-1, 1], np.mean(edges[..., 1] - edges[..., 0])) for ell, edges in zip(self.ells, self.sedges)}
+        if slim is not None:   # window.py:596-626
+            slim = dict(slim)
+            if self.s is not None:
+                snew, ellsnew = [], []
+                for ill, ell in enumerate(self.ells):
+                    if ell not in slim: continue
+                    ss = self.s[ill]
+                    if slim[ell] is not None:
+                        lo, hi, *step = slim[ell]
+                        ss = ss[(ss >= lo) & (ss <= hi)]
+                    if ss.size:
+                        snew.append(ss); ellsnew.append(ell)
+                self.s, self.ells = snew, tuple(ellsnew)
+            elif list(self.ells) != list(slim):
+                raise ValueError('incompatible ells = {} and slim = {}'.format(self.ells, list(slim)))
+            if self.sedges is None and all(slim[ell] is not None for ell in self.ells):
+                self.sedges = []
+                for ill, ell in enumerate(self.ells):
+                    lo, hi, *step = slim[ell]
+                    if not step: step = ((hi - lo) / self.s[ill].size,) if self.s is not None else (_default_step,)
+                    edges = np.arange(lo, hi + step[0] / 2., step=step[0])
+                    self.sedges.append(np.column_stack([edges[:-1], edges[1:]]))
+        if self.sedges is None:
+            if self.s is not None:
+                self.sedges = []
+                for xx in self.s:
+                    tmp = (xx[:-1] + xx[1:]) / 2.
+                    tmp = np.concatenate([[tmp[0] - (xx[1] - xx[0])], tmp, [tmp[-1] + (xx[-1] - xx[-2])]])
+                    self.sedges.append(np.column_stack([tmp[:-1], tmp[1:]]))
+            else:
+                edges = np.arange(20. - _default_step / 2., 150 + _default_step, _default_step)
+                self.sedges = [np.column_stack([edges[:-1], edges[1:]])] * len(self.ells)
+        if self.s is None:
+            self.s = [np.mean(edges, axis=-1) for edges in self.sedges]
+        self.s = [np.array(ss) for ss in self.s]
+        theory = init.get('theory', None)
+        if theory is None:
+            raise ValueError('provide theory (e.g. DampedBAOWigglesTracerCorrelationFunctionMultipoles)')
+        self.theory = self._require(theory)
+        self.matrix_full, self.smask, self.offset = None, None, None
+        if wmatrix is None:   # window.py:649-656
+            self.ellsin = tuple(self.ells)
+            self.sin = np.unique(np.concatenate(self.s, axis=0))
+            if not all(ss.shape == self.sin.shape and np.allclose(ss, self.sin) for ss in self.s):
+                smask = [np.searchsorted(self.sin, ss, side='left') for ss in self.s]
+                self.smask = np.concatenate([self.sin.size * i + sm for i, sm in enumerate(smask)], axis=0)
+        elif isinstance(wmatrix, dict):
+            if 'wcounts' in wmatrix:
+                raise NotImplementedError('RR-count window matrices are out of scope')
+            self.ellsin = tuple(self.ells)
+            self.sin, matrix_full = window_matrix_bininteg(self.sedges, **wmatrix)
+            self.matrix_full = matrix_full.T
+        elif isinstance(wmatrix, np.ndarray):   # window.py:667-681 (note the reference transposes the input)
+            from scipy import linalg
+            self.ellsin = tuple(ellsin or self.ells)
+            matrix_full = np.array(wmatrix, dtype='f8').T
+            sin = np.asarray(sin).flatten()
+            self.sin = sin.copy()
+            wmatrix_rebin = linalg.block_diag(*[utils.matrix_lininterp(self.sin, sin) for ell in self.ellsin])
+            self.matrix_full = matrix_full.dot(wmatrix_rebin.T)
+        else:
+            raise ValueError('unrecognized wmatrix {}'.format(wmatrix))
+        self.theory.init.update(s=self.sin, ells=self.ellsin)
+        self.theory.initialize()
+        self.shotnoise = 0.
+        self._initialized = True
+        return self
+
+    kmask = property(lambda self: self.smask)
+
+    def _window_spec(self):
+        self.initialize()
+        fold = self.theory._fold()                                       # theory vector = fold . [device output, broadband parameters]
+        wmatrix = fold if self.matrix_full is None else self.matrix_full.dot(fold)
+        return dict(wmatrix=wmatrix, kmask=None if self.smask is None else np.asarray(self.smask, dtype='i4'), offset=self.offset)
+
+    @property
+    def size(self):
+        self.initialize()
+        return sum(len(ss) for ss in self.s)
+
+
+class TracerCorrelationFunctionMultipolesObservable(BaseCalculator):
+    """Correlation function multipoles observable (correlation_function.py:20-120): ``data`` (flat array or dict of parameters),
+    ``covariance``, ``slim`` / ``s`` / ``sedges`` / ``ells`` / ``wmatrix`` / ``theory`` forwarded to the window."""
+    name = 'correlation2poles'
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        init = dict(self.init)
+        data, covariance, wmatrix = init.pop('data', None), init.pop('covariance', None), init.pop('wmatrix', None)
+        self.name = init.pop('name', self.name)
+        self.covariance = None if covariance is None else np.asarray(covariance, dtype='f8')
+        self.nobs = init.pop('nobs', None)
+        self.transform = None
+        if isinstance(wmatrix, WindowedCorrelationFunctionMultipoles):
+            self.wmatrix = wmatrix
+        else:
+            self.wmatrix = WindowedCorrelationFunctionMultipoles()
+            if wmatrix is not None: self.wmatrix.init.update(wmatrix=wmatrix)
+        self._require(self.wmatrix)
+        self.wmatrix.init.update(init)
+        self.wmatrix.initialize()
+        for name in ['s', 'ells', 'sedges']:
+            setattr(self, name, getattr(self.wmatrix, name))
+        self._data_params = None
+        if isinstance(data, dict):
+            self._data_params, self.flatdata = dict(data), None
+        elif data is None:
+            raise ValueError('provide data (flat array or dict of parameters to generate it from theory)')
+        else:
+            self.flatdata = np.ravel(np.asarray(data, dtype='f8'))
+            if self.flatdata.size != self.wmatrix.size:
+                raise ValueError('data size {:d} does not match the window output size {:d}'.format(self.flatdata.size, self.wmatrix.size))
+        self._initialized = True
+        return self
+
+    def _observable_spec(self, flatdata=None):
+        self.initialize()
+        spec = self.wmatrix.theory._theory_spec()
+        spec.update(self.wmatrix._window_spec())
+        spec['transform'] = np.array([0], dtype='i4')
+        spec['flatdata'] = flatdata if flatdata is not None else self.flatdata
+        return spec

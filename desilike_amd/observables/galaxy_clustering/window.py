@@ -143,7 +143,12 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
 
     def _window_spec(self):
         self.initialize()
-        return dict(wmatrix=self.matrix_full, kmask=None if self.kmask is None else np.asarray(self.kmask, dtype='i4'), offset=self.offset,
+        wmatrix = self.matrix_full
+        fold = getattr(self.theory, '_fold', None)
+        if fold is not None:   # theories whose constant linear tail (broadband terms) is folded into the window matrix
+            fold = fold()
+            wmatrix = fold if wmatrix is None else wmatrix.dot(fold)
+        return dict(wmatrix=wmatrix, kmask=None if self.kmask is None else np.asarray(self.kmask, dtype='i4'), offset=self.offset,
                     shotnoise_in=self.shotnoisein, shotnoise_out=self.shotnoiseout)
 
     @property

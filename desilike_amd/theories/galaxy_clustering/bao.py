@@ -1,0 +1,160 @@
+"""BAO wiggle models with broadband terms (reference: desilike/theories/galaxy_clustering/bao.py).
+
+Host-side mirrors of ``DampedBAOWigglesTracerPowerSpectrumMultipoles`` (422-560) and
+``DampedBAOWigglesTracerCorrelationFunctionMultipoles`` (790-960) for the default wiggle model 'standard' (117-140), reconstruction modes
+'', 'recsym', 'reciso', and the 'power' broadband (495-534, 881-905).  Per point the GPU evaluates the wiggle multipoles P_ell(k_in)
+(``dl_bao_kernel``); everything downstream is linear and constant, so it is folded into the window matrix once at compile time:
+the broadband matrices, and for the correlation function the whole P_ell -> xi_ell chain of ``get_corr``
+(theories/galaxy_clustering/base.py:127-136: log-k interpolation, damped tail, FFTLog, interpolation to s) as one Hankel operator
+(:func:`desilike_amd.fftlog.hankel_operator`).  Other wiggle models / kernel broadbands of the reference are not implemented (raise).
+"""
+import re
+
+import numpy as np
+
+from ...base import BaseCalculator
+from ...parameter import ParameterCollection
+from ... import utils
+from .power_template import BAOPowerSpectrumTemplate
+
+_BAO_PARAMS = {'b1': dict(prior=dict(limits=[0.2, 4.]), ref=dict(limits=[1.5, 2.5]), proposal=0.1, latex='b'),
+               'dbeta': dict(value=1., prior=dict(limits=[0.7, 1.3]), ref=dict(limits=[0.8, 1.2]), delta=0.02, proposal=0.1, latex=r'd\beta'),
+               'sigmas': dict(value=0., prior=dict(limits=[0., 10.]), ref=dict(limits=[0., 1.]), latex=r'\Sigma_{s}'),
+               'sigmapar': dict(value=9., prior=dict(limits=[0.1, 10.]), latex=r'\Sigma_{\parallel}', fixed=True),
+               'sigmaper': dict(value=6., prior=dict(limits=[0.1, 10.]), latex=r'\Sigma_{\perp}', fixed=True)}
+
+
+class _BaseDampedBAOTracer(BaseCalculator):
+    _kind = 2   # DL_THEORY_BAO_DAMPED
+    _klim = (1e-4, 1., 2000)   # template knots, bao.py:67
+    _powers = ()
+    _ref_limits = (-1e2, 1e2)
+
+    @classmethod
+    def _default_params(cls, broadband='power', **kwargs):
+        import copy
+        if broadband != 'power':
+            raise NotImplementedError('only the "power" broadband is implemented on the GPU path')
+        params = copy.deepcopy(_BAO_PARAMS)
+        for ell in (0, 2, 4):
+            for pow in cls._powers:
+                params['al{:d}_{:d}'.format(ell, pow)] = dict(value=0., ref=dict(limits=list(cls._ref_limits)), delta=0.005, latex='a_{{{:d}, {:d}}}'.format(ell, pow))
+        return params
+
+    def _init_wiggles(self, k):
+        init = self.init
+        self.ells = tuple(init.get('ells', (0, 2)))
+        self.mode = str(init.get('mode', ''))
+        if self.mode not in ['', 'recsym', 'reciso']:
+            raise ValueError('Reconstruction mode {} must be one of {}'.format(self.mode, ['', 'recsym', 'reciso']))
+        self.model = str(init.get('model', 'standard'))
+        if self.model != 'standard':
+            raise NotImplementedError('only the wiggle model "standard" (bao.py:125-137) is implemented on the GPU path')
+        self.smoothing_radius = float(init.get('smoothing_radius', 15.))
+        self.kin = np.array(k, dtype='f8')
+        self.mu, wmu = utils.weights_mu(init.get('mu', 10), method='leggauss')   # bao.py:109
+        self.wmu = utils.multipole_weights(self.mu, wmu, self.ells)
+        template = init.get('template', None)
+        if template is None:
+            template = self.init['template'] = BAOPowerSpectrumTemplate()
+        self.template = self._require(template)
+        tk = template.init.get('k', None)
+        knots = np.geomspace(min(self._klim[0], self.kin[0] / 2, tk[0] if tk is not None else 1.), max(self._klim[1], self.kin[-1] * 2, tk[0] if tk is not None else 0.), self._klim[2])
+        template.init.update(k=knots, with_now=template.init.get('with_now', None) or 'peakaverage')
+        if init.get('z', None) is not None: template.init.update(z=init['z'])
+        template.initialize()
+        self.z = template.z
+        if template.apmode != 'qparqper':
+            pass
+        # broadband orders (bao.py:24-41): parameters al{ell}_{pow} of the multipoles in use; others are dropped
+        self.broadband_orders = {ell: {} for ell in self.ells}
+        for param in list(self.init.params):
+            match = re.match('al(.*)_(.*)', param.basename)
+            if match:
+                ell, pow = int(match.group(1)), int(match.group(2))
+                if ell in self.ells: self.broadband_orders[ell][param.name] = pow
+                else: del self.init.params[param.name]
+
+    def _broadband_matrix(self, x, xp):
+        """[n_ell * len(x), n_bb]: columns (x / xp)^pow of each multipole's broadband parameters (bao.py:497-499)."""
+        names = [name for ell in self.ells for name in self.broadband_orders[ell]]
+        matrix = np.zeros((len(self.ells), len(x), len(names)), dtype='f8')
+        for ill, ell in enumerate(self.ells):
+            for name, pow in self.broadband_orders[ell].items():
+                matrix[ill, :, names.index(name)] = (x / xp)**pow
+        return names, matrix.reshape(-1, len(names))
+
+    def _theory_spec(self):
+        self.initialize()
+        template = self.template
+        spec = dict(theory=np.array([self._kind], dtype='i4'), nd=[1.], ells_in=np.array(self.ells, dtype='i4'), kin=self.kin, mu=self.mu, wmu_ell=self.wmu,
+                    bao_mode=np.array([1 if self.mode == 'reciso' else 0], dtype='i4'), smoothing_radius=[self.smoothing_radius], pknow_dd_fid=template.pknow_dd_fid)
+        spec.update(template._template_spec())
+        spec['template'] = np.array([0], dtype='i4')   # the BAO template never changes P(k) (power_template.py:372-376)
+        return spec
+
+    def _input_map(self):
+        toret = {name: name for name in ['qpar', 'qper', 'qiso', 'qap', 'df', 'dbeta', 'sigmas', 'sigmapar', 'sigmaper']}
+        toret['b1X'] = toret['b1Y'] = 'b1'
+        toret['pass'] = list(self._broadband_names)
+        return toret
+
+    def _all_params(self):
+        self.initialize()
+        ap = [param for param in self.template.params if param.basename in ('qpar', 'qper', 'qiso', 'qap')]
+        others = [param for param in self.template.params if param not in ap]
+        return ParameterCollection(ap + others) + self.params
+
+
+class DampedBAOWigglesTracerPowerSpectrumMultipoles(_BaseDampedBAOTracer):
+    """BAO power spectrum multipoles with broadband terms (bao.py:422-560, 117-151)."""
+    _powers = range(-3, 2)
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        k = self.init.get('k', None)
+        if k is None: k = np.linspace(0.01, 0.2, 101)
+        self._init_wiggles(k)
+        self.k = self.kin
+        kp = self.init.get('kp', None)
+        self.kp = 2. * np.pi / self.template.fiducial.rs_drag if kp is None else float(kp)   # bao.py:488
+        self._broadband_names, self.broadband_matrix = self._broadband_matrix(self.k, self.kp)
+        self._initialized = True
+        return self
+
+    def _fold(self):
+        """Theory vector [n_ell * n_k] = fold . [P_ell(k_in), broadband parameters]."""
+        return np.hstack([np.eye(len(self.ells) * len(self.k)), self.broadband_matrix])
+
+
+class DampedBAOWigglesTracerCorrelationFunctionMultipoles(_BaseDampedBAOTracer):
+    """BAO correlation function multipoles with broadband terms (bao.py:790-960; Hankel transform tgc/base.py:46-139)."""
+    _powers = range(-2, 3)
+    _ref_limits = (-1e-3, 1e-3)
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        from ...fftlog import hankel_operator
+        from scipy import linalg
+        s = self.init.get('s', None)
+        if s is None: s = np.linspace(20., 200, 101)
+        self.s = np.array(s, dtype='f8')
+        interp_order = {'linear': 1, 'cubic': 3}.get(self.init.get('interp_order', 1), self.init.get('interp_order', 1))
+        if interp_order != 1:
+            raise NotImplementedError('only interp_order = 1 (the default) is implemented')
+        kfft = np.logspace(-4., 3., 2048)                          # tgc/base.py:62
+        kin = self.init.get('k', None)
+        if kin is None: kin = np.geomspace(kfft[0], 0.6, 300)      # tgc/base.py:66
+        self._init_wiggles(kin)
+        sp = self.init.get('sp', None)
+        self.sp = 2. * np.pi / 0.02 if sp is None else float(sp)   # bao.py:855
+        self._broadband_names, self.broadband_matrix = self._broadband_matrix(self.s, self.sp)
+        self.hankel = hankel_operator(self.kin, self.s, self.ells, k=kfft)
+        self._hankel_block = linalg.block_diag(*self.hankel)
+        self._initialized = True
+        return self
+
+    def _fold(self):
+        return np.hstack([self._hankel_block, self.broadband_matrix])

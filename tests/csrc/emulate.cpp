@@ -20,6 +20,14 @@ int emu_config_set_i32(dl_config* cfg, const char* key, const int32_t* data, int
 const char* emu_last_error(void) { return g_err.c_str(); }
 
 static void run_point(const DlObsDev& o, const double* th, double* prow, double* trow) {
+    if (o.theory == 2) {   // BAO wiggle model
+        std::vector<double> lds(dl_bao_shared_doubles(o.n_in));
+        const int nthr = DL_FS_THREADS;
+        for (int tid = 0; tid < nthr; ++tid) dl_bao_phaseA(tid, nthr, o, th, lds.data());
+        for (int tid = 0; tid < nthr; ++tid) dl_bao_phaseB(tid, nthr, o, lds.data());
+        for (int tid = 0; tid < nthr; ++tid) dl_store_with_pass(tid, nthr, o, th, lds.data() + DL_BAO_PT, prow);
+        return;
+    }
     std::vector<double> lds(dl_fs_shared_doubles(o.n_t, o.n_in));
     DlFsShared s = dl_fs_shared_carve(lds.data(), o.n_t, o.n_in);
     const int nthr = DL_FS_THREADS;
@@ -40,7 +48,7 @@ static void run_point(const DlObsDev& o, const double* th, double* prow, double*
         else if (!eft) dl_fs_phase3<true, 5, false>(tid, nthr, o, s, trow);
         else dl_fs_phase3<true, 5, true>(tid, nthr, o, s, trow);
     }
-    for (int tid = 0; tid < nthr; ++tid) dl_fs_phase4(tid, nthr, o, s, prow, o.n_in);
+    for (int tid = 0; tid < nthr; ++tid) dl_fs_phase4(tid, nthr, o, s, th, prow, o.n_in);
 }
 
 // power [B, n_in], tables [B, 3, n_in] (may be null)
@@ -51,8 +59,11 @@ int emu_eval_theory(const dl_config* cfg, const double* theta, int64_t B, int io
     if (!dl_build_obs(*cfg, iobs, P, oh, arena, g_err)) return 1;
     oh.rebase(arena.data.data());
     oh.dev.col_offset = 0;
-    for (int64_t b = 0; b < B; ++b)
-        run_point(oh.dev, theta + b * P, power + b * oh.dev.n_in, tables ? tables + b * 3 * oh.dev.n_in : nullptr);
+    std::vector<double> rowbuf(oh.n_cols());
+    for (int64_t b = 0; b < B; ++b) {
+        run_point(oh.dev, theta + b * P, rowbuf.data(), tables ? tables + b * 3 * oh.dev.n_in : nullptr);
+        std::copy(rowbuf.begin(), rowbuf.begin() + oh.dev.n_in, power + b * oh.dev.n_in);
+    }
     return 0;
 }
 
@@ -66,7 +77,7 @@ int emu_eval_batch(const dl_config* cfg, const double* theta, int64_t B, double*
     for (int i = 0; i < nobs; ++i) {
         if (!dl_build_obs(*cfg, i, P, obs[i], arena, g_err)) return 1;
         row0.push_back(n); col0.push_back(K);
-        n += obs[i].n_out; K += obs[i].dev.n_in;
+        n += obs[i].n_out; K += obs[i].n_cols();
     }
     for (int i = 0; i < nobs; ++i) { obs[i].rebase(arena.data.data()); obs[i].dev.col_offset = col0[i]; }
     const auto& prec = cfg->F("precision");
@@ -79,7 +90,7 @@ int emu_eval_batch(const dl_config* cfg, const double* theta, int64_t B, double*
         for (int i = 0; i < nobs; ++i)
             for (int r = 0; r < obs[i].n_out; ++r) {
                 double sum = 0.;
-                for (int k = 0; k < obs[i].dev.n_in; ++k) sum += obs[i].weff[(size_t)r * obs[i].dev.n_in + k] * power[col0[i] + k];
+                for (int k = 0; k < obs[i].n_cols(); ++k) sum += obs[i].weff[(size_t)r * obs[i].n_cols() + k] * power[col0[i] + k];
                 flat[row0[i] + r] = sum + obs[i].bias[r];
             }
         if (flattheory) std::copy(flat.begin(), flat.end(), flattheory + b * n);

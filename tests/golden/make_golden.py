@@ -283,11 +283,79 @@ def cfg5():
          **obs, **{k: v for k, v in out.items() if not k.startswith('int_')})
 
 
+def extract_bao_observable(obs, space='xi'):
+    wm = obs.wmatrix
+    theory = wm.theory
+    pt = theory.pt if space == 'pk' else theory.power
+    template = pt.template
+    c = {'ells': np.array(wm.ells), 'ellsin': np.array(wm.ellsin), 'kin': np.asarray(pt.k), 'mu': np.asarray(pt.mu), 'wmu_ell': np.asarray(pt.wmu),
+         'k11': np.asarray(template.k), 'pk_dd_fid': np.asarray(template.pk_dd_fid), 'pknow_dd_fid': np.asarray(template.pknow_dd_fid), 'f_fid': float(template.f_fid),
+         'mode': pt.mode, 'model': pt.model, 'smoothing_radius': pt.smoothing_radius, 'flatdata': np.asarray(obs.flatdata), 'broadband': theory.broadband}
+    names = [name for ell in theory.ells for name in theory.broadband_orders[ell]]
+    c['broadband_params'] = np.array(names)
+    if space == 'xi':
+        c['s'] = np.asarray(theory.s); c['sp'] = theory.sp; c['sout'] = np.concatenate(wm.s)
+        bb = np.zeros((len(theory.ells), len(theory.s), len(names)))
+    else:
+        c['kp'] = theory.kp; c['kout'] = np.concatenate(wm.k)
+        bb = np.zeros((len(theory.ells), len(theory.k), len(names)))
+        c['shotnoisein'], c['shotnoiseout'] = np.asarray(wm.shotnoisein), np.asarray(wm.shotnoiseout)
+    for ill, ell in enumerate(theory.ells):
+        for name, row in zip(theory.broadband_orders[ell], np.asarray(theory.broadband_matrix[ell])):
+            bb[ill, :, names.index(name)] = row
+    c['broadband_matrix'] = bb
+    if wm.matrix_full is not None: c['matrix_full'] = np.asarray(wm.matrix_full)
+    if getattr(wm, 'smask', None) is not None: c['smask'] = np.asarray(wm.smask)
+    return c
+
+
+def cfg4(space='xi'):
+    """BASELINE config 4: Damped-BAO xi_ell (ell = 0, 2; 30 s-bins) via FFTLog + Gaussian likelihood; space='pk': the P_ell version with a binning window."""
+    from desilike.theories.galaxy_clustering import BAOPowerSpectrumTemplate, DampedBAOWigglesTracerCorrelationFunctionMultipoles, DampedBAOWigglesTracerPowerSpectrumMultipoles
+    from desilike.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable
+    template = BAOPowerSpectrumTemplate(z=0.5)
+    if space == 'xi':
+        theory = DampedBAOWigglesTracerCorrelationFunctionMultipoles(template=template, mode='reciso')
+        obs = TracerCorrelationFunctionMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, s=np.linspace(22.5, 167.5, 30), ells=(0, 2), theory=theory)
+        n, scale = 60, 3e-4
+    else:
+        theory = DampedBAOWigglesTracerPowerSpectrumMultipoles(template=template)
+        obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, kedges=np.linspace(0.02, 0.3, 57), ells=(0, 2), wmatrix={'resolution': 3}, theory=theory)
+        n, scale = 112, 30.
+    for name in ['sigmapar', 'sigmaper']:
+        theory.init.params[name].update(fixed=False, ref=dict(dist='norm', loc=8., scale=0.5))
+    rng = np.random.RandomState(4)
+    A = rng.standard_normal((n, n)) * scale
+    cov = A.dot(A.T) + (10. * scale)**2 * np.eye(n)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+    like()
+    names = like.varied_params.names()
+    theta = sample_theta(like, 24, seed=9)
+    vlike = vmap(like, backend=None, errors='return', return_derived=True)
+    t0 = time.time()
+    (logpost, derived), errors = vlike({name: theta[:, i] for i, name in enumerate(names)})
+    dt = (time.time() - t0) / len(theta)
+    print('cfg4 {} reference: {:.1f} evals/s'.format(space, 1. / dt))
+    power, corr, flat = [], [], []
+    for row in theta:
+        like(**dict(zip(names, row)))
+        pt = theory.pt if space == 'pk' else theory.power
+        power.append(np.asarray(pt.power).copy())
+        corr.append(np.asarray(theory.corr if space == 'xi' else theory.power).copy())
+        flat.append(np.asarray(like.flattheory).copy())
+    save('cfg4_bao_' + space, names=np.array(names), theta=theta, obs0=extract_bao_observable(obs, space=space), precision=np.asarray(like.precision), covariance=cov,
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]),
+         logposterior=np.asarray(logpost), loglikelihood=np.asarray(derived[like._param_loglikelihood]), logprior=np.asarray(derived[like._param_logprior]),
+         wiggle_power=np.array(power), theory=np.array(corr), flattheory=np.array(flat), ref_seconds_per_eval=dt)
+
+
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
     if 'cfg2_variants' in todo: cfg2_variants()
     if 'marg_grid' in todo: marg_grid()
     if 'cfg5' in todo: cfg5()
+    if 'cfg4' in todo: cfg4('xi')
+    if 'cfg4_pk' in todo: cfg4('pk')

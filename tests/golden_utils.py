@@ -68,3 +68,34 @@ def spec_from_golden(g):
         observables.append(obs)
         iobs += 1
     return dict(n_params=np.array([len(names)]), priors=g['priors'], precision=g['precision'], observables=observables)
+
+
+def spec_from_golden_bao(g):
+    """Spec of a BAO fixture (cfg4_bao_xi / cfg4_bao_pk): wiggle model on the device, Hankel operator and broadband folded into the window."""
+    from desilike_amd.fftlog import hankel_operator
+    from scipy import linalg
+    names = [str(n) for n in g['names']]
+    c = g['obs0']
+    ells = [int(ell) for ell in c['ells']]
+
+    def inp(name, default):
+        return (names.index(name), default) if name in names else (-1, default)
+
+    bbnames = [str(n) for n in c['broadband_params']]
+    nbb = len(bbnames)
+    bbflat = c['broadband_matrix'].reshape(-1, nbb)        # [(ell, x), n_bb]
+    if 's' in c:
+        H = linalg.block_diag(*hankel_operator(c['kin'], c['s'], ells))
+        wmatrix = np.hstack([H, bbflat])
+        extra = {}
+    else:
+        wmatrix = np.hstack([c['matrix_full'], c['matrix_full'].dot(bbflat)])
+        extra = dict(shotnoise_in=c['shotnoisein'], shotnoise_out=c['shotnoiseout'])
+    inputs = {'qpar': inp('qpar', 1.), 'qper': inp('qper', 1.), 'df': inp('df', 1.), 'b1X': inp('b1', 1.), 'b1Y': inp('b1', 1.), 'dbeta': inp('dbeta', 1.), 'sigmas': inp('sigmas', 0.),
+              'sigmapar': inp('sigmapar', 9.), 'sigmaper': inp('sigmaper', 6.)}
+    passin = [inp(name, 0.) for name in bbnames]
+    inputs['pass'] = ([t[0] for t in passin], [t[1] for t in passin])
+    obs = dict(theory=np.array([2]), template=np.array([0]), apmode=np.array([0]), transform=np.array([0]), eta=[1. / 3.], f_fid=[c['f_fid']], nd=[1.],
+               ells_in=np.asarray(c['ellsin'], dtype='i4'), kin=c['kin'], mu=c['mu'], wmu_ell=c['wmu_ell'], k_t=c['k11'], pk_dd_fid=c['pk_dd_fid'], pknow_dd_fid=c['pknow_dd_fid'],
+               bao_mode=np.array([1 if str(c['mode']) == 'reciso' else 0]), smoothing_radius=[float(c['smoothing_radius'])], wmatrix=wmatrix, flatdata=c['flatdata'], inputs=inputs, **extra)
+    return dict(n_params=np.array([len(names)]), priors=g['priors'], precision=g['precision'], observables=[obs])

@@ -33,3 +33,17 @@ def test_emulated_two_tracers():
     assert np.allclose(flat, g['flattheory'], rtol=1e-11, atol=1e-8)
     tol = 1e-10 * np.maximum(1., np.abs(g['loglikelihood']))
     assert (np.abs(loglike - g['loglikelihood']) <= tol).all()
+
+
+@pytest.mark.parametrize('space', ['xi', 'pk'])
+def test_emulated_bao_vs_reference(space):
+    """BAO wiggle kernel (bao.py:117-140) + Hankel operator / broadband folded into the window, vs the reference running on the oracle's FFTLog."""
+    from golden_utils import spec_from_golden_bao
+    g = load_golden('cfg4_bao_' + space)
+    emu = Emulation(spec_from_golden_bao(g))
+    power, _ = emu.eval_theory(g['theta'])
+    assert np.allclose(power, g['wiggle_power'], rtol=1e-11, atol=1e-12 * np.abs(g['wiggle_power']).max())
+    loglike, flat = emu.eval_batch(g['theta'])
+    assert np.allclose(flat, g['flattheory'], rtol=1e-10, atol=1e-12 * np.abs(g['flattheory']).max())
+    tol = 1e-10 * np.maximum(1., np.abs(g['loglikelihood']))
+    assert (np.abs(loglike - g['loglikelihood']) <= tol).all(), np.abs((loglike - g['loglikelihood']) / g['loglikelihood']).max()

@@ -106,3 +106,41 @@ def test_two_tracer_spec_matches_reference():
             assert np.allclose(np.ravel(o[key]), np.ravel(r[key]), rtol=1e-13, atol=1e-300), key
         for name, (col, const) in r['inputs'].items():
             if col >= 0: assert names[o['inputs'][name][0]] == rnames[col], name
+
+
+def make_cfg4(space='xi', data=None):
+    from desilike_amd.theories.galaxy_clustering import BAOPowerSpectrumTemplate, DampedBAOWigglesTracerCorrelationFunctionMultipoles, DampedBAOWigglesTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable, TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    g = load_golden('cfg4_bao_' + space)
+    template = BAOPowerSpectrumTemplate(z=0.5)
+    data = g['obs0']['flatdata'] if data is None else data
+    if space == 'xi':
+        theory = DampedBAOWigglesTracerCorrelationFunctionMultipoles(template=template, mode='reciso')
+        obs = TracerCorrelationFunctionMultipolesObservable(data=data, s=np.linspace(22.5, 167.5, 30), ells=(0, 2), theory=theory)
+    else:
+        theory = DampedBAOWigglesTracerPowerSpectrumMultipoles(template=template)
+        obs = TracerPowerSpectrumMultipolesObservable(data=data, kedges=np.linspace(0.02, 0.3, 57), ells=(0, 2), wmatrix={'resolution': 3}, theory=theory)
+    for name in ['sigmapar', 'sigmaper']:
+        theory.init.params[name].update(fixed=False, ref=dict(dist='norm', loc=8., scale=0.5))
+    return g, ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
+
+
+@pytest.mark.parametrize('space', ['xi', 'pk'])
+def test_bao_spec_matches_reference_constants(space):
+    from golden_utils import spec_from_golden_bao
+    g, like = make_cfg4(space)
+    assert sorted(like.varied_params.names()) == sorted(str(n) for n in g['names'])
+    spec = like._spec({}, like._flatdata_list(), like.precision)
+    ref = spec_from_golden_bao(g)
+    o, r = spec['observables'][0], ref['observables'][0]
+    for key in ['kin', 'mu', 'wmu_ell', 'k_t', 'pk_dd_fid', 'pknow_dd_fid', 'f_fid', 'bao_mode', 'smoothing_radius', 'theory', 'template']:
+        assert np.allclose(np.ravel(o[key]), np.ravel(r[key]), rtol=1e-13, atol=1e-300), key
+    # broadband columns may be ordered differently: compare the window matrix column by parameter name
+    names, rnames = like.varied_params.names(), [str(n) for n in g['names']]
+    n_in = len(o['kin']) * len(o['ells_in'])
+    assert np.allclose(o['wmatrix'][:, :n_in], r['wmatrix'][:, :n_in], rtol=1e-12, atol=1e-14 * np.abs(r['wmatrix']).max())
+    pcols, rpcols = o['inputs']['pass'][0], r['inputs']['pass'][0]
+    for ic, col in enumerate(pcols):
+        jc = [rnames[c] for c in rpcols].index(names[col])
+        assert np.allclose(o['wmatrix'][:, n_in + ic], r['wmatrix'][:, n_in + jc], rtol=1e-12, atol=0)

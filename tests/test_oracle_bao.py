@@ -1,0 +1,60 @@
+"""CPU: pin the BAO restatement (bao.py:117-151, 495-534, 881-905; theories/galaxy_clustering/base.py:127-136) to fixtures captured from the
+reference, and the FFTLog implementations (third-party in the reference: parity unpinned) to each other and to the brute-force integral."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as orc
+from golden_utils import load_golden, prior_list
+
+
+def bao_point(g, row):
+    c = g['obs0']
+    names = [str(n) for n in g['names']]
+    p = dict(zip(names, row))
+    f = p.get('dbeta', 1.) * c['f_fid'] * p.get('df', 1.)
+    power = orc.bao_damped_power(c['kin'], c['mu'], c['wmu_ell'], c['k11'], c['pk_dd_fid'], c['pknow_dd_fid'], f, qpar=p.get('qpar', 1.), qper=p.get('qper', 1.), b1=p['b1'],
+                                 sigmas=p.get('sigmas', 0.), sigmapar=p.get('sigmapar', 9.), sigmaper=p.get('sigmaper', 6.), mode=str(c['mode']), smoothing_radius=float(c['smoothing_radius']))
+    al = np.array([p.get(str(n), 0.) for n in c['broadband_params']])
+    return power, c['broadband_matrix'].dot(al)
+
+
+@pytest.mark.parametrize('space', ['xi', 'pk'])
+def test_bao_chain_vs_reference(space):
+    g = load_golden('cfg4_bao_' + space)
+    c = g['obs0']
+    priors = prior_list(g)
+    ells = tuple(int(ell) for ell in c['ells'])
+    for i, row in enumerate(g['theta']):
+        power, broadband = bao_point(g, row)
+        assert np.allclose(power, g['wiggle_power'][i], rtol=1e-11, atol=1e-12 * np.abs(g['wiggle_power'][i]).max())
+        if space == 'xi':
+            theory = orc.get_corr(power, c['kin'], c['s'], ells) + broadband
+            flat = np.ravel(theory)
+        else:
+            theory = power + broadband
+            flat = orc.window_apply(theory, matrix_full=c['matrix_full'], shotnoisein=c['shotnoisein'], shotnoiseout=c['shotnoiseout'])
+        assert np.allclose(theory, g['theory'][i], rtol=1e-11, atol=1e-13 * np.abs(g['theory'][i]).max())
+        logl = orc.gaussian_loglikelihood(flat, c['flatdata'], g['precision'])[0]
+        assert abs(logl - g['loglikelihood'][i]) <= 1e-10 * max(1., abs(g['loglikelihood'][i]))
+        assert np.isclose(orc.logprior(row, priors), g['logprior'][i], rtol=1e-13, atol=1e-13)
+
+
+def test_fftlog_implementations_and_bruteforce():
+    from desilike_amd.fftlog import PowerToCorrelation, hankel_operator
+    g = load_golden('cfg4_bao_xi')
+    c = g['obs0']
+    k = np.logspace(-4., 3., 2048)
+    power = g['wiggle_power'][0]
+    # same construction as get_corr on the FFTLog grid
+    ref = orc.get_corr(power, c['kin'], c['s'], (0, 2))
+    H = hankel_operator(c['kin'], c['s'], (0, 2))
+    mine = np.einsum('lsk,lk->ls', H, power)
+    assert np.allclose(mine, ref, rtol=1e-11, atol=1e-13 * np.abs(ref).max())     # two implementations of Hamilton's algorithm
+    # physical check: brute-force integral (theories/galaxy_clustering/base.py:163-168), agreement limited by truncation / damping of the tail
+    brute = orc.bruteforce_correlation(c['kin'], power, c['s'], (0, 2))
+    assert np.allclose(mine[0], brute[0], rtol=0.02, atol=2e-5)
+    a, b = PowerToCorrelation(k, ell=(0, 2)), orc.FFTLogPowerToCorrelation(k, ell=(0, 2))
+    pk = np.array([np.interp(np.log10(k), np.log10(c['kin']), p, right=0.) for p in power])
+    (sa, xa), (sb, xb) = a(pk), b(pk)
+    mask = (sa[0] > 20.) & (sa[0] < 200.)
+    assert np.allclose(sa, sb, rtol=1e-14) and np.allclose(xa[:, mask], xb[:, mask], rtol=1e-12, atol=0.)   # identical to rounding where the data live
