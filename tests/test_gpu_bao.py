@@ -46,7 +46,7 @@ def test_bao_xi_vs_oracle_seeded_and_marginalised_broadband():
     c = g['obs0']
     names = like.varied_params.names()
     rng = np.random.RandomState(77)
-    theta = np.column_stack([param.ref.sample(size=8192, random_state=rng) for param in like.varied_params])
+    theta = np.column_stack([np.clip(param.ref.sample(size=8192, random_state=rng), *param.prior.limits) for param in like.varied_params])
     ctx = like._get_context()
     loglike, logprior, status = ctx.eval_batch_host(theta)
     assert (status == 0).all() and np.isfinite(loglike).all()
@@ -64,6 +64,7 @@ def test_bao_xi_vs_oracle_seeded_and_marginalised_broadband():
     assert abs(np.diff(ll, 3)).max() < 1e-7 * abs(ll).max()
     # marginalise all broadband terms
     g3, like3 = make_cfg4('xi')
+    like3.initialize()
     theory = like3.observables[0].wmatrix.theory
     for param in theory.init.params.select(basename='al*'):
         param.update(derived='.marg')
