@@ -414,3 +414,62 @@ def bao_damped_power(k, mu, wmu_ell, k_t, pk_dd, pknow_dd, f, qpar=1., qper=1., 
     pknow = interp1d(np.log10(kk), logkt, pknow_dd, method='cubic')
     pkmu = B * pknow + Cap * pkwap
     return np.sum(pkmu * wmu_ell[:, None, :], axis=-1)
+
+
+# ----------------------------------------------------------------------------------------------
+# a5 (velocileptors part): table-level bias combination                      full_shape.py:1182-1186, 1300-1313, 1577-1599, 1479-1488
+# ----------------------------------------------------------------------------------------------
+def velocileptors_pars(params, sigma8, f, basis='physical', model='rept', snd=1., fsat=1., sigv=1.):
+    """The 11 'pars' (b1, b2, bs, b3, alpha0, alpha2, alpha4, alpha6, sn0, sn2, sn4) fed to the table combination.
+
+    ``basis='physical'``: full_shape.py:1300-1307 (LPT) / 1577-1592 (REPT: Eulerian b1 = 1 + b1L, b2 = 8/21 b1L + b2L);
+    ``model='rept'`` additionally applies the co-evolution shift of combine_bias_terms_poles (1479-1488)."""
+    if basis == 'physical':
+        b1L, b2L, bsL, b3L = params['b1p'] / sigma8 - 1., params['b2p'] / sigma8**2, params['bsp'] / sigma8**2, params['b3p'] / sigma8**3
+        pars = [1. + b1L, 8. / 21. * b1L + b2L, bsL, b3L] if model == 'rept' else [b1L, b2L, bsL, b3L]
+        pars += [(1 + b1L)**2 * params['alpha0p'], f * (1 + b1L) * (params['alpha0p'] + params['alpha2p']),
+                 f * (f * params['alpha2p'] + (1 + b1L) * params['alpha4p']), f**2 * params['alpha4p']]
+        pars += [params['sn{:d}p'.format(i)] * snd * (fsat if i > 0 else 1.) * sigv**i for i in [0, 2, 4]]
+    else:
+        pars = [params[name] for name in ['b1', 'b2', 'bs', 'b3', 'alpha0', 'alpha2', 'alpha4', 'alpha6', 'sn0', 'sn2', 'sn4']]
+    if model == 'rept':   # full_shape.py:1481-1485
+        pars = list(pars)
+        b1 = pars[0]
+        pars[2] = pars[2] - (2 / 7) * (b1 - 1.)
+        pars[3] = 3 * pars[3] + (b1 - 1.)
+    return pars
+
+
+def tablevel_combine_bias_terms_poles(pktable, pars, nd=1e-4):
+    """full_shape.py:1182-1186: sum over the 19 bias monomials, in this order."""
+    b1, b2, bs, b3, alpha0, alpha2, alpha4, alpha6, sn0, sn2, sn4 = pars
+    bias_monomials = np.array([1, b1, b1**2, b2, b1 * b2, b2**2, bs, b1 * bs, b2 * bs, bs**2, b3, b1 * b3, alpha0, alpha2, alpha4, alpha6, sn0 / nd, sn2 / nd, sn4 / nd])
+    return np.sum(pktable * bias_monomials, axis=-1)
+
+
+# ----------------------------------------------------------------------------------------------
+# a12: emulator forward pass.  THIRD-PARTY in the reference (cosmoprimo.emulators.tools, un-vendored, no pinned version): PARITY UNPINNED.
+# Restated from the data layouts the reference writes: Taylor -- emulators/__init__.py:471-507 (center, powers, derivatives already divided by
+# the factorials); MLP -- emulators/conversion.py:20-35, 63-96 (min-max x-scaler, dense layers '(v @ kernel) + bias', silu / relu / tanh,
+# inverse min-max y-scaler).  Pins: Taylor reproduces a polynomial calculator exactly (emulators/tests/test_taylor.py:99-104 checks the centre).
+# ----------------------------------------------------------------------------------------------
+def taylor_predict(x, center, powers, derivatives):
+    """y = sum_t derivatives[t] prod_p (x_p - c_p)^powers[t, p]; x [..., P] -> y [..., *yshape]."""
+    dx = np.asarray(x, dtype='f8') - center
+    monomials = np.prod(dx[..., None, :]**powers, axis=-1)          # [..., n_terms]
+    return np.tensordot(monomials, derivatives, axes=([-1], [0]))
+
+
+def mlp_predict(x, xlimits, layers, activation, ylimits=None):
+    """x [..., P]; xlimits [P, 2]; layers: list of (kernel [in, out], bias [out]); ylimits [..., 2] broadcastable to the output."""
+    v = (np.asarray(x, dtype='f8') - xlimits[..., 0]) / (xlimits[..., 1] - xlimits[..., 0])       # conversion.py:75-77
+    for ilayer, (kernel, bias) in enumerate(layers):
+        v = v.dot(kernel) + bias                                                                   # conversion.py:25
+        if ilayer < len(layers) - 1:                                                               # conversion.py:27-34
+            if activation == 'silu': v = v / (1. + np.exp(-v))
+            elif activation == 'relu': v = np.maximum(v, 0.)
+            elif activation == 'tanh': v = np.tanh(v)
+            else: raise ValueError(activation)
+    if ylimits is not None:
+        v = v * (ylimits[..., 1] - ylimits[..., 0]) + ylimits[..., 0]                              # conversion.py:79 (inverse)
+    return v

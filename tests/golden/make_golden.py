@@ -349,8 +349,70 @@ def cfg4(space='xi'):
          wiggle_power=np.array(power), theory=np.array(corr), flattheory=np.array(flat), ref_seconds_per_eval=dt)
 
 
+def cfg3_table():
+    """Velocileptors-style table combination (full_shape.py:1182-1186, 1573-1599, 1479-1488) run by the REFERENCE on a stand-in PT node.
+
+    velocileptors itself is an external CPU code (absent, out of scope): the PT calculator is replaced by a subclass that keeps the reference's
+    ``combine_bias_terms_poles`` but produces a synthetic ``pktable`` that is an exact quadratic polynomial of the template parameters
+    (so that a second-order Taylor emulator reproduces it exactly), with sigma8, fsigma8 varying too."""
+    from desilike.theories.galaxy_clustering.full_shape import REPTVelocileptorsPowerSpectrumMultipoles, REPTVelocileptorsTracerPowerSpectrumMultipoles
+
+    ells = (0, 2, 4)
+
+    def make_tables(kpt):
+        base = 2e4 * (kpt / 0.05)**0.96 / (1. + (kpt / 0.02)**2.5)
+        tables = np.array([[[base * amp * (1. + 0.3 * np.sin(3. * m + ell + 20. * kpt * (1 + t))) for m in range(19)] for ell in ells] for t, amp in enumerate([1., 0.3, -0.2, 0.15, 0.1, 0.05])])
+        tables = np.moveaxis(tables, 2, -1)                        # [6, n_ell, n_kpt, 19]
+        tables[..., 16:] = 0.
+        for ill in range(3): tables[0, ill, :, 16 + ill] = kpt**(2 * ill) if ill else 1.   # stochastic monomials: 1, k^2-like, k^4-like
+        return tables
+
+    class FakePT(REPTVelocileptorsPowerSpectrumMultipoles):
+
+        _params = {'qpar': dict(value=1., prior=dict(limits=[0.8, 1.2]), ref=dict(limits=[0.98, 1.02])), 'qper': dict(value=1., prior=dict(limits=[0.8, 1.2]), ref=dict(limits=[0.98, 1.02])),
+                   'dm': dict(value=0., prior=dict(limits=[-1., 1.]), ref=dict(limits=[-0.05, 0.05]))}
+
+        def initialize(self, k=None, ells=(0, 2, 4), **kwargs):
+            self.k = np.linspace(0.01, 0.2, 101) if k is None else np.asarray(k, dtype='f8')
+            self.ells = tuple(ells)
+            self.tables = make_tables(self.k)
+            self.z = np.array(0.8)
+            self.options = {}
+
+        def calculate(self, qpar=1., qper=1., dm=0.):
+            x = [qpar - 1., qper - 1., dm]
+            tables = self.tables
+            self.pktable = tables[0] + x[0] * tables[1] + x[1] * tables[2] + x[2] * tables[3] + x[0] * x[2] * tables[4] + x[1]**2 * tables[5]
+            self.sigma8 = 0.8 * (1. + 0.2 * dm + 0.1 * x[0]**2)
+            self.fsigma8 = 0.45 * (1. + 0.3 * x[1] - 0.1 * dm)
+
+    pt = FakePT()
+    theory = REPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, tracer='LRG')
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1p': 1.6, 'b2p': 0.3, 'alpha0p': 2.}, kedges=np.linspace(0.02, 0.2, 37), ells=(0, 2, 4), wmatrix={'resolution': 2}, theory=theory, shotnoise=8e3)
+    cov = spd_covariance(108, seed=8, diag=4e4, amp=40.)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+    like()
+    names = like.varied_params.names()
+    theta = sample_theta(like, 24, seed=17)
+    vlike = vmap(like, backend=None, errors='return', return_derived=True)
+    (logpost, derived), errors = vlike({name: theta[:, i] for i, name in enumerate(names)})
+    assert not errors, errors
+    power, flat = [], []
+    for row in theta:
+        like(**dict(zip(names, row)))
+        power.append(np.asarray(theory.power).copy()); flat.append(np.asarray(like.flattheory).copy())
+    wm = obs.wmatrix
+    obs0 = dict(kpt=np.asarray(pt.k), k=np.asarray(theory.k), ells=np.array(theory.ells), tables=pt.tables, nd=theory.nd, snd=theory.snd, fsat=theory.fsat, sigv=theory.options['sigv'],
+                matrix_full=np.asarray(wm.matrix_full), shotnoisein=np.asarray(wm.shotnoisein), shotnoiseout=np.asarray(wm.shotnoiseout), flatdata=np.asarray(obs.flatdata))
+    save('cfg3_velocileptors_table', names=np.array(names), theta=theta, obs0=obs0, precision=np.asarray(like.precision), covariance=cov,
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]),
+         logposterior=np.asarray(logpost), loglikelihood=np.asarray(derived[like._param_loglikelihood]), logprior=np.asarray(derived[like._param_logprior]),
+         power=np.array(power), flattheory=np.array(flat))
+    print(names)
+
+
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -359,3 +421,4 @@ if __name__ == '__main__':
     if 'cfg5' in todo: cfg5()
     if 'cfg4' in todo: cfg4('xi')
     if 'cfg4_pk' in todo: cfg4('pk')
+    if 'cfg3_table' in todo: cfg3_table()

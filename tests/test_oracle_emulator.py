@@ -1,0 +1,56 @@
+"""CPU: velocileptors-style table combination pinned to the reference (run on a stand-in PT node, fixture cfg3_velocileptors_table) and the
+emulator forward restatements (third-party in the reference: parity unpinned; Taylor pinned by exactness on a polynomial calculator)."""
+import numpy as np
+
+from oracle import np_oracle as orc
+from golden_utils import load_golden, prior_list
+from emulator_utils import taylor_state, EMU_PARAMS
+
+
+def table_point(g, row, state):
+    c = g['obs0']
+    names = [str(n) for n in g['names']]
+    p = dict(zip(names, row))
+    x = np.array([p[name] for name in EMU_PARAMS])
+    pktable = orc.taylor_predict(x, **state['pktable'])
+    sigma8, fsigma8 = orc.taylor_predict(x, **state['sigma8']), orc.taylor_predict(x, **state['fsigma8'])
+    params = {name: p.get(name, 0.) for name in ['b1p', 'b2p', 'bsp', 'b3p', 'alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p', 'sn4p']}
+    pars = orc.velocileptors_pars(params, sigma8, fsigma8 / sigma8, basis='physical', model='rept', snd=float(c['snd']), fsat=float(c['fsat']), sigv=float(c['sigv']))
+    power_pt = orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=float(c['nd']))
+    return orc.interp1d(c['k'], c['kpt'], power_pt.T).T          # full_shape.py:1598
+
+
+def test_velocileptors_table_chain_vs_reference():
+    g = load_golden('cfg3_velocileptors_table')
+    c = g['obs0']
+    state = taylor_state(g)
+    priors = prior_list(g)
+    for i, row in enumerate(g['theta']):
+        power = table_point(g, row, state)
+        assert np.allclose(power, g['power'][i], rtol=1e-12, atol=1e-12 * np.abs(g['power'][i]).max())
+        flat = orc.window_apply(power, matrix_full=c['matrix_full'], shotnoisein=c['shotnoisein'], shotnoiseout=c['shotnoiseout'])
+        assert np.allclose(flat, g['flattheory'][i], rtol=1e-12, atol=1e-9)
+        logl = orc.gaussian_loglikelihood(flat, c['flatdata'], g['precision'])[0]
+        assert abs(logl - g['loglikelihood'][i]) <= 1e-10 * max(1., abs(g['loglikelihood'][i]))
+        assert np.isclose(orc.logprior(row, priors), g['logprior'][i], rtol=1e-13, atol=1e-13)
+
+
+def test_emulator_restatements():
+    rng = np.random.RandomState(0)
+    # Taylor: exact on a polynomial, and equal to the centre value at the centre (emulators/tests/test_taylor.py:99-104)
+    center, powers = np.array([0.5, -1.]), np.array([[0, 0], [1, 0], [0, 1], [2, 0], [1, 1]])
+    derivs = rng.standard_normal((5, 3, 4))
+    x = rng.standard_normal((7, 2))
+    dx = x - center
+    expected = derivs[0] + dx[:, 0, None, None] * derivs[1] + dx[:, 1, None, None] * derivs[2] + dx[:, 0, None, None]**2 * derivs[3] + (dx[:, 0] * dx[:, 1])[:, None, None] * derivs[4]
+    assert np.allclose(orc.taylor_predict(x, center, powers, derivs), expected, rtol=1e-14)
+    assert np.array_equal(orc.taylor_predict(center, center, powers, derivs), derivs[0])
+    # MLP: one hidden silu layer against the explicit formula
+    xlimits = np.array([[0., 2.], [-1., 1.]])
+    k1, b1, k2, b2 = rng.standard_normal((2, 5)), rng.standard_normal(5), rng.standard_normal((5, 3)), rng.standard_normal(3)
+    ylimits = np.array([[0., 1.], [1., 3.], [-2., 2.]])
+    v = (x - xlimits[:, 0]) / (xlimits[:, 1] - xlimits[:, 0])
+    h = v.dot(k1) + b1
+    h = h / (1. + np.exp(-h))
+    expected = (h.dot(k2) + b2) * (ylimits[:, 1] - ylimits[:, 0]) + ylimits[:, 0]
+    assert np.allclose(orc.mlp_predict(x, xlimits, [(k1, b1), (k2, b2)], 'silu', ylimits), expected, rtol=1e-14)
