@@ -87,10 +87,13 @@ def fill_config(spec, set_f64, set_i32):
                 for okey, ovalue in obs.items():
                     if okey == 'inputs':
                         for name, (col, const) in ovalue.items():
-                            if name in ('ct', 'sn', 'pass'):
+                            if name in ('ct', 'sn', 'pass', 'x', 'vp'):
                                 put('obs{:d}.in.{}'.format(iobs, name), np.array([[c, v] for c, v in zip(np.ravel(col), np.ravel(const))], dtype='f8'))
                             else:
                                 put('obs{:d}.in.{}'.format(iobs, name), np.array([col, const], dtype='f8'))
+                    elif okey.startswith('emu') and isinstance(ovalue, dict):
+                        for name, array in ovalue.items():
+                            put('obs{:d}.{}.{}'.format(iobs, okey, name), array)
                     elif okey == 'marg':
                         for name, index in ovalue.items():
                             put('obs{:d}.marg.{}'.format(iobs, name), np.asarray(index, dtype='i4'))

@@ -82,6 +82,8 @@ static int dl_upload(dl_ctx* ctx, T** dst, const std::vector<T>& src) {
     return 0;
 }
 
+static_assert(sizeof(DlObsDev) <= 4096, "DlObsDev travels in the kernarg segment (4 KiB)");
+
 extern "C" {
 
 dl_config* dl_config_new(void) { return new dl_config(); }
@@ -138,7 +140,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
         if (ctx->obs[i].dev.transform != 0) ctx->any_transform = true;
     }
     for (auto& ob : ctx->obs)
-        if ((ob.dev.theory == 2 ? dl_bao_shared_doubles(ob.dev.n_in) : dl_fs_shared_doubles(ob.dev.n_t, ob.dev.n_in)) * sizeof(double) > 160 * 1024)
+        if ((ob.dev.theory == 3 ? 0 : ob.dev.theory == 2 ? dl_bao_shared_doubles(ob.dev.n_in) : dl_fs_shared_doubles(ob.dev.n_t, ob.dev.n_in)) * sizeof(double) > 160 * 1024)
             return bail("dl_create: template / theory grid too large for the 160 KiB LDS");
     ctx->n_data = row;
     int n = ctx->n_data;
@@ -221,8 +223,18 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
                     if (sidx >= ns) return bail("dl_create: marg index out of range");
                     if (ctx->marg.var_slot[sidx] < 0) ctx->marg.var_slot[sidx] = ctx->n_var++;
                 }
+        for (auto& ob : ctx->obs)
+            if (ob.dev.theory == 3)
+                for (int c = 0; c < DL_N_VPARS; ++c) {
+                    int sidx = ob.marg_vp[c];
+                    if (sidx < 0) continue;
+                    if (sidx >= ns) return bail("dl_create: marg index out of range");
+                    if (ctx->marg.var_slot[sidx] < 0) ctx->marg.var_slot[sidx] = ctx->n_var++;
+                }
         for (auto& ob : ctx->obs) {
             ob.dev.n_var = ctx->n_var;
+            if (ob.dev.theory == 3)
+                for (int c = 0; c < DL_N_VPARS; ++c) ob.dev.vp_slot[c] = ob.marg_vp[c] >= 0 ? ctx->marg.var_slot[ob.marg_vp[c]] : -1;
             for (int c = 0; c < ob.dev.n_ct; ++c)
                 for (int t = 0; t < 2; ++t) ob.dev.marg_ct_slot[c][t] = ob.marg_ct[c][t] >= 0 ? ctx->marg.var_slot[ob.marg_ct[c][t]] : -1;
         }

@@ -58,6 +58,8 @@ struct DlObsHost {
     std::vector<double> flatdata; // [n_out]
     size_t off_kin, off_lkin, off_mu, off_wmu, off_xt, off_pk, off_th, off_lg, off_ih, off_dlt, off_A, off_nC, off_inv, off_gf, off_gb, off_coef, off_ct, off_sn;
     size_t off_cw, off_cn, off_pknowk;
+    size_t off_eng[3][6];   // xlo, xinv, weights, center, powers, coef of each emulator engine
+    int marg_vp[DL_N_VPARS];
     int marg_pass[DL_MAX_PASS];
     int n_cols() const { return dev.n_in + dev.n_pass; }   // columns of this observable in the theory vector / window matrix
 
@@ -68,6 +70,10 @@ struct DlObsHost {
         dev.sp_gf = base + off_gf; dev.sp_gb = base + off_gb; dev.coef_fixed = base + off_coef;
         dev.ct_matrix = base + off_ct; dev.sn_matrix = base + off_sn;
         dev.coef_w = base + off_cw; dev.coef_n = base + off_cn; dev.pknow_k = base + off_pknowk;
+        for (int e = 0; e < 3; ++e) {
+            dev.eng[e].xlo = base + off_eng[e][0]; dev.eng[e].xinv = base + off_eng[e][1]; dev.eng[e].weights = base + off_eng[e][2];
+            dev.eng[e].center = base + off_eng[e][3]; dev.eng[e].powers = base + off_eng[e][4]; dev.eng[e].coef = base + off_eng[e][5];
+        }
     }
 };
 
@@ -172,6 +178,139 @@ inline bool dl_cholesky(std::vector<double>& P, int n) {
     return true;
 }
 
+// window part shared by every theory kind: effective matrix (matrix / identity / row selection) and additive bias (window.py:445-473)
+inline bool dl_build_window(const dl_config& cfg, const std::string& p, DlObsHost& oh, std::string& err) {
+    DlObsDev& d = oh.dev;
+    const auto& wm = cfg.F(p + "wmatrix");
+    const auto& kmask = cfg.I(p + "kmask");
+    const auto& offset = cfg.F(p + "offset");
+    const auto& snin_w = cfg.F(p + "shotnoise_in");
+    const auto& snout_w = cfg.F(p + "shotnoise_out");
+    const auto& flatdata = cfg.F(p + "flatdata");
+    const int n_cols = d.n_in + d.n_pass;
+    if (wm.empty() && d.n_pass > 0) { err = p + "pass-through parameters need an explicit wmatrix with n_in + n_pass columns"; return false; }
+    int n_rows = wm.empty() ? d.n_in : (int)(wm.size() / n_cols);
+    if (!wm.empty() && (size_t)n_rows * n_cols != wm.size()) { err = p + "wmatrix size is not a multiple of the theory vector size"; return false; }
+    oh.n_out = kmask.empty() ? n_rows : (int)kmask.size();
+    if ((int)flatdata.size() != oh.n_out) { err = p + "flatdata size does not match the window output size"; return false; }
+    if (!offset.empty() && (int)offset.size() != n_rows) { err = p + "offset size mismatch"; return false; }
+    if (!snout_w.empty() && (int)snout_w.size() != oh.n_out) { err = p + "shotnoise_out size mismatch"; return false; }
+    if (!snin_w.empty() && (int)snin_w.size() != d.n_ell) { err = p + "shotnoise_in size mismatch"; return false; }
+    oh.weff.assign((size_t)oh.n_out * n_cols, 0.);
+    oh.bias.assign(oh.n_out, 0.);
+    oh.flatdata = flatdata;
+    for (int r = 0; r < oh.n_out; ++r) {
+        int src = kmask.empty() ? r : kmask[r];
+        if (src < 0 || src >= n_rows) { err = p + "kmask entry out of range"; return false; }
+        double* row = &oh.weff[(size_t)r * n_cols];
+        if (wm.empty()) row[src] = 1.;
+        else std::memcpy(row, &wm[(size_t)src * n_cols], sizeof(double) * n_cols);
+        double b = 0.;
+        if (!snin_w.empty())
+            for (int l = 0; l < d.n_ell; ++l) {
+                if (snin_w[l] == 0.) continue;
+                double sum = 0.;
+                for (int i = 0; i < d.n_kin; ++i) sum += row[(size_t)l * d.n_kin + i];
+                b += sum * snin_w[l];
+            }
+        if (!offset.empty()) b += offset[src];
+        if (!snout_w.empty()) b -= snout_w[r];
+        oh.bias[r] = b;
+    }
+    return true;
+}
+
+// Emulated theory (kind 3): emulator engines (MLP / Taylor) + bias monomials; the window matrix has n_basis * n_mono (+ n_pass) columns.
+inline bool dl_build_emulated_obs(const dl_config& cfg, const std::string& p, int n_params, DlObsHost& oh, DlArena& arena, std::string& err) {
+    DlObsDev& d = oh.dev;
+    d.transform = cfg.i(p + "transform", 0);
+    const auto& xin = cfg.F(p + "in.x");
+    d.n_x = (int)(xin.size() / 2);
+    if (d.n_x < 1 || d.n_x > DL_MAX_X) { err = p + "in.x: between 1 and 16 emulator inputs supported"; return false; }
+    for (int c = 0; c < d.n_x; ++c) {
+        d.x_in[c].col = (int32_t)std::lround(xin[2 * c]); d.x_in[c].pad = 0; d.x_in[c].value = xin[2 * c + 1];
+        if (d.x_in[c].col >= n_params) { err = p + "in.x: theta column out of range"; return false; }
+    }
+    d.mono_mode = cfg.i(p + "mono_mode", 0);
+    d.n_mono = d.mono_mode == 0 ? 1 : DL_N_MONO;
+    const auto& vpin = cfg.F(p + "in.vp");
+    const auto& mvp = cfg.I(p + "marg.vp");
+    const double vdef[DL_N_VPARS] = {1., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
+    for (int c = 0; c < DL_N_VPARS; ++c) {
+        d.vp_in[c].col = -1; d.vp_in[c].pad = 0; d.vp_in[c].value = vdef[c];
+        if (2 * c + 1 < (int)vpin.size()) { d.vp_in[c].col = (int32_t)std::lround(vpin[2 * c]); d.vp_in[c].value = vpin[2 * c + 1]; }
+        if (d.vp_in[c].col >= n_params) { err = p + "in.vp: theta column out of range"; return false; }
+        oh.marg_vp[c] = (c < (int)mvp.size()) ? mvp[c] : -1;
+        d.vp_slot[c] = -1;
+        if (oh.marg_vp[c] >= 0 && c < 4) { err = p + "only alpha* and sn* can be solved analytically (full_shape.py:1226)"; return false; }
+    }
+    const auto& vconst = cfg.F(p + "vconst");
+    d.snd = vconst.size() > 0 ? vconst[0] : 1.; d.fsat = vconst.size() > 1 ? vconst[1] : 1.; d.sigv = vconst.size() > 2 ? vconst[2] : 1.;
+    d.nd = vconst.size() > 3 ? vconst[3] : 1e-4;
+    for (int e = 0; e < 3; ++e) {
+        std::string q = p + "emu" + std::to_string(e) + ".";
+        DlObsDev::Engine& en = d.eng[e];
+        std::memset(&en, 0, sizeof(en));
+        en.type = cfg.i(q + "type", -1);
+        en.cst = cfg.f(q + "const", e == 1 ? 1. : 0.);
+        std::vector<double> xlo(1, 0.), xinv(1, 0.), weights(1, 0.), center(1, 0.), powers(1, 0.), coef(1, 0.);
+        if (e == 0 && en.type < 0) { err = p + "emu0 (the table engine) is required"; return false; }
+        if (en.type == 0) {
+            const auto& xl = cfg.F(q + "xlimits");
+            const auto& widths = cfg.I(q + "widths");
+            const auto& w = cfg.F(q + "weights");
+            const auto& yl = cfg.F(q + "ylimits");
+            en.act = cfg.i(q + "act", 0);
+            en.n_layers = (int)widths.size() - 1;
+            if ((int)xl.size() != 2 * d.n_x || en.n_layers < 1 || en.n_layers > DL_MAX_LAYERS || widths[0] != d.n_x) { err = q + "inconsistent MLP description"; return false; }
+            size_t expect = 0;
+            for (int l = 0; l <= en.n_layers; ++l) {
+                en.widths[l] = widths[l];
+                if (widths[l] < 1 || widths[l] > DL_MAX_WIDTH) { err = q + "layer widths must be in [1, 256]"; return false; }
+                if (l) expect += (size_t)widths[l - 1] * widths[l] + widths[l];
+            }
+            if (w.size() != expect) { err = q + "weights size does not match the layer widths"; return false; }
+            xlo.assign(d.n_x, 0.); xinv.assign(d.n_x, 0.);
+            for (int c = 0; c < d.n_x; ++c) { xlo[c] = xl[2 * c]; xinv[c] = 1. / (xl[2 * c + 1] - xl[2 * c]); }
+            weights = w;
+            if (e != 0) {
+                if (widths[en.n_layers] != 1 || yl.size() != 2) { err = q + "scalar engines need one output and ylimits"; return false; }
+                en.ylo = yl[0]; en.yscale = yl[1] - yl[0];
+            } else d.n_basis = widths[en.n_layers] + 1;    // last hidden layer + the bias row of the folded final layer
+        } else if (en.type == 1) {
+            const auto& ce = cfg.F(q + "center");
+            const auto& po = cfg.I(q + "powers");
+            const auto& co = cfg.F(q + "coef");
+            en.n_terms = (int)(po.size() / d.n_x);
+            if ((int)ce.size() != d.n_x || en.n_terms < 1 || en.n_terms > DL_MAX_WIDTH || (size_t)en.n_terms * d.n_x != po.size()) { err = q + "inconsistent Taylor description (<= 256 terms)"; return false; }
+            center = ce;
+            powers.assign(po.begin(), po.end());
+            if (e != 0) {
+                if ((int)co.size() != en.n_terms) { err = q + "coef size must match powers"; return false; }
+                coef = co;
+            } else d.n_basis = en.n_terms;
+        }
+        oh.off_eng[e][0] = arena.push(xlo); oh.off_eng[e][1] = arena.push(xinv); oh.off_eng[e][2] = arena.push(weights);
+        oh.off_eng[e][3] = arena.push(center); oh.off_eng[e][4] = arena.push(powers); oh.off_eng[e][5] = arena.push(coef);
+    }
+    d.n_ell = 1; d.n_kin = d.n_basis * d.n_mono; d.n_in = d.n_kin; d.ell0 = -1;
+    d.n_mu = 0; d.n_t = 0;
+    const auto& pin = cfg.F(p + "in.pass");
+    d.n_pass = (int)(pin.size() / 2);
+    if (d.n_pass > DL_MAX_PASS) { err = p + "at most 16 pass-through parameters supported"; return false; }
+    const auto& mpass = cfg.I(p + "marg.pass");
+    for (int c = 0; c < DL_MAX_PASS; ++c) oh.marg_pass[c] = (c < (int)mpass.size()) ? mpass[c] : -1;
+    for (int c = 0; c < d.n_pass; ++c) { d.pass_in[c].col = (int32_t)std::lround(pin[2 * c]); d.pass_in[c].pad = 0; d.pass_in[c].value = pin[2 * c + 1]; }
+    for (int c = 0; c < DL_MAX_EFT; ++c) { oh.marg_sn[c] = -1; oh.marg_ct[c][0] = oh.marg_ct[c][1] = -1; d.marg_ct_slot[c][0] = d.marg_ct_slot[c][1] = -1; }
+    oh.marg_sn0 = -1;
+    // unused arrays still need valid offsets
+    std::vector<double> dummy(2, 0.);
+    size_t off = arena.push(dummy);
+    oh.off_kin = oh.off_lkin = oh.off_mu = oh.off_wmu = oh.off_xt = oh.off_pk = oh.off_th = oh.off_lg = oh.off_ih = oh.off_dlt = oh.off_A = oh.off_nC = oh.off_inv = off;
+    oh.off_gf = oh.off_gb = oh.off_coef = oh.off_ct = oh.off_sn = oh.off_cw = oh.off_cn = oh.off_pknowk = off;
+    return dl_build_window(cfg, p, oh, err);
+}
+
 // Build the constants of observable `iobs` from the key/value store.
 inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost& oh, DlArena& arena, std::string& err) {
     std::string p = "obs" + std::to_string(iobs) + ".";
@@ -181,6 +320,7 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     d.templ = cfg.i(p + "template", 0);
     d.apmode = cfg.i(p + "apmode", 0);
     d.transform = cfg.i(p + "transform", 0);
+    if (d.theory == 3) return dl_build_emulated_obs(cfg, p, n_params, oh, arena, err);
     const auto& ells = cfg.I(p + "ells_in");
     const auto& kin = cfg.F(p + "kin");
     const auto& mu = cfg.F(p + "mu");
@@ -344,42 +484,7 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     oh.off_ct = arena.push(ctm); oh.off_sn = arena.push(snm);
     oh.off_cw = arena.push(coef_w); oh.off_cn = arena.push(coef_n); oh.off_pknowk = arena.push(pknow_k);
 
-    // ---- window: effective matrix and additive bias (window.py:445-473) ----
-    const auto& wm = cfg.F(p + "wmatrix");
-    const auto& kmask = cfg.I(p + "kmask");
-    const auto& offset = cfg.F(p + "offset");
-    const auto& snin_w = cfg.F(p + "shotnoise_in");
-    const auto& snout_w = cfg.F(p + "shotnoise_out");
-    const auto& flatdata = cfg.F(p + "flatdata");
-    const int n_cols = d.n_in + d.n_pass;
-    if (wm.empty() && d.n_pass > 0) { err = p + "pass-through parameters need an explicit wmatrix with n_in + n_pass columns"; return false; }
-    int n_rows = wm.empty() ? d.n_in : (int)(wm.size() / n_cols);
-    if (!wm.empty() && (size_t)n_rows * n_cols != wm.size()) { err = p + "wmatrix size is not a multiple of n_ell * n_kin (+ n_pass)"; return false; }
-    oh.n_out = kmask.empty() ? n_rows : (int)kmask.size();
-    if ((int)flatdata.size() != oh.n_out) { err = p + "flatdata size does not match the window output size"; return false; }
-    if (!offset.empty() && (int)offset.size() != n_rows) { err = p + "offset size mismatch"; return false; }
-    if (!snout_w.empty() && (int)snout_w.size() != oh.n_out) { err = p + "shotnoise_out size mismatch"; return false; }
-    if (!snin_w.empty() && (int)snin_w.size() != d.n_ell) { err = p + "shotnoise_in size mismatch"; return false; }
-    oh.weff.assign((size_t)oh.n_out * n_cols, 0.);
-    oh.bias.assign(oh.n_out, 0.);
-    oh.flatdata = flatdata;
-    for (int r = 0; r < oh.n_out; ++r) {
-        int src = kmask.empty() ? r : kmask[r];
-        if (src < 0 || src >= n_rows) { err = p + "kmask entry out of range"; return false; }
-        double* row = &oh.weff[(size_t)r * n_cols];
-        if (wm.empty()) row[src] = 1.;
-        else std::memcpy(row, &wm[(size_t)src * n_cols], sizeof(double) * n_cols);
-        double b = 0.;
-        if (!snin_w.empty())
-            for (int l = 0; l < d.n_ell; ++l) {
-                if (snin_w[l] == 0.) continue;
-                double sum = 0.;
-                for (int i = 0; i < d.n_kin; ++i) sum += row[(size_t)l * d.n_kin + i];
-                b += sum * snin_w[l];
-            }
-        if (!offset.empty()) b += offset[src];
-        if (!snout_w.empty()) b -= snout_w[r];
-        oh.bias[r] = b;
-    }
-    return true;
+    for (int c = 0; c < DL_N_VPARS; ++c) { oh.marg_vp[c] = -1; d.vp_slot[c] = -1; }
+    for (int e = 0; e < 3; ++e) { d.eng[e].type = -1; for (int q = 0; q < 6; ++q) oh.off_eng[e][q] = oh.off_kin; }
+    return dl_build_window(cfg, p, oh, err);
 }

@@ -66,10 +66,22 @@ __global__ __launch_bounds__(DL_FS_THREADS) void dl_bao_kernel(const DlObsDev o,
     dl_store_with_pass(tid, DL_FS_THREADS, o, th, lds + DL_BAO_PT, power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset);
 }
 
+// emulated theory: MLP / Taylor forward pass and feature expansion, one workgroup per point
+__global__ __launch_bounds__(DL_FS_THREADS) void dl_emulated_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power, int64_t ld_power) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x;
+    dl_emu_point(o, theta + (size_t)b * n_params, lds, power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset, ld_power);
+}
+
 void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
                          int64_t ld_tables, hipStream_t stream) {
     static const int stop_after = getenv("DL_FS_STOP") ? atoi(getenv("DL_FS_STOP")) : 0;   // per-phase timing diagnostics
     for (int i = 0; i < n_obs; ++i) {  // one launch per observable (1-2 in practice)
+        if (obs_host[i].theory == 3) {   // DL_THEORY_EMULATED
+            size_t shm = dl_emu_shared_doubles(obs_host[i].n_var) * sizeof(double);
+            hipLaunchKernelGGL(dl_emulated_kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power);
+            continue;
+        }
         if (obs_host[i].theory == 2) {   // DL_THEORY_BAO_DAMPED
             size_t shm = dl_bao_shared_doubles(obs_host[i].n_in) * sizeof(double);
             if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_bao_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

@@ -219,9 +219,12 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
                 if iname == 'ct':
                     res = [[resolve(pn, 0.) for pn in pair] for pair in pname]
                     if res: inputs['ct'] = ([[r[0] for r in pair] for pair in res], [[r[1] for r in pair] for pair in res])
-                elif iname in ('sn', 'pass'):
+                elif iname in ('sn', 'pass', 'x'):
                     res = [resolve(pn, 0.) for pn in pname]
                     if res: inputs[iname] = ([r[0] for r in res], [r[1] for r in res])
+                elif iname == 'vp':   # velocileptors 'pars': the reference's defaults are 0, except b1 (full_shape.py:1290-1293)
+                    res = [resolve(pn, 1. if ip == 0 and pn == 'b1' else 0.) for ip, pn in enumerate(pname)]
+                    inputs[iname] = ([r[0] for r in res], [r[1] for r in res])
                 else:
                     inputs[iname] = resolve(pname, defaults[iname])
             spec['inputs'] = inputs
@@ -236,9 +239,10 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
                 if 'sn0' in imap: marg['sn0'] = [sindex(imap['sn0'])]
                 if 'sn' in imap and imap['sn']: marg['sn'] = [sindex(pn) for pn in imap['sn']]
                 if 'pass' in imap and imap['pass']: marg['pass'] = [sindex(pn) for pn in imap['pass']]
+                if 'vp' in imap: marg['vp'] = [sindex(pn) for pn in imap['vp']]
                 if 'ct' in imap and imap['ct']: marg['ct'] = [[sindex(pn) for pn in pair] for pair in imap['ct']]
                 for iname, pname in imap.items():
-                    if iname not in ('sn0', 'sn', 'ct', 'pass') and pname in solved_names:
+                    if iname in ('x',) and any(pn in solved_names for pn in pname) or iname not in ('sn0', 'sn', 'ct', 'pass', 'vp', 'x') and pname in solved_names:
                         raise PipelineError('parameter {} cannot be solved analytically: the theory is not linear in it'.format(pname))
                 spec['marg'] = marg
             observables.append(spec)
@@ -272,6 +276,7 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         return self._contexts[key]
 
     def _flatdata_list(self):
+        self.initialize()
         return [obs.flatdata for obs in self.observables]
 
     def _generate_data(self):

@@ -128,6 +128,8 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
             shotnoise = 0.
         else:
             shotnoise = float(shotnoise)
+            if getattr(self.theory, '_kind', None) == 3:   # theories scaling their stochastic terms by the shot noise take it from the observable (window.py:441-443)
+                self.theory.init.setdefault('shotnoise', shotnoise)
         self.shotnoise = shotnoise
         # window.py:445-457
         self.shotnoisein = np.array([shotnoise * (ell == 0) for ell in self.ellsin], dtype='f8')
@@ -143,13 +145,18 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
 
     def _window_spec(self):
         self.initialize()
-        wmatrix = self.matrix_full
+        wmatrix, offset, shotnoisein = self.matrix_full, self.offset, self.shotnoisein
         fold = getattr(self.theory, '_fold', None)
-        if fold is not None:   # theories whose constant linear tail (broadband terms) is folded into the window matrix
+        if fold is not None:   # theories whose constant linear tail (broadband terms, emulator output layer, ...) is folded into the window matrix
             fold = fold()
+            if np.any(shotnoisein != 0.):   # W . (sn_in (x) 1) (window.py:471) no longer maps onto device columns: fold it into the offset
+                vector = np.repeat(shotnoisein, len(self.kin))
+                extra = vector if wmatrix is None else wmatrix.dot(vector)
+                offset = extra if offset is None else offset + extra
+            shotnoisein = None
             wmatrix = fold if wmatrix is None else wmatrix.dot(fold)
-        return dict(wmatrix=wmatrix, kmask=None if self.kmask is None else np.asarray(self.kmask, dtype='i4'), offset=self.offset,
-                    shotnoise_in=self.shotnoisein, shotnoise_out=self.shotnoiseout)
+        return dict(wmatrix=wmatrix, kmask=None if self.kmask is None else np.asarray(self.kmask, dtype='i4'), offset=offset,
+                    shotnoise_in=shotnoisein, shotnoise_out=self.shotnoiseout)
 
     @property
     def size(self):

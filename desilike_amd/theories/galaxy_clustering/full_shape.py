@@ -191,3 +191,143 @@ class EFTLikeKaiserTracerPowerSpectrumMultipoles(KaiserTracerPowerSpectrumMultip
         toret['ct'] = [(nsX + name, nsY + name) for name in self.counterterm_params]
         toret['sn'] = [nsC + name for name in self.stochastic_params]
         return toret
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# velocileptors-style tracers on top of an EMULATED perturbation-theory node
+# ----------------------------------------------------------------------------------------------------------------------
+def get_physical_stochastic_settings(tracer=None):
+    """Preset satellite fraction / velocity dispersion per tracer (values of the reference, full_shape.py:1077-1091)."""
+    if tracer is not None:
+        tracer = str(tracer).upper()
+        settings = {'BGS': {'fsat': 0.15, 'sigv': 150 * (10)**(1 / 3) * (1 + 0.2)**(1 / 2) / 70.},
+                    'LRG': {'fsat': 0.15, 'sigv': 150 * (10)**(1 / 3) * (1 + 0.8)**(1 / 2) / 70.},
+                    'ELG': {'fsat': 0.10, 'sigv': 150 * 2.1**(1 / 2) / 70.},
+                    'QSO': {'fsat': 0.03, 'sigv': 150 * (10)**(0.7 / 3) * (2.4)**(1 / 2) / 70.}}
+        try:
+            return settings[tracer]
+        except KeyError:
+            raise ValueError('unknown tracer: {}, please use any of {}'.format(tracer, list(settings.keys())))
+    return {'fsat': 0.1, 'sigv': 5.}
+
+
+class _BaseVelocileptorsTracer(BaseCalculator):
+    """Table-level velocileptors tracer (full_shape.py:1182-1186) fed by an :class:`desilike_amd.emulators.EmulatedCalculator` ``pt``
+    (the PT engines themselves are external CPU codes: SURVEY.md section 2 row 7).
+
+    Parameters: ``pt`` (EmulatedCalculator with 'pktable', 'sigma8', 'fsigma8'), ``k``, ``ells``, ``prior_basis`` ('physical' | 'standard'),
+    ``tracer`` / ``fsat`` / ``sigv`` / ``shotnoise`` (full_shape.py:1154-1157), ``freedom`` is not implemented.
+    """
+    _kind = 3   # DL_THEORY_EMULATED
+    _rept = False
+    _names = ['b1', 'b2', 'bs', 'b3', 'alpha0', 'alpha2', 'alpha4', 'alpha6', 'sn0', 'sn2', 'sn4']
+
+    @classmethod
+    def _default_params(cls, prior_basis='physical', pt=None, **kwargs):
+        params = {}
+        if pt is not None:
+            for name in pt.param_names:
+                params[name] = dict(pt.param_specs.get(name, dict(value=None)))
+        if prior_basis == 'physical':   # full_shape.py:1126-1134
+            params['b1p'] = dict(prior=dict(dist='uniform', limits=[0., 3.]), ref=dict(dist='norm', loc=1., scale=0.1))
+            for name in ['b2p', 'bsp']:
+                params[name] = dict(prior=dict(dist='norm', loc=0., scale=5.), ref=dict(dist='norm', loc=0., scale=1.))
+            params['b3p'] = dict(value=0., fixed=True, prior=dict(dist='norm', loc=0., scale=5.))
+            for name in ['alpha0p', 'alpha2p', 'alpha4p']:
+                params[name] = dict(prior=dict(dist='norm', loc=0., scale=12.5), ref=dict(dist='norm', loc=0., scale=1.))
+            params['alpha6p'] = dict(value=0., fixed=True)
+            for name in ['sn0p', 'sn2p', 'sn4p']:
+                params[name] = dict(prior=dict(dist='norm', loc=0., scale=2. if name == 'sn0p' else 5.), ref=dict(dist='norm', loc=0., scale=1.))
+        else:
+            params['b1'] = dict(value=1. if cls._rept else 0., prior=dict(limits=[-1., 5.]), ref=dict(dist='norm', loc=1., scale=0.1))
+            for name in cls._names[1:]:
+                params[name] = dict(value=0., prior=dict(dist='norm', loc=0., scale=100.), ref=dict(dist='norm', loc=0., scale=1.))
+        return params
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        from scipy import interpolate
+        init = self.init
+        self.pt = init.get('pt', None)
+        if self.pt is None:
+            raise ValueError('provide pt=EmulatedCalculator(...): the perturbation-theory engines are external CPU codes (out of scope)')
+        self.prior_basis = init.get('prior_basis', 'physical')
+        self.is_physical_prior = self.prior_basis == 'physical'
+        self.ells = tuple(init.get('ells', self.pt.ells))
+        k = init.get('k', None)
+        self.k = self.pt.k.copy() if k is None else np.array(k, dtype='f8')
+        self.z = self.pt.z
+        shotnoise = float(init.get('shotnoise', 1e4))
+        self.nd = 1e-4                                               # full_shape.py:1154
+        self.fsat = self.snd = self.sigv = 1.
+        if self.is_physical_prior:
+            settings = get_physical_stochastic_settings(tracer=init.get('tracer', None))
+            self.fsat = settings['fsat'] if init.get('fsat', None) is None else float(init['fsat'])
+            self.sigv = settings['sigv'] if init.get('sigv', None) is None else float(init['sigv'])
+            self.snd = shotnoise * self.nd                           # full_shape.py:1157
+        for ell, fix in [(4, ['alpha4', 'alpha6', 'sn4']), (2, ['alpha2', 'sn2'])]:   # full_shape.py:1148-1152
+            if ell not in self.ells:
+                for name in fix:
+                    name = name + 'p' if self.is_physical_prior else name
+                    if name in self.init.params: self.init.params[name].update(value=0., fixed=True)
+        # cubic interpolation pt.k -> k (full_shape.py:1312, 1598) as a constant matrix
+        index = [self.pt.ells.index(ell) for ell in self.ells]
+        self._ell_index = index
+        if self.k.shape == self.pt.k.shape and np.array_equal(self.k, self.pt.k):
+            self._interp = np.eye(self.k.size)
+        else:
+            self._interp = interpolate.interp1d(self.pt.k, np.eye(self.pt.k.size), kind='cubic', axis=0, fill_value='extrapolate')(self.k)
+        self._initialized = True
+        return self
+
+    def _fold(self):
+        """Theory vector P_ell(k) [n_ell * n_k] = fold . phi, phi[(h, m)] = basis_h mono_m."""
+        engine = self.pt.engines[self.pt.table_name]
+        nb = engine.n_basis
+        nellpt, nkpt = len(self.pt.ells), self.pt.k.size
+        if self.pt.table_name == 'pktable':
+            table = engine.basis_matrix().reshape(nb, nellpt, nkpt, 19)[:, self._ell_index]          # [h, ell, kpt, m]
+            fold = np.einsum('kq,hlqm->lkhm', self._interp, table)
+            return fold.reshape(len(self.ells) * self.k.size, nb * 19)
+        table = engine.basis_matrix().reshape(nb, nellpt, nkpt)[:, self._ell_index]
+        return np.einsum('kq,hlq->lkh', self._interp, table).reshape(len(self.ells) * self.k.size, nb)
+
+    def _theory_spec(self):
+        self.initialize()
+        if self.pt.table_name == 'pktable':
+            mode = {(True, False): 1, (True, True): 2, (False, False): 3, (False, True): 4}[(self.is_physical_prior, self._rept)]
+        else:
+            mode = 0
+        spec = dict(theory=np.array([self._kind], dtype='i4'), mono_mode=np.array([mode], dtype='i4'), vconst=[self.snd, self.fsat, self.sigv, self.nd])
+        spec.update(self.pt.engine_specs())
+        return spec
+
+    def _input_map(self):
+        suffix = 'p' if self.is_physical_prior else ''
+        toret = {'x': list(self.pt.param_names)}
+        if self.pt.table_name == 'pktable':
+            toret['vp'] = [name + suffix for name in self._names]
+        return toret
+
+    def _all_params(self):
+        self.initialize()
+        return self.params.copy()
+
+
+class LPTVelocileptorsTracerPowerSpectrumMultipoles(_BaseVelocileptorsTracer):
+    """Velocileptors LPT tracer multipoles (full_shape.py:1225-1313) from emulated tables."""
+    _rept = False
+
+
+class REPTVelocileptorsTracerPowerSpectrumMultipoles(_BaseVelocileptorsTracer):
+    """Velocileptors REPT tracer multipoles (full_shape.py:1496-1599, co-evolution shift 1479-1488) from emulated tables."""
+    _rept = True
+
+
+class EmulatedTracerPowerSpectrumMultipoles(_BaseVelocileptorsTracer):
+    """Any tracer theory emulated as a whole: ``pt`` emulates the array 'power' [n_ell, n_k] (EmulatedCalculator.calculate, emulators/__init__.py:408-409)."""
+
+    @classmethod
+    def _default_params(cls, pt=None, **kwargs):
+        return {name: dict(pt.param_specs.get(name, dict(value=None))) for name in (pt.param_names if pt is not None else [])}

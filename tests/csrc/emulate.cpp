@@ -20,6 +20,11 @@ int emu_config_set_i32(dl_config* cfg, const char* key, const int32_t* data, int
 const char* emu_last_error(void) { return g_err.c_str(); }
 
 static void run_point(const DlObsDev& o, const double* th, double* prow, double* trow) {
+    if (o.theory == 3) {   // emulated theory
+        std::vector<double> lds(dl_emu_shared_doubles(o.n_var));
+        dl_emu_point(o, th, lds.data(), prow, o.n_in + o.n_pass);
+        return;
+    }
     if (o.theory == 2) {   // BAO wiggle model
         std::vector<double> lds(dl_bao_shared_doubles(o.n_in));
         const int nthr = DL_FS_THREADS;

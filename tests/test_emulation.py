@@ -47,3 +47,15 @@ def test_emulated_bao_vs_reference(space):
     assert np.allclose(flat, g['flattheory'], rtol=1e-10, atol=1e-12 * np.abs(g['flattheory']).max())
     tol = 1e-10 * np.maximum(1., np.abs(g['loglikelihood']))
     assert (np.abs(loglike - g['loglikelihood']) <= tol).all(), np.abs((loglike - g['loglikelihood']) / g['loglikelihood']).max()
+
+
+def test_emulated_velocileptors_vs_reference():
+    """Taylor-emulated PT node + REPT velocileptors tracer: device features x folded matrix vs the reference running the same (polynomial) node."""
+    from test_host_api import make_cfg3
+    g, like = make_cfg3()
+    spec = like._spec({}, like._flatdata_list(), like.precision)
+    emu = Emulation(spec)
+    loglike, flat = emu.eval_batch(g['theta'])
+    assert np.allclose(flat, g['flattheory'], rtol=1e-11, atol=1e-8)
+    tol = 1e-10 * np.maximum(1., np.abs(g['loglikelihood']))
+    assert (np.abs(loglike - g['loglikelihood']) <= tol).all(), np.abs((loglike - g['loglikelihood']) / g['loglikelihood']).max()

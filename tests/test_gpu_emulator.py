@@ -1,0 +1,110 @@
+"""GPU (-m gpu): BASELINE config 3 -- emulated perturbation-theory tables (Taylor exact vs the reference fixture; MLP vs the NumPy oracle),
+velocileptors bias combination, analytic marginalisation of counter / stochastic terms, 4096 batched evaluations."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as orc
+from golden_utils import load_golden
+from test_host_api import make_cfg3
+from test_oracle_emulator import table_point
+from emulator_utils import taylor_state, EMU_PARAMS
+
+pytestmark = pytest.mark.gpu
+
+
+def test_taylor_emulated_velocileptors_vs_reference():
+    from desilike_amd import vmap
+    g, like = make_cfg3()
+    names = [str(n) for n in g['names']]
+    (logpost, derived), errors = vmap(like, errors='return', return_derived=True)({name: g['theta'][:, i] for i, name in enumerate(names)})
+    assert errors == {}
+    assert (np.abs(logpost - g['logposterior']) <= 1e-10 * np.maximum(1., np.abs(g['logposterior']))).all()
+    like._evaluate_dict({name: g['theta'][:3, i] for i, name in enumerate(names)}, (3,), errors='return', return_flattheory=True)
+    assert np.allclose(like.flattheory, g['flattheory'][:3], rtol=1e-11, atol=1e-8)
+
+
+def make_mlp_likelihood(marg=True, seed=1):
+    from desilike_amd.emulators import EmulatedCalculator, MLPEmulatorEngine
+    from desilike_amd.theories.galaxy_clustering import LPTVelocileptorsTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    g = load_golden('cfg3_velocileptors_table')
+    rng = np.random.RandomState(seed)
+    kpt = np.concatenate([[0.0005], np.geomspace(0.0015, 0.025, 20), np.arange(0.03, 0.51, 0.01)])
+    nk, nin, hidden = kpt.size, 3, [64, 64, 64]
+    base = 2e4 * (kpt / 0.05)**0.96 / (1. + (kpt / 0.02)**2.5)
+
+    def mlp(nout, ylimits, widths):
+        layers, last = [], nin
+        for width in widths + [nout]:
+            layers.append((rng.standard_normal((last, width)) / last**0.5, 0.1 * rng.standard_normal(width)))
+            last = width
+        return MLPEmulatorEngine(xlimits=[[0.9, 1.1], [0.9, 1.1], [-0.1, 0.1]], layers=layers, activation='silu', ylimits=ylimits)
+
+    amp = np.concatenate([[1.], 0.2 * np.ones(11), 0.05 * np.ones(4), [0., 0., 0.]])
+    ylim = np.stack([-(base[None, :, None] * amp) * np.ones((3, 1, 1)), (base[None, :, None] * amp) * np.ones((3, 1, 1))], axis=-1).reshape(-1, 2)
+    table = mlp(3 * nk * 19, ylim, hidden)
+    table.yshape = (3, nk, 19)
+    # stochastic monomials are exact constants (1, k^2, k^4 on the diagonal ells): zero output range + offset via ylimits lo = hi
+    yl = table.ylimits.copy().reshape(3, nk, 19, 2)
+    for ill in range(3): yl[ill, :, 16 + ill, :] = (kpt**(2 * ill))[:, None]
+    table.ylimits = yl.reshape(-1, 2)
+    engines = {'pktable': table, 'sigma8': mlp(1, [[0.7, 0.9]], [16]), 'fsigma8': mlp(1, [[0.4, 0.5]], [16])}
+    specs = {'qpar': dict(value=1., prior=dict(limits=[0.8, 1.2]), ref=dict(limits=[0.98, 1.02])), 'qper': dict(value=1., prior=dict(limits=[0.8, 1.2]), ref=dict(limits=[0.98, 1.02])),
+             'dm': dict(value=0., prior=dict(limits=[-1., 1.]), ref=dict(limits=[-0.05, 0.05]))}
+    pt = EmulatedCalculator(EMU_PARAMS, engines, k=kpt, ells=(0, 2, 4), z=0.8, param_specs=specs)
+    theory = LPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, tracer='ELG')
+    solved = ['alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p'] if marg else []
+    for name in solved:
+        theory.init.params[name].update(derived='.marg')
+    theory.init.params['sn4p'].update(fixed=True, value=0.3)
+    obs = TracerPowerSpectrumMultipolesObservable(data=g['obs0']['flatdata'], kedges=np.linspace(0.02, 0.2, 37), ells=(0, 2, 4), wmatrix={'resolution': 2}, theory=theory, shotnoise=8e3)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
+    return g, like, pt, theory, solved
+
+
+def oracle_flat(like, pt, theory, row, names, x):
+    p = dict(zip(names, row)); p.update(x)
+    xin = np.array([p[name] for name in EMU_PARAMS])
+    eng = pt.engines
+    pktable = orc.mlp_predict(xin, eng['pktable'].xlimits, eng['pktable'].layers, 'silu', eng['pktable'].ylimits).reshape(3, -1, 19)
+    sigma8 = orc.mlp_predict(xin, eng['sigma8'].xlimits, eng['sigma8'].layers, 'silu', eng['sigma8'].ylimits)[0]
+    fsigma8 = orc.mlp_predict(xin, eng['fsigma8'].xlimits, eng['fsigma8'].layers, 'silu', eng['fsigma8'].ylimits)[0]
+    params = {name: p.get(name, like.all_params[name].value) for name in ['b1p', 'b2p', 'bsp', 'b3p', 'alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p', 'sn4p']}
+    pars = orc.velocileptors_pars(params, sigma8, fsigma8 / sigma8, basis='physical', model='lpt', snd=theory.snd, fsat=theory.fsat, sigv=theory.sigv)
+    power = orc.interp1d(theory.k, pt.k, orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=theory.nd).T).T
+    wm = like.observables[0].wmatrix
+    return orc.window_apply(power, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout)
+
+
+def test_mlp_emulated_marginalised_4096():
+    g, like, pt, theory, solved = make_mlp_likelihood(marg=True)
+    names = like.varied_params.names()
+    assert like.solved_params.names() == solved
+    rng = np.random.RandomState(3)
+    theta = np.column_stack([np.clip(param.ref.sample(size=4096, random_state=rng), *param.prior.limits) for param in like.varied_params])
+    ctx = like._get_context()
+    loglike, logprior, status, xsolved = ctx.eval_batch_host(theta, return_solved=True)
+    assert (status == 0).all() and np.isfinite(loglike).all()
+    flatdata = like.flatdata
+    nsol = len(solved)
+    locs, scales = np.zeros(nsol), np.array([like.all_params[name].prior.scale for name in solved])
+    for i in range(0, 4096, 256):
+        f0 = oracle_flat(like, pt, theory, theta[i], names, {name: 0. for name in solved})
+        T = np.array([oracle_flat(like, pt, theory, theta[i], names, {n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
+        sol = orc.solve_marginalized(f0 - flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=locs, prior_scale=scales, marg_mask=np.ones(nsol, dtype='?'))
+        assert abs(loglike[i] - sol['loglikelihood']) <= 1e-9 * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
+        assert np.allclose(xsolved[i], sol['x'], rtol=1e-7, atol=1e-9)
+
+
+def test_mlp_emulated_not_marginalised():
+    g, like, pt, theory, solved = make_mlp_likelihood(marg=False)
+    names = like.varied_params.names()
+    rng = np.random.RandomState(4)
+    theta = np.column_stack([np.clip(param.ref.sample(size=64, random_state=rng), *param.prior.limits) for param in like.varied_params])
+    loglike, logprior, status, flat = like._get_context().eval_batch_host(theta, return_flattheory=True)
+    for i in range(0, 64, 8):
+        ref = oracle_flat(like, pt, theory, theta[i], names, {})
+        assert np.allclose(flat[i], ref, rtol=1e-11, atol=1e-12 * np.abs(ref).max())
+        logl = orc.gaussian_loglikelihood(ref, like.flatdata, like.precision)[0]
+        assert abs(loglike[i] - logl) <= 1e-10 * max(1., abs(logl))

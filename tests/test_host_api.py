@@ -144,3 +144,35 @@ def test_bao_spec_matches_reference_constants(space):
     for ic, col in enumerate(pcols):
         jc = [rnames[c] for c in rpcols].index(names[col])
         assert np.allclose(o['wmatrix'][:, n_in + ic], r['wmatrix'][:, n_in + jc], rtol=1e-12, atol=0)
+
+
+def make_cfg3(engine='taylor', data=None, marg=False):
+    """REPT velocileptors tracer on an emulated PT node = the stand-in node of fixture cfg3_velocileptors_table as an exact Taylor emulator."""
+    from desilike_amd.emulators import EmulatedCalculator, TaylorEmulatorEngine
+    from desilike_amd.theories.galaxy_clustering import REPTVelocileptorsTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    from emulator_utils import taylor_state, EMU_PARAMS
+    g = load_golden('cfg3_velocileptors_table')
+    c = g['obs0']
+    engines = {name: TaylorEmulatorEngine(**state) for name, state in taylor_state(g).items()}
+    specs = {'qpar': dict(value=1., prior=dict(limits=[0.8, 1.2]), ref=dict(limits=[0.98, 1.02])), 'qper': dict(value=1., prior=dict(limits=[0.8, 1.2]), ref=dict(limits=[0.98, 1.02])),
+             'dm': dict(value=0., prior=dict(limits=[-1., 1.]), ref=dict(limits=[-0.05, 0.05]))}
+    pt = EmulatedCalculator(EMU_PARAMS, engines, k=c['kpt'], ells=(0, 2, 4), z=0.8, param_specs=specs)
+    theory = REPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, tracer='LRG')
+    if marg:
+        for name in ['alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p']:
+            theory.init.params[name].update(derived='.marg')
+    obs = TracerPowerSpectrumMultipolesObservable(data=c['flatdata'] if data is None else data, kedges=np.linspace(0.02, 0.2, 37), ells=(0, 2, 4), wmatrix={'resolution': 2}, theory=theory, shotnoise=8e3)
+    return g, ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
+
+
+def test_emulated_velocileptors_spec():
+    g, like = make_cfg3()
+    assert like.varied_params.names() == [str(n) for n in g['names']]
+    assert np.allclose([p.prior.spec() for p in like.varied_params], g['priors'])
+    spec = like._spec({}, like._flatdata_list(), like.precision)
+    obs = spec['observables'][0]
+    assert obs['wmatrix'].shape == (108, 6 * 19) and int(obs['mono_mode'][0]) == 2
+    theory = like.observables[0].wmatrix.theory
+    assert np.allclose(theory.k, g['obs0']['k'], rtol=1e-14) and np.isclose(theory.sigv, g['obs0']['sigv']) and np.isclose(theory.snd, g['obs0']['snd'])
