@@ -1,0 +1,121 @@
+"""Fisher matrix of a Gaussian likelihood (reference: desilike/fisher.py:642-809, 63-640; differentiation.py).
+
+``Fisher(likelihood)(**center)`` evaluates the theory vector on the whole finite-difference stencil of the varied parameters as ONE GPU
+batch (the reference's ``Differentiation`` scatters the stencil points over MPI ranks, differentiation.py:394-398), forms
+``d(flatdiff)/d(theta)`` by central differences of step ``Parameter.delta`` and applies the reference's Gaussian finalisation
+(fisher.py:731-750): ``hessian = -dD P dD^T``, ``gradient = -dD P D``, ``offset = -D P D`` (no 1/2, as in the reference, line 746),
+plus the Gaussian prior terms (fisher.py:706-716).  The P x P algebra is init-time scale and stays on the host.
+"""
+import numpy as np
+
+
+class LikelihoodFisher(object):
+    """Gaussian approximation of a likelihood around ``center`` (fisher.py:63-640, the parts the hot path produces / consumes)."""
+
+    def __init__(self, center, params, offset=0., gradient=None, hessian=None, with_prior=False):
+        self._center = np.asarray(center, dtype='f8')
+        self._params = list(params)
+        n = self._center.size
+        self._offset = float(offset)
+        self._gradient = np.zeros(n) if gradient is None else np.asarray(gradient, dtype='f8')
+        self._hessian = np.zeros((n, n)) if hessian is None else np.asarray(hessian, dtype='f8')
+        self.with_prior = bool(with_prior)
+
+    def names(self):
+        return [str(param) for param in self._params]
+
+    def _solve(self):
+        return np.linalg.solve(self._hessian, self._gradient)   # fisher.py:216-221
+
+    @property
+    def chi2min(self):
+        flatdiff = -self._solve()   # fisher.py:224-227
+        return -2. * (self._offset + self._gradient.dot(flatdiff) + 0.5 * flatdiff.dot(self._hessian).dot(flatdiff))
+
+    def mean(self):
+        return self._center - self._solve()   # fisher.py:229-243
+
+    def center(self):
+        return self._center.copy()
+
+    def precision(self):
+        return -self._hessian
+
+    def covariance(self):
+        return np.linalg.inv(-self._hessian)
+
+    def std(self):
+        return np.diag(self.covariance())**0.5
+
+    def __add__(self, other):
+        """Sum of independent Gaussian likelihoods expanded around the same centre."""
+        assert self.names() == other.names() and np.allclose(self._center, other._center)
+        return LikelihoodFisher(self._center, self._params, self._offset + other._offset, self._gradient + other._gradient, self._hessian + other._hessian,
+                                with_prior=self.with_prior or other.with_prior)
+
+    def to_likelihood(self):
+        return FisherGaussianLikelihood(self)
+
+
+class FisherGaussianLikelihood(object):
+    """Gaussian-in-parameters likelihood built from a :class:`LikelihoodFisher` (likelihoods/galaxy_clustering/fisher.py:31-60 / fisher.py 'to_likelihood'):
+    ``loglikelihood(theta) = offset + g (theta - c) + 1/2 (theta - c) H (theta - c)``."""
+
+    def __init__(self, fisher):
+        self.fisher = fisher
+
+    def __call__(self, **params):
+        diff = np.array([params[name] for name in self.fisher.names()]) - self.fisher._center
+        return self.fisher._offset + self.fisher._gradient.dot(diff) + 0.5 * diff.dot(self.fisher._hessian).dot(diff)
+
+
+class Fisher(object):
+    """Estimate the Fisher matrix of ``likelihood`` (a Gaussian likelihood of this package) by finite differences on the GPU."""
+
+    def __init__(self, likelihood):
+        self.likelihood = likelihood
+        self.varied_params = likelihood.varied_params
+        if len(likelihood.solved_params):
+            raise NotImplementedError('Fisher with analytically solved parameters: vary them instead (they are linear)')
+
+    def __call__(self, **params):
+        like = self.likelihood
+        like.initialize()
+        varied = self.varied_params
+        center = np.array([params.get(param.name, param.value) for param in varied], dtype='f8')
+        steps = []
+        for param in varied:   # Parameter.delta = (value, step below, step above), parameter.py:898-915; limited by the prior bounds
+            _, lower, upper = param.delta
+            lower = min(lower, params.get(param.name, param.value) - param.prior.limits[0])
+            upper = min(upper, param.prior.limits[1] - params.get(param.name, param.value))
+            steps.append((lower, upper))
+        nvar = len(varied)
+        points = np.repeat(center[None, :], 2 * nvar + 1, axis=0)
+        for i, (lower, upper) in enumerate(steps):
+            points[1 + 2 * i, i] -= lower
+            points[2 + 2 * i, i] += upper
+        ctx = like._get_context()
+        loglike, logprior, status, flat = ctx.eval_batch_host(points, return_flattheory=True)   # one batch for the whole stencil
+        flatdiff = flat[0] - like.flatdata                                                       # likelihoods/base.py:659
+        flatderiv = np.array([(flat[2 + 2 * i] - flat[1 + 2 * i]) / (steps[i][0] + steps[i][1]) for i in range(nvar)])
+        precision = like.precision
+        if precision.ndim == 1:
+            diffp, derivp = flatdiff * precision, flatderiv * precision
+        else:
+            diffp, derivp = flatdiff.dot(precision), flatderiv.dot(precision)
+        offset = -diffp.dot(flatdiff.T)            # fisher.py:746 (no 1/2: reproduced as is)
+        gradient = -derivp.dot(flatdiff.T)         # fisher.py:747
+        hessian = -derivp.dot(flatderiv.T)         # fisher.py:748
+        likelihood_fisher = LikelihoodFisher(center, varied, offset=offset, gradient=gradient, hessian=hessian)
+        # Gaussian priors (fisher.py:706-716)
+        poffset, pgradient, phessian = 0., [], []
+        for param, value in zip(varied, center):
+            loc, scale = (param.prior.loc, param.prior.scale) if param.prior.dist == 'norm' else (0., np.inf)
+            prec = scale**(-2)
+            poffset += -0.5 * (value - loc)**2 * prec
+            pgradient.append(-(value - loc) * prec)
+            phessian.append(-prec)
+        prior_fisher = LikelihoodFisher(center, varied, offset=poffset, gradient=pgradient, hessian=np.diag(phessian), with_prior=True)
+        self.flatderiv, self.flatdiff = flatderiv, flatdiff
+        self.likelihood_fisher, self.prior_fisher = likelihood_fisher, prior_fisher
+        return likelihood_fisher + prior_fisher

@@ -473,3 +473,24 @@ def mlp_predict(x, xlimits, layers, activation, ylimits=None):
     if ylimits is not None:
         v = v * (ylimits[..., 1] - ylimits[..., 0]) + ylimits[..., 0]                              # conversion.py:79 (inverse)
     return v
+
+
+# ----------------------------------------------------------------------------------------------
+# a13: Fisher algebra                         fisher.py:731-750 (Gaussian finalize), 216-257 (LikelihoodFisher), 50-53 (FisherGaussianLikelihood)
+# The reference's driver (Differentiation + mpi scatter) needs mpi4py: not runnable here.  The algebra below is a line-by-line restatement;
+# it is pinned by finite differences of the reference-pinned likelihood (tests/test_oracle.py fixtures) in tests/test_fisher.py.
+# ----------------------------------------------------------------------------------------------
+def fisher_gaussian(flatdiff, flatderiv, precision):
+    """flatdiff [n], flatderiv [P, n] = d(flatdiff)/d(theta) -> offset, gradient, hessian (fisher.py:739-748; NOTE offset = -d P d, no 1/2: line 746)."""
+    if precision.ndim == 1:
+        diffp, derivp = flatdiff * precision, flatderiv * precision
+    else:
+        diffp, derivp = flatdiff.dot(precision), flatderiv.dot(precision)
+    return -diffp.dot(flatdiff.T), -derivp.dot(flatdiff.T), -derivp.dot(flatderiv.T)
+
+
+def fisher_mean_chi2min(center, offset, gradient, hessian):
+    """LikelihoodFisher.mean / chi2min, fisher.py:216-232."""
+    solve = np.linalg.solve(hessian, gradient)
+    flatdiff = -solve
+    return center - solve, -2. * (offset + gradient.dot(flatdiff) + 0.5 * flatdiff.dot(hessian).dot(flatdiff))

@@ -1,0 +1,59 @@
+"""Fisher algebra (fisher.py:731-750, 216-257): CPU test of the restatement; GPU test of the batched finite-difference driver."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as orc
+
+
+def test_fisher_algebra_linear_model():
+    # linear model: Fisher is exact; mean = generalised least squares solution, chi2min = residual chi2
+    rng = np.random.RandomState(0)
+    n, p = 40, 3
+    A = rng.standard_normal((p, n))
+    data = rng.standard_normal(n) * 2.
+    C = rng.standard_normal((n, n)); prec = np.linalg.inv(C.dot(C.T) + n * np.eye(n))
+    center = np.array([0.3, -0.2, 1.])
+    flatdiff = center.dot(A) - data
+    offset, gradient, hessian = orc.fisher_gaussian(flatdiff, A, prec)
+    assert np.isclose(offset, -flatdiff.dot(prec).dot(flatdiff))          # no 1/2: fisher.py:746
+    mean, chi2min = orc.fisher_mean_chi2min(center, offset, gradient, hessian)
+    gls = np.linalg.solve(A.dot(prec).dot(A.T), A.dot(prec).dot(data))
+    assert np.allclose(mean, gls, rtol=1e-10)
+    # with the reference's convention chi2min = -2 (offset + ...) uses offset = -chi2 (not -chi2 / 2): reproduce as is
+    resid = gls.dot(A) - data
+    d = -np.linalg.solve(hessian, gradient)
+    assert np.isclose(chi2min, -2. * (offset + gradient.dot(d) + 0.5 * d.dot(hessian).dot(d)))
+    from desilike_amd.fisher import LikelihoodFisher
+    fisher = LikelihoodFisher(center, ['a', 'b', 'c'], offset, gradient, hessian)
+    assert np.allclose(fisher.mean(), mean) and np.isclose(fisher.chi2min, chi2min)
+    assert np.allclose(fisher.covariance(), np.linalg.inv(A.dot(prec).dot(A.T)))
+
+
+@pytest.mark.gpu
+def test_fisher_driver_on_gpu():
+    from test_host_api import make_cfg2
+    from desilike_amd.fisher import Fisher
+    g, like = make_cfg2(dense=False)
+    fisher = Fisher(like)
+    center = dict(qpar=1., qper=1., dm=0., df=1., b1=2., sn0=0.)
+    result = fisher(**center)
+    names = like.varied_params.names()
+    # derivative of the theory vector against the oracle-pinned path: finite differences of the loglikelihood itself
+    ctx = like._get_context()
+    x0 = np.array([center[name] for name in names])
+    eps = np.array([1e-4, 1e-4, 1e-3, 1e-3, 1e-3, 1e-2])
+    grad = np.zeros(6)
+    for i in range(6):
+        up, dn = x0.copy(), x0.copy()
+        up[i] += eps[i]; dn[i] -= eps[i]
+        ll = ctx.eval_batch_host(np.array([up, dn]))[0]
+        grad[i] = (ll[0] - ll[1]) / (2 * eps[i])
+    # d(logL)/d(theta) = -dD P D = likelihood gradient (fisher.py:747)
+    assert np.allclose(fisher.likelihood_fisher._gradient, grad, rtol=2e-3, atol=1e-6 * np.abs(grad).max())
+    offset, gradient, hessian = orc.fisher_gaussian(fisher.flatdiff, fisher.flatderiv, like.precision)
+    assert np.allclose(fisher.likelihood_fisher._hessian, hessian, rtol=1e-12) and np.isclose(fisher.likelihood_fisher._offset, offset, rtol=1e-12, atol=1e-12)
+    # data generated at b1 = 2 -> centre is the best fit: zero gradient, chi2min = 0, positive-definite precision
+    assert np.abs(result.mean() - x0).max() < 1e-6 and abs(result.chi2min) < 1e-8
+    assert (np.linalg.eigvalsh(result.precision()) > 0).all()
+    # sn0 has a Gaussian prior (scale 1000): its precision adds to the diagonal (fisher.py:712-714)
+    assert np.isclose(result.precision()[5, 5] - fisher.likelihood_fisher.precision()[5, 5], 1e-6, rtol=1e-9)
