@@ -146,7 +146,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     int n = ctx->n_data;
     int K = (int)col;
     ctx->K_pad = round_up(K, 32);
-    ctx->N_pad = round_up(n, 32);
+    ctx->N_pad = round_up(n, 128);   // N tile of the tiled GEMM
     // ---- precision -> Cholesky factor (likelihoods/base.py:13-17: chi2 = d P d = |L^T d|^2) ----
     const auto& prec = cfg->F("precision");
     std::vector<double> L((size_t)n * n, 0.);
@@ -319,7 +319,8 @@ static int dl_reserve(dl_ctx* ctx, int64_t B) {
     ctx->cap = 0;
     const size_t R = 1 + ctx->n_var;   // rows per point: power + point-dependent derivative rows (analytic marginalisation)
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->power_ws, (size_t)need * R * ctx->K_pad * sizeof(double)));
-    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->delta_ws, (size_t)need * R * ctx->N_pad * sizeof(double)));
+    // residual slabs: split-K partial sums, S * M <= M + 16384 + 64 rows (dl_gemm_tiled_splits)
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->delta_ws, ((size_t)need * R + 16384 + 2048) * ctx->N_pad * sizeof(double)));
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->flat_ws, (size_t)need * ctx->N_pad * sizeof(double)));
     // the K padding columns of the power buffer are never written by the theory kernel and must be finite
     DL_HIP_CHECK(ctx, hipMemset(ctx->power_ws, 0, (size_t)need * R * ctx->K_pad * sizeof(double)));
@@ -345,6 +346,9 @@ int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logli
         dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream);
         if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[1], stream));
         bool need_flat = ctx->any_transform || flattheory_dev != nullptr;
+        int n_slabs = 1, cps = 0;
+        int64_t slab_stride = 0;
+        const double* fin_bias = nullptr;   // the direct GEMM (transform path) adds its bias itself
         if (need_flat) {
             // flattheory = W . power + bias (window.py:459-473), then optional cubic transform (power_spectrum.py:402-404)
             dl_launch_window_gemm(ctx->power_ws, (int64_t)R * ctx->K_pad, ctx->wt_full_dev, ctx->K_pad, ctx->bias_full_dev, ctx->flat_ws, ctx->N_pad, nb, ctx->N_pad,
@@ -359,17 +363,20 @@ int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logli
             dl_launch_window_gemm(ctx->flat_ws, ctx->N_pad, ctx->wh_dev, ctx->N_pad, ctx->bias_wh_dev, ctx->delta_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad, ctx->N_pad,
                                   1, stream);
         } else {
-            // dtilde = (L^T W) . power + L^T (bias - flatdata): window convolution and precision folded in one fp64 MFMA GEMM
-            dl_launch_window_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, ctx->N_pad, nb * R, ctx->N_pad, ctx->N_pad,
-                                  ctx->K_pad, R, stream);
+            // dtilde = (L^T W) . power + L^T (bias - flatdata): window convolution and precision folded in one fp64 MFMA GEMM (split-K slabs, bias added by finalize)
+            n_slabs = dl_gemm_tiled_splits(nb * R, ctx->N_pad, ctx->K_pad, &cps);
+            slab_stride = (int64_t)nb * R * ctx->N_pad;
+            fin_bias = ctx->bias_white_dev;
+            dl_launch_window_gemm_tiled(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->delta_ws, slab_stride, ctx->N_pad, nb * R, ctx->N_pad, ctx->K_pad, n_slabs, cps,
+                                        stream);
         }
         if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
         if (ctx->n_solved > 0)
-            dl_launch_finalize_marg(ctx->delta_ws, ctx->N_pad, n, R, ctx->marg, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr,
+            dl_launch_finalize_marg(ctx->delta_ws, ctx->N_pad, n, R, n_slabs, slab_stride, fin_bias, ctx->marg, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr,
                                     logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr,
                                     solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr, stream);
         else
-            dl_launch_finalize(ctx->delta_ws, ctx->N_pad, n, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
+            dl_launch_finalize(ctx->delta_ws, ctx->N_pad, n, n_slabs, slab_stride, fin_bias, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
                                status_dev ? status_dev + b0 : nullptr, stream);
         if (prof) { DL_HIP_CHECK(ctx, hipEventRecord(ev[3], stream)); ctx->prof_calls++; }
     }

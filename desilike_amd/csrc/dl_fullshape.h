@@ -106,6 +106,8 @@ struct DlObsDev {
     const double *ct_matrix, *sn_matrix;           // [n_ell, n_kin, n_ct], [n_ell, n_kin, n_sn]
 };
 
+DL_HD int dl_fs_n_dd0(const DlObsDev& o) { return (o.n_var > 0 && o.n_ct > 0) ? o.n_kin : 0; }   // P_dd,l=0 kept for the derivative rows
+
 // Layout of the small per-point scratch `pt` (doubles) in workgroup-shared memory
 enum {
     DL_PT_QPAR = 0, DL_PT_QPER, DL_PT_JAC, DL_PT_F, DL_PT_B1X, DL_PT_B1Y, DL_PT_SN0ND, DL_PT_DAMP,
@@ -129,16 +131,18 @@ struct DlFsShared {
     double* pt;    // [DL_PT_SIZE]
 };
 
-// out [n_in] + dd0 [n_kin <= n_in] alias y, M, z
+// out [n_in] + dd0 [n_kin <= n_in] alias y, M, z.  Sized to keep 4 workgroups per CU at the benchmark shape (4 x 38.9 KB <= 160 KB).
 DL_HD size_t dl_fs_work_doubles(int n_t, int n_in) { size_t w = 3 * (size_t)n_t; if (2 * (size_t)n_in > w) w = 2 * (size_t)n_in; return (w + 1) & ~(size_t)1; }
+DL_HD size_t dl_fs_work_doubles(int n_t, int n_in, int n_dd0) { size_t w = 3 * (size_t)n_t; if ((size_t)n_in + n_dd0 > w) w = (size_t)n_in + n_dd0; return (w + 1) & ~(size_t)1; }
 DL_HD size_t dl_fs_shared_doubles(int n_t, int n_in) { return 4 * (size_t)n_t + dl_fs_work_doubles(n_t, n_in) + DL_PT_SIZE; }
+DL_HD size_t dl_fs_shared_doubles_obs(const DlObsDev& o) { return 4 * (size_t)o.n_t + dl_fs_work_doubles(o.n_t, o.n_in, dl_fs_n_dd0(o)) + DL_PT_SIZE; }
 
-DL_HD DlFsShared dl_fs_shared_carve(double* base, int n_t, int n_in) {
+DL_HD DlFsShared dl_fs_shared_carve(double* base, int n_t, int n_in, int n_dd0 = -1) {
     DlFsShared s;
     s.coef = base;                       // first: keeps the 32-byte coefficient groups 16-byte aligned
     s.y = base + 4 * (size_t)n_t; s.M = base + 5 * (size_t)n_t; s.z = base + 6 * (size_t)n_t;
     s.out = s.y;
-    s.pt = s.y + dl_fs_work_doubles(n_t, n_in);
+    s.pt = s.y + (n_dd0 < 0 ? dl_fs_work_doubles(n_t, n_in) : dl_fs_work_doubles(n_t, n_in, n_dd0));
     return s;
 }
 

@@ -25,8 +25,14 @@ struct DlMargDev {
     double x0[DL_MAX_SOLVED], loc[DL_MAX_SOLVED], prec[DL_MAX_SOLVED];
     const double* tconst;                // [n_s, N_pad] point-independent part of Tt_s = L^T W dpower/dx_s
 };
-void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, const DlMargDev& mg, const double* theta, int n_params, const double* priors,
-                             int64_t B, double* loglike, double* logprior, int32_t* status, double* solved, hipStream_t stream);
+void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride, const double* bias, const DlMargDev& mg,
+                             const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, double* solved,
+                             hipStream_t stream);
 void dl_launch_transform(double* flat, int64_t ld, const double* data, const int32_t* transform, int n, int64_t B, hipStream_t stream);
-void dl_launch_finalize(const double* dtilde, int64_t ld, int n, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
-                        int32_t* status, hipStream_t stream);
+// tiled split-K variant: writes n_splits partial slabs (no bias); N_pad multiple of 128, K_pad multiple of 16
+int dl_gemm_tiled_splits(int64_t M, int N_pad, int K_pad, int* chunks_per_split);
+void dl_launch_window_gemm_tiled(const double* A, int64_t lda, const double* Wt, int64_t ldw, double* slabs, int64_t slab_stride, int64_t ldc, int64_t M, int N_pad, int K_pad,
+                                 int n_splits, int chunks_per_split, hipStream_t stream);
+// residual of a row = bias (may be null) + sum of the n_slabs partial slabs (slab_stride doubles apart)
+void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, int64_t slab_stride, const double* bias, const double* theta, int n_params,
+                        const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, hipStream_t stream);

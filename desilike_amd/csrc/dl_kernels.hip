@@ -7,6 +7,7 @@
 //   dl_finalize_kernel  : chi2 = |whitened residual|^2 by wavefront shuffles, priors, status (rows a8 + a9).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "dl_fullshape.h"
@@ -22,7 +23,7 @@ __global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_kernel(const Dl
                                                                      int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
-    const DlFsShared s = dl_fs_shared_carve(lds, o.n_t, o.n_in);
+    const DlFsShared s = dl_fs_shared_carve(lds, o.n_t, o.n_in, dl_fs_n_dd0(o));
     const double* th = theta + (size_t)b * n_params;
     const int tid = threadIdx.x, nthr = DL_FS_THREADS;
     if (stop_after == -1) return;  // stop_after != 0: timing diagnostics only (DL_FS_STOP), outputs are then incomplete
@@ -88,7 +89,7 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
             hipLaunchKernelGGL(dl_bao_kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power);
             continue;
         }
-        size_t shmem = dl_fs_shared_doubles(obs_host[i].n_t, obs_host[i].n_in) * sizeof(double);
+        size_t shmem = dl_fs_shared_doubles_obs(obs_host[i]) * sizeof(double);
         auto launch = [&](auto kernel) {
             if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  // e.g. 2000-knot BAO tables
             hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shmem, stream, obs_host[i], theta, n_params, power, ld_power, tables, ld_tables, stop_after);
@@ -199,6 +200,40 @@ void dl_launch_window_gemm(const double* A, int64_t lda, const double* Wt, int64
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tiled split-K fp64 MFMA GEMM (main chi2 path):  slab[s][M, N] = A[M, Ks] . Wt[N, Ks]^T over the K-slice Ks of split s.
+//   workgroup = 8 waves = 64 (M) x 128 (N) output tile; waves arranged 2 (M) x 4 (N), each 32 x 32 = 2 x 2 MFMA tiles (4 accumulators).
+//   The kernel is bound by the LATENCY of operand delivery, not by MFMA issue or bandwidth (measured: ~2 us per dependent global round trip
+//   with a 16-wide K step, whatever the number of workgroups), so K advances in "panels" of up to 96 columns = 6 x 16: a thread issues all
+//   18 16-byte loads of a panel back to back (full 128-byte row segments, 8 lanes x 16 B), the panel is staged once through LDS
+//   (192 rows x 98 doubles = 147 KB: one workgroup per CU; row stride = 4 banks mod 64 keeps the 32 lanes of a ds_read_b64 group on distinct banks)
+//   and multiplied with 96 MFMAs per wave; the loads of the next panel are in flight meanwhile.  One round trip is exposed per workgroup.
+//   Split-K over blockIdx.z keeps ~one workgroup per CU at small M; the partial slabs are summed by the finalize kernels
+//   (deterministic order, no atomics).
+// ------------------------------------------------------------------------------------------------
+#include "dl_gemm_tiled.h"
+
+// number of K splits: ~one workgroup per CU at small M, whole panels per split
+int dl_gemm_tiled_splits(int64_t M, int N_pad, int K_pad, int* chunks_per_split) {
+    int64_t mtiles = (M + DL_GT_M - 1) / DL_GT_M, ntiles = N_pad / DL_GT_N;
+    int nchunks = K_pad / DL_GT_K;
+    static const int target = getenv("DL_GEMM_WGS") ? atoi(getenv("DL_GEMM_WGS")) : 256;   // tuning knob (<= 256: the slab workspace is sized for that)
+    int64_t want = std::max<int64_t>(target / (mtiles * ntiles), 1);
+    int S = (int)std::min<int64_t>(want, std::min(nchunks, 32));
+    int cps = (nchunks + S - 1) / S;
+    if (S > 1) cps = (cps + DL_GT_PANEL - 1) / DL_GT_PANEL * DL_GT_PANEL;   // whole panels
+    *chunks_per_split = cps;
+    return (nchunks + cps - 1) / cps;
+}
+
+void dl_launch_window_gemm_tiled(const double* A, int64_t lda, const double* Wt, int64_t ldw, double* slabs, int64_t slab_stride, int64_t ldc, int64_t M, int N_pad, int K_pad,
+                                 int n_splits, int chunks_per_split, hipStream_t stream) {
+    dim3 grid((unsigned)((M + DL_GT_M - 1) / DL_GT_M), (unsigned)(N_pad / DL_GT_N), (unsigned)n_splits);
+    static bool optin = false;
+    if (!optin) { (void)hipFuncSetAttribute((const void*)dl_window_gemm_tiled_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_GT_LDS_BYTES); optin = true; }
+    hipLaunchKernelGGL((dl_window_gemm_tiled_kernel<true, true, true>), grid, dim3(512), DL_GT_LDS_BYTES, stream, A, lda, Wt, ldw, slabs, slab_stride, ldc, (int)M, chunks_per_split, K_pad / DL_GT_K);
+}
+
+// ------------------------------------------------------------------------------------------------
 // observable transform (power_spectrum.py:402-404): flat -> (3 (flat / data)^(1/3) - 2) data, in place
 // ------------------------------------------------------------------------------------------------
 __global__ void dl_transform_kernel(double* __restrict__ flat, int64_t ld, const double* __restrict__ data, const int32_t* __restrict__ transform, int n, int64_t B) {
@@ -227,7 +262,8 @@ __device__ __forceinline__ double dl_wave_sum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void dl_finalize_kernel(const double* __restrict__ dtilde, int64_t ld, int n, const double* __restrict__ theta, int n_params,
+__global__ __launch_bounds__(256) void dl_finalize_kernel(const double* __restrict__ dtilde, int64_t ld, int n, int n_slabs, int64_t slab_stride,
+                                                          const double* __restrict__ bias, const double* __restrict__ theta, int n_params,
                                                           const double* __restrict__ priors, int64_t B, double* __restrict__ loglike,
                                                           double* __restrict__ logprior, int32_t* __restrict__ status) {
     const int lane = threadIdx.x & 63;
@@ -235,7 +271,17 @@ __global__ __launch_bounds__(256) void dl_finalize_kernel(const double* __restri
     if (b >= B) return;
     const double* row = dtilde + (size_t)b * ld;
     double sum = 0.;
-    for (int j = lane; j < n; j += 64) { double v = row[j]; sum = fma(v, v, sum); }
+    for (int j = lane; j < n; j += 64) {
+        double v = bias ? bias[j] : 0.;
+        int sl = 0;
+        for (; sl + 4 <= n_slabs; sl += 4) {   // independent loads in flight; fixed summation order: deterministic
+            double t0 = row[(size_t)sl * slab_stride + j], t1 = row[(size_t)(sl + 1) * slab_stride + j];
+            double t2 = row[(size_t)(sl + 2) * slab_stride + j], t3 = row[(size_t)(sl + 3) * slab_stride + j];
+            v += (t0 + t1) + (t2 + t3);
+        }
+        for (; sl < n_slabs; ++sl) v += row[(size_t)sl * slab_stride + j];
+        sum = fma(v, v, sum);
+    }
     sum = dl_wave_sum(sum);
     // priors: lanes stride over parameters
     double lp = 0.;
@@ -264,9 +310,10 @@ __global__ __launch_bounds__(256) void dl_finalize_kernel(const double* __restri
     }
 }
 
-void dl_launch_finalize(const double* dtilde, int64_t ld, int n, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
-                        int32_t* status, hipStream_t stream) {
-    hipLaunchKernelGGL(dl_finalize_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, theta, n_params, priors, B, loglike, logprior, status);
+void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, int64_t slab_stride, const double* bias, const double* theta, int n_params,
+                        const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, hipStream_t stream) {
+    hipLaunchKernelGGL(dl_finalize_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, n_slabs, slab_stride, bias, theta, n_params, priors, B, loglike,
+                       logprior, status);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -276,7 +323,8 @@ void dl_launch_finalize(const double* dtilde, int64_t ld, int n, const double* t
 //   loglike = -1/2 |dt|^2 + 1/2 dx H_L dx + g_L dx - 1/2 logdet(-H[marg, marg]),  logprior += sum -1/2 (x0 + dx - loc)^2 prec.
 // Tt_s = tconst[s] (+ row 1 + var_slot[s] of the point when the derivative depends on the point).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __restrict__ dtilde, int64_t ld, int n, int rows_per_point, DlMargDev mg,
+__global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __restrict__ dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride,
+                                                               const double* __restrict__ bias, DlMargDev mg,
                                                                const double* __restrict__ theta, int n_params, const double* __restrict__ priors, int64_t B,
                                                                double* __restrict__ loglike, double* __restrict__ logprior, int32_t* __restrict__ status,
                                                                double* __restrict__ solved) {
@@ -291,7 +339,12 @@ __global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __r
 #pragma unroll
     for (int q = 0; q < DL_MARG_NJ; ++q) {
         int j = lane + 64 * q;
-        dj[q] = (j < n) ? row0[j] : 0.;
+        double v0 = 0.;
+        if (j < n) {
+            v0 = bias ? bias[j] : 0.;
+            for (int sl = 0; sl < n_slabs; ++sl) v0 += row0[(size_t)sl * slab_stride + j];
+        }
+        dj[q] = v0;
         chi2 = fma(dj[q], dj[q], chi2);
     }
     chi2 = dl_wave_sum(chi2);
@@ -305,7 +358,8 @@ __global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __r
             double v = 0.;
             if (j < n) {
                 v = mg.tconst[(size_t)s * ld + j];
-                if (mg.var_slot[s] >= 0) v += row0[(size_t)(1 + mg.var_slot[s]) * ld + j];
+                if (mg.var_slot[s] >= 0)
+                    for (int sl = 0; sl < n_slabs; ++sl) v += row0[(size_t)sl * slab_stride + (size_t)(1 + mg.var_slot[s]) * ld + j];
             }
             ts[q] = v;
         }
@@ -321,7 +375,8 @@ __global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __r
                 double v = 0.;
                 if (j < n) {
                     v = mg.tconst[(size_t)t * ld + j];
-                    if (mg.var_slot[t] >= 0) v += row0[(size_t)(1 + mg.var_slot[t]) * ld + j];
+                    if (mg.var_slot[t] >= 0)
+                        for (int sl = 0; sl < n_slabs; ++sl) v += row0[(size_t)sl * slab_stride + (size_t)(1 + mg.var_slot[t]) * ld + j];
                 }
                 a2 = fma(ts[q], v, a2);
             }
@@ -427,8 +482,9 @@ __global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __r
     }
 }
 
-void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, const DlMargDev& mg, const double* theta, int n_params, const double* priors,
-                             int64_t B, double* loglike, double* logprior, int32_t* status, double* solved, hipStream_t stream) {
-    hipLaunchKernelGGL(dl_finalize_marg_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, mg, theta, n_params, priors, B, loglike,
-                       logprior, status, solved);
+void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride, const double* bias, const DlMargDev& mg,
+                             const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, double* solved,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(dl_finalize_marg_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
+                       n_params, priors, B, loglike, logprior, status, solved);
 }
