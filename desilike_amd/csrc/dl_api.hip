@@ -145,7 +145,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     ctx->n_data = row;
     int n = ctx->n_data;
     int K = (int)col;
-    ctx->K_pad = round_up(K, 32);
+    ctx->K_pad = round_up(K, 128);   // whole 128-wide panels of the chi2 GEMM (dl_chi2_gemm.h); padding columns are zero in both operands
     ctx->N_pad = round_up(n, 128);   // N tile of the tiled GEMM
     // ---- precision -> Cholesky factor (likelihoods/base.py:13-17: chi2 = d P d = |L^T d|^2) ----
     const auto& prec = cfg->F("precision");
@@ -358,7 +358,12 @@ int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logli
                 DL_HIP_CHECK(ctx, hipMemcpy2DAsync(flattheory_dev + (size_t)b0 * n, (size_t)n * sizeof(double), ctx->flat_ws, (size_t)ctx->N_pad * sizeof(double),
                                                    (size_t)n * sizeof(double), (size_t)nb, hipMemcpyDeviceToDevice, stream));
         }
-        if (ctx->any_transform) {
+        // plain likelihood: chi2 is additive over the columns of the whitened residual -> column-split GEMM that emits partial chi2 only
+        static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 8192;   // above: split-K slabs + finalize (tuning knob)
+        const bool chi2_path = !ctx->any_transform && ctx->n_solved == 0 && nb <= chi2_max_rows;
+        if (chi2_path) {
+            dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad, stream);
+        } else if (ctx->any_transform) {
             // dtilde = L^T (flattheory - flatdata)
             dl_launch_window_gemm(ctx->flat_ws, ctx->N_pad, ctx->wh_dev, ctx->N_pad, ctx->bias_wh_dev, ctx->delta_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad, ctx->N_pad,
                                   1, stream);
@@ -371,7 +376,10 @@ int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logli
                                         stream);
         }
         if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
-        if (ctx->n_solved > 0)
+        if (chi2_path)
+            dl_launch_finalize_part(ctx->delta_ws, ctx->N_pad / 16, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
+                                    status_dev ? status_dev + b0 : nullptr, stream);
+        else if (ctx->n_solved > 0)
             dl_launch_finalize_marg(ctx->delta_ws, ctx->N_pad, n, R, n_slabs, slab_stride, fin_bias, ctx->marg, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr,
                                     logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr,
                                     solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr, stream);

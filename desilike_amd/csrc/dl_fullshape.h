@@ -28,8 +28,12 @@
 
 #if defined(__HIPCC__)
 #define DL_HD __host__ __device__ __forceinline__
+// pins the order of an unrolled loop: the four accumulators must be complete, and no memory access may move across (without it the scheduler
+// turns the convolution below into four serial chains over the whole window, with the window held in 120 VGPRs)
+#define DL_PIN4(a, b, c, d) __asm__ volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
 #else
 #define DL_HD inline
+#define DL_PIN4(a, b, c, d)
 #endif
 
 #define DL_MAX_ELL 5
@@ -45,6 +49,13 @@
 #define DL_N_MONO 19       // bias monomials (full_shape.py:1185)
 #define DL_MAX_PASS 16     // pass-through columns: linear (broadband) parameters appended to the theory vector
 #define DL_MAX_SOLVED 16   // analytically solved (marginalised / best-fit) linear parameters
+#define DL_FIR_D 28        // half-width of the convolution that inverts the uniform-knot spline system: |mu|^28 = 1e-16, mu = sqrt(3) - 2
+#define DL_FIR_PAD 32      // zeros either side of the knot values in LDS (>= DL_FIR_D + 4)
+// taps t_e, e = 0 .. DL_FIR_D, of  w_j = sum_e t_|e| y_{j+e}:  w solves w_{j-1} + 4 w_j + w_{j+1} = y_{j-1} - 2 y_j + y_{j+1} on the infinite grid:
+// t_0 = 2 c (mu - 1), t_e = c (1 - mu)^2 mu^(e-1), c = 1 / (2 sqrt 3)
+#define DL_FIR_TAPS { -0.7320508075688774, 0.4641016151377547, -0.12435565298214114, 0.033320996790809666, -0.008928334181097484, 0.002392339933580261, -0.0006410255532235571, 0.0001717622793139658, -4.602356403230609e-05, 1.2331976815258487e-05, -3.3043432287278414e-06, 8.85396099652874e-07, -2.3724116988365352e-07, 6.356857988173978e-08, -1.7033149643305495e-08, 4.564018691482174e-09, -1.2229251226231984e-09, 3.2768179901061786e-10, -8.780207341927256e-11, 2.3526494666472232e-11, -6.303905246616353e-12, 1.6891263199931699e-12, -4.5260003335632413e-13, 1.212738134321263e-13, -3.24952203721809e-14, 8.707068056597241e-15, -2.333051854208057e-15, 6.251393602349824e-16, -1.675055867318723e-16 }
+#define DL_FIR_MU (-0.2679491924311228)       // sqrt(3) - 2
+#define DL_FIR_LN_ABS_MU (-1.3169578969248164)
 #define DL_SEG_QMAX 12     // dot-product terms per thread: warm-up length <= DL_SEG_PARTS * DL_SEG_QMAX = 48
 
 struct DlInput {
@@ -60,7 +71,8 @@ struct DlObsDev {
     int32_t n_ell, n_kin, n_mu, n_t;
     int32_t n_in, ell0, n_ct, n_sn;
     int32_t seg_len, seg_warm, n_seg, fixed_spline;
-    int32_t uniform_knots, pad0;     // knots uniform in log10 k (to < 1e-6 of the spacing): interval index = floor of the scaled abscissa
+    int32_t uniform_knots, toeplitz; // knots uniform in log10 k (to < 1e-6 of the spacing): interval index = floor of the scaled abscissa;
+                                     // toeplitz: uniform to rounding (< 1e-11 of the spacing): spline moments by the convolution dl_fs_phase2_fir
     int64_t col_offset;  // first column of this observable in a row of the (concatenated) power buffer
     // analytic marginalisation: each point owns 1 + n_var consecutive rows of the power buffer; row 1 + v holds
     // d(power) / d(solved parameter of variable slot v) (counter terms: the derivative depends on the point through P_dd,l=0)
@@ -118,7 +130,8 @@ enum {
     DL_PT_SN = DL_PT_CT + DL_MAX_EFT,               // sn / nd
     DL_PT_OM = DL_PT_SN + DL_MAX_EFT,               // [n_mu][8]: jac w_l(mu) (b1X + f mu'^2)(b1Y + f mu'^2) for l < 5, [5] = jac w_{l=0}: fused weights
     DL_PT_W3 = DL_PT_OM + 8 * DL_MAX_MU,            // [n_mu][5][3]: jac w_l(mu) (1, f mu'^2, (f mu'^2)^2): separate-table weights
-    DL_PT_PART = DL_PT_W3 + 15 * DL_MAX_MU,         // [DL_FS_THREADS] partial dot products of the segmented sweeps
+    DL_PT_LQH = DL_PT_W3 + 15 * DL_MAX_MU,          // log10(F_m / qper) inv_hx: the shift in units of the knot spacing (uniform knots)
+    DL_PT_PART = DL_PT_LQH + DL_MAX_MU,             // [DL_FS_THREADS] partial dot products of the segmented sweeps / mu^k table of the convolution path
     DL_PT_SIZE = DL_PT_PART + DL_FS_THREADS
 };
 
@@ -137,12 +150,15 @@ DL_HD size_t dl_fs_work_doubles(int n_t, int n_in, int n_dd0) { size_t w = 3 * (
 DL_HD size_t dl_fs_shared_doubles(int n_t, int n_in) { return 4 * (size_t)n_t + dl_fs_work_doubles(n_t, n_in) + DL_PT_SIZE; }
 DL_HD size_t dl_fs_shared_doubles_obs(const DlObsDev& o) { return 4 * (size_t)o.n_t + dl_fs_work_doubles(o.n_t, o.n_in, dl_fs_n_dd0(o)) + DL_PT_SIZE; }
 
-DL_HD DlFsShared dl_fs_shared_carve(double* base, int n_t, int n_in, int n_dd0 = -1) {
+// toep: layout of the convolution path (dl_fs_phase2_fir): y sits DL_FIR_PAD zeros inside the work region, M (the moments) right after the padded y
+DL_HD DlFsShared dl_fs_shared_carve(double* base, int n_t, int n_in, int n_dd0 = -1, bool toep = false) {
     DlFsShared s;
     s.coef = base;                       // first: keeps the 32-byte coefficient groups 16-byte aligned
-    s.y = base + 4 * (size_t)n_t; s.M = base + 5 * (size_t)n_t; s.z = base + 6 * (size_t)n_t;
-    s.out = s.y;
-    s.pt = s.y + (n_dd0 < 0 ? dl_fs_work_doubles(n_t, n_in) : dl_fs_work_doubles(n_t, n_in, n_dd0));
+    double* work = base + 4 * (size_t)n_t;
+    if (toep) { s.y = work + DL_FIR_PAD; s.M = work + (size_t)n_t + 2 * DL_FIR_PAD; s.z = s.M; }
+    else { s.y = work; s.M = work + (size_t)n_t; s.z = work + 2 * (size_t)n_t; }
+    s.out = work;
+    s.pt = work + (n_dd0 < 0 ? dl_fs_work_doubles(n_t, n_in) : dl_fs_work_doubles(n_t, n_in, n_dd0));
     return s;
 }
 
@@ -158,40 +174,48 @@ DL_HD void dl_ap_qparqper(const DlObsDev& o, const double* th, double& qpar, dou
 
 // phase 0 + 1 (no barrier needed between them): per-point scalars, per-mu AP factors and weights, template at the knots
 DL_HD void dl_fs_phase01(int tid, int nthr, const DlObsDev& o, const double* th, const DlFsShared& s) {
-    if (tid < o.n_mu || tid == 0) {
+    // the mu nodes are handled by the LAST threads of the workgroup (they own fewer template knots below) and thread 0 keeps the scalars
+    const int mnode = nthr - 1 - tid;
+    if (mnode < o.n_mu || tid == 0) {
         double qpar, qper;
         dl_ap_qparqper(o, th, qpar, qper);
         double sigpar = dl_get(o.sigpar, th), sigper = dl_get(o.sigper, th);
         double jac = 1. / (qpar * qper * qper);                    // tgc/base.py:217
         double f = o.f_fid * dl_get(o.df, th);                     // power_template.py:757
         double b1X = dl_get(o.b1X, th), b1Y = dl_get(o.b1Y, th);
-        if (tid < o.n_mu) {
-            // ap_k_mu, tgc/base.py:216-222: factorap = sqrt(1 + mu^2 (1/qap^2 - 1)); muap = mu / qap / factorap
-            double qap = qpar / qper;
-            double mu = o.mu[tid];
-            double fac = sqrt(1. + mu * mu * (1. / (qap * qap) - 1.));
-            double mup = mu / qap / fac;
-            double mup2 = mup * mup;
-            s.pt[DL_PT_FAC + tid] = fac;
-            s.pt[DL_PT_LQ + tid] = log10(fac / qper);  // log10(kap) = log10(k) + log10(factorap / qper)
+        if (mnode < o.n_mu) {
+            // ap_k_mu, tgc/base.py:216-222: factorap = sqrt(1 + mu^2 (1/qap^2 - 1)); muap = mu / qap / factorap.
+            // Written so that the square root, the division and the logarithm all start from x = factorap^2 (short dependent chain):
+            // muap^2 = mu^2 / (qap^2 x), log10(factorap / qper) = log10(x) / 2 - log10(qper)
+            const int m = mnode;
+            double rq = qper / qpar;                                // 1 / qap
+            double iq2 = rq * rq;
+            double mu = o.mu[m];
+            double x = 1. + mu * mu * (iq2 - 1.);
+            double fac = sqrt(x);
+            double mup2 = mu * mu * iq2 / x;
+            s.pt[DL_PT_FAC + m] = fac;
+            const double lq = 0.5 * log10(x) - log10(qper);       // log10(kap) = log10(k) + log10(factorap / qper)
+            s.pt[DL_PT_LQ + m] = lq;
+            s.pt[DL_PT_LQH + m] = lq * o.inv_hx;
             // full_shape.py:492: sigmapar^2 muap^2 + sigmaper^2 (1 - muap^2)
-            s.pt[DL_PT_SD + tid] = sigpar * sigpar * mup2 + sigper * sigper * (1. - mup2);
+            s.pt[DL_PT_SD + m] = sigpar * sigpar * mup2 + sigper * sigper * (1. - mup2);
             double fm2 = f * mup2;
             double bias = (b1X + fm2) * (b1Y + fm2);               // = b1X b1Y + (b1X + b1Y) f mu'^2 + f^2 mu'^4, full_shape.py:550
             for (int l = 0; l < DL_MAX_ELL; ++l) {
-                double w = (l < o.n_ell) ? jac * o.wmu[l * o.n_mu + tid] : 0.;
-                s.pt[DL_PT_OM + tid * 8 + l] = w * bias;
-                s.pt[DL_PT_W3 + (tid * 5 + l) * 3 + 0] = w;
-                s.pt[DL_PT_W3 + (tid * 5 + l) * 3 + 1] = w * fm2;
-                s.pt[DL_PT_W3 + (tid * 5 + l) * 3 + 2] = w * (fm2 * fm2);
+                double w = (l < o.n_ell) ? jac * o.wmu[l * o.n_mu + m] : 0.;
+                s.pt[DL_PT_OM + m * 8 + l] = w * bias;
+                s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 0] = w;
+                s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 1] = w * fm2;
+                s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 2] = w * (fm2 * fm2);
             }
-            s.pt[DL_PT_OM + tid * 8 + 5] = (o.ell0 >= 0) ? jac * o.wmu[o.ell0 * o.n_mu + tid] : 0.;
-            s.pt[DL_PT_OM + tid * 8 + 6] = 0.;
-            s.pt[DL_PT_OM + tid * 8 + 7] = 0.;
+            s.pt[DL_PT_OM + m * 8 + 5] = (o.ell0 >= 0) ? jac * o.wmu[o.ell0 * o.n_mu + m] : 0.;
+            s.pt[DL_PT_OM + m * 8 + 6] = 0.;
+            s.pt[DL_PT_OM + m * 8 + 7] = 0.;
         }
         if (tid == 0) {
             for (int mm = o.n_mu; mm < ((o.n_mu + 3) & ~3); ++mm) {   // pad the mu nodes to a multiple of 4 with zero weights (unrolled loops)
-                s.pt[DL_PT_LQ + mm] = 0.; s.pt[DL_PT_FAC + mm] = 0.; s.pt[DL_PT_SD + mm] = 0.;
+                s.pt[DL_PT_LQ + mm] = 0.; s.pt[DL_PT_LQH + mm] = 0.; s.pt[DL_PT_FAC + mm] = 0.; s.pt[DL_PT_SD + mm] = 0.;
                 for (int c = 0; c < 8; ++c) s.pt[DL_PT_OM + mm * 8 + c] = 0.;
                 for (int c = 0; c < 15; ++c) s.pt[DL_PT_W3 + mm * 15 + c] = 0.;
             }
@@ -210,6 +234,7 @@ DL_HD void dl_fs_phase01(int tid, int nthr, const DlObsDev& o, const double* th,
         }
     }
     const int n_t = o.n_t;
+    if (o.toeplitz && !o.fixed_spline && tid < 2 * DL_FIR_PAD) s.y[tid < DL_FIR_PAD ? tid - DL_FIR_PAD : n_t + tid - DL_FIR_PAD] = 0.;   // zero padding
     if (o.fixed_spline) {
         for (int j = tid; j < 4 * n_t; j += nthr) s.coef[j] = o.coef_fixed[j];
     } else if (o.templ == 1) {
@@ -329,6 +354,86 @@ DL_HD void dl_fs_phase2d(int tid, int nthr, const DlObsDev& o, const DlFsShared&
     }
 }
 
+// ---- uniform knots (o.toeplitz): the two sweeps of the tridiagonal solve become ONE convolution, without a serial chain ----------------
+// Uniform spacing h: M_{j-1} + 4 M_j + M_{j+1} = r_j = 6 / h^2 (y_{j-1} - 2 y_j + y_{j+1}) (2 <= j <= n-3), and the not-a-knot conditions reduce to
+// M_1 = r_1 / 6, M_{n-2} = r_{n-2} / 6.  With w = (6 / h^2) sum_e t_|e| y_{j+e} (the solution on the infinite grid; y zero-padded: whatever sits
+// outside the table only feeds the homogeneous part), M_j = w_j + a mu^(j-1) + b mu^(n-2-j), a = r_1 / 6 - w_1, b = r_{n-2} / 6 - w_{n-2}:
+// the correction matters within ~30 knots of either end.  Each thread produces 4 consecutive w_j from one sliding window of 2 D + 4 knot values.
+DL_HD void dl_fs_phase2_fir(int tid, int nthr, const DlObsDev& o, const DlFsShared& s) {
+    const double T[DL_FIR_D + 1] = DL_FIR_TAPS;
+    const int n = o.n_t;
+    const double scale = 6. * o.inv_hx * o.inv_hx;
+    for (int j0 = 4 * tid; j0 < n; j0 += 4 * nthr) {
+        double acc[4] = {0., 0., 0., 0.};
+        const double* yp = s.y + j0 - DL_FIR_D;   // knot j0 - D + p
+        // groups of four window positions, the next group's values requested before the current one is consumed
+        double cur[4], nxt[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur[c] = yp[c];
+#pragma unroll
+        for (int gq = 0; gq < (2 * DL_FIR_D + 4) / 4; ++gq) {
+            if (gq + 1 < (2 * DL_FIR_D + 4) / 4) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) nxt[c] = yp[4 * (gq + 1) + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int p = 4 * gq + c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = p - DL_FIR_D - q;
+                    if (e >= -DL_FIR_D && e <= DL_FIR_D) acc[q] = fma(T[e < 0 ? -e : e], cur[c], acc[q]);
+                }
+            }
+            DL_PIN4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (j0 + q < n) s.M[j0 + q] = acc[q] * scale;
+    }
+    // the upper half of the workgroup has no window to convolve (n <= 2 nthr): it tabulates mu^k for the end corrections
+    for (int k = tid - nthr / 2; k >= 0 && k <= 2 * DL_FIR_PAD; k += (nthr + 1) / 2) {
+        double v = exp((double)k * DL_FIR_LN_ABS_MU);
+        s.pt[DL_PT_PART + k] = (k & 1) ? -v : v;
+    }
+}
+
+DL_HD double dl_fir_mu_pow(const DlFsShared& s, int k) {   // mu^k (tabulated by dl_fs_phase2_fir), 0 beyond the reach of the end corrections
+    return (k <= 2 * DL_FIR_PAD) ? s.pt[DL_PT_PART + k] : 0.;
+}
+
+// moments -> interval polynomials in u = (x - x0) inv_hx - j, end corrections applied on the fly.  dlt_pref[it] = o.dlt[tid + it nthr], loaded by
+// the caller at the top of the kernel (the round trip overlaps the earlier phases); iterations beyond DL_TOEP_PREF read o.dlt directly.
+#define DL_TOEP_PREF 2
+DL_HD void dl_fs_phase2d_toep(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, const double* dlt_pref) {
+    const int n = o.n_t;
+    const double hx = 1. / o.inv_hx, ihx = o.inv_hx;
+    const double sc6 = o.inv_hx * o.inv_hx;       // r_j / 6
+    const double a = sc6 * ((s.y[0] - s.y[1]) - (s.y[1] - s.y[2])) - s.M[1];
+    const double b = sc6 * ((s.y[n - 3] - s.y[n - 2]) - (s.y[n - 2] - s.y[n - 1])) - s.M[n - 2];
+    int it = 0;
+    for (int j = tid; j < n - 1; j += nthr, ++it) {
+        // moments of knots jl = max(j, 1), jl + 1 (and jl + 2 at the right end / jl - 1 .. for the not-a-knot extrapolation)
+        auto moment = [&](int i) { return s.M[i] + a * dl_fir_mu_pow(s, i - 1) + b * dl_fir_mu_pow(s, n - 2 - i); };   // 1 <= i <= n - 2
+        double Ml, Mr;
+        if (j == 0) { double m1 = moment(1), m2 = moment(2); Ml = o.end0a * m1 + o.end0b * m2; Mr = m1; }
+        else if (j == n - 2) { double m1 = moment(n - 2), m2 = moment(n - 3); Ml = m1; Mr = o.end1a * m1 + o.end1b * m2; }
+        else { Ml = moment(j); Mr = moment(j + 1); }
+        const double yl = s.y[j], yr = s.y[j + 1];
+        const double c0 = yl;
+        const double c1 = (yr - yl) * ihx - hx * (2. * Ml + Mr) * (1. / 6.);
+        const double c2 = 0.5 * Ml;
+        const double c3 = (Mr - Ml) * ihx * (1. / 6.);
+        const double dl = -(it < DL_TOEP_PREF ? dlt_pref[it] : o.dlt[j]);
+        s.coef[4 * j + 0] = c0 + dl * (c1 + dl * (c2 + dl * c3));
+        s.coef[4 * j + 1] = hx * (c1 + dl * (2. * c2 + 3. * dl * c3));
+        s.coef[4 * j + 2] = hx * hx * (c2 + 3. * dl * c3);
+        s.coef[4 * j + 3] = hx * hx * hx * c3;
+    }
+}
+
 // interval index j and local coordinate u of abscissa x (log10 k'); extrapolation continues the end pieces like
 // scipy's fill_value='extrapolate'
 template <bool UNIF>
@@ -361,14 +466,26 @@ DL_HD double dl_spline_eval(const DlObsDev& o, const DlFsShared& s, double x) {
     return fma(fma(fma(c[3], u, c[2]), u, c[1]), u, c[0]);
 }
 
+// uniform knots, abscissa already in units of the knot spacing: t = (x - x0) inv_hx
+DL_HD double dl_spline_eval_t(const DlObsDev& o, const DlFsShared& s, double t) {
+    double tc = t > 0. ? t : 0.;
+    int j = (int)tc;
+    if (j > o.n_t - 2) j = o.n_t - 2;
+    const double u = t - (double)j;
+    const double* c = s.coef + 4 * j;
+    return fma(fma(fma(c[3], u, c[2]), u, c[1]), u, c[0]);
+}
+
 // phase 3: (k, mu) evaluation, multipole projection, tracer combination; writes power (and tables).
 // NL = number of multipole accumulators compiled in (3 or 5; weights of absent multipoles are zero); the mu loop is
 // unrolled by 4 (nodes padded with zero weights) so that four independent evaluation chains are in flight per thread.
 // FAST: uniform knots, no separate tables (straight-line inner loop); EFT: counter terms present (needs P_dd,l=0).
 // The generic instantiation <false, 5, true> decides everything at run time.
 // Results go to the LDS tile s.out (dl_fs_phase4 stores it): no global store, hence no store-completion wait, in the loop.
+// lk_pref[it] = o.lkin[tid + it nthr] for it < DL_P3_PREF, loaded by the caller at the top of the kernel (nullptr: read here).
+#define DL_P3_PREF 2
 template <bool FAST, int NL, bool EFT>
-DL_HD void dl_fs_phase3(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, double* tables_row) {
+DL_HD void dl_fs_phase3(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, double* tables_row, const double* lk_pref = nullptr) {
     const double qper = s.pt[DL_PT_QPER], sn0nd = s.pt[DL_PT_SN0ND];
     const double b1X = s.pt[DL_PT_B1X], b1Y = s.pt[DL_PT_B1Y];
     const bool damp = s.pt[DL_PT_DAMP] != 0.;
@@ -376,8 +493,9 @@ DL_HD void dl_fs_phase3(int tid, int nthr, const DlObsDev& o, const DlFsShared& 
     const bool TABLES = !FAST && tables_row != nullptr;
     const int n_ell = o.n_ell, n_kin = o.n_kin;
     const int n_mu4 = (o.n_mu + 3) & ~3;
-    for (int i = tid; i < n_kin; i += nthr) {
-        const double lk = o.lkin[i];
+    int it = 0;
+    for (int i = tid; i < n_kin; i += nthr, ++it) {
+        const double lk = (lk_pref != nullptr && it < DL_P3_PREF) ? lk_pref[it] : o.lkin[i];
         const double kq = damp ? o.kin[i] / qper : 0.;   // tgc/base.py:220: kap = k / qper * factorap
         double p[NL];
         double dd[FAST ? 1 : NL], dt[FAST ? 1 : NL], tt[FAST ? 1 : NL];
@@ -449,6 +567,88 @@ DL_HD void dl_fs_phase3(int tid, int nthr, const DlObsDev& o, const DlFsShared& 
             }
         }
         if (EFT && o.n_var > 0) s.out[o.n_in + i] = dd0;   // needed by the derivative rows (phase 4)
+    }
+}
+
+// FAST variant of phase 3 that walks TWO wavenumbers (i, i + nthr) per pass of the mu loop: the per-mu shifts and fused weights are read from LDS
+// once for both (phase 3 is bound by LDS bandwidth: 32 B of interval coefficients + ~40 B of weights per evaluation), and eight independent
+// evaluation chains are in flight.  Same arithmetic, in the same order, per wavenumber as dl_fs_phase3<true, NL, EFT>.
+template <int NL, bool EFT>
+DL_HD void dl_fs_phase3_pair(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, const double* lk_pref = nullptr) {
+    const double qper = s.pt[DL_PT_QPER], sn0nd = s.pt[DL_PT_SN0ND];
+    const bool damp = s.pt[DL_PT_DAMP] != 0.;
+    const bool need_dd0 = EFT && o.n_ct > 0;
+    const int n_ell = o.n_ell, n_kin = o.n_kin;
+    const int n_mu4 = (o.n_mu + 3) & ~3;
+    auto finish = [&](int i, const double* p, double dd0) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (l < n_ell) {
+                double pl = p[l] + (l == o.ell0 ? sn0nd : 0.);
+                if (EFT && o.n_ct > 0) {  // full_shape.py:633
+                    double acc = 0.;
+                    for (int c = 0; c < o.n_ct; ++c) acc += o.ct_matrix[((size_t)l * n_kin + i) * o.n_ct + c] * s.pt[DL_PT_CT + c];
+                    pl += acc * dd0;
+                }
+                if (EFT && o.n_sn > 0) {  // full_shape.py:634
+                    double acc = 0.;
+                    for (int c = 0; c < o.n_sn; ++c) acc += o.sn_matrix[((size_t)l * n_kin + i) * o.n_sn + c] * s.pt[DL_PT_SN + c];
+                    pl += acc;
+                }
+                s.out[(size_t)l * n_kin + i] = pl;
+            }
+        }
+        if (EFT && o.n_var > 0) s.out[o.n_in + i] = dd0;   // needed by the derivative rows (phase 4)
+    };
+    int it = 0;
+    for (int i = tid; i < n_kin; i += 2 * nthr, it += 2) {
+        const int i2 = i + nthr;
+        const bool two = i2 < n_kin;
+        // abscissae in units of the knot spacing: t = (log10 k - x0) inv_hx + log10(F_m / qper) inv_hx
+        const double lkA = (((lk_pref != nullptr && it < DL_P3_PREF) ? lk_pref[it] : o.lkin[i]) - o.x0) * o.inv_hx;
+        const double lkB = !two ? lkA : (((lk_pref != nullptr && it + 1 < DL_P3_PREF) ? lk_pref[it + 1] : o.lkin[i2]) - o.x0) * o.inv_hx;
+        const double kqA = damp ? o.kin[i] / qper : 0.;   // tgc/base.py:220: kap = k / qper * factorap
+        const double kqB = (damp && two) ? o.kin[i2] / qper : 0.;
+        double pA[NL], pB[NL];
+        double dd0A = 0., dd0B = 0.;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) pA[l] = pB[l] = 0.;
+        for (int m0 = 0; m0 < n_mu4; m0 += 4) {
+            double lq[4], TA[4], TB[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lq[q] = s.pt[DL_PT_LQH + m0 + q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) TA[q] = dl_spline_eval_t(o, s, lkA + lq[q]);
+            if (two) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) TB[q] = dl_spline_eval_t(o, s, lkB + lq[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) TB[q] = 0.;
+            }
+            if (damp) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double fac = s.pt[DL_PT_FAC + m0 + q], sd = s.pt[DL_PT_SD + m0 + q];
+                    double kap = kqA * fac;
+                    TA[q] *= exp(-(kap * kap * sd) / 2.);  // full_shape.py:492-493
+                    if (two) { kap = kqB * fac; TB[q] *= exp(-(kap * kap * sd) / 2.); }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double* om = s.pt + DL_PT_OM + (m0 + q) * 8;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const double w = om[l];
+                    pA[l] = fma(w, TA[q], pA[l]);
+                    pB[l] = fma(w, TB[q], pB[l]);
+                }
+                if (need_dd0) { const double w = om[5]; dd0A = fma(w, TA[q], dd0A); dd0B = fma(w, TB[q], dd0B); }
+            }
+        }
+        finish(i, pA, dd0A);
+        if (two) finish(i2, pB, dd0B);
     }
 }
 

@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -383,6 +384,11 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         dlt[j] = x_t[j] - (d.x0 + j / d.inv_hx);
         if (std::fabs(dlt[j] * d.inv_hx) > 1e-6) d.uniform_knots = 0;
     }
+    // knots uniform to rounding (geomspace tables): the spline system is Toeplitz and is inverted by a convolution (dl_fs_phase2_fir);
+    // DL_NO_TOEPLITZ=1 keeps the general segmented sweeps (diagnostics)
+    d.toeplitz = (d.uniform_knots && d.n_t >= 4 * DL_FIR_PAD && !getenv("DL_NO_TOEPLITZ")) ? 1 : 0;
+    for (int j = 0; j + 1 < d.n_t && d.toeplitz; ++j)
+        if (std::fabs((x_t[j + 1] - x_t[j]) * d.inv_hx - 1.) > 1e-11) d.toeplitz = 0;
     // segmented sweeps: 64 segments, the state entering each is a dot product with products of the multipliers
     int m = d.n_t - 2;
     d.seg_warm = sp.warm;

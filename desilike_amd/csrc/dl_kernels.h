@@ -36,3 +36,7 @@ void dl_launch_window_gemm_tiled(const double* A, int64_t lda, const double* Wt,
 // residual of a row = bias (may be null) + sum of the n_slabs partial slabs (slab_stride doubles apart)
 void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, int64_t slab_stride, const double* bias, const double* theta, int n_params,
                         const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, hipStream_t stream);
+// chi2 GEMM path: part[M, N_pad / 16] = partial chi2 per 16-column block (bias added inside), summed with the priors by dl_launch_finalize_part
+void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, hipStream_t stream);
+void dl_launch_finalize_part(const double* part, int n_tiles, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
+                             int32_t* status, hipStream_t stream);

@@ -23,14 +23,30 @@ __global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_kernel(const Dl
                                                                      int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
-    const DlFsShared s = dl_fs_shared_carve(lds, o.n_t, o.n_in, dl_fs_n_dd0(o));
+    // FAST instantiations are only launched when the convolution path applies (or the spline is fixed): the segmented sweeps are not compiled in
+    const bool toep = !o.fixed_spline && (FAST || o.toeplitz);
+    const DlFsShared s = dl_fs_shared_carve(lds, o.n_t, o.n_in, dl_fs_n_dd0(o), toep);
     const double* th = theta + (size_t)b * n_params;
     const int tid = threadIdx.x, nthr = DL_FS_THREADS;
     if (stop_after == -1) return;  // stop_after != 0: timing diagnostics only (DL_FS_STOP), outputs are then incomplete
+    // constants of the later phases are requested now: their round trip hides behind phase 0/1
+    double dlt_pref[DL_TOEP_PREF];
+#pragma unroll
+    for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (toep && tid + it * nthr < o.n_t - 1) ? o.dlt[tid + it * nthr] : 0.;
+    double lk_pref[DL_P3_PREF];
+#pragma unroll
+    for (int it = 0; it < DL_P3_PREF; ++it) lk_pref[it] = (tid + it * nthr < o.n_kin) ? o.lkin[tid + it * nthr] : 0.;
     dl_fs_phase01(tid, nthr, o, th, s);
     __syncthreads();
     if (stop_after == 1) return;
-    if (!o.fixed_spline) {
+    if (toep) {
+        dl_fs_phase2_fir(tid, nthr, o, s);
+        __syncthreads();
+        if (stop_after == 2) return;
+        dl_fs_phase2d_toep(tid, nthr, o, s, dlt_pref);
+        __syncthreads();
+        if (stop_after == 5) return;
+    } else if (!FAST && !o.fixed_spline) {
         dl_fs_phase2a(tid, nthr, o, s);
         __syncthreads();
         if (stop_after == 2) return;
@@ -50,7 +66,8 @@ __global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_kernel(const Dl
     }
     double* prow = power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset;
     double* trow = tables ? tables + (size_t)b * ld_tables : nullptr;
-    dl_fs_phase3<FAST, NL, EFT>(tid, nthr, o, s, trow);
+    if (FAST && !EFT) dl_fs_phase3_pair<NL, EFT>(tid, nthr, o, s, lk_pref);   // (with counter terms the pair variant spills registers)
+    else dl_fs_phase3<FAST, NL, EFT>(tid, nthr, o, s, trow, lk_pref);
     __syncthreads();
     dl_fs_phase4(tid, nthr, o, s, th, prow, ld_power);
 }
@@ -96,7 +113,7 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
         };
         const DlObsDev& oh = obs_host[i];
         bool nl3 = oh.n_ell <= 3, eft = oh.n_ct > 0 || oh.n_sn > 0;
-        if (tables || !oh.uniform_knots) launch(dl_fullshape_kernel<false, 5, true>);   // generic: run-time decisions
+        if (tables || !oh.uniform_knots || !(oh.toeplitz || oh.fixed_spline)) launch(dl_fullshape_kernel<false, 5, true>);   // generic: run-time decisions
         else if (nl3 && !eft) launch(dl_fullshape_kernel<true, 3, false>);
         else if (nl3) launch(dl_fullshape_kernel<true, 3, true>);
         else if (!eft) launch(dl_fullshape_kernel<true, 5, false>);
@@ -211,6 +228,7 @@ void dl_launch_window_gemm(const double* A, int64_t lda, const double* Wt, int64
 //   (deterministic order, no atomics).
 // ------------------------------------------------------------------------------------------------
 #include "dl_gemm_tiled.h"
+#include "dl_chi2_gemm.h"
 
 // number of K splits: ~one workgroup per CU at small M, whole panels per split
 int dl_gemm_tiled_splits(int64_t M, int N_pad, int K_pad, int* chunks_per_split) {
@@ -271,16 +289,29 @@ __global__ __launch_bounds__(256) void dl_finalize_kernel(const double* __restri
     if (b >= B) return;
     const double* row = dtilde + (size_t)b * ld;
     double sum = 0.;
-    for (int j = lane; j < n; j += 64) {
-        double v = bias ? bias[j] : 0.;
+    // split-K slabs are summed in a fixed order (deterministic); two columns x eight slabs = 16 independent loads in flight per lane
+    for (int j = lane; j < n; j += 128) {
+        const bool two = (j + 64 < n);
+        double v0 = bias ? bias[j] : 0., v1 = (bias && two) ? bias[j + 64] : 0.;
         int sl = 0;
-        for (; sl + 4 <= n_slabs; sl += 4) {   // independent loads in flight; fixed summation order: deterministic
-            double t0 = row[(size_t)sl * slab_stride + j], t1 = row[(size_t)(sl + 1) * slab_stride + j];
-            double t2 = row[(size_t)(sl + 2) * slab_stride + j], t3 = row[(size_t)(sl + 3) * slab_stride + j];
-            v += (t0 + t1) + (t2 + t3);
+        for (; sl + 8 <= n_slabs; sl += 8) {
+            double t[8], u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { t[q] = row[(size_t)(sl + q) * slab_stride + j]; u[q] = two ? row[(size_t)(sl + q) * slab_stride + j + 64] : 0.; }
+            v0 += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            v1 += ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
         }
-        for (; sl < n_slabs; ++sl) v += row[(size_t)sl * slab_stride + j];
-        sum = fma(v, v, sum);
+        double t[8], u[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            bool on = sl + q < n_slabs;
+            t[q] = on ? row[(size_t)(sl + q) * slab_stride + j] : 0.;
+            u[q] = (on && two) ? row[(size_t)(sl + q) * slab_stride + j + 64] : 0.;
+        }
+        v0 += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        v1 += ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
+        sum = fma(v0, v0, sum);
+        sum = fma(v1, v1, sum);
     }
     sum = dl_wave_sum(sum);
     // priors: lanes stride over parameters
@@ -314,6 +345,53 @@ void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, in
                         const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, hipStream_t stream) {
     hipLaunchKernelGGL(dl_finalize_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, n_slabs, slab_stride, bias, theta, n_params, priors, B, loglike,
                        logprior, status);
+}
+
+// ------------------------------------------------------------------------------------------------
+// chi2 GEMM path (plain likelihood): partial chi2 per (point, 16-column block) from dl_chi2_gemm_kernel, then one THREAD per point
+// sums them in a fixed order and adds the priors (same status logic as dl_finalize_kernel).
+// ------------------------------------------------------------------------------------------------
+void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, hipStream_t stream) {
+    const int n_tiles = N_pad / DL_CG_N;
+    const int64_t mblocks = (M + DL_CG_M - 1) / DL_CG_M;
+    const unsigned grid = (unsigned)(8 * n_tiles * ((mblocks + 7) / 8));
+    static bool optin = false;
+    if (!optin) { (void)hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES); optin = true; }
+    hipLaunchKernelGGL((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(512), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles);
+}
+
+__global__ __launch_bounds__(256) void dl_finalize_part_kernel(const double* __restrict__ part, int n_tiles, const double* __restrict__ theta, int n_params,
+                                                               const double* __restrict__ priors, int64_t B, double* __restrict__ loglike,
+                                                               double* __restrict__ logprior, int32_t* __restrict__ status) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double chi2 = 0.;
+    for (int t = 0; t < n_tiles; ++t) chi2 += part[(size_t)b * n_tiles + t];
+    double lp = 0.;
+    bool nan_in = false;
+    const double inf = __builtin_huge_val();
+    for (int p = 0; p < n_params; ++p) {
+        double x = theta[(size_t)b * n_params + p];
+        const double* pr = priors + 5 * p;
+        if (x != x) nan_in = true;
+        bool isin = (pr[1] <= x) && (x <= pr[2]);
+        double v = 0.;
+        if (pr[0] == 1.) { double t = x - pr[3]; v = -0.5 * (t * t) / (pr[4] * pr[4]); }   // parameter.py:2007
+        lp += isin ? v : -inf;
+    }
+    double ll = -0.5 * chi2;
+    int st = DL_ST_OK;
+    if (nan_in) st = DL_ST_NAN_INPUT;
+    else if (lp == -inf) st = DL_ST_OUT_OF_PRIOR;
+    else if (!(ll == ll) || ll == inf || ll == -inf) st = DL_ST_NONFINITE;
+    if (loglike) loglike[b] = ll;
+    if (logprior) logprior[b] = lp;
+    if (status) status[b] = st;
+}
+
+void dl_launch_finalize_part(const double* part, int n_tiles, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
+                             int32_t* status, hipStream_t stream) {
+    hipLaunchKernelGGL(dl_finalize_part_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, part, n_tiles, theta, n_params, priors, B, loglike, logprior, status);
 }
 
 // ------------------------------------------------------------------------------------------------

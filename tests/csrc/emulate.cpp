@@ -34,10 +34,18 @@ static void run_point(const DlObsDev& o, const double* th, double* prow, double*
         return;
     }
     std::vector<double> lds(dl_fs_shared_doubles(o.n_t, o.n_in));
-    DlFsShared s = dl_fs_shared_carve(lds.data(), o.n_t, o.n_in);
+    const bool toep = o.toeplitz && !o.fixed_spline;
+    DlFsShared s = dl_fs_shared_carve(lds.data(), o.n_t, o.n_in, -1, toep);
     const int nthr = DL_FS_THREADS;
     for (int tid = 0; tid < nthr; ++tid) dl_fs_phase01(tid, nthr, o, th, s);
-    if (!o.fixed_spline) {
+    if (toep) {
+        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2_fir(tid, nthr, o, s);
+        for (int tid = 0; tid < nthr; ++tid) {
+            double dlt_pref[DL_TOEP_PREF];
+            for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (tid + it * nthr < o.n_t - 1) ? o.dlt[tid + it * nthr] : 0.;
+            dl_fs_phase2d_toep(tid, nthr, o, s, dlt_pref);
+        }
+    } else if (!o.fixed_spline) {
         for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2a(tid, nthr, o, s);
         for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2b_dot(tid, nthr, o, s);
         for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2b(tid, nthr, o, s);
@@ -47,10 +55,10 @@ static void run_point(const DlObsDev& o, const double* th, double* prow, double*
     }
     for (int tid = 0; tid < nthr; ++tid) {
         bool nl3 = o.n_ell <= 3, eft = o.n_ct > 0 || o.n_sn > 0;   // same dispatch as dl_launch_fullshape
-        if (trow || !o.uniform_knots) dl_fs_phase3<false, 5, true>(tid, nthr, o, s, trow);
-        else if (nl3 && !eft) dl_fs_phase3<true, 3, false>(tid, nthr, o, s, trow);
+        if (trow || !o.uniform_knots || !(o.toeplitz || o.fixed_spline)) dl_fs_phase3<false, 5, true>(tid, nthr, o, s, trow);
+        else if (nl3 && !eft) dl_fs_phase3_pair<3, false>(tid, nthr, o, s);
         else if (nl3) dl_fs_phase3<true, 3, true>(tid, nthr, o, s, trow);
-        else if (!eft) dl_fs_phase3<true, 5, false>(tid, nthr, o, s, trow);
+        else if (!eft) dl_fs_phase3_pair<5, false>(tid, nthr, o, s);
         else dl_fs_phase3<true, 5, true>(tid, nthr, o, s, trow);
     }
     for (int tid = 0; tid < nthr; ++tid) dl_fs_phase4(tid, nthr, o, s, th, prow, o.n_in);

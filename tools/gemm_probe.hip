@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 #include "dl_gemm_tiled.h"
+#include "dl_chi2_gemm.h"
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -41,7 +42,7 @@ static void timeit(const char* name, int reps, hipStream_t st, F launch, bool re
 }
 
 int main(int argc, char** argv) {
-    const int M = argc > 1 ? atoi(argv[1]) : 1024, N = 128, K = 1344;
+    const int M = argc > 1 ? atoi(argv[1]) : 1024, N = 128, K = argc > 2 ? atoi(argv[2]) : 1280;
     const int reps = 50;
     hipStream_t st;
     CHECK(hipStreamCreate(&st));
@@ -87,6 +88,23 @@ int main(int argc, char** argv) {
         timeit(nm, reps, st, [&] { GEMM(true, false, false, cps); }, false, A, nA);
         snprintf(nm, sizeof nm, "cps=%d: nothing", cps);
         timeit(nm, reps, st, [&] { GEMM(false, false, false, cps); }, false, A, nA);
+    }
+    // chi2 GEMM (column split, full K, partial chi2 only)
+    {
+        double *bias, *part;
+        CHECK(hipMalloc(&bias, N * 8)); CHECK(hipMemset(bias, 0, N * 8));
+        CHECK(hipMalloc(&part, (int64_t)M * (N / DL_CG_N) * 8));
+        CHECK(hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES));
+        CHECK(hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES));
+        CHECK(hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES));
+        const int ntl = N / DL_CG_N;
+        const unsigned grid = 8 * ntl * (((M + DL_CG_M - 1) / DL_CG_M + 7) / 8);
+#define CHI2(L, MM) hipLaunchKernelGGL((dl_chi2_gemm_kernel<L, MM>), dim3(grid), dim3(512), DL_CG_LDS_BYTES, st, A, (int64_t)K, W, (int64_t)K, bias, part, M, K, ntl)
+        printf("chi2 GEMM: grid %u, LDS %d B\n", grid, (int)DL_CG_LDS_BYTES);
+        timeit("chi2: full", reps, st, [&] { CHI2(true, true); }, false, A, nA);
+        timeit("chi2: full, A refilled", reps, st, [&] { CHI2(true, true); }, true, A, nA);
+        timeit("chi2: no load", reps, st, [&] { CHI2(false, true); }, false, A, nA);
+        timeit("chi2: no mfma", reps, st, [&] { CHI2(true, false); }, false, A, nA);
     }
     CHECK(hipStreamSynchronize(st));
     return 0;
