@@ -53,6 +53,8 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
 #define DL_TEMPLATE_SHAPEFIT  1   /* power_template.py:747-761 */
 #define DL_THEORY_KAISER      0   /* full_shape.py:488-500, 545-550 */
 #define DL_THEORY_EFT_KAISER  1   /* + counter / stochastic terms full_shape.py:628-634 */
+#define DL_THEORY_BAO_DAMPED  2   /* damped BAO wiggles, 'standard' model bao.py:117-140 (+ broadband terms as pass-through columns, bao.py:495-534, 881-905) */
+#define DL_THEORY_EMULATED    3   /* emulated P_ell tables (Taylor / MLP engines, emulators/base.py) + velocileptors bias-table combination full_shape.py:1150-1190 */
 #define DL_APMODE_QPARQPER    0   /* theories/galaxy_clustering/base.py:341-350 */
 #define DL_APMODE_QISO        1
 #define DL_APMODE_QAP         2
@@ -83,6 +85,14 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
  *   obs<i>.kmask    i32[n_out]      row selection applied after the matrix / identity
  *   obs<i>.offset   f64[n_out_before_mask], obs<i>.shotnoise_in f64[n_ell], obs<i>.shotnoise_out f64[n_out]
  *   obs<i>.flatdata f64[n_out]
+ *   obs<i>.in.pass  f64[n_pass*2]  parameters the observable is linear in through a constant matrix: appended to the theory vector as pass-through
+ *                     columns n_in .. n_in+n_pass-1; obs<i>.wmatrix then has n_in+n_pass columns (BAO broadband terms; folded Hankel / emulator operators)
+ *   BAO model (theory = 2): obs<i>.pknow_dd_fid f64[n_t] (no-wiggle table), obs<i>.in.dbeta, .in.sigmas, .in.sigmapar, .in.sigmaper f64[2],
+ *                     obs<i>.bao_mode i32[1] (0 '' / recsym, 1 reciso), obs<i>.smoothing_radius f64[1]
+ *   emulated theory (theory = 3): obs<i>.in.x f64[n_x*2] emulator inputs, obs<i>.in.vp f64[11*2] velocileptors 'pars' (b1 b2 bs b3 alpha0 alpha2 alpha4 alpha6
+ *                     sn0 sn2 sn4), obs<i>.mono_mode i32[1] (0 none, 1 LPT physical basis, 2 REPT physical, 3 LPT direct, 4 REPT direct), obs<i>.vconst f64[3] (snd fsat sigv),
+ *                     obs<i>.emu<e>.{type i32[1] (-1 constant, 0 MLP, 1 Taylor), xlimits, widths, act, weights, ylimits, center, powers, coef, const}
+ *                     for e = 0 (table basis), 1 (sigma8), 2 (fsigma8); obs<i>.marg.vp i32[11], obs<i>.marg.pass i32[n_pass]
  *   marg.kind       i32[n_s]    analytically solved linear parameters (likelihoods/base.py:314-413): 1 = marginalised ('.marg'), 0 = best fit ('.best')
  *   marg.prior      f64[n_s*2]  (loc, 1 / scale^2) of their Gaussian priors (0 precision = flat prior)
  *   marg.x0         f64[n_s]    values at which the theory is evaluated (the parameters' default values, likelihoods/base.py:355)
