@@ -125,33 +125,52 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs a GPU: the hot path has no CPU fallback')
+    local_rank = local_rank % torch.cuda.device_count()   # (only differs when the N > 1 path is smoke-tested on a 1-GPU box: DL_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl', device_id=device)
+        backend = os.environ.get('DL_BENCH_BACKEND', 'nccl')   # "nccl" IS RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     likelihood = make_likelihood(local_rank)
     ctx = likelihood._get_context()
     B = args.batch
+    # N > 1: two independent walker ensembles (chains) alternate, so that the all-gather of one ensemble's log-posteriors (RCCL, its own stream) overlaps the
+    # evaluation of the other; every step is still one pass of the hot path over B points per GPU plus one all-gather (desilike_amd/parallel.py)
+    nslots = 2 if distributed else 1
     theta_host = sample_theta(likelihood, B, seed=42 + rank)
-    theta = torch.as_tensor(theta_host, dtype=torch.float64, device=device).contiguous()
-    loglike = torch.empty(B, dtype=torch.float64, device=device)
-    logprior = torch.empty(B, dtype=torch.float64, device=device)
-    status = torch.empty(B, dtype=torch.int32, device=device)
-    logpost = torch.empty(B, dtype=torch.float64, device=device)
-    gathered = torch.empty(world * B, dtype=torch.float64, device=device) if distributed else None
+    thetas = [torch.as_tensor(theta_host if slot == 0 else sample_theta(likelihood, B, seed=4242 + rank), dtype=torch.float64, device=device).contiguous() for slot in range(nslots)]
+    loglikes = [torch.empty(B, dtype=torch.float64, device=device) for slot in range(nslots)]
+    logpriors = [torch.empty(B, dtype=torch.float64, device=device) for slot in range(nslots)]
+    statuses = [torch.empty(B, dtype=torch.int32, device=device) for slot in range(nslots)]
+    logposts = [torch.empty(B, dtype=torch.float64, device=device) for slot in range(nslots)]
+    loglike, status = loglikes[0], statuses[0]
     stream = torch.cuda.current_stream(device)
+    pipe = None
+    if distributed:
+        from desilike_amd.parallel import PipelinedAllGather
+        pipe = PipelinedAllGather((B,), torch.float64, device, nslots=nslots)
+    counter = [0]
 
     def step():
-        ctx.eval_batch(theta, loglike=loglike, logprior=logprior, status=status, stream=stream.cuda_stream)
+        slot = counter[0] % nslots
+        counter[0] += 1
+        if distributed and pipe.pending(slot):
+            pipe.result(slot)   # the stream waits for the gather this ensemble issued two steps ago (its buffers are about to be overwritten)
+        ctx.eval_batch(thetas[slot], loglike=loglikes[slot], logprior=logpriors[slot], status=statuses[slot], stream=stream.cuda_stream)
         if distributed:
             # the path's one real exchange: every rank needs every walker's log-posterior (samplers/base.py:200)
-            torch.add(loglike, logprior, out=logpost)
-            dist.all_gather_into_tensor(gathered, logpost)
+            torch.add(loglikes[slot], logpriors[slot], out=logposts[slot])
+            pipe.submit(slot, logposts[slot])
 
     def barrier():
         if distributed:
+            for slot in range(nslots):
+                if pipe.pending(slot): pipe.result(slot)
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -181,7 +200,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    assert int((status != 0).sum().item()) == 0, 'non-OK status in the benchmark batch'
+    assert all(int((st != 0).sum().item()) == 0 for st in statuses), 'non-OK status in the benchmark batch'
     if rank == 0:
         value = world * B * args.steps / elapsed
         flops = {'theory': FLOP_THEORY, 'window_gemm': FLOP_GEMM, 'finalize': FLOP_FINAL}

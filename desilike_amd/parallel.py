@@ -67,3 +67,48 @@ class WalkerSharding(object):
             tensor = tensor.to(self.device)
         self.dist.broadcast(tensor, src=src, group=self.group)
         return tensor.cpu().numpy()
+
+
+class PipelinedAllGather(object):
+    """Double-buffered asynchronous all-gather of per-point results, for drivers that keep several independent walker ensembles (chains) in flight.
+
+    ``submit(slot, local)`` starts the all-gather of ensemble ``slot``'s local results on the collective's own stream and returns at once: the caller goes
+    on enqueueing the evaluation of the *other* ensemble, whose kernels overlap the (latency-bound, kilobyte-sized) collective.  ``result(slot)`` makes the
+    current stream wait for that collective and returns the gathered rows.  One collective per ensemble step, never split (xGMI is point-to-point:
+    a small all-gather costs a ring latency whatever its size).  A slot must be drained (``result``) before it is submitted again.
+    """
+
+    def __init__(self, shape, dtype, device, nslots=2, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        shape = tuple(shape)
+        self.gathered = [torch.empty((self.world * shape[0],) + shape[1:], dtype=dtype, device=device) for _ in range(nslots)]
+        self.work = [None] * nslots
+        self.local = [None] * nslots
+
+    def submit(self, slot, local):
+        if self.work[slot] is not None:
+            raise RuntimeError('slot {:d} resubmitted before its result was taken'.format(slot))
+        if self.world == 1:
+            self.local[slot] = local
+            self.work[slot] = True
+            return
+        self.local[slot] = local   # keep the input alive until the collective has consumed it
+        self.work[slot] = self.dist.all_gather_into_tensor(self.gathered[slot], local, group=self.group, async_op=True)
+
+    def pending(self, slot):
+        return self.work[slot] is not None
+
+    def result(self, slot):
+        work = self.work[slot]
+        if work is None:
+            raise RuntimeError('nothing submitted in slot {:d}'.format(slot))
+        self.work[slot] = None
+        if self.world == 1:
+            return self.local[slot]
+        work.wait()   # stream-ordered on GPUs (the current stream waits for the collective), blocking on CPU backends
+        return self.gathered[slot]

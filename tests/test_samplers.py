@@ -100,3 +100,42 @@ def test_walker_sharding_gloo_world2():
     for rank in range(2):
         assert np.allclose(results[rank][0], expected, equal_nan=True)     # every rank holds every walker's log-posterior
     assert np.allclose(results[0][2], results[1][2])                       # identical chains on all ranks
+
+
+def _pipelined_worker(rank, world, port, results):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from desilike_amd.parallel import PipelinedAllGather
+    nloc = 5
+    pipe = PipelinedAllGather((nloc,), torch.float64, 'cpu', nslots=2)
+    out = []
+    for step in range(6):   # two ensembles alternate: the gather of one is in flight while the other is "evaluated"
+        slot = step % 2
+        if pipe.pending(slot):
+            out.append(pipe.result(slot).clone())
+        local = torch.arange(nloc, dtype=torch.float64) + 100. * rank + 1000. * step
+        pipe.submit(slot, local)
+    for slot in [0, 1]:
+        out.append(pipe.result(slot).clone())
+    try:
+        pipe.result(0)
+        raised = False
+    except RuntimeError:
+        raised = True
+    results[rank] = (torch.stack(out).numpy(), raised)
+    dist.destroy_process_group()
+
+
+def test_pipelined_allgather_gloo_world2():
+    import torch.multiprocessing as mp
+    manager = mp.Manager()
+    results = manager.dict()
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_pipelined_worker, args=(2, port, results), nprocs=2, join=True)
+    expected = np.array([np.concatenate([np.arange(5) + 100. * rank + 1000. * step for rank in range(2)]) for step in range(6)])
+    for rank in range(2):
+        got, raised = results[rank]
+        assert raised
+        assert np.array_equal(got, expected)   # results come back in submission order, every rank sees every rank's rows
