@@ -161,11 +161,12 @@ def main():
         counter[0] += 1
         if distributed and pipe.pending(slot):
             pipe.result(slot)   # the stream waits for the gather this ensemble issued two steps ago (its buffers are about to be overwritten)
-        ctx.eval_batch(thetas[slot], loglike=loglikes[slot], logprior=logpriors[slot], status=statuses[slot], stream=stream.cuda_stream)
         if distributed:
-            # the path's one real exchange: every rank needs every walker's log-posterior (samplers/base.py:200)
-            torch.add(loglikes[slot], logpriors[slot], out=logposts[slot])
+            # the path's one real exchange: every rank needs every walker's log-posterior (samplers/base.py:200); written directly by the finalize kernel
+            ctx.eval_logposterior(thetas[slot], logposts[slot], status=statuses[slot], stream=stream.cuda_stream)
             pipe.submit(slot, logposts[slot])
+        else:
+            ctx.eval_batch(thetas[slot], loglike=loglikes[slot], logprior=logpriors[slot], status=statuses[slot], stream=stream.cuda_stream)
 
     def barrier():
         if distributed:

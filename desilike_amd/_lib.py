@@ -25,6 +25,7 @@ SYMBOLS = {
     'dl_last_error': (ctypes.c_char_p, [ctypes.c_void_p]),
     'dl_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
     'dl_eval_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_eval_logposterior': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_theory': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_batch_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
     'dl_eval_theory_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, ctypes.c_int32, _c_double_p, _c_double_p]),
@@ -195,6 +196,18 @@ class Context(object):
         self._check(self._lib.dl_eval_batch(self._handle, ctypes.c_void_p(theta.data_ptr()), B, ptr(loglike, torch.float64, (B,)), ptr(logprior, torch.float64, (B,)),
                                             ptr(flattheory, torch.float64, (B, self.n_data)), ptr(status, torch.int32, (B,)),
                                             ptr(solved, torch.float64, (B, self.n_solved)), ctypes.c_void_p(stream)))
+
+    def eval_logposterior(self, theta, logposterior, status=None, stream=None):
+        """``logposterior[B]`` = loglikelihood + logprior, -inf where the sampler would reject the point (samplers/base.py:185-191); torch tensors, asynchronous."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(theta.device).cuda_stream
+        B = theta.shape[0]
+        assert theta.is_contiguous() and theta.dtype == torch.float64 and theta.shape[1] == self.n_params
+        assert logposterior.is_contiguous() and logposterior.dtype == torch.float64 and tuple(logposterior.shape) == (B,)
+        assert status is None or (status.is_contiguous() and status.dtype == torch.int32 and tuple(status.shape) == (B,))
+        self._check(self._lib.dl_eval_logposterior(self._handle, ctypes.c_void_p(theta.data_ptr()), B, ctypes.c_void_p(logposterior.data_ptr()),
+                                                   None if status is None else ctypes.c_void_p(status.data_ptr()), ctypes.c_void_p(stream)))
 
     def profile_enable(self, every=1):
         """Bracket kernels with HIP events on one ``eval_batch`` call out of ``every`` (0 / False: off)."""

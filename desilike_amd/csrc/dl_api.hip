@@ -328,8 +328,8 @@ static int dl_reserve(dl_ctx* ctx, int64_t B) {
     return 0;
 }
 
-int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* loglike_dev, double* logprior_dev, double* flattheory_dev, int32_t* status_dev,
-                  double* solved_dev, void* hip_stream) {
+static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double* loglike_dev, double* logprior_dev, double* flattheory_dev, int32_t* status_dev,
+                        double* solved_dev, void* hip_stream, int post_mode) {
     if (!ctx) { g_last_error = "dl_eval_batch: null context"; return 1; }
     if (B < 0 || (B > 0 && !theta_dev)) return dl_fail(ctx, "dl_eval_batch: invalid batch");
     if (B == 0) return 0;
@@ -378,19 +378,29 @@ int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logli
         if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
         if (chi2_path)
             dl_launch_finalize_part(ctx->delta_ws, ctx->N_pad / 16, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
-                                    status_dev ? status_dev + b0 : nullptr, stream);
+                                    status_dev ? status_dev + b0 : nullptr, post_mode, stream);
         else if (ctx->n_solved > 0)
             dl_launch_finalize_marg(ctx->delta_ws, ctx->N_pad, n, R, n_slabs, slab_stride, fin_bias, ctx->marg, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr,
                                     logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr,
-                                    solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr, stream);
+                                    solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr, post_mode, stream);
         else
             dl_launch_finalize(ctx->delta_ws, ctx->N_pad, n, n_slabs, slab_stride, fin_bias, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
-                               status_dev ? status_dev + b0 : nullptr, stream);
+                               status_dev ? status_dev + b0 : nullptr, post_mode, stream);
         if (prof) { DL_HIP_CHECK(ctx, hipEventRecord(ev[3], stream)); ctx->prof_calls++; }
     }
     if (ctx->profile) ctx->eval_calls++;
     DL_HIP_CHECK(ctx, hipGetLastError());
     return 0;
+}
+
+int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* loglike_dev, double* logprior_dev, double* flattheory_dev, int32_t* status_dev,
+                  double* solved_dev, void* hip_stream) {
+    return dl_eval_impl(ctx, theta_dev, B, loglike_dev, logprior_dev, flattheory_dev, status_dev, solved_dev, hip_stream, 0);
+}
+
+int dl_eval_logposterior(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logposterior_dev, int32_t* status_dev, void* hip_stream) {
+    if (ctx && B > 0 && !logposterior_dev) return dl_fail(ctx, "dl_eval_logposterior: null output");
+    return dl_eval_impl(ctx, theta_dev, B, logposterior_dev, nullptr, nullptr, status_dev, nullptr, hip_stream, 1);
 }
 
 int dl_eval_theory(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs, double* power_dev, double* tables_dev, void* hip_stream) {

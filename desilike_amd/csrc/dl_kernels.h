@@ -27,16 +27,17 @@ struct DlMargDev {
 };
 void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride, const double* bias, const DlMargDev& mg,
                              const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, double* solved,
-                             hipStream_t stream);
+                             int post_mode, hipStream_t stream);
 void dl_launch_transform(double* flat, int64_t ld, const double* data, const int32_t* transform, int n, int64_t B, hipStream_t stream);
 // tiled split-K variant: writes n_splits partial slabs (no bias); N_pad multiple of 128, K_pad multiple of 16
 int dl_gemm_tiled_splits(int64_t M, int N_pad, int K_pad, int* chunks_per_split);
 void dl_launch_window_gemm_tiled(const double* A, int64_t lda, const double* Wt, int64_t ldw, double* slabs, int64_t slab_stride, int64_t ldc, int64_t M, int N_pad, int K_pad,
                                  int n_splits, int chunks_per_split, hipStream_t stream);
-// residual of a row = bias (may be null) + sum of the n_slabs partial slabs (slab_stride doubles apart)
+// residual of a row = bias (may be null) + sum of the n_slabs partial slabs (slab_stride doubles apart).
+// post_mode (all finalize launchers): write the log-posterior (loglike + logprior, -inf unless status OK: samplers/base.py:185-191) to `loglike`
 void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, int64_t slab_stride, const double* bias, const double* theta, int n_params,
-                        const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, hipStream_t stream);
+                        const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream);
 // chi2 GEMM path: part[M, N_pad / 16] = partial chi2 per 16-column block (bias added inside), summed with the priors by dl_launch_finalize_part
 void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, hipStream_t stream);
 void dl_launch_finalize_part(const double* part, int n_tiles, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
-                             int32_t* status, hipStream_t stream);
+                             int32_t* status, int post_mode, hipStream_t stream);

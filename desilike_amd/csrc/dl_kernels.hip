@@ -283,7 +283,7 @@ __device__ __forceinline__ double dl_wave_sum(double v) {
 __global__ __launch_bounds__(256) void dl_finalize_kernel(const double* __restrict__ dtilde, int64_t ld, int n, int n_slabs, int64_t slab_stride,
                                                           const double* __restrict__ bias, const double* __restrict__ theta, int n_params,
                                                           const double* __restrict__ priors, int64_t B, double* __restrict__ loglike,
-                                                          double* __restrict__ logprior, int32_t* __restrict__ status) {
+                                                          double* __restrict__ logprior, int32_t* __restrict__ status, int post_mode) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -335,16 +335,16 @@ __global__ __launch_bounds__(256) void dl_finalize_kernel(const double* __restri
         if (nan_in) st = DL_ST_NAN_INPUT;
         else if (lp == -inf) st = DL_ST_OUT_OF_PRIOR;
         else if (!(ll == ll) || ll == inf || ll == -inf) st = DL_ST_NONFINITE;
-        if (loglike) loglike[b] = ll;
+        if (loglike) loglike[b] = post_mode ? (st == DL_ST_OK ? ll + lp : -inf) : ll;   // post_mode: log-posterior with the samplers' conventions (samplers/base.py:185-191)
         if (logprior) logprior[b] = lp;
         if (status) status[b] = st;
     }
 }
 
 void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, int64_t slab_stride, const double* bias, const double* theta, int n_params,
-                        const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, hipStream_t stream) {
+                        const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream) {
     hipLaunchKernelGGL(dl_finalize_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, n_slabs, slab_stride, bias, theta, n_params, priors, B, loglike,
-                       logprior, status);
+                       logprior, status, post_mode);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -362,7 +362,7 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
 
 __global__ __launch_bounds__(256) void dl_finalize_part_kernel(const double* __restrict__ part, int n_tiles, const double* __restrict__ theta, int n_params,
                                                                const double* __restrict__ priors, int64_t B, double* __restrict__ loglike,
-                                                               double* __restrict__ logprior, int32_t* __restrict__ status) {
+                                                               double* __restrict__ logprior, int32_t* __restrict__ status, int post_mode) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double chi2 = 0.;
@@ -384,14 +384,14 @@ __global__ __launch_bounds__(256) void dl_finalize_part_kernel(const double* __r
     if (nan_in) st = DL_ST_NAN_INPUT;
     else if (lp == -inf) st = DL_ST_OUT_OF_PRIOR;
     else if (!(ll == ll) || ll == inf || ll == -inf) st = DL_ST_NONFINITE;
-    if (loglike) loglike[b] = ll;
+    if (loglike) loglike[b] = post_mode ? (st == DL_ST_OK ? ll + lp : -inf) : ll;
     if (logprior) logprior[b] = lp;
     if (status) status[b] = st;
 }
 
 void dl_launch_finalize_part(const double* part, int n_tiles, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
-                             int32_t* status, hipStream_t stream) {
-    hipLaunchKernelGGL(dl_finalize_part_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, part, n_tiles, theta, n_params, priors, B, loglike, logprior, status);
+                             int32_t* status, int post_mode, hipStream_t stream) {
+    hipLaunchKernelGGL(dl_finalize_part_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, part, n_tiles, theta, n_params, priors, B, loglike, logprior, status, post_mode);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __r
                                                                const double* __restrict__ bias, DlMargDev mg,
                                                                const double* __restrict__ theta, int n_params, const double* __restrict__ priors, int64_t B,
                                                                double* __restrict__ loglike, double* __restrict__ logprior, int32_t* __restrict__ status,
-                                                               double* __restrict__ solved) {
+                                                               double* __restrict__ solved, int post_mode) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __r
         if (nan_in) st = DL_ST_NAN_INPUT;
         else if (lp == -inf) st = DL_ST_OUT_OF_PRIOR;
         else if (!ok || !(ll == ll) || ll == inf || ll == -inf) st = DL_ST_NONFINITE;
-        if (loglike) loglike[b] = ll;
+        if (loglike) loglike[b] = post_mode ? (st == DL_ST_OK ? ll + lptot : -inf) : ll;
         if (logprior) logprior[b] = lptot;
         if (status) status[b] = st;
     }
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __r
 
 void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride, const double* bias, const DlMargDev& mg,
                              const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, double* solved,
-                             hipStream_t stream) {
+                             int post_mode, hipStream_t stream) {
     hipLaunchKernelGGL(dl_finalize_marg_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
-                       n_params, priors, B, loglike, logprior, status, solved);
+                       n_params, priors, B, loglike, logprior, status, solved, post_mode);
 }

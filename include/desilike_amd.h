@@ -121,6 +121,11 @@ int  dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B,
                    double* loglike_dev, double* logprior_dev, double* flattheory_dev,
                    int32_t* status_dev, double* solved_dev, void* hip_stream);
 
+/* What a sampler consumes (BasePosteriorSampler.logposterior, desilike/samplers/base.py:144-200): logposterior_dev[B] = loglikelihood + logprior, and -inf
+ * for points outside the prior, with NaN inputs or a non-finite likelihood (samplers/base.py:185-191); status_dev[B] optional.  One launch sequence, no
+ * separate addition.  Asynchronous on ``hip_stream``. */
+int  dl_eval_logposterior(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logposterior_dev, int32_t* status_dev, void* hip_stream);
+
 /* Theory state of observable ``iobs`` for parity / plots / emulation:
  * power_dev [B, n_ell, n_kin] and (optional) tables_dev [B, 3, n_ell, n_kin] = pk_dd, pk_dt, pk_tt. */
 int  dl_eval_theory(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs,
