@@ -28,6 +28,7 @@ struct dl_ctx {
     double* arena_dev = nullptr;     // per-observable theory constants
     std::vector<DlObsDev> obs_kernarg; // observables with device pointers, passed by value to the theory kernel
     double* priors_dev = nullptr;    // [P, 5]
+    int32_t* gemm_counters = nullptr;// [<= 2048 / 32 + 8] arrival counters of the fused chi2 GEMM finalize (zero between launches)
     double* wt_white_dev = nullptr;  // [N_pad, K_pad]  L^T . blockdiag(W_obs)          (chi2 path)
     double* bias_white_dev = nullptr;// [N_pad]         L^T . (bias - flatdata)
     double* wt_full_dev = nullptr;   // [N_pad, K_pad]  blockdiag(W_obs)                 (flattheory path)
@@ -268,6 +269,10 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     if (dl_upload(ctx, &ctx->arena_dev, arena.data)) { dl_destroy(ctx); return 1; }
     ctx->obs_kernarg.resize(ctx->n_obs);
     for (int i = 0; i < ctx->n_obs; ++i) { ctx->obs[i].rebase(ctx->arena_dev); ctx->obs_kernarg[i] = ctx->obs[i].dev; }
+    {   // arrival counters of the fused chi2-GEMM finalize: one per 32-row block of the largest pass that takes that path (self-resetting)
+        size_t nbytes = (16384 / 32 + 8) * sizeof(int32_t);
+        if (hipMalloc((void**)&ctx->gemm_counters, nbytes) != hipSuccess || hipMemset(ctx->gemm_counters, 0, nbytes) != hipSuccess) { dl_fail(ctx, "dl_create: counter allocation failed"); dl_destroy(ctx); return 1; }
+    }
     if (dl_upload(ctx, &ctx->priors_dev, priors) || dl_upload(ctx, &ctx->wt_white_dev, wt_white) ||
         dl_upload(ctx, &ctx->bias_white_dev, bias_white) || dl_upload(ctx, &ctx->wt_full_dev, wt_full) || dl_upload(ctx, &ctx->bias_full_dev, bias_full) ||
         dl_upload(ctx, &ctx->wh_dev, wh) || dl_upload(ctx, &ctx->bias_wh_dev, bias_wh) || dl_upload(ctx, &ctx->flatdata_dev, flatdata) ||
@@ -284,7 +289,7 @@ void dl_destroy(dl_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     void* ptrs[] = {ctx->arena_dev, ctx->priors_dev, ctx->wt_white_dev, ctx->bias_white_dev, ctx->wt_full_dev, ctx->bias_full_dev, ctx->wh_dev,
                     ctx->bias_wh_dev, ctx->flatdata_dev, ctx->transform_dev, ctx->tconst_dev, ctx->power_ws, ctx->delta_ws, ctx->flat_ws, ctx->theta_stage, ctx->out_stage,
-                    ctx->status_stage};
+                    ctx->status_stage, ctx->gemm_counters};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -361,8 +366,14 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         // plain likelihood: chi2 is additive over the columns of the whitened residual -> column-split GEMM that emits partial chi2 only
         static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 2048;   // above: split-K slabs + finalize win (measured: 4096 rows 40 vs 49 us; 1024 rows 18 vs 13 us)
         const bool chi2_path = !ctx->any_transform && ctx->n_solved == 0 && nb <= chi2_max_rows;
+        // DL_CHI2_FUSED=1: finalize inside the GEMM's last-arriving workgroups.  Off by default: measured 19.1 us (GEMM 17.1) against 17.5 us for GEMM + the
+        // separate 1024-thread finalize launch -- the device-scope counter round trip and the dependent tail cost more than the launch they save.
+        static const bool chi2_fused = getenv("DL_CHI2_FUSED") && atoi(getenv("DL_CHI2_FUSED")) != 0;
         if (chi2_path) {
-            dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad, stream);
+            if (nb > 16384) return dl_fail(ctx, "dl_eval_batch: DL_CHI2_GEMM_MAX above 16384 rows");
+            dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad,
+                                chi2_fused ? ctx->gemm_counters : nullptr, th, P, ctx->priors_dev, loglike_dev ? loglike_dev + b0 : nullptr,
+                                logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr, post_mode, stream);
         } else if (ctx->any_transform) {
             // dtilde = L^T (flattheory - flatdata)
             dl_launch_window_gemm(ctx->flat_ws, ctx->N_pad, ctx->wh_dev, ctx->N_pad, ctx->bias_wh_dev, ctx->delta_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad, ctx->N_pad,
@@ -376,7 +387,9 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
                                         stream);
         }
         if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
-        if (chi2_path)
+        if (chi2_path && chi2_fused) {
+            // finalize fused into the GEMM
+        } else if (chi2_path)
             dl_launch_finalize_part(ctx->delta_ws, ctx->N_pad / 16, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
                                     status_dev ? status_dev + b0 : nullptr, post_mode, stream);
         else if (ctx->n_solved > 0)

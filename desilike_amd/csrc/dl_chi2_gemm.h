@@ -27,9 +27,22 @@ typedef double dl_cg_double4 __attribute__((ext_vector_type(4)));
 #define DL_CG_NBUF 3                       // LDS panel buffers
 #define DL_CG_LDS_BYTES (DL_CG_NBUF * DL_CG_ROWS * DL_CG_LD * 8)
 
+// Fused finalize (fin.counters != nullptr): the workgroup that completes a row block's last column block (device-scope counter) sums the partials of its 32
+// points in a fixed order (deterministic whoever arrives last), adds the priors and writes loglike / logprior / status -- no separate finalize launch
+// (a launch ramp plus a cold read of the partials, 4.3 us of a 34 us step).  The counter resets itself for the next launch.
+struct DlChi2Fin {
+    int32_t* counters;       // [row blocks], zero before the first launch; nullptr: partials only (dl_finalize_part_kernel follows)
+    const double* theta;     // [M, n_params]
+    const double* priors;    // [n_params, 5]
+    double* loglike;         // may be null
+    double* logprior;        // may be null
+    int32_t* status;         // may be null
+    int32_t n_params, post_mode;
+};
+
 template <bool DO_LOAD, bool DO_MMA>
 __global__ __launch_bounds__(512) void dl_chi2_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
-                                                           const double* __restrict__ bias, double* __restrict__ part, int M, int K_pad, int n_tiles) {
+                                                           const double* __restrict__ bias, double* __restrict__ part, int M, int K_pad, int n_tiles, DlChi2Fin fin) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
@@ -106,7 +119,48 @@ __global__ __launch_bounds__(512) void dl_chi2_gemm_kernel(const double* __restr
             sq += __shfl_xor(sq, 4, 64);
             sq += __shfl_xor(sq, 8, 64);
             int row = m0 + 16 * wave + g + 4 * r;
-            if (r16 == 0 && row < M) part[(size_t)row * n_tiles + nt] = sq;
+            // agent-scope (write-through, sc1) store: performed device-wide once the wave's vmcnt drains -- no L2 write-back fence is needed before the counter
+            if (r16 == 0 && row < M) __hip_atomic_store(part + (size_t)row * n_tiles + nt, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    if (fin.counters == nullptr) return;
+    // Hand-over without cache-maintenance fences: an agent-scope release (buffer_wbl2) walks the XCD's L2 -- 256 of them cost +20 us -- and a full
+    // __threadfence() also invalidates it under the workgroups still streaming `power` and W~ (+40 us).  Instead every access to the partials and the counter
+    // is itself an agent-scope (sc1) access: stores above are complete when __syncthreads() has drained vmcnt, the counter is an L2-side atomic, the last
+    // arriver's loads below bypass non-coherent lines.
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) {
+        int done = __hip_atomic_fetch_add(fin.counters + mb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (done == n_tiles - 1);
+        if (s_last) __hip_atomic_store(fin.counters + mb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream-ordered)
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // (no acquire fence: the partials are read below with agent-scope loads, which do not hit in the non-coherent L2)
+    const int row = m0 + tid;
+    if (tid < DL_CG_M && row < M) {
+        double chi2 = 0.;
+        for (int t = 0; t < n_tiles; ++t) chi2 += __hip_atomic_load(part + (size_t)row * n_tiles + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double lp = 0.;
+        bool nan_in = false;
+        const double inf = __builtin_huge_val();
+        for (int p = 0; p < fin.n_params; ++p) {
+            double x = fin.theta[(size_t)row * fin.n_params + p];
+            const double* pr = fin.priors + 5 * p;
+            if (x != x) nan_in = true;
+            bool isin = (pr[1] <= x) && (x <= pr[2]);
+            double v = 0.;
+            if (pr[0] == 1.) { double t = x - pr[3]; v = -0.5 * (t * t) / (pr[4] * pr[4]); }   // parameter.py:2007
+            lp += isin ? v : -inf;
+        }
+        double ll = -0.5 * chi2;
+        int st = 0;                    // DL_STATUS_OK
+        if (nan_in) st = 3;            // DL_STATUS_NAN_INPUT
+        else if (lp == -inf) st = 1;   // DL_STATUS_OUT_OF_PRIOR
+        else if (!(ll == ll) || ll == inf || ll == -inf) st = 2;   // DL_STATUS_NONFINITE
+        if (fin.loglike) fin.loglike[row] = fin.post_mode ? (st == 0 ? ll + lp : -inf) : ll;
+        if (fin.logprior) fin.logprior[row] = lp;
+        if (fin.status) fin.status[row] = st;
     }
 }

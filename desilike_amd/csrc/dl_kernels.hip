@@ -351,13 +351,17 @@ void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, in
 // chi2 GEMM path (plain likelihood): partial chi2 per (point, 16-column block) from dl_chi2_gemm_kernel, then one THREAD per point
 // sums them in a fixed order and adds the priors (same status logic as dl_finalize_kernel).
 // ------------------------------------------------------------------------------------------------
-void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, hipStream_t stream) {
+void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, int32_t* counters,
+                         const double* theta, int n_params, const double* priors, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream) {
     const int n_tiles = N_pad / DL_CG_N;
     const int64_t mblocks = (M + DL_CG_M - 1) / DL_CG_M;
     const unsigned grid = (unsigned)(8 * n_tiles * ((mblocks + 7) / 8));
     static bool optin = false;
     if (!optin) { (void)hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES); optin = true; }
-    hipLaunchKernelGGL((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(512), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles);
+    DlChi2Fin fin;
+    fin.counters = counters; fin.theta = theta; fin.priors = priors; fin.loglike = loglike; fin.logprior = logprior; fin.status = status;
+    fin.n_params = n_params; fin.post_mode = post_mode;
+    hipLaunchKernelGGL((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(512), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin);
 }
 
 __global__ __launch_bounds__(256) void dl_finalize_part_kernel(const double* __restrict__ part, int n_tiles, const double* __restrict__ theta, int n_params,
