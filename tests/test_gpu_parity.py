@@ -128,3 +128,23 @@ def test_logposterior_entry_point(contexts):
     assert np.array_equal(np.isneginf(got), np.isneginf(expected)) and np.isneginf(got[2])
     finite = np.isfinite(expected)
     assert np.allclose(got[finite], expected[finite], rtol=1e-15, atol=0.)
+
+
+def test_repeatable_bitwise(contexts):
+    """The chi2 GEMM stages its operands by LDS-DMA ordered only by counted waits and barriers: a misplaced wait shows up as run-to-run differences.
+    300 evaluations of one ragged batch must be bit-identical (fixed summation orders everywhere: no atomics on the data path)."""
+    import torch
+    g, ctx = contexts('cfg2_shapefit_window_dense')
+    rng = np.random.RandomState(11)
+    lo = np.array([0.9, 0.9, -0.5, 0.5, 0.5, -3.])
+    hi = np.array([1.1, 1.1, 0.5, 1.5, 3.5, 3.])
+    theta = torch.as_tensor(rng.uniform(lo, hi, size=(1000 + 13, 6)), dtype=torch.float64, device='cuda').contiguous()
+    first, out = None, torch.empty(len(theta), dtype=torch.float64, device='cuda')
+    for it in range(300):
+        ctx.eval_batch(theta, loglike=out)
+        if first is None:
+            first = out.clone()
+        else:
+            assert torch.equal(first, out), it
+    torch.cuda.synchronize()
+    assert torch.isfinite(first).all()
