@@ -31,15 +31,19 @@
 // pins the order of an unrolled loop: the four accumulators must be complete, and no memory access may move across (without it the scheduler
 // turns the convolution below into four serial chains over the whole window, with the window held in 120 VGPRs)
 #define DL_PIN4(a, b, c, d) __asm__ volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
+// streaming store: the row goes out to memory while the kernel is still running instead of sitting dirty in L2 until the end-of-kernel write-back
+#define DL_STREAM_STORE(ptr, value) __hip_atomic_store((ptr), (value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
 #define DL_HD inline
 #define DL_PIN4(a, b, c, d)
+#define DL_STREAM_STORE(ptr, value) (*(ptr) = (value))
 #endif
 
 #define DL_MAX_ELL 5
 #define DL_MAX_MU 32
 #define DL_MAX_EFT 8
 #define DL_FS_THREADS 256
+#define DL_FS_KT 192          // threads of the fast kernel that build the spline (waves 0-2); wave 3 runs the per-mu chain beside them
 #define DL_MAX_SEG 64
 #define DL_SEG_PARTS 4      // threads cooperating on the warm-up dot product of one segment (DL_MAX_SEG * DL_SEG_PARTS = DL_FS_THREADS)
 #define DL_MAX_X 16        // emulator inputs
@@ -172,67 +176,83 @@ DL_HD void dl_ap_qparqper(const DlObsDev& o, const double* th, double& qpar, dou
     }
 }
 
-// phase 0 + 1 (no barrier needed between them): per-point scalars, per-mu AP factors and weights, template at the knots
-DL_HD void dl_fs_phase01(int tid, int nthr, const DlObsDev& o, const double* th, const DlFsShared& s) {
-    // the mu nodes are handled by the LAST threads of the workgroup (they own fewer template knots below) and thread 0 keeps the scalars
-    const int mnode = nthr - 1 - tid;
-    if (mnode < o.n_mu || tid == 0) {
-        double qpar, qper;
-        dl_ap_qparqper(o, th, qpar, qper);
-        double sigpar = dl_get(o.sigpar, th), sigper = dl_get(o.sigper, th);
-        double jac = 1. / (qpar * qper * qper);                    // tgc/base.py:217
-        double f = o.f_fid * dl_get(o.df, th);                     // power_template.py:757
-        double b1X = dl_get(o.b1X, th), b1Y = dl_get(o.b1Y, th);
-        if (mnode < o.n_mu) {
-            // ap_k_mu, tgc/base.py:216-222: factorap = sqrt(1 + mu^2 (1/qap^2 - 1)); muap = mu / qap / factorap.
-            // Written so that the square root, the division and the logarithm all start from x = factorap^2 (short dependent chain):
-            // muap^2 = mu^2 / (qap^2 x), log10(factorap / qper) = log10(x) / 2 - log10(qper)
-            const int m = mnode;
-            double rq = qper / qpar;                                // 1 / qap
-            double iq2 = rq * rq;
-            double mu = o.mu[m];
-            double x = 1. + mu * mu * (iq2 - 1.);
-            double fac = sqrt(x);
-            double mup2 = mu * mu * iq2 / x;
-            s.pt[DL_PT_FAC + m] = fac;
-            const double lq = 0.5 * log10(x) - log10(qper);       // log10(kap) = log10(k) + log10(factorap / qper)
-            s.pt[DL_PT_LQ + m] = lq;
-            s.pt[DL_PT_LQH + m] = lq * o.inv_hx;
-            // full_shape.py:492: sigmapar^2 muap^2 + sigmaper^2 (1 - muap^2)
-            s.pt[DL_PT_SD + m] = sigpar * sigpar * mup2 + sigper * sigper * (1. - mup2);
-            double fm2 = f * mup2;
-            double bias = (b1X + fm2) * (b1Y + fm2);               // = b1X b1Y + (b1X + b1Y) f mu'^2 + f^2 mu'^4, full_shape.py:550
-            for (int l = 0; l < DL_MAX_ELL; ++l) {
-                double w = (l < o.n_ell) ? jac * o.wmu[l * o.n_mu + m] : 0.;
-                s.pt[DL_PT_OM + m * 8 + l] = w * bias;
-                s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 0] = w;
-                s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 1] = w * fm2;
-                s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 2] = w * (fm2 * fm2);
-            }
-            s.pt[DL_PT_OM + m * 8 + 5] = (o.ell0 >= 0) ? jac * o.wmu[o.ell0 * o.n_mu + m] : 0.;
-            s.pt[DL_PT_OM + m * 8 + 6] = 0.;
-            s.pt[DL_PT_OM + m * 8 + 7] = 0.;
-        }
-        if (tid == 0) {
-            for (int mm = o.n_mu; mm < ((o.n_mu + 3) & ~3); ++mm) {   // pad the mu nodes to a multiple of 4 with zero weights (unrolled loops)
-                s.pt[DL_PT_LQ + mm] = 0.; s.pt[DL_PT_LQH + mm] = 0.; s.pt[DL_PT_FAC + mm] = 0.; s.pt[DL_PT_SD + mm] = 0.;
-                for (int c = 0; c < 8; ++c) s.pt[DL_PT_OM + mm * 8 + c] = 0.;
-                for (int c = 0; c < 15; ++c) s.pt[DL_PT_W3 + mm * 15 + c] = 0.;
-            }
-            s.pt[DL_PT_QPAR] = qpar;
-            s.pt[DL_PT_QPER] = qper;
-            s.pt[DL_PT_JAC] = jac;
-            s.pt[DL_PT_F] = f;
-            s.pt[DL_PT_B1X] = b1X;
-            s.pt[DL_PT_B1Y] = b1Y;
-            s.pt[DL_PT_SN0ND] = dl_get(o.sn0, th) / o.nd;          // full_shape.py:549
-            s.pt[DL_PT_DAMP] = (sigpar != 0. || sigper != 0.) ? 1. : 0.;
-            for (int c = 0; c < o.n_ct; ++c)                       // full_shape.py:630
-                s.pt[DL_PT_CT + c] = 0.5 * (dl_get(o.ct_in[c][0], th) + dl_get(o.ct_in[c][1], th));
-            for (int c = 0; c < o.n_sn; ++c)                       // full_shape.py:631
-                s.pt[DL_PT_SN + c] = dl_get(o.sn_in[c], th) / o.nd;
-        }
+// ---- phase 0 + 1: per-point scalars, per-mu AP factors and weights, template at the knots ---------------------------------------------------
+// The per-mu work is a LONG dependent chain (division -> log10 / division / square root -> weights: ~150 fp64 operations deep, ~3 us) whose results
+// are only needed by phase 3.  It is written in three parts so that the fast kernel can run it in a wave of its own, one part per phase, beside the
+// knot / convolution / coefficient work of the other waves (in-kernel stamps: phase 01 took 4.3 us of a 9.2 us workgroup life with the chain inside it).
+struct DlMuCarry {
+    double qpar, qper, jac, f, b1X, b1Y, sigpar, sigper;   // per-point scalars
+    double mu, iq2, x;                                      // part A
+    double fac, lq, mup2;                                   // part B
+};
+
+// part A: scalars, x = factorap^2 (m: mu node, clamped by the caller)
+DL_HD void dl_fs_mu_partA(const DlObsDev& o, const double* th, int m, DlMuCarry& c) {
+    dl_ap_qparqper(o, th, c.qpar, c.qper);
+    c.sigpar = dl_get(o.sigpar, th); c.sigper = dl_get(o.sigper, th);
+    c.jac = 1. / (c.qpar * c.qper * c.qper);                  // tgc/base.py:217
+    c.f = o.f_fid * dl_get(o.df, th);                          // power_template.py:757
+    c.b1X = dl_get(o.b1X, th); c.b1Y = dl_get(o.b1Y, th);
+    // ap_k_mu, tgc/base.py:216-222: factorap = sqrt(1 + mu^2 (1/qap^2 - 1)); muap = mu / qap / factorap.
+    // Written so that the square root, the division and the logarithm all start from x = factorap^2 (short dependent chain):
+    // muap^2 = mu^2 / (qap^2 x), log10(factorap / qper) = log10(x) / 2 - log10(qper)
+    const double rq = c.qper / c.qpar;                         // 1 / qap
+    c.iq2 = rq * rq;
+    c.mu = o.mu[m];
+    c.x = 1. + c.mu * c.mu * (c.iq2 - 1.);
+}
+
+// part B: the transcendental part
+DL_HD void dl_fs_mu_partB(DlMuCarry& c) {
+    c.fac = sqrt(c.x);
+    c.mup2 = c.mu * c.mu * c.iq2 / c.x;
+    c.lq = 0.5 * log10(c.x) - log10(c.qper);                   // log10(kap) = log10(k) + log10(factorap / qper)
+}
+
+// part C: weights of mu node m -> LDS
+DL_HD void dl_fs_mu_partC(const DlObsDev& o, const DlFsShared& s, int m, const DlMuCarry& c) {
+    s.pt[DL_PT_FAC + m] = c.fac;
+    s.pt[DL_PT_LQ + m] = c.lq;
+    s.pt[DL_PT_LQH + m] = c.lq * o.inv_hx;
+    // full_shape.py:492: sigmapar^2 muap^2 + sigmaper^2 (1 - muap^2)
+    s.pt[DL_PT_SD + m] = c.sigpar * c.sigpar * c.mup2 + c.sigper * c.sigper * (1. - c.mup2);
+    const double fm2 = c.f * c.mup2;
+    const double bias = (c.b1X + fm2) * (c.b1Y + fm2);         // = b1X b1Y + (b1X + b1Y) f mu'^2 + f^2 mu'^4, full_shape.py:550
+    for (int l = 0; l < DL_MAX_ELL; ++l) {
+        double w = (l < o.n_ell) ? c.jac * o.wmu[l * o.n_mu + m] : 0.;
+        s.pt[DL_PT_OM + m * 8 + l] = w * bias;
+        s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 0] = w;
+        s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 1] = w * fm2;
+        s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 2] = w * (fm2 * fm2);
     }
+    s.pt[DL_PT_OM + m * 8 + 5] = (o.ell0 >= 0) ? c.jac * o.wmu[o.ell0 * o.n_mu + m] : 0.;
+    s.pt[DL_PT_OM + m * 8 + 6] = 0.;
+    s.pt[DL_PT_OM + m * 8 + 7] = 0.;
+}
+
+// per-point scalars and the zero padding of the mu nodes (one thread)
+DL_HD void dl_fs_scalars(const DlObsDev& o, const double* th, const DlFsShared& s, const DlMuCarry& c) {
+    for (int mm = o.n_mu; mm < ((o.n_mu + 3) & ~3); ++mm) {   // pad the mu nodes to a multiple of 4 with zero weights (unrolled loops)
+        s.pt[DL_PT_LQ + mm] = 0.; s.pt[DL_PT_LQH + mm] = 0.; s.pt[DL_PT_FAC + mm] = 0.; s.pt[DL_PT_SD + mm] = 0.;
+        for (int q = 0; q < 8; ++q) s.pt[DL_PT_OM + mm * 8 + q] = 0.;
+        for (int q = 0; q < 15; ++q) s.pt[DL_PT_W3 + mm * 15 + q] = 0.;
+    }
+    s.pt[DL_PT_QPAR] = c.qpar;
+    s.pt[DL_PT_QPER] = c.qper;
+    s.pt[DL_PT_JAC] = c.jac;
+    s.pt[DL_PT_F] = c.f;
+    s.pt[DL_PT_B1X] = c.b1X;
+    s.pt[DL_PT_B1Y] = c.b1Y;
+    s.pt[DL_PT_SN0ND] = dl_get(o.sn0, th) / o.nd;              // full_shape.py:549
+    s.pt[DL_PT_DAMP] = (c.sigpar != 0. || c.sigper != 0.) ? 1. : 0.;
+    for (int q = 0; q < o.n_ct; ++q)                           // full_shape.py:630
+        s.pt[DL_PT_CT + q] = 0.5 * (dl_get(o.ct_in[q][0], th) + dl_get(o.ct_in[q][1], th));
+    for (int q = 0; q < o.n_sn; ++q)                           // full_shape.py:631
+        s.pt[DL_PT_SN + q] = dl_get(o.sn_in[q], th) / o.nd;
+}
+
+// template at the knots (or the fixed interval polynomials), nthr threads
+DL_HD void dl_fs_knots(int tid, int nthr, const DlObsDev& o, const double* th, const DlFsShared& s) {
     const int n_t = o.n_t;
     if (o.toeplitz && !o.fixed_spline && tid < 2 * DL_FIR_PAD) s.y[tid < DL_FIR_PAD ? tid - DL_FIR_PAD : n_t + tid - DL_FIR_PAD] = 0.;   // zero padding
     if (o.fixed_spline) {
@@ -244,6 +264,18 @@ DL_HD void dl_fs_phase01(int tid, int nthr, const DlObsDev& o, const double* th,
     } else {
         for (int j = tid; j < n_t; j += nthr) s.y[j] = o.pk_fid[j];
     }
+}
+
+// the whole of phase 0 + 1 in one call (general kernel, host-side constant folding): mu nodes on the last threads, scalars on thread 0
+DL_HD void dl_fs_phase01(int tid, int nthr, const DlObsDev& o, const double* th, const DlFsShared& s) {
+    const int mnode = nthr - 1 - tid;
+    if (mnode < o.n_mu || tid == 0) {
+        DlMuCarry c;
+        dl_fs_mu_partA(o, th, mnode < o.n_mu ? mnode : 0, c);
+        if (mnode < o.n_mu) { dl_fs_mu_partB(c); dl_fs_mu_partC(o, s, mnode, c); }
+        if (tid == 0) dl_fs_scalars(o, th, s, c);
+    }
+    dl_fs_knots(tid, nthr, o, th, s);
 }
 
 // phase 2a: right-hand side of the reduced (n_t - 2 unknowns) not-a-knot system, pre-multiplied by the pivots
@@ -393,8 +425,8 @@ DL_HD void dl_fs_phase2_fir(int tid, int nthr, const DlObsDev& o, const DlFsShar
         for (int q = 0; q < 4; ++q)
             if (j0 + q < n) s.M[j0 + q] = acc[q] * scale;
     }
-    // the upper half of the workgroup has no window to convolve (n <= 2 nthr): it tabulates mu^k for the end corrections
-    for (int k = tid - nthr / 2; k >= 0 && k <= 2 * DL_FIR_PAD; k += (nthr + 1) / 2) {
+    // the last 2 DL_FIR_PAD + 1 threads (no window to convolve while n <= 4 (nthr - 65)) tabulate mu^k for the end corrections
+    for (int k = tid - (nthr - 2 * DL_FIR_PAD - 1); k >= 0 && k <= 2 * DL_FIR_PAD; k += nthr) {
         double v = exp((double)k * DL_FIR_LN_ABS_MU);
         s.pt[DL_PT_PART + k] = (k & 1) ? -v : v;
     }
@@ -406,7 +438,7 @@ DL_HD double dl_fir_mu_pow(const DlFsShared& s, int k) {   // mu^k (tabulated by
 
 // moments -> interval polynomials in u = (x - x0) inv_hx - j, end corrections applied on the fly.  dlt_pref[it] = o.dlt[tid + it nthr], loaded by
 // the caller at the top of the kernel (the round trip overlaps the earlier phases); iterations beyond DL_TOEP_PREF read o.dlt directly.
-#define DL_TOEP_PREF 2
+#define DL_TOEP_PREF 3
 DL_HD void dl_fs_phase2d_toep(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, const double* dlt_pref) {
     const int n = o.n_t;
     const double hx = 1. / o.inv_hx, ihx = o.inv_hx;
@@ -655,7 +687,7 @@ DL_HD void dl_fs_phase3_pair(int tid, int nthr, const DlObsDev& o, const DlFsSha
 // phase 4: coalesced store of the staged multipoles
 // power_row: row 0 of this point (already offset by col_offset); ld: leading dimension of the power buffer
 DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, const double* th, double* power_row, int64_t ld) {
-    for (int idx = tid; idx < o.n_in; idx += nthr) power_row[idx] = s.out[idx];
+    for (int idx = tid; idx < o.n_in; idx += nthr) DL_STREAM_STORE(&power_row[idx], s.out[idx]);
     for (int c = tid; c < o.n_pass; c += nthr) power_row[o.n_in + c] = dl_get(o.pass_in[c], th);
     if (o.n_var > 0 && o.n_ct > 0) {
         // d(power)/d(ct) = 0.5 ct_matrix[:, c] P_dd,l=0 per tracer (full_shape.py:630, 633): rows 1 + slot of this point

@@ -8,7 +8,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "dl_fullshape.h"
 #include "dl_kernels.h"
@@ -20,9 +22,13 @@
 // global-memory pointer (global_load, not flat_load) and every scalar field is an SGPR, never re-read in a loop.
 template <bool FAST, int NL, bool EFT>
 __global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power,
-                                                                     int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after) {
+                                                                     int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
+    // DL_FS_STAMPS diagnostics: s_memtime (shader clock) of thread 0 at entry, after each barrier and at exit, 8 slots per workgroup
+#define DL_STAMP(slot) if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();
+    DL_STAMP(0)
+    if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();   // 100 MHz, same on every XCD
     // FAST instantiations are only launched when the convolution path applies (or the spline is fixed): the segmented sweeps are not compiled in
     const bool toep = !o.fixed_spline && (FAST || o.toeplitz);
     const DlFsShared s = dl_fs_shared_carve(lds, o.n_t, o.n_in, dl_fs_n_dd0(o), toep);
@@ -30,46 +36,87 @@ __global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_kernel(const Dl
     const int tid = threadIdx.x, nthr = DL_FS_THREADS;
     if (stop_after == -1) return;  // stop_after != 0: timing diagnostics only (DL_FS_STOP), outputs are then incomplete
     // constants of the later phases are requested now: their round trip hides behind phase 0/1
-    double dlt_pref[DL_TOEP_PREF];
-#pragma unroll
-    for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (toep && tid + it * nthr < o.n_t - 1) ? o.dlt[tid + it * nthr] : 0.;
     double lk_pref[DL_P3_PREF];
 #pragma unroll
     for (int it = 0; it < DL_P3_PREF; ++it) lk_pref[it] = (tid + it * nthr < o.n_kin) ? o.lkin[tid + it * nthr] : 0.;
-    dl_fs_phase01(tid, nthr, o, th, s);
-    __syncthreads();
-    if (stop_after == 1) return;
-    if (toep) {
-        dl_fs_phase2_fir(tid, nthr, o, s);
+    if (FAST) {
+        // Waves 0-2 (DL_FS_KT threads) build the spline: knots -> convolution -> interval polynomials.  Wave 3 runs the per-mu chain beside them, one part
+        // per phase (its results are first read in phase 3), lane 63 of it keeps the per-point scalars.
+        constexpr int KT = DL_FS_KT;
+        const bool mu_wave = tid >= KT;
+        const int m = tid - KT;                                  // mu node of this lane of the mu wave
+        const bool mu_lane = mu_wave && m < o.n_mu, scalar_lane = (tid == nthr - 1);
+        DlMuCarry c;
+        double dlt_pref[DL_TOEP_PREF];
+#pragma unroll
+        for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (toep && !mu_wave && tid + it * KT < o.n_t - 1) ? o.dlt[tid + it * KT] : 0.;
+        if (mu_wave) dl_fs_mu_partA(o, th, mu_lane ? m : 0, c);
+        else dl_fs_knots(tid, KT, o, th, s);
+        if (o.fixed_spline && mu_wave) {
+            dl_fs_mu_partB(c);
+            if (mu_lane) dl_fs_mu_partC(o, s, m, c);
+            if (scalar_lane) dl_fs_scalars(o, th, s, c);
+        }
         __syncthreads();
-        if (stop_after == 2) return;
-        dl_fs_phase2d_toep(tid, nthr, o, s, dlt_pref);
+        DL_STAMP(1)
+        if (stop_after == 1) return;
+        if (toep) {
+            if (mu_wave) dl_fs_mu_partB(c);
+            else dl_fs_phase2_fir(tid, KT, o, s);
+            __syncthreads();
+            DL_STAMP(2)
+            if (stop_after == 2) return;
+            if (mu_wave) {
+                if (mu_lane) dl_fs_mu_partC(o, s, m, c);
+                if (scalar_lane) dl_fs_scalars(o, th, s, c);
+            } else dl_fs_phase2d_toep(tid, KT, o, s, dlt_pref);
+            __syncthreads();
+            DL_STAMP(3)
+            if (stop_after == 5) return;
+        }
+    } else {
+        dl_fs_phase01(tid, nthr, o, th, s);
         __syncthreads();
-        if (stop_after == 5) return;
-    } else if (!FAST && !o.fixed_spline) {
-        dl_fs_phase2a(tid, nthr, o, s);
-        __syncthreads();
-        if (stop_after == 2) return;
-        dl_fs_phase2b_dot(tid, nthr, o, s);
-        __syncthreads();
-        dl_fs_phase2b(tid, nthr, o, s);
-        __syncthreads();
-        if (stop_after == 3) return;
-        dl_fs_phase2c_dot(tid, nthr, o, s);
-        __syncthreads();
-        dl_fs_phase2c(tid, nthr, o, s);
-        __syncthreads();
-        if (stop_after == 4) return;
-        dl_fs_phase2d(tid, nthr, o, s);
-        __syncthreads();
-        if (stop_after == 5) return;
+        if (stop_after == 1) return;
+        if (toep) {
+            double dlt_pref[DL_TOEP_PREF];
+#pragma unroll
+            for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (tid + it * nthr < o.n_t - 1) ? o.dlt[tid + it * nthr] : 0.;
+            dl_fs_phase2_fir(tid, nthr, o, s);
+            __syncthreads();
+            if (stop_after == 2) return;
+            dl_fs_phase2d_toep(tid, nthr, o, s, dlt_pref);
+            __syncthreads();
+            if (stop_after == 5) return;
+        } else if (!o.fixed_spline) {
+            dl_fs_phase2a(tid, nthr, o, s);
+            __syncthreads();
+            if (stop_after == 2) return;
+            dl_fs_phase2b_dot(tid, nthr, o, s);
+            __syncthreads();
+            dl_fs_phase2b(tid, nthr, o, s);
+            __syncthreads();
+            if (stop_after == 3) return;
+            dl_fs_phase2c_dot(tid, nthr, o, s);
+            __syncthreads();
+            dl_fs_phase2c(tid, nthr, o, s);
+            __syncthreads();
+            if (stop_after == 4) return;
+            dl_fs_phase2d(tid, nthr, o, s);
+            __syncthreads();
+            if (stop_after == 5) return;
+        }
     }
     double* prow = power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset;
     double* trow = tables ? tables + (size_t)b * ld_tables : nullptr;
     if (FAST && !EFT) dl_fs_phase3_pair<NL, EFT>(tid, nthr, o, s, lk_pref);   // (with counter terms the pair variant spills registers)
     else dl_fs_phase3<FAST, NL, EFT>(tid, nthr, o, s, trow, lk_pref);
     __syncthreads();
+    DL_STAMP(4)
     dl_fs_phase4(tid, nthr, o, s, th, prow, ld_power);
+    DL_STAMP(5)
+    if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#undef DL_STAMP
 }
 
 // BAO wiggle model: one workgroup per point; constant splines read from global memory, no per-point spline build
@@ -94,6 +141,13 @@ __global__ __launch_bounds__(DL_FS_THREADS) void dl_emulated_kernel(const DlObsD
 void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
                          int64_t ld_tables, hipStream_t stream) {
     static const int stop_after = getenv("DL_FS_STOP") ? atoi(getenv("DL_FS_STOP")) : 0;   // per-phase timing diagnostics
+    // DL_FS_STAMPS=<file>: in-kernel timestamps of the launches with B >= 256 are appended to <file> as text (synchronises: diagnostics only)
+    static const char* stamp_file = getenv("DL_FS_STAMPS");
+    static unsigned long long* stamps_dev = nullptr;
+    static int stamp_launches = 0;
+    if (stamp_file && !stamps_dev) { (void)hipMalloc((void**)&stamps_dev, (size_t)65536 * 8 * sizeof(unsigned long long)); }
+    unsigned long long* stamps = (stamp_file && B >= 256 && B <= 65536 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
+    if (stamp_file && B >= 256) stamp_launches++;
     for (int i = 0; i < n_obs; ++i) {  // one launch per observable (1-2 in practice)
         if (obs_host[i].theory == 3) {   // DL_THEORY_EMULATED
             size_t shm = dl_emu_shared_doubles(obs_host[i].n_var) * sizeof(double);
@@ -109,7 +163,17 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
         size_t shmem = dl_fs_shared_doubles_obs(obs_host[i]) * sizeof(double);
         auto launch = [&](auto kernel) {
             if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  // e.g. 2000-knot BAO tables
-            hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shmem, stream, obs_host[i], theta, n_params, power, ld_power, tables, ld_tables, stop_after);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shmem, stream, obs_host[i], theta, n_params, power, ld_power, tables, ld_tables, stop_after, stamps);
+            if (stamps) {
+                (void)hipStreamSynchronize(stream);
+                std::vector<unsigned long long> h((size_t)B * 8);
+                (void)hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+                if (FILE* f = fopen(stamp_file, "a")) {
+                    for (int64_t w = 0; w < B; ++w) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", h[(size_t)w * 8 + q]); fprintf(f, "\n"); }
+                    fprintf(f, "#\n");
+                    fclose(f);
+                }
+            }
         };
         const DlObsDev& oh = obs_host[i];
         bool nl3 = oh.n_ell <= 3, eft = oh.n_ct > 0 || oh.n_sn > 0;

@@ -37,21 +37,54 @@ static void run_point(const DlObsDev& o, const double* th, double* prow, double*
     const bool toep = o.toeplitz && !o.fixed_spline;
     DlFsShared s = dl_fs_shared_carve(lds.data(), o.n_t, o.n_in, -1, toep);
     const int nthr = DL_FS_THREADS;
-    for (int tid = 0; tid < nthr; ++tid) dl_fs_phase01(tid, nthr, o, th, s);
-    if (toep) {
-        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2_fir(tid, nthr, o, s);
+    const bool fast = !(trow || !o.uniform_knots || !(o.toeplitz || o.fixed_spline));   // same dispatch as dl_launch_fullshape
+    if (fast) {
+        // mirrors dl_fullshape_kernel<FAST = true>: threads 0 .. KT-1 build the spline, the last wave runs the per-mu chain, one part per phase
+        const int KT = DL_FS_KT;
+        std::vector<DlMuCarry> carry(nthr);
+        auto mu_lane = [&](int tid) { return tid >= KT && tid - KT < o.n_mu; };
         for (int tid = 0; tid < nthr; ++tid) {
-            double dlt_pref[DL_TOEP_PREF];
-            for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (tid + it * nthr < o.n_t - 1) ? o.dlt[tid + it * nthr] : 0.;
-            dl_fs_phase2d_toep(tid, nthr, o, s, dlt_pref);
+            if (tid >= KT) dl_fs_mu_partA(o, th, mu_lane(tid) ? tid - KT : 0, carry[tid]);
+            else dl_fs_knots(tid, KT, o, th, s);
+            if (o.fixed_spline && tid >= KT) {
+                dl_fs_mu_partB(carry[tid]);
+                if (mu_lane(tid)) dl_fs_mu_partC(o, s, tid - KT, carry[tid]);
+                if (tid == nthr - 1) dl_fs_scalars(o, th, s, carry[tid]);
+            }
         }
-    } else if (!o.fixed_spline) {
-        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2a(tid, nthr, o, s);
-        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2b_dot(tid, nthr, o, s);
-        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2b(tid, nthr, o, s);
-        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2c_dot(tid, nthr, o, s);
-        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2c(tid, nthr, o, s);
-        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2d(tid, nthr, o, s);
+        if (toep) {
+            for (int tid = 0; tid < nthr; ++tid) {
+                if (tid >= KT) dl_fs_mu_partB(carry[tid]);
+                else dl_fs_phase2_fir(tid, KT, o, s);
+            }
+            for (int tid = 0; tid < nthr; ++tid) {
+                if (tid >= KT) {
+                    if (mu_lane(tid)) dl_fs_mu_partC(o, s, tid - KT, carry[tid]);
+                    if (tid == nthr - 1) dl_fs_scalars(o, th, s, carry[tid]);
+                } else {
+                    double dlt_pref[DL_TOEP_PREF];
+                    for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (tid + it * KT < o.n_t - 1) ? o.dlt[tid + it * KT] : 0.;
+                    dl_fs_phase2d_toep(tid, KT, o, s, dlt_pref);
+                }
+            }
+        }
+    } else {
+        for (int tid = 0; tid < nthr; ++tid) dl_fs_phase01(tid, nthr, o, th, s);
+        if (toep) {
+            for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2_fir(tid, nthr, o, s);
+            for (int tid = 0; tid < nthr; ++tid) {
+                double dlt_pref[DL_TOEP_PREF];
+                for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (tid + it * nthr < o.n_t - 1) ? o.dlt[tid + it * nthr] : 0.;
+                dl_fs_phase2d_toep(tid, nthr, o, s, dlt_pref);
+            }
+        } else if (!o.fixed_spline) {
+            for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2a(tid, nthr, o, s);
+            for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2b_dot(tid, nthr, o, s);
+            for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2b(tid, nthr, o, s);
+            for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2c_dot(tid, nthr, o, s);
+            for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2c(tid, nthr, o, s);
+            for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2d(tid, nthr, o, s);
+        }
     }
     for (int tid = 0; tid < nthr; ++tid) {
         bool nl3 = o.n_ell <= 3, eft = o.n_ct > 0 || o.n_sn > 0;   // same dispatch as dl_launch_fullshape
