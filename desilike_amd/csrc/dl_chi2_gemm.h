@@ -5,7 +5,7 @@
 //   part[b, nt] -- M x N_pad / 16 doubles instead of the M x N_pad x (K splits) residual slabs of the split-K kernel (dl_gemm_tiled.h),
 //   which the plain-likelihood finalize then sums in a fixed order (deterministic).
 //
-//   workgroup = 8 waves; K advances in 128-wide panels: 32 A rows + 16 Wt rows x 128 k = 48 KB, fetched as full 1 KB row segments (one wave =
+//   workgroup = DL_CG_WAVES waves; K advances in 128-wide panels: 32 A rows + 16 Wt rows x 128 k = 48 KB, fetched as full 1 KB row segments (one wave =
 //   one row), staged through LDS (rows padded to 130 doubles: bank stride 4 mod 64, conflict-free ds_read_b64 for the MFMA operand layout),
 //   by LDS-DMA (global_load_lds_dwordx4), triple-buffered in LDS with two panels in flight (operands come cold from the theory kernel).
 //   Within a panel the 32 k-steps of v_mfma_f64_16x16x4_f64 are dealt round-robin to the 8 waves (in-workgroup split-K, reduced through LDS at
@@ -23,7 +23,10 @@ typedef double dl_cg_double4 __attribute__((ext_vector_type(4)));
 #define DL_CG_KP 128                       // panel width
 #define DL_CG_LD (DL_CG_KP + 2)            // padded LDS row (doubles)
 #define DL_CG_ROWS (DL_CG_M + DL_CG_N)
-#define DL_CG_VPT (DL_CG_ROWS / 8)         // row segments (1 KB LDS-DMA pieces) per wave and panel = 6
+#ifndef DL_CG_WAVES
+#define DL_CG_WAVES 16                     // waves per workgroup: 4 per SIMD hide the LDS-read -> MFMA latency of each other (8: 8.0 us main loop; 16: see DESIGN)
+#endif
+#define DL_CG_VPT (DL_CG_ROWS / DL_CG_WAVES)   // row segments (1 KB LDS-DMA pieces) per wave and panel
 #define DL_CG_NBUF 3                       // LDS panel buffers
 #define DL_CG_LDS_BYTES (DL_CG_NBUF * DL_CG_ROWS * DL_CG_LD * 8)
 
@@ -38,10 +41,11 @@ struct DlChi2Fin {
     double* logprior;        // may be null
     int32_t* status;         // may be null
     int32_t n_params, post_mode;
+    unsigned long long* stamps;   // DL_CG_STAMPS diagnostics (nullptr in production): 8 slots per workgroup, see dl_fullshape_kernel
 };
 
 template <bool DO_LOAD, bool DO_MMA>
-__global__ __launch_bounds__(512) void dl_chi2_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
+__global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
                                                            const double* __restrict__ bias, double* __restrict__ part, int M, int K_pad, int n_tiles, DlChi2Fin fin) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -52,77 +56,86 @@ __global__ __launch_bounds__(512) void dl_chi2_gemm_kernel(const double* __restr
     const int nt = rest % n_tiles, mb = xcd + 8 * (rest / n_tiles);
     const int m0 = mb * DL_CG_M, n0 = nt * DL_CG_N;
     if (m0 >= M) return;
+#define DL_CG_STAMP(slot, fn) if (fin.stamps != nullptr && tid == 0) fin.stamps[(size_t)blockIdx.x * 8 + (slot)] = fn();
+    DL_CG_STAMP(0, __builtin_amdgcn_s_memtime) DL_CG_STAMP(6, __builtin_amdgcn_s_memrealtime)
     // staging by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write): piece i of wave w is the 1 KB segment of row w + 8 i of the
     // panel (rows 0-31 = A, 32-47 = Wt); the LDS destination of a piece is wave-uniform base + 16 B x lane
     const char* src[DL_CG_VPT];
 #pragma unroll
     for (int i = 0; i < DL_CG_VPT; ++i) {
-        int row = wave + 8 * i;
+        int row = wave + DL_CG_WAVES * i;
         const double* base;
         if (row < DL_CG_M) { int ar = m0 + row; if (ar > M - 1) ar = M - 1; base = A + (size_t)ar * lda; }
         else base = Wt + (size_t)(n0 + row - DL_CG_M) * ldw;
         src[i] = reinterpret_cast<const char*>(base) + 16 * lane;
     }
+    const double bj = bias[n0 + r16];        // requested now, used in the epilogue
     const int n_panels = K_pad / DL_CG_KP;   // K_pad is a multiple of the panel width (padding columns are zero in A and Wt)
-    constexpr int BUF = DL_CG_ROWS * DL_CG_LD, NJ = DL_CG_KP / 4 / 8;   // doubles per LDS buffer; k-steps per wave and panel
-    // panels beyond the last are redirected to the last one (and never read): the number of requests in flight stays the same in every iteration
+    constexpr int BUF = DL_CG_ROWS * DL_CG_LD, NJ = DL_CG_KP / 4 / DL_CG_WAVES;   // doubles per LDS buffer; k-steps per wave and panel
 #define DL_CG_DMA(p)                                                                                                                 \
-    {   const size_t off = (size_t)((p) < n_panels ? (p) : n_panels - 1) * (DL_CG_KP * 8);                                           \
+    {   const size_t off = (size_t)(p) * (DL_CG_KP * 8);                                                                             \
         double* dst = lds + ((p) % DL_CG_NBUF) * BUF + wave * DL_CG_LD;                                                              \
         _Pragma("unroll") for (int i = 0; i < DL_CG_VPT; ++i)                                                                        \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + off),                          \
-                                             (__attribute__((address_space(3))) void*)(dst + 8 * i * DL_CG_LD), 16, 0, 0); }
+                                             (__attribute__((address_space(3))) void*)(dst + DL_CG_WAVES * i * DL_CG_LD), 16, 0, 0); }
     dl_cg_double4 acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
     const double* la = lds + r16 * DL_CG_LD + g;
-    // prologue: panels 0 and 1 requested; panel 0 landed (counted wait: the 6 pieces of panel 1 may still fly) and visible (barrier)
-    if (DO_LOAD) { DL_CG_DMA(0) DL_CG_DMA(1) }
-    __asm__ volatile("s_waitcnt vmcnt(%0)" : : "n"(DL_CG_VPT) : "memory");
+    // prologue: panels 0 and 1 requested; panel 0 landed (counted wait: the pieces of panel 1 may still fly) and visible (barrier)
+    if (DO_LOAD) { DL_CG_DMA(0) if (n_panels > 1) { DL_CG_DMA(1) } }
+    if (n_panels > 1) __asm__ volatile("s_waitcnt vmcnt(%0)" : : "n"(DL_CG_VPT) : "memory");
+    else __asm__ volatile("s_waitcnt vmcnt(0)" : : : "memory");
     __builtin_amdgcn_s_barrier();
+    DL_CG_STAMP(1, __builtin_amdgcn_s_memtime)
+#define DL_CG_MULTIPLY(p)                                                                                                            \
+    {   const double* lb = la + ((p) % DL_CG_NBUF) * BUF;                                                                            \
+        double a0[NJ], a1[NJ], bb[NJ];                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                                             \
+            const int ks = wave + DL_CG_WAVES * j; a0[j] = lb[4 * ks]; a1[j] = lb[16 * DL_CG_LD + 4 * ks]; bb[j] = lb[32 * DL_CG_LD + 4 * ks]; } \
+        if (DO_MMA) { _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                               \
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[j], bb[j], acc0, 0, 0, 0);                                                \
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[j], bb[j], acc1, 0, 0, 0); } } }
     // iteration p: request panel p + 2 (its buffer held panel p - 1, whose reads every wave retired before the last barrier), read the operands of
-    // panel p, multiply, then wait until the wave's own pieces of panel p + 1 have landed (the 6 youngest requests, panel p + 2, stay in flight)
-    // and its LDS reads are back; one raw barrier per panel (no vmcnt(0) anywhere in the loop)
-    for (int p = 0; p < n_panels; ++p) {
+    // panel p, multiply, then wait until the wave's own pieces of panel p + 1 have landed (the youngest requests, panel p + 2, stay in flight)
+    // and its LDS reads are back; one raw barrier per panel, no vmcnt(0) in the steady loop; the last two panels are peeled (nothing left to request)
+    int p = 0;
+    for (; p + 2 < n_panels; ++p) {
         if (DO_LOAD) { DL_CG_DMA(p + 2) }
-        const double* lb = la + (p % DL_CG_NBUF) * BUF;
-        double a0[NJ], a1[NJ], bb[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) { const int ks = wave + 8 * j; a0[j] = lb[4 * ks]; a1[j] = lb[16 * DL_CG_LD + 4 * ks]; bb[j] = lb[32 * DL_CG_LD + 4 * ks]; }
-        if (DO_MMA) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[j], bb[j], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[j], bb[j], acc1, 0, 0, 0);
-            }
-        }
+        DL_CG_MULTIPLY(p)
         __asm__ volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(DL_CG_VPT) : "memory");
         __builtin_amdgcn_s_barrier();
     }
+    if (p + 1 < n_panels) {
+        DL_CG_MULTIPLY(p)
+        __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : : "memory");
+        __builtin_amdgcn_s_barrier();
+        ++p;
+    }
+    DL_CG_MULTIPLY(p)
+#undef DL_CG_MULTIPLY
 #undef DL_CG_DMA
-    __asm__ volatile("s_waitcnt vmcnt(0)" : : : "memory");   // the redirected tail requests still target LDS: drain them before it is reused below
+    DL_CG_STAMP(2, __builtin_amdgcn_s_memtime)
     // in-workgroup reduction of the 8 k-slices, then bias, square, sum over the 16 columns
     __syncthreads();
-    double* red = lds;   // [8 waves][2 tiles][4 regs][64 lanes]
+    double* red = lds;   // [waves][2 tiles][4 regs][64 lanes]
 #pragma unroll
     for (int r = 0; r < 4; ++r) { red[((wave * 2 + 0) * 4 + r) * 64 + lane] = acc0[r]; red[((wave * 2 + 1) * 4 + r) * 64 + lane] = acc1[r]; }
     __syncthreads();
-    if (wave < 2) {   // wave t owns rows 16 t .. 16 t + 15
-        const double bj = bias[n0 + r16];
+    if (wave < 8) {   // wave (t, r) = (wave & 1, wave >> 1): accumulator register r of row tile t (rows 16 t + (lane >> 4) + 4 r), all 16 columns
+        const int t = wave & 1, r = wave >> 1;
+        double v = bj;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double v = bj;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) v += red[((w * 2 + wave) * 4 + r) * 64 + lane];
-            double sq = v * v;
-            // C layout: reg r of lane l = C[row (l >> 4) + 4 r][col l & 15]: sum the 16 lanes of a lane group
-            sq += __shfl_xor(sq, 1, 64);
-            sq += __shfl_xor(sq, 2, 64);
-            sq += __shfl_xor(sq, 4, 64);
-            sq += __shfl_xor(sq, 8, 64);
-            int row = m0 + 16 * wave + g + 4 * r;
-            // agent-scope (write-through, sc1) store: performed device-wide once the wave's vmcnt drains -- no L2 write-back fence is needed before the counter
-            if (r16 == 0 && row < M) __hip_atomic_store(part + (size_t)row * n_tiles + nt, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        for (int w = 0; w < DL_CG_WAVES; ++w) v += red[((w * 2 + t) * 4 + r) * 64 + lane];   // fixed order: deterministic
+        double sq = v * v;
+        // C layout: reg r of lane l = C[row (l >> 4) + 4 r][col l & 15]: sum the 16 lanes of a lane group
+        sq += __shfl_xor(sq, 1, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        sq += __shfl_xor(sq, 4, 64);
+        sq += __shfl_xor(sq, 8, 64);
+        const int row = m0 + 16 * t + g + 4 * r;
+        // agent-scope (write-through, sc1) store: performed device-wide once the wave's vmcnt drains -- no L2 write-back fence is needed before the counter
+        if (r16 == 0 && row < M) __hip_atomic_store(part + (size_t)row * n_tiles + nt, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    DL_CG_STAMP(3, __builtin_amdgcn_s_memtime) DL_CG_STAMP(4, __builtin_amdgcn_s_memtime) DL_CG_STAMP(5, __builtin_amdgcn_s_memtime) DL_CG_STAMP(7, __builtin_amdgcn_s_memrealtime)
     if (fin.counters == nullptr) return;
     // Hand-over without cache-maintenance fences: an agent-scope release (buffer_wbl2) walks the XCD's L2 -- 256 of them cost +20 us -- and a full
     // __threadfence() also invalidates it under the workgroups still streaming `power` and W~ (+40 us).  Instead every access to the partials and the counter

@@ -425,7 +425,23 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
     DlChi2Fin fin;
     fin.counters = counters; fin.theta = theta; fin.priors = priors; fin.loglike = loglike; fin.logprior = logprior; fin.status = status;
     fin.n_params = n_params; fin.post_mode = post_mode;
-    hipLaunchKernelGGL((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(512), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin);
+    static const char* stamp_file = getenv("DL_CG_STAMPS");   // diagnostics: in-kernel timestamps of launches 30..33 appended to the file (synchronises)
+    static unsigned long long* stamps_dev = nullptr;
+    static int stamp_launches = 0;
+    if (stamp_file && !stamps_dev) (void)hipMalloc((void**)&stamps_dev, (size_t)65536 * 8 * sizeof(unsigned long long));
+    fin.stamps = (stamp_file && grid <= 65536 && M >= 256 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
+    if (stamp_file && M >= 256) stamp_launches++;
+    hipLaunchKernelGGL((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin);
+    if (fin.stamps) {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h((size_t)grid * 8);
+        (void)hipMemcpy(h.data(), fin.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(stamp_file, "a")) {
+            for (unsigned w = 0; w < grid; ++w) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", h[(size_t)w * 8 + q]); fprintf(f, "\n"); }
+            fprintf(f, "#\n");
+            fclose(f);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void dl_finalize_part_kernel(const double* __restrict__ part, int n_tiles, const double* __restrict__ theta, int n_params,
