@@ -478,6 +478,43 @@ void dl_launch_finalize_part(const double* part, int n_tiles, const double* thet
     hipLaunchKernelGGL(dl_finalize_part_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, part, n_tiles, theta, n_params, priors, B, loglike, logprior, status, post_mode);
 }
 
+// ---- lane-parallel dense algebra for the <= 15 x 15 systems of the marginalised finalize: lane i owns row i in registers, rows are exchanged with
+// v_readlane (uniform source lane).  The first version did this serially on lane 0 with the matrices in scratch memory: 90 us per 4096 points.
+__device__ __forceinline__ double dl_readlane(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+
+// Cholesky A = C C^T of the SPD matrix whose row `lane` is a[0 .. 15] (only the leading m x m block matters; rows >= m must be unit vectors).
+// On return a[] holds row `lane` of C (lower part) and invc[j] = 1 / C[j][j] (uniform); returns log det A; ok = false if a pivot is not positive.
+// The pivots form one dependent chain: per step only a reciprocal square root sits on it (no division, no logarithm -- the log-determinant is taken
+// afterwards, one pivot per lane in parallel).
+__device__ __forceinline__ double dl_lane_cholesky(double (&a)[16], double (&invc)[16], int m, int lane, bool& ok) {
+    double dmine = 1.;   // pivot of this lane's own row
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        invc[j] = 1.;
+        if (j < m) {
+            double djj = dl_readlane(a[j], j);
+            if (!(djj > 0.)) { ok = false; djj = 1.; }
+            const double inv = 1. / sqrt(djj);
+            invc[j] = inv;
+            if (lane == j) dmine = djj;
+            const double cij = (lane > j) ? a[j] * inv : (lane == j ? djj * inv : 0.);
+            a[j] = cij;
+#pragma unroll
+            for (int k = j + 1; k < 16; ++k) a[k] -= cij * dl_readlane(cij, k);   // A[i][k] -= C[i][j] C[k][j]
+        }
+    }
+    const double lg = log(dmine);   // log det A = sum_j log d_jj
+    double logdet = 0.;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) if (j < m) logdet += dl_readlane(lg, j);
+    return logdet;
+}
+
 // ------------------------------------------------------------------------------------------------
 // finalize with analytic marginalisation / best fit of n_s linear parameters (likelihoods/base.py:129-200, 314-413),
 // one wavefront per point.  In whitened variables (dt = L^T Delta, Tt_s = L^T dDelta/dx_s):
@@ -485,19 +522,67 @@ void dl_launch_finalize_part(const double* part, int n_tiles, const double* thet
 //   loglike = -1/2 |dt|^2 + 1/2 dx H_L dx + g_L dx - 1/2 logdet(-H[marg, marg]),  logprior += sum -1/2 (x0 + dx - loc)^2 prec.
 // Tt_s = tconst[s] (+ row 1 + var_slot[s] of the point when the derivative depends on the point).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __restrict__ dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride,
+// LANES: lane-parallel algebra (n_s <= 15, no scratch memory); otherwise the serial fallback (n_s = 16) is compiled
+template <bool LANES>
+__global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* __restrict__ dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride,
                                                                const double* __restrict__ bias, DlMargDev mg,
                                                                const double* __restrict__ theta, int n_params, const double* __restrict__ priors, int64_t B,
                                                                double* __restrict__ loglike, double* __restrict__ logprior, int32_t* __restrict__ status,
-                                                               double* __restrict__ solved, int post_mode) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
+                                                               double* __restrict__ solved, int post_mode, unsigned long long* __restrict__ stamps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#define DL_FM_STAMP(slot) if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();
+    DL_FM_STAMP(0)
+    if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    const bool active = b < B;
+    if (!active) b = B - 1;   // spare waves of the last workgroup recompute the last point (the barrier below is common) and store nothing
     const int ns = mg.n_s;
     const double* row0 = dtilde + (size_t)b * rows_per_point * ld;
+    double chi2 = 0.;
+    double HL[DL_MAX_SOLVED * (DL_MAX_SOLVED + 1) / 2];   // lower triangle of -H_L = Tt Tt^T (lane-uniform)
+    double gL[DL_MAX_SOLVED];                              // Tt dt = -g_L
+    __shared__ double gram_lds[4][16 * 16];
+    if (LANES) {
+        // Gram matrix of X = [dt; Tt_1 .. Tt_ns] (1 + ns <= 16 rows, n columns) with v_mfma_f64_16x16x4_f64: the A operand of lane l is X[l & 15][4 k + (l >> 4)]
+        // and the B operand X^T[4 k + (l >> 4)][l & 15] -- the same register.  chi2 = G[0][0], Tt dt = G[0][1 + s], Tt Tt^T = G[1 + s][1 + t].
+        const int xr = lane & 15, g = lane >> 4;
+        const double* cptr = nullptr;   // point-independent part of row xr (bias / tconst)
+        const double* vptr = nullptr;   // point-dependent part (rows of this point in the residual buffer)
+        if (xr == 0) { cptr = bias; vptr = row0; }
+        else if (xr <= ns) {
+            cptr = mg.tconst + (size_t)(xr - 1) * ld;
+            int vs = -1;
+#pragma unroll
+            for (int s = 0; s < DL_MAX_SOLVED; ++s) if (s == xr - 1) vs = mg.var_slot[s];
+            if (vs >= 0) vptr = row0 + (size_t)(1 + vs) * ld;
+        }
+        dl_double4 acc = {0., 0., 0., 0.};
+        const int n_ks = (n + 3) / 4;
+        for (int k0 = 0; k0 < n_ks; k0 += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {   // eight k-steps of independent loads in flight (the kernel is bound by these round trips)
+                const int col = 4 * (k0 + u) + g;
+                double v = 0.;
+                if (col < n) {
+                    if (cptr) v = cptr[col];
+                    if (vptr) for (int sl = 0; sl < n_slabs; ++sl) v += vptr[(size_t)sl * slab_stride + col];
+                }
+                x[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], x[u], acc, 0, 0, 0);
+        }
+        DL_FM_STAMP(1)
+        // C layout: register r of lane l = G[(l >> 4) + 4 r][l & 15]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gram_lds[wave][(g + 4 * r) * 16 + xr] = acc[r];
+        __syncthreads();
+        DL_FM_STAMP(2)
+        // (the lane-parallel solve below reads G from LDS)
+    } else if (!LANES) {
     // per-lane slices of dt and of every Tt_s (n <= 64 * DL_MARG_NJ)
     double dj[DL_MARG_NJ];
-    double chi2 = 0.;
 #pragma unroll
     for (int q = 0; q < DL_MARG_NJ; ++q) {
         int j = lane + 64 * q;
@@ -510,8 +595,6 @@ __global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __r
         chi2 = fma(dj[q], dj[q], chi2);
     }
     chi2 = dl_wave_sum(chi2);
-    double HL[DL_MAX_SOLVED * (DL_MAX_SOLVED + 1) / 2];   // lower triangle of -H_L = Tt Tt^T (lane-uniform after the reductions)
-    double gL[DL_MAX_SOLVED];                              // Tt dt = -g_L
     for (int s = 0; s < ns; ++s) {
         double ts[DL_MARG_NJ];
 #pragma unroll
@@ -545,6 +628,7 @@ __global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __r
             HL[s * (s + 1) / 2 + t] = dl_wave_sum(a2);
         }
     }
+    }
     // priors of the sampled parameters
     double lp = 0.;
     int nan_in = 0;
@@ -560,7 +644,97 @@ __global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __r
     }
     lp = dl_wave_sum(lp);
     nan_in = __any(nan_in);
-    if (lane == 0) {
+    if (LANES) {
+        // ---- lane-parallel solve (lane i <-> solved parameter i) ----
+        const double* G = gram_lds[wave];
+        __shared__ double chol_lds[4][16 * 16];
+        double* Cm = chol_lds[wave];
+        double prec_i = 0., x0_i = 0., loc_i = 0.;
+        int marg_i = 0;
+#pragma unroll
+        for (int s = 0; s < DL_MAX_SOLVED; ++s) if (s == lane) { prec_i = mg.prec[s]; x0_i = mg.x0[s]; loc_i = mg.loc[s]; marg_i = mg.is_marg[s]; }
+        const bool mine = lane < ns;
+        // A = -H = Tt Tt^T + diag(prec) (SPD); rhs = g = -(Tt dt) - (x0 - loc) prec; dx = A^-1 g
+        double a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = (mine && k < ns) ? G[(1 + lane) * 16 + 1 + k] + (k == lane ? prec_i : 0.) : (k == lane ? 1. : 0.);
+        double gi = mine ? -G[1 + lane] - (x0_i - loc_i) * prec_i : 0.;
+        bool ok = true;
+        DL_FM_STAMP(3)
+        double invc[16];
+        const double logdet_all = dl_lane_cholesky(a, invc, ns, lane, ok);
+        DL_FM_STAMP(4)
+        // forward substitution C y = g
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < ns) {
+                const double yj = dl_readlane(gi, j) * invc[j];
+                if (lane > j) gi -= a[j] * yj; else if (lane == j) gi = yj;
+            }
+        }
+        // backward substitution C^T dx = y needs column entries C[j][i]: rows go through LDS (same wave: LDS operations of a wave execute in order)
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Cm[lane * 16 + k] = a[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+            if (j < ns) {
+                const double xj = dl_readlane(gi, j) * invc[j];
+                if (lane < j) gi -= Cm[j * 16 + (lane & 15)] * xj; else if (lane == j) gi = xj;
+            }
+        }
+        const double dxi = mine ? gi : 0.;
+        // 1/2 dx H_L dx + g_L dx  (likelihoods/base.py:385-386), H_L = -Tt Tt^T, g_L = -Tt dt
+        double rowdot = 0.;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) if (t < ns) rowdot += (mine ? G[(1 + lane) * 16 + 1 + t] : 0.) * dl_readlane(dxi, t);
+        const double xs = x0_i + dxi;
+        const double quad_i = dxi * rowdot, lin_i = mine ? G[1 + lane] * dxi : 0.;
+        const double lps_i = mine ? -0.5 * (xs - loc_i) * (xs - loc_i) * prec_i : 0.;   // 363-364 with parameter.py:2007 (0 for flat priors: prec = 0)
+        double quad = 0., lin = 0., lps = 0.;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) if (t < ns) { quad += dl_readlane(quad_i, t); lin += dl_readlane(lin_i, t); lps += dl_readlane(lps_i, t); }   // fixed order
+        if (mine && active && solved) solved[(size_t)b * ns + lane] = xs;
+        double ll = -0.5 * G[0] - 0.5 * quad - lin;
+        // -1/2 logdet(-H[marg, marg]) (394-404); all-marg: reuse the Cholesky above, else factor the compacted sub-block
+        if (mg.n_marg == ns) ll -= 0.5 * logdet_all;
+        else if (mg.n_marg > 0) {
+            int pos_i = 0;
+#pragma unroll
+            for (int s = 0; s < DL_MAX_SOLVED; ++s) if (s < lane && s < ns && mg.is_marg[s]) pos_i++;
+            __builtin_amdgcn_wave_barrier();
+            if (mine && marg_i) {
+                int pos_k = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (k < ns && mg.is_marg[k]) { Cm[pos_i * 16 + pos_k] = G[(1 + lane) * 16 + 1 + k] + (k == lane ? prec_i : 0.); pos_k++; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int nm = mg.n_marg;
+            double sub[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sub[k] = (lane < nm && k < nm) ? Cm[(lane & 15) * 16 + k] : (k == lane ? 1. : 0.);
+            double invs[16];
+            ll -= 0.5 * dl_lane_cholesky(sub, invs, nm, lane, ok);
+        }
+        if (lane == 0 && active) {
+            const double lptot = lp + lps;
+            int st = DL_ST_OK;
+            if (nan_in) st = DL_ST_NAN_INPUT;
+            else if (lp == -inf) st = DL_ST_OUT_OF_PRIOR;
+            else if (!ok || !(ll == ll) || ll == inf || ll == -inf) st = DL_ST_NONFINITE;
+            if (loglike) loglike[b] = post_mode ? (st == DL_ST_OK ? ll + lptot : -inf) : ll;
+            if (logprior) logprior[b] = lptot;
+            if (status) status[b] = st;
+        }
+        DL_FM_STAMP(5)
+        if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+        return;
+    }
+    if (!LANES && lane == 0 && active) {
         // A = -H = Tt Tt^T + diag(prec) (SPD); rhs = g = -(Tt dt) - (x0 - loc) prec; dx = A^-1 g
         double A[DL_MAX_SOLVED][DL_MAX_SOLVED], g[DL_MAX_SOLVED], dx[DL_MAX_SOLVED];
         for (int s = 0; s < ns; ++s) {
@@ -647,6 +821,27 @@ __global__ __launch_bounds__(256) void dl_finalize_marg_kernel(const double* __r
 void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride, const double* bias, const DlMargDev& mg,
                              const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, double* solved,
                              int post_mode, hipStream_t stream) {
-    hipLaunchKernelGGL(dl_finalize_marg_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
-                       n_params, priors, B, loglike, logprior, status, solved, post_mode);
+    static const char* stamp_file = getenv("DL_FM_STAMPS");   // diagnostics, see dl_launch_fullshape
+    static unsigned long long* stamps_dev = nullptr;
+    static int stamp_launches = 0;
+    const unsigned grid = (unsigned)((B + 3) / 4);
+    if (stamp_file && !stamps_dev) (void)hipMalloc((void**)&stamps_dev, (size_t)65536 * 8 * sizeof(unsigned long long));
+    unsigned long long* stamps = (stamp_file && grid <= 65536 && B >= 256 && stamp_launches >= 10 && stamp_launches < 12) ? stamps_dev : nullptr;
+    if (stamp_file && B >= 256) stamp_launches++;
+    if (mg.n_s < 16)
+        hipLaunchKernelGGL(dl_finalize_marg_kernel<true>, dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
+                           n_params, priors, B, loglike, logprior, status, solved, post_mode, stamps);
+    else
+        hipLaunchKernelGGL(dl_finalize_marg_kernel<false>, dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
+                           n_params, priors, B, loglike, logprior, status, solved, post_mode, stamps);
+    if (stamps) {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h((size_t)grid * 8);
+        (void)hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(stamp_file, "a")) {
+            for (unsigned w = 0; w < grid; ++w) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", h[(size_t)w * 8 + q]); fprintf(f, "\n"); }
+            fprintf(f, "#\n");
+            fclose(f);
+        }
+    }
 }

@@ -1,0 +1,44 @@
+"""Timing of the other BASELINE configurations on the GPU (not bench lines: parity-test workloads, timed for DESIGN.md):
+config 3 (MLP-emulated velocileptors tables + 5 analytically marginalised parameters, B = 4096), config 4 (damped-BAO xi_ell, B = 8192),
+config 5 shape (two-tracer sum, B = 256).  HIP events of the library, one call in two."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import torch
+
+
+def time_likelihood(label, like, B, steps=40):
+    ctx = like._get_context()
+    rng = np.random.RandomState(3)
+    theta = np.column_stack([np.clip(param.ref.sample(size=B, random_state=rng), *param.prior.limits) for param in like.varied_params])
+    th = torch.as_tensor(theta, dtype=torch.float64, device='cuda').contiguous()
+    out = torch.empty(B, dtype=torch.float64, device='cuda')
+    st = torch.empty(B, dtype=torch.int32, device='cuda')
+    for _ in range(5): ctx.eval_logposterior(th, out, status=st)
+    torch.cuda.synchronize()
+    ctx.profile_enable(2)
+    t0 = time.perf_counter()
+    for _ in range(steps): ctx.eval_logposterior(th, out, status=st)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ms = ctx.profile_read(); ctx.profile_enable(0)
+    ok = int((st == 0).sum().item())
+    print('%-58s B=%5d  %8.1f us/step  %7.2f M evals/s  kernels (raw event intervals, us): theory %.1f gemm %.1f finalize %.1f  [%d ok]' % (
+        label, B, 1e6 * dt, B / dt / 1e6, *(1e3 * (ms[k] + ms['event_overhead']) for k in ['theory', 'window_gemm', 'finalize']), ok))
+
+
+def main():
+    from test_gpu_emulator import make_mlp_likelihood
+    from test_host_api import make_cfg4
+    g, like, pt, theory, solved = make_mlp_likelihood(marg=True)
+    time_likelihood('cfg3: MLP-emulated tables + 5 marginalised parameters', like, 4096)
+    g, like, pt, theory, solved = make_mlp_likelihood(marg=False)
+    time_likelihood('cfg3 without marginalisation', like, 4096)
+    for space in ['xi', 'pk']:
+        g, like = make_cfg4(space)
+        time_likelihood('cfg4: damped BAO ' + space, like, 8192)
+
+
+if __name__ == '__main__':
+    main()
