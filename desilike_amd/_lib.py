@@ -25,6 +25,7 @@ SYMBOLS = {
     'dl_last_error': (ctypes.c_char_p, [ctypes.c_void_p]),
     'dl_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
     'dl_eval_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_eval_batch_derived': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_logposterior': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_theory': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_batch_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
@@ -170,6 +171,24 @@ class Context(object):
         if return_solved: toret += (solved,)
         return toret
 
+    def eval_batch_derived_host(self, theta):
+        """numpy in / numpy out: (loglike, logprior, status, solved [B, n_solved], hessian [B, n_solved, n_solved]); stages through device tensors."""
+        import torch
+        theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
+        if theta.shape[1] != self.n_params:
+            raise ValueError('theta must have shape (B, {:d}), found {}'.format(self.n_params, theta.shape))
+        B, ns = theta.shape[0], self.n_solved
+        device = torch.device('cuda', self.device)
+        th = torch.as_tensor(theta, dtype=torch.float64, device=device).contiguous()
+        loglike, logprior = torch.empty(B, dtype=torch.float64, device=device), torch.empty(B, dtype=torch.float64, device=device)
+        status = torch.empty(B, dtype=torch.int32, device=device)
+        solved, hessian = torch.empty((B, ns), dtype=torch.float64, device=device), torch.empty((B, ns, ns), dtype=torch.float64, device=device)
+        if B:
+            self.eval_batch_derived(th, loglike=loglike, logprior=logprior, status=status, solved=solved, hessian=hessian,
+                                    stream=torch.cuda.current_stream(device).cuda_stream)
+            torch.cuda.synchronize(device)
+        return tuple(t.cpu().numpy() for t in (loglike, logprior, status, solved, hessian))
+
     def eval_theory_host(self, theta, iobs=0, return_tables=False):
         theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
         B = theta.shape[0]
@@ -196,6 +215,23 @@ class Context(object):
         self._check(self._lib.dl_eval_batch(self._handle, ctypes.c_void_p(theta.data_ptr()), B, ptr(loglike, torch.float64, (B,)), ptr(logprior, torch.float64, (B,)),
                                             ptr(flattheory, torch.float64, (B, self.n_data)), ptr(status, torch.int32, (B,)),
                                             ptr(solved, torch.float64, (B, self.n_solved)), ctypes.c_void_p(stream)))
+
+    def eval_batch_derived(self, theta, loglike=None, logprior=None, status=None, solved=None, hessian=None, stream=None):
+        """``eval_batch`` plus ``hessian [B, n_solved, n_solved]``: likelihood Hessian w.r.t. the analytically solved parameters (torch tensors, asynchronous)."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(theta.device).cuda_stream
+        B = theta.shape[0]
+        assert theta.is_contiguous() and theta.dtype == torch.float64 and theta.shape[1] == self.n_params
+
+        def ptr(tensor, dtype, shape):
+            if tensor is None: return None
+            assert tensor.is_contiguous() and tensor.dtype == dtype and tuple(tensor.shape) == shape, (tensor.shape, shape)
+            return ctypes.c_void_p(tensor.data_ptr())
+
+        self._check(self._lib.dl_eval_batch_derived(self._handle, ctypes.c_void_p(theta.data_ptr()), B, ptr(loglike, torch.float64, (B,)), ptr(logprior, torch.float64, (B,)),
+                                                    ptr(status, torch.int32, (B,)), ptr(solved, torch.float64, (B, self.n_solved)),
+                                                    ptr(hessian, torch.float64, (B, self.n_solved, self.n_solved)), ctypes.c_void_p(stream)))
 
     def eval_logposterior(self, theta, logposterior, status=None, stream=None):
         """``logposterior[B]`` = loglikelihood + logprior, -inf where the sampler would reject the point (samplers/base.py:185-191); torch tensors, asynchronous."""

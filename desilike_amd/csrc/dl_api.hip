@@ -334,7 +334,7 @@ static int dl_reserve(dl_ctx* ctx, int64_t B) {
 }
 
 static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double* loglike_dev, double* logprior_dev, double* flattheory_dev, int32_t* status_dev,
-                        double* solved_dev, void* hip_stream, int post_mode) {
+                        double* solved_dev, void* hip_stream, int post_mode, double* hessian_dev = nullptr) {
     if (!ctx) { g_last_error = "dl_eval_batch: null context"; return 1; }
     if (B < 0 || (B > 0 && !theta_dev)) return dl_fail(ctx, "dl_eval_batch: invalid batch");
     if (B == 0) return 0;
@@ -395,7 +395,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         else if (ctx->n_solved > 0)
             dl_launch_finalize_marg(ctx->delta_ws, ctx->N_pad, n, R, n_slabs, slab_stride, fin_bias, ctx->marg, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr,
                                     logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr,
-                                    solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr, post_mode, stream);
+                                    solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr,
+                                    hessian_dev ? hessian_dev + (size_t)b0 * ctx->n_solved * ctx->n_solved : nullptr, post_mode, stream);
         else
             dl_launch_finalize(ctx->delta_ws, ctx->N_pad, n, n_slabs, slab_stride, fin_bias, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
                                status_dev ? status_dev + b0 : nullptr, post_mode, stream);
@@ -409,6 +410,12 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
 int dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B, double* loglike_dev, double* logprior_dev, double* flattheory_dev, int32_t* status_dev,
                   double* solved_dev, void* hip_stream) {
     return dl_eval_impl(ctx, theta_dev, B, loglike_dev, logprior_dev, flattheory_dev, status_dev, solved_dev, hip_stream, 0);
+}
+
+int dl_eval_batch_derived(dl_ctx* ctx, const double* theta_dev, int64_t B, double* loglike_dev, double* logprior_dev, int32_t* status_dev, double* solved_dev,
+                          double* hessian_dev, void* hip_stream) {
+    if (ctx && hessian_dev && ctx->n_solved == 0) return dl_fail(ctx, "dl_eval_batch_derived: no analytically solved parameter in this likelihood");
+    return dl_eval_impl(ctx, theta_dev, B, loglike_dev, logprior_dev, nullptr, status_dev, solved_dev, hip_stream, 0, hessian_dev);
 }
 
 int dl_eval_logposterior(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logposterior_dev, int32_t* status_dev, void* hip_stream) {

@@ -528,7 +528,8 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
                                                                const double* __restrict__ bias, DlMargDev mg,
                                                                const double* __restrict__ theta, int n_params, const double* __restrict__ priors, int64_t B,
                                                                double* __restrict__ loglike, double* __restrict__ logprior, int32_t* __restrict__ status,
-                                                               double* __restrict__ solved, int post_mode, unsigned long long* __restrict__ stamps) {
+                                                               double* __restrict__ solved, double* __restrict__ hessian, int post_mode,
+                                                               unsigned long long* __restrict__ stamps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #define DL_FM_STAMP(slot) if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();
     DL_FM_STAMP(0)
@@ -697,6 +698,10 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
 #pragma unroll
         for (int t = 0; t < 16; ++t) if (t < ns) { quad += dl_readlane(quad_i, t); lin += dl_readlane(lin_i, t); lps += dl_readlane(lps_i, t); }   // fixed order
         if (mine && active && solved) solved[(size_t)b * ns + lane] = xs;
+        if (mine && active && hessian) {   // likelihood Hessian H_L = -Tt Tt^T w.r.t. the solved parameters (derived output, likelihoods/base.py:388-390)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (k < ns) hessian[((size_t)b * ns + lane) * ns + k] = -G[(1 + lane) * 16 + 1 + k];
+        }
         double ll = -0.5 * G[0] - 0.5 * quad - lin;
         // -1/2 logdet(-H[marg, marg]) (394-404); all-marg: reuse the Cholesky above, else factor the compacted sub-block
         if (mg.n_marg == ns) ll -= 0.5 * logdet_all;
@@ -778,6 +783,7 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
             double xs = mg.x0[s] + dx[s];
             lps += -0.5 * (xs - mg.loc[s]) * (xs - mg.loc[s]) * mg.prec[s];   // 363-364 with parameter.py:2007 (0 for flat priors: prec = 0)
             if (solved) solved[(size_t)b * ns + s] = xs;
+            if (hessian) for (int t = 0; t < ns; ++t) hessian[((size_t)b * ns + s) * ns + t] = -HL[(s >= t) ? s * (s + 1) / 2 + t : t * (t + 1) / 2 + s];
         }
         double ll = -0.5 * chi2 - 0.5 * quad - lin;
         // -1/2 logdet(-H[marg, marg]) (394-404); all-marg: reuse the Cholesky above, else factor the sub-block
@@ -820,7 +826,7 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
 
 void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride, const double* bias, const DlMargDev& mg,
                              const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, double* solved,
-                             int post_mode, hipStream_t stream) {
+                             double* hessian, int post_mode, hipStream_t stream) {
     static const char* stamp_file = getenv("DL_FM_STAMPS");   // diagnostics, see dl_launch_fullshape
     static unsigned long long* stamps_dev = nullptr;
     static int stamp_launches = 0;
@@ -830,10 +836,10 @@ void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_p
     if (stamp_file && B >= 256) stamp_launches++;
     if (mg.n_s < 16)
         hipLaunchKernelGGL(dl_finalize_marg_kernel<true>, dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
-                           n_params, priors, B, loglike, logprior, status, solved, post_mode, stamps);
+                           n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps);
     else
         hipLaunchKernelGGL(dl_finalize_marg_kernel<false>, dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
-                           n_params, priors, B, loglike, logprior, status, solved, post_mode, stamps);
+                           n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps);
     if (stamps) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h((size_t)grid * 8);

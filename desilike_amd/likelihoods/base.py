@@ -325,7 +325,14 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         self.initialize()
         theta, fixed = self._split_params(flat)
         ctx = self._get_context(fixed)
-        out = ctx.eval_batch_host(theta, return_flattheory=return_flattheory, return_solved=ctx.n_solved > 0)
+        hessian = None
+        if return_derived and ctx.n_solved and not return_flattheory:
+            # derived outputs of a marginalised fit: solution and likelihood Hessian w.r.t. the solved parameters (likelihoods/base.py:361-368, 388-390)
+            out = ctx.eval_batch_derived_host(theta)
+            hessian = out[4]
+            out = out[:4]
+        else:
+            out = ctx.eval_batch_host(theta, return_flattheory=return_flattheory, return_solved=ctx.n_solved > 0)
         loglike, logprior, status = out[:3]
         if return_flattheory:
             self.flattheory = out[3].reshape(shape + (ctx.n_data,))
@@ -344,6 +351,16 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             if ctx.n_solved:   # solution of the analytically solved parameters (likelihoods/base.py:361-368)
                 for param, column in zip(self.solved_params, out[-1].T):
                     derived[param] = column.reshape(shape)
+                if hessian is not None:
+                    # the reference stores these as ParameterArray(loglikelihood, derivs=[(), (p1, p2), ...]) (likelihoods/base.py:388-390, 409-411); here: one
+                    # array per pair, keyed (name, (p1, p2)) -> 'name.p1.p2'; the prior's Hessian is the constant -1 / scale^2 on the diagonal
+                    names = self.solved_params.names()
+                    for i1, p1 in enumerate(names):
+                        for i2, p2 in enumerate(names[i1:], start=i1):
+                            derived['{}.{}.{}'.format(self._param_loglikelihood, p1, p2)] = hessian[:, i1, i2].reshape(shape)
+                    for param in self.solved_params:
+                        scale = getattr(param.prior, 'scale', np.inf) if param.prior.dist == 'norm' else np.inf
+                        derived['{}.{}.{}'.format(self._param_logprior, param.name, param.name)] = np.full(shape, -1. / scale**2 if np.isfinite(scale) else 0.)
             return (logposterior, derived), errs
         return logposterior, errs
 

@@ -121,6 +121,12 @@ int  dl_eval_batch(dl_ctx* ctx, const double* theta_dev, int64_t B,
                    double* loglike_dev, double* logprior_dev, double* flattheory_dev,
                    int32_t* status_dev, double* solved_dev, void* hip_stream);
 
+/* dl_eval_batch plus the derived outputs the reference attaches to the log-likelihood of a marginalised fit (likelihoods/base.py:388-390, consumed by
+ * Chain.sample_solved, samples/chain.py:229-263): hessian_dev[B, n_solved, n_solved] = second derivatives of the log-likelihood w.r.t. the analytically
+ * solved parameters, -T^T P T (the prior's part is the constant -diag(1 / scale^2) of marg.prior).  Any output may be NULL. */
+int  dl_eval_batch_derived(dl_ctx* ctx, const double* theta_dev, int64_t B, double* loglike_dev, double* logprior_dev, int32_t* status_dev,
+                           double* solved_dev, double* hessian_dev, void* hip_stream);
+
 /* What a sampler consumes (BasePosteriorSampler.logposterior, desilike/samplers/base.py:144-200): logposterior_dev[B] = loglikelihood + logprior, and -inf
  * for points outside the prior, with NaN inputs or a non-finite likelihood (samplers/base.py:185-191); status_dev[B] optional.  One launch sequence, no
  * separate addition.  Asynchronous on ``hip_stream``. */

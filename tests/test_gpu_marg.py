@@ -62,6 +62,14 @@ def test_marg_vs_oracle_with_counterterms():
     ctx = like._get_context()
     loglike, logprior, status, solved = ctx.eval_batch_host(theta, return_solved=True)
     assert (status == 0).all()
+    # derived outputs: likelihood Hessian w.r.t. the solved parameters, same numbers through the derived entry point and the call surface
+    d_loglike, d_logprior, d_status, d_solved, hessian = ctx.eval_batch_derived_host(theta)
+    assert np.array_equal(d_loglike, loglike) and np.array_equal(d_logprior, logprior) and np.array_equal(d_solved, solved) and np.array_equal(d_status, status)
+    from desilike_amd import vmap
+    (logpost, derived), errors = vmap(like, errors='return', return_derived=True)({name: theta[:, i] for i, name in enumerate(names)})
+    assert errors == {} and np.allclose(logpost, loglike + logprior, rtol=1e-14, atol=0.)
+    assert np.array_equal(derived['loglikelihood.ct0_2.sn0_2'], hessian[:, 0, 2]) and np.array_equal(derived['ct2_2'], solved[:, 1])
+    assert np.allclose(derived['logprior.ct0_2.ct0_2'], -1. / 30.**2) and np.allclose(derived['logprior.sn0_2.sn0_2'], 0.)
     # oracle: theory at x0 and derivative columns by unit steps of the (exactly linear) solved parameters
     c = observable_constants(g)
     theory.initialize()
@@ -82,5 +90,6 @@ def test_marg_vs_oracle_with_counterterms():
         sol = orc.solve_marginalized(f0 - c['flatdata'], T, like.precision, x0=x0, prior_loc=[0., 1., 0.], prior_scale=[30., 50., np.inf], marg_mask=[True, False, True])
         assert abs(loglike[i] - sol['loglikelihood']) <= 1e-9 * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
         assert np.allclose(solved[i], sol['x'], rtol=1e-8, atol=1e-10)
+        assert np.allclose(hessian[i], sol['likelihood_hessian'], rtol=1e-10, atol=1e-12 * np.abs(sol['likelihood_hessian']).max())
         lp_ref = orc.logprior(row, [dict(dist=['uniform', 'norm'][int(pr[0])], limits=(pr[1], pr[2]), loc=pr[3], scale=pr[4]) for pr in [p.prior.spec() for p in like.varied_params]]) + sol['logprior_solved']
         assert np.isclose(logprior[i], lp_ref, rtol=1e-10, atol=1e-10)
