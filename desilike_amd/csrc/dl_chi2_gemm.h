@@ -82,6 +82,22 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     const double* la = lds + r16 * DL_CG_LD + g;
     // prologue: panels 0 and 1 requested; panel 0 landed (counted wait: the pieces of panel 1 may still fly) and visible (barrier)
     if (DO_LOAD) { DL_CG_DMA(0) if (n_panels > 1) { DL_CG_DMA(1) } }
+    // fused finalize: the priors depend on theta only -- lanes 0-31 of wave 0 evaluate them for the 32 points of the row block now, while the first panels
+    // are in flight (whichever column block arrives last will need them; two registers are carried through the main loop)
+    double fin_lp = 0.;
+    int fin_nan = 0;
+    if (fin.counters != nullptr && wave == 0 && lane < DL_CG_M && m0 + lane < M) {
+        const double inf = __builtin_huge_val();
+        for (int p = 0; p < fin.n_params; ++p) {
+            double x = fin.theta[(size_t)(m0 + lane) * fin.n_params + p];
+            const double* pr = fin.priors + 5 * p;
+            if (x != x) fin_nan = 1;
+            bool isin = (pr[1] <= x) && (x <= pr[2]);
+            double v = 0.;
+            if (pr[0] == 1.) { double t = x - pr[3]; v = -0.5 * (t * t) / (pr[4] * pr[4]); }   // parameter.py:2007
+            fin_lp += isin ? v : -inf;
+        }
+    }
     if (n_panels > 1) __asm__ volatile("s_waitcnt vmcnt(%0)" : : "n"(DL_CG_VPT) : "memory");
     else __asm__ volatile("s_waitcnt vmcnt(0)" : : : "memory");
     __builtin_amdgcn_s_barrier();
@@ -139,37 +155,24 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     if (fin.counters == nullptr) return;
     // Hand-over without cache-maintenance fences: an agent-scope release (buffer_wbl2) walks the XCD's L2 -- 256 of them cost +20 us -- and a full
     // __threadfence() also invalidates it under the workgroups still streaming `power` and W~ (+40 us).  Instead every access to the partials and the counter
-    // is itself an agent-scope (sc1) access: stores above are complete when __syncthreads() has drained vmcnt, the counter is an L2-side atomic, the last
-    // arriver's loads below bypass non-coherent lines.
-    __shared__ int s_last;
+    // is itself an agent-scope (sc1) access: the stores above are performed once vmcnt has drained, the counter is a memory-side atomic, the last
+    // arriver's loads bypass non-coherent lines.  One barrier, then wave 0 alone: counter round trip, 8 partial loads, outputs.
+    __asm__ volatile("s_waitcnt vmcnt(0)" : : : "memory");
     __syncthreads();
-    if (tid == 0) {
-        int done = __hip_atomic_fetch_add(fin.counters + mb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (done == n_tiles - 1);
-        if (s_last) __hip_atomic_store(fin.counters + mb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream-ordered)
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // (no acquire fence: the partials are read below with agent-scope loads, which do not hit in the non-coherent L2)
-    const int row = m0 + tid;
-    if (tid < DL_CG_M && row < M) {
+    if (wave != 0) return;
+    int done = 0;
+    if (lane == 0) done = __hip_atomic_fetch_add(fin.counters + mb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    done = __builtin_amdgcn_readfirstlane(done);
+    if (done != n_tiles - 1) return;
+    if (lane == 0) __hip_atomic_store(fin.counters + mb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream-ordered)
+    const int row = m0 + lane;
+    if (lane < DL_CG_M && row < M) {
         double chi2 = 0.;
-        for (int t = 0; t < n_tiles; ++t) chi2 += __hip_atomic_load(part + (size_t)row * n_tiles + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        double lp = 0.;
-        bool nan_in = false;
+        for (int t = 0; t < n_tiles; ++t) chi2 += __hip_atomic_load(part + (size_t)row * n_tiles + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // fixed order
         const double inf = __builtin_huge_val();
-        for (int p = 0; p < fin.n_params; ++p) {
-            double x = fin.theta[(size_t)row * fin.n_params + p];
-            const double* pr = fin.priors + 5 * p;
-            if (x != x) nan_in = true;
-            bool isin = (pr[1] <= x) && (x <= pr[2]);
-            double v = 0.;
-            if (pr[0] == 1.) { double t = x - pr[3]; v = -0.5 * (t * t) / (pr[4] * pr[4]); }   // parameter.py:2007
-            lp += isin ? v : -inf;
-        }
-        double ll = -0.5 * chi2;
+        const double lp = fin_lp, ll = -0.5 * chi2;
         int st = 0;                    // DL_STATUS_OK
-        if (nan_in) st = 3;            // DL_STATUS_NAN_INPUT
+        if (fin_nan) st = 3;           // DL_STATUS_NAN_INPUT
         else if (lp == -inf) st = 1;   // DL_STATUS_OUT_OF_PRIOR
         else if (!(ll == ll) || ll == inf || ll == -inf) st = 2;   // DL_STATUS_NONFINITE
         if (fin.loglike) fin.loglike[row] = fin.post_mode ? (st == 0 ? ll + lp : -inf) : ll;
