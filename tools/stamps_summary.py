@@ -25,3 +25,7 @@ for ib, a in enumerate(blocks):
         print('  chip-wide (100 MHz clock): workgroup starts: median %.2f p90 %.2f max %.2f us; exits: median %.2f max %.2f us' % (
             np.median(st), np.percentile(st, 90), st.max(), np.median(en), en.max()))
         print('  start time by workgroup id (every 64th): ' + ' '.join('%.1f' % v for v in st[::64]))
+    if a.shape[1] >= 8:
+        life = (a[:, 5] - a[:, 0]) / GHZ / 1e3
+        q = len(life) // 4
+        print('  workgroup life by id quartile: ' + ' '.join('%.2f' % np.median(life[i * q:(i + 1) * q]) for i in range(4)) + ' ; slowest ids: ' + ' '.join(str(i) for i in np.argsort(life)[-12:]))
