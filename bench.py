@@ -5,7 +5,7 @@
 Workload (BASELINE.json configs[1]): ShapeFit + Kaiser P_ell, ell = (0, 2, 4), 40 k-bins, dense synthetic
 survey-like window (120 x 1200), full 120 x 120 precision; one *step* = one pass of the hot path over a batch of
 1024 parameter points per GPU (theta already resident in HBM).  N > 1: one process per GPU (torchrun), walkers
-sharded contiguously (weak scaling: 1024 points per rank), one RCCL all-gather of the log-posteriors per step.
+sharded contiguously (weak scaling: 1024 points per rank), log-posteriors exchanged by asynchronous RCCL all-gathers, bucketed over 8 steps.
 Prints ONE JSON line (rank 0).  Synthetic inputs only; nothing here reads /root/reference.
 """
 import argparse
@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BATCH = 1024
+GATHER_EVERY = 8   # N > 1: steps per bucketed all-gather of log-posteriors
 # Algorithmic FLOP per evaluation (DESIGN.md "Measurement"), fp64 add/mul = 1, transcendental = 20
 FLOP_THEORY = 23e3 + 5e3 + 288e3 + 57.6e3 + 7e3    # template factor, spline coefficients, AP + spline eval, GL projection, tracer combine
 FLOP_GEMM = 288e3 + 29e3                            # window GEMM 2 n n_in + chi2 2 n^2 + 2 n (precision folded into the window matrix)
@@ -122,7 +123,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get('DL_BENCH_FORCE_DIST', '0') == '1'   # (forcing: smoke test of the RCCL code path with a single rank on a 1-GPU box)
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs a GPU: the hot path has no CPU fallback')
     local_rank = local_rank % torch.cuda.device_count()   # (only differs when the N > 1 path is smoke-tested on a 1-GPU box: DL_BENCH_BACKEND=gloo)
@@ -139,39 +140,38 @@ def main():
     likelihood = make_likelihood(local_rank)
     ctx = likelihood._get_context()
     B = args.batch
-    # N > 1: two independent walker ensembles (chains) alternate, so that the all-gather of one ensemble's log-posteriors (RCCL, its own stream) overlaps the
-    # evaluation of the other; every step is still one pass of the hot path over B points per GPU plus one all-gather (desilike_amd/parallel.py)
+    # N > 1: independent walker ensembles (chains) are kept in flight so that the exchange of log-posteriors never stalls the evaluation: the finalize kernel
+    # writes each step's log-posteriors straight into a bucket, and one asynchronous RCCL all-gather (its own stream) ships a bucket of GATHER_EVERY steps while the
+    # next bucket is being evaluated (desilike_amd/parallel.py: a kilobyte all-gather costs ~25 us of host issue time whatever its size -- issued every step it
+    # would take as long as the step itself).  Every step is still one pass of the hot path over B points per GPU; every result is all-gathered.
     nslots = 2 if distributed else 1
     theta_host = sample_theta(likelihood, B, seed=42 + rank)
     thetas = [torch.as_tensor(theta_host if slot == 0 else sample_theta(likelihood, B, seed=4242 + rank), dtype=torch.float64, device=device).contiguous() for slot in range(nslots)]
     loglikes = [torch.empty(B, dtype=torch.float64, device=device) for slot in range(nslots)]
     logpriors = [torch.empty(B, dtype=torch.float64, device=device) for slot in range(nslots)]
-    statuses = [torch.empty(B, dtype=torch.int32, device=device) for slot in range(nslots)]
-    logposts = [torch.empty(B, dtype=torch.float64, device=device) for slot in range(nslots)]
+    statuses = [torch.zeros(B, dtype=torch.int32, device=device) for slot in range(nslots)]
     loglike, status = loglikes[0], statuses[0]
     stream = torch.cuda.current_stream(device)
-    pipe = None
+    bucket = None
     if distributed:
-        from desilike_amd.parallel import PipelinedAllGather
-        pipe = PipelinedAllGather((B,), torch.float64, device, nslots=nslots)
+        from desilike_amd.parallel import BucketedAllGather
+        bucket = BucketedAllGather(B, torch.float64, device, steps_per_bucket=GATHER_EVERY, keep=False,
+                                   force_collective=os.environ.get('DL_BENCH_FORCE_DIST', '0') == '1')
     counter = [0]
 
     def step():
         slot = counter[0] % nslots
         counter[0] += 1
-        if distributed and pipe.pending(slot):
-            pipe.result(slot)   # the stream waits for the gather this ensemble issued two steps ago (its buffers are about to be overwritten)
         if distributed:
-            # the path's one real exchange: every rank needs every walker's log-posterior (samplers/base.py:200); written directly by the finalize kernel
-            ctx.eval_logposterior(thetas[slot], logposts[slot], status=statuses[slot], stream=stream.cuda_stream)
-            pipe.submit(slot, logposts[slot])
+            # the path's one real exchange: every rank needs every walker's log-posterior (samplers/base.py:200)
+            ctx.eval_logposterior(thetas[slot], bucket.slot(), status=statuses[slot], stream=stream.cuda_stream)
+            bucket.advance()
         else:
             ctx.eval_batch(thetas[slot], loglike=loglikes[slot], logprior=logpriors[slot], status=statuses[slot], stream=stream.cuda_stream)
 
     def barrier():
         if distributed:
-            for slot in range(nslots):
-                if pipe.pending(slot): pipe.result(slot)
+            bucket.results()   # flush the partial bucket, wait for every collective in flight
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -213,7 +213,7 @@ def main():
                   'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
                   'data': 'synthetic',
                   'config': {'workload': 'BASELINE configs[1]: ShapeFit+Kaiser P_ell ell=(0,2,4) x 40 k-bins, dense window 120x1200 (n_kin=400/ell), 120x120 precision, '
-                                         '{:d} batched param points per GPU per step'.format(B), 'batch_per_gpu': B, 'n_params': 6, 'parallelism': 'walkers x{:d}'.format(world)},
+                                         '{:d} batched param points per GPU per step'.format(B), 'batch_per_gpu': B, 'n_params': 6, 'parallelism': 'walkers x{:d}'.format(world) + (', log-posteriors all-gathered in buckets of {:d} steps'.format(GATHER_EVERY) if distributed else '')},
                   'roofline': {'bound': 'mfma', 'kernel': kernel_name,
                                'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
                                'flop_per_launch': flops[dominant] * B, 'avg_launch_ms': kernel_ms[dominant]},

@@ -139,3 +139,44 @@ def test_pipelined_allgather_gloo_world2():
         got, raised = results[rank]
         assert raised
         assert np.array_equal(got, expected)   # results come back in submission order, every rank sees every rank's rows
+
+
+def _bucketed_worker(rank, world, port, results):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from desilike_amd.parallel import BucketedAllGather
+    nloc, k = 5, 3
+    bucket = BucketedAllGather(nloc, torch.float64, 'cpu', steps_per_bucket=k)
+    seen = []
+    for step in range(8):   # 8 steps = 2 full buckets + one partial (flushed by results())
+        out = bucket.slot()
+        out.copy_(torch.arange(nloc, dtype=torch.float64) + 100. * rank + 1000. * step)
+        bucket.advance()
+        if step == 6:   # drain in the middle: everything submitted so far comes back
+            seen.extend(t.clone() for t in bucket.results())
+    seen.extend(t.clone() for t in bucket.results())
+    results[rank] = [t.numpy() for t in seen]
+    dist.destroy_process_group()
+
+
+def test_bucketed_allgather_gloo_world2():
+    import torch.multiprocessing as mp
+    manager = mp.Manager()
+    results = manager.dict()
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_bucketed_worker, args=(2, port, results), nprocs=2, join=True)
+    for rank in range(2):
+        got = results[rank]
+        assert all(g.shape == (2, 3, 5) for g in got)
+        steps = sorted(set(int(v // 1000) for g in got for v in g.ravel() if v >= 0.))
+        assert steps == list(range(8))   # every step's results arrived somewhere
+        for g in got:
+            for r in range(2):
+                rows = g[r]
+                live = [row for row in rows if not (row == 0.).all() or True]
+                for row in rows:
+                    step = int(row[0] // 1000)
+                    if (row == 0.).all(): continue   # unused tail of the partial bucket
+                    assert np.array_equal(row, np.arange(5) + 100. * r + 1000. * step)
