@@ -292,7 +292,10 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             if obs.flatdata is not None: continue
             data_params = obs._data_params
             fixed = {name: value for name, value in data_params.items() if name not in varied}
-            ctx = Context(self._spec(fixed, zeros, np.ones(sum(sizes))), device=self.device)
+            spec = self._spec(fixed, zeros, np.ones(sum(sizes)))
+            for ospec in spec['observables']:   # generated data = window output, BEFORE any observable transform (power_spectrum.py:95-97)
+                ospec['transform'] = np.array([0], dtype='i4')
+            ctx = Context(spec, device=self.device)
             theta = np.array([[data_params.get(param.name, param.value) for param in varied]], dtype='f8')
             flat = ctx.eval_batch_host(theta, return_flattheory=True)[3][0]
             ctx.close()
