@@ -89,3 +89,78 @@ def test_variant_vs_oracle(case):
         n = like.precision.shape[0]
         hartlap = (case['nobs'] - n - 2.) / (case['nobs'] - 1.)
         assert np.isclose(like.hartlap2007_factor, hartlap)
+
+
+def _oracle_constants(like, obs, theory, tpl):
+    wm = obs.wmatrix
+    return dict(template='shapefit', k11=tpl.k, pk_dd_fid=tpl.pk_dd_fid, f_fid=tpl.f_fid, kp=tpl.kp, a=tpl.a, kin=theory.k, mu=theory.mu, wmu_ell=theory.wmu,
+                ellsin=theory.ells, nd=theory.nd, matrix_full=wm.matrix_full, kmask=wm.kmask, offset=wm.offset, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout,
+                flatdata=obs.flatdata)
+
+
+def _check_against_oracle(like, obs, theory, tpl, nrows=24):
+    names = like.varied_params.names()
+    rng = np.random.RandomState(23)
+    theta = np.column_stack([np.clip(param.ref.sample(size=nrows, random_state=rng), *param.prior.limits) for param in like.varied_params])
+    loglike, logprior, status, flat = like._get_context().eval_batch_host(theta, return_flattheory=True)
+    assert (status == 0).all()
+    c = _oracle_constants(like, obs, theory, tpl)
+    for i in range(0, nrows, 2):
+        p = dict(zip(names, theta[i])); p['b1'] = (p['b1'], p['b1'])
+        out = orc.fullshape_observable(c, p)
+        assert np.allclose(flat[i], out['flattheory'], rtol=1e-11, atol=1e-12 * np.abs(out['flattheory']).max()), i
+        ref = orc.gaussian_loglikelihood(out['flattheory'], obs.flatdata, like.precision)[0]
+        assert abs(loglike[i] - ref) <= 1e-10 * max(1., abs(ref)), (i, loglike[i], ref)
+
+
+def test_window_variants_vs_oracle():
+    """Row selection without a window matrix (different k ranges per multipole: klim), and a user-provided dense matrix with rebinned input k,
+    more input than output multipoles and a window shot-noise vector (window.py:249-324, 445-457)."""
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    rng = np.random.RandomState(9)
+    # (1) k-range cuts per multipole on measured k's: theory evaluated on the union of k's, rows selected by kmask
+    k = np.arange(0.015, 0.2, 0.01)
+    tpl = ShapeFitPowerSpectrumTemplate(z=0.8)
+    theory = KaiserTracerPowerSpectrumMultipoles(template=tpl)
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 1.7}, k=k, ells=(0, 2, 4), klim={0: (0.02, 0.2), 2: (0.02, 0.15), 4: (0.05, 0.1)}, theory=theory, shotnoise=2e3)
+    obs.initialize()
+    n = sum(len(kk) for kk in obs.wmatrix.k)
+    like = ObservablesGaussianLikelihood(observables=[obs], precision=1. / rng.uniform(1e4, 4e4, size=n))
+    like.initialize()
+    assert obs.wmatrix.kmask is not None and n < 3 * len(k)
+    _check_against_oracle(like, obs, theory, tpl)
+    # (2) dense user matrix: 3 input multipoles on a fine grid (rebinned by 2) -> 2 output multipoles, window shot-noise vector
+    kout = np.arange(0.025, 0.2, 0.01)
+    kin = np.linspace(0.001, 0.35, 140)
+    nout = 2 * len(kout)
+    wmat = np.abs(rng.standard_normal((nout, 3 * len(kin)))) * 0.02
+    for ill in range(2):
+        for i, kk in enumerate(kout):
+            wmat[ill * len(kout) + i, ill * len(kin) + np.argmin(np.abs(kin - kk))] += 1.
+    wmat /= wmat.sum(axis=1)[:, None]
+    tpl = ShapeFitPowerSpectrumTemplate(z=0.8)
+    theory = KaiserTracerPowerSpectrumMultipoles(template=tpl)
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 1.7}, k=kout, ells=(0, 2), wmatrix=wmat, kin=kin, kinrebin=2, ellsin=(0, 2, 4), theory=theory, shotnoise=2e3,
+                                                  wshotnoise=0.1 * rng.uniform(size=nout))
+    A = rng.standard_normal((nout, nout)) * 15.
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + 1e4 * np.eye(nout))
+    like.initialize()
+    assert theory.k.size == 70 and obs.wmatrix.matrix_full.shape == (nout, 210)
+    _check_against_oracle(like, obs, theory, tpl)
+
+
+def test_chunked_batch_boundaries():
+    """Batches above the 32768-point internal pass are looped inside dl_eval_batch: results must not depend on where the chunk boundary falls."""
+    like, obs, theory, tpl = build(template='shapefit')
+    rng = np.random.RandomState(31)
+    B = 32768 + 77
+    theta = np.column_stack([np.clip(param.ref.sample(size=B, random_state=rng), *param.prior.limits) for param in like.varied_params])
+    ctx = like._get_context()
+    loglike, logprior, status = ctx.eval_batch_host(theta)
+    assert (status == 0).all()
+    pick = np.r_[0:5, 32760:32768 + 77]
+    small = ctx.eval_batch_host(theta[pick])
+    assert (np.abs(loglike[pick] - small[0]) <= 1e-10 * np.maximum(1., np.abs(small[0]))).all()
+    assert np.array_equal(logprior[pick], small[1])
