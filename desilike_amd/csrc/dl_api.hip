@@ -324,8 +324,8 @@ static int dl_reserve(dl_ctx* ctx, int64_t B) {
     ctx->cap = 0;
     const size_t R = 1 + ctx->n_var;   // rows per point: power + point-dependent derivative rows (analytic marginalisation)
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->power_ws, (size_t)need * R * ctx->K_pad * sizeof(double)));
-    // residual slabs: split-K partial sums, S * M <= M + 16384 + 64 rows (dl_gemm_tiled_splits)
-    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->delta_ws, ((size_t)need * R + 16384 + 2048) * ctx->N_pad * sizeof(double)));
+    // residual slabs: split-K partial sums, S * M <= max(2 M, M + 16384 + 64) rows (dl_gemm_tiled_splits)
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->delta_ws, std::max<size_t>(2 * (size_t)need * R, (size_t)need * R + 16384 + 2048) * ctx->N_pad * sizeof(double)));
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->flat_ws, (size_t)need * ctx->N_pad * sizeof(double)));
     // the K padding columns of the power buffer are never written by the theory kernel and must be finite
     DL_HIP_CHECK(ctx, hipMemset(ctx->power_ws, 0, (size_t)need * R * ctx->K_pad * sizeof(double)));

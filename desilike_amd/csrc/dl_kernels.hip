@@ -299,8 +299,16 @@ int dl_gemm_tiled_splits(int64_t M, int N_pad, int K_pad, int* chunks_per_split)
     int64_t mtiles = (M + DL_GT_M - 1) / DL_GT_M, ntiles = N_pad / DL_GT_N;
     int nchunks = K_pad / DL_GT_K;
     static const int target = getenv("DL_GEMM_WGS") ? atoi(getenv("DL_GEMM_WGS")) : 256;   // tuning knob (<= 256: the slab workspace is sized for that)
-    int64_t want = std::max<int64_t>(target / (mtiles * ntiles), 1);
-    int S = (int)std::min<int64_t>(want, std::min(nchunks, 32));
+    int64_t tiles = mtiles * ntiles;
+    int S;
+    if (tiles <= target) {
+        S = (int)std::min<int64_t>(std::max<int64_t>(target / tiles, 1), std::min(nchunks, 32));   // small M: ~one workgroup per CU
+    } else {
+        // large M: one workgroup per CU at a time, so the launch runs in ceil(tiles S / CUs) rounds of (chunks / S + c0) each (c0 ~ 12 chunks of fixed cost per
+        // workgroup); a second split pays when it removes a half-empty round (e.g. 384 tiles on 256 CUs: 2 x 92 -> 3 x 52).  At most 2: the slab workspace.
+        auto cost = [&](int s) { return (double)((tiles * s + target - 1) / target) * ((double)((nchunks + s - 1) / s) + 12.); };
+        S = (nchunks >= 2 * DL_GT_PANEL && cost(2) < 0.95 * cost(1)) ? 2 : 1;
+    }
     int cps = (nchunks + S - 1) / S;
     if (S > 1) cps = (cps + DL_GT_PANEL - 1) / DL_GT_PANEL * DL_GT_PANEL;   // whole panels
     *chunks_per_split = cps;
