@@ -37,6 +37,11 @@ struct dl_ctx {
     double* bias_wh_dev = nullptr;   // [N_pad]        -L^T . flatdata
     double* flatdata_dev = nullptr;  // [N_pad]
     int32_t* transform_dev = nullptr;// [N_pad]
+    // feature path of the emulated theories (dl_feature_gemm.h): every observable separable, no pass-through columns
+    bool feat_ok = false;
+    int64_t feat_ld = 0;             // doubles per point record (all observables)
+    std::vector<double*> gfrag_dev;  // per observable: whitened folded operator in MFMA fragment order
+    double* feat_ws = nullptr;       // [cap, feat_ld]
     // workspaces (grown on demand, never inside dl_eval_* once large enough)
     int64_t cap = 0;
     double* power_ws = nullptr;      // [cap, K_pad]
@@ -194,6 +199,35 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
         bias_white[i] = bsum;
         bias_wh[i] = -dsum;
     }
+    // ---- feature path: per observable G[(m, j)][h] = W~[j][(h, m)] in fragment order [N_pad / 16][nb_pad / 8][19][lane = col + 16 g][e]: k = 8 q + 2 g + e ----
+    std::vector<std::vector<double>> gfrag_host;
+    ctx->feat_ok = ctx->n_obs > 0 && !ctx->any_transform && !getenv("DL_NO_FEATURE_PATH");
+    for (int i = 0; i < ctx->n_obs && ctx->feat_ok; ++i) {
+        const DlObsDev& d = ctx->obs[i].dev;
+        if (d.theory != 3 || d.n_mono != DL_N_MONO || d.n_pass != 0) ctx->feat_ok = false;
+    }
+    if (ctx->feat_ok) {
+        int64_t off = 0;
+        for (int i = 0; i < ctx->n_obs; ++i) {
+            DlObsDev& d = ctx->obs[i].dev;
+            d.nb_pad = round_up(d.n_basis, 8);
+            d.feat_off = off;
+            off += d.nb_pad + (int64_t)17 * DL_FG_MONO_LD;   // records sized for the largest number of rows (1 + DL_MAX_SOLVED); n_var is fixed below
+            const int nq = d.nb_pad / 8, njb = ctx->N_pad / 16;
+            std::vector<double> gf((size_t)njb * nq * DL_FG_NM * 64 * 2, 0.);
+            for (int jb = 0; jb < njb; ++jb)
+                for (int q = 0; q < nq; ++q)
+                    for (int m = 0; m < DL_FG_NM; ++m)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 2; ++e) {
+                                int j = jb * 16 + (lane & 15), h = 8 * q + 2 * (lane >> 4) + e;
+                                double v = (h < d.n_basis) ? wt_white[(size_t)j * ctx->K_pad + d.col_offset + (size_t)h * DL_N_MONO + m] : 0.;
+                                gf[((((size_t)jb * nq + q) * DL_FG_NM + m) * 64 + lane) * 2 + e] = v;
+                            }
+            gfrag_host.push_back(std::move(gf));
+        }
+        ctx->feat_ld = off;
+    }
     // ---- analytic marginalisation (likelihoods/base.py:314-413): solved parameters, constant / point-dependent derivative columns ----
     {
         const auto& kind = cfg->I("marg.kind");
@@ -267,6 +301,11 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     }
     // ---- upload ----
     if (dl_upload(ctx, &ctx->arena_dev, arena.data)) { dl_destroy(ctx); return 1; }
+    for (auto& gf : gfrag_host) {
+        double* dev = nullptr;
+        if (dl_upload(ctx, &dev, gf)) { dl_destroy(ctx); return 1; }
+        ctx->gfrag_dev.push_back(dev);
+    }
     ctx->obs_kernarg.resize(ctx->n_obs);
     for (int i = 0; i < ctx->n_obs; ++i) { ctx->obs[i].rebase(ctx->arena_dev); ctx->obs_kernarg[i] = ctx->obs[i].dev; }
     {   // arrival counters of the fused chi2-GEMM finalize: one per 32-row block of the largest pass that takes that path (self-resetting)
@@ -291,6 +330,8 @@ void dl_destroy(dl_ctx* ctx) {
                     ctx->bias_wh_dev, ctx->flatdata_dev, ctx->transform_dev, ctx->tconst_dev, ctx->power_ws, ctx->delta_ws, ctx->flat_ws, ctx->theta_stage, ctx->out_stage,
                     ctx->status_stage, ctx->gemm_counters};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (double* p : ctx->gfrag_dev) if (p) (void)hipFree(p);
+    if (ctx->feat_ws) (void)hipFree(ctx->feat_ws);
     for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -320,13 +361,14 @@ static int dl_reserve(dl_ctx* ctx, int64_t B) {
     int64_t need = std::min<int64_t>(B, DL_CHUNK);
     if (need <= ctx->cap) return 0;
     need = std::min<int64_t>(std::max<int64_t>(need, 1024), DL_CHUNK);
-    for (double** p : {&ctx->power_ws, &ctx->delta_ws, &ctx->flat_ws}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    for (double** p : {&ctx->power_ws, &ctx->delta_ws, &ctx->flat_ws, &ctx->feat_ws}) if (*p) { (void)hipFree(*p); *p = nullptr; }
     ctx->cap = 0;
     const size_t R = 1 + ctx->n_var;   // rows per point: power + point-dependent derivative rows (analytic marginalisation)
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->power_ws, (size_t)need * R * ctx->K_pad * sizeof(double)));
     // residual slabs: split-K partial sums, S * M <= max(2 M, M + 16384 + 64) rows (dl_gemm_tiled_splits)
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->delta_ws, std::max<size_t>(2 * (size_t)need * R, (size_t)need * R + 16384 + 2048) * ctx->N_pad * sizeof(double)));
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->flat_ws, (size_t)need * ctx->N_pad * sizeof(double)));
+    if (ctx->feat_ok) DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->feat_ws, (size_t)need * ctx->feat_ld * sizeof(double)));
     // the K padding columns of the power buffer are never written by the theory kernel and must be finite
     DL_HIP_CHECK(ctx, hipMemset(ctx->power_ws, 0, (size_t)need * R * ctx->K_pad * sizeof(double)));
     ctx->cap = need;
@@ -348,9 +390,11 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         bool prof = ctx->profile && b0 == 0 && (ctx->eval_calls % ctx->prof_every == 0);
         hipEvent_t* ev = prof ? &ctx->ev[(size_t)(ctx->prof_calls % dl_ctx::NPOOL) * 4] : nullptr;
         if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[0], stream));
-        dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream);
-        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[1], stream));
         bool need_flat = ctx->any_transform || flattheory_dev != nullptr;
+        // emulated (separable) theories: the theory kernel writes only the factors (basis, monomial rows), the feature GEMM turns them into residual rows
+        const bool feat_path = ctx->feat_ok && !need_flat;
+        dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, feat_path ? ctx->feat_ws : nullptr, ctx->feat_ld);
+        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[1], stream));
         int n_slabs = 1, cps = 0;
         int64_t slab_stride = 0;
         const double* fin_bias = nullptr;   // the direct GEMM (transform path) adds its bias itself
@@ -364,8 +408,14 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
                                                    (size_t)n * sizeof(double), (size_t)nb, hipMemcpyDeviceToDevice, stream));
         }
         // plain likelihood: chi2 is additive over the columns of the whitened residual -> column-split GEMM that emits partial chi2 only
+        if (feat_path) {
+            for (int i = 0; i < ctx->n_obs; ++i)
+                dl_launch_feature_gemm(ctx->feat_ws, ctx->feat_ld, ctx->obs_kernarg[i].feat_off, ctx->obs_kernarg[i].nb_pad, R, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, nb,
+                                       i > 0, stream);
+            fin_bias = ctx->bias_white_dev;
+        }
         static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 2048;   // above: split-K slabs + finalize win (measured: 4096 rows 40 vs 49 us; 1024 rows 18 vs 13 us)
-        const bool chi2_path = !ctx->any_transform && ctx->n_solved == 0 && nb <= chi2_max_rows;
+        const bool chi2_path = !feat_path && !ctx->any_transform && ctx->n_solved == 0 && nb <= chi2_max_rows;
         // DL_CHI2_FUSED=1: finalize inside the GEMM's last-arriving workgroups.  Off by default: measured 19.1 us (GEMM 17.1) against 17.5 us for GEMM + the
         // separate 1024-thread finalize launch -- the device-scope counter round trip and the dependent tail cost more than the launch they save.
         static const bool chi2_fused = getenv("DL_CHI2_FUSED") && atoi(getenv("DL_CHI2_FUSED")) != 0;
@@ -374,6 +424,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
             dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad,
                                 chi2_fused ? ctx->gemm_counters : nullptr, th, P, ctx->priors_dev, loglike_dev ? loglike_dev + b0 : nullptr,
                                 logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr, post_mode, stream);
+        } else if (feat_path) {
+            // residual rows already in delta_ws (one slab, bias added by the finalize kernels)
         } else if (ctx->any_transform) {
             // dtilde = L^T (flattheory - flatdata)
             dl_launch_window_gemm(ctx->flat_ws, ctx->N_pad, ctx->wh_dev, ctx->N_pad, ctx->bias_wh_dev, ctx->delta_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad, ctx->N_pad,

@@ -1,0 +1,93 @@
+// Feature GEMM of the emulated (velocileptors-table) theories: whitened residual rows without ever forming the feature vectors.
+//
+//   The theory vector of these observables is separable, phi[(h, m)] = basis_h(theta) * mono_m(theta) (h: emulator basis = last hidden layer of the
+//   MLP / Taylor monomials, m: 19 bias monomials, full_shape.py:1182-1186), and so is every derivative row of an analytically solved parameter
+//   (d phi / d x_s = basis_h * dmono_s,m).  With G[(m, j)][h] = W~[j][(h, m)] (the folded last layer x k-interpolation x window x L^T operator, regrouped):
+//       U[m][j] = sum_h G[(m, j)][h] basis_h            -- ONE GEMM per point, K = n_basis (~65), shared by all rows
+//       row_r[j] = sum_m mono_r[m] U[m][j]              -- 19 FMAs per output in the epilogue, r = 0 (residual), 1 .. n_var (derivative rows)
+//   instead of (1 + n_var) dense rows of K = 19 n_basis (~1235) through the generic GEMM: 6x fewer flops at 5 solved parameters, and the theory kernel
+//   writes 80 + 20 (1 + n_var) doubles per point instead of 1280 (1 + n_var).
+//
+//   Workgroup = 16 points x 128 output columns, 8 waves = 8 column blocks of 16; a wave holds U[16 points][m][16 columns] for 10 (then 9) monomials in MFMA
+//   accumulators (v_mfma_f64_16x16x4_f64), K advances 8 at a time: the A operand (basis, 16 x n_basis) comes from LDS, the B operand streams from L2 in
+//   fragment order (the host lays G out as [column block][k / 8][m][lane][2]: one load instruction = 1 KB contiguous), double-buffered in registers,
+//   loads never under control flow.  k -> (MFMA step, lane group) is permuted identically for A and B: lane group g owns k = 8 q + 2 g + {0, 1}.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double dl_fg_double2 __attribute__((ext_vector_type(2)));
+typedef double dl_fg_double4 __attribute__((ext_vector_type(4)));
+
+#define DL_FG_PTS 16          // points per workgroup (one MFMA row tile)
+#ifndef DL_FG_NM
+#define DL_FG_NM 19           // bias monomials
+#define DL_FG_MONO_LD 20      // monomial row padded to 20 doubles
+#endif
+#define DL_FG_MG 10           // monomials per accumulator group (two groups: 10 + 9)
+
+// LDS row stride (doubles) of a point record: >= rec_len, = 2 mod 32 (the 16 points of an operand read then hit distinct banks, rows stay 16-byte aligned)
+static inline __host__ __device__ int dl_fg_lds_stride(int rec_len) { return (rec_len + 31) / 32 * 32 + 2; }
+
+// feat: [B, feat_ld] point records, this observable's record at column feat_off: basis [nb_pad] then mono [R][DL_FG_MONO_LD]
+// gfrag: [N_pad / 16][nb_pad / 8][19][64][2]; out: [B * R, ldo] (+= if accumulate)
+__global__ __launch_bounds__(512) void dl_feature_gemm_kernel(const double* __restrict__ feat, int64_t feat_ld, int64_t feat_off, int nb_pad, int R,
+                                                              const double* __restrict__ gfrag, double* __restrict__ out, int64_t ldo, int64_t B, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, g = lane >> 4;
+    const int64_t p0 = (int64_t)blockIdx.x * DL_FG_PTS;
+    const int jb = blockIdx.y * 8 + wave;               // 16-column block of this wave
+    const int rec_len = nb_pad + R * DL_FG_MONO_LD;
+    const int stride = dl_fg_lds_stride(rec_len);
+    // stage the 16 point records (rows beyond B repeat the last point; their outputs are not stored)
+    for (int idx = tid; idx < DL_FG_PTS * rec_len; idx += 512) {
+        int pt = idx / rec_len, c = idx - pt * rec_len;
+        int64_t b = p0 + pt < B ? p0 + pt : B - 1;
+        lds[pt * stride + c] = feat[(size_t)b * feat_ld + feat_off + c];
+    }
+    __syncthreads();
+    const int nq = nb_pad / 8;
+    const dl_fg_double2* gw = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * nq * DL_FG_NM * 64 + lane;
+    const double* arow = lds + col * stride + 2 * g;                 // A operand of lane (point = col index of the lane, k group g)
+    for (int mg = 0; mg < 2; ++mg) {
+        const int m0 = mg * DL_FG_MG;
+        dl_fg_double4 acc[DL_FG_MG];
+#pragma unroll
+        for (int i = 0; i < DL_FG_MG; ++i) acc[i] = (dl_fg_double4){0., 0., 0., 0.};
+        dl_fg_double2 bcur[DL_FG_MG], bnxt[DL_FG_MG];
+        // monomial m0 + i, clamped to the last one in the short group (its accumulator is ignored): the load count is the same on every path
+#pragma unroll
+        for (int i = 0; i < DL_FG_MG; ++i) { int m = m0 + i < DL_FG_NM ? m0 + i : DL_FG_NM - 1; bcur[i] = gw[(size_t)(0 * DL_FG_NM + m) * 64]; }
+        for (int q = 0; q < nq; ++q) {
+            const int qn = q + 1 < nq ? q + 1 : q;
+#pragma unroll
+            for (int i = 0; i < DL_FG_MG; ++i) { int m = m0 + i < DL_FG_NM ? m0 + i : DL_FG_NM - 1; bnxt[i] = gw[(size_t)(qn * DL_FG_NM + m) * 64]; }
+            const dl_fg_double2 a = *reinterpret_cast<const dl_fg_double2*>(arow + 8 * q);
+#pragma unroll
+            for (int i = 0; i < DL_FG_MG; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bcur[i].x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bcur[i].y, acc[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < DL_FG_MG; ++i) bcur[i] = bnxt[i];
+        }
+        // epilogue: accumulator register rr of lane (col, g) = U[point g + 4 rr][m][column jb * 16 + col]; contract with the monomial rows of that point
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int pt = g + 4 * rr;
+            if (p0 + pt < B) {
+                const double* mono = lds + pt * stride + nb_pad;
+                for (int r = 0; r < R; ++r) {
+                    double v = 0.;
+#pragma unroll
+                    for (int i = 0; i < DL_FG_MG; ++i)
+                        if (m0 + i < DL_FG_NM) v = fma(mono[r * DL_FG_MONO_LD + m0 + i], acc[i][rr], v);
+                    double* dst = out + ((size_t)(p0 + pt) * R + r) * ldo + jb * 16 + col;
+                    if (mg > 0 || accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}

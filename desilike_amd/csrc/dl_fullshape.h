@@ -96,6 +96,8 @@ struct DlObsDev {
     // emulated theory (kind 3): features phi[(h, m)] = basis_h(theta) * mono_m(theta); the last emulator layer, the bias-table sum
     // (full_shape.py:1182-1186), the k-interpolation and the window are ONE matrix folded on the host (desilike_amd/emulators.py)
     int32_t n_x, n_basis, n_mono, mono_mode;   // mono_mode: 0 none, 1 LPT physical basis, 2 REPT physical, 3 LPT direct, 4 REPT direct
+    int32_t nb_pad, feat_pad;                  // feature path (dl_feature_gemm.h): n_basis rounded up to 8; (unused)
+    int64_t feat_off;                          // column of this observable's record [basis nb_pad | mono (1 + n_var) x 20] in a row of the feature buffer
     DlInput x_in[DL_MAX_X];
     DlInput vp_in[DL_N_VPARS];                 // b1(p) b2(p) bs(p) b3(p) alpha0(p) alpha2(p) alpha4(p) alpha6 sn0(p) sn2(p) sn4(p)
     int32_t vp_slot[DL_N_VPARS];               // variable (derivative-row) slot of an analytically solved alpha* / sn*, or -1
@@ -942,8 +944,9 @@ DL_HD double* dl_emu_engine(const DlObsDev& o, int ie, double* lds) {
     return nxt;
 }
 
-// features of one point: row0[(h, m)] = basis_h mono_m, derivative rows (1 + slot)[(h, m)] = basis_h dmono_slot,m, pass-through columns
-DL_HD void dl_emu_point(const DlObsDev& o, const double* th, double* lds, double* row0, int64_t ld) {
+// features of one point: row0[(h, m)] = basis_h mono_m, derivative rows (1 + slot)[(h, m)] = basis_h dmono_slot,m, pass-through columns.
+// feat_rec != nullptr (feature path, dl_feature_gemm.h): only the factors are written, basis [nb_pad] then the monomial rows [(1 + n_var)][20].
+DL_HD void dl_emu_point(const DlObsDev& o, const double* th, double* lds, double* row0, int64_t ld, double* feat_rec = nullptr) {
     DL_PAR_BEGIN
         if (tid < o.n_x) lds[DL_EM_X + tid] = dl_get(o.x_in[tid], th);
     DL_PAR_END
@@ -966,6 +969,16 @@ DL_HD void dl_emu_point(const DlObsDev& o, const double* th, double* lds, double
             if (o.eng[0].type == 0) basis[o.n_basis - 1] = 1.;      // bias row of the folded final layer
         }
     DL_PAR_END
+    if (feat_rec != nullptr) {
+        DL_PAR_BEGIN
+            for (int h = tid; h < o.nb_pad; h += DL_FS_THREADS) feat_rec[h] = h < o.n_basis ? basis[h] : 0.;
+            for (int idx = tid; idx < (1 + o.n_var) * 20; idx += DL_FS_THREADS) {
+                int r = idx / 20, m = idx - r * 20;
+                feat_rec[o.nb_pad + idx] = m < DL_N_MONO ? mono[(size_t)r * DL_N_MONO + m] : 0.;
+            }
+        DL_PAR_END
+        return;
+    }
     DL_PAR_BEGIN
         const int nm = o.n_mono;
         for (int idx = tid; idx < o.n_in; idx += DL_FS_THREADS) {

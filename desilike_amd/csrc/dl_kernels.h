@@ -12,7 +12,7 @@
 
 // obs_host: HOST array of observables whose pointers already point into device memory (passed by value to the kernel)
 void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
-                         int64_t ld_tables, hipStream_t stream);
+                         int64_t ld_tables, hipStream_t stream, double* feat = nullptr, int64_t feat_ld = 0);
 // bias is added to rows r with r % bias_period == 0 only (bias_period = 1: every row)
 void dl_launch_window_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* C, int64_t ldc, int64_t M, int N_valid, int N_pad,
                            int K_pad, int bias_period, hipStream_t stream);
@@ -43,3 +43,11 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
                          const double* theta, int n_params, const double* priors, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream);
 void dl_launch_finalize_part(const double* part, int n_tiles, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
                              int32_t* status, int post_mode, hipStream_t stream);
+#ifndef DL_FG_NM
+#define DL_FG_NM 19           // bias monomials of the velocileptors table combination
+#define DL_FG_MONO_LD 20      // monomial rows are padded to 20 doubles in the point records
+#endif
+// emulated theories, feature path: residual rows out[B * R, ldo] (+)= monomial rows x (G . basis) from the point records written by the theory kernel (dl_feature_gemm.h);
+// gfrag = the whitened folded operator of the observable in fragment order [N_pad / 16][nb_pad / 8][19][64][2]
+void dl_launch_feature_gemm(const double* feat, int64_t feat_ld, int64_t feat_off, int nb_pad, int R, const double* gfrag, double* out, int64_t ldo, int N_pad, int64_t B,
+                            int accumulate, hipStream_t stream);

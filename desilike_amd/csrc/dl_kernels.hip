@@ -132,14 +132,16 @@ __global__ __launch_bounds__(DL_FS_THREADS) void dl_bao_kernel(const DlObsDev o,
 }
 
 // emulated theory: MLP / Taylor forward pass and feature expansion, one workgroup per point
-__global__ __launch_bounds__(DL_FS_THREADS) void dl_emulated_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power, int64_t ld_power) {
+__global__ __launch_bounds__(DL_FS_THREADS) void dl_emulated_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power, int64_t ld_power,
+                                                                   double* __restrict__ feat, int64_t feat_ld) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
-    dl_emu_point(o, theta + (size_t)b * n_params, lds, power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset, ld_power);
+    dl_emu_point(o, theta + (size_t)b * n_params, lds, power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset, ld_power,
+                 feat ? feat + (size_t)b * feat_ld + o.feat_off : nullptr);
 }
 
 void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
-                         int64_t ld_tables, hipStream_t stream) {
+                         int64_t ld_tables, hipStream_t stream, double* feat, int64_t feat_ld) {
     static const int stop_after = getenv("DL_FS_STOP") ? atoi(getenv("DL_FS_STOP")) : 0;   // per-phase timing diagnostics
     // DL_FS_STAMPS=<file>: in-kernel timestamps of the launches with B >= 256 are appended to <file> as text (synchronises: diagnostics only)
     static const char* stamp_file = getenv("DL_FS_STAMPS");
@@ -151,7 +153,7 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
     for (int i = 0; i < n_obs; ++i) {  // one launch per observable (1-2 in practice)
         if (obs_host[i].theory == 3) {   // DL_THEORY_EMULATED
             size_t shm = dl_emu_shared_doubles(obs_host[i].n_var) * sizeof(double);
-            hipLaunchKernelGGL(dl_emulated_kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power);
+            hipLaunchKernelGGL(dl_emulated_kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power, feat, feat_ld);
             continue;
         }
         if (obs_host[i].theory == 2) {   // DL_THEORY_BAO_DAMPED
@@ -293,6 +295,7 @@ void dl_launch_window_gemm(const double* A, int64_t lda, const double* Wt, int64
 // ------------------------------------------------------------------------------------------------
 #include "dl_gemm_tiled.h"
 #include "dl_chi2_gemm.h"
+#include "dl_feature_gemm.h"
 
 // number of K splits: ~one workgroup per CU at small M, whole panels per split
 int dl_gemm_tiled_splits(int64_t M, int N_pad, int K_pad, int* chunks_per_split) {
@@ -417,6 +420,18 @@ void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, in
                         const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream) {
     hipLaunchKernelGGL(dl_finalize_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, n_slabs, slab_stride, bias, theta, n_params, priors, B, loglike,
                        logprior, status, post_mode);
+}
+
+// ------------------------------------------------------------------------------------------------
+// feature GEMM of the emulated theories (dl_feature_gemm.h): residual rows [B * R, N_pad] from the point records
+// ------------------------------------------------------------------------------------------------
+void dl_launch_feature_gemm(const double* feat, int64_t feat_ld, int64_t feat_off, int nb_pad, int R, const double* gfrag, double* out, int64_t ldo, int N_pad, int64_t B,
+                            int accumulate, hipStream_t stream) {
+    const int rec_len = nb_pad + R * DL_FG_MONO_LD;
+    const size_t shm = (size_t)DL_FG_PTS * dl_fg_lds_stride(rec_len) * sizeof(double);
+    if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_feature_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(dl_feature_gemm_kernel, dim3((unsigned)((B + DL_FG_PTS - 1) / DL_FG_PTS), (unsigned)(N_pad / 128)), dim3(512), shm, stream, feat, feat_ld, feat_off, nb_pad, R,
+                       gfrag, out, ldo, B, accumulate);
 }
 
 // ------------------------------------------------------------------------------------------------
