@@ -1,0 +1,139 @@
+// Batched emulator forward pass for the feature path: 16 parameter points per workgroup, every dense layer of the MLP engines as an fp64
+// MFMA product [16 points x n_in] . [n_in x n_out] (the per-point kernel dl_emulated_kernel evaluates a layer with one thread per output unit and a
+// serial chain of n_in FMAs fed by global loads: 57 us per 4096 points against ~10 us here).  Activations live in LDS, weights stream from L2 in their
+// stored [in, out] layout (a B-operand load = 16 consecutive outputs of one input row: 128 contiguous bytes).  Taylor engines, the velocileptors bias
+// monomials (one thread per point) and the point records of dl_feature_gemm.h follow.  Device-only (MFMA): validated on the GPU against the oracle and
+// the reference fixture (tests/test_gpu_emulator.py), like the feature GEMM.
+#pragma once
+#include "dl_fullshape.h"
+
+typedef double dl_eb_double4 __attribute__((ext_vector_type(4)));
+
+#define DL_EB_PTS 16
+
+static inline __host__ __device__ int dl_eb_ld(const DlObsDev& o) {   // LDS row length of an activation buffer: widest layer / most Taylor terms, multiple of 4, + 2
+    int w = o.n_x;
+    for (int ie = 0; ie < 3; ++ie) {
+        const DlObsDev::Engine& e = o.eng[ie];
+        if (e.type == 0) { for (int l = 0; l <= e.n_layers; ++l) if (e.widths[l] > w) w = e.widths[l]; }
+        else if (e.type == 1 && e.n_terms > w) w = e.n_terms;
+    }
+    if (o.n_basis > w) w = o.n_basis;
+    return (w + 3) / 4 * 4 + 2;
+}
+static inline __host__ __device__ size_t dl_eb_shared_doubles(const DlObsDev& o) {
+    return (size_t)DL_EB_PTS * (DL_MAX_X + 2 * dl_eb_ld(o) + 4 + (size_t)(1 + o.n_var) * DL_N_MONO);
+}
+
+#if defined(__HIPCC__)
+__global__ __launch_bounds__(256) void dl_emulated_batch_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, int64_t B, double* __restrict__ feat,
+                                                                int64_t feat_ld) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, g = lane >> 4;
+    const int LD = dl_eb_ld(o);
+    double* x = lds;                                      // [16][DL_MAX_X]
+    double* buf0 = x + DL_EB_PTS * DL_MAX_X;              // [16][LD]
+    double* buf1 = buf0 + DL_EB_PTS * LD;                 // [16][LD]
+    double* scal = buf1 + DL_EB_PTS * LD;                 // [16][4]: sigma8 (1), fsigma8 (2)
+    double* mono = scal + DL_EB_PTS * 4;                  // [16][(1 + n_var) * 19]
+    const int64_t p0 = (int64_t)blockIdx.x * DL_EB_PTS;
+    for (int idx = tid; idx < DL_EB_PTS * o.n_x; idx += 256) {
+        int pt = idx / o.n_x, i = idx - pt * o.n_x;
+        int64_t b = p0 + pt < B ? p0 + pt : B - 1;
+        x[pt * DL_MAX_X + i] = dl_get(o.x_in[i], theta + (size_t)b * n_params);
+    }
+    __syncthreads();
+    double* basis = buf0;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int ie = pass == 2 ? 0 : pass + 1;          // scalar engines first, the table basis last (it stays in LDS)
+        const DlObsDev::Engine& e = o.eng[ie];
+        if (e.type < 0) continue;
+        double* cur = buf0;
+        double* nxt = buf1;
+        if (e.type == 0) {
+            // scaled inputs (conversion.py:75-77), zero-padded to a multiple of 4 columns
+            const int nin0 = (o.n_x + 3) & ~3;
+            for (int idx = tid; idx < DL_EB_PTS * nin0; idx += 256) {
+                int pt = idx / nin0, i = idx - pt * nin0;
+                cur[pt * LD + i] = i < o.n_x ? (x[pt * DL_MAX_X + i] - e.xlo[i]) * e.xinv[i] : 0.;
+            }
+            __syncthreads();
+            const double* w = e.weights;
+            for (int layer = 0; layer < e.n_layers; ++layer) {
+                const int nin = e.widths[layer], nout = e.widths[layer + 1];
+                const bool last = (layer == e.n_layers - 1);
+                const bool activate = !(last && ie != 0);   // the table engine stops after its last HIDDEN layer (its final linear layer is folded on the host)
+                const int ksteps = (nin + 3) / 4, tiles = (nout + 15) / 16, nout4 = (nout + 3) & ~3;
+                for (int t = wave; t < tiles; t += 4) {
+                    const int oc = 16 * t + col;
+                    dl_eb_double4 acc = {0., 0., 0., 0.};
+                    for (int ks0 = 0; ks0 < ksteps; ks0 += 8) {   // eight k-steps of weight loads in flight (each is an L2 round trip otherwise)
+                        double bv[8], av[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int k = 4 * (ks0 + u) + g;
+                            bv[u] = (ks0 + u < ksteps && k < nin && oc < nout) ? w[(size_t)k * nout + oc] : 0.;   // B[k][output unit]
+                            av[u] = (ks0 + u < ksteps) ? cur[col * LD + k] : 0.;                                  // A[point = lane & 15][k]   (columns >= nin are zero)
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+                    }
+                    const double bias = oc < nout ? w[(size_t)nin * nout + oc] : 0.;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {       // accumulator register r = out[point g + 4 r][oc]
+                        double v = acc[r] + bias;
+                        if (activate) v = dl_activation(e.act, v);
+                        if (oc < nout4) nxt[(g + 4 * r) * LD + oc] = oc < nout ? v : 0.;
+                    }
+                }
+                __syncthreads();
+                w += (size_t)nin * nout + nout;
+                double* tmp = cur; cur = nxt; nxt = tmp;
+            }
+            if (ie != 0) {
+                if (tid < DL_EB_PTS) scal[tid * 4 + ie] = cur[tid * LD] * e.yscale + e.ylo;   // conversion.py:79 (inverse scaler)
+            } else {
+                basis = cur;
+                if (tid < DL_EB_PTS) basis[tid * LD + o.n_basis - 1] = 1.;                    // bias row of the folded final layer
+            }
+            __syncthreads();
+        } else {
+            // Taylor: monomials prod_p (x_p - c_p)^powers[t, p] (emulators/__init__.py:471-507)
+            for (int idx = tid; idx < DL_EB_PTS * e.n_terms; idx += 256) {
+                int pt = idx / e.n_terms, t = idx - pt * e.n_terms;
+                double mon = 1.;
+                for (int p = 0; p < o.n_x; ++p) mon *= dl_ipow(x[pt * DL_MAX_X + p] - e.center[p], (int)e.powers[(size_t)t * o.n_x + p]);
+                nxt[pt * LD + t] = mon;
+            }
+            __syncthreads();
+            if (ie != 0) {
+                if (tid < DL_EB_PTS) {
+                    double sum = 0.;
+                    for (int t = 0; t < e.n_terms; ++t) sum = fma(e.coef[t], nxt[tid * LD + t], sum);
+                    scal[tid * 4 + ie] = sum;
+                }
+            } else basis = nxt;
+            __syncthreads();
+        }
+    }
+    // bias monomials and their derivatives w.r.t. the solved parameters: one thread per point
+    if (tid < DL_EB_PTS) {
+        int64_t b = p0 + tid < B ? p0 + tid : B - 1;
+        const double sigma8 = o.eng[1].type >= 0 ? scal[tid * 4 + 1] : o.eng[1].cst;
+        const double fsigma8 = o.eng[2].type >= 0 ? scal[tid * 4 + 2] : o.eng[2].cst;
+        dl_velocileptors_monomials(o, theta + (size_t)b * n_params, sigma8, fsigma8, mono + (size_t)tid * (1 + o.n_var) * DL_N_MONO);
+    }
+    __syncthreads();
+    // point records of the feature GEMM: basis [nb_pad] | monomial rows [(1 + n_var)][20]
+    const int rec_len = o.nb_pad + (1 + o.n_var) * 20;
+    for (int idx = tid; idx < DL_EB_PTS * rec_len; idx += 256) {
+        int pt = idx / rec_len, c = idx - pt * rec_len;
+        if (p0 + pt >= B) continue;
+        double v;
+        if (c < o.nb_pad) v = c < o.n_basis ? basis[pt * LD + c] : 0.;
+        else { int q = c - o.nb_pad, r = q / 20, m = q - r * 20; v = m < DL_N_MONO ? mono[((size_t)pt * (1 + o.n_var) + r) * DL_N_MONO + m] : 0.; }
+        feat[(size_t)(p0 + pt) * feat_ld + o.feat_off + c] = v;
+    }
+}
+#endif

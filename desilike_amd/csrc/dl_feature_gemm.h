@@ -50,6 +50,11 @@ __global__ __launch_bounds__(512) void dl_feature_gemm_kernel(const double* __re
     const int nq = nb_pad / 8;
     const dl_fg_double2* gw = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * nq * DL_FG_NM * 64 + lane;
     const double* arow = lds + col * stride + 2 * g;                 // A operand of lane (point = col index of the lane, k group g)
+    double outv[4][6];   // rows 0-5 of the four points of this lane, carried from the first monomial group to the second
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int u = 0; u < 6; ++u) outv[rr][u] = 0.;
     for (int mg = 0; mg < 2; ++mg) {
         const int m0 = mg * DL_FG_MG;
         dl_fg_double4 acc[DL_FG_MG];
@@ -72,20 +77,36 @@ __global__ __launch_bounds__(512) void dl_feature_gemm_kernel(const double* __re
 #pragma unroll
             for (int i = 0; i < DL_FG_MG; ++i) bcur[i] = bnxt[i];
         }
-        // epilogue: accumulator register rr of lane (col, g) = U[point g + 4 rr][m][column jb * 16 + col]; contract with the monomial rows of that point
+        // epilogue: accumulator register rr of lane (col, g) = U[point g + 4 rr][m][column jb * 16 + col]; contract with the monomial rows of that point.
+        // The first six rows of a point are carried in registers across the two monomial groups and stored once (writing partial rows and adding to them
+        // in the second group tripled the output traffic: 14 of 48 us at 6 rows per point); rows beyond six take the read-modify-write route, six at a time
+        // with their old values requested together.
+        for (int r0 = 0; r0 < R; r0 += 6) {
+            const bool in_regs = (r0 == 0);
+            double old[4][6];
+            const bool rmw = in_regs ? (mg == 1 && accumulate) : (mg > 0 || accumulate);
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int pt = g + 4 * rr;
-            if (p0 + pt < B) {
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int pt = g + 4 * rr, r = r0 + u;
+                    old[rr][u] = (rmw && r < R && p0 + pt < B) ? out[((size_t)(p0 + pt) * R + r) * ldo + jb * 16 + col] : 0.;
+                }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int pt = g + 4 * rr;
                 const double* mono = lds + pt * stride + nb_pad;
-                for (int r = 0; r < R; ++r) {
-                    double v = 0.;
 #pragma unroll
-                    for (int i = 0; i < DL_FG_MG; ++i)
-                        if (m0 + i < DL_FG_NM) v = fma(mono[r * DL_FG_MONO_LD + m0 + i], acc[i][rr], v);
-                    double* dst = out + ((size_t)(p0 + pt) * R + r) * ldo + jb * 16 + col;
-                    if (mg > 0 || accumulate) v += *dst;
-                    *dst = v;
+                for (int u = 0; u < 6; ++u) {
+                    const int r = r0 + u;
+                    if (r < R && p0 + pt < B) {
+                        double v = (in_regs && mg == 1) ? outv[rr][u] + old[rr][u] : old[rr][u];
+#pragma unroll
+                        for (int i = 0; i < DL_FG_MG; ++i)
+                            if (m0 + i < DL_FG_NM) v = fma(mono[r * DL_FG_MONO_LD + m0 + i], acc[i][rr], v);
+                        if (in_regs && mg == 0) outv[rr][u] = v;
+                        else out[((size_t)(p0 + pt) * R + r) * ldo + jb * 16 + col] = v;
+                    }
                 }
             }
         }

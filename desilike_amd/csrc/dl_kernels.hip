@@ -14,6 +14,7 @@
 
 #include "dl_fullshape.h"
 #include "dl_kernels.h"
+#include "dl_emu_batch.h"
 
 // ------------------------------------------------------------------------------------------------
 // theory kernel
@@ -151,6 +152,12 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
     unsigned long long* stamps = (stamp_file && B >= 256 && B <= 65536 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
     if (stamp_file && B >= 256) stamp_launches++;
     for (int i = 0; i < n_obs; ++i) {  // one launch per observable (1-2 in practice)
+        if (obs_host[i].theory == 3 && feat != nullptr && !getenv("DL_NO_EMU_BATCH")) {   // feature path: 16 points per workgroup, MLP layers by MFMA
+            size_t shm = dl_eb_shared_doubles(obs_host[i]) * sizeof(double);
+            if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_emulated_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            hipLaunchKernelGGL(dl_emulated_batch_kernel, dim3((unsigned)((B + DL_EB_PTS - 1) / DL_EB_PTS)), dim3(256), shm, stream, obs_host[i], theta, n_params, B, feat, feat_ld);
+            continue;
+        }
         if (obs_host[i].theory == 3) {   // DL_THEORY_EMULATED
             size_t shm = dl_emu_shared_doubles(obs_host[i].n_var) * sizeof(double);
             hipLaunchKernelGGL(dl_emulated_kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power, feat, feat_ld);
