@@ -40,5 +40,17 @@ def main():
         time_likelihood('cfg4: damped BAO ' + space, like, 8192)
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
+
+
+def small_batches():
+    """config 5 shape: two tracers summed, half-ensembles of 256 walkers (32 per GPU at 8 GPUs): per-call latency matters, not throughput."""
+    from test_host_api import make_cfg5
+    g, like = make_cfg5()
+    for B in (32, 256, 1024):
+        time_likelihood('cfg5: two-tracer sum (240 data points)', like, B, steps=200)
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'small':
+    small_batches()
