@@ -135,10 +135,12 @@ enum {
     DL_PT_CT = DL_PT_SD + DL_MAX_MU,                // 0.5 (ctX + ctY)
     DL_PT_SN = DL_PT_CT + DL_MAX_EFT,               // sn / nd
     DL_PT_OM = DL_PT_SN + DL_MAX_EFT,               // [n_mu][8]: jac w_l(mu) (b1X + f mu'^2)(b1Y + f mu'^2) for l < 5, [5] = jac w_{l=0}: fused weights
-    DL_PT_W3 = DL_PT_OM + 8 * DL_MAX_MU,            // [n_mu][5][3]: jac w_l(mu) (1, f mu'^2, (f mu'^2)^2): separate-table weights
-    DL_PT_LQH = DL_PT_W3 + 15 * DL_MAX_MU,          // log10(F_m / qper) inv_hx: the shift in units of the knot spacing (uniform knots)
+    DL_PT_LQH = DL_PT_OM + 8 * DL_MAX_MU,           // log10(F_m / qper) inv_hx: the shift in units of the knot spacing (uniform knots)
     DL_PT_PART = DL_PT_LQH + DL_MAX_MU,             // [DL_FS_THREADS] partial dot products of the segmented sweeps / mu^k table of the convolution path
-    DL_PT_SIZE = DL_PT_PART + DL_FS_THREADS
+    DL_PT_SIZE_FAST = DL_PT_PART + 2 * DL_FIR_PAD + 8,   // the fast kernels stop here: 65 table entries, no separate-table weights (31 KB per workgroup at the
+                                                    // benchmark shape: five workgroups per CU)
+    DL_PT_W3 = DL_PT_PART + DL_FS_THREADS,          // [n_mu][5][3]: jac w_l(mu) (1, f mu'^2, (f mu'^2)^2): separate-table weights (general kernel only)
+    DL_PT_SIZE = DL_PT_W3 + 15 * DL_MAX_MU
 };
 
 struct DlFsShared {
@@ -154,7 +156,7 @@ struct DlFsShared {
 DL_HD size_t dl_fs_work_doubles(int n_t, int n_in) { size_t w = 3 * (size_t)n_t; if (2 * (size_t)n_in > w) w = 2 * (size_t)n_in; return (w + 1) & ~(size_t)1; }
 DL_HD size_t dl_fs_work_doubles(int n_t, int n_in, int n_dd0) { size_t w = 3 * (size_t)n_t; if ((size_t)n_in + n_dd0 > w) w = (size_t)n_in + n_dd0; return (w + 1) & ~(size_t)1; }
 DL_HD size_t dl_fs_shared_doubles(int n_t, int n_in) { return 4 * (size_t)n_t + dl_fs_work_doubles(n_t, n_in) + DL_PT_SIZE; }
-DL_HD size_t dl_fs_shared_doubles_obs(const DlObsDev& o) { return 4 * (size_t)o.n_t + dl_fs_work_doubles(o.n_t, o.n_in, dl_fs_n_dd0(o)) + DL_PT_SIZE; }
+DL_HD size_t dl_fs_shared_doubles_obs(const DlObsDev& o, bool fast = false) { return 4 * (size_t)o.n_t + dl_fs_work_doubles(o.n_t, o.n_in, dl_fs_n_dd0(o)) + (fast ? DL_PT_SIZE_FAST : DL_PT_SIZE); }
 
 // toep: layout of the convolution path (dl_fs_phase2_fir): y sits DL_FIR_PAD zeros inside the work region, M (the moments) right after the padded y
 DL_HD DlFsShared dl_fs_shared_carve(double* base, int n_t, int n_in, int n_dd0 = -1, bool toep = false) {
@@ -212,7 +214,7 @@ DL_HD void dl_fs_mu_partB(DlMuCarry& c) {
 }
 
 // part C: weights of mu node m -> LDS
-DL_HD void dl_fs_mu_partC(const DlObsDev& o, const DlFsShared& s, int m, const DlMuCarry& c) {
+DL_HD void dl_fs_mu_partC(const DlObsDev& o, const DlFsShared& s, int m, const DlMuCarry& c, bool w3 = true) {
     s.pt[DL_PT_FAC + m] = c.fac;
     s.pt[DL_PT_LQ + m] = c.lq;
     s.pt[DL_PT_LQH + m] = c.lq * o.inv_hx;
@@ -223,9 +225,11 @@ DL_HD void dl_fs_mu_partC(const DlObsDev& o, const DlFsShared& s, int m, const D
     for (int l = 0; l < DL_MAX_ELL; ++l) {
         double w = (l < o.n_ell) ? c.jac * o.wmu[l * o.n_mu + m] : 0.;
         s.pt[DL_PT_OM + m * 8 + l] = w * bias;
-        s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 0] = w;
-        s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 1] = w * fm2;
-        s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 2] = w * (fm2 * fm2);
+        if (w3) {
+            s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 0] = w;
+            s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 1] = w * fm2;
+            s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 2] = w * (fm2 * fm2);
+        }
     }
     s.pt[DL_PT_OM + m * 8 + 5] = (o.ell0 >= 0) ? c.jac * o.wmu[o.ell0 * o.n_mu + m] : 0.;
     s.pt[DL_PT_OM + m * 8 + 6] = 0.;
@@ -233,11 +237,11 @@ DL_HD void dl_fs_mu_partC(const DlObsDev& o, const DlFsShared& s, int m, const D
 }
 
 // per-point scalars and the zero padding of the mu nodes (one thread)
-DL_HD void dl_fs_scalars(const DlObsDev& o, const double* th, const DlFsShared& s, const DlMuCarry& c) {
+DL_HD void dl_fs_scalars(const DlObsDev& o, const double* th, const DlFsShared& s, const DlMuCarry& c, bool w3 = true) {
     for (int mm = o.n_mu; mm < ((o.n_mu + 3) & ~3); ++mm) {   // pad the mu nodes to a multiple of 4 with zero weights (unrolled loops)
         s.pt[DL_PT_LQ + mm] = 0.; s.pt[DL_PT_LQH + mm] = 0.; s.pt[DL_PT_FAC + mm] = 0.; s.pt[DL_PT_SD + mm] = 0.;
         for (int q = 0; q < 8; ++q) s.pt[DL_PT_OM + mm * 8 + q] = 0.;
-        for (int q = 0; q < 15; ++q) s.pt[DL_PT_W3 + mm * 15 + q] = 0.;
+        if (w3) for (int q = 0; q < 15; ++q) s.pt[DL_PT_W3 + mm * 15 + q] = 0.;
     }
     s.pt[DL_PT_QPAR] = c.qpar;
     s.pt[DL_PT_QPER] = c.qper;

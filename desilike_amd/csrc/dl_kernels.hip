@@ -21,8 +21,10 @@
 // ------------------------------------------------------------------------------------------------
 // The observable's constants travel BY VALUE in the kernarg segment: every pointer in it is then known to be a
 // global-memory pointer (global_load, not flat_load) and every scalar field is an SGPR, never re-read in a loop.
-template <bool FAST, int NL, bool EFT>
-__global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power,
+// DENSE (fast kernels without counter terms): 71 VGPRs and 31 KB of LDS, five workgroups per CU -- for batches that keep every CU oversubscribed (+9 % at 32768 points);
+// otherwise the two-wavenumber projection loop with 122 VGPRs, four workgroups per CU (shorter workgroup life: 14.0 vs 15.5 us per launch at 1024 points).
+template <bool FAST, int NL, bool EFT, bool DENSE = false>
+__global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power,
                                                                      int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
@@ -55,8 +57,8 @@ __global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_kernel(const Dl
         else dl_fs_knots(tid, KT, o, th, s);
         if (o.fixed_spline && mu_wave) {
             dl_fs_mu_partB(c);
-            if (mu_lane) dl_fs_mu_partC(o, s, m, c);
-            if (scalar_lane) dl_fs_scalars(o, th, s, c);
+            if (mu_lane) dl_fs_mu_partC(o, s, m, c, false);
+            if (scalar_lane) dl_fs_scalars(o, th, s, c, false);
         }
         __syncthreads();
         DL_STAMP(1)
@@ -68,8 +70,8 @@ __global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_kernel(const Dl
             DL_STAMP(2)
             if (stop_after == 2) return;
             if (mu_wave) {
-                if (mu_lane) dl_fs_mu_partC(o, s, m, c);
-                if (scalar_lane) dl_fs_scalars(o, th, s, c);
+                if (mu_lane) dl_fs_mu_partC(o, s, m, c, false);
+                if (scalar_lane) dl_fs_scalars(o, th, s, c, false);
             } else dl_fs_phase2d_toep(tid, KT, o, s, dlt_pref);
             __syncthreads();
             DL_STAMP(3)
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_kernel(const Dl
     }
     double* prow = power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset;
     double* trow = tables ? tables + (size_t)b * ld_tables : nullptr;
-    if (FAST && !EFT) dl_fs_phase3_pair<NL, EFT>(tid, nthr, o, s, lk_pref);   // (with counter terms the pair variant spills registers)
+    if (FAST && !EFT && !DENSE) dl_fs_phase3_pair<NL, EFT>(tid, nthr, o, s, lk_pref);   // (with counter terms the pair variant spills registers)
     else dl_fs_phase3<FAST, NL, EFT>(tid, nthr, o, s, trow, lk_pref);
     __syncthreads();
     DL_STAMP(4)
@@ -169,7 +171,9 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
             hipLaunchKernelGGL(dl_bao_kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power);
             continue;
         }
-        size_t shmem = dl_fs_shared_doubles_obs(obs_host[i]) * sizeof(double);
+        const DlObsDev& oh = obs_host[i];
+        const bool generic = tables || !oh.uniform_knots || !(oh.toeplitz || oh.fixed_spline);
+        size_t shmem = dl_fs_shared_doubles_obs(obs_host[i], !generic) * sizeof(double);
         auto launch = [&](auto kernel) {
             if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  // e.g. 2000-knot BAO tables
             hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shmem, stream, obs_host[i], theta, n_params, power, ld_power, tables, ld_tables, stop_after, stamps);
@@ -184,12 +188,11 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
                 }
             }
         };
-        const DlObsDev& oh = obs_host[i];
         bool nl3 = oh.n_ell <= 3, eft = oh.n_ct > 0 || oh.n_sn > 0;
-        if (tables || !oh.uniform_knots || !(oh.toeplitz || oh.fixed_spline)) launch(dl_fullshape_kernel<false, 5, true>);   // generic: run-time decisions
-        else if (nl3 && !eft) launch(dl_fullshape_kernel<true, 3, false>);
+        if (generic) launch(dl_fullshape_kernel<false, 5, true>);   // generic: run-time decisions
+        else if (nl3 && !eft) { if (B > 4096) launch(dl_fullshape_kernel<true, 3, false, true>); else launch(dl_fullshape_kernel<true, 3, false>); }
         else if (nl3) launch(dl_fullshape_kernel<true, 3, true>);
-        else if (!eft) launch(dl_fullshape_kernel<true, 5, false>);
+        else if (!eft) { if (B > 4096) launch(dl_fullshape_kernel<true, 5, false, true>); else launch(dl_fullshape_kernel<true, 5, false>); }
         else launch(dl_fullshape_kernel<true, 5, true>);
     }
 }
