@@ -304,6 +304,7 @@ void dl_launch_window_gemm(const double* A, int64_t lda, const double* Wt, int64
 //   (deterministic order, no atomics).
 // ------------------------------------------------------------------------------------------------
 #include "dl_gemm_tiled.h"
+#include "dl_gemm_dma.h"
 #include "dl_chi2_gemm.h"
 #include "dl_feature_gemm.h"
 
@@ -330,6 +331,15 @@ int dl_gemm_tiled_splits(int64_t M, int N_pad, int K_pad, int* chunks_per_split)
 
 void dl_launch_window_gemm_tiled(const double* A, int64_t lda, const double* Wt, int64_t ldw, double* slabs, int64_t slab_stride, int64_t ldc, int64_t M, int N_pad, int K_pad,
                                  int n_splits, int chunks_per_split, hipStream_t stream) {
+    static const bool use_dma = !(getenv("DL_GEMM_DMA") && atoi(getenv("DL_GEMM_DMA")) == 0);   // DL_GEMM_DMA=0: register-staged predecessor (diagnostics)
+    if (use_dma && chunks_per_split % 2 == 0 && K_pad % DL_GD_KP == 0) {
+        dim3 grid((unsigned)((M + DL_GD_M - 1) / DL_GD_M), (unsigned)(N_pad / DL_GD_N), (unsigned)n_splits);
+        static bool optin_dma = false;
+        if (!optin_dma) { (void)hipFuncSetAttribute((const void*)dl_window_gemm_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DL_GD_LDS_BYTES); optin_dma = true; }
+        hipLaunchKernelGGL(dl_window_gemm_dma_kernel, grid, dim3(64 * DL_GD_WAVES), DL_GD_LDS_BYTES, stream, A, lda, Wt, ldw, slabs, slab_stride, ldc, (int)M, chunks_per_split / 2,
+                           K_pad / DL_GD_KP);
+        return;
+    }
     dim3 grid((unsigned)((M + DL_GT_M - 1) / DL_GT_M), (unsigned)(N_pad / DL_GT_N), (unsigned)n_splits);
     static bool optin = false;
     if (!optin) { (void)hipFuncSetAttribute((const void*)dl_window_gemm_tiled_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_GT_LDS_BYTES); optin = true; }
