@@ -416,6 +416,11 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         }
         static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 2048;   // above: split-K slabs + finalize win (measured: 4096 rows 40 vs 49 us; 1024 rows 18 vs 13 us)
         const bool chi2_path = !feat_path && !ctx->any_transform && ctx->n_solved == 0 && nb <= chi2_max_rows;
+        // larger plain batches: the LDS-DMA split-K GEMM with the same partial-chi2 epilogue (no residual slab is written or read)
+        int cps_probe = 0;
+        const bool chi2_big = !feat_path && !ctx->any_transform && ctx->n_solved == 0 && !chi2_path && ctx->K_pad % 32 == 0 && !getenv("DL_NO_CHI2_BIG") &&
+                              dl_gemm_tiled_splits(nb, ctx->N_pad, ctx->K_pad, &cps_probe) == 1;   // enough row tiles to fill the chip without splitting K
+        int part_tiles = ctx->N_pad / 16;
         // DL_CHI2_FUSED=1: finalize inside the GEMM's last-arriving workgroups.  Off by default: measured 19.1 us (GEMM 17.1) against 17.5 us for GEMM + the
         // separate 1024-thread finalize launch -- the device-scope counter round trip and the dependent tail cost more than the launch they save.
         static const bool chi2_fused = getenv("DL_CHI2_FUSED") && atoi(getenv("DL_CHI2_FUSED")) != 0;
@@ -424,6 +429,9 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
             dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad,
                                 chi2_fused ? ctx->gemm_counters : nullptr, th, P, ctx->priors_dev, loglike_dev ? loglike_dev + b0 : nullptr,
                                 logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr, post_mode, stream);
+        } else if (chi2_big) {
+            dl_launch_window_gemm_dma_chi2(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad, stream);
+            part_tiles = dl_gemm_dma_chi2_parts(ctx->N_pad);
         } else if (feat_path) {
             // residual rows already in delta_ws (one slab, bias added by the finalize kernels)
         } else if (ctx->any_transform) {
@@ -441,8 +449,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
         if (chi2_path && chi2_fused) {
             // finalize fused into the GEMM
-        } else if (chi2_path)
-            dl_launch_finalize_part(ctx->delta_ws, ctx->N_pad / 16, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
+        } else if (chi2_path || chi2_big)
+            dl_launch_finalize_part(ctx->delta_ws, part_tiles, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
                                     status_dev ? status_dev + b0 : nullptr, post_mode, stream);
         else if (ctx->n_solved > 0)
             dl_launch_finalize_marg(ctx->delta_ws, ctx->N_pad, n, R, n_slabs, slab_stride, fin_bias, ctx->marg, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr,

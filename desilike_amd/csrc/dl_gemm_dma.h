@@ -26,9 +26,13 @@ typedef double dl_gd_double4 __attribute__((ext_vector_type(4)));
 #define DL_GD_VPT (DL_GD_PIECES / DL_GD_WAVES)        // pieces per wave and panel
 #define DL_GD_LDS_BYTES (DL_GD_NBUF * DL_GD_BUF * 8)
 
-// panels_per_split panels of K per blockIdx.z; n_panels = K_pad / 32
+// panels_per_split panels of K per blockIdx.z; n_panels = K_pad / 32.
+// CHI2 (single split only): instead of the residual slab, bias is added and the squares are summed over each wave's 16 DL_GD_TJ columns: part[M, N_pad / (16 TJ)]
+// partial chi2 per row, finished by dl_finalize_part_kernel (plain likelihood: the residual itself is never needed).
+template <bool CHI2>
 __global__ __launch_bounds__(64 * DL_GD_WAVES) void dl_window_gemm_dma_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
-                                                                 double* __restrict__ slabs, int64_t slab_stride, int64_t ldc, int M, int panels_per_split, int n_panels) {
+                                                                 double* __restrict__ slabs, int64_t slab_stride, int64_t ldc, int M, int panels_per_split, int n_panels,
+                                                                 const double* __restrict__ bias) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
@@ -95,6 +99,28 @@ __global__ __launch_bounds__(64 * DL_GD_WAVES) void dl_window_gemm_dma_kernel(co
     DL_GD_MULTIPLY(p)
 #undef DL_GD_DMA
 #undef DL_GD_MULTIPLY
+    if (CHI2) {
+        const int n_parts = (int)(gridDim.y * DL_GD_WN);
+        double bj[DL_GD_TJ];
+#pragma unroll
+        for (int j = 0; j < DL_GD_TJ; ++j) bj[j] = bias[n0 + wn * 16 * DL_GD_TJ + 16 * j + r16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double sq = 0.;
+#pragma unroll
+                for (int j = 0; j < DL_GD_TJ; ++j) { const double v = acc[i][j][r] + bj[j]; sq = fma(v, v, sq); }
+                // C layout: reg r of lane l = C[row (l >> 4) + 4 r][col l & 15]: sum the 16 lanes of a lane group
+                sq += __shfl_xor(sq, 1, 64);
+                sq += __shfl_xor(sq, 2, 64);
+                sq += __shfl_xor(sq, 4, 64);
+                sq += __shfl_xor(sq, 8, 64);
+                const int row = m0 + wm * 32 + 16 * i + g + 4 * r;
+                if (r16 == 0 && row < M) slabs[(size_t)row * n_parts + blockIdx.y * DL_GD_WN + wn] = sq;
+            }
+        return;
+    }
     double* out = slabs + (size_t)split * slab_stride;
 #pragma unroll
     for (int i = 0; i < 2; ++i)

@@ -51,3 +51,6 @@ void dl_launch_finalize_part(const double* part, int n_tiles, const double* thet
 // gfrag = the whitened folded operator of the observable in fragment order [N_pad / 16][nb_pad / 8][19][64][2]
 void dl_launch_feature_gemm(const double* feat, int64_t feat_ld, int64_t feat_off, int nb_pad, int R, const double* gfrag, double* out, int64_t ldo, int N_pad, int64_t B,
                             int accumulate, hipStream_t stream);
+// large plain-likelihood batches: LDS-DMA split-K GEMM (one split) with the partial-chi2 epilogue (dl_gemm_dma.h), finished by dl_launch_finalize_part
+int dl_gemm_dma_chi2_parts(int N_pad);
+void dl_launch_window_gemm_dma_chi2(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, hipStream_t stream);

@@ -335,15 +335,29 @@ void dl_launch_window_gemm_tiled(const double* A, int64_t lda, const double* Wt,
     if (use_dma && chunks_per_split % 2 == 0 && K_pad % DL_GD_KP == 0) {
         dim3 grid((unsigned)((M + DL_GD_M - 1) / DL_GD_M), (unsigned)(N_pad / DL_GD_N), (unsigned)n_splits);
         static bool optin_dma = false;
-        if (!optin_dma) { (void)hipFuncSetAttribute((const void*)dl_window_gemm_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DL_GD_LDS_BYTES); optin_dma = true; }
-        hipLaunchKernelGGL(dl_window_gemm_dma_kernel, grid, dim3(64 * DL_GD_WAVES), DL_GD_LDS_BYTES, stream, A, lda, Wt, ldw, slabs, slab_stride, ldc, (int)M, chunks_per_split / 2,
-                           K_pad / DL_GD_KP);
+        if (!optin_dma) {
+            (void)hipFuncSetAttribute((const void*)dl_window_gemm_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_GD_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)dl_window_gemm_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_GD_LDS_BYTES);
+            optin_dma = true;
+        }
+        hipLaunchKernelGGL(dl_window_gemm_dma_kernel<false>, grid, dim3(64 * DL_GD_WAVES), DL_GD_LDS_BYTES, stream, A, lda, Wt, ldw, slabs, slab_stride, ldc, (int)M,
+                           chunks_per_split / 2, K_pad / DL_GD_KP, nullptr);
         return;
     }
     dim3 grid((unsigned)((M + DL_GT_M - 1) / DL_GT_M), (unsigned)(N_pad / DL_GT_N), (unsigned)n_splits);
     static bool optin = false;
     if (!optin) { (void)hipFuncSetAttribute((const void*)dl_window_gemm_tiled_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_GT_LDS_BYTES); optin = true; }
     hipLaunchKernelGGL((dl_window_gemm_tiled_kernel<true, true, true>), grid, dim3(512), DL_GT_LDS_BYTES, stream, A, lda, Wt, ldw, slabs, slab_stride, ldc, (int)M, chunks_per_split, K_pad / DL_GT_K);
+}
+
+// split-K GEMM (single split) with the partial-chi2 epilogue: part[M, dl_gemm_dma_chi2_parts(N_pad)]
+int dl_gemm_dma_chi2_parts(int N_pad) { return N_pad / (16 * DL_GD_TJ); }
+void dl_launch_window_gemm_dma_chi2(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, hipStream_t stream) {
+    dim3 grid((unsigned)((M + DL_GD_M - 1) / DL_GD_M), (unsigned)(N_pad / DL_GD_N), 1);
+    static bool optin = false;
+    if (!optin) { (void)hipFuncSetAttribute((const void*)dl_window_gemm_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_GD_LDS_BYTES); optin = true; }
+    hipLaunchKernelGGL(dl_window_gemm_dma_kernel<true>, grid, dim3(64 * DL_GD_WAVES), DL_GD_LDS_BYTES, stream, A, lda, Wt, ldw, part, (int64_t)0, (int64_t)0, (int)M, K_pad / DL_GD_KP,
+                       K_pad / DL_GD_KP, bias);
 }
 
 // ------------------------------------------------------------------------------------------------
