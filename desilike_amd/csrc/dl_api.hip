@@ -393,7 +393,9 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         bool need_flat = ctx->any_transform || flattheory_dev != nullptr;
         // emulated (separable) theories: the theory kernel writes only the factors (basis, monomial rows), the feature GEMM turns them into residual rows
         const bool feat_path = ctx->feat_ok && !need_flat;
-        dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, feat_path ? ctx->feat_ws : nullptr, ctx->feat_ld);
+        static const bool emu_fused = !getenv("DL_NO_EMU_FUSED");   // DL_NO_EMU_FUSED=1: theory kernel -> point records in HBM -> feature GEMM (two launches)
+        if (!(feat_path && emu_fused))
+            dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, feat_path ? ctx->feat_ws : nullptr, ctx->feat_ld);
         if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[1], stream));
         int n_slabs = 1, cps = 0;
         int64_t slab_stride = 0;
@@ -409,9 +411,11 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         }
         // plain likelihood: chi2 is additive over the columns of the whitened residual -> column-split GEMM that emits partial chi2 only
         if (feat_path) {
-            for (int i = 0; i < ctx->n_obs; ++i)
-                dl_launch_feature_gemm(ctx->feat_ws, ctx->feat_ld, ctx->obs_kernarg[i].feat_off, ctx->obs_kernarg[i].nb_pad, R, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, nb,
-                                       i > 0, stream);
+            for (int i = 0; i < ctx->n_obs; ++i) {
+                if (emu_fused) dl_launch_emulated_feature(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, stream);
+                else dl_launch_feature_gemm(ctx->feat_ws, ctx->feat_ld, ctx->obs_kernarg[i].feat_off, ctx->obs_kernarg[i].nb_pad, R, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad,
+                                            ctx->N_pad, nb, i > 0, stream);
+            }
             fin_bias = ctx->bias_white_dev;
         }
         static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 2048;   // above: split-K slabs + finalize win (measured: 4096 rows 40 vs 49 us; 1024 rows 18 vs 13 us)

@@ -6,6 +6,7 @@
 // the reference fixture (tests/test_gpu_emulator.py), like the feature GEMM.
 #pragma once
 #include "dl_fullshape.h"
+#include "dl_feature_gemm.h"
 
 typedef double dl_eb_double4 __attribute__((ext_vector_type(4)));
 
@@ -26,9 +27,11 @@ static inline __host__ __device__ size_t dl_eb_shared_doubles(const DlObsDev& o)
 }
 
 #if defined(__HIPCC__)
-__global__ __launch_bounds__(256) void dl_emulated_batch_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, int64_t B, double* __restrict__ feat,
-                                                                int64_t feat_ld) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+// forward pass of 16 points with NTHR threads; the point records (basis [nb_pad] | monomial rows [(1 + n_var)][20]) go to rec[pt * rec_stride + c]
+// (LDS, fused kernel) or, if rec == nullptr, to the feature buffer in global memory.  `lds`: dl_eb_shared_doubles(o) doubles of workspace.
+template <int NTHR, bool TO_LDS>
+__device__ __forceinline__ void dl_eb_forward(const DlObsDev& o, const double* __restrict__ theta, int n_params, int64_t B, int64_t p0, double* lds, double* rec, int rec_stride,
+                                              double* __restrict__ feat, int64_t feat_ld) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
     const int LD = dl_eb_ld(o);
@@ -37,8 +40,7 @@ __global__ __launch_bounds__(256) void dl_emulated_batch_kernel(const DlObsDev o
     double* buf1 = buf0 + DL_EB_PTS * LD;                 // [16][LD]
     double* scal = buf1 + DL_EB_PTS * LD;                 // [16][4]: sigma8 (1), fsigma8 (2)
     double* mono = scal + DL_EB_PTS * 4;                  // [16][(1 + n_var) * 19]
-    const int64_t p0 = (int64_t)blockIdx.x * DL_EB_PTS;
-    for (int idx = tid; idx < DL_EB_PTS * o.n_x; idx += 256) {
+    for (int idx = tid; idx < DL_EB_PTS * o.n_x; idx += NTHR) {
         int pt = idx / o.n_x, i = idx - pt * o.n_x;
         int64_t b = p0 + pt < B ? p0 + pt : B - 1;
         x[pt * DL_MAX_X + i] = dl_get(o.x_in[i], theta + (size_t)b * n_params);
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void dl_emulated_batch_kernel(const DlObsDev o
         if (e.type == 0) {
             // scaled inputs (conversion.py:75-77), zero-padded to a multiple of 4 columns
             const int nin0 = (o.n_x + 3) & ~3;
-            for (int idx = tid; idx < DL_EB_PTS * nin0; idx += 256) {
+            for (int idx = tid; idx < DL_EB_PTS * nin0; idx += NTHR) {
                 int pt = idx / nin0, i = idx - pt * nin0;
                 cur[pt * LD + i] = i < o.n_x ? (x[pt * DL_MAX_X + i] - e.xlo[i]) * e.xinv[i] : 0.;
             }
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void dl_emulated_batch_kernel(const DlObsDev o
                 const bool last = (layer == e.n_layers - 1);
                 const bool activate = !(last && ie != 0);   // the table engine stops after its last HIDDEN layer (its final linear layer is folded on the host)
                 const int ksteps = (nin + 3) / 4, tiles = (nout + 15) / 16, nout4 = (nout + 3) & ~3;
-                for (int t = wave; t < tiles; t += 4) {
+                for (int t = wave; t < tiles; t += NTHR / 64) {
                     const int oc = 16 * t + col;
                     dl_eb_double4 acc = {0., 0., 0., 0.};
                     for (int ks0 = 0; ks0 < ksteps; ks0 += 8) {   // eight k-steps of weight loads in flight (each is an L2 round trip otherwise)
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void dl_emulated_batch_kernel(const DlObsDev o
             __syncthreads();
         } else {
             // Taylor: monomials prod_p (x_p - c_p)^powers[t, p] (emulators/__init__.py:471-507)
-            for (int idx = tid; idx < DL_EB_PTS * e.n_terms; idx += 256) {
+            for (int idx = tid; idx < DL_EB_PTS * e.n_terms; idx += NTHR) {
                 int pt = idx / e.n_terms, t = idx - pt * e.n_terms;
                 double mon = 1.;
                 for (int p = 0; p < o.n_x; ++p) mon *= dl_ipow(x[pt * DL_MAX_X + p] - e.center[p], (int)e.powers[(size_t)t * o.n_x + p]);
@@ -127,13 +129,37 @@ __global__ __launch_bounds__(256) void dl_emulated_batch_kernel(const DlObsDev o
     __syncthreads();
     // point records of the feature GEMM: basis [nb_pad] | monomial rows [(1 + n_var)][20]
     const int rec_len = o.nb_pad + (1 + o.n_var) * 20;
-    for (int idx = tid; idx < DL_EB_PTS * rec_len; idx += 256) {
+    for (int idx = tid; idx < DL_EB_PTS * rec_len; idx += NTHR) {
         int pt = idx / rec_len, c = idx - pt * rec_len;
-        if (p0 + pt >= B) continue;
         double v;
         if (c < o.nb_pad) v = c < o.n_basis ? basis[pt * LD + c] : 0.;
         else { int q = c - o.nb_pad, r = q / 20, m = q - r * 20; v = m < DL_N_MONO ? mono[((size_t)pt * (1 + o.n_var) + r) * DL_N_MONO + m] : 0.; }
-        feat[(size_t)(p0 + pt) * feat_ld + o.feat_off + c] = v;
+        if (TO_LDS) rec[pt * rec_stride + c] = v;
+        else if (p0 + pt < B) feat[(size_t)(p0 + pt) * feat_ld + o.feat_off + c] = v;
     }
+}
+
+// records to the feature buffer (the feature GEMM follows as a separate launch)
+__global__ __launch_bounds__(256) void dl_emulated_batch_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, int64_t B, double* __restrict__ feat,
+                                                                int64_t feat_ld) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    dl_eb_forward<256, false>(o, theta, n_params, B, (int64_t)blockIdx.x * DL_EB_PTS, lds, lds, 0, feat, feat_ld);
+}
+
+// FUSED: theta -> emulator forward (MFMA) -> point records in LDS -> feature GEMM -> residual rows: the records never leave the CU and one launch
+// (ramp, completion, cold hand-over) disappears.  LDS: forward workspace, then the 16 records.
+static inline __host__ __device__ size_t dl_ef_shared_doubles(const DlObsDev& o) {
+    return (dl_eb_shared_doubles(o) + 1) / 2 * 2 + (size_t)DL_FG_PTS * dl_fg_lds_stride(o.nb_pad + (1 + o.n_var) * DL_FG_MONO_LD);
+}
+__global__ __launch_bounds__(512) void dl_emulated_feature_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ gfrag,
+                                                                  double* __restrict__ out, int64_t ldo, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int64_t p0 = (int64_t)blockIdx.x * DL_EB_PTS;
+    const int R = 1 + o.n_var;
+    const int stride = dl_fg_lds_stride(o.nb_pad + R * DL_FG_MONO_LD);
+    double* rec = lds + (dl_eb_shared_doubles(o) + 1) / 2 * 2;
+    dl_eb_forward<512, true>(o, theta, n_params, B, p0, lds, rec, stride, out, 0);
+    __syncthreads();
+    dl_fg_compute(rec, stride, o.nb_pad, R, gfrag, out, ldo, B, p0, accumulate);
 }
 #endif

@@ -29,24 +29,13 @@ typedef double dl_fg_double4 __attribute__((ext_vector_type(4)));
 // LDS row stride (doubles) of a point record: >= rec_len, = 2 mod 32 (the 16 points of an operand read then hit distinct banks, rows stay 16-byte aligned)
 static inline __host__ __device__ int dl_fg_lds_stride(int rec_len) { return (rec_len + 31) / 32 * 32 + 2; }
 
-// feat: [B, feat_ld] point records, this observable's record at column feat_off: basis [nb_pad] then mono [R][DL_FG_MONO_LD]
-// gfrag: [N_pad / 16][nb_pad / 8][19][64][2]; out: [B * R, ldo] (+= if accumulate)
-__global__ __launch_bounds__(512) void dl_feature_gemm_kernel(const double* __restrict__ feat, int64_t feat_ld, int64_t feat_off, int nb_pad, int R,
-                                                              const double* __restrict__ gfrag, double* __restrict__ out, int64_t ldo, int64_t B, int accumulate) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+// the product and the epilogue, from 16 point records already in LDS (row stride `stride` doubles: basis [nb_pad] then mono [R][DL_FG_MONO_LD]);
+// gfrag: [N_pad / 16][nb_pad / 8][19][64][2]; out: [B * R, ldo] (+= if accumulate); 512 threads, blockIdx.y = group of 8 column blocks
+__device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int nb_pad, int R, const double* __restrict__ gfrag, double* __restrict__ out, int64_t ldo,
+                                              int64_t B, int64_t p0, int accumulate) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
-    const int64_t p0 = (int64_t)blockIdx.x * DL_FG_PTS;
     const int jb = blockIdx.y * 8 + wave;               // 16-column block of this wave
-    const int rec_len = nb_pad + R * DL_FG_MONO_LD;
-    const int stride = dl_fg_lds_stride(rec_len);
-    // stage the 16 point records (rows beyond B repeat the last point; their outputs are not stored)
-    for (int idx = tid; idx < DL_FG_PTS * rec_len; idx += 512) {
-        int pt = idx / rec_len, c = idx - pt * rec_len;
-        int64_t b = p0 + pt < B ? p0 + pt : B - 1;
-        lds[pt * stride + c] = feat[(size_t)b * feat_ld + feat_off + c];
-    }
-    __syncthreads();
     const int nq = nb_pad / 8;
     const dl_fg_double2* gw = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * nq * DL_FG_NM * 64 + lane;
     const double* arow = lds + col * stride + 2 * g;                 // A operand of lane (point = col index of the lane, k group g)
@@ -111,4 +100,22 @@ __global__ __launch_bounds__(512) void dl_feature_gemm_kernel(const double* __re
             }
         }
     }
+}
+
+// feat: [B, feat_ld] point records written by the theory kernel, this observable's record at column feat_off
+__global__ __launch_bounds__(512) void dl_feature_gemm_kernel(const double* __restrict__ feat, int64_t feat_ld, int64_t feat_off, int nb_pad, int R,
+                                                              const double* __restrict__ gfrag, double* __restrict__ out, int64_t ldo, int64_t B, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.x * DL_FG_PTS;
+    const int rec_len = nb_pad + R * DL_FG_MONO_LD;
+    const int stride = dl_fg_lds_stride(rec_len);
+    // stage the 16 point records (rows beyond B repeat the last point; their outputs are not stored)
+    for (int idx = tid; idx < DL_FG_PTS * rec_len; idx += 512) {
+        int pt = idx / rec_len, c = idx - pt * rec_len;
+        int64_t b = p0 + pt < B ? p0 + pt : B - 1;
+        lds[pt * stride + c] = feat[(size_t)b * feat_ld + feat_off + c];
+    }
+    __syncthreads();
+    dl_fg_compute(lds, stride, nb_pad, R, gfrag, out, ldo, B, p0, accumulate);
 }

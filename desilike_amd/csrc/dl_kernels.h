@@ -54,3 +54,6 @@ void dl_launch_feature_gemm(const double* feat, int64_t feat_ld, int64_t feat_of
 // large plain-likelihood batches: LDS-DMA split-K GEMM (one split) with the partial-chi2 epilogue (dl_gemm_dma.h), finished by dl_launch_finalize_part
 int dl_gemm_dma_chi2_parts(int N_pad);
 void dl_launch_window_gemm_dma_chi2(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, hipStream_t stream);
+// emulated theories, fused: emulator forward pass (MFMA) and feature GEMM of one observable in one launch (dl_emu_batch.h)
+void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
+                                hipStream_t stream);

@@ -468,6 +468,15 @@ void dl_launch_feature_gemm(const double* feat, int64_t feat_ld, int64_t feat_of
                        gfrag, out, ldo, B, accumulate);
 }
 
+// fused emulator forward + feature GEMM (dl_emu_batch.h): theta -> residual rows of one observable in one launch
+void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
+                                hipStream_t stream) {
+    const size_t shm = dl_ef_shared_doubles(obs) * sizeof(double);
+    if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_emulated_feature_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(dl_emulated_feature_kernel, dim3((unsigned)((B + DL_EB_PTS - 1) / DL_EB_PTS), (unsigned)(N_pad / 128)), dim3(512), shm, stream, obs, theta, n_params, B, gfrag,
+                       out, ldo, accumulate);
+}
+
 // ------------------------------------------------------------------------------------------------
 // chi2 GEMM path (plain likelihood): partial chi2 per (point, 16-column block) from dl_chi2_gemm_kernel, then one THREAD per point
 // sums them in a fixed order and adds the priors (same status logic as dl_finalize_kernel).
