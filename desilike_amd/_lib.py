@@ -32,6 +32,9 @@ SYMBOLS = {
     'dl_eval_theory_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, ctypes.c_int32, _c_double_p, _c_double_p]),
     'dl_profile_enable': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'dl_profile_read': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int32]),
+    'dl_fftlog_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_double_p, _c_double_p, _c_double_p]),
+    'dl_fftlog_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_fftlog_destroy': (None, [ctypes.c_void_p]),
 }
 
 
@@ -253,3 +256,42 @@ class Context(object):
         ms = np.zeros(5, dtype='f8')
         self._check(self._lib.dl_profile_read(self._handle, _f64_ptr(ms), 5))
         return dict(theory=ms[0], window_gemm=ms[1], finalize=ms[2], total=ms[3], event_overhead=ms[4])
+
+
+class FFTLogPlan(object):
+    """Owner of one ``dl_fftlog`` plan (include/desilike_amd.h): batched FFTLog Hankel transform of ``fun [B, n_ell, n]`` on one GPU."""
+
+    def __init__(self, n, npad, pre, u, post, device=0):
+        lib = load()
+        pre = np.ascontiguousarray(pre, dtype='f8')
+        u = np.ascontiguousarray(u, dtype='f8')          # [n_ell, npad // 2 + 1, 2]
+        post = np.ascontiguousarray(post, dtype='f8')    # [n_ell, n]
+        self.n, self.npad, self.n_ell, self.device = int(n), int(npad), int(post.shape[0]), int(device)
+        if pre.shape != (self.n,) or u.shape != (self.n_ell, self.npad // 2 + 1, 2) or post.shape != (self.n_ell, self.n):
+            raise ValueError('inconsistent FFTLog plan arrays: pre {}, u {}, post {}'.format(pre.shape, u.shape, post.shape))
+        handle = ctypes.c_void_p()
+        if lib.dl_fftlog_create(ctypes.byref(handle), self.device, self.n, self.npad, self.n_ell, _f64_ptr(pre), _f64_ptr(u), _f64_ptr(post)) != 0:
+            raise LibraryError(lib.dl_last_error(None).decode())
+        self._lib, self._handle = lib, handle
+
+    def apply(self, fun, out=None, stream=None):
+        """``fun``: contiguous float64 CUDA(ROCm) tensor [B, n_ell, n] on this plan's device; returns ``out`` (allocated if None); asynchronous on ``stream``."""
+        import torch
+        assert fun.is_cuda and fun.is_contiguous() and fun.dtype == torch.float64 and tuple(fun.shape[1:]) == (self.n_ell, self.n), fun.shape
+        if out is None: out = torch.empty_like(fun)
+        assert out.is_contiguous() and out.dtype == torch.float64 and out.shape == fun.shape and out.device == fun.device
+        if stream is None: stream = torch.cuda.current_stream(fun.device).cuda_stream
+        if self._lib.dl_fftlog_apply(self._handle, ctypes.c_void_p(fun.data_ptr()), fun.shape[0], ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)) != 0:
+            raise LibraryError(self._lib.dl_last_error(None).decode())
+        return out
+
+    def close(self):
+        if getattr(self, '_handle', None):
+            self._lib.dl_fftlog_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -12,6 +12,7 @@
 #include "dl_kernels.h"
 
 static thread_local std::string g_last_error;
+void dl_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 
 struct dl_ctx {
     int device = 0;

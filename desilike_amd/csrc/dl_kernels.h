@@ -57,3 +57,5 @@ void dl_launch_window_gemm_dma_chi2(const double* A, int64_t lda, const double* 
 // emulated theories, fused: emulator forward pass (MFMA) and feature GEMM of one observable in one launch (dl_emu_batch.h)
 void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
                                 hipStream_t stream);
+// last-error string of the C ABI (thread-local, read by dl_last_error(NULL)); set by translation units other than dl_api.hip
+void dl_set_last_error(const char* msg);

@@ -12,6 +12,12 @@ Because every step of the reference's ``get_corr`` (theories/galaxy_clustering/b
 the FFTLog grid, linear-in-log high-k tail with Gaussian damping, FFTLog, linear interpolation to the data separations) is LINEAR in
 P_\ell(k_in), the whole map is one constant matrix per multipole (``hankel_operator``) which the GPU path folds into the window matrix:
 the FFT never runs in the hot loop.
+
+Two engines share the grid constants computed here (Mellin coefficients, low-ringing offset, pre / post factors):
+``engine='hip'`` runs the batched LDS-resident transform of the C ABI (``dl_fftlog_*``, csrc/dl_fftlog.hip: one workgroup per (point, multipole)) --
+this is what the theory classes use to build their operator (all unit vectors of the input grid in ONE batch) and what transforms batches of
+P_ell already resident on the GPU; ``engine='numpy'`` (``numpy.fft``) is the host restatement of the same algorithm kept for the CPU checks
+(tests/test_oracle_bao.py) -- it is never a fallback: ``engine='hip'`` raises without the library or a GPU.
 """
 import numpy as np
 from scipy import special
@@ -44,7 +50,10 @@ class PowerToCorrelation(object):
     ``k`` must be log-spaced; the input is zero-padded to ``minfolds * N`` points (half on each side) before the transform.
     """
 
-    def __init__(self, k, ell=0, q=0, lowring=True, minfolds=2):
+    def __init__(self, k, ell=0, q=0, lowring=True, minfolds=2, engine='numpy', device=None):
+        if engine not in ('numpy', 'hip'):
+            raise ValueError('engine must be "numpy" or "hip"')
+        self.engine, self.device, self._plan = engine, device, None
         self.k = np.asarray(k, dtype='f8')
         self.ells = np.atleast_1d(ell)
         if q != 0:
@@ -66,7 +75,33 @@ class PowerToCorrelation(object):
             self.s.append(np.exp(offset) / self.kpad[::-1])
         self.prefactor = [(-1.)**(ell // 2) / (2. * np.pi)**1.5 for ell in self.ells]
 
+    def _get_plan(self):
+        """Device plan (``dl_fftlog_create``): uploads k^{3/2}, u_ell and prefactor * s^{-3/2} once."""
+        if self._plan is None:
+            import os
+            from ._lib import FFTLogPlan
+            device = self.device
+            if device is None: device = int(os.environ.get('LOCAL_RANK', 0))
+            sl = slice(self.pad, self.pad + self.k.size)
+            u = np.array([np.column_stack([u.real, u.imag]) for u in self.u], dtype='f8')
+            post = np.array([prefactor * s[sl]**(-1.5) for prefactor, s in zip(self.prefactor, self.s)], dtype='f8')
+            self._plan = FFTLogPlan(self.k.size, self.npad, self.k**1.5, u, post, device=device)
+        return self._plan
+
+    def apply_device(self, fun, out=None, stream=None):
+        """``fun [B, n_ell, N]`` CUDA(ROCm) torch tensor -> ``xi [B, n_ell, N]`` on the same device, asynchronous on ``stream`` (no host round trip)."""
+        return self._get_plan().apply(fun, out=out, stream=stream)
+
     def __call__(self, fun):
+        if self.engine == 'hip':
+            import torch
+            plan = self._get_plan()
+            fun = np.asarray(fun, dtype='f8')
+            shape = fun.shape
+            fun = fun.reshape((-1,) + (len(self.ells), self.k.size))
+            xi = plan.apply(torch.as_tensor(fun, dtype=torch.float64, device=torch.device('cuda', plan.device)).contiguous()).cpu().numpy()
+            sl = slice(self.pad, self.pad + self.k.size)
+            return np.array([s[sl] for s in self.s]), xi.reshape(shape)
         fun = np.atleast_2d(np.asarray(fun, dtype='f8'))
         s, xi = [], []
         for ill in range(len(self.ells)):
@@ -91,16 +126,34 @@ def correlation_from_power(power, kin, k, logk_high, damp_high, kmask_mid, fftlo
     return np.array([np.interp(s, sss, cc) for sss, cc in zip(ss, corr)])
 
 
-def hankel_operator(kin, s, ells, k=None):
+def hankel_operator(kin, s, ells, k=None, engine='numpy', device=None):
     r"""Matrices H_\ell [len(s), len(kin)] with \xi_\ell(s) = H_\ell P_\ell(k_in), reproducing the reference's ``get_corr`` grids
-    (theories/galaxy_clustering/base.py:62-77: k = logspace(-4, 3, 2048), tail beyond kin[-1])."""
+    (theories/galaxy_clustering/base.py:62-77: k = logspace(-4, 3, 2048), tail beyond kin[-1]).
+
+    ``engine='hip'``: the transforms of all len(kin) unit vectors run as ONE batch of the device FFTLog (``dl_fftlog_apply``)."""
     kin = np.asarray(kin, dtype='f8')
     if k is None: k = np.logspace(-4., 3., 2048)
     mask = k > kin[-1]
     logk_high = np.log10(k[mask] / kin[-1])
     damp_high = np.exp(-(k[mask] / kin[-1] - 1.)**2 / (2. * (10.)**2))
-    fftlog = PowerToCorrelation(k, ell=ells, q=0, lowring=True)
+    fftlog = PowerToCorrelation(k, ell=ells, q=0, lowring=True, engine=engine, device=device)
     nell = len(ells)
+    if engine == 'hip':
+        # interpolation + tail of every unit vector (the same for all multipoles), then one batched transform, then the interpolation to s
+        logkin, logk_mid = np.log10(kin), np.log10(k[~mask])
+        unit = np.zeros(kin.size, dtype='f8')
+        tmp = np.empty((kin.size, k.size), dtype='f8')
+        for i in range(kin.size):
+            unit[i] = 1.
+            slope_high = (unit[-1] - unit[-2]) / np.log10(kin[-1] / kin[-2])
+            tmp[i] = np.concatenate([np.interp(logk_mid, logkin, unit), (unit[-1] + slope_high * logk_high) * damp_high])
+            unit[i] = 0.
+        ss, corr = fftlog(np.repeat(tmp[:, None, :], nell, axis=1))     # corr [n_kin, n_ell, N]
+        H = np.empty((nell, len(s), kin.size), dtype='f8')
+        for ill in range(nell):
+            for i in range(kin.size):
+                H[ill, :, i] = np.interp(s, ss[ill], corr[i, ill])
+        return H
     H = np.zeros((nell, len(s), kin.size), dtype='f8')
     basis = np.zeros((nell, kin.size), dtype='f8')
     for i in range(kin.size):

@@ -136,8 +136,6 @@ class DampedBAOWigglesTracerCorrelationFunctionMultipoles(_BaseDampedBAOTracer):
     def initialize(self):
         if self._initialized:
             return self
-        from ...fftlog import hankel_operator
-        from scipy import linalg
         s = self.init.get('s', None)
         if s is None: s = np.linspace(20., 200, 101)
         self.s = np.array(s, dtype='f8')
@@ -151,10 +149,22 @@ class DampedBAOWigglesTracerCorrelationFunctionMultipoles(_BaseDampedBAOTracer):
         sp = self.init.get('sp', None)
         self.sp = 2. * np.pi / 0.02 if sp is None else float(sp)   # bao.py:855
         self._broadband_names, self.broadband_matrix = self._broadband_matrix(self.s, self.sp)
-        self.hankel = hankel_operator(self.kin, self.s, self.ells, k=kfft)
-        self._hankel_block = linalg.block_diag(*self.hankel)
+        self._kfft, self._hankel = kfft, None
         self._initialized = True
         return self
+
+    @property
+    def hankel(self):
+        """Hankel operators H_ell [n_s, n_kin], built at first use by ONE batch of the device FFTLog (``dl_fftlog_apply``: all unit vectors of the input grid)."""
+        if self._hankel is None:
+            from ...fftlog import hankel_operator
+            self._hankel = hankel_operator(self.kin, self.s, self.ells, k=self._kfft, engine='hip')
+        return self._hankel
+
+    @property
+    def _hankel_block(self):
+        from scipy import linalg
+        return linalg.block_diag(*self.hankel)
 
     def _fold(self):
         return np.hstack([self._hankel_block, self.broadband_matrix])

@@ -153,6 +153,18 @@ int  dl_eval_theory_host(dl_ctx* ctx, const double* theta, int64_t B, int32_t io
 int  dl_profile_enable(dl_ctx* ctx, int enable);
 int  dl_profile_read(dl_ctx* ctx, double* ms, int32_t n);
 
+/* ---- FFTLog Hankel transform (row a11) --------------------------------------------------------
+ * Batched device version of the reference's third-party ``cosmoprimo.PowerToCorrelation(k, ell, q=0, lowring=True)`` (call sites
+ * theories/galaxy_clustering/base.py:76-77, 135; used by get_corr 127-136): for every (point, multipole)
+ *     out = post_ell * reverse(irfft(rfft(zero-pad(fun * pre)) * u_ell))   restricted to the n un-padded points.
+ * The grid constants are computed by the host (desilike_amd/fftlog.py: pre[n] = k^{3/2}; u[n_ell, npad/2 + 1, 2] = Mellin coefficients (re, im) with the
+ * low-ringing offset; post[n_ell, n] = (-1)^{ell/2} (2 pi)^{-3/2} s^{-3/2}); npad = power of two in [16, 8192], zero padding (npad - n) / 2 in front.
+ * dl_fftlog_apply: fun_dev, out_dev [B, n_ell, n] device arrays, asynchronous on ``hip_stream``.  Errors: non-zero, message via dl_last_error(NULL). */
+typedef struct dl_fftlog dl_fftlog;
+int  dl_fftlog_create(dl_fftlog** out, int device, int32_t n, int32_t npad, int32_t n_ell, const double* pre, const double* u, const double* post);
+int  dl_fftlog_apply(dl_fftlog* plan, const double* fun_dev, int64_t B, double* out_dev, void* hip_stream);
+void dl_fftlog_destroy(dl_fftlog* plan);
+
 #ifdef __cplusplus
 }
 #endif

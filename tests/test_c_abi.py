@@ -46,3 +46,8 @@ def test_config_store_and_errors_without_gpu():
     assert lib.dl_eval_batch(None, None, 1, None, None, None, None, None, None) != 0
     assert lib.dl_eval_logposterior(None, None, 1, None, None, None) != 0
     assert lib.dl_info(None, b'n_params') == -1
+    assert lib.dl_fftlog_apply(None, None, 1, None, None) != 0
+    if not torch.cuda.is_available():   # no GPU: the FFTLog plan cannot be created either (no host fallback behind the ABI)
+        from desilike_amd.fftlog import PowerToCorrelation
+        with pytest.raises(_lib.LibraryError):
+            PowerToCorrelation(np.logspace(-3., 1., 64), ell=(0,), engine='hip', device=0)(np.ones((1, 64)))

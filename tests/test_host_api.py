@@ -126,7 +126,7 @@ def make_cfg4(space='xi', data=None):
     return g, ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
 
 
-@pytest.mark.parametrize('space', ['xi', 'pk'])
+@pytest.mark.parametrize('space', [pytest.param('xi', marks=pytest.mark.gpu), 'pk'])   # 'xi': the theory builds its Hankel operator with the device FFTLog
 def test_bao_spec_matches_reference_constants(space):
     from golden_utils import spec_from_golden_bao
     g, like = make_cfg4(space)
@@ -139,7 +139,8 @@ def test_bao_spec_matches_reference_constants(space):
     # broadband columns may be ordered differently: compare the window matrix column by parameter name
     names, rnames = like.varied_params.names(), [str(n) for n in g['names']]
     n_in = len(o['kin']) * len(o['ells_in'])
-    assert np.allclose(o['wmatrix'][:, :n_in], r['wmatrix'][:, :n_in], rtol=1e-12, atol=1e-14 * np.abs(r['wmatrix']).max())
+    # 'xi': device-built Hankel operator vs host-built; entries far below the largest one carry the FFT's rounding noise
+    assert np.allclose(o['wmatrix'][:, :n_in], r['wmatrix'][:, :n_in], rtol=1e-12 if space == 'pk' else 1e-9, atol=(1e-14 if space == 'pk' else 1e-13) * np.abs(r['wmatrix']).max())
     pcols, rpcols = o['inputs']['pass'][0], r['inputs']['pass'][0]
     for ic, col in enumerate(pcols):
         jc = [rnames[c] for c in rpcols].index(names[col])
