@@ -37,8 +37,13 @@ class BaseLikelihood(BaseCalculator):
 
     @property
     def solved_params(self):
-        """Parameters solved analytically ('.marg', '.best', '.auto'): likelihoods/base.py:262-271."""
-        return ParameterCollection([param for param in self.all_params if param.solved])
+        """Parameters solved analytically at every point ('.marg', '.best', '.auto'): likelihoods/base.py:262-271."""
+        return ParameterCollection([param for param in self.all_params if param.solved and not param.derived.startswith('.prec')])
+
+    @property
+    def prec_params(self):
+        """Parameters marginalised ONCE into the precision matrix ('.prec'): likelihoods/base.py:262-267."""
+        return ParameterCollection([param for param in self.all_params if param.solved and param.derived.startswith('.prec')])
 
     # ---- evaluation -------------------------------------------------------------------------------
     def __call__(self, *args, return_derived=False, **kwargs):
@@ -180,6 +185,7 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             self.precision = self.precision_hartlap2007 / self.percival2014_factor
         self._contexts = {}
         self._flatdata = None
+        self._precision_input = self.precision
         self._initialized = True
         self._generate_data()
         return self
@@ -252,8 +258,6 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             kind, mprior, x0 = [], [], []
             for param in solved:
                 derived = param.derived
-                if derived.startswith('.prec'):
-                    raise NotImplementedError("'.prec' (one-off precision marginalisation) is not implemented: use '.marg'")
                 if derived.startswith('.auto'):
                     derived = derived.replace('.auto', self.solved_default)                     # likelihoods/base.py:336-337
                 kind.append(1 if derived.startswith('.marg') else 0)
@@ -271,9 +275,53 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         if key not in self._contexts:
             if len(self._contexts) > 8:
                 self._contexts.pop(next(iter(self._contexts))).close()
-            flatdata = self._flatdata_list()
-            self._contexts[key] = Context(self._spec(fixed_values, flatdata, self.precision), device=self.device)
+            flatdata, precision = self._flatdata_list(), self._precision_input
+            if len(self.prec_params):
+                flatdata, precision = self._marginalize_precision(fixed_values, flatdata, precision)
+            self._contexts[key] = Context(self._spec(fixed_values, flatdata, precision), device=self.device)
+            # what the context holds, as the reference exposes it (likelihoods/base.py:308-309)
+            self.precision, self.flatdata = precision, np.concatenate(flatdata)
         return self._contexts[key]
+
+    def _marginalize_precision(self, fixed_values, flatdata_list, precision):
+        r"""'.prec' parameters (likelihoods/base.py:257-312): linear parameters marginalised once, at the current values of the others, into
+
+            P <- P - P T^T (T P T^T + diag(1 / scale^2))^{-1} T P ,     flatdata <- flatdata - \sum_i loc_i T_i ,
+
+        T_i = d(flattheory) / d(p_i) (constant along p_i: the theory is linear in it).  The reference takes T from automatic differentiation; here the two
+        evaluations flattheory(p_i = 1) - flattheory(p_i = 0) of the device theory give it exactly (to rounding).  Afterwards the parameter stays at its
+        default value, like any fixed parameter.  A 1-D (diagonal) input precision becomes a full matrix (the reference's line 308 broadcasts the 1-D array
+        against the 2-D correction instead: not reproduced)."""
+        from .._lib import Context
+        prec_params = self.prec_params
+        varied = self.varied_params
+        theta = np.array([[float(fixed_values.get(param.name, param.value)) for param in varied]], dtype='f8')   # pipeline.input_values (likelihoods/base.py:288)
+        base = dict(fixed_values)
+        for param in prec_params: base[param.name] = 0.                                                         # likelihoods/base.py:290
+
+        def flattheory(fixed):
+            ctx = Context(self._spec(fixed, flatdata_list, precision), device=self.device)
+            flat = ctx.eval_batch_host(theta, return_flattheory=True)[3][0]
+            ctx.close()
+            return flat
+
+        flat0 = flattheory(base)
+        T = np.array([flattheory({**base, param.name: 1.}) - flat0 for param in prec_params])                    # [n_prec, n]
+        if not np.isfinite(T).all():
+            raise PipelineError("'.prec': non-finite theory at the current parameter values")
+        full = np.diag(precision) if precision.ndim == 1 else precision
+        derivp = T.dot(full)
+        prior_hessian = np.array([-param.prior.scale**(-2) if param.prior.dist == 'norm' else 0. for param in prec_params])   # likelihoods/base.py:180-183
+        posterior_hessian = -derivp.dot(T.T) + np.diag(prior_hessian)
+        new_precision = full - derivp.T.dot(np.linalg.solve(-posterior_hessian, derivp))                        # likelihoods/base.py:308
+        loc = np.array([getattr(param.prior, 'loc', 0.) if param.prior.dist == 'norm' else 0. for param in prec_params])
+        shift = loc.dot(T)                                                                                      # flatdiff(loc) - flatdiff(0), likelihoods/base.py:309
+        new_flatdata, start = [], 0
+        for flatdata in flatdata_list:
+            new_flatdata.append(flatdata - shift[start:start + flatdata.size])
+            start += flatdata.size
+        self.prec_derivatives = T
+        return new_flatdata, new_precision
 
     def _flatdata_list(self):
         self.initialize()

@@ -138,3 +138,39 @@ def test_marg_two_tracers_vs_oracle():
         sol = orc.solve_marginalized(f0 - flatdata, T, like.precision, x0=x0, prior_loc=[0., 0.], prior_scale=[2., np.inf], marg_mask=[True, False])
         assert abs(loglike[i] - sol['loglikelihood']) <= 1e-9 * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
         assert np.allclose(xs[i], sol['x'], rtol=1e-8, atol=1e-10)
+
+
+def test_prec_one_off_precision_marginalisation():
+    """'.prec' (likelihoods/base.py:257-312): the linear parameter is marginalised ONCE into the precision matrix and the data vector.  Against the oracle's
+    restatement with the derivative taken through the oracle, the Woodbury identity P_new^-1 = C + scale^2 T T^T, and the per-point '.marg' result:
+    logposterior('.prec') = logposterior('.marg') + 1/2 log(T P T^T + 1 / scale^2) when the derivative does not depend on the other parameters (sn0)."""
+    from desilike_amd import vmap
+    g = load_golden('marg_sn0_grid')
+    like, like_marg = make_marg_likelihood(g, solved='.prec'), make_marg_likelihood(g, solved='.marg')
+    names = [str(n) for n in g['names']]
+    vnames = [name for name in names if name != 'sn0']
+    assert like.varied_params.names() == vnames and like.prec_params.names() == ['sn0'] and len(like.solved_params) == 0
+    assert like.all_params['sn0'].value == 0.
+    theta = {name: g['theta'][:, i] for i, name in enumerate(names) if name != 'sn0'}
+    (logpost, derived), errors = vmap(like, errors='return', return_derived=True)(theta)
+    (logpost_marg, derived_marg), errors_marg = vmap(like_marg, errors='return', return_derived=True)(theta)
+    assert errors == {} and errors_marg == {}
+    # derivative through the oracle at the default values of the other parameters
+    c = observable_constants(g)
+    p = {param.name: param.value for param in like.varied_params}
+    p['b1'] = (p['b1'], p['b1'])
+    T = (orc.fullshape_observable(c, dict(p, sn0=1.))['flattheory'] - orc.fullshape_observable(c, dict(p, sn0=0.))['flattheory'])[None, :]
+    assert np.allclose(like.prec_derivatives, T, rtol=1e-9, atol=1e-12 * np.abs(T).max())
+    P0 = like._precision_input
+    P_ref = orc.marginalize_precision(P0, T, [1.5])
+    assert np.allclose(like.precision, P_ref, rtol=1e-8, atol=1e-10 * np.abs(P_ref).max())
+    cov_new = np.linalg.inv(P0) + 1.5**2 * T.T.dot(T)
+    assert np.allclose(like.precision.dot(cov_new), np.eye(len(cov_new)), rtol=0., atol=1e-8)
+    assert np.allclose(like.flatdata, c['flatdata'] - 0.2 * T[0], rtol=1e-12, atol=1e-12 * np.abs(c['flatdata']).max())
+    a = float(T.dot(P0).dot(T.T)[0, 0]) + 1.5**(-2)
+    assert np.allclose(logpost, logpost_marg + 0.5 * np.log(a), rtol=1e-9, atol=1e-9)
+    # and directly against the oracle's Gaussian likelihood with the marginalised precision and shifted data
+    for i in range(0, len(logpost), 7):
+        q = dict(zip(names, g['theta'][i])); q['b1'] = (q['b1'], q['b1']); q['sn0'] = 0.
+        ref = orc.gaussian_loglikelihood(orc.fullshape_observable(c, q)['flattheory'], c['flatdata'] - 0.2 * T[0], P_ref)[0]
+        assert abs(derived['loglikelihood'][i] - ref) <= 1e-9 * max(1., abs(ref))
