@@ -88,7 +88,7 @@ class KaiserTracerPowerSpectrumMultipoles(BaseCalculator):
             shotnoise = np.sqrt(np.prod(shotnoise))  # cross-correlation: geometric mean (full_shape.py:155-157)
         self.nd = 1. / float(shotnoise)
         k = init.get('k', None)
-        if k is None: k = np.linspace(0.01, 0.2, 101)
+        if k is None: k = self._default_k()
         self.k = np.array(k, dtype='f8')
         self.ells = tuple(init.get('ells', (0, 2, 4)))
         self.mu, wmu = utils.weights_mu(init.get('mu', 8), method=init.get('method', 'leggauss'))
@@ -108,6 +108,9 @@ class KaiserTracerPowerSpectrumMultipoles(BaseCalculator):
         self._set_eft()
         self._initialized = True  # after template.init.update, which invalidates dependents
         return self
+
+    def _default_k(self):
+        return np.linspace(0.01, 0.2, 101)
 
     def _set_eft(self):
         self.counterterm_params, self.stochastic_params = [], []
@@ -191,6 +194,52 @@ class EFTLikeKaiserTracerPowerSpectrumMultipoles(KaiserTracerPowerSpectrumMultip
         toret['ct'] = [(nsX + name, nsY + name) for name in self.counterterm_params]
         toret['sn'] = [nsC + name for name in self.stochastic_params]
         return toret
+
+
+class _CorrelationFunctionFromPowerSpectrum(object):
+    r"""Correlation function multipoles as Hankel transforms of the power spectrum multipoles (full_shape.py:336-364 on top of tgc/base.py:46-139):
+    the device evaluates P_\ell on ``kin = geomspace(1e-4, 0.6, 300)`` (tgc/base.py:62-66) and ``get_corr`` -- interpolation to the FFTLog grid, high-k tail,
+    FFTLog, interpolation to ``s``, all linear in P_\ell -- is the constant operator ``hankel`` folded into the window matrix.  The operator is built at first use
+    by ONE batch of the device FFTLog (``dl_fftlog_apply``).  The stochastic terms have no parameter here (``_stochastic_bias_params = []`` in the reference)."""
+    _stochastic_bias_params = []
+
+    def _default_k(self):
+        return np.geomspace(1e-4, 0.6, 300)
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        s = self.init.get('s', None)
+        if s is None: s = np.linspace(20., 200, 101)
+        self.s = np.array(s, dtype='f8')
+        interp_order = {'linear': 1, 'cubic': 3}.get(self.init.get('interp_order', 1), self.init.get('interp_order', 1))
+        if interp_order != 1:
+            raise NotImplementedError('only interp_order = 1 (the default) is implemented')
+        self._kfft, self._hankel = np.logspace(-4., 3., 2048), None
+        super(_CorrelationFunctionFromPowerSpectrum, self).initialize()
+        self.kin = self.k
+        return self
+
+    @property
+    def hankel(self):
+        if self._hankel is None:
+            from ...fftlog import hankel_operator
+            self._hankel = hankel_operator(self.kin, self.s, self.ells, k=self._kfft, engine='hip')
+        return self._hankel
+
+    def _fold(self):
+        from scipy import linalg
+        return linalg.block_diag(*self.hankel)
+
+
+class KaiserTracerCorrelationFunctionMultipoles(_CorrelationFunctionFromPowerSpectrum, KaiserTracerPowerSpectrumMultipoles):
+    """Kaiser tracer correlation function multipoles (full_shape.py:553-574): parameters b1, sigmapar, sigmaper."""
+    _own_params = {**_B1, **_SIGMA}
+
+
+class EFTLikeKaiserTracerCorrelationFunctionMultipoles(_CorrelationFunctionFromPowerSpectrum, EFTLikeKaiserTracerPowerSpectrumMultipoles):
+    """EFT-like Kaiser tracer correlation function multipoles (full_shape.py:664-687): parameters b1, ct{ell}_2, sigmapar, sigmaper."""
+    _own_params = {name: conf for name, conf in EFTLikeKaiserTracerPowerSpectrumMultipoles._own_params.items() if not name.startswith('sn')}
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -411,8 +411,47 @@ def cfg3_table():
     print(names)
 
 
+def kaiser_xi(eft=False):
+    """Full-shape correlation function multipoles: (EFT-like) Kaiser P_ell -> xi_ell through get_corr (tgc/base.py:46-139; FFTLog = the refstub's transform,
+    third-party in the reference) with a ShapeFit template, ell = (0, 2, 4), 30 s-bins."""
+    from desilike.theories.galaxy_clustering import KaiserTracerCorrelationFunctionMultipoles, EFTLikeKaiserTracerCorrelationFunctionMultipoles
+    from desilike.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    theory = (EFTLikeKaiserTracerCorrelationFunctionMultipoles if eft else KaiserTracerCorrelationFunctionMultipoles)(template=template)
+    obs = TracerCorrelationFunctionMultipolesObservable(data={'b1': 2.}, s=np.linspace(22.5, 167.5, 30), ells=(0, 2, 4), theory=theory)
+    n, scale = 90, 3e-4
+    rng = np.random.RandomState(14)
+    A = rng.standard_normal((n, n)) * scale
+    cov = A.dot(A.T) + (10. * scale)**2 * np.eye(n)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+    like()
+    names = like.varied_params.names()
+    theta = sample_theta(like, 24, seed=19)
+    vlike = vmap(like, backend=None, errors='return', return_derived=True)
+    (logpost, derived), errors = vlike({name: theta[:, i] for i, name in enumerate(names)})
+    assert not errors
+    power, corr, flat = [], [], []
+    for row in theta:
+        like(**dict(zip(names, row)))
+        power.append(np.asarray(theory.power.power).copy())
+        corr.append(np.asarray(theory.corr).copy())
+        flat.append(np.asarray(like.flattheory).copy())
+    wm, pw = obs.wmatrix, theory.power
+    pt, tmpl = pw.pt, pw.pt.template
+    c = {'ells': np.array(wm.ells), 'ellsin': np.array(wm.ellsin), 'kin': np.asarray(pt.k), 'mu': np.asarray(pt.mu), 'wmu_ell': np.asarray(pt.wmu), 'k11': np.asarray(tmpl.k),
+         'pk_dd_fid': np.asarray(tmpl.pk_dd_fid), 'f_fid': float(tmpl.f_fid), 'kp': tmpl.kp, 'a': tmpl.a, 'nd': pw.nd, 's': np.asarray(theory.s), 'sout': np.concatenate(wm.s),
+         'flatdata': np.asarray(obs.flatdata), 'template': tmpl.__class__.__name__}
+    if eft:
+        c.update(ct_matrix=np.asarray(pw.counterterm_matrix), sn_matrix=np.asarray(pw.stochastic_matrix), ct_params=np.array(pw.counterterm_params), sn_params=np.array(pw.stochastic_params))
+    save('kaiser_xi' + ('_eft' if eft else ''), names=np.array(names), theta=theta, obs0=c, precision=np.asarray(like.precision), covariance=cov,
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]),
+         logposterior=np.asarray(logpost), loglikelihood=np.asarray(derived[like._param_loglikelihood]), logprior=np.asarray(derived[like._param_logprior]),
+         power=np.array(power), theory=np.array(corr), flattheory=np.array(flat))
+    print(names)
+
+
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -421,4 +460,6 @@ if __name__ == '__main__':
     if 'cfg5' in todo: cfg5()
     if 'cfg4' in todo: cfg4('xi')
     if 'cfg4_pk' in todo: cfg4('pk')
+    if 'kaiser_xi' in todo: kaiser_xi(False)
+    if 'kaiser_xi_eft' in todo: kaiser_xi(True)
     if 'cfg3_table' in todo: cfg3_table()
