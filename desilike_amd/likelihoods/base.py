@@ -81,7 +81,7 @@ class BaseGaussianLikelihood(BaseLikelihood):
 def _collect_varied(observables):
     all_params = ParameterCollection()
     for obs in observables:
-        for param in obs.wmatrix.theory._all_params():
+        for param in list(obs.wmatrix.theory._all_params()) + list(getattr(obs.wmatrix, '_extra_params', lambda: [])()):
             if param.name in all_params:
                 if all_params[param.name] != param:
                     # same name used with different settings by two calculators: the first definition wins, like one shared pipeline parameter
@@ -221,7 +221,10 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
 
             defaults = dict(qpar=1., qper=1., qiso=1., qap=1., df=1., dm=0., dn=0., sigmapar=0., sigmaper=0., b1X=1., b1Y=1., sn0=0., dbeta=1., sigmas=0.)
             inputs = {}
-            for iname, pname in theory._input_map().items():
+            imap = dict(theory._input_map())
+            window_pass = getattr(obs.wmatrix, '_pass_params', lambda: [])()   # systematic templates: pass-through columns appended by the window
+            if window_pass: imap['pass'] = list(imap.get('pass', [])) + list(window_pass)
+            for iname, pname in imap.items():
                 if iname == 'ct':
                     res = [[resolve(pn, 0.) for pn in pair] for pair in pname]
                     if res: inputs['ct'] = ([[r[0] for r in pair] for pair in res], [[r[1] for r in pair] for pair in res])
@@ -236,7 +239,6 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             spec['inputs'] = inputs
             if solved_names:
                 # analytically solved parameters must enter the theory linearly: shot-noise like and counter terms (full_shape.py:545-550, 628-634)
-                imap = theory._input_map()
 
                 def sindex(pname):
                     return solved_names.index(pname) if pname in solved_names else -1

@@ -1,3 +1,5 @@
-from .window import WindowedPowerSpectrumMultipoles, window_matrix_bininteg
+from .window import (WindowedPowerSpectrumMultipoles, window_matrix_bininteg, SystematicTemplatePowerSpectrumMultipoles,
+                     TopHatFiberCollisionsPowerSpectrumMultipoles)
 from .power_spectrum import TracerPowerSpectrumMultipolesObservable
-from .correlation_function import WindowedCorrelationFunctionMultipoles, TracerCorrelationFunctionMultipolesObservable
+from .correlation_function import (WindowedCorrelationFunctionMultipoles, TracerCorrelationFunctionMultipolesObservable,
+                                   SystematicTemplateCorrelationFunctionMultipoles)

@@ -5,6 +5,15 @@ import numpy as np
 from ...base import BaseCalculator
 from ... import utils
 from ...utils import window_matrix_bininteg
+from .window import SystematicTemplatePowerSpectrumMultipoles, _append_systematic_templates
+
+
+class SystematicTemplateCorrelationFunctionMultipoles(SystematicTemplatePowerSpectrumMultipoles):
+    """Systematic templates for correlation function multipoles (window.py:1363-1384): ``flatcorr += sum_i syst_i template_i``."""
+    _xname = 's'
+
+    def _default_x(self):
+        return np.linspace(20., 200, 101)
 
 
 class WindowedCorrelationFunctionMultipoles(BaseCalculator):
@@ -93,6 +102,13 @@ class WindowedCorrelationFunctionMultipoles(BaseCalculator):
             self.matrix_full = matrix_full.dot(wmatrix_rebin.T)
         else:
             raise ValueError('unrecognized wmatrix {}'.format(wmatrix))
+        systematic_templates = init.get('systematic_templates', None)
+        if systematic_templates is not None:   # window.py:697-701
+            if not isinstance(systematic_templates, SystematicTemplateCorrelationFunctionMultipoles):
+                systematic_templates = SystematicTemplateCorrelationFunctionMultipoles(templates=systematic_templates)
+            systematic_templates.init.update(s=self.s, ells=self.ells)
+            systematic_templates.initialize()
+        self.systematic_templates = systematic_templates
         self.theory.init.update(s=self.sin, ells=self.ellsin)
         self.theory.initialize()
         self.shotnoise = 0.
@@ -105,7 +121,16 @@ class WindowedCorrelationFunctionMultipoles(BaseCalculator):
         self.initialize()
         fold = self.theory._fold()                                       # theory vector = fold . [device output, broadband parameters]
         wmatrix = fold if self.matrix_full is None else self.matrix_full.dot(fold)
+        wmatrix = _append_systematic_templates(wmatrix, self.systematic_templates, self.smask, wmatrix.shape[1])
         return dict(wmatrix=wmatrix, kmask=None if self.smask is None else np.asarray(self.smask, dtype='i4'), offset=self.offset)
+
+    def _pass_params(self):
+        self.initialize()
+        return list(self.systematic_templates.templates) if self.systematic_templates is not None else []
+
+    def _extra_params(self):
+        self.initialize()
+        return list(self.systematic_templates.params) if self.systematic_templates is not None else []
 
     @property
     def size(self):

@@ -11,6 +11,109 @@ from ... import utils
 from ...utils import window_matrix_bininteg  # noqa: F401
 
 
+def get_templates(templates, ells=(0, 2, 4), x=None):
+    """name -> flat template [sum of the output sizes]; lists are named 'syst_{i}' (window.py:1253-1272); callables take (ell, x)."""
+    from collections.abc import Mapping
+    if templates is None: templates = {}
+    if not isinstance(templates, Mapping):
+        if callable(templates) or (isinstance(templates, np.ndarray) and templates.ndim == 1): templates = [templates]
+        templates = {'syst_{:d}'.format(i): template for i, template in enumerate(templates)}
+    toret = {}
+    for name, template in templates.items():
+        if x is not None:
+            if callable(template):
+                template = np.concatenate([template(ell, xx) for ell, xx in zip(ells, x)])
+            template = np.ravel(np.asarray(template, dtype='f8'))
+            size = sum(xx.size for xx in x)
+            if template.size != size:
+                raise ValueError('provided template is size {:d}, but expected {:d} = sum({})'.format(template.size, size, [xx.size for xx in x]))
+        toret[name] = template
+    return toret
+
+
+class SystematicTemplatePowerSpectrumMultipoles(BaseCalculator):
+    """Systematic templates added to the windowed multipoles, ``flatpower += sum_i syst_i template_i`` (window.py:1275-1309, 472-473): one linear parameter
+    per template (analytically solvable), carried to the GPU as pass-through columns of the window matrix."""
+
+    @classmethod
+    def _default_params(cls, templates=None, **kwargs):
+        return {name: dict(value=0., ref=dict(limits=[-1e-3, 1e-3]), delta=0.005, latex='s_{{{:d}}}'.format(i)) for i, name in enumerate(get_templates(templates))}
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        self.ells = tuple(self.init.get('ells', (0, 2, 4)))
+        x = self.init.get(self._xname, None)
+        if x is None: x = self._default_x()
+        if not isinstance(x, (tuple, list)): x = [x] * len(self.ells)
+        setattr(self, self._xname, tuple(np.asarray(xx, dtype='f8') for xx in x))
+        self.templates = get_templates(self.init.get('templates', ()), ells=self.ells, x=getattr(self, self._xname))
+        self._initialized = True
+        return self
+
+    _xname = 'k'
+
+    def _default_x(self):
+        return np.linspace(0.01, 0.2, 101)
+
+
+class TopHatFiberCollisionsPowerSpectrumMultipoles(BaseCalculator):
+    r"""Fiber-collision kernels of Hahn et al. 2016 (arXiv:1609.01714, appendix) for a top-hat pair-loss function of amplitude ``fs`` below the
+    transverse scale ``Dfc`` (reference: window.py:972-1049).  Init-time constants only:
+    ``kernel_correlated [n_ell, n_ellin, n_k, n_kin]`` (the multipoles are multiplied by it: identity minus the collided pairs) and
+    ``kernel_uncorrelated [n_ell, n_k]`` (an offset); the window folds both into its matrix / offset (window.py:428-438)."""
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        from scipy import special
+        init = self.init
+        k = init.get('k', None)
+        if k is None: k = np.linspace(0.01, 0.2, 101)
+        self.k = np.array(k, dtype='f8')
+        self.ells = tuple(init.get('ells', (0, 2, 4)))
+        theory = init.get('theory', None)
+        if theory is None:
+            from ...theories.galaxy_clustering import KaiserTracerPowerSpectrumMultipoles
+            theory = KaiserTracerPowerSpectrumMultipoles()
+        self.theory = theory
+        theory.initialize()
+        self.kin, self.ellsin = np.array(theory.k, dtype='f8'), tuple(theory.ells)
+        self.with_uncorrelated = bool(init.get('with_uncorrelated', True))
+        self.fs, self.Dfc = float(init.get('fs', 1.)), float(init.get('Dfc', 0.))
+
+        def W2D(x):   # Fourier transform of the unit disc
+            return 2. * special.j1(x) / x
+
+        # polynomials H_{l l'} of the ratio of the smaller to the larger wavenumber (Hahn et al., appendix), l > l'
+        def Hpoly(lmax, lmin, x):
+            # (2, 0): x^2 - 1; (4, 0): 7/4 x^4 - 5/2 x^2 + 3/4; (4, 2): x^4 - x^2; (6, 0): 33/8 x^6 - 63/8 x^4 + 35/8 x^2 - 5/8; (6, 2): 11/4 x^6 - 9/2 x^4 + 7/4 x^2; (6, 4): x^6 - x^4
+            table = {(2, 0): {2: 1., 0: -1.}, (4, 0): {4: 7. / 4., 2: -5. / 2., 0: 3. / 4.}, (4, 2): {4: 1., 2: -1.},
+                     (6, 0): {6: 33. / 8., 4: -63. / 8., 2: 35. / 8., 0: -5. / 8.}, (6, 2): {6: 11. / 4., 4: -9. / 2., 2: 7. / 4.}, (6, 4): {6: 1., 4: -1.}}
+            return sum(coeff * x**power for power, coeff in table[(lmax, lmin)].items())
+
+        leg0 = np.array([(2. * ell + 1.) * special.eval_legendre(ell, 0.) for ell in self.ells])
+        self.kernel_uncorrelated = -leg0[:, None] * self.fs * (np.pi * self.Dfc)**2 / self.k * W2D(self.k * self.Dfc)
+        kk, qq = np.meshgrid(self.k, self.kin, indexing='ij')
+        ratio = np.minimum(kk, qq) / np.maximum(kk, qq)
+        base = np.minimum(qq / kk, 1.) * W2D(qq * self.Dfc)
+        measure = self.kin * utils.weights_trapz(self.kin)
+        diag = utils.matrix_lininterp(self.kin, self.k).T
+        kernels = np.zeros((len(self.ells), len(self.ellsin), len(self.k), len(self.kin)), dtype='f8')
+        for iout, ellout in enumerate(self.ells):
+            for iin, ellin in enumerate(self.ellsin):
+                if ellin == ellout:
+                    fll = base * ratio**ellout
+                    kernels[iout, iin] = diag
+                else:
+                    fll = np.where(((ellout >= ellin) & (kk >= qq)) | ((ellout <= ellin) & (kk <= qq)),
+                                   base * (2. * ellout + 1.) / 2. * Hpoly(max(ellout, ellin), min(ellout, ellin), ratio), 0.)
+                kernels[iout, iin] -= self.fs * self.Dfc**2 / 2. * fll * measure
+        self.kernel_correlated = kernels
+        self._initialized = True
+        return self
+
+
 class WindowedPowerSpectrumMultipoles(BaseCalculator):
     """
     Window effect on the power spectrum multipoles.
@@ -29,6 +132,7 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
         klim, k, kedges, ells = init.get('klim', None), init.get('k', None), init.get('kedges', None), init.get('ells', None)
         wmatrix, kin, kinrebin, kinlim, ellsin = init.get('wmatrix', None), init.get('kin', None), init.get('kinrebin', 1), init.get('kinlim', None), init.get('ellsin', None)
         shotnoise, wshotnoise = init.get('shotnoise', None), init.get('wshotnoise', None)
+        fiber_collisions, systematic_templates = init.get('fiber_collisions', None), init.get('systematic_templates', None)
         if ells is None:
             ells = list(klim) if klim is not None else (0, 2, 4)
         self.ells = tuple(ells)
@@ -123,6 +227,25 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
             self.matrix_full = matrix_full.dot(wmatrix_rebin.T)
         else:
             raise NotImplementedError('window matrices from files / lsstypes / pypower objects are out of scope: pass a 2D array with kin and ellsin')
+        if fiber_collisions is not None:   # window.py:428-438: kernels folded into the matrix / offset
+            self.theory.init.update(k=self.kin, ells=self.ellsin)
+            fiber_collisions.init.update(k=self.kin, ells=self.ellsin, theory=self.theory)
+            fiber_collisions.initialize()
+            kc = fiber_collisions.kernel_correlated
+            kernel = np.block([[kc[iout, iin] for iin in range(kc.shape[1])] for iout in range(kc.shape[0])])
+            uncorrelated = fiber_collisions.kernel_uncorrelated.ravel() if fiber_collisions.with_uncorrelated else None
+            if self.matrix_full is None:
+                self.offset, self.matrix_full = uncorrelated, kernel
+            else:
+                if uncorrelated is not None: self.offset = self.matrix_full.dot(uncorrelated)
+                self.matrix_full = self.matrix_full.dot(kernel)
+            self.ellsin, self.kin = fiber_collisions.ellsin, fiber_collisions.kin
+        if systematic_templates is not None:   # window.py:439-443
+            if not isinstance(systematic_templates, SystematicTemplatePowerSpectrumMultipoles):
+                systematic_templates = SystematicTemplatePowerSpectrumMultipoles(templates=systematic_templates)
+            systematic_templates.init.update(k=self.k, ells=self.ells)
+            systematic_templates.initialize()
+        self.systematic_templates = systematic_templates
         self.theory.init.update(k=self.kin, ells=self.ellsin)
         if shotnoise is None:
             shotnoise = 0.
@@ -155,10 +278,33 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
                 offset = extra if offset is None else offset + extra
             shotnoisein = None
             wmatrix = fold if wmatrix is None else wmatrix.dot(fold)
+        wmatrix = _append_systematic_templates(wmatrix, self.systematic_templates, self.kmask, len(self.ellsin) * len(self.kin))
         return dict(wmatrix=wmatrix, kmask=None if self.kmask is None else np.asarray(self.kmask, dtype='i4'), offset=offset,
                     shotnoise_in=shotnoisein, shotnoise_out=self.shotnoiseout)
+
+    def _pass_params(self):
+        """Names of the parameters the window adds as pass-through columns (systematic templates)."""
+        self.initialize()
+        return list(self.systematic_templates.templates) if self.systematic_templates is not None else []
+
+    def _extra_params(self):
+        self.initialize()
+        return list(self.systematic_templates.params) if self.systematic_templates is not None else []
 
     @property
     def size(self):
         self.initialize()
         return sum(len(kk) for kk in self.k)
+
+
+def _append_systematic_templates(wmatrix, systematic_templates, mask, n_in):
+    """Window matrix with one more pass-through column per systematic template.  The templates live on the OUTPUT grid (after the row selection ``mask``):
+    their values are scattered to the selected rows of the un-masked matrix."""
+    if systematic_templates is None or not systematic_templates.templates:
+        return wmatrix
+    if wmatrix is None: wmatrix = np.eye(n_in)
+    columns = np.zeros((wmatrix.shape[0], len(systematic_templates.templates)), dtype='f8')
+    rows = np.arange(wmatrix.shape[0]) if mask is None else np.asarray(mask)
+    for icol, template in enumerate(systematic_templates.templates.values()):
+        columns[rows, icol] = template
+    return np.hstack([wmatrix, columns])

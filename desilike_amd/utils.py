@@ -109,3 +109,14 @@ def blockinv(blocks, check_valid='raise'):
     invShur = inv(A - B.dot(invD).dot(C), check_valid=check_valid)
     toret = np.block([[invShur, -invShur.dot(B).dot(invD)], [-invD.dot(C).dot(invShur), invD + invD.dot(C).dot(invShur).dot(B).dot(invD)]])
     return toret
+
+
+def weights_trapz(x):
+    """Trapezoidal integration weights on the (non-uniform) grid ``x`` (reference: utils.py:614-622)."""
+    x = np.asarray(x, dtype='f8')
+    if x.size <= 1:
+        return np.ones(max(x.size, 1), dtype='f8')[:x.size] if x.size else np.array(1.)
+    w = np.empty_like(x)
+    w[0], w[-1] = x[1] - x[0], x[-1] - x[-2]
+    w[1:-1] = x[2:] - x[:-2]
+    return w / 2.

@@ -411,6 +411,60 @@ def cfg3_table():
     print(names)
 
 
+def syst_template_0(ell, k):
+    return 1e3 * (ell == 0) / (1. + (k / 0.02)**2)
+
+
+def cfg2_fc_syst():
+    """Window extras (row a6): top-hat fiber collisions folded into the binning matrix (window.py:428-438, 972-1049) and two systematic templates
+    (window.py:439-443, 472-473, 1253-1309), klim row selection on top."""
+    from desilike.observables.galaxy_clustering import TopHatFiberCollisionsPowerSpectrumMultipoles
+    import desilike.utils as ref_utils
+
+    def weights_trapz(x):
+        # the reference's utils.weights_trapz (utils.py:614-622) relies on jnp.insert clamping an out-of-range index (jax is absent here and numpy raises):
+        # same weights, written for numpy -- the ONLY line of the reference replaced for this fixture
+        x = np.asarray(x)
+        return np.concatenate([[x[1] - x[0]], x[2:] - x[:-2], [x[-1] - x[-2]]]) / 2.
+
+    ref_utils.weights_trapz = weights_trapz
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    theory = KaiserTracerPowerSpectrumMultipoles(template=template)
+    kedges = np.linspace(0., 0.2, 41)
+    kc = (kedges[:-1] + kedges[1:]) / 2.
+    klim = {0: (0.02, 0.2, 0.005), 2: (0.02, 0.18, 0.005), 4: (0.03, 0.15, 0.005)}
+    nout = [int(((kc >= lo) & (kc <= hi)).sum()) for lo, hi, step in klim.values()]
+    rng = np.random.RandomState(21)
+    template1 = 50. * rng.standard_normal(sum(nout))
+    fiber = TopHatFiberCollisionsPowerSpectrumMultipoles(fs=0.6, Dfc=2.5)
+    # data: the same model without the row selection, evaluated at b1 = 2, then cut by the observable itself (power_spectrum.py:108)
+    obs_full = TracerPowerSpectrumMultipolesObservable(data={'b1': 2.}, kedges=kedges, ells=(0, 2, 4), wmatrix={'resolution': 4}, shotnoise=1e4,
+                                                       theory=KaiserTracerPowerSpectrumMultipoles(template=ShapeFitPowerSpectrumTemplate(z=0.5)),
+                                                       fiber_collisions=TopHatFiberCollisionsPowerSpectrumMultipoles(fs=0.6, Dfc=2.5))
+    ObservablesGaussianLikelihood(observables=[obs_full], covariance=np.eye(120))()
+    obs = TracerPowerSpectrumMultipolesObservable(data=np.asarray(obs_full.flatdata), k=kc, klim=klim, ells=(0, 2, 4), wmatrix={'resolution': 4}, theory=theory, shotnoise=1e4,
+                                                  fiber_collisions=fiber, systematic_templates=[syst_template_0, template1])
+    n = sum(nout)
+    cov = spd_covariance(n, seed=3)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+    for param in like.all_params.select(basename='syst_*'):
+        param.update(prior=dict(dist='norm', loc=0., scale=2.), ref=dict(dist='norm', loc=0., scale=0.5))
+    like()
+    names = like.varied_params.names()
+    theta = special_rows(sample_theta(like, 24, seed=23), names)
+    out = run_batch(like, [obs], theta, names, nint=4)
+    c = extract_observable(obs)
+    c['templates'] = np.array(list(obs.wmatrix.systematic_templates.templates.values()))
+    c['template_names'] = np.array(list(obs.wmatrix.systematic_templates.templates))
+    c['kernel_correlated'] = np.asarray(fiber.kernel_correlated)
+    c['kernel_uncorrelated'] = np.asarray(fiber.kernel_uncorrelated)
+    c['fs'], c['Dfc'] = fiber.fs, fiber.Dfc
+    c['template1'] = template1
+    save('cfg2_fc_syst', names=np.array(names), theta=theta, obs0=c, precision=np.asarray(like.precision), covariance=cov,
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]), **out)
+    print(names)
+
+
 def kaiser_xi(eft=False):
     """Full-shape correlation function multipoles: (EFT-like) Kaiser P_ell -> xi_ell through get_corr (tgc/base.py:46-139; FFTLog = the refstub's transform,
     third-party in the reference) with a ShapeFit template, ell = (0, 2, 4), 30 s-bins."""
@@ -451,7 +505,7 @@ def kaiser_xi(eft=False):
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -460,6 +514,7 @@ if __name__ == '__main__':
     if 'cfg5' in todo: cfg5()
     if 'cfg4' in todo: cfg4('xi')
     if 'cfg4_pk' in todo: cfg4('pk')
+    if 'cfg2_fc_syst' in todo: cfg2_fc_syst()
     if 'kaiser_xi' in todo: kaiser_xi(False)
     if 'kaiser_xi_eft' in todo: kaiser_xi(True)
     if 'cfg3_table' in todo: cfg3_table()

@@ -85,3 +85,27 @@ def test_kaiser_xi_eft_seeded_batch_and_marginalised_counterterms():
         sol = orc.solve_marginalized(f0 - g['obs0']['flatdata'], T, like3.precision, x0=np.zeros(3), prior_loc=np.zeros(3), prior_scale=np.full(3, 100.), marg_mask=np.ones(3, dtype='?'))
         assert abs(ll3[i] - sol['loglikelihood']) <= 1e-9 * max(1., abs(sol['loglikelihood'])), (ll3[i], sol['loglikelihood'])
         assert np.allclose(xs[i], sol['x'], rtol=1e-7, atol=1e-9)
+
+
+def test_xi_systematic_template_is_an_additive_linear_term():
+    """window.py:1363-1384, 731-733: flatcorr += syst_0 * template, on top of the fixture-pinned xi_ell."""
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerCorrelationFunctionMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    g = load_golden('kaiser_xi')
+    theory = KaiserTracerCorrelationFunctionMultipoles(template=ShapeFitPowerSpectrumTemplate(z=0.5))
+    obs = TracerCorrelationFunctionMultipolesObservable(data=g['obs0']['flatdata'], s=np.linspace(22.5, 167.5, 30), ells=(0, 2, 4), theory=theory,
+                                                        systematic_templates=[lambda ell, s: (ell == 2) * 1e-3 * (s / 100.)**-2])
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
+    names = like.varied_params.names()
+    assert 'syst_0' in names
+    rnames = [str(n) for n in g['names']]
+    theta = np.column_stack([g['theta'][:, rnames.index(n)] if n in rnames else np.linspace(-1., 1., len(g['theta'])) for n in names])
+    loglike, logprior, status, flat = like._get_context().eval_batch_host(theta, return_flattheory=True)
+    s = np.linspace(22.5, 167.5, 30)
+    template = np.concatenate([np.zeros(30), 1e-3 * (s / 100.)**-2, np.zeros(30)])
+    expected = g['flattheory'] + theta[:, names.index('syst_0')][:, None] * template
+    assert np.allclose(flat, expected, rtol=1e-9, atol=1e-12 * np.abs(expected).max())
+    for i in range(len(theta)):
+        ref = orc.gaussian_loglikelihood(expected[i], g['obs0']['flatdata'], like.precision)[0]
+        assert abs(loglike[i] - ref) <= 1e-9 * max(1., abs(ref))
