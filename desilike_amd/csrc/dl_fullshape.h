@@ -80,7 +80,7 @@ struct DlObsDev {
     int64_t col_offset;  // first column of this observable in a row of the (concatenated) power buffer
     // analytic marginalisation: each point owns 1 + n_var consecutive rows of the power buffer; row 1 + v holds
     // d(power) / d(solved parameter of variable slot v) (counter terms: the derivative depends on the point through P_dd,l=0)
-    int32_t n_var, pad1;
+    int32_t n_var, damping_fid;            // damping_fid: damping evaluated at the FIDUCIAL (k, mu) (SimpleTracerPowerSpectrumMultipoles, full_shape.py:410-414)
     int32_t marg_ct_slot[DL_MAX_EFT][2];   // variable slot fed by counter term c through tracer X / Y, or -1
     double eta, f_fid, a, nd, x0, inv_hx;
     double end0a, end0b, end1a, end1b;  // not-a-knot end relations: M[0] = end0a M[1] + end0b M[2]; M[n-1] = end1a M[n-2] + end1b M[n-3]
@@ -219,7 +219,14 @@ DL_HD void dl_fs_mu_partC(const DlObsDev& o, const DlFsShared& s, int m, const D
     s.pt[DL_PT_LQ + m] = c.lq;
     s.pt[DL_PT_LQH + m] = c.lq * o.inv_hx;
     // full_shape.py:492: sigmapar^2 muap^2 + sigmaper^2 (1 - muap^2)
-    s.pt[DL_PT_SD + m] = c.sigpar * c.sigpar * c.mup2 + c.sigper * c.sigper * (1. - c.mup2);
+    if (o.damping_fid) {
+        // full_shape.py:410-411: exp(-k^2 (sigmapar^2 mu^2 + sigmaper^2 (1 - mu^2)) / 2) at the fiducial (k, mu); phase 3 forms (k / qper * factorap)^2 SD,
+        // so SD carries qper^2 / factorap^2 (x = factorap^2)
+        const double mu2 = c.mu * c.mu;
+        s.pt[DL_PT_SD + m] = (c.sigpar * c.sigpar * mu2 + c.sigper * c.sigper * (1. - mu2)) * (c.qper * c.qper) / c.x;
+    } else {
+        s.pt[DL_PT_SD + m] = c.sigpar * c.sigpar * c.mup2 + c.sigper * c.sigper * (1. - c.mup2);
+    }
     const double fm2 = c.f * c.mup2;
     const double bias = (c.b1X + fm2) * (c.b1Y + fm2);         // = b1X b1Y + (b1X + b1Y) f mu'^2 + f^2 mu'^4, full_shape.py:550
     for (int l = 0; l < DL_MAX_ELL; ++l) {

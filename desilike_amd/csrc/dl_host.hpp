@@ -321,6 +321,7 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     d.templ = cfg.i(p + "template", 0);
     d.apmode = cfg.i(p + "apmode", 0);
     d.transform = cfg.i(p + "transform", 0);
+    d.damping_fid = cfg.i(p + "damping_fid", 0);
     if (d.theory == 3) return dl_build_emulated_obs(cfg, p, n_params, oh, arena, err);
     const auto& ells = cfg.I(p + "ells_in");
     const auto& kin = cfg.F(p + "kin");

@@ -1,6 +1,6 @@
 from .power_template import (BasePowerSpectrumTemplate, FixedPowerSpectrumTemplate, StandardPowerSpectrumTemplate,
                              ShapeFitPowerSpectrumTemplate, BAOPowerSpectrumTemplate)
-from .full_shape import (KaiserTracerPowerSpectrumMultipoles, EFTLikeKaiserTracerPowerSpectrumMultipoles, KaiserTracerCorrelationFunctionMultipoles,
+from .full_shape import (KaiserTracerPowerSpectrumMultipoles, SimpleTracerPowerSpectrumMultipoles, EFTLikeKaiserTracerPowerSpectrumMultipoles, KaiserTracerCorrelationFunctionMultipoles,
                          EFTLikeKaiserTracerCorrelationFunctionMultipoles, LPTVelocileptorsTracerPowerSpectrumMultipoles,
                          REPTVelocileptorsTracerPowerSpectrumMultipoles, EmulatedTracerPowerSpectrumMultipoles)
 from .bao import DampedBAOWigglesTracerPowerSpectrumMultipoles, DampedBAOWigglesTracerCorrelationFunctionMultipoles

@@ -55,6 +55,7 @@ class KaiserTracerPowerSpectrumMultipoles(BaseCalculator):
         Tracer namespace(s) for the bias parameters (full_shape.py:59-133).
     """
     _kind = 0  # DL_THEORY_KAISER
+    _damping_fid = False
     _klim = (1e-3, 1., 500)   # template knots, full_shape.py:19
     _deterministic_bias_params = ['b1']
     _stochastic_bias_params = ['sn0']
@@ -124,6 +125,7 @@ class KaiserTracerPowerSpectrumMultipoles(BaseCalculator):
     def _theory_spec(self):
         self.initialize()
         spec = dict(theory=np.array([self._kind], dtype='i4'), nd=[self.nd], ells_in=np.array(self.ells, dtype='i4'), kin=self.k, mu=self.mu, wmu_ell=self.wmu)
+        if self._damping_fid: spec['damping_fid'] = np.array([1], dtype='i4')
         spec.update(self.template._template_spec())
         return spec
 
@@ -140,6 +142,13 @@ class KaiserTracerPowerSpectrumMultipoles(BaseCalculator):
         ap = [param for param in self.template.params if param.basename in ('qpar', 'qper', 'qiso', 'qap')]
         others = [param for param in self.template.params if param not in ap]
         return ParameterCollection(ap + others) + self.params
+
+
+class SimpleTracerPowerSpectrumMultipoles(KaiserTracerPowerSpectrumMultipoles):
+    r"""Kaiser tracer multipoles with FIXED damping, "essentially used for Fisher forecasts" (full_shape.py:367-414): the Gaussian damping
+    :math:`\exp[-k^2 (\Sigma_\parallel^2 \mu^2 + \Sigma_\perp^2 (1 - \mu^2)) / 2]` is evaluated at the fiducial :math:`(k, \mu)`, not the AP-distorted ones, and
+    :math:`s_{n,0} / \bar n` is added to :math:`P(k, \mu)` before the projection (identical after it: the quadrature integrates the Legendre polynomials exactly)."""
+    _damping_fid = True
 
 
 class EFTLikeKaiserTracerPowerSpectrumMultipoles(KaiserTracerPowerSpectrumMultipoles):

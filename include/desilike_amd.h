@@ -72,6 +72,7 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
  *   precision       f64[n*n] or f64[n]  precision matrix (or its diagonal), n = total data size
  *                                        (Hartlap / Percival factors already applied by the host: likelihoods/base.py:623-656)
  *   obs<i>.theory, .template, .apmode, .transform   i32[1]
+ *   obs<i>.damping_fid  i32[1]  1: Gaussian damping at the fiducial (k, mu) (SimpleTracerPowerSpectrumMultipoles full_shape.py:410-411) instead of the AP-distorted ones (492-493)
  *   obs<i>.eta, .f_fid, .a, .kp, .nd                f64[1]
  *   obs<i>.ells_in  i32[n_ell]      theory multipoles
  *   obs<i>.kin      f64[n_kin]      theory wavenumbers (same for every multipole)

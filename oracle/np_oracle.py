@@ -120,6 +120,15 @@ def kaiser_pktable(k, mu, wmu_ell, k11, pk11, f, qpar=1., qper=1., sigmapar=0., 
     return to_poles(pktable), to_poles(f * muap**2 * pktable), to_poles(f**2 * muap**4 * pktable)
 
 
+def simple_tracer_power(k, mu, wmu_ell, k11, pk11, f, nd, b1X, b1Y, sn0, qpar=1., qper=1., sigmapar=0., sigmaper=0.):
+    """SimpleTracerPowerSpectrumMultipoles.calculate, full_shape.py:405-414: damping at the FIDUCIAL (k, mu), sn0 / nd added to P(k, mu) before the projection."""
+    jac, kap, muap = ap_k_mu(k, mu, qpar=qpar, qper=qper)
+    sigmanl2 = k[:, None]**2 * (sigmapar**2 * mu**2 + sigmaper**2 * (1. - mu**2))
+    damping = np.exp(-sigmanl2 / 2.)
+    pkmu = jac * damping * (b1X + f * muap**2) * (b1Y + f * muap**2) * interp1d(np.log10(kap), np.log10(k11), pk11, method='cubic') + sn0 / nd
+    return np.sum(pkmu * wmu_ell[:, None, :], axis=-1)
+
+
 # ----------------------------------------------------------------------------------------------
 # a5: tracer combine                                          full_shape.py:545-550, 628-634
 # ----------------------------------------------------------------------------------------------
@@ -264,11 +273,15 @@ def fullshape_observable(c, p):
         pk11 = c['pk_dd_fid']
     f = c['f_fid'] * p.get('df', 1.)
     out['pk_dd_template'], out['f'] = pk11, f
-    dd, dt, tt = kaiser_pktable(c['kin'], c['mu'], c['wmu_ell'], k11, pk11, f, qpar=p.get('qpar', 1.), qper=p.get('qper', 1.),
-                                sigmapar=p.get('sigmapar', 0.), sigmaper=p.get('sigmaper', 0.))
-    out['pk_dd'], out['pk_dt'], out['pk_tt'] = dd, dt, tt
     b1X, b1Y = p['b1']
-    power = kaiser_tracer_power(c['ellsin'], dd, dt, tt, c['nd'], b1X, b1Y, p.get('sn0', 0.))
+    if c.get('simple_tracer', False):
+        power = simple_tracer_power(c['kin'], c['mu'], c['wmu_ell'], k11, pk11, f, c['nd'], b1X, b1Y, p.get('sn0', 0.), qpar=p.get('qpar', 1.), qper=p.get('qper', 1.),
+                                    sigmapar=p.get('sigmapar', 0.), sigmaper=p.get('sigmaper', 0.))
+    else:
+        dd, dt, tt = kaiser_pktable(c['kin'], c['mu'], c['wmu_ell'], k11, pk11, f, qpar=p.get('qpar', 1.), qper=p.get('qper', 1.),
+                                    sigmapar=p.get('sigmapar', 0.), sigmaper=p.get('sigmaper', 0.))
+        out['pk_dd'], out['pk_dt'], out['pk_tt'] = dd, dt, tt
+        power = kaiser_tracer_power(c['ellsin'], dd, dt, tt, c['nd'], b1X, b1Y, p.get('sn0', 0.))
     if c.get('ct_matrix', None) is not None:
         power = eftlike_addon(power, c['ellsin'], dd, c['ct_matrix'], p['ct'], c['sn_matrix'], p['sn'], c['nd'])
     out['power'] = power

@@ -465,6 +465,38 @@ def cfg2_fc_syst():
     print(names)
 
 
+def simple_tracer():
+    """SimpleTracerPowerSpectrumMultipoles (full_shape.py:367-414): damping at the fiducial (k, mu), sn0 / nd added before the projection; Standard template, qisoqap."""
+    from desilike.theories.galaxy_clustering import SimpleTracerPowerSpectrumMultipoles
+    template = StandardPowerSpectrumTemplate(z=0.5, apmode='qisoqap')
+    theory = SimpleTracerPowerSpectrumMultipoles(template=template)
+    for name in ['sigmapar', 'sigmaper']:
+        theory.init.params[name].update(fixed=False)
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'sigmapar': 4., 'sigmaper': 3.}, kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 3}, theory=theory, shotnoise=1e4)
+    cov = spd_covariance(120, seed=5)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+    like()
+    names = like.varied_params.names()
+    theta = sample_theta(like, 24, seed=29)
+    vlike = vmap(like, backend=None, errors='return', return_derived=True)
+    (logpost, derived), errors = vlike({name: theta[:, i] for i, name in enumerate(names)})
+    assert not errors
+    power, flat = [], []
+    for row in theta:
+        like(**dict(zip(names, row)))
+        power.append(np.asarray(theory.power).copy())
+        flat.append(np.asarray(like.flattheory).copy())
+    wm, tmpl = obs.wmatrix, theory.template
+    c = {'ells': np.array(wm.ells), 'ellsin': np.array(wm.ellsin), 'kin': np.asarray(theory.k), 'mu': np.asarray(theory.mu), 'wmu_ell': np.asarray(theory.wmu), 'k11': np.asarray(tmpl.k),
+         'pk_dd_fid': np.asarray(tmpl.pk_dd_fid), 'f_fid': float(tmpl.f_fid), 'nd': theory.nd, 'eta': tmpl.eta, 'matrix_full': np.asarray(wm.matrix_full),
+         'shotnoisein': np.asarray(wm.shotnoisein), 'shotnoiseout': np.asarray(wm.shotnoiseout), 'flatdata': np.asarray(obs.flatdata), 'template': tmpl.__class__.__name__}
+    save('simple_tracer', names=np.array(names), theta=theta, obs0=c, precision=np.asarray(like.precision), covariance=cov,
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]),
+         logposterior=np.asarray(logpost), loglikelihood=np.asarray(derived[like._param_loglikelihood]), logprior=np.asarray(derived[like._param_logprior]),
+         power=np.array(power), flattheory=np.array(flat))
+    print(names)
+
+
 def kaiser_xi(eft=False):
     """Full-shape correlation function multipoles: (EFT-like) Kaiser P_ell -> xi_ell through get_corr (tgc/base.py:46-139; FFTLog = the refstub's transform,
     third-party in the reference) with a ShapeFit template, ell = (0, 2, 4), 30 s-bins."""
@@ -505,7 +537,7 @@ def kaiser_xi(eft=False):
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -515,6 +547,7 @@ if __name__ == '__main__':
     if 'cfg4' in todo: cfg4('xi')
     if 'cfg4_pk' in todo: cfg4('pk')
     if 'cfg2_fc_syst' in todo: cfg2_fc_syst()
+    if 'simple_tracer' in todo: simple_tracer()
     if 'kaiser_xi' in todo: kaiser_xi(False)
     if 'kaiser_xi_eft' in todo: kaiser_xi(True)
     if 'cfg3_table' in todo: cfg3_table()
