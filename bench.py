@@ -218,7 +218,7 @@ def main():
                                'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
                                'flop_per_launch': flops[dominant] * B, 'avg_launch_ms': kernel_ms[dominant]},
                   'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize', 'total', 'event_overhead']}}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not distributed and not args.no_cpu_baseline:   # (the forced single-rank RCCL smoke mode writes log-posteriors into buckets, not `loglike`)
             base, check = cpu_baseline(likelihood, theta_host)
             gpu = loglike[:len(check)].cpu().numpy()
             assert (np.abs(gpu - check) <= 1e-10 * np.maximum(1., np.abs(check))).all(), 'GPU / oracle mismatch in bench'
