@@ -51,7 +51,7 @@
 #define DL_MAX_WIDTH 256   // hidden units per layer (one thread each)
 #define DL_N_VPARS 11      // velocileptors 'pars': b1 b2 bs b3 alpha0 alpha2 alpha4 alpha6 sn0 sn2 sn4 (full_shape.py:1184)
 #define DL_N_MONO 19       // bias monomials (full_shape.py:1185)
-#define DL_MAX_PASS 16     // pass-through columns: linear (broadband) parameters appended to the theory vector
+#define DL_MAX_PASS 32     // pass-through columns: linear (broadband) parameters appended to the theory vector
 #define DL_MAX_SOLVED 16   // analytically solved (marginalised / best-fit) linear parameters
 #define DL_FIR_D 28        // half-width of the convolution that inverts the uniform-knot spline system: |mu|^28 = 1e-16, mu = sqrt(3) - 2
 #define DL_FIR_PAD 32      // zeros either side of the knot values in LDS (>= DL_FIR_D + 4)

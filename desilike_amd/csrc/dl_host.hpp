@@ -298,7 +298,7 @@ inline bool dl_build_emulated_obs(const dl_config& cfg, const std::string& p, in
     d.n_mu = 0; d.n_t = 0;
     const auto& pin = cfg.F(p + "in.pass");
     d.n_pass = (int)(pin.size() / 2);
-    if (d.n_pass > DL_MAX_PASS) { err = p + "at most 16 pass-through parameters supported"; return false; }
+    if (d.n_pass > DL_MAX_PASS) { err = p + "at most 32 pass-through parameters supported"; return false; }
     const auto& mpass = cfg.I(p + "marg.pass");
     for (int c = 0; c < DL_MAX_PASS; ++c) oh.marg_pass[c] = (c < (int)mpass.size()) ? mpass[c] : -1;
     for (int c = 0; c < d.n_pass; ++c) { d.pass_in[c].col = (int32_t)std::lround(pin[2 * c]); d.pass_in[c].pad = 0; d.pass_in[c].value = pin[2 * c + 1]; }
@@ -354,7 +354,7 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     {
         const auto& pin = cfg.F(p + "in.pass");
         d.n_pass = (int)(pin.size() / 2);
-        if (d.n_pass > DL_MAX_PASS) { err = p + "at most 16 pass-through (broadband) parameters supported"; return false; }
+        if (d.n_pass > DL_MAX_PASS) { err = p + "at most 32 pass-through (broadband) parameters supported"; return false; }
         const auto& mpass = cfg.I(p + "marg.pass");
         for (int c = 0; c < DL_MAX_PASS; ++c) oh.marg_pass[c] = (c < (int)mpass.size()) ? mpass[c] : -1;
         for (int c = 0; c < d.n_pass; ++c) {

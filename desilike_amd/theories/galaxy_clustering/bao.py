@@ -6,7 +6,9 @@ Host-side mirrors of ``DampedBAOWigglesTracerPowerSpectrumMultipoles`` (422-560)
 (``dl_bao_kernel``); everything downstream is linear and constant, so it is folded into the window matrix once at compile time:
 the broadband matrices, and for the correlation function the whole P_ell -> xi_ell chain of ``get_corr``
 (theories/galaxy_clustering/base.py:127-136: log-k interpolation, damped tail, FFTLog, interpolation to s) as one Hankel operator
-(:func:`desilike_amd.fftlog.hankel_operator`).  Other wiggle models / kernel broadbands of the reference are not implemented (raise).
+(:func:`desilike_amd.fftlog.hankel_operator`).  Broadband parameterisations: powers of k / s ('power', 'power3', 'even-power') and sums of
+mass-assignment-like kernels in Fourier space ('ngp', 'cic', 'tsc', 'pcs'; 'pcs2' for the correlation function), bao.py:468-523, 833-905 -- all
+constant matrices.  Other wiggle models of the reference are not implemented (raise).
 """
 import re
 
@@ -24,6 +26,35 @@ _BAO_PARAMS = {'b1': dict(prior=dict(limits=[0.2, 4.]), ref=dict(limits=[1.5, 2.
                'sigmaper': dict(value=6., prior=dict(limits=[0.1, 10.]), latex=r'\Sigma_{\perp}', fixed=True)}
 
 
+_KERNELS = ('ngp', 'cic', 'tsc', 'pcs')
+
+
+def _kernel_func(x, kernel='tsc'):
+    """B-spline kernels of order 0-3 at distance ``x >= 0`` from the node, in units of the node spacing (bao.py:43-60)."""
+    x = np.asarray(x, dtype='f8')
+    if kernel == 'ngp':
+        return np.where(x < 0.5, 1., 0.)
+    if kernel == 'cic':
+        return np.where(x < 1., 1. - x, 0.)
+    if kernel == 'tsc':
+        return np.where(x < 0.5, 0.75 - x**2, np.where(x < 1.5, 0.5 * (1.5 - x)**2, 0.))
+    if kernel == 'pcs':
+        return np.where(x < 1., (4. - 6. * x**2 + 3. * x**3) / 6., np.where(x < 2., (2. - x)**3 / 6., 0.))
+    raise ValueError('Unknown kernel: {}'.format(kernel))
+
+
+def _get_orders(base, params, ells):
+    """{ell: {parameter name: index}} of the parameters '<base><ell>_<index>'; parameters of multipoles not in use are dropped (bao.py:24-41)."""
+    orders = {ell: {} for ell in ells}
+    for param in list(params):
+        match = re.match(base + '(.*)_(.*)$', param.basename)
+        if match:
+            ell, index = int(match.group(1)), int(match.group(2))
+            if ell in orders: orders[ell][param.name] = index
+            else: del params[param.name]
+    return orders
+
+
 class _BaseDampedBAOTracer(BaseCalculator):
     _kind = 2   # DL_THEORY_BAO_DAMPED
     _klim = (1e-4, 1., 2000)   # template knots, bao.py:67
@@ -32,13 +63,34 @@ class _BaseDampedBAOTracer(BaseCalculator):
 
     @classmethod
     def _default_params(cls, broadband='power', **kwargs):
+        """bao.py:462-481 (power spectrum) / 833-853 (correlation function)."""
         import copy
-        if broadband != 'power':
-            raise NotImplementedError('only the "power" broadband is implemented on the GPU path')
+        broadband = str(broadband)
         params = copy.deepcopy(_BAO_PARAMS)
-        for ell in (0, 2, 4):
-            for pow in cls._powers:
-                params['al{:d}_{:d}'.format(ell, pow)] = dict(value=0., ref=dict(limits=list(cls._ref_limits)), delta=0.005, latex='a_{{{:d}, {:d}}}'.format(ell, pow))
+        if 'power' in broadband:
+            for ell in (0, 2, 4):
+                for pow in cls._powers:
+                    param = dict(value=0., ref=dict(limits=list(cls._ref_limits)), delta=0.005, latex='a_{{{:d}, {:d}}}'.format(ell, pow))
+                    if broadband == 'power3' and pow not in (-2, -1, 0): param.update(fixed=True)
+                    if cls._space == 'xi' and broadband == 'even-power' and pow not in (0, 2): param.update(fixed=True)
+                    params['al{:d}_{:d}'.format(ell, pow)] = param
+        elif broadband[:3] in _KERNELS:
+            for ell in (0, 2, 4):
+                if cls._space == 'pk':
+                    for ik in range(-2, 10):   # loose prior "just to regularize the fit"
+                        params['al{:d}_{:d}'.format(ell, ik)] = dict(value=0., prior=dict(dist='norm', loc=0., scale=1e4), ref=dict(limits=[-1e-2, 1e-2]), delta=0.005,
+                                                                       latex='a_{{{:d}, {:d}}}'.format(ell, ik))
+                else:
+                    for ik in range(-2, 3):    # infinite prior
+                        param = dict(value=0., prior=None, ref=dict(limits=[-1e2, 1e2]), delta=0.005, latex='a_{{{:d}, {:d}}}'.format(ell, ik))
+                        if broadband == 'pcs2' and (ell == 0 or ik not in (0, 1)): param.update(fixed=True)
+                        params['al{:d}_{:d}'.format(ell, ik)] = param
+            if cls._space == 'xi':   # the powers of s come after the Fourier-space kernels (they belong to the correlation function calculator, bao.py:885-890)
+                for ell in (0, 2, 4):
+                    for ik in (0, 2):
+                        params['bl{:d}_{:d}'.format(ell, ik)] = dict(value=0., ref=dict(limits=[-1e-3, 1e-3]), delta=0.005, latex='b_{{{:d}, {:d}}}'.format(ell, ik))
+        else:
+            raise ValueError('Unknown kernel: {}'.format(broadband))
         return params
 
     def _init_wiggles(self, k):
@@ -67,13 +119,32 @@ class _BaseDampedBAOTracer(BaseCalculator):
         if template.apmode != 'qparqper':
             pass
         # broadband orders (bao.py:24-41): parameters al{ell}_{pow} of the multipoles in use; others are dropped
-        self.broadband_orders = {ell: {} for ell in self.ells}
-        for param in list(self.init.params):
-            match = re.match('al(.*)_(.*)', param.basename)
-            if match:
-                ell, pow = int(match.group(1)), int(match.group(2))
-                if ell in self.ells: self.broadband_orders[ell][param.name] = pow
-                else: del self.init.params[param.name]
+        self.broadband = str(init.get('broadband', 'power'))
+        self.broadband_orders = _get_orders('al', self.init.params, self.ells)
+
+    def _pknow_fid(self, k):
+        """No-wiggle fiducial power at ``k``: cubic interpolation in log10 k on the template knots (``_interp(template, 'pknow_dd_fid', k)``, bao.py:18-19)."""
+        from scipy import interpolate
+        return interpolate.interp1d(np.log10(self.template.k), self.template.pknow_dd_fid, kind='cubic', fill_value='extrapolate', assume_sorted=True)(np.log10(k))
+
+    def _kernel_broadband_matrix(self, k, kp, kernel):
+        """[n_ell * len(k), n_bb]: kernel(|k / kp - ik|) scaled by the no-wiggle power at the node (bao.py:505-516); nodes whose kernel vanishes on ``k`` are dropped,
+        and so are their parameters."""
+        columns, names = [], []
+        for ill, ell in enumerate(self.ells):
+            kept = {}
+            for name, ik in self.broadband_orders[ell].items():
+                kern = _kernel_func(np.abs(k / kp - ik), kernel=kernel)
+                if not np.allclose(kern, 0., rtol=0., atol=1e-8):
+                    column = np.zeros((len(self.ells), len(k)), dtype='f8')
+                    column[ill] = kern * self._pknow_fid(np.clip(ik * kp, k[0], k[-1]))
+                    columns.append(column.ravel()); names.append(name)
+                    kept[name] = ik
+                else:
+                    del self.init.params[name]
+            self.broadband_orders[ell] = kept
+        matrix = np.array(columns, dtype='f8').T if columns else np.zeros((len(self.ells) * len(k), 0), dtype='f8')
+        return names, matrix
 
     def _broadband_matrix(self, x, xp):
         """[n_ell * len(x), n_bb]: columns (x / xp)^pow of each multipole's broadband parameters (bao.py:497-499)."""
@@ -109,6 +180,7 @@ class _BaseDampedBAOTracer(BaseCalculator):
 class DampedBAOWigglesTracerPowerSpectrumMultipoles(_BaseDampedBAOTracer):
     """BAO power spectrum multipoles with broadband terms (bao.py:422-560, 117-151)."""
     _powers = range(-3, 2)
+    _space = 'pk'
 
     def initialize(self):
         if self._initialized:
@@ -119,7 +191,10 @@ class DampedBAOWigglesTracerPowerSpectrumMultipoles(_BaseDampedBAOTracer):
         self.k = self.kin
         kp = self.init.get('kp', None)
         self.kp = 2. * np.pi / self.template.fiducial.rs_drag if kp is None else float(kp)   # bao.py:488
-        self._broadband_names, self.broadband_matrix = self._broadband_matrix(self.k, self.kp)
+        if 'power' in self.broadband:
+            self._broadband_names, self.broadband_matrix = self._broadband_matrix(self.k, self.kp)
+        else:
+            self._broadband_names, self.broadband_matrix = self._kernel_broadband_matrix(self.k, self.kp, self.broadband)
         self._initialized = True
         return self
 
@@ -132,6 +207,7 @@ class DampedBAOWigglesTracerCorrelationFunctionMultipoles(_BaseDampedBAOTracer):
     """BAO correlation function multipoles with broadband terms (bao.py:790-960; Hankel transform tgc/base.py:46-139)."""
     _powers = range(-2, 3)
     _ref_limits = (-1e-3, 1e-3)
+    _space = 'xi'
 
     def initialize(self):
         if self._initialized:
@@ -148,10 +224,35 @@ class DampedBAOWigglesTracerCorrelationFunctionMultipoles(_BaseDampedBAOTracer):
         self._init_wiggles(kin)
         sp = self.init.get('sp', None)
         self.sp = 2. * np.pi / 0.02 if sp is None else float(sp)   # bao.py:855
-        self._broadband_names, self.broadband_matrix = self._broadband_matrix(self.s, self.sp)
         self._kfft, self._hankel = kfft, None
+        self._fourier_broadband = None
+        if 'power' in self.broadband:
+            self._broadband_names, self.broadband_matrix = self._broadband_matrix(self.s, self.sp)
+        else:
+            # kernels in Fourier space (bao.py:861-863: the power spectrum class with this broadband, Hankel-transformed with it) + powers of s for 'bl*' (885-890)
+            self.broadband = self.broadband[:3]
+            kp = self.init.get('kp', None)
+            self.kp = 2. * np.pi / self.template.fiducial.rs_drag if kp is None else float(kp)
+            names_k, self._fourier_broadband = self._kernel_broadband_matrix(self.kin, self.kp, self.broadband)
+            self._bl_orders = _get_orders('bl', self.init.params, self.ells)
+            names_s = [name for ell in self.ells for name in self._bl_orders[ell]]
+            matrix_s = np.zeros((len(self.ells), len(self.s), len(names_s)), dtype='f8')
+            for ill, ell in enumerate(self.ells):
+                for name, pow in self._bl_orders[ell].items():
+                    matrix_s[ill, :, names_s.index(name)] = (self.s / self.sp)**pow
+            self._broadband_names, self._s_broadband = names_k + names_s, matrix_s.reshape(-1, len(names_s))
         self._initialized = True
         return self
+
+    @property
+    def broadband_matrix(self):
+        if self._fourier_broadband is None:
+            return self._broadband_matrix_s
+        return np.hstack([self._hankel_block.dot(self._fourier_broadband), self._s_broadband])
+
+    @broadband_matrix.setter
+    def broadband_matrix(self, value):
+        self._broadband_matrix_s = value
 
     @property
     def hankel(self):

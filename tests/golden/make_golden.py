@@ -415,6 +415,60 @@ def syst_template_0(ell, k):
     return 1e3 * (ell == 0) / (1. + (k / 0.02)**2)
 
 
+def cfg4_kernel_broadband(space='xi'):
+    """Damped BAO with the kernel broadbands (bao.py:468-523, 833-905): 'pcs' for P_ell (cubic B-spline nodes every kp, scaled by the no-wiggle power), 'pcs2' for
+    xi_ell (the same kernels Hankel-transformed with the multipoles + powers of s: bl*)."""
+    from desilike.theories.galaxy_clustering import BAOPowerSpectrumTemplate, DampedBAOWigglesTracerCorrelationFunctionMultipoles, DampedBAOWigglesTracerPowerSpectrumMultipoles
+    from desilike.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable
+    template = BAOPowerSpectrumTemplate(z=0.5)
+    if space == 'xi':
+        theory = DampedBAOWigglesTracerCorrelationFunctionMultipoles(template=template, mode='recsym', broadband='pcs2')
+        obs = TracerCorrelationFunctionMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, s=np.linspace(22.5, 167.5, 30), ells=(0, 2), theory=theory)
+        n, scale = 60, 3e-4
+    else:
+        theory = DampedBAOWigglesTracerPowerSpectrumMultipoles(template=template, broadband='pcs')
+        obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, kedges=np.linspace(0.02, 0.3, 57), ells=(0, 2), wmatrix={'resolution': 3}, theory=theory)
+        n, scale = 112, 30.
+    rng = np.random.RandomState(4)
+    A = rng.standard_normal((n, n)) * scale
+    cov = A.dot(A.T) + (10. * scale)**2 * np.eye(n)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+    like()
+    names = like.varied_params.names()
+    theta = sample_theta(like, 16, seed=39)
+    vlike = vmap(like, backend=None, errors='return', return_derived=True)
+    (logpost, derived), errors = vlike({name: theta[:, i] for i, name in enumerate(names)})
+    assert not errors
+    power, corr, flat = [], [], []
+    for row in theta:
+        like(**dict(zip(names, row)))
+        pt = theory.pt
+        power.append(np.asarray(pt.power).copy())
+        corr.append(np.asarray(theory.corr if space == 'xi' else theory.power).copy())
+        flat.append(np.asarray(like.flattheory).copy())
+    ptheory = theory.power if space == 'xi' else theory      # the tracer power spectrum class carrying the Fourier-space kernels
+    knames = [name for ell in ptheory.ells for name in ptheory.broadband_orders[ell]]
+    kmat = np.zeros((len(ptheory.ells), len(ptheory.k), len(knames)))
+    for ill, ell in enumerate(ptheory.ells):
+        for name, row in zip(ptheory.broadband_orders[ell], np.asarray(ptheory.broadband_matrix[ell])):
+            kmat[ill, :, knames.index(name)] = row
+    c = {'flatdata': np.asarray(obs.flatdata), 'kin': np.asarray(ptheory.k), 'kp': ptheory.kp, 'kernel_params': np.array(knames), 'kernel_matrix': kmat}
+    if space == 'xi':
+        snames = [name for ell in theory.ells for name in theory.broadband_orders[ell]]
+        smat = np.zeros((len(theory.ells), len(theory.s), len(snames)))
+        for ill, ell in enumerate(theory.ells):
+            for name, row in zip(theory.broadband_orders[ell], np.asarray(theory.broadband_matrix[ell])):
+                smat[ill, :, snames.index(name)] = row
+        c.update(s=np.asarray(theory.s), sp=theory.sp, s_params=np.array(snames), s_matrix=smat)
+    else:
+        c.update(matrix_full=np.asarray(obs.wmatrix.matrix_full), shotnoisein=np.asarray(obs.wmatrix.shotnoisein), shotnoiseout=np.asarray(obs.wmatrix.shotnoiseout))
+    save('cfg4_bao_' + space + '_pcs', names=np.array(names), theta=theta, obs0=c, precision=np.asarray(like.precision), covariance=cov,
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]),
+         logposterior=np.asarray(logpost), loglikelihood=np.asarray(derived[like._param_loglikelihood]), logprior=np.asarray(derived[like._param_logprior]),
+         wiggle_power=np.array(power), theory=np.array(corr), flattheory=np.array(flat))
+    print(names)
+
+
 def cfg2_fc_syst():
     """Window extras (row a6): top-hat fiber collisions folded into the binning matrix (window.py:428-438, 972-1049) and two systematic templates
     (window.py:439-443, 472-473, 1253-1309), klim row selection on top."""
@@ -537,7 +591,7 @@ def kaiser_xi(eft=False):
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -546,6 +600,7 @@ if __name__ == '__main__':
     if 'cfg5' in todo: cfg5()
     if 'cfg4' in todo: cfg4('xi')
     if 'cfg4_pk' in todo: cfg4('pk')
+    if 'cfg4_pcs' in todo: cfg4_kernel_broadband('xi'); cfg4_kernel_broadband('pk')
     if 'cfg2_fc_syst' in todo: cfg2_fc_syst()
     if 'simple_tracer' in todo: simple_tracer()
     if 'kaiser_xi' in todo: kaiser_xi(False)
