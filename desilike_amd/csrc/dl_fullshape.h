@@ -89,7 +89,8 @@ struct DlObsDev {
     DlInput sn_in[DL_MAX_EFT];
     // pass-through columns n_in .. n_in + n_pass - 1 of the theory vector: parameters the observable is linear in through a constant
     // matrix folded into the window (BAO broadband terms bao.py:495-534, 881-905)
-    int32_t n_pass, bao_mode;              // bao_mode: 0 = '' / 'recsym', 1 = 'reciso' (bao.py:131)
+    int32_t n_pass, bao_mode;              // bao_mode bits 0-3: 0 = '' / 'recsym', 1 = 'reciso' (bao.py:131); bits 4-7: wiggle model, 0 = 'standard' (bao.py:123-136), else
+                                           // 8 | (1: 'fix-damping') | (2: 'move-all') | (4: 'fog-damping') (bao.py:137-150)
     DlInput pass_in[DL_MAX_PASS];
     DlInput dbeta, sigmas;                 // BAO wiggle model (bao.py:117)
     double smoothing_radius;
@@ -727,7 +728,7 @@ DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& 
 // memory (L1 / L2 resident).  Phase A: per-mu AP factors; phase B: one k per thread, mu loop unrolled by 4; output staged in LDS.
 // ------------------------------------------------------------------------------------------------------------------------
 enum { DL_BAO_QPER = 0, DL_BAO_F, DL_BAO_B1, DL_BAO_SIGS, DL_BAO_LQ = 8, DL_BAO_FAC = DL_BAO_LQ + DL_MAX_MU, DL_BAO_MUP2 = DL_BAO_FAC + DL_MAX_MU,
-       DL_BAO_SD = DL_BAO_MUP2 + DL_MAX_MU, DL_BAO_PT = DL_BAO_SD + DL_MAX_MU };
+       DL_BAO_SD = DL_BAO_MUP2 + DL_MAX_MU, DL_BAO_SDF = DL_BAO_SD + DL_MAX_MU, DL_BAO_PT = DL_BAO_SDF + DL_MAX_MU };
 
 DL_HD size_t dl_bao_shared_doubles(int n_in) { return DL_BAO_PT + (size_t)n_in; }
 
@@ -745,8 +746,9 @@ DL_HD void dl_bao_phaseA(int tid, int nthr, const DlObsDev& o, const double* th,
             lds[DL_BAO_LQ + tid] = log10(fac / qper);
             lds[DL_BAO_MUP2 + tid] = mup * mup;
             lds[DL_BAO_SD + tid] = sigpar * sigpar * (mup * mup) + sigper * sigper * (1. - mup * mup);   // bao.py:129
+            lds[DL_BAO_SDF + tid] = sigpar * sigpar * (mu * mu) + sigper * sigper * (1. - mu * mu);       // 'fix-damping': fiducial mu (bao.py:137-138)
         } else if (tid < ((o.n_mu + 3) & ~3)) {
-            lds[DL_BAO_FAC + tid] = 0.; lds[DL_BAO_LQ + tid] = 0.; lds[DL_BAO_MUP2 + tid] = 0.; lds[DL_BAO_SD + tid] = 0.;
+            lds[DL_BAO_FAC + tid] = 0.; lds[DL_BAO_LQ + tid] = 0.; lds[DL_BAO_MUP2 + tid] = 0.; lds[DL_BAO_SD + tid] = 0.; lds[DL_BAO_SDF + tid] = 0.;
         }
         if (tid == 0) {
             lds[DL_BAO_QPER] = qper;
@@ -760,12 +762,14 @@ DL_HD void dl_bao_phaseA(int tid, int nthr, const DlObsDev& o, const double* th,
 DL_HD void dl_bao_phaseB(int tid, int nthr, const DlObsDev& o, double* lds) {
     const double qper = lds[DL_BAO_QPER], f = lds[DL_BAO_F], b1 = lds[DL_BAO_B1], sigmas = lds[DL_BAO_SIGS];
     const int n_ell = o.n_ell, n_mu = o.n_mu, n_kin = o.n_kin, n_mu4 = (o.n_mu + 3) & ~3;
+    const int reciso = (o.bao_mode & 15) == 1, model = o.bao_mode >> 4;
+    const bool fix_damping = model & 1, move_all = model & 2, fog_damping = model & 4;
     double* out = lds + DL_BAO_PT;
     for (int i = tid; i < n_kin; i += nthr) {
         const double kk = o.kin[i], lk = o.lkin[i], pknow = o.pknow_k[i];
         const double kq = kk / qper;
         double sk = 0.;
-        if (o.bao_mode == 1) { double kr = kk * o.smoothing_radius; sk = exp(-0.5 * (kr * kr)); }   // bao.py:131, fiducial coordinates
+        if (reciso) { double kr = kk * o.smoothing_radius; sk = exp(-0.5 * (kr * kr)); }   // bao.py:131, fiducial coordinates
         double p[DL_MAX_ELL];
 #pragma unroll
         for (int l = 0; l < DL_MAX_ELL; ++l) p[l] = 0.;
@@ -781,14 +785,33 @@ DL_HD void dl_bao_phaseB(int tid, int nthr, const DlObsDev& o, double* lds) {
                 double pkw = fma(fma(fma(c[3], u, c[2]), u, c[1]), u, c[0]);                    // [P_dd - P_now](k')
                 double kap = kq * lds[DL_BAO_FAC + m];
                 double mup2 = lds[DL_BAO_MUP2 + m];
-                double ca = b1 + f * mup2 * (1. - sk);
-                double Cap = ca * ca * exp(-(kap * kap * lds[DL_BAO_SD + m]) / 2.);             // bao.py:129-132
                 double mu = (m < n_mu) ? o.mu[m] : 0.;
-                double sm = sigmas * kk * mu;
-                double den = 1. + sm * sm / 2.;
-                double fog = 1. / (den * den);                                                   // bao.py:133
-                double cb = b1 + f * mu * mu * (1. - sk);
-                pkmu[q] = cb * cb * fog * pknow + Cap * pkw;                                     // bao.py:134-136
+                if (model == 0) {   // 'standard' (Chen 2023)
+                    double ca = b1 + f * mup2 * (1. - sk);
+                    double Cap = ca * ca * exp(-(kap * kap * lds[DL_BAO_SD + m]) / 2.);         // bao.py:129-132
+                    double sm = sigmas * kk * mu;
+                    double den = 1. + sm * sm / 2.;
+                    double fog = 1. / (den * den);                                               // bao.py:133
+                    double cb = b1 + f * mu * mu * (1. - sk);
+                    pkmu[q] = cb * cb * fog * pknow + Cap * pkw;                                 // bao.py:134-136
+                } else {            // bao.py:137-150
+                    const double* cn = o.coef_n + 4 * (size_t)j;
+                    double pknowap = fma(fma(fma(cn[3], u, cn[2]), u, cn[1]), u, cn[0]);        // P_now(k')
+                    // damping of the wiggles: at the fiducial (k, mu) ('fix-damping') or at the distorted ones; SD[m] holds the distorted-mu combination
+                    double snl2 = fix_damping ? kk * kk * lds[DL_BAO_SDF + m] : kap * kap * lds[DL_BAO_SD + m];
+                    double dw = pkw / pknowap * exp(-snl2 / 2.);
+                    // smooth part: everything at the distorted (k', mu') ('move-all') or at the fiducial ones
+                    double ks = move_all ? kap : kk, mus2 = move_all ? mup2 : mu * mu;
+                    double pkn = move_all ? pknowap : pknow;
+                    double sm2 = sigmas * sigmas * ks * ks * mus2;
+                    double den = 1. + sm2 / 2.;
+                    double fog = 1. / (den * den);
+                    double sks = sk;
+                    if (reciso && move_all) { double kr = ks * o.smoothing_radius; sks = exp(-0.5 * (kr * kr)); }
+                    double cb = b1 + f * mus2 * (1. - sks);
+                    double smooth = cb * cb * pkn;
+                    pkmu[q] = fog_damping ? smooth * fog * (1. + dw) : smooth * (fog + dw);     // Beutler 2016 / Howlett 2023
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

@@ -8,7 +8,8 @@ the broadband matrices, and for the correlation function the whole P_ell -> xi_e
 (theories/galaxy_clustering/base.py:127-136: log-k interpolation, damped tail, FFTLog, interpolation to s) as one Hankel operator
 (:func:`desilike_amd.fftlog.hankel_operator`).  Broadband parameterisations: powers of k / s ('power', 'power3', 'even-power') and sums of
 mass-assignment-like kernels in Fourier space ('ngp', 'cic', 'tsc', 'pcs'; 'pcs2' for the correlation function), bao.py:468-523, 833-905 -- all
-constant matrices.  Other wiggle models of the reference are not implemented (raise).
+constant matrices.  Wiggle models: 'standard' and the 'fix-damping' / 'move-all' / 'fog-damping' family of
+``DampedBAOWigglesPowerSpectrumMultipoles`` (bao.py:117-151); the Resummed / Flexible classes are not implemented.
 """
 import re
 
@@ -99,9 +100,10 @@ class _BaseDampedBAOTracer(BaseCalculator):
         self.mode = str(init.get('mode', ''))
         if self.mode not in ['', 'recsym', 'reciso']:
             raise ValueError('Reconstruction mode {} must be one of {}'.format(self.mode, ['', 'recsym', 'reciso']))
-        self.model = str(init.get('model', 'standard'))
+        self.model = str(init.get('model', 'standard'))   # 'standard' (bao.py:123-136) or any combination of 'fix-damping', 'move-all', 'fog-damping' (137-150)
+        self._model_bits = 0
         if self.model != 'standard':
-            raise NotImplementedError('only the wiggle model "standard" (bao.py:125-137) is implemented on the GPU path')
+            self._model_bits = 8 | (1 if 'fix-damping' in self.model else 0) | (2 if 'move-all' in self.model else 0) | (4 if 'fog-damping' in self.model else 0)
         self.smoothing_radius = float(init.get('smoothing_radius', 15.))
         self.kin = np.array(k, dtype='f8')
         self.mu, wmu = utils.weights_mu(init.get('mu', 10), method='leggauss')   # bao.py:109
@@ -159,7 +161,7 @@ class _BaseDampedBAOTracer(BaseCalculator):
         self.initialize()
         template = self.template
         spec = dict(theory=np.array([self._kind], dtype='i4'), nd=[1.], ells_in=np.array(self.ells, dtype='i4'), kin=self.kin, mu=self.mu, wmu_ell=self.wmu,
-                    bao_mode=np.array([1 if self.mode == 'reciso' else 0], dtype='i4'), smoothing_radius=[self.smoothing_radius], pknow_dd_fid=template.pknow_dd_fid)
+                    bao_mode=np.array([(1 if self.mode == 'reciso' else 0) | (self._model_bits << 4)], dtype='i4'), smoothing_radius=[self.smoothing_radius], pknow_dd_fid=template.pknow_dd_fid)
         spec.update(template._template_spec())
         spec['template'] = np.array([0], dtype='i4')   # the BAO template never changes P(k) (power_template.py:372-376)
         return spec

@@ -410,13 +410,24 @@ def get_corr(power, kin, s, ells, k=None, fftlog=None):
     return np.array([np.interp(s, sss, cc) for sss, cc in zip(ss, corr)])
 
 
-def bao_damped_power(k, mu, wmu_ell, k_t, pk_dd, pknow_dd, f, qpar=1., qper=1., b1=1., sigmas=0., sigmapar=9., sigmaper=6., mode='', smoothing_radius=15.):
-    """bao.py:117-140, model 'standard' (Chen 2023); ``f`` already includes dbeta (bao.py:119)."""
+def bao_damped_power(k, mu, wmu_ell, k_t, pk_dd, pknow_dd, f, qpar=1., qper=1., b1=1., sigmas=0., sigmapar=9., sigmaper=6., mode='', smoothing_radius=15., model='standard'):
+    """bao.py:117-151: model 'standard' (Chen 2023) or the 'fix-damping' / 'move-all' / 'fog-damping' family (137-150); ``f`` already includes dbeta (bao.py:119)."""
     jac, kap, muap = ap_k_mu(k, mu, qpar=qpar, qper=qper)
     logkt = np.log10(k_t)
     pknowap = interp1d(np.log10(kap), logkt, pknow_dd, method='cubic')
     pkap = interp1d(np.log10(kap), logkt, pk_dd, method='cubic')
     kk = k[:, None]
+    if model != 'standard':
+        kd, mud = (kk, mu) if 'fix-damping' in model else (kap, muap)                                   # 137-138
+        sigma_nl2 = kd**2 * (sigmapar**2 * mud**2 + sigmaper**2 * (1. - mud**2))
+        damped_wiggles = (pkap - pknowap) / pknowap * np.exp(-sigma_nl2 / 2.)                           # 140
+        ks, mus = (kap, muap) if 'move-all' in model else (kk, mu)                                      # 141-142
+        pknow = interp1d(np.log10(ks * np.ones_like(kap)), logkt, pknow_dd, method='cubic')
+        fog = 1. / (1. + (sigmas * ks * mus)**2 / 2.)**2.
+        sk = np.exp(-1. / 2. * (ks * smoothing_radius)**2) if mode == 'reciso' else 0.
+        pksmooth = (b1 + f * mus**2 * (1 - sk))**2 * pknow
+        pkmu = pksmooth * fog * (1. + damped_wiggles) if 'fog-damping' in model else pksmooth * (fog + damped_wiggles)   # 147-150
+        return np.sum(pkmu * wmu_ell[:, None, :], axis=-1)
     pkwap = pkap - pknowap
     sigma_nl2ap = kap**2 * (sigmapar**2 * muap**2 + sigmaper**2 * (1. - muap**2))
     sk = 0.

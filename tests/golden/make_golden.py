@@ -469,6 +469,51 @@ def cfg4_kernel_broadband(space='xi'):
     print(names)
 
 
+def cfg4_models():
+    """The non-standard wiggle models of DampedBAOWigglesPowerSpectrumMultipoles (bao.py:137-150): Beutler 2016 ('fog-damping_move-all') for P_ell, 'fix-damping' with
+    reciso for xi_ell, and the Howlett 2023 form ('move-all')."""
+    from desilike.theories.galaxy_clustering import BAOPowerSpectrumTemplate, DampedBAOWigglesTracerCorrelationFunctionMultipoles, DampedBAOWigglesTracerPowerSpectrumMultipoles
+    from desilike.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable
+    out = {}
+    for tag, space, model, mode in [('a', 'pk', 'fog-damping_move-all', ''), ('b', 'xi', 'fix-damping', 'reciso'), ('c', 'pk', 'move-all', 'reciso')]:
+        template = BAOPowerSpectrumTemplate(z=0.5)
+        if space == 'xi':
+            theory = DampedBAOWigglesTracerCorrelationFunctionMultipoles(template=template, mode=mode, model=model)
+            obs = TracerCorrelationFunctionMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, s=np.linspace(22.5, 167.5, 30), ells=(0, 2), theory=theory)
+            n, scale = 60, 3e-4
+        else:
+            theory = DampedBAOWigglesTracerPowerSpectrumMultipoles(template=template, mode=mode, model=model)
+            obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, kedges=np.linspace(0.02, 0.3, 57), ells=(0, 2), wmatrix={'resolution': 3}, theory=theory)
+            n, scale = 112, 30.
+        for name in ['sigmapar', 'sigmaper']:
+            theory.init.params[name].update(fixed=False, ref=dict(dist='norm', loc=8., scale=0.5))
+        for param in theory.init.params.select(basename='al*'):
+            param.update(fixed=True)
+        rng = np.random.RandomState(4)
+        A = rng.standard_normal((n, n)) * scale
+        cov = A.dot(A.T) + (10. * scale)**2 * np.eye(n)
+        like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+        like()
+        names = like.varied_params.names()
+        theta = sample_theta(like, 12, seed=49)
+        (logpost, derived), errors = vmap(like, backend=None, errors='return', return_derived=True)({name: theta[:, i] for i, name in enumerate(names)})
+        assert not errors
+        power = []
+        for row in theta:
+            like(**dict(zip(names, row)))
+            power.append(np.asarray(theory.pt.power).copy())
+        pt = theory.pt
+        tmpl = pt.template
+        if tag == 'a':
+            out.update(kin_pk=np.asarray(pt.k), mu=np.asarray(pt.mu), wmu_ell=np.asarray(pt.wmu), k11=np.asarray(tmpl.k), pk_dd_fid=np.asarray(tmpl.pk_dd_fid),
+                       pknow_dd_fid=np.asarray(tmpl.pknow_dd_fid), f_fid=float(tmpl.f_fid))
+        if space == 'xi': out['kin_xi'] = np.asarray(pt.k)
+        out.update({tag + '_names': np.array(names), tag + '_theta': theta, tag + '_flatdata': np.asarray(obs.flatdata), tag + '_covariance': cov, tag + '_model': model, tag + '_mode': mode,
+                    tag + '_space': space, tag + '_wiggle_power': np.array(power), tag + '_loglikelihood': np.asarray(derived[like._param_loglikelihood]),
+                    tag + '_logprior': np.asarray(derived[like._param_logprior])})
+    save('cfg4_bao_models', **out)
+
+
 def cfg2_fc_syst():
     """Window extras (row a6): top-hat fiber collisions folded into the binning matrix (window.py:428-438, 972-1049) and two systematic templates
     (window.py:439-443, 472-473, 1253-1309), klim row selection on top."""
@@ -591,7 +636,7 @@ def kaiser_xi(eft=False):
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -601,6 +646,7 @@ if __name__ == '__main__':
     if 'cfg4' in todo: cfg4('xi')
     if 'cfg4_pk' in todo: cfg4('pk')
     if 'cfg4_pcs' in todo: cfg4_kernel_broadband('xi'); cfg4_kernel_broadband('pk')
+    if 'cfg4_models' in todo: cfg4_models()
     if 'cfg2_fc_syst' in todo: cfg2_fc_syst()
     if 'simple_tracer' in todo: simple_tracer()
     if 'kaiser_xi' in todo: kaiser_xi(False)

@@ -1,0 +1,61 @@
+"""The non-standard wiggle models of DampedBAOWigglesPowerSpectrumMultipoles (bao.py:137-150: 'fix-damping', 'move-all', 'fog-damping' and their combinations)
+against a fixture from the reference (tests/golden/make_golden.py cfg4_models).  CPU: oracle restatement of the wiggle multipoles; GPU (-m gpu): call surface."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as orc
+
+TAGS = ['a', 'b', 'c']
+
+
+def load():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cfg4_bao_models.npz'), allow_pickle=False)
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_bao_models_oracle_vs_reference(tag):
+    g = load()
+    names = [str(n) for n in g[tag + '_names']]
+    kin = g['kin_xi'] if str(g[tag + '_space']) == 'xi' else g['kin_pk']
+    for i, row in enumerate(g[tag + '_theta']):
+        p = dict(zip(names, row))
+        f = p.get('dbeta', 1.) * float(g['f_fid']) * p.get('df', 1.)
+        power = orc.bao_damped_power(kin, g['mu'], g['wmu_ell'], g['k11'], g['pk_dd_fid'], g['pknow_dd_fid'], f, qpar=p['qpar'], qper=p['qper'], b1=p['b1'], sigmas=p.get('sigmas', 0.),
+                                     sigmapar=p['sigmapar'], sigmaper=p['sigmaper'], mode=str(g[tag + '_mode']), smoothing_radius=15., model=str(g[tag + '_model']))
+        ref = g[tag + '_wiggle_power'][i]
+        assert np.allclose(power, ref, rtol=1e-10, atol=1e-11 * np.abs(ref).max())   # two not-a-knot solvers over 2000 knots (scipy's banded solve vs the oracle's): ~1e-12 of the amplitude
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', TAGS)
+def test_bao_models_call_surface_vs_reference(tag):
+    from desilike_amd import vmap
+    from desilike_amd.theories.galaxy_clustering import BAOPowerSpectrumTemplate, DampedBAOWigglesTracerCorrelationFunctionMultipoles, DampedBAOWigglesTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable, TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    g = load()
+    space, model, mode = str(g[tag + '_space']), str(g[tag + '_model']), str(g[tag + '_mode'])
+    template = BAOPowerSpectrumTemplate(z=0.5)
+    if space == 'xi':
+        theory = DampedBAOWigglesTracerCorrelationFunctionMultipoles(template=template, mode=mode, model=model)
+        obs = TracerCorrelationFunctionMultipolesObservable(data=g[tag + '_flatdata'], s=np.linspace(22.5, 167.5, 30), ells=(0, 2), theory=theory)
+    else:
+        theory = DampedBAOWigglesTracerPowerSpectrumMultipoles(template=template, mode=mode, model=model)
+        obs = TracerPowerSpectrumMultipolesObservable(data=g[tag + '_flatdata'], kedges=np.linspace(0.02, 0.3, 57), ells=(0, 2), wmatrix={'resolution': 3}, theory=theory)
+    for name in ['sigmapar', 'sigmaper']:
+        theory.init.params[name].update(fixed=False, ref=dict(dist='norm', loc=8., scale=0.5))
+    for param in theory.init.params.select(basename='al*'):
+        param.update(fixed=True)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=g[tag + '_covariance'])
+    names = [str(n) for n in g[tag + '_names']]
+    assert like.varied_params.names() == names
+    theta = g[tag + '_theta']
+    (logpost, derived), errors = vmap(like, errors='return', return_derived=True)({name: theta[:, i] for i, name in enumerate(names)})
+    assert errors == {}
+    ref = g[tag + '_loglikelihood']
+    assert (np.abs(derived['loglikelihood'] - ref) <= 1e-10 * np.maximum(1., np.abs(ref))).all()
+    assert np.allclose(derived['logprior'], g[tag + '_logprior'], rtol=1e-13, atol=1e-13)
+    power = like._get_context().eval_theory_host(theta, iobs=0)
+    assert np.allclose(power, g[tag + '_wiggle_power'], rtol=1e-11, atol=1e-12 * np.abs(g[tag + '_wiggle_power']).max())
