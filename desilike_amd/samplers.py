@@ -195,3 +195,167 @@ class EmceeSampler(BasePosteriorSampler):
         self.chain = {name: data[name] for name in data.files}
         last = np.column_stack([self.chain[param.name][-1] for param in self.varied_params])
         self._last = (last, self.chain['logposterior'][-1])
+
+
+def _expand_dict(values, names):
+    """Value or {name / wildcard pattern: value} -> {name: value} (utils.expand_dict of the reference)."""
+    import fnmatch
+    if not isinstance(values, dict):
+        return {name: values for name in names}
+    toret = {name: None for name in names}
+    for pattern, value in values.items():
+        for name in fnmatch.filter(names, str(pattern)):
+            toret[name] = value
+    return toret
+
+
+class _BatchEvaluator(object):
+    """Common part of the grid / QMC samplers: ONE batched evaluation of the likelihood on all points (rows sharded over the process group if any),
+    derived outputs and fixed parameters attached like the reference (samplers/grid.py:108-117, samplers/qmc.py:126-141)."""
+
+    def _evaluate(self, samples, errors='raise'):
+        calculator = self.calculator
+        shape = samples.shape
+        flat = {name: np.ravel(value) for name, value in samples.to_dict().items()}
+        names = list(flat)
+        size = flat[names[0]].size if names else 1
+
+        def local(rows):
+            (logposterior, derived), errs = vmap(calculator, errors='return', return_derived=True)({name: rows[:, i] for i, name in enumerate(names)})
+            out = np.column_stack([np.asarray(derived[key], dtype='f8') for key in sorted(derived)])
+            for ipoint in errs: out[ipoint] = np.nan
+            self._derived_names = sorted(derived)
+            return out
+
+        values = np.column_stack([flat[name] for name in names]) if names else np.zeros((size, 0))
+        out = self.sharding.map(local, values)
+        bad = np.isnan(out).any(axis=1)
+        if errors == 'raise' and bad.any():
+            raise ValueError('non-finite evaluation at points {}'.format(np.flatnonzero(bad).tolist()))
+        for param in calculator.all_params:
+            if param.fixed and param.derived is False:
+                samples[param] = np.full(shape, param.value, dtype='f8')
+        for iname, name in enumerate(self._derived_names):
+            samples[name] = out[:, iname].reshape(shape)
+        return samples
+
+
+class GridSampler(_BatchEvaluator):
+    """Evaluate the likelihood on a grid (desilike/samplers/grid.py): ``size`` (int or {name: int}), ``ref_scale``, ``grid`` ({name: values}) as in the reference;
+    ``run()`` returns ``Samples`` with the varied parameters (meshgrid, 'ij'), the fixed ones, and the derived ``loglikelihood`` / ``logprior`` (+ solved parameters)."""
+    name = 'grid'
+
+    def __init__(self, calculator, sharding=None, save_fn=None, **kwargs):
+        self.calculator = calculator
+        self.varied_params = calculator.varied_params
+        self.sharding = sharding if sharding is not None else WalkerSharding()
+        self.save_fn = save_fn
+        self.set_grid(**kwargs)
+
+    def set_grid(self, size=1, ref_scale=1., grid=None):
+        from .parameter import ParameterError
+        self.ref_scale = float(ref_scale)
+        names = self.varied_params.names()
+        grids, sizes = _expand_dict(grid, names), _expand_dict(size, names)
+        self.grid = []
+        for param in self.varied_params:
+            grid, size = grids[param.name], sizes[param.name]
+            if grid is None:
+                if size is None:
+                    raise ValueError('size (and grid) not specified for parameter {}'.format(param.name))
+                size = int(size)
+                if size < 1:
+                    raise ValueError('size is {} < 1 for parameter {}'.format(size, param.name))
+                center, limits = param.value, np.array(param.ref.limits, dtype='f8')
+                if not limits[0] <= center <= limits[1]:
+                    raise ParameterError('Parameter {} value {} is not in reference limits {}'.format(param.name, center, param.ref.limits))
+                if size == 1:
+                    grid = [center]
+                else:   # samplers/grid.py:80-93
+                    if param.ref.is_limited() and param.ref.dist == 'uniform':
+                        edges = self.ref_scale * (limits - center) + center
+                    elif param.proposal:
+                        edges = self.ref_scale * np.array([-param.proposal, param.proposal]) + center
+                    else:
+                        raise ParameterError('Provide proper parameter reference distribution or proposal for {}'.format(param.name))
+                    low, high = np.linspace(edges[0], center, size // 2 + 1), np.linspace(center, edges[1], size // 2 + 1)
+                    grid = np.concatenate([low, high[1:]]) if size % 2 else np.concatenate([low[:-1], high[1:]])
+            else:
+                grid = np.sort(np.ravel(grid))
+            self.grid.append(np.asarray(grid, dtype='f8'))
+        self.samples = Samples(np.meshgrid(*self.grid, indexing='ij'), params=self.varied_params)
+
+    def run(self, **kwargs):
+        if kwargs: self.set_grid(**kwargs)
+        self.samples = self._evaluate(self.samples)
+        if self.save_fn is not None:
+            np.savez(self.save_fn, **self.samples)
+        return self.samples
+
+
+class RQuasiRandomSequence(object):
+    r"""Roberts' additive recurrence R_d: :math:`x_n = (s + n \alpha) \bmod 1`, :math:`\alpha_j = \phi_d^{-(j + 1)}`, :math:`\phi_d` the real root of
+    :math:`x^{d+1} = x + 1` (the reference's default QMC engine, samplers/qmc.py:12-36)."""
+
+    def __init__(self, d, seed=0.5):
+        self.d, self.seed = int(d), float(seed)
+        phi = 1.
+        while abs(phi**(self.d + 1) - phi - 1.) > 1e-12:   # Newton's method
+            phi -= (phi**(self.d + 1) - phi - 1.) / ((self.d + 1) * phi**self.d - 1.)
+        self.alpha = np.array([phi**(-(1 + j)) for j in range(self.d)])
+        self.num_generated = 0
+
+    def random(self, n=1):
+        toret = (self.seed + np.arange(self.num_generated + 1, self.num_generated + n + 1)[:, None] * self.alpha) % 1.
+        self.num_generated += n
+        return toret
+
+    def reset(self):
+        self.num_generated = 0
+        return self
+
+    def fast_forward(self, n):
+        self.num_generated += n
+        return self
+
+
+class QMCSampler(_BatchEvaluator):
+    """Quasi Monte-Carlo sequences (desilike/samplers/qmc.py): engines 'rqrs' (default), 'sobol', 'halton', 'lhs' (scipy.stats.qmc) scaled to
+    ``value +- proposal`` of each varied parameter; non-finite evaluations are kept as NaN (``errors='nan'``), resumable through ``samples`` / ``offset``."""
+    name = 'qmc'
+
+    def __init__(self, calculator, samples=None, sharding=None, engine='rqrs', save_fn=None, **kwargs):
+        self.calculator = calculator
+        self.varied_params = calculator.varied_params
+        self.sharding = sharding if sharding is not None else WalkerSharding()
+        ndim = len(self.varied_params)
+        if engine == 'rqrs':
+            self.engine = RQuasiRandomSequence(ndim, **kwargs)
+        elif isinstance(engine, str):
+            from scipy.stats import qmc
+            self.engine = {'sobol': qmc.Sobol, 'halton': qmc.Halton, 'lhs': qmc.LatinHypercube}[engine](d=ndim, **kwargs)
+        else:
+            self.engine = engine
+        if isinstance(samples, str):
+            data = np.load(samples)
+            samples = Samples({name: data[name] for name in data.files})
+        self.samples = samples
+        self.save_fn = save_fn
+
+    def run(self, niterations=300, offset=None):
+        lower = [param.value - param.proposal for param in self.varied_params]
+        upper = [param.value + param.proposal for param in self.varied_params]
+        self.engine.reset()
+        if offset is None:
+            offset = len(next(iter(self.samples.values()))) if self.samples else 0
+        if offset: self.engine.fast_forward(offset)
+        unit = self.engine.random(n=niterations)
+        samples = Samples((np.asarray(lower) + unit * (np.asarray(upper) - np.asarray(lower))).T, params=self.varied_params)
+        samples = self._evaluate(samples, errors='nan')
+        if self.samples:
+            self.samples = Samples({name: np.concatenate([self.samples[name], samples[name]]) for name in samples})
+        else:
+            self.samples = samples
+        if self.save_fn is not None:
+            np.savez(self.save_fn, **self.samples)
+        return self.samples

@@ -36,3 +36,20 @@ def test_ensemble_sampler_on_gpu():
     ll, lp, st = like.evaluate_batch(torch.as_tensor(theta, dtype=torch.float64, device='cuda:0'))
     torch.cuda.synchronize()
     assert np.allclose((ll + lp).cpu().numpy(), sampler.logposterior(theta), rtol=1e-12, atol=1e-10)
+
+
+def test_grid_and_qmc_samplers_on_gpu():
+    """samplers/grid.py, samplers/qmc.py: the whole grid / sequence is one batched evaluation; same numbers as the vmap surface, marginalised parameters attached."""
+    from desilike_amd import vmap
+    from desilike_amd.samplers import GridSampler, QMCSampler
+    g, like = make_cfg5()
+    names = like.varied_params.names()
+    size = {name: 1 for name in names}
+    size.update({'LRG.b1': 5, 'qpar': 3})
+    samples = GridSampler(like, size=size).run()
+    shape = tuple(size[name] for name in names)
+    assert samples['LRG.b1'].shape == shape
+    (logpost, derived), errors = vmap(like, errors='return', return_derived=True)({name: samples[name] for name in names})
+    assert errors == {} and np.array_equal(samples['loglikelihood'], derived['loglikelihood']) and np.array_equal(samples['logprior'], derived['logprior'])
+    qmc = QMCSampler(like).run(niterations=64)
+    assert qmc['loglikelihood'].shape == (64,) and np.isfinite(qmc['loglikelihood']).all()

@@ -180,3 +180,46 @@ def test_bucketed_allgather_gloo_world2():
                     step = int(row[0] // 1000)
                     if (row == 0.).all(): continue   # unused tail of the partial bucket
                     assert np.array_equal(row, np.arange(5) + 100. * r + 1000. * step)
+
+
+class ToyWithFixed(ToyGaussianLikelihood):
+    """+ ``all_params`` (one fixed parameter) for the grid / QMC samplers, which attach fixed parameters to their output (samplers/grid.py:112-113)."""
+
+    def __init__(self):
+        super(ToyWithFixed, self).__init__()
+        self.all_params = ParameterCollection(list(self.varied_params) + [Parameter('c', value=3., fixed=True)])
+
+
+def test_grid_sampler():
+    from desilike_amd.samplers import GridSampler
+    like = ToyWithFixed()
+    sampler = GridSampler(like, size={'a': 5, 'b': 4}, ref_scale=0.5)
+    samples = sampler.run()
+    assert samples['a'].shape == (5, 4) and samples['loglikelihood'].shape == (5, 4)
+    # 'a': uniform reference [-1, 1] around its centre 0, scaled by 0.5; 'b': value +- proposal (= reference std 1), even size drops the centre once (samplers/grid.py:80-93)
+    assert np.allclose(sampler.grid[0], np.linspace(-0.5, 0.5, 5)) and np.allclose(sampler.grid[1], [-0.5, -0.25, 0.25, 0.5])
+    x = np.stack([samples['a'], samples['b']], axis=-1) - like.mean
+    assert np.allclose(samples['loglikelihood'], -0.5 * np.einsum('...j,jk,...k->...', x, like.precision, x))
+    assert np.allclose(samples['logprior'], -0.5 * (samples['b'] / 10.)**2) and np.all(samples['c'] == 3.)
+    assert like.ncalls == 1                                                      # the whole grid is ONE batched evaluation
+    samples = sampler.run(grid={'a': [0.2, 0.1], 'b': [0.]})
+    assert samples['a'].shape == (2, 1) and np.allclose(samples['a'][:, 0], [0.1, 0.2])
+
+
+def test_qmc_sampler():
+    from desilike_amd.samplers import QMCSampler, RQuasiRandomSequence
+    seq = RQuasiRandomSequence(2).random(3)
+    plastic = 1.32471795724474602596                                            # real root of x^3 = x + 1
+    expected = (0.5 + np.arange(1, 4)[:, None] * np.array([1. / plastic, 1. / plastic**2])) % 1.
+    assert np.allclose(seq, expected, rtol=0., atol=1e-12) and np.allclose(seq[0], [0.2548776662, 0.0698402910], atol=1e-9)
+    like = ToyWithFixed()
+    sampler = QMCSampler(like)
+    samples = sampler.run(niterations=10)
+    assert samples['a'].shape == (10,) and np.isfinite(samples['loglikelihood']).all()
+    lower, upper = np.array([p.value - p.proposal for p in like.varied_params]), np.array([p.value + p.proposal for p in like.varied_params])
+    unit = RQuasiRandomSequence(2).random(15)
+    assert np.allclose(np.column_stack([samples['a'], samples['b']]), lower + unit[:10] * (upper - lower))
+    samples = sampler.run(niterations=5)                                        # resumes after the 10 points already drawn
+    assert samples['a'].shape == (15,) and np.allclose(np.column_stack([samples['a'], samples['b']]), lower + unit * (upper - lower))
+    sobol = QMCSampler(like, engine='sobol', seed=3).run(niterations=8)
+    assert sobol['a'].shape == (8,) and (np.abs(sobol['a']) <= upper[0]).all()
