@@ -589,7 +589,7 @@ __device__ __forceinline__ double dl_lane_cholesky(double (&a)[16], double (&inv
 // Tt_s = tconst[s] (+ row 1 + var_slot[s] of the point when the derivative depends on the point).
 // ------------------------------------------------------------------------------------------------
 // LANES: lane-parallel algebra (n_s <= 15, no scratch memory); otherwise the serial fallback (n_s = 16) is compiled
-template <bool LANES>
+template <bool LANES, bool STAGED>
 __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* __restrict__ dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride,
                                                                const double* __restrict__ bias, DlMargDev mg,
                                                                const double* __restrict__ theta, int n_params, const double* __restrict__ priors, int64_t B,
@@ -608,7 +608,22 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
     double chi2 = 0.;
     double HL[DL_MAX_SOLVED * (DL_MAX_SOLVED + 1) / 2];   // lower triangle of -H_L = Tt Tt^T (lane-uniform)
     double gL[DL_MAX_SOLVED];                              // Tt dt = -g_L
-    __shared__ double gram_lds[4][16 * 16];
+    // priors of the sampled parameters: the loads are issued first so that their round trip overlaps the staging of the Gram operands
+    double lp = 0.;
+    int nan_in = 0;
+    const double inf = __builtin_huge_val();
+    for (int p = lane; p < n_params; p += 64) {
+        double x = theta[(size_t)b * n_params + p];
+        const double* pr = priors + 5 * p;
+        if (x != x) nan_in = 1;
+        bool isin = (pr[1] <= x) && (x <= pr[2]);
+        double v = 0.;
+        if (pr[0] == 1.) { double t = x - pr[3]; v = -0.5 * (t * t) / (pr[4] * pr[4]); }
+        lp += isin ? v : -inf;
+    }
+    __shared__ double gram_lds[4][STAGED ? 2 : 16 * 16];   // (staged variant: G and the Cholesky rows reuse the wave's staging area)
+    double* Gw = gram_lds[wave];
+    double* Cw = nullptr;
     if (LANES) {
         // Gram matrix of X = [dt; Tt_1 .. Tt_ns] (1 + ns <= 16 rows, n columns) with v_mfma_f64_16x16x4_f64: the A operand of lane l is X[l & 15][4 k + (l >> 4)]
         // and the B operand X^T[4 k + (l >> 4)][l & 15] -- the same register.  chi2 = G[0][0], Tt dt = G[0][1 + s], Tt Tt^T = G[1 + s][1 + t].
@@ -625,6 +640,42 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
         }
         dl_double4 acc = {0., 0., 0., 0.};
         const int n_ks = (n + 3) / 4;
+        if (STAGED) {
+            // Rows of X staged in LDS by coalesced 16-byte loads, ALL in flight at once (one memory round trip instead of one per batch of k-steps:
+            // the direct operand loads below touch 16 different rows per instruction and were 12.7 us of a 20 us workgroup life), constant and point-dependent
+            // parts added on the way in; the MFMA operands then come from LDS.  Per wave: (1 + ns) rows of `stride` doubles.
+            extern __shared__ __attribute__((aligned(16))) double dl_fm_dyn[];
+            const int rows = 1 + ns, n4 = 4 * n_ks, stride = n4 + 4;
+            const int region = rows * stride > 512 ? rows * stride : 512;   // doubles per wave: the staged rows, then G [16][16] | Cholesky rows [16][16] in the same place
+            double* X = dl_fm_dyn + (size_t)wave * region;
+            Gw = X; Cw = X + 256;
+            for (int c0 = 2 * lane; c0 < n4; c0 += 128) {
+#pragma unroll 4
+                for (int r = 0; r < rows; ++r) {
+                    const double* cp = (r == 0) ? bias : mg.tconst + (size_t)(r - 1) * ld;
+                    const int vs = (r == 0) ? 0 : mg.var_slot[r - 1];
+                    const double* vp = (r == 0) ? row0 : (vs >= 0 ? row0 + (size_t)(1 + vs) * ld : nullptr);
+                    dl_double2 v = {0., 0.};
+                    if (cp) v = *reinterpret_cast<const dl_double2*>(cp + c0);
+                    if (vp) for (int sl = 0; sl < n_slabs; ++sl) v += *reinterpret_cast<const dl_double2*>(vp + (size_t)sl * slab_stride + c0);
+                    if (c0 >= n) v.x = 0.;
+                    if (c0 + 1 >= n) v.y = 0.;
+                    *reinterpret_cast<dl_double2*>(X + (size_t)r * stride + c0) = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool live = xr <= ns;
+            const double* xrow = X + (size_t)(live ? xr : 0) * stride + g;
+            for (int k0 = 0; k0 < n_ks; k0 += 8) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = (live && k0 + u < n_ks) ? xrow[4 * (k0 + u)] : 0.;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], x[u], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();   // every operand read of this wave precedes the overwrite of the staging area by G
+        } else
         for (int k0 = 0; k0 < n_ks; k0 += 8) {
             double x[8];
 #pragma unroll
@@ -643,7 +694,7 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
         DL_FM_STAMP(1)
         // C layout: register r of lane l = G[(l >> 4) + 4 r][l & 15]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gram_lds[wave][(g + 4 * r) * 16 + xr] = acc[r];
+        for (int r = 0; r < 4; ++r) Gw[(g + 4 * r) * 16 + xr] = acc[r];
         __syncthreads();
         DL_FM_STAMP(2)
         // (the lane-parallel solve below reads G from LDS)
@@ -696,26 +747,13 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
         }
     }
     }
-    // priors of the sampled parameters
-    double lp = 0.;
-    int nan_in = 0;
-    const double inf = __builtin_huge_val();
-    for (int p = lane; p < n_params; p += 64) {
-        double x = theta[(size_t)b * n_params + p];
-        const double* pr = priors + 5 * p;
-        if (x != x) nan_in = 1;
-        bool isin = (pr[1] <= x) && (x <= pr[2]);
-        double v = 0.;
-        if (pr[0] == 1.) { double t = x - pr[3]; v = -0.5 * (t * t) / (pr[4] * pr[4]); }
-        lp += isin ? v : -inf;
-    }
     lp = dl_wave_sum(lp);
     nan_in = __any(nan_in);
     if (LANES) {
         // ---- lane-parallel solve (lane i <-> solved parameter i) ----
-        const double* G = gram_lds[wave];
-        __shared__ double chol_lds[4][16 * 16];
-        double* Cm = chol_lds[wave];
+        const double* G = Gw;
+        __shared__ double chol_lds[4][STAGED ? 2 : 16 * 16];
+        double* Cm = STAGED ? Cw : chol_lds[wave];
         double prec_i = 0., x0_i = 0., loc_i = 0.;
         int marg_i = 0;
 #pragma unroll
@@ -900,11 +938,18 @@ void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_p
     if (stamp_file && !stamps_dev) (void)hipMalloc((void**)&stamps_dev, (size_t)65536 * 8 * sizeof(unsigned long long));
     unsigned long long* stamps = (stamp_file && grid <= 65536 && B >= 256 && stamp_launches >= 10 && stamp_launches < 12) ? stamps_dev : nullptr;
     if (stamp_file && B >= 256) stamp_launches++;
-    if (mg.n_s < 16)
-        hipLaunchKernelGGL(dl_finalize_marg_kernel<true>, dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
+    static const bool allow_staged = !getenv("DL_FM_NO_STAGE");   // DL_FM_NO_STAGE=1: operands of the Gram product straight from global memory (comparison)
+    const size_t region = std::max<size_t>((size_t)(1 + mg.n_s) * (((n + 3) & ~3) + 4), 512);
+    const size_t shm = 4 * region * sizeof(double);   // staged rows of the four waves (reused for G and the Cholesky rows)
+    if (mg.n_s < 16 && allow_staged && shm <= 96 * 1024) {
+        if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_finalize_marg_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL((dl_finalize_marg_kernel<true, true>), dim3(grid), dim3(256), shm, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
+                           n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps);
+    } else if (mg.n_s < 16)
+        hipLaunchKernelGGL((dl_finalize_marg_kernel<true, false>), dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
                            n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps);
     else
-        hipLaunchKernelGGL(dl_finalize_marg_kernel<false>, dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
+        hipLaunchKernelGGL((dl_finalize_marg_kernel<false, false>), dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
                            n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps);
     if (stamps) {
         (void)hipStreamSynchronize(stream);
