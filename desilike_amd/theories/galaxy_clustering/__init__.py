@@ -2,5 +2,6 @@ from .power_template import (BasePowerSpectrumTemplate, FixedPowerSpectrumTempla
                              ShapeFitPowerSpectrumTemplate, BAOPowerSpectrumTemplate)
 from .full_shape import (KaiserTracerPowerSpectrumMultipoles, SimpleTracerPowerSpectrumMultipoles, EFTLikeKaiserTracerPowerSpectrumMultipoles, KaiserTracerCorrelationFunctionMultipoles,
                          EFTLikeKaiserTracerCorrelationFunctionMultipoles, LPTVelocileptorsTracerPowerSpectrumMultipoles,
-                         REPTVelocileptorsTracerPowerSpectrumMultipoles, EmulatedTracerPowerSpectrumMultipoles)
+                         REPTVelocileptorsTracerPowerSpectrumMultipoles, EmulatedTracerPowerSpectrumMultipoles,
+                         LPTVelocileptorsTracerCorrelationFunctionMultipoles, REPTVelocileptorsTracerCorrelationFunctionMultipoles)
 from .bao import DampedBAOWigglesTracerPowerSpectrumMultipoles, DampedBAOWigglesTracerCorrelationFunctionMultipoles

@@ -383,6 +383,52 @@ class REPTVelocileptorsTracerPowerSpectrumMultipoles(_BaseVelocileptorsTracer):
     _rept = True
 
 
+class _VelocileptorsCorrelationFunction(object):
+    r"""Velocileptors tracer correlation function multipoles as Hankel transforms of the power spectrum multipoles (full_shape.py:1317-1343, 1603-1629 on top of
+    tgc/base.py:46-139): P_\ell is evaluated on ``kin = geomspace(1e-4, 0.6, 300)`` (cubic interpolation / extrapolation from the emulated node's own k), the
+    Hankel operator (built by the device FFTLog) multiplies the folded table operator; no stochastic parameters (``_stochastic_bias_params = []``)."""
+
+    @classmethod
+    def _default_params(cls, **kwargs):
+        params = super(_VelocileptorsCorrelationFunction, cls)._default_params(**kwargs)
+        return {name: conf for name, conf in params.items() if not name.startswith('sn')}
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        s = self.init.get('s', None)
+        if s is None: s = np.linspace(20., 200, 101)
+        self.s = np.array(s, dtype='f8')
+        interp_order = {'linear': 1, 'cubic': 3}.get(self.init.get('interp_order', 1), self.init.get('interp_order', 1))
+        if interp_order != 1:
+            raise NotImplementedError('only interp_order = 1 (the default) is implemented')
+        self._kfft, self._hankel = np.logspace(-4., 3., 2048), None
+        if self.init.get('k', None) is None:
+            self.init['k'] = np.geomspace(self._kfft[0], 0.6, 300)     # tgc/base.py:66
+        super(_VelocileptorsCorrelationFunction, self).initialize()
+        self.kin = self.k
+        return self
+
+    @property
+    def hankel(self):
+        if self._hankel is None:
+            from ...fftlog import hankel_operator
+            self._hankel = hankel_operator(self.kin, self.s, self.ells, k=self._kfft, engine='hip')
+        return self._hankel
+
+    def _fold(self):
+        from scipy import linalg
+        return linalg.block_diag(*self.hankel).dot(super(_VelocileptorsCorrelationFunction, self)._fold())
+
+
+class LPTVelocileptorsTracerCorrelationFunctionMultipoles(_VelocileptorsCorrelationFunction, LPTVelocileptorsTracerPowerSpectrumMultipoles):
+    """Velocileptors LPT tracer correlation function multipoles (full_shape.py:1317-1343) from emulated tables."""
+
+
+class REPTVelocileptorsTracerCorrelationFunctionMultipoles(_VelocileptorsCorrelationFunction, REPTVelocileptorsTracerPowerSpectrumMultipoles):
+    """Velocileptors REPT tracer correlation function multipoles (full_shape.py:1603-1629) from emulated tables."""
+
+
 class EmulatedTracerPowerSpectrumMultipoles(_BaseVelocileptorsTracer):
     """Any tracer theory emulated as a whole: ``pt`` emulates the array 'power' [n_ell, n_k] (EmulatedCalculator.calculate, emulators/__init__.py:408-409)."""
 

@@ -411,6 +411,68 @@ def cfg3_table():
     print(names)
 
 
+def cfg3_table_xi():
+    """REPT velocileptors correlation function multipoles (full_shape.py:1603-1629): the table combination of cfg3_table on the 300-point log grid of get_corr,
+    Hankel-transformed (tgc/base.py:127-136), run by the reference on the same kind of stand-in PT node."""
+    from desilike.theories.galaxy_clustering.full_shape import REPTVelocileptorsPowerSpectrumMultipoles, REPTVelocileptorsTracerCorrelationFunctionMultipoles
+    from desilike.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable
+
+    ells = (0, 2, 4)
+
+    def make_tables(kpt):
+        base = 2e4 * (kpt / 0.05)**0.96 / (1. + (kpt / 0.02)**2.5) * np.exp(-(kpt / 0.4)**2)
+        tables = np.array([[[base * amp * (1. + 0.3 * np.sin(3. * m + ell + 20. * np.minimum(kpt, 0.3) * (1 + t))) for m in range(19)] for ell in ells] for t, amp in enumerate([1., 0.3, -0.2, 0.15, 0.1, 0.05])])
+        tables = np.moveaxis(tables, 2, -1)                        # [6, n_ell, n_kpt, 19]
+        tables[..., 16:] = 0.
+        return tables
+
+    class FakePT(REPTVelocileptorsPowerSpectrumMultipoles):
+
+        _params = {'qpar': dict(value=1., prior=dict(limits=[0.8, 1.2]), ref=dict(limits=[0.98, 1.02])), 'qper': dict(value=1., prior=dict(limits=[0.8, 1.2]), ref=dict(limits=[0.98, 1.02])),
+                   'dm': dict(value=0., prior=dict(limits=[-1., 1.]), ref=dict(limits=[-0.05, 0.05]))}
+
+        def initialize(self, k=None, ells=(0, 2, 4), **kwargs):
+            self.k = np.linspace(0.01, 0.2, 101) if k is None else np.asarray(k, dtype='f8')
+            self.ells = tuple(ells)
+            self.tables = make_tables(self.k)
+            self.z = np.array(0.8)
+            self.options = {}
+
+        def calculate(self, qpar=1., qper=1., dm=0.):
+            x = [qpar - 1., qper - 1., dm]
+            tables = self.tables
+            self.pktable = tables[0] + x[0] * tables[1] + x[1] * tables[2] + x[2] * tables[3] + x[0] * x[2] * tables[4] + x[1]**2 * tables[5]
+            self.sigma8 = 0.8 * (1. + 0.2 * dm + 0.1 * x[0]**2)
+            self.fsigma8 = 0.45 * (1. + 0.3 * x[1] - 0.1 * dm)
+
+    pt = FakePT()
+    theory = REPTVelocileptorsTracerCorrelationFunctionMultipoles(pt=pt, tracer='LRG')
+    obs = TracerCorrelationFunctionMultipolesObservable(data={'b1p': 1.6, 'b2p': 0.3, 'alpha0p': 2.}, s=np.linspace(22.5, 167.5, 30), ells=(0, 2, 4), theory=theory)
+    n, scale = 90, 3e-4
+    rng = np.random.RandomState(24)
+    A = rng.standard_normal((n, n)) * scale
+    cov = A.dot(A.T) + (10. * scale)**2 * np.eye(n)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+    like()
+    names = like.varied_params.names()
+    theta = sample_theta(like, 16, seed=27)
+    vlike = vmap(like, backend=None, errors='return', return_derived=True)
+    (logpost, derived), errors = vlike({name: theta[:, i] for i, name in enumerate(names)})
+    assert not errors, errors
+    power, corr, flat = [], [], []
+    for row in theta:
+        like(**dict(zip(names, row)))
+        power.append(np.asarray(theory.power.power).copy()); corr.append(np.asarray(theory.corr).copy()); flat.append(np.asarray(like.flattheory).copy())
+    pw = theory.power
+    obs0 = dict(kpt=np.asarray(pt.k), k=np.asarray(pw.k), ells=np.array(pw.ells), tables=pt.tables, nd=pw.nd, snd=pw.snd, fsat=pw.fsat, sigv=pw.options['sigv'], s=np.asarray(theory.s),
+                flatdata=np.asarray(obs.flatdata))
+    save('cfg3_velocileptors_table_xi', names=np.array(names), theta=theta, obs0=obs0, precision=np.asarray(like.precision), covariance=cov,
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]),
+         logposterior=np.asarray(logpost), loglikelihood=np.asarray(derived[like._param_loglikelihood]), logprior=np.asarray(derived[like._param_logprior]),
+         power=np.array(power), theory=np.array(corr), flattheory=np.array(flat))
+    print(names)
+
+
 def syst_template_0(ell, k):
     return 1e3 * (ell == 0) / (1. + (k / 0.02)**2)
 
@@ -636,7 +698,7 @@ def kaiser_xi(eft=False):
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -646,6 +708,7 @@ if __name__ == '__main__':
     if 'cfg4' in todo: cfg4('xi')
     if 'cfg4_pk' in todo: cfg4('pk')
     if 'cfg4_pcs' in todo: cfg4_kernel_broadband('xi'); cfg4_kernel_broadband('pk')
+    if 'cfg3_table_xi' in todo: cfg3_table_xi()
     if 'cfg4_models' in todo: cfg4_models()
     if 'cfg2_fc_syst' in todo: cfg2_fc_syst()
     if 'simple_tracer' in todo: simple_tracer()
