@@ -119,3 +119,37 @@ class Fisher(object):
         self.flatderiv, self.flatdiff = flatderiv, flatdiff
         self.likelihood_fisher, self.prior_fisher = likelihood_fisher, prior_fisher
         return likelihood_fisher + prior_fisher
+
+
+def logposterior_value_and_grad(likelihood, theta):
+    r"""Log-posterior and its gradient w.r.t. the varied parameters for a batch of points, by central differences evaluated as ONE GPU batch.
+
+    What gradient-based samplers ask of the likelihood (``jax.value_and_grad(logposterior)``: desilike/samplers/hmc.py:194, nuts.py:205, mclmc.py); the reference
+    obtains it from jax tracing, here the stencil ``theta_b \pm h_p e_p`` of all B points and P parameters (B (2 P + 1) rows) goes through ``dl_eval_logposterior``
+    in one call.  Steps are ``Parameter.delta`` (parameter.py:898-915), shortened where a prior bound is closer (one-sided there).  Analytically solved parameters
+    are marginalised inside every evaluation.  Returns ``(logposterior [B], gradient [B, P])``; rows outside the prior get ``-inf`` and a NaN gradient.
+    """
+    import torch
+    likelihood.initialize()
+    varied = likelihood.varied_params
+    theta = np.atleast_2d(np.asarray(theta, dtype='f8'))
+    B, P = theta.shape
+    assert P == len(varied)
+    lower, upper = np.empty((B, P)), np.empty((B, P))
+    for ip, param in enumerate(varied):
+        _, lo, hi = param.delta
+        lower[:, ip] = np.clip(np.minimum(lo, theta[:, ip] - param.prior.limits[0]), 0., None)
+        upper[:, ip] = np.clip(np.minimum(hi, param.prior.limits[1] - theta[:, ip]), 0., None)
+    points = np.repeat(theta[:, None, :], 2 * P + 1, axis=1)                 # [B, 1 + 2 P, P]
+    index = np.arange(P)
+    points[:, 1 + 2 * index, index] -= lower
+    points[:, 2 + 2 * index, index] += upper
+    ctx = likelihood._get_context()
+    device = torch.device('cuda', ctx.device)
+    pts = torch.as_tensor(points.reshape(-1, P), dtype=torch.float64, device=device).contiguous()
+    out = torch.empty(pts.shape[0], dtype=torch.float64, device=device)
+    ctx.eval_logposterior(pts, out)
+    logpost = out.cpu().numpy().reshape(B, 2 * P + 1)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        gradient = (logpost[:, 2::2] - logpost[:, 1::2]) / (lower + upper)
+    return logpost[:, 0], gradient

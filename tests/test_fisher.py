@@ -60,3 +60,44 @@ def test_fisher_driver_on_gpu():
     assert (np.linalg.eigvalsh(result.precision()) > 0).all()
     # sn0 has a Gaussian prior (scale 1000): its precision adds to the diagonal (fisher.py:712-714)
     assert np.isclose(result.precision()[5, 5] - fisher.likelihood_fisher.precision()[5, 5], 1e-6, rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_logposterior_value_and_grad():
+    """Batched finite-difference gradient (the value_and_grad gradient-based samplers need, samplers/hmc.py:194): against the oracle's log-posterior on the same stencil,
+    and against the analytic gradient along a parameter the model is linear in (sn0)."""
+    from desilike_amd.fisher import logposterior_value_and_grad
+    from golden_utils import load_golden, observable_constants, prior_list
+    from test_gpu_marg import make_marg_likelihood
+    from oracle import np_oracle as orc
+    g = load_golden('marg_sn0_grid')
+    like = make_marg_likelihood(g, solved=False)
+    names = like.varied_params.names()
+    rnames = [str(n) for n in g['names']]
+    theta = g['theta'][:6][:, [rnames.index(n) for n in names]]
+    value, grad = logposterior_value_and_grad(like, theta)
+    c = observable_constants(g)
+    priors = [dict(dist=param.prior.dist, limits=param.prior.limits, loc=getattr(param.prior, 'loc', 0.) if param.prior.dist == 'norm' else 0.,
+                   scale=getattr(param.prior, 'scale', 1.) if param.prior.dist == 'norm' else 1.) for param in like.varied_params]
+
+    def logpost(row):
+        p = dict(zip(names, row)); p['b1'] = (p['b1'], p['b1'])
+        return orc.gaussian_loglikelihood(orc.fullshape_observable(c, p)['flattheory'], c['flatdata'], like.precision)[0] + orc.logprior(row, priors)
+
+    for i, row in enumerate(theta):
+        assert abs(value[i] - logpost(row)) <= 1e-10 * max(1., abs(value[i]))
+        for ip, param in enumerate(like.varied_params):
+            _, lo, hi = param.delta
+            lo, hi = min(lo, row[ip] - param.prior.limits[0]), min(hi, param.prior.limits[1] - row[ip])
+            up, dn = row.copy(), row.copy()
+            up[ip] += hi; dn[ip] -= lo
+            ref = (logpost(up) - logpost(dn)) / (lo + hi)
+            assert abs(grad[i, ip] - ref) <= 1e-6 * max(1., abs(ref)), (i, param.name, grad[i, ip], ref)
+    # analytic: d logL / d sn0 = -T P Delta (T = d flattheory / d sn0, constant), + Gaussian prior term
+    isn = names.index('sn0')
+    p0 = dict(zip(names, theta[0])); p0['b1'] = (p0['b1'], p0['b1'])
+    f0 = orc.fullshape_observable(c, p0)['flattheory']
+    T = orc.fullshape_observable(c, dict(p0, sn0=p0['sn0'] + 1.))['flattheory'] - f0
+    prior = like.varied_params['sn0'].prior
+    analytic = -T.dot(like.precision).dot(f0 - c['flatdata']) - (theta[0, isn] - prior.loc) / prior.scale**2
+    assert abs(grad[0, isn] - analytic) <= 1e-7 * max(1., abs(analytic))
