@@ -5,15 +5,16 @@
 // out = prefactor_ell * s^{-3/2} * A.  The Mellin coefficients u_ell (loggamma of a complex argument, low-ringing offset) and the
 // pre / post factors are constants of the grid, computed once on the host (desilike_amd/fftlog.py) and uploaded at dl_fftlog_create.
 //
-// One 512-thread workgroup per (point, multipole).  The padded REAL sequence is packed into N2 = npad / 2 complex numbers that live in
-// LDS for the whole transform, beside the twiddle table W_{npad}^m (N2 entries, loaded once per workgroup): 64 KB at npad = 4096.
-//   forward : decimation-in-frequency radix-2^2 passes (two stages per barrier), natural order in -> bit-reversed order out;
+// One 128-thread workgroup per (point, multipole).  The padded REAL sequence is packed into N2 = npad / 2 complex numbers that live in LDS for the whole
+// transform (32 KB at npad = 4096: four workgroups per CU); the twiddle table W_{npad}^m (N2 entries) stays in global memory (L1-resident, a few values per pass).
+//   forward : decimation in frequency, FOUR radix-2 stages fused per pass on 16 elements held in registers (11 stages = 4 + 4 + 3: three LDS round trips),
+//             natural order in -> bit-reversed order out; one table twiddle per stage and thread, the others by compile-time unit roots;
 //   spectrum: real-FFT unpacking X[m] = Fe[m] + W^m Fo[m], multiplication by u[m] and re-packing for the inverse, on the pair
 //             (m, N2 - m) addressed through __brev (the pair is a closed set: no barrier inside);
-//   inverse : decimation-in-time radix-2^2 passes with conjugate twiddles, bit-reversed in -> natural out (no permutation pass at all);
+//   inverse : decimation in time with conjugate twiddles, 3 + 4 + 4 fused stages, bit-reversed in -> natural out (no permutation pass at all);
 //   output  : reversed, scaled, coalesced store of the n un-padded points.
-// Algorithmic work: 2 x 2.5 N2 log2 N2 complex-FFT FLOP + ~40 N2 (spectrum step) per (point, multipole) = 0.2 MFLOP at npad = 4096;
-// bound: LDS bandwidth (every radix-2^2 pass moves 2 x 16 B x N2).
+// Algorithmic work: 2 x 2.5 N2 log2 N2 complex-FFT FLOP + ~40 N2 (spectrum step) per (point, multipole) = 0.53 MFLOP at npad = 4096;
+// bound: LDS bandwidth (6 fused passes + the spectrum step, each moving 2 x 16 B x N2: 0.45 MB per transform).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -29,64 +30,113 @@ __device__ __forceinline__ dl_ff_c dl_ff_mul(dl_ff_c a, dl_ff_c b) { return dl_f
 __device__ __forceinline__ dl_ff_c dl_ff_mulc(dl_ff_c a, dl_ff_c b) { return dl_ff_c{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }   // a * conj(b)
 __device__ __forceinline__ dl_ff_c dl_ff_conj(dl_ff_c a) { return dl_ff_c{a.x, -a.y}; }
 
-// fun [B, n_ell, n]; pre [n]; u [n_ell, N2 + 1] complex; post [n_ell, n]; tw_g [N2] complex = exp(-i pi m / N2); out [B, n_ell, n]
-#define DL_FF_THREADS 512
+#define DL_FF_THREADS 128
+// LDS position of complex element i: one slot of padding every 16 elements (= 64 banks), so that the power-of-two strides of the fused passes (lanes 8 or 128
+// elements apart) spread over all banks instead of piling onto a few (the un-skewed layout left the two small-stride passes 8- to 32-way conflicted)
+#define DL_FF_P(i) ((i) + ((i) >> 4))
+
+// exp(-i pi r / half), r < half <= 8: the twiddle of butterfly r of a fused stage relative to butterfly 0 (compile-time constants after unrolling)
+__device__ __forceinline__ dl_ff_c dl_ff_unit(int r, int half) {
+    // angle index on the 16-point half circle: q = r * (8 / half), exp(-i pi q / 8)
+    const double c8[9] = {1., 0.92387953251128674, 0.70710678118654752, 0.38268343236508977, 0., -0.38268343236508977, -0.70710678118654752, -0.92387953251128674, -1.};
+    const double s8[9] = {0., 0.38268343236508977, 0.70710678118654752, 0.92387953251128674, 1., 0.92387953251128674, 0.70710678118654752, 0.38268343236508977, 0.};
+    const int q = r * (8 / half);
+    return dl_ff_c{c8[q], -s8[q]};
+}
+
+// S fused radix-2 stages on the 2^S elements x[i0 + e hl] held in registers (one LDS round trip per S stages).
+//   DIF (forward, natural -> bit-reversed order): stage half-sizes hl 2^(S-1), ..., hl;  DIT (inverse, conjugate twiddles): hl, ..., hl 2^(S-1).
+// The twiddle of the butterfly (e, e + half) of a stage of half-size hs = hl half is W_{2 hs}^(j + r hl), r = e mod half: one table value tw[j N2 / hs]
+// (exp(-i pi m / N2), from global memory: L1-resident, requested together with the LDS loads) times the constant exp(-i pi r / half).
+template <int S, bool INVERSE>
+__device__ __forceinline__ void dl_ff_pass(dl_ff_c* x, const dl_ff_c* __restrict__ tw, int N2, int hl, int tid) {
+    constexpr int R = 1 << S;
+    for (int t = tid; t < (N2 >> S); t += DL_FF_THREADS) {
+        const int g = t / hl, j = t - g * hl, i0 = g * (hl << S) + j;
+        dl_ff_c v[R], base[S];
+#pragma unroll
+        for (int e = 0; e < R; ++e) v[e] = x[DL_FF_P(i0 + e * hl)];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {   // base twiddle of the stage with half = 2^s element steps: hs = hl << s
+            base[s] = tw[j * (N2 / (hl << s))];
+        }
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            const int ls = INVERSE ? st : S - 1 - st;     // log2 of the stage's half in element steps
+            const int half = 1 << ls;
+#pragma unroll
+            for (int e = 0; e < R; ++e) {
+                if (e & half) continue;
+                const int r = e & (half - 1);
+                const dl_ff_c w = (r == 0) ? base[ls] : dl_ff_mul(base[ls], dl_ff_unit(r, half));
+                if (INVERSE) {
+                    const dl_ff_c b = dl_ff_mulc(v[e + half], w), a = v[e];
+                    v[e] = a + b;
+                    v[e + half] = a - b;
+                } else {
+                    const dl_ff_c a = v[e], b = v[e + half];
+                    v[e] = a + b;
+                    v[e + half] = dl_ff_mul(a - b, w);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < R; ++e) x[DL_FF_P(i0 + e * hl)] = v[e];
+    }
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ void dl_ff_pass_s(int S, dl_ff_c* x, const dl_ff_c* __restrict__ tw, int N2, int hl, int tid) {
+    switch (S) {
+        case 4: dl_ff_pass<4, INVERSE>(x, tw, N2, hl, tid); break;
+        case 3: dl_ff_pass<3, INVERSE>(x, tw, N2, hl, tid); break;
+        case 2: dl_ff_pass<2, INVERSE>(x, tw, N2, hl, tid); break;
+        default: dl_ff_pass<1, INVERSE>(x, tw, N2, hl, tid);
+    }
+}
+
+// fun [B, n_ell, n]; pre [n]; u [n_ell, N2 + 1] complex; post [n_ell, n]; tw [N2] complex = exp(-i pi m / N2); out [B, n_ell, n]
 __global__ __launch_bounds__(DL_FF_THREADS) void dl_fftlog_kernel(const double* __restrict__ fun, const double* __restrict__ pre, const dl_ff_c* __restrict__ u,
-                                                        const double* __restrict__ post, const dl_ff_c* __restrict__ tw_g, double* __restrict__ out, int n, int pad,
-                                                        int L, int n_ell) {
+                                                                  const double* __restrict__ post, const dl_ff_c* __restrict__ tw, double* __restrict__ out, int n, int pad,
+                                                                  int L, int n_ell) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     const int N2 = 1 << L, tid = threadIdx.x;
     dl_ff_c* x = reinterpret_cast<dl_ff_c*>(lds_raw);
-    dl_ff_c* tw = x + N2;
     const int ell = blockIdx.x % n_ell;
     const double* f = fun + (size_t)blockIdx.x * n;
     for (int j = tid; j < N2; j += DL_FF_THREADS) {
-        tw[j] = tw_g[j];
         const int q0 = 2 * j - pad, q1 = q0 + 1;
         dl_ff_c v;
         v.x = (q0 >= 0 && q0 < n) ? f[q0] * pre[q0] : 0.;
         v.y = (q1 >= 0 && q1 < n) ? f[q1] * pre[q1] : 0.;
-        x[j] = v;
+        x[DL_FF_P(j)] = v;
     }
     __syncthreads();
-    // ---- forward, decimation in frequency
-    int h = N2 >> 1;
-    if (L & 1) {
-        for (int t = tid; t < (N2 >> 1); t += DL_FF_THREADS) {
-            const int j = t;   // h = N2 / 2: a single group
-            dl_ff_c a = x[j], b = x[j + h];
-            x[j] = a + b;
-            x[j + h] = dl_ff_mul(a - b, tw[j * (N2 / h)]);
+    // ---- forward, decimation in frequency: passes of 4 fused stages from the top, the remainder last
+    const int Slast = (L & 3) ? (L & 3) : 4;
+    {
+        int done = 0;   // stages done
+        while (done < L) {
+            const int S = (L - done > Slast) ? 4 : Slast;
+            // the S stages have half-sizes N2 >> (done + 1), ..., N2 >> (done + S): hl = the smallest
+            dl_ff_pass_s<false>(S, x, tw, N2, N2 >> (done + S), tid);
+            done += S;
+            __syncthreads();
         }
-        h >>= 1;
-        __syncthreads();
     }
-    for (; h >= 2; h >>= 2) {
-        const int h2 = h >> 1, sh = N2 / h;
-        for (int t = tid; t < (N2 >> 2); t += DL_FF_THREADS) {
-            const int g = t / h2, j = t - g * h2, i0 = g * 2 * h + j;
-            dl_ff_c a0 = x[i0], a1 = x[i0 + h2], a2 = x[i0 + h], a3 = x[i0 + h + h2];
-            dl_ff_c b0 = a0 + a2, b2 = dl_ff_mul(a0 - a2, tw[j * sh]), b1 = a1 + a3, b3 = dl_ff_mul(a1 - a3, tw[(j + h2) * sh]);
-            const dl_ff_c wc = tw[j * 2 * sh];
-            x[i0] = b0 + b1;
-            x[i0 + h2] = dl_ff_mul(b0 - b1, wc);
-            x[i0 + h] = b2 + b3;
-            x[i0 + h + h2] = dl_ff_mul(b2 - b3, wc);
-        }
-        __syncthreads();
-    }
-    // ---- spectrum: bin m sits at bit-reversed position
+    // ---- spectrum: bin m sits at the bit-reversed position
     const dl_ff_c* ul = u + (size_t)ell * (N2 + 1);
     for (int m = tid; m <= (N2 >> 1); m += DL_FF_THREADS) {
         if (m == 0) {
-            dl_ff_c z = x[0];
+            dl_ff_c z = x[0];   // (position of element 0 is 0)
             // rfft bins 0 and N2 are real; irfft ignores the imaginary parts of both
             const double y0 = (z.x + z.y) * ul[0].x, yn = (z.x - z.y) * ul[N2].x;
             x[0] = dl_ff_c{0.5 * (y0 + yn), 0.5 * (y0 - yn)};
             continue;
         }
         const int mm = N2 - m;
-        const int pm = (int)(__brev((unsigned)m) >> (32 - L)), pmm = (int)(__brev((unsigned)mm) >> (32 - L));
+        const int bm = (int)(__brev((unsigned)m) >> (32 - L)), bmm = (int)(__brev((unsigned)mm) >> (32 - L));
+        const int pm = DL_FF_P(bm), pmm = DL_FF_P(bmm);
         const dl_ff_c zm = x[pm], zc = dl_ff_conj(x[pmm]), w = tw[m];
         const dl_ff_c s = zm + zc, d = zm - zc;
         const dl_ff_c fe = dl_ff_c{0.5 * s.x, 0.5 * s.y}, fo = dl_ff_c{0.5 * d.y, -0.5 * d.x};   // fo = -i d / 2
@@ -98,32 +148,15 @@ __global__ __launch_bounds__(DL_FF_THREADS) void dl_fftlog_kernel(const double* 
         if (mm != m) x[pmm] = dl_ff_c{ge.x + go.y, go.x - ge.y};       // conj(ge) + i conj(go)
     }
     __syncthreads();
-    // ---- inverse, decimation in time, conjugate twiddles
-    h = 1;
-    for (; 2 * h <= (N2 >> 1); h <<= 2) {
-        const int sh = N2 / (2 * h);
-        for (int t = tid; t < (N2 >> 2); t += DL_FF_THREADS) {
-            const int g = t / h, j = t - g * h, i0 = g * 4 * h + j;
-            dl_ff_c a0 = x[i0], a1 = x[i0 + h], a2 = x[i0 + 2 * h], a3 = x[i0 + 3 * h];
-            const dl_ff_c w = tw[j * 2 * sh];
-            const dl_ff_c t1 = dl_ff_mulc(a1, w), t3 = dl_ff_mulc(a3, w);
-            dl_ff_c b0 = a0 + t1, b1 = a0 - t1, b2 = a2 + t3, b3 = a2 - t3;
-            const dl_ff_c s2 = dl_ff_mulc(b2, tw[j * sh]), s3 = dl_ff_mulc(b3, tw[(j + h) * sh]);
-            x[i0] = b0 + s2;
-            x[i0 + 2 * h] = b0 - s2;
-            x[i0 + h] = b1 + s3;
-            x[i0 + 3 * h] = b1 - s3;
+    // ---- inverse, decimation in time, conjugate twiddles: the remainder first, then passes of 4 fused stages
+    {
+        int done = 0;
+        while (done < L) {
+            const int S = (done == 0) ? Slast : 4;
+            dl_ff_pass_s<true>(S, x, tw, N2, 1 << done, tid);
+            done += S;
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    if (L & 1) {   // h = N2 / 2
-        for (int t = tid; t < (N2 >> 1); t += DL_FF_THREADS) {
-            const int j = t;
-            dl_ff_c a = x[j], b = dl_ff_mulc(x[j + h], tw[2 * j]);
-            x[j] = a + b;
-            x[j + h] = a - b;
-        }
-        __syncthreads();
     }
     // ---- output: A = a'[::-1], un-padded
     const double scale = 1. / (double)N2;
@@ -131,7 +164,10 @@ __global__ __launch_bounds__(DL_FF_THREADS) void dl_fftlog_kernel(const double* 
     double* o = out + (size_t)blockIdx.x * n;
     const double* xr = reinterpret_cast<const double*>(x);
     const int npad = 2 * N2;
-    for (int i = tid; i < n; i += DL_FF_THREADS) o[i] = po[i] * (xr[npad - 1 - pad - i] * scale);
+    for (int i = tid; i < n; i += DL_FF_THREADS) {
+        const int q = npad - 1 - pad - i;   // real sample q = component (q & 1) of complex element q >> 1
+        o[i] = po[i] * (xr[2 * DL_FF_P(q >> 1) + (q & 1)] * scale);
+    }
 }
 
 struct dl_fftlog {
@@ -186,7 +222,7 @@ int dl_fftlog_create(dl_fftlog** out, int device, int32_t n, int32_t npad, int32
             return dl_ff_fail(nullptr, msg);
         }
     }
-    const size_t shm = (size_t)N2 * 2 * sizeof(dl_ff_c);
+    const size_t shm = (size_t)(N2 + (N2 >> 4) + 1) * sizeof(dl_ff_c);
     if (shm > 48 * 1024) DL_FF_CHECK(plan, hipFuncSetAttribute((const void*)dl_fftlog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     *out = plan;
     return 0;
@@ -199,7 +235,7 @@ int dl_fftlog_apply(dl_fftlog* plan, const double* fun_dev, int64_t B, double* o
     if (B * plan->n_ell > 0x7fffffffLL) return dl_ff_fail(plan, "dl_fftlog_apply: batch too large for one launch");
     DL_FF_CHECK(plan, hipSetDevice(plan->device));
     const int N2 = plan->npad / 2;
-    const size_t shm = (size_t)N2 * 2 * sizeof(dl_ff_c);
+    const size_t shm = (size_t)(N2 + (N2 >> 4) + 1) * sizeof(dl_ff_c);
     hipLaunchKernelGGL(dl_fftlog_kernel, dim3((unsigned)(B * plan->n_ell)), dim3(DL_FF_THREADS), shm, (hipStream_t)hip_stream, fun_dev, plan->pre,
                        reinterpret_cast<const dl_ff_c*>(plan->u), plan->post, reinterpret_cast<const dl_ff_c*>(plan->tw), out_dev, plan->n, plan->pad, plan->L, plan->n_ell);
     DL_FF_CHECK(plan, hipGetLastError());
