@@ -1,8 +1,9 @@
 """Emulated calculators: forward pass of Taylor / MLP emulators on the GPU.
 
 In the reference, ``desilike.emulators.Emulator`` wraps the third-party ``cosmoprimo.emulators.tools`` engines (un-vendored) and
-``EmulatedCalculator`` (emulators/__init__.py:394-418) replaces any calculator by ``emulator.predict(params)`` -> state arrays.  Training /
-sampling of the emulator is out of scope; this module holds the *fitted* engines in the layouts the reference writes:
+``EmulatedCalculator`` (emulators/__init__.py:394-418) replaces any calculator by ``emulator.predict(params)`` -> state arrays.  This module holds the
+*fitted* engines in the layouts the reference writes, and fits the Taylor engine itself (:func:`fit_taylor`: the whole finite-difference stencil is one GPU
+batch; MLP training is out of scope):
 
 * :class:`TaylorEmulatorEngine` -- ``center [P]``, ``powers [n_terms, P]``, ``derivatives [n_terms, *yshape]`` already divided by the factorials
   (emulators/__init__.py:471-507): ``y = sum_t derivatives[t] prod_p (x_p - c_p)^powers[t, p]``;
@@ -40,6 +41,60 @@ class TaylorEmulatorEngine(object):
         if scalar:
             spec['coef'] = self.derivatives.reshape(self.n_basis)
         return spec
+
+
+def finite_difference_weights(nodes, order):
+    """Weights w with sum_i w[i] f(nodes[i]) ~ f^(order)(0): Fornberg's recursion (Math. Comp. 51, 1988) for arbitrary nodes."""
+    nodes = np.asarray(nodes, dtype='f8')
+    n = nodes.size
+    c = np.zeros((n, order + 1), dtype='f8')
+    c[0, 0] = 1.
+    c1 = 1.
+    for i in range(1, n):
+        c2 = 1.
+        mn = min(i, order)
+        for j in range(i):
+            c3 = nodes[i] - nodes[j]
+            c2 *= c3
+            if j == i - 1:
+                for k in range(mn, 0, -1):
+                    c[i, k] = c1 * (k * c[i - 1, k - 1] - nodes[i - 1] * c[i - 1, k]) / c2
+                c[i, 0] = -c1 * nodes[i - 1] * c[i - 1, 0] / c2
+            for k in range(mn, 0, -1):
+                c[j, k] = (nodes[i] * c[j, k] - k * c[j, k - 1]) / c3
+            c[j, 0] = nodes[i] * c[j, 0] / c3
+        c1 = c2
+    return c[:, order]
+
+
+def fit_taylor(function, center, delta, order=3, accuracy=2):
+    r"""Fit a :class:`TaylorEmulatorEngine` of total order ``order`` around ``center`` by central finite differences (what the reference's
+    ``TaylorEmulatorEngine.get_default_samples`` / ``_fit_no_operation`` produce through ``Differentiation``, emulators/__init__.py:430-507).
+
+    ``function(points [N, P]) -> values [N, *yshape]`` is called ONCE with the whole tensor stencil (nodes ``center_p + i delta_p``, ``|i| <= (order + 1) // 2 - 1 +
+    accuracy // 2``): with a GPU theory behind it (e.g. ``Context.eval_theory_host``) the fit is a single batch.  Derivatives
+    :math:`\partial^\alpha f`, :math:`|\alpha| \le` ``order``, are tensor products of 1-D stencils; the engine stores them divided by :math:`\alpha!`.
+    """
+    import itertools
+    from math import factorial
+    center, delta = np.asarray(center, dtype='f8'), np.broadcast_to(np.asarray(delta, dtype='f8'), np.shape(center))
+    ndim = center.size
+    m = (order + 1) // 2 - 1 + max(accuracy // 2, 1)
+    offsets = np.arange(-m, m + 1)
+    grid = np.stack(np.meshgrid(*([offsets] * ndim), indexing='ij'), axis=-1).reshape(-1, ndim)
+    values = np.asarray(function(center + grid * delta), dtype='f8')
+    yshape = values.shape[1:]
+    values = values.reshape((offsets.size,) * ndim + (-1,))
+    weights = [finite_difference_weights(offsets.astype('f8'), d) for d in range(order + 1)]     # in units of delta^-d
+    powers, derivatives = [], []
+    for alpha in itertools.product(range(order + 1), repeat=ndim):
+        if sum(alpha) > order: continue
+        term = values
+        for axis, d in enumerate(alpha):   # contract the leading axis each time: the remaining parameter axes move up
+            term = np.tensordot(weights[d] / delta[axis]**d, term, axes=(0, 0))
+        powers.append(alpha)
+        derivatives.append(term.reshape(yshape) / np.prod([factorial(d) for d in alpha]))
+    return TaylorEmulatorEngine(center, np.array(powers, dtype='i4'), np.array(derivatives))
 
 
 class MLPEmulatorEngine(object):
@@ -115,3 +170,31 @@ class EmulatedCalculator(object):
             else:
                 specs['emu{:d}'.format(ie)] = engine.spec(scalar=True)
         return specs
+
+
+def emulate_power(likelihood, iobs=0, order=3, accuracy=2, delta_scale=1., params=None):
+    """Taylor emulator of the theory multipoles ``power [n_ell, n_k]`` of observable ``iobs`` of a GPU likelihood, as an :class:`EmulatedCalculator` for
+    :class:`desilike_amd.theories.galaxy_clustering.EmulatedTracerPowerSpectrumMultipoles` (the reference's ``Emulator(theory, engine=TaylorEmulatorEngine(order)).fit()``,
+    emulators/__init__.py:131-240): expansion around the parameters' default values with steps ``Parameter.delta`` (scaled by ``delta_scale``), the stencil
+    evaluated by ``dl_eval_theory`` as one batch."""
+    likelihood.initialize()
+    ctx = likelihood._get_context()
+    varied = likelihood.varied_params
+    theory = likelihood.observables[iobs].wmatrix.theory
+    names = [param.name for param in varied] if params is None else list(params)
+    index = [varied.names().index(name) for name in names]
+    center_all = np.array([param.value for param in varied], dtype='f8')
+    delta = np.array([delta_scale * 0.5 * (varied[name].delta[1] + varied[name].delta[2]) for name in names], dtype='f8')
+
+    def function(points):
+        theta = np.repeat(center_all[None, :], len(points), axis=0)
+        theta[:, index] = points
+        return ctx.eval_theory_host(theta, iobs=iobs)
+
+    engine = fit_taylor(function, center_all[index], delta, order=order, accuracy=accuracy)
+    specs = {}
+    for name in names:
+        param = varied[name]
+        specs[name] = dict(value=param.value, prior=dict(dist=param.prior.dist, limits=list(param.prior.limits), **({'loc': param.prior.loc, 'scale': param.prior.scale} if param.prior.dist == 'norm' else {})),
+                           ref=dict(dist=param.ref.dist, limits=list(param.ref.limits), **({'loc': param.ref.loc, 'scale': param.ref.scale} if param.ref.dist == 'norm' else {})))
+    return EmulatedCalculator(names, {'power': engine}, k=theory.k, ells=theory.ells, z=getattr(theory, 'z', 1.), param_specs=specs)

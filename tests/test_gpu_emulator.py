@@ -139,3 +139,34 @@ def test_feature_path_matches_dense_path_and_is_repeatable():
             ctx.eval_logposterior(th, out)
             if first is None: first = out.clone()
             else: assert torch.equal(first, out), it
+
+
+def test_taylor_emulator_fitted_on_the_gpu_theory():
+    """(f2) Taylor emulator of the Kaiser multipoles fitted by ONE batch of dl_eval_theory (emulators/__init__.py:430-507), then used through
+    EmulatedTracerPowerSpectrumMultipoles: exact at the centre (test_taylor.py:99-104), converging with the order nearby."""
+    from desilike_amd.emulators import emulate_power
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles, EmulatedTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    g = load_golden('cfg2_shapefit_window')
+    kedges = np.linspace(0., 0.2, 41)
+
+    def make(theory):
+        obs = TracerPowerSpectrumMultipolesObservable(data=g['obs0']['flatdata'], kedges=kedges, ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=1e4)
+        return ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
+
+    direct = make(KaiserTracerPowerSpectrumMultipoles(template=ShapeFitPowerSpectrumTemplate(z=0.5)))
+    names = direct.varied_params.names()
+    center = np.array([param.value for param in direct.varied_params])
+    rng = np.random.RandomState(12)
+    delta = np.array([0.5 * (param.delta[1] + param.delta[2]) for param in direct.varied_params])
+    theta = np.vstack([center, center + 0.5 * delta * rng.uniform(-1., 1., (32, len(names)))])
+    ref = direct._get_context().eval_batch_host(theta)[0]
+    errors = {}
+    for order in (2, 4):
+        emulated = make(EmulatedTracerPowerSpectrumMultipoles(pt=emulate_power(direct, order=order)))
+        assert emulated.varied_params.names() == names
+        ll = emulated._get_context().eval_batch_host(theta)[0]
+        assert abs(ll[0] - ref[0]) <= 1e-9 * max(1., abs(ref[0]))                 # the centre is reproduced
+        errors[order] = np.abs(ll[1:] - ref[1:]).max()
+    assert errors[4] < 0.05 * errors[2] and errors[4] < 1e-3 * np.abs(ref).max(), errors

@@ -54,3 +54,28 @@ def test_emulator_restatements():
     h = h / (1. + np.exp(-h))
     expected = (h.dot(k2) + b2) * (ylimits[:, 1] - ylimits[:, 0]) + ylimits[:, 0]
     assert np.allclose(orc.mlp_predict(x, xlimits, [(k1, b1), (k2, b2)], 'silu', ylimits), expected, rtol=1e-14)
+
+
+def test_fit_taylor_exact_on_polynomials():
+    """emulators/tests/test_taylor.py:99-104 (the Taylor emulator reproduces the centre) and exactness on a polynomial of the fitted order; Fornberg weights."""
+    from desilike_amd.emulators import fit_taylor, finite_difference_weights
+    assert np.allclose(finite_difference_weights([-1., 0., 1.], 2), [1., -2., 1.]) and np.allclose(finite_difference_weights([-2., -1., 0., 1., 2.], 1), [1. / 12., -2. / 3., 0., 2. / 3., -1. / 12.])
+    rng = np.random.RandomState(0)
+    center = np.array([0.5, -1., 2.])
+    coef = {(0, 0, 0): rng.standard_normal((2, 3)), (1, 0, 0): rng.standard_normal((2, 3)), (0, 2, 0): rng.standard_normal((2, 3)), (1, 1, 1): rng.standard_normal((2, 3)),
+            (0, 0, 3): rng.standard_normal((2, 3))}
+    calls = []
+
+    def function(x):
+        calls.append(len(x))
+        dx = x - center
+        return sum(c[None] * np.prod(dx**np.array(a), axis=1)[:, None, None] for a, c in coef.items())
+
+    engine = fit_taylor(function, center, [0.1, 0.2, 0.05], order=3, accuracy=2)
+    assert calls == [5**3]                                                       # the whole stencil in ONE call
+    x = center + rng.uniform(-1., 1., (7, 3))
+    assert np.allclose(orc.taylor_predict(x, engine.center, engine.powers, engine.derivatives), function(x), rtol=1e-10, atol=1e-11)
+    assert np.allclose(orc.taylor_predict(center, engine.center, engine.powers, engine.derivatives), coef[(0, 0, 0)], rtol=1e-13)
+    for alpha, c in coef.items():
+        term = [tuple(p) for p in engine.powers].index(alpha)
+        assert np.allclose(engine.derivatives[term], c, rtol=1e-9, atol=1e-10)
