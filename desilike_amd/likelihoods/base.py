@@ -387,9 +387,8 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         else:
             out = ctx.eval_batch_host(theta, return_flattheory=return_flattheory, return_solved=ctx.n_solved > 0)
         loglike, logprior, status = out[:3]
-        if return_flattheory:
-            self.flattheory = out[3].reshape(shape + (ctx.n_data,))
-            self.flatdiff = self.flattheory - self.flatdata
+        self._last_point = (theta, dict(fixed), shape)    # state of the last call: ``flattheory`` / ``flatdiff`` / observables' theory vectors are produced on demand
+        self._flattheory = out[3].reshape(shape + (ctx.n_data,)) if return_flattheory else None
         errs = {}
         bad = np.flatnonzero(status >= 2)
         if bad.size:
@@ -416,6 +415,47 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
                         derived['{}.{}.{}'.format(self._param_logprior, param.name, param.name)] = np.full(shape, -1. / scale**2 if np.isfinite(scale) else 0.)
             return (logposterior, derived), errs
         return logposterior, errs
+
+    @property
+    def flattheory(self):
+        """Theory vector of the LAST call (likelihoods/base.py:658-664), at the default values of analytically solved parameters: evaluated on demand (the
+        hot path does not write it unless asked)."""
+        if getattr(self, '_flattheory', None) is None:
+            if getattr(self, '_last_point', None) is None:
+                raise AttributeError('flattheory is available after the likelihood has been called')
+            theta, fixed, shape = self._last_point
+            ctx = self._get_context(fixed)
+            self._flattheory = ctx.eval_batch_host(theta, return_flattheory=True)[3].reshape(shape + (ctx.n_data,))
+        return self._flattheory
+
+    @flattheory.setter
+    def flattheory(self, value):
+        self._flattheory = value
+
+    @property
+    def flatdiff(self):
+        """``flattheory - flatdata`` of the last call (likelihoods/base.py:659)."""
+        return self.flattheory - self.flatdata
+
+    @property
+    def catch_errors(self):
+        """Exception classes the samplers turn into -inf (likelihoods/base.py:247-255): none here, per-point failures are status codes of the C ABI."""
+        return ()
+
+    def observable_flattheory(self, iobs=0):
+        """Slice of ``flattheory`` of observable ``iobs`` (what ``observable.flattheory`` holds in the reference, power_spectrum.py:400-404)."""
+        sizes = [obs.wmatrix.size for obs in self.observables]
+        start = sum(sizes[:iobs])
+        return self.flattheory[..., start:start + sizes[iobs]]
+
+    def theory_power(self, iobs=0):
+        """Theory multipoles ``power [n_ell, n_k]`` of observable ``iobs`` at the last call (the ``power`` state of the reference's theory calculators,
+        full_shape.py:502-510), through ``dl_eval_theory``."""
+        if getattr(self, '_last_point', None) is None:
+            raise AttributeError('theory_power is available after the likelihood has been called')
+        theta, fixed, shape = self._last_point
+        power = self._get_context(fixed).eval_theory_host(theta, iobs=iobs)
+        return power.reshape(shape + power.shape[1:])
 
     def evaluate_batch(self, theta, loglike=None, logprior=None, status=None, flattheory=None, stream=None):
         """Fast path: ``theta`` is a float64 torch tensor [B, n_varied] resident on this likelihood's GPU

@@ -19,6 +19,12 @@ def test_likelihood_call_surface(dense):
         assert abs(logpost - g['logposterior'][i]) <= 1e-10 * max(1., abs(g['logposterior'][i]))
         assert abs(like.loglikelihood - g['loglikelihood'][i]) <= 1e-10 * max(1., abs(g['loglikelihood'][i]))
         assert np.isclose(like.logprior, g['logprior'][i], rtol=1e-13, atol=1e-13)
+        # state of the last call, as the reference leaves it on the calculators (likelihoods/base.py:658-664; power_spectrum.py:400-404; full_shape.py:502-510)
+        assert np.allclose(like.flattheory, g['flattheory'][i], rtol=1e-11, atol=1e-8) and np.allclose(like.flatdiff, g['flattheory'][i] - like.flatdata, rtol=1e-11, atol=1e-8)
+        assert np.allclose(like.observable_flattheory(0), g['flattheory'][i], rtol=1e-11, atol=1e-8)
+        if i < g['int_power'].shape[0]:
+            assert np.allclose(like.theory_power(0), g['int_power'][i, 0], rtol=1e-11, atol=1e-12 * np.abs(g['int_power'][i, 0]).max())
+    assert like.catch_errors == ()
     # missing parameters take their default value (b1 -> ref centre 1.5, base.py:1194-1196)
     assert np.isfinite(like())
 
