@@ -395,8 +395,15 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         // emulated (separable) theories: the theory kernel writes only the factors (basis, monomial rows), the feature GEMM turns them into residual rows
         const bool feat_path = ctx->feat_ok && !need_flat;
         static const bool emu_fused = !getenv("DL_NO_EMU_FUSED");   // DL_NO_EMU_FUSED=1: theory kernel -> point records in HBM -> feature GEMM (two launches)
+        static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 2048;   // above: split-K slabs + finalize win (measured: 4096 rows 40 vs 49 us; 1024 rows 18 vs 13 us)
+        const bool chi2_path = !feat_path && !ctx->any_transform && ctx->n_solved == 0 && nb <= chi2_max_rows;
+        // the chi2 GEMM consumes row block mb (32 points; the LDS-DMA GEMM: 64) on XCD mb % 8: have the theory kernel produce it there (power then waits in that XCD's L2:
+        // -0.5 us per 1024 points)
+        static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;   // 0: off, 1: chi2 GEMM path, 2: also the large-batch GEMM
+        const int xcd_block = !xcd_local ? 0 : chi2_path ? 32 : (xcd_local > 1 && !feat_path && !ctx->any_transform && ctx->n_solved == 0 && ctx->N_pad == 128) ? 64 : 0;
         if (!(feat_path && emu_fused))
-            dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, feat_path ? ctx->feat_ws : nullptr, ctx->feat_ld);
+            dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, feat_path ? ctx->feat_ws : nullptr, ctx->feat_ld,
+                                xcd_block);
         if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[1], stream));
         int n_slabs = 1, cps = 0;
         int64_t slab_stride = 0;
@@ -419,8 +426,6 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
             }
             fin_bias = ctx->bias_white_dev;
         }
-        static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 2048;   // above: split-K slabs + finalize win (measured: 4096 rows 40 vs 49 us; 1024 rows 18 vs 13 us)
-        const bool chi2_path = !feat_path && !ctx->any_transform && ctx->n_solved == 0 && nb <= chi2_max_rows;
         // larger plain batches: the LDS-DMA split-K GEMM with the same partial-chi2 epilogue (no residual slab is written or read)
         int cps_probe = 0;
         const bool chi2_big = !feat_path && !ctx->any_transform && ctx->n_solved == 0 && !chi2_path && ctx->K_pad % 32 == 0 && !getenv("DL_NO_CHI2_BIG") &&

@@ -12,7 +12,7 @@
 
 // obs_host: HOST array of observables whose pointers already point into device memory (passed by value to the kernel)
 void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
-                         int64_t ld_tables, hipStream_t stream, double* feat = nullptr, int64_t feat_ld = 0);
+                         int64_t ld_tables, hipStream_t stream, double* feat = nullptr, int64_t feat_ld = 0, int xcd_block = 0);   // xcd_block: rows per row block of the consuming GEMM (0: points in launch order)
 // bias is added to rows r with r % bias_period == 0 only (bias_period = 1: every row)
 void dl_launch_window_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* C, int64_t ldc, int64_t M, int N_valid, int N_pad,
                            int K_pad, int bias_period, hipStream_t stream);

@@ -27,7 +27,12 @@ template <bool FAST, int NL, bool EFT, bool DENSE = false>
 __global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power,
                                                                      int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int b = blockIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs; the GEMM that follows runs row block mb (xblk = 32 or 64 points) on XCD mb % 8.  With xblk > 0 the points are dealt
+    // so that a row block is PRODUCED on the XCD that consumes it (B a multiple of 8 xblk): workgroup w = xcd + 8 r handles point xblk (xcd + 8 (r / xblk)) + r % xblk.
+    const int xblk = (stop_after >> 8) & 0xff;
+    stop_after = xblk ? 0 : stop_after;
+    const int wg = blockIdx.x;
+    const int b = xblk ? xblk * ((wg & 7) + 8 * ((wg >> 3) / xblk)) + ((wg >> 3) % xblk) : wg;
     // DL_FS_STAMPS diagnostics: s_memtime (shader clock) of thread 0 at entry, after each barrier and at exit, 8 slots per workgroup
 #define DL_STAMP(slot) if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();
     DL_STAMP(0)
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(DL_FS_THREADS) void dl_emulated_kernel(const DlObsD
 }
 
 void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
-                         int64_t ld_tables, hipStream_t stream, double* feat, int64_t feat_ld) {
+                         int64_t ld_tables, hipStream_t stream, double* feat, int64_t feat_ld, int xcd_block) {
     static const int stop_after = getenv("DL_FS_STOP") ? atoi(getenv("DL_FS_STOP")) : 0;   // per-phase timing diagnostics
     // DL_FS_STAMPS=<file>: in-kernel timestamps of the launches with B >= 256 are appended to <file> as text (synchronises: diagnostics only)
     static const char* stamp_file = getenv("DL_FS_STAMPS");
@@ -176,7 +181,8 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
         size_t shmem = dl_fs_shared_doubles_obs(obs_host[i], !generic) * sizeof(double);
         auto launch = [&](auto kernel) {
             if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  // e.g. 2000-knot BAO tables
-            hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shmem, stream, obs_host[i], theta, n_params, power, ld_power, tables, ld_tables, stop_after, stamps);
+            const int flags = (xcd_block > 0 && stop_after == 0 && B % (8 * xcd_block) == 0) ? (xcd_block << 8) : stop_after;
+            hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shmem, stream, obs_host[i], theta, n_params, power, ld_power, tables, ld_tables, flags, stamps);
             if (stamps) {
                 (void)hipStreamSynchronize(stream);
                 std::vector<unsigned long long> h((size_t)B * 8);
