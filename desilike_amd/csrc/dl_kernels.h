@@ -27,7 +27,7 @@ struct DlMargDev {
 };
 void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride, const double* bias, const DlMargDev& mg,
                              const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, double* solved,
-                             double* hessian /* [B, n_s, n_s] likelihood Hessian w.r.t. the solved parameters, may be null */, int post_mode, hipStream_t stream);
+                             double* hessian /* [B, n_s, n_s] likelihood Hessian w.r.t. the solved parameters, may be null */, int post_mode, hipStream_t stream, bool xcd_tile16 = false);   // xcd_tile16: the rows were written by 16-point workgroups in launch order (feature GEMM)
 void dl_launch_transform(double* flat, int64_t ld, const double* data, const int32_t* transform, int n, int64_t B, hipStream_t stream);
 // tiled split-K variant: writes n_splits partial slabs (no bias); N_pad multiple of 128, K_pad multiple of 16
 int dl_gemm_tiled_splits(int64_t M, int N_pad, int K_pad, int* chunks_per_split);

@@ -607,6 +607,13 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
     DL_FM_STAMP(0)
     if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
     int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (post_mode & 0x100) {
+        // residual rows written by a 16-point workgroup of the feature GEMM (workgroup t on XCD t % 8): read them on the XCD that wrote them
+        // (this workgroup w = xcd + 8 r takes quarter r % 4 of tile xcd + 8 (r / 4); B a multiple of 128)
+        const int64_t w = blockIdx.x, xcd = w & 7, r = w >> 3;
+        b = 16 * (xcd + 8 * (r >> 2)) + 4 * (r & 3) + wave;
+    }
+    post_mode &= 0xff;
     const bool active = b < B;
     if (!active) b = B - 1;   // spare waves of the last workgroup recompute the last point (the barrier below is common) and store nothing
     const int ns = mg.n_s;
@@ -936,7 +943,7 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
 
 void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride, const double* bias, const DlMargDev& mg,
                              const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, double* solved,
-                             double* hessian, int post_mode, hipStream_t stream) {
+                             double* hessian, int post_mode, hipStream_t stream, bool xcd_tile16) {
     static const char* stamp_file = getenv("DL_FM_STAMPS");   // diagnostics, see dl_launch_fullshape
     static unsigned long long* stamps_dev = nullptr;
     static int stamp_launches = 0;
@@ -944,6 +951,8 @@ void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_p
     if (stamp_file && !stamps_dev) (void)hipMalloc((void**)&stamps_dev, (size_t)65536 * 8 * sizeof(unsigned long long));
     unsigned long long* stamps = (stamp_file && grid <= 65536 && B >= 256 && stamp_launches >= 10 && stamp_launches < 12) ? stamps_dev : nullptr;
     if (stamp_file && B >= 256) stamp_launches++;
+    static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;
+    if (xcd_local && xcd_tile16 && B % 128 == 0) post_mode |= 0x100;
     static const bool allow_staged = !getenv("DL_FM_NO_STAGE");   // DL_FM_NO_STAGE=1: operands of the Gram product straight from global memory (comparison)
     const size_t region = std::max<size_t>((size_t)(1 + mg.n_s) * (((n + 3) & ~3) + 4), 512);
     const size_t shm = 4 * region * sizeof(double);   // staged rows of the four waves (reused for G and the Cholesky rows)
