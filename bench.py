@@ -178,7 +178,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.profile_enable(0 if args.no_events else 16)   # HIP events on the launch stream around each kernel, on 1 timed step out of 16 (an event record costs ~4 us of stream time)
+    every = max(1, min(40, args.steps // 5))   # HIP events on the launch stream around each kernel, on 1 timed step out of 40 (>= 5 samples; an event record costs ~4 us of stream time)
+    ctx.profile_enable(0 if args.no_events else every)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
