@@ -30,6 +30,7 @@ SYMBOLS = {
     'dl_eval_theory': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_batch_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
     'dl_eval_theory_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, ctypes.c_int32, _c_double_p, _c_double_p]),
+    'dl_eval_logposterior_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_int32_p]),
     'dl_profile_enable': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'dl_profile_read': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int32]),
     'dl_fftlog_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_double_p, _c_double_p, _c_double_p]),
@@ -173,6 +174,16 @@ class Context(object):
         if return_flattheory: toret += (flat,)
         if return_solved: toret += (solved,)
         return toret
+
+    def eval_logposterior_host(self, theta):
+        """numpy in / numpy out: (logposterior [B], status [B]) with the samplers' -inf conventions applied on the device (samplers/base.py:144-200)."""
+        theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
+        if theta.shape[1] != self.n_params:
+            raise ValueError('theta must have shape (B, {:d}), found {}'.format(self.n_params, theta.shape))
+        B = theta.shape[0]
+        logposterior, status = np.empty(B, dtype='f8'), np.empty(B, dtype='i4')
+        self._check(self._lib.dl_eval_logposterior_host(self._handle, _f64_ptr(theta), B, _f64_ptr(logposterior), _i32_ptr(status)))
+        return logposterior, status
 
     def eval_batch_derived_host(self, theta):
         """numpy in / numpy out: (loglike, logprior, status, solved [B, n_solved], hessian [B, n_solved, n_solved]); stages through device tensors."""

@@ -523,6 +523,10 @@ class SumLikelihood(BaseLikelihood):
         self.initialize()
         return self._fused.evaluate_batch(*args, **kwargs)
 
+    def _get_context(self, fixed_values=None):
+        self.initialize()
+        return self._fused._get_context(fixed_values)
+
     @property
     def size(self):
         return self._fused.size

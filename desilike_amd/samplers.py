@@ -26,6 +26,7 @@ class BasePosteriorSampler(object):
         self.sharding = sharding if sharding is not None else WalkerSharding()
         self._vlikelihood = vmap(likelihood, errors='return', return_derived=True)
         self.derived = None
+        self.fast = True   # False: always go through vmap(likelihood) (derived parameters kept by the likelihood's own call surface)
 
     def logprior(self, values):
         """Sum of the priors of the varied parameters (samplers/base.py:202-205)."""
@@ -38,6 +39,11 @@ class BasePosteriorSampler(object):
     def _logposterior_local(self, values):
         """samplers/base.py:144-193 for the rows handled by this process."""
         values = np.atleast_2d(np.asarray(values, dtype='f8'))
+        get_context = getattr(self.likelihood, '_get_context', None)
+        if self.fast and get_context is not None and values.shape[0]:
+            # GPU likelihoods: the same conventions (NaN rows, rows outside the prior, non-finite results -> -inf) are applied by the finalize kernels:
+            # ONE C-ABI call per batch instead of the dictionary round trip below
+            return get_context().eval_logposterior_host(values)[0]
         toret = np.full(values.shape[0], -np.inf)
         mask = ~np.isnan(values).any(axis=1)                      # bcast_values, samplers/base.py:57-61
         if not mask.any():

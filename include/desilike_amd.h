@@ -144,6 +144,9 @@ int  dl_eval_batch_host(dl_ctx* ctx, const double* theta, int64_t B,
                         double* loglike, double* logprior, double* flattheory, int32_t* status, double* solved);
 int  dl_eval_theory_host(dl_ctx* ctx, const double* theta, int64_t B, int32_t iobs,
                          double* power, double* tables);
+/* dl_eval_logposterior with host pointers: what BasePosteriorSampler.logposterior (desilike/samplers/base.py:144-200) returns for ``values [B, ndim]``, one call
+ * (pinned staging, one copy in, one copy out, one synchronisation of a private stream); status may be NULL. */
+int  dl_eval_logposterior_host(dl_ctx* ctx, const double* theta, int64_t B, double* logposterior, int32_t* status);
 
 /* ---- measurement -----------------------------------------------------------------------------*/
 /* enable > 0: dl_eval_batch brackets each kernel with HIP events on the launch stream, on one call out of

@@ -53,3 +53,21 @@ def test_grid_and_qmc_samplers_on_gpu():
     assert errors == {} and np.array_equal(samples['loglikelihood'], derived['loglikelihood']) and np.array_equal(samples['logprior'], derived['logprior'])
     qmc = QMCSampler(like).run(niterations=64)
     assert qmc['loglikelihood'].shape == (64,) and np.isfinite(qmc['loglikelihood']).all()
+
+
+def test_sampler_fast_path_matches_call_surface():
+    """BasePosteriorSampler.logposterior through ONE dl_eval_logposterior_host call vs the vmap(likelihood) route (samplers/base.py:144-200 conventions: NaN rows, rows outside
+    the prior, scalar input)."""
+    from desilike_amd.samplers import BasePosteriorSampler
+    g, like = make_cfg5()
+    fast, slow = BasePosteriorSampler(like, seed=1), BasePosteriorSampler(like, seed=1)
+    slow.fast = False
+    rng = np.random.RandomState(3)
+    values = np.column_stack([param.ref.sample(size=37, random_state=rng) for param in like.varied_params])
+    values[3, 0] = np.nan
+    values[5, 1] = 7.      # qper outside its prior
+    a, b = fast.logposterior(values), slow.logposterior(values)
+    assert np.isneginf(a[3]) and np.isneginf(a[5]) and np.isneginf(b[3]) and np.isneginf(b[5])
+    ok = np.isfinite(b)
+    assert ok.sum() == 35 and np.array_equal(np.isfinite(a), ok) and np.allclose(a[ok], b[ok], rtol=1e-13, atol=1e-10)
+    assert np.isclose(fast.logposterior(values[0]), b[0], rtol=1e-13, atol=1e-10)
