@@ -178,7 +178,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    every = max(1, min(40, args.steps // 5))   # HIP events on the launch stream around each kernel, on 1 timed step out of 40 (>= 5 samples; an event record costs ~4 us of stream time)
+    every = max(1, min(25, args.steps // 8))   # HIP events on the launch stream around each kernel, on 1 timed step out of 25 (8 samples at 200 steps, median; an event record costs ~4 us of stream time)
     ctx.profile_enable(0 if args.no_events else every)
     barrier()
     t0 = time.perf_counter()

@@ -635,7 +635,9 @@ int dl_profile_read(dl_ctx* ctx, double* ms, int32_t n) {
     if (!ctx || !ms || n < 4) return dl_fail(ctx, "dl_profile_read: need room for 4 values");
     if (ctx->ev.empty() || ctx->prof_calls == 0) return dl_fail(ctx, "dl_profile_read: no profiled call recorded");
     int64_t ncalls = std::min<int64_t>(ctx->prof_calls, dl_ctx::NPOOL);
-    ms[0] = ms[1] = ms[2] = ms[3] = 0.;
+    // MEDIAN over the sampled calls: a record that lands on a busy command processor stretches one interval by microseconds, and with a handful of samples
+    // the mean follows it
+    std::vector<double> samples[4];
     for (int64_t c = 0; c < ncalls; ++c) {
         hipEvent_t* ev = &ctx->ev[(size_t)c * 4];
         DL_HIP_CHECK(ctx, hipEventSynchronize(ev[3]));
@@ -645,9 +647,14 @@ int dl_profile_read(dl_ctx* ctx, double* ms, int32_t n) {
         DL_HIP_CHECK(ctx, hipEventElapsedTime(&t23, ev[2], ev[3]));
         DL_HIP_CHECK(ctx, hipEventElapsedTime(&t03, ev[0], ev[3]));
         double oh = ctx->ev_overhead_ms;
-        ms[0] += std::max(0., t01 - oh); ms[1] += std::max(0., t12 - oh); ms[2] += std::max(0., t23 - oh); ms[3] += std::max(0., t03 - oh);
+        samples[0].push_back(std::max(0., t01 - oh)); samples[1].push_back(std::max(0., t12 - oh)); samples[2].push_back(std::max(0., t23 - oh));
+        samples[3].push_back(std::max(0., t03 - oh));
     }
-    for (int i = 0; i < 4; ++i) ms[i] /= (double)ncalls;
+    for (int i = 0; i < 4; ++i) {
+        std::sort(samples[i].begin(), samples[i].end());
+        const size_t m = samples[i].size();
+        ms[i] = (m & 1) ? samples[i][m / 2] : 0.5 * (samples[i][m / 2 - 1] + samples[i][m / 2]);
+    }
     if (n >= 5) ms[4] = ctx->ev_overhead_ms;
     return 0;
 }

@@ -151,7 +151,7 @@ int  dl_eval_logposterior_host(dl_ctx* ctx, const double* theta, int64_t B, doub
 /* ---- measurement -----------------------------------------------------------------------------*/
 /* enable > 0: dl_eval_batch brackets each kernel with HIP events on the launch stream, on one call out of
  * ``enable`` (sampling keeps the cost of the event records, ~3.5 us each, out of the measured throughput).
- * dl_profile_read synchronises and returns per-kernel milliseconds averaged over the (up to 256) sampled calls,
+ * dl_profile_read synchronises and returns per-kernel milliseconds, the median over the (up to 256) sampled calls,
  * after subtracting the calibrated cost of an empty event-to-event interval:
  * ms[0] theory kernel, ms[1] window GEMM, ms[2] chi2/prior finalize, ms[3] whole call, ms[4] (if n >= 5) the overhead subtracted. */
 int  dl_profile_enable(dl_ctx* ctx, int enable);
