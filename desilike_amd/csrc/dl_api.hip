@@ -159,7 +159,15 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     // ---- precision -> Cholesky factor (likelihoods/base.py:13-17: chi2 = d P d = |L^T d|^2) ----
     const auto& prec = cfg->F("precision");
     std::vector<double> L((size_t)n * n, 0.);
-    if ((int64_t)prec.size() == (int64_t)n * n) {
+    bool dense_factor = false;
+    if (cfg->has_f64("precision_factor")) {
+        // any factor with precision = F F^T, given by the host (possibly rank-deficient: the posterior marginalised over linear parameters with flat priors,
+        // desilike_amd/likelihoods/base.py::_posterior_spec); chi2 = |F^T d|^2
+        const auto& fac = cfg->F("precision_factor");
+        if ((int64_t)fac.size() != (int64_t)n * n) return bail("dl_create: precision_factor must have n_data^2 entries");
+        L = fac;
+        dense_factor = true;
+    } else if ((int64_t)prec.size() == (int64_t)n * n) {
         L = prec;
         // symmetrise (the reference uses the matrix as given in d.P.d, which only sees the symmetric part)
         for (int i = 0; i < n; ++i)
@@ -190,7 +198,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     for (int i = 0; i < n; ++i) {
         double* dst = &wt_white[(size_t)i * ctx->K_pad];
         double bsum = 0., dsum = 0.;
-        for (int j = i; j < n; ++j) {
+        for (int j = dense_factor ? 0 : i; j < n; ++j) {
             double lji = L[(size_t)j * n + i];
             if (lji == 0.) continue;
             const double* src = &wt_full[(size_t)j * ctx->K_pad];

@@ -199,11 +199,12 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             device = int(os.environ.get('LOCAL_RANK', 0))
         return int(device)
 
-    def _spec(self, fixed_values, flatdata_list, precision):
-        """Nested likelihood spec flattened by ``_lib.fill_config`` into the C-ABI config keys (include/desilike_amd.h)."""
+    def _spec(self, fixed_values, flatdata_list, precision, drop_solved=False):
+        """Nested likelihood spec flattened by ``_lib.fill_config`` into the C-ABI config keys (include/desilike_amd.h).
+        ``drop_solved``: analytically solved parameters are treated as fixed (at ``fixed_values`` or their default value)."""
         varied = self.varied_params
         names = varied.names()
-        solved = self.solved_params
+        solved = ParameterCollection() if drop_solved else self.solved_params
         solved_names = solved.names()
         observables = []
         for obs, flatdata in zip(self.observables, flatdata_list):
@@ -284,6 +285,88 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             # what the context holds, as the reference exposes it (likelihoods/base.py:308-309)
             self.precision, self.flatdata = precision, np.concatenate(flatdata)
         return self._contexts[key]
+
+    def _solved_are_constant(self):
+        """True if the derivative of the theory vector w.r.t. every analytically solved parameter is the same at all points: shot-noise like terms and
+        pass-through columns (broadband terms, systematic templates); counter terms and velocileptors parameters multiply point-dependent spectra."""
+        solved_names = self.solved_params.names()
+        if not solved_names:
+            return False
+        constant = set()
+        for obs in self.observables:
+            imap = obs.wmatrix.theory._input_map()
+            if 'sn0' in imap: constant.add(imap['sn0'])
+            constant.update(imap.get('sn', []))
+            constant.update(imap.get('pass', []))
+            constant.update(getattr(obs.wmatrix, '_pass_params', lambda: [])())
+            if imap.get('vp', None):   # velocileptors: every solved parameter multiplies emulated tables
+                constant.difference_update(imap['vp'])
+        return all(name in constant for name in solved_names)
+
+    def _get_posterior_context(self, fixed_values=None):
+        r"""Context and constant offset such that ``logposterior = ctx.eval_logposterior(theta) + offset`` (what samplers consume).
+
+        When every analytically solved parameter has a point-independent derivative row T (:meth:`_solved_are_constant`), solving / marginalising them at each point
+        (likelihoods/base.py:314-413) is the same as a plain Gaussian likelihood with the marginalised precision -- the one-off transformation the reference offers as
+        '.prec' (257-312), here applied to '.marg' / '.best' parameters for the SUM loglikelihood + logprior:
+
+            P' = L Q L^T,  Q = 1 - T~^T (T~ T~^T + D)^{-1} T~,  T~ = T L,  P = L L^T,  D = diag(1 / scale^2),
+            data' = data + (x0 - loc) T  (Gaussian priors),   offset = -1/2 logdet (T~ T~^T + D)[marg, marg]
+
+        so the marginalised fit runs through the chi2 GEMM at the cost of the non-marginalised one (no residual rows, no per-point Cholesky).  Q is singular for flat
+        priors: the device takes the factor F = L V sqrt(lambda) of P' = F F^T (eigen-decomposition of Q) instead of a Cholesky factor.  Separate ``loglikelihood`` /
+        ``logprior`` / solved values still come from the per-point path (:meth:`_get_context`)."""
+        self.initialize()
+        fixed_values = dict(fixed_values or {})
+        if not len(self.solved_params):
+            return self._get_context(fixed_values), 0.
+        if not self._solved_are_constant():
+            return self._get_context(fixed_values), 0.
+        key = ('posterior',) + tuple(sorted(fixed_values.items()))
+        if key not in self._contexts:
+            from .._lib import Context
+            flatdata_list, precision = self._flatdata_list(), self._precision_input
+            if len(self.prec_params):
+                flatdata_list, precision = self._marginalize_precision(fixed_values, flatdata_list, precision)
+            solved = self.solved_params
+            varied = self.varied_params
+            theta = np.array([[float(fixed_values.get(param.name, param.value)) for param in varied]], dtype='f8')
+            x0 = np.array([float(fixed_values.get(param.name, param.value)) for param in solved], dtype='f8')
+            base = dict(fixed_values)
+            base.update({param.name: value for param, value in zip(solved, x0)})
+
+            def flattheory(fixed):
+                ctx = Context(self._spec(fixed, flatdata_list, precision, drop_solved=True), device=self.device)
+                flat = ctx.eval_batch_host(theta, return_flattheory=True)[3][0]
+                ctx.close()
+                return flat
+
+            flat0 = flattheory(base)
+            T = np.array([flattheory({**base, param.name: value + 1.}) - flat0 for param, value in zip(solved, x0)])        # [n_s, n]
+            full = np.diag(precision) if precision.ndim == 1 else 0.5 * (precision + precision.T)
+            L = np.linalg.cholesky(full)
+            Tt = T.dot(L)
+            loc = np.array([param.prior.loc if param.prior.dist == 'norm' else 0. for param in solved])
+            prec = np.array([param.prior.scale**(-2) if param.prior.dist == 'norm' else 0. for param in solved])                 # likelihoods/base.py:180-183
+            A = Tt.dot(Tt.T) + np.diag(prec)
+            Q = np.eye(full.shape[0]) - Tt.T.dot(np.linalg.solve(A, Tt))
+            lam, V = np.linalg.eigh(0.5 * (Q + Q.T))
+            factor = L.dot(V * np.sqrt(np.clip(lam, 0., None)))
+            shift = np.where(prec > 0., x0 - loc, 0.).dot(T)
+            new_flatdata, start = [], 0
+            for flatdata in flatdata_list:
+                new_flatdata.append(flatdata + shift[start:start + flatdata.size])
+                start += flatdata.size
+            marg = np.array([(param.derived.replace('.auto', self.solved_default) if param.derived.startswith('.auto') else param.derived).startswith('.marg') for param in solved])
+            offset = -0.5 * np.linalg.slogdet(A[np.ix_(marg, marg)])[1] if marg.any() else 0.                                     # likelihoods/base.py:394-404
+            spec = self._spec(base, new_flatdata, factor.dot(factor.T), drop_solved=True)
+            spec['precision_factor'] = factor
+            if len(self._contexts) > 8:
+                self._contexts.pop(next(iter(self._contexts))).close()
+            self._contexts[key] = Context(spec, device=self.device)
+            self._posterior_offsets = getattr(self, '_posterior_offsets', {})
+            self._posterior_offsets[key] = float(offset)
+        return self._contexts[key], self._posterior_offsets[key]
 
     def _marginalize_precision(self, fixed_values, flatdata_list, precision):
         r"""'.prec' parameters (likelihoods/base.py:257-312): linear parameters marginalised once, at the current values of the others, into
@@ -526,6 +609,10 @@ class SumLikelihood(BaseLikelihood):
     def _get_context(self, fixed_values=None):
         self.initialize()
         return self._fused._get_context(fixed_values)
+
+    def _get_posterior_context(self, fixed_values=None):
+        self.initialize()
+        return self._fused._get_posterior_context(fixed_values)
 
     @property
     def size(self):

@@ -39,11 +39,13 @@ class BasePosteriorSampler(object):
     def _logposterior_local(self, values):
         """samplers/base.py:144-193 for the rows handled by this process."""
         values = np.atleast_2d(np.asarray(values, dtype='f8'))
-        get_context = getattr(self.likelihood, '_get_context', None)
+        get_context = getattr(self.likelihood, '_get_posterior_context', None)
         if self.fast and get_context is not None and values.shape[0]:
             # GPU likelihoods: the same conventions (NaN rows, rows outside the prior, non-finite results -> -inf) are applied by the finalize kernels:
-            # ONE C-ABI call per batch instead of the dictionary round trip below
-            return get_context().eval_logposterior_host(values)[0]
+            # ONE C-ABI call per batch instead of the dictionary round trip below; linear parameters with constant derivative rows are marginalised once, into the
+            # precision matrix, instead of at every point
+            ctx, offset = get_context()
+            return ctx.eval_logposterior_host(values)[0] + offset
         toret = np.full(values.shape[0], -np.inf)
         mask = ~np.isnan(values).any(axis=1)                      # bcast_values, samplers/base.py:57-61
         if not mask.any():

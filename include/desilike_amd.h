@@ -71,6 +71,8 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
  *   n_obs           i32[1]
  *   precision       f64[n*n] or f64[n]  precision matrix (or its diagonal), n = total data size
  *                                        (Hartlap / Percival factors already applied by the host: likelihoods/base.py:623-656)
+ *   precision_factor f64[n*n]  optional: any F with precision = F F^T (may be rank-deficient), used instead of the Cholesky factor of ``precision``
+ *                                        (posterior marginalised once over linear parameters with constant derivative rows, likelihoods/base.py:257-312)
  *   obs<i>.theory, .template, .apmode, .transform   i32[1]
  *   obs<i>.damping_fid  i32[1]  1: Gaussian damping at the fiducial (k, mu) (SimpleTracerPowerSpectrumMultipoles full_shape.py:410-411) instead of the AP-distorted ones (492-493)
  *   obs<i>.eta, .f_fid, .a, .kp, .nd                f64[1]

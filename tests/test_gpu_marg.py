@@ -174,3 +174,54 @@ def test_prec_one_off_precision_marginalisation():
         q = dict(zip(names, g['theta'][i])); q['b1'] = (q['b1'], q['b1']); q['sn0'] = 0.
         ref = orc.gaussian_loglikelihood(orc.fullshape_observable(c, q)['flattheory'], c['flatdata'] - 0.2 * T[0], P_ref)[0]
         assert abs(derived['loglikelihood'][i] - ref) <= 1e-9 * max(1., abs(ref))
+
+
+@pytest.mark.parametrize('case', ['sn0_marg', 'sn0_best', 'bao_broadband', 'templates'])
+def test_posterior_context_equals_per_point_marginalisation(case):
+    """Solved parameters with point-independent derivative rows: marginalising them once into the precision factor (``_get_posterior_context``: what the samplers'
+    fast path evaluates, one chi2 GEMM, no per-point solve) gives the same loglikelihood + logprior as the per-point solve (likelihoods/base.py:314-413) -- Gaussian and
+    flat priors (singular marginalised precision), '.marg' and '.best', x0 != loc."""
+    if case.startswith('sn0'):
+        g = load_golden('marg_sn0_grid')
+        like = make_marg_likelihood(g, solved='.marg' if case == 'sn0_marg' else '.best')
+    elif case == 'bao_broadband':
+        from test_host_api import make_cfg4
+        g, like = make_cfg4('xi')
+        like.initialize()
+        for param in like.observables[0].wmatrix.theory.init.params.select(basename='al*'):
+            param.update(derived='.marg')
+        like._invalidate()
+    else:
+        from test_window_extras import make_likelihood
+        g = load_golden('cfg2_fc_syst')
+        like = make_likelihood(g, solved='.marg')[0]
+    assert like._solved_are_constant()
+    rng = np.random.RandomState(11)
+    theta = np.column_stack([np.clip(param.ref.sample(size=64, random_state=rng), *param.prior.limits) for param in like.varied_params])
+    theta[5, 0] = np.nan
+    loglike, logprior, status = like._get_context().eval_batch_host(theta)[:3]
+    ctx, offset = like._get_posterior_context()
+    assert ctx.n_solved == 0
+    logpost, status_p = ctx.eval_logposterior_host(theta)
+    logpost = logpost + offset
+    ok = status == 0
+    assert ok.sum() == 63 and np.array_equal(status_p == 0, ok) and np.isneginf(logpost[~ok]).all()
+    ref = loglike[ok] + logprior[ok]
+    assert (np.abs(logpost[ok] - ref) <= 1e-9 * np.maximum(1., np.abs(ref))).all(), np.abs(logpost[ok] - ref).max()
+    # the samplers take this route
+    from desilike_amd.samplers import BasePosteriorSampler
+    assert np.allclose(BasePosteriorSampler(like).logposterior(theta[:5]), ref[:5], rtol=1e-9, atol=1e-9)
+
+
+def test_posterior_context_falls_back_for_point_dependent_derivatives():
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, EFTLikeKaiserTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    g = load_golden('cfg2_shapefit_window')
+    theory = EFTLikeKaiserTracerPowerSpectrumMultipoles(template=ShapeFitPowerSpectrumTemplate(z=0.5))
+    theory.init.params['ct0_2'].update(derived='.marg')
+    obs = TracerPowerSpectrumMultipolesObservable(data=g['obs0']['flatdata'], kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=1e4)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
+    assert not like._solved_are_constant()
+    ctx, offset = like._get_posterior_context()
+    assert ctx is like._get_context() and offset == 0. and ctx.n_solved == 1

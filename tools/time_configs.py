@@ -8,8 +8,8 @@ import numpy as np
 import torch
 
 
-def time_likelihood(label, like, B, steps=40):
-    ctx = like._get_context()
+def time_likelihood(label, like, B, steps=40, posterior=False):
+    ctx = like._get_posterior_context()[0] if posterior else like._get_context()
     rng = np.random.RandomState(3)
     theta = np.column_stack([np.clip(param.ref.sample(size=B, random_state=rng), *param.prior.limits) for param in like.varied_params])
     th = torch.as_tensor(theta, dtype=torch.float64, device='cuda').contiguous()
@@ -38,6 +38,14 @@ def main():
     for space in ['xi', 'pk']:
         g, like = make_cfg4(space)
         time_likelihood('cfg4: damped BAO ' + space, like, 8192)
+    # the DESI-style BAO fit: every broadband term solved analytically
+    g, like = make_cfg4('xi')
+    like.initialize()
+    for param in like.observables[0].wmatrix.theory.init.params.select(basename='al*'):
+        param.update(derived='.marg')
+    like._invalidate()
+    time_likelihood('cfg4: damped BAO xi, 10 broadband terms marginalised', like, 8192)
+    time_likelihood('  same, marginalised once into the precision (samplers)', like, 8192, posterior=True)
 
 
 if __name__ == '__main__' and len(sys.argv) == 1:
