@@ -553,6 +553,22 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         ctx.eval_batch(theta, loglike=loglike, logprior=logprior, flattheory=flattheory, status=status, stream=stream)
         return loglike, logprior, status
 
+    def evaluate_logposterior(self, theta, logposterior=None, status=None, stream=None):
+        """Fast path for samplers resident on the GPU: ``theta`` float64 torch tensor [B, n_varied] on this likelihood's device -> ``logposterior [B]``
+        (loglikelihood + logprior with the samplers' -inf conventions, samplers/base.py:144-200), asynchronous on ``stream``.  Linear parameters with constant
+        derivative rows are marginalised once into the precision (:meth:`_get_posterior_context`)."""
+        import torch
+        ctx, offset = self._get_posterior_context()
+        if logposterior is None: logposterior = torch.empty(theta.shape[0], dtype=torch.float64, device=theta.device)
+        ctx.eval_logposterior(theta, logposterior, status=status, stream=stream)
+        if offset != 0.:
+            if stream is None:
+                logposterior += offset
+            else:
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=theta.device)):
+                    logposterior += offset
+        return logposterior
+
     @property
     def size(self):
         return len(self.flatdata)
@@ -613,6 +629,10 @@ class SumLikelihood(BaseLikelihood):
     def _get_posterior_context(self, fixed_values=None):
         self.initialize()
         return self._fused._get_posterior_context(fixed_values)
+
+    def evaluate_logposterior(self, *args, **kwargs):
+        self.initialize()
+        return self._fused.evaluate_logposterior(*args, **kwargs)
 
     @property
     def size(self):

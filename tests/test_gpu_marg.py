@@ -211,6 +211,10 @@ def test_posterior_context_equals_per_point_marginalisation(case):
     # the samplers take this route
     from desilike_amd.samplers import BasePosteriorSampler
     assert np.allclose(BasePosteriorSampler(like).logposterior(theta[:5]), ref[:5], rtol=1e-9, atol=1e-9)
+    import torch
+    dev = like.evaluate_logposterior(torch.as_tensor(theta, dtype=torch.float64, device='cuda:0').contiguous())
+    torch.cuda.synchronize()
+    assert np.allclose(dev.cpu().numpy()[ok], ref, rtol=1e-9, atol=1e-9)
 
 
 def test_posterior_context_falls_back_for_point_dependent_derivatives():
