@@ -89,10 +89,13 @@ struct DlObsDev {
     DlInput sn_in[DL_MAX_EFT];
     // pass-through columns n_in .. n_in + n_pass - 1 of the theory vector: parameters the observable is linear in through a constant
     // matrix folded into the window (BAO broadband terms bao.py:495-534, 881-905)
-    int32_t n_pass, bao_mode;              // bao_mode bits 0-3: 0 = '' / 'recsym', 1 = 'reciso' (bao.py:131); bits 4-7: wiggle model, 0 = 'standard' (bao.py:123-136), else
-                                           // 8 | (1: 'fix-damping') | (2: 'move-all') | (4: 'fog-damping') (bao.py:137-150)
+    int32_t n_pass, bao_mode;              // bao_mode bits 0-3: 0 = '' / 'recsym', 1 = 'reciso' (bao.py:131); bits 4-8: wiggle model, 0 = 'standard' (bao.py:123-136), else
+                                           // 8 | (1: 'fix-damping') | (2: 'move-all') | (4: 'fog-damping') (bao.py:137-150), or 16 | (2: 'move-all') | (4: 'fog-damping'):
+                                           // resummed wiggles (bao.py:165-266)
     DlInput pass_in[DL_MAX_PASS];
     DlInput dbeta, sigmas;                 // BAO wiggle model (bao.py:117)
+    DlInput dres;                          // resummed wiggles: growth rescaling d (bao.py:201)
+    double res_sig[4];                     // resummed wiggles: sigma_dd^2, sigma_nl^2, sigma_x^2, shotnoise * sigma_sn^2 (bao.py:186-199)
     double smoothing_radius;
     // emulated theory (kind 3): features phi[(h, m)] = basis_h(theta) * mono_m(theta); the last emulator layer, the bias-table sum
     // (full_shape.py:1182-1186), the k-interpolation and the window are ONE matrix folded on the host (desilike_amd/emulators.py)
@@ -727,7 +730,7 @@ DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& 
 // The BAO template does not change P(k) (power_template.py:372-376): both splines are constants, held as interval polynomials in global
 // memory (L1 / L2 resident).  Phase A: per-mu AP factors; phase B: one k per thread, mu loop unrolled by 4; output staged in LDS.
 // ------------------------------------------------------------------------------------------------------------------------
-enum { DL_BAO_QPER = 0, DL_BAO_F, DL_BAO_B1, DL_BAO_SIGS, DL_BAO_LQ = 8, DL_BAO_FAC = DL_BAO_LQ + DL_MAX_MU, DL_BAO_MUP2 = DL_BAO_FAC + DL_MAX_MU,
+enum { DL_BAO_QPER = 0, DL_BAO_F, DL_BAO_B1, DL_BAO_SIGS, DL_BAO_D, DL_BAO_LQ = 8, DL_BAO_FAC = DL_BAO_LQ + DL_MAX_MU, DL_BAO_MUP2 = DL_BAO_FAC + DL_MAX_MU,
        DL_BAO_SD = DL_BAO_MUP2 + DL_MAX_MU, DL_BAO_SDF = DL_BAO_SD + DL_MAX_MU, DL_BAO_PT = DL_BAO_SDF + DL_MAX_MU };
 
 DL_HD size_t dl_bao_shared_doubles(int n_in) { return DL_BAO_PT + (size_t)n_in; }
@@ -755,11 +758,12 @@ DL_HD void dl_bao_phaseA(int tid, int nthr, const DlObsDev& o, const double* th,
             lds[DL_BAO_F] = dl_get(o.dbeta, th) * (o.f_fid * dl_get(o.df, th));   // bao.py:119 with power_template.py:374
             lds[DL_BAO_B1] = dl_get(o.b1X, th);
             lds[DL_BAO_SIGS] = dl_get(o.sigmas, th);
+            lds[DL_BAO_D] = dl_get(o.dres, th);
         }
     }
 }
 
-template <bool STANDARD>
+template <int MODEL>   // 0: 'standard', 1: 'fix-damping' / 'move-all' / 'fog-damping' family, 2: resummed wiggles
 DL_HD void dl_bao_phaseB_m(int tid, int nthr, const DlObsDev& o, double* lds) {
     const double qper = lds[DL_BAO_QPER], f = lds[DL_BAO_F], b1 = lds[DL_BAO_B1], sigmas = lds[DL_BAO_SIGS];
     const int n_ell = o.n_ell, n_mu = o.n_mu, n_kin = o.n_kin, n_mu4 = (o.n_mu + 3) & ~3;
@@ -787,7 +791,7 @@ DL_HD void dl_bao_phaseB_m(int tid, int nthr, const DlObsDev& o, double* lds) {
                 double kap = kq * lds[DL_BAO_FAC + m];
                 double mup2 = lds[DL_BAO_MUP2 + m];
                 double mu = (m < n_mu) ? o.mu[m] : 0.;
-                if (STANDARD) {   // 'standard' (Chen 2023); compile-time: as a run-time branch inside the unrolled mu loop it cost 27 % of the kernel
+                if (MODEL == 0) {   // 'standard' (Chen 2023); compile-time: as a run-time branch inside the unrolled mu loop it cost 27 % of the kernel
                     double ca = b1 + f * mup2 * (1. - sk);
                     double Cap = ca * ca * exp(-(kap * kap * lds[DL_BAO_SD + m]) / 2.);         // bao.py:129-132
                     double sm = sigmas * kk * mu;
@@ -799,8 +803,28 @@ DL_HD void dl_bao_phaseB_m(int tid, int nthr, const DlObsDev& o, double* lds) {
                     const double* cn = o.coef_n + 4 * (size_t)j;
                     double pknowap = fma(fma(fma(cn[3], u, cn[2]), u, cn[1]), u, cn[0]);        // P_now(k')
                     // damping of the wiggles: at the fiducial (k, mu) ('fix-damping') or at the distorted ones; SD[m] holds the distorted-mu combination
-                    double snl2 = fix_damping ? kk * kk * lds[DL_BAO_SDF + m] : kap * kap * lds[DL_BAO_SD + m];
-                    double dw = pkw / pknowap * exp(-snl2 / 2.);
+                    double dw;
+                    if (MODEL == 2) {
+                        // ResummedPowerSpectrumWiggles.wiggles at (k', mu') (bao.py:201-222): b1 Eulerian bias, d rescales the growth factor
+                        const double dd = lds[DL_BAO_D], fm = f * mup2;
+                        const double e0 = -0.5 * (1. + f * (f + 2.) * mup2) * kap * kap * dd * dd;
+                        const double sdd2 = o.res_sig[0] + o.res_sig[3] / (b1 * b1);
+                        double rw;
+                        if (reciso) {
+                            double kr = kap * o.smoothing_radius;
+                            const double skr = exp(-0.5 * (kr * kr)), skc = 1. - skr;
+                            const double t = b1 + fm * skc - skr;
+                            const double sds2 = (1. + fm) * sdd2 + f * (1. + f) * mup2 * o.res_sig[2];
+                            const double sss2 = sdd2 + f * fm * o.res_sig[1] + 2. * fm * o.res_sig[2];
+                            rw = t * t * exp(e0 * sdd2) + 2. * t * (1. + fm) * skr * exp(e0 * sds2) + (1. + fm) * (1. + fm) * skr * skr * exp(e0 * sss2);
+                        } else {
+                            rw = (b1 + fm) * (b1 + fm) * exp(e0 * sdd2);
+                        }
+                        dw = rw * pkw / pknowap;
+                    } else {
+                        double snl2 = fix_damping ? kk * kk * lds[DL_BAO_SDF + m] : kap * kap * lds[DL_BAO_SD + m];
+                        dw = pkw / pknowap * exp(-snl2 / 2.);
+                    }
                     // smooth part: everything at the distorted (k', mu') ('move-all') or at the fiducial ones
                     double ks = move_all ? kap : kk, mus2 = move_all ? mup2 : mu * mu;
                     double pkn = move_all ? pknowap : pknow;
@@ -831,8 +855,10 @@ DL_HD void dl_bao_phaseB_m(int tid, int nthr, const DlObsDev& o, double* lds) {
 }
 
 DL_HD void dl_bao_phaseB(int tid, int nthr, const DlObsDev& o, double* lds) {
-    if ((o.bao_mode >> 4) == 0) dl_bao_phaseB_m<true>(tid, nthr, o, lds);
-    else dl_bao_phaseB_m<false>(tid, nthr, o, lds);
+    const int model = o.bao_mode >> 4;
+    if (model == 0) dl_bao_phaseB_m<0>(tid, nthr, o, lds);
+    else if (model & 16) dl_bao_phaseB_m<2>(tid, nthr, o, lds);
+    else dl_bao_phaseB_m<1>(tid, nthr, o, lds);
 }
 
 // coalesced store of the multipoles + pass-through columns

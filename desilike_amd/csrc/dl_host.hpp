@@ -346,7 +346,7 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     struct { const char* name; DlInput* in; double def; } inputs[] = {
         {"qpar", &d.qpar, 1.}, {"qper", &d.qper, 1.}, {"qiso", &d.qiso, 1.}, {"qap", &d.qap, 1.}, {"df", &d.df, 1.}, {"dm", &d.dm, 0.}, {"dn", &d.dn, 0.},
         {"sigmapar", &d.sigpar, 0.}, {"sigmaper", &d.sigper, 0.}, {"b1X", &d.b1X, 1.}, {"b1Y", &d.b1Y, 1.}, {"sn0", &d.sn0, 0.},
-        {"dbeta", &d.dbeta, 1.}, {"sigmas", &d.sigmas, 0.}};
+        {"dbeta", &d.dbeta, 1.}, {"sigmas", &d.sigmas, 0.}, {"dres", &d.dres, 1.}};
     for (auto& it : inputs) {
         *it.in = dl_input_from(cfg, p + "in." + it.name, it.def);
         if (it.in->col >= n_params) { err = p + "in." + it.name + ": theta column out of range"; return false; }
@@ -363,6 +363,8 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         }
         d.bao_mode = cfg.i(p + "bao_mode", 0);
         d.smoothing_radius = cfg.f(p + "smoothing_radius", 15.);
+        const auto& res = cfg.F(p + "resummed");   // sigma_dd^2, sigma_nl^2, sigma_x^2, shotnoise * sigma_sn^2 (bao.py:186-199)
+        for (int q = 0; q < 4; ++q) d.res_sig[q] = q < (int)res.size() ? res[q] : 0.;
     }
     // template knots in log10 k (full_shape.py:498: interp1d(log10(kap), log10(k11), pk11))
     std::vector<double> x_t(d.n_t), sf_th(d.n_t), sf_lg(d.n_t), lkin(d.n_kin);

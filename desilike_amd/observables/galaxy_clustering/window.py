@@ -251,7 +251,7 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
             shotnoise = 0.
         else:
             shotnoise = float(shotnoise)
-            if getattr(self.theory, '_kind', None) == 3:   # theories scaling their stochastic terms by the shot noise take it from the observable (window.py:441-443)
+            if getattr(self.theory, '_kind', None) == 3 or getattr(self.theory, '_wants_shotnoise', False):   # theories using the shot noise take it from the observable (window.py:441-443)
                 self.theory.init.setdefault('shotnoise', shotnoise)
         self.shotnoise = shotnoise
         # window.py:445-457

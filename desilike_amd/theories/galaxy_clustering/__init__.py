@@ -4,4 +4,5 @@ from .full_shape import (KaiserTracerPowerSpectrumMultipoles, SimpleTracerPowerS
                          EFTLikeKaiserTracerCorrelationFunctionMultipoles, LPTVelocileptorsTracerPowerSpectrumMultipoles,
                          REPTVelocileptorsTracerPowerSpectrumMultipoles, EmulatedTracerPowerSpectrumMultipoles,
                          LPTVelocileptorsTracerCorrelationFunctionMultipoles, REPTVelocileptorsTracerCorrelationFunctionMultipoles)
-from .bao import DampedBAOWigglesTracerPowerSpectrumMultipoles, DampedBAOWigglesTracerCorrelationFunctionMultipoles
+from .bao import (DampedBAOWigglesTracerPowerSpectrumMultipoles, DampedBAOWigglesTracerCorrelationFunctionMultipoles,
+                  ResummedBAOWigglesTracerPowerSpectrumMultipoles, ResummedBAOWigglesTracerCorrelationFunctionMultipoles)

@@ -62,12 +62,20 @@ class _BaseDampedBAOTracer(BaseCalculator):
     _powers = ()
     _ref_limits = (-1e2, 1e2)
 
+    _resummed = False
+    _wants_shotnoise = False
+
     @classmethod
     def _default_params(cls, broadband='power', **kwargs):
         """bao.py:462-481 (power spectrum) / 833-853 (correlation function)."""
         import copy
         broadband = str(broadband)
         params = copy.deepcopy(_BAO_PARAMS)
+        if cls._resummed:   # bao.yaml: b1, dbeta, sigmas, d
+            params = {name: params[name] for name in ['b1', 'dbeta', 'sigmas']}
+            params['dbeta'].update(ref=dict(limits=[0.95, 1.05]))
+            if cls._space == 'pk':   # (the correlation function class has no 'd' parameter in bao.yaml: d = 1)
+                params['d'] = dict(value=1., fixed=True, prior=dict(limits=[0., 4.]), ref=dict(limits=[0.8, 1.2]), latex='d')
         if 'power' in broadband:
             for ell in (0, 2, 4):
                 for pow in cls._powers:
@@ -102,7 +110,9 @@ class _BaseDampedBAOTracer(BaseCalculator):
             raise ValueError('Reconstruction mode {} must be one of {}'.format(self.mode, ['', 'recsym', 'reciso']))
         self.model = str(init.get('model', 'standard'))   # 'standard' (bao.py:123-136) or any combination of 'fix-damping', 'move-all', 'fog-damping' (137-150)
         self._model_bits = 0
-        if self.model != 'standard':
+        if self._resummed:
+            self._model_bits = 16 | (2 if 'move-all' in self.model else 0) | (4 if 'fog-damping' in self.model else 0)
+        elif self.model != 'standard':
             self._model_bits = 8 | (1 if 'fix-damping' in self.model else 0) | (2 if 'move-all' in self.model else 0) | (4 if 'fog-damping' in self.model else 0)
         self.smoothing_radius = float(init.get('smoothing_radius', 15.))
         self.kin = np.array(k, dtype='f8')
@@ -120,9 +130,25 @@ class _BaseDampedBAOTracer(BaseCalculator):
         self.z = template.z
         if template.apmode != 'qparqper':
             pass
+        if self._resummed:
+            self._set_resummation(float(init.get('shotnoise', 0.)))
         # broadband orders (bao.py:24-41): parameters al{ell}_{pow} of the multipoles in use; others are dropped
         self.broadband = str(init.get('broadband', 'power'))
         self.broadband_orders = _get_orders('al', self.init.params, self.ells)
+
+    def _set_resummation(self, shotnoise):
+        """Damping scales of the resummed wiggles (ResummedPowerSpectrumWiggles.calculate, bao.py:186-199): constants of the (fixed) BAO template."""
+        from scipy import special, integrate
+        template = self.template
+        k, pklin = template.k, template.pknow_dd_fid
+        j0 = special.jn(0, template.fiducial.rs_drag * k)
+        sk = np.exp(-0.5 * (k * self.smoothing_radius)**2) if self.mode else 0.
+        skc = 1. - sk
+        self.shotnoise = shotnoise
+        self.sigma_sn2 = 1. / self.smoothing_radius / 6. / np.pi**1.5
+        self.sigma_nl2 = 1. / (3. * np.pi**2) * integrate.simpson((1. - j0) * pklin, x=k)
+        self.sigma_dd2 = 1. / (3. * np.pi**2) * integrate.simpson((1. - j0) * skc**2 * pklin, x=k)
+        self.sigma_x2 = 1. / (3. * np.pi**2) * integrate.simpson((1. - j0) * skc * pklin, x=k) if self.mode == 'reciso' else 0.
 
     def _pknow_fid(self, k):
         """No-wiggle fiducial power at ``k``: cubic interpolation in log10 k on the template knots (``_interp(template, 'pknow_dd_fid', k)``, bao.py:18-19)."""
@@ -164,11 +190,14 @@ class _BaseDampedBAOTracer(BaseCalculator):
                     bao_mode=np.array([(1 if self.mode == 'reciso' else 0) | (self._model_bits << 4)], dtype='i4'), smoothing_radius=[self.smoothing_radius], pknow_dd_fid=template.pknow_dd_fid)
         spec.update(template._template_spec())
         spec['template'] = np.array([0], dtype='i4')   # the BAO template never changes P(k) (power_template.py:372-376)
+        if self._resummed:
+            spec['resummed'] = np.array([self.sigma_dd2, self.sigma_nl2, self.sigma_x2, self.shotnoise * self.sigma_sn2], dtype='f8')
         return spec
 
     def _input_map(self):
         toret = {name: name for name in ['qpar', 'qper', 'qiso', 'qap', 'df', 'dbeta', 'sigmas', 'sigmapar', 'sigmaper']}
         toret['b1X'] = toret['b1Y'] = 'b1'
+        if self._resummed: toret['dres'] = 'd'
         toret['pass'] = list(self._broadband_names)
         return toret
 
@@ -271,3 +300,15 @@ class DampedBAOWigglesTracerCorrelationFunctionMultipoles(_BaseDampedBAOTracer):
 
     def _fold(self):
         return np.hstack([self._hankel_block, self.broadband_matrix])
+
+
+class ResummedBAOWigglesTracerPowerSpectrumMultipoles(DampedBAOWigglesTracerPowerSpectrumMultipoles):
+    """BAO power spectrum multipoles with resummed wiggles and broadband terms (bao.py:165-266, 670-717): the damping of the wiggles follows from the template
+    (three integrals over the no-wiggle power, constants here), parameters b1, dbeta, sigmas, d; ``model`` may contain 'move-all', 'fog-damping'."""
+    _resummed = True
+    _wants_shotnoise = True   # "to be given shot noise by window matrix" (bao.py:236)
+
+
+class ResummedBAOWigglesTracerCorrelationFunctionMultipoles(DampedBAOWigglesTracerCorrelationFunctionMultipoles):
+    """BAO correlation function multipoles with resummed wiggles (bao.py:1051-1096)."""
+    _resummed = True

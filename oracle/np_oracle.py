@@ -440,6 +440,49 @@ def bao_damped_power(k, mu, wmu_ell, k_t, pk_dd, pknow_dd, f, qpar=1., qper=1., 
     return np.sum(pkmu * wmu_ell[:, None, :], axis=-1)
 
 
+def bao_resummation_scales(k_t, pknow_dd, rs_drag, mode='', smoothing_radius=15.):
+    """ResummedPowerSpectrumWiggles.calculate, bao.py:186-199: sigma_dd^2, sigma_nl^2, sigma_x^2, sigma_sn^2 (Simpson integrals over the template knots)."""
+    from scipy import special, integrate
+    j0 = special.jn(0, rs_drag * k_t)
+    sk = np.exp(-1. / 2. * (k_t * smoothing_radius)**2) if mode else 0.
+    skc = 1. - sk
+    sigma_sn2 = 1. / smoothing_radius / 6 / np.pi**(3. / 2.)
+    sigma_nl2 = 1. / (3. * np.pi**2) * integrate.simpson((1. - j0) * pknow_dd, x=k_t)
+    sigma_dd2 = 1. / (3. * np.pi**2) * integrate.simpson((1. - j0) * skc**2 * pknow_dd, x=k_t)
+    sigma_x2 = 1. / (3. * np.pi**2) * integrate.simpson((1. - j0) * skc * pknow_dd, x=k_t) if mode == 'reciso' else 0.
+    return sigma_dd2, sigma_nl2, sigma_x2, sigma_sn2
+
+
+def bao_resummed_power(k, mu, wmu_ell, k_t, pk_dd, pknow_dd, f, scales, shotnoise=0., qpar=1., qper=1., b1=1., sigmas=0., d=1., mode='', smoothing_radius=15., model='standard'):
+    """ResummedBAOWigglesPowerSpectrumMultipoles.calculate (bao.py:246-266) with ResummedPowerSpectrumWiggles.wiggles (201-222); ``f`` includes dbeta."""
+    sigma_dd2, sigma_nl2, sigma_x2, sigma_sn2 = scales
+    jac, kap, muap = ap_k_mu(k, mu, qpar=qpar, qper=qper)
+    logkt = np.log10(k_t)
+    pknowap = interp1d(np.log10(kap), logkt, pknow_dd, method='cubic')
+    wig = interp1d(np.log10(kap), logkt, pk_dd, method='cubic') - pknowap
+    ksq = (1 + f * (f + 2) * muap**2) * kap**2                                                      # 204
+    sdd2 = sigma_dd2 + shotnoise * sigma_sn2 / b1**2
+    sk = np.exp(-1. / 2. * (kap * smoothing_radius)**2)
+    skc = 1. - sk
+    if mode == 'reciso':                                                                            # 211-216
+        res = (b1 + f * muap**2 * skc - sk)**2 * np.exp(-1. / 2. * ksq * d**2 * sdd2)
+        sigma_ds2 = (1. + f * muap**2) * sdd2 + f * (1. + f) * muap**2 * sigma_x2
+        res = res + 2. * (b1 + f * muap**2 * skc - sk) * (1 + f * muap**2) * sk * np.exp(-1. / 2. * ksq * d**2 * sigma_ds2)
+        sigma_ss2 = sdd2 + f**2 * muap**2 * sigma_nl2 + 2 * f * muap**2 * sigma_x2
+        res = res + (1 + f * muap**2)**2 * sk**2 * np.exp(-1. / 2. * ksq * d**2 * sigma_ss2)
+    else:                                                                                           # 209-210, 217-218
+        res = (b1 + f * muap**2)**2 * np.exp(-1. / 2. * ksq * d**2 * sdd2)
+    damped_wiggles = res * wig / pknowap                                                            # 251
+    kk = k[:, None]
+    ks, mus = (kap, muap) if 'move-all' in model else (kk, mu)
+    pknow = interp1d(np.log10(ks * np.ones_like(kap)), logkt, pknow_dd, method='cubic')
+    fog = 1. / (1. + (sigmas * ks * mus)**2 / 2.)**2.
+    sks = np.exp(-1. / 2. * (ks * smoothing_radius)**2) if mode == 'reciso' else 0.
+    pksmooth = (b1 + f * mus**2 * (1 - sks))**2 * pknow
+    pkmu = pksmooth * fog * (1. + damped_wiggles) if 'fog-damping' in model else pksmooth * (fog + damped_wiggles)
+    return np.sum(pkmu * wmu_ell[:, None, :], axis=-1)
+
+
 # ----------------------------------------------------------------------------------------------
 # a5 (velocileptors part): table-level bias combination                      full_shape.py:1182-1186, 1300-1313, 1577-1599, 1479-1488
 # ----------------------------------------------------------------------------------------------

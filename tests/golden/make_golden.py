@@ -576,6 +576,49 @@ def cfg4_models():
     save('cfg4_bao_models', **out)
 
 
+def cfg4_resummed():
+    """Resummed BAO wiggles (bao.py:165-266, 670-717, 1051-1096): P_ell with reciso reconstruction and shot noise, xi_ell with recsym and the Beutler-like smooth part."""
+    from desilike.theories.galaxy_clustering import BAOPowerSpectrumTemplate, ResummedBAOWigglesTracerCorrelationFunctionMultipoles, ResummedBAOWigglesTracerPowerSpectrumMultipoles
+    from desilike.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable
+    out = {}
+    for tag, space, model, mode in [('a', 'pk', 'standard', 'reciso'), ('b', 'xi', 'fog-damping_move-all', 'recsym'), ('c', 'pk', 'move-all', '')]:
+        template = BAOPowerSpectrumTemplate(z=0.5)
+        if space == 'xi':
+            theory = ResummedBAOWigglesTracerCorrelationFunctionMultipoles(template=template, mode=mode, model=model)
+            obs = TracerCorrelationFunctionMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, s=np.linspace(22.5, 167.5, 30), ells=(0, 2), theory=theory)
+            n, scale = 60, 3e-4
+        else:
+            theory = ResummedBAOWigglesTracerPowerSpectrumMultipoles(template=template, mode=mode, model=model)
+            obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, kedges=np.linspace(0.02, 0.3, 57), ells=(0, 2), wmatrix={'resolution': 3}, theory=theory, shotnoise=3e3)
+            n, scale = 112, 30.
+        if space == 'pk': theory.init.params['d'].update(fixed=False)   # (the correlation function class has no 'd' parameter: bao.yaml)
+        for param in theory.init.params.select(basename='al*'):
+            param.update(fixed=True)
+        rng = np.random.RandomState(4)
+        A = rng.standard_normal((n, n)) * scale
+        cov = A.dot(A.T) + (10. * scale)**2 * np.eye(n)
+        like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+        like()
+        names = like.varied_params.names()
+        theta = sample_theta(like, 12, seed=59)
+        (logpost, derived), errors = vmap(like, backend=None, errors='return', return_derived=True)({name: theta[:, i] for i, name in enumerate(names)})
+        assert not errors
+        power = []
+        for row in theta:
+            like(**dict(zip(names, row)))
+            power.append(np.asarray(theory.pt.power).copy())
+        pt = theory.pt
+        tmpl, wig = pt.template, pt.wiggles
+        if tag == 'a':
+            out.update(mu=np.asarray(pt.mu), wmu_ell=np.asarray(pt.wmu), f_fid=float(tmpl.f_fid), rs_drag=float(tmpl.cosmo.rs_drag))
+        out.update({tag + '_kin': np.asarray(pt.k), tag + '_k11': np.asarray(tmpl.k), tag + '_pk_dd_fid': np.asarray(tmpl.pk_dd_fid), tag + '_pknow_dd_fid': np.asarray(tmpl.pknow_dd_fid)})
+        out.update({tag + '_names': np.array(names), tag + '_theta': theta, tag + '_flatdata': np.asarray(obs.flatdata), tag + '_covariance': cov, tag + '_model': model, tag + '_mode': mode,
+                    tag + '_space': space, tag + '_wiggle_power': np.array(power), tag + '_loglikelihood': np.asarray(derived[like._param_loglikelihood]),
+                    tag + '_logprior': np.asarray(derived[like._param_logprior]), tag + '_shotnoise': float(wig.shotnoise),
+                    tag + '_sigmas2': np.array([wig.sigma_dd2, wig.sigma_nl2, getattr(wig, 'sigma_x2', 0.), wig.sigma_sn2])})
+    save('cfg4_bao_resummed', **out)
+
+
 def cfg2_fc_syst():
     """Window extras (row a6): top-hat fiber collisions folded into the binning matrix (window.py:428-438, 972-1049) and two systematic templates
     (window.py:439-443, 472-473, 1253-1309), klim row selection on top."""
@@ -698,7 +741,7 @@ def kaiser_xi(eft=False):
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi', 'cfg4_resummed']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -710,6 +753,7 @@ if __name__ == '__main__':
     if 'cfg4_pcs' in todo: cfg4_kernel_broadband('xi'); cfg4_kernel_broadband('pk')
     if 'cfg3_table_xi' in todo: cfg3_table_xi()
     if 'cfg4_models' in todo: cfg4_models()
+    if 'cfg4_resummed' in todo: cfg4_resummed()
     if 'cfg2_fc_syst' in todo: cfg2_fc_syst()
     if 'simple_tracer' in todo: simple_tracer()
     if 'kaiser_xi' in todo: kaiser_xi(False)
