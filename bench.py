@@ -216,10 +216,12 @@ def main():
                   'data': 'synthetic',
                   'config': {'workload': 'BASELINE configs[1]: ShapeFit+Kaiser P_ell ell=(0,2,4) x 40 k-bins, dense window 120x1200 (n_kin=400/ell), 120x120 precision, '
                                          '{:d} batched param points per GPU per step'.format(B), 'batch_per_gpu': B, 'n_params': 6, 'parallelism': 'walkers x{:d}'.format(world) + (', log-posteriors all-gathered in buckets of {:d} steps'.format(GATHER_EVERY) if distributed else '')},
-                  'roofline': {'bound': 'mfma', 'kernel': kernel_name,
+                  'roofline': {'bound': 'mfma', 'bound_detail': {'theory': 'fp64 VALU (transcendentals, spline evaluation, projection); its 78.6 TFLOP/s peak equals the fp64 matrix peak',
+                                                                  'window_gemm': 'fp64 MFMA (v_mfma_f64_16x16x4_f64)', 'finalize': 'launch latency'}[dominant], 'kernel': kernel_name,
                                'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
                                'flop_per_launch': flops[dominant] * per_launch, 'avg_launch_ms': kernel_ms[dominant]},
-                  'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize', 'total', 'event_overhead']}}
+                  'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize', 'total', 'event_overhead']},
+                  'kernel_frac_of_fp64_peak': {name: flops[name] * per_launch / (kernel_ms[name] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS for name in ['theory', 'window_gemm']}}
         if world == 1 and not distributed and not args.no_cpu_baseline:   # (the forced single-rank RCCL smoke mode writes log-posteriors into buckets, not `loglike`)
             base, check = cpu_baseline(likelihood, theta_host)
             gpu = loglike[:len(check)].cpu().numpy()
