@@ -164,3 +164,18 @@ def test_chunked_batch_boundaries():
     small = ctx.eval_batch_host(theta[pick])
     assert (np.abs(loglike[pick] - small[0]) <= 1e-10 * np.maximum(1., np.abs(small[0]))).all()
     assert np.array_equal(logprior[pick], small[1])
+
+
+def test_xcd_local_point_assignment_is_a_pure_permutation():
+    """Batches that are multiples of 256 take the XCD-local point assignment of the theory kernel (a row block is produced on the XCD whose chi2 GEMM workgroups consume
+    it); other sizes keep launch order.  Same numbers either way, two observables included."""
+    from test_host_api import make_cfg5
+    g, like = make_cfg5()
+    rng = np.random.RandomState(21)
+    theta = np.column_stack([np.clip(param.ref.sample(size=768, random_state=rng), *param.prior.limits) for param in like.varied_params])
+    ctx = like._get_context()
+    full = ctx.eval_batch_host(theta)               # 768 = 3 x 256: XCD-local
+    part = ctx.eval_batch_host(theta[:767])         # 767: launch order
+    one = ctx.eval_batch_host(theta[512:513])
+    assert np.array_equal(full[0][:767], part[0]) and np.array_equal(full[1][:767], part[1]) and np.array_equal(full[2][:767], part[2])
+    assert full[0][512] == one[0][0]
