@@ -64,6 +64,7 @@ class _BaseDampedBAOTracer(BaseCalculator):
 
     _resummed = False
     _wants_shotnoise = False
+    _default_model = 'standard'
 
     @classmethod
     def _default_params(cls, broadband='power', **kwargs):
@@ -108,7 +109,7 @@ class _BaseDampedBAOTracer(BaseCalculator):
         self.mode = str(init.get('mode', ''))
         if self.mode not in ['', 'recsym', 'reciso']:
             raise ValueError('Reconstruction mode {} must be one of {}'.format(self.mode, ['', 'recsym', 'reciso']))
-        self.model = str(init.get('model', 'standard'))   # 'standard' (bao.py:123-136) or any combination of 'fix-damping', 'move-all', 'fog-damping' (137-150)
+        self.model = str(init.get('model', self._default_model))   # 'standard' (bao.py:123-136) or any combination of 'fix-damping', 'move-all', 'fog-damping' (137-150)
         self._model_bits = 0
         if self._resummed:
             self._model_bits = 16 | (2 if 'move-all' in self.model else 0) | (4 if 'fog-damping' in self.model else 0)
@@ -312,3 +313,13 @@ class ResummedBAOWigglesTracerPowerSpectrumMultipoles(DampedBAOWigglesTracerPowe
 class ResummedBAOWigglesTracerCorrelationFunctionMultipoles(DampedBAOWigglesTracerCorrelationFunctionMultipoles):
     """BAO correlation function multipoles with resummed wiggles (bao.py:1051-1096)."""
     _resummed = True
+
+
+class SimpleBAOWigglesTracerPowerSpectrumMultipoles(DampedBAOWigglesTracerPowerSpectrumMultipoles):
+    """As :class:`DampedBAOWigglesTracerPowerSpectrumMultipoles` with the wiggles damped at the fiducial (k, mu): ``model='fix-damping'`` by default (bao.py:154-162, 630-668)."""
+    _default_model = 'fix-damping'
+
+
+class SimpleBAOWigglesTracerCorrelationFunctionMultipoles(DampedBAOWigglesTracerCorrelationFunctionMultipoles):
+    """Correlation function counterpart of :class:`SimpleBAOWigglesTracerPowerSpectrumMultipoles` (bao.py:1008-1048)."""
+    _default_model = 'fix-damping'
