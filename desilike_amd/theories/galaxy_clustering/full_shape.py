@@ -274,7 +274,7 @@ class _BaseVelocileptorsTracer(BaseCalculator):
     (the PT engines themselves are external CPU codes: SURVEY.md section 2 row 7).
 
     Parameters: ``pt`` (EmulatedCalculator with 'pktable', 'sigma8', 'fsigma8'), ``k``, ``ells``, ``prior_basis`` ('physical' | 'standard'),
-    ``tracer`` / ``fsat`` / ``sigv`` / ``shotnoise`` (full_shape.py:1154-1157), ``freedom`` is not implemented.
+    ``tracer`` / ``fsat`` / ``sigv`` / ``shotnoise`` (full_shape.py:1154-1157), ``freedom`` (None, 'max', 'min': parameter presets, 1100-1117).
     """
     _kind = 3   # DL_THEORY_EMULATED
     _rept = False
@@ -300,6 +300,25 @@ class _BaseVelocileptorsTracer(BaseCalculator):
             params['b1'] = dict(value=1. if cls._rept else 0., prior=dict(limits=[-1., 5.]), ref=dict(dist='norm', loc=1., scale=0.1))
             for name in cls._names[1:]:
                 params[name] = dict(value=0., prior=dict(dist='norm', loc=0., scale=100.), ref=dict(dist='norm', loc=0., scale=1.))
+        # ``freedom`` presets (full_shape.py:1100-1117): applied before the physical-basis priors, which then only keep the list of fixed parameters
+        freedom = kwargs.get('freedom', None)
+        suffix = 'p' if prior_basis == 'physical' else ''
+        fix = []
+        if freedom == 'max':
+            fix += ['alpha6']
+            if not suffix:
+                for name in ['b1', 'b2', 'bs', 'b3']: params[name].update(fixed=False)
+                for name in ['b2', 'bs', 'b3']: params[name].update(prior=dict(limits=[-15., 15.]))
+                for name in cls._names[4:]: params[name].update(prior=None)
+        elif freedom == 'min':
+            fix += ['b3', 'bs', 'alpha6']
+            if not suffix:
+                params['b2'].update(prior=dict(dist='norm', loc=0., scale=10.))
+                for name in cls._names[4:]: params[name].update(prior=None)
+        elif freedom is not None:
+            raise ValueError("freedom must be None, 'max' or 'min'")
+        for name in fix:
+            params[name + suffix].update(value=0., fixed=True)
         return params
 
     def initialize(self):
