@@ -51,6 +51,7 @@
 #define DL_MAX_WIDTH 256   // hidden units per layer (one thread each)
 #define DL_N_VPARS 11      // velocileptors 'pars': b1 b2 bs b3 alpha0 alpha2 alpha4 alpha6 sn0 sn2 sn4 (full_shape.py:1184)
 #define DL_N_MONO 19       // bias monomials (full_shape.py:1185)
+#define DL_MAX_ML 40       // multiplicative wiggle terms of the flexible BAO model (bao.py:310-322: up to 12 nodes per multipole)
 #define DL_MAX_PASS 32     // pass-through columns: linear (broadband) parameters appended to the theory vector
 #define DL_MAX_SOLVED 16   // analytically solved (marginalised / best-fit) linear parameters
 #define DL_FIR_D 28        // half-width of the convolution that inverts the uniform-knot spline system: |mu|^28 = 1e-16, mu = sqrt(3) - 2
@@ -91,11 +92,16 @@ struct DlObsDev {
     // matrix folded into the window (BAO broadband terms bao.py:495-534, 881-905)
     int32_t n_pass, bao_mode;              // bao_mode bits 0-3: 0 = '' / 'recsym', 1 = 'reciso' (bao.py:131); bits 4-8: wiggle model, 0 = 'standard' (bao.py:123-136), else
                                            // 8 | (1: 'fix-damping') | (2: 'move-all') | (4: 'fog-damping') (bao.py:137-150), or 16 | (2: 'move-all') | (4: 'fog-damping'):
-                                           // resummed wiggles (bao.py:165-266)
+                                           // resummed wiggles (bao.py:165-266), or 32 | (2: 'move-all'): flexible wiggles (bao.py:269-391)
     DlInput pass_in[DL_MAX_PASS];
     DlInput dbeta, sigmas;                 // BAO wiggle model (bao.py:117)
     DlInput dres;                          // resummed wiggles: growth rescaling d (bao.py:201)
     double res_sig[4];                     // resummed wiggles: sigma_dd^2, sigma_nl^2, sigma_x^2, shotnoise * sigma_sn^2 (bao.py:186-199)
+    // flexible wiggles (bao.py:269-391): terms ml_i K_i(k) L_{ell_i}(mu) multiplying the wiggles; K [n_ml, n_kin] sits behind ct_matrix, the Legendre
+    // polynomials L_ell(mu) [n_ell, n_mu] behind sn_matrix (both unused by the BAO kernels otherwise)
+    int32_t n_ml, pad_ml;
+    int32_t ml_ell[DL_MAX_ML];             // index (in ells_in) of the multipole each term belongs to
+    DlInput ml_in[DL_MAX_ML];
     double smoothing_radius;
     // emulated theory (kind 3): features phi[(h, m)] = basis_h(theta) * mono_m(theta); the last emulator layer, the bias-table sum
     // (full_shape.py:1182-1186), the k-interpolation and the window are ONE matrix folded on the host (desilike_amd/emulators.py)
@@ -731,7 +737,7 @@ DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& 
 // memory (L1 / L2 resident).  Phase A: per-mu AP factors; phase B: one k per thread, mu loop unrolled by 4; output staged in LDS.
 // ------------------------------------------------------------------------------------------------------------------------
 enum { DL_BAO_QPER = 0, DL_BAO_F, DL_BAO_B1, DL_BAO_SIGS, DL_BAO_D, DL_BAO_LQ = 8, DL_BAO_FAC = DL_BAO_LQ + DL_MAX_MU, DL_BAO_MUP2 = DL_BAO_FAC + DL_MAX_MU,
-       DL_BAO_SD = DL_BAO_MUP2 + DL_MAX_MU, DL_BAO_SDF = DL_BAO_SD + DL_MAX_MU, DL_BAO_PT = DL_BAO_SDF + DL_MAX_MU };
+       DL_BAO_SD = DL_BAO_MUP2 + DL_MAX_MU, DL_BAO_SDF = DL_BAO_SD + DL_MAX_MU, DL_BAO_ML = DL_BAO_SDF + DL_MAX_MU, DL_BAO_PT = DL_BAO_ML + DL_MAX_ML };
 
 DL_HD size_t dl_bao_shared_doubles(int n_in) { return DL_BAO_PT + (size_t)n_in; }
 
@@ -759,11 +765,12 @@ DL_HD void dl_bao_phaseA(int tid, int nthr, const DlObsDev& o, const double* th,
             lds[DL_BAO_B1] = dl_get(o.b1X, th);
             lds[DL_BAO_SIGS] = dl_get(o.sigmas, th);
             lds[DL_BAO_D] = dl_get(o.dres, th);
+            for (int i = 0; i < o.n_ml; ++i) lds[DL_BAO_ML + i] = dl_get(o.ml_in[i], th);
         }
     }
 }
 
-template <int MODEL>   // 0: 'standard', 1: 'fix-damping' / 'move-all' / 'fog-damping' family, 2: resummed wiggles
+template <int MODEL>   // 0: 'standard', 1: 'fix-damping' / 'move-all' / 'fog-damping' family, 2: resummed wiggles, 3: flexible wiggles
 DL_HD void dl_bao_phaseB_m(int tid, int nthr, const DlObsDev& o, double* lds) {
     const double qper = lds[DL_BAO_QPER], f = lds[DL_BAO_F], b1 = lds[DL_BAO_B1], sigmas = lds[DL_BAO_SIGS];
     const int n_ell = o.n_ell, n_mu = o.n_mu, n_kin = o.n_kin, n_mu4 = (o.n_mu + 3) & ~3;
@@ -778,6 +785,17 @@ DL_HD void dl_bao_phaseB_m(int tid, int nthr, const DlObsDev& o, double* lds) {
         double p[DL_MAX_ELL];
 #pragma unroll
         for (int l = 0; l < DL_MAX_ELL; ++l) p[l] = 0.;
+        double mult[DL_MAX_ELL];   // flexible wiggles: delta_{ell 0} + sum_i ml_i K_i(k) of each multipole (bao.py:363-366), at the fiducial k
+        if (MODEL == 3) {
+#pragma unroll
+            for (int l = 0; l < DL_MAX_ELL; ++l) mult[l] = (l == o.ell0) ? 1. : 0.;
+            for (int q = 0; q < o.n_ml; ++q) {
+                const double v = lds[DL_BAO_ML + q] * o.ct_matrix[(size_t)q * n_kin + i];
+                const int lq = o.ml_ell[q];
+#pragma unroll
+                for (int l = 0; l < DL_MAX_ELL; ++l) if (l == lq) mult[l] += v;
+            }
+        }
         for (int m0 = 0; m0 < n_mu4; m0 += 4) {
             double pkmu[4];
 #pragma unroll
@@ -804,7 +822,14 @@ DL_HD void dl_bao_phaseB_m(int tid, int nthr, const DlObsDev& o, double* lds) {
                     double pknowap = fma(fma(fma(cn[3], u, cn[2]), u, cn[1]), u, cn[0]);        // P_now(k')
                     // damping of the wiggles: at the fiducial (k, mu) ('fix-damping') or at the distorted ones; SD[m] holds the distorted-mu combination
                     double dw;
-                    if (MODEL == 2) {
+                    if (MODEL == 3) {
+                        // wiggles(k') / P_now(k') times sum_ell mult_ell(k) L_ell(mu), Legendre polynomials at the fiducial mu (bao.py:360-368, 375)
+                        double lsum = 0.;
+#pragma unroll
+                        for (int l = 0; l < DL_MAX_ELL; ++l)
+                            if (l < n_ell && m < n_mu) lsum = fma(mult[l], o.sn_matrix[l * n_mu + m], lsum);
+                        dw = lsum * pkw / pknowap;
+                    } else if (MODEL == 2) {
                         // ResummedPowerSpectrumWiggles.wiggles at (k', mu') (bao.py:201-222): b1 Eulerian bias, d rescales the growth factor
                         const double dd = lds[DL_BAO_D], fm = f * mup2;
                         const double e0 = -0.5 * (1. + f * (f + 2.) * mup2) * kap * kap * dd * dd;
@@ -835,7 +860,8 @@ DL_HD void dl_bao_phaseB_m(int tid, int nthr, const DlObsDev& o, double* lds) {
                     if (reciso && move_all) { double kr = ks * o.smoothing_radius; sks = exp(-0.5 * (kr * kr)); }
                     double cb = b1 + f * mus2 * (1. - sks);
                     double smooth = cb * cb * pkn;
-                    pkmu[q] = fog_damping ? smooth * fog * (1. + dw) : smooth * (fog + dw);     // Beutler 2016 / Howlett 2023
+                    if (MODEL == 3) pkmu[q] = smooth * (1. + dw);                                    // no damping, no Finger-of-God (bao.py:382)
+                    else pkmu[q] = fog_damping ? smooth * fog * (1. + dw) : smooth * (fog + dw);     // Beutler 2016 / Howlett 2023
                 }
             }
 #pragma unroll
@@ -857,6 +883,7 @@ DL_HD void dl_bao_phaseB_m(int tid, int nthr, const DlObsDev& o, double* lds) {
 DL_HD void dl_bao_phaseB(int tid, int nthr, const DlObsDev& o, double* lds) {
     const int model = o.bao_mode >> 4;
     if (model == 0) dl_bao_phaseB_m<0>(tid, nthr, o, lds);
+    else if (model & 32) dl_bao_phaseB_m<3>(tid, nthr, o, lds);
     else if (model & 16) dl_bao_phaseB_m<2>(tid, nthr, o, lds);
     else dl_bao_phaseB_m<1>(tid, nthr, o, lds);
 }

@@ -456,11 +456,27 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
             pknow_k[i] = std::fma(std::fma(std::fma(c[3], u, c[2]), u, c[1]), u, c[0]);
         }
     }
+    // flexible BAO wiggles: kernel matrix K [n_ml, n_kin] and Legendre table [n_ell, n_mu] travel in the slots of the (otherwise unused) EFT matrices
+    const bool flexible = d.theory == 2 && cfg.has_f64(p + "ml_matrix");
+    if (flexible) {
+        const auto& mlin = cfg.F(p + "in.ml");
+        const auto& mlell = cfg.I(p + "ml_ell");
+        d.n_ml = (int)mlell.size();
+        if (d.n_ml > DL_MAX_ML) { err = p + "at most 40 multiplicative wiggle terms supported"; return false; }
+        if ((int)mlin.size() != 2 * d.n_ml || (int)cfg.F(p + "ml_matrix").size() != d.n_ml * d.n_kin || (int)cfg.F(p + "legendre").size() != d.n_ell * d.n_mu) {
+            err = p + "ml_matrix / ml_ell / in.ml / legendre sizes do not match"; return false;
+        }
+        for (int q = 0; q < d.n_ml; ++q) {
+            d.ml_ell[q] = mlell[q];
+            d.ml_in[q].col = (int32_t)std::lround(mlin[2 * q]); d.ml_in[q].pad = 0; d.ml_in[q].value = mlin[2 * q + 1];
+            if (d.ml_in[q].col >= n_params || mlell[q] < 0 || mlell[q] >= d.n_ell) { err = p + "in.ml / ml_ell out of range"; return false; }
+        }
+    }
     // EFT-like terms
-    const auto& ctm = cfg.F(p + "ct_matrix");
-    const auto& snm = cfg.F(p + "sn_matrix");
-    d.n_ct = ctm.empty() ? 0 : (int)(ctm.size() / d.n_in);
-    d.n_sn = snm.empty() ? 0 : (int)(snm.size() / d.n_in);
+    const auto& ctm = flexible ? cfg.F(p + "ml_matrix") : cfg.F(p + "ct_matrix");
+    const auto& snm = flexible ? cfg.F(p + "legendre") : cfg.F(p + "sn_matrix");
+    d.n_ct = (flexible || ctm.empty()) ? 0 : (int)(ctm.size() / d.n_in);
+    d.n_sn = (flexible || snm.empty()) ? 0 : (int)(snm.size() / d.n_in);
     if (d.n_ct > DL_MAX_EFT || d.n_sn > DL_MAX_EFT) { err = p + "at most 8 counter / stochastic terms supported"; return false; }
     if (d.n_ct > 0 && d.ell0 < 0) { err = p + "counter terms need the monopole in ells_in (full_shape.py:633)"; return false; }
     const auto& ctin = cfg.F(p + "in.ct");

@@ -127,14 +127,16 @@ __global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_ker
 #undef DL_STAMP
 }
 
-// BAO wiggle model: one workgroup per point; constant splines read from global memory, no per-point spline build
+// BAO wiggle model: one workgroup per point; constant splines read from global memory, no per-point spline build.  One kernel per wiggle model: registers are
+// allocated for the worst branch of a kernel (all four models behind one run-time switch: 165 VGPRs, three waves per SIMD, the standard model 15 % slower).
+template <int MODEL>
 __global__ __launch_bounds__(DL_FS_THREADS) void dl_bao_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power, int64_t ld_power) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const double* th = theta + (size_t)b * n_params;
     dl_bao_phaseA(tid, DL_FS_THREADS, o, th, lds);
     __syncthreads();
-    dl_bao_phaseB(tid, DL_FS_THREADS, o, lds);
+    dl_bao_phaseB_m<MODEL>(tid, DL_FS_THREADS, o, lds);
     __syncthreads();
     dl_store_with_pass(tid, DL_FS_THREADS, o, th, lds + DL_BAO_PT, power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset);
 }
@@ -172,8 +174,15 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
         }
         if (obs_host[i].theory == 2) {   // DL_THEORY_BAO_DAMPED
             size_t shm = dl_bao_shared_doubles(obs_host[i].n_in) * sizeof(double);
-            if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_bao_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            hipLaunchKernelGGL(dl_bao_kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power);
+            auto launch_bao = [&](auto kernel) {
+                if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power);
+            };
+            const int model = obs_host[i].bao_mode >> 4;
+            if (model == 0) launch_bao(dl_bao_kernel<0>);
+            else if (model & 32) launch_bao(dl_bao_kernel<3>);
+            else if (model & 16) launch_bao(dl_bao_kernel<2>);
+            else launch_bao(dl_bao_kernel<1>);
             continue;
         }
         const DlObsDev& oh = obs_host[i];

@@ -63,6 +63,7 @@ class _BaseDampedBAOTracer(BaseCalculator):
     _ref_limits = (-1e2, 1e2)
 
     _resummed = False
+    _flexible = False
     _wants_shotnoise = False
     _default_model = 'standard'
 
@@ -72,6 +73,18 @@ class _BaseDampedBAOTracer(BaseCalculator):
         import copy
         broadband = str(broadband)
         params = copy.deepcopy(_BAO_PARAMS)
+        if cls._flexible:   # bao.yaml: b1, dbeta (fixed: degenerate) + multiplicative wiggle terms ml{ell}_{i} (bao.py:310-322)
+            params = {name: params[name] for name in ['b1', 'dbeta']}
+            params['dbeta'].update(fixed=True, ref=dict(limits=[0.95, 1.05]))
+            wiggles = str(kwargs.get('wiggles', 'pcs'))
+            for ell in (0, 2, 4):
+                if wiggles == 'power':
+                    for pow in range(-3, 2):
+                        params['ml{:d}_{:d}'.format(ell, pow)] = dict(value=0., ref=dict(limits=[-1e2, 1e2]), delta=0.005, latex='a_{{{:d}, {:d}}}'.format(ell, pow))
+                else:
+                    for ik in range(-2, 10):
+                        params['ml{:d}_{:d}'.format(ell, ik)] = dict(value=0., prior=dict(dist='norm', loc=0., scale=1e4), ref=dict(limits=[-1e-2, 1e-2]), delta=0.005,
+                                                                       latex='a_{{{:d}, {:d}}}'.format(ell, ik))
         if cls._resummed:   # bao.yaml: b1, dbeta, sigmas, d
             params = {name: params[name] for name in ['b1', 'dbeta', 'sigmas']}
             params['dbeta'].update(ref=dict(limits=[0.95, 1.05]))
@@ -111,7 +124,9 @@ class _BaseDampedBAOTracer(BaseCalculator):
             raise ValueError('Reconstruction mode {} must be one of {}'.format(self.mode, ['', 'recsym', 'reciso']))
         self.model = str(init.get('model', self._default_model))   # 'standard' (bao.py:123-136) or any combination of 'fix-damping', 'move-all', 'fog-damping' (137-150)
         self._model_bits = 0
-        if self._resummed:
+        if self._flexible:
+            self._model_bits = 32 | (2 if 'move-all' in self.model else 0)
+        elif self._resummed:
             self._model_bits = 16 | (2 if 'move-all' in self.model else 0) | (4 if 'fog-damping' in self.model else 0)
         elif self.model != 'standard':
             self._model_bits = 8 | (1 if 'fix-damping' in self.model else 0) | (2 if 'move-all' in self.model else 0) | (4 if 'fog-damping' in self.model else 0)
@@ -133,6 +148,8 @@ class _BaseDampedBAOTracer(BaseCalculator):
             pass
         if self._resummed:
             self._set_resummation(float(init.get('shotnoise', 0.)))
+        if self._flexible:
+            self._set_flexible_wiggles()
         # broadband orders (bao.py:24-41): parameters al{ell}_{pow} of the multipoles in use; others are dropped
         self.broadband = str(init.get('broadband', 'power'))
         self.broadband_orders = _get_orders('al', self.init.params, self.ells)
@@ -150,6 +167,32 @@ class _BaseDampedBAOTracer(BaseCalculator):
         self.sigma_nl2 = 1. / (3. * np.pi**2) * integrate.simpson((1. - j0) * pklin, x=k)
         self.sigma_dd2 = 1. / (3. * np.pi**2) * integrate.simpson((1. - j0) * skc**2 * pklin, x=k)
         self.sigma_x2 = 1. / (3. * np.pi**2) * integrate.simpson((1. - j0) * skc * pklin, x=k) if self.mode == 'reciso' else 0.
+
+    def _set_flexible_wiggles(self):
+        """Kernels of the multiplicative wiggle terms (FlexibleBAOWigglesPowerSpectrumMultipoles.set_params, bao.py:337-358): K_i(k) = (k / kp)^pow or a B-spline node;
+        nodes whose kernel vanishes on the theory wavenumbers are dropped with their parameters."""
+        from scipy import special
+        init = self.init
+        self.wiggles = str(init.get('wiggles', 'pcs'))
+        kp = init.get('kp', None)
+        self.kp = 2. * np.pi / self.template.fiducial.rs_drag if kp is None else float(kp)
+        orders = _get_orders('ml', self.init.params, self.ells)
+        names, ells, rows = [], [], []
+        for ill, ell in enumerate(self.ells):
+            for name, index in orders[ell].items():
+                if self.wiggles == 'power':
+                    kernel = (self.kin / self.kp)**index
+                elif self.wiggles in _KERNELS:
+                    kernel = _kernel_func(np.abs(self.kin / self.kp - index), kernel=self.wiggles)
+                    if np.allclose(kernel, 0., rtol=0., atol=1e-8):
+                        del self.init.params[name]
+                        continue
+                else:
+                    raise ValueError('Unknown kernel: {}'.format(self.wiggles))
+                names.append(name); ells.append(ill); rows.append(kernel)
+        self.wiggles_params, self.wiggles_ells = names, np.array(ells, dtype='i4')
+        self.wiggles_matrix = np.array(rows, dtype='f8').reshape(len(names), len(self.kin))
+        self.legendre = np.array([special.eval_legendre(ell, self.mu) for ell in self.ells], dtype='f8')
 
     def _pknow_fid(self, k):
         """No-wiggle fiducial power at ``k``: cubic interpolation in log10 k on the template knots (``_interp(template, 'pknow_dd_fid', k)``, bao.py:18-19)."""
@@ -193,12 +236,15 @@ class _BaseDampedBAOTracer(BaseCalculator):
         spec['template'] = np.array([0], dtype='i4')   # the BAO template never changes P(k) (power_template.py:372-376)
         if self._resummed:
             spec['resummed'] = np.array([self.sigma_dd2, self.sigma_nl2, self.sigma_x2, self.shotnoise * self.sigma_sn2], dtype='f8')
+        if self._flexible:
+            spec.update(ml_matrix=self.wiggles_matrix, ml_ell=self.wiggles_ells, legendre=self.legendre)
         return spec
 
     def _input_map(self):
         toret = {name: name for name in ['qpar', 'qper', 'qiso', 'qap', 'df', 'dbeta', 'sigmas', 'sigmapar', 'sigmaper']}
         toret['b1X'] = toret['b1Y'] = 'b1'
         if self._resummed: toret['dres'] = 'd'
+        if self._flexible: toret['ml'] = list(self.wiggles_params)
         toret['pass'] = list(self._broadband_names)
         return toret
 
@@ -323,3 +369,14 @@ class SimpleBAOWigglesTracerPowerSpectrumMultipoles(DampedBAOWigglesTracerPowerS
 class SimpleBAOWigglesTracerCorrelationFunctionMultipoles(DampedBAOWigglesTracerCorrelationFunctionMultipoles):
     """Correlation function counterpart of :class:`SimpleBAOWigglesTracerPowerSpectrumMultipoles` (bao.py:1008-1048)."""
     _default_model = 'fix-damping'
+
+
+class FlexibleBAOWigglesTracerPowerSpectrumMultipoles(DampedBAOWigglesTracerPowerSpectrumMultipoles):
+    """BAO power spectrum multipoles with terms multiplying the wiggles and no damping parameter (bao.py:269-391, 719-763): parameters b1, dbeta and
+    ``ml{ell}_{i}`` (``wiggles`` = 'pcs' / 'tsc' / 'cic' / 'ngp' nodes of period ``kp``, or 'power' for powers of k / kp); ``model`` may contain 'move-all'."""
+    _flexible = True
+
+
+class FlexibleBAOWigglesTracerCorrelationFunctionMultipoles(DampedBAOWigglesTracerCorrelationFunctionMultipoles):
+    """Correlation function counterpart of :class:`FlexibleBAOWigglesTracerPowerSpectrumMultipoles` (bao.py:1099-1144)."""
+    _flexible = True

@@ -92,6 +92,8 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
  *                     columns n_in .. n_in+n_pass-1; obs<i>.wmatrix then has n_in+n_pass columns (BAO broadband terms; folded Hankel / emulator operators)
  *   BAO model (theory = 2): obs<i>.pknow_dd_fid f64[n_t] (no-wiggle table), obs<i>.in.dbeta, .in.sigmas, .in.sigmapar, .in.sigmaper f64[2],
  *                     obs<i>.bao_mode i32[1] (bits 0-3: 0 '' / recsym, 1 reciso; bits 4-7: wiggle model, 0 'standard', else 8 | 1 'fix-damping' | 2 'move-all' | 4 'fog-damping', bao.py:137-150), obs<i>.smoothing_radius f64[1]
+ *                     flexible wiggles (bao.py:269-391): obs<i>.ml_matrix f64[n_ml*n_kin] kernels K_i(k), obs<i>.ml_ell i32[n_ml] multipole index of each term,
+ *                     obs<i>.in.ml f64[n_ml*2], obs<i>.legendre f64[n_ell*n_mu] L_ell(mu); obs<i>.resummed f64[4] damping scales of the resummed wiggles (bao.py:186-199), obs<i>.in.dres
  *   emulated theory (theory = 3): obs<i>.in.x f64[n_x*2] emulator inputs, obs<i>.in.vp f64[11*2] velocileptors 'pars' (b1 b2 bs b3 alpha0 alpha2 alpha4 alpha6
  *                     sn0 sn2 sn4), obs<i>.mono_mode i32[1] (0 none, 1 LPT physical basis, 2 REPT physical, 3 LPT direct, 4 REPT direct), obs<i>.vconst f64[3] (snd fsat sigv),
  *                     obs<i>.emu<e>.{type i32[1] (-1 constant, 0 MLP, 1 Taylor), xlimits, widths, act, weights, ylimits, center, powers, coef, const}

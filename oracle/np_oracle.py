@@ -483,6 +483,27 @@ def bao_resummed_power(k, mu, wmu_ell, k_t, pk_dd, pknow_dd, f, scales, shotnois
     return np.sum(pkmu * wmu_ell[:, None, :], axis=-1)
 
 
+def bao_flexible_power(k, mu, wmu_ell, ells, k_t, pk_dd, pknow_dd, f, ml_matrix, ml_values, qpar=1., qper=1., b1=1., mode='', smoothing_radius=15., model='standard'):
+    """FlexibleBAOWigglesPowerSpectrumMultipoles.calculate / get_wiggles (bao.py:360-383): ``ml_matrix`` [n_ell, n_k, n_ml] kernels, ``ml_values`` [n_ml]; ``f`` includes dbeta."""
+    from scipy import special
+    jac, kap, muap = ap_k_mu(k, mu, qpar=qpar, qper=qper)
+    logkt = np.log10(k_t)
+    pknowap = interp1d(np.log10(kap), logkt, pknow_dd, method='cubic')
+    wiggles = interp1d(np.log10(kap), logkt, pk_dd, method='cubic') - pknowap
+    damped_wiggles = 0.
+    for ill, ell in enumerate(ells):
+        mult = ml_matrix[ill].dot(ml_values)
+        if ell == 0: mult = mult + 1.
+        damped_wiggles = damped_wiggles + wiggles * mult[:, None] * special.legendre(ell)(mu)
+    damped_wiggles = damped_wiggles / pknowap
+    kk = k[:, None]
+    ks, mus = (kap, muap) if 'move-all' in model else (kk, mu)
+    pknow = interp1d(np.log10(ks * np.ones_like(kap)), logkt, pknow_dd, method='cubic')
+    sk = np.exp(-1. / 2. * (ks * smoothing_radius)**2) if mode == 'reciso' else 0.
+    pkmu = (b1 + f * mus**2 * (1 - sk))**2 * pknow * (1. + damped_wiggles)
+    return np.sum(pkmu * wmu_ell[:, None, :], axis=-1)
+
+
 # ----------------------------------------------------------------------------------------------
 # a5 (velocileptors part): table-level bias combination                      full_shape.py:1182-1186, 1300-1313, 1577-1599, 1479-1488
 # ----------------------------------------------------------------------------------------------

@@ -619,6 +619,54 @@ def cfg4_resummed():
     save('cfg4_bao_resummed', **out)
 
 
+def cfg4_flexible():
+    """Flexible BAO wiggles (bao.py:269-391, 719-763, 1099-1144): multiplicative terms ml{ell}_{i} on the wiggles ('pcs' nodes or powers of k), no damping."""
+    from desilike.theories.galaxy_clustering import BAOPowerSpectrumTemplate, FlexibleBAOWigglesTracerCorrelationFunctionMultipoles, FlexibleBAOWigglesTracerPowerSpectrumMultipoles
+    from desilike.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable
+    out = {}
+    for tag, space, model, mode, wiggles in [('a', 'pk', 'standard', 'reciso', 'pcs'), ('b', 'xi', 'move-all', '', 'pcs'), ('c', 'pk', 'standard', '', 'power')]:
+        template = BAOPowerSpectrumTemplate(z=0.5)
+        if space == 'xi':
+            theory = FlexibleBAOWigglesTracerCorrelationFunctionMultipoles(template=template, mode=mode, model=model, wiggles=wiggles)
+            obs = TracerCorrelationFunctionMultipolesObservable(data={'b1': 2.}, s=np.linspace(22.5, 167.5, 30), ells=(0, 2), theory=theory)
+            n, scale = 60, 3e-4
+        else:
+            theory = FlexibleBAOWigglesTracerPowerSpectrumMultipoles(template=template, mode=mode, model=model, wiggles=wiggles)
+            obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2.}, kedges=np.linspace(0.02, 0.3, 57), ells=(0, 2), wmatrix={'resolution': 3}, theory=theory)
+            n, scale = 112, 30.
+        rng = np.random.RandomState(4)
+        A = rng.standard_normal((n, n)) * scale
+        cov = A.dot(A.T) + (10. * scale)**2 * np.eye(n)
+        like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+        for param in like.all_params.select(basename='al*'):
+            param.update(fixed=True)
+        for param in like.all_params.select(basename='ml*'):
+            param.update(ref=dict(limits=[-0.3, 0.3]))
+        like()
+        names = like.varied_params.names()
+        theta = sample_theta(like, 10, seed=69)
+        (logpost, derived), errors = vmap(like, backend=None, errors='return', return_derived=True)({name: theta[:, i] for i, name in enumerate(names)})
+        assert not errors
+        power = []
+        for row in theta:
+            like(**dict(zip(names, row)))
+            power.append(np.asarray(theory.pt.power).copy())
+        pt = theory.pt
+        tmpl = pt.template
+        mlnames = [name for ell in pt.ells for name in pt.wiggles_orders[ell]]
+        mlmat = np.zeros((len(pt.ells), len(pt.k), len(mlnames)))
+        for ill, ell in enumerate(pt.ells):
+            for name, row in zip(pt.wiggles_orders[ell], np.asarray(pt.wiggles_matrix[ell])):
+                mlmat[ill, :, mlnames.index(name)] = row
+        if tag == 'a': out.update(mu=np.asarray(pt.mu), wmu_ell=np.asarray(pt.wmu), f_fid=float(tmpl.f_fid))
+        out.update({tag + '_kin': np.asarray(pt.k), tag + '_k11': np.asarray(tmpl.k), tag + '_pk_dd_fid': np.asarray(tmpl.pk_dd_fid), tag + '_pknow_dd_fid': np.asarray(tmpl.pknow_dd_fid),
+                    tag + '_names': np.array(names), tag + '_theta': theta, tag + '_flatdata': np.asarray(obs.flatdata), tag + '_covariance': cov, tag + '_model': model, tag + '_mode': mode,
+                    tag + '_space': space, tag + '_wiggles': wiggles, tag + '_kp': float(pt.kp), tag + '_ml_names': np.array(mlnames), tag + '_ml_matrix': mlmat,
+                    tag + '_wiggle_power': np.array(power), tag + '_loglikelihood': np.asarray(derived[like._param_loglikelihood]), tag + '_logprior': np.asarray(derived[like._param_logprior])})
+        print(tag, names)
+    save('cfg4_bao_flexible', **out)
+
+
 def cfg2_fc_syst():
     """Window extras (row a6): top-hat fiber collisions folded into the binning matrix (window.py:428-438, 972-1049) and two systematic templates
     (window.py:439-443, 472-473, 1253-1309), klim row selection on top."""
@@ -741,7 +789,7 @@ def kaiser_xi(eft=False):
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi', 'cfg4_resummed']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi', 'cfg4_resummed', 'cfg4_flexible']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -754,6 +802,7 @@ if __name__ == '__main__':
     if 'cfg3_table_xi' in todo: cfg3_table_xi()
     if 'cfg4_models' in todo: cfg4_models()
     if 'cfg4_resummed' in todo: cfg4_resummed()
+    if 'cfg4_flexible' in todo: cfg4_flexible()
     if 'cfg2_fc_syst' in todo: cfg2_fc_syst()
     if 'simple_tracer' in todo: simple_tracer()
     if 'kaiser_xi' in todo: kaiser_xi(False)
