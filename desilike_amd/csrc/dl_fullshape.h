@@ -93,15 +93,15 @@ struct DlObsDev {
     int32_t n_pass, bao_mode;              // bao_mode bits 0-3: 0 = '' / 'recsym', 1 = 'reciso' (bao.py:131); bits 4-8: wiggle model, 0 = 'standard' (bao.py:123-136), else
                                            // 8 | (1: 'fix-damping') | (2: 'move-all') | (4: 'fog-damping') (bao.py:137-150), or 16 | (2: 'move-all') | (4: 'fog-damping'):
                                            // resummed wiggles (bao.py:165-266), or 32 | (2: 'move-all'): flexible wiggles (bao.py:269-391)
-    DlInput pass_in[DL_MAX_PASS];
+    const double* pass_tab;                // [n_pass][2]: theta column (or -1), constant value -- in the arena (see ml_tab)
     DlInput dbeta, sigmas;                 // BAO wiggle model (bao.py:117)
     DlInput dres;                          // resummed wiggles: growth rescaling d (bao.py:201)
     double res_sig[4];                     // resummed wiggles: sigma_dd^2, sigma_nl^2, sigma_x^2, shotnoise * sigma_sn^2 (bao.py:186-199)
     // flexible wiggles (bao.py:269-391): terms ml_i K_i(k) L_{ell_i}(mu) multiplying the wiggles; K [n_ml, n_kin] sits behind ct_matrix, the Legendre
     // polynomials L_ell(mu) [n_ell, n_mu] behind sn_matrix (both unused by the BAO kernels otherwise)
     int32_t n_ml, pad_ml;
-    int32_t ml_ell[DL_MAX_ML];             // index (in ells_in) of the multipole each term belongs to
-    DlInput ml_in[DL_MAX_ML];
+    const double* ml_tab;                  // [n_ml][3]: theta column (or -1), constant value, index (in ells_in) of the term's multipole -- in the arena, not in
+                                           // the kernarg segment (the struct travels by value with every launch of every theory kernel)
     double smoothing_radius;
     // emulated theory (kind 3): features phi[(h, m)] = basis_h(theta) * mono_m(theta); the last emulator layer, the bias-table sum
     // (full_shape.py:1182-1186), the k-interpolation and the window are ONE matrix folded on the host (desilike_amd/emulators.py)
@@ -711,7 +711,7 @@ DL_HD void dl_fs_phase3_pair(int tid, int nthr, const DlObsDev& o, const DlFsSha
 // power_row: row 0 of this point (already offset by col_offset); ld: leading dimension of the power buffer
 DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, const double* th, double* power_row, int64_t ld) {
     for (int idx = tid; idx < o.n_in; idx += nthr) DL_STREAM_STORE(&power_row[idx], s.out[idx]);
-    for (int c = tid; c < o.n_pass; c += nthr) power_row[o.n_in + c] = dl_get(o.pass_in[c], th);
+    for (int c = tid; c < o.n_pass; c += nthr) { const int col = (int)o.pass_tab[2 * c]; power_row[o.n_in + c] = col >= 0 ? th[col] : o.pass_tab[2 * c + 1]; }
     if (o.n_var > 0 && o.n_ct > 0) {
         // d(power)/d(ct) = 0.5 ct_matrix[:, c] P_dd,l=0 per tracer (full_shape.py:630, 633): rows 1 + slot of this point
         for (int c = 0; c < o.n_ct; ++c) {
@@ -765,7 +765,7 @@ DL_HD void dl_bao_phaseA(int tid, int nthr, const DlObsDev& o, const double* th,
             lds[DL_BAO_B1] = dl_get(o.b1X, th);
             lds[DL_BAO_SIGS] = dl_get(o.sigmas, th);
             lds[DL_BAO_D] = dl_get(o.dres, th);
-            for (int i = 0; i < o.n_ml; ++i) lds[DL_BAO_ML + i] = dl_get(o.ml_in[i], th);
+            for (int i = 0; i < o.n_ml; ++i) { const int col = (int)o.ml_tab[3 * i]; lds[DL_BAO_ML + i] = col >= 0 ? th[col] : o.ml_tab[3 * i + 1]; }
         }
     }
 }
@@ -791,7 +791,7 @@ DL_HD void dl_bao_phaseB_m(int tid, int nthr, const DlObsDev& o, double* lds) {
             for (int l = 0; l < DL_MAX_ELL; ++l) mult[l] = (l == o.ell0) ? 1. : 0.;
             for (int q = 0; q < o.n_ml; ++q) {
                 const double v = lds[DL_BAO_ML + q] * o.ct_matrix[(size_t)q * n_kin + i];
-                const int lq = o.ml_ell[q];
+                const int lq = (int)o.ml_tab[3 * q + 2];
 #pragma unroll
                 for (int l = 0; l < DL_MAX_ELL; ++l) if (l == lq) mult[l] += v;
             }
@@ -891,7 +891,7 @@ DL_HD void dl_bao_phaseB(int tid, int nthr, const DlObsDev& o, double* lds) {
 // coalesced store of the multipoles + pass-through columns
 DL_HD void dl_store_with_pass(int tid, int nthr, const DlObsDev& o, const double* th, const double* out, double* power_row) {
     for (int idx = tid; idx < o.n_in; idx += nthr) power_row[idx] = out[idx];
-    for (int c = tid; c < o.n_pass; c += nthr) power_row[o.n_in + c] = dl_get(o.pass_in[c], th);
+    for (int c = tid; c < o.n_pass; c += nthr) { const int col = (int)o.pass_tab[2 * c]; power_row[o.n_in + c] = col >= 0 ? th[col] : o.pass_tab[2 * c + 1]; }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1080,6 +1080,6 @@ DL_HD void dl_emu_point(const DlObsDev& o, const double* th, double* lds, double
             row0[idx] = bh * mono[m];
             for (int v = 0; v < o.n_var; ++v) row0[(size_t)(1 + v) * ld + idx] = bh * mono[(size_t)(1 + v) * DL_N_MONO + m];
         }
-        for (int c = tid; c < o.n_pass; c += DL_FS_THREADS) row0[o.n_in + c] = dl_get(o.pass_in[c], th);
+        for (int c = tid; c < o.n_pass; c += DL_FS_THREADS) { const int col = (int)o.pass_tab[2 * c]; row0[o.n_in + c] = col >= 0 ? th[col] : o.pass_tab[2 * c + 1]; }
     DL_PAR_END
 }

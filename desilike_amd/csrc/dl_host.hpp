@@ -58,7 +58,7 @@ struct DlObsHost {
     std::vector<double> bias;     // [n_out]: W . (sn_in (x) 1) + offset[mask] - sn_out        (window.py:459-473)
     std::vector<double> flatdata; // [n_out]
     size_t off_kin, off_lkin, off_mu, off_wmu, off_xt, off_pk, off_th, off_lg, off_ih, off_dlt, off_A, off_nC, off_inv, off_gf, off_gb, off_coef, off_ct, off_sn;
-    size_t off_cw, off_cn, off_pknowk;
+    size_t off_cw, off_cn, off_pknowk, off_ml, off_pass;
     size_t off_eng[3][6];   // xlo, xinv, weights, center, powers, coef of each emulator engine
     int marg_vp[DL_N_VPARS];
     int marg_pass[DL_MAX_PASS];
@@ -70,7 +70,7 @@ struct DlObsHost {
         dev.ih = base + off_ih; dev.dlt = base + off_dlt; dev.sp_A = base + off_A; dev.sp_nC = base + off_nC; dev.sp_inv = base + off_inv;
         dev.sp_gf = base + off_gf; dev.sp_gb = base + off_gb; dev.coef_fixed = base + off_coef;
         dev.ct_matrix = base + off_ct; dev.sn_matrix = base + off_sn;
-        dev.coef_w = base + off_cw; dev.coef_n = base + off_cn; dev.pknow_k = base + off_pknowk;
+        dev.coef_w = base + off_cw; dev.coef_n = base + off_cn; dev.pknow_k = base + off_pknowk; dev.ml_tab = base + off_ml; dev.pass_tab = base + off_pass;
         for (int e = 0; e < 3; ++e) {
             dev.eng[e].xlo = base + off_eng[e][0]; dev.eng[e].xinv = base + off_eng[e][1]; dev.eng[e].weights = base + off_eng[e][2];
             dev.eng[e].center = base + off_eng[e][3]; dev.eng[e].powers = base + off_eng[e][4]; dev.eng[e].coef = base + off_eng[e][5];
@@ -301,14 +301,18 @@ inline bool dl_build_emulated_obs(const dl_config& cfg, const std::string& p, in
     if (d.n_pass > DL_MAX_PASS) { err = p + "at most 32 pass-through parameters supported"; return false; }
     const auto& mpass = cfg.I(p + "marg.pass");
     for (int c = 0; c < DL_MAX_PASS; ++c) oh.marg_pass[c] = (c < (int)mpass.size()) ? mpass[c] : -1;
-    for (int c = 0; c < d.n_pass; ++c) { d.pass_in[c].col = (int32_t)std::lround(pin[2 * c]); d.pass_in[c].pad = 0; d.pass_in[c].value = pin[2 * c + 1]; }
+    {
+        std::vector<double> pass_tab(std::max<size_t>(pin.size(), 2), 0.);
+        for (int c = 0; c < d.n_pass; ++c) { pass_tab[2 * c] = (double)std::lround(pin[2 * c]); pass_tab[2 * c + 1] = pin[2 * c + 1]; }
+        oh.off_pass = arena.push(pass_tab);
+    }
     for (int c = 0; c < DL_MAX_EFT; ++c) { oh.marg_sn[c] = -1; oh.marg_ct[c][0] = oh.marg_ct[c][1] = -1; d.marg_ct_slot[c][0] = d.marg_ct_slot[c][1] = -1; }
     oh.marg_sn0 = -1;
     // unused arrays still need valid offsets
     std::vector<double> dummy(2, 0.);
     size_t off = arena.push(dummy);
     oh.off_kin = oh.off_lkin = oh.off_mu = oh.off_wmu = oh.off_xt = oh.off_pk = oh.off_th = oh.off_lg = oh.off_ih = oh.off_dlt = oh.off_A = oh.off_nC = oh.off_inv = off;
-    oh.off_gf = oh.off_gb = oh.off_coef = oh.off_ct = oh.off_sn = oh.off_cw = oh.off_cn = oh.off_pknowk = off;
+    oh.off_gf = oh.off_gb = oh.off_coef = oh.off_ct = oh.off_sn = oh.off_cw = oh.off_cn = oh.off_pknowk = oh.off_ml = off;
     return dl_build_window(cfg, p, oh, err);
 }
 
@@ -351,15 +355,17 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         *it.in = dl_input_from(cfg, p + "in." + it.name, it.def);
         if (it.in->col >= n_params) { err = p + "in." + it.name + ": theta column out of range"; return false; }
     }
+    std::vector<double> pass_tab;
     {
         const auto& pin = cfg.F(p + "in.pass");
         d.n_pass = (int)(pin.size() / 2);
         if (d.n_pass > DL_MAX_PASS) { err = p + "at most 32 pass-through (broadband) parameters supported"; return false; }
         const auto& mpass = cfg.I(p + "marg.pass");
         for (int c = 0; c < DL_MAX_PASS; ++c) oh.marg_pass[c] = (c < (int)mpass.size()) ? mpass[c] : -1;
+        pass_tab.assign(std::max<size_t>(pin.size(), 2), 0.);
         for (int c = 0; c < d.n_pass; ++c) {
-            d.pass_in[c].col = (int32_t)std::lround(pin[2 * c]); d.pass_in[c].pad = 0; d.pass_in[c].value = pin[2 * c + 1];
-            if (d.pass_in[c].col >= n_params) { err = p + "in.pass: theta column out of range"; return false; }
+            pass_tab[2 * c] = (double)std::lround(pin[2 * c]); pass_tab[2 * c + 1] = pin[2 * c + 1];
+            if ((int)pass_tab[2 * c] >= n_params) { err = p + "in.pass: theta column out of range"; return false; }
         }
         d.bao_mode = cfg.i(p + "bao_mode", 0);
         d.smoothing_radius = cfg.f(p + "smoothing_radius", 15.);
@@ -458,6 +464,7 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     }
     // flexible BAO wiggles: kernel matrix K [n_ml, n_kin] and Legendre table [n_ell, n_mu] travel in the slots of the (otherwise unused) EFT matrices
     const bool flexible = d.theory == 2 && cfg.has_f64(p + "ml_matrix");
+    std::vector<double> ml_tab;
     if (flexible) {
         const auto& mlin = cfg.F(p + "in.ml");
         const auto& mlell = cfg.I(p + "ml_ell");
@@ -467,9 +474,9 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
             err = p + "ml_matrix / ml_ell / in.ml / legendre sizes do not match"; return false;
         }
         for (int q = 0; q < d.n_ml; ++q) {
-            d.ml_ell[q] = mlell[q];
-            d.ml_in[q].col = (int32_t)std::lround(mlin[2 * q]); d.ml_in[q].pad = 0; d.ml_in[q].value = mlin[2 * q + 1];
-            if (d.ml_in[q].col >= n_params || mlell[q] < 0 || mlell[q] >= d.n_ell) { err = p + "in.ml / ml_ell out of range"; return false; }
+            const int col = (int)std::lround(mlin[2 * q]);
+            if (col >= n_params || mlell[q] < 0 || mlell[q] >= d.n_ell) { err = p + "in.ml / ml_ell out of range"; return false; }
+            ml_tab.push_back((double)col); ml_tab.push_back(mlin[2 * q + 1]); ml_tab.push_back((double)mlell[q]);
         }
     }
     // EFT-like terms
@@ -508,6 +515,9 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     oh.off_gf = arena.push(gf); oh.off_gb = arena.push(gb); oh.off_coef = arena.push(coef);
     oh.off_ct = arena.push(ctm); oh.off_sn = arena.push(snm);
     oh.off_cw = arena.push(coef_w); oh.off_cn = arena.push(coef_n); oh.off_pknowk = arena.push(pknow_k);
+    if (ml_tab.empty()) ml_tab.assign(3, 0.);
+    oh.off_ml = arena.push(ml_tab);
+    oh.off_pass = arena.push(pass_tab);
 
     for (int c = 0; c < DL_N_VPARS; ++c) { oh.marg_vp[c] = -1; d.vp_slot[c] = -1; }
     for (int e = 0; e < 3; ++e) { d.eng[e].type = -1; for (int q = 0; q < 6; ++q) oh.off_eng[e][q] = oh.off_kin; }
