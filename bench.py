@@ -175,17 +175,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    import gc
+    gc.collect()   # whatever set-up garbage holds device resources is released now, not by a collector pass inside the timed loop (hipFree synchronises the device)
     for _ in range(args.warmup):
         step()
     barrier()
     every = max(1, min(25, args.steps // 8))   # HIP events on the launch stream around each kernel, on 1 timed step out of 25 (8 samples at 200 steps, median; an event record costs ~4 us of stream time)
     ctx.profile_enable(0 if args.no_events else every)
     barrier()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     kernel_ms = ctx.profile_read() if not args.no_events else dict(theory=1., window_gemm=1., finalize=1., total=1., event_overhead=0.)
     ctx.profile_enable(0)
     if not args.no_events and not distributed:

@@ -88,6 +88,12 @@ class PowerToCorrelation(object):
             self._plan = FFTLogPlan(self.k.size, self.npad, self.k**1.5, u, post, device=device)
         return self._plan
 
+    def close(self):
+        """Release the device plan (if any)."""
+        if self._plan is not None:
+            self._plan.close()
+            self._plan = None
+
     def apply_device(self, fun, out=None, stream=None):
         """``fun [B, n_ell, N]`` CUDA(ROCm) torch tensor -> ``xi [B, n_ell, N]`` on the same device, asynchronous on ``stream`` (no host round trip)."""
         return self._get_plan().apply(fun, out=out, stream=stream)
@@ -149,6 +155,7 @@ def hankel_operator(kin, s, ells, k=None, engine='numpy', device=None):
             tmp[i] = np.concatenate([np.interp(logk_mid, logkin, unit), (unit[-1] + slope_high * logk_high) * damp_high])
             unit[i] = 0.
         ss, corr = fftlog(np.repeat(tmp[:, None, :], nell, axis=1))     # corr [n_kin, n_ell, N]
+        fftlog.close()   # free the device plan now (a hipFree deferred to the garbage collector would synchronise the device at an arbitrary later time)
         H = np.empty((nell, len(s), kin.size), dtype='f8')
         for ill in range(nell):
             for i in range(kin.size):

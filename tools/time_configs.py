@@ -15,6 +15,8 @@ def time_likelihood(label, like, B, steps=40, posterior=False):
     th = torch.as_tensor(theta, dtype=torch.float64, device='cuda').contiguous()
     out = torch.empty(B, dtype=torch.float64, device='cuda')
     st = torch.empty(B, dtype=torch.int32, device='cuda')
+    import gc
+    gc.collect()   # contexts of the previous likelihood are destroyed NOW (hipFree / hipEventDestroy synchronise the device: 70 ms if the collector runs inside the timed loop)
     for _ in range(5): ctx.eval_logposterior(th, out, status=st)
     torch.cuda.synchronize()
     ctx.profile_enable(2)
