@@ -231,9 +231,21 @@ def main():
             gpu = loglike[:len(check)].cpu().numpy()
             assert (np.abs(gpu - check) <= 1e-10 * np.maximum(1., np.abs(check))).all(), 'GPU / oracle mismatch in bench'
             result['cpu_baseline'] = base
-        print(json.dumps(result))
+    else:
+        result = None
+    # RCCL writes its version banner through C stdio: buffered when stdout is a pipe, it would come out AFTER the JSON line, at process exit.  Every rank flushes its
+    # C stdio now, then a barrier, then rank 0 prints: the JSON line is the last line of the job's stdout
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+    if result is not None:
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == '__main__':
