@@ -17,8 +17,13 @@ def local_slice(size, rank, world):
 class WalkerSharding(object):
     """Evaluate a batch function on the local share of the rows and all-gather the results on every rank."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, min_shard_rows=4096):
+        """``min_shard_rows``: below this many rows every rank evaluates ALL rows and nothing is exchanged.  The evaluation is latency-bound at small batches
+        (34 us for 32 as for 256 points of the two-tracer likelihood) while a synchronous all-gather through the host costs ~100 us: sharding 512 walkers over 8 GPUs is
+        slower than evaluating them redundantly (the kernels are deterministic: every rank gets the same bits); the break-even is a few thousand points.  Several
+        GPUs then serve independent chains, as the reference's ``chains=N`` does over MPI communicators (utils.py:1090).  0: always shard."""
         import torch.distributed as dist
+        self.min_shard_rows = int(min_shard_rows)
         self.dist = dist
         self.group = group
         self.active = dist.is_available() and dist.is_initialized()
@@ -53,6 +58,8 @@ class WalkerSharding(object):
     def map(self, func, values):
         """``func(values_local) -> array[len(values_local), ...]`` applied to this rank's slice; returns the full result everywhere."""
         values = np.asarray(values)
+        if not self.active or self.world == 1 or len(values) < self.min_shard_rows:
+            return np.asarray(func(values))
         sl = self.slice(len(values))
         local = np.asarray(func(values[sl]))
         return self.allgather_rows(np.ascontiguousarray(local), len(values))

@@ -57,6 +57,17 @@ def test_stretch_move_recovers_gaussian():
     assert 0.2 < sampler.acceptance_fraction.mean() < 0.9
 
 
+def test_small_batches_are_not_sharded():
+    """Below ``min_shard_rows`` every rank evaluates all rows (no exchange): the function sees the whole batch even when a process group is active."""
+    from desilike_amd.parallel import WalkerSharding
+    sharding = WalkerSharding()
+    sharding.active, sharding.world, sharding.rank = True, 8, 3      # pretend: rank 3 of 8 (no collective may be called)
+    seen = []
+    values = np.arange(20.).reshape(10, 2)
+    out = sharding.map(lambda rows: (seen.append(len(rows)), rows.sum(axis=1))[1], values)
+    assert seen == [10] and np.array_equal(out, values.sum(axis=1))
+
+
 def test_local_slice():
     from desilike_amd.parallel import local_slice
     for size in [0, 1, 7, 256, 1000]:
@@ -73,7 +84,7 @@ def _worker(rank, world, port, results):
     from desilike_amd.samplers import EmceeSampler
     from desilike_amd.parallel import WalkerSharding
     like = ToyGaussianLikelihood()
-    sharding = WalkerSharding()
+    sharding = WalkerSharding(min_shard_rows=0)   # (the default keeps small batches un-sharded: here the exchange itself is under test)
     assert sharding.world == world and sharding.rank == rank
     rng = np.random.RandomState(3)
     values = rng.uniform(-1., 1., size=(13, 2))                  # ragged: 13 rows over 2 ranks
