@@ -203,11 +203,12 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
                 }
             }
         };
+        static const int64_t dense_min = getenv("DL_FS_DENSE_MIN") ? atoll(getenv("DL_FS_DENSE_MIN")) : 4096;   // batches above: the 5-workgroups-per-CU variant
         bool nl3 = oh.n_ell <= 3, eft = oh.n_ct > 0 || oh.n_sn > 0;
         if (generic) launch(dl_fullshape_kernel<false, 5, true>);   // generic: run-time decisions
-        else if (nl3 && !eft) { if (B > 4096) launch(dl_fullshape_kernel<true, 3, false, true>); else launch(dl_fullshape_kernel<true, 3, false>); }
+        else if (nl3 && !eft) { if (B > dense_min) launch(dl_fullshape_kernel<true, 3, false, true>); else launch(dl_fullshape_kernel<true, 3, false>); }
         else if (nl3) launch(dl_fullshape_kernel<true, 3, true>);
-        else if (!eft) { if (B > 4096) launch(dl_fullshape_kernel<true, 5, false, true>); else launch(dl_fullshape_kernel<true, 5, false>); }
+        else if (!eft) { if (B > dense_min) launch(dl_fullshape_kernel<true, 5, false, true>); else launch(dl_fullshape_kernel<true, 5, false>); }
         else launch(dl_fullshape_kernel<true, 5, true>);
     }
 }
