@@ -4,13 +4,19 @@
 
 Workload (BASELINE.json configs[1]): ShapeFit + Kaiser P_ell, ell = (0, 2, 4), 40 k-bins, dense synthetic
 survey-like window (120 x 1200), full 120 x 120 precision; one *step* = one pass of the hot path over a batch of
-1024 parameter points per GPU (theta already resident in HBM).  N > 1: one process per GPU (torchrun), walkers
-sharded contiguously (weak scaling: 1024 points per rank), log-posteriors exchanged by asynchronous RCCL all-gathers, bucketed over 8 steps.
+1024 parameter points per GPU (theta already resident in HBM).
+
+N > 1: one process per GPU.  Launched under ``torchrun`` (RANK / WORLD_SIZE in the environment) each process is one rank; launched plainly
+(``python bench.py --gpus N``) the parent -- which never touches the GPU -- starts the N ranks itself as fresh child processes and relays rank 0's JSON line.
+Walkers are sharded contiguously (weak scaling: 1024 points per rank and step); the log-posteriors are exchanged by RCCL all-gathers issued through the library's
+own C ABI (``dl_comm_*``; asynchronous, bucketed over 8 steps).  The line also carries BASELINE configs[4] as written -- ONE 512-walker ensemble on two config-2
+tracers, sharded over the ranks with a synchronous all-gather per half-step (strong scaling) -- under ``config5_strong``.
 Prints ONE JSON line (rank 0).  Synthetic inputs only; nothing here reads /root/reference.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,6 +32,9 @@ FLOP_THEORY = 23e3 + 5e3 + 288e3 + 57.6e3 + 7e3    # template factor, spline coe
 FLOP_GEMM = 288e3 + 29e3                            # window GEMM 2 n n_in + chi2 2 n^2 + 2 n (precision folded into the window matrix)
 FLOP_FINAL = 2 * 120 + 5 * 6
 PEAK_FP64_TFLOPS = 78.6                             # MI355X public spec, FP64 vector = FP64 matrix (the CDNA4 guide lists no fp64 row)
+# The reference itself (desilike through tests/golden/refstub), timed in the BUILD container by tests/golden/make_golden.py on this workload's shape
+# (vmap(likelihood) python loop, 1 process, Xeon 2.1 GHz): it cannot run on the GPU box, so the number is quoted, not measured here
+REFERENCE_IN_BUILD_CONTAINER = {'value': 430., 'unit': 'evals/s', 'cores': 1, 'range': [359., 572.], 'where': 'build container (Xeon 2.1 GHz), tests/golden/make_golden.py / SURVEY.md section 6'}
 
 
 def dense_window(kedges, ells, resolution=10, seed=7):
@@ -46,18 +55,41 @@ def dense_window(kedges, ells, resolution=10, seed=7):
     return kin, binmat.dot(mix) * (1. + 0.01 * rng.standard_normal((binmat.shape[0], mix.shape[1])))
 
 
-def make_likelihood(device):
+def synthetic_covariance(n, seed=1):
+    rng = np.random.RandomState(seed)
+    A = rng.standard_normal((n, n)) * 30.
+    return A.dot(A.T) + 1e4 * np.eye(n)
+
+
+def make_observable(tracer=None, b1=2., shotnoise=1e4, template=None, seed=7):
     from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles
     from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
-    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
     kedges = np.linspace(0., 0.2, 41)
-    kin, wmat = dense_window(kedges, (0, 2, 4))
-    template = ShapeFitPowerSpectrumTemplate(z=0.5)
-    theory = KaiserTracerPowerSpectrumMultipoles(template=template)
-    observable = TracerPowerSpectrumMultipolesObservable(data={'b1': 2.}, kedges=kedges, ells=(0, 2, 4), wmatrix=wmat, kin=kin, ellsin=(0, 2, 4), theory=theory, shotnoise=1e4)
-    rng = np.random.RandomState(1)
-    A = rng.standard_normal((120, 120)) * 30.
-    likelihood = ObservablesGaussianLikelihood(observables=[observable], covariance=A.dot(A.T) + 1e4 * np.eye(120), device=device)
+    kin, wmat = dense_window(kedges, (0, 2, 4), seed=seed)
+    if template is None: template = ShapeFitPowerSpectrumTemplate(z=0.5, fiducial='synthetic')
+    kwargs = {} if tracer is None else dict(tracers=tracer)
+    theory = KaiserTracerPowerSpectrumMultipoles(template=template, **kwargs)
+    data = {'b1': b1} if tracer is None else {'{}.b1'.format(tracer): b1}
+    return TracerPowerSpectrumMultipolesObservable(data=data, kedges=kedges, ells=(0, 2, 4), wmatrix=wmat, kin=kin, ellsin=(0, 2, 4), theory=theory, shotnoise=shotnoise)
+
+
+def make_likelihood(device):
+    """BASELINE configs[1]."""
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    likelihood = ObservablesGaussianLikelihood(observables=[make_observable()], covariance=synthetic_covariance(120), device=device)
+    likelihood.initialize()
+    return likelihood
+
+
+def make_likelihood_config5(device):
+    """BASELINE configs[4]: two config-2 tracers (separate b1 / sn0 namespaces, shared ShapeFit parameters), n = 240, block-diagonal precision."""
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    from scipy import linalg
+    template = ShapeFitPowerSpectrumTemplate(z=0.5, fiducial='synthetic')
+    observables = [make_observable('LRG', 2., 1e4, template, seed=7), make_observable('ELG', 1.3, 4e3, template, seed=8)]
+    covariance = linalg.block_diag(synthetic_covariance(120, seed=1), synthetic_covariance(120, seed=2))
+    likelihood = ObservablesGaussianLikelihood(observables=observables, covariance=covariance, device=device)
     likelihood.initialize()
     return likelihood
 
@@ -77,22 +109,60 @@ def oracle_constants(likelihood):
                 wmu_ell=theory.wmu, ellsin=theory.ells, nd=theory.nd, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout, flatdata=obs.flatdata)
 
 
-def cpu_baseline(likelihood, theta, budget=12.):
-    """The NumPy oracle (restatement of the reference's numpy path, pinned to its golden vectors) on 1 host core, bounded sample."""
+def _oracle_loop(payload):
+    """One CPU worker of the baseline: the NumPy oracle cycling over the points of one step for ``budget`` seconds; returns (evaluations, seconds, first log-likelihoods)."""
+    c, names, precision, theta, budget, ncheck = payload
+    sys.path.insert(0, ROOT)
     from oracle import np_oracle as orc
+    import contextlib
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)   # one BLAS thread per worker: the reported core count is the number of workers
+    except ImportError:
+        limiter = contextlib.nullcontext()
+    with limiter:
+        t0, n, check = time.perf_counter(), 0, []
+        while time.perf_counter() - t0 < budget:
+            p = dict(zip(names, theta[n % len(theta)]))
+            p['b1'] = (p['b1'], p['b1'])
+            out = orc.fullshape_observable(c, p)
+            logl = orc.gaussian_loglikelihood(out['flattheory'], c['flatdata'], precision)[0]
+            if n < ncheck: check.append(logl)
+            n += 1
+        dt = time.perf_counter() - t0
+    return n, dt, np.array(check)
+
+
+def cpu_baseline(likelihood, theta, budget=10.):
+    """The NumPy oracle (restatement of the reference's numpy path, pinned to its golden vectors) on the host cores, bounded samples: 1 process / 1 thread, then
+    N = nproc independent processes each cycling over the step's points (the reference's MPI data parallelism, desilike/base.py:310-316)."""
     c = oracle_constants(likelihood)
     names = likelihood.varied_params.names()
-    precision = likelihood.precision
-    t0, n, check = time.perf_counter(), 0, []
-    while time.perf_counter() - t0 < budget:
-        p = dict(zip(names, theta[n % len(theta)]))
-        p['b1'] = (p['b1'], p['b1'])
-        out = orc.fullshape_observable(c, p)
-        logl = orc.gaussian_loglikelihood(out['flattheory'], c['flatdata'], precision)[0]
-        if n < len(theta): check.append(logl)
-        n += 1
-    dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit='evals/s', cores=1, kind='port', sample='{:d} evaluations cycling over the {:d} points of one step, {:.1f} s, NumPy oracle, 1 thread'.format(n, len(theta), dt)), np.array(check)
+    n, dt, check = _oracle_loop((c, names, likelihood.precision, theta, budget, len(theta)))
+    base = dict(value=n / dt, unit='evals/s', cores=1, kind='port',
+                sample='{:d} evaluations cycling over the {:d} points of one step, {:.1f} s, NumPy oracle, 1 process, 1 thread'.format(n, len(theta), dt),
+                reference_in_build_container=REFERENCE_IN_BUILD_CONTAINER)
+    ncores = os.cpu_count() or 1
+    try:
+        import multiprocessing as mp
+        saved = {key: os.environ.get(key) for key in ['OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS']}
+        for key in saved: os.environ[key] = '1'
+        try:
+            with mp.get_context('spawn').Pool(ncores) as pool:   # fresh interpreters: nothing of this process's GPU state is inherited
+                t0 = time.perf_counter()
+                results = pool.map(_oracle_loop, [(c, names, likelihood.precision, theta, budget, 0)] * ncores)
+                wall = time.perf_counter() - t0
+        finally:
+            for key, value in saved.items():
+                if value is None: os.environ.pop(key, None)
+                else: os.environ[key] = value
+        total = sum(r[0] for r in results)
+        span = max(r[1] for r in results)
+        base['multi'] = dict(value=total / span, unit='evals/s', cores=ncores, kind='port',
+                             sample='{:d} independent processes x {:.1f} s, {:d} evaluations in total ({:.1f} s wall incl. start-up)'.format(ncores, span, total, wall))
+    except Exception as exc:   # the 1-core number stands on its own
+        base['multi'] = dict(error=repr(exc))
+    return base, check
 
 
 def hbm_traffic(kernel_name):
@@ -109,54 +179,170 @@ def hbm_traffic(kernel_name):
     return None, None
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(ngpus):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as fresh child processes (this parent has made no GPU call and makes none), relay rank 0's
+    stdout (the JSON line), send the other ranks' output to stderr; the first failure ends the job."""
+    port = free_port()
+    procs = []
+    for rank in range(ngpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if rank == 0 else sys.stderr))
+    code = 0
+    pending = list(procs)
+    while pending:
+        for proc in list(pending):
+            rc = proc.poll()
+            if rc is None: continue
+            pending.remove(proc)
+            if rc != 0 and code == 0:
+                code = rc
+                for other in pending: other.terminate()   # exactly the children started above
+        time.sleep(0.05)
+    return code
+
+
+def timed_steps(step, barrier, steps):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def config5_strong(group, device, local_rank, rank, world, iterations, warmup=10):
+    """BASELINE configs[4] as written: ONE ensemble of 512 walkers on the two-tracer likelihood; every half-step's 256 proposals are split over the ranks
+    (min_shard_rows = 0) and the log-posteriors all-gathered synchronously (in place, on the evaluation stream) before the accept step: strong scaling."""
+    import torch
+    from desilike_amd.samplers import EmceeSampler
+    from desilike_amd.parallel import WalkerSharding, RcclGroup
+    likelihood = make_likelihood_config5(local_rank)
+    sharding = WalkerSharding(group=group, min_shard_rows=0)
+    sampler = EmceeSampler(likelihood, nwalkers=512, seed=42, sharding=sharding, device_resident=True)
+    start, logposterior = sampler._get_start(512)
+    ens = sampler._get_ensemble()
+    ens.set_state(start, logposterior)
+    nparams = ens.n_params
+    chain = torch.empty((iterations, 512, nparams), dtype=torch.float64, device=device)
+    chain_logp = torch.empty((iterations, 512), dtype=torch.float64, device=device)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if group is not None: group.barrier()
+        torch.cuda.synchronize(device)
+
+    ens.run(warmup)
+    barrier()
+    t0 = time.perf_counter()
+    ens.run(iterations, chain=chain, chain_logp=chain_logp)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if group is not None: elapsed = group.max(elapsed)
+    coords, logp, nacc = ens.get_state()
+    sharded = isinstance(group, RcclGroup) and world > 1
+    assert np.isfinite(logp).all() and np.isfinite(chain_logp.cpu().numpy()).all()
+    return {'workload': 'BASELINE configs[4]: EnsembleSampler (stretch move), 512 walkers x two config-2 tracers (n = 240), {:d} ensemble updates, device-resident'.format(iterations),
+            'value': 512 * iterations / elapsed, 'unit': 'evals/s', 'scaling': 'strong', 'n_gpus': world, 'us_per_update': 1e6 * elapsed / iterations,
+            'rows_per_gpu_per_half_step': ens.info('rows_per_rank'), 'sharded': sharded,
+            'exchange': 'one in-place ncclAllGather of 256 log-posteriors per half-step on the evaluation stream' if sharded else 'none (single rank, or a host-side group: every rank evaluates all walkers)',
+            'acceptance_fraction': float(nacc.sum()) / (512. * ens.info('iteration')), 'n_params': nparams}
+
+
+def dry_run(rank, world):
+    """Everything of the N-rank launch path that does not need a GPU: ranks started, host-side group formed, one exchange, rank 0 prints the line skeleton."""
+    from desilike_amd import parallel
+    group = None
+    gathered = np.array([0.])
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        group = parallel.TorchGroup()
+        gathered = parallel.WalkerSharding(group=group, min_shard_rows=0).map(lambda rows: rows[:, 0] * 2., np.arange(10.)[:, None])
+        assert np.array_equal(gathered, 2. * np.arange(10.))
+        elapsed = group.max(float(rank))
+        assert elapsed == world - 1
+        group.barrier()
+    if rank == 0:
+        print(json.dumps({'metric': 'log-likelihood evals/sec (full-shape P_ell, 3x40 bins)', 'value': None, 'n_gpus': world, 'dry_run': True,
+                          'config': {'ranks': group.world if group is not None else 1, 'collective': 'torch.distributed gloo' if group is not None else 'none'}}), flush=True)
+    if group is not None:
+        group.barrier()
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
     parser.add_argument('--steps', type=int, default=200)
     parser.add_argument('--warmup', type=int, default=20)
     parser.add_argument('--batch', type=int, default=BATCH)
+    parser.add_argument('--prewarm-ms', type=float, default=400., help='untimed fixed-duration run of the step before the W warm-up steps (clocks ramp up; reported as prewarm_ms)')
+    parser.add_argument('--config5-iterations', type=int, default=100, help='ensemble updates of the strong-scaling configs[4] measurement (0: skip)')
     parser.add_argument('--no-cpu-baseline', action='store_true')
-    parser.add_argument('--no-events', action='store_true', help='diagnostic: do not bracket kernels with HIP events in the timed region')
+    parser.add_argument('--dry-run', action='store_true', help='launcher check without a GPU: start the ranks, form the (gloo) group, exchange, print the line skeleton')
+    parser.add_argument('--no-events', action='store_true', help='diagnostic: no HIP events attached to the kernels in the timed region')
     args = parser.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))    # (before anything that could touch HIP is imported)
 
     import torch
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    distributed = world > 1 or os.environ.get('DL_BENCH_FORCE_DIST', '0') == '1'   # (forcing: smoke test of the RCCL code path with a single rank on a 1-GPU box)
+    if args.dry_run:
+        return dry_run(rank, world)
+    backend = os.environ.get('DL_BENCH_BACKEND', 'rccl')   # 'gloo': smoke test of the N > 1 code path on a 1-GPU box (ranks share the GPU, host-side exchange)
+    force_dist = os.environ.get('DL_BENCH_FORCE_DIST', '0') == '1'   # single-rank RCCL communicator: exercises the collective calls on a 1-GPU box
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs a GPU: the hot path has no CPU fallback')
-    local_rank = local_rank % torch.cuda.device_count()   # (only differs when the N > 1 path is smoke-tested on a 1-GPU box: DL_BENCH_BACKEND=gloo)
+    ndev = torch.cuda.device_count()
+    if world > ndev and backend == 'rccl':
+        raise RuntimeError('{:d} ranks but {:d} GPU(s) visible: RCCL needs one GPU per rank (DL_BENCH_BACKEND=gloo runs the N > 1 code path with the ranks sharing a GPU)'.format(world, ndev))
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if distributed:
-        import torch.distributed as dist
-        backend = os.environ.get('DL_BENCH_BACKEND', 'nccl')   # "nccl" IS RCCL on ROCm
-        if backend == 'nccl':
-            dist.init_process_group(backend='nccl', device_id=device)
+    group, collective = None, 'none'
+    if world > 1 or force_dist:
+        from desilike_amd import parallel
+        if backend == 'rccl':
+            group = parallel.RcclGroup(local_rank, rank=rank, world=world)
+            collective = 'RCCL {} through the C ABI (dl_comm_allgather_f64)'.format(group.rccl_version)
         else:
-            dist.init_process_group(backend=backend)
+            import torch.distributed as dist
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            group = parallel.TorchGroup()
+            collective = 'torch.distributed ' + backend
+        parallel.set_default_group(group)
+    distributed = group is not None
 
     likelihood = make_likelihood(local_rank)
     ctx = likelihood._get_context()
     B = args.batch
     # N > 1: independent walker ensembles (chains) are kept in flight so that the exchange of log-posteriors never stalls the evaluation: the finalize kernel
     # writes each step's log-posteriors straight into a bucket, and one asynchronous RCCL all-gather (its own stream) ships a bucket of GATHER_EVERY steps while the
-    # next bucket is being evaluated (desilike_amd/parallel.py: a kilobyte all-gather costs ~25 us of host issue time whatever its size -- issued every step it
-    # would take as long as the step itself).  Every step is still one pass of the hot path over B points per GPU; every result is all-gathered.
+    # next bucket is being evaluated (desilike_amd/parallel.py).  Every step is still one pass of the hot path over B points per GPU; every result is all-gathered.
     nslots = 2 if distributed else 1
     theta_host = sample_theta(likelihood, B, seed=42 + rank)
     thetas = [torch.as_tensor(theta_host if slot == 0 else sample_theta(likelihood, B, seed=4242 + rank), dtype=torch.float64, device=device).contiguous() for slot in range(nslots)]
     loglikes = [torch.empty(B, dtype=torch.float64, device=device) for slot in range(nslots)]
     logpriors = [torch.empty(B, dtype=torch.float64, device=device) for slot in range(nslots)]
     statuses = [torch.zeros(B, dtype=torch.int32, device=device) for slot in range(nslots)]
-    loglike, status = loglikes[0], statuses[0]
+    loglike = loglikes[0]
     stream = torch.cuda.current_stream(device)
     bucket = None
     if distributed:
         from desilike_amd.parallel import BucketedAllGather
-        bucket = BucketedAllGather(B, torch.float64, device, steps_per_bucket=GATHER_EVERY, keep=False,
-                                   force_collective=os.environ.get('DL_BENCH_FORCE_DIST', '0') == '1')
+        bucket = BucketedAllGather(B, torch.float64, device, steps_per_bucket=GATHER_EVERY, keep=False, group=group, force_collective=force_dist)
     counter = [0]
 
     def step():
@@ -172,41 +358,39 @@ def main():
     def barrier():
         if distributed:
             bucket.results()   # flush the partial bucket, wait for every collective in flight
-            dist.barrier()
+            torch.cuda.synchronize(device)
+            group.barrier()
         torch.cuda.synchronize(device)
 
     import gc
     gc.collect()   # whatever set-up garbage holds device resources is released now, not by a collector pass inside the timed loop (hipFree synchronises the device)
+    # fixed-duration pre-warm (its own key in the line): a 20-step run is 0.6 ms of GPU work -- without it the timed region would start on idle clocks
+    t0 = time.perf_counter()
+    prewarm_steps = 0
+    while 1e3 * (time.perf_counter() - t0) < args.prewarm_ms:
+        for _ in range(16): step()
+        torch.cuda.synchronize(device)
+        prewarm_steps += 16
+    prewarm_ms = 1e3 * (time.perf_counter() - t0)
     for _ in range(args.warmup):
         step()
     barrier()
-    every = max(1, min(25, args.steps // 8))   # HIP events on the launch stream around each kernel, on 1 timed step out of 25 (8 samples at 200 steps, median; an event record costs ~4 us of stream time)
+    # HIP events attached to the kernels' own dispatch packets on the launch stream (hipExtLaunchKernelGGL: no event records between the kernels), on at least 8
+    # steps of the timed region whatever --steps is
+    every = max(1, min(25, args.steps // 8))
     ctx.profile_enable(0 if args.no_events else every)
-    barrier()
     gc.disable()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_steps(step, barrier, args.steps)
     gc.enable()
-    kernel_ms = ctx.profile_read() if not args.no_events else dict(theory=1., window_gemm=1., finalize=1., total=1., event_overhead=0.)
+    kernel_ms = ctx.profile_read() if not args.no_events else dict(theory=1., window_gemm=1., finalize=1., total=1., event_overhead=0., samples=0)
     ctx.profile_enable(0)
-    if not args.no_events and not distributed:
-        # An event record costs stream time of its own (3.5-4.6 us, the library's calibrated `event_overhead`), part of which overlaps the launch ramp of the
-        # kernel behind it.  The three kernels ARE the step: re-attribute with one common offset such that the three durations sum to the measured step time
-        # (conservative: the step time still carries the sampled event records).  These durations agree with `rocprofv3 --kernel-trace` (profiles/).
-        raw = {name: kernel_ms[name] + kernel_ms['event_overhead'] for name in ['theory', 'window_gemm', 'finalize']}
-        offset = (sum(raw.values()) - 1e3 * elapsed / args.steps) / 3.
-        if 0. < offset < min(raw.values()):
-            for name in raw: kernel_ms[name] = raw[name] - offset
-            kernel_ms['event_overhead'] = offset
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = group.max(elapsed)
 
     assert all(int((st != 0).sum().item()) == 0 for st in statuses), 'non-OK status in the benchmark batch'
+    strong = None
+    if args.config5_iterations > 0 and B == BATCH:
+        strong = config5_strong(group, device, local_rank, rank, world, args.config5_iterations)
     if rank == 0:
         value = world * B * args.steps / elapsed
         flops = {'theory': FLOP_THEORY, 'window_gemm': FLOP_GEMM, 'finalize': FLOP_FINAL}
@@ -215,17 +399,25 @@ def main():
         traffic, traffic_source = hbm_traffic(kernel_name) if B == BATCH else (None, None)
         per_launch = min(B, 32768)   # batches above 32768 points are evaluated in internal passes of 32768: the kernel intervals are per pass
         achieved = flops[dominant] * per_launch / (kernel_ms[dominant] * 1e-3) / 1e12
+        # which unit bounds the dominant kernel: the theory kernel issues no MFMA (fp64 VALU: transcendentals, spline evaluation, projection -- its 78.6 TFLOP/s peak
+        # equals the fp64 matrix peak); the chi2 GEMM is fp64 MFMA (v_mfma_f64_16x16x4_f64)
+        bound = {'theory': 'valu', 'window_gemm': 'mfma', 'finalize': 'latency'}[dominant]
         result = {'metric': 'log-likelihood evals/sec (full-shape P_ell, 3x40 bins)', 'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
                   'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
-                  'data': 'synthetic',
+                  'data': 'synthetic', 'prewarm_ms': prewarm_ms, 'prewarm_steps': prewarm_steps,
                   'config': {'workload': 'BASELINE configs[1]: ShapeFit+Kaiser P_ell ell=(0,2,4) x 40 k-bins, dense window 120x1200 (n_kin=400/ell), 120x120 precision, '
-                                         '{:d} batched param points per GPU per step'.format(B), 'batch_per_gpu': B, 'n_params': 6, 'parallelism': 'walkers x{:d}'.format(world) + (', log-posteriors all-gathered in buckets of {:d} steps'.format(GATHER_EVERY) if distributed else '')},
-                  'roofline': {'bound': 'mfma', 'bound_detail': {'theory': 'fp64 VALU (transcendentals, spline evaluation, projection); its 78.6 TFLOP/s peak equals the fp64 matrix peak',
-                                                                  'window_gemm': 'fp64 MFMA (v_mfma_f64_16x16x4_f64)', 'finalize': 'launch latency'}[dominant], 'kernel': kernel_name,
-                               'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
-                               'flop_per_launch': flops[dominant] * per_launch, 'avg_launch_ms': kernel_ms[dominant]},
-                  'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize', 'total', 'event_overhead']},
+                                         '{:d} batched param points per GPU per step'.format(B), 'batch_per_gpu': B, 'n_params': 6,
+                             'parallelism': 'walkers x{:d}'.format(world) + (', log-posteriors all-gathered in buckets of {:d} steps'.format(GATHER_EVERY) if distributed else ''),
+                             'collective': collective, 'ranks': group.world if distributed else 1},
+                  'roofline': {'bound': bound, 'bound_detail': {'theory': 'fp64 VALU (no MFMA in this kernel: transcendentals, spline evaluation, projection); peak = 78.6 TFLOP/s fp64 vector',
+                                                                 'window_gemm': 'fp64 MFMA (v_mfma_f64_16x16x4_f64), peak = 78.6 TFLOP/s fp64 matrix', 'finalize': 'launch latency'}[dominant],
+                               'kernel': kernel_name, 'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS, 'traffic': traffic,
+                               'traffic_source': traffic_source, 'flop_per_launch': flops[dominant] * per_launch, 'avg_launch_ms': kernel_ms[dominant],
+                               'event_samples': int(kernel_ms.get('samples', 0))},
+                  'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize', 'total']},
                   'kernel_frac_of_fp64_peak': {name: flops[name] * per_launch / (kernel_ms[name] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS for name in ['theory', 'window_gemm']}}
+        if strong is not None:
+            result['config5_strong'] = strong
         if world == 1 and not distributed and not args.no_cpu_baseline:   # (the forced single-rank RCCL smoke mode writes log-posteriors into buckets, not `loglike`)
             base, check = cpu_baseline(likelihood, theta_host)
             gpu = loglike[:len(check)].cpu().numpy()
@@ -242,10 +434,15 @@ def main():
         pass
     sys.stdout.flush()
     if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+        group.barrier()
     if result is not None:
         print(json.dumps(result), flush=True)
+    if distributed:
+        group.barrier()
+        group.close()
+        if backend != 'rccl':
+            import torch.distributed as dist
+            dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -36,6 +36,18 @@ SYMBOLS = {
     'dl_fftlog_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_double_p, _c_double_p, _c_double_p]),
     'dl_fftlog_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_fftlog_destroy': (None, [ctypes.c_void_p]),
+    'dl_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    'dl_comm_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]),
+    'dl_comm_destroy': (None, [ctypes.c_void_p]),
+    'dl_comm_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
+    'dl_comm_allgather_f64': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    'dl_comm_broadcast_f64': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    'dl_ensemble_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int32, ctypes.c_double, ctypes.c_uint64, ctypes.c_double, ctypes.c_void_p]),
+    'dl_ensemble_destroy': (None, [ctypes.c_void_p]),
+    'dl_ensemble_set_state': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, ctypes.c_void_p]),
+    'dl_ensemble_run': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_ensemble_get_state': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
+    'dl_ensemble_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
 }
 
 
@@ -65,6 +77,21 @@ def load():
             func.restype, func.argtypes = restype, argtypes
         _lib = lib
     return _lib
+
+
+def rccl_library_path():
+    """RCCL to bind (``dl_comm_*`` load it with dlopen): ``DL_RCCL_PATH`` if set, else the copy PyTorch-ROCm bundles (the one already mapped into this process when
+    torch is imported: one RCCL and one HIP runtime per process), else ``None`` (the library's own search: already-loaded copy, default path, /opt/rocm/lib)."""
+    path = os.environ.get('DL_RCCL_PATH', None)
+    if path:
+        return path
+    try:
+        import torch
+        path = os.path.join(os.path.dirname(os.path.abspath(torch.__file__)), 'lib', 'librccl.so')
+        if os.path.isfile(path): return path
+    except ImportError:
+        pass
+    return None
 
 
 def _f64_ptr(array):
@@ -260,13 +287,13 @@ class Context(object):
                                                    None if status is None else ctypes.c_void_p(status.data_ptr()), ctypes.c_void_p(stream)))
 
     def profile_enable(self, every=1):
-        """Bracket kernels with HIP events on one ``eval_batch`` call out of ``every`` (0 / False: off)."""
+        """Attach HIP events to the kernels' dispatch packets on one ``eval_batch`` call out of ``every`` (0 / False: off)."""
         self._check(self._lib.dl_profile_enable(self._handle, int(every)))
 
     def profile_read(self):
-        ms = np.zeros(5, dtype='f8')
-        self._check(self._lib.dl_profile_read(self._handle, _f64_ptr(ms), 5))
-        return dict(theory=ms[0], window_gemm=ms[1], finalize=ms[2], total=ms[3], event_overhead=ms[4])
+        ms = np.zeros(6, dtype='f8')
+        self._check(self._lib.dl_profile_read(self._handle, _f64_ptr(ms), 6))
+        return dict(theory=ms[0], window_gemm=ms[1], finalize=ms[2], total=ms[3], event_overhead=ms[4], samples=int(ms[5]))
 
 
 class FFTLogPlan(object):
@@ -299,6 +326,72 @@ class FFTLogPlan(object):
     def close(self):
         if getattr(self, '_handle', None):
             self._lib.dl_fftlog_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceEnsemble(object):
+    """Owner of one ``dl_ensemble`` (include/desilike_amd.h): affine-invariant ensemble sampler resident on the GPU of ``ctx``; ``group``: an
+    :class:`desilike_amd.parallel.RcclGroup` to shard every half-step's proposals over the ranks (or ``None``)."""
+
+    def __init__(self, ctx, nwalkers, a=2., seed=0, offset=0., group=None):
+        lib = load()
+        handle = ctypes.c_void_p()
+        comm = getattr(group, 'handle', None)
+        if lib.dl_ensemble_create(ctypes.byref(handle), ctx._handle, int(nwalkers), float(a), ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), float(offset), comm) != 0:
+            raise LibraryError(lib.dl_last_error(None).decode())
+        self._lib, self._handle, self._ctx, self._group = lib, handle, ctx, group   # (the context and the group must outlive the ensemble)
+        self.nwalkers, self.n_params, self.device = int(nwalkers), ctx.n_params, ctx.device
+
+    def _check(self, rc):
+        if rc != 0:
+            raise LibraryError(self._lib.dl_last_error(None).decode())
+
+    def info(self, key):
+        return int(self._lib.dl_ensemble_info(self._handle, key.encode()))
+
+    def _stream(self, stream):
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream(torch.device('cuda', self.device)).cuda_stream if stream is None else stream)
+
+    def set_state(self, coords, logposterior=None, stream=None):
+        coords = np.ascontiguousarray(coords, dtype='f8')
+        if coords.shape != (self.nwalkers, self.n_params):
+            raise ValueError('coords must have shape ({:d}, {:d}), found {}'.format(self.nwalkers, self.n_params, coords.shape))
+        if logposterior is not None:
+            logposterior = np.ascontiguousarray(logposterior, dtype='f8')
+            if logposterior.shape != (self.nwalkers,): raise ValueError('logposterior must have shape ({:d},)'.format(self.nwalkers))
+        self._check(self._lib.dl_ensemble_set_state(self._handle, _f64_ptr(coords), _f64_ptr(logposterior), self._stream(stream)))
+
+    def run(self, niterations, thin_by=1, chain=None, chain_logp=None, stream=None):
+        """Enqueue ``niterations`` ensemble updates (asynchronous); ``chain [niterations // thin_by, nwalkers, P]`` / ``chain_logp [niterations // thin_by, nwalkers]``:
+        float64 device tensors receiving the ensemble after every ``thin_by``-th update (optional)."""
+        import torch
+        nrec = int(niterations) // int(thin_by)
+
+        def ptr(tensor, shape):
+            if tensor is None: return None
+            assert tensor.is_cuda and tensor.is_contiguous() and tensor.dtype == torch.float64 and tuple(tensor.shape) == shape, (tensor.shape, shape)
+            return ctypes.c_void_p(tensor.data_ptr())
+
+        self._check(self._lib.dl_ensemble_run(self._handle, int(niterations), int(thin_by), ptr(chain, (nrec, self.nwalkers, self.n_params)),
+                                              ptr(chain_logp, (nrec, self.nwalkers)), self._stream(stream)))
+
+    def get_state(self, stream=None):
+        """(coords [nwalkers, P], logposterior [nwalkers], naccepted [nwalkers]) as numpy arrays; synchronises the stream."""
+        coords, logp = np.empty((self.nwalkers, self.n_params), dtype='f8'), np.empty(self.nwalkers, dtype='f8')
+        nacc = np.empty(self.nwalkers, dtype='i8')
+        self._check(self._lib.dl_ensemble_get_state(self._handle, _f64_ptr(coords), _f64_ptr(logp), nacc.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), self._stream(stream)))
+        return coords, logp, nacc
+
+    def close(self):
+        if getattr(self, '_handle', None):
+            self._lib.dl_ensemble_destroy(self._handle)
             self._handle = None
 
     def __del__(self):

@@ -55,14 +55,18 @@ struct dl_ctx {
     int32_t* status_stage = nullptr; // device
     double* host_stage = nullptr;    // pinned host mirror: theta[cap * P] | out[3 * cap]
     hipStream_t host_stream = nullptr;   // private stream of the *_host entry points
+    // the workspaces are shared by every call on this context: a call on another stream than the previous one waits for it (event recorded on the old stream
+    // at the moment of the switch: calls that stay on one stream pay nothing)
+    hipStream_t last_stream = nullptr;
+    bool has_last_stream = false;
+    hipEvent_t order_event = nullptr;
     // profiling
     bool profile = false;
     static const int NPOOL = 256;            // event sets kept: dl_profile_read averages over the calls recorded since dl_profile_enable
-    std::vector<hipEvent_t> ev;              // [NPOOL * 4]
+    std::vector<hipEvent_t> ev;              // [NPOOL * 6]: (start, stop) of the theory kernel, the GEMM, the finalize kernel
     int64_t prof_calls = 0;                  // profiled calls recorded
     int64_t eval_calls = 0;                  // dl_eval_batch calls since dl_profile_enable
     int prof_every = 1;                      // record events on one call out of prof_every (sampling keeps the event overhead out of the throughput)
-    double ev_overhead_ms = 0.;              // calibrated cost of an empty event-to-event interval, subtracted from every interval
     std::string last_error;
 };
 
@@ -76,6 +80,19 @@ struct dl_ctx {
             return 1;                                                                                            \
         }                                                                                                        \
     } while (0)
+
+// Serialise the calls on one context across streams (the header's contract): everything enqueued so far on the stream of the previous call is finished before
+// work enqueued from now on ``stream`` starts.
+static int dl_order_streams(dl_ctx* ctx, hipStream_t stream) {
+    if (ctx->has_last_stream && ctx->last_stream != stream) {
+        if (!ctx->order_event) DL_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming));
+        DL_HIP_CHECK(ctx, hipEventRecord(ctx->order_event, ctx->last_stream));
+        DL_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->order_event, 0));
+    }
+    ctx->last_stream = stream;
+    ctx->has_last_stream = true;
+    return 0;
+}
 
 static int dl_fail(dl_ctx* ctx, const std::string& msg) {
     if (ctx) ctx->last_error = msg;
@@ -344,6 +361,7 @@ void dl_destroy(dl_ctx* ctx) {
     for (double* p : ctx->gfrag_dev) if (p) (void)hipFree(p);
     if (ctx->feat_ws) (void)hipFree(ctx->feat_ws);
     for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
     delete ctx;
@@ -359,6 +377,7 @@ int64_t dl_info(const dl_ctx* ctx, const char* key) {
     if (k == "K_pad") return ctx->K_pad;
     if (k == "N_pad") return ctx->N_pad;
     if (k == "n_solved") return ctx->n_solved;
+    if (k == "device") return ctx->device;
     for (int i = 0; i < ctx->n_obs; ++i) {
         if (k == "n_in_obs" + std::to_string(i)) return ctx->obs[i].dev.n_in;
         if (k == "n_out_obs" + std::to_string(i)) return ctx->obs[i].n_out;
@@ -374,6 +393,7 @@ static int dl_reserve(dl_ctx* ctx, int64_t B) {
     int64_t need = std::min<int64_t>(B, DL_CHUNK);
     if (need <= ctx->cap) return 0;
     need = std::min<int64_t>(std::max<int64_t>(need, 1024), DL_CHUNK);
+    if (ctx->cap > 0) DL_HIP_CHECK(ctx, hipDeviceSynchronize());   // kernels of earlier calls (any stream) may still read the workspaces about to be freed
     for (double** p : {&ctx->power_ws, &ctx->delta_ws, &ctx->flat_ws, &ctx->feat_ws}) if (*p) { (void)hipFree(*p); *p = nullptr; }
     ctx->cap = 0;
     const size_t R = 1 + ctx->n_var;   // rows per point: power + point-dependent derivative rows (analytic marginalisation)
@@ -394,15 +414,22 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
     if (B < 0 || (B > 0 && !theta_dev)) return dl_fail(ctx, "dl_eval_batch: invalid batch");
     if (B == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
+    dl_prof_events.start = dl_prof_events.stop = nullptr;   // (an earlier call that failed half-way may have left them set)
     DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (dl_order_streams(ctx, stream)) return 1;
     if (dl_reserve(ctx, B)) return 1;
     const int n = ctx->n_data, P = ctx->n_params, R = 1 + ctx->n_var;
     for (int64_t b0 = 0; b0 < B; b0 += DL_CHUNK) {
         int64_t nb = std::min<int64_t>(DL_CHUNK, B - b0);
         const double* th = theta_dev + (size_t)b0 * P;
         bool prof = ctx->profile && b0 == 0 && (ctx->eval_calls % ctx->prof_every == 0);
-        hipEvent_t* ev = prof ? &ctx->ev[(size_t)(ctx->prof_calls % dl_ctx::NPOOL) * 4] : nullptr;
-        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[0], stream));
+        hipEvent_t* ev = prof ? &ctx->ev[(size_t)(ctx->prof_calls % dl_ctx::NPOOL) * 6] : nullptr;
+        // events attached to the dispatch packets of the launches of phase k (0 theory, 1 GEMM, 2 finalize; dl_kernels.h): with several launches in a phase
+        // (one theory launch per observable) the pair holds the LAST one
+        auto prof_phase = [&](int k) {
+            dl_prof_events.start = (ev && k >= 0) ? ev[2 * k] : nullptr;
+            dl_prof_events.stop = (ev && k >= 0) ? ev[2 * k + 1] : nullptr;
+        };
         bool need_flat = ctx->any_transform || flattheory_dev != nullptr;
         // emulated (separable) theories: the theory kernel writes only the factors (basis, monomial rows), the feature GEMM turns them into residual rows
         const bool feat_path = ctx->feat_ok && !need_flat;
@@ -413,10 +440,11 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         // -0.5 us per 1024 points)
         static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;   // 0: off, 1: chi2 GEMM path, 2: also the large-batch GEMM
         const int xcd_block = !xcd_local ? 0 : chi2_path ? 32 : (xcd_local > 1 && !feat_path && !ctx->any_transform && ctx->n_solved == 0 && ctx->N_pad == 128) ? 64 : 0;
+        prof_phase(0);
         if (!(feat_path && emu_fused))
             dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, feat_path ? ctx->feat_ws : nullptr, ctx->feat_ld,
                                 xcd_block);
-        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[1], stream));
+        prof_phase(1);
         int n_slabs = 1, cps = 0;
         int64_t slab_stride = 0;
         const double* fin_bias = nullptr;   // the direct GEMM (transform path) adds its bias itself
@@ -447,7 +475,7 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         // separate 1024-thread finalize launch -- the device-scope counter round trip and the dependent tail cost more than the launch they save.
         static const bool chi2_fused = getenv("DL_CHI2_FUSED") && atoi(getenv("DL_CHI2_FUSED")) != 0;
         if (chi2_path) {
-            if (nb > 16384) return dl_fail(ctx, "dl_eval_batch: DL_CHI2_GEMM_MAX above 16384 rows");
+            if (nb > 16384) { prof_phase(-1); return dl_fail(ctx, "dl_eval_batch: DL_CHI2_GEMM_MAX above 16384 rows"); }
             dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad,
                                 chi2_fused ? ctx->gemm_counters : nullptr, th, P, ctx->priors_dev, loglike_dev ? loglike_dev + b0 : nullptr,
                                 logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr, post_mode, stream);
@@ -468,7 +496,7 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
             dl_launch_window_gemm_tiled(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->delta_ws, slab_stride, ctx->N_pad, nb * R, ctx->N_pad, ctx->K_pad, n_slabs, cps,
                                         stream);
         }
-        if (prof) DL_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
+        prof_phase(2);
         if (chi2_path && chi2_fused) {
             // finalize fused into the GEMM
         } else if (chi2_path || chi2_big)
@@ -482,7 +510,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         else
             dl_launch_finalize(ctx->delta_ws, ctx->N_pad, n, n_slabs, slab_stride, fin_bias, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
                                status_dev ? status_dev + b0 : nullptr, post_mode, stream);
-        if (prof) { DL_HIP_CHECK(ctx, hipEventRecord(ev[3], stream)); ctx->prof_calls++; }
+        prof_phase(-1);
+        if (prof) ctx->prof_calls++;
     }
     if (ctx->profile) ctx->eval_calls++;
     DL_HIP_CHECK(ctx, hipGetLastError());
@@ -516,7 +545,10 @@ int dl_eval_theory(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs
     DlObsDev tmp = ctx->obs_kernarg[iobs];
     tmp.col_offset = 0;
     tmp.n_pass = 0;   // rows of exactly n_in doubles
-    tmp.n_var = 0;
+    tmp.n_var = 0;    // no derivative rows: the slots that would address them are cleared (they index LDS sized by n_var)
+    for (int c = 0; c < DL_N_VPARS; ++c) tmp.vp_slot[c] = -1;
+    for (int c = 0; c < DL_MAX_EFT; ++c) tmp.marg_ct_slot[c][0] = tmp.marg_ct_slot[c][1] = -1;
+    if (dl_order_streams(ctx, stream)) return 1;
     dl_launch_fullshape(&tmp, 1, theta_dev, ctx->n_params, B, power_dev, tmp.n_in, tables_dev, 3 * (int64_t)tmp.n_in, stream);
     DL_HIP_CHECK(ctx, hipGetLastError());
     return 0;
@@ -596,17 +628,24 @@ int dl_eval_theory_host(dl_ctx* ctx, const double* theta, int64_t B, int32_t iob
     if (B <= 0 || !theta || !power) return dl_fail(ctx, "dl_eval_theory_host: invalid argument");
     DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (dl_stage_reserve(ctx, B)) return 1;
-    int n_in = ctx->obs[iobs].dev.n_in;
+    hipStream_t stream = ctx->host_stream;
+    const int n_in = ctx->obs[iobs].dev.n_in;
     double *pdev = nullptr, *tdev = nullptr;
-    DL_HIP_CHECK(ctx, hipMalloc((void**)&pdev, (size_t)B * n_in * sizeof(double)));
-    if (tables) DL_HIP_CHECK(ctx, hipMalloc((void**)&tdev, (size_t)B * 3 * n_in * sizeof(double)));
-    DL_HIP_CHECK(ctx, hipMemcpy(ctx->theta_stage, theta, (size_t)B * ctx->n_params * sizeof(double), hipMemcpyHostToDevice));
-    int rc = dl_eval_theory(ctx, ctx->theta_stage, B, iobs, pdev, tdev, nullptr);
-    if (rc == 0) {
-        (void)hipMemcpy(power, pdev, (size_t)B * n_in * sizeof(double), hipMemcpyDeviceToHost);
-        if (tables) (void)hipMemcpy(tables, tdev, (size_t)B * 3 * n_in * sizeof(double), hipMemcpyDeviceToHost);
+    hipError_t e = hipMalloc((void**)&pdev, (size_t)B * n_in * sizeof(double));
+    if (e == hipSuccess && tables) e = hipMalloc((void**)&tdev, (size_t)B * 3 * n_in * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->theta_stage, theta, (size_t)B * ctx->n_params * sizeof(double), hipMemcpyHostToDevice, stream);
+    int rc = 0;
+    if (e == hipSuccess) {
+        rc = dl_eval_theory(ctx, ctx->theta_stage, B, iobs, pdev, tdev, stream);
+        if (rc == 0) {
+            e = hipMemcpyAsync(power, pdev, (size_t)B * n_in * sizeof(double), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess && tables) e = hipMemcpyAsync(tables, tdev, (size_t)B * 3 * n_in * sizeof(double), hipMemcpyDeviceToHost, stream);
+        }
+        hipError_t es = hipStreamSynchronize(stream);   // (also on failure: the buffers below are freed)
+        if (e == hipSuccess) e = es;
     }
-    (void)hipFree(pdev);
+    if (e != hipSuccess && rc == 0) rc = dl_fail(ctx, std::string("dl_eval_theory_host: ") + hipGetErrorString(e));
+    if (pdev) (void)hipFree(pdev);
     if (tdev) (void)hipFree(tdev);
     return rc;
 }
@@ -615,22 +654,8 @@ int dl_profile_enable(dl_ctx* ctx, int enable) {
     if (!ctx) { g_last_error = "dl_profile_enable: null context"; return 1; }
     DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (enable && ctx->ev.empty()) {
-        ctx->ev.assign((size_t)dl_ctx::NPOOL * 4, nullptr);
+        ctx->ev.assign((size_t)dl_ctx::NPOOL * 6, nullptr);
         for (auto& e : ctx->ev) DL_HIP_CHECK(ctx, hipEventCreate(&e));
-    }
-    if (enable) {
-        // calibrate the cost of an event-to-event interval with nothing in between (median of 32), on the default stream
-        std::vector<float> gaps;
-        for (int i = 0; i < 32; ++i) {
-            DL_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], nullptr));
-            DL_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], nullptr));
-            DL_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[1]));
-            float t = 0;
-            DL_HIP_CHECK(ctx, hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
-            gaps.push_back(t);
-        }
-        std::sort(gaps.begin(), gaps.end());
-        ctx->ev_overhead_ms = gaps[gaps.size() / 2];
     }
     ctx->profile = enable != 0;
     ctx->prof_every = enable > 1 ? enable : 1;
@@ -643,27 +668,30 @@ int dl_profile_read(dl_ctx* ctx, double* ms, int32_t n) {
     if (!ctx || !ms || n < 4) return dl_fail(ctx, "dl_profile_read: need room for 4 values");
     if (ctx->ev.empty() || ctx->prof_calls == 0) return dl_fail(ctx, "dl_profile_read: no profiled call recorded");
     int64_t ncalls = std::min<int64_t>(ctx->prof_calls, dl_ctx::NPOOL);
-    // MEDIAN over the sampled calls: a record that lands on a busy command processor stretches one interval by microseconds, and with a handful of samples
-    // the mean follows it
+    // MEDIAN over the sampled calls.  The intervals are the dispatch packets' own start / stop timestamps (hipExtLaunchKernelGGL): kernel durations as
+    // rocprofv3 --kernel-trace reports them; [3] = start of the first kernel to the stop of the last one.  A phase without a launch reports 0.
     std::vector<double> samples[4];
     for (int64_t c = 0; c < ncalls; ++c) {
-        hipEvent_t* ev = &ctx->ev[(size_t)c * 4];
-        DL_HIP_CHECK(ctx, hipEventSynchronize(ev[3]));
-        float t01 = 0, t12 = 0, t23 = 0, t03 = 0;
-        DL_HIP_CHECK(ctx, hipEventElapsedTime(&t01, ev[0], ev[1]));
-        DL_HIP_CHECK(ctx, hipEventElapsedTime(&t12, ev[1], ev[2]));
-        DL_HIP_CHECK(ctx, hipEventElapsedTime(&t23, ev[2], ev[3]));
-        DL_HIP_CHECK(ctx, hipEventElapsedTime(&t03, ev[0], ev[3]));
-        double oh = ctx->ev_overhead_ms;
-        samples[0].push_back(std::max(0., t01 - oh)); samples[1].push_back(std::max(0., t12 - oh)); samples[2].push_back(std::max(0., t23 - oh));
-        samples[3].push_back(std::max(0., t03 - oh));
+        hipEvent_t* ev = &ctx->ev[(size_t)c * 6];
+        (void)hipEventSynchronize(ev[5]);
+        int first = -1;
+        for (int k = 0; k < 3; ++k) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, ev[2 * k], ev[2 * k + 1]) != hipSuccess) { (void)hipGetLastError(); t = 0; }
+            else if (first < 0) first = k;
+            samples[k].push_back(t);
+        }
+        float t = 0;
+        if (first < 0 || hipEventElapsedTime(&t, ev[2 * first], ev[5]) != hipSuccess) { (void)hipGetLastError(); t = 0; }
+        samples[3].push_back(t);
     }
     for (int i = 0; i < 4; ++i) {
         std::sort(samples[i].begin(), samples[i].end());
         const size_t m = samples[i].size();
         ms[i] = (m & 1) ? samples[i][m / 2] : 0.5 * (samples[i][m / 2 - 1] + samples[i][m / 2]);
     }
-    if (n >= 5) ms[4] = ctx->ev_overhead_ms;
+    if (n >= 5) ms[4] = 0.;   // (no event-record overhead to subtract any more)
+    if (n >= 6) ms[5] = (double)ncalls;
     return 0;
 }
 

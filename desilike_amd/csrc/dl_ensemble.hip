@@ -1,0 +1,299 @@
+// dl_ensemble.hip -- device-resident affine-invariant ensemble sampler (include/desilike_amd.h, dl_ensemble_*).
+//
+// What the reference does on the host per ensemble update (desilike/samplers/emcee.py:69-111 -> emcee.EnsembleSampler(vectorize=True) with its default
+// StretchMove: Goodman & Weare 2010, two half-ensemble updates; the log-posterior of a half is ONE batched call, desilike/samplers/base.py:144-200) runs here as one
+// enqueued sequence per half-step with no host synchronisation:
+//
+//     [accept previous half | permutation | stretch proposals]  ->  dl_eval_logposterior (this rank's share)  ->  ncclAllGather (N > 1)  ->  next ...
+//
+// Walker positions, log-posteriors, acceptance counts and the random number generator live on the device; the host only enqueues and, at the end of a run,
+// drains the chain.  Random numbers are COUNTER-BASED (Philox4x32-10, Salmon et al. 2011): the draw for (iteration, half-step, walker slot) is a pure
+// function of the seed, so every rank of a sharded run holds the same ensemble without exchanging anything but log-posteriors, and the NumPy
+// ``EnsembleStretchMove`` of the host package reproduces the chain bit for bit with the same generator (tests/test_gpu_sampler.py).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/desilike_amd.h"
+#include "dl_kernels.h"
+
+namespace {
+
+int fail(const std::string& msg) {
+    dl_set_last_error(msg.c_str());
+    return 1;
+}
+
+#define DL_ENS_HIP(call)                                                                              \
+    do {                                                                                              \
+        hipError_t err__ = (call);                                                                    \
+        if (err__ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(err__));   \
+    } while (0)
+
+struct DlPhilox {
+    uint32_t x[4];
+};
+
+// Philox4x32-10 (Random123): counter c[4], key k[2]
+__host__ __device__ inline DlPhilox dl_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return DlPhilox{{c0, c1, c2, c3}};
+}
+
+// 53-bit uniform on [0, 1) from two 32-bit words (the construction of numpy's random_sample)
+__host__ __device__ inline double dl_uniform53(uint32_t hi, uint32_t lo) { return ((double)(hi >> 5) * 67108864. + (double)(lo >> 6)) * (1. / 9007199254740992.); }
+
+enum { DL_ENS_STREAM_PERM = 0, DL_ENS_STREAM_MOVE = 1, DL_ENS_STREAM_ACCEPT = 3 };   // + half-step for the last two
+
+struct DlEnsArgs {
+    double* coords;        // [nw, P]
+    double* logp;          // [nw]
+    long long* nacc;       // [nw]
+    int32_t* perm;         // [nw]: first half = walkers updated in half-step 0, second half = half-step 1
+    double* prop;          // [half_pad, P] proposals of the pending half-step
+    double* factors;       // [half] (P - 1) log z
+    double* newlp;         // [half_pad] log-posteriors of the proposals (all ranks' shares after the all-gather)
+    double* chain;         // record target of this launch: [nw, P] or null
+    double* chain_logp;    // [nw] or null
+    int32_t nw, P;
+    double a, offset;
+    uint32_t k0, k1;
+    long long it_acc, it_prop;   // iteration of the half-step to accept / to propose
+    int32_t half_acc, half_prop; // 0 / 1, or -1: nothing to accept / propose
+};
+
+// One workgroup: the ensemble is a few hundred walkers x <= 64 parameters.  Phases separated by barriers (global memory written before a barrier is visible
+// to the workgroup after it).
+__global__ __launch_bounds__(256) void dl_ensemble_step_kernel(const DlEnsArgs s) {
+#pragma clang fp contract(off)   // the NumPy driver rounds after every operation: no fused multiply-adds here
+    extern __shared__ unsigned long long keys[];   // [nw] sort keys of the permutation
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int half = s.nw / 2, P = s.P;
+    const double inf = __builtin_huge_val();
+    if (s.half_acc >= 0) {
+        // accept / reject the pending proposals (emcee moves/red_blue.py: lnpdiff = factors + new_log_prob - log_prob; accepted = log(u) < lnpdiff)
+        const int32_t* set = s.perm + s.half_acc * half;
+        for (int j = tid; j < half; j += nthr) {
+            const int i = set[j];
+            const DlPhilox r = dl_philox4x32((uint32_t)s.it_acc, (uint32_t)((unsigned long long)s.it_acc >> 32), (uint32_t)j, DL_ENS_STREAM_ACCEPT + s.half_acc, s.k0, s.k1);
+            const double u = dl_uniform53(r.x[0], r.x[1]);
+            double lp = s.newlp[j];
+            if (lp != lp) lp = -inf;                     // NaN results count as -inf (samplers/base.py:187-189)
+            lp = lp + s.offset;
+            const double lnpdiff = (s.factors[j] + lp) - s.logp[i];
+            const bool accepted = log(u) < lnpdiff;
+            if (accepted) {
+                for (int p = 0; p < P; ++p) s.coords[(size_t)i * P + p] = s.prop[(size_t)j * P + p];
+                s.logp[i] = lp;
+                s.nacc[i] += 1;
+            }
+        }
+        __syncthreads();
+    }
+    if (s.chain != nullptr) {
+        for (int e = tid; e < s.nw * P; e += nthr) s.chain[e] = s.coords[e];
+        if (s.chain_logp != nullptr)
+            for (int e = tid; e < s.nw; e += nthr) s.chain_logp[e] = s.logp[e];
+    }
+    if (s.half_prop < 0) return;
+    if (s.half_prop == 0) {
+        // random split of the ensemble into two halves: walkers ranked by a 64-bit key each (ties by index) -- numpy: argsort(keys, kind='stable')
+        for (int i = tid; i < s.nw; i += nthr) {
+            const DlPhilox r = dl_philox4x32((uint32_t)s.it_prop, (uint32_t)((unsigned long long)s.it_prop >> 32), (uint32_t)i, DL_ENS_STREAM_PERM, s.k0, s.k1);
+            keys[i] = ((unsigned long long)r.x[0] << 32) | r.x[1];
+        }
+        __syncthreads();
+        for (int i = tid; i < s.nw; i += nthr) {
+            const unsigned long long ki = keys[i];
+            int rank = 0;
+            for (int j = 0; j < s.nw; ++j) { const unsigned long long kj = keys[j]; rank += (kj < ki) || (kj == ki && j < i); }
+            s.perm[rank] = i;
+        }
+        __syncthreads();
+    }
+    {
+        // stretch move (emcee moves/stretch.py): z ~ g(z) on [1/a, a], partner drawn from the complementary half, q = c - (c - s) z
+        const int32_t* set = s.perm + s.half_prop * half;
+        const int32_t* comp = s.perm + (1 - s.half_prop) * half;
+        for (int j = tid; j < half; j += nthr) {
+            const DlPhilox r = dl_philox4x32((uint32_t)s.it_prop, (uint32_t)((unsigned long long)s.it_prop >> 32), (uint32_t)j, DL_ENS_STREAM_MOVE + s.half_prop, s.k0, s.k1);
+            const double u = dl_uniform53(r.x[0], r.x[1]);
+            const double t = (s.a - 1.) * u + 1.;
+            const double zz = (t * t) / s.a;
+            const int ic = comp[r.x[2] % (uint32_t)half], is = set[j];
+            for (int p = 0; p < P; ++p) {
+                const double c = s.coords[(size_t)ic * P + p], x = s.coords[(size_t)is * P + p];
+                s.prop[(size_t)j * P + p] = c - (c - x) * zz;
+            }
+            s.factors[j] = (P - 1.) * log(zz);
+        }
+    }
+}
+
+}  // namespace
+
+struct dl_ensemble {
+    dl_ctx* ctx = nullptr;
+    dl_comm* comm = nullptr;
+    int device = 0, nw = 0, P = 0, rank = 0, world = 1;
+    int64_t count = 0;            // proposals per rank and half-step (the last ranks' shares may be shorter or empty)
+    double a = 2., offset = 0.;
+    uint64_t seed = 0;
+    long long iteration = 0;      // ensemble updates done since creation (the counter of the random number generator)
+    bool have_logp = false;
+    double *coords = nullptr, *logp = nullptr, *prop = nullptr, *factors = nullptr, *newlp = nullptr;
+    long long* nacc = nullptr;
+    int32_t* perm = nullptr;
+};
+
+extern "C" {
+
+void dl_ensemble_destroy(dl_ensemble* ens) {
+    if (!ens) return;
+    (void)hipSetDevice(ens->device);
+    for (void* p : {(void*)ens->coords, (void*)ens->logp, (void*)ens->prop, (void*)ens->factors, (void*)ens->newlp, (void*)ens->nacc, (void*)ens->perm})
+        if (p) (void)hipFree(p);
+    delete ens;
+}
+
+int dl_ensemble_create(dl_ensemble** out, dl_ctx* ctx, int32_t nwalkers, double a, uint64_t seed, double offset, dl_comm* comm) {
+    if (!out || !ctx) return fail("dl_ensemble_create: null argument");
+    *out = nullptr;
+    const int P = (int)dl_info(ctx, "n_params");
+    if (nwalkers < 2 || nwalkers % 2 || nwalkers > 8192) return fail("dl_ensemble_create: nwalkers must be even, in [2, 8192]");
+    if (!(a > 1.)) return fail("dl_ensemble_create: stretch parameter a must be > 1");
+    dl_ensemble* ens = new dl_ensemble();
+    ens->ctx = ctx; ens->comm = comm; ens->nw = nwalkers; ens->P = P; ens->a = a; ens->seed = seed; ens->offset = offset;
+    ens->device = (int)dl_info(ctx, "device");
+    if (comm) {
+        ens->rank = (int)dl_comm_info(comm, "rank"); ens->world = (int)dl_comm_info(comm, "world");
+        if ((int)dl_comm_info(comm, "device") != ens->device) { delete ens; return fail("dl_ensemble_create: communicator and context live on different devices"); }
+    }
+    const int half = nwalkers / 2;
+    ens->count = (half + ens->world - 1) / ens->world;
+    const size_t half_pad = (size_t)ens->count * ens->world;
+    auto bail = [&](const std::string& msg) { dl_ensemble_destroy(ens); return fail(msg); };
+    if (hipSetDevice(ens->device) != hipSuccess) return bail("dl_ensemble_create: hipSetDevice failed");
+    if (hipMalloc((void**)&ens->coords, (size_t)nwalkers * P * sizeof(double)) != hipSuccess || hipMalloc((void**)&ens->logp, (size_t)nwalkers * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&ens->prop, half_pad * P * sizeof(double)) != hipSuccess || hipMalloc((void**)&ens->factors, half_pad * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&ens->newlp, half_pad * sizeof(double)) != hipSuccess || hipMalloc((void**)&ens->nacc, (size_t)nwalkers * sizeof(long long)) != hipSuccess ||
+        hipMalloc((void**)&ens->perm, (size_t)nwalkers * sizeof(int32_t)) != hipSuccess)
+        return bail("dl_ensemble_create: device allocation failed");
+    if (hipMemset(ens->nacc, 0, (size_t)nwalkers * sizeof(long long)) != hipSuccess || hipMemset(ens->prop, 0, half_pad * P * sizeof(double)) != hipSuccess ||
+        hipMemset(ens->newlp, 0, half_pad * sizeof(double)) != hipSuccess)
+        return bail("dl_ensemble_create: hipMemset failed");
+    *out = ens;
+    return 0;
+}
+
+// Evaluate this rank's share of ``n`` rows of ``theta_dev`` into ``out_dev[n_pad]`` and all-gather (count rows per rank)
+static int dl_ens_logposterior(dl_ensemble* ens, const double* theta_dev, int n, double* out_dev, hipStream_t stream) {
+    const int64_t lo = std::min<int64_t>((int64_t)ens->rank * ens->count, n), hi = std::min<int64_t>(lo + ens->count, n);
+    if (hi > lo && dl_eval_logposterior(ens->ctx, theta_dev + (size_t)lo * ens->P, hi - lo, out_dev + lo, nullptr, stream)) return 1;
+    if (ens->comm && ens->world > 1)
+        return dl_comm_allgather_f64(ens->comm, out_dev + (size_t)ens->rank * ens->count, out_dev, ens->count, stream);
+    return 0;
+}
+
+int dl_ensemble_set_state(dl_ensemble* ens, const double* coords, const double* logposterior, void* hip_stream) {
+    if (!ens || !coords) return fail("dl_ensemble_set_state: null argument");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DL_ENS_HIP(hipSetDevice(ens->device));
+    DL_ENS_HIP(hipMemcpyAsync(ens->coords, coords, (size_t)ens->nw * ens->P * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (logposterior) DL_ENS_HIP(hipMemcpyAsync(ens->logp, logposterior, (size_t)ens->nw * sizeof(double), hipMemcpyHostToDevice, stream));
+    DL_ENS_HIP(hipStreamSynchronize(stream));   // the host buffers may be pageable
+    ens->have_logp = logposterior != nullptr;
+    return 0;
+}
+
+int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, double* chain_dev, double* chain_logp_dev, void* hip_stream) {
+    if (!ens) return fail("dl_ensemble_run: null ensemble");
+    if (niterations < 0 || thin_by < 1) return fail("dl_ensemble_run: invalid argument");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DL_ENS_HIP(hipSetDevice(ens->device));
+    const int nw = ens->nw, P = ens->P, half = nw / 2;
+    if (!ens->have_logp) {
+        // log-posterior of the starting positions: two half-ensemble batches through the same sharded path
+        for (int h = 0; h < 2; ++h) {
+            if (dl_ens_logposterior(ens, ens->coords + (size_t)h * half * P, half, ens->newlp, stream)) return 1;
+            DL_ENS_HIP(hipMemcpyAsync(ens->logp + (size_t)h * half, ens->newlp, (size_t)half * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
+        if (ens->offset != 0.) {
+            // rare path (marginalised posteriors with a constant): add the offset on the host
+            std::vector<double> tmp(nw);
+            DL_ENS_HIP(hipMemcpyAsync(tmp.data(), ens->logp, (size_t)nw * sizeof(double), hipMemcpyDeviceToHost, stream));
+            DL_ENS_HIP(hipStreamSynchronize(stream));
+            for (double& v : tmp) v = (v != v ? -__builtin_huge_val() : v) + ens->offset;
+            DL_ENS_HIP(hipMemcpyAsync(ens->logp, tmp.data(), (size_t)nw * sizeof(double), hipMemcpyHostToDevice, stream));
+            DL_ENS_HIP(hipStreamSynchronize(stream));
+        }
+        ens->have_logp = true;
+    }
+    if (niterations == 0) return 0;
+    DlEnsArgs s;
+    std::memset(&s, 0, sizeof(s));
+    s.coords = ens->coords; s.logp = ens->logp; s.nacc = ens->nacc; s.perm = ens->perm; s.prop = ens->prop; s.factors = ens->factors; s.newlp = ens->newlp;
+    s.nw = nw; s.P = P; s.a = ens->a; s.offset = ens->offset;
+    s.k0 = (uint32_t)ens->seed; s.k1 = (uint32_t)(ens->seed >> 32);
+    const size_t shm = (size_t)nw * sizeof(unsigned long long);
+    s.half_acc = -1;
+    const long long it0 = ens->iteration;
+    // the launch that proposes half-step (it, h) also accepts the half-step before it; the accept of half-step 1 completes an iteration: recorded there
+    auto set_record = [&]() {
+        s.chain = nullptr; s.chain_logp = nullptr;
+        if (s.half_acc != 1 || !chain_dev) return;
+        const long long done = s.it_acc - it0 + 1;
+        if (done % thin_by) return;
+        const size_t row = (size_t)(done / thin_by - 1);
+        s.chain = chain_dev + row * nw * P;
+        s.chain_logp = chain_logp_dev ? chain_logp_dev + row * nw : nullptr;
+    };
+    for (long long it = it0; it < it0 + niterations; ++it)
+        for (int h = 0; h < 2; ++h) {
+            s.it_prop = it; s.half_prop = h;
+            set_record();
+            hipLaunchKernelGGL(dl_ensemble_step_kernel, dim3(1), dim3(256), shm, stream, s);
+            if (dl_ens_logposterior(ens, ens->prop, half, ens->newlp, stream)) return 1;
+            s.it_acc = it; s.half_acc = h;
+        }
+    s.half_prop = -1;
+    set_record();
+    hipLaunchKernelGGL(dl_ensemble_step_kernel, dim3(1), dim3(256), shm, stream, s);
+    DL_ENS_HIP(hipGetLastError());
+    ens->iteration += niterations;
+    return 0;
+}
+
+int dl_ensemble_get_state(dl_ensemble* ens, double* coords, double* logposterior, int64_t* naccepted, void* hip_stream) {
+    if (!ens) return fail("dl_ensemble_get_state: null ensemble");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DL_ENS_HIP(hipSetDevice(ens->device));
+    if (coords) DL_ENS_HIP(hipMemcpyAsync(coords, ens->coords, (size_t)ens->nw * ens->P * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (logposterior) DL_ENS_HIP(hipMemcpyAsync(logposterior, ens->logp, (size_t)ens->nw * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (naccepted) DL_ENS_HIP(hipMemcpyAsync(naccepted, ens->nacc, (size_t)ens->nw * sizeof(long long), hipMemcpyDeviceToHost, stream));
+    DL_ENS_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int64_t dl_ensemble_info(const dl_ensemble* ens, const char* key) {
+    if (!ens || !key) return -1;
+    std::string k(key);
+    if (k == "nwalkers") return ens->nw;
+    if (k == "n_params") return ens->P;
+    if (k == "iteration") return ens->iteration;
+    if (k == "rank") return ens->rank;
+    if (k == "world") return ens->world;
+    if (k == "rows_per_rank") return ens->count;
+    return -1;
+}
+
+}  // extern "C"

@@ -303,7 +303,10 @@ inline bool dl_build_emulated_obs(const dl_config& cfg, const std::string& p, in
     for (int c = 0; c < DL_MAX_PASS; ++c) oh.marg_pass[c] = (c < (int)mpass.size()) ? mpass[c] : -1;
     {
         std::vector<double> pass_tab(std::max<size_t>(pin.size(), 2), 0.);
-        for (int c = 0; c < d.n_pass; ++c) { pass_tab[2 * c] = (double)std::lround(pin[2 * c]); pass_tab[2 * c + 1] = pin[2 * c + 1]; }
+        for (int c = 0; c < d.n_pass; ++c) {
+            pass_tab[2 * c] = (double)std::lround(pin[2 * c]); pass_tab[2 * c + 1] = pin[2 * c + 1];
+            if ((int)pass_tab[2 * c] >= n_params) { err = p + "in.pass: theta column out of range"; return false; }
+        }
         oh.off_pass = arena.push(pass_tab);
     }
     for (int c = 0; c < DL_MAX_EFT; ++c) { oh.marg_sn[c] = -1; oh.marg_ct[c][0] = oh.marg_ct[c][1] = -1; d.marg_ct_slot[c][0] = d.marg_ct_slot[c][1] = -1; }
@@ -493,10 +496,12 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         for (int t = 0; t < 2; ++t) {
             d.ct_in[c][t].col = (int32_t)std::lround(ctin[(c * 2 + t) * 2]);
             d.ct_in[c][t].value = ctin[(c * 2 + t) * 2 + 1];
+            if (d.ct_in[c][t].col >= n_params) { err = p + "in.ct: theta column out of range"; return false; }
         }
     for (int c = 0; c < d.n_sn; ++c) {
         d.sn_in[c].col = (int32_t)std::lround(snin[c * 2]);
         d.sn_in[c].value = snin[c * 2 + 1];
+        if (d.sn_in[c].col >= n_params) { err = p + "in.sn: theta column out of range"; return false; }
     }
     {
         const auto& msn0 = cfg.I(p + "marg.sn0");

@@ -1,9 +1,21 @@
 // dl_kernels.h -- launchers of the gfx950 kernels (definitions in dl_kernels.hip)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "dl_fullshape.h"
+
+// Kernel-interval measurement (dl_profile_*): when dl_eval_* sets these events around a launcher, the kernel is launched with hipExtLaunchKernelGGL, which
+// attaches them to the dispatch packet itself -- start / stop are the packet's own timestamps (what rocprofv3 --kernel-trace reads), no barrier packets
+// are inserted between the kernels (an hipEventRecord between two launches costs 3.5-4.6 us of stream time).
+struct DlProfEvents { hipEvent_t start = nullptr, stop = nullptr; };
+extern thread_local DlProfEvents dl_prof_events;
+#define DL_LAUNCH(kernel, grid, block, shm, stream, ...)                                                                                       \
+    do {                                                                                                                                       \
+        if (dl_prof_events.start) hipExtLaunchKernelGGL(kernel, grid, block, shm, stream, dl_prof_events.start, dl_prof_events.stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);                                                                \
+    } while (0)
 
 #define DL_ST_OK 0
 #define DL_ST_OUT_OF_PRIOR 1

@@ -16,6 +16,8 @@
 #include "dl_kernels.h"
 #include "dl_emu_batch.h"
 
+thread_local DlProfEvents dl_prof_events;
+
 // ------------------------------------------------------------------------------------------------
 // theory kernel
 // ------------------------------------------------------------------------------------------------
@@ -164,19 +166,19 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
         if (obs_host[i].theory == 3 && feat != nullptr && !getenv("DL_NO_EMU_BATCH")) {   // feature path: 16 points per workgroup, MLP layers by MFMA
             size_t shm = dl_eb_shared_doubles(obs_host[i]) * sizeof(double);
             if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_emulated_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            hipLaunchKernelGGL(dl_emulated_batch_kernel, dim3((unsigned)((B + DL_EB_PTS - 1) / DL_EB_PTS)), dim3(256), shm, stream, obs_host[i], theta, n_params, B, feat, feat_ld);
+            DL_LAUNCH(dl_emulated_batch_kernel, dim3((unsigned)((B + DL_EB_PTS - 1) / DL_EB_PTS)), dim3(256), shm, stream, obs_host[i], theta, n_params, B, feat, feat_ld);
             continue;
         }
         if (obs_host[i].theory == 3) {   // DL_THEORY_EMULATED
             size_t shm = dl_emu_shared_doubles(obs_host[i].n_var) * sizeof(double);
-            hipLaunchKernelGGL(dl_emulated_kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power, feat, feat_ld);
+            DL_LAUNCH(dl_emulated_kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power, feat, feat_ld);
             continue;
         }
         if (obs_host[i].theory == 2) {   // DL_THEORY_BAO_DAMPED
             size_t shm = dl_bao_shared_doubles(obs_host[i].n_in) * sizeof(double);
             auto launch_bao = [&](auto kernel) {
                 if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-                hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power);
+                DL_LAUNCH(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power);
             };
             const int model = obs_host[i].bao_mode >> 4;
             if (model == 0) launch_bao(dl_bao_kernel<0>);
@@ -191,7 +193,7 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
         auto launch = [&](auto kernel) {
             if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  // e.g. 2000-knot BAO tables
             const int flags = (xcd_block > 0 && stop_after == 0 && B % (8 * xcd_block) == 0) ? (xcd_block << 8) : stop_after;
-            hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shmem, stream, obs_host[i], theta, n_params, power, ld_power, tables, ld_tables, flags, stamps);
+            DL_LAUNCH(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shmem, stream, obs_host[i], theta, n_params, power, ld_power, tables, ld_tables, flags, stamps);
             if (stamps) {
                 (void)hipStreamSynchronize(stream);
                 std::vector<unsigned long long> h((size_t)B * 8);
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(64 * DL_GEMM_WAVES) void dl_window_gemm_kernel(cons
 void dl_launch_window_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* C, int64_t ldc, int64_t M, int N_valid, int N_pad,
                            int K_pad, int bias_period, hipStream_t stream) {
     dim3 grid((unsigned)((M + 15) / 16), (unsigned)(N_pad / 32));
-    hipLaunchKernelGGL(dl_window_gemm_kernel, grid, dim3(64 * DL_GEMM_WAVES), 0, stream, A, lda, Wt, ldw, bias, C, ldc, (int)M, N_valid, K_pad, bias_period);
+    DL_LAUNCH(dl_window_gemm_kernel, grid, dim3(64 * DL_GEMM_WAVES), 0, stream, A, lda, Wt, ldw, bias, C, ldc, (int)M, N_valid, K_pad, bias_period);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -356,14 +358,14 @@ void dl_launch_window_gemm_tiled(const double* A, int64_t lda, const double* Wt,
             (void)hipFuncSetAttribute((const void*)dl_window_gemm_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_GD_LDS_BYTES);
             optin_dma = true;
         }
-        hipLaunchKernelGGL(dl_window_gemm_dma_kernel<false>, grid, dim3(64 * DL_GD_WAVES), DL_GD_LDS_BYTES, stream, A, lda, Wt, ldw, slabs, slab_stride, ldc, (int)M,
+        DL_LAUNCH(dl_window_gemm_dma_kernel<false>, grid, dim3(64 * DL_GD_WAVES), DL_GD_LDS_BYTES, stream, A, lda, Wt, ldw, slabs, slab_stride, ldc, (int)M,
                            chunks_per_split / 2, K_pad / DL_GD_KP, nullptr);
         return;
     }
     dim3 grid((unsigned)((M + DL_GT_M - 1) / DL_GT_M), (unsigned)(N_pad / DL_GT_N), (unsigned)n_splits);
     static bool optin = false;
     if (!optin) { (void)hipFuncSetAttribute((const void*)dl_window_gemm_tiled_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_GT_LDS_BYTES); optin = true; }
-    hipLaunchKernelGGL((dl_window_gemm_tiled_kernel<true, true, true>), grid, dim3(512), DL_GT_LDS_BYTES, stream, A, lda, Wt, ldw, slabs, slab_stride, ldc, (int)M, chunks_per_split, K_pad / DL_GT_K);
+    DL_LAUNCH((dl_window_gemm_tiled_kernel<true, true, true>), grid, dim3(512), DL_GT_LDS_BYTES, stream, A, lda, Wt, ldw, slabs, slab_stride, ldc, (int)M, chunks_per_split, K_pad / DL_GT_K);
 }
 
 // split-K GEMM (single split) with the partial-chi2 epilogue: part[M, dl_gemm_dma_chi2_parts(N_pad)]
@@ -372,7 +374,7 @@ void dl_launch_window_gemm_dma_chi2(const double* A, int64_t lda, const double* 
     dim3 grid((unsigned)((M + DL_GD_M - 1) / DL_GD_M), (unsigned)(N_pad / DL_GD_N), 1);
     static bool optin = false;
     if (!optin) { (void)hipFuncSetAttribute((const void*)dl_window_gemm_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_GD_LDS_BYTES); optin = true; }
-    hipLaunchKernelGGL(dl_window_gemm_dma_kernel<true>, grid, dim3(64 * DL_GD_WAVES), DL_GD_LDS_BYTES, stream, A, lda, Wt, ldw, part, (int64_t)0, (int64_t)0, (int)M, K_pad / DL_GD_KP,
+    DL_LAUNCH(dl_window_gemm_dma_kernel<true>, grid, dim3(64 * DL_GD_WAVES), DL_GD_LDS_BYTES, stream, A, lda, Wt, ldw, part, (int64_t)0, (int64_t)0, (int)M, K_pad / DL_GD_KP,
                        K_pad / DL_GD_KP, bias);
 }
 
@@ -392,7 +394,7 @@ __global__ void dl_transform_kernel(double* __restrict__ flat, int64_t ld, const
 
 void dl_launch_transform(double* flat, int64_t ld, const double* data, const int32_t* transform, int n, int64_t B, hipStream_t stream) {
     int64_t total = B * n;
-    hipLaunchKernelGGL(dl_transform_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, flat, ld, data, transform, n, B);
+    DL_LAUNCH(dl_transform_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, flat, ld, data, transform, n, B);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256) void dl_finalize_kernel(const double* __restri
 
 void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, int64_t slab_stride, const double* bias, const double* theta, int n_params,
                         const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream) {
-    hipLaunchKernelGGL(dl_finalize_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, n_slabs, slab_stride, bias, theta, n_params, priors, B, loglike,
+    DL_LAUNCH(dl_finalize_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, dtilde, ld, n, n_slabs, slab_stride, bias, theta, n_params, priors, B, loglike,
                        logprior, status, post_mode);
 }
 
@@ -480,7 +482,7 @@ void dl_launch_feature_gemm(const double* feat, int64_t feat_ld, int64_t feat_of
     const int rec_len = nb_pad + R * DL_FG_MONO_LD;
     const size_t shm = (size_t)DL_FG_PTS * dl_fg_lds_stride(rec_len) * sizeof(double);
     if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_feature_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(dl_feature_gemm_kernel, dim3((unsigned)((B + DL_FG_PTS - 1) / DL_FG_PTS), (unsigned)(N_pad / 128)), dim3(512), shm, stream, feat, feat_ld, feat_off, nb_pad, R,
+    DL_LAUNCH(dl_feature_gemm_kernel, dim3((unsigned)((B + DL_FG_PTS - 1) / DL_FG_PTS), (unsigned)(N_pad / 128)), dim3(512), shm, stream, feat, feat_ld, feat_off, nb_pad, R,
                        gfrag, out, ldo, B, accumulate);
 }
 
@@ -489,7 +491,7 @@ void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_
                                 hipStream_t stream) {
     const size_t shm = dl_ef_shared_doubles(obs) * sizeof(double);
     if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_emulated_feature_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(dl_emulated_feature_kernel, dim3((unsigned)((B + DL_EB_PTS - 1) / DL_EB_PTS), (unsigned)(N_pad / 128)), dim3(512), shm, stream, obs, theta, n_params, B, gfrag,
+    DL_LAUNCH(dl_emulated_feature_kernel, dim3((unsigned)((B + DL_EB_PTS - 1) / DL_EB_PTS), (unsigned)(N_pad / 128)), dim3(512), shm, stream, obs, theta, n_params, B, gfrag,
                        out, ldo, accumulate);
 }
 
@@ -513,7 +515,7 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
     if (stamp_file && !stamps_dev) (void)hipMalloc((void**)&stamps_dev, (size_t)65536 * 8 * sizeof(unsigned long long));
     fin.stamps = (stamp_file && grid <= 65536 && M >= 256 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
     if (stamp_file && M >= 256) stamp_launches++;
-    hipLaunchKernelGGL((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin);
+    DL_LAUNCH((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin);
     if (fin.stamps) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h((size_t)grid * 8);
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(256) void dl_finalize_part_kernel(const double* __r
 
 void dl_launch_finalize_part(const double* part, int n_tiles, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
                              int32_t* status, int post_mode, hipStream_t stream) {
-    hipLaunchKernelGGL(dl_finalize_part_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, part, n_tiles, theta, n_params, priors, B, loglike, logprior, status, post_mode);
+    DL_LAUNCH(dl_finalize_part_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, part, n_tiles, theta, n_params, priors, B, loglike, logprior, status, post_mode);
 }
 
 // ---- lane-parallel dense algebra for the <= 15 x 15 systems of the marginalised finalize: lane i owns row i in registers, rows are exchanged with
@@ -968,13 +970,13 @@ void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_p
     const size_t shm = 4 * region * sizeof(double);   // staged rows of the four waves (reused for G and the Cholesky rows)
     if (mg.n_s < 16 && allow_staged && shm <= 96 * 1024) {
         if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_finalize_marg_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        hipLaunchKernelGGL((dl_finalize_marg_kernel<true, true>), dim3(grid), dim3(256), shm, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
+        DL_LAUNCH((dl_finalize_marg_kernel<true, true>), dim3(grid), dim3(256), shm, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
                            n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps);
     } else if (mg.n_s < 16)
-        hipLaunchKernelGGL((dl_finalize_marg_kernel<true, false>), dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
+        DL_LAUNCH((dl_finalize_marg_kernel<true, false>), dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
                            n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps);
     else
-        hipLaunchKernelGGL((dl_finalize_marg_kernel<false, false>), dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
+        DL_LAUNCH((dl_finalize_marg_kernel<false, false>), dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
                            n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps);
     if (stamps) {
         (void)hipStreamSynchronize(stream);

@@ -55,11 +55,25 @@ class SyntheticFiducial(object):
         return self._pk(k, 0.)
 
 
+class FiducialWarning(UserWarning):
+    """The synthetic stand-in cosmology was used where the reference would have used a real one."""
+
+
 def get_fiducial(fiducial):
-    if fiducial is None or (isinstance(fiducial, str) and fiducial.lower() in ('synthetic', 'desi')):
-        # 'DESI' is the reference's default (a cosmoprimo.fiducial entry): not available without cosmoprimo,
-        # so the synthetic analytic cosmology stands in; pass a TabulatedFiducial for a real analysis.
+    """``TabulatedFiducial`` / ``SyntheticFiducial`` instance, dict of ``TabulatedFiducial`` arguments, or 'synthetic' (explicit opt-in: benchmarks, fixtures).
+    The reference's default 'DESI' (a ``cosmoprimo.fiducial`` entry, power_template.py:49-66) cannot be honoured without cosmoprimo: the synthetic
+    analytic cosmology stands in WITH A WARNING -- its P(k), growth rate and sound horizon are not DESI's; pass tables exported from a Boltzmann code
+    for a real analysis."""
+    if isinstance(fiducial, str) and fiducial.lower() == 'synthetic':
         return SyntheticFiducial()
+    if fiducial is None or (isinstance(fiducial, str) and fiducial.lower() == 'desi'):
+        import warnings
+        warnings.warn("fiducial={!r}: no Boltzmann code on this path, the SYNTHETIC analytic cosmology (BBKS-like P(k), f = 0.8, r_d = 100 Mpc/h) stands in; pass "
+                      "fiducial=TabulatedFiducial(k, pk_dd, f, pknow_dd=..., rs_drag=...) (or a dict of these) for real data, or fiducial='synthetic' to "
+                      "silence this warning".format(fiducial), FiducialWarning, stacklevel=3)
+        return SyntheticFiducial()
+    if isinstance(fiducial, str):
+        raise ValueError('unknown fiducial {!r}'.format(fiducial))
     if isinstance(fiducial, dict):
         return TabulatedFiducial(**fiducial)
     return fiducial

@@ -6,6 +6,7 @@ from ...base import BaseCalculator
 from ... import utils
 from ...utils import window_matrix_bininteg
 from .window import SystematicTemplatePowerSpectrumMultipoles, _append_systematic_templates
+from ._binning import MultipoleBins
 
 
 class SystematicTemplateCorrelationFunctionMultipoles(SystematicTemplatePowerSpectrumMultipoles):
@@ -24,57 +25,11 @@ class WindowedCorrelationFunctionMultipoles(BaseCalculator):
         if self._initialized:
             return self
         init = self.init
-        _default_step = 5.
-        slim, s, sedges, ells = init.get('slim', None), init.get('s', None), init.get('sedges', None), init.get('ells', None)
         wmatrix, sin, ellsin = init.get('wmatrix', None), init.get('sin', None), init.get('ellsin', None)
-        if ells is None:
-            ells = list(slim) if slim is not None else (0, 2, 4)
-        self.ells = tuple(ells)
-        self.s = self.sedges = None
-        if s is not None:
-            if np.ndim(s[0]) == 0: s = [s] * len(self.ells)
-            self.s = [np.array(ss, dtype='f8') for ss in s]
-        if sedges is not None:
-            if np.ndim(sedges[0]) == 0: sedges = [sedges] * len(self.ells)
-            self.sedges = [np.array(ss, dtype='f8') for ss in sedges]
-            self.sedges = [np.column_stack([edges[:-1], edges[1:]]) if edges.ndim <= 1 else edges for edges in self.sedges]
-            if slim is None:
-                slim = {ell: (edges[0, 0], edges[-1, 1], np.mean(edges[..., 1] - edges[..., 0])) for ell, edges in zip(self.ells, self.sedges)}
-        if slim is not None:   # window.py:596-626
-            slim = dict(slim)
-            if self.s is not None:
-                snew, ellsnew = [], []
-                for ill, ell in enumerate(self.ells):
-                    if ell not in slim: continue
-                    ss = self.s[ill]
-                    if slim[ell] is not None:
-                        lo, hi, *step = slim[ell]
-                        ss = ss[(ss >= lo) & (ss <= hi)]
-                    if ss.size:
-                        snew.append(ss); ellsnew.append(ell)
-                self.s, self.ells = snew, tuple(ellsnew)
-            elif list(self.ells) != list(slim):
-                raise ValueError('incompatible ells = {} and slim = {}'.format(self.ells, list(slim)))
-            if self.sedges is None and all(slim[ell] is not None for ell in self.ells):
-                self.sedges = []
-                for ill, ell in enumerate(self.ells):
-                    lo, hi, *step = slim[ell]
-                    if not step: step = ((hi - lo) / self.s[ill].size,) if self.s is not None else (_default_step,)
-                    edges = np.arange(lo, hi + step[0] / 2., step=step[0])
-                    self.sedges.append(np.column_stack([edges[:-1], edges[1:]]))
-        if self.sedges is None:
-            if self.s is not None:
-                self.sedges = []
-                for xx in self.s:
-                    tmp = (xx[:-1] + xx[1:]) / 2.
-                    tmp = np.concatenate([[tmp[0] - (xx[1] - xx[0])], tmp, [tmp[-1] + (xx[-1] - xx[-2])]])
-                    self.sedges.append(np.column_stack([tmp[:-1], tmp[1:]]))
-            else:
-                edges = np.arange(20. - _default_step / 2., 150 + _default_step, _default_step)
-                self.sedges = [np.column_stack([edges[:-1], edges[1:]])] * len(self.ells)
-        if self.s is None:
-            self.s = [np.mean(edges, axis=-1) for edges in self.sedges]
-        self.s = [np.array(ss) for ss in self.s]
+        # output binning (window.py:583-640): rules in _binning.MultipoleBins
+        bins = MultipoleBins.resolve(x=init.get('s', None), edges=init.get('sedges', None), lim=init.get('slim', None), ells=init.get('ells', None),
+                                     default_step=5., default_edges=np.arange(17.5, 155., 5.), label='s', lim_from_edges=True)
+        self.ells, self.s, self.sedges, self.smasklim = bins.ells, bins.x, bins.edges, bins.masklim
         theory = init.get('theory', None)
         if theory is None:
             raise ValueError('provide theory (e.g. DampedBAOWigglesTracerCorrelationFunctionMultipoles)')
@@ -82,24 +37,17 @@ class WindowedCorrelationFunctionMultipoles(BaseCalculator):
         self.matrix_full, self.smask, self.offset = None, None, None
         if wmatrix is None:   # window.py:649-656
             self.ellsin = tuple(self.ells)
-            self.sin = np.unique(np.concatenate(self.s, axis=0))
-            if not all(ss.shape == self.sin.shape and np.allclose(ss, self.sin) for ss in self.s):
-                smask = [np.searchsorted(self.sin, ss, side='left') for ss in self.s]
-                self.smask = np.concatenate([self.sin.size * i + sm for i, sm in enumerate(smask)], axis=0)
+            self.sin, self.smask = bins.input_grid()
         elif isinstance(wmatrix, dict):
             if 'wcounts' in wmatrix:
                 raise NotImplementedError('RR-count window matrices are out of scope')
             self.ellsin = tuple(self.ells)
             self.sin, matrix_full = window_matrix_bininteg(self.sedges, **wmatrix)
             self.matrix_full = matrix_full.T
-        elif isinstance(wmatrix, np.ndarray):   # window.py:667-681 (note the reference transposes the input)
-            from scipy import linalg
+        elif isinstance(wmatrix, np.ndarray):   # window.py:667-681: the reference takes the matrix as [input, output] here (transposed w.r.t. P_ell)
             self.ellsin = tuple(ellsin or self.ells)
-            matrix_full = np.array(wmatrix, dtype='f8').T
-            sin = np.asarray(sin).flatten()
-            self.sin = sin.copy()
-            wmatrix_rebin = linalg.block_diag(*[utils.matrix_lininterp(self.sin, sin) for ell in self.ellsin])
-            self.matrix_full = matrix_full.dot(wmatrix_rebin.T)
+            self.sin = np.ravel(np.asarray(sin, dtype='f8')).copy()
+            self.matrix_full = np.array(wmatrix, dtype='f8').T
         else:
             raise ValueError('unrecognized wmatrix {}'.format(wmatrix))
         systematic_templates = init.get('systematic_templates', None)

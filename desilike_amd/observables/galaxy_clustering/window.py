@@ -9,6 +9,7 @@ import numpy as np
 from ...base import BaseCalculator
 from ... import utils
 from ...utils import window_matrix_bininteg  # noqa: F401
+from ._binning import MultipoleBins
 
 
 def get_templates(templates, ells=(0, 2, 4), x=None):
@@ -128,71 +129,13 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
         if self._initialized:
             return self
         init = self.init
-        _default_step = 0.01
-        klim, k, kedges, ells = init.get('klim', None), init.get('k', None), init.get('kedges', None), init.get('ells', None)
         wmatrix, kin, kinrebin, kinlim, ellsin = init.get('wmatrix', None), init.get('kin', None), init.get('kinrebin', 1), init.get('kinlim', None), init.get('ellsin', None)
         shotnoise, wshotnoise = init.get('shotnoise', None), init.get('wshotnoise', None)
         fiber_collisions, systematic_templates = init.get('fiber_collisions', None), init.get('systematic_templates', None)
-        if ells is None:
-            ells = list(klim) if klim is not None else (0, 2, 4)
-        self.ells = tuple(ells)
-        self.k = self.kmasklim = self.kedges = None
-        if k is not None:
-            if np.ndim(k[0]) == 0: k = [k] * len(self.ells)
-            self.k = [np.array(kk, dtype='f8') for kk in k]
-            if len(self.k) != len(self.ells): raise ValueError("provide as many k's as ells")
-        input_klim = klim is not None
-        if kedges is not None:
-            if np.ndim(kedges[0]) == 0: kedges = [kedges] * len(self.ells)
-            self.kedges = [np.array(kk, dtype='f8') for kk in kedges]
-            self.kedges = [np.column_stack([edges[:-1], edges[1:]]) if edges.ndim <= 1 else edges for edges in self.kedges]
-            if len(self.kedges) != len(self.ells): raise ValueError('provide as many kedges as ells')
-            if klim is None:
-                klim = {ell: (edges[0, 0], edges[-1, 1], np.mean(edges[..., 1] - edges[..., 0])) for ell, edges in zip(self.ells, self.kedges)}
-        if input_klim:  # window.py:249-282
-            klim = dict(klim)
-            if self.k is not None:
-                k, ells, self.kmasklim = [], [], {}
-                for ill, ell in enumerate(self.ells):
-                    kk = self.k[ill]
-                    self.kmasklim[ell] = np.zeros(len(kk), dtype='?')
-                    if ell not in klim: continue
-                    self.kmasklim[ell][...] = True
-                    if klim[ell] is not None:
-                        (lo, hi, *step) = klim[ell]
-                        kmask = (kk >= lo) & (kk <= hi)
-                        kk = kk[kmask]
-                        self.kmasklim[ell][...] = kmask
-                    if kk.size:
-                        k.append(kk)
-                        ells.append(ell)
-                self.k, self.ells = k, tuple(ells)
-            elif list(self.ells) != list(klim):
-                raise ValueError('incompatible ells = {} and klim = {}; just remove ells?'.format(self.ells, list(klim)))
-            kedges = []
-            for ill, ell in enumerate(self.ells):
-                if klim[ell] is None:
-                    kedges = None
-                    break
-                (lo, hi, *step) = klim[ell]
-                if not step:
-                    step = ((hi - lo) / self.k[ill].size,) if self.k is not None else (_default_step,)
-                edges = np.arange(lo, hi + step[0] / 2., step=step[0])
-                kedges.append(np.column_stack([edges[:-1], edges[1:]]))
-            if self.kedges is None: self.kedges = kedges
-        if self.kedges is None:
-            if self.k is not None:
-                self.kedges = []
-                for xx in self.k:
-                    tmp = (xx[:-1] + xx[1:]) / 2.
-                    tmp = np.concatenate([[tmp[0] - (xx[1] - xx[0])], tmp, [tmp[-1] + (xx[-1] - xx[-2])]])
-                    self.kedges.append(np.column_stack([tmp[:-1], tmp[1:]]))
-            else:
-                edges = np.arange(0.01 - _default_step / 2., 0.2 + _default_step, _default_step)
-                self.kedges = [np.column_stack([edges[:-1], edges[1:]])] * len(self.ells)
-        if self.k is None:
-            self.k = [np.mean(edges, axis=-1) for edges in self.kedges]
-        self.k = [np.array(kk) for kk in self.k]
+        # output binning (window.py:214-292): rules in _binning.MultipoleBins
+        bins = MultipoleBins.resolve(x=init.get('k', None), edges=init.get('kedges', None), lim=init.get('klim', None), ells=init.get('ells', None),
+                                     default_step=0.01, default_edges=np.arange(0.005, 0.21, 0.01), label='k')
+        self.ells, self.k, self.kedges, self.kmasklim = bins.ells, bins.x, bins.edges, bins.masklim
 
         theory = init.get('theory', None)
         if theory is None:
@@ -203,28 +146,22 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
         self.matrix_full, self.kmask, self.offset = None, None, None
         if wmatrix is None:  # window.py:294-305
             self.ellsin = tuple(self.ells)
-            self.kin = np.unique(np.concatenate(self.k, axis=0))
-            if not all(kk.shape == self.kin.shape and np.allclose(kk, self.kin) for kk in self.k):
-                kmask = [np.searchsorted(self.kin, kk, side='left') for kk in self.k]
-                assert all(np.allclose(self.kin[km], kk) for kk, km in zip(self.k, kmask)), self.k
-                self.kmask = np.concatenate([self.kin.size * i + km for i, km in enumerate(kmask)], axis=0)
+            self.kin, self.kmask = bins.input_grid()
         elif isinstance(wmatrix, dict):  # window.py:306-310
             self.ellsin = tuple(self.ells)
             self.kin, matrix_full = window_matrix_bininteg(self.kedges, **wmatrix)
             self.matrix_full = matrix_full.T
-        elif isinstance(wmatrix, np.ndarray):  # window.py:311-324
-            from scipy import linalg
+        elif isinstance(wmatrix, np.ndarray):  # window.py:311-324: dense matrix given on (ellsin, kin), optionally rebinned / cut along its input axis
             self.ellsin = tuple(ellsin or self.ells)
             matrix_full = np.array(wmatrix, dtype='f8')
-            ksize = sum(len(kk) for kk in self.k)
-            if matrix_full.shape[0] != ksize:
-                raise ValueError('output "wmatrix" size is {:d}, but got {:d} output "k"'.format(matrix_full.shape[0], ksize))
-            kin = np.asarray(kin).flatten()
-            self.kin = kin.copy()
-            if kinrebin is not None: self.kin = self.kin[::kinrebin]
+            if matrix_full.shape[0] != bins.size:
+                raise ValueError('output "wmatrix" size is {:d}, but got {:d} output "k"'.format(matrix_full.shape[0], bins.size))
+            kin_given = np.ravel(np.asarray(kin, dtype='f8'))
+            self.kin = kin_given[::kinrebin] if kinrebin is not None else kin_given.copy()
             if kinlim is not None: self.kin = self.kin[(self.kin >= kinlim[0]) & (self.kin <= kinlim[-1])]
-            wmatrix_rebin = linalg.block_diag(*[utils.matrix_lininterp(self.kin, kin) for ell in self.ellsin])
-            self.matrix_full = matrix_full.dot(wmatrix_rebin.T)
+            rebin = utils.matrix_lininterp(self.kin, kin_given)                     # [len(kin), len(kin_given)], the same for every input multipole
+            blocks = matrix_full.reshape(matrix_full.shape[0], len(self.ellsin), kin_given.size)
+            self.matrix_full = np.einsum('oli,ki->olk', blocks, rebin).reshape(matrix_full.shape[0], -1)
         else:
             raise NotImplementedError('window matrices from files / lsstypes / pypower objects are out of scope: pass a 2D array with kin and ellsin')
         if fiber_collisions is not None:   # window.py:428-438: kernels folded into the matrix / offset
@@ -254,13 +191,15 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
             if getattr(self.theory, '_kind', None) == 3 or getattr(self.theory, '_wants_shotnoise', False):   # theories using the shot noise take it from the observable (window.py:441-443)
                 self.theory.init.setdefault('shotnoise', shotnoise)
         self.shotnoise = shotnoise
-        # window.py:445-457
-        self.shotnoisein = np.array([shotnoise * (ell == 0) for ell in self.ellsin], dtype='f8')
-        wshotnoisebase = np.concatenate([np.full_like(kk, (ell == 0), dtype='f8') for ell, kk in zip(self.ells, self.k)])
-        self.shotnoiseout = shotnoise * wshotnoisebase
-        if wshotnoise is not None:
-            self.shotnoisein[...] = 0.
-            self.shotnoiseout[...] = shotnoise * (wshotnoisebase - np.asarray(wshotnoise))
+        # shot noise (window.py:445-457): added to the monopole of the theory before the window, removed from the monopole rows after it; a window
+        # that carries its own response to a constant (``wshotnoise``) takes both roles
+        monopole_rows = np.concatenate([np.full(len(kk), float(ell == 0)) for ell, kk in zip(self.ells, self.k)])
+        if wshotnoise is None:
+            self.shotnoisein = shotnoise * np.array([float(ell == 0) for ell in self.ellsin])
+            self.shotnoiseout = shotnoise * monopole_rows
+        else:
+            self.shotnoisein = np.zeros(len(self.ellsin), dtype='f8')
+            self.shotnoiseout = shotnoise * (monopole_rows - np.asarray(wshotnoise, dtype='f8'))
         self.wshotnoise = wshotnoise
         self.theory.initialize()
         self._initialized = True

@@ -15,6 +15,73 @@ from .parameter import Samples
 from .parallel import WalkerSharding
 
 
+class CounterRNG(object):
+    """Counter-based random numbers for the ensemble sampler: Philox4x32-10 (Salmon et al. 2011, Random123) keyed by a 64-bit ``seed``; the draw for
+    (iteration, stream, index) is a pure function of the seed.  The device-resident sampler (csrc/dl_ensemble.hip) evaluates the same function, so the
+    host and the GPU drivers -- and every rank of a sharded run -- produce the same chain without exchanging random state."""
+    PERM, MOVE, ACCEPT = 0, 1, 3   # stream ids (+ half-step for the last two)
+
+    def __init__(self, seed=0):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+
+    @staticmethod
+    def philox4x32(counter, key):
+        """``counter [..., 4]``, ``key [..., 2]`` uint32 -> uint32 ``[..., 4]`` (10 rounds)."""
+        c = [np.asarray(counter[..., i], dtype=np.uint64) for i in range(4)]
+        k0, k1 = np.asarray(key[..., 0], dtype=np.uint64), np.asarray(key[..., 1], dtype=np.uint64)
+        mask = np.uint64(0xFFFFFFFF)
+        for _ in range(10):
+            p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+            c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & mask, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & mask]
+            k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+        return np.stack(c, axis=-1).astype(np.uint32)
+
+    def draw(self, iteration, stream, n):
+        """uint32 ``[n, 4]``: words of index 0 .. n - 1 of ``stream`` at ``iteration``."""
+        counter = np.empty((n, 4), dtype=np.uint32)
+        counter[:, 0], counter[:, 1] = int(iteration) & 0xFFFFFFFF, (int(iteration) >> 32) & 0xFFFFFFFF
+        counter[:, 2], counter[:, 3] = np.arange(n, dtype=np.uint32), stream
+        key = np.array([self.seed & 0xFFFFFFFF, self.seed >> 32], dtype=np.uint32)
+        return self.philox4x32(counter, key)
+
+    @staticmethod
+    def uniform53(hi, lo):
+        """53-bit uniform on [0, 1) from two 32-bit words (numpy's ``random_sample`` construction)."""
+        return ((hi >> np.uint32(5)).astype('f8') * 67108864. + (lo >> np.uint32(6)).astype('f8')) / 9007199254740992.
+
+    def permutation(self, iteration, n):
+        words = self.draw(iteration, self.PERM, n)
+        keys = (words[:, 0].astype(np.uint64) << np.uint64(32)) | words[:, 1].astype(np.uint64)
+        return np.argsort(keys, kind='stable')
+
+    def move(self, iteration, half, n):
+        """(uniform [n], partner index in [0, n) [n]) of a half-step's stretch proposals."""
+        words = self.draw(iteration, self.MOVE + half, n)
+        return self.uniform53(words[:, 0], words[:, 1]), (words[:, 2] % np.uint32(n)).astype(int)
+
+    def accept(self, iteration, half, n):
+        words = self.draw(iteration, self.ACCEPT + half, n)
+        return self.uniform53(words[:, 0], words[:, 1])
+
+
+def _sync_random_state(rng, seed, sharding):
+    """One random stream for all ranks of a sharded sampler (the reference broadcasts rng / seed: samplers/base.py:213-217, 278): without it every rank would
+    propose different walkers and evaluate slices of different ensembles."""
+    if rng is None and seed is None:
+        seed = int(np.random.SeedSequence().entropy % (2**32))
+    if sharding.active and sharding.world > 1:
+        if rng is not None:
+            kind, keys, pos, has_gauss, cached = rng.get_state()
+            state = sharding.broadcast(np.concatenate([keys.astype('f8'), [pos, has_gauss, cached]]))
+            rng = np.random.RandomState()
+            rng.set_state((kind, state[:-3].astype(np.uint32), int(state[-3]), int(state[-2]), float(state[-1])))
+        else:
+            seed = int(sharding.broadcast(np.array([float(seed)]))[0])
+    if rng is None:
+        rng = np.random.RandomState(seed=seed)
+    return rng, seed
+
+
 class BasePosteriorSampler(object):
 
     def __init__(self, likelihood, rng=None, seed=None, max_tries=1000, ref_scale=1., sharding=None):
@@ -22,8 +89,8 @@ class BasePosteriorSampler(object):
         self.varied_params = likelihood.varied_params
         self.max_tries = int(max_tries)
         self.ref_scale = float(ref_scale)
-        self.rng = rng if rng is not None else np.random.RandomState(seed=seed)
         self.sharding = sharding if sharding is not None else WalkerSharding()
+        self.rng, self.seed = _sync_random_state(rng, seed, self.sharding)
         self._vlikelihood = vmap(likelihood, errors='return', return_derived=True)
         self.derived = None
         self.fast = True   # False: always go through vmap(likelihood) (derived parameters kept by the likelihood's own call surface)
@@ -36,15 +103,22 @@ class BasePosteriorSampler(object):
             toret += param.prior(column)
         return toret
 
+    def _posterior_context(self):
+        """(device context, offset) of a GPU likelihood, or ``None``."""
+        get_context = getattr(self.likelihood, '_get_posterior_context', None)
+        if self.fast and get_context is not None:
+            return get_context()
+        return None
+
     def _logposterior_local(self, values):
         """samplers/base.py:144-193 for the rows handled by this process."""
         values = np.atleast_2d(np.asarray(values, dtype='f8'))
-        get_context = getattr(self.likelihood, '_get_posterior_context', None)
-        if self.fast and get_context is not None and values.shape[0]:
+        context = self._posterior_context()
+        if context is not None and values.shape[0]:
             # GPU likelihoods: the same conventions (NaN rows, rows outside the prior, non-finite results -> -inf) are applied by the finalize kernels:
             # ONE C-ABI call per batch instead of the dictionary round trip below; linear parameters with constant derivative rows are marginalised once, into the
             # precision matrix, instead of at every point
-            ctx, offset = get_context()
+            ctx, offset = context
             return ctx.eval_logposterior_host(values)[0] + offset
         toret = np.full(values.shape[0], -np.inf)
         mask = ~np.isnan(values).any(axis=1)                      # bcast_values, samplers/base.py:57-61
@@ -72,7 +146,11 @@ class BasePosteriorSampler(object):
         values = np.asarray(values, dtype='f8')
         isscalar = values.ndim == 1
         values = np.atleast_2d(values)
-        toret = self.sharding.map(self._logposterior_local, values)
+        context = self._posterior_context()
+        if context is not None and values.shape[0] and self.sharding.sharded(values.shape[0]):
+            toret = self.sharding.map_logposterior(context[0], values, offset=context[1])   # device-resident exchange (RCCL through the C ABI)
+        else:
+            toret = self.sharding.map(self._logposterior_local, values)
         return toret[0] if isscalar else toret
 
     def _get_start(self, size):
@@ -100,7 +178,10 @@ class BasePosteriorSampler(object):
 
 class EnsembleStretchMove(object):
     """Affine-invariant ensemble sampler (Goodman & Weare 2010, stretch move with a = 2), vectorised: ``log_prob_fn(coords [n, ndim]) -> [n]``
-    is called once per half-ensemble, like ``emcee.EnsembleSampler(vectorize=True)`` with its default move."""
+    is called once per half-ensemble, like ``emcee.EnsembleSampler(vectorize=True)`` with its default move.
+
+    ``rng``: a ``numpy.random.RandomState`` (sequential draws) or a :class:`CounterRNG` (counter-based draws: the chain is then bit-identical to the
+    device-resident sampler's, ``dl_ensemble_*``)."""
 
     def __init__(self, nwalkers, ndim, log_prob_fn, a=2., rng=None):
         if nwalkers % 2 or nwalkers < 2 * ndim:
@@ -113,14 +194,22 @@ class EnsembleStretchMove(object):
     def step(self, coords, log_prob):
         coords, log_prob = coords.copy(), log_prob.copy()
         half = self.nwalkers // 2
-        perm = self.rng.permutation(self.nwalkers)
-        for first, second in [(perm[:half], perm[half:]), (perm[half:], perm[:half])]:
-            zz = ((self.a - 1.) * self.rng.uniform(size=half) + 1.)**2 / self.a          # g(z) ~ 1 / sqrt(z) on [1 / a, a]
-            partners = coords[second][self.rng.randint(half, size=half)]
+        counter = isinstance(self.rng, CounterRNG)
+        perm = self.rng.permutation(self.niterations, self.nwalkers) if counter else self.rng.permutation(self.nwalkers)
+        for ihalf, (first, second) in enumerate([(perm[:half], perm[half:]), (perm[half:], perm[:half])]):
+            if counter:
+                uz, partner = self.rng.move(self.niterations, ihalf, half)
+            else:
+                uz = self.rng.uniform(size=half)
+                partner = self.rng.randint(half, size=half)
+            zz = ((self.a - 1.) * uz + 1.)**2 / self.a          # g(z) ~ 1 / sqrt(z) on [1 / a, a]
+            partners = coords[second][partner]
             proposal = partners - (partners - coords[first]) * zz[:, None]
             new_log_prob = self.log_prob_fn(proposal)
-            lnpdiff = (self.ndim - 1.) * np.log(zz) + new_log_prob - log_prob[first]
-            accepted = np.log(self.rng.uniform(size=half)) < lnpdiff
+            with np.errstate(invalid='ignore', divide='ignore'):
+                lnpdiff = ((self.ndim - 1.) * np.log(zz) + new_log_prob) - log_prob[first]
+                ua = self.rng.accept(self.niterations, ihalf, half) if counter else self.rng.uniform(size=half)
+                accepted = np.log(ua) < lnpdiff
             idx = first[accepted]
             coords[idx], log_prob[idx] = proposal[accepted], new_log_prob[accepted]
             self.naccepted[idx] += 1
@@ -133,10 +222,15 @@ class EnsembleStretchMove(object):
 
 
 class EmceeSampler(BasePosteriorSampler):
-    """Ensemble sampler with the reference's constructor surface (desilike/samplers/emcee.py:8-69)."""
+    """Ensemble sampler with the reference's constructor surface (desilike/samplers/emcee.py:8-69).
+
+    ``device_resident`` (default: True for GPU likelihoods unless ``use_emcee=True``): the whole ensemble update runs on the GPU (``dl_ensemble_*``: stretch
+    proposals, log-posterior, accept / reject and the counter-based random generator on the device, one all-gather of log-posteriors per half-step over RCCL when
+    the sampler's group is an :class:`~desilike_amd.parallel.RcclGroup`); the host drains the chain once per ``run``.  Otherwise ``emcee`` if installed, else the
+    built-in :class:`EnsembleStretchMove` on the host."""
     name = 'emcee'
 
-    def __init__(self, likelihood, nwalkers=None, use_emcee=None, **kwargs):
+    def __init__(self, likelihood, nwalkers=None, use_emcee=None, device_resident=None, a=2., **kwargs):
         super(EmceeSampler, self).__init__(likelihood, **kwargs)
         ndim = len(self.varied_params)
         if nwalkers is None:
@@ -145,17 +239,38 @@ class EmceeSampler(BasePosteriorSampler):
             nwalkers = int(eval(nwalkers, {'ndim': ndim}))
         self.nwalkers = int(nwalkers)
         self.chain = None
+        self.a = float(a)
+        if device_resident is None:
+            device_resident = use_emcee is not True and getattr(likelihood, '_get_posterior_context', None) is not None
+        self.device_resident = bool(device_resident)
+        self._ensemble = None
         emcee = None
-        if use_emcee is not False:
+        if use_emcee is not False and not self.device_resident:
             try:
                 import emcee
             except ImportError:
                 if use_emcee: raise
         self._emcee = emcee
-        if emcee is not None:
+        if self.device_resident:
+            if self.nwalkers % 2 or self.nwalkers < 2 * ndim:
+                raise ValueError('nwalkers must be even and at least 2 * ndim')
+            self.sampler = None
+        elif emcee is not None:
             self.sampler = emcee.EnsembleSampler(self.nwalkers, ndim, self.logposterior, vectorize=True)   # samplers/emcee.py:69
         else:
-            self.sampler = EnsembleStretchMove(self.nwalkers, ndim, self.logposterior, rng=self.rng)
+            self.sampler = EnsembleStretchMove(self.nwalkers, ndim, self.logposterior, a=self.a, rng=self.rng)
+
+    def _get_ensemble(self):
+        if self._ensemble is None:
+            from ._lib import DeviceEnsemble
+            from .parallel import RcclGroup
+            ctx, offset = self.likelihood._get_posterior_context()
+            group = self.sharding.group if (self.sharding.sharded(self.nwalkers // 2) and isinstance(self.sharding.group, RcclGroup)) else None
+            # one 64-bit key for the device generator, drawn from the (rank-synchronised) host generator
+            key = int(self.rng.randint(0, 2**32, dtype=np.uint64)) | (int(self.rng.randint(0, 2**32, dtype=np.uint64)) << 32)
+            self._ensemble = DeviceEnsemble(ctx, self.nwalkers, a=self.a, seed=key, offset=offset, group=group)
+            self.counter_seed = key
+        return self._ensemble
 
     def run(self, niterations=300, thin_by=1, start=None):
         """Run ``niterations`` ensemble updates; returns dict(name -> [niterations, nwalkers]) incl. 'logposterior' (cf. samplers/emcee.py:101-111)."""
@@ -167,7 +282,20 @@ class EmceeSampler(BasePosteriorSampler):
         else:
             start = np.asarray(start, dtype='f8')
             logposterior = self.logposterior(start)
-        if self._emcee is not None:
+        if self.device_resident:
+            import torch
+            ens = self._get_ensemble()
+            device = torch.device('cuda', ens.device)
+            if self.chain is None or self._last[0] is not start:
+                ens.set_state(start, logposterior)
+            coords = torch.empty((niterations, self.nwalkers, ens.n_params), dtype=torch.float64, device=device)
+            logp = torch.empty((niterations, self.nwalkers), dtype=torch.float64, device=device)
+            ens.run(niterations * thin_by, thin_by=thin_by, chain=coords, chain_logp=logp)
+            coords, logp = coords.cpu().numpy(), logp.cpu().numpy()    # the one synchronisation of the run
+            self._last = (coords[-1], logp[-1]) if niterations else (start, logposterior)
+            self._naccepted = ens.get_state()[2]
+            self._niterations = ens.info('iteration')
+        elif self._emcee is not None:
             self.sampler._random = self.rng
             state = self._emcee.State(start, log_prob=logposterior)
             for state in self.sampler.sample(initial_state=state, iterations=niterations, thin_by=thin_by, store=True):
@@ -192,6 +320,8 @@ class EmceeSampler(BasePosteriorSampler):
 
     @property
     def acceptance_fraction(self):
+        if self.device_resident:
+            return self._naccepted / max(self._niterations, 1)
         return self.sampler.acceptance_fraction
 
     def save(self, fn):
@@ -203,6 +333,8 @@ class EmceeSampler(BasePosteriorSampler):
         self.chain = {name: data[name] for name in data.files}
         last = np.column_stack([self.chain[param.name][-1] for param in self.varied_params])
         self._last = (last, self.chain['logposterior'][-1])
+        if self._ensemble is not None:
+            self._ensemble.set_state(*self._last)
 
 
 def _expand_dict(values, names):

@@ -36,79 +36,102 @@ def multipole_weights(mu, wmu, ells):
 
 
 def matrix_lininterp(xin, xout):
-    """Matrix for linear interpolation from ``xin`` to ``xout`` (utils.py:646-657), shape (len(xin), len(xout))."""
-    xin = np.asarray(xin)
-    toret = np.zeros((len(xin), len(xout)), dtype='f8')
-    for iout, xo in enumerate(xout):
-        iin = np.searchsorted(xin, xo, side='right') - 1
-        if 0 <= iin < len(xin) - 1:
-            frac = (xo - xin[iin]) / (xin[iin + 1] - xin[iin])
-            toret[iin, iout] = 1. - frac
-            toret[iin + 1, iout] = frac
-        elif np.isclose(xo, xin[-1]):
-            toret[iin, iout] = 1.
-    return toret
+    """Linear-interpolation operator from the sorted grid ``xin`` to the points ``xout``: ``f(xout) = M^T f(xin)``, ``M`` of shape (len(xin), len(xout)).
+    Points outside ``[xin[0], xin[-1]]`` get a zero column, except a point at (to rounding) the last node, which takes that node's value
+    (behaviour of the reference's utils.py:646-657)."""
+    xin, xout = np.asarray(xin, dtype='f8'), np.atleast_1d(np.asarray(xout, dtype='f8'))
+    nin, columns = xin.size, np.arange(xout.size)
+    matrix = np.zeros((nin, xout.size), dtype='f8')
+    left = np.searchsorted(xin, xout, side='right') - 1          # node at or below each point
+    inside = (left >= 0) & (left < nin - 1)
+    lo = left[inside]
+    t = (xout[inside] - xin[lo]) / (xin[lo + 1] - xin[lo])
+    matrix[lo, columns[inside]] = 1. - t
+    matrix[lo + 1, columns[inside]] = t
+    at_end = (left == nin - 1) & np.isclose(xout, xin[-1])
+    matrix[nin - 1, columns[at_end]] = 1.
+    return matrix
+
+
+def _shell_mean(lo, hi):
+    """Volume-weighted mean radius of the spherical shell [lo, hi]: int x x^2 dx / int x^2 dx."""
+    return 0.75 * (hi**4 - lo**4) / (hi**3 - lo**3)
 
 
 def window_matrix_bininteg(list_edges, resolution=1):
-    """Binning window matrix in the continuous limit (observables/galaxy_clustering/window.py:14-68).
+    """Binning matrix in the continuous limit (behaviour of observables/galaxy_clustering/window.py:14-68): the average of the theory over a bin, weighted by the
+    volume x^2 dx of spherical shells, is approximated by splitting every bin into ``resolution`` shells, each contributing the theory linearly interpolated
+    at its volume-weighted mean radius from one common input grid (shells of width min(bin width) / resolution spanning all bins).
 
-    Returns ``xin`` and the matrix of shape (n_in_total, n_out_total).
-    """
+    ``list_edges``: per multipole an array [n_bins, 2] of (low, high) (or one such array).  Returns the input grid ``xin`` and the block-diagonal matrix
+    [n_multipoles * len(xin), total number of bins]."""
     resolution = int(resolution)
     if resolution <= 0:
         raise ValueError('resolution must be a strictly positive integer')
     if np.ndim(list_edges[0]) == 0:
         list_edges = [list_edges]
     list_edges = [np.asarray(edges, dtype='f8') for edges in list_edges]
-    step = min((edges[..., 1] - edges[..., 0]).min() for edges in list_edges) / resolution
-    start, stop = min(np.min(edges) for edges in list_edges), max(np.max(edges) for edges in list_edges)
-    edgesin = np.arange(start, stop + step / 2., step)
-    xin = 3. / 4. * (edgesin[1:]**4 - edgesin[:-1]**4) / (edgesin[1:]**3 - edgesin[:-1]**3)
-    matrices = []
+    width = min(np.min(edges[..., 1] - edges[..., 0]) for edges in list_edges) / resolution
+    first, last = min(edges.min() for edges in list_edges), max(edges.max() for edges in list_edges)
+    grid = np.arange(first, last + 0.5 * width, width)
+    xin = _shell_mean(grid[:-1], grid[1:])
+    blocks = []
     for edges in list_edges:
-        x, w = [], []
-        for ibin, edge in enumerate(edges):
-            edge = np.linspace(*edge, resolution + 1)
-            x.append(3. / 4. * (edge[1:]**4 - edge[:-1]**4) / (edge[1:]**3 - edge[:-1]**3))
-            line = np.zeros(len(edges) * resolution, dtype='f8')
-            tmp = edge[1:]**3 - edge[:-1]**3
-            line[ibin * resolution:(ibin + 1) * resolution] = tmp / tmp.sum()
-            w.append(line)
-        matrices.append(matrix_lininterp(xin, np.concatenate(x)).dot(np.column_stack(w)))
-    n = len(matrices)
-    full = np.block([[matrices[i] if i == j else np.zeros((matrices[i].shape[0], matrices[j].shape[1])) for j in range(n)] for i in range(n)])
+        shells = np.linspace(edges[:, 0], edges[:, 1], resolution + 1, axis=-1)            # [n_bins, resolution + 1]
+        lo, hi = shells[:, :-1], shells[:, 1:]
+        volume = hi**3 - lo**3
+        weight = volume / volume.sum(axis=-1, keepdims=True)                               # shells of a bin, normalised
+        interp = matrix_lininterp(xin, _shell_mean(lo, hi).ravel())                         # [len(xin), n_bins * resolution]
+        blocks.append((interp * weight.ravel()).reshape(xin.size, len(edges), resolution).sum(axis=-1))
+    nrows, ncols = xin.size * len(blocks), sum(block.shape[1] for block in blocks)
+    full = np.zeros((nrows, ncols), dtype='f8')
+    col = 0
+    for ill, block in enumerate(blocks):
+        full[ill * xin.size:(ill + 1) * xin.size, col:col + block.shape[1]] = block
+        col += block.shape[1]
     return xin, full
 
 
 def inv(mat, check_valid='raise'):
-    """Matrix inverse with the reference's 1e-3 validity check (utils.py:495-558)."""
+    """Matrix inverse, checked: ``mat . inverse`` must be the identity to 1e-3 (what the reference demands of an inverse covariance, utils.py:495-558);
+    ``check_valid``: 'raise', 'warn' or 'ignore'."""
     mat = np.asarray(mat, dtype='f8')
     if mat.ndim == 0:
         return 1. / mat
-    toret = np.linalg.inv(mat)
-    if check_valid != 'ignore':
-        tmp = mat.dot(toret)
-        if not np.allclose(tmp, np.eye(tmp.shape[0]), rtol=1e-3, atol=1e-3):
-            msg = 'Numerically inaccurate inverse matrix, max absolute diff {:.6f}.'.format(np.max(np.abs(tmp - np.eye(tmp.shape[0]))))
-            if check_valid == 'raise':
-                raise np.linalg.LinAlgError(msg)
-            import warnings
-            warnings.warn(msg)
-    return toret
+    inverse = np.linalg.inv(mat)
+    if check_valid == 'ignore':
+        return inverse
+    error = np.abs(mat.dot(inverse) - np.eye(mat.shape[0]))
+    if not (error <= 1e-3 + 1e-3 * np.eye(mat.shape[0])).all():
+        msg = 'Numerically inaccurate inverse matrix, max absolute diff {:.6f}.'.format(error.max())
+        if check_valid == 'raise':
+            raise np.linalg.LinAlgError(msg)
+        import warnings
+        warnings.warn(msg)
+    return inverse
 
 
 def blockinv(blocks, check_valid='raise'):
-    """Block-wise (Schur complement) inverse, recursing over the first block like utils.py:561-599."""
-    A = np.asarray(blocks[0][0])
-    if (len(blocks), len(blocks[0])) == (1, 1):
-        return inv(A, check_valid=check_valid)
-    B = np.block([list(blocks[0][1:])])
-    C = np.block([[b[0]] for b in blocks[1:]])
-    invD = blockinv([b[1:] for b in blocks[1:]], check_valid=check_valid)
-    invShur = inv(A - B.dot(invD).dot(C), check_valid=check_valid)
-    toret = np.block([[invShur, -invShur.dot(B).dot(invD)], [-invD.dot(C).dot(invShur), invD + invD.dot(C).dot(invShur).dot(B).dot(invD)]])
-    return toret
+    """Inverse of a matrix given as a square list of lists of blocks, by block elimination -- the leading block against the (recursively inverted) remainder
+    through its Schur complement, each dense inverse checked by :func:`inv`.  The reference inverts joint covariances this way (utils.py:561-599,
+    likelihoods/base.py:617-619): numerically this is not the same as inverting the assembled matrix, so the order of elimination is kept."""
+    nblocks = len(blocks)
+    head = np.asarray(blocks[0][0], dtype='f8')
+    if nblocks == 1:
+        return inv(head, check_valid=check_valid)
+    right = np.concatenate([np.atleast_2d(b) for b in blocks[0][1:]], axis=1)              # head row, remaining columns
+    below = np.concatenate([np.atleast_2d(row[0]) for row in blocks[1:]], axis=0)          # head column, remaining rows
+    rest_inv = blockinv([row[1:] for row in blocks[1:]], check_valid=check_valid)
+    right_rest = right.dot(rest_inv)
+    schur_inv = inv(head - right_rest.dot(below), check_valid=check_valid)
+    rest_below = rest_inv.dot(below)
+    n0, n = head.shape[0], head.shape[0] + rest_inv.shape[0]
+    out = np.empty((n, n), dtype='f8')
+    out[:n0, :n0] = schur_inv
+    out[:n0, n0:] = -schur_inv.dot(right).dot(rest_inv)
+    out[n0:, :n0] = -rest_below.dot(schur_inv)
+    out[n0:, n0:] = rest_inv + rest_below.dot(schur_inv).dot(right).dot(rest_inv)
+    return out
 
 
 def weights_trapz(x):

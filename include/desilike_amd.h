@@ -26,8 +26,10 @@
  *  - return code 0 = success; non-zero = error, message via dl_last_error(ctx) (or dl_last_error(NULL)
  *    for errors before a context exists).  Per-point numerical failures are NOT errors: they are
  *    reported in ``status`` (the Python host maps them to -inf exactly like samplers/base.py:185-191).
- *  - calls on one dl_ctx are serialised on the HIP stream passed in (NULL = default stream);
- *    different contexts (devices) are independent; no global mutable state except the last-error string.
+ *  - a dl_ctx is used by one host thread at a time.  Its calls are asynchronous on the HIP stream passed in (NULL = default stream) and are
+ *    serialised ACROSS streams by the library: a call issued on another stream than the previous call on the same context (the *_host entry points
+ *    use a private stream) first waits, on the device, for that previous call -- the workspaces of a context are shared by all its calls.
+ *    Different contexts (devices) are independent; no global mutable state except the last-error string.
  *  - the library FAILS (non-zero) when no GPU is present: there is no CPU fallback.
  */
 #ifndef DESILIKE_AMD_H
@@ -115,7 +117,7 @@ int  dl_create(dl_ctx** out, int device, const dl_config* cfg);
 void dl_destroy(dl_ctx* ctx);
 const char* dl_last_error(const dl_ctx* ctx);
 
-/* integer properties: "n_params", "n_data", "n_obs", "n_in_total", "n_in_obs<i>", "n_out_obs<i>", "n_solved" */
+/* integer properties: "n_params", "n_data", "n_obs", "n_in_total", "n_in_obs<i>", "n_out_obs<i>", "n_solved", "device" */
 int64_t dl_info(const dl_ctx* ctx, const char* key);
 
 /* ---- evaluation ------------------------------------------------------------------------------*/
@@ -153,11 +155,11 @@ int  dl_eval_theory_host(dl_ctx* ctx, const double* theta, int64_t B, int32_t io
 int  dl_eval_logposterior_host(dl_ctx* ctx, const double* theta, int64_t B, double* logposterior, int32_t* status);
 
 /* ---- measurement -----------------------------------------------------------------------------*/
-/* enable > 0: dl_eval_batch brackets each kernel with HIP events on the launch stream, on one call out of
- * ``enable`` (sampling keeps the cost of the event records, ~3.5 us each, out of the measured throughput).
- * dl_profile_read synchronises and returns per-kernel milliseconds, the median over the (up to 256) sampled calls,
- * after subtracting the calibrated cost of an empty event-to-event interval:
- * ms[0] theory kernel, ms[1] window GEMM, ms[2] chi2/prior finalize, ms[3] whole call, ms[4] (if n >= 5) the overhead subtracted. */
+/* enable > 0: on one dl_eval_* call out of ``enable`` the kernels are launched with start / stop HIP events attached to their dispatch packets
+ * (hipExtLaunchKernelGGL: the packets' own timestamps, as rocprofv3 --kernel-trace reads them; no event records between the kernels).
+ * dl_profile_read synchronises and returns per-kernel milliseconds, the median over the (up to 256) sampled calls:
+ * ms[0] theory kernel, ms[1] window / chi2 GEMM, ms[2] chi2 / prior finalize, ms[3] start of the first kernel to the end of the last,
+ * ms[4] (if n >= 5) 0 (kept for compatibility), ms[5] (if n >= 6) number of sampled calls. */
 int  dl_profile_enable(dl_ctx* ctx, int enable);
 int  dl_profile_read(dl_ctx* ctx, double* ms, int32_t n);
 
@@ -172,6 +174,46 @@ typedef struct dl_fftlog dl_fftlog;
 int  dl_fftlog_create(dl_fftlog** out, int device, int32_t n, int32_t npad, int32_t n_ell, const double* pre, const double* u, const double* post);
 int  dl_fftlog_apply(dl_fftlog* plan, const double* fun_dev, int64_t B, double* out_dev, void* hip_stream);
 void dl_fftlog_destroy(dl_fftlog* plan);
+
+/* ---- exchange across the GPUs of a node (SURVEY 8b ``dl_allgather_logl``; 8e) -------------------------------------------------
+ * One process per GPU.  The reference parallelises over parameter points only: ``vmap(..., backend='mpi')`` scatters the points and gathers the results
+ * (desilike/base.py:310-335), samplers broadcast the log-posteriors to all ranks (desilike/samplers/base.py:196-200).  Here the one exchange is an
+ * all-gather of per-point results over RCCL (xGMI), enqueued on the caller's HIP stream: no host synchronisation.  RCCL is bound at run time (dlopen):
+ * ``rccl_library_path`` NULL = the copy already loaded in the process (e.g. PyTorch's), else the default search path.
+ * Bootstrap: rank 0 calls dl_comm_unique_id and ships the 128 bytes to the other ranks by any host channel (the Python host uses a TCP store at
+ * MASTER_ADDR:MASTER_PORT); every rank then calls dl_comm_create (collective).  Errors: non-zero, message via dl_last_error(NULL). */
+typedef struct dl_comm dl_comm;
+#define DL_COMM_ID_BYTES 128
+int  dl_comm_unique_id(char* id /* [DL_COMM_ID_BYTES] */, const char* rccl_library_path);
+int  dl_comm_create(dl_comm** out, int device, int rank, int world, const char* id /* [DL_COMM_ID_BYTES] */, const char* rccl_library_path);
+void dl_comm_destroy(dl_comm* comm);
+/* integer properties: "rank", "world", "device", "rccl_version" (comm may be NULL for the last) */
+int64_t dl_comm_info(const dl_comm* comm, const char* key);
+/* recv_dev[world * count] <- concatenation over ranks of send_dev[count]; in place when send_dev == recv_dev + rank * count.  Asynchronous on ``hip_stream``. */
+int  dl_comm_allgather_f64(dl_comm* comm, const double* send_dev, double* recv_dev, int64_t count, void* hip_stream);
+/* buf_dev[count] of rank ``root`` -> every rank (walker positions must be identical on all ranks: desilike/samplers/base.py:45-54) */
+int  dl_comm_broadcast_f64(dl_comm* comm, double* buf_dev, int64_t count, int root, void* hip_stream);
+
+/* ---- device-resident ensemble sampler (BASELINE configs[4]) ------------------------------------------------------------------
+ * The affine-invariant stretch move that ``EmceeSampler`` drives on the host in the reference (desilike/samplers/emcee.py:69-111: emcee.EnsembleSampler(...,
+ * vectorize=True), default StretchMove; log-posterior conventions of desilike/samplers/base.py:144-200), with walker positions, log-posteriors and the
+ * counter-based random number generator (Philox4x32-10 keyed by ``seed``) resident on the GPU: per half-step ONE small kernel (accept the previous half,
+ * draw the split, stretch proposals), dl_eval_logposterior on this rank's share of the proposals, and -- with a communicator -- one in-place
+ * dl_comm_allgather_f64; nothing synchronises with the host.  Every rank holds the full ensemble (identical bits: the draws are pure functions of
+ * (seed, iteration, half-step, slot)); rank r evaluates proposals [r * c, (r + 1) * c) of a half-step, c = ceil(nwalkers / 2 / world).
+ * ``offset``: constant added to every log-posterior (dl_eval_logposterior of a posterior context marginalised once over linear parameters). */
+typedef struct dl_ensemble dl_ensemble;
+int  dl_ensemble_create(dl_ensemble** out, dl_ctx* ctx, int32_t nwalkers, double a, uint64_t seed, double offset, dl_comm* comm /* may be NULL */);
+void dl_ensemble_destroy(dl_ensemble* ens);
+/* host arrays coords[nwalkers, P], logposterior[nwalkers] (NULL: evaluated at the next dl_ensemble_run); synchronises ``hip_stream`` */
+int  dl_ensemble_set_state(dl_ensemble* ens, const double* coords, const double* logposterior, void* hip_stream);
+/* ``niterations`` ensemble updates, enqueued on ``hip_stream`` (asynchronous).  chain_dev[niterations / thin_by, nwalkers, P] and
+ * chain_logp_dev[niterations / thin_by, nwalkers] (device, caller-owned, either may be NULL) receive the ensemble after every thin_by-th update. */
+int  dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, double* chain_dev, double* chain_logp_dev, void* hip_stream);
+/* host arrays (any may be NULL): current positions, log-posteriors, number of accepted proposals per walker; synchronises ``hip_stream`` */
+int  dl_ensemble_get_state(dl_ensemble* ens, double* coords, double* logposterior, int64_t* naccepted, void* hip_stream);
+/* integer properties: "nwalkers", "n_params", "iteration", "rank", "world", "rows_per_rank" */
+int64_t dl_ensemble_info(const dl_ensemble* ens, const char* key);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,6 @@
 """GPU (-m gpu): BASELINE config 5 geometry -- two tracers, joint covariance, walkers evaluated as one batch; sampler call surface."""
+import os
+
 import numpy as np
 import pytest
 
@@ -25,7 +27,7 @@ def test_two_tracers_vs_reference():
 def test_ensemble_sampler_on_gpu():
     from desilike_amd.samplers import EmceeSampler
     g, like = make_cfg5()
-    sampler = EmceeSampler(like, nwalkers=64, seed=42, use_emcee=False)
+    sampler = EmceeSampler(like, nwalkers=64, seed=42, use_emcee=False, device_resident=False)   # host driver (NumPy stretch move) around the GPU likelihood
     chain = sampler.run(niterations=40)
     assert chain['logposterior'].shape == (40, 64) and np.isfinite(chain['logposterior']).all()
     # the ensemble climbs towards the posterior mode
@@ -71,3 +73,95 @@ def test_sampler_fast_path_matches_call_surface():
     ok = np.isfinite(b)
     assert ok.sum() == 35 and np.array_equal(np.isfinite(a), ok) and np.allclose(a[ok], b[ok], rtol=1e-13, atol=1e-10)
     assert np.isclose(fast.logposterior(values[0]), b[0], rtol=1e-13, atol=1e-10)
+
+
+def test_device_resident_ensemble_matches_numpy_driver():
+    """dl_ensemble_*: proposals, log-posterior, accept / reject and the counter-based generator on the device reproduce, bit for bit, the chain of the NumPy
+    ``EnsembleStretchMove`` driven by the same generator (emcee's stretch move, samplers/emcee.py:69-111; conventions of samplers/base.py:144-200)."""
+    from desilike_amd.samplers import EmceeSampler, EnsembleStretchMove, CounterRNG
+    g, like = make_cfg5()
+    nwalkers, niterations = 64, 30
+    sampler = EmceeSampler(like, nwalkers=nwalkers, seed=42)
+    assert sampler.device_resident
+    start, logp0 = sampler._get_start(nwalkers)
+    chain = sampler.run(niterations=niterations, start=start)
+    chain = sampler.run(niterations=10)                                           # resumes from the device state
+    assert chain['logposterior'].shape == (niterations + 10, nwalkers)
+    host = EnsembleStretchMove(nwalkers, len(like.varied_params), sampler.logposterior, rng=CounterRNG(sampler.counter_seed))
+    coords, logp = start.copy(), sampler.logposterior(start)
+    for it in range(niterations + 10):
+        coords, logp = host.step(coords, logp)
+        got = np.column_stack([chain[param.name][it] for param in like.varied_params])
+        assert np.array_equal(got, coords), it
+        assert np.array_equal(chain['logposterior'][it], logp), it
+    assert np.array_equal(sampler.acceptance_fraction, host.acceptance_fraction)
+    assert 0.1 < sampler.acceptance_fraction.mean() < 0.9
+    # thinning keeps every other ensemble
+    again = EmceeSampler(like, nwalkers=nwalkers, seed=42)
+    thin = again.run(niterations=5, thin_by=2, start=start)
+    assert thin['logposterior'].shape == (5, nwalkers)
+
+
+def test_device_ensemble_out_of_prior_and_nan_start():
+    """Walkers proposed outside the prior are rejected (log-posterior -inf on the device); the chain never leaves the prior."""
+    from desilike_amd.samplers import EmceeSampler
+    g, like = make_cfg5()
+    sampler = EmceeSampler(like, nwalkers=32, seed=3, ref_scale=4.)             # wide start: many proposals land outside qpar / qper limits
+    chain = sampler.run(niterations=50)
+    assert np.isfinite(chain['logposterior']).all()
+    for param in like.varied_params:
+        lo, hi = param.prior.limits
+        assert (chain[param.name] >= lo).all() and (chain[param.name] <= hi).all()
+
+
+def test_rccl_group_single_rank():
+    """dl_comm_*: the RCCL binding of the C ABI with one rank (the multi-rank exchange needs one GPU per rank: the driver's multi-GPU run)."""
+    import torch
+    from desilike_amd.parallel import RcclGroup, WalkerSharding, BucketedAllGather
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29400 + os.getpid() % 500))
+    group = RcclGroup(0, rank=0, world=1)
+    assert group.rccl_version > 20000
+    send = torch.arange(7, dtype=torch.float64, device='cuda:0')
+    recv = torch.zeros(7, dtype=torch.float64, device='cuda:0')
+    group.allgather_into(recv, send)
+    group.barrier()
+    assert torch.equal(recv, send)
+    assert np.array_equal(group.broadcast(np.arange(5.)), np.arange(5.))
+    assert group.max(3.5) == 3.5
+    # sharded log-posterior through the device-resident exchange = the plain host call
+    g, like = make_cfg5()
+    ctx, offset = like._get_posterior_context()
+    rng = np.random.RandomState(3)
+    values = np.column_stack([param.ref.sample(size=37, random_state=rng) for param in like.varied_params])
+    sharding = WalkerSharding(group=group, min_shard_rows=0)
+    sharding.world = 1
+    expected = ctx.eval_logposterior_host(values)[0] + offset
+    assert np.array_equal(sharding.map_logposterior(ctx, values, offset=offset), expected)
+    # the in-place path itself (world forced to look sharded)
+    sharding.sharded = lambda size: True
+    assert np.array_equal(sharding.map_logposterior(ctx, values, offset=offset), expected)
+    # bucketed asynchronous all-gather on the side stream
+    bucket = BucketedAllGather(5, torch.float64, torch.device('cuda:0'), steps_per_bucket=3, group=group, force_collective=True)
+    for step in range(7):
+        bucket.slot().copy_(torch.arange(5, dtype=torch.float64, device='cuda:0') + 10. * step)
+        bucket.advance()
+    out = [t.cpu().numpy() for t in bucket.results()]
+    torch.cuda.synchronize()
+    steps = sorted(int(row[0] // 10) for t in out for row in t[0] if not (row == 0.).all() or True)
+    assert set(range(7)) <= set(steps)
+    group.close()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """``python bench.py --gpus 2`` without a launcher starts its own ranks (host-side gloo exchange because both share this box's single GPU) and reports n_gpus = 2."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DL_BENCH_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '16', '--warmup', '4', '--prewarm-ms', '50', '--config5-iterations', '4'],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['config']['ranks'] == 2 and line['value'] > 0.
+    assert line['config5_strong']['n_gpus'] == 2

@@ -234,3 +234,84 @@ def test_qmc_sampler():
     assert samples['a'].shape == (15,) and np.allclose(np.column_stack([samples['a'], samples['b']]), lower + unit * (upper - lower))
     sobol = QMCSampler(like, engine='sobol', seed=3).run(niterations=8)
     assert sobol['a'].shape == (8,) and (np.abs(sobol['a']) <= upper[0]).all()
+
+
+def test_counter_rng_known_answers():
+    """Philox4x32-10 against the Random123 known-answer vectors; the derived draws."""
+    from desilike_amd.samplers import CounterRNG
+
+    def words(counter, key):
+        return ['{:08x}'.format(int(v)) for v in CounterRNG.philox4x32(np.array([counter], dtype=np.uint32), np.array([key], dtype=np.uint32))[0]]
+
+    assert words([0, 0, 0, 0], [0, 0]) == ['6627e8d5', 'e169c58d', 'bc57ac4c', '9b00dbd8']
+    assert words([0xffffffff] * 4, [0xffffffff] * 2) == ['408f276d', '41c83b0e', 'a20bc7c6', '6d5451fd']
+    assert words([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == ['d16cfe09', '94fdcceb', '5001e420', '24126ea1']
+    rng = CounterRNG(seed=123456789012345)
+    perm = rng.permutation(5, 64)
+    assert sorted(perm) == list(range(64)) and not np.array_equal(perm, rng.permutation(6, 64))
+    u, partner = rng.move(5, 1, 32)
+    assert ((u >= 0.) & (u < 1.)).all() and ((partner >= 0) & (partner < 32)).all()
+    assert np.array_equal(u, CounterRNG(seed=123456789012345).move(5, 1, 32)[0])          # pure function of (seed, iteration, stream, index)
+    big = np.concatenate([rng.accept(it, 0, 512) for it in range(40)])
+    assert abs(big.mean() - 0.5) < 0.01 and abs(big.var() - 1. / 12.) < 0.005
+
+
+def test_stretch_move_counter_rng_recovers_gaussian():
+    from desilike_amd.samplers import BasePosteriorSampler, EnsembleStretchMove, CounterRNG
+    like = ToyGaussianLikelihood()
+    base = BasePosteriorSampler(like, seed=1)
+    sampler = EnsembleStretchMove(20, 2, base.logposterior, rng=CounterRNG(7))
+    start, logp = base._get_start(20)
+    chain = []
+    for it in range(2000):
+        start, logp = sampler.step(start, logp)
+        chain.append(start.copy())
+    samples = np.concatenate(chain[500:])
+    assert np.allclose(samples.mean(axis=0), like.mean, atol=0.03)
+    assert np.allclose(samples.std(axis=0), np.diag(like.cov)**0.5, rtol=0.1)
+
+
+def _unseeded_worker(rank, world, port, results):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from desilike_amd.samplers import EmceeSampler
+    from desilike_amd.parallel import WalkerSharding
+    like = ToyGaussianLikelihood()
+    os.environ['DL_CHECK_SHARDING'] = '1'
+    # no seed (rank 0's entropy is broadcast), then a user generator that differs per rank (rank 0's state is broadcast)
+    chains = []
+    for kwargs in [dict(), dict(rng=np.random.RandomState(100 + rank))]:
+        sampler = EmceeSampler(like, nwalkers=12, use_emcee=False, sharding=WalkerSharding(min_shard_rows=0), **kwargs)
+        sampler.run(niterations=10)
+        chains.append(sampler.chain['a'].copy())
+    results[rank] = chains
+    dist.destroy_process_group()
+
+
+def test_unseeded_samplers_share_one_random_stream_gloo_world2():
+    """with a process group the ranks must propose the same walkers (seed / generator state broadcast from rank 0, samplers/base.py:213-217)."""
+    import torch.multiprocessing as mp
+    manager = mp.Manager()
+    results = manager.dict()
+    port = 35500 + os.getpid() % 2000
+    mp.spawn(_unseeded_worker, args=(2, port, results), nprocs=2, join=True)
+    for a, b in zip(results[0], results[1]):
+        assert np.array_equal(a, b)
+
+
+def test_bench_spawns_its_ranks():
+    """``python bench.py --gpus 2`` with no launcher in the environment starts 2 ranks itself and reports n_gpus = 2 (--dry-run: the part that needs no GPU)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {key: value for key, value in os.environ.items() if key not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [line for line in out.stdout.decode().splitlines() if line.startswith('{')]
+    assert len(lines) == 1                                                      # ONE JSON line, from rank 0
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['ranks'] == 2
+    # under a launcher (WORLD_SIZE set) the process is one rank and spawns nothing
+    env.update(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--dry-run'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0 and json.loads(out.stdout.decode().strip().splitlines()[-1])['n_gpus'] == 1
