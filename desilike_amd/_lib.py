@@ -27,6 +27,7 @@ SYMBOLS = {
     'dl_eval_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_batch_derived': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_logposterior': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_eval_fisher': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_theory': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_batch_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
     'dl_eval_theory_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, ctypes.c_int32, _c_double_p, _c_double_p]),
@@ -285,6 +286,24 @@ class Context(object):
         assert status is None or (status.is_contiguous() and status.dtype == torch.int32 and tuple(status.shape) == (B,))
         self._check(self._lib.dl_eval_logposterior(self._handle, ctypes.c_void_p(theta.data_ptr()), B, ctypes.c_void_p(logposterior.data_ptr()),
                                                    None if status is None else ctypes.c_void_p(status.data_ptr()), ctypes.c_void_p(stream)))
+
+    def eval_fisher(self, centers, steps, hessian=None, gradient=None, offset=None, stream=None):
+        """Fisher algebra on the device (``dl_eval_fisher``): ``centers [B, P]``, ``steps [B, P, 2]`` (lower, upper) -> ``hessian [B, P, P]``, ``gradient [B, P]``,
+        ``offset [B]`` (float64 device tensors, allocated if ``None``); asynchronous on ``stream``."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(centers.device).cuda_stream
+        B, P = centers.shape
+        assert P == self.n_params and centers.is_contiguous() and centers.dtype == torch.float64
+        assert steps.is_contiguous() and steps.dtype == torch.float64 and tuple(steps.shape) == (B, P, 2)
+        if hessian is None: hessian = torch.empty((B, P, P), dtype=torch.float64, device=centers.device)
+        if gradient is None: gradient = torch.empty((B, P), dtype=torch.float64, device=centers.device)
+        if offset is None: offset = torch.empty(B, dtype=torch.float64, device=centers.device)
+        for tensor, shape in [(hessian, (B, P, P)), (gradient, (B, P)), (offset, (B,))]:
+            assert tensor.is_contiguous() and tensor.dtype == torch.float64 and tuple(tensor.shape) == shape
+        self._check(self._lib.dl_eval_fisher(self._handle, ctypes.c_void_p(centers.data_ptr()), ctypes.c_void_p(steps.data_ptr()), B, ctypes.c_void_p(hessian.data_ptr()),
+                                             ctypes.c_void_p(gradient.data_ptr()), ctypes.c_void_p(offset.data_ptr()), ctypes.c_void_p(stream)))
+        return hessian, gradient, offset
 
     def profile_enable(self, every=1):
         """Attach HIP events to the kernels' dispatch packets on one ``eval_batch`` call out of ``every`` (0 / False: off)."""

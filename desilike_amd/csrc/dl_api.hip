@@ -48,6 +48,7 @@ struct dl_ctx {
     double* power_ws = nullptr;      // [cap, K_pad]
     double* delta_ws = nullptr;      // [cap, N_pad]
     double* flat_ws = nullptr;       // [cap, N_pad]  (transform path / flattheory staging)
+    double* stencil_ws = nullptr;    // [cap, n_params] theta rows of the Fisher stencil
     // host staging for the *_host entry points
     int64_t stage_cap = 0;
     double* theta_stage = nullptr;   // device
@@ -355,7 +356,7 @@ void dl_destroy(dl_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     void* ptrs[] = {ctx->arena_dev, ctx->priors_dev, ctx->wt_white_dev, ctx->bias_white_dev, ctx->wt_full_dev, ctx->bias_full_dev, ctx->wh_dev,
-                    ctx->bias_wh_dev, ctx->flatdata_dev, ctx->transform_dev, ctx->tconst_dev, ctx->power_ws, ctx->delta_ws, ctx->flat_ws, ctx->theta_stage, ctx->out_stage,
+                    ctx->bias_wh_dev, ctx->flatdata_dev, ctx->transform_dev, ctx->tconst_dev, ctx->power_ws, ctx->delta_ws, ctx->flat_ws, ctx->stencil_ws, ctx->theta_stage, ctx->out_stage,
                     ctx->status_stage, ctx->gemm_counters};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (double* p : ctx->gfrag_dev) if (p) (void)hipFree(p);
@@ -394,7 +395,7 @@ static int dl_reserve(dl_ctx* ctx, int64_t B) {
     if (need <= ctx->cap) return 0;
     need = std::min<int64_t>(std::max<int64_t>(need, 1024), DL_CHUNK);
     if (ctx->cap > 0) DL_HIP_CHECK(ctx, hipDeviceSynchronize());   // kernels of earlier calls (any stream) may still read the workspaces about to be freed
-    for (double** p : {&ctx->power_ws, &ctx->delta_ws, &ctx->flat_ws, &ctx->feat_ws}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    for (double** p : {&ctx->power_ws, &ctx->delta_ws, &ctx->flat_ws, &ctx->feat_ws, &ctx->stencil_ws}) if (*p) { (void)hipFree(*p); *p = nullptr; }
     ctx->cap = 0;
     const size_t R = 1 + ctx->n_var;   // rows per point: power + point-dependent derivative rows (analytic marginalisation)
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->power_ws, (size_t)need * R * ctx->K_pad * sizeof(double)));
@@ -402,6 +403,7 @@ static int dl_reserve(dl_ctx* ctx, int64_t B) {
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->delta_ws, std::max<size_t>(2 * (size_t)need * R, (size_t)need * R + 16384 + 2048) * ctx->N_pad * sizeof(double)));
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->flat_ws, (size_t)need * ctx->N_pad * sizeof(double)));
     if (ctx->feat_ok) DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->feat_ws, (size_t)need * ctx->feat_ld * sizeof(double)));
+    DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->stencil_ws, (size_t)need * ctx->n_params * sizeof(double)));
     // the K padding columns of the power buffer are never written by the theory kernel and must be finite
     DL_HIP_CHECK(ctx, hipMemset(ctx->power_ws, 0, (size_t)need * R * ctx->K_pad * sizeof(double)));
     ctx->cap = need;
@@ -532,6 +534,59 @@ int dl_eval_batch_derived(dl_ctx* ctx, const double* theta_dev, int64_t B, doubl
 int dl_eval_logposterior(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logposterior_dev, int32_t* status_dev, void* hip_stream) {
     if (ctx && B > 0 && !logposterior_dev) return dl_fail(ctx, "dl_eval_logposterior: null output");
     return dl_eval_impl(ctx, theta_dev, B, logposterior_dev, nullptr, nullptr, status_dev, nullptr, hip_stream, 1);
+}
+
+int dl_eval_fisher(dl_ctx* ctx, const double* centers_dev, const double* steps_dev, int64_t B, double* hessian_dev, double* gradient_dev, double* offset_dev, void* hip_stream) {
+    if (!ctx) { g_last_error = "dl_eval_fisher: null context"; return 1; }
+    if (B < 0 || (B > 0 && (!centers_dev || !steps_dev))) return dl_fail(ctx, "dl_eval_fisher: invalid argument");
+    if (ctx->n_solved > 0) return dl_fail(ctx, "dl_eval_fisher: the context has analytically solved parameters: create it with these parameters varied (the reference does the same, fisher.py:688-695)");
+    const int P = ctx->n_params, n = ctx->n_data, S = 1 + 2 * P;
+    if (P > 31) return dl_fail(ctx, "dl_eval_fisher: at most 31 varied parameters");
+    if (dl_fisher_waves(n, P, nullptr) < 1) return dl_fail(ctx, "dl_eval_fisher: data vector too long for the LDS-resident Gram product");
+    if (B == 0) return 0;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    dl_prof_events.start = dl_prof_events.stop = nullptr;
+    DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (dl_order_streams(ctx, stream)) return 1;
+    const int64_t per_pass = std::max<int64_t>(1, DL_CHUNK / S);   // centres per internal pass (stencil rows <= DL_CHUNK)
+    if (dl_reserve(ctx, std::min<int64_t>(B, per_pass) * S)) return 1;
+    for (int64_t b0 = 0; b0 < B; b0 += per_pass) {
+        const int64_t nc = std::min<int64_t>(per_pass, B - b0), nb = nc * S;
+        const double* steps = steps_dev + (size_t)b0 * P * 2;
+        dl_launch_fisher_stencil(centers_dev + (size_t)b0 * P, steps, P, nc, ctx->stencil_ws, stream);
+        const double* th = ctx->stencil_ws;
+        int n_slabs = 1, cps = 0;
+        int64_t slab_stride = 0;
+        const double* bias = nullptr;
+        static const bool emu_fused = !getenv("DL_NO_EMU_FUSED");
+        if (ctx->feat_ok) {
+            // emulated (separable) theories: residual rows straight from the feature GEMM
+            if (!emu_fused) dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, ctx->feat_ws, ctx->feat_ld, 0);
+            for (int i = 0; i < ctx->n_obs; ++i) {
+                if (emu_fused) dl_launch_emulated_feature(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, stream);
+                else dl_launch_feature_gemm(ctx->feat_ws, ctx->feat_ld, ctx->obs_kernarg[i].feat_off, ctx->obs_kernarg[i].nb_pad, 1, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad,
+                                            ctx->N_pad, nb, i > 0, stream);
+            }
+            bias = ctx->bias_white_dev;
+        } else {
+            dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, nullptr, 0, 0);
+            if (ctx->any_transform) {
+                // flattheory -> observable transform -> whitened residual (bias added by the direct GEMM)
+                dl_launch_window_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_full_dev, ctx->K_pad, ctx->bias_full_dev, ctx->flat_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad, ctx->K_pad, 1, stream);
+                dl_launch_transform(ctx->flat_ws, ctx->N_pad, ctx->flatdata_dev, ctx->transform_dev, n, nb, stream);
+                dl_launch_window_gemm(ctx->flat_ws, ctx->N_pad, ctx->wh_dev, ctx->N_pad, ctx->bias_wh_dev, ctx->delta_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad, ctx->N_pad, 1, stream);
+            } else {
+                n_slabs = dl_gemm_tiled_splits(nb, ctx->N_pad, ctx->K_pad, &cps);
+                slab_stride = (int64_t)nb * ctx->N_pad;
+                bias = ctx->bias_white_dev;
+                dl_launch_window_gemm_tiled(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->delta_ws, slab_stride, ctx->N_pad, nb, ctx->N_pad, ctx->K_pad, n_slabs, cps, stream);
+            }
+        }
+        dl_launch_fisher(ctx->delta_ws, ctx->N_pad, n, n_slabs, slab_stride, bias, steps, P, nc, hessian_dev ? hessian_dev + (size_t)b0 * P * P : nullptr,
+                         gradient_dev ? gradient_dev + (size_t)b0 * P : nullptr, offset_dev ? offset_dev + b0 : nullptr, stream);
+    }
+    DL_HIP_CHECK(ctx, hipGetLastError());
+    return 0;
 }
 
 int dl_eval_theory(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs, double* power_dev, double* tables_dev, void* hip_stream) {

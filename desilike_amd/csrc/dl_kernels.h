@@ -69,5 +69,10 @@ void dl_launch_window_gemm_dma_chi2(const double* A, int64_t lda, const double* 
 // emulated theories, fused: emulator forward pass (MFMA) and feature GEMM of one observable in one launch (dl_emu_batch.h)
 void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
                                 hipStream_t stream);
+// Fisher algebra (dl_fisher.hip): stencil rows of theta, then per centre the Gram matrix of [residual; derivative rows]
+void dl_launch_fisher_stencil(const double* centers, const double* steps, int P, int64_t B, double* theta, hipStream_t stream);
+int dl_fisher_waves(int n, int P, size_t* shm_bytes);   // centres per workgroup (0: too large for the LDS)
+void dl_launch_fisher(const double* rows, int64_t ld, int n, int n_slabs, int64_t slab_stride, const double* bias, const double* steps, int P, int64_t B, double* hessian,
+                      double* gradient, double* offset, hipStream_t stream);
 // last-error string of the C ABI (thread-local, read by dl_last_error(NULL)); set by translation units other than dl_api.hip
 void dl_set_last_error(const char* msg);

@@ -1,10 +1,10 @@
 """Fisher matrix of a Gaussian likelihood (reference: desilike/fisher.py:642-809, 63-640; differentiation.py).
 
 ``Fisher(likelihood)(**center)`` evaluates the theory vector on the whole finite-difference stencil of the varied parameters as ONE GPU
-batch (the reference's ``Differentiation`` scatters the stencil points over MPI ranks, differentiation.py:394-398), forms
-``d(flatdiff)/d(theta)`` by central differences of step ``Parameter.delta`` and applies the reference's Gaussian finalisation
-(fisher.py:731-750): ``hessian = -dD P dD^T``, ``gradient = -dD P D``, ``offset = -D P D`` (no 1/2, as in the reference, line 746),
-plus the Gaussian prior terms (fisher.py:706-716).  The P x P algebra is init-time scale and stays on the host.
+batch (the reference's ``Differentiation`` scatters the stencil points over MPI ranks, differentiation.py:394-398) and ``dl_eval_fisher``
+(csrc/dl_fisher.hip) forms ``d(flatdiff)/d(theta)`` by central differences of step ``Parameter.delta`` and the reference's Gaussian finalisation
+(fisher.py:731-750) on the device: ``hessian = -dD P dD^T``, ``gradient = -dD P D``, ``offset = -D P D`` (no 1/2, as in the reference, line 746).
+The host adds the Gaussian prior terms (fisher.py:706-716) and keeps the P x P ``LikelihoodFisher`` algebra (216-257).
 """
 import numpy as np
 
@@ -70,42 +70,62 @@ class FisherGaussianLikelihood(object):
 
 
 class Fisher(object):
-    """Estimate the Fisher matrix of ``likelihood`` (a Gaussian likelihood of this package) by finite differences on the GPU."""
+    """Estimate the Fisher matrix of ``likelihood`` (a Gaussian likelihood of this package) by finite differences, entirely on the GPU: the stencil of all
+    centres goes through the theory kernels and the whitened window GEMM as one batch and ``dl_eval_fisher`` forms ``offset``, ``gradient`` and ``hessian``
+    (fisher.py:739-748) with an fp64 MFMA Gram product per centre.
 
-    def __init__(self, likelihood):
+    Analytically solved parameters ('.marg' / '.best' / '.auto' / '.prec') are VARIED, as in the reference, which warns and works on a copy of the likelihood with
+    ``derived=False`` for them (fisher.py:688-695)."""
+
+    def __init__(self, likelihood, delta_scale=1.):
         self.likelihood = likelihood
-        self.varied_params = likelihood.varied_params
-        if len(likelihood.solved_params):
-            raise NotImplementedError('Fisher with analytically solved parameters: vary them instead (they are linear)')
+        likelihood.initialize()
+        self.delta_scale = float(delta_scale)
+        solved = [param for param in likelihood.all_params if param.solved]
+        if solved:
+            import warnings
+            warnings.warn('solved parameters: {}; cannot proceed with solved parameters, so they are varied in the Fisher estimate'.format([param.name for param in solved]))
+        from .parameter import ParameterCollection
+        self.varied_params = ParameterCollection(list(likelihood.varied_params) + solved)
+        self._solved_names = [param.name for param in solved]
+        self._ctx = None
+
+    def _get_context(self):
+        if self._ctx is None:
+            like = self.likelihood
+            if self._solved_names:
+                from ._lib import Context
+                self._ctx = Context(like._spec({}, like._flatdata_list(), like._precision_input, vary_solved=True), device=like.device)
+            else:
+                self._ctx = like._get_context()
+        return self._ctx
+
+    def steps(self, centers):
+        """Lower / upper finite-difference steps ``[B, P, 2]`` at ``centers [B, P]``: ``Parameter.delta`` = (value, step below, step above) (parameter.py:898-915)
+        scaled by ``delta_scale``, shortened where a prior bound is closer."""
+        centers = np.atleast_2d(centers)
+        steps = np.empty(centers.shape + (2,), dtype='f8')
+        for ip, param in enumerate(self.varied_params):
+            _, lower, upper = param.delta
+            steps[:, ip, 0] = np.minimum(lower * self.delta_scale, centers[:, ip] - param.prior.limits[0])
+            steps[:, ip, 1] = np.minimum(upper * self.delta_scale, param.prior.limits[1] - centers[:, ip])
+        if not (steps.sum(axis=-1) > 0.).all():
+            raise ValueError('zero finite-difference interval: a centre sits on both prior bounds of a parameter')
+        return np.clip(steps, 0., None)
+
+    def evaluate(self, centers):
+        """``centers [B, P]`` (columns ordered as :attr:`varied_params`) -> (offset [B], gradient [B, P], hessian [B, P, P]) of the likelihood term, one GPU batch."""
+        import torch
+        centers = np.ascontiguousarray(np.atleast_2d(centers), dtype='f8')
+        ctx = self._get_context()
+        device = torch.device('cuda', ctx.device)
+        hessian, gradient, offset = ctx.eval_fisher(torch.as_tensor(centers, device=device), torch.as_tensor(self.steps(centers), device=device).contiguous())
+        return offset.cpu().numpy(), gradient.cpu().numpy(), hessian.cpu().numpy()
 
     def __call__(self, **params):
-        like = self.likelihood
-        like.initialize()
         varied = self.varied_params
         center = np.array([params.get(param.name, param.value) for param in varied], dtype='f8')
-        steps = []
-        for param in varied:   # Parameter.delta = (value, step below, step above), parameter.py:898-915; limited by the prior bounds
-            _, lower, upper = param.delta
-            lower = min(lower, params.get(param.name, param.value) - param.prior.limits[0])
-            upper = min(upper, param.prior.limits[1] - params.get(param.name, param.value))
-            steps.append((lower, upper))
-        nvar = len(varied)
-        points = np.repeat(center[None, :], 2 * nvar + 1, axis=0)
-        for i, (lower, upper) in enumerate(steps):
-            points[1 + 2 * i, i] -= lower
-            points[2 + 2 * i, i] += upper
-        ctx = like._get_context()
-        loglike, logprior, status, flat = ctx.eval_batch_host(points, return_flattheory=True)   # one batch for the whole stencil
-        flatdiff = flat[0] - like.flatdata                                                       # likelihoods/base.py:659
-        flatderiv = np.array([(flat[2 + 2 * i] - flat[1 + 2 * i]) / (steps[i][0] + steps[i][1]) for i in range(nvar)])
-        precision = like.precision
-        if precision.ndim == 1:
-            diffp, derivp = flatdiff * precision, flatderiv * precision
-        else:
-            diffp, derivp = flatdiff.dot(precision), flatderiv.dot(precision)
-        offset = -diffp.dot(flatdiff.T)            # fisher.py:746 (no 1/2: reproduced as is)
-        gradient = -derivp.dot(flatdiff.T)         # fisher.py:747
-        hessian = -derivp.dot(flatderiv.T)         # fisher.py:748
+        offset, gradient, hessian = (array[0] for array in self.evaluate(center[None, :]))
         likelihood_fisher = LikelihoodFisher(center, varied, offset=offset, gradient=gradient, hessian=hessian)
         # Gaussian priors (fisher.py:706-716)
         poffset, pgradient, phessian = 0., [], []
@@ -116,7 +136,6 @@ class Fisher(object):
             pgradient.append(-(value - loc) * prec)
             phessian.append(-prec)
         prior_fisher = LikelihoodFisher(center, varied, offset=poffset, gradient=pgradient, hessian=np.diag(phessian), with_prior=True)
-        self.flatderiv, self.flatdiff = flatderiv, flatdiff
         self.likelihood_fisher, self.prior_fisher = likelihood_fisher, prior_fisher
         return likelihood_fisher + prior_fisher
 

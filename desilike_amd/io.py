@@ -1,0 +1,275 @@
+"""On-disk formats at the edges of the hot path.
+
+* **Chains** -- exactly the files ``desilike.samples.Chain.save`` writes (parameter.py:2164-2182 for ``.npz`` / ``.npy``; state layout parameter.py:612-616,
+  923-933, 1338-1344, 2057-2061; chain attributes samples/chain.py:96-97), so that chains produced here are read by the reference's post-processing:
+  ``.npz`` keys ``__class__`` (``('desilike.samples.chain.Chain',)``), ``others`` (dict: ``attrs``, ``_derived``, ``_logposterior`` ...), ``params`` (list of
+  ``{'param': <Parameter state>, 'derivs': None | [ {name: order}, ... ]}``), ``data.<i>`` (arrays, derivatives along the LAST axis).
+  The derived ``loglikelihood`` / ``logprior`` of an analytically marginalised fit carry the Hessian w.r.t. the solved parameters as derivatives
+  ``[(), (p1, p1), (p1, p2), ...]`` (upper triangle, row-major: likelihoods/base.py:342-351, 372, 388-390, 409-411), which ``Chain.sample_solved``
+  (samples/chain.py:229-263) consumes.  Validated in the build container by ``tests/golden/validate_chain_io.py`` (the reference loads files written here
+  and runs ``sample_solved`` on them; outputs committed as fixtures).
+* **Window / data / covariance arrays** -- array-level containers (``.npz``) holding what ``WindowedPowerSpectrumMultipoles`` needs
+  (``matrix [n_out, n_ellin * n_kin]``, ``kin``, ``ellsin``, ``k`` per multipole, ``ells``, optional ``wshotnoise``), and a reader of pypower's legacy
+  ``BaseMatrix`` ``.npy`` state (the format window.py:325-334 loads through pypower; restated from pypower's published ``__getstate__`` layout --
+  pypower is absent here: unpinned).  lsstypes objects are not read (third-party container, absent).
+"""
+import os
+
+import numpy as np
+
+from .parameter import Parameter, ParameterCollection, Samples
+
+CHAIN_CLASS = ('desilike.samples.chain.Chain',)
+_CHAIN_NAMES = dict(_logposterior='logposterior', _loglikelihood='loglikelihood', _logprior='logprior', _aweight='aweight', _fweight='fweight', _weight='weight')
+
+
+def solved_derivs(solved_names):
+    """Derivative keys of the loglikelihood / logprior arrays of a marginalised fit: zero lag, then the upper triangle of the Hessian w.r.t. the solved
+    parameters, row-major (likelihoods/base.py:342-351)."""
+    derivs = [()]
+    for i1, p1 in enumerate(solved_names):
+        for p2 in solved_names[i1:]:
+            derivs.append((p1, p2))
+    return derivs
+
+
+def pack_hessian(value, hessian):
+    """``value [...]``, ``hessian [..., n_s, n_s]`` -> ``[..., 1 + n_s (n_s + 1) / 2]``: the array layout of ``ParameterArray(value, derivs=solved_derivs(...))``
+    (``jnp.insert(hessian[derivs_indices], 0, value)``, likelihoods/base.py:372, 389)."""
+    value, hessian = np.asarray(value, dtype='f8'), np.asarray(hessian, dtype='f8')
+    iu = np.triu_indices(hessian.shape[-1])
+    return np.concatenate([value[..., None], hessian[..., iu[0], iu[1]]], axis=-1)
+
+
+def unpack_hessian(array, n_solved):
+    """Inverse of :func:`pack_hessian`: (value [...], symmetric hessian [..., n_s, n_s])."""
+    array = np.asarray(array)
+    iu = np.triu_indices(n_solved)
+    hessian = np.zeros(array.shape[:-1] + (n_solved, n_solved), dtype='f8')
+    hessian[..., iu[0], iu[1]] = array[..., 1:]
+    hessian[..., iu[1], iu[0]] = array[..., 1:]
+    return array[..., 0], hessian
+
+
+def _deriv_state(deriv):
+    """(p1, p2) -> {'p1': 1, 'p2': 1} / {'p1': 2}: the dict form of the reference's ``Deriv`` (parameter.py:204-251, saved by 615)."""
+    state = {}
+    for name in deriv:
+        state[str(name)] = state.get(str(name), 0) + 1
+    return state
+
+
+def parameter_state(param, derived=None):
+    """State dict of a parameter as the reference's ``Parameter.__getstate__`` writes it (parameter.py:923-933: ``_attrs`` of line 658 without 'depends', + 'updated')."""
+    if not isinstance(param, Parameter):
+        param = Parameter(str(param), derived=True if derived is None else derived)
+    state = param.__getstate__()
+    value = state['value']
+    out = {'basename': state['basename'], 'namespace': state['namespace'] or '', 'value': param.value if value is None and not param.derived else value,
+           'fixed': bool(state['fixed']), 'derived': state['derived'] if derived is None else derived, 'prior': dict(state['prior']), 'ref': dict(state['ref']),
+           'proposal': state['proposal'], 'delta': state['delta'], 'latex': state['latex'], 'shape': (), 'drop': False, 'updated': True}
+    for key in ('prior', 'ref'):
+        out[key]['limits'] = tuple(float(lim) for lim in out[key]['limits'])
+    return out
+
+
+class ChainFile(object):
+    """One chain as name -> array (derivatives, if any, along the last axis), with parameter states and derivative keys.
+
+    ``arrays``: ordered dict name -> array ``[ashape..., (n_derivs)]``; ``params``: name -> :class:`Parameter` (missing names become derived parameters);
+    ``derivs``: name -> list of tuples (e.g. :func:`solved_derivs`) for arrays that carry derivatives."""
+
+    def __init__(self, arrays, params=None, derivs=None, attrs=None):
+        self.arrays = {str(name): np.asarray(value) for name, value in arrays.items()}
+        params = params or {}
+        if isinstance(params, (ParameterCollection, list, tuple)):
+            params = {str(param): param for param in params}
+        self.params = {str(name): param for name, param in params.items()}
+        self.derivs = {str(name): [tuple(deriv) for deriv in value] for name, value in (derivs or {}).items()}
+        self.attrs = dict(attrs or {})
+
+    @classmethod
+    def from_sampler(cls, sampler, derived=None):
+        """Chain of an :class:`~desilike_amd.samplers.EmceeSampler` run (``sampler.chain``: name -> [niterations, nwalkers]); ``derived``: optional output of
+        ``vmap(likelihood, return_derived=True)`` on the chain's points (solved parameters, loglikelihood / logprior with their Hessian entries)."""
+        arrays = dict(sampler.chain)
+        params = {param.name: param for param in sampler.varied_params}
+        derivs = {}
+        if derived is not None:
+            arrays.update(derived.arrays if isinstance(derived, ChainFile) else derived)
+            if isinstance(derived, ChainFile):
+                params.update(derived.params); derivs.update(derived.derivs)
+        return cls(arrays, params=params, derivs=derivs)
+
+    @property
+    def shape(self):
+        for name, value in self.arrays.items():
+            return value.shape[:value.ndim - (1 if name in self.derivs else 0)]
+        return ()
+
+    def state(self):
+        """The reference's ``Chain.__getstate__`` (parameter.py:1338-1344 + 612-616)."""
+        data, derived_names = [], []
+        for name, value in self.arrays.items():
+            param = self.params.get(name, None)
+            is_output = name in _CHAIN_NAMES.values() or param is None
+            pstate = parameter_state(param if param is not None else name, derived=True if is_output else None)
+            derivs = self.derivs.get(name, None)
+            data.append({'value': np.asarray(value), 'param': pstate, 'derivs': None if derivs is None else [_deriv_state(deriv) for deriv in derivs]})
+        state = {'data': data, 'attrs': dict(self.attrs), '_derived': derived_names}
+        state.update(_CHAIN_NAMES)
+        return state
+
+    def save(self, filename):
+        """Write ``.npz`` (one array per parameter, metadata pickled: parameter.py:2172-2180) or ``.npy`` (whole state pickled: 2181-2182)."""
+        filename = str(filename)
+        dirname = os.path.dirname(filename)
+        if dirname: os.makedirs(dirname, exist_ok=True)
+        state = {'__class__': CHAIN_CLASS, **self.state()}
+        if filename.endswith('.npz'):
+            others = {key: value for key, value in state.items() if key not in ('data', '__class__')}
+            statez = {'others': others, '__class__': state['__class__'], 'params': []}
+            for iarray, array in enumerate(state['data']):
+                statez['data.{:d}'.format(iarray)] = array['value']
+                statez['params'].append({key: value for key, value in array.items() if key != 'value'})
+            np.savez(filename, **statez)
+        else:
+            np.save(filename, state, allow_pickle=True)
+
+    @classmethod
+    def load(cls, filename):
+        """Read a chain written by :meth:`save` or by the reference (parameter.py:2184-2202)."""
+        filename = str(filename)
+        raw = np.load(filename, allow_pickle=True)
+        if filename.endswith('.npz'):
+            raw = dict(raw)
+            meta = raw.pop('params')[()]
+            data = [{**param, 'value': raw.pop('data.{:d}'.format(iarray))} for iarray, param in enumerate(meta)]
+            others = dict(raw['others'][()]) if 'others' in raw else {name: value[()] for name, value in raw.items() if name != '__class__'}
+        else:
+            state = dict(raw[()])
+            data = state.pop('data')
+            others = state
+        arrays, params, derivs = {}, {}, {}
+        for item in data:
+            pstate = dict(item['param'])
+            for key in ('shape', 'drop', 'updated', 'saved', 'depends'):
+                pstate.pop(key, None)
+            derived = pstate.get('derived', False)
+            if isinstance(derived, str) and not derived.startswith('.'):
+                pstate['derived'] = True     # defined by an expression in the reference: an output here
+            param = Parameter(**pstate)
+            arrays[param.name] = np.asarray(item['value'])
+            params[param.name] = param
+            if item.get('derivs', None) is not None:
+                derivs[param.name] = [tuple(sorted(name for name, order in dict(deriv).items() for _ in range(int(order)))) for deriv in item['derivs']]
+        return cls(arrays, params=params, derivs=derivs, attrs=others.get('attrs', {}))
+
+    def to_samples(self):
+        """:class:`Samples` of the zero-lag values (derivative axes dropped)."""
+        samples = Samples()
+        for name, value in self.arrays.items():
+            samples[name] = value[..., 0] if name in self.derivs else value
+        return samples
+
+
+def derived_for_chain(likelihood, chain):
+    """Derived outputs of ``likelihood`` on the points of ``chain`` (name -> [...]) in the reference's layout: solved parameters, ``loglikelihood`` and
+    ``logprior`` arrays with the Hessian entries w.r.t. the solved parameters along the last axis (likelihoods/base.py:361-411) -- ONE GPU batch
+    (``dl_eval_batch_derived``).  Returns a :class:`ChainFile` fragment to merge into the chain."""
+    from .base import vmap
+    varied = likelihood.varied_params
+    shape = np.shape(chain[varied.names()[0]])
+    points = {name: np.ravel(chain[name]) for name in varied.names()}
+    (logposterior, derived), errors = vmap(likelihood, errors='return', return_derived=True)(points)
+    solved = likelihood.solved_params
+    names = solved.names()
+    arrays, params, derivs = {}, {}, {}
+    for param in solved:
+        arrays[param.name] = np.asarray(derived[param]).reshape(shape)
+        params[param.name] = param
+    ll_name, lp_name = str(likelihood._param_loglikelihood), str(likelihood._param_logprior)
+    if names and '{}.{}.{}'.format(ll_name, names[0], names[0]) in derived:
+        ns = len(names)
+        for name in (ll_name, lp_name):
+            hessian = np.zeros(shape + (ns, ns), dtype='f8')
+            for i1, p1 in enumerate(names):
+                for i2, p2 in enumerate(names):
+                    key = '{}.{}.{}'.format(name, *((p1, p2) if i1 <= i2 else (p2, p1)))
+                    if key in derived: hessian[..., i1, i2] = np.asarray(derived[key]).reshape(shape)
+            arrays[name] = pack_hessian(np.asarray(derived[name]).reshape(shape), hessian)
+            derivs[name] = solved_derivs(names)
+    else:
+        for name in (ll_name, lp_name):
+            arrays[name] = np.asarray(derived[name]).reshape(shape)
+    return ChainFile(arrays, params=params, derivs=derivs)
+
+
+# ---- window / data arrays -----------------------------------------------------------------------------------------------------------------
+
+def save_window(filename, matrix, kin, ellsin, k, ells, wshotnoise=None):
+    """Array-level window container (``.npz``): ``matrix [sum_l len(k_l), len(ellsin) * len(kin)]`` (rows: output multipoles concatenated), ``kin``, ``ellsin``,
+    ``k`` (one array per output multipole), ``ells``, optional ``wshotnoise`` (response of the window to a constant, window.py:451-457)."""
+    payload = dict(matrix=np.asarray(matrix, dtype='f8'), kin=np.asarray(kin, dtype='f8'), ellsin=np.asarray(ellsin, dtype='i8'), ells=np.asarray(ells, dtype='i8'))
+    for ill, kk in enumerate(k):
+        payload['k.{:d}'.format(ill)] = np.asarray(kk, dtype='f8')
+    if wshotnoise is not None: payload['wshotnoise'] = np.asarray(wshotnoise, dtype='f8')
+    np.savez(filename, **payload)
+
+
+def _legacy_matrix_state(state):
+    """pypower ``BaseMatrix`` state (``.npy``: value [n_in, n_out], xin / xout lists per projection, projsin / projsout as dicts with 'ell', 'wa_order') ->
+    window arrays.  pypower is absent from this image: layout restated from its published ``__getstate__`` (unpinned)."""
+    value = np.asarray(state['value'], dtype='f8')
+    xin, xout = [np.asarray(x, dtype='f8') for x in state['xin']], [np.asarray(x, dtype='f8') for x in state['xout']]
+
+    def ell_of(proj):
+        return int(proj['ell'] if isinstance(proj, dict) else getattr(proj, 'ell'))
+
+    keep_in = [i for i, proj in enumerate(state['projsin']) if (proj.get('wa_order', None) if isinstance(proj, dict) else getattr(proj, 'wa_order', None)) in (None, 0)]
+    if not all(np.allclose(xin[i], xin[keep_in[0]]) for i in keep_in):
+        raise ValueError('input coordinates of the window differ between multipoles: rebin them to one grid first')
+    starts = np.concatenate([[0], np.cumsum([x.size for x in xin])])
+    rows = np.concatenate([np.arange(starts[i], starts[i + 1]) for i in keep_in])
+    out = dict(matrix=value[rows].T, kin=xin[keep_in[0]], ellsin=[ell_of(state['projsin'][i]) for i in keep_in], k=xout, ells=[ell_of(proj) for proj in state['projsout']])
+    vector = state.get('vectorout', None)
+    if vector is not None: out['wshotnoise'] = np.concatenate([np.asarray(v, dtype='f8') for v in vector])
+    return out
+
+
+def load_window(filename):
+    """Window arrays from :func:`save_window` files (``.npz``) or a pypower ``BaseMatrix`` state (``.npy``); returns the keyword arguments
+    ``WindowedPowerSpectrumMultipoles`` takes for a dense matrix: ``wmatrix``, ``kin``, ``ellsin``, ``k``, ``ells`` (+ ``wshotnoise``)."""
+    filename = str(filename)
+    if filename.endswith('.npy'):
+        state = np.load(filename, allow_pickle=True)[()]
+        if 'poles' in state: state = state['poles']
+        arrays = _legacy_matrix_state(state)
+    else:
+        raw = np.load(filename, allow_pickle=False)
+        arrays = dict(matrix=raw['matrix'], kin=raw['kin'], ellsin=raw['ellsin'].tolist(), ells=raw['ells'].tolist(), k=[raw['k.{:d}'.format(ill)] for ill in range(len(raw['ells']))])
+        if 'wshotnoise' in raw: arrays['wshotnoise'] = raw['wshotnoise']
+    kwargs = dict(wmatrix=np.asarray(arrays['matrix'], dtype='f8'), kin=np.asarray(arrays['kin'], dtype='f8'), ellsin=tuple(int(ell) for ell in arrays['ellsin']),
+                  k=[np.asarray(kk, dtype='f8') for kk in arrays['k']], ells=tuple(int(ell) for ell in arrays['ells']))
+    if arrays.get('wshotnoise', None) is not None: kwargs['wshotnoise'] = np.asarray(arrays['wshotnoise'], dtype='f8')
+    return kwargs
+
+
+def save_data(filename, k, ells, data, covariance=None, shotnoise=None):
+    """Measurement container (``.npz``): ``data`` flat (multipoles concatenated), ``k`` per multipole, optional ``covariance [n, n]`` and ``shotnoise``."""
+    payload = dict(ells=np.asarray(ells, dtype='i8'), data=np.ravel(np.asarray(data, dtype='f8')))
+    for ill, kk in enumerate(k):
+        payload['k.{:d}'.format(ill)] = np.asarray(kk, dtype='f8')
+    if covariance is not None: payload['covariance'] = np.asarray(covariance, dtype='f8')
+    if shotnoise is not None: payload['shotnoise'] = np.array(float(shotnoise))
+    np.savez(filename, **payload)
+
+
+def load_data(filename):
+    """Keyword arguments of ``TracerPowerSpectrumMultipolesObservable`` from a :func:`save_data` file: ``data``, ``k``, ``ells`` (+ ``covariance``, ``shotnoise``)."""
+    raw = np.load(str(filename), allow_pickle=False)
+    ells = tuple(int(ell) for ell in raw['ells'])
+    kwargs = dict(data=raw['data'], k=[raw['k.{:d}'.format(ill)] for ill in range(len(ells))], ells=ells)
+    if 'covariance' in raw: kwargs['covariance'] = raw['covariance']
+    if 'shotnoise' in raw: kwargs['shotnoise'] = float(raw['shotnoise'])
+    return kwargs

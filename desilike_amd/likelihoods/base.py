@@ -199,10 +199,14 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             device = int(os.environ.get('LOCAL_RANK', 0))
         return int(device)
 
-    def _spec(self, fixed_values, flatdata_list, precision, drop_solved=False):
+    def _spec(self, fixed_values, flatdata_list, precision, drop_solved=False, vary_solved=False):
         """Nested likelihood spec flattened by ``_lib.fill_config`` into the C-ABI config keys (include/desilike_amd.h).
-        ``drop_solved``: analytically solved parameters are treated as fixed (at ``fixed_values`` or their default value)."""
+        ``drop_solved``: analytically solved parameters are treated as fixed (at ``fixed_values`` or their default value);
+        ``vary_solved``: they (and '.prec' parameters) become sampled parameters, appended to the theta columns (Fisher, fisher.py:688-695)."""
         varied = self.varied_params
+        if vary_solved:
+            varied = ParameterCollection(list(varied) + [param for param in self.all_params if param.solved])
+            drop_solved = True
         names = varied.names()
         solved = ParameterCollection() if drop_solved else self.solved_params
         solved_names = solved.names()

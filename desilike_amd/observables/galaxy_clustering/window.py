@@ -4,6 +4,8 @@ Init-time only: builds ``kin``, ``ellsin``, ``matrix_full`` (binning matrix ``wi
 user-provided dense matrix 307-321), ``kmask`` (297-305) and the shot-noise bookkeeping (445-457).  The product
 ``W . (power + sn_in) + offset - sn_out`` (459-473) for a batch is the fp64 MFMA GEMM ``dl_window_gemm``.
 """
+import os
+
 import numpy as np
 
 from ...base import BaseCalculator
@@ -132,6 +134,16 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
         wmatrix, kin, kinrebin, kinlim, ellsin = init.get('wmatrix', None), init.get('kin', None), init.get('kinrebin', 1), init.get('kinlim', None), init.get('ellsin', None)
         shotnoise, wshotnoise = init.get('shotnoise', None), init.get('wshotnoise', None)
         fiber_collisions, systematic_templates = init.get('fiber_collisions', None), init.get('systematic_templates', None)
+        if isinstance(wmatrix, (str, os.PathLike)):
+            # window matrix from a file (window.py:325-334): array-level containers, see desilike_amd/io.py (lsstypes / pypower objects themselves are not read)
+            from ... import io
+            loaded = io.load_window(wmatrix)
+            wmatrix = loaded.pop('wmatrix')
+            if kin is None: kin = loaded['kin']
+            if ellsin is None: ellsin = loaded['ellsin']
+            if wshotnoise is None: wshotnoise = loaded.get('wshotnoise', None)
+            for key in ('k', 'ells'):
+                if init.get(key, None) is None and init.get('kedges', None) is None and init.get('klim', None) is None: init[key] = loaded[key]
         # output binning (window.py:214-292): rules in _binning.MultipoleBins
         bins = MultipoleBins.resolve(x=init.get('k', None), edges=init.get('kedges', None), lim=init.get('klim', None), ells=init.get('ells', None),
                                      default_step=0.01, default_edges=np.arange(0.005, 0.21, 0.01), label='k')
@@ -163,7 +175,7 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
             blocks = matrix_full.reshape(matrix_full.shape[0], len(self.ellsin), kin_given.size)
             self.matrix_full = np.einsum('oli,ki->olk', blocks, rebin).reshape(matrix_full.shape[0], -1)
         else:
-            raise NotImplementedError('window matrices from files / lsstypes / pypower objects are out of scope: pass a 2D array with kin and ellsin')
+            raise NotImplementedError('lsstypes / pypower window objects are not read: pass a 2D array with kin and ellsin, or a file written by desilike_amd.io.save_window')
         if fiber_collisions is not None:   # window.py:428-438: kernels folded into the matrix / offset
             self.theory.init.update(k=self.kin, ells=self.ellsin)
             fiber_collisions.init.update(k=self.kin, ells=self.ellsin, theory=self.theory)

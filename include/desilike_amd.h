@@ -139,6 +139,14 @@ int  dl_eval_batch_derived(dl_ctx* ctx, const double* theta_dev, int64_t B, doub
  * separate addition.  Asynchronous on ``hip_stream``. */
 int  dl_eval_logposterior(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logposterior_dev, int32_t* status_dev, void* hip_stream);
 
+/* Fisher algebra of the Gaussian likelihood (desilike/fisher.py:731-750; LikelihoodFisher consumes the result, fisher.py:216-257).  For each of the B centres
+ * (centers_dev [B, P]) the central-difference stencil centre -+ (lower_p, upper_p) e_p (steps_dev [B, P, 2], all positive; what the reference's Differentiation
+ * derives from Parameter.delta, differentiation.py:306-352) is evaluated as one batch; per centre
+ *     offset = -D.precision.D (no 1/2, fisher.py:746),  gradient [P] = -dD.precision.D,  hessian [P, P] = -dD.precision.dD^T,   dD_p = (D(c + u_p e_p) - D(c - l_p e_p)) / (l_p + u_p)
+ * D = flattheory - flatdata.  Outputs (any may be NULL): hessian_dev [B, P, P], gradient_dev [B, P], offset_dev [B].  The context must have no analytically
+ * solved parameter (vary them: the reference's Fisher does the same, fisher.py:688-695); P <= 31.  Asynchronous on ``hip_stream``. */
+int  dl_eval_fisher(dl_ctx* ctx, const double* centers_dev, const double* steps_dev, int64_t B, double* hessian_dev, double* gradient_dev, double* offset_dev, void* hip_stream);
+
 /* Theory state of observable ``iobs`` for parity / plots / emulation:
  * power_dev [B, n_ell, n_kin] and (optional) tables_dev [B, 3, n_ell, n_kin] = pk_dd, pk_dt, pk_tt. */
 int  dl_eval_theory(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs,

@@ -29,18 +29,57 @@ def test_fisher_algebra_linear_model():
     assert np.allclose(fisher.covariance(), np.linalg.inv(A.dot(prec).dot(A.T)))
 
 
+def _oracle_fisher(c, names, precision, center, steps):
+    """fisher.py:739-748 on vectors computed by the ORACLE (the restatement pinned on the reference's outputs of this fixture): flattheory on the stencil,
+    central differences, then the reference's algebra."""
+    def flattheory(row):
+        p = dict(zip(names, row)); p['b1'] = (p['b1'], p['b1'])
+        return orc.fullshape_observable(c, p)['flattheory']
+
+    flatdiff = flattheory(center) - c['flatdata']
+    flatderiv = []
+    for ip in range(len(names)):
+        up, dn = center.copy(), center.copy()
+        up[ip] += steps[ip, 1]; dn[ip] -= steps[ip, 0]
+        flatderiv.append((flattheory(up) - flattheory(dn)) / (steps[ip, 0] + steps[ip, 1]))
+    return orc.fisher_gaussian(flatdiff, np.array(flatderiv), precision)
+
+
 @pytest.mark.gpu
-def test_fisher_driver_on_gpu():
+def test_fisher_kernel_vs_oracle():
+    """dl_eval_fisher (stencil through the theory kernels + whitened GEMM, MFMA Gram product per centre) against the oracle's vectors and algebra."""
     from test_host_api import make_cfg2
+    from golden_utils import observable_constants
     from desilike_amd.fisher import Fisher
     g, like = make_cfg2(dense=False)
     fisher = Fisher(like)
     names = like.varied_params.names()
+    c = observable_constants(g)
+    rng = np.random.RandomState(5)
+    centers = np.array([[1.01, 0.995, 0.01, 1.02, 1.9, 0.1], [1., 1., 0., 1., 2., 0.]] + [[param.ref.sample(random_state=rng) for param in like.varied_params] for _ in range(3)])
+    centers[4, 0] = like.varied_params['qpar'].prior.limits[1] - 1e-4          # next to a prior bound: the upper step is shortened
+    steps = fisher.steps(centers)
+    assert steps[4, 0, 1] == pytest.approx(1e-4) and (steps > 0.).all()
+    offset, gradient, hessian = fisher.evaluate(centers)
+    for ib, center in enumerate(centers):
+        ref = _oracle_fisher(c, names, like.precision, center, steps[ib])
+        assert np.isclose(offset[ib], ref[0], rtol=1e-10, atol=1e-10), ib
+        assert np.allclose(gradient[ib], ref[1], rtol=1e-8, atol=1e-8 * np.abs(ref[1]).max()), ib
+        assert np.allclose(hessian[ib], ref[2], rtol=1e-8, atol=1e-8 * np.abs(ref[2]).max()), ib
+        assert np.array_equal(hessian[ib], hessian[ib].T)
+    # offset = -D P D = 2 logL (no 1/2, fisher.py:746); a batch of one centre gives the same bits as the batch of five
     ctx = like._get_context()
-    # (1) away from the best fit: d(logL)/d(theta) = -dD P D = likelihood gradient (fisher.py:747), checked by differences of the GPU loglikelihood
-    center = dict(qpar=1.01, qper=0.995, dm=0.01, df=1.02, b1=1.9, sn0=0.1)
-    fisher(**center)
-    x0 = np.array([center[name] for name in names])
+    assert np.allclose(offset, 2. * ctx.eval_batch_host(centers)[0], rtol=1e-10, atol=1e-9)
+    single = fisher.evaluate(centers[2])
+    assert np.array_equal(single[2][0], hessian[2]) and np.array_equal(single[1][0], gradient[2])
+    # the call surface: data generated at b1 = 2 -> the centre is the best fit: mean = centre, chi2min = 0, positive-definite precision
+    result = fisher(qpar=1., qper=1., dm=0., df=1., b1=2., sn0=0.)
+    assert np.abs(result.mean() - centers[1]).max() < 1e-6 and abs(result.chi2min) < 1e-8
+    assert (np.linalg.eigvalsh(result.precision()) > 0).all()
+    # sn0 has a Gaussian prior (scale 1000): its precision adds to the diagonal (fisher.py:712-714)
+    assert np.isclose(result.precision()[5, 5] - fisher.likelihood_fisher.precision()[5, 5], 1e-6, rtol=1e-9)
+    # the likelihood gradient is the derivative of logL: differences of the GPU loglikelihood
+    x0 = centers[0]
     eps = np.array([1e-4, 1e-4, 1e-3, 1e-3, 1e-3, 1e-2])
     grad = np.zeros(6)
     for i in range(6):
@@ -48,18 +87,31 @@ def test_fisher_driver_on_gpu():
         up[i] += eps[i]; dn[i] -= eps[i]
         ll = ctx.eval_batch_host(np.array([up, dn]))[0]
         grad[i] = (ll[0] - ll[1]) / (2 * eps[i])
-    assert np.allclose(fisher.likelihood_fisher._gradient, grad, rtol=5e-3, atol=1e-4 * np.abs(grad).max())
-    offset, gradient, hessian = orc.fisher_gaussian(fisher.flatdiff, fisher.flatderiv, like.precision)
-    assert np.allclose(fisher.likelihood_fisher._hessian, hessian, rtol=1e-12) and np.isclose(fisher.likelihood_fisher._offset, offset, rtol=1e-12, atol=1e-12)
-    assert np.isclose(offset, 2. * ctx.eval_batch_host(x0[None, :])[0][0], rtol=1e-10)     # offset = -D P D = 2 logL (no 1/2, fisher.py:746)
-    # (2) data generated at b1 = 2: the centre is the best fit -> mean = centre, chi2min = 0, positive-definite precision
-    center = dict(qpar=1., qper=1., dm=0., df=1., b1=2., sn0=0.)
-    result = fisher(**center)
-    x0 = np.array([center[name] for name in names])
-    assert np.abs(result.mean() - x0).max() < 1e-6 and abs(result.chi2min) < 1e-8
-    assert (np.linalg.eigvalsh(result.precision()) > 0).all()
-    # sn0 has a Gaussian prior (scale 1000): its precision adds to the diagonal (fisher.py:712-714)
-    assert np.isclose(result.precision()[5, 5] - fisher.likelihood_fisher.precision()[5, 5], 1e-6, rtol=1e-9)
+    assert np.allclose(gradient[0], grad, rtol=5e-3, atol=1e-4 * np.abs(grad).max())
+
+
+@pytest.mark.gpu
+def test_fisher_varies_solved_parameters():
+    """Analytically solved parameters are varied in the Fisher estimate, like the reference (fisher.py:688-695: warning + derived=False on a copy)."""
+    from golden_utils import load_golden, observable_constants
+    from test_gpu_marg import make_marg_likelihood
+    from desilike_amd.fisher import Fisher
+    g = load_golden('marg_sn0_grid')
+    like = make_marg_likelihood(g, solved='.marg')
+    with pytest.warns(UserWarning, match='solved parameters'):
+        fisher = Fisher(like)
+    names = fisher.varied_params.names()
+    assert names[-1] == 'sn0' and 'sn0' not in like.varied_params.names()
+    c = observable_constants(g)
+    center = np.array([1.005, 0.998, 0.004, 1.01, 1.95, 0.3])
+    steps = fisher.steps(center)
+    offset, gradient, hessian = fisher.evaluate(center)
+    ref = _oracle_fisher(c, names, like.precision, center, steps[0])
+    assert np.isclose(offset[0], ref[0], rtol=1e-10) and np.allclose(gradient[0], ref[1], rtol=1e-8, atol=1e-8 * np.abs(ref[1]).max())
+    assert np.allclose(hessian[0], ref[2], rtol=1e-8, atol=1e-8 * np.abs(ref[2]).max())
+    result = fisher(**dict(zip(names, center)))
+    prior = like.all_params['sn0'].prior
+    assert np.isclose(result.precision()[5, 5] - fisher.likelihood_fisher.precision()[5, 5], prior.scale**-2, rtol=1e-9)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,95 @@
+"""The drop-in boundary, proven from the reference side.
+
+``tests/golden/boundary_*.npz`` hold the flat ``dl_config`` key -> array sets that ``integration/desilike_mi355x.py::extract_config`` -- the binding a desilike
+maintainer adds -- read off REAL initialised reference likelihoods in the build container (tests/golden/make_boundary_fixture.py), with
+the reference's own ``vmap(likelihood, return_derived=True)`` outputs on a theta batch.  GPU: the context is created from those keys alone through ctypes (no
+``desilike_amd`` host mirror, no oracle) and must reproduce the reference's log-likelihoods to the north star's 1e-10.  CPU: the same keys are what the host mirror
+compiles for the same pipeline."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, 'integration'))
+
+FIXTURES = ['cfg2_dense', 'two_tracers', 'eft_qisoqap']
+
+
+def load_fixture(name):
+    g = np.load(os.path.join(HERE, 'golden', 'boundary_{}.npz'.format(name)))
+    cfg = {key[4:]: g[key] for key in g.files if key.startswith('cfg/')}
+    return g, cfg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', FIXTURES)
+def test_context_from_reference_side_keys(name):
+    import torch  # noqa: F401  (loads the HIP runtime PyTorch bundles first: one runtime per process)
+    from desilike_mi355x import Library
+    g, cfg = load_fixture(name)
+    library = Library(os.path.join(ROOT, 'desilike_amd', 'lib', 'libdesilike_amd.so'))
+    ctx = library.create(cfg, device=0)
+    loglike, logprior, status = library.eval_batch(ctx, g['theta'])
+    ref_ll, ref_lp = g['loglikelihood'], g['logprior']
+    inside = np.isfinite(ref_lp)
+    assert (~inside).sum() >= 1 and np.array_equal(status[~inside], np.ones((~inside).sum(), dtype='i4')) and np.isneginf(logprior[~inside]).all()
+    assert (status[inside] == 0).all()
+    tol = 1e-10 * np.maximum(1., np.abs(ref_ll))
+    assert (np.abs(loglike - ref_ll)[inside] <= tol[inside]).all(), np.abs(loglike - ref_ll)[inside].max()
+    assert np.allclose(logprior[inside], ref_lp[inside], rtol=1e-13, atol=1e-13)
+    library.lib.dl_destroy(ctx)
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_reference_side_keys_are_the_keys_of_the_header(name):
+    """Every extracted key is one the header documents, the store accepts them, and without a GPU dl_create refuses (no CPU fallback)."""
+    import re
+    import torch
+    from desilike_mi355x import Library
+    g, cfg = load_fixture(name)
+    header = open(os.path.join(ROOT, 'include', 'desilike_amd.h')).read()
+    for key in cfg:
+        tail = re.sub(r'^obs\d+\.', '', key)
+        needle = tail if not tail.startswith('in.') else 'in.'
+        assert needle.split('.')[-1] in header or needle in header, key
+    if not torch.cuda.is_available():
+        library = Library(os.path.join(ROOT, 'desilike_amd', 'lib', 'libdesilike_amd.so'))
+        with pytest.raises(RuntimeError, match='no HIP device'):
+            library.create(cfg, device=0)
+
+
+def test_host_mirror_compiles_the_same_keys():
+    """The same pipeline written with the host mirror (import swap) compiles to the key set the reference-side extraction produced."""
+    from desilike_amd._lib import fill_config
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    g, cfg = load_fixture('two_tracers')
+    template = ShapeFitPowerSpectrumTemplate(z=0.5, fiducial='synthetic')
+    observables = []
+    for iobs, (tracer, kmax, shotnoise) in enumerate([('LRG', 0.2, 1e4), ('ELG', 0.15, 4e3)]):
+        theory = KaiserTracerPowerSpectrumMultipoles(template=template, tracers=tracer)
+        nk = int(round(kmax / 0.005))
+        observables.append(TracerPowerSpectrumMultipolesObservable(data=cfg['obs{:d}.flatdata'.format(iobs)], kedges=np.linspace(0., kmax, nk + 1), ells=(0, 2, 4),
+                                                                   wmatrix={'resolution': 4}, theory=theory, shotnoise=shotnoise))
+    rng = np.random.RandomState(2)
+    A = rng.standard_normal((210, 210)) * 30.
+    like = ObservablesGaussianLikelihood(observables=observables, covariance=A.dot(A.T) + 1e4 * np.eye(210))
+    like.initialize()
+    mirror = {}
+    fill_config(like._spec({}, like._flatdata_list(), like.precision), lambda key, a: mirror.__setitem__(key, a), lambda key, a: mirror.__setitem__(key, a))
+    names, rnames = like.varied_params.names(), [str(n) for n in g['names']]
+    assert sorted(names) == sorted(rnames)
+    for key, value in cfg.items():
+        assert key in mirror, key
+        if '.in.' in key:   # (theta column, default): columns may be ordered differently, the parameter they name must be the same
+            col, rcol = int(mirror[key][0]), int(value[0])
+            assert (col < 0) == (rcol < 0) and (col < 0 or names[col] == rnames[rcol]), key
+        elif key == 'priors':
+            for iname, name in enumerate(rnames):
+                assert np.array_equal(mirror[key].reshape(-1, 5)[names.index(name)], value[iname]), name
+        else:
+            assert np.allclose(np.ravel(mirror[key]), np.ravel(value), rtol=1e-9 if key == 'precision' else 1e-13, atol=1e-14 if key == 'precision' else 1e-300), key
