@@ -218,7 +218,7 @@ def timed_steps(step, barrier, steps):
     return time.perf_counter() - t0
 
 
-def config5_strong(group, device, local_rank, rank, world, iterations, warmup=10):
+def config5_strong(group, device, local_rank, rank, world, iterations, warmup=300):
     """BASELINE configs[4] as written: ONE ensemble of 512 walkers on the two-tracer likelihood; every half-step's 256 proposals are split over the ranks
     (min_shard_rows = 0) and the log-posteriors all-gathered synchronously (in place, on the evaluation stream) before the accept step: strong scaling."""
     import torch
@@ -365,10 +365,12 @@ def main():
     import gc
     gc.collect()   # whatever set-up garbage holds device resources is released now, not by a collector pass inside the timed loop (hipFree synchronises the device)
     # fixed-duration pre-warm (its own key in the line): a 20-step run is 0.6 ms of GPU work -- without it the timed region would start on idle clocks
+    # (the pre-warm evaluates without the exchange: its length is time-based, hence different on every rank -- collectives must be issued in the same number everywhere)
+    scratch = torch.empty(B, dtype=torch.float64, device=device)
     t0 = time.perf_counter()
     prewarm_steps = 0
     while 1e3 * (time.perf_counter() - t0) < args.prewarm_ms:
-        for _ in range(16): step()
+        for _ in range(16): ctx.eval_logposterior(thetas[0], scratch, status=statuses[0], stream=stream.cuda_stream)
         torch.cuda.synchronize(device)
         prewarm_steps += 16
     prewarm_ms = 1e3 * (time.perf_counter() - t0)
@@ -377,12 +379,16 @@ def main():
     barrier()
     # HIP events attached to the kernels' own dispatch packets on the launch stream (hipExtLaunchKernelGGL: no event records between the kernels), on at least 8
     # steps of the timed region whatever --steps is
-    every = max(1, min(25, args.steps // 8))
-    ctx.profile_enable(0 if args.no_events else every)
+    # Long runs: all three kernels on 8+ sampled steps (0.4 us per step of overhead at 200 steps).  Short runs (the driver's --steps 20): a kernel launched with
+    # events is followed by a ~3 us gap, so each sampled step carries events on ONE kernel (the theory kernel on 3 sampled steps out of 4): at 20 steps, 10 sampled
+    # steps = 8 samples of the theory kernel + 1 of each other kernel for ~1.6 us per step.
+    rotate = args.steps < 100
+    every = max(1, min(25, args.steps // (10 if rotate else 8)))
+    ctx.profile_enable(0 if args.no_events else every, rotate=rotate)
     gc.disable()
     elapsed = timed_steps(step, barrier, args.steps)
     gc.enable()
-    kernel_ms = ctx.profile_read() if not args.no_events else dict(theory=1., window_gemm=1., finalize=1., total=1., event_overhead=0., samples=0)
+    kernel_ms = ctx.profile_read() if not args.no_events else dict(theory=1., window_gemm=1., finalize=1., total=1., event_overhead=0., samples=0, samples_per_kernel={})
     ctx.profile_enable(0)
     if distributed:
         elapsed = group.max(elapsed)
@@ -413,9 +419,10 @@ def main():
                                                                  'window_gemm': 'fp64 MFMA (v_mfma_f64_16x16x4_f64), peak = 78.6 TFLOP/s fp64 matrix', 'finalize': 'launch latency'}[dominant],
                                'kernel': kernel_name, 'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS, 'traffic': traffic,
                                'traffic_source': traffic_source, 'flop_per_launch': flops[dominant] * per_launch, 'avg_launch_ms': kernel_ms[dominant],
-                               'event_samples': int(kernel_ms.get('samples', 0))},
-                  'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize', 'total']},
-                  'kernel_frac_of_fp64_peak': {name: flops[name] * per_launch / (kernel_ms[name] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS for name in ['theory', 'window_gemm']}}
+                               'event_samples': int(kernel_ms.get('samples_per_kernel', {}).get(dominant, kernel_ms.get('samples', 0))),
+                               'event_mode': 'one kernel per sampled step' if rotate else 'all kernels of a sampled step'},
+                  'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize']},
+                  'kernel_frac_of_fp64_peak': {name: flops[name] * per_launch / (kernel_ms[name] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS for name in ['theory', 'window_gemm'] if kernel_ms[name] > 0.}}
         if strong is not None:
             result['config5_strong'] = strong
         if world == 1 and not distributed and not args.no_cpu_baseline:   # (the forced single-rank RCCL smoke mode writes log-posteriors into buckets, not `loglike`)

@@ -305,14 +305,16 @@ class Context(object):
                                              ctypes.c_void_p(gradient.data_ptr()), ctypes.c_void_p(offset.data_ptr()), ctypes.c_void_p(stream)))
         return hessian, gradient, offset
 
-    def profile_enable(self, every=1):
-        """Attach HIP events to the kernels' dispatch packets on one ``eval_batch`` call out of ``every`` (0 / False: off)."""
-        self._check(self._lib.dl_profile_enable(self._handle, int(every)))
+    def profile_enable(self, every=1, rotate=False):
+        """Attach HIP events to the kernels' dispatch packets on one ``eval_batch`` call out of ``every`` (0 / False: off); ``rotate``: one kernel per
+        sampled call (short runs: a kernel launched with events costs the step ~3 us)."""
+        self._check(self._lib.dl_profile_enable(self._handle, int(every) | ((1 << 16) if rotate and every else 0)))
 
     def profile_read(self):
-        ms = np.zeros(6, dtype='f8')
-        self._check(self._lib.dl_profile_read(self._handle, _f64_ptr(ms), 6))
-        return dict(theory=ms[0], window_gemm=ms[1], finalize=ms[2], total=ms[3], event_overhead=ms[4], samples=int(ms[5]))
+        ms = np.zeros(9, dtype='f8')
+        self._check(self._lib.dl_profile_read(self._handle, _f64_ptr(ms), 9))
+        return dict(theory=ms[0], window_gemm=ms[1], finalize=ms[2], total=ms[3], event_overhead=ms[4], samples=int(ms[5]),
+                    samples_per_kernel=dict(theory=int(ms[6]), window_gemm=int(ms[7]), finalize=int(ms[8])))
 
 
 class FFTLogPlan(object):

@@ -64,10 +64,12 @@ struct dl_ctx {
     // profiling
     bool profile = false;
     static const int NPOOL = 256;            // event sets kept: dl_profile_read averages over the calls recorded since dl_profile_enable
+    std::vector<int8_t> prof_phase_of;       // [NPOOL] phase that carried events in each sampled call (-1: all)
     std::vector<hipEvent_t> ev;              // [NPOOL * 6]: (start, stop) of the theory kernel, the GEMM, the finalize kernel
     int64_t prof_calls = 0;                  // profiled calls recorded
     int64_t eval_calls = 0;                  // dl_eval_batch calls since dl_profile_enable
     int prof_every = 1;                      // record events on one call out of prof_every (sampling keeps the event overhead out of the throughput)
+    bool prof_rotate = false;                // one kernel per sampled call carries events (theory on 3 sampled calls out of 4, GEMM and finalize in turn on the 4th)
     std::string last_error;
 };
 
@@ -428,9 +430,13 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         hipEvent_t* ev = prof ? &ctx->ev[(size_t)(ctx->prof_calls % dl_ctx::NPOOL) * 6] : nullptr;
         // events attached to the dispatch packets of the launches of phase k (0 theory, 1 GEMM, 2 finalize; dl_kernels.h): with several launches in a phase
         // (one theory launch per observable) the pair holds the LAST one
+        const int64_t pc = ctx->prof_calls;
+        const int only = !ctx->prof_rotate ? -1 : (pc % 4 != 3 ? 0 : 1 + (int)((pc / 4) % 2));   // rotating mode: the one phase of this sampled call
+        if (prof) ctx->prof_phase_of[(size_t)(pc % dl_ctx::NPOOL)] = (int8_t)only;
         auto prof_phase = [&](int k) {
-            dl_prof_events.start = (ev && k >= 0) ? ev[2 * k] : nullptr;
-            dl_prof_events.stop = (ev && k >= 0) ? ev[2 * k + 1] : nullptr;
+            const bool on = ev && k >= 0 && (only < 0 || only == k);
+            dl_prof_events.start = on ? ev[2 * k] : nullptr;
+            dl_prof_events.stop = on ? ev[2 * k + 1] : nullptr;
         };
         bool need_flat = ctx->any_transform || flattheory_dev != nullptr;
         // emulated (separable) theories: the theory kernel writes only the factors (basis, monomial rows), the feature GEMM turns them into residual rows
@@ -708,10 +714,13 @@ int dl_eval_theory_host(dl_ctx* ctx, const double* theta, int64_t B, int32_t iob
 int dl_profile_enable(dl_ctx* ctx, int enable) {
     if (!ctx) { g_last_error = "dl_profile_enable: null context"; return 1; }
     DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (enable && ctx->ev.empty()) {
+    if ((enable & 0xffff) && ctx->ev.empty()) {
         ctx->ev.assign((size_t)dl_ctx::NPOOL * 6, nullptr);
         for (auto& e : ctx->ev) DL_HIP_CHECK(ctx, hipEventCreate(&e));
     }
+    ctx->prof_phase_of.assign(dl_ctx::NPOOL, -1);
+    ctx->prof_rotate = (enable & (1 << 16)) != 0;
+    enable &= 0xffff;
     ctx->profile = enable != 0;
     ctx->prof_every = enable > 1 ? enable : 1;
     ctx->prof_calls = 0;
@@ -728,18 +737,23 @@ int dl_profile_read(dl_ctx* ctx, double* ms, int32_t n) {
     std::vector<double> samples[4];
     for (int64_t c = 0; c < ncalls; ++c) {
         hipEvent_t* ev = &ctx->ev[(size_t)c * 6];
-        (void)hipEventSynchronize(ev[5]);
-        int first = -1;
+        const int only = ctx->prof_phase_of.empty() ? -1 : ctx->prof_phase_of[(size_t)c];
+        int first = -1, last = -1;
         for (int k = 0; k < 3; ++k) {
+            if (only >= 0 && only != k) continue;
+            (void)hipEventSynchronize(ev[2 * k + 1]);
             float t = 0;
-            if (hipEventElapsedTime(&t, ev[2 * k], ev[2 * k + 1]) != hipSuccess) { (void)hipGetLastError(); t = 0; }
-            else if (first < 0) first = k;
+            if (hipEventElapsedTime(&t, ev[2 * k], ev[2 * k + 1]) != hipSuccess) { (void)hipGetLastError(); continue; }
+            if (first < 0) first = k;
+            last = k;
             samples[k].push_back(t);
         }
         float t = 0;
-        if (first < 0 || hipEventElapsedTime(&t, ev[2 * first], ev[5]) != hipSuccess) { (void)hipGetLastError(); t = 0; }
-        samples[3].push_back(t);
+        if (only < 0 && first >= 0 && hipEventElapsedTime(&t, ev[2 * first], ev[2 * last + 1]) == hipSuccess) samples[3].push_back(t);
+        else (void)hipGetLastError();
     }
+    for (int i = 0; i < 4; ++i) if (samples[i].empty()) samples[i].push_back(0.);
+    if (n >= 9) for (int i = 0; i < 3; ++i) ms[6 + i] = (samples[i].size() == 1 && samples[i][0] == 0.) ? 0. : (double)samples[i].size();
     for (int i = 0; i < 4; ++i) {
         std::sort(samples[i].begin(), samples[i].end());
         const size_t m = samples[i].size();

@@ -52,6 +52,7 @@ __host__ __device__ inline DlPhilox dl_philox4x32(uint32_t c0, uint32_t c1, uint
 // 53-bit uniform on [0, 1) from two 32-bit words (the construction of numpy's random_sample)
 __host__ __device__ inline double dl_uniform53(uint32_t hi, uint32_t lo) { return ((double)(hi >> 5) * 67108864. + (double)(lo >> 6)) * (1. / 9007199254740992.); }
 
+#define DL_ENS_THREADS 1024   // one workgroup: ranking the 64-bit keys of the random split is O(nwalkers^2 / threads) LDS reads per thread
 enum { DL_ENS_STREAM_PERM = 0, DL_ENS_STREAM_MOVE = 1, DL_ENS_STREAM_ACCEPT = 3 };   // + half-step for the last two
 
 struct DlEnsArgs {
@@ -73,7 +74,7 @@ struct DlEnsArgs {
 
 // One workgroup: the ensemble is a few hundred walkers x <= 64 parameters.  Phases separated by barriers (global memory written before a barrier is visible
 // to the workgroup after it).
-__global__ __launch_bounds__(256) void dl_ensemble_step_kernel(const DlEnsArgs s) {
+__global__ __launch_bounds__(DL_ENS_THREADS) void dl_ensemble_step_kernel(const DlEnsArgs s) {
 #pragma clang fp contract(off)   // the NumPy driver rounds after every operation: no fused multiply-adds here
     extern __shared__ unsigned long long keys[];   // [nw] sort keys of the permutation
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -261,13 +262,13 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
         for (int h = 0; h < 2; ++h) {
             s.it_prop = it; s.half_prop = h;
             set_record();
-            hipLaunchKernelGGL(dl_ensemble_step_kernel, dim3(1), dim3(256), shm, stream, s);
+            hipLaunchKernelGGL(dl_ensemble_step_kernel, dim3(1), dim3(DL_ENS_THREADS), shm, stream, s);
             if (dl_ens_logposterior(ens, ens->prop, half, ens->newlp, stream)) return 1;
             s.it_acc = it; s.half_acc = h;
         }
     s.half_prop = -1;
     set_record();
-    hipLaunchKernelGGL(dl_ensemble_step_kernel, dim3(1), dim3(256), shm, stream, s);
+    hipLaunchKernelGGL(dl_ensemble_step_kernel, dim3(1), dim3(DL_ENS_THREADS), shm, stream, s);
     DL_ENS_HIP(hipGetLastError());
     ens->iteration += niterations;
     return 0;

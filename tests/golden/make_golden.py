@@ -411,6 +411,62 @@ def cfg3_table():
     print(names)
 
 
+def cfg3_full():
+    """BASELINE configs[2] at the size SURVEY.md section 8d states (MLP in = 6, 4 x 64 silu, 3 * 128 * 19 = 7296 outputs; 19-monomial combination; cubic
+    interpolation to n_kin = 400; binning window 120 x 1200): the REFERENCE's REPT velocileptors tracer + window + Gaussian likelihood on a stand-in PT node whose
+    ``pktable`` / ``sigma8`` / ``fsigma8`` come from the MLPs of tests/emulator_utils.cfg3_full_engines (forward pass = the oracle's restatement of
+    emulators/conversion.py:20-96; the engine itself is third-party and absent: unpinned).  Pins table combination -> interpolation -> window -> chi2 at full size."""
+    from desilike.theories.galaxy_clustering.full_shape import REPTVelocileptorsPowerSpectrumMultipoles, REPTVelocileptorsTracerPowerSpectrumMultipoles
+    sys.path.insert(0, os.path.join(os.path.dirname(here)))
+    from emulator_utils import CFG3_PARAMS, CFG3_SPECS, cfg3_full_kpt, cfg3_full_engines
+    from oracle import np_oracle as orc
+    engines = cfg3_full_engines()
+
+    def predict(name, x):
+        e = engines[name]
+        return orc.mlp_predict(x, e['xlimits'], e['layers'], 'silu', e['ylimits']).reshape(e['yshape'])
+
+    class FakePT(REPTVelocileptorsPowerSpectrumMultipoles):
+
+        _params = {name: dict(spec) for name, spec in CFG3_SPECS.items()}
+
+        def initialize(self, k=None, ells=(0, 2, 4), **kwargs):
+            self.k = cfg3_full_kpt()
+            self.ells = tuple(ells)
+            self.z = np.array(0.8)
+            self.options = {}
+
+        def calculate(self, **params):
+            x = np.array([params[name] for name in CFG3_PARAMS])
+            self.pktable = predict('pktable', x)
+            self.sigma8, self.fsigma8 = float(predict('sigma8', x)[0]), float(predict('fsigma8', x)[0])
+
+    pt = FakePT()
+    theory = REPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, tracer='LRG')
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1p': 1.6, 'b2p': 0.3, 'alpha0p': 2.}, kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=8e3)
+    cov = spd_covariance(120, seed=9, diag=4e4, amp=40.)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+    like()
+    names = like.varied_params.names()
+    theta = sample_theta(like, 16, seed=19)
+    vlike = vmap(like, backend=None, errors='return', return_derived=True)
+    (logpost, derived), errors = vlike({name: theta[:, i] for i, name in enumerate(names)})
+    assert not errors, errors
+    power, flat = [], []
+    for row in theta[:4]:
+        like(**dict(zip(names, row)))
+        power.append(np.asarray(theory.power).copy()); flat.append(np.asarray(like.flattheory).copy())
+    wm = obs.wmatrix
+    assert wm.matrix_full.shape == (120, 1200)
+    obs0 = dict(k=np.asarray(theory.k), ells=np.array(theory.ells), nd=theory.nd, snd=theory.snd, fsat=theory.fsat, sigv=theory.options['sigv'],
+                shotnoisein=np.asarray(wm.shotnoisein), shotnoiseout=np.asarray(wm.shotnoiseout), flatdata=np.asarray(obs.flatdata))
+    save('cfg3_full', names=np.array(names), theta=theta, obs0=obs0, cov_seed=np.array([9]),
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]),
+         logposterior=np.asarray(logpost), loglikelihood=np.asarray(derived[like._param_loglikelihood]), logprior=np.asarray(derived[like._param_logprior]),
+         power=np.array(power), flattheory=np.array(flat))
+    print(names)
+
+
 def cfg3_table_xi():
     """REPT velocileptors correlation function multipoles (full_shape.py:1603-1629): the table combination of cfg3_table on the 300-point log grid of get_corr,
     Hankel-transformed (tgc/base.py:127-136), run by the reference on the same kind of stand-in PT node."""
@@ -789,7 +845,7 @@ def kaiser_xi(eft=False):
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi', 'cfg4_resummed', 'cfg4_flexible']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi', 'cfg4_resummed', 'cfg4_flexible', 'cfg3_full']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -808,3 +864,4 @@ if __name__ == '__main__':
     if 'kaiser_xi' in todo: kaiser_xi(False)
     if 'kaiser_xi_eft' in todo: kaiser_xi(True)
     if 'cfg3_table' in todo: cfg3_table()
+    if 'cfg3_full' in todo: cfg3_full()

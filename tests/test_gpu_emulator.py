@@ -170,3 +170,81 @@ def test_taylor_emulator_fitted_on_the_gpu_theory():
         assert abs(ll[0] - ref[0]) <= 1e-9 * max(1., abs(ref[0]))                 # the centre is reproduced
         errors[order] = np.abs(ll[1:] - ref[1:]).max()
     assert errors[4] < 0.05 * errors[2] and errors[4] < 1e-3 * np.abs(ref).max(), errors
+
+
+# ---- BASELINE configs[2] at the size SURVEY.md section 8d states ------------------------------------------------------------------------------------------
+def make_cfg3_full(marg=True, model='rept'):
+    """MLP in = 6 -> 4 x 64 silu -> 3 * 128 * 19 = 7296 outputs; 19-monomial combination; cubic interpolation to n_kin = 400; binning window 120 x 1200;
+    solved: alpha0p, alpha2p, alpha4p, sn0p, sn2p (n_s = 5) with their Gaussian priors (full_shape.py:1130-1133)."""
+    from desilike_amd.emulators import EmulatedCalculator, MLPEmulatorEngine
+    from desilike_amd.theories.galaxy_clustering import REPTVelocileptorsTracerPowerSpectrumMultipoles, LPTVelocileptorsTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    from emulator_utils import CFG3_PARAMS, CFG3_SPECS, cfg3_full_kpt, cfg3_full_engines
+    g = load_golden('cfg3_full')
+    engines = {}
+    for name, e in cfg3_full_engines().items():
+        engines[name] = MLPEmulatorEngine(xlimits=e['xlimits'], layers=e['layers'], activation='silu', ylimits=e['ylimits'], yshape=e['yshape'])
+    pt = EmulatedCalculator(CFG3_PARAMS, engines, k=cfg3_full_kpt(), ells=(0, 2, 4), z=0.8, param_specs=CFG3_SPECS)
+    cls = REPTVelocileptorsTracerPowerSpectrumMultipoles if model == 'rept' else LPTVelocileptorsTracerPowerSpectrumMultipoles
+    theory = cls(pt=pt, tracer='LRG')
+    solved = ['alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p'] if marg else []
+    for name in solved:
+        theory.init.params[name].update(derived='.marg')
+    obs = TracerPowerSpectrumMultipolesObservable(data=g['obs0']['flatdata'], kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=8e3)
+    rng = np.random.RandomState(int(g['cov_seed'][0]))
+    A = rng.standard_normal((120, 120)) * 40.
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + 4e4 * np.eye(120))
+    return g, like, pt, theory, solved
+
+
+def test_cfg3_full_size_vs_reference():
+    """The reference ran its own velocileptors combination + interpolation + window + chi2 on the tables of these MLPs (tests/golden/make_golden.py::cfg3_full)."""
+    from desilike_amd import vmap
+    g, like, pt, theory, solved = make_cfg3_full(marg=False)
+    names = [str(n) for n in g['names']]
+    assert like.varied_params.names() == names
+    wm = like.observables[0].wmatrix
+    assert wm.matrix_full.shape == (120, 1200) and len(theory.k) == 400 and pt.engines['pktable'].layers[-1][0].shape == (64, 7296)
+    (logpost, derived), errors = vmap(like, errors='return', return_derived=True)({name: g['theta'][:, i] for i, name in enumerate(names)})
+    assert errors == {}
+    assert (np.abs(derived[like._param_loglikelihood] - g['loglikelihood']) <= 1e-10 * np.maximum(1., np.abs(g['loglikelihood']))).all(), np.abs(derived[like._param_loglikelihood] - g['loglikelihood']).max()
+    assert np.allclose(derived[like._param_logprior], g['logprior'], rtol=1e-12, atol=1e-12)
+    like._evaluate_dict({name: g['theta'][:4, i] for i, name in enumerate(names)}, (4,), errors='return', return_flattheory=True)
+    assert np.allclose(like.flattheory, g['flattheory'], rtol=1e-11, atol=1e-8)
+
+
+def test_cfg3_full_size_marginalised_4096():
+    """The 4096-point batch of BASELINE configs[2], 5 analytically marginalised parameters: feature path vs the oracle's per-point solve on reference-pinned theory
+    vectors (theory of the solved parameters' unit vectors through the same oracle chain)."""
+    from emulator_utils import CFG3_PARAMS
+    g, like, pt, theory, solved = make_cfg3_full(marg=True)
+    names = like.varied_params.names()
+    assert like.solved_params.names() == solved
+    rng = np.random.RandomState(3)
+    theta = np.column_stack([np.clip(param.ref.sample(size=4096, random_state=rng), *param.prior.limits) for param in like.varied_params])
+    ctx = like._get_context()
+    loglike, logprior, status, xsolved = ctx.eval_batch_host(theta, return_solved=True)
+    assert (status == 0).all() and np.isfinite(loglike).all()
+    nsol = len(solved)
+    scales = np.array([like.all_params[name].prior.scale for name in solved])
+    wm = like.observables[0].wmatrix
+    eng = pt.engines
+
+    def flat(row, x):
+        p = dict(zip(names, row)); p.update(x)
+        xin = np.array([p[name] for name in CFG3_PARAMS])
+        pktable = orc.mlp_predict(xin, eng['pktable'].xlimits, eng['pktable'].layers, 'silu', eng['pktable'].ylimits).reshape(3, -1, 19)
+        sigma8 = orc.mlp_predict(xin, eng['sigma8'].xlimits, eng['sigma8'].layers, 'silu', eng['sigma8'].ylimits)[0]
+        fsigma8 = orc.mlp_predict(xin, eng['fsigma8'].xlimits, eng['fsigma8'].layers, 'silu', eng['fsigma8'].ylimits)[0]
+        params = {name: p.get(name, like.all_params[name].value) for name in ['b1p', 'b2p', 'bsp', 'b3p', 'alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p', 'sn4p']}
+        pars = orc.velocileptors_pars(params, sigma8, fsigma8 / sigma8, basis='physical', model='rept', snd=theory.snd, fsat=theory.fsat, sigv=theory.sigv)
+        power = orc.interp1d(theory.k, pt.k, orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=theory.nd).T).T
+        return orc.window_apply(power, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout)
+
+    for i in range(0, 4096, 1024):
+        f0 = flat(theta[i], {name: 0. for name in solved})
+        T = np.array([flat(theta[i], {n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
+        sol = orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=np.zeros(nsol), prior_scale=scales, marg_mask=np.ones(nsol, dtype='?'))
+        assert abs(loglike[i] - sol['loglikelihood']) <= 1e-9 * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
+        assert np.allclose(xsolved[i], sol['x'], rtol=1e-7, atol=1e-9)

@@ -79,3 +79,38 @@ def test_fit_taylor_exact_on_polynomials():
     for alpha, c in coef.items():
         term = [tuple(p) for p in engine.powers].index(alpha)
         assert np.allclose(engine.derivatives[term], c, rtol=1e-9, atol=1e-10)
+
+
+def test_cfg3_full_size_oracle_vs_reference():
+    """BASELINE configs[2] at SURVEY 8d's size: the oracle chain (MLP tables -> 19-monomial combination -> cubic interpolation to n_kin = 400 -> 120 x 1200 binning
+    window -> chi2) against what the reference computed from the same tables (tests/golden/make_golden.py::cfg3_full)."""
+    from emulator_utils import CFG3_PARAMS, cfg3_full_kpt, cfg3_full_engines
+    from desilike_amd.utils import window_matrix_bininteg
+    g = load_golden('cfg3_full')
+    eng = cfg3_full_engines()
+    names = [str(n) for n in g['names']]
+    kedges = np.linspace(0., 0.2, 41)
+    kin, matrix = window_matrix_bininteg([np.column_stack([kedges[:-1], kedges[1:]])] * 3, resolution=10)
+    c = g['obs0']
+    assert matrix.T.shape == (120, 1200) and np.allclose(kin, c['k'], rtol=1e-14)
+    rng = np.random.RandomState(int(g['cov_seed'][0]))
+    A = rng.standard_normal((120, 120)) * 40.
+    precision = np.linalg.inv(A.dot(A.T) + 4e4 * np.eye(120))
+
+    def predict(name, x):
+        return orc.mlp_predict(x, eng[name]['xlimits'], eng[name]['layers'], 'silu', eng[name]['ylimits'])
+
+    for i, row in enumerate(g['theta']):
+        p = dict(zip(names, row))
+        x = np.array([p[name] for name in CFG3_PARAMS])
+        pktable = predict('pktable', x).reshape(3, -1, 19)
+        sigma8, fsigma8 = predict('sigma8', x)[0], predict('fsigma8', x)[0]
+        params = {name: p.get(name, 0.) for name in ['b1p', 'b2p', 'bsp', 'b3p', 'alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p', 'sn4p']}
+        pars = orc.velocileptors_pars(params, sigma8, fsigma8 / sigma8, basis='physical', model='rept', snd=float(c['snd']), fsat=float(c['fsat']), sigv=float(c['sigv']))
+        power = orc.interp1d(kin, cfg3_full_kpt(), orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=float(c['nd'])).T).T
+        flat = orc.window_apply(power, matrix_full=matrix.T, shotnoisein=c['shotnoisein'], shotnoiseout=c['shotnoiseout'])
+        if i < len(g['power']):
+            assert np.allclose(power, g['power'][i], rtol=1e-12, atol=1e-12 * np.abs(power).max())
+            assert np.allclose(flat, g['flattheory'][i], rtol=1e-12, atol=1e-12 * np.abs(flat).max())
+        logl = orc.gaussian_loglikelihood(flat, c['flatdata'], precision)[0]
+        assert abs(logl - g['loglikelihood'][i]) <= 1e-10 * max(1., abs(g['loglikelihood'][i]))

@@ -1,15 +1,26 @@
-# Per-round measurement recipe (run on the GPU box through gpurun): bench line, kernel trace + stats, HBM-traffic counters in separate passes.
-#   usage: bash tools/prof_round.sh r01c
-TAG=${1:-r01x}
+# Per-round measurement recipe (run on the GPU box through gpurun): bench lines, kernel trace + stats, HBM-traffic and SQ counters in separate passes.
+#   usage: bash tools/prof_round.sh r02a
+# The program goes directly after `rocprofv3 ... --` (python3 itself: no env / bash -c hop, the profiler's preloaded library has initialised the GPU already).
+TAG=${1:-r02x}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python3 $R/bench.py --no-cpu-baseline --steps 200 --warmup 20 > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $TAG -- python3 $R/bench.py --no-cpu-baseline --no-events --steps 20 --warmup 5 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $TAG -- python3 $R/bench.py --no-cpu-baseline --no-events --steps 20 --warmup 5 > /dev/null 2>&1
+timeout 600 python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+timeout 300 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_steps20.json 2>> $OUT/${TAG}_bench.err     # the driver's command
+B="$R/bench.py --no-cpu-baseline --config5-iterations 0"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python3 $B --steps 200 --warmup 20 > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $TAG -- python3 $B --no-events --steps 20 --warmup 5 --prewarm-ms 20 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $TAG -- python3 $B --no-events --steps 20 --warmup 5 --prewarm-ms 20 > /dev/null 2>&1
+# SQ counters of the final kernels (north star: MFMA utilisation, LDS conflicts): three passes of <= 8 SQ counters
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_sq1 -o $TAG -- python3 $B --no-events --steps 20 --warmup 5 --prewarm-ms 20 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc_sq2 -o $TAG -- python3 $B --no-events --steps 20 --warmup 5 --prewarm-ms 20 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq3 -o $TAG -- python3 $B --no-events --steps 20 --warmup 5 --prewarm-ms 20 > /dev/null 2>&1
+# BASELINE configs[4]: the device-resident ensemble (per-kernel stats of an ensemble update)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ens -o $TAG -- python3 $R/tools/time_sampler.py > $OUT/${TAG}_time_sampler.txt 2>/dev/null
 cd $R
 cp $OUT/trace/*kernel_stats.csv $OUT/${TAG}_kernel_stats.csv 2>/dev/null
+cp $OUT/trace_ens/*kernel_stats.csv $OUT/${TAG}_ensemble_kernel_stats.csv 2>/dev/null
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/${TAG}_pmc_hbm_traffic.txt 2>&1
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
+python3 tools/sq_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 > $OUT/${TAG}_pmc_sq_counters.txt 2>&1
+rm -rf $OUT/trace $OUT/trace_ens $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3

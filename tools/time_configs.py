@@ -26,17 +26,20 @@ def time_likelihood(label, like, B, steps=40, posterior=False):
     dt = (time.perf_counter() - t0) / steps
     ms = ctx.profile_read(); ctx.profile_enable(0)
     ok = int((st == 0).sum().item())
-    print('%-58s B=%5d  %8.1f us/step  %7.2f M evals/s  kernels (raw event intervals, us): theory %.1f gemm %.1f finalize %.1f  [%d ok]' % (
-        label, B, 1e6 * dt, B / dt / 1e6, *(1e3 * (ms[k] + ms['event_overhead']) for k in ['theory', 'window_gemm', 'finalize']), ok))
+    print('%-58s B=%5d  %8.1f us/step  %7.2f M evals/s  kernels (dispatch-event intervals, us): theory %.1f gemm %.1f finalize %.1f  [%d ok]' % (
+        label, B, 1e6 * dt, B / dt / 1e6, *(1e3 * ms[k] for k in ['theory', 'window_gemm', 'finalize']), ok))
 
 
 def main():
-    from test_gpu_emulator import make_mlp_likelihood
+    from test_gpu_emulator import make_mlp_likelihood, make_cfg3_full
     from test_host_api import make_cfg4
+    # BASELINE configs[2] at the size SURVEY 8d states: in = 6, 4 x 64 silu, 3 * 128 * 19 outputs, n_kin = 400, W 120 x 1200, n_s = 5
+    g, like, pt, theory, solved = make_cfg3_full(marg=True)
+    time_likelihood('cfg3 (SURVEY 8d size): MLP tables + 5 marginalised parameters', like, 4096)
+    g, like, pt, theory, solved = make_cfg3_full(marg=False)
+    time_likelihood('cfg3 (SURVEY 8d size) without marginalisation', like, 4096)
     g, like, pt, theory, solved = make_mlp_likelihood(marg=True)
-    time_likelihood('cfg3: MLP-emulated tables + 5 marginalised parameters', like, 4096)
-    g, like, pt, theory, solved = make_mlp_likelihood(marg=False)
-    time_likelihood('cfg3 without marginalisation', like, 4096)
+    time_likelihood('reduced shape of round 1 (in = 3, 3 x 64, 69 k): + 5 marginalised', like, 4096)
     for space in ['xi', 'pk']:
         g, like = make_cfg4(space)
         time_likelihood('cfg4: damped BAO ' + space, like, 8192)

@@ -1,25 +1,27 @@
-"""Config 5 end to end: EmceeSampler (built-in stretch move), 512 walkers x 2-tracer likelihood, 200 iterations on one GPU: wall time per ensemble update, split into
-the GPU evaluation (two half-ensemble calls of 256 points) and the host side (proposals, conventions, copies)."""
+"""BASELINE configs[4] end to end on one GPU: 512 walkers x two config-2 tracers (n = 240), device-resident ensemble (dl_ensemble_*) against the host-driven
+stretch move (NumPy proposals around one dl_eval_logposterior_host call per half-step); wall time per ensemble update."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT)
 import numpy as np
-from test_host_api import make_cfg5
+import torch
+from bench import make_likelihood_config5
 from desilike_amd.samplers import EmceeSampler
 
-g, like = make_cfg5()
-sampler = EmceeSampler(like, nwalkers=512, seed=42, use_emcee=False)
-sampler.run(niterations=5)
-t0 = time.perf_counter()
-chain = sampler.run(niterations=200)
-dt = (time.perf_counter() - t0) / 200
+like = make_likelihood_config5(0)
+for device_resident in (True, False):
+    sampler = EmceeSampler(like, nwalkers=512, seed=42, use_emcee=False, device_resident=device_resident)
+    sampler.run(niterations=300 if device_resident else 20)
+    torch.cuda.synchronize()
+    niter = 500 if device_resident else 200
+    t0 = time.perf_counter()
+    chain = sampler.run(niterations=niter)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / niter
+    print('%-46s ensemble update (512 walkers): %7.1f us = %5.2f M evals/s; acceptance %.2f' % (
+        'device-resident (dl_ensemble_run, chain drained once)' if device_resident else 'host-driven (NumPy stretch move + host calls)', 1e6 * dt, 512 / dt / 1e6, sampler.acceptance_fraction.mean()))
 theta = np.column_stack([chain[p.name][-1][:256] for p in like.varied_params])
+ctx = like._get_posterior_context()[0]
 t0 = time.perf_counter()
-for _ in range(200): sampler.logposterior(theta)
-dl = (time.perf_counter() - t0) / 200
-ctx = like._get_context()
-t0 = time.perf_counter()
-for _ in range(200): ctx.eval_batch_host(theta)
-dc = (time.perf_counter() - t0) / 200
-print('ensemble update (512 walkers): %.1f us = %.2f M evals/s;  logposterior(256 points): %.1f us;  dl_eval_batch_host(256 points): %.1f us;  acceptance %.2f' % (
-    1e6 * dt, 512 / dt / 1e6, 1e6 * dl, 1e6 * dc, sampler.acceptance_fraction.mean()))
+for _ in range(200): ctx.eval_logposterior_host(theta)
+print('dl_eval_logposterior_host(256 points): %.1f us' % (1e6 * (time.perf_counter() - t0) / 200))
