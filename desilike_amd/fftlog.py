@@ -120,23 +120,34 @@ class PowerToCorrelation(object):
         return np.array(s), np.array(xi)
 
 
-def correlation_from_power(power, kin, k, logk_high, damp_high, kmask_mid, fftlog, s):
-    """``get_corr`` of the reference (theories/galaxy_clustering/base.py:127-136) for interp_order = 1."""
+def _interp_to_grid(logk, logkin, pk, interp_order=1):
+    """P_ell from the theory grid to the FFTLog grid, in log10 k: linear (``interp_order = 1``) or the numpy-backend cubic of the reference's ``interp1d``
+    (``interp_order = 3``: scipy not-a-knot cubic with extrapolation, desilike/jax.py:263-265)."""
+    if interp_order == 1:
+        return np.interp(logk, logkin, pk)
+    from scipy import interpolate
+    return interpolate.interp1d(logkin, pk, kind='cubic', fill_value='extrapolate', axis=0)(logk)
+
+
+def correlation_from_power(power, kin, k, logk_high, damp_high, kmask_mid, fftlog, s, interp_order=1):
+    """``get_corr`` of the reference (theories/galaxy_clustering/base.py:127-136)."""
     tmp = []
     logkin = np.log10(kin)
     for pk in power:
         slope_high = (pk[-1] - pk[-2]) / np.log10(kin[-1] / kin[-2])
-        interp = np.interp(np.log10(k[kmask_mid]), logkin, pk)
+        interp = _interp_to_grid(np.log10(k[kmask_mid]), logkin, pk, interp_order=interp_order)
         tmp.append(np.concatenate([interp, (pk[-1] + slope_high * logk_high) * damp_high], axis=-1))
     ss, corr = fftlog(np.vstack(tmp))
     return np.array([np.interp(s, sss, cc) for sss, cc in zip(ss, corr)])
 
 
-def hankel_operator(kin, s, ells, k=None, engine='numpy', device=None):
+def hankel_operator(kin, s, ells, k=None, engine='numpy', device=None, interp_order=1):
     r"""Matrices H_\ell [len(s), len(kin)] with \xi_\ell(s) = H_\ell P_\ell(k_in), reproducing the reference's ``get_corr`` grids
     (theories/galaxy_clustering/base.py:62-77: k = logspace(-4, 3, 2048), tail beyond kin[-1]).
 
-    ``engine='hip'``: the transforms of all len(kin) unit vectors run as ONE batch of the device FFTLog (``dl_fftlog_apply``)."""
+    ``engine='hip'``: the transforms of all len(kin) unit vectors run as ONE batch of the device FFTLog (``dl_fftlog_apply``).
+    ``interp_order``: 1 (linear) or 3 (cubic) interpolation of P_ell to the FFTLog grid (tgc/base.py:54-57, 132) -- either is linear in P_ell, so it folds
+    into the operator."""
     kin = np.asarray(kin, dtype='f8')
     if k is None: k = np.logspace(-4., 3., 2048)
     mask = k > kin[-1]
@@ -152,7 +163,7 @@ def hankel_operator(kin, s, ells, k=None, engine='numpy', device=None):
         for i in range(kin.size):
             unit[i] = 1.
             slope_high = (unit[-1] - unit[-2]) / np.log10(kin[-1] / kin[-2])
-            tmp[i] = np.concatenate([np.interp(logk_mid, logkin, unit), (unit[-1] + slope_high * logk_high) * damp_high])
+            tmp[i] = np.concatenate([_interp_to_grid(logk_mid, logkin, unit, interp_order=interp_order), (unit[-1] + slope_high * logk_high) * damp_high])
             unit[i] = 0.
         ss, corr = fftlog(np.repeat(tmp[:, None, :], nell, axis=1))     # corr [n_kin, n_ell, N]
         fftlog.close()   # free the device plan now (a hipFree deferred to the garbage collector would synchronise the device at an arbitrary later time)
@@ -165,6 +176,6 @@ def hankel_operator(kin, s, ells, k=None, engine='numpy', device=None):
     basis = np.zeros((nell, kin.size), dtype='f8')
     for i in range(kin.size):
         basis[:, i] = 1.
-        H[:, :, i] = correlation_from_power(basis, kin, k, logk_high, damp_high, ~mask, fftlog, s)
+        H[:, :, i] = correlation_from_power(basis, kin, k, logk_high, damp_high, ~mask, fftlog, s, interp_order=interp_order)
         basis[:, i] = 0.
     return H

@@ -293,12 +293,12 @@ class DampedBAOWigglesTracerCorrelationFunctionMultipoles(_BaseDampedBAOTracer):
         s = self.init.get('s', None)
         if s is None: s = np.linspace(20., 200, 101)
         self.s = np.array(s, dtype='f8')
-        interp_order = {'linear': 1, 'cubic': 3}.get(self.init.get('interp_order', 1), self.init.get('interp_order', 1))
-        if interp_order != 1:
-            raise NotImplementedError('only interp_order = 1 (the default) is implemented')
+        self.interp_order = {'linear': 1, 'cubic': 3}.get(self.init.get('interp_order', 1), self.init.get('interp_order', 1))
+        if self.interp_order not in (1, 3):
+            raise ValueError('interp_order must be one of [1, 3]')    # tgc/base.py:54-57
         kfft = np.logspace(-4., 3., 2048)                          # tgc/base.py:62
         kin = self.init.get('k', None)
-        if kin is None: kin = np.geomspace(kfft[0], 0.6, 300)      # tgc/base.py:66
+        if kin is None: kin = np.geomspace(kfft[0], 0.6, int(300. / self.interp_order + 0.5))      # tgc/base.py:66
         self._init_wiggles(kin)
         sp = self.init.get('sp', None)
         self.sp = 2. * np.pi / 0.02 if sp is None else float(sp)   # bao.py:855
@@ -337,7 +337,7 @@ class DampedBAOWigglesTracerCorrelationFunctionMultipoles(_BaseDampedBAOTracer):
         """Hankel operators H_ell [n_s, n_kin], built at first use by ONE batch of the device FFTLog (``dl_fftlog_apply``: all unit vectors of the input grid)."""
         if self._hankel is None:
             from ...fftlog import hankel_operator
-            self._hankel = hankel_operator(self.kin, self.s, self.ells, k=self._kfft, engine='hip')
+            self._hankel = hankel_operator(self.kin, self.s, self.ells, k=self._kfft, engine='hip', interp_order=self.interp_order)
         return self._hankel
 
     @property

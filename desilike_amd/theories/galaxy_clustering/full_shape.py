@@ -213,7 +213,7 @@ class _CorrelationFunctionFromPowerSpectrum(object):
     _stochastic_bias_params = []
 
     def _default_k(self):
-        return np.geomspace(1e-4, 0.6, 300)
+        return np.geomspace(1e-4, 0.6, int(300. / getattr(self, 'interp_order', 1) + 0.5))   # tgc/base.py:66
 
     def initialize(self):
         if self._initialized:
@@ -221,9 +221,9 @@ class _CorrelationFunctionFromPowerSpectrum(object):
         s = self.init.get('s', None)
         if s is None: s = np.linspace(20., 200, 101)
         self.s = np.array(s, dtype='f8')
-        interp_order = {'linear': 1, 'cubic': 3}.get(self.init.get('interp_order', 1), self.init.get('interp_order', 1))
-        if interp_order != 1:
-            raise NotImplementedError('only interp_order = 1 (the default) is implemented')
+        self.interp_order = {'linear': 1, 'cubic': 3}.get(self.init.get('interp_order', 1), self.init.get('interp_order', 1))
+        if self.interp_order not in (1, 3):
+            raise ValueError('interp_order must be one of [1, 3]')    # tgc/base.py:54-57
         self._kfft, self._hankel = np.logspace(-4., 3., 2048), None
         super(_CorrelationFunctionFromPowerSpectrum, self).initialize()
         self.kin = self.k
@@ -233,7 +233,7 @@ class _CorrelationFunctionFromPowerSpectrum(object):
     def hankel(self):
         if self._hankel is None:
             from ...fftlog import hankel_operator
-            self._hankel = hankel_operator(self.kin, self.s, self.ells, k=self._kfft, engine='hip')
+            self._hankel = hankel_operator(self.kin, self.s, self.ells, k=self._kfft, engine='hip', interp_order=self.interp_order)
         return self._hankel
 
     def _fold(self):
@@ -418,12 +418,12 @@ class _VelocileptorsCorrelationFunction(object):
         s = self.init.get('s', None)
         if s is None: s = np.linspace(20., 200, 101)
         self.s = np.array(s, dtype='f8')
-        interp_order = {'linear': 1, 'cubic': 3}.get(self.init.get('interp_order', 1), self.init.get('interp_order', 1))
-        if interp_order != 1:
-            raise NotImplementedError('only interp_order = 1 (the default) is implemented')
+        self.interp_order = {'linear': 1, 'cubic': 3}.get(self.init.get('interp_order', 1), self.init.get('interp_order', 1))
+        if self.interp_order not in (1, 3):
+            raise ValueError('interp_order must be one of [1, 3]')    # tgc/base.py:54-57
         self._kfft, self._hankel = np.logspace(-4., 3., 2048), None
         if self.init.get('k', None) is None:
-            self.init['k'] = np.geomspace(self._kfft[0], 0.6, 300)     # tgc/base.py:66
+            self.init['k'] = np.geomspace(self._kfft[0], 0.6, int(300. / self.interp_order + 0.5))     # tgc/base.py:66
         super(_VelocileptorsCorrelationFunction, self).initialize()
         self.kin = self.k
         return self
@@ -432,7 +432,7 @@ class _VelocileptorsCorrelationFunction(object):
     def hankel(self):
         if self._hankel is None:
             from ...fftlog import hankel_operator
-            self._hankel = hankel_operator(self.kin, self.s, self.ells, k=self._kfft, engine='hip')
+            self._hankel = hankel_operator(self.kin, self.s, self.ells, k=self._kfft, engine='hip', interp_order=self.interp_order)
         return self._hankel
 
     def _fold(self):

@@ -393,8 +393,8 @@ def bruteforce_correlation(kin, power, s, ells):
     return np.array(corr)
 
 
-def get_corr(power, kin, s, ells, k=None, fftlog=None):
-    """theories/galaxy_clustering/base.py:62-77, 127-136 (interp_order = 1)."""
+def get_corr(power, kin, s, ells, k=None, fftlog=None, interp_order=1):
+    """theories/galaxy_clustering/base.py:62-77, 127-136; ``interp_order`` 1 (linear) or 3 (numpy backend: scipy cubic, jax.py:263-265), base.py:54-57."""
     if k is None: k = np.logspace(-4., 3., 2048)
     mask = k > kin[-1]
     logk_high = np.log10(k[mask] / kin[-1])
@@ -404,7 +404,7 @@ def get_corr(power, kin, s, ells, k=None, fftlog=None):
     tmp = []
     for pk in power:
         slope_high = (pk[-1] - pk[-2]) / np.log10(kin[-1] / kin[-2])
-        interp = interp1d(np.log10(k_mid), np.log10(kin), pk, method=1)
+        interp = interp1d(np.log10(k_mid), np.log10(kin), pk, method={1: 1, 3: 'cubic'}[interp_order])
         tmp.append(np.concatenate([interp, (pk[-1] + slope_high * logk_high) * damp_high], axis=-1))
     ss, corr = fftlog(np.vstack(tmp))
     return np.array([np.interp(s, sss, cc) for sss, cc in zip(ss, corr)])

@@ -805,13 +805,14 @@ def simple_tracer():
     print(names)
 
 
-def kaiser_xi(eft=False):
+def kaiser_xi(eft=False, interp_order=1):
     """Full-shape correlation function multipoles: (EFT-like) Kaiser P_ell -> xi_ell through get_corr (tgc/base.py:46-139; FFTLog = the refstub's transform,
     third-party in the reference) with a ShapeFit template, ell = (0, 2, 4), 30 s-bins."""
     from desilike.theories.galaxy_clustering import KaiserTracerCorrelationFunctionMultipoles, EFTLikeKaiserTracerCorrelationFunctionMultipoles
     from desilike.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable
     template = ShapeFitPowerSpectrumTemplate(z=0.5)
-    theory = (EFTLikeKaiserTracerCorrelationFunctionMultipoles if eft else KaiserTracerCorrelationFunctionMultipoles)(template=template)
+    kwargs = {} if interp_order == 1 else dict(interp_order=interp_order)     # 3: cubic interpolation of P_ell (100-point theory grid) to the FFTLog grid, tgc/base.py:54-57, 66, 132
+    theory = (EFTLikeKaiserTracerCorrelationFunctionMultipoles if eft else KaiserTracerCorrelationFunctionMultipoles)(template=template, **kwargs)
     obs = TracerCorrelationFunctionMultipolesObservable(data={'b1': 2.}, s=np.linspace(22.5, 167.5, 30), ells=(0, 2, 4), theory=theory)
     n, scale = 90, 3e-4
     rng = np.random.RandomState(14)
@@ -820,7 +821,7 @@ def kaiser_xi(eft=False):
     like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
     like()
     names = like.varied_params.names()
-    theta = sample_theta(like, 24, seed=19)
+    theta = sample_theta(like, 24 if interp_order == 1 else 8, seed=19)
     vlike = vmap(like, backend=None, errors='return', return_derived=True)
     (logpost, derived), errors = vlike({name: theta[:, i] for i, name in enumerate(names)})
     assert not errors
@@ -837,7 +838,7 @@ def kaiser_xi(eft=False):
          'flatdata': np.asarray(obs.flatdata), 'template': tmpl.__class__.__name__}
     if eft:
         c.update(ct_matrix=np.asarray(pw.counterterm_matrix), sn_matrix=np.asarray(pw.stochastic_matrix), ct_params=np.array(pw.counterterm_params), sn_params=np.array(pw.stochastic_params))
-    save('kaiser_xi' + ('_eft' if eft else ''), names=np.array(names), theta=theta, obs0=c, precision=np.asarray(like.precision), covariance=cov,
+    save('kaiser_xi' + ('_eft' if eft else '') + ('_cubic' if interp_order == 3 else ''), names=np.array(names), theta=theta, obs0=c, precision=np.asarray(like.precision), covariance=cov,
          priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]),
          logposterior=np.asarray(logpost), loglikelihood=np.asarray(derived[like._param_loglikelihood]), logprior=np.asarray(derived[like._param_logprior]),
          power=np.array(power), theory=np.array(corr), flattheory=np.array(flat))
@@ -845,7 +846,7 @@ def kaiser_xi(eft=False):
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi', 'cfg4_resummed', 'cfg4_flexible', 'cfg3_full']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi', 'cfg4_resummed', 'cfg4_flexible', 'cfg3_full', 'kaiser_xi_cubic']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -865,3 +866,4 @@ if __name__ == '__main__':
     if 'kaiser_xi_eft' in todo: kaiser_xi(True)
     if 'cfg3_table' in todo: cfg3_table()
     if 'cfg3_full' in todo: cfg3_full()
+    if 'kaiser_xi_cubic' in todo: kaiser_xi(eft=False, interp_order=3)

@@ -85,3 +85,20 @@ def test_plan_argument_errors():
         FFTLogPlan(10, 24, np.ones(10), np.ones((1, 13, 2)), np.ones((1, 10)), device=0)       # npad not a power of two
     with pytest.raises(LibraryError):
         FFTLogPlan(10, 16384, np.ones(10), np.ones((1, 8193, 2)), np.ones((1, 10)), device=0)  # npad too large for LDS
+
+
+def test_device_fftlog_against_analytic_hankel_pairs():
+    """The device transform against closed-form pairs (Gaussian-damped power laws, Gradshteyn & Ryzhik 6.631.4) -- independent of scipy's and of the host
+    restatement's conventions (see tests/test_oracle_bao.py::test_fftlog_oracle_against_analytic_hankel_pairs)."""
+    from desilike_amd.fftlog import PowerToCorrelation
+    k = np.logspace(-4., 3., 2048)
+    ells = (0, 2, 4)
+    dev = PowerToCorrelation(k, ell=ells, engine='hip', device=0)
+    sigmas = (6., 12., 25.)
+    fun = np.array([[k**ell * np.exp(-0.5 * (k * sigma)**2) for ell in ells] for sigma in sigmas])
+    s, xi = dev(fun)
+    for isig, sigma in enumerate(sigmas):
+        for ill, ell in enumerate(ells):
+            analytic = (-1.)**(ell // 2) / (2. * np.pi**2) * np.sqrt(np.pi / 2.) * s[ill]**ell * sigma**(-(2 * ell + 3)) * np.exp(-0.5 * (s[ill] / sigma)**2)
+            mask = (s[ill] > 1.) & (s[ill] < 200.)
+            assert np.abs(xi[isig, ill][mask] - analytic[mask]).max() <= (1e-8 if ell == 0 else 1e-12) * np.abs(analytic[mask]).max(), (sigma, ell)

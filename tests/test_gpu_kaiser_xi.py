@@ -17,12 +17,13 @@ def make_kaiser_xi(name, data=None):
     from desilike_amd.likelihoods import ObservablesGaussianLikelihood
     g = load_golden(name)
     template = ShapeFitPowerSpectrumTemplate(z=0.5)
-    theory = (EFTLikeKaiserTracerCorrelationFunctionMultipoles if name.endswith('eft') else KaiserTracerCorrelationFunctionMultipoles)(template=template)
+    kwargs = dict(interp_order=3) if name.endswith('cubic') else {}
+    theory = (EFTLikeKaiserTracerCorrelationFunctionMultipoles if name.endswith('eft') else KaiserTracerCorrelationFunctionMultipoles)(template=template, **kwargs)
     obs = TracerCorrelationFunctionMultipolesObservable(data=g['obs0']['flatdata'] if data is None else data, s=np.linspace(22.5, 167.5, 30), ells=(0, 2, 4), theory=theory)
     return g, ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
 
 
-@pytest.mark.parametrize('name', ['kaiser_xi', 'kaiser_xi_eft'])
+@pytest.mark.parametrize('name', ['kaiser_xi', 'kaiser_xi_eft', 'kaiser_xi_cubic'])
 def test_kaiser_xi_call_surface_vs_reference(name):
     from desilike_amd import vmap
     g, like = make_kaiser_xi(name)

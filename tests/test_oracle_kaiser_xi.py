@@ -8,7 +8,7 @@ from oracle import np_oracle as orc
 from golden_utils import load_golden, prior_list
 
 
-def kaiser_xi_point(g, row):
+def kaiser_xi_point(g, row, interp_order=1):
     c = dict(g['obs0'])
     names = [str(n) for n in g['names']]
     p = dict(zip(names, row))
@@ -19,15 +19,16 @@ def kaiser_xi_point(g, row):
         p['ct'] = [2. * p.get(str(n), 0.) for n in c['ct_params']]   # auto-correlation: sum over the two (identical) tracers
         p['sn'] = [0.] * len(c['sn_params'])
     power = orc.fullshape_observable(c, p)['power']
-    return power, orc.get_corr(power, c['kin'], c['s'], tuple(int(ell) for ell in c['ells']))
+    return power, orc.get_corr(power, c['kin'], c['s'], tuple(int(ell) for ell in c['ells']), interp_order=interp_order)
 
 
-@pytest.mark.parametrize('name', ['kaiser_xi', 'kaiser_xi_eft'])
+@pytest.mark.parametrize('name', ['kaiser_xi', 'kaiser_xi_eft', 'kaiser_xi_cubic'])
 def test_kaiser_xi_chain_vs_reference(name):
     g = load_golden(name)
     priors = prior_list(g)
+    assert len(g['obs0']['kin']) == (100 if name.endswith('cubic') else 300)     # tgc/base.py:66
     for i, row in enumerate(g['theta']):
-        power, corr = kaiser_xi_point(g, row)
+        power, corr = kaiser_xi_point(g, row, interp_order=3 if name.endswith('cubic') else 1)
         assert np.allclose(power, g['power'][i], rtol=1e-11, atol=1e-12 * np.abs(g['power'][i]).max())
         assert np.allclose(corr, g['theory'][i], rtol=1e-10, atol=1e-12 * np.abs(g['theory'][i]).max())
         logl = orc.gaussian_loglikelihood(np.ravel(corr), g['obs0']['flatdata'], g['precision'])[0]
