@@ -374,16 +374,17 @@ def main():
         torch.cuda.synchronize(device)
         prewarm_steps += 16
     prewarm_ms = 1e3 * (time.perf_counter() - t0)
+    rotate = args.steps < 100
+    every = max(1, min(25, args.steps // (10 if rotate else 8)))
+    if not args.no_events: ctx.profile_enable(1, rotate=rotate)   # the warm-up steps go through the event path too (its first use allocates: not a sample)
     for _ in range(args.warmup):
         step()
     barrier()
     # HIP events attached to the kernels' own dispatch packets on the launch stream (hipExtLaunchKernelGGL: no event records between the kernels), on at least 8
     # steps of the timed region whatever --steps is
     # Long runs: all three kernels on 8+ sampled steps (0.4 us per step of overhead at 200 steps).  Short runs (the driver's --steps 20): a kernel launched with
-    # events is followed by a ~3 us gap, so each sampled step carries events on ONE kernel (the theory kernel on 3 sampled steps out of 4): at 20 steps, 10 sampled
-    # steps = 8 samples of the theory kernel + 1 of each other kernel for ~1.6 us per step.
-    rotate = args.steps < 100
-    every = max(1, min(25, args.steps // (10 if rotate else 8)))
+    # events is followed by a ~3 us gap, so each sampled step carries events on ONE kernel (theory, GEMM, theory, finalize, theory, ...): at 20 steps, 10 sampled
+    # steps = 6 samples of the theory kernel + 2 of each other kernel (medians) for ~1.6 us per step.
     ctx.profile_enable(0 if args.no_events else every, rotate=rotate)
     gc.disable()
     elapsed = timed_steps(step, barrier, args.steps)

@@ -31,6 +31,7 @@ struct dl_ctx {
     double* priors_dev = nullptr;    // [P, 5]
     int32_t* gemm_counters = nullptr;// [<= 2048 / 32 + 8] arrival counters of the fused chi2 GEMM finalize (zero between launches)
     double* wt_white_dev = nullptr;  // [N_pad, K_pad]  L^T . blockdiag(W_obs)          (chi2 path)
+    std::vector<uint8_t> panel_ranges;   // [N_pad / 16][2]: 128-wide K panels of wt_white with non-zero entries per 16-row column block (chi2 GEMM skips the others)
     double* bias_white_dev = nullptr;// [N_pad]         L^T . (bias - flatdata)
     double* wt_full_dev = nullptr;   // [N_pad, K_pad]  blockdiag(W_obs)                 (flattheory path)
     double* bias_full_dev = nullptr; // [N_pad]
@@ -69,7 +70,7 @@ struct dl_ctx {
     int64_t prof_calls = 0;                  // profiled calls recorded
     int64_t eval_calls = 0;                  // dl_eval_batch calls since dl_profile_enable
     int prof_every = 1;                      // record events on one call out of prof_every (sampling keeps the event overhead out of the throughput)
-    bool prof_rotate = false;                // one kernel per sampled call carries events (theory on 3 sampled calls out of 4, GEMM and finalize in turn on the 4th)
+    bool prof_rotate = false;                // one kernel per sampled call carries events, in the order theory, GEMM, theory, finalize, theory
     std::string last_error;
 };
 
@@ -229,6 +230,23 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
         }
         bias_white[i] = bsum;
         bias_wh[i] = -dsum;
+    }
+    // ---- non-zero K panels per 16-row block of the whitened operator (block-diagonal precisions leave whole panels zero) ----
+    if (ctx->K_pad / 128 <= 255 && !getenv("DL_NO_PANEL_SKIP")) {
+        const int n_tiles = ctx->N_pad / 16, n_panels = ctx->K_pad / 128;
+        ctx->panel_ranges.assign((size_t)2 * n_tiles, 0);
+        for (int t = 0; t < n_tiles; ++t) {
+            int lo = n_panels, hi = 0;
+            for (int r = 16 * t; r < 16 * t + 16; ++r)
+                for (int p = 0; p < n_panels; ++p) {
+                    const double* seg = &wt_white[(size_t)r * ctx->K_pad + (size_t)p * 128];
+                    bool nz = false;
+                    for (int k = 0; k < 128 && !nz; ++k) nz = seg[k] != 0.;
+                    if (nz) { lo = std::min(lo, p); hi = std::max(hi, p + 1); }
+                }
+            if (hi <= lo) { lo = 0; hi = 1; }   // an all-zero block (padding rows): one panel of zeros
+            ctx->panel_ranges[2 * t] = (uint8_t)lo; ctx->panel_ranges[2 * t + 1] = (uint8_t)hi;
+        }
     }
     // ---- feature path: per observable G[(m, j)][h] = W~[j][(h, m)] in fragment order [N_pad / 16][nb_pad / 8][19][lane = col + 16 g][e]: k = 8 q + 2 g + e ----
     std::vector<std::vector<double>> gfrag_host;
@@ -431,7 +449,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         // events attached to the dispatch packets of the launches of phase k (0 theory, 1 GEMM, 2 finalize; dl_kernels.h): with several launches in a phase
         // (one theory launch per observable) the pair holds the LAST one
         const int64_t pc = ctx->prof_calls;
-        const int only = !ctx->prof_rotate ? -1 : (pc % 4 != 3 ? 0 : 1 + (int)((pc / 4) % 2));   // rotating mode: the one phase of this sampled call
+        static const int8_t rotation[5] = {0, 1, 0, 2, 0};
+        const int only = !ctx->prof_rotate ? -1 : rotation[pc % 5];   // rotating mode: the one phase of this sampled call
         if (prof) ctx->prof_phase_of[(size_t)(pc % dl_ctx::NPOOL)] = (int8_t)only;
         auto prof_phase = [&](int k) {
             const bool on = ev && k >= 0 && (only < 0 || only == k);
@@ -486,7 +505,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
             if (nb > 16384) { prof_phase(-1); return dl_fail(ctx, "dl_eval_batch: DL_CHI2_GEMM_MAX above 16384 rows"); }
             dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad,
                                 chi2_fused ? ctx->gemm_counters : nullptr, th, P, ctx->priors_dev, loglike_dev ? loglike_dev + b0 : nullptr,
-                                logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr, post_mode, stream);
+                                logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr, post_mode, stream,
+                                ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data());
         } else if (chi2_big) {
             dl_launch_window_gemm_dma_chi2(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad, stream);
             part_tiles = dl_gemm_dma_chi2_parts(ctx->N_pad);

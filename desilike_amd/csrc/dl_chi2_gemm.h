@@ -44,9 +44,18 @@ struct DlChi2Fin {
     unsigned long long* stamps;   // DL_CG_STAMPS diagnostics (nullptr in production): 8 slots per workgroup, see dl_fullshape_kernel
 };
 
+// Panels of K that hold non-zero entries of the 16 Wt rows of each column block (by value in the kernarg segment: scalar registers).  With a block-diagonal
+// precision (several observables with independent covariances, SumLikelihood) Wt = L^T blockdiag(W_obs) is block diagonal: a column block of observable i
+// only meets the K range of observable i -- the other panels multiply zeros and are skipped (two config-2 tracers: 10 of 19 panels per column block).
+#define DL_CG_MAX_TILES 32
+struct DlChi2Panels {
+    uint8_t lo[DL_CG_MAX_TILES], hi[DL_CG_MAX_TILES];   // [p_lo, p_hi) per column block; hi = 0: all panels
+};
+
 template <bool DO_LOAD, bool DO_MMA>
 __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
-                                                           const double* __restrict__ bias, double* __restrict__ part, int M, int K_pad, int n_tiles, DlChi2Fin fin) {
+                                                           const double* __restrict__ bias, double* __restrict__ part, int M, int K_pad, int n_tiles, DlChi2Fin fin,
+                                                           DlChi2Panels panels) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
@@ -60,6 +69,8 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     DL_CG_STAMP(0, __builtin_amdgcn_s_memtime) DL_CG_STAMP(6, __builtin_amdgcn_s_memrealtime)
     // staging by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write): piece i of wave w is the 1 KB segment of row w + 8 i of the
     // panel (rows 0-31 = A, 32-47 = Wt); the LDS destination of a piece is wave-uniform base + 16 B x lane
+    int p_lo = 0, p_hi = K_pad / DL_CG_KP;   // K_pad is a multiple of the panel width (padding columns are zero in A and Wt)
+    if (nt < DL_CG_MAX_TILES && panels.hi[nt] != 0) { p_lo = panels.lo[nt]; p_hi = panels.hi[nt]; }
     const char* src[DL_CG_VPT];
 #pragma unroll
     for (int i = 0; i < DL_CG_VPT; ++i) {
@@ -67,10 +78,10 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
         const double* base;
         if (row < DL_CG_M) { int ar = m0 + row; if (ar > M - 1) ar = M - 1; base = A + (size_t)ar * lda; }
         else base = Wt + (size_t)(n0 + row - DL_CG_M) * ldw;
-        src[i] = reinterpret_cast<const char*>(base) + 16 * lane;
+        src[i] = reinterpret_cast<const char*>(base) + 16 * lane + (size_t)p_lo * (DL_CG_KP * 8);
     }
     const double bj = bias[n0 + r16];        // requested now, used in the epilogue
-    const int n_panels = K_pad / DL_CG_KP;   // K_pad is a multiple of the panel width (padding columns are zero in A and Wt)
+    const int n_panels = p_hi - p_lo;
     constexpr int BUF = DL_CG_ROWS * DL_CG_LD, NJ = DL_CG_KP / 4 / DL_CG_WAVES;   // doubles per LDS buffer; k-steps per wave and panel
 #define DL_CG_DMA(p)                                                                                                                 \
     {   const size_t off = (size_t)(p) * (DL_CG_KP * 8);                                                                             \

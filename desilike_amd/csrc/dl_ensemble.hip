@@ -52,6 +52,7 @@ __host__ __device__ inline DlPhilox dl_philox4x32(uint32_t c0, uint32_t c1, uint
 // 53-bit uniform on [0, 1) from two 32-bit words (the construction of numpy's random_sample)
 __host__ __device__ inline double dl_uniform53(uint32_t hi, uint32_t lo) { return ((double)(hi >> 5) * 67108864. + (double)(lo >> 6)) * (1. / 9007199254740992.); }
 
+#define DL_ENS_PRE 4           // results of the pending half-step prefetched per thread (covers nwalkers <= 8 DL_ENS_THREADS)
 #define DL_ENS_THREADS 1024   // one workgroup: ranking the 64-bit keys of the random split is O(nwalkers^2 / threads) LDS reads per thread
 enum { DL_ENS_STREAM_PERM = 0, DL_ENS_STREAM_MOVE = 1, DL_ENS_STREAM_ACCEPT = 3 };   // + half-step for the last two
 
@@ -72,59 +73,102 @@ struct DlEnsArgs {
     int32_t half_acc, half_prop; // 0 / 1, or -1: nothing to accept / propose
 };
 
-// One workgroup: the ensemble is a few hundred walkers x <= 64 parameters.  Phases separated by barriers (global memory written before a barrier is visible
-// to the workgroup after it).
+// One workgroup: the ensemble is a few hundred walkers x <= 64 parameters.  STAGED: positions, log-posteriors and the split live in LDS for the duration of the
+// launch (one coalesced load at the top, one write-back at the end): the dependent global round trips of the phases (split -> positions of a walker and of its
+// partner -> proposal) become LDS accesses (profiles/r02a: 15.5 us per launch on average, 30 us for the launches that draw a split, with the state in global memory).
+// Phases are separated by barriers (memory written before a barrier is visible to the workgroup after it).
+template <bool STAGED>
 __global__ __launch_bounds__(DL_ENS_THREADS) void dl_ensemble_step_kernel(const DlEnsArgs s) {
 #pragma clang fp contract(off)   // the NumPy driver rounds after every operation: no fused multiply-adds here
-    extern __shared__ unsigned long long keys[];   // [nw] sort keys of the permutation
+    extern __shared__ __attribute__((aligned(16))) unsigned long long dl_ens_lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int half = s.nw / 2, P = s.P;
+    const int nw = s.nw, half = nw / 2, P = s.P;
+    const int parts = (DL_ENS_THREADS / nw) > 1 ? DL_ENS_THREADS / nw : 1;      // threads that share the ranking of one walker
+    unsigned long long* keys = dl_ens_lds;                                        // [nw] sort keys of the split
+    int* rankpart = reinterpret_cast<int*>(keys + nw);                            // [parts, nw]
+    double* lds_state = reinterpret_cast<double*>(rankpart + (size_t)((parts * nw + 1) & ~1));
+    double* coords = STAGED ? lds_state : s.coords;                               // [nw, P]
+    double* logp = STAGED ? lds_state + (size_t)nw * P : s.logp;                  // [nw]
+    int32_t* perm = STAGED ? reinterpret_cast<int32_t*>(lds_state + (size_t)nw * (P + 1)) : s.perm;   // [nw]
     const double inf = __builtin_huge_val();
+    // the pending half-step's results are requested first: their round trip overlaps the staging of the state
+    double pre_lp[DL_ENS_PRE], pre_f[DL_ENS_PRE];
+    if (s.half_acc >= 0) {
+#pragma unroll
+        for (int q = 0; q < DL_ENS_PRE; ++q) {
+            const int j = tid + q * nthr;
+            pre_lp[q] = j < half ? s.newlp[j] : 0.;
+            pre_f[q] = j < half ? s.factors[j] : 0.;
+        }
+    }
+    if (STAGED) {
+        for (int e = tid; e < nw * P; e += nthr) coords[e] = s.coords[e];
+        for (int e = tid; e < nw; e += nthr) { logp[e] = s.logp[e]; perm[e] = s.perm[e]; }
+        __syncthreads();
+    }
     if (s.half_acc >= 0) {
         // accept / reject the pending proposals (emcee moves/red_blue.py: lnpdiff = factors + new_log_prob - log_prob; accepted = log(u) < lnpdiff)
-        const int32_t* set = s.perm + s.half_acc * half;
-        for (int j = tid; j < half; j += nthr) {
+        const int32_t* set = perm + s.half_acc * half;
+        int q = 0;
+        for (int j = tid; j < half; j += nthr, ++q) {
             const int i = set[j];
             const DlPhilox r = dl_philox4x32((uint32_t)s.it_acc, (uint32_t)((unsigned long long)s.it_acc >> 32), (uint32_t)j, DL_ENS_STREAM_ACCEPT + s.half_acc, s.k0, s.k1);
             const double u = dl_uniform53(r.x[0], r.x[1]);
-            double lp = s.newlp[j];
+            double lp = q < DL_ENS_PRE ? pre_lp[q] : s.newlp[j];
+            const double fj = q < DL_ENS_PRE ? pre_f[q] : s.factors[j];
             if (lp != lp) lp = -inf;                     // NaN results count as -inf (samplers/base.py:187-189)
             lp = lp + s.offset;
-            const double lnpdiff = (s.factors[j] + lp) - s.logp[i];
+            const double lnpdiff = (fj + lp) - logp[i];
             const bool accepted = log(u) < lnpdiff;
             if (accepted) {
-                for (int p = 0; p < P; ++p) s.coords[(size_t)i * P + p] = s.prop[(size_t)j * P + p];
-                s.logp[i] = lp;
+                for (int p = 0; p < P; ++p) coords[(size_t)i * P + p] = s.prop[(size_t)j * P + p];
+                logp[i] = lp;
                 s.nacc[i] += 1;
             }
         }
         __syncthreads();
+        if (STAGED) {   // write-back of the state the accept step changed
+            for (int e = tid; e < nw * P; e += nthr) s.coords[e] = coords[e];
+            for (int e = tid; e < nw; e += nthr) s.logp[e] = logp[e];
+        }
     }
     if (s.chain != nullptr) {
-        for (int e = tid; e < s.nw * P; e += nthr) s.chain[e] = s.coords[e];
+        for (int e = tid; e < nw * P; e += nthr) s.chain[e] = coords[e];
         if (s.chain_logp != nullptr)
-            for (int e = tid; e < s.nw; e += nthr) s.chain_logp[e] = s.logp[e];
+            for (int e = tid; e < nw; e += nthr) s.chain_logp[e] = logp[e];
     }
     if (s.half_prop < 0) return;
     if (s.half_prop == 0) {
         // random split of the ensemble into two halves: walkers ranked by a 64-bit key each (ties by index) -- numpy: argsort(keys, kind='stable')
-        for (int i = tid; i < s.nw; i += nthr) {
+        for (int i = tid; i < nw; i += nthr) {
             const DlPhilox r = dl_philox4x32((uint32_t)s.it_prop, (uint32_t)((unsigned long long)s.it_prop >> 32), (uint32_t)i, DL_ENS_STREAM_PERM, s.k0, s.k1);
             keys[i] = ((unsigned long long)r.x[0] << 32) | r.x[1];
         }
         __syncthreads();
-        for (int i = tid; i < s.nw; i += nthr) {
+        // rank of walker i = number of keys below its own: `parts` threads share the scan of one walker (nw <= DL_ENS_THREADS), partial counts meet in LDS
+        const int span = (nw + parts - 1) / parts;
+        for (int t = tid; t < parts * nw; t += nthr) {
+            const int i = t % nw, part = t / nw;
             const unsigned long long ki = keys[i];
+            const int j0 = part * span, j1 = (j0 + span < nw) ? j0 + span : nw;
             int rank = 0;
-            for (int j = 0; j < s.nw; ++j) { const unsigned long long kj = keys[j]; rank += (kj < ki) || (kj == ki && j < i); }
-            s.perm[rank] = i;
+#pragma unroll 8
+            for (int j = j0; j < j1; ++j) { const unsigned long long kj = keys[j]; rank += (int)((kj < ki) | ((kj == ki) & (j < i))); }
+            rankpart[part * nw + i] = rank;
+        }
+        __syncthreads();
+        for (int i = tid; i < nw; i += nthr) {
+            int rank = 0;
+            for (int part = 0; part < parts; ++part) rank += rankpart[part * nw + i];
+            perm[rank] = i;
+            if (STAGED) s.perm[rank] = i;
         }
         __syncthreads();
     }
     {
         // stretch move (emcee moves/stretch.py): z ~ g(z) on [1/a, a], partner drawn from the complementary half, q = c - (c - s) z
-        const int32_t* set = s.perm + s.half_prop * half;
-        const int32_t* comp = s.perm + (1 - s.half_prop) * half;
+        const int32_t* set = perm + s.half_prop * half;
+        const int32_t* comp = perm + (1 - s.half_prop) * half;
         for (int j = tid; j < half; j += nthr) {
             const DlPhilox r = dl_philox4x32((uint32_t)s.it_prop, (uint32_t)((unsigned long long)s.it_prop >> 32), (uint32_t)j, DL_ENS_STREAM_MOVE + s.half_prop, s.k0, s.k1);
             const double u = dl_uniform53(r.x[0], r.x[1]);
@@ -132,11 +176,31 @@ __global__ __launch_bounds__(DL_ENS_THREADS) void dl_ensemble_step_kernel(const 
             const double zz = (t * t) / s.a;
             const int ic = comp[r.x[2] % (uint32_t)half], is = set[j];
             for (int p = 0; p < P; ++p) {
-                const double c = s.coords[(size_t)ic * P + p], x = s.coords[(size_t)is * P + p];
+                const double c = coords[(size_t)ic * P + p], x = coords[(size_t)is * P + p];
                 s.prop[(size_t)j * P + p] = c - (c - x) * zz;
             }
             s.factors[j] = (P - 1.) * log(zz);
         }
+    }
+}
+
+// LDS bytes of a launch; staged = false: keys and partial ranks only
+size_t dl_ens_shared_bytes(int nw, int P, bool staged) {
+    const int parts = (DL_ENS_THREADS / nw) > 1 ? DL_ENS_THREADS / nw : 1;
+    size_t bytes = (size_t)nw * 8 + (size_t)((parts * nw + 1) & ~1) * 4;
+    if (staged) bytes += (size_t)nw * (P + 1) * 8 + (size_t)nw * 4;
+    return (bytes + 15) & ~(size_t)15;
+}
+
+void dl_ens_launch(const DlEnsArgs& s, hipStream_t stream) {
+    const bool staged = dl_ens_shared_bytes(s.nw, s.P, true) <= 144 * 1024;
+    const size_t shm = dl_ens_shared_bytes(s.nw, s.P, staged);
+    if (staged) {
+        if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_ensemble_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(dl_ensemble_step_kernel<true>, dim3(1), dim3(DL_ENS_THREADS), shm, stream, s);
+    } else {
+        if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_ensemble_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(dl_ensemble_step_kernel<false>, dim3(1), dim3(DL_ENS_THREADS), shm, stream, s);
     }
 }
 
@@ -245,7 +309,6 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
     s.coords = ens->coords; s.logp = ens->logp; s.nacc = ens->nacc; s.perm = ens->perm; s.prop = ens->prop; s.factors = ens->factors; s.newlp = ens->newlp;
     s.nw = nw; s.P = P; s.a = ens->a; s.offset = ens->offset;
     s.k0 = (uint32_t)ens->seed; s.k1 = (uint32_t)(ens->seed >> 32);
-    const size_t shm = (size_t)nw * sizeof(unsigned long long);
     s.half_acc = -1;
     const long long it0 = ens->iteration;
     // the launch that proposes half-step (it, h) also accepts the half-step before it; the accept of half-step 1 completes an iteration: recorded there
@@ -262,13 +325,13 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
         for (int h = 0; h < 2; ++h) {
             s.it_prop = it; s.half_prop = h;
             set_record();
-            hipLaunchKernelGGL(dl_ensemble_step_kernel, dim3(1), dim3(DL_ENS_THREADS), shm, stream, s);
+            dl_ens_launch(s, stream);
             if (dl_ens_logposterior(ens, ens->prop, half, ens->newlp, stream)) return 1;
             s.it_acc = it; s.half_acc = h;
         }
     s.half_prop = -1;
     set_record();
-    hipLaunchKernelGGL(dl_ensemble_step_kernel, dim3(1), dim3(DL_ENS_THREADS), shm, stream, s);
+    dl_ens_launch(s, stream);
     DL_ENS_HIP(hipGetLastError());
     ens->iteration += niterations;
     return 0;

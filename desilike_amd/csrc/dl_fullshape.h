@@ -157,7 +157,8 @@ struct DlFsShared {
     double* y;     // [n_t] template power at the knots
     double* M;     // [n_t] pivot-scaled right-hand side, then spline moments (second derivatives) M[1 .. n_t-2]
     double* z;     // [n_t] forward-sweep result
-    double* coef;  // [n_t][4] per-interval polynomial in the fractional knot index
+    double* coef;  // per-interval polynomial in the fractional knot index, TWO PLANES: (c0, c1) of interval j at coef[2 j], (c2, c3) at coef[2 n_t + 2 j] -- lanes that
+                   // evaluate neighbouring intervals then read consecutive 16-byte slots (ds_read_b128 conflict-free; [n_t][4] rows put them 32 bytes apart: 2-way)
     double* out;   // [n_in] output multipoles, staged for one coalesced store (ALIASES y, M, z: dead once coef is built)
     double* pt;    // [DL_PT_SIZE]
 };
@@ -279,7 +280,7 @@ DL_HD void dl_fs_knots(int tid, int nthr, const DlObsDev& o, const double* th, c
     const int n_t = o.n_t;
     if (o.toeplitz && !o.fixed_spline && tid < 2 * DL_FIR_PAD) s.y[tid < DL_FIR_PAD ? tid - DL_FIR_PAD : n_t + tid - DL_FIR_PAD] = 0.;   // zero padding
     if (o.fixed_spline) {
-        for (int j = tid; j < 4 * n_t; j += nthr) s.coef[j] = o.coef_fixed[j];
+        for (int j = tid; j < 4 * n_t; j += nthr) s.coef[(j & 2) * n_t + 2 * (j >> 2) + (j & 1)] = o.coef_fixed[j];   // host rows [n_t][4] -> the two planes
     } else if (o.templ == 1) {
         // power_template.py:749: exp(dm / a * tanh(a * log(k / kp)) + dn * log(k / kp))
         double dm_a = dl_get(o.dm, th) / o.a, dn = dl_get(o.dn, th);
@@ -405,7 +406,7 @@ DL_HD void dl_fs_phase2d(int tid, int nthr, const DlObsDev& o, const DlFsShared&
         } else {
             d0 = c0; d1 = c1 * h; d2 = c2 * h * h; d3 = c3 * h * h * h;
         }
-        s.coef[4 * j + 0] = d0; s.coef[4 * j + 1] = d1; s.coef[4 * j + 2] = d2; s.coef[4 * j + 3] = d3;
+        s.coef[2 * j + 0] = d0; s.coef[2 * j + 1] = d1; s.coef[2 * n + 2 * j + 0] = d2; s.coef[2 * n + 2 * j + 1] = d3;
     }
 }
 
@@ -482,10 +483,10 @@ DL_HD void dl_fs_phase2d_toep(int tid, int nthr, const DlObsDev& o, const DlFsSh
         const double c2 = 0.5 * Ml;
         const double c3 = (Mr - Ml) * ihx * (1. / 6.);
         const double dl = -(it < DL_TOEP_PREF ? dlt_pref[it] : o.dlt[j]);
-        s.coef[4 * j + 0] = c0 + dl * (c1 + dl * (c2 + dl * c3));
-        s.coef[4 * j + 1] = hx * (c1 + dl * (2. * c2 + 3. * dl * c3));
-        s.coef[4 * j + 2] = hx * hx * (c2 + 3. * dl * c3);
-        s.coef[4 * j + 3] = hx * hx * hx * c3;
+        s.coef[2 * j + 0] = c0 + dl * (c1 + dl * (c2 + dl * c3));
+        s.coef[2 * j + 1] = hx * (c1 + dl * (2. * c2 + 3. * dl * c3));
+        s.coef[2 * n + 2 * j + 0] = hx * hx * (c2 + 3. * dl * c3);
+        s.coef[2 * n + 2 * j + 1] = hx * hx * hx * c3;
     }
 }
 
@@ -517,8 +518,9 @@ DL_HD double dl_spline_eval(const DlObsDev& o, const DlFsShared& s, double x) {
     int j;
     double u;
     dl_spline_locate<UNIF>(o, x, j, u);
-    const double* c = s.coef + 4 * j;
-    return fma(fma(fma(c[3], u, c[2]), u, c[1]), u, c[0]);
+    const double* c = s.coef + 2 * j;
+    const double* d = c + 2 * o.n_t;
+    return fma(fma(fma(d[1], u, d[0]), u, c[1]), u, c[0]);
 }
 
 // uniform knots, abscissa already in units of the knot spacing: t = (x - x0) inv_hx
@@ -527,8 +529,9 @@ DL_HD double dl_spline_eval_t(const DlObsDev& o, const DlFsShared& s, double t) 
     int j = (int)tc;
     if (j > o.n_t - 2) j = o.n_t - 2;
     const double u = t - (double)j;
-    const double* c = s.coef + 4 * j;
-    return fma(fma(fma(c[3], u, c[2]), u, c[1]), u, c[0]);
+    const double* c = s.coef + 2 * j;
+    const double* d = c + 2 * o.n_t;
+    return fma(fma(fma(d[1], u, d[0]), u, c[1]), u, c[0]);
 }
 
 // phase 3: (k, mu) evaluation, multipole projection, tracer combination; writes power (and tables).

@@ -433,7 +433,8 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         DlObsDev tmp = d;
         tmp.ih = sp.ih.data(); tmp.x_t = x_t.data(); tmp.dlt = dlt.data();
         dl_fs_phase2d(0, 1, tmp, sh);
-        for (size_t c = 0; c < coef.size(); ++c) coef[c] = sh.coef[c];
+        for (int j = 0; j < d.n_t; ++j)   // the two planes of the shared layout -> rows [n_t][4] (what coef_fixed / coef_w / coef_n hold)
+            for (int q = 0; q < 4; ++q) coef[(size_t)4 * j + q] = sh.coef[(size_t)(q >> 1) * 2 * d.n_t + 2 * j + (q & 1)];
     }
     // BAO wiggle model (bao.py:117-140): constant splines of P_now and of the wiggle P_dd - P_now, P_now at the fiducial k
     std::vector<double> coef_w(4, 0.), coef_n(4, 0.), pknow_k(2, 0.);
@@ -449,7 +450,9 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
             DlObsDev tmp = d;
             tmp.ih = sp.ih.data(); tmp.x_t = x_t.data(); tmp.dlt = dlt.data();
             dl_fs_phase2d(0, 1, tmp, sh);
-            out.assign(sh.coef, sh.coef + (size_t)4 * d.n_t);
+            out.assign((size_t)4 * d.n_t, 0.);
+            for (int j = 0; j < d.n_t; ++j)
+                for (int q = 0; q < 4; ++q) out[(size_t)4 * j + q] = sh.coef[(size_t)(q >> 1) * 2 * d.n_t + 2 * j + (q & 1)];
         };
         std::vector<double> wig(d.n_t);
         for (int j = 0; j < d.n_t; ++j) wig[j] = pk[j] - pknow[j];

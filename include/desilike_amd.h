@@ -169,7 +169,7 @@ int  dl_eval_logposterior_host(dl_ctx* ctx, const double* theta, int64_t B, doub
  * ms[0] theory kernel, ms[1] window / chi2 GEMM, ms[2] chi2 / prior finalize, ms[3] start of the first kernel to the end of the last,
  * ms[4] (if n >= 5) 0 (kept for compatibility), ms[5] (if n >= 6) number of sampled calls, ms[6..8] (if n >= 9) samples per kernel.
  * enable | (1 << 16): rotating mode -- a kernel launched with events is followed by a ~3 us gap, so each sampled call attaches them to ONE kernel only
- * (the theory kernel on three sampled calls out of four, the GEMM and the finalize kernel in turn on the fourth); ms[3] is then 0. */
+ * (in the order theory, GEMM, theory, finalize, theory, ...); ms[3] is then 0. */
 int  dl_profile_enable(dl_ctx* ctx, int enable);
 int  dl_profile_read(dl_ctx* ctx, double* ms, int32_t n);
 

@@ -22,5 +22,5 @@ cd $R
 cp $OUT/trace/*kernel_stats.csv $OUT/${TAG}_kernel_stats.csv 2>/dev/null
 cp $OUT/trace_ens/*kernel_stats.csv $OUT/${TAG}_ensemble_kernel_stats.csv 2>/dev/null
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/${TAG}_pmc_hbm_traffic.txt 2>&1
-python3 tools/sq_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 > $OUT/${TAG}_pmc_sq_counters.txt 2>&1
+python3 tools/sq_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 --stats $OUT/${TAG}_kernel_stats.csv > $OUT/${TAG}_pmc_sq_counters.txt 2>&1
 rm -rf $OUT/trace $OUT/trace_ens $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3
