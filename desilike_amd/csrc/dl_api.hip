@@ -17,6 +17,7 @@ void dl_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 struct dl_ctx {
     int device = 0;
     int n_params = 0, n_obs = 0, n_data = 0;
+    int n_white = 0;                 // width of the whitened residual rows (= n_data, or more when the observables' row ranges are aligned to 16: see dl_create)
     int N_pad = 0, K_pad = 0, max_n_t = 0;
     bool any_transform = false;
     // analytic marginalisation
@@ -176,7 +177,6 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     int n = ctx->n_data;
     int K = (int)col;
     ctx->K_pad = round_up(K, 128);   // whole 128-wide panels of the chi2 GEMM (dl_chi2_gemm.h); padding columns are zero in both operands
-    ctx->N_pad = round_up(n, 128);   // N tile of the tiled GEMM
     // ---- precision -> Cholesky factor (likelihoods/base.py:13-17: chi2 = d P d = |L^T d|^2) ----
     const auto& prec = cfg->F("precision");
     std::vector<double> L((size_t)n * n, 0.);
@@ -200,6 +200,32 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
             L[(size_t)i * n + i] = std::sqrt(prec[i]);
         }
     } else return bail("dl_create: precision must have n_data^2 or n_data entries");
+    // ---- position of each whitened row in the residual layout ----
+    // Row i of L^T X mixes the data rows j >= i with L[j][i] != 0.  With independent observables (block-diagonal precision: SumLikelihood, joint covariances
+    // without cross terms) L is block diagonal and whitened row i belongs to the observable of data row i: each observable's rows then start on a multiple of 16,
+    // so that no 16-row column block of the chi2 GEMM straddles two observables (a straddling block needs the K ranges of both: it alone kept the launch at the
+    // full K, profiles/r02b).  chi2 is a sum over the whitened rows: where they sit does not matter, padding rows are zero in every operand.
+    std::vector<int> wr(n);
+    for (int i = 0; i < n; ++i) wr[i] = i;
+    ctx->n_white = n;
+    if (ctx->n_obs > 1 && !dense_factor && !getenv("DL_NO_ROW_ALIGN")) {
+        std::vector<int> owner(n);
+        for (int o = 0; o < ctx->n_obs; ++o)
+            for (int r = 0; r < ctx->obs[o].n_out; ++r) owner[ctx->obs_row0[o] + r] = o;
+        bool block_diagonal = true;
+        for (int j = 0; j < n && block_diagonal; ++j)
+            for (int i = 0; i < j; ++i)
+                if (owner[i] != owner[j] && L[(size_t)j * n + i] != 0.) { block_diagonal = false; break; }
+        if (block_diagonal) {
+            int pos = 0;
+            for (int o = 0; o < ctx->n_obs; ++o) {
+                pos = round_up(pos, 16);
+                for (int r = 0; r < ctx->obs[o].n_out; ++r) wr[ctx->obs_row0[o] + r] = pos++;
+            }
+            ctx->n_white = pos;
+        }
+    }
+    ctx->N_pad = round_up(ctx->n_white, 128);   // N tile of the tiled GEMM
     // ---- assemble GEMM operands ----
     size_t NK = (size_t)ctx->N_pad * ctx->K_pad;
     std::vector<double> wt_full(NK, 0.), wt_white(NK, 0.), bias_full(ctx->N_pad, 0.), bias_white(ctx->N_pad, 0.), flatdata(ctx->N_pad, 0.);
@@ -217,7 +243,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     }
     // whitened: row i of (L^T . X) = sum_{j >= i} L[j][i] X[j]
     for (int i = 0; i < n; ++i) {
-        double* dst = &wt_white[(size_t)i * ctx->K_pad];
+        double* dst = &wt_white[(size_t)wr[i] * ctx->K_pad];
         double bsum = 0., dsum = 0.;
         for (int j = dense_factor ? 0 : i; j < n; ++j) {
             double lji = L[(size_t)j * n + i];
@@ -226,10 +252,10 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
             for (int k = 0; k < K; ++k) dst[k] += lji * src[k];
             bsum += lji * (bias_full[j] - flatdata[j]);
             dsum += lji * flatdata[j];
-            wh[(size_t)i * ctx->N_pad + j] = lji;
+            wh[(size_t)wr[i] * ctx->N_pad + j] = lji;
         }
-        bias_white[i] = bsum;
-        bias_wh[i] = -dsum;
+        bias_white[wr[i]] = bsum;
+        bias_wh[wr[i]] = -dsum;
     }
     // ---- non-zero K panels per 16-row block of the whitened operator (block-diagonal precisions leave whole panels zero) ----
     if (ctx->K_pad / 128 <= 255 && !getenv("DL_NO_PANEL_SKIP")) {
@@ -286,7 +312,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
         if (ns > DL_MAX_SOLVED) return bail("dl_create: at most 16 analytically solved parameters");
         if ((int)mprior.size() != 2 * ns || (int)mx0.size() != ns) return bail("dl_create: marg.prior / marg.x0 sizes do not match marg.kind");
         if (ns > 0 && ctx->any_transform) return bail("dl_create: analytic marginalisation needs a theory linear in the solved parameters (no observable transform)");
-        if (ns > 0 && n > 64 * DL_MARG_NJ) return bail("dl_create: analytic marginalisation supports up to 512 data points");
+        if (ns > 0 && ctx->n_white > 64 * DL_MARG_NJ) return bail("dl_create: analytic marginalisation supports up to 512 data points");
         ctx->n_solved = ns;
         std::memset(&ctx->marg, 0, sizeof(ctx->marg));
         ctx->marg.n_s = ns;
@@ -338,7 +364,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
                     if (ob.marg_sn[c] == s_)
                         for (int idx = 0; idx < od.n_in; ++idx) dst[idx] += snm[(size_t)idx * od.n_sn + c] / od.nd;
             }
-            for (int i = 0; i < n; ++i) {
+            for (int i = 0; i < ctx->n_white; ++i) {   // (whitened rows in their residual layout; alignment padding rows are zero)
                 double sum = 0.;
                 const double* wrow = &wt_white[(size_t)i * ctx->K_pad];
                 for (int k = 0; k < K; ++k) sum += wrow[k] * dvec[k];
@@ -531,12 +557,12 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
             dl_launch_finalize_part(ctx->delta_ws, part_tiles, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
                                     status_dev ? status_dev + b0 : nullptr, post_mode, stream);
         else if (ctx->n_solved > 0)
-            dl_launch_finalize_marg(ctx->delta_ws, ctx->N_pad, n, R, n_slabs, slab_stride, fin_bias, ctx->marg, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr,
+            dl_launch_finalize_marg(ctx->delta_ws, ctx->N_pad, ctx->n_white, R, n_slabs, slab_stride, fin_bias, ctx->marg, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr,
                                     logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr,
                                     solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr,
                                     hessian_dev ? hessian_dev + (size_t)b0 * ctx->n_solved * ctx->n_solved : nullptr, post_mode, stream, feat_path && ctx->n_obs == 1);
         else
-            dl_launch_finalize(ctx->delta_ws, ctx->N_pad, n, n_slabs, slab_stride, fin_bias, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
+            dl_launch_finalize(ctx->delta_ws, ctx->N_pad, ctx->n_white, n_slabs, slab_stride, fin_bias, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
                                status_dev ? status_dev + b0 : nullptr, post_mode, stream);
         prof_phase(-1);
         if (prof) ctx->prof_calls++;
@@ -568,7 +594,7 @@ int dl_eval_fisher(dl_ctx* ctx, const double* centers_dev, const double* steps_d
     if (ctx->n_solved > 0) return dl_fail(ctx, "dl_eval_fisher: the context has analytically solved parameters: create it with these parameters varied (the reference does the same, fisher.py:688-695)");
     const int P = ctx->n_params, n = ctx->n_data, S = 1 + 2 * P;
     if (P > 31) return dl_fail(ctx, "dl_eval_fisher: at most 31 varied parameters");
-    if (dl_fisher_waves(n, P, nullptr) < 1) return dl_fail(ctx, "dl_eval_fisher: data vector too long for the LDS-resident Gram product");
+    if (dl_fisher_waves(ctx->n_white, P, nullptr) < 1) return dl_fail(ctx, "dl_eval_fisher: data vector too long for the LDS-resident Gram product");
     if (B == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
     dl_prof_events.start = dl_prof_events.stop = nullptr;
@@ -608,7 +634,7 @@ int dl_eval_fisher(dl_ctx* ctx, const double* centers_dev, const double* steps_d
                 dl_launch_window_gemm_tiled(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->delta_ws, slab_stride, ctx->N_pad, nb, ctx->N_pad, ctx->K_pad, n_slabs, cps, stream);
             }
         }
-        dl_launch_fisher(ctx->delta_ws, ctx->N_pad, n, n_slabs, slab_stride, bias, steps, P, nc, hessian_dev ? hessian_dev + (size_t)b0 * P * P : nullptr,
+        dl_launch_fisher(ctx->delta_ws, ctx->N_pad, ctx->n_white, n_slabs, slab_stride, bias, steps, P, nc, hessian_dev ? hessian_dev + (size_t)b0 * P * P : nullptr,
                          gradient_dev ? gradient_dev + (size_t)b0 * P : nullptr, offset_dev ? offset_dev + b0 : nullptr, stream);
     }
     DL_HIP_CHECK(ctx, hipGetLastError());

@@ -84,8 +84,8 @@ __global__ __launch_bounds__(DL_ENS_THREADS) void dl_ensemble_step_kernel(const 
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int nw = s.nw, half = nw / 2, P = s.P;
     const int parts = (DL_ENS_THREADS / nw) > 1 ? DL_ENS_THREADS / nw : 1;      // threads that share the ranking of one walker
-    unsigned long long* keys = dl_ens_lds;                                        // [nw] sort keys of the split
-    int* rankpart = reinterpret_cast<int*>(keys + nw);                            // [parts, nw]
+    uint32_t* keys = reinterpret_cast<uint32_t*>(dl_ens_lds);                     // [nw] sort keys of the split (the slot is sized for 8 bytes per walker)
+    int* rankpart = reinterpret_cast<int*>(dl_ens_lds + nw);                      // [parts, nw]
     double* lds_state = reinterpret_cast<double*>(rankpart + (size_t)((parts * nw + 1) & ~1));
     double* coords = STAGED ? lds_state : s.coords;                               // [nw, P]
     double* logp = STAGED ? lds_state + (size_t)nw * P : s.logp;                  // [nw]
@@ -139,21 +139,23 @@ __global__ __launch_bounds__(DL_ENS_THREADS) void dl_ensemble_step_kernel(const 
     }
     if (s.half_prop < 0) return;
     if (s.half_prop == 0) {
-        // random split of the ensemble into two halves: walkers ranked by a 64-bit key each (ties by index) -- numpy: argsort(keys, kind='stable')
+        // random split of the ensemble into two halves: walkers ranked by a 32-bit key each = 19 random bits above the walker index (13 bits: distinct keys,
+        // ties of the random part fall back on the index) -- numpy: argsort((x0 & ~0x1fff) | i).  One compare + one add per pair: the O(nwalkers^2) ranking runs
+        // on ONE CU (a 64-bit key with a separate tie rule cost 8.5 us of a 30 us launch at 512 walkers, profiles/r02b)
         for (int i = tid; i < nw; i += nthr) {
             const DlPhilox r = dl_philox4x32((uint32_t)s.it_prop, (uint32_t)((unsigned long long)s.it_prop >> 32), (uint32_t)i, DL_ENS_STREAM_PERM, s.k0, s.k1);
-            keys[i] = ((unsigned long long)r.x[0] << 32) | r.x[1];
+            keys[i] = (r.x[0] & ~0x1fffu) | (uint32_t)i;
         }
         __syncthreads();
         // rank of walker i = number of keys below its own: `parts` threads share the scan of one walker (nw <= DL_ENS_THREADS), partial counts meet in LDS
         const int span = (nw + parts - 1) / parts;
         for (int t = tid; t < parts * nw; t += nthr) {
             const int i = t % nw, part = t / nw;
-            const unsigned long long ki = keys[i];
+            const uint32_t ki = keys[i];
             const int j0 = part * span, j1 = (j0 + span < nw) ? j0 + span : nw;
             int rank = 0;
-#pragma unroll 8
-            for (int j = j0; j < j1; ++j) { const unsigned long long kj = keys[j]; rank += (int)((kj < ki) | ((kj == ki) & (j < i))); }
+#pragma unroll 16
+            for (int j = j0; j < j1; ++j) rank += (int)(keys[j] < ki);
             rankpart[part * nw + i] = rank;
         }
         __syncthreads();

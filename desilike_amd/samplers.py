@@ -50,8 +50,9 @@ class CounterRNG(object):
         return ((hi >> np.uint32(5)).astype('f8') * 67108864. + (lo >> np.uint32(6)).astype('f8')) / 9007199254740992.
 
     def permutation(self, iteration, n):
+        # 19 random bits above the walker index (n <= 8192): distinct keys, ties of the random part fall back on the index (csrc/dl_ensemble.hip)
         words = self.draw(iteration, self.PERM, n)
-        keys = (words[:, 0].astype(np.uint64) << np.uint64(32)) | words[:, 1].astype(np.uint64)
+        keys = (words[:, 0] & np.uint32(0xFFFFE000)) | np.arange(n, dtype=np.uint32)
         return np.argsort(keys, kind='stable')
 
     def move(self, iteration, half, n):
