@@ -374,18 +374,19 @@ def main():
         torch.cuda.synchronize(device)
         prewarm_steps += 16
     prewarm_ms = 1e3 * (time.perf_counter() - t0)
-    rotate = args.steps < 100
-    every = max(1, min(25, args.steps // (10 if rotate else 8)))
-    if not args.no_events: ctx.profile_enable(1, rotate=rotate)   # the warm-up steps go through the event path too (its first use allocates: not a sample)
+    # Long runs: all three kernels on 8+ sampled steps (0.4 us per step of overhead at 200 steps).  Short runs (the driver's --steps 20): a kernel launched with
+    # events is followed by a ~3 us gap, so only the kernel that dominates the step (the theory kernel: established by the long runs and by rocprofv3,
+    # profiles/) carries events, on every second step: 10 samples for ~1.6 us per step; the other kernels are reported as null.
+    short = args.steps < 100
+    only = 'theory' if short else None
+    every = max(1, min(25, args.steps // (10 if short else 8)))
+    if not args.no_events: ctx.profile_enable(1, only=only)   # the warm-up steps go through the event path too (its first use allocates: not a sample)
     for _ in range(args.warmup):
         step()
     barrier()
     # HIP events attached to the kernels' own dispatch packets on the launch stream (hipExtLaunchKernelGGL: no event records between the kernels), on at least 8
     # steps of the timed region whatever --steps is
-    # Long runs: all three kernels on 8+ sampled steps (0.4 us per step of overhead at 200 steps).  Short runs (the driver's --steps 20): a kernel launched with
-    # events is followed by a ~3 us gap, so each sampled step carries events on ONE kernel (theory, GEMM, theory, finalize, theory, ...): at 20 steps, 10 sampled
-    # steps = 6 samples of the theory kernel + 2 of each other kernel (medians) for ~1.6 us per step.
-    ctx.profile_enable(0 if args.no_events else every, rotate=rotate)
+    ctx.profile_enable(0 if args.no_events else every, only=only)
     gc.disable()
     elapsed = timed_steps(step, barrier, args.steps)
     gc.enable()
@@ -401,7 +402,7 @@ def main():
     if rank == 0:
         value = world * B * args.steps / elapsed
         flops = {'theory': FLOP_THEORY, 'window_gemm': FLOP_GEMM, 'finalize': FLOP_FINAL}
-        dominant = max(['theory', 'window_gemm', 'finalize'], key=lambda name: kernel_ms[name])
+        dominant = 'theory' if short else max(['theory', 'window_gemm', 'finalize'], key=lambda name: kernel_ms[name])
         kernel_name = {'theory': 'dl_fullshape_kernel', 'window_gemm': 'dl_chi2_gemm_kernel', 'finalize': 'dl_finalize_part_kernel'}[dominant]
         traffic, traffic_source = hbm_traffic(kernel_name) if B == BATCH else (None, None)
         per_launch = min(B, 32768)   # batches above 32768 points are evaluated in internal passes of 32768: the kernel intervals are per pass
@@ -421,8 +422,8 @@ def main():
                                'kernel': kernel_name, 'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS, 'traffic': traffic,
                                'traffic_source': traffic_source, 'flop_per_launch': flops[dominant] * per_launch, 'avg_launch_ms': kernel_ms[dominant],
                                'event_samples': int(kernel_ms.get('samples_per_kernel', {}).get(dominant, kernel_ms.get('samples', 0))),
-                               'event_mode': 'one kernel per sampled step' if rotate else 'all kernels of a sampled step'},
-                  'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize']},
+                               'event_mode': 'the dominant kernel only, every {:d} steps (short run)'.format(every) if short else 'all kernels of a sampled step, every {:d} steps'.format(every)},
+                  'kernel_ms': {name: (kernel_ms[name] if kernel_ms[name] > 0. else None) for name in ['theory', 'window_gemm', 'finalize']},
                   'kernel_frac_of_fp64_peak': {name: flops[name] * per_launch / (kernel_ms[name] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS for name in ['theory', 'window_gemm'] if kernel_ms[name] > 0.}}
         if strong is not None:
             result['config5_strong'] = strong

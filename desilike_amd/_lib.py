@@ -305,10 +305,13 @@ class Context(object):
                                              ctypes.c_void_p(gradient.data_ptr()), ctypes.c_void_p(offset.data_ptr()), ctypes.c_void_p(stream)))
         return hessian, gradient, offset
 
-    def profile_enable(self, every=1, rotate=False):
-        """Attach HIP events to the kernels' dispatch packets on one ``eval_batch`` call out of ``every`` (0 / False: off); ``rotate``: one kernel per
-        sampled call (short runs: a kernel launched with events costs the step ~3 us)."""
-        self._check(self._lib.dl_profile_enable(self._handle, int(every) | ((1 << 16) if rotate and every else 0)))
+    def profile_enable(self, every=1, only=None):
+        """Attach HIP events to the kernels' dispatch packets on one ``eval_batch`` call out of ``every`` (0 / False: off); ``only``: 'theory' /
+        'window_gemm' / 'finalize' -- a single kernel per sampled call (short runs: every kernel launched with events costs the step ~3 us)."""
+        flags = 0
+        if only is not None and every:
+            flags = (1 << 16) | (['theory', 'window_gemm', 'finalize'].index(only) << 17)
+        self._check(self._lib.dl_profile_enable(self._handle, int(every) | flags))
 
     def profile_read(self):
         ms = np.zeros(9, dtype='f8')

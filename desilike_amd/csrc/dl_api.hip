@@ -71,7 +71,8 @@ struct dl_ctx {
     int64_t prof_calls = 0;                  // profiled calls recorded
     int64_t eval_calls = 0;                  // dl_eval_batch calls since dl_profile_enable
     int prof_every = 1;                      // record events on one call out of prof_every (sampling keeps the event overhead out of the throughput)
-    bool prof_rotate = false;                // one kernel per sampled call carries events, in the order theory, GEMM, theory, finalize, theory
+    bool prof_rotate = false;                // single-kernel mode: only phase prof_only carries events on a sampled call
+    int prof_only = 0;
     std::string last_error;
 };
 
@@ -475,8 +476,7 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         // events attached to the dispatch packets of the launches of phase k (0 theory, 1 GEMM, 2 finalize; dl_kernels.h): with several launches in a phase
         // (one theory launch per observable) the pair holds the LAST one
         const int64_t pc = ctx->prof_calls;
-        static const int8_t rotation[5] = {0, 1, 0, 2, 0};
-        const int only = !ctx->prof_rotate ? -1 : rotation[pc % 5];   // rotating mode: the one phase of this sampled call
+        const int only = !ctx->prof_rotate ? -1 : ctx->prof_only;   // single-kernel mode: the one phase that carries events
         if (prof) ctx->prof_phase_of[(size_t)(pc % dl_ctx::NPOOL)] = (int8_t)only;
         auto prof_phase = [&](int k) {
             const bool on = ev && k >= 0 && (only < 0 || only == k);
@@ -766,6 +766,8 @@ int dl_profile_enable(dl_ctx* ctx, int enable) {
     }
     ctx->prof_phase_of.assign(dl_ctx::NPOOL, -1);
     ctx->prof_rotate = (enable & (1 << 16)) != 0;
+    ctx->prof_only = (enable >> 17) & 3;
+    if (ctx->prof_only > 2) ctx->prof_only = 0;
     enable &= 0xffff;
     ctx->profile = enable != 0;
     ctx->prof_every = enable > 1 ? enable : 1;

@@ -43,11 +43,15 @@ def _exchange_bytes(payload, rank, world):
         return box[0]
     from datetime import timedelta
     host = os.environ.get('MASTER_ADDR', '127.0.0.1')
-    port = int(os.environ.get('DL_COMM_PORT', int(os.environ.get('MASTER_PORT', 29500)) + 1))
     if not _stores:
-        _stores.append(dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=timedelta(seconds=300), wait_for_workers=False))
+        if os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '') == 'True' and 'DL_COMM_PORT' not in os.environ:
+            # under torchrun the agent already hosts a store at MASTER_ADDR:MASTER_PORT (what torch's own env:// rendezvous connects to): every rank is a client
+            _stores.append(dist.TCPStore(host, int(os.environ['MASTER_PORT']), world, is_master=False, timeout=timedelta(seconds=300)))
+        else:
+            port = int(os.environ.get('DL_COMM_PORT', int(os.environ.get('MASTER_PORT', 29500)) + 1))
+            _stores.append(dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=timedelta(seconds=300), wait_for_workers=False))
     store = _stores[0]
-    key = 'dl_comm_id_{:d}'.format(_store_calls[0])
+    key = 'desilike_amd/comm_id/{}/{:d}'.format(os.environ.get('TORCHELASTIC_RUN_ID', 'job'), _store_calls[0])
     _store_calls[0] += 1
     if rank == 0:
         store.set(key, payload)

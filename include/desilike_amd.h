@@ -168,8 +168,9 @@ int  dl_eval_logposterior_host(dl_ctx* ctx, const double* theta, int64_t B, doub
  * dl_profile_read synchronises and returns per-kernel milliseconds, the median over the (up to 256) sampled calls:
  * ms[0] theory kernel, ms[1] window / chi2 GEMM, ms[2] chi2 / prior finalize, ms[3] start of the first kernel to the end of the last,
  * ms[4] (if n >= 5) 0 (kept for compatibility), ms[5] (if n >= 6) number of sampled calls, ms[6..8] (if n >= 9) samples per kernel.
- * enable | (1 << 16): rotating mode -- a kernel launched with events is followed by a ~3 us gap, so each sampled call attaches them to ONE kernel only
- * (in the order theory, GEMM, theory, finalize, theory, ...); ms[3] is then 0. */
+ * enable | (1 << 16) | (k << 17): single-kernel mode -- a kernel launched with events is followed by a ~3 us gap in the stream, so a sampled call attaches
+ * them to ONE kernel only (k = 0 theory, 1 GEMM, 2 finalize); the other entries of ms[] are then 0.  (Without the gap that follows an instrumented
+ * predecessor, the interval also contains the overlap with the predecessor's drain: ~0.2 us for the theory kernel.) */
 int  dl_profile_enable(dl_ctx* ctx, int enable);
 int  dl_profile_read(dl_ctx* ctx, double* ms, int32_t n);
 

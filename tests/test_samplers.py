@@ -315,3 +315,41 @@ def test_bench_spawns_its_ranks():
     env.update(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--dry-run'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert out.returncode == 0 and json.loads(out.stdout.decode().strip().splitlines()[-1])['n_gpus'] == 1
+
+
+def test_comm_bootstrap_under_torchrun_and_plain_launch(tmp_path):
+    """The 128-byte RCCL id travels from rank 0 to the others over a TCP store: torchrun's own agent store (clients of MASTER_PORT) or, launched plainly
+    (bench.py --gpus N), a store rank 0 hosts on MASTER_PORT + 1 -- the two ways the driver may start the ranks."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'exchange.py'
+    script.write_text('''
+import os, sys
+sys.path.insert(0, {root!r})
+from desilike_amd.parallel import _exchange_bytes
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+for it in range(2):
+    payload = _exchange_bytes(bytes([it, 7, 9] * 40) if rank == 0 else None, rank, world)
+    assert payload == bytes([it, 7, 9] * 40), (rank, payload)
+# (in the product the ranks meet again in the collective dl_comm_create; here rank 0, which may host the store, must not leave before the others have read)
+from desilike_amd.parallel import _stores
+_stores[0].set('test/done/{{:d}}'.format(rank), '1')
+_stores[0].wait(['test/done/{{:d}}'.format(r) for r in range(world)])
+open(os.path.join({tmp!r}, 'ok_{{}}_{{:d}}'.format(os.environ.get('TORCHELASTIC_USE_AGENT_STORE'), rank)), 'w').write('ok')
+'''.format(root=root, tmp=str(tmp_path)))
+    env = {key: value for key, value in os.environ.items() if key not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_USE_AGENT_STORE')}
+    def free_port():
+        import socket
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            return s.getsockname()[1]
+
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(free_port()), str(script)],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert out.returncode == 0 and all((tmp_path / 'ok_True_{:d}'.format(rank)).exists() for rank in range(2)), out.stdout.decode()[-2000:]
+    port, comm_port = free_port(), free_port()
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DL_COMM_PORT=str(comm_port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for rank in range(2)]
+    for rank, proc in enumerate(procs):
+        text = proc.communicate(timeout=300)[0].decode()
+        assert proc.returncode == 0 and (tmp_path / 'ok_None_{:d}'.format(rank)).exists(), text[-2000:]
