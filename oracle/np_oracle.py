@@ -295,10 +295,14 @@ def fullshape_observable(c, p):
 # ----------------------------------------------------------------------------------------------
 # a10: analytic marginalisation / best-fit of linear nuisance parameters
 #      likelihoods/base.py:129-200 (FastFisher.__call__), 314-413 (BaseLikelihood._solve)
-# PARITY UNPINNED by the reference itself: the reference needs jax (likelihoods/base.py:130) which is absent here, and its
-# tests only run/plot (samplers/tests/test_base.py:380-408).  Pinned instead by (i) the Gaussian-integral identity against
-# the reference's own NON-marginalised likelihood evaluated on a grid of the solved parameter (golden fixture
-# tests/golden/marg_sn0_grid.npz) and (ii) closed forms, in tests/test_oracle_marg.py.
+# The reference's own `_solve` cannot run here (it needs jax, likelihoods/base.py:130) and its tests only run / plot
+# (samplers/tests/test_base.py:380-408): no direct output of it exists to compare with -- "pinned by identity on reference outputs":
+#  (i) tests/golden/marg_sn0_grid.npz: the reference's NON-marginalised posterior on a grid of one solved parameter; the Gaussian integral must equal the
+#      marginalised value (tests/test_oracle_marg.py, 1e-6);
+#  (ii) tests/golden/marg_multi.npz: the exact quadratic form (c, g, H) of the reference's non-marginalised log-posterior in SEVERAL linear parameters (two counter
+#      terms with point-dependent derivative rows + a stochastic term; two tracers), obtained from the reference on a stencil; the closed forms
+#      x* = x0 - H^-1 g, c - g H^-1 g / 2 - logdet(-H[M, M]) / 2 pin this function and the HIP path to 1e-8 (tests/test_marg_multi.py), '.marg' / '.best' mixes included;
+#  (iii) closed forms with flat priors / diagonal precisions (tests/test_oracle_marg.py).
 # ----------------------------------------------------------------------------------------------
 def solve_marginalized(flatdiff, flatderiv, precision, x0, prior_loc, prior_scale, marg_mask):
     """One parameter point.

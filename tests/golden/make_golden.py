@@ -260,6 +260,85 @@ def marg_grid():
          priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]))
 
 
+def marg_multi():
+    """Multi-parameter pin of analytic marginalisation (likelihoods/base.py:314-413; the reference's own implementation needs jax): the reference's NON-marginalised
+    log-posterior is an exact quadratic form of the linear parameters x,  log p(x) = c + g.(x - x0) + 1/2 (x - x0)^T H (x - x0)  (H includes the Gaussian priors of x).
+    It is evaluated by the reference on the stencil {x0, x0 +- d_i e_i, x0 + d_i e_i + d_j e_j}; (c, g, H) follow exactly and with them the closed forms
+        x* = x0 - H^-1 g,   logposterior(.best) = c - 1/2 g H^-1 g,   logposterior(.marg over M) = that - 1/2 logdet(-H[M, M])      (reference convention 394-404: no 2 pi).
+    Cases: (a) EFT-like Kaiser with two counter terms (derivative rows depend on the point) and a stochastic term, (b) two tracers with both shot-noise terms."""
+    def quadratic_form(like, names, row, solved, x0, steps):
+        base = dict(zip(names, row))
+
+        def logpost(x):
+            return like(**{**base, **dict(zip(solved, x))})
+
+        ns = len(solved)
+        f0 = logpost(x0)
+        g, H = np.zeros(ns), np.zeros((ns, ns))
+        fp, fm = np.zeros(ns), np.zeros(ns)
+        for i in range(ns):
+            e = np.zeros(ns); e[i] = steps[i]
+            fp[i], fm[i] = logpost(x0 + e), logpost(x0 - e)
+            g[i] = (fp[i] - fm[i]) / (2. * steps[i])
+            H[i, i] = (fp[i] - 2. * f0 + fm[i]) / steps[i]**2
+        for i in range(ns):
+            for j in range(i + 1, ns):
+                e = np.zeros(ns); e[i], e[j] = steps[i], steps[j]
+                fpp = logpost(x0 + e)
+                H[i, j] = H[j, i] = (fpp - fp[i] - fp[j] + f0) / (steps[i] * steps[j])
+        # exactness check: an independent point
+        e = 0.37 * np.asarray(steps) * (1. + np.arange(ns))
+        assert abs(logpost(x0 + e) - (f0 + g.dot(e) + 0.5 * e.dot(H).dot(e))) < 1e-8 * max(1., abs(f0)), 'the reference posterior is not quadratic in the solved parameters'
+        return f0, g, H
+
+    out = {}
+    # (a) EFT-like Kaiser: ct0_2, ct2_2 (point-dependent derivative rows), sn0_2
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    theory = EFTLikeKaiserTracerPowerSpectrumMultipoles(template=template)
+    theory.init.params['ct0_2'].update(prior=dict(dist='norm', loc=0., scale=30.))
+    theory.init.params['ct2_2'].update(prior=dict(dist='norm', loc=1., scale=50.))
+    theory.init.params['sn0_2'].update(prior=dict(dist='norm', loc=0., scale=5.))
+    for name in ['ct4_2', 'sn2_2', 'sn4_2']:
+        theory.init.params[name].update(fixed=True, value=0.)
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 1.9, 'ct0_2': 3., 'sn0_2': 0.5}, kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 3}, theory=theory, shotnoise=1e4)
+    cov = spd_covariance(120, seed=21)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=cov)
+    like()
+    names = like.varied_params.names()
+    solved = ['ct0_2', 'ct2_2', 'sn0_2']
+    others = [name for name in names if name not in solved]
+    theta = sample_theta(like, 5, seed=23)
+    x0 = np.array([like.all_params[name].value for name in solved])
+    rows = []
+    for row in theta:
+        rows.append(quadratic_form(like, names, row, solved, x0, steps=[10., 15., 2.]))
+    out['a'] = dict(names=np.array(others), solved=np.array(solved), theta=theta[:, [names.index(name) for name in others]], x0=x0,
+                    c=np.array([r[0] for r in rows]), g=np.array([r[1] for r in rows]), H=np.array([r[2] for r in rows]),
+                    prior=np.array([[0., 30.], [1., 50.], [0., 5.]]), flatdata=np.asarray(obs.flatdata), covariance=cov)
+    # (b) two tracers, LRG.sn0 and ELG.sn0
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    observables = []
+    for tracer, b1, kmax in [('LRG', 2., 0.2), ('ELG', 1.3, 0.15)]:
+        theory = KaiserTracerPowerSpectrumMultipoles(template=template, tracers=tracer)
+        theory.init.params[tracer + '.sn0'].update(prior=dict(dist='norm', loc=0.1, scale=2.))
+        nk = int(round(kmax / 0.005))
+        observables.append(TracerPowerSpectrumMultipolesObservable(data={tracer + '.b1': b1, tracer + '.sn0': 0.3}, kedges=np.linspace(0., kmax, nk + 1), ells=(0, 2, 4), wmatrix={'resolution': 4},
+                                                                   theory=theory, shotnoise=1e4 if tracer == 'LRG' else 4e3))
+    cov = spd_covariance(210, seed=22)
+    like = ObservablesGaussianLikelihood(observables=observables, covariance=cov)
+    like()
+    names = like.varied_params.names()
+    solved = ['LRG.sn0', 'ELG.sn0']
+    others = [name for name in names if name not in solved]
+    theta = sample_theta(like, 5, seed=24)
+    x0 = np.array([like.all_params[name].value for name in solved])
+    rows = [quadratic_form(like, names, row, solved, x0, steps=[1.5, 1.5]) for row in theta]
+    out['b'] = dict(names=np.array(others), solved=np.array(solved), theta=theta[:, [names.index(name) for name in others]], x0=x0,
+                    c=np.array([r[0] for r in rows]), g=np.array([r[1] for r in rows]), H=np.array([r[2] for r in rows]), prior=np.array([[0.1, 2.], [0.1, 2.]]),
+                    flatdata0=np.asarray(observables[0].flatdata), flatdata1=np.asarray(observables[1].flatdata), covariance=cov)
+    save('marg_multi', **out)
+
+
 def cfg5():
     """BASELINE config 5 (one walker batch): two tracers, one ObservablesGaussianLikelihood with a joint covariance, shared ShapeFit template,
     per-tracer b1 / sn0 namespaces (full_shape.py:59-133; likelihoods/base.py:567, 662-664)."""
@@ -846,7 +925,7 @@ def kaiser_xi(eft=False, interp_order=1):
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi', 'cfg4_resummed', 'cfg4_flexible', 'cfg3_full', 'kaiser_xi_cubic']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi', 'cfg4_resummed', 'cfg4_flexible', 'cfg3_full', 'kaiser_xi_cubic', 'marg_multi']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -867,3 +946,4 @@ if __name__ == '__main__':
     if 'cfg3_table' in todo: cfg3_table()
     if 'cfg3_full' in todo: cfg3_full()
     if 'kaiser_xi_cubic' in todo: kaiser_xi(eft=False, interp_order=3)
+    if 'marg_multi' in todo: marg_multi()

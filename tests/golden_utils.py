@@ -99,3 +99,16 @@ def spec_from_golden_bao(g):
                ells_in=np.asarray(c['ellsin'], dtype='i4'), kin=c['kin'], mu=c['mu'], wmu_ell=c['wmu_ell'], k_t=c['k11'], pk_dd_fid=c['pk_dd_fid'], pknow_dd_fid=c['pknow_dd_fid'],
                bao_mode=np.array([1 if str(c['mode']) == 'reciso' else 0]), smoothing_radius=[float(c['smoothing_radius'])], wmatrix=wmatrix, flatdata=c['flatdata'], inputs=inputs, **extra)
     return dict(n_params=np.array([len(names)]), priors=g['priors'], precision=g['precision'], observables=[obs])
+
+
+def constants_from_mirror(obs):
+    """Oracle-side constants dict of an initialised host-mirror observable (no GPU needed): what ``observable_constants`` reads from a fixture."""
+    obs.initialize()
+    wm, theory = obs.wmatrix, obs.wmatrix.theory
+    template = theory.template
+    c = dict(template='shapefit' if type(template).__name__.startswith('ShapeFit') else 'fixed', k11=template.k, pk_dd_fid=template.pk_dd_fid, f_fid=template.f_fid,
+             kp=getattr(template, 'kp', 0.03), a=getattr(template, 'a', 0.6), kin=theory.k, mu=theory.mu, wmu_ell=theory.wmu, ellsin=tuple(theory.ells), ells=tuple(wm.ells), nd=theory.nd,
+             matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout, flatdata=obs.flatdata)
+    if hasattr(theory, 'counterterm_matrix'):
+        c.update(ct_matrix=theory.counterterm_matrix, sn_matrix=theory.stochastic_matrix, ct_params=list(theory.counterterm_params), sn_params=list(theory.stochastic_params))
+    return c
