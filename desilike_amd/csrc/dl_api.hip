@@ -29,6 +29,7 @@ struct dl_ctx {
     // device constants
     double* arena_dev = nullptr;     // per-observable theory constants
     std::vector<DlObsDev> obs_kernarg; // observables with device pointers, passed by value to the theory kernel
+    DlObsDev* obs_array_dev = nullptr; // the same structs in device memory (one theory launch for several observables)
     double* priors_dev = nullptr;    // [P, 5]
     int32_t* gemm_counters = nullptr;// [<= 2048 / 32 + 8] arrival counters of the fused chi2 GEMM finalize (zero between launches)
     double* wt_white_dev = nullptr;  // [N_pad, K_pad]  L^T . blockdiag(W_obs)          (chi2 path)
@@ -384,6 +385,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     }
     ctx->obs_kernarg.resize(ctx->n_obs);
     for (int i = 0; i < ctx->n_obs; ++i) { ctx->obs[i].rebase(ctx->arena_dev); ctx->obs_kernarg[i] = ctx->obs[i].dev; }
+    if (dl_upload(ctx, &ctx->obs_array_dev, ctx->obs_kernarg)) { dl_destroy(ctx); return 1; }
     {   // arrival counters of the fused chi2-GEMM finalize: one per 32-row block of the largest pass that takes that path (self-resetting)
         size_t nbytes = (16384 / 32 + 8) * sizeof(int32_t);
         if (hipMalloc((void**)&ctx->gemm_counters, nbytes) != hipSuccess || hipMemset(ctx->gemm_counters, 0, nbytes) != hipSuccess) { dl_fail(ctx, "dl_create: counter allocation failed"); dl_destroy(ctx); return 1; }
@@ -404,7 +406,7 @@ void dl_destroy(dl_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     void* ptrs[] = {ctx->arena_dev, ctx->priors_dev, ctx->wt_white_dev, ctx->bias_white_dev, ctx->wt_full_dev, ctx->bias_full_dev, ctx->wh_dev,
                     ctx->bias_wh_dev, ctx->flatdata_dev, ctx->transform_dev, ctx->tconst_dev, ctx->power_ws, ctx->delta_ws, ctx->flat_ws, ctx->stencil_ws, ctx->theta_stage, ctx->out_stage,
-                    ctx->status_stage, ctx->gemm_counters};
+                    ctx->status_stage, ctx->gemm_counters, ctx->obs_array_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (double* p : ctx->gfrag_dev) if (p) (void)hipFree(p);
     if (ctx->feat_ws) (void)hipFree(ctx->feat_ws);
@@ -496,7 +498,7 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         prof_phase(0);
         if (!(feat_path && emu_fused))
             dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, feat_path ? ctx->feat_ws : nullptr, ctx->feat_ld,
-                                xcd_block);
+                                xcd_block, ctx->obs_array_dev);
         prof_phase(1);
         int n_slabs = 1, cps = 0;
         int64_t slab_stride = 0;
@@ -621,7 +623,7 @@ int dl_eval_fisher(dl_ctx* ctx, const double* centers_dev, const double* steps_d
             }
             bias = ctx->bias_white_dev;
         } else {
-            dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, nullptr, 0, 0);
+            dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, nullptr, 0, 0, ctx->obs_array_dev);
             if (ctx->any_transform) {
                 // flattheory -> observable transform -> whitened residual (bias added by the direct GEMM)
                 dl_launch_window_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_full_dev, ctx->K_pad, ctx->bias_full_dev, ctx->flat_ws, ctx->N_pad, nb, ctx->N_pad, ctx->N_pad, ctx->K_pad, 1, stream);
@@ -813,3 +815,24 @@ int dl_profile_read(dl_ctx* ctx, double* ms, int32_t n) {
 }
 
 }  // extern "C"
+
+int dl_internal_eval_partials(dl_ctx* ctx, const double* theta_dev, int64_t B, const double** part, int* n_tiles, const double** priors, hipStream_t stream) {
+    if (!ctx || !theta_dev || !part || !n_tiles || !priors || B <= 0) return 1;
+    static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 2048;
+    if (ctx->feat_ok || ctx->any_transform || ctx->n_solved != 0 || B > chi2_max_rows || B > DL_CHUNK) return 2;
+    for (auto& ob : ctx->obs) if (ob.dev.theory == 3) return 2;
+    dl_prof_events.start = dl_prof_events.stop = nullptr;
+    DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (dl_order_streams(ctx, stream)) return 1;
+    if (dl_reserve(ctx, B)) return 1;
+    static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;
+    dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, theta_dev, ctx->n_params, B, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, nullptr, 0, xcd_local ? 32 : 0, ctx->obs_array_dev);
+    dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, B, ctx->N_pad, ctx->K_pad, nullptr, theta_dev, ctx->n_params,
+                        ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream, ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data());
+    *part = ctx->delta_ws;
+    *n_tiles = ctx->N_pad / 16;
+    *priors = ctx->priors_dev;
+    DL_HIP_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+

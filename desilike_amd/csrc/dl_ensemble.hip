@@ -19,6 +19,7 @@
 
 #include "../../include/desilike_amd.h"
 #include "dl_kernels.h"
+#include "dl_finalize_part.h"
 
 namespace {
 
@@ -66,6 +67,9 @@ struct DlEnsArgs {
     double* newlp;         // [half_pad] log-posteriors of the proposals (all ranks' shares after the all-gather)
     double* chain;         // record target of this launch: [nw, P] or null
     double* chain_logp;    // [nw] or null
+    const double* part;    // deferred finalize (single rank, plain likelihood): partial chi2 [half, n_tiles] of the pending proposals straight from the chi2 GEMM,
+    const double* priors;  // ... prior table [P, 5]: this kernel sums the partials, adds the priors and applies the status rules itself (no finalize launch)
+    int32_t n_tiles;
     int32_t nw, P;
     double a, offset;
     uint32_t k0, k1;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(DL_ENS_THREADS) void dl_ensemble_step_kernel(const 
 #pragma unroll
         for (int q = 0; q < DL_ENS_PRE; ++q) {
             const int j = tid + q * nthr;
-            pre_lp[q] = j < half ? s.newlp[j] : 0.;
+            pre_lp[q] = (j < half && s.part == nullptr) ? s.newlp[j] : 0.;
             pre_f[q] = j < half ? s.factors[j] : 0.;
         }
     }
@@ -114,7 +118,13 @@ __global__ __launch_bounds__(DL_ENS_THREADS) void dl_ensemble_step_kernel(const 
             const int i = set[j];
             const DlPhilox r = dl_philox4x32((uint32_t)s.it_acc, (uint32_t)((unsigned long long)s.it_acc >> 32), (uint32_t)j, DL_ENS_STREAM_ACCEPT + s.half_acc, s.k0, s.k1);
             const double u = dl_uniform53(r.x[0], r.x[1]);
-            double lp = q < DL_ENS_PRE ? pre_lp[q] : s.newlp[j];
+            double lp;
+            if (s.part != nullptr) {
+                double ll, lpr;
+                int st;
+                dl_finalize_point(s.part + (size_t)j * s.n_tiles, s.n_tiles, s.prop + (size_t)j * P, P, s.priors, ll, lpr, st);
+                lp = st == 0 ? ll + lpr : -inf;          // what dl_eval_logposterior writes (samplers/base.py:185-191)
+            } else lp = q < DL_ENS_PRE ? pre_lp[q] : s.newlp[j];
             const double fj = q < DL_ENS_PRE ? pre_f[q] : s.factors[j];
             if (lp != lp) lp = -inf;                     // NaN results count as -inf (samplers/base.py:187-189)
             lp = lp + s.offset;
@@ -217,6 +227,7 @@ struct dl_ensemble {
     uint64_t seed = 0;
     long long iteration = 0;      // ensemble updates done since creation (the counter of the random number generator)
     bool have_logp = false;
+    bool deferred = true;         // finish the proposals' log-posteriors inside the step kernel (single rank, contexts on the chi2 GEMM path)
     double *coords = nullptr, *logp = nullptr, *prop = nullptr, *factors = nullptr, *newlp = nullptr;
     long long* nacc = nullptr;
     int32_t* perm = nullptr;
@@ -328,7 +339,13 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
             s.it_prop = it; s.half_prop = h;
             set_record();
             dl_ens_launch(s, stream);
-            if (dl_ens_logposterior(ens, ens->prop, half, ens->newlp, stream)) return 1;
+            s.part = nullptr;
+            if (ens->deferred && !(ens->comm && ens->world > 1) && !getenv("DL_ENS_NO_DEFER")) {
+                int rc = dl_internal_eval_partials(ens->ctx, ens->prop, half, &s.part, &s.n_tiles, &s.priors, stream);
+                if (rc == 1) return 1;
+                if (rc == 2) { ens->deferred = false; s.part = nullptr; }
+            }
+            if (s.part == nullptr && dl_ens_logposterior(ens, ens->prop, half, ens->newlp, stream)) return 1;
             s.it_acc = it; s.half_acc = h;
         }
     s.half_prop = -1;

@@ -1,0 +1,29 @@
+// chi2 / prior / status of ONE point from the partial chi2 of the column blocks of the chi2 GEMM (dl_chi2_gemm.h): shared by dl_finalize_part_kernel and by the
+// ensemble step kernel (dl_ensemble.hip), which finishes the pending half-step's proposals itself instead of waiting for a separate finalize launch.
+// Priors: parameter.py:1994-2017 (uniform / norm, maximum removed, closed limits); status rules of include/desilike_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+__device__ __forceinline__ void dl_finalize_point(const double* __restrict__ part_row, int n_tiles, const double* __restrict__ theta_row, int n_params,
+                                                  const double* __restrict__ priors, double& ll, double& lp, int& st) {
+    double chi2 = 0.;
+    for (int t = 0; t < n_tiles; ++t) chi2 += part_row[t];   // fixed order: deterministic
+    lp = 0.;
+    bool nan_in = false;
+    const double inf = __builtin_huge_val();
+    for (int p = 0; p < n_params; ++p) {
+        double x = theta_row[p];
+        const double* pr = priors + 5 * p;
+        if (x != x) nan_in = true;
+        bool isin = (pr[1] <= x) && (x <= pr[2]);
+        double v = 0.;
+        if (pr[0] == 1.) { double t = x - pr[3]; v = -0.5 * (t * t) / (pr[4] * pr[4]); }   // parameter.py:2007
+        lp += isin ? v : -inf;
+    }
+    ll = -0.5 * chi2;
+    st = 0;                                                                   // DL_STATUS_OK
+    if (nan_in) st = 3;                                                       // DL_STATUS_NAN_INPUT
+    else if (lp == -inf) st = 1;                                              // DL_STATUS_OUT_OF_PRIOR
+    else if (!(ll == ll) || ll == inf || ll == -inf) st = 2;                  // DL_STATUS_NONFINITE
+}

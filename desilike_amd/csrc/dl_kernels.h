@@ -24,7 +24,8 @@ extern thread_local DlProfEvents dl_prof_events;
 
 // obs_host: HOST array of observables whose pointers already point into device memory (passed by value to the kernel)
 void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
-                         int64_t ld_tables, hipStream_t stream, double* feat = nullptr, int64_t feat_ld = 0, int xcd_block = 0);   // xcd_block: rows per row block of the consuming GEMM (0: points in launch order)
+                         int64_t ld_tables, hipStream_t stream, double* feat = nullptr, int64_t feat_ld = 0, int xcd_block = 0,   // xcd_block: rows per row block of the consuming GEMM (0: points in launch order)
+                         const DlObsDev* obs_dev = nullptr);   // obs_dev: the same observables as a DEVICE array (enables one launch for all of them)
 // bias is added to rows r with r % bias_period == 0 only (bias_period = 1: every row)
 void dl_launch_window_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* C, int64_t ldc, int64_t M, int N_valid, int N_pad,
                            int K_pad, int bias_period, hipStream_t stream);
@@ -75,5 +76,10 @@ void dl_launch_fisher_stencil(const double* centers, const double* steps, int P,
 int dl_fisher_waves(int n, int P, size_t* shm_bytes);   // centres per workgroup (0: too large for the LDS)
 void dl_launch_fisher(const double* rows, int64_t ld, int n, int n_slabs, int64_t slab_stride, const double* bias, const double* steps, int P, int64_t B, double* hessian,
                       double* gradient, double* offset, hipStream_t stream);
+// Internal (dl_api.hip -> dl_ensemble.hip): theory + chi2 GEMM of B <= 2048 points of a plain likelihood, WITHOUT the finalize launch: *part = partial chi2
+// [B, *n_tiles] (the context's workspace: valid until its next call), *priors = the prior table [P, 5].  Returns 0, 1 (error) or 2 (this context / batch does not
+// take the chi2 GEMM path: use dl_eval_logposterior).
+struct dl_ctx;
+int dl_internal_eval_partials(dl_ctx* ctx, const double* theta_dev, int64_t B, const double** part, int* n_tiles, const double** priors, hipStream_t stream);
 // last-error string of the C ABI (thread-local, read by dl_last_error(NULL)); set by translation units other than dl_api.hip
 void dl_set_last_error(const char* msg);

@@ -16,6 +16,7 @@
 #include "dl_fullshape.h"
 #include "dl_kernels.h"
 #include "dl_emu_batch.h"
+#include "dl_finalize_part.h"
 
 thread_local DlProfEvents dl_prof_events;
 
@@ -26,9 +27,9 @@ thread_local DlProfEvents dl_prof_events;
 // global-memory pointer (global_load, not flat_load) and every scalar field is an SGPR, never re-read in a loop.
 // DENSE (fast kernels without counter terms): 71 VGPRs and 31 KB of LDS, five workgroups per CU -- for batches that keep every CU oversubscribed (+9 % at 32768 points);
 // otherwise the two-wavenumber projection loop with 122 VGPRs, four workgroups per CU (shorter workgroup life: 14.0 vs 15.5 us per launch at 1024 points).
-template <bool FAST, int NL, bool EFT, bool DENSE = false>
-__global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power,
-                                                                     int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after, unsigned long long* __restrict__ stamps) {
+template <bool FAST, int NL, bool EFT, bool DENSE>
+__device__ __forceinline__ void dl_fullshape_body(const DlObsDev& o, const double* __restrict__ theta, int n_params, double* __restrict__ power,
+                                                  int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // Workgroups are dealt round-robin to the 8 XCDs; the GEMM that follows runs row block mb (xblk = 32 or 64 points) on XCD mb % 8.  With xblk > 0 the points are dealt
     // so that a row block is PRODUCED on the XCD that consumes it (B a multiple of 8 xblk): workgroup w = xcd + 8 r handles point xblk (xcd + 8 (r / xblk)) + r % xblk.
@@ -130,6 +131,21 @@ __global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_ker
 #undef DL_STAMP
 }
 
+template <bool FAST, int NL, bool EFT, bool DENSE = false>
+__global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power,
+                                                                     int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after, unsigned long long* __restrict__ stamps) {
+    dl_fullshape_body<FAST, NL, EFT, DENSE>(o, theta, n_params, power, ld_power, tables, ld_tables, stop_after, stamps);
+}
+
+// Several observables in ONE launch (blockIdx.y = observable): two DlObsDev (2 x 2016 bytes) do not fit the 4 KB kernarg segment, so the structs are read from a
+// device array -- uniform, read-only addresses: scalar loads all the same.  Saves one launch ramp / drain per extra observable where the step is launch-latency
+// bound (two tracers x 256 walkers: 2 x 8.6 us -> one launch).
+template <bool FAST, int NL, bool EFT, bool DENSE = false>
+__global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_multi_kernel(const DlObsDev* __restrict__ obs, const double* __restrict__ theta, int n_params,
+                                                                           double* __restrict__ power, int64_t ld_power, int stop_after) {
+    dl_fullshape_body<FAST, NL, EFT, DENSE>(obs[blockIdx.y], theta, n_params, power, ld_power, nullptr, 0, stop_after, nullptr);
+}
+
 // BAO wiggle model: one workgroup per point; constant splines read from global memory, no per-point spline build.  One kernel per wiggle model: registers are
 // allocated for the worst branch of a kernel (all four models behind one run-time switch: 165 VGPRs, three waves per SIMD, the standard model 15 % slower).
 template <int MODEL>
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(DL_FS_THREADS) void dl_emulated_kernel(const DlObsD
 }
 
 void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, double* tables,
-                         int64_t ld_tables, hipStream_t stream, double* feat, int64_t feat_ld, int xcd_block) {
+                         int64_t ld_tables, hipStream_t stream, double* feat, int64_t feat_ld, int xcd_block, const DlObsDev* obs_dev) {
     static const int stop_after = getenv("DL_FS_STOP") ? atoi(getenv("DL_FS_STOP")) : 0;   // per-phase timing diagnostics
     // DL_FS_STAMPS=<file>: in-kernel timestamps of the launches with B >= 256 are appended to <file> as text (synchronises: diagnostics only)
     static const char* stamp_file = getenv("DL_FS_STAMPS");
@@ -163,6 +179,29 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
     if (stamp_file && !stamps_dev) { (void)hipMalloc((void**)&stamps_dev, (size_t)65536 * 8 * sizeof(unsigned long long)); }
     unsigned long long* stamps = (stamp_file && B >= 256 && B <= 65536 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
     if (stamp_file && B >= 256) stamp_launches++;
+    // all observables in one launch when they share a fast instantiation (same multipole count class, no counter terms, no separate tables, same LDS footprint class)
+    static const bool merge = !getenv("DL_NO_MERGED_THEORY");
+    if (merge && obs_dev != nullptr && n_obs > 1 && n_obs <= 8 && tables == nullptr && feat == nullptr && stop_after == 0 && !stamp_file) {
+        bool same = true, eft0 = obs_host[0].n_ct > 0 || obs_host[0].n_sn > 0, nl3 = obs_host[0].n_ell <= 3;
+        size_t shmem = 0;
+        for (int i = 0; i < n_obs && same; ++i) {
+            const DlObsDev& oh = obs_host[i];
+            const bool generic = !oh.uniform_knots || !(oh.toeplitz || oh.fixed_spline);
+            if (oh.theory == 2 || oh.theory == 3 || generic || (oh.n_ct > 0 || oh.n_sn > 0) != eft0 || (oh.n_ell <= 3) != nl3) same = false;
+            shmem = std::max(shmem, dl_fs_shared_doubles_obs(oh, true) * sizeof(double));
+        }
+        if (same && !eft0) {
+            static const int64_t dense_min = getenv("DL_FS_DENSE_MIN") ? atoll(getenv("DL_FS_DENSE_MIN")) : 4096;
+            auto launch = [&](auto kernel) {
+                if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                const int flags = (xcd_block > 0 && B % (8 * xcd_block) == 0) ? (xcd_block << 8) : 0;
+                DL_LAUNCH(kernel, dim3((unsigned)B, (unsigned)n_obs), dim3(DL_FS_THREADS), shmem, stream, obs_dev, theta, n_params, power, ld_power, flags);
+            };
+            if (nl3) { if (B * n_obs > dense_min) launch(dl_fullshape_multi_kernel<true, 3, false, true>); else launch(dl_fullshape_multi_kernel<true, 3, false>); }
+            else { if (B * n_obs > dense_min) launch(dl_fullshape_multi_kernel<true, 5, false, true>); else launch(dl_fullshape_multi_kernel<true, 5, false>); }
+            return;
+        }
+    }
     for (int i = 0; i < n_obs; ++i) {  // one launch per observable (1-2 in practice)
         if (obs_host[i].theory == 3 && feat != nullptr && !getenv("DL_NO_EMU_BATCH")) {   // feature path: 16 points per workgroup, MLP layers by MFMA
             size_t shm = dl_eb_shared_doubles(obs_host[i]) * sizeof(double);
@@ -539,25 +578,10 @@ __global__ __launch_bounds__(256) void dl_finalize_part_kernel(const double* __r
                                                                double* __restrict__ logprior, int32_t* __restrict__ status, int post_mode) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    double chi2 = 0.;
-    for (int t = 0; t < n_tiles; ++t) chi2 += part[(size_t)b * n_tiles + t];
-    double lp = 0.;
-    bool nan_in = false;
     const double inf = __builtin_huge_val();
-    for (int p = 0; p < n_params; ++p) {
-        double x = theta[(size_t)b * n_params + p];
-        const double* pr = priors + 5 * p;
-        if (x != x) nan_in = true;
-        bool isin = (pr[1] <= x) && (x <= pr[2]);
-        double v = 0.;
-        if (pr[0] == 1.) { double t = x - pr[3]; v = -0.5 * (t * t) / (pr[4] * pr[4]); }   // parameter.py:2007
-        lp += isin ? v : -inf;
-    }
-    double ll = -0.5 * chi2;
-    int st = DL_ST_OK;
-    if (nan_in) st = DL_ST_NAN_INPUT;
-    else if (lp == -inf) st = DL_ST_OUT_OF_PRIOR;
-    else if (!(ll == ll) || ll == inf || ll == -inf) st = DL_ST_NONFINITE;
+    double ll, lp;
+    int st;
+    dl_finalize_point(part + (size_t)b * n_tiles, n_tiles, theta + (size_t)b * n_params, n_params, priors, ll, lp, st);
     if (loglike) loglike[b] = post_mode ? (st == DL_ST_OK ? ll + lp : -inf) : ll;
     if (logprior) logprior[b] = lp;
     if (status) status[b] = st;
