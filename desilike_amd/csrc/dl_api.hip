@@ -513,7 +513,14 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
                                                    (size_t)n * sizeof(double), (size_t)nb, hipMemcpyDeviceToDevice, stream));
         }
         // plain likelihood: chi2 is additive over the columns of the whitened residual -> column-split GEMM that emits partial chi2 only
-        if (feat_path) {
+        // marginalised fits on one emulated observable: Gram-matrix epilogue in the fused kernel -- the residual rows never reach memory (DL_NO_GRAM_EPILOGUE=1: rows + Gram in the finalize)
+        bool gram_done = false;
+        static const bool gram_epilogue = !getenv("DL_NO_GRAM_EPILOGUE");
+        if (feat_path && emu_fused && gram_epilogue && ctx->n_obs == 1 && ctx->n_solved > 0 && ctx->N_pad == 128) {
+            gram_done = dl_launch_emulated_feature_gram(ctx->obs_kernarg[0], th, P, nb, ctx->gfrag_dev[0], ctx->bias_white_dev, ctx->marg, ctx->n_white, ctx->delta_ws, stream);
+            if (gram_done) fin_bias = ctx->bias_white_dev;
+        }
+        if (feat_path && !gram_done) {
             for (int i = 0; i < ctx->n_obs; ++i) {
                 if (emu_fused) dl_launch_emulated_feature(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, stream);
                 else dl_launch_feature_gemm(ctx->feat_ws, ctx->feat_ld, ctx->obs_kernarg[i].feat_off, ctx->obs_kernarg[i].nb_pad, R, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad,
@@ -562,7 +569,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
             dl_launch_finalize_marg(ctx->delta_ws, ctx->N_pad, ctx->n_white, R, n_slabs, slab_stride, fin_bias, ctx->marg, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr,
                                     logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr,
                                     solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr,
-                                    hessian_dev ? hessian_dev + (size_t)b0 * ctx->n_solved * ctx->n_solved : nullptr, post_mode, stream, feat_path && ctx->n_obs == 1);
+                                    hessian_dev ? hessian_dev + (size_t)b0 * ctx->n_solved * ctx->n_solved : nullptr, post_mode, stream, feat_path && ctx->n_obs == 1,
+                                    gram_done ? ctx->delta_ws : nullptr);
         else
             dl_launch_finalize(ctx->delta_ws, ctx->N_pad, ctx->n_white, n_slabs, slab_stride, fin_bias, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
                                status_dev ? status_dev + b0 : nullptr, post_mode, stream);

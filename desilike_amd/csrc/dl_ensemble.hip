@@ -101,7 +101,8 @@ __global__ __launch_bounds__(DL_ENS_THREADS) void dl_ensemble_step_kernel(const 
 #pragma unroll
         for (int q = 0; q < DL_ENS_PRE; ++q) {
             const int j = tid + q * nthr;
-            pre_lp[q] = (j < half && s.part == nullptr) ? s.newlp[j] : 0.;
+            // (deferred finalize: the partial chi2 of the slot are summed now -- their round trip overlaps the staging; pre_lp then holds chi2)
+            pre_lp[q] = j >= half ? 0. : (s.part == nullptr ? s.newlp[j] : dl_chi2_of_parts(s.part + (size_t)j * s.n_tiles, s.n_tiles));
             pre_f[q] = j < half ? s.factors[j] : 0.;
         }
     }
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(DL_ENS_THREADS) void dl_ensemble_step_kernel(const 
             if (s.part != nullptr) {
                 double ll, lpr;
                 int st;
-                dl_finalize_point(s.part + (size_t)j * s.n_tiles, s.n_tiles, s.prop + (size_t)j * P, P, s.priors, ll, lpr, st);
+                const double chi2 = q < DL_ENS_PRE ? pre_lp[q] : dl_chi2_of_parts(s.part + (size_t)j * s.n_tiles, s.n_tiles);
+                dl_finalize_from_chi2(chi2, s.prop + (size_t)j * P, P, s.priors, ll, lpr, st);
                 lp = st == 0 ? ll + lpr : -inf;          // what dl_eval_logposterior writes (samplers/base.py:185-191)
             } else lp = q < DL_ENS_PRE ? pre_lp[q] : s.newlp[j];
             const double fj = q < DL_ENS_PRE ? pre_f[q] : s.factors[j];

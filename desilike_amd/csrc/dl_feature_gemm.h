@@ -29,10 +29,23 @@ typedef double dl_fg_double4 __attribute__((ext_vector_type(4)));
 // LDS row stride (doubles) of a point record: >= rec_len, = 2 mod 32 (the 16 points of an operand read then hit distinct banks, rows stay 16-byte aligned)
 static inline __host__ __device__ int dl_fg_lds_stride(int rec_len) { return (rec_len + 31) / 32 * 32 + 2; }
 
+// Gram-matrix epilogue (analytic marginalisation, one observable, N_pad = 128): the rows X = [residual + bias; derivative rows + tconst_s] of the 16 points go to
+// LDS instead of memory and each wave forms G = X X^T of two points with v_mfma_f64_16x16x4_f64 (A and B operands are one register); only G [16, 16] per point is
+// written -- 2 KB instead of (1 + n_var) x 1 KB of rows that the marginalised finalize would read back (25 MB per 4096 points at 5 solved parameters).
+#define DL_FG_XLD 132   // LDS row stride of X (doubles): 128 columns + 4 (the 16 rows of an operand read fall on distinct bank groups)
+struct DlFgGram {
+    double* x;                 // LDS [16 points][xr][DL_FG_XLD], rows beyond the used ones are not read
+    int xr;                    // rows of X = 1 + n_s
+    int row_of[6];             // X row of device row r (0: residual; r >= 1: 1 + solved index of the parameter whose derivative row r is)
+    const double* cst[6];      // constant part added to device row r: bias, or tconst of that solved parameter ([128] each)
+    double* gram;              // [B, 256]
+};
+
 // the product and the epilogue, from 16 point records already in LDS (row stride `stride` doubles: basis [nb_pad] then mono [R][DL_FG_MONO_LD]);
 // gfrag: [N_pad / 16][nb_pad / 8][19][64][2]; out: [B * R, ldo] (+= if accumulate); 512 threads, blockIdx.y = group of 8 column blocks
+template <bool GRAM = false>
 __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int nb_pad, int R, const double* __restrict__ gfrag, double* __restrict__ out, int64_t ldo,
-                                              int64_t B, int64_t p0, int accumulate) {
+                                              int64_t B, int64_t p0, int accumulate, const DlFgGram* gr = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
     const int jb = blockIdx.y * 8 + wave;               // 16-column block of this wave
@@ -94,9 +107,30 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
                         for (int i = 0; i < DL_FG_MG; ++i)
                             if (m0 + i < DL_FG_NM) v = fma(mono[r * DL_FG_MONO_LD + m0 + i], acc[i][rr], v);
                         if (in_regs && mg == 0) outv[rr][u] = v;
+                        else if (GRAM) gr->x[((size_t)pt * gr->xr + gr->row_of[r]) * DL_FG_XLD + jb * 16 + col] = v + gr->cst[r][jb * 16 + col];
                         else out[((size_t)(p0 + pt) * R + r) * ldo + jb * 16 + col] = v;
                     }
                 }
+            }
+        }
+    }
+    if (GRAM) {
+        __syncthreads();   // all rows of the 16 points are in LDS
+        const int xrow = lane & 15;
+        const bool live = xrow < gr->xr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pt = 2 * wave + h;
+            const double* xp = gr->x + ((size_t)pt * gr->xr + (live ? xrow : 0)) * DL_FG_XLD + g;
+            dl_fg_double4 acc = {0., 0., 0., 0.};
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const double xv = live ? xp[4 * k] : 0.;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, xv, acc, 0, 0, 0);
+            }
+            if (p0 + pt < B) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gr->gram[(size_t)(p0 + pt) * 256 + (g + 4 * r) * 16 + xrow] = acc[r];   // C layout: G[(l >> 4) + 4 r][l & 15]
             }
         }
     }

@@ -5,10 +5,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-__device__ __forceinline__ void dl_finalize_point(const double* __restrict__ part_row, int n_tiles, const double* __restrict__ theta_row, int n_params,
-                                                  const double* __restrict__ priors, double& ll, double& lp, int& st) {
+__device__ __forceinline__ double dl_chi2_of_parts(const double* __restrict__ part_row, int n_tiles) {
     double chi2 = 0.;
     for (int t = 0; t < n_tiles; ++t) chi2 += part_row[t];   // fixed order: deterministic
+    return chi2;
+}
+
+__device__ __forceinline__ void dl_finalize_from_chi2(double chi2, const double* __restrict__ theta_row, int n_params, const double* __restrict__ priors, double& ll, double& lp,
+                                                      int& st) {
     lp = 0.;
     bool nan_in = false;
     const double inf = __builtin_huge_val();
@@ -26,4 +30,9 @@ __device__ __forceinline__ void dl_finalize_point(const double* __restrict__ par
     if (nan_in) st = 3;                                                       // DL_STATUS_NAN_INPUT
     else if (lp == -inf) st = 1;                                              // DL_STATUS_OUT_OF_PRIOR
     else if (!(ll == ll) || ll == inf || ll == -inf) st = 2;                  // DL_STATUS_NONFINITE
+}
+
+__device__ __forceinline__ void dl_finalize_point(const double* __restrict__ part_row, int n_tiles, const double* __restrict__ theta_row, int n_params,
+                                                  const double* __restrict__ priors, double& ll, double& lp, int& st) {
+    dl_finalize_from_chi2(dl_chi2_of_parts(part_row, n_tiles), theta_row, n_params, priors, ll, lp, st);
 }

@@ -40,7 +40,8 @@ struct DlMargDev {
 };
 void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride, const double* bias, const DlMargDev& mg,
                              const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, double* solved,
-                             double* hessian /* [B, n_s, n_s] likelihood Hessian w.r.t. the solved parameters, may be null */, int post_mode, hipStream_t stream, bool xcd_tile16 = false);   // xcd_tile16: the rows were written by 16-point workgroups in launch order (feature GEMM)
+                             double* hessian /* [B, n_s, n_s] likelihood Hessian w.r.t. the solved parameters, may be null */, int post_mode, hipStream_t stream, bool xcd_tile16 = false,   // xcd_tile16: the rows were written by 16-point workgroups in launch order (feature GEMM)
+                             const double* gram = nullptr);   // gram [B, 16, 16]: Gram matrix of [dt; Tt_1 .. Tt_ns] already formed by the feature GEMM's epilogue (dtilde is not read)
 void dl_launch_transform(double* flat, int64_t ld, const double* data, const int32_t* transform, int n, int64_t B, hipStream_t stream);
 // tiled split-K variant: writes n_splits partial slabs (no bias); N_pad multiple of 128, K_pad multiple of 16
 int dl_gemm_tiled_splits(int64_t M, int N_pad, int K_pad, int* chunks_per_split);
@@ -71,6 +72,10 @@ void dl_launch_window_gemm_dma_chi2(const double* A, int64_t lda, const double* 
 // emulated theories, fused: emulator forward pass (MFMA) and feature GEMM of one observable in one launch (dl_emu_batch.h)
 void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
                                 hipStream_t stream);
+// ... with the Gram-matrix epilogue: gram [B, 16, 16] = Gram matrix of [residual + bias; derivative rows + tconst] per point instead of the rows themselves (one observable,
+// N_pad = 128).  Returns false (nothing launched) when the rows of 16 points do not fit the LDS next to the forward pass.
+bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, const double* bias, const DlMargDev& mg, int n_valid,
+                                     double* gram, hipStream_t stream);
 // Fisher algebra (dl_fisher.hip): stencil rows of theta, then per centre the Gram matrix of [residual; derivative rows]
 void dl_launch_fisher_stencil(const double* centers, const double* steps, int P, int64_t B, double* theta, hipStream_t stream);
 int dl_fisher_waves(int n, int P, size_t* shm_bytes);   // centres per workgroup (0: too large for the LDS)

@@ -535,6 +535,29 @@ void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_
                        out, ldo, accumulate);
 }
 
+bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, const double* bias, const DlMargDev& mg, int n_valid,
+                                     double* gram, hipStream_t stream) {
+    const int R = 1 + obs.n_var;
+    if (R > 6 || mg.n_s < 1 || mg.n_s > 15 || n_valid > 128) return false;
+    DlEfGramArgs ga;
+    std::memset(&ga, 0, sizeof(ga));
+    ga.xr = 1 + mg.n_s; ga.gram = gram;
+    ga.row_of[0] = 0; ga.cst[0] = bias;
+    for (int s = 0; s < mg.n_s; ++s) {
+        const int slot = mg.var_slot[s];
+        if (slot >= 0) {
+            if (1 + slot >= R) return false;
+            ga.row_of[1 + slot] = 1 + s; ga.cst[1 + slot] = mg.tconst + (size_t)s * 128;   // (N_pad = 128: tconst rows are 128 doubles apart)
+        } else { ga.const_row[ga.n_const] = 1 + s; ga.const_ptr[ga.n_const] = mg.tconst + (size_t)s * 128; ga.n_const++; }
+    }
+    for (int r = 1; r < R; ++r) if (ga.cst[r] == nullptr) return false;   // a device row that feeds no solved parameter
+    const size_t shm = dl_ef_gram_shared_doubles(obs, ga.xr) * sizeof(double);
+    if (shm > 156 * 1024) return false;
+    (void)hipFuncSetAttribute((const void*)dl_emulated_feature_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    DL_LAUNCH(dl_emulated_feature_gram_kernel, dim3((unsigned)((B + DL_EB_PTS - 1) / DL_EB_PTS), 1), dim3(512), shm, stream, obs, theta, n_params, B, gfrag, ga);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // chi2 GEMM path (plain likelihood): partial chi2 per (point, 16-column block) from dl_chi2_gemm_kernel, then one THREAD per point
 // sums them in a fixed order and adds the priors (same status logic as dl_finalize_kernel).
@@ -643,7 +666,8 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
                                                                const double* __restrict__ theta, int n_params, const double* __restrict__ priors, int64_t B,
                                                                double* __restrict__ loglike, double* __restrict__ logprior, int32_t* __restrict__ status,
                                                                double* __restrict__ solved, double* __restrict__ hessian, int post_mode,
-                                                               unsigned long long* __restrict__ stamps) {
+                                                               unsigned long long* __restrict__ stamps, const double* __restrict__ gram) {
+    // gram != nullptr: G [B, 16, 16] was formed by the feature GEMM's epilogue (dl_feature_gemm.h): no residual rows to read, no Gram product here
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #define DL_FM_STAMP(slot) if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();
     DL_FM_STAMP(0)
@@ -695,7 +719,10 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
         }
         dl_double4 acc = {0., 0., 0., 0.};
         const int n_ks = (n + 3) / 4;
-        if (STAGED) {
+        if (gram != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Gw[lane + 64 * q] = gram[(size_t)b * 256 + lane + 64 * q];
+        } else if (STAGED) {
             // Rows of X staged in LDS by coalesced 16-byte loads, ALL in flight at once (one memory round trip instead of one per batch of k-steps:
             // the direct operand loads below touch 16 different rows per instruction and were 12.7 us of a 20 us workgroup life), constant and point-dependent
             // parts added on the way in; the MFMA operands then come from LDS.  Per wave: (1 + ns) rows of `stride` doubles.
@@ -748,8 +775,10 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
         }
         DL_FM_STAMP(1)
         // C layout: register r of lane l = G[(l >> 4) + 4 r][l & 15]
+        if (gram == nullptr) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Gw[(g + 4 * r) * 16 + xr] = acc[r];
+            for (int r = 0; r < 4; ++r) Gw[(g + 4 * r) * 16 + xr] = acc[r];
+        }
         __syncthreads();
         DL_FM_STAMP(2)
         // (the lane-parallel solve below reads G from LDS)
@@ -985,7 +1014,7 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
 
 void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride, const double* bias, const DlMargDev& mg,
                              const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, double* solved,
-                             double* hessian, int post_mode, hipStream_t stream, bool xcd_tile16) {
+                             double* hessian, int post_mode, hipStream_t stream, bool xcd_tile16, const double* gram) {
     static const char* stamp_file = getenv("DL_FM_STAMPS");   // diagnostics, see dl_launch_fullshape
     static unsigned long long* stamps_dev = nullptr;
     static int stamp_launches = 0;
@@ -998,16 +1027,19 @@ void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_p
     static const bool allow_staged = !getenv("DL_FM_NO_STAGE");   // DL_FM_NO_STAGE=1: operands of the Gram product straight from global memory (comparison)
     const size_t region = std::max<size_t>((size_t)(1 + mg.n_s) * (((n + 3) & ~3) + 4), 512);
     const size_t shm = 4 * region * sizeof(double);   // staged rows of the four waves (reused for G and the Cholesky rows)
-    if (mg.n_s < 16 && allow_staged && shm <= 96 * 1024) {
+    if (gram != nullptr) {   // (needs n_s < 16: checked by the caller)
+        DL_LAUNCH((dl_finalize_marg_kernel<true, false>), dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
+                           n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps, gram);
+    } else if (mg.n_s < 16 && allow_staged && shm <= 96 * 1024) {
         if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_finalize_marg_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         DL_LAUNCH((dl_finalize_marg_kernel<true, true>), dim3(grid), dim3(256), shm, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
-                           n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps);
+                           n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps, nullptr);
     } else if (mg.n_s < 16)
         DL_LAUNCH((dl_finalize_marg_kernel<true, false>), dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
-                           n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps);
+                           n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps, nullptr);
     else
         DL_LAUNCH((dl_finalize_marg_kernel<false, false>), dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
-                           n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps);
+                           n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps, nullptr);
     if (stamps) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h((size_t)grid * 8);

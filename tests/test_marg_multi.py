@@ -92,7 +92,7 @@ def test_hip_marginalisation_vs_reference_quadratic_form(case, flags):
     g, like = make_case(case, flags)
     others = [str(n) for n in g['names']]
     solved = [str(n) for n in g['solved']]
-    assert like.varied_params.names() == others and like.solved_params.names() == solved
+    assert sorted(like.varied_params.names()) == sorted(others) and sorted(like.solved_params.names()) == sorted(solved)   # (the reference orders the tracers' blocks differently)
     (logpost, derived), errors = vmap(like, errors='return', return_derived=True)({name: g['theta'][:, i] for i, name in enumerate(others)})
     assert errors == {}
     mask = np.array([flag == '.marg' for flag in flags])
