@@ -57,10 +57,6 @@ class InitConfig(dict):
         return self[key]
 
 
-class _TrackedCollection(ParameterCollection):
-    """ParameterCollection whose parameters report updates to the owning calculator."""
-
-
 class BaseCalculator(object):
     """Base calculator: ``init`` (arguments + params), ``params``, lazy ``initialize`` (base.py:1119-1323)."""
 

@@ -172,27 +172,33 @@ struct DlEfGramArgs {
     const double* const_ptr[DL_MAX_SOLVED];   // ... and their tconst rows
     double* gram;
 };
-static inline __host__ __device__ size_t dl_ef_gram_shared_doubles(const DlObsDev& o, int xr) { return dl_ef_shared_doubles(o) + (size_t)DL_FG_PTS * xr * DL_FG_XLD; }
+// LDS: the 16 records | union(forward workspace, X rows): the workspace is dead once the records are written
+static inline __host__ __device__ size_t dl_ef_gram_rec_doubles(const DlObsDev& o) { return ((size_t)DL_FG_PTS * dl_fg_lds_stride(o.nb_pad + (1 + o.n_var) * DL_FG_MONO_LD) + 1) / 2 * 2; }
+static inline __host__ __device__ size_t dl_ef_gram_shared_doubles(const DlObsDev& o, int xr) {
+    const size_t work = dl_eb_shared_doubles(o), x = (size_t)DL_FG_PTS * xr * DL_FG_XLD;
+    return dl_ef_gram_rec_doubles(o) + (work > x ? work : x);
+}
 __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ gfrag,
                                                                        const DlEfGramArgs ga) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int64_t p0 = (int64_t)blockIdx.x * DL_EB_PTS;
     const int R = 1 + o.n_var;
     const int stride = dl_fg_lds_stride(o.nb_pad + R * DL_FG_MONO_LD);
-    double* rec = lds + (dl_eb_shared_doubles(o) + 1) / 2 * 2;
+    double* rec = lds;
+    double* work = lds + dl_ef_gram_rec_doubles(o);
+    dl_eb_forward<512, true>(o, theta, n_params, B, p0, work, rec, stride, nullptr, 0);
+    __syncthreads();   // the records are complete, the forward workspace is free: X takes its place
     DlFgGram gr;
-    gr.x = lds + dl_ef_shared_doubles(o);
+    gr.x = work;
     gr.xr = ga.xr; gr.gram = ga.gram;
 #pragma unroll
     for (int r = 0; r < 6; ++r) { gr.row_of[r] = ga.row_of[r]; gr.cst[r] = ga.cst[r]; }
-    // rows of solved parameters whose derivative does not depend on the point: the constant itself
+    // rows of solved parameters whose derivative does not depend on the point: the constant itself (visible to the Gram phase after the barrier inside dl_fg_compute)
     for (int c = 0; c < ga.n_const; ++c)
         for (int idx = threadIdx.x; idx < DL_FG_PTS * 128; idx += 512) {
             const int pt = idx >> 7, col = idx & 127;
             gr.x[((size_t)pt * gr.xr + ga.const_row[c]) * DL_FG_XLD + col] = ga.const_ptr[c][col];
         }
-    dl_eb_forward<512, true>(o, theta, n_params, B, p0, lds, rec, stride, nullptr, 0);
-    __syncthreads();
     dl_fg_compute<true>(rec, stride, o.nb_pad, R, gfrag, nullptr, 0, B, p0, 0, &gr);
 }
 #endif

@@ -180,7 +180,7 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
     unsigned long long* stamps = (stamp_file && B >= 256 && B <= 65536 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
     if (stamp_file && B >= 256) stamp_launches++;
     // all observables in one launch when they share a fast instantiation (same multipole count class, no counter terms, no separate tables, same LDS footprint class)
-    static const bool merge = !getenv("DL_NO_MERGED_THEORY");
+    const bool merge = !getenv("DL_NO_MERGED_THEORY");   // (read at every launch: the tests compare both paths in one process)
     if (merge && obs_dev != nullptr && n_obs > 1 && n_obs <= 8 && tables == nullptr && feat == nullptr && stop_after == 0 && !stamp_file) {
         bool same = true, eft0 = obs_host[0].n_ct > 0 || obs_host[0].n_sn > 0, nl3 = obs_host[0].n_ell <= 3;
         size_t shmem = 0;

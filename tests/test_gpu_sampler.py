@@ -165,3 +165,45 @@ def test_bench_two_ranks_on_one_gpu():
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['config']['ranks'] == 2 and line['value'] > 0.
     assert line['config5_strong']['n_gpus'] == 2
+
+
+def test_config5_as_stated_device_vs_host_driver():
+    """BASELINE configs[4] as written: 512 walkers on TWO config-2 tracers (dense 120 x 1200 windows, n = 240, block-diagonal precision: the chi2 GEMM skips the
+    other tracer's K panels, one theory launch for both observables, the step kernel finishes the proposals itself).  The device-resident ensemble and the
+    host-driven stretch move with the same counter-based generator give the same chain, bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_likelihood_config5
+    from desilike_amd.samplers import EmceeSampler, EnsembleStretchMove, CounterRNG
+    like = make_likelihood_config5(0)
+    assert like.size == 240 and len(like.varied_params) == 8
+    ctx = like._get_context()
+    assert ctx.info('N_pad') == 256 and ctx.info('K_pad') == 2432
+    sampler = EmceeSampler(like, nwalkers=512, seed=42)
+    start, logp0 = sampler._get_start(512)
+    chain = sampler.run(niterations=12, start=start)
+    host = EnsembleStretchMove(512, 8, sampler.logposterior, rng=CounterRNG(sampler.counter_seed))
+    coords, logp = start.copy(), sampler.logposterior(start)
+    for it in range(12):
+        coords, logp = host.step(coords, logp)
+        assert np.array_equal(np.column_stack([chain[param.name][it] for param in like.varied_params]), coords), it
+        assert np.array_equal(chain['logposterior'][it], logp), it
+    # the merged theory launch / panel skipping / aligned rows against the straightforward paths of the same library
+    import torch
+    theta = torch.as_tensor(coords, dtype=torch.float64, device='cuda:0').contiguous()
+    ref = torch.empty(512, dtype=torch.float64, device='cuda:0')
+    ctx.eval_logposterior(theta, ref)
+    torch.cuda.synchronize()
+    for flag in ['DL_NO_MERGED_THEORY', 'DL_NO_PANEL_SKIP', 'DL_NO_ROW_ALIGN']:
+        os.environ[flag] = '1'
+    try:
+        from desilike_amd._lib import Context
+        plain = Context(like._spec({}, like._flatdata_list(), like.precision), device=0)
+        out = torch.empty(512, dtype=torch.float64, device='cuda:0')
+        plain.eval_logposterior(theta, out)
+        torch.cuda.synchronize()
+        plain.close()
+    finally:
+        for flag in ['DL_NO_MERGED_THEORY', 'DL_NO_PANEL_SKIP', 'DL_NO_ROW_ALIGN']:
+            del os.environ[flag]
+    assert torch.allclose(out, ref, rtol=1e-13, atol=1e-10)
