@@ -247,7 +247,7 @@ def config5_strong(group, device, local_rank, rank, world, iterations, warmup=30
     elapsed = time.perf_counter() - t0
     if group is not None: elapsed = group.max(elapsed)
     coords, logp, nacc = ens.get_state()
-    sharded = isinstance(group, RcclGroup) and world > 1
+    sharded = isinstance(group, RcclGroup) and (world > 1 or os.environ.get('DL_ENS_FORCE_COMM', None) is not None)
     assert np.isfinite(logp).all() and np.isfinite(chain_logp.cpu().numpy()).all()
     return {'workload': 'BASELINE configs[4]: EnsembleSampler (stretch move), 512 walkers x two config-2 tracers (n = 240), {:d} ensemble updates, device-resident'.format(iterations),
             'value': 512 * iterations / elapsed, 'unit': 'evals/s', 'scaling': 'strong', 'n_gpus': world, 'us_per_update': 1e6 * elapsed / iterations,

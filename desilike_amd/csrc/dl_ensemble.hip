@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -279,7 +280,9 @@ int dl_ensemble_create(dl_ensemble** out, dl_ctx* ctx, int32_t nwalkers, double 
 static int dl_ens_logposterior(dl_ensemble* ens, const double* theta_dev, int n, double* out_dev, hipStream_t stream) {
     const int64_t lo = std::min<int64_t>((int64_t)ens->rank * ens->count, n), hi = std::min<int64_t>(lo + ens->count, n);
     if (hi > lo && dl_eval_logposterior(ens->ctx, theta_dev + (size_t)lo * ens->P, hi - lo, out_dev + lo, nullptr, stream)) return 1;
-    if (ens->comm && ens->world > 1)
+    // (DL_ENS_FORCE_COMM=1: the collective is issued even with a single rank -- smoke test of the in-stream RCCL call on a 1-GPU box)
+    static const bool force = getenv("DL_ENS_FORCE_COMM") != nullptr;
+    if (ens->comm && (ens->world > 1 || force))
         return dl_comm_allgather_f64(ens->comm, out_dev + (size_t)ens->rank * ens->count, out_dev, ens->count, stream);
     return 0;
 }
@@ -342,7 +345,7 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
             set_record();
             dl_ens_launch(s, stream);
             s.part = nullptr;
-            if (ens->deferred && !(ens->comm && ens->world > 1) && !getenv("DL_ENS_NO_DEFER")) {
+            if (ens->deferred && !(ens->comm && (ens->world > 1 || getenv("DL_ENS_FORCE_COMM"))) && !getenv("DL_ENS_NO_DEFER")) {
                 int rc = dl_internal_eval_partials(ens->ctx, ens->prop, half, &s.part, &s.n_tiles, &s.priors, stream);
                 if (rc == 1) return 1;
                 if (rc == 2) { ens->deferred = false; s.part = nullptr; }

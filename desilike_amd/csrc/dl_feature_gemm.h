@@ -107,7 +107,7 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
                         for (int i = 0; i < DL_FG_MG; ++i)
                             if (m0 + i < DL_FG_NM) v = fma(mono[r * DL_FG_MONO_LD + m0 + i], acc[i][rr], v);
                         if (in_regs && mg == 0) outv[rr][u] = v;
-                        else if (GRAM) gr->x[((size_t)pt * gr->xr + gr->row_of[r]) * DL_FG_XLD + jb * 16 + col] = v + gr->cst[r][jb * 16 + col];
+                        else if (GRAM) gr->x[((size_t)pt * gr->xr + gr->row_of[u]) * DL_FG_XLD + jb * 16 + col] = v + gr->cst[u][jb * 16 + col];   // (r = u: R <= 6)
                         else out[((size_t)(p0 + pt) * R + r) * ldo + jb * 16 + col] = v;
                     }
                 }
@@ -118,20 +118,24 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
         __syncthreads();   // all rows of the 16 points are in LDS
         const int xrow = lane & 15;
         const bool live = xrow < gr->xr;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int pt = 2 * wave + h;
-            const double* xp = gr->x + ((size_t)pt * gr->xr + (live ? xrow : 0)) * DL_FG_XLD + g;
-            dl_fg_double4 acc = {0., 0., 0., 0.};
+        // the two points of this wave side by side: two independent MFMA chains (one chain alone is 32 dependent MFMAs of 64 cycles)
+        const double* xp0 = gr->x + ((size_t)(2 * wave) * gr->xr + (live ? xrow : 0)) * DL_FG_XLD + g;
+        const double* xp1 = xp0 + (size_t)gr->xr * DL_FG_XLD;
+        dl_fg_double4 acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
 #pragma unroll 8
-            for (int k = 0; k < 32; ++k) {
-                const double xv = live ? xp[4 * k] : 0.;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, xv, acc, 0, 0, 0);
-            }
-            if (p0 + pt < B) {
+        for (int k = 0; k < 32; ++k) {
+            const double x0 = live ? xp0[4 * k] : 0., x1 = live ? xp1[4 * k] : 0.;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc1, 0, 0, 0);
+        }
+        // C layout: G[(l >> 4) + 4 r][l & 15]
+        if (p0 + 2 * wave < B) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gr->gram[(size_t)(p0 + pt) * 256 + (g + 4 * r) * 16 + xrow] = acc[r];   // C layout: G[(l >> 4) + 4 r][l & 15]
-            }
+            for (int r = 0; r < 4; ++r) gr->gram[(size_t)(p0 + 2 * wave) * 256 + (g + 4 * r) * 16 + xrow] = acc0[r];
+        }
+        if (p0 + 2 * wave + 1 < B) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gr->gram[(size_t)(p0 + 2 * wave + 1) * 256 + (g + 4 * r) * 16 + xrow] = acc1[r];
         }
     }
 }

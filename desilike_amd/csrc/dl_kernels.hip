@@ -553,7 +553,8 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
     for (int r = 1; r < R; ++r) if (ga.cst[r] == nullptr) return false;   // a device row that feeds no solved parameter
     const size_t shm = dl_ef_gram_shared_doubles(obs, ga.xr) * sizeof(double);
     if (shm > 156 * 1024) return false;
-    (void)hipFuncSetAttribute((const void*)dl_emulated_feature_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    static size_t shm_set = 0;
+    if (shm > shm_set) { (void)hipFuncSetAttribute((const void*)dl_emulated_feature_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); shm_set = shm; }
     DL_LAUNCH(dl_emulated_feature_gram_kernel, dim3((unsigned)((B + DL_EB_PTS - 1) / DL_EB_PTS), 1), dim3(512), shm, stream, obs, theta, n_params, B, gfrag, ga);
     return true;
 }

@@ -266,7 +266,9 @@ class EmceeSampler(BasePosteriorSampler):
             from ._lib import DeviceEnsemble
             from .parallel import RcclGroup
             ctx, offset = self.likelihood._get_posterior_context()
-            group = self.sharding.group if (self.sharding.sharded(self.nwalkers // 2) and isinstance(self.sharding.group, RcclGroup)) else None
+            import os
+            forced = os.environ.get('DL_ENS_FORCE_COMM', None) is not None and isinstance(self.sharding.group, RcclGroup)   # single-rank smoke test of the in-stream collective
+            group = self.sharding.group if ((self.sharding.sharded(self.nwalkers // 2) or forced) and isinstance(self.sharding.group, RcclGroup)) else None
             # one 64-bit key for the device generator, drawn from the (rank-synchronised) host generator
             key = int(self.rng.randint(0, 2**32, dtype=np.uint64)) | (int(self.rng.randint(0, 2**32, dtype=np.uint64)) << 32)
             self._ensemble = DeviceEnsemble(ctx, self.nwalkers, a=self.a, seed=key, offset=offset, group=group)
