@@ -49,6 +49,14 @@ SYMBOLS = {
     'dl_ensemble_run': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_ensemble_get_state': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
     'dl_ensemble_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
+    'dl_mlp_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int32, _c_int32_p, ctypes.c_int32, _c_double_p]),
+    'dl_mlp_destroy': (None, [ctypes.c_void_p]),
+    'dl_mlp_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
+    'dl_mlp_train': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                    ctypes.c_double, _c_double_p, ctypes.c_void_p]),
+    'dl_mlp_loss_and_grad': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _c_double_p, _c_double_p, ctypes.c_void_p]),
+    'dl_mlp_forward': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_mlp_get_weights': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_void_p]),
 }
 
 
@@ -287,6 +295,20 @@ class Context(object):
         self._check(self._lib.dl_eval_logposterior(self._handle, ctypes.c_void_p(theta.data_ptr()), B, ctypes.c_void_p(logposterior.data_ptr()),
                                                    None if status is None else ctypes.c_void_p(status.data_ptr()), ctypes.c_void_p(stream)))
 
+    def eval_theory(self, theta, power, iobs=0, tables=None, stream=None):
+        """Theory multipoles of observable ``iobs`` into the device tensor ``power [B, n_ell, n_kin]`` (``dl_eval_theory``; torch tensors, asynchronous)."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(theta.device).cuda_stream
+        B = theta.shape[0]
+        n_ell, n_kin = self.info('n_ell_obs{:d}'.format(iobs)), self.info('n_kin_obs{:d}'.format(iobs))
+        assert theta.is_contiguous() and theta.dtype == torch.float64 and theta.shape[1] == self.n_params
+        assert power.is_contiguous() and power.dtype == torch.float64 and tuple(power.shape) == (B, n_ell, n_kin)
+        assert tables is None or (tables.is_contiguous() and tables.dtype == torch.float64 and tuple(tables.shape) == (B, 3, n_ell, n_kin))
+        self._check(self._lib.dl_eval_theory(self._handle, ctypes.c_void_p(theta.data_ptr()), B, int(iobs), ctypes.c_void_p(power.data_ptr()),
+                                             None if tables is None else ctypes.c_void_p(tables.data_ptr()), ctypes.c_void_p(stream)))
+        return power
+
     def eval_fisher(self, centers, steps, hessian=None, gradient=None, offset=None, stream=None):
         """Fisher algebra on the device (``dl_eval_fisher``): ``centers [B, P]``, ``steps [B, P, 2]`` (lower, upper) -> ``hessian [B, P, P]``, ``gradient [B, P]``,
         ``offset [B]`` (float64 device tensors, allocated if ``None``); asynchronous on ``stream``."""
@@ -416,6 +438,71 @@ class DeviceEnsemble(object):
     def close(self):
         if getattr(self, '_handle', None):
             self._lib.dl_ensemble_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MLPTrainer(object):
+    """Owner of one ``dl_mlp`` (include/desilike_amd.h): fp64 Adam training of a dense network on one GPU.  ``layers``: list of (kernel [n_in, n_out], bias [n_out])
+    initial values; ``activation``: 'silu' / 'relu' / 'tanh'."""
+
+    def __init__(self, layers, activation='silu', device=0):
+        lib = load()
+        self.shapes = [(np.shape(kernel), np.shape(bias)) for kernel, bias in layers]
+        widths = np.array([self.shapes[0][0][0]] + [shape[0][1] for shape in self.shapes], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.concatenate([np.ravel(kernel), np.ravel(bias)]) for kernel, bias in layers]), dtype='f8')
+        handle = ctypes.c_void_p()
+        if lib.dl_mlp_create(ctypes.byref(handle), int(device), len(layers), _i32_ptr(widths), {'silu': 0, 'relu': 1, 'tanh': 2}[activation], _f64_ptr(flat)) != 0:
+            raise LibraryError(lib.dl_last_error(None).decode())
+        self._lib, self._handle, self.device = lib, handle, int(device)
+        self.n_weights = int(lib.dl_mlp_info(handle, b'n_weights'))
+
+    def _check(self, rc):
+        if rc != 0: raise LibraryError(self._lib.dl_last_error(None).decode())
+
+    def _stream(self, stream):
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream(torch.device('cuda', self.device)).cuda_stream if stream is None else stream)
+
+    def train(self, x, y, batch, nsteps, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, return_loss=True, stream=None):
+        """``nsteps`` Adam steps on consecutive chunks of ``batch`` rows of the device tensors ``x [S, n_in]``, ``y [S, n_out]``; returns the batch losses [nsteps]."""
+        import torch
+        assert x.is_cuda and y.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype == torch.float64 and x.shape[0] == y.shape[0]
+        loss = np.empty(int(nsteps), dtype='f8') if return_loss else None
+        self._check(self._lib.dl_mlp_train(self._handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), x.shape[0], int(batch), int(nsteps), float(lr), float(beta1),
+                                           float(beta2), float(eps), _f64_ptr(loss), self._stream(stream)))
+        return loss
+
+    def loss_and_grad(self, x, y, stream=None):
+        loss, grad = np.empty(1, dtype='f8'), np.empty(self.n_weights, dtype='f8')
+        self._check(self._lib.dl_mlp_loss_and_grad(self._handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), x.shape[0], _f64_ptr(loss), _f64_ptr(grad), self._stream(stream)))
+        return float(loss[0]), grad
+
+    def forward(self, x, stream=None):
+        import torch
+        out = torch.empty((x.shape[0], int(self._lib.dl_mlp_info(self._handle, b'n_out'))), dtype=torch.float64, device=x.device)
+        self._check(self._lib.dl_mlp_forward(self._handle, ctypes.c_void_p(x.data_ptr()), x.shape[0], ctypes.c_void_p(out.data_ptr()), self._stream(stream)))
+        return out
+
+    def layers(self, stream=None):
+        """Current parameters as a list of (kernel [n_in, n_out], bias [n_out])."""
+        flat = np.empty(self.n_weights, dtype='f8')
+        self._check(self._lib.dl_mlp_get_weights(self._handle, _f64_ptr(flat), self._stream(stream)))
+        out, off = [], 0
+        for kshape, bshape in self.shapes:
+            nk, nb = int(np.prod(kshape)), int(np.prod(bshape))
+            out.append((flat[off:off + nk].reshape(kshape).copy(), flat[off + nk:off + nk + nb].copy()))
+            off += nk + nb
+        return out
+
+    def close(self):
+        if getattr(self, '_handle', None):
+            self._lib.dl_mlp_destroy(self._handle)
             self._handle = None
 
     def __del__(self):

@@ -2,8 +2,8 @@
 
 In the reference, ``desilike.emulators.Emulator`` wraps the third-party ``cosmoprimo.emulators.tools`` engines (un-vendored) and
 ``EmulatedCalculator`` (emulators/__init__.py:394-418) replaces any calculator by ``emulator.predict(params)`` -> state arrays.  This module holds the
-*fitted* engines in the layouts the reference writes, and fits the Taylor engine itself (:func:`fit_taylor`: the whole finite-difference stencil is one GPU
-batch; MLP training is out of scope):
+*fitted* engines in the layouts the reference writes, and fits them on the GPU: the Taylor engine (:func:`fit_taylor`: the whole finite-difference stencil is one GPU
+batch) and the MLP engine (:func:`fit_mlp`: fp64 Adam with hand-written forward / backward kernels, ``dl_mlp_*``):
 
 * :class:`TaylorEmulatorEngine` -- ``center [P]``, ``powers [n_terms, P]``, ``derivatives [n_terms, *yshape]`` already divided by the factorials
   (emulators/__init__.py:471-507): ``y = sum_t derivatives[t] prod_p (x_p - c_p)^powers[t, p]``;
@@ -132,6 +132,46 @@ class MLPEmulatorEngine(object):
         return spec
 
 
+def fit_mlp(x, y, hidden=(64, 64, 64), activation='silu', nsteps=3000, batch=None, lr=2e-3, lr_decay=0.2, seed=0, device=0, yshape=None, return_loss=False):
+    """Train an :class:`MLPEmulatorEngine` on samples ``x [S, P]`` -> ``y [S, ...]`` on the GPU (what the reference's ``Emulator(..., engine=MLPEmulatorEngine(...)).fit()`` does
+    through the third-party engine, emulators/__init__.py:510-533).  Min-max scalers of inputs and outputs as emulators/conversion.py:75-79 (constant outputs get a zero
+    range: reproduced exactly); weights ~ N(0, 1 / fan_in) from ``RandomState(seed)``, zero biases; Adam on the mean squared error of the scaled outputs, ``nsteps`` steps on
+    consecutive chunks of ``batch`` samples (default: all) of a fixed shuffle, learning rate decayed geometrically to ``lr * lr_decay``; fp64 throughout.
+    ``x``, ``y``: numpy arrays or float64 tensors already on the GPU (``dl_eval_theory`` outputs never leave it)."""
+    import torch
+    from ._lib import MLPTrainer
+    dev = torch.device('cuda', device)
+    xt = torch.as_tensor(x, dtype=torch.float64, device=dev)
+    yt = torch.as_tensor(y, dtype=torch.float64, device=dev)
+    if yshape is None: yshape = tuple(yt.shape[1:])
+    yt = yt.reshape(yt.shape[0], -1)
+    nsamples, nin, nout = xt.shape[0], xt.shape[1], yt.shape[1]
+    xlo, xhi = xt.min(dim=0).values, xt.max(dim=0).values
+    ylo, yhi = yt.min(dim=0).values, yt.max(dim=0).values
+    xscale = torch.where(xhi > xlo, xhi - xlo, torch.ones_like(xlo))
+    yscale = torch.where(yhi > ylo, yhi - ylo, torch.ones_like(ylo))
+    rng = np.random.RandomState(seed)
+    order = torch.as_tensor(rng.permutation(nsamples), device=dev)
+    xs = ((xt - xlo) / xscale)[order].contiguous()
+    ys = ((yt - ylo) / yscale)[order].contiguous()
+    layers, last = [], nin
+    for width in list(hidden) + [nout]:
+        layers.append((rng.standard_normal((last, width)) / last**0.5, np.zeros(width)))
+        last = width
+    trainer = MLPTrainer(layers, activation=activation, device=device)
+    if batch is None: batch = nsamples
+    losses, nstages = [], 8
+    for stage in range(nstages):   # geometric learning-rate schedule in a few stages (each stage = one enqueued dl_mlp_train call)
+        steps = nsteps // nstages + (nsteps % nstages if stage == nstages - 1 else 0)
+        if steps: losses.append(trainer.train(xs, ys, batch, steps, lr=lr * lr_decay**(stage / max(nstages - 1, 1))))
+    fitted = trainer.layers()
+    trainer.close()
+    xlimits = np.column_stack([xlo.cpu().numpy(), (xlo + xscale).cpu().numpy()])
+    ylimits = np.column_stack([ylo.cpu().numpy(), torch.where(yhi > ylo, yhi, ylo).cpu().numpy()])
+    engine = MLPEmulatorEngine(xlimits=xlimits, layers=fitted, activation=activation, ylimits=ylimits, yshape=yshape)
+    return (engine, np.concatenate(losses)) if return_loss else engine
+
+
 class EmulatedCalculator(object):
     """Stand-in for a calculator whose state arrays are emulated (emulators/__init__.py:394-418).
 
@@ -172,8 +212,11 @@ class EmulatedCalculator(object):
         return specs
 
 
-def emulate_power(likelihood, iobs=0, order=3, accuracy=2, delta_scale=1., params=None):
-    """Taylor emulator of the theory multipoles ``power [n_ell, n_k]`` of observable ``iobs`` of a GPU likelihood, as an :class:`EmulatedCalculator` for
+def emulate_power(likelihood, iobs=0, order=3, accuracy=2, delta_scale=1., params=None, engine='taylor', nsamples=4096, **mlp_kwargs):
+    """``engine='mlp'``: MLP emulator trained on the GPU (:func:`fit_mlp`) on ``nsamples`` points of the R_d quasi-random sequence over the box ``value +- delta_scale x
+    proposal`` of each parameter (the reference's ``QMCSampler`` + ``MLPEmulatorEngine``, samplers/qmc.py, emulators/__init__.py:510-533), the theory evaluated by
+    ``dl_eval_theory`` as one batch whose output never leaves the device.  Default ``engine='taylor'``:
+    Taylor emulator of the theory multipoles ``power [n_ell, n_k]`` of observable ``iobs`` of a GPU likelihood, as an :class:`EmulatedCalculator` for
     :class:`desilike_amd.theories.galaxy_clustering.EmulatedTracerPowerSpectrumMultipoles` (the reference's ``Emulator(theory, engine=TaylorEmulatorEngine(order)).fit()``,
     emulators/__init__.py:131-240): expansion around the parameters' default values with steps ``Parameter.delta`` (scaled by ``delta_scale``), the stencil
     evaluated by ``dl_eval_theory`` as one batch."""
@@ -191,7 +234,21 @@ def emulate_power(likelihood, iobs=0, order=3, accuracy=2, delta_scale=1., param
         theta[:, index] = points
         return ctx.eval_theory_host(theta, iobs=iobs)
 
-    engine = fit_taylor(function, center_all[index], delta, order=order, accuracy=accuracy)
+    if engine == 'mlp':
+        import torch
+        from .samplers import RQuasiRandomSequence
+        half = np.array([delta_scale * varied[name].proposal for name in names], dtype='f8')
+        lower, upper = np.array([max(c - h, varied[name].prior.limits[0]) for c, h, name in zip(center_all[index], half, names)]), np.array([min(c + h, varied[name].prior.limits[1]) for c, h, name in zip(center_all[index], half, names)])
+        points = lower + RQuasiRandomSequence(len(names)).random(nsamples) * (upper - lower)
+        theta = np.repeat(center_all[None, :], nsamples, axis=0)
+        theta[:, index] = points
+        device = torch.device('cuda', ctx.device)
+        n_ell, n_kin = ctx.info('n_ell_obs{:d}'.format(iobs)), ctx.info('n_kin_obs{:d}'.format(iobs))
+        power = torch.empty((nsamples, n_ell, n_kin), dtype=torch.float64, device=device)
+        ctx.eval_theory(torch.as_tensor(theta, dtype=torch.float64, device=device).contiguous(), power, iobs=iobs)
+        engine = fit_mlp(torch.as_tensor(points, dtype=torch.float64, device=device), power, device=ctx.device, **mlp_kwargs)
+    else:
+        engine = fit_taylor(function, center_all[index], delta, order=order, accuracy=accuracy)
     specs = {}
     for name in names:
         param = varied[name]

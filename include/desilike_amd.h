@@ -226,6 +226,23 @@ int  dl_ensemble_get_state(dl_ensemble* ens, double* coords, double* logposterio
 /* integer properties: "nwalkers", "n_params", "iteration", "rank", "world", "rows_per_rank" */
 int64_t dl_ensemble_info(const dl_ensemble* ens, const char* key);
 
+/* ---- MLP emulator training ---------------------------------------------------------------------------------------
+ * The reference trains its MLP emulators through the third-party engine ``cosmoprimo.emulators.tools.MLPEmulatorEngine`` (desilike/emulators/__init__.py:510-533;
+ * network structure: emulators/conversion.py:20-96).  Here: fp64 mini-batch Adam on the mean squared error of the (already scaled) outputs, entirely on the device
+ * (fp64 MFMA GEMMs for forward / backward, fixed summation orders: deterministic).  Parameters are one flat vector: per layer the kernel [n_in, n_out] row-major,
+ * then the bias [n_out].  activation: 0 silu, 1 relu, 2 tanh between the layers; the last layer is linear.  x_dev [n_samples, n_in], y_dev [n_samples, n_out] device
+ * arrays.  Batches are consecutive chunks of ``batch`` samples (the caller shuffles the set); dl_mlp_train enqueues ``n_steps`` Adam steps on ``hip_stream`` and, if
+ * loss_host != NULL, copies the per-step batch losses [n_steps] back (then synchronises).  Errors: non-zero, message via dl_last_error(NULL). */
+typedef struct dl_mlp dl_mlp;
+int  dl_mlp_create(dl_mlp** out, int device, int32_t n_layers, const int32_t* widths /* [n_layers + 1] */, int32_t activation, const double* weights /* host, flat */);
+void dl_mlp_destroy(dl_mlp* net);
+int64_t dl_mlp_info(const dl_mlp* net, const char* key);   /* "n_weights", "n_layers", "n_in", "n_out", "step" */
+int  dl_mlp_train(dl_mlp* net, const double* x_dev, const double* y_dev, int64_t n_samples, int64_t batch, int64_t n_steps, double lr, double beta1, double beta2, double eps,
+                  double* loss_host, void* hip_stream);
+int  dl_mlp_loss_and_grad(dl_mlp* net, const double* x_dev, const double* y_dev, int64_t rows, double* loss_host /* [1] */, double* grad_host /* [n_weights] */, void* hip_stream);
+int  dl_mlp_forward(dl_mlp* net, const double* x_dev, int64_t rows, double* y_dev /* [rows, n_out] */, void* hip_stream);
+int  dl_mlp_get_weights(dl_mlp* net, double* weights /* host, flat */, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

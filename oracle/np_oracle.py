@@ -586,3 +586,61 @@ def fisher_mean_chi2min(center, offset, gradient, hessian):
     solve = np.linalg.solve(hessian, gradient)
     flatdiff = -solve
     return center - solve, -2. * (offset + gradient.dot(flatdiff) + 0.5 * flatdiff.dot(hessian).dot(flatdiff))
+
+
+# ----------------------------------------------------------------------------------------------
+# f2: MLP emulator training.  THIRD-PARTY in the reference (cosmoprimo.emulators.tools.MLPEmulatorEngine; desilike/emulators/__init__.py:510-533 only wraps it):
+# PARITY UNPINNED.  Restated as the published algorithm: mean squared error of the scaled outputs, back-propagation through the layers of emulators/conversion.py:20-35,
+# Adam (Kingma & Ba 2015) with bias correction.  Pins: gradient against finite differences (tests/test_oracle_emulator.py), the HIP trainer against this restatement
+# step by step (tests/test_gpu_mlp_train.py).
+# ----------------------------------------------------------------------------------------------
+def _mlp_act(z, activation):
+    if activation == 'silu': return z / (1. + np.exp(-z))
+    if activation == 'relu': return np.maximum(z, 0.)
+    if activation == 'tanh': return np.tanh(z)
+    raise ValueError(activation)
+
+
+def _mlp_act_prime(z, activation):
+    if activation == 'silu':
+        s = 1. / (1. + np.exp(-z))
+        return s * (1. + z * (1. - s))
+    if activation == 'relu': return (z > 0.).astype('f8')
+    if activation == 'tanh': return 1. - np.tanh(z)**2
+    raise ValueError(activation)
+
+
+def mlp_loss_and_grad(layers, x, y, activation='silu'):
+    """Mean squared error of the network output (last layer linear) and its gradient: list of (dkernel, dbias)."""
+    zs, acts, a = [], [x], x
+    for il, (kernel, bias) in enumerate(layers):
+        z = a.dot(kernel) + bias
+        zs.append(z)
+        a = _mlp_act(z, activation) if il < len(layers) - 1 else z
+        acts.append(a)
+    diff = a - y
+    loss = np.mean(diff**2)
+    delta = 2. * diff / diff.size
+    grads = [None] * len(layers)
+    for il in range(len(layers) - 1, -1, -1):
+        grads[il] = (acts[il].T.dot(delta), delta.sum(axis=0))
+        if il > 0: delta = delta.dot(layers[il][0].T) * _mlp_act_prime(zs[il - 1], activation)
+    return loss, grads
+
+
+def mlp_adam(layers, x, y, batch, nsteps, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, activation='silu'):
+    """``nsteps`` Adam steps on consecutive chunks of ``batch`` samples (step t uses chunk t mod (S // batch)); returns (layers, losses)."""
+    layers = [(kernel.copy(), bias.copy()) for kernel, bias in layers]
+    moments = [[np.zeros_like(kernel), np.zeros_like(bias), np.zeros_like(kernel), np.zeros_like(bias)] for kernel, bias in layers]
+    chunks, losses = len(x) // batch, []
+    for t in range(1, nsteps + 1):
+        c = (t - 1) % chunks
+        loss, grads = mlp_loss_and_grad(layers, x[c * batch:(c + 1) * batch], y[c * batch:(c + 1) * batch], activation)
+        losses.append(loss)
+        c1, c2 = 1. - beta1**t, 1. - beta2**t
+        for il, (gk, gb) in enumerate(grads):
+            for ip, g in enumerate([gk, gb]):
+                m = moments[il][ip] = beta1 * moments[il][ip] + (1. - beta1) * g
+                v = moments[il][2 + ip] = beta2 * moments[il][2 + ip] + (1. - beta2) * g * g
+                layers[il][ip][...] -= lr * (m / c1) / (np.sqrt(v / c2) + eps)
+    return layers, np.array(losses)

@@ -114,3 +114,27 @@ def test_cfg3_full_size_oracle_vs_reference():
             assert np.allclose(flat, g['flattheory'][i], rtol=1e-12, atol=1e-12 * np.abs(flat).max())
         logl = orc.gaussian_loglikelihood(flat, c['flatdata'], precision)[0]
         assert abs(logl - g['loglikelihood'][i]) <= 1e-10 * max(1., abs(g['loglikelihood'][i]))
+
+
+def test_mlp_training_oracle_gradient_and_adam():
+    """The restated MLP training (oracle mlp_loss_and_grad / mlp_adam, row f2): gradient against central finite differences, Adam decreases the loss of a smooth target."""
+    rng = np.random.RandomState(0)
+    for activation in ['silu', 'tanh', 'relu']:
+        layers = [(rng.standard_normal((3, 5)) / 3**0.5, 0.1 * rng.standard_normal(5)), (rng.standard_normal((5, 4)) / 5**0.5, 0.1 * rng.standard_normal(4)),
+                  (rng.standard_normal((4, 7)) / 2., 0.1 * rng.standard_normal(7))]
+        x, y = rng.uniform(0., 1., (11, 3)), rng.standard_normal((11, 7))
+        loss, grads = orc.mlp_loss_and_grad(layers, x, y, activation)
+        for il in range(3):
+            for ip in range(2):
+                flat = layers[il][ip].ravel()
+                for idx in rng.choice(flat.size, size=min(6, flat.size), replace=False):
+                    old = flat[idx]
+                    flat[idx] = old + 1e-6; up = orc.mlp_loss_and_grad(layers, x, y, activation)[0]
+                    flat[idx] = old - 1e-6; dn = orc.mlp_loss_and_grad(layers, x, y, activation)[0]
+                    flat[idx] = old
+                    assert abs((up - dn) / 2e-6 - grads[il][ip].ravel()[idx]) <= 1e-7 * max(1., abs(grads[il][ip].ravel()[idx])), (activation, il, ip, idx)
+    x = rng.uniform(0., 1., (256, 2))
+    y = np.column_stack([np.sin(3. * x[:, 0]) * x[:, 1], x[:, 0]**2 - x[:, 1]])
+    layers = [(rng.standard_normal((2, 16)) / 2**0.5, np.zeros(16)), (rng.standard_normal((16, 2)) / 4., np.zeros(2))]
+    fitted, losses = orc.mlp_adam(layers, x, y, batch=64, nsteps=400, lr=1e-2, activation='silu')
+    assert losses[-20:].mean() < 0.05 * losses[:4].mean()
