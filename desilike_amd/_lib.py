@@ -124,6 +124,8 @@ def fill_config(spec, set_f64, set_i32):
             set_f64(key, np.ascontiguousarray(value.ravel(), dtype=np.float64))
 
     for key, value in spec.items():
+        if key.startswith('_'):    # host-side entries (Context reads '_expand')
+            continue
         if key == 'observables':
             for iobs, obs in enumerate(value):
                 for okey, ovalue in obs.items():
@@ -175,6 +177,34 @@ class Context(object):
             raise LibraryError(lib.dl_last_error(None).decode())
         self._lib, self._handle, self.device = lib, handle, int(device)
         self.n_params, self.n_data, self.n_obs, self.n_solved = (self.info(name) for name in ['n_params', 'n_data', 'n_obs', 'n_solved'])
+        # parameters derived from others by an expression (parameter.py:758-807) are extra theta columns of the device context, computed here from the caller's
+        # columns: ``expand(theta [B, n_params]) -> [B, n_device_params]`` (numpy array or torch tensor, whatever it is given), set by the likelihood
+        self.n_device_params, self.expand = self.n_params, None
+        if spec.get('_expand', None) is not None:
+            self.set_expand(*spec['_expand'])
+
+    def set_expand(self, expand, n_params):
+        """Callers pass ``theta [B, n_params]``; the device context receives ``expand(theta) [B, n_device_params]``."""
+        self.expand, self.n_params = expand, int(n_params)
+
+    def _host_theta(self, theta):
+        theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
+        if theta.shape[1] != self.n_params:
+            raise ValueError('theta must have shape (B, {:d}), found {}'.format(self.n_params, theta.shape))
+        if self.expand is not None:
+            theta = np.ascontiguousarray(self.expand(theta), dtype='f8')
+            assert theta.shape[1] == self.n_device_params
+        return theta
+
+    def _device_theta(self, theta, stream):
+        import torch
+        assert theta.is_contiguous() and theta.dtype == torch.float64 and theta.shape[1] == self.n_params
+        if self.expand is not None:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=theta.device)):   # the extra columns are computed on the stream the evaluation runs on
+                theta = self.expand(theta).contiguous()
+            assert theta.shape[1] == self.n_device_params
+            self._expanded = theta    # alive until the next call on this context (calls on one context are serialised: include/desilike_amd.h)
+        return theta
 
     def info(self, key):
         return int(self._lib.dl_info(self._handle, key.encode()))
@@ -197,9 +227,7 @@ class Context(object):
     # ---- host-pointer entry points (numpy in / numpy out) ----
     def eval_batch_host(self, theta, return_flattheory=False, return_solved=False):
         """numpy in / numpy out: (loglike, logprior, status[, flattheory][, solved])."""
-        theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
-        if theta.shape[1] != self.n_params:
-            raise ValueError('theta must have shape (B, {:d}), found {}'.format(self.n_params, theta.shape))
+        theta = self._host_theta(theta)
         B = theta.shape[0]
         loglike, logprior, status = np.empty(B, dtype='f8'), np.empty(B, dtype='f8'), np.empty(B, dtype='i4')
         flat = np.empty((B, self.n_data), dtype='f8') if return_flattheory else None
@@ -213,9 +241,7 @@ class Context(object):
 
     def eval_logposterior_host(self, theta):
         """numpy in / numpy out: (logposterior [B], status [B]) with the samplers' -inf conventions applied on the device (samplers/base.py:144-200)."""
-        theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
-        if theta.shape[1] != self.n_params:
-            raise ValueError('theta must have shape (B, {:d}), found {}'.format(self.n_params, theta.shape))
+        theta = self._host_theta(theta)
         B = theta.shape[0]
         logposterior, status = np.empty(B, dtype='f8'), np.empty(B, dtype='i4')
         self._check(self._lib.dl_eval_logposterior_host(self._handle, _f64_ptr(theta), B, _f64_ptr(logposterior), _i32_ptr(status)))
@@ -224,9 +250,7 @@ class Context(object):
     def eval_batch_derived_host(self, theta):
         """numpy in / numpy out: (loglike, logprior, status, solved [B, n_solved], hessian [B, n_solved, n_solved]); stages through device tensors."""
         import torch
-        theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
-        if theta.shape[1] != self.n_params:
-            raise ValueError('theta must have shape (B, {:d}), found {}'.format(self.n_params, theta.shape))
+        theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')    # (columns of derived-by-expression parameters are added by eval_batch_derived)
         B, ns = theta.shape[0], self.n_solved
         device = torch.device('cuda', self.device)
         th = torch.as_tensor(theta, dtype=torch.float64, device=device).contiguous()
@@ -240,7 +264,7 @@ class Context(object):
         return tuple(t.cpu().numpy() for t in (loglike, logprior, status, solved, hessian))
 
     def eval_theory_host(self, theta, iobs=0, return_tables=False):
-        theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
+        theta = self._host_theta(theta)
         B = theta.shape[0]
         n_ell, n_kin = self.info('n_ell_obs{:d}'.format(iobs)), self.info('n_kin_obs{:d}'.format(iobs))
         power = np.empty((B, n_ell, n_kin), dtype='f8')
@@ -255,7 +279,7 @@ class Context(object):
         if stream is None:
             stream = torch.cuda.current_stream(theta.device).cuda_stream
         B = theta.shape[0]
-        assert theta.is_contiguous() and theta.dtype == torch.float64 and theta.shape[1] == self.n_params
+        theta = self._device_theta(theta, stream)
 
         def ptr(tensor, dtype, shape):
             if tensor is None: return None
@@ -272,7 +296,7 @@ class Context(object):
         if stream is None:
             stream = torch.cuda.current_stream(theta.device).cuda_stream
         B = theta.shape[0]
-        assert theta.is_contiguous() and theta.dtype == torch.float64 and theta.shape[1] == self.n_params
+        theta = self._device_theta(theta, stream)
 
         def ptr(tensor, dtype, shape):
             if tensor is None: return None
@@ -289,7 +313,7 @@ class Context(object):
         if stream is None:
             stream = torch.cuda.current_stream(theta.device).cuda_stream
         B = theta.shape[0]
-        assert theta.is_contiguous() and theta.dtype == torch.float64 and theta.shape[1] == self.n_params
+        theta = self._device_theta(theta, stream)
         assert logposterior.is_contiguous() and logposterior.dtype == torch.float64 and tuple(logposterior.shape) == (B,)
         assert status is None or (status.is_contiguous() and status.dtype == torch.int32 and tuple(status.shape) == (B,))
         self._check(self._lib.dl_eval_logposterior(self._handle, ctypes.c_void_p(theta.data_ptr()), B, ctypes.c_void_p(logposterior.data_ptr()),
@@ -302,7 +326,7 @@ class Context(object):
             stream = torch.cuda.current_stream(theta.device).cuda_stream
         B = theta.shape[0]
         n_ell, n_kin = self.info('n_ell_obs{:d}'.format(iobs)), self.info('n_kin_obs{:d}'.format(iobs))
-        assert theta.is_contiguous() and theta.dtype == torch.float64 and theta.shape[1] == self.n_params
+        theta = self._device_theta(theta, stream)
         assert power.is_contiguous() and power.dtype == torch.float64 and tuple(power.shape) == (B, n_ell, n_kin)
         assert tables is None or (tables.is_contiguous() and tables.dtype == torch.float64 and tuple(tables.shape) == (B, 3, n_ell, n_kin))
         self._check(self._lib.dl_eval_theory(self._handle, ctypes.c_void_p(theta.data_ptr()), B, int(iobs), ctypes.c_void_p(power.data_ptr()),
@@ -316,6 +340,8 @@ class Context(object):
         if stream is None:
             stream = torch.cuda.current_stream(centers.device).cuda_stream
         B, P = centers.shape
+        if self.expand is not None:
+            raise NotImplementedError('Fisher algebra with parameters derived by an expression: differentiate w.r.t. the device columns and apply the chain rule on the host')
         assert P == self.n_params and centers.is_contiguous() and centers.dtype == torch.float64
         assert steps.is_contiguous() and steps.dtype == torch.float64 and tuple(steps.shape) == (B, P, 2)
         if hessian is None: hessian = torch.empty((B, P, P), dtype=torch.float64, device=centers.device)
@@ -387,6 +413,8 @@ class DeviceEnsemble(object):
 
     def __init__(self, ctx, nwalkers, a=2., seed=0, offset=0., group=None):
         lib = load()
+        if ctx.expand is not None:
+            raise NotImplementedError('the device-resident ensemble proposes in the columns of the device context: parameters derived by an expression need the host-driven sampler')
         handle = ctypes.c_void_p()
         comm = getattr(group, 'handle', None)
         if lib.dl_ensemble_create(ctypes.byref(handle), ctx._handle, int(nwalkers), float(a), ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), float(offset), comm) != 0:

@@ -36,6 +36,11 @@ class BaseLikelihood(BaseCalculator):
         return ParameterCollection([param for param in self.all_params if param.varied and not param.solved and param.derived is False])
 
     @property
+    def dependent_params(self):
+        """Parameters computed from others by an expression, ``derived='{a} * {b}'`` (parameter.py:758-807, base.py:533-545): not sampled, reported as derived."""
+        return ParameterCollection([param for param in self.all_params if param.depends])
+
+    @property
     def solved_params(self):
         """Parameters solved analytically at every point ('.marg', '.best', '.auto'): likelihoods/base.py:262-271."""
         return ParameterCollection([param for param in self.all_params if param.solved and not param.derived.startswith('.prec')])
@@ -207,7 +212,12 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         if vary_solved:
             varied = ParameterCollection(list(varied) + [param for param in self.all_params if param.solved])
             drop_solved = True
-        names = varied.names()
+        # parameters derived by an expression are extra columns of the device theta, filled by Context.expand (:meth:`_expand_theta`); no prior of their own
+        # (the reference's logprior runs over varied_params only: likelihoods/base.py:231-236)
+        dependents = self.dependent_params
+        if vary_solved and len(dependents):
+            raise NotImplementedError('Fisher algebra with parameters derived by an expression ({}) is not implemented'.format(dependents.names()))
+        names = varied.names() + dependents.names()
         solved = ParameterCollection() if drop_solved else self.solved_params
         solved_names = solved.names()
         observables = []
@@ -259,8 +269,12 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
                         raise PipelineError('parameter {} cannot be solved analytically: the theory is not linear in it'.format(pname))
                 spec['marg'] = marg
             observables.append(spec)
-        priors = np.array([param.prior.spec() for param in varied], dtype='f8').reshape(len(names), 5)
+        from ..parameter import ParameterPrior
+        # a varied dependent keeps its own prior, like in pipeline.params.prior (parameter.py:1889-1897)
+        priors = np.array([param.prior.spec() for param in varied] + [(param.prior if param.varied else ParameterPrior()).spec() for param in dependents], dtype='f8').reshape(len(names), 5)
         spec = dict(n_params=np.array([len(names)], dtype='i4'), priors=priors, precision=precision, observables=observables)
+        if len(dependents):
+            spec['_expand'] = (self._make_expand(varied, dependents, fixed_values), len(varied))
         if solved_names:
             kind, mprior, x0 = [], [], []
             for param in solved:
@@ -274,9 +288,59 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             spec['marg'] = dict(kind=np.array(kind, dtype='i4'), prior=np.array(mprior, dtype='f8'), x0=np.array(x0, dtype='f8'))
         return spec
 
+    def _make_expand(self, varied, dependents, fixed_values):
+        """``theta [B, len(varied)] -> [B, len(varied) + len(dependents)]``: the columns of parameters derived by an expression, evaluated from the sampled columns
+        and the values of fixed parameters (parameter.py:795-807; the pipeline does this before every calculation: base.py:536-539).  Works on numpy arrays
+        and torch tensors alike; dependents may depend on other dependents (resolved in order, cycles are an error)."""
+        names = varied.names()
+        constants = {param.name: float(fixed_values.get(param.name, param.value)) for param in self._all_params if param.name not in names and not param.depends}
+        order, done, pending = [], set(names) | set(constants), list(dependents)
+        while pending:
+            ready = [param for param in pending if all(name in done for name in param.depends)]
+            if not ready:
+                unknown = sorted(set(name for param in pending for name in param.depends if name not in self._all_params))
+                if unknown:
+                    raise PipelineError('parameters {} are derived from {}, which are not parameters of the pipeline: {}'.format([p.name for p in pending], unknown, self._all_params.names()))
+                raise PipelineError('parameters {} are derived from each other'.format([param.name for param in pending]))
+            for param in ready:
+                order.append(param); done.add(param.name); pending.remove(param)
+        columns = {param.name: len(names) + i for i, param in enumerate(dependents)}
+
+        def expand(theta):
+            values = dict(constants)
+            for i, name in enumerate(names): values[name] = theta[:, i]
+            extra = {}
+            for param in order:
+                values[param.name] = extra[columns[param.name]] = param.eval(**values)
+            if isinstance(theta, np.ndarray):
+                out = np.empty((theta.shape[0], len(names) + len(columns)), dtype='f8')
+                out[:, :len(names)] = theta
+                for col, value in extra.items(): out[:, col] = value
+                return out
+            import torch
+            out = torch.empty((theta.shape[0], len(names) + len(columns)), dtype=theta.dtype, device=theta.device)
+            out[:, :len(names)] = theta
+            for col, value in extra.items(): out[:, col] = value
+            return out
+
+        return expand
+
+    def _check_params(self):
+        """Drop the compiled contexts if ``all_params`` changed since they were built (``likelihood.all_params['b1'].update(fixed=True)``, a new parameter ...):
+        the reference re-reads its parameters at every call (base.py:533-539).  One integer comparison when nothing changed."""
+        from ..parameter import generation
+        current = generation()
+        if current != getattr(self, '_params_generation', None):
+            signature = tuple((param.name, repr(param.__getstate__())) for param in self._all_params)
+            if signature != getattr(self, '_params_signature', signature):
+                for ctx in self._contexts.values(): ctx.close()
+                self._contexts = {}
+            self._params_signature, self._params_generation = signature, generation()
+
     def _get_context(self, fixed_values=None):
         from .._lib import Context
         self.initialize()
+        self._check_params()
         fixed_values = dict(fixed_values or {})
         key = tuple(sorted(fixed_values.items()))
         if key not in self._contexts:
@@ -321,6 +385,7 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         priors: the device takes the factor F = L V sqrt(lambda) of P' = F F^T (eigen-decomposition of Q) instead of a Cholesky factor.  Separate ``loglikelihood`` /
         ``logprior`` / solved values still come from the per-point path (:meth:`_get_context`)."""
         self.initialize()
+        self._check_params()
         fixed_values = dict(fixed_values or {})
         if not len(self.solved_params):
             return self._get_context(fixed_values), 0.
@@ -487,6 +552,9 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             derived = Samples()
             derived[self._param_loglikelihood] = loglike.reshape(shape)
             derived[self._param_logprior] = logprior.reshape(shape)
+            if ctx.expand is not None:   # parameters derived by an expression are reported with the derived parameters (base.py:541-545)
+                for param, column in zip(self.dependent_params, ctx.expand(theta)[:, theta.shape[1]:].T):
+                    derived[param] = column.reshape(shape)
             if ctx.n_solved:   # solution of the analytically solved parameters (likelihoods/base.py:361-368)
                 for param, column in zip(self.solved_params, out[-1].T):
                     derived[param] = column.reshape(shape)

@@ -137,6 +137,7 @@ class Parameter(object):
     _attrs = ['basename', 'namespace', 'value', 'fixed', 'derived', 'prior', 'ref', 'proposal', 'delta', 'latex']
 
     def __init__(self, basename, namespace='', value=None, fixed=None, derived=False, prior=None, ref=None, proposal=None, delta=None, latex=None):
+        _generation[0] += 1
         if isinstance(basename, Parameter):
             self.__dict__.update(copy.deepcopy(basename.__dict__))
             return
@@ -158,15 +159,16 @@ class Parameter(object):
             delta = (delta,) * 2
         self._delta = None if delta is None else tuple(delta)
         if isinstance(derived, str):
-            if derived not in ALLOWED_SOLVED:
-                raise ParameterError('derived parameters defined by an expression are evaluated on the host by the caller; the GPU path supports {}'.format(ALLOWED_SOLVED))
-            if self._prior.is_limited():
-                raise ParameterError('Prior must be "norm" or "uniform" with no limits to use analytic marginalisation for {}'.format(self._basename))
+            if derived in ALLOWED_SOLVED:
+                if self._prior.is_limited():
+                    raise ParameterError('Prior must be "norm" or "uniform" with no limits to use analytic marginalisation for {}'.format(self._basename))
+            elif not self._placeholders(derived):
+                raise ParameterError('derived must be one of {} or an expression of other parameters in braces, e.g. "{{a}} + {{b}}" (parameter.py:758-776); found {!r}'.format(ALLOWED_SOLVED, derived))
             self._derived = derived
         else:
             self._derived = bool(derived)
         if fixed is None:
-            fixed = prior is None and ref is None
+            fixed = prior is None and ref is None and not self.depends     # parameter.py:778-779
         self._fixed = bool(fixed)
 
     basename = property(lambda self: self._basename)
@@ -198,6 +200,40 @@ class Parameter(object):
         if len(delta) == 2:
             delta = (self.value,) + tuple(delta)
         return delta
+
+    @staticmethod
+    def _placeholders(expression):
+        import re
+        return re.findall(r'\{(.*?)\}', expression)
+
+    @property
+    def depends(self):
+        """Names of the parameters this one is computed from (``derived='{a} + {b}'``: parameter.py:758-776), in order of appearance; empty otherwise."""
+        if isinstance(self._derived, str) and self._derived not in ALLOWED_SOLVED:
+            names = []
+            for name in self._placeholders(self._derived):
+                if name not in names: names.append(name)
+            return names
+        return []
+
+    def eval(self, **values):
+        """Value given the values of all parameters (parameter.py:795-807): the expression with each ``{name}`` replaced by ``values[name]`` (scalars, numpy arrays or
+        torch tensors: arithmetic operators work on all of them; ``np`` / ``jnp`` name numpy for host arrays), or ``values[self.name]`` for an ordinary parameter."""
+        depends = self.depends
+        if not depends:
+            return values[self.name]
+        missing = [name for name in depends if name not in values]
+        if missing:
+            raise ParameterError('Parameter {} is to be derived from parameters {}, as {}, but {} are not provided'.format(self.name, depends, self._derived, missing))
+        expression, local = self._derived, {}
+        for i, name in enumerate(depends):
+            key = '_dl_arg{:d}_'.format(i)
+            expression = expression.replace('{' + name + '}', key)
+            local[key] = values[name]
+        xp = np
+        if any(type(value).__module__.startswith('torch') for value in local.values()):
+            import torch as xp      # device tensors: sqrt / exp / log ... have the same names
+        return eval(expression, {'__builtins__': {}, 'np': xp, 'jnp': xp, 'abs': abs, 'min': min, 'max': max}, local)
 
     @property
     def solved(self):
@@ -252,6 +288,13 @@ class Parameter(object):
         return hash(self.name)
 
 
+_generation = [0]   # bumped by every Parameter construction / update and every change of a collection: compiled contexts check it before trusting their cache
+
+
+def generation():
+    return _generation[0]
+
+
 class ParameterCollection(object):
     """Ordered name -> :class:`Parameter` collection (parameter.py:1657-1897)."""
 
@@ -280,6 +323,7 @@ class ParameterCollection(object):
         return None
 
     def set(self, param):
+        _generation[0] += 1
         i = self._index(param.name)
         if i is None: self.data.append(param)
         else: self.data[i] = param
@@ -296,6 +340,7 @@ class ParameterCollection(object):
         if i is None:
             if default: return default[0]
             raise KeyError('Parameter {} not found'.format(name))
+        _generation[0] += 1
         return self.data.pop(i)
 
     def __getitem__(self, name):
@@ -369,12 +414,29 @@ class ParameterCollection(object):
         if other in (0, None): return self.copy()
         return ParameterCollection(other) + self
 
+    def eval(self, **params):
+        """Values of all parameters that can be computed from ``params``, e.g. ``{'a': 2., 'b': 3., 'c': 5.}`` if ``c.derived`` is '{a} + {b}' (parameter.py:1872-1887)."""
+        toret = {}
+        pending = list(self.data)
+        values = dict(params)
+        while pending:   # parameters derived from derived ones: as many passes as levels
+            left = []
+            for param in pending:
+                try:
+                    values[param.name] = toret[param.name] = param.eval(**values)
+                except (ParameterError, KeyError):
+                    left.append(param)
+            if len(left) == len(pending): break
+            pending = left
+        return {param.name: toret[param.name] for param in self.data if param.name in toret}
+
     def prior(self, **params):
-        """Total log-prior of varied, non-solved parameters (parameter.py:1889-1897)."""
+        """Total log-prior of varied, non-solved parameters, including those derived from others by an expression (parameter.py:1889-1897)."""
+        values = self.eval(**params)
         toret = 0.
         for param in self.data:
-            if param.varied and not param.solved and param.name in params:
-                toret = toret + param.prior(params[param.name])
+            if param.varied and not param.solved and (param.depends or param.derived is False) and param.name in values:
+                toret = toret + param.prior(values[param.name])
         return toret
 
     def __repr__(self):

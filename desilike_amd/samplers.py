@@ -242,7 +242,8 @@ class EmceeSampler(BasePosteriorSampler):
         self.chain = None
         self.a = float(a)
         if device_resident is None:
-            device_resident = use_emcee is not True and getattr(likelihood, '_get_posterior_context', None) is not None
+            # (parameters derived by an expression are computed by the host wrapper of the context: the device-resident ensemble does not see them)
+            device_resident = use_emcee is not True and getattr(likelihood, '_get_posterior_context', None) is not None and not len(getattr(likelihood, 'dependent_params', []))
         self.device_resident = bool(device_resident)
         self._ensemble = None
         emcee = None
