@@ -10,6 +10,7 @@
 #include "../../include/desilike_amd.h"
 #include "dl_host.hpp"
 #include "dl_kernels.h"
+#include "dl_prior.h"
 
 static thread_local std::string g_last_error;
 void dl_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
@@ -20,6 +21,7 @@ struct dl_ctx {
     int n_white = 0;                 // width of the whitened residual rows (= n_data, or more when the observables' row ranges are aligned to 16: see dl_create)
     int N_pad = 0, K_pad = 0, max_n_t = 0;
     bool any_transform = false;
+    bool priors_general = false;     // a prior of a kind beyond uniform / norm is present (dl_prior.h)
     // analytic marginalisation
     int n_solved = 0, n_var = 0;
     DlMargDev marg;
@@ -157,6 +159,12 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     if (ctx->n_params < 1 || ctx->n_obs < 1) return bail("dl_create: n_params and n_obs must be set (>= 1)");
     const auto& priors = cfg->F("priors");
     if ((int)priors.size() != 5 * ctx->n_params) return bail("dl_create: priors must have 5 entries per parameter");
+    for (int p = 0; p < ctx->n_params; ++p) {   // (kind, lo, hi, loc, scale): kinds of dl_prior.h
+        const double kind = priors[5 * p];
+        if (!(kind >= 0. && kind <= (double)DL_PRIOR_MAX_KIND && kind == (double)(int)kind)) return bail("dl_create: unknown prior kind (0 uniform, 1 norm, 2-9: see include/desilike_amd.h)");
+        if (kind >= 1. && !(priors[5 * p + 4] > 0.)) return bail("dl_create: the scale of a prior must be positive");
+        if (kind >= 2.) ctx->priors_general = true;
+    }
     // ---- observables ----
     DlArena arena;
     ctx->obs.resize(ctx->n_obs);
@@ -535,7 +543,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         int part_tiles = ctx->N_pad / 16;
         // DL_CHI2_FUSED=1: finalize inside the GEMM's last-arriving workgroups.  Off by default: measured 19.1 us (GEMM 17.1) against 17.5 us for GEMM + the
         // separate 1024-thread finalize launch -- the device-scope counter round trip and the dependent tail cost more than the launch they save.
-        static const bool chi2_fused = getenv("DL_CHI2_FUSED") && atoi(getenv("DL_CHI2_FUSED")) != 0;
+        static const bool chi2_fused_env = getenv("DL_CHI2_FUSED") && atoi(getenv("DL_CHI2_FUSED")) != 0;
+        const bool chi2_fused = chi2_fused_env && !ctx->priors_general;   // (the experimental fused finalize of the GEMM knows uniform / norm priors only)
         if (chi2_path) {
             if (nb > 16384) { prof_phase(-1); return dl_fail(ctx, "dl_eval_batch: DL_CHI2_GEMM_MAX above 16384 rows"); }
             dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad,

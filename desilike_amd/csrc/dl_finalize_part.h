@@ -2,6 +2,7 @@
 // ensemble step kernel (dl_ensemble.hip), which finishes the pending half-step's proposals itself instead of waiting for a separate finalize launch.
 // Priors: parameter.py:1994-2017 (uniform / norm, maximum removed, closed limits); status rules of include/desilike_amd.h.
 #pragma once
+#include "dl_prior.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -20,10 +21,7 @@ __device__ __forceinline__ void dl_finalize_from_chi2(double chi2, const double*
         double x = theta_row[p];
         const double* pr = priors + 5 * p;
         if (x != x) nan_in = true;
-        bool isin = (pr[1] <= x) && (x <= pr[2]);
-        double v = 0.;
-        if (pr[0] == 1.) { double t = x - pr[3]; v = -0.5 * (t * t) / (pr[4] * pr[4]); }   // parameter.py:2007
-        lp += isin ? v : -inf;
+        lp += dl_prior_logpdf(pr, x);
     }
     ll = -0.5 * chi2;
     st = 0;                                                                   // DL_STATUS_OK

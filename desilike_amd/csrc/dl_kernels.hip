@@ -489,10 +489,7 @@ __global__ __launch_bounds__(256) void dl_finalize_kernel(const double* __restri
         double x = theta[(size_t)b * n_params + p];
         const double* pr = priors + 5 * p;
         if (x != x) nan_in = 1;
-        bool isin = (pr[1] <= x) && (x <= pr[2]);
-        double v = 0.;
-        if (pr[0] == 1.) { double t = x - pr[3]; v = -0.5 * (t * t) / (pr[4] * pr[4]); }   // parameter.py:2007
-        lp += isin ? v : -inf;
+        lp += dl_prior_logpdf(pr, x);
     }
     lp = dl_wave_sum(lp);
     nan_in = __any(nan_in);
@@ -696,10 +693,7 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
         double x = theta[(size_t)b * n_params + p];
         const double* pr = priors + 5 * p;
         if (x != x) nan_in = 1;
-        bool isin = (pr[1] <= x) && (x <= pr[2]);
-        double v = 0.;
-        if (pr[0] == 1.) { double t = x - pr[3]; v = -0.5 * (t * t) / (pr[4] * pr[4]); }
-        lp += isin ? v : -inf;
+        lp += dl_prior_logpdf(pr, x);
     }
     __shared__ double gram_lds[4][STAGED ? 2 : 16 * 16];   // (staged variant: G and the Cholesky rows reuse the wave's staging area)
     double* Gw = gram_lds[wave];

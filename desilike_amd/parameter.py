@@ -17,8 +17,15 @@ class ParameterError(Exception):
     pass
 
 
+# prior kinds of the device table (csrc/dl_prior.h): uniform, norm, then scipy.stats location-scale families whose density is finite and non-zero at loc
+PRIOR_KINDS = ['uniform', 'norm', 'expon', 'laplace', 'cauchy', 'logistic', 'halfnorm', 'halfcauchy', 'gumbel_r', 'gumbel_l']
+
+
 class ParameterPrior(object):
-    """1D prior: 'uniform' (possibly improper) or 'norm', optionally truncated to ``limits`` (parameter.py:1908-2017)."""
+    """1D prior (parameter.py:1908-2017): 'uniform' (possibly improper) or 'norm', optionally truncated to ``limits``; or one of the location-scale families of
+    scipy.stats in :data:`PRIOR_KINDS` with explicit ``loc`` (and ``scale``, default 1), evaluated like the reference as ``rv.logpdf(x) - rv.logpdf(loc)`` (2012-2016).
+    Not reproduced: limits on those families (the reference maps them onto scipy's ``trunc<dist>`` with the arguments of ``truncnorm``, 1958-1963) and a missing
+    ``loc`` (the reference then removes ``logpdf(mean(limits)) = logpdf(nan)``)."""
 
     def __init__(self, dist='uniform', limits=None, **kwargs):
         if isinstance(dist, ParameterPrior):
@@ -32,25 +39,40 @@ class ParameterPrior(object):
         self.limits = (float(limits[0]), float(limits[1]))
         self.dist = str(dist)
         if self.dist.startswith('trunc'): self.dist = self.dist[5:]
-        if self.dist not in ('uniform', 'norm'):
-            raise ParameterError('only "uniform" and "norm" priors are supported on the GPU path, found {}'.format(self.dist))
+        if self.dist not in PRIOR_KINDS:
+            raise ParameterError('prior distribution must be one of {}, found {}'.format(PRIOR_KINDS, self.dist))
         self.attrs = {name: float(value) for name, value in kwargs.items()}
         if self.dist == 'norm':
             self.attrs.setdefault('loc', 0.)
             self.attrs.setdefault('scale', 1.)
+        elif self.dist != 'uniform':
+            if self.is_limited():
+                raise ParameterError('limits are supported for "uniform" and "norm" priors only, found {} with limits {}'.format(self.dist, self.limits))
+            if 'loc' not in self.attrs:
+                raise ParameterError('prior {} needs an explicit loc: its log-density is reported relative to the value at loc (parameter.py:2012-2016)'.format(self.dist))
+            self.attrs.setdefault('scale', 1.)
+            unknown = [name for name in self.attrs if name not in ('loc', 'scale')]
+            if unknown:
+                raise ParameterError('prior {} takes loc and scale only, found {}'.format(self.dist, unknown))
+        if self.dist != 'uniform' and not self.attrs['scale'] > 0.:
+            raise ParameterError('the scale of a prior must be positive')
 
     def copy(self):
         return ParameterPrior(self)
 
     @property
     def loc(self):
-        if self.dist == 'norm': return self.attrs['loc']
+        if self.dist != 'uniform': return self.attrs['loc']
         raise AttributeError('uniform distribution has no loc')
 
     @property
     def scale(self):
-        if self.dist == 'norm': return self.attrs['scale']
+        if self.dist != 'uniform': return self.attrs['scale']
         raise AttributeError('uniform distribution has no scale')
+
+    def _rv(self):
+        from scipy import stats
+        return getattr(stats, self.dist)(loc=self.attrs['loc'], scale=self.attrs['scale'])
 
     def is_proper(self):
         return self.dist != 'uniform' or not np.isinf(self.limits).any()
@@ -72,6 +94,12 @@ class ParameterPrior(object):
                 toret = toret - np.log(self.limits[1] - self.limits[0])
             return toret
         loc, scale = self.attrs['loc'], self.attrs['scale']
+        if self.dist != 'norm':   # parameter.py:2012-2016
+            rv = self._rv()
+            with np.errstate(divide='ignore'):
+                toret = rv.logpdf(x)
+                if remove_zerolag: toret = toret - rv.logpdf(loc)
+            return np.where(isin, toret, -np.inf)
         toret = np.where(isin, -0.5 * (x - loc)**2 / scale**2, -np.inf)
         if not remove_zerolag:
             from scipy import special
@@ -82,7 +110,7 @@ class ParameterPrior(object):
     __call__ = logpdf
 
     def center(self):
-        if self.dist == 'norm':
+        if self.dist != 'uniform':
             return self.attrs['loc']
         if self.is_limited():
             return float(np.mean([lim for lim in self.limits if not np.isinf(lim)]))
@@ -91,6 +119,8 @@ class ParameterPrior(object):
     def std(self):
         if self.dist == 'norm':
             return self.attrs['scale']
+        if self.dist != 'uniform':
+            return float(self._rv().std())
         if not self.is_proper():
             raise AttributeError('improper uniform distribution has no std')
         return (self.limits[1] - self.limits[0]) / 12.**0.5
@@ -103,6 +133,8 @@ class ParameterPrior(object):
         if self.dist == 'uniform':
             return rng.uniform(self.limits[0], self.limits[1], size=size)
         loc, scale = self.attrs['loc'], self.attrs['scale']
+        if self.dist != 'norm':
+            return self._rv().rvs(size=size, random_state=rng)
         if not self.is_limited():
             return loc + scale * rng.standard_normal(size=size)
         from scipy import stats
@@ -111,8 +143,8 @@ class ParameterPrior(object):
 
     def spec(self):
         """Row (kind, lo, hi, loc, scale) of the C-ABI ``priors`` table (include/desilike_amd.h)."""
-        if self.dist == 'norm':
-            return [1., self.limits[0], self.limits[1], self.attrs['loc'], self.attrs['scale']]
+        if self.dist != 'uniform':
+            return [float(PRIOR_KINDS.index(self.dist)), self.limits[0], self.limits[1], self.attrs['loc'], self.attrs['scale']]
         return [0., self.limits[0], self.limits[1], 0., 1.]
 
     def __getstate__(self):
@@ -160,7 +192,7 @@ class Parameter(object):
         self._delta = None if delta is None else tuple(delta)
         if isinstance(derived, str):
             if derived in ALLOWED_SOLVED:
-                if self._prior.is_limited():
+                if self._prior.dist not in ('norm', 'uniform') or self._prior.is_limited():      # parameter.py:762-764
                     raise ParameterError('Prior must be "norm" or "uniform" with no limits to use analytic marginalisation for {}'.format(self._basename))
             elif not self._placeholders(derived):
                 raise ParameterError('derived must be one of {} or an expression of other parameters in braces, e.g. "{{a}} + {{b}}" (parameter.py:758-776); found {!r}'.format(ALLOWED_SOLVED, derived))

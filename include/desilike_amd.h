@@ -69,7 +69,9 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
 /* ---- configuration store ---------------------------------------------------------------------
  * Keys (all arrays are copied; "obs<i>." prefix = i-th observable of ObservablesGaussianLikelihood):
  *   n_params        i32[1]   number of sampled parameters P (= columns of theta)
- *   priors          f64[P*5] rows (kind, lo, hi, loc, scale)                   parameter.py:1994-2007
+ *   priors          f64[P*5] rows (kind, lo, hi, loc, scale)                   parameter.py:1994-2017
+ *                            kind 0 uniform, 1 norm (fast paths 2003-2007); scipy.stats location-scale families evaluated as rv.logpdf(x) - rv.logpdf(loc)
+ *                            (2012-2016): 2 expon, 3 laplace, 4 cauchy, 5 logistic, 6 halfnorm, 7 halfcauchy, 8 gumbel_r, 9 gumbel_l (csrc/dl_prior.h)
  *   n_obs           i32[1]
  *   precision       f64[n*n] or f64[n]  precision matrix (or its diagonal), n = total data size
  *                                        (Hartlap / Percival factors already applied by the host: likelihoods/base.py:623-656)

@@ -41,10 +41,11 @@ def extract_config(likelihood):
     priors = []
     for param in likelihood.varied_params:
         prior = param.prior
-        if prior.dist not in ('uniform', 'norm'):
-            raise NotImplementedError('prior {} of {} is not supported on the device'.format(prior.dist, param.name))
-        priors.append([float(prior.dist == 'norm'), prior.limits[0], prior.limits[1], getattr(prior, 'loc', 0.) if prior.dist == 'norm' else 0.,
-                       getattr(prior, 'scale', 1.) if prior.dist == 'norm' else 1.])
+        kinds = ['uniform', 'norm', 'expon', 'laplace', 'cauchy', 'logistic', 'halfnorm', 'halfcauchy', 'gumbel_r', 'gumbel_l']   # csrc/dl_prior.h
+        if prior.dist not in kinds or (kinds.index(prior.dist) >= 2 and prior.is_limited()):
+            raise NotImplementedError('prior {} of {} is not supported on the device'.format(prior, param.name))
+        kind = kinds.index(prior.dist)
+        priors.append([float(kind), prior.limits[0], prior.limits[1], prior.attrs.get('loc', 0.) if kind else 0., prior.attrs.get('scale', 1.) if kind else 1.])
     cfg['priors'] = np.array(priors, dtype='f8')
     for iobs, obs in enumerate(likelihood.observables):
         p = 'obs{:d}.'.format(iobs)

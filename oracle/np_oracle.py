@@ -236,13 +236,17 @@ def gaussian_loglikelihood(flattheory, flatdata, precision):
 # a9: priors                                                parameter.py:1889-1897, 1994-2017
 # ----------------------------------------------------------------------------------------------
 def prior_logpdf(x, dist='uniform', limits=(-np.inf, np.inf), loc=0., scale=1.):
-    """Zero-lag-removed log-pdf, closed limits; parameter.py:1994-2007 (uniform and norm fast paths)."""
+    """Zero-lag-removed log-pdf, closed limits; parameter.py:1994-2017 (uniform and norm fast paths, scipy.stats for the rest)."""
     isin = (limits[0] <= x) & (x <= limits[1])
     if dist == 'uniform':
         return np.where(isin, 0., -np.inf)
     if dist == 'norm':
         return np.where(isin, -0.5 * (x - loc)**2 / scale**2, -np.inf)
-    raise NotImplementedError(dist)
+    # any other distribution: scipy's frozen rv, value at loc removed (parameter.py:1958-1966, 2012-2016)
+    from scipy import stats
+    rv = getattr(stats, dist)(loc=loc, scale=scale)
+    with np.errstate(divide='ignore'):
+        return np.where(isin, rv.logpdf(x) - rv.logpdf(loc), -np.inf)
 
 
 def logprior(theta, priors):
