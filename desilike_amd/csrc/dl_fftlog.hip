@@ -17,7 +17,9 @@
 // bound: LDS bandwidth (6 fused passes + the spectrum step, each moving 2 x 16 B x N2: 0.45 MB per transform).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -170,8 +172,280 @@ __global__ __launch_bounds__(DL_FF_THREADS) void dl_fftlog_kernel(const double* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The reference's grid (2048 points -> npad = 4096, N2 = 2048 complex), specialised: PERSISTENT workgroups, radix-16 passes written as a constant
+// 16-point transform + one twiddle per register slot, every twiddle that does not depend on the data kept for the life of the workgroup.
+//   N2 = 16 x 16 x 8.  Forward (decimation in frequency, natural -> bit-reversed):
+//     pass A  thread j (0..127) owns x[j + 128 e], e < 16: loaded from global memory straight into registers (only e = 4..11 carry data: the rest is the zero
+//             padding), constant 16-point DIF, slot e times W_2048^(j brev4(e)) -- 15 twiddles per thread, PERSISTENT in registers -- then LDS;
+//     pass B  thread t = 8 g + j owns x[128 g + j + 8 e]: LDS -> registers, 16-point DIF, slot e times W_128^(j brev4(e)) (128 distinct values: a 2 KB LDS table);
+//     pass C  two items per thread, x[8 t + e], e < 8: plain 8-point DIF (no twiddles left).
+//   Spectrum step as in the general kernel, with W_4096^m = W^tid x (compile-time 32nd root of unity) and u_ell[m], u_ell[N2 - m] requested right after pass A
+//   (they arrive behind passes B and C).  Inverse = the conjugate transposes in reverse order (C', B', A'); pass A' ends in registers and is stored from there,
+//   reversed and scaled (16-byte stores).  Two LDS round trips fewer than the general kernel, no table loads inside the passes, raw s_barrier with lgkmcnt-only
+//   waits so that the table requests stay in flight across barriers.
+// ------------------------------------------------------------------------------------------------------------------------
+#define DL_FF4_N2 2048
+#define DL_FF4_L 11
+
+// v * exp(-i pi q / 8) (forward) or v * exp(+i pi q / 8) (INV), q = 0..7 known at compile time after unrolling
+template <bool INV>
+__device__ __forceinline__ dl_ff_c dl_ff_rot(int q, dl_ff_c v) {
+    const double h = 0.70710678118654752, c1 = 0.92387953251128674, s1 = 0.38268343236508977;
+    switch (q) {
+        case 0: return v;
+        case 4: return INV ? dl_ff_c{-v.y, v.x} : dl_ff_c{v.y, -v.x};
+        case 2: return INV ? dl_ff_c{(v.x - v.y) * h, (v.x + v.y) * h} : dl_ff_c{(v.x + v.y) * h, (v.y - v.x) * h};
+        case 6: return INV ? dl_ff_c{-(v.x + v.y) * h, (v.x - v.y) * h} : dl_ff_c{(v.y - v.x) * h, -(v.x + v.y) * h};
+        default: {
+            const double c = (q == 1) ? c1 : (q == 3) ? s1 : (q == 5) ? -s1 : -c1;    // cos(pi q / 8)
+            const double s = (q == 1 || q == 7) ? s1 : c1;                               // sin(pi q / 8)
+            return INV ? dl_ff_c{v.x * c - v.y * s, v.y * c + v.x * s} : dl_ff_c{v.x * c + v.y * s, v.y * c - v.x * s};
+        }
+    }
+}
+
+// constant 2^S-point transform on registers: DIF forward (natural -> bit-reversed) or its conjugate transpose (bit-reversed -> natural)
+template <int S, bool INV>
+__device__ __forceinline__ void dl_ff_const(dl_ff_c* v) {
+    constexpr int R = 1 << S;
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+        const int half = INV ? (1 << st) : (R >> (st + 1));
+#pragma unroll
+        for (int e = 0; e < R; ++e) {
+            if (e & half) continue;
+            const int q = (e & (half - 1)) * (8 / half);
+            if (INV) {
+                const dl_ff_c a = v[e], b = dl_ff_rot<true>(q, v[e + half]);
+                v[e] = a + b;
+                v[e + half] = a - b;
+            } else {
+                const dl_ff_c a = v[e], b = v[e + half];
+                v[e] = a + b;
+                v[e + half] = dl_ff_rot<false>(q, a - b);
+            }
+        }
+    }
+}
+
+// forward stages FIRST .. S - 1 of dl_ff_const<S, false> (the earlier ones done by the caller)
+template <int S, int FIRST>
+__device__ __forceinline__ void dl_ff_const_from(dl_ff_c* v) {
+    constexpr int R = 1 << S;
+#pragma unroll
+    for (int st = FIRST; st < S; ++st) {
+        const int half = R >> (st + 1);
+#pragma unroll
+        for (int e = 0; e < R; ++e) {
+            if (e & half) continue;
+            const int q = (e & (half - 1)) * (8 / half);
+            const dl_ff_c a = v[e], b = v[e + half];
+            v[e] = a + b;
+            v[e + half] = dl_ff_rot<false>(q, a - b);
+        }
+    }
+}
+
+__device__ __forceinline__ constexpr int dl_ff_brev4(int e) { return ((e & 1) << 3) | ((e & 2) << 1) | ((e & 4) >> 1) | ((e & 8) >> 3); }
+
+// T[q] = w1^(q & 1) w2^((q >> 1) & 1) w4^((q >> 2) & 1), q = 1 .. 7 (four products); the caller forms T[q + 8] = T[q] w8 where it uses them
+__device__ __forceinline__ void dl_ff_twiddle_products(dl_ff_c& w1, dl_ff_c& w2, dl_ff_c& w4, dl_ff_c& w8, dl_ff_c* T) {
+    // (opaque to the optimiser: the products are loop invariants, and hoisted out of the transform loop they would be fifteen resident twiddles again)
+    __asm__ volatile("" : "+v"(w1.x), "+v"(w1.y), "+v"(w2.x), "+v"(w2.y), "+v"(w4.x), "+v"(w4.y), "+v"(w8.x), "+v"(w8.y));
+    T[1] = w1; T[2] = w2; T[4] = w4;
+    T[3] = dl_ff_mul(w1, w2); T[5] = dl_ff_mul(w1, w4); T[6] = dl_ff_mul(w2, w4); T[7] = dl_ff_mul(T[3], w4);
+}
+
+// this wave's LDS traffic has landed, then the workgroup barrier: global requests stay in flight (no vmcnt wait)
+__device__ __forceinline__ void dl_ff_lds_barrier() {
+    __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// entry m (< 4096) of the full circle exp(-i pi m / 2048) from the half-circle table
+__device__ __forceinline__ dl_ff_c dl_ff_tw_full(const dl_ff_c* __restrict__ tw, int m) {
+    const dl_ff_c w = tw[m & (DL_FF4_N2 - 1)];
+    return (m & DL_FF4_N2) ? dl_ff_c{-w.x, -w.y} : w;
+}
+
+// fun / out [total, 2048] (total = B n_ell transforms, multipole = transform % n_ell); pre [2048]; u [n_ell, 2049] complex; post [n_ell, 2048]; tw [2048] complex
+__global__ __launch_bounds__(DL_FF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restrict__ pre, const dl_ff_c* __restrict__ u, const double* __restrict__ post,
+                          const dl_ff_c* __restrict__ tw, double* __restrict__ out, int n_ell, int total) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    constexpr int N2 = DL_FF4_N2, n = 2048, pad = 1024;
+    const int tid = threadIdx.x;
+    dl_ff_c* x = reinterpret_cast<dl_ff_c*>(lds_raw);
+    dl_ff_c* twB = x + (N2 + (N2 >> 4) + 1);             // [q][j]: W_128^(j q)
+    // ---- persistent twiddles
+    // W_2048^(j q) = exp(-i pi 2 j q / 2048) for q = 1, 2, 4, 8; the other eleven are products formed where they are used (keeping all fifteen resident, with
+    // the operands in flight on top, overflows the 256 registers a wave has at this occupancy)
+    const dl_ff_c twA1 = dl_ff_tw_full(tw, 2 * tid), twA2 = dl_ff_tw_full(tw, 4 * tid), twA4 = dl_ff_tw_full(tw, 8 * tid), twA8 = dl_ff_tw_full(tw, 16 * tid);
+    const dl_ff_c wt = tw[tid];                                                              // W_4096^tid (spectrum step)
+    { const int j = tid & 7, q = tid >> 3; twB[q * 8 + j] = dl_ff_tw_full(tw, 32 * j * q); } // W_128^(j q) = exp(-i pi 32 j q / 2048)
+    const int jB = tid & 7, gB = tid >> 3, rtid = 127 - tid;
+    __syncthreads();
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+        const int ell = id % n_ell;
+        const double* f = fun + (size_t)id * n;
+        const dl_ff_c* ul = u + (size_t)ell * (N2 + 1);
+        dl_ff_c v[16];
+        // ---- pass A: element j + 128 e = real samples q0 = 2 (j + 128 e) - pad, q0 + 1; data for e = 4 .. 11 only, so the first stage (pairs (e, e + 8)) has one
+        //      zero operand everywhere: v[e] = b, v[e + 8] = rot(-b) for e < 4 (a = 0), v[e] = a, v[e + 8] = rot(a) for e >= 4 (b = 0)
+        {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                // samples q0 = 2 tid + 256 e (= 2 (tid + 128 (e + 4)) - 1024), q0 + 1: uniform base + one per-thread offset for every table (tid or 127 - tid)
+                const dl_ff_c fv = reinterpret_cast<const dl_ff_c*>(f + 256 * e)[tid], pv = reinterpret_cast<const dl_ff_c*>(pre + 256 * e)[tid];
+                const dl_ff_c d = dl_ff_c{fv.x * pv.x, fv.y * pv.y};   // element e + 4
+                if (e < 4) { v[e + 4] = d; v[e + 12] = dl_ff_rot<false>(e + 4, d); }                       // a = d, b = 0; slot (e + 4) + 8, q = e + 4
+                else { v[e - 4] = d; v[e + 4] = dl_ff_rot<false>(e - 4, dl_ff_c{-d.x, -d.y}); }           // a = 0, b = d (element e + 4 = (e - 4) + 8); q = e - 4
+            }
+        }
+        dl_ff_const_from<4, 1>(v);
+        x[DL_FF_P(tid)] = v[0];
+        {
+            dl_ff_c T[8], w1 = twA1, w2 = twA2, w4 = twA4, w8 = twA8;
+            dl_ff_twiddle_products(w1, w2, w4, w8, T);
+#pragma unroll
+            for (int e = 1; e < 16; ++e) {
+                const int q = dl_ff_brev4(e);
+                const dl_ff_c t = (q < 8) ? T[q] : (q == 8) ? w8 : dl_ff_mul(T[q - 8], w8);
+                x[DL_FF_P(tid + 128 * e)] = dl_ff_mul(v[e], t);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the spectrum step's coefficients: requested now, used after passes B and C
+        dl_ff_c um[4], umm[4];     // bins m = tid + 128 i, i < 4 now; i + 4 takes the place of i as soon as i is consumed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            um[i] = (ul + 128 * i)[tid];                      // u[m], m = tid + 128 i
+            umm[i] = (ul + (N2 - 127 - 128 * i))[rtid];       // u[N2 - m]
+        }
+        dl_ff_lds_barrier();
+        // ---- pass B
+        {
+            const int i0 = 128 * gB + jB;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = x[DL_FF_P(i0 + 8 * e)];
+            dl_ff_const<4, false>(v);
+            x[DL_FF_P(i0)] = v[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) x[DL_FF_P(i0 + 8 * e)] = dl_ff_mul(v[e], twB[dl_ff_brev4(e) * 8 + jB]);
+        }
+        dl_ff_lds_barrier();
+        // ---- pass C: two independent 8-point transforms per thread
+        {
+            dl_ff_c a[8], b[8];
+            const int iA = 8 * tid, iB = 8 * (tid + 128);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a[e] = x[DL_FF_P(iA + e)]; b[e] = x[DL_FF_P(iB + e)]; }
+            dl_ff_const<3, false>(a);
+            dl_ff_const<3, false>(b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[DL_FF_P(iA + e)] = a[e]; x[DL_FF_P(iB + e)] = b[e]; }
+        }
+        dl_ff_lds_barrier();
+        // ---- spectrum: bin m sits at the bit-reversed position; W_4096^m = W^tid exp(-i pi i / 16)
+        {
+            const double c16[8] = {1., 0.98078528040323043, 0.92387953251128674, 0.83146961230254524, 0.70710678118654752, 0.55557023301960218, 0.38268343236508977, 0.19509032201612825};
+            const double s16[8] = {0., 0.19509032201612825, 0.38268343236508977, 0.55557023301960218, 0.70710678118654752, 0.83146961230254524, 0.92387953251128674, 0.98078528040323043};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = tid + 128 * i, mm = N2 - m;
+                if (m == 0) {   // (i = 0, thread 0) rfft bins 0 and N2 are real; irfft ignores the imaginary parts of both
+                    const dl_ff_c z = x[0];
+                    const double y0 = (z.x + z.y) * um[0].x, yn = (z.x - z.y) * umm[0].x;
+                    x[0] = dl_ff_c{0.5 * (y0 + yn), 0.5 * (y0 - yn)};
+                    um[0] = (ul + 512)[tid]; umm[0] = (ul + (N2 - 127 - 512))[rtid];
+                    continue;
+                }
+                const int pm = DL_FF_P((int)(__brev((unsigned)m) >> (32 - DL_FF4_L))), pmm = DL_FF_P((int)(__brev((unsigned)mm) >> (32 - DL_FF4_L)));
+                const dl_ff_c w = (i == 0) ? wt : dl_ff_c{wt.x * c16[i] + wt.y * s16[i], wt.y * c16[i] - wt.x * s16[i]};
+                const dl_ff_c zm = x[pm], zc = dl_ff_conj(x[pmm]);
+                const dl_ff_c s = zm + zc, d = zm - zc;
+                const dl_ff_c fe = dl_ff_c{0.5 * s.x, 0.5 * s.y}, fo = dl_ff_c{0.5 * d.y, -0.5 * d.x};   // fo = -i d / 2
+                const dl_ff_c wfo = dl_ff_mul(w, fo);
+                const dl_ff_c ym = dl_ff_mul(fe + wfo, um[i & 3]), ymmc = dl_ff_mulc(fe - wfo, umm[i & 3]);     // ymmc = conj(Y[N2 - m])
+                if (i < 4) { um[i] = (ul + (128 * i + 512))[tid]; umm[i] = (ul + (N2 - 127 - 128 * i - 512))[rtid]; }
+                const dl_ff_c gs = ym + ymmc, gd = dl_ff_mulc(ym - ymmc, w);
+                const dl_ff_c ge = dl_ff_c{0.5 * gs.x, 0.5 * gs.y}, go = dl_ff_c{0.5 * gd.x, 0.5 * gd.y};
+                x[pm] = dl_ff_c{ge.x - go.y, ge.y + go.x};                     // ge + i go
+                x[pmm] = dl_ff_c{ge.x + go.y, go.x - ge.y};                    // conj(ge) + i conj(go)   (m < 1024 here: mm != m)
+            }
+            if (tid == 0) {   // m = 1024 = N2 - m: W^m = -i
+                const int pm = DL_FF_P((int)(__brev(1024u) >> (32 - DL_FF4_L)));
+                const dl_ff_c w = dl_ff_c{0., -1.}, uh = ul[1024];
+                const dl_ff_c zm = x[pm], zc = dl_ff_conj(zm);
+                const dl_ff_c s = zm + zc, d = zm - zc;
+                const dl_ff_c fe = dl_ff_c{0.5 * s.x, 0.5 * s.y}, fo = dl_ff_c{0.5 * d.y, -0.5 * d.x};
+                const dl_ff_c wfo = dl_ff_mul(w, fo);
+                const dl_ff_c ym = dl_ff_mul(fe + wfo, uh), ymmc = dl_ff_mulc(fe - wfo, uh);
+                const dl_ff_c gs = ym + ymmc, gd = dl_ff_mulc(ym - ymmc, w);
+                const dl_ff_c ge = dl_ff_c{0.5 * gs.x, 0.5 * gs.y}, go = dl_ff_c{0.5 * gd.x, 0.5 * gd.y};
+                x[pm] = dl_ff_c{ge.x - go.y, ge.y + go.x};
+            }
+        }
+        // the output factors: requested now, used after the inverse passes
+        dl_ff_c pv[8];
+        {
+            const double* po = post + (size_t)ell * n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = reinterpret_cast<const dl_ff_c*>(po + (1792 - 256 * e))[rtid];     // post[2046 - 2 tid - 256 e], [.. + 1]
+        }
+        dl_ff_lds_barrier();
+        // ---- inverse pass C'
+        {
+            dl_ff_c a[8], b[8];
+            const int iA = 8 * tid, iB = 8 * (tid + 128);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a[e] = x[DL_FF_P(iA + e)]; b[e] = x[DL_FF_P(iB + e)]; }
+            dl_ff_const<3, true>(a);
+            dl_ff_const<3, true>(b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[DL_FF_P(iA + e)] = a[e]; x[DL_FF_P(iB + e)] = b[e]; }
+        }
+        dl_ff_lds_barrier();
+        // ---- inverse pass B'
+        {
+            const int i0 = 128 * gB + jB;
+            v[0] = x[DL_FF_P(i0)];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) v[e] = dl_ff_mulc(x[DL_FF_P(i0 + 8 * e)], twB[dl_ff_brev4(e) * 8 + jB]);
+            dl_ff_const<4, true>(v);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[DL_FF_P(i0 + 8 * e)] = v[e];
+        }
+        dl_ff_lds_barrier();
+        // ---- inverse pass A' -> registers -> global memory
+        v[0] = x[DL_FF_P(tid)];
+        {
+            dl_ff_c T[8], w1 = twA1, w2 = twA2, w4 = twA4, w8 = twA8;
+            dl_ff_twiddle_products(w1, w2, w4, w8, T);
+#pragma unroll
+            for (int e = 1; e < 16; ++e) {
+                const int q = dl_ff_brev4(e);
+                const dl_ff_c t = (q < 8) ? T[q] : (q == 8) ? w8 : dl_ff_mul(T[q - 8], w8);
+                v[e] = dl_ff_mulc(x[DL_FF_P(tid + 128 * e)], t);
+            }
+        }
+        dl_ff_lds_barrier();   // every wave has read its elements: the next transform may overwrite the LDS image
+        dl_ff_const<4, true>(v);
+        {
+            // A = a'[::-1], un-padded: real sample q -> out[3071 - q]; element j + 128 e (e = 4 .. 11) = samples q0 = 2 tid + 256 e (e - 4 -> e), q0 + 1 -> out[2046 - q0'], out[2047 - q0']
+            const double scale = 1. / (double)N2;
+            double* o = out + (size_t)id * n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const dl_ff_c r = v[e + 4];
+                reinterpret_cast<dl_ff_c*>(o + (1792 - 256 * e))[rtid] = dl_ff_c{pv[e].x * (r.y * scale), pv[e].y * (r.x * scale)};
+            }
+        }
+    }
+}
+
 struct dl_fftlog {
-    int device = 0, n = 0, npad = 0, n_ell = 0, L = 0, pad = 0;
+    int device = 0, n = 0, npad = 0, n_ell = 0, L = 0, pad = 0, n_cu = 256;
     double *pre = nullptr, *u = nullptr, *post = nullptr, *tw = nullptr;
     std::string last_error;
 };
@@ -224,6 +498,10 @@ int dl_fftlog_create(dl_fftlog** out, int device, int32_t n, int32_t npad, int32
     }
     const size_t shm = (size_t)(N2 + (N2 >> 4) + 1) * sizeof(dl_ff_c);
     if (shm > 48 * 1024) DL_FF_CHECK(plan, hipFuncSetAttribute((const void*)dl_fftlog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) plan->n_cu = prop.multiProcessorCount;
+    }
     *out = plan;
     return 0;
 }
@@ -235,6 +513,16 @@ int dl_fftlog_apply(dl_fftlog* plan, const double* fun_dev, int64_t B, double* o
     if (B * plan->n_ell > 0x7fffffffLL) return dl_ff_fail(plan, "dl_fftlog_apply: batch too large for one launch");
     DL_FF_CHECK(plan, hipSetDevice(plan->device));
     const int N2 = plan->npad / 2;
+    static const bool generic_only = getenv("DL_FFTLOG_GENERIC") && atoi(getenv("DL_FFTLOG_GENERIC")) != 0;
+    if (plan->npad == 4096 && plan->n == 2048 && !generic_only) {   // the reference's grid: persistent radix-16 kernel
+        const size_t shm4 = (size_t)(N2 + (N2 >> 4) + 1 + 128) * sizeof(dl_ff_c);
+        const int64_t total = B * plan->n_ell;
+        const int64_t resident = 4 * (int64_t)plan->n_cu;           // four workgroups per CU (LDS)
+        hipLaunchKernelGGL(dl_fftlog4096_kernel, dim3((unsigned)std::min<int64_t>(total, resident)), dim3(DL_FF_THREADS), shm4, (hipStream_t)hip_stream, fun_dev, plan->pre,
+                           reinterpret_cast<const dl_ff_c*>(plan->u), plan->post, reinterpret_cast<const dl_ff_c*>(plan->tw), out_dev, plan->n_ell, (int)total);
+        DL_FF_CHECK(plan, hipGetLastError());
+        return 0;
+    }
     const size_t shm = (size_t)(N2 + (N2 >> 4) + 1) * sizeof(dl_ff_c);
     hipLaunchKernelGGL(dl_fftlog_kernel, dim3((unsigned)(B * plan->n_ell)), dim3(DL_FF_THREADS), shm, (hipStream_t)hip_stream, fun_dev, plan->pre,
                        reinterpret_cast<const dl_ff_c*>(plan->u), plan->post, reinterpret_cast<const dl_ff_c*>(plan->tw), out_dev, plan->n, plan->pad, plan->L, plan->n_ell);
