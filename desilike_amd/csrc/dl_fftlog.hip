@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/desilike_amd.h"
@@ -187,6 +188,9 @@ __global__ __launch_bounds__(DL_FF_THREADS) void dl_fftlog_kernel(const double* 
 // ------------------------------------------------------------------------------------------------------------------------
 #define DL_FF4_N2 2048
 #define DL_FF4_L 11
+#ifndef DL_FF4_POST_STAGE
+#define DL_FF4_POST_STAGE 4   // the output factors are requested after this many stages of the last 16-point transform (earlier: register spills)
+#endif
 
 // v * exp(-i pi q / 8) (forward) or v * exp(+i pi q / 8) (INV), q = 0..7 known at compile time after unrolling
 template <bool INV>
@@ -206,11 +210,11 @@ __device__ __forceinline__ dl_ff_c dl_ff_rot(int q, dl_ff_c v) {
 }
 
 // constant 2^S-point transform on registers: DIF forward (natural -> bit-reversed) or its conjugate transpose (bit-reversed -> natural)
-template <int S, bool INV>
+template <int S, bool INV, int ST0 = 0, int ST1 = S>
 __device__ __forceinline__ void dl_ff_const(dl_ff_c* v) {
     constexpr int R = 1 << S;
 #pragma unroll
-    for (int st = 0; st < S; ++st) {
+    for (int st = ST0; st < ST1; ++st) {
         const int half = INV ? (1 << st) : (R >> (st + 1));
 #pragma unroll
         for (int e = 0; e < R; ++e) {
@@ -262,6 +266,22 @@ __device__ __forceinline__ void dl_ff_lds_barrier() {
     __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// work item r (0 .. 1022) of the spectrum step -> position b of its bin m = brev11(b) and position p of the partner bin N2 - m:
+//   the bins m = 2^k (4 j + 1) occupy the positions [2^(10-k), 2^(10-k) + 2^(9-k)), their partners the next 2^(9-k) positions in reverse order
+__host__ __device__ __forceinline__ void dl_ff4_pair(int r, int& b, int& p) {
+    const int i = r >> 7, t = r & 127;
+    if (i < 4) { b = 1024 + r; p = 2047 - r; }                                  // k = 0: 512 pairs
+    else if (i < 6) { b = 512 + (r - 512); p = 1023 - (r - 512); }              // k = 1: 256 pairs
+    else if (i == 6) { b = 256 + t; p = 511 - t; }                              // k = 2: 128 pairs
+    else {                                                                      // k = 3 .. 9: 64 + 32 + ... + 1 pairs
+        const int v = t + 1;
+        int a = 0;
+        while ((2 << a) <= v) ++a;                                              // floor(log2(v))
+        const int c = v - (1 << a);
+        b = (2 << a) + c; p = (4 << a) - 1 - c;
+    }
+}
+
 // entry m (< 4096) of the full circle exp(-i pi m / 2048) from the half-circle table
 __device__ __forceinline__ dl_ff_c dl_ff_tw_full(const dl_ff_c* __restrict__ tw, int m) {
     const dl_ff_c w = tw[m & (DL_FF4_N2 - 1)];
@@ -270,8 +290,8 @@ __device__ __forceinline__ dl_ff_c dl_ff_tw_full(const dl_ff_c* __restrict__ tw,
 
 // fun / out [total, 2048] (total = B n_ell transforms, multipole = transform % n_ell); pre [2048]; u [n_ell, 2049] complex; post [n_ell, 2048]; tw [2048] complex
 __global__ __launch_bounds__(DL_FF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restrict__ pre, const dl_ff_c* __restrict__ u, const double* __restrict__ post,
-                          const dl_ff_c* __restrict__ tw, double* __restrict__ out, int n_ell, int total) {
+void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restrict__ pre, const dl_ff_c* __restrict__ u, const dl_ff_c* __restrict__ u1,
+                          const dl_ff_c* __restrict__ u2, const double* __restrict__ post, const dl_ff_c* __restrict__ tw, double* __restrict__ out, int n_ell, int total) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     constexpr int N2 = DL_FF4_N2, n = 2048, pad = 1024;
     const int tid = threadIdx.x;
@@ -281,14 +301,28 @@ void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restri
     // W_2048^(j q) = exp(-i pi 2 j q / 2048) for q = 1, 2, 4, 8; the other eleven are products formed where they are used (keeping all fifteen resident, with
     // the operands in flight on top, overflows the 256 registers a wave has at this occupancy)
     const dl_ff_c twA1 = dl_ff_tw_full(tw, 2 * tid), twA2 = dl_ff_tw_full(tw, 4 * tid), twA4 = dl_ff_tw_full(tw, 8 * tid), twA8 = dl_ff_tw_full(tw, 16 * tid);
-    const dl_ff_c wt = tw[tid];                                                              // W_4096^tid (spectrum step)
+    // spectrum step: W_4096^(16 brev7(tid)); work item 896 + tid (the short runs): positions of the pair and W_4096^m
+    const dl_ff_c wt = tw[16 * (int)(__brev((unsigned)tid) >> 25)];
+    int b7, p7;
+    dl_ff4_pair(896 + (tid < 127 ? tid : 0), b7, p7);
+    const dl_ff_c wt7 = tw[(int)(__brev((unsigned)b7) >> (32 - DL_FF4_L))];
     { const int j = tid & 7, q = tid >> 3; twB[q * 8 + j] = dl_ff_tw_full(tw, 32 * j * q); } // W_128^(j q) = exp(-i pi 32 j q / 2048)
     const int jB = tid & 7, gB = tid >> 3, rtid = 127 - tid;
     __syncthreads();
+    // the input row of a transform is requested during the inverse passes of the one before it (HBM latency off the critical path)
+    dl_ff_c fv[8];
+    if ((int)blockIdx.x < total) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fv[e] = reinterpret_cast<const dl_ff_c*>(fun + (size_t)blockIdx.x * n + 256 * e)[tid];
+    }
+    // ... and the input factors during the last inverse pass (kept resident they cost 32 registers through the passes that need them most)
+    dl_ff_c pr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pr[e] = reinterpret_cast<const dl_ff_c*>(pre + 256 * e)[tid];
     for (int id = blockIdx.x; id < total; id += gridDim.x) {
         const int ell = id % n_ell;
-        const double* f = fun + (size_t)id * n;
         const dl_ff_c* ul = u + (size_t)ell * (N2 + 1);
+        const dl_ff_c *u1l = u1 + (size_t)ell * 1024, *u2l = u2 + (size_t)ell * 1024;
         dl_ff_c v[16];
         // ---- pass A: element j + 128 e = real samples q0 = 2 (j + 128 e) - pad, q0 + 1; data for e = 4 .. 11 only, so the first stage (pairs (e, e + 8)) has one
         //      zero operand everywhere: v[e] = b, v[e + 8] = rot(-b) for e < 4 (a = 0), v[e] = a, v[e + 8] = rot(a) for e >= 4 (b = 0)
@@ -296,8 +330,7 @@ void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restri
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 // samples q0 = 2 tid + 256 e (= 2 (tid + 128 (e + 4)) - 1024), q0 + 1: uniform base + one per-thread offset for every table (tid or 127 - tid)
-                const dl_ff_c fv = reinterpret_cast<const dl_ff_c*>(f + 256 * e)[tid], pv = reinterpret_cast<const dl_ff_c*>(pre + 256 * e)[tid];
-                const dl_ff_c d = dl_ff_c{fv.x * pv.x, fv.y * pv.y};   // element e + 4
+                const dl_ff_c d = dl_ff_c{fv[e].x * pr[e].x, fv[e].y * pr[e].y};   // element e + 4
                 if (e < 4) { v[e + 4] = d; v[e + 12] = dl_ff_rot<false>(e + 4, d); }                       // a = d, b = 0; slot (e + 4) + 8, q = e + 4
                 else { v[e - 4] = d; v[e + 4] = dl_ff_rot<false>(e - 4, dl_ff_c{-d.x, -d.y}); }           // a = 0, b = d (element e + 4 = (e - 4) + 8); q = e - 4
             }
@@ -319,8 +352,8 @@ void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restri
         dl_ff_c um[4], umm[4];     // bins m = tid + 128 i, i < 4 now; i + 4 takes the place of i as soon as i is consumed
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            um[i] = (ul + 128 * i)[tid];                      // u[m], m = tid + 128 i
-            umm[i] = (ul + (N2 - 127 - 128 * i))[rtid];       // u[N2 - m]
+            um[i] = (u1l + 128 * i)[tid];                     // u[m] of work item tid + 128 i
+            umm[i] = (u2l + 128 * i)[tid];                    // u[N2 - m]
         }
         dl_ff_lds_barrier();
         // ---- pass B
@@ -346,52 +379,51 @@ void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restri
             for (int e = 0; e < 8; ++e) { x[DL_FF_P(iA + e)] = a[e]; x[DL_FF_P(iB + e)] = b[e]; }
         }
         dl_ff_lds_barrier();
-        // ---- spectrum: bin m sits at the bit-reversed position; W_4096^m = W^tid exp(-i pi i / 16)
+        // ---- spectrum.  Bin m sits at position brev(m).  The pairs (m, N2 - m) are walked by POSITION, not by m: the bins m = 2^k (4 j + 1) sit in the run of
+        //      positions [2^(10-k), 2^(10-k) + 2^(9-k)) and their partners N2 - m in the next run of the same length, in reverse order (dl_ff4_pair) -- consecutive
+        //      lanes touch consecutive LDS slots on both sides (walking m = tid + 128 i instead puts the 16 lanes of a ds_read_b128 on two bank groups: half of
+        //      the kernel's LDS cycles were bank conflicts of this step).  The coefficient tables are stored in the same order (u1 / u2, built at plan creation);
+        //      W_4096^m = W^(16 brev7(tid)) x a compile-time root for the three long runs (work items 0 .. 895), one resident value for the short ones.
         {
-            const double c16[8] = {1., 0.98078528040323043, 0.92387953251128674, 0.83146961230254524, 0.70710678118654752, 0.55557023301960218, 0.38268343236508977, 0.19509032201612825};
-            const double s16[8] = {0., 0.19509032201612825, 0.38268343236508977, 0.55557023301960218, 0.70710678118654752, 0.83146961230254524, 0.92387953251128674, 0.98078528040323043};
+            // exp(-i pi c / 2048), c = m mod 16 of work items 128 i + tid, i < 7: 1, 9, 5, 13 (k = 0), 2, 10 (k = 1), 4 (k = 2)
+            const double cw[7] = {0.99999882345170188, 0.9999047010828529, 0.99997058643097414, 0.99980116988788426, 0.99999529380957619, 0.99988234745421256, 0.99998117528260111};
+            const double sw[7] = {0.0015339801862847655, 0.013805388528060391, 0.007669828739531097, 0.019940428551514441, 0.0030679567629659761, 0.0153392062849881, 0.0061358846491544753};
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int m = tid + 128 * i, mm = N2 - m;
-                if (m == 0) {   // (i = 0, thread 0) rfft bins 0 and N2 are real; irfft ignores the imaginary parts of both
-                    const dl_ff_c z = x[0];
-                    const double y0 = (z.x + z.y) * um[0].x, yn = (z.x - z.y) * umm[0].x;
-                    x[0] = dl_ff_c{0.5 * (y0 + yn), 0.5 * (y0 - yn)};
-                    um[0] = (ul + 512)[tid]; umm[0] = (ul + (N2 - 127 - 512))[rtid];
-                    continue;
-                }
-                const int pm = DL_FF_P((int)(__brev((unsigned)m) >> (32 - DL_FF4_L))), pmm = DL_FF_P((int)(__brev((unsigned)mm) >> (32 - DL_FF4_L)));
-                const dl_ff_c w = (i == 0) ? wt : dl_ff_c{wt.x * c16[i] + wt.y * s16[i], wt.y * c16[i] - wt.x * s16[i]};
+                int pb, pp;       // positions of bin m and of its partner N2 - m
+                if (i < 4) { pb = 1024 + tid + 128 * i; pp = 2047 - (tid + 128 * i); }
+                else if (i < 6) { pb = 512 + tid + 128 * (i - 4); pp = 1023 - (tid + 128 * (i - 4)); }
+                else if (i == 6) { pb = 256 + tid; pp = 511 - tid; }
+                else { pb = b7; pp = p7; }
+                const int pm = DL_FF_P(pb), pmm = DL_FF_P(pp);
+                const dl_ff_c w = (i == 7) ? wt7 : dl_ff_c{wt.x * cw[i < 7 ? i : 0] + wt.y * sw[i < 7 ? i : 0], wt.y * cw[i < 7 ? i : 0] - wt.x * sw[i < 7 ? i : 0]};
                 const dl_ff_c zm = x[pm], zc = dl_ff_conj(x[pmm]);
                 const dl_ff_c s = zm + zc, d = zm - zc;
                 const dl_ff_c fe = dl_ff_c{0.5 * s.x, 0.5 * s.y}, fo = dl_ff_c{0.5 * d.y, -0.5 * d.x};   // fo = -i d / 2
                 const dl_ff_c wfo = dl_ff_mul(w, fo);
                 const dl_ff_c ym = dl_ff_mul(fe + wfo, um[i & 3]), ymmc = dl_ff_mulc(fe - wfo, umm[i & 3]);     // ymmc = conj(Y[N2 - m])
-                if (i < 4) { um[i] = (ul + (128 * i + 512))[tid]; umm[i] = (ul + (N2 - 127 - 128 * i - 512))[rtid]; }
+                if (i < 4) { um[i] = (u1l + (128 * i + 512))[tid]; umm[i] = (u2l + (128 * i + 512))[tid]; }
                 const dl_ff_c gs = ym + ymmc, gd = dl_ff_mulc(ym - ymmc, w);
                 const dl_ff_c ge = dl_ff_c{0.5 * gs.x, 0.5 * gs.y}, go = dl_ff_c{0.5 * gd.x, 0.5 * gd.y};
-                x[pm] = dl_ff_c{ge.x - go.y, ge.y + go.x};                     // ge + i go
-                x[pmm] = dl_ff_c{ge.x + go.y, go.x - ge.y};                    // conj(ge) + i conj(go)   (m < 1024 here: mm != m)
+                if (i < 7 || tid != 127) {   // (work item 1023 does not exist: thread 127 ran the arithmetic on harmless values)
+                    x[pm] = dl_ff_c{ge.x - go.y, ge.y + go.x};                     // ge + i go
+                    x[pmm] = dl_ff_c{ge.x + go.y, go.x - ge.y};                    // conj(ge) + i conj(go)
+                }
             }
-            if (tid == 0) {   // m = 1024 = N2 - m: W^m = -i
-                const int pm = DL_FF_P((int)(__brev(1024u) >> (32 - DL_FF4_L)));
-                const dl_ff_c w = dl_ff_c{0., -1.}, uh = ul[1024];
-                const dl_ff_c zm = x[pm], zc = dl_ff_conj(zm);
-                const dl_ff_c s = zm + zc, d = zm - zc;
-                const dl_ff_c fe = dl_ff_c{0.5 * s.x, 0.5 * s.y}, fo = dl_ff_c{0.5 * d.y, -0.5 * d.x};
-                const dl_ff_c wfo = dl_ff_mul(w, fo);
-                const dl_ff_c ym = dl_ff_mul(fe + wfo, uh), ymmc = dl_ff_mulc(fe - wfo, uh);
-                const dl_ff_c gs = ym + ymmc, gd = dl_ff_mulc(ym - ymmc, w);
-                const dl_ff_c ge = dl_ff_c{0.5 * gs.x, 0.5 * gs.y}, go = dl_ff_c{0.5 * gd.x, 0.5 * gd.y};
-                x[pm] = dl_ff_c{ge.x - go.y, ge.y + go.x};
+            if (tid == 127) {
+                // m = 1024 = N2 - m, W^m = -i: the pair formulas collapse to x <- x conj(u[1024]) (position brev(1024) = 1)
+                x[DL_FF_P(1)] = dl_ff_mulc(x[DL_FF_P(1)], ul[1024]);
+                // m = 0: rfft bins 0 and N2 are real (packed as the two components of element 0); irfft ignores the imaginary parts of both
+                const dl_ff_c z = x[0];
+                const double y0 = (z.x + z.y) * ul[0].x, yn = (z.x - z.y) * ul[N2].x;
+                x[0] = dl_ff_c{0.5 * (y0 + yn), 0.5 * (y0 - yn)};
             }
         }
-        // the output factors: requested now, used after the inverse passes
-        dl_ff_c pv[8];
+        // the next transform's input row: requested now, used at the top of the next iteration
         {
-            const double* po = post + (size_t)ell * n;
+            const int next = (id + (int)gridDim.x < total) ? id + (int)gridDim.x : id;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pv[e] = reinterpret_cast<const dl_ff_c*>(po + (1792 - 256 * e))[rtid];     // post[2046 - 2 tid - 256 e], [.. + 1]
+            for (int e = 0; e < 8; ++e) fv[e] = reinterpret_cast<const dl_ff_c*>(fun + (size_t)next * n + 256 * e)[tid];
         }
         dl_ff_lds_barrier();
         // ---- inverse pass C'
@@ -417,7 +449,8 @@ void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restri
             for (int e = 0; e < 16; ++e) x[DL_FF_P(i0 + 8 * e)] = v[e];
         }
         dl_ff_lds_barrier();
-        // ---- inverse pass A' -> registers -> global memory
+        // ---- inverse pass A' -> registers -> global memory; the output factors are requested half-way through the 16-point transform (earlier, they
+        //      are 32 more live registers where the pass needs the most)
         v[0] = x[DL_FF_P(tid)];
         {
             dl_ff_c T[8], w1 = twA1, w2 = twA2, w4 = twA4, w8 = twA8;
@@ -427,10 +460,26 @@ void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restri
                 const int q = dl_ff_brev4(e);
                 const dl_ff_c t = (q < 8) ? T[q] : (q == 8) ? w8 : dl_ff_mul(T[q - 8], w8);
                 v[e] = dl_ff_mulc(x[DL_FF_P(tid + 128 * e)], t);
+                if (e == 5 || e == 10) __builtin_amdgcn_sched_barrier(0);   // (three batches of LDS reads: all sixteen in flight at once overflow the register file here)
             }
         }
         dl_ff_lds_barrier();   // every wave has read its elements: the next transform may overwrite the LDS image
-        dl_ff_const<4, true>(v);
+        {
+            const double* prel = pre;
+            __asm__ volatile("" : "+s"(prel));    // (not a loop invariant for the optimiser: see above)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pr[e] = reinterpret_cast<const dl_ff_c*>(prel + 256 * e)[tid];
+        }
+        dl_ff_const<4, true, 0, DL_FF4_POST_STAGE>(v);
+        __builtin_amdgcn_sched_barrier(0);
+        dl_ff_c pv[8];
+        {
+            const double* po = post + (size_t)ell * n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = reinterpret_cast<const dl_ff_c*>(po + (1792 - 256 * e))[rtid];     // post[2046 - 2 tid - 256 e], [.. + 1]
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dl_ff_const<4, true, DL_FF4_POST_STAGE, 4>(v);
         {
             // A = a'[::-1], un-padded: real sample q -> out[3071 - q]; element j + 128 e (e = 4 .. 11) = samples q0 = 2 tid + 256 e (e - 4 -> e), q0 + 1 -> out[2046 - q0'], out[2047 - q0']
             const double scale = 1. / (double)N2;
@@ -447,6 +496,7 @@ void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restri
 struct dl_fftlog {
     int device = 0, n = 0, npad = 0, n_ell = 0, L = 0, pad = 0, n_cu = 256;
     double *pre = nullptr, *u = nullptr, *post = nullptr, *tw = nullptr;
+    double *u1 = nullptr, *u2 = nullptr;   // npad = 4096: u[m], u[N2 - m] in the order of the spectrum step's work items ([n_ell, 1024] complex each)
     std::string last_error;
 };
 
@@ -496,6 +546,30 @@ int dl_fftlog_create(dl_fftlog** out, int device, int32_t n, int32_t npad, int32
             return dl_ff_fail(nullptr, msg);
         }
     }
+    if (npad == 4096 && n == 2048) {
+        std::vector<double> u1((size_t)n_ell * 1024 * 2), u2(u1.size());
+        for (int l = 0; l < n_ell; ++l) {
+            const double* ul = u + (size_t)l * (N2 + 1) * 2;
+            for (int r = 0; r < 1024; ++r) {
+                int b, p;
+                dl_ff4_pair(r < 1023 ? r : 1022, b, p);
+                int m = 0;
+                for (int bit = 0; bit < 11; ++bit) m |= ((b >> bit) & 1) << (10 - bit);
+                const size_t o = ((size_t)l * 1024 + r) * 2;
+                u1[o] = ul[2 * m]; u1[o + 1] = ul[2 * m + 1];
+                u2[o] = ul[2 * (N2 - m)]; u2[o + 1] = ul[2 * (N2 - m) + 1];
+            }
+        }
+        for (auto up : {std::make_pair(&plan->u1, &u1), std::make_pair(&plan->u2, &u2)}) {
+            hipError_t err = hipMalloc((void**)up.first, up.second->size() * sizeof(double));
+            if (err == hipSuccess) err = hipMemcpy(*up.first, up.second->data(), up.second->size() * sizeof(double), hipMemcpyHostToDevice);
+            if (err != hipSuccess) {
+                std::string msg = std::string("dl_fftlog_create: ") + hipGetErrorString(err);
+                dl_fftlog_destroy(plan);
+                return dl_ff_fail(nullptr, msg);
+            }
+        }
+    }
     const size_t shm = (size_t)(N2 + (N2 >> 4) + 1) * sizeof(dl_ff_c);
     if (shm > 48 * 1024) DL_FF_CHECK(plan, hipFuncSetAttribute((const void*)dl_fftlog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     {
@@ -519,7 +593,8 @@ int dl_fftlog_apply(dl_fftlog* plan, const double* fun_dev, int64_t B, double* o
         const int64_t total = B * plan->n_ell;
         const int64_t resident = 4 * (int64_t)plan->n_cu;           // four workgroups per CU (LDS)
         hipLaunchKernelGGL(dl_fftlog4096_kernel, dim3((unsigned)std::min<int64_t>(total, resident)), dim3(DL_FF_THREADS), shm4, (hipStream_t)hip_stream, fun_dev, plan->pre,
-                           reinterpret_cast<const dl_ff_c*>(plan->u), plan->post, reinterpret_cast<const dl_ff_c*>(plan->tw), out_dev, plan->n_ell, (int)total);
+                           reinterpret_cast<const dl_ff_c*>(plan->u), reinterpret_cast<const dl_ff_c*>(plan->u1), reinterpret_cast<const dl_ff_c*>(plan->u2), plan->post,
+                           reinterpret_cast<const dl_ff_c*>(plan->tw), out_dev, plan->n_ell, (int)total);
         DL_FF_CHECK(plan, hipGetLastError());
         return 0;
     }
@@ -532,7 +607,7 @@ int dl_fftlog_apply(dl_fftlog* plan, const double* fun_dev, int64_t B, double* o
 
 void dl_fftlog_destroy(dl_fftlog* plan) {
     if (!plan) return;
-    for (double* p : {plan->pre, plan->u, plan->post, plan->tw})
+    for (double* p : {plan->pre, plan->u, plan->post, plan->tw, plan->u1, plan->u2})
         if (p) (void)hipFree(p);
     delete plan;
 }
