@@ -525,9 +525,13 @@ DL_HD double dl_spline_eval(const DlObsDev& o, const DlFsShared& s, double x) {
 
 // uniform knots, abscissa already in units of the knot spacing: t = (x - x0) inv_hx
 DL_HD double dl_spline_eval_t(const DlObsDev& o, const DlFsShared& s, double t) {
-    double tc = t > 0. ? t : 0.;
-    int j = (int)tc;
+    int j = (int)t;                       // truncation: 0 for t in (-1, 0); clamped to [0, n_t - 2] as integers: one v_med3_i32 (n_t >= 2) instead of a 64-bit max and a min
+#if defined(__HIP_DEVICE_COMPILE__)
+    __asm__("v_med3_i32 %0, %1, 0, %2" : "=v"(j) : "v"(j), "s"(o.n_t - 2));
+#else
+    j = j < 0 ? 0 : j;
     if (j > o.n_t - 2) j = o.n_t - 2;
+#endif
     const double u = t - (double)j;
     const double* c = s.coef + 2 * j;
     const double* d = c + 2 * o.n_t;
