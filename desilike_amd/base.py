@@ -82,6 +82,39 @@ class BaseCalculator(object):
     def params(self, params):
         self.init.params = params
 
+    def _all_params(self):
+        """Parameters of this calculator and of the calculators it requires (overridden by the theories: template + own)."""
+        return self.init.params
+
+    @property
+    def all_params(self):
+        """All parameters of the pipeline below this calculator (base.py:1302-1305): a live view, ``calculator.all_params['b1'].update(...)`` acts on the
+        calculator's own parameter."""
+        self.initialize()
+        view = ParameterCollection()
+        for collection in self._param_collections():
+            for param in collection:
+                if param.name not in view: view.data.append(param)
+        return view
+
+    def _param_collections(self):
+        """The :class:`ParameterCollection` objects ``all_params`` is made of, own parameters last."""
+        return [self.init.params]
+
+    @all_params.setter
+    def all_params(self, config):
+        """``calculator.all_params = {...} | ParameterCollection | 'params.yaml'``: update the pipeline's parameters by name, patterns and meta entries
+        (:meth:`ParameterCollection.update_config`; base.py:1307-1310)."""
+        view = self.all_params
+        before = view.names()
+        added = view.update_config(config)
+        for name in added: self.init.params.set(view[name])
+        for name in before:
+            if name not in view:
+                for collection in self._param_collections():
+                    if name in collection: collection.pop(name)
+        self._invalidate()
+
     def _invalidate(self):
         self._initialized = False
         for dep in getattr(self, '_dependents', []):

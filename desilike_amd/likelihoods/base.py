@@ -30,6 +30,13 @@ class BaseLikelihood(BaseCalculator):
         self.initialize()
         return self._all_params
 
+    @all_params.setter
+    def all_params(self, config):
+        """``likelihood.all_params = {'sn0': {'derived': '.marg'}} | {'*': {...}} | ParameterCollection | 'params.yaml'`` (base.py:1307-1310): update the pipeline's
+        parameters by name, patterns and meta entries (:meth:`ParameterCollection.update_config`); the compiled contexts follow (:meth:`_check_params`)."""
+        self.initialize()
+        self._all_params.update_config(config)
+
     @property
     def varied_params(self):
         """Sampled parameters: varied, not derived, not solved (base.py:1273-1281)."""

@@ -428,6 +428,83 @@ class ParameterCollection(object):
         for name, conf in kwargs.items():
             self[name].update(**conf)
 
+    def update_config(self, config, accept_new=None):
+        """Apply a parameter configuration to the parameters of this collection IN PLACE, with the semantics of ``calculator.all_params = config`` /
+        ``pipeline.params = config`` (base.py:1307-1310, 436-470; parameter.py:1472-1547, 1588-1620):
+
+        - ``config``: dict ``name -> settings`` (``dict(value=..., fixed=..., prior=..., ref=..., delta=..., derived=..., latex=...)``, a number = the value, or a
+          :class:`Parameter`), a :class:`ParameterCollection`, or the name of a YAML file holding such a dict;
+        - names with ``*`` are patterns applied to every matching parameter (``{'*': {'prior': ...}}``, ``{'*mega_m': ...}``);
+        - meta entries ``.fixed`` / ``.varied`` / ``.derived`` (name, pattern, list of them, or ``dict name -> bool``) and ``.delete``;
+        - order: deletions, meta entries, patterns, then the exact names (an explicit entry wins over a pattern of the same configuration);
+        - an exact name that is not in the collection is a NEW parameter if other parameters are derived from it (``derived='{b}**2'``; or if ``accept_new(name)``
+          says so), otherwise an error ("Cannot attribute parameter ... to any calculator", base.py:463-464).
+        Returns the names of the parameters that were added."""
+        import fnmatch
+        import numbers
+        if isinstance(config, str):
+            import yaml
+            with open(config, 'r') as file:
+                config = yaml.safe_load(file) or {}
+        if isinstance(config, ParameterCollection):
+            config = {param.name: param for param in config}
+        config = dict(config)
+
+        def matching(pattern):
+            return [param for param in self.data if fnmatch.fnmatchcase(param.name, str(pattern))]
+
+        def meta(key):
+            value = config.pop(key, {})
+            if isinstance(value, dict): return dict(value)
+            if isinstance(value, (list, tuple)): return {name: True for name in value}
+            return {value: True}
+
+        fixed = {name: bool(value) for name, value in meta('.fixed').items()}
+        fixed.update({name: not bool(value) for name, value in meta('.varied').items()})
+        derived, delete = meta('.derived'), meta('.delete')
+        if config.pop('.namespace', None):
+            raise ParameterError('.namespace entries are not supported: name the parameters in full (namespace.basename)')
+        for name, flag in delete.items():
+            if flag:
+                for param in matching(name): self.pop(param.name)
+        for name, flag in fixed.items():
+            for param in matching(name): param.update(fixed=flag)
+        for name, flag in derived.items():
+            for param in matching(name): param.update(derived=bool(flag))
+
+        def settings(conf):
+            if isinstance(conf, Parameter):
+                state = conf.__getstate__()
+                return {key: value for key, value in state.items() if key not in ('basename', 'namespace')}
+            if isinstance(conf, numbers.Number): return {'value': conf}
+            conf = dict(conf or {})
+            for key in ('name', 'basename', 'namespace'): conf.pop(key, None)
+            return conf
+
+        # names other parameters are (or, with this configuration, will be) derived from
+        referenced = set(name for param in self.data for name in param.depends)
+        for conf in config.values():
+            expression = conf.derived if isinstance(conf, Parameter) else (conf.get('derived', None) if isinstance(conf, dict) else None)
+            if isinstance(expression, str): referenced.update(Parameter._placeholders(expression))
+        if accept_new is None:
+            accept_new = referenced.__contains__
+        exact = {}
+        for name, conf in config.items():
+            if '*' in str(name):
+                for param in matching(name): param.update(**settings(conf))
+            else:
+                exact[str(name)] = conf
+        added = []
+        for name, conf in exact.items():
+            if name in self:
+                self[name].update(**settings(conf))
+            elif accept_new(name):
+                self.set(conf.copy() if isinstance(conf, Parameter) else Parameter(basename=name, **settings(conf)))
+                added.append(name)
+            else:
+                raise ParameterError('Cannot attribute parameter {} to any calculator: parameters are {}'.format(name, self.names()))
+        return added
+
     def clear(self):
         self.data = []
 

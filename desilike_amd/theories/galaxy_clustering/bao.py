@@ -254,6 +254,9 @@ class _BaseDampedBAOTracer(BaseCalculator):
         others = [param for param in self.template.params if param not in ap]
         return ParameterCollection(ap + others) + self.params
 
+    def _param_collections(self):
+        return [self.template.init.params, self.init.params]
+
 
 class DampedBAOWigglesTracerPowerSpectrumMultipoles(_BaseDampedBAOTracer):
     """BAO power spectrum multipoles with broadband terms (bao.py:422-560, 117-151)."""

@@ -143,6 +143,9 @@ class KaiserTracerPowerSpectrumMultipoles(BaseCalculator):
         others = [param for param in self.template.params if param not in ap]
         return ParameterCollection(ap + others) + self.params
 
+    def _param_collections(self):
+        return [self.template.init.params, self.init.params]
+
 
 class SimpleTracerPowerSpectrumMultipoles(KaiserTracerPowerSpectrumMultipoles):
     r"""Kaiser tracer multipoles with FIXED damping, "essentially used for Fisher forecasts" (full_shape.py:367-414): the Gaussian damping
