@@ -115,8 +115,50 @@ class BaseCalculator(object):
                     if name in collection: collection.pop(name)
         self._invalidate()
 
+    # ---- standalone evaluation: calculator(**params) (base.py:1194-1196) -------------------------------------------------------------
+    def __call__(self, *args, **kwargs):
+        """``theory(b1=2., qpar=1.01).power``, ``observable(b1=2.).flattheory``: evaluate the pipeline below this calculator at these parameters (the others at
+        their default values) and return the calculator, its products set as attributes (the reference: ``BaseCalculator.__call__`` -> ``get()`` = ``self``).
+        The evaluation is the device one: a likelihood with unit precision is compiled around the calculator (kept until its parameters or arguments change), the
+        theory vector comes from ``dl_eval_theory`` / the ``flattheory`` output of ``dl_eval_batch``."""
+        params = {}
+        for arg in args: params.update(arg)
+        params.update(kwargs)
+        self.initialize()
+        signature = tuple((param.name, repr(param.__getstate__())) for param in self.all_params)
+        cache = getattr(self, '_standalone', None)
+        if cache is None or cache[0] != signature:
+            cache = (signature,) + self._standalone_pipeline()
+            self._standalone = cache
+        likelihood = cache[1]
+        likelihood(**params)
+        self._standalone_products(likelihood)
+        return self
+
+    def _standalone_pipeline(self):
+        """(likelihood, [hidden calculators]) evaluating this calculator; theories and observables override."""
+        raise NotImplementedError('{} cannot be evaluated on its own: call the observable or the likelihood it belongs to'.format(self.__class__.__name__))
+
+    def _standalone_products(self, likelihood):
+        pass
+
+    def _standalone_theory_pipeline(self):
+        """For tracer theories: a hidden observable that takes the theory at its own ``k`` (or ``s``) and ``ells`` with no window, zero data, unit precision."""
+        from .likelihoods import ObservablesGaussianLikelihood
+        from .observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable, TracerCorrelationFunctionMultipolesObservable
+        self.initialize()
+        ells = tuple(self.ells)
+        if hasattr(self, 's') and getattr(self, '_standalone_space', 'pk') == 'xi':
+            x = np.array(self.s, dtype='f8')
+            observable = TracerCorrelationFunctionMultipolesObservable(data=np.zeros(len(ells) * x.size), s=x, ells=ells, theory=self)
+        else:
+            x = np.array(self.k, dtype='f8')
+            observable = TracerPowerSpectrumMultipolesObservable(data=np.zeros(len(ells) * x.size), k=x, ells=ells, theory=self)
+        return ObservablesGaussianLikelihood(observables=[observable], precision=np.ones(len(ells) * x.size)), [observable]
+
     def _invalidate(self):
         self._initialized = False
+        self._standalone = None
         for dep in getattr(self, '_dependents', []):
             dep._invalidate()
 

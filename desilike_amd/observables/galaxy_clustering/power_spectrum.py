@@ -61,6 +61,17 @@ class TracerPowerSpectrumMultipolesObservable(BaseCalculator):
         self._initialized = True
         return self
 
+    def _standalone_pipeline(self):
+        from ...likelihoods import ObservablesGaussianLikelihood
+        self.initialize()
+        return ObservablesGaussianLikelihood(observables=[self], precision=np.ones(self.wmatrix.size)), []
+
+    def _standalone_products(self, likelihood):
+        """``flattheory`` and ``theory`` (one array per multipole) at the last call (power_spectrum.py:400-404 / correlation_function.py:380-381)."""
+        self.flattheory = np.array(likelihood.observable_flattheory(0))
+        sizes = [len(xx) for xx in self.wmatrix.k]
+        self.theory = [self.flattheory[sum(sizes[:ill]):sum(sizes[:ill + 1])] for ill in range(len(sizes))]
+
     @property
     def theory_calculator(self):
         self.initialize()

@@ -258,6 +258,20 @@ class _BaseDampedBAOTracer(BaseCalculator):
         return [self.template.init.params, self.init.params]
 
 
+    @property
+    def _standalone_space(self):
+        return self._space
+
+    def _standalone_pipeline(self):
+        return self._standalone_theory_pipeline()
+
+    def _standalone_products(self, likelihood):
+        """``power [n_ell, n_k]`` (``corr [n_ell, n_s]`` for the correlation function classes) at the last call (full_shape.py:502-510, tgc/base.py:127-136)."""
+        flat = np.array(likelihood.observable_flattheory(0))
+        if self._space == 'xi': self.corr = flat.reshape(len(self.ells), -1)
+        else: self.power = flat.reshape(len(self.ells), -1)
+
+
 class DampedBAOWigglesTracerPowerSpectrumMultipoles(_BaseDampedBAOTracer):
     """BAO power spectrum multipoles with broadband terms (bao.py:422-560, 117-151)."""
     _powers = range(-3, 2)

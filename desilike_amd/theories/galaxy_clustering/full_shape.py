@@ -146,6 +146,17 @@ class KaiserTracerPowerSpectrumMultipoles(BaseCalculator):
     def _param_collections(self):
         return [self.template.init.params, self.init.params]
 
+    _standalone_space = 'pk'
+
+    def _standalone_pipeline(self):
+        return self._standalone_theory_pipeline()
+
+    def _standalone_products(self, likelihood):
+        """``power [n_ell, n_k]`` (``corr [n_ell, n_s]`` for the correlation function classes) at the last call (full_shape.py:502-510, tgc/base.py:127-136)."""
+        flat = np.array(likelihood.observable_flattheory(0))
+        if self._standalone_space == 'xi': self.corr = flat.reshape(len(self.ells), -1)
+        else: self.power = flat.reshape(len(self.ells), -1)
+
 
 class SimpleTracerPowerSpectrumMultipoles(KaiserTracerPowerSpectrumMultipoles):
     r"""Kaiser tracer multipoles with FIXED damping, "essentially used for Fisher forecasts" (full_shape.py:367-414): the Gaussian damping
@@ -213,6 +224,7 @@ class _CorrelationFunctionFromPowerSpectrum(object):
     the device evaluates P_\ell on ``kin = geomspace(1e-4, 0.6, 300)`` (tgc/base.py:62-66) and ``get_corr`` -- interpolation to the FFTLog grid, high-k tail,
     FFTLog, interpolation to ``s``, all linear in P_\ell -- is the constant operator ``hankel`` folded into the window matrix.  The operator is built at first use
     by ONE batch of the device FFTLog (``dl_fftlog_apply``).  The stochastic terms have no parameter here (``_stochastic_bias_params = []`` in the reference)."""
+    _standalone_space = 'xi'
     _stochastic_bias_params = []
 
     def _default_k(self):
@@ -394,6 +406,17 @@ class _BaseVelocileptorsTracer(BaseCalculator):
         self.initialize()
         return self.params.copy()
 
+    _standalone_space = 'pk'
+
+    def _standalone_pipeline(self):
+        return self._standalone_theory_pipeline()
+
+    def _standalone_products(self, likelihood):
+        """``power [n_ell, n_k]`` (``corr [n_ell, n_s]`` for the correlation function classes) at the last call (full_shape.py:502-510, tgc/base.py:127-136)."""
+        flat = np.array(likelihood.observable_flattheory(0))
+        if self._standalone_space == 'xi': self.corr = flat.reshape(len(self.ells), -1)
+        else: self.power = flat.reshape(len(self.ells), -1)
+
 
 class LPTVelocileptorsTracerPowerSpectrumMultipoles(_BaseVelocileptorsTracer):
     """Velocileptors LPT tracer multipoles (full_shape.py:1225-1313) from emulated tables."""
@@ -409,6 +432,7 @@ class _VelocileptorsCorrelationFunction(object):
     r"""Velocileptors tracer correlation function multipoles as Hankel transforms of the power spectrum multipoles (full_shape.py:1317-1343, 1603-1629 on top of
     tgc/base.py:46-139): P_\ell is evaluated on ``kin = geomspace(1e-4, 0.6, 300)`` (cubic interpolation / extrapolation from the emulated node's own k), the
     Hankel operator (built by the device FFTLog) multiplies the folded table operator; no stochastic parameters (``_stochastic_bias_params = []``)."""
+    _standalone_space = 'xi'
 
     @classmethod
     def _default_params(cls, **kwargs):
