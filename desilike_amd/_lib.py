@@ -74,6 +74,9 @@ def load():
     if _lib is None:
         if not os.path.isfile(_LIB_PATH):
             raise LibraryError('HIP library {} not found: build it with `python -c "import __graft_entry__ as g; g.build()"`; there is no CPU fallback'.format(_LIB_PATH))
+        # kernel arguments in device memory (latency-bound launches wait for them first; the runtime's default on ROCm 7, stated for older defaults; no effect once
+        # HIP is initialised)
+        os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
         try:
             # PyTorch-ROCm wheels bundle their own libamdhip64: load it FIRST so that this library binds to the same HIP runtime
             # (two HIP runtimes in one process do not see each other's devices: "No HIP GPUs are available")
