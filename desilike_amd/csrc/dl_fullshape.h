@@ -744,7 +744,9 @@ DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& 
 // memory (L1 / L2 resident).  Phase A: per-mu AP factors; phase B: one k per thread, mu loop unrolled by 4; output staged in LDS.
 // ------------------------------------------------------------------------------------------------------------------------
 enum { DL_BAO_QPER = 0, DL_BAO_F, DL_BAO_B1, DL_BAO_SIGS, DL_BAO_D, DL_BAO_LQ = 8, DL_BAO_FAC = DL_BAO_LQ + DL_MAX_MU, DL_BAO_MUP2 = DL_BAO_FAC + DL_MAX_MU,
-       DL_BAO_SD = DL_BAO_MUP2 + DL_MAX_MU, DL_BAO_SDF = DL_BAO_SD + DL_MAX_MU, DL_BAO_ML = DL_BAO_SDF + DL_MAX_MU, DL_BAO_PT = DL_BAO_ML + DL_MAX_ML };
+       DL_BAO_SD = DL_BAO_MUP2 + DL_MAX_MU, DL_BAO_SDF = DL_BAO_SD + DL_MAX_MU, DL_BAO_ML = DL_BAO_SDF + DL_MAX_MU, DL_BAO_REC = DL_BAO_ML + DL_MAX_ML,
+       DL_BAO_PT = DL_BAO_REC + 12 * DL_MAX_MU };
+// DL_BAO_REC: per-mu records of the 'standard' model's fast path, 12 doubles each: lq / hx, 1/2 fac^2 SD, 1/2 (sigmas mu)^2, f mu^2, f mu'^2, -, w_0 .. w_4, -
 
 DL_HD size_t dl_bao_shared_doubles(int n_in) { return DL_BAO_PT + (size_t)n_in; }
 
@@ -763,8 +765,20 @@ DL_HD void dl_bao_phaseA(int tid, int nthr, const DlObsDev& o, const double* th,
             lds[DL_BAO_MUP2 + tid] = mup * mup;
             lds[DL_BAO_SD + tid] = sigpar * sigpar * (mup * mup) + sigper * sigper * (1. - mup * mup);   // bao.py:129
             lds[DL_BAO_SDF + tid] = sigpar * sigpar * (mu * mu) + sigper * sigper * (1. - mu * mu);       // 'fix-damping': fiducial mu (bao.py:137-138)
+            // record of the fast path (dl_bao_phaseB_std): everything of the (k, mu) evaluation that depends on mu only
+            double* rec = lds + DL_BAO_REC + 12 * tid;
+            const double f = dl_get(o.dbeta, th) * (o.f_fid * dl_get(o.df, th)), sigmas = dl_get(o.sigmas, th);
+            rec[0] = lds[DL_BAO_LQ + tid] * o.inv_hx;
+            rec[1] = 0.5 * (fac * fac) * lds[DL_BAO_SD + tid];
+            rec[2] = 0.5 * (sigmas * mu) * (sigmas * mu);
+            rec[3] = f * (mu * mu);
+            rec[4] = f * (mup * mup);
+            rec[5] = 0.;
+            for (int l = 0; l < DL_MAX_ELL; ++l) rec[6 + l] = (l < o.n_ell) ? o.wmu[l * o.n_mu + tid] : 0.;
+            rec[11] = 0.;
         } else if (tid < ((o.n_mu + 3) & ~3)) {
             lds[DL_BAO_FAC + tid] = 0.; lds[DL_BAO_LQ + tid] = 0.; lds[DL_BAO_MUP2 + tid] = 0.; lds[DL_BAO_SD + tid] = 0.; lds[DL_BAO_SDF + tid] = 0.;
+            for (int q = 0; q < 12; ++q) lds[DL_BAO_REC + 12 * tid + q] = 0.;    // zero weights: the padded nodes add nothing
         }
         if (tid == 0) {
             lds[DL_BAO_QPER] = qper;
@@ -777,8 +791,71 @@ DL_HD void dl_bao_phaseA(int tid, int nthr, const DlObsDev& o, const double* th,
     }
 }
 
+// 1 / x to rounding: hardware seed + two Newton steps on the device (5 instructions against ~20 of the IEEE division)
+DL_HD double dl_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.), r, r);
+    r = fma(fma(-x, r, 1.), r, r);
+    return r;
+#else
+    return 1. / x;
+#endif
+}
+
+// 'standard' model on uniform knots (the reference's BAO templates: geomspace tables), bao.py:117-136 -- same formula as dl_bao_phaseB_m<0>, with everything that
+// depends on mu only taken from the per-mu records of phase A (LDS broadcasts: no global loads of nodes / weights in the loop), the abscissa in units of the knot
+// spacing (one add, integer clamp), the Finger-of-God factor 1 / (1 + (sigmas k mu)^2 / 2)^2 through dl_rcp.  NL = multipole accumulators compiled in.
+template <int NL>
+DL_HD void dl_bao_phaseB_std(int tid, int nthr, const DlObsDev& o, double* lds) {
+    const double qper = lds[DL_BAO_QPER], b1 = lds[DL_BAO_B1];
+    const int n_kin = o.n_kin, n_mu4 = (o.n_mu + 3) & ~3, nm2 = o.n_t - 2;
+    const int reciso = (o.bao_mode & 15) == 1;
+    double* out = lds + DL_BAO_PT;
+    for (int i = tid; i < n_kin; i += nthr) {
+        const double kk = o.kin[i], pknow = o.pknow_k[i];
+        const double lkh = (o.lkin[i] - o.x0) * o.inv_hx;
+        const double kq = kk / qper, kq2 = kq * kq, kk2 = kk * kk;
+        double omsk = 1.;
+        if (reciso) { double kr = kk * o.smoothing_radius; omsk = 1. - exp(-0.5 * (kr * kr)); }   // bao.py:131, fiducial coordinates
+        double p[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) p[l] = 0.;
+        for (int m0 = 0; m0 < n_mu4; m0 += 4) {
+            double pkmu[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double* rec = lds + DL_BAO_REC + 12 * (m0 + q);
+                const double t = lkh + rec[0];
+                int j = (int)t;
+                j = j < 0 ? 0 : (j > nm2 ? nm2 : j);
+                const double u = t - (double)j;
+                const double* c = o.coef_w + 4 * (size_t)j;
+                const double pkw = fma(fma(fma(c[3], u, c[2]), u, c[1]), u, c[0]);                     // [P_dd - P_now](k')
+                const double ca = fma(rec[4], omsk, b1), cb = fma(rec[3], omsk, b1);                   // b1 + f mu'^2 (1 - S(k)), b1 + f mu^2 (1 - S(k))
+                const double Cap = ca * ca * exp(-(kq2 * rec[1]));                                     // bao.py:129-132
+                const double r = dl_rcp(fma(kk2, rec[2], 1.));                                         // bao.py:133
+                pkmu[q] = cb * cb * (r * r) * pknow + Cap * pkw;                                       // bao.py:134-136
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double* w = lds + DL_BAO_REC + 12 * (m0 + q) + 6;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) p[l] = fma(w[l], pkmu[q], p[l]);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+            if (l < o.n_ell) out[(size_t)l * n_kin + i] = p[l];
+    }
+}
+
 template <int MODEL>   // 0: 'standard', 1: 'fix-damping' / 'move-all' / 'fog-damping' family, 2: resummed wiggles, 3: flexible wiggles
 DL_HD void dl_bao_phaseB_m(int tid, int nthr, const DlObsDev& o, double* lds) {
+    if (MODEL == 0 && o.uniform_knots && o.n_mu <= DL_MAX_MU - 3) {
+        if (o.n_ell <= 3) dl_bao_phaseB_std<3>(tid, nthr, o, lds); else dl_bao_phaseB_std<DL_MAX_ELL>(tid, nthr, o, lds);
+        return;
+    }
     const double qper = lds[DL_BAO_QPER], f = lds[DL_BAO_F], b1 = lds[DL_BAO_B1], sigmas = lds[DL_BAO_SIGS];
     const int n_ell = o.n_ell, n_mu = o.n_mu, n_kin = o.n_kin, n_mu4 = (o.n_mu + 3) & ~3;
     const int reciso = (o.bao_mode & 15) == 1, model = o.bao_mode >> 4;

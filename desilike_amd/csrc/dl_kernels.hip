@@ -148,16 +148,29 @@ __global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_mul
 
 // BAO wiggle model: one workgroup per point; constant splines read from global memory, no per-point spline build.  One kernel per wiggle model: registers are
 // allocated for the worst branch of a kernel (all four models behind one run-time switch: 165 VGPRs, three waves per SIMD, the standard model 15 % slower).
+// Workgroup size by batch (dl_bao_threads): ONE wave per point once the batch fills the chip (>= 4096 points: 16 resident workgroups per CU overlap each other's
+// per-mu chain and no wave waits at a barrier for another: 101 -> 86 us per 8192 points of the damped-BAO xi model, 70 -> 54 us for P_ell), 128 threads from 2048
+// points, 256 threads (the shortest life of a single point) below.  More threads than wavenumbers were tried: 320 / 384 threads per point, 146 us.
 template <int MODEL>
-__global__ __launch_bounds__(DL_FS_THREADS) void dl_bao_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power, int64_t ld_power) {
+__global__ __launch_bounds__(512) void dl_bao_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power, int64_t ld_power) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const double* th = theta + (size_t)b * n_params;
-    dl_bao_phaseA(tid, DL_FS_THREADS, o, th, lds);
+    dl_bao_phaseA(tid, nthr, o, th, lds);
     __syncthreads();
-    dl_bao_phaseB_m<MODEL>(tid, DL_FS_THREADS, o, lds);
+    dl_bao_phaseB_m<MODEL>(tid, nthr, o, lds);
     __syncthreads();
-    dl_store_with_pass(tid, DL_FS_THREADS, o, th, lds + DL_BAO_PT, power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset);
+    dl_store_with_pass(tid, nthr, o, th, lds + DL_BAO_PT, power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset);
+}
+
+static int dl_bao_threads(int n_kin, int64_t B) {
+    static const int forced = getenv("DL_BAO_THREADS") ? atoi(getenv("DL_BAO_THREADS")) : 0;
+    if (forced >= 64 && forced <= 512 && forced % 64 == 0) return forced;
+    int t = (n_kin + 63) / 64 * 64;
+    t = t > 256 ? 256 : t;
+    if (B >= 4096) t = 64;
+    else if (B >= 2048 && t > 128) t = 128;
+    return t;
 }
 
 // emulated theory: MLP / Taylor forward pass and feature expansion, one workgroup per point
@@ -218,7 +231,7 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
             size_t shm = dl_bao_shared_doubles(obs_host[i].n_in) * sizeof(double);
             auto launch_bao = [&](auto kernel) {
                 if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-                DL_LAUNCH(kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power);
+                DL_LAUNCH(kernel, dim3((unsigned)B), dim3((unsigned)dl_bao_threads(obs_host[i].n_kin, B)), shm, stream, obs_host[i], theta, n_params, power, ld_power);
             };
             const int model = obs_host[i].bao_mode >> 4;
             if (model == 0) launch_bao(dl_bao_kernel<0>);
