@@ -188,8 +188,11 @@ __global__ __launch_bounds__(DL_FF_THREADS) void dl_fftlog_kernel(const double* 
 // ------------------------------------------------------------------------------------------------------------------------
 #define DL_FF4_N2 2048
 #define DL_FF4_L 11
+#ifndef DL_FF4_SYNC_AFTER_APRIME
+#define DL_FF4_SYNC_AFTER_APRIME 1
+#endif
 #ifndef DL_FF4_POST_STAGE
-#define DL_FF4_POST_STAGE 4   // the output factors are requested after this many stages of the last 16-point transform (earlier: register spills)
+#define DL_FF4_POST_STAGE 0   // the output factors are requested after this many stages of the last 16-point transform (0: with the input factors, before it)
 #endif
 
 // v * exp(-i pi q / 8) (forward) or v * exp(+i pi q / 8) (INV), q = 0..7 known at compile time after unrolling
@@ -261,26 +264,44 @@ __device__ __forceinline__ void dl_ff_twiddle_products(dl_ff_c& w1, dl_ff_c& w2,
     T[3] = dl_ff_mul(w1, w2); T[5] = dl_ff_mul(w1, w4); T[6] = dl_ff_mul(w2, w4); T[7] = dl_ff_mul(T[3], w4);
 }
 
+// spectrum step on the pair (X[m], X[N2 - m]) in place: real-FFT unpacking X = Fe + W^m Fo, multiplication by u[m] / u[N2 - m], re-packing for the inverse transform
+__device__ __forceinline__ void dl_ff_pair_update(dl_ff_c& xm, dl_ff_c& xmm, dl_ff_c w, dl_ff_c um, dl_ff_c umm) {
+    const dl_ff_c zm = xm, zc = dl_ff_conj(xmm);
+    const dl_ff_c s = zm + zc, d = zm - zc;
+    const dl_ff_c fe = dl_ff_c{0.5 * s.x, 0.5 * s.y}, fo = dl_ff_c{0.5 * d.y, -0.5 * d.x};   // fo = -i d / 2
+    const dl_ff_c wfo = dl_ff_mul(w, fo);
+    const dl_ff_c ym = dl_ff_mul(fe + wfo, um), ymmc = dl_ff_mulc(fe - wfo, umm);            // ymmc = conj(Y[N2 - m])
+    const dl_ff_c gs = ym + ymmc, gd = dl_ff_mulc(ym - ymmc, w);
+    const dl_ff_c ge = dl_ff_c{0.5 * gs.x, 0.5 * gs.y}, go = dl_ff_c{0.5 * gd.x, 0.5 * gd.y};
+    xm = dl_ff_c{ge.x - go.y, ge.y + go.x};                     // ge + i go
+    xmm = dl_ff_c{ge.x + go.y, go.x - ge.y};                    // conj(ge) + i conj(go)
+}
+
 // this wave's LDS traffic has landed, then the workgroup barrier: global requests stay in flight (no vmcnt wait)
 __device__ __forceinline__ void dl_ff_lds_barrier() {
     __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// work item r (0 .. 1022) of the spectrum step -> position b of its bin m = brev11(b) and position p of the partner bin N2 - m:
-//   the bins m = 2^k (4 j + 1) occupy the positions [2^(10-k), 2^(10-k) + 2^(9-k)), their partners the next 2^(9-k) positions in reverse order
-__host__ __device__ __forceinline__ void dl_ff4_pair(int r, int& b, int& p) {
-    const int i = r >> 7, t = r & 127;
-    if (i < 4) { b = 1024 + r; p = 2047 - r; }                                  // k = 0: 512 pairs
-    else if (i < 6) { b = 512 + (r - 512); p = 1023 - (r - 512); }              // k = 1: 256 pairs
-    else if (i == 6) { b = 256 + t; p = 511 - t; }                              // k = 2: 128 pairs
-    else {                                                                      // k = 3 .. 9: 64 + 32 + ... + 1 pairs
-        const int v = t + 1;
-        int a = 0;
-        while ((2 << a) <= v) ++a;                                              // floor(log2(v))
-        const int c = v - (1 << a);
-        b = (2 << a) + c; p = (4 << a) - 1 - c;
-    }
+// The spectrum step pairs bin m (position brev11(m)) with bin N2 - m.  The bins m = 2^k (4 j + 1) occupy the positions [2^(10-k), 2^(10-k) + 2^(9-k)), their partners
+// the next 2^(9-k) positions in reverse order; in blocks of 8 positions: thread t owns block A and its mirror B, slot e of A pairs with slot 7 - e of B.
+#define DL_FF4_NU 1032    // coefficient table entries per multipole: item e * 128 + t (slot e of thread t's block A), then the seven pairs inside blocks 0 / 1
+__host__ __device__ __forceinline__ void dl_ff4_blocks(int t, int& A, int& B) {
+    if (t < 64) { A = 128 + t; B = 255 - t; }                    // k = 0: positions 1024 .. 2047
+    else if (t < 96) { A = t; B = 191 - t; }                     // k = 1: 64 + j, 127 - j with j = t - 64
+    else if (t < 112) { A = t - 64; B = 159 - t; }               // k = 2: 32 + j, 63 - j, j = t - 96
+    else if (t < 120) { A = t - 96; B = 143 - t; }               // k = 3: 16 + j, 31 - j, j = t - 112
+    else if (t < 124) { A = t - 112; B = 135 - t; }              // k = 4: 8 + j, 15 - j, j = t - 120
+    else if (t < 126) { A = t - 120; B = 131 - t; }              // k = 5: 4 + j, 7 - j, j = t - 124
+    else if (t == 126) { A = 2; B = 3; }                         // k = 6
+    else { A = 0; B = 1; }                                       // positions 0 .. 15: pairs inside the two blocks (dl_ff4_special_pair)
 }
+// pair i (0 .. 6) inside blocks 0 / 1: positions (8, 15), (9, 14), (10, 13), (11, 12), (4, 7), (5, 6), (2, 3)
+__host__ __device__ __forceinline__ void dl_ff4_special_pair(int i, int& p, int& pm) {
+    if (i < 4) { p = 8 + i; pm = 15 - i; }
+    else if (i < 6) { p = i; pm = 11 - i; }
+    else { p = 2; pm = 3; }
+}
+__host__ __device__ __forceinline__ constexpr int dl_ff_brev3(int e) { return ((e & 1) << 2) | (e & 2) | ((e & 4) >> 2); }
 
 // entry m (< 4096) of the full circle exp(-i pi m / 2048) from the half-circle table
 __device__ __forceinline__ dl_ff_c dl_ff_tw_full(const dl_ff_c* __restrict__ tw, int m) {
@@ -301,11 +322,13 @@ void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restri
     // W_2048^(j q) = exp(-i pi 2 j q / 2048) for q = 1, 2, 4, 8; the other eleven are products formed where they are used (keeping all fifteen resident, with
     // the operands in flight on top, overflows the 256 registers a wave has at this occupancy)
     const dl_ff_c twA1 = dl_ff_tw_full(tw, 2 * tid), twA2 = dl_ff_tw_full(tw, 4 * tid), twA4 = dl_ff_tw_full(tw, 8 * tid), twA8 = dl_ff_tw_full(tw, 16 * tid);
-    // spectrum step: W_4096^(16 brev7(tid)); work item 896 + tid (the short runs): positions of the pair and W_4096^m
-    const dl_ff_c wt = tw[16 * (int)(__brev((unsigned)tid) >> 25)];
-    int b7, p7;
-    dl_ff4_pair(896 + (tid < 127 ? tid : 0), b7, p7);
-    const dl_ff_c wt7 = tw[(int)(__brev((unsigned)b7) >> (32 - DL_FF4_L))];
+    // spectrum step: the pair of 8-blocks of this thread and W_4096^(brev8(blkA)); lanes 64 .. 70: the pair inside blocks 0 / 1 they look after
+    int blkA, blkB;
+    dl_ff4_blocks(tid, blkA, blkB);
+    const dl_ff_c wt = tw[(int)(__brev((unsigned)blkA) >> 24)];
+    int posS = 2, posSm = 3;
+    dl_ff4_special_pair(tid >= 64 && tid < 71 ? tid - 64 : 6, posS, posSm);
+    const dl_ff_c wS = tw[(int)(__brev((unsigned)posS) >> (32 - DL_FF4_L))];
     { const int j = tid & 7, q = tid >> 3; twB[q * 8 + j] = dl_ff_tw_full(tw, 32 * j * q); } // W_128^(j q) = exp(-i pi 32 j q / 2048)
     const int jB = tid & 7, gB = tid >> 3, rtid = 127 - tid;
     __syncthreads();
@@ -322,7 +345,7 @@ void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restri
     for (int id = blockIdx.x; id < total; id += gridDim.x) {
         const int ell = id % n_ell;
         const dl_ff_c* ul = u + (size_t)ell * (N2 + 1);
-        const dl_ff_c *u1l = u1 + (size_t)ell * 1024, *u2l = u2 + (size_t)ell * 1024;
+        const dl_ff_c *u1l = u1 + (size_t)ell * DL_FF4_NU, *u2l = u2 + (size_t)ell * DL_FF4_NU;
         dl_ff_c v[16];
         // ---- pass A: element j + 128 e = real samples q0 = 2 (j + 128 e) - pad, q0 + 1; data for e = 4 .. 11 only, so the first stage (pairs (e, e + 8)) has one
         //      zero operand everywhere: v[e] = b, v[e + 8] = rot(-b) for e < 4 (a = 0), v[e] = a, v[e + 8] = rot(a) for e >= 4 (b = 0)
@@ -352,7 +375,7 @@ void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restri
         dl_ff_c um[4], umm[4];     // bins m = tid + 128 i, i < 4 now; i + 4 takes the place of i as soon as i is consumed
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            um[i] = (u1l + 128 * i)[tid];                     // u[m] of work item tid + 128 i
+            um[i] = (u1l + 128 * i)[tid];                     // u[m] of the pair (slot i of block A, slot 7 - i of block B)
             umm[i] = (u2l + 128 * i)[tid];                    // u[N2 - m]
         }
         dl_ff_lds_barrier();
@@ -367,75 +390,62 @@ void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restri
             for (int e = 1; e < 16; ++e) x[DL_FF_P(i0 + 8 * e)] = dl_ff_mul(v[e], twB[dl_ff_brev4(e) * 8 + jB]);
         }
         dl_ff_lds_barrier();
-        // ---- pass C: two independent 8-point transforms per thread
+        // ---- pass C, spectrum step and inverse pass C' in ONE register-resident phase.  Pass C works on blocks of 8 consecutive positions; the bins of the run of
+        //      positions [2^(10-k), 2^(10-k) + 2^(9-k)) have their partners N2 - m in the next run of the same length in reverse order (dl_ff4_blocks), so a pair of
+        //      8-blocks (A, B = the mirror of A in the partner run) is closed under the pairing: slot e of A goes with slot 7 - e of B.  A thread loads its two blocks,
+        //      runs the two 8-point transforms, the 8 pair updates and the two inverse 8-point transforms on registers, and writes back: two LDS round trips and two
+        //      barriers fewer than with the three phases apart.  127 block pairs cover the positions 16 .. 2047 (dl_ff4_blocks); blocks 0 and 1 (thread 127) pair
+        //      within themselves: that thread parks its transformed blocks in LDS, seven lanes of its own wave do the seven pairs (positions 2 .. 15) and one the two
+        //      real bins (positions 0, 1) there, and it takes the blocks back -- same wave: program order, no barrier.
+        //      Bin of slot e of block A: m = brev3(e) 2^8 + brev8(A), so W_4096^m = W^(brev8(A)) (resident) x exp(-i pi brev3(e) / 8) (compile time).
         {
             dl_ff_c a[8], b[8];
-            const int iA = 8 * tid, iB = 8 * (tid + 128);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { a[e] = x[DL_FF_P(iA + e)]; b[e] = x[DL_FF_P(iB + e)]; }
+            for (int e = 0; e < 8; ++e) { a[e] = x[DL_FF_P(8 * blkA + e)]; b[e] = x[DL_FF_P(8 * blkB + e)]; }
             dl_ff_const<3, false>(a);
             dl_ff_const<3, false>(b);
+            if (tid == 127) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { x[DL_FF_P(iA + e)] = a[e]; x[DL_FF_P(iB + e)] = b[e]; }
-        }
-        dl_ff_lds_barrier();
-        // ---- spectrum.  Bin m sits at position brev(m).  The pairs (m, N2 - m) are walked by POSITION, not by m: the bins m = 2^k (4 j + 1) sit in the run of
-        //      positions [2^(10-k), 2^(10-k) + 2^(9-k)) and their partners N2 - m in the next run of the same length, in reverse order (dl_ff4_pair) -- consecutive
-        //      lanes touch consecutive LDS slots on both sides (walking m = tid + 128 i instead puts the 16 lanes of a ds_read_b128 on two bank groups: half of
-        //      the kernel's LDS cycles were bank conflicts of this step).  The coefficient tables are stored in the same order (u1 / u2, built at plan creation);
-        //      W_4096^m = W^(16 brev7(tid)) x a compile-time root for the three long runs (work items 0 .. 895), one resident value for the short ones.
-        {
-            // exp(-i pi c / 2048), c = m mod 16 of work items 128 i + tid, i < 7: 1, 9, 5, 13 (k = 0), 2, 10 (k = 1), 4 (k = 2)
-            const double cw[7] = {0.99999882345170188, 0.9999047010828529, 0.99997058643097414, 0.99980116988788426, 0.99999529380957619, 0.99988234745421256, 0.99998117528260111};
-            const double sw[7] = {0.0015339801862847655, 0.013805388528060391, 0.007669828739531097, 0.019940428551514441, 0.0030679567629659761, 0.0153392062849881, 0.0061358846491544753};
+                for (int e = 0; e < 8; ++e) { x[DL_FF_P(e)] = a[e]; x[DL_FF_P(8 + e)] = b[e]; }
+            }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int pb, pp;       // positions of bin m and of its partner N2 - m
-                if (i < 4) { pb = 1024 + tid + 128 * i; pp = 2047 - (tid + 128 * i); }
-                else if (i < 6) { pb = 512 + tid + 128 * (i - 4); pp = 1023 - (tid + 128 * (i - 4)); }
-                else if (i == 6) { pb = 256 + tid; pp = 511 - tid; }
-                else { pb = b7; pp = p7; }
-                const int pm = DL_FF_P(pb), pmm = DL_FF_P(pp);
-                const dl_ff_c w = (i == 7) ? wt7 : dl_ff_c{wt.x * cw[i < 7 ? i : 0] + wt.y * sw[i < 7 ? i : 0], wt.y * cw[i < 7 ? i : 0] - wt.x * sw[i < 7 ? i : 0]};
-                const dl_ff_c zm = x[pm], zc = dl_ff_conj(x[pmm]);
-                const dl_ff_c s = zm + zc, d = zm - zc;
-                const dl_ff_c fe = dl_ff_c{0.5 * s.x, 0.5 * s.y}, fo = dl_ff_c{0.5 * d.y, -0.5 * d.x};   // fo = -i d / 2
-                const dl_ff_c wfo = dl_ff_mul(w, fo);
-                const dl_ff_c ym = dl_ff_mul(fe + wfo, um[i & 3]), ymmc = dl_ff_mulc(fe - wfo, umm[i & 3]);     // ymmc = conj(Y[N2 - m])
-                if (i < 4) { um[i] = (u1l + (128 * i + 512))[tid]; umm[i] = (u2l + (128 * i + 512))[tid]; }
-                const dl_ff_c gs = ym + ymmc, gd = dl_ff_mulc(ym - ymmc, w);
-                const dl_ff_c ge = dl_ff_c{0.5 * gs.x, 0.5 * gs.y}, go = dl_ff_c{0.5 * gd.x, 0.5 * gd.y};
-                if (i < 7 || tid != 127) {   // (work item 1023 does not exist: thread 127 ran the arithmetic on harmless values)
-                    x[pm] = dl_ff_c{ge.x - go.y, ge.y + go.x};                     // ge + i go
-                    x[pmm] = dl_ff_c{ge.x + go.y, go.x - ge.y};                    // conj(ge) + i conj(go)
+            for (int e = 0; e < 8; ++e) {
+                const dl_ff_c w = dl_ff_rot<false>(dl_ff_brev3(e), wt);
+                dl_ff_pair_update(a[e], b[7 - e], w, um[e & 3], umm[e & 3]);
+                if (e < 4) { um[e] = (u1l + 128 * (e + 4))[tid]; umm[e] = (u2l + 128 * (e + 4))[tid]; }
+            }
+            if (tid >= 64) {   // wave 1: the pairs inside blocks 0 and 1
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int ls = tid - 64;
+                if (ls < 7) {
+                    const int pm = DL_FF_P(posS), pmm = DL_FF_P(posSm);
+                    dl_ff_c zm = x[pm], zmm = x[pmm];
+                    dl_ff_pair_update(zm, zmm, wS, (u1l + 1024)[ls], (u2l + 1024)[ls]);
+                    x[pm] = zm; x[pmm] = zmm;
+                } else if (ls == 7) {
+                    // m = 1024 = N2 - m, W^m = -i: the pair formulas collapse to x <- x conj(u[1024]) (position brev(1024) = 1)
+                    x[DL_FF_P(1)] = dl_ff_mulc(x[DL_FF_P(1)], ul[1024]);
+                    // m = 0: rfft bins 0 and N2 are real (packed as the two components of element 0); irfft ignores the imaginary parts of both
+                    const dl_ff_c z = x[0];
+                    const double y0 = (z.x + z.y) * ul[0].x, yn = (z.x - z.y) * ul[N2].x;
+                    x[0] = dl_ff_c{0.5 * (y0 + yn), 0.5 * (y0 - yn)};
+                }
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (tid == 127) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { a[e] = x[DL_FF_P(e)]; b[e] = x[DL_FF_P(8 + e)]; }
                 }
             }
-            if (tid == 127) {
-                // m = 1024 = N2 - m, W^m = -i: the pair formulas collapse to x <- x conj(u[1024]) (position brev(1024) = 1)
-                x[DL_FF_P(1)] = dl_ff_mulc(x[DL_FF_P(1)], ul[1024]);
-                // m = 0: rfft bins 0 and N2 are real (packed as the two components of element 0); irfft ignores the imaginary parts of both
-                const dl_ff_c z = x[0];
-                const double y0 = (z.x + z.y) * ul[0].x, yn = (z.x - z.y) * ul[N2].x;
-                x[0] = dl_ff_c{0.5 * (y0 + yn), 0.5 * (y0 - yn)};
-            }
+            dl_ff_const<3, true>(a);
+            dl_ff_const<3, true>(b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[DL_FF_P(8 * blkA + e)] = a[e]; x[DL_FF_P(8 * blkB + e)] = b[e]; }
         }
         // the next transform's input row: requested now, used at the top of the next iteration
         {
             const int next = (id + (int)gridDim.x < total) ? id + (int)gridDim.x : id;
 #pragma unroll
             for (int e = 0; e < 8; ++e) fv[e] = reinterpret_cast<const dl_ff_c*>(fun + (size_t)next * n + 256 * e)[tid];
-        }
-        dl_ff_lds_barrier();
-        // ---- inverse pass C'
-        {
-            dl_ff_c a[8], b[8];
-            const int iA = 8 * tid, iB = 8 * (tid + 128);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { a[e] = x[DL_FF_P(iA + e)]; b[e] = x[DL_FF_P(iB + e)]; }
-            dl_ff_const<3, true>(a);
-            dl_ff_const<3, true>(b);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { x[DL_FF_P(iA + e)] = a[e]; x[DL_FF_P(iB + e)] = b[e]; }
         }
         dl_ff_lds_barrier();
         // ---- inverse pass B'
@@ -463,7 +473,11 @@ void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restri
                 if (e == 5 || e == 10) __builtin_amdgcn_sched_barrier(0);   // (three batches of LDS reads: all sixteen in flight at once overflow the register file here)
             }
         }
-        dl_ff_lds_barrier();   // every wave has read its elements: the next transform may overwrite the LDS image
+#if DL_FF4_SYNC_AFTER_APRIME
+        dl_ff_lds_barrier();
+#else
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         {
             const double* prel = pre;
             __asm__ volatile("" : "+s"(prel));    // (not a loop invariant for the optimiser: see above)
@@ -547,15 +561,17 @@ int dl_fftlog_create(dl_fftlog** out, int device, int32_t n, int32_t npad, int32
         }
     }
     if (npad == 4096 && n == 2048) {
-        std::vector<double> u1((size_t)n_ell * 1024 * 2), u2(u1.size());
+        std::vector<double> u1((size_t)n_ell * DL_FF4_NU * 2), u2(u1.size());
+        auto brev11 = [](int p) { int m = 0; for (int bit = 0; bit < 11; ++bit) m |= ((p >> bit) & 1) << (10 - bit); return m; };
         for (int l = 0; l < n_ell; ++l) {
             const double* ul = u + (size_t)l * (N2 + 1) * 2;
-            for (int r = 0; r < 1024; ++r) {
-                int b, p;
-                dl_ff4_pair(r < 1023 ? r : 1022, b, p);
-                int m = 0;
-                for (int bit = 0; bit < 11; ++bit) m |= ((b >> bit) & 1) << (10 - bit);
-                const size_t o = ((size_t)l * 1024 + r) * 2;
+            for (int r = 0; r < DL_FF4_NU; ++r) {
+                int p = 2, pm = 3;                       // (entries that no work item reads: any valid pair)
+                if (r < 1024 && (r & 127) < 127) { int A, B; dl_ff4_blocks(r & 127, A, B); p = 8 * A + (r >> 7); pm = 8 * B + 7 - (r >> 7); }
+                else if (r >= 1024 && r < 1031) dl_ff4_special_pair(r - 1024, p, pm);
+                const int m = brev11(p);
+                if (brev11(pm) != (N2 - m) % N2) { dl_fftlog_destroy(plan); return dl_ff_fail(nullptr, "dl_fftlog_create: internal error (pairing of the spectrum step)"); }
+                const size_t o = ((size_t)l * DL_FF4_NU + r) * 2;
                 u1[o] = ul[2 * m]; u1[o + 1] = ul[2 * m + 1];
                 u2[o] = ul[2 * (N2 - m)]; u2[o + 1] = ul[2 * (N2 - m) + 1];
             }
