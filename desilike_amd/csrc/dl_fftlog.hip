@@ -178,13 +178,14 @@ __global__ __launch_bounds__(DL_FF_THREADS) void dl_fftlog_kernel(const double* 
 // 16-point transform + one twiddle per register slot, every twiddle that does not depend on the data kept for the life of the workgroup.
 //   N2 = 16 x 16 x 8.  Forward (decimation in frequency, natural -> bit-reversed):
 //     pass A  thread j (0..127) owns x[j + 128 e], e < 16: loaded from global memory straight into registers (only e = 4..11 carry data: the rest is the zero
-//             padding), constant 16-point DIF, slot e times W_2048^(j brev4(e)) -- 15 twiddles per thread, PERSISTENT in registers -- then LDS;
+//             padding), constant 16-point DIF, slot e times W_2048^(j brev4(e)) -- four resident twiddles per thread, the other eleven are products -- then LDS;
 //     pass B  thread t = 8 g + j owns x[128 g + j + 8 e]: LDS -> registers, 16-point DIF, slot e times W_128^(j brev4(e)) (128 distinct values: a 2 KB LDS table);
-//     pass C  two items per thread, x[8 t + e], e < 8: plain 8-point DIF (no twiddles left).
-//   Spectrum step as in the general kernel, with W_4096^m = W^tid x (compile-time 32nd root of unity) and u_ell[m], u_ell[N2 - m] requested right after pass A
-//   (they arrive behind passes B and C).  Inverse = the conjugate transposes in reverse order (C', B', A'); pass A' ends in registers and is stored from there,
-//   reversed and scaled (16-byte stores).  Two LDS round trips fewer than the general kernel, no table loads inside the passes, raw s_barrier with lgkmcnt-only
-//   waits so that the table requests stay in flight across barriers.
+//     pass C  two blocks of 8 consecutive positions per thread: plain 8-point DIF (no twiddles left), on registers, followed IN THE SAME REGISTERS by
+//   the spectrum step (the two blocks of a thread are chosen so that they are closed under the pairing m <-> N2 - m: see the phase itself) and the inverse pass C';
+//   u_ell[m], u_ell[N2 - m] come from tables laid out in work-item order at plan creation, requested right after pass A (they arrive behind pass B).
+//   Inverse = the conjugate transposes in reverse order (C', B', A'); pass A' ends in registers and is stored from there, reversed and scaled (16-byte stores).
+//   Three LDS round trips (the general kernel: seven), no table loads inside the passes, raw s_barrier with lgkmcnt-only waits so that the table requests stay
+//   in flight across barriers.
 // ------------------------------------------------------------------------------------------------------------------------
 #define DL_FF4_N2 2048
 #define DL_FF4_L 11
