@@ -22,8 +22,8 @@ static inline __host__ __device__ int dl_eb_ld(const DlObsDev& o) {   // LDS row
     if (o.n_basis > w) w = o.n_basis;
     return (w + 3) / 4 * 4 + 2;
 }
-static inline __host__ __device__ size_t dl_eb_shared_doubles(const DlObsDev& o) {
-    return (size_t)DL_EB_PTS * (DL_MAX_X + 2 * dl_eb_ld(o) + 4 + (size_t)(1 + o.n_var) * DL_N_MONO);
+static inline __host__ __device__ size_t dl_eb_shared_doubles(const DlObsDev& o) {   // inputs | two activation buffers PER ENGINE | scalars | monomial rows
+    return (size_t)DL_EB_PTS * (DL_MAX_X + 6 * dl_eb_ld(o) + 4 + (size_t)(1 + o.n_var) * DL_N_MONO);
 }
 
 #if defined(__HIPCC__)
@@ -36,9 +36,8 @@ __device__ __forceinline__ void dl_eb_forward(const DlObsDev& o, const double* _
     const int col = lane & 15, g = lane >> 4;
     const int LD = dl_eb_ld(o);
     double* x = lds;                                      // [16][DL_MAX_X]
-    double* buf0 = x + DL_EB_PTS * DL_MAX_X;              // [16][LD]
-    double* buf1 = buf0 + DL_EB_PTS * LD;                 // [16][LD]
-    double* scal = buf1 + DL_EB_PTS * LD;                 // [16][4]: sigma8 (1), fsigma8 (2)
+    double* bufs = x + DL_EB_PTS * DL_MAX_X;              // engine ie: [2][16][LD] at bufs + ie * 2 * 16 * LD
+    double* scal = bufs + 6 * DL_EB_PTS * LD;             // [16][4]: sigma8 (1), fsigma8 (2)
     double* mono = scal + DL_EB_PTS * 4;                  // [16][(1 + n_var) * 19]
     for (int idx = tid; idx < DL_EB_PTS * o.n_x; idx += NTHR) {
         int pt = idx / o.n_x, i = idx - pt * o.n_x;
@@ -46,41 +45,66 @@ __device__ __forceinline__ void dl_eb_forward(const DlObsDev& o, const double* _
         x[pt * DL_MAX_X + i] = dl_get(o.x_in[i], theta + (size_t)b * n_params);
     }
     __syncthreads();
-    double* basis = buf0;
-    for (int pass = 0; pass < 3; ++pass) {
-        const int ie = pass == 2 ? 0 : pass + 1;          // scalar engines first, the table basis last (it stays in LDS)
+    // ---- MLP engines, SIDE BY SIDE: the table basis on half of the waves, the two scalar engines (sigma8, fsigma8) on a quarter each, one barrier per layer for all
+    //      of them (one after the other the three engines were 15 barrier-separated layers, each an L2 round trip for its weights: 24 of the fused kernel's 70 us).
+    //      A layer = [16 points x n_in] . [n_in x n_out] by MFMA, 16 output units per tile; all k-steps of a tile's weights are requested at once.
+    constexpr int NW = NTHR / 64;
+    int n_mlp = 0, max_layers = 0;
+    for (int ie = 0; ie < 3; ++ie) if (o.eng[ie].type == 0) { ++n_mlp; if (o.eng[ie].n_layers > max_layers) max_layers = o.eng[ie].n_layers; }
+    // wave range of engine ie: [w0, w0 + nw)
+    int my_ie = -1, my_w0 = 0, my_nw = 0;
+    {
+        int w0 = 0;
+        for (int ie = 0; ie < 3; ++ie) {
+            if (o.eng[ie].type != 0) continue;
+            int nw = n_mlp == 1 ? NW : (n_mlp == 2 ? NW / 2 : (ie == 0 ? NW / 2 : NW / 4));
+            if (nw < 1) nw = 1;
+            if (wave >= w0 && wave < w0 + nw) { my_ie = ie; my_w0 = w0; my_nw = nw; }
+            w0 += nw;
+        }
+        if (NW < n_mlp) { my_ie = -2; }   // (fewer waves than engines: not launched that way)
+    }
+    // scaled inputs (conversion.py:75-77) of every MLP engine, zero-padded to a multiple of 4 columns
+    const int nin0 = (o.n_x + 3) & ~3;
+    for (int ie = 0; ie < 3; ++ie) {
         const DlObsDev::Engine& e = o.eng[ie];
-        if (e.type < 0) continue;
-        double* cur = buf0;
-        double* nxt = buf1;
-        if (e.type == 0) {
-            // scaled inputs (conversion.py:75-77), zero-padded to a multiple of 4 columns
-            const int nin0 = (o.n_x + 3) & ~3;
-            for (int idx = tid; idx < DL_EB_PTS * nin0; idx += NTHR) {
-                int pt = idx / nin0, i = idx - pt * nin0;
-                cur[pt * LD + i] = i < o.n_x ? (x[pt * DL_MAX_X + i] - e.xlo[i]) * e.xinv[i] : 0.;
-            }
-            __syncthreads();
-            const double* w = e.weights;
-            for (int layer = 0; layer < e.n_layers; ++layer) {
+        if (e.type != 0) continue;
+        double* cur = bufs + (size_t)ie * 2 * DL_EB_PTS * LD;
+        for (int idx = tid; idx < DL_EB_PTS * nin0; idx += NTHR) {
+            int pt = idx / nin0, i = idx - pt * nin0;
+            cur[pt * LD + i] = i < o.n_x ? (x[pt * DL_MAX_X + i] - e.xlo[i]) * e.xinv[i] : 0.;
+        }
+    }
+    __syncthreads();
+    {
+        const DlObsDev::Engine& e = o.eng[my_ie >= 0 ? my_ie : 0];
+        double* cur = bufs + (size_t)(my_ie >= 0 ? my_ie : 0) * 2 * DL_EB_PTS * LD;
+        double* nxt = cur + DL_EB_PTS * LD;
+        const double* w = e.weights;
+        for (int layer = 0; layer < max_layers; ++layer) {
+            if (my_ie >= 0 && layer < e.n_layers) {
                 const int nin = e.widths[layer], nout = e.widths[layer + 1];
                 const bool last = (layer == e.n_layers - 1);
-                const bool activate = !(last && ie != 0);   // the table engine stops after its last HIDDEN layer (its final linear layer is folded on the host)
+                const bool activate = !(last && my_ie != 0);   // the table engine stops after its last HIDDEN layer (its final linear layer is folded on the host)
                 const int ksteps = (nin + 3) / 4, tiles = (nout + 15) / 16, nout4 = (nout + 3) & ~3;
-                for (int t = wave; t < tiles; t += NTHR / 64) {
+                for (int t = wave - my_w0; t < tiles; t += my_nw) {
                     const int oc = 16 * t + col;
-                    dl_eb_double4 acc = {0., 0., 0., 0.};
-                    for (int ks0 = 0; ks0 < ksteps; ks0 += 8) {   // eight k-steps of weight loads in flight (each is an L2 round trip otherwise)
-                        double bv[8], av[8];
+                    dl_eb_double4 acc = {0., 0., 0., 0.}, acc2 = {0., 0., 0., 0.};   // two chains: a dependent MFMA waits 64 cycles
+                    for (int ks0 = 0; ks0 < ksteps; ks0 += 16) {   // sixteen k-steps of weight loads in flight: one L2 round trip per tile for layers up to 64 inputs
+                        double bw[16], av[16];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
+                        for (int u = 0; u < 16; ++u) {
                             const int k = 4 * (ks0 + u) + g;
-                            bv[u] = (ks0 + u < ksteps && k < nin && oc < nout) ? w[(size_t)k * nout + oc] : 0.;   // B[k][output unit]
+                            bw[u] = (ks0 + u < ksteps && k < nin && oc < nout) ? w[(size_t)k * nout + oc] : 0.;   // B[k][output unit]
                             av[u] = (ks0 + u < ksteps) ? cur[col * LD + k] : 0.;                                  // A[point = lane & 15][k]   (columns >= nin are zero)
                         }
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+                        for (int u = 0; u < 16; u += 2) {
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bw[u], acc, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], bw[u + 1], acc2, 0, 0, 0);
+                        }
                     }
+                    acc += acc2;
                     const double bias = oc < nout ? w[(size_t)nin * nout + oc] : 0.;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {       // accumulator register r = out[point g + 4 r][oc]
@@ -89,36 +113,43 @@ __device__ __forceinline__ void dl_eb_forward(const DlObsDev& o, const double* _
                         if (oc < nout4) nxt[(g + 4 * r) * LD + oc] = oc < nout ? v : 0.;
                     }
                 }
-                __syncthreads();
                 w += (size_t)nin * nout + nout;
                 double* tmp = cur; cur = nxt; nxt = tmp;
             }
-            if (ie != 0) {
-                if (tid < DL_EB_PTS) scal[tid * 4 + ie] = cur[tid * LD] * e.yscale + e.ylo;   // conversion.py:79 (inverse scaler)
-            } else {
-                basis = cur;
-                if (tid < DL_EB_PTS) basis[tid * LD + o.n_basis - 1] = 1.;                    // bias row of the folded final layer
-            }
-            __syncthreads();
-        } else {
-            // Taylor: monomials prod_p (x_p - c_p)^powers[t, p] (emulators/__init__.py:471-507)
-            for (int idx = tid; idx < DL_EB_PTS * e.n_terms; idx += NTHR) {
-                int pt = idx / e.n_terms, t = idx - pt * e.n_terms;
-                double mon = 1.;
-                for (int p = 0; p < o.n_x; ++p) mon *= dl_ipow(x[pt * DL_MAX_X + p] - e.center[p], (int)e.powers[(size_t)t * o.n_x + p]);
-                nxt[pt * LD + t] = mon;
-            }
-            __syncthreads();
-            if (ie != 0) {
-                if (tid < DL_EB_PTS) {
-                    double sum = 0.;
-                    for (int t = 0; t < e.n_terms; ++t) sum = fma(e.coef[t], nxt[tid * LD + t], sum);
-                    scal[tid * 4 + ie] = sum;
-                }
-            } else basis = nxt;
             __syncthreads();
         }
     }
+    // results of the MLP engines: scalar engines -> scal (inverse scaler, conversion.py:79); table basis stays in LDS
+    double* basis = bufs;
+    for (int ie = 0; ie < 3; ++ie) {
+        const DlObsDev::Engine& e = o.eng[ie];
+        if (e.type != 0) continue;
+        double* fin = bufs + (size_t)ie * 2 * DL_EB_PTS * LD + ((e.n_layers & 1) ? DL_EB_PTS * LD : 0);   // the buffer the last layer wrote
+        if (ie != 0) { if (tid < DL_EB_PTS) scal[tid * 4 + ie] = fin[tid * LD] * e.yscale + e.ylo; }
+        else { basis = fin; if (tid < DL_EB_PTS) basis[tid * LD + o.n_basis - 1] = 1.; }                    // bias row of the folded final layer
+    }
+    // Taylor engines: monomials prod_p (x_p - c_p)^powers[t, p] (emulators/__init__.py:471-507)
+    for (int pass = 0; pass < 3; ++pass) {
+        const int ie = pass == 2 ? 0 : pass + 1;
+        const DlObsDev::Engine& e = o.eng[ie];
+        if (e.type != 1) continue;
+        double* nxt = bufs + (size_t)ie * 2 * DL_EB_PTS * LD;
+        for (int idx = tid; idx < DL_EB_PTS * e.n_terms; idx += NTHR) {
+            int pt = idx / e.n_terms, t = idx - pt * e.n_terms;
+            double mon = 1.;
+            for (int p = 0; p < o.n_x; ++p) mon *= dl_ipow(x[pt * DL_MAX_X + p] - e.center[p], (int)e.powers[(size_t)t * o.n_x + p]);
+            nxt[pt * LD + t] = mon;
+        }
+        __syncthreads();
+        if (ie != 0) {
+            if (tid < DL_EB_PTS) {
+                double sum = 0.;
+                for (int t = 0; t < e.n_terms; ++t) sum = fma(e.coef[t], nxt[tid * LD + t], sum);
+                scal[tid * 4 + ie] = sum;
+            }
+        } else basis = nxt;
+    }
+    __syncthreads();
     // bias monomials and their derivatives w.r.t. the solved parameters: one thread per point
     if (tid < DL_EB_PTS) {
         int64_t b = p0 + tid < B ? p0 + tid : B - 1;

@@ -66,6 +66,27 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
         // monomial m0 + i, clamped to the last one in the short group (its accumulator is ignored): the load count is the same on every path
 #pragma unroll
         for (int i = 0; i < DL_FG_MG; ++i) { int m = m0 + i < DL_FG_NM ? m0 + i : DL_FG_NM - 1; bcur[i] = gw[(size_t)(0 * DL_FG_NM + m) * 64]; }
+        if (GRAM) {
+            // TWO steps of the operand in flight (the carried rows live in LDS in this variant, which frees the registers for it): a 16-point workgroup has its CU
+            // to itself, so the bytes in flight per wave are what the L2 round trip is divided by -- with one step (10 KB) the waves were parked half of their life
+            dl_fg_double2 bnx2[DL_FG_MG];
+            const int q1 = 1 < nq ? 1 : nq - 1;
+#pragma unroll
+            for (int i = 0; i < DL_FG_MG; ++i) { int m = m0 + i < DL_FG_NM ? m0 + i : DL_FG_NM - 1; bnxt[i] = gw[(size_t)(q1 * DL_FG_NM + m) * 64]; }
+            for (int q = 0; q < nq; ++q) {
+                const int qn = q + 2 < nq ? q + 2 : nq - 1;
+#pragma unroll
+                for (int i = 0; i < DL_FG_MG; ++i) { int m = m0 + i < DL_FG_NM ? m0 + i : DL_FG_NM - 1; bnx2[i] = gw[(size_t)(qn * DL_FG_NM + m) * 64]; }
+                const dl_fg_double2 a = *reinterpret_cast<const dl_fg_double2*>(arow + 8 * q);
+#pragma unroll
+                for (int i = 0; i < DL_FG_MG; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bcur[i].x, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bcur[i].y, acc[i], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < DL_FG_MG; ++i) { bcur[i] = bnxt[i]; bnxt[i] = bnx2[i]; }
+            }
+        } else {
         for (int q = 0; q < nq; ++q) {
             const int qn = q + 1 < nq ? q + 1 : q;
 #pragma unroll
@@ -78,6 +99,7 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
             }
 #pragma unroll
             for (int i = 0; i < DL_FG_MG; ++i) bcur[i] = bnxt[i];
+        }
         }
         // epilogue: accumulator register rr of lane (col, g) = U[point g + 4 rr][m][column jb * 16 + col]; contract with the monomial rows of that point.
         // The first six rows of a point are carried in registers across the two monomial groups and stored once (writing partial rows and adding to them
@@ -102,12 +124,21 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
                 for (int u = 0; u < 6; ++u) {
                     const int r = r0 + u;
                     if (r < R && p0 + pt < B) {
-                        double v = (in_regs && mg == 1) ? outv[rr][u] + old[rr][u] : old[rr][u];
+                        double v;
+                        if (GRAM) {   // (r = u: R <= 6) the partial row of the first monomial group waits in its place in X
+                            double* xv = gr->x + ((size_t)pt * gr->xr + gr->row_of[u]) * DL_FG_XLD + jb * 16 + col;
+                            v = mg == 1 ? *xv : 0.;
+#pragma unroll
+                            for (int i = 0; i < DL_FG_MG; ++i)
+                                if (m0 + i < DL_FG_NM) v = fma(mono[r * DL_FG_MONO_LD + m0 + i], acc[i][rr], v);
+                            *xv = mg == 1 ? v + gr->cst[u][jb * 16 + col] : v;
+                            continue;
+                        }
+                        v = (in_regs && mg == 1) ? outv[rr][u] + old[rr][u] : old[rr][u];
 #pragma unroll
                         for (int i = 0; i < DL_FG_MG; ++i)
                             if (m0 + i < DL_FG_NM) v = fma(mono[r * DL_FG_MONO_LD + m0 + i], acc[i][rr], v);
                         if (in_regs && mg == 0) outv[rr][u] = v;
-                        else if (GRAM) gr->x[((size_t)pt * gr->xr + gr->row_of[u]) * DL_FG_XLD + jb * 16 + col] = v + gr->cst[u][jb * 16 + col];   // (r = u: R <= 6)
                         else out[((size_t)(p0 + pt) * R + r) * ldo + jb * 16 + col] = v;
                     }
                 }

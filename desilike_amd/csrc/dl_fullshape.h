@@ -986,7 +986,7 @@ enum { DL_EM_X = 0, DL_EM_BUF0 = DL_MAX_X, DL_EM_BUF1 = DL_EM_BUF0 + DL_MAX_WIDT
 DL_HD size_t dl_emu_shared_doubles(int n_var) { return DL_EM_MONO + (size_t)(1 + n_var) * DL_N_MONO; }
 
 DL_HD double dl_activation(int act, double v) {
-    if (act == 0) return v / (1. + exp(-v));      // silu, conversion.py:29
+    if (act == 0) return v * dl_rcp(1. + exp(-v));  // silu, conversion.py:29 (reciprocal by Newton steps: to rounding, a third of the division's instructions)
     if (act == 1) return v > 0. ? v : 0.;         // relu, conversion.py:31
     return tanh(v);                                // tanh, conversion.py:33
 }
