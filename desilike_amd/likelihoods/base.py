@@ -340,8 +340,7 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         if current != getattr(self, '_params_generation', None):
             signature = tuple((param.name, repr(param.__getstate__())) for param in self._all_params)
             if signature != getattr(self, '_params_signature', signature):
-                for ctx in self._contexts.values(): ctx.close()
-                self._contexts = {}
+                self._contexts = {}   # (dropped, not closed: a device-resident ensemble may still hold one; unreferenced contexts free their device memory themselves)
             self._params_signature, self._params_generation = signature, generation()
 
     def _get_context(self, fixed_values=None):
