@@ -635,17 +635,46 @@ __device__ __forceinline__ double dl_readlane(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+// the same for FOUR systems per wavefront (lanes 16 q .. 16 q + 15 hold system q): the value of lane j of the caller's own group of 16 (ds_bpermute)
+// (DPP row_newbcast: lane j of every row of 16 lanes to the whole row, at register speed -- j is a compile-time constant after unrolling; ds_bpermute, the
+//  generic shuffle, costs an LDS round trip per exchange on the dependent chain of the factorisation)
+__device__ __forceinline__ double dl_grouplane(double v, int j) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (j) {
+        case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 0, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 0, 0xf, 0xf, false); break;
+        case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 1, 0xf, 0xf, false); break;
+        case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 2, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 2, 0xf, 0xf, false); break;
+        case 3: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 3, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 3, 0xf, 0xf, false); break;
+        case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 4, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 4, 0xf, 0xf, false); break;
+        case 5: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 5, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 5, 0xf, 0xf, false); break;
+        case 6: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 6, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 6, 0xf, 0xf, false); break;
+        case 7: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 7, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 7, 0xf, 0xf, false); break;
+        case 8: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 8, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 8, 0xf, 0xf, false); break;
+        case 9: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 9, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 9, 0xf, 0xf, false); break;
+        case 10: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 10, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 10, 0xf, 0xf, false); break;
+        case 11: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 11, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 11, 0xf, 0xf, false); break;
+        case 12: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 12, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 12, 0xf, 0xf, false); break;
+        case 13: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 13, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 13, 0xf, 0xf, false); break;
+        case 14: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 14, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 14, 0xf, 0xf, false); break;
+        case 15: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + 15, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + 15, 0xf, 0xf, false); break;
+        default: break;
+    }
+    return __hiloint2double(hi, lo);
+}
+
 // Cholesky A = C C^T of the SPD matrix whose row `lane` is a[0 .. 15] (only the leading m x m block matters; rows >= m must be unit vectors).
 // On return a[] holds row `lane` of C (lower part) and invc[j] = 1 / C[j][j] (uniform); returns log det A; ok = false if a pivot is not positive.
 // The pivots form one dependent chain: per step only a reciprocal square root sits on it (no division, no logarithm -- the log-determinant is taken
 // afterwards, one pivot per lane in parallel).
+// PACK: four systems per wavefront, `lane` = lane within the group of 16 (0 .. 15), rows exchanged with dl_grouplane; the returns are then per group.
+template <bool PACK = false>
 __device__ __forceinline__ double dl_lane_cholesky(double (&a)[16], double (&invc)[16], int m, int lane, bool& ok) {
     double dmine = 1.;   // pivot of this lane's own row
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         invc[j] = 1.;
         if (j < m) {
-            double djj = dl_readlane(a[j], j);
+            double djj = PACK ? dl_grouplane(a[j], j) : dl_readlane(a[j], j);
             if (!(djj > 0.)) { ok = false; djj = 1.; }
             const double inv = 1. / sqrt(djj);
             invc[j] = inv;
@@ -653,13 +682,13 @@ __device__ __forceinline__ double dl_lane_cholesky(double (&a)[16], double (&inv
             const double cij = (lane > j) ? a[j] * inv : (lane == j ? djj * inv : 0.);
             a[j] = cij;
 #pragma unroll
-            for (int k = j + 1; k < 16; ++k) a[k] -= cij * dl_readlane(cij, k);   // A[i][k] -= C[i][j] C[k][j]
+            for (int k = j + 1; k < 16; ++k) a[k] -= cij * (PACK ? dl_grouplane(cij, k) : dl_readlane(cij, k));   // A[i][k] -= C[i][j] C[k][j]
         }
     }
     const double lg = log(dmine);   // log det A = sum_j log d_jj
     double logdet = 0.;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) if (j < m) logdet += dl_readlane(lg, j);
+    for (int j = 0; j < 16; ++j) if (j < m) logdet += PACK ? dl_grouplane(lg, j) : dl_readlane(lg, j);
     return logdet;
 }
 
@@ -691,7 +720,7 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
         b = 16 * (xcd + 8 * (r >> 2)) + 4 * (r & 3) + wave;
     }
     post_mode &= 0xff;
-    const bool active = b < B;
+    bool active = b < B;
     if (!active) b = B - 1;   // spare waves of the last workgroup recompute the last point (the barrier below is common) and store nothing
     const int ns = mg.n_s;
     const double* row0 = dtilde + (size_t)b * rows_per_point * ld;
@@ -709,6 +738,9 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
         lp += dl_prior_logpdf(pr, x);
     }
     __shared__ double gram_lds[4][STAGED ? 2 : 16 * 16];   // (staged variant: G and the Cholesky rows reuse the wave's staging area)
+    __shared__ double pk_lp[4];       // hand-over of the waves' points to the wavefront that solves all four (LANES)
+    __shared__ long long pk_b[4];
+    __shared__ int pk_flags[4];
     double* Gw = gram_lds[wave];
     double* Cw = nullptr;
     if (LANES) {
@@ -787,9 +819,14 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
 #pragma unroll
             for (int r = 0; r < 4; ++r) Gw[(g + 4 * r) * 16 + xr] = acc[r];
         }
+        // The solve below runs the FOUR points of the workgroup in ONE wavefront, 16 lanes each (it needs 16 lanes per point: with a wavefront per point three
+        // quarters of every instruction were idle lanes, and the kernel was bound by the issue of those instructions): what the other waves know goes through LDS
+        lp = dl_wave_sum(lp);
+        nan_in = __any(nan_in);
+        if (lane == 0) { pk_lp[wave] = lp; pk_b[wave] = (long long)b; pk_flags[wave] = (nan_in ? 1 : 0) | (active ? 2 : 0); }
         __syncthreads();
         DL_FM_STAMP(2)
-        // (the lane-parallel solve below reads G from LDS)
+        if (wave != 0) return;
     } else if (!LANES) {
     // per-lane slices of dt and of every Tt_s (n <= 64 * DL_MARG_NJ)
     double dj[DL_MARG_NJ];
@@ -839,64 +876,71 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
         }
     }
     }
-    lp = dl_wave_sum(lp);
-    nan_in = __any(nan_in);
+    if (!LANES) { lp = dl_wave_sum(lp); nan_in = __any(nan_in); }
     if (LANES) {
-        // ---- lane-parallel solve (lane i <-> solved parameter i) ----
-        const double* G = Gw;
+        // ---- lane-parallel solve, four points per wavefront: lanes 16 q + i <-> point q of the workgroup, solved parameter i ----
+        const int q = lane >> 4, li = lane & 15;
         __shared__ double chol_lds[4][STAGED ? 2 : 16 * 16];
-        double* Cm = STAGED ? Cw : chol_lds[wave];
+        const double* G;
+        double* Cm;
+        if (STAGED && gram == nullptr) {
+            extern __shared__ __attribute__((aligned(16))) double dl_fm_dyn[];
+            const int rows = 1 + ns, n4 = 4 * ((n + 3) / 4), stride = n4 + 4;
+            const int region = rows * stride > 512 ? rows * stride : 512;
+            G = dl_fm_dyn + (size_t)q * region; Cm = dl_fm_dyn + (size_t)q * region + 256;
+        } else { G = gram_lds[q]; Cm = chol_lds[q]; }
+        lp = pk_lp[q]; b = (int64_t)pk_b[q];
+        const bool nan_q = (pk_flags[q] & 1) != 0;
+        active = (pk_flags[q] & 2) != 0;
         double prec_i = 0., x0_i = 0., loc_i = 0.;
         int marg_i = 0;
 #pragma unroll
-        for (int s = 0; s < DL_MAX_SOLVED; ++s) if (s == lane) { prec_i = mg.prec[s]; x0_i = mg.x0[s]; loc_i = mg.loc[s]; marg_i = mg.is_marg[s]; }
-        const bool mine = lane < ns;
+        for (int s = 0; s < DL_MAX_SOLVED; ++s) if (s == li) { prec_i = mg.prec[s]; x0_i = mg.x0[s]; loc_i = mg.loc[s]; marg_i = mg.is_marg[s]; }
+        const bool mine = li < ns;
         // A = -H = Tt Tt^T + diag(prec) (SPD); rhs = g = -(Tt dt) - (x0 - loc) prec; dx = A^-1 g
         double a[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = (mine && k < ns) ? G[(1 + lane) * 16 + 1 + k] + (k == lane ? prec_i : 0.) : (k == lane ? 1. : 0.);
-        double gi = mine ? -G[1 + lane] - (x0_i - loc_i) * prec_i : 0.;
+        for (int k = 0; k < 16; ++k) a[k] = (mine && k < ns) ? G[(1 + li) * 16 + 1 + k] + (k == li ? prec_i : 0.) : (k == li ? 1. : 0.);
+        double gi = mine ? -G[1 + li] - (x0_i - loc_i) * prec_i : 0.;
         bool ok = true;
         DL_FM_STAMP(3)
         double invc[16];
-        const double logdet_all = dl_lane_cholesky(a, invc, ns, lane, ok);
+        const double logdet_all = dl_lane_cholesky<true>(a, invc, ns, li, ok);
         DL_FM_STAMP(4)
         // forward substitution C y = g
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (j < ns) {
-                const double yj = dl_readlane(gi, j) * invc[j];
-                if (lane > j) gi -= a[j] * yj; else if (lane == j) gi = yj;
+                const double yj = dl_grouplane(gi, j) * invc[j];
+                if (li > j) gi -= a[j] * yj; else if (li == j) gi = yj;
             }
         }
         // backward substitution C^T dx = y needs column entries C[j][i]: rows go through LDS (same wave: LDS operations of a wave execute in order)
-        if (lane < 16) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) Cm[lane * 16 + k] = a[k];
-        }
+        for (int k = 0; k < 16; ++k) Cm[li * 16 + k] = a[k];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 15; j >= 0; --j) {
             if (j < ns) {
-                const double xj = dl_readlane(gi, j) * invc[j];
-                if (lane < j) gi -= Cm[j * 16 + (lane & 15)] * xj; else if (lane == j) gi = xj;
+                const double xj = dl_grouplane(gi, j) * invc[j];
+                if (li < j) gi -= Cm[j * 16 + li] * xj; else if (li == j) gi = xj;
             }
         }
         const double dxi = mine ? gi : 0.;
         // 1/2 dx H_L dx + g_L dx  (likelihoods/base.py:385-386), H_L = -Tt Tt^T, g_L = -Tt dt
         double rowdot = 0.;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) if (t < ns) rowdot += (mine ? G[(1 + lane) * 16 + 1 + t] : 0.) * dl_readlane(dxi, t);
+        for (int t = 0; t < 16; ++t) if (t < ns) rowdot += (mine ? G[(1 + li) * 16 + 1 + t] : 0.) * dl_grouplane(dxi, t);
         const double xs = x0_i + dxi;
-        const double quad_i = dxi * rowdot, lin_i = mine ? G[1 + lane] * dxi : 0.;
+        const double quad_i = dxi * rowdot, lin_i = mine ? G[1 + li] * dxi : 0.;
         const double lps_i = mine ? -0.5 * (xs - loc_i) * (xs - loc_i) * prec_i : 0.;   // 363-364 with parameter.py:2007 (0 for flat priors: prec = 0)
         double quad = 0., lin = 0., lps = 0.;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) if (t < ns) { quad += dl_readlane(quad_i, t); lin += dl_readlane(lin_i, t); lps += dl_readlane(lps_i, t); }   // fixed order
-        if (mine && active && solved) solved[(size_t)b * ns + lane] = xs;
+        for (int t = 0; t < 16; ++t) if (t < ns) { quad += dl_grouplane(quad_i, t); lin += dl_grouplane(lin_i, t); lps += dl_grouplane(lps_i, t); }   // fixed order
+        if (mine && active && solved) solved[(size_t)b * ns + li] = xs;
         if (mine && active && hessian) {   // likelihood Hessian H_L = -Tt Tt^T w.r.t. the solved parameters (derived output, likelihoods/base.py:388-390)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) if (k < ns) hessian[((size_t)b * ns + lane) * ns + k] = -G[(1 + lane) * 16 + 1 + k];
+            for (int k = 0; k < 16; ++k) if (k < ns) hessian[((size_t)b * ns + li) * ns + k] = -G[(1 + li) * 16 + 1 + k];
         }
         double ll = -0.5 * G[0] - 0.5 * quad - lin;
         // -1/2 logdet(-H[marg, marg]) (394-404); all-marg: reuse the Cholesky above, else factor the compacted sub-block
@@ -904,27 +948,27 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
         else if (mg.n_marg > 0) {
             int pos_i = 0;
 #pragma unroll
-            for (int s = 0; s < DL_MAX_SOLVED; ++s) if (s < lane && s < ns && mg.is_marg[s]) pos_i++;
+            for (int s = 0; s < DL_MAX_SOLVED; ++s) if (s < li && s < ns && mg.is_marg[s]) pos_i++;
             __builtin_amdgcn_wave_barrier();
             if (mine && marg_i) {
                 int pos_k = 0;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    if (k < ns && mg.is_marg[k]) { Cm[pos_i * 16 + pos_k] = G[(1 + lane) * 16 + 1 + k] + (k == lane ? prec_i : 0.); pos_k++; }
+                    if (k < ns && mg.is_marg[k]) { Cm[pos_i * 16 + pos_k] = G[(1 + li) * 16 + 1 + k] + (k == li ? prec_i : 0.); pos_k++; }
                 }
             }
             __builtin_amdgcn_wave_barrier();
             const int nm = mg.n_marg;
             double sub[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) sub[k] = (lane < nm && k < nm) ? Cm[(lane & 15) * 16 + k] : (k == lane ? 1. : 0.);
+            for (int k = 0; k < 16; ++k) sub[k] = (li < nm && k < nm) ? Cm[li * 16 + k] : (k == li ? 1. : 0.);
             double invs[16];
-            ll -= 0.5 * dl_lane_cholesky(sub, invs, nm, lane, ok);
+            ll -= 0.5 * dl_lane_cholesky<true>(sub, invs, nm, li, ok);
         }
-        if (lane == 0 && active) {
+        if (li == 0 && active) {
             const double lptot = lp + lps;
             int st = DL_ST_OK;
-            if (nan_in) st = DL_ST_NAN_INPUT;
+            if (nan_q) st = DL_ST_NAN_INPUT;
             else if (lp == -inf) st = DL_ST_OUT_OF_PRIOR;
             else if (!ok || !(ll == ll) || ll == inf || ll == -inf) st = DL_ST_NONFINITE;
             if (loglike) loglike[b] = post_mode ? (st == DL_ST_OK ? ll + lptot : -inf) : ll;
