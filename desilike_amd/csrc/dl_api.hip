@@ -552,7 +552,7 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
                                 logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr, post_mode, stream,
                                 ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data());
         } else if (chi2_big) {
-            dl_launch_window_gemm_dma_chi2(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad, stream);
+            dl_launch_window_gemm_dma_chi2(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad, stream, ctx->n_white);
             part_tiles = dl_gemm_dma_chi2_parts(ctx->N_pad);
         } else if (feat_path) {
             // residual rows already in delta_ws (one slab, bias added by the finalize kernels)
@@ -566,7 +566,7 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
             slab_stride = (int64_t)nb * R * ctx->N_pad;
             fin_bias = ctx->bias_white_dev;
             dl_launch_window_gemm_tiled(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->delta_ws, slab_stride, ctx->N_pad, nb * R, ctx->N_pad, ctx->K_pad, n_slabs, cps,
-                                        stream);
+                                        stream, ctx->n_white);
         }
         prof_phase(2);
         if (chi2_path && chi2_fused) {
@@ -650,7 +650,7 @@ int dl_eval_fisher(dl_ctx* ctx, const double* centers_dev, const double* steps_d
                 n_slabs = dl_gemm_tiled_splits(nb, ctx->N_pad, ctx->K_pad, &cps);
                 slab_stride = (int64_t)nb * ctx->N_pad;
                 bias = ctx->bias_white_dev;
-                dl_launch_window_gemm_tiled(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->delta_ws, slab_stride, ctx->N_pad, nb, ctx->N_pad, ctx->K_pad, n_slabs, cps, stream);
+                dl_launch_window_gemm_tiled(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->delta_ws, slab_stride, ctx->N_pad, nb, ctx->N_pad, ctx->K_pad, n_slabs, cps, stream, ctx->n_white);
             }
         }
         dl_launch_fisher(ctx->delta_ws, ctx->N_pad, ctx->n_white, n_slabs, slab_stride, bias, steps, P, nc, hessian_dev ? hessian_dev + (size_t)b0 * P * P : nullptr,

@@ -32,7 +32,7 @@ typedef double dl_gd_double4 __attribute__((ext_vector_type(4)));
 template <bool CHI2>
 __global__ __launch_bounds__(64 * DL_GD_WAVES) void dl_window_gemm_dma_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
                                                                  double* __restrict__ slabs, int64_t slab_stride, int64_t ldc, int M, int panels_per_split, int n_panels,
-                                                                 const double* __restrict__ bias) {
+                                                                 const double* __restrict__ bias, int n_live) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
@@ -63,13 +63,17 @@ __global__ __launch_bounds__(64 * DL_GD_WAVES) void dl_window_gemm_dma_kernel(co
     const int sr = r16 & 3, s4 = sr << 2, gh = g >> 1;
     const double* la = lds + ((wm * 32) / 4 + (r16 >> 2)) * DL_GD_PLD + sr * 32 + (g & 1);                       // A tile i: + 4 i pieces
     const double* lw = lds + (DL_GD_M / 4 + (wn * 16 * DL_GD_TJ) / 4 + (r16 >> 2)) * DL_GD_PLD + sr * 32 + (g & 1);   // Wt tile j: + 4 j pieces
+    // columns >= n_live are padding (all-zero rows of Wt: 60 data points padded to the 128-wide tile): a wave whose columns are all padding stages its pieces
+    // and meets the barriers like the others, but issues no MFMA -- the accumulators stay zero, which is the product.  (The waves of a column group sit on the
+    // same SIMDs as their live twins: the MFMA work per SIMD halves with half of the tile live.)
+    const bool live = n0 + wn * 16 * DL_GD_TJ < n_live;
     dl_gd_double4 acc[2][DL_GD_TJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < DL_GD_TJ; ++j) acc[i][j] = (dl_gd_double4){0., 0., 0., 0.};
 #define DL_GD_MULTIPLY(p)                                                                                                         \
-    {   const int bo = (((p) - pa) % DL_GD_NBUF) * DL_GD_BUF;                                                                     \
+    if (live) {   const int bo = (((p) - pa) % DL_GD_NBUF) * DL_GD_BUF;                                                           \
         _Pragma("unroll") for (int ks = 0; ks < DL_GD_KP / 4; ++ks) {                                                             \
             const int off = bo + ((((2 * ks) ^ s4) + gh) << 1);                                                                   \
             const double a0 = la[off], a1 = la[off + 4 * DL_GD_PLD];                                                              \

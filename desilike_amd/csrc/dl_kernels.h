@@ -46,7 +46,7 @@ void dl_launch_transform(double* flat, int64_t ld, const double* data, const int
 // tiled split-K variant: writes n_splits partial slabs (no bias); N_pad multiple of 128, K_pad multiple of 16
 int dl_gemm_tiled_splits(int64_t M, int N_pad, int K_pad, int* chunks_per_split);
 void dl_launch_window_gemm_tiled(const double* A, int64_t lda, const double* Wt, int64_t ldw, double* slabs, int64_t slab_stride, int64_t ldc, int64_t M, int N_pad, int K_pad,
-                                 int n_splits, int chunks_per_split, hipStream_t stream);
+                                 int n_splits, int chunks_per_split, hipStream_t stream, int n_live = 0);
 // residual of a row = bias (may be null) + sum of the n_slabs partial slabs (slab_stride doubles apart).
 // post_mode (all finalize launchers): write the log-posterior (loglike + logprior, -inf unless status OK: samplers/base.py:185-191) to `loglike`
 void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, int64_t slab_stride, const double* bias, const double* theta, int n_params,
@@ -68,7 +68,7 @@ void dl_launch_feature_gemm(const double* feat, int64_t feat_ld, int64_t feat_of
                             int accumulate, hipStream_t stream);
 // large plain-likelihood batches: LDS-DMA split-K GEMM (one split) with the partial-chi2 epilogue (dl_gemm_dma.h), finished by dl_launch_finalize_part
 int dl_gemm_dma_chi2_parts(int N_pad);
-void dl_launch_window_gemm_dma_chi2(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, hipStream_t stream);
+void dl_launch_window_gemm_dma_chi2(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, hipStream_t stream, int n_live = 0);
 // emulated theories, fused: emulator forward pass (MFMA) and feature GEMM of one observable in one launch (dl_emu_batch.h)
 void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
                                 hipStream_t stream);

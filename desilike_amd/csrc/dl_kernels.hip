@@ -401,7 +401,7 @@ int dl_gemm_tiled_splits(int64_t M, int N_pad, int K_pad, int* chunks_per_split)
 }
 
 void dl_launch_window_gemm_tiled(const double* A, int64_t lda, const double* Wt, int64_t ldw, double* slabs, int64_t slab_stride, int64_t ldc, int64_t M, int N_pad, int K_pad,
-                                 int n_splits, int chunks_per_split, hipStream_t stream) {
+                                 int n_splits, int chunks_per_split, hipStream_t stream, int n_live) {
     static const bool use_dma = !(getenv("DL_GEMM_DMA") && atoi(getenv("DL_GEMM_DMA")) == 0);   // DL_GEMM_DMA=0: register-staged predecessor (diagnostics)
     if (use_dma && chunks_per_split % 2 == 0 && K_pad % DL_GD_KP == 0) {
         dim3 grid((unsigned)((M + DL_GD_M - 1) / DL_GD_M), (unsigned)(N_pad / DL_GD_N), (unsigned)n_splits);
@@ -412,7 +412,7 @@ void dl_launch_window_gemm_tiled(const double* A, int64_t lda, const double* Wt,
             optin_dma = true;
         }
         DL_LAUNCH(dl_window_gemm_dma_kernel<false>, grid, dim3(64 * DL_GD_WAVES), DL_GD_LDS_BYTES, stream, A, lda, Wt, ldw, slabs, slab_stride, ldc, (int)M,
-                           chunks_per_split / 2, K_pad / DL_GD_KP, nullptr);
+                           chunks_per_split / 2, K_pad / DL_GD_KP, nullptr, n_live > 0 ? n_live : N_pad);
         return;
     }
     dim3 grid((unsigned)((M + DL_GT_M - 1) / DL_GT_M), (unsigned)(N_pad / DL_GT_N), (unsigned)n_splits);
@@ -423,12 +423,13 @@ void dl_launch_window_gemm_tiled(const double* A, int64_t lda, const double* Wt,
 
 // split-K GEMM (single split) with the partial-chi2 epilogue: part[M, dl_gemm_dma_chi2_parts(N_pad)]
 int dl_gemm_dma_chi2_parts(int N_pad) { return N_pad / (16 * DL_GD_TJ); }
-void dl_launch_window_gemm_dma_chi2(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, hipStream_t stream) {
+void dl_launch_window_gemm_dma_chi2(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, hipStream_t stream,
+                                    int n_live) {
     dim3 grid((unsigned)((M + DL_GD_M - 1) / DL_GD_M), (unsigned)(N_pad / DL_GD_N), 1);
     static bool optin = false;
     if (!optin) { (void)hipFuncSetAttribute((const void*)dl_window_gemm_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_GD_LDS_BYTES); optin = true; }
     DL_LAUNCH(dl_window_gemm_dma_kernel<true>, grid, dim3(64 * DL_GD_WAVES), DL_GD_LDS_BYTES, stream, A, lda, Wt, ldw, part, (int64_t)0, (int64_t)0, (int)M, K_pad / DL_GD_KP,
-                       K_pad / DL_GD_KP, bias);
+                       K_pad / DL_GD_KP, bias, n_live > 0 ? n_live : N_pad);
 }
 
 // ------------------------------------------------------------------------------------------------
