@@ -19,7 +19,7 @@ struct dl_ctx {
     int device = 0;
     int n_params = 0, n_obs = 0, n_data = 0;
     int n_white = 0;                 // width of the whitened residual rows (= n_data, or more when the observables' row ranges are aligned to 16: see dl_create)
-    int N_pad = 0, K_pad = 0, max_n_t = 0;
+    int N_pad = 0, K_pad = 0, K_live = 0, max_n_t = 0;   // K_live: columns of the theory vector before the padding to whole GEMM panels
     bool any_transform = false;
     bool priors_general = false;     // a prior of a kind beyond uniform / norm is present (dl_prior.h)
     // analytic marginalisation
@@ -186,6 +186,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     ctx->n_data = row;
     int n = ctx->n_data;
     int K = (int)col;
+    ctx->K_live = K;
     ctx->K_pad = round_up(K, 128);   // whole 128-wide panels of the chi2 GEMM (dl_chi2_gemm.h); padding columns are zero in both operands
     // ---- precision -> Cholesky factor (likelihoods/base.py:13-17: chi2 = d P d = |L^T d|^2) ----
     const auto& prec = cfg->F("precision");
@@ -550,7 +551,7 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
             dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad,
                                 chi2_fused ? ctx->gemm_counters : nullptr, th, P, ctx->priors_dev, loglike_dev ? loglike_dev + b0 : nullptr,
                                 logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr, post_mode, stream,
-                                ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data());
+                                ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live);
         } else if (chi2_big) {
             dl_launch_window_gemm_dma_chi2(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad, stream, ctx->n_white);
             part_tiles = dl_gemm_dma_chi2_parts(ctx->N_pad);
@@ -845,7 +846,7 @@ int dl_internal_eval_partials(dl_ctx* ctx, const double* theta_dev, int64_t B, c
     static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;
     dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, theta_dev, ctx->n_params, B, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, nullptr, 0, xcd_local ? 32 : 0, ctx->obs_array_dev);
     dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, B, ctx->N_pad, ctx->K_pad, nullptr, theta_dev, ctx->n_params,
-                        ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream, ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data());
+                        ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream, ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live);
     *part = ctx->delta_ws;
     *n_tiles = ctx->N_pad / 16;
     *priors = ctx->priors_dev;

@@ -55,7 +55,7 @@ struct DlChi2Panels {
 template <bool DO_LOAD, bool DO_MMA>
 __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
                                                            const double* __restrict__ bias, double* __restrict__ part, int M, int K_pad, int n_tiles, DlChi2Fin fin,
-                                                           DlChi2Panels panels) {
+                                                           DlChi2Panels panels, int k_live) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
@@ -121,6 +121,15 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
         if (DO_MMA) { _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                               \
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[j], bb[j], acc0, 0, 0, 0);                                                \
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[j], bb[j], acc1, 0, 0, 0); } } }
+    // the last panel of K is partly padding (1200 of 1280 columns: 12 of its 32 k-steps are live): waves whose k-steps are padding skip their MFMAs there
+#define DL_CG_MULTIPLY_LIM(p, lim)                                                                                                   \
+    {   const double* lb = la + ((p) % DL_CG_NBUF) * BUF;                                                                            \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                                             \
+            const int ks = wave + DL_CG_WAVES * j;                                                                                   \
+            if (DO_MMA && ks < (lim)) {                                                                                              \
+                const double a0 = lb[4 * ks], a1 = lb[16 * DL_CG_LD + 4 * ks], bb = lb[32 * DL_CG_LD + 4 * ks];                      \
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bb, acc0, 0, 0, 0);                                                  \
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bb, acc1, 0, 0, 0); } } }
     // iteration p: request panel p + 2 (its buffer held panel p - 1, whose reads every wave retired before the last barrier), read the operands of
     // panel p, multiply, then wait until the wave's own pieces of panel p + 1 have landed (the youngest requests, panel p + 2, stay in flight)
     // and its LDS reads are back; one raw barrier per panel, no vmcnt(0) in the steady loop; the last two panels are peeled (nothing left to request)
@@ -137,8 +146,13 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
         __builtin_amdgcn_s_barrier();
         ++p;
     }
-    DL_CG_MULTIPLY(p)
+    {
+        int lim = (k_live - (p_lo + p) * DL_CG_KP + 3) / 4;        // live k-steps of this (last) panel
+        lim = lim < 0 ? 0 : (lim > DL_CG_KP / 4 ? DL_CG_KP / 4 : lim);
+        DL_CG_MULTIPLY_LIM(p, lim)
+    }
 #undef DL_CG_MULTIPLY
+#undef DL_CG_MULTIPLY_LIM
 #undef DL_CG_DMA
     DL_CG_STAMP(2, __builtin_amdgcn_s_memtime)
     // in-workgroup reduction of the 8 k-slices, then bias, square, sum over the 16 columns

@@ -576,7 +576,7 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
 // ------------------------------------------------------------------------------------------------
 void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, int32_t* counters,
                          const double* theta, int n_params, const double* priors, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream,
-                         const uint8_t* panel_ranges) {
+                         const uint8_t* panel_ranges, int k_live) {
     const int n_tiles = N_pad / DL_CG_N;
     const int64_t mblocks = (M + DL_CG_M - 1) / DL_CG_M;
     const unsigned grid = (unsigned)(8 * n_tiles * ((mblocks + 7) / 8));
@@ -595,7 +595,7 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
     std::memset(&panels, 0, sizeof(panels));
     if (panel_ranges != nullptr && n_tiles <= DL_CG_MAX_TILES)
         for (int t = 0; t < n_tiles; ++t) { panels.lo[t] = panel_ranges[2 * t]; panels.hi[t] = panel_ranges[2 * t + 1]; }
-    DL_LAUNCH((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels);
+    DL_LAUNCH((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad);
     if (fin.stamps) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h((size_t)grid * 8);

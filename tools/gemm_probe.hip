@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
         CHECK(hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES));
         const int ntl = N / DL_CG_N;
         const unsigned grid = 8 * ntl * (((M + DL_CG_M - 1) / DL_CG_M + 7) / 8);
-#define CHI2(L, MM) hipLaunchKernelGGL((dl_chi2_gemm_kernel<L, MM>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, st, A, (int64_t)K, W, (int64_t)K, bias, part, M, K, ntl, DlChi2Fin{}, DlChi2Panels{})
+#define CHI2(L, MM) hipLaunchKernelGGL((dl_chi2_gemm_kernel<L, MM>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, st, A, (int64_t)K, W, (int64_t)K, bias, part, M, K, ntl, DlChi2Fin{}, DlChi2Panels{}, K)
         printf("chi2 GEMM: grid %u, LDS %d B\n", grid, (int)DL_CG_LDS_BYTES);
         timeit("chi2: full", reps, st, [&] { CHI2(true, true); }, false, A, nA);
         timeit("chi2: full, A refilled", reps, st, [&] { CHI2(true, true); }, true, A, nA);
