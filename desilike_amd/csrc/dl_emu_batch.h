@@ -90,6 +90,22 @@ __device__ __forceinline__ void dl_eb_forward(const DlObsDev& o, const double* _
                 for (int t = wave - my_w0; t < tiles; t += my_nw) {
                     const int oc = 16 * t + col;
                     dl_eb_double4 acc = {0., 0., 0., 0.}, acc2 = {0., 0., 0., 0.};   // two chains: a dependent MFMA waits 64 cycles
+                    if (nin == 64 && 16 * t + 16 <= nout) {
+                        // a full tile of a 64-input layer (the hidden layers): straight-line -- one pointer and a constant stride for the sixteen weight loads,
+                        // immediate offsets for the activations.  The general loop below spends ~1000 instructions per tile on predicates and 64-bit addresses
+                        // (3 us per layer for 16 MFMAs).
+                        const double* wp = w + (size_t)g * nout + oc;
+                        const size_t ws = 4 * (size_t)nout;
+                        const double* ap = cur + col * LD + g;
+                        double bw[16], av[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) { bw[u] = wp[u * ws]; av[u] = ap[4 * u]; }
+#pragma unroll
+                        for (int u = 0; u < 16; u += 2) {
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bw[u], acc, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], bw[u + 1], acc2, 0, 0, 0);
+                        }
+                    } else
                     for (int ks0 = 0; ks0 < ksteps; ks0 += 16) {   // sixteen k-steps of weight loads in flight: one L2 round trip per tile for layers up to 64 inputs
                         double bw[16], av[16];
 #pragma unroll
