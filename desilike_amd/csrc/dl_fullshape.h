@@ -809,7 +809,7 @@ DL_HD double dl_rcp(double x) {
 template <int NL>
 DL_HD void dl_bao_phaseB_std(int tid, int nthr, const DlObsDev& o, double* lds) {
     const double qper = lds[DL_BAO_QPER], b1 = lds[DL_BAO_B1];
-    const int n_kin = o.n_kin, n_mu4 = (o.n_mu + 3) & ~3, nm2 = o.n_t - 2;
+    const int n_kin = o.n_kin, nm2 = o.n_t - 2;
     const int reciso = (o.bao_mode & 15) == 1;
     double* out = lds + DL_BAO_PT;
     for (int i = tid; i < n_kin; i += nthr) {
@@ -821,29 +821,41 @@ DL_HD void dl_bao_phaseB_std(int tid, int nthr, const DlObsDev& o, double* lds) 
         double p[NL];
 #pragma unroll
         for (int l = 0; l < NL; ++l) p[l] = 0.;
-        for (int m0 = 0; m0 < n_mu4; m0 += 4) {
+        auto evaluate = [&](int m) {
+            const double* rec = lds + DL_BAO_REC + 12 * m;
+            const double t = lkh + rec[0];
+            int j = (int)t;
+            j = j < 0 ? 0 : (j > nm2 ? nm2 : j);
+            const double u = t - (double)j;
+            const double* c = o.coef_w + 4 * (size_t)j;
+            const double pkw = fma(fma(fma(c[3], u, c[2]), u, c[1]), u, c[0]);                     // [P_dd - P_now](k')
+            const double ca = fma(rec[4], omsk, b1), cb = fma(rec[3], omsk, b1);                   // b1 + f mu'^2 (1 - S(k)), b1 + f mu^2 (1 - S(k))
+            const double Cap = ca * ca * exp(-(kq2 * rec[1]));                                     // bao.py:129-132
+            const double r = dl_rcp(fma(kk2, rec[2], 1.));                                         // bao.py:133
+            return cb * cb * (r * r) * pknow + Cap * pkw;                                          // bao.py:134-136
+        };
+        auto accumulate = [&](int m, double pkmu) {
+            const double* w = lds + DL_BAO_REC + 12 * m + 6;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) p[l] = fma(w[l], pkmu, p[l]);
+        };
+        // four nodes at a time (independent chains), then the remainder by two and by one: the reference's 10 nodes are 4 + 4 + 2, not three groups of four with
+        // two zero-weight evaluations
+        const int n_mu = o.n_mu;
+        int m0 = 0;
+        for (; m0 + 4 <= n_mu; m0 += 4) {
             double pkmu[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double* rec = lds + DL_BAO_REC + 12 * (m0 + q);
-                const double t = lkh + rec[0];
-                int j = (int)t;
-                j = j < 0 ? 0 : (j > nm2 ? nm2 : j);
-                const double u = t - (double)j;
-                const double* c = o.coef_w + 4 * (size_t)j;
-                const double pkw = fma(fma(fma(c[3], u, c[2]), u, c[1]), u, c[0]);                     // [P_dd - P_now](k')
-                const double ca = fma(rec[4], omsk, b1), cb = fma(rec[3], omsk, b1);                   // b1 + f mu'^2 (1 - S(k)), b1 + f mu^2 (1 - S(k))
-                const double Cap = ca * ca * exp(-(kq2 * rec[1]));                                     // bao.py:129-132
-                const double r = dl_rcp(fma(kk2, rec[2], 1.));                                         // bao.py:133
-                pkmu[q] = cb * cb * (r * r) * pknow + Cap * pkw;                                       // bao.py:134-136
-            }
+            for (int q = 0; q < 4; ++q) pkmu[q] = evaluate(m0 + q);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double* w = lds + DL_BAO_REC + 12 * (m0 + q) + 6;
-#pragma unroll
-                for (int l = 0; l < NL; ++l) p[l] = fma(w[l], pkmu[q], p[l]);
-            }
+            for (int q = 0; q < 4; ++q) accumulate(m0 + q, pkmu[q]);
         }
+        if (m0 + 2 <= n_mu) {
+            const double e0 = evaluate(m0), e1 = evaluate(m0 + 1);
+            accumulate(m0, e0); accumulate(m0 + 1, e1);
+            m0 += 2;
+        }
+        if (m0 < n_mu) accumulate(m0, evaluate(m0));
 #pragma unroll
         for (int l = 0; l < NL; ++l)
             if (l < o.n_ell) out[(size_t)l * n_kin + i] = p[l];
