@@ -462,8 +462,13 @@ static int dl_reserve(dl_ctx* ctx, int64_t B) {
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->flat_ws, (size_t)need * ctx->N_pad * sizeof(double)));
     if (ctx->feat_ok) DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->feat_ws, (size_t)need * ctx->feat_ld * sizeof(double)));
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->stencil_ws, (size_t)need * ctx->n_params * sizeof(double)));
-    // the K padding columns of the power buffer are never written by the theory kernel and must be finite
+    // the K padding columns of the power buffer are never written by the theory kernel and must be finite (they meet zeros of the operators); the other
+    // workspaces are zeroed too: recycled device memory holds whatever the previous owner left, and 0 x NaN is NaN
     DL_HIP_CHECK(ctx, hipMemset(ctx->power_ws, 0, (size_t)need * R * ctx->K_pad * sizeof(double)));
+    DL_HIP_CHECK(ctx, hipMemset(ctx->delta_ws, 0, std::max<size_t>(2 * (size_t)need * R, (size_t)need * R + 16384 + 2048) * ctx->N_pad * sizeof(double)));
+    DL_HIP_CHECK(ctx, hipMemset(ctx->flat_ws, 0, (size_t)need * ctx->N_pad * sizeof(double)));
+    if (ctx->feat_ok) DL_HIP_CHECK(ctx, hipMemset(ctx->feat_ws, 0, (size_t)need * ctx->feat_ld * sizeof(double)));
+    DL_HIP_CHECK(ctx, hipMemset(ctx->stencil_ws, 0, (size_t)need * ctx->n_params * sizeof(double)));
     ctx->cap = need;
     return 0;
 }

@@ -791,9 +791,12 @@ DL_HD void dl_bao_phaseA(int tid, int nthr, const DlObsDev& o, const double* th,
     }
 }
 
-// 1 / x to rounding: hardware seed + two Newton steps on the device (5 instructions against ~20 of the IEEE division)
+// 1 / x for x >= 1, to rounding: hardware seed + two Newton steps on the device (6 instructions against ~20 of the IEEE division).  x is clamped to 1e300 first:
+// the Newton step of an infinite x would be inf * 0 (the callers square the result: 1e-600 is the same 0 as 1 / inf^2; a NaN x only comes from NaN inputs, which
+// the finalize kernels flag on their own)
 DL_HD double dl_rcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    x = fmin(x, 1e300);
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.), r, r);
     r = fma(fma(-x, r, 1.), r, r);
@@ -998,7 +1001,7 @@ enum { DL_EM_X = 0, DL_EM_BUF0 = DL_MAX_X, DL_EM_BUF1 = DL_EM_BUF0 + DL_MAX_WIDT
 DL_HD size_t dl_emu_shared_doubles(int n_var) { return DL_EM_MONO + (size_t)(1 + n_var) * DL_N_MONO; }
 
 DL_HD double dl_activation(int act, double v) {
-    if (act == 0) return v * dl_rcp(1. + exp(-v));  // silu, conversion.py:29 (reciprocal by Newton steps: to rounding, a third of the division's instructions)
+    if (act == 0) return v / (1. + exp(-v));      // silu, conversion.py:29
     if (act == 1) return v > 0. ? v : 0.;         // relu, conversion.py:31
     return tanh(v);                                // tanh, conversion.py:33
 }
