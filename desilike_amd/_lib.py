@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libdesilike_amd.so')
+_LIB_PATH = os.environ.get('DL_LIB_PATH') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libdesilike_amd.so')   # DL_LIB_PATH: another build of the same library (A/B runs of a kernel change on one box)
 _lib = None
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)

@@ -4,7 +4,7 @@
 // StretchMove: Goodman & Weare 2010, two half-ensemble updates; the log-posterior of a half is ONE batched call, desilike/samplers/base.py:144-200) runs here as one
 // enqueued sequence per half-step with no host synchronisation:
 //
-//     [accept previous half | permutation | stretch proposals]  ->  dl_eval_logposterior (this rank's share)  ->  ncclAllGather (N > 1)  ->  next ...
+//     [accept previous half | stretch proposals]  ->  dl_eval_logposterior (this rank's share)  ->  ncclAllGather (N > 1)  ->  next ...
 //
 // Walker positions, log-posteriors, acceptance counts and the random number generator live on the device; the host only enqueues and, at the end of a run,
 // drains the chain.  Random numbers are COUNTER-BASED (Philox4x32-10, Salmon et al. 2011): the draw for (iteration, half-step, walker slot) is a pure
@@ -54,15 +54,45 @@ __host__ __device__ inline DlPhilox dl_philox4x32(uint32_t c0, uint32_t c1, uint
 // 53-bit uniform on [0, 1) from two 32-bit words (the construction of numpy's random_sample)
 __host__ __device__ inline double dl_uniform53(uint32_t hi, uint32_t lo) { return ((double)(hi >> 5) * 67108864. + (double)(lo >> 6)) * (1. / 9007199254740992.); }
 
-#define DL_ENS_PRE 4           // results of the pending half-step prefetched per thread (covers nwalkers <= 8 DL_ENS_THREADS)
-#define DL_ENS_THREADS 1024   // one workgroup: ranking the 64-bit keys of the random split is O(nwalkers^2 / threads) LDS reads per thread
+#define DL_ENS_THREADS 1024   // one workgroup
 enum { DL_ENS_STREAM_PERM = 0, DL_ENS_STREAM_MOVE = 1, DL_ENS_STREAM_ACCEPT = 3 };   // + half-step for the last two
+
+// Random split of the ensemble into two halves: position r holds walker F(r), F a keyed bijection of [0, nw) -- four rounds of (odd multiplier, offset) mod 2^m
+// and a right xor-shift, m = bit length of nw - 1, keyed by eight Philox words of the iteration, cycle-walked back into [0, nw).  Every element is a pure function
+// of (seed, iteration, r): nothing is ranked, stored or exchanged (the argsort of random keys this replaces was an O(nw^2) scan on the one CU of the step kernel:
+// 5.7 us of the launch at 512 walkers); the keys of a launch are made on the host and travel in the kernel arguments.  samplers.py CounterRNG.permutation is the
+// NumPy statement of the same map.
+struct DlEnsSplit {
+    uint32_t mul[4], add[4], mask, shift, nw;
+};
+
+DlEnsSplit dl_ens_split(long long iteration, int nw, uint32_t k0, uint32_t k1) {
+    const DlPhilox ka = dl_philox4x32((uint32_t)iteration, (uint32_t)((unsigned long long)iteration >> 32), 0u, DL_ENS_STREAM_PERM, k0, k1);
+    const DlPhilox kb = dl_philox4x32((uint32_t)iteration, (uint32_t)((unsigned long long)iteration >> 32), 1u, DL_ENS_STREAM_PERM, k0, k1);
+    DlEnsSplit f;
+    int m = 1;
+    while (m < 31 && (1u << m) < (uint32_t)nw) ++m;
+    for (int round = 0; round < 4; ++round) { f.mul[round] = ka.x[round] | 1u; f.add[round] = kb.x[round]; }
+    f.mask = (1u << m) - 1u; f.shift = (uint32_t)(m + 1) / 2; f.nw = (uint32_t)nw;
+    return f;
+}
+
+__device__ __forceinline__ int dl_ens_split_at(const DlEnsSplit& f, int r) {
+    uint32_t x = (uint32_t)r;
+    do {
+#pragma unroll
+        for (int round = 0; round < 4; ++round) {
+            x = (x * f.mul[round] + f.add[round]) & f.mask;
+            x ^= x >> f.shift;
+        }
+    } while (x >= f.nw);
+    return (int)x;
+}
 
 struct DlEnsArgs {
     double* coords;        // [nw, P]
     double* logp;          // [nw]
     long long* nacc;       // [nw]
-    int32_t* perm;         // [nw]: first half = walkers updated in half-step 0, second half = half-step 1
     double* prop;          // [half_pad, P] proposals of the pending half-step
     double* factors;       // [half] (P - 1) log z
     double* newlp;         // [half_pad] log-posteriors of the proposals (all ranks' shares after the all-gather)
@@ -76,147 +106,204 @@ struct DlEnsArgs {
     uint32_t k0, k1;
     long long it_acc, it_prop;   // iteration of the half-step to accept / to propose
     int32_t half_acc, half_prop; // 0 / 1, or -1: nothing to accept / propose
+    DlEnsSplit split_acc, split_prop;   // the splits of those two iterations
 };
 
-// One workgroup: the ensemble is a few hundred walkers x <= 64 parameters.  STAGED: positions, log-posteriors and the split live in LDS for the duration of the
-// launch (one coalesced load at the top, one write-back at the end): the dependent global round trips of the phases (split -> positions of a walker and of its
-// partner -> proposal) become LDS accesses (profiles/r02a: 15.5 us per launch on average, 30 us for the launches that draw a split, with the state in global memory).
-// Phases are separated by barriers (memory written before a barrier is visible to the workgroup after it).
-template <bool STAGED>
-__global__ __launch_bounds__(DL_ENS_THREADS) void dl_ensemble_step_kernel(const DlEnsArgs s) {
-#pragma clang fp contract(off)   // the NumPy driver rounds after every operation: no fused multiply-adds here
-    extern __shared__ __attribute__((aligned(16))) unsigned long long dl_ens_lds[];
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int nw = s.nw, half = nw / 2, P = s.P;
-    const int parts = (DL_ENS_THREADS / nw) > 1 ? DL_ENS_THREADS / nw : 1;      // threads that share the ranking of one walker
-    uint32_t* keys = reinterpret_cast<uint32_t*>(dl_ens_lds);                     // [nw] sort keys of the split (the slot is sized for 8 bytes per walker)
-    int* rankpart = reinterpret_cast<int*>(dl_ens_lds + nw);                      // [parts, nw]
-    double* lds_state = reinterpret_cast<double*>(rankpart + (size_t)((parts * nw + 1) & ~1));
-    double* coords = STAGED ? lds_state : s.coords;                               // [nw, P]
-    double* logp = STAGED ? lds_state + (size_t)nw * P : s.logp;                  // [nw]
-    int32_t* perm = STAGED ? reinterpret_cast<int32_t*>(lds_state + (size_t)nw * (P + 1)) : s.perm;   // [nw]
-    const double inf = __builtin_huge_val();
-    // the pending half-step's results are requested first: their round trip overlaps the staging of the state
-    double pre_lp[DL_ENS_PRE], pre_f[DL_ENS_PRE];
-    if (s.half_acc >= 0) {
-#pragma unroll
-        for (int q = 0; q < DL_ENS_PRE; ++q) {
-            const int j = tid + q * nthr;
-            // (deferred finalize: the partial chi2 of the slot are summed now -- their round trip overlaps the staging; pre_lp then holds chi2)
-            pre_lp[q] = j >= half ? 0. : (s.part == nullptr ? s.newlp[j] : dl_chi2_of_parts(s.part + (size_t)j * s.n_tiles, s.n_tiles));
-            pre_f[q] = j < half ? s.factors[j] : 0.;
+// draws of slot j of the half-step to accept: walker and log(u); of the half-step to propose: walker, partner, z and (P - 1) log z
+// (emcee moves/red_blue.py, moves/stretch.py: z ~ g(z) on [1/a, a], partner from the complementary half)
+__device__ __forceinline__ void dl_ens_draw_accept(const DlEnsArgs& s, int j, int half, int& i, double& logu) {
+#pragma clang fp contract(off)
+    i = dl_ens_split_at(s.split_acc, s.half_acc * half + j);
+    const DlPhilox r = dl_philox4x32((uint32_t)s.it_acc, (uint32_t)((unsigned long long)s.it_acc >> 32), (uint32_t)j, DL_ENS_STREAM_ACCEPT + s.half_acc, s.k0, s.k1);
+    logu = log(dl_uniform53(r.x[0], r.x[1]));
+}
+
+__device__ __forceinline__ void dl_ens_draw_move(const DlEnsArgs& s, int j, int half, int& is, int& ic, double& zz, double& factor) {
+#pragma clang fp contract(off)
+    const DlPhilox r = dl_philox4x32((uint32_t)s.it_prop, (uint32_t)((unsigned long long)s.it_prop >> 32), (uint32_t)j, DL_ENS_STREAM_MOVE + s.half_prop, s.k0, s.k1);
+    const double u = dl_uniform53(r.x[0], r.x[1]);
+    const double t = (s.a - 1.) * u + 1.;
+    zz = (t * t) / s.a;
+    factor = (s.P - 1.) * log(zz);
+    ic = dl_ens_split_at(s.split_prop, (1 - s.half_prop) * half + (int)(r.x[2] % (uint32_t)half));
+    is = dl_ens_split_at(s.split_prop, s.half_prop * half + j);
+}
+
+// asynchronous copy of n doubles (16-byte aligned source) into LDS: 16-byte LDS-DMA chunks (global_load_lds_dwordx4: no registers, nothing waits until the
+// workgroup's barrier), lane l of a wavefront writes chunk l of the wavefront's 1 KB slot.  rot_c > 0: rows of rot_c chunks, chunk c of row r lands at position
+// (c + r) % rot_c of the row (threads that walk their own row chunk by chunk then spread over the LDS banks instead of all hitting the same two).
+__device__ __forceinline__ void dl_ens_stage(double* dst, const double* __restrict__ src, int n, int rot_c, int wave, int lane, int nthr) {
+    const int chunks = n >> 1;
+    for (int c0 = wave * 64; c0 < chunks; c0 += nthr) {
+        const int slot = c0 + lane;
+        if (slot < chunks) {
+            int from = slot;
+            if (rot_c > 0) { const int r = slot / rot_c, cp = slot - r * rot_c; int c = cp - r % rot_c; if (c < 0) c += rot_c; from = r * rot_c + c; }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * (size_t)from), (__attribute__((address_space(3))) void*)(dst + 2 * (size_t)c0), 16, 0, 0);
         }
     }
-    if (STAGED) {
-        for (int e = tid; e < nw * P; e += nthr) coords[e] = s.coords[e];
-        for (int e = tid; e < nw; e += nthr) { logp[e] = s.logp[e]; perm[e] = s.perm[e]; }
-        __syncthreads();
+    if ((n & 1) && wave == 0 && lane == 0) dst[n - 1] = src[n - 1];
+}
+
+// One workgroup: the ensemble is a few hundred walkers x <= 64 parameters.  Everything the launch reads -- positions, log-posteriors, the pending proposals, their
+// partial chi2 and the prior table -- is requested at the top as LDS-DMA (one round trip for all of it; with register loads in run-time loops every loop iteration
+// was a round trip of its own: 6 us), the random draws and logarithms of both phases are computed in the shadow of that round trip (accept draws on the first waves,
+// move draws on waves of the other half of the workgroup: different SIMD slots), and the phases after the barrier touch LDS only and end in fire-and-forget stores.
+template <int THREADS, int NB>
+__global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlEnsArgs s) {
+#pragma clang fp contract(off)   // the NumPy driver rounds after every operation: no fused multiply-adds here
+    extern __shared__ __attribute__((aligned(16))) double dl_ens_lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = s.nw, half = nw / 2, P = s.P, n_tiles = s.part != nullptr ? s.n_tiles : 0;
+    double* coords = dl_ens_lds;                                  // [nw, P]
+    double* logp = coords + (size_t)nw * P;                       // [nw]
+    double* prop = logp + nw;                                     // [half, P] pending proposals (the new ones go straight to global memory)
+    double* parts = prop + (((size_t)half * P + 1) & ~(size_t)1); // [half, n_tiles], chunks rotated by the row index
+    double* priors = parts + (size_t)half * n_tiles;              // [P, 5]
+    const double inf = __builtin_huge_val();
+    const bool accepting = s.half_acc >= 0, proposing = s.half_prop >= 0;
+    dl_ens_stage(coords, s.coords, nw * P, 0, wave, lane, nthr);
+    dl_ens_stage(logp, s.logp, nw, 0, wave, lane, nthr);
+    double lp0 = 0., f0 = 0.;
+    if (accepting) {
+        dl_ens_stage(prop, s.prop, half * P, 0, wave, lane, nthr);
+        if (s.part != nullptr) {
+            dl_ens_stage(parts, s.part, half * n_tiles, n_tiles / 2, wave, lane, nthr);
+            for (int e = nthr - 1 - tid; e < 5 * P; e += nthr) priors[e] = s.priors[e];   // (register loads: on the last wavefront, which has no draws to make meanwhile)
+        } else if (tid < half) lp0 = s.newlp[tid];
+        if (tid < half) f0 = s.factors[tid];
     }
-    if (s.half_acc >= 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    // in the shadow of the round trip: the draws of this thread's first slot of either phase
+    const int jp0 = (tid + nthr / 2) % nthr;      // the move phase starts half a workgroup away from the accept phase
+    int i0 = 0, is0 = 0, ic0 = 0;
+    double logu0 = 0., zz0 = 0., fac0 = 0.;
+    if (accepting && tid < half) dl_ens_draw_accept(s, tid, half, i0, logu0);
+    if (proposing && jp0 < half) dl_ens_draw_move(s, jp0, half, is0, ic0, zz0, fac0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (accepting) {
         // accept / reject the pending proposals (emcee moves/red_blue.py: lnpdiff = factors + new_log_prob - log_prob; accepted = log(u) < lnpdiff)
-        const int32_t* set = perm + s.half_acc * half;
-        int q = 0;
-        for (int j = tid; j < half; j += nthr, ++q) {
-            const int i = set[j];
-            const DlPhilox r = dl_philox4x32((uint32_t)s.it_acc, (uint32_t)((unsigned long long)s.it_acc >> 32), (uint32_t)j, DL_ENS_STREAM_ACCEPT + s.half_acc, s.k0, s.k1);
-            const double u = dl_uniform53(r.x[0], r.x[1]);
-            double lp;
+        for (int j = tid; j < half; j += nthr) {
+            int i = i0;
+            double logu = logu0, lp = lp0, fj = f0;
+            if (j != tid) { dl_ens_draw_accept(s, j, half, i, logu); fj = s.factors[j]; if (s.part == nullptr) lp = s.newlp[j]; }
             if (s.part != nullptr) {
-                double ll, lpr;
+                // partial chi2 of the slot, summed in the order of dl_chi2_of_parts
+                const int C = n_tiles / 2;
+                const double* row = parts + (size_t)j * n_tiles;
+                double chi2 = 0.;
+                int cp = j % C;
+                for (int k0 = 0; k0 < C; k0 += 4) {   // (n_tiles is a multiple of 8)
+                    double v[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[2 * k] = row[2 * cp]; v[2 * k + 1] = row[2 * cp + 1]; cp = cp + 1 == C ? 0 : cp + 1; }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) chi2 += v[k];
+                }
+                double ll, lpr, x0[8];
                 int st;
-                const double chi2 = q < DL_ENS_PRE ? pre_lp[q] : dl_chi2_of_parts(s.part + (size_t)j * s.n_tiles, s.n_tiles);
-                dl_finalize_from_chi2(chi2, s.prop + (size_t)j * P, P, s.priors, ll, lpr, st);
+                dl_load_theta8(prop + (size_t)j * P, P, 0, x0);
+                dl_finalize_from_chi2<NB>(chi2, x0, prop + (size_t)j * P, P, priors, ll, lpr, st);
                 lp = st == 0 ? ll + lpr : -inf;          // what dl_eval_logposterior writes (samplers/base.py:185-191)
-            } else lp = q < DL_ENS_PRE ? pre_lp[q] : s.newlp[j];
-            const double fj = q < DL_ENS_PRE ? pre_f[q] : s.factors[j];
+            }
             if (lp != lp) lp = -inf;                     // NaN results count as -inf (samplers/base.py:187-189)
             lp = lp + s.offset;
             const double lnpdiff = (fj + lp) - logp[i];
-            const bool accepted = log(u) < lnpdiff;
-            if (accepted) {
-                for (int p = 0; p < P; ++p) coords[(size_t)i * P + p] = s.prop[(size_t)j * P + p];
-                logp[i] = lp;
-                s.nacc[i] += 1;
+            if (logu < lnpdiff) {
+                for (int p = 0; p < P; ++p) { const double v = prop[(size_t)j * P + p]; coords[(size_t)i * P + p] = v; s.coords[(size_t)i * P + p] = v; }
+                logp[i] = lp; s.logp[i] = lp;
+                (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(s.nacc) + i, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // no return value: nothing waits
             }
         }
         __syncthreads();
-        if (STAGED) {   // write-back of the state the accept step changed
-            for (int e = tid; e < nw * P; e += nthr) s.coords[e] = coords[e];
-            for (int e = tid; e < nw; e += nthr) s.logp[e] = logp[e];
-        }
     }
     if (s.chain != nullptr) {
         for (int e = tid; e < nw * P; e += nthr) s.chain[e] = coords[e];
         if (s.chain_logp != nullptr)
             for (int e = tid; e < nw; e += nthr) s.chain_logp[e] = logp[e];
     }
-    if (s.half_prop < 0) return;
-    if (s.half_prop == 0) {
-        // random split of the ensemble into two halves: walkers ranked by a 32-bit key each = 19 random bits above the walker index (13 bits: distinct keys,
-        // ties of the random part fall back on the index) -- numpy: argsort((x0 & ~0x1fff) | i).  One compare + one add per pair: the O(nwalkers^2) ranking runs
-        // on ONE CU (a 64-bit key with a separate tie rule cost 8.5 us of a 30 us launch at 512 walkers, profiles/r02b)
-        for (int i = tid; i < nw; i += nthr) {
-            const DlPhilox r = dl_philox4x32((uint32_t)s.it_prop, (uint32_t)((unsigned long long)s.it_prop >> 32), (uint32_t)i, DL_ENS_STREAM_PERM, s.k0, s.k1);
-            keys[i] = (r.x[0] & ~0x1fffu) | (uint32_t)i;
+    if (!proposing) return;
+    for (int j = jp0; j < half; j += nthr) {
+        int is = is0, ic = ic0;
+        double zz = zz0, fac = fac0;
+        if (j != jp0) dl_ens_draw_move(s, j, half, is, ic, zz, fac);
+        for (int p = 0; p < P; ++p) {
+            const double c = coords[(size_t)ic * P + p], x = coords[(size_t)is * P + p];
+            s.prop[(size_t)j * P + p] = c - (c - x) * zz;      // q = c - (c - s) z
         }
-        __syncthreads();
-        // rank of walker i = number of keys below its own: `parts` threads share the scan of one walker (nw <= DL_ENS_THREADS), partial counts meet in LDS
-        const int span = (nw + parts - 1) / parts;
-        for (int t = tid; t < parts * nw; t += nthr) {
-            const int i = t % nw, part = t / nw;
-            const uint32_t ki = keys[i];
-            const int j0 = part * span, j1 = (j0 + span < nw) ? j0 + span : nw;
-            int rank = 0;
-#pragma unroll 16
-            for (int j = j0; j < j1; ++j) rank += (int)(keys[j] < ki);
-            rankpart[part * nw + i] = rank;
-        }
-        __syncthreads();
-        for (int i = tid; i < nw; i += nthr) {
-            int rank = 0;
-            for (int part = 0; part < parts; ++part) rank += rankpart[part * nw + i];
-            perm[rank] = i;
-            if (STAGED) s.perm[rank] = i;
-        }
-        __syncthreads();
-    }
-    {
-        // stretch move (emcee moves/stretch.py): z ~ g(z) on [1/a, a], partner drawn from the complementary half, q = c - (c - s) z
-        const int32_t* set = perm + s.half_prop * half;
-        const int32_t* comp = perm + (1 - s.half_prop) * half;
-        for (int j = tid; j < half; j += nthr) {
-            const DlPhilox r = dl_philox4x32((uint32_t)s.it_prop, (uint32_t)((unsigned long long)s.it_prop >> 32), (uint32_t)j, DL_ENS_STREAM_MOVE + s.half_prop, s.k0, s.k1);
-            const double u = dl_uniform53(r.x[0], r.x[1]);
-            const double t = (s.a - 1.) * u + 1.;
-            const double zz = (t * t) / s.a;
-            const int ic = comp[r.x[2] % (uint32_t)half], is = set[j];
-            for (int p = 0; p < P; ++p) {
-                const double c = coords[(size_t)ic * P + p], x = coords[(size_t)is * P + p];
-                s.prop[(size_t)j * P + p] = c - (c - x) * zz;
-            }
-            s.factors[j] = (P - 1.) * log(zz);
-        }
+        s.factors[j] = fac;
     }
 }
 
-// LDS bytes of a launch; staged = false: keys and partial ranks only
-size_t dl_ens_shared_bytes(int nw, int P, bool staged) {
-    const int parts = (DL_ENS_THREADS / nw) > 1 ? DL_ENS_THREADS / nw : 1;
-    size_t bytes = (size_t)nw * 8 + (size_t)((parts * nw + 1) & ~1) * 4;
-    if (staged) bytes += (size_t)nw * (P + 1) * 8 + (size_t)nw * 4;
-    return (bytes + 15) & ~(size_t)15;
+// The same step with the state in global memory (ensembles whose state does not fit the LDS of one CU): phases separated by barriers (memory written before a
+// barrier is visible to the workgroup after it).
+__global__ __launch_bounds__(DL_ENS_THREADS) void dl_ensemble_step_kernel(const DlEnsArgs s) {
+#pragma clang fp contract(off)
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int nw = s.nw, half = nw / 2, P = s.P;
+    const double inf = __builtin_huge_val();
+    if (s.half_acc >= 0) {
+        for (int j = tid; j < half; j += nthr) {
+            int i;
+            double logu, lp;
+            dl_ens_draw_accept(s, j, half, i, logu);
+            if (s.part != nullptr) {
+                double ll, lpr, x0[8];
+                int st;
+                dl_load_theta8(s.prop + (size_t)j * P, P, 0, x0);
+                dl_finalize_from_chi2<2>(dl_chi2_of_parts(s.part + (size_t)j * s.n_tiles, s.n_tiles), x0, s.prop + (size_t)j * P, P, s.priors, ll, lpr, st);
+                lp = st == 0 ? ll + lpr : -inf;
+            } else lp = s.newlp[j];
+            if (lp != lp) lp = -inf;
+            lp = lp + s.offset;
+            const double lnpdiff = (s.factors[j] + lp) - s.logp[i];
+            if (logu < lnpdiff) {
+                for (int p = 0; p < P; ++p) s.coords[(size_t)i * P + p] = s.prop[(size_t)j * P + p];
+                s.logp[i] = lp;
+                (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(s.nacc) + i, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+    if (s.chain != nullptr) {
+        for (int e = tid; e < nw * P; e += nthr) s.chain[e] = s.coords[e];
+        if (s.chain_logp != nullptr)
+            for (int e = tid; e < nw; e += nthr) s.chain_logp[e] = s.logp[e];
+    }
+    if (s.half_prop < 0) return;
+    for (int j = tid; j < half; j += nthr) {
+        int is, ic;
+        double zz, fac;
+        dl_ens_draw_move(s, j, half, is, ic, zz, fac);
+        for (int p = 0; p < P; ++p) {
+            const double c = s.coords[(size_t)ic * P + p], x = s.coords[(size_t)is * P + p];
+            s.prop[(size_t)j * P + p] = c - (c - x) * zz;
+        }
+        s.factors[j] = fac;
+    }
+}
+
+// LDS bytes of the LDS-resident step: positions, log-posteriors, pending proposals, their partial chi2 (n_tiles = 0: none), prior table
+size_t dl_ens_shared_bytes(int nw, int P, int n_tiles) {
+    const size_t half = (size_t)(nw / 2);
+    return ((size_t)nw * P + nw + ((half * P + 1) & ~(size_t)1) + half * n_tiles + (size_t)5 * P) * 8 + 16;
 }
 
 void dl_ens_launch(const DlEnsArgs& s, hipStream_t stream) {
-    const bool staged = dl_ens_shared_bytes(s.nw, s.P, true) <= 144 * 1024;
-    const size_t shm = dl_ens_shared_bytes(s.nw, s.P, staged);
-    if (staged) {
-        if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_ensemble_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        hipLaunchKernelGGL(dl_ensemble_step_kernel<true>, dim3(1), dim3(DL_ENS_THREADS), shm, stream, s);
-    } else {
-        if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_ensemble_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        hipLaunchKernelGGL(dl_ensemble_step_kernel<false>, dim3(1), dim3(DL_ENS_THREADS), shm, stream, s);
-    }
+    const int n_tiles = s.part != nullptr ? s.n_tiles : 0;
+    const size_t shm = dl_ens_shared_bytes(s.nw, s.P, n_tiles);
+    const bool force_global = getenv("DL_ENS_GLOBAL") != nullptr;   // (tests: the global-memory variant on a small ensemble)
+    if (shm <= 144 * 1024 && n_tiles % 8 == 0 && !force_global) {
+        // up to 512 walkers: 512 threads (one slot per thread in either phase, 256 registers each); beyond: 1024 threads
+        if (s.nw <= 512) {
+            if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_ensemble_step_lds_kernel<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            hipLaunchKernelGGL((dl_ensemble_step_lds_kernel<512, 4>), dim3(1), dim3(512), shm, stream, s);
+        } else {
+            if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_ensemble_step_lds_kernel<1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            hipLaunchKernelGGL((dl_ensemble_step_lds_kernel<1024, 2>), dim3(1), dim3(1024), shm, stream, s);
+        }
+    } else hipLaunchKernelGGL(dl_ensemble_step_kernel, dim3(1), dim3(DL_ENS_THREADS), 0, stream, s);
 }
 
 }  // namespace
@@ -233,7 +320,6 @@ struct dl_ensemble {
     bool deferred = true;         // finish the proposals' log-posteriors inside the step kernel (single rank, contexts on the chi2 GEMM path)
     double *coords = nullptr, *logp = nullptr, *prop = nullptr, *factors = nullptr, *newlp = nullptr;
     long long* nacc = nullptr;
-    int32_t* perm = nullptr;
 };
 
 extern "C" {
@@ -241,7 +327,7 @@ extern "C" {
 void dl_ensemble_destroy(dl_ensemble* ens) {
     if (!ens) return;
     (void)hipSetDevice(ens->device);
-    for (void* p : {(void*)ens->coords, (void*)ens->logp, (void*)ens->prop, (void*)ens->factors, (void*)ens->newlp, (void*)ens->nacc, (void*)ens->perm})
+    for (void* p : {(void*)ens->coords, (void*)ens->logp, (void*)ens->prop, (void*)ens->factors, (void*)ens->newlp, (void*)ens->nacc})
         if (p) (void)hipFree(p);
     delete ens;
 }
@@ -266,8 +352,7 @@ int dl_ensemble_create(dl_ensemble** out, dl_ctx* ctx, int32_t nwalkers, double 
     if (hipSetDevice(ens->device) != hipSuccess) return bail("dl_ensemble_create: hipSetDevice failed");
     if (hipMalloc((void**)&ens->coords, (size_t)nwalkers * P * sizeof(double)) != hipSuccess || hipMalloc((void**)&ens->logp, (size_t)nwalkers * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&ens->prop, half_pad * P * sizeof(double)) != hipSuccess || hipMalloc((void**)&ens->factors, half_pad * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&ens->newlp, half_pad * sizeof(double)) != hipSuccess || hipMalloc((void**)&ens->nacc, (size_t)nwalkers * sizeof(long long)) != hipSuccess ||
-        hipMalloc((void**)&ens->perm, (size_t)nwalkers * sizeof(int32_t)) != hipSuccess)
+        hipMalloc((void**)&ens->newlp, half_pad * sizeof(double)) != hipSuccess || hipMalloc((void**)&ens->nacc, (size_t)nwalkers * sizeof(long long)) != hipSuccess)
         return bail("dl_ensemble_create: device allocation failed");
     if (hipMemset(ens->nacc, 0, (size_t)nwalkers * sizeof(long long)) != hipSuccess || hipMemset(ens->prop, 0, half_pad * P * sizeof(double)) != hipSuccess ||
         hipMemset(ens->newlp, 0, half_pad * sizeof(double)) != hipSuccess)
@@ -324,7 +409,7 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
     if (niterations == 0) return 0;
     DlEnsArgs s;
     std::memset(&s, 0, sizeof(s));
-    s.coords = ens->coords; s.logp = ens->logp; s.nacc = ens->nacc; s.perm = ens->perm; s.prop = ens->prop; s.factors = ens->factors; s.newlp = ens->newlp;
+    s.coords = ens->coords; s.logp = ens->logp; s.nacc = ens->nacc; s.prop = ens->prop; s.factors = ens->factors; s.newlp = ens->newlp;
     s.nw = nw; s.P = P; s.a = ens->a; s.offset = ens->offset;
     s.k0 = (uint32_t)ens->seed; s.k1 = (uint32_t)(ens->seed >> 32);
     s.half_acc = -1;
@@ -342,6 +427,7 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
     for (long long it = it0; it < it0 + niterations; ++it)
         for (int h = 0; h < 2; ++h) {
             s.it_prop = it; s.half_prop = h;
+            if (h == 0) s.split_prop = dl_ens_split(it, nw, s.k0, s.k1);
             set_record();
             dl_ens_launch(s, stream);
             s.part = nullptr;
@@ -351,7 +437,7 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
                 if (rc == 2) { ens->deferred = false; s.part = nullptr; }
             }
             if (s.part == nullptr && dl_ens_logposterior(ens, ens->prop, half, ens->newlp, stream)) return 1;
-            s.it_acc = it; s.half_acc = h;
+            s.it_acc = it; s.half_acc = h; s.split_acc = s.split_prop;
         }
     s.half_prop = -1;
     set_record();

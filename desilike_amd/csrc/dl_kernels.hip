@@ -608,15 +608,31 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
     }
 }
 
-__global__ __launch_bounds__(256) void dl_finalize_part_kernel(const double* __restrict__ part, int n_tiles, const double* __restrict__ theta, int n_params,
+// one thread per point; the prior table is staged in LDS (one cooperative load whose round trip overlaps those of the thread's own partial sums and theta row:
+// read through uniform scalar loads it was three dependent round trips per parameter)
+__global__ __launch_bounds__(64) void dl_finalize_part_kernel(const double* __restrict__ part, int n_tiles, const double* __restrict__ theta, int n_params,
                                                                const double* __restrict__ priors, int64_t B, double* __restrict__ loglike,
                                                                double* __restrict__ logprior, int32_t* __restrict__ status, int post_mode) {
+    extern __shared__ __attribute__((aligned(16))) double dl_fp_priors[];   // [n_params, 5]
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t bb = b < B ? b : B - 1;
+    // every global load of the thread is requested before the first wait: prior table entries, partial sums, parameter values
+    double pv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) pv[q] = priors[(int)threadIdx.x + q * 64 < 5 * n_params ? (int)threadIdx.x + q * 64 : 0];
+    double x0[8];
+    dl_load_theta8(theta + (size_t)bb * n_params, n_params, 0, x0);
+    const double chi2 = dl_chi2_of_parts(part + (size_t)bb * n_tiles, n_tiles);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if ((int)threadIdx.x + q * 64 < 5 * n_params) dl_fp_priors[threadIdx.x + q * 64] = pv[q];
+    for (int e = threadIdx.x + 128; e < 5 * n_params; e += 64) dl_fp_priors[e] = priors[e];   // (more than 25 parameters)
+    __syncthreads();
     if (b >= B) return;
     const double inf = __builtin_huge_val();
     double ll, lp;
     int st;
-    dl_finalize_point(part + (size_t)b * n_tiles, n_tiles, theta + (size_t)b * n_params, n_params, priors, ll, lp, st);
+    dl_finalize_from_chi2(chi2, x0, theta + (size_t)b * n_params, n_params, dl_fp_priors, ll, lp, st);
     if (loglike) loglike[b] = post_mode ? (st == DL_ST_OK ? ll + lp : -inf) : ll;
     if (logprior) logprior[b] = lp;
     if (status) status[b] = st;
@@ -624,7 +640,9 @@ __global__ __launch_bounds__(256) void dl_finalize_part_kernel(const double* __r
 
 void dl_launch_finalize_part(const double* part, int n_tiles, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
                              int32_t* status, int post_mode, hipStream_t stream) {
-    DL_LAUNCH(dl_finalize_part_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, part, n_tiles, theta, n_params, priors, B, loglike, logprior, status, post_mode);
+    const size_t shm = (size_t)5 * n_params * sizeof(double);
+    if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_finalize_part_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    DL_LAUNCH(dl_finalize_part_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), shm, stream, part, n_tiles, theta, n_params, priors, B, loglike, logprior, status, post_mode);
 }
 
 // ---- lane-parallel dense algebra for the <= 15 x 15 systems of the marginalised finalize: lane i owns row i in registers, rows are exchanged with
