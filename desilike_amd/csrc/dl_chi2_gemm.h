@@ -49,8 +49,8 @@ struct DlChi2Fin {
 // only meets the K range of observable i -- the other panels multiply zeros and are skipped (two config-2 tracers: 10 of 19 panels per column block).
 #define DL_CG_MAX_TILES 32
 struct DlChi2Panels {
-    uint8_t lo[DL_CG_MAX_TILES], hi[DL_CG_MAX_TILES];   // [p_lo, p_hi) per column block; hi = 0: all panels
-};
+    uint32_t range[DL_CG_MAX_TILES];   // p_lo | p_hi << 8: panels [p_lo, p_hi) of the column block; p_hi = 0: all panels.  One dword per block: a uniform index into the
+};                                     // kernel arguments is then ONE scalar load (byte arrays were two dependent vector loads ahead of the first panel request)
 
 template <bool DO_LOAD, bool DO_MMA>
 __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     // staging by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write): piece i of wave w is the 1 KB segment of row w + 8 i of the
     // panel (rows 0-31 = A, 32-47 = Wt); the LDS destination of a piece is wave-uniform base + 16 B x lane
     int p_lo = 0, p_hi = K_pad / DL_CG_KP;   // K_pad is a multiple of the panel width (padding columns are zero in A and Wt)
-    if (nt < DL_CG_MAX_TILES && panels.hi[nt] != 0) { p_lo = panels.lo[nt]; p_hi = panels.hi[nt]; }
+    const uint32_t range = panels.range[nt < DL_CG_MAX_TILES ? nt : 0];
+    if (nt < DL_CG_MAX_TILES && (range >> 8) != 0) { p_lo = (int)(range & 0xffu); p_hi = (int)(range >> 8); }
     const char* src[DL_CG_VPT];
 #pragma unroll
     for (int i = 0; i < DL_CG_VPT; ++i) {

@@ -69,7 +69,13 @@ struct DlInput {
     double value;
 };
 
+// On the device the load is unconditional (column 0 for a fixed input, then a select): behind a branch every parameter of a point was a load-and-wait of its own
+// (seven to ten serialized round trips at the head of the per-point chain); unconditional loads are issued back to back and waited for once.
+#ifdef __HIP_DEVICE_COMPILE__
+DL_HD double dl_get(const DlInput& in, const double* th) { const double v = th[in.col >= 0 ? in.col : 0]; return in.col >= 0 ? v : in.value; }
+#else
 DL_HD double dl_get(const DlInput& in, const double* th) { return in.col >= 0 ? th[in.col] : in.value; }
+#endif
 
 struct DlObsDev {
     int32_t theory, templ, apmode, transform;
@@ -199,6 +205,7 @@ struct DlMuCarry {
     double qpar, qper, jac, f, b1X, b1Y, sigpar, sigper;   // per-point scalars
     double mu, iq2, x;                                      // part A
     double fac, lq, mup2;                                   // part B
+    double w[DL_MAX_ELL + 1];                               // Legendre weights of the node (multipoles, then ell0): requested in part A, used in part C
 };
 
 // part A: scalars, x = factorap^2 (m: mu node, clamped by the caller)
@@ -214,6 +221,9 @@ DL_HD void dl_fs_mu_partA(const DlObsDev& o, const double* th, int m, DlMuCarry&
     const double rq = c.qper / c.qpar;                         // 1 / qap
     c.iq2 = rq * rq;
     c.mu = o.mu[m];
+    // (unconditional loads: behind `l < n_ell` each was a load-and-wait of its own in part C)
+    for (int l = 0; l < DL_MAX_ELL; ++l) c.w[l] = o.wmu[(l < o.n_ell ? l : 0) * o.n_mu + m];
+    c.w[DL_MAX_ELL] = o.wmu[(o.ell0 >= 0 ? o.ell0 : 0) * o.n_mu + m];
     c.x = 1. + c.mu * c.mu * (c.iq2 - 1.);
 }
 
@@ -241,7 +251,7 @@ DL_HD void dl_fs_mu_partC(const DlObsDev& o, const DlFsShared& s, int m, const D
     const double fm2 = c.f * c.mup2;
     const double bias = (c.b1X + fm2) * (c.b1Y + fm2);         // = b1X b1Y + (b1X + b1Y) f mu'^2 + f^2 mu'^4, full_shape.py:550
     for (int l = 0; l < DL_MAX_ELL; ++l) {
-        double w = (l < o.n_ell) ? c.jac * o.wmu[l * o.n_mu + m] : 0.;
+        double w = (l < o.n_ell) ? c.jac * c.w[l] : 0.;
         s.pt[DL_PT_OM + m * 8 + l] = w * bias;
         if (w3) {
             s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 0] = w;
@@ -249,7 +259,7 @@ DL_HD void dl_fs_mu_partC(const DlObsDev& o, const DlFsShared& s, int m, const D
             s.pt[DL_PT_W3 + (m * 5 + l) * 3 + 2] = w * (fm2 * fm2);
         }
     }
-    s.pt[DL_PT_OM + m * 8 + 5] = (o.ell0 >= 0) ? c.jac * o.wmu[o.ell0 * o.n_mu + m] : 0.;
+    s.pt[DL_PT_OM + m * 8 + 5] = (o.ell0 >= 0) ? c.jac * c.w[DL_MAX_ELL] : 0.;
     s.pt[DL_PT_OM + m * 8 + 6] = 0.;
     s.pt[DL_PT_OM + m * 8 + 7] = 0.;
 }

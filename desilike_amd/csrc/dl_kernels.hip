@@ -594,7 +594,7 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
     DlChi2Panels panels;
     std::memset(&panels, 0, sizeof(panels));
     if (panel_ranges != nullptr && n_tiles <= DL_CG_MAX_TILES)
-        for (int t = 0; t < n_tiles; ++t) { panels.lo[t] = panel_ranges[2 * t]; panels.hi[t] = panel_ranges[2 * t + 1]; }
+        for (int t = 0; t < n_tiles; ++t) panels.range[t] = (uint32_t)panel_ranges[2 * t] | ((uint32_t)panel_ranges[2 * t + 1] << 8);
     DL_LAUNCH((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad);
     if (fin.stamps) {
         (void)hipStreamSynchronize(stream);
