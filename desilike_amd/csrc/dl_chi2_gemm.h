@@ -12,6 +12,7 @@
 //   the end); each k-step feeds two MFMAs (rows 0-15, 16-31) that share the Wt operand.
 //   The 8 column blocks that share a row block are mapped to the same XCD (blockIdx % 8), so A is fetched once per XCD L2.
 #pragma once
+#include "dl_scalar_prefetch.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
                                                            const double* __restrict__ bias, double* __restrict__ part, int M, int K_pad, int n_tiles, DlChi2Fin fin,
                                                            DlChi2Panels panels, int k_live) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    dl_kernarg_prefetch<256>();   // pointers, sizes, finalize block, panel ranges: four lines, one round trip
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     // XCD-aware decode of the linear workgroup id L = xcd + 8 (nt + n_tiles q): row block = xcd + 8 q

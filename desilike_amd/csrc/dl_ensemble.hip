@@ -21,6 +21,7 @@
 #include "../../include/desilike_amd.h"
 #include "dl_kernels.h"
 #include "dl_finalize_part.h"
+#include "dl_scalar_prefetch.h"
 
 namespace {
 
@@ -153,6 +154,7 @@ template <int THREADS, int NB>
 __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlEnsArgs s) {
 #pragma clang fp contract(off)   // the NumPy driver rounds after every operation: no fused multiply-adds here
     extern __shared__ __attribute__((aligned(16))) double dl_ens_lds[];
+    dl_kernarg_prefetch<sizeof(DlEnsArgs)>();
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = s.nw, half = nw / 2, P = s.P, n_tiles = s.part != nullptr ? s.n_tiles : 0;
     double* coords = dl_ens_lds;                                  // [nw, P]

@@ -17,6 +17,7 @@
 #include "dl_kernels.h"
 #include "dl_emu_batch.h"
 #include "dl_finalize_part.h"
+#include "dl_scalar_prefetch.h"
 
 thread_local DlProfEvents dl_prof_events;
 
@@ -27,22 +28,6 @@ thread_local DlProfEvents dl_prof_events;
 // global-memory pointer (global_load, not flat_load) and every scalar field is an SGPR, never re-read in a loop.
 // DENSE (fast kernels without counter terms): 71 VGPRs and 31 KB of LDS, five workgroups per CU -- for batches that keep every CU oversubscribed (+9 % at 32768 points);
 // otherwise the two-wavenumber projection loop with 122 VGPRs, four workgroups per CU (shorter workgroup life: 14.0 vs 15.5 us per launch at 1024 points).
-// The observable's description (2 KB of scalars and pointers) is read field by field through the scalar cache; the compiler places each s_load next to its first
-// use, so a cold description costs one scalar-cache miss per 64-byte line ON the dependent chain of the first phase.  Requesting every line at entry (results
-// discarded: the loads share their destination registers) turns that into one round trip; the real loads then hit the scalar cache.
-// 64-byte lines [A0, A1) and [B0, B1) (byte offsets from p).  ONE asm statement: the destination registers belong to it from the first request to the wait.
-template <int A0, int A1, int B0, int B1>
-__device__ __forceinline__ void dl_scalar_prefetch(const void* p) {
-    __asm__ volatile(
-        "s_mov_b32 s83, %1\n"
-        "1: s_load_dwordx16 s[84:99], %0, s83\n\ts_add_u32 s83, s83, 64\n\ts_cmp_lt_u32 s83, %2\n\ts_cbranch_scc1 1b\n"
-        "s_mov_b32 s83, %3\n"
-        "2: s_load_dwordx16 s[84:99], %0, s83\n\ts_add_u32 s83, s83, 64\n\ts_cmp_lt_u32 s83, %4\n\ts_cbranch_scc1 2b\n"
-        "s_waitcnt lgkmcnt(0)"
-        : : "s"(p), "n"(A0), "n"(A1), "n"(B0), "n"(B1)
-        : "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "scc", "memory");
-}
-
 // ... of the parts of a description the Kaiser / EFT kernels read: the head (sizes, constants, parameter slots) and the tail (table pointers).  ONE wavefront of
 // the workgroup asks (all four asking: 13.6 us against 11.9 us without -- the scalar cache serves several CUs), and
 // the asking wavefront must also WAIT -- the destination registers are only borrowed for the duration of the asm statement, a load still in flight afterwards
@@ -642,6 +627,7 @@ __global__ __launch_bounds__(64) void dl_finalize_part_kernel(const double* __re
                                                                const double* __restrict__ priors, int64_t B, double* __restrict__ loglike,
                                                                double* __restrict__ logprior, int32_t* __restrict__ status, int post_mode) {
     extern __shared__ __attribute__((aligned(16))) double dl_fp_priors[];   // [n_params, 5]
+    dl_kernarg_prefetch<96>();
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t bb = b < B ? b : B - 1;
     // every global load of the thread is requested before the first wait: prior table entries, partial sums, parameter values
