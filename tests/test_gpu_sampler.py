@@ -102,6 +102,39 @@ def test_device_resident_ensemble_matches_numpy_driver():
     assert thin['logposterior'].shape == (5, nwalkers)
 
 
+def test_device_ensemble_global_memory_variant():
+    """The step kernel with the state in global memory (ensembles beyond the LDS of one CU; DL_ENS_GLOBAL=1 forces it) and the 1024-thread instantiation of the
+    LDS kernel (more than 512 walkers) give the chains of the default kernel / of the NumPy driver, bit for bit."""
+    import os
+    from desilike_amd.samplers import EmceeSampler, EnsembleStretchMove, CounterRNG
+    g, like = make_cfg5()
+    nwalkers, niterations = 64, 12
+    ref = EmceeSampler(like, nwalkers=nwalkers, seed=7)
+    start, _ = ref._get_start(nwalkers)
+    chain_ref = ref.run(niterations=niterations, start=start)
+    os.environ['DL_ENS_GLOBAL'] = '1'
+    try:
+        other = EmceeSampler(like, nwalkers=nwalkers, seed=7)
+        other._get_start(nwalkers)                                                 # (the device key is the generator's next draw: same history, same key)
+        chain = other.run(niterations=niterations, start=start)
+    finally:
+        del os.environ['DL_ENS_GLOBAL']
+    for name in chain_ref.keys() if hasattr(chain_ref, 'keys') else ['logposterior']:
+        assert np.array_equal(np.asarray(chain[name]), np.asarray(chain_ref[name])), name
+    assert np.array_equal(other.acceptance_fraction, ref.acceptance_fraction)
+    # 640 walkers: the 1024-thread kernel, against the NumPy driver
+    nwalkers, niterations = 640, 4
+    big = EmceeSampler(like, nwalkers=nwalkers, seed=11)
+    start, _ = big._get_start(nwalkers)
+    chain = big.run(niterations=niterations, start=start)
+    host = EnsembleStretchMove(nwalkers, len(like.varied_params), big.logposterior, rng=CounterRNG(big.counter_seed))
+    coords, logp = start.copy(), big.logposterior(start)
+    for it in range(niterations):
+        coords, logp = host.step(coords, logp)
+        assert np.array_equal(np.column_stack([chain[param.name][it] for param in like.varied_params]), coords), it
+        assert np.array_equal(chain['logposterior'][it], logp), it
+
+
 def test_device_ensemble_out_of_prior_and_nan_start():
     """Walkers proposed outside the prior are rejected (log-posterior -inf on the device); the chain never leaves the prior."""
     from desilike_amd.samplers import EmceeSampler

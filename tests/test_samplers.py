@@ -249,6 +249,21 @@ def test_counter_rng_known_answers():
     rng = CounterRNG(seed=123456789012345)
     perm = rng.permutation(5, 64)
     assert sorted(perm) == list(range(64)) and not np.array_equal(perm, rng.permutation(6, 64))
+    # the split is a keyed bijection of [0, n) for every n (cycle-walking from the next power of two), and as a random split it is uniform: first-half membership,
+    # co-membership of pairs and the walker in position 0, over 3000 iterations at n = 48, against the binomial / multinomial expectations
+    for n in (2, 3, 5, 48, 100, 513):
+        assert all(sorted(rng.permutation(it, n)) == list(range(n)) for it in range(20)), n
+    n, T = 48, 3000
+    first, co, pos0 = np.zeros(n), np.zeros((n, n)), np.zeros(n)
+    for it in range(T):
+        p = rng.permutation(it, n)
+        h = np.zeros(n); h[p[:n // 2]] = 1.
+        first += h; co += np.outer(h, h); pos0[p[0]] += 1
+    assert np.abs(first / T - 0.5).max() < 5. * np.sqrt(0.25 / T)
+    pair = co[np.triu_indices(n, 1)] / T
+    expected = (n / 2 - 1.) / (n - 1.) / 2.
+    assert abs(pair.mean() - expected) < 1e-3 and np.abs(pair - expected).max() < 5. * np.sqrt(expected * (1. - expected) / T)
+    assert ((pos0 - T / n)**2 / (T / n)).sum() / (n - 1) < 1.6       # chi2 / dof of the position-0 histogram
     u, partner = rng.move(5, 1, 32)
     assert ((u >= 0.) & (u < 1.)).all() and ((partner >= 0) & (partner < 32)).all()
     assert np.array_equal(u, CounterRNG(seed=123456789012345).move(5, 1, 32)[0])          # pure function of (seed, iteration, stream, index)
