@@ -379,16 +379,17 @@ def main():
     prewarm_ms = 1e3 * (time.perf_counter() - t0)
     # Long runs: all three kernels on 8+ sampled steps (0.4 us per step of overhead at 200 steps).  Short runs (the driver's --steps 20): a kernel launched with
     # events is followed by a ~3 us gap, so only the kernel that dominates the step (the theory kernel: established by the long runs and by rocprofv3,
-    # profiles/) carries events, on every second step: 10 samples for ~1.6 us per step; the other kernels are reported as null.
+    # profiles/) carries events, on every fourth step: 5 samples at --steps 20.  A sampled launch costs the step ~5 us (measured at --steps 20: 26.9 - 27.2 us per step
+    # with 10 samples, 24.4 - 24.8 us without events; tools/sync_probe.py: the closing synchronisation is not the difference); the other kernels are reported as null.
     short = args.steps < 100
     only = 'theory' if short else None
-    every = max(1, min(25, args.steps // (10 if short else 8)))
+    every = max(1, min(25, args.steps // (5 if short else 8)))
     if not args.no_events: ctx.profile_enable(1, only=only)   # the warm-up steps go through the event path too (its first use allocates: not a sample)
     for _ in range(args.warmup):
         step()
     barrier()
-    # HIP events attached to the kernels' own dispatch packets on the launch stream (hipExtLaunchKernelGGL: no event records between the kernels), on at least 8
-    # steps of the timed region whatever --steps is
+    # HIP events attached to the kernels' own dispatch packets on the launch stream (hipExtLaunchKernelGGL: no event records between the kernels), on 8 or more
+    # steps of a long timed region, 5 of the driver's 20
     ctx.profile_enable(0 if args.no_events else every, only=only)
     gc.disable()
     elapsed = timed_steps(step, barrier, args.steps)
