@@ -508,7 +508,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         // the chi2 GEMM consumes row block mb (32 points; the LDS-DMA GEMM: 64) on XCD mb % 8: have the theory kernel produce it there (power then waits in that XCD's L2:
         // -0.5 us per 1024 points)
         static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;   // 0: off, 1: chi2 GEMM path, 2: also the large-batch GEMM
-        const int xcd_block = !xcd_local ? 0 : chi2_path ? 32 : (xcd_local > 1 && !feat_path && !ctx->any_transform && ctx->n_solved == 0 && ctx->N_pad == 128) ? 64 : 0;
+        const bool chi2_fused_early = getenv("DL_CHI2_FUSED") != nullptr && atoi(getenv("DL_CHI2_FUSED")) != 0 && !ctx->priors_general;
+        const int xcd_block = !xcd_local ? 0 : chi2_path ? (chi2_fused_early ? 32 : dl_chi2_gemm_row_tile(nb, ctx->N_pad)) : (xcd_local > 1 && !feat_path && !ctx->any_transform && ctx->n_solved == 0 && ctx->N_pad == 128) ? 64 : 0;
         prof_phase(0);
         if (!(feat_path && emu_fused))
             dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, feat_path ? ctx->feat_ws : nullptr, ctx->feat_ld,
@@ -849,7 +850,7 @@ int dl_internal_eval_partials(dl_ctx* ctx, const double* theta_dev, int64_t B, c
     if (dl_order_streams(ctx, stream)) return 1;
     if (dl_reserve(ctx, B)) return 1;
     static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;
-    dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, theta_dev, ctx->n_params, B, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, nullptr, 0, xcd_local ? 32 : 0, ctx->obs_array_dev);
+    dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, theta_dev, ctx->n_params, B, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, nullptr, 0, xcd_local ? dl_chi2_gemm_row_tile(B, ctx->N_pad) : 0, ctx->obs_array_dev);
     dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, B, ctx->N_pad, ctx->K_pad, nullptr, theta_dev, ctx->n_params,
                         ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream, ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live);
     *part = ctx->delta_ws;

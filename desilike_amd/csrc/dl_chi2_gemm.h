@@ -29,7 +29,7 @@ typedef double dl_cg_double4 __attribute__((ext_vector_type(4)));
 #endif
 #define DL_CG_VPT (DL_CG_ROWS / DL_CG_WAVES)   // row segments (1 KB LDS-DMA pieces) per wave and panel
 #define DL_CG_NBUF 3                       // LDS panel buffers
-#define DL_CG_LDS_BYTES (DL_CG_NBUF * DL_CG_ROWS * DL_CG_LD * 8)
+#define DL_CG_LDS_BYTES (DL_CG_NBUF * DL_CG_ROWS * DL_CG_LD * 8)   // (32-row tile; the 16-row tile uses the same allocation)
 
 // Fused finalize (fin.counters != nullptr): the workgroup that completes a row block's last column block (device-scope counter) sums the partials of its 32
 // points in a fixed order (deterministic whoever arrives last), adds the priors and writes loglike / logprior / status -- no separate finalize launch
@@ -53,7 +53,9 @@ struct DlChi2Panels {
     uint32_t range[DL_CG_MAX_TILES];   // p_lo | p_hi << 8: panels [p_lo, p_hi) of the column block; p_hi = 0: all panels.  One dword per block: a uniform index into the
 };                                     // kernel arguments is then ONE scalar load (byte arrays were two dependent vector loads ahead of the first panel request)
 
-template <bool DO_LOAD, bool DO_MMA>
+// MT: rows per workgroup, 32 or 16 (16: batches whose 32-row blocks would leave CUs without a workgroup -- 256 walkers x 16 column blocks = 128 workgroups of 32 rows,
+// 256 of 16 rows, each moving 32 instead of 48 KB per panel; the partial sums of a row do not depend on the tile height)
+template <bool DO_LOAD, bool DO_MMA, int MT = DL_CG_M>
 __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
                                                            const double* __restrict__ bias, double* __restrict__ part, int M, int K_pad, int n_tiles, DlChi2Fin fin,
                                                            DlChi2Panels panels, int k_live) {
@@ -65,7 +67,8 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     const int L = blockIdx.x;
     const int xcd = L & 7, rest = L >> 3;
     const int nt = rest % n_tiles, mb = xcd + 8 * (rest / n_tiles);
-    const int m0 = mb * DL_CG_M, n0 = nt * DL_CG_N;
+    constexpr int ROWS = MT + DL_CG_N, VPT = ROWS / DL_CG_WAVES, MTILES = MT / 16;
+    const int m0 = mb * MT, n0 = nt * DL_CG_N;
     if (m0 >= M) return;
 #define DL_CG_STAMP(slot, fn) if (fin.stamps != nullptr && tid == 0) fin.stamps[(size_t)blockIdx.x * 8 + (slot)] = fn();
     DL_CG_STAMP(0, __builtin_amdgcn_s_memtime) DL_CG_STAMP(6, __builtin_amdgcn_s_memrealtime)
@@ -74,22 +77,22 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     int p_lo = 0, p_hi = K_pad / DL_CG_KP;   // K_pad is a multiple of the panel width (padding columns are zero in A and Wt)
     const uint32_t range = panels.range[nt < DL_CG_MAX_TILES ? nt : 0];
     if (nt < DL_CG_MAX_TILES && (range >> 8) != 0) { p_lo = (int)(range & 0xffu); p_hi = (int)(range >> 8); }
-    const char* src[DL_CG_VPT];
+    const char* src[VPT];
 #pragma unroll
-    for (int i = 0; i < DL_CG_VPT; ++i) {
+    for (int i = 0; i < VPT; ++i) {
         int row = wave + DL_CG_WAVES * i;
         const double* base;
-        if (row < DL_CG_M) { int ar = m0 + row; if (ar > M - 1) ar = M - 1; base = A + (size_t)ar * lda; }
-        else base = Wt + (size_t)(n0 + row - DL_CG_M) * ldw;
+        if (row < MT) { int ar = m0 + row; if (ar > M - 1) ar = M - 1; base = A + (size_t)ar * lda; }
+        else base = Wt + (size_t)(n0 + row - MT) * ldw;
         src[i] = reinterpret_cast<const char*>(base) + 16 * lane + (size_t)p_lo * (DL_CG_KP * 8);
     }
     const double bj = bias[n0 + r16];        // requested now, used in the epilogue
     const int n_panels = p_hi - p_lo;
-    constexpr int BUF = DL_CG_ROWS * DL_CG_LD, NJ = DL_CG_KP / 4 / DL_CG_WAVES;   // doubles per LDS buffer; k-steps per wave and panel
+    constexpr int BUF = ROWS * DL_CG_LD, NJ = DL_CG_KP / 4 / DL_CG_WAVES;   // doubles per LDS buffer; k-steps per wave and panel
 #define DL_CG_DMA(p)                                                                                                                 \
     {   const size_t off = (size_t)(p) * (DL_CG_KP * 8);                                                                             \
         double* dst = lds + ((p) % DL_CG_NBUF) * BUF + wave * DL_CG_LD;                                                              \
-        _Pragma("unroll") for (int i = 0; i < DL_CG_VPT; ++i)                                                                        \
+        _Pragma("unroll") for (int i = 0; i < VPT; ++i)                                                                               \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + off),                          \
                                              (__attribute__((address_space(3))) void*)(dst + DL_CG_WAVES * i * DL_CG_LD), 16, 0, 0); }
     dl_cg_double4 acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     // are in flight (whichever column block arrives last will need them; two registers are carried through the main loop)
     double fin_lp = 0.;
     int fin_nan = 0;
-    if (fin.counters != nullptr && wave == 0 && lane < DL_CG_M && m0 + lane < M) {
+    if (fin.counters != nullptr && wave == 0 && lane < MT && m0 + lane < M) {
         const double inf = __builtin_huge_val();
         for (int p = 0; p < fin.n_params; ++p) {
             double x = fin.theta[(size_t)(m0 + lane) * fin.n_params + p];
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
             fin_lp += isin ? v : -inf;
         }
     }
-    if (n_panels > 1) __asm__ volatile("s_waitcnt vmcnt(%0)" : : "n"(DL_CG_VPT) : "memory");
+    if (n_panels > 1) __asm__ volatile("s_waitcnt vmcnt(%0)" : : "n"(VPT) : "memory");
     else __asm__ volatile("s_waitcnt vmcnt(0)" : : : "memory");
     __builtin_amdgcn_s_barrier();
     DL_CG_STAMP(1, __builtin_amdgcn_s_memtime)
@@ -120,19 +123,19 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     {   const double* lb = la + ((p) % DL_CG_NBUF) * BUF;                                                                            \
         double a0[NJ], a1[NJ], bb[NJ];                                                                                               \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                                             \
-            const int ks = wave + DL_CG_WAVES * j; a0[j] = lb[4 * ks]; a1[j] = lb[16 * DL_CG_LD + 4 * ks]; bb[j] = lb[32 * DL_CG_LD + 4 * ks]; } \
+            const int ks = wave + DL_CG_WAVES * j; a0[j] = lb[4 * ks]; a1[j] = MTILES > 1 ? lb[16 * DL_CG_LD + 4 * ks] : 0.; bb[j] = lb[MT * DL_CG_LD + 4 * ks]; } \
         if (DO_MMA) { _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                               \
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[j], bb[j], acc0, 0, 0, 0);                                                \
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[j], bb[j], acc1, 0, 0, 0); } } }
+            if (MTILES > 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[j], bb[j], acc1, 0, 0, 0); } } }
     // the last panel of K is partly padding (1200 of 1280 columns: 12 of its 32 k-steps are live): waves whose k-steps are padding skip their MFMAs there
 #define DL_CG_MULTIPLY_LIM(p, lim)                                                                                                   \
     {   const double* lb = la + ((p) % DL_CG_NBUF) * BUF;                                                                            \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                                             \
             const int ks = wave + DL_CG_WAVES * j;                                                                                   \
             if (DO_MMA && ks < (lim)) {                                                                                              \
-                const double a0 = lb[4 * ks], a1 = lb[16 * DL_CG_LD + 4 * ks], bb = lb[32 * DL_CG_LD + 4 * ks];                      \
+                const double a0 = lb[4 * ks], a1 = MTILES > 1 ? lb[16 * DL_CG_LD + 4 * ks] : 0., bb = lb[MT * DL_CG_LD + 4 * ks];    \
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bb, acc0, 0, 0, 0);                                                  \
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bb, acc1, 0, 0, 0); } } }
+                if (MTILES > 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bb, acc1, 0, 0, 0); } } }
     // iteration p: request panel p + 2 (its buffer held panel p - 1, whose reads every wave retired before the last barrier), read the operands of
     // panel p, multiply, then wait until the wave's own pieces of panel p + 1 have landed (the youngest requests, panel p + 2, stay in flight)
     // and its LDS reads are back; one raw barrier per panel, no vmcnt(0) in the steady loop; the last two panels are peeled (nothing left to request)
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     for (; p + 2 < n_panels; ++p) {
         if (DO_LOAD) { DL_CG_DMA(p + 2) }
         DL_CG_MULTIPLY(p)
-        __asm__ volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(DL_CG_VPT) : "memory");
+        __asm__ volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(VPT) : "memory");
         __builtin_amdgcn_s_barrier();
     }
     if (p + 1 < n_panels) {
@@ -162,10 +165,10 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     __syncthreads();
     double* red = lds;   // [waves][2 tiles][4 regs][64 lanes]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { red[((wave * 2 + 0) * 4 + r) * 64 + lane] = acc0[r]; red[((wave * 2 + 1) * 4 + r) * 64 + lane] = acc1[r]; }
+    for (int r = 0; r < 4; ++r) { red[((wave * 2 + 0) * 4 + r) * 64 + lane] = acc0[r]; if (MTILES > 1) red[((wave * 2 + 1) * 4 + r) * 64 + lane] = acc1[r]; }
     __syncthreads();
-    if (wave < 8) {   // wave (t, r) = (wave & 1, wave >> 1): accumulator register r of row tile t (rows 16 t + (lane >> 4) + 4 r), all 16 columns
-        const int t = wave & 1, r = wave >> 1;
+    if (wave < 4 * MTILES) {   // wave (t, r) = (wave % MTILES, wave / MTILES): accumulator register r of row tile t (rows 16 t + (lane >> 4) + 4 r), all 16 columns
+        const int t = wave % MTILES, r = wave / MTILES;
         double v = bj;
 #pragma unroll
         for (int w = 0; w < DL_CG_WAVES; ++w) v += red[((w * 2 + t) * 4 + r) * 64 + lane];   // fixed order: deterministic
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     if (done != n_tiles - 1) return;
     if (lane == 0) __hip_atomic_store(fin.counters + mb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream-ordered)
     const int row = m0 + lane;
-    if (lane < DL_CG_M && row < M) {
+    if (lane < MT && row < M) {
         double chi2 = 0.;
         for (int t = 0; t < n_tiles; ++t) chi2 += __hip_atomic_load(part + (size_t)row * n_tiles + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // fixed order
         const double inf = __builtin_huge_val();

@@ -53,6 +53,7 @@ void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, in
                         const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream);
 // chi2 GEMM path: part[M, N_pad / 16] = partial chi2 per 16-column block (bias added inside), summed with the priors by dl_launch_finalize_part
 // counters != nullptr ([ceil(M / 32) rounded up to 8] zeroed int32): the finalize (priors, status, outputs) is fused into the GEMM's last-arriving workgroups
+int dl_chi2_gemm_row_tile(int64_t M, int N_pad);   // 32 or 16: rows per workgroup the chi2 GEMM will use for a batch of M points (the theory kernel deals the points to the XCDs accordingly)
 void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, int32_t* counters,
                          const double* theta, int n_params, const double* priors, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream,
                          const uint8_t* panel_ranges = nullptr, int k_live = 0);   // panel_ranges [N_pad / 16][2]: 128-wide K panels [lo, hi) with non-zero Wt entries per column block (host array), or null

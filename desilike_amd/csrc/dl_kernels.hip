@@ -587,14 +587,26 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
 // chi2 GEMM path (plain likelihood): partial chi2 per (point, 16-column block) from dl_chi2_gemm_kernel, then one THREAD per point
 // sums them in a fixed order and adds the priors (same status logic as dl_finalize_kernel).
 // ------------------------------------------------------------------------------------------------
+// rows per workgroup of the chi2 GEMM for a batch of M points: 16 when 32-row blocks would occupy at most half of the 256 CUs (DL_CG_MT=32 / 16 overrides: diagnostics)
+int dl_chi2_gemm_row_tile(int64_t M, int N_pad) {
+    static const int forced = getenv("DL_CG_MT") ? atoi(getenv("DL_CG_MT")) : 0;
+    if (forced == 16 || forced == 32) return forced;
+    return ((M + DL_CG_M - 1) / DL_CG_M) * (N_pad / DL_CG_N) <= 128 ? 16 : DL_CG_M;
+}
+
 void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, int32_t* counters,
                          const double* theta, int n_params, const double* priors, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream,
                          const uint8_t* panel_ranges, int k_live) {
     const int n_tiles = N_pad / DL_CG_N;
-    const int64_t mblocks = (M + DL_CG_M - 1) / DL_CG_M;
+    const int mt = counters == nullptr ? dl_chi2_gemm_row_tile(M, N_pad) : DL_CG_M;   // (the experimental fused finalize counts 32-row blocks)
+    const int64_t mblocks = (M + mt - 1) / mt;
     const unsigned grid = (unsigned)(8 * n_tiles * ((mblocks + 7) / 8));
     static bool optin = false;
-    if (!optin) { (void)hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES); optin = true; }
+    if (!optin) {
+        (void)hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<true, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES);
+        optin = true;
+    }
     DlChi2Fin fin;
     fin.counters = counters; fin.theta = theta; fin.priors = priors; fin.loglike = loglike; fin.logprior = logprior; fin.status = status;
     fin.n_params = n_params; fin.post_mode = post_mode;
@@ -608,7 +620,8 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
     std::memset(&panels, 0, sizeof(panels));
     if (panel_ranges != nullptr && n_tiles <= DL_CG_MAX_TILES)
         for (int t = 0; t < n_tiles; ++t) panels.range[t] = (uint32_t)panel_ranges[2 * t] | ((uint32_t)panel_ranges[2 * t + 1] << 8);
-    DL_LAUNCH((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad);
+    if (mt == 16) DL_LAUNCH((dl_chi2_gemm_kernel<true, true, 16>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_NBUF * (16 + DL_CG_N) * DL_CG_LD * 8, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad);
+    else DL_LAUNCH((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad);
     if (fin.stamps) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h((size_t)grid * 8);
