@@ -589,7 +589,8 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
 // ------------------------------------------------------------------------------------------------
 // rows per workgroup of the chi2 GEMM for a batch of M points: 16 when 32-row blocks would occupy at most half of the 256 CUs (DL_CG_MT=32 / 16 overrides: diagnostics)
 int dl_chi2_gemm_row_tile(int64_t M, int N_pad) {
-    static const int forced = getenv("DL_CG_MT") ? atoi(getenv("DL_CG_MT")) : 0;
+    const char* env = getenv("DL_CG_MT");   // (read at every launch: the tests compare both tiles in one process)
+    const int forced = env ? atoi(env) : 0;
     if (forced == 16 || forced == 32) return forced;
     return ((M + DL_CG_M - 1) / DL_CG_M) * (N_pad / DL_CG_N) <= 128 ? 16 : DL_CG_M;
 }

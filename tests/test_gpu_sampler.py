@@ -240,3 +240,16 @@ def test_config5_as_stated_device_vs_host_driver():
         for flag in ['DL_NO_MERGED_THEORY', 'DL_NO_PANEL_SKIP', 'DL_NO_ROW_ALIGN']:
             del os.environ[flag]
     assert torch.allclose(out, ref, rtol=1e-13, atol=1e-10)
+    # the chi2 GEMM's two row tiles (16 rows per workgroup below 129 workgroups of 32 rows: the 256-point half-steps; 32 otherwise): the partial sums of a row do
+    # not depend on the tile, so the results are the same bit for bit
+    half = theta[:256].contiguous()
+    out16, out32 = torch.empty(256, dtype=torch.float64, device='cuda:0'), torch.empty(256, dtype=torch.float64, device='cuda:0')
+    ctx.eval_logposterior(half, out16)
+    torch.cuda.synchronize()
+    os.environ['DL_CG_MT'] = '32'
+    try:
+        ctx.eval_logposterior(half, out32)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ['DL_CG_MT']
+    assert torch.equal(out16, out32) and torch.equal(out16, ref[:256])
