@@ -289,7 +289,7 @@ def main():
     parser.add_argument('--warmup', type=int, default=20)
     parser.add_argument('--batch', type=int, default=BATCH)
     parser.add_argument('--prewarm-ms', type=float, default=400., help='untimed fixed-duration run of the step before the W warm-up steps (clocks ramp up; reported as prewarm_ms)')
-    parser.add_argument('--config5-iterations', type=int, default=100, help='ensemble updates of the strong-scaling configs[4] measurement (0: skip)')
+    parser.add_argument('--config5-iterations', type=int, default=300, help='ensemble updates of the strong-scaling configs[4] measurement (0: skip)')
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--dry-run', action='store_true', help='launcher check without a GPU: start the ranks, form the (gloo) group, exchange, print the line skeleton')
     parser.add_argument('--no-events', action='store_true', help='diagnostic: no HIP events attached to the kernels in the timed region')
