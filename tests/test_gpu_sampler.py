@@ -135,6 +135,28 @@ def test_device_ensemble_global_memory_variant():
         assert np.array_equal(chain['logposterior'][it], logp), it
 
 
+def test_device_ensemble_odd_shapes():
+    """Ensemble shapes that are not multiples of anything: 7 parameters (config 2) x 18 or 22 walkers -- 9 / 11 proposals per half-step, an odd number of doubles in
+    the proposal block and a last LDS-DMA chunk that is only half there -- against the NumPy driver, bit for bit; and the same on the two-tracer likelihood with 30
+    walkers (15 proposals per half-step: one workgroup of the 16-row GEMM tile, partly filled)."""
+    from test_host_api import make_cfg2
+    from desilike_amd.samplers import EmceeSampler, EnsembleStretchMove, CounterRNG
+    for like, nwalkers in [(make_cfg2()[1], 18), (make_cfg2()[1], 22), (make_cfg5()[1], 30)]:
+        ndim, niterations = len(like.varied_params), 8
+        assert nwalkers >= 2 * ndim
+        sampler = EmceeSampler(like, nwalkers=nwalkers, seed=5)
+        assert sampler.device_resident
+        start, _ = sampler._get_start(nwalkers)
+        chain = sampler.run(niterations=niterations, start=start)
+        host = EnsembleStretchMove(nwalkers, ndim, sampler.logposterior, rng=CounterRNG(sampler.counter_seed))
+        coords, logp = start.copy(), sampler.logposterior(start)
+        for it in range(niterations):
+            coords, logp = host.step(coords, logp)
+            assert np.array_equal(np.column_stack([chain[param.name][it] for param in like.varied_params]), coords), (nwalkers, it)
+            assert np.array_equal(chain['logposterior'][it], logp), (nwalkers, it)
+        assert np.array_equal(sampler.acceptance_fraction, host.acceptance_fraction)
+
+
 def test_device_ensemble_out_of_prior_and_nan_start():
     """Walkers proposed outside the prior are rejected (log-posterior -inf on the device); the chain never leaves the prior."""
     from desilike_amd.samplers import EmceeSampler
