@@ -102,6 +102,7 @@ struct DlEnsArgs {
     const double* part;    // deferred finalize (single rank, plain likelihood): partial chi2 [half, n_tiles] of the pending proposals straight from the chi2 GEMM,
     const double* priors;  // ... prior table [P, 5]: this kernel sums the partials, adds the priors and applies the status rules itself (no finalize launch)
     int32_t n_tiles;
+    int32_t stage_parts;   // partial chi2 staged in LDS with the rest (0: read from global memory in the accept phase -- ensembles whose state alone fills the LDS)
     int32_t nw, P;
     double a, offset;
     uint32_t k0, k1;
@@ -156,12 +157,12 @@ __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlE
     extern __shared__ __attribute__((aligned(16))) double dl_ens_lds[];
     dl_kernarg_prefetch<sizeof(DlEnsArgs)>();
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = s.nw, half = nw / 2, P = s.P, n_tiles = s.part != nullptr ? s.n_tiles : 0;
+    const int nw = s.nw, half = nw / 2, P = s.P, n_tiles = s.part != nullptr ? s.n_tiles : 0, n_tiles_lds = s.stage_parts ? n_tiles : 0;
     double* coords = dl_ens_lds;                                  // [nw, P]
     double* logp = coords + (size_t)nw * P;                       // [nw]
     double* prop = logp + nw;                                     // [half, P] pending proposals (the new ones go straight to global memory)
     double* parts = prop + (((size_t)half * P + 1) & ~(size_t)1); // [half, n_tiles], chunks rotated by the row index
-    double* priors = parts + (size_t)half * n_tiles;              // [P, 5]
+    double* priors = parts + (size_t)half * n_tiles_lds;          // [P, 5]
     const double inf = __builtin_huge_val();
     const bool accepting = s.half_acc >= 0, proposing = s.half_prop >= 0;
     dl_ens_stage(coords, s.coords, nw * P, 0, wave, lane, nthr);
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlE
     if (accepting) {
         dl_ens_stage(prop, s.prop, half * P, 0, wave, lane, nthr);
         if (s.part != nullptr) {
-            dl_ens_stage(parts, s.part, half * n_tiles, n_tiles / 2, wave, lane, nthr);
+            if (n_tiles_lds) dl_ens_stage(parts, s.part, half * n_tiles, n_tiles / 2, wave, lane, nthr);
             for (int e = nthr - 1 - tid; e < 5 * P; e += nthr) priors[e] = s.priors[e];   // (register loads: on the last wavefront, which has no draws to make meanwhile)
         } else if (tid < half) lp0 = s.newlp[tid];
         if (tid < half) f0 = s.factors[tid];
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlE
                 const double* row = parts + (size_t)j * n_tiles;
                 double chi2 = 0.;
                 int cp = j % C;
-                for (int k0 = 0; k0 < C; k0 += 4) {   // (n_tiles is a multiple of 8)
+                if (n_tiles_lds == 0) chi2 = dl_chi2_of_parts(s.part + (size_t)j * n_tiles, n_tiles);
+                else for (int k0 = 0; k0 < C; k0 += 4) {   // (n_tiles is a multiple of 8)
                     double v[8];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { v[2 * k] = row[2 * cp]; v[2 * k + 1] = row[2 * cp + 1]; cp = cp + 1 == C ? 0 : cp + 1; }
@@ -292,11 +294,13 @@ size_t dl_ens_shared_bytes(int nw, int P, int n_tiles) {
     return ((size_t)nw * P + nw + ((half * P + 1) & ~(size_t)1) + half * n_tiles + (size_t)5 * P) * 8 + 16;
 }
 
-void dl_ens_launch(const DlEnsArgs& s, hipStream_t stream) {
-    const int n_tiles = s.part != nullptr ? s.n_tiles : 0;
-    const size_t shm = dl_ens_shared_bytes(s.nw, s.P, n_tiles);
+void dl_ens_launch(const DlEnsArgs& s_in, hipStream_t stream) {
+    const int n_tiles = s_in.part != nullptr ? s_in.n_tiles : 0;
+    DlEnsArgs s = s_in;
+    s.stage_parts = n_tiles > 0 && n_tiles % 8 == 0 && dl_ens_shared_bytes(s.nw, s.P, n_tiles) <= 144 * 1024;   // (the staged rows are walked in groups of four 16-byte chunks)
+    const size_t shm = dl_ens_shared_bytes(s.nw, s.P, s.stage_parts ? n_tiles : 0);
     const bool force_global = getenv("DL_ENS_GLOBAL") != nullptr;   // (tests: the global-memory variant on a small ensemble)
-    if (shm <= 144 * 1024 && n_tiles % 8 == 0 && !force_global) {
+    if (shm <= 144 * 1024 && !force_global) {
         // up to 512 walkers: 512 threads (one slot per thread in either phase, 256 registers each); beyond: 1024 threads
         if (s.nw <= 512) {
             if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_ensemble_step_lds_kernel<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

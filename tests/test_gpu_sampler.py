@@ -122,8 +122,14 @@ def test_device_ensemble_global_memory_variant():
     for name in chain_ref.keys() if hasattr(chain_ref, 'keys') else ['logposterior']:
         assert np.array_equal(np.asarray(chain[name]), np.asarray(chain_ref[name])), name
     assert np.array_equal(other.acceptance_fraction, ref.acceptance_fraction)
-    # 640 walkers: the 1024-thread kernel, against the NumPy driver
-    nwalkers, niterations = 640, 4
+    # 640 walkers: the 1024-thread kernel; 1024 walkers: the same with the partial chi2 left in global memory (positions + proposals alone take 107 KB of LDS);
+    # 2048 walkers: beyond the LDS, the global-memory kernel chosen by size -- each against the NumPy driver
+    for nwalkers, niterations in [(640, 4), (1024, 3), (2048, 2)]:
+        _check_against_numpy_driver(like, nwalkers, niterations)
+
+
+def _check_against_numpy_driver(like, nwalkers, niterations):
+    from desilike_amd.samplers import EmceeSampler, EnsembleStretchMove, CounterRNG
     big = EmceeSampler(like, nwalkers=nwalkers, seed=11)
     start, _ = big._get_start(nwalkers)
     chain = big.run(niterations=niterations, start=start)
