@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -109,6 +110,7 @@ struct DlEnsArgs {
     long long it_acc, it_prop;   // iteration of the half-step to accept / to propose
     int32_t half_acc, half_prop; // 0 / 1, or -1: nothing to accept / propose
     DlEnsSplit split_acc, split_prop;   // the splits of those two iterations
+    unsigned long long* stamps;         // DL_ENS_STAMPS diagnostics (nullptr in production): time spent per phase, summed over the launches (100 MHz clock), [7] = launches
 };
 
 // draws of slot j of the half-step to accept: walker and log(u); of the half-step to propose: walker, partner, z and (P - 1) log z
@@ -151,10 +153,13 @@ __device__ __forceinline__ void dl_ens_stage(double* dst, const double* __restri
 // partial chi2 and the prior table -- is requested at the top as LDS-DMA (one round trip for all of it; with register loads in run-time loops every loop iteration
 // was a round trip of its own: 6 us), the random draws and logarithms of both phases are computed in the shadow of that round trip (accept draws on the first waves,
 // move draws on waves of the other half of the workgroup: different SIMD slots), and the phases after the barrier touch LDS only and end in fire-and-forget stores.
+// (diagnostics: everything outstanding is waited for, then the time since the previous stamp is added to slot k by thread 0)
+#define DL_ENS_STAMP(k) if (s.stamps != nullptr) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (threadIdx.x == 0) atomicAdd(s.stamps + (k), t_ - t_last); t_last = t_; }
 template <int THREADS, int NB>
 __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlEnsArgs s) {
 #pragma clang fp contract(off)   // the NumPy driver rounds after every operation: no fused multiply-adds here
     extern __shared__ __attribute__((aligned(16))) double dl_ens_lds[];
+    unsigned long long t_last = s.stamps != nullptr ? __builtin_amdgcn_s_memrealtime() : 0ull;
     dl_kernarg_prefetch<sizeof(DlEnsArgs)>();
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = s.nw, half = nw / 2, P = s.P, n_tiles = s.part != nullptr ? s.n_tiles : 0, n_tiles_lds = s.stage_parts ? n_tiles : 0;
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlE
         } else if (tid < half) lp0 = s.newlp[tid];
         if (tid < half) f0 = s.factors[tid];
     }
+    DL_ENS_STAMP(0)   // requests issued (and, with stamps on, landed: the wait is part of the stamp)
     __builtin_amdgcn_sched_barrier(0);
     // in the shadow of the round trip: the draws of this thread's first slot of either phase
     const int jp0 = (tid + nthr / 2) % nthr;      // the move phase starts half a workgroup away from the accept phase
@@ -184,7 +190,9 @@ __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlE
     if (accepting && tid < half) dl_ens_draw_accept(s, tid, half, i0, logu0);
     if (proposing && jp0 < half) dl_ens_draw_move(s, jp0, half, is0, ic0, zz0, fac0);
     __builtin_amdgcn_sched_barrier(0);
+    DL_ENS_STAMP(1)   // draws
     __syncthreads();
+    DL_ENS_STAMP(2)   // barrier
     if (accepting) {
         // accept / reject the pending proposals (emcee moves/red_blue.py: lnpdiff = factors + new_log_prob - log_prob; accepted = log(u) < lnpdiff)
         for (int j = tid; j < half; j += nthr) {
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlE
         }
         __syncthreads();
     }
+    DL_ENS_STAMP(3)   // accept
     if (s.chain != nullptr) {
         for (int e = tid; e < nw * P; e += nthr) s.chain[e] = coords[e];
         if (s.chain_logp != nullptr)
@@ -238,7 +247,10 @@ __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlE
         }
         s.factors[j] = fac;
     }
+    DL_ENS_STAMP(4)   // record + move
+    if (s.stamps != nullptr && threadIdx.x == 0) atomicAdd(s.stamps + 7, 1ull);
 }
+#undef DL_ENS_STAMP
 
 // The same step with the state in global memory (ensembles whose state does not fit the LDS of one CU): phases separated by barriers (memory written before a
 // barrier is visible to the workgroup after it).
@@ -415,6 +427,11 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
     if (niterations == 0) return 0;
     DlEnsArgs s;
     std::memset(&s, 0, sizeof(s));
+    static unsigned long long* stamps_dev = nullptr;   // DL_ENS_STAMPS=1: per-phase times of the step kernel, printed at the end of the run (synchronises)
+    const bool stamps_on = getenv("DL_ENS_STAMPS") != nullptr;
+    if (stamps_on && !stamps_dev) DL_ENS_HIP(hipMalloc((void**)&stamps_dev, 8 * sizeof(unsigned long long)));
+    if (stamps_on) DL_ENS_HIP(hipMemsetAsync(stamps_dev, 0, 8 * sizeof(unsigned long long), stream));
+    s.stamps = stamps_on ? stamps_dev : nullptr;
     s.coords = ens->coords; s.logp = ens->logp; s.nacc = ens->nacc; s.prop = ens->prop; s.factors = ens->factors; s.newlp = ens->newlp;
     s.nw = nw; s.P = P; s.a = ens->a; s.offset = ens->offset;
     s.k0 = (uint32_t)ens->seed; s.k1 = (uint32_t)(ens->seed >> 32);
@@ -449,6 +466,13 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
     set_record();
     dl_ens_launch(s, stream);
     DL_ENS_HIP(hipGetLastError());
+    if (stamps_on) {
+        unsigned long long h[8];
+        DL_ENS_HIP(hipMemcpyAsync(h, stamps_dev, sizeof(h), hipMemcpyDeviceToHost, stream));
+        DL_ENS_HIP(hipStreamSynchronize(stream));
+        const double n = h[7] ? 100. * (double)h[7] : 1.;
+        fprintf(stderr, "dl_ensemble_run: step kernel, us per launch over %llu launches: requests + landing %.2f, draws %.2f, barrier %.2f, accept %.2f, record + move %.2f\n", h[7], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n);
+    }
     ens->iteration += niterations;
     return 0;
 }
