@@ -155,7 +155,7 @@ __device__ __forceinline__ void dl_ens_stage(double* dst, const double* __restri
 // move draws on waves of the other half of the workgroup: different SIMD slots), and the phases after the barrier touch LDS only and end in fire-and-forget stores.
 // (diagnostics: everything outstanding is waited for, then the time since the previous stamp is added to slot k by thread 0)
 #define DL_ENS_STAMP(k) if (s.stamps != nullptr) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (threadIdx.x == 0) atomicAdd(s.stamps + (k), t_ - t_last); t_last = t_; }
-template <int THREADS, int NB>
+template <int THREADS>
 __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlEnsArgs s) {
 #pragma clang fp contract(off)   // the NumPy driver rounds after every operation: no fused multiply-adds here
     extern __shared__ __attribute__((aligned(16))) double dl_ens_lds[];
@@ -213,10 +213,18 @@ __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlE
 #pragma unroll
                     for (int k = 0; k < 8; ++k) chi2 += v[k];
                 }
-                double ll, lpr, x0[8];
+                // (one copy of the prior code, walked parameter by parameter: unrolled in batches with the families of dl_prior.h inlined in every copy the accept
+                //  phase was 6554 instructions for the same 3.3 us)
+                double ll, lpr = 0.;
+                bool nan_in = false;
                 int st;
-                dl_load_theta8(prop + (size_t)j * P, P, 0, x0);
-                dl_finalize_from_chi2<NB>(chi2, x0, prop + (size_t)j * P, P, priors, ll, lpr, st);
+#pragma nounroll
+                for (int p = 0; p < P; ++p) {
+                    const double x = prop[(size_t)j * P + p];
+                    if (x != x) nan_in = true;
+                    lpr += dl_prior_logpdf(priors + 5 * p, x);
+                }
+                dl_finalize_status(chi2, lpr, nan_in, ll, st);
                 lp = st == 0 ? ll + lpr : -inf;          // what dl_eval_logposterior writes (samplers/base.py:185-191)
             }
             if (lp != lp) lp = -inf;                     // NaN results count as -inf (samplers/base.py:187-189)
@@ -313,13 +321,13 @@ void dl_ens_launch(const DlEnsArgs& s_in, hipStream_t stream) {
     const size_t shm = dl_ens_shared_bytes(s.nw, s.P, s.stage_parts ? n_tiles : 0);
     const bool force_global = getenv("DL_ENS_GLOBAL") != nullptr;   // (tests: the global-memory variant on a small ensemble)
     if (shm <= 144 * 1024 && !force_global) {
-        // up to 512 walkers: 512 threads (one slot per thread in either phase, 256 registers each); beyond: 1024 threads
+        // up to 512 walkers: 512 threads (one slot per thread in either phase); beyond: 1024 threads
         if (s.nw <= 512) {
-            if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_ensemble_step_lds_kernel<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            hipLaunchKernelGGL((dl_ensemble_step_lds_kernel<512, 4>), dim3(1), dim3(512), shm, stream, s);
+            if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_ensemble_step_lds_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            hipLaunchKernelGGL((dl_ensemble_step_lds_kernel<512>), dim3(1), dim3(512), shm, stream, s);
         } else {
-            if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_ensemble_step_lds_kernel<1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            hipLaunchKernelGGL((dl_ensemble_step_lds_kernel<1024, 2>), dim3(1), dim3(1024), shm, stream, s);
+            if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_ensemble_step_lds_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            hipLaunchKernelGGL((dl_ensemble_step_lds_kernel<1024>), dim3(1), dim3(1024), shm, stream, s);
         }
     } else hipLaunchKernelGGL(dl_ensemble_step_kernel, dim3(1), dim3(DL_ENS_THREADS), 0, stream, s);
 }

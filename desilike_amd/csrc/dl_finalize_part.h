@@ -21,6 +21,16 @@ __device__ __forceinline__ double dl_chi2_of_parts(const double* __restrict__ pa
     return chi2;
 }
 
+// log-likelihood and status of a point from its chi2, its summed log-prior and the NaN flag of its parameters (status rules of include/desilike_amd.h)
+__device__ __forceinline__ void dl_finalize_status(double chi2, double lp, bool nan_in, double& ll, int& st) {
+    const double inf = __builtin_huge_val();
+    ll = -0.5 * chi2;
+    st = 0;                                                                   // DL_STATUS_OK
+    if (nan_in) st = 3;                                                       // DL_STATUS_NAN_INPUT
+    else if (lp == -inf) st = 1;                                              // DL_STATUS_OUT_OF_PRIOR
+    else if (!(ll == ll) || ll == inf || ll == -inf) st = 2;                  // DL_STATUS_NONFINITE
+}
+
 // eight parameter values of a point from p0 on (beyond n_params: the last one again)
 __device__ __forceinline__ void dl_load_theta8(const double* __restrict__ theta_row, int n_params, int p0, double (&x)[8]) {
 #pragma unroll
@@ -59,10 +69,6 @@ __device__ __forceinline__ void dl_finalize_from_chi2(double chi2, const double 
             }
         }
     }
-    ll = -0.5 * chi2;
-    st = 0;                                                                   // DL_STATUS_OK
-    if (nan_in) st = 3;                                                       // DL_STATUS_NAN_INPUT
-    else if (lp == -inf) st = 1;                                              // DL_STATUS_OUT_OF_PRIOR
-    else if (!(ll == ll) || ll == inf || ll == -inf) st = 2;                  // DL_STATUS_NONFINITE
+    dl_finalize_status(chi2, lp, nan_in, ll, st);
 }
 
