@@ -206,7 +206,13 @@ __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlE
                 double chi2 = 0.;
                 int cp = j % C;
                 if (n_tiles_lds == 0) chi2 = dl_chi2_of_parts(s.part + (size_t)j * n_tiles, n_tiles);
-                else for (int k0 = 0; k0 < C; k0 += 4) {   // (n_tiles is a multiple of 8)
+                else if (C == 8) {   // 16 column blocks (two tracers): the whole row in one batch of reads
+                    double v[16];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { v[2 * k] = row[2 * cp]; v[2 * k + 1] = row[2 * cp + 1]; cp = (cp + 1) & 7; }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) chi2 += v[k];
+                } else for (int k0 = 0; k0 < C; k0 += 4) {   // (n_tiles is a multiple of 8)
                     double v[8];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { v[2 * k] = row[2 * cp]; v[2 * k + 1] = row[2 * cp + 1]; cp = cp + 1 == C ? 0 : cp + 1; }
@@ -231,7 +237,13 @@ __global__ __launch_bounds__(THREADS) void dl_ensemble_step_lds_kernel(const DlE
             lp = lp + s.offset;
             const double lnpdiff = (fj + lp) - logp[i];
             if (logu < lnpdiff) {
-                for (int p = 0; p < P; ++p) { const double v = prop[(size_t)j * P + p]; coords[(size_t)i * P + p] = v; s.coords[(size_t)i * P + p] = v; }
+                for (int p0 = 0; p0 < P; p0 += 8) {   // (reads of eight values together, then the writes: a read -> write loop pays the LDS latency per parameter)
+                    double v[8];
+                    dl_load_theta8(prop + (size_t)j * P, P, p0, v);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (p0 + q < P) { coords[(size_t)i * P + p0 + q] = v[q]; s.coords[(size_t)i * P + p0 + q] = v[q]; }
+                }
                 logp[i] = lp; s.logp[i] = lp;
                 (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(s.nacc) + i, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // no return value: nothing waits
             }
