@@ -141,6 +141,28 @@ def _check_against_numpy_driver(like, nwalkers, niterations):
         assert np.array_equal(chain['logposterior'][it], logp), it
 
 
+def test_device_ensemble_separate_finalize_path():
+    """DL_ENS_NO_DEFER=1: the proposals' log-posteriors come from the finalize kernel (the path every rank of a sharded run takes: the all-gather ships
+    log-posteriors) instead of being finished inside the step kernel from the partial chi2 -- same chain, bit for bit, at 64 and at 640 walkers."""
+    from desilike_amd.samplers import EmceeSampler
+    g, like = make_cfg5()
+    for nwalkers, niterations in [(64, 10), (640, 3)]:
+        ref = EmceeSampler(like, nwalkers=nwalkers, seed=9)
+        start, _ = ref._get_start(nwalkers)
+        chain_ref = ref.run(niterations=niterations, start=start)
+        os.environ['DL_ENS_NO_DEFER'] = '1'
+        try:
+            other = EmceeSampler(like, nwalkers=nwalkers, seed=9)
+            other._get_start(nwalkers)
+            chain = other.run(niterations=niterations, start=start)
+        finally:
+            del os.environ['DL_ENS_NO_DEFER']
+        for param in like.varied_params:
+            assert np.array_equal(chain[param.name], chain_ref[param.name]), (nwalkers, param.name)
+        assert np.array_equal(chain['logposterior'], chain_ref['logposterior'])
+        assert np.array_equal(other.acceptance_fraction, ref.acceptance_fraction)
+
+
 def test_device_ensemble_odd_shapes():
     """Ensemble shapes that are not multiples of anything: 7 parameters (config 2) x 18 or 22 walkers -- 9 / 11 proposals per half-step, an odd number of doubles in
     the proposal block and a last LDS-DMA chunk that is only half there -- against the NumPy driver, bit for bit; and the same on the two-tracer likelihood with 30
