@@ -233,6 +233,22 @@ def test_rccl_group_single_rank():
     torch.cuda.synchronize()
     steps = sorted(int(row[0] // 10) for t in out for row in t[0] if not (row == 0.).all() or True)
     assert set(range(7)) <= set(steps)
+    # the device-resident ensemble with the in-stream all-gather of the proposals' log-posteriors per half-step (DL_ENS_FORCE_COMM: the sharded path on one rank)
+    # gives the chain of the single-rank path
+    from desilike_amd.samplers import EmceeSampler
+    ref = EmceeSampler(like, nwalkers=64, seed=13)
+    start, _ = ref._get_start(64)
+    chain_ref = ref.run(niterations=6, start=start)
+    os.environ['DL_ENS_FORCE_COMM'] = '1'
+    try:
+        sharded = EmceeSampler(like, nwalkers=64, seed=13, sharding=WalkerSharding(group=group, min_shard_rows=0), device_resident=True)
+        sharded._get_start(64)
+        chain = sharded.run(niterations=6, start=start)
+        assert sharded._get_ensemble().info('rows_per_rank') == 32
+    finally:
+        del os.environ['DL_ENS_FORCE_COMM']
+    assert np.array_equal(chain['logposterior'], chain_ref['logposterior'])
+    for param in like.varied_params: assert np.array_equal(chain[param.name], chain_ref[param.name])
     group.close()
 
 
