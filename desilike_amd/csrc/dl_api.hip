@@ -487,7 +487,7 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
     for (int64_t b0 = 0; b0 < B; b0 += DL_CHUNK) {
         int64_t nb = std::min<int64_t>(DL_CHUNK, B - b0);
         const double* th = theta_dev + (size_t)b0 * P;
-        bool prof = ctx->profile && b0 == 0 && (ctx->eval_calls % ctx->prof_every == 0);
+        bool prof = ctx->profile && b0 == 0 && (ctx->eval_calls % ctx->prof_every == ctx->prof_every / 2);   // (the middle call of every window: not the first call after a synchronisation)
         hipEvent_t* ev = prof ? &ctx->ev[(size_t)(ctx->prof_calls % dl_ctx::NPOOL) * 6] : nullptr;
         // events attached to the dispatch packets of the launches of phase k (0 theory, 1 GEMM, 2 finalize; dl_kernels.h): with several launches in a phase
         // (one theory launch per observable) the pair holds the LAST one
