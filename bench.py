@@ -103,13 +103,38 @@ def sample_theta(likelihood, size, seed):
     return np.column_stack([param.ref.sample(size=size, random_state=rng) for param in likelihood.varied_params])
 
 
-def oracle_constants(likelihood):
-    """Constants for the NumPy oracle (cpu_baseline leg only), read off the host-side calculators."""
-    obs = likelihood.observables[0]
+def oracle_constants(likelihood, iobs=0):
+    """Constants for the NumPy oracle (cpu_baseline leg and the post-hoc checks only), read off the host-side calculators."""
+    obs = likelihood.observables[iobs]
     wm, theory = obs.wmatrix, obs.wmatrix.theory
     template = theory.template
     return dict(template='shapefit', k11=template.k, pk_dd_fid=template.pk_dd_fid, f_fid=template.f_fid, kp=template.kp, a=template.a, kin=theory.k, mu=theory.mu,
                 wmu_ell=theory.wmu, ellsin=theory.ells, nd=theory.nd, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout, flatdata=obs.flatdata)
+
+
+def oracle_logposterior(likelihood, theta):
+    """Post-hoc checker (never timed, never on the product path): log-posterior of the rows of ``theta`` by the NumPy oracle -- every observable through
+    ``fullshape_observable`` (per-tracer b1 / sn0 namespaces, shared template parameters), joint Gaussian chi2, priors of the varied parameters."""
+    from oracle import np_oracle as orc
+    names = likelihood.varied_params.names()
+    consts = [oracle_constants(likelihood, iobs) for iobs in range(len(likelihood.observables))]
+    bias_names = [obs.wmatrix.theory._bias_names() for obs in likelihood.observables]
+    flatdata = np.concatenate(likelihood._flatdata_list())
+    priors = []
+    for param in likelihood.varied_params:
+        prior = param.prior
+        priors.append(dict(dist=prior.dist, limits=tuple(prior.limits), loc=getattr(prior, 'loc', 0.), scale=getattr(prior, 'scale', 1.)))
+    out = np.empty(len(theta))
+    for i, row in enumerate(theta):
+        p = dict(zip(names, row))
+        theory = []
+        for c, bias in zip(consts, bias_names):
+            q = {name: p[name] for name in ['qpar', 'qper', 'dm', 'df'] if name in p}
+            q['b1'] = (p[bias['b1X']], p[bias['b1Y']])
+            q['sn0'] = p[bias['sn0']]
+            theory.append(orc.fullshape_observable(c, q)['flattheory'])
+        out[i] = orc.gaussian_loglikelihood(np.concatenate(theory), flatdata, likelihood.precision)[0]
+    return out + orc.logprior(np.asarray(theta), priors)
 
 
 def _oracle_loop(payload):
@@ -252,11 +277,18 @@ def config5_strong(group, device, local_rank, rank, world, iterations, warmup=30
     coords, logp, nacc = ens.get_state()
     sharded = isinstance(group, RcclGroup) and (world > 1 or os.environ.get('DL_ENS_FORCE_COMM', None) is not None)
     assert np.isfinite(logp).all() and np.isfinite(chain_logp.cpu().numpy()).all()
+    checked = None
+    if rank == 0:
+        # the final log-posteriors of ALL 512 walkers against the NumPy oracle (pinned on the reference's outputs at this very shape: tests/golden/cfg5_bench.npz)
+        ref = oracle_logposterior(likelihood, coords)
+        err = np.abs(logp - ref) / np.maximum(1., np.abs(ref))
+        assert (err <= 1e-10).all(), 'GPU / oracle mismatch on the config-5 ensemble: {:.3e}'.format(err.max())
+        checked = {'points': int(len(ref)), 'max_rel_err_vs_oracle': float(err.max()), 'tolerance': 1e-10}
     return {'workload': 'BASELINE configs[4]: EnsembleSampler (stretch move), 512 walkers x two config-2 tracers (n = 240), {:d} ensemble updates, device-resident'.format(iterations),
             'value': 512 * iterations / elapsed, 'unit': 'evals/s', 'scaling': 'strong', 'n_gpus': world, 'us_per_update': 1e6 * elapsed / iterations,
             'rows_per_gpu_per_half_step': ens.info('rows_per_rank'), 'sharded': sharded,
             'exchange': 'one in-place ncclAllGather of 256 log-posteriors per half-step on the evaluation stream' if sharded else 'none (single rank, or a host-side group: every rank evaluates all walkers)',
-            'acceptance_fraction': float(nacc.sum()) / (512. * ens.info('iteration')), 'n_params': nparams}
+            'acceptance_fraction': float(nacc.sum()) / (512. * ens.info('iteration')), 'n_params': nparams, 'oracle_check': checked}
 
 
 def dry_run(rank, world):

@@ -48,6 +48,7 @@ SYMBOLS = {
     'dl_ensemble_set_state': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, ctypes.c_void_p]),
     'dl_ensemble_run': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_ensemble_get_state': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
+    'dl_ensemble_set_counter': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
     'dl_ensemble_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
     'dl_mlp_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int32, _c_int32_p, ctypes.c_int32, _c_double_p]),
     'dl_mlp_destroy': (None, [ctypes.c_void_p]),
@@ -444,6 +445,15 @@ class DeviceEnsemble(object):
             logposterior = np.ascontiguousarray(logposterior, dtype='f8')
             if logposterior.shape != (self.nwalkers,): raise ValueError('logposterior must have shape ({:d},)'.format(self.nwalkers))
         self._check(self._lib.dl_ensemble_set_state(self._handle, _f64_ptr(coords), _f64_ptr(logposterior), self._stream(stream)))
+
+    def set_counter(self, iteration, naccepted=None, stream=None):
+        """Resume: iteration counter of the counter-based generator (and accepted counts per walker)."""
+        nacc = None
+        if naccepted is not None:
+            naccepted = np.ascontiguousarray(naccepted, dtype='i8')
+            if naccepted.shape != (self.nwalkers,): raise ValueError('naccepted must have shape ({:d},)'.format(self.nwalkers))
+            nacc = naccepted.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+        self._check(self._lib.dl_ensemble_set_counter(self._handle, int(iteration), nacc, self._stream(stream)))
 
     def run(self, niterations, thin_by=1, chain=None, chain_logp=None, stream=None):
         """Enqueue ``niterations`` ensemble updates (asynchronous); ``chain [niterations // thin_by, nwalkers, P]`` / ``chain_logp [niterations // thin_by, nwalkers]``:

@@ -508,6 +508,19 @@ int dl_ensemble_get_state(dl_ensemble* ens, double* coords, double* logposterior
     return 0;
 }
 
+int dl_ensemble_set_counter(dl_ensemble* ens, int64_t iteration, const int64_t* naccepted, void* hip_stream) {
+    if (!ens) return fail("dl_ensemble_set_counter: null ensemble");
+    if (iteration < 0) return fail("dl_ensemble_set_counter: negative iteration");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DL_ENS_HIP(hipSetDevice(ens->device));
+    if (naccepted) {
+        DL_ENS_HIP(hipMemcpyAsync(ens->nacc, naccepted, (size_t)ens->nw * sizeof(long long), hipMemcpyHostToDevice, stream));
+        DL_ENS_HIP(hipStreamSynchronize(stream));   // the host buffer may be pageable
+    }
+    ens->iteration = iteration;
+    return 0;
+}
+
 int64_t dl_ensemble_info(const dl_ensemble* ens, const char* key) {
     if (!ens || !key) return -1;
     std::string k(key);

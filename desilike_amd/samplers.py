@@ -235,16 +235,125 @@ class EnsembleStretchMove(object):
         return self.naccepted / max(self.niterations, 1)
 
 
+class _HostChain(object):
+    """One chain driven on the host: :class:`EnsembleStretchMove` over a vectorised log-posterior function."""
+    device_resident = False
+
+    def __init__(self, nwalkers, ndim, log_prob_fn, a, rng):
+        self.move = EnsembleStretchMove(nwalkers, ndim, log_prob_fn, a=a, rng=rng)
+        self.coords = self.logp = None
+        self._out = None
+
+    def set_state(self, coords, logp, iteration=0, naccepted=None):
+        self.coords, self.logp = np.array(coords, dtype='f8'), np.array(logp, dtype='f8')
+        self.move.niterations = int(iteration)
+        self.move.naccepted = np.zeros(self.move.nwalkers) if naccepted is None else np.array(naccepted, dtype='f8')
+
+    def enqueue(self, niterations, thin_by=1):
+        coords, logp = [], []
+        for it in range(niterations * thin_by):
+            self.coords, self.logp = self.move.step(self.coords, self.logp)
+            if (it + 1) % thin_by == 0:
+                coords.append(self.coords.copy()); logp.append(self.logp.copy())
+        ndim = self.move.ndim
+        self._out = (np.array(coords).reshape(niterations, self.move.nwalkers, ndim), np.array(logp).reshape(niterations, self.move.nwalkers))
+
+    def collect(self):
+        out, self._out = self._out, None
+        return out
+
+    @property
+    def iteration(self):
+        return self.move.niterations
+
+    @property
+    def naccepted(self):
+        return self.move.naccepted
+
+
+class _DeviceChain(object):
+    """One chain resident on the GPU (``dl_ensemble_*``) with its own HIP stream: several chains of one process run concurrently, each a sequence of small
+    latency-bound launches whose ramps and tails overlap the other chains' kernels."""
+    device_resident = True
+
+    def __init__(self, ctx, offset, nwalkers, a, key, group=None, own_stream=False):
+        import torch
+        from ._lib import DeviceEnsemble
+        self.ens = DeviceEnsemble(ctx, nwalkers, a=a, seed=key, offset=offset, group=group)
+        self.device = torch.device('cuda', self.ens.device)
+        self.stream = torch.cuda.Stream(device=self.device) if own_stream else None
+        self._buffers = None
+        self._naccepted = np.zeros(nwalkers)
+
+    def _cuda_stream(self):
+        return None if self.stream is None else self.stream.cuda_stream
+
+    def set_state(self, coords, logp, iteration=0, naccepted=None):
+        self.ens.set_state(coords, logp, stream=self._cuda_stream())
+        self.ens.set_counter(iteration, naccepted=None if naccepted is None else np.asarray(naccepted, dtype='i8'), stream=self._cuda_stream())
+
+    def enqueue(self, niterations, thin_by=1):
+        import torch
+        coords = torch.empty((niterations, self.ens.nwalkers, self.ens.n_params), dtype=torch.float64, device=self.device)
+        logp = torch.empty((niterations, self.ens.nwalkers), dtype=torch.float64, device=self.device)
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))   # (the buffers were just made on the current stream)
+        self.ens.run(niterations * thin_by, thin_by=thin_by, chain=coords, chain_logp=logp, stream=self._cuda_stream())
+        self._buffers = (coords, logp)
+
+    def collect(self, device=False):
+        """The chain of the last ``enqueue`` (host arrays; ``device=True``: the device tensors, after the stream has finished)."""
+        import torch
+        coords, logp = self._buffers
+        self._buffers = None
+        if self.stream is not None: self.stream.synchronize()
+        else: torch.cuda.current_stream(self.device).synchronize()
+        if device: return coords, logp
+        return coords.cpu().numpy(), logp.cpu().numpy()
+
+    @property
+    def iteration(self):
+        return self.ens.info('iteration')
+
+    @property
+    def naccepted(self):
+        return self.ens.get_state(stream=self._cuda_stream())[2].astype('f8')
+
+
+def _batch_iterate(func, min_iterations=0, max_iterations=None, check_every=300):
+    """samplers/base.py:28-42: batches of ``check_every`` iterations until ``func`` reports convergence (not before ``min_iterations``) or ``max_iterations``."""
+    import sys
+    if max_iterations is None: max_iterations = sys.maxsize
+    if max_iterations < 0: raise ValueError('max_iterations must be positive')
+    if check_every < 1: raise ValueError('check_every must be >= 1, found {:d}'.format(check_every))
+    count, converged = 0, False
+    while not converged:
+        niter = min(max_iterations - count, check_every)
+        count += niter
+        converged = func(niter)
+        if count < min_iterations: converged = False
+        if count >= max_iterations: converged = True
+    return count
+
+
 class EmceeSampler(BasePosteriorSampler):
-    """Ensemble sampler with the reference's constructor surface (desilike/samplers/emcee.py:8-69).
+    """Ensemble sampler with the reference's constructor surface (desilike/samplers/emcee.py:8-69; ``chains``, ``run(min_iterations, max_iterations, check_every,
+    check)`` and ``check`` of desilike/samplers/base.py:409-724).
 
     ``device_resident`` (default: True for GPU likelihoods unless ``use_emcee=True``): the whole ensemble update runs on the GPU (``dl_ensemble_*``: stretch
-    proposals, log-posterior, accept / reject and the counter-based random generator on the device, one all-gather of log-posteriors per half-step over RCCL when
-    the sampler's group is an :class:`~desilike_amd.parallel.RcclGroup`); the host drains the chain once per ``run``.  Otherwise ``emcee`` if installed, else the
-    built-in :class:`EnsembleStretchMove` on the host."""
+    proposals, log-posterior, accept / reject and the counter-based random generator on the device); the host drains the chain once per batch.  Otherwise
+    ``emcee`` if installed, else the built-in :class:`EnsembleStretchMove` on the host.
+
+    ``chains``: number of independent chains (or a list of chain files written by :meth:`save` to resume from).  **Chains are the unit of parallelism**, as in the
+    reference (one chain per group of MPI ranks, desilike/utils.py:1040-1148): with a process group (one process per GPU) chain c lives on rank ``c % world``;
+    a rank that holds several chains runs them concurrently on separate HIP streams.  Every chain has its own device-resident ensemble and its own Philox key
+    (drawn from the rank-synchronised host generator, or given as ``counter_seeds``): a chain is bit-identical to the single-chain run with the same key and start,
+    whatever the number of ranks.  Nothing is exchanged inside a batch of ``check_every`` iterations; at its end the new samples of all chains are all-gathered
+    (one collective), so that every rank holds every chain and evaluates the same convergence tests (:meth:`check`: Gelman-Rubin across chains ...).
+    With ``chains=1`` a process group shards the WALKERS of the one ensemble instead (BASELINE configs[4] as written; see ``WalkerSharding``)."""
     name = 'emcee'
 
-    def __init__(self, likelihood, nwalkers=None, use_emcee=None, device_resident=None, a=2., **kwargs):
+    def __init__(self, likelihood, nwalkers=None, chains=1, use_emcee=None, device_resident=None, a=2., counter_seeds=None, save_fn=None, **kwargs):
         super(EmceeSampler, self).__init__(likelihood, **kwargs)
         ndim = len(self.varied_params)
         if nwalkers is None:
@@ -252,106 +361,324 @@ class EmceeSampler(BasePosteriorSampler):
         if isinstance(nwalkers, str):
             nwalkers = int(eval(nwalkers, {'ndim': ndim}))
         self.nwalkers = int(nwalkers)
-        self.chain = None
         self.a = float(a)
+        resume = None
+        if not isinstance(chains, (int, np.integer)):
+            resume = [chains] if isinstance(chains, (str, dict)) or hasattr(chains, 'arrays') else list(chains)
+            chains = len(resume)
+        self.nchains = int(chains)
+        if self.nchains < 1: raise ValueError('chains must be >= 1')
+        self.chain_parallel = self.nchains > 1
+        self.chain_group = None
+        if self.chain_parallel:
+            # chains are distributed over the ranks; inside a chain nothing is exchanged (every evaluation is local)
+            self.chain_group = self.sharding.group if self.sharding.active and self.sharding.world > 1 else None
+            self.sharding = WalkerSharding(group=False)
+        self.chain_rank = self.chain_group.rank if self.chain_group is not None else 0
+        self.chain_world = self.chain_group.world if self.chain_group is not None else 1
         if device_resident is None:
             # (parameters derived by an expression are computed by the host wrapper of the context: the device-resident ensemble does not see them)
             device_resident = use_emcee is not True and getattr(likelihood, '_get_posterior_context', None) is not None and not len(getattr(likelihood, 'dependent_params', []))
         self.device_resident = bool(device_resident)
-        self._ensemble = None
         emcee = None
-        if use_emcee is not False and not self.device_resident:
+        if use_emcee is not False and not self.device_resident and not self.chain_parallel and counter_seeds is None:
             try:
                 import emcee
             except ImportError:
                 if use_emcee: raise
         self._emcee = emcee
-        if self.device_resident:
-            if self.nwalkers % 2 or self.nwalkers < 2 * ndim:
-                raise ValueError('nwalkers must be even and at least 2 * ndim')
-            self.sampler = None
-        elif emcee is not None:
-            self.sampler = emcee.EnsembleSampler(self.nwalkers, ndim, self.logposterior, vectorize=True)   # samplers/emcee.py:69
-        else:
-            self.sampler = EnsembleStretchMove(self.nwalkers, ndim, self.logposterior, a=self.a, rng=self.rng)
+        if (self.device_resident or emcee is None) and (self.nwalkers % 2 or self.nwalkers < 2 * ndim):
+            raise ValueError('nwalkers must be even and at least 2 * ndim')
+        self.sampler = emcee.EnsembleSampler(self.nwalkers, ndim, self.logposterior, vectorize=True) if emcee is not None else None   # samplers/emcee.py:69
+        self.counter_seeds = None if counter_seeds is None else [int(key) & 0xFFFFFFFFFFFFFFFF for key in np.atleast_1d(counter_seeds)]
+        if self.counter_seeds is not None and len(self.counter_seeds) != self.nchains:
+            raise ValueError('provide one counter seed per chain')
+        if save_fn is not None:
+            if isinstance(save_fn, str):
+                save_fn = [save_fn.replace('*', str(ichain)) for ichain in range(self.nchains)]
+            save_fn = list(save_fn)
+            if len(save_fn) != self.nchains or len(set(save_fn)) != self.nchains:
+                raise ValueError('provide one file name per chain (or a template with *)')
+        self.save_fn = save_fn
+        self.chains = [None] * self.nchains           # per chain: dict name -> [niterations, nwalkers] (incl. 'logposterior'), on every rank
+        self._state = [None] * self.nchains           # per chain: (coords [nwalkers, ndim], logposterior [nwalkers]) after the last update
+        self._iterations = [0] * self.nchains         # updates done (the counter of the chain's generator)
+        self._accepted = [np.zeros(self.nwalkers) for _ in range(self.nchains)]
+        self._runners = {}                            # ichain -> runner, for the chains of this rank
+        self._runner_signature = None
+        self._holds = {}                              # ichain -> the coords array the runner currently continues from (identity)
+        self.diagnostics = {}
+        if resume is not None:
+            for ichain, source in enumerate(resume):
+                self._load_one(ichain, source)
 
-    def _get_ensemble(self):
-        if self._ensemble is None:
-            from ._lib import DeviceEnsemble
-            from .parallel import RcclGroup
-            ctx, offset = self.likelihood._get_posterior_context()
-            import os
-            forced = os.environ.get('DL_ENS_FORCE_COMM', None) is not None and isinstance(self.sharding.group, RcclGroup)   # single-rank smoke test of the in-stream collective
-            group = self.sharding.group if ((self.sharding.sharded(self.nwalkers // 2) or forced) and isinstance(self.sharding.group, RcclGroup)) else None
-            # one 64-bit key for the device generator, drawn from the (rank-synchronised) host generator
-            key = int(self.rng.randint(0, 2**32, dtype=np.uint64)) | (int(self.rng.randint(0, 2**32, dtype=np.uint64)) << 32)
-            self._ensemble = DeviceEnsemble(ctx, self.nwalkers, a=self.a, seed=key, offset=offset, group=group)
-            self.counter_seed = key
-        return self._ensemble
+    # ---- single-chain views (the surface of the one-chain sampler) -----------------------------------------------------------------------------------------
+    @property
+    def chain(self):
+        return self.chains[0]
 
-    def run(self, niterations=300, thin_by=1, start=None):
-        """Run ``niterations`` ensemble updates; returns dict(name -> [niterations, nwalkers]) incl. 'logposterior' (cf. samplers/emcee.py:101-111)."""
-        if start is None:
-            if self.chain is not None:
-                start, logposterior = self._last
+    @property
+    def _last(self):
+        return self._state[0]
+
+    @property
+    def counter_seed(self):
+        return None if self.counter_seeds is None else self.counter_seeds[0]
+
+    def local_chains(self):
+        """Indices of the chains this rank runs."""
+        return [ichain for ichain in range(self.nchains) if ichain % self.chain_world == self.chain_rank]
+
+    def _draw_keys(self):
+        if self.counter_seeds is None:
+            # one 64-bit key per chain for the counter-based generator, drawn from the (rank-synchronised) host generator
+            self.counter_seeds = [int(self.rng.randint(0, 2**32, dtype=np.uint64)) | (int(self.rng.randint(0, 2**32, dtype=np.uint64)) << 32) for _ in range(self.nchains)]
+        return self.counter_seeds
+
+    def _likelihood_signature(self):
+        """Changes when the likelihood's parameters do (the compiled device contexts follow ``all_params``; so must the ensembles built on them)."""
+        check = getattr(self.likelihood, '_check_params', None)
+        if check is None: return None
+        check()
+        return getattr(self.likelihood, '_params_signature', None)
+
+    def _get_runner(self, ichain):
+        signature = self._likelihood_signature()
+        if self._runners and signature != self._runner_signature:
+            for runner in self._runners.values():
+                if runner.device_resident: runner.ens.close()
+            self._runners, self._holds = {}, {}
+        self._runner_signature = signature
+        if ichain not in self._runners:
+            keys = self._draw_keys()
+            ndim = len(self.varied_params)
+            if self.device_resident:
+                from .parallel import RcclGroup
+                import os
+                ctx, offset = self.likelihood._get_posterior_context()
+                group = None
+                if not self.chain_parallel:
+                    forced = os.environ.get('DL_ENS_FORCE_COMM', None) is not None and isinstance(self.sharding.group, RcclGroup)   # single-rank smoke test of the in-stream collective
+                    group = self.sharding.group if ((self.sharding.sharded(self.nwalkers // 2) or forced) and isinstance(self.sharding.group, RcclGroup)) else None
+                self._runners[ichain] = _DeviceChain(ctx, offset, self.nwalkers, self.a, keys[ichain], group=group, own_stream=len(self.local_chains()) > 1)
             else:
-                start, logposterior = self._get_start(self.nwalkers)
-        else:
+                counter = self.chain_parallel or self._counter_requested
+                rng = CounterRNG(keys[ichain]) if counter else self.rng
+                self._runners[ichain] = _HostChain(self.nwalkers, ndim, self.logposterior, self.a, rng)
+        return self._runners[ichain]
+
+    @property
+    def _counter_requested(self):
+        return getattr(self, '_explicit_counter', False)
+
+    def _get_ensemble(self, ichain=0):
+        """The device ensemble of chain ``ichain`` (``DeviceEnsemble``)."""
+        return self._get_runner(ichain).ens
+
+    def _starts(self, start=None):
+        """(coords, logposterior) per chain that has none yet: drawn like the reference, chain after chain from the synchronised generator (samplers/base.py:274-323)."""
+        if start is not None:
             start = np.asarray(start, dtype='f8')
-            logposterior = self.logposterior(start)
-        if self.device_resident:
-            import torch
-            ens = self._get_ensemble()
-            device = torch.device('cuda', ens.device)
-            if self.chain is None or self._last[0] is not start:
-                ens.set_state(start, logposterior)
-            coords = torch.empty((niterations, self.nwalkers, ens.n_params), dtype=torch.float64, device=device)
-            logp = torch.empty((niterations, self.nwalkers), dtype=torch.float64, device=device)
-            ens.run(niterations * thin_by, thin_by=thin_by, chain=coords, chain_logp=logp)
-            coords, logp = coords.cpu().numpy(), logp.cpu().numpy()    # the one synchronisation of the run
-            self._last = (coords[-1], logp[-1]) if niterations else (start, logposterior)
-            self._naccepted = ens.get_state()[2]
-            self._niterations = ens.info('iteration')
-        elif self._emcee is not None:
+            if start.ndim == 2 and self.nchains == 1: start = start[None]
+            if start.shape != (self.nchains, self.nwalkers, len(self.varied_params)):
+                raise ValueError('Provide start with shape {}'.format((self.nchains, self.nwalkers, len(self.varied_params))))
+            logp = self.logposterior(start.reshape(-1, start.shape[-1])).reshape(self.nchains, self.nwalkers)
+            for ichain in range(self.nchains):
+                self._state[ichain] = (start[ichain], logp[ichain])
+                self._holds.pop(ichain, None)
+            return
+        for ichain in range(self.nchains):
+            if self._state[ichain] is None:
+                self._state[ichain] = self._get_start(self.nwalkers)
+
+    def _run_batch(self, niterations, thin_by=1):
+        """``niterations`` recorded updates of every chain: the chains of this rank concurrently, then one all-gather of the new samples."""
+        local = self.local_chains()
+        ndim = len(self.varied_params)
+        if self._emcee is not None:
+            start, logposterior = self._state[0]
             self.sampler._random = self.rng
             state = self._emcee.State(start, log_prob=logposterior)
+            first = self.sampler.iteration
             for state in self.sampler.sample(initial_state=state, iterations=niterations, thin_by=thin_by, store=True):
                 pass
-            coords, logp = self.sampler.get_chain(), self.sampler.get_log_prob()
-            self._last = (coords[-1], logp[-1])
+            new = {0: (self.sampler.get_chain()[first:], self.sampler.get_log_prob()[first:])}
+            self._accepted[0] = self.sampler.acceptance_fraction * self.sampler.iteration
+            self._iterations[0] = self.sampler.iteration
         else:
-            coords, logp = [], []
-            for it in range(niterations * thin_by):
-                start, logposterior = self.sampler.step(start, logposterior)
-                if (it + 1) % thin_by == 0:
-                    coords.append(start.copy()); logp.append(logposterior.copy())
-            coords, logp = np.array(coords), np.array(logp)
-            self._last = (start, logposterior)
-        chain = {param.name: coords[..., iparam] for iparam, param in enumerate(self.varied_params)}
-        chain['logposterior'] = logp
-        if self.chain is None:
-            self.chain = chain
+            runners = []
+            for ichain in local:
+                runner = self._get_runner(ichain)
+                coords, logp = self._state[ichain]
+                if self._holds.get(ichain, None) is not coords:      # a new runner, a loaded chain, a new start: hand over positions, log-posteriors and counters
+                    runner.set_state(coords, logp, iteration=self._iterations[ichain], naccepted=self._accepted[ichain])
+                runners.append(runner)
+            for runner in runners:
+                runner.enqueue(niterations, thin_by=thin_by)        # (device chains: asynchronous, one stream each)
+            new = {}
+            for ichain, runner in zip(local, runners):
+                new[ichain] = runner.collect()                       # the one synchronisation of the batch
+                self._accepted[ichain] = np.asarray(runner.naccepted, dtype='f8')
+                self._iterations[ichain] = runner.iteration
+        if self.chain_group is not None:
+            new = self._gather_chains(new, niterations, ndim)
+        for ichain in range(self.nchains):
+            coords, logp = new[ichain]
+            if niterations:
+                self._state[ichain] = (coords[-1], logp[-1])
+            if ichain in self._runners: self._holds[ichain] = self._state[ichain][0]
+            chain = {param.name: coords[..., iparam] for iparam, param in enumerate(self.varied_params)}
+            chain['logposterior'] = logp
+            if self.chains[ichain] is None:
+                self.chains[ichain] = chain
+            else:
+                self.chains[ichain] = {name: np.concatenate([self.chains[ichain][name], chain[name]], axis=0) for name in chain}
+
+    def _gather_chains(self, new, niterations, ndim):
+        """All-gather of the batch's samples: every rank ends up with every chain (one collective per batch: [chains per rank, niterations, nwalkers, ndim + 1 + 2]
+        doubles per rank; the two extra columns carry the accepted counts and the iteration counter)."""
+        nmax = (self.nchains + self.chain_world - 1) // self.chain_world
+        block = np.zeros((nmax, niterations + 1, self.nwalkers, ndim + 1), dtype='f8')
+        for slot, ichain in enumerate(self.local_chains()):
+            coords, logp = new[ichain]
+            block[slot, :niterations, :, :ndim], block[slot, :niterations, :, ndim] = coords, logp
+            block[slot, niterations, :, 0], block[slot, niterations, 0, 1] = self._accepted[ichain], self._iterations[ichain]
+        gathered = np.asarray(self.chain_group.allgather(block)).reshape(self.chain_world, nmax, niterations + 1, self.nwalkers, ndim + 1)
+        out = {}
+        for ichain in range(self.nchains):
+            rank, slot = ichain % self.chain_world, ichain // self.chain_world
+            out[ichain] = (gathered[rank, slot, :niterations, :, :ndim].copy(), gathered[rank, slot, :niterations, :, ndim].copy())
+            self._accepted[ichain], self._iterations[ichain] = gathered[rank, slot, niterations, :, 0].copy(), int(gathered[rank, slot, niterations, 0, 1])
+        return out
+
+    def run(self, niterations=300, thin_by=1, start=None, min_iterations=0, max_iterations=None, check_every=None, check=None):
+        """Run the chains.  ``niterations`` updates in one batch (``check_every=None``; cf. samplers/emcee.py:101-111), or batches of ``check_every`` updates until
+        the convergence tests of :meth:`check` pass (not before ``min_iterations``) or ``max_iterations`` is reached (samplers/base.py:409-502); ``check``: ``True`` /
+        dict of criteria / ``False``.  Chains are saved to ``save_fn`` after every batch (rank 0).  Returns the chain (dict name -> [niterations, nwalkers]) for one
+        chain, the list of chains otherwise."""
+        self._starts(start)
+        if check_every is None:
+            self._run_batch(int(niterations), thin_by=thin_by)
+            if self.save_fn is not None: self.save()
         else:
-            self.chain = {name: np.concatenate([self.chain[name], chain[name]], axis=0) for name in chain}
-        return self.chain
+            run_check = bool(check) or isinstance(check, dict)
+            criteria = check if isinstance(check, dict) else {}
+
+            def batch(niter):
+                self._run_batch(niter, thin_by=thin_by)
+                if self.save_fn is not None: self.save()
+                return self.check(**criteria) if run_check else False
+
+            _batch_iterate(batch, min_iterations=min_iterations, max_iterations=niterations if max_iterations is None else max_iterations, check_every=int(check_every))
+        return self.chains[0] if self.nchains == 1 else self.chains
+
+    def check(self, nsplits=4, burnin=0.5, stable_over=2, max_eigen_gr=0.03, max_diag_gr=None, max_geweke=None, max_geweke_pvalue=None, min_ess=None, reliable_ess=50,
+              max_dact=None, min_eigen_gr=None, min_diag_gr=None, min_geweke=None, min_geweke_pvalue=None, max_ess=None, min_dact=None, quiet=True):
+        """Convergence tests on the chains gathered so far (samplers/base.py:504-690; every rank holds every chain, so every rank gets the same answer): Gelman-Rubin
+        (eigenvalues and diagonal) across the chains split in ``nsplits``, Geweke, integrated autocorrelation time per walker; each criterion must hold over
+        ``stable_over`` consecutive calls.  Statistics are appended to ``self.diagnostics``.  (The reference's 'cl_diag_gr' -- Gelman-Rubin on interval limits -- is
+        not computed.)"""
+        from . import diagnostics as diag
+        if not isinstance(self.diagnostics, diag.Diagnostics): self.diagnostics = diag.Diagnostics(self.diagnostics)
+        d = self.diagnostics
+        if any(chain is None for chain in self.chains): return False
+        assert nsplits > 1
+        names = self.varied_params.names()
+        arrays = [np.stack([chain[name] for name in names], axis=-1) for chain in self.chains]     # [niterations, nwalkers, ndim] per chain
+        size = arrays[0].shape[0]
+        if 0 < burnin < 1: burnin = int(burnin * size + 0.5)
+        burnin = int(burnin)
+        nsplits = int((nsplits + self.nchains - 1) / self.nchains)
+        lensplits = (size - burnin) // nsplits
+        split = [array[burnin + islab * lensplits:burnin + (islab + 1) * lensplits] for islab in range(nsplits) for array in arrays]
+        if any(s.shape[0] < 1 for s in split): return False
+        kw = dict(stable_over=stable_over, quiet=quiet, log=print)
+        toret = True
+
+        def attempt(func, default=np.nan):
+            try: return func()
+            except (ValueError, np.linalg.LinAlgError): return default
+
+        eigen_gr = attempt(lambda: diag.gelman_rubin(split, method='eigen', check_valid='ignore').max() - 1.)
+        toret &= d.add_test('eigen_gr', 'max eigen Gelman-Rubin - 1', eigen_gr, limits=(min_eigen_gr, max_eigen_gr), **kw)
+        diag_gr = attempt(lambda: diag.gelman_rubin(split, method='diag').max() - 1.)
+        toret &= d.add_test('diag_gr', 'max diag Gelman-Rubin - 1', diag_gr, limits=(min_diag_gr, max_diag_gr), **kw)
+        all_geweke = attempt(lambda: diag.geweke(split, first=0.1, last=0.5))
+        toret &= d.add_test('geweke', 'max Geweke', np.max(all_geweke), limits=(min_geweke, max_geweke), **kw)
+        from scipy import stats
+        pvalue = attempt(lambda: stats.normaltest(all_geweke, axis=None).pvalue)
+        toret &= d.add_test('geweke_pvalue', 'Geweke p-value', pvalue, limits=(min_geweke_pvalue, max_geweke_pvalue), **kw)
+        walkers = np.concatenate([np.moveaxis(array[burnin:], 1, 0) for array in arrays])            # one series per walker (samplers/base.py:646-651)
+        iact = attempt(lambda: diag.integrated_autocorrelation_time(walkers), default=np.full(len(names), np.nan))
+        d.add('iact', iact)
+        nsamples = walkers.shape[1]
+        toret &= d.add_test('iterations_over_iact', 'effective sample size = ({:d} iterations / integrated autocorrelation time)'.format(nsamples) + (' (reliable)' if reliable_ess * iact.max() < nsamples else ''),
+                            nsamples / iact.max(), limits=(min_ess, max_ess), **kw)
+        if len(d['iact']) >= 2:
+            rel = np.abs(d['iact'][-2] / d['iact'][-1] - 1.).max()
+            toret &= d.add_test('dact', 'max variation of integrated autocorrelation time', rel, limits=(min_dact, max_dact), **kw)
+        return bool(toret)
 
     @property
     def acceptance_fraction(self):
-        if self.device_resident:
-            return self._naccepted / max(self._niterations, 1)
-        return self.sampler.acceptance_fraction
+        """Accepted fraction per walker of chain 0 (one chain), or ``[nchains, nwalkers]``."""
+        out = np.array([self._accepted[ichain] / max(self._iterations[ichain], 1) for ichain in range(self.nchains)])
+        return out[0] if self.nchains == 1 else out
 
-    def save(self, fn):
-        """Chains as ``.npz`` (the reference's checkpoint format, parameter.py:2164-2182): resume with ``load``."""
-        np.savez(fn, **self.chain)
+    # ---- checkpoints -----------------------------------------------------------------------------------------------------------------------------------------
+    def _chain_file(self, ichain):
+        from .io import ChainFile
+        attrs = {'sampler': self.name, 'nwalkers': self.nwalkers, 'a': self.a, 'iteration': int(self._iterations[ichain]), 'naccepted': np.asarray(self._accepted[ichain]).tolist(),
+                 'counter_seed': None if self.counter_seeds is None else int(self.counter_seeds[ichain])}
+        return ChainFile(dict(self.chains[ichain]), params={param.name: param for param in self.varied_params}, attrs=attrs)
+
+    def save(self, fn=None):
+        """Chains in the reference's checkpoint format (``Chain.save``, parameter.py:2164-2182: read by the reference's ``Chain.load`` and by :meth:`load`); the
+        attributes carry what resuming the very same chain needs (iteration counter and key of the counter-based generator, accepted counts).  One file per chain
+        (``fn``: a name for a single chain, a list, or a template with ``*``; default ``save_fn``); written by rank 0 of the chains' group."""
+        if fn is None: fn = self.save_fn
+        if fn is None: raise ValueError('provide a file name')
+        if isinstance(fn, str): fn = [fn.replace('*', str(ichain)) for ichain in range(self.nchains)]
+        if len(fn) != self.nchains: raise ValueError('provide one file name per chain')
+        if self.chain_rank != 0 or (not self.chain_parallel and self.sharding.rank != 0): return
+        for ichain, name in enumerate(fn):
+            if self.chains[ichain] is not None: self._chain_file(ichain).save(name)
+
+    def _load_one(self, ichain, source):
+        from .io import ChainFile
+        chain = source if hasattr(source, 'arrays') else ChainFile.load(source)
+        names = self.varied_params.names()
+        self.chains[ichain] = {name: np.asarray(chain.arrays[name], dtype='f8') for name in names + ['logposterior']}
+        last = np.column_stack([self.chains[ichain][name][-1] for name in names])
+        self._state[ichain] = (last, self.chains[ichain]['logposterior'][-1].copy())
+        self._holds.pop(ichain, None)            # whatever a runner holds is not this state: handed over at the next run
+        attrs = chain.attrs
+        self._iterations[ichain] = int(attrs.get('iteration', self.chains[ichain]['logposterior'].shape[0]))
+        nacc = attrs.get('naccepted', None)
+        self._accepted[ichain] = np.zeros(self.nwalkers) if nacc is None else np.asarray(nacc, dtype='f8')
+        key = attrs.get('counter_seed', None)
+        if key is not None:
+            if self.counter_seeds is None: self.counter_seeds = [None] * self.nchains
+            if self.counter_seeds[ichain] is not None and self.counter_seeds[ichain] != int(key) and ichain in self._runners:
+                runner = self._runners.pop(ichain)
+                if runner.device_resident: runner.ens.close()
+            self.counter_seeds[ichain] = int(key)
+            if any(k is None for k in self.counter_seeds):   # (partly loaded: the remaining keys are drawn when the chains start)
+                pass
 
     def load(self, fn):
-        data = np.load(fn)
-        self.chain = {name: data[name] for name in data.files}
-        last = np.column_stack([self.chain[param.name][-1] for param in self.varied_params])
-        self._last = (last, self.chain['logposterior'][-1])
-        if self._ensemble is not None:
-            self._ensemble.set_state(*self._last)
+        """Resume from files written by :meth:`save` (one name, a list, or a template with ``*``): the next :meth:`run` continues these chains -- positions,
+        log-posteriors, generator key and counter are handed to the (possibly new) ensembles, so the continuation is the chain an uninterrupted run would give."""
+        if isinstance(fn, str): fn = [fn.replace('*', str(ichain)) for ichain in range(self.nchains)]
+        if len(fn) != self.nchains: raise ValueError('provide one file name per chain')
+        for ichain, name in enumerate(fn):
+            self._load_one(ichain, name)
+        if self.counter_seeds is not None and any(key is None for key in self.counter_seeds):
+            self.counter_seeds = None
+        for ichain, runner in list(self._runners.items()):
+            if runner.device_resident and self.counter_seeds is not None:
+                # an ensemble keeps the key it was created with: recreate those whose key changed
+                pass
 
 
 def _expand_dict(values, names):

@@ -225,6 +225,9 @@ int  dl_ensemble_set_state(dl_ensemble* ens, const double* coords, const double*
 int  dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, double* chain_dev, double* chain_logp_dev, void* hip_stream);
 /* host arrays (any may be NULL): current positions, log-posteriors, number of accepted proposals per walker; synchronises ``hip_stream`` */
 int  dl_ensemble_get_state(dl_ensemble* ens, double* coords, double* logposterior, int64_t* naccepted, void* hip_stream);
+/* resume: the iteration counter of the random number generator (the draw of update i is a pure function of (seed, i): a sampler that restores positions, seed and
+ * counter continues the very chain it saved) and, if not NULL, the accepted-proposal counts per walker [nwalkers] (host) */
+int  dl_ensemble_set_counter(dl_ensemble* ens, int64_t iteration, const int64_t* naccepted, void* hip_stream);
 /* integer properties: "nwalkers", "n_params", "iteration", "rank", "world", "rows_per_rank" */
 int64_t dl_ensemble_info(const dl_ensemble* ens, const char* key);
 

@@ -362,6 +362,49 @@ def cfg5():
          **obs, **{k: v for k, v in out.items() if not k.startswith('int_')})
 
 
+def cfg5_bench():
+    """The shape bench.py times for BASELINE configs[4] (``bench.make_likelihood_config5``): two config-2 tracers, each with the dense synthetic 120 x 1200 window
+    (seeds 7 / 8), shared ShapeFit template, per-tracer b1 / sn0 namespaces, block-diagonal joint covariance (n = 240, 8 varied parameters), run by the REFERENCE
+    (full_shape.py:59-133; likelihoods/base.py:567, 617-619, 662-664).  The big inputs (windows 2 x 1.15 MB, covariance 0.46 MB) are regenerated by the test from the
+    same seeds: the fixture keeps their checksums (sum, sum of squares, a strided sample) so that a drift of the generators is caught, plus the template tables, flatdata and
+    every output of the reference.  theta: 64 draws of Parameter.ref (what the sampler starts from) + 61 draws of a five times wider cloud (where walkers wander) + the
+    special rows (outside the prior, on the closed limit)."""
+    from scipy import linalg
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    kedges = np.linspace(0., 0.2, 41)
+    observables, windows = [], []
+    for tracer, b1, shotnoise, seed in [('LRG', 2., 1e4, 7), ('ELG', 1.3, 4e3, 8)]:
+        kin, wmat = dense_window(kedges, (0, 2, 4), seed=seed)
+        windows.append(wmat)
+        theory = KaiserTracerPowerSpectrumMultipoles(template=template, tracers=tracer)
+        observables.append(TracerPowerSpectrumMultipolesObservable(data={tracer + '.b1': b1}, kedges=kedges, ells=(0, 2, 4), wmatrix=wmat, kin=kin, ellsin=(0, 2, 4), theory=theory, shotnoise=shotnoise))
+    cov = linalg.block_diag(spd_covariance(120, seed=1), spd_covariance(120, seed=2))
+    like = ObservablesGaussianLikelihood(observables=observables, covariance=cov)
+    assert abs(like(**{'LRG.b1': 2., 'ELG.b1': 1.3})) < 1e-16
+    names = like.varied_params.names()
+    assert sorted(names) == sorted(['qpar', 'qper', 'dm', 'df', 'LRG.b1', 'LRG.sn0', 'ELG.b1', 'ELG.sn0']), names   # (the reference's own order: the test maps columns by name)
+    narrow = sample_theta(like, 64, seed=42)
+    centre = np.array([param.value for param in like.varied_params])
+    wide = centre + 5. * (sample_theta(like, 64, seed=43) - centre)
+    theta = np.concatenate([narrow, wide])
+    iq, ib = names.index('qpar'), names.index('ELG.b1')
+    theta[-1, iq] = 1.3; theta[-2, ib] = -0.5; theta[-3, ib] = 4.
+    out = run_batch(like, observables, theta, names, nint=0)
+    print('cfg5_bench reference: {:.1f} evals/s'.format(1. / out['ref_seconds_per_eval']))
+
+    def checksum(a):
+        a = np.asarray(a, dtype='f8')
+        return np.concatenate([[a.sum(), (a**2).sum()], a.ravel()[::997][:64]])
+
+    tmpl = observables[0].wmatrix.theory.pt.template
+    precision = np.asarray(like.precision)
+    save('cfg5_bench', names=np.array(names), theta=theta, k11=np.asarray(tmpl.k), pk_dd_fid=np.asarray(tmpl.pk_dd_fid), f_fid=np.array(float(tmpl.f_fid)),
+         flatdata=np.concatenate([np.asarray(o.flatdata) for o in observables]), window_checksum=np.array([checksum(w) for w in windows]), covariance_checksum=checksum(cov),
+         precision_checksum=checksum(precision), window_seeds=np.array([7, 8]), covariance_seeds=np.array([1, 2]),
+         priors=np.array([[{'uniform': 0, 'norm': 1}[s['dist']], s['lo'], s['hi'], s['loc'], s['scale']] for s in map(prior_spec, like.varied_params)]),
+         **{k: v for k, v in out.items() if not k.startswith('int_')})
+
+
 def extract_bao_observable(obs, space='xi'):
     wm = obs.wmatrix
     theory = wm.theory
@@ -925,7 +968,7 @@ def kaiser_xi(eft=False, interp_order=1):
 
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi', 'cfg4_resummed', 'cfg4_flexible', 'cfg3_full', 'kaiser_xi_cubic', 'marg_multi']
+    todo = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg2_dense', 'cfg2_variants', 'marg_grid', 'cfg5', 'cfg4', 'cfg4_pk', 'cfg3_table', 'kaiser_xi', 'kaiser_xi_eft', 'cfg2_fc_syst', 'simple_tracer', 'cfg4_pcs', 'cfg4_models', 'cfg3_table_xi', 'cfg4_resummed', 'cfg4_flexible', 'cfg3_full', 'kaiser_xi_cubic', 'marg_multi', 'cfg5_bench']
     if 'cfg1' in todo: cfg1()
     if 'cfg2' in todo: cfg2(dense=False)
     if 'cfg2_dense' in todo: cfg2(dense=True)
@@ -947,3 +990,4 @@ if __name__ == '__main__':
     if 'cfg3_full' in todo: cfg3_full()
     if 'kaiser_xi_cubic' in todo: kaiser_xi(eft=False, interp_order=3)
     if 'marg_multi' in todo: marg_multi()
+    if 'cfg5_bench' in todo: cfg5_bench()

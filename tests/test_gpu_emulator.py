@@ -93,7 +93,7 @@ def test_mlp_emulated_marginalised_4096():
         f0 = oracle_flat(like, pt, theory, theta[i], names, {name: 0. for name in solved})
         T = np.array([oracle_flat(like, pt, theory, theta[i], names, {n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
         sol = orc.solve_marginalized(f0 - flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=locs, prior_scale=scales, marg_mask=np.ones(nsol, dtype='?'))
-        assert abs(loglike[i] - sol['loglikelihood']) <= 1e-9 * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
+        assert abs(loglike[i] - sol['loglikelihood']) <= 1e-10 * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
         assert np.allclose(xsolved[i], sol['x'], rtol=1e-7, atol=1e-9)
 
 
@@ -172,6 +172,10 @@ def test_taylor_emulator_fitted_on_the_gpu_theory():
     assert errors[4] < 0.05 * errors[2] and errors[4] < 1e-3 * np.abs(ref).max(), errors
 
 
+# north star: 1e-10 on logL -- also for the analytically marginalised value
+MARG_TOL = 1e-10
+
+
 # ---- BASELINE configs[2] at the size SURVEY.md section 8d states ------------------------------------------------------------------------------------------
 def make_cfg3_full(marg=True, model='rept'):
     """MLP in = 6 -> 4 x 64 silu -> 3 * 128 * 19 = 7296 outputs; 19-monomial combination; cubic interpolation to n_kin = 400; binning window 120 x 1200;
@@ -242,9 +246,14 @@ def test_cfg3_full_size_marginalised_4096():
         power = orc.interp1d(theory.k, pt.k, orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=theory.nd).T).T
         return orc.window_apply(power, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout)
 
-    for i in range(0, 4096, 1024):
+    worst = 0.
+    for i in range(0, 4096, 64):    # 64 points spread over the batch (every 16-point tile position modulo 64 is the same lane: the offsets below walk the tile)
+        i += (i // 64) % 16
         f0 = flat(theta[i], {name: 0. for name in solved})
         T = np.array([flat(theta[i], {n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
         sol = orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=np.zeros(nsol), prior_scale=scales, marg_mask=np.ones(nsol, dtype='?'))
-        assert abs(loglike[i] - sol['loglikelihood']) <= 1e-9 * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
+        err = abs(loglike[i] - sol['loglikelihood']) / max(1., abs(sol['loglikelihood']))
+        worst = max(worst, err)
+        assert err <= MARG_TOL, (i, loglike[i], sol['loglikelihood'], err)
         assert np.allclose(xsolved[i], sol['x'], rtol=1e-7, atol=1e-9)
+    print('cfg3 marginalised, 64 of 4096 points: max relative error on logL {:.2e}'.format(worst))
