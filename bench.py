@@ -291,6 +291,213 @@ def config5_strong(group, device, local_rank, rank, world, iterations, warmup=30
             'acceptance_fraction': float(nacc.sum()) / (512. * ens.info('iteration')), 'n_params': nparams, 'oracle_check': checked}
 
 
+def _timed_context(ctx, theta, steps, warmup, posterior_out, status, device):
+    """Seconds per call of ``ctx.eval_logposterior`` on the resident batch ``theta`` + the library's dispatch-attached kernel intervals (median, ms) of sampled calls."""
+    import torch
+    for _ in range(warmup): ctx.eval_logposterior(theta, posterior_out, status=status)
+    torch.cuda.synchronize(device)
+    every = max(1, steps // 8)
+    ctx.profile_enable(every)
+    t0 = time.perf_counter()
+    for _ in range(steps): ctx.eval_logposterior(theta, posterior_out, status=status)
+    torch.cuda.synchronize(device)
+    elapsed = (time.perf_counter() - t0) / steps
+    kernel_ms = ctx.profile_read()
+    ctx.profile_enable(0)
+    return elapsed, kernel_ms
+
+
+def cfg3_flop_counts(pt, n, n_solved, n_mono=19):
+    """The BUILD's own algorithmic count for BASELINE configs[2] (emulated theories): the last MLP layer x k-interpolation x window x L^T are
+    folded into ONE operator at context creation, so a point costs the hidden layers of the three engines, the product of that operator with the basis
+    (n_mono x n columns x n_basis), the monomial contraction of the 1 + n_solved rows, and the Gram matrix of those rows (SURVEY 8d's 1.8 MFLOP counts the
+    unfolded last layer 64 x 7296 and the 120 x 1200 window separately; against it the fused kernel would run above the peak)."""
+    hidden = pt.engines['pktable'].layers[:-1]
+    forward = sum(2 * k.shape[0] * k.shape[1] + 25 * k.shape[1] for k, b in hidden)                   # MACs + one silu (exp, division ~ 25) per unit
+    forward += sum(2 * k.shape[0] * k.shape[1] + 25 * k.shape[1] for name in ['sigma8', 'fsigma8'] for k, b in pt.engines[name].layers)
+    n_basis = hidden[-1][0].shape[1] + 1
+    return {'forward': forward, 'folded_operator': 2 * n_mono * n * n_basis, 'monomial_rows': 2 * n_mono * n * (1 + n_solved), 'gram': (1 + n_solved) * (2 + n_solved) * n,
+            'solve': 2 * n_solved**3 // 3 + 4 * n_solved**2}
+
+
+def other_configs(device, steps=40, warmup=5, ncheck=8):
+    """BASELINE configs[2] (MLP-emulated tables + 5 analytically marginalised parameters, 4096 points) and configs[3] (damped-BAO xi_ell through the Hankel operator,
+    8192 points) on this GPU: evaluations / s over ``steps`` calls on a resident batch, the dominant kernel's roofline fraction with the build's own FLOP count, and a
+    post-hoc check of ``ncheck`` points against the NumPy oracle (the parity tests proper: tests/test_gpu_emulator.py, tests/test_gpu_bao.py)."""
+    import gc
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_gpu_emulator import make_cfg3_full, cfg3_oracle_solution
+    from test_host_api import make_cfg4
+    from test_oracle_bao import bao_point
+    from oracle import np_oracle as orc
+    out = []
+
+    def sample(like, B, seed):
+        rng = np.random.RandomState(seed)
+        return np.column_stack([np.clip(param.ref.sample(size=B, random_state=rng), *param.prior.limits) for param in like.varied_params])
+
+    # ---- configs[2] ----
+    g, like, pt, theory, solved = make_cfg3_full(marg=True)
+    B = 4096
+    ctx = like._get_context()
+    theta_host = sample(like, B, 3)
+    theta = torch.as_tensor(theta_host, dtype=torch.float64, device=device).contiguous()
+    post, status = torch.empty(B, dtype=torch.float64, device=device), torch.zeros(B, dtype=torch.int32, device=device)
+    gc.collect()
+    elapsed, kernel_ms = _timed_context(ctx, theta, steps, warmup, post, status, device)
+    assert int((status != 0).sum().item()) == 0
+    loglike = ctx.eval_batch_host(theta_host[:ncheck])[0]
+    err = max(abs(loglike[i] - cfg3_oracle_solution(like, pt, theory, solved, theta_host[i])['loglikelihood']) / max(1., abs(loglike[i])) for i in range(ncheck))
+    assert err <= 1e-10, 'GPU / oracle mismatch on configs[2]: {:.3e}'.format(err)
+    flops = cfg3_flop_counts(pt, n=like.flatdata.size, n_solved=len(solved))
+    fused = flops['forward'] + flops['folded_operator'] + flops['monomial_rows'] + flops['gram']
+    slot = max(['theory', 'window_gemm'], key=lambda name: kernel_ms[name])
+    achieved = fused * B / (kernel_ms[slot] * 1e-3) / 1e12
+    out.append({'workload': 'BASELINE configs[2]: MLP-emulated velocileptors-style tables (in 6 -> 4 x 64 silu -> 3 x 128 x 19) + 19-monomial combination + cubic interpolation to n_kin = 400 + window 120 x 1200 '
+                            '+ 5 analytically marginalised parameters, {:d} batched points'.format(B),
+                'value': B / elapsed, 'unit': 'evals/s', 'ms_per_step': 1e3 * elapsed, 'steps': steps, 'dtype': 'f64', 'batch': B,
+                'roofline': {'bound': 'mfma', 'kernel': 'dl_emulated_feature_gram_kernel (MLP forward + folded-operator product + Gram epilogue, one launch)', 'flop_per_eval': flops,
+                             'flop_per_launch': fused * B, 'avg_launch_ms': kernel_ms[slot], 'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS,
+                             'flop_count': "the build's own algorithm (last layer x interpolation x window x L^T folded at create): DESIGN.md section 4; SURVEY 8d's unfolded 1.8 MFLOP / eval would exceed the peak"},
+                'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize']},
+                'oracle_check': {'points': ncheck, 'max_rel_err_vs_oracle': float(err), 'tolerance': 1e-10}})
+    del ctx, like, pt, theory
+    gc.collect()
+
+    # ---- configs[3] ----
+    g, like = make_cfg4('xi')
+    B = 8192
+    ctx = like._get_context()
+    names = like.varied_params.names()
+    theta_host = sample(like, B, 77)
+    theta = torch.as_tensor(theta_host, dtype=torch.float64, device=device).contiguous()
+    post, status = torch.empty(B, dtype=torch.float64, device=device), torch.zeros(B, dtype=torch.int32, device=device)
+    gc.collect()
+    elapsed, kernel_ms = _timed_context(ctx, theta, steps, warmup, post, status, device)
+    assert int((status != 0).sum().item()) == 0
+    loglike = ctx.eval_batch_host(theta_host[:ncheck])[0]
+    c = g['obs0']
+    gfix = dict(g); gfix['names'] = np.array(names)
+    err = 0.
+    for i in range(ncheck):
+        power, broadband = bao_point(gfix, theta_host[i])
+        ref = orc.gaussian_loglikelihood(np.ravel(orc.get_corr(power, c['kin'], c['s'], (0, 2)) + broadband), c['flatdata'], like.precision)[0]
+        err = max(err, abs(loglike[i] - ref) / max(1., abs(ref)))
+    assert err <= 1e-10, 'GPU / oracle mismatch on configs[3]: {:.3e}'.format(err)
+    nkin, nmu, n = len(c['kin']), len(c['mu']), like.flatdata.size
+    nbb = len(c['broadband_params'])
+    flops = {'bao_theory': 150 * nkin * nmu, 'hankel_window_gemm': 2 * n * (2 * nkin + nbb), 'chi2': 2 * n * n + 2 * n}
+    achieved = flops['bao_theory'] * B / (kernel_ms['theory'] * 1e-3) / 1e12
+    out.append({'workload': 'BASELINE configs[3]: damped-BAO xi_ell (ell = 0, 2; 30 s-bins; 300 log-k x 10 mu; FFTLog Hankel transform folded into a constant operator) + Gaussian likelihood, '
+                            '{:d} batched points'.format(B),
+                'value': B / elapsed, 'unit': 'evals/s', 'ms_per_step': 1e3 * elapsed, 'steps': steps, 'dtype': 'f64', 'batch': B,
+                'roofline': {'bound': 'valu', 'kernel': 'dl_bao_kernel (P(k, mu) on the 300-point log grid, no MFMA)', 'flop_per_eval': flops, 'flop_per_launch': flops['bao_theory'] * B,
+                             'avg_launch_ms': kernel_ms['theory'], 'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS,
+                             'flop_count': "SURVEY 8d's 150 FLOP per (k, mu) evaluation for the theory kernel; the FFTLog of SURVEY's count (0.49 MFLOP / eval) does not run per step: get_corr is linear in "
+                                           "P_ell, the build applies it as a 60 x 610 operator inside the window GEMM"},
+                'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize']},
+                'oracle_check': {'points': ncheck, 'max_rel_err_vs_oracle': float(err), 'tolerance': 1e-10}})
+    del ctx, like
+    gc.collect()
+    return out
+
+
+def sustained_leg(step, barrier, seconds, B, world, seconds_per_step, group=None):
+    """The same step for >= ``seconds`` of wall time (the driver's GPU-busy sampling sees nothing of a 0.5 ms timed region): evaluations / s over the whole stretch.
+    The number of steps is fixed beforehand from the timed region's rate (the same on every rank: the exchange is issued per step)."""
+    nsteps = 256 * max(1, int(np.ceil(1.05 * seconds / seconds_per_step / 256.)))
+    barrier()
+    t0 = time.perf_counter()
+    for block in range(nsteps // 256):
+        for _ in range(256): step()
+        if block % 64 == 63: barrier()      # keep the launch queue bounded
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if group is not None: elapsed = group.max(elapsed)
+    return {'seconds': elapsed, 'steps': nsteps, 'value': world * B * nsteps / elapsed, 'unit': 'evals/s', 'ms_per_step': 1e3 * elapsed / nsteps}
+
+
+def streams_leg(likelihood, device, B, ks=(1, 2, 4), steps=400, seed=777):
+    """K independent batches in flight on K HIP streams (one context replica each: same constants, own workspaces): each kernel of a 1024-point step fills the chip
+    for one round and pays its ramp and drain alone; with several steps in flight those tails overlap.  Evaluations / s at K = 1, 2, 4."""
+    import torch
+    out = []
+    for K in ks:
+        ctxs = [likelihood._get_context(replica=i) for i in range(K)]
+        streams = [torch.cuda.Stream(device=device) for _ in range(K)]
+        thetas = [torch.as_tensor(sample_theta(likelihood, B, seed + i), dtype=torch.float64, device=device).contiguous() for i in range(K)]
+        posts = [torch.empty(B, dtype=torch.float64, device=device) for _ in range(K)]
+        stats = [torch.zeros(B, dtype=torch.int32, device=device) for _ in range(K)]
+        torch.cuda.synchronize(device)
+
+        def run(n):
+            for _ in range(n):
+                for ctx, stream, theta, post, stat in zip(ctxs, streams, thetas, posts, stats):
+                    ctx.eval_logposterior(theta, post, status=stat, stream=stream.cuda_stream)
+            torch.cuda.synchronize(device)
+
+        run(20)
+        t0 = time.perf_counter()
+        run(steps)
+        elapsed = time.perf_counter() - t0
+        assert all(int((stat != 0).sum().item()) == 0 for stat in stats)
+        if K > 1:   # same points through replica 0 alone: same bits
+            check = torch.empty(B, dtype=torch.float64, device=device)
+            ctxs[0].eval_logposterior(thetas[-1], check)
+            torch.cuda.synchronize(device)
+            assert torch.equal(check, posts[-1]), 'context replicas disagree'
+        out.append({'streams': K, 'value': K * B * steps / elapsed, 'unit': 'evals/s', 'us_per_step': 1e6 * elapsed / (K * steps)})
+    return out
+
+
+def chains_weak(group, local_rank, rank, world, chains_per_gpu=(1, 2, 4), iterations=300, warmup=100):
+    """Chain-parallel sampling THROUGH THE SAMPLER (the reference's own scaling mode: one chain per group of ranks, desilike/utils.py:1040-1148): K chains per GPU,
+    each a device-resident 512-walker ensemble on the two-tracer likelihood with its own Philox key and HIP stream; nothing is exchanged inside the run, the new samples
+    of all chains are all-gathered once at its end (what `check_every` does in production).  Weak scaling: chains = K x n_gpus."""
+    import torch
+    from desilike_amd.samplers import EmceeSampler
+    from desilike_amd.parallel import WalkerSharding
+    likelihood = make_likelihood_config5(local_rank)
+    device = torch.device('cuda', local_rank)
+    out = []
+    for K in chains_per_gpu:
+        sampler = EmceeSampler(likelihood, nwalkers=512, chains=K * world, seed=42, sharding=WalkerSharding(group=group if group is not None else False), device_resident=True)
+        sampler.run(niterations=warmup)
+        torch.cuda.synchronize(device)
+        if group is not None: group.barrier()
+        t0 = time.perf_counter()
+        sampler.run(niterations=iterations)          # enqueue K ensembles on K streams, drain, all-gather the chains
+        torch.cuda.synchronize(device)
+        if group is not None: group.barrier()
+        elapsed = time.perf_counter() - t0
+        if group is not None: elapsed = group.max(elapsed)
+        logp = np.array([chain['logposterior'][-1] for chain in sampler.chains])
+        assert np.isfinite(logp).all() and len(sampler.chains) == K * world
+        entry = {'chains_per_gpu': K, 'chains': K * world, 'value': K * world * 512 * iterations / elapsed, 'unit': 'evals/s', 'us_per_update_per_chain': 1e6 * elapsed / iterations,
+                 'includes': 'enqueue, device run, drain of the chains to the host, all-gather of the chains across ranks'}
+        if rank == 0 and K == chains_per_gpu[-1]:
+            # every chain's final ensemble against the oracle (16 walkers each)
+            names = likelihood.varied_params.names()
+            worst = 0.
+            for chain in sampler.chains:
+                coords = np.column_stack([chain[name][-1] for name in names])[::32]
+                ref = oracle_logposterior(likelihood, coords)
+                worst = max(worst, float((np.abs(chain['logposterior'][-1][::32] - ref) / np.maximum(1., np.abs(ref))).max()))
+            assert worst <= 1e-10, 'GPU / oracle mismatch on the chains: {:.3e}'.format(worst)
+            entry['oracle_check'] = {'points': 16 * len(sampler.chains), 'max_rel_err_vs_oracle': worst, 'tolerance': 1e-10}
+            entry['gelman_rubin_eigen_minus_1'] = None
+            if K * world > 1:
+                sampler.check(max_eigen_gr=0.03)
+                entry['gelman_rubin_eigen_minus_1'] = float(sampler.diagnostics['eigen_gr'][-1])
+        out.append(entry)
+        for runner in sampler._runners.values(): runner.ens.close()
+    best = max(out, key=lambda entry: entry['value'])
+    return {'workload': 'EmceeSampler(chains = K x n_gpus, nwalkers = 512) on two config-2 tracers (n = 240): chain-parallel, device-resident, {:d} updates per chain'.format(iterations),
+            'scaling': 'weak', 'n_gpus': world, 'value': best['value'], 'unit': 'evals/s', 'best_chains_per_gpu': best['chains_per_gpu'], 'per_k': out,
+            'exchange': 'none inside the run; one all-gather of the chains at the end' if world > 1 else 'none (single rank)'}
+
+
 def dry_run(rank, world):
     """Everything of the N-rank launch path that does not need a GPU: ranks started, host-side group formed, one exchange, rank 0 prints the line skeleton."""
     from desilike_amd import parallel
@@ -323,6 +530,10 @@ def main():
     parser.add_argument('--prewarm-ms', type=float, default=400., help='untimed fixed-duration run of the step before the W warm-up steps (clocks ramp up; reported as prewarm_ms)')
     parser.add_argument('--config5-iterations', type=int, default=300, help='ensemble updates of the strong-scaling configs[4] measurement (0: skip)')
     parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--sustained-seconds', type=float, default=3., help='fixed-duration run of the same step after the timed region, reported as `sustained` (0: skip)')
+    parser.add_argument('--no-other-configs', action='store_true', help='skip BASELINE configs[2] / configs[3] (`other_configs`)')
+    parser.add_argument('--no-streams', action='store_true', help='skip the K-batches-in-flight measurement (`streams`)')
+    parser.add_argument('--chains-iterations', type=int, default=300, help='ensemble updates per chain of the chain-parallel sampler measurement `chains_weak` (0: skip)')
     parser.add_argument('--dry-run', action='store_true', help='launcher check without a GPU: start the ranks, form the (gloo) group, exchange, print the line skeleton')
     parser.add_argument('--no-events', action='store_true', help='diagnostic: no HIP events attached to the kernels in the timed region')
     args = parser.parse_args()
@@ -432,6 +643,10 @@ def main():
         elapsed = group.max(elapsed)
 
     assert all(int((st != 0).sum().item()) == 0 for st in statuses), 'non-OK status in the benchmark batch'
+    sustained = sustained_leg(step, barrier, args.sustained_seconds, B, world, elapsed / args.steps, group=group) if args.sustained_seconds > 0. else None
+    streams = streams_leg(likelihood, device, B) if (not args.no_streams and not distributed and B == BATCH) else None
+    others = other_configs(device) if (not args.no_other_configs and rank == 0 and B == BATCH) else None
+    chains = chains_weak(group if (distributed and world > 1) else None, local_rank, rank, world, iterations=args.chains_iterations) if (args.chains_iterations > 0 and B == BATCH) else None
     strong = None
     if args.config5_iterations > 0 and B == BATCH:
         strong = config5_strong(group, device, local_rank, rank, world, args.config5_iterations)
@@ -461,6 +676,12 @@ def main():
                                'event_mode': 'the dominant kernel only, every {:d} steps (short run)'.format(every) if short else 'all kernels of a sampled step, every {:d} steps'.format(every)},
                   'kernel_ms': {name: (kernel_ms[name] if kernel_ms[name] > 0. else None) for name in ['theory', 'window_gemm', 'finalize']},
                   'kernel_frac_of_fp64_peak': {name: flops[name] * per_launch / (kernel_ms[name] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS for name in ['theory', 'window_gemm'] if kernel_ms[name] > 0.}}
+        if sustained is not None:
+            sustained['agrees_with_value_within'] = abs(sustained['value'] / value - 1.)
+            result['sustained'] = sustained
+        if streams is not None: result['streams'] = streams
+        if others is not None: result['other_configs'] = others
+        if chains is not None: result['chains_weak'] = chains
         if strong is not None:
             result['config5_strong'] = strong
         if world == 1 and not distributed and not args.no_cpu_baseline:   # (the forced single-rank RCCL smoke mode writes log-posteriors into buckets, not `loglike`)

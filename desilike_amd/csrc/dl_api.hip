@@ -508,7 +508,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         // the chi2 GEMM consumes row block mb (32 points; the LDS-DMA GEMM: 64) on XCD mb % 8: have the theory kernel produce it there (power then waits in that XCD's L2:
         // -0.5 us per 1024 points)
         static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;   // 0: off, 1: chi2 GEMM path, 2: also the large-batch GEMM
-        const bool chi2_fused_early = getenv("DL_CHI2_FUSED") != nullptr && atoi(getenv("DL_CHI2_FUSED")) != 0 && !ctx->priors_general;
+        static const bool chi2_fused_env_early = getenv("DL_CHI2_FUSED") != nullptr && atoi(getenv("DL_CHI2_FUSED")) != 0;
+        const bool chi2_fused_early = chi2_fused_env_early && !ctx->priors_general;
         const int xcd_block = !xcd_local ? 0 : chi2_path ? (chi2_fused_early ? 32 : dl_chi2_gemm_row_tile(nb, ctx->N_pad)) : (xcd_local > 1 && !feat_path && !ctx->any_transform && ctx->n_solved == 0 && ctx->N_pad == 128) ? 64 : 0;
         prof_phase(0);
         if (!(feat_path && emu_fused))
@@ -545,7 +546,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         }
         // larger plain batches: the LDS-DMA split-K GEMM with the same partial-chi2 epilogue (no residual slab is written or read)
         int cps_probe = 0;
-        const bool chi2_big = !feat_path && !ctx->any_transform && ctx->n_solved == 0 && !chi2_path && ctx->K_pad % 32 == 0 && !getenv("DL_NO_CHI2_BIG") &&
+        static const bool chi2_big_allowed = !getenv("DL_NO_CHI2_BIG");
+        const bool chi2_big = !feat_path && !ctx->any_transform && ctx->n_solved == 0 && !chi2_path && ctx->K_pad % 32 == 0 && chi2_big_allowed &&
                               dl_gemm_tiled_splits(nb, ctx->N_pad, ctx->K_pad, &cps_probe) == 1;   // enough row tiles to fill the chip without splitting K
         int part_tiles = ctx->N_pad / 16;
         // DL_CHI2_FUSED=1: finalize inside the GEMM's last-arriving workgroups.  Off by default: measured 19.1 us (GEMM 17.1) against 17.5 us for GEMM + the

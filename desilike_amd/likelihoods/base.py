@@ -195,7 +195,7 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             nparams = len([param for param in self._all_params if param.varied and param.derived is False or param.solved])
             self.percival2014_factor = (1 + B * (nbins - nparams)) / (1 + A + B * (nparams + 1))
             self.precision = self.precision_hartlap2007 / self.percival2014_factor
-        self._contexts = {}
+        self._contexts, self._context_specs = {}, {}
         self._flatdata = None
         self._precision_input = self.precision
         self._initialized = True
@@ -340,25 +340,40 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         if current != getattr(self, '_params_generation', None):
             signature = tuple((param.name, repr(param.__getstate__())) for param in self._all_params)
             if signature != getattr(self, '_params_signature', signature):
-                self._contexts = {}   # (dropped, not closed: a device-resident ensemble may still hold one; unreferenced contexts free their device memory themselves)
+                self._contexts, self._context_specs = {}, {}   # (dropped, not closed: a device-resident ensemble may still hold one; unreferenced contexts free their device memory themselves)
             self._params_signature, self._params_generation = signature, generation()
 
-    def _get_context(self, fixed_values=None):
+    MAX_CONTEXTS = 32
+
+    def _replica(self, key, replica):
+        """Context ``replica`` > 0 of the compiled configuration ``key``: same constants, its own device workspaces -- callers that keep several evaluations in flight
+        on different HIP streams (chains of a chain-parallel sampler, pipelined batches) need one context per stream (calls on ONE context are serialised by contract:
+        include/desilike_amd.h)."""
+        from .._lib import Context
+        rkey = ('replica', int(replica)) + key
+        if rkey not in self._contexts:
+            if len(self._contexts) > self.MAX_CONTEXTS:
+                self._contexts.pop(next(iter(self._contexts))).close()
+            self._contexts[rkey] = Context(self._context_specs[key], device=self.device)
+        return self._contexts[rkey]
+
+    def _get_context(self, fixed_values=None, replica=0):
         from .._lib import Context
         self.initialize()
         self._check_params()
         fixed_values = dict(fixed_values or {})
         key = tuple(sorted(fixed_values.items()))
         if key not in self._contexts:
-            if len(self._contexts) > 8:
+            if len(self._contexts) > self.MAX_CONTEXTS:
                 self._contexts.pop(next(iter(self._contexts))).close()
             flatdata, precision = self._flatdata_list(), self._precision_input
             if len(self.prec_params):
                 flatdata, precision = self._marginalize_precision(fixed_values, flatdata, precision)
-            self._contexts[key] = Context(self._spec(fixed_values, flatdata, precision), device=self.device)
+            self._context_specs[key] = self._spec(fixed_values, flatdata, precision)
+            self._contexts[key] = Context(self._context_specs[key], device=self.device)
             # what the context holds, as the reference exposes it (likelihoods/base.py:308-309)
             self.precision, self.flatdata = precision, np.concatenate(flatdata)
-        return self._contexts[key]
+        return self._contexts[key] if not replica else self._replica(key, replica)
 
     def _solved_are_constant(self):
         """True if the derivative of the theory vector w.r.t. every analytically solved parameter is the same at all points: shot-noise like terms and
@@ -377,7 +392,7 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
                 constant.difference_update(imap['vp'])
         return all(name in constant for name in solved_names)
 
-    def _get_posterior_context(self, fixed_values=None):
+    def _get_posterior_context(self, fixed_values=None, replica=0):
         r"""Context and constant offset such that ``logposterior = ctx.eval_logposterior(theta) + offset`` (what samplers consume).
 
         When every analytically solved parameter has a point-independent derivative row T (:meth:`_solved_are_constant`), solving / marginalising them at each point
@@ -394,9 +409,9 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         self._check_params()
         fixed_values = dict(fixed_values or {})
         if not len(self.solved_params):
-            return self._get_context(fixed_values), 0.
+            return self._get_context(fixed_values, replica=replica), 0.
         if not self._solved_are_constant():
-            return self._get_context(fixed_values), 0.
+            return self._get_context(fixed_values, replica=replica), 0.
         key = ('posterior',) + tuple(sorted(fixed_values.items()))
         if key not in self._contexts:
             from .._lib import Context
@@ -436,12 +451,13 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             offset = -0.5 * np.linalg.slogdet(A[np.ix_(marg, marg)])[1] if marg.any() else 0.                                     # likelihoods/base.py:394-404
             spec = self._spec(base, new_flatdata, factor.dot(factor.T), drop_solved=True)
             spec['precision_factor'] = factor
-            if len(self._contexts) > 8:
+            if len(self._contexts) > self.MAX_CONTEXTS:
                 self._contexts.pop(next(iter(self._contexts))).close()
+            self._context_specs[key] = spec
             self._contexts[key] = Context(spec, device=self.device)
             self._posterior_offsets = getattr(self, '_posterior_offsets', {})
             self._posterior_offsets[key] = float(offset)
-        return self._contexts[key], self._posterior_offsets[key]
+        return (self._contexts[key] if not replica else self._replica(key, replica)), self._posterior_offsets[key]
 
     def _marginalize_precision(self, fixed_values, flatdata_list, precision):
         r"""'.prec' parameters (likelihoods/base.py:257-312): linear parameters marginalised once, at the current values of the others, into
@@ -704,7 +720,7 @@ class SumLikelihood(BaseLikelihood):
         self.initialize()
         return self._fused._get_context(fixed_values)
 
-    def _get_posterior_context(self, fixed_values=None):
+    def _get_posterior_context(self, fixed_values=None, replica=0):
         self.initialize()
         return self._fused._get_posterior_context(fixed_values)
 

@@ -51,7 +51,8 @@ def _exchange_bytes(payload, rank, world):
             port = int(os.environ.get('DL_COMM_PORT', int(os.environ.get('MASTER_PORT', 29500)) + 1))
             _stores.append(dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=timedelta(seconds=300), wait_for_workers=False))
     store = _stores[0]
-    key = 'desilike_amd/comm_id/{}/{:d}'.format(os.environ.get('TORCHELASTIC_RUN_ID', 'job'), _store_calls[0])
+    # (the restart count keeps the attempts of an elastic job apart: same run id and agent store, but a stale id of the previous attempt must not be picked up)
+    key = 'desilike_amd/comm_id/{}/{}/{:d}'.format(os.environ.get('TORCHELASTIC_RUN_ID', 'job'), os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'), _store_calls[0])
     _store_calls[0] += 1
     if rank == 0:
         store.set(key, payload)
@@ -261,6 +262,8 @@ class WalkerSharding(object):
         0: always shard."""
         if group is None:
             group = get_default_group()
+        elif group is False:   # explicitly local: no group even if a default one is set (chains of a chain-parallel sampler)
+            group = None
         elif not hasattr(group, 'allgather'):
             group = TorchGroup(group=group, device=device)
         self.min_shard_rows = int(min_shard_rows)

@@ -169,10 +169,10 @@ class Parameter(object):
     _attrs = ['basename', 'namespace', 'value', 'fixed', 'derived', 'prior', 'ref', 'proposal', 'delta', 'latex']
 
     def __init__(self, basename, namespace='', value=None, fixed=None, derived=False, prior=None, ref=None, proposal=None, delta=None, latex=None):
-        _generation[0] += 1
-        if isinstance(basename, Parameter):
+        if isinstance(basename, Parameter):   # (a copy changes nothing anybody compiled)
             self.__dict__.update(copy.deepcopy(basename.__dict__))
             return
+        _generation[0] += 1
         if isinstance(basename, dict):
             state = dict(basename)
             if 'name' in state: state['basename'] = state.pop('name')
@@ -345,7 +345,7 @@ class ParameterCollection(object):
                     self.set(Parameter(basename=name, **(conf or {})))
             return
         for item in data:
-            self.set(item if isinstance(item, Parameter) else Parameter(item))
+            self._set(item if isinstance(item, Parameter) else Parameter(item))
 
     def _index(self, name):
         name = str(name)
@@ -354,11 +354,16 @@ class ParameterCollection(object):
                 return i
         return None
 
-    def set(self, param):
-        _generation[0] += 1
+    def _set(self, param):
         i = self._index(param.name)
         if i is None: self.data.append(param)
         else: self.data[i] = param
+
+    def set(self, param):
+        """Add / replace a parameter.  Bumps the global generation: compiled contexts re-check their parameters.  (Building a collection from existing parameters
+        -- the ``varied_params`` / ``solved_params`` views made at every call -- goes through :meth:`_set` and does not.)"""
+        _generation[0] += 1
+        self._set(param)
 
     def get(self, name, *default):
         i = self._index(name)

@@ -390,6 +390,7 @@ class EmceeSampler(BasePosteriorSampler):
         if (self.device_resident or emcee is None) and (self.nwalkers % 2 or self.nwalkers < 2 * ndim):
             raise ValueError('nwalkers must be even and at least 2 * ndim')
         self.sampler = emcee.EnsembleSampler(self.nwalkers, ndim, self.logposterior, vectorize=True) if emcee is not None else None   # samplers/emcee.py:69
+        self._counter_given = counter_seeds is not None    # host-driven chains then draw from the counter-based generator too (same chain as the device's)
         self.counter_seeds = None if counter_seeds is None else [int(key) & 0xFFFFFFFFFFFFFFFF for key in np.atleast_1d(counter_seeds)]
         if self.counter_seeds is not None and len(self.counter_seeds) != self.nchains:
             raise ValueError('provide one counter seed per chain')
@@ -407,6 +408,7 @@ class EmceeSampler(BasePosteriorSampler):
         self._runners = {}                            # ichain -> runner, for the chains of this rank
         self._runner_signature = None
         self._holds = {}                              # ichain -> the coords array the runner currently continues from (identity)
+        self._refresh = set()                         # chains whose stored log-posteriors must be re-evaluated (the likelihood's parameters changed)
         self.diagnostics = {}
         if resume is not None:
             for ichain, source in enumerate(resume):
@@ -448,6 +450,7 @@ class EmceeSampler(BasePosteriorSampler):
             for runner in self._runners.values():
                 if runner.device_resident: runner.ens.close()
             self._runners, self._holds = {}, {}
+            self._refresh = set(range(self.nchains))     # the log-posteriors of the current positions belong to the old parameters: re-evaluated at hand-over
         self._runner_signature = signature
         if ichain not in self._runners:
             keys = self._draw_keys()
@@ -455,21 +458,19 @@ class EmceeSampler(BasePosteriorSampler):
             if self.device_resident:
                 from .parallel import RcclGroup
                 import os
-                ctx, offset = self.likelihood._get_posterior_context()
+                local = self.local_chains()
+                # one context per chain of this rank: the chains run concurrently on separate streams and a context's workspaces serve one call at a time
+                replica = local.index(ichain) if ichain in local else 0
+                ctx, offset = self.likelihood._get_posterior_context(replica=replica) if replica else self.likelihood._get_posterior_context()
                 group = None
                 if not self.chain_parallel:
                     forced = os.environ.get('DL_ENS_FORCE_COMM', None) is not None and isinstance(self.sharding.group, RcclGroup)   # single-rank smoke test of the in-stream collective
                     group = self.sharding.group if ((self.sharding.sharded(self.nwalkers // 2) or forced) and isinstance(self.sharding.group, RcclGroup)) else None
                 self._runners[ichain] = _DeviceChain(ctx, offset, self.nwalkers, self.a, keys[ichain], group=group, own_stream=len(self.local_chains()) > 1)
             else:
-                counter = self.chain_parallel or self._counter_requested
-                rng = CounterRNG(keys[ichain]) if counter else self.rng
+                rng = CounterRNG(keys[ichain]) if (self.chain_parallel or self._counter_given) else self.rng
                 self._runners[ichain] = _HostChain(self.nwalkers, ndim, self.logposterior, self.a, rng)
         return self._runners[ichain]
-
-    @property
-    def _counter_requested(self):
-        return getattr(self, '_explicit_counter', False)
 
     def _get_ensemble(self, ichain=0):
         """The device ensemble of chain ``ichain`` (``DeviceEnsemble``)."""
@@ -510,6 +511,10 @@ class EmceeSampler(BasePosteriorSampler):
             for ichain in local:
                 runner = self._get_runner(ichain)
                 coords, logp = self._state[ichain]
+                if ichain in self._refresh:
+                    self._refresh.discard(ichain)
+                    logp = self.logposterior(coords)
+                    self._state[ichain] = (coords, logp)
                 if self._holds.get(ichain, None) is not coords:      # a new runner, a loaded chain, a new start: hand over positions, log-posteriors and counters
                     runner.set_state(coords, logp, iteration=self._iterations[ichain], naccepted=self._accepted[ichain])
                 runners.append(runner)
@@ -659,26 +664,19 @@ class EmceeSampler(BasePosteriorSampler):
         key = attrs.get('counter_seed', None)
         if key is not None:
             if self.counter_seeds is None: self.counter_seeds = [None] * self.nchains
-            if self.counter_seeds[ichain] is not None and self.counter_seeds[ichain] != int(key) and ichain in self._runners:
-                runner = self._runners.pop(ichain)
-                if runner.device_resident: runner.ens.close()
             self.counter_seeds[ichain] = int(key)
-            if any(k is None for k in self.counter_seeds):   # (partly loaded: the remaining keys are drawn when the chains start)
-                pass
+        runner = self._runners.pop(ichain, None)   # an ensemble keeps the key it was created with: the next run builds one on the loaded key
+        if runner is not None and runner.device_resident: runner.ens.close()
 
     def load(self, fn):
         """Resume from files written by :meth:`save` (one name, a list, or a template with ``*``): the next :meth:`run` continues these chains -- positions,
-        log-posteriors, generator key and counter are handed to the (possibly new) ensembles, so the continuation is the chain an uninterrupted run would give."""
+        log-posteriors, generator key and counter are handed to new ensembles, so the continuation is the chain an uninterrupted run would give."""
         if isinstance(fn, str): fn = [fn.replace('*', str(ichain)) for ichain in range(self.nchains)]
         if len(fn) != self.nchains: raise ValueError('provide one file name per chain')
         for ichain, name in enumerate(fn):
             self._load_one(ichain, name)
         if self.counter_seeds is not None and any(key is None for key in self.counter_seeds):
-            self.counter_seeds = None
-        for ichain, runner in list(self._runners.items()):
-            if runner.device_resident and self.counter_seeds is not None:
-                # an ensemble keeps the key it was created with: recreate those whose key changed
-                pass
+            self.counter_seeds = None    # (files without keys, e.g. written by the reference: new keys are drawn)
 
 
 def _expand_dict(values, names):

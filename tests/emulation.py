@@ -7,18 +7,27 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _emu = None
+SANITIZE_FLAGS = ['-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer', '-g']
+
+
+def build_emulation(sanitize=False):
+    """Compile tests/csrc/emulate.cpp (the device phase functions of desilike_amd/csrc/dl_fullshape.h + the host-side constant folding of dl_host.hpp, run on the CPU);
+    ``sanitize``: the AddressSanitizer + UndefinedBehaviorSanitizer build (CPU only: GPU sanitizers are not available on this pool), to be loaded in a process started
+    with libasan preloaded (tests/test_emulation.py::test_emulation_under_sanitizers)."""
+    build = os.path.join(HERE, 'csrc', '_build')
+    os.makedirs(build, exist_ok=True)
+    so = os.path.join(build, 'libdl_emulate_asan.so' if sanitize else 'libdl_emulate.so')
+    src = os.path.join(HERE, 'csrc', 'emulate.cpp')
+    deps = [src] + [os.path.join(HERE, '..', 'desilike_amd', 'csrc', name) for name in ['dl_fullshape.h', 'dl_host.hpp']]
+    if not os.path.isfile(so) or any(os.path.getmtime(dep) > os.path.getmtime(so) for dep in deps):
+        subprocess.check_call(['g++', '-O1' if sanitize else '-O2', '-std=c++17', '-fPIC', '-shared'] + (SANITIZE_FLAGS if sanitize else []) + ['-o', so, src])
+    return so
 
 
 def load_emulation():
     global _emu
     if _emu is None:
-        build = os.path.join(HERE, 'csrc', '_build')
-        os.makedirs(build, exist_ok=True)
-        so = os.path.join(build, 'libdl_emulate.so')
-        src = os.path.join(HERE, 'csrc', 'emulate.cpp')
-        deps = [src] + [os.path.join(HERE, '..', 'desilike_amd', 'csrc', name) for name in ['dl_fullshape.h', 'dl_host.hpp']]
-        if not os.path.isfile(so) or any(os.path.getmtime(dep) > os.path.getmtime(so) for dep in deps):
-            subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-o', so, src])
+        so = build_emulation(sanitize=os.environ.get('DL_EMULATION_SANITIZE', '0') == '1')
         lib = ctypes.CDLL(so)
         dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
         lib.emu_config_new.restype = ctypes.c_void_p

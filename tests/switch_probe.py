@@ -1,0 +1,111 @@
+"""Child process of tests/test_gpu_switches.py: parity checks of the sections named on the command line, under whatever ``DL_*`` kernel-selection switches the parent put
+in the environment (most are read once per process).  Prints ``switch probe ok`` at the end."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+
+from golden_utils import load_golden, spec_from_golden, observable_constants
+from oracle import np_oracle as orc
+
+
+def close(got, ref, what):
+    err = np.abs(got - ref) / np.maximum(1., np.abs(ref))
+    assert (err <= 1e-10).all(), (what, float(err.max()))
+
+
+def section_fs():
+    """config 2 (dense window): the 64 reference points, and a 2537-row batch (ragged; above the chi2-GEMM limit when DL_CHI2_GEMM_MAX is lowered) against the oracle."""
+    from desilike_amd._lib import Context
+    g = load_golden('cfg2_shapefit_window_dense')
+    ctx = Context(spec_from_golden(g), device=0)
+    loglike, logprior, status = ctx.eval_batch_host(g['theta'])
+    close(loglike, g['loglikelihood'], 'cfg2 dense vs reference')
+    assert np.array_equal(status == 1, np.isneginf(g['logprior']))
+    rng = np.random.RandomState(5)
+    theta = rng.uniform([0.9, 0.9, -0.5, 0.5, 0.5, -3.], [1.1, 1.1, 0.5, 1.5, 3.5, 3.], size=(2537, 6))
+    loglike = ctx.eval_batch_host(theta)[0]
+    c, names = observable_constants(g), [str(n) for n in g['names']]
+    rows = np.arange(0, 2537, 181)
+    ref = []
+    for row in theta[rows]:
+        p = dict(zip(names, row)); p['b1'] = (p['b1'], p['b1'])
+        ref.append(orc.gaussian_loglikelihood(orc.fullshape_observable(c, p)['flattheory'], c['flatdata'], g['precision'])[0])
+    close(loglike[rows], np.array(ref), 'cfg2 dense 2537 rows vs oracle')
+    for B in [1, 33, 1024]:
+        close(ctx.eval_batch_host(theta[:B])[0], loglike[:B], 'batch {:d} vs the 2537-row pass'.format(B))
+
+
+def section_two():
+    """the benchmarked two-tracer shape against the reference fixture"""
+    import bench
+    g = load_golden('cfg5_bench')
+    like = bench.make_likelihood_config5(0)
+    names, rnames = like.varied_params.names(), [str(n) for n in g['names']]
+    theta = g['theta'][:, [rnames.index(name) for name in names]]
+    ctx, offset = like._get_posterior_context()
+    ref = g['loglikelihood'] + g['logprior']
+    for B in [128, 37, 256]:
+        th = np.concatenate([theta, theta])[:B]
+        got = ctx.eval_logposterior_host(th)[0] + offset
+        r = np.concatenate([ref, ref])[:B]
+        fin = np.isfinite(r)
+        assert np.array_equal(np.isneginf(got), ~fin)
+        close(got[fin], r[fin], 'two tracers, {:d} rows'.format(B))
+
+
+def section_ens():
+    """device-resident ensemble vs the NumPy stretch move with the same counter-based generator, bit for bit"""
+    import bench
+    from desilike_amd.samplers import EmceeSampler, EnsembleStretchMove, CounterRNG
+    like = bench.make_likelihood_config5(0)
+    sampler = EmceeSampler(like, nwalkers=64, seed=42)
+    start, _ = sampler._get_start(64)
+    chain = sampler.run(niterations=8, start=start)
+    host = EnsembleStretchMove(64, 8, sampler.logposterior, rng=CounterRNG(sampler.counter_seed))
+    coords, logp = start.copy(), sampler.logposterior(start)
+    for it in range(8):
+        coords, logp = host.step(coords, logp)
+        assert np.array_equal(chain['logposterior'][it], logp), it
+
+
+def section_emu():
+    """config 3 at full size: the reference fixture (no marginalisation) and the oracle's marginalised solve"""
+    from desilike_amd import vmap
+    from test_gpu_emulator import make_cfg3_full, cfg3_oracle_solution
+    g, like, pt, theory, solved = make_cfg3_full(marg=False)
+    names = [str(n) for n in g['names']]
+    (logpost, derived), errors = vmap(like, errors='return', return_derived=True)({name: g['theta'][:, i] for i, name in enumerate(names)})
+    assert errors == {}
+    close(derived[like._param_loglikelihood], g['loglikelihood'], 'cfg3 vs reference')
+    g, like, pt, theory, solved = make_cfg3_full(marg=True)
+    rng = np.random.RandomState(3)
+    theta = np.column_stack([np.clip(param.ref.sample(size=300, random_state=rng), *param.prior.limits) for param in like.varied_params])
+    loglike = like._get_context().eval_batch_host(theta)[0]
+    for i in [0, 157, 299]:
+        close(loglike[i], cfg3_oracle_solution(like, pt, theory, solved, theta[i])['loglikelihood'], 'cfg3 marginalised vs oracle')
+
+
+def section_bao():
+    """config 4 (xi_ell and P_ell) against the reference fixtures, at the fixture's size and inside a 5000-row batch (one wave per point above 4096 rows)"""
+    from desilike_amd import vmap
+    from test_host_api import make_cfg4
+    for space in ['xi', 'pk']:
+        g, like = make_cfg4(space)
+        rnames = [str(n) for n in g['names']]
+        (logpost, derived), errors = vmap(like, errors='return', return_derived=True)({name: g['theta'][:, i] for i, name in enumerate(rnames)})
+        assert errors == {}
+        close(logpost, g['logposterior'], 'cfg4 ' + space)
+        names = like.varied_params.names()
+        theta = np.tile(g['theta'][:, [rnames.index(n) for n in names]], (5000 // len(g['theta']) + 1, 1))[:5000]
+        loglike = like._get_context().eval_batch_host(theta)[0]
+        close(loglike[:len(g['theta'])], g['loglikelihood'], 'cfg4 ' + space + ' in a 5000-row batch')
+
+
+if __name__ == '__main__':
+    for name in sys.argv[1:]:
+        globals()['section_' + name]()
+    print('switch probe ok')

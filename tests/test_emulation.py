@@ -59,3 +59,25 @@ def test_emulated_velocileptors_vs_reference():
     assert np.allclose(flat, g['flattheory'], rtol=1e-11, atol=1e-8)
     tol = 1e-10 * np.maximum(1., np.abs(g['loglikelihood']))
     assert (np.abs(loglike - g['loglikelihood']) <= tol).all(), np.abs((loglike - g['loglikelihood']) / g['loglikelihood']).max()
+
+
+def test_emulation_under_sanitizers():
+    """SURVEY.md section 5 (sanitizer runs on the CPU build): the device phase functions and the host-side constant folding compiled with AddressSanitizer +
+    UndefinedBehaviorSanitizer, driven through the fixtures of this file in a child interpreter with libasan preloaded; any report fails the test."""
+    import os, subprocess, sys
+    from emulation import build_emulation
+    build_emulation(sanitize=True)
+    libasan = subprocess.check_output(['g++', '-print-file-name=libasan.so']).decode().strip()
+    if not os.path.isabs(libasan) or not os.path.isfile(libasan):
+        pytest.skip('libasan not found')
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ('import sys; sys.path.insert(0, {here!r}); sys.path.insert(0, {root!r})\n'
+            'import test_emulation as t\n'
+            'for name in ["cfg1_kaiser_nowindow", "cfg2_shapefit_window_dense", "cfg2v_eft_damping_qisoqap"]: t.test_emulated_kernel_vs_reference(name)\n'
+            't.test_emulated_two_tracers()\n'
+            'print("sanitized emulation ok")\n').format(here=here, root=os.path.dirname(here))
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS='detect_leaks=0:abort_on_error=0:halt_on_error=1', UBSAN_OPTIONS='print_stacktrace=1:halt_on_error=1', DL_EMULATION_SANITIZE='1')
+    out = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    err = out.stderr.decode()
+    assert out.returncode == 0 and 'sanitized emulation ok' in out.stdout.decode(), err[-3000:]
+    assert 'AddressSanitizer' not in err and 'runtime error' not in err, err[-3000:]

@@ -202,6 +202,35 @@ def make_cfg3_full(marg=True, model='rept'):
     return g, like, pt, theory, solved
 
 
+def cfg3_oracle_solution(like, pt, theory, solved, row):
+    """The NumPy oracle's analytically marginalised solution of BASELINE configs[2] at one point ``row`` of the varied parameters: MLP tables -> velocileptors
+    combination -> cubic interpolation -> window (the chain pinned on the reference by tests/golden/cfg3_full.npz), derivative rows of the solved parameters from unit
+    vectors through the same chain (the theory is linear in them), then ``solve_marginalized`` (likelihoods/base.py:314-413).  Shared with bench.py's post-hoc check."""
+    from emulator_utils import CFG3_PARAMS
+    names = like.varied_params.names()
+    nsol = len(solved)
+    scales = np.array([like.all_params[name].prior.scale for name in solved])
+    wm = like.observables[0].wmatrix
+    eng = pt.engines
+
+    def flat(x):
+        p = dict(zip(names, row)); p.update(x)
+        xin = np.array([p[name] for name in CFG3_PARAMS])
+        pktable = orc.mlp_predict(xin, eng['pktable'].xlimits, eng['pktable'].layers, 'silu', eng['pktable'].ylimits).reshape(3, -1, 19)
+        sigma8 = orc.mlp_predict(xin, eng['sigma8'].xlimits, eng['sigma8'].layers, 'silu', eng['sigma8'].ylimits)[0]
+        fsigma8 = orc.mlp_predict(xin, eng['fsigma8'].xlimits, eng['fsigma8'].layers, 'silu', eng['fsigma8'].ylimits)[0]
+        params = {name: p.get(name, like.all_params[name].value) for name in ['b1p', 'b2p', 'bsp', 'b3p', 'alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p', 'sn4p']}
+        pars = orc.velocileptors_pars(params, sigma8, fsigma8 / sigma8, basis='physical', model='rept', snd=theory.snd, fsat=theory.fsat, sigv=theory.sigv)
+        power = orc.interp1d(theory.k, pt.k, orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=theory.nd).T).T
+        return orc.window_apply(power, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout)
+
+    f0 = flat({name: 0. for name in solved})
+    if not nsol:
+        return {'loglikelihood': orc.gaussian_loglikelihood(f0, like.flatdata, like.precision)[0]}
+    T = np.array([flat({n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
+    return orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=np.zeros(nsol), prior_scale=scales, marg_mask=np.ones(nsol, dtype='?'))
+
+
 def test_cfg3_full_size_vs_reference():
     """The reference ran its own velocileptors combination + interpolation + window + chi2 on the tables of these MLPs (tests/golden/make_golden.py::cfg3_full)."""
     from desilike_amd import vmap
@@ -231,27 +260,10 @@ def test_cfg3_full_size_marginalised_4096():
     loglike, logprior, status, xsolved = ctx.eval_batch_host(theta, return_solved=True)
     assert (status == 0).all() and np.isfinite(loglike).all()
     nsol = len(solved)
-    scales = np.array([like.all_params[name].prior.scale for name in solved])
-    wm = like.observables[0].wmatrix
-    eng = pt.engines
-
-    def flat(row, x):
-        p = dict(zip(names, row)); p.update(x)
-        xin = np.array([p[name] for name in CFG3_PARAMS])
-        pktable = orc.mlp_predict(xin, eng['pktable'].xlimits, eng['pktable'].layers, 'silu', eng['pktable'].ylimits).reshape(3, -1, 19)
-        sigma8 = orc.mlp_predict(xin, eng['sigma8'].xlimits, eng['sigma8'].layers, 'silu', eng['sigma8'].ylimits)[0]
-        fsigma8 = orc.mlp_predict(xin, eng['fsigma8'].xlimits, eng['fsigma8'].layers, 'silu', eng['fsigma8'].ylimits)[0]
-        params = {name: p.get(name, like.all_params[name].value) for name in ['b1p', 'b2p', 'bsp', 'b3p', 'alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p', 'sn4p']}
-        pars = orc.velocileptors_pars(params, sigma8, fsigma8 / sigma8, basis='physical', model='rept', snd=theory.snd, fsat=theory.fsat, sigv=theory.sigv)
-        power = orc.interp1d(theory.k, pt.k, orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=theory.nd).T).T
-        return orc.window_apply(power, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout)
-
     worst = 0.
     for i in range(0, 4096, 64):    # 64 points spread over the batch (every 16-point tile position modulo 64 is the same lane: the offsets below walk the tile)
         i += (i // 64) % 16
-        f0 = flat(theta[i], {name: 0. for name in solved})
-        T = np.array([flat(theta[i], {n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
-        sol = orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=np.zeros(nsol), prior_scale=scales, marg_mask=np.ones(nsol, dtype='?'))
+        sol = cfg3_oracle_solution(like, pt, theory, solved, theta[i])
         err = abs(loglike[i] - sol['loglikelihood']) / max(1., abs(sol['loglikelihood']))
         worst = max(worst, err)
         assert err <= MARG_TOL, (i, loglike[i], sol['loglikelihood'], err)

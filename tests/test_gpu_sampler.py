@@ -258,12 +258,15 @@ def test_bench_two_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DL_BENCH_BACKEND='gloo')
     env.pop('WORLD_SIZE', None); env.pop('RANK', None)
-    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '16', '--warmup', '4', '--prewarm-ms', '50', '--config5-iterations', '4'],
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '16', '--warmup', '4', '--prewarm-ms', '50', '--config5-iterations', '4', '--chains-iterations', '6',
+                          '--sustained-seconds', '0.2', '--no-other-configs', '--no-cpu-baseline'],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['config']['ranks'] == 2 and line['value'] > 0.
     assert line['config5_strong']['n_gpus'] == 2
+    assert line['chains_weak']['n_gpus'] == 2 and [entry['chains'] for entry in line['chains_weak']['per_k']] == [2, 4, 8]      # chain-parallel sampler: K chains per rank
+    assert line['sustained']['steps'] >= 256
 
 
 def test_config5_as_stated_device_vs_host_driver():
@@ -319,3 +322,67 @@ def test_config5_as_stated_device_vs_host_driver():
     finally:
         del os.environ['DL_CG_MT']
     assert torch.equal(out16, out32) and torch.equal(out16, ref[:256])
+
+
+# ---- chains as the unit of parallelism: one device-resident ensemble per chain, several chains of a process on separate streams -------------------------------------
+def test_two_chains_on_two_streams_are_the_single_chain_runs():
+    """chains = 2 on ONE GPU (two ensembles, two HIP streams, enqueued back to back) == two single-chain runs with the same keys and starts, bit for bit."""
+    from desilike_amd.samplers import EmceeSampler
+    g, like = make_cfg5()
+    nwalkers, niterations = 64, 25
+    both = EmceeSampler(like, nwalkers=nwalkers, chains=2, seed=42)
+    assert both.device_resident and both.chain_parallel and both.local_chains() == [0, 1]
+    both._starts()
+    starts = np.array([both._state[ichain][0] for ichain in range(2)])
+    chains = both.run(niterations=niterations, check_every=10, check=False)          # three batches: 10 + 10 + 5
+    assert both._runners[0].stream is not None and both._runners[0].stream.cuda_stream != both._runners[1].stream.cuda_stream
+    assert chains[0]['logposterior'].shape == (niterations, nwalkers)
+    assert not np.array_equal(chains[0]['qpar'], chains[1]['qpar'])
+    for ichain in range(2):
+        single = EmceeSampler(like, nwalkers=nwalkers, seed=1, counter_seeds=[both.counter_seeds[ichain]])
+        chain = single.run(niterations=niterations, start=starts[ichain])
+        for name in chain:
+            assert np.array_equal(chain[name], chains[ichain][name]), (ichain, name)
+        assert np.array_equal(single.acceptance_fraction, both.acceptance_fraction[ichain])
+    assert both.check(max_eigen_gr=100.) in (True, False) and len(both.diagnostics['eigen_gr']) == 1
+
+
+def test_device_resident_resume_from_checkpoint(tmp_path):
+    """load() into a fresh sampler, then run() -- the new ensemble must take over positions, log-posteriors, key and counter of the file (it used to
+    sample from uninitialised device memory): run -> save -> load -> run == the uninterrupted run."""
+    from desilike_amd.samplers import EmceeSampler
+    g, like = make_cfg5()
+    nwalkers = 64
+    full = EmceeSampler(like, nwalkers=nwalkers, seed=9)
+    start, _ = full._get_start(nwalkers)
+    full.run(niterations=35, start=start)
+    first = EmceeSampler(like, nwalkers=nwalkers, seed=9, counter_seeds=[full.counter_seed])
+    first.run(niterations=20, start=start)
+    fn = str(tmp_path / 'chain.npz')
+    first.save(fn)
+    fresh = EmceeSampler(like, nwalkers=nwalkers, seed=1234)
+    fresh.load(fn)
+    chain = fresh.run(niterations=15)
+    assert chain['logposterior'].shape == (35, nwalkers)
+    for name in chain:
+        assert np.array_equal(chain[name], full.chain[name]), name
+    assert np.array_equal(fresh.acceptance_fraction, full.acceptance_fraction)
+    # the same through the constructor (chains = files), and load() on a sampler whose ensemble already exists
+    again = EmceeSampler(like, nwalkers=nwalkers, chains=[fn])
+    assert np.array_equal(again.run(niterations=15)['qpar'], full.chain['qpar'])
+    used = EmceeSampler(like, nwalkers=nwalkers, seed=3)
+    used.run(niterations=4)
+    used.load(fn)
+    assert np.array_equal(used.run(niterations=15)['logposterior'], full.chain['logposterior'])
+
+
+def test_device_ensemble_follows_parameter_changes():
+    """a change of ``likelihood.all_params`` after the first run must reach the device-resident ensemble (it used to keep the old context)."""
+    from desilike_amd.samplers import EmceeSampler
+    g, like = make_cfg5()
+    sampler = EmceeSampler(like, nwalkers=32, seed=5)
+    sampler.run(niterations=5)
+    like.all_params['LRG.b1'].update(prior=dict(dist='norm', loc=2., scale=0.01))
+    chain = sampler.run(niterations=5)
+    coords = np.column_stack([chain[param.name][-1] for param in like.varied_params])
+    assert np.allclose(chain['logposterior'][-1], sampler.logposterior(coords), rtol=1e-12, atol=1e-9)   # (the host route re-reads the parameters at every call)

@@ -368,3 +368,110 @@ open(os.path.join({tmp!r}, 'ok_{{}}_{{:d}}'.format(os.environ.get('TORCHELASTIC_
     for rank, proc in enumerate(procs):
         text = proc.communicate(timeout=300)[0].decode()
         assert proc.returncode == 0 and (tmp_path / 'ok_None_{:d}'.format(rank)).exists(), text[-2000:]
+
+
+# ---- chains as the unit of parallelism (samplers/base.py:409-502, utils.py:1040-1148) ---------------------------------------------------------------------------
+def _chains_reference(nchains=3, niterations=40, nwalkers=12, seed=11):
+    """Single process: ``nchains`` chains of the toy posterior through the host-driven counter-based stretch move."""
+    from desilike_amd.samplers import EmceeSampler
+    from desilike_amd.parallel import WalkerSharding
+    sampler = EmceeSampler(ToyGaussianLikelihood(), nwalkers=nwalkers, chains=nchains, seed=seed, use_emcee=False, sharding=WalkerSharding(group=False))
+    sampler.run(niterations=niterations)
+    return sampler
+
+
+def test_chains_are_independent_and_reproducible():
+    from desilike_amd.samplers import EmceeSampler
+    from desilike_amd.parallel import WalkerSharding
+    sampler = _chains_reference()
+    assert len(sampler.chains) == 3 and all(chain['a'].shape == (40, 12) for chain in sampler.chains)
+    assert len(set(sampler.counter_seeds)) == 3
+    assert not np.array_equal(sampler.chains[0]['a'], sampler.chains[1]['a'])
+    # chain c == the single-chain run with chain c's key and start
+    for ichain in [0, 2]:
+        start = np.column_stack([sampler.chains[ichain][name][0] for name in ['a', 'b']])   # (the state after the first update: continue from there)
+        single = EmceeSampler(ToyGaussianLikelihood(), nwalkers=12, chains=1, seed=99, use_emcee=False, counter_seeds=[sampler.counter_seeds[ichain]], sharding=WalkerSharding(group=False))
+        single._state[0] = (start, sampler.chains[ichain]['logposterior'][0].copy())
+        single._iterations[0] = 1
+        single.run(niterations=39)
+        for name in ['a', 'b', 'logposterior']:
+            assert np.array_equal(single.chain[name], sampler.chains[ichain][name][1:]), (ichain, name)
+    # batches of check_every updates give the same chains as one run
+    batched = EmceeSampler(ToyGaussianLikelihood(), nwalkers=12, chains=3, seed=11, use_emcee=False, sharding=WalkerSharding(group=False))
+    batched.run(niterations=40, check_every=15, check=False)
+    for c0, c1 in zip(sampler.chains, batched.chains):
+        assert all(np.array_equal(c0[name], c1[name]) for name in c0)
+    assert np.array_equal(batched.acceptance_fraction, sampler.acceptance_fraction) and batched.acceptance_fraction.shape == (3, 12)
+
+
+def test_chain_checkpoint_resume(tmp_path):
+    """run -> save -> load into a NEW sampler -> run == the uninterrupted run (key, counter, positions and accepted counts travel in the file; reference layout)."""
+    from desilike_amd.samplers import EmceeSampler
+    from desilike_amd.parallel import WalkerSharding
+    from desilike_amd.io import ChainFile
+    full = _chains_reference(nchains=2, niterations=30)
+    first = EmceeSampler(ToyGaussianLikelihood(), nwalkers=12, chains=2, seed=11, use_emcee=False, sharding=WalkerSharding(group=False), save_fn=str(tmp_path / 'chain_*.npz'))
+    first.run(niterations=18)
+    saved = ChainFile.load(str(tmp_path / 'chain_1.npz'))
+    assert saved.attrs['iteration'] == 18 and saved.attrs['counter_seed'] == first.counter_seeds[1] and saved.arrays['a'].shape == (18, 12)
+    resumed = EmceeSampler(ToyGaussianLikelihood(), nwalkers=12, chains=[str(tmp_path / 'chain_0.npz'), str(tmp_path / 'chain_1.npz')], seed=5, use_emcee=False, sharding=WalkerSharding(group=False))
+    resumed.run(niterations=12)
+    for c0, c1 in zip(full.chains, resumed.chains):
+        assert all(np.array_equal(c0[name], c1[name]) for name in c0)
+    assert np.array_equal(resumed.acceptance_fraction, full.acceptance_fraction)
+    # load() on an existing sampler that already ran something else
+    other = EmceeSampler(ToyGaussianLikelihood(), nwalkers=12, chains=2, seed=77, use_emcee=False, sharding=WalkerSharding(group=False))
+    other.run(niterations=3)
+    other.load(str(tmp_path / 'chain_*.npz'))
+    other.run(niterations=12)
+    for c0, c1 in zip(full.chains, other.chains):
+        assert all(np.array_equal(c0[name], c1[name]) for name in c0)
+
+
+def test_convergence_check_stops_the_run():
+    from desilike_amd.samplers import EmceeSampler
+    from desilike_amd.parallel import WalkerSharding
+    sampler = EmceeSampler(ToyGaussianLikelihood(), nwalkers=16, chains=4, seed=3, use_emcee=False, sharding=WalkerSharding(group=False))
+    sampler.run(min_iterations=200, max_iterations=4000, check_every=200, check={'max_eigen_gr': 0.05, 'stable_over': 2})
+    niterations = sampler.chains[0]['a'].shape[0]
+    assert 400 <= niterations < 4000 and niterations % 200 == 0            # stopped by the criterion, not by max_iterations
+    d = sampler.diagnostics
+    assert len(d['eigen_gr']) == niterations // 200 and all(d['eigen_gr_test'][-2:]) and d['eigen_gr'][-1] < 0.05
+    assert set(['diag_gr', 'geweke', 'geweke_pvalue', 'iact', 'iterations_over_iact']) <= set(d)
+    samples = np.column_stack([np.concatenate([chain[name][niterations // 2:].ravel() for chain in sampler.chains]) for name in ['a', 'b']])
+    like = ToyGaussianLikelihood()
+    assert np.allclose(samples.mean(axis=0), like.mean, atol=0.03) and np.allclose(samples.std(axis=0), np.diag(like.cov)**0.5, rtol=0.1)
+
+
+def _chains_worker(rank, world, port, results):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from desilike_amd.samplers import EmceeSampler
+    like = ToyGaussianLikelihood()
+    sampler = EmceeSampler(like, nwalkers=12, chains=3, seed=11 + 100 * rank, use_emcee=False)   # (different seeds on the ranks: rank 0's is broadcast)
+    assert sampler.chain_world == world and sampler.local_chains() == ([0, 2] if rank == 0 else [1])
+    sampler.run(niterations=40, check_every=15, check=False)
+    converged = sampler.check(max_eigen_gr=10.)
+    results[rank] = ([{name: value.copy() for name, value in chain.items()} for chain in sampler.chains], like.ncalls, sampler.counter_seeds, sampler.acceptance_fraction,
+                     dict(sampler.diagnostics), converged)
+    dist.destroy_process_group()
+
+
+def test_chain_parallel_gloo_world2():
+    """3 chains over 2 ranks (rank 0: chains 0 and 2, rank 1: chain 1): every rank ends up with all chains, bit-identical to the single-process run, having evaluated
+    only its own; the convergence statistics agree on all ranks."""
+    import torch.multiprocessing as mp
+    manager = mp.Manager()
+    results = manager.dict()
+    port = 35500 + os.getpid() % 2000
+    mp.spawn(_chains_worker, args=(2, port, results), nprocs=2, join=True)
+    ref = _chains_reference()
+    for rank in range(2):
+        chains, ncalls, keys, accepted, diag, converged = results[rank]
+        assert keys == ref.counter_seeds
+        for c0, c1 in zip(ref.chains, chains):
+            assert all(np.array_equal(c0[name], c1[name]) for name in c0)
+        assert np.array_equal(accepted, ref.acceptance_fraction)
+    assert results[0][1] > results[1][1]                       # rank 0 ran two chains, rank 1 one
+    assert results[0][4]['eigen_gr'] == results[1][4]['eigen_gr'] and results[0][5] == results[1][5]

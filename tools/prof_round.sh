@@ -1,10 +1,12 @@
 # Per-round measurement recipe (run on the GPU box through gpurun): bench lines, kernel trace + stats, HBM-traffic and SQ counters in separate passes.
 #   usage: bash tools/prof_round.sh r02a
 # The program goes directly after `rocprofv3 ... --` (python3 itself: no env / bash -c hop, the profiler's preloaded library has initialised the GPU already).
-TAG=${1:-r02x}
-R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/$TAG
-mkdir -p $OUT
+set -u
+TAG=${1:-r03x}
+R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+[ -f "$R/bench.py" ] || { echo "prof_round.sh: $R is not the repository root" >&2; exit 1; }
+OUT="$R/gpurun_out/$TAG"
+mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 timeout 300 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_steps20.json 2>> $OUT/${TAG}_bench.err     # the driver's command
@@ -27,4 +29,4 @@ cp $OUT/trace/*kernel_stats.csv $OUT/${TAG}_kernel_stats.csv 2>/dev/null
 cp $OUT/trace_ens/*kernel_stats.csv $OUT/${TAG}_ensemble_kernel_stats.csv 2>/dev/null
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/${TAG}_pmc_hbm_traffic.txt 2>&1
 python3 tools/sq_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 --stats $OUT/${TAG}_kernel_stats.csv > $OUT/${TAG}_pmc_sq_counters.txt 2>&1
-rm -rf $OUT/trace $OUT/trace_ens $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3
+rm -rf "$OUT/trace" "$OUT/trace_ens" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq1" "$OUT/pmc_sq2" "$OUT/pmc_sq3"
