@@ -10,6 +10,7 @@
 #include "../../include/desilike_amd.h"
 #include "dl_host.hpp"
 #include "dl_kernels.h"
+#include "dl_ens_fold.h"
 #include "dl_prior.h"
 
 static thread_local std::string g_last_error;
@@ -841,6 +842,40 @@ int dl_profile_read(dl_ctx* ctx, double* ms, int32_t n) {
 }
 
 }  // extern "C"
+
+static bool dl_fold_applicable(const dl_ctx* ctx, int64_t B) {
+    static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 2048;
+    if (ctx->feat_ok || ctx->any_transform || ctx->n_solved != 0 || B > chi2_max_rows || B > DL_CHUNK || ctx->n_params > 32) return false;
+    for (auto& ob : ctx->obs) {
+        const DlObsDev& oh = ob.dev;
+        const bool generic = !oh.uniform_knots || !(oh.toeplitz || oh.fixed_spline);
+        if (oh.theory == 2 || oh.theory == 3 || generic || oh.n_ct > 0 || oh.n_sn > 0 || (oh.n_ell <= 3) != (ctx->obs[0].dev.n_ell <= 3)) return false;
+    }
+    return ctx->n_obs >= 1 && ctx->n_obs <= 8;
+}
+
+int dl_internal_fold_info(dl_ctx* ctx, int64_t B, int* n_tiles, const double** priors) {
+    if (!ctx || !n_tiles || !priors || B <= 0) return 1;
+    if (!dl_fold_applicable(ctx, B)) return 2;
+    *n_tiles = ctx->N_pad / 16;
+    *priors = ctx->priors_dev;
+    return 0;
+}
+
+int dl_internal_eval_fold(dl_ctx* ctx, const DlEnsFold& fold, int64_t B, double* part_out, hipStream_t stream) {
+    if (!ctx || !part_out || B <= 0) return 1;
+    if (!dl_fold_applicable(ctx, B)) return 2;
+    dl_prof_events.start = dl_prof_events.stop = nullptr;
+    DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (dl_order_streams(ctx, stream)) return 1;
+    if (dl_reserve(ctx, B)) return 1;
+    static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;
+    if (!dl_launch_fullshape_ens(ctx->obs_kernarg.data(), ctx->n_obs, ctx->obs_array_dev, fold, B, ctx->power_ws, ctx->K_pad, xcd_local ? dl_chi2_gemm_row_tile(B, ctx->N_pad) : 0, stream)) return 2;
+    dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, part_out, B, ctx->N_pad, ctx->K_pad, nullptr, nullptr, ctx->n_params,
+                        ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream, ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live);
+    DL_HIP_CHECK(ctx, hipGetLastError());
+    return 0;
+}
 
 int dl_internal_eval_partials(dl_ctx* ctx, const double* theta_dev, int64_t B, const double** part, int* n_tiles, const double** priors, hipStream_t stream) {
     if (!ctx || !theta_dev || !part || !n_tiles || !priors || B <= 0) return 1;

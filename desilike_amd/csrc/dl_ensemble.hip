@@ -22,6 +22,7 @@
 #include "../../include/desilike_amd.h"
 #include "dl_kernels.h"
 #include "dl_finalize_part.h"
+#include "dl_ens_fold.h"
 #include "dl_scalar_prefetch.h"
 
 namespace {
@@ -37,60 +38,7 @@ int fail(const std::string& msg) {
         if (err__ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(err__));   \
     } while (0)
 
-struct DlPhilox {
-    uint32_t x[4];
-};
-
-// Philox4x32-10 (Random123): counter c[4], key k[2]
-__host__ __device__ inline DlPhilox dl_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int round = 0; round < 10; ++round) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return DlPhilox{{c0, c1, c2, c3}};
-}
-
-// 53-bit uniform on [0, 1) from two 32-bit words (the construction of numpy's random_sample)
-__host__ __device__ inline double dl_uniform53(uint32_t hi, uint32_t lo) { return ((double)(hi >> 5) * 67108864. + (double)(lo >> 6)) * (1. / 9007199254740992.); }
-
 #define DL_ENS_THREADS 1024   // one workgroup
-enum { DL_ENS_STREAM_PERM = 0, DL_ENS_STREAM_MOVE = 1, DL_ENS_STREAM_ACCEPT = 3 };   // + half-step for the last two
-
-// Random split of the ensemble into two halves: position r holds walker F(r), F a keyed bijection of [0, nw) -- four rounds of (odd multiplier, offset) mod 2^m
-// and a right xor-shift, m = bit length of nw - 1, keyed by eight Philox words of the iteration, cycle-walked back into [0, nw).  Every element is a pure function
-// of (seed, iteration, r): nothing is ranked, stored or exchanged (the argsort of random keys this replaces was an O(nw^2) scan on the one CU of the step kernel:
-// 5.7 us of the launch at 512 walkers); the keys of a launch are made on the host and travel in the kernel arguments.  samplers.py CounterRNG.permutation is the
-// NumPy statement of the same map.
-struct DlEnsSplit {
-    uint32_t mul[4], add[4], mask, shift, nw;
-};
-
-DlEnsSplit dl_ens_split(long long iteration, int nw, uint32_t k0, uint32_t k1) {
-    const DlPhilox ka = dl_philox4x32((uint32_t)iteration, (uint32_t)((unsigned long long)iteration >> 32), 0u, DL_ENS_STREAM_PERM, k0, k1);
-    const DlPhilox kb = dl_philox4x32((uint32_t)iteration, (uint32_t)((unsigned long long)iteration >> 32), 1u, DL_ENS_STREAM_PERM, k0, k1);
-    DlEnsSplit f;
-    int m = 1;
-    while (m < 31 && (1u << m) < (uint32_t)nw) ++m;
-    for (int round = 0; round < 4; ++round) { f.mul[round] = ka.x[round] | 1u; f.add[round] = kb.x[round]; }
-    f.mask = (1u << m) - 1u; f.shift = (uint32_t)(m + 1) / 2; f.nw = (uint32_t)nw;
-    return f;
-}
-
-__device__ __forceinline__ int dl_ens_split_at(const DlEnsSplit& f, int r) {
-    uint32_t x = (uint32_t)r;
-    do {
-#pragma unroll
-        for (int round = 0; round < 4; ++round) {
-            x = (x * f.mul[round] + f.add[round]) & f.mask;
-            x ^= x >> f.shift;
-        }
-    } while (x >= f.nw);
-    return (int)x;
-}
-
 struct DlEnsArgs {
     double* coords;        // [nw, P]
     double* logp;          // [nw]
@@ -358,6 +306,12 @@ struct dl_ensemble {
     bool deferred = true;         // finish the proposals' log-posteriors inside the step kernel (single rank, contexts on the chi2 GEMM path)
     double *coords = nullptr, *logp = nullptr, *prop = nullptr, *factors = nullptr, *newlp = nullptr;
     long long* nacc = nullptr;
+    // folded update (dl_ens_fold.h): ping-pong buffers of the pending half-step's inputs -- parity 0 aliases prop / factors, parity 1 and the partial chi2 are extra
+    int fold = -1;                // -1: not yet decided, 0: no (three launches per half-step), 1: yes (two)
+    int fold_tiles = 0;
+    const double* fold_priors = nullptr;
+    double *prop1 = nullptr, *factors1 = nullptr, *part2[2] = {nullptr, nullptr};
+    double *coords_alt = nullptr, *logp_alt = nullptr;   // the other state buffer (the extra workgroups of a folded theory launch write it; then the roles swap)
 };
 
 extern "C" {
@@ -365,7 +319,8 @@ extern "C" {
 void dl_ensemble_destroy(dl_ensemble* ens) {
     if (!ens) return;
     (void)hipSetDevice(ens->device);
-    for (void* p : {(void*)ens->coords, (void*)ens->logp, (void*)ens->prop, (void*)ens->factors, (void*)ens->newlp, (void*)ens->nacc})
+    for (void* p : {(void*)ens->coords, (void*)ens->logp, (void*)ens->prop, (void*)ens->factors, (void*)ens->newlp, (void*)ens->nacc, (void*)ens->prop1, (void*)ens->factors1,
+                    (void*)ens->part2[0], (void*)ens->part2[1], (void*)ens->coords_alt, (void*)ens->logp_alt})
         if (p) (void)hipFree(p);
     delete ens;
 }
@@ -467,8 +422,55 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
         s.chain = chain_dev + row * nw * P;
         s.chain_logp = chain_logp_dev ? chain_logp_dev + row * nw : nullptr;
     };
+    // Folded update: decided once per ensemble (single rank, plain likelihood on the chi2-GEMM path with fast full-shape kernels); DL_ENS_NO_FOLD=1 keeps the
+    // three-launch sequence (comparison, tests)
+    if (ens->fold < 0) {
+        ens->fold = 0;
+        const bool comm_on = ens->comm && (ens->world > 1 || getenv("DL_ENS_FORCE_COMM"));
+        if (ens->deferred && !comm_on && !getenv("DL_ENS_NO_DEFER") && !getenv("DL_ENS_NO_FOLD") && !getenv("DL_ENS_GLOBAL") &&
+            dl_internal_fold_info(ens->ctx, half, &ens->fold_tiles, &ens->fold_priors) == 0) {
+            const size_t half_pad = (size_t)ens->count * ens->world;
+            if (hipMalloc((void**)&ens->prop1, half_pad * P * sizeof(double)) == hipSuccess && hipMalloc((void**)&ens->factors1, half_pad * sizeof(double)) == hipSuccess &&
+                hipMalloc((void**)&ens->part2[0], half_pad * ens->fold_tiles * sizeof(double)) == hipSuccess &&
+                hipMalloc((void**)&ens->part2[1], half_pad * ens->fold_tiles * sizeof(double)) == hipSuccess &&
+                hipMalloc((void**)&ens->coords_alt, (size_t)nw * P * sizeof(double)) == hipSuccess && hipMalloc((void**)&ens->logp_alt, (size_t)nw * sizeof(double)) == hipSuccess)
+                ens->fold = 1;
+        }
+    }
+    bool folded = ens->fold == 1;
+    DlEnsFold f;
+    std::memset(&f, 0, sizeof(f));
+    static unsigned long long* fold_stamps_dev = nullptr;   // DL_ENS_FOLD_STAMPS=1: phase times of the theory kernel's proposal prologue, printed at the end of the run (synchronises)
+    const bool fold_stamps = folded && getenv("DL_ENS_FOLD_STAMPS") != nullptr;
+    if (fold_stamps && !fold_stamps_dev) DL_ENS_HIP(hipMalloc((void**)&fold_stamps_dev, (size_t)8192 * 8 * sizeof(unsigned long long)));
+    if (fold_stamps) f.stamps = fold_stamps_dev;
+    if (folded) {
+        f.nacc = ens->nacc; f.priors = ens->fold_priors; f.a = ens->a; f.offset = ens->offset;
+        f.nw = nw; f.P = P; f.n_tiles = ens->fold_tiles; f.k0 = s.k0; f.k1 = s.k1;
+        f.pend.half = -1;
+    }
     for (long long it = it0; it < it0 + niterations; ++it)
         for (int h = 0; h < 2; ++h) {
+            if (folded) {
+                // half-step (it, h): its proposals / factors / partial chi2 go to the buffers of parity h; the pending half-step's sit in parity 1 - h
+                double* prop_h = h ? ens->prop1 : ens->prop; double* fac_h = h ? ens->factors1 : ens->factors;
+                if (h == 0) s.split_prop = dl_ens_split(it, nw, s.k0, s.k1);
+                f.it_prop = it; f.half_prop = h; f.split_prop = s.split_prop; f.prop_out = prop_h; f.factors_out = fac_h;
+                set_record();     // (record target of the accept that is pending: written by this half-step's chi2 GEMM)
+                f.chain = s.chain; f.chain_logp = s.chain_logp;
+                f.coords = ens->coords; f.logp = ens->logp; f.coords_out = ens->coords_alt; f.logp_out = ens->logp_alt;
+                const int rc = dl_internal_eval_fold(ens->ctx, f, half, ens->part2[h], stream);
+                if (rc == 1) return 1;
+                if (rc == 2) {
+                    if (f.pend.half >= 0) return fail("dl_ensemble_run: the context left the folded path in the middle of a run");
+                    ens->fold = 0; folded = false;      // (first half-step of the first run: nothing pending yet -- fall through to the three-launch sequence)
+                } else {
+                    if (f.pend.half >= 0) { std::swap(ens->coords, ens->coords_alt); std::swap(ens->logp, ens->logp_alt); }   // the launch wrote the state after the pending accepts
+                    f.pend.prop = prop_h; f.pend.factors = fac_h; f.pend.part = ens->part2[h]; f.pend.it = it; f.pend.half = h; f.pend.split = s.split_prop;
+                    s.it_acc = it; s.half_acc = h; s.split_acc = s.split_prop;
+                    continue;
+                }
+            }
             s.it_prop = it; s.half_prop = h;
             if (h == 0) s.split_prop = dl_ens_split(it, nw, s.k0, s.k1);
             set_record();
@@ -482,6 +484,11 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
             if (s.part == nullptr && dl_ens_logposterior(ens, ens->prop, half, ens->newlp, stream)) return 1;
             s.it_acc = it; s.half_acc = h; s.split_acc = s.split_prop;
         }
+    if (folded && f.pend.half >= 0) {
+        // the last half-step's accept: the step kernel (accept + record, nothing to propose) on the pending buffers
+        s.prop = const_cast<double*>(f.pend.prop); s.factors = const_cast<double*>(f.pend.factors); s.part = f.pend.part; s.n_tiles = ens->fold_tiles; s.priors = ens->fold_priors;
+        s.coords = ens->coords; s.logp = ens->logp;
+    }
     s.half_prop = -1;
     set_record();
     dl_ens_launch(s, stream);
@@ -492,6 +499,15 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
         DL_ENS_HIP(hipStreamSynchronize(stream));
         const double n = h[7] ? 100. * (double)h[7] : 1.;
         fprintf(stderr, "dl_ensemble_run: step kernel, us per launch over %llu launches: requests + landing %.2f, draws %.2f, barrier %.2f, accept %.2f, record + move %.2f\n", h[7], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n);
+    }
+    if (fold_stamps) {
+        std::vector<unsigned long long> h((size_t)half * 16);
+        DL_ENS_HIP(hipMemcpyAsync(h.data(), fold_stamps_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        DL_ENS_HIP(hipStreamSynchronize(stream));
+        double acc[6] = {0., 0., 0., 0., 0., 0.};
+        for (int b = 0; b < half; ++b) for (int q = 0; q < 6; ++q) acc[q] += (double)(h[(size_t)b * 8 + q + 1] - h[(size_t)b * 8 + q]);
+        fprintf(stderr, "dl_ensemble_run: theory kernel of the last half-step, mean shader-clock ticks per workgroup: kernarg prefetch %.0f, draw + splits %.0f, decisions (loads + sums) %.0f, theta %.0f, barrier %.0f, phases %.0f\n",
+                acc[0] / half, acc[1] / half, acc[2] / half, acc[3] / half, acc[4] / half, acc[5] / half);
     }
     ens->iteration += niterations;
     return 0;

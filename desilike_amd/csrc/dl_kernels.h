@@ -87,5 +87,12 @@ void dl_launch_fisher(const double* rows, int64_t ld, int n, int n_slabs, int64_
 // take the chi2 GEMM path: use dl_eval_logposterior).
 struct dl_ctx;
 int dl_internal_eval_partials(dl_ctx* ctx, const double* theta_dev, int64_t B, const double** part, int* n_tiles, const double** priors, hipStream_t stream);
+// Folded ensemble update (dl_ens_fold.h): theory launch that derives the B proposals of the half-step described by `fold` itself + chi2 GEMM that writes the accepts
+// of the pending half-step; part_out [B, n_tiles] receives the proposals' partial chi2.  dl_internal_fold_info: 0 if the context takes this path (then *n_tiles and
+// *priors are set), 2 if not.
+struct DlEnsFold;
+int dl_internal_fold_info(dl_ctx* ctx, int64_t B, int* n_tiles, const double** priors);
+int dl_internal_eval_fold(dl_ctx* ctx, const DlEnsFold& fold, int64_t B, double* part_out, hipStream_t stream);
+bool dl_launch_fullshape_ens(const DlObsDev* obs_host, int n_obs, const DlObsDev* obs_dev, const DlEnsFold& f, int64_t B, double* power, int64_t ld_power, int xcd_block, hipStream_t stream);
 // last-error string of the C ABI (thread-local, read by dl_last_error(NULL)); set by translation units other than dl_api.hip
 void dl_set_last_error(const char* msg);

@@ -18,6 +18,7 @@
 #include "dl_emu_batch.h"
 #include "dl_finalize_part.h"
 #include "dl_scalar_prefetch.h"
+#include "dl_ens_fold.h"
 
 thread_local DlProfEvents dl_prof_events;
 
@@ -39,16 +40,19 @@ __device__ __forceinline__ void dl_obs_prefetch(const void* p) {
     dl_scalar_prefetch<0, (offsetof(DlObsDev, ct_in) + 63) / 64 * 64, offsetof(DlObsDev, coef_w) / 64 * 64, (sizeof(DlObsDev) + 63) / 64 * 64>(p);
 }
 
-template <bool FAST, int NL, bool EFT, bool DENSE>
+// Workgroups are dealt round-robin to the 8 XCDs; with xblk > 0 workgroup w = xcd + 8 r handles point xblk (xcd + 8 (r / xblk)) + r % xblk (see dl_fullshape_body)
+__device__ __forceinline__ int dl_fs_point_of_wg(int wg, int xblk) { return xblk ? xblk * ((wg & 7) + 8 * ((wg >> 3) / xblk)) + ((wg >> 3) % xblk) : wg; }
+
+template <bool FAST, int NL, bool EFT, bool DENSE, bool TH_ROW = false>
 __device__ __forceinline__ void dl_fullshape_body(const DlObsDev& o, const double* __restrict__ theta, int n_params, double* __restrict__ power,
-                                                  int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after, unsigned long long* __restrict__ stamps) {
+                                                  int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after, unsigned long long* __restrict__ stamps,
+                                                  const double* th_row = nullptr) {   // th_row: the point's parameters already in LDS (dl_fullshape_ens_kernel)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // Workgroups are dealt round-robin to the 8 XCDs; the GEMM that follows runs row block mb (xblk = 32 or 64 points) on XCD mb % 8.  With xblk > 0 the points are dealt
     // so that a row block is PRODUCED on the XCD that consumes it (B a multiple of 8 xblk): workgroup w = xcd + 8 r handles point xblk (xcd + 8 (r / xblk)) + r % xblk.
     const int xblk = (stop_after >> 8) & 0xff;
     stop_after = xblk ? 0 : stop_after;
-    const int wg = blockIdx.x;
-    const int b = xblk ? xblk * ((wg & 7) + 8 * ((wg >> 3) / xblk)) + ((wg >> 3) % xblk) : wg;
+    const int b = dl_fs_point_of_wg(blockIdx.x, xblk);
     // DL_FS_STAMPS diagnostics: s_memtime (shader clock) of thread 0 at entry, after each barrier and at exit, 8 slots per workgroup
 #define DL_STAMP(slot) if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();
     DL_STAMP(0)
@@ -56,7 +60,7 @@ __device__ __forceinline__ void dl_fullshape_body(const DlObsDev& o, const doubl
     // FAST instantiations are only launched when the convolution path applies (or the spline is fixed): the segmented sweeps are not compiled in
     const bool toep = !o.fixed_spline && (FAST || o.toeplitz);
     const DlFsShared s = dl_fs_shared_carve(lds, o.n_t, o.n_in, dl_fs_n_dd0(o), toep);
-    const double* th = theta + (size_t)b * n_params;
+    const double* th = TH_ROW ? th_row : theta + (size_t)b * n_params;
     const int tid = threadIdx.x, nthr = DL_FS_THREADS;
     if (stop_after == -1) return;  // stop_after != 0: timing diagnostics only (DL_FS_STOP), outputs are then incomplete
     // constants of the later phases are requested now: their round trip hides behind phase 0/1
@@ -157,6 +161,130 @@ template <bool FAST, int NL, bool EFT, bool DENSE = false>
 __global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_multi_kernel(const DlObsDev* __restrict__ obs, const double* __restrict__ theta, int n_params,
                                                                            double* __restrict__ power, int64_t ld_power, int stop_after) {
     dl_fullshape_body<FAST, NL, EFT, DENSE>(obs[blockIdx.y], theta, n_params, power, ld_power, nullptr, 0, stop_after, nullptr);
+}
+
+// ---- folded ensemble update (dl_ens_fold.h): the workgroup derives the proposal it evaluates --------------------------------------------------------------------
+// Wave 0 of the workgroup of slot b: the slot's move draw (uniform over the lanes), then the two halves of the wave re-evaluate the pending accepts of the slot's own
+// walker and of its partner if they wait for one (dl_ens_decide2: lane-parallel, one round of loads -- the rows either decision can select are requested in the same
+// round), then lanes p < P form theta_p = c_p - (c_p - x_p) z.  The row goes to LDS (the kernel's phases read the parameters from there); observable 0's workgroup
+// also publishes it with the stretch factor: the NEXT half-step's launches need them for THIS half-step's accept.
+#define DL_ENS_MAXP 32
+#define DL_ENS_SLOTS_PER_WG 8    // an extra workgroup (4 waves) writes the state of 8 pending slots: two per wave
+#define DL_EF_STAMP(slot) if (f.stamps != nullptr && publish && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); f.stamps[(size_t)b * 8 + (slot)] = __builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ void dl_ens_propose(const DlEnsFold& f, int b, bool publish, double* __restrict__ th_out, double* __restrict__ scratch) {
+#pragma clang fp contract(off)   // the NumPy driver rounds after every operation
+    const int lane = threadIdx.x & 63;
+    DL_EF_STAMP(1)
+    const int half = f.nw / 2, P = f.P;
+    const DlPhilox r = dl_philox4x32((uint32_t)f.it_prop, (uint32_t)((unsigned long long)f.it_prop >> 32), (uint32_t)b, DL_ENS_STREAM_MOVE + f.half_prop, f.k0, f.k1);
+    const double u = dl_uniform53(r.x[0], r.x[1]);
+    const double t = (f.a - 1.) * u + 1.;
+    const double zz = (t * t) / f.a;                       // z ~ g(z) on [1 / a, a] (emcee moves/stretch.py)
+    const int ic = dl_ens_split_at(f.split_prop, (1 - f.half_prop) * half + (int)(r.x[2] % (uint32_t)half));
+    const int is = dl_ens_split_at(f.split_prop, f.half_prop * half + b);
+    // pending accepts of the slot's own walker (decision A: lanes 0-31) and of its partner (B: lanes 32-63), if they wait for one
+    const int sA = dl_ens_pending_slot(f.pend, is, half), sB = dl_ens_pending_slot(f.pend, ic, half);
+    const int p = lane < P ? lane : P - 1;
+    DL_EF_STAMP(2)
+    // (requested with the decisions' loads: whichever row a decision selects is then already on its way)
+    const double x_old = f.coords[(size_t)is * P + p], c_old = f.coords[(size_t)ic * P + p];
+    const double x_new = f.pend.half >= 0 ? f.pend.prop[(size_t)(sA >= 0 ? sA : 0) * P + p] : 0., c_new = f.pend.half >= 0 ? f.pend.prop[(size_t)(sB >= 0 ? sB : 0) * P + p] : 0.;
+    bool ax = false, ac = false;
+    if (sA >= 0 || sB >= 0) {
+        const DlEnsDecision2 d = dl_ens_decide2(f.pend, f.priors, P, f.n_tiles, f.offset, f.k0, f.k1, sA, f.logp[is], sB, f.logp[ic], scratch);
+        ax = d.acc[0]; ac = d.acc[1];
+    }
+    DL_EF_STAMP(3)
+    if (lane < P) {
+        const double c = ac ? c_new : c_old, x = ax ? x_new : x_old;
+        const double q = c - (c - x) * zz;                 // q = c - (c - s) z
+        th_out[lane] = q;
+        if (publish) f.prop_out[(size_t)b * P + lane] = q;
+    }
+    if (publish && lane == 0) f.factors_out[b] = (P - 1.) * log(zz);
+    DL_EF_STAMP(4)
+}
+
+// Extra workgroup e of the launch: state after the pending accepts of slots [8 e, 8 e + 8) -- wave v handles slots 8 e + 2 v (lanes 0-31) and + 1 (lanes 32-63): the
+// slot's walker (accepted: the proposal and its log-posterior, else the old row) and one walker outside the pending half (copied) go to the OTHER state buffer, and
+// to the chain record if one is due: between them the extra workgroups write every walker.
+__device__ __forceinline__ void dl_ens_write_state(const DlEnsFold& f, int e, double* __restrict__ scratch) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = f.nw / 2, P = f.P, hl = lane & 31, hb = lane >> 5;
+    const int s0 = DL_ENS_SLOTS_PER_WG * e + 2 * wave, s1 = s0 + 1;
+    if (s0 >= half) return;
+    const bool two = s1 < half;
+    const int w0 = dl_ens_split_at(f.pend.split, f.pend.half * half + s0), w1 = two ? dl_ens_split_at(f.pend.split, f.pend.half * half + s1) : w0;
+    const double lw0 = f.logp[w0], lw1 = f.logp[w1];
+    const int s = hb ? s1 : s0, w = hb ? w1 : w0;
+    const int n = dl_ens_split_at(f.pend.split, (1 - f.pend.half) * half + (hb && !two ? s0 : s));   // a walker outside the pending half: copied
+    const int p = hl < P ? hl : P - 1;
+    const double v_old = f.coords[(size_t)w * P + p], v_new = f.pend.prop[(size_t)(hb && !two ? s0 : s) * P + p], v_n = f.coords[(size_t)n * P + p];
+    const double ln = f.logp[n];
+    const DlEnsDecision2 d = dl_ens_decide2(f.pend, f.priors, P, f.n_tiles, f.offset, f.k0, f.k1, s0, lw0, two ? s1 : -1, lw1, scratch + DL_ENS_SCRATCH * wave);
+    if (hb && !two) return;
+    const bool acc = hb ? d.acc[1] : d.acc[0];
+    const double lp = hb ? d.lp[1] : d.lp[0], lw = hb ? lw1 : lw0;
+    if (hl < P) {
+        const double v = acc ? v_new : v_old;
+        f.coords_out[(size_t)w * P + hl] = v; f.coords_out[(size_t)n * P + hl] = v_n;
+        if (f.chain != nullptr) { f.chain[(size_t)w * P + hl] = v; f.chain[(size_t)n * P + hl] = v_n; }
+    }
+    if (hl == 0) {
+        const double lv = acc ? lp : lw;
+        f.logp_out[w] = lv; f.logp_out[n] = ln;
+        if (acc) f.nacc[w] += 1;
+        if (f.chain_logp != nullptr) { f.chain_logp[w] = lv; f.chain_logp[n] = ln; }
+    }
+}
+
+// (non-DENSE: three workgroups per CU instead of four -- 168 registers: the prologue's values and the two-wavenumber projection loop do not fit 128 without spills,
+//  and a half-ensemble of a few hundred proposals does not fill four slots per CU anyway)
+template <int NL, bool DENSE = false>
+__global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 3) void dl_fullshape_ens_kernel(const DlObsDev* __restrict__ obs, const DlEnsFold f, double* __restrict__ power, int64_t ld_power,
+                                                                         int flags, int B) {
+    __shared__ double dl_ens_theta[DL_ENS_MAXP];
+    __shared__ double dl_ens_scratch[DL_ENS_SCRATCH * (DL_FS_THREADS / 64)];
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+    dl_kernarg_prefetch<(sizeof(DlEnsFold) + 8 + 63) / 64 * 64 + 64>();    // the fold description and the pointers behind it: one round trip instead of one per line
+    if ((int)blockIdx.x >= B) {                        // extra workgroups: the state after the pending accepts (nothing of this launch reads it)
+        if (blockIdx.y == 0 && f.pend.half >= 0) dl_ens_write_state(f, (int)blockIdx.x - B, dl_ens_scratch);
+        return;
+    }
+    if (threadIdx.x < 64) dl_ens_propose(f, dl_fs_point_of_wg(blockIdx.x, (flags >> 8) & 0xff), blockIdx.y == 0, dl_ens_theta, dl_ens_scratch);
+    else if (threadIdx.x < 128) {
+        // a second wavefront touches the lines of the observable's description the phases will read (scalar cache: shared by the waves of the CU) while wave 0 derives
+        // the proposal
+        dl_scalar_prefetch<0, (offsetof(DlObsDev, ct_in) + 63) / 64 * 64, offsetof(DlObsDev, coef_w) / 64 * 64, (sizeof(DlObsDev) + 63) / 64 * 64>((const void*)(obs + blockIdx.y));
+    }
+    __syncthreads();
+    if (f.stamps != nullptr && blockIdx.y == 0 && threadIdx.x == 0) { f.stamps[(size_t)dl_fs_point_of_wg(blockIdx.x, (flags >> 8) & 0xff) * 8 + 0] = t_entry; f.stamps[(size_t)dl_fs_point_of_wg(blockIdx.x, (flags >> 8) & 0xff) * 8 + 5] = __builtin_amdgcn_s_memtime(); }
+    dl_fullshape_body<true, NL, false, DENSE, true>(obs[blockIdx.y], nullptr, f.P, power, ld_power, nullptr, 0, flags, nullptr, dl_ens_theta);
+    if (f.stamps != nullptr && blockIdx.y == 0 && threadIdx.x == 0) f.stamps[(size_t)dl_fs_point_of_wg(blockIdx.x, (flags >> 8) & 0xff) * 8 + 6] = __builtin_amdgcn_s_memtime();
+}
+
+// One launch for all observables of a fast (uniform knots, no counter terms) full-shape likelihood, proposals derived in the kernel; false: not applicable
+bool dl_launch_fullshape_ens(const DlObsDev* obs_host, int n_obs, const DlObsDev* obs_dev, const DlEnsFold& f, int64_t B, double* power, int64_t ld_power, int xcd_block, hipStream_t stream) {
+    if (obs_dev == nullptr || n_obs < 1 || n_obs > 8 || f.P > DL_ENS_MAXP || f.P > 64) return false;
+    const bool nl3 = obs_host[0].n_ell <= 3;
+    size_t shmem = 0;
+    for (int i = 0; i < n_obs; ++i) {
+        const DlObsDev& oh = obs_host[i];
+        const bool generic = !oh.uniform_knots || !(oh.toeplitz || oh.fixed_spline);
+        if (oh.theory == 2 || oh.theory == 3 || generic || oh.n_ct > 0 || oh.n_sn > 0 || (oh.n_ell <= 3) != nl3) return false;
+        shmem = std::max(shmem, dl_fs_shared_doubles_obs(oh, true) * sizeof(double));
+    }
+    static const int64_t dense_min = getenv("DL_FS_DENSE_MIN") ? atoll(getenv("DL_FS_DENSE_MIN")) : 4096;
+    auto launch = [&](auto kernel) {
+        if (shmem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        const int flags = (xcd_block > 0 && B % (8 * xcd_block) == 0) ? (xcd_block << 8) : 0;
+        const int n_extra = f.pend.half >= 0 ? (int)((B + DL_ENS_SLOTS_PER_WG - 1) / DL_ENS_SLOTS_PER_WG) : 0;   // workgroups that write the state after the pending accepts
+        DL_LAUNCH(kernel, dim3((unsigned)(B + n_extra), (unsigned)n_obs), dim3(DL_FS_THREADS), shmem, stream, obs_dev, f, power, ld_power, flags, (int)B);
+    };
+    if (nl3) { if (B * n_obs > dense_min) launch(dl_fullshape_ens_kernel<3, true>); else launch(dl_fullshape_ens_kernel<3>); }
+    else { if (B * n_obs > dense_min) launch(dl_fullshape_ens_kernel<5, true>); else launch(dl_fullshape_ens_kernel<5>); }
+    return true;
 }
 
 // BAO wiggle model: one workgroup per point; constant splines read from global memory, no per-point spline build.  One kernel per wiggle model: registers are

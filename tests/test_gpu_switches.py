@@ -24,7 +24,7 @@ SWITCHES = [({}, 'fs two ens emu bao'),
             ({'DL_CHI2_FUSED': '1'}, 'fs'),
             ({'DL_FS_DENSE_MIN': '256'}, 'fs two'), ({'DL_FS_DENSE_MIN': '1000000'}, 'fs'),
             ({'DL_NO_MERGED_THEORY': '1'}, 'two ens'), ({'DL_NO_PANEL_SKIP': '1'}, 'two'), ({'DL_NO_ROW_ALIGN': '1'}, 'two ens'),
-            ({'DL_ENS_GLOBAL': '1'}, 'ens'), ({'DL_ENS_NO_DEFER': '1'}, 'ens'),
+            ({'DL_ENS_GLOBAL': '1'}, 'ens'), ({'DL_ENS_NO_DEFER': '1'}, 'ens'), ({'DL_ENS_NO_FOLD': '1'}, 'ens'),
             ({'DL_NO_EMU_FUSED': '1'}, 'emu'), ({'DL_NO_GRAM_EPILOGUE': '1'}, 'emu'), ({'DL_NO_EMU_BATCH': '1'}, 'emu'), ({'DL_NO_FEATURE_PATH': '1'}, 'emu'),
             ({'DL_FM_NO_STAGE': '1'}, 'emu bao'),
             ({'DL_BAO_THREADS': '64'}, 'bao'), ({'DL_BAO_THREADS': '128'}, 'bao'), ({'DL_BAO_THREADS': '256'}, 'bao'),
