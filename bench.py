@@ -406,7 +406,7 @@ def other_configs(device, steps=40, warmup=5, ncheck=8):
 def sustained_leg(step, barrier, seconds, B, world, seconds_per_step, group=None):
     """The same step for >= ``seconds`` of wall time (the driver's GPU-busy sampling sees nothing of a 0.5 ms timed region): evaluations / s over the whole stretch.
     The number of steps is fixed beforehand from the timed region's rate (the same on every rank: the exchange is issued per step)."""
-    nsteps = 256 * max(1, int(np.ceil(1.05 * seconds / seconds_per_step / 256.)))
+    nsteps = 256 * max(1, int(np.ceil(1.15 * seconds / seconds_per_step / 256.)))
     barrier()
     t0 = time.perf_counter()
     for block in range(nsteps // 256):
@@ -463,7 +463,7 @@ def chains_weak(group, local_rank, rank, world, chains_per_gpu=(1, 2, 4), iterat
     out = []
     for K in chains_per_gpu:
         sampler = EmceeSampler(likelihood, nwalkers=512, chains=K * world, seed=42, sharding=WalkerSharding(group=group if group is not None else False), device_resident=True)
-        sampler.run(niterations=warmup)
+        sampler.run(niterations=iterations)     # (warm-up of the same length: the staging buffers of the timed run exist)
         torch.cuda.synchronize(device)
         if group is not None: group.barrier()
         t0 = time.perf_counter()
@@ -622,11 +622,12 @@ def main():
     prewarm_ms = 1e3 * (time.perf_counter() - t0)
     # Long runs: all three kernels on 8+ sampled steps (0.4 us per step of overhead at 200 steps).  Short runs (the driver's --steps 20): a kernel launched with
     # events is followed by a ~3 us gap, so only the kernel that dominates the step (the theory kernel: established by the long runs and by rocprofv3,
-    # profiles/) carries events, on every fourth step: 5 samples at --steps 20.  A sampled launch costs the step ~5 us (measured at --steps 20: 26.9 - 27.2 us per step
-    # with 10 samples, 24.4 - 24.8 us without events; tools/sync_probe.py: the closing synchronisation is not the difference); the other kernels are reported as null.
+    # profiles/) carries events, on every sixth step: 3 samples at --steps 20 (5 until round 3: the `sustained` leg below runs without events and the two figures are meant
+    # to be compared).  A sampled launch costs the step ~5 us (measured at --steps 20: 26.9 - 27.2 us per step with 10 samples, 24.4 - 24.8 us without events;
+    # tools/sync_probe.py: the closing synchronisation is not the difference); the other kernels are reported as null.
     short = args.steps < 100
     only = 'theory' if short else None
-    every = max(1, min(25, args.steps // (5 if short else 8)))
+    every = max(1, min(25, args.steps // (3 if short else 8)))
     if not args.no_events: ctx.profile_enable(1, only=only)   # the warm-up steps go through the event path too (its first use allocates: not a sample)
     for _ in range(args.warmup):
         step()

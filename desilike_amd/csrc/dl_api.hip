@@ -407,6 +407,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
         dl_destroy(ctx);
         return 1;
     }
+    if (hipDeviceSynchronize() != hipSuccess) { dl_fail(ctx, "dl_create: hipDeviceSynchronize failed"); dl_destroy(ctx); return 1; }   // (null-stream memsets vs non-blocking streams: see dl_reserve)
     *out = ctx;
     return 0;
 }
@@ -470,6 +471,10 @@ static int dl_reserve(dl_ctx* ctx, int64_t B) {
     DL_HIP_CHECK(ctx, hipMemset(ctx->flat_ws, 0, (size_t)need * ctx->N_pad * sizeof(double)));
     if (ctx->feat_ok) DL_HIP_CHECK(ctx, hipMemset(ctx->feat_ws, 0, (size_t)need * ctx->feat_ld * sizeof(double)));
     DL_HIP_CHECK(ctx, hipMemset(ctx->stencil_ws, 0, (size_t)need * ctx->n_params * sizeof(double)));
+    // the memsets run on the null stream and may still be in flight when this returns; the caller's stream (the private host stream, torch's side streams) is a
+    // non-blocking one that does not wait for the null stream: without this synchronisation its kernels could be overtaken by the zeroing of the buffer they write
+    // (seen once as a 2.6e-6 error on one row of the first large batch of a context, in a child of tests/test_gpu_switches.py running beside three others)
+    DL_HIP_CHECK(ctx, hipDeviceSynchronize());
     ctx->cap = need;
     return 0;
 }

@@ -350,6 +350,7 @@ int dl_ensemble_create(dl_ensemble** out, dl_ctx* ctx, int32_t nwalkers, double 
     if (hipMemset(ens->nacc, 0, (size_t)nwalkers * sizeof(long long)) != hipSuccess || hipMemset(ens->prop, 0, half_pad * P * sizeof(double)) != hipSuccess ||
         hipMemset(ens->newlp, 0, half_pad * sizeof(double)) != hipSuccess)
         return bail("dl_ensemble_create: hipMemset failed");
+    if (hipDeviceSynchronize() != hipSuccess) return bail("dl_ensemble_create: hipDeviceSynchronize failed");   // (null-stream memsets vs the caller's non-blocking streams)
     *out = ens;
     return 0;
 }

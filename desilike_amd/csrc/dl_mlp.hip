@@ -248,6 +248,7 @@ int dl_mlp_create(dl_mlp** out, int device, int32_t n_layers, const int32_t* wid
         return bail("dl_mlp_create: device allocation failed");
     if (hipMemcpy(net->w, weights, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemset(net->m, 0, bytes) != hipSuccess || hipMemset(net->v, 0, bytes) != hipSuccess)
         return bail("dl_mlp_create: upload failed");
+    if (hipDeviceSynchronize() != hipSuccess) return bail("dl_mlp_create: hipDeviceSynchronize failed");   // (null-stream memsets vs the caller's non-blocking streams)
     *out = net;
     return 0;
 }

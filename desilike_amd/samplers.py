@@ -282,7 +282,7 @@ class _DeviceChain(object):
         self.ens = DeviceEnsemble(ctx, nwalkers, a=a, seed=key, offset=offset, group=group)
         self.device = torch.device('cuda', self.ens.device)
         self.stream = torch.cuda.Stream(device=self.device) if own_stream else None
-        self._buffers = None
+        self._buffers = self._device_buffers = self._host_buffers = None
         self._naccepted = np.zeros(nwalkers)
 
     def _cuda_stream(self):
@@ -293,23 +293,31 @@ class _DeviceChain(object):
         self.ens.set_counter(iteration, naccepted=None if naccepted is None else np.asarray(naccepted, dtype='i8'), stream=self._cuda_stream())
 
     def enqueue(self, niterations, thin_by=1):
+        """``niterations`` recorded updates and the copy of the recorded chain to (pinned) host memory, all enqueued on the chain's stream: nothing waits here, the copies
+        of one chain overlap the updates of the others."""
         import torch
-        coords = torch.empty((niterations, self.ens.nwalkers, self.ens.n_params), dtype=torch.float64, device=self.device)
-        logp = torch.empty((niterations, self.ens.nwalkers), dtype=torch.float64, device=self.device)
+        shape = (niterations, self.ens.nwalkers, self.ens.n_params)
+        if self._device_buffers is None or tuple(self._device_buffers[0].shape) != shape:
+            self._device_buffers = (torch.empty(shape, dtype=torch.float64, device=self.device), torch.empty(shape[:2], dtype=torch.float64, device=self.device))
+            self._host_buffers = (torch.empty(shape, dtype=torch.float64, pin_memory=True), torch.empty(shape[:2], dtype=torch.float64, pin_memory=True))
+        coords, logp = self._device_buffers
+        stream = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
         if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))   # (the buffers were just made on the current stream)
-        self.ens.run(niterations * thin_by, thin_by=thin_by, chain=coords, chain_logp=logp, stream=self._cuda_stream())
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))   # (buffers made / last read on the current stream)
+        self.ens.run(niterations * thin_by, thin_by=thin_by, chain=coords, chain_logp=logp, stream=stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            self._host_buffers[0].copy_(coords, non_blocking=True)
+            self._host_buffers[1].copy_(logp, non_blocking=True)
         self._buffers = (coords, logp)
 
     def collect(self, device=False):
-        """The chain of the last ``enqueue`` (host arrays; ``device=True``: the device tensors, after the stream has finished)."""
+        """The chain of the last ``enqueue`` (host arrays; ``device=True``: the device tensors), once the chain's stream has finished."""
         import torch
         coords, logp = self._buffers
         self._buffers = None
-        if self.stream is not None: self.stream.synchronize()
-        else: torch.cuda.current_stream(self.device).synchronize()
+        (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).synchronize()
         if device: return coords, logp
-        return coords.cpu().numpy(), logp.cpu().numpy()
+        return self._host_buffers[0].numpy(), self._host_buffers[1].numpy()     # (views of the pinned staging buffers: valid until the next enqueue; the caller copies)
 
     @property
     def iteration(self):
@@ -318,6 +326,41 @@ class _DeviceChain(object):
     @property
     def naccepted(self):
         return self.ens.get_state(stream=self._cuda_stream())[2].astype('f8')
+
+
+class _ChainStore(object):
+    """Samples of one chain, growing by batches: coords [n, nwalkers, ndim], logposterior [n, nwalkers] in arrays with amortised doubling -- appending a batch is ONE
+    copy of the batch (straight out of the pinned staging buffer of the device chain), whatever the length of the chain so far."""
+
+    def __init__(self):
+        self.size = 0
+        self._coords = self._logp = None
+
+    def __bool__(self):
+        return self._coords is not None
+
+    def append(self, coords, logp):
+        n = coords.shape[0]
+        if self._coords is None:
+            cap = max(n, 1)
+            self._coords, self._logp = np.empty((cap,) + coords.shape[1:], dtype='f8'), np.empty((cap,) + logp.shape[1:], dtype='f8')
+        elif self.size + n > self._coords.shape[0]:
+            cap = max(2 * self._coords.shape[0], self.size + n)
+            for name in ['_coords', '_logp']:
+                old = getattr(self, name)
+                new = np.empty((cap,) + old.shape[1:], dtype='f8')
+                new[:self.size] = old[:self.size]
+                setattr(self, name, new)
+        self._coords[self.size:self.size + n], self._logp[self.size:self.size + n] = coords, logp
+        self.size += n
+
+    @property
+    def coords(self):
+        return self._coords[:self.size]
+
+    @property
+    def logp(self):
+        return self._logp[:self.size]
 
 
 def _batch_iterate(func, min_iterations=0, max_iterations=None, check_every=300):
@@ -401,7 +444,7 @@ class EmceeSampler(BasePosteriorSampler):
             if len(save_fn) != self.nchains or len(set(save_fn)) != self.nchains:
                 raise ValueError('provide one file name per chain (or a template with *)')
         self.save_fn = save_fn
-        self.chains = [None] * self.nchains           # per chain: dict name -> [niterations, nwalkers] (incl. 'logposterior'), on every rank
+        self._blocks = [_ChainStore() for _ in range(self.nchains)]   # per chain: coords [n, nwalkers, ndim], logposterior [n, nwalkers] so far, on every rank
         self._state = [None] * self.nchains           # per chain: (coords [nwalkers, ndim], logposterior [nwalkers]) after the last update
         self._iterations = [0] * self.nchains         # updates done (the counter of the chain's generator)
         self._accepted = [np.zeros(self.nwalkers) for _ in range(self.nchains)]
@@ -413,6 +456,18 @@ class EmceeSampler(BasePosteriorSampler):
         if resume is not None:
             for ichain, source in enumerate(resume):
                 self._load_one(ichain, source)
+
+    @property
+    def chains(self):
+        """Per chain: dict name -> [niterations, nwalkers] (incl. 'logposterior'; views of the chain's store), or None before the first update."""
+        out = []
+        for store in self._blocks:
+            if not store:
+                out.append(None); continue
+            chain = {param.name: store.coords[..., iparam] for iparam, param in enumerate(self.varied_params)}
+            chain['logposterior'] = store.logp
+            out.append(chain)
+        return out
 
     # ---- single-chain views (the surface of the one-chain sampler) -----------------------------------------------------------------------------------------
     @property
@@ -530,14 +585,9 @@ class EmceeSampler(BasePosteriorSampler):
         for ichain in range(self.nchains):
             coords, logp = new[ichain]
             if niterations:
-                self._state[ichain] = (coords[-1], logp[-1])
+                self._state[ichain] = (coords[-1].copy(), logp[-1].copy())
             if ichain in self._runners: self._holds[ichain] = self._state[ichain][0]
-            chain = {param.name: coords[..., iparam] for iparam, param in enumerate(self.varied_params)}
-            chain['logposterior'] = logp
-            if self.chains[ichain] is None:
-                self.chains[ichain] = chain
-            else:
-                self.chains[ichain] = {name: np.concatenate([self.chains[ichain][name], chain[name]], axis=0) for name in chain}
+            self._blocks[ichain].append(coords, logp)
 
     def _gather_chains(self, new, niterations, ndim):
         """All-gather of the batch's samples: every rank ends up with every chain (one collective per batch: [chains per rank, niterations, nwalkers, ndim + 1 + 2]
@@ -586,10 +636,10 @@ class EmceeSampler(BasePosteriorSampler):
         from . import diagnostics as diag
         if not isinstance(self.diagnostics, diag.Diagnostics): self.diagnostics = diag.Diagnostics(self.diagnostics)
         d = self.diagnostics
-        if any(chain is None for chain in self.chains): return False
+        if any(not store for store in self._blocks): return False
         assert nsplits > 1
         names = self.varied_params.names()
-        arrays = [np.stack([chain[name] for name in names], axis=-1) for chain in self.chains]     # [niterations, nwalkers, ndim] per chain
+        arrays = [store.coords for store in self._blocks]     # [niterations, nwalkers, ndim] per chain
         size = arrays[0].shape[0]
         if 0 < burnin < 1: burnin = int(burnin * size + 0.5)
         burnin = int(burnin)
@@ -647,18 +697,20 @@ class EmceeSampler(BasePosteriorSampler):
         if len(fn) != self.nchains: raise ValueError('provide one file name per chain')
         if self.chain_rank != 0 or (not self.chain_parallel and self.sharding.rank != 0): return
         for ichain, name in enumerate(fn):
-            if self.chains[ichain] is not None: self._chain_file(ichain).save(name)
+            if self._blocks[ichain]: self._chain_file(ichain).save(name)
 
     def _load_one(self, ichain, source):
         from .io import ChainFile
         chain = source if hasattr(source, 'arrays') else ChainFile.load(source)
         names = self.varied_params.names()
-        self.chains[ichain] = {name: np.asarray(chain.arrays[name], dtype='f8') for name in names + ['logposterior']}
-        last = np.column_stack([self.chains[ichain][name][-1] for name in names])
-        self._state[ichain] = (last, self.chains[ichain]['logposterior'][-1].copy())
+        coords = np.stack([np.asarray(chain.arrays[name], dtype='f8') for name in names], axis=-1)
+        logp = np.asarray(chain.arrays['logposterior'], dtype='f8')
+        self._blocks[ichain] = _ChainStore()
+        self._blocks[ichain].append(coords, logp)
+        self._state[ichain] = (coords[-1].copy(), logp[-1].copy())
         self._holds.pop(ichain, None)            # whatever a runner holds is not this state: handed over at the next run
         attrs = chain.attrs
-        self._iterations[ichain] = int(attrs.get('iteration', self.chains[ichain]['logposterior'].shape[0]))
+        self._iterations[ichain] = int(attrs.get('iteration', logp.shape[0]))
         nacc = attrs.get('naccepted', None)
         self._accepted[ichain] = np.zeros(self.nwalkers) if nacc is None else np.asarray(nacc, dtype='f8')
         key = attrs.get('counter_seed', None)

@@ -648,3 +648,100 @@ def mlp_adam(layers, x, y, batch, nsteps, lr=1e-3, beta1=0.9, beta2=0.999, eps=1
                 v = moments[il][2 + ip] = beta2 * moments[il][2 + ip] + (1. - beta2) * g * g
                 layers[il][ip][...] -= lr * (m / c1) / (np.sqrt(v / c2) + eps)
     return layers, np.array(losses)
+
+
+# ----------------------------------------------------------------------------------------------
+# f4: Gaussian covariance of power-spectrum / correlation-function multipoles
+#     observables/galaxy_clustering/covariance.py:14-41 (integral_legendre_product), 274-456 (ObservablesCovarianceMatrix.run / _run)
+# Pinned on the reference's own output: tests/golden/covariance.npz (tests/golden/make_covariance_fixture.py), tests/test_covariance.py.
+# ----------------------------------------------------------------------------------------------
+def integral_legendre_product(ells, mu_range=(-1., 1.)):
+    """covariance.py:14-41: integral over mu of the product of the Legendre polynomials of orders ``ells``."""
+    poly = special.legendre(0)
+    for ell in ells:
+        poly = poly * special.legendre(ell)
+    integ = poly.integ()
+    return integ(mu_range[-1]) - integ(mu_range[0])
+
+
+def gaussian_covariance_block(obs1, obs2, theory1, theory2, resolution=1):
+    """covariance.py:355-456 (``_run``) for one pair of observables of the same tracer.  ``obs``: dict(kind='pk' | 'xi', ells, edges=[per multipole: [n, 2]],
+    volume, shotnoise); ``theory``: dict(k [n_k], ells, power [n_ell, n_k]).  Returns the block [n1, n2]."""
+    if obs1['kind'] == 'pk' and obs2['kind'] == 'xi':                         # covariance.py:420-421
+        return gaussian_covariance_block(obs2, obs1, theory2, theory1, resolution=resolution).T
+    volume = min(obs1['volume'], obs2['volume'])                              # BaseFootprint.__and__ (covariance.py:99-101)
+    shotnoise = [obs1['shotnoise'], obs2['shotnoise']]
+    theories = [theory1, theory2]
+
+    def pk(it, k, ell):                                                       # covariance.py:361-371
+        theory = theories[it]
+        ill = list(theory['ells']).index(ell)
+        return np.interp(k, theory['k'], theory['power'][ill] + (ell == 0) * shotnoise[it])
+
+    def sigma_k(ell1, ell2, k, remove_zero_lag=False):                        # covariance.py:373-382
+        toret = 0.
+        for la in theories[0]['ells']:
+            for lb in theories[1]['ells']:
+                zero_lag = remove_zero_lag * (la == 0) * (lb == 0) * shotnoise[0] * shotnoise[1]
+                toret = toret + (pk(0, k, la) * pk(1, k, lb) - zero_lag) * integral_legendre_product((la, lb, ell1, ell2))
+        return (2 * ell1 + 1) * (2 * ell2 + 1) / volume * toret
+
+    def bin_volume(edges):                                                    # covariance.py:384-388
+        return 4. / 3. * np.pi * (edges[1]**3 - edges[0]**3)
+
+    def integ_points(edges):                                                  # covariance.py:392-393
+        return np.linspace(edges[0], edges[1], resolution + 2)[1:-1]
+
+    def weights_trapz(x):                                                     # utils.py:614-622
+        return np.concatenate([[x[1] - x[0]], x[2:] - x[:-2], [x[-1] - x[-2]]]) / 2.
+
+    cache = {}
+    kinds = (obs1['kind'], obs2['kind'])
+
+    def bin_cov(ells, ibins):
+        bins = [np.asarray(o['edges'][list(o['ells']).index(ell)][ibin]) for o, ell, ibin in zip((obs1, obs2), ells, ibins)]
+        if kinds == ('pk', 'pk'):                                             # covariance.py:397-406
+            inter = (max(bins[0][0], bins[1][0]), min(bins[0][1], bins[1][1]))
+            if inter[0] >= inter[1]: return 0.
+            k = integ_points(inter)
+            return (2. * np.pi)**3 * bin_volume(inter) / (bin_volume(bins[0]) * bin_volume(bins[1])) * np.sum(k**2 * sigma_k(ells[0], ells[1], k)) / np.sum(k**2)
+        if kinds == ('xi', 'pk'):                                             # covariance.py:408-416
+            s, k = integ_points(bins[0]), integ_points(bins[1])
+            weights = np.sum(s[:, None]**2 * special.spherical_jn(ells[0], s[:, None] * k), axis=0) / np.sum(s**2)
+            return np.sign(1j**ells[0]).real * np.sum(k**2 * sigma_k(ells[0], ells[1], k) * weights) / np.sum(k**2)
+        # xi x xi: covariance.py:423-446
+        if 'k' not in cache:
+            ks = [theory['k'] for theory in theories]
+            k = np.unique(np.concatenate(ks))
+            cache['k'] = k[(k >= max(kk.min() for kk in ks)) & (k <= min(kk.max() for kk in ks))]
+        k = cache['k']
+        if ells not in cache:
+            cache[ells] = sigma_k(ells[0], ells[1], k, remove_zero_lag=True) * (4. * np.pi * k**2 * weights_trapz(k))
+        ss = [integ_points(b) for b in bins]
+        weights = np.prod([np.sum(s[:, None]**2 * special.spherical_jn(ell, s[:, None] * k), axis=0) / np.sum(s**2) for s, ell in zip(ss, ells)], axis=0)
+        toret = np.sign(1j**sum(ells)).real / (2. * np.pi)**3 * np.sum(cache[ells] * weights)
+        inter = (max(bins[0][0], bins[1][0]), min(bins[0][1], bins[1][1]))
+        if inter[0] >= inter[1]: return toret
+        sn = integral_legendre_product((0, 0) + tuple(ells)) * shotnoise[0] * shotnoise[1] * (2 * ells[0] + 1) * (2 * ells[1] + 1) / volume
+        return toret + np.sign(1j**sum(ells)).real * bin_volume(inter) / (bin_volume(bins[0]) * bin_volume(bins[1])) * sn
+
+    rows = []
+    for ill1, ell1 in enumerate(obs1['ells']):
+        row = []
+        for ill2, ell2 in enumerate(obs2['ells']):
+            n1, n2 = len(obs1['edges'][ill1]), len(obs2['edges'][ill2])
+            row.append(np.array([[bin_cov((ell1, ell2), (i1, i2)) for i2 in range(n2)] for i1 in range(n1)], dtype='f8'))
+        rows.append(row)
+    return np.block(rows)
+
+
+def gaussian_covariance(observables, theories, resolution=1):
+    """covariance.py:343-353: blocks for every pair of observables, the diagonal blocks symmetrised."""
+    nobs = len(observables)
+    blocks = [[None] * nobs for _ in range(nobs)]
+    for io1 in range(nobs):
+        for io2 in range(io1 + 1):
+            c = gaussian_covariance_block(observables[io1], observables[io2], theories[io1], theories[io2], resolution=resolution)
+            if io1 == io2: blocks[io1][io2] = (c + c.T) / 2.
+            else: blocks[io1][io2], blocks[io2][io1] = c, c.T
+    return np.block(blocks)

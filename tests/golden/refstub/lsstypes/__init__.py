@@ -1,27 +1,43 @@
-"""Empty stand-in for the un-vendored third-party package ``lsstypes`` (test infrastructure only)."""
+"""Stand-in for the un-vendored third-party package ``lsstypes`` (test infrastructure only): plain containers that keep what they are given -- the reference
+wraps its results in them (e.g. ``CovarianceMatrix(value=..., observable=...)``, observables/galaxy_clustering/covariance.py:340-342); nothing is computed here."""
 
 
-class CovarianceMatrix(object):
+class _Container(object):
+
+    def __init__(self, *args, **kwargs):
+        self.args = args
+        self.__dict__.update(kwargs)
+
+
+class CovarianceMatrix(_Container):
     pass
 
 
-class WindowMatrix(object):
+class WindowMatrix(_Container):
     pass
 
 
-class ObservableTree(object):
+class ObservableTree(_Container):
     pass
 
 
-class ObservableLeaf(object):
+class ObservableLeaf(_Container):
     pass
 
 
-class Mesh2SpectrumPoles(object):
+class Mesh2SpectrumPoles(_Container):
     pass
 
 
-class Mesh2SpectrumPole(object):
+class Mesh2SpectrumPole(_Container):
+    pass
+
+
+class Count2CorrelationPoles(_Container):
+    pass
+
+
+class Count2CorrelationPole(_Container):
     pass
 
 
