@@ -58,6 +58,10 @@ SYMBOLS = {
     'dl_mlp_loss_and_grad': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _c_double_p, _c_double_p, ctypes.c_void_p]),
     'dl_mlp_forward': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_mlp_get_weights': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_void_p]),
+    'dl_cov_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int32, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int32_p, _c_double_p, ctypes.c_int64, _c_int32_p,
+                                     _c_double_p, ctypes.c_int64, _c_int32_p, _c_double_p, ctypes.c_int32, _c_double_p, ctypes.c_int64, _c_int32_p]),
+    'dl_cov_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_cov_destroy': (None, [ctypes.c_void_p]),
 }
 
 
@@ -479,6 +483,48 @@ class DeviceEnsemble(object):
     def close(self):
         if getattr(self, '_handle', None):
             self._lib.dl_ensemble_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CovariancePlan(object):
+    """Owner of one ``dl_cov`` plan (include/desilike_amd.h): Gaussian covariance of multipole observables from theory spectra resident on the GPU.  ``arrays``: dict with the
+    plan's host arrays (built by ``desilike_amd.observables.galaxy_clustering.covariance``)."""
+
+    def __init__(self, n, n_ell, n_k, ell0, shotnoise, cell_i, cell_d, pt_i, pt_d, gtab, sym, device=0):
+        lib = load()
+        n_ell, n_k, ell0 = (np.ascontiguousarray(a, dtype=np.int32) for a in (n_ell, n_k, ell0))
+        shotnoise = np.ascontiguousarray(shotnoise, dtype='f8')
+        cell_i, pt_i, sym = (np.ascontiguousarray(a, dtype=np.int32) for a in (np.reshape(cell_i, (-1, 8)), np.reshape(pt_i, (-1, 2)), np.reshape(sym, (-1, 2))))
+        cell_d, pt_d, gtab = (np.ascontiguousarray(a, dtype='f8') for a in (np.reshape(cell_d, (-1, 4)), np.reshape(pt_d, (-1, 6)), np.reshape(gtab, (-1, 5, 5))))
+        handle = ctypes.c_void_p()
+        if lib.dl_cov_create(ctypes.byref(handle), int(device), int(n), len(n_ell), _i32_ptr(n_ell), _i32_ptr(n_k), _i32_ptr(ell0), _f64_ptr(shotnoise), len(cell_i), _i32_ptr(cell_i),
+                             _f64_ptr(cell_d), len(pt_i), _i32_ptr(pt_i), _f64_ptr(pt_d), len(gtab), _f64_ptr(gtab), len(sym), _i32_ptr(sym)) != 0:
+            raise LibraryError(lib.dl_last_error(None).decode())
+        self._lib, self._handle, self.device, self.n, self.shapes = lib, handle, int(device), int(n), [(int(a), int(b)) for a, b in zip(n_ell, n_k)]
+
+    def apply(self, powers, out=None, stream=None):
+        """``powers``: one float64 device tensor ``[B, n_ell, n_k]`` per theory; returns the covariance matrices ``[B, n, n]`` (device tensor; asynchronous)."""
+        import torch
+        B = powers[0].shape[0]
+        for power, shape in zip(powers, self.shapes):
+            assert power.is_cuda and power.is_contiguous() and power.dtype == torch.float64 and tuple(power.shape) == (B,) + shape, (power.shape, shape)
+        if out is None: out = torch.empty((B, self.n, self.n), dtype=torch.float64, device=powers[0].device)
+        assert out.is_contiguous() and out.dtype == torch.float64 and tuple(out.shape) == (B, self.n, self.n)
+        if stream is None: stream = torch.cuda.current_stream(powers[0].device).cuda_stream
+        ptrs = (ctypes.c_void_p * len(powers))(*[power.data_ptr() for power in powers])
+        if self._lib.dl_cov_apply(self._handle, ptrs, B, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)) != 0:
+            raise LibraryError(self._lib.dl_last_error(None).decode())
+        return out
+
+    def close(self):
+        if getattr(self, '_handle', None):
+            self._lib.dl_cov_destroy(self._handle)
             self._handle = None
 
     def __del__(self):

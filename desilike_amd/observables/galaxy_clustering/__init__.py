@@ -3,3 +3,4 @@ from .window import (WindowedPowerSpectrumMultipoles, window_matrix_bininteg, Sy
 from .power_spectrum import TracerPowerSpectrumMultipolesObservable
 from .correlation_function import (WindowedCorrelationFunctionMultipoles, TracerCorrelationFunctionMultipolesObservable,
                                    SystematicTemplateCorrelationFunctionMultipoles)
+from .covariance import ObservablesCovarianceMatrix, BoxFootprint, CutskyFootprint, BaseFootprint

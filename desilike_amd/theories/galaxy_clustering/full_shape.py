@@ -100,7 +100,7 @@ class KaiserTracerPowerSpectrumMultipoles(BaseCalculator):
         self.template = self._require(template)
         # template knots with margin for the AP effect (full_shape.py:29)
         tk = template.init.get('k', None)
-        kin = np.geomspace(min(self._klim[0], self.k[0] / 2, tk[0] if tk is not None else 1.), max(self._klim[1], self.k[-1] * 2, tk[0] if tk is not None else 0.), self._klim[2])
+        kin = np.geomspace(min(self._klim[0], self.k[0] / 2, tk[0] if tk is not None else 1.), max(self._klim[1], self.k[-1] * 2, tk[-1] if tk is not None else 0.), self._klim[2])   # (a template shared by several theories ends up with knots that cover them all)
         template.init.update(k=kin)
         if init.get('z', None) is not None:
             template.init.update(z=init['z'])

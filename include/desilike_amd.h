@@ -248,6 +248,27 @@ int  dl_mlp_loss_and_grad(dl_mlp* net, const double* x_dev, const double* y_dev,
 int  dl_mlp_forward(dl_mlp* net, const double* x_dev, int64_t rows, double* y_dev /* [rows, n_out] */, void* hip_stream);
 int  dl_mlp_get_weights(dl_mlp* net, double* weights /* host, flat */, void* hip_stream);
 
+/* ---- Gaussian covariance of P_ell / xi_ell observables ------------------------------------------------------------------
+ * Reference: desilike/observables/galaxy_clustering/covariance.py:355-456 (ObservablesCovarianceMatrix._run).  Every element is
+ *     C[row, col] = front / den * sum_q (sigma(k_q) w_q) w2_q + const,   sigma(k) = prefactor * sum_{la, lb} (P1_la(k) P2_lb(k) - zero lag) G[la][lb],
+ * P the theory multipoles (+ shot noise on the monopole) interpolated linearly between the theory's wavenumbers like np.interp.  The plan (host arrays, copied) lists
+ *   cell_i [n_cells, 8]  row, col, theory of the first / second observable, index into gtab, zero-lag flag (xi x xi: the product of the shot noises is removed from the
+ *                        monopole x monopole term), first point, number of points;
+ *   cell_d [n_cells, 4]  prefactor, front, den, const;
+ *   pt_i   [n_points, 2] interval j of k_q in the wavenumbers of theory 1 / theory 2 (0 <= j <= n_k - 2);
+ *   pt_d   [n_points, 6] (k_q - k_j, k_{j+1} - k_j) for theory 1, the same for theory 2, w, w2;
+ *   gtab   [n_gtab, 5, 5] integral of L_la L_lb L_l1 L_l2 over mu, indexed by the positions of la / lb in the theories' multipoles;
+ *   sym    [n_sym, 2]    pairs (row, col) of the diagonal blocks replaced by their mean with the transposed element (covariance.py:349-351);
+ * theory t: n_ell[t] <= 5 multipoles on n_k[t] wavenumbers, ell0[t] = position of the monopole (-1: none), shotnoise[t] added to it.
+ * dl_cov_apply: power_dev[t] = device array [B, n_ell[t], n_k[t]] (e.g. from dl_eval_theory), cov_dev [B, n, n] device output (zero where no cell writes); asynchronous
+ * on ``hip_stream``; B <= 65535. */
+typedef struct dl_cov dl_cov;
+int  dl_cov_create(dl_cov** out, int device, int32_t n, int32_t n_theories, const int32_t* n_ell, const int32_t* n_k, const int32_t* ell0, const double* shotnoise,
+                   int64_t n_cells, const int32_t* cell_i, const double* cell_d, int64_t n_points, const int32_t* pt_i, const double* pt_d, int32_t n_gtab, const double* gtab,
+                   int64_t n_sym, const int32_t* sym);
+int  dl_cov_apply(dl_cov* plan, const double* const* power_dev, int64_t B, double* cov_dev, void* hip_stream);
+void dl_cov_destroy(dl_cov* plan);
+
 #ifdef __cplusplus
 }
 #endif
