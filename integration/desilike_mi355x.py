@@ -3,9 +3,13 @@
 This module imports ``desilike`` (the reference), never ``desilike_amd``'s Python mirror: it talks to ``libdesilike_amd.so`` through ctypes only
 (include/desilike_amd.h).  Two pieces:
 
-* :func:`extract_config` -- walks an *initialised* reference ``ObservablesGaussianLikelihood`` (Kaiser / EFT-like Kaiser tracer theories on
-  ShapeFit / Standard / Fixed templates, any window handled by ``WindowedPowerSpectrumMultipoles``, one or several observables, tracer namespaces)
-  and returns the flat ``{key: array}`` set of ``dl_config`` (keys documented in the header);
+* :func:`extract_config` -- walks an *initialised* reference ``ObservablesGaussianLikelihood`` and returns the flat ``{key: array}`` set of ``dl_config`` (keys
+  documented in the header).  Covered: Kaiser / EFT-like Kaiser tracer power spectrum AND correlation function multipoles on ShapeFit / Standard / Fixed templates;
+  damped-BAO tracer power spectrum and correlation function multipoles ('standard' wiggle model, 'power' broadband terms); any window handled by
+  ``WindowedPowerSpectrumMultipoles``; one or several observables, tracer namespaces; parameters solved analytically ('.marg' / '.best' / '.auto': shot-noise like
+  terms, counter / stochastic terms, broadband terms).  For correlation functions ``get_corr`` (FFTLog) is linear in P_ell: the binding applies THE REFERENCE'S OWN
+  ``theory.get_corr`` -- cosmoprimo's transform in a real installation -- to the unit vectors of the theory's k grid once, and hands the resulting operator to the
+  device folded into the window matrix (desilike/theories/galaxy_clustering/base.py:127-136);
 * :class:`MI355XGaussianLikelihood` -- a ``BaseGaussianLikelihood`` whose ``calculate`` is ONE ``dl_eval_batch_host`` call; ``evaluate(values [B, P])`` is the
   batched entry for samplers.
 
@@ -18,7 +22,7 @@ import numpy as np
 
 # enumerations of include/desilike_amd.h
 DL_TEMPLATE_FIXED, DL_TEMPLATE_SHAPEFIT = 0, 1
-DL_THEORY_KAISER, DL_THEORY_EFT_KAISER = 0, 1
+DL_THEORY_KAISER, DL_THEORY_EFT_KAISER, DL_THEORY_BAO_DAMPED = 0, 1, 2
 DL_APMODE = {'qparqper': 0, 'qiso': 1, 'qap': 2, 'qisoqap': 3}
 
 
@@ -27,13 +31,52 @@ def _apmode(template):
     return DL_APMODE[getattr(apeffect, 'mode', 'qparqper')]
 
 
+def _has(calculator, name):
+    try:
+        getattr(calculator, name)
+        return True
+    except AttributeError:
+        return False
+
+
+def hankel_operator(theory):
+    """``[n_ell][n_s, n_k]``: the reference's ``get_corr`` (tgc/base.py:127-136: interpolation to the FFTLog grid, high-k tail, FFTLog, interpolation to s -- linear
+    in P_ell) applied to the unit vectors of the theory's k grid; every multipole's row gets the same unit vector in one call."""
+    nk, n_ell = len(theory.kin), len(theory.ells)
+    columns = []
+    for j in range(nk):
+        unit = np.zeros((n_ell, nk), dtype='f8')
+        unit[:, j] = 1.
+        columns.append(np.asarray(theory.get_corr(unit), dtype='f8'))       # [n_ell, n_s]
+    return np.stack(columns, axis=-1)                                        # [n_ell, n_s, n_k]
+
+
+def _block_diag(blocks):
+    n, m = sum(b.shape[0] for b in blocks), sum(b.shape[1] for b in blocks)
+    out = np.zeros((n, m), dtype='f8')
+    r = c = 0
+    for b in blocks:
+        out[r:r + b.shape[0], c:c + b.shape[1]] = b
+        r += b.shape[0]; c += b.shape[1]
+    return out
+
+
 def extract_config(likelihood):
-    """Flat ``dl_config`` of an initialised reference likelihood: ``{key: float64 / int32 array}``, plus ``varied`` (theta column order) under ``'__varied__'``."""
+    """Flat ``dl_config`` of an initialised reference likelihood: ``{key: float64 / int32 array}``, plus ``varied`` (theta column order) under ``'__varied__'`` and the
+    analytically solved parameters under ``'__solved__'``."""
     varied = likelihood.varied_params.names()
+    solved_params = [param for param in likelihood.all_params if param.solved and not str(param.derived).startswith('.prec')]
+    solved = [param.name for param in solved_params]
     cfg = {}
 
     def column(name, default):
         return np.array([varied.index(name) if name in varied else -1, default], dtype='f8')
+
+    def sindex(name):
+        return solved.index(name) if name in solved else -1
+
+    def value_of(name, default):
+        return float(likelihood.all_params[name].value) if name in likelihood.all_params else default
 
     cfg['n_params'] = np.array([len(varied)], dtype='i4')
     cfg['n_obs'] = np.array([len(likelihood.observables)], dtype='i4')
@@ -47,49 +90,102 @@ def extract_config(likelihood):
         kind = kinds.index(prior.dist)
         priors.append([float(kind), prior.limits[0], prior.limits[1], prior.attrs.get('loc', 0.) if kind else 0., prior.attrs.get('scale', 1.) if kind else 1.])
     cfg['priors'] = np.array(priors, dtype='f8')
+    if solved:
+        # likelihoods/base.py:314-413: '.marg' (1) / '.best' (0) per solved parameter, Gaussian prior (loc, 1 / scale^2; flat: 0), expansion point = current value
+        default = getattr(likelihood, 'solved_default', '.marg')
+        kind, mprior, x0 = [], [], []
+        for param in solved_params:
+            derived = str(param.derived)
+            if derived.startswith('.auto'): derived = derived.replace('.auto', default)
+            kind.append(1 if derived.startswith('.marg') else 0)
+            loc, scale = (param.prior.attrs['loc'], param.prior.attrs['scale']) if param.prior.dist == 'norm' else (0., np.inf)
+            mprior.append([loc, scale**(-2)])
+            x0.append(float(param.value))
+        cfg['marg.kind'], cfg['marg.prior'], cfg['marg.x0'] = np.array(kind, dtype='i4'), np.array(mprior, dtype='f8'), np.array(x0, dtype='f8')
     for iobs, obs in enumerate(likelihood.observables):
         p = 'obs{:d}.'.format(iobs)
         wm = obs.wmatrix
         theory = wm.theory
-        pt, template = theory.pt, theory.pt.template
-        eft = hasattr(theory, 'counterterm_matrix')
+        xi = hasattr(theory, 'get_corr')                                    # correlation function multipoles: Hankel transform of a power spectrum theory
+        ptheory = theory.power if xi else theory                           # the tracer power spectrum calculator ...
+        pt = ptheory.pt if 'pt' in ptheory.__dict__ or hasattr(type(ptheory), 'pt') or _has(ptheory, 'pt') else ptheory   # ... (the BAO correlation function classes hold the wiggle calculator itself: bao.py:881-905)
+        if pt is ptheory: ptheory = theory
+        template = pt.template
+        bao = hasattr(pt, 'smoothing_radius')
+        eft = hasattr(ptheory, 'counterterm_matrix')
         shapefit = template.__class__.__name__.startswith('ShapeFit')
-        cfg[p + 'theory'] = np.array([DL_THEORY_EFT_KAISER if eft else DL_THEORY_KAISER], dtype='i4')
-        cfg[p + 'template'] = np.array([DL_TEMPLATE_SHAPEFIT if shapefit else DL_TEMPLATE_FIXED], dtype='i4')
+        cfg[p + 'theory'] = np.array([DL_THEORY_BAO_DAMPED if bao else DL_THEORY_EFT_KAISER if eft else DL_THEORY_KAISER], dtype='i4')
+        cfg[p + 'template'] = np.array([DL_TEMPLATE_SHAPEFIT if shapefit and not bao else DL_TEMPLATE_FIXED], dtype='i4')
         cfg[p + 'apmode'] = np.array([_apmode(template)], dtype='i4')
         cfg[p + 'transform'] = np.array([1 if getattr(obs, 'transform', None) == 'cubic' else 0], dtype='i4')
         cfg[p + 'eta'] = np.array([getattr(getattr(template, 'apeffect', None), 'eta', 1. / 3.)], dtype='f8')
         cfg[p + 'f_fid'] = np.array([template.f_fid], dtype='f8')
         cfg[p + 'a'] = np.array([getattr(template, 'a', 0.6)], dtype='f8')
         cfg[p + 'kp'] = np.array([getattr(template, 'kp', 0.03)], dtype='f8')
-        cfg[p + 'nd'] = np.array([theory.nd], dtype='f8')
-        cfg[p + 'ells_in'] = np.asarray(wm.ellsin, dtype='i4')
+        cfg[p + 'nd'] = np.array([1. if bao else ptheory.nd], dtype='f8')
+        cfg[p + 'ells_in'] = np.asarray(ptheory.ells if xi else wm.ellsin, dtype='i4')
         cfg[p + 'kin'] = np.asarray(pt.k, dtype='f8')
         cfg[p + 'mu'], cfg[p + 'wmu_ell'] = np.asarray(pt.mu, dtype='f8'), np.asarray(pt.wmu, dtype='f8')
         cfg[p + 'k_t'], cfg[p + 'pk_dd_fid'] = np.asarray(template.k, dtype='f8'), np.asarray(template.pk_dd_fid, dtype='f8')
-        if wm.matrix_full is not None: cfg[p + 'wmatrix'] = np.asarray(wm.matrix_full, dtype='f8')
-        if getattr(wm, 'kmask', None) is not None: cfg[p + 'kmask'] = np.asarray(wm.kmask, dtype='i4')
-        if getattr(wm, 'offset', None) is not None: cfg[p + 'offset'] = np.asarray(wm.offset, dtype='f8')
-        cfg[p + 'shotnoise_in'], cfg[p + 'shotnoise_out'] = np.asarray(wm.shotnoisein, dtype='f8'), np.asarray(wm.shotnoiseout, dtype='f8')
         cfg[p + 'flatdata'] = np.asarray(obs.flatdata, dtype='f8')
         # parameter -> theta column (or constant): tracer namespaces prefix the bias / shot-noise parameters (full_shape.py:88-128)
         names = {param.basename: param.name for param in theory.all_params}
+        names.update({param.basename: param.name for param in ptheory.all_params})
         names.update({param.basename: param.name for param in pt.all_params})
-        defaults = dict(qpar=1., qper=1., qiso=1., qap=1., df=1., dm=0., dn=0., sigmapar=0., sigmaper=0., sn0=0.)
+        # pass-through columns appended to the theory vector: broadband terms of the BAO classes (bao.py:495-534, 881-905), in the order of the multipoles
+        pass_names, pass_matrix = [], None
+        if bao:
+            if pt.model != 'standard':
+                raise NotImplementedError('wiggle model {}: this binding covers the standard one (the library has them all: desilike_amd/theories/galaxy_clustering/bao.py)'.format(pt.model))
+            cfg[p + 'pknow_dd_fid'] = np.asarray(template.pknow_dd_fid, dtype='f8')
+            cfg[p + 'bao_mode'] = np.array([1 if pt.mode == 'reciso' else 0], dtype='i4')
+            cfg[p + 'smoothing_radius'] = np.array([pt.smoothing_radius], dtype='f8')
+            pass_names = [name for ell in theory.ells for name in theory.broadband_orders[ell]]
+            nx = len(theory.s) if xi else len(theory.k)
+            pass_matrix = np.zeros((len(theory.ells), nx, len(pass_names)), dtype='f8')
+            for ill, ell in enumerate(theory.ells):
+                for name, row in zip(theory.broadband_orders[ell], np.asarray(theory.broadband_matrix[ell])):
+                    pass_matrix[ill, :, pass_names.index(name)] = row
+            pass_matrix = pass_matrix.reshape(-1, len(pass_names))
+            pass_names = [names.get(name, name) for name in pass_names]
+        if xi:
+            if getattr(wm, 'matrix_full', None) is not None or getattr(wm, 'smask', None) is not None:
+                raise NotImplementedError('binned / masked correlation function windows: fold wm.matrix_full into the operator like the power spectrum branch does')
+            window = _block_diag(list(hankel_operator(theory)))
+        else:
+            window = None if wm.matrix_full is None else np.asarray(wm.matrix_full, dtype='f8')
+            if getattr(wm, 'kmask', None) is not None: cfg[p + 'kmask'] = np.asarray(wm.kmask, dtype='i4')
+            if getattr(wm, 'offset', None) is not None: cfg[p + 'offset'] = np.asarray(wm.offset, dtype='f8')
+            cfg[p + 'shotnoise_in'], cfg[p + 'shotnoise_out'] = np.asarray(wm.shotnoisein, dtype='f8'), np.asarray(wm.shotnoiseout, dtype='f8')
+        if pass_names:
+            if window is None: window = np.eye(pass_matrix.shape[0])
+            window = np.hstack([window, window.dot(pass_matrix) if not xi else pass_matrix])
+            cfg[p + 'in.pass'] = np.array([column(name, value_of(name, 0.)) for name in pass_names], dtype='f8')
+        if window is not None: cfg[p + 'wmatrix'] = window
+        defaults = dict(qpar=1., qper=1., qiso=1., qap=1., df=1., dm=0., dn=0., sigmapar=9. if bao else 0., sigmaper=6. if bao else 0.)
+        if bao: defaults.update(dbeta=1., sigmas=0.)
+        else: defaults.update(sn0=0.)
+        if xi and not bao: defaults.pop('sn0')                             # no stochastic parameter for correlation functions (full_shape.py:336-364)
         for key, default in defaults.items():
             pname = names.get(key, key)
-            value = likelihood.all_params[pname].value if pname in likelihood.all_params else default
-            cfg[p + 'in.' + key] = column(pname, value)
+            cfg[p + 'in.' + key] = column(pname, value_of(pname, default))
         b1 = names.get('b1', 'b1')
-        value = likelihood.all_params[b1].value if b1 in likelihood.all_params else 1.
-        cfg[p + 'in.b1X'] = cfg[p + 'in.b1Y'] = column(b1, value)
+        cfg[p + 'in.b1X'] = cfg[p + 'in.b1Y'] = column(b1, value_of(b1, 1.))
         if eft:
-            cfg[p + 'ct_matrix'], cfg[p + 'sn_matrix'] = np.asarray(theory.counterterm_matrix, dtype='f8'), np.asarray(theory.stochastic_matrix, dtype='f8')
-            ct = [column(names.get(str(n), str(n)), likelihood.all_params[names.get(str(n), str(n))].value) for n in theory.counterterm_params]
-            sn = [column(names.get(str(n), str(n)), likelihood.all_params[names.get(str(n), str(n))].value) for n in theory.stochastic_params]
-            cfg[p + 'in.ct'] = np.array([[c, c] for c in ct], dtype='f8')      # auto-spectrum: the X and Y tracer inputs of a term are the same parameter
-            cfg[p + 'in.sn'] = np.array(sn, dtype='f8')
+            cfg[p + 'ct_matrix'], cfg[p + 'sn_matrix'] = np.asarray(ptheory.counterterm_matrix, dtype='f8'), np.asarray(ptheory.stochastic_matrix, dtype='f8')
+            ct_names = [names.get(str(n), str(n)) for n in ptheory.counterterm_params]
+            sn_names = [names.get(str(n), str(n)) for n in ptheory.stochastic_params]
+            cfg[p + 'in.ct'] = np.array([[column(n, value_of(n, 0.))] * 2 for n in ct_names], dtype='f8')      # auto-spectrum: the X and Y tracer inputs of a term are the same parameter
+            cfg[p + 'in.sn'] = np.array([column(n, value_of(n, 0.)) for n in sn_names], dtype='f8')
+        if solved:
+            # which inputs of this observable are solved analytically (they must enter its theory linearly: full_shape.py:545-550, 628-634, bao.py:495-534)
+            if p + 'in.sn0' in cfg: cfg[p + 'marg.sn0'] = np.array([sindex(names.get('sn0', 'sn0'))], dtype='i4')
+            if pass_names: cfg[p + 'marg.pass'] = np.array([sindex(name) for name in pass_names], dtype='i4')
+            if eft:
+                cfg[p + 'marg.ct'] = np.array([[sindex(n)] * 2 for n in ct_names], dtype='i4')
+                cfg[p + 'marg.sn'] = np.array([sindex(n) for n in sn_names], dtype='i4')
     cfg['__varied__'] = np.array(varied)
+    cfg['__solved__'] = np.array(solved)
     return cfg
 
 
@@ -131,15 +227,18 @@ class Library(object):
             lib.dl_config_free(handle_cfg)
         return ctx
 
-    def eval_batch(self, ctx, theta):
-        """(loglikelihood [B], logprior [B], status [B]) of ``theta [B, P]``: one ``dl_eval_batch_host`` call."""
+    def eval_batch(self, ctx, theta, n_solved=0):
+        """(loglikelihood [B], logprior [B], status [B]) of ``theta [B, P]``: one ``dl_eval_batch_host`` call; ``n_solved`` > 0: also the values of the analytically
+        solved parameters ``[B, n_solved]`` (likelihoods/base.py:361-365)."""
         theta = np.ascontiguousarray(np.atleast_2d(theta), dtype='f8')
         B = theta.shape[0]
         loglike, logprior, status = np.empty(B), np.empty(B), np.empty(B, dtype=np.int32)
+        solved = np.empty((B, n_solved)) if n_solved else None
         dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
-        if self.lib.dl_eval_batch_host(ctx, theta.ctypes.data_as(dp), B, loglike.ctypes.data_as(dp), logprior.ctypes.data_as(dp), None, status.ctypes.data_as(ip), None) != 0:
+        if self.lib.dl_eval_batch_host(ctx, theta.ctypes.data_as(dp), B, loglike.ctypes.data_as(dp), logprior.ctypes.data_as(dp), None, status.ctypes.data_as(ip),
+                                       solved.ctypes.data_as(dp) if n_solved else None) != 0:
             raise RuntimeError(self.lib.dl_last_error(ctx).decode())
-        return loglike, logprior, status
+        return (loglike, logprior, status, solved) if n_solved else (loglike, logprior, status)
 
 
 def make_calculator():

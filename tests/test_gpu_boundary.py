@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(ROOT, 'integration'))
 
-FIXTURES = ['cfg2_dense', 'two_tracers', 'eft_qisoqap']
+FIXTURES = ['cfg2_dense', 'two_tracers', 'eft_qisoqap', 'cfg4_xi', 'cfg4_pk', 'kaiser_xi']     # cfg4_*: BASELINE configs[3] (damped BAO); *_xi: the reference's own get_corr as a folded operator
+MARG_FIXTURES = ['cfg4_xi_marg', 'two_tracers_marg']                                                  # analytically solved parameters ('.marg')
 
 
 def load_fixture(name):
@@ -43,7 +44,35 @@ def test_context_from_reference_side_keys(name):
     library.lib.dl_destroy(ctx)
 
 
-@pytest.mark.parametrize('name', FIXTURES)
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', MARG_FIXTURES)
+def test_marginalised_context_from_reference_side_keys(name):
+    """Contexts with analytically solved parameters, created from the reference-side keys through ctypes.  The reference's own ``_solve`` needs jax (absent here): the
+    fixture holds the exact quadratic form (c, g, H) of the reference's NON-marginalised log-posterior in the solved parameters x (evaluated by the reference on a
+    stencil), from which  x* = x0 - H^-1 g,  logposterior = c - g H^-1 g / 2 - logdet(-H) / 2  (likelihoods/base.py:385-404: no 2 pi) follow exactly."""
+    import torch  # noqa: F401
+    from desilike_mi355x import Library
+    g, cfg = load_fixture(name)
+    library = Library(os.path.join(ROOT, 'desilike_amd', 'lib', 'libdesilike_amd.so'))
+    ctx = library.create(cfg, device=0)
+    ns = len(g['solved'])
+    n = len(g['marg_c'])
+    theta = g['theta'][:n]
+    loglike, logprior, status, solved = library.eval_batch(ctx, theta, n_solved=ns)
+    inside = status == 0
+    assert inside.sum() >= n - 1
+    for i in np.flatnonzero(inside):
+        c, grad, H = g['marg_c'][i], g['marg_g'][i], g['marg_H'][i]
+        dx = -np.linalg.solve(H, grad)
+        ref = c + 0.5 * grad.dot(dx) - 0.5 * np.linalg.slogdet(-H)[1]
+        got = loglike[i] + logprior[i]
+        assert abs(got - ref) <= 1e-8 * max(1., abs(ref)), (i, got, ref)            # (the stencil's finite differences of an exact quadratic: rounding ~1e-9 of |c|)
+        # (x* from differences of log-posteriors of size |c| over the stencil: the gradient carries ~1e-13 |c| / step of rounding -- parts in 1e5 of the small broadband terms)
+        assert np.allclose(solved[i], g['marg_x0'] + dx, rtol=1e-4, atol=1e-6 * np.abs(g['marg_x0'] + dx).max())
+    library.lib.dl_destroy(ctx)
+
+
+@pytest.mark.parametrize('name', FIXTURES + MARG_FIXTURES)
 def test_reference_side_keys_are_the_keys_of_the_header(name):
     """Every extracted key is one the header documents, the store accepts them, and without a GPU dl_create refuses (no CPU fallback)."""
     import re
