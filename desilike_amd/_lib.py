@@ -27,6 +27,7 @@ SYMBOLS = {
     'dl_eval_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_batch_derived': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_logposterior': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_eval_logposterior_grad': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_fisher': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_theory': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_batch_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
@@ -340,6 +341,24 @@ class Context(object):
         self._check(self._lib.dl_eval_theory(self._handle, ctypes.c_void_p(theta.data_ptr()), B, int(iobs), ctypes.c_void_p(power.data_ptr()),
                                              None if tables is None else ctypes.c_void_p(tables.data_ptr()), ctypes.c_void_p(stream)))
         return power
+
+    def eval_logposterior_grad(self, theta, logposterior=None, grad=None, status=None, stream=None):
+        """Log-posterior ``[B]`` and its analytic gradient ``[B, P]`` (``dl_eval_logposterior_grad``; float64 device tensors, allocated if ``None``; asynchronous).
+        Returns ``(logposterior, grad)``, or ``None`` when the context is outside the analytic gradient's scope (the caller differentiates numerically)."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(theta.device).cuda_stream
+        if self.expand is not None:
+            return None      # parameters derived by an expression: chain rule through the expression is not implemented
+        B = theta.shape[0]
+        assert theta.is_contiguous() and theta.dtype == torch.float64 and theta.shape[1] == self.n_params
+        if logposterior is None: logposterior = torch.empty(B, dtype=torch.float64, device=theta.device)
+        if grad is None: grad = torch.empty((B, self.n_params), dtype=torch.float64, device=theta.device)
+        rc = self._lib.dl_eval_logposterior_grad(self._handle, ctypes.c_void_p(theta.data_ptr()), B, ctypes.c_void_p(logposterior.data_ptr()), ctypes.c_void_p(grad.data_ptr()),
+                                                 None if status is None else ctypes.c_void_p(status.data_ptr()), ctypes.c_void_p(stream))
+        if rc == 2: return None
+        self._check(rc)
+        return logposterior, grad
 
     def eval_fisher(self, centers, steps, hessian=None, gradient=None, offset=None, stream=None):
         """Fisher algebra on the device (``dl_eval_fisher``): ``centers [B, P]``, ``steps [B, P, 2]`` (lower, upper) -> ``hessian [B, P, P]``, ``gradient [B, P]``,

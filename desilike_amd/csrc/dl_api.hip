@@ -62,6 +62,10 @@ struct dl_ctx {
     int32_t* status_stage = nullptr; // device
     double* host_stage = nullptr;    // pinned host mirror: theta[cap * P] | out[3 * cap]
     hipStream_t host_stream = nullptr;   // private stream of the *_host entry points
+    // analytic gradient (dl_eval_logposterior_grad): -W~^T [K_pad, N_pad], a zero bias [K_pad], residual rows [cap, N_pad], Y [cap, K_pad], per-observable sums [cap, n_obs, 8]
+    double *grad_wtT = nullptr, *grad_zero = nullptr, *grad_delta = nullptr, *grad_y = nullptr, *grad_phys = nullptr;
+    int32_t* grad_status = nullptr;
+    int64_t grad_cap = 0;
     // the workspaces are shared by every call on this context: a call on another stream than the previous one waits for it (event recorded on the old stream
     // at the moment of the switch: calls that stay on one stream pay nothing)
     hipStream_t last_stream = nullptr;
@@ -415,6 +419,8 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
 void dl_destroy(dl_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    for (double* p : {ctx->grad_wtT, ctx->grad_zero, ctx->grad_delta, ctx->grad_y, ctx->grad_phys}) if (p) (void)hipFree(p);
+    if (ctx->grad_status) (void)hipFree(ctx->grad_status);
     void* ptrs[] = {ctx->arena_dev, ctx->priors_dev, ctx->wt_white_dev, ctx->bias_white_dev, ctx->wt_full_dev, ctx->bias_full_dev, ctx->wh_dev,
                     ctx->bias_wh_dev, ctx->flatdata_dev, ctx->transform_dev, ctx->tconst_dev, ctx->power_ws, ctx->delta_ws, ctx->flat_ws, ctx->stencil_ws, ctx->theta_stage, ctx->out_stage,
                     ctx->status_stage, ctx->gemm_counters, ctx->obs_array_dev};
@@ -670,6 +676,61 @@ int dl_eval_fisher(dl_ctx* ctx, const double* centers_dev, const double* steps_d
         }
         dl_launch_fisher(ctx->delta_ws, ctx->N_pad, ctx->n_white, n_slabs, slab_stride, bias, steps, P, nc, hessian_dev ? hessian_dev + (size_t)b0 * P * P : nullptr,
                          gradient_dev ? gradient_dev + (size_t)b0 * P : nullptr, offset_dev ? offset_dev + b0 : nullptr, stream);
+    }
+    DL_HIP_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+// log-posterior and its gradient: theory -> residual rows d~ (direct GEMM) -> chi2 + priors, Y = -d~ W~ (second GEMM) -> gradient workgroups -> chain rule.
+// Returns 2 (nothing launched) when the context is outside the analytic gradient's scope (dl_fullshape_grad.h): the caller differentiates numerically.
+int dl_eval_logposterior_grad(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logposterior_dev, double* grad_dev, int32_t* status_dev, void* hip_stream) {
+    if (!ctx) { g_last_error = "dl_eval_logposterior_grad: null context"; return 1; }
+    if (B < 0 || (B > 0 && (!theta_dev || !logposterior_dev || !grad_dev))) return dl_fail(ctx, "dl_eval_logposterior_grad: invalid argument");
+    if (ctx->feat_ok || ctx->any_transform || ctx->n_solved != 0 || ctx->priors_general || !dl_grad_applicable(ctx->obs_kernarg.data(), ctx->n_obs)) return 2;
+    if (B == 0) return 0;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    dl_prof_events.start = dl_prof_events.stop = nullptr;
+    DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (dl_order_streams(ctx, stream)) return 1;
+    // per pass: at most 2048 points (the chi2 GEMM with the residual output: partial chi2 for the log-posterior AND the rows d~ for the gradient, in one launch)
+    const int64_t per_pass = 2048;
+    if (dl_reserve(ctx, std::min<int64_t>(B, per_pass))) return 1;
+    const int P = ctx->n_params, Np = ctx->N_pad, Kp = ctx->K_pad;
+    if (!ctx->grad_wtT) {
+        std::vector<double> w((size_t)Np * Kp), wt((size_t)Kp * Np);
+        DL_HIP_CHECK(ctx, hipMemcpy(w.data(), ctx->wt_white_dev, w.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int j = 0; j < Np; ++j) for (int k = 0; k < Kp; ++k) wt[(size_t)k * Np + j] = -w[(size_t)j * Kp + k];
+        DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->grad_wtT, wt.size() * sizeof(double)));
+        DL_HIP_CHECK(ctx, hipMemcpy(ctx->grad_wtT, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice));
+        DL_HIP_CHECK(ctx, hipDeviceSynchronize());
+    }
+    const int64_t need = std::min<int64_t>(B, per_pass);
+    if (need > ctx->grad_cap) {
+        if (ctx->grad_cap > 0) DL_HIP_CHECK(ctx, hipDeviceSynchronize());
+        for (double** p : {&ctx->grad_delta, &ctx->grad_y, &ctx->grad_phys}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+        if (ctx->grad_status) { (void)hipFree(ctx->grad_status); ctx->grad_status = nullptr; }
+        ctx->grad_cap = 0;
+        const int64_t cap = std::max<int64_t>((need + 63) / 64 * 64, 256);     // (whole 64-row tiles of the second GEMM)
+        DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->grad_delta, (size_t)cap * Np * sizeof(double)));
+        DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->grad_y, (size_t)cap * Kp * sizeof(double)));
+        DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->grad_phys, (size_t)cap * ctx->n_obs * 8 * sizeof(double)));
+        DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->grad_status, (size_t)cap * sizeof(int32_t)));
+        DL_HIP_CHECK(ctx, hipMemset(ctx->grad_delta, 0, (size_t)cap * Np * sizeof(double)));
+        DL_HIP_CHECK(ctx, hipDeviceSynchronize());
+        ctx->grad_cap = cap;
+    }
+    static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;
+    for (int64_t b0 = 0; b0 < B; b0 += per_pass) {
+        const int64_t nb = std::min<int64_t>(per_pass, B - b0);
+        const double* th = theta_dev + (size_t)b0 * P;
+        int32_t* st = status_dev ? status_dev + b0 : ctx->grad_status;      // (the gradient's finalize needs the status whether the caller wants it or not)
+        dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, nullptr, 0, xcd_local ? dl_chi2_gemm_row_tile(nb, Np) : 0, ctx->obs_array_dev);
+        dl_launch_chi2_gemm(ctx->power_ws, Kp, ctx->wt_white_dev, Kp, ctx->bias_white_dev, ctx->delta_ws, nb, Np, Kp, nullptr, th, P, ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream,
+                            ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live, ctx->grad_delta, Np);
+        dl_launch_finalize_part(ctx->delta_ws, Np / 16, th, P, ctx->priors_dev, nb, logposterior_dev + b0, nullptr, st, 1, stream);
+        // Y = -d~ W~: [nb, N_pad] x [N_pad, K_pad] through the LDS-DMA tiled GEMM, one split (K = N_pad: 4 panels), no bias
+        dl_launch_window_gemm_tiled(ctx->grad_delta, Np, ctx->grad_wtT, Np, ctx->grad_y, 0, Kp, nb, Kp, Np, 1, Np / 16, stream, 0);
+        dl_launch_fullshape_grad(ctx->obs_kernarg.data(), ctx->n_obs, ctx->obs_array_dev, th, P, nb, ctx->grad_y, Kp, ctx->grad_phys, ctx->priors_dev, st, grad_dev + (size_t)b0 * P, stream);
     }
     DL_HIP_CHECK(ctx, hipGetLastError());
     return 0;

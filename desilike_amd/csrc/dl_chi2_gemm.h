@@ -55,10 +55,11 @@ struct DlChi2Panels {
 
 // MT: rows per workgroup, 32 or 16 (16: batches whose 32-row blocks would leave CUs without a workgroup -- 256 walkers x 16 column blocks = 128 workgroups of 32 rows,
 // 256 of 16 rows, each moving 32 instead of 48 KB per panel; the partial sums of a row do not depend on the tile height)
-template <bool DO_LOAD, bool DO_MMA, int MT = DL_CG_M>
+// RESID: the residual itself is ALSO written, resid [M, ldr] (the analytic gradient needs d~ as well as chi2: dl_eval_logposterior_grad)
+template <bool DO_LOAD, bool DO_MMA, int MT = DL_CG_M, bool RESID = false>
 __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
                                                            const double* __restrict__ bias, double* __restrict__ part, int M, int K_pad, int n_tiles, DlChi2Fin fin,
-                                                           DlChi2Panels panels, int k_live) {
+                                                           DlChi2Panels panels, int k_live, double* __restrict__ resid, int64_t ldr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     dl_kernarg_prefetch<256>();   // pointers, sizes, finalize block, panel ranges: four lines, one round trip
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
         double v = bj;
 #pragma unroll
         for (int w = 0; w < DL_CG_WAVES; ++w) v += red[((w * 2 + t) * 4 + r) * 64 + lane];   // fixed order: deterministic
+        if (RESID) { const int rrow = m0 + 16 * t + g + 4 * r; if (rrow < M) resid[(size_t)rrow * ldr + n0 + r16] = v; }
         double sq = v * v;
         // C layout: reg r of lane l = C[row (l >> 4) + 4 r][col l & 15]: sum the 16 lanes of a lane group
         sq += __shfl_xor(sq, 1, 64);

@@ -56,7 +56,7 @@ void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, in
 int dl_chi2_gemm_row_tile(int64_t M, int N_pad);   // 32 or 16: rows per workgroup the chi2 GEMM will use for a batch of M points (the theory kernel deals the points to the XCDs accordingly)
 void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, int32_t* counters,
                          const double* theta, int n_params, const double* priors, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream,
-                         const uint8_t* panel_ranges = nullptr, int k_live = 0);   // panel_ranges [N_pad / 16][2]: 128-wide K panels [lo, hi) with non-zero Wt entries per column block (host array), or null
+                         const uint8_t* panel_ranges = nullptr, int k_live = 0, double* resid = nullptr, int64_t ldr = 0);   // resid [M, ldr]: the residual rows themselves, also written (may be null); panel_ranges [N_pad / 16][2]: 128-wide K panels [lo, hi) with non-zero Wt entries per column block (host array), or null
 void dl_launch_finalize_part(const double* part, int n_tiles, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
                              int32_t* status, int post_mode, hipStream_t stream);
 #ifndef DL_FG_NM
@@ -94,5 +94,10 @@ struct DlEnsFold;
 int dl_internal_fold_info(dl_ctx* ctx, int64_t B, int* n_tiles, const double** priors);
 int dl_internal_eval_fold(dl_ctx* ctx, const DlEnsFold& fold, int64_t B, double* part_out, hipStream_t stream);
 bool dl_launch_fullshape_ens(const DlObsDev* obs_host, int n_obs, const DlObsDev* obs_dev, const DlEnsFold& f, int64_t B, double* power, int64_t ld_power, int xcd_block, hipStream_t stream);
+// analytic gradient (dl_fullshape_grad.h): per (point, observable) sums over the physical inputs -> gphys [B, n_obs, 8], then chain rule + prior gradient -> grad [B, P];
+// Y [B, ldy] = -d~ W~ (the columns of every observable at its col_offset)
+bool dl_grad_applicable(const DlObsDev* obs_host, int n_obs);
+void dl_launch_fullshape_grad(const DlObsDev* obs_host, int n_obs, const DlObsDev* obs_dev, const double* theta, int n_params, int64_t B, const double* Y, int64_t ldy, double* gphys,
+                              const double* priors, const int32_t* status, double* grad, hipStream_t stream);
 // last-error string of the C ABI (thread-local, read by dl_last_error(NULL)); set by translation units other than dl_api.hip
 void dl_set_last_error(const char* msg);

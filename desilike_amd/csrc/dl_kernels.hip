@@ -19,6 +19,7 @@
 #include "dl_finalize_part.h"
 #include "dl_scalar_prefetch.h"
 #include "dl_ens_fold.h"
+#include "dl_fullshape_grad.h"
 
 thread_local DlProfEvents dl_prof_events;
 
@@ -285,6 +286,115 @@ bool dl_launch_fullshape_ens(const DlObsDev* obs_host, int n_obs, const DlObsDev
     if (nl3) { if (B * n_obs > dense_min) launch(dl_fullshape_ens_kernel<3, true>); else launch(dl_fullshape_ens_kernel<3>); }
     else { if (B * n_obs > dense_min) launch(dl_fullshape_ens_kernel<5, true>); else launch(dl_fullshape_ens_kernel<5>); }
     return true;
+}
+
+// ---- analytic gradient (dl_fullshape_grad.h): one workgroup per (point, observable) contracts d(theory vector) / d(physical inputs) with Y = -W~^T d~ ----------------
+// Phases (barriers between them): per-mu chain + gradient weights on wave 3 beside the template at the knots on waves 0-2; the template's dm-derivative data; the two
+// convolutions; the two sets of interval polynomials; the (k, mu) contraction; [the dn spline and its contraction]; the fixed-order reduction.  72 KB of LDS: two
+// workgroups per CU.
+template <int NL>
+__global__ __launch_bounds__(DL_FS_THREADS, 4) void dl_fullshape_grad_kernel(const DlObsDev* __restrict__ obs, const double* __restrict__ theta, int n_params,
+                                                                              const double* __restrict__ Y, int64_t ldy, double* __restrict__ gphys) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const DlObsDev& o = obs[blockIdx.y];
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = DL_FS_THREADS;
+    constexpr int KT = DL_FS_KT;
+    const double* th = theta + (size_t)b * n_params;
+    const bool toep = o.toeplitz && !o.fixed_spline;
+    const DlFsShared s = dl_fs_shared_carve(lds, o.n_t, o.n_in, dl_fs_n_dd0(o), toep);
+    double* gw = s.pt + DL_PT_SIZE_FAST;
+    double* red = gw + (size_t)DL_MAX_MU * DL_GW;
+    // the spline of whatever sits in s.y: convolution, barrier, interval polynomials (waves 0-2), barrier
+    auto build = [&]() {
+        if (tid < KT) dl_fs_phase2_fir(tid, KT, o, s);
+        __syncthreads();
+        if (tid < KT) {
+            double dlt_pref[DL_TOEP_PREF];
+#pragma unroll
+            for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (tid + it * KT < o.n_t - 1) ? o.dlt[tid + it * KT] : 0.;
+            dl_fs_phase2d_toep(tid, KT, o, s, dlt_pref);
+        }
+        __syncthreads();
+    };
+    // wave 3: the per-mu chain and the gradient weights, beside the template at the knots and its convolution on waves 0-2 (their results are first read in the
+    // contraction: the barrier after the convolution is the first one this wave's work must be finished by)
+    if (tid >= KT) {
+        const int m = tid - KT;
+        const bool mu_lane = m < o.n_mu;
+        DlMuCarry c;
+        dl_fs_mu_partA(o, th, mu_lane ? m : 0, c);
+        dl_fs_mu_partB(c);
+        if (mu_lane) { dl_fs_mu_partC(o, s, m, c, false); dl_fs_grad_weights(o, m, c, gw); }
+        if (tid == nthr - 1) { dl_fs_scalars(o, th, s, c, false); dl_fs_grad_weights_pad(o, gw); }
+    } else dl_fs_knots(tid, KT, o, th, s);
+    __syncthreads();
+    if (toep) build();
+    double acc[DL_NPHYS];
+#pragma unroll
+    for (int p = 0; p < DL_NPHYS; ++p) acc[p] = 0.;
+    const double* Yrow = Y + (size_t)b * ldy + o.col_offset;
+    dl_fs_grad_phase3<NL>(tid, nthr, o, s, gw, Yrow, 0, acc);
+    if (toep && o.templ == 1) {
+        for (int which = 0; which < 2; ++which) {
+            if (which == 0 ? o.dm.col < 0 : o.dn.col < 0) continue;
+            __syncthreads();                          // (everyone is done with the previous spline)
+            if (tid < KT) dl_fs_grad_knots(tid, KT, o, th, s, which);
+            __syncthreads();
+            build();
+            dl_fs_grad_phase3<NL>(tid, nthr, o, s, gw, Yrow, 1 + which, acc);
+        }
+    }
+    // reduction in a fixed order: butterfly inside each wavefront (shuffles: registers), then the four wavefronts' sums through LDS.  (Eight threads walking 256 LDS
+    // values each, one dependent read-and-add after the other -- the host emulation's dl_fs_grad_reduce -- took 10 us.)
+#pragma unroll
+    for (int p = 0; p < DL_NPHYS; ++p) {
+        double v = acc[p];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((tid & 63) == 0) red[(tid >> 6) * DL_NPHYS + p] = v;
+    }
+    __syncthreads();
+    if (tid < DL_NPHYS) {
+        double v = 0.;
+#pragma unroll
+        for (int w = 0; w < DL_FS_THREADS / 64; ++w) v += red[w * DL_NPHYS + tid];
+        gphys[((size_t)b * gridDim.y + blockIdx.y) * DL_NPHYS + tid] = v;
+    }
+}
+
+// chain rule to the theta columns + gradient of the log-prior (uniform: 0, norm: -(x - loc) / scale^2); rows whose log-posterior is -inf get a zero gradient
+__global__ __launch_bounds__(64) void dl_grad_finalize_kernel(const DlObsDev* __restrict__ obs, int n_obs, const double* __restrict__ theta, int n_params, const double* __restrict__ priors,
+                                                               const double* __restrict__ gphys, const int32_t* __restrict__ status, int64_t B, double* __restrict__ grad) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* th = theta + (size_t)b * n_params;
+    double* g = grad + (size_t)b * n_params;
+    const bool ok = status == nullptr || status[b] == 0;
+    for (int p = 0; p < n_params; ++p) {
+        const double* pr = priors + 5 * p;
+        g[p] = (ok && pr[0] == 1.) ? -(th[p] - pr[3]) / (pr[4] * pr[4]) : 0.;          // parameter.py:2007 differentiated
+    }
+    if (!ok) return;
+    for (int i = 0; i < n_obs; ++i) dl_fs_grad_chain(obs[i], th, gphys + ((size_t)b * n_obs + i) * DL_NPHYS, g);
+}
+
+bool dl_grad_applicable(const DlObsDev* obs_host, int n_obs) {
+    if (n_obs < 1) return false;
+    for (int i = 0; i < n_obs; ++i) if (!dl_fs_grad_applicable(obs_host[i])) return false;
+    return true;
+}
+
+void dl_launch_fullshape_grad(const DlObsDev* obs_host, int n_obs, const DlObsDev* obs_dev, const double* theta, int n_params, int64_t B, const double* Y, int64_t ldy, double* gphys,
+                              const double* priors, const int32_t* status, double* grad, hipStream_t stream) {
+    size_t shm = 0;
+    bool nl3 = true;
+    for (int i = 0; i < n_obs; ++i) { shm = std::max(shm, dl_fs_grad_shared_doubles(obs_host[i]) * sizeof(double)); nl3 = nl3 && obs_host[i].n_ell <= 3; }
+    auto launch = [&](auto kernel) {
+        if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        DL_LAUNCH(kernel, dim3((unsigned)B, (unsigned)n_obs), dim3(DL_FS_THREADS), shm, stream, obs_dev, theta, n_params, Y, ldy, gphys);
+    };
+    if (nl3) launch(dl_fullshape_grad_kernel<3>); else launch(dl_fullshape_grad_kernel<5>);
+    hipLaunchKernelGGL(dl_grad_finalize_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, obs_dev, n_obs, theta, n_params, priors, gphys, status, B, grad);
 }
 
 // BAO wiggle model: one workgroup per point; constant splines read from global memory, no per-point spline build.  One kernel per wiggle model: registers are
@@ -725,7 +835,7 @@ int dl_chi2_gemm_row_tile(int64_t M, int N_pad) {
 
 void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, int32_t* counters,
                          const double* theta, int n_params, const double* priors, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream,
-                         const uint8_t* panel_ranges, int k_live) {
+                         const uint8_t* panel_ranges, int k_live, double* resid, int64_t ldr) {
     const int n_tiles = N_pad / DL_CG_N;
     const int mt = counters == nullptr ? dl_chi2_gemm_row_tile(M, N_pad) : DL_CG_M;   // (the experimental fused finalize counts 32-row blocks)
     const int64_t mblocks = (M + mt - 1) / mt;
@@ -734,6 +844,8 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
     if (!optin) {
         (void)hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<true, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<true, true, DL_CG_M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)dl_chi2_gemm_kernel<true, true, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DL_CG_LDS_BYTES);
         optin = true;
     }
     DlChi2Fin fin;
@@ -749,8 +861,12 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
     std::memset(&panels, 0, sizeof(panels));
     if (panel_ranges != nullptr && n_tiles <= DL_CG_MAX_TILES)
         for (int t = 0; t < n_tiles; ++t) panels.range[t] = (uint32_t)panel_ranges[2 * t] | ((uint32_t)panel_ranges[2 * t + 1] << 8);
-    if (mt == 16) DL_LAUNCH((dl_chi2_gemm_kernel<true, true, 16>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_NBUF * (16 + DL_CG_N) * DL_CG_LD * 8, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad);
-    else DL_LAUNCH((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad);
+    double* const no_resid = nullptr;
+    if (resid != nullptr) {
+        if (mt == 16) DL_LAUNCH((dl_chi2_gemm_kernel<true, true, 16, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_NBUF * (16 + DL_CG_N) * DL_CG_LD * 8, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad, resid, ldr);
+        else DL_LAUNCH((dl_chi2_gemm_kernel<true, true, DL_CG_M, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad, resid, ldr);
+    } else if (mt == 16) DL_LAUNCH((dl_chi2_gemm_kernel<true, true, 16>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_NBUF * (16 + DL_CG_N) * DL_CG_LD * 8, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad, no_resid, (int64_t)0);
+    else DL_LAUNCH((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad, no_resid, (int64_t)0);
     if (fin.stamps) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h((size_t)grid * 8);

@@ -148,6 +148,13 @@ int  dl_eval_logposterior(dl_ctx* ctx, const double* theta_dev, int64_t B, doubl
  * D = flattheory - flatdata.  Outputs (any may be NULL): hessian_dev [B, P, P], gradient_dev [B, P], offset_dev [B].  The context must have no analytically
  * solved parameter (vary them: the reference's Fisher does the same, fisher.py:688-695); P <= 31.  Asynchronous on ``hip_stream``. */
 int  dl_eval_fisher(dl_ctx* ctx, const double* centers_dev, const double* steps_dev, int64_t B, double* hessian_dev, double* gradient_dev, double* offset_dev, void* hip_stream);
+/* log-posterior [B] and its ANALYTIC gradient [B, P] (what the reference's gradient-based samplers take from jax.value_and_grad: desilike/samplers/hmc.py:194,
+ * samplers/nuts.py:205): d logL / d theta = Y . d(theory vector) / d theta with Y = -W~^T d~, the derivative contracted on the fly by the theory's gradient kernel
+ * (qpar / qper through every AP mode, df, dm, dn, b1 of either tracer, sn0; the spline of the template is linear in its data, so d / d dm is the spline of
+ * d template / d dm), + the gradient of uniform / Gaussian priors.  Rows whose log-posterior is -inf get a zero gradient.  status_dev may be NULL.
+ * Returns 0; 1 on error; 2 -- nothing launched -- when the context is outside the scope (Kaiser tracers without counter terms on uniform template knots, no damping,
+ * no observable transform, no solved parameters, uniform / norm priors): differentiate numerically then (dl_eval_logposterior on a stencil). */
+int  dl_eval_logposterior_grad(dl_ctx* ctx, const double* theta_dev, int64_t B, double* logposterior_dev, double* grad_dev, int32_t* status_dev, void* hip_stream);
 
 /* Theory state of observable ``iobs`` for parity / plots / emulation:
  * power_dev [B, n_ell, n_kin] and (optional) tables_dev [B, 3, n_ell, n_kin] = pk_dd, pk_dt, pk_tt. */

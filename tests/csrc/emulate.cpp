@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../desilike_amd/csrc/dl_host.hpp"
+#include "../../desilike_amd/csrc/dl_fullshape_grad.h"
 
 static std::string g_err;
 
@@ -97,6 +98,56 @@ static void run_point(const DlObsDev& o, const double* th, double* prow, double*
     for (int tid = 0; tid < nthr; ++tid) dl_fs_phase4(tid, nthr, o, s, th, prow, o.n_in);
 }
 
+// gradient workgroup (dl_fullshape_grad_kernel, dl_kernels.hip) of one (point, observable): Y = this observable's columns of -W~^T d~; gphys [DL_NPHYS]
+static bool run_point_grad(const DlObsDev& o, const double* th, const double* Y, double* gphys) {
+    if (!dl_fs_grad_applicable(o)) return false;
+    std::vector<double> lds(dl_fs_grad_shared_doubles(o, true) + 64, 0.);
+    const bool toep = o.toeplitz && !o.fixed_spline;
+    DlFsShared s = dl_fs_shared_carve(lds.data(), o.n_t, o.n_in, dl_fs_n_dd0(o), toep);
+    double* gw = s.pt + DL_PT_SIZE_FAST;
+    double* red = gw + (size_t)DL_MAX_MU * DL_GW;
+    double* out = red + (size_t)DL_FS_THREADS * DL_NPHYS;
+    const int nthr = DL_FS_THREADS, KT = DL_FS_KT;
+    std::vector<DlMuCarry> carry(nthr);
+    auto mu_lane = [&](int tid) { return tid >= KT && tid - KT < o.n_mu; };
+    for (int tid = 0; tid < nthr; ++tid) {
+        if (tid >= KT) {
+            dl_fs_mu_partA(o, th, mu_lane(tid) ? tid - KT : 0, carry[tid]);
+            dl_fs_mu_partB(carry[tid]);
+            if (mu_lane(tid)) { dl_fs_mu_partC(o, s, tid - KT, carry[tid], false); dl_fs_grad_weights(o, tid - KT, carry[tid], gw); }
+            if (tid == nthr - 1) { dl_fs_scalars(o, th, s, carry[tid], false); dl_fs_grad_weights_pad(o, gw); }
+        } else dl_fs_knots(tid, KT, o, th, s);
+    }
+    auto build = [&]() {
+        for (int tid = 0; tid < KT; ++tid) dl_fs_phase2_fir(tid, KT, o, s);
+        for (int tid = 0; tid < KT; ++tid) {
+            double dlt_pref[DL_TOEP_PREF];
+            for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (tid + it * KT < o.n_t - 1) ? o.dlt[tid + it * KT] : 0.;
+            dl_fs_phase2d_toep(tid, KT, o, s, dlt_pref);
+        }
+    };
+    auto contract = [&](int pass) {
+        for (int tid = 0; tid < nthr; ++tid) {
+            if (o.n_ell <= 3) dl_fs_grad_phase3<3>(tid, nthr, o, s, gw, Y, pass, red + (size_t)tid * DL_NPHYS);
+            else dl_fs_grad_phase3<5>(tid, nthr, o, s, gw, Y, pass, red + (size_t)tid * DL_NPHYS);
+        }
+    };
+    if (toep) build();
+    std::fill(red, red + (size_t)nthr * DL_NPHYS, 0.);
+    contract(0);
+    if (toep && o.templ == 1) {
+        for (int which = 0; which < 2; ++which) {
+            if (which == 0 ? o.dm.col < 0 : o.dn.col < 0) continue;
+            for (int tid = 0; tid < KT; ++tid) dl_fs_grad_knots(tid, KT, o, th, s, which);
+            build();
+            contract(1 + which);
+        }
+    }
+    for (int tid = 0; tid < nthr; ++tid) dl_fs_grad_reduce(tid, nthr, red, out);
+    std::copy(out, out + DL_NPHYS, gphys);
+    return true;
+}
+
 // power [B, n_in], tables [B, 3, n_in] (may be null)
 int emu_eval_theory(const dl_config* cfg, const double* theta, int64_t B, int iobs, double* power, double* tables) {
     int P = cfg->i("n_params", -1);
@@ -151,6 +202,53 @@ int emu_eval_batch(const dl_config* cfg, const double* theta, int64_t B, double*
             chi2 += d * d;
         }
         loglike[b] = -0.5 * chi2;
+    }
+    return 0;
+}
+
+// analytic gradient of the log-likelihood with the device's gradient phase functions (dl_fullshape_grad.h): loglike [B], grad [B, P]; returns 2 if not applicable
+int emu_eval_grad(const dl_config* cfg, const double* theta, int64_t B, double* loglike, double* grad) {
+    int P = cfg->i("n_params", -1), nobs = cfg->i("n_obs", -1);
+    DlArena arena;
+    std::vector<DlObsHost> obs(nobs);
+    int n = 0, K = 0;
+    std::vector<int> row0, col0;
+    for (int i = 0; i < nobs; ++i) {
+        if (!dl_build_obs(*cfg, i, P, obs[i], arena, g_err)) return 1;
+        row0.push_back(n); col0.push_back(K);
+        n += obs[i].n_out; K += obs[i].n_cols();
+    }
+    for (int i = 0; i < nobs; ++i) { obs[i].rebase(arena.data.data()); obs[i].dev.col_offset = col0[i]; }
+    const auto& prec = cfg->F("precision");
+    std::vector<double> L((size_t)n * n, 0.);
+    if ((int64_t)prec.size() == (int64_t)n * n) { L = prec; if (!dl_cholesky(L, n)) { g_err = "not positive definite"; return 1; } }
+    else for (int i = 0; i < n; ++i) L[(size_t)i * n + i] = std::sqrt(prec[i]);
+    std::vector<double> power(K), flat(n), d(n), v(n), Y(K);
+    for (int64_t b = 0; b < B; ++b) {
+        for (int i = 0; i < nobs; ++i) run_point(obs[i].dev, theta + b * P, power.data() + col0[i], nullptr);
+        for (int i = 0; i < nobs; ++i)
+            for (int r = 0; r < obs[i].n_out; ++r) {
+                double sum = 0.;
+                for (int k = 0; k < obs[i].n_cols(); ++k) sum += obs[i].weff[(size_t)r * obs[i].n_cols() + k] * power[col0[i] + k];
+                flat[row0[i] + r] = sum + obs[i].bias[r] - obs[i].flatdata[r];
+            }
+        double chi2 = 0.;
+        for (int i = 0; i < n; ++i) { double t = 0.; for (int j = i; j < n; ++j) t += L[(size_t)j * n + i] * flat[j]; d[i] = t; chi2 += t * t; }     // d~ = L^T (flat - data)
+        loglike[b] = -0.5 * chi2;
+        for (int j = 0; j < n; ++j) { double t = 0.; for (int i = 0; i <= j; ++i) t += L[(size_t)j * n + i] * d[i]; v[j] = t; }                        // L d~ = precision (flat - data)
+        for (int i = 0; i < nobs; ++i)
+            for (int k = 0; k < obs[i].n_cols(); ++k) {
+                double t = 0.;
+                for (int r = 0; r < obs[i].n_out; ++r) t += obs[i].weff[(size_t)r * obs[i].n_cols() + k] * v[row0[i] + r];
+                Y[col0[i] + k] = -t;
+            }
+        double* g = grad + b * P;
+        std::fill(g, g + P, 0.);
+        for (int i = 0; i < nobs; ++i) {
+            double gphys[DL_NPHYS];
+            if (!run_point_grad(obs[i].dev, theta + b * P, Y.data() + col0[i], gphys)) return 2;
+            dl_fs_grad_chain(obs[i].dev, theta + b * P, gphys, g);
+        }
     }
     return 0;
 }

@@ -18,7 +18,7 @@ def build_emulation(sanitize=False):
     os.makedirs(build, exist_ok=True)
     so = os.path.join(build, 'libdl_emulate_asan.so' if sanitize else 'libdl_emulate.so')
     src = os.path.join(HERE, 'csrc', 'emulate.cpp')
-    deps = [src] + [os.path.join(HERE, '..', 'desilike_amd', 'csrc', name) for name in ['dl_fullshape.h', 'dl_host.hpp']]
+    deps = [src] + [os.path.join(HERE, '..', 'desilike_amd', 'csrc', name) for name in ['dl_fullshape.h', 'dl_fullshape_grad.h', 'dl_host.hpp']]
     if not os.path.isfile(so) or any(os.path.getmtime(dep) > os.path.getmtime(so) for dep in deps):
         subprocess.check_call(['g++', '-O1' if sanitize else '-O2', '-std=c++17', '-fPIC', '-shared'] + (SANITIZE_FLAGS if sanitize else []) + ['-o', so, src])
     return so
@@ -37,6 +37,7 @@ def load_emulation():
         lib.emu_last_error.restype = ctypes.c_char_p
         lib.emu_eval_theory.argtypes = [ctypes.c_void_p, dp, ctypes.c_int64, ctypes.c_int, dp, dp]
         lib.emu_eval_batch.argtypes = [ctypes.c_void_p, dp, ctypes.c_int64, dp, dp]
+        lib.emu_eval_grad.argtypes = [ctypes.c_void_p, dp, ctypes.c_int64, dp, dp]
         _emu = lib
     return _emu
 
@@ -70,6 +71,16 @@ class Emulation(object):
         if self.lib.emu_eval_batch(self.cfg, theta.ctypes.data_as(dp), len(theta), loglike.ctypes.data_as(dp), flat.ctypes.data_as(dp)):
             raise RuntimeError(self.lib.emu_last_error().decode())
         return loglike, flat
+
+    def eval_grad(self, theta):
+        """(loglike [B], gradient [B, P]) by the device's analytic gradient phases (csrc/dl_fullshape_grad.h); None if the configuration is out of their scope."""
+        theta = np.ascontiguousarray(theta, dtype='f8')
+        loglike, grad = np.empty(len(theta)), np.empty(theta.shape)
+        dp = ctypes.POINTER(ctypes.c_double)
+        rc = self.lib.emu_eval_grad(self.cfg, theta.ctypes.data_as(dp), len(theta), loglike.ctypes.data_as(dp), grad.ctypes.data_as(dp))
+        if rc == 2: return None
+        if rc: raise RuntimeError(self.lib.emu_last_error().decode())
+        return loglike, grad
 
     def __del__(self):
         self.lib.emu_config_free(self.cfg)

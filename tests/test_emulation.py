@@ -81,3 +81,47 @@ def test_emulation_under_sanitizers():
     err = out.stderr.decode()
     assert out.returncode == 0 and 'sanitized emulation ok' in out.stdout.decode(), err[-3000:]
     assert 'AddressSanitizer' not in err and 'runtime error' not in err, err[-3000:]
+
+
+@pytest.mark.parametrize('name', ['cfg1_kaiser_nowindow', 'cfg2_shapefit_window_dense', 'cfg5_two_tracers'])
+def test_emulated_analytic_gradient(name):
+    """The device's gradient phase functions (csrc/dl_fullshape_grad.h: contraction of d(theory) / d(qpar, qper, f, b1, sn0, dm) with Y = -W~^T d~, chain rule to the
+    sampled parameters) run on the CPU, against the five-point stencil of the emulated log-likelihood (itself pinned on the reference above)."""
+    g = load_golden(name)
+    emu = Emulation(spec_from_golden(g))
+    theta = g['theta'][:3].copy()
+    logl, grad = emu.eval_grad(theta)
+    assert np.allclose(logl, emu.eval_batch(theta)[0], rtol=1e-13, atol=1e-12)
+    fd = np.zeros_like(grad)
+    for p in range(theta.shape[1]):
+        h = 1e-3
+
+        def f(x):
+            th = theta.copy(); th[:, p] += x
+            return emu.eval_batch(th)[0]
+
+        fd[:, p] = (-f(2 * h) + 8 * f(h) - 8 * f(-h) + f(-2 * h)) / (12 * h)
+    assert (np.abs(grad - fd).max(axis=0) <= 1e-8 * np.abs(fd).max(axis=0)).all(), np.abs(grad - fd).max(axis=0) / np.abs(fd).max(axis=0)
+
+
+def test_emulated_analytic_gradient_with_dn():
+    """dn sampled as well (a third spline pass: the template's dn-derivative), on the config-2 fixture with one more theta column."""
+    g = load_golden('cfg2_shapefit_window')
+    spec = spec_from_golden(g)
+    P = int(spec['n_params'][0])
+    spec['n_params'] = np.array([P + 1])
+    spec['priors'] = np.vstack([spec['priors'], [0., -0.5, 0.5, 0., 1.]])
+    spec['observables'][0]['inputs']['dn'] = (P, 0.)
+    emu = Emulation(spec)
+    theta = np.column_stack([g['theta'][:3], [0.02, -0.03, 0.01]])
+    logl, grad = emu.eval_grad(theta)
+    fd = np.zeros_like(grad)
+    for p in range(P + 1):
+        h = 1e-3
+
+        def f(x):
+            th = theta.copy(); th[:, p] += x
+            return emu.eval_batch(th)[0]
+
+        fd[:, p] = (-f(2 * h) + 8 * f(h) - 8 * f(-h) + f(-2 * h)) / (12 * h)
+    assert (np.abs(grad - fd).max(axis=0) <= 1e-8 * np.abs(fd).max(axis=0)).all(), np.abs(grad - fd).max(axis=0) / np.abs(fd).max(axis=0)

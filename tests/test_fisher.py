@@ -129,7 +129,7 @@ def test_logposterior_value_and_grad():
     names = like.varied_params.names()
     rnames = [str(n) for n in g['names']]
     theta = g['theta'][:6][:, [rnames.index(n) for n in names]]
-    value, grad = logposterior_value_and_grad(like, theta)
+    value, grad = logposterior_value_and_grad(like, theta, method='finite')
     c = observable_constants(g)
     priors = [dict(dist=param.prior.dist, limits=param.prior.limits, loc=getattr(param.prior, 'loc', 0.) if param.prior.dist == 'norm' else 0.,
                    scale=getattr(param.prior, 'scale', 1.) if param.prior.dist == 'norm' else 1.) for param in like.varied_params]
@@ -155,3 +155,59 @@ def test_logposterior_value_and_grad():
     prior = like.varied_params['sn0'].prior
     analytic = -T.dot(like.precision).dot(f0 - c['flatdata']) - (theta[0, isn] - prior.loc) / prior.scale**2
     assert abs(grad[0, isn] - analytic) <= 1e-7 * max(1., abs(analytic))
+
+
+@pytest.mark.gpu
+def test_analytic_gradient_vs_oracle_and_finite_differences():
+    """dl_eval_logposterior_grad (the value_and_grad of the gradient-based samplers): against the five-point stencil of the NumPy ORACLE's
+    log-posterior (1e-8 of the largest component), against the library's own central differences, and for two tracers sharing template parameters."""
+    import torch
+    from desilike_amd.fisher import logposterior_value_and_grad
+    from golden_utils import load_golden, observable_constants, prior_list
+    from oracle import np_oracle as orc
+    from test_host_api import make_cfg2, make_cfg5
+    g, like = make_cfg2()
+    names = like.varied_params.names()
+    theta = g['theta'][:6, [[str(n) for n in g['names']].index(name) for name in names]]
+    value, grad = logposterior_value_and_grad(like, theta, method='analytic')
+    c, priors = observable_constants(g), prior_list(g)
+
+    def oracle(th):
+        out = []
+        for row in th:
+            p = dict(zip(names, row)); p['b1'] = (p['b1'], p['b1'])
+            out.append(orc.gaussian_loglikelihood(orc.fullshape_observable(c, p)['flattheory'], c['flatdata'], like.precision)[0])
+        return np.array(out) + orc.logprior(th, [priors[[str(n) for n in g['names']].index(name)] for name in names])
+
+    assert (np.abs(value - oracle(theta)) <= 1e-10 * np.maximum(1., np.abs(value))).all()
+    fd = np.zeros_like(grad)
+    for p in range(theta.shape[1]):
+        h = 1e-3
+
+        def f(x):
+            th = theta.copy(); th[:, p] += x
+            return oracle(th)
+
+        fd[:, p] = (-f(2 * h) + 8 * f(h) - 8 * f(-h) + f(-2 * h)) / (12 * h)
+    assert (np.abs(grad - fd).max(axis=0) <= 1e-8 * np.abs(fd).max(axis=0)).all(), np.abs(grad - fd).max(axis=0) / np.abs(fd).max(axis=0)
+    value_fd, grad_fd = logposterior_value_and_grad(like, theta, method='finite')
+    assert np.array_equal(np.isfinite(value), np.isfinite(value_fd)) and np.allclose(value, value_fd, rtol=1e-12, atol=1e-9)
+    assert np.allclose(grad, grad_fd, rtol=1e-3, atol=1e-5 * np.abs(grad).max())        # (central differences with the parameters' own, large, steps: O(h^2) off)
+    # rows outside the prior: -inf and a zero gradient; NaN inputs likewise
+    bad = theta[:2].copy(); bad[0, 0] = 5.; bad[1, 1] = np.nan
+    value, grad = logposterior_value_and_grad(like, bad, method='analytic')
+    assert np.isneginf(value).all() and (grad == 0.).all()
+    # two tracers (shared qpar, qper, dm, df; namespaced b1, sn0): the columns shared by both observables receive both contributions
+    g5, like5 = make_cfg5()
+    names5 = like5.varied_params.names()
+    theta5 = g5['theta'][:4, [[str(n) for n in g5['names']].index(name) for name in names5]]
+    value5, grad5 = logposterior_value_and_grad(like5, theta5, method='analytic')
+    _, grad5_fd = logposterior_value_and_grad(like5, theta5, method='finite')
+    assert np.allclose(grad5, grad5_fd, rtol=1e-3, atol=1e-5 * np.abs(grad5).max())
+    ref = g5['loglikelihood'][:4] + g5['logprior'][:4]
+    assert (np.abs(value5 - ref) <= 1e-10 * np.maximum(1., np.abs(ref))).all()
+    # out of scope -> the caller is told (and 'auto' falls back to central differences)
+    from test_host_api import make_cfg4
+    g4, like4 = make_cfg4('pk')
+    with pytest.raises(NotImplementedError):
+        logposterior_value_and_grad(like4, g4['theta'][:2, [[str(n) for n in g4['names']].index(name) for name in like4.varied_params.names()]], method='analytic')
