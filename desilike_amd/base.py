@@ -57,6 +57,46 @@ class InitConfig(dict):
         return self[key]
 
 
+class Monitor(object):
+    """Accumulated execution time and number of data points (the subset of desilike/utils.py:734-800 the pipeline uses: ``start`` / ``stop`` / ``add`` / ``reset`` /
+    ``counter`` / ``get('time', average=...)``).  Here the data points are kernel intervals read off the device (dispatch-attached events), not host clocks."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self._counter, self._time, self._start = 0, 0., None
+
+    def start(self):
+        import time
+        self._start = time.time()
+
+    def stop(self):
+        import time
+        self.add(time.time() - self._start)
+
+    def add(self, seconds, count=1):
+        self._counter += int(count)
+        self._time += float(seconds)
+
+    @property
+    def counter(self):
+        return self._counter
+
+    def get(self, quantity='time', average=True):
+        if quantity != 'time': raise ValueError('only time is monitored')
+        if average: return self._time / self._counter if self._counter else 0.
+        return self._time
+
+
+class RuntimeInfo(object):
+    """What the reference keeps per calculator in ``calculator.runtime_info`` for scheduling decisions (base.py:1070-1075, 695-735): ``monitor`` (time spent in the
+    calculator's part of the evaluations) and ``speed`` (evaluations per second of that part; ``None`` until :meth:`BaseLikelihood._set_speed` measured it)."""
+
+    def __init__(self, calculator):
+        self.calculator, self.monitor, self.speed = calculator, Monitor(), None
+
+
 class BaseCalculator(object):
     """Base calculator: ``init`` (arguments + params), ``params``, lazy ``initialize`` (base.py:1119-1323)."""
 
@@ -67,6 +107,7 @@ class BaseCalculator(object):
             raise TypeError('{} takes keyword arguments only'.format(self.__class__.__name__))
         self._dependents = []
         self._initialized = False
+        self.runtime_info = RuntimeInfo(self)
         self.init = InitConfig(self, kwargs, ParameterCollection(self._default_params(**kwargs)))
 
     @classmethod

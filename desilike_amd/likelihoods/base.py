@@ -57,6 +57,42 @@ class BaseLikelihood(BaseCalculator):
         """Parameters marginalised ONCE into the precision matrix ('.prec'): likelihoods/base.py:262-267."""
         return ParameterCollection([param for param in self.all_params if param.solved and param.derived.startswith('.prec')])
 
+    def _set_speed(self, niterations=10, override=False, seed=42, batch=1024):
+        """Measure and set the calculators' speed (base.py:695-735: ``calculator.runtime_info.speed`` = evaluations per second of the calculator's own part, from
+        ``niterations`` evaluations at parameters drawn from their ``ref`` distributions).  Here an evaluation is a batch of ``batch`` points and the parts are the
+        device kernels, timed by the events attached to their dispatch packets (``dl_profile_*``): the theory kernel is booked on the theory calculators (template
+        included), the window / chi2 GEMM on the window calculators, the finalize (priors, status) on the likelihood.  Returns {calculator: speed}."""
+        import torch
+        self.initialize()
+        ctx = self._get_context()
+        rng = np.random.RandomState(seed)
+        device = torch.device('cuda', ctx.device)
+        groups = {'theory': [obs.wmatrix.theory for obs in self.observables], 'window_gemm': [obs.wmatrix for obs in self.observables], 'finalize': [self]}
+        for calculators in groups.values():
+            for calculator in calculators: calculator.runtime_info.monitor.reset()
+        out = torch.empty(batch, dtype=torch.float64, device=device)
+        for _ in range(int(niterations)):
+            theta = np.column_stack([param.ref.sample(size=batch, random_state=rng) if param.ref.is_proper() else np.full(batch, param.value) for param in self.varied_params])
+            th = torch.as_tensor(theta, dtype=torch.float64, device=device).contiguous()
+            ctx.eval_logposterior(th, out)             # (untimed: clocks, caches)
+            ctx.profile_enable(1)
+            ctx.eval_logposterior(th, out)
+            torch.cuda.synchronize(device)
+            ms = ctx.profile_read()
+            ctx.profile_enable(0)
+            for name, calculators in groups.items():
+                for calculator in calculators:
+                    calculator.runtime_info.monitor.add(1e-3 * ms[name] / len(calculators), count=batch)
+        speeds = {}
+        for calculators in groups.values():
+            for calculator in calculators:
+                monitor = calculator.runtime_info.monitor
+                if calculator.runtime_info.speed is None or override:
+                    total = monitor.get('time', average=False)
+                    calculator.runtime_info.speed = monitor.counter / total if total > 0. else 1e6       # (base.py:724-727)
+                speeds[calculator] = calculator.runtime_info.speed
+        return speeds
+
     # ---- evaluation -------------------------------------------------------------------------------
     def __call__(self, *args, return_derived=False, **kwargs):
         """``likelihood(**params)`` or ``likelihood(dict)`` -> loglikelihood + logprior (base.py:1194-1196, likelihoods/base.py:242-245)."""

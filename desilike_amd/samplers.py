@@ -342,8 +342,9 @@ class _ChainStore(object):
     def append(self, coords, logp):
         n = coords.shape[0]
         if self._coords is None:
-            cap = max(n, 1)
-            self._coords, self._logp = np.empty((cap,) + coords.shape[1:], dtype='f8'), np.empty((cap,) + logp.shape[1:], dtype='f8')
+            cap = 4 * max(n, 1)          # (room for the next batches; zero-filled: the pages are touched now, not inside a later, possibly timed, append)
+            self._coords, self._logp = np.zeros((cap,) + coords.shape[1:], dtype='f8'), np.zeros((cap,) + logp.shape[1:], dtype='f8')
+            self._coords.fill(0.); self._logp.fill(0.)
         elif self.size + n > self._coords.shape[0]:
             cap = max(2 * self._coords.shape[0], self.size + n)
             for name in ['_coords', '_logp']:

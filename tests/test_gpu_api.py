@@ -70,3 +70,19 @@ def test_fixed_parameter_override():
     damped = like(b1=1.8, sigmapar=4., sigmaper=3.)   # fixed parameters can still be passed explicitly, like in the reference
     assert damped != base and np.isfinite(damped)
     assert like(b1=1.8) == base
+
+
+def test_set_speed_reports_per_calculator_speeds():
+    """base.py:695-735: ``runtime_info.speed`` of the calculators (evaluations per second of their own part), measured from the device kernels' own intervals."""
+    from test_host_api import make_cfg2
+    g, like = make_cfg2(dense=True)
+    speeds = like._set_speed(niterations=3, batch=256)
+    theory, window = like.observables[0].wmatrix.theory, like.observables[0].wmatrix
+    assert set(speeds) == {theory, window, like}
+    for calculator in (theory, window, like):
+        info = calculator.runtime_info
+        assert info.monitor.counter == 3 * 256 and info.speed == speeds[calculator] and 1e5 < info.speed < 1e10
+    total = 1. / sum(1. / speed for speed in speeds.values())
+    assert total > 1e5                                   # (the north star's figure, on 256-point batches)
+    before = dict(speeds)
+    assert like._set_speed(niterations=1, batch=256) == before        # speeds already set are left untouched (override=False)

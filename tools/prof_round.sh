@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 timeout 300 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_steps20.json 2>> $OUT/${TAG}_bench.err     # the driver's command
-B="$R/bench.py --no-cpu-baseline --config5-iterations 0"
+B="$R/bench.py --no-cpu-baseline --config5-iterations 0 --no-other-configs --no-streams --chains-iterations 0 --sustained-seconds 0"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python3 $B --steps 200 --warmup 20 > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $TAG -- python3 $B --no-events --steps 20 --warmup 5 --prewarm-ms 20 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $TAG -- python3 $B --no-events --steps 20 --warmup 5 --prewarm-ms 20 > /dev/null 2>&1
@@ -22,11 +22,22 @@ timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ens -o $TAG -- python3 $R/tools/time_sampler.py > $OUT/${TAG}_time_sampler.txt 2>/dev/null
 # single-rank RCCL smoke run: the N > 1 code path (bucketed all-gathers on the side stream, in-place all-gather inside the ensemble's half-steps) with real RCCL calls on this 1-GPU box
 DL_BENCH_FORCE_DIST=1 DL_ENS_FORCE_COMM=1 timeout 600 python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_single_rank_rccl.json 2>/dev/null
-# the other BASELINE configurations (parity-test workloads, timed for DESIGN.md): configs[2] at SURVEY 8d's size, configs[3]
+# the other BASELINE configurations: configs[2] at SURVEY 8d's size, configs[3] -- timings and the kernel traces that the bench line's `other_configs` fractions are checked against
 timeout 900 python3 $R/tools/time_configs.py > $OUT/${TAG}_time_configs.txt 2>/dev/null
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg -o $TAG -- python3 $R/tools/time_configs.py > /dev/null 2>&1
+python3 $R/tools/kernel_stats.py $OUT/trace_cfg > $OUT/${TAG}_cfg3_cfg4_kernel_stats.txt 2>&1
+# analytic gradient: cost against one evaluation and against the finite-difference stencil; kernels of the gradient path
+timeout 600 python3 $R/tools/time_grad.py > $OUT/${TAG}_time_grad.txt 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_grad -o $TAG -- python3 $R/tools/time_grad.py > /dev/null 2>&1
+python3 $R/tools/kernel_stats.py $OUT/trace_grad >> $OUT/${TAG}_time_grad.txt 2>&1
+# K chains (device-resident ensembles) on K streams of this GPU: wall time per update, and how the kernels of one chain look in the trace
+for K in 1 2 4; do timeout 300 python3 $R/tools/chains_probe.py $K 2>/dev/null | tail -1; done > $OUT/${TAG}_streams_chains.txt
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_chain -o $TAG -- python3 $R/tools/chains_probe.py 1 200 > /dev/null 2>&1
+python3 $R/tools/kernel_stats.py $OUT/trace_chain >> $OUT/${TAG}_streams_chains.txt 2>&1
+DL_ENS_FOLD_STAMPS=1 timeout 300 python3 $R/tools/chains_probe.py 1 100 2>&1 | grep dl_ensemble_run | tail -1 >> $OUT/${TAG}_streams_chains.txt
 cd $R
 cp $OUT/trace/*kernel_stats.csv $OUT/${TAG}_kernel_stats.csv 2>/dev/null
 cp $OUT/trace_ens/*kernel_stats.csv $OUT/${TAG}_ensemble_kernel_stats.csv 2>/dev/null
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/${TAG}_pmc_hbm_traffic.txt 2>&1
 python3 tools/sq_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3 --stats $OUT/${TAG}_kernel_stats.csv > $OUT/${TAG}_pmc_sq_counters.txt 2>&1
-rm -rf "$OUT/trace" "$OUT/trace_ens" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq1" "$OUT/pmc_sq2" "$OUT/pmc_sq3"
+rm -rf "$OUT/trace_cfg" "$OUT/trace_grad" "$OUT/trace_chain" "$OUT/trace" "$OUT/trace_ens" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq1" "$OUT/pmc_sq2" "$OUT/pmc_sq3"
