@@ -130,6 +130,197 @@ def simple_tracer_power(k, mu, wmu_ell, k11, pk11, f, nd, b1X, b1Y, sn0, qpar=1.
 
 
 # ----------------------------------------------------------------------------------------------
+# f2: TNS one-loop tables (the reference's own in-repo PT producer)        full_shape.py:688-899
+# ----------------------------------------------------------------------------------------------
+def weights_trapz(x):
+    """Trapezoidal weights, utils.py:620-622 (``jnp.insert`` with jax's index clamping: the last index lands at the end)."""
+    x = np.asarray(x, dtype='f8')
+    return np.concatenate([[x[1] - x[0]], x[2:] - x[:-2], [x[-1] - x[-2]]]) / 2.
+
+
+def tns_k11(k):
+    """Wavenumbers of the loop tables, full_shape.py:875."""
+    return np.linspace(k[0] * 0.7, k[-1] * 1.3, int(len(k) * 1.6 + 0.5))
+
+
+def tns_kernels(k, q, wq):
+    """Angle-integrated 13-type kernels (density, velocity) and the A-term kernel, [n_k, n_q] / [5, n_k, n_q]; full_shape.py:688-746."""
+    jq = q**2 * wq / (4. * np.pi**2)
+    x = q / k[:, None]
+
+    def series13(x, poly, num, far, near):
+        # closed form, its large-x expansion (x > 10) and its expansion around x = 1 (|x - 1| < 0.01): full_shape.py:695-716
+        lg = 2. * np.log(np.abs((x - 1.) / (x + 1.)))
+        out = (6. / x**2 + poly[0] + poly[1] * x**2 + poly[2] * x**4 + 0.75 * (1. / x - x)**3 * (2. + poly[3] * x**2) * lg) / num
+        m = x > 10.
+        out[m] = far[0] + far[1] / x[m]**2 + far[2] / x[m]**4
+        dx = x - 1.
+        m = np.abs(dx) < 0.01
+        out[m] = near[0] + near[1] * dx[m] + near[2] * dx[m]**2
+        return out / x**2
+
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ff = series13(x, (-79., 50., -21., 7.), 504., (-61. / 630., 2. / 105., -10. / 1323.), (-11. / 126., 1. / 126., -29. / 252.))
+        gg = series13(x, (-41., 2., -3., 1.), 168., (-3. / 10., 26. / 245., -38. / 2205.), (-3. / 14., -5. / 42., -1. / 84.))
+        ka = np.zeros((5,) + x.shape, dtype='f8')    # full_shape.py:721-744
+        lx = np.zeros_like(x)
+        m = np.abs(x - 1.) > 1e-16
+        lx[m] = np.log(np.abs((x[m] + 1.) / (x[m] - 1.)))
+        ka[0] = -1. / 84. / x * (2 * x * (19 - 24 * x**2 + 9 * x**4) - 9 * (x**2 - 1)**3 * lx)
+        ka[1] = 1. / 112. / x**3 * (2 * x * (x**2 + 1) * (3 - 14 * x**2 + 3 * x**4) - 3 * (x**2 - 1)**4 * lx)
+        ka[2] = 1. / 336. / x**3 * (2 * x * (9 - 185 * x**2 + 159 * x**4 - 63 * x**6) + 9 * (x**2 - 1)**3 * (7 * x**2 + 1) * lx)
+        ka[4] = 1. / 336. / x**3 * (2 * x * (9 - 109 * x**2 + 63 * x**4 - 27 * x**6) + 9 * (x**2 - 1)**3 * (3 * x**2 + 1) * lx)
+    m = x < 1e-4
+    xm = x[m]
+    ka[0][m] = 8 * xm**8 / 735 + 24 * xm**6 / 245 - 24 * xm**4 / 35 + 8 * xm**2 / 7 - 2. / 3
+    ka[1][m] = -16 * xm**8 / 8085 - 16 * xm**6 / 735 + 48 * xm**4 / 245 - 16 * xm**2 / 35
+    ka[2][m] = 32 * xm**8 / 1617 + 128 * xm**6 / 735 - 288 * xm**4 / 245 + 64 * xm**2 / 35 - 4. / 3
+    ka[4][m] = 24 * xm**8 / 2695 + 8 * xm**6 / 105 - 24 * xm**4 / 49 + 24 * xm**2 / 35 - 2. / 3
+    m = x > 1e2
+    xm = x[m]
+    ka[0][m] = 2. / 105 - 24 / (245 * xm**2) - 8 / (735 * xm**4) - 8 / (2695 * xm**6) - 8 / (7007 * xm**8)
+    ka[1][m] = -16. / 35 + 48 / (245 * xm**2) - 16 / (735 * xm**4) - 16 / (8085 * xm**6) - 16 / (35035 * xm**8)
+    ka[2][m] = -44. / 105 - 32 / (735 * xm**4) - 64 / (8085 * xm**6) - 96 / (35035 * xm**8)
+    ka[4][m] = -46. / 105 + 24 / (245 * xm**2) - 8 / (245 * xm**4) - 8 / (1617 * xm**6) - 8 / (5005 * xm**8)
+    ka[3] = ka[1]
+    return 2 * jq * ff, 2 * jq * gg, jq * ka / x**2
+
+
+TNS_NAMES = ['pk11', 'pk_dd', 'pk_b2d', 'pk_bs2d', 'pk_sig3sq', 'pk_b22', 'pk_b2s2', 'pk_bs22', 'pk_dt', 'pk_b2t', 'pk_bs2t', 'pk_tt']   # full_shape.py:882
+
+
+def tns_geometry_A(x, mu):
+    """The ten polynomial kernels of the A term, Taruya et al. 2010 eq. A3 as coded in full_shape.py:800-810."""
+    kA = [-x**3 / 7. * (mu + 6 * mu**3 + x**2 * mu * (-3 + 10 * mu**2) + x * (-3 + mu**2 - 12 * mu**4)),
+          x**4 / 14. * (mu**2 - 1) * (-1 + 7 * x * mu - 6 * mu**2),
+          x**3 / 14. * (x**2 * mu * (13 - 41 * mu**2) - 4 * (mu + 6 * mu**3) + x * (5 + 9 * mu**2 + 42 * mu**4)),
+          None,
+          x**3 / 14. * (1 - 7 * x * mu + 6 * mu**2) * (-2 * mu + x * (-1 + 3 * mu**2))]
+    kA[3] = kA[1]
+    ktA = [1. / 7. * (mu + x - 2 * x * mu**2) * (3 * x + 7 * mu - 10 * x * mu**2),
+           x / 14. * (mu**2 - 1) * (3 * x + 7 * mu - 10 * x * mu**2),
+           1. / 14. * (28 * mu**2 + x * mu * (25 - 81 * mu**2) + x**2 * (1 - 27 * mu**2 + 54 * mu**4)),
+           x / 14. * (1 - mu**2) * (x - 7 * mu + 6 * x * mu**2),
+           1. / 14. * (x - 7 * mu + 6 * x * mu**2) * (-2 * mu - x + 3 * x * mu**2)]
+    return kA, ktA
+
+
+def tns_geometry_B(x, mu, xmu):
+    """The twelve polynomial kernels of the B term (n, a, b as commented in full_shape.py:813-826), WITHOUT the common 1 / (x^2 xmu)."""
+    m21 = mu**2 - 1.
+    return [x**2 * m21 / 2.,
+            3. * x**2 * m21**2 / 8.,
+            3. * x**4 * m21**2 / xmu / 8.,
+            5. * x**4 * m21**3 / xmu / 16.,
+            x * (x + 2. * mu - 3. * x * mu**2) / 2.,
+            -3. * x * m21 * (-x - 2. * mu + 5. * x * mu**2) / 4.,
+            3. * x**2 * m21 * (-2. + x**2 + 6. * x * mu - 5. * x**2 * mu**2) / xmu / 4.,
+            -3. * x**2 * m21**2 * (6. - 5. * x**2 - 30. * x * mu + 35. * x**2 * mu**2) / xmu / 16.,
+            x * (4. * mu * (3. - 5. * mu**2) + x * (3. - 30. * mu**2 + 35. * mu**4)) / 8.,
+            x * (-8. * mu + x * (-12. + 36. * mu**2 + 12. * x * mu * (3. - 5. * mu**2) + x**2 * (3. - 30. * mu**2 + 35. * mu**4))) / xmu / 8.,
+            3. * x * m21 * (-8. * mu + x * (-12. + 60. * mu**2 + 20. * x * mu * (3. - 7. * mu**2) + 5. * x**2 * (1. - 14. * mu**2 + 21. * mu**4))) / xmu / 16.,
+            x * (8. * mu * (-3. + 5. * mu**2) - 6. * x * (3. - 30. * mu**2 + 35. * mu**4) + 6. * x**2 * mu * (15. - 70. * mu**2 + 63 * mu**4)
+                 + x**3 * (5. - 21. * mu**2 * (5. - 15. * mu**2 + 11. * mu**4))) / xmu / 16.]
+
+
+def tns_pt(k11, q, wq, pk_q, kernels=None, nmu=10):
+    """One-loop tables of the TNS model on ``k11``: dict of the twelve spectra of ``TNS_NAMES`` [n_k] + 'A' [5, n_k] + 'B' [12, n_k].
+
+    full_shape.py:749-833: P22-type integrals over q (trapezoid on the template's own k grid) and the cosine mu (10 Gauss-Legendre nodes on (0, 1)),
+    P(|k - q|) by LINEAR interpolation of the template with zero outside its range; P13-type terms from the precomputed kernels.
+    """
+    if kernels is None: kernels = tns_kernels(k11, q, wq)
+    k13d, k13t, ka = kernels
+    k = k11[:, None]
+    jq = q**2 * wq / (4. * np.pi**2)
+    x = q / k
+    mus, wmus = weights_leggauss_sym(nmu)
+    pk_k = np.interp(k11, q, pk_q)
+    out = {name: 0. for name in ['b2d', 'bs2d', 'b2t', 'bs2t', 'sig3sq', 'b22', 'b2s2', 'bs22', '22dd', '22dt', '22tt']}
+    A, B = np.zeros((5, len(k11))), np.zeros((12, len(k11)))
+    for mu, wmu in zip(mus, wmus):
+        kdq = k * q * mu
+        kq2 = k**2 - 2. * kdq + q**2
+        qdkq = kdq - q**2
+        c2 = qdkq**2 / (q**2 * kq2)
+        half = 0.5 * qdkq * (1. / q**2 + 1. / kq2)
+        F2d = 5. / 7. + half + 2. / 7. * c2
+        F2t = 3. / 7. + half + 4. / 7. * c2
+        S = c2 - 1. / 3.
+        D = 2. / 7. * (mu**2 - 1.)
+        pk_kq = np.interp(np.sqrt(kq2), q, pk_q, left=0., right=0.)
+        pp = jq * pk_q * pk_kq
+        out['b2d'] += wmu * np.sum(pp * F2d, axis=-1)
+        out['bs2d'] += wmu * np.sum(pp * F2d * S, axis=-1)
+        out['b2t'] += wmu * np.sum(pp * F2t, axis=-1)
+        out['bs2t'] += wmu * np.sum(pp * F2t * S, axis=-1)
+        out['sig3sq'] += wmu * np.sum(105. / 16. * jq * pk_q * (D * S + 8. / 63.), axis=-1)
+        out['b22'] += wmu / 2. * np.sum(jq * pk_q * (pk_kq - pk_q), axis=-1)
+        out['b2s2'] += wmu / 2. * np.sum(jq * pk_q * (pk_kq * S - 2. / 3. * pk_q), axis=-1)
+        out['bs22'] += wmu / 2. * np.sum(jq * pk_q * (pk_kq * S**2 - 4. / 9. * pk_q), axis=-1)
+        out['22dd'] += 2 * wmu * np.sum(F2d**2 * pp, axis=-1)
+        out['22dt'] += 2 * wmu * np.sum(F2d * F2t * pp, axis=-1)
+        out['22tt'] += 2 * wmu * np.sum(F2t**2 * pp, axis=-1)
+        xmu = kq2 / k**2
+        kA, ktA = tns_geometry_A(x, mu)
+        for i in range(5):
+            A[i] += wmu * np.sum(jq / x**2 * (kA[i] * pk_k[:, None] + ktA[i] * pk_q) * pk_kq / xmu**2, axis=-1)
+        ppb = pp / (x**2 * xmu)
+        for i, cb in enumerate(tns_geometry_B(x, mu, xmu)):
+            B[i] += wmu * np.sum(cb * ppb, axis=-1)
+    A += pk_k * np.sum(ka * pk_q, axis=-1)
+    pk13_dd = 2. * np.sum(k13d * pk_q, axis=-1) * pk_k
+    pk13_tt = 2. * np.sum(k13t * pk_q, axis=-1) * pk_k
+    pk13_dt = (pk13_dd + pk13_tt) / 2.
+    tab = {'pk11': pk_k, 'pk_dd': pk_k + out['22dd'] + pk13_dd, 'pk_b2d': out['b2d'], 'pk_bs2d': out['bs2d'], 'pk_sig3sq': out['sig3sq'] * pk_k,
+           'pk_b22': out['b22'], 'pk_b2s2': out['b2s2'], 'pk_bs22': out['bs22'], 'pk_dt': pk_k + out['22dt'] + pk13_dt, 'pk_b2t': out['b2t'],
+           'pk_bs2t': out['bs2t'], 'pk_tt': pk_k + out['22tt'] + pk13_tt, 'A': A, 'B': B}
+    return tab
+
+
+def tns_table_matrix(tab):
+    """The 29 rows [pk11 ... pk_tt, A0..A4, B0..B11] x n_k11 in the order of full_shape.py:882-883."""
+    return np.concatenate([np.array([tab[name] for name in TNS_NAMES]), tab['A'], tab['B']], axis=0)
+
+
+def tns_pktable(k, mu, wmu_ell, q, pk_q, f, qpar=1., qper=1., sigmav=0., fog='lorentzian', kernels=None, k11=None):
+    """``TNSPowerSpectrumMultipoles.calculate``, full_shape.py:865-899: dict name -> [n_ell, n_k] (A, B: [3, n_ell, n_k] for the b1^2, b1, 1 terms)."""
+    jac, kap, muap = ap_k_mu(k, mu, qpar=qpar, qper=qper)
+    if fog == 'lorentzian': damping = 1. / (1. + (sigmav * kap * muap)**2 / 2.)**2.
+    else: damping = np.exp(-(sigmav * kap * muap)**2)
+    if k11 is None: k11 = tns_k11(k)
+    tab = tns_table_matrix(tns_pt(k11, q, weights_trapz(q), pk_q, kernels=kernels))
+    t = jac * damping * np.moveaxis(interp1d(np.log10(kap), np.log10(k11), tab.T, method='cubic'), [0, 1], [1, 2])   # [29, n_k, n_mu]
+    A, B = t[12:17], t[17:]
+    m2 = muap**2
+    Ac = [f * A[0] * m2, f**2 * (A[1] * m2 + A[2] * m2**2), f**3 * (A[3] * m2**2 + A[4] * m2**3)]
+    Bc = [f**2 * (B[0] * m2 + B[4] * m2**2), -f**3 * ((B[1] + B[2]) * m2 + (B[5] + B[6]) * m2**2 + (B[8] + B[9]) * m2**3),
+          f**4 * (B[3] * m2 + B[7] * m2**2 + B[10] * m2**3 + B[11] * m2**4)]
+
+    def to_poles(pkmu):
+        return np.sum(pkmu[None, ...] * wmu_ell[:, None, :], axis=-1)
+
+    out = {}
+    for i, name in enumerate(TNS_NAMES):
+        fac = 1. if i < 8 else (f * m2 if i < 11 else f**2 * m2**2)
+        out[name] = to_poles(fac * t[i])
+    out['A'] = np.array([to_poles(a) for a in Ac])
+    out['B'] = np.array([to_poles(b) for b in Bc])
+    return out
+
+
+def tns_tracer_power(pt, nd, b1=1., b2=0., bs=0., b3=0., sn0=0.):
+    """``TNSTracerPowerSpectrumMultipoles.calculate``, full_shape.py:957-971 (as coded: sn0 / nd goes to EVERY multipole; the last pk_sig3sq term carries no f mu^2)."""
+    power = b1**2 * pt['pk_dd'] + 2. * b1 * pt['pk_dt'] + pt['pk_tt'] + sn0 / nd
+    bs2 = bs - 4. / 7. * (b1 - 1.)
+    b3nl = b3 + 32. / 315. * (b1 - 1.)
+    power = power + 2 * b1 * b2 * pt['pk_b2d'] + 2. * b1 * bs2 * pt['pk_bs2d'] + 2 * b1 * b3nl * pt['pk_sig3sq'] + b2**2 * pt['pk_b22'] \
+        + 2 * b2 * bs2 * pt['pk_b2s2'] + bs2**2 * pt['pk_bs22'] + b2 * pt['pk_b2t'] + b3nl * pt['pk_sig3sq']
+    power = power + b1**2 * (pt['A'][0] + pt['B'][0]) + b1 * (pt['A'][1] + pt['B'][1]) + (pt['A'][2] + pt['B'][2])
+    return power
+
+
+# ----------------------------------------------------------------------------------------------
 # a5: tracer combine                                          full_shape.py:545-550, 628-634
 # ----------------------------------------------------------------------------------------------
 def kaiser_tracer_power(ells, pk_dd, pk_dt, pk_tt, nd, b1X, b1Y, sn0):

@@ -16,7 +16,10 @@ class BaseSection(object):
 class SyntheticPk(object):
     """P(k) = A (k/0.05)^ns T_BBKS(k/keq)^2 (1 + wiggle sin(k rs) exp(-(8k)^2)), times ``scale``."""
 
-    def __init__(self, A=2.5e4, n_s=0.965, keq=0.015, rs=100., wiggle=0.05, scale=1.):
+    def __init__(self, A=None, n_s=0.965, keq=0.015, rs=100., wiggle=0.05, scale=1.):
+        if A is None:   # REFSTUB_PK_SCALE: amplitude knob of the synthetic spectrum (the one-loop fixtures want loop terms of realistic relative size)
+            import os
+            A = 2.5e4 * float(os.environ.get('REFSTUB_PK_SCALE', '1'))
         self.A, self.n_s, self.keq, self.rs, self.wiggle, self.scale = A, n_s, keq, rs, wiggle, scale
 
     def clone(self, **kwargs):

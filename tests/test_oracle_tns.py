@@ -1,0 +1,100 @@
+"""Oracle restatement of the reference's TNS one-loop theory (full_shape.py:688-971) against golden vectors of the reference itself
+(tests/golden/make_tns_fixture.py): kernels, the 29 loop tables, the projected tables, the tracer power, the likelihood."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as oc
+
+here = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = ['tns', 'tns_eft', 'tns_standard_gaussian']
+
+
+def load(name):
+    return dict(np.load(os.path.join(here, 'golden', name + '.npz'), allow_pickle=True))
+
+
+def tns_oracle_point(g, row, kernels=None, return_all=False):
+    """Log-likelihood (and intermediates) of one theta row of a TNS fixture, by the oracle."""
+    names = list(g['names'])
+    p = dict(zip(names, row))
+    k, mu, wmu_ell, q = g['c.kin'], g['c.mu'], g['c.wmu_ell'], g['c.k11']
+    template = str(g['c.template'])
+    pk_q = g['c.pk_dd_fid'] * (oc.shapefit_factor(q, float(g['c.kp']), float(g['c.a']), dm=p.get('dm', 0.), dn=p.get('dn', 0.)) if 'ShapeFit' in template else 1.)
+    f = float(g['c.f_fid']) * p.get('df', 1.)
+    pt = oc.tns_pktable(k, mu, wmu_ell, q, pk_q, f, qpar=p.get('qpar', 1.), qper=p.get('qper', 1.), sigmav=p.get('sigmav', 0.), fog=str(g['fog']), kernels=kernels, k11=g['k11_table'])
+    nd = float(g['c.nd'])
+    power = oc.tns_tracer_power(pt, nd, b1=p['b1'], b2=p['b2'], bs=p.get('bs', 0.), b3=p.get('b3', 0.), sn0=p['sn0'])
+    if bool(g['eft']):
+        ells = list(g['c.ells'])
+        ctv = np.array([2. * p[str(name)] for name in g['c.ct_params']])   # summed over the two (identical) tracers
+        snv = np.array([p[str(name)] for name in g['c.sn_params']])
+        power = oc.eftlike_addon(power, ells, pt['pk11'], g['c.ct_matrix'], ctv, g['c.sn_matrix'], snv, nd)
+    flat = oc.window_apply(power, matrix_full=g['c.matrix_full'], shotnoisein=g['c.shotnoisein'], shotnoiseout=g['c.shotnoiseout'])
+    logl = oc.gaussian_loglikelihood(flat, g['c.flatdata'], g['precision'])[0]
+    if return_all: return logl, pt, power, flat, pk_q
+    return logl
+
+
+def test_trapz_weights_and_table_grid():
+    g = load('tns')
+    assert np.allclose(oc.tns_k11(g['c.kin']), g['k11_table'], rtol=1e-15)
+    wq = oc.weights_trapz(g['c.k11'])
+    assert np.isclose(wq.sum(), g['c.k11'][-1] - g['c.k11'][0], rtol=1e-14)
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_kernels(name):
+    g = load(name)
+    q = g['c.k11']
+    rows = g['kernel_rows']
+    k13d, k13t, ka = oc.tns_kernels(g['k11_table'][rows], q, oc.weights_trapz(q))
+    for mine, ref in [(k13d, g['kernel13_d']), (k13t, g['kernel13_t']), (ka, g['kernel_a'])]:
+        assert np.allclose(mine, ref, rtol=1e-13, atol=1e-300)
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_loop_tables_and_power(name):
+    g = load(name)
+    q = g['c.k11']
+    kernels = oc.tns_kernels(g['k11_table'], q, oc.weights_trapz(q))
+    for i in range(3):
+        row = g['theta'][i]
+        if not np.all(np.isfinite(row)): row = g['theta'][0]
+        logl, pt, power, flat, pk_q = tns_oracle_point(g, row, kernels=kernels, return_all=True)
+        assert np.allclose(pk_q, g['int_pk_dd_template'][i], rtol=1e-13)
+        tab = oc.tns_table_matrix(oc.tns_pt(g['k11_table'], q, oc.weights_trapz(q), pk_q, kernels=kernels))
+        ref = g['int_tables'][i]
+        for r in range(29):   # every table to 1e-11 of its own largest entry (the sums are the reference's, in the reference's order)
+            assert np.max(np.abs(tab[r] - ref[r])) <= 1e-11 * np.max(np.abs(ref[r])), r
+        poles = np.concatenate([np.array([pt[key] for key in oc.TNS_NAMES]), pt['A'], pt['B']], axis=0)
+        refp = g['int_poles'][i]
+        for r in range(poles.shape[0]):
+            assert np.max(np.abs(poles[r] - refp[r])) <= 1e-11 * np.max(np.abs(refp[r])), r
+        assert np.allclose(power, g['int_power'][i], rtol=1e-11, atol=1e-11 * np.max(np.abs(power)))
+        assert np.allclose(flat, g['int_flattheory'][i], rtol=1e-11, atol=1e-11 * np.max(np.abs(flat)))
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_loglikelihood(name):
+    g = load(name)
+    q = g['c.k11']
+    kernels = oc.tns_kernels(g['k11_table'], q, oc.weights_trapz(q))
+    checked = 0
+    for i, row in enumerate(g['theta']):
+        if not np.all(np.isfinite(row)) or not np.isfinite(g['logprior'][i]): continue
+        logl = tns_oracle_point(g, row, kernels=kernels)
+        assert abs(logl - g['loglikelihood'][i]) <= 1e-10 * max(1., abs(g['loglikelihood'][i])), (i, logl, g['loglikelihood'][i])
+        checked += 1
+    assert checked >= 8
+
+
+def test_loop_terms_matter():
+    """The fixture is sensitive to the loop terms: dropping them moves the power by several per cent at k = 0.2."""
+    g = load('tns')
+    i = 0
+    tab = g['int_tables'][i]
+    k11 = g['k11_table']
+    sel = k11 > 0.15
+    assert np.max(np.abs(tab[1][sel] / tab[0][sel] - 1.)) > 0.02     # pk_dd vs pk11
