@@ -31,6 +31,7 @@ SYMBOLS = {
     'dl_eval_fisher': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_theory': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_batch_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
+    'dl_eval_tns_tables': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     'dl_eval_theory_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, ctypes.c_int32, _c_double_p, _c_double_p]),
     'dl_eval_logposterior_host': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_int32_p]),
     'dl_profile_enable': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
@@ -341,6 +342,19 @@ class Context(object):
         self._check(self._lib.dl_eval_theory(self._handle, ctypes.c_void_p(theta.data_ptr()), B, int(iobs), ctypes.c_void_p(power.data_ptr()),
                                              None if tables is None else ctypes.c_void_p(tables.data_ptr()), ctypes.c_void_p(stream)))
         return power
+
+    def eval_tns_tables(self, theta, n_k11, iobs=0, stream=None):
+        """The 29 one-loop tables ``[B, 29, n_k11]`` of a TNS observable before AP / damping / projection (``dl_eval_tns_tables``); ``theta``: array or device tensor."""
+        import torch
+        if not torch.is_tensor(theta):
+            theta = torch.as_tensor(np.ascontiguousarray(theta, dtype='f8'), device='cuda:{:d}'.format(self.device))
+        if stream is None:
+            stream = torch.cuda.current_stream(theta.device).cuda_stream
+        B = theta.shape[0]
+        theta = self._device_theta(theta, stream)
+        tables = torch.empty((B, 29, int(n_k11)), dtype=torch.float64, device=theta.device)
+        self._check(self._lib.dl_eval_tns_tables(self._handle, ctypes.c_void_p(theta.data_ptr()), B, int(iobs), ctypes.c_void_p(tables.data_ptr()), ctypes.c_void_p(stream)))
+        return tables
 
     def eval_logposterior_grad(self, theta, logposterior=None, grad=None, status=None, stream=None):
         """Log-posterior ``[B]`` and its analytic gradient ``[B, P]`` (``dl_eval_logposterior_grad``; float64 device tensors, allocated if ``None``; asynchronous).

@@ -186,7 +186,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
         if (ctx->obs[i].dev.transform != 0) ctx->any_transform = true;
     }
     for (auto& ob : ctx->obs)
-        if ((ob.dev.theory == 3 ? 0 : ob.dev.theory == 2 ? dl_bao_shared_doubles(ob.dev.n_in) : dl_fs_shared_doubles(ob.dev.n_t, ob.dev.n_in)) * sizeof(double) > 160 * 1024)
+        if ((ob.dev.theory == 3 || ob.dev.theory == 4 ? 0 : ob.dev.theory == 2 ? dl_bao_shared_doubles(ob.dev.n_in) : dl_fs_shared_doubles(ob.dev.n_t, ob.dev.n_in)) * sizeof(double) > 160 * 1024)
             return bail("dl_create: template / theory grid too large for the 160 KiB LDS");
     ctx->n_data = row;
     int n = ctx->n_data;
@@ -371,7 +371,9 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
             for (auto& ob : ctx->obs) {
                 const DlObsDev& od = ob.dev;
                 double* dst = &dvec[od.col_offset];
-                if (ob.marg_sn0 == s_ && od.ell0 >= 0)
+                if (ob.marg_sn0 == s_ && od.theory == 4)   // TNS: sn0 / nd is added to every multipole (full_shape.py:961)
+                    for (int idx = 0; idx < od.n_in; ++idx) dst[idx] += 1. / od.nd;
+                else if (ob.marg_sn0 == s_ && od.ell0 >= 0)
                     for (int i = 0; i < od.n_kin; ++i) dst[(size_t)od.ell0 * od.n_kin + i] += 1. / od.nd;
                 for (int c = 0; c < od.n_pass; ++c)
                     if (ob.marg_pass[c] == s_) dst[od.n_in + c] += 1.;   // pass-through column: derivative = unit vector
@@ -426,6 +428,7 @@ void dl_destroy(dl_ctx* ctx) {
                     ctx->status_stage, ctx->gemm_counters, ctx->obs_array_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (double* p : ctx->gfrag_dev) if (p) (void)hipFree(p);
+    for (auto& ob : ctx->obs) if (ob.tns) { dl_tns_destroy(ob.tns); ob.tns = nullptr; }
     if (ctx->feat_ws) (void)hipFree(ctx->feat_ws);
     for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
@@ -756,6 +759,20 @@ int dl_eval_theory(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs
     return 0;
 }
 
+int dl_eval_tns_tables(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs, double* tables_dev, void* hip_stream) {
+    if (!ctx) { g_last_error = "dl_eval_tns_tables: null context"; return 1; }
+    if (iobs < 0 || iobs >= ctx->n_obs) return dl_fail(ctx, "dl_eval_tns_tables: observable index out of range");
+    if (ctx->obs[iobs].dev.theory != 4) return dl_fail(ctx, "dl_eval_tns_tables: the observable's theory is not the TNS model");
+    if (B < 0 || (B > 0 && (!theta_dev || !tables_dev))) return dl_fail(ctx, "dl_eval_tns_tables: invalid argument");
+    if (B == 0) return 0;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (dl_order_streams(ctx, stream)) return 1;
+    if (dl_tns_tables(ctx->obs_kernarg[iobs], theta_dev, ctx->n_params, B, tables_dev, stream)) return dl_fail(ctx, std::string("dl_eval_tns_tables: ") + dl_last_error(nullptr));
+    DL_HIP_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
 static int dl_stage_reserve(dl_ctx* ctx, int64_t B) {
     if (!ctx->host_stream) DL_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->host_stream, hipStreamNonBlocking));
     if (B <= ctx->stage_cap) return 0;
@@ -915,7 +932,7 @@ static bool dl_fold_applicable(const dl_ctx* ctx, int64_t B) {
     for (auto& ob : ctx->obs) {
         const DlObsDev& oh = ob.dev;
         const bool generic = !oh.uniform_knots || !(oh.toeplitz || oh.fixed_spline);
-        if (oh.theory == 2 || oh.theory == 3 || generic || oh.n_ct > 0 || oh.n_sn > 0 || (oh.n_ell <= 3) != (ctx->obs[0].dev.n_ell <= 3)) return false;
+        if (oh.theory >= 2 || generic || oh.n_ct > 0 || oh.n_sn > 0 || (oh.n_ell <= 3) != (ctx->obs[0].dev.n_ell <= 3)) return false;
     }
     return ctx->n_obs >= 1 && ctx->n_obs <= 8;
 }

@@ -138,6 +138,10 @@ struct DlObsDev {
                                                    // segment seg sits at [q][4 seg + part] (zero beyond the warm-up length / the ends of the system)
     const double *coef_fixed;                      // [n_t, 4] interval polynomials of the fiducial table (fixed templates)
     const double *ct_matrix, *sn_matrix;           // [n_ell, n_kin, n_ct], [n_ell, n_kin, n_sn]
+    // TNS one-loop theory (kind 4, dl_tns.h): FoG dispersion and the non-linear bias parameters (full_shape.py:865, 957-971); tns_plan: HOST handle of the
+    // geometry tables and the per-evaluation workspace (dl_tns.hip), never dereferenced on the device
+    DlInput sigmav, b2, bs, b3;
+    void* tns_plan;
 };
 
 DL_HD int dl_fs_n_dd0(const DlObsDev& o) { return (o.n_var > 0 && o.n_ct > 0) ? o.n_kin : 0; }   // P_dd,l=0 kept for the derivative rows

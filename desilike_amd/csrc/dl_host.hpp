@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "dl_fullshape.h"
+#include "dl_tns.h"
 
 struct dl_config {
     std::map<std::string, std::vector<double>> f64;
@@ -47,8 +48,10 @@ struct DlArena {
     size_t push(const std::vector<double>& v) { return push(v.data(), v.size()); }
 };
 
+struct DlTnsPlan;
 struct DlObsHost {
     DlObsDev dev;   // pointers are OFFSETS into arena (in doubles) until rebase()
+    DlTnsPlan* tns = nullptr;   // TNS one-loop theory: geometry tables + workspace (dl_tns.hip), owned by the observable
     int n_out = 0;  // data size of this observable
     // analytic marginalisation: index of the solved parameter fed by each linear input of this observable (-1: not solved)
     int marg_sn0 = -1;
@@ -353,7 +356,8 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     struct { const char* name; DlInput* in; double def; } inputs[] = {
         {"qpar", &d.qpar, 1.}, {"qper", &d.qper, 1.}, {"qiso", &d.qiso, 1.}, {"qap", &d.qap, 1.}, {"df", &d.df, 1.}, {"dm", &d.dm, 0.}, {"dn", &d.dn, 0.},
         {"sigmapar", &d.sigpar, 0.}, {"sigmaper", &d.sigper, 0.}, {"b1X", &d.b1X, 1.}, {"b1Y", &d.b1Y, 1.}, {"sn0", &d.sn0, 0.},
-        {"dbeta", &d.dbeta, 1.}, {"sigmas", &d.sigmas, 0.}, {"dres", &d.dres, 1.}};
+        {"dbeta", &d.dbeta, 1.}, {"sigmas", &d.sigmas, 0.}, {"dres", &d.dres, 1.},
+        {"sigmav", &d.sigmav, 0.}, {"b2", &d.b2, 0.}, {"bs", &d.bs, 0.}, {"b3", &d.b3, 0.}};
     for (auto& it : inputs) {
         *it.in = dl_input_from(cfg, p + "in." + it.name, it.def);
         if (it.in->col >= n_params) { err = p + "in." + it.name + ": theta column out of range"; return false; }
@@ -529,5 +533,21 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
 
     for (int c = 0; c < DL_N_VPARS; ++c) { oh.marg_vp[c] = -1; d.vp_slot[c] = -1; }
     for (int e = 0; e < 3; ++e) { d.eng[e].type = -1; for (int q = 0; q < 6; ++q) oh.off_eng[e][q] = oh.off_kin; }
+    if (d.theory == 4) {   // TNS one-loop tables: geometry on the device, once (dl_tns.h)
+#ifdef __HIPCC__
+        const auto& k11 = cfg.F(p + "tns_k11");
+        const auto& tmu = cfg.F(p + "tns_mu");
+        const auto& twmu = cfg.F(p + "tns_wmu");
+        if (k11.empty() || tmu.empty() || tmu.size() != twmu.size()) { err = p + "tns_k11 / tns_mu / tns_wmu are required by the TNS theory"; return false; }
+        if (d.n_pass != 0) { err = p + "pass-through columns are not supported by the TNS theory"; return false; }
+        if ((size_t)12 * k11.size() * sizeof(double) + (size_t)(d.n_in + d.n_kin) * sizeof(double) > 150 * 1024) { err = p + "TNS table grid too large for the LDS (n_k11 <= 1500)"; return false; }
+        const char* terr = nullptr;
+        oh.tns = dl_tns_create(k11.data(), (int)k11.size(), k_t.data(), d.n_t, tmu.data(), twmu.data(), (int)tmu.size(), cfg.i(p + "tns_fog", 0), &terr);
+        if (!oh.tns) { err = p + (terr ? terr : "tns: plan creation failed"); return false; }
+        d.tns_plan = oh.tns;
+#else
+        err = p + "the TNS theory is not part of the CPU emulation"; return false;
+#endif
+    }
     return dl_build_window(cfg, p, oh, err);
 }

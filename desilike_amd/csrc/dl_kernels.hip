@@ -15,6 +15,7 @@
 
 #include "dl_fullshape.h"
 #include "dl_kernels.h"
+#include "dl_tns.h"
 #include "dl_emu_batch.h"
 #include "dl_finalize_part.h"
 #include "dl_scalar_prefetch.h"
@@ -273,7 +274,7 @@ bool dl_launch_fullshape_ens(const DlObsDev* obs_host, int n_obs, const DlObsDev
     for (int i = 0; i < n_obs; ++i) {
         const DlObsDev& oh = obs_host[i];
         const bool generic = !oh.uniform_knots || !(oh.toeplitz || oh.fixed_spline);
-        if (oh.theory == 2 || oh.theory == 3 || generic || oh.n_ct > 0 || oh.n_sn > 0 || (oh.n_ell <= 3) != nl3) return false;
+        if (oh.theory >= 2 || generic || oh.n_ct > 0 || oh.n_sn > 0 || (oh.n_ell <= 3) != nl3) return false;
         shmem = std::max(shmem, dl_fs_shared_doubles_obs(oh, true) * sizeof(double));
     }
     static const int64_t dense_min = getenv("DL_FS_DENSE_MIN") ? atoll(getenv("DL_FS_DENSE_MIN")) : 4096;
@@ -451,7 +452,7 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
         for (int i = 0; i < n_obs && same; ++i) {
             const DlObsDev& oh = obs_host[i];
             const bool generic = !oh.uniform_knots || !(oh.toeplitz || oh.fixed_spline);
-            if (oh.theory == 2 || oh.theory == 3 || generic || (oh.n_ct > 0 || oh.n_sn > 0) != eft0 || (oh.n_ell <= 3) != nl3) same = false;
+            if (oh.theory >= 2 || generic || (oh.n_ct > 0 || oh.n_sn > 0) != eft0 || (oh.n_ell <= 3) != nl3) same = false;
             shmem = std::max(shmem, dl_fs_shared_doubles_obs(oh, true) * sizeof(double));
         }
         if (same && !eft0) {
@@ -467,6 +468,10 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
         }
     }
     for (int i = 0; i < n_obs; ++i) {  // one launch per observable (1-2 in practice)
+        if (obs_host[i].theory == 4) {   // DL_THEORY_TNS: loop GEMM + assembly (dl_tns.hip)
+            dl_launch_tns(obs_host[i], theta, n_params, B, power, ld_power, stream);
+            continue;
+        }
         if (obs_host[i].theory == 3 && feat != nullptr && !getenv("DL_NO_EMU_BATCH")) {   // feature path: 16 points per workgroup, MLP layers by MFMA
             size_t shm = dl_eb_shared_doubles(obs_host[i]) * sizeof(double);
             if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_emulated_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

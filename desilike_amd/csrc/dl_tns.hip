@@ -1,0 +1,484 @@
+// dl_tns.hip -- TNS one-loop tables on gfx950 (see dl_tns.h): geometry at context creation, loop GEMM + assembly per evaluation.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dl_tns.h"
+#include "dl_kernels.h"
+#include "dl_host.hpp"
+
+typedef double dl_tns_double4 __attribute__((ext_vector_type(4)));
+typedef double dl_tns_double2 __attribute__((ext_vector_type(2)));
+
+struct DlTnsPlan {
+    DlTnsDev dev;
+    std::vector<void*> allocs;
+    size_t bytes = 0;
+    // per-evaluation workspace (grown on demand; a plan serves one context, whose calls are serialised on its stream)
+    int64_t cap_pts = 0;
+    double* pk = nullptr;       // [nqp][cap_pts]
+    double* qq = nullptr;       // [cap_pts]
+    double* tables = nullptr;   // [cap_pts][n11][DL_TNS_NTAB]
+    std::string err;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// geometry (once per context)
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// bilinear coefficients + interpolation records: one thread per (k, mu, q)
+__global__ __launch_bounds__(256) void dl_tns_geometry_kernel(DlTnsDev t, int32_t* geomj, double* geomw, double* coef) {
+    const int ik = blockIdx.x, im = blockIdx.y;
+    const double k = t.k11[ik], mu = t.mus[im], wmu = t.mus[t.n_mu + im];
+    for (int iq = threadIdx.x; iq < t.nqp; iq += blockDim.x) {
+        const size_t kappa = (size_t)ik * t.K + (size_t)im * t.nqp + iq;
+        double c[DL_TNS_NCOL];
+        for (int i = 0; i < DL_TNS_NCOL; ++i) c[i] = 0.;
+        int j = 0;
+        double w0 = 0., w1 = 0.;
+        if (iq < t.n_q) {
+            DlTnsGeom g;
+            dl_tns_geometry(k, t.q[iq], t.jq[iq], mu, wmu, g);
+            for (int i = 0; i < 27; ++i) c[i] = g.c[i];
+            dl_tns_interp_weights(t.q, t.n_q, g.r, j, w0, w1);
+        }
+        geomj[kappa] = j;
+        geomw[2 * kappa] = w0; geomw[2 * kappa + 1] = w1;
+        for (int i = 0; i < 16; ++i) { coef[(kappa * 16 + i) * 2] = c[i]; coef[(kappa * 16 + i) * 2 + 1] = c[16 + i]; }
+    }
+}
+
+// linear coefficients that are sums over the cosines or closed forms: one thread per (k, q)
+__global__ __launch_bounds__(256) void dl_tns_geometry_lin_kernel(DlTnsDev t, double* lin) {
+    const int ik = blockIdx.x;
+    const double k = t.k11[ik];
+    int jk; double wk0, wk1;
+    dl_tns_interp_weights(t.q, t.n_q, k, jk, wk0, wk1);   // pk_k = interp(k11, q, pk_q): full_shape.py:763 (k11 lies inside the template's range)
+    for (int iq = threadIdx.x; iq < t.nqp; iq += blockDim.x) {
+        double* row = lin + ((size_t)ik * t.nqp + iq) * DL_TNS_NLIN;
+        for (int i = 0; i < DL_TNS_NLIN; ++i) row[i] = 0.;
+        if (iq >= t.n_q) continue;
+        const double q = t.q[iq], jq = t.jq[iq];
+        row[DL_TL_PK] = (iq == jk ? wk0 : 0.) + (iq == jk + 1 ? wk1 : 0.);
+        double s3 = 0.;
+        for (int im = 0; im < t.n_mu; ++im) {
+            DlTnsGeom g;
+            dl_tns_geometry(k, q, jq, t.mus[im], t.mus[t.n_mu + im], g);
+            s3 += g.sig3;
+        }
+        row[DL_TL_SIG3] = s3;
+        double ff, gg, ka[4];
+        dl_tns_kernels13(q / k, ff, gg);
+        dl_tns_kernels_a(q / k, ka);
+        row[DL_TL_13D] = 2. * jq * ff;
+        row[DL_TL_13T] = 2. * jq * gg;
+        for (int i = 0; i < 4; ++i) row[DL_TL_KA0 + i] = jq * ka[i];
+    }
+}
+
+// A-term kernels multiplying P(k) P(|k - q|), folded over the interpolation onto the template's own wavenumbers: ONE thread per (k, kernel) walks the (mu, q) in
+// order (a fixed summation order: the result does not depend on the launch)
+__global__ __launch_bounds__(64) void dl_tns_geometry_fold_kernel(DlTnsDev t, const int32_t* geomj, const double* geomw, double* lin) {
+    const int ik = blockIdx.x, u = threadIdx.x;
+    if (u >= 4) return;
+    const int i = (u == 0) ? 0 : (u == 1) ? 1 : (u == 2) ? 2 : 4;
+    const double k = t.k11[ik];
+    for (int im = 0; im < t.n_mu; ++im)
+        for (int iq = 0; iq < t.n_q; ++iq) {
+            const size_t kappa = (size_t)ik * t.K + (size_t)im * t.nqp + iq;
+            const double w0 = geomw[2 * kappa], w1 = geomw[2 * kappa + 1];
+            if (w0 == 0. && w1 == 0.) continue;
+            DlTnsGeom g;
+            dl_tns_geometry(k, t.q[iq], t.jq[iq], t.mus[im], t.mus[t.n_mu + im], g);
+            const int j = geomj[kappa];
+            lin[((size_t)ik * t.nqp + j) * DL_TNS_NLIN + DL_TL_EA0 + u] += g.ca[i] * w0;
+            lin[((size_t)ik * t.nqp + j + 1) * DL_TNS_NLIN + DL_TL_EA0 + u] += g.ca[i] * w1;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// per evaluation
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// template of every point at the template's wavenumbers, wavenumber-major: pk [nqp][ldp]; qq [b] = sum_q jq P(q)^2.  64 points per workgroup.
+__global__ __launch_bounds__(256) void dl_tns_pk_kernel(DlObsDev o, DlTnsDev t, const double* __restrict__ theta, int n_params, int64_t B, int64_t ldp,
+                                                        double* __restrict__ pk, double* __restrict__ qq) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = b < B;
+    const double* th = theta + (size_t)(live ? b : 0) * n_params;
+    const double dm_a = dl_get(o.dm, th) / o.a, dn = dl_get(o.dn, th);
+    double acc = 0.;
+    for (int j = grp; j < t.nqp; j += 4) {
+        double v = 0.;
+        if (live && j < t.n_q) v = (o.templ == 1) ? o.pk_fid[j] * exp(dm_a * o.sf_th[j] + dn * o.sf_lg[j]) : o.pk_fid[j];   // power_template.py:749
+        if (b < ldp) pk[(size_t)j * ldp + b] = v;
+        acc = fma(t.jq[j] * v, v, acc);
+    }
+    part[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0 && b < ldp) qq[b] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// The loop GEMM: workgroup = (k, 32 points), 8 waves.  LDS: the points' templates [nqp][32]; every wave takes every 8th group of 4 (mu, q) pairs, forms the left
+// operand of its two 16-point tiles in registers and multiplies it with the [4 x 32] coefficient block it loaded from L2 (4 MFMA per step); then the linear tables
+// (left operand = the templates themselves); the 8 partial accumulators are summed in wave order through LDS and the 29 table entries written.
+#define DL_TNS_WAVES 8
+#define DL_TNS_UNROLL 4
+
+__global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev t, const double* __restrict__ pk, const double* __restrict__ qq, int64_t ldp, int n_tiles,
+                                                                       double* __restrict__ tables) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    // workgroups of one k share an XCD (consecutive workgroup ids go round the 8 XCDs): its coefficients are fetched from HBM once
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ik = (slot / n_tiles) * 8 + xcd, tile = slot % n_tiles;
+    if (ik >= t.n11) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p16 = lane & 15, kk = lane >> 4;
+    double* spk = lds;                                       // [nqp][32]
+    double* sums = lds + (size_t)t.nqp * DL_TNS_PTS;         // [32][48]
+    for (int idx = tid; idx < t.nqp * DL_TNS_PTS; idx += 64 * DL_TNS_WAVES)
+        spk[idx] = pk[(size_t)(idx >> 5) * ldp + (size_t)tile * DL_TNS_PTS + (idx & 31)];
+    __syncthreads();
+    dl_tns_double4 acc[2][2], accl[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { acc[m][0] = (dl_tns_double4){0., 0., 0., 0.}; acc[m][1] = acc[m][0]; accl[m] = acc[m][0]; }
+    const int nsteps = t.K / 4;
+    const int32_t* gj = t.geomj + (size_t)ik * t.K + kk;
+    const dl_tns_double2* gw = reinterpret_cast<const dl_tns_double2*>(t.geomw) + (size_t)ik * t.K + kk;
+    const dl_tns_double2* gc = reinterpret_cast<const dl_tns_double2*>(t.coef) + ((size_t)ik * t.K + kk) * 16 + p16;
+    const double* spt = spk + p16;
+    // groups of DL_TNS_UNROLL steps, software-pipelined: the loads of the next group are in flight while this one is multiplied
+    int32_t j0[DL_TNS_UNROLL], j0n[DL_TNS_UNROLL];
+    dl_tns_double2 w[DL_TNS_UNROLL], wn[DL_TNS_UNROLL], c[DL_TNS_UNROLL], cn[DL_TNS_UNROLL];
+    const int stride = DL_TNS_WAVES * DL_TNS_UNROLL;
+    auto load = [&](int s0, int32_t* jj, dl_tns_double2* ww, dl_tns_double2* cc) {
+#pragma unroll
+        for (int u = 0; u < DL_TNS_UNROLL; ++u) {
+            int s = s0 + u;
+            if (s >= nsteps) s = nsteps - 1;            // (tail: reloaded, not used)
+            jj[u] = gj[(size_t)4 * s]; ww[u] = gw[(size_t)4 * s]; cc[u] = gc[(size_t)4 * s * 16];
+        }
+    };
+    int s0 = wave * DL_TNS_UNROLL;
+    if (s0 < nsteps) load(s0, j0, w, c);
+    for (; s0 < nsteps; s0 += stride) {
+        if (s0 + stride < nsteps) load(s0 + stride, j0n, wn, cn);
+        double pq[DL_TNS_UNROLL][2], pa[DL_TNS_UNROLL][2], pb[DL_TNS_UNROLL][2];
+#pragma unroll
+        for (int u = 0; u < DL_TNS_UNROLL; ++u) {
+            const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;
+            const int iq = (4 * s) % t.nqp + kk;
+            const double* ra = spt + (size_t)j0[u] * DL_TNS_PTS;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { pq[u][m] = spt[(size_t)iq * DL_TNS_PTS + 16 * m]; pa[u][m] = ra[16 * m]; pb[u][m] = ra[DL_TNS_PTS + 16 * m]; }
+        }
+#pragma unroll
+        for (int u = 0; u < DL_TNS_UNROLL; ++u) {
+            if (s0 + u < nsteps) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const double g = pq[u][m] * fma(w[u].x, pa[u][m], w[u].y * pb[u][m]);
+                    acc[m][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(g, c[u].x, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(g, c[u].y, acc[m][1], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < DL_TNS_UNROLL; ++u) { j0[u] = j0n[u]; w[u] = wn[u]; c[u] = cn[u]; }
+    }
+    // linear tables: left operand = the templates
+    const double* gl = t.lin + ((size_t)ik * t.nqp + kk) * DL_TNS_NLIN + p16;
+    for (int s = wave; s < t.nqp / 4; s += DL_TNS_WAVES) {
+        const double cl = gl[(size_t)4 * s * DL_TNS_NLIN];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) accl[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(spt[(size_t)(4 * s + kk) * DL_TNS_PTS + 16 * m], cl, accl[m], 0, 0, 0);
+    }
+    __syncthreads();                                         // every wave is done with the templates: their space takes the partial accumulators
+    double* red = lds;                                       // [wave][m][tile3][r][lane]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[(((size_t)(wave * 2 + m) * 3 + 0) * 4 + r) * 64 + lane] = acc[m][0][r];
+            red[(((size_t)(wave * 2 + m) * 3 + 1) * 4 + r) * 64 + lane] = acc[m][1][r];
+            red[(((size_t)(wave * 2 + m) * 3 + 2) * 4 + r) * 64 + lane] = accl[m][r];
+        }
+    __syncthreads();
+    for (int idx = tid; idx < DL_TNS_PTS * 48; idx += 64 * DL_TNS_WAVES) {
+        const int pt = idx / 48, col = idx % 48;
+        const int m = pt >> 4, prow = pt & 15, tl = col >> 4, c16 = col & 15;
+        const int r = prow >> 2, g = prow & 3;                // accumulator row = g + 4 r  (g = lane >> 4)
+        double sum = 0.;
+        for (int wv = 0; wv < DL_TNS_WAVES; ++wv) sum += red[(((size_t)(wv * 2 + m) * 3 + tl) * 4 + r) * 64 + g * 16 + c16];
+        sums[idx] = sum;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < DL_TNS_PTS * DL_TNS_NTAB; idx += 64 * DL_TNS_WAVES) {
+        const int pt = idx >> 5, r = idx & 31;
+        const int64_t b = (int64_t)tile * DL_TNS_PTS + pt;
+        const double v = dl_tns_table_entry(r, sums + pt * 48, sums + pt * 48 + 32, qq[b], t.sumw);
+        tables[((size_t)b * t.n11 + ik) * DL_TNS_NTAB + r] = v;
+    }
+}
+
+// Assembly: one workgroup per point.  LDS: Q [6][n11] | M [6][n11] | cvec [6][32] | mu records | out [n_in + n_kin]
+enum { DL_TA_QPER = 0, DL_TA_JAC, DL_TA_SIGV, DL_TA_SN0ND, DL_TA_MU = 8 };   // per mu: factorap, mu'^2 (then weights [n_ell + 1])
+
+__global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsDev t, const double* __restrict__ theta, int n_params, const double* __restrict__ tables,
+                                                              double* __restrict__ power, int64_t ld_power) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int64_t b = blockIdx.x;
+    const double* th = theta + (size_t)b * n_params;
+    const int n11 = t.n11, nq = (o.n_ct > 0) ? 6 : 5;
+    double* Q = lds;
+    double* M = Q + (size_t)6 * n11;
+    double* cvec = M + (size_t)6 * n11;
+    double* sc = cvec + 6 * 32;
+    double* murec = sc + 8;                                   // [n_mu][8]: factorap, mu'^2, w_ell (n_ell <= 5), w_ell0
+    double* out = murec + (size_t)8 * DL_MAX_MU;              // [n_in] then dd0 [n_kin]
+    double qpar, qper;
+    dl_ap_qparqper(o, th, qpar, qper);
+    const double f = o.f_fid * dl_get(o.df, th);
+    const double jac = 1. / (qpar * qper * qper);
+    if (tid < 6 * 32) cvec[tid] = dl_tns_combine_coef(tid >> 5, tid & 31, f, dl_get(o.b1X, th), dl_get(o.b2, th), dl_get(o.bs, th), dl_get(o.b3, th));
+    if (tid >= 192 && tid < 192 + o.n_mu) {
+        const int m = tid - 192;
+        const double mu = o.mu[m], rq = qper / qpar;
+        const double x = 1. + mu * mu * (rq * rq - 1.);       // factorap^2 (tgc/base.py:216-222)
+        murec[8 * m] = sqrt(x);
+        murec[8 * m + 1] = mu * mu * rq * rq / x;
+        for (int l = 0; l < DL_MAX_ELL; ++l) murec[8 * m + 2 + l] = l < o.n_ell ? jac * o.wmu[l * o.n_mu + m] : 0.;
+        murec[8 * m + 7] = o.ell0 >= 0 ? jac * o.wmu[o.ell0 * o.n_mu + m] : 0.;
+    }
+    __syncthreads();
+    const double* tb = tables + (size_t)b * n11 * DL_TNS_NTAB;
+    for (int i = tid; i < n11; i += nthr) {
+        double v[DL_TNS_NTAB];
+        const dl_tns_double4* src = reinterpret_cast<const dl_tns_double4*>(tb + (size_t)i * DL_TNS_NTAB);
+#pragma unroll
+        for (int r4 = 0; r4 < DL_TNS_NTAB / 4; ++r4) { const dl_tns_double4 x4 = src[r4]; v[4 * r4] = x4.x; v[4 * r4 + 1] = x4.y; v[4 * r4 + 2] = x4.z; v[4 * r4 + 3] = x4.w; }
+        for (int n = 0; n < nq; ++n) {
+            double s = 0.;
+#pragma unroll
+            for (int r = 0; r < 29; ++r) s = fma(cvec[n * 32 + r], v[r], s);
+            Q[(size_t)n * n11 + i] = s;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n11; i += nthr) {                   // second derivatives of the not-a-knot splines: M = S Q
+        double a[6] = {0., 0., 0., 0., 0., 0.};
+        for (int j = 0; j < n11; ++j) {
+            const double s = t.spT[(size_t)j * n11 + i];
+            for (int n = 0; n < nq; ++n) a[n] = fma(s, Q[(size_t)n * n11 + j], a[n]);
+        }
+        for (int n = 0; n < nq; ++n) M[(size_t)n * n11 + i] = a[n];
+    }
+    __syncthreads();
+    const double sigmav = dl_get(o.sigmav, th), sn0nd = dl_get(o.sn0, th) / o.nd;
+    for (int ik = tid; ik < o.n_kin; ik += nthr) {
+        double p[DL_MAX_ELL] = {0., 0., 0., 0., 0.}, dd0 = 0.;
+        const double kq = o.kin[ik] / qper;
+        for (int m = 0; m < o.n_mu; ++m) {
+            const double kap = kq * murec[8 * m], m2 = murec[8 * m + 1];
+            int i = (int)floor((kap - t.k11_0) * t.inv_dk11);
+            i = i < 0 ? 0 : (i > n11 - 2 ? n11 - 2 : i);
+            const double x = log10(kap), xl = t.x11[i], xr = t.x11[i + 1], h = xr - xl;
+            const double a = (xr - x) / h, bb = (x - xl) / h;
+            const double ca = (a * a * a - a) * h * h / 6., cb = (bb * bb * bb - bb) * h * h / 6.;
+            double v[6];
+            for (int n = 0; n < nq; ++n) {
+                const double* Qn = Q + (size_t)n * n11; const double* Mn = M + (size_t)n * n11;
+                v[n] = a * Qn[i] + bb * Qn[i + 1] + ca * Mn[i] + cb * Mn[i + 1];
+            }
+            const double sk = sigmav * kap, s2 = sk * sk * m2;   // (sigmav kap muap)^2
+            const double damp = t.fog == 0 ? 1. / ((1. + s2 / 2.) * (1. + s2 / 2.)) : exp(-s2);   // full_shape.py:870-873
+            const double pkmu = damp * (v[0] + m2 * (v[1] + m2 * (v[2] + m2 * (v[3] + m2 * v[4]))));
+            for (int l = 0; l < DL_MAX_ELL; ++l) p[l] = fma(murec[8 * m + 2 + l], pkmu, p[l]);
+            if (nq == 6) dd0 = fma(murec[8 * m + 7], damp * v[5], dd0);
+        }
+        for (int l = 0; l < o.n_ell; ++l) {
+            double val = p[l] + sn0nd;                          // full_shape.py:961: on EVERY multipole
+            const size_t idx = (size_t)l * o.n_kin + ik;
+            for (int c = 0; c < o.n_ct; ++c) val += o.ct_matrix[idx * o.n_ct + c] * 0.5 * (dl_get(o.ct_in[c][0], th) + dl_get(o.ct_in[c][1], th)) * dd0;   // full_shape.py:630, 633
+            for (int c = 0; c < o.n_sn; ++c) val += o.sn_matrix[idx * o.n_sn + c] * dl_get(o.sn_in[c], th) / o.nd;                                         // full_shape.py:631, 634
+            out[idx] = val;
+        }
+        if (nq == 6) out[o.n_in + ik] = dd0;
+    }
+    __syncthreads();
+    double* power_row = power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset;
+    for (int idx = tid; idx < o.n_in; idx += nthr) power_row[idx] = out[idx];
+    if (o.n_var > 0 && o.n_ct > 0) {                            // derivative rows of analytically solved counter terms (as dl_fs_phase4)
+        for (int c = 0; c < o.n_ct; ++c)
+            for (int tt = 0; tt < 2; ++tt) {
+                const int slot = o.marg_ct_slot[c][tt];
+                if (slot < 0) continue;
+                if (tt == 1 && o.marg_ct_slot[c][0] == slot) continue;
+                const double wgt = (o.marg_ct_slot[c][0] == o.marg_ct_slot[c][1]) ? 1. : 0.5;
+                double* drow = power_row + (size_t)(1 + slot) * ld_power;
+                for (int idx = tid; idx < o.n_in; idx += nthr) drow[idx] = wgt * o.ct_matrix[(size_t)idx * o.n_ct + c] * out[o.n_in + idx % o.n_kin];
+            }
+    }
+}
+
+static size_t dl_tns_assemble_shared(const DlObsDev& o, const DlTnsDev& t) {
+    return ((size_t)12 * t.n11 + 6 * 32 + 8 + (size_t)8 * DL_MAX_MU + o.n_in + o.n_kin) * sizeof(double);
+}
+
+// copies the 29 used entries of the loop kernel's records into [B][29][n11] (diagnostics / parity)
+__global__ void dl_tns_tables_kernel(const double* __restrict__ rec, int n11, int64_t B, double* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * 29 * n11) return;
+    const int i = (int)(idx % n11), r = (int)((idx / n11) % 29);
+    const int64_t b = idx / ((int64_t)29 * n11);
+    out[idx] = rec[((size_t)b * n11 + i) * DL_TNS_NTAB + r];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+static T* tns_alloc(DlTnsPlan* plan, size_t n, const T* host = nullptr) {
+    T* dev = nullptr;
+    if (hipMalloc((void**)&dev, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    plan->allocs.push_back(dev);
+    plan->bytes += n * sizeof(T);
+    if (host && hipMemcpy(dev, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (!host && hipMemset(dev, 0, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    return dev;
+}
+
+DlTnsPlan* dl_tns_create(const double* k11, int n11, const double* q, int n_q, const double* mus, const double* wmus, int n_mu, int fog, const char** err) {
+    static std::string msg;
+    auto fail = [&](DlTnsPlan* plan, const std::string& m) { msg = m; if (err) *err = msg.c_str(); dl_tns_destroy(plan); return (DlTnsPlan*)nullptr; };
+    if (n11 < 5 || n_q < 4 || n_mu < 1 || n_mu > DL_TNS_MAX_MU) return fail(nullptr, "tns: table / template / cosine grid sizes out of range");
+    for (int i = 0; i + 1 < n_q; ++i) if (!(q[i + 1] > q[i])) return fail(nullptr, "tns: template wavenumbers must increase");
+    if (!(k11[0] > q[0]) || !(k11[n11 - 1] < q[n_q - 1])) return fail(nullptr, "tns: table wavenumbers must lie inside the template's range (full_shape.py:29, 875)");
+    DlTnsPlan* plan = new DlTnsPlan();
+    DlTnsDev& t = plan->dev;
+    std::memset(&t, 0, sizeof(t));
+    t.n11 = n11; t.n_q = n_q; t.nqp = (n_q + 3) & ~3; t.n_mu = n_mu; t.K = n_mu * t.nqp; t.fog = fog;
+    t.k11_0 = k11[0]; t.inv_dk11 = (n11 - 1) / (k11[n11 - 1] - k11[0]);
+    for (int i = 0; i + 1 < n11; ++i)
+        if (std::fabs((k11[i + 1] - k11[i]) * t.inv_dk11 - 1.) > 1e-9) return fail(plan, "tns: table wavenumbers must be uniformly spaced (full_shape.py:875)");
+    std::vector<double> x11(n11), qp(t.nqp), jq(t.nqp, 0.), mw(2 * n_mu);
+    for (int i = 0; i < n11; ++i) x11[i] = std::log10(k11[i]);
+    for (int j = 0; j < t.nqp; ++j) qp[j] = q[j < n_q ? j : n_q - 1];
+    const double pi = 3.14159265358979323846;
+    for (int j = 0; j < n_q; ++j) {   // trapezoidal weights (utils.py:620-622) times q^2 / (4 pi^2) (full_shape.py:753)
+        const double wq = (j == 0 ? q[1] - q[0] : j == n_q - 1 ? q[n_q - 1] - q[n_q - 2] : q[j + 1] - q[j - 1]) / 2.;
+        jq[j] = q[j] * q[j] * wq / (4. * pi * pi);
+    }
+    t.sumw = 0.;
+    for (int m = 0; m < n_mu; ++m) { mw[m] = mus[m]; mw[n_mu + m] = wmus[m]; t.sumw += wmus[m]; }
+    // operator y -> second derivatives of the not-a-knot spline on x11 (transposed): columns from unit vectors through the same sweeps the templates use
+    DlSplineSetup sp;
+    std::string serr;
+    if (!dl_spline_setup(x11, sp, serr)) return fail(plan, "tns: " + serr);
+    std::vector<double> spT((size_t)n11 * n11), unit(n11, 0.), Mv;
+    for (int j = 0; j < n11; ++j) {
+        unit[j] = 1.;
+        dl_spline_moments_serial(unit, sp, Mv);
+        Mv[0] = sp.end0a * Mv[1] + sp.end0b * Mv[2];
+        Mv[n11 - 1] = sp.end1a * Mv[n11 - 2] + sp.end1b * Mv[n11 - 3];
+        for (int i = 0; i < n11; ++i) spT[(size_t)j * n11 + i] = Mv[i];
+        unit[j] = 0.;
+    }
+    t.k11 = tns_alloc(plan, n11, k11); t.x11 = tns_alloc(plan, n11, x11.data()); t.q = tns_alloc(plan, t.nqp, qp.data()); t.jq = tns_alloc(plan, t.nqp, jq.data());
+    t.mus = tns_alloc(plan, 2 * n_mu, mw.data()); t.spT = tns_alloc(plan, spT.size(), spT.data());
+    int32_t* geomj = tns_alloc<int32_t>(plan, (size_t)n11 * t.K);
+    double* geomw = tns_alloc<double>(plan, (size_t)n11 * t.K * 2);
+    double* coef = tns_alloc<double>(plan, (size_t)n11 * t.K * DL_TNS_NCOL);
+    double* lin = tns_alloc<double>(plan, (size_t)n11 * t.nqp * DL_TNS_NLIN);
+    if (!t.k11 || !t.x11 || !t.q || !t.jq || !t.mus || !t.spT || !geomj || !geomw || !coef || !lin) return fail(plan, "tns: device allocation failed");
+    t.geomj = geomj; t.geomw = geomw; t.coef = coef; t.lin = lin;
+    if (hipDeviceSynchronize() != hipSuccess) return fail(plan, "tns: hipDeviceSynchronize failed");
+    hipLaunchKernelGGL(dl_tns_geometry_kernel, dim3(n11, n_mu), dim3(256), 0, 0, t, geomj, geomw, coef);
+    hipLaunchKernelGGL(dl_tns_geometry_lin_kernel, dim3(n11), dim3(256), 0, 0, t, lin);
+    hipLaunchKernelGGL(dl_tns_geometry_fold_kernel, dim3(n11), dim3(64), 0, 0, t, geomj, geomw, lin);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail(plan, "tns: geometry kernels failed");
+    return plan;
+}
+
+void dl_tns_destroy(DlTnsPlan* plan) {
+    if (!plan) return;
+    for (void* p : plan->allocs) (void)hipFree(p);
+    if (plan->pk) (void)hipFree(plan->pk);
+    if (plan->qq) (void)hipFree(plan->qq);
+    if (plan->tables) (void)hipFree(plan->tables);
+    delete plan;
+}
+
+size_t dl_tns_bytes(const DlTnsPlan* plan) { return plan ? plan->bytes : 0; }
+
+static bool tns_reserve(DlTnsPlan* plan, int64_t pts) {
+    if (pts <= plan->cap_pts) return true;
+    (void)hipDeviceSynchronize();   // (a smaller workspace may still be in use by launches in flight)
+    if (plan->pk) (void)hipFree(plan->pk);
+    if (plan->qq) (void)hipFree(plan->qq);
+    if (plan->tables) (void)hipFree(plan->tables);
+    plan->pk = plan->qq = plan->tables = nullptr;
+    plan->cap_pts = 0;
+    const DlTnsDev& t = plan->dev;
+    if (hipMalloc((void**)&plan->pk, (size_t)t.nqp * pts * sizeof(double)) != hipSuccess || hipMalloc((void**)&plan->qq, (size_t)pts * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&plan->tables, (size_t)pts * t.n11 * DL_TNS_NTAB * sizeof(double)) != hipSuccess) return false;
+    plan->cap_pts = pts;
+    return true;
+}
+
+// pass size: the table records of a pass (n11 x 256 B per point) stay below 1 GiB
+static int64_t tns_pass_points(const DlTnsDev& t) {
+    int64_t pts = ((int64_t)1 << 30) / ((int64_t)t.n11 * DL_TNS_NTAB * 8);
+    pts = pts / DL_TNS_PTS * DL_TNS_PTS;
+    return pts < DL_TNS_PTS ? DL_TNS_PTS : (pts > 8192 ? 8192 : pts);
+}
+
+static bool tns_run_loop(DlTnsPlan* plan, const DlObsDev& obs, const double* theta, int n_params, int64_t nb, hipStream_t stream) {
+    const DlTnsDev& t = plan->dev;
+    const int64_t ldp = (nb + DL_TNS_PTS - 1) / DL_TNS_PTS * DL_TNS_PTS;
+    if (!tns_reserve(plan, ldp)) { dl_set_last_error("tns: workspace allocation failed"); return false; }
+    DL_LAUNCH(dl_tns_pk_kernel, dim3((unsigned)((ldp + 63) / 64)), dim3(256), 0, stream, obs, t, theta, n_params, nb, ldp, plan->pk, plan->qq);
+    const int n_tiles = (int)(ldp / DL_TNS_PTS);
+    const size_t shm = ((size_t)t.nqp * DL_TNS_PTS + (size_t)DL_TNS_PTS * 48) * sizeof(double);
+    const size_t red = (size_t)DL_TNS_WAVES * 2 * 3 * 4 * 64 * sizeof(double);
+    const size_t lds_bytes = std::max(shm, red + (size_t)DL_TNS_PTS * 48 * sizeof(double));
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    const unsigned grid = (unsigned)(((t.n11 + 7) / 8) * n_tiles * 8);
+    DL_LAUNCH(dl_tns_loop_kernel, dim3(grid), dim3(64 * DL_TNS_WAVES), lds_bytes, stream, t, plan->pk, plan->qq, ldp, n_tiles, plan->tables);
+    return true;
+}
+
+void dl_launch_tns(const DlObsDev& obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, hipStream_t stream) {
+    DlTnsPlan* plan = (DlTnsPlan*)obs.tns_plan;
+    if (!plan) { dl_set_last_error("tns: observable without a plan"); return; }
+    const DlTnsDev& t = plan->dev;
+    const int64_t pass = tns_pass_points(t);
+    const size_t shm = dl_tns_assemble_shared(obs, t);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    for (int64_t b0 = 0; b0 < B; b0 += pass) {
+        const int64_t nb = std::min(pass, B - b0);
+        const double* th = theta + (size_t)b0 * n_params;
+        if (!tns_run_loop(plan, obs, th, n_params, nb, stream)) return;
+        DL_LAUNCH(dl_tns_assemble_kernel, dim3((unsigned)nb), dim3(256), shm, stream, obs, t, th, n_params, plan->tables, power + (size_t)b0 * (1 + obs.n_var) * ld_power, ld_power);
+    }
+}
+
+int dl_tns_tables(const DlObsDev& obs, const double* theta, int n_params, int64_t B, double* tables_dev, hipStream_t stream) {
+    DlTnsPlan* plan = (DlTnsPlan*)obs.tns_plan;
+    if (!plan) { dl_set_last_error("tns: observable without a plan"); return 1; }
+    const DlTnsDev& t = plan->dev;
+    const int64_t pass = tns_pass_points(t);
+    for (int64_t b0 = 0; b0 < B; b0 += pass) {
+        const int64_t nb = std::min(pass, B - b0);
+        if (!tns_run_loop(plan, obs, theta + (size_t)b0 * n_params, n_params, nb, stream)) return 1;
+        const int64_t total = nb * 29 * t.n11;
+        hipLaunchKernelGGL(dl_tns_tables_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, plan->tables, t.n11, nb, tables_dev + (size_t)b0 * 29 * t.n11);
+    }
+    return 0;
+}

@@ -267,6 +267,98 @@ class EFTLikeKaiserTracerCorrelationFunctionMultipoles(_CorrelationFunctionFromP
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# TNS one-loop theory: the reference's own perturbation-theory producer (full_shape.py:688-1037)
+# ----------------------------------------------------------------------------------------------------------------------
+_NORM15 = dict(prior=dict(dist='norm', loc=0., scale=15.), ref=dict(dist='norm', loc=0., scale=0.5))
+_TNS_BIAS = {**_B1, 'b2': dict(latex='b_{2}', **_NORM15), 'bs': dict(latex='b_{s}', fixed=True, **_NORM15), 'b3': dict(latex='b_{3}', fixed=True, **_NORM15)}
+_SIGMAV = {'sigmav': dict(prior=dict(dist='norm', loc=0., scale=20., limits=[0., 10.]), ref=dict(dist='norm', loc=0., scale=0.5), latex=r'\sigma_{v}')}
+
+
+class TNSTracerPowerSpectrumMultipoles(KaiserTracerPowerSpectrumMultipoles):
+    r"""
+    TNS (Taruya, Nishimichi & Saito 2010) tracer power spectrum multipoles with one-loop bias terms, as ``TNSPowerSpectrumMultipoles`` +
+    ``TNSTracerPowerSpectrumMultipoles`` compute them (full_shape.py:836-971): the 29 one-loop tables (P22 / P13 of density and velocity, the b2 / bs / b3 terms,
+    the A and B correction terms) on ``k11 = linspace(0.7 k[0], 1.3 k[-1], 1.6 len(k))`` from the template by direct integration (``tns_pt``, 749-833), cubic
+    interpolation to the AP-distorted wavenumbers, Lorentzian or Gaussian finger-of-god damping, Legendre projection, bias combination.  On the device the
+    integration is a batched fp64 MFMA GEMM against geometry tables built once per context (csrc/dl_tns.h).
+
+    Parameters: b1, b2, bs, b3 (bs, b3 fixed by default; ``freedom='max'`` frees them, ``'min'`` fixes them to 0), sn0, sigmav.
+    Options: ``nloop=1``, ``fog='lorentzian' | 'gaussian'``, ``freedom=None | 'max' | 'min'``.
+    """
+    _kind = 4  # DL_THEORY_TNS
+    _klim = (1e-3, 2., 500)   # full_shape.py:855
+    _deterministic_bias_params = ['b1', 'b2', 'bs', 'b3']
+    _stochastic_bias_params = ['sn0']
+    _own_params = {**_TNS_BIAS, **_SN0, **_SIGMAV}
+    _nmu_loop = 10   # cosines of the loop integrals (full_shape.py:757)
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        init = self.init
+        self.nloop = int(init.get('nloop', 1))
+        if self.nloop not in [1]:
+            raise ValueError('nloop must be 1 (1-loop)')    # full_shape.py:860-861
+        self.fog = init.get('fog', 'lorentzian')
+        if self.fog not in ['lorentzian', 'gaussian']:
+            raise ValueError('fog must be lorentzian or gaussian')   # full_shape.py:862-863
+        tracers = init.get('tracers', None)
+        if tracers is not None and not isinstance(tracers, str) and len(set(tracers)) > 1:
+            raise ValueError('cross-correlations are not implemented for the TNS model')   # _with_cross = False (full_shape.py:64)
+        freedom = init.get('freedom', None)
+        fix = []
+        if freedom == 'max':    # full_shape.py:946-955
+            for param in init.params.select(basename=['b1', 'b2', 'bs', 'b3']): param.update(fixed=False)
+            fix += ['alpha6']
+        if freedom == 'min':
+            fix += ['b3', 'bs']
+        for param in init.params.select(basename=fix): param.update(value=0., fixed=True)
+        super(TNSTracerPowerSpectrumMultipoles, self).initialize()
+        self.k11 = np.linspace(self.k[0] * 0.7, self.k[-1] * 1.3, int(len(self.k) * 1.6 + 0.5))   # full_shape.py:875
+        return self
+
+    def _theory_spec(self):
+        spec = super(TNSTracerPowerSpectrumMultipoles, self)._theory_spec()
+        mus, wmus = utils.weights_mu(self._nmu_loop, method='leggauss')
+        spec.update(tns_k11=self.k11, tns_mu=np.asarray(mus, dtype='f8'), tns_wmu=np.asarray(wmus, dtype='f8'), tns_fog=np.array([{'lorentzian': 0, 'gaussian': 1}[self.fog]], dtype='i4'))
+        return spec
+
+    def _input_map(self):
+        toret = super(TNSTracerPowerSpectrumMultipoles, self)._input_map()
+        nsX = multitracer_namespace(self.tracers)[0]
+        nsX = nsX + '.' if nsX else ''
+        for name in ['sigmapar', 'sigmaper']: toret.pop(name, None)
+        toret.update(b2=nsX + 'b2', bs=nsX + 'bs', b3=nsX + 'b3', sigmav='sigmav')
+        return toret
+
+
+class EFTLikeTNSTracerPowerSpectrumMultipoles(TNSTracerPowerSpectrumMultipoles, EFTLikeKaiserTracerPowerSpectrumMultipoles):
+    """TNS multipoles with the EFT-like counter terms ``ct{ell}_2`` (times the projected linear spectrum, monopole) and stochastic terms ``sn{ell}_2``
+    (full_shape.py:996-1014 on the mixin 577-634).  As in the reference's parameter file, there is no ``sigmav`` here (the damping is 1)."""
+    _deterministic_bias_params = ['b1', 'b2', 'bs', 'b3', 'ct0_2', 'ct2_2', 'ct4_2']
+    _stochastic_bias_params = ['sn0', 'sn0_2', 'sn2_2', 'sn4_2']
+    _own_params = {**_TNS_BIAS, **{name: conf for name, conf in EFTLikeKaiserTracerPowerSpectrumMultipoles._own_params.items() if name.startswith(('ct', 'sn'))}}
+
+    def _input_map(self):
+        toret = TNSTracerPowerSpectrumMultipoles._input_map(self)
+        toret.pop('sigmav', None)
+        nsX, nsY, nsC = (ns + '.' if ns else '' for ns in multitracer_namespace(self.tracers))
+        toret['ct'] = [(nsX + name, nsY + name) for name in self.counterterm_params]
+        toret['sn'] = [nsC + name for name in self.stochastic_params]
+        return toret
+
+
+class TNSTracerCorrelationFunctionMultipoles(_CorrelationFunctionFromPowerSpectrum, TNSTracerPowerSpectrumMultipoles):
+    """TNS tracer correlation function multipoles (full_shape.py:974-993): the Hankel transform of the power spectrum multipoles, folded into the window."""
+    _own_params = {**_TNS_BIAS, **_SIGMAV}
+
+
+class EFTLikeTNSTracerCorrelationFunctionMultipoles(_CorrelationFunctionFromPowerSpectrum, EFTLikeTNSTracerPowerSpectrumMultipoles):
+    """EFT-like TNS tracer correlation function multipoles (full_shape.py:1017-1037)."""
+    _own_params = {name: conf for name, conf in EFTLikeTNSTracerPowerSpectrumMultipoles._own_params.items() if not name.startswith('sn')}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # velocileptors-style tracers on top of an EMULATED perturbation-theory node
 # ----------------------------------------------------------------------------------------------------------------------
 def get_physical_stochastic_settings(tracer=None):

@@ -161,6 +161,12 @@ int  dl_eval_logposterior_grad(dl_ctx* ctx, const double* theta_dev, int64_t B, 
 int  dl_eval_theory(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs,
                     double* power_dev, double* tables_dev, void* hip_stream);
 
+/* TNS one-loop theory (obs<i>.theory = 4; reference: tns_kernels / tns_pt / TNSPowerSpectrumMultipoles / TNSTracerPowerSpectrumMultipoles, full_shape.py:688-971):
+ * the 29 loop tables of the points on the table wavenumbers tns_k11, BEFORE the AP distortion / damping / projection -- tables_dev [B, 29, n_k11] in the order of
+ * full_shape.py:882-883 (pk11, pk_dd, pk_b2d, pk_bs2d, pk_sig3sq, pk_b22, pk_b2s2, pk_bs22, pk_dt, pk_b2t, pk_bs2t, pk_tt, A0..A4, B0..B11).  For parity and plots:
+ * dl_eval_batch / dl_eval_logposterior / dl_eval_theory run the same kernels and continue to the multipoles. */
+int  dl_eval_tns_tables(dl_ctx* ctx, const double* theta_dev, int64_t B, int32_t iobs, double* tables_dev, void* hip_stream);
+
 /* Host-pointer conveniences (copy in, evaluate on the default stream, copy out, synchronise):
  * used by the scalar ``likelihood(**params)`` call surface (desilike/base.py:1194-1196). */
 int  dl_eval_batch_host(dl_ctx* ctx, const double* theta, int64_t B,

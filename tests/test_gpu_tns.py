@@ -1,0 +1,141 @@
+"""GPU (-m gpu): the TNS one-loop theory on the device (csrc/dl_tns.hip), through the C ABI, against golden vectors of the reference itself
+(tests/golden/make_tns_fixture.py: the reference's tns_kernels / tns_pt / TNSPowerSpectrumMultipoles / TNSTracerPowerSpectrumMultipoles, full_shape.py:688-971)
+and against the NumPy oracle on seeded points.  Tolerances: 1e-10 on logL (relative above 1); the loop tables to 1e-10 of their largest entry."""
+import numpy as np
+import pytest
+
+from test_oracle_tns import load, tns_oracle_point, FIXTURES
+
+pytestmark = pytest.mark.gpu
+
+
+def spec_from_tns_golden(g):
+    from oracle import np_oracle as oc
+    names = [str(n) for n in g['names']]
+
+    def inp(name, default):
+        return (names.index(name), default) if name in names else (-1, default)
+
+    inputs = {'qpar': inp('qpar', 1.), 'qper': inp('qper', 1.), 'df': inp('df', 1.), 'dm': inp('dm', 0.), 'dn': inp('dn', 0.), 'b1X': inp('b1', 1.), 'b1Y': inp('b1', 1.), 'sn0': inp('sn0', 0.),
+              'b2': inp('b2', 0.), 'bs': inp('bs', 0.), 'b3': inp('b3', 0.), 'sigmav': inp('sigmav', 0.)}
+    mus, wmus = oc.weights_leggauss_sym(10)
+    obs = dict(theory=np.array([4]), template=np.array([1 if str(g['c.template']).startswith('ShapeFit') else 0]), apmode=np.array([0]), transform=np.array([0]), eta=[1. / 3.],
+               f_fid=[float(g['c.f_fid'])], a=[float(g['c.a']) if 'c.a' in g else 0.6], kp=[float(g['c.kp']) if 'c.kp' in g else 0.03], nd=[float(g['c.nd'])],
+               ells_in=np.asarray(g['c.ellsin'], dtype='i4'), kin=g['c.kin'], mu=g['c.mu'], wmu_ell=g['c.wmu_ell'], k_t=g['c.k11'], pk_dd_fid=g['c.pk_dd_fid'],
+               wmatrix=g['c.matrix_full'], kmask=None, offset=None, shotnoise_in=g['c.shotnoisein'], shotnoise_out=g['c.shotnoiseout'], flatdata=g['c.flatdata'],
+               tns_k11=g['k11_table'], tns_mu=mus, tns_wmu=wmus, tns_fog=np.array([{'lorentzian': 0, 'gaussian': 1}[str(g['fog'])]], dtype='i4'))
+    if bool(g['eft']):
+        obs['ct_matrix'], obs['sn_matrix'] = g['c.ct_matrix'], g['c.sn_matrix']
+        ct = [[inp(str(n), 0.)] * 2 for n in g['c.ct_params']]
+        sn = [inp(str(n), 0.) for n in g['c.sn_params']]
+        inputs['ct'] = ([[t[0] for t in row] for row in ct], [[t[1] for t in row] for row in ct])
+        inputs['sn'] = ([t[0] for t in sn], [t[1] for t in sn])
+    obs['inputs'] = inputs
+    return dict(n_params=np.array([len(names)]), priors=g['priors'], precision=g['precision'], observables=[obs])
+
+
+@pytest.fixture(scope='module')
+def contexts():
+    from desilike_amd._lib import Context
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            g = load(name)
+            cache[name] = (g, Context(spec_from_tns_golden(g), device=0))
+        return cache[name]
+
+    yield get
+    for g, ctx in cache.values(): ctx.close()
+
+
+def clean_rows(g, n):
+    theta = g['theta'][:n].copy()
+    for i in range(n):
+        if not np.all(np.isfinite(theta[i])): theta[i] = g['theta'][0]
+    return theta
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_loop_tables_vs_reference(contexts, name):
+    g, ctx = contexts(name)
+    nint = g['int_tables'].shape[0]
+    tables = ctx.eval_tns_tables(clean_rows(g, nint), len(g['k11_table'])).cpu().numpy()
+    for i in range(nint):
+        for r in range(29):
+            ref = g['int_tables'][i][r]
+            assert np.max(np.abs(tables[i, r] - ref)) <= 1e-10 * np.max(np.abs(ref)), (i, r, np.max(np.abs(tables[i, r] - ref)) / np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_power_vs_reference(contexts, name):
+    g, ctx = contexts(name)
+    nint = g['int_power'].shape[0]
+    power = ctx.eval_theory_host(clean_rows(g, nint), iobs=0)
+    ref = g['int_power']
+    assert np.allclose(power, ref, rtol=1e-10, atol=1e-11 * np.abs(ref).max()), np.abs(power - ref).max() / np.abs(ref).max()
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_loglikelihood_vs_reference(contexts, name):
+    g, ctx = contexts(name)
+    loglike, logprior, status, flat = ctx.eval_batch_host(g['theta'], return_flattheory=True)
+    ok = np.isfinite(g['theta']).all(axis=1)
+    tol = 1e-10 * np.maximum(1., np.abs(g['loglikelihood'][ok]))
+    assert (np.abs(loglike[ok] - g['loglikelihood'][ok]) <= tol).all(), (np.abs(loglike[ok] - g['loglikelihood'][ok]) / np.maximum(1., np.abs(g['loglikelihood'][ok]))).max()
+    finite = np.isfinite(g['logprior'])
+    assert np.allclose(logprior[finite], g['logprior'][finite], rtol=1e-13, atol=1e-13)
+    assert np.array_equal(status == 1, np.isneginf(g['logprior']) & ok)
+
+
+def test_vs_oracle_ragged_batch(contexts):
+    """67 seeded points (three 32-point tiles, the last one ragged) against the oracle."""
+    from oracle import np_oracle as oc
+    g, ctx = contexts('tns')
+    names = [str(n) for n in g['names']]
+    rng = np.random.RandomState(7)
+    lo = dict(qpar=0.95, qper=0.95, dm=-0.05, df=0.8, sigmav=0., b1=1., b2=-1., bs=-1., b3=-1., sn0=-0.5)
+    hi = dict(qpar=1.05, qper=1.05, dm=0.05, df=1.2, sigmav=6., b1=3., b2=1., bs=1., b3=1., sn0=0.5)
+    theta = np.column_stack([rng.uniform(lo[n], hi[n], 67) for n in names])
+    loglike, logprior, status = ctx.eval_batch_host(theta)
+    q = g['c.k11']
+    kernels = oc.tns_kernels(g['k11_table'], q, oc.weights_trapz(q))
+    idx = list(range(0, 67, 6)) + [64, 65, 66]
+    ref = np.array([tns_oracle_point(g, theta[i], kernels=kernels) for i in idx])
+    assert (np.abs(loglike[idx] - ref) <= 1e-10 * np.maximum(1., np.abs(ref))).all(), (np.abs(loglike[idx] - ref) / np.maximum(1., np.abs(ref))).max()
+    assert (status == 0).all()
+
+
+def test_host_mirror_matches_oracle():
+    """The mirror of the reference's classes (desilike_amd TNSTracerPowerSpectrumMultipoles + observable + likelihood) compiles to the same pipeline: its
+    log-likelihood at seeded points equals the oracle's on the mirror's own constants."""
+    from oracle import np_oracle as oc
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, TNSTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    theory = TNSTracerPowerSpectrumMultipoles(template=template, fog='gaussian', freedom='max')
+    kedges = np.linspace(0., 0.2, 21)
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'b2': 0.3, 'sigmav': 2.}, kedges=kedges, ells=(0, 2), wmatrix={'resolution': 2}, theory=theory, shotnoise=1e4)
+    rng = np.random.RandomState(5)
+    A = rng.standard_normal((40, 40)) * 50.
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + 1e5 * np.eye(40))
+    like.initialize()
+    names = like.varied_params.names()
+    assert set(['b1', 'b2', 'bs', 'b3', 'sn0', 'sigmav']) <= set(names)
+    theta = np.column_stack([like.varied_params[n].ref.sample(size=5, random_state=rng) if like.varied_params[n].ref.is_proper() else np.full(5, like.varied_params[n].value) for n in names])
+    if 'sigmav' in names: theta[:, names.index('sigmav')] = rng.uniform(0.5, 4., 5)
+    loglike = np.array([like(**dict(zip(names, row))) - like.logprior for row in theta])
+    wm = obs.wmatrix
+    q = template.k
+    k11 = oc.tns_k11(theory.k)
+    kernels = oc.tns_kernels(k11, q, oc.weights_trapz(q))
+    for i, row in enumerate(theta):
+        p = dict(zip(names, row))
+        pk_q = template.pk_dd_fid * oc.shapefit_factor(q, template.kp, template.a, dm=p.get('dm', 0.), dn=p.get('dn', 0.))
+        pt = oc.tns_pktable(theory.k, theory.mu, theory.wmu, q, pk_q, template.f_fid * p.get('df', 1.), qpar=p.get('qpar', 1.), qper=p.get('qper', 1.), sigmav=p['sigmav'], fog='gaussian',
+                            kernels=kernels, k11=k11)
+        power = oc.tns_tracer_power(pt, theory.nd, b1=p['b1'], b2=p['b2'], bs=p['bs'], b3=p['b3'], sn0=p['sn0'])
+        flat = oc.window_apply(power, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout)
+        ref = oc.gaussian_loglikelihood(flat, obs.flatdata, like.precision)[0]
+        assert abs(loglike[i] - ref) <= 1e-10 * max(1., abs(ref)), (i, loglike[i], ref)
