@@ -31,7 +31,7 @@ enum { DL_TL_PK = 0, DL_TL_SIG3, DL_TL_13D, DL_TL_13T, DL_TL_KA0 = 4, DL_TL_EA0 
 
 struct DlTnsDev {
     int32_t n11, n_q, nqp, n_mu;     // table wavenumbers; template wavenumbers (nqp: rounded up to a multiple of 4); loop cosines
-    int32_t K, fog, pad0, pad1;      // K = n_mu * nqp; fog: 0 lorentzian, 1 gaussian (full_shape.py:870-873)
+    int32_t K, fog, Kp, pad1;        // K = n_mu * n_q pairs (mu, q), Kp: rounded up to whole rounds of the loop kernel's waves (zero coefficients); fog: 0 lorentzian, 1 gaussian (full_shape.py:870-873)
     double k11_0, inv_dk11;          // k11 = linspace: interval index of the spline evaluation
     double sumw;                     // sum of the cosine weights
     const double* k11;               // [n11]
@@ -39,9 +39,9 @@ struct DlTnsDev {
     const double* q;                 // [nqp] template wavenumbers (padding: last value)
     const double* jq;                // [nqp] q^2 wq / (4 pi^2) (padding: 0)
     const double* mus;               // [n_mu] loop cosines, then [n_mu] weights
-    const int32_t* geomj;            // [n11][K] j0
-    const double* geomw;             // [n11][K][2] w0, w1
-    const double* coef;              // [n11][K][16][2]: columns c and 16 + c interleaved
+    const int32_t* geomj;            // [n11][Kp][2] j0 (interval of |k - q| in the template's wavenumbers), index of q
+    const double* geomw;             // [n11][Kp][2] w0, w1
+    const double* coef;              // [n11][Kp][16][2]: columns c and 16 + c interleaved
     const double* lin;               // [n11][nqp][16]
     const double* spT;               // [n11][n11] transposed operator y -> second derivatives of the not-a-knot spline on x11
 };

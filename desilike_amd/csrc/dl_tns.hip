@@ -28,23 +28,25 @@ struct DlTnsPlan {
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // geometry (once per context)
 // ---------------------------------------------------------------------------------------------------------------------------------------------
-// bilinear coefficients + interpolation records: one thread per (k, mu, q)
+// bilinear coefficients + interpolation records: one thread per (k, pair (mu, q)); pairs beyond K are padding (zero coefficients)
 __global__ __launch_bounds__(256) void dl_tns_geometry_kernel(DlTnsDev t, int32_t* geomj, double* geomw, double* coef) {
-    const int ik = blockIdx.x, im = blockIdx.y;
-    const double k = t.k11[ik], mu = t.mus[im], wmu = t.mus[t.n_mu + im];
-    for (int iq = threadIdx.x; iq < t.nqp; iq += blockDim.x) {
-        const size_t kappa = (size_t)ik * t.K + (size_t)im * t.nqp + iq;
+    const int ik = blockIdx.x;
+    const double k = t.k11[ik];
+    for (int kap = blockIdx.y * blockDim.x + threadIdx.x; kap < t.Kp; kap += gridDim.y * blockDim.x) {
+        const size_t kappa = (size_t)ik * t.Kp + kap;
         double c[DL_TNS_NCOL];
         for (int i = 0; i < DL_TNS_NCOL; ++i) c[i] = 0.;
-        int j = 0;
+        int j = 0, iq = 0;
         double w0 = 0., w1 = 0.;
-        if (iq < t.n_q) {
+        if (kap < t.K) {
+            const int im = kap / t.n_q;
+            iq = kap % t.n_q;
             DlTnsGeom g;
-            dl_tns_geometry(k, t.q[iq], t.jq[iq], mu, wmu, g);
+            dl_tns_geometry(k, t.q[iq], t.jq[iq], t.mus[im], t.mus[t.n_mu + im], g);
             for (int i = 0; i < 27; ++i) c[i] = g.c[i];
             dl_tns_interp_weights(t.q, t.n_q, g.r, j, w0, w1);
         }
-        geomj[kappa] = j;
+        geomj[2 * kappa] = j; geomj[2 * kappa + 1] = iq;
         geomw[2 * kappa] = w0; geomw[2 * kappa + 1] = w1;
         for (int i = 0; i < 16; ++i) { coef[(kappa * 16 + i) * 2] = c[i]; coef[(kappa * 16 + i) * 2 + 1] = c[16 + i]; }
     }
@@ -87,12 +89,12 @@ __global__ __launch_bounds__(64) void dl_tns_geometry_fold_kernel(DlTnsDev t, co
     const double k = t.k11[ik];
     for (int im = 0; im < t.n_mu; ++im)
         for (int iq = 0; iq < t.n_q; ++iq) {
-            const size_t kappa = (size_t)ik * t.K + (size_t)im * t.nqp + iq;
+            const size_t kappa = (size_t)ik * t.Kp + (size_t)im * t.n_q + iq;
             const double w0 = geomw[2 * kappa], w1 = geomw[2 * kappa + 1];
             if (w0 == 0. && w1 == 0.) continue;
             DlTnsGeom g;
             dl_tns_geometry(k, t.q[iq], t.jq[iq], t.mus[im], t.mus[t.n_mu + im], g);
-            const int j = geomj[kappa];
+            const int j = geomj[2 * kappa];
             lin[((size_t)ik * t.nqp + j) * DL_TNS_NLIN + DL_TL_EA0 + u] += g.ca[i] * w0;
             lin[((size_t)ik * t.nqp + j + 1) * DL_TNS_NLIN + DL_TL_EA0 + u] += g.ca[i] * w1;
         }
@@ -101,7 +103,9 @@ __global__ __launch_bounds__(64) void dl_tns_geometry_fold_kernel(DlTnsDev t, co
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // per evaluation
 // ---------------------------------------------------------------------------------------------------------------------------------------------
-// template of every point at the template's wavenumbers, wavenumber-major: pk [nqp][ldp]; qq [b] = sum_q jq P(q)^2.  64 points per workgroup.
+// template of every point at the template's wavenumbers, wavenumber-major: pk [nqp][ldp]; qq [part][b] = partial sums of sum_q jq P(q)^2 (added in a fixed order by the
+// loop kernel).  Workgroup = 64 points x one of DL_TNS_QPARTS ranges of wavenumbers.
+#define DL_TNS_QPARTS 8
 __global__ __launch_bounds__(256) void dl_tns_pk_kernel(DlObsDev o, DlTnsDev t, const double* __restrict__ theta, int n_params, int64_t B, int64_t ldp,
                                                         double* __restrict__ pk, double* __restrict__ qq) {
     __shared__ double part[4][64];
@@ -110,8 +114,10 @@ __global__ __launch_bounds__(256) void dl_tns_pk_kernel(DlObsDev o, DlTnsDev t, 
     const bool live = b < B;
     const double* th = theta + (size_t)(live ? b : 0) * n_params;
     const double dm_a = dl_get(o.dm, th) / o.a, dn = dl_get(o.dn, th);
+    const int per = (t.nqp + DL_TNS_QPARTS - 1) / DL_TNS_QPARTS;
+    const int j0 = blockIdx.y * per, j1 = min(j0 + per, t.nqp);
     double acc = 0.;
-    for (int j = grp; j < t.nqp; j += 4) {
+    for (int j = j0 + grp; j < j1; j += 4) {
         double v = 0.;
         if (live && j < t.n_q) v = (o.templ == 1) ? o.pk_fid[j] * exp(dm_a * o.sf_th[j] + dn * o.sf_lg[j]) : o.pk_fid[j];   // power_template.py:749
         if (b < ldp) pk[(size_t)j * ldp + b] = v;
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void dl_tns_pk_kernel(DlObsDev o, DlTnsDev t, 
     }
     part[grp][lane] = acc;
     __syncthreads();
-    if (grp == 0 && b < ldp) qq[b] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (grp == 0 && b < ldp) qq[(size_t)blockIdx.y * ldp + b] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 // The loop GEMM: workgroup = (k, 32 points), 8 waves.  LDS: the points' templates [nqp][32]; every wave takes every 8th group of 4 (mu, q) pairs, forms the left
@@ -145,50 +151,83 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
     dl_tns_double4 acc[2][2], accl[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) { acc[m][0] = (dl_tns_double4){0., 0., 0., 0.}; acc[m][1] = acc[m][0]; accl[m] = acc[m][0]; }
-    const int nsteps = t.K / 4;
-    const int32_t* gj = t.geomj + (size_t)ik * t.K + kk;
-    const dl_tns_double2* gw = reinterpret_cast<const dl_tns_double2*>(t.geomw) + (size_t)ik * t.K + kk;
-    const dl_tns_double2* gc = reinterpret_cast<const dl_tns_double2*>(t.coef) + ((size_t)ik * t.K + kk) * 16 + p16;
+    // Every wave takes every 8th group of DL_TNS_UNROLL steps (a step = 4 pairs (mu, q)); Kp holds a whole number of rounds.  Three-stage software pipeline: while
+    // group g is multiplied, the LDS operands of group g + 1 are being read (their interpolation records arrived one iteration ago) and the records / coefficients
+    // of group g + 2 are in flight from L2.
+    typedef int32_t dl_tns_int2 __attribute__((ext_vector_type(2)));
+    struct Rec { dl_tns_int2 j[DL_TNS_UNROLL]; dl_tns_double2 w[DL_TNS_UNROLL], c[DL_TNS_UNROLL]; };
+    struct Raw { double pq[DL_TNS_UNROLL][2], pa[DL_TNS_UNROLL][2], pb[DL_TNS_UNROLL][2]; };
+    struct Lhs { double g[DL_TNS_UNROLL][2]; };
+    const int ngroups = t.Kp / (4 * DL_TNS_UNROLL), rounds = ngroups / DL_TNS_WAVES;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const dl_tns_int2* gj = reinterpret_cast<const dl_tns_int2*>(t.geomj) + (size_t)ik * t.Kp + kk;
+    const dl_tns_double2* gw = reinterpret_cast<const dl_tns_double2*>(t.geomw) + (size_t)ik * t.Kp + kk;
+    const dl_tns_double2* gc = reinterpret_cast<const dl_tns_double2*>(t.coef) + ((size_t)ik * t.Kp + kk) * 16 + p16;
     const double* spt = spk + p16;
-    // groups of DL_TNS_UNROLL steps, software-pipelined: the loads of the next group are in flight while this one is multiplied
-    int32_t j0[DL_TNS_UNROLL], j0n[DL_TNS_UNROLL];
-    dl_tns_double2 w[DL_TNS_UNROLL], wn[DL_TNS_UNROLL], c[DL_TNS_UNROLL], cn[DL_TNS_UNROLL];
-    const int stride = DL_TNS_WAVES * DL_TNS_UNROLL;
-    auto load = [&](int s0, int32_t* jj, dl_tns_double2* ww, dl_tns_double2* cc) {
+    auto load = [&](int round, Rec& r) {
+        const int g = (round < rounds ? round : rounds - 1) * DL_TNS_WAVES + wave_s;   // (past the end: reloaded, not used)
+        const size_t e = (size_t)g * DL_TNS_UNROLL * 4;
+#pragma unroll
+        for (int u = 0; u < DL_TNS_UNROLL; ++u) { r.j[u] = gj[e + 4 * u]; r.w[u] = gw[e + 4 * u]; r.c[u] = gc[(e + 4 * u) * 16]; }
+    };
+    auto read = [&](const Rec& r, Raw& o) {
 #pragma unroll
         for (int u = 0; u < DL_TNS_UNROLL; ++u) {
-            int s = s0 + u;
-            if (s >= nsteps) s = nsteps - 1;            // (tail: reloaded, not used)
-            jj[u] = gj[(size_t)4 * s]; ww[u] = gw[(size_t)4 * s]; cc[u] = gc[(size_t)4 * s * 16];
+            const double* ra = spt + r.j[u].x * DL_TNS_PTS;
+            const double* rq = spt + r.j[u].y * DL_TNS_PTS;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { o.pq[u][m] = rq[16 * m]; o.pa[u][m] = ra[16 * m]; o.pb[u][m] = ra[DL_TNS_PTS + 16 * m]; }
         }
     };
-    int s0 = wave * DL_TNS_UNROLL;
-    if (s0 < nsteps) load(s0, j0, w, c);
-    for (; s0 < nsteps; s0 += stride) {
-        if (s0 + stride < nsteps) load(s0 + stride, j0n, wn, cn);
-        double pq[DL_TNS_UNROLL][2], pa[DL_TNS_UNROLL][2], pb[DL_TNS_UNROLL][2];
+    auto form = [&](const Rec& r, const Raw& o, Lhs& l) {
 #pragma unroll
-        for (int u = 0; u < DL_TNS_UNROLL; ++u) {
-            const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;
-            const int iq = (4 * s) % t.nqp + kk;
-            const double* ra = spt + (size_t)j0[u] * DL_TNS_PTS;
+        for (int u = 0; u < DL_TNS_UNROLL; ++u)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) { pq[u][m] = spt[(size_t)iq * DL_TNS_PTS + 16 * m]; pa[u][m] = ra[16 * m]; pb[u][m] = ra[DL_TNS_PTS + 16 * m]; }
-        }
+            for (int m = 0; m < 2; ++m) l.g[u][m] = o.pq[u][m] * fma(r.w[u].x, o.pa[u][m], r.w[u].y * o.pb[u][m]);
+    };
+    auto multiply = [&](const Rec& r, const Lhs& l) {
 #pragma unroll
-        for (int u = 0; u < DL_TNS_UNROLL; ++u) {
-            if (s0 + u < nsteps) {
+        for (int u = 0; u < DL_TNS_UNROLL; ++u)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const double g = pq[u][m] * fma(w[u].x, pa[u][m], w[u].y * pb[u][m]);
-                    acc[m][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(g, c[u].x, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(g, c[u].y, acc[m][1], 0, 0, 0);
-                }
+            for (int m = 0; m < 2; ++m) {
+                acc[m][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(l.g[u][m], r.c[u].x, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l.g[u][m], r.c[u].y, acc[m][1], 0, 0, 0);
             }
-        }
-#pragma unroll
-        for (int u = 0; u < DL_TNS_UNROLL; ++u) { j0[u] = j0n[u]; w[u] = wn[u]; c[u] = cn[u]; }
+    };
+    // one round: RA is multiplied (its left operand LA was formed one round ago); the LDS operands of RB are read at the start and turned into LB after the MFMAs
+    // have been issued; the records and coefficients of RC are requested from L2.  The roles rotate through three register sets (no copies: a copy would wait for
+    // the load it moves), the scheduling barriers keep the compiler from sinking the requests to their uses.
+#define DL_TNS_ROUND(RA, RB, RC, LA, LB, rnd)                 \
+    load((rnd) + 2, RC);                                       \
+    read(RB, raw);                                             \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    multiply(RA, LA);                                          \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    form(RB, raw, LB);                                         \
+    __builtin_amdgcn_sched_barrier(0);
+    Rec r0, r1, r2;
+    Raw raw;
+    Lhs l0, l1;
+    load(0, r0);
+    load(1, r1);
+    read(r0, raw);
+    form(r0, raw, l0);
+    int round = 0;
+    for (; round + 6 <= rounds; round += 6) {
+        DL_TNS_ROUND(r0, r1, r2, l0, l1, round)
+        DL_TNS_ROUND(r1, r2, r0, l1, l0, round + 1)
+        DL_TNS_ROUND(r2, r0, r1, l0, l1, round + 2)
+        DL_TNS_ROUND(r0, r1, r2, l1, l0, round + 3)
+        DL_TNS_ROUND(r1, r2, r0, l0, l1, round + 4)
+        DL_TNS_ROUND(r2, r0, r1, l1, l0, round + 5)
     }
+    // tail: the same sequence, round by round
+    if (round < rounds) { DL_TNS_ROUND(r0, r1, r2, l0, l1, round) ++round; }
+    if (round < rounds) { DL_TNS_ROUND(r1, r2, r0, l1, l0, round) ++round; }
+    if (round < rounds) { DL_TNS_ROUND(r2, r0, r1, l0, l1, round) ++round; }
+    if (round < rounds) { DL_TNS_ROUND(r0, r1, r2, l1, l0, round) ++round; }
+    if (round < rounds) { DL_TNS_ROUND(r1, r2, r0, l0, l1, round) ++round; }
+#undef DL_TNS_ROUND
     // linear tables: left operand = the templates
     const double* gl = t.lin + ((size_t)ik * t.nqp + kk) * DL_TNS_NLIN + p16;
     for (int s = wave; s < t.nqp / 4; s += DL_TNS_WAVES) {
@@ -219,7 +258,9 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
     for (int idx = tid; idx < DL_TNS_PTS * DL_TNS_NTAB; idx += 64 * DL_TNS_WAVES) {
         const int pt = idx >> 5, r = idx & 31;
         const int64_t b = (int64_t)tile * DL_TNS_PTS + pt;
-        const double v = dl_tns_table_entry(r, sums + pt * 48, sums + pt * 48 + 32, qq[b], t.sumw);
+        double qqv = 0.;
+        for (int p = 0; p < DL_TNS_QPARTS; ++p) qqv += qq[(size_t)p * ldp + b];
+        const double v = dl_tns_table_entry(r, sums + pt * 48, sums + pt * 48 + 32, qqv, t.sumw);
         tables[((size_t)b * t.n11 + ik) * DL_TNS_NTAB + r] = v;
     }
 }
@@ -361,7 +402,8 @@ DlTnsPlan* dl_tns_create(const double* k11, int n11, const double* q, int n_q, c
     DlTnsPlan* plan = new DlTnsPlan();
     DlTnsDev& t = plan->dev;
     std::memset(&t, 0, sizeof(t));
-    t.n11 = n11; t.n_q = n_q; t.nqp = (n_q + 3) & ~3; t.n_mu = n_mu; t.K = n_mu * t.nqp; t.fog = fog;
+    t.n11 = n11; t.n_q = n_q; t.nqp = (n_q + 3) & ~3; t.n_mu = n_mu; t.K = n_mu * n_q; t.fog = fog;
+    { const int round = 4 * DL_TNS_UNROLL * DL_TNS_WAVES; t.Kp = (t.K + round - 1) / round * round; }
     t.k11_0 = k11[0]; t.inv_dk11 = (n11 - 1) / (k11[n11 - 1] - k11[0]);
     for (int i = 0; i + 1 < n11; ++i)
         if (std::fabs((k11[i + 1] - k11[i]) * t.inv_dk11 - 1.) > 1e-9) return fail(plan, "tns: table wavenumbers must be uniformly spaced (full_shape.py:875)");
@@ -390,14 +432,14 @@ DlTnsPlan* dl_tns_create(const double* k11, int n11, const double* q, int n_q, c
     }
     t.k11 = tns_alloc(plan, n11, k11); t.x11 = tns_alloc(plan, n11, x11.data()); t.q = tns_alloc(plan, t.nqp, qp.data()); t.jq = tns_alloc(plan, t.nqp, jq.data());
     t.mus = tns_alloc(plan, 2 * n_mu, mw.data()); t.spT = tns_alloc(plan, spT.size(), spT.data());
-    int32_t* geomj = tns_alloc<int32_t>(plan, (size_t)n11 * t.K);
-    double* geomw = tns_alloc<double>(plan, (size_t)n11 * t.K * 2);
-    double* coef = tns_alloc<double>(plan, (size_t)n11 * t.K * DL_TNS_NCOL);
+    int32_t* geomj = tns_alloc<int32_t>(plan, (size_t)n11 * t.Kp * 2);
+    double* geomw = tns_alloc<double>(plan, (size_t)n11 * t.Kp * 2);
+    double* coef = tns_alloc<double>(plan, (size_t)n11 * t.Kp * DL_TNS_NCOL);
     double* lin = tns_alloc<double>(plan, (size_t)n11 * t.nqp * DL_TNS_NLIN);
     if (!t.k11 || !t.x11 || !t.q || !t.jq || !t.mus || !t.spT || !geomj || !geomw || !coef || !lin) return fail(plan, "tns: device allocation failed");
     t.geomj = geomj; t.geomw = geomw; t.coef = coef; t.lin = lin;
     if (hipDeviceSynchronize() != hipSuccess) return fail(plan, "tns: hipDeviceSynchronize failed");
-    hipLaunchKernelGGL(dl_tns_geometry_kernel, dim3(n11, n_mu), dim3(256), 0, 0, t, geomj, geomw, coef);
+    hipLaunchKernelGGL(dl_tns_geometry_kernel, dim3(n11, 8), dim3(256), 0, 0, t, geomj, geomw, coef);
     hipLaunchKernelGGL(dl_tns_geometry_lin_kernel, dim3(n11), dim3(256), 0, 0, t, lin);
     hipLaunchKernelGGL(dl_tns_geometry_fold_kernel, dim3(n11), dim3(64), 0, 0, t, geomj, geomw, lin);
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail(plan, "tns: geometry kernels failed");
@@ -424,7 +466,7 @@ static bool tns_reserve(DlTnsPlan* plan, int64_t pts) {
     plan->pk = plan->qq = plan->tables = nullptr;
     plan->cap_pts = 0;
     const DlTnsDev& t = plan->dev;
-    if (hipMalloc((void**)&plan->pk, (size_t)t.nqp * pts * sizeof(double)) != hipSuccess || hipMalloc((void**)&plan->qq, (size_t)pts * sizeof(double)) != hipSuccess ||
+    if (hipMalloc((void**)&plan->pk, (size_t)t.nqp * pts * sizeof(double)) != hipSuccess || hipMalloc((void**)&plan->qq, (size_t)DL_TNS_QPARTS * pts * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&plan->tables, (size_t)pts * t.n11 * DL_TNS_NTAB * sizeof(double)) != hipSuccess) return false;
     plan->cap_pts = pts;
     return true;
@@ -441,7 +483,7 @@ static bool tns_run_loop(DlTnsPlan* plan, const DlObsDev& obs, const double* the
     const DlTnsDev& t = plan->dev;
     const int64_t ldp = (nb + DL_TNS_PTS - 1) / DL_TNS_PTS * DL_TNS_PTS;
     if (!tns_reserve(plan, ldp)) { dl_set_last_error("tns: workspace allocation failed"); return false; }
-    DL_LAUNCH(dl_tns_pk_kernel, dim3((unsigned)((ldp + 63) / 64)), dim3(256), 0, stream, obs, t, theta, n_params, nb, ldp, plan->pk, plan->qq);
+    DL_LAUNCH(dl_tns_pk_kernel, dim3((unsigned)((ldp + 63) / 64), DL_TNS_QPARTS), dim3(256), 0, stream, obs, t, theta, n_params, nb, ldp, plan->pk, plan->qq);
     const int n_tiles = (int)(ldp / DL_TNS_PTS);
     const size_t shm = ((size_t)t.nqp * DL_TNS_PTS + (size_t)DL_TNS_PTS * 48) * sizeof(double);
     const size_t red = (size_t)DL_TNS_WAVES * 2 * 3 * 4 * 64 * sizeof(double);
