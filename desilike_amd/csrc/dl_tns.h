@@ -19,7 +19,8 @@
 
 #define DL_TNS_NCOL 32        // bilinear tables per k (27 used)
 #define DL_TNS_NLIN 16        // linear tables per k (12 used)
-#define DL_TNS_NTAB 32        // table entries per (point, k) written by the loop kernel (29 used): full_shape.py:882-883 order
+#define DL_TNS_NTAB 29        // tables per k, in the order of full_shape.py:882-883
+#define DL_TNS_NREC 48        // sums per (point, k) written by the loop kernel: 32 bilinear, 16 linear
 #define DL_TNS_PTS 32         // points per workgroup of the loop kernel
 #define DL_TNS_MAX_MU 16
 

@@ -21,7 +21,8 @@ struct DlTnsPlan {
     int64_t cap_pts = 0;
     double* pk = nullptr;       // [nqp][cap_pts]
     double* qq = nullptr;       // [cap_pts]
-    double* tables = nullptr;   // [cap_pts][n11][DL_TNS_NTAB]
+    double* tables = nullptr;   // [cap_pts][n11][DL_TNS_NREC] sums of the loop kernel
+    int64_t ldp = 0;            // leading dimension of pk / qq at the last launch
     std::string err;
 };
 
@@ -128,23 +129,32 @@ __global__ __launch_bounds__(256) void dl_tns_pk_kernel(DlObsDev o, DlTnsDev t, 
     if (grp == 0 && b < ldp) qq[(size_t)blockIdx.y * ldp + b] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
-// The loop GEMM: workgroup = (k, 32 points), 8 waves.  LDS: the points' templates [nqp][32]; every wave takes every 8th group of 4 (mu, q) pairs, forms the left
-// operand of its two 16-point tiles in registers and multiplies it with the [4 x 32] coefficient block it loaded from L2 (4 MFMA per step); then the linear tables
-// (left operand = the templates themselves); the 8 partial accumulators are summed in wave order through LDS and the 29 table entries written.
+// The loop GEMM.  LDS: the templates of 32 points [nqp][32]; a wave forms the left operand of its two 16-point tiles in registers and multiplies it with the [4 x 32]
+// coefficient block it loaded from L2 (4 MFMA per step of 4 pairs (mu, q)); then the linear tables (left operand = the templates themselves).  Two ways of dealing
+// the work to the 8 waves of a workgroup:
+//   WAVEK = true   every wave owns one table wavenumber (8 per workgroup) and runs the whole pair list: no reduction, no barrier after the templates have landed,
+//                  the template tile is loaded once per 8 wavenumbers -- used when that still gives every CU a workgroup;
+//   WAVEK = false  one wavenumber per workgroup, the waves take every 8th round of the pair list and their partial accumulators are summed in wave order through
+//                  LDS -- small batches.
+// Output: the raw sums [point][k][48]; the assembly kernel turns them into the 29 tables.
 #define DL_TNS_WAVES 8
 #define DL_TNS_UNROLL 4
 
-__global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev t, const double* __restrict__ pk, const double* __restrict__ qq, int64_t ldp, int n_tiles,
-                                                                       double* __restrict__ tables) {
+template <bool WAVEK>
+__global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev t, const double* __restrict__ pk, int64_t ldp, int n_tiles, double* __restrict__ sums_out) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    // workgroups of one k share an XCD (consecutive workgroup ids go round the 8 XCDs): its coefficients are fetched from HBM once
+    // workgroups of one (group of) k share an XCD (consecutive workgroup ids go round the 8 XCDs): the coefficients are fetched from HBM once
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int ik = (slot / n_tiles) * 8 + xcd, tile = slot % n_tiles;
-    if (ik >= t.n11) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int kgroup = (slot / n_tiles) * 8 + xcd, tile = slot % n_tiles;
+    const int ik_raw = WAVEK ? kgroup * DL_TNS_WAVES + wave_s : kgroup;
+    if (!WAVEK && ik_raw >= t.n11) return;
+    if (WAVEK && kgroup * DL_TNS_WAVES >= t.n11) return;
+    const bool live = ik_raw < t.n11;                        // (WAVEK: waves beyond the last wavenumber repeat it and do not store)
+    const int ik = live ? ik_raw : t.n11 - 1;
     const int p16 = lane & 15, kk = lane >> 4;
     double* spk = lds;                                       // [nqp][32]
-    double* sums = lds + (size_t)t.nqp * DL_TNS_PTS;         // [32][48]
     for (int idx = tid; idx < t.nqp * DL_TNS_PTS; idx += 64 * DL_TNS_WAVES)
         spk[idx] = pk[(size_t)(idx >> 5) * ldp + (size_t)tile * DL_TNS_PTS + (idx & 31)];
     __syncthreads();
@@ -158,14 +168,14 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
     struct Rec { dl_tns_int2 j[DL_TNS_UNROLL]; dl_tns_double2 w[DL_TNS_UNROLL], c[DL_TNS_UNROLL]; };
     struct Raw { double pq[DL_TNS_UNROLL][2], pa[DL_TNS_UNROLL][2], pb[DL_TNS_UNROLL][2]; };
     struct Lhs { double g[DL_TNS_UNROLL][2]; };
-    const int ngroups = t.Kp / (4 * DL_TNS_UNROLL), rounds = ngroups / DL_TNS_WAVES;
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int ngroups = t.Kp / (4 * DL_TNS_UNROLL), rounds = WAVEK ? ngroups : ngroups / DL_TNS_WAVES;
     const dl_tns_int2* gj = reinterpret_cast<const dl_tns_int2*>(t.geomj) + (size_t)ik * t.Kp + kk;
     const dl_tns_double2* gw = reinterpret_cast<const dl_tns_double2*>(t.geomw) + (size_t)ik * t.Kp + kk;
     const dl_tns_double2* gc = reinterpret_cast<const dl_tns_double2*>(t.coef) + ((size_t)ik * t.Kp + kk) * 16 + p16;
     const double* spt = spk + p16;
     auto load = [&](int round, Rec& r) {
-        const int g = (round < rounds ? round : rounds - 1) * DL_TNS_WAVES + wave_s;   // (past the end: reloaded, not used)
+        const int rr = round < rounds ? round : rounds - 1;                            // (past the end: reloaded, not used)
+        const int g = WAVEK ? rr : rr * DL_TNS_WAVES + wave_s;
         const size_t e = (size_t)g * DL_TNS_UNROLL * 4;
 #pragma unroll
         for (int u = 0; u < DL_TNS_UNROLL; ++u) { r.j[u] = gj[e + 4 * u]; r.w[u] = gw[e + 4 * u]; r.c[u] = gc[(e + 4 * u) * 16]; }
@@ -230,10 +240,22 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
 #undef DL_TNS_ROUND
     // linear tables: left operand = the templates
     const double* gl = t.lin + ((size_t)ik * t.nqp + kk) * DL_TNS_NLIN + p16;
-    for (int s = wave; s < t.nqp / 4; s += DL_TNS_WAVES) {
+    for (int s = WAVEK ? 0 : wave_s; s < t.nqp / 4; s += WAVEK ? 1 : DL_TNS_WAVES) {
         const double cl = gl[(size_t)4 * s * DL_TNS_NLIN];
 #pragma unroll
         for (int m = 0; m < 2; ++m) accl[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(spt[(size_t)(4 * s + kk) * DL_TNS_PTS + 16 * m], cl, accl[m], 0, 0, 0);
+    }
+    if (WAVEK) {   // accumulator element r of lane (kk, p16): point 16 m + kk + 4 r, column p16
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double* rec = sums_out + (((size_t)tile * DL_TNS_PTS + 16 * m + kk + 4 * r) * t.n11 + ik) * DL_TNS_NREC + p16;
+                    rec[0] = acc[m][0][r]; rec[16] = acc[m][1][r]; rec[32] = accl[m][r];
+                }
+        }
+        return;
     }
     __syncthreads();                                         // every wave is done with the templates: their space takes the partial accumulators
     double* red = lds;                                       // [wave][m][tile3][r][lane]
@@ -246,30 +268,21 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
             red[(((size_t)(wave * 2 + m) * 3 + 2) * 4 + r) * 64 + lane] = accl[m][r];
         }
     __syncthreads();
-    for (int idx = tid; idx < DL_TNS_PTS * 48; idx += 64 * DL_TNS_WAVES) {
-        const int pt = idx / 48, col = idx % 48;
+    for (int idx = tid; idx < DL_TNS_PTS * DL_TNS_NREC; idx += 64 * DL_TNS_WAVES) {
+        const int pt = idx / DL_TNS_NREC, col = idx % DL_TNS_NREC;
         const int m = pt >> 4, prow = pt & 15, tl = col >> 4, c16 = col & 15;
         const int r = prow >> 2, g = prow & 3;                // accumulator row = g + 4 r  (g = lane >> 4)
         double sum = 0.;
         for (int wv = 0; wv < DL_TNS_WAVES; ++wv) sum += red[(((size_t)(wv * 2 + m) * 3 + tl) * 4 + r) * 64 + g * 16 + c16];
-        sums[idx] = sum;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < DL_TNS_PTS * DL_TNS_NTAB; idx += 64 * DL_TNS_WAVES) {
-        const int pt = idx >> 5, r = idx & 31;
-        const int64_t b = (int64_t)tile * DL_TNS_PTS + pt;
-        double qqv = 0.;
-        for (int p = 0; p < DL_TNS_QPARTS; ++p) qqv += qq[(size_t)p * ldp + b];
-        const double v = dl_tns_table_entry(r, sums + pt * 48, sums + pt * 48 + 32, qqv, t.sumw);
-        tables[((size_t)b * t.n11 + ik) * DL_TNS_NTAB + r] = v;
+        sums_out[(((size_t)tile * DL_TNS_PTS + pt) * t.n11 + ik) * DL_TNS_NREC + col] = sum;
     }
 }
 
 // Assembly: one workgroup per point.  LDS: Q [6][n11] | M [6][n11] | cvec [6][32] | mu records | out [n_in + n_kin]
 enum { DL_TA_QPER = 0, DL_TA_JAC, DL_TA_SIGV, DL_TA_SN0ND, DL_TA_MU = 8 };   // per mu: factorap, mu'^2 (then weights [n_ell + 1])
 
-__global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsDev t, const double* __restrict__ theta, int n_params, const double* __restrict__ tables,
-                                                              double* __restrict__ power, int64_t ld_power) {
+__global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsDev t, const double* __restrict__ theta, int n_params, const double* __restrict__ raw,
+                                                              const double* __restrict__ qq, int64_t ldp, double* __restrict__ power, int64_t ld_power) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int64_t b = blockIdx.x;
@@ -296,12 +309,16 @@ __global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsD
         murec[8 * m + 7] = o.ell0 >= 0 ? jac * o.wmu[o.ell0 * o.n_mu + m] : 0.;
     }
     __syncthreads();
-    const double* tb = tables + (size_t)b * n11 * DL_TNS_NTAB;
+    const double* tb = raw + (size_t)b * n11 * DL_TNS_NREC;
+    double qqv = 0.;
+    for (int p = 0; p < DL_TNS_QPARTS; ++p) qqv += qq[(size_t)p * ldp + b];
     for (int i = tid; i < n11; i += nthr) {
-        double v[DL_TNS_NTAB];
-        const dl_tns_double4* src = reinterpret_cast<const dl_tns_double4*>(tb + (size_t)i * DL_TNS_NTAB);
+        double rec[DL_TNS_NREC], v[DL_TNS_NTAB];
+        const dl_tns_double4* src = reinterpret_cast<const dl_tns_double4*>(tb + (size_t)i * DL_TNS_NREC);
 #pragma unroll
-        for (int r4 = 0; r4 < DL_TNS_NTAB / 4; ++r4) { const dl_tns_double4 x4 = src[r4]; v[4 * r4] = x4.x; v[4 * r4 + 1] = x4.y; v[4 * r4 + 2] = x4.z; v[4 * r4 + 3] = x4.w; }
+        for (int r4 = 0; r4 < DL_TNS_NREC / 4; ++r4) { const dl_tns_double4 x4 = src[r4]; rec[4 * r4] = x4.x; rec[4 * r4 + 1] = x4.y; rec[4 * r4 + 2] = x4.z; rec[4 * r4 + 3] = x4.w; }
+#pragma unroll
+        for (int r = 0; r < DL_TNS_NTAB; ++r) v[r] = dl_tns_table_entry(r, rec, rec + 32, qqv, t.sumw);
         for (int n = 0; n < nq; ++n) {
             double s = 0.;
 #pragma unroll
@@ -370,13 +387,16 @@ static size_t dl_tns_assemble_shared(const DlObsDev& o, const DlTnsDev& t) {
     return ((size_t)12 * t.n11 + 6 * 32 + 8 + (size_t)8 * DL_MAX_MU + o.n_in + o.n_kin) * sizeof(double);
 }
 
-// copies the 29 used entries of the loop kernel's records into [B][29][n11] (diagnostics / parity)
-__global__ void dl_tns_tables_kernel(const double* __restrict__ rec, int n11, int64_t B, double* __restrict__ out) {
+// the 29 tables [B][29][n11] from the loop kernel's sums (diagnostics / parity)
+__global__ void dl_tns_tables_kernel(DlTnsDev t, const double* __restrict__ raw, const double* __restrict__ qq, int64_t ldp, int64_t B, double* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * 29 * n11) return;
-    const int i = (int)(idx % n11), r = (int)((idx / n11) % 29);
-    const int64_t b = idx / ((int64_t)29 * n11);
-    out[idx] = rec[((size_t)b * n11 + i) * DL_TNS_NTAB + r];
+    if (idx >= B * DL_TNS_NTAB * t.n11) return;
+    const int i = (int)(idx % t.n11), r = (int)((idx / t.n11) % DL_TNS_NTAB);
+    const int64_t b = idx / ((int64_t)DL_TNS_NTAB * t.n11);
+    double qqv = 0.;
+    for (int p = 0; p < DL_TNS_QPARTS; ++p) qqv += qq[(size_t)p * ldp + b];
+    const double* rec = raw + ((size_t)b * t.n11 + i) * DL_TNS_NREC;
+    out[idx] = dl_tns_table_entry(r, rec, rec + 32, qqv, t.sumw);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
@@ -467,14 +487,14 @@ static bool tns_reserve(DlTnsPlan* plan, int64_t pts) {
     plan->cap_pts = 0;
     const DlTnsDev& t = plan->dev;
     if (hipMalloc((void**)&plan->pk, (size_t)t.nqp * pts * sizeof(double)) != hipSuccess || hipMalloc((void**)&plan->qq, (size_t)DL_TNS_QPARTS * pts * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&plan->tables, (size_t)pts * t.n11 * DL_TNS_NTAB * sizeof(double)) != hipSuccess) return false;
+        hipMalloc((void**)&plan->tables, (size_t)pts * t.n11 * DL_TNS_NREC * sizeof(double)) != hipSuccess) return false;
     plan->cap_pts = pts;
     return true;
 }
 
 // pass size: the table records of a pass (n11 x 256 B per point) stay below 1 GiB
 static int64_t tns_pass_points(const DlTnsDev& t) {
-    int64_t pts = ((int64_t)1 << 30) / ((int64_t)t.n11 * DL_TNS_NTAB * 8);
+    int64_t pts = ((int64_t)1 << 30) / ((int64_t)t.n11 * DL_TNS_NREC * 8);
     pts = pts / DL_TNS_PTS * DL_TNS_PTS;
     return pts < DL_TNS_PTS ? DL_TNS_PTS : (pts > 8192 ? 8192 : pts);
 }
@@ -484,14 +504,26 @@ static bool tns_run_loop(DlTnsPlan* plan, const DlObsDev& obs, const double* the
     const int64_t ldp = (nb + DL_TNS_PTS - 1) / DL_TNS_PTS * DL_TNS_PTS;
     if (!tns_reserve(plan, ldp)) { dl_set_last_error("tns: workspace allocation failed"); return false; }
     DL_LAUNCH(dl_tns_pk_kernel, dim3((unsigned)((ldp + 63) / 64), DL_TNS_QPARTS), dim3(256), 0, stream, obs, t, theta, n_params, nb, ldp, plan->pk, plan->qq);
+    plan->ldp = ldp;
     const int n_tiles = (int)(ldp / DL_TNS_PTS);
-    const size_t shm = ((size_t)t.nqp * DL_TNS_PTS + (size_t)DL_TNS_PTS * 48) * sizeof(double);
-    const size_t red = (size_t)DL_TNS_WAVES * 2 * 3 * 4 * 64 * sizeof(double);
-    const size_t lds_bytes = std::max(shm, red + (size_t)DL_TNS_PTS * 48 * sizeof(double));
+    const size_t tmpl = (size_t)t.nqp * DL_TNS_PTS * sizeof(double), red = (size_t)DL_TNS_WAVES * 2 * 3 * 4 * 64 * sizeof(double);
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-    const unsigned grid = (unsigned)(((t.n11 + 7) / 8) * n_tiles * 8);
-    DL_LAUNCH(dl_tns_loop_kernel, dim3(grid), dim3(64 * DL_TNS_WAVES), lds_bytes, stream, t, plan->pk, plan->qq, ldp, n_tiles, plan->tables);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    // one wavenumber per wave when that still fills the chip (DL_TNS_WAVEK=0 / 1 forces a variant: diagnostics)
+    static const char* force = getenv("DL_TNS_WAVEK");
+    const int kgroups = (t.n11 + DL_TNS_WAVES - 1) / DL_TNS_WAVES;
+    const bool wavek = force ? atoi(force) != 0 : (int64_t)kgroups * n_tiles >= 256;
+    if (wavek) {
+        const unsigned grid = (unsigned)(((kgroups + 7) / 8) * n_tiles * 8);
+        DL_LAUNCH(dl_tns_loop_kernel<true>, dim3(grid), dim3(64 * DL_TNS_WAVES), tmpl, stream, t, plan->pk, ldp, n_tiles, plan->tables);
+    } else {
+        const unsigned grid = (unsigned)(((t.n11 + 7) / 8) * n_tiles * 8);
+        DL_LAUNCH(dl_tns_loop_kernel<false>, dim3(grid), dim3(64 * DL_TNS_WAVES), std::max(tmpl, red), stream, t, plan->pk, ldp, n_tiles, plan->tables);
+    }
     return true;
 }
 
@@ -507,7 +539,7 @@ void dl_launch_tns(const DlObsDev& obs, const double* theta, int n_params, int64
         const int64_t nb = std::min(pass, B - b0);
         const double* th = theta + (size_t)b0 * n_params;
         if (!tns_run_loop(plan, obs, th, n_params, nb, stream)) return;
-        DL_LAUNCH(dl_tns_assemble_kernel, dim3((unsigned)nb), dim3(256), shm, stream, obs, t, th, n_params, plan->tables, power + (size_t)b0 * (1 + obs.n_var) * ld_power, ld_power);
+        DL_LAUNCH(dl_tns_assemble_kernel, dim3((unsigned)nb), dim3(256), shm, stream, obs, t, th, n_params, plan->tables, plan->qq, plan->ldp, power + (size_t)b0 * (1 + obs.n_var) * ld_power, ld_power);
     }
 }
 
@@ -519,8 +551,8 @@ int dl_tns_tables(const DlObsDev& obs, const double* theta, int n_params, int64_
     for (int64_t b0 = 0; b0 < B; b0 += pass) {
         const int64_t nb = std::min(pass, B - b0);
         if (!tns_run_loop(plan, obs, theta + (size_t)b0 * n_params, n_params, nb, stream)) return 1;
-        const int64_t total = nb * 29 * t.n11;
-        hipLaunchKernelGGL(dl_tns_tables_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, plan->tables, t.n11, nb, tables_dev + (size_t)b0 * 29 * t.n11);
+        const int64_t total = nb * DL_TNS_NTAB * t.n11;
+        hipLaunchKernelGGL(dl_tns_tables_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, t, plan->tables, plan->qq, plan->ldp, nb, tables_dev + (size_t)b0 * DL_TNS_NTAB * t.n11);
     }
     return 0;
 }
