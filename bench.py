@@ -400,6 +400,48 @@ def other_configs(device, steps=40, warmup=5, ncheck=8):
                 'oracle_check': {'points': ncheck, 'max_rel_err_vs_oracle': float(err), 'tolerance': 1e-10}})
     del ctx, like
     gc.collect()
+
+    # ---- TNS one-loop theory: the reference's own perturbation-theory producer (full_shape.py:688-971), the step left of the path ----
+    from test_oracle_tns import load as load_tns, tns_oracle_point
+    from test_gpu_tns import spec_from_tns_golden
+    from desilike_amd._lib import Context
+    g = load_tns('tns')
+    ctx = Context(spec_from_tns_golden(g), device=device.index or 0)
+    B, tsteps = 4096, max(4, steps // 8)
+    rng = np.random.RandomState(11)
+    names = [str(name) for name in g['names']]
+    lo = dict(qpar=0.97, qper=0.97, dm=-0.03, df=0.9, sigmav=0., b1=1.2, b2=-1., bs=-1., b3=-1., sn0=-0.5)
+    hi = dict(qpar=1.03, qper=1.03, dm=0.03, df=1.1, sigmav=6., b1=2.8, b2=1., bs=1., b3=1., sn0=0.5)
+    theta_host = np.column_stack([rng.uniform(lo[name], hi[name], B) for name in names])
+    theta = torch.as_tensor(theta_host, dtype=torch.float64, device=device).contiguous()
+    post, status = torch.empty(B, dtype=torch.float64, device=device), torch.zeros(B, dtype=torch.int32, device=device)
+    elapsed, kernel_ms = _timed_context(ctx, theta, tsteps, 2, post, status, device)
+    assert int((status != 0).sum().item()) == 0
+    ntns = min(ncheck, 4)
+    loglike = ctx.eval_batch_host(theta_host[:ntns])[0]
+    q = g['c.k11']
+    kernels = orc.tns_kernels(g['k11_table'], q, orc.weights_trapz(q))
+    err = 0.
+    for i in range(ntns):
+        ref = tns_oracle_point(g, theta_host[i], kernels=kernels)
+        err = max(err, abs(loglike[i] - ref) / max(1., abs(ref)))
+    assert err <= 1e-10, 'GPU / oracle mismatch on the TNS theory: {:.3e}'.format(err)
+    n11, nq, nmu, nkin = len(g['k11_table']), len(q), 10, len(g['c.kin'])
+    flops = {'loop_gemm_algorithmic': 2 * n11 * (nq * nmu * 27 + nq * 12), 'loop_gemm_executed': 2 * n11 * (5120 * 32 + 500 * 16) if (nq, nmu) == (500, 10) else None,
+             'assembly': 2 * 29 * 5 * n11 + 2 * 5 * n11 * n11 + 60 * nkin * len(g['c.mu']), 'window_gemm': 2 * len(g['c.flatdata']) * 3 * nkin}
+    achieved = flops['loop_gemm_algorithmic'] * B / (kernel_ms['theory'] * 1e-3) / 1e12
+    out.append({'workload': 'TNS one-loop theory (reference: tns_pt, full_shape.py:749-833): 29 loop tables on {:d} wavenumbers from {:d} template wavenumbers x {:d} cosines per point, spline / AP / FoG / '
+                            'projection to 3 x {:d} multipoles, window 120 x {:d}, Gaussian likelihood, {:d} batched points'.format(n11, nq, nmu, nkin, 3 * nkin, B),
+                'value': B / elapsed, 'unit': 'evals/s', 'ms_per_step': 1e3 * elapsed, 'steps': tsteps, 'dtype': 'f64', 'batch': B,
+                'roofline': {'bound': 'mfma', 'kernel': 'dl_tns_loop_kernel (per table wavenumber: [points x 5000 pairs (mu, q)] . [5000 x 27 + 500 x 12] fp64 MFMA GEMM, left operand formed in registers from '
+                                                        'LDS-resident templates)', 'flop_per_eval': flops, 'flop_per_launch': flops['loop_gemm_algorithmic'] * B, 'avg_launch_ms': kernel_ms['theory'],
+                             'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS,
+                             'flop_count': 'the 27 bilinear + 12 linear tables the reference integrates (the kernel pads them to 32 + 16 columns and the pair list to 5120: executed count beside it)'},
+                'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize']},
+                'oracle_check': {'points': ntns, 'max_rel_err_vs_oracle': float(err), 'tolerance': 1e-10}})
+    ctx.close()
+    del ctx
+    gc.collect()
     return out
 
 

@@ -173,48 +173,46 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
     const dl_tns_double2* gw = reinterpret_cast<const dl_tns_double2*>(t.geomw) + (size_t)ik * t.Kp + kk;
     const dl_tns_double2* gc = reinterpret_cast<const dl_tns_double2*>(t.coef) + ((size_t)ik * t.Kp + kk) * 16 + p16;
     const double* spt = spk + p16;
-    auto load = [&](int round, Rec& r) {
-        const int rr = round < rounds ? round : rounds - 1;                            // (past the end: reloaded, not used)
+    // element offset (in pairs) of the first step of a round (past the end: the last round again, requested and not used)
+    auto round_offset = [&](int round) {
+        const int rr = round < rounds ? round : rounds - 1;
         const int g = WAVEK ? rr : rr * DL_TNS_WAVES + wave_s;
-        const size_t e = (size_t)g * DL_TNS_UNROLL * 4;
-#pragma unroll
-        for (int u = 0; u < DL_TNS_UNROLL; ++u) { r.j[u] = gj[e + 4 * u]; r.w[u] = gw[e + 4 * u]; r.c[u] = gc[(e + 4 * u) * 16]; }
+        return (size_t)g * DL_TNS_UNROLL * 4;
     };
-    auto read = [&](const Rec& r, Raw& o) {
+    auto load_step = [&](size_t e, int u, Rec& r) { r.j[u] = gj[e + 4 * u]; r.w[u] = gw[e + 4 * u]; r.c[u] = gc[(e + 4 * u) * 16]; };
+    auto read_step = [&](const Rec& r, int u, Raw& o) {
+        const double* ra = spt + r.j[u].x * DL_TNS_PTS;
+        const double* rq = spt + r.j[u].y * DL_TNS_PTS;
 #pragma unroll
-        for (int u = 0; u < DL_TNS_UNROLL; ++u) {
-            const double* ra = spt + r.j[u].x * DL_TNS_PTS;
-            const double* rq = spt + r.j[u].y * DL_TNS_PTS;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) { o.pq[u][m] = rq[16 * m]; o.pa[u][m] = ra[16 * m]; o.pb[u][m] = ra[DL_TNS_PTS + 16 * m]; }
-        }
+        for (int m = 0; m < 2; ++m) { o.pq[u][m] = rq[16 * m]; o.pa[u][m] = ra[16 * m]; o.pb[u][m] = ra[DL_TNS_PTS + 16 * m]; }
     };
-    auto form = [&](const Rec& r, const Raw& o, Lhs& l) {
+    auto form_step = [&](const Rec& r, const Raw& o, int u, Lhs& l) {
 #pragma unroll
-        for (int u = 0; u < DL_TNS_UNROLL; ++u)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) l.g[u][m] = o.pq[u][m] * fma(r.w[u].x, o.pa[u][m], r.w[u].y * o.pb[u][m]);
+        for (int m = 0; m < 2; ++m) l.g[u][m] = o.pq[u][m] * fma(r.w[u].x, o.pa[u][m], r.w[u].y * o.pb[u][m]);
     };
-    auto multiply = [&](const Rec& r, const Lhs& l) {
-#pragma unroll
-        for (int u = 0; u < DL_TNS_UNROLL; ++u)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                acc[m][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(l.g[u][m], r.c[u].x, acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l.g[u][m], r.c[u].y, acc[m][1], 0, 0, 0);
-            }
+    auto mfma_pair = [&](const Rec& r, const Lhs& l, int u, int m) {
+        acc[m][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(l.g[u][m], r.c[u].x, acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l.g[u][m], r.c[u].y, acc[m][1], 0, 0, 0);
     };
-    // one round: RA is multiplied (its left operand LA was formed one round ago); the LDS operands of RB are read at the start and turned into LB after the MFMAs
-    // have been issued; the records and coefficients of RC are requested from L2.  The roles rotate through three register sets (no copies: a copy would wait for
-    // the load it moves), the scheduling barriers keep the compiler from sinking the requests to their uses.
-#define DL_TNS_ROUND(RA, RB, RC, LA, LB, rnd)                 \
-    load((rnd) + 2, RC);                                       \
-    read(RB, raw);                                             \
-    __builtin_amdgcn_sched_barrier(0);                         \
-    multiply(RA, LA);                                          \
-    __builtin_amdgcn_sched_barrier(0);                         \
-    form(RB, raw, LB);                                         \
-    __builtin_amdgcn_sched_barrier(0);
+    auto load = [&](int round, Rec& r) { const size_t e = round_offset(round); for (int u = 0; u < DL_TNS_UNROLL; ++u) load_step(e, u, r); };
+    auto read = [&](const Rec& r, Raw& o) { for (int u = 0; u < DL_TNS_UNROLL; ++u) read_step(r, u, o); };
+    auto form = [&](const Rec& r, const Raw& o, Lhs& l) { for (int u = 0; u < DL_TNS_UNROLL; ++u) form_step(r, o, u, l); };
+    // One round: RA is multiplied (its left operand LA was formed one round ago); the records and coefficients of RC are requested from L2 during the first MFMAs,
+    // the LDS operands of RB are read during the next ones and turned into LB during the last ones.  The roles rotate through three register sets (no copies: a copy
+    // would wait for the load it moves).  The order is pinned chunk by chunk (two MFMAs, then a few other instructions): left to itself the scheduler sinks the
+    // requests to their uses.
+static_assert(DL_TNS_UNROLL == 4, "the round below names its four steps");
+#define DL_TNS_FENCE __builtin_amdgcn_sched_barrier(0);
+#define DL_TNS_ROUND(RA, RB, RC, LA, LB, rnd)                                                          \
+    { const size_t e_ = round_offset((rnd) + 2);                                                        \
+    mfma_pair(RA, LA, 0, 0); DL_TNS_FENCE load_step(e_, 0, RC); load_step(e_, 1, RC); DL_TNS_FENCE      \
+    mfma_pair(RA, LA, 0, 1); DL_TNS_FENCE load_step(e_, 2, RC); load_step(e_, 3, RC); DL_TNS_FENCE      \
+    mfma_pair(RA, LA, 1, 0); DL_TNS_FENCE read_step(RB, 0, raw); read_step(RB, 1, raw); DL_TNS_FENCE    \
+    mfma_pair(RA, LA, 1, 1); DL_TNS_FENCE read_step(RB, 2, raw); read_step(RB, 3, raw); DL_TNS_FENCE    \
+    mfma_pair(RA, LA, 2, 0); DL_TNS_FENCE form_step(RB, raw, 0, LB); DL_TNS_FENCE                       \
+    mfma_pair(RA, LA, 2, 1); DL_TNS_FENCE form_step(RB, raw, 1, LB); DL_TNS_FENCE                       \
+    mfma_pair(RA, LA, 3, 0); DL_TNS_FENCE form_step(RB, raw, 2, LB); DL_TNS_FENCE                       \
+    mfma_pair(RA, LA, 3, 1); DL_TNS_FENCE form_step(RB, raw, 3, LB); DL_TNS_FENCE }
     Rec r0, r1, r2;
     Raw raw;
     Lhs l0, l1;
@@ -503,7 +501,7 @@ static bool tns_run_loop(DlTnsPlan* plan, const DlObsDev& obs, const double* the
     const DlTnsDev& t = plan->dev;
     const int64_t ldp = (nb + DL_TNS_PTS - 1) / DL_TNS_PTS * DL_TNS_PTS;
     if (!tns_reserve(plan, ldp)) { dl_set_last_error("tns: workspace allocation failed"); return false; }
-    DL_LAUNCH(dl_tns_pk_kernel, dim3((unsigned)((ldp + 63) / 64), DL_TNS_QPARTS), dim3(256), 0, stream, obs, t, theta, n_params, nb, ldp, plan->pk, plan->qq);
+    hipLaunchKernelGGL(dl_tns_pk_kernel, dim3((unsigned)((ldp + 63) / 64), DL_TNS_QPARTS), dim3(256), 0, stream, obs, t, theta, n_params, nb, ldp, plan->pk, plan->qq);   // (the profiling events go to the loop kernel)
     plan->ldp = ldp;
     const int n_tiles = (int)(ldp / DL_TNS_PTS);
     const size_t tmpl = (size_t)t.nqp * DL_TNS_PTS * sizeof(double), red = (size_t)DL_TNS_WAVES * 2 * 3 * 4 * 64 * sizeof(double);
@@ -539,7 +537,7 @@ void dl_launch_tns(const DlObsDev& obs, const double* theta, int n_params, int64
         const int64_t nb = std::min(pass, B - b0);
         const double* th = theta + (size_t)b0 * n_params;
         if (!tns_run_loop(plan, obs, th, n_params, nb, stream)) return;
-        DL_LAUNCH(dl_tns_assemble_kernel, dim3((unsigned)nb), dim3(256), shm, stream, obs, t, th, n_params, plan->tables, plan->qq, plan->ldp, power + (size_t)b0 * (1 + obs.n_var) * ld_power, ld_power);
+        hipLaunchKernelGGL(dl_tns_assemble_kernel, dim3((unsigned)nb), dim3(256), shm, stream, obs, t, th, n_params, plan->tables, plan->qq, plan->ldp, power + (size_t)b0 * (1 + obs.n_var) * ld_power, ld_power);
     }
 }
 

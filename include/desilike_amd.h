@@ -63,6 +63,7 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
 #define DL_APMODE_QISOQAP     3
 #define DL_PRIOR_UNIFORM      0
 #define DL_PRIOR_NORM         1
+#define DL_THEORY_TNS         4   /* TNS one-loop tables + tracer bias combination, full_shape.py:688-971 (csrc/dl_tns.h) */
 #define DL_TRANSFORM_NONE     0
 #define DL_TRANSFORM_CUBIC    1   /* power_spectrum.py:402-404 */
 
@@ -98,6 +99,10 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
  *                     obs<i>.bao_mode i32[1] (bits 0-3: 0 '' / recsym, 1 reciso; bits 4-7: wiggle model, 0 'standard', else 8 | 1 'fix-damping' | 2 'move-all' | 4 'fog-damping', bao.py:137-150), obs<i>.smoothing_radius f64[1]
  *                     flexible wiggles (bao.py:269-391): obs<i>.ml_matrix f64[n_ml*n_kin] kernels K_i(k), obs<i>.ml_ell i32[n_ml] multipole index of each term,
  *                     obs<i>.in.ml f64[n_ml*2], obs<i>.legendre f64[n_ell*n_mu] L_ell(mu); obs<i>.resummed f64[4] damping scales of the resummed wiggles (bao.py:186-199), obs<i>.in.dres
+ *   TNS one-loop theory (theory = 4; full_shape.py:688-971): obs<i>.tns_k11 f64[n_k11] table wavenumbers (linspace(0.7 kin[0], 1.3 kin[-1], int(1.6 n_kin + 0.5)), full_shape.py:875),
+ *                     obs<i>.tns_mu, obs<i>.tns_wmu f64[10] cosines and weights of the loop integrals (utils.weights_mu(10, 'leggauss'), full_shape.py:757), obs<i>.tns_fog i32[1]
+ *                     (0 lorentzian, 1 gaussian, full_shape.py:870-873); obs<i>.in.sigmav, .in.b2, .in.bs, .in.b3 f64[2] (b1 through in.b1X); obs<i>.k_t = the template's
+ *                     500 wavenumbers geomspace(1e-3, 2) (full_shape.py:855) are also the integration grid; EFT-like terms (ct_matrix, sn_matrix) as for theory 1
  *   emulated theory (theory = 3): obs<i>.in.x f64[n_x*2] emulator inputs, obs<i>.in.vp f64[11*2] velocileptors 'pars' (b1 b2 bs b3 alpha0 alpha2 alpha4 alpha6
  *                     sn0 sn2 sn4), obs<i>.mono_mode i32[1] (0 none, 1 LPT physical basis, 2 REPT physical, 3 LPT direct, 4 REPT direct), obs<i>.vconst f64[3] (snd fsat sigv),
  *                     obs<i>.emu<e>.{type i32[1] (-1 constant, 0 MLP, 1 Taylor), xlimits, widths, act, weights, ylimits, center, powers, coef, const}

@@ -22,7 +22,7 @@ import numpy as np
 
 # enumerations of include/desilike_amd.h
 DL_TEMPLATE_FIXED, DL_TEMPLATE_SHAPEFIT = 0, 1
-DL_THEORY_KAISER, DL_THEORY_EFT_KAISER, DL_THEORY_BAO_DAMPED = 0, 1, 2
+DL_THEORY_KAISER, DL_THEORY_EFT_KAISER, DL_THEORY_BAO_DAMPED, DL_THEORY_TNS = 0, 1, 2, 4
 DL_APMODE = {'qparqper': 0, 'qiso': 1, 'qap': 2, 'qisoqap': 3}
 
 
@@ -114,7 +114,14 @@ def extract_config(likelihood):
         bao = hasattr(pt, 'smoothing_radius')
         eft = hasattr(ptheory, 'counterterm_matrix')
         shapefit = template.__class__.__name__.startswith('ShapeFit')
-        cfg[p + 'theory'] = np.array([DL_THEORY_BAO_DAMPED if bao else DL_THEORY_EFT_KAISER if eft else DL_THEORY_KAISER], dtype='i4')
+        tns = pt.__class__.__name__.startswith('TNS')                       # the reference's own one-loop producer (full_shape.py:836-971)
+        cfg[p + 'theory'] = np.array([DL_THEORY_BAO_DAMPED if bao else DL_THEORY_TNS if tns else DL_THEORY_EFT_KAISER if eft else DL_THEORY_KAISER], dtype='i4')
+        if tns:
+            k = np.asarray(pt.k, dtype='f8')
+            cfg[p + 'tns_k11'] = np.linspace(k[0] * 0.7, k[-1] * 1.3, int(len(k) * 1.6 + 0.5))                # full_shape.py:875 (a local of calculate)
+            x, w = np.polynomial.legendre.leggauss(20)                                                         # utils.weights_mu(10, 'leggauss'): full_shape.py:757
+            cfg[p + 'tns_mu'], cfg[p + 'tns_wmu'] = x[10:], (w[10:] + w[9::-1]) / 2.
+            cfg[p + 'tns_fog'] = np.array([{'lorentzian': 0, 'gaussian': 1}[pt.options['fog']]], dtype='i4')
         cfg[p + 'template'] = np.array([DL_TEMPLATE_SHAPEFIT if shapefit and not bao else DL_TEMPLATE_FIXED], dtype='i4')
         cfg[p + 'apmode'] = np.array([_apmode(template)], dtype='i4')
         cfg[p + 'transform'] = np.array([1 if getattr(obs, 'transform', None) == 'cubic' else 0], dtype='i4')
@@ -163,6 +170,9 @@ def extract_config(likelihood):
             cfg[p + 'in.pass'] = np.array([column(name, value_of(name, 0.)) for name in pass_names], dtype='f8')
         if window is not None: cfg[p + 'wmatrix'] = window
         defaults = dict(qpar=1., qper=1., qiso=1., qap=1., df=1., dm=0., dn=0., sigmapar=9. if bao else 0., sigmaper=6. if bao else 0.)
+        if tns:
+            for key in ['sigmapar', 'sigmaper']: defaults.pop(key)
+            defaults.update(sigmav=0., b2=0., bs=0., b3=0.)
         if bao: defaults.update(dbeta=1., sigmas=0.)
         else: defaults.update(sn0=0.)
         if xi and not bao: defaults.pop('sn0')                             # no stochastic parameter for correlation functions (full_shape.py:336-364)

@@ -93,7 +93,20 @@ def dump(name, eft=False, fog='lorentzian', template='shapefit', resolution=3, s
     print(name, names, 'logL range', np.nanmin(out['loglikelihood'][np.isfinite(out['loglikelihood'])]), np.nanmax(out['loglikelihood'][np.isfinite(out['loglikelihood'])]), 'errors', len(errors))
 
 
+def boundary():
+    """Reference-side binding on real TNS likelihoods (integration/desilike_mi355x.py::extract_config): the key sets + the reference's own outputs, as
+    tests/golden/make_boundary_fixture.py does for the other theories (replayed by tests/test_gpu_boundary.py)."""
+    import make_boundary_fixture as mb
+    for name, cls, fog in [('tns', TNSTracerPowerSpectrumMultipoles, 'gaussian'), ('tns_eft', EFTLikeTNSTracerPowerSpectrumMultipoles, 'lorentzian')]:
+        theory = cls(template=ShapeFitPowerSpectrumTemplate(z=0.5), fog=fog)
+        if name == 'tns': theory.init.params['bs'].update(fixed=False)
+        obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'b2': 0.5}, kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 1}, theory=theory, shotnoise=1e4)
+        likelihood = ObservablesGaussianLikelihood(observables=[obs], covariance=mg.spd_covariance(120, seed=5, diag=2e5, amp=150.))
+        mb.dump(name, likelihood, size=16, seed=9)
+
+
 if __name__ == '__main__':
+    boundary()
     dump('tns')
     dump('tns_eft', eft=True, resolution=1, size=12, free=())
     dump('tns_standard_gaussian', template='standard', fog='gaussian', resolution=1, size=12, ells=(0, 2))
