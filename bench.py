@@ -422,9 +422,11 @@ def other_configs(device, steps=40, warmup=5, ncheck=8):
     q = g['c.k11']
     kernels = orc.tns_kernels(g['k11_table'], q, orc.weights_trapz(q))
     err = 0.
+    t0 = time.perf_counter()
     for i in range(ntns):
         ref = tns_oracle_point(g, theta_host[i], kernels=kernels)
         err = max(err, abs(loglike[i] - ref) / max(1., abs(ref)))
+    oracle_seconds = (time.perf_counter() - t0) / ntns
     assert err <= 1e-10, 'GPU / oracle mismatch on the TNS theory: {:.3e}'.format(err)
     n11, nq, nmu, nkin = len(g['k11_table']), len(q), 10, len(g['c.kin'])
     flops = {'loop_gemm_algorithmic': 2 * n11 * (nq * nmu * 27 + nq * 12), 'loop_gemm_executed': 2 * n11 * (5120 * 32 + 500 * 16) if (nq, nmu) == (500, 10) else None,
@@ -438,7 +440,10 @@ def other_configs(device, steps=40, warmup=5, ncheck=8):
                              'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS,
                              'flop_count': 'the 27 bilinear + 12 linear tables the reference integrates (the kernel pads them to 32 + 16 columns and the pair list to 5120: executed count beside it)'},
                 'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize']},
-                'oracle_check': {'points': ntns, 'max_rel_err_vs_oracle': float(err), 'tolerance': 1e-10}})
+                'oracle_check': {'points': ntns, 'max_rel_err_vs_oracle': float(err), 'tolerance': 1e-10},
+                'cpu_baseline': {'value': 1. / oracle_seconds, 'unit': 'evals/s', 'cores': 1, 'kind': 'port', 'sample': '{:d} evaluations of the NumPy oracle (kernels precomputed), 1 process'.format(ntns),
+                                 'reference_in_build_container': {'value': 2.44, 'unit': 'evals/s', 'cores': 1, 'where': "the reference's own TNS likelihood (numpy fallback of its jax code, "
+                                                                  "tests/golden/make_tns_fixture.py harness), build container (Xeon 2.1 GHz)"}}})
     ctx.close()
     del ctx
     gc.collect()

@@ -105,6 +105,19 @@ def section_bao():
         close(loglike[:len(g['theta'])], g['loglikelihood'], 'cfg4 ' + space + ' in a 5000-row batch')
 
 
+def section_tns():
+    """the TNS one-loop theory against the reference fixture, at the fixture's size (one tile: split-K loop kernel) and inside a 1100-row batch (one wavenumber per wave)"""
+    from desilike_amd._lib import Context
+    from test_oracle_tns import load
+    from test_gpu_tns import spec_from_tns_golden
+    g = load('tns')
+    ctx = Context(spec_from_tns_golden(g), device=0)
+    ok = np.isfinite(g['theta']).all(axis=1)
+    close(ctx.eval_batch_host(g['theta'])[0][ok], g['loglikelihood'][ok], 'tns vs reference')
+    theta = np.tile(g['theta'][ok], (1100 // ok.sum() + 1, 1))[:1100]
+    close(ctx.eval_batch_host(theta)[0][:ok.sum()], g['loglikelihood'][ok], 'tns in a 1100-row batch')
+
+
 if __name__ == '__main__':
     for name in sys.argv[1:]:
         globals()['section_' + name]()
