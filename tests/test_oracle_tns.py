@@ -98,3 +98,20 @@ def test_loop_terms_matter():
     k11 = g['k11_table']
     sel = k11 > 0.15
     assert np.max(np.abs(tab[1][sel] / tab[0][sel] - 1.)) > 0.02     # pk_dd vs pk11
+
+
+@pytest.mark.parametrize('name,eft', [('tns', False), ('tns_eft', True)])
+def test_host_mirror_parameters_match_the_reference(name, eft):
+    """The mirror classes declare the parameters of the reference's parameter files (full_shape.yaml): same varied names, same priors, as recorded from the reference."""
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, TNSTracerPowerSpectrumMultipoles, EFTLikeTNSTracerPowerSpectrumMultipoles
+    g = load(name)
+    theory = (EFTLikeTNSTracerPowerSpectrumMultipoles if eft else TNSTracerPowerSpectrumMultipoles)(template=ShapeFitPowerSpectrumTemplate(z=0.5, fiducial='synthetic'))
+    if not eft:
+        for pname in ['bs', 'b3']: theory.init.params[pname].update(fixed=False)
+    params = theory._all_params()
+    varied = [param.name for param in params if param.varied]
+    rnames = [str(n) for n in g['names']]
+    assert sorted(varied) == sorted(rnames), (varied, rnames)
+    for iname, pname in enumerate(rnames):
+        assert np.array_equal(np.asarray(params[pname].prior.spec(), dtype='f8'), g['priors'][iname]), pname
+    assert np.allclose(theory.k11, oc.tns_k11(theory.k)) and theory.template.k.size == 500 and np.isclose(theory.template.k[-1], 2.)
