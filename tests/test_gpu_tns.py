@@ -139,3 +139,107 @@ def test_host_mirror_matches_oracle():
         flat = oc.window_apply(power, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout)
         ref = oc.gaussian_loglikelihood(flat, obs.flatdata, like.precision)[0]
         assert abs(loglike[i] - ref) <= 1e-10 * max(1., abs(ref)), (i, loglike[i], ref)
+
+
+def _mirror_tns(cls_name, marg=None, xi=False, fog='lorentzian', seed=5):
+    import desilike_amd.theories.galaxy_clustering as tg
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable, TracerCorrelationFunctionMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    template = ShapeFitPowerSpectrumTemplate(z=0.5, fiducial='synthetic')
+    kw = {} if 'EFTLike' in cls_name else {'fog': fog}
+    theory = getattr(tg, cls_name)(template=template, **kw)
+    for pname, conf in (marg or {}).items(): theory.init.params[pname].update(**conf)
+    rng = np.random.RandomState(seed)
+    data = {'b1': 2., 'b2': 0.4}
+    if xi:
+        obs = TracerCorrelationFunctionMultipolesObservable(data=data, s=np.linspace(32.5, 147.5, 16), ells=(0, 2), theory=theory)
+        n = 32
+    else:
+        obs = TracerPowerSpectrumMultipolesObservable(data=data, kedges=np.linspace(0., 0.2, 21), ells=(0, 2, 4), wmatrix={'resolution': 2}, theory=theory, shotnoise=1e4)
+        n = 60
+    A = rng.standard_normal((n, n))
+    scale = 1e-4 if xi else 50.
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=(A.dot(A.T) + 10. * n * np.eye(n)) * scale**2)
+    like.initialize()
+    return like, obs, theory, template
+
+
+def _oracle_flat(theory, template, obs, p, ct=None, sn=None):
+    from oracle import np_oracle as oc
+    q = template.k
+    k11 = oc.tns_k11(theory.k)
+    if not hasattr(theory, '_oracle_kernels'): theory._oracle_kernels = oc.tns_kernels(k11, q, oc.weights_trapz(q))
+    pk_q = template.pk_dd_fid * oc.shapefit_factor(q, template.kp, template.a, dm=p.get('dm', 0.), dn=p.get('dn', 0.))
+    pt = oc.tns_pktable(theory.k, theory.mu, theory.wmu, q, pk_q, template.f_fid * p.get('df', 1.), qpar=p.get('qpar', 1.), qper=p.get('qper', 1.), sigmav=p.get('sigmav', 0.),
+                        fog=theory.fog, kernels=theory._oracle_kernels, k11=k11)
+    power = oc.tns_tracer_power(pt, theory.nd, b1=p['b1'], b2=p.get('b2', 0.), bs=p.get('bs', 0.), b3=p.get('b3', 0.), sn0=p.get('sn0', 0.))
+    if ct is not None:
+        power = oc.eftlike_addon(power, list(theory.ells), pt['pk11'], theory.counterterm_matrix, [2. * v for v in ct], theory.stochastic_matrix, sn, theory.nd)
+    return power
+
+
+def test_analytic_marginalisation_of_tns_terms():
+    """sn0 on EVERY multipole (full_shape.py:961) and an EFT-like counter term (derivative proportional to the projected linear spectrum) solved analytically: the
+    device's solve against the oracle's ``_solve`` restatement with derivative columns from unit steps of the (exactly linear) parameters."""
+    from oracle import np_oracle as oc
+    like, obs, theory, template = _mirror_tns('EFTLikeTNSTracerPowerSpectrumMultipoles',
+                                              marg={'sn0': dict(derived='.marg', prior=dict(dist='norm', loc=0., scale=2.)), 'ct0_2': dict(derived='.marg', prior=dict(dist='norm', loc=0., scale=40.)),
+                                                    'ct2_2': dict(derived='.best'), 'ct4_2': dict(fixed=True, value=0.), 'sn2_2': dict(fixed=True, value=0.), 'sn4_2': dict(fixed=True, value=0.)})
+    names = like.varied_params.names()
+    solved = like.solved_params.names()
+    assert sorted(solved) == ['ct0_2', 'ct2_2', 'sn0']
+    rng = np.random.RandomState(3)
+    theta = np.column_stack([param.ref.sample(size=9, random_state=rng) for param in like.varied_params])
+    loglike, logprior, status, xs = like._get_context().eval_batch_host(theta, return_solved=True)
+    assert (status == 0).all()
+    wm = obs.wmatrix
+    ctn, snn = theory.counterterm_params, theory.stochastic_params
+    x0 = np.array([param.value for param in like.solved_params])
+    loc = np.array([param.prior.loc if param.prior.dist == 'norm' else 0. for param in like.solved_params])
+    scale = np.array([param.prior.scale if param.prior.dist == 'norm' else np.inf for param in like.solved_params])
+    mask = [str(param.derived).startswith('.marg') for param in like.solved_params]
+
+    def flat(row, x):
+        p = dict(zip(names, row)); p.update(dict(zip(solved, x)))
+        power = _oracle_flat(theory, template, obs, p, ct=[p.get(n, 0.) for n in ctn], sn=[p.get(n, 0.) for n in snn])
+        return oc.window_apply(power, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout)
+
+    for i, row in enumerate(theta[:5]):
+        f0 = flat(row, x0)
+        T = np.array([flat(row, x0 + np.eye(len(solved))[s]) - f0 for s in range(len(solved))])
+        sol = oc.solve_marginalized(f0 - obs.flatdata, T, like.precision, x0=x0, prior_loc=loc, prior_scale=scale, marg_mask=mask)
+        assert abs(loglike[i] - sol['loglikelihood']) <= 1e-10 * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
+        assert np.allclose(xs[i], sol['x'], rtol=1e-7, atol=1e-9)
+
+
+def test_correlation_function_multipoles():
+    """TNS xi_ell: the power spectrum multipoles on the 300-point log grid (k11: 480 table wavenumbers), Hankel transform folded into the window."""
+    from oracle import np_oracle as oc
+    like, obs, theory, template = _mirror_tns('TNSTracerCorrelationFunctionMultipoles', xi=True, fog='gaussian')
+    names = like.varied_params.names()
+    assert 'sn0' not in names and 'sigmav' in names
+    rng = np.random.RandomState(1)
+    theta = np.column_stack([param.ref.sample(size=3, random_state=rng) if param.ref.is_proper() else np.full(3, param.value) for param in like.varied_params])
+    theta[:, names.index('sigmav')] = rng.uniform(0.5, 3., 3)
+    loglike = like._get_context().eval_batch_host(theta)[0]
+    for i, row in enumerate(theta):
+        p = dict(zip(names, row))
+        power = _oracle_flat(theory, template, obs, p)
+        flat = np.ravel(oc.get_corr(power, theory.kin, theory.s, theory.ells))
+        ref = oc.gaussian_loglikelihood(flat, obs.flatdata, like.precision)[0]
+        assert abs(loglike[i] - ref) <= 1e-10 * max(1., abs(ref)), (i, loglike[i], ref)
+
+
+def test_ensemble_sampler_on_a_tns_likelihood():
+    """The device-resident stretch-move sampler drives the TNS likelihood like any other: chain log-posteriors equal direct evaluations of the chain's points."""
+    from desilike_amd.samplers import EmceeSampler
+    like, obs, theory, template = _mirror_tns('TNSTracerPowerSpectrumMultipoles')
+    sampler = EmceeSampler(like, nwalkers=32, seed=7)
+    sampler.run(niterations=6)
+    chain = sampler.chain
+    names = like.varied_params.names()
+    last = np.column_stack([np.asarray(chain[name])[-1] for name in names])
+    direct = like._get_posterior_context()[0].eval_logposterior_host(last)[0] + like._get_posterior_context()[1]
+    assert np.allclose(np.asarray(chain['logposterior'])[-1], direct, rtol=1e-12, atol=1e-9)
+    assert 0. < np.mean(sampler.acceptance_fraction) <= 1.
