@@ -253,4 +253,58 @@ int emu_eval_grad(const dl_config* cfg, const double* theta, int64_t B, double* 
     return 0;
 }
 
+// TNS one-loop theory (csrc/dl_tns.h): the arithmetic of the geometry kernels, of the loop GEMM (sums over the pairs (mu, q) in the kernels' pair order) and of
+// dl_tns_table_entry, run sequentially: tables [29][n11] of ONE template pk [n_q].  Returns the number of (k, mu, q) whose |k - q| falls outside the template.
+int emu_tns_tables(const double* k11, int n11, const double* q, int n_q, const double* mus, const double* wmus, int n_mu, const double* pk, double* tables) {
+    const double pi = 3.14159265358979323846;
+    std::vector<double> jq(n_q);
+    for (int j = 0; j < n_q; ++j) {
+        const double wq = (j == 0 ? q[1] - q[0] : j == n_q - 1 ? q[n_q - 1] - q[n_q - 2] : q[j + 1] - q[j - 1]) / 2.;
+        jq[j] = q[j] * q[j] * wq / (4. * pi * pi);
+    }
+    double qq = 0., sumw = 0.;
+    for (int j = 0; j < n_q; ++j) qq = std::fma(jq[j] * pk[j], pk[j], qq);
+    for (int m = 0; m < n_mu; ++m) sumw += wmus[m];
+    int outside = 0;
+    for (int ik = 0; ik < n11; ++ik) {
+        const double k = k11[ik];
+        double S[DL_TNS_NCOL], Lv[DL_TNS_NLIN];
+        for (int i = 0; i < DL_TNS_NCOL; ++i) S[i] = 0.;
+        for (int i = 0; i < DL_TNS_NLIN; ++i) Lv[i] = 0.;
+        int jk; double wk0, wk1;
+        dl_tns_interp_weights(q, n_q, k, jk, wk0, wk1);
+        Lv[DL_TL_PK] = wk0 * pk[jk] + wk1 * pk[jk + 1];
+        for (int im = 0; im < n_mu; ++im)
+            for (int iq = 0; iq < n_q; ++iq) {
+                DlTnsGeom g;
+                dl_tns_geometry(k, q[iq], jq[iq], mus[im], wmus[im], g);
+                int j; double w0, w1;
+                dl_tns_interp_weights(q, n_q, g.r, j, w0, w1);
+                if (w0 == 0. && w1 == 0.) ++outside;
+                const double plin = std::fma(w0, pk[j], w1 * pk[j + 1]);
+                const double G = pk[iq] * plin;
+                for (int i = 0; i < 27; ++i) S[i] = std::fma(G, g.c[i], S[i]);
+                Lv[DL_TL_SIG3] = std::fma(g.sig3, pk[iq], Lv[DL_TL_SIG3]);
+                const int idx[4] = {0, 1, 2, 4};
+                for (int u = 0; u < 4; ++u) Lv[DL_TL_EA0 + u] = std::fma(g.ca[idx[u]], plin, Lv[DL_TL_EA0 + u]);   // (the device folds these over the interpolation first: same sum, other order)
+            }
+        for (int iq = 0; iq < n_q; ++iq) {
+            double ff, gg, ka[4];
+            dl_tns_kernels13(q[iq] / k, ff, gg);
+            dl_tns_kernels_a(q[iq] / k, ka);
+            Lv[DL_TL_13D] = std::fma(2. * jq[iq] * ff, pk[iq], Lv[DL_TL_13D]);
+            Lv[DL_TL_13T] = std::fma(2. * jq[iq] * gg, pk[iq], Lv[DL_TL_13T]);
+            for (int u = 0; u < 4; ++u) Lv[DL_TL_KA0 + u] = std::fma(jq[iq] * ka[u], pk[iq], Lv[DL_TL_KA0 + u]);
+        }
+        for (int r = 0; r < DL_TNS_NTAB; ++r) tables[(size_t)r * n11 + ik] = dl_tns_table_entry(r, S, Lv, qq, sumw);
+    }
+    return outside;
+}
+
+// coefficients of the 29 tables (+ pk11) in the five mu'^2n polynomials of P(k, mu) and the counter-term table: cvec [6][32] (dl_tns_combine_coef)
+void emu_tns_combine(double f, double b1, double b2, double bs, double b3, double* cvec) {
+    for (int n = 0; n < 6; ++n)
+        for (int r = 0; r < 32; ++r) cvec[n * 32 + r] = dl_tns_combine_coef(n, r, f, b1, b2, bs, b3);
+}
+
 }  // extern "C"

@@ -18,7 +18,7 @@ def build_emulation(sanitize=False):
     os.makedirs(build, exist_ok=True)
     so = os.path.join(build, 'libdl_emulate_asan.so' if sanitize else 'libdl_emulate.so')
     src = os.path.join(HERE, 'csrc', 'emulate.cpp')
-    deps = [src] + [os.path.join(HERE, '..', 'desilike_amd', 'csrc', name) for name in ['dl_fullshape.h', 'dl_fullshape_grad.h', 'dl_host.hpp']]
+    deps = [src] + [os.path.join(HERE, '..', 'desilike_amd', 'csrc', name) for name in ['dl_fullshape.h', 'dl_fullshape_grad.h', 'dl_host.hpp', 'dl_tns.h']]
     if not os.path.isfile(so) or any(os.path.getmtime(dep) > os.path.getmtime(so) for dep in deps):
         subprocess.check_call(['g++', '-O1' if sanitize else '-O2', '-std=c++17', '-fPIC', '-shared'] + (SANITIZE_FLAGS if sanitize else []) + ['-o', so, src])
     return so
@@ -38,6 +38,8 @@ def load_emulation():
         lib.emu_eval_theory.argtypes = [ctypes.c_void_p, dp, ctypes.c_int64, ctypes.c_int, dp, dp]
         lib.emu_eval_batch.argtypes = [ctypes.c_void_p, dp, ctypes.c_int64, dp, dp]
         lib.emu_eval_grad.argtypes = [ctypes.c_void_p, dp, ctypes.c_int64, dp, dp]
+        lib.emu_tns_tables.argtypes = [dp, ctypes.c_int, dp, ctypes.c_int, dp, dp, ctypes.c_int, dp, dp]
+        lib.emu_tns_combine.argtypes = [ctypes.c_double] * 5 + [dp]
         _emu = lib
     return _emu
 
@@ -84,3 +86,20 @@ class Emulation(object):
 
     def __del__(self):
         self.lib.emu_config_free(self.cfg)
+
+
+def tns_tables(k11, q, mus, wmus, pk):
+    """The 29 TNS loop tables [29, n_k11] of one template, by the device's own functions (csrc/dl_tns.h) run sequentially on the CPU."""
+    lib = load_emulation()
+    k11, q, mus, wmus, pk = (np.ascontiguousarray(a, dtype='f8') for a in (k11, q, mus, wmus, pk))
+    out = np.empty((29, len(k11)), dtype='f8')
+    dp = ctypes.POINTER(ctypes.c_double)
+    outside = lib.emu_tns_tables(k11.ctypes.data_as(dp), len(k11), q.ctypes.data_as(dp), len(q), mus.ctypes.data_as(dp), wmus.ctypes.data_as(dp), len(mus), pk.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    return out, outside
+
+
+def tns_combine(f, b1, b2, bs, b3):
+    lib = load_emulation()
+    out = np.empty((6, 32), dtype='f8')
+    lib.emu_tns_combine(f, b1, b2, bs, b3, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return out

@@ -115,3 +115,43 @@ def test_host_mirror_parameters_match_the_reference(name, eft):
     for iname, pname in enumerate(rnames):
         assert np.array_equal(np.asarray(params[pname].prior.spec(), dtype='f8'), g['priors'][iname]), pname
     assert np.allclose(theory.k11, oc.tns_k11(theory.k)) and theory.template.k.size == 500 and np.isclose(theory.template.k[-1], 2.)
+
+
+def test_device_functions_on_the_cpu_against_the_reference_tables():
+    """csrc/dl_tns.h (geometry, interpolation records, P13 / A kernels, table entries) compiled for the host and run sequentially: the 29 tables of the fixture's first
+    templates equal the reference's own (1e-10 of each table's largest entry) -- the arithmetic the GPU kernels execute, checked without a GPU."""
+    from emulation import tns_tables
+    g = load('tns')
+    mus, wmus = oc.weights_leggauss_sym(10)
+    for i in range(2):
+        tables, outside = tns_tables(g['k11_table'], g['c.k11'], mus, wmus, g['int_pk_dd_template'][i])
+        assert outside > 0     # some |k - q| fall below the template's range: the zero-weight branch is exercised
+        for r in range(29):
+            ref = g['int_tables'][i][r]
+            assert np.max(np.abs(tables[r] - ref)) <= 1e-10 * np.max(np.abs(ref)), (i, r)
+
+
+def test_device_bias_combination_against_the_reference_power():
+    """dl_tns_combine_coef: the coefficients of the 29 projected tables in the tracer power reproduce the reference's ``power`` from the reference's own projected
+    tables (mu'^2n factors and f powers are already inside the projected tables, so the mu'^2n classes are summed)."""
+    from emulation import tns_combine
+    g = load('tns')
+    names = [str(n) for n in g['names']]
+    for i in range(3):
+        row = g['theta'][i] if np.all(np.isfinite(g['theta'][i])) else g['theta'][0]
+        p = dict(zip(names, row))
+        f = float(g['int_f'][i])
+        cvec = tns_combine(f, p['b1'], p['b2'], p['bs'], p['b3'])
+        poles = g['int_poles'][i]                        # rows: 12 spectra (projected WITH their f mu'^2 factors), A [3], B [3] (grouped by b1^2, b1, 1, with f and mu' inside)
+        b1 = p['b1']
+        power = sum(cvec[0][r] * poles[r] for r in range(1, 8))
+        power = power + 2. * b1 * poles[8] + p['b2'] * poles[9] + poles[11]          # pk_dt, pk_b2t, pk_tt carry f mu'^2 / f^2 mu'^4 already
+        power = power + b1**2 * (poles[12] + poles[15]) + b1 * (poles[13] + poles[16]) + (poles[14] + poles[17])
+        power = power + p['sn0'] / float(g['c.nd'])
+        assert np.allclose(power, g['int_power'][i], rtol=1e-11, atol=1e-11 * np.abs(g['int_power'][i]).max())
+        # the f / b1 factors the device puts on the raw tables: consistent with the groups above
+        assert np.isclose(cvec[1][8], 2. * b1 * f) and np.isclose(cvec[1][9], p['b2'] * f) and np.isclose(cvec[2][11], f * f)
+        assert np.isclose(cvec[1][12], b1 * b1 * f) and np.isclose(cvec[1][13], b1 * f * f) and np.isclose(cvec[2][14], b1 * f * f) and np.isclose(cvec[2][15], f**3) and np.isclose(cvec[3][16], f**3)
+        assert np.isclose(cvec[1][17], b1 * b1 * f * f) and np.isclose(cvec[1][18], -b1 * f**3) and np.isclose(cvec[1][19], -b1 * f**3) and np.isclose(cvec[1][20], f**4)
+        assert np.isclose(cvec[2][21], b1 * b1 * f * f) and np.isclose(cvec[2][22], -b1 * f**3) and np.isclose(cvec[2][24], f**4) and np.isclose(cvec[3][25], -b1 * f**3) and np.isclose(cvec[3][27], f**4)
+        assert np.isclose(cvec[4][28], f**4) and cvec[5][0] == 1. and np.count_nonzero(cvec[5]) == 1
