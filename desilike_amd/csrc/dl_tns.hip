@@ -276,68 +276,109 @@ static_assert(DL_TNS_UNROLL == 4, "the round below names its four steps");
     }
 }
 
-// Assembly: one workgroup per point.  LDS: Q [6][n11] | M [6][n11] | cvec [6][32] | mu records | out [n_in + n_kin]
-enum { DL_TA_QPER = 0, DL_TA_JAC, DL_TA_SIGV, DL_TA_SN0ND, DL_TA_MU = 8 };   // per mu: factorap, mu'^2 (then weights [n_ell + 1])
+// Assembly: PPW points per workgroup (the dense spline operator, 8 n11^2 bytes from L2, is read once per workgroup: 1.2 GB per 4096 points at one point each).
+// LDS per point: Q [6][n11] | M [6][n11] | cvec [6][32] | mu records [DL_MAX_MU][8] | scalars [8] | out [n_in + n_kin]
+DL_HD size_t dl_tns_assemble_doubles(int n11, int n_in, int n_kin) { return (size_t)12 * n11 + 6 * 32 + (size_t)8 * DL_MAX_MU + 8 + n_in + n_kin; }
 
-__global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsDev t, const double* __restrict__ theta, int n_params, const double* __restrict__ raw,
+template <int PPW>
+__global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsDev t, const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ raw,
                                                               const double* __restrict__ qq, int64_t ldp, double* __restrict__ power, int64_t ld_power) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int64_t b = blockIdx.x;
-    const double* th = theta + (size_t)b * n_params;
     const int n11 = t.n11, nq = (o.n_ct > 0) ? 6 : 5;
-    double* Q = lds;
-    double* M = Q + (size_t)6 * n11;
-    double* cvec = M + (size_t)6 * n11;
-    double* sc = cvec + 6 * 32;
-    double* murec = sc + 8;                                   // [n_mu][8]: factorap, mu'^2, w_ell (n_ell <= 5), w_ell0
-    double* out = murec + (size_t)8 * DL_MAX_MU;              // [n_in] then dd0 [n_kin]
-    double qpar, qper;
-    dl_ap_qparqper(o, th, qpar, qper);
-    const double f = o.f_fid * dl_get(o.df, th);
-    const double jac = 1. / (qpar * qper * qper);
-    if (tid < 6 * 32) cvec[tid] = dl_tns_combine_coef(tid >> 5, tid & 31, f, dl_get(o.b1X, th), dl_get(o.b2, th), dl_get(o.bs, th), dl_get(o.b3, th));
-    if (tid >= 192 && tid < 192 + o.n_mu) {
-        const int m = tid - 192;
-        const double mu = o.mu[m], rq = qper / qpar;
-        const double x = 1. + mu * mu * (rq * rq - 1.);       // factorap^2 (tgc/base.py:216-222)
-        murec[8 * m] = sqrt(x);
-        murec[8 * m + 1] = mu * mu * rq * rq / x;
-        for (int l = 0; l < DL_MAX_ELL; ++l) murec[8 * m + 2 + l] = l < o.n_ell ? jac * o.wmu[l * o.n_mu + m] : 0.;
-        murec[8 * m + 7] = o.ell0 >= 0 ? jac * o.wmu[o.ell0 * o.n_mu + m] : 0.;
+    const size_t per = dl_tns_assemble_doubles(n11, o.n_in, o.n_kin);
+    const int64_t b0 = (int64_t)blockIdx.x * PPW;
+    // ---- per-point scalars, combination coefficients, mu records ----
+    for (int p = 0; p < PPW; ++p) {
+        const int64_t b = b0 + p < B ? b0 + p : B - 1;           // (a ragged last workgroup repeats the last point and does not store it)
+        const double* th = theta + (size_t)b * n_params;
+        double* base = lds + p * per;
+        double* cvec = base + (size_t)12 * n11;
+        double* murec = cvec + 6 * 32;
+        double* sc = murec + (size_t)8 * DL_MAX_MU;
+        double qpar, qper;
+        dl_ap_qparqper(o, th, qpar, qper);
+        const double f = o.f_fid * dl_get(o.df, th);
+        const double jac = 1. / (qpar * qper * qper);
+        if (tid < 6 * 32) cvec[tid] = dl_tns_combine_coef(tid >> 5, tid & 31, f, dl_get(o.b1X, th), dl_get(o.b2, th), dl_get(o.bs, th), dl_get(o.b3, th));
+        if (tid >= 192 && tid < 192 + o.n_mu) {
+            const int m = tid - 192;
+            const double mu = o.mu[m], rq = qper / qpar;
+            const double x = 1. + mu * mu * (rq * rq - 1.);       // factorap^2 (tgc/base.py:216-222)
+            murec[8 * m] = sqrt(x);
+            murec[8 * m + 1] = mu * mu * rq * rq / x;
+            for (int l = 0; l < DL_MAX_ELL; ++l) murec[8 * m + 2 + l] = l < o.n_ell ? jac * o.wmu[l * o.n_mu + m] : 0.;
+            murec[8 * m + 7] = o.ell0 >= 0 ? jac * o.wmu[o.ell0 * o.n_mu + m] : 0.;
+        }
+        if (tid == 255) {
+            double qqv = 0.;
+            for (int pp = 0; pp < DL_TNS_QPARTS; ++pp) qqv += qq[(size_t)pp * ldp + b];
+            sc[0] = qper; sc[1] = dl_get(o.sigmav, th); sc[2] = dl_get(o.sn0, th) / o.nd; sc[3] = qqv;
+        }
     }
     __syncthreads();
-    const double* tb = raw + (size_t)b * n11 * DL_TNS_NREC;
-    double qqv = 0.;
-    for (int p = 0; p < DL_TNS_QPARTS; ++p) qqv += qq[(size_t)p * ldp + b];
-    for (int i = tid; i < n11; i += nthr) {
+    // ---- the 29 tables from the sums, combined into the polynomials Q_n ----
+    for (int idx = tid; idx < n11 * PPW; idx += nthr) {
+        const int p = idx / n11, i = idx - p * n11;
+        const int64_t b = b0 + p < B ? b0 + p : B - 1;
+        double* base = lds + p * per;
+        const double* cvec = base + (size_t)12 * n11;
+        const double qqv = cvec[6 * 32 + 8 * DL_MAX_MU + 3];
         double rec[DL_TNS_NREC], v[DL_TNS_NTAB];
-        const dl_tns_double4* src = reinterpret_cast<const dl_tns_double4*>(tb + (size_t)i * DL_TNS_NREC);
+        const dl_tns_double4* src = reinterpret_cast<const dl_tns_double4*>(raw + ((size_t)b * n11 + i) * DL_TNS_NREC);
 #pragma unroll
         for (int r4 = 0; r4 < DL_TNS_NREC / 4; ++r4) { const dl_tns_double4 x4 = src[r4]; rec[4 * r4] = x4.x; rec[4 * r4 + 1] = x4.y; rec[4 * r4 + 2] = x4.z; rec[4 * r4 + 3] = x4.w; }
 #pragma unroll
         for (int r = 0; r < DL_TNS_NTAB; ++r) v[r] = dl_tns_table_entry(r, rec, rec + 32, qqv, t.sumw);
         for (int n = 0; n < nq; ++n) {
-            double s = 0.;
+            double sum = 0.;
 #pragma unroll
-            for (int r = 0; r < 29; ++r) s = fma(cvec[n * 32 + r], v[r], s);
-            Q[(size_t)n * n11 + i] = s;
+            for (int r = 0; r < DL_TNS_NTAB; ++r) sum = fma(cvec[n * 32 + r], v[r], sum);
+            base[(size_t)n * n11 + i] = sum;
         }
     }
     __syncthreads();
-    for (int i = tid; i < n11; i += nthr) {                   // second derivatives of the not-a-knot splines: M = S Q
-        double a[6] = {0., 0., 0., 0., 0., 0.};
-        for (int j = 0; j < n11; ++j) {
-            const double s = t.spT[(size_t)j * n11 + i];
-            for (int n = 0; n < nq; ++n) a[n] = fma(s, Q[(size_t)n * n11 + j], a[n]);
+    // ---- second derivatives of the not-a-knot splines: M = S Q (operator elements requested eight at a time, each used for every polynomial of every point) ----
+    for (int i = tid; i < n11; i += nthr) {
+        double a[PPW][6];
+#pragma unroll
+        for (int p = 0; p < PPW; ++p)
+#pragma unroll
+            for (int n = 0; n < 6; ++n) a[p][n] = 0.;
+        for (int j0 = 0; j0 < n11; j0 += 8) {
+            double sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv[u] = t.spT[(size_t)(j0 + u < n11 ? j0 + u : n11 - 1) * n11 + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 + u < n11) {
+#pragma unroll
+                    for (int p = 0; p < PPW; ++p) {
+                        const double* Qp = lds + p * per;
+                        for (int n = 0; n < nq; ++n) a[p][n] = fma(sv[u], Qp[(size_t)n * n11 + j0 + u], a[p][n]);
+                    }
+                }
+            }
         }
-        for (int n = 0; n < nq; ++n) M[(size_t)n * n11 + i] = a[n];
+#pragma unroll
+        for (int p = 0; p < PPW; ++p)
+            for (int n = 0; n < nq; ++n) lds[p * per + (size_t)(6 + n) * n11 + i] = a[p][n];
     }
     __syncthreads();
-    const double sigmav = dl_get(o.sigmav, th), sn0nd = dl_get(o.sn0, th) / o.nd;
-    for (int ik = tid; ik < o.n_kin; ik += nthr) {
-        double p[DL_MAX_ELL] = {0., 0., 0., 0., 0.}, dd0 = 0.;
-        const double kq = o.kin[ik] / qper;
+    // ---- evaluation at the AP-distorted (k, mu), damping, projection, bias-independent additions ----
+    for (int idx = tid; idx < o.n_kin * PPW; idx += nthr) {
+        const int p = idx / o.n_kin, ik = idx - p * o.n_kin;
+        const int64_t b = b0 + p < B ? b0 + p : B - 1;
+        const double* th = theta + (size_t)b * n_params;
+        double* base = lds + p * per;
+        const double* Q = base;
+        const double* M = base + (size_t)6 * n11;
+        const double* murec = base + (size_t)12 * n11 + 6 * 32;
+        const double* sc = murec + (size_t)8 * DL_MAX_MU;
+        double* out = base + (size_t)12 * n11 + 6 * 32 + (size_t)8 * DL_MAX_MU + 8;
+        const double sigmav = sc[1], sn0nd = sc[2];
+        double pl[DL_MAX_ELL] = {0., 0., 0., 0., 0.}, dd0 = 0.;
+        const double kq = o.kin[ik] / sc[0];
         for (int m = 0; m < o.n_mu; ++m) {
             const double kap = kq * murec[8 * m], m2 = murec[8 * m + 1];
             int i = (int)floor((kap - t.k11_0) * t.inv_dk11);
@@ -353,36 +394,36 @@ __global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsD
             const double sk = sigmav * kap, s2 = sk * sk * m2;   // (sigmav kap muap)^2
             const double damp = t.fog == 0 ? 1. / ((1. + s2 / 2.) * (1. + s2 / 2.)) : exp(-s2);   // full_shape.py:870-873
             const double pkmu = damp * (v[0] + m2 * (v[1] + m2 * (v[2] + m2 * (v[3] + m2 * v[4]))));
-            for (int l = 0; l < DL_MAX_ELL; ++l) p[l] = fma(murec[8 * m + 2 + l], pkmu, p[l]);
+            for (int l = 0; l < DL_MAX_ELL; ++l) pl[l] = fma(murec[8 * m + 2 + l], pkmu, pl[l]);
             if (nq == 6) dd0 = fma(murec[8 * m + 7], damp * v[5], dd0);
         }
         for (int l = 0; l < o.n_ell; ++l) {
-            double val = p[l] + sn0nd;                          // full_shape.py:961: on EVERY multipole
-            const size_t idx = (size_t)l * o.n_kin + ik;
-            for (int c = 0; c < o.n_ct; ++c) val += o.ct_matrix[idx * o.n_ct + c] * 0.5 * (dl_get(o.ct_in[c][0], th) + dl_get(o.ct_in[c][1], th)) * dd0;   // full_shape.py:630, 633
-            for (int c = 0; c < o.n_sn; ++c) val += o.sn_matrix[idx * o.n_sn + c] * dl_get(o.sn_in[c], th) / o.nd;                                         // full_shape.py:631, 634
-            out[idx] = val;
+            double val = pl[l] + sn0nd;                         // full_shape.py:961: on EVERY multipole
+            const size_t ix = (size_t)l * o.n_kin + ik;
+            for (int c = 0; c < o.n_ct; ++c) val += o.ct_matrix[ix * o.n_ct + c] * 0.5 * (dl_get(o.ct_in[c][0], th) + dl_get(o.ct_in[c][1], th)) * dd0;   // full_shape.py:630, 633
+            for (int c = 0; c < o.n_sn; ++c) val += o.sn_matrix[ix * o.n_sn + c] * dl_get(o.sn_in[c], th) / o.nd;                                         // full_shape.py:631, 634
+            out[ix] = val;
         }
         if (nq == 6) out[o.n_in + ik] = dd0;
     }
     __syncthreads();
-    double* power_row = power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset;
-    for (int idx = tid; idx < o.n_in; idx += nthr) power_row[idx] = out[idx];
-    if (o.n_var > 0 && o.n_ct > 0) {                            // derivative rows of analytically solved counter terms (as dl_fs_phase4)
-        for (int c = 0; c < o.n_ct; ++c)
-            for (int tt = 0; tt < 2; ++tt) {
-                const int slot = o.marg_ct_slot[c][tt];
-                if (slot < 0) continue;
-                if (tt == 1 && o.marg_ct_slot[c][0] == slot) continue;
-                const double wgt = (o.marg_ct_slot[c][0] == o.marg_ct_slot[c][1]) ? 1. : 0.5;
-                double* drow = power_row + (size_t)(1 + slot) * ld_power;
-                for (int idx = tid; idx < o.n_in; idx += nthr) drow[idx] = wgt * o.ct_matrix[(size_t)idx * o.n_ct + c] * out[o.n_in + idx % o.n_kin];
-            }
+    for (int p = 0; p < PPW; ++p) {
+        if (b0 + p >= B) break;
+        const double* out = lds + p * per + (size_t)12 * n11 + 6 * 32 + (size_t)8 * DL_MAX_MU + 8;
+        double* power_row = power + (size_t)(b0 + p) * (1 + o.n_var) * ld_power + o.col_offset;
+        for (int idx = tid; idx < o.n_in; idx += nthr) power_row[idx] = out[idx];
+        if (o.n_var > 0 && o.n_ct > 0) {                        // derivative rows of analytically solved counter terms (as dl_fs_phase4)
+            for (int c = 0; c < o.n_ct; ++c)
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int slot = o.marg_ct_slot[c][tt];
+                    if (slot < 0) continue;
+                    if (tt == 1 && o.marg_ct_slot[c][0] == slot) continue;
+                    const double wgt = (o.marg_ct_slot[c][0] == o.marg_ct_slot[c][1]) ? 1. : 0.5;
+                    double* drow = power_row + (size_t)(1 + slot) * ld_power;
+                    for (int idx = tid; idx < o.n_in; idx += nthr) drow[idx] = wgt * o.ct_matrix[(size_t)idx * o.n_ct + c] * out[o.n_in + idx % o.n_kin];
+                }
+        }
     }
-}
-
-static size_t dl_tns_assemble_shared(const DlObsDev& o, const DlTnsDev& t) {
-    return ((size_t)12 * t.n11 + 6 * 32 + 8 + (size_t)8 * DL_MAX_MU + o.n_in + o.n_kin) * sizeof(double);
 }
 
 // the 29 tables [B][29][n11] from the loop kernel's sums (diagnostics / parity)
@@ -530,14 +571,24 @@ void dl_launch_tns(const DlObsDev& obs, const double* theta, int n_params, int64
     if (!plan) { dl_set_last_error("tns: observable without a plan"); return; }
     const DlTnsDev& t = plan->dev;
     const int64_t pass = tns_pass_points(t);
-    const size_t shm = dl_tns_assemble_shared(obs, t);
+    const size_t per = dl_tns_assemble_doubles(t.n11, obs.n_in, obs.n_kin) * sizeof(double);
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
     for (int64_t b0 = 0; b0 < B; b0 += pass) {
         const int64_t nb = std::min(pass, B - b0);
         const double* th = theta + (size_t)b0 * n_params;
         if (!tns_run_loop(plan, obs, th, n_params, nb, stream)) return;
-        hipLaunchKernelGGL(dl_tns_assemble_kernel, dim3((unsigned)nb), dim3(256), shm, stream, obs, t, th, n_params, plan->tables, plan->qq, plan->ldp, power + (size_t)b0 * (1 + obs.n_var) * ld_power, ld_power);
+        double* prow = power + (size_t)b0 * (1 + obs.n_var) * ld_power;
+        // points per workgroup: as many as fit the LDS twice over (two workgroups per CU), fewer for small batches (every CU a workgroup)
+        int ppw = (4 * per <= 76 * 1024 && nb >= 1024) ? 4 : (2 * per <= 76 * 1024 && nb >= 512) ? 2 : 1;
+        if (ppw == 4) hipLaunchKernelGGL(dl_tns_assemble_kernel<4>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 4 * per, stream, obs, t, th, n_params, nb, plan->tables, plan->qq, plan->ldp, prow, ld_power);
+        else if (ppw == 2) hipLaunchKernelGGL(dl_tns_assemble_kernel<2>, dim3((unsigned)((nb + 1) / 2)), dim3(256), 2 * per, stream, obs, t, th, n_params, nb, plan->tables, plan->qq, plan->ldp, prow, ld_power);
+        else hipLaunchKernelGGL(dl_tns_assemble_kernel<1>, dim3((unsigned)nb), dim3(256), per, stream, obs, t, th, n_params, nb, plan->tables, plan->qq, plan->ldp, prow, ld_power);
     }
 }
 
