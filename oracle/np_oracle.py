@@ -321,6 +321,32 @@ def tns_tracer_power(pt, nd, b1=1., b2=0., bs=0., b3=0., sn0=0.):
 
 
 # ----------------------------------------------------------------------------------------------
+# scale-dependent bias from local primordial non-Gaussianity          primordial_non_gaussianity.py:75-116
+# ----------------------------------------------------------------------------------------------
+def png_alpha_prim(kin, pk_dd, pk_prim, h):
+    """``alpha(k)`` of method 'prim': square root of the primordial potential spectrum over the density spectrum; primordial_non_gaussianity.py:84-86."""
+    pphi_prim = 9 / 25 * 2 * np.pi**2 / kin**3 * pk_prim / h**3
+    return 1. / (pk_dd / pphi_prim)**0.5
+
+
+def png_bfnl(mode, b1, fnl_loc=0., p=1., bphi=1., bfnl_loc=0.):
+    """``bfnl_loc`` of one tracer for the three parameterisations; primordial_non_gaussianity.py:97-106."""
+    if mode == 'bphi': return bphi * fnl_loc
+    if mode == 'b-p': return 2. * 1.686 * (b1 - p) * fnl_loc
+    return bfnl_loc
+
+
+def png_tracer_power(k, mu, wmu_ell, kin, pk_dd, alpha, f, nd, b1X, b1Y, bfnlX, bfnlY, sn0=0., sigmasX=0., sigmasY=0., qpar=1., qper=1.):
+    """``PNGTracerPowerSpectrumMultipoles.calculate``, primordial_non_gaussianity.py:75-112: ``kin, pk_dd, alpha`` WITHOUT the template's first wavenumber (line 95)."""
+    jac, kap, muap = ap_k_mu(k, mu, qpar=qpar, qper=qper)
+    a = interp1d(np.log10(kap), np.log10(kin), alpha, method='cubic')
+    bX, bY = b1X + bfnlX * a, b1Y + bfnlY * a
+    fog = 1. / ((1. + sigmasX**2 * kap**2 * muap**2 / 2.) * (1. + sigmasY**2 * kap**2 * muap**2 / 2.))
+    pkmu = jac * fog * (bX + f * muap**2) * (bY + f * muap**2) * interp1d(np.log10(kap), np.log10(kin), pk_dd, method='cubic') + sn0 / nd
+    return np.sum(pkmu * wmu_ell[:, None, :], axis=-1)
+
+
+# ----------------------------------------------------------------------------------------------
 # a5: tracer combine                                          full_shape.py:545-550, 628-634
 # ----------------------------------------------------------------------------------------------
 def kaiser_tracer_power(ells, pk_dd, pk_dt, pk_tt, nd, b1X, b1Y, sn0):

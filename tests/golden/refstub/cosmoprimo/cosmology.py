@@ -97,7 +97,7 @@ class Cosmology(object):
         class _Primordial(object):
 
             def pk_interpolator(self, **kwargs):
-                return lambda k: 2.1e-9 * (np.asarray(k) / 0.05)**(cosmo.n_s - 1.) * 2. * np.pi**2 / np.asarray(k)**3
+                return lambda k: 2.1e-9 * (np.asarray(k) / 0.05)**(cosmo.n_s - 1.)   # dimensionless primordial spectrum A_s (k / k_pivot)^(n_s - 1)
 
         return _Primordial()
 
