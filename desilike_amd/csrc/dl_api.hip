@@ -186,7 +186,7 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
         if (ctx->obs[i].dev.transform != 0) ctx->any_transform = true;
     }
     for (auto& ob : ctx->obs)
-        if ((ob.dev.theory == 3 || ob.dev.theory == 4 ? 0 : ob.dev.theory == 2 ? dl_bao_shared_doubles(ob.dev.n_in) : dl_fs_shared_doubles(ob.dev.n_t, ob.dev.n_in)) * sizeof(double) > 160 * 1024)
+        if ((ob.dev.theory == 3 || ob.dev.theory == 4 ? 0 : ob.dev.theory == 5 ? dl_png_shared_doubles(ob.dev.n_t, ob.dev.n_in) : ob.dev.theory == 2 ? dl_bao_shared_doubles(ob.dev.n_in) : dl_fs_shared_doubles(ob.dev.n_t, ob.dev.n_in)) * sizeof(double) > 160 * 1024)
             return bail("dl_create: template / theory grid too large for the 160 KiB LDS");
     ctx->n_data = row;
     int n = ctx->n_data;

@@ -142,6 +142,13 @@ struct DlObsDev {
     // geometry tables and the per-evaluation workspace (dl_tns.hip), never dereferenced on the device
     DlInput sigmav, b2, bs, b3;
     void* tns_plan;
+    // scale-dependent bias from local primordial non-Gaussianity (kind 5; primordial_non_gaussianity.py:75-112): bX = b1X + bfnlX alpha(k'), with bfnl = bphi fnl_loc
+    // (png_mode 0, 'bphi') or 2 * 1.686 (b1 - p) fnl_loc (1, 'b-p'); Lorentzian damping per tracer (sigmas: X, sigmasY); alpha at the knots = png_alpha (fiducial
+    // template) * sqrt(norm / template factor), norm = template factor at the normalisation wavenumber (png_th0, png_lg0; 0, 0: none -- method 'prim')
+    DlInput fnl, pX, pY, bphiX, bphiY, sigmasY;
+    int32_t png_mode, pad_png;
+    double png_th0, png_lg0;
+    const double* png_alpha;               // [n_t]
 };
 
 DL_HD int dl_fs_n_dd0(const DlObsDev& o) { return (o.n_var > 0 && o.n_ct > 0) ? o.n_kin : 0; }   // P_dd,l=0 kept for the derivative rows
@@ -178,6 +185,9 @@ DL_HD size_t dl_fs_work_doubles(int n_t, int n_in) { size_t w = 3 * (size_t)n_t;
 DL_HD size_t dl_fs_work_doubles(int n_t, int n_in, int n_dd0) { size_t w = 3 * (size_t)n_t; if ((size_t)n_in + n_dd0 > w) w = (size_t)n_in + n_dd0; return (w + 1) & ~(size_t)1; }
 DL_HD size_t dl_fs_shared_doubles(int n_t, int n_in) { return 4 * (size_t)n_t + dl_fs_work_doubles(n_t, n_in) + DL_PT_SIZE; }
 DL_HD size_t dl_fs_shared_doubles_obs(const DlObsDev& o, bool fast = false) { return 4 * (size_t)o.n_t + dl_fs_work_doubles(o.n_t, o.n_in, dl_fs_n_dd0(o)) + (fast ? DL_PT_SIZE_FAST : DL_PT_SIZE); }
+
+// PNG kernel (dl_kernels.hip): the generic layout | coefA [4 n_t] | mu records [DL_MAX_MU][8] | scalars [16]
+DL_HD size_t dl_png_shared_doubles(int n_t, int n_in) { return dl_fs_shared_doubles(n_t, n_in) + 4 * (size_t)n_t + 8 * DL_MAX_MU + 16; }
 
 // toep: layout of the convolution path (dl_fs_phase2_fir): y sits DL_FIR_PAD zeros inside the work region, M (the moments) right after the padded y
 DL_HD DlFsShared dl_fs_shared_carve(double* base, int n_t, int n_in, int n_dd0 = -1, bool toep = false) {

@@ -61,7 +61,7 @@ struct DlObsHost {
     std::vector<double> bias;     // [n_out]: W . (sn_in (x) 1) + offset[mask] - sn_out        (window.py:459-473)
     std::vector<double> flatdata; // [n_out]
     size_t off_kin, off_lkin, off_mu, off_wmu, off_xt, off_pk, off_th, off_lg, off_ih, off_dlt, off_A, off_nC, off_inv, off_gf, off_gb, off_coef, off_ct, off_sn;
-    size_t off_cw, off_cn, off_pknowk, off_ml, off_pass;
+    size_t off_cw, off_cn, off_pknowk, off_ml, off_pass, off_png = 0;
     size_t off_eng[3][6];   // xlo, xinv, weights, center, powers, coef of each emulator engine
     int marg_vp[DL_N_VPARS];
     int marg_pass[DL_MAX_PASS];
@@ -73,7 +73,7 @@ struct DlObsHost {
         dev.ih = base + off_ih; dev.dlt = base + off_dlt; dev.sp_A = base + off_A; dev.sp_nC = base + off_nC; dev.sp_inv = base + off_inv;
         dev.sp_gf = base + off_gf; dev.sp_gb = base + off_gb; dev.coef_fixed = base + off_coef;
         dev.ct_matrix = base + off_ct; dev.sn_matrix = base + off_sn;
-        dev.coef_w = base + off_cw; dev.coef_n = base + off_cn; dev.pknow_k = base + off_pknowk; dev.ml_tab = base + off_ml; dev.pass_tab = base + off_pass;
+        dev.coef_w = base + off_cw; dev.coef_n = base + off_cn; dev.pknow_k = base + off_pknowk; dev.ml_tab = base + off_ml; dev.pass_tab = base + off_pass; dev.png_alpha = base + off_png;
         for (int e = 0; e < 3; ++e) {
             dev.eng[e].xlo = base + off_eng[e][0]; dev.eng[e].xinv = base + off_eng[e][1]; dev.eng[e].weights = base + off_eng[e][2];
             dev.eng[e].center = base + off_eng[e][3]; dev.eng[e].powers = base + off_eng[e][4]; dev.eng[e].coef = base + off_eng[e][5];
@@ -311,6 +311,7 @@ inline bool dl_build_emulated_obs(const dl_config& cfg, const std::string& p, in
             if ((int)pass_tab[2 * c] >= n_params) { err = p + "in.pass: theta column out of range"; return false; }
         }
         oh.off_pass = arena.push(pass_tab);
+        oh.off_png = oh.off_pass;
     }
     for (int c = 0; c < DL_MAX_EFT; ++c) { oh.marg_sn[c] = -1; oh.marg_ct[c][0] = oh.marg_ct[c][1] = -1; d.marg_ct_slot[c][0] = d.marg_ct_slot[c][1] = -1; }
     oh.marg_sn0 = -1;
@@ -357,7 +358,8 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         {"qpar", &d.qpar, 1.}, {"qper", &d.qper, 1.}, {"qiso", &d.qiso, 1.}, {"qap", &d.qap, 1.}, {"df", &d.df, 1.}, {"dm", &d.dm, 0.}, {"dn", &d.dn, 0.},
         {"sigmapar", &d.sigpar, 0.}, {"sigmaper", &d.sigper, 0.}, {"b1X", &d.b1X, 1.}, {"b1Y", &d.b1Y, 1.}, {"sn0", &d.sn0, 0.},
         {"dbeta", &d.dbeta, 1.}, {"sigmas", &d.sigmas, 0.}, {"dres", &d.dres, 1.},
-        {"sigmav", &d.sigmav, 0.}, {"b2", &d.b2, 0.}, {"bs", &d.bs, 0.}, {"b3", &d.b3, 0.}};
+        {"sigmav", &d.sigmav, 0.}, {"b2", &d.b2, 0.}, {"bs", &d.bs, 0.}, {"b3", &d.b3, 0.},
+        {"fnl_loc", &d.fnl, 0.}, {"pX", &d.pX, 1.}, {"pY", &d.pY, 1.}, {"bphiX", &d.bphiX, 1.}, {"bphiY", &d.bphiY, 1.}, {"sigmasY", &d.sigmasY, 0.}};
     for (auto& it : inputs) {
         *it.in = dl_input_from(cfg, p + "in." + it.name, it.def);
         if (it.in->col >= n_params) { err = p + "in." + it.name + ": theta column out of range"; return false; }
@@ -392,7 +394,7 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     d.end0a = sp.end0a; d.end0b = sp.end0b; d.end1a = sp.end1a; d.end1b = sp.end1b;
     d.x0 = x_t[0];
     d.inv_hx = (d.n_t - 1) / (x_t[d.n_t - 1] - x_t[0]);
-    d.fixed_spline = (d.templ == 0);
+    d.fixed_spline = (d.templ == 0) && d.theory != 5;   // (the PNG kernel builds its two splines per point)
     // deviation of the knot table from an exactly uniform grid in log10 k (geomspace knots: rounding only)
     std::vector<double> dlt(d.n_t);
     d.uniform_knots = 1;
@@ -527,9 +529,20 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     oh.off_gf = arena.push(gf); oh.off_gb = arena.push(gb); oh.off_coef = arena.push(coef);
     oh.off_ct = arena.push(ctm); oh.off_sn = arena.push(snm);
     oh.off_cw = arena.push(coef_w); oh.off_cn = arena.push(coef_n); oh.off_pknowk = arena.push(pknow_k);
+    std::vector<double> png_alpha(2, 0.);
+    if (d.theory == 5) {   // scale-dependent bias (primordial_non_gaussianity.py:75-112)
+        const auto& al = cfg.F(p + "png_alpha");
+        if ((int)al.size() != d.n_t) { err = p + "png_alpha (alpha at the template knots) is required by the PNG theory"; return false; }
+        if (d.n_ct > 0 || d.n_sn > 0 || d.n_pass > 0) { err = p + "counter / stochastic / pass-through terms are not part of the PNG theory"; return false; }
+        png_alpha = al;
+        d.png_mode = cfg.i(p + "png_mode", 1);
+        const auto& nk = cfg.F(p + "png_knorm");   // normalisation wavenumber of the transfer function (methods other than 'prim'), absent: none
+        if (!nk.empty()) { d.png_lg0 = std::log(nk[0] / kp); d.png_th0 = std::tanh(d.a * d.png_lg0); }
+    }
     if (ml_tab.empty()) ml_tab.assign(3, 0.);
     oh.off_ml = arena.push(ml_tab);
     oh.off_pass = arena.push(pass_tab);
+    oh.off_png = arena.push(png_alpha);
 
     for (int c = 0; c < DL_N_VPARS; ++c) { oh.marg_vp[c] = -1; d.vp_slot[c] = -1; }
     for (int e = 0; e < 3; ++e) { d.eng[e].type = -1; for (int q = 0; q < 6; ++q) oh.off_eng[e][q] = oh.off_kin; }

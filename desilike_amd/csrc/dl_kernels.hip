@@ -156,6 +156,118 @@ __global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_ker
     dl_fullshape_body<FAST, NL, EFT, DENSE>(o, theta, n_params, power, ld_power, tables, ld_tables, stop_after, stamps);
 }
 
+// ---- scale-dependent bias from local primordial non-Gaussianity (theory kind 5; primordial_non_gaussianity.py:75-112) ---------------------------------------------
+//   P(k, mu) = jac fog (bX + f mu'^2) (bY + f mu'^2) P(k') + sn0 / nd,   bX = b1X + bfnlX alpha(k'),   fog = 1 / ((1 + sX^2 k'^2 mu'^2 / 2) (1 + sY^2 k'^2 mu'^2 / 2)),
+// with TWO not-a-knot splines in log10 k' per point: the template and alpha = alpha_fid sqrt(norm / template factor).  One workgroup per point; the spline phases of
+// the generic kernel (dl_fullshape.h) run twice on the same work area, the interval polynomials of alpha are kept beside those of the template.
+// LDS: generic layout (coef [4 n_t] | work | pt) | coefA [4 n_t] | mu records [DL_MAX_MU][8] | scalars [16]
+
+__device__ __forceinline__ void dl_png_build_spline(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, bool toep) {
+    if (toep) {
+        double dlt_pref[DL_TOEP_PREF];
+#pragma unroll
+        for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (tid + it * nthr < o.n_t - 1) ? o.dlt[tid + it * nthr] : 0.;
+        dl_fs_phase2_fir(tid, nthr, o, s);
+        __syncthreads();
+        dl_fs_phase2d_toep(tid, nthr, o, s, dlt_pref);
+    } else {
+        dl_fs_phase2a(tid, nthr, o, s);
+        __syncthreads();
+        dl_fs_phase2b_dot(tid, nthr, o, s);
+        __syncthreads();
+        dl_fs_phase2b(tid, nthr, o, s);
+        __syncthreads();
+        dl_fs_phase2c_dot(tid, nthr, o, s);
+        __syncthreads();
+        dl_fs_phase2c(tid, nthr, o, s);
+        __syncthreads();
+        dl_fs_phase2d(tid, nthr, o, s);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(DL_FS_THREADS) void dl_png_kernel(DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power, int64_t ld_power) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, nthr = DL_FS_THREADS, n_t = o.n_t;
+    const int64_t b = blockIdx.x;
+    const double* th = theta + (size_t)b * n_params;
+    const bool toep = o.toeplitz;
+    const DlFsShared s = dl_fs_shared_carve(lds, n_t, o.n_in, -1, toep);
+    double* coefA = lds + dl_fs_shared_doubles(n_t, o.n_in);
+    double* murec = coefA + 4 * (size_t)n_t;                 // per mu: log10(factorap / qper), factorap, mu'^2, -, w_ell [4] (the fifth multipole weight sits in slot 3)
+    double* sc = murec + 8 * DL_MAX_MU;
+    const double dm_a = dl_get(o.dm, th) / o.a, dn = dl_get(o.dn, th);
+    // ---- scalars and mu records ----
+    if (tid == nthr - 1) {
+        double qpar, qper;
+        dl_ap_qparqper(o, th, qpar, qper);
+        const double b1X = dl_get(o.b1X, th), b1Y = dl_get(o.b1Y, th), fnl = dl_get(o.fnl, th);
+        sc[0] = qper; sc[1] = 1. / (qpar * qper * qper); sc[2] = o.f_fid * dl_get(o.df, th); sc[3] = b1X; sc[4] = b1Y;
+        // primordial_non_gaussianity.py:97-104
+        sc[5] = o.png_mode == 0 ? dl_get(o.bphiX, th) * fnl : 2. * 1.686 * (b1X - dl_get(o.pX, th)) * fnl;
+        sc[6] = o.png_mode == 0 ? dl_get(o.bphiY, th) * fnl : 2. * 1.686 * (b1Y - dl_get(o.pY, th)) * fnl;
+        const double sX = dl_get(o.sigmas, th), sY = dl_get(o.sigmasY, th);
+        sc[7] = 0.5 * sX * sX; sc[8] = 0.5 * sY * sY; sc[9] = dl_get(o.sn0, th) / o.nd;
+    }
+    if (tid >= nthr - 1 - o.n_mu && tid < nthr - 1) {
+        const int m = nthr - 2 - tid;
+        double qpar, qper;
+        dl_ap_qparqper(o, th, qpar, qper);
+        const double mu = o.mu[m], rq = qper / qpar;
+        const double x = 1. + mu * mu * (rq * rq - 1.);       // factorap^2, tgc/base.py:216-222
+        murec[8 * m] = 0.5 * log10(x) - log10(qper);
+        murec[8 * m + 1] = sqrt(x);
+        murec[8 * m + 2] = mu * mu * rq * rq / x;
+        murec[8 * m + 3] = o.n_ell > 4 ? o.wmu[4 * o.n_mu + m] : 0.;
+        for (int l = 0; l < 4; ++l) murec[8 * m + 4 + l] = l < o.n_ell ? o.wmu[l * o.n_mu + m] : 0.;
+    }
+    // ---- alpha at the knots, its spline, kept aside ----
+    if (toep && tid < 2 * DL_FIR_PAD) s.y[tid < DL_FIR_PAD ? tid - DL_FIR_PAD : n_t + tid - DL_FIR_PAD] = 0.;
+    {
+        const double norm = o.templ == 1 ? exp(dm_a * o.png_th0 + dn * o.png_lg0) : 1.;
+        for (int j = tid; j < n_t; j += nthr) {
+            const double fac = o.templ == 1 ? exp(dm_a * o.sf_th[j] + dn * o.sf_lg[j]) : 1.;
+            s.y[j] = o.png_alpha[j] * sqrt(norm / fac);        // alpha ~ 1 / sqrt(P) (primordial_non_gaussianity.py:86, 89-93)
+        }
+    }
+    __syncthreads();
+    dl_png_build_spline(tid, nthr, o, s, toep);
+    for (int j = tid; j < 4 * n_t; j += nthr) coefA[j] = s.coef[j];
+    __syncthreads();
+    // ---- the template at the knots, its spline ----
+    for (int j = tid; j < n_t; j += nthr) s.y[j] = o.templ == 1 ? o.pk_fid[j] * exp(dm_a * o.sf_th[j] + dn * o.sf_lg[j]) : o.pk_fid[j];
+    __syncthreads();
+    dl_png_build_spline(tid, nthr, o, s, toep);
+    // ---- (k, mu) evaluation and projection ----
+    const double qper = sc[0], jac = sc[1], f = sc[2], b1X = sc[3], b1Y = sc[4], bfX = sc[5], bfY = sc[6], hsX = sc[7], hsY = sc[8], sn0nd = sc[9];
+    double* out = s.out;                                        // aliases the spline work area: every thread is past it
+    __syncthreads();
+    for (int ik = tid; ik < o.n_kin; ik += nthr) {
+        const double lk = o.lkin[ik], kq = o.kin[ik] / qper;
+        double acc[DL_MAX_ELL] = {0., 0., 0., 0., 0.};
+        for (int m = 0; m < o.n_mu; ++m) {
+            const double* r = murec + 8 * m;
+            int j; double u;
+            dl_spline_locate<false>(o, lk + r[0], j, u);
+            const double* c = s.coef + 2 * j; const double* d = c + 2 * n_t;
+            const double* ca = coefA + 2 * j; const double* da = ca + 2 * n_t;
+            const double pk = fma(fma(fma(d[1], u, d[0]), u, c[1]), u, c[0]);
+            const double al = fma(fma(fma(da[1], u, da[0]), u, ca[1]), u, ca[0]);
+            const double kap = kq * r[1], mup2 = r[2];
+            const double km2 = kap * kap * mup2;
+            const double fog = 1. / ((1. + hsX * km2) * (1. + hsY * km2));
+            const double fm2 = f * mup2;
+            const double pkmu = jac * fog * (b1X + bfX * al + fm2) * (b1Y + bfY * al + fm2) * pk + sn0nd;   // primordial_non_gaussianity.py:108-111
+            for (int l = 0; l < 4; ++l) acc[l] = fma(r[4 + l], pkmu, acc[l]);
+            acc[4] = fma(r[3], pkmu, acc[4]);
+        }
+        for (int l = 0; l < o.n_ell; ++l) out[(size_t)l * o.n_kin + ik] = acc[l];
+    }
+    __syncthreads();
+    double* prow = power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset;
+    for (int idx = tid; idx < o.n_in; idx += nthr) prow[idx] = out[idx];
+}
+
 // Several observables in ONE launch (blockIdx.y = observable): two DlObsDev (2 x 2016 bytes) do not fit the 4 KB kernarg segment, so the structs are read from a
 // device array -- uniform, read-only addresses: scalar loads all the same.  Saves one launch ramp / drain per extra observable where the step is launch-latency
 // bound (two tracers x 256 walkers: 2 x 8.6 us -> one launch).
@@ -468,6 +580,12 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
         }
     }
     for (int i = 0; i < n_obs; ++i) {  // one launch per observable (1-2 in practice)
+        if (obs_host[i].theory == 5) {   // DL_THEORY_PNG
+            const size_t shm = dl_png_shared_doubles(obs_host[i].n_t, obs_host[i].n_in) * sizeof(double);
+            if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_png_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            DL_LAUNCH(dl_png_kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power);
+            continue;
+        }
         if (obs_host[i].theory == 4) {   // DL_THEORY_TNS: loop GEMM + assembly (dl_tns.hip)
             dl_launch_tns(obs_host[i], theta, n_params, B, power, ld_power, stream);
             continue;

@@ -10,7 +10,8 @@ import numpy as np
 class TabulatedFiducial(object):
     """Fiducial given as tables (e.g. exported once from cosmoprimo / CLASS / CAMB on a CPU node)."""
 
-    def __init__(self, k, pk_dd, f, pknow_dd=None, sigma8=None, rs_drag=None):
+    def __init__(self, k, pk_dd, f, pknow_dd=None, sigma8=None, rs_drag=None, h=None, A_s=None, n_s=None, k_pivot=0.05):
+        self.h, self.A_s, self.n_s, self.k_pivot = h, A_s, n_s, k_pivot   # primordial spectrum A_s (k / k_pivot)^(n_s - 1) and h: only the PNG theory needs them
         self.k = np.asarray(k, dtype='f8')
         self._logpk = np.log(np.asarray(pk_dd, dtype='f8'))
         self._logpknow = None if pknow_dd is None else np.log(np.asarray(pknow_dd, dtype='f8'))
@@ -33,6 +34,12 @@ class TabulatedFiducial(object):
             raise ValueError('no-wiggle table not provided')
         return self._interp(k, self._logpknow)
 
+    def pk_prim(self, k):
+        """Dimensionless primordial spectrum (what ``cosmo.get_primordial(mode='scalar').pk_interpolator()`` returns, primordial_non_gaussianity.py:83)."""
+        if self.A_s is None or self.n_s is None or self.h is None:
+            raise ValueError('the PNG theory needs the primordial spectrum: pass h, A_s, n_s (and k_pivot, in the units of k) to TabulatedFiducial')
+        return self.A_s * (np.asarray(k, dtype='f8') / self.k_pivot)**(self.n_s - 1.)
+
 
 class SyntheticFiducial(object):
     r"""Analytic synthetic cosmology used for benchmarks and fixtures:
@@ -41,6 +48,10 @@ class SyntheticFiducial(object):
     def __init__(self, A=2.5e4, n_s=0.965, keq=0.015, rs=100., wiggle=0.05, f=0.8):
         self.A, self.n_s, self.keq, self.rs, self.wiggle, self.f = A, n_s, keq, rs, wiggle, f
         self.rs_drag = rs
+        self.h, self.A_s, self.k_pivot = 0.7, 2.1e-9, 0.05
+
+    def pk_prim(self, k):
+        return self.A_s * (np.asarray(k, dtype='f8') / self.k_pivot)**(self.n_s - 1.)
 
     def _pk(self, k, wiggle):
         k = np.asarray(k, dtype='f8')

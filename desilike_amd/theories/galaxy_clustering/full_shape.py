@@ -267,6 +267,74 @@ class EFTLikeKaiserTracerCorrelationFunctionMultipoles(_CorrelationFunctionFromP
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# scale-dependent bias from local primordial non-Gaussianity (primordial_non_gaussianity.py)
+# ----------------------------------------------------------------------------------------------------------------------
+class PNGTracerPowerSpectrumMultipoles(KaiserTracerPowerSpectrumMultipoles):
+    r"""
+    Kaiser tracer power spectrum multipoles with the scale-dependent bias sourced by local primordial non-Gaussianity (primordial_non_gaussianity.py:12-116):
+    :math:`b \to b_1 + b_{f_\mathrm{NL}} \alpha(k')`, Lorentzian damping :math:`1 / (1 + \sigma_s^2 k'^2 \mu'^2 / 2)` per tracer, shot noise added before the projection.
+
+    Parameters: ``mode='b-p'`` (parameters fnl_loc, p: :math:`b_{f_\mathrm{NL}} = 2 \cdot 1.686 (b_1 - p) f_\mathrm{NL}`) or ``'bphi'`` (fnl_loc, bphi); b1, sigmas, sn0.
+    ``method='prim'``: :math:`\alpha = \sqrt{P_\phi / P_{dd}}` from the fiducial's primordial spectrum (the transfer-function method needs growth factors of a cosmology
+    engine: out of scope).  The reference's mode 'bfnl' does not run in the reference itself (a tuple is multiplied with an array, line 106) and is not offered.
+    Template knots as in the reference: 1000 log-spaced wavenumbers (its extra first knot at 1e-4 only normalises the transfer function of the other method, line 95).
+    """
+    _kind = 5  # DL_THEORY_PNG
+    _klim = (1e-3, 1., 1000)   # primordial_non_gaussianity.py:72
+    _deterministic_bias_params = ['b1', 'sigmas', 'bphi', 'p']
+    _stochastic_bias_params = ['sn0']
+    _own_params = {'fnl_loc': dict(prior=dict(limits=[-300., 300.]), ref=dict(limits=[-10., 10.]), delta=1., latex=r'f_{\mathrm{NL}}^{\mathrm{loc}}'),      # primordial_non_gaussianity.yaml
+                   'bphi': dict(prior=dict(limits=[-10., 10.]), ref=dict(limits=[3., 4.]), delta=0.1, latex=r'b_{\phi}'),
+                   'p': dict(value=1., prior=dict(limits=[0., 3.]), ref=dict(limits=[0.5, 1.5]), delta=0.1, latex='p'),
+                   'b1': dict(value=2., prior=dict(limits=[0.1, 10.]), ref=dict(limits=[1.5, 2.5]), delta=0.1, latex='b_{1}'),
+                   'sn0': dict(prior=dict(dist='norm', loc=0., scale=1000.), ref=dict(dist='norm', loc=0., scale=0.1), delta=0.05, latex='s_{n, 0}'),
+                   'sigmas': dict(value=0., prior=dict(limits=[0., 10.]), ref=dict(limits=[1., 4.]), delta=0.2, latex=r'\Sigma_{s}')}
+
+    @classmethod
+    def _default_params(cls, tracers=None, mode='b-p', **kwargs):
+        params = super(PNGTracerPowerSpectrumMultipoles, cls)._default_params(tracers=tracers)
+        if mode not in ('bphi', 'b-p'):
+            raise ValueError('Unknown mode {}; it must be one of ["bphi", "b-p"]'.format(mode))   # primordial_non_gaussianity.py:57-66 ('bfnl': see the class docstring)
+        drop = 'p' if mode == 'bphi' else 'bphi'
+        return {name: conf for name, conf in params.items() if name.split('.')[-1] != drop}
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        init = self.init
+        self.method = str(init.get('method', 'prim'))
+        if self.method != 'prim':
+            raise NotImplementedError("method {!r}: the transfer-function normalisation needs growth factors of a cosmology engine; only 'prim' is available".format(self.method))
+        self.mode = str(init.get('mode', 'b-p'))
+        init.setdefault('ells', (0, 2))            # primordial_non_gaussianity.py:68
+        init.setdefault('mu', 20)
+        template = init.get('template', None)
+        if template is None:
+            from .power_template import FixedPowerSpectrumTemplate
+            init['template'] = FixedPowerSpectrumTemplate()
+        super(PNGTracerPowerSpectrumMultipoles, self).initialize()
+        kt = self.template.k
+        fid = self.template.fiducial
+        pphi_prim = 9 / 25 * 2 * np.pi**2 / kt**3 * fid.pk_prim(kt) / fid.h**3      # primordial_non_gaussianity.py:85-86
+        self.alpha_fid = 1. / (self.template.pk_dd_fid / pphi_prim)**0.5
+        return self
+
+    def _theory_spec(self):
+        spec = super(PNGTracerPowerSpectrumMultipoles, self)._theory_spec()
+        spec.update(png_alpha=self.alpha_fid, png_mode=np.array([{'bphi': 0, 'b-p': 1}[self.mode]], dtype='i4'))
+        return spec
+
+    def _input_map(self):
+        toret = super(PNGTracerPowerSpectrumMultipoles, self)._input_map()
+        nsX, nsY, nsC = (ns + '.' if ns else '' for ns in multitracer_namespace(self.tracers))
+        for name in ['sigmapar', 'sigmaper']: toret.pop(name, None)
+        toret.update(fnl_loc='fnl_loc', sigmas=nsX + 'sigmas', sigmasY=nsY + 'sigmas')
+        if self.mode == 'bphi': toret.update(bphiX=nsX + 'bphi', bphiY=nsY + 'bphi')
+        else: toret.update(pX=nsX + 'p', pY=nsY + 'p')
+        return toret
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # TNS one-loop theory: the reference's own perturbation-theory producer (full_shape.py:688-1037)
 # ----------------------------------------------------------------------------------------------------------------------
 _NORM15 = dict(prior=dict(dist='norm', loc=0., scale=15.), ref=dict(dist='norm', loc=0., scale=0.5))

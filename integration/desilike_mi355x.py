@@ -22,7 +22,7 @@ import numpy as np
 
 # enumerations of include/desilike_amd.h
 DL_TEMPLATE_FIXED, DL_TEMPLATE_SHAPEFIT = 0, 1
-DL_THEORY_KAISER, DL_THEORY_EFT_KAISER, DL_THEORY_BAO_DAMPED, DL_THEORY_TNS = 0, 1, 2, 4
+DL_THEORY_KAISER, DL_THEORY_EFT_KAISER, DL_THEORY_BAO_DAMPED, DL_THEORY_TNS, DL_THEORY_PNG = 0, 1, 2, 4, 5
 DL_APMODE = {'qparqper': 0, 'qiso': 1, 'qap': 2, 'qisoqap': 3}
 
 
@@ -115,7 +115,8 @@ def extract_config(likelihood):
         eft = hasattr(ptheory, 'counterterm_matrix')
         shapefit = template.__class__.__name__.startswith('ShapeFit')
         tns = pt.__class__.__name__.startswith('TNS')                       # the reference's own one-loop producer (full_shape.py:836-971)
-        cfg[p + 'theory'] = np.array([DL_THEORY_BAO_DAMPED if bao else DL_THEORY_TNS if tns else DL_THEORY_EFT_KAISER if eft else DL_THEORY_KAISER], dtype='i4')
+        png = pt.__class__.__name__.startswith('PNGTracerPower')            # scale-dependent bias (primordial_non_gaussianity.py:12-116)
+        cfg[p + 'theory'] = np.array([DL_THEORY_BAO_DAMPED if bao else DL_THEORY_TNS if tns else DL_THEORY_PNG if png else DL_THEORY_EFT_KAISER if eft else DL_THEORY_KAISER], dtype='i4')
         if tns:
             k = np.asarray(pt.k, dtype='f8')
             cfg[p + 'tns_k11'] = np.linspace(k[0] * 0.7, k[-1] * 1.3, int(len(k) * 1.6 + 0.5))                # full_shape.py:875 (a local of calculate)
@@ -134,6 +135,15 @@ def extract_config(likelihood):
         cfg[p + 'kin'] = np.asarray(pt.k, dtype='f8')
         cfg[p + 'mu'], cfg[p + 'wmu_ell'] = np.asarray(pt.mu, dtype='f8'), np.asarray(pt.wmu, dtype='f8')
         cfg[p + 'k_t'], cfg[p + 'pk_dd_fid'] = np.asarray(template.k, dtype='f8'), np.asarray(template.pk_dd_fid, dtype='f8')
+        if png:
+            if pt.method != 'prim' or pt.mode not in ('bphi', 'b-p'):
+                raise NotImplementedError("PNG theory: method 'prim' and modes 'bphi' / 'b-p' are covered")
+            kt, cosmo = np.asarray(template.k, dtype='f8'), template.cosmo
+            pphi_prim = 9 / 25 * 2 * np.pi**2 / kt**3 * cosmo.get_primordial(mode='scalar').pk_interpolator()(kt) / cosmo.h**3          # primordial_non_gaussianity.py:83-86, at the fiducial template
+            alpha = 1. / (np.asarray(template.pk_dd_fid, dtype='f8') / pphi_prim)**0.5
+            # the first wavenumber only normalises the transfer function of the other method (line 95): not a knot of the interpolation
+            cfg[p + 'k_t'], cfg[p + 'pk_dd_fid'], cfg[p + 'png_alpha'] = kt[1:], cfg[p + 'pk_dd_fid'][1:], alpha[1:]
+            cfg[p + 'png_mode'] = np.array([{'bphi': 0, 'b-p': 1}[pt.mode]], dtype='i4')
         cfg[p + 'flatdata'] = np.asarray(obs.flatdata, dtype='f8')
         # parameter -> theta column (or constant): tracer namespaces prefix the bias / shot-noise parameters (full_shape.py:88-128)
         names = {param.basename: param.name for param in theory.all_params}
@@ -173,6 +183,9 @@ def extract_config(likelihood):
         if tns:
             for key in ['sigmapar', 'sigmaper']: defaults.pop(key)
             defaults.update(sigmav=0., b2=0., bs=0., b3=0.)
+        if png:
+            for key in ['sigmapar', 'sigmaper']: defaults.pop(key)
+            defaults.update(fnl_loc=0., sigmas=0.)
         if bao: defaults.update(dbeta=1., sigmas=0.)
         else: defaults.update(sn0=0.)
         if xi and not bao: defaults.pop('sn0')                             # no stochastic parameter for correlation functions (full_shape.py:336-364)
@@ -181,6 +194,11 @@ def extract_config(likelihood):
             cfg[p + 'in.' + key] = column(pname, value_of(pname, default))
         b1 = names.get('b1', 'b1')
         cfg[p + 'in.b1X'] = cfg[p + 'in.b1Y'] = column(b1, value_of(b1, 1.))
+        if png:   # auto-spectrum: the X and Y tracer inputs are the same parameters
+            cfg[p + 'in.sigmasY'] = cfg[p + 'in.sigmas']
+            for key in ['p', 'bphi']:
+                pname = names.get(key, key)
+                cfg[p + 'in.' + key + 'X'] = cfg[p + 'in.' + key + 'Y'] = column(pname, value_of(pname, 1.))
         if eft:
             cfg[p + 'ct_matrix'], cfg[p + 'sn_matrix'] = np.asarray(ptheory.counterterm_matrix, dtype='f8'), np.asarray(ptheory.stochastic_matrix, dtype='f8')
             ct_names = [names.get(str(n), str(n)) for n in ptheory.counterterm_params]

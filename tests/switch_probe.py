@@ -118,6 +118,17 @@ def section_tns():
     close(ctx.eval_batch_host(theta)[0][:ok.sum()], g['loglikelihood'][ok], 'tns in a 1100-row batch')
 
 
+def section_png():
+    """the PNG theory (two splines per point) against the reference fixtures"""
+    from desilike_amd._lib import Context
+    from test_oracle_png import load
+    from test_gpu_png import spec_from_png_golden
+    for name in ['png_bp_fixed', 'png_bphi_shapefit']:
+        g = load(name)
+        ctx = Context(spec_from_png_golden(g), device=0)
+        close(ctx.eval_batch_host(g['theta'])[0], g['loglikelihood'], name + ' vs reference')
+
+
 if __name__ == '__main__':
     for name in sys.argv[1:]:
         globals()['section_' + name]()
