@@ -280,3 +280,20 @@ def test_tns_next_to_a_kaiser_observable():
         flat2 = oc.window_apply(power2, matrix_full=obs2.wmatrix.matrix_full, shotnoisein=obs2.wmatrix.shotnoisein, shotnoiseout=obs2.wmatrix.shotnoiseout)
         ref = oc.gaussian_loglikelihood(np.concatenate([flat1, flat2]), like.flatdata, like.precision)[0]
         assert abs(loglike[i] - ref) <= 1e-10 * max(1., abs(ref)), (i, loglike[i], ref)
+
+
+def test_large_batch_properties(contexts):
+    """4100 rows (one wavenumber per wave; ragged last tile) built from 20 distinct points: equal rows give bit-equal results wherever they sit in the batch, and the
+    numbers agree with the 20-point evaluation (split-K loop kernel, one point per assembly workgroup) to 1e-12 -- summation orders differ, nothing else."""
+    g, ctx = contexts('tns')
+    ok = np.isfinite(g['theta']).all(axis=1) & np.isfinite(g['logprior'])
+    base = g['theta'][ok][:20]
+    small = ctx.eval_batch_host(base)[0]
+    assert (np.abs(small - g['loglikelihood'][ok][:20]) <= 1e-10 * np.maximum(1., np.abs(small))).all()
+    rng = np.random.RandomState(0)
+    idx = rng.randint(0, len(base), size=4100)
+    big = ctx.eval_batch_host(base[idx])[0]
+    for i in range(len(base)):
+        vals = big[idx == i]
+        assert len(vals) > 100 and (vals == vals[0]).all(), i
+    assert (np.abs(big - small[idx]) <= 1e-12 * np.maximum(1., np.abs(small[idx]))).all(), (np.abs(big - small[idx]) / np.maximum(1., np.abs(small[idx]))).max()
