@@ -23,7 +23,6 @@ struct DlTnsPlan {
     double* qq = nullptr;       // [cap_pts]
     double* tables = nullptr;   // [cap_pts][n11][DL_TNS_NREC] sums of the loop kernel
     int64_t ldp = 0;            // leading dimension of pk / qq at the last launch
-    std::string err;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
@@ -453,7 +452,7 @@ static T* tns_alloc(DlTnsPlan* plan, size_t n, const T* host = nullptr) {
 }
 
 DlTnsPlan* dl_tns_create(const double* k11, int n11, const double* q, int n_q, const double* mus, const double* wmus, int n_mu, int fog, const char** err) {
-    static std::string msg;
+    static thread_local std::string msg;
     auto fail = [&](DlTnsPlan* plan, const std::string& m) { msg = m; if (err) *err = msg.c_str(); dl_tns_destroy(plan); return (DlTnsPlan*)nullptr; };
     if (n11 < 5 || n_q < 4 || n_mu < 1 || n_mu > DL_TNS_MAX_MU) return fail(nullptr, "tns: table / template / cosine grid sizes out of range");
     for (int i = 0; i + 1 < n_q; ++i) if (!(q[i + 1] > q[i])) return fail(nullptr, "tns: template wavenumbers must increase");
@@ -546,12 +545,9 @@ static bool tns_run_loop(DlTnsPlan* plan, const DlObsDev& obs, const double* the
     plan->ldp = ldp;
     const int n_tiles = (int)(ldp / DL_TNS_PTS);
     const size_t tmpl = (size_t)t.nqp * DL_TNS_PTS * sizeof(double), red = (size_t)DL_TNS_WAVES * 2 * 3 * 4 * 64 * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    // (set at every call: the attribute is per device, and a process may hold contexts on several)
+    (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // one wavenumber per wave when that still fills the chip (DL_TNS_WAVEK=0 / 1 forces a variant: diagnostics)
     static const char* force = getenv("DL_TNS_WAVEK");
     const int kgroups = (t.n11 + DL_TNS_WAVES - 1) / DL_TNS_WAVES;
@@ -572,13 +568,9 @@ void dl_launch_tns(const DlObsDev& obs, const double* theta, int n_params, int64
     const DlTnsDev& t = plan->dev;
     const int64_t pass = tns_pass_points(t);
     const size_t per = dl_tns_assemble_doubles(t.n11, obs.n_in, obs.n_kin) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int64_t b0 = 0; b0 < B; b0 += pass) {
         const int64_t nb = std::min(pass, B - b0);
         const double* th = theta + (size_t)b0 * n_params;
