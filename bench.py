@@ -608,8 +608,15 @@ def main():
     if world > 1 or force_dist:
         from desilike_amd import parallel
         if backend == 'rccl':
-            group = parallel.RcclGroup(local_rank, rank=rank, world=world)
-            collective = 'RCCL {} through the C ABI (dl_comm_allgather_f64)'.format(group.rccl_version)
+            try:
+                group = parallel.RcclGroup(local_rank, rank=rank, world=world)
+                collective = 'RCCL {} through the C ABI (dl_comm_allgather_f64)'.format(group.rccl_version)
+            except Exception as exc:   # (a failure to load / initialise RCCL through the library is the same on every rank: they all take torch's binding of the same RCCL)
+                print('bench.py rank {:d}: RCCL through the C ABI failed ({}); falling back to torch.distributed nccl'.format(rank, exc), file=sys.stderr, flush=True)
+                import torch.distributed as dist
+                dist.init_process_group(backend='nccl', rank=rank, world_size=world)
+                group = parallel.TorchGroup(device=local_rank)
+                collective = 'torch.distributed nccl (RCCL)'
         else:
             import torch.distributed as dist
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
