@@ -762,6 +762,75 @@ DL_HD void dl_fs_phase4(int tid, int nthr, const DlObsDev& o, const DlFsShared& 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// PNG theory (kind 5; primordial_non_gaussianity.py:75-112): phases of dl_png_kernel (dl_kernels.hip), shared with the CPU emulation.
+//   murec [n_mu][8]: log10(factorap / qper), factorap, mu'^2, w_4, w_0 .. w_3;  sc [16]: qper, jac, f, b1X, b1Y, bfnlX, bfnlY, sX^2 / 2, sY^2 / 2, sn0 / nd
+// ------------------------------------------------------------------------------------------------------------------------
+DL_HD void dl_png_setup(int tid, int nthr, const DlObsDev& o, const double* th, double* murec, double* sc) {
+    if (tid == nthr - 1) {
+        double qpar, qper;
+        dl_ap_qparqper(o, th, qpar, qper);
+        const double b1X = dl_get(o.b1X, th), b1Y = dl_get(o.b1Y, th), fnl = dl_get(o.fnl, th);
+        sc[0] = qper; sc[1] = 1. / (qpar * qper * qper); sc[2] = o.f_fid * dl_get(o.df, th); sc[3] = b1X; sc[4] = b1Y;
+        // primordial_non_gaussianity.py:97-104
+        sc[5] = o.png_mode == 0 ? dl_get(o.bphiX, th) * fnl : 2. * 1.686 * (b1X - dl_get(o.pX, th)) * fnl;
+        sc[6] = o.png_mode == 0 ? dl_get(o.bphiY, th) * fnl : 2. * 1.686 * (b1Y - dl_get(o.pY, th)) * fnl;
+        const double sX = dl_get(o.sigmas, th), sY = dl_get(o.sigmasY, th);
+        sc[7] = 0.5 * sX * sX; sc[8] = 0.5 * sY * sY; sc[9] = dl_get(o.sn0, th) / o.nd;
+    }
+    if (tid >= nthr - 1 - o.n_mu && tid < nthr - 1) {
+        const int m = nthr - 2 - tid;
+        double qpar, qper;
+        dl_ap_qparqper(o, th, qpar, qper);
+        const double mu = o.mu[m], rq = qper / qpar;
+        const double x = 1. + mu * mu * (rq * rq - 1.);       // factorap^2, tgc/base.py:216-222
+        murec[8 * m] = 0.5 * log10(x) - log10(qper);
+        murec[8 * m + 1] = sqrt(x);
+        murec[8 * m + 2] = mu * mu * rq * rq / x;
+        murec[8 * m + 3] = o.n_ell > 4 ? o.wmu[4 * o.n_mu + m] : 0.;
+        for (int l = 0; l < 4; ++l) murec[8 * m + 4 + l] = l < o.n_ell ? o.wmu[l * o.n_mu + m] : 0.;
+    }
+}
+
+// alpha (alpha_fid sqrt(norm / template factor): alpha ~ 1 / sqrt(P), lines 86, 89-93) or the template at the knots
+DL_HD void dl_png_knots(int tid, int nthr, const DlObsDev& o, const double* th, const DlFsShared& s, bool alpha) {
+    const int n_t = o.n_t;
+    const double dm_a = dl_get(o.dm, th) / o.a, dn = dl_get(o.dn, th);
+    if (o.toeplitz && tid < 2 * DL_FIR_PAD) s.y[tid < DL_FIR_PAD ? tid - DL_FIR_PAD : n_t + tid - DL_FIR_PAD] = 0.;
+    const double norm = (alpha && o.templ == 1) ? exp(dm_a * o.png_th0 + dn * o.png_lg0) : 1.;
+    for (int j = tid; j < n_t; j += nthr) {
+        const double fac = o.templ == 1 ? exp(dm_a * o.sf_th[j] + dn * o.sf_lg[j]) : 1.;
+        s.y[j] = alpha ? o.png_alpha[j] * sqrt(norm / fac) : o.pk_fid[j] * fac;
+    }
+}
+
+// (k, mu) evaluation of both splines, bias, damping, projection (lines 107-112): out [n_ell][n_kin]
+DL_HD void dl_png_eval(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, const double* coefA, const double* murec, const double* sc, double* out) {
+    const int n_t = o.n_t;
+    const double qper = sc[0], jac = sc[1], f = sc[2], b1X = sc[3], b1Y = sc[4], bfX = sc[5], bfY = sc[6], hsX = sc[7], hsY = sc[8], sn0nd = sc[9];
+    for (int ik = tid; ik < o.n_kin; ik += nthr) {
+        const double lk = o.lkin[ik], kq = o.kin[ik] / qper;
+        double acc[DL_MAX_ELL] = {0., 0., 0., 0., 0.};
+        for (int m = 0; m < o.n_mu; ++m) {
+            const double* r = murec + 8 * m;
+            int j; double u;
+            dl_spline_locate<false>(o, lk + r[0], j, u);
+            const double* c = s.coef + 2 * j; const double* d = c + 2 * n_t;
+            const double* ca = coefA + 2 * j; const double* da = ca + 2 * n_t;
+            const double pk = fma(fma(fma(d[1], u, d[0]), u, c[1]), u, c[0]);
+            const double al = fma(fma(fma(da[1], u, da[0]), u, ca[1]), u, ca[0]);
+            const double kap = kq * r[1], mup2 = r[2];
+            const double km2 = kap * kap * mup2;
+            const double fog = 1. / ((1. + hsX * km2) * (1. + hsY * km2));
+            const double fm2 = f * mup2;
+            const double pkmu = jac * fog * (b1X + bfX * al + fm2) * (b1Y + bfY * al + fm2) * pk + sn0nd;   // lines 108-111
+            for (int l = 0; l < 4; ++l) acc[l] = fma(r[4 + l], pkmu, acc[l]);
+            acc[4] = fma(r[3], pkmu, acc[4]);
+        }
+        for (int l = 0; l < o.n_ell; ++l) out[(size_t)l * o.n_kin + ik] = acc[l];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // BAO wiggle model, 'standard' (Chen 2023): DampedBAOWigglesPowerSpectrumMultipoles.calculate bao.py:117-140.
 //   P(k, mu) = B(k, mu) P_now(k) + C(k', mu') [P_dd - P_now](k'),  P_ell = sum_mu w_ell(mu) P(k, mu)   (no Jacobian in this model)
 // The BAO template does not change P(k) (power_template.py:372-376): both splines are constants, held as interval polynomials in global

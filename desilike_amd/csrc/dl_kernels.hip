@@ -194,78 +194,21 @@ __global__ __launch_bounds__(DL_FS_THREADS) void dl_png_kernel(DlObsDev o, const
     const bool toep = o.toeplitz;
     const DlFsShared s = dl_fs_shared_carve(lds, n_t, o.n_in, -1, toep);
     double* coefA = lds + dl_fs_shared_doubles(n_t, o.n_in);
-    double* murec = coefA + 4 * (size_t)n_t;                 // per mu: log10(factorap / qper), factorap, mu'^2, -, w_ell [4] (the fifth multipole weight sits in slot 3)
+    double* murec = coefA + 4 * (size_t)n_t;
     double* sc = murec + 8 * DL_MAX_MU;
-    const double dm_a = dl_get(o.dm, th) / o.a, dn = dl_get(o.dn, th);
-    // ---- scalars and mu records ----
-    if (tid == nthr - 1) {
-        double qpar, qper;
-        dl_ap_qparqper(o, th, qpar, qper);
-        const double b1X = dl_get(o.b1X, th), b1Y = dl_get(o.b1Y, th), fnl = dl_get(o.fnl, th);
-        sc[0] = qper; sc[1] = 1. / (qpar * qper * qper); sc[2] = o.f_fid * dl_get(o.df, th); sc[3] = b1X; sc[4] = b1Y;
-        // primordial_non_gaussianity.py:97-104
-        sc[5] = o.png_mode == 0 ? dl_get(o.bphiX, th) * fnl : 2. * 1.686 * (b1X - dl_get(o.pX, th)) * fnl;
-        sc[6] = o.png_mode == 0 ? dl_get(o.bphiY, th) * fnl : 2. * 1.686 * (b1Y - dl_get(o.pY, th)) * fnl;
-        const double sX = dl_get(o.sigmas, th), sY = dl_get(o.sigmasY, th);
-        sc[7] = 0.5 * sX * sX; sc[8] = 0.5 * sY * sY; sc[9] = dl_get(o.sn0, th) / o.nd;
-    }
-    if (tid >= nthr - 1 - o.n_mu && tid < nthr - 1) {
-        const int m = nthr - 2 - tid;
-        double qpar, qper;
-        dl_ap_qparqper(o, th, qpar, qper);
-        const double mu = o.mu[m], rq = qper / qpar;
-        const double x = 1. + mu * mu * (rq * rq - 1.);       // factorap^2, tgc/base.py:216-222
-        murec[8 * m] = 0.5 * log10(x) - log10(qper);
-        murec[8 * m + 1] = sqrt(x);
-        murec[8 * m + 2] = mu * mu * rq * rq / x;
-        murec[8 * m + 3] = o.n_ell > 4 ? o.wmu[4 * o.n_mu + m] : 0.;
-        for (int l = 0; l < 4; ++l) murec[8 * m + 4 + l] = l < o.n_ell ? o.wmu[l * o.n_mu + m] : 0.;
-    }
-    // ---- alpha at the knots, its spline, kept aside ----
-    if (toep && tid < 2 * DL_FIR_PAD) s.y[tid < DL_FIR_PAD ? tid - DL_FIR_PAD : n_t + tid - DL_FIR_PAD] = 0.;
-    {
-        const double norm = o.templ == 1 ? exp(dm_a * o.png_th0 + dn * o.png_lg0) : 1.;
-        for (int j = tid; j < n_t; j += nthr) {
-            const double fac = o.templ == 1 ? exp(dm_a * o.sf_th[j] + dn * o.sf_lg[j]) : 1.;
-            s.y[j] = o.png_alpha[j] * sqrt(norm / fac);        // alpha ~ 1 / sqrt(P) (primordial_non_gaussianity.py:86, 89-93)
-        }
-    }
+    dl_png_setup(tid, nthr, o, th, murec, sc);
+    dl_png_knots(tid, nthr, o, th, s, true);                    // alpha at the knots, its spline, kept aside
     __syncthreads();
     dl_png_build_spline(tid, nthr, o, s, toep);
     for (int j = tid; j < 4 * n_t; j += nthr) coefA[j] = s.coef[j];
     __syncthreads();
-    // ---- the template at the knots, its spline ----
-    for (int j = tid; j < n_t; j += nthr) s.y[j] = o.templ == 1 ? o.pk_fid[j] * exp(dm_a * o.sf_th[j] + dn * o.sf_lg[j]) : o.pk_fid[j];
+    dl_png_knots(tid, nthr, o, th, s, false);                   // the template at the knots, its spline
     __syncthreads();
     dl_png_build_spline(tid, nthr, o, s, toep);
-    // ---- (k, mu) evaluation and projection ----
-    const double qper = sc[0], jac = sc[1], f = sc[2], b1X = sc[3], b1Y = sc[4], bfX = sc[5], bfY = sc[6], hsX = sc[7], hsY = sc[8], sn0nd = sc[9];
-    double* out = s.out;                                        // aliases the spline work area: every thread is past it
-    __syncthreads();
-    for (int ik = tid; ik < o.n_kin; ik += nthr) {
-        const double lk = o.lkin[ik], kq = o.kin[ik] / qper;
-        double acc[DL_MAX_ELL] = {0., 0., 0., 0., 0.};
-        for (int m = 0; m < o.n_mu; ++m) {
-            const double* r = murec + 8 * m;
-            int j; double u;
-            dl_spline_locate<false>(o, lk + r[0], j, u);
-            const double* c = s.coef + 2 * j; const double* d = c + 2 * n_t;
-            const double* ca = coefA + 2 * j; const double* da = ca + 2 * n_t;
-            const double pk = fma(fma(fma(d[1], u, d[0]), u, c[1]), u, c[0]);
-            const double al = fma(fma(fma(da[1], u, da[0]), u, ca[1]), u, ca[0]);
-            const double kap = kq * r[1], mup2 = r[2];
-            const double km2 = kap * kap * mup2;
-            const double fog = 1. / ((1. + hsX * km2) * (1. + hsY * km2));
-            const double fm2 = f * mup2;
-            const double pkmu = jac * fog * (b1X + bfX * al + fm2) * (b1Y + bfY * al + fm2) * pk + sn0nd;   // primordial_non_gaussianity.py:108-111
-            for (int l = 0; l < 4; ++l) acc[l] = fma(r[4 + l], pkmu, acc[l]);
-            acc[4] = fma(r[3], pkmu, acc[4]);
-        }
-        for (int l = 0; l < o.n_ell; ++l) out[(size_t)l * o.n_kin + ik] = acc[l];
-    }
+    dl_png_eval(tid, nthr, o, s, coefA, murec, sc, s.out);      // (s.out aliases the spline work area: every thread is past it)
     __syncthreads();
     double* prow = power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset;
-    for (int idx = tid; idx < o.n_in; idx += nthr) prow[idx] = out[idx];
+    for (int idx = tid; idx < o.n_in; idx += nthr) prow[idx] = s.out[idx];
 }
 
 // Several observables in ONE launch (blockIdx.y = observable): two DlObsDev (2 x 2016 bytes) do not fit the 4 KB kernarg segment, so the structs are read from a

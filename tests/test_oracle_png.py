@@ -56,3 +56,20 @@ def test_scale_dependent_bias_matters():
     row[names.index('fnl_loc')] = 0.
     nofnl = png_oracle_point(g, row, return_all=True)[1]
     assert np.abs(base[0, 0] / nofnl[0, 0] - 1.) > 0.01     # the monopole at the lowest k moves by more than a per cent
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_device_phases_on_the_cpu_against_the_reference(name):
+    """The phase functions of ``dl_png_kernel`` (csrc/dl_fullshape.h) and the host-side constant folding, compiled for the host and run thread by thread
+    (tests/csrc/emulate.cpp): power and log-likelihood of the reference's points, without a GPU."""
+    from emulation import Emulation
+    from test_gpu_png import spec_from_png_golden
+    g = load(name)
+    emu = Emulation(spec_from_png_golden(g))
+    n = len(g['int_power'])
+    power = emu.eval_theory(g['theta'][:n], iobs=0)[0]
+    assert np.allclose(power.reshape(g['int_power'].shape), g['int_power'], rtol=1e-10, atol=1e-12 * np.abs(g['int_power']).max())
+    ok = np.isfinite(g['logprior'])
+    loglike = emu.eval_batch(g['theta'][ok])[0]
+    ref = g['loglikelihood'][ok]
+    assert (np.abs(loglike - ref) <= 1e-10 * np.maximum(1., np.abs(ref))).all(), (np.abs(loglike - ref) / np.maximum(1., np.abs(ref))).max()
