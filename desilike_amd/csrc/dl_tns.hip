@@ -548,10 +548,15 @@ static bool tns_run_loop(DlTnsPlan* plan, const DlObsDev& obs, const double* the
     // (set at every call: the attribute is per device, and a process may hold contexts on several)
     (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    // one wavenumber per wave when that still fills the chip (DL_TNS_WAVEK=0 / 1 forces a variant: diagnostics)
+    // Which variant: both run in rounds of one workgroup per CU; a one-wavenumber-per-wave workgroup lasts ~7 times a split-K one (8 times the MFMAs, no reduction,
+    // one template load per 8 wavenumbers) and there are 8 times fewer of them -- whichever needs less time in whole rounds (measured crossover: ~700 - 1000 points
+    // at 192 wavenumbers).  DL_TNS_WAVEK=0 / 1 forces a variant (diagnostics, tests).
     static const char* force = getenv("DL_TNS_WAVEK");
     const int kgroups = (t.n11 + DL_TNS_WAVES - 1) / DL_TNS_WAVES;
-    const bool wavek = force ? atoi(force) != 0 : (int64_t)kgroups * n_tiles >= 256;
+    static int n_cu = 0;
+    if (n_cu == 0) { int dev = 0; hipDeviceProp_t prop; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
+    const int64_t rounds_w = ((int64_t)kgroups * n_tiles + n_cu - 1) / n_cu, rounds_s = ((int64_t)t.n11 * n_tiles + n_cu - 1) / n_cu;
+    const bool wavek = force ? atoi(force) != 0 : 7 * rounds_w < rounds_s;
     if (wavek) {
         const unsigned grid = (unsigned)(((kgroups + 7) / 8) * n_tiles * 8);
         DL_LAUNCH(dl_tns_loop_kernel<true>, dim3(grid), dim3(64 * DL_TNS_WAVES), tmpl, stream, t, plan->pk, ldp, n_tiles, plan->tables);
