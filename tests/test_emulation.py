@@ -75,6 +75,9 @@ def test_emulation_under_sanitizers():
             'import test_emulation as t\n'
             'for name in ["cfg1_kaiser_nowindow", "cfg2_shapefit_window_dense", "cfg2v_eft_damping_qisoqap"]: t.test_emulated_kernel_vs_reference(name)\n'
             't.test_emulated_two_tracers()\n'
+            'import test_oracle_png as p, test_oracle_tns as n\n'
+            'p.test_device_phases_on_the_cpu_against_the_reference("png_bphi_shapefit")\n'
+            'n.test_device_functions_on_the_cpu_against_the_reference_tables()\n'
             'print("sanitized emulation ok")\n').format(here=here, root=os.path.dirname(here))
     env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS='detect_leaks=0:abort_on_error=0:halt_on_error=1', UBSAN_OPTIONS='print_stacktrace=1:halt_on_error=1', DL_EMULATION_SANITIZE='1')
     out = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
