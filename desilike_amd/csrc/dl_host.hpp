@@ -553,7 +553,7 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         const auto& twmu = cfg.F(p + "tns_wmu");
         if (k11.empty() || tmu.empty() || tmu.size() != twmu.size()) { err = p + "tns_k11 / tns_mu / tns_wmu are required by the TNS theory"; return false; }
         if (d.n_pass != 0) { err = p + "pass-through columns are not supported by the TNS theory"; return false; }
-        if ((size_t)12 * k11.size() * sizeof(double) + (size_t)(d.n_in + d.n_kin) * sizeof(double) > 150 * 1024) { err = p + "TNS table grid too large for the LDS (n_k11 <= 1500)"; return false; }
+        if (dl_tns_assemble_doubles((int)k11.size(), d.n_in, d.n_kin, 1) * sizeof(double) > 156 * 1024) { err = p + "TNS table grid too large for the LDS of the assembly kernel (about 550 table wavenumbers)"; return false; }
         const char* terr = nullptr;
         oh.tns = dl_tns_create(k11.data(), (int)k11.size(), k_t.data(), d.n_t, tmu.data(), twmu.data(), (int)tmu.size(), cfg.i(p + "tns_fog", 0), &terr);
         if (!oh.tns) { err = p + (terr ? terr : "tns: plan creation failed"); return false; }

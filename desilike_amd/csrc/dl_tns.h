@@ -244,6 +244,11 @@ DL_HD double dl_tns_combine_coef(int n, int r, double f, double b1, double b2, d
     return r == 0 ? 1. : 0.;                              // n = 5: pk11 (counter terms)
 }
 
+// LDS of the assembly kernel (dl_tns.hip): Q [16][ldq] | M [16][ldq] | per point: cvec [6][32] | mu records [DL_MAX_MU][8] | scalars [8] | out [n_in + n_kin]
+DL_HD int dl_tns_ldq(int n11) { return n11 | 1; }
+DL_HD size_t dl_tns_assemble_point_doubles(int n_in, int n_kin) { return 6 * 32 + (size_t)8 * DL_MAX_MU + 8 + n_in + n_kin; }
+DL_HD size_t dl_tns_assemble_doubles(int n11, int n_in, int n_kin, int ppw) { return (size_t)32 * dl_tns_ldq(n11) + ppw * dl_tns_assemble_point_doubles(n_in, n_kin); }
+
 // host side (dl_tns.hip)
 #ifdef __HIPCC__
 struct DlTnsPlan;

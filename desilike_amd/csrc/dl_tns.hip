@@ -275,24 +275,25 @@ static_assert(DL_TNS_UNROLL == 4, "the round below names its four steps");
     }
 }
 
-// Assembly: PPW points per workgroup (the dense spline operator, 8 n11^2 bytes from L2, is read once per workgroup: 1.2 GB per 4096 points at one point each).
-// LDS per point: Q [6][n11] | M [6][n11] | cvec [6][32] | mu records [DL_MAX_MU][8] | scalars [8] | out [n_in + n_kin]
-DL_HD size_t dl_tns_assemble_doubles(int n11, int n_in, int n_kin) { return (size_t)12 * n11 + 6 * 32 + (size_t)8 * DL_MAX_MU + 8 + n_in + n_kin; }
+// Assembly: PPW points per workgroup, PPW x (5 or 6) polynomials = at most 16 rows of one MFMA tile.
+// LDS: Q [16][ldq] | M [16][ldq] (ldq = n11 rounded up to odd: rows of a tile land in different banks) | per point: cvec [6][32] | mu records [DL_MAX_MU][8] | scalars [8] | out [n_in + n_kin]
 
 template <int PPW>
 __global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsDev t, const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ raw,
                                                               const double* __restrict__ qq, int64_t ldp, double* __restrict__ power, int64_t ld_power) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int n11 = t.n11, nq = (o.n_ct > 0) ? 6 : 5;
-    const size_t per = dl_tns_assemble_doubles(n11, o.n_in, o.n_kin);
+    const int n11 = t.n11, nq = (o.n_ct > 0) ? 6 : 5, ldq = dl_tns_ldq(n11);
+    double* Q = lds;                                            // row p nq + n
+    double* M = lds + (size_t)16 * ldq;
+    double* extra = lds + (size_t)32 * ldq;
+    const size_t per = dl_tns_assemble_point_doubles(o.n_in, o.n_kin);
     const int64_t b0 = (int64_t)blockIdx.x * PPW;
     // ---- per-point scalars, combination coefficients, mu records ----
     for (int p = 0; p < PPW; ++p) {
         const int64_t b = b0 + p < B ? b0 + p : B - 1;           // (a ragged last workgroup repeats the last point and does not store it)
         const double* th = theta + (size_t)b * n_params;
-        double* base = lds + p * per;
-        double* cvec = base + (size_t)12 * n11;
+        double* cvec = extra + p * per;
         double* murec = cvec + 6 * 32;
         double* sc = murec + (size_t)8 * DL_MAX_MU;
         double qpar, qper;
@@ -315,13 +316,13 @@ __global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsD
             sc[0] = qper; sc[1] = dl_get(o.sigmav, th); sc[2] = dl_get(o.sn0, th) / o.nd; sc[3] = qqv;
         }
     }
+    for (int idx = tid + PPW * nq * ldq; idx < 16 * ldq; idx += nthr) Q[idx] = 0.;   // unused rows of the tile
     __syncthreads();
     // ---- the 29 tables from the sums, combined into the polynomials Q_n ----
     for (int idx = tid; idx < n11 * PPW; idx += nthr) {
         const int p = idx / n11, i = idx - p * n11;
         const int64_t b = b0 + p < B ? b0 + p : B - 1;
-        double* base = lds + p * per;
-        const double* cvec = base + (size_t)12 * n11;
+        const double* cvec = extra + p * per;
         const double qqv = cvec[6 * 32 + 8 * DL_MAX_MU + 3];
         double rec[DL_TNS_NREC], v[DL_TNS_NTAB];
         const dl_tns_double4* src = reinterpret_cast<const dl_tns_double4*>(raw + ((size_t)b * n11 + i) * DL_TNS_NREC);
@@ -333,35 +334,37 @@ __global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsD
             double sum = 0.;
 #pragma unroll
             for (int r = 0; r < DL_TNS_NTAB; ++r) sum = fma(cvec[n * 32 + r], v[r], sum);
-            base[(size_t)n * n11 + i] = sum;
+            Q[(size_t)(p * nq + n) * ldq + i] = sum;
         }
     }
     __syncthreads();
-    // ---- second derivatives of the not-a-knot splines: M = S Q (operator elements requested eight at a time, each used for every polynomial of every point) ----
-    for (int i = tid; i < n11; i += nthr) {
-        double a[PPW][6];
+    // ---- second derivatives of the not-a-knot splines, M = Q S^T: one 16-row MFMA tile (the polynomials of the workgroup's points), 16 knots per column tile, the
+    //      operator streams from L2 (336 us of a 450 us launch as a scalar loop: 4.5 TFLOP/s) ----
+    {
+        const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kk = lane >> 4;
+        const int ntiles = (n11 + 15) / 16, nsteps = (n11 + 3) / 4;
+        const double* qrow = Q + (size_t)r16 * ldq;
+        for (int t0 = wave; t0 < ntiles; t0 += 12) {              // three column tiles per pass and wave: t0, t0 + 4, t0 + 8
+            dl_tns_double4 acc[3];
+            int col[3];
 #pragma unroll
-        for (int p = 0; p < PPW; ++p)
+            for (int u = 0; u < 3; ++u) { acc[u] = (dl_tns_double4){0., 0., 0., 0.}; const int tt = t0 + 4 * u; col[u] = tt < ntiles ? tt * 16 + r16 : -1; if (col[u] >= n11) col[u] = -1; }
+            for (int st = 0; st < nsteps; ++st) {
+                const int j = 4 * st + kk;
+                const bool jin = j < n11;
+                const double a = jin ? qrow[j] : 0.;
+                double bv[3];
 #pragma unroll
-            for (int n = 0; n < 6; ++n) a[p][n] = 0.;
-        for (int j0 = 0; j0 < n11; j0 += 8) {
-            double sv[8];
+                for (int u = 0; u < 3; ++u) bv[u] = (jin && col[u] >= 0) ? t.spT[(size_t)j * n11 + col[u]] : 0.;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) sv[u] = t.spT[(size_t)(j0 + u < n11 ? j0 + u : n11 - 1) * n11 + i];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (j0 + u < n11) {
-#pragma unroll
-                    for (int p = 0; p < PPW; ++p) {
-                        const double* Qp = lds + p * per;
-                        for (int n = 0; n < nq; ++n) a[p][n] = fma(sv[u], Qp[(size_t)n * n11 + j0 + u], a[p][n]);
-                    }
-                }
+                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[u], acc[u], 0, 0, 0);
             }
-        }
 #pragma unroll
-        for (int p = 0; p < PPW; ++p)
-            for (int n = 0; n < nq; ++n) lds[p * per + (size_t)(6 + n) * n11 + i] = a[p][n];
+            for (int u = 0; u < 3; ++u)
+                if (col[u] >= 0)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) M[(size_t)(kk + 4 * r) * ldq + col[u]] = acc[u][r];   // accumulator element r of lane (kk, r16): row kk + 4 r, column r16
+        }
     }
     __syncthreads();
     // ---- evaluation at the AP-distorted (k, mu), damping, projection, bias-independent additions ----
@@ -369,12 +372,11 @@ __global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsD
         const int p = idx / o.n_kin, ik = idx - p * o.n_kin;
         const int64_t b = b0 + p < B ? b0 + p : B - 1;
         const double* th = theta + (size_t)b * n_params;
-        double* base = lds + p * per;
-        const double* Q = base;
-        const double* M = base + (size_t)6 * n11;
-        const double* murec = base + (size_t)12 * n11 + 6 * 32;
+        const double* Qp = Q + (size_t)p * nq * ldq;
+        const double* Mp = M + (size_t)p * nq * ldq;
+        const double* murec = extra + p * per + 6 * 32;
         const double* sc = murec + (size_t)8 * DL_MAX_MU;
-        double* out = base + (size_t)12 * n11 + 6 * 32 + (size_t)8 * DL_MAX_MU + 8;
+        double* out = extra + p * per + 6 * 32 + (size_t)8 * DL_MAX_MU + 8;
         const double sigmav = sc[1], sn0nd = sc[2];
         double pl[DL_MAX_ELL] = {0., 0., 0., 0., 0.}, dd0 = 0.;
         const double kq = o.kin[ik] / sc[0];
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsD
             const double ca = (a * a * a - a) * h * h / 6., cb = (bb * bb * bb - bb) * h * h / 6.;
             double v[6];
             for (int n = 0; n < nq; ++n) {
-                const double* Qn = Q + (size_t)n * n11; const double* Mn = M + (size_t)n * n11;
+                const double* Qn = Qp + (size_t)n * ldq; const double* Mn = Mp + (size_t)n * ldq;
                 v[n] = a * Qn[i] + bb * Qn[i + 1] + ca * Mn[i] + cb * Mn[i + 1];
             }
             const double sk = sigmav * kap, s2 = sk * sk * m2;   // (sigmav kap muap)^2
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsD
     __syncthreads();
     for (int p = 0; p < PPW; ++p) {
         if (b0 + p >= B) break;
-        const double* out = lds + p * per + (size_t)12 * n11 + 6 * 32 + (size_t)8 * DL_MAX_MU + 8;
+        const double* out = extra + p * per + 6 * 32 + (size_t)8 * DL_MAX_MU + 8;
         double* power_row = power + (size_t)(b0 + p) * (1 + o.n_var) * ld_power + o.col_offset;
         for (int idx = tid; idx < o.n_in; idx += nthr) power_row[idx] = out[idx];
         if (o.n_var > 0 && o.n_ct > 0) {                        // derivative rows of analytically solved counter terms (as dl_fs_phase4)
@@ -572,20 +574,23 @@ void dl_launch_tns(const DlObsDev& obs, const double* theta, int n_params, int64
     if (!plan) { dl_set_last_error("tns: observable without a plan"); return; }
     const DlTnsDev& t = plan->dev;
     const int64_t pass = tns_pass_points(t);
-    const size_t per = dl_tns_assemble_doubles(t.n11, obs.n_in, obs.n_kin) * sizeof(double);
     (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)dl_tns_assemble_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int nq = obs.n_ct > 0 ? 6 : 5;
     for (int64_t b0 = 0; b0 < B; b0 += pass) {
         const int64_t nb = std::min(pass, B - b0);
         const double* th = theta + (size_t)b0 * n_params;
         if (!tns_run_loop(plan, obs, th, n_params, nb, stream)) return;
         double* prow = power + (size_t)b0 * (1 + obs.n_var) * ld_power;
-        // points per workgroup: as many as fit the LDS twice over (two workgroups per CU), fewer for small batches (every CU a workgroup)
-        int ppw = (4 * per <= 76 * 1024 && nb >= 1024) ? 4 : (2 * per <= 76 * 1024 && nb >= 512) ? 2 : 1;
-        if (ppw == 4) hipLaunchKernelGGL(dl_tns_assemble_kernel<4>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 4 * per, stream, obs, t, th, n_params, nb, plan->tables, plan->qq, plan->ldp, prow, ld_power);
-        else if (ppw == 2) hipLaunchKernelGGL(dl_tns_assemble_kernel<2>, dim3((unsigned)((nb + 1) / 2)), dim3(256), 2 * per, stream, obs, t, th, n_params, nb, plan->tables, plan->qq, plan->ldp, prow, ld_power);
-        else hipLaunchKernelGGL(dl_tns_assemble_kernel<1>, dim3((unsigned)nb), dim3(256), per, stream, obs, t, th, n_params, nb, plan->tables, plan->qq, plan->ldp, prow, ld_power);
+        // points per workgroup: as many polynomials as the 16-row tile holds when the batch still gives every CU two workgroups, one point otherwise
+        int ppw = nb >= 1536 ? 16 / nq : nb >= 1024 ? 2 : 1;
+        while (ppw > 1 && dl_tns_assemble_doubles(t.n11, obs.n_in, obs.n_kin, ppw) * sizeof(double) > 80 * 1024) --ppw;
+        const size_t shm = dl_tns_assemble_doubles(t.n11, obs.n_in, obs.n_kin, ppw) * sizeof(double);
+        const dim3 grid((unsigned)((nb + ppw - 1) / ppw));
+        if (ppw == 3) hipLaunchKernelGGL(dl_tns_assemble_kernel<3>, grid, dim3(256), shm, stream, obs, t, th, n_params, nb, plan->tables, plan->qq, plan->ldp, prow, ld_power);
+        else if (ppw == 2) hipLaunchKernelGGL(dl_tns_assemble_kernel<2>, grid, dim3(256), shm, stream, obs, t, th, n_params, nb, plan->tables, plan->qq, plan->ldp, prow, ld_power);
+        else hipLaunchKernelGGL(dl_tns_assemble_kernel<1>, grid, dim3(256), shm, stream, obs, t, th, n_params, nb, plan->tables, plan->qq, plan->ldp, prow, ld_power);
     }
 }
 
