@@ -429,7 +429,7 @@ def other_configs(device, steps=40, warmup=5, ncheck=8):
     oracle_seconds = (time.perf_counter() - t0) / ntns
     assert err <= 1e-10, 'GPU / oracle mismatch on the TNS theory: {:.3e}'.format(err)
     n11, nq, nmu, nkin = len(g['k11_table']), len(q), 10, len(g['c.kin'])
-    flops = {'loop_gemm_algorithmic': 2 * n11 * (nq * nmu * 27 + nq * 12), 'loop_gemm_executed': 2 * n11 * (5120 * 32 + 500 * 16) if (nq, nmu) == (500, 10) else None,
+    flops = {'loop_gemm_algorithmic': 2 * n11 * (nq * nmu * 27 + nq * 12), 'loop_gemm_executed': 2 * n11 * (-(-nq * nmu // 16) * 16 * 32 + -(-nq // 4) * 4 * 16),
              'assembly': 2 * 29 * 5 * n11 + 2 * 5 * n11 * n11 + 60 * nkin * len(g['c.mu']), 'window_gemm': 2 * len(g['c.flatdata']) * 3 * nkin}
     achieved = flops['loop_gemm_algorithmic'] * B / (kernel_ms['theory'] * 1e-3) / 1e12
     out.append({'workload': 'TNS one-loop theory (reference: tns_pt, full_shape.py:749-833): 29 loop tables on {:d} wavenumbers from {:d} template wavenumbers x {:d} cosines per point, spline / AP / FoG / '
@@ -438,7 +438,7 @@ def other_configs(device, steps=40, warmup=5, ncheck=8):
                 'roofline': {'bound': 'mfma', 'kernel': 'dl_tns_loop_kernel (per table wavenumber: [points x 5000 pairs (mu, q)] . [5000 x 27 + 500 x 12] fp64 MFMA GEMM, left operand formed in registers from '
                                                         'LDS-resident templates)', 'flop_per_eval': flops, 'flop_per_launch': flops['loop_gemm_algorithmic'] * B, 'avg_launch_ms': kernel_ms['theory'],
                              'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS,
-                             'flop_count': 'the 27 bilinear + 12 linear tables the reference integrates (the kernel pads them to 32 + 16 columns and the pair list to 5120: executed count beside it)'},
+                             'flop_count': 'the 27 bilinear + 12 linear tables the reference integrates (the kernel pads them to 32 + 16 columns and the pair list to a multiple of 16: executed count beside it)'},
                 'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize']},
                 'oracle_check': {'points': ntns, 'max_rel_err_vs_oracle': float(err), 'tolerance': 1e-10},
                 'cpu_baseline': {'value': 1. / oracle_seconds, 'unit': 'evals/s', 'cores': 1, 'kind': 'port', 'sample': '{:d} evaluations of the NumPy oracle (kernels precomputed), 1 process'.format(ntns),

@@ -32,7 +32,7 @@ enum { DL_TL_PK = 0, DL_TL_SIG3, DL_TL_13D, DL_TL_13T, DL_TL_KA0 = 4, DL_TL_EA0 
 
 struct DlTnsDev {
     int32_t n11, n_q, nqp, n_mu;     // table wavenumbers; template wavenumbers (nqp: rounded up to a multiple of 4); loop cosines
-    int32_t K, fog, Kp, pad1;        // K = n_mu * n_q pairs (mu, q), Kp: rounded up to whole rounds of the loop kernel's waves (zero coefficients); fog: 0 lorentzian, 1 gaussian (full_shape.py:870-873)
+    int32_t K, fog, Kp, pad1;        // K = n_mu * n_q pairs (mu, q), Kp: rounded up to whole rounds of 16 pairs (zero coefficients); fog: 0 lorentzian, 1 gaussian (full_shape.py:870-873)
     double k11_0, inv_dk11;          // k11 = linspace: interval index of the spline evaluation
     double sumw;                     // sum of the cosine weights
     const double* k11;               // [n11]

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
     struct Rec { dl_tns_int2 j[DL_TNS_UNROLL]; dl_tns_double2 w[DL_TNS_UNROLL], c[DL_TNS_UNROLL]; };
     struct Raw { double pq[DL_TNS_UNROLL][2], pa[DL_TNS_UNROLL][2], pb[DL_TNS_UNROLL][2]; };
     struct Lhs { double g[DL_TNS_UNROLL][2]; };
-    const int ngroups = t.Kp / (4 * DL_TNS_UNROLL), rounds = WAVEK ? ngroups : ngroups / DL_TNS_WAVES;
+    const int ngroups = t.Kp / (4 * DL_TNS_UNROLL);                                      // rounds of this wave: all of them, or every 8th starting at its index
+    const int rounds = WAVEK ? ngroups : ngroups / DL_TNS_WAVES + (wave_s < ngroups % DL_TNS_WAVES ? 1 : 0);
     const dl_tns_int2* gj = reinterpret_cast<const dl_tns_int2*>(t.geomj) + (size_t)ik * t.Kp + kk;
     const dl_tns_double2* gw = reinterpret_cast<const dl_tns_double2*>(t.geomw) + (size_t)ik * t.Kp + kk;
     const dl_tns_double2* gc = reinterpret_cast<const dl_tns_double2*>(t.coef) + ((size_t)ik * t.Kp + kk) * 16 + p16;
@@ -463,7 +464,7 @@ DlTnsPlan* dl_tns_create(const double* k11, int n11, const double* q, int n_q, c
     DlTnsDev& t = plan->dev;
     std::memset(&t, 0, sizeof(t));
     t.n11 = n11; t.n_q = n_q; t.nqp = (n_q + 3) & ~3; t.n_mu = n_mu; t.K = n_mu * n_q; t.fog = fog;
-    { const int round = 4 * DL_TNS_UNROLL * DL_TNS_WAVES; t.Kp = (t.K + round - 1) / round * round; }
+    { const int round = 4 * DL_TNS_UNROLL; t.Kp = (t.K + round - 1) / round * round; if (t.Kp < round * DL_TNS_WAVES) t.Kp = round * DL_TNS_WAVES; }   // whole rounds; every wave of the split-K variant at least one
     t.k11_0 = k11[0]; t.inv_dk11 = (n11 - 1) / (k11[n11 - 1] - k11[0]);
     for (int i = 0; i + 1 < n11; ++i)
         if (std::fabs((k11[i + 1] - k11[i]) * t.inv_dk11 - 1.) > 1e-9) return fail(plan, "tns: table wavenumbers must be uniformly spaced (full_shape.py:875)");
