@@ -169,9 +169,11 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
     struct Lhs { double g[DL_TNS_UNROLL][2]; };
     const int ngroups = t.Kp / (4 * DL_TNS_UNROLL);                                      // rounds of this wave: all of them, or every 8th starting at its index
     const int rounds = WAVEK ? ngroups : ngroups / DL_TNS_WAVES + (wave_s < ngroups % DL_TNS_WAVES ? 1 : 0);
-    const dl_tns_int2* gj = reinterpret_cast<const dl_tns_int2*>(t.geomj) + (size_t)ik * t.Kp + kk;
-    const dl_tns_double2* gw = reinterpret_cast<const dl_tns_double2*>(t.geomw) + (size_t)ik * t.Kp + kk;
-    const dl_tns_double2* gc = reinterpret_cast<const dl_tns_double2*>(t.coef) + ((size_t)ik * t.Kp + kk) * 16 + p16;
+    // wave-uniform base pointers (scalar registers) + a 32-bit lane offset: the address arithmetic of the requests stays on the scalar unit
+    const dl_tns_int2* gj = reinterpret_cast<const dl_tns_int2*>(t.geomj) + (size_t)ik * t.Kp;
+    const dl_tns_double2* gw = reinterpret_cast<const dl_tns_double2*>(t.geomw) + (size_t)ik * t.Kp;
+    const dl_tns_double2* gc = reinterpret_cast<const dl_tns_double2*>(t.coef) + (size_t)ik * t.Kp * 16;
+    const int lane_rec = kk, lane_c = kk * 16 + p16;
     const double* spt = spk + p16;
     // element offset (in pairs) of the first step of a round (past the end: the last round again, requested and not used)
     auto round_offset = [&](int round) {
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
         const int g = WAVEK ? rr : rr * DL_TNS_WAVES + wave_s;
         return (size_t)g * DL_TNS_UNROLL * 4;
     };
-    auto load_step = [&](size_t e, int u, Rec& r) { r.j[u] = gj[e + 4 * u]; r.w[u] = gw[e + 4 * u]; r.c[u] = gc[(e + 4 * u) * 16]; };
+    auto load_step = [&](size_t e, int u, Rec& r) { r.j[u] = (gj + e + 4 * u)[lane_rec]; r.w[u] = (gw + e + 4 * u)[lane_rec]; r.c[u] = (gc + (e + 4 * u) * 16)[lane_c]; };
     auto read_step = [&](const Rec& r, int u, Raw& o) {
         const double* ra = spt + r.j[u].x * DL_TNS_PTS;
         const double* rq = spt + r.j[u].y * DL_TNS_PTS;
