@@ -40,7 +40,7 @@ struct DlTnsDev {
     const double* q;                 // [nqp] template wavenumbers (padding: last value)
     const double* jq;                // [nqp] q^2 wq / (4 pi^2) (padding: 0)
     const double* mus;               // [n_mu] loop cosines, then [n_mu] weights
-    const int32_t* geomj;            // [n11][Kp][2] j0 (interval of |k - q| in the template's wavenumbers), index of q
+    const int32_t* geomj;            // [n11][Kp][16][2] per lane of a 16-point tile: LDS byte offsets of P(j0) (interval of |k - q| in the template's wavenumbers) and of P(q)
     const double* geomw;             // [n11][Kp][2] w0, w1
     const double* coef;              // [n11][Kp][16][2]: columns c and 16 + c interleaved
     const double* lin;               // [n11][nqp][16]

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void dl_tns_geometry_kernel(DlTnsDev t, int32_
             for (int i = 0; i < 27; ++i) c[i] = g.c[i];
             dl_tns_interp_weights(t.q, t.n_q, g.r, j, w0, w1);
         }
-        geomj[2 * kappa] = j; geomj[2 * kappa + 1] = iq;
+        // per lane of a 16-point tile: the LDS byte offsets (within the template tile [nqp][32]) of P(j0) and of P(q) -- the loop kernel uses them as they are
+        for (int p = 0; p < 16; ++p) { geomj[(kappa * 16 + p) * 2] = (j * DL_TNS_PTS + p) * 8; geomj[(kappa * 16 + p) * 2 + 1] = (iq * DL_TNS_PTS + p) * 8; }
         geomw[2 * kappa] = w0; geomw[2 * kappa + 1] = w1;
         for (int i = 0; i < 16; ++i) { coef[(kappa * 16 + i) * 2] = c[i]; coef[(kappa * 16 + i) * 2 + 1] = c[16 + i]; }
     }
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(64) void dl_tns_geometry_fold_kernel(DlTnsDev t, co
             if (w0 == 0. && w1 == 0.) continue;
             DlTnsGeom g;
             dl_tns_geometry(k, t.q[iq], t.jq[iq], t.mus[im], t.mus[t.n_mu + im], g);
-            const int j = geomj[2 * kappa];
+            const int j = geomj[kappa * 32] / (8 * DL_TNS_PTS);
             lin[((size_t)ik * t.nqp + j) * DL_TNS_NLIN + DL_TL_EA0 + u] += g.ca[i] * w0;
             lin[((size_t)ik * t.nqp + j + 1) * DL_TNS_NLIN + DL_TL_EA0 + u] += g.ca[i] * w1;
         }
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
     const int ngroups = t.Kp / (4 * DL_TNS_UNROLL);                                      // rounds of this wave: all of them, or every 8th starting at its index
     const int rounds = WAVEK ? ngroups : ngroups / DL_TNS_WAVES + (wave_s < ngroups % DL_TNS_WAVES ? 1 : 0);
     // wave-uniform base pointers (scalar registers) + a 32-bit lane offset: the address arithmetic of the requests stays on the scalar unit
-    const dl_tns_int2* gj = reinterpret_cast<const dl_tns_int2*>(t.geomj) + (size_t)ik * t.Kp;
+    const dl_tns_int2* gj = reinterpret_cast<const dl_tns_int2*>(t.geomj) + (size_t)ik * t.Kp * 16;
     const dl_tns_double2* gw = reinterpret_cast<const dl_tns_double2*>(t.geomw) + (size_t)ik * t.Kp;
     const dl_tns_double2* gc = reinterpret_cast<const dl_tns_double2*>(t.coef) + (size_t)ik * t.Kp * 16;
     const int lane_rec = kk, lane_c = kk * 16 + p16;
@@ -181,10 +182,14 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
         const int g = WAVEK ? rr : rr * DL_TNS_WAVES + wave_s;
         return (size_t)g * DL_TNS_UNROLL * 4;
     };
-    auto load_step = [&](size_t e, int u, Rec& r) { r.j[u] = (gj + e + 4 * u)[lane_rec]; r.w[u] = (gw + e + 4 * u)[lane_rec]; r.c[u] = (gc + (e + 4 * u) * 16)[lane_c]; };
+    auto load_step = [&](size_t e, int u, Rec& r) { r.j[u] = (gj + (e + 4 * u) * 16)[lane_c]; r.w[u] = (gw + e + 4 * u)[lane_rec]; r.c[u] = (gc + (e + 4 * u) * 16)[lane_c]; };
     auto read_step = [&](const Rec& r, int u, Raw& o) {
-        const double* ra = spt + r.j[u].x * DL_TNS_PTS;
-        const double* rq = spt + r.j[u].y * DL_TNS_PTS;
+        // The record holds this lane's LDS byte addresses (the template tile is the first thing in the kernel's LDS, which starts at 0: dynamic LDS only -- asserted by
+        // the parity tests); built from the integer, the address goes into the ds_read as it is (through `lds + offset` the compiler adds the segment's base, 0, with
+        // a vector instruction per read).
+        typedef const __attribute__((address_space(3))) double* lds_cptr;
+        lds_cptr ra = (lds_cptr)(uint32_t)r.j[u].x;
+        lds_cptr rq = (lds_cptr)(uint32_t)r.j[u].y;
 #pragma unroll
         for (int m = 0; m < 2; ++m) { o.pq[u][m] = rq[16 * m]; o.pa[u][m] = ra[16 * m]; o.pb[u][m] = ra[DL_TNS_PTS + 16 * m]; }
     };
@@ -495,7 +500,7 @@ DlTnsPlan* dl_tns_create(const double* k11, int n11, const double* q, int n_q, c
     }
     t.k11 = tns_alloc(plan, n11, k11); t.x11 = tns_alloc(plan, n11, x11.data()); t.q = tns_alloc(plan, t.nqp, qp.data()); t.jq = tns_alloc(plan, t.nqp, jq.data());
     t.mus = tns_alloc(plan, 2 * n_mu, mw.data()); t.spT = tns_alloc(plan, spT.size(), spT.data());
-    int32_t* geomj = tns_alloc<int32_t>(plan, (size_t)n11 * t.Kp * 2);
+    int32_t* geomj = tns_alloc<int32_t>(plan, (size_t)n11 * t.Kp * 32);
     double* geomw = tns_alloc<double>(plan, (size_t)n11 * t.Kp * 2);
     double* coef = tns_alloc<double>(plan, (size_t)n11 * t.Kp * DL_TNS_NCOL);
     double* lin = tns_alloc<double>(plan, (size_t)n11 * t.nqp * DL_TNS_NLIN);
