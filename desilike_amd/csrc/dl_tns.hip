@@ -155,6 +155,8 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
     const int ik = live ? ik_raw : t.n11 - 1;
     const int p16 = lane & 15, kk = lane >> 4;
     double* spk = lds;                                       // [nqp][32]
+    // (the records address this tile by absolute LDS byte offsets: it must start at 0 -- true while the kernel has no static LDS)
+    if ((uint32_t)(size_t)(const __attribute__((address_space(3))) double*)spk != 0u) __builtin_trap();
     for (int idx = tid; idx < t.nqp * DL_TNS_PTS; idx += 64 * DL_TNS_WAVES)
         spk[idx] = pk[(size_t)(idx >> 5) * ldp + (size_t)tile * DL_TNS_PTS + (idx & 31)];
     __syncthreads();
