@@ -52,6 +52,8 @@ struct DlTnsPlan;
 struct DlObsHost {
     DlObsDev dev;   // pointers are OFFSETS into arena (in doubles) until rebase()
     DlTnsPlan* tns = nullptr;   // TNS one-loop theory: geometry tables + workspace (dl_tns.hip), owned by the observable
+    std::vector<double> tns_k11, tns_mu, tns_wmu, tns_kt;   // ... its table wavenumbers, loop cosines and template wavenumbers (host copies: the CPU emulation works from them)
+    int tns_fog = 0;
     int n_out = 0;  // data size of this observable
     // analytic marginalisation: index of the solved parameter fed by each linear input of this observable (-1: not solved)
     int marg_sn0 = -1;
@@ -547,19 +549,20 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     for (int c = 0; c < DL_N_VPARS; ++c) { oh.marg_vp[c] = -1; d.vp_slot[c] = -1; }
     for (int e = 0; e < 3; ++e) { d.eng[e].type = -1; for (int q = 0; q < 6; ++q) oh.off_eng[e][q] = oh.off_kin; }
     if (d.theory == 4) {   // TNS one-loop tables: geometry on the device, once (dl_tns.h)
-#ifdef __HIPCC__
         const auto& k11 = cfg.F(p + "tns_k11");
         const auto& tmu = cfg.F(p + "tns_mu");
         const auto& twmu = cfg.F(p + "tns_wmu");
         if (k11.empty() || tmu.empty() || tmu.size() != twmu.size()) { err = p + "tns_k11 / tns_mu / tns_wmu are required by the TNS theory"; return false; }
         if (d.n_pass != 0) { err = p + "pass-through columns are not supported by the TNS theory"; return false; }
         if (dl_tns_assemble_doubles((int)k11.size(), d.n_in, d.n_kin, 1) * sizeof(double) > 156 * 1024) { err = p + "TNS table grid too large for the LDS of the assembly kernel (about 550 table wavenumbers)"; return false; }
+        oh.tns_k11 = k11; oh.tns_mu = tmu; oh.tns_wmu = twmu; oh.tns_kt = k_t; oh.tns_fog = cfg.i(p + "tns_fog", 0);
+#ifdef __HIPCC__
         const char* terr = nullptr;
-        oh.tns = dl_tns_create(k11.data(), (int)k11.size(), k_t.data(), d.n_t, tmu.data(), twmu.data(), (int)tmu.size(), cfg.i(p + "tns_fog", 0), &terr);
+        oh.tns = dl_tns_create(k11.data(), (int)k11.size(), k_t.data(), d.n_t, tmu.data(), twmu.data(), (int)tmu.size(), oh.tns_fog, &terr);
         if (!oh.tns) { err = p + (terr ? terr : "tns: plan creation failed"); return false; }
         d.tns_plan = oh.tns;
 #else
-        err = p + "the TNS theory is not part of the CPU emulation"; return false;
+        d.tns_plan = &oh;   // CPU emulation (tests/csrc/emulate.cpp): the host record itself (it must not move while the observable is in use)
 #endif
     }
     return dl_build_window(cfg, p, oh, err);

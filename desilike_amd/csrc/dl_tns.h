@@ -244,6 +244,54 @@ DL_HD double dl_tns_combine_coef(int n, int r, double f, double b1, double b2, d
     return r == 0 ? 1. : 0.;                              // n = 5: pk11 (counter terms)
 }
 
+// ---- assembly, per theory wavenumber ik: the polynomials Q_n (rows of Q, second derivatives in M, row stride ldq) at the AP-distorted (k, mu), damping, projection,
+//      shot noise and EFT-like terms (full_shape.py:865-899, 957-971, 628-634): out [n_ell][n_kin] (+ the projected linear spectrum, monopole, at out [n_in + ik] when
+//      counter terms need it).  murec [n_mu][8]: factorap, mu'^2, jac w_ell [5], jac w_(ell = 0);  sc: qper, sigmav, sn0 / nd.  Shared by dl_tns_assemble_kernel and the
+//      CPU emulation. ----
+DL_HD void dl_tns_eval_k(const DlObsDev& o, int fog, double k11_0, double inv_dk11, const double* x11, int n11, int ldq, int nq, const double* Q, const double* M,
+                         const double* murec, const double* sc, const double* th, int ik, double* out) {
+    const double sigmav = sc[1], sn0nd = sc[2];
+    double pl[DL_MAX_ELL] = {0., 0., 0., 0., 0.}, dd0 = 0.;
+    const double kq = o.kin[ik] / sc[0];
+    for (int m = 0; m < o.n_mu; ++m) {
+        const double kap = kq * murec[8 * m], m2 = murec[8 * m + 1];
+        int i = (int)floor((kap - k11_0) * inv_dk11);
+        i = i < 0 ? 0 : (i > n11 - 2 ? n11 - 2 : i);
+        const double x = log10(kap), xl = x11[i], xr = x11[i + 1], h = xr - xl;
+        const double a = (xr - x) / h, bb = (x - xl) / h;
+        const double ca = (a * a * a - a) * h * h / 6., cb = (bb * bb * bb - bb) * h * h / 6.;
+        double v[6];
+        for (int n = 0; n < nq; ++n) {
+            const double* Qn = Q + (size_t)n * ldq; const double* Mn = M + (size_t)n * ldq;
+            v[n] = a * Qn[i] + bb * Qn[i + 1] + ca * Mn[i] + cb * Mn[i + 1];
+        }
+        const double sk = sigmav * kap, s2 = sk * sk * m2;   // (sigmav kap muap)^2
+        const double damp = fog == 0 ? 1. / ((1. + s2 / 2.) * (1. + s2 / 2.)) : exp(-s2);   // full_shape.py:870-873
+        const double pkmu = damp * (v[0] + m2 * (v[1] + m2 * (v[2] + m2 * (v[3] + m2 * v[4]))));
+        for (int l = 0; l < DL_MAX_ELL; ++l) pl[l] = fma(murec[8 * m + 2 + l], pkmu, pl[l]);
+        if (nq == 6) dd0 = fma(murec[8 * m + 7], damp * v[5], dd0);
+    }
+    for (int l = 0; l < o.n_ell; ++l) {
+        double val = pl[l] + sn0nd;                         // full_shape.py:961: on EVERY multipole
+        const size_t ix = (size_t)l * o.n_kin + ik;
+        for (int c = 0; c < o.n_ct; ++c) val += o.ct_matrix[ix * o.n_ct + c] * 0.5 * (dl_get(o.ct_in[c][0], th) + dl_get(o.ct_in[c][1], th)) * dd0;   // full_shape.py:630, 633
+        for (int c = 0; c < o.n_sn; ++c) val += o.sn_matrix[ix * o.n_sn + c] * dl_get(o.sn_in[c], th) / o.nd;                                         // full_shape.py:631, 634
+        out[ix] = val;
+    }
+    if (nq == 6) out[o.n_in + ik] = dd0;
+}
+
+// per-mu records of the assembly (murec, see dl_tns_eval_k)
+DL_HD void dl_tns_mu_record(const DlObsDev& o, double qpar, double qper, int m, double* murec) {
+    const double jac = 1. / (qpar * qper * qper);
+    const double mu = o.mu[m], rq = qper / qpar;
+    const double x = 1. + mu * mu * (rq * rq - 1.);       // factorap^2 (tgc/base.py:216-222)
+    murec[8 * m] = sqrt(x);
+    murec[8 * m + 1] = mu * mu * rq * rq / x;
+    for (int l = 0; l < DL_MAX_ELL; ++l) murec[8 * m + 2 + l] = l < o.n_ell ? jac * o.wmu[l * o.n_mu + m] : 0.;
+    murec[8 * m + 7] = o.ell0 >= 0 ? jac * o.wmu[o.ell0 * o.n_mu + m] : 0.;
+}
+
 // LDS of the assembly kernel (dl_tns.hip): Q [16][ldq] | M [16][ldq] | per point: cvec [6][32] | mu records [DL_MAX_MU][8] | scalars [8] | out [n_in + n_kin]
 DL_HD int dl_tns_ldq(int n11) { return n11 | 1; }
 DL_HD size_t dl_tns_assemble_point_doubles(int n_in, int n_kin) { return 6 * 32 + (size_t)8 * DL_MAX_MU + 8 + n_in + n_kin; }

@@ -311,15 +311,7 @@ __global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsD
         const double f = o.f_fid * dl_get(o.df, th);
         const double jac = 1. / (qpar * qper * qper);
         if (tid < 6 * 32) cvec[tid] = dl_tns_combine_coef(tid >> 5, tid & 31, f, dl_get(o.b1X, th), dl_get(o.b2, th), dl_get(o.bs, th), dl_get(o.b3, th));
-        if (tid >= 192 && tid < 192 + o.n_mu) {
-            const int m = tid - 192;
-            const double mu = o.mu[m], rq = qper / qpar;
-            const double x = 1. + mu * mu * (rq * rq - 1.);       // factorap^2 (tgc/base.py:216-222)
-            murec[8 * m] = sqrt(x);
-            murec[8 * m + 1] = mu * mu * rq * rq / x;
-            for (int l = 0; l < DL_MAX_ELL; ++l) murec[8 * m + 2 + l] = l < o.n_ell ? jac * o.wmu[l * o.n_mu + m] : 0.;
-            murec[8 * m + 7] = o.ell0 >= 0 ? jac * o.wmu[o.ell0 * o.n_mu + m] : 0.;
-        }
+        if (tid >= 192 && tid < 192 + o.n_mu) dl_tns_mu_record(o, qpar, qper, tid - 192, murec);
         if (tid == 255) {
             double qqv = 0.;
             for (int pp = 0; pp < DL_TNS_QPARTS; ++pp) qqv += qq[(size_t)pp * ldp + b];
@@ -387,35 +379,7 @@ __global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsD
         const double* murec = extra + p * per + 6 * 32;
         const double* sc = murec + (size_t)8 * DL_MAX_MU;
         double* out = extra + p * per + 6 * 32 + (size_t)8 * DL_MAX_MU + 8;
-        const double sigmav = sc[1], sn0nd = sc[2];
-        double pl[DL_MAX_ELL] = {0., 0., 0., 0., 0.}, dd0 = 0.;
-        const double kq = o.kin[ik] / sc[0];
-        for (int m = 0; m < o.n_mu; ++m) {
-            const double kap = kq * murec[8 * m], m2 = murec[8 * m + 1];
-            int i = (int)floor((kap - t.k11_0) * t.inv_dk11);
-            i = i < 0 ? 0 : (i > n11 - 2 ? n11 - 2 : i);
-            const double x = log10(kap), xl = t.x11[i], xr = t.x11[i + 1], h = xr - xl;
-            const double a = (xr - x) / h, bb = (x - xl) / h;
-            const double ca = (a * a * a - a) * h * h / 6., cb = (bb * bb * bb - bb) * h * h / 6.;
-            double v[6];
-            for (int n = 0; n < nq; ++n) {
-                const double* Qn = Qp + (size_t)n * ldq; const double* Mn = Mp + (size_t)n * ldq;
-                v[n] = a * Qn[i] + bb * Qn[i + 1] + ca * Mn[i] + cb * Mn[i + 1];
-            }
-            const double sk = sigmav * kap, s2 = sk * sk * m2;   // (sigmav kap muap)^2
-            const double damp = t.fog == 0 ? 1. / ((1. + s2 / 2.) * (1. + s2 / 2.)) : exp(-s2);   // full_shape.py:870-873
-            const double pkmu = damp * (v[0] + m2 * (v[1] + m2 * (v[2] + m2 * (v[3] + m2 * v[4]))));
-            for (int l = 0; l < DL_MAX_ELL; ++l) pl[l] = fma(murec[8 * m + 2 + l], pkmu, pl[l]);
-            if (nq == 6) dd0 = fma(murec[8 * m + 7], damp * v[5], dd0);
-        }
-        for (int l = 0; l < o.n_ell; ++l) {
-            double val = pl[l] + sn0nd;                         // full_shape.py:961: on EVERY multipole
-            const size_t ix = (size_t)l * o.n_kin + ik;
-            for (int c = 0; c < o.n_ct; ++c) val += o.ct_matrix[ix * o.n_ct + c] * 0.5 * (dl_get(o.ct_in[c][0], th) + dl_get(o.ct_in[c][1], th)) * dd0;   // full_shape.py:630, 633
-            for (int c = 0; c < o.n_sn; ++c) val += o.sn_matrix[ix * o.n_sn + c] * dl_get(o.sn_in[c], th) / o.nd;                                         // full_shape.py:631, 634
-            out[ix] = val;
-        }
-        if (nq == 6) out[o.n_in + ik] = dd0;
+        dl_tns_eval_k(o, t.fog, t.k11_0, t.inv_dk11, t.x11, n11, ldq, nq, Qp, Mp, murec, sc, th, ik, out);
     }
     __syncthreads();
     for (int p = 0; p < PPW; ++p) {

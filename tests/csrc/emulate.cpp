@@ -20,7 +20,46 @@ int emu_config_set_f64(dl_config* cfg, const char* key, const double* data, int6
 int emu_config_set_i32(dl_config* cfg, const char* key, const int32_t* data, int64_t n) { cfg->i32[key] = std::vector<int32_t>(data, data + n); return 0; }
 const char* emu_last_error(void) { return g_err.c_str(); }
 
+extern "C" int emu_tns_tables(const double* k11, int n11, const double* q, int n_q, const double* mus, const double* wmus, int n_mu, const double* pk, double* tables);
+
+// TNS one-loop theory of ONE point: the template, the 29 tables by the device's geometry / table functions run sequentially (emu_tns_tables), then what
+// dl_tns_assemble_kernel does -- combination into the polynomials Q_n, second derivatives through the same not-a-knot operator the plan builds, dl_tns_eval_k
+static void run_point_tns(const DlObsDev& o, const double* th, double* prow) {
+    const DlObsHost& oh = *static_cast<const DlObsHost*>(o.tns_plan);
+    const int n11 = (int)oh.tns_k11.size(), n_q = o.n_t, nq = o.n_ct > 0 ? 6 : 5, ldq = dl_tns_ldq(n11);
+    std::vector<double> pk(n_q), tables((size_t)DL_TNS_NTAB * n11);
+    const double dm_a = dl_get(o.dm, th) / o.a, dn = dl_get(o.dn, th);
+    for (int j = 0; j < n_q; ++j) pk[j] = o.templ == 1 ? o.pk_fid[j] * std::exp(dm_a * o.sf_th[j] + dn * o.sf_lg[j]) : o.pk_fid[j];
+    emu_tns_tables(oh.tns_k11.data(), n11, oh.tns_kt.data(), n_q, oh.tns_mu.data(), oh.tns_wmu.data(), (int)oh.tns_mu.size(), pk.data(), tables.data());
+    double qpar, qper;
+    dl_ap_qparqper(o, th, qpar, qper);
+    const double f = o.f_fid * dl_get(o.df, th);
+    std::vector<double> Q((size_t)6 * ldq, 0.), M((size_t)6 * ldq, 0.), murec(8 * DL_MAX_MU, 0.), x11(n11);
+    for (int n = 0; n < nq; ++n)
+        for (int i = 0; i < n11; ++i) {
+            double sum = 0.;
+            for (int r = 0; r < DL_TNS_NTAB; ++r) sum = std::fma(dl_tns_combine_coef(n, r, f, dl_get(o.b1X, th), dl_get(o.b2, th), dl_get(o.bs, th), dl_get(o.b3, th)), tables[(size_t)r * n11 + i], sum);
+            Q[(size_t)n * ldq + i] = sum;
+        }
+    for (int i = 0; i < n11; ++i) x11[i] = std::log10(oh.tns_k11[i]);
+    DlSplineSetup sp;
+    std::string serr;
+    dl_spline_setup(x11, sp, serr);
+    for (int n = 0; n < nq; ++n) {
+        std::vector<double> y(Q.begin() + (size_t)n * ldq, Q.begin() + (size_t)n * ldq + n11), Mv;
+        dl_spline_moments_serial(y, sp, Mv);
+        for (int i = 0; i < n11; ++i) M[(size_t)n * ldq + i] = Mv[i];
+    }
+    for (int m = 0; m < o.n_mu; ++m) dl_tns_mu_record(o, qpar, qper, m, murec.data());
+    const double sc[4] = {qper, dl_get(o.sigmav, th), dl_get(o.sn0, th) / o.nd, 0.};
+    std::vector<double> out((size_t)o.n_in + o.n_kin, 0.);
+    const double inv_dk11 = (n11 - 1) / (oh.tns_k11[n11 - 1] - oh.tns_k11[0]);
+    for (int ik = 0; ik < o.n_kin; ++ik) dl_tns_eval_k(o, oh.tns_fog, oh.tns_k11[0], inv_dk11, x11.data(), n11, ldq, nq, Q.data(), M.data(), murec.data(), sc, th, ik, out.data());
+    for (int idx = 0; idx < o.n_in; ++idx) prow[idx] = out[idx];
+}
+
 static void run_point(const DlObsDev& o, const double* th, double* prow, double* trow) {
+    if (o.theory == 4) { run_point_tns(o, th, prow); return; }
     if (o.theory == 3) {   // emulated theory
         std::vector<double> lds(dl_emu_shared_doubles(o.n_var));
         dl_emu_point(o, th, lds.data(), prow, o.n_in + o.n_pass);

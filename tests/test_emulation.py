@@ -78,6 +78,7 @@ def test_emulation_under_sanitizers():
             'import test_oracle_png as p, test_oracle_tns as n\n'
             'p.test_device_phases_on_the_cpu_against_the_reference("png_bphi_shapefit")\n'
             'n.test_device_functions_on_the_cpu_against_the_reference_tables()\n'
+            'n.test_whole_device_path_on_the_cpu_against_the_reference("tns_standard_gaussian")\n'
             'print("sanitized emulation ok")\n').format(here=here, root=os.path.dirname(here))
     env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS='detect_leaks=0:abort_on_error=0:halt_on_error=1', UBSAN_OPTIONS='print_stacktrace=1:halt_on_error=1', DL_EMULATION_SANITIZE='1')
     out = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)

@@ -155,3 +155,23 @@ def test_device_bias_combination_against_the_reference_power():
         assert np.isclose(cvec[1][17], b1 * b1 * f * f) and np.isclose(cvec[1][18], -b1 * f**3) and np.isclose(cvec[1][19], -b1 * f**3) and np.isclose(cvec[1][20], f**4)
         assert np.isclose(cvec[2][21], b1 * b1 * f * f) and np.isclose(cvec[2][22], -b1 * f**3) and np.isclose(cvec[2][24], f**4) and np.isclose(cvec[3][25], -b1 * f**3) and np.isclose(cvec[3][27], f**4)
         assert np.isclose(cvec[4][28], f**4) and cvec[5][0] == 1. and np.count_nonzero(cvec[5]) == 1
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_whole_device_path_on_the_cpu_against_the_reference(name):
+    """The TNS path end to end on the CPU -- host-side constant folding (dl_host.hpp), the device's geometry / table functions, the combination into the mu'^2n
+    polynomials, the spline operator and dl_tns_eval_k (what the assembly kernel runs), window, chi2 -- against the reference's power and log-likelihoods."""
+    from emulation import Emulation
+    from test_gpu_tns import spec_from_tns_golden
+    g = load(name)
+    emu = Emulation(spec_from_tns_golden(g))
+    rows = g['theta'][:2].copy()
+    for i in range(2):
+        if not np.all(np.isfinite(rows[i])): rows[i] = g['theta'][0]
+    power = emu.eval_theory(rows, iobs=0)[0]
+    ref = g['int_power'][:2]
+    assert np.allclose(power.reshape(ref.shape), ref, rtol=1e-10, atol=1e-11 * np.abs(ref).max()), np.abs(power.reshape(ref.shape) - ref).max() / np.abs(ref).max()
+    ok = np.isfinite(g['theta']).all(axis=1) & np.isfinite(g['logprior'])
+    idx = np.flatnonzero(ok)[:3]
+    loglike = emu.eval_batch(g['theta'][idx])[0]
+    assert (np.abs(loglike - g['loglikelihood'][idx]) <= 1e-10 * np.maximum(1., np.abs(g['loglikelihood'][idx]))).all()
