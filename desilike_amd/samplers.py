@@ -8,6 +8,8 @@ installed and otherwise the built-in affine-invariant stretch move (Goodman & We
 half-ensemble exactly like emcee's default ``StretchMove``.  With ``torch.distributed`` initialised (one process per GPU) the walkers of
 every call are sharded across ranks and the log-posteriors all-gathered (``desilike_amd.parallel.WalkerSharding``).
 """
+import os
+
 import numpy as np
 
 from .base import vmap
@@ -826,6 +828,88 @@ class GridSampler(_BatchEvaluator):
         if self.save_fn is not None:
             np.savez(self.save_fn, **self.samples)
         return self.samples
+
+
+class ImportanceSampler(_BatchEvaluator):
+    """Importance-sample input chains with a (new) likelihood (desilike/samplers/importance.py): every point of every chain is evaluated -- here as ONE batch per chain
+    on the device -- and ``aweight`` is multiplied by ``exp(logposterior - max logposterior)`` of the new likelihood (``subtract_input=True``: first divided by the same
+    factor of the input chain's stored log-posterior).  As in the reference the chain's ``loglikelihood`` / ``logprior`` (and the solved / derived outputs) are
+    replaced by the new likelihood's, its stored ``logposterior`` array is left as it was, fixed parameters are filled in, and ``size`` / ``nvaried`` / ``ndof`` go
+    to ``attrs``; analytically solved parameters are marginalised (``solved_default = '.marg'``, importance.py:37).
+
+    ``chains``: :class:`~desilike_amd.io.ChainFile`, path of a chain file (``.npy`` / ``.npz``, written here or by the reference), or a list of these."""
+    name = 'importance'
+
+    def __init__(self, likelihood, chains, save_fn=None, sharding=None):
+        from .io import ChainFile
+        self.likelihood = self.calculator = likelihood
+        likelihood.solved_default = '.marg'
+        self.varied_params = likelihood.varied_params
+        if not len(self.varied_params):
+            raise ValueError('No parameters to be varied!')
+        self.sharding = sharding if sharding is not None else WalkerSharding()
+        if isinstance(chains, (str, os.PathLike, ChainFile)): chains = [chains]
+        self.input_chains = [ChainFile.load(str(chain)) if isinstance(chain, (str, os.PathLike)) else chain for chain in chains]
+        self.save_fn = save_fn
+        if save_fn is not None:
+            if isinstance(save_fn, (str, os.PathLike)):
+                self.save_fn = [str(save_fn).replace('*', '{}').format(i) for i in range(self.nchains)]
+            elif len(save_fn) != self.nchains:
+                raise ValueError('Provide {:d} chain file names'.format(self.nchains))
+        self.chains = [None] * self.nchains
+
+    @property
+    def nchains(self):
+        return len(self.input_chains)
+
+    def run(self, subtract_input=False):
+        from .io import ChainFile
+        names = self.varied_params.names()
+        for ichain, chain in enumerate(self.input_chains):
+            arrays = {name: np.array(value) for name, value in chain.arrays.items()}
+            shape = chain.shape
+
+            def zero_lag(name):
+                value = arrays[name]
+                return value[..., 0] if name in chain.derivs else value
+
+            aweight = np.array(arrays['aweight'], dtype='f8') if 'aweight' in arrays else np.ones(shape, dtype='f8')
+            if subtract_input:     # importance.py:104-109 (a chain without a stored log-posterior counts as zeros: samples/chain.py:168-172)
+                logposterior = zero_lag('logposterior') if 'logposterior' in arrays else np.zeros(shape, dtype='f8')
+                mask = np.isfinite(logposterior)
+                aweight = aweight / np.exp(logposterior - (logposterior[mask].max() if mask.any() else 0.))
+            missing = [name for name in names if name not in arrays]
+            if missing:
+                raise KeyError('chain {:d} lacks the varied parameters {}'.format(ichain, missing))
+            samples = Samples([np.asarray(arrays[name], dtype='f8') for name in names], params=self.varied_params)
+            samples = self._evaluate(samples, errors='return')
+            derivs = {name: value for name, value in chain.derivs.items()}
+            for name in samples:
+                arrays[name] = np.asarray(samples[name])
+                derivs.pop(name, None)       # (zero-lag values: the Hessian entries of a marginalised input chain do not describe the new likelihood)
+            for name in ['loglikelihood', 'logprior']:
+                arrays[name] = np.where(np.isnan(arrays[name]), -np.inf, arrays[name])      # importance.py:141-143
+            logposterior = arrays['loglikelihood'] + arrays['logprior']
+            mask = np.isfinite(logposterior)
+            with np.errstate(invalid='ignore'):
+                aweight = aweight * np.exp(logposterior - (logposterior[mask].max() if mask.any() else 0.))
+            arrays['aweight'] = aweight
+            attrs = dict(chain.attrs)
+            size = int(np.size(self.likelihood.flatdata))
+            nvaried = len(names) + len(self.likelihood.solved_params)
+            attrs.update(size=size, nvaried=nvaried, ndof=size - nvaried)                       # importance.py:149-155, likelihoods/base.py:445-457
+            params = dict(chain.params)
+            params.update({param.name: param for param in self.likelihood.all_params if param.name in arrays})
+            self.chains[ichain] = ChainFile(arrays, params=params, derivs=derivs, attrs=attrs)
+            if self.save_fn is not None:
+                self.chains[ichain].save(self.save_fn[ichain])
+        return self.chains
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_value, exc_traceback):
+        pass
 
 
 class RQuasiRandomSequence(object):

@@ -386,3 +386,44 @@ def test_device_ensemble_follows_parameter_changes():
     chain = sampler.run(niterations=5)
     coords = np.column_stack([chain[param.name][-1] for param in like.varied_params])
     assert np.allclose(chain['logposterior'][-1], sampler.logposterior(coords), rtol=1e-12, atol=1e-9)   # (the host route re-reads the parameters at every call)
+
+
+def test_importance_sampler(tmp_path):
+    """desilike/samplers/importance.py: chains of one likelihood re-weighted by another (here: the same observable with twice the covariance), every chain point
+    evaluated in one batch; the weights, the replaced loglikelihood / logprior, the attributes and the chain-file round trip."""
+    from desilike_amd import vmap
+    from desilike_amd.io import ChainFile
+    from desilike_amd.samplers import EmceeSampler, ImportanceSampler
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+
+    def make(scale):
+        theory = KaiserTracerPowerSpectrumMultipoles(template=ShapeFitPowerSpectrumTemplate(z=0.5, fiducial='synthetic'))
+        obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2.}, kedges=np.linspace(0., 0.2, 21), ells=(0, 2), wmatrix={'resolution': 2}, theory=theory, shotnoise=1e4)
+        return ObservablesGaussianLikelihood(observables=[obs], covariance=scale * 4e5 * np.eye(40))
+
+    like_a, like_b = make(1.), make(2.)
+    sampler = EmceeSampler(like_a, nwalkers=32, seed=3)
+    sampler.run(niterations=12)
+    chain = ChainFile.from_sampler(sampler)
+    fn_in, fn_out = str(tmp_path / 'in.npz'), str(tmp_path / 'out_*.npy')
+    chain.save(fn_in)
+    with ImportanceSampler(like_b, fn_in, save_fn=fn_out) as importance:
+        out, = importance.run(subtract_input=True)
+    names = like_b.varied_params.names()
+    points = {name: np.ravel(chain.arrays[name]) for name in names}
+    (logpost_b, derived_b), errors = vmap(like_b, errors='return', return_derived=True)(points)
+    assert errors == {}
+    shape = chain.shape
+    assert np.array_equal(out.arrays['loglikelihood'], np.asarray(derived_b['loglikelihood']).reshape(shape)) and np.array_equal(out.arrays['logprior'], np.asarray(derived_b['logprior']).reshape(shape))
+    lp_a, lp_b = chain.arrays['logposterior'], np.asarray(logpost_b).reshape(shape)
+    expected = np.exp(lp_b - lp_b[np.isfinite(lp_b)].max()) / np.exp(lp_a - lp_a[np.isfinite(lp_a)].max())
+    assert np.allclose(out.arrays['aweight'], expected, rtol=1e-12, atol=0.)
+    assert np.array_equal(out.arrays['logposterior'], lp_a)                       # the stored log-posterior stays the input's (as in the reference)
+    assert out.attrs['size'] == 40 and out.attrs['nvaried'] == len(names) and out.attrs['ndof'] == 40 - len(names)
+    back = ChainFile.load(fn_out.replace('*', '0'))
+    assert np.array_equal(back.arrays['aweight'], out.arrays['aweight']) and sorted(back.arrays) == sorted(out.arrays)
+    # halving the precision flattens the posterior: the weights grow away from the input chain's best point
+    ibest = np.unravel_index(np.argmax(lp_a), shape)
+    assert out.arrays['aweight'][ibest] <= np.median(out.arrays['aweight']) * 1.0000001 or out.arrays['aweight'].max() > out.arrays['aweight'][ibest]
