@@ -297,3 +297,20 @@ def test_large_batch_properties(contexts):
         vals = big[idx == i]
         assert len(vals) > 100 and (vals == vals[0]).all(), i
     assert (np.abs(big - small[idx]) <= 1e-12 * np.maximum(1., np.abs(small[idx]))).all(), (np.abs(big - small[idx]) / np.maximum(1., np.abs(small[idx]))).max()
+
+
+def test_eftlike_correlation_function_multipoles():
+    """EFT-like TNS xi_ell (counter terms times the projected linear spectrum, Hankel operator folded into the window; no stochastic terms in configuration space)."""
+    from oracle import np_oracle as oc
+    like, obs, theory, template = _mirror_tns('EFTLikeTNSTracerCorrelationFunctionMultipoles', xi=True)
+    names = like.varied_params.names()
+    assert 'ct0_2' in names and 'ct2_2' in names and not any(name.startswith('sn') for name in names) and 'sigmav' not in names
+    rng = np.random.RandomState(4)
+    theta = np.column_stack([param.ref.sample(size=2, random_state=rng) if param.ref.is_proper() else np.full(2, param.value) for param in like.varied_params])
+    loglike = like._get_context().eval_batch_host(theta)[0]
+    for i, row in enumerate(theta):
+        p = dict(zip(names, row))
+        power = _oracle_flat(theory, template, obs, p, ct=[p.get(n, 0.) for n in theory.counterterm_params], sn=[0. for n in theory.stochastic_params])
+        flat = np.ravel(oc.get_corr(power, theory.kin, theory.s, theory.ells))
+        ref = oc.gaussian_loglikelihood(flat, obs.flatdata, like.precision)[0]
+        assert abs(loglike[i] - ref) <= 1e-10 * max(1., abs(ref)), (i, loglike[i], ref)
