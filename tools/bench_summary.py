@@ -5,7 +5,10 @@ import sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print('value {:.3e} {} | {:.2f} us/step | roofline frac {:.3f} | kernels {}'.format(d['value'], d['unit'], 1e3 * d['ms_per_step'], d['roofline']['frac'], d.get('kernel_ms')))
 if 'sustained' in d: print('sustained {:.3e} | streams {}'.format(d['sustained']['value'], ['{:.3e}'.format(s['value']) for s in d.get('streams', [])]))
-for c in d.get('other_configs', []):
+others = d.get('other_configs') or []
+if isinstance(others, dict): others = [others]
+for c in others:
+    if 'error' in c: print('  ' + str(c)); continue
     print('  {:<60s} {:.3e} evals/s  frac {:.3f}  oracle err {:.1e}'.format(c['workload'][:60], c['value'], c['roofline']['frac'], c['oracle_check']['max_rel_err_vs_oracle']))
 if 'config5_strong' in d: print('config 5: {:.2f} us per update ({:.3e} evals/s), oracle err {:.1e}'.format(d['config5_strong']['us_per_update'], d['config5_strong']['value'], d['config5_strong']['oracle_check']['max_rel_err_vs_oracle']))
 if 'chains_weak' in d: print('chains_weak: {:.3e} evals/s'.format(d['chains_weak']['value']))
