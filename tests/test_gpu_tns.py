@@ -314,3 +314,21 @@ def test_eftlike_correlation_function_multipoles():
         flat = np.ravel(oc.get_corr(power, theory.kin, theory.s, theory.ells))
         ref = oc.gaussian_loglikelihood(flat, obs.flatdata, like.precision)[0]
         assert abs(loglike[i] - ref) <= 1e-10 * max(1., abs(ref)), (i, loglike[i], ref)
+
+
+def test_edge_cases(contexts):
+    """NaN inputs, a single point (the scalar ``likelihood()`` call surface), an empty batch, and the 'data generated from the theory' identity."""
+    g, ctx = contexts('tns')
+    ok = np.isfinite(g['theta']).all(axis=1) & np.isfinite(g['logprior'])
+    theta = g['theta'][ok][:5].copy()
+    theta[1, 2] = np.nan
+    loglike, logprior, status = ctx.eval_batch_host(theta)
+    assert status[1] == 3 and status[0] == 0 and np.isfinite(loglike[[0, 2, 3, 4]]).all()
+    l1 = ctx.eval_batch_host(g['theta'][ok][:1])[0]
+    assert abs(l1[0] - g['loglikelihood'][ok][0]) <= 1e-10 * max(1., abs(g['loglikelihood'][ok][0]))
+    assert ctx.eval_batch_host(np.zeros((0, ctx.n_params)))[0].size == 0
+    # the fixture's data are the reference's theory at (b1, b2, sigmav) = (2, 0.5, 3), everything else at its default: logL = 0 there (likelihoods/tests/test_galaxy_clustering.py:6-16)
+    names = [str(n) for n in g['names']]
+    fid = dict(qpar=1., qper=1., dm=0., df=1., sigmav=3., b1=2., b2=0.5, bs=0., b3=0., sn0=0.)
+    lf = ctx.eval_batch_host(np.array([[fid[name] for name in names]]))[0]
+    assert abs(lf[0]) < 1e-9, lf
