@@ -186,8 +186,9 @@ DL_HD size_t dl_fs_work_doubles(int n_t, int n_in, int n_dd0) { size_t w = 3 * (
 DL_HD size_t dl_fs_shared_doubles(int n_t, int n_in) { return 4 * (size_t)n_t + dl_fs_work_doubles(n_t, n_in) + DL_PT_SIZE; }
 DL_HD size_t dl_fs_shared_doubles_obs(const DlObsDev& o, bool fast = false) { return 4 * (size_t)o.n_t + dl_fs_work_doubles(o.n_t, o.n_in, dl_fs_n_dd0(o)) + (fast ? DL_PT_SIZE_FAST : DL_PT_SIZE); }
 
-// PNG kernel (dl_kernels.hip): the generic layout | coefA [4 n_t] | mu records [DL_MAX_MU][8] | scalars [16]
-DL_HD size_t dl_png_shared_doubles(int n_t, int n_in) { return dl_fs_shared_doubles(n_t, n_in) + 4 * (size_t)n_t + 8 * DL_MAX_MU + 16; }
+// PNG kernel (dl_kernels.hip): the generic layout (its coefficient region [4 n_t] holds the knot values and second derivatives of the two splines: alpha, template) |
+// mu records [DL_MAX_MU][8] | scalars [16]
+DL_HD size_t dl_png_shared_doubles(int n_t, int n_in) { return dl_fs_shared_doubles(n_t, n_in) + 8 * DL_MAX_MU + 16; }
 
 // toep: layout of the convolution path (dl_fs_phase2_fir): y sits DL_FIR_PAD zeros inside the work region, M (the moments) right after the padded y
 DL_HD DlFsShared dl_fs_shared_carve(double* base, int n_t, int n_in, int n_dd0 = -1, bool toep = false) {
@@ -803,8 +804,35 @@ DL_HD void dl_png_knots(int tid, int nthr, const DlObsDev& o, const double* th, 
     }
 }
 
-// (k, mu) evaluation of both splines, bias, damping, projection (lines 107-112): out [n_ell][n_kin]
-DL_HD void dl_png_eval(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, const double* coefA, const double* murec, const double* sc, double* out) {
+// knot values and second derivatives of the spline just built on s.y (toep: s.M holds the convolution w, the end corrections are applied here as dl_fs_phase2d_toep
+// does; otherwise s.M [1 .. n - 2] are final) -> yout [n_t], mout [n_t] (two workgroups per CU instead of one: 2 n_t doubles per spline, not 4 n_t of interval polynomials)
+DL_HD void dl_png_keep_spline(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, bool toep, double* yout, double* mout) {
+    const int n = o.n_t;
+    double a = 0., b = 0.;
+    if (toep) {
+        const double sc6 = o.inv_hx * o.inv_hx;
+        a = sc6 * ((s.y[0] - s.y[1]) - (s.y[1] - s.y[2])) - s.M[1];
+        b = sc6 * ((s.y[n - 3] - s.y[n - 2]) - (s.y[n - 2] - s.y[n - 1])) - s.M[n - 2];
+    }
+    auto moment = [&](int i) { return toep ? s.M[i] + a * dl_fir_mu_pow(s, i - 1) + b * dl_fir_mu_pow(s, n - 2 - i) : s.M[i]; };   // 1 <= i <= n - 2
+    for (int j = tid; j < n; j += nthr) {
+        double m;
+        if (j == 0) m = o.end0a * moment(1) + o.end0b * moment(2);
+        else if (j == n - 1) m = o.end1a * moment(n - 2) + o.end1b * moment(n - 3);
+        else m = moment(j);
+        mout[j] = m;
+        yout[j] = s.y[j];
+    }
+}
+
+DL_HD double dl_png_spline_value(const DlObsDev& o, const double* y, const double* m, int j, double x) {
+    const double xl = o.x_t[j], xr = o.x_t[j + 1], h = xr - xl;
+    const double a = (xr - x) / h, b = (x - xl) / h;
+    return a * y[j] + b * y[j + 1] + ((a * a * a - a) * m[j] + (b * b * b - b) * m[j + 1]) * (h * h) * (1. / 6.);
+}
+
+// (k, mu) evaluation of both splines, bias, damping, projection (lines 107-112): out [n_ell][n_kin]; tabs = alpha knots | alpha second derivatives | template knots | ...
+DL_HD void dl_png_eval(int tid, int nthr, const DlObsDev& o, const double* tabs, const double* murec, const double* sc, double* out) {
     const int n_t = o.n_t;
     const double qper = sc[0], jac = sc[1], f = sc[2], b1X = sc[3], b1Y = sc[4], bfX = sc[5], bfY = sc[6], hsX = sc[7], hsY = sc[8], sn0nd = sc[9];
     for (int ik = tid; ik < o.n_kin; ik += nthr) {
@@ -812,12 +840,11 @@ DL_HD void dl_png_eval(int tid, int nthr, const DlObsDev& o, const DlFsShared& s
         double acc[DL_MAX_ELL] = {0., 0., 0., 0., 0.};
         for (int m = 0; m < o.n_mu; ++m) {
             const double* r = murec + 8 * m;
+            const double x = lk + r[0];
             int j; double u;
-            dl_spline_locate<false>(o, lk + r[0], j, u);
-            const double* c = s.coef + 2 * j; const double* d = c + 2 * n_t;
-            const double* ca = coefA + 2 * j; const double* da = ca + 2 * n_t;
-            const double pk = fma(fma(fma(d[1], u, d[0]), u, c[1]), u, c[0]);
-            const double al = fma(fma(fma(da[1], u, da[0]), u, ca[1]), u, ca[0]);
+            dl_spline_locate<false>(o, x, j, u);
+            const double al = dl_png_spline_value(o, tabs, tabs + n_t, j, x);
+            const double pk = dl_png_spline_value(o, tabs + 2 * n_t, tabs + 3 * n_t, j, x);
             const double kap = kq * r[1], mup2 = r[2];
             const double km2 = kap * kap * mup2;
             const double fog = 1. / ((1. + hsX * km2) * (1. + hsY * km2));

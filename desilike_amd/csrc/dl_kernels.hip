@@ -162,14 +162,9 @@ __global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_ker
 // the generic kernel (dl_fullshape.h) run twice on the same work area, the interval polynomials of alpha are kept beside those of the template.
 // LDS: generic layout (coef [4 n_t] | work | pt) | coefA [4 n_t] | mu records [DL_MAX_MU][8] | scalars [16]
 
-__device__ __forceinline__ void dl_png_build_spline(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, bool toep) {
+__device__ __forceinline__ void dl_png_build_moments(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, bool toep) {
     if (toep) {
-        double dlt_pref[DL_TOEP_PREF];
-#pragma unroll
-        for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (tid + it * nthr < o.n_t - 1) ? o.dlt[tid + it * nthr] : 0.;
         dl_fs_phase2_fir(tid, nthr, o, s);
-        __syncthreads();
-        dl_fs_phase2d_toep(tid, nthr, o, s, dlt_pref);
     } else {
         dl_fs_phase2a(tid, nthr, o, s);
         __syncthreads();
@@ -180,32 +175,32 @@ __device__ __forceinline__ void dl_png_build_spline(int tid, int nthr, const DlO
         dl_fs_phase2c_dot(tid, nthr, o, s);
         __syncthreads();
         dl_fs_phase2c(tid, nthr, o, s);
-        __syncthreads();
-        dl_fs_phase2d(tid, nthr, o, s);
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(DL_FS_THREADS) void dl_png_kernel(DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power, int64_t ld_power) {
+__global__ __launch_bounds__(DL_FS_THREADS, 2) void dl_png_kernel(DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power, int64_t ld_power) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nthr = DL_FS_THREADS, n_t = o.n_t;
     const int64_t b = blockIdx.x;
     const double* th = theta + (size_t)b * n_params;
     const bool toep = o.toeplitz;
     const DlFsShared s = dl_fs_shared_carve(lds, n_t, o.n_in, -1, toep);
-    double* coefA = lds + dl_fs_shared_doubles(n_t, o.n_in);
-    double* murec = coefA + 4 * (size_t)n_t;
+    double* tabs = s.coef;                                      // alpha knots | alpha second derivatives | template knots | template second derivatives
+    double* murec = lds + dl_fs_shared_doubles(n_t, o.n_in);
     double* sc = murec + 8 * DL_MAX_MU;
     dl_png_setup(tid, nthr, o, th, murec, sc);
-    dl_png_knots(tid, nthr, o, th, s, true);                    // alpha at the knots, its spline, kept aside
+    dl_png_knots(tid, nthr, o, th, s, true);                    // alpha at the knots, its spline
     __syncthreads();
-    dl_png_build_spline(tid, nthr, o, s, toep);
-    for (int j = tid; j < 4 * n_t; j += nthr) coefA[j] = s.coef[j];
+    dl_png_build_moments(tid, nthr, o, s, toep);
+    dl_png_keep_spline(tid, nthr, o, s, toep, tabs, tabs + n_t);
     __syncthreads();
     dl_png_knots(tid, nthr, o, th, s, false);                   // the template at the knots, its spline
     __syncthreads();
-    dl_png_build_spline(tid, nthr, o, s, toep);
-    dl_png_eval(tid, nthr, o, s, coefA, murec, sc, s.out);      // (s.out aliases the spline work area: every thread is past it)
+    dl_png_build_moments(tid, nthr, o, s, toep);
+    dl_png_keep_spline(tid, nthr, o, s, toep, tabs + 2 * n_t, tabs + 3 * n_t);
+    __syncthreads();
+    dl_png_eval(tid, nthr, o, tabs, murec, sc, s.out);          // (s.out aliases the spline work area: every thread is past it)
     __syncthreads();
     double* prow = power + (size_t)b * (1 + o.n_var) * ld_power + o.col_offset;
     for (int idx = tid; idx < o.n_in; idx += nthr) prow[idx] = s.out[idx];

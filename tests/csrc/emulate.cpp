@@ -70,34 +70,29 @@ static void run_point(const DlObsDev& o, const double* th, double* prow, double*
         const int nthr = DL_FS_THREADS;
         const bool toep = o.toeplitz;
         DlFsShared s = dl_fs_shared_carve(lds.data(), o.n_t, o.n_in, -1, toep);
-        double* coefA = lds.data() + dl_fs_shared_doubles(o.n_t, o.n_in);
-        double* murec = coefA + 4 * (size_t)o.n_t;
+        double* tabs = s.coef;
+        double* murec = lds.data() + dl_fs_shared_doubles(o.n_t, o.n_in);
         double* sc = murec + 8 * DL_MAX_MU;
         auto build = [&]() {
             if (toep) {
                 for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2_fir(tid, nthr, o, s);
-                for (int tid = 0; tid < nthr; ++tid) {
-                    double dlt_pref[DL_TOEP_PREF];
-                    for (int it = 0; it < DL_TOEP_PREF; ++it) dlt_pref[it] = (tid + it * nthr < o.n_t - 1) ? o.dlt[tid + it * nthr] : 0.;
-                    dl_fs_phase2d_toep(tid, nthr, o, s, dlt_pref);
-                }
             } else {
                 for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2a(tid, nthr, o, s);
                 for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2b_dot(tid, nthr, o, s);
                 for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2b(tid, nthr, o, s);
                 for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2c_dot(tid, nthr, o, s);
                 for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2c(tid, nthr, o, s);
-                for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2d(tid, nthr, o, s);
             }
         };
         for (int tid = 0; tid < nthr; ++tid) dl_png_setup(tid, nthr, o, th, murec, sc);
         for (int tid = 0; tid < nthr; ++tid) dl_png_knots(tid, nthr, o, th, s, true);
         build();
-        for (int j = 0; j < 4 * o.n_t; ++j) coefA[j] = s.coef[j];
+        for (int tid = 0; tid < nthr; ++tid) dl_png_keep_spline(tid, nthr, o, s, toep, tabs, tabs + o.n_t);
         for (int tid = 0; tid < nthr; ++tid) dl_png_knots(tid, nthr, o, th, s, false);
         build();
+        for (int tid = 0; tid < nthr; ++tid) dl_png_keep_spline(tid, nthr, o, s, toep, tabs + 2 * o.n_t, tabs + 3 * o.n_t);
         std::vector<double> out(o.n_in);
-        for (int tid = 0; tid < nthr; ++tid) dl_png_eval(tid, nthr, o, s, coefA, murec, sc, out.data());
+        for (int tid = 0; tid < nthr; ++tid) dl_png_eval(tid, nthr, o, tabs, murec, sc, out.data());
         for (int idx = 0; idx < o.n_in; ++idx) prow[idx] = out[idx];
         return;
     }
