@@ -432,6 +432,7 @@ DlTnsPlan* dl_tns_create(const double* k11, int n11, const double* q, int n_q, c
     auto fail = [&](DlTnsPlan* plan, const std::string& m) { msg = m; if (err) *err = msg.c_str(); dl_tns_destroy(plan); return (DlTnsPlan*)nullptr; };
     if (n11 < 5 || n_q < 4 || n_mu < 1 || n_mu > DL_TNS_MAX_MU) return fail(nullptr, "tns: table / template / cosine grid sizes out of range");
     for (int i = 0; i + 1 < n_q; ++i) if (!(q[i + 1] > q[i])) return fail(nullptr, "tns: template wavenumbers must increase");
+    if ((size_t)((n_q + 3) & ~3) * DL_TNS_PTS * sizeof(double) > 150 * 1024) return fail(nullptr, "tns: template grid too large for the loop kernel's LDS tile (32 points x n_t wavenumbers <= 150 KB: n_t <= 600; the reference uses 500, full_shape.py:855)");
     if (!(k11[0] > q[0]) || !(k11[n11 - 1] < q[n_q - 1])) return fail(nullptr, "tns: table wavenumbers must lie inside the template's range (full_shape.py:29, 875)");
     DlTnsPlan* plan = new DlTnsPlan();
     DlTnsDev& t = plan->dev;
