@@ -88,6 +88,51 @@ __global__ __launch_bounds__(64 * DL_GD_WAVES) void dl_window_gemm_dma_kernel(co
     else __asm__ volatile("s_waitcnt vmcnt(0)" : : : "memory");
     __builtin_amdgcn_s_barrier();
     int p = pa;
+    // Steady state, three panels per trip with the buffer of each known at compile time.  With a run-time buffer index every k-step pays vector instructions for the
+    // permuted operand offset and every request for its 64-bit address (20 + 3 per 16 MFMAs: `v_mfma_f64` runs at the vector unit's own rate, those instructions are
+    // not free beside it).  Here the eight permuted offsets of a lane are registers computed once (two sets: buffers 0 / 1 within the 16-bit immediate of a DS read,
+    // buffer 2 beyond it), the per-lane request pointers advance once per trip and the panel inside the trip is the request's immediate offset -- which an LDS-DMA
+    // instruction adds to BOTH its addresses, so the LDS base handed over in M0 is moved back by as much.  The generic loop below takes what is left.
+    static_assert(DL_GD_NBUF == 3 && DL_GD_KP == 32, "the unrolled loop rotates three buffers of eight k-steps");
+    {
+        const double* pa01[DL_GD_KP / 4]; const double* pa2[DL_GD_KP / 4]; const double* pw01[DL_GD_KP / 4]; const double* pw2[DL_GD_KP / 4];
+#pragma unroll
+        for (int ks = 0; ks < DL_GD_KP / 4; ++ks) {
+            const int off = ((((2 * ks) ^ s4) + gh) << 1);
+            pa01[ks] = la + off; pa2[ks] = la + 2 * DL_GD_BUF + off; pw01[ks] = lw + off; pw2[ks] = lw + 2 * DL_GD_BUF + off;
+        }
+        const char* srcp[DL_GD_VPT];
+#pragma unroll
+        for (int i = 0; i < DL_GD_VPT; ++i) srcp[i] = src[i] + (size_t)(pa + 3) * (DL_GD_KP * 8);   // panel pa + 3: the middle request of the first trip (immediates -1, 0, +1 panels)
+#define DL_GD_DMA_B(j, B)                                                                                                           \
+    {   constexpr int imm = ((j) - 1) * (DL_GD_KP * 8);                                                                             \
+        double* dst = lds + (B) * DL_GD_BUF + wave * DL_GD_PLD - imm / 8;                                                           \
+        _Pragma("unroll") for (int i = 0; i < DL_GD_VPT; ++i)                                                                       \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcp[i],                                \
+                                             (__attribute__((address_space(3))) void*)(dst + DL_GD_WAVES * i * DL_GD_PLD), 16, imm, 0); }
+#define DL_GD_MULTIPLY_B(PA, PW, boff)                                                                                              \
+    if (live) {                                                                                                                     \
+        _Pragma("unroll") for (int ks = 0; ks < DL_GD_KP / 4; ++ks) {                                                               \
+            const double a0 = (PA)[ks][(boff)], a1 = (PA)[ks][(boff) + 4 * DL_GD_PLD];                                              \
+            _Pragma("unroll") for (int j = 0; j < DL_GD_TJ; ++j) {                                                                  \
+                const double bj = (PW)[ks][(boff) + 4 * j * DL_GD_PLD];                                                             \
+                acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bj, acc[0][j], 0, 0, 0);                                       \
+                acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bj, acc[1][j], 0, 0, 0);                                       \
+            } } }
+#define DL_GD_STEP_B(j, B, PA, PW, boff)                                                                                            \
+    {   DL_GD_DMA_B(j, ((B) + 2) % DL_GD_NBUF)                                                                                      \
+        DL_GD_MULTIPLY_B(PA, PW, boff)                                                                                              \
+        __asm__ volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(DL_GD_VPT) : "memory");                                           \
+        __builtin_amdgcn_s_barrier(); }
+        for (; p + 4 < pb; p += 3) {     // (p - pa is a multiple of 3 here: panel p sits in buffer 0)
+            DL_GD_STEP_B(0, 0, pa01, pw01, 0) DL_GD_STEP_B(1, 1, pa01, pw01, DL_GD_BUF) DL_GD_STEP_B(2, 2, pa2, pw2, 0)
+#pragma unroll
+            for (int i = 0; i < DL_GD_VPT; ++i) srcp[i] += 3 * (DL_GD_KP * 8);
+        }
+#undef DL_GD_STEP_B
+#undef DL_GD_MULTIPLY_B
+#undef DL_GD_DMA_B
+    }
     for (; p + 2 < pb; ++p) {
         DL_GD_DMA(p + 2)
         DL_GD_MULTIPLY(p)
