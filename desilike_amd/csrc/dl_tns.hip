@@ -132,26 +132,29 @@ __global__ __launch_bounds__(256) void dl_tns_pk_kernel(DlObsDev o, DlTnsDev t, 
 // The loop GEMM.  LDS: the templates of 32 points [nqp][32]; a wave forms the left operand of its two 16-point tiles in registers and multiplies it with the [4 x 32]
 // coefficient block it loaded from L2 (4 MFMA per step of 4 pairs (mu, q)); then the linear tables (left operand = the templates themselves).  Two ways of dealing
 // the work to the 8 waves of a workgroup:
-//   WAVEK = true   every wave owns one table wavenumber (8 per workgroup) and runs the whole pair list: no reduction, no barrier after the templates have landed,
-//                  the template tile is loaded once per 8 wavenumbers -- used when that still gives every CU a workgroup;
-//   WAVEK = false  one wavenumber per workgroup, the waves take every 8th round of the pair list and their partial accumulators are summed in wave order through
-//                  LDS -- small batches.
+//   W = 1  every wave owns one table wavenumber (8 per workgroup) and runs the whole pair list: no reduction, no barrier after the templates have landed, the template
+//          tile is loaded once per 8 wavenumbers -- large batches;
+//   W = 8  one wavenumber per workgroup, the waves take every 8th round of the pair list and their partial accumulators are summed in wave order through LDS -- small
+//          batches;  W = 2, 4: in between (2 or 4 waves per wavenumber, 4 or 2 wavenumbers per workgroup).  The launcher picks the variant that needs the least time
+//          in whole rounds of workgroups.
 // Output: the raw sums [point][k][48]; the assembly kernel turns them into the 29 tables.
 #define DL_TNS_WAVES 8
 #define DL_TNS_UNROLL 4
 
-template <bool WAVEK>
+template <int W>   // waves per table wavenumber: 1 (WAVEK below), 2, 4 or 8 -- a workgroup works on 8 / W wavenumbers
 __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev t, const double* __restrict__ pk, int64_t ldp, int n_tiles, double* __restrict__ sums_out) {
+    constexpr bool WAVEK = (W == 1);
+    constexpr int KPW = DL_TNS_WAVES / W;                    // wavenumbers per workgroup
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // workgroups of one (group of) k share an XCD (consecutive workgroup ids go round the 8 XCDs): the coefficients are fetched from HBM once
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const int kgroup = (slot / n_tiles) * 8 + xcd, tile = slot % n_tiles;
-    const int ik_raw = WAVEK ? kgroup * DL_TNS_WAVES + wave_s : kgroup;
-    if (!WAVEK && ik_raw >= t.n11) return;
-    if (WAVEK && kgroup * DL_TNS_WAVES >= t.n11) return;
-    const bool live = ik_raw < t.n11;                        // (WAVEK: waves beyond the last wavenumber repeat it and do not store)
+    const int kslot = wave_s / W, part = wave_s % W;         // which of the workgroup's wavenumbers, which share of its pair list
+    const int ik_raw = kgroup * KPW + kslot;
+    if (kgroup * KPW >= t.n11) return;
+    const bool live = ik_raw < t.n11;                        // (waves beyond the last wavenumber repeat it and do not store)
     const int ik = live ? ik_raw : t.n11 - 1;
     const int p16 = lane & 15, kk = lane >> 4;
     double* spk = lds;                                       // [nqp][32]
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
     struct Raw { double pq[DL_TNS_UNROLL][2], pa[DL_TNS_UNROLL][2], pb[DL_TNS_UNROLL][2]; };
     struct Lhs { double g[DL_TNS_UNROLL][2]; };
     const int ngroups = t.Kp / (4 * DL_TNS_UNROLL);                                      // rounds of this wave: all of them, or every 8th starting at its index
-    const int rounds = WAVEK ? ngroups : ngroups / DL_TNS_WAVES + (wave_s < ngroups % DL_TNS_WAVES ? 1 : 0);
+    const int rounds = ngroups / W + (part < ngroups % W ? 1 : 0);
     // wave-uniform base pointers (scalar registers) + a 32-bit lane offset: the address arithmetic of the requests stays on the scalar unit
     const dl_tns_int2* gj = reinterpret_cast<const dl_tns_int2*>(t.geomj) + (size_t)ik * t.Kp * 16;
     const dl_tns_double2* gw = reinterpret_cast<const dl_tns_double2*>(t.geomw) + (size_t)ik * t.Kp;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
     // element offset (in pairs) of the first step of a round (past the end: the last round again, requested and not used)
     auto round_offset = [&](int round) {
         const int rr = round < rounds ? round : rounds - 1;
-        const int g = WAVEK ? rr : rr * DL_TNS_WAVES + wave_s;
+        const int g = rr * W + part;
         return (size_t)g * DL_TNS_UNROLL * 4;
     };
     auto load_step = [&](size_t e, int u, Rec& r) { r.j[u] = (gj + (e + 4 * u) * 16)[lane_c]; r.w[u] = (gw + e + 4 * u)[lane_rec]; r.c[u] = (gc + (e + 4 * u) * 16)[lane_c]; };
@@ -247,7 +250,7 @@ static_assert(DL_TNS_UNROLL == 4, "the round below names its four steps");
 #undef DL_TNS_ROUND
     // linear tables: left operand = the templates
     const double* gl = t.lin + ((size_t)ik * t.nqp + kk) * DL_TNS_NLIN + p16;
-    for (int s = WAVEK ? 0 : wave_s; s < t.nqp / 4; s += WAVEK ? 1 : DL_TNS_WAVES) {
+    for (int s = part; s < t.nqp / 4; s += W) {
         const double cl = gl[(size_t)4 * s * DL_TNS_NLIN];
 #pragma unroll
         for (int m = 0; m < 2; ++m) accl[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(spt[(size_t)(4 * s + kk) * DL_TNS_PTS + 16 * m], cl, accl[m], 0, 0, 0);
@@ -275,13 +278,16 @@ static_assert(DL_TNS_UNROLL == 4, "the round below names its four steps");
             red[(((size_t)(wave * 2 + m) * 3 + 2) * 4 + r) * 64 + lane] = accl[m][r];
         }
     __syncthreads();
-    for (int idx = tid; idx < DL_TNS_PTS * DL_TNS_NREC; idx += 64 * DL_TNS_WAVES) {
-        const int pt = idx / DL_TNS_NREC, col = idx % DL_TNS_NREC;
+    for (int idx = tid; idx < KPW * DL_TNS_PTS * DL_TNS_NREC; idx += 64 * DL_TNS_WAVES) {
+        const int ks = idx / (DL_TNS_PTS * DL_TNS_NREC), rem = idx % (DL_TNS_PTS * DL_TNS_NREC);
+        const int pt = rem / DL_TNS_NREC, col = rem % DL_TNS_NREC;
         const int m = pt >> 4, prow = pt & 15, tl = col >> 4, c16 = col & 15;
         const int r = prow >> 2, g = prow & 3;                // accumulator row = g + 4 r  (g = lane >> 4)
+        const int ikk = kgroup * KPW + ks;
+        if (ikk >= t.n11) continue;
         double sum = 0.;
-        for (int wv = 0; wv < DL_TNS_WAVES; ++wv) sum += red[(((size_t)(wv * 2 + m) * 3 + tl) * 4 + r) * 64 + g * 16 + c16];
-        sums_out[(((size_t)tile * DL_TNS_PTS + pt) * t.n11 + ik) * DL_TNS_NREC + col] = sum;
+        for (int wv = 0; wv < W; ++wv) sum += red[(((size_t)((ks * W + wv) * 2 + m) * 3 + tl) * 4 + r) * 64 + g * 16 + c16];   // in wave order: deterministic
+        sums_out[(((size_t)tile * DL_TNS_PTS + pt) * t.n11 + ikk) * DL_TNS_NREC + col] = sum;
     }
 }
 
@@ -522,25 +528,35 @@ static bool tns_run_loop(DlTnsPlan* plan, const DlObsDev& obs, const double* the
     plan->ldp = ldp;
     const int n_tiles = (int)(ldp / DL_TNS_PTS);
     const size_t tmpl = (size_t)t.nqp * DL_TNS_PTS * sizeof(double), red = (size_t)DL_TNS_WAVES * 2 * 3 * 4 * 64 * sizeof(double);
-    // (set at every call: the attribute is per device, and a process may hold contexts on several)
-    (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    // Which variant: both run in rounds of one workgroup per CU; a one-wavenumber-per-wave workgroup lasts ~7 times a split-K one (8 times the MFMAs, no reduction,
-    // one template load per 8 wavenumbers) and there are 8 times fewer of them -- whichever needs less time in whole rounds (measured crossover: ~700 - 1000 points
-    // at 192 wavenumbers).  DL_TNS_WAVEK=0 / 1 forces a variant (diagnostics, tests).
+    // Which variant: all run in rounds of one workgroup per CU; a workgroup with W waves per wavenumber lasts about 20 + 55 (8 / W) microseconds at 500 x 10 pairs
+    // (measured: 75 at W = 8, 460 at W = 1) and there are n11 W / 8 x tiles of them -- whichever needs the least time in whole rounds.  DL_TNS_WAVEK=0 / 1 forces
+    // W = 8 / 1, DL_TNS_W=<1|2|4|8> any variant (diagnostics, tests).
     static const char* force = getenv("DL_TNS_WAVEK");
-    const int kgroups = (t.n11 + DL_TNS_WAVES - 1) / DL_TNS_WAVES;
+    static const char* force_w = getenv("DL_TNS_W");
     static int n_cu = 0;
     if (n_cu == 0) { int dev = 0; hipDeviceProp_t prop; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
-    const int64_t rounds_w = ((int64_t)kgroups * n_tiles + n_cu - 1) / n_cu, rounds_s = ((int64_t)t.n11 * n_tiles + n_cu - 1) / n_cu;
-    const bool wavek = force ? atoi(force) != 0 : 7 * rounds_w < rounds_s;
-    if (wavek) {
-        const unsigned grid = (unsigned)(((kgroups + 7) / 8) * n_tiles * 8);
-        DL_LAUNCH(dl_tns_loop_kernel<true>, dim3(grid), dim3(64 * DL_TNS_WAVES), tmpl, stream, t, plan->pk, ldp, n_tiles, plan->tables);
-    } else {
-        const unsigned grid = (unsigned)(((t.n11 + 7) / 8) * n_tiles * 8);
-        DL_LAUNCH(dl_tns_loop_kernel<false>, dim3(grid), dim3(64 * DL_TNS_WAVES), std::max(tmpl, red), stream, t, plan->pk, ldp, n_tiles, plan->tables);
+    int w_best = 8;
+    double t_best = 1e300;
+    for (int w = 8; w >= 1; w /= 2) {
+        const int kpw = DL_TNS_WAVES / w;
+        const int64_t wgs = (int64_t)((t.n11 + kpw - 1) / kpw) * n_tiles, rounds = (wgs + n_cu - 1) / n_cu;
+        const double cost = (double)rounds * (20. + 55. * (8. / w) * ((double)t.Kp / 5008.));
+        if (cost < t_best) { t_best = cost; w_best = w; }
     }
+    if (force) w_best = atoi(force) != 0 ? 1 : 8;
+    if (force_w) { const int w = atoi(force_w); if (w == 1 || w == 2 || w == 4 || w == 8) w_best = w; }
+    const int kpw = DL_TNS_WAVES / w_best;
+    const int kgroups = (t.n11 + kpw - 1) / kpw;
+    const unsigned grid = (unsigned)(((kgroups + 7) / 8) * n_tiles * 8);
+    const size_t lds_bytes = w_best == 1 ? tmpl : std::max(tmpl, red);
+    (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)dl_tns_loop_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (w_best == 1) { DL_LAUNCH(dl_tns_loop_kernel<1>, dim3(grid), dim3(64 * DL_TNS_WAVES), lds_bytes, stream, t, plan->pk, ldp, n_tiles, plan->tables); }
+    else if (w_best == 2) { DL_LAUNCH(dl_tns_loop_kernel<2>, dim3(grid), dim3(64 * DL_TNS_WAVES), lds_bytes, stream, t, plan->pk, ldp, n_tiles, plan->tables); }
+    else if (w_best == 4) { DL_LAUNCH(dl_tns_loop_kernel<4>, dim3(grid), dim3(64 * DL_TNS_WAVES), lds_bytes, stream, t, plan->pk, ldp, n_tiles, plan->tables); }
+    else { DL_LAUNCH(dl_tns_loop_kernel<8>, dim3(grid), dim3(64 * DL_TNS_WAVES), lds_bytes, stream, t, plan->pk, ldp, n_tiles, plan->tables); }
     return true;
 }
 

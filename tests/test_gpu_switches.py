@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 # (environment, sections of tests/switch_probe.py the switch can affect)
 SWITCHES = [({}, 'fs two ens emu bao tns png'),
-            ({'DL_TNS_WAVEK': '0'}, 'tns'), ({'DL_TNS_WAVEK': '1'}, 'tns'),                 # TNS loop kernel: split-K / one wavenumber per wave, whatever the batch
+            ({'DL_TNS_WAVEK': '0'}, 'tns'), ({'DL_TNS_WAVEK': '1'}, 'tns'), ({'DL_TNS_W': '2'}, 'tns'), ({'DL_TNS_W': '4'}, 'tns'),                 # TNS loop kernel: split-K / one wavenumber per wave, whatever the batch
             ({'DL_NO_TOEPLITZ': '1'}, 'fs two png'),                                        # general-knot spline solve (segmented Thomas) instead of the FIR form
             ({'DL_XCD_LOCAL': '0'}, 'fs emu'), ({'DL_XCD_LOCAL': '2', 'DL_CHI2_GEMM_MAX': '512'}, 'fs'),
             ({'DL_CHI2_GEMM_MAX': '512'}, 'fs two'),                                     # 2537 rows through the LDS-DMA GEMM with the partial-chi2 epilogue
