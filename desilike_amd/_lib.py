@@ -52,6 +52,14 @@ SYMBOLS = {
     'dl_ensemble_get_state': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
     'dl_ensemble_set_counter': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
     'dl_ensemble_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
+    'dl_mh_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                    ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_double, ctypes.c_uint64, ctypes.c_double, ctypes.c_int64]),
+    'dl_mh_destroy': (None, [ctypes.c_void_p]),
+    'dl_mh_set_covariance': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_void_p]),
+    'dl_mh_set_state': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, ctypes.c_void_p]),
+    'dl_mh_run': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_mh_get_state': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p]),
+    'dl_mh_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
     'dl_mlp_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int32, _c_int32_p, ctypes.c_int32, _c_double_p]),
     'dl_mlp_destroy': (None, [ctypes.c_void_p]),
     'dl_mlp_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
@@ -623,6 +631,97 @@ class MLPTrainer(object):
     def close(self):
         if getattr(self, '_handle', None):
             self._lib.dl_mlp_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceMH(object):
+    """Owner of one ``dl_mh`` (include/desilike_amd.h): ``nchains`` blocked Metropolis-Hastings chains x ``vectorize`` speculative proposals per try, resident on the
+    GPU of ``ctx``.  ``order``: sorted (block) position -> column of the context; ``blocks`` / ``oversample``: block sizes (slowest first) and oversampling factors."""
+
+    def __init__(self, ctx, nchains, vectorize=1, blocks=None, oversample=None, order=None, chain_ids=None, proposal_scale=2.4, seed=0, offset=0., max_tries=1000):
+        lib = load()
+        if ctx.expand is not None:
+            raise NotImplementedError('the device-resident sampler proposes in the columns of the device context: parameters derived by an expression need the host-driven sampler')
+        P = ctx.n_params
+        blocks = np.ascontiguousarray([P] if blocks is None else blocks, dtype='i4')
+        oversample = np.ascontiguousarray(np.ones(len(blocks)) if oversample is None else oversample, dtype='i4')
+        order = np.ascontiguousarray(np.arange(P) if order is None else order, dtype='i4')
+        chain_ids = np.ascontiguousarray(np.arange(nchains) if chain_ids is None else chain_ids, dtype='i4')
+        if len(oversample) != len(blocks) or len(order) != P or len(chain_ids) != nchains:
+            raise ValueError('blocks / oversample / order / chain_ids have inconsistent sizes')
+        i32 = ctypes.POINTER(ctypes.c_int32)
+        handle = ctypes.c_void_p()
+        if lib.dl_mh_create(ctypes.byref(handle), ctx._handle, int(nchains), int(vectorize), chain_ids.ctypes.data_as(i32), order.ctypes.data_as(i32), blocks.ctypes.data_as(i32),
+                            oversample.ctypes.data_as(i32), len(blocks), float(proposal_scale), ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), float(offset), int(max_tries)) != 0:
+            raise LibraryError(lib.dl_last_error(None).decode())
+        self._lib, self._handle, self._ctx = lib, handle, ctx     # (the context must outlive the sampler)
+        self.nchains, self.vectorize, self.n_params, self.device = int(nchains), int(vectorize), P, ctx.device
+
+    def _check(self, rc):
+        if rc != 0:
+            raise LibraryError(self._lib.dl_last_error(None).decode())
+
+    def info(self, key):
+        return int(self._lib.dl_mh_info(self._handle, key.encode()))
+
+    def _stream(self, stream):
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream(torch.device('cuda', self.device)).cuda_stream if stream is None else stream)
+
+    def set_covariance(self, cholesky, stream=None):
+        """Lower-triangular Cholesky factor [P, P] of the proposal covariance, parameters in sorted (block) order."""
+        cholesky = np.ascontiguousarray(cholesky, dtype='f8')
+        if cholesky.shape != (self.n_params,) * 2: raise ValueError('cholesky must have shape ({0:d}, {0:d})'.format(self.n_params))
+        self._check(self._lib.dl_mh_set_covariance(self._handle, _f64_ptr(cholesky), self._stream(stream)))
+
+    def set_state(self, coords, logposterior=None, weight=None, naccepted=None, tries=0, stream=None):
+        coords = np.ascontiguousarray(coords, dtype='f8')
+        if coords.shape != (self.nchains, self.n_params):
+            raise ValueError('coords must have shape ({:d}, {:d}), found {}'.format(self.nchains, self.n_params, coords.shape))
+        i64 = ctypes.POINTER(ctypes.c_int64)
+
+        def vector(values, dtype):
+            if values is None: return None
+            values = np.ascontiguousarray(values, dtype=dtype)
+            if values.shape != (self.nchains,): raise ValueError('expected one value per chain')
+            return values
+
+        logposterior, weight, naccepted = vector(logposterior, 'f8'), vector(weight, 'i8'), vector(naccepted, 'i8')
+        self._check(self._lib.dl_mh_set_state(self._handle, _f64_ptr(coords), _f64_ptr(logposterior), None if weight is None else weight.ctypes.data_as(i64),
+                                              None if naccepted is None else naccepted.ctypes.data_as(i64), int(tries), self._stream(stream)))
+
+    def run(self, ntries, thin_by=1, stream=None):
+        """Enqueue ``ntries`` tries of every chain (asynchronous); returns the device tensors (coords [nchains, ntries, P], logposterior [nchains, ntries],
+        weight [nchains, ntries], count [nchains]) that hold the ``count`` states recorded by this call once the stream has run."""
+        import torch
+        device = torch.device('cuda', self.device)
+        ntries = int(ntries)
+        coords = torch.empty((self.nchains, max(ntries, 1), self.n_params), dtype=torch.float64, device=device)
+        logp = torch.empty((self.nchains, max(ntries, 1)), dtype=torch.float64, device=device)
+        weight = torch.empty((self.nchains, max(ntries, 1)), dtype=torch.int64, device=device)
+        count = torch.zeros(self.nchains, dtype=torch.int32, device=device)
+        self._check(self._lib.dl_mh_run(self._handle, ntries, int(thin_by), ctypes.c_void_p(coords.data_ptr()), ctypes.c_void_p(logp.data_ptr()), ctypes.c_void_p(weight.data_ptr()),
+                                        ctypes.c_void_p(count.data_ptr()), self._stream(stream)))
+        return coords, logp, weight, count
+
+    def get_state(self, stream=None):
+        """(coords [nchains, P], logposterior, weight, naccepted, consecutive failed tries) as numpy arrays; synchronises the stream."""
+        coords, logp = np.empty((self.nchains, self.n_params), dtype='f8'), np.empty(self.nchains, dtype='f8')
+        weight, nacc, fails = np.empty(self.nchains, dtype='i8'), np.empty(self.nchains, dtype='i8'), np.empty(self.nchains, dtype='i4')
+        i64 = ctypes.POINTER(ctypes.c_int64)
+        self._check(self._lib.dl_mh_get_state(self._handle, _f64_ptr(coords), _f64_ptr(logp), weight.ctypes.data_as(i64), nacc.ctypes.data_as(i64),
+                                              fails.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), self._stream(stream)))
+        return coords, logp, weight, nacc, fails
+
+    def close(self):
+        if getattr(self, '_handle', None):
+            self._lib.dl_mh_destroy(self._handle)
             self._handle = None
 
     def __del__(self):

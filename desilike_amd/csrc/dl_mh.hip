@@ -1,0 +1,353 @@
+// dl_mh.hip -- device-resident blocked Metropolis-Hastings sampler (include/desilike_amd.h, dl_mh_*).
+//
+// The reference's own MCMC (desilike/samplers/mcmc.py: MHSampler 25-127 + BlockProposer 199-328, the CosmoMC / cobaya blocked proposal) advances ONE chain per
+// group of MPI ranks and uses the ranks of the group speculatively: ``vectorize`` proposals are drawn from the current state, their log-posteriors evaluated in
+// parallel, and the first one that passes the Metropolis test is taken, the rejected ones before it adding to the weight of the current state (mcmc.py:94-105).
+// Here C chains x V speculative proposals are ONE batch of C V rows of dl_eval_logposterior; positions, log-posteriors, weights, the accepted samples and the
+// random draws (dl_mh.h: pure functions of (seed, chain, call counter)) live on the device, and a try is two launches with no host synchronisation:
+//
+//     [Metropolis scan of the previous try | record the state that is left | V new proposals per chain]  ->  dl_eval_logposterior(C V rows)  ->  ...
+//
+// One workgroup per chain, one wavefront per proposal slot (<= 16 at a time); a lane per parameter.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/desilike_amd.h"
+#include "dl_kernels.h"
+#include "dl_mh.h"
+
+struct dl_mh {
+    dl_ctx* ctx = nullptr;
+    int device = 0;
+    int C = 0, V = 0, P = 0, nblocks = 0, n_rep = 0;
+    double scale = 2.4, offset = 0.;
+    uint64_t seed = 0;
+    int64_t max_tries = 1000, tries = 0;
+    bool have_logp = false, have_cov = false;
+    // device
+    double *coords = nullptr, *logp = nullptr, *prop = nullptr, *newlp = nullptr, *L = nullptr;
+    long long *weight = nullptr, *naccepted = nullptr;
+    int32_t *fails = nullptr, *chain_ids = nullptr, *order = nullptr, *rep_block = nullptr, *block_start = nullptr, *block_reps = nullptr;
+};
+
+namespace {
+
+int fail(const std::string& msg) {
+    dl_set_last_error(msg.c_str());
+    return 1;
+}
+
+#define DL_MH_HIP(call)                                                                               \
+    do {                                                                                              \
+        hipError_t err__ = (call);                                                                    \
+        if (err__ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(err__));   \
+    } while (0)
+
+struct DlMhArgs {
+    double *coords, *logp, *prop;
+    const double *newlp, *L;
+    long long *weight, *naccepted;
+    int32_t* fails;
+    const int32_t *chain_ids, *order, *rep_block, *block_start, *block_reps;
+    double *out_coords, *out_logp;       // records of this run: [C, cap, P], [C, cap]
+    long long* out_weight;               // [C, cap]
+    int32_t* out_count;                  // [C]
+    int32_t C, V, P, n_rep, cap, thin_by;
+    double scale, offset;
+    uint32_t k0, k1;
+    long long try_acc, try_prop;         // try whose proposals are pending / to draw; -1: none
+    long long max_tries;
+};
+
+__device__ __forceinline__ double dl_mh_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// direction of proposer call: column j of the Haar rotation m of block ib (b parameters), lane i holds component i (lanes >= b: 0).  Householder reflections of
+// Gaussian vectors applied to the unit vector e_j, last reflection first, then the signs D (Stewart 1980 as in scipy.stats.special_ortho_group; mcmc.py:170-173)
+__device__ __forceinline__ double dl_mh_direction(int lane, int b, int j, uint64_t m, uint32_t chain, int ib, uint32_t k0, uint32_t k1) {
+    double y = lane == j ? 1. : 0., dsign = 1., dprod = 1.;
+    for (int k = b - 2; k >= 0; --k) {
+        double x = (lane >= k && lane < b) ? dl_mh_rot_gauss(m, chain, ib, k, lane - k, k0, k1) : 0.;
+        const double norm2 = dl_mh_wave_sum(x * x);
+        const double x0 = __shfl(x, k, 64);
+        const double dk = x0 < 0. ? -1. : 1.;
+        const double x0n = x0 + dk * sqrt(norm2);
+        if (lane == k) { x = x0n; dsign = dk; }
+        dprod *= dk;
+        const double xx = (norm2 - x0 * x0) + x0n * x0n;
+        const double dot = dl_mh_wave_sum(x * y);
+        y -= 2. * x * (dot / xx);
+    }
+    if (lane == b - 1) dsign = (((b - 1) & 1) ? -1. : 1.) * dprod;
+    return y * dsign;
+}
+
+__global__ __launch_bounds__(1024) void dl_mh_step_kernel(const DlMhArgs s) {
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int P = s.P, V = s.V;
+    const uint32_t chain = (uint32_t)s.chain_ids[c];
+    // ---- Metropolis scan of the pending try (every wavefront takes the same decision from the same data; wavefront 0 writes it after the barrier) ----------------
+    const double cur_lp = s.logp[c];
+    double state = lane < P ? s.coords[(size_t)c * P + lane] : 0.;   // lane = parameter (context order)
+    double new_lp = cur_lp;
+    int first = -1;
+    if (s.try_acc >= 0) {
+        bool acc = false;
+        double lp = 0.;
+        if (lane < V) {
+            lp = s.newlp[(size_t)c * V + lane];
+            lp = (lp != lp ? -__builtin_huge_val() : lp) + s.offset;                                    // samplers/base.py:187-189
+            const double e = dl_mh_accept_exp((uint64_t)s.try_acc * V + lane, chain, s.k0, s.k1);
+            acc = lp > -__builtin_huge_val() && (lp > cur_lp || e > cur_lp - lp);                       // mcmc.py:107-112
+        }
+        const unsigned long long mask = __ballot(acc);
+        if (mask) {
+            first = __ffsll((long long)mask) - 1;
+            new_lp = __shfl(lp, first, 64);
+        }
+    }
+    const double old_state = state;
+    if (first >= 0 && lane < P) state = s.prop[((size_t)c * V + first) * P + lane];
+    __syncthreads();                                                    // every wavefront has read the pending proposals and the old state
+    if (wave == 0 && s.try_acc >= 0) {
+        if (first >= 0) {
+            const long long iter = s.naccepted[c];
+            if (iter > 0 && iter % s.thin_by == 0) {                    // the state that is left is recorded with its final weight; the start is skipped (mcmc.py:97-99)
+                const int slot = s.out_count[c];
+                if (slot < s.cap) {
+                    if (lane < P) s.out_coords[((size_t)c * s.cap + slot) * P + lane] = old_state;
+                    if (lane == 0) { s.out_logp[(size_t)c * s.cap + slot] = cur_lp; s.out_weight[(size_t)c * s.cap + slot] = s.weight[c] + first; s.out_count[c] = slot + 1; }
+                }
+            }
+            if (lane < P) s.coords[(size_t)c * P + lane] = state;
+            if (lane == 0) { s.logp[c] = new_lp; s.weight[c] = 1; s.naccepted[c] = iter + 1; s.fails[c] = 0; }
+        } else if (lane == 0) {
+            s.weight[c] += V;
+            s.fails[c] += 1;
+        }
+    }
+    if (s.try_prop < 0) return;
+    // ---- V new proposals from the (new) state: a wavefront per slot ---------------------------------------------------------------------------------------------
+    for (int v = wave; v < V; v += nwaves) {
+        const uint64_t n = (uint64_t)s.try_prop * V + v;
+        const uint64_t q = n / (uint64_t)s.n_rep;
+        const uint32_t p = (uint32_t)(n % (uint64_t)s.n_rep);
+        const DlMhKeys keys = dl_mh_perm_keys(q, chain, s.k0, s.k1);
+        const int ib = s.rep_block[dl_mh_perm_at(keys, p, (uint32_t)s.n_rep)];
+        int cnt = 0;                                                    // earlier calls of this cycle that went to the same block
+        for (uint32_t p0 = 0; p0 < p; p0 += 64) {
+            const uint32_t pp = p0 + lane;
+            const bool same = pp < p && s.rep_block[dl_mh_perm_at(keys, pp, (uint32_t)s.n_rep)] == ib;
+            cnt += __popcll(__ballot(same));
+        }
+        const int start = s.block_start[ib], b = s.block_start[ib + 1] - start;
+        const uint64_t calls = q * (uint64_t)s.block_reps[ib] + (uint64_t)cnt;
+        double sign = 1.;
+        const double radius = dl_mh_radial(n, chain, b, s.k0, s.k1, &sign);
+        double y;
+        if (b == 1) y = lane == 0 ? sign : 0.;                          // mcmc.py:165-166
+        else y = dl_mh_direction(lane, b, (int)(calls % (uint64_t)b), calls / (uint64_t)b, chain, ib, s.k0, s.k1);
+        y *= radius * s.scale;
+        // jump of the sorted parameters start .. P - 1: L[start:, start : start + b] . y (mcmc.py:290-296, 315-327); lane i = sorted index start + i
+        double delta = 0.;
+        const int i = start + lane;
+        for (int jj = 0; jj < b; ++jj) {
+            const double yj = __shfl(y, jj, 64);
+            if (i < P) delta += s.L[(size_t)i * P + start + jj] * yj;
+        }
+        // scatter into context order: sorted index i is parameter order[i]
+        double* row = s.prop + ((size_t)c * V + v) * P;
+        const int sorted = lane < P ? lane : 0;                         // (every lane takes part in the exchanges; the lanes beyond P write nothing)
+        const int target = s.order[sorted];
+        const double base = __shfl(state, target, 64);
+        const double jump = __shfl(delta, sorted >= start ? sorted - start : 0, 64);
+        if (lane < P) row[target] = base + (sorted >= start ? jump : 0.);   // the parameters of slower blocks keep their values
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void dl_mh_destroy(dl_mh* mh) {
+    if (!mh) return;
+    (void)hipSetDevice(mh->device);
+    for (void* p : {(void*)mh->coords, (void*)mh->logp, (void*)mh->prop, (void*)mh->newlp, (void*)mh->L, (void*)mh->weight, (void*)mh->naccepted, (void*)mh->fails,
+                    (void*)mh->chain_ids, (void*)mh->order, (void*)mh->rep_block, (void*)mh->block_start, (void*)mh->block_reps})
+        if (p) (void)hipFree(p);
+    delete mh;
+}
+
+int dl_mh_create(dl_mh** out, dl_ctx* ctx, int32_t nchains, int32_t vectorize, const int32_t* chain_ids, const int32_t* order, const int32_t* blocks,
+                 const int32_t* oversample, int32_t nblocks, double proposal_scale, uint64_t seed, double offset, int64_t max_tries) {
+    if (!out || !ctx || !blocks || nblocks < 1) return fail("dl_mh_create: null argument");
+    *out = nullptr;
+    const int P = (int)dl_info(ctx, "n_params");
+    if (P < 1 || P > DL_MH_MAX_P) return fail("dl_mh_create: the sampler takes 1 .. 64 parameters");
+    if (nchains < 1 || vectorize < 1 || vectorize > DL_MH_MAX_V) return fail("dl_mh_create: nchains >= 1 and 1 <= vectorize <= 64");
+    if (!(proposal_scale > 0.) || max_tries < 1) return fail("dl_mh_create: proposal_scale and max_tries must be positive");
+    std::vector<int32_t> start(nblocks + 1, 0), reps(nblocks), rep_block;
+    for (int ib = 0; ib < nblocks; ++ib) {
+        const int o = oversample ? oversample[ib] : 1;
+        if (blocks[ib] < 1 || o < 1) return fail("dl_mh_create: block sizes and oversampling factors must be >= 1");
+        start[ib + 1] = start[ib] + blocks[ib];
+        reps[ib] = blocks[ib] * o;
+        rep_block.insert(rep_block.end(), (size_t)reps[ib], ib);      // mcmc.py:254: every parameter index of the block repeated `o` times
+    }
+    if (start[nblocks] != P) return fail("dl_mh_create: the blocks must add up to the number of parameters");
+    if ((int)rep_block.size() > DL_MH_MAX_REP || nblocks > 64) return fail("dl_mh_create: too many blocks / cycler entries");
+    std::vector<int32_t> ord(P), ids(nchains);
+    std::vector<char> seen(P, 0);
+    for (int i = 0; i < P; ++i) {
+        ord[i] = order ? order[i] : i;
+        if (ord[i] < 0 || ord[i] >= P || seen[ord[i]]) return fail("dl_mh_create: order must be a permutation of the parameters");
+        seen[ord[i]] = 1;
+    }
+    for (int c = 0; c < nchains; ++c) ids[c] = chain_ids ? chain_ids[c] : c;
+    dl_mh* mh = new dl_mh();
+    mh->ctx = ctx; mh->device = (int)dl_info(ctx, "device"); mh->C = nchains; mh->V = vectorize; mh->P = P; mh->nblocks = nblocks; mh->n_rep = (int)rep_block.size();
+    mh->scale = proposal_scale; mh->seed = seed; mh->offset = offset; mh->max_tries = max_tries;
+    auto bail = [&](const std::string& msg) { dl_mh_destroy(mh); return fail(msg); };
+    if (hipSetDevice(mh->device) != hipSuccess) return bail("dl_mh_create: hipSetDevice failed");
+    const size_t C = nchains, V = vectorize;
+    bool ok = hipMalloc((void**)&mh->coords, C * P * sizeof(double)) == hipSuccess && hipMalloc((void**)&mh->logp, C * sizeof(double)) == hipSuccess &&
+              hipMalloc((void**)&mh->prop, C * V * P * sizeof(double)) == hipSuccess && hipMalloc((void**)&mh->newlp, C * V * sizeof(double)) == hipSuccess &&
+              hipMalloc((void**)&mh->L, (size_t)P * P * sizeof(double)) == hipSuccess && hipMalloc((void**)&mh->weight, C * sizeof(long long)) == hipSuccess &&
+              hipMalloc((void**)&mh->naccepted, C * sizeof(long long)) == hipSuccess && hipMalloc((void**)&mh->fails, C * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void**)&mh->chain_ids, C * sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&mh->order, (size_t)P * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void**)&mh->rep_block, rep_block.size() * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void**)&mh->block_start, start.size() * sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&mh->block_reps, reps.size() * sizeof(int32_t)) == hipSuccess;
+    if (!ok) return bail("dl_mh_create: device allocation failed");
+    ok = hipMemset(mh->prop, 0, C * V * P * sizeof(double)) == hipSuccess && hipMemset(mh->newlp, 0, C * V * sizeof(double)) == hipSuccess &&
+         hipMemset(mh->naccepted, 0, C * sizeof(long long)) == hipSuccess && hipMemset(mh->fails, 0, C * sizeof(int32_t)) == hipSuccess &&
+         hipMemset(mh->L, 0, (size_t)P * P * sizeof(double)) == hipSuccess &&
+         hipMemcpy(mh->chain_ids, ids.data(), C * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(mh->order, ord.data(), (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(mh->rep_block, rep_block.data(), rep_block.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(mh->block_start, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(mh->block_reps, reps.data(), reps.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) return bail("dl_mh_create: initialisation of the device arrays failed");
+    if (hipDeviceSynchronize() != hipSuccess) return bail("dl_mh_create: hipDeviceSynchronize failed");
+    *out = mh;
+    return 0;
+}
+
+int dl_mh_set_covariance(dl_mh* mh, const double* cholesky, void* hip_stream) {
+    if (!mh || !cholesky) return fail("dl_mh_set_covariance: null argument");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const int P = mh->P;
+    for (int i = 0; i < P; ++i) {
+        if (!(cholesky[(size_t)i * P + i] > 0.)) return fail("dl_mh_set_covariance: the Cholesky factor must have a positive diagonal");
+        for (int j = 0; j < P; ++j) {
+            const double v = cholesky[(size_t)i * P + j];
+            if (v != v || (j > i && v != 0.)) return fail("dl_mh_set_covariance: expected a finite lower-triangular factor [P, P] (sorted parameter order)");
+        }
+    }
+    DL_MH_HIP(hipSetDevice(mh->device));
+    DL_MH_HIP(hipMemcpyAsync(mh->L, cholesky, (size_t)P * P * sizeof(double), hipMemcpyHostToDevice, stream));
+    DL_MH_HIP(hipStreamSynchronize(stream));   // the host buffer may be pageable
+    mh->have_cov = true;
+    return 0;
+}
+
+int dl_mh_set_state(dl_mh* mh, const double* coords, const double* logposterior, const int64_t* weight, const int64_t* naccepted, int64_t tries, void* hip_stream) {
+    if (!mh || !coords) return fail("dl_mh_set_state: null argument");
+    if (tries < 0) return fail("dl_mh_set_state: negative try counter");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DL_MH_HIP(hipSetDevice(mh->device));
+    const size_t C = mh->C;
+    std::vector<long long> w(C, 1), na(C, 0);
+    if (weight) for (size_t c = 0; c < C; ++c) w[c] = weight[c];
+    if (naccepted) for (size_t c = 0; c < C; ++c) na[c] = naccepted[c];
+    DL_MH_HIP(hipMemcpyAsync(mh->coords, coords, C * mh->P * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (logposterior) DL_MH_HIP(hipMemcpyAsync(mh->logp, logposterior, C * sizeof(double), hipMemcpyHostToDevice, stream));
+    DL_MH_HIP(hipMemcpyAsync(mh->weight, w.data(), C * sizeof(long long), hipMemcpyHostToDevice, stream));
+    DL_MH_HIP(hipMemcpyAsync(mh->naccepted, na.data(), C * sizeof(long long), hipMemcpyHostToDevice, stream));
+    DL_MH_HIP(hipMemsetAsync(mh->fails, 0, C * sizeof(int32_t), stream));
+    DL_MH_HIP(hipStreamSynchronize(stream));
+    mh->have_logp = logposterior != nullptr;
+    mh->tries = tries;
+    return 0;
+}
+
+int dl_mh_run(dl_mh* mh, int64_t ntries, int32_t thin_by, double* out_coords_dev, double* out_logp_dev, int64_t* out_weight_dev, int32_t* out_count_dev, void* hip_stream) {
+    if (!mh) return fail("dl_mh_run: null sampler");
+    if (ntries < 0 || thin_by < 1) return fail("dl_mh_run: invalid argument");
+    if (ntries > 0 && (!out_coords_dev || !out_logp_dev || !out_weight_dev || !out_count_dev)) return fail("dl_mh_run: the record buffers are required");
+    if (!mh->have_cov) return fail("dl_mh_run: no proposal covariance (dl_mh_set_covariance)");
+    if (ntries > 0x7fffffff) return fail("dl_mh_run: at most 2^31 - 1 tries per call");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DL_MH_HIP(hipSetDevice(mh->device));
+    const int C = mh->C, V = mh->V, P = mh->P;
+    if (!mh->have_logp) {
+        if (dl_eval_logposterior(mh->ctx, mh->coords, C, mh->logp, nullptr, stream)) return 1;
+        std::vector<double> tmp(C);
+        DL_MH_HIP(hipMemcpyAsync(tmp.data(), mh->logp, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, stream));
+        DL_MH_HIP(hipStreamSynchronize(stream));
+        for (double& v : tmp) {
+            v = (v != v ? -__builtin_huge_val() : v) + mh->offset;
+            if (!(v > -__builtin_huge_val())) return fail("dl_mh_run: the log-posterior of a starting position is not finite");
+        }
+        DL_MH_HIP(hipMemcpyAsync(mh->logp, tmp.data(), (size_t)C * sizeof(double), hipMemcpyHostToDevice, stream));
+        DL_MH_HIP(hipStreamSynchronize(stream));
+        mh->have_logp = true;
+    }
+    if (ntries == 0) return 0;
+    DL_MH_HIP(hipMemsetAsync(out_count_dev, 0, (size_t)C * sizeof(int32_t), stream));
+    DlMhArgs s;
+    std::memset(&s, 0, sizeof(s));
+    s.coords = mh->coords; s.logp = mh->logp; s.prop = mh->prop; s.newlp = mh->newlp; s.L = mh->L; s.weight = mh->weight; s.naccepted = mh->naccepted; s.fails = mh->fails;
+    s.chain_ids = mh->chain_ids; s.order = mh->order; s.rep_block = mh->rep_block; s.block_start = mh->block_start; s.block_reps = mh->block_reps;
+    s.out_coords = out_coords_dev; s.out_logp = out_logp_dev; s.out_weight = reinterpret_cast<long long*>(out_weight_dev); s.out_count = out_count_dev;
+    s.C = C; s.V = V; s.P = P; s.n_rep = mh->n_rep; s.cap = (int32_t)ntries; s.thin_by = thin_by;
+    s.scale = mh->scale; s.offset = mh->offset; s.k0 = (uint32_t)mh->seed; s.k1 = (uint32_t)(mh->seed >> 32);
+    s.max_tries = mh->max_tries;
+    const unsigned threads = 64u * (unsigned)std::min(V, 16);
+    s.try_acc = -1;
+    for (int64_t t = mh->tries; t < mh->tries + ntries; ++t) {
+        s.try_prop = t;
+        hipLaunchKernelGGL(dl_mh_step_kernel, dim3(C), dim3(threads), 0, stream, s);
+        if (dl_eval_logposterior(mh->ctx, mh->prop, (int64_t)C * V, mh->newlp, nullptr, stream)) return 1;
+        s.try_acc = t;
+    }
+    s.try_prop = -1;
+    hipLaunchKernelGGL(dl_mh_step_kernel, dim3(C), dim3(64), 0, stream, s);
+    DL_MH_HIP(hipGetLastError());
+    mh->tries += ntries;
+    return 0;
+}
+
+int dl_mh_get_state(dl_mh* mh, double* coords, double* logposterior, int64_t* weight, int64_t* naccepted, int32_t* fails, void* hip_stream) {
+    if (!mh) return fail("dl_mh_get_state: null sampler");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DL_MH_HIP(hipSetDevice(mh->device));
+    const size_t C = mh->C;
+    if (coords) DL_MH_HIP(hipMemcpyAsync(coords, mh->coords, C * mh->P * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (logposterior) DL_MH_HIP(hipMemcpyAsync(logposterior, mh->logp, C * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (weight) DL_MH_HIP(hipMemcpyAsync(weight, mh->weight, C * sizeof(long long), hipMemcpyDeviceToHost, stream));
+    if (naccepted) DL_MH_HIP(hipMemcpyAsync(naccepted, mh->naccepted, C * sizeof(long long), hipMemcpyDeviceToHost, stream));
+    if (fails) DL_MH_HIP(hipMemcpyAsync(fails, mh->fails, C * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    DL_MH_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int64_t dl_mh_info(const dl_mh* mh, const char* key) {
+    if (!mh || !key) return -1;
+    const std::string k(key);
+    if (k == "nchains") return mh->C;
+    if (k == "vectorize") return mh->V;
+    if (k == "n_params") return mh->P;
+    if (k == "tries") return mh->tries;
+    if (k == "cycle") return mh->n_rep;
+    if (k == "max_tries") return mh->max_tries;
+    return -1;
+}
+
+}  // extern "C"

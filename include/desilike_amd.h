@@ -253,6 +253,35 @@ int  dl_ensemble_set_counter(dl_ensemble* ens, int64_t iteration, const int64_t*
 /* integer properties: "nwalkers", "n_params", "iteration", "rank", "world", "rows_per_rank" */
 int64_t dl_ensemble_info(const dl_ensemble* ens, const char* key);
 
+/* ---- device-resident blocked Metropolis-Hastings sampler ----------------------------------------------------------------------------------
+ * The reference's own MCMC (desilike/samplers/mcmc.py: MHSampler 25-127, BlockProposer 199-328 -- the CosmoMC / cobaya fast-slow blocked proposal: cycle through
+ * the columns of a random rotation of every block, radial scale from a mixture, jump = Cholesky factor of the proposal covariance x direction), with ``nchains``
+ * chains x ``vectorize`` speculative proposals per try (mcmc.py:86-105: the first proposal that passes the Metropolis test is taken, the rejected ones before it
+ * add to the weight of the current state) evaluated as ONE batch of nchains x vectorize rows of dl_eval_logposterior.  Positions, log-posteriors, weights and the
+ * random draws (csrc/dl_mh.h: Philox4x32-10, pure functions of (seed, chain id, proposer call)) are resident on the GPU; a try is one small kernel + the evaluation,
+ * nothing synchronises with the host.  Not built: dragging (mcmc.py:52-84 -- it exists to spare evaluations of slow parameters; here every parameter costs the same launch).
+ *   chain_ids[nchains]   global index of every chain (NULL: 0 .. nchains - 1): chains are reproducible whatever the rank that runs them
+ *   order[P]             sorted (block) position i -> parameter index of the context (NULL: identity); blocks[nblocks] sizes in sorted order, slowest first;
+ *                        oversample[nblocks] (NULL: 1) as BlockProposer's oversample_factors
+ *   offset               constant added to every log-posterior (posterior contexts marginalised once over linear parameters) */
+typedef struct dl_mh dl_mh;
+int  dl_mh_create(dl_mh** out, dl_ctx* ctx, int32_t nchains, int32_t vectorize, const int32_t* chain_ids, const int32_t* order, const int32_t* blocks,
+                  const int32_t* oversample, int32_t nblocks, double proposal_scale, uint64_t seed, double offset, int64_t max_tries);
+void dl_mh_destroy(dl_mh* mh);
+/* lower-triangular Cholesky factor [P, P] (host, row-major) of the proposal covariance of the parameters in SORTED order (BlockProposer.set_covariance, mcmc.py:298-328) */
+int  dl_mh_set_covariance(dl_mh* mh, const double* cholesky, void* hip_stream);
+/* host arrays: coords[nchains, P] (context order), logposterior[nchains] (NULL: evaluated at the next dl_mh_run; must be finite), weight[nchains] of the current
+ * states (NULL: 1), naccepted[nchains] (NULL: 0), and the try counter of the random draws (resume: a chain continues from (position, counters) alone) */
+int  dl_mh_set_state(dl_mh* mh, const double* coords, const double* logposterior, const int64_t* weight, const int64_t* naccepted, int64_t tries, void* hip_stream);
+/* ``ntries`` tries of every chain, enqueued on ``hip_stream`` (asynchronous).  A state is recorded when the chain leaves it (with its final weight; the starting
+ * state is skipped and every thin_by-th accepted state kept, mcmc.py:97-99): out_coords_dev[nchains, ntries, P], out_logp_dev[nchains, ntries],
+ * out_weight_dev[nchains, ntries] hold the out_count_dev[nchains] records of this call (device, caller-owned). */
+int  dl_mh_run(dl_mh* mh, int64_t ntries, int32_t thin_by, double* out_coords_dev, double* out_logp_dev, int64_t* out_weight_dev, int32_t* out_count_dev, void* hip_stream);
+/* host arrays (any may be NULL): current positions, log-posteriors, weights, accepted moves, consecutive tries without an accepted proposal; synchronises */
+int  dl_mh_get_state(dl_mh* mh, double* coords, double* logposterior, int64_t* weight, int64_t* naccepted, int32_t* fails, void* hip_stream);
+/* integer properties: "nchains", "vectorize", "n_params", "tries", "cycle" (entries of the parameter cycler), "max_tries" */
+int64_t dl_mh_info(const dl_mh* mh, const char* key);
+
 /* ---- MLP emulator training ---------------------------------------------------------------------------------------
  * The reference trains its MLP emulators through the third-party engine ``cosmoprimo.emulators.tools.MLPEmulatorEngine`` (desilike/emulators/__init__.py:510-533;
  * network structure: emulators/conversion.py:20-96).  Here: fp64 mini-batch Adam on the mean squared error of the (already scaled) outputs, entirely on the device

@@ -962,3 +962,199 @@ def gaussian_covariance(observables, theories, resolution=1):
             if io1 == io2: blocks[io1][io2] = (c + c.T) / 2.
             else: blocks[io1][io2], blocks[io2][io1] = c, c.T
     return np.block(blocks)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# Blocked Metropolis-Hastings sampler (desilike/samplers/mcmc.py).  Two sources of random draws:
+#   MHNumpyDraws   the reference's own sequence of numpy RandomState calls (mcmc.py:107-112, 150-183): with the same seed the restatement reproduces the
+#                  reference's chain bit for bit (tests/golden/mh_*.npz, generated by the reference's classes);
+#   MHPhiloxDraws  the counter-based draws of the device sampler (desilike_amd/csrc/dl_mh.h): pure functions of (seed, chain, proposer call).
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+def mh_format_blocks(blocks, oversample_factors=None):
+    """mcmc.py:247-256: starts of the blocks, the block of every parameter, the cycler's repeated parameter indices."""
+    blocks = np.array(blocks, dtype='i4')
+    oversample_factors = np.ones(len(blocks), dtype='i4') if oversample_factors is None else np.array(oversample_factors, dtype='i4')
+    block_starts = np.insert(np.cumsum(blocks), 0, 0)
+    indices_repeated = np.concatenate([np.repeat(np.arange(b) + s, o) for b, s, o in zip(blocks, block_starts, oversample_factors)])
+    param_block_indices = np.concatenate([np.full(b, ib, dtype='i4') for ib, b in enumerate(blocks)])
+    return blocks, oversample_factors, block_starts, indices_repeated, param_block_indices
+
+
+def mh_transforms(covariance, blocks):
+    """mcmc.py:298-328: per block the columns of the Cholesky factor, from the block's first row down."""
+    covariance = np.array(covariance, dtype='f8')
+    L = np.linalg.cholesky(covariance)
+    block_starts = np.insert(np.cumsum(blocks), 0, 0)
+    return [L[start:, start:start + b] for start, b in zip(block_starts, blocks)]
+
+
+class MHNumpyDraws(object):
+    """The reference's draws: one numpy RandomState consumed in the reference's order."""
+
+    def __init__(self, rng, blocks, oversample_factors=None):
+        from scipy.stats import special_ortho_group
+        self._so = special_ortho_group
+        self.rng = rng
+        self.blocks, self.oversample_factors, self.block_starts, self.indices_repeated, self.param_block_indices = mh_format_blocks(blocks, oversample_factors)
+        self.cycler_loop, self.cycler_indices = -1, (list(range(len(self.indices_repeated))) if len(self.indices_repeated) <= 2 else None)
+        if self.cycler_indices is not None: self.cycler_indices = list(self.indices_repeated)   # mcmc.py:146-147
+        self.block_loop, self.rotmat = [-1] * len(self.blocks), [None] * len(self.blocks)
+
+    def _radius(self, b):   # mcmc.py:176-183
+        if self.rng.uniform() < 0.33:
+            return self.rng.standard_exponential()
+        return np.sqrt(self.rng.chisquare(min(b, 2)))
+
+    def direction(self, call):
+        """(block, direction x radius) of the next proposer call (mcmc.py:150-155, 163-173, 270-277); ``call`` is not used: the draws are sequential."""
+        nrep = len(self.indices_repeated)
+        self.cycler_loop = (self.cycler_loop + 1) % nrep
+        if self.cycler_loop == 0 and nrep > 2:
+            self.cycler_indices = self.rng.permutation(self.indices_repeated)
+        ib = int(self.param_block_indices[self.cycler_indices[self.cycler_loop]])
+        b = int(self.blocks[ib])
+        if b == 1:
+            return ib, np.array([self.rng.choice([-1, 1]) * self._radius(b)])
+        self.block_loop[ib] = (self.block_loop[ib] + 1) % b
+        if self.block_loop[ib] == 0:
+            self.rotmat[ib] = self._so.rvs(b, random_state=self.rng)
+        return ib, self.rotmat[ib][:, self.block_loop[ib]] * self._radius(b)
+
+    def exponential(self, call):
+        return self.rng.standard_exponential()
+
+
+def _mh_philox(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al. 2011) on python integers."""
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def _mh_uniform53(hi, lo):
+    return ((hi >> 5) * 67108864. + (lo >> 6)) / 9007199254740992.
+
+
+class MHPhiloxDraws(object):
+    """The device sampler's draws (csrc/dl_mh.h), as functions of the proposer call ``n`` of chain ``chain``."""
+    PERM_A, PERM_B, RADIAL, RADIAL2, ACCEPT, ROT = 16, 17, 18, 19, 20, 21
+
+    def __init__(self, seed, chain, blocks, oversample_factors=None):
+        self.k0, self.k1, self.chain = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF, int(chain)
+        self.blocks, self.oversample_factors, self.block_starts, self.indices_repeated, self.param_block_indices = mh_format_blocks(blocks, oversample_factors)
+        self.rep_block = self.param_block_indices[self.indices_repeated]
+
+    def _words(self, counter, stream):
+        return _mh_philox(counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF, self.chain, stream, self.k0, self.k1)
+
+    def permutation(self, cycle):
+        n = len(self.rep_block)
+        if n <= 2: return list(range(n))
+        ka, kb = self._words(cycle, self.PERM_A), self._words(cycle, self.PERM_B)
+        bits = max(int(n - 1).bit_length(), 1)
+        mask, shift = (1 << bits) - 1, (bits + 1) // 2
+        out = []
+        for p in range(n):
+            y = p
+            while True:
+                for r in range(4):
+                    y = (y * (ka[r] | 1) + kb[r]) & mask
+                    y ^= y >> shift
+                if y < n: break
+            out.append(y)
+        return out
+
+    def gauss(self, m, ib, refl, element):
+        w = self._words(m, self.ROT | (ib << 8) | (refl << 14) | ((element >> 1) << 20))
+        rho, phi = np.sqrt(-2. * np.log1p(-_mh_uniform53(w[0], w[1]))), 2. * np.pi * _mh_uniform53(w[2], w[3])
+        return rho * np.sin(phi) if element & 1 else rho * np.cos(phi)
+
+    def rotation_column(self, m, ib, b, j):
+        """Column j of the Haar rotation: Householder reflections of Gaussian vectors (Stewart 1980; scipy.stats.special_ortho_group) applied to e_j."""
+        y = np.zeros(b); y[j] = 1.
+        D = np.ones(b)
+        for k in range(b - 2, -1, -1):
+            x = np.array([self.gauss(m, ib, k, e) for e in range(b - k)])
+            norm2 = np.sum(x**2)
+            x0 = x[0]
+            D[k] = -1. if x0 < 0. else 1.
+            x[0] = x0 + D[k] * np.sqrt(norm2)
+            xx = (norm2 - x0**2) + x[0]**2
+            y[k:] -= 2. * x * (np.dot(x, y[k:]) / xx)
+        D[b - 1] = (-1.)**(b - 1) * np.prod(D[:b - 1])
+        return D * y
+
+    def direction(self, call):
+        nrep = len(self.rep_block)
+        q, p = divmod(int(call), nrep)
+        perm = self.permutation(q)
+        ib = int(self.rep_block[perm[p]])
+        b = int(self.blocks[ib])
+        calls = q * int(self.blocks[ib] * self.oversample_factors[ib]) + sum(int(self.rep_block[perm[pp]]) == ib for pp in range(p))
+        w = self._words(call, self.RADIAL)
+        mix, e = _mh_uniform53(w[0], w[1]), -np.log1p(-_mh_uniform53(w[2], w[3]))
+        if b >= 2:
+            radius = e if mix < 0.33 else np.sqrt(2. * e)
+            return ib, self.rotation_column(calls // b, ib, b, calls % b) * radius
+        w2 = self._words(call, self.RADIAL2)
+        g = np.sqrt(2. * e) * np.cos(2. * np.pi * _mh_uniform53(w2[0], w2[1]))
+        radius = e if mix < 0.33 else abs(g)
+        return ib, np.array([(1. if w2[2] & 1 else -1.) * radius])
+
+    def exponential(self, call):
+        w = self._words(call, self.ACCEPT)
+        return -np.log1p(-_mh_uniform53(w[0], w[1]))
+
+
+def mh_jump(draws, transforms, call, proposal_scale=2.4):
+    """mcmc.py:290-296: the jump of proposer call ``call``: zero for the parameters of slower blocks."""
+    ib, direction = draws.direction(call)
+    ndim = int(draws.block_starts[-1])
+    jump = np.zeros(ndim)
+    jump[draws.block_starts[ib]:] += transforms[ib].dot(direction * proposal_scale)
+    return jump
+
+
+def mh_sample(log_prob_fn, start, draws, transforms, proposal_scale=2.4, iterations=None, ntries=None, thin_by=1, vectorize=1, max_tries=1000, start_log_prob=None):
+    """MHSampler.sample without dragging (mcmc.py:45-105): ``vectorize`` proposals per try from the current state, the first accepted one is taken, the rejected
+    ones before it add to the weight.  Stops after ``iterations`` + 1 accepted moves (the reference's loop) or after ``ntries`` tries (the device's unit).
+    Returns (chain, weight, log_prob) of the recorded states and the final (coords, log_prob, weight)."""
+    coords = np.array(start, dtype='f8')
+    log_prob = float(log_prob_fn(coords[None, :])[0]) if start_log_prob is None else float(start_log_prob)
+    weight, states = 1, []
+    tries, it, call = 0, 0, 0
+
+    def mh_accept(proposal_log_prob, current_log_prob, call):   # mcmc.py:107-112
+        if proposal_log_prob == -np.inf: return False
+        if proposal_log_prob > current_log_prob: return True
+        return draws.exponential(call) > (current_log_prob - proposal_log_prob)
+
+    while True:
+        if iterations is not None and it > iterations: break
+        accept = False
+        for itry in range(max_tries):
+            if ntries is not None and tries >= ntries: break
+            proposals = coords + np.array([mh_jump(draws, transforms, call + i, proposal_scale=proposal_scale) for i in range(vectorize)])
+            proposals_log_prob = np.asarray(log_prob_fn(proposals), dtype='f8')
+            base = call
+            call += vectorize
+            tries += 1
+            for i in range(vectorize):
+                accept = mh_accept(proposals_log_prob[i], log_prob, base + i)
+                if accept: break
+                weight += 1
+            if accept:
+                if it > 0 and it % thin_by == 0:
+                    states.append((coords, log_prob, weight))
+                coords, log_prob, weight = proposals[i], float(proposals_log_prob[i]), 1
+                break
+        if ntries is not None and tries >= ntries and not accept: break
+        if not accept:
+            raise ValueError('Could not find finite log posterior after {:d} tries'.format(max_tries))
+        it += 1
+        if ntries is not None and tries >= ntries: break
+    ndim = len(coords)
+    chain = np.array([s[0] for s in states]).reshape(len(states), ndim)
+    return chain, np.array([s[2] for s in states], dtype='i8'), np.array([s[1] for s in states], dtype='f8'), (coords, log_prob, weight)

@@ -1,0 +1,127 @@
+"""GPU (-m gpu): the device-resident blocked Metropolis-Hastings sampler (dl_mh_*; reference desilike/samplers/mcmc.py) against the oracle's restatement of the
+reference's MHSampler + BlockProposer (pinned bit for bit on chains of the reference itself, tests/test_oracle_mh.py) driven by the same counter-based draws."""
+import numpy as np
+import pytest
+
+from test_host_api import make_cfg5
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(nchains, seed=3):
+    g, like = make_cfg5()
+    ctx, offset = like._get_posterior_context()
+    P = ctx.n_params
+    rng = np.random.RandomState(seed)
+    center = np.array([param.value for param in like.varied_params], dtype='f8')
+    sigma = np.array([0.02 * max(abs(v), 0.5) for v in center])
+    a = rng.standard_normal((P, P))
+    corr = a.dot(a.T) / P + 2. * np.eye(P)
+    d = np.sqrt(np.diag(corr))
+    cov = corr / d[:, None] / d[None, :] * sigma[:, None] * sigma[None, :]
+    start = center + 0.5 * sigma * rng.standard_normal((nchains, P))
+    return like, ctx, offset, cov, start
+
+
+def _oracle_chain(ctx, offset, order, blocks, oversample, cov_sorted, start_ctx, seed, chain_id, ntries, vectorize, thin_by, scale=2.4):
+    from oracle import np_oracle as orc
+    order = np.asarray(order)
+
+    def log_prob_fn(x_sorted):
+        x_sorted = np.atleast_2d(x_sorted)
+        x = np.empty_like(x_sorted)
+        x[:, order] = x_sorted
+        lp = ctx.eval_logposterior_host(x)[0]
+        lp = np.where(np.isnan(lp), -np.inf, lp) + offset
+        return lp
+
+    draws = orc.MHPhiloxDraws(seed, chain_id, blocks, oversample)
+    transforms = orc.mh_transforms(cov_sorted, blocks)
+    chain, weight, logp, final = orc.mh_sample(log_prob_fn, start_ctx[order], draws, transforms, proposal_scale=scale, ntries=ntries, thin_by=thin_by, vectorize=vectorize)
+    out = np.empty_like(chain)
+    out[:, order] = chain
+    fin = np.empty_like(final[0])
+    fin[order] = final[0]
+    return out, weight, logp, (fin, final[1], final[2])
+
+
+@pytest.mark.parametrize('blocks,oversample,vectorize,thin_by', [([5, 3], [1, 2], 4, 2), ([8], [1], 1, 1), ([1, 6, 1], [1, 1, 3], 3, 1)])
+def test_device_chains_match_the_oracle(blocks, oversample, vectorize, thin_by):
+    import torch
+    from desilike_amd._lib import DeviceMH
+    nchains, ntries, seed = 3, 50, 0x9e3779b97f4a7c15
+    like, ctx, offset, cov, start = _setup(nchains)
+    P = ctx.n_params
+    order = np.random.RandomState(5).permutation(P)
+    cov_sorted = cov[np.ix_(order, order)]
+    chain_ids = [7, 0, 12]
+    mh = DeviceMH(ctx, nchains, vectorize=vectorize, blocks=blocks, oversample=oversample, order=order, chain_ids=chain_ids, seed=seed, offset=offset)
+    assert mh.info('cycle') == int(np.sum(np.array(blocks) * np.array(oversample)))
+    mh.set_covariance(np.linalg.cholesky(cov_sorted))
+    mh.set_state(start)
+    coords, logp, weight, count = mh.run(ntries, thin_by=thin_by)
+    torch.cuda.synchronize()
+    fcoords, flogp, fweight, fnacc, fails = mh.get_state()
+    coords, logp, weight, count = coords.cpu().numpy(), logp.cpu().numpy(), weight.cpu().numpy(), count.cpu().numpy()
+    assert mh.info('tries') == ntries
+    for c in range(nchains):
+        ochain, oweight, ologp, ofinal = _oracle_chain(ctx, offset, order, blocks, oversample, cov_sorted, start[c], seed, chain_ids[c], ntries, vectorize, thin_by)
+        n = int(count[c])
+        assert n == len(oweight) and n > 3, (n, len(oweight))
+        assert np.array_equal(weight[c, :n], oweight)
+        assert np.allclose(coords[c, :n], ochain, rtol=1e-11, atol=1e-13)
+        assert np.allclose(logp[c, :n], ologp, rtol=1e-10, atol=1e-9)
+        assert np.allclose(fcoords[c], ofinal[0], rtol=1e-11, atol=1e-13) and np.isclose(flogp[c], ofinal[1], rtol=1e-10, atol=1e-9) and fweight[c] == ofinal[2]
+        assert fails[c] < 20
+    # continuing the run is the same chain as one longer run (nothing but positions and counters is carried over)
+    coords2, logp2, weight2, count2 = mh.run(20, thin_by=thin_by)
+    torch.cuda.synchronize()
+    c = 1
+    ochain, oweight, ologp, ofinal = _oracle_chain(ctx, offset, order, blocks, oversample, cov_sorted, start[c], seed, chain_ids[c], ntries + 20, vectorize, thin_by)
+    n1, n2 = int(count[c]), int(count2[c].item())
+    assert n1 + n2 == len(oweight)
+    assert np.array_equal(np.concatenate([weight[c, :n1], weight2[c, :n2].cpu().numpy()]), oweight)
+    assert np.allclose(coords2[c, :n2].cpu().numpy(), ochain[n1:], rtol=1e-11, atol=1e-13)
+
+
+def test_device_state_round_trip_and_errors():
+    import torch
+    from desilike_amd._lib import DeviceMH, LibraryError
+    like, ctx, offset, cov, start = _setup(4)
+    P = ctx.n_params
+    L = np.linalg.cholesky(cov)
+    a = DeviceMH(ctx, 4, vectorize=2, seed=11, offset=offset)
+    a.set_covariance(L)
+    a.set_state(start)
+    ra = a.run(30)
+    torch.cuda.synchronize()
+    sa = a.get_state()
+    # resume in a new object from (positions, log-posteriors, weights, counters) after 12 tries
+    b = DeviceMH(ctx, 4, vectorize=2, seed=11, offset=offset)
+    b.set_covariance(L)
+    b.set_state(start)
+    rb1 = b.run(12)
+    torch.cuda.synchronize()
+    coords, logp, weight, nacc, fails = b.get_state()
+    c = DeviceMH(ctx, 4, vectorize=2, seed=11, offset=offset)
+    c.set_covariance(L)
+    c.set_state(coords, logposterior=logp, weight=weight, naccepted=nacc, tries=12)
+    rc = c.run(18)
+    torch.cuda.synchronize()
+    sc = c.get_state()
+    for x, y in zip(sa, sc): assert np.array_equal(x, y)
+    for ich in range(4):
+        n = int(ra[3][ich].item()); n1 = int(rb1[3][ich].item()); n2 = int(rc[3][ich].item())
+        assert n == n1 + n2
+        assert torch.equal(ra[0][ich, :n], torch.cat([rb1[0][ich, :n1], rc[0][ich, :n2]]))
+        assert torch.equal(ra[2][ich, :n], torch.cat([rb1[2][ich, :n1], rc[2][ich, :n2]]))
+    with pytest.raises(LibraryError): DeviceMH(ctx, 2, vectorize=65)
+    with pytest.raises(LibraryError): DeviceMH(ctx, 2, blocks=[3, 3])
+    with pytest.raises(LibraryError): DeviceMH(ctx, 2, order=np.zeros(P))
+    d = DeviceMH(ctx, 2, seed=1)
+    with pytest.raises(LibraryError): d.run(5)                 # no covariance
+    with pytest.raises(LibraryError): d.set_covariance(L.T)     # upper-triangular
+    d.set_covariance(L)
+    bad = start[:2].copy(); bad[0, 1] = 1e3                      # outside the prior: no finite starting log-posterior
+    d.set_state(bad)
+    with pytest.raises(LibraryError): d.run(5)
