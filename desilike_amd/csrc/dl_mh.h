@@ -55,7 +55,7 @@ __host__ __device__ inline double dl_mh_accept_exp(uint64_t n, uint32_t chain, u
 }
 
 // radial scale of proposer call n for a block of b parameters, and the sign used by one-parameter blocks (mcmc.py:165-166, 176-183)
-__host__ __device__ inline double dl_mh_radial(uint64_t n, uint32_t chain, int b, uint32_t k0, uint32_t k1, double* sign) {
+__device__ inline double dl_mh_radial(uint64_t n, uint32_t chain, int b, uint32_t k0, uint32_t k1, double* sign) {
     const DlPhilox r = dl_philox4x32((uint32_t)n, (uint32_t)(n >> 32), chain, DL_MH_STREAM_RADIAL, k0, k1);
     const double mix = dl_uniform53(r.x[0], r.x[1]);
     const double e = -log1p(-dl_uniform53(r.x[2], r.x[3]));
@@ -63,7 +63,7 @@ __host__ __device__ inline double dl_mh_radial(uint64_t n, uint32_t chain, int b
     if (b >= 2) radius = mix < 0.33 ? e : sqrt(2. * e);                                     // chi2(2) = 2 x exponential
     else {
         const DlPhilox r2 = dl_philox4x32((uint32_t)n, (uint32_t)(n >> 32), chain, DL_MH_STREAM_RADIAL2, k0, k1);
-        const double g = sqrt(2. * e) * cos(6.283185307179586 * dl_uniform53(r2.x[0], r2.x[1]));   // chi2(1) = (standard normal)^2
+        const double g = sqrt(2. * e) * cospi(2. * dl_uniform53(r2.x[0], r2.x[1]));   // chi2(1) = (standard normal)^2
         radius = mix < 0.33 ? e : fabs(g);
         if (sign) *sign = (r2.x[2] & 1u) ? 1. : -1.;
     }
@@ -71,9 +71,9 @@ __host__ __device__ inline double dl_mh_radial(uint64_t n, uint32_t chain, int b
 }
 
 // Gaussian number `element` of reflection `refl` of rotation m of block ib
-__host__ __device__ inline double dl_mh_rot_gauss(uint64_t m, uint32_t chain, int ib, int refl, int element, uint32_t k0, uint32_t k1) {
+__device__ inline double dl_mh_rot_gauss(uint64_t m, uint32_t chain, int ib, int refl, int element, uint32_t k0, uint32_t k1) {
     const uint32_t stream = (uint32_t)DL_MH_STREAM_ROT | ((uint32_t)ib << 8) | ((uint32_t)refl << 14) | ((uint32_t)(element >> 1) << 20);
     const DlPhilox r = dl_philox4x32((uint32_t)m, (uint32_t)(m >> 32), chain, stream, k0, k1);
-    const double rho = sqrt(-2. * log1p(-dl_uniform53(r.x[0], r.x[1]))), phi = 6.283185307179586 * dl_uniform53(r.x[2], r.x[3]);
-    return (element & 1) ? rho * sin(phi) : rho * cos(phi);
+    const double rho = sqrt(-2. * log1p(-dl_uniform53(r.x[0], r.x[1]))), phi2 = 2. * dl_uniform53(r.x[2], r.x[3]);
+    return (element & 1) ? rho * sinpi(phi2) : rho * cospi(phi2);
 }

@@ -8,7 +8,7 @@
 //
 //     [Metropolis scan of the previous try | record the state that is left | V new proposals per chain]  ->  dl_eval_logposterior(C V rows)  ->  ...
 //
-// One workgroup per chain, one wavefront per proposal slot (<= 16 at a time); a lane per parameter.
+// One wavefront per (chain, proposal slot), a lane per parameter; the wavefronts of a chain repeat the (cheap) Metropolis scan instead of synchronising.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -29,9 +29,12 @@ struct dl_mh {
     int64_t max_tries = 1000, tries = 0;
     bool have_logp = false, have_cov = false;
     // device
-    double *coords = nullptr, *logp = nullptr, *prop = nullptr, *newlp = nullptr, *L = nullptr;
-    long long *weight = nullptr, *naccepted = nullptr;
-    int32_t *fails = nullptr, *chain_ids = nullptr, *order = nullptr, *rep_block = nullptr, *block_start = nullptr, *block_reps = nullptr;
+    // the state (positions, log-posteriors, weights, counters) and the proposals exist twice: a launch reads one copy and writes the other, so that the wavefronts
+    // of a chain (one per proposal slot, spread over the chip) need no barrier between the Metropolis scan and the new proposals
+    double *coords[2] = {nullptr, nullptr}, *logp[2] = {nullptr, nullptr}, *prop[2] = {nullptr, nullptr}, *newlp = nullptr, *L = nullptr;
+    long long *weight[2] = {nullptr, nullptr}, *naccepted[2] = {nullptr, nullptr};
+    int32_t *fails[2] = {nullptr, nullptr}, *chain_ids = nullptr, *order = nullptr, *rep_block = nullptr, *block_start = nullptr, *block_reps = nullptr;
+    int cur = 0, cur_prop = 0;
 };
 
 namespace {
@@ -48,10 +51,13 @@ int fail(const std::string& msg) {
     } while (0)
 
 struct DlMhArgs {
-    double *coords, *logp, *prop;
+    const double *coords, *logp, *prop;  // state before this launch, pending proposals
+    double *coords_out, *logp_out, *prop_out;
     const double *newlp, *L;
-    long long *weight, *naccepted;
-    int32_t* fails;
+    const long long *weight, *naccepted;
+    long long *weight_out, *naccepted_out;
+    const int32_t* fails;
+    int32_t* fails_out;
     const int32_t *chain_ids, *order, *rep_block, *block_start, *block_reps;
     double *out_coords, *out_logp;       // records of this run: [C, cap, P], [C, cap]
     long long* out_weight;               // [C, cap]
@@ -70,8 +76,15 @@ __device__ __forceinline__ double dl_mh_wave_sum(double v) {
 }
 
 // direction of proposer call: column j of the Haar rotation m of block ib (b parameters), lane i holds component i (lanes >= b: 0).  Householder reflections of
-// Gaussian vectors applied to the unit vector e_j, last reflection first, then the signs D (Stewart 1980 as in scipy.stats.special_ortho_group; mcmc.py:170-173)
-__device__ __forceinline__ double dl_mh_direction(int lane, int b, int j, uint64_t m, uint32_t chain, int ib, uint32_t k0, uint32_t k1) {
+// Gaussian vectors applied to the unit vector e_j, last reflection first, then the signs D (Stewart 1980 as in scipy.stats.special_ortho_group; mcmc.py:170-173).
+// Reflection k acts on the components >= k only: the ones with k > j leave e_j alone and contribute their sign alone.
+//   wide blocks (b > DL_MH_LDS_B): every reflection draws its Gaussians when it is applied;
+//   b <= DL_MH_LDS_B: all Gaussians the column needs are drawn in ONE pass over the lanes (a Philox call gives a pair) into the wavefront's LDS rows, every lane sums
+//   the squares of its own row, and the loop over the reflections is one LDS read, one short reduction and two FMAs per reflection (a single wavefront runs this
+//   kernel's critical path: its length is what a try pays).
+#define DL_MH_LDS_B 32
+
+__device__ __forceinline__ double dl_mh_direction_wide(int lane, int b, int j, uint64_t m, uint32_t chain, int ib, uint32_t k0, uint32_t k1) {
     double y = lane == j ? 1. : 0., dsign = 1., dprod = 1.;
     for (int k = b - 2; k >= 0; --k) {
         double x = (lane >= k && lane < b) ? dl_mh_rot_gauss(m, chain, ib, k, lane - k, k0, k1) : 0.;
@@ -89,11 +102,61 @@ __device__ __forceinline__ double dl_mh_direction(int lane, int b, int j, uint64
     return y * dsign;
 }
 
-__global__ __launch_bounds__(1024) void dl_mh_step_kernel(const DlMhArgs s) {
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+__device__ __forceinline__ double dl_mh_direction(int lane, int b, int j, uint64_t m, uint32_t chain, int ib, uint32_t k0, uint32_t k1, double* g /* LDS [DL_MH_LDS_B][DL_MH_LDS_B] of this wavefront */) {
+    if (b > DL_MH_LDS_B) return dl_mh_direction_wide(lane, b, j, m, chain, ib, k0, k1);
+    const int kmax = j < b - 2 ? j : b - 2, pb = (b + 1) >> 1;
+    const int full = (kmax + 1) * pb, slots = full + (b - 2 - kmax);       // whole rows 0 .. kmax, the first pair of the rows above (their signs)
+    for (int sl = lane; sl < slots; sl += 64) {
+        const int k = sl < full ? sl / pb : kmax + 1 + (sl - full), pr = sl < full ? sl % pb : 0;
+        if (2 * pr < b - k) {
+            const uint32_t stream = (uint32_t)DL_MH_STREAM_ROT | ((uint32_t)ib << 8) | ((uint32_t)k << 14) | ((uint32_t)pr << 20);
+            const DlPhilox r = dl_philox4x32((uint32_t)m, (uint32_t)(m >> 32), chain, stream, k0, k1);
+            const double rho = sqrt(-2. * log1p(-dl_uniform53(r.x[0], r.x[1])));
+            double sn, cs;
+            sincospi(2. * dl_uniform53(r.x[2], r.x[3]), &sn, &cs);
+            g[k * DL_MH_LDS_B + 2 * pr] = rho * cs;
+            if (2 * pr + 1 < b - k) g[k * DL_MH_LDS_B + 2 * pr + 1] = rho * sn;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the rows are in LDS
+    // lane k: sum of squares, sign and modified first element of row k
+    double norm2 = 0., x0 = 1.;
+    if (lane <= b - 2) {
+        x0 = g[lane * DL_MH_LDS_B];
+        if (lane <= kmax) for (int e = 0; e < b - lane; ++e) { const double t = g[lane * DL_MH_LDS_B + e]; norm2 += t * t; }
+    }
+    const double dk = x0 < 0. ? -1. : 1.;                                 // lanes above b - 2: + 1
+    double dprod = dk;                                                     // product of the signs of all reflections
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) dprod *= __shfl_xor(dprod, off, 64);
+    const double x0n = x0 + dk * sqrt(norm2), xx = (norm2 - x0 * x0) + x0n * x0n;
+    int width = 1;
+    while (width < b) width <<= 1;
+    double y = lane == j ? 1. : 0.;
+    for (int k = kmax; k >= 0; --k) {
+        double x = (lane > k && lane < b) ? g[k * DL_MH_LDS_B + lane - k] : 0.;
+        const double x0k = __shfl(x0n, k, 64), xxk = __shfl(xx, k, 64);
+        if (lane == k) x = x0k;
+        double dot = x * y;
+        for (int off = width >> 1; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);   // (the lanes beyond the block hold zeros)
+        y -= 2. * x * (dot / xxk);
+    }
+    const double dsign = lane == b - 1 ? (((b - 1) & 1) ? -1. : 1.) * dprod : dk;
+    return y * dsign;
+}
+
+#define DL_MH_WAVES 4   // wavefronts per workgroup: independent (chain, slot) pairs
+
+__global__ __launch_bounds__(64 * DL_MH_WAVES) void dl_mh_step_kernel(const DlMhArgs s) {
+    __shared__ double gauss[DL_MH_WAVES][DL_MH_LDS_B * DL_MH_LDS_B];
+    const int lane = threadIdx.x & 63;
     const int P = s.P, V = s.V;
+    const long long pair = (long long)blockIdx.x * DL_MH_WAVES + (threadIdx.x >> 6);
+    if (pair >= (long long)s.C * V) return;
+    const int c = (int)(pair / V), v = (int)(pair % V);
     const uint32_t chain = (uint32_t)s.chain_ids[c];
-    // ---- Metropolis scan of the pending try (every wavefront takes the same decision from the same data; wavefront 0 writes it after the barrier) ----------------
+    // ---- Metropolis scan of the pending try: every wavefront of the chain takes the same decision from the same data; the wavefront of slot 0 writes it ------------
     const double cur_lp = s.logp[c];
     double state = lane < P ? s.coords[(size_t)c * P + lane] : 0.;   // lane = parameter (context order)
     double new_lp = cur_lp;
@@ -115,27 +178,27 @@ __global__ __launch_bounds__(1024) void dl_mh_step_kernel(const DlMhArgs s) {
     }
     const double old_state = state;
     if (first >= 0 && lane < P) state = s.prop[((size_t)c * V + first) * P + lane];
-    __syncthreads();                                                    // every wavefront has read the pending proposals and the old state
-    if (wave == 0 && s.try_acc >= 0) {
+    if (v == 0) {
+        long long weight = s.weight[c], iter = s.naccepted[c];
+        int fails = s.fails[c];
         if (first >= 0) {
-            const long long iter = s.naccepted[c];
             if (iter > 0 && iter % s.thin_by == 0) {                    // the state that is left is recorded with its final weight; the start is skipped (mcmc.py:97-99)
                 const int slot = s.out_count[c];
                 if (slot < s.cap) {
                     if (lane < P) s.out_coords[((size_t)c * s.cap + slot) * P + lane] = old_state;
-                    if (lane == 0) { s.out_logp[(size_t)c * s.cap + slot] = cur_lp; s.out_weight[(size_t)c * s.cap + slot] = s.weight[c] + first; s.out_count[c] = slot + 1; }
+                    if (lane == 0) { s.out_logp[(size_t)c * s.cap + slot] = cur_lp; s.out_weight[(size_t)c * s.cap + slot] = weight + first; s.out_count[c] = slot + 1; }
                 }
             }
-            if (lane < P) s.coords[(size_t)c * P + lane] = state;
-            if (lane == 0) { s.logp[c] = new_lp; s.weight[c] = 1; s.naccepted[c] = iter + 1; s.fails[c] = 0; }
-        } else if (lane == 0) {
-            s.weight[c] += V;
-            s.fails[c] += 1;
+            weight = 1; iter += 1; fails = 0;
+        } else if (s.try_acc >= 0) {
+            weight += V; fails += 1;
         }
+        if (lane < P) s.coords_out[(size_t)c * P + lane] = state;
+        if (lane == 0) { s.logp_out[c] = new_lp; s.weight_out[c] = weight; s.naccepted_out[c] = iter; s.fails_out[c] = fails; }
     }
     if (s.try_prop < 0) return;
-    // ---- V new proposals from the (new) state: a wavefront per slot ---------------------------------------------------------------------------------------------
-    for (int v = wave; v < V; v += nwaves) {
+    // ---- the proposal of slot v from the (new) state -------------------------------------------------------------------------------------------------------------
+    {
         const uint64_t n = (uint64_t)s.try_prop * V + v;
         const uint64_t q = n / (uint64_t)s.n_rep;
         const uint32_t p = (uint32_t)(n % (uint64_t)s.n_rep);
@@ -153,7 +216,7 @@ __global__ __launch_bounds__(1024) void dl_mh_step_kernel(const DlMhArgs s) {
         const double radius = dl_mh_radial(n, chain, b, s.k0, s.k1, &sign);
         double y;
         if (b == 1) y = lane == 0 ? sign : 0.;                          // mcmc.py:165-166
-        else y = dl_mh_direction(lane, b, (int)(calls % (uint64_t)b), calls / (uint64_t)b, chain, ib, s.k0, s.k1);
+        else y = dl_mh_direction(lane, b, (int)(calls % (uint64_t)b), calls / (uint64_t)b, chain, ib, s.k0, s.k1, gauss[threadIdx.x >> 6]);
         y *= radius * s.scale;
         // jump of the sorted parameters start .. P - 1: L[start:, start : start + b] . y (mcmc.py:290-296, 315-327); lane i = sorted index start + i
         double delta = 0.;
@@ -163,7 +226,7 @@ __global__ __launch_bounds__(1024) void dl_mh_step_kernel(const DlMhArgs s) {
             if (i < P) delta += s.L[(size_t)i * P + start + jj] * yj;
         }
         // scatter into context order: sorted index i is parameter order[i]
-        double* row = s.prop + ((size_t)c * V + v) * P;
+        double* row = s.prop_out + ((size_t)c * V + v) * P;
         const int sorted = lane < P ? lane : 0;                         // (every lane takes part in the exchanges; the lanes beyond P write nothing)
         const int target = s.order[sorted];
         const double base = __shfl(state, target, 64);
@@ -179,7 +242,8 @@ extern "C" {
 void dl_mh_destroy(dl_mh* mh) {
     if (!mh) return;
     (void)hipSetDevice(mh->device);
-    for (void* p : {(void*)mh->coords, (void*)mh->logp, (void*)mh->prop, (void*)mh->newlp, (void*)mh->L, (void*)mh->weight, (void*)mh->naccepted, (void*)mh->fails,
+    for (void* p : {(void*)mh->coords[0], (void*)mh->coords[1], (void*)mh->logp[0], (void*)mh->logp[1], (void*)mh->prop[0], (void*)mh->prop[1], (void*)mh->newlp, (void*)mh->L,
+                    (void*)mh->weight[0], (void*)mh->weight[1], (void*)mh->naccepted[0], (void*)mh->naccepted[1], (void*)mh->fails[0], (void*)mh->fails[1],
                     (void*)mh->chain_ids, (void*)mh->order, (void*)mh->rep_block, (void*)mh->block_start, (void*)mh->block_reps})
         if (p) (void)hipFree(p);
     delete mh;
@@ -217,16 +281,19 @@ int dl_mh_create(dl_mh** out, dl_ctx* ctx, int32_t nchains, int32_t vectorize, c
     auto bail = [&](const std::string& msg) { dl_mh_destroy(mh); return fail(msg); };
     if (hipSetDevice(mh->device) != hipSuccess) return bail("dl_mh_create: hipSetDevice failed");
     const size_t C = nchains, V = vectorize;
-    bool ok = hipMalloc((void**)&mh->coords, C * P * sizeof(double)) == hipSuccess && hipMalloc((void**)&mh->logp, C * sizeof(double)) == hipSuccess &&
-              hipMalloc((void**)&mh->prop, C * V * P * sizeof(double)) == hipSuccess && hipMalloc((void**)&mh->newlp, C * V * sizeof(double)) == hipSuccess &&
-              hipMalloc((void**)&mh->L, (size_t)P * P * sizeof(double)) == hipSuccess && hipMalloc((void**)&mh->weight, C * sizeof(long long)) == hipSuccess &&
-              hipMalloc((void**)&mh->naccepted, C * sizeof(long long)) == hipSuccess && hipMalloc((void**)&mh->fails, C * sizeof(int32_t)) == hipSuccess &&
+    bool ok = true;
+    for (int d = 0; d < 2; ++d)
+        ok = ok && hipMalloc((void**)&mh->coords[d], C * P * sizeof(double)) == hipSuccess && hipMalloc((void**)&mh->logp[d], C * sizeof(double)) == hipSuccess &&
+             hipMalloc((void**)&mh->prop[d], C * V * P * sizeof(double)) == hipSuccess && hipMalloc((void**)&mh->weight[d], C * sizeof(long long)) == hipSuccess &&
+             hipMalloc((void**)&mh->naccepted[d], C * sizeof(long long)) == hipSuccess && hipMalloc((void**)&mh->fails[d], C * sizeof(int32_t)) == hipSuccess &&
+             hipMemset(mh->prop[d], 0, C * V * P * sizeof(double)) == hipSuccess && hipMemset(mh->naccepted[d], 0, C * sizeof(long long)) == hipSuccess &&
+             hipMemset(mh->fails[d], 0, C * sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&mh->newlp, C * V * sizeof(double)) == hipSuccess && hipMalloc((void**)&mh->L, (size_t)P * P * sizeof(double)) == hipSuccess &&
               hipMalloc((void**)&mh->chain_ids, C * sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&mh->order, (size_t)P * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void**)&mh->rep_block, rep_block.size() * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void**)&mh->block_start, start.size() * sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&mh->block_reps, reps.size() * sizeof(int32_t)) == hipSuccess;
     if (!ok) return bail("dl_mh_create: device allocation failed");
-    ok = hipMemset(mh->prop, 0, C * V * P * sizeof(double)) == hipSuccess && hipMemset(mh->newlp, 0, C * V * sizeof(double)) == hipSuccess &&
-         hipMemset(mh->naccepted, 0, C * sizeof(long long)) == hipSuccess && hipMemset(mh->fails, 0, C * sizeof(int32_t)) == hipSuccess &&
+    ok = hipMemset(mh->newlp, 0, C * V * sizeof(double)) == hipSuccess &&
          hipMemset(mh->L, 0, (size_t)P * P * sizeof(double)) == hipSuccess &&
          hipMemcpy(mh->chain_ids, ids.data(), C * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(mh->order, ord.data(), (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
@@ -266,11 +333,12 @@ int dl_mh_set_state(dl_mh* mh, const double* coords, const double* logposterior,
     std::vector<long long> w(C, 1), na(C, 0);
     if (weight) for (size_t c = 0; c < C; ++c) w[c] = weight[c];
     if (naccepted) for (size_t c = 0; c < C; ++c) na[c] = naccepted[c];
-    DL_MH_HIP(hipMemcpyAsync(mh->coords, coords, C * mh->P * sizeof(double), hipMemcpyHostToDevice, stream));
-    if (logposterior) DL_MH_HIP(hipMemcpyAsync(mh->logp, logposterior, C * sizeof(double), hipMemcpyHostToDevice, stream));
-    DL_MH_HIP(hipMemcpyAsync(mh->weight, w.data(), C * sizeof(long long), hipMemcpyHostToDevice, stream));
-    DL_MH_HIP(hipMemcpyAsync(mh->naccepted, na.data(), C * sizeof(long long), hipMemcpyHostToDevice, stream));
-    DL_MH_HIP(hipMemsetAsync(mh->fails, 0, C * sizeof(int32_t), stream));
+    const int d = mh->cur;
+    DL_MH_HIP(hipMemcpyAsync(mh->coords[d], coords, C * mh->P * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (logposterior) DL_MH_HIP(hipMemcpyAsync(mh->logp[d], logposterior, C * sizeof(double), hipMemcpyHostToDevice, stream));
+    DL_MH_HIP(hipMemcpyAsync(mh->weight[d], w.data(), C * sizeof(long long), hipMemcpyHostToDevice, stream));
+    DL_MH_HIP(hipMemcpyAsync(mh->naccepted[d], na.data(), C * sizeof(long long), hipMemcpyHostToDevice, stream));
+    DL_MH_HIP(hipMemsetAsync(mh->fails[d], 0, C * sizeof(int32_t), stream));
     DL_MH_HIP(hipStreamSynchronize(stream));
     mh->have_logp = logposterior != nullptr;
     mh->tries = tries;
@@ -287,15 +355,15 @@ int dl_mh_run(dl_mh* mh, int64_t ntries, int32_t thin_by, double* out_coords_dev
     DL_MH_HIP(hipSetDevice(mh->device));
     const int C = mh->C, V = mh->V, P = mh->P;
     if (!mh->have_logp) {
-        if (dl_eval_logposterior(mh->ctx, mh->coords, C, mh->logp, nullptr, stream)) return 1;
+        if (dl_eval_logposterior(mh->ctx, mh->coords[mh->cur], C, mh->logp[mh->cur], nullptr, stream)) return 1;
         std::vector<double> tmp(C);
-        DL_MH_HIP(hipMemcpyAsync(tmp.data(), mh->logp, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, stream));
+        DL_MH_HIP(hipMemcpyAsync(tmp.data(), mh->logp[mh->cur], (size_t)C * sizeof(double), hipMemcpyDeviceToHost, stream));
         DL_MH_HIP(hipStreamSynchronize(stream));
         for (double& v : tmp) {
             v = (v != v ? -__builtin_huge_val() : v) + mh->offset;
             if (!(v > -__builtin_huge_val())) return fail("dl_mh_run: the log-posterior of a starting position is not finite");
         }
-        DL_MH_HIP(hipMemcpyAsync(mh->logp, tmp.data(), (size_t)C * sizeof(double), hipMemcpyHostToDevice, stream));
+        DL_MH_HIP(hipMemcpyAsync(mh->logp[mh->cur], tmp.data(), (size_t)C * sizeof(double), hipMemcpyHostToDevice, stream));
         DL_MH_HIP(hipStreamSynchronize(stream));
         mh->have_logp = true;
     }
@@ -303,22 +371,30 @@ int dl_mh_run(dl_mh* mh, int64_t ntries, int32_t thin_by, double* out_coords_dev
     DL_MH_HIP(hipMemsetAsync(out_count_dev, 0, (size_t)C * sizeof(int32_t), stream));
     DlMhArgs s;
     std::memset(&s, 0, sizeof(s));
-    s.coords = mh->coords; s.logp = mh->logp; s.prop = mh->prop; s.newlp = mh->newlp; s.L = mh->L; s.weight = mh->weight; s.naccepted = mh->naccepted; s.fails = mh->fails;
+    s.newlp = mh->newlp; s.L = mh->L;
     s.chain_ids = mh->chain_ids; s.order = mh->order; s.rep_block = mh->rep_block; s.block_start = mh->block_start; s.block_reps = mh->block_reps;
     s.out_coords = out_coords_dev; s.out_logp = out_logp_dev; s.out_weight = reinterpret_cast<long long*>(out_weight_dev); s.out_count = out_count_dev;
     s.C = C; s.V = V; s.P = P; s.n_rep = mh->n_rep; s.cap = (int32_t)ntries; s.thin_by = thin_by;
     s.scale = mh->scale; s.offset = mh->offset; s.k0 = (uint32_t)mh->seed; s.k1 = (uint32_t)(mh->seed >> 32);
     s.max_tries = mh->max_tries;
-    const unsigned threads = 64u * (unsigned)std::min(V, 16);
+    const unsigned grid = (unsigned)(((long long)C * V + DL_MH_WAVES - 1) / DL_MH_WAVES);
+    auto launch = [&]() {   // reads the current copy of the state and the pending proposals, writes the other copies
+        const int d = mh->cur, e = mh->cur_prop;
+        s.coords = mh->coords[d]; s.logp = mh->logp[d]; s.weight = mh->weight[d]; s.naccepted = mh->naccepted[d]; s.fails = mh->fails[d]; s.prop = mh->prop[e];
+        s.coords_out = mh->coords[1 - d]; s.logp_out = mh->logp[1 - d]; s.weight_out = mh->weight[1 - d]; s.naccepted_out = mh->naccepted[1 - d]; s.fails_out = mh->fails[1 - d];
+        s.prop_out = mh->prop[1 - e];
+        hipLaunchKernelGGL(dl_mh_step_kernel, dim3(grid), dim3(64 * DL_MH_WAVES), 0, stream, s);
+        mh->cur = 1 - d; mh->cur_prop = 1 - e;
+    };
     s.try_acc = -1;
     for (int64_t t = mh->tries; t < mh->tries + ntries; ++t) {
         s.try_prop = t;
-        hipLaunchKernelGGL(dl_mh_step_kernel, dim3(C), dim3(threads), 0, stream, s);
-        if (dl_eval_logposterior(mh->ctx, mh->prop, (int64_t)C * V, mh->newlp, nullptr, stream)) return 1;
+        launch();
+        if (dl_eval_logposterior(mh->ctx, mh->prop[mh->cur_prop], (int64_t)C * V, mh->newlp, nullptr, stream)) return 1;
         s.try_acc = t;
     }
     s.try_prop = -1;
-    hipLaunchKernelGGL(dl_mh_step_kernel, dim3(C), dim3(64), 0, stream, s);
+    launch();
     DL_MH_HIP(hipGetLastError());
     mh->tries += ntries;
     return 0;
@@ -329,11 +405,12 @@ int dl_mh_get_state(dl_mh* mh, double* coords, double* logposterior, int64_t* we
     hipStream_t stream = (hipStream_t)hip_stream;
     DL_MH_HIP(hipSetDevice(mh->device));
     const size_t C = mh->C;
-    if (coords) DL_MH_HIP(hipMemcpyAsync(coords, mh->coords, C * mh->P * sizeof(double), hipMemcpyDeviceToHost, stream));
-    if (logposterior) DL_MH_HIP(hipMemcpyAsync(logposterior, mh->logp, C * sizeof(double), hipMemcpyDeviceToHost, stream));
-    if (weight) DL_MH_HIP(hipMemcpyAsync(weight, mh->weight, C * sizeof(long long), hipMemcpyDeviceToHost, stream));
-    if (naccepted) DL_MH_HIP(hipMemcpyAsync(naccepted, mh->naccepted, C * sizeof(long long), hipMemcpyDeviceToHost, stream));
-    if (fails) DL_MH_HIP(hipMemcpyAsync(fails, mh->fails, C * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    const int d = mh->cur;
+    if (coords) DL_MH_HIP(hipMemcpyAsync(coords, mh->coords[d], C * mh->P * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (logposterior) DL_MH_HIP(hipMemcpyAsync(logposterior, mh->logp[d], C * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (weight) DL_MH_HIP(hipMemcpyAsync(weight, mh->weight[d], C * sizeof(long long), hipMemcpyDeviceToHost, stream));
+    if (naccepted) DL_MH_HIP(hipMemcpyAsync(naccepted, mh->naccepted[d], C * sizeof(long long), hipMemcpyDeviceToHost, stream));
+    if (fails) DL_MH_HIP(hipMemcpyAsync(fails, mh->fails[d], C * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     DL_MH_HIP(hipStreamSynchronize(stream));
     return 0;
 }

@@ -13,10 +13,11 @@ def _flat(chain):
     return chain.reshape(-1, chain.shape[-1])
 
 
-def gelman_rubin(chains, method='eigen', check_valid='raise'):
+def gelman_rubin(chains, method='eigen', check_valid='raise', weights=None):
     """Gelman-Rubin statistics (Brooks & Gelman 1998) of two or more chains: covariance of the chain means ("between") against the mean of the chains' covariances
     ("within") -- samples/diagnostics.py:13-107.  ``method='eigen'``: eigenvalues of ``W^-1 V`` (after scaling by the standard deviations), else the diagonal ratio.
-    Returns an array of size ndim (ascending eigenvalues for 'eigen')."""
+    Returns an array of size ndim (ascending eigenvalues for 'eigen').  ``weights``: per chain the integer multiplicities of its samples (Metropolis-Hastings chains;
+    the reference's frequency weights, diagnostics.py:78-84: means and covariances are weighted, the chains count by their summed weights)."""
     chains = [_flat(chain) for chain in chains]
     nchains = len(chains)
     if nchains < 2:
@@ -24,8 +25,14 @@ def gelman_rubin(chains, method='eigen', check_valid='raise'):
     sizes = np.array([chain.shape[0] for chain in chains], dtype='f8')
     if (sizes < 2).any():
         raise ValueError('Not enough samples ({}) to estimate Gelman-Rubin'.format(sizes))
-    means = np.array([chain.mean(axis=0) for chain in chains])
-    covs = np.array([np.atleast_2d(np.cov(chain, rowvar=False, ddof=1)) for chain in chains])
+    if weights is None:
+        means = np.array([chain.mean(axis=0) for chain in chains])
+        covs = np.array([np.atleast_2d(np.cov(chain, rowvar=False, ddof=1)) for chain in chains])
+    else:
+        weights = [np.asarray(weight, dtype='i8').ravel() for weight in weights]
+        means = np.array([np.average(chain, weights=weight, axis=0) for chain, weight in zip(chains, weights)])
+        covs = np.array([np.atleast_2d(np.cov(chain, rowvar=False, fweights=weight, ddof=1)) for chain, weight in zip(chains, weights)])
+        sizes = np.array([weight.sum() for weight in weights], dtype='f8')      # wsum = w2sum for frequency weights
     # unit weights: wsum = w2sum = size (diagnostics.py:80-84)
     Wn1 = np.average(covs, weights=sizes, axis=0)
     Wn = np.average(((sizes - 1.) / sizes)[:, None, None] * covs, weights=sizes, axis=0)
@@ -78,18 +85,24 @@ def integrated_autocorrelation_time(series, c=5.):
     return taus[window]
 
 
-def geweke(chains, first=0.1, last=0.5):
+def geweke(chains, first=0.1, last=0.5, weights=None):
     """Geweke statistics: difference of the means of the first ``first`` and the last ``1 - last`` fractions of each chain over the root of the summed variances
     (diagnostics.py:306-343); returns ``[ndim, nchains]``."""
     out = []
-    for chain in chains:
+    for ichain, chain in enumerate(chains):
         chain = _flat(chain)
         size = chain.shape[0]
         ifirst, ilast = int(first * size + 0.5), int(last * size + 0.5)
         head, tail = chain[:ifirst], chain[ilast:]
         if head.shape[0] < 2 or tail.shape[0] < 2:
             raise ValueError('Not enough samples ({:d}) to estimate geweke'.format(size))
-        out.append(np.abs(head.mean(axis=0) - tail.mean(axis=0)) / (head.var(axis=0, ddof=1) + tail.var(axis=0, ddof=1))**0.5)
+        if weights is None:
+            out.append(np.abs(head.mean(axis=0) - tail.mean(axis=0)) / (head.var(axis=0, ddof=1) + tail.var(axis=0, ddof=1))**0.5)
+        else:   # frequency weights (diagnostics.py:330-339)
+            weight = np.asarray(weights[ichain], dtype='i8').ravel()
+            whead, wtail = weight[:ifirst], weight[ilast:]
+            var = [np.diag(np.atleast_2d(np.cov(part, rowvar=False, fweights=w, ddof=1))) for part, w in ((head, whead), (tail, wtail))]
+            out.append(np.abs(np.average(head, weights=whead, axis=0) - np.average(tail, weights=wtail, axis=0)) / (var[0] + var[1])**0.5)
     return np.array(out).T
 
 

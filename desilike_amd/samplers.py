@@ -978,3 +978,11 @@ class QMCSampler(_BatchEvaluator):
         if self.save_fn is not None:
             np.savez(self.save_fn, **self.samples)
         return self.samples
+
+
+def __getattr__(name):
+    # the blocked Metropolis-Hastings sampler lives in its own module (which imports this one)
+    if name in ('MCMCSampler', 'MHDraws'):
+        from . import mcmc
+        return getattr(mcmc, name)
+    raise AttributeError('module {!r} has no attribute {!r}'.format(__name__, name))

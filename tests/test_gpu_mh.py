@@ -125,3 +125,46 @@ def test_device_state_round_trip_and_errors():
     bad = start[:2].copy(); bad[0, 1] = 1e3                      # outside the prior: no finite starting log-posterior
     d.set_state(bad)
     with pytest.raises(LibraryError): d.run(5)
+
+
+def test_sampler_on_the_device_equals_the_host_driver():
+    """MCMCSampler: the device-resident chains (dl_mh_*) and the host driver (NumPy proposals around the same GPU likelihood) give the same chains from the same seed."""
+    from desilike_amd.samplers import MCMCSampler
+    g, like = make_cfg5()
+    names = like.varied_params.names()
+    blocks = [[1, names[:5]], [2, names[5:]]]
+    like2 = make_cfg5()[1]
+    _, _, _, cov, start = _setup(3)
+    kw = dict(blocks=blocks, chains=3, vectorize=4, seed=3, learn=False, covariance=cov)
+    dev, host = MCMCSampler(like, **kw), MCMCSampler(like2, device_resident=False, **kw)
+    assert dev.device_resident and not host.device_resident and dev.counter_seed == host.counter_seed
+    cd = dev.run(check_every=30, max_iterations=60, start=start)
+    ch = host.run(check_every=30, max_iterations=60, start=start)
+    for a, b in zip(cd, ch):
+        assert a['fweight'].size > 5 and np.array_equal(a['fweight'], b['fweight'])
+        for name in names: assert np.allclose(a[name], b[name], rtol=1e-11, atol=1e-13)
+        assert np.allclose(a['logposterior'], b['logposterior'], rtol=1e-10, atol=1e-9)
+
+
+def test_sampler_learns_and_converges_on_the_device(tmp_path):
+    from desilike_amd.samplers import MCMCSampler, EmceeSampler
+    g, like = make_cfg5()
+    names = like.varied_params.names()
+    sampler = MCMCSampler(like, chains=8, seed=1, save_fn=str(tmp_path / 'mh_*.npy'))
+    assert sampler.device_resident and sampler.vectorize == 32
+    chains = sampler.run(check_every=300, min_iterations=600, max_iterations=3000, check={'max_eigen_gr': 0.05, 'stable_over': 1})
+    assert sampler.diagnostics['eigen_gr'][-1] < 0.3
+    rate = sampler.acceptance_rate
+    assert np.all(rate > 0.02) and np.all(rate < 0.9)
+    x = np.concatenate([np.column_stack([chain[name] for name in names])[chain['fweight'].size // 2:] for chain in chains])
+    w = np.concatenate([chain['fweight'][chain['fweight'].size // 2:] for chain in chains])
+    mean = np.average(x, weights=w, axis=0)
+    std = np.sqrt(np.average((x - mean)**2, weights=w, axis=0))
+    # the same posterior through the ensemble sampler
+    ens = EmceeSampler(make_cfg5()[1], nwalkers=64, seed=2)
+    chain = ens.run(niterations=1500)
+    y = np.column_stack([chain[name][500:].ravel() for name in names])
+    assert np.all(np.abs(mean - y.mean(axis=0)) < 0.35 * y.std(axis=0)), (mean, y.mean(axis=0), y.std(axis=0))
+    assert np.allclose(std, y.std(axis=0), rtol=0.35)
+    assert all(np.isfinite(chain['logposterior']).all() for chain in chains)
+    assert (tmp_path / 'mh_0.npy').exists()
