@@ -557,6 +557,41 @@ def chains_weak(group, local_rank, rank, world, chains_per_gpu=(1, 2, 4), iterat
             'exchange': 'none inside the run; one all-gather of the chains at the end' if world > 1 else 'none (single rank)'}
 
 
+def mh_chains(local_rank, configs=((256, 1), (256, 4)), tries=300):
+    """The reference's own Metropolis-Hastings sampler (desilike/samplers/mcmc.py) THROUGH THE SAMPLER on the two-tracer likelihood: C chains x V speculative proposals per
+    try are one batch, device-resident (dl_mh_*).  Single rank, no collective.  Every chain's current state is checked against the oracle."""
+    import torch
+    from desilike_amd.samplers import MCMCSampler
+    from desilike_amd.parallel import WalkerSharding
+    likelihood = make_likelihood_config5(local_rank)
+    device = torch.device('cuda', local_rank)
+    names = likelihood.varied_params.names()
+    out = []
+    for C, V in configs:
+        sampler = MCMCSampler(likelihood, chains=C, vectorize=V, seed=42, sharding=WalkerSharding(group=False))
+        sampler.run(check_every=tries, max_iterations=3 * tries)  # warm-up: burn-in from the reference distributions, the proposal covariance learnt from the chains twice
+        sampler.learn = False                                      # (timed: the sampling itself)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        sampler.run(check_every=tries, max_iterations=tries)
+        torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t0
+        coords = np.array([state[0] for state in sampler._state])[::max(1, C // 32)]
+        logp = np.array([state[1] for state in sampler._state])[::max(1, C // 32)]
+        ref = oracle_logposterior(likelihood, coords)
+        worst = float((np.abs(logp - ref) / np.maximum(1., np.abs(ref))).max())
+        assert worst <= 1e-10, 'GPU / oracle mismatch on the Metropolis-Hastings chains: {:.3e}'.format(worst)
+        naccepted = int(sum(state[3] for state in sampler._state))
+        out.append({'chains': C, 'vectorize': V, 'rows_per_try': C * V, 'value': C * V * tries / elapsed, 'unit': 'evals/s', 'us_per_try': 1e6 * elapsed / tries,
+                    'accepted_moves_per_s': sum(len(chain['fweight']) for chain in sampler.chains) / elapsed if all(chain is not None for chain in sampler.chains) else None,
+                    'mean_acceptance_rate': float(np.nanmean(sampler.acceptance_rate)), 'accepted_moves_total': naccepted,
+                    'includes': 'enqueue, device run, drain of the recorded states to the host', 'oracle_check': {'points': int(len(ref)), 'max_rel_err_vs_oracle': worst, 'tolerance': 1e-10}})
+        sampler._runner.close()
+    best = max(out, key=lambda entry: entry['value'])
+    return {'workload': 'MCMCSampler (blocked Metropolis-Hastings, desilike/samplers/mcmc.py) on two config-2 tracers (n = 240, 8 parameters): chains x speculative proposals in one batch, '
+                        'device-resident, {:d} tries'.format(tries), 'n_gpus': 1, 'value': best['value'], 'unit': 'evals/s', 'per_config': out}
+
+
 def dry_run(rank, world):
     """Everything of the N-rank launch path that does not need a GPU: ranks started, host-side group formed, one exchange, rank 0 prints the line skeleton."""
     from desilike_amd import parallel
@@ -723,6 +758,7 @@ def main():
     streams = guarded('streams', lambda: streams_leg(likelihood, device, B)) if (not args.no_streams and not distributed and B == BATCH) else None
     others = guarded('other_configs', lambda: other_configs(device)) if (not args.no_other_configs and rank == 0 and B == BATCH) else None
     chains = chains_weak(group if (distributed and world > 1) else None, local_rank, rank, world, iterations=args.chains_iterations) if (args.chains_iterations > 0 and B == BATCH) else None
+    mh = guarded('mh_chains', lambda: mh_chains(local_rank)) if (args.chains_iterations > 0 and rank == 0 and B == BATCH) else None
     strong = None
     if args.config5_iterations > 0 and B == BATCH:
         strong = config5_strong(group, device, local_rank, rank, world, args.config5_iterations)
@@ -758,6 +794,7 @@ def main():
         if streams is not None: result['streams'] = streams
         if others is not None: result['other_configs'] = others
         if chains is not None: result['chains_weak'] = chains
+        if mh is not None: result['mh_chains'] = mh
         if strong is not None:
             result['config5_strong'] = strong
         if world == 1 and not distributed and not args.no_cpu_baseline:   # (the forced single-rank RCCL smoke mode writes log-posteriors into buckets, not `loglike`)
