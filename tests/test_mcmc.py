@@ -66,6 +66,16 @@ def test_weighted_diagnostics_equal_the_expanded_chains():
     assert np.allclose(gw[:, 0], expected, rtol=1e-12)
 
 
+def test_weighted_diagnostics_against_the_reference():
+    """Gelman-Rubin / Geweke with frequency weights against the reference's own functions on chains of this sampler (tests/golden/validate_mh_chain.py)."""
+    from desilike_amd import diagnostics as diag
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mh_weighted_diagnostics.npz')))
+    x, w = [np.column_stack([g['a0'], g['b0']]), np.column_stack([g['a1'], g['b1']])], [g['w0'], g['w1']]
+    assert np.allclose(diag.gelman_rubin(x, method='eigen', weights=w), g['eigen_gr'], rtol=1e-10)
+    assert np.allclose(diag.gelman_rubin(x, method='diag', weights=w), g['diag_gr'], rtol=1e-10)
+    assert np.allclose(diag.geweke(x, weights=w), g['geweke'], rtol=1e-10)
+
+
 def test_sampler_recovers_the_toy_posterior(tmp_path):
     from desilike_amd.samplers import MCMCSampler
     like = ToyGaussianLikelihood()
