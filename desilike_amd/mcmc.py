@@ -193,7 +193,7 @@ class _DeviceMH(object):
         count = count.cpu().numpy()                                                          # the one synchronisation of the batch
         nmax = int(count.max()) if count.size else 0
         coords, logp, weight = coords[:, :nmax].cpu().numpy(), logp[:, :nmax].cpu().numpy(), weight[:, :nmax].cpu().numpy()
-        return [(coords[c, :count[c]].copy(), logp[c, :count[c]].copy(), weight[c, :count[c]].copy()) for c in range(self.nchains)]
+        return [(coords[c, :count[c]], logp[c, :count[c]], weight[c, :count[c]]) for c in range(self.nchains)]      # views of the batch's host copy
 
     def get_state(self):
         return self.mh.get_state()
@@ -204,6 +204,24 @@ class _DeviceMH(object):
 
     def close(self):
         self.mh.close()
+
+
+class _WeightedStore(object):
+    """Recorded states of one chain, growing by batches: ``store[0]`` coords [n, ndim], ``store[1]`` log-posteriors [n], ``store[2]`` multiplicities [n].  A batch is
+    appended as it comes (no copy of what is there); the pieces are joined when the arrays are asked for."""
+
+    def __init__(self, coords, logp, weight):
+        self._pieces, self._joined = [(np.asarray(coords, dtype='f8'), np.asarray(logp, dtype='f8'), np.asarray(weight, dtype='i8'))], None
+
+    def append(self, coords, logp, weight):
+        if self._joined is not None: self._pieces, self._joined = [self._joined], None
+        self._pieces.append((coords, logp, np.asarray(weight, dtype='i8')))
+
+    def __getitem__(self, index):
+        if self._joined is None:
+            self._joined = self._pieces[0] if len(self._pieces) == 1 else tuple(np.concatenate([piece[i] for piece in self._pieces]) for i in range(3))
+            self._pieces = [self._joined]
+        return self._joined[index]
 
 
 def _format_blocks(blocks, names):
@@ -438,8 +456,8 @@ class MCMCSampler(BasePosteriorSampler):
             x, lp, w, state = new[ichain]
             self._state[ichain] = (np.array(state[0]), float(state[1]), int(state[2]), int(state[3]))
             if x.shape[0]:
-                if self._store[ichain] is None: self._store[ichain] = [x, lp, w.astype('i8')]
-                else: self._store[ichain] = [np.concatenate([old, add]) for old, add in zip(self._store[ichain], (x, lp, w.astype('i8')))]
+                if self._store[ichain] is None: self._store[ichain] = _WeightedStore(x, lp, w)
+                else: self._store[ichain].append(x, lp, w)
         self.diagnostics['naccepted'] = [int(self._state[ichain][3]) for ichain in range(self.nchains)]
 
     def _gather(self, new, ntries, ndim):
@@ -550,7 +568,7 @@ class MCMCSampler(BasePosteriorSampler):
         coords = np.stack([np.asarray(chain.arrays[name], dtype='f8').ravel() for name in names], axis=-1)
         logp = np.asarray(chain.arrays['logposterior'], dtype='f8').ravel()
         weight = np.asarray(chain.arrays['fweight'], dtype='i8').ravel() if 'fweight' in chain.arrays else np.ones(logp.size, dtype='i8')
-        self._store[ichain] = [coords, logp, weight]
+        self._store[ichain] = _WeightedStore(coords, logp, weight)
         attrs = chain.attrs
         state = attrs.get('state', None)
         if state is not None and attrs.get('sampler', None) == self.name:
