@@ -637,7 +637,7 @@ int dl_eval_fisher(dl_ctx* ctx, const double* centers_dev, const double* steps_d
     if (ctx->n_solved > 0) return dl_fail(ctx, "dl_eval_fisher: the context has analytically solved parameters: create it with these parameters varied (the reference does the same, fisher.py:688-695)");
     const int P = ctx->n_params, n = ctx->n_data, S = 1 + 2 * P;
     if (P > 31) return dl_fail(ctx, "dl_eval_fisher: at most 31 varied parameters");
-    if (dl_fisher_waves(ctx->n_white, P, nullptr) < 1) return dl_fail(ctx, "dl_eval_fisher: data vector too long for the LDS-resident Gram product");
+    if (dl_fisher_waves(ctx->n_white, P, nullptr, nullptr) < 1) return dl_fail(ctx, "dl_eval_fisher: too many parameters for the LDS-resident Gram product");
     if (B == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
     dl_prof_events.start = dl_prof_events.stop = nullptr;

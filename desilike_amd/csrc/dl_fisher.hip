@@ -37,18 +37,28 @@ void dl_launch_fisher_stencil(const double* centers, const double* steps, int P,
 // TILES = ceil((P + 1) / 16): 16 x 16 tiles of the Gram matrix per side (1 or 2).  One wavefront per centre, WAVES of them per workgroup.
 template <int TILES>
 __global__ __launch_bounds__(256) void dl_fisher_kernel(const double* __restrict__ rows, int64_t ld, int n, int n_slabs, int64_t slab_stride, const double* __restrict__ bias,
-                                                        const double* __restrict__ steps, int P, int64_t B, int waves, double* __restrict__ hessian,
+                                                        const double* __restrict__ steps, int P, int64_t B, int waves, int chunk, double* __restrict__ hessian,
                                                         double* __restrict__ gradient, double* __restrict__ offset) {
     extern __shared__ __attribute__((aligned(16))) double dl_fi_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b = (int64_t)blockIdx.x * waves + wave;
     if (wave >= waves || b >= B) return;
     const int S = 1 + 2 * P, nrows = 1 + P;
-    const int n_ks = (n + 3) / 4, n4 = 4 * n_ks, stride = n4 + 4;   // (+4 doubles: rows of an operand read 16 apart fall on different LDS banks)
+    // the rows are staged `chunk` columns at a time (a multiple of 4; the whole row when it fits: short data vectors), the Gram tiles accumulate over the chunks
+    const int n4 = 4 * ((n + 3) / 4), stride = chunk + 4;   // (+4 doubles: rows of an operand read 16 apart fall on different LDS banks)
     double* X = dl_fi_lds + (size_t)wave * (TILES * 16) * stride;
     const double* row0 = rows + (size_t)b * S * ld;
+    const int xr = lane & 15, g = lane >> 4;
+    dl_fi_double4 acc[TILES][TILES];
+#pragma unroll
+    for (int i = 0; i < TILES; ++i)
+#pragma unroll
+        for (int j = 0; j < TILES; ++j) acc[i][j] = dl_fi_double4{0., 0., 0., 0.};
+    for (int base = 0; base < n4; base += chunk) {
+    const int width = n4 - base < chunk ? n4 - base : chunk;
     // stage X: coalesced 16-byte loads of the stencil rows (all slabs), differences formed on the way in
-    for (int c0 = 2 * lane; c0 < n4; c0 += 128) {
+    for (int cc = 2 * lane; cc < width; cc += 128) {
+        const int c0 = base + cc;
         for (int r = 0; r < TILES * 16; ++r) {
             dl_fi_double2 v = {0., 0.};
             if (r == 0) {
@@ -68,19 +78,13 @@ __global__ __launch_bounds__(256) void dl_fisher_kernel(const double* __restrict
             }
             if (c0 >= n) v.x = 0.;
             if (c0 + 1 >= n) v.y = 0.;
-            *reinterpret_cast<dl_fi_double2*>(X + (size_t)r * stride + c0) = v;
+            *reinterpret_cast<dl_fi_double2*>(X + (size_t)r * stride + cc) = v;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // Gram matrix with v_mfma_f64_16x16x4_f64: operand of tile t, lane l = X[16 t + (l & 15)][4 k + (l >> 4)] (A and B operands of a diagonal tile are one register)
-    const int xr = lane & 15, g = lane >> 4;
-    dl_fi_double4 acc[TILES][TILES];
-#pragma unroll
-    for (int i = 0; i < TILES; ++i)
-#pragma unroll
-        for (int j = 0; j < TILES; ++j) acc[i][j] = dl_fi_double4{0., 0., 0., 0.};
-    for (int k = 0; k < n_ks; ++k) {
+    for (int k = 0; k < width / 4; ++k) {
         double x[TILES];
 #pragma unroll
         for (int t = 0; t < TILES; ++t) x[t] = X[(size_t)(16 * t + xr) * stride + 4 * k + g];
@@ -88,6 +92,9 @@ __global__ __launch_bounds__(256) void dl_fisher_kernel(const double* __restrict
         for (int i = 0; i < TILES; ++i)
 #pragma unroll
             for (int j = i; j < TILES; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[i], x[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                        // the chunk has been read: the next one may overwrite it
     }
     // C layout: register r of lane l = G[16 i + (l >> 4) + 4 r][16 j + (l & 15)]
 #pragma unroll
@@ -109,22 +116,31 @@ __global__ __launch_bounds__(256) void dl_fisher_kernel(const double* __restrict
             }
 }
 
-int dl_fisher_waves(int n, int P, size_t* shm_bytes) {
-    const int tiles = (P + 1 + 15) / 16;
-    const size_t per_wave = (size_t)tiles * 16 * (4 * ((n + 3) / 4) + 4) * sizeof(double);
-    int waves = (int)std::min<size_t>(4, (150 * 1024) / std::max<size_t>(per_wave, 1));
-    if (shm_bytes) *shm_bytes = per_wave * std::max(waves, 1);
-    return waves;   // 0: the rows of one centre do not fit the LDS
+// waves per workgroup and columns staged at a time: a whole row per wavefront when four (or fewer) of them fit the LDS, else four wavefronts with the largest
+// chunk of columns that fits (long data vectors: P(k, mu) grids of forecasts)
+int dl_fisher_waves(int n, int P, size_t* shm_bytes, int* chunk_out) {
+    const int tiles = (P + 1 + 15) / 16, n4 = 4 * ((n + 3) / 4);
+    const size_t budget = 150 * 1024, row_bytes = (size_t)tiles * 16 * sizeof(double);
+    int waves = (int)std::min<size_t>(4, budget / (row_bytes * (size_t)(n4 + 4))), chunk = n4;
+    if (waves < 1) {
+        waves = 4;
+        chunk = (int)(budget / waves / row_bytes) - 4;
+        chunk = chunk / 4 * 4;
+    }
+    if (chunk_out) *chunk_out = chunk;
+    if (shm_bytes) *shm_bytes = row_bytes * (size_t)(chunk + 4) * waves;
+    return chunk >= 4 ? waves : 0;
 }
 
 void dl_launch_fisher(const double* rows, int64_t ld, int n, int n_slabs, int64_t slab_stride, const double* bias, const double* steps, int P, int64_t B, double* hessian,
                       double* gradient, double* offset, hipStream_t stream) {
     size_t shm = 0;
-    const int waves = dl_fisher_waves(n, P, &shm);
+    int chunk = 0;
+    const int waves = dl_fisher_waves(n, P, &shm, &chunk);
     const unsigned grid = (unsigned)((B + waves - 1) / waves);
     auto launch = [&](auto kernel) {
         if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        DL_LAUNCH(kernel, dim3(grid), dim3(64 * waves), shm, stream, rows, ld, n, n_slabs, slab_stride, bias, steps, P, B, waves, hessian, gradient, offset);
+        DL_LAUNCH(kernel, dim3(grid), dim3(64 * waves), shm, stream, rows, ld, n, n_slabs, slab_stride, bias, steps, P, B, waves, chunk, hessian, gradient, offset);
     };
     if (P + 1 <= 16) launch(dl_fisher_kernel<1>);
     else launch(dl_fisher_kernel<2>);

@@ -79,7 +79,7 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
                                      double* gram, hipStream_t stream);
 // Fisher algebra (dl_fisher.hip): stencil rows of theta, then per centre the Gram matrix of [residual; derivative rows]
 void dl_launch_fisher_stencil(const double* centers, const double* steps, int P, int64_t B, double* theta, hipStream_t stream);
-int dl_fisher_waves(int n, int P, size_t* shm_bytes);   // centres per workgroup (0: too large for the LDS)
+int dl_fisher_waves(int n, int P, size_t* shm_bytes, int* chunk);   // centres per workgroup and columns staged at a time (0: no chunk fits the LDS)
 void dl_launch_fisher(const double* rows, int64_t ld, int n, int n_slabs, int64_t slab_stride, const double* bias, const double* steps, int P, int64_t B, double* hessian,
                       double* gradient, double* offset, hipStream_t stream);
 // Internal (dl_api.hip -> dl_ensemble.hip): theory + chi2 GEMM of B <= 2048 points of a plain likelihood, WITHOUT the finalize launch: *part = partial chi2
