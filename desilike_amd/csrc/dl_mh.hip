@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "../../include/desilike_amd.h"
 #include "dl_kernels.h"
 #include "dl_mh.h"
+#include "dl_finalize_part.h"
 
 struct dl_mh {
     dl_ctx* ctx = nullptr;
@@ -28,6 +30,7 @@ struct dl_mh {
     uint64_t seed = 0;
     int64_t max_tries = 1000, tries = 0;
     bool have_logp = false, have_cov = false;
+    bool deferred = true;    // the Metropolis scan finishes the proposals from the chi2 GEMM's partial sums (until the context declines: dl_internal_eval_partials)
     // device
     // the state (positions, log-posteriors, weights, counters) and the proposals exist twice: a launch reads one copy and writes the other, so that the wavefronts
     // of a chain (one per proposal slot, spread over the chip) need no barrier between the Metropolis scan and the new proposals
@@ -54,6 +57,8 @@ struct DlMhArgs {
     const double *coords, *logp, *prop;  // state before this launch, pending proposals
     double *coords_out, *logp_out, *prop_out;
     const double *newlp, *L;
+    const double *part, *priors;         // deferred finalize (plain likelihoods on the chi2-GEMM path): partial chi2 [C V, n_tiles] of the pending proposals straight from
+    int32_t n_tiles, pad_;               // the chi2 GEMM, prior table [P, 5] -- the scan sums them and applies the status rules itself (no finalize launch); else null
     const long long *weight, *naccepted;
     long long *weight_out, *naccepted_out;
     const int32_t* fails;
@@ -165,7 +170,14 @@ __global__ __launch_bounds__(64 * DL_MH_WAVES) void dl_mh_step_kernel(const DlMh
         bool acc = false;
         double lp = 0.;
         if (lane < V) {
-            lp = s.newlp[(size_t)c * V + lane];
+            if (s.part != nullptr) {
+                const double* row = s.prop + ((size_t)c * V + lane) * P;
+                double ll, lpr, x0[8];
+                int st;
+                dl_load_theta8(row, P, 0, x0);
+                dl_finalize_from_chi2<2>(dl_chi2_of_parts(s.part + ((size_t)c * V + lane) * s.n_tiles, s.n_tiles), x0, row, P, s.priors, ll, lpr, st);
+                lp = st == 0 ? ll + lpr : -__builtin_huge_val();
+            } else lp = s.newlp[(size_t)c * V + lane];
             lp = (lp != lp ? -__builtin_huge_val() : lp) + s.offset;                                    // samplers/base.py:187-189
             const double e = dl_mh_accept_exp((uint64_t)s.try_acc * V + lane, chain, s.k0, s.k1);
             acc = lp > -__builtin_huge_val() && (lp > cur_lp || e > cur_lp - lp);                       // mcmc.py:107-112
@@ -278,6 +290,7 @@ int dl_mh_create(dl_mh** out, dl_ctx* ctx, int32_t nchains, int32_t vectorize, c
     dl_mh* mh = new dl_mh();
     mh->ctx = ctx; mh->device = (int)dl_info(ctx, "device"); mh->C = nchains; mh->V = vectorize; mh->P = P; mh->nblocks = nblocks; mh->n_rep = (int)rep_block.size();
     mh->scale = proposal_scale; mh->seed = seed; mh->offset = offset; mh->max_tries = max_tries;
+    mh->deferred = getenv("DL_MH_NO_DEFER") == nullptr;
     auto bail = [&](const std::string& msg) { dl_mh_destroy(mh); return fail(msg); };
     if (hipSetDevice(mh->device) != hipSuccess) return bail("dl_mh_create: hipSetDevice failed");
     const size_t C = nchains, V = vectorize;
@@ -390,7 +403,13 @@ int dl_mh_run(dl_mh* mh, int64_t ntries, int32_t thin_by, double* out_coords_dev
     for (int64_t t = mh->tries; t < mh->tries + ntries; ++t) {
         s.try_prop = t;
         launch();
-        if (dl_eval_logposterior(mh->ctx, mh->prop[mh->cur_prop], (int64_t)C * V, mh->newlp, nullptr, stream)) return 1;
+        s.part = nullptr;
+        if (mh->deferred) {
+            const int rc = dl_internal_eval_partials(mh->ctx, mh->prop[mh->cur_prop], (int64_t)C * V, &s.part, &s.n_tiles, &s.priors, stream);
+            if (rc == 1) return 1;
+            if (rc == 2) { mh->deferred = false; s.part = nullptr; }
+        }
+        if (s.part == nullptr && dl_eval_logposterior(mh->ctx, mh->prop[mh->cur_prop], (int64_t)C * V, mh->newlp, nullptr, stream)) return 1;
         s.try_acc = t;
     }
     s.try_prop = -1;

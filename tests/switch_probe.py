@@ -72,6 +72,21 @@ def section_ens():
         assert np.array_equal(chain['logposterior'][it], logp), it
 
 
+def section_mh():
+    """device-resident Metropolis-Hastings chains vs the host driver (NumPy proposals, same counter-based draws): same weights, same positions"""
+    import bench
+    from desilike_amd.samplers import MCMCSampler
+    kw = dict(chains=3, vectorize=4, seed=7, learn=False)
+    dev = MCMCSampler(bench.make_likelihood_config5(0), **kw)
+    host = MCMCSampler(bench.make_likelihood_config5(0), device_resident=False, **kw)
+    start = dev._get_start(3)[0]
+    cd, ch = dev.run(check_every=25, max_iterations=50, start=start), host.run(check_every=25, max_iterations=50, start=start)
+    for a, b in zip(cd, ch):
+        assert a['fweight'].size > 3 and np.array_equal(a['fweight'], b['fweight'])
+        close(a['logposterior'], b['logposterior'], 'mh chains: device vs host driver')
+        assert np.allclose(a['qpar'], b['qpar'], rtol=1e-11, atol=1e-13)
+
+
 def section_emu():
     """config 3 at full size: the reference fixture (no marginalisation) and the oracle's marginalised solve"""
     from desilike_amd import vmap
