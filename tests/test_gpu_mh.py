@@ -168,3 +168,44 @@ def test_sampler_learns_and_converges_on_the_device(tmp_path):
     assert np.allclose(std, y.std(axis=0), rtol=0.35)
     assert all(np.isfinite(chain['logposterior']).all() for chain in chains)
     assert (tmp_path / 'mh_0.npy').exists()
+
+
+def _many_parameter_likelihood(ntemplates=30):
+    """config 2 with ``ntemplates`` systematic templates as sampled pass-through parameters: 6 + ntemplates dimensions."""
+    from golden_utils import load_golden
+    from test_window_extras import KLIM
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    g = load_golden('cfg2_fc_syst')
+    kedges = np.linspace(0., 0.2, 41)
+
+    def template(i):
+        return lambda ell, k: 2e2 * (ell == 2 * (i % 3)) / (1. + (k / (0.01 + 0.005 * i))**2)
+
+    theory = KaiserTracerPowerSpectrumMultipoles(template=ShapeFitPowerSpectrumTemplate(z=0.5))
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2.}, k=(kedges[:-1] + kedges[1:]) / 2., klim=KLIM, ells=(0, 2, 4),
+                                                  wmatrix={'resolution': 2}, theory=theory, shotnoise=1e4, systematic_templates=[template(i) for i in range(ntemplates)])
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
+    for param in like.all_params.select(basename='syst_*'):
+        param.update(prior=dict(dist='norm', loc=0., scale=2.), ref=dict(dist='norm', loc=0., scale=0.05), proposal=0.05)
+    like._invalidate()
+    return like
+
+
+@pytest.mark.parametrize('split', [None, 20, 33])
+def test_wide_blocks_on_the_device_equal_the_host_driver(split):
+    """Blocks of more than 16 / more than 32 parameters (the rotation column from LDS rows in several passes / with the Gaussians drawn reflection by reflection)."""
+    from desilike_amd.samplers import MCMCSampler
+    names = _many_parameter_likelihood().varied_params.names()
+    assert len(names) == 36
+    blocks = None if split is None else [[1, names[:split]], [2, names[split:]]]
+    kw = dict(blocks=blocks, chains=2, vectorize=3, seed=17, learn=False, proposal_scale=0.6)
+    dev, host = MCMCSampler(_many_parameter_likelihood(), **kw), MCMCSampler(_many_parameter_likelihood(), device_resident=False, **kw)
+    assert dev.device_resident and dev.blocks == ([36] if split is None else [split, 36 - split])
+    start = dev._get_start(2)[0]
+    cd, ch = dev.run(check_every=40, max_iterations=40, start=start), host.run(check_every=40, max_iterations=40, start=start)
+    for a, b in zip(cd, ch):
+        assert a['fweight'].size > 3 and np.array_equal(a['fweight'], b['fweight'])
+        for name in names: assert np.allclose(a[name], b[name], rtol=1e-10, atol=1e-12), name
+        assert np.allclose(a['logposterior'], b['logposterior'], rtol=1e-10, atol=1e-8)
