@@ -242,7 +242,8 @@ class MCMCSampler(BasePosteriorSampler):
 
     blocks : ``[[oversample_factor, [names]], ...]`` (mcmc.py:352-361); default one block of all parameters (a device likelihood has no fast / slow hierarchy).
     covariance : proposal covariance: ``None`` (the parameters' ``proposal`` squared), array [ndim, ndim] in the order of ``varied_params``, ``(names, array)``, or chain
-        file(s) / :class:`~desilike_amd.io.ChainFile` to estimate it from (second half, weighted); parameters it does not cover take ``proposal`` squared.
+        file(s) / :class:`~desilike_amd.io.ChainFile` to estimate it from (second half, weighted), or the :class:`~desilike_amd.profilers.Profiles` of a maximisation;
+        parameters it does not cover take ``proposal`` squared.
     learn : update the proposal covariance from the chains before every batch (mcmc.py:467-497); a dict restricts it: ``{'every': '40 * ndim', 'max_eigen_gr': 0.1,
         'min_eigen_gr': 0.03, 'burnin': 0.5}``.
     chains : number of chains, or a list of files written by :meth:`save` to resume from.  Chains are distributed over the ranks of the process group (chain c on rank
@@ -310,6 +311,7 @@ class MCMCSampler(BasePosteriorSampler):
         ndim = len(names)
         cov = np.diag([float(param.proposal)**2 for param in self.varied_params])
         if source is None: return cov
+        if isinstance(getattr(source, 'covariance', None), tuple): source = source.covariance      # profiles of a maximisation (profilers.Profiles): (names, matrix)
         given = None
         if isinstance(source, (tuple, list)) and len(source) == 2 and not hasattr(source[0], 'arrays') and np.ndim(source[1]) == 2:
             given = ([str(name) for name in source[0]], np.asarray(source[1], dtype='f8'))
