@@ -985,4 +985,7 @@ def __getattr__(name):
     if name in ('MCMCSampler', 'MHDraws'):
         from . import mcmc
         return getattr(mcmc, name)
+    if name == 'HMCSampler':
+        from . import hmc
+        return hmc.HMCSampler
     raise AttributeError('module {!r} has no attribute {!r}'.format(__name__, name))
