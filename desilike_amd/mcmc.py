@@ -172,31 +172,52 @@ class _HostMH(object):
 
 
 class _DeviceMH(object):
-    """The chains of this rank resident on the GPU (``dl_mh_*``)."""
+    """Chains of this rank resident on the GPU (``dl_mh_*``), optionally on a HIP stream of their own."""
     device_resident = True
 
-    def __init__(self, ctx, offset, chain_ids, vectorize, blocks, oversample, order, proposal_scale, seed, max_tries):
+    def __init__(self, ctx, offset, chain_ids, vectorize, blocks, oversample, order, proposal_scale, seed, max_tries, own_stream=False):
+        import torch
         from ._lib import DeviceMH
         self.mh = DeviceMH(ctx, len(chain_ids), vectorize=vectorize, blocks=blocks, oversample=oversample, order=order, chain_ids=chain_ids, proposal_scale=proposal_scale,
                            seed=seed, offset=offset, max_tries=max_tries)
         self.nchains = len(chain_ids)
+        self.stream = torch.cuda.Stream(device=torch.device('cuda', self.mh.device)) if own_stream else None
+        self._pending = None
+
+    def _cuda_stream(self):
+        return None if self.stream is None else self.stream.cuda_stream
 
     def set_covariance(self, cholesky):
-        self.mh.set_covariance(cholesky)
+        self.mh.set_covariance(cholesky, stream=self._cuda_stream())
 
     def set_state(self, coords, logposterior=None, weight=None, naccepted=None, tries=0):
-        self.mh.set_state(coords, logposterior=logposterior, weight=weight, naccepted=naccepted, tries=tries)
+        self.mh.set_state(coords, logposterior=logposterior, weight=weight, naccepted=naccepted, tries=tries, stream=self._cuda_stream())
 
-    def run(self, ntries, thin_by=1):
+    def enqueue(self, ntries, thin_by=1):
         import torch
-        coords, logp, weight, count = self.mh.run(ntries, thin_by=thin_by)
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.stream.device))
+            with torch.cuda.stream(self.stream):      # (the record buffers are allocated and filled on the chains' stream)
+                self._pending = self.mh.run(ntries, thin_by=thin_by, stream=self._cuda_stream())
+        else:
+            self._pending = self.mh.run(ntries, thin_by=thin_by)
+
+    def collect(self):
+        import torch
+        coords, logp, weight, count = self._pending
+        self._pending = None
+        if self.stream is not None: self.stream.synchronize()
         count = count.cpu().numpy()                                                          # the one synchronisation of the batch
         nmax = int(count.max()) if count.size else 0
         coords, logp, weight = coords[:, :nmax].cpu().numpy(), logp[:, :nmax].cpu().numpy(), weight[:, :nmax].cpu().numpy()
         return [(coords[c, :count[c]], logp[c, :count[c]], weight[c, :count[c]]) for c in range(self.nchains)]      # views of the batch's host copy
 
+    def run(self, ntries, thin_by=1):
+        self.enqueue(ntries, thin_by=thin_by)
+        return self.collect()
+
     def get_state(self):
-        return self.mh.get_state()
+        return self.mh.get_state(stream=self._cuda_stream())
 
     @property
     def tries(self):
@@ -204,6 +225,62 @@ class _DeviceMH(object):
 
     def close(self):
         self.mh.close()
+
+
+class _DeviceMHGroups(object):
+    """The chains of this rank in ``len(parts)`` groups, each a :class:`_DeviceMH` with its own device context and HIP stream: the tries of the groups are enqueued
+    one after the other and run concurrently -- the step kernel of one group (a single wavefront's critical path) in the shadow of another group's evaluation."""
+    device_resident = True
+
+    def __init__(self, parts):
+        self.parts = parts                         # [(runner, slots of its chains in the rank's list)]
+        self.nchains = sum(len(slots) for _, slots in parts)
+
+    def set_covariance(self, cholesky):
+        for runner, _ in self.parts: runner.set_covariance(cholesky)
+
+    def set_state(self, coords, logposterior=None, weight=None, naccepted=None, tries=0):
+        pick = lambda values, slots: None if values is None else np.asarray(values)[slots]
+        for runner, slots in self.parts:
+            runner.set_state(np.asarray(coords)[slots], logposterior=pick(logposterior, slots), weight=pick(weight, slots), naccepted=pick(naccepted, slots), tries=tries)
+
+    def run(self, ntries, thin_by=1):
+        for runner, _ in self.parts: runner.enqueue(ntries, thin_by=thin_by)
+        out = [None] * self.nchains
+        for runner, slots in self.parts:
+            for slot, record in zip(slots, runner.collect()): out[slot] = record
+        return out
+
+    def get_state(self):
+        states = [runner.get_state() for runner, _ in self.parts]
+        out = []
+        for i in range(5):
+            merged = np.empty((self.nchains,) + states[0][i].shape[1:], dtype=states[0][i].dtype)
+            for (runner, slots), state in zip(self.parts, states): merged[slots] = state[i]
+            out.append(merged)
+        return tuple(out)
+
+    def close(self):
+        for runner, _ in self.parts: runner.close()
+
+
+class _ChainsView(object):
+    """``sampler.chains``: a read-only sequence of per-chain dictionaries, built on access."""
+
+    def __init__(self, sampler):
+        self._sampler = sampler
+
+    def __len__(self):
+        return self._sampler.nchains
+
+    def __getitem__(self, index):
+        if isinstance(index, slice): return [self._sampler._chain_dict(i) for i in range(*index.indices(len(self)))]
+        if index < 0: index += len(self)
+        if not 0 <= index < len(self): raise IndexError(index)
+        return self._sampler._chain_dict(index)
+
+    def __iter__(self):
+        return (self._sampler._chain_dict(i) for i in range(len(self)))
 
 
 class _WeightedStore(object):
@@ -248,11 +325,13 @@ class MCMCSampler(BasePosteriorSampler):
         'min_eigen_gr': 0.03, 'burnin': 0.5}``.
     chains : number of chains, or a list of files written by :meth:`save` to resume from.  Chains are distributed over the ranks of the process group (chain c on rank
         ``c % world``); all chains of a rank advance in the same batch.
-    vectorize : speculative proposals per chain and try (mcmc.py:86-105); default: what fills a batch of 256 rows on a device likelihood, 1 on the host."""
+    vectorize : speculative proposals per chain and try (mcmc.py:86-105); default: what fills a batch of 256 rows on a device likelihood, 1 on the host.
+    streams : groups of chains that run concurrently on HIP streams of their own, each with its own device context (device-resident chains; default 1: one batch for
+        all chains measured faster than half-size groups side by side); a chain does not depend on the grouping."""
     name = 'mcmc'
 
     def __init__(self, likelihood, blocks=None, oversample_power=0.4, covariance=None, proposal_scale=2.4, learn=True, drag=False, chains=1, vectorize=None,
-                 device_resident=None, counter_seed=None, save_fn=None, **kwargs):
+                 device_resident=None, counter_seed=None, save_fn=None, streams=None, **kwargs):
         super(MCMCSampler, self).__init__(likelihood, **kwargs)
         if drag: raise NotImplementedError('dragging (mcmc.py:52-84) is not built: every parameter of a device likelihood costs the same launch')
         names = self.varied_params.names()
@@ -279,6 +358,8 @@ class MCMCSampler(BasePosteriorSampler):
         nlocal = len(self.local_chains())
         if vectorize is None: vectorize = max(1, min(64, 256 // max(nlocal, 1))) if self.device_resident else 1
         self.vectorize = int(vectorize)
+        if streams is None: streams = 1      # (measured on the config-5 likelihood: two half-size groups are slower than one batch, profiles/r03u_mh_sampler.txt)
+        self.streams = max(1, min(int(streams), max(nlocal, 1))) if self.device_resident else 1
         if not 1 <= self.vectorize <= 64: raise ValueError('vectorize must be in [1, 64]')
         if counter_seed is None:
             counter_seed = int(self.rng.randint(0, 2**32, dtype=np.uint64)) | (int(self.rng.randint(0, 2**32, dtype=np.uint64)) << 32)
@@ -381,17 +462,18 @@ class MCMCSampler(BasePosteriorSampler):
     def local_chains(self):
         return [ichain for ichain in range(self.nchains) if ichain % self.chain_world == self.chain_rank]
 
+    def _chain_dict(self, ichain):
+        store = self._store[ichain]
+        if store is None: return None
+        chain = {param.name: store[0][:, iparam] for iparam, param in enumerate(self.varied_params)}
+        chain['fweight'], chain['logposterior'] = store[2], store[1]
+        return chain
+
     @property
     def chains(self):
-        """Per chain: dict name -> [n] with 'logposterior' and the multiplicities 'fweight' (mcmc.py:544-547), or None before the first recorded state."""
-        out = []
-        for store in self._store:
-            if store is None:
-                out.append(None); continue
-            chain = {param.name: store[0][:, iparam] for iparam, param in enumerate(self.varied_params)}
-            chain['fweight'], chain['logposterior'] = store[2], store[1]
-            out.append(chain)
-        return out
+        """Per chain: dict name -> [n] with 'logposterior' and the multiplicities 'fweight' (mcmc.py:544-547), or None before the first recorded state.  A sequence
+        that builds a chain's dictionary when it is asked for (hundreds of chains advance per batch: nothing per chain is done on the way)."""
+        return _ChainsView(self)
 
     @property
     def chain(self):
@@ -414,7 +496,13 @@ class MCMCSampler(BasePosteriorSampler):
         if self._runner is None:
             local = self.local_chains()
             kw = dict(vectorize=self.vectorize, blocks=self.blocks, oversample=self.oversample_factors, order=self.order, proposal_scale=self.proposal_scale, seed=self.counter_seed)
-            if self.device_resident:
+            if self.device_resident and self.streams > 1:
+                parts = []
+                for igroup, slots in enumerate(np.array_split(np.arange(len(local)), self.streams)):
+                    ctx, offset = self.likelihood._get_posterior_context(replica=igroup) if igroup else self.likelihood._get_posterior_context()
+                    parts.append((_DeviceMH(ctx, offset, [local[slot] for slot in slots], max_tries=self.max_tries, own_stream=True, **kw), slots))
+                self._runner = _DeviceMHGroups(parts)
+            elif self.device_resident:
                 ctx, offset = self.likelihood._get_posterior_context()
                 self._runner = _DeviceMH(ctx, offset, local, max_tries=self.max_tries, **kw)
             else:
@@ -451,15 +539,17 @@ class MCMCSampler(BasePosteriorSampler):
         coords, logp, weight, naccepted, fails = runner.get_state()
         if (np.asarray(fails) >= self.max_tries).any():
             raise ValueError('Could not find finite log posterior after {:d} tries'.format(self.max_tries))      # mcmc.py:102-103
-        new = {ichain: records[slot] + ((coords[slot], logp[slot], int(weight[slot]), int(naccepted[slot])),) for slot, ichain in enumerate(local)}
+        weight, naccepted, logp = np.asarray(weight).tolist(), np.asarray(naccepted).tolist(), np.asarray(logp, dtype='f8').tolist()     # (python scalars in bulk)
+        new = {ichain: records[slot] + ((coords[slot], logp[slot], weight[slot], naccepted[slot]),) for slot, ichain in enumerate(local)}
         if self.chain_group is not None: new = self._gather(new, ntries, ndim)
         self._tries += ntries
+        state, store = self._state, self._store
         for ichain in range(self.nchains):
-            x, lp, w, state = new[ichain]
-            self._state[ichain] = (np.array(state[0]), float(state[1]), int(state[2]), int(state[3]))
-            if x.shape[0]:
-                if self._store[ichain] is None: self._store[ichain] = _WeightedStore(x, lp, w)
-                else: self._store[ichain].append(x, lp, w)
+            x, lp, w, current = new[ichain]
+            state[ichain] = current
+            if len(lp):
+                if store[ichain] is None: store[ichain] = _WeightedStore(x, lp, w)
+                else: store[ichain].append(x, lp, w)
         self.diagnostics['naccepted'] = [int(self._state[ichain][3]) for ichain in range(self.nchains)]
 
     def _gather(self, new, ntries, ndim):

@@ -209,3 +209,18 @@ def test_wide_blocks_on_the_device_equal_the_host_driver(split):
         assert a['fweight'].size > 3 and np.array_equal(a['fweight'], b['fweight'])
         for name in names: assert np.allclose(a[name], b[name], rtol=1e-10, atol=1e-12), name
         assert np.allclose(a['logposterior'], b['logposterior'], rtol=1e-10, atol=1e-8)
+
+
+def test_stream_groups_do_not_change_the_chains():
+    """Groups of chains on HIP streams of their own (separate device contexts, concurrent tries): the chains are those of the single-stream run."""
+    from desilike_amd.samplers import MCMCSampler
+    _, _, _, cov, start = _setup(6)
+    kw = dict(chains=6, vectorize=4, seed=21, learn=False, covariance=cov)
+    one, three = MCMCSampler(make_cfg5()[1], streams=1, **kw), MCMCSampler(make_cfg5()[1], streams=3, **kw)
+    assert one.streams == 1 and three.streams == 3
+    ca = one.run(check_every=30, max_iterations=60, start=start)
+    cb = three.run(check_every=30, max_iterations=60, start=start)
+    for a, b in zip(ca, cb):
+        assert a['fweight'].size > 5 and np.array_equal(a['fweight'], b['fweight']) and np.array_equal(a['logposterior'], b['logposterior'])
+        assert np.array_equal(a['qpar'], b['qpar'])
+    assert [state[3] for state in one._state] == [state[3] for state in three._state]
