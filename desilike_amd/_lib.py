@@ -58,6 +58,7 @@ SYMBOLS = {
     'dl_mh_set_covariance': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_void_p]),
     'dl_mh_set_state': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, ctypes.c_void_p]),
     'dl_mh_run': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'dl_mh_run_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, _c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p]),
     'dl_mh_get_state': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p]),
     'dl_mh_info': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
     'dl_mlp_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int32, _c_int32_p, ctypes.c_int32, _c_double_p]),

@@ -38,6 +38,11 @@ struct dl_mh {
     long long *weight[2] = {nullptr, nullptr}, *naccepted[2] = {nullptr, nullptr};
     int32_t *fails[2] = {nullptr, nullptr}, *chain_ids = nullptr, *order = nullptr, *rep_block = nullptr, *block_start = nullptr, *block_reps = nullptr;
     int cur = 0, cur_prop = 0;
+    // record buffers of dl_mh_run_host (host-pointer variant for FFI callers), grown on demand
+    double *rec_coords = nullptr, *rec_logp = nullptr;
+    long long* rec_weight = nullptr;
+    int32_t* rec_count = nullptr;
+    int64_t rec_cap = 0;
 };
 
 namespace {
@@ -256,7 +261,8 @@ void dl_mh_destroy(dl_mh* mh) {
     (void)hipSetDevice(mh->device);
     for (void* p : {(void*)mh->coords[0], (void*)mh->coords[1], (void*)mh->logp[0], (void*)mh->logp[1], (void*)mh->prop[0], (void*)mh->prop[1], (void*)mh->newlp, (void*)mh->L,
                     (void*)mh->weight[0], (void*)mh->weight[1], (void*)mh->naccepted[0], (void*)mh->naccepted[1], (void*)mh->fails[0], (void*)mh->fails[1],
-                    (void*)mh->chain_ids, (void*)mh->order, (void*)mh->rep_block, (void*)mh->block_start, (void*)mh->block_reps})
+                    (void*)mh->chain_ids, (void*)mh->order, (void*)mh->rep_block, (void*)mh->block_start, (void*)mh->block_reps, (void*)mh->rec_coords, (void*)mh->rec_logp,
+                    (void*)mh->rec_weight, (void*)mh->rec_count})
         if (p) (void)hipFree(p);
     delete mh;
 }
@@ -416,6 +422,31 @@ int dl_mh_run(dl_mh* mh, int64_t ntries, int32_t thin_by, double* out_coords_dev
     launch();
     DL_MH_HIP(hipGetLastError());
     mh->tries += ntries;
+    return 0;
+}
+
+int dl_mh_run_host(dl_mh* mh, int64_t ntries, int32_t thin_by, double* out_coords, double* out_logp, int64_t* out_weight, int32_t* out_count, void* hip_stream) {
+    if (!mh) return fail("dl_mh_run_host: null sampler");
+    if (ntries < 0 || (ntries > 0 && (!out_coords || !out_logp || !out_weight || !out_count))) return fail("dl_mh_run_host: invalid argument");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DL_MH_HIP(hipSetDevice(mh->device));
+    const size_t C = mh->C, P = mh->P;
+    if (ntries > mh->rec_cap) {
+        DL_MH_HIP(hipStreamSynchronize(stream));
+        for (void* p : {(void*)mh->rec_coords, (void*)mh->rec_logp, (void*)mh->rec_weight, (void*)mh->rec_count}) if (p) (void)hipFree(p);
+        mh->rec_coords = mh->rec_logp = nullptr; mh->rec_weight = nullptr; mh->rec_count = nullptr; mh->rec_cap = 0;
+        if (hipMalloc((void**)&mh->rec_coords, C * ntries * P * sizeof(double)) != hipSuccess || hipMalloc((void**)&mh->rec_logp, C * ntries * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&mh->rec_weight, C * ntries * sizeof(long long)) != hipSuccess || hipMalloc((void**)&mh->rec_count, C * sizeof(int32_t)) != hipSuccess)
+            return fail("dl_mh_run_host: device allocation failed");
+        mh->rec_cap = ntries;
+    }
+    if (ntries == 0) return dl_mh_run(mh, 0, thin_by, nullptr, nullptr, nullptr, nullptr, hip_stream);
+    if (dl_mh_run(mh, ntries, thin_by, mh->rec_coords, mh->rec_logp, reinterpret_cast<int64_t*>(mh->rec_weight), mh->rec_count, hip_stream)) return 1;
+    DL_MH_HIP(hipMemcpyAsync(out_coords, mh->rec_coords, C * ntries * P * sizeof(double), hipMemcpyDeviceToHost, stream));
+    DL_MH_HIP(hipMemcpyAsync(out_logp, mh->rec_logp, C * ntries * sizeof(double), hipMemcpyDeviceToHost, stream));
+    DL_MH_HIP(hipMemcpyAsync(out_weight, mh->rec_weight, C * ntries * sizeof(long long), hipMemcpyDeviceToHost, stream));
+    DL_MH_HIP(hipMemcpyAsync(out_count, mh->rec_count, C * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    DL_MH_HIP(hipStreamSynchronize(stream));
     return 0;
 }
 

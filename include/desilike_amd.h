@@ -277,6 +277,8 @@ int  dl_mh_set_state(dl_mh* mh, const double* coords, const double* logposterior
  * state is skipped and every thin_by-th accepted state kept, mcmc.py:97-99): out_coords_dev[nchains, ntries, P], out_logp_dev[nchains, ntries],
  * out_weight_dev[nchains, ntries] hold the out_count_dev[nchains] records of this call (device, caller-owned). */
 int  dl_mh_run(dl_mh* mh, int64_t ntries, int32_t thin_by, double* out_coords_dev, double* out_logp_dev, int64_t* out_weight_dev, int32_t* out_count_dev, void* hip_stream);
+/* the same with HOST record arrays of the same shapes (callers without device memory of their own: FFI bindings); the sampler keeps the device buffers; synchronises */
+int  dl_mh_run_host(dl_mh* mh, int64_t ntries, int32_t thin_by, double* out_coords, double* out_logp, int64_t* out_weight, int32_t* out_count, void* hip_stream);
 /* host arrays (any may be NULL): current positions, log-posteriors, weights, accepted moves, consecutive tries without an accepted proposal; synchronises */
 int  dl_mh_get_state(dl_mh* mh, double* coords, double* logposterior, int64_t* weight, int64_t* naccepted, int32_t* fails, void* hip_stream);
 /* integer properties: "nchains", "vectorize", "n_params", "tries", "cycle" (entries of the parameter cycler), "max_tries" */

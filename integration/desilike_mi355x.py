@@ -231,6 +231,14 @@ class Library(object):
         lib.dl_destroy.argtypes = [ctypes.c_void_p]
         lib.dl_last_error.restype, lib.dl_last_error.argtypes = ctypes.c_char_p, [ctypes.c_void_p]
         lib.dl_eval_batch_host.argtypes = [ctypes.c_void_p, dp, ctypes.c_int64, dp, dp, dp, ip, dp]
+        lp = ctypes.POINTER(ctypes.c_int64)
+        lib.dl_mh_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ip, ip, ip, ip, ctypes.c_int32, ctypes.c_double, ctypes.c_uint64,
+                                     ctypes.c_double, ctypes.c_int64]
+        lib.dl_mh_destroy.argtypes = [ctypes.c_void_p]
+        lib.dl_mh_set_covariance.argtypes = [ctypes.c_void_p, dp, ctypes.c_void_p]
+        lib.dl_mh_set_state.argtypes = [ctypes.c_void_p, dp, dp, lp, lp, ctypes.c_int64, ctypes.c_void_p]
+        lib.dl_mh_run_host.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, dp, dp, lp, ip, ctypes.c_void_p]
+        lib.dl_mh_get_state.argtypes = [ctypes.c_void_p, dp, dp, lp, lp, ip, ctypes.c_void_p]
 
     def create(self, cfg, device=0):
         """``dl_create`` from a flat key -> array set; returns the opaque context handle."""
@@ -267,6 +275,45 @@ class Library(object):
                                        solved.ctypes.data_as(dp) if n_solved else None) != 0:
             raise RuntimeError(self.lib.dl_last_error(ctx).decode())
         return (loglike, logprior, status, solved) if n_solved else (loglike, logprior, status)
+
+
+class MetropolisHastings(object):
+    """What desilike's ``MHSampler`` (samplers/mcmc.py:25-127) does around ``BlockProposer`` (199-328), through ``dl_mh_*``: ``nchains`` chains x ``vectorize``
+    speculative proposals per try as one batch on the GPU.  ``covariance``: proposal covariance of the varied parameters; ``blocks`` / ``oversample_factors`` as
+    ``BlockProposer`` takes them (sizes in sorted order, slowest first) with ``order`` = sorted position -> column of the varied parameters."""
+
+    def __init__(self, library, ctx, covariance, nchains=1, vectorize=1, blocks=None, oversample_factors=None, order=None, proposal_scale=2.4, seed=0, max_tries=1000):
+        self.library, lib = library, library.lib
+        covariance = np.asarray(covariance, dtype='f8')
+        self.ndim = ndim = covariance.shape[0]
+        ip = ctypes.POINTER(ctypes.c_int32)
+        blocks = np.ascontiguousarray([ndim] if blocks is None else blocks, dtype=np.int32)
+        over = np.ascontiguousarray(np.ones(len(blocks)) if oversample_factors is None else oversample_factors, dtype=np.int32)
+        order = np.ascontiguousarray(np.arange(ndim) if order is None else order, dtype=np.int32)
+        self.handle, self.nchains = ctypes.c_void_p(), int(nchains)
+        if lib.dl_mh_create(ctypes.byref(self.handle), ctx, self.nchains, int(vectorize), None, order.ctypes.data_as(ip), blocks.ctypes.data_as(ip), over.ctypes.data_as(ip),
+                            len(blocks), float(proposal_scale), ctypes.c_uint64(int(seed)), 0., int(max_tries)) != 0:
+            raise RuntimeError(lib.dl_last_error(None).decode())
+        cholesky = np.ascontiguousarray(np.linalg.cholesky(covariance[np.ix_(order, order)]))                  # BlockProposer.set_covariance, mcmc.py:312
+        if lib.dl_mh_set_covariance(self.handle, cholesky.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), None) != 0:
+            raise RuntimeError(lib.dl_last_error(None).decode())
+
+    def sample(self, start, iterations=300, thin_by=1):
+        """``iterations`` tries of every chain from ``start [nchains, ndim]`` (first call) or from where the chains are; returns per chain
+        (coords [n, ndim], weight [n], log_prob [n]): ``get_chain / get_weight / get_log_prob`` of ``MHSampler``."""
+        lib, dp, lp = self.library.lib, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
+        if start is not None:
+            start = np.ascontiguousarray(np.asarray(start, dtype='f8').reshape(self.nchains, self.ndim))
+            if lib.dl_mh_set_state(self.handle, start.ctypes.data_as(dp), None, None, None, 0, None) != 0: raise RuntimeError(lib.dl_last_error(None).decode())
+        coords, logp = np.empty((self.nchains, iterations, self.ndim)), np.empty((self.nchains, iterations))
+        weight, count = np.empty((self.nchains, iterations), dtype=np.int64), np.empty(self.nchains, dtype=np.int32)
+        if lib.dl_mh_run_host(self.handle, int(iterations), int(thin_by), coords.ctypes.data_as(dp), logp.ctypes.data_as(dp), weight.ctypes.data_as(lp),
+                              count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), None) != 0:
+            raise RuntimeError(lib.dl_last_error(None).decode())
+        return [(coords[c, :count[c]].copy(), weight[c, :count[c]].copy(), logp[c, :count[c]].copy()) for c in range(self.nchains)]
+
+    def close(self):
+        if self.handle: self.library.lib.dl_mh_destroy(self.handle); self.handle = None
 
 
 def make_calculator():

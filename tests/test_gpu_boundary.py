@@ -122,3 +122,41 @@ def test_host_mirror_compiles_the_same_keys():
                 assert np.array_equal(mirror[key].reshape(-1, 5)[names.index(name)], value[iname]), name
         else:
             assert np.allclose(np.ravel(mirror[key]), np.ravel(value), rtol=1e-9 if key == 'precision' else 1e-13, atol=1e-14 if key == 'precision' else 1e-300), key
+
+
+@pytest.mark.gpu
+def test_metropolis_hastings_through_the_binding():
+    """The reference-side ctypes binding of the sampler ABI (``dl_mh_*`` with host record arrays): a context created from the keys of a real desilike likelihood, chains
+    equal to the oracle's restatement of the reference's MHSampler + BlockProposer with the same counter-based draws."""
+    import torch  # noqa: F401
+    from desilike_mi355x import Library, MetropolisHastings
+    from oracle import np_oracle as orc
+    g, cfg = load_fixture(FIXTURES[0])
+    library = Library(os.path.join(ROOT, 'desilike_amd', 'lib', 'libdesilike_amd.so'))
+    ctx = library.create(cfg, device=0)
+    inside = np.isfinite(g['logprior'])
+    theta = g['theta'][inside]
+    ndim = theta.shape[1]
+    sigma = 0.05 * theta.std(axis=0)
+    covariance = np.diag(sigma**2)
+    blocks, over, order, seed = [ndim - 2, 2], [1, 2], np.arange(ndim)[::-1].copy(), 77
+    start = theta[:2] * 1.
+    sampler = MetropolisHastings(library, ctx, covariance, nchains=2, vectorize=3, blocks=blocks, oversample_factors=over, order=order, seed=seed)
+    chains = sampler.sample(start, iterations=40, thin_by=1)
+    more = sampler.sample(None, iterations=20, thin_by=1)
+
+    def log_prob_fn(x_sorted):
+        x = np.empty_like(np.atleast_2d(x_sorted)); x[:, order] = np.atleast_2d(x_sorted)
+        loglike, logprior, status = library.eval_batch(ctx, x)
+        return np.where(status == 0, loglike + logprior, -np.inf)
+
+    transforms = orc.mh_transforms(covariance[np.ix_(order, order)], blocks)
+    for c in range(2):
+        draws = orc.MHPhiloxDraws(seed, c, blocks, over)
+        chain, weight, logp, final = orc.mh_sample(log_prob_fn, start[c][order], draws, transforms, ntries=60, vectorize=3)
+        got = np.concatenate([chains[c][0], more[c][0]])[:, order]
+        assert len(weight) > 5 and np.array_equal(np.concatenate([chains[c][1], more[c][1]]), weight)
+        assert np.allclose(got, chain, rtol=1e-11, atol=1e-13)
+        assert np.allclose(np.concatenate([chains[c][2], more[c][2]]), logp, rtol=1e-10, atol=1e-9)
+    sampler.close()
+    library.lib.dl_destroy(ctx)
