@@ -224,3 +224,25 @@ def test_stream_groups_do_not_change_the_chains():
         assert a['fweight'].size > 5 and np.array_equal(a['fweight'], b['fweight']) and np.array_equal(a['logposterior'], b['logposterior'])
         assert np.array_equal(a['qpar'], b['qpar'])
     assert [state[3] for state in one._state] == [state[3] for state in three._state]
+
+
+def _few_parameter_likelihood(keep):
+    g, like = make_cfg5()
+    like.all_params = {param.name: {'fixed': True} for param in like.varied_params if param.name not in keep}
+    return like
+
+
+@pytest.mark.parametrize('keep,blocks,vectorize', [(['qpar'], None, 64), (['qpar', 'qper'], [[1, ['qpar']], [4, ['qper']]], 5), (['qpar', 'qper', 'df'], None, 1)])
+def test_edge_shapes_on_the_device_equal_the_host_driver(keep, blocks, vectorize):
+    """One parameter (a block of one: sign x radius, no rotation), two one-parameter blocks with oversampling (the cycler keeps its order for two entries or fewer; here five
+    entries), the largest number of speculative proposals, a single chain."""
+    from desilike_amd.samplers import MCMCSampler
+    kw = dict(blocks=blocks, chains=1, vectorize=vectorize, seed=5, learn=False)
+    dev, host = MCMCSampler(_few_parameter_likelihood(keep), **kw), MCMCSampler(_few_parameter_likelihood(keep), device_resident=False, **kw)
+    assert dev.device_resident and len(dev.varied_params) == len(keep)
+    start = dev._get_start(1)[0]
+    cd, ch = dev.run(check_every=40, max_iterations=80, start=start), host.run(check_every=40, max_iterations=80, start=start)
+    a, b = cd[0], ch[0]
+    assert a['fweight'].size > 5 and np.array_equal(a['fweight'], b['fweight'])
+    for name in keep: assert np.allclose(a[name], b[name], rtol=1e-11, atol=1e-13)
+    assert np.allclose(a['logposterior'], b['logposterior'], rtol=1e-10, atol=1e-9)
