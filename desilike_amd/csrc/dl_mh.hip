@@ -166,14 +166,51 @@ __global__ __launch_bounds__(64 * DL_MH_WAVES) void dl_mh_step_kernel(const DlMh
     if (pair >= (long long)s.C * V) return;
     const int c = (int)(pair / V), v = (int)(pair % V);
     const uint32_t chain = (uint32_t)s.chain_ids[c];
+    // The jump of this wavefront's slot does not depend on the chain's state: it is formed FIRST, in the shadow of the loads the Metropolis scan waits for (state,
+    // log-posterior, the pending proposals' results) -- the kernel is one wavefront's critical path, and the dependent round trips are what it is made of.
+    const double* __restrict__ logp_in = s.logp;
+    const double* __restrict__ coords_in = s.coords;
+    const double cur_lp = logp_in[c];
+    double state = lane < P ? coords_in[(size_t)c * P + lane] : 0.;   // lane = parameter (context order)
+    double lp = 0.;
+    if (s.try_acc >= 0 && lane < V && s.part == nullptr) lp = s.newlp[(size_t)c * V + lane];
+    const int sorted = lane < P ? lane : 0;                             // (every lane takes part in the exchanges below; the lanes beyond P write nothing)
+    const int target = s.order[sorted];                                 // sorted index i is parameter order[i] of the context
+    double delta = 0.;
+    int start = 0;
+    if (s.try_prop >= 0) {
+        const uint64_t n = (uint64_t)s.try_prop * V + v;
+        const uint64_t q = n / (uint64_t)s.n_rep;
+        const uint32_t p = (uint32_t)(n % (uint64_t)s.n_rep);
+        const DlMhKeys keys = dl_mh_perm_keys(q, chain, s.k0, s.k1);
+        const int ib = s.rep_block[dl_mh_perm_at(keys, p, (uint32_t)s.n_rep)];
+        int cnt = 0;                                                    // earlier calls of this cycle that went to the same block
+        for (uint32_t p0 = 0; p0 < p; p0 += 64) {
+            const uint32_t pp = p0 + lane;
+            const bool same = pp < p && s.rep_block[dl_mh_perm_at(keys, pp, (uint32_t)s.n_rep)] == ib;
+            cnt += __popcll(__ballot(same));
+        }
+        start = s.block_start[ib];
+        const int b = s.block_start[ib + 1] - start;
+        const uint64_t calls = q * (uint64_t)s.block_reps[ib] + (uint64_t)cnt;
+        double sign = 1.;
+        const double radius = dl_mh_radial(n, chain, b, s.k0, s.k1, &sign);
+        double y;
+        if (b == 1) y = lane == 0 ? sign : 0.;                          // mcmc.py:165-166
+        else y = dl_mh_direction(lane, b, (int)(calls % (uint64_t)b), calls / (uint64_t)b, chain, ib, s.k0, s.k1, gauss[threadIdx.x >> 6]);
+        y *= radius * s.scale;
+        // jump of the sorted parameters start .. P - 1: L[start:, start : start + b] . y (mcmc.py:290-296, 315-327); lane i = sorted index start + i
+        const int i = start + lane;
+        for (int jj = 0; jj < b; ++jj) {
+            const double yj = __shfl(y, jj, 64);
+            if (i < P) delta += s.L[(size_t)i * P + start + jj] * yj;
+        }
+    }
     // ---- Metropolis scan of the pending try: every wavefront of the chain takes the same decision from the same data; the wavefront of slot 0 writes it ------------
-    const double cur_lp = s.logp[c];
-    double state = lane < P ? s.coords[(size_t)c * P + lane] : 0.;   // lane = parameter (context order)
     double new_lp = cur_lp;
     int first = -1;
     if (s.try_acc >= 0) {
         bool acc = false;
-        double lp = 0.;
         if (lane < V) {
             if (s.part != nullptr) {
                 const double* row = s.prop + ((size_t)c * V + lane) * P;
@@ -182,7 +219,7 @@ __global__ __launch_bounds__(64 * DL_MH_WAVES) void dl_mh_step_kernel(const DlMh
                 dl_load_theta8(row, P, 0, x0);
                 dl_finalize_from_chi2<2>(dl_chi2_of_parts(s.part + ((size_t)c * V + lane) * s.n_tiles, s.n_tiles), x0, row, P, s.priors, ll, lpr, st);
                 lp = st == 0 ? ll + lpr : -__builtin_huge_val();
-            } else lp = s.newlp[(size_t)c * V + lane];
+            }
             lp = (lp != lp ? -__builtin_huge_val() : lp) + s.offset;                                    // samplers/base.py:187-189
             const double e = dl_mh_accept_exp((uint64_t)s.try_acc * V + lane, chain, s.k0, s.k1);
             acc = lp > -__builtin_huge_val() && (lp > cur_lp || e > cur_lp - lp);                       // mcmc.py:107-112
@@ -214,42 +251,11 @@ __global__ __launch_bounds__(64 * DL_MH_WAVES) void dl_mh_step_kernel(const DlMh
         if (lane == 0) { s.logp_out[c] = new_lp; s.weight_out[c] = weight; s.naccepted_out[c] = iter; s.fails_out[c] = fails; }
     }
     if (s.try_prop < 0) return;
-    // ---- the proposal of slot v from the (new) state -------------------------------------------------------------------------------------------------------------
-    {
-        const uint64_t n = (uint64_t)s.try_prop * V + v;
-        const uint64_t q = n / (uint64_t)s.n_rep;
-        const uint32_t p = (uint32_t)(n % (uint64_t)s.n_rep);
-        const DlMhKeys keys = dl_mh_perm_keys(q, chain, s.k0, s.k1);
-        const int ib = s.rep_block[dl_mh_perm_at(keys, p, (uint32_t)s.n_rep)];
-        int cnt = 0;                                                    // earlier calls of this cycle that went to the same block
-        for (uint32_t p0 = 0; p0 < p; p0 += 64) {
-            const uint32_t pp = p0 + lane;
-            const bool same = pp < p && s.rep_block[dl_mh_perm_at(keys, pp, (uint32_t)s.n_rep)] == ib;
-            cnt += __popcll(__ballot(same));
-        }
-        const int start = s.block_start[ib], b = s.block_start[ib + 1] - start;
-        const uint64_t calls = q * (uint64_t)s.block_reps[ib] + (uint64_t)cnt;
-        double sign = 1.;
-        const double radius = dl_mh_radial(n, chain, b, s.k0, s.k1, &sign);
-        double y;
-        if (b == 1) y = lane == 0 ? sign : 0.;                          // mcmc.py:165-166
-        else y = dl_mh_direction(lane, b, (int)(calls % (uint64_t)b), calls / (uint64_t)b, chain, ib, s.k0, s.k1, gauss[threadIdx.x >> 6]);
-        y *= radius * s.scale;
-        // jump of the sorted parameters start .. P - 1: L[start:, start : start + b] . y (mcmc.py:290-296, 315-327); lane i = sorted index start + i
-        double delta = 0.;
-        const int i = start + lane;
-        for (int jj = 0; jj < b; ++jj) {
-            const double yj = __shfl(y, jj, 64);
-            if (i < P) delta += s.L[(size_t)i * P + start + jj] * yj;
-        }
-        // scatter into context order: sorted index i is parameter order[i]
-        double* row = s.prop_out + ((size_t)c * V + v) * P;
-        const int sorted = lane < P ? lane : 0;                         // (every lane takes part in the exchanges; the lanes beyond P write nothing)
-        const int target = s.order[sorted];
-        const double base = __shfl(state, target, 64);
-        const double jump = __shfl(delta, sorted >= start ? sorted - start : 0, 64);
-        if (lane < P) row[target] = base + (sorted >= start ? jump : 0.);   // the parameters of slower blocks keep their values
-    }
+    // ---- the proposal of slot v: the (new) state + the jump, scattered into context order -------------------------------------------------------------------------
+    double* row = s.prop_out + ((size_t)c * V + v) * P;
+    const double base = __shfl(state, target, 64);
+    const double jump = __shfl(delta, sorted >= start ? sorted - start : 0, 64);
+    if (lane < P) row[target] = base + (sorted >= start ? jump : 0.);   // the parameters of slower blocks keep their values
 }
 
 }  // namespace
