@@ -42,14 +42,16 @@ class Profiles(object):
         return cls(state['start'], state['bestfit'], state['error'], tuple(state['covariance']), attrs=state.get('attrs', None))
 
 
-def levenberg_marquardt(evaluate, start, lower, upper, max_iterations=100, xtol=1e-7, ftol=1e-9, damping=1e-3):
+def levenberg_marquardt(evaluate, start, lower, upper, max_iterations=100, xtol=1e-7, ftol=1e-9, damping=1e-3, free=None):
     """Maximise f over a batch of starts.  ``evaluate(points [S, P]) -> (f [S], gradient [S, P], curvature [S, P, P])`` with ``curvature`` positive semi-definite
     (minus the Gauss-Newton Hessian); ``lower`` / ``upper``: bounds [P].  Per iteration ONE call of ``evaluate`` on the candidates of the starts still running: a
     candidate that improves f is taken (its derivatives are already there) and the damping relaxed, otherwise the damping grows and the step is redone from the kept
     derivatives.  Stops a start when an accepted step is below ``xtol`` in units of the curvature's standard deviations or improves f by less than ``ftol``.
+    ``free``: boolean mask [P] (or [S, P]) of the coordinates that move; the others keep their starting values (profiles along a parameter).
     Returns (points, f, gradient, curvature, iterations [S], converged [S])."""
     x = np.array(start, dtype='f8')
     S, P = x.shape
+    free = np.ones((S, P), dtype='?') if free is None else np.broadcast_to(np.asarray(free, dtype='?'), (S, P))
     f, g, H = evaluate(x)
     f, g, H = np.array(f, dtype='f8'), np.array(g, dtype='f8'), np.array(H, dtype='f8')
     if not np.isfinite(f).all(): raise ValueError('the objective is not finite at a starting point')
@@ -65,8 +67,10 @@ def levenberg_marquardt(evaluate, start, lower, upper, max_iterations=100, xtol=
         candidates, scaled = np.empty((index.size, P)), np.empty(index.size)
         for slot, s in enumerate(index):
             diag = np.maximum(np.diag(H[s]), 1e-300)
-            step = np.linalg.solve(H[s] + lam[s] * np.diag(diag), g[s])          # (H + lam diag H) step = gradient
-            candidates[slot] = np.clip(x[s] + step, lo, hi)
+            m = free[s]
+            step = np.zeros(P)
+            step[m] = np.linalg.solve((H[s] + lam[s] * np.diag(diag))[np.ix_(m, m)], g[s][m])      # (H + lam diag H) step = gradient, in the moving coordinates
+            candidates[slot] = np.where(m, np.clip(x[s] + step, lo, hi), x[s])
             scaled[slot] = np.max(np.abs(candidates[slot] - x[s]) * np.sqrt(diag))   # step in units of the (conditional) standard deviations
         fc, gc, Hc = evaluate(candidates)
         iterations[index] += 1
@@ -154,3 +158,61 @@ class GaussNewtonProfiler(BasePosteriorSampler):
                                  attrs={'iterations': iterations.tolist(), 'converged': converged.tolist(), 'gradient_norm': np.abs(g / np.sqrt(np.maximum(H[:, np.arange(len(names)), np.arange(len(names))], 1e-300))).max(axis=1).tolist()})
         if self.save_fn is not None: self.profiles.save(self.save_fn)
         return self.profiles
+
+    def profile(self, params=None, size=30, cl=2., max_iterations=100, xtol=1e-7, ftol=1e-9):
+        """1D profiles (profilers/base.py ``profile``): for ``size`` values of each parameter within ``cl`` errors of the best fit, the posterior maximised over all the
+        OTHER parameters -- every grid point of every profiled parameter is a row of the same Levenberg-Marquardt batch.  Needs :meth:`maximize` first.  Fills and
+        returns ``profiles.profile``: name -> array [size, 2] of (value, maximised log-posterior)."""
+        if self.profiles is None: raise ValueError('run maximize first')
+        names = [param.name for param in self.params]
+        params = names if params is None else [str(name) for name in (params if isinstance(params, (list, tuple)) else [params])]
+        best = self.profiles.choice()
+        center = np.array([best[name] for name in names])
+        index = self.profiles.argmax()
+        lower = np.array([param.prior.limits[0] for param in self.params], dtype='f8')
+        upper = np.array([param.prior.limits[1] for param in self.params], dtype='f8')
+        starts, free, grids = [], [], {}
+        for name in params:
+            ip = names.index(name)
+            error = float(self.profiles.error[name][index])
+            grid = np.linspace(max(center[ip] - cl * error, lower[ip]), min(center[ip] + cl * error, upper[ip]), size)
+            if np.isfinite(lower[ip]) and grid[0] <= lower[ip]: grid[0] = lower[ip] + 1e-9 * error
+            if np.isfinite(upper[ip]) and grid[-1] >= upper[ip]: grid[-1] = upper[ip] - 1e-9 * error
+            grids[name] = grid
+            block = np.tile(center, (size, 1))
+            block[:, ip] = grid
+            # the other parameters start on the Gaussian ridge of the best fit: x_j = x^_j + C_jp / C_pp (x_p - x^_p)
+            cov = self.profiles.covariance[1]
+            if np.isfinite(cov).all() and cov[ip, ip] > 0.:
+                block += np.outer(grid - center[ip], cov[:, ip] / cov[ip, ip]) * (np.arange(len(names)) != ip)
+                block = np.clip(block, np.where(np.isfinite(lower), lower + 1e-12, -np.inf), np.where(np.isfinite(upper), upper - 1e-12, np.inf))
+                block[:, ip] = grid
+            mask = np.ones((size, len(names)), dtype='?'); mask[:, ip] = False
+            starts.append(block); free.append(mask)
+        x, f, g, H, iterations, converged = levenberg_marquardt(self._evaluate, np.concatenate(starts), lower, upper, max_iterations=max_iterations, xtol=xtol, ftol=ftol,
+                                                                free=np.concatenate(free))
+        self.profiles.profile = getattr(self.profiles, 'profile', None) or {}
+        for iname, name in enumerate(params):
+            self.profiles.profile[name] = np.column_stack([grids[name], f[iname * size:(iname + 1) * size]])
+        return self.profiles.profile
+
+    def interval(self, params=None, cl=1., size=30):
+        """Lower and upper limits where the profile drops by ``cl^2 / 2`` below the maximum (profilers/base.py ``interval``; from :meth:`profile`, by linear interpolation
+        between grid points).  Returns and stores ``profiles.interval``: name -> (lower - bestfit, upper - bestfit); ``nan`` where the profile does not reach the level."""
+        profile = self.profile(params=params, size=size, cl=2. * cl + 1.)
+        best = self.profiles.choice()
+        self.profiles.interval = getattr(self.profiles, 'interval', None) or {}
+        for name, table in profile.items():
+            values, logp = table[:, 0], table[:, 1]
+            level = best['logposterior'] - 0.5 * cl**2
+            limits = []
+            for side in (values < best[name], values > best[name]):
+                v, l = values[side], logp[side]
+                order = np.argsort(np.abs(v - best[name]))
+                v, l = np.concatenate([[best[name]], v[order]]), np.concatenate([[best['logposterior']], l[order]])
+                below = np.flatnonzero(l < level)
+                if not below.size: limits.append(np.nan); continue
+                i = below[0]
+                limits.append(v[i - 1] + (level - l[i - 1]) / (l[i] - l[i - 1]) * (v[i] - v[i - 1]) - best[name])
+            self.profiles.interval[name] = tuple(limits)
+        return self.profiles.interval

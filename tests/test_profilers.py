@@ -33,6 +33,25 @@ def test_levenberg_marquardt_on_analytic_problems():
         levenberg_marquardt(lambda p: (np.full(len(p), np.nan), np.zeros((len(p), 2)), np.tile(np.eye(2), (len(p), 1, 1))), np.zeros((1, 2)), np.full(2, -1.), np.full(2, 1.))
 
 
+def test_profile_of_a_gaussian_is_its_marginal_parabola():
+    """Coordinates held fixed (profiles along a parameter): the maximum over the others of a correlated Gaussian is the parabola of the marginal variance."""
+    from desilike_amd.profilers import levenberg_marquardt
+    cov = np.array([[1., 0.8, 0.1], [0.8, 2., 0.3], [0.1, 0.3, 0.5]])
+    prec, mean = np.linalg.inv(cov), np.array([0.3, -1., 2.])
+
+    def evaluate(points):
+        d = points - mean
+        return -0.5 * np.einsum('ij,jk,ik->i', d, prec, d), -d.dot(prec), np.tile(prec, (len(points), 1, 1))
+
+    grid = np.linspace(-2., 2., 9)
+    start = np.tile(mean + 0.2, (9, 1)); start[:, 0] = mean[0] + grid
+    free = np.ones((9, 3), dtype='?'); free[:, 0] = False
+    x, f, g, H, iterations, converged = levenberg_marquardt(evaluate, start, np.full(3, -np.inf), np.full(3, np.inf), free=free)
+    assert converged.all() and np.array_equal(x[:, 0], start[:, 0])
+    assert np.allclose(f, -0.5 * grid**2 / cov[0, 0], atol=1e-10)
+    assert np.allclose(x[:, 1:], mean[1:] + np.outer(grid, cov[1:, 0] / cov[0, 0]), atol=1e-6)      # the conditional mean: the ridge
+
+
 @pytest.mark.gpu
 def test_maximum_of_a_likelihood_generated_from_its_theory():
     """config-5 shape (two tracers, 8 parameters), data = theory at known parameters, flat priors: the posterior maximum is there, chi2 = 0."""
@@ -67,6 +86,23 @@ def test_maximum_of_a_likelihood_generated_from_its_theory():
     from desilike_amd.fisher import Fisher
     fisher = Fisher(like2)(**{name: best[name] for name in names})
     assert np.allclose(np.sqrt(np.diag(np.linalg.inv(-fisher._hessian))), errors, rtol=1e-5)
+    # profiles along two parameters and their intervals: near the maximum the posterior is Gaussian in the data, -2 Delta log L = (Delta x / sigma)^2
+    tables = profiler.profile(params=['LRG.b1', 'qpar'], size=9, cl=1.5)
+    for name in ['LRG.b1', 'qpar']:
+        values, logp = tables[name][:, 0], tables[name][:, 1]
+        sigma = profiles.error[name][profiles.argmax()]
+        expected = best['logposterior'] - 0.5 * ((values - best[name]) / sigma)**2
+        assert np.all(logp <= best['logposterior'] + 1e-7)
+        inner = np.abs(values - best[name]) <= 0.4 * sigma
+        assert inner.sum() >= 3 and np.allclose(logp[inner], expected[inner], rtol=0., atol=0.25 * 0.5 * 0.4**2)       # the Gaussian parabola close to the maximum
+        assert np.all(np.diff(logp[values <= best[name]]) > 0.) and np.all(np.diff(logp[values >= best[name]]) < 0.)  # one maximum
+        # maximised over the others >= the slice with the others kept at the best fit
+        points = np.tile(got, (len(values), 1)); points[:, names.index(name)] = values
+        assert np.all(logp >= profiler.logposterior(points) - 1e-8)
+    intervals = profiler.interval(params=['LRG.b1'], cl=1., size=13)
+    lo, hi = intervals['LRG.b1']
+    sigma = profiles.error['LRG.b1'][profiles.argmax()]
+    assert -2. * sigma < lo < -0.5 * sigma and 0.5 * sigma < hi < 2. * sigma, (lo, hi, sigma)
     # the profiles seed a Metropolis-Hastings sampler's proposal
     from desilike_amd.samplers import MCMCSampler
     sampler = MCMCSampler(like2, chains=4, covariance=profiles, seed=1, learn=False)
