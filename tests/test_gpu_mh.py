@@ -246,3 +246,19 @@ def test_edge_shapes_on_the_device_equal_the_host_driver(keep, blocks, vectorize
     assert a['fweight'].size > 5 and np.array_equal(a['fweight'], b['fweight'])
     for name in keep: assert np.allclose(a[name], b[name], rtol=1e-11, atol=1e-13)
     assert np.allclose(a['logposterior'], b['logposterior'], rtol=1e-10, atol=1e-9)
+
+
+def test_sampler_resumes_device_chains_from_files(tmp_path):
+    """save -> a NEW sampler built from the files -> run: the continuation is what the uninterrupted run gives (positions, weights, counters and the key of the
+    counter-based draws travel in the files; the device sampler receives them before its first try)."""
+    from desilike_amd.samplers import MCMCSampler
+    _, _, _, cov, start = _setup(3)
+    kw = dict(vectorize=4, seed=8, learn=False, covariance=cov)
+    a = MCMCSampler(make_cfg5()[1], chains=3, save_fn=str(tmp_path / 'mh_*.npy'), **kw)
+    a.run(check_every=40, max_iterations=40, start=start)
+    b = MCMCSampler(make_cfg5()[1], chains=[str(tmp_path / 'mh_{:d}.npy'.format(i)) for i in range(3)], learn=False)
+    assert b.device_resident and b._tries == 40 and b.counter_seed == a.counter_seed and np.allclose(b.covariance, cov)
+    a.save_fn = None
+    ca, cb = a.run(check_every=30, max_iterations=30), b.run(check_every=30, max_iterations=30)
+    for x, y in zip(ca, cb):
+        assert x['fweight'].size > 8 and np.array_equal(x['fweight'], y['fweight']) and np.array_equal(x['qpar'], y['qpar']) and np.array_equal(x['logposterior'], y['logposterior'])
