@@ -67,7 +67,12 @@ def levenberg_marquardt(evaluate, start, lower, upper, max_iterations=100, xtol=
         candidates, scaled = np.empty((index.size, P)), np.empty(index.size)
         for slot, s in enumerate(index):
             diag = np.maximum(np.diag(H[s]), 1e-300)
-            m = free[s]
+            # moving coordinates: the free ones, minus those that sit on a bound with the gradient pointing outwards (active set: solving for them and clipping the
+            # step would distort the step of the others and stall the iteration against the bound)
+            m = free[s] & ~(((x[s] <= lo) & (g[s] < 0.)) | ((x[s] >= hi) & (g[s] > 0.)))
+            if not m.any():
+                candidates[slot], scaled[slot] = x[s], 0.
+                continue
             step = np.zeros(P)
             step[m] = np.linalg.solve((H[s] + lam[s] * np.diag(diag))[np.ix_(m, m)], g[s][m])      # (H + lam diag H) step = gradient, in the moving coordinates
             candidates[slot] = np.where(m, np.clip(x[s] + step, lo, hi), x[s])
@@ -195,6 +200,40 @@ class GaussNewtonProfiler(BasePosteriorSampler):
         for iname, name in enumerate(params):
             self.profiles.profile[name] = np.column_stack([grids[name], f[iname * size:(iname + 1) * size]])
         return self.profiles.profile
+
+    def grid(self, params, size=10, cl=2., max_iterations=100, xtol=1e-7, ftol=1e-9):
+        """Best fits on a tensor grid of ``params`` (profilers/base.py ``grid``): ``size`` values per parameter within ``cl`` errors of the best fit, the posterior
+        maximised over all the other parameters at every grid point -- the whole grid is one Levenberg-Marquardt batch (two parameters: the surface whose level lines
+        are the confidence contours).  Fills and returns ``profiles.grid``: (list of the grid axes, maximised log-posterior of shape [size] * len(params))."""
+        if self.profiles is None: raise ValueError('run maximize first')
+        names = [param.name for param in self.params]
+        params = [str(name) for name in (params if isinstance(params, (list, tuple)) else [params])]
+        sizes = [int(size)] * len(params) if np.ndim(size) == 0 else [int(n) for n in size]
+        best, index = self.profiles.choice(), self.profiles.argmax()
+        center = np.array([best[name] for name in names])
+        lower = np.array([param.prior.limits[0] for param in self.params], dtype='f8')
+        upper = np.array([param.prior.limits[1] for param in self.params], dtype='f8')
+        columns, axes = [names.index(name) for name in params], []
+        for ip, n, name in zip(columns, sizes, params):
+            error = float(self.profiles.error[name][index])
+            axis = np.linspace(max(center[ip] - cl * error, lower[ip]), min(center[ip] + cl * error, upper[ip]), n)
+            if np.isfinite(lower[ip]) and axis[0] <= lower[ip]: axis[0] = lower[ip] + 1e-9 * error
+            if np.isfinite(upper[ip]) and axis[-1] >= upper[ip]: axis[-1] = upper[ip] - 1e-9 * error
+            axes.append(axis)
+        mesh = np.stack(np.meshgrid(*axes, indexing='ij'), axis=-1).reshape(-1, len(params))
+        start = np.tile(center, (mesh.shape[0], 1))
+        start[:, columns] = mesh
+        cov = self.profiles.covariance[1]
+        if np.isfinite(cov).all():
+            # the other parameters start on the Gaussian ridge: x_o = x^_o + C_og C_gg^-1 (x_g - x^_g)
+            others = [i for i in range(len(names)) if i not in columns]
+            if others:
+                shift = np.linalg.solve(cov[np.ix_(columns, columns)], (mesh - center[columns]).T).T.dot(cov[np.ix_(columns, others)])
+                start[:, others] = np.clip(center[others] + shift, np.where(np.isfinite(lower[others]), lower[others] + 1e-12, -np.inf), np.where(np.isfinite(upper[others]), upper[others] - 1e-12, np.inf))
+        free = np.ones(start.shape, dtype='?'); free[:, columns] = False
+        x, f, g, H, iterations, converged = levenberg_marquardt(self._evaluate, start, lower, upper, max_iterations=max_iterations, xtol=xtol, ftol=ftol, free=free)
+        self.profiles.grid = (axes, f.reshape(sizes))
+        return self.profiles.grid
 
     def interval(self, params=None, cl=1., size=30):
         """Lower and upper limits where the profile drops by ``cl^2 / 2`` below the maximum (profilers/base.py ``interval``; from :meth:`profile`, by linear interpolation

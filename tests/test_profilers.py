@@ -103,6 +103,12 @@ def test_maximum_of_a_likelihood_generated_from_its_theory():
     lo, hi = intervals['LRG.b1']
     sigma = profiles.error['LRG.b1'][profiles.argmax()]
     assert -2. * sigma < lo < -0.5 * sigma and 0.5 * sigma < hi < 2. * sigma, (lo, hi, sigma)
+    # a two-parameter grid: nothing above the maximum, the highest cell is the one next to the best fit, its maxima along one axis are the 1D profile of the other
+    axes, surface = profiler.grid(['LRG.b1', 'qpar'], size=5, cl=1.)
+    nearest = tuple(int(np.argmin(np.abs(axis - best[name]))) for axis, name in zip(axes, ['LRG.b1', 'qpar']))
+    assert surface.shape == (5, 5) and np.all(surface <= best['logposterior'] + 1e-7) and tuple(int(i) for i in np.unravel_index(np.argmax(surface), surface.shape)) == nearest
+    line = profiler.profile(params=['LRG.b1'], size=5, cl=1.)['LRG.b1']
+    assert np.allclose(axes[0], line[:, 0]) and np.allclose(surface.max(axis=1), line[:, 1], atol=0.06)      # (a grid of 5 values of the other parameter against its continuum)
     # the profiles seed a Metropolis-Hastings sampler's proposal
     from desilike_amd.samplers import MCMCSampler
     sampler = MCMCSampler(like2, chains=4, covariance=profiles, seed=1, learn=False)
