@@ -2,5 +2,6 @@ from .window import (WindowedPowerSpectrumMultipoles, window_matrix_bininteg, Sy
                      TopHatFiberCollisionsPowerSpectrumMultipoles)
 from .power_spectrum import TracerPowerSpectrumMultipolesObservable
 from .correlation_function import (WindowedCorrelationFunctionMultipoles, TracerCorrelationFunctionMultipolesObservable,
-                                   SystematicTemplateCorrelationFunctionMultipoles)
+                                   SystematicTemplateCorrelationFunctionMultipoles, TopHatFiberCollisionsCorrelationFunctionMultipoles,
+                                   FiberCollisionsCorrelationFunctionMultipoles)
 from .covariance import ObservablesCovarianceMatrix, BoxFootprint, CutskyFootprint, BaseFootprint

@@ -17,6 +17,101 @@ class SystematicTemplateCorrelationFunctionMultipoles(SystematicTemplatePowerSpe
         return np.linspace(20., 200, 101)
 
 
+def _legendre_pair_primitive(*ells):
+    """Primitive F(mu) of the product of the Legendre polynomials of orders ``ells`` (numpy polynomial, highest power first)."""
+    from numpy.polynomial import legendre as npleg
+    poly = np.array([1.])
+    for ell in ells:
+        coeffs = np.zeros(int(ell) + 1); coeffs[-1] = 1.
+        poly = np.polymul(poly, npleg.leg2poly(coeffs)[::-1])
+    return np.polyint(poly)
+
+
+def _integral_beyond(primitive, mu_min):
+    """Integral over |mu| > mu_min, mu in [-1, 1], of the polynomial whose primitive is ``primitive``."""
+    F = lambda mu: np.polyval(primitive, mu)
+    return F(1.) - F(mu_min) + F(-mu_min) - F(-1.)
+
+
+class TopHatFiberCollisionsCorrelationFunctionMultipoles(BaseCalculator):
+    r"""Fiber collisions in configuration space (Hahn et al. 2016, arXiv:1609.01714; reference: window.py:1192-1250): a fraction ``fs`` of the pairs with transverse
+    separation below ``Dfc`` is lost -- at separation s these are the pairs with :math:`|\mu| > \mu_{min}(s) = \sqrt{1 - (D_{fc} / s)^2}`.  The multipoles mix at fixed s:
+
+    .. math:: \xi^{fc}_\ell(s) = \sum_{\ell'} \Big[\delta_{\ell\ell'} - f_s \frac{2 \ell + 1}{2} \int_{|\mu| > \mu_{min}} L_\ell L_{\ell'} d\mu\Big] \xi_{\ell'}(s)
+              - f_s \frac{2 \ell + 1}{2} \int_{|\mu| > \mu_{min}} L_\ell d\mu
+
+    Init-time constants only: ``kernel_correlated [n_ell, n_ellin, n_s]``, ``kernel_uncorrelated [n_ell, n_s]`` (exact polynomial integrals); the window folds them into its
+    matrix and offset (window.py:688-706).  ``mu_range_cut``: divide by the uncut range of mu (window.py:1243-1245)."""
+
+    def _segments(self):
+        """[(weight, transverse scale)]: the pair-loss function as a sum of top hats; here one."""
+        return [(self.fs, np.array([0., self.Dfc]))]
+
+    def _read_kernel(self, init):
+        self.fs, self.Dfc = float(init.get('fs', 1.)), float(init.get('Dfc', 0.))
+        self.mu_range_cut = bool(init.get('mu_range_cut', False))
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        init = self.init
+        self.ells = tuple(init.get('ells', (0, 2, 4)))
+        theory = init.get('theory', None)
+        if theory is None:
+            from ...theories.galaxy_clustering import KaiserTracerCorrelationFunctionMultipoles
+            theory = KaiserTracerCorrelationFunctionMultipoles()
+        self.theory = theory
+        if init.get('s', None) is not None: theory.init.update(s=np.asarray(init['s'], dtype='f8'))
+        theory.initialize()
+        self.s, self.ellsin = np.array(theory.s, dtype='f8'), tuple(theory.ells)
+        self.sin = self.s
+        self.with_uncorrelated = bool(init.get('with_uncorrelated', True))
+        self._read_kernel(init)
+
+        def lost(*ells):   # sum over the top hats of weight x [pairs beyond mu_min(outer edge) - pairs beyond mu_min(inner edge)]
+            primitive, total = _legendre_pair_primitive(*ells), 0.
+            for weight, edges in self._segments():
+                mu_min = np.sqrt(np.clip(1. - (edges[:, None] / self.s)**2, 0., None))
+                beyond = _integral_beyond(primitive, mu_min)
+                total = total + weight * (beyond[1] - beyond[0])
+            return total
+
+        self.kernel_uncorrelated = -np.array([(2. * ell + 1.) / 2. * lost(ell) for ell in self.ells])
+        kernels = np.empty((len(self.ells), len(self.ellsin), self.s.size), dtype='f8')
+        for iout, ellout in enumerate(self.ells):
+            for iin, ellin in enumerate(self.ellsin):
+                kernels[iout, iin] = float(ellin == ellout) - (2. * ellout + 1.) / 2. * lost(ellout, ellin)
+                if getattr(self, 'mu_range_cut', False):
+                    mu_min = np.sqrt(np.clip(1. - (self.Dfc / self.s)**2, 0., None))
+                    kernels[iout, iin][mu_min > 0.] /= mu_min[mu_min > 0.]
+        self.kernel_correlated = kernels
+        self._initialized = True
+        return self
+
+
+class FiberCollisionsCorrelationFunctionMultipoles(TopHatFiberCollisionsCorrelationFunctionMultipoles):
+    """The same with a pair-loss function tabulated in transverse separation: ``kernel`` (the fraction of pairs lost) at ``sep``, read as a sum of top hats -- one per
+    interval of ``sep``, at the mean of the two tabulated values (reference: window.py:1132-1189).  As in the reference, a table that does not start at ``sep = 0`` is
+    extended down to 0 with its first value, and the number of intervals used stays that of the table as given (window.py:865-875, 1162-1166)."""
+
+    def _read_kernel(self, init):
+        sep, kernel = np.array(init['sep'], dtype='f8'), np.array(init['kernel'], dtype='f8')
+        self._nsegments = sep.size - 1
+        if kernel.size == 1: kernel = np.full_like(sep, kernel.flat[0])
+        if sep[0] > 0.: sep, kernel = np.insert(sep, 0, 0.), np.insert(kernel, 0, kernel[0])
+        self.sep, self.kernel = sep, kernel
+        self.mu_range_cut = False
+
+    def _segments(self):
+        return [(0.5 * (self.kernel[i] + self.kernel[i + 1]), self.sep[i:i + 2]) for i in range(self._nsegments)]
+
+    def to_tophat(self):
+        """The top hat with the same lost fraction and first moment (window.py:1186-1189)."""
+        fs = np.trapezoid(self.kernel, x=self.sep) / np.trapezoid(self.sep, x=self.sep)
+        Dfc = 2. * np.trapezoid(self.sep * self.kernel, x=self.sep) / np.trapezoid(self.kernel, x=self.sep)
+        return TopHatFiberCollisionsCorrelationFunctionMultipoles(s=self.s, ells=self.ells, theory=self.theory, fs=fs, Dfc=Dfc)
+
+
 class WindowedCorrelationFunctionMultipoles(BaseCalculator):
     """Window (binning) effect on correlation function multipoles: ``slim``, ``s``, ``sedges``, ``ells``,
     ``wmatrix`` (None, ``{'resolution': n}`` or 2D array with ``sin``, ``ellsin``), ``theory`` -- same meaning as the reference's."""
@@ -50,6 +145,20 @@ class WindowedCorrelationFunctionMultipoles(BaseCalculator):
             self.matrix_full = np.array(wmatrix, dtype='f8').T
         else:
             raise ValueError('unrecognized wmatrix {}'.format(wmatrix))
+        fiber_collisions = init.get('fiber_collisions', None)
+        if fiber_collisions is not None:   # window.py:688-706: xi -> K xi + u at every input separation, then the window
+            self.theory.init.update(s=self.sin, ells=self.ellsin)
+            fiber_collisions.init.update(ells=self.ellsin, theory=self.theory, s=self.sin)
+            fiber_collisions.initialize()
+            kc = fiber_collisions.kernel_correlated
+            kernel = np.block([[np.diag(kc[iout, iin]) for iin in range(kc.shape[1])] for iout in range(kc.shape[0])])
+            uncorrelated = fiber_collisions.kernel_uncorrelated.ravel() if fiber_collisions.with_uncorrelated else None
+            if self.matrix_full is None:
+                self.offset, self.matrix_full = uncorrelated, kernel
+            else:
+                if uncorrelated is not None: self.offset = self.matrix_full.dot(uncorrelated)
+                self.matrix_full = self.matrix_full.dot(kernel)
+        self.fiber_collisions = fiber_collisions
         systematic_templates = init.get('systematic_templates', None)
         if systematic_templates is not None:   # window.py:697-701
             if not isinstance(systematic_templates, SystematicTemplateCorrelationFunctionMultipoles):
