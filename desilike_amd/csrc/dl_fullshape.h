@@ -92,6 +92,8 @@ struct DlObsDev {
     double eta, f_fid, a, nd, x0, inv_hx;
     double end0a, end0b, end1a, end1b;  // not-a-knot end relations: M[0] = end0a M[1] + end0b M[2]; M[n-1] = end1a M[n-2] + end1b M[n-3]
     DlInput qpar, qper, qiso, qap, df, dm, dn, sigpar, sigper, b1X, b1Y, sn0;
+    DlInput to_m, to_n, qto, dpto;         // turn-over template (template kind 2): slopes below / above the turn-over, its shift and amplitude (power_template.py:1324-1333)
+    double lkto_fid, lpkto_fid;            // log10 of the fiducial turn-over wavenumber, ln of the fiducial power there
     DlInput ct_in[DL_MAX_EFT][2];
     DlInput sn_in[DL_MAX_EFT];
     // pass-through columns n_in .. n_in + n_pass - 1 of the theory vector: parameters the observable is linear in through a constant
@@ -310,6 +312,14 @@ DL_HD void dl_fs_knots(int tid, int nthr, const DlObsDev& o, const double* th, c
         // power_template.py:749: exp(dm / a * tanh(a * log(k / kp)) + dn * log(k / kp))
         double dm_a = dl_get(o.dm, th) / o.a, dn = dl_get(o.dn, th);
         for (int j = tid; j < n_t; j += nthr) s.y[j] = o.pk_fid[j] * exp(dm_a * o.sf_th[j] + dn * o.sf_lg[j]);
+    } else if (o.templ == 2) {
+        // power_template.py:1326-1333: x = log10 k / log10 k_TO - 1, P = P_TO^(1 - m x^2) where x > 0 (below the turn-over), P_TO^(1 - n x^2) above
+        const double inv_lkto = 1. / (o.lkto_fid + log10(dl_get(o.qto, th))), lp = o.lpkto_fid + log(dl_get(o.dpto, th));
+        const double cm = dl_get(o.to_m, th), cn = dl_get(o.to_n, th);
+        for (int j = tid; j < n_t; j += nthr) {
+            const double x = o.x_t[j] * inv_lkto - 1.;
+            s.y[j] = exp(lp * (1. - (x > 0. ? cm : cn) * (x * x)));
+        }
     } else {
         for (int j = tid; j < n_t; j += nthr) s.y[j] = o.pk_fid[j];
     }

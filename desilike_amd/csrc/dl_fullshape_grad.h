@@ -182,7 +182,7 @@ DL_HD void dl_fs_grad_chain(const DlObsDev& o, const double* th, const double* g
 DL_HD bool dl_fs_grad_applicable(const DlObsDev& o) {
     const bool fast = o.uniform_knots && (o.toeplitz || o.fixed_spline);
     const bool damping = o.sigpar.col >= 0 || o.sigper.col >= 0 || o.sigpar.value != 0. || o.sigper.value != 0.;
-    return o.theory == 0 && fast && !damping && o.n_ct == 0 && o.n_sn == 0 && o.n_pass == 0 && o.n_var == 0 && !o.damping_fid;
+    return o.theory == 0 && o.templ <= 1 && fast && !damping && o.n_ct == 0 && o.n_sn == 0 && o.n_pass == 0 && o.n_var == 0 && !o.damping_fid;   // (templates: fixed / ShapeFit)
 }
 
 // LDS doubles of the gradient workgroup: the forward layout (fast), the per-mu records, the reduction scratch (one row of sums per wavefront; the host emulation

@@ -361,6 +361,7 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         {"sigmapar", &d.sigpar, 0.}, {"sigmaper", &d.sigper, 0.}, {"b1X", &d.b1X, 1.}, {"b1Y", &d.b1Y, 1.}, {"sn0", &d.sn0, 0.},
         {"dbeta", &d.dbeta, 1.}, {"sigmas", &d.sigmas, 0.}, {"dres", &d.dres, 1.},
         {"sigmav", &d.sigmav, 0.}, {"b2", &d.b2, 0.}, {"bs", &d.bs, 0.}, {"b3", &d.b3, 0.},
+        {"m", &d.to_m, 0.6}, {"n", &d.to_n, 0.9}, {"qto", &d.qto, 1.}, {"dpto", &d.dpto, 1.},
         {"fnl_loc", &d.fnl, 0.}, {"pX", &d.pX, 1.}, {"pY", &d.pY, 1.}, {"bphiX", &d.bphiX, 1.}, {"bphiY", &d.bphiY, 1.}, {"sigmasY", &d.sigmasY, 0.}};
     for (auto& it : inputs) {
         *it.in = dl_input_from(cfg, p + "in." + it.name, it.def);
@@ -383,6 +384,12 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         const auto& res = cfg.F(p + "resummed");   // sigma_dd^2, sigma_nl^2, sigma_x^2, shotnoise * sigma_sn^2 (bao.py:186-199)
         for (int q = 0; q < 4; ++q) d.res_sig[q] = q < (int)res.size() ? res[q] : 0.;
     }
+    if (d.templ == 2) {
+        const double kto = cfg.f(p + "kto_fid", 0.), pkto = cfg.f(p + "pkto_fid", 0.);
+        if (!(kto > 0.) || !(pkto > 0.)) { err = p + "turn-over template: kto_fid and pkto_fid must be positive"; return false; }
+        if (d.theory != 0 && d.theory != 1) { err = p + "turn-over template: Kaiser / EFT-like Kaiser / Simple theories only"; return false; }
+        d.lkto_fid = std::log10(kto); d.lpkto_fid = std::log(pkto);
+    } else if (d.templ < 0 || d.templ > 2) { err = p + "unknown template kind"; return false; }
     // template knots in log10 k (full_shape.py:498: interp1d(log10(kap), log10(k11), pk11))
     std::vector<double> x_t(d.n_t), sf_th(d.n_t), sf_lg(d.n_t), lkin(d.n_kin);
     for (int j = 0; j < d.n_t; ++j) {

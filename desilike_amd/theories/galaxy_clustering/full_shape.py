@@ -132,6 +132,7 @@ class KaiserTracerPowerSpectrumMultipoles(BaseCalculator):
     def _input_map(self):
         """kernel input name -> parameter name (+ EFT lists)."""
         toret = {name: name for name in ['qpar', 'qper', 'qiso', 'qap', 'df', 'dm', 'dn', 'sigmapar', 'sigmaper']}
+        toret.update(getattr(self.template, '_extra_inputs', {}))      # inputs of the template's own (turn-over: m, n, qto, dpto)
         toret.update(self._bias_names())
         return toret
 

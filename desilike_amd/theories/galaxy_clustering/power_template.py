@@ -76,6 +76,7 @@ class BasePowerSpectrumTemplate(BaseCalculator):
 
     # names of the kernel inputs this template feeds, mapped to parameter basenames
     _input_names = ['qpar', 'qper', 'qiso', 'qap', 'df', 'dm', 'dn']
+    _extra_inputs = {}      # kernel input -> parameter basename, for templates with inputs of their own
 
 
 class FixedPowerSpectrumTemplate(BasePowerSpectrumTemplate):
@@ -117,3 +118,60 @@ class ShapeFitPowerSpectrumTemplate(BasePowerSpectrumTemplate):
         self.a = float(self.init.get('a', 0.6))
         self.kp = float(self.init.get('kp', 0.03))
         return super(ShapeFitPowerSpectrumTemplate, self).initialize()
+
+
+def find_turn_over(k, pk):
+    """Turn-over of a tabulated spectrum: vertex of the parabola through the three points around the maximum in (log10 k, log10 P) (the reference's estimate,
+    power_template.py:1205-1220).  Returns the wavenumber; the power there is read off the spectrum itself."""
+    k, pk = np.asarray(k, dtype='f8'), np.asarray(pk, dtype='f8')
+    imax = int(np.argmax(pk))
+    if imax == 0 or imax == k.size - 1: raise ValueError('the maximum of the spectrum sits at the end of its table')
+    x, y = np.log10(k[imax - 1:imax + 2]), np.log10(pk[imax - 1:imax + 2])
+    # Lagrange form of the parabola: y(t) = sum_i y_i prod_{j != i} (t - x_j) / (x_i - x_j); its vertex
+    w = np.array([y[0] / ((x[0] - x[1]) * (x[0] - x[2])), y[1] / ((x[1] - x[0]) * (x[1] - x[2])), y[2] / ((x[2] - x[0]) * (x[2] - x[1]))])
+    curvature = w.sum()
+    if not curvature < 0.: raise ValueError('no maximum between the three highest points')
+    vertex = (w[0] * (x[1] + x[2]) + w[1] * (x[0] + x[2]) + w[2] * (x[0] + x[1])) / (2. * curvature)
+    return 10.**vertex
+
+
+class TurnOverPowerSpectrumTemplate(BasePowerSpectrumTemplate):
+    r"""Turn-over template (power_template.py:1293-1340; arXiv:2302.07484): the spectrum around its maximum as two half-parabolas in log-log,
+
+    .. math:: P(k) = P_{TO}^{1 - m x^2} \; (x > 0), \quad P_{TO}^{1 - n x^2} \; (x \le 0), \qquad x = \log_{10} k / \log_{10} k_{TO} - 1,
+
+    with :math:`k_{TO} = q_{TO} k_{TO}^{fid}`, :math:`P_{TO} = dp_{TO} P_{TO}^{fid}`, ``f = f_fid df`` and the single Alcock-Paczynski parameter ``qap``.  The fiducial
+    turn-over is found on the fiducial spectrum (:func:`find_turn_over`), or given: ``kTO_fid``, ``pkTO_dd_fid``."""
+    _kind = 2  # DL_TEMPLATE_TURNOVER
+    _own_params = {'m': dict(value=0.57, prior=dict(limits=[-1., 10.]), ref=dict(limits=[0., 1.]), delta=0.01, latex='m'),
+                   'n': dict(value=0.89, prior=dict(limits=[0., 10.]), ref=dict(limits=[0.5, 1.]), delta=0.01, latex='n'),
+                   'dpto': dict(value=1., fixed=True, prior=dict(limits=[0., 2.]), ref=dict(limits=[0.9, 1.1]), delta=0.01, latex=r'(P / P^{\mathrm{fid}})(k_{\mathrm{TO}})'),
+                   'qto': dict(value=1., prior=dict(limits=[0.5, 1.5]), ref=dict(limits=[0.99, 1.01]), delta=0.008, latex=r'q_{\mathrm{TO}}')}
+    _extra_inputs = {'m': 'm', 'n': 'n', 'qto': 'qto', 'dpto': 'dpto'}
+
+    @classmethod
+    def _default_params(cls, **kwargs):
+        # power_template.yaml:424-477: m, n, dpto, qto, qap (fixed), df (fixed)
+        import copy
+        params = copy.deepcopy(cls._own_params)
+        params['qap'] = dict(copy.deepcopy(_AP['qap']), fixed=True)
+        params['df'] = dict(copy.deepcopy(_DF['df']), fixed=True)
+        return params
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        self.init['apmode'] = 'qap'                      # power_template.py:1324
+        super(TurnOverPowerSpectrumTemplate, self).initialize()
+        kTO, pkTO = self.init.get('kTO_fid', None), self.init.get('pkTO_dd_fid', None)
+        if kTO is None:
+            grid = np.geomspace(1e-4, 10., 1201)
+            kTO = find_turn_over(grid, self.fiducial.pk_dd(grid))
+        if pkTO is None: pkTO = float(np.ravel(self.fiducial.pk_dd(np.array([kTO])))[0])
+        self.kTO_fid, self.pkTO_dd_fid = float(kTO), float(pkTO)
+        return self
+
+    def _template_spec(self):
+        spec = super(TurnOverPowerSpectrumTemplate, self)._template_spec()
+        spec.update(kto_fid=[self.kTO_fid], pkto_fid=[self.pkTO_dd_fid])
+        return spec

@@ -53,6 +53,8 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
 /* enumerations used as values of integer config keys */
 #define DL_TEMPLATE_FIXED     0   /* Fixed / Standard / BAO templates: fiducial table, only f = f_fid * df varies (power_template.py:198-202, 592-596, 372-376) */
 #define DL_TEMPLATE_SHAPEFIT  1   /* power_template.py:747-761 */
+#define DL_TEMPLATE_TURNOVER  2   /* power_template.py:1324-1333: P(k) = P_TO^(1 - m x^2) below the turn-over, P_TO^(1 - n x^2) above, x = log10 k / log10 k_TO - 1; keys
+                                   * "kto_fid", "pkto_fid" (fiducial turn-over), inputs "in.m", "in.n", "in.qto", "in.dpto"; Kaiser-type theories */
 #define DL_THEORY_KAISER      0   /* full_shape.py:488-500, 545-550 */
 #define DL_THEORY_EFT_KAISER  1   /* + counter / stochastic terms full_shape.py:628-634 */
 #define DL_THEORY_BAO_DAMPED  2   /* damped BAO wiggles, 'standard' model bao.py:117-140 (+ broadband terms as pass-through columns, bao.py:495-534, 881-905) */

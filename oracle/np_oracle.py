@@ -63,6 +63,13 @@ def ap_k_mu(k, mu, qpar=1., qper=1.):
 # ----------------------------------------------------------------------------------------------
 # a2: templates                                 power_template.py:747-761, 592-596, 372-376, 198-202
 # ----------------------------------------------------------------------------------------------
+def turnover_pk(k, kTO_fid, pkTO_fid, m=0.6, n=0.9, qto=1., dpto=1.):
+    """power_template.py:1326-1333: x = log10 k / log10 k_TO - 1; P_TO^(1 - m x^2) where x > 0, P_TO^(1 - n x^2) elsewhere."""
+    kTO, pkTO = kTO_fid * qto, pkTO_fid * dpto
+    x = np.log10(k) / np.log10(kTO) - 1.
+    return np.where(x > 0., pkTO**(1. - m * x**2), pkTO**(1. - n * x**2))
+
+
 def shapefit_factor(k, kp, a, dm=0., dn=0.):
     """power_template.py:749: exp(dm / a tanh(a ln(k / kp)) + dn ln(k / kp))."""
     return np.exp(dm / a * np.tanh(a * np.log(k / kp)) + dn * np.log(k / kp))
@@ -490,6 +497,8 @@ def fullshape_observable(c, p):
     if c['template'] == 'shapefit':
         factor = shapefit_factor(k11, c['kp'], c['a'], dm=p.get('dm', 0.), dn=p.get('dn', 0.))
         pk11 = c['pk_dd_fid'] * factor
+    elif c['template'] == 'turnover':
+        pk11 = turnover_pk(k11, c['kTO_fid'], c['pkTO_dd_fid'], m=p.get('m', 0.6), n=p.get('n', 0.9), qto=p.get('qto', 1.), dpto=p.get('dpto', 1.))
     else:  # fixed / standard / bao: power_template.py:107-108
         pk11 = c['pk_dd_fid']
     f = c['f_fid'] * p.get('df', 1.)

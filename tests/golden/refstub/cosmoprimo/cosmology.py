@@ -21,6 +21,7 @@ class SyntheticPk(object):
             import os
             A = 2.5e4 * float(os.environ.get('REFSTUB_PK_SCALE', '1'))
         self.A, self.n_s, self.keq, self.rs, self.wiggle, self.scale = A, n_s, keq, rs, wiggle, scale
+        self.k = np.geomspace(1e-4, 10., 1201)      # tabulation grid of an interpolator (read by the reference's turn-over finder, power_template.py:1205-1220)
 
     def clone(self, **kwargs):
         state = dict(A=self.A, n_s=self.n_s, keq=self.keq, rs=self.rs, wiggle=self.wiggle, scale=self.scale)

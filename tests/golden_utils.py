@@ -26,7 +26,7 @@ def load_golden(name):
 def observable_constants(g, iobs=0):
     """Oracle-side constants dict of observable ``iobs`` from a golden fixture."""
     c = dict(g['obs{:d}'.format(iobs)])
-    c['template'] = {'ShapeFitPowerSpectrumTemplate': 'shapefit'}.get(c['template'], 'fixed')
+    c['template'] = {'ShapeFitPowerSpectrumTemplate': 'shapefit', 'turnover': 'turnover'}.get(str(c['template']), 'fixed')
     c['ellsin'] = tuple(int(ell) for ell in c['ellsin'])
     c['ells'] = tuple(int(ell) for ell in c['ells'])
     return c
