@@ -150,7 +150,7 @@ def fill_config(spec, set_f64, set_i32):
                 for okey, ovalue in obs.items():
                     if okey == 'inputs':
                         for name, (col, const) in ovalue.items():
-                            if name in ('ct', 'sn', 'pass', 'x', 'vp', 'ml'):
+                            if name in ('ct', 'sn', 'pass', 'x', 'vp', 'ml', 'band'):
                                 put('obs{:d}.in.{}'.format(iobs, name), np.array([[c, v] for c, v in zip(np.ravel(col), np.ravel(const))], dtype='f8'))
                             else:
                                 put('obs{:d}.in.{}'.format(iobs, name), np.array([col, const], dtype='f8'))

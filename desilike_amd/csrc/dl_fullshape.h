@@ -52,6 +52,7 @@
 #define DL_N_VPARS 11      // velocileptors 'pars': b1 b2 bs b3 alpha0 alpha2 alpha4 alpha6 sn0 sn2 sn4 (full_shape.py:1184)
 #define DL_N_MONO 19       // bias monomials (full_shape.py:1185)
 #define DL_MAX_ML 40       // multiplicative wiggle terms of the flexible BAO model (bao.py:310-322: up to 12 nodes per multipole)
+#define DL_MAX_BAND 16     // bands of the velocity-divergence template
 #define DL_MAX_PASS 32     // pass-through columns: linear (broadband) parameters appended to the theory vector
 #define DL_MAX_SOLVED 16   // analytically solved (marginalised / best-fit) linear parameters
 #define DL_FIR_D 28        // half-width of the convolution that inverts the uniform-knot spline system: |mu|^28 = 1e-16, mu = sqrt(3) - 2
@@ -94,6 +95,10 @@ struct DlObsDev {
     DlInput qpar, qper, qiso, qap, df, dm, dn, sigpar, sigper, b1X, b1Y, sn0;
     DlInput to_m, to_n, qto, dpto;         // turn-over template (template kind 2): slopes below / above the turn-over, its shift and amplitude (power_template.py:1324-1333)
     double lkto_fid, lpkto_fid;            // log10 of the fiducial turn-over wavenumber, ln of the fiducial power there
+    // band template (template kind 3, power_template.py:893-961): P_tt = P_tt_fid (1 + sum_i (dptt_i - 1) tent_i(k)), P_dd = P_tt / f^2
+    int32_t n_band, pad_band;
+    DlInput band_in[DL_MAX_BAND];
+    const double* band_tab;                // [n_band][n_t] tent functions at the knots
     DlInput ct_in[DL_MAX_EFT][2];
     DlInput sn_in[DL_MAX_EFT];
     // pass-through columns n_in .. n_in + n_pass - 1 of the theory vector: parameters the observable is linear in through a constant
@@ -319,6 +324,14 @@ DL_HD void dl_fs_knots(int tid, int nthr, const DlObsDev& o, const double* th, c
         for (int j = tid; j < n_t; j += nthr) {
             const double x = o.x_t[j] * inv_lkto - 1.;
             s.y[j] = exp(lp * (1. - (x > 0. ? cm : cn) * (x * x)));
+        }
+    } else if (o.templ == 3) {
+        // power_template.py:955-961: the fiducial P_tt modulated by the bands, over f^2 = (f_fid df)^2 (pk_fid holds P_tt_fid / f_fid^2)
+        const double df = dl_get(o.df, th), inv_df2 = 1. / (df * df);
+        for (int j = tid; j < n_t; j += nthr) {
+            double factor = 1.;
+            for (int i = 0; i < o.n_band; ++i) factor += (dl_get(o.band_in[i], th) - 1.) * o.band_tab[(size_t)i * n_t + j];
+            s.y[j] = o.pk_fid[j] * factor * inv_df2;
         }
     } else {
         for (int j = tid; j < n_t; j += nthr) s.y[j] = o.pk_fid[j];

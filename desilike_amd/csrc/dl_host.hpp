@@ -63,7 +63,7 @@ struct DlObsHost {
     std::vector<double> bias;     // [n_out]: W . (sn_in (x) 1) + offset[mask] - sn_out        (window.py:459-473)
     std::vector<double> flatdata; // [n_out]
     size_t off_kin, off_lkin, off_mu, off_wmu, off_xt, off_pk, off_th, off_lg, off_ih, off_dlt, off_A, off_nC, off_inv, off_gf, off_gb, off_coef, off_ct, off_sn;
-    size_t off_cw, off_cn, off_pknowk, off_ml, off_pass, off_png = 0;
+    size_t off_cw, off_cn, off_pknowk, off_ml, off_pass, off_png = 0, off_band = 0;
     size_t off_eng[3][6];   // xlo, xinv, weights, center, powers, coef of each emulator engine
     int marg_vp[DL_N_VPARS];
     int marg_pass[DL_MAX_PASS];
@@ -75,7 +75,7 @@ struct DlObsHost {
         dev.ih = base + off_ih; dev.dlt = base + off_dlt; dev.sp_A = base + off_A; dev.sp_nC = base + off_nC; dev.sp_inv = base + off_inv;
         dev.sp_gf = base + off_gf; dev.sp_gb = base + off_gb; dev.coef_fixed = base + off_coef;
         dev.ct_matrix = base + off_ct; dev.sn_matrix = base + off_sn;
-        dev.coef_w = base + off_cw; dev.coef_n = base + off_cn; dev.pknow_k = base + off_pknowk; dev.ml_tab = base + off_ml; dev.pass_tab = base + off_pass; dev.png_alpha = base + off_png;
+        dev.coef_w = base + off_cw; dev.coef_n = base + off_cn; dev.pknow_k = base + off_pknowk; dev.ml_tab = base + off_ml; dev.pass_tab = base + off_pass; dev.png_alpha = base + off_png; dev.band_tab = base + off_band;
         for (int e = 0; e < 3; ++e) {
             dev.eng[e].xlo = base + off_eng[e][0]; dev.eng[e].xinv = base + off_eng[e][1]; dev.eng[e].weights = base + off_eng[e][2];
             dev.eng[e].center = base + off_eng[e][3]; dev.eng[e].powers = base + off_eng[e][4]; dev.eng[e].coef = base + off_eng[e][5];
@@ -313,7 +313,7 @@ inline bool dl_build_emulated_obs(const dl_config& cfg, const std::string& p, in
             if ((int)pass_tab[2 * c] >= n_params) { err = p + "in.pass: theta column out of range"; return false; }
         }
         oh.off_pass = arena.push(pass_tab);
-        oh.off_png = oh.off_pass;
+        oh.off_png = oh.off_pass; oh.off_band = oh.off_pass;
     }
     for (int c = 0; c < DL_MAX_EFT; ++c) { oh.marg_sn[c] = -1; oh.marg_ct[c][0] = oh.marg_ct[c][1] = -1; d.marg_ct_slot[c][0] = d.marg_ct_slot[c][1] = -1; }
     oh.marg_sn0 = -1;
@@ -389,7 +389,18 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         if (!(kto > 0.) || !(pkto > 0.)) { err = p + "turn-over template: kto_fid and pkto_fid must be positive"; return false; }
         if (d.theory != 0 && d.theory != 1) { err = p + "turn-over template: Kaiser / EFT-like Kaiser / Simple theories only"; return false; }
         d.lkto_fid = std::log10(kto); d.lpkto_fid = std::log(pkto);
-    } else if (d.templ < 0 || d.templ > 2) { err = p + "unknown template kind"; return false; }
+    } else if (d.templ == 3) {
+        const auto& bin = cfg.F(p + "in.band");
+        const auto& btab = cfg.F(p + "band_templates");
+        d.n_band = (int)(bin.size() / 2);
+        if (d.n_band < 1 || d.n_band > DL_MAX_BAND) { err = p + "band template: 1 .. 16 bands (in.band)"; return false; }
+        if ((int)btab.size() != d.n_band * d.n_t) { err = p + "band template: band_templates must be [n_band, n_t]"; return false; }
+        if (d.theory != 0 && d.theory != 1) { err = p + "band template: Kaiser / EFT-like Kaiser / Simple theories only"; return false; }
+        for (int i = 0; i < d.n_band; ++i) {
+            d.band_in[i].col = (int)std::lround(bin[2 * i]); d.band_in[i].value = bin[2 * i + 1];
+            if (d.band_in[i].col >= n_params) { err = p + "in.band: theta column out of range"; return false; }
+        }
+    } else if (d.templ < 0 || d.templ > 3) { err = p + "unknown template kind"; return false; }
     // template knots in log10 k (full_shape.py:498: interp1d(log10(kap), log10(k11), pk11))
     std::vector<double> x_t(d.n_t), sf_th(d.n_t), sf_lg(d.n_t), lkin(d.n_kin);
     for (int j = 0; j < d.n_t; ++j) {
@@ -552,6 +563,10 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     oh.off_ml = arena.push(ml_tab);
     oh.off_pass = arena.push(pass_tab);
     oh.off_png = arena.push(png_alpha);
+    {
+        std::vector<double> band_tab = d.templ == 3 ? cfg.F(p + "band_templates") : std::vector<double>(2, 0.);
+        oh.off_band = arena.push(band_tab);
+    }
 
     for (int c = 0; c < DL_N_VPARS; ++c) { oh.marg_vp[c] = -1; d.vp_slot[c] = -1; }
     for (int e = 0; e < 3; ++e) { d.eng[e].type = -1; for (int q = 0; q < 6; ++q) oh.off_eng[e][q] = oh.off_kin; }

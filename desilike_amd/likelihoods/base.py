@@ -286,6 +286,9 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
                 if iname == 'ct':
                     res = [[resolve(pn, 0.) for pn in pair] for pair in pname]
                     if res: inputs['ct'] = ([[r[0] for r in pair] for pair in res], [[r[1] for r in pair] for pair in res])
+                elif iname == 'band':   # band template: amplitudes relative to the fiducial (default 1)
+                    res = [resolve(pn, 1.) for pn in pname]
+                    inputs[iname] = ([r[0] for r in res], [r[1] for r in res])
                 elif iname in ('sn', 'pass', 'x', 'ml'):
                     res = [resolve(pn, 0.) for pn in pname]
                     if res: inputs[iname] = ([r[0] for r in res], [r[1] for r in res])
@@ -308,7 +311,7 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
                 if 'vp' in imap: marg['vp'] = [sindex(pn) for pn in imap['vp']]
                 if 'ct' in imap and imap['ct']: marg['ct'] = [[sindex(pn) for pn in pair] for pair in imap['ct']]
                 for iname, pname in imap.items():
-                    if iname in ('x', 'ml') and any(pn in solved_names for pn in pname) or iname not in ('sn0', 'sn', 'ct', 'pass', 'vp', 'x', 'ml') and pname in solved_names:
+                    if iname in ('x', 'ml') and any(pn in solved_names for pn in pname) or iname not in ('sn0', 'sn', 'ct', 'pass', 'vp', 'x', 'ml', 'band') and pname in solved_names:
                         raise PipelineError('parameter {} cannot be solved analytically: the theory is not linear in it'.format(pname))
                 spec['marg'] = marg
             observables.append(spec)

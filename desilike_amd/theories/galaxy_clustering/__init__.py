@@ -1,5 +1,5 @@
 from .power_template import (BasePowerSpectrumTemplate, FixedPowerSpectrumTemplate, StandardPowerSpectrumTemplate,
-                             ShapeFitPowerSpectrumTemplate, BAOPowerSpectrumTemplate, TurnOverPowerSpectrumTemplate, find_turn_over)
+                             ShapeFitPowerSpectrumTemplate, BAOPowerSpectrumTemplate, TurnOverPowerSpectrumTemplate, BandVelocityPowerSpectrumTemplate, find_turn_over)
 from .full_shape import (KaiserTracerPowerSpectrumMultipoles, SimpleTracerPowerSpectrumMultipoles, EFTLikeKaiserTracerPowerSpectrumMultipoles, KaiserTracerCorrelationFunctionMultipoles,
                          EFTLikeKaiserTracerCorrelationFunctionMultipoles, LPTVelocileptorsTracerPowerSpectrumMultipoles,
                          REPTVelocileptorsTracerPowerSpectrumMultipoles, EmulatedTracerPowerSpectrumMultipoles,

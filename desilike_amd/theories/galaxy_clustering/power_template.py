@@ -175,3 +175,65 @@ class TurnOverPowerSpectrumTemplate(BasePowerSpectrumTemplate):
         spec = super(TurnOverPowerSpectrumTemplate, self)._template_spec()
         spec.update(kto_fid=[self.kTO_fid], pkto_fid=[self.pkTO_dd_fid])
         return spec
+
+
+class BandVelocityPowerSpectrumTemplate(BasePowerSpectrumTemplate):
+    r"""Velocity-divergence power spectrum in bands (power_template.py:868-970): around the pivots ``kp`` the fiducial :math:`P_{\theta\theta}` is modulated by tent
+    functions with amplitudes ``dptt0``, ``dptt1``, ... (1 = fiducial), :math:`P_{\theta\theta} = P^{fid}_{\theta\theta} [1 + \sum_i (dptt_i - 1) T_i(k)]`,
+    :math:`P_{dd} = P_{\theta\theta} / (f_{fid} df)^2`; single Alcock-Paczynski parameter ``qap``.
+
+    ``kp``: the pivots, or (first, last) with the number of bands given by ``nbands`` (default: the ``dptt*`` parameters passed in ``params``; the reference counts
+    them in its parameter file).  The fiducial provider gives :math:`P_{dd}`: the fiducial :math:`P_{\theta\theta}` is ``f_fid^2 P_dd`` (linear theory), or pass
+    ``pk_tt_fid`` on ``k``."""
+    _kind = 3  # DL_TEMPLATE_BANDS
+    _base_param_name = 'dptt'
+
+    @classmethod
+    def _default_params(cls, nbands=None, kp=None, **kwargs):
+        import copy
+        if nbands is None: nbands = len(kp) if kp is not None and len(np.atleast_1d(kp)) != 2 else 0
+        params = {'qap': copy.deepcopy(_AP['qap']), 'df': dict(copy.deepcopy(_DF['df']), fixed=True)}
+        for i in range(int(nbands)):
+            params['{}{:d}'.format(cls._base_param_name, i)] = dict(value=1., prior=dict(limits=[0., 3.]), ref=dict(dist='norm', loc=1., scale=0.01), delta=0.005)
+        return params
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        self.init['apmode'] = 'qap'                      # power_template.py:894
+        super(BandVelocityPowerSpectrumTemplate, self).initialize()
+        names = sorted((param.basename for param in self.params if param.basename.startswith(self._base_param_name) and param.basename[len(self._base_param_name):].isdigit()),
+                       key=lambda name: int(name[len(self._base_param_name):]))
+        nkp = len(names)
+        kp = self.init.get('kp', None)
+        if kp is None:
+            if not nkp: raise ValueError('No parameter {}* found'.format(self._base_param_name))
+            step = (self.k[-1] - self.k[0]) / nkp
+            kp = (self.k[0] + step / 2., self.k[-1] - step / 2.)
+        kp = np.array(kp, dtype='f8')
+        if nkp and kp.size == 2: kp = np.linspace(kp[0], kp[1], nkp)
+        if kp.size != nkp: raise ValueError('{:d} (!= {:d} parameters {}*) points have been provided'.format(kp.size, nkp, self._base_param_name))
+        if names != ['{}{:d}'.format(self._base_param_name, i) for i in range(nkp)]: raise ValueError('Found parameters {}, expected {}0 .. {}{:d}'.format(names, self._base_param_name, self._base_param_name, nkp - 1))
+        if kp[0] < self.k[0] or kp[-1] > self.k[-1]: raise ValueError('the pivots must lie inside the theory wavenumbers')
+        self.kp, self._band_names = kp, names
+        # tent functions (power_template.py:931-939)
+        edges = np.concatenate([[self.k[0]], kp, [self.k[-1]]])
+        tents = []
+        for ip, pivot in enumerate(kp):
+            distance = self.k - pivot
+            tents.append(np.maximum(1. - np.where(distance < 0., distance / (edges[ip] - pivot), distance / (edges[ip + 2] - pivot)), 0.))
+        self.templates = np.array(tents)
+        pk_tt_fid = self.init.get('pk_tt_fid', None)
+        self.pk_tt_fid = self.f_fid**2 * self.pk_dd_fid if pk_tt_fid is None else np.asarray(pk_tt_fid, dtype='f8')
+        self.pk_dd_fid = self.pk_tt_fid / self.f_fid**2     # power_template.py:945
+        return self
+
+    @property
+    def _extra_inputs(self):
+        self.initialize()
+        return {'band': list(self._band_names)}
+
+    def _template_spec(self):
+        spec = super(BandVelocityPowerSpectrumTemplate, self)._template_spec()
+        spec.update(band_templates=self.templates)
+        return spec

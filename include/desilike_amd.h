@@ -55,6 +55,8 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
 #define DL_TEMPLATE_SHAPEFIT  1   /* power_template.py:747-761 */
 #define DL_TEMPLATE_TURNOVER  2   /* power_template.py:1324-1333: P(k) = P_TO^(1 - m x^2) below the turn-over, P_TO^(1 - n x^2) above, x = log10 k / log10 k_TO - 1; keys
                                    * "kto_fid", "pkto_fid" (fiducial turn-over), inputs "in.m", "in.n", "in.qto", "in.dpto"; Kaiser-type theories */
+#define DL_TEMPLATE_BANDS     3   /* power_template.py:893-961: P_tt = P_tt_fid (1 + sum_i (dptt_i - 1) tent_i(k)), P_dd = P_tt / (f_fid df)^2; keys "band_templates" [n_band, n_t] (tent
+                                   * functions at the template knots), "in.band" [n_band, 2] (theta column or -1, value); "pk_dd_fid" = P_tt_fid / f_fid^2; Kaiser-type theories */
 #define DL_THEORY_KAISER      0   /* full_shape.py:488-500, 545-550 */
 #define DL_THEORY_EFT_KAISER  1   /* + counter / stochastic terms full_shape.py:628-634 */
 #define DL_THEORY_BAO_DAMPED  2   /* damped BAO wiggles, 'standard' model bao.py:117-140 (+ broadband terms as pass-through columns, bao.py:495-534, 881-905) */

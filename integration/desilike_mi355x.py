@@ -21,7 +21,7 @@ import ctypes
 import numpy as np
 
 # enumerations of include/desilike_amd.h
-DL_TEMPLATE_FIXED, DL_TEMPLATE_SHAPEFIT, DL_TEMPLATE_TURNOVER = 0, 1, 2
+DL_TEMPLATE_FIXED, DL_TEMPLATE_SHAPEFIT, DL_TEMPLATE_TURNOVER, DL_TEMPLATE_BANDS = 0, 1, 2, 3
 DL_THEORY_KAISER, DL_THEORY_EFT_KAISER, DL_THEORY_BAO_DAMPED, DL_THEORY_TNS, DL_THEORY_PNG = 0, 1, 2, 4, 5
 DL_APMODE = {'qparqper': 0, 'qiso': 1, 'qap': 2, 'qisoqap': 3}
 
@@ -124,7 +124,8 @@ def extract_config(likelihood):
             cfg[p + 'tns_mu'], cfg[p + 'tns_wmu'] = x[10:], (w[10:] + w[9::-1]) / 2.
             cfg[p + 'tns_fog'] = np.array([{'lorentzian': 0, 'gaussian': 1}[pt.options['fog']]], dtype='i4')
         turnover = template.__class__.__name__.startswith('TurnOver')      # power_template.py:1293-1340
-        cfg[p + 'template'] = np.array([DL_TEMPLATE_TURNOVER if turnover else DL_TEMPLATE_SHAPEFIT if shapefit and not bao else DL_TEMPLATE_FIXED], dtype='i4')
+        bands = template.__class__.__name__.startswith('BandVelocity')      # power_template.py:868-970
+        cfg[p + 'template'] = np.array([DL_TEMPLATE_BANDS if bands else DL_TEMPLATE_TURNOVER if turnover else DL_TEMPLATE_SHAPEFIT if shapefit and not bao else DL_TEMPLATE_FIXED], dtype='i4')
         if turnover: cfg[p + 'kto_fid'], cfg[p + 'pkto_fid'] = np.array([template.kTO_fid], dtype='f8'), np.array([template.pkTO_dd_fid], dtype='f8')
         cfg[p + 'apmode'] = np.array([_apmode(template)], dtype='i4')
         cfg[p + 'transform'] = np.array([1 if getattr(obs, 'transform', None) == 'cubic' else 0], dtype='i4')
@@ -189,6 +190,10 @@ def extract_config(likelihood):
             for key in ['sigmapar', 'sigmaper']: defaults.pop(key)
             defaults.update(fnl_loc=0., sigmas=0.)
         if turnover: defaults.update(m=0.6, n=0.9, qto=1., dpto=1.)
+        if bands:
+            cfg[p + 'band_templates'] = np.asarray(template.templates, dtype='f8')
+            band_names = [names.get('dptt{:d}'.format(i), 'dptt{:d}'.format(i)) for i in range(len(template.templates))]
+            cfg[p + 'in.band'] = np.array([column(name, value_of(name, 1.)) for name in band_names], dtype='f8')
         if bao: defaults.update(dbeta=1., sigmas=0.)
         else: defaults.update(sn0=0.)
         if xi and not bao: defaults.pop('sn0')                             # no stochastic parameter for correlation functions (full_shape.py:336-364)

@@ -70,6 +70,20 @@ def turnover_pk(k, kTO_fid, pkTO_fid, m=0.6, n=0.9, qto=1., dpto=1.):
     return np.where(x > 0., pkTO**(1. - m * x**2), pkTO**(1. - n * x**2))
 
 
+def band_templates(k, kp):
+    """power_template.py:931-939: tent functions of the theory wavenumbers around the pivots ``kp`` (the first and last wavenumber close the outer tents)."""
+    k, kp = np.asarray(k, dtype='f8'), np.asarray(kp, dtype='f8')
+    ekp = np.concatenate([[k[0]], kp, [k[-1]]])
+    out = []
+    for ip, pivot in enumerate(kp):
+        diff = k - pivot
+        neg = diff < 0
+        diff[neg] /= (ekp[ip] - pivot)
+        diff[~neg] /= (ekp[ip + 2] - pivot)
+        out.append(np.maximum(1. - diff, 0.))
+    return np.array(out)
+
+
 def shapefit_factor(k, kp, a, dm=0., dn=0.):
     """power_template.py:749: exp(dm / a tanh(a ln(k / kp)) + dn ln(k / kp))."""
     return np.exp(dm / a * np.tanh(a * np.log(k / kp)) + dn * np.log(k / kp))
@@ -499,6 +513,9 @@ def fullshape_observable(c, p):
         pk11 = c['pk_dd_fid'] * factor
     elif c['template'] == 'turnover':
         pk11 = turnover_pk(k11, c['kTO_fid'], c['pkTO_dd_fid'], m=p.get('m', 0.6), n=p.get('n', 0.9), qto=p.get('qto', 1.), dpto=p.get('dpto', 1.))
+    elif c['template'] == 'bands':   # power_template.py:955-961: P_tt = P_tt_fid (1 + sum (dptt_i - 1) tent_i), P_dd = P_tt / (f_fid df)^2
+        factor = 1. + (np.asarray(p['dptt'], dtype='f8') - 1.).dot(c['band_templates'])
+        pk11 = c['pk_tt_fid'] * factor / (c['f_fid'] * p.get('df', 1.))**2
     else:  # fixed / standard / bao: power_template.py:107-108
         pk11 = c['pk_dd_fid']
     f = c['f_fid'] * p.get('df', 1.)

@@ -57,7 +57,7 @@ def extract_observable(obs):
         c['pknow_dd_fid'] = np.asarray(template.pknow_dd_fid)
     c['f_fid'] = float(template.f_fid)
     c['template'] = template.__class__.__name__
-    if hasattr(template, 'kp'):
+    if hasattr(template, 'kp') and hasattr(template, 'a'):      # ShapeFit (the band template's ``kp`` are its pivots)
         c['kp'], c['a'] = template.kp, template.a
     c['nd'] = theory.nd
     if wm.matrix_full is not None: c['matrix_full'] = np.asarray(wm.matrix_full)
