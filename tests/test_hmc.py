@@ -77,3 +77,30 @@ def test_hmc_on_the_device_with_the_analytic_gradient():
     assert torch.allclose(la, lf, rtol=1e-12, atol=1e-9)
     scale = torch.as_tensor(np.sqrt(np.diag(sampler.inverse_mass_matrix)), device='cuda:0')
     assert float(((ga - gf) * scale).abs().max()) < 2e-2 * max(1., float((ga * scale).abs().max()))      # (the differences use the parameters' coarse `delta` steps)
+
+
+def _worker(rank, world, port, results):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from desilike_amd.samplers import HMCSampler
+    from desilike_amd.parallel import WalkerSharding
+    like = ToyGaussianLikelihood()
+    sampler = HMCSampler(like, chains=6, seed=4, step_size=0.05, num_integration_steps=6, adaptation={'niterations': 60}, sharding=WalkerSharding(min_shard_rows=0))
+    assert sampler.chain_world == world and sampler.local_chains() == [c for c in range(6) if c % world == rank]
+    chains = sampler.run(check_every=80, max_iterations=160)
+    results[rank] = (np.array([chain['a'] for chain in chains]), sampler.step_size, np.asarray(sampler.inverse_mass_matrix).copy(), sampler.acceptance_rate.copy())
+    dist.destroy_process_group()
+
+
+def test_hmc_chains_over_two_ranks():
+    """Chains distributed over a gloo group of two: every rank ends with every chain, the same step size and mass matrix (averaged after the warm-up)."""
+    import torch.multiprocessing as mp
+    manager = mp.Manager()
+    results = manager.dict()
+    port = 37500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, results), nprocs=2, join=True)
+    a, b = results[0], results[1]
+    assert a[0].shape == (6, 160) and np.array_equal(a[0], b[0])
+    assert a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert 0.5 < a[3].mean() <= 1. and abs(a[0][:, 40:].mean() - 0.5) < 0.1
