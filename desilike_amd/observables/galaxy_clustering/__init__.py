@@ -3,5 +3,5 @@ from .window import (WindowedPowerSpectrumMultipoles, window_matrix_bininteg, Sy
 from .power_spectrum import TracerPowerSpectrumMultipolesObservable
 from .correlation_function import (WindowedCorrelationFunctionMultipoles, TracerCorrelationFunctionMultipolesObservable,
                                    SystematicTemplateCorrelationFunctionMultipoles, TopHatFiberCollisionsCorrelationFunctionMultipoles,
-                                   FiberCollisionsCorrelationFunctionMultipoles)
+                                   FiberCollisionsCorrelationFunctionMultipoles, window_matrix_RR)
 from .covariance import ObservablesCovarianceMatrix, BoxFootprint, CutskyFootprint, BaseFootprint

@@ -33,6 +33,50 @@ def _integral_beyond(primitive, mu_min):
     return F(1.) - F(mu_min) + F(-mu_min) - F(-1.)
 
 
+def window_matrix_RR(soutedges, sedges, muedges, wcounts, ellsin=(0, 2, 4), resolution=1):
+    r"""Window matrix of correlation function multipoles estimated with random-random pair counts ``wcounts [n_s, n_mu]`` on the fine grid ``sedges`` x ``muedges``
+    (reference: window.py:71-138).  Within an output bin (``factor`` fine bins) the estimator weights every fine separation bin by its share of the pairs at each mu, so the
+    measured multipole :math:`\ell` receives the theory multipole :math:`\ell'` through
+
+    .. math:: (2 \ell + 1) \sum_{\mu\,bins} \frac{RR(s, \mu)}{\sum_{s' \in bin} RR(s', \mu)} \int_{\mu\,bin} L_\ell L_{\ell'} d\mu \Big/ \sum_{non-empty} \Delta\mu ,
+
+    followed by the volume-weighted integration of the theory over the fine bins (:func:`window_matrix_bininteg`).  ``soutedges``: dict multipole -> output edges ((low, high) pairs as the
+    reference carries them, or 1D; each starting on a fine edge, widths a multiple of the fine width).  Returns (sin, matrix [n_ellin * n_sin, n_out]) with the theory separations nothing depends on removed."""
+    def pairs(edges):   # (low, high) per bin, as the reference carries edges; a 1D array of edges is accepted
+        edges = np.asarray(edges, dtype='f8')
+        return np.column_stack([edges[:-1], edges[1:]]) if edges.ndim == 1 else edges
+
+    sedges, muedges, wcounts = pairs(sedges), pairs(muedges), np.asarray(wcounts, dtype='f8')
+    sin, binmatrix = window_matrix_bininteg([sedges], resolution=resolution)          # [n_sin, n_fine]
+    dmu = muedges[:, 1] - muedges[:, 0]
+    lines, used = [], np.zeros(sin.size, dtype='?')
+    for ellout, edges in soutedges.items():
+        edges = pairs(edges)
+        first = np.flatnonzero(sedges[:, 0] == edges[0, 0])
+        if not first.size: raise ValueError('output edges {} not found in RR s-edges {}'.format(edges, sedges))
+        first = int(first[0])
+        factor = int(np.rint((edges[0, 1] - edges[0, 0]) / (sedges[first, 1] - sedges[first, 0])))
+        if factor == 0: raise ValueError('s-resolution of RR counts is larger than required output s-binning')
+        line = []
+        for ellin in ellsin:
+            primitive = _legendre_pair_primitive(ellout, ellin)
+            integral = np.polyval(primitive, muedges[:, 1]) - np.polyval(primitive, muedges[:, 0])
+            fine = np.zeros((len(sedges), len(edges)), dtype='f8')
+            for iout in range(len(edges)):
+                rows = slice(first + factor * iout, first + factor * (iout + 1))
+                counts = wcounts[rows]
+                total = counts.sum(axis=0)
+                filled = total != 0.
+                share = counts / np.where(filled, total, 1.)
+                fine[rows, iout] = (2. * ellout + 1.) * np.sum(share * filled * integral, axis=-1) / np.sum(filled * dmu)
+            block = binmatrix.dot(fine)                                                 # [n_sin, n_out of this multipole]
+            used |= np.any(block != 0., axis=1)
+            line.append(block.T)
+        lines.append(line)
+    matrix = np.block([[block[:, used] for block in line] for line in lines])          # [n_out, n_ellin * n_sin kept]
+    return sin[used], matrix.T
+
+
 class TopHatFiberCollisionsCorrelationFunctionMultipoles(BaseCalculator):
     r"""Fiber collisions in configuration space (Hahn et al. 2016, arXiv:1609.01714; reference: window.py:1192-1250): a fraction ``fs`` of the pairs with transverse
     separation below ``Dfc`` is lost -- at separation s these are the pairs with :math:`|\mu| > \mu_{min}(s) = \sqrt{1 - (D_{fc} / s)^2}`.  The multipoles mix at fixed s:
@@ -134,10 +178,12 @@ class WindowedCorrelationFunctionMultipoles(BaseCalculator):
             self.ellsin = tuple(self.ells)
             self.sin, self.smask = bins.input_grid()
         elif isinstance(wmatrix, dict):
-            if 'wcounts' in wmatrix:
-                raise NotImplementedError('RR-count window matrices are out of scope')
-            self.ellsin = tuple(self.ells)
-            self.sin, matrix_full = window_matrix_bininteg(self.sedges, **wmatrix)
+            if 'wcounts' in wmatrix:   # window.py:659-662: Legendre mixing from the mu-distribution of the RR counts
+                self.ellsin = tuple(ellsin or self.ells)
+                self.sin, matrix_full = window_matrix_RR({ell: self.sedges[ill] for ill, ell in enumerate(self.ells)}, ellsin=self.ellsin, **wmatrix)
+            else:
+                self.ellsin = tuple(self.ells)
+                self.sin, matrix_full = window_matrix_bininteg(self.sedges, **wmatrix)
             self.matrix_full = matrix_full.T
         elif isinstance(wmatrix, np.ndarray):   # window.py:667-681: the reference takes the matrix as [input, output] here (transposed w.r.t. P_ell)
             self.ellsin = tuple(ellsin or self.ells)
