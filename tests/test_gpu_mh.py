@@ -262,3 +262,29 @@ def test_sampler_resumes_device_chains_from_files(tmp_path):
     ca, cb = a.run(check_every=30, max_iterations=30), b.run(check_every=30, max_iterations=30)
     for x, y in zip(ca, cb):
         assert x['fweight'].size > 8 and np.array_equal(x['fweight'], y['fweight']) and np.array_equal(x['qpar'], y['qpar']) and np.array_equal(x['logposterior'], y['logposterior'])
+
+
+def test_marginalised_likelihood_on_the_device_equals_the_host_driver():
+    """Analytically marginalised shot-noise terms: the device chains sample the marginalised posterior (the constant of the marginalisation travels as the offset)."""
+    from desilike_amd.samplers import MCMCSampler
+
+    def build():
+        g, like = make_cfg5()
+        like.all_params = {'*.sn0': {'derived': '.marg'}}
+        return like
+
+    a = build()
+    assert len(a.solved_params) == 2 and len(a.varied_params) == 6
+    kw = dict(chains=2, vectorize=3, seed=12, learn=False)
+    dev, host = MCMCSampler(a, **kw), MCMCSampler(build(), device_resident=False, **kw)
+    assert dev.device_resident
+    start = dev._get_start(2)[0]
+    cd, ch = dev.run(check_every=40, max_iterations=40, start=start), host.run(check_every=40, max_iterations=40, start=start)
+    for x, y in zip(cd, ch):
+        assert x['fweight'].size > 4 and np.array_equal(x['fweight'], y['fweight'])
+        assert np.allclose(x['logposterior'], y['logposterior'], rtol=1e-10, atol=1e-8)
+        assert np.allclose(x['qpar'], y['qpar'], rtol=1e-11, atol=1e-13)
+    # the recorded log-posteriors are those of the sampler's own call surface
+    names = a.varied_params.names()
+    points = np.column_stack([cd[0][name] for name in names])
+    assert np.allclose(dev.logposterior(points), cd[0]['logposterior'], rtol=1e-10, atol=1e-8)
