@@ -288,3 +288,24 @@ def test_marginalised_likelihood_on_the_device_equals_the_host_driver():
     names = a.varied_params.names()
     points = np.column_stack([cd[0][name] for name in names])
     assert np.allclose(dev.logposterior(points), cd[0]['logposterior'], rtol=1e-10, atol=1e-8)
+
+
+def test_a_thousand_chains_sample_the_same_posterior_as_the_ensemble_sampler():
+    """Full-size batch (1024 chains = 1024 rows per try): after burn-in the weighted ensemble of the chains' states has the moments the stretch-move sampler finds."""
+    from desilike_amd.samplers import MCMCSampler, EmceeSampler
+    g, like = make_cfg5()
+    names = like.varied_params.names()
+    sampler = MCMCSampler(like, chains=1024, vectorize=1, seed=31)
+    sampler.run(check_every=250, max_iterations=2500)            # the proposal covariance is learnt from the pooled chains after each batch
+    chains = sampler.chains
+    x = np.concatenate([np.column_stack([chain[name] for name in names])[chain['fweight'].size // 2:] for chain in chains if chain is not None])
+    w = np.concatenate([chain['fweight'][chain['fweight'].size // 2:] for chain in chains if chain is not None])
+    assert x.shape[0] > 20000
+    mean = np.average(x, weights=w, axis=0)
+    std = np.sqrt(np.average((x - mean)**2, weights=w, axis=0))
+    ens = EmceeSampler(make_cfg5()[1], nwalkers=64, seed=2)
+    chain = ens.run(niterations=1500)
+    y = np.column_stack([chain[name][500:].ravel() for name in names])
+    assert np.all(np.abs(mean - y.mean(axis=0)) < 0.2 * y.std(axis=0)), (mean - y.mean(axis=0)) / y.std(axis=0)
+    assert np.allclose(std, y.std(axis=0), rtol=0.15), std / y.std(axis=0)
+    assert 0.1 < np.nanmean(sampler.acceptance_rate) < 0.6
