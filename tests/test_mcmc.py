@@ -156,3 +156,19 @@ def test_chains_over_two_ranks_equal_the_single_process_run():
             assert np.array_equal(a, chain['a']) and np.array_equal(w, chain['fweight'])      # every rank holds every chain; chains do not depend on the ranks
         assert np.allclose(cov, single.covariance, rtol=1e-12) and np.allclose(gr, single.diagnostics['eigen_gr'], rtol=1e-10)
     assert results[1][3] < results[0][3] or results[0][3] < 3 * 450 + 50                     # the ranks evaluated their own chains only
+
+
+def test_learning_under_conditions():
+    """``learn`` as a dictionary (mcmc.py:439-444, 467-483): the proposal covariance is updated only every so many samples and while Gelman-Rubin is inside the window."""
+    from desilike_amd.samplers import MCMCSampler
+    like = ToyGaussianLikelihood()
+    start_cov = np.diag([0.3, 0.3])**2
+    always = MCMCSampler(like, chains=3, vectorize=2, seed=6, covariance=start_cov, learn={'every': '5 * ndim', 'max_eigen_gr': 1e3, 'min_eigen_gr': -1., 'stable_over': 1})
+    always.run(check_every=100, max_iterations=400)
+    assert not np.allclose(always.covariance, start_cov) and 'eigen_gr' in always.learn_diagnostics
+    never = MCMCSampler(like, chains=3, vectorize=2, seed=6, covariance=start_cov, learn={'max_eigen_gr': 1e-12, 'stable_over': 1})     # the window is never met
+    never.run(check_every=100, max_iterations=400)
+    assert np.allclose(never.covariance, start_cov)
+    rare = MCMCSampler(like, chains=3, vectorize=2, seed=6, covariance=start_cov, learn={'every': 10**9, 'max_eigen_gr': 1e3, 'stable_over': 1})      # not enough new samples
+    rare.run(check_every=100, max_iterations=300)
+    assert np.allclose(rare.covariance, start_cov)
