@@ -173,6 +173,48 @@ class ChainFile(object):
         return samples
 
 
+    # ---- weighted statistics (the subset of desilike/samples/chain.py a fit is read with: weight 190-192, mean 746-757, covariance 666-700, remove_burnin 265-283, concatenate) ----
+    def _values(self, name):
+        value = np.asarray(self.arrays[str(name)], dtype='f8')
+        return (value[..., 0] if str(name) in self.derivs else value).ravel()
+
+    @property
+    def weight(self):
+        """Total weight of every sample: ``aweight * fweight`` (each 1 when absent), flattened."""
+        size = int(np.prod(self.shape))
+        aweight = self._values('aweight') if 'aweight' in self.arrays else np.ones(size)
+        fweight = self._values('fweight') if 'fweight' in self.arrays else np.ones(size)
+        return aweight * fweight
+
+    def mean(self, name):
+        return float(np.average(self._values(name), weights=self.weight))
+
+    def covariance(self, names, ddof=1):
+        """Weighted covariance of ``names`` (numpy's estimator with frequency and reliability weights, as the reference uses it)."""
+        names = [names] if isinstance(names, str) else list(names)
+        values = np.column_stack([self._values(name) for name in names])
+        size = values.shape[0]
+        fweight = np.rint(self._values('fweight')).astype('i8') if 'fweight' in self.arrays else None
+        aweight = self._values('aweight') if 'aweight' in self.arrays else None
+        return np.atleast_2d(np.cov(values, rowvar=False, fweights=fweight, aweights=aweight, ddof=ddof)) if size > 1 else np.full((len(names),) * 2, np.nan)
+
+    def std(self, name):
+        return float(np.sqrt(self.covariance([name])[0, 0]))
+
+    def remove_burnin(self, burnin=0.5):
+        """Drop the first ``burnin`` fraction (or number) of the steps along the first axis."""
+        nsteps = self.shape[0] if len(self.shape) else 0
+        skip = int(burnin * nsteps + 0.5) if 0 < burnin < 1 else int(burnin)
+        return ChainFile({name: value[skip:] for name, value in self.arrays.items()}, params=self.params, derivs=self.derivs, attrs=self.attrs)
+
+    @classmethod
+    def concatenate(cls, chains):
+        """Chains one after the other along the first axis (same columns)."""
+        chains = list(chains)
+        return cls({name: np.concatenate([np.asarray(chain.arrays[name]) for chain in chains]) for name in chains[0].arrays}, params=chains[0].params, derivs=chains[0].derivs,
+                   attrs=chains[0].attrs)
+
+
 def derived_for_chain(likelihood, chain):
     """Derived outputs of ``likelihood`` on the points of ``chain`` (name -> [...]) in the reference's layout: solved parameters, ``loglikelihood`` and
     ``logprior`` arrays with the Hessian entries w.r.t. the solved parameters along the last axis (likelihoods/base.py:361-411) -- ONE GPU batch

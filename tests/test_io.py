@@ -110,3 +110,22 @@ def test_window_and_data_containers(tmp_path):
     io.save_data(fn, k, (0, 2), rng.standard_normal(35), covariance=cov, shotnoise=1e3)
     kd = io.load_data(fn)
     assert kd['ells'] == (0, 2) and kd['data'].shape == (35,) and np.array_equal(kd['covariance'], cov) and kd['shotnoise'] == 1e3
+
+
+def test_chain_statistics_with_weights():
+    """ChainFile.mean / std / covariance / remove_burnin / concatenate with frequency weights: the values the reference's Chain gives for the chains of the
+    Metropolis-Hastings sampler (tests/golden/validate_mh_chain.py checks mean and covariance against the reference itself) = statistics of the expanded samples."""
+    import numpy as np
+    from desilike_amd.io import ChainFile
+    rng = np.random.RandomState(0)
+    a, b, w = rng.standard_normal(300), rng.standard_normal(300) * 2. + 1., rng.randint(1, 6, size=300)
+    chain = ChainFile({'a': a, 'b': b, 'fweight': w, 'logposterior': -0.5 * a**2})
+    ea, eb = np.repeat(a, w), np.repeat(b, w)
+    assert np.isclose(chain.mean('a'), ea.mean()) and np.isclose(chain.std('b'), eb.std(ddof=1))
+    assert np.allclose(chain.covariance(['a', 'b']), np.cov(np.column_stack([ea, eb]), rowvar=False, ddof=1))
+    cut = chain.remove_burnin(0.5)
+    assert cut.shape == (150,) and np.isclose(cut.mean('a'), np.repeat(a[150:], w[150:]).mean())
+    both = ChainFile.concatenate([cut, cut])
+    assert both.shape == (300,) and np.isclose(both.mean('b'), cut.mean('b'))
+    plain = ChainFile({'a': a.reshape(100, 3)})
+    assert np.isclose(plain.mean('a'), a.mean()) and np.isclose(plain.std('a'), a.std(ddof=1))
