@@ -24,6 +24,10 @@ for i in range(2):
     assert np.array_equal(np.asarray(chain['a']), mine['a']) and np.array_equal(np.asarray(chain.fweight), mine['fweight']) and np.array_equal(np.asarray(chain.logposterior), mine['logposterior'])
     print(i, chain.shape, 'weighted mean a (reference Chain.mean):', float(chain.mean('a')), 'ours:', np.average(mine['a'], weights=mine['fweight']), 'cov', np.asarray(chain.covariance(['a','b'])).ravel())
     assert np.isclose(float(chain.mean('a')), np.average(mine['a'], weights=mine['fweight']))
+    from desilike_amd.io import ChainFile
+    ours = ChainFile.load(os.path.join(tmp, 'c_{:d}.npy'.format(i)))      # the statistics of desilike_amd.io.ChainFile against the reference's Chain
+    assert np.isclose(ours.mean('a'), float(chain.mean('a')), rtol=1e-13) and np.allclose(ours.covariance(['a', 'b']), np.asarray(chain.covariance(['a', 'b'])), rtol=1e-12)
+    assert np.isclose(ours.std('b'), float(chain.std('b')), rtol=1e-12)
 # Gelman-Rubin of the reference on these weighted chains vs ours
 from desilike.samples import diagnostics as rdiag
 chains = [Chain.load(os.path.join(tmp, 'c_{:d}.npy'.format(i))) for i in range(2)]
