@@ -52,6 +52,7 @@
 #define DL_N_VPARS 11      // velocileptors 'pars': b1 b2 bs b3 alpha0 alpha2 alpha4 alpha6 sn0 sn2 sn4 (full_shape.py:1184)
 #define DL_N_MONO 19       // bias monomials (full_shape.py:1185)
 #define DL_MAX_ML 40       // multiplicative wiggle terms of the flexible BAO model (bao.py:310-322: up to 12 nodes per multipole)
+#define DL_PNG_MAX_MU 48   // mu nodes of the PNG kernel (its tracer-velocity variant integrates 81 trapezoid nodes on [-1, 1]: 41 after folding)
 #define DL_MAX_BAND 16     // bands of the velocity-divergence template
 #define DL_MAX_PASS 32     // pass-through columns: linear (broadband) parameters appended to the theory vector
 #define DL_MAX_SOLVED 16   // analytically solved (marginalised / best-fit) linear parameters
@@ -99,6 +100,10 @@ struct DlObsDev {
     int32_t n_band, pad_band;
     DlInput band_in[DL_MAX_BAND];
     const double* band_tab;                // [n_band][n_t] tent functions at the knots
+    // tracer-velocity variant of the PNG theory (primordial_non_gaussianity.py:196-330): P = jac fog (b + f mu'^2) (bv f mu' velfac / k') P(k'), fog = sinc(sigmau k') / (1 + sigmas^2 k'^2 mu'^2 / 2)
+    int32_t png_vel, pad_vel;
+    DlInput bv, sigmau;
+    double png_velfac;                     // 100 / (1 + z)
     DlInput ct_in[DL_MAX_EFT][2];
     DlInput sn_in[DL_MAX_EFT];
     // pass-through columns n_in .. n_in + n_pass - 1 of the theory vector: parameters the observable is linear in through a constant
@@ -194,8 +199,8 @@ DL_HD size_t dl_fs_shared_doubles(int n_t, int n_in) { return 4 * (size_t)n_t + 
 DL_HD size_t dl_fs_shared_doubles_obs(const DlObsDev& o, bool fast = false) { return 4 * (size_t)o.n_t + dl_fs_work_doubles(o.n_t, o.n_in, dl_fs_n_dd0(o)) + (fast ? DL_PT_SIZE_FAST : DL_PT_SIZE); }
 
 // PNG kernel (dl_kernels.hip): the generic layout (its coefficient region [4 n_t] holds the knot values and second derivatives of the two splines: alpha, template) |
-// mu records [DL_MAX_MU][8] | scalars [16]
-DL_HD size_t dl_png_shared_doubles(int n_t, int n_in) { return dl_fs_shared_doubles(n_t, n_in) + 8 * DL_MAX_MU + 16; }
+// mu records [DL_PNG_MAX_MU][8] | scalars [16]
+DL_HD size_t dl_png_shared_doubles(int n_t, int n_in) { return dl_fs_shared_doubles(n_t, n_in) + 8 * DL_PNG_MAX_MU + 16; }
 
 // toep: layout of the convolution path (dl_fs_phase2_fir): y sits DL_FIR_PAD zeros inside the work region, M (the moments) right after the padded y
 DL_HD DlFsShared dl_fs_shared_carve(double* base, int n_t, int n_in, int n_dd0 = -1, bool toep = false) {
@@ -800,6 +805,7 @@ DL_HD void dl_png_setup(int tid, int nthr, const DlObsDev& o, const double* th, 
         sc[6] = o.png_mode == 0 ? dl_get(o.bphiY, th) * fnl : 2. * 1.686 * (b1Y - dl_get(o.pY, th)) * fnl;
         const double sX = dl_get(o.sigmas, th), sY = dl_get(o.sigmasY, th);
         sc[7] = 0.5 * sX * sX; sc[8] = 0.5 * sY * sY; sc[9] = dl_get(o.sn0, th) / o.nd;
+        sc[10] = dl_get(o.bv, th) * sc[2] * o.png_velfac; sc[11] = dl_get(o.sigmau, th);      // velocity variant: bv f 100 / (1 + z), sigma_u
     }
     if (tid >= nthr - 1 - o.n_mu && tid < nthr - 1) {
         const int m = nthr - 2 - tid;
@@ -872,7 +878,11 @@ DL_HD void dl_png_eval(int tid, int nthr, const DlObsDev& o, const double* tabs,
             const double km2 = kap * kap * mup2;
             const double fog = 1. / ((1. + hsX * km2) * (1. + hsY * km2));
             const double fm2 = f * mup2;
-            const double pkmu = jac * fog * (b1X + bfX * al + fm2) * (b1Y + bfY * al + fm2) * pk + sn0nd;   // lines 108-111
+            double pkmu;
+            if (o.png_vel) {   // lines 313-319: no stochastic term, one damping scale times sinc(sigma_u k') (numpy's sinc: sin(pi x) / (pi x))
+                const double xs = sc[11] * kap, snc = xs == 0. ? 1. : sin(3.141592653589793 * xs) / (3.141592653589793 * xs);
+                pkmu = jac * (snc / (1. + hsX * km2)) * (b1X + bfX * al + fm2) * (sc[10] * sqrt(mup2) / kap) * pk;
+            } else pkmu = jac * fog * (b1X + bfX * al + fm2) * (b1Y + bfY * al + fm2) * pk + sn0nd;   // lines 108-111
             for (int l = 0; l < 4; ++l) acc[l] = fma(r[4 + l], pkmu, acc[l]);
             acc[4] = fma(r[3], pkmu, acc[4]);
         }

@@ -345,7 +345,7 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
     d.n_ell = (int)ells.size(); d.n_kin = (int)kin.size(); d.n_mu = (int)mu.size(); d.n_t = (int)k_t.size();
     d.n_in = d.n_ell * d.n_kin;
     if (d.n_ell < 1 || d.n_ell > DL_MAX_ELL) { err = p + "ells_in: between 1 and 5 multipoles supported"; return false; }
-    if (d.n_mu < 1 || d.n_mu > DL_MAX_MU) { err = p + "mu: between 1 and 32 nodes supported"; return false; }
+    if (d.n_mu < 1 || d.n_mu > (d.theory == 5 ? DL_PNG_MAX_MU : DL_MAX_MU)) { err = p + "mu: between 1 and 32 nodes supported (48 by the PNG theory)"; return false; }
     if (d.n_kin < 1) { err = p + "kin missing"; return false; }
     if ((int)wmu.size() != d.n_ell * d.n_mu) { err = p + "wmu_ell must have n_ell * n_mu entries"; return false; }
     if ((int)pk.size() != d.n_t) { err = p + "pk_dd_fid and k_t sizes differ"; return false; }
@@ -361,6 +361,7 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         {"sigmapar", &d.sigpar, 0.}, {"sigmaper", &d.sigper, 0.}, {"b1X", &d.b1X, 1.}, {"b1Y", &d.b1Y, 1.}, {"sn0", &d.sn0, 0.},
         {"dbeta", &d.dbeta, 1.}, {"sigmas", &d.sigmas, 0.}, {"dres", &d.dres, 1.},
         {"sigmav", &d.sigmav, 0.}, {"b2", &d.b2, 0.}, {"bs", &d.bs, 0.}, {"b3", &d.b3, 0.},
+        {"bv", &d.bv, 1.}, {"sigmau", &d.sigmau, 0.},
         {"m", &d.to_m, 0.6}, {"n", &d.to_n, 0.9}, {"qto", &d.qto, 1.}, {"dpto", &d.dpto, 1.},
         {"fnl_loc", &d.fnl, 0.}, {"pX", &d.pX, 1.}, {"pY", &d.pY, 1.}, {"bphiX", &d.bphiX, 1.}, {"bphiY", &d.bphiY, 1.}, {"sigmasY", &d.sigmasY, 0.}};
     for (auto& it : inputs) {
@@ -556,6 +557,8 @@ inline bool dl_build_obs(const dl_config& cfg, int iobs, int n_params, DlObsHost
         if (d.n_ct > 0 || d.n_sn > 0 || d.n_pass > 0) { err = p + "counter / stochastic / pass-through terms are not part of the PNG theory"; return false; }
         png_alpha = al;
         d.png_mode = cfg.i(p + "png_mode", 1);
+        d.png_vel = cfg.i(p + "png_velocity", 0);
+        d.png_velfac = cfg.f(p + "png_velfac", 100.);
         const auto& nk = cfg.F(p + "png_knorm");   // normalisation wavenumber of the transfer function (methods other than 'prim'), absent: none
         if (!nk.empty()) { d.png_lg0 = std::log(nk[0] / kp); d.png_th0 = std::tanh(d.a * d.png_lg0); }
     }

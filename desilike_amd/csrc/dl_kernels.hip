@@ -160,7 +160,7 @@ __global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_ker
 //   P(k, mu) = jac fog (bX + f mu'^2) (bY + f mu'^2) P(k') + sn0 / nd,   bX = b1X + bfnlX alpha(k'),   fog = 1 / ((1 + sX^2 k'^2 mu'^2 / 2) (1 + sY^2 k'^2 mu'^2 / 2)),
 // with TWO not-a-knot splines in log10 k' per point: the template and alpha = alpha_fid sqrt(norm / template factor).  One workgroup per point; the spline phases of
 // the generic kernel (dl_fullshape.h) run twice on the same work area, the interval polynomials of alpha are kept beside those of the template.
-// LDS: generic layout (coef [4 n_t] | work | pt) | coefA [4 n_t] | mu records [DL_MAX_MU][8] | scalars [16]
+// LDS: generic layout (coef [4 n_t] | work | pt) | coefA [4 n_t] | mu records [DL_PNG_MAX_MU][8] | scalars [16]
 
 __device__ __forceinline__ void dl_png_build_moments(int tid, int nthr, const DlObsDev& o, const DlFsShared& s, bool toep) {
     if (toep) {
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(DL_FS_THREADS, 2) void dl_png_kernel(DlObsDev o, co
     const DlFsShared s = dl_fs_shared_carve(lds, n_t, o.n_in, -1, toep);
     double* tabs = s.coef;                                      // alpha knots | alpha second derivatives | template knots | template second derivatives
     double* murec = lds + dl_fs_shared_doubles(n_t, o.n_in);
-    double* sc = murec + 8 * DL_MAX_MU;
+    double* sc = murec + 8 * DL_PNG_MAX_MU;
     dl_png_setup(tid, nthr, o, th, murec, sc);
     dl_png_knots(tid, nthr, o, th, s, true);                    // alpha at the knots, its spline
     __syncthreads();

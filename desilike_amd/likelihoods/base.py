@@ -277,7 +277,7 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
                     return (-1, float(self._all_params[pname].value))
                 return (-1, default)
 
-            defaults = dict(qpar=1., qper=1., qiso=1., qap=1., df=1., dm=0., dn=0., sigmapar=0., sigmaper=0., b1X=1., b1Y=1., sn0=0., dbeta=1., sigmas=0., dres=1., sigmav=0., b2=0., bs=0., b3=0., fnl_loc=0., pX=1., pY=1., bphiX=1., bphiY=1., sigmasY=0., m=0.6, n=0.9, qto=1., dpto=1.)
+            defaults = dict(qpar=1., qper=1., qiso=1., qap=1., df=1., dm=0., dn=0., sigmapar=0., sigmaper=0., b1X=1., b1Y=1., sn0=0., dbeta=1., sigmas=0., dres=1., sigmav=0., b2=0., bs=0., b3=0., fnl_loc=0., pX=1., pY=1., bphiX=1., bphiY=1., sigmasY=0., m=0.6, n=0.9, qto=1., dpto=1., bv=1., sigmau=0.)
             inputs = {}
             imap = dict(theory._input_map())
             window_pass = getattr(obs.wmatrix, '_pass_params', lambda: [])()   # systematic templates: pass-through columns appended by the window

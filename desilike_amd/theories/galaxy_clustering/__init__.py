@@ -5,7 +5,7 @@ from .full_shape import (KaiserTracerPowerSpectrumMultipoles, SimpleTracerPowerS
                          REPTVelocileptorsTracerPowerSpectrumMultipoles, EmulatedTracerPowerSpectrumMultipoles,
                          LPTVelocileptorsTracerCorrelationFunctionMultipoles, REPTVelocileptorsTracerCorrelationFunctionMultipoles,
                          TNSTracerPowerSpectrumMultipoles, EFTLikeTNSTracerPowerSpectrumMultipoles, TNSTracerCorrelationFunctionMultipoles,
-                         EFTLikeTNSTracerCorrelationFunctionMultipoles, PNGTracerPowerSpectrumMultipoles)
+                         EFTLikeTNSTracerCorrelationFunctionMultipoles, PNGTracerPowerSpectrumMultipoles, PNGTracerVelocityPowerSpectrumMultipoles)
 from .bao import (DampedBAOWigglesTracerPowerSpectrumMultipoles, DampedBAOWigglesTracerCorrelationFunctionMultipoles,
                   ResummedBAOWigglesTracerPowerSpectrumMultipoles, ResummedBAOWigglesTracerCorrelationFunctionMultipoles,
                   SimpleBAOWigglesTracerPowerSpectrumMultipoles, SimpleBAOWigglesTracerCorrelationFunctionMultipoles,

@@ -335,6 +335,49 @@ class PNGTracerPowerSpectrumMultipoles(KaiserTracerPowerSpectrumMultipoles):
         return toret
 
 
+class PNGTracerVelocityPowerSpectrumMultipoles(PNGTracerPowerSpectrumMultipoles):
+    r"""
+    Tracer-velocity cross power spectrum multipoles with the scale-dependent bias of local primordial non-Gaussianity (primordial_non_gaussianity.py:196-330; the
+    reference models :math:`-i P`): odd multipoles (default 1, 3) of
+
+    .. math:: P(k, \mu) = J \; \frac{\mathrm{sinc}(\sigma_u k')}{1 + \sigma_s^2 k'^2 \mu'^2 / 2} \; (b_1 + b_{f_\mathrm{NL}} \alpha(k') + f \mu'^2) \; \frac{100 \, b_v f \mu'}{(1 + z) k'} \; P_{dd}(k') .
+
+    The reference integrates 81 trapezoid nodes in :math:`\mu \in [-1, 1]`; the integrand times an odd Legendre polynomial is even in :math:`\mu`, so the device
+    evaluates the 41 nodes :math:`\mu \ge 0` with the weights of the mirror nodes added (same sum).  Parameters b1, bv, sigmas, sigmau, fnl_loc and p (``mode='b-p'``)
+    or bphi (``'bphi'``); one tracer, no stochastic term."""
+    _stochastic_bias_params = []
+    _own_params = {**{name: conf for name, conf in PNGTracerPowerSpectrumMultipoles._own_params.items() if name != 'sn0'},
+                   'bv': dict(value=1., prior=dict(limits=[0., 3.]), ref=dict(limits=[0.9, 1.1]), delta=0.05, latex='b_{v}'),
+                   'sigmau': dict(value=0., prior=dict(limits=[0., 20.]), ref=dict(limits=[0., 5.]), delta=0.2, latex=r'\sigma_{u}')}
+
+    def initialize(self):
+        if self._initialized:
+            return self
+        self.init.setdefault('ells', (1, 3))       # primordial_non_gaussianity.py:243
+        if self.init.get('tracers', None) is not None: raise NotImplementedError('one tracer (primordial_non_gaussianity.py:243-262)')
+        super(PNGTracerVelocityPowerSpectrumMultipoles, self).initialize()
+        if any(ell % 2 == 0 for ell in self.ells): raise ValueError('odd multipoles only: the integrand is odd in mu')
+        # the reference's grid: np.linspace(-1, 1, 81), trapezoid weights over its length (utils.py:633-639), folded onto mu >= 0
+        full = np.linspace(-1., 1., 81)
+        weight = utils.weights_trapz(full) / (full[-1] - full[0])
+        half = full >= -1e-12
+        self.mu = np.abs(full[half])
+        folded = np.where(self.mu > 0., 2., 1.) * weight[half]
+        self.wmu = utils.multipole_weights(self.mu, folded, self.ells)
+        return self
+
+    def _theory_spec(self):
+        spec = super(PNGTracerVelocityPowerSpectrumMultipoles, self)._theory_spec()
+        spec.update(png_velocity=np.array([1], dtype='i4'), png_velfac=[100. / (1. + self.z)])
+        return spec
+
+    def _input_map(self):
+        toret = super(PNGTracerVelocityPowerSpectrumMultipoles, self)._input_map()
+        toret.pop('sn0', None)
+        toret.update(bv='bv', sigmau='sigmau')
+        return toret
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # TNS one-loop theory: the reference's own perturbation-theory producer (full_shape.py:688-1037)
 # ----------------------------------------------------------------------------------------------------------------------

@@ -367,6 +367,17 @@ def png_tracer_power(k, mu, wmu_ell, kin, pk_dd, alpha, f, nd, b1X, b1Y, bfnlX, 
     return np.sum(pkmu * wmu_ell[:, None, :], axis=-1)
 
 
+def png_velocity_power(k, mu, wmu_ell, kin, pk_dd, alpha, f, z, b1, bfnl, bv=1., sigmas=0., sigmau=0., qpar=1., qper=1.):
+    """``PNGTracerVelocityPowerSpectrumMultipoles.calculate``, primordial_non_gaussianity.py:284-320 (the tracer-velocity cross spectrum without its factor i):
+    ``mu`` is the reference's grid on [-1, 1] (81 trapezoid nodes), ``wmu_ell`` the weights of the odd multipoles."""
+    jac, kap, muap = ap_k_mu(k, mu, qpar=qpar, qper=qper)
+    bias = b1 + bfnl * interp1d(np.log10(kap), np.log10(kin), alpha, method='cubic')
+    vel_bias = bv * f * muap * 100. / (1. + z) / kap
+    fog = 1. / (1. + sigmas**2 * kap**2 * muap**2 / 2.) * np.sinc(sigmau * kap)
+    pkmu = jac * fog * (bias + f * muap**2) * vel_bias * interp1d(np.log10(kap), np.log10(kin), pk_dd, method='cubic')
+    return np.sum(pkmu * wmu_ell[:, None, :], axis=-1)
+
+
 # ----------------------------------------------------------------------------------------------
 # a5: tracer combine                                          full_shape.py:545-550, 628-634
 # ----------------------------------------------------------------------------------------------

@@ -72,7 +72,7 @@ static void run_point(const DlObsDev& o, const double* th, double* prow, double*
         DlFsShared s = dl_fs_shared_carve(lds.data(), o.n_t, o.n_in, -1, toep);
         double* tabs = s.coef;
         double* murec = lds.data() + dl_fs_shared_doubles(o.n_t, o.n_in);
-        double* sc = murec + 8 * DL_MAX_MU;
+        double* sc = murec + 8 * DL_PNG_MAX_MU;
         auto build = [&]() {
             if (toep) {
                 for (int tid = 0; tid < nthr; ++tid) dl_fs_phase2_fir(tid, nthr, o, s);
