@@ -95,3 +95,25 @@ def test_device_against_the_reference():
              f_fid=template.f_fid, kp=template.kp, a=template.a)
     expected = oracle_power(m, g['theta'][0])
     assert np.allclose(got, expected, rtol=1e-10, atol=1e-12 * np.abs(expected).max())
+
+
+@pytest.mark.gpu
+def test_likelihood_on_the_odd_multipoles():
+    """End to end: windowed observable of the odd multipoles, mock data from the theory, Gaussian likelihood -- zero at the truth, the batch equals the scalar calls."""
+    from desilike_amd import vmap
+    from desilike_amd.theories.galaxy_clustering import PNGTracerVelocityPowerSpectrumMultipoles, ShapeFitPowerSpectrumTemplate
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    theory = PNGTracerVelocityPowerSpectrumMultipoles(template=ShapeFitPowerSpectrumTemplate(z=0.5, fiducial='synthetic'))
+    truth = {'b1': 2., 'bv': 1.1, 'fnl_loc': 20., 'sigmau': 3.}
+    obs = TracerPowerSpectrumMultipolesObservable(data=truth, kedges=np.linspace(0.005, 0.105, 21), ells=(1, 3), wmatrix={'resolution': 2}, theory=theory)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=np.diag(np.full(40, 1e8)))
+    like.initialize()
+    assert like.flatdata.shape == (40,) and np.isfinite(like.flatdata).all() and np.abs(like.flatdata).max() > 0.
+    assert abs(like(**truth)) < 1e-12 and like(**dict(truth, bv=1.3)) < -1e-3
+    names = like.varied_params.names()
+    rng = np.random.RandomState(1)
+    theta = np.column_stack([np.clip(param.ref.sample(size=9, random_state=rng), *param.prior.limits) for param in like.varied_params])
+    (logpost, derived), errors = vmap(like, errors='return', return_derived=True)({name: theta[:, i] for i, name in enumerate(names)})
+    for i in [0, 4, 8]:
+        assert np.isclose(like(**dict(zip(names, theta[i]))), derived[like._param_loglikelihood][i], rtol=1e-12, atol=1e-12)
