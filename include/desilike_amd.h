@@ -110,7 +110,9 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
  *                     500 wavenumbers geomspace(1e-3, 2) (full_shape.py:855) are also the integration grid; EFT-like terms (ct_matrix, sn_matrix) as for theory 1
  *   PNG theory (theory = 5; primordial_non_gaussianity.py:75-112): obs<i>.png_alpha f64[n_t] alpha(k) = sqrt(P_phi / P_dd) of the fiducial template at the knots (the device rescales
  *                     it with the template factor per point), obs<i>.png_mode i32[1] (0 'bphi': bfnl = bphi fnl_loc; 1 'b-p': bfnl = 2 * 1.686 (b1 - p) fnl_loc), optional obs<i>.png_knorm f64[1]
- *                     (normalisation wavenumber of the transfer-function method); obs<i>.in.fnl_loc, .in.pX, .in.pY, .in.bphiX, .in.bphiY, .in.sigmas, .in.sigmasY f64[2] (b1 through in.b1X / in.b1Y)
+ *                     (normalisation wavenumber of the transfer-function method); obs<i>.in.fnl_loc, .in.pX, .in.pY, .in.bphiX, .in.bphiY, .in.sigmas, .in.sigmasY f64[2] (b1 through in.b1X / in.b1Y);
+ *                     tracer-velocity variant (primordial_non_gaussianity.py:196-330): obs<i>.png_velocity i32[1] = 1, obs<i>.png_velfac f64[1] = 100 / (1 + z), obs<i>.in.bv, .in.sigmau f64[2];
+ *                     odd multipoles in ells_in, mu / wmu_ell on the nodes mu >= 0 with the weights of the mirror nodes added (<= 48 nodes)
  *   emulated theory (theory = 3): obs<i>.in.x f64[n_x*2] emulator inputs, obs<i>.in.vp f64[11*2] velocileptors 'pars' (b1 b2 bs b3 alpha0 alpha2 alpha4 alpha6
  *                     sn0 sn2 sn4), obs<i>.mono_mode i32[1] (0 none, 1 LPT physical basis, 2 REPT physical, 3 LPT direct, 4 REPT direct), obs<i>.vconst f64[3] (snd fsat sigv),
  *                     obs<i>.emu<e>.{type i32[1] (-1 constant, 0 MLP, 1 Taylor), xlimits, widths, act, weights, ylimits, center, powers, coef, const}

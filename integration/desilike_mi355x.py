@@ -115,7 +115,8 @@ def extract_config(likelihood):
         eft = hasattr(ptheory, 'counterterm_matrix')
         shapefit = template.__class__.__name__.startswith('ShapeFit')
         tns = pt.__class__.__name__.startswith('TNS')                       # the reference's own one-loop producer (full_shape.py:836-971)
-        png = pt.__class__.__name__.startswith('PNGTracerPower')            # scale-dependent bias (primordial_non_gaussianity.py:12-116)
+        pngvel = pt.__class__.__name__.startswith('PNGTracerVelocity')     # its tracer-velocity variant (primordial_non_gaussianity.py:196-330)
+        png = pt.__class__.__name__.startswith('PNGTracerPower') or pngvel  # scale-dependent bias (primordial_non_gaussianity.py:12-116)
         cfg[p + 'theory'] = np.array([DL_THEORY_BAO_DAMPED if bao else DL_THEORY_TNS if tns else DL_THEORY_PNG if png else DL_THEORY_EFT_KAISER if eft else DL_THEORY_KAISER], dtype='i4')
         if tns:
             k = np.asarray(pt.k, dtype='f8')
@@ -133,10 +134,15 @@ def extract_config(likelihood):
         cfg[p + 'f_fid'] = np.array([template.f_fid], dtype='f8')
         cfg[p + 'a'] = np.array([getattr(template, 'a', 0.6)], dtype='f8')
         cfg[p + 'kp'] = np.array([getattr(template, 'kp', 0.03)], dtype='f8')
-        cfg[p + 'nd'] = np.array([1. if bao else ptheory.nd], dtype='f8')
+        cfg[p + 'nd'] = np.array([1. if bao else getattr(ptheory, 'nd', 1.)], dtype='f8')
         cfg[p + 'ells_in'] = np.asarray(ptheory.ells if xi else wm.ellsin, dtype='i4')
         cfg[p + 'kin'] = np.asarray(pt.k, dtype='f8')
         cfg[p + 'mu'], cfg[p + 'wmu_ell'] = np.asarray(pt.mu, dtype='f8'), np.asarray(pt.wmu, dtype='f8')
+        if pngvel:   # 81 trapezoid nodes on [-1, 1]: the integrand times an odd Legendre polynomial is even in mu -- the nodes mu >= 0 with the mirror weights added
+            half = cfg[p + 'mu'] >= -1e-12
+            cfg[p + 'wmu_ell'] = np.where(np.abs(cfg[p + 'mu'][half]) > 0., 2., 1.) * cfg[p + 'wmu_ell'][:, half]
+            cfg[p + 'mu'] = np.abs(cfg[p + 'mu'][half])
+            cfg[p + 'png_velocity'], cfg[p + 'png_velfac'] = np.array([1], dtype='i4'), np.array([100. / (1. + float(pt.z))], dtype='f8')
         cfg[p + 'k_t'], cfg[p + 'pk_dd_fid'] = np.asarray(template.k, dtype='f8'), np.asarray(template.pk_dd_fid, dtype='f8')
         if png:
             if pt.method != 'prim' or pt.mode not in ('bphi', 'b-p'):
@@ -189,6 +195,7 @@ def extract_config(likelihood):
         if png:
             for key in ['sigmapar', 'sigmaper']: defaults.pop(key)
             defaults.update(fnl_loc=0., sigmas=0.)
+            if pngvel: defaults.update(bv=1., sigmau=0.)
         if turnover: defaults.update(m=0.6, n=0.9, qto=1., dpto=1.)
         if bands:
             cfg[p + 'band_templates'] = np.asarray(template.templates, dtype='f8')

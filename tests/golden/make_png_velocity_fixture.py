@@ -26,7 +26,22 @@ utils.weights_trapz = _weights_trapz
 from desilike.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate   # noqa: E402
 from desilike.theories.galaxy_clustering.primordial_non_gaussianity import PNGTracerVelocityPowerSpectrumMultipoles   # noqa: E402
 
+def boundary():
+    """The reference-side binding's key set for a likelihood on the odd multipoles: tests/golden/boundary_png_velocity.npz."""
+    import make_boundary_fixture as mb
+    from desilike.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike.likelihoods import ObservablesGaussianLikelihood
+    theory = PNGTracerVelocityPowerSpectrumMultipoles(template=ShapeFitPowerSpectrumTemplate(z=0.5), mode='b-p')
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'bv': 1.1, 'fnl_loc': 20., 'sigmau': 3.}, kedges=np.linspace(0.005, 0.105, 21), ells=(1, 3), wmatrix={'resolution': 2}, theory=theory)
+    likelihood = ObservablesGaussianLikelihood(observables=[obs], covariance=mg.spd_covariance(40, seed=8, diag=1e10, amp=2e4))
+    likelihood()
+    mb.dump('png_velocity', likelihood, size=16, seed=10)
+
+
 if __name__ == '__main__':
+    if '--boundary' in sys.argv:
+        boundary()
+        sys.exit(0)
     template = ShapeFitPowerSpectrumTemplate(z=0.5)
     theory = PNGTracerVelocityPowerSpectrumMultipoles(template=template, k=np.linspace(0.005, 0.15, 30), mode='b-p')
     theory()

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(ROOT, 'integration'))
 
-FIXTURES = ['cfg2_dense', 'two_tracers', 'eft_qisoqap', 'cfg4_xi', 'cfg4_pk', 'kaiser_xi', 'tns', 'tns_eft', 'png', 'turnover', 'bands']     # cfg4_*: BASELINE configs[3] (damped BAO); *_xi: the reference's own get_corr as a folded operator; tns*: the reference's one-loop TNS theory (tests/golden/make_tns_fixture.py)
+FIXTURES = ['cfg2_dense', 'two_tracers', 'eft_qisoqap', 'cfg4_xi', 'cfg4_pk', 'kaiser_xi', 'tns', 'tns_eft', 'png', 'turnover', 'bands', 'png_velocity']     # cfg4_*: BASELINE configs[3] (damped BAO); *_xi: the reference's own get_corr as a folded operator; tns*: the reference's one-loop TNS theory (tests/golden/make_tns_fixture.py)
 MARG_FIXTURES = ['cfg4_xi_marg', 'two_tracers_marg']                                                  # analytically solved parameters ('.marg')
 
 
