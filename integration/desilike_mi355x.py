@@ -7,7 +7,8 @@ This module imports ``desilike`` (the reference), never ``desilike_amd``'s Pytho
   documented in the header).  Covered: Kaiser / EFT-like Kaiser tracer power spectrum AND correlation function multipoles on ShapeFit / Standard / Fixed templates;
   damped-BAO tracer power spectrum and correlation function multipoles ('standard' wiggle model, 'power' broadband terms); any window handled by
   ``WindowedPowerSpectrumMultipoles``; one or several observables, tracer namespaces; parameters solved analytically ('.marg' / '.best' / '.auto': shot-noise like
-  terms, counter / stochastic terms, broadband terms).  For correlation functions ``get_corr`` (FFTLog) is linear in P_ell: the binding applies THE REFERENCE'S OWN
+  terms, counter / stochastic terms, broadband terms); **emulated perturbation-theory nodes** -- the LPT / REPT velocileptors tracer power spectrum multipoles whose
+  ``pt`` is an ``EmulatedCalculator`` (emulators/__init__.py:394-418) with Taylor or MLP engines (BASELINE configs[2]): :func:`_extract_emulated`.  For correlation functions ``get_corr`` (FFTLog) is linear in P_ell: the binding applies THE REFERENCE'S OWN
   ``theory.get_corr`` -- cosmoprimo's transform in a real installation -- to the unit vectors of the theory's k grid once, and hands the resulting operator to the
   device folded into the window matrix (desilike/theories/galaxy_clustering/base.py:127-136);
 * :class:`MI355XGaussianLikelihood` -- a ``BaseGaussianLikelihood`` whose ``calculate`` is ONE ``dl_eval_batch_host`` call; ``evaluate(values [B, P])`` is the
@@ -22,7 +23,7 @@ import numpy as np
 
 # enumerations of include/desilike_amd.h
 DL_TEMPLATE_FIXED, DL_TEMPLATE_SHAPEFIT, DL_TEMPLATE_TURNOVER, DL_TEMPLATE_BANDS = 0, 1, 2, 3
-DL_THEORY_KAISER, DL_THEORY_EFT_KAISER, DL_THEORY_BAO_DAMPED, DL_THEORY_TNS, DL_THEORY_PNG = 0, 1, 2, 4, 5
+DL_THEORY_KAISER, DL_THEORY_EFT_KAISER, DL_THEORY_BAO_DAMPED, DL_THEORY_EMULATED, DL_THEORY_TNS, DL_THEORY_PNG = 0, 1, 2, 3, 4, 5
 DL_APMODE = {'qparqper': 0, 'qiso': 1, 'qap': 2, 'qisoqap': 3}
 
 
@@ -59,6 +60,150 @@ def _block_diag(blocks):
         out[r:r + b.shape[0], c:c + b.shape[1]] = b
         r += b.shape[0]; c += b.shape[1]
     return out
+
+
+# ---- emulated perturbation-theory node (BASELINE configs[2]) ---------------------------------------------------------------------------
+_VP_NAMES = ['b1', 'b2', 'bs', 'b3', 'alpha0', 'alpha2', 'alpha4', 'alpha6', 'sn0', 'sn2', 'sn4']       # velocileptors 'pars', full_shape.py:1290-1293
+_ACTIVATIONS = [('silu', 0, lambda v: v / (1. + np.exp(-v))), ('relu', 1, lambda v: np.maximum(v, 0.)), ('tanh', 2, np.tanh)]   # emulators/conversion.py:27-34
+
+
+def _affine(function, shape, what):
+    """(offset, slope) of an elementwise affine map probed at 0, 1 and 2: the min-max scalers of the engines (emulators/conversion.py:75-79) -- whatever their
+    expression strings are.  Anything else (scalers that use the inputs ``X``, PCA, ...) is refused."""
+    try:
+        v0, v1, v2 = (np.asarray(function(np.full(shape, value, dtype='f8')), dtype='f8') for value in (0., 1., 2.))
+    except Exception as exc:
+        raise NotImplementedError('{}: only constant elementwise affine operations are supported on the device ({})'.format(what, exc))
+    if v0.shape != tuple(shape) or not np.allclose(v2 - v1, v1 - v0, rtol=1e-12, atol=1e-300):
+        raise NotImplementedError('{}: not an elementwise affine operation'.format(what))
+    return v0, v1 - v0
+
+
+def _engine_description(engine):
+    """The fitted state of one emulator engine, read off the attributes the reference itself writes and reads:
+
+    * Taylor: ``center [P]``, ``powers [T, P]``, ``derivatives [T, *yshape]`` already divided by the factorials (emulators/__init__.py:471-507);
+    * MLP: ``model_operations``: dense layers ``(v[..., None, :] @ kernel)[..., 0, :] + bias`` with ``_locals = {kernel, bias}`` and activations between them
+      (emulators/conversion.py:20-35; ``operation._locals``: full_shape.py:1441), ``xoperations`` / ``yoperations``: min-max scalers (conversion.py:75-79).
+
+    Returns ``dict(kind='taylor', center, powers, table [T, n_out])`` or ``dict(kind='mlp', xlimits [P, 2], act, hidden [(kernel, bias)...], table [H + 1, n_out])`` where
+    ``table`` is the LAST LINEAR map of the engine (Taylor: the derivatives; MLP: final layer with the y-scaler folded in, last row = bias): output = basis . table."""
+    yshape = tuple(engine.yshape)
+    nout = int(np.prod(yshape, dtype='i8'))
+    if hasattr(engine, 'derivatives'):
+        if getattr(engine, 'xoperations', None) or getattr(engine, 'yoperations', None):
+            raise NotImplementedError('Taylor engine with operations')      # the reference asserts the same: emulators/__init__.py:435-436
+        center = np.asarray(engine.center, dtype='f8')
+        powers = np.asarray(engine.powers, dtype='i4').reshape(-1, center.size)
+        return dict(kind='taylor', center=center, powers=powers, table=np.asarray(engine.derivatives, dtype='f8').reshape(len(powers), nout))
+    if not hasattr(engine, 'model_operations'):
+        raise NotImplementedError('engine {}: Taylor and MLP engines are covered'.format(type(engine).__name__))
+    layers, acts = [], []
+    probe = np.array([-1.3, -0.2, 0., 0.7, 2.1])
+    for operation in engine.model_operations:
+        if 'kernel' in operation._locals:
+            kernel, bias = np.asarray(operation._locals['kernel'], dtype='f8'), np.asarray(operation._locals['bias'], dtype='f8')
+            if kernel.ndim != 2: raise NotImplementedError('stacked MLP kernels (several networks in one engine: emulators/conversion.py:58-66)')
+            layers.append((kernel, bias.reshape(kernel.shape[1])))
+        else:
+            out = np.asarray(operation(probe), dtype='f8')
+            match = [code for name, code, function in _ACTIVATIONS if np.allclose(out, function(probe), rtol=1e-14, atol=1e-15)]
+            if not match: raise NotImplementedError('activation not one of silu / relu / tanh')
+            acts.append(match[0])
+    if len(layers) < 2 or len(acts) != len(layers) - 1 or len(set(acts)) != 1:
+        raise NotImplementedError('MLP engines: >= 1 hidden layer, one activation for all of them')
+    nin = layers[0][0].shape[0]
+    xoperations = list(getattr(engine, 'xoperations', []))
+    yoperations = list(getattr(engine, 'yoperations', []))
+
+    def xscale(v):
+        for operation in xoperations: v = operation(v)
+        return v
+
+    def yunscale(v):
+        for operation in yoperations[::-1]: v = operation.inverse(v)
+        return v
+
+    x0, xslope = _affine(xscale, (nin,), 'xoperations')               # scaled = x0 + xslope x = (x - lo) / (hi - lo)
+    lo = -x0 / xslope
+    y0, yslope = _affine(yunscale, yshape, 'yoperations')             # y = y0 + yslope v
+    kernel, bias = layers[-1]
+    table = np.vstack([kernel * yslope.reshape(nout), bias * yslope.reshape(nout) + y0.reshape(nout)])
+    return dict(kind='mlp', xlimits=np.column_stack([lo, lo + 1. / xslope]), act=acts[0], hidden=layers[:-1], table=table, last=(kernel, bias), ylimits=np.column_stack([y0.reshape(nout), (y0 + yslope).reshape(nout)]))
+
+
+def _engine_keys(description, scalar):
+    """``obs<i>.emu<e>.*`` keys (include/desilike_amd.h): the table engine (e = 0) ships its trunk only -- the last linear map is folded into the window matrix."""
+    if description['kind'] == 'taylor':
+        keys = dict(type=np.array([1], dtype='i4'), center=description['center'], powers=description['powers'])
+        if scalar: keys['coef'] = description['table'].reshape(-1)
+        return keys
+    layers = description['hidden'] + ([description['last']] if scalar else [])
+    widths = [layers[0][0].shape[0]] + [kernel.shape[1] for kernel, bias in layers]
+    keys = dict(type=np.array([0], dtype='i4'), xlimits=description['xlimits'], widths=np.array(widths, dtype='i4'), act=np.array([description['act']], dtype='i4'),
+                weights=np.concatenate([np.concatenate([kernel.ravel(), bias.ravel()]) for kernel, bias in layers]))
+    if scalar: keys['ylimits'] = description['ylimits'][0]
+    return keys
+
+
+def _extract_emulated(cfg, p, obs, theory, pt, column, value_of, sindex, solved):
+    """Velocileptors-type tracer theory whose ``pt`` is an ``EmulatedCalculator`` (emulators/__init__.py:394-418): ``pktable [n_ell, n_kpt, 19]``, ``sigma8``, ``fsigma8``
+    come from ``pt.emulator.engines``; the tracer combines the 19 bias monomials (full_shape.py:1182-1186) and interpolates to its own k (full_shape.py:1312, 1598).
+    Everything after the engines' trunks is constant and linear -- last layer (Taylor: derivative table), k-interpolation, window matrix: multiplied together here once
+    and handed over as ``obs<i>.wmatrix`` with ``n_basis * 19`` columns; the device evaluates the trunk and the monomials per point."""
+    from desilike.jax import interp1d
+    wm = obs.wmatrix
+    emulator = pt.emulator
+    if getattr(emulator, 'xoperations', None) or getattr(emulator, 'yoperations', None):
+        raise NotImplementedError('emulator-level operations (redshift interpolation of the jaxeffort emulators, full_shape.py:1443) are not covered')
+    engines = emulator.engines
+    if 'pktable' not in engines:
+        raise NotImplementedError("emulated node without a 'pktable' engine")
+    name = type(theory).__name__
+    rept = name.startswith('REPT')
+    if not (rept or name.startswith('LPT')) or 'Tracer' not in name or hasattr(theory, 'get_corr'):
+        raise NotImplementedError('emulated node under {}: the LPT / REPT velocileptors tracer power spectrum multipoles are covered'.format(name))
+    physical = bool(theory.is_physical_prior)
+    table = _engine_description(engines['pktable'])
+    xnames = [str(n) for n in engines['pktable'].params]
+    ptnames = {param.basename: param.name for param in pt.all_params}
+    cfg[p + 'theory'] = np.array([DL_THEORY_EMULATED], dtype='i4')
+    cfg[p + 'transform'] = np.array([1 if getattr(obs, 'transform', None) == 'cubic' else 0], dtype='i4')
+    cfg[p + 'mono_mode'] = np.array([{(True, False): 1, (True, True): 2, (False, False): 3, (False, True): 4}[(physical, rept)]], dtype='i4')
+    cfg[p + 'vconst'] = np.array([theory.snd, theory.fsat, theory.options['sigv'] if physical else 1., theory.nd], dtype='f8')      # full_shape.py:1154-1157
+    cfg[p + 'in.x'] = np.array([column(ptnames.get(n, n), value_of(ptnames.get(n, n), 0.)) for n in xnames], dtype='f8')
+    names = {param.basename: param.name for param in theory.all_params}
+    vp = [names.get(n + ('p' if physical else ''), n + ('p' if physical else '')) for n in _VP_NAMES]
+    defaults = dict(theory.required_bias_params)                                                                                   # 0, except b1 = 1 (full_shape.py:1290-1293)
+    cfg[p + 'in.vp'] = np.array([column(n, value_of(n, defaults.get(b + ('p' if physical else ''), 0.))) for n, b in zip(vp, _VP_NAMES)], dtype='f8')
+    for ie, ename in [(0, 'pktable'), (1, 'sigma8'), (2, 'fsigma8')]:
+        if ename in engines:
+            if ie and [str(n) for n in engines[ename].params] != xnames: raise NotImplementedError('engines with different inputs')
+            keys = _engine_keys(table if ie == 0 else _engine_description(engines[ename]), scalar=ie > 0)
+        else:                                                          # a fixed output of the emulated calculator (emulator.fixed -> attribute: emulators/__init__.py:386-388)
+            keys = {'const': np.array([float(getattr(pt, ename))], dtype='f8')}
+        for key, value in keys.items(): cfg[p + 'emu{:d}.{}'.format(ie, key)] = value
+    # fold: theory vector [n_ell * n_k] = fold . phi, phi[(h, m)] = basis_h(x) monomial_m(pars)
+    kpt, k = np.asarray(pt.k, dtype='f8'), np.asarray(theory.k, dtype='f8')
+    ptells = list(pt.ells)
+    index = [ptells.index(ell) for ell in theory.ells]
+    nb = table['table'].shape[0]
+    tab = table['table'].reshape(nb, len(ptells), kpt.size, 19)[:, index]                                                         # [h, ell, kpt, m]
+    interp = np.asarray(interp1d(k, kpt, np.eye(kpt.size)), dtype='f8')                                                           # the reference's own interpolation (desilike/jax.py:211-265), linear in the table
+    fold = np.einsum('kq,hlqm->lkhm', interp, tab).reshape(len(index) * k.size, nb * 19)
+    window = None if wm.matrix_full is None else np.asarray(wm.matrix_full, dtype='f8')
+    offset = None if getattr(wm, 'offset', None) is None else np.asarray(wm.offset, dtype='f8')
+    shotnoisein = np.asarray(wm.shotnoisein, dtype='f8')
+    if np.any(shotnoisein != 0.):    # W . (sn_in (x) 1) (window.py:471) does not map onto the feature columns: into the offset
+        vector = np.repeat(shotnoisein, len(wm.kin))
+        extra = vector if window is None else window.dot(vector)
+        offset = extra if offset is None else offset + extra
+    cfg[p + 'wmatrix'] = fold if window is None else window.dot(fold)
+    if offset is not None: cfg[p + 'offset'] = offset
+    if getattr(wm, 'kmask', None) is not None: cfg[p + 'kmask'] = np.asarray(wm.kmask, dtype='i4')
+    cfg[p + 'shotnoise_out'] = np.asarray(wm.shotnoiseout, dtype='f8')
+    cfg[p + 'flatdata'] = np.asarray(obs.flatdata, dtype='f8')
+    if solved: cfg[p + 'marg.vp'] = np.array([sindex(n) for n in vp], dtype='i4')
 
 
 def extract_config(likelihood):
@@ -106,6 +251,10 @@ def extract_config(likelihood):
         p = 'obs{:d}.'.format(iobs)
         wm = obs.wmatrix
         theory = wm.theory
+        node = theory.pt if _has(theory, 'pt') else None
+        if node is not None and _has(node, 'emulator'):                     # emulated perturbation-theory node (emulators/__init__.py:394-418): BASELINE configs[2]
+            _extract_emulated(cfg, p, obs, theory, node, column, value_of, sindex, solved)
+            continue
         xi = hasattr(theory, 'get_corr')                                    # correlation function multipoles: Hankel transform of a power spectrum theory
         ptheory = theory.power if xi else theory                           # the tracer power spectrum calculator ...
         pt = ptheory.pt if 'pt' in ptheory.__dict__ or hasattr(type(ptheory), 'pt') or _has(ptheory, 'pt') else ptheory   # ... (the BAO correlation function classes hold the wiggle calculator itself: bao.py:881-905)

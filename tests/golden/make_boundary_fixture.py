@@ -36,13 +36,63 @@ def covariance(n, seed):
     return A.dot(A.T) + 1e4 * np.eye(n)
 
 
+def exact_quadratic(logpost, x0):
+    """(c, g, H) with ``logpost(x0 + d) = c + g.d + d.H.d / 2`` EXACTLY: the reference's log-posterior is a quadratic polynomial of the parameters its theory is linear in, so
+    the values at x0, x0 +- s_i e_i and x0 + s_i e_i + s_j e_j determine it with no truncation error, whatever the steps.  The steps are chosen for the ROUNDING: a first pass
+    at unit-like steps estimates the curvatures, the second takes s_i = 2^n ~ sqrt(2 |c| / |H_ii|) -- the second difference is then as large as the values themselves, so that
+    g and H carry the relative rounding of the reference's own values (~1e-15), not ~1e-9 as small-step finite differences of numbers of size |c| do.  Steps are powers of two:
+    x0 +- s, s^2 and s_i s_j are exact; differences are taken in extended precision."""
+    ld = np.longdouble
+    ns = len(x0)
+    f0 = ld(logpost(x0))
+    if not np.isfinite(float(f0)):      # a point outside the prior of a sampled parameter: nothing to solve
+        return float(f0), np.full(ns, np.nan), np.full((ns, ns), np.nan)
+
+    def diagonal(steps):
+        fp, fm = np.zeros(ns, dtype=ld), np.zeros(ns, dtype=ld)
+        for i in range(ns):
+            e = np.zeros(ns); e[i] = steps[i]
+            fp[i], fm[i] = logpost(x0 + e), logpost(x0 - e)
+        return fp, fm
+
+    steps = np.ones(ns)
+    for _ in range(2):
+        fp, fm = diagonal(steps)
+        assert np.isfinite(fp.astype('f8')).all() and np.isfinite(fm.astype('f8')).all(), 'step outside the prior of a solved parameter'
+        curvature = np.abs(((fp - 2 * f0 + fm) / ld(steps)**2).astype('f8'))
+        steps = 2.**np.round(np.log2(np.sqrt(2. * max(abs(float(f0)), 1.) / curvature)))
+    fp, fm = diagonal(steps)
+    s = steps.astype(ld)
+    g = (fp - fm) / (2 * s)
+    H = np.zeros((ns, ns), dtype=ld)
+    H[np.diag_indices(ns)] = (fp - 2 * f0 + fm) / s**2
+    for i in range(ns):
+        for j in range(i + 1, ns):
+            e = np.zeros(ns); e[i], e[j] = steps[i], steps[j]
+            H[i, j] = H[j, i] = (ld(logpost(x0 + e)) - fp[i] - fp[j] + f0) / (s[i] * s[j])
+    # the quadratic reproduces the reference at a point it was not built from
+    rng = np.random.RandomState(0)
+    d = (rng.uniform(-1., 1., ns) * steps)
+    check = float(f0 + g.dot(d) + 0.5 * d.dot(H).dot(d))
+    value = logpost(x0 + d)
+    assert abs(check - value) <= 1e-12 * max(1., abs(value), abs(float(f0))), (check, value)
+    return float(f0), g.astype('f8'), H.astype('f8')
+
+
+SELECTED = set(sys.argv[1:])     # fixture names to (re)generate; none: all of them
+
+
 def dump(name, likelihood, size=48, seed=42, unsolved=None):
-    """``unsolved``: for likelihoods with analytically solved parameters (the reference's ``_solve`` needs jax: not runnable here) the same pipeline WITHOUT the
+    """``likelihood`` / ``unsolved``: likelihoods, or callables that build them (so that only the selected fixtures cost anything).
+    ``unsolved``: for likelihoods with analytically solved parameters (the reference's ``_solve`` needs jax: not runnable here) the same pipeline WITHOUT the
     '.marg' / '.best' flags -- the reference evaluates that one on a stencil of the solved parameters, which gives the exact quadratic form (value, gradient, Hessian)
     of its log-posterior in them; the closed forms of the marginalised / profiled posterior follow (the pin of tests/golden/make_golden.py::marg_multi)."""
+    if SELECTED and name not in SELECTED: return
+    if not hasattr(likelihood, 'all_params'): likelihood = likelihood()
+    if unsolved is not None and not hasattr(unsolved, 'all_params'): unsolved = unsolved()
     try:
         likelihood()
-    except ModuleNotFoundError as exc:   # analytic solve (likelihoods/base.py:130: jax): the pipeline itself has been initialised and calculated by then
+    except (ModuleNotFoundError, AttributeError) as exc:   # analytic solve (likelihoods/base.py:130, 157: jax): the pipeline itself has been initialised and calculated by then
         assert 'jax' in str(exc) and unsolved is not None
     cfg = extract_config(likelihood)
     names = [str(n) for n in cfg['__varied__']]
@@ -55,25 +105,10 @@ def dump(name, likelihood, size=48, seed=42, unsolved=None):
         out['solved'] = np.array(solved)
         unsolved()
         x0 = np.array([likelihood.all_params[n].value for n in solved])
-        steps = np.array([max(abs(likelihood.all_params[n].proposal or 1.), 1e-2) * 5. for n in solved])
-        ns = len(solved)
         rows = []
         for row in theta[:12]:
             base = dict(zip(names, row))
-
-            def logpost(x): return unsolved(**{**base, **dict(zip(solved, x))})
-
-            f0 = logpost(x0)
-            g, H, fp = np.zeros(ns), np.zeros((ns, ns)), np.zeros(ns)
-            for i in range(ns):
-                e = np.zeros(ns); e[i] = steps[i]
-                fp[i], fm = logpost(x0 + e), logpost(x0 - e)
-                g[i], H[i, i] = (fp[i] - fm) / (2. * steps[i]), (fp[i] - 2. * f0 + fm) / steps[i]**2
-            for i in range(ns):
-                for j in range(i + 1, ns):
-                    e = np.zeros(ns); e[i], e[j] = steps[i], steps[j]
-                    H[i, j] = H[j, i] = (logpost(x0 + e) - fp[i] - fp[j] + f0) / (steps[i] * steps[j])
-            rows.append((f0, g, H))
+            rows.append(exact_quadratic(lambda x: unsolved(**{**base, **dict(zip(solved, x))}), x0))
         out.update(marg_x0=x0, marg_c=np.array([r[0] for r in rows]), marg_g=np.array([r[1] for r in rows]), marg_H=np.array([r[2] for r in rows]))
         errors = {}
     else:
@@ -82,6 +117,87 @@ def dump(name, likelihood, size=48, seed=42, unsolved=None):
     fn = os.path.join(here, 'boundary_{}.npz'.format(name))
     np.savez_compressed(fn, **out)
     print('saved', fn, '{:.1f} kB'.format(os.path.getsize(fn) / 1e3), 'keys', len(cfg) - 1, 'errors', len(errors))
+
+
+def emulated_pt(cls, engines, params, specs, k, ells=(0, 2, 4), z=0.8):
+    """A REAL ``EmulatedCalculator`` of the reference (emulators/__init__.py:394-418) built by the reference's own ``Emulator.to_calculator`` (150-208) from a fitted
+    state: the engines are the third-party part (cosmoprimo.emulators.tools, absent: tests/golden/refstub stands in with the attribute surface the reference's code
+    fixes -- ``center / powers / derivatives`` (emulators/__init__.py:471-507), ``model_operations`` / ``xoperations`` / ``yoperations`` with ``_locals``
+    (emulators/conversion.py:20-96)); they are DATA here: weights and limits from tests/emulator_utils.py, nothing is trained."""
+    from desilike.emulators import Emulator, Operation, MLPEmulatorEngine, TaylorEmulatorEngine
+    from desilike.io import BaseConfig
+    from desilike.parameter import ParameterCollection, Parameter
+    from desilike.utils import serialize_class
+
+    def mlp(e):
+        engine = MLPEmulatorEngine.__new__(MLPEmulatorEngine)
+        engine.model_operations = []
+        for ilayer, (kernel, bias) in enumerate(e['layers']):                                   # the reference's own expression strings: emulators/conversion.py:25-34, 75-79
+            engine.model_operations.append(Operation('(v[..., None, :] @ kernel)[..., 0, :] + bias', locals={'kernel': kernel, 'bias': bias}))
+            if ilayer < len(e['layers']) - 1: engine.model_operations.append(Operation('v / (1 + jnp.exp(-v))', locals={}))
+        yshape = tuple(e['yshape']) if tuple(e['yshape']) != (1,) else ()
+        engine.xoperations = [Operation('(v - limits[..., 0]) / (limits[..., 1] - limits[..., 0])', locals={'limits': np.asarray(e['xlimits'])})]
+        engine.yoperations = [Operation('((v - limits[..., 0]) / (limits[..., 1] - limits[..., 0]))', inverse='v * (limits[..., 1] - limits[..., 0]) + limits[..., 0]',
+                                        locals={'limits': np.asarray(e['ylimits']).reshape(yshape + (2,))})]
+        engine.params, engine.xshape, engine.yshape = list(params), (len(params),), yshape
+        return engine
+
+    def taylor(e):
+        engine = TaylorEmulatorEngine.__new__(TaylorEmulatorEngine)
+        engine.center, engine.powers, engine.derivatives = np.asarray(e['center'], dtype='f8'), np.asarray(e['powers'], dtype='i4'), np.asarray(e['derivatives'], dtype='f8')
+        engine.xoperations, engine.yoperations = [], []
+        engine.params, engine.xshape, engine.yshape = list(params), (len(params),), engine.derivatives.shape[1:]
+        return engine
+
+    emulator = Emulator.__new__(Emulator)
+    emulator.engines = {name: (taylor(e) if 'derivatives' in e else mlp(e)) for name, e in engines.items()}
+    emulator.xoperations, emulator.yoperations, emulator.defaults = [], [], {}
+    emulator.fixed = {'k': np.asarray(k, dtype='f8'), 'ells': tuple(ells), 'z': np.array(z)}
+    emulator.varied_params = list(params)
+    emulator.in_calculator_state = ['pktable']
+    emulator.is_calculator_sequence = False
+    emulator.calculator__class__ = serialize_class(cls)
+    emulator.yaml_data = BaseConfig({'class': cls.__name__, 'info': {}, 'params': {}})
+    emulator.all_params = ParameterCollection([Parameter(name, **spec) for name, spec in specs.items()])
+    return emulator.to_calculator()
+
+
+def emulated_fixtures():
+    """BASELINE configs[2] through the reference-side binding: the reference's velocileptors tracer classes on top of an ``EmulatedCalculator`` node."""
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    from desilike.theories.galaxy_clustering.full_shape import (LPTVelocileptorsPowerSpectrumMultipoles, LPTVelocileptorsTracerPowerSpectrumMultipoles,
+                                                                REPTVelocileptorsPowerSpectrumMultipoles, REPTVelocileptorsTracerPowerSpectrumMultipoles)
+    from emulator_utils import CFG3_PARAMS, CFG3_SPECS, cfg3_full_kpt, cfg3_full_engines, taylor_state, EMU_PARAMS
+    from golden_utils import load_golden
+    from make_golden import spd_covariance
+    kedges = np.linspace(0., 0.2, 41)
+
+    # the size SURVEY 8d states: MLP 6 -> 4 x 64 silu -> 3 * 128 * 19 outputs, n_kin = 400, binning window 120 x 1200; LPT, physical prior basis
+    def cfg3(marg):
+        pt = emulated_pt(LPTVelocileptorsPowerSpectrumMultipoles, cfg3_full_engines(), CFG3_PARAMS, CFG3_SPECS, cfg3_full_kpt())
+        theory = LPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, tracer='LRG')
+        if marg:
+            for name in ['alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p']: theory.init.params[name].update(derived='.marg')
+        theory.init.params['sn4p'].update(fixed=True, value=0.3)
+        obs = TracerPowerSpectrumMultipolesObservable(data={'b1p': 1.6, 'b2p': 0.3, 'alpha0p': 2.}, kedges=kedges, ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=8e3)
+        return ObservablesGaussianLikelihood(observables=[obs], covariance=spd_covariance(120, seed=9, diag=4e4, amp=40.))
+
+    dump('cfg3', lambda: cfg3(False), size=24, seed=19)
+    dump('cfg3_marg', lambda: cfg3(True), size=24, seed=19, unsolved=lambda: cfg3(False))
+
+    # Taylor engines (exact second-order tables of fixture cfg3_velocileptors_table), REPT with its co-evolution shift, physical basis; and the standard basis
+    def cfg3_taylor(prior_basis):
+        g = load_golden('cfg3_velocileptors_table')
+        specs = {'qpar': dict(value=1., prior=dict(limits=[0.8, 1.2]), ref=dict(limits=[0.98, 1.02])), 'qper': dict(value=1., prior=dict(limits=[0.8, 1.2]), ref=dict(limits=[0.98, 1.02])),
+                 'dm': dict(value=0., prior=dict(limits=[-1., 1.]), ref=dict(limits=[-0.05, 0.05]))}
+        pt = emulated_pt(REPTVelocileptorsPowerSpectrumMultipoles, taylor_state(g), EMU_PARAMS, specs, g['obs0']['kpt'])
+        theory = REPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, tracer='ELG', prior_basis=prior_basis)
+        data = {'b1p': 1.2, 'b2p': 0.4} if prior_basis == 'physical' else {'b1': 1.7, 'b2': 0.4, 'alpha0': 3.}
+        obs = TracerPowerSpectrumMultipolesObservable(data=data, kedges=np.linspace(0.02, 0.2, 37), ells=(0, 2, 4), wmatrix={'resolution': 2}, theory=theory, shotnoise=8e3)
+        return ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
+
+    dump('cfg3_taylor', lambda: cfg3_taylor('physical'), size=24, seed=29)
+    dump('cfg3_taylor_standard', lambda: cfg3_taylor('standard'), size=24, seed=39)
 
 
 def main():
@@ -130,10 +246,10 @@ def main():
         A = rng.standard_normal((n, n)) * scale
         return ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + (10. * scale)**2 * np.eye(n))
 
-    dump('cfg4_xi', bao_likelihood('xi'), size=24, seed=9)
-    dump('cfg4_pk', bao_likelihood('pk'), size=24, seed=9)
+    dump('cfg4_xi', lambda: bao_likelihood('xi'), size=24, seed=9)
+    dump('cfg4_pk', lambda: bao_likelihood('pk'), size=24, seed=9)
     # (5) the DESI-style BAO fit: every broadband term solved analytically
-    dump('cfg4_xi_marg', bao_likelihood('xi', marg=True), size=24, seed=9, unsolved=bao_likelihood('xi'))
+    dump('cfg4_xi_marg', lambda: bao_likelihood('xi', marg=True), size=24, seed=9, unsolved=lambda: bao_likelihood('xi'))
     # (6) Kaiser xi_ell (ShapeFit template)
     theory = KaiserTracerCorrelationFunctionMultipoles(template=ShapeFitPowerSpectrumTemplate(z=0.5))
     obs = TracerCorrelationFunctionMultipolesObservable(data={'b1': 2.}, s=np.linspace(22.5, 167.5, 30), ells=(0, 2, 4), theory=theory)
@@ -153,7 +269,9 @@ def main():
                                                                        wmatrix={'resolution': 4}, theory=theory, shotnoise=shotnoise))
         return ObservablesGaussianLikelihood(observables=observables, covariance=covariance(210, 22))
 
-    dump('two_tracers_marg', two_tracers(True), size=24, seed=24, unsolved=two_tracers(False))
+    dump('two_tracers_marg', lambda: two_tracers(True), size=24, seed=24, unsolved=lambda: two_tracers(False))
+    # (8) BASELINE configs[2]: emulated perturbation-theory node
+    emulated_fixtures()
 
 
 if __name__ == '__main__':

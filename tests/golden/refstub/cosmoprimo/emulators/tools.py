@@ -1,22 +1,122 @@
-class Emulator(object):
-    pass
+"""Stand-in for the un-vendored ``cosmoprimo.emulators.tools`` (TEST INFRASTRUCTURE ONLY; never shipped to the GPU box).
 
+The reference's ``desilike.emulators`` subclasses these third-party classes (``/root/reference/desilike/emulators/__init__.py:55, 430, 510``); its OWN code fixes the
+attribute surface that is restated here, nothing more:
 
-class PointEmulatorEngine(object):
-    pass
+* Taylor engine: ``center``, ``powers``, ``derivatives`` (written by the reference's ``_fit_no_operation``, emulators/__init__.py:471-507), ``params``, ``xshape``, ``yshape``;
+* MLP engine: ``model_operations`` = list of :class:`Operation` whose ``_locals`` hold ``kernel`` / ``bias`` and whose expressions are the reference's own strings
+  (emulators/conversion.py:20-35), ``xoperations`` / ``yoperations`` = min-max scalers with ``_locals['limits']`` (conversion.py:75-79; ``operation._locals`` /
+  ``operation.update(locals=...)``: full_shape.py:1440-1441);
+* emulator: ``engines``, ``xoperations``, ``yoperations``, ``defaults``, ``fixed``, ``varied_params``, ``in_calculator_state``, ``predict(params) -> state``,
+  ``deepcopy`` (emulators/__init__.py:150-208, 386-409; full_shape.py:1416-1443).
 
+With it ``Emulator.to_calculator()`` -- the reference's own code -- builds a real ``EmulatedCalculator`` that the reference's velocileptors tracer classes accept as ``pt``.
+The forward pass below is plain NumPy evaluation of the operations' own expression strings; the engine is third-party: parity of the engine itself stays unpinned.
+"""
+import copy
 
-class TaylorEmulatorEngine(object):
-    pass
-
-
-class MLPEmulatorEngine(object):
-    pass
+import numpy as np
 
 
 class Operation(object):
+    """``direct`` / ``inverse``: Python expressions of ``v`` (the array or state dictionary), ``X`` (inputs) and the ``locals``; ``jnp`` is NumPy here."""
+
+    def __init__(self, direct='v', inverse=None, locals=None):
+        self._direct, self._inverse, self._locals = direct, inverse, dict(locals or {})
+
+    def _eval(self, expression, v, X=None):
+        if not expression: return v
+        scope = {'np': np, 'jnp': np, 'v': v, 'X': X}
+        scope.update(self._locals)
+        toret = None
+        for piece in expression.split(';'):     # "statement; statement; v" (conversion.py:50-51)
+            piece = piece.strip()
+            if not piece: continue
+            try:
+                toret = eval(piece, scope)
+            except SyntaxError:
+                exec(piece, scope); toret = scope['v']
+        return toret
+
+    def __call__(self, v, X=None):
+        return self._eval(self._direct, v, X=X)
+
+    def inverse(self, v, X=None):
+        return self._eval(self._inverse, v, X=X)
+
+    def update(self, **kwargs):
+        for name, value in kwargs.items(): setattr(self, '_' + name, value)
+
+    def clone(self, **kwargs):
+        new = self.copy()
+        new.update(**kwargs)
+        return new
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+    def __getstate__(self):
+        return {'direct': self._direct, 'inverse': self._inverse, 'locals': self._locals}
+
+    def __setstate__(self, state):
+        self._direct, self._inverse, self._locals = state['direct'], state['inverse'], dict(state['locals'])
+
+
+class PCAOperation(Operation):
     pass
 
 
-class PCAOperation(object):
-    pass
+class BaseEmulatorEngine(object):
+    name = 'base'
+
+    def __init__(self, params=None, xshape=None, yshape=None, xoperations=None, yoperations=None):
+        self.params, self.xshape, self.yshape = params, xshape, yshape
+        self.xoperations, self.yoperations = list(xoperations or []), list(yoperations or [])
+
+    def predict(self, X):
+        v = np.asarray(X, dtype='f8')
+        for operation in self.xoperations: v = operation(v, X=X)
+        v = self._predict_no_operation(v)
+        for operation in self.yoperations[::-1]: v = operation.inverse(v, X=X)
+        return v
+
+
+class PointEmulatorEngine(BaseEmulatorEngine):
+    name = 'point'
+
+
+class TaylorEmulatorEngine(BaseEmulatorEngine):
+    """``y = sum_t derivatives[t] prod_p (x_p - center_p)^powers[t, p]``, derivatives already divided by the factorials (emulators/__init__.py:471-507)."""
+    name = 'taylor'
+
+    def _predict_no_operation(self, x):
+        monomials = np.prod((x - self.center)**self.powers, axis=-1)
+        return np.tensordot(monomials, self.derivatives, axes=(0, 0))
+
+
+class MLPEmulatorEngine(BaseEmulatorEngine):
+    name = 'mlp'
+
+    def _predict_no_operation(self, x):
+        v = x
+        for operation in self.model_operations: v = operation(v)
+        return np.asarray(v).reshape(self.yshape)
+
+
+class Emulator(object):
+
+    def predict(self, params):
+        X = np.array([params[name] for name in self.varied_params], dtype='f8')
+        state = {name: engine.predict(X) for name, engine in self.engines.items()}
+        state.update(self.fixed)
+        for operation in self.yoperations[::-1]: state = operation.inverse(state, X=params)
+        return state
+
+    def deepcopy(self):
+        return copy.deepcopy(self)
+
+    def __getstate__(self):
+        return dict(self.__dict__)
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)

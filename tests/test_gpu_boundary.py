@@ -15,8 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(ROOT, 'integration'))
 
-FIXTURES = ['cfg2_dense', 'two_tracers', 'eft_qisoqap', 'cfg4_xi', 'cfg4_pk', 'kaiser_xi', 'tns', 'tns_eft', 'png', 'turnover', 'bands', 'png_velocity']     # cfg4_*: BASELINE configs[3] (damped BAO); *_xi: the reference's own get_corr as a folded operator; tns*: the reference's one-loop TNS theory (tests/golden/make_tns_fixture.py)
-MARG_FIXTURES = ['cfg4_xi_marg', 'two_tracers_marg']                                                  # analytically solved parameters ('.marg')
+FIXTURES = ['cfg2_dense', 'two_tracers', 'eft_qisoqap', 'cfg4_xi', 'cfg4_pk', 'kaiser_xi', 'tns', 'tns_eft', 'png', 'turnover', 'bands', 'png_velocity', 'cfg3', 'cfg3_taylor', 'cfg3_taylor_standard']     # cfg4_*: BASELINE configs[3] (damped BAO); *_xi: the reference's own get_corr as a folded operator; tns*: the reference's one-loop TNS theory (tests/golden/make_tns_fixture.py)
+MARG_FIXTURES = ['cfg4_xi_marg', 'two_tracers_marg', 'cfg3_marg']                                     # analytically solved parameters ('.marg'); cfg3*: BASELINE configs[2], the reference's
+# velocileptors tracer on a real EmulatedCalculator node (MLP 6 -> 4 x 64 -> 7296 / Taylor engines) built by the reference's own Emulator.to_calculator
 
 
 def load_fixture(name):
@@ -48,8 +49,10 @@ def test_context_from_reference_side_keys(name):
 @pytest.mark.parametrize('name', MARG_FIXTURES)
 def test_marginalised_context_from_reference_side_keys(name):
     """Contexts with analytically solved parameters, created from the reference-side keys through ctypes.  The reference's own ``_solve`` needs jax (absent here): the
-    fixture holds the exact quadratic form (c, g, H) of the reference's NON-marginalised log-posterior in the solved parameters x (evaluated by the reference on a
-    stencil), from which  x* = x0 - H^-1 g,  logposterior = c - g H^-1 g / 2 - logdet(-H) / 2  (likelihoods/base.py:385-404: no 2 pi) follow exactly."""
+    fixture holds the exact quadratic form (c, g, H) of the reference's NON-marginalised log-posterior in the solved parameters x (the posterior IS a quadratic polynomial
+    of them: values at x0, x0 +- s_i e_i, x0 + s_i e_i + s_j e_j with steps as large as the curvature allows determine it to the rounding of the reference's own values:
+    tests/golden/make_boundary_fixture.py::exact_quadratic), from which  x* = x0 - H^-1 g,  logposterior = c - g H^-1 g / 2 - logdet(-H) / 2  (likelihoods/base.py:385-404:
+    no 2 pi) follow exactly.  Tolerance: the north star's 1e-10."""
     import torch  # noqa: F401
     from desilike_mi355x import Library
     g, cfg = load_fixture(name)
@@ -66,9 +69,8 @@ def test_marginalised_context_from_reference_side_keys(name):
         dx = -np.linalg.solve(H, grad)
         ref = c + 0.5 * grad.dot(dx) - 0.5 * np.linalg.slogdet(-H)[1]
         got = loglike[i] + logprior[i]
-        assert abs(got - ref) <= 1e-8 * max(1., abs(ref)), (i, got, ref)            # (the stencil's finite differences of an exact quadratic: rounding ~1e-9 of |c|)
-        # (x* from differences of log-posteriors of size |c| over the stencil: the gradient carries ~1e-13 |c| / step of rounding -- parts in 1e5 of the small broadband terms)
-        assert np.allclose(solved[i], g['marg_x0'] + dx, rtol=1e-4, atol=1e-6 * np.abs(g['marg_x0'] + dx).max())
+        assert abs(got - ref) <= 1e-10 * max(1., abs(ref)), (i, got, ref)
+        assert np.allclose(solved[i], g['marg_x0'] + dx, rtol=1e-7, atol=1e-9 * np.abs(g['marg_x0'] + dx).max())
     library.lib.dl_destroy(ctx)
 
 
@@ -122,6 +124,44 @@ def test_host_mirror_compiles_the_same_keys():
                 assert np.array_equal(mirror[key].reshape(-1, 5)[names.index(name)], value[iname]), name
         else:
             assert np.allclose(np.ravel(mirror[key]), np.ravel(value), rtol=1e-9 if key == 'precision' else 1e-13, atol=1e-14 if key == 'precision' else 1e-300), key
+
+
+def test_host_mirror_compiles_the_same_keys_for_the_emulated_node():
+    """BASELINE configs[2]: the keys ``extract_config`` read off the reference's LPT velocileptors tracer on a real ``EmulatedCalculator`` node are the keys the host mirror
+    compiles for the same pipeline written with its own classes and the same engine state."""
+    from desilike_amd._lib import fill_config
+    from desilike_amd.emulators import EmulatedCalculator, MLPEmulatorEngine
+    from desilike_amd.theories.galaxy_clustering import LPTVelocileptorsTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    from emulator_utils import CFG3_PARAMS, CFG3_SPECS, cfg3_full_kpt, cfg3_full_engines
+    for name, solved in [('cfg3', []), ('cfg3_marg', ['alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p'])]:
+        g, cfg = load_fixture(name)
+        engines = {key: MLPEmulatorEngine(xlimits=e['xlimits'], layers=e['layers'], activation='silu', ylimits=e['ylimits'], yshape=e['yshape']) for key, e in cfg3_full_engines().items()}
+        pt = EmulatedCalculator(CFG3_PARAMS, engines, k=cfg3_full_kpt(), ells=(0, 2, 4), z=0.8, param_specs=CFG3_SPECS)
+        theory = LPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, tracer='LRG')
+        for pname in solved: theory.init.params[pname].update(derived='.marg')
+        theory.init.params['sn4p'].update(fixed=True, value=0.3)
+        obs = TracerPowerSpectrumMultipolesObservable(data=cfg['obs0.flatdata'], kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=8e3)
+        rng = np.random.RandomState(9)
+        A = rng.standard_normal((120, 120)) * 40.
+        like = ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + 4e4 * np.eye(120))
+        like.initialize()
+        mirror = {}
+        fill_config(like._spec({}, like._flatdata_list(), like.precision), lambda key, a: mirror.__setitem__(key, a), lambda key, a: mirror.__setitem__(key, a))
+        names, rnames = like.varied_params.names(), [str(n) for n in g['names']]
+        assert sorted(names) == sorted(rnames) and like.solved_params.names() == solved == [str(n) for n in g['solved']] if solved else sorted(names) == sorted(rnames)
+        for key, value in cfg.items():
+            assert key in mirror, key
+            if '.in.' in key:
+                for (col, const), (rcol, rconst) in zip(mirror[key].reshape(-1, 2), value.reshape(-1, 2)):
+                    assert (col < 0) == (rcol < 0) and (names[int(col)] == rnames[int(rcol)] if col >= 0 else const == rconst), key
+            elif key == 'priors':
+                for iname, pname in enumerate(rnames):
+                    assert np.array_equal(mirror[key].reshape(-1, 5)[names.index(pname)], value[iname]), pname
+            else:
+                scale = np.abs(np.ravel(value)).max() if np.ravel(value).dtype.kind == 'f' else 0.
+                assert np.allclose(np.ravel(mirror[key]), np.ravel(value), rtol=1e-9 if key == 'precision' else 1e-12, atol=1e-13 * scale), key
 
 
 @pytest.mark.gpu
