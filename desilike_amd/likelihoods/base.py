@@ -384,6 +384,16 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
 
     MAX_CONTEXTS = 32
 
+    def _evict(self):
+        """Keep the cache of compiled contexts bounded: the oldest entries are DROPPED, never closed -- a device-resident ensemble / Metropolis-Hastings runner (one replica
+        per chain or stream) or a caller of ``_get_context`` may still hold one; runners keep a reference to their context, and an unreferenced ``Context`` frees its device
+        memory in ``__del__``.  The spec of a configuration goes with its last context."""
+        while len(self._contexts) > self.MAX_CONTEXTS:
+            self._contexts.pop(next(iter(self._contexts)))
+        base = {key[2:] if key and key[0] == 'replica' else key for key in self._contexts}
+        for key in [key for key in self._context_specs if key not in base]:
+            del self._context_specs[key]
+
     def _replica(self, key, replica):
         """Context ``replica`` > 0 of the compiled configuration ``key``: same constants, its own device workspaces -- callers that keep several evaluations in flight
         on different HIP streams (chains of a chain-parallel sampler, pipelined batches) need one context per stream (calls on ONE context are serialised by contract:
@@ -391,9 +401,10 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         from .._lib import Context
         rkey = ('replica', int(replica)) + key
         if rkey not in self._contexts:
-            if len(self._contexts) > self.MAX_CONTEXTS:
-                self._contexts.pop(next(iter(self._contexts))).close()
-            self._contexts[rkey] = Context(self._context_specs[key], device=self.device)
+            spec = self._context_specs[key]
+            self._evict()
+            self._context_specs[key] = spec
+            self._contexts[rkey] = Context(spec, device=self.device)
         return self._contexts[rkey]
 
     def _get_context(self, fixed_values=None, replica=0):
@@ -403,8 +414,7 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         fixed_values = dict(fixed_values or {})
         key = tuple(sorted(fixed_values.items()))
         if key not in self._contexts:
-            if len(self._contexts) > self.MAX_CONTEXTS:
-                self._contexts.pop(next(iter(self._contexts))).close()
+            self._evict()
             flatdata, precision = self._flatdata_list(), self._precision_input
             if len(self.prec_params):
                 flatdata, precision = self._marginalize_precision(fixed_values, flatdata, precision)
@@ -490,8 +500,7 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
             offset = -0.5 * np.linalg.slogdet(A[np.ix_(marg, marg)])[1] if marg.any() else 0.                                     # likelihoods/base.py:394-404
             spec = self._spec(base, new_flatdata, factor.dot(factor.T), drop_solved=True)
             spec['precision_factor'] = factor
-            if len(self._contexts) > self.MAX_CONTEXTS:
-                self._contexts.pop(next(iter(self._contexts))).close()
+            self._evict()
             self._context_specs[key] = spec
             self._contexts[key] = Context(spec, device=self.device)
             self._posterior_offsets = getattr(self, '_posterior_offsets', {})
@@ -755,13 +764,13 @@ class SumLikelihood(BaseLikelihood):
         self.initialize()
         return self._fused.evaluate_batch(*args, **kwargs)
 
-    def _get_context(self, fixed_values=None):
+    def _get_context(self, fixed_values=None, replica=0):
         self.initialize()
-        return self._fused._get_context(fixed_values)
+        return self._fused._get_context(fixed_values, replica=replica)
 
     def _get_posterior_context(self, fixed_values=None, replica=0):
         self.initialize()
-        return self._fused._get_posterior_context(fixed_values)
+        return self._fused._get_posterior_context(fixed_values, replica=replica)
 
     def evaluate_logposterior(self, *args, **kwargs):
         self.initialize()

@@ -208,3 +208,36 @@ def test_default_fiducial_warns():
             ShapeFitPowerSpectrumTemplate(z=0.5).initialize()
     with pytest.raises(ValueError):
         get_fiducial('planck')
+
+
+def test_context_cache_eviction_never_closes_and_replicas_are_distinct(monkeypatch):
+    """The cache of compiled contexts is bounded by dropping references, never by closing: a device-resident runner (one replica per chain / stream) may still hold an
+    evicted context (more than MAX_CONTEXTS chains on one rank was a use-after-free).  ``SumLikelihood`` hands out one context per replica too."""
+    from desilike_amd import _lib
+    from desilike_amd.likelihoods import SumLikelihood
+
+    class FakeContext(object):
+        closed, created = [], 0
+
+        def __init__(self, spec, device=0):
+            FakeContext.created += 1
+            self.spec = spec
+
+        def close(self):
+            FakeContext.closed.append(self)
+
+    monkeypatch.setattr(_lib, 'Context', FakeContext)
+    g, like = make_cfg2()
+    like.initialize()
+    monkeypatch.setattr(type(like), 'MAX_CONTEXTS', 4)
+    held = [like._get_context(replica=i) for i in range(12)]          # what 12 chains of a chain-parallel sampler hold
+    assert len(set(map(id, held))) == 12 and FakeContext.closed == []
+    assert len(like._contexts) <= 5
+    assert like._get_context(replica=11) is held[11]
+    like._get_context(replica=3)                                      # an evicted replica is compiled again from the kept spec
+    like._get_context({'df': 1.01})
+    assert FakeContext.closed == []
+    g2, like2 = make_cfg2()
+    total = SumLikelihood(likelihoods=[like2])
+    a, b = total._get_posterior_context(replica=0)[0], total._get_posterior_context(replica=1)[0]
+    assert a is not b and total._get_context(replica=1) is b
