@@ -62,6 +62,11 @@ struct dl_ctx {
     int32_t* status_stage = nullptr; // device
     double* host_stage = nullptr;    // pinned host mirror: theta[cap * P] | out[3 * cap]
     hipStream_t host_stream = nullptr;   // private stream of the *_host entry points
+    double* host_stage_dev = nullptr;    // the pinned buffer as the device sees it (hipHostMallocMapped): theta read and results written by the kernels themselves
+    uint64_t* host_flag = nullptr;       // pinned, mapped: sequence number of the last finished *_host call, written by the device after the results
+    uint64_t* host_flag_dev = nullptr;
+    uint64_t host_seq = 0;
+    hipEvent_t host_event = nullptr;
     // analytic gradient (dl_eval_logposterior_grad): -W~^T [K_pad, N_pad], a zero bias [K_pad], residual rows [cap, N_pad], Y [cap, K_pad], per-observable sums [cap, n_obs, 8]
     double *grad_wtT = nullptr, *grad_zero = nullptr, *grad_delta = nullptr, *grad_y = nullptr, *grad_phys = nullptr;
     int32_t* grad_status = nullptr;
@@ -433,6 +438,8 @@ void dl_destroy(dl_ctx* ctx) {
     for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+    if (ctx->host_flag) (void)hipHostFree(ctx->host_flag);
+    if (ctx->host_event) (void)hipEventDestroy(ctx->host_event);
     if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
     delete ctx;
 }
@@ -782,38 +789,91 @@ static int dl_stage_reserve(dl_ctx* ctx, int64_t B) {
     int64_t cap = std::max<int64_t>(B, 64);
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->theta_stage, (size_t)cap * ctx->n_params * sizeof(double)));
     DL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->out_stage, (size_t)cap * 3 * sizeof(double)));   // per call: loglike[B] | logprior[B] | status[B] (int32), one block
-    DL_HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->host_stage, (size_t)cap * (ctx->n_params + 3) * sizeof(double), hipHostMallocDefault));
+    DL_HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->host_stage, (size_t)cap * (ctx->n_params + 3) * sizeof(double), hipHostMallocMapped));
+    DL_HIP_CHECK(ctx, hipHostGetDevicePointer((void**)&ctx->host_stage_dev, ctx->host_stage, 0));
+    if (!ctx->host_flag) {
+        DL_HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->host_flag, 64, hipHostMallocMapped));
+        DL_HIP_CHECK(ctx, hipHostGetDevicePointer((void**)&ctx->host_flag_dev, ctx->host_flag, 0));
+        *ctx->host_flag = 0;
+        DL_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->host_event, hipEventDisableTiming));
+    }
     ctx->stage_cap = cap;
     return 0;
 }
 
-// Host-pointer evaluation: theta through a pinned staging buffer, one asynchronous copy in, the kernels, ONE copy out (loglike | logprior | status packed in one
-// block), one synchronisation of a private stream (the first version used pageable copies on the default stream: 109 us per 256-point call for 34 us of kernels).
+// Completion flag of the mapped *_host path: launched after the last kernel of the call on the same (in-order) stream, so every result -- written by the kernels
+// straight into the caller-visible pinned buffer -- is out before the sequence number is; the host spins on it instead of paying a stream synchronisation.
+__global__ void dl_host_flag_kernel(uint64_t* flag, uint64_t seq) {
+    __threadfence_system();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// DL_HOST_MODE: 0 staged copies + stream synchronisation (the first version), 1 mapped buffers + stream synchronisation, 2 mapped + event polling,
+// 3 (default) mapped + completion flag (+ a stream query at the start of the next call), 4 the flag alone
+static int dl_host_mode() {
+    const char* env = std::getenv("DL_HOST_MODE");
+    return env ? std::atoi(env) : 3;
+}
+
+// Host-pointer evaluation (what the reference-side binding and any unmodified desilike sampler call: samplers/base.py:144-200, samplers/emcee.py:69).
+// Default (mode 3): theta is copied into a pinned, device-mapped buffer which the kernels read in place; the finalize kernel writes loglike | logprior | status
+// straight into the same buffer; a one-thread kernel then publishes the call's sequence number and the host spins on it -- no copy engine, no DtoH, no
+// hipStreamSynchronize (the staged version: one async copy in, one out, one synchronisation: 75 - 240 us per 256-point call depending on the box).
+// flattheory / solved outputs keep the staged path (large, rare).
 static int dl_eval_host_impl(dl_ctx* ctx, const double* theta, int64_t B, double* loglike, double* logprior, double* flattheory, int32_t* status, double* solved,
                              double* logposterior) {
     DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (dl_stage_reserve(ctx, B)) return 1;
     hipStream_t stream = ctx->host_stream;
     const int P = ctx->n_params;
+    int mode = dl_host_mode();
+    // the flag path never tells the runtime that a call has finished: without this query it retires ~1000 dispatches at once every ~250 calls (eight calls in a row
+    // 15 - 30 us slower); asked at the start of the next call, when the previous one is long finished, it retires them as it goes
+    if (mode == 3 && ctx->host_seq) (void)hipStreamQuery(stream);
     double *flat_dev = nullptr, *solved_dev = nullptr;
     if (flattheory) DL_HIP_CHECK(ctx, hipMalloc((void**)&flat_dev, (size_t)B * ctx->n_data * sizeof(double)));
     if (solved && ctx->n_solved > 0) DL_HIP_CHECK(ctx, hipMalloc((void**)&solved_dev, (size_t)B * ctx->n_solved * sizeof(double)));
+    if (flat_dev || solved_dev) mode = 0;
     double* host_in = ctx->host_stage;
     double* host_out = ctx->host_stage + (size_t)ctx->stage_cap * P;
     std::copy(theta, theta + (size_t)B * P, host_in);
-    DL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->theta_stage, host_in, (size_t)B * P * sizeof(double), hipMemcpyHostToDevice, stream));
-    double* ll_dev = ctx->out_stage;
-    double* lp_dev = ctx->out_stage + B;
-    int32_t* st_dev = reinterpret_cast<int32_t*>(ctx->out_stage + 2 * B);
+    const double* theta_dev = ctx->theta_stage;
+    double* out_dev = ctx->out_stage;
+    if (mode == 0) DL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->theta_stage, host_in, (size_t)B * P * sizeof(double), hipMemcpyHostToDevice, stream));
+    else { theta_dev = ctx->host_stage_dev; out_dev = ctx->host_stage_dev + (size_t)ctx->stage_cap * P; }
+    double* ll_dev = out_dev;
+    double* lp_dev = out_dev + B;
+    int32_t* st_dev = reinterpret_cast<int32_t*>(out_dev + 2 * B);
     int rc;
-    if (logposterior) rc = dl_eval_logposterior(ctx, ctx->theta_stage, B, ll_dev, st_dev, stream);
-    else rc = dl_eval_batch(ctx, ctx->theta_stage, B, ll_dev, lp_dev, flat_dev, st_dev, solved_dev, stream);
+    if (logposterior) rc = dl_eval_logposterior(ctx, theta_dev, B, ll_dev, st_dev, stream);
+    else rc = dl_eval_batch(ctx, theta_dev, B, ll_dev, lp_dev, flat_dev, st_dev, solved_dev, stream);
     if (rc == 0) {
-        const size_t out_bytes = (size_t)B * 2 * sizeof(double) + (size_t)B * sizeof(int32_t);
-        hipError_t e = hipMemcpyAsync(host_out, ctx->out_stage, out_bytes, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess && flattheory) e = hipMemcpyAsync(flattheory, flat_dev, (size_t)B * ctx->n_data * sizeof(double), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess && solved_dev) e = hipMemcpyAsync(solved, solved_dev, (size_t)B * ctx->n_solved * sizeof(double), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        hipError_t e = hipSuccess;
+        if (mode == 0) {
+            const size_t out_bytes = (size_t)B * 2 * sizeof(double) + (size_t)B * sizeof(int32_t);
+            e = hipMemcpyAsync(host_out, ctx->out_stage, out_bytes, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess && flattheory) e = hipMemcpyAsync(flattheory, flat_dev, (size_t)B * ctx->n_data * sizeof(double), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess && solved_dev) e = hipMemcpyAsync(solved, solved_dev, (size_t)B * ctx->n_solved * sizeof(double), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        } else if (mode == 1) {
+            e = hipStreamSynchronize(stream);
+        } else if (mode == 2) {
+            e = hipEventRecord(ctx->host_event, stream);
+            while (e == hipSuccess && (e = hipEventQuery(ctx->host_event)) == hipErrorNotReady) e = hipSuccess;
+        } else {
+            const uint64_t seq = ++ctx->host_seq;
+            dl_host_flag_kernel<<<1, 1, 0, stream>>>(ctx->host_flag_dev, seq);
+            e = hipGetLastError();
+            volatile uint64_t* flag = ctx->host_flag;
+            for (uint64_t spins = 0; e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spins) {
+                __builtin_ia32_pause();
+                if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(stream) != hipErrorNotReady) {   // a failed kernel never writes the flag: ask the runtime now and then
+                    e = hipStreamSynchronize(stream);
+                    if (e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) e = hipErrorUnknown;
+                    break;
+                }
+            }
+        }
         if (e != hipSuccess) rc = dl_fail(ctx, std::string("dl_eval_batch_host: ") + hipGetErrorString(e));
     }
     if (rc == 0) {

@@ -186,6 +186,218 @@ __device__ __forceinline__ void dl_eb_forward(const DlObsDev& o, const double* _
     }
 }
 
+// ---- forward pass of the FUSED kernels (records straight into LDS), restructured around its latencies (in-kernel stamps, config 3: the version above took 19 of the
+//      57 us of a workgroup's life with the matrix pipe idle): (i) the weights of a layer do not depend on the activations: every wave requests the weights of its NEXT tile
+//      before the activation / barrier of the current layer, the first layer's at kernel entry beside theta; (ii) the velocileptors 'pars' are fetched at entry too and
+//      the bias monomials are formed by one otherwise idle wave as soon as the scalar engines (sigma8, fsigma8: fewer layers) have finished, beside the remaining layers
+//      of the table engine, straight into the records; (iii) the last hidden layer of the table engine writes the basis into the records itself: no copy pass.  Barriers:
+//      entry, one per layer, the caller's (nine before).  Same arithmetic in the same order as dl_eb_forward: results are bit-identical.
+template <int NTHR>
+__device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const double* __restrict__ theta, int n_params, int64_t B, int64_t p0, double* lds, double* rec,
+                                                    int rec_stride, unsigned long long* st = nullptr) {
+    int st_slot = 8;   // DL_EF_STAMPS diagnostics: slots 8.. of the workgroup = after the entry barrier, then after every layer's barrier (the monomials before the first of the second run)
+#define DL_EB_STAMP if (st != nullptr && threadIdx.x == 0 && st_slot < 16) st[st_slot] = __builtin_amdgcn_s_memtime(); ++st_slot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, g = lane >> 4;
+    const int LD = dl_eb_ld(o);
+    double* x = lds;                                      // [16][DL_MAX_X]
+    double* bufs = x + DL_EB_PTS * DL_MAX_X;              // engine ie: [2][16][LD] at bufs + ie * 2 * 16 * LD
+    double* scal = bufs + 6 * DL_EB_PTS * LD;             // [16][4]: sigma8 (1), fsigma8 (2)
+    double* vpv = scal + DL_EB_PTS * 4;                   // [16][12]: velocileptors 'pars' inputs of the 16 points
+    constexpr int NW = NTHR / 64;
+    int n_mlp = 0, max_layers = 0, mono_at = 0;
+    bool any_taylor = false;
+    for (int ie = 0; ie < 3; ++ie) {
+        if (o.eng[ie].type == 0) { ++n_mlp; if (o.eng[ie].n_layers > max_layers) max_layers = o.eng[ie].n_layers; if (ie && o.eng[ie].n_layers > mono_at) mono_at = o.eng[ie].n_layers; }
+        if (o.eng[ie].type == 1) any_taylor = true;
+    }
+    int my_ie = -1, my_w0 = 0, my_nw = 1;
+    {
+        int w0 = 0;
+        for (int ie = 0; ie < 3; ++ie) {
+            if (o.eng[ie].type != 0) continue;
+            int nw = n_mlp == 1 ? NW : (n_mlp == 2 ? NW / 2 : (ie == 0 ? NW / 2 : NW / 4));
+            if (nw < 1) nw = 1;
+            if (wave >= w0 && wave < w0 + nw) { my_ie = ie; my_w0 = w0; my_nw = nw; }
+            w0 += nw;
+        }
+    }
+    const DlObsDev::Engine& e = o.eng[my_ie >= 0 ? my_ie : 0];
+    const double* w = e.weights;
+    const int t0 = wave - my_w0;                          // first tile of this wave in every layer
+    double bw[16], bbias = 0.;
+    // Two tile shapes are served from registers requested ahead of their use: kind 2 = a full tile of a 64-input layer (the hidden layers: sixteen k-steps, one
+    // pointer and a constant stride, no predicates), kind 1 = a layer with <= 16 inputs (input layers, the scalar engines' output layer: four k-steps, predicated by a
+    // clamped address and a select).  Everything else takes the general loop of dl_eb_forward, weights requested where they are used.
+    auto tile_kind = [&](int nin, int nout, int t) { return (nin == 64 && 16 * t + 16 <= nout) ? 2 : (nin <= 16 ? 1 : 0); };
+    auto request = [&](const double* wl, int nin, int nout, int t, int kind) {
+        const int oc = 16 * t + col;
+        if (kind == 2) {
+            const double* wp = wl + (unsigned)(g * nout + oc);
+            const unsigned ws = 4u * (unsigned)nout;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) bw[u] = wp[u * ws];
+            bbias = wl[(unsigned)(nin * nout + oc)];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * u + g;
+                const bool ok = k < nin && oc < nout;
+                const double v = wl[ok ? (unsigned)(k * nout + oc) : 0u];
+                bw[u] = ok ? v : 0.;
+            }
+            const double bv = wl[(unsigned)(nin * nout + (oc < nout ? oc : 0))];
+            bbias = oc < nout ? bv : 0.;
+        }
+    };
+    int have = 0;                                         // kind of the tile (t0 of the coming layer) whose weights bw / bbias hold, or 0
+    if (my_ie >= 0 && mono_at > 0 && e.n_layers > 0 && t0 < (e.widths[1] + 15) / 16) {
+        have = tile_kind(e.widths[0], e.widths[1], t0);
+        if (have) request(w, e.widths[0], e.widths[1], t0, have);
+    }
+    // inputs: x (Taylor engines), the scaled inputs of every MLP engine (conversion.py:75-77; zero-padded to a multiple of 4 columns), the 'pars' inputs
+    const int nin0 = (o.n_x + 3) & ~3;
+    for (int idx = tid; idx < DL_EB_PTS * nin0; idx += NTHR) {
+        const int pt = idx / nin0, i = idx - pt * nin0;
+        const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
+        const double v = i < o.n_x ? dl_get(o.x_in[i], theta + (size_t)b * n_params) : 0.;
+        if (i < o.n_x) x[pt * DL_MAX_X + i] = v;
+        for (int ie = 0; ie < 3; ++ie) {
+            const DlObsDev::Engine& en = o.eng[ie];
+            if (en.type == 0) bufs[(size_t)ie * 2 * DL_EB_PTS * LD + pt * LD + i] = i < o.n_x ? (v - en.xlo[i]) * en.xinv[i] : 0.;
+        }
+    }
+    for (int idx = tid; idx < DL_EB_PTS * DL_N_VPARS; idx += NTHR) {
+        const int pt = idx / DL_N_VPARS, c = idx - pt * DL_N_VPARS;
+        const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
+        vpv[pt * 12 + c] = dl_get(o.vp_in[c], theta + (size_t)b * n_params);
+    }
+    // bias row of the folded final layer (MLP table engine) and the zero padding of the basis
+    for (int idx = tid; idx < DL_EB_PTS * (o.nb_pad - o.n_basis + 1); idx += NTHR) {
+        const int pt = idx / (o.nb_pad - o.n_basis + 1), c = o.n_basis - 1 + (idx - pt * (o.nb_pad - o.n_basis + 1));
+        if (c >= o.n_basis) rec[pt * rec_stride + c] = 0.;
+        else if (o.eng[0].type == 0) rec[pt * rec_stride + c] = 1.;
+    }
+    __syncthreads();
+    DL_EB_STAMP
+    if (any_taylor) {   // Taylor engines: monomials prod_p (x_p - c_p)^powers[t, p] (emulators/__init__.py:471-507); table engine: they ARE the basis
+        for (int ie = 0; ie < 3; ++ie) {
+            const DlObsDev::Engine& en = o.eng[ie];
+            if (en.type != 1) continue;
+            double* dst = ie == 0 ? rec : bufs + (size_t)ie * 2 * DL_EB_PTS * LD;
+            const int ldd = ie == 0 ? rec_stride : LD;
+            for (int idx = tid; idx < DL_EB_PTS * en.n_terms; idx += NTHR) {
+                const int pt = idx / en.n_terms, t = idx - pt * en.n_terms;
+                double mon = 1.;
+                for (int p = 0; p < o.n_x; ++p) mon *= dl_ipow(x[pt * DL_MAX_X + p] - en.center[p], (int)en.powers[(size_t)t * o.n_x + p]);
+                dst[pt * ldd + t] = mon;
+            }
+        }
+        __syncthreads();
+        for (int ie = 1; ie < 3; ++ie) {
+            const DlObsDev::Engine& en = o.eng[ie];
+            if (en.type != 1 || tid >= DL_EB_PTS) continue;
+            const double* src = bufs + (size_t)ie * 2 * DL_EB_PTS * LD;
+            double sum = 0.;
+            for (int t = 0; t < en.n_terms; ++t) sum = fma(en.coef[t], src[tid * LD + t], sum);
+            scal[tid * 4 + ie] = sum;
+        }
+        __syncthreads();
+    }
+    auto monomials = [&]() {   // one lane per point of the last wave: 'pars' -> 19 monomials and the derivative rows, straight into the records (rows of 20)
+        if (wave == NW - 1 && lane < DL_EB_PTS) {
+            const double sigma8 = o.eng[1].type >= 0 ? scal[lane * 4 + 1] : o.eng[1].cst;
+            const double fsigma8 = o.eng[2].type >= 0 ? scal[lane * 4 + 2] : o.eng[2].cst;
+            dl_velocileptors_monomials(o, nullptr, sigma8, fsigma8, rec + (size_t)lane * rec_stride + o.nb_pad, DL_FG_MONO_LD, vpv + lane * 12);
+        }
+    };
+    double* cur = bufs + (size_t)(my_ie >= 0 ? my_ie : 0) * 2 * DL_EB_PTS * LD;
+    double* nxt = cur + DL_EB_PTS * LD;
+    if (mono_at > max_layers) mono_at = max_layers;
+    // layers [l0, l1): two calls, the monomials between them -- no prefetched weights are alive across that (register-hungry) code
+    auto run_layers = [&](int l0, int l1) {
+    for (int layer = l0; layer < l1; ++layer) {
+        if (my_ie >= 0 && layer < e.n_layers) {
+            const int nin = e.widths[layer], nout = e.widths[layer + 1];
+            const bool last = (layer == e.n_layers - 1);
+            const bool activate = !(last && my_ie != 0);   // the table engine stops after its last HIDDEN layer (its final linear layer is folded on the host)
+            const int ksteps = (nin + 3) / 4, tiles = (nout + 15) / 16, nout4 = (nout + 3) & ~3;
+            const double* wn = w + (size_t)nin * nout + nout;   // the next layer's weights
+            for (int t = t0; t < tiles; t += my_nw) {
+                const int oc = 16 * t + col;
+                dl_eb_double4 acc = {0., 0., 0., 0.}, acc2 = {0., 0., 0., 0.};   // two chains (even / odd k-steps), as in dl_eb_forward
+                const int kind = tile_kind(nin, nout, t);
+                if (kind) {
+                    if (!(have && t == t0)) request(w, nin, nout, t, kind);
+                    const double* ap = cur + col * LD + g;
+                    if (kind == 2) {
+                        double av[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) av[u] = ap[4 * u];
+#pragma unroll
+                        for (int u = 0; u < 16; u += 2) {
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bw[u], acc, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], bw[u + 1], acc2, 0, 0, 0);
+                        }
+                    } else {
+                        double av[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) av[u] = ap[u < ksteps ? 4 * u : 0];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bw[0], acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bw[1], acc2, 0, 0, 0);
+                        if (ksteps > 2) {
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bw[2], acc, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bw[3], acc2, 0, 0, 0);
+                        }
+                    }
+                } else {
+                    for (int ks0 = 0; ks0 < ksteps; ks0 += 4) {   // (four k-steps at a time: sixteen made this rarely taken path the register peak of the kernel)
+                        double bq[4], av[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int k = 4 * (ks0 + u) + g;
+                            bq[u] = (ks0 + u < ksteps && k < nin && oc < nout) ? w[(size_t)k * nout + oc] : 0.;
+                            av[u] = (ks0 + u < ksteps) ? cur[col * LD + k] : 0.;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u += 2) {
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bq[u], acc, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], bq[u + 1], acc2, 0, 0, 0);
+                        }
+                    }
+                    bbias = oc < nout ? w[(size_t)nin * nout + oc] : 0.;
+                }
+                acc += acc2;
+                const double bias = bbias;
+                have = 0;
+                // the weights of this wave's first tile of the NEXT layer: on their way during the activation and the barrier
+                if (t + my_nw >= tiles && !last && layer + 1 < l1 && t0 < (e.widths[layer + 2] + 15) / 16) {
+                    have = tile_kind(nout, e.widths[layer + 2], t0);
+                    if (have) request(wn, nout, e.widths[layer + 2], t0, have);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {       // accumulator register r = out[point g + 4 r][oc]
+                    double v = acc[r] + bias;
+                    if (activate) v = dl_activation(e.act, v);
+                    if (last && my_ie == 0) { if (oc < nout) rec[(g + 4 * r) * rec_stride + oc] = v; }                       // the basis of the table engine
+                    else if (last) { if (oc == 0) scal[(g + 4 * r) * 4 + my_ie] = v * e.yscale + e.ylo; }                    // inverse scaler, conversion.py:79
+                    else if (oc < nout4) nxt[(g + 4 * r) * LD + oc] = oc < nout ? v : 0.;
+                }
+            }
+            w = wn;
+            double* tmp = cur; cur = nxt; nxt = tmp;
+        }
+        __syncthreads();
+        DL_EB_STAMP
+    }
+    };
+    run_layers(0, mono_at);
+    have = 0;
+    monomials();
+    run_layers(mono_at, max_layers);
+#undef DL_EB_STAMP
+}
+
 // records to the feature buffer (the feature GEMM follows as a separate launch)
 __global__ __launch_bounds__(256) void dl_emulated_batch_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, int64_t B, double* __restrict__ feat,
                                                                 int64_t feat_ld) {
@@ -205,7 +417,7 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_kernel(const DlObsDev
     const int R = 1 + o.n_var;
     const int stride = dl_fg_lds_stride(o.nb_pad + R * DL_FG_MONO_LD);
     double* rec = lds + (dl_eb_shared_doubles(o) + 1) / 2 * 2;
-    dl_eb_forward<512, true>(o, theta, n_params, B, p0, lds, rec, stride, out, 0);
+    dl_eb_forward_fused<512>(o, theta, n_params, B, p0, lds, rec, stride);
     __syncthreads();
     dl_fg_compute(rec, stride, o.nb_pad, R, gfrag, out, ldo, B, p0, accumulate);
 }
@@ -218,6 +430,7 @@ struct DlEfGramArgs {
     int const_row[DL_MAX_SOLVED];      // X rows that are constants only ...
     const double* const_ptr[DL_MAX_SOLVED];   // ... and their tconst rows
     double* gram;
+    unsigned long long* stamps;        // DL_EF_STAMPS diagnostics
 };
 // LDS: the 16 records | union(forward workspace, X rows): the workspace is dead once the records are written
 static inline __host__ __device__ size_t dl_ef_gram_rec_doubles(const DlObsDev& o) { return ((size_t)DL_FG_PTS * dl_fg_lds_stride(o.nb_pad + (1 + o.n_var) * DL_FG_MONO_LD) + 1) / 2 * 2; }
@@ -233,11 +446,13 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const DlO
     const int stride = dl_fg_lds_stride(o.nb_pad + R * DL_FG_MONO_LD);
     double* rec = lds;
     double* work = lds + dl_ef_gram_rec_doubles(o);
-    dl_eb_forward<512, true>(o, theta, n_params, B, p0, work, rec, stride, nullptr, 0);
+    if (ga.stamps != nullptr && threadIdx.x == 0) ga.stamps[(size_t)blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memtime();
+    dl_eb_forward_fused<512>(o, theta, n_params, B, p0, work, rec, stride, ga.stamps != nullptr ? ga.stamps + (size_t)blockIdx.x * 16 : nullptr);
     __syncthreads();   // the records are complete, the forward workspace is free: X takes its place
+    if (ga.stamps != nullptr && threadIdx.x == 0) ga.stamps[(size_t)blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memtime();
     DlFgGram gr;
     gr.x = work;
-    gr.xr = ga.xr; gr.gram = ga.gram;
+    gr.xr = ga.xr; gr.gram = ga.gram; gr.stamps = ga.stamps;
 #pragma unroll
     for (int r = 0; r < 6; ++r) { gr.row_of[r] = ga.row_of[r]; gr.cst[r] = ga.cst[r]; }
     // rows of solved parameters whose derivative does not depend on the point: the constant itself (visible to the Gram phase after the barrier inside dl_fg_compute)

@@ -39,7 +39,9 @@ struct DlFgGram {
     int row_of[6];             // X row of device row r (0: residual; r >= 1: 1 + solved index of the parameter whose derivative row r is)
     const double* cst[6];      // constant part added to device row r: bias, or tconst of that solved parameter ([128] each)
     double* gram;              // [B, 256]
+    unsigned long long* stamps;   // DL_EF_STAMPS diagnostics (null in production): 16 x s_memtime per workgroup
 };
+#define DL_FG_STAMP(slot) if (GRAM && gr->stamps != nullptr && threadIdx.x == 0) gr->stamps[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime();
 
 // the product and the epilogue, from 16 point records already in LDS (row stride `stride` doubles: basis [nb_pad] then mono [R][DL_FG_MONO_LD]);
 // gfrag: [N_pad / 16][nb_pad / 8][19][64][2]; out: [B * R, ldo] (+= if accumulate); 512 threads, blockIdx.y = group of 8 column blocks
@@ -58,6 +60,7 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
 #pragma unroll
         for (int u = 0; u < 6; ++u) outv[rr][u] = 0.;
     for (int mg = 0; mg < 2; ++mg) {
+        if (mg == 1) { DL_FG_STAMP(3) }
         const int m0 = mg * DL_FG_MG;
         dl_fg_double4 acc[DL_FG_MG];
 #pragma unroll
@@ -101,10 +104,53 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
             for (int i = 0; i < DL_FG_MG; ++i) bcur[i] = bnxt[i];
         }
         }
+        DL_FG_STAMP(2 + 2 * mg)
         // epilogue: accumulator register rr of lane (col, g) = U[point g + 4 rr][m][column jb * 16 + col]; contract with the monomial rows of that point.
         // The first six rows of a point are carried in registers across the two monomial groups and stored once (writing partial rows and adding to them
         // in the second group tripled the output traffic: 14 of 48 us at 6 rows per point); rows beyond six take the read-modify-write route, six at a time
         // with their old values requested together.
+        if (GRAM) {
+            // Gram variant (R <= 6, rows live in X): per point of this lane the ten monomials of three rows come from LDS in ONE batch of 16-byte reads, then three
+            // independent chains of ten FMAs -- written with a load under `if (r < R && ...)` per row the compiler waited for every LDS round trip in turn
+            // (epilogues 6.1 + 8.6 us of a 57 us workgroup life; the pad monomial of the short group is an exact zero in the record: no predicate on m).
+            const int cbase = jb * 16 + col;
+            double cst[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) cst[u] = mg == 1 ? gr->cst[u < R ? u : 0][cbase] : 0.;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int pt = g + 4 * rr;
+                const double* mono = lds + pt * stride + nb_pad + m0;
+                double* xb = gr->x + (size_t)pt * gr->xr * DL_FG_XLD + cbase;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    dl_fg_double2 mm[3][DL_FG_MG / 2];
+                    double v[3];
+#pragma unroll
+                    for (int u3 = 0; u3 < 3; ++u3) {
+                        const int u = 3 * h + u3, uc = u < R ? u : 0;
+#pragma unroll
+                        for (int j = 0; j < DL_FG_MG / 2; ++j) mm[u3][j] = *reinterpret_cast<const dl_fg_double2*>(mono + uc * DL_FG_MONO_LD + 2 * j);
+                        v[u3] = xb[(size_t)gr->row_of[uc] * DL_FG_XLD];      // (mg == 0: whatever is there, not used)
+                    }
+#pragma unroll
+                    for (int u3 = 0; u3 < 3; ++u3) {
+                        double w = mg == 1 ? v[u3] : 0.;
+#pragma unroll
+                        for (int j = 0; j < DL_FG_MG / 2; ++j) {
+                            w = fma(mm[u3][j].x, acc[2 * j][rr], w);
+                            w = fma(mm[u3][j].y, acc[2 * j + 1][rr], w);
+                        }
+                        v[u3] = mg == 1 ? w + cst[3 * h + u3] : w;
+                    }
+#pragma unroll
+                    for (int u3 = 0; u3 < 3; ++u3) {
+                        const int u = 3 * h + u3;
+                        if (u < R) xb[(size_t)gr->row_of[u] * DL_FG_XLD] = v[u3];
+                    }
+                }
+            }
+        } else
         for (int r0 = 0; r0 < R; r0 += 6) {
             const bool in_regs = (r0 == 0);
             double old[4][6];
@@ -125,15 +171,6 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
                     const int r = r0 + u;
                     if (r < R && p0 + pt < B) {
                         double v;
-                        if (GRAM) {   // (r = u: R <= 6) the partial row of the first monomial group waits in its place in X
-                            double* xv = gr->x + ((size_t)pt * gr->xr + gr->row_of[u]) * DL_FG_XLD + jb * 16 + col;
-                            v = mg == 1 ? *xv : 0.;
-#pragma unroll
-                            for (int i = 0; i < DL_FG_MG; ++i)
-                                if (m0 + i < DL_FG_NM) v = fma(mono[r * DL_FG_MONO_LD + m0 + i], acc[i][rr], v);
-                            *xv = mg == 1 ? v + gr->cst[u][jb * 16 + col] : v;
-                            continue;
-                        }
                         v = (in_regs && mg == 1) ? outv[rr][u] + old[rr][u] : old[rr][u];
 #pragma unroll
                         for (int i = 0; i < DL_FG_MG; ++i)
@@ -146,7 +183,35 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
         }
     }
     if (GRAM) {
+        DL_FG_STAMP(5)
         __syncthreads();   // all rows of the 16 points are in LDS
+        DL_FG_STAMP(6)
+        if (gr->xr <= 8) {
+            // TWO points per 16-row tile (rows 0-7: point 2 wave, rows 8-15: point 2 wave + 1; the off-diagonal 8 x 8 blocks are cross products nobody needs): half the
+            // MFMAs of a tile per point, and the 32 operand values of a lane are requested from LDS together, ahead of the chain (the loop read two values, waited, issued
+            // two MFMAs: 5 us for 64 MFMAs).  One chain in k order per point pair: G equals the one-point-per-tile product bit for bit.
+            const int j = lane & 15, pp = j >> 3, row = j & 7;
+            const bool live = row < gr->xr;
+            const double* xp = gr->x + ((size_t)(2 * wave + pp) * gr->xr + (live ? row : 0)) * DL_FG_XLD + g;
+            double xv[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) xv[k] = xp[4 * k];
+            dl_fg_double4 acc0 = {0., 0., 0., 0.};
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { const double x0 = live ? xv[k] : 0.; acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc0, 0, 0, 0); }
+            // every entry of the two 16 x 16 slots is written (the buffer is a shared workspace): zeros outside the 8 x 8 block, then the block
+            const int64_t pa = p0 + 2 * wave;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = lane + 64 * q, pt2 = idx >> 8, pos = idx & 255;
+                if (((pos >> 4) >= 8 || (pos & 15) >= 8) && pa + pt2 < B) gr->gram[(size_t)(pa + pt2) * 256 + pos] = 0.;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {   // C layout: G[(l >> 4) + 4 r][l & 15]
+                const int i = g + 4 * r;
+                if ((i >> 3) == pp && pa + pp < B) gr->gram[(size_t)(pa + pp) * 256 + (i & 7) * 16 + row] = acc0[r];
+            }
+        } else {
         const int xrow = lane & 15;
         const bool live = xrow < gr->xr;
         // the two points of this wave side by side: two independent MFMA chains (one chain alone is 32 dependent MFMAs of 64 cycles)
@@ -168,6 +233,8 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
 #pragma unroll
             for (int r = 0; r < 4; ++r) gr->gram[(size_t)(p0 + 2 * wave + 1) * 256 + (g + 4 * r) * 16 + xrow] = acc1[r];
         }
+        }
+        DL_FG_STAMP(7)
     }
 }
 

@@ -1183,9 +1183,10 @@ DL_HD void dl_emu_layer(int tid, const DlObsDev::Engine& e, int layer, const dou
 }
 
 // velocileptors 'pars' -> 19 monomials, and the monomials' derivatives w.r.t. analytically solved alpha* / sn* (full_shape.py:1182-1186, 1300-1307, 1577-1592, 1479-1488)
-DL_HD void dl_velocileptors_monomials(const DlObsDev& o, const double* th, double sigma8, double fsigma8, double* mono) {
+// ``ms``: row stride of ``mono`` (entries DL_N_MONO .. ms - 1 of every row are set to zero); ``vpre``: the eleven 'pars' inputs already fetched (else read from ``th``)
+DL_HD void dl_velocileptors_monomials(const DlObsDev& o, const double* th, double sigma8, double fsigma8, double* mono, int ms = DL_N_MONO, const double* vpre = nullptr) {
     double v[DL_N_VPARS];
-    for (int c = 0; c < DL_N_VPARS; ++c) v[c] = dl_get(o.vp_in[c], th);
+    for (int c = 0; c < DL_N_VPARS; ++c) v[c] = vpre != nullptr ? vpre[c] : dl_get(o.vp_in[c], th);
     double pars[DL_N_VPARS];
     double one_b1L = 1., f = 0.;
     const bool physical = (o.mono_mode == 1 || o.mono_mode == 2), rept = (o.mono_mode == 2 || o.mono_mode == 4);
@@ -1215,11 +1216,12 @@ DL_HD void dl_velocileptors_monomials(const DlObsDev& o, const double* th, doubl
     m0[0] = 1.; m0[1] = b1; m0[2] = b1 * b1; m0[3] = b2; m0[4] = b1 * b2; m0[5] = b2 * b2; m0[6] = bs; m0[7] = b1 * bs; m0[8] = b2 * bs; m0[9] = bs * bs;
     m0[10] = b3; m0[11] = b1 * b3; m0[12] = pars[4]; m0[13] = pars[5]; m0[14] = pars[6]; m0[15] = pars[7];
     m0[16] = pars[8] / o.nd; m0[17] = pars[9] / o.nd; m0[18] = pars[10] / o.nd;
+    for (int m = DL_N_MONO; m < ms; ++m) m0[m] = 0.;
     for (int c = 4; c < DL_N_VPARS; ++c) {
         int slot = o.vp_slot[c];
         if (slot < 0) continue;
-        double* d = mono + (size_t)(1 + slot) * DL_N_MONO;
-        for (int m = 0; m < DL_N_MONO; ++m) d[m] = 0.;
+        double* d = mono + (size_t)(1 + slot) * ms;
+        for (int m = 0; m < ms; ++m) d[m] = 0.;
         if (physical) {
             if (c == 4) { d[12] = one_b1L * one_b1L; d[13] = f * one_b1L; }
             else if (c == 5) { d[13] = f * one_b1L; d[14] = f * f; }

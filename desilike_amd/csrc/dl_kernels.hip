@@ -878,7 +878,25 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
     if (shm > 156 * 1024) return false;
     static size_t shm_set = 0;
     if (shm > shm_set) { (void)hipFuncSetAttribute((const void*)dl_emulated_feature_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); shm_set = shm; }
-    DL_LAUNCH(dl_emulated_feature_gram_kernel, dim3((unsigned)((B + DL_EB_PTS - 1) / DL_EB_PTS), 1), dim3(512), shm, stream, obs, theta, n_params, B, gfrag, ga);
+    static const char* stamp_file = getenv("DL_EF_STAMPS");   // diagnostics: s_memtime at the phase boundaries of launches 30..33 appended to the file (synchronises)
+    static unsigned long long* stamps_dev = nullptr;
+    static int stamp_launches = 0;
+    const unsigned grid = (unsigned)((B + DL_EB_PTS - 1) / DL_EB_PTS);
+    if (stamp_file && !stamps_dev) (void)hipMalloc((void**)&stamps_dev, (size_t)8192 * 16 * sizeof(unsigned long long));
+    ga.stamps = (stamp_file && grid <= 8192 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
+    if (stamp_file) stamp_launches++;
+    if (ga.stamps) (void)hipMemsetAsync(ga.stamps, 0, (size_t)grid * 16 * sizeof(unsigned long long), stream);
+    DL_LAUNCH(dl_emulated_feature_gram_kernel, dim3(grid, 1), dim3(512), shm, stream, obs, theta, n_params, B, gfrag, ga);
+    if (ga.stamps) {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h((size_t)grid * 16);
+        (void)hipMemcpy(h.data(), ga.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(stamp_file, "a")) {
+            for (unsigned w = 0; w < grid; ++w) { for (int q = 0; q < 16; ++q) fprintf(f, "%llu ", h[(size_t)w * 16 + q]); fprintf(f, "\n"); }
+            fprintf(f, "#\n");
+            fclose(f);
+        }
+    }
     return true;
 }
 
