@@ -23,7 +23,7 @@ static inline __host__ __device__ int dl_eb_ld(const DlObsDev& o) {   // LDS row
     return (w + 3) / 4 * 4 + 2;
 }
 static inline __host__ __device__ size_t dl_eb_shared_doubles(const DlObsDev& o) {   // inputs | two activation buffers PER ENGINE | scalars | monomial rows
-    return (size_t)DL_EB_PTS * (DL_MAX_X + 6 * dl_eb_ld(o) + 4 + (size_t)(1 + o.n_var) * DL_N_MONO);
+    return (size_t)DL_EB_PTS * (DL_MAX_X + 6 * dl_eb_ld(o) + 4 + (size_t)(1 + o.n_var) * DL_N_MONO) + DL_EB_PTS * 32;   // (+ theta rows of the 16 points, <= 32 columns: fused forward)
 }
 
 #if defined(__HIPCC__)
@@ -194,10 +194,14 @@ __device__ __forceinline__ void dl_eb_forward(const DlObsDev& o, const double* _
 //      entry, one per layer, the caller's (nine before).  Same arithmetic in the same order as dl_eb_forward: results are bit-identical.
 template <int NTHR>
 __device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const double* __restrict__ theta, int n_params, int64_t B, int64_t p0, double* lds, double* rec,
-                                                    int rec_stride, unsigned long long* st = nullptr) {
+                                                    int rec_stride, unsigned long long* st = nullptr, bool th_early = false, double th_val = 0.) {
     int st_slot = 8;   // DL_EF_STAMPS diagnostics: slots 8.. of the workgroup = after the entry barrier, then after every layer's barrier (the monomials before the first of the second run)
-#define DL_EB_STAMP if (st != nullptr && threadIdx.x == 0 && st_slot < 16) st[st_slot] = __builtin_amdgcn_s_memtime(); ++st_slot;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define DL_EB_STAMP if (st != nullptr && threadIdx.x == 0 && st_slot < 14) st[st_slot] = __builtin_amdgcn_s_memtime(); ++st_slot;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index as a SCALAR: everything that hangs on it -- the engine of this wave, its layer widths and pointers (fields of the kernel-argument struct), the
+    // branches on them -- is then scalar loads and scalar branches; as `tid >> 6` it is a vector value to the compiler, and each of those fields was fetched by a
+    // vector load from the kernel-argument segment in the middle of the layer chain
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g = lane >> 4;
     const int LD = dl_eb_ld(o);
     double* x = lds;                                      // [16][DL_MAX_X]
@@ -257,10 +261,18 @@ __device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const dou
     }
     // inputs: x (Taylor engines), the scaled inputs of every MLP engine (conversion.py:75-77; zero-padded to a multiple of 4 columns), the 'pars' inputs
     const int nin0 = (o.n_x + 3) & ~3;
+    // theta was requested before the first access to `o` (th_val = theta[point tid / 32][column tid % 32]): the rows go through LDS, and the input tables
+    // (lane-dependent fields of `o`: vector loads from the kernel-argument segment) are fetched meanwhile -- one round trip at entry instead of two in a row
+    double* trow = lds + (size_t)DL_EB_PTS * (DL_MAX_X + 6 * LD + 4 + (size_t)(1 + o.n_var) * DL_N_MONO);   // [16][32]
+    if (th_early) { trow[tid] = th_val; __syncthreads(); }
+    {
     for (int idx = tid; idx < DL_EB_PTS * nin0; idx += NTHR) {
         const int pt = idx / nin0, i = idx - pt * nin0;
         const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
-        const double v = i < o.n_x ? dl_get(o.x_in[i], theta + (size_t)b * n_params) : 0.;
+        const DlInput xin = o.x_in[i < o.n_x ? i : 0];
+        const int xc = xin.col >= 0 ? xin.col : 0;
+        const double tv = th_early ? trow[pt * 32 + xc] : theta[(size_t)b * n_params + xc];     // (two loads, not one through a pointer that is LDS or global)
+        const double v = i < o.n_x ? (xin.col >= 0 ? tv : xin.value) : 0.;
         if (i < o.n_x) x[pt * DL_MAX_X + i] = v;
         for (int ie = 0; ie < 3; ++ie) {
             const DlObsDev::Engine& en = o.eng[ie];
@@ -270,7 +282,11 @@ __device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const dou
     for (int idx = tid; idx < DL_EB_PTS * DL_N_VPARS; idx += NTHR) {
         const int pt = idx / DL_N_VPARS, c = idx - pt * DL_N_VPARS;
         const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
-        vpv[pt * 12 + c] = dl_get(o.vp_in[c], theta + (size_t)b * n_params);
+        const DlInput vin = o.vp_in[c];
+        const int vc = vin.col >= 0 ? vin.col : 0;
+        const double tv = th_early ? trow[pt * 32 + vc] : theta[(size_t)b * n_params + vc];
+        vpv[pt * 12 + c] = vin.col >= 0 ? tv : vin.value;
+    }
     }
     // bias row of the folded final layer (MLP table engine) and the zero padding of the basis
     for (int idx = tid; idx < DL_EB_PTS * (o.nb_pad - o.n_basis + 1); idx += NTHR) {
@@ -304,11 +320,14 @@ __device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const dou
         }
         __syncthreads();
     }
-    auto monomials = [&]() {   // one lane per point of the last wave: 'pars' -> 19 monomials and the derivative rows, straight into the records (rows of 20)
-        if (wave == NW - 1 && lane < DL_EB_PTS) {
-            const double sigma8 = o.eng[1].type >= 0 ? scal[lane * 4 + 1] : o.eng[1].cst;
-            const double fsigma8 = o.eng[2].type >= 0 ? scal[lane * 4 + 2] : o.eng[2].cst;
-            dl_velocileptors_monomials(o, nullptr, sigma8, fsigma8, rec + (size_t)lane * rec_stride + o.nb_pad, DL_FG_MONO_LD, vpv + lane * 12);
+    auto monomials = [&]() {   // one lane per (point, row) of the last two waves: 'pars' -> 19 monomials / one derivative row, straight into the records (rows of 20)
+        if (wave >= NW - 2) {  // (one lane per point writing all rows took longer than a layer of the table engine beside it)
+            const int task = (wave - (NW - 2)) * 64 + lane, pt = task & 15, r = task >> 4;
+            if (r < 1 + o.n_var) {
+                const double sigma8 = o.eng[1].type >= 0 ? scal[pt * 4 + 1] : o.eng[1].cst;
+                const double fsigma8 = o.eng[2].type >= 0 ? scal[pt * 4 + 2] : o.eng[2].cst;
+                dl_velocileptors_monomials(o, nullptr, sigma8, fsigma8, rec + (size_t)pt * rec_stride + o.nb_pad, DL_FG_MONO_LD, vpv + pt * 12, r);
+            }
         }
     };
     double* cur = bufs + (size_t)(my_ie >= 0 ? my_ie : 0) * 2 * DL_EB_PTS * LD;
@@ -375,10 +394,26 @@ __device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const dou
                     have = tile_kind(nout, e.widths[layer + 2], t0);
                     if (have) request(wn, nout, e.widths[layer + 2], t0, have);
                 }
+                // accumulator register r = out[point g + 4 r][oc].  The branch on the activation sits OUTSIDE the four evaluations: inside (dl_activation per value)
+                // each exponential was a basic block of its own and the four dependent chains ran one after the other (1.2 us of a 2.2 us layer)
+                double vv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {       // accumulator register r = out[point g + 4 r][oc]
-                    double v = acc[r] + bias;
-                    if (activate) v = dl_activation(e.act, v);
+                for (int r = 0; r < 4; ++r) vv[r] = acc[r] + bias;
+                if (activate) {
+                    if (e.act == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vv[r] = vv[r] / (1. + exp(-vv[r]));      // silu, conversion.py:29 (the expression of dl_activation)
+                    } else if (e.act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vv[r] = vv[r] > 0. ? vv[r] : 0.;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vv[r] = tanh(vv[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = vv[r];
                     if (last && my_ie == 0) { if (oc < nout) rec[(g + 4 * r) * rec_stride + oc] = v; }                       // the basis of the table engine
                     else if (last) { if (oc == 0) scal[(g + 4 * r) * 4 + my_ie] = v * e.yscale + e.ylo; }                    // inverse scaler, conversion.py:79
                     else if (oc < nout4) nxt[(g + 4 * r) * LD + oc] = oc < nout ? v : 0.;
@@ -431,6 +466,7 @@ struct DlEfGramArgs {
     const double* const_ptr[DL_MAX_SOLVED];   // ... and their tconst rows
     double* gram;
     unsigned long long* stamps;        // DL_EF_STAMPS diagnostics
+    int nz[6][2];                      // support of the derivative rows (dl_velocileptors_row_support)
 };
 // LDS: the 16 records | union(forward workspace, X rows): the workspace is dead once the records are written
 static inline __host__ __device__ size_t dl_ef_gram_rec_doubles(const DlObsDev& o) { return ((size_t)DL_FG_PTS * dl_fg_lds_stride(o.nb_pad + (1 + o.n_var) * DL_FG_MONO_LD) + 1) / 2 * 2; }
@@ -438,21 +474,32 @@ static inline __host__ __device__ size_t dl_ef_gram_shared_doubles(const DlObsDe
     const size_t work = dl_eb_shared_doubles(o), x = (size_t)DL_FG_PTS * xr * DL_FG_XLD;
     return dl_ef_gram_rec_doubles(o) + (work > x ? work : x);
 }
-__global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ gfrag,
+// (theta, n_params, B first: they arrive in SGPRs with the wave (kernel-argument preload), and the theta rows of the 16 points are requested before the first access to
+//  the descriptor `o` -- that access is a round trip to the kernel-argument segment which the theta loads used to wait for: two round trips in a row at entry)
+__global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ gfrag, const DlObsDev o,
                                                                        const DlEfGramArgs ga) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int64_t p0 = (int64_t)blockIdx.x * DL_EB_PTS;
+    const bool th_early = n_params <= 32;
+    double th_val = 0.;
+    if (th_early) {
+        const int pt = threadIdx.x >> 5, j = threadIdx.x & 31;
+        const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
+        th_val = theta[(size_t)b * n_params + (j < n_params ? j : 0)];
+    }
     const int R = 1 + o.n_var;
     const int stride = dl_fg_lds_stride(o.nb_pad + R * DL_FG_MONO_LD);
     double* rec = lds;
     double* work = lds + dl_ef_gram_rec_doubles(o);
-    if (ga.stamps != nullptr && threadIdx.x == 0) ga.stamps[(size_t)blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memtime();
-    dl_eb_forward_fused<512>(o, theta, n_params, B, p0, work, rec, stride, ga.stamps != nullptr ? ga.stamps + (size_t)blockIdx.x * 16 : nullptr);
+    if (ga.stamps != nullptr && threadIdx.x == 0) { ga.stamps[(size_t)blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memtime(); ga.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime(); }
+    dl_eb_forward_fused<512>(o, theta, n_params, B, p0, work, rec, stride, ga.stamps != nullptr ? ga.stamps + (size_t)blockIdx.x * 16 : nullptr, th_early, th_val);
     __syncthreads();   // the records are complete, the forward workspace is free: X takes its place
     if (ga.stamps != nullptr && threadIdx.x == 0) ga.stamps[(size_t)blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memtime();
     DlFgGram gr;
     gr.x = work;
     gr.xr = ga.xr; gr.gram = ga.gram; gr.stamps = ga.stamps;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { gr.nz[r][0] = ga.nz[r][0]; gr.nz[r][1] = ga.nz[r][1]; }
 #pragma unroll
     for (int r = 0; r < 6; ++r) { gr.row_of[r] = ga.row_of[r]; gr.cst[r] = ga.cst[r]; }
     // rows of solved parameters whose derivative does not depend on the point: the constant itself (visible to the Gram phase after the barrier inside dl_fg_compute)
@@ -461,6 +508,7 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const DlO
             const int pt = idx >> 7, col = idx & 127;
             gr.x[((size_t)pt * gr.xr + ga.const_row[c]) * DL_FG_XLD + col] = ga.const_ptr[c][col];
         }
-    dl_fg_compute<true>(rec, stride, o.nb_pad, R, gfrag, nullptr, 0, B, p0, 0, &gr);
+    dl_fg_compute_gram(rec, stride, o.nb_pad, R, gfrag, B, p0, &gr);
+    if (ga.stamps != nullptr && threadIdx.x == 0) ga.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime();   // (100 MHz, chip-wide: calibrates the shader clock)
 }
 #endif

@@ -40,8 +40,61 @@ struct DlFgGram {
     const double* cst[6];      // constant part added to device row r: bias, or tconst of that solved parameter ([128] each)
     double* gram;              // [B, 256]
     unsigned long long* stamps;   // DL_EF_STAMPS diagnostics (null in production): 16 x s_memtime per workgroup
+    int nz[6][2];              // monomials the derivative row r >= 1 touches (dl_velocileptors_row_support), -1: none
 };
 #define DL_FG_STAMP(slot) if (GRAM && gr->stamps != nullptr && threadIdx.x == 0) gr->stamps[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime();
+
+// G = X X^T of the workgroup's 16 points from their rows in LDS (after a barrier): wave w takes points 2 w, 2 w + 1
+__device__ __forceinline__ void dl_fg_gram_phase(const DlFgGram* gr, int wave, int lane, int g, int64_t B, int64_t p0) {
+    if (gr->xr <= 8) {
+        // TWO points per 16-row tile (rows 0-7: point 2 wave, rows 8-15: point 2 wave + 1; the off-diagonal 8 x 8 blocks are cross products nobody needs): half the
+        // MFMAs of a tile per point, and the 32 operand values of a lane are requested from LDS together, ahead of the chain (the loop read two values, waited, issued
+        // two MFMAs: 5 us for 64 MFMAs).  One chain in k order per point pair: G equals the one-point-per-tile product bit for bit.
+        const int j = lane & 15, pp = j >> 3, row = j & 7;
+        const bool live = row < gr->xr;
+        const double* xp = gr->x + ((size_t)(2 * wave + pp) * gr->xr + (live ? row : 0)) * DL_FG_XLD + g;
+        double xv[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) xv[k] = xp[4 * k];
+        dl_fg_double4 acc0 = {0., 0., 0., 0.};
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { const double x0 = live ? xv[k] : 0.; acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc0, 0, 0, 0); }
+        // every entry of the two 16 x 16 slots is written (the buffer is a shared workspace): zeros outside the 8 x 8 block, then the block
+        const int64_t pa = p0 + 2 * wave;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = lane + 64 * q, pt2 = idx >> 8, pos = idx & 255;
+            if (((pos >> 4) >= 8 || (pos & 15) >= 8) && pa + pt2 < B) gr->gram[(size_t)(pa + pt2) * 256 + pos] = 0.;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // C layout: G[(l >> 4) + 4 r][l & 15]
+            const int i = g + 4 * r;
+            if ((i >> 3) == pp && pa + pp < B) gr->gram[(size_t)(pa + pp) * 256 + (i & 7) * 16 + row] = acc0[r];
+        }
+    } else {
+    const int xrow = lane & 15;
+    const bool live = xrow < gr->xr;
+    // the two points of this wave side by side: two independent MFMA chains (one chain alone is 32 dependent MFMAs of 64 cycles)
+    const double* xp0 = gr->x + ((size_t)(2 * wave) * gr->xr + (live ? xrow : 0)) * DL_FG_XLD + g;
+    const double* xp1 = xp0 + (size_t)gr->xr * DL_FG_XLD;
+    dl_fg_double4 acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+        const double x0 = live ? xp0[4 * k] : 0., x1 = live ? xp1[4 * k] : 0.;
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc1, 0, 0, 0);
+    }
+    // C layout: G[(l >> 4) + 4 r][l & 15]
+    if (p0 + 2 * wave < B) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gr->gram[(size_t)(p0 + 2 * wave) * 256 + (g + 4 * r) * 16 + xrow] = acc0[r];
+    }
+    if (p0 + 2 * wave + 1 < B) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gr->gram[(size_t)(p0 + 2 * wave + 1) * 256 + (g + 4 * r) * 16 + xrow] = acc1[r];
+    }
+    }
+}
 
 // the product and the epilogue, from 16 point records already in LDS (row stride `stride` doubles: basis [nb_pad] then mono [R][DL_FG_MONO_LD]);
 // gfrag: [N_pad / 16][nb_pad / 8][19][64][2]; out: [B * R, ldo] (+= if accumulate); 512 threads, blockIdx.y = group of 8 column blocks
@@ -186,56 +239,162 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
         DL_FG_STAMP(5)
         __syncthreads();   // all rows of the 16 points are in LDS
         DL_FG_STAMP(6)
-        if (gr->xr <= 8) {
-            // TWO points per 16-row tile (rows 0-7: point 2 wave, rows 8-15: point 2 wave + 1; the off-diagonal 8 x 8 blocks are cross products nobody needs): half the
-            // MFMAs of a tile per point, and the 32 operand values of a lane are requested from LDS together, ahead of the chain (the loop read two values, waited, issued
-            // two MFMAs: 5 us for 64 MFMAs).  One chain in k order per point pair: G equals the one-point-per-tile product bit for bit.
-            const int j = lane & 15, pp = j >> 3, row = j & 7;
-            const bool live = row < gr->xr;
-            const double* xp = gr->x + ((size_t)(2 * wave + pp) * gr->xr + (live ? row : 0)) * DL_FG_XLD + g;
-            double xv[32];
-#pragma unroll
-            for (int k = 0; k < 32; ++k) xv[k] = xp[4 * k];
-            dl_fg_double4 acc0 = {0., 0., 0., 0.};
-#pragma unroll
-            for (int k = 0; k < 32; ++k) { const double x0 = live ? xv[k] : 0.; acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc0, 0, 0, 0); }
-            // every entry of the two 16 x 16 slots is written (the buffer is a shared workspace): zeros outside the 8 x 8 block, then the block
-            const int64_t pa = p0 + 2 * wave;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int idx = lane + 64 * q, pt2 = idx >> 8, pos = idx & 255;
-                if (((pos >> 4) >= 8 || (pos & 15) >= 8) && pa + pt2 < B) gr->gram[(size_t)(pa + pt2) * 256 + pos] = 0.;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {   // C layout: G[(l >> 4) + 4 r][l & 15]
-                const int i = g + 4 * r;
-                if ((i >> 3) == pp && pa + pp < B) gr->gram[(size_t)(pa + pp) * 256 + (i & 7) * 16 + row] = acc0[r];
-            }
-        } else {
-        const int xrow = lane & 15;
-        const bool live = xrow < gr->xr;
-        // the two points of this wave side by side: two independent MFMA chains (one chain alone is 32 dependent MFMAs of 64 cycles)
-        const double* xp0 = gr->x + ((size_t)(2 * wave) * gr->xr + (live ? xrow : 0)) * DL_FG_XLD + g;
-        const double* xp1 = xp0 + (size_t)gr->xr * DL_FG_XLD;
-        dl_fg_double4 acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) {
-            const double x0 = live ? xp0[4 * k] : 0., x1 = live ? xp1[4 * k] : 0.;
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc1, 0, 0, 0);
-        }
-        // C layout: G[(l >> 4) + 4 r][l & 15]
-        if (p0 + 2 * wave < B) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gr->gram[(size_t)(p0 + 2 * wave) * 256 + (g + 4 * r) * 16 + xrow] = acc0[r];
-        }
-        if (p0 + 2 * wave + 1 < B) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gr->gram[(size_t)(p0 + 2 * wave + 1) * 256 + (g + 4 * r) * 16 + xrow] = acc1[r];
-        }
-        }
+        dl_fg_gram_phase(gr, wave, lane, g, B, p0);
         DL_FG_STAMP(7)
     }
+}
+
+// ---- Gram variant, round 4: monomial groups of compile-time size, the two waves of a SIMD on DIFFERENT schedules -----------------------------------------------
+// In-kernel stamps (config 3): the main loops run at the matrix pipe's rate (two waves per SIMD), but both waves of a SIMD reached their epilogues -- LDS reads and
+// fp64 FMAs, no MFMA -- at the same time, twice: 7 us of a 48 us workgroup life with the matrix pipe idle, and the barrier before the Gram phase waited for the
+// slower partner.  Waves 0-3 now take the monomials in groups of (10, 9), waves 4-7 (their SIMD partners) in groups of (6, 10, 3): an epilogue of one meets a main
+// loop of the other.  Every output still sums its monomials in the order 0..18 from zero (partial sums wait in X between groups): results are bit-identical.
+// The operand registers rotate by unrolling the k loop three times (two steps in flight) instead of being copied (80 moves per step).
+template <int CNT>
+__device__ __forceinline__ void dl_fg_gram_mainloop(const double* arow, const dl_fg_double2* __restrict__ gw, int nq, int m0, dl_fg_double4 (&acc)[CNT]) {
+    dl_fg_double2 b0[CNT], b1[CNT], b2[CNT];
+#define DL_FG_LOAD(b, qq) { const int q_ = (qq) < nq ? (qq) : nq - 1; _Pragma("unroll") for (int i = 0; i < CNT; ++i) b[i] = gw[(size_t)(q_ * DL_FG_NM + m0 + i) * 64]; }
+#define DL_FG_MUL(b, qq) { const dl_fg_double2 a_ = *reinterpret_cast<const dl_fg_double2*>(arow + 8 * (qq)); \
+        _Pragma("unroll") for (int i = 0; i < CNT; ++i) { acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.x, b[i].x, acc[i], 0, 0, 0); \
+                                                          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.y, b[i].y, acc[i], 0, 0, 0); } }
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) acc[i] = (dl_fg_double4){0., 0., 0., 0.};
+    DL_FG_LOAD(b0, 0)
+    DL_FG_LOAD(b1, 1)
+    int q = 0;
+#ifdef DL_FG_X_NOLOAD   // timing experiment: the operand is requested once, the loop multiplies what it has
+    DL_FG_LOAD(b2, 2)
+    for (; q + 3 <= nq; q += 3) { DL_FG_MUL(b0, q) DL_FG_MUL(b1, q + 1) DL_FG_MUL(b2, q + 2) }
+#else
+    for (; q + 3 <= nq; q += 3) {
+        DL_FG_LOAD(b2, q + 2) DL_FG_MUL(b0, q)
+        DL_FG_LOAD(b0, q + 3) DL_FG_MUL(b1, q + 1)
+        DL_FG_LOAD(b1, q + 4) DL_FG_MUL(b2, q + 2)
+    }
+#endif
+    if (q < nq) { DL_FG_MUL(b0, q) }
+    if (q + 1 < nq) { DL_FG_MUL(b1, q + 1) }
+#undef DL_FG_LOAD
+#undef DL_FG_MUL
+}
+
+// rows of the lane's four points += sum over the group's monomials (m0 even); first: the partial rows start from zero; last: the constant part of every row is added.
+// Row 0 (the residual) is dense in the monomials.  The derivative rows are not: the row of a solved alpha* / sn* touches one or two monomials (gr->nz), the other
+// seventeen entries of its monomial row are exact zeros -- multiplying them was 4/5 of the epilogue's LDS reads and FMAs (7 us of the kernel; the LDS pipe of the CU
+// was the bound: 240 16-byte broadcast reads per wave).  The sums run over the same monomials in the same order: bit-identical results.
+template <int CNT>
+__device__ __forceinline__ void dl_fg_gram_epilogue(const dl_fg_double4 (&acc)[CNT], const double* lds, int stride, int nb_pad, int R, int m0, bool first, bool last,
+                                                    const DlFgGram* gr, int cbase, int g) {
+    constexpr int NP = (CNT + 1) / 2;
+#ifdef DL_FG_X_NOEPI     // timing experiment: no epilogue (one value per group keeps the accumulators alive)
+    { double w = 0.; _Pragma("unroll") for (int i = 0; i < CNT; ++i) w += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3]; gr->x[threadIdx.x + 512 * (m0 & 7)] = w; }
+    return;
+#endif
+    double cst[6];                                                                    // constant parts of the rows: requested together, ahead of everything else
+#pragma unroll
+    for (int u = 0; u < 6; ++u) cst[u] = last ? gr->cst[u < R ? u : 0][cbase] : 0.;
+    double* xb0 = gr->x + (size_t)g * gr->xr * DL_FG_XLD + cbase;                    // X rows of point g (+ 4 rr: 4 xr DL_FG_XLD doubles further)
+    const size_t xpt = (size_t)4 * gr->xr * DL_FG_XLD;
+    {   // row 0
+        dl_fg_double2 mm[4][NP];
+        double v[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const double* mono = lds + (g + 4 * rr) * stride + nb_pad + m0;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) mm[rr][j] = *reinterpret_cast<const dl_fg_double2*>(mono + 2 * j);
+            v[rr] = xb0[rr * xpt + (size_t)gr->row_of[0] * DL_FG_XLD];               // (first group: whatever is there, not used)
+        }
+        const double c0 = cst[0];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            double w = first ? 0. : v[rr];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                w = fma(mm[rr][j].x, acc[2 * j][rr], w);
+                if (2 * j + 1 < CNT) w = fma(mm[rr][j].y, acc[2 * j + 1][rr], w);
+            }
+            xb0[rr * xpt + (size_t)gr->row_of[0] * DL_FG_XLD] = last ? w + c0 : w;
+        }
+    }
+    // derivative rows: three passes -- every LDS read of every row first (the rows a monomial of this group feeds, or all of them in the last group), then the FMAs
+    // and the constant parts, then the writes: row by row each read was waited for in turn (4.4 us for the last group)
+    double xr_[5][4], dr_[5][2][4];
+    bool hit[5][2], touch[5];
+#pragma unroll
+    for (int u = 1; u < 6; ++u) {
+#pragma unroll
+        for (int z = 0; z < 2; ++z) { const int m = gr->nz[u][z]; hit[u - 1][z] = u < R && m >= m0 && m < m0 + CNT; }
+        touch[u - 1] = u < R && (first || last || hit[u - 1][0] || hit[u - 1][1]);
+        if (touch[u - 1]) {
+            const double* xu = xb0 + (size_t)gr->row_of[u] * DL_FG_XLD;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) xr_[u - 1][rr] = xu[rr * xpt];            // (first group: whatever is there, not used)
+#pragma unroll
+            for (int z = 0; z < 2; ++z)
+                if (hit[u - 1][z]) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) dr_[u - 1][z][rr] = lds[(g + 4 * rr) * stride + nb_pad + u * DL_FG_MONO_LD + gr->nz[u][z]];
+                }
+        }
+    }
+#pragma unroll
+    for (int u = 1; u < 6; ++u) {
+        if (!touch[u - 1]) continue;
+        if (first) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) xr_[u - 1][rr] = 0.;
+        }
+#pragma unroll
+        for (int z = 0; z < 2; ++z) {
+            if (!hit[u - 1][z]) continue;
+            const int m = gr->nz[u][z];
+#pragma unroll
+            for (int i = 0; i < CNT; ++i)
+                if (m == m0 + i) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) xr_[u - 1][rr] = fma(dr_[u - 1][z][rr], acc[i][rr], xr_[u - 1][rr]);
+                }
+        }
+        if (last) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) xr_[u - 1][rr] += cst[u];
+        }
+    }
+#pragma unroll
+    for (int u = 1; u < 6; ++u) {
+        if (!touch[u - 1]) continue;
+        double* xu = xb0 + (size_t)gr->row_of[u] * DL_FG_XLD;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) xu[rr * xpt] = xr_[u - 1][rr];
+    }
+}
+
+// 16 point records in LDS -> G = X X^T of the 16 points (R <= 6 device rows, N_pad = 128, 512 threads)
+__device__ __forceinline__ void dl_fg_compute_gram(const double* lds, int stride, int nb_pad, int R, const double* __restrict__ gfrag, int64_t B, int64_t p0, const DlFgGram* gr) {
+    constexpr bool GRAM = true;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the operand base of the wave and the team branch)
+    const int col = lane & 15, g = lane >> 4;
+    const int jb = wave;                                // 16-column block of this wave
+    const int nq = nb_pad / 8;
+    const dl_fg_double2* gw = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * nq * DL_FG_NM * 64 + lane;
+    const double* arow = lds + col * stride + 2 * g;
+    const int cbase = jb * 16 + col;
+    if (wave < 4) {   // monomial groups (8, 6, 5); the SIMD partners (waves 4-7): (4, 8, 7) -- group starts are even (16-byte reads of the monomial rows)
+        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 0, acc); DL_FG_STAMP(2) dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g); }
+        DL_FG_STAMP(3)
+        { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6>(arow, gw, nq, 8, acc); dl_fg_gram_epilogue<6>(acc, lds, stride, nb_pad, R, 8, false, false, gr, cbase, g); }
+        { dl_fg_double4 acc[5]; dl_fg_gram_mainloop<5>(arow, gw, nq, 14, acc); DL_FG_STAMP(4) dl_fg_gram_epilogue<5>(acc, lds, stride, nb_pad, R, 14, false, true, gr, cbase, g); }
+    } else {
+        { dl_fg_double4 acc[4]; dl_fg_gram_mainloop<4>(arow, gw, nq, 0, acc); dl_fg_gram_epilogue<4>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g); }
+        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 4, acc); dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 4, false, false, gr, cbase, g); }
+        { dl_fg_double4 acc[7]; dl_fg_gram_mainloop<7>(arow, gw, nq, 12, acc); dl_fg_gram_epilogue<7>(acc, lds, stride, nb_pad, R, 12, false, true, gr, cbase, g); }
+    }
+    DL_FG_STAMP(5)
+    __syncthreads();   // all rows of the 16 points are in LDS
+    DL_FG_STAMP(6)
+    dl_fg_gram_phase(gr, wave, lane, g, B, p0);
+    DL_FG_STAMP(7)
 }
 
 // feat: [B, feat_ld] point records written by the theory kernel, this observable's record at column feat_off

@@ -1184,7 +1184,9 @@ DL_HD void dl_emu_layer(int tid, const DlObsDev::Engine& e, int layer, const dou
 
 // velocileptors 'pars' -> 19 monomials, and the monomials' derivatives w.r.t. analytically solved alpha* / sn* (full_shape.py:1182-1186, 1300-1307, 1577-1592, 1479-1488)
 // ``ms``: row stride of ``mono`` (entries DL_N_MONO .. ms - 1 of every row are set to zero); ``vpre``: the eleven 'pars' inputs already fetched (else read from ``th``)
-DL_HD void dl_velocileptors_monomials(const DlObsDev& o, const double* th, double sigma8, double fsigma8, double* mono, int ms = DL_N_MONO, const double* vpre = nullptr) {
+// ``only_row`` >= 0: write that row alone (0: the monomials, r >= 1: the derivative row of slot r - 1) -- the rows of a point spread over several threads
+DL_HD void dl_velocileptors_monomials(const DlObsDev& o, const double* th, double sigma8, double fsigma8, double* mono, int ms = DL_N_MONO, const double* vpre = nullptr,
+                                      int only_row = -1) {
     double v[DL_N_VPARS];
     for (int c = 0; c < DL_N_VPARS; ++c) v[c] = vpre != nullptr ? vpre[c] : dl_get(o.vp_in[c], th);
     double pars[DL_N_VPARS];
@@ -1212,14 +1214,16 @@ DL_HD void dl_velocileptors_monomials(const DlObsDev& o, const double* th, doubl
         pars[3] = 3. * pars[3] + (b1 - 1.);
     }
     const double b1 = pars[0], b2 = pars[1], bs = pars[2], b3 = pars[3];
-    double* m0 = mono;
-    m0[0] = 1.; m0[1] = b1; m0[2] = b1 * b1; m0[3] = b2; m0[4] = b1 * b2; m0[5] = b2 * b2; m0[6] = bs; m0[7] = b1 * bs; m0[8] = b2 * bs; m0[9] = bs * bs;
-    m0[10] = b3; m0[11] = b1 * b3; m0[12] = pars[4]; m0[13] = pars[5]; m0[14] = pars[6]; m0[15] = pars[7];
-    m0[16] = pars[8] / o.nd; m0[17] = pars[9] / o.nd; m0[18] = pars[10] / o.nd;
-    for (int m = DL_N_MONO; m < ms; ++m) m0[m] = 0.;
+    if (only_row <= 0) {
+        double* m0 = mono;
+        m0[0] = 1.; m0[1] = b1; m0[2] = b1 * b1; m0[3] = b2; m0[4] = b1 * b2; m0[5] = b2 * b2; m0[6] = bs; m0[7] = b1 * bs; m0[8] = b2 * bs; m0[9] = bs * bs;
+        m0[10] = b3; m0[11] = b1 * b3; m0[12] = pars[4]; m0[13] = pars[5]; m0[14] = pars[6]; m0[15] = pars[7];
+        m0[16] = pars[8] / o.nd; m0[17] = pars[9] / o.nd; m0[18] = pars[10] / o.nd;
+        for (int m = DL_N_MONO; m < ms; ++m) m0[m] = 0.;
+    }
     for (int c = 4; c < DL_N_VPARS; ++c) {
         int slot = o.vp_slot[c];
-        if (slot < 0) continue;
+        if (slot < 0 || (only_row >= 0 && only_row != 1 + slot)) continue;
         double* d = mono + (size_t)(1 + slot) * ms;
         for (int m = 0; m < ms; ++m) d[m] = 0.;
         if (physical) {
@@ -1231,6 +1235,22 @@ DL_HD void dl_velocileptors_monomials(const DlObsDev& o, const double* th, doubl
             if (c < 8) d[12 + (c - 4)] = 1.;
             else d[16 + (c - 8)] = 1. / o.nd;
         }
+    }
+}
+
+// which monomials the derivative row of velocileptors parameter c (4 .. 10: alpha0 .. sn4) touches -- the support of the rows dl_velocileptors_monomials writes
+// (at most two, ascending; -1: none).  The Gram epilogue of the feature GEMM (dl_feature_gemm.h) multiplies only these.
+DL_HD void dl_velocileptors_row_support(const DlObsDev& o, int c, int nz[2]) {
+    const bool physical = (o.mono_mode == 1 || o.mono_mode == 2);
+    nz[0] = nz[1] = -1;
+    if (physical) {
+        if (c == 4) { nz[0] = 12; nz[1] = 13; }
+        else if (c == 5) { nz[0] = 13; nz[1] = 14; }
+        else if (c == 6) { nz[0] = 14; nz[1] = 15; }
+        else if (c >= 8) nz[0] = 16 + (c - 8);
+    } else {
+        if (c < 8) nz[0] = 12 + (c - 4);
+        else nz[0] = 16 + (c - 8);
     }
 }
 

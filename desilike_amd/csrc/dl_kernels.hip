@@ -874,6 +874,11 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
         } else { ga.const_row[ga.n_const] = 1 + s; ga.const_ptr[ga.n_const] = mg.tconst + (size_t)s * 128; ga.n_const++; }
     }
     for (int r = 1; r < R; ++r) if (ga.cst[r] == nullptr) return false;   // a device row that feeds no solved parameter
+    for (int r = 0; r < 6; ++r) ga.nz[r][0] = ga.nz[r][1] = -1;
+    for (int c = 4; c < DL_N_VPARS; ++c) {   // the monomials each derivative row touches
+        const int slot = obs.vp_slot[c];
+        if (slot >= 0 && 1 + slot < 6) dl_velocileptors_row_support(obs, c, ga.nz[1 + slot]);
+    }
     const size_t shm = dl_ef_gram_shared_doubles(obs, ga.xr) * sizeof(double);
     if (shm > 156 * 1024) return false;
     static size_t shm_set = 0;
@@ -886,7 +891,7 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
     ga.stamps = (stamp_file && grid <= 8192 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
     if (stamp_file) stamp_launches++;
     if (ga.stamps) (void)hipMemsetAsync(ga.stamps, 0, (size_t)grid * 16 * sizeof(unsigned long long), stream);
-    DL_LAUNCH(dl_emulated_feature_gram_kernel, dim3(grid, 1), dim3(512), shm, stream, obs, theta, n_params, B, gfrag, ga);
+    DL_LAUNCH(dl_emulated_feature_gram_kernel, dim3(grid, 1), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, ga);
     if (ga.stamps) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h((size_t)grid * 16);

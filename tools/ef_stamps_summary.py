@@ -11,7 +11,11 @@ for line in open(sys.argv[1]):
         cur.append([float(v) for v in line.split()])
 names = ['forward (MLP engines, monomials, records)', 'feature GEMM, monomials 0-9', 'epilogue 0', 'feature GEMM, monomials 10-18', 'epilogue 1', 'barrier', 'Gram matrices']
 for ib, a in enumerate(blocks):
-    fwd = a[:, 8:] if a.shape[1] > 8 else None
+    fwd = a[:, 8:14] if a.shape[1] > 8 else None
+    if a.shape[1] >= 16 and (a[:, 15] > a[:, 14]).all():   # s_memrealtime (100 MHz) at entry / exit against s_memtime: the shader clock during the kernel
+        ghz = np.median((a[:, 7] - a[:, 0]) / ((a[:, 15] - a[:, 14]) * 10.))
+        span = (a[:, 15].max() - a[:, 14].min()) * 0.01
+        print('launch %d: shader clock %.3f GHz (the times below assume 2.4); first entry -> last exit on the chip-wide clock: %.2f us' % (ib, ghz, span))
     a = a[:, :8]
     d = np.diff(a, axis=1) / 2.4e3
     print('launch %d: %d workgroups; life median %.2f us max %.2f us' % (ib, len(a), np.median((a[:, 7] - a[:, 0]) / 2.4e3), ((a[:, 7] - a[:, 0]) / 2.4e3).max()))
