@@ -246,6 +246,39 @@ def timed_steps(step, barrier, steps):
     return time.perf_counter() - t0
 
 
+def init_rccl_group(parallel, local_rank, rank, world, timeout=180.):
+    """``parallel.RcclGroup`` with a deadline and a self-check.  ``ncclCommInitRank`` blocks until every rank has arrived: a rank that died (or a wrong WORLD_SIZE) would
+    hang the job silently -- the communicator is created on a helper thread and a rank that waits longer than ``timeout`` seconds raises.  Then every rank all-gathers its
+    own rank number and checks the result: the first collective of the run either works, visibly, or fails here."""
+    import threading
+    import torch
+    box = {}
+
+    def create():
+        try:
+            box['group'] = parallel.RcclGroup(local_rank, rank=rank, world=world)
+        except BaseException as exc:   # noqa: BLE001 (reported by the caller)
+            box['error'] = exc
+
+    thread = threading.Thread(target=create, daemon=True)
+    thread.start()
+    thread.join(timeout)
+    if thread.is_alive():
+        raise TimeoutError('communicator not created after {:.0f} s (DL_COMM_TIMEOUT): is every one of the {:d} ranks alive and on its own GPU?'.format(timeout, world))
+    if 'error' in box:
+        raise box['error']
+    group = box['group']
+    device = torch.device('cuda', local_rank)
+    send = torch.full((4,), float(rank), dtype=torch.float64, device=device)
+    recv = torch.full((4 * world,), -1., dtype=torch.float64, device=device)
+    group.allgather_into(recv, send)
+    torch.cuda.synchronize(device)
+    expected = torch.arange(world, dtype=torch.float64, device=device).repeat_interleave(4)
+    if not torch.equal(recv, expected):
+        raise RuntimeError('RCCL all-gather self-check failed on rank {:d}: got {}'.format(rank, recv.cpu().tolist()))
+    return group
+
+
 def config5_strong(group, device, local_rank, rank, world, iterations, warmup=300):
     """BASELINE configs[4] as written: ONE ensemble of 512 walkers on the two-tracer likelihood; every half-step's 256 proposals are split over the ranks
     (min_shard_rows = 0) and the log-posteriors all-gathered synchronously (in place, on the evaluation stream) before the accept step: strong scaling."""
@@ -630,6 +663,7 @@ def main():
     parser.add_argument('--chains-iterations', type=int, default=300, help='ensemble updates per chain of the chain-parallel sampler measurement `chains_weak` (0: skip)')
     parser.add_argument('--dry-run', action='store_true', help='launcher check without a GPU: start the ranks, form the (gloo) group, exchange, print the line skeleton')
     parser.add_argument('--no-events', action='store_true', help='diagnostic: no HIP events attached to the kernels in the timed region')
+    parser.add_argument('--allow-torch-fallback', action='store_true', help="diagnostic: if RCCL through the C ABI (dl_comm_*) fails, go on with torch.distributed's nccl binding instead of failing")
     args = parser.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -655,15 +689,20 @@ def main():
     if world > 1 or force_dist:
         from desilike_amd import parallel
         if backend == 'rccl':
+            # The exchange of the N > 1 line is RCCL through the library's own C ABI (dl_comm_*).  If that fails the run FAILS (per-rank error line, non-zero exit):
+            # a line measured on torch.distributed's binding instead would hide a broken communicator behind a green result (--allow-torch-fallback: diagnostics only).
             try:
-                group = parallel.RcclGroup(local_rank, rank=rank, world=world)
+                group = init_rccl_group(parallel, local_rank, rank, world, timeout=float(os.environ.get('DL_COMM_TIMEOUT', 180.)))
                 collective = 'RCCL {} through the C ABI (dl_comm_allgather_f64)'.format(group.rccl_version)
-            except Exception as exc:   # (a failure to load / initialise RCCL through the library is the same on every rank: they all take torch's binding of the same RCCL)
-                print('bench.py rank {:d}: RCCL through the C ABI failed ({}); falling back to torch.distributed nccl'.format(rank, exc), file=sys.stderr, flush=True)
+            except Exception as exc:
+                print('bench.py rank {:d} / {:d} (GPU {:d}): RCCL through the C ABI failed: {}'.format(rank, world, local_rank, exc), file=sys.stderr, flush=True)
+                if not args.allow_torch_fallback:
+                    sys.stderr.flush()
+                    os._exit(3)   # (not sys.exit: a rank stuck in ncclCommInitRank on another thread must not keep the process alive)
                 import torch.distributed as dist
                 dist.init_process_group(backend='nccl', rank=rank, world_size=world)
                 group = parallel.TorchGroup(device=local_rank)
-                collective = 'torch.distributed nccl (RCCL)'
+                collective = 'torch.distributed nccl (RCCL) -- FALLBACK, the C-ABI communicator failed'
         else:
             import torch.distributed as dist
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -779,7 +818,7 @@ def main():
                   'config': {'workload': 'BASELINE configs[1]: ShapeFit+Kaiser P_ell ell=(0,2,4) x 40 k-bins, dense window 120x1200 (n_kin=400/ell), 120x120 precision, '
                                          '{:d} batched param points per GPU per step'.format(B), 'batch_per_gpu': B, 'n_params': 6,
                              'parallelism': 'walkers x{:d}'.format(world) + (', log-posteriors all-gathered in buckets of {:d} steps'.format(GATHER_EVERY) if distributed else ''),
-                             'collective': collective, 'ranks': group.world if distributed else 1},
+                             'collective': collective, 'ranks': group.world if distributed else 1, 'rccl_version': getattr(group, 'rccl_version', None) if distributed else None},
                   'roofline': {'bound': bound, 'bound_detail': {'theory': 'fp64 VALU (no MFMA in this kernel: transcendentals, spline evaluation, projection); peak = 78.6 TFLOP/s fp64 vector',
                                                                  'window_gemm': 'fp64 MFMA (v_mfma_f64_16x16x4_f64), peak = 78.6 TFLOP/s fp64 matrix', 'finalize': 'launch latency'}[dominant],
                                'kernel': kernel_name, 'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS, 'traffic': traffic,

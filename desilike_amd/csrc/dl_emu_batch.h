@@ -234,26 +234,28 @@ __device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const dou
     // pointer and a constant stride, no predicates), kind 1 = a layer with <= 16 inputs (input layers, the scalar engines' output layer: four k-steps, predicated by a
     // clamped address and a select).  Everything else takes the general loop of dl_eb_forward, weights requested where they are used.
     auto tile_kind = [&](int nin, int nout, int t) { return (nin == 64 && 16 * t + 16 <= nout) ? 2 : (nin <= 16 ? 1 : 0); };
-    auto request = [&](const double* wl, int nin, int nout, int t, int kind) {
+    double bwn[16], bbn = 0.;                              // second set: the NEXT layer's weights, requested before the MFMAs of the current one
+    auto request_to = [&](double (&dst)[16], double& dbias, const double* wl, int nin, int nout, int t, int kind) {
         const int oc = 16 * t + col;
         if (kind == 2) {
             const double* wp = wl + (unsigned)(g * nout + oc);
             const unsigned ws = 4u * (unsigned)nout;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) bw[u] = wp[u * ws];
-            bbias = wl[(unsigned)(nin * nout + oc)];
+            for (int u = 0; u < 16; ++u) dst[u] = wp[u * ws];
+            dbias = wl[(unsigned)(nin * nout + oc)];
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = 4 * u + g;
                 const bool ok = k < nin && oc < nout;
                 const double v = wl[ok ? (unsigned)(k * nout + oc) : 0u];
-                bw[u] = ok ? v : 0.;
+                dst[u] = ok ? v : 0.;
             }
             const double bv = wl[(unsigned)(nin * nout + (oc < nout ? oc : 0))];
-            bbias = oc < nout ? bv : 0.;
+            dbias = oc < nout ? bv : 0.;
         }
     };
+    auto request = [&](const double* wl, int nin, int nout, int t, int kind) { request_to(bw, bbias, wl, nin, nout, t, kind); };
     int have = 0;                                         // kind of the tile (t0 of the coming layer) whose weights bw / bbias hold, or 0
     if (my_ie >= 0 && mono_at > 0 && e.n_layers > 0 && t0 < (e.widths[1] + 15) / 16) {
         have = tile_kind(e.widths[0], e.widths[1], t0);
@@ -346,6 +348,14 @@ __device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const dou
                 const int oc = 16 * t + col;
                 dl_eb_double4 acc = {0., 0., 0., 0.}, acc2 = {0., 0., 0., 0.};   // two chains (even / odd k-steps), as in dl_eb_forward
                 const int kind = tile_kind(nin, nout, t);
+                // the weights of this wave's first tile of the NEXT layer go out before the MFMAs of this one (a layer's weights do not depend on activations):
+                // requested after them they were still 0.55 us away when the next layer wanted them
+                int have_next = 0;
+                if (t + my_nw >= tiles && !last && layer + 1 < l1 && t0 < (e.widths[layer + 2] + 15) / 16) {
+                    have_next = tile_kind(nout, e.widths[layer + 2], t0);
+                    if (have_next && kind && (have && t == t0)) request_to(bwn, bbn, wn, nout, e.widths[layer + 2], t0, have_next);
+                    else have_next = -have_next;    // (negative: not requested yet -- after the MFMAs, into the first set)
+                }
                 if (kind) {
                     if (!(have && t == t0)) request(w, nin, nout, t, kind);
                     const double* ap = cur + col * LD + g;
@@ -389,11 +399,12 @@ __device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const dou
                 acc += acc2;
                 const double bias = bbias;
                 have = 0;
-                // the weights of this wave's first tile of the NEXT layer: on their way during the activation and the barrier
-                if (t + my_nw >= tiles && !last && layer + 1 < l1 && t0 < (e.widths[layer + 2] + 15) / 16) {
-                    have = tile_kind(nout, e.widths[layer + 2], t0);
-                    if (have) request(wn, nout, e.widths[layer + 2], t0, have);
-                }
+                if (have_next > 0) {
+                    have = have_next;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) bw[u] = bwn[u];
+                    bbias = bbn;
+                } else if (have_next < 0) { have = -have_next; request(wn, nout, e.widths[layer + 2], t0, have); }
                 // accumulator register r = out[point g + 4 r][oc].  The branch on the activation sits OUTSIDE the four evaluations: inside (dl_activation per value)
                 // each exponential was a basic block of its own and the four dependent chains ran one after the other (1.2 us of a 2.2 us layer)
                 double vv[4];
@@ -493,8 +504,6 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const dou
     double* work = lds + dl_ef_gram_rec_doubles(o);
     if (ga.stamps != nullptr && threadIdx.x == 0) { ga.stamps[(size_t)blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memtime(); ga.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime(); }
     dl_eb_forward_fused<512>(o, theta, n_params, B, p0, work, rec, stride, ga.stamps != nullptr ? ga.stamps + (size_t)blockIdx.x * 16 : nullptr, th_early, th_val);
-    __syncthreads();   // the records are complete, the forward workspace is free: X takes its place
-    if (ga.stamps != nullptr && threadIdx.x == 0) ga.stamps[(size_t)blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memtime();
     DlFgGram gr;
     gr.x = work;
     gr.xr = ga.xr; gr.gram = ga.gram; gr.stamps = ga.stamps;
@@ -502,13 +511,20 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const dou
     for (int r = 0; r < 6; ++r) { gr.nz[r][0] = ga.nz[r][0]; gr.nz[r][1] = ga.nz[r][1]; }
 #pragma unroll
     for (int r = 0; r < 6; ++r) { gr.row_of[r] = ga.row_of[r]; gr.cst[r] = ga.cst[r]; }
-    // rows of solved parameters whose derivative does not depend on the point: the constant itself (visible to the Gram phase after the barrier inside dl_fg_compute)
-    for (int c = 0; c < ga.n_const; ++c)
-        for (int idx = threadIdx.x; idx < DL_FG_PTS * 128; idx += 512) {
-            const int pt = idx >> 7, col = idx & 127;
-            gr.x[((size_t)pt * gr.xr + ga.const_row[c]) * DL_FG_XLD + col] = ga.const_ptr[c][col];
-        }
-    dl_fg_compute_gram(rec, stride, o.nb_pad, R, gfrag, B, p0, &gr);
+    // (the first operand request of the feature GEMM goes out, THEN:) the records are complete, the forward workspace is free: X takes its place
+    auto after_request = [&]() {
+        // a barrier that waits for this wave's LDS traffic only: __syncthreads() also waits for the operand request that was just issued (vmcnt(0)); the records are
+        // LDS writes, and what the other waves read after the barrier is LDS
+        asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");
+        if (ga.stamps != nullptr && threadIdx.x == 0) ga.stamps[(size_t)blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memtime();
+        // rows of solved parameters whose derivative does not depend on the point: the constant itself (visible to the Gram phase after the barrier before it)
+        for (int c = 0; c < ga.n_const; ++c)
+            for (int idx = threadIdx.x; idx < DL_FG_PTS * 128; idx += 512) {
+                const int pt = idx >> 7, col = idx & 127;
+                gr.x[((size_t)pt * gr.xr + ga.const_row[c]) * DL_FG_XLD + col] = ga.const_ptr[c][col];
+            }
+    };
+    dl_fg_compute_gram(rec, stride, o.nb_pad, R, gfrag, B, p0, &gr, after_request);
     if (ga.stamps != nullptr && threadIdx.x == 0) ga.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime();   // (100 MHz, chip-wide: calibrates the shader clock)
 }
 #endif

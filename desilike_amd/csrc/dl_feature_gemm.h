@@ -250,28 +250,33 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
 // slower partner.  Waves 0-3 now take the monomials in groups of (10, 9), waves 4-7 (their SIMD partners) in groups of (6, 10, 3): an epilogue of one meets a main
 // loop of the other.  Every output still sums its monomials in the order 0..18 from zero (partial sums wait in X between groups): results are bit-identical.
 // The operand registers rotate by unrolling the k loop three times (two steps in flight) instead of being copied (80 moves per step).
+// the first two k-steps of a group's operand, requested AHEAD of its main loop (during the previous group's epilogue; for the first group before the barrier that
+// follows the forward pass): a group is only nq (9) steps long, and started cold every group paid the L2 round trip with the matrix pipe idle whenever the SIMD
+// partner was not streaming (the timelines of both waves of a SIMD: a wave alone reached 57 % of the pipe's rate)
+template <int CNT> struct DlFgAhead { dl_fg_double2 b0[CNT], b1[CNT]; };
 template <int CNT>
-__device__ __forceinline__ void dl_fg_gram_mainloop(const double* arow, const dl_fg_double2* __restrict__ gw, int nq, int m0, dl_fg_double4 (&acc)[CNT]) {
+__device__ __forceinline__ void dl_fg_gram_request(DlFgAhead<CNT>& ah, const dl_fg_double2* __restrict__ gw, int nq, int m0) {
+    const int q1 = 1 < nq ? 1 : nq - 1;
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) ah.b0[i] = gw[(size_t)(m0 + i) * 64];
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) ah.b1[i] = gw[(size_t)(q1 * DL_FG_NM + m0 + i) * 64];
+}
+template <int CNT>
+__device__ __forceinline__ void dl_fg_gram_mainloop(const double* arow, const dl_fg_double2* __restrict__ gw, int nq, int m0, dl_fg_double4 (&acc)[CNT], const DlFgAhead<CNT>& ah) {
     dl_fg_double2 b0[CNT], b1[CNT], b2[CNT];
 #define DL_FG_LOAD(b, qq) { const int q_ = (qq) < nq ? (qq) : nq - 1; _Pragma("unroll") for (int i = 0; i < CNT; ++i) b[i] = gw[(size_t)(q_ * DL_FG_NM + m0 + i) * 64]; }
 #define DL_FG_MUL(b, qq) { const dl_fg_double2 a_ = *reinterpret_cast<const dl_fg_double2*>(arow + 8 * (qq)); \
         _Pragma("unroll") for (int i = 0; i < CNT; ++i) { acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.x, b[i].x, acc[i], 0, 0, 0); \
                                                           acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.y, b[i].y, acc[i], 0, 0, 0); } }
 #pragma unroll
-    for (int i = 0; i < CNT; ++i) acc[i] = (dl_fg_double4){0., 0., 0., 0.};
-    DL_FG_LOAD(b0, 0)
-    DL_FG_LOAD(b1, 1)
+    for (int i = 0; i < CNT; ++i) { acc[i] = (dl_fg_double4){0., 0., 0., 0.}; b0[i] = ah.b0[i]; b1[i] = ah.b1[i]; }
     int q = 0;
-#ifdef DL_FG_X_NOLOAD   // timing experiment: the operand is requested once, the loop multiplies what it has
-    DL_FG_LOAD(b2, 2)
-    for (; q + 3 <= nq; q += 3) { DL_FG_MUL(b0, q) DL_FG_MUL(b1, q + 1) DL_FG_MUL(b2, q + 2) }
-#else
     for (; q + 3 <= nq; q += 3) {
         DL_FG_LOAD(b2, q + 2) DL_FG_MUL(b0, q)
         DL_FG_LOAD(b0, q + 3) DL_FG_MUL(b1, q + 1)
         DL_FG_LOAD(b1, q + 4) DL_FG_MUL(b2, q + 2)
     }
-#endif
     if (q < nq) { DL_FG_MUL(b0, q) }
     if (q + 1 < nq) { DL_FG_MUL(b1, q + 1) }
 #undef DL_FG_LOAD
@@ -284,15 +289,8 @@ __device__ __forceinline__ void dl_fg_gram_mainloop(const double* arow, const dl
 // was the bound: 240 16-byte broadcast reads per wave).  The sums run over the same monomials in the same order: bit-identical results.
 template <int CNT>
 __device__ __forceinline__ void dl_fg_gram_epilogue(const dl_fg_double4 (&acc)[CNT], const double* lds, int stride, int nb_pad, int R, int m0, bool first, bool last,
-                                                    const DlFgGram* gr, int cbase, int g) {
+                                                    const DlFgGram* gr, int cbase, int g, const double (&cst)[6]) {
     constexpr int NP = (CNT + 1) / 2;
-#ifdef DL_FG_X_NOEPI     // timing experiment: no epilogue (one value per group keeps the accumulators alive)
-    { double w = 0.; _Pragma("unroll") for (int i = 0; i < CNT; ++i) w += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3]; gr->x[threadIdx.x + 512 * (m0 & 7)] = w; }
-    return;
-#endif
-    double cst[6];                                                                    // constant parts of the rows: requested together, ahead of everything else
-#pragma unroll
-    for (int u = 0; u < 6; ++u) cst[u] = last ? gr->cst[u < R ? u : 0][cbase] : 0.;
     double* xb0 = gr->x + (size_t)g * gr->xr * DL_FG_XLD + cbase;                    // X rows of point g (+ 4 rr: 4 xr DL_FG_XLD doubles further)
     const size_t xpt = (size_t)4 * gr->xr * DL_FG_XLD;
     {   // row 0
@@ -317,61 +315,72 @@ __device__ __forceinline__ void dl_fg_gram_epilogue(const dl_fg_double4 (&acc)[C
             xb0[rr * xpt + (size_t)gr->row_of[0] * DL_FG_XLD] = last ? w + c0 : w;
         }
     }
-    // derivative rows: three passes -- every LDS read of every row first (the rows a monomial of this group feeds, or all of them in the last group), then the FMAs
-    // and the constant parts, then the writes: row by row each read was waited for in turn (4.4 us for the last group)
-    double xr_[5][4], dr_[5][2][4];
-    bool hit[5][2], touch[5];
+    // derivative rows, in two batches of rows (1-3, 4-5; register budget: the next group's operand is already in flight), three passes per batch -- every LDS read
+    // first (the rows a monomial of this group feeds, or all of them in the last group), then the FMAs and the constant parts, then the writes: row by row each read
+    // was waited for in turn (4.4 us for the last group)
 #pragma unroll
-    for (int u = 1; u < 6; ++u) {
+    for (int u0 = 1; u0 < 6; u0 += 3) {
+        double xr_[3][4], dr_[3][2][4];
+        bool hit[3][2], touch[3];
 #pragma unroll
-        for (int z = 0; z < 2; ++z) { const int m = gr->nz[u][z]; hit[u - 1][z] = u < R && m >= m0 && m < m0 + CNT; }
-        touch[u - 1] = u < R && (first || last || hit[u - 1][0] || hit[u - 1][1]);
-        if (touch[u - 1]) {
-            const double* xu = xb0 + (size_t)gr->row_of[u] * DL_FG_XLD;
+        for (int k = 0; k < 3; ++k) {
+            const int u = u0 + k;
+            if (u >= 6) { touch[k] = hit[k][0] = hit[k][1] = false; continue; }
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) xr_[u - 1][rr] = xu[rr * xpt];            // (first group: whatever is there, not used)
+            for (int z = 0; z < 2; ++z) { const int m = gr->nz[u][z]; hit[k][z] = u < R && m >= m0 && m < m0 + CNT; }
+            touch[k] = u < R && (first || last || hit[k][0] || hit[k][1]);
+            if (touch[k]) {
+                const double* xu = xb0 + (size_t)gr->row_of[u] * DL_FG_XLD;
 #pragma unroll
-            for (int z = 0; z < 2; ++z)
-                if (hit[u - 1][z]) {
+                for (int rr = 0; rr < 4; ++rr) xr_[k][rr] = xu[rr * xpt];            // (first group: whatever is there, not used)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) dr_[u - 1][z][rr] = lds[(g + 4 * rr) * stride + nb_pad + u * DL_FG_MONO_LD + gr->nz[u][z]];
-                }
-        }
-    }
+                for (int z = 0; z < 2; ++z)
+                    if (hit[k][z]) {
 #pragma unroll
-    for (int u = 1; u < 6; ++u) {
-        if (!touch[u - 1]) continue;
-        if (first) {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) xr_[u - 1][rr] = 0.;
+                        for (int rr = 0; rr < 4; ++rr) dr_[k][z][rr] = lds[(g + 4 * rr) * stride + nb_pad + u * DL_FG_MONO_LD + gr->nz[u][z]];
+                    }
+            }
         }
 #pragma unroll
-        for (int z = 0; z < 2; ++z) {
-            if (!hit[u - 1][z]) continue;
-            const int m = gr->nz[u][z];
+        for (int k = 0; k < 3; ++k) {
+            const int u = u0 + k;
+            if (u >= 6 || !touch[k]) continue;
+            if (first) {
 #pragma unroll
-            for (int i = 0; i < CNT; ++i)
-                if (m == m0 + i) {
+                for (int rr = 0; rr < 4; ++rr) xr_[k][rr] = 0.;
+            }
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) xr_[u - 1][rr] = fma(dr_[u - 1][z][rr], acc[i][rr], xr_[u - 1][rr]);
-                }
+            for (int z = 0; z < 2; ++z) {
+                if (!hit[k][z]) continue;
+                const int m = gr->nz[u][z];
+#pragma unroll
+                for (int i = 0; i < CNT; ++i)
+                    if (m == m0 + i) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) xr_[k][rr] = fma(dr_[k][z][rr], acc[i][rr], xr_[k][rr]);
+                    }
+            }
+            if (last) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) xr_[k][rr] += cst[u];
+            }
         }
-        if (last) {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) xr_[u - 1][rr] += cst[u];
+        for (int k = 0; k < 3; ++k) {
+            const int u = u0 + k;
+            if (u >= 6 || !touch[k]) continue;
+            double* xu = xb0 + (size_t)gr->row_of[u] * DL_FG_XLD;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) xu[rr * xpt] = xr_[k][rr];
         }
-    }
-#pragma unroll
-    for (int u = 1; u < 6; ++u) {
-        if (!touch[u - 1]) continue;
-        double* xu = xb0 + (size_t)gr->row_of[u] * DL_FG_XLD;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) xu[rr * xpt] = xr_[u - 1][rr];
     }
 }
 
-// 16 point records in LDS -> G = X X^T of the 16 points (R <= 6 device rows, N_pad = 128, 512 threads)
-__device__ __forceinline__ void dl_fg_compute_gram(const double* lds, int stride, int nb_pad, int R, const double* __restrict__ gfrag, int64_t B, int64_t p0, const DlFgGram* gr) {
+// 16 point records in LDS -> G = X X^T of the 16 points (R <= 6 device rows, N_pad = 128, 512 threads).  Called BEFORE the barrier that completes the records: the
+// barrier is inside, after the first operand request
+template <class AfterRequest>
+__device__ __forceinline__ void dl_fg_compute_gram(const double* lds, int stride, int nb_pad, int R, const double* __restrict__ gfrag, int64_t B, int64_t p0, const DlFgGram* gr,
+                                                   AfterRequest&& after_request) {
     constexpr bool GRAM = true;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the operand base of the wave and the team branch)
     const int col = lane & 15, g = lane >> 4;
@@ -380,16 +389,27 @@ __device__ __forceinline__ void dl_fg_compute_gram(const double* lds, int stride
     const dl_fg_double2* gw = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * nq * DL_FG_NM * 64 + lane;
     const double* arow = lds + col * stride + 2 * g;
     const int cbase = jb * 16 + col;
-    if (wave < 4) {   // monomial groups (8, 6, 5); the SIMD partners (waves 4-7): (4, 8, 7) -- group starts are even (16-byte reads of the monomial rows)
-        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 0, acc); DL_FG_STAMP(2) dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g); }
+    double cst[6] = {0., 0., 0., 0., 0., 0.};   // constant parts of the rows (used by the last epilogue): requested before the last main loop, which hides the round trip
+#define DL_FG_CST _Pragma("unroll") for (int u = 0; u < 6; ++u) cst[u] = gr->cst[u < R ? u : 0][cbase];
+    // monomial groups (8, 6, 5) on waves 0-3, (4, 8, 7) on their SIMD partners -- group starts are even (16-byte reads of the monomial rows); the first two steps of
+    // every group's operand are requested before the epilogue of the group before it
+    if (wave < 4) {
+        DlFgAhead<8> a0; DlFgAhead<6> a1; DlFgAhead<5> a2;
+        dl_fg_gram_request<8>(a0, gw, nq, 0);
+        after_request();   // (barrier: the records of the forward pass are complete)
+        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 0, acc, a0); DL_FG_STAMP(2) dl_fg_gram_request<6>(a1, gw, nq, 8); dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g, cst); }
         DL_FG_STAMP(3)
-        { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6>(arow, gw, nq, 8, acc); dl_fg_gram_epilogue<6>(acc, lds, stride, nb_pad, R, 8, false, false, gr, cbase, g); }
-        { dl_fg_double4 acc[5]; dl_fg_gram_mainloop<5>(arow, gw, nq, 14, acc); DL_FG_STAMP(4) dl_fg_gram_epilogue<5>(acc, lds, stride, nb_pad, R, 14, false, true, gr, cbase, g); }
+        { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6>(arow, gw, nq, 8, acc, a1); dl_fg_gram_request<5>(a2, gw, nq, 14); DL_FG_CST dl_fg_gram_epilogue<6>(acc, lds, stride, nb_pad, R, 8, false, false, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[5]; dl_fg_gram_mainloop<5>(arow, gw, nq, 14, acc, a2); DL_FG_STAMP(4) dl_fg_gram_epilogue<5>(acc, lds, stride, nb_pad, R, 14, false, true, gr, cbase, g, cst); }
     } else {
-        { dl_fg_double4 acc[4]; dl_fg_gram_mainloop<4>(arow, gw, nq, 0, acc); dl_fg_gram_epilogue<4>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g); }
-        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 4, acc); dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 4, false, false, gr, cbase, g); }
-        { dl_fg_double4 acc[7]; dl_fg_gram_mainloop<7>(arow, gw, nq, 12, acc); dl_fg_gram_epilogue<7>(acc, lds, stride, nb_pad, R, 12, false, true, gr, cbase, g); }
+        DlFgAhead<4> a0; DlFgAhead<8> a1; DlFgAhead<7> a2;
+        dl_fg_gram_request<4>(a0, gw, nq, 0);
+        after_request();
+        { dl_fg_double4 acc[4]; dl_fg_gram_mainloop<4>(arow, gw, nq, 0, acc, a0); dl_fg_gram_request<8>(a1, gw, nq, 4); dl_fg_gram_epilogue<4>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 4, acc, a1); dl_fg_gram_request<7>(a2, gw, nq, 12); DL_FG_CST dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 4, false, false, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[7]; dl_fg_gram_mainloop<7>(arow, gw, nq, 12, acc, a2); dl_fg_gram_epilogue<7>(acc, lds, stride, nb_pad, R, 12, false, true, gr, cbase, g, cst); }
     }
+#undef DL_FG_CST
     DL_FG_STAMP(5)
     __syncthreads();   // all rows of the 16 points are in LDS
     DL_FG_STAMP(6)

@@ -113,6 +113,40 @@ def test_walker_sharding_gloo_world2():
     assert np.allclose(results[0][2], results[1][2])                       # identical chains on all ranks
 
 
+def _strong_worker(rank, world, port, results):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from desilike_amd.samplers import EmceeSampler
+    from desilike_amd.parallel import WalkerSharding
+    like = ToyGaussianLikelihood()
+    sharding = WalkerSharding(min_shard_rows=0)                  # BASELINE configs[4] as written: every half-step is split over the ranks, whatever its size
+    sampler = EmceeSampler(like, nwalkers=14, seed=11, use_emcee=False, sharding=sharding)   # half-steps of 7 proposals over 2 ranks: 4 + 3 rows (ragged)
+    chain = sampler.run(niterations=40)
+    results[rank] = (chain['a'].copy(), chain['b'].copy(), chain['logposterior'].copy(), like.ncalls, sampler.acceptance_fraction.copy())
+    dist.destroy_process_group()
+
+
+def test_strong_config5_path_ragged_walkers_gloo_world2():
+    """The strong-scaling mode of BASELINE configs[4] (one ensemble, every half-step's proposals sharded over the ranks, log-posteriors all-gathered before the accept
+    step) on two ranks with a walker count that does not divide: both ranks hold THE chain a single process produces from the same seed, and each rank evaluated
+    only its share of the proposals."""
+    import torch.multiprocessing as mp
+    from desilike_amd.samplers import EmceeSampler
+    manager = mp.Manager()
+    results = manager.dict()
+    port = 35500 + os.getpid() % 2000
+    mp.spawn(_strong_worker, args=(2, port, results), nprocs=2, join=True)
+    like = ToyGaussianLikelihood()
+    single = EmceeSampler(like, nwalkers=14, seed=11, use_emcee=False)
+    chain = single.run(niterations=40)
+    for rank in range(2):
+        a, b, logp, ncalls, acceptance = results[rank]
+        assert np.array_equal(a, chain['a']) and np.array_equal(b, chain['b']) and np.array_equal(logp, chain['logposterior'])
+        assert np.array_equal(acceptance, single.acceptance_fraction)
+    assert results[0][3] > 0 and results[1][3] > 0
+
+
 def _pipelined_worker(rank, world, port, results):
     import torch
     import torch.distributed as dist

@@ -28,3 +28,8 @@ for ib, a in enumerate(blocks):
             print('    forward: %-36s median %6.2f us' % ('entry -> inputs in LDS (barrier)' if n == 0 else 'layer %d done (barrier)' % (n - 1), np.median((fwd[:, q] - prev) / 2.4e3)))
             prev = fwd[:, q]
         if used: print('    forward: %-36s median %6.2f us' % ('last barrier -> records complete', np.median((a[:, 1] - prev) / 2.4e3)))
+    if fwd is not None and (fwd > 0).all():   # temporary: the timeline of wave 4 (team 1) relative to the forward's end
+        t0 = a[:, 1]
+        lab = ['G4 start', 'G4 end', 'E end', 'G8 end', 'E end', 'G7 end']
+        print('    wave 4: ' + '  '.join('%s %.2f' % (l, np.median((fwd[:, q] - t0) / 2.4e3)) for q, l in enumerate(lab)))
+        print('    wave 0: G8 end %.2f  E end %.2f  G6+E+G5 end %.2f  E end %.2f  barrier passed %.2f' % tuple(np.median((a[:, q] - t0) / 2.4e3) for q in (2, 3, 4, 5, 6)))
