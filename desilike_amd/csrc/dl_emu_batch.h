@@ -266,8 +266,38 @@ __device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const dou
     // theta was requested before the first access to `o` (th_val = theta[point tid / 32][column tid % 32]): the rows go through LDS, and the input tables
     // (lane-dependent fields of `o`: vector loads from the kernel-argument segment) are fetched meanwhile -- one round trip at entry instead of two in a row
     double* trow = lds + (size_t)DL_EB_PTS * (DL_MAX_X + 6 * LD + 4 + (size_t)(1 + o.n_var) * DL_N_MONO);   // [16][32]
+    if (th_early && DL_EB_PTS * nin0 <= NTHR && DL_EB_PTS * DL_N_VPARS <= NTHR) {
+        // one (point, input) and one (point, 'pars' entry) per thread: the descriptors -- lane-dependent fields of `o`, the scalers of the engines: a round trip each
+        // to the kernel-argument segment / L2 -- are requested BEFORE the barrier that publishes the theta rows, not after it (two round trips in a row at entry)
+        const int pt = tid / nin0, i = tid - pt * nin0;
+        const bool xlive = tid < DL_EB_PTS * nin0, xreal = xlive && i < o.n_x;
+        const DlInput xin = o.x_in[xreal ? i : 0];
+        double xlo[3], xinv[3];
+#pragma unroll
+        for (int ie = 0; ie < 3; ++ie) {
+            const DlObsDev::Engine& en = o.eng[ie];
+            xlo[ie] = en.type == 0 ? en.xlo[xreal ? i : 0] : 0.;
+            xinv[ie] = en.type == 0 ? en.xinv[xreal ? i : 0] : 0.;
+        }
+        const int vpt = tid / DL_N_VPARS, vc_ = tid - vpt * DL_N_VPARS;
+        const bool vlive = tid < DL_EB_PTS * DL_N_VPARS;
+        const DlInput vin = o.vp_in[vlive ? vc_ : 0];
+        trow[tid] = th_val;
+        __syncthreads();
+        if (xlive) {
+            const double tv = trow[pt * 32 + (xin.col >= 0 ? xin.col : 0)];
+            const double v = xreal ? (xin.col >= 0 ? tv : xin.value) : 0.;
+            if (xreal) x[pt * DL_MAX_X + i] = v;
+#pragma unroll
+            for (int ie = 0; ie < 3; ++ie)
+                if (o.eng[ie].type == 0) bufs[(size_t)ie * 2 * DL_EB_PTS * LD + pt * LD + i] = xreal ? (v - xlo[ie]) * xinv[ie] : 0.;
+        }
+        if (vlive) {
+            const double tv = trow[vpt * 32 + (vin.col >= 0 ? vin.col : 0)];
+            vpv[vpt * 12 + vc_] = vin.col >= 0 ? tv : vin.value;
+        }
+    } else {
     if (th_early) { trow[tid] = th_val; __syncthreads(); }
-    {
     for (int idx = tid; idx < DL_EB_PTS * nin0; idx += NTHR) {
         const int pt = idx / nin0, i = idx - pt * nin0;
         const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
@@ -490,6 +520,16 @@ static inline __host__ __device__ size_t dl_ef_gram_shared_doubles(const DlObsDe
 __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ gfrag, const DlObsDev o,
                                                                        const DlEfGramArgs ga) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    {   // Every 64-byte line of the kernel-argument segment (the descriptor `o` is 1.5 KB) is touched by one batch of scalar loads at entry: the fields are read
+        // where they are first needed -- engine after engine, layer after layer, then `ga` -- and each first touch of a line was a miss of the scalar cache in
+        // the middle of a dependent chain; now they are hits.
+        constexpr int n_lines = (int)((32 + sizeof(DlObsDev) + sizeof(DlEfGramArgs) + 63) / 64);
+        const __attribute__((address_space(4))) int* kargs = (const __attribute__((address_space(4))) int*)__builtin_amdgcn_kernarg_segment_ptr();
+        int touched = 0;
+#pragma unroll
+        for (int l = 0; l < n_lines; ++l) touched |= kargs[16 * l];
+        asm volatile("; kernel arguments touched: %0" :: "s"(touched));
+    }
     const int64_t p0 = (int64_t)blockIdx.x * DL_EB_PTS;
     const bool th_early = n_params <= 32;
     double th_val = 0.;
