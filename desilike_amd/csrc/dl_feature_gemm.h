@@ -262,23 +262,28 @@ __device__ __forceinline__ void dl_fg_gram_request(DlFgAhead<CNT>& ah, const dl_
 #pragma unroll
     for (int i = 0; i < CNT; ++i) ah.b1[i] = gw[(size_t)(q1 * DL_FG_NM + m0 + i) * 64];
 }
-template <int CNT>
+// D operand buffers, D - 1 steps in flight (the first two come from the request made ahead).  Two steps are enough while both waves of a SIMD stream MFMAs (each
+// advances at half speed); the LAST group of a wave often runs with its partner already finished, and alone, two steps ahead, a wave reached 60 % of the pipe's rate
+// (timeline of both waves: 104 cycles per MFMA instead of 64): the last groups run deeper (they hold no request for a next group: the registers are there).
+template <int CNT, int D = 3>
 __device__ __forceinline__ void dl_fg_gram_mainloop(const double* arow, const dl_fg_double2* __restrict__ gw, int nq, int m0, dl_fg_double4 (&acc)[CNT], const DlFgAhead<CNT>& ah) {
-    dl_fg_double2 b0[CNT], b1[CNT], b2[CNT];
-#define DL_FG_LOAD(b, qq) { const int q_ = (qq) < nq ? (qq) : nq - 1; _Pragma("unroll") for (int i = 0; i < CNT; ++i) b[i] = gw[(size_t)(q_ * DL_FG_NM + m0 + i) * 64]; }
-#define DL_FG_MUL(b, qq) { const dl_fg_double2 a_ = *reinterpret_cast<const dl_fg_double2*>(arow + 8 * (qq)); \
-        _Pragma("unroll") for (int i = 0; i < CNT; ++i) { acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.x, b[i].x, acc[i], 0, 0, 0); \
-                                                          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.y, b[i].y, acc[i], 0, 0, 0); } }
+    dl_fg_double2 b[D][CNT];
+#define DL_FG_LOAD(bb, qq) { const int q_ = (qq) < nq ? (qq) : nq - 1; _Pragma("unroll") for (int i = 0; i < CNT; ++i) bb[i] = gw[(size_t)(q_ * DL_FG_NM + m0 + i) * 64]; }
+#define DL_FG_MUL(bb, qq) { const dl_fg_double2 a_ = *reinterpret_cast<const dl_fg_double2*>(arow + 8 * (qq)); \
+        _Pragma("unroll") for (int i = 0; i < CNT; ++i) { acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.x, bb[i].x, acc[i], 0, 0, 0); \
+                                                          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.y, bb[i].y, acc[i], 0, 0, 0); } }
 #pragma unroll
-    for (int i = 0; i < CNT; ++i) { acc[i] = (dl_fg_double4){0., 0., 0., 0.}; b0[i] = ah.b0[i]; b1[i] = ah.b1[i]; }
+    for (int i = 0; i < CNT; ++i) { acc[i] = (dl_fg_double4){0., 0., 0., 0.}; b[0][i] = ah.b0[i]; b[1][i] = ah.b1[i]; }
+#pragma unroll
+    for (int d = 2; d < D - 1; ++d) DL_FG_LOAD(b[d], d)
     int q = 0;
-    for (; q + 3 <= nq; q += 3) {
-        DL_FG_LOAD(b2, q + 2) DL_FG_MUL(b0, q)
-        DL_FG_LOAD(b0, q + 3) DL_FG_MUL(b1, q + 1)
-        DL_FG_LOAD(b1, q + 4) DL_FG_MUL(b2, q + 2)
+    for (; q + D <= nq; q += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) { DL_FG_LOAD(b[(d + D - 1) % D], q + d + D - 1) DL_FG_MUL(b[d], q + d) }
     }
-    if (q < nq) { DL_FG_MUL(b0, q) }
-    if (q + 1 < nq) { DL_FG_MUL(b1, q + 1) }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (q + d < nq) { DL_FG_MUL(b[d], q + d) }
 #undef DL_FG_LOAD
 #undef DL_FG_MUL
 }
@@ -400,14 +405,14 @@ __device__ __forceinline__ void dl_fg_compute_gram(const double* lds, int stride
         { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 0, acc, a0); DL_FG_STAMP(2) dl_fg_gram_request<6>(a1, gw, nq, 8); dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g, cst); }
         DL_FG_STAMP(3)
         { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6>(arow, gw, nq, 8, acc, a1); dl_fg_gram_request<5>(a2, gw, nq, 14); DL_FG_CST dl_fg_gram_epilogue<6>(acc, lds, stride, nb_pad, R, 8, false, false, gr, cbase, g, cst); }
-        { dl_fg_double4 acc[5]; dl_fg_gram_mainloop<5>(arow, gw, nq, 14, acc, a2); DL_FG_STAMP(4) dl_fg_gram_epilogue<5>(acc, lds, stride, nb_pad, R, 14, false, true, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[5]; dl_fg_gram_mainloop<5, 5>(arow, gw, nq, 14, acc, a2); DL_FG_STAMP(4) dl_fg_gram_epilogue<5>(acc, lds, stride, nb_pad, R, 14, false, true, gr, cbase, g, cst); }
     } else {
         DlFgAhead<4> a0; DlFgAhead<8> a1; DlFgAhead<7> a2;
         dl_fg_gram_request<4>(a0, gw, nq, 0);
         after_request();
         { dl_fg_double4 acc[4]; dl_fg_gram_mainloop<4>(arow, gw, nq, 0, acc, a0); dl_fg_gram_request<8>(a1, gw, nq, 4); dl_fg_gram_epilogue<4>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g, cst); }
         { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 4, acc, a1); dl_fg_gram_request<7>(a2, gw, nq, 12); DL_FG_CST dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 4, false, false, gr, cbase, g, cst); }
-        { dl_fg_double4 acc[7]; dl_fg_gram_mainloop<7>(arow, gw, nq, 12, acc, a2); dl_fg_gram_epilogue<7>(acc, lds, stride, nb_pad, R, 12, false, true, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[7]; dl_fg_gram_mainloop<7, 4>(arow, gw, nq, 12, acc, a2); dl_fg_gram_epilogue<7>(acc, lds, stride, nb_pad, R, 12, false, true, gr, cbase, g, cst); }
     }
 #undef DL_FG_CST
     DL_FG_STAMP(5)
