@@ -809,7 +809,8 @@ __global__ void dl_host_flag_kernel(uint64_t* flag, uint64_t seq) {
 }
 
 // DL_HOST_MODE: 0 staged copies + stream synchronisation (the first version), 1 mapped buffers + stream synchronisation, 2 mapped + event polling,
-// 3 (default) mapped + completion flag (+ a stream query at the start of the next call), 4 the flag alone
+// 3 (default) mapped + completion flag (+ a stream query at the start of one call in eight), 4 the flag alone.  Tried and dropped (profiles/r04a_host_call_modes.txt):
+// a stream synchronisation after the flag (46 us median: the runtime's own wait path), polling hipStreamQuery (41 us, long tail)
 static int dl_host_mode() {
     const char* env = std::getenv("DL_HOST_MODE");
     return env ? std::atoi(env) : 3;
@@ -827,9 +828,10 @@ static int dl_eval_host_impl(dl_ctx* ctx, const double* theta, int64_t B, double
     hipStream_t stream = ctx->host_stream;
     const int P = ctx->n_params;
     int mode = dl_host_mode();
-    // the flag path never tells the runtime that a call has finished: without this query it retires ~1000 dispatches at once every ~250 calls (eight calls in a row
-    // 15 - 30 us slower); asked at the start of the next call, when the previous one is long finished, it retires them as it goes
-    if (mode == 3 && ctx->host_seq) (void)hipStreamQuery(stream);
+    // the flag path never tells the runtime that a call has finished: left alone it retires ~1000 dispatches at once every ~250 calls (eight calls in a row 15 - 30 us
+    // slower).  A stream query at the start of a call -- the previous one is long finished -- lets it retire them; a query costs ~6 us plus what it retires (one call
+    // in 32: those calls +20 us, p99 = 1.57 x median; every call: median +7 us): one call in 8 pays it (p99 / median, measured: profiles/r04*_host_call*)
+    if (mode == 3 && ctx->host_seq && (ctx->host_seq & 7) == 0) (void)hipStreamQuery(stream);
     double *flat_dev = nullptr, *solved_dev = nullptr;
     if (flattheory) DL_HIP_CHECK(ctx, hipMalloc((void**)&flat_dev, (size_t)B * ctx->n_data * sizeof(double)));
     if (solved && ctx->n_solved > 0) DL_HIP_CHECK(ctx, hipMalloc((void**)&solved_dev, (size_t)B * ctx->n_solved * sizeof(double)));
@@ -860,7 +862,8 @@ static int dl_eval_host_impl(dl_ctx* ctx, const double* theta, int64_t B, double
         } else if (mode == 2) {
             e = hipEventRecord(ctx->host_event, stream);
             while (e == hipSuccess && (e = hipEventQuery(ctx->host_event)) == hipErrorNotReady) e = hipSuccess;
-        } else {
+
+        } else {   // modes 3, 4
             const uint64_t seq = ++ctx->host_seq;
             dl_host_flag_kernel<<<1, 1, 0, stream>>>(ctx->host_flag_dev, seq);
             e = hipGetLastError();
@@ -873,6 +876,7 @@ static int dl_eval_host_impl(dl_ctx* ctx, const double* theta, int64_t B, double
                     break;
                 }
             }
+
         }
         if (e != hipSuccess) rc = dl_fail(ctx, std::string("dl_eval_batch_host: ") + hipGetErrorString(e));
     }
