@@ -179,6 +179,10 @@ class ObservablesGaussianLikelihood(BaseGaussianLikelihood):
         self.correct_covariance = correct_covariance
         sizes = [obs.wmatrix.size for obs in self.observables]
         size = sum(sizes)
+        if covariance is not None and not isinstance(covariance, np.ndarray):
+            from ..observables.galaxy_clustering import _containers
+            if _containers.is_matrix_container(covariance):   # an lsstypes-like CovarianceMatrix (duck-typed: .value(), .observable), likelihoods/base.py:594-603
+                covariance = _containers.read_covariance(covariance, self.observables)
         if covariance is None and precision is None:
             if all(getattr(obs, 'covariance', None) is not None for obs in self.observables):  # likelihoods/base.py:552-566
                 covariance = np.zeros((size, size), dtype='f8')

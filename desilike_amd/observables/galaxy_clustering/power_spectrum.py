@@ -3,6 +3,7 @@ import numpy as np
 
 from ...base import BaseCalculator
 from .window import WindowedPowerSpectrumMultipoles
+from . import _containers
 
 
 class TracerPowerSpectrumMultipolesObservable(BaseCalculator):
@@ -20,7 +21,8 @@ class TracerPowerSpectrumMultipolesObservable(BaseCalculator):
         Forwarded to :class:`WindowedPowerSpectrumMultipoles`.
     transform : str, default=None
         ``None`` or 'cubic' (power_spectrum.py:400-404).
-    Loading measurements from files / lsstypes objects is out of scope.
+    ``data`` may also be a measurement container or a list of mocks (duck-typed: ``.ells``, ``.get(ells=ell)`` -> ``.coords('k')``, ``.edges('k')``, ``.value()``;
+    see :mod:`._containers`): the binning, the shot noise and -- from several mocks -- the covariance default to theirs.
     """
     name = 'spectrum2poles'
 
@@ -40,6 +42,27 @@ class TracerPowerSpectrumMultipolesObservable(BaseCalculator):
             if wmatrix is not None:
                 self.wmatrix.init.update(wmatrix=wmatrix)
         self._require(self.wmatrix)
+        # measurements given as (lsstypes-like, duck-typed) containers: one object or a list of mocks (power_spectrum.py:123-233) -> flat data vector = their mean;
+        # binning and shot noise default to the containers' own
+        mocks = None
+        items = list(data) if isinstance(data, (list, tuple)) else [data]
+        if items and all(_containers.is_measurement(item) for item in items):
+            klim = init.get('klim', None)
+            read = [_containers.read_measurement(item, lim=klim if isinstance(klim, dict) else None, coord='k') for item in items]
+            ells, list_k, list_edges = read[0][0], read[0][1], read[0][2]
+            for other in read[1:]:
+                if other[0] != ells or not all(np.allclose(a, b, rtol=1e-3, atol=0.) for a, b in zip(other[1], list_k)):
+                    raise ValueError('the mocks do not share the multipoles / k-bins of the first one')
+            if init.get('k', None) is None and init.get('kedges', None) is None:
+                init['ells'] = ells
+                if all(edges is not None for edges in list_edges): init['kedges'] = list_edges
+                else: init['k'] = list_k
+                init.pop('klim', None)
+            if init.get('shotnoise', None) is None and read[0][4] is not None: init['shotnoise'] = float(np.mean([r[4] for r in read]))
+            mocks = np.array([np.concatenate(r[3]) for r in read])
+            data = mocks.mean(axis=0)
+            if len(read) > 1 and self.covariance is None:   # covariance from the mocks (power_spectrum.py:97-104)
+                self.covariance, self.nobs = np.cov(mocks, rowvar=False, ddof=1), len(read)
         self.wmatrix.init.update(init)
         self.wmatrix.initialize()
         for name in ['k', 'ells', 'kedges']:

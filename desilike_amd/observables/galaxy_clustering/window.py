@@ -11,6 +11,7 @@ import numpy as np
 from ...base import BaseCalculator
 from ... import utils
 from ...utils import window_matrix_bininteg  # noqa: F401
+from . import _containers
 from ._binning import MultipoleBins
 
 
@@ -174,8 +175,19 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
             rebin = utils.matrix_lininterp(self.kin, kin_given)                     # [len(kin), len(kin_given)], the same for every input multipole
             blocks = matrix_full.reshape(matrix_full.shape[0], len(self.ellsin), kin_given.size)
             self.matrix_full = np.einsum('oli,ki->olk', blocks, rebin).reshape(matrix_full.shape[0], -1)
+        elif _containers.is_matrix_container(wmatrix):   # window.py:337-352: an lsstypes-like WindowMatrix (duck-typed: .value(), .theory, .observable)
+            matrix_full, kin_given, self.ellsin = _containers.read_window(wmatrix, self.ells, self.k, ellsin=ellsin)
+            if kin is not None:   # rebinned along the input axis (window.py:347-349)
+                self.kin = np.ravel(np.asarray(kin, dtype='f8'))
+                rebin = utils.matrix_lininterp(self.kin, kin_given)
+                blocks = matrix_full.reshape(matrix_full.shape[0], len(self.ellsin), kin_given.size)
+                matrix_full = np.einsum('oli,ki->olk', blocks, rebin).reshape(matrix_full.shape[0], -1)
+            else:
+                self.kin = kin_given
+            self.matrix_full = matrix_full
         else:
-            raise NotImplementedError('lsstypes / pypower window objects are not read: pass a 2D array with kin and ellsin, or a file written by desilike_amd.io.save_window')
+            raise NotImplementedError('window matrix of type {}: pass a 2D array with kin and ellsin, a file written by desilike_amd.io.save_window, or an object with '
+                                      '.value(), .theory, .observable (desilike_amd/observables/galaxy_clustering/_containers.py)'.format(type(wmatrix).__name__))
         if fiber_collisions is not None:   # window.py:428-438: kernels folded into the matrix / offset
             self.theory.init.update(k=self.kin, ells=self.ellsin)
             fiber_collisions.init.update(k=self.kin, ells=self.ellsin, theory=self.theory)
