@@ -353,16 +353,40 @@ def cfg3_flop_counts(pt, n, n_solved, n_mono=19):
             'solve': 2 * n_solved**3 // 3 + 4 * n_solved**2}
 
 
+def host_call_leg(likelihood, sizes=(1, 16, 256, 1024), ncalls=500):
+    """The host-array entry point (``dl_eval_logposterior_host``: what the reference-side binding and an unmodified desilike sampler call, samplers/base.py:144-200,
+    samplers/emcee.py:69): NumPy arrays in, NumPy arrays out, one call per batch -- PCIe-inclusive by construction.  Median / p99 / mean time per call (host clock around
+    the ctypes call) of ``ncalls`` calls at each batch size, after 50 untimed ones; the results are checked against the device-resident path bit for bit."""
+    import torch
+    ctx = likelihood._get_posterior_context()[0]
+    theta_all = np.ascontiguousarray(sample_theta(likelihood, max(sizes), seed=77))
+    device = torch.device('cuda', ctx.device)
+    ref = torch.empty(max(sizes), dtype=torch.float64, device=device)
+    ctx.eval_logposterior(torch.as_tensor(theta_all, dtype=torch.float64, device=device).contiguous(), ref)
+    torch.cuda.synchronize(device)
+    ref = ref.cpu().numpy()
+    out = {}
+    for B in sizes:
+        theta = np.ascontiguousarray(theta_all[:B])
+        for _ in range(50): got = ctx.eval_logposterior_host(theta)[0]
+        assert np.array_equal(got, ref[:B], equal_nan=True), 'host-array entry point differs from the device-resident path'
+        t = np.empty(ncalls)
+        for i in range(ncalls):
+            t0 = time.perf_counter_ns()
+            ctx.eval_logposterior_host(theta)
+            t[i] = 1e-3 * (time.perf_counter_ns() - t0)
+        out[str(B)] = {'median_us': float(np.median(t)), 'p99_us': float(np.percentile(t, 99)), 'mean_us': float(t.mean()), 'evals_per_s': float(B / (1e-6 * t.mean()))}
+    return {'entry_point': 'dl_eval_logposterior_host (host pointers in / out; pinned, device-mapped staging read and written by the kernels themselves; completion flag)',
+            'calls_per_size': ncalls, 'includes': 'ctypes call, staging copy, PCIe reads / writes of the kernels, completion wait', 'per_batch_size': out}
+
+
 def other_configs(device, steps=40, warmup=5, ncheck=8):
     """BASELINE configs[2] (MLP-emulated tables + 5 analytically marginalised parameters, 4096 points) and configs[3] (damped-BAO xi_ell through the Hankel operator,
     8192 points) on this GPU: evaluations / s over ``steps`` calls on a resident batch, the dominant kernel's roofline fraction with the build's own FLOP count, and a
     post-hoc check of ``ncheck`` points against the NumPy oracle (the parity tests proper: tests/test_gpu_emulator.py, tests/test_gpu_bao.py)."""
     import gc
     import torch
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    from test_gpu_emulator import make_cfg3_full, cfg3_oracle_solution
-    from test_host_api import make_cfg4
-    from test_oracle_bao import bao_point
+    from bench_configs import make_cfg3_full, cfg3_oracle_solution, make_cfg4, bao_point
     from oracle import np_oracle as orc
     out = []
 
@@ -447,8 +471,7 @@ def other_configs(device, steps=40, warmup=5, ncheck=8):
 def _tns_config(device, steps, ncheck, orc):
     import gc
     import torch
-    from test_oracle_tns import load as load_tns, tns_oracle_point
-    from test_gpu_tns import spec_from_tns_golden
+    from bench_configs import load_tns, tns_oracle_point, spec_from_tns_golden
     from desilike_amd._lib import Context
     g = load_tns('tns')
     ctx = Context(spec_from_tns_golden(g), device=device.index or 0)
@@ -660,6 +683,7 @@ def main():
     parser.add_argument('--sustained-seconds', type=float, default=3., help='fixed-duration run of the same step after the timed region, reported as `sustained` (0: skip)')
     parser.add_argument('--no-other-configs', action='store_true', help='skip BASELINE configs[2] / configs[3] (`other_configs`)')
     parser.add_argument('--no-streams', action='store_true', help='skip the K-batches-in-flight measurement (`streams`)')
+    parser.add_argument('--no-host-call', action='store_true', help='skip the host-array entry point measurement (`host_call`)')
     parser.add_argument('--chains-iterations', type=int, default=300, help='ensemble updates per chain of the chain-parallel sampler measurement `chains_weak` (0: skip)')
     parser.add_argument('--dry-run', action='store_true', help='launcher check without a GPU: start the ranks, form the (gloo) group, exchange, print the line skeleton')
     parser.add_argument('--no-events', action='store_true', help='diagnostic: no HIP events attached to the kernels in the timed region')
@@ -796,6 +820,7 @@ def main():
 
     streams = guarded('streams', lambda: streams_leg(likelihood, device, B)) if (not args.no_streams and not distributed and B == BATCH) else None
     others = guarded('other_configs', lambda: other_configs(device)) if (not args.no_other_configs and rank == 0 and B == BATCH) else None
+    host_call = guarded('host_call', lambda: host_call_leg(likelihood)) if (rank == 0 and B == BATCH and not args.no_host_call) else None
     chains = chains_weak(group if (distributed and world > 1) else None, local_rank, rank, world, iterations=args.chains_iterations) if (args.chains_iterations > 0 and B == BATCH) else None
     mh = guarded('mh_chains', lambda: mh_chains(local_rank)) if (args.chains_iterations > 0 and rank == 0 and B == BATCH) else None
     strong = None
@@ -831,6 +856,7 @@ def main():
             sustained['agrees_with_value_within'] = abs(sustained['value'] / value - 1.)
             result['sustained'] = sustained
         if streams is not None: result['streams'] = streams
+        if host_call is not None: result['host_call'] = host_call
         if others is not None: result['other_configs'] = others
         if chains is not None: result['chains_weak'] = chains
         if mh is not None: result['mh_chains'] = mh

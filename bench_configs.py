@@ -1,0 +1,187 @@
+"""Likelihood builders and oracle evaluation helpers of the benchmarked configurations, shared by ``bench.py``, ``tests/`` and ``tools/`` (the benchmark no
+longer imports test modules).  Each builder constructs a BASELINE configuration with the host mirror's classes on the committed fixtures of ``tests/golden/``; the
+``*_point`` / ``*_solution`` helpers evaluate the same configuration with the NumPy oracle (checker's side: only ``tests/``, ``__graft_entry__.smoke()`` and the
+post-hoc asserts / ``cpu_baseline`` leg of ``bench.py`` call them)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for path in (ROOT, os.path.join(ROOT, 'tests')):
+    if path not in sys.path: sys.path.insert(0, path)
+
+from golden_utils import load_golden   # noqa: E402  (fixture reader: tests/golden_utils.py)
+
+here = os.path.join(ROOT, 'tests')
+
+
+def _orc():
+    from oracle import np_oracle
+    return np_oracle
+
+
+# ---- BASELINE configs[2] at the size SURVEY.md section 8d states ------------------------------------------------------------------------------------------
+def make_cfg3_full(marg=True, model='rept'):
+    """MLP in = 6 -> 4 x 64 silu -> 3 * 128 * 19 = 7296 outputs; 19-monomial combination; cubic interpolation to n_kin = 400; binning window 120 x 1200;
+    solved: alpha0p, alpha2p, alpha4p, sn0p, sn2p (n_s = 5) with their Gaussian priors (full_shape.py:1130-1133)."""
+    from desilike_amd.emulators import EmulatedCalculator, MLPEmulatorEngine
+    from desilike_amd.theories.galaxy_clustering import REPTVelocileptorsTracerPowerSpectrumMultipoles, LPTVelocileptorsTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    from emulator_utils import CFG3_PARAMS, CFG3_SPECS, cfg3_full_kpt, cfg3_full_engines
+    g = load_golden('cfg3_full')
+    engines = {}
+    for name, e in cfg3_full_engines().items():
+        engines[name] = MLPEmulatorEngine(xlimits=e['xlimits'], layers=e['layers'], activation='silu', ylimits=e['ylimits'], yshape=e['yshape'])
+    pt = EmulatedCalculator(CFG3_PARAMS, engines, k=cfg3_full_kpt(), ells=(0, 2, 4), z=0.8, param_specs=CFG3_SPECS)
+    cls = REPTVelocileptorsTracerPowerSpectrumMultipoles if model == 'rept' else LPTVelocileptorsTracerPowerSpectrumMultipoles
+    theory = cls(pt=pt, tracer='LRG')
+    solved = ['alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p'] if marg else []
+    for name in solved:
+        theory.init.params[name].update(derived='.marg')
+    obs = TracerPowerSpectrumMultipolesObservable(data=g['obs0']['flatdata'], kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=8e3)
+    rng = np.random.RandomState(int(g['cov_seed'][0]))
+    A = rng.standard_normal((120, 120)) * 40.
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + 4e4 * np.eye(120))
+    return g, like, pt, theory, solved
+
+
+def cfg3_oracle_solution(like, pt, theory, solved, row):
+    """The NumPy oracle's analytically marginalised solution of BASELINE configs[2] at one point ``row`` of the varied parameters: MLP tables -> velocileptors
+    combination -> cubic interpolation -> window (the chain pinned on the reference by tests/golden/cfg3_full.npz), derivative rows of the solved parameters from unit
+    vectors through the same chain (the theory is linear in them), then ``solve_marginalized`` (likelihoods/base.py:314-413).  Shared with bench.py's post-hoc check."""
+    orc = _orc()
+    from emulator_utils import CFG3_PARAMS
+    names = like.varied_params.names()
+    nsol = len(solved)
+    scales = np.array([like.all_params[name].prior.scale for name in solved])
+    wm = like.observables[0].wmatrix
+    eng = pt.engines
+
+    def flat(x):
+        p = dict(zip(names, row)); p.update(x)
+        xin = np.array([p[name] for name in CFG3_PARAMS])
+        pktable = orc.mlp_predict(xin, eng['pktable'].xlimits, eng['pktable'].layers, 'silu', eng['pktable'].ylimits).reshape(3, -1, 19)
+        sigma8 = orc.mlp_predict(xin, eng['sigma8'].xlimits, eng['sigma8'].layers, 'silu', eng['sigma8'].ylimits)[0]
+        fsigma8 = orc.mlp_predict(xin, eng['fsigma8'].xlimits, eng['fsigma8'].layers, 'silu', eng['fsigma8'].ylimits)[0]
+        params = {name: p.get(name, like.all_params[name].value) for name in ['b1p', 'b2p', 'bsp', 'b3p', 'alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p', 'sn4p']}
+        pars = orc.velocileptors_pars(params, sigma8, fsigma8 / sigma8, basis='physical', model='rept', snd=theory.snd, fsat=theory.fsat, sigv=theory.sigv)
+        power = orc.interp1d(theory.k, pt.k, orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=theory.nd).T).T
+        return orc.window_apply(power, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout)
+
+    f0 = flat({name: 0. for name in solved})
+    if not nsol:
+        return {'loglikelihood': orc.gaussian_loglikelihood(f0, like.flatdata, like.precision)[0]}
+    T = np.array([flat({n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
+    return orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=np.zeros(nsol), prior_scale=scales, marg_mask=np.ones(nsol, dtype='?'))
+
+
+def make_cfg2(dense=False, data=None):
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    g = load_golden('cfg2_shapefit_window' + ('_dense' if dense else ''))
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    theory = KaiserTracerPowerSpectrumMultipoles(template=template)
+    kw = dict(wmatrix=g['obs0']['matrix_full'], kin=g['obs0']['kin'], ellsin=(0, 2, 4)) if dense else dict(wmatrix={'resolution': 10})
+    obs = TracerPowerSpectrumMultipolesObservable(data=g['obs0']['flatdata'] if data is None else data, kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), theory=theory, shotnoise=1e4, **kw)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
+    return g, like
+
+
+def make_cfg4(space='xi', data=None):
+    from desilike_amd.theories.galaxy_clustering import BAOPowerSpectrumTemplate, DampedBAOWigglesTracerCorrelationFunctionMultipoles, DampedBAOWigglesTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable, TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    g = load_golden('cfg4_bao_' + space)
+    template = BAOPowerSpectrumTemplate(z=0.5)
+    data = g['obs0']['flatdata'] if data is None else data
+    if space == 'xi':
+        theory = DampedBAOWigglesTracerCorrelationFunctionMultipoles(template=template, mode='reciso')
+        obs = TracerCorrelationFunctionMultipolesObservable(data=data, s=np.linspace(22.5, 167.5, 30), ells=(0, 2), theory=theory)
+    else:
+        theory = DampedBAOWigglesTracerPowerSpectrumMultipoles(template=template)
+        obs = TracerPowerSpectrumMultipolesObservable(data=data, kedges=np.linspace(0.02, 0.3, 57), ells=(0, 2), wmatrix={'resolution': 3}, theory=theory)
+    for name in ['sigmapar', 'sigmaper']:
+        theory.init.params[name].update(fixed=False, ref=dict(dist='norm', loc=8., scale=0.5))
+    return g, ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
+
+
+def make_cfg5():
+    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    g = load_golden('cfg5_two_tracers')
+    template = ShapeFitPowerSpectrumTemplate(z=0.5)
+    observables = []
+    for iobs, (tracer, kmax) in enumerate([('LRG', 0.2), ('ELG', 0.15)]):
+        theory = KaiserTracerPowerSpectrumMultipoles(template=template, tracers=tracer)
+        nk = int(round(kmax / 0.005))
+        observables.append(TracerPowerSpectrumMultipolesObservable(data=g['obs{:d}'.format(iobs)]['flatdata'], kedges=np.linspace(0., kmax, nk + 1), ells=(0, 2, 4),
+                                                                   wmatrix={'resolution': 4}, theory=theory, shotnoise=1e4 if tracer == 'LRG' else 4e3))
+    return g, ObservablesGaussianLikelihood(observables=observables, covariance=g['covariance'])
+
+
+def bao_point(g, row):
+    orc = _orc()
+    c = g['obs0']
+    names = [str(n) for n in g['names']]
+    p = dict(zip(names, row))
+    f = p.get('dbeta', 1.) * c['f_fid'] * p.get('df', 1.)
+    power = orc.bao_damped_power(c['kin'], c['mu'], c['wmu_ell'], c['k11'], c['pk_dd_fid'], c['pknow_dd_fid'], f, qpar=p.get('qpar', 1.), qper=p.get('qper', 1.), b1=p['b1'],
+                                 sigmas=p.get('sigmas', 0.), sigmapar=p.get('sigmapar', 9.), sigmaper=p.get('sigmaper', 6.), mode=str(c['mode']), smoothing_radius=float(c['smoothing_radius']))
+    al = np.array([p.get(str(n), 0.) for n in c['broadband_params']])
+    return power, c['broadband_matrix'].dot(al)
+
+
+def load_tns(name):
+    return dict(np.load(os.path.join(here, 'golden', name + '.npz'), allow_pickle=True))
+
+
+def tns_oracle_point(g, row, kernels=None, return_all=False):
+    """Log-likelihood (and intermediates) of one theta row of a TNS fixture, by the oracle."""
+    oc = _orc()
+    names = list(g['names'])
+    p = dict(zip(names, row))
+    k, mu, wmu_ell, q = g['c.kin'], g['c.mu'], g['c.wmu_ell'], g['c.k11']
+    template = str(g['c.template'])
+    pk_q = g['c.pk_dd_fid'] * (oc.shapefit_factor(q, float(g['c.kp']), float(g['c.a']), dm=p.get('dm', 0.), dn=p.get('dn', 0.)) if 'ShapeFit' in template else 1.)
+    f = float(g['c.f_fid']) * p.get('df', 1.)
+    pt = oc.tns_pktable(k, mu, wmu_ell, q, pk_q, f, qpar=p.get('qpar', 1.), qper=p.get('qper', 1.), sigmav=p.get('sigmav', 0.), fog=str(g['fog']), kernels=kernels, k11=g['k11_table'])
+    nd = float(g['c.nd'])
+    power = oc.tns_tracer_power(pt, nd, b1=p['b1'], b2=p['b2'], bs=p.get('bs', 0.), b3=p.get('b3', 0.), sn0=p['sn0'])
+    if bool(g['eft']):
+        ells = list(g['c.ells'])
+        ctv = np.array([2. * p[str(name)] for name in g['c.ct_params']])   # summed over the two (identical) tracers
+        snv = np.array([p[str(name)] for name in g['c.sn_params']])
+        power = oc.eftlike_addon(power, ells, pt['pk11'], g['c.ct_matrix'], ctv, g['c.sn_matrix'], snv, nd)
+    flat = oc.window_apply(power, matrix_full=g['c.matrix_full'], shotnoisein=g['c.shotnoisein'], shotnoiseout=g['c.shotnoiseout'])
+    logl = oc.gaussian_loglikelihood(flat, g['c.flatdata'], g['precision'])[0]
+    if return_all: return logl, pt, power, flat, pk_q
+    return logl
+
+
+def spec_from_tns_golden(g):
+    from oracle import np_oracle as oc
+    names = [str(n) for n in g['names']]
+
+    def inp(name, default):
+        return (names.index(name), default) if name in names else (-1, default)
+
+    inputs = {'qpar': inp('qpar', 1.), 'qper': inp('qper', 1.), 'df': inp('df', 1.), 'dm': inp('dm', 0.), 'dn': inp('dn', 0.), 'b1X': inp('b1', 1.), 'b1Y': inp('b1', 1.), 'sn0': inp('sn0', 0.),
+              'b2': inp('b2', 0.), 'bs': inp('bs', 0.), 'b3': inp('b3', 0.), 'sigmav': inp('sigmav', 0.)}
+    mus, wmus = oc.weights_leggauss_sym(10)
+    obs = dict(theory=np.array([4]), template=np.array([1 if str(g['c.template']).startswith('ShapeFit') else 0]), apmode=np.array([0]), transform=np.array([0]), eta=[1. / 3.],
+               f_fid=[float(g['c.f_fid'])], a=[float(g['c.a']) if 'c.a' in g else 0.6], kp=[float(g['c.kp']) if 'c.kp' in g else 0.03], nd=[float(g['c.nd'])],
+               ells_in=np.asarray(g['c.ellsin'], dtype='i4'), kin=g['c.kin'], mu=g['c.mu'], wmu_ell=g['c.wmu_ell'], k_t=g['c.k11'], pk_dd_fid=g['c.pk_dd_fid'],
+               wmatrix=g['c.matrix_full'], kmask=None, offset=None, shotnoise_in=g['c.shotnoisein'], shotnoise_out=g['c.shotnoiseout'], flatdata=g['c.flatdata'],
+               tns_k11=g['k11_table'], tns_mu=mus, tns_wmu=wmus, tns_fog=np.array([{'lorentzian': 0, 'gaussian': 1}[str(g['fog'])]], dtype='i4'))
+    if bool(g['eft']):
+        obs['ct_matrix'], obs['sn_matrix'] = g['c.ct_matrix'], g['c.sn_matrix']
+        ct = [[inp(str(n), 0.)] * 2 for n in g['c.ct_params']]
+        sn = [inp(str(n), 0.) for n in g['c.sn_params']]
+        inputs['ct'] = ([[t[0] for t in row] for row in ct], [[t[1] for t in row] for row in ct])
+        inputs['sn'] = ([t[0] for t in sn], [t[1] for t in sn])
+    obs['inputs'] = inputs
+    return dict(n_params=np.array([len(names)]), priors=g['priors'], precision=g['precision'], observables=[obs])

@@ -8,6 +8,7 @@ from golden_utils import load_golden
 from test_host_api import make_cfg3
 from test_oracle_emulator import table_point
 from emulator_utils import taylor_state, EMU_PARAMS
+from bench_configs import make_cfg3_full, cfg3_oracle_solution   # noqa: E402,F401  (shared with bench.py / tools)
 
 pytestmark = pytest.mark.gpu
 
@@ -174,61 +175,6 @@ def test_taylor_emulator_fitted_on_the_gpu_theory():
 
 # north star: 1e-10 on logL -- also for the analytically marginalised value
 MARG_TOL = 1e-10
-
-
-# ---- BASELINE configs[2] at the size SURVEY.md section 8d states ------------------------------------------------------------------------------------------
-def make_cfg3_full(marg=True, model='rept'):
-    """MLP in = 6 -> 4 x 64 silu -> 3 * 128 * 19 = 7296 outputs; 19-monomial combination; cubic interpolation to n_kin = 400; binning window 120 x 1200;
-    solved: alpha0p, alpha2p, alpha4p, sn0p, sn2p (n_s = 5) with their Gaussian priors (full_shape.py:1130-1133)."""
-    from desilike_amd.emulators import EmulatedCalculator, MLPEmulatorEngine
-    from desilike_amd.theories.galaxy_clustering import REPTVelocileptorsTracerPowerSpectrumMultipoles, LPTVelocileptorsTracerPowerSpectrumMultipoles
-    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
-    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
-    from emulator_utils import CFG3_PARAMS, CFG3_SPECS, cfg3_full_kpt, cfg3_full_engines
-    g = load_golden('cfg3_full')
-    engines = {}
-    for name, e in cfg3_full_engines().items():
-        engines[name] = MLPEmulatorEngine(xlimits=e['xlimits'], layers=e['layers'], activation='silu', ylimits=e['ylimits'], yshape=e['yshape'])
-    pt = EmulatedCalculator(CFG3_PARAMS, engines, k=cfg3_full_kpt(), ells=(0, 2, 4), z=0.8, param_specs=CFG3_SPECS)
-    cls = REPTVelocileptorsTracerPowerSpectrumMultipoles if model == 'rept' else LPTVelocileptorsTracerPowerSpectrumMultipoles
-    theory = cls(pt=pt, tracer='LRG')
-    solved = ['alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p'] if marg else []
-    for name in solved:
-        theory.init.params[name].update(derived='.marg')
-    obs = TracerPowerSpectrumMultipolesObservable(data=g['obs0']['flatdata'], kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=8e3)
-    rng = np.random.RandomState(int(g['cov_seed'][0]))
-    A = rng.standard_normal((120, 120)) * 40.
-    like = ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + 4e4 * np.eye(120))
-    return g, like, pt, theory, solved
-
-
-def cfg3_oracle_solution(like, pt, theory, solved, row):
-    """The NumPy oracle's analytically marginalised solution of BASELINE configs[2] at one point ``row`` of the varied parameters: MLP tables -> velocileptors
-    combination -> cubic interpolation -> window (the chain pinned on the reference by tests/golden/cfg3_full.npz), derivative rows of the solved parameters from unit
-    vectors through the same chain (the theory is linear in them), then ``solve_marginalized`` (likelihoods/base.py:314-413).  Shared with bench.py's post-hoc check."""
-    from emulator_utils import CFG3_PARAMS
-    names = like.varied_params.names()
-    nsol = len(solved)
-    scales = np.array([like.all_params[name].prior.scale for name in solved])
-    wm = like.observables[0].wmatrix
-    eng = pt.engines
-
-    def flat(x):
-        p = dict(zip(names, row)); p.update(x)
-        xin = np.array([p[name] for name in CFG3_PARAMS])
-        pktable = orc.mlp_predict(xin, eng['pktable'].xlimits, eng['pktable'].layers, 'silu', eng['pktable'].ylimits).reshape(3, -1, 19)
-        sigma8 = orc.mlp_predict(xin, eng['sigma8'].xlimits, eng['sigma8'].layers, 'silu', eng['sigma8'].ylimits)[0]
-        fsigma8 = orc.mlp_predict(xin, eng['fsigma8'].xlimits, eng['fsigma8'].layers, 'silu', eng['fsigma8'].ylimits)[0]
-        params = {name: p.get(name, like.all_params[name].value) for name in ['b1p', 'b2p', 'bsp', 'b3p', 'alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p', 'sn4p']}
-        pars = orc.velocileptors_pars(params, sigma8, fsigma8 / sigma8, basis='physical', model='rept', snd=theory.snd, fsat=theory.fsat, sigv=theory.sigv)
-        power = orc.interp1d(theory.k, pt.k, orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=theory.nd).T).T
-        return orc.window_apply(power, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout)
-
-    f0 = flat({name: 0. for name in solved})
-    if not nsol:
-        return {'loglikelihood': orc.gaussian_loglikelihood(f0, like.flatdata, like.precision)[0]}
-    T = np.array([flat({n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
-    return orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=np.zeros(nsol), prior_scale=scales, marg_mask=np.ones(nsol, dtype='?'))
 
 
 def test_cfg3_full_size_vs_reference():

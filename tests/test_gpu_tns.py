@@ -5,33 +5,9 @@ import numpy as np
 import pytest
 
 from test_oracle_tns import load, tns_oracle_point, FIXTURES
+from bench_configs import spec_from_tns_golden   # noqa: E402,F401  (shared with bench.py / tools)
 
 pytestmark = pytest.mark.gpu
-
-
-def spec_from_tns_golden(g):
-    from oracle import np_oracle as oc
-    names = [str(n) for n in g['names']]
-
-    def inp(name, default):
-        return (names.index(name), default) if name in names else (-1, default)
-
-    inputs = {'qpar': inp('qpar', 1.), 'qper': inp('qper', 1.), 'df': inp('df', 1.), 'dm': inp('dm', 0.), 'dn': inp('dn', 0.), 'b1X': inp('b1', 1.), 'b1Y': inp('b1', 1.), 'sn0': inp('sn0', 0.),
-              'b2': inp('b2', 0.), 'bs': inp('bs', 0.), 'b3': inp('b3', 0.), 'sigmav': inp('sigmav', 0.)}
-    mus, wmus = oc.weights_leggauss_sym(10)
-    obs = dict(theory=np.array([4]), template=np.array([1 if str(g['c.template']).startswith('ShapeFit') else 0]), apmode=np.array([0]), transform=np.array([0]), eta=[1. / 3.],
-               f_fid=[float(g['c.f_fid'])], a=[float(g['c.a']) if 'c.a' in g else 0.6], kp=[float(g['c.kp']) if 'c.kp' in g else 0.03], nd=[float(g['c.nd'])],
-               ells_in=np.asarray(g['c.ellsin'], dtype='i4'), kin=g['c.kin'], mu=g['c.mu'], wmu_ell=g['c.wmu_ell'], k_t=g['c.k11'], pk_dd_fid=g['c.pk_dd_fid'],
-               wmatrix=g['c.matrix_full'], kmask=None, offset=None, shotnoise_in=g['c.shotnoisein'], shotnoise_out=g['c.shotnoiseout'], flatdata=g['c.flatdata'],
-               tns_k11=g['k11_table'], tns_mu=mus, tns_wmu=wmus, tns_fog=np.array([{'lorentzian': 0, 'gaussian': 1}[str(g['fog'])]], dtype='i4'))
-    if bool(g['eft']):
-        obs['ct_matrix'], obs['sn_matrix'] = g['c.ct_matrix'], g['c.sn_matrix']
-        ct = [[inp(str(n), 0.)] * 2 for n in g['c.ct_params']]
-        sn = [inp(str(n), 0.) for n in g['c.sn_params']]
-        inputs['ct'] = ([[t[0] for t in row] for row in ct], [[t[1] for t in row] for row in ct])
-        inputs['sn'] = ([t[0] for t in sn], [t[1] for t in sn])
-    obs['inputs'] = inputs
-    return dict(n_params=np.array([len(names)]), priors=g['priors'], precision=g['precision'], observables=[obs])
 
 
 @pytest.fixture(scope='module')

@@ -4,19 +4,7 @@ import numpy as np
 import pytest
 
 from golden_utils import load_golden, spec_from_golden
-
-
-def make_cfg2(dense=False, data=None):
-    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles
-    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
-    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
-    g = load_golden('cfg2_shapefit_window' + ('_dense' if dense else ''))
-    template = ShapeFitPowerSpectrumTemplate(z=0.5)
-    theory = KaiserTracerPowerSpectrumMultipoles(template=template)
-    kw = dict(wmatrix=g['obs0']['matrix_full'], kin=g['obs0']['kin'], ellsin=(0, 2, 4)) if dense else dict(wmatrix={'resolution': 10})
-    obs = TracerPowerSpectrumMultipolesObservable(data=g['obs0']['flatdata'] if data is None else data, kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), theory=theory, shotnoise=1e4, **kw)
-    like = ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
-    return g, like
+from bench_configs import make_cfg2, make_cfg4, make_cfg5   # noqa: E402,F401  (shared with bench.py / tools)
 
 
 @pytest.mark.parametrize('dense', [False, True])
@@ -78,21 +66,6 @@ def test_no_cpu_fallback():
         like(b1=2.)
 
 
-def make_cfg5():
-    from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles
-    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
-    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
-    g = load_golden('cfg5_two_tracers')
-    template = ShapeFitPowerSpectrumTemplate(z=0.5)
-    observables = []
-    for iobs, (tracer, kmax) in enumerate([('LRG', 0.2), ('ELG', 0.15)]):
-        theory = KaiserTracerPowerSpectrumMultipoles(template=template, tracers=tracer)
-        nk = int(round(kmax / 0.005))
-        observables.append(TracerPowerSpectrumMultipolesObservable(data=g['obs{:d}'.format(iobs)]['flatdata'], kedges=np.linspace(0., kmax, nk + 1), ells=(0, 2, 4),
-                                                                   wmatrix={'resolution': 4}, theory=theory, shotnoise=1e4 if tracer == 'LRG' else 4e3))
-    return g, ObservablesGaussianLikelihood(observables=observables, covariance=g['covariance'])
-
-
 def test_two_tracer_spec_matches_reference():
     g, like = make_cfg5()
     # same parameters as the reference (its pipeline happens to order the tracer blocks differently: only the set is compared)
@@ -106,24 +79,6 @@ def test_two_tracer_spec_matches_reference():
             assert np.allclose(np.ravel(o[key]), np.ravel(r[key]), rtol=1e-13, atol=1e-300), key
         for name, (col, const) in r['inputs'].items():
             if col >= 0: assert names[o['inputs'][name][0]] == rnames[col], name
-
-
-def make_cfg4(space='xi', data=None):
-    from desilike_amd.theories.galaxy_clustering import BAOPowerSpectrumTemplate, DampedBAOWigglesTracerCorrelationFunctionMultipoles, DampedBAOWigglesTracerPowerSpectrumMultipoles
-    from desilike_amd.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable, TracerPowerSpectrumMultipolesObservable
-    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
-    g = load_golden('cfg4_bao_' + space)
-    template = BAOPowerSpectrumTemplate(z=0.5)
-    data = g['obs0']['flatdata'] if data is None else data
-    if space == 'xi':
-        theory = DampedBAOWigglesTracerCorrelationFunctionMultipoles(template=template, mode='reciso')
-        obs = TracerCorrelationFunctionMultipolesObservable(data=data, s=np.linspace(22.5, 167.5, 30), ells=(0, 2), theory=theory)
-    else:
-        theory = DampedBAOWigglesTracerPowerSpectrumMultipoles(template=template)
-        obs = TracerPowerSpectrumMultipolesObservable(data=data, kedges=np.linspace(0.02, 0.3, 57), ells=(0, 2), wmatrix={'resolution': 3}, theory=theory)
-    for name in ['sigmapar', 'sigmaper']:
-        theory.init.params[name].update(fixed=False, ref=dict(dist='norm', loc=8., scale=0.5))
-    return g, ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
 
 
 @pytest.mark.parametrize('space', [pytest.param('xi', marks=pytest.mark.gpu), 'pk'])   # 'xi': the theory builds its Hankel operator with the device FFTLog

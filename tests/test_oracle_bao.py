@@ -5,17 +5,7 @@ import pytest
 
 from oracle import np_oracle as orc
 from golden_utils import load_golden, prior_list
-
-
-def bao_point(g, row):
-    c = g['obs0']
-    names = [str(n) for n in g['names']]
-    p = dict(zip(names, row))
-    f = p.get('dbeta', 1.) * c['f_fid'] * p.get('df', 1.)
-    power = orc.bao_damped_power(c['kin'], c['mu'], c['wmu_ell'], c['k11'], c['pk_dd_fid'], c['pknow_dd_fid'], f, qpar=p.get('qpar', 1.), qper=p.get('qper', 1.), b1=p['b1'],
-                                 sigmas=p.get('sigmas', 0.), sigmapar=p.get('sigmapar', 9.), sigmaper=p.get('sigmaper', 6.), mode=str(c['mode']), smoothing_radius=float(c['smoothing_radius']))
-    al = np.array([p.get(str(n), 0.) for n in c['broadband_params']])
-    return power, c['broadband_matrix'].dot(al)
+from bench_configs import bao_point   # noqa: E402,F401  (shared with bench.py)
 
 
 @pytest.mark.parametrize('space', ['xi', 'pk'])

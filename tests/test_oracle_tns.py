@@ -6,35 +6,10 @@ import numpy as np
 import pytest
 
 from oracle import np_oracle as oc
+from bench_configs import load_tns as load, tns_oracle_point   # noqa: E402,F401  (shared with bench.py / tools)
 
 here = os.path.dirname(os.path.abspath(__file__))
 FIXTURES = ['tns', 'tns_eft', 'tns_standard_gaussian']
-
-
-def load(name):
-    return dict(np.load(os.path.join(here, 'golden', name + '.npz'), allow_pickle=True))
-
-
-def tns_oracle_point(g, row, kernels=None, return_all=False):
-    """Log-likelihood (and intermediates) of one theta row of a TNS fixture, by the oracle."""
-    names = list(g['names'])
-    p = dict(zip(names, row))
-    k, mu, wmu_ell, q = g['c.kin'], g['c.mu'], g['c.wmu_ell'], g['c.k11']
-    template = str(g['c.template'])
-    pk_q = g['c.pk_dd_fid'] * (oc.shapefit_factor(q, float(g['c.kp']), float(g['c.a']), dm=p.get('dm', 0.), dn=p.get('dn', 0.)) if 'ShapeFit' in template else 1.)
-    f = float(g['c.f_fid']) * p.get('df', 1.)
-    pt = oc.tns_pktable(k, mu, wmu_ell, q, pk_q, f, qpar=p.get('qpar', 1.), qper=p.get('qper', 1.), sigmav=p.get('sigmav', 0.), fog=str(g['fog']), kernels=kernels, k11=g['k11_table'])
-    nd = float(g['c.nd'])
-    power = oc.tns_tracer_power(pt, nd, b1=p['b1'], b2=p['b2'], bs=p.get('bs', 0.), b3=p.get('b3', 0.), sn0=p['sn0'])
-    if bool(g['eft']):
-        ells = list(g['c.ells'])
-        ctv = np.array([2. * p[str(name)] for name in g['c.ct_params']])   # summed over the two (identical) tracers
-        snv = np.array([p[str(name)] for name in g['c.sn_params']])
-        power = oc.eftlike_addon(power, ells, pt['pk11'], g['c.ct_matrix'], ctv, g['c.sn_matrix'], snv, nd)
-    flat = oc.window_apply(power, matrix_full=g['c.matrix_full'], shotnoisein=g['c.shotnoisein'], shotnoiseout=g['c.shotnoiseout'])
-    logl = oc.gaussian_loglikelihood(flat, g['c.flatdata'], g['precision'])[0]
-    if return_all: return logl, pt, power, flat, pk_q
-    return logl
 
 
 def test_trapz_weights_and_table_grid():

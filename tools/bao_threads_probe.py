@@ -3,7 +3,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from time_configs import time_likelihood
-from test_host_api import make_cfg4
+from bench_configs import make_cfg4
 for space in ('xi', 'pk'):
     g, like = make_cfg4(space)
     for B in (32, 256, 1024, 2048, 4096, 8192, 32768):

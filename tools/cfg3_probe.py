@@ -3,6 +3,6 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 from time_configs import time_likelihood
-from test_gpu_emulator import make_cfg3_full
+from bench_configs import make_cfg3_full
 g, like, pt, theory, solved = make_cfg3_full(marg=True)
 time_likelihood('cfg3 (SURVEY 8d size): MLP tables + 5 marginalised parameters', like, 4096, steps=int(os.environ.get('STEPS', 40)))

@@ -2,7 +2,7 @@ import sys, time
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np
 from oracle import np_oracle as orc
-from test_host_api import make_cfg2
+from bench_configs import make_cfg2
 from desilike_amd.emulators import emulate_power
 g, like = make_cfg2(dense=False)
 names = like.varied_params.names()

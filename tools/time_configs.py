@@ -31,8 +31,9 @@ def time_likelihood(label, like, B, steps=40, posterior=False):
 
 
 def main():
-    from test_gpu_emulator import make_mlp_likelihood, make_cfg3_full
-    from test_host_api import make_cfg4
+    from test_gpu_emulator import make_mlp_likelihood
+    from bench_configs import make_cfg3_full
+    from bench_configs import make_cfg4
     # BASELINE configs[2] at the size SURVEY 8d states: in = 6, 4 x 64 silu, 3 * 128 * 19 outputs, n_kin = 400, W 120 x 1200, n_s = 5
     g, like, pt, theory, solved = make_cfg3_full(marg=True)
     time_likelihood('cfg3 (SURVEY 8d size): MLP tables + 5 marginalised parameters', like, 4096)
@@ -59,7 +60,7 @@ if __name__ == '__main__' and len(sys.argv) == 1:
 
 def small_batches():
     """config 5 shape: two tracers summed, half-ensembles of 256 walkers (32 per GPU at 8 GPUs): per-call latency matters, not throughput."""
-    from test_host_api import make_cfg5
+    from bench_configs import make_cfg5
     g, like = make_cfg5()
     for B in (32, 256, 1024):
         time_likelihood('cfg5: two-tracer sum (240 data points)', like, B, steps=200)

@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
-from test_host_api import make_cfg2   # noqa: E402
+from bench_configs import make_cfg2   # noqa: E402
 from desilike_amd.samplers import HMCSampler   # noqa: E402
 
 

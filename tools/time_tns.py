@@ -8,8 +8,8 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
-from test_oracle_tns import load   # noqa: E402
-from test_gpu_tns import spec_from_tns_golden   # noqa: E402
+from bench_configs import load_tns as load   # noqa: E402
+from bench_configs import spec_from_tns_golden   # noqa: E402
 from desilike_amd._lib import Context   # noqa: E402
 
 
