@@ -1183,58 +1183,80 @@ DL_HD void dl_emu_layer(int tid, const DlObsDev::Engine& e, int layer, const dou
 }
 
 // velocileptors 'pars' -> 19 monomials, and the monomials' derivatives w.r.t. analytically solved alpha* / sn* (full_shape.py:1182-1186, 1300-1307, 1577-1592, 1479-1488)
+// The arithmetic in three pieces, so that the fused forward pass (dl_emu_batch.h) can spread the writes of a point over lanes with the SAME operations in the same order:
+// 'pars' (full_shape.py:1300-1307, 1577-1592; co-evolution 1479-1488) ...
+struct DlVeloPre { double pars[DL_N_VPARS], one_b1L, f, sn_scale[3]; bool physical; };
+DL_HD void dl_velocileptors_prelude(const DlObsDev& o, const double* v, double sigma8, double fsigma8, DlVeloPre& p) {
+    p.one_b1L = 1.; p.f = 0.;
+    p.physical = (o.mono_mode == 1 || o.mono_mode == 2);
+    const bool rept = (o.mono_mode == 2 || o.mono_mode == 4);
+    p.sn_scale[0] = p.sn_scale[1] = p.sn_scale[2] = 1.;
+    if (p.physical) {
+        p.f = fsigma8 / sigma8;
+        double b1L = v[0] / sigma8 - 1., b2L = v[1] / (sigma8 * sigma8), bsL = v[2] / (sigma8 * sigma8), b3L = v[3] / (sigma8 * sigma8 * sigma8);
+        p.one_b1L = 1. + b1L;
+        if (rept) { p.pars[0] = 1. + b1L; p.pars[1] = 8. / 21. * b1L + b2L; p.pars[2] = bsL; p.pars[3] = b3L; }
+        else { p.pars[0] = b1L; p.pars[1] = b2L; p.pars[2] = bsL; p.pars[3] = b3L; }
+        p.pars[4] = p.one_b1L * p.one_b1L * v[4];
+        p.pars[5] = p.f * p.one_b1L * (v[4] + v[5]);
+        p.pars[6] = p.f * (p.f * v[5] + p.one_b1L * v[6]);
+        p.pars[7] = p.f * p.f * v[6];
+        p.sn_scale[0] = o.snd; p.sn_scale[1] = o.snd * o.fsat * (o.sigv * o.sigv); p.sn_scale[2] = o.snd * o.fsat * (o.sigv * o.sigv) * (o.sigv * o.sigv);
+        for (int i = 0; i < 3; ++i) p.pars[8 + i] = v[8 + i] * p.sn_scale[i];
+    } else {
+        for (int c = 0; c < DL_N_VPARS; ++c) p.pars[c] = v[c];
+    }
+    if (rept) {   // co-evolution part, full_shape.py:1481-1485
+        double b1 = p.pars[0];
+        p.pars[2] = p.pars[2] - (2. / 7.) * (b1 - 1.);
+        p.pars[3] = 3. * p.pars[3] + (b1 - 1.);
+    }
+}
+// ... the 19 bias monomials (full_shape.py:1182-1186; r0[19] = 0: the padding of a row of 20) ...
+DL_HD void dl_velocileptors_row0(const DlObsDev& o, const DlVeloPre& p, double* r0) {
+    const double b1 = p.pars[0], b2 = p.pars[1], bs = p.pars[2], b3 = p.pars[3];
+    r0[0] = 1.; r0[1] = b1; r0[2] = b1 * b1; r0[3] = b2; r0[4] = b1 * b2; r0[5] = b2 * b2; r0[6] = bs; r0[7] = b1 * bs; r0[8] = b2 * bs; r0[9] = bs * bs;
+    r0[10] = b3; r0[11] = b1 * b3; r0[12] = p.pars[4]; r0[13] = p.pars[5]; r0[14] = p.pars[6]; r0[15] = p.pars[7];
+    r0[16] = p.pars[8] / o.nd; r0[17] = p.pars[9] / o.nd; r0[18] = p.pars[10] / o.nd; r0[19] = 0.;
+}
+// ... and the non-zero entries of the derivative row of parameter c (4 .. 10): up to two (monomial, value) pairs, monomials ascending, -1: none
+DL_HD void dl_velocileptors_drow(const DlObsDev& o, const DlVeloPre& p, int c, int nz[2], double dv[2]) {
+    nz[0] = nz[1] = -1; dv[0] = dv[1] = 0.;
+    if (p.physical) {
+        if (c == 4) { nz[0] = 12; dv[0] = p.one_b1L * p.one_b1L; nz[1] = 13; dv[1] = p.f * p.one_b1L; }
+        else if (c == 5) { nz[0] = 13; dv[0] = p.f * p.one_b1L; nz[1] = 14; dv[1] = p.f * p.f; }
+        else if (c == 6) { nz[0] = 14; dv[0] = p.f * p.one_b1L; nz[1] = 15; dv[1] = p.f * p.f; }
+        else if (c >= 8) { nz[0] = 16 + (c - 8); dv[0] = (c == 8 ? p.sn_scale[0] : c == 9 ? p.sn_scale[1] : p.sn_scale[2]) / o.nd; }
+    } else {
+        if (c < 8) { nz[0] = 12 + (c - 4); dv[0] = 1.; }
+        else { nz[0] = 16 + (c - 8); dv[0] = 1. / o.nd; }
+    }
+}
+
 // ``ms``: row stride of ``mono`` (entries DL_N_MONO .. ms - 1 of every row are set to zero); ``vpre``: the eleven 'pars' inputs already fetched (else read from ``th``)
-// ``only_row`` >= 0: write that row alone (0: the monomials, r >= 1: the derivative row of slot r - 1) -- the rows of a point spread over several threads
+// ``only_row`` >= 0: write that row alone (0: the monomials, r >= 1: the derivative row of slot r - 1)
 DL_HD void dl_velocileptors_monomials(const DlObsDev& o, const double* th, double sigma8, double fsigma8, double* mono, int ms = DL_N_MONO, const double* vpre = nullptr,
                                       int only_row = -1) {
     double v[DL_N_VPARS];
     for (int c = 0; c < DL_N_VPARS; ++c) v[c] = vpre != nullptr ? vpre[c] : dl_get(o.vp_in[c], th);
-    double pars[DL_N_VPARS];
-    double one_b1L = 1., f = 0.;
-    const bool physical = (o.mono_mode == 1 || o.mono_mode == 2), rept = (o.mono_mode == 2 || o.mono_mode == 4);
-    double sn_scale[3] = {1., 1., 1.};
-    if (physical) {
-        f = fsigma8 / sigma8;
-        double b1L = v[0] / sigma8 - 1., b2L = v[1] / (sigma8 * sigma8), bsL = v[2] / (sigma8 * sigma8), b3L = v[3] / (sigma8 * sigma8 * sigma8);
-        one_b1L = 1. + b1L;
-        if (rept) { pars[0] = 1. + b1L; pars[1] = 8. / 21. * b1L + b2L; pars[2] = bsL; pars[3] = b3L; }
-        else { pars[0] = b1L; pars[1] = b2L; pars[2] = bsL; pars[3] = b3L; }
-        pars[4] = one_b1L * one_b1L * v[4];
-        pars[5] = f * one_b1L * (v[4] + v[5]);
-        pars[6] = f * (f * v[5] + one_b1L * v[6]);
-        pars[7] = f * f * v[6];
-        sn_scale[0] = o.snd; sn_scale[1] = o.snd * o.fsat * (o.sigv * o.sigv); sn_scale[2] = o.snd * o.fsat * (o.sigv * o.sigv) * (o.sigv * o.sigv);
-        for (int i = 0; i < 3; ++i) pars[8 + i] = v[8 + i] * sn_scale[i];
-    } else {
-        for (int c = 0; c < DL_N_VPARS; ++c) pars[c] = v[c];
-    }
-    if (rept) {   // co-evolution part, full_shape.py:1481-1485
-        double b1 = pars[0];
-        pars[2] = pars[2] - (2. / 7.) * (b1 - 1.);
-        pars[3] = 3. * pars[3] + (b1 - 1.);
-    }
-    const double b1 = pars[0], b2 = pars[1], bs = pars[2], b3 = pars[3];
+    DlVeloPre p;
+    dl_velocileptors_prelude(o, v, sigma8, fsigma8, p);
     if (only_row <= 0) {
-        double* m0 = mono;
-        m0[0] = 1.; m0[1] = b1; m0[2] = b1 * b1; m0[3] = b2; m0[4] = b1 * b2; m0[5] = b2 * b2; m0[6] = bs; m0[7] = b1 * bs; m0[8] = b2 * bs; m0[9] = bs * bs;
-        m0[10] = b3; m0[11] = b1 * b3; m0[12] = pars[4]; m0[13] = pars[5]; m0[14] = pars[6]; m0[15] = pars[7];
-        m0[16] = pars[8] / o.nd; m0[17] = pars[9] / o.nd; m0[18] = pars[10] / o.nd;
-        for (int m = DL_N_MONO; m < ms; ++m) m0[m] = 0.;
+        double r0[20];
+        dl_velocileptors_row0(o, p, r0);
+        for (int m = 0; m < DL_N_MONO; ++m) mono[m] = r0[m];
+        for (int m = DL_N_MONO; m < ms; ++m) mono[m] = 0.;
     }
     for (int c = 4; c < DL_N_VPARS; ++c) {
         int slot = o.vp_slot[c];
         if (slot < 0 || (only_row >= 0 && only_row != 1 + slot)) continue;
         double* d = mono + (size_t)(1 + slot) * ms;
         for (int m = 0; m < ms; ++m) d[m] = 0.;
-        if (physical) {
-            if (c == 4) { d[12] = one_b1L * one_b1L; d[13] = f * one_b1L; }
-            else if (c == 5) { d[13] = f * one_b1L; d[14] = f * f; }
-            else if (c == 6) { d[14] = f * one_b1L; d[15] = f * f; }
-            else if (c >= 8) d[16 + (c - 8)] = sn_scale[c - 8] / o.nd;
-        } else {
-            if (c < 8) d[12 + (c - 4)] = 1.;
-            else d[16 + (c - 8)] = 1. / o.nd;
-        }
+        int nz[2];
+        double dv[2];
+        dl_velocileptors_drow(o, p, c, nz, dv);
+        if (nz[0] >= 0) d[nz[0]] = dv[0];
+        if (nz[1] >= 0) d[nz[1]] = dv[1];
     }
 }
 
