@@ -349,7 +349,9 @@ def cfg3_flop_counts(pt, n, n_solved, n_mono=19):
     forward = sum(2 * k.shape[0] * k.shape[1] + 25 * k.shape[1] for k, b in hidden)                   # MACs + one silu (exp, division ~ 25) per unit
     forward += sum(2 * k.shape[0] * k.shape[1] + 25 * k.shape[1] for name in ['sigma8', 'fsigma8'] for k, b in pt.engines[name].layers)
     n_basis = hidden[-1][0].shape[1] + 1
-    return {'forward': forward, 'folded_operator': 2 * n_mono * n * n_basis, 'monomial_rows': 2 * n_mono * n * (1 + n_solved), 'gram': (1 + n_solved) * (2 + n_solved) * n,
+    # monomial rows: the residual row contracts all n_mono monomials; the derivative row of a solved alpha* / sn* has at most two non-zero monomials (round 4: the
+    # kernel multiplies only those, so the dense count 2 n_mono n (1 + n_solved) of round 3 would credit work that is no longer done)
+    return {'forward': forward, 'folded_operator': 2 * n_mono * n * n_basis, 'monomial_rows': 2 * n * (n_mono + 2 * n_solved), 'gram': (1 + n_solved) * (2 + n_solved) * n,
             'solve': 2 * n_solved**3 // 3 + 4 * n_solved**2}
 
 
