@@ -206,11 +206,16 @@ class HMCSampler(BasePosteriorSampler):
         lp, grad = self._value_and_grad(q)
         if not bool(torch.isfinite(lp).all()): raise ValueError('the log-posterior of a starting position is not finite')
         if not self._adapted:
-            q, lp, grad = self._warmup(q, lp, grad)
-            if self.chain_group is not None:      # every rank adapted on its own chains: take the mean step size and mass matrix
-                packed = np.concatenate([[self.step_size], np.asarray(self.inverse_mass_matrix).ravel()])
-                packed = np.asarray(self.chain_group.allgather(packed)).reshape(self.chain_world, -1).mean(axis=0)
-                self.step_size, self.inverse_mass_matrix = float(packed[0]), packed[1:].reshape(np.asarray(self.inverse_mass_matrix).shape)
+            # a rank without chains (fewer chains than ranks) has nothing to adapt on: it would average NaNs into everybody's step size
+            if len(local): q, lp, grad = self._warmup(q, lp, grad)
+            if self.chain_group is not None:      # every rank adapted on its own chains: mean step size and mass matrix, weighted by the number of chains of the rank
+                shape = np.asarray(self.inverse_mass_matrix).shape
+                packed = np.concatenate([[float(len(local))], [self.step_size if len(local) else 0.], np.asarray(self.inverse_mass_matrix, dtype='f8').ravel() if len(local) else np.zeros(int(np.prod(shape)))])
+                packed = np.asarray(self.chain_group.allgather(packed)).reshape(self.chain_world, -1)
+                weights = packed[:, 0] / packed[:, 0].sum()
+                mean = (weights[:, None] * packed[:, 1:]).sum(axis=0)
+                self.step_size, self.inverse_mass_matrix = float(mean[0]), mean[1:].reshape(shape)
+                self._adapted = True
         minv, chol = self._mass(device)
         nrec = niterations // thin_by
         coords = torch.empty((nrec, len(local), q.shape[1]), dtype=torch.float64, device=device)

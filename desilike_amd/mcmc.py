@@ -525,6 +525,8 @@ class MCMCSampler(BasePosteriorSampler):
             self._handed = False
 
     def _run_batch(self, ntries, thin_by=1):
+        if ntries <= 0:   # (max_iterations reached exactly at a resume: nothing to do -- and the gathered block keeps its record count in row 0, the state in row ntries)
+            return
         runner = self._get_runner()
         self._prepare()
         local = self.local_chains()
