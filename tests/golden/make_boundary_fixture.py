@@ -196,6 +196,14 @@ def emulated_fixtures():
         obs = TracerPowerSpectrumMultipolesObservable(data=data, kedges=np.linspace(0.02, 0.2, 37), ells=(0, 2, 4), wmatrix={'resolution': 2}, theory=theory, shotnoise=8e3)
         return ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
 
+    def cfg3_taylor_marg(marg):
+        like = cfg3_taylor('physical')
+        if marg:
+            theory = like.observables[0].wmatrix.theory
+            for name in ['alpha0p', 'alpha2p', 'sn0p']: theory.init.params[name].update(derived='.marg')
+        return like
+
+    dump('cfg3_taylor_marg', lambda: cfg3_taylor_marg(True), size=24, seed=29, unsolved=lambda: cfg3_taylor_marg(False))
     dump('cfg3_taylor', lambda: cfg3_taylor('physical'), size=24, seed=29)
     dump('cfg3_taylor_standard', lambda: cfg3_taylor('standard'), size=24, seed=39)
 
@@ -270,6 +278,13 @@ def main():
         return ObservablesGaussianLikelihood(observables=observables, covariance=covariance(210, 22))
 
     dump('two_tracers_marg', lambda: two_tracers(True), size=24, seed=24, unsolved=lambda: two_tracers(False))
+
+    def two_tracers_mixed():   # LRG.sn0 marginalised, ELG.sn0 at its best fit ('.best': likelihoods/base.py:336-404 -- no determinant for it)
+        like = two_tracers(True)
+        like.observables[1].wmatrix.theory.init.params['ELG.sn0'].update(derived='.best')
+        return like
+
+    dump('two_tracers_mixed', two_tracers_mixed, size=24, seed=24, unsolved=lambda: two_tracers(False))
     # (8) BASELINE configs[2]: emulated perturbation-theory node
     emulated_fixtures()
 

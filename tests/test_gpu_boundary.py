@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(ROOT, 'integration'))
 
 FIXTURES = ['cfg2_dense', 'two_tracers', 'eft_qisoqap', 'cfg4_xi', 'cfg4_pk', 'kaiser_xi', 'tns', 'tns_eft', 'png', 'turnover', 'bands', 'png_velocity', 'cfg3', 'cfg3_taylor', 'cfg3_taylor_standard']     # cfg4_*: BASELINE configs[3] (damped BAO); *_xi: the reference's own get_corr as a folded operator; tns*: the reference's one-loop TNS theory (tests/golden/make_tns_fixture.py)
-MARG_FIXTURES = ['cfg4_xi_marg', 'two_tracers_marg', 'cfg3_marg']                                     # analytically solved parameters ('.marg'); cfg3*: BASELINE configs[2], the reference's
+MARG_FIXTURES = ['cfg4_xi_marg', 'two_tracers_marg', 'cfg3_marg', 'two_tracers_mixed', 'cfg3_taylor_marg']                                     # analytically solved parameters ('.marg'); cfg3*: BASELINE configs[2], the reference's
 # velocileptors tracer on a real EmulatedCalculator node (MLP 6 -> 4 x 64 -> 7296 / Taylor engines) built by the reference's own Emulator.to_calculator
 
 
@@ -67,7 +67,8 @@ def test_marginalised_context_from_reference_side_keys(name):
     for i in np.flatnonzero(inside):
         c, grad, H = g['marg_c'][i], g['marg_g'][i], g['marg_H'][i]
         dx = -np.linalg.solve(H, grad)
-        ref = c + 0.5 * grad.dot(dx) - 0.5 * np.linalg.slogdet(-H)[1]
+        marg = np.asarray(cfg['marg.kind']).astype(bool)           # '.marg' parameters contribute their determinant, '.best' ones do not (likelihoods/base.py:394-404)
+        ref = c + 0.5 * grad.dot(dx) - (0.5 * np.linalg.slogdet(-H[np.ix_(marg, marg)])[1] if marg.any() else 0.)
         got = loglike[i] + logprior[i]
         assert abs(got - ref) <= 1e-10 * max(1., abs(ref)), (i, got, ref)
         assert np.allclose(solved[i], g['marg_x0'] + dx, rtol=1e-7, atol=1e-9 * np.abs(g['marg_x0'] + dx).max())
