@@ -834,7 +834,10 @@ static int dl_eval_host_impl(dl_ctx* ctx, const double* theta, int64_t B, double
     if (mode == 3 && ctx->host_seq && (ctx->host_seq & 7) == 0) (void)hipStreamQuery(stream);
     double *flat_dev = nullptr, *solved_dev = nullptr;
     if (flattheory) DL_HIP_CHECK(ctx, hipMalloc((void**)&flat_dev, (size_t)B * ctx->n_data * sizeof(double)));
-    if (solved && ctx->n_solved > 0) DL_HIP_CHECK(ctx, hipMalloc((void**)&solved_dev, (size_t)B * ctx->n_solved * sizeof(double)));
+    if (solved && ctx->n_solved > 0 && hipMalloc((void**)&solved_dev, (size_t)B * ctx->n_solved * sizeof(double)) != hipSuccess) {
+        if (flat_dev) (void)hipFree(flat_dev);
+        return dl_fail(ctx, "dl_eval_batch_host: allocation of the solved-parameter block failed");
+    }
     if (flat_dev || solved_dev) mode = 0;
     double* host_in = ctx->host_stage;
     double* host_out = ctx->host_stage + (size_t)ctx->stage_cap * P;
@@ -844,8 +847,12 @@ static int dl_eval_host_impl(dl_ctx* ctx, const double* theta, int64_t B, double
     // theta: read in place from the mapped buffer by every kernel that needs it -- up to 4096 points; above, each of those reads crosses PCIe again and one
     // asynchronous copy to device memory is cheaper (8192 points: 178 -> 173 us, 32768: 590 -> 540 us; 1024: 45 against 59 us the other way)
     const bool theta_mapped = mode != 0 && B <= 4096;
-    if (!theta_mapped) DL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->theta_stage, host_in, (size_t)B * P * sizeof(double), hipMemcpyHostToDevice, stream));
-    else theta_dev = ctx->host_stage_dev;
+    if (theta_mapped) theta_dev = ctx->host_stage_dev;
+    else if (hipMemcpyAsync(ctx->theta_stage, host_in, (size_t)B * P * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) {
+        if (flat_dev) (void)hipFree(flat_dev);
+        if (solved_dev) (void)hipFree(solved_dev);
+        return dl_fail(ctx, "dl_eval_batch_host: copy of the parameter block failed");
+    }
     if (mode != 0) out_dev = ctx->host_stage_dev + (size_t)ctx->stage_cap * P;
     double* ll_dev = out_dev;
     double* lp_dev = out_dev + B;

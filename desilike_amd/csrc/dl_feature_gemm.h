@@ -247,7 +247,7 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
 // ---- Gram variant, round 4: monomial groups of compile-time size, the two waves of a SIMD on DIFFERENT schedules -----------------------------------------------
 // In-kernel stamps (config 3): the main loops run at the matrix pipe's rate (two waves per SIMD), but both waves of a SIMD reached their epilogues -- LDS reads and
 // fp64 FMAs, no MFMA -- at the same time, twice: 7 us of a 48 us workgroup life with the matrix pipe idle, and the barrier before the Gram phase waited for the
-// slower partner.  Waves 0-3 now take the monomials in groups of (10, 9), waves 4-7 (their SIMD partners) in groups of (6, 10, 3): an epilogue of one meets a main
+// slower partner.  Waves 0-3 now take the monomials in groups of (8, 6, 5), waves 4-7 (their SIMD partners) in groups of (4, 8, 7): an epilogue of one meets a main
 // loop of the other.  Every output still sums its monomials in the order 0..18 from zero (partial sums wait in X between groups): results are bit-identical.
 // The operand registers rotate by unrolling the k loop three times (two steps in flight) instead of being copied (80 moves per step).
 // the first two k-steps of a group's operand, requested AHEAD of its main loop (during the previous group's epilogue; for the first group before the barrier that
