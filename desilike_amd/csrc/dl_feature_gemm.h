@@ -59,13 +59,9 @@ __device__ __forceinline__ void dl_fg_gram_phase(const DlFgGram* gr, int wave, i
         dl_fg_double4 acc0 = {0., 0., 0., 0.};
 #pragma unroll
         for (int k = 0; k < 32; ++k) { const double x0 = live ? xv[k] : 0.; acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc0, 0, 0, 0); }
-        // every entry of the two 16 x 16 slots is written (the buffer is a shared workspace): zeros outside the 8 x 8 block, then the block
+        // only the 8 x 8 block of a point's 16 x 16 slot is written: the finalize kernels read entries [i][j], i, j <= n_s, and nothing else (zero-filling the rest
+        // of the shared workspace was 6 MB of stores per 4096 points)
         const int64_t pa = p0 + 2 * wave;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int idx = lane + 64 * q, pt2 = idx >> 8, pos = idx & 255;
-            if (((pos >> 4) >= 8 || (pos & 15) >= 8) && pa + pt2 < B) gr->gram[(size_t)(pa + pt2) * 256 + pos] = 0.;
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {   // C layout: G[(l >> 4) + 4 r][l & 15]
             const int i = g + 4 * r;

@@ -1439,6 +1439,164 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
     }
 }
 
+// ---- the same finalize when the Gram matrix G [B, 16, 16] of X = [dt; Tt_1 .. Tt_ns] is already there (feature GEMM of the emulated path): ONE LANE PER POINT ----
+// The solve of a point is a few hundred flops on an (ns x ns) system.  The lane-parallel kernel above gives it 16 lanes and pays a cross-lane exchange per
+// elimination step on one dependent chain (10.6 us per 4096 points of config 3, 1024 workgroups for 150 kFLOP); here a lane keeps the lower triangle of its point
+// in registers (NS is a compile-time size: no indexing at run time, no scratch) and runs Cholesky, the two substitutions and the quadratic forms serially --
+// no LDS, no barrier, no cross-lane traffic; 64 points per wavefront.  Same formulas (likelihoods/base.py:129-200, 314-413), sums in index order.
+// Partially marginalised sets (n_marg < ns): rows / columns of the parameters that are only solved become unit vectors in the second factorisation
+// (the determinant of the marginalised block is unchanged) instead of being compacted away.
+// 1 / sqrt(d), d > 0 normal: v_rsq_f64 (about 26 bits) and two Newton steps -- a dozen instructions on the pivot chain instead of a square root and a division
+__device__ __forceinline__ double dl_rsqrt_pos(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double h = 0.5 * y, e = fma(-d * y, h, 0.5);
+        y = fma(y, e, y);
+    }
+    return y;
+}
+
+template <int NS>
+__global__ __launch_bounds__(128) void dl_finalize_marg_gram_kernel(const double* __restrict__ gram, DlMargDev mg, const double* __restrict__ theta, int n_params,
+                                                                     const double* __restrict__ priors, int64_t B, double* __restrict__ loglike, double* __restrict__ logprior,
+                                                                     int32_t* __restrict__ status, double* __restrict__ solved, double* __restrict__ hessian, int post_mode) {
+    const int lane = threadIdx.x & 63;
+    const bool prior_wave = threadIdx.x >= 64;   // wave 1: the priors of the same 64 points, beside the solve (a quarter of the instructions of a point)
+    __shared__ double lp_lds[64];
+    __shared__ int nan_lds[64];
+    int64_t b = (int64_t)blockIdx.x * 64 + lane;
+    if (post_mode & 0x100) {
+        // G of points 16 t .. 16 t + 15 was written by workgroup t of the feature GEMM, on XCD t % 8: workgroup w = xcd + 8 r reads tiles xcd + 8 (4 r + j), j = lane / 16
+        const int64_t w = blockIdx.x, xcd = w & 7, r = w >> 3;
+        b = 16 * (xcd + 8 * (4 * r + (lane >> 4))) + (lane & 15);
+    }
+    post_mode &= 0xff;
+    const bool active = b < B;
+    if (!active) b = B - 1;
+    const double* G = gram + (size_t)b * 256;
+    const double inf = __builtin_huge_val();
+    if (prior_wave) {
+        double lp = 0.;
+        int nan_in = 0;
+        for (int p0 = 0; p0 < n_params; p0 += 4) {
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = p0 + u < n_params ? theta[(size_t)b * n_params + p0 + u] : 0.;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (p0 + u < n_params) {
+                    if (x[u] != x[u]) nan_in = 1;
+                    lp += dl_prior_logpdf(priors + 5 * (p0 + u), x[u]);
+                }
+        }
+        lp_lds[lane] = lp; nan_lds[lane] = nan_in;
+        __syncthreads();
+        return;
+    }
+    // every load of the lane first: lower triangle of G
+    double H[NS][NS], gd[NS];
+    const double g00 = G[0];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        gd[s] = G[1 + s];
+#pragma unroll
+        for (int t = 0; t <= s; ++t) H[s][t] = G[(1 + s) * 16 + 1 + t];
+    }
+    // A = -H = Tt Tt^T + diag(prec) (SPD); rhs = g = -(Tt dt) - (x0 - loc) prec; dx = A^-1 g
+    double C[NS][NS], inv[NS], dx[NS];
+    bool ok = true;
+    // log det = log of the product of the pivots: mantissas and exponents apart (the product of NS <= 8 mantissas in [1/2, 1) cannot underflow), ONE logarithm
+    double mant_all = 1.;
+    int exp_all = 0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        double d = H[j][j] + mg.prec[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= C[j][k] * C[j][k];
+        if (!(d > 0.) || d == inf) { ok = false; d = 1.; }
+        mant_all *= __builtin_amdgcn_frexp_mant(d); exp_all += __builtin_amdgcn_frexp_exp(d);
+        inv[j] = dl_rsqrt_pos(d);
+        C[j][j] = d * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < NS; ++i) {
+            double sum = H[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sum -= C[i][k] * C[j][k];
+            C[i][j] = sum * inv[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {   // forward, backward substitution
+        double sum = -gd[i] - (mg.x0[i] - mg.loc[i]) * mg.prec[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) sum -= C[i][k] * dx[k];
+        dx[i] = sum * inv[i];
+    }
+#pragma unroll
+    for (int i = NS - 1; i >= 0; --i) {
+        double sum = dx[i];
+#pragma unroll
+        for (int k = i + 1; k < NS; ++k) sum -= C[k][i] * dx[k];
+        dx[i] = sum * inv[i];
+    }
+    // 1/2 dx H_L dx + g_L dx  (likelihoods/base.py:385-386), H_L = -Tt Tt^T, g_L = -Tt dt
+    double quad = 0., lin = 0., lps = 0.;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double rowsum = 0.;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) rowsum += (s >= t ? H[s][t] : H[t][s]) * dx[t];
+        quad += dx[s] * rowsum;
+        lin += gd[s] * dx[s];
+        const double xs = mg.x0[s] + dx[s];
+        lps += -0.5 * (xs - mg.loc[s]) * (xs - mg.loc[s]) * mg.prec[s];   // 363-364 with parameter.py:2007 (0 for flat priors: prec = 0)
+        if (active && solved) solved[(size_t)b * NS + s] = xs;
+        if (active && hessian) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t) hessian[((size_t)b * NS + s) * NS + t] = -(s >= t ? H[s][t] : H[t][s]);
+        }
+    }
+    double ll = -0.5 * g00 - 0.5 * quad - lin;
+    // -1/2 logdet(-H[marg, marg]) (394-404); all-marg: the factorisation above
+    if (mg.n_marg == NS) ll -= 0.5 * (log(mant_all) + (double)exp_all * 0.693147180559945309417);
+    else if (mg.n_marg > 0) {
+        double S[NS][NS], mant2 = 1.;
+        int exp2 = 0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const bool mj = mg.is_marg[j] != 0;
+            double d = mj ? H[j][j] + mg.prec[j] : 1.;
+#pragma unroll
+            for (int k = 0; k < j; ++k) d -= S[j][k] * S[j][k];
+            if (!(d > 0.) || d == inf) { ok = false; d = 1.; }
+            mant2 *= __builtin_amdgcn_frexp_mant(d); exp2 += __builtin_amdgcn_frexp_exp(d);
+            const double invj = dl_rsqrt_pos(d);
+#pragma unroll
+            for (int i = j + 1; i < NS; ++i) {
+                double sum = (mj && mg.is_marg[i] != 0) ? H[i][j] : 0.;
+#pragma unroll
+                for (int k = 0; k < j; ++k) sum -= S[i][k] * S[j][k];
+                S[i][j] = sum * invj;
+            }
+        }
+        ll -= 0.5 * (log(mant2) + (double)exp2 * 0.693147180559945309417);
+    }
+    __syncthreads();   // the priors of the other wave
+    const double lp = lp_lds[lane];
+    const bool nan_in = nan_lds[lane] != 0;
+    if (active) {
+        const double lptot = lp + lps;
+        int st = DL_ST_OK;
+        if (nan_in) st = DL_ST_NAN_INPUT;
+        else if (lp == -inf) st = DL_ST_OUT_OF_PRIOR;
+        else if (!ok || !(ll == ll) || ll == inf || ll == -inf) st = DL_ST_NONFINITE;
+        if (loglike) loglike[b] = post_mode ? (st == DL_ST_OK ? ll + lptot : -inf) : ll;
+        if (logprior) logprior[b] = lptot;
+        if (status) status[b] = st;
+    }
+}
+
 void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride, const double* bias, const DlMargDev& mg,
                              const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior, int32_t* status, double* solved,
                              double* hessian, int post_mode, hipStream_t stream, bool xcd_tile16, const double* gram) {
@@ -1454,6 +1612,23 @@ void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_p
     static const bool allow_staged = !getenv("DL_FM_NO_STAGE");   // DL_FM_NO_STAGE=1: operands of the Gram product straight from global memory (comparison)
     const size_t region = std::max<size_t>((size_t)(1 + mg.n_s) * (((n + 3) & ~3) + 4), 512);
     const size_t shm = 4 * region * sizeof(double);   // staged rows of the four waves (reused for G and the Cholesky rows)
+    const bool lane_solve = !getenv("DL_FM_NO_LANE_SOLVE");   // DL_FM_NO_LANE_SOLVE=1: the 16-lanes-per-point kernel also with a ready Gram matrix (read at every launch: the tests compare both in one process)
+    if (gram != nullptr && lane_solve && mg.n_s >= 1 && mg.n_s <= 8) {
+        const unsigned grid64 = (unsigned)((B + 63) / 64);
+        const int mode = (xcd_local && xcd_tile16 && B % 512 == 0) ? ((post_mode & 0xff) | 0x100) : (post_mode & 0xff);
+        auto launch = [&](auto kernel) { DL_LAUNCH(kernel, dim3(grid64), dim3(128), 0, stream, gram, mg, theta, n_params, priors, B, loglike, logprior, status, solved, hessian, mode); };
+        switch (mg.n_s) {
+            case 1: launch(dl_finalize_marg_gram_kernel<1>); break;
+            case 2: launch(dl_finalize_marg_gram_kernel<2>); break;
+            case 3: launch(dl_finalize_marg_gram_kernel<3>); break;
+            case 4: launch(dl_finalize_marg_gram_kernel<4>); break;
+            case 5: launch(dl_finalize_marg_gram_kernel<5>); break;
+            case 6: launch(dl_finalize_marg_gram_kernel<6>); break;
+            case 7: launch(dl_finalize_marg_gram_kernel<7>); break;
+            default: launch(dl_finalize_marg_gram_kernel<8>); break;
+        }
+        return;
+    }
     if (gram != nullptr) {   // (needs n_s < 16: checked by the caller)
         DL_LAUNCH((dl_finalize_marg_kernel<true, false>), dim3(grid), dim3(256), 0, stream, dtilde, ld, n, rows_per_point, n_slabs, slab_stride, bias, mg, theta,
                            n_params, priors, B, loglike, logprior, status, solved, hessian, post_mode, stamps, gram);

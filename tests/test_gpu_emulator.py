@@ -24,7 +24,7 @@ def test_taylor_emulated_velocileptors_vs_reference():
     assert np.allclose(like.flattheory, g['flattheory'][:3], rtol=1e-11, atol=1e-8)
 
 
-def make_mlp_likelihood(marg=True, seed=1):
+def make_mlp_likelihood(marg=True, seed=1, derived=None):
     from desilike_amd.emulators import EmulatedCalculator, MLPEmulatorEngine
     from desilike_amd.theories.galaxy_clustering import LPTVelocileptorsTracerPowerSpectrumMultipoles
     from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
@@ -56,8 +56,9 @@ def make_mlp_likelihood(marg=True, seed=1):
     pt = EmulatedCalculator(EMU_PARAMS, engines, k=kpt, ells=(0, 2, 4), z=0.8, param_specs=specs)
     theory = LPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, tracer='ELG')
     solved = ['alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p'] if marg else []
+    if derived is not None: solved = list(derived)
     for name in solved:
-        theory.init.params[name].update(derived='.marg')
+        theory.init.params[name].update(derived='.marg' if derived is None else derived[name])
     theory.init.params['sn4p'].update(fixed=True, value=0.3)
     obs = TracerPowerSpectrumMultipolesObservable(data=g['obs0']['flatdata'], kedges=np.linspace(0.02, 0.2, 37), ells=(0, 2, 4), wmatrix={'resolution': 2}, theory=theory, shotnoise=8e3)
     like = ObservablesGaussianLikelihood(observables=[obs], covariance=g['covariance'])
@@ -171,6 +172,46 @@ def test_taylor_emulator_fitted_on_the_gpu_theory():
         assert abs(ll[0] - ref[0]) <= 1e-9 * max(1., abs(ref[0]))                 # the centre is reproduced
         errors[order] = np.abs(ll[1:] - ref[1:]).max()
     assert errors[4] < 0.05 * errors[2] and errors[4] < 1e-3 * np.abs(ref).max(), errors
+
+
+def test_gram_finalize_one_lane_per_point():
+    """The finalize of the fused emulator path (`dl_finalize_marg_gram_kernel`: one lane per point on the Gram matrix the feature GEMM leaves) against the 16-lanes-per-point
+    kernel of the same library (DL_FM_NO_LANE_SOLVE=1) and against the oracle: all solved parameters marginalised, a mix of '.best' and '.marg' (the marginalised
+    sub-block's determinant), a single '.best'; ragged batch."""
+    import os
+    cases = [None,
+             {'alpha0p': '.marg', 'alpha2p': '.best', 'alpha4p': '.marg', 'sn0p': '.best'},
+             {'sn0p': '.best'},
+             {'alpha0p': '.best', 'alpha2p': '.best', 'alpha4p': '.marg', 'sn0p': '.marg', 'sn2p': '.marg'}]
+    for derived in cases:
+        g, like, pt, theory, solved = make_mlp_likelihood(marg=True, derived=derived)
+        assert like.solved_params.names() == solved
+        names = like.varied_params.names()
+        rng = np.random.RandomState(21)
+        theta = np.column_stack([np.clip(param.ref.sample(size=1000 + 7, random_state=rng), *param.prior.limits) for param in like.varied_params])
+        theta[5, 0] = np.nan                                   # status codes travel through the same kernel
+        theta[6, 1] = like.varied_params[names[1]].prior.limits[1] + 1.
+        ctx = like._get_context()
+        fast = ctx.eval_batch_host(theta, return_solved=True)
+        os.environ['DL_FM_NO_LANE_SOLVE'] = '1'
+        try:
+            wide = ctx.eval_batch_host(theta, return_solved=True)
+        finally:
+            del os.environ['DL_FM_NO_LANE_SOLVE']
+        assert np.array_equal(fast[2], wide[2]) and fast[2][5] != 0 and fast[2][6] != 0 and (np.delete(fast[2], [5, 6]) == 0).all()
+        good = fast[2] == 0
+        assert (np.abs(fast[0][good] - wide[0][good]) <= 1e-12 * np.maximum(1., np.abs(wide[0][good]))).all(), np.abs(fast[0][good] - wide[0][good]).max()
+        assert np.allclose(fast[1][good], wide[1][good], rtol=1e-12, atol=1e-12)
+        assert np.allclose(fast[3][good], wide[3][good], rtol=1e-9, atol=1e-11)
+        nsol = len(solved)
+        scales = np.array([like.all_params[name].prior.scale for name in solved])
+        mask = np.array([derived is None or derived[name] == '.marg' for name in solved])
+        for i in (0, 17, 500, 1006):
+            f0 = oracle_flat(like, pt, theory, theta[i], names, {name: 0. for name in solved})
+            T = np.array([oracle_flat(like, pt, theory, theta[i], names, {n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
+            sol = orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=np.zeros(nsol), prior_scale=scales, marg_mask=mask)
+            assert abs(fast[0][i] - sol['loglikelihood']) <= 1e-10 * max(1., abs(sol['loglikelihood'])), (derived, i, fast[0][i], sol['loglikelihood'])
+            assert np.allclose(fast[3][i], sol['x'], rtol=1e-7, atol=1e-9)
 
 
 # north star: 1e-10 on logL -- also for the analytically marginalised value
