@@ -552,11 +552,15 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         }
         // plain likelihood: chi2 is additive over the columns of the whitened residual -> column-split GEMM that emits partial chi2 only
         // marginalised fits on one emulated observable: Gram-matrix epilogue in the fused kernel -- the residual rows never reach memory (DL_NO_GRAM_EPILOGUE=1: rows + Gram in the finalize)
-        bool gram_done = false;
+        bool gram_done = false, finalized_in_kernel = false;
         static const bool gram_epilogue = !getenv("DL_NO_GRAM_EPILOGUE");
         if (feat_path && emu_fused && gram_epilogue && ctx->n_obs == 1 && ctx->n_solved > 0 && ctx->N_pad == 128) {
-            gram_done = dl_launch_emulated_feature_gram(ctx->obs_kernarg[0], th, P, nb, ctx->gfrag_dev[0], ctx->bias_white_dev, ctx->marg, ctx->n_white, ctx->delta_ws, stream);
+            DlGramFinalize fin = {ctx->priors_dev, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr,
+                                  solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr, hessian_dev ? hessian_dev + (size_t)b0 * ctx->n_solved * ctx->n_solved : nullptr,
+                                  post_mode, false};
+            gram_done = dl_launch_emulated_feature_gram(ctx->obs_kernarg[0], th, P, nb, ctx->gfrag_dev[0], ctx->bias_white_dev, ctx->marg, ctx->n_white, ctx->delta_ws, stream, &fin);
             if (gram_done) fin_bias = ctx->bias_white_dev;
+            finalized_in_kernel = gram_done && fin.done;
         }
         if (feat_path && !gram_done) {
             for (int i = 0; i < ctx->n_obs; ++i) {
@@ -602,6 +606,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         prof_phase(2);
         if (chi2_path && chi2_fused) {
             // finalize fused into the GEMM
+        } else if (finalized_in_kernel) {
+            // marginalised finalize in the tail of the fused emulator / feature-GEMM kernel
         } else if (chi2_path || chi2_big)
             dl_launch_finalize_part(ctx->delta_ws, part_tiles, th, P, ctx->priors_dev, nb, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
                                     status_dev ? status_dev + b0 : nullptr, post_mode, stream);

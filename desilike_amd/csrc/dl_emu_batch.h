@@ -7,6 +7,7 @@
 #pragma once
 #include "dl_fullshape.h"
 #include "dl_feature_gemm.h"
+#include "dl_marg_solve.h"
 
 typedef double dl_eb_double4 __attribute__((ext_vector_type(4)));
 
@@ -509,6 +510,17 @@ struct DlEfGramArgs {
     unsigned long long* stamps;        // DL_EF_STAMPS diagnostics
     int nz[6][2];                      // support of the derivative rows (dl_velocileptors_row_support)
 };
+// The marginalised finalize in the tail of the same kernel (n_s <= 7): the Gram blocks of the workgroup's 16 points stay in LDS, lanes 0-15 of wave 0 solve a point
+// each (dl_marg_solve.h) while lanes 0-15 of wave 1 sum the priors of the same points; the other waves have left.  Against a separate launch (4.3 us, of which a
+// wave lives 1.3 us, plus the stream-order gap before it): no Gram matrix through memory, one kernel boundary less per step.
+struct DlEfSolve {
+    int enabled, post_mode;
+    const double* priors;
+    double *loglike, *logprior;
+    int32_t* status;
+    double *solved, *hessian;
+    DlMargDev mg;
+};
 // LDS: the 16 records | union(forward workspace, X rows): the workspace is dead once the records are written
 static inline __host__ __device__ size_t dl_ef_gram_rec_doubles(const DlObsDev& o) { return ((size_t)DL_FG_PTS * dl_fg_lds_stride(o.nb_pad + (1 + o.n_var) * DL_FG_MONO_LD) + 1) / 2 * 2; }
 static inline __host__ __device__ size_t dl_ef_gram_shared_doubles(const DlObsDev& o, int xr) {
@@ -517,13 +529,19 @@ static inline __host__ __device__ size_t dl_ef_gram_shared_doubles(const DlObsDe
 }
 // (theta, n_params, B first: they arrive in SGPRs with the wave (kernel-argument preload), and the theta rows of the 16 points are requested before the first access to
 //  the descriptor `o` -- that access is a round trip to the kernel-argument segment which the theta loads used to wait for: two round trips in a row at entry)
+template <int NS>
+__device__ __forceinline__ void dl_ef_solve_point(const double* gl, const DlEfSolve& sv, int64_t b, double& ll, double& lps, bool& ok) {
+    ll = dl_marg_solve_lane<NS>([&](int i, int j) { return gl[i * 8 + j]; }, sv.mg, sv.solved ? sv.solved + (size_t)b * NS : nullptr,
+                                sv.hessian ? sv.hessian + (size_t)b * NS * NS : nullptr, lps, ok);
+}
+
 __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ gfrag, const DlObsDev o,
-                                                                       const DlEfGramArgs ga) {
+                                                                       const DlEfGramArgs ga, const DlEfSolve sv) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     {   // Every 64-byte line of the kernel-argument segment (the descriptor `o` is 1.5 KB) is touched by one batch of scalar loads at entry: the fields are read
         // where they are first needed -- engine after engine, layer after layer, then `ga` -- and each first touch of a line was a miss of the scalar cache in
         // the middle of a dependent chain; now they are hits.
-        constexpr int n_lines = (int)((32 + sizeof(DlObsDev) + sizeof(DlEfGramArgs) + 63) / 64);
+        constexpr int n_lines = (int)((32 + sizeof(DlObsDev) + sizeof(DlEfGramArgs) + sizeof(DlEfSolve) + 63) / 64);
         const __attribute__((address_space(4))) int* kargs = (const __attribute__((address_space(4))) int*)__builtin_amdgcn_kernarg_segment_ptr();
         int touched = 0;
 #pragma unroll
@@ -538,15 +556,22 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const dou
         const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
         th_val = theta[(size_t)b * n_params + (j < n_params ? j : 0)];
     }
+    // fused finalize: the parameter rows and the prior table stay in LDS for the tail (requested here with the rest of the entry loads, stored after the forward pass)
+    const bool keep = sv.enabled && th_early;
+    __shared__ double keep_theta[DL_FG_PTS * 32], keep_pr[32 * 5], prior_term[DL_FG_PTS][33], lp_lds[DL_FG_PTS];
+    __shared__ int nan_lds[DL_FG_PTS];
+    double pr_val = 0.;
+    if (keep && (int)threadIdx.x < 5 * n_params) pr_val = sv.priors[threadIdx.x];
     const int R = 1 + o.n_var;
     const int stride = dl_fg_lds_stride(o.nb_pad + R * DL_FG_MONO_LD);
     double* rec = lds;
     double* work = lds + dl_ef_gram_rec_doubles(o);
     if (ga.stamps != nullptr && threadIdx.x == 0) { ga.stamps[(size_t)blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memtime(); ga.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime(); }
     dl_eb_forward_fused<512>(o, theta, n_params, B, p0, work, rec, stride, ga.stamps != nullptr ? ga.stamps + (size_t)blockIdx.x * 16 : nullptr, th_early, th_val);
+    if (keep) { keep_theta[threadIdx.x] = th_val; if ((int)threadIdx.x < 5 * n_params) keep_pr[threadIdx.x] = pr_val; }   // (visible after the barriers of the feature GEMM)
     DlFgGram gr;
     gr.x = work;
-    gr.xr = ga.xr; gr.gram = ga.gram; gr.stamps = ga.stamps;
+    gr.xr = ga.xr; gr.gram = sv.enabled ? nullptr : ga.gram; gr.stamps = ga.stamps;
 #pragma unroll
     for (int r = 0; r < 6; ++r) { gr.nz[r][0] = ga.nz[r][0]; gr.nz[r][1] = ga.nz[r][1]; }
 #pragma unroll
@@ -565,6 +590,49 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const dou
             }
     };
     dl_fg_compute_gram(rec, stride, o.nb_pad, R, gfrag, B, p0, &gr, after_request);
+    if (sv.enabled) {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const int64_t b = p0 + (lane & 15);
+        if (wave == 1) {
+            // priors of the 16 points, BEFORE the barrier (beside whatever the slower waves still do): one (point, parameter) term per lane and round from LDS, then lanes
+            // 0-15 sum the terms of their point in parameter order -- the sum of dl_marg_priors_lane bit for bit
+            const int pt = lane & 15;
+            if (keep) {
+                for (int p = lane >> 4; p < n_params; p += 4) prior_term[pt][p] = dl_prior_logpdf(keep_pr + 5 * p, keep_theta[pt * 32 + p]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < DL_FG_PTS) {
+                    double lp = 0.;
+                    int nan_in = 0;
+                    for (int p = 0; p < n_params; ++p) { const double x = keep_theta[pt * 32 + p]; if (x != x) nan_in = 1; lp += prior_term[pt][p]; }
+                    lp_lds[lane] = lp; nan_lds[lane] = nan_in;
+                }
+            } else if (lane < DL_FG_PTS) {
+                double lp;
+                int nan_in;
+                dl_marg_priors_lane(theta + (size_t)(b < B ? b : B - 1) * n_params, n_params, sv.priors, lp, nan_in);
+                lp_lds[lane] = lp; nan_lds[lane] = nan_in;
+            }
+        }
+        __syncthreads();   // the Gram blocks of the 16 points and their priors are in LDS
+        if (wave >= 1) return;
+        if (lane < DL_FG_PTS && b < B) {
+            double ll = 0., lps = 0.;
+            bool ok = true;
+            const double* gl = gr.x + (size_t)lane * gr.xr * DL_FG_XLD;
+            switch (sv.mg.n_s) {
+                case 1: dl_ef_solve_point<1>(gl, sv, b, ll, lps, ok); break;
+                case 2: dl_ef_solve_point<2>(gl, sv, b, ll, lps, ok); break;
+                case 3: dl_ef_solve_point<3>(gl, sv, b, ll, lps, ok); break;
+                case 4: dl_ef_solve_point<4>(gl, sv, b, ll, lps, ok); break;
+                case 5: dl_ef_solve_point<5>(gl, sv, b, ll, lps, ok); break;
+                case 6: dl_ef_solve_point<6>(gl, sv, b, ll, lps, ok); break;
+                default: dl_ef_solve_point<7>(gl, sv, b, ll, lps, ok); break;
+            }
+            dl_marg_store_lane(ll, lps, ok, lp_lds[lane], nan_lds[lane] != 0, sv.post_mode, b, sv.loglike, sv.logprior, sv.status);
+        }
+    }
     if (ga.stamps != nullptr && threadIdx.x == 0) ga.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime();   // (100 MHz, chip-wide: calibrates the shader clock)
 }
 #endif

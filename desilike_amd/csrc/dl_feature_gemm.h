@@ -38,7 +38,7 @@ struct DlFgGram {
     int xr;                    // rows of X = 1 + n_s
     int row_of[6];             // X row of device row r (0: residual; r >= 1: 1 + solved index of the parameter whose derivative row r is)
     const double* cst[6];      // constant part added to device row r: bias, or tconst of that solved parameter ([128] each)
-    double* gram;              // [B, 256]
+    double* gram;              // [B, 256]; null: the 8 x 8 block of point pt goes to LDS instead, x + pt xr DL_FG_XLD + 8 i + j (the solve follows in the same kernel)
     unsigned long long* stamps;   // DL_EF_STAMPS diagnostics (null in production): 16 x s_memtime per workgroup
     int nz[6][2];              // monomials the derivative row r >= 1 touches (dl_velocileptors_row_support), -1: none
 };
@@ -62,6 +62,17 @@ __device__ __forceinline__ void dl_fg_gram_phase(const DlFgGram* gr, int wave, i
         // only the 8 x 8 block of a point's 16 x 16 slot is written: the finalize kernels read entries [i][j], i, j <= n_s, and nothing else (zero-filling the rest
         // of the shared workspace was 6 MB of stores per 4096 points)
         const int64_t pa = p0 + 2 * wave;
+        if (gr->gram == nullptr) {
+            // over the X rows of the wave's own two points: every operand read of this wave precedes these writes (LDS operations of a wave execute in order), no
+            // other wave reads these rows
+            double* gl = gr->x + (size_t)(2 * wave + pp) * gr->xr * DL_FG_XLD;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = g + 4 * r;
+                if ((i >> 3) == pp) gl[(i & 7) * 8 + row] = acc0[r];
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {   // C layout: G[(l >> 4) + 4 r][l & 15]
             const int i = g + 4 * r;

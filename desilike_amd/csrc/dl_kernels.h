@@ -75,8 +75,17 @@ void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_
                                 hipStream_t stream);
 // ... with the Gram-matrix epilogue: gram [B, 16, 16] = Gram matrix of [residual + bias; derivative rows + tconst] per point instead of the rows themselves (one observable,
 // N_pad = 128).  Returns false (nothing launched) when the rows of 16 points do not fit the LDS next to the forward pass.
+// fin != nullptr and n_s <= 7: the marginalised finalize runs in the tail of the same kernel (outputs of DlGramFinalize; *fin->done = true), nothing is written to `gram`.
+struct DlGramFinalize {
+    const double* priors;
+    double *loglike, *logprior;   // [B] or null
+    int32_t* status;              // [B] or null
+    double *solved, *hessian;     // [B, n_s], [B, n_s, n_s] or null
+    int post_mode;
+    bool done;
+};
 bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, const double* bias, const DlMargDev& mg, int n_valid,
-                                     double* gram, hipStream_t stream);
+                                     double* gram, hipStream_t stream, DlGramFinalize* fin = nullptr);
 // Fisher algebra (dl_fisher.hip): stencil rows of theta, then per centre the Gram matrix of [residual; derivative rows]
 void dl_launch_fisher_stencil(const double* centers, const double* steps, int P, int64_t B, double* theta, hipStream_t stream);
 int dl_fisher_waves(int n, int P, size_t* shm_bytes, int* chunk);   // centres per workgroup and columns staged at a time (0: no chunk fits the LDS)

@@ -18,6 +18,7 @@
 #include "dl_tns.h"
 #include "dl_emu_batch.h"
 #include "dl_finalize_part.h"
+#include "dl_marg_solve.h"
 #include "dl_scalar_prefetch.h"
 #include "dl_ens_fold.h"
 #include "dl_fullshape_grad.h"
@@ -859,7 +860,7 @@ void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_
 }
 
 bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, const double* bias, const DlMargDev& mg, int n_valid,
-                                     double* gram, hipStream_t stream) {
+                                     double* gram, hipStream_t stream, DlGramFinalize* fin) {
     const int R = 1 + obs.n_var;
     if (R > 6 || mg.n_s < 1 || mg.n_s > 15 || n_valid > 128) return false;
     DlEfGramArgs ga;
@@ -880,7 +881,7 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
         if (slot >= 0 && 1 + slot < 6) dl_velocileptors_row_support(obs, c, ga.nz[1 + slot]);
     }
     const size_t shm = dl_ef_gram_shared_doubles(obs, ga.xr) * sizeof(double);
-    if (shm > 156 * 1024) return false;
+    if (shm > 146 * 1024) return false;   // (the kernel also holds 10 KB of static LDS: parameter rows, prior table and prior terms of the fused finalize)
     static size_t shm_set = 0;
     if (shm > shm_set) { (void)hipFuncSetAttribute((const void*)dl_emulated_feature_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); shm_set = shm; }
     static const char* stamp_file = getenv("DL_EF_STAMPS");   // diagnostics: s_memtime at the phase boundaries of launches 30..33 appended to the file (synchronises)
@@ -891,7 +892,14 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
     ga.stamps = (stamp_file && grid <= 8192 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
     if (stamp_file) stamp_launches++;
     if (ga.stamps) (void)hipMemsetAsync(ga.stamps, 0, (size_t)grid * 16 * sizeof(unsigned long long), stream);
-    DL_LAUNCH(dl_emulated_feature_gram_kernel, dim3(grid, 1), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, ga);
+    DlEfSolve sv;
+    std::memset(&sv, 0, sizeof(sv));
+    if (fin != nullptr && ga.xr <= 8 && !getenv("DL_NO_FUSED_SOLVE")) {   // (DL_NO_FUSED_SOLVE=1: Gram matrix to memory + dl_finalize_marg_gram_kernel; read at every launch: the tests compare)
+        sv.enabled = 1; sv.post_mode = fin->post_mode & 0xff; sv.priors = fin->priors; sv.loglike = fin->loglike; sv.logprior = fin->logprior; sv.status = fin->status;
+        sv.solved = fin->solved; sv.hessian = fin->hessian; sv.mg = mg;
+        fin->done = true;
+    }
+    DL_LAUNCH(dl_emulated_feature_gram_kernel, dim3(grid, 1), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, ga, sv);
     if (ga.stamps) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h((size_t)grid * 16);
@@ -1442,25 +1450,12 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
 // ---- the same finalize when the Gram matrix G [B, 16, 16] of X = [dt; Tt_1 .. Tt_ns] is already there (feature GEMM of the emulated path): ONE LANE PER POINT ----
 // The solve of a point is a few hundred flops on an (ns x ns) system.  The lane-parallel kernel above gives it 16 lanes and pays a cross-lane exchange per
 // elimination step on one dependent chain (10.6 us per 4096 points of config 3, 1024 workgroups for 150 kFLOP); here a lane keeps the lower triangle of its point
-// in registers (NS is a compile-time size: no indexing at run time, no scratch) and runs Cholesky, the two substitutions and the quadratic forms serially --
-// no LDS, no barrier, no cross-lane traffic; 64 points per wavefront.  Same formulas (likelihoods/base.py:129-200, 314-413), sums in index order.
-// Partially marginalised sets (n_marg < ns): rows / columns of the parameters that are only solved become unit vectors in the second factorisation
-// (the determinant of the marginalised block is unchanged) instead of being compacted away.
-// 1 / sqrt(d), d > 0 normal: v_rsq_f64 (about 26 bits) and two Newton steps -- a dozen instructions on the pivot chain instead of a square root and a division
-__device__ __forceinline__ double dl_rsqrt_pos(double d) {
-    double y = __builtin_amdgcn_rsq(d);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const double h = 0.5 * y, e = fma(-d * y, h, 0.5);
-        y = fma(y, e, y);
-    }
-    return y;
-}
-
+// in registers and runs Cholesky, the two substitutions and the quadratic forms serially (dl_marg_solve.h); 64 points per wavefront, the priors of the same points
+// on a second wavefront beside it.
 template <int NS>
 __global__ __launch_bounds__(128) void dl_finalize_marg_gram_kernel(const double* __restrict__ gram, DlMargDev mg, const double* __restrict__ theta, int n_params,
-                                                                     const double* __restrict__ priors, int64_t B, double* __restrict__ loglike, double* __restrict__ logprior,
-                                                                     int32_t* __restrict__ status, double* __restrict__ solved, double* __restrict__ hessian, int post_mode) {
+                                                                      const double* __restrict__ priors, int64_t B, double* __restrict__ loglike, double* __restrict__ logprior,
+                                                                      int32_t* __restrict__ status, double* __restrict__ solved, double* __restrict__ hessian, int post_mode) {
     const int lane = threadIdx.x & 63;
     const bool prior_wave = threadIdx.x >= 64;   // wave 1: the priors of the same 64 points, beside the solve (a quarter of the instructions of a point)
     __shared__ double lp_lds[64];
@@ -1474,127 +1469,21 @@ __global__ __launch_bounds__(128) void dl_finalize_marg_gram_kernel(const double
     post_mode &= 0xff;
     const bool active = b < B;
     if (!active) b = B - 1;
-    const double* G = gram + (size_t)b * 256;
-    const double inf = __builtin_huge_val();
     if (prior_wave) {
-        double lp = 0.;
-        int nan_in = 0;
-        for (int p0 = 0; p0 < n_params; p0 += 4) {
-            double x[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = p0 + u < n_params ? theta[(size_t)b * n_params + p0 + u] : 0.;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (p0 + u < n_params) {
-                    if (x[u] != x[u]) nan_in = 1;
-                    lp += dl_prior_logpdf(priors + 5 * (p0 + u), x[u]);
-                }
-        }
+        double lp;
+        int nan_in;
+        dl_marg_priors_lane(theta + (size_t)b * n_params, n_params, priors, lp, nan_in);
         lp_lds[lane] = lp; nan_lds[lane] = nan_in;
         __syncthreads();
         return;
     }
-    // every load of the lane first: lower triangle of G
-    double H[NS][NS], gd[NS];
-    const double g00 = G[0];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        gd[s] = G[1 + s];
-#pragma unroll
-        for (int t = 0; t <= s; ++t) H[s][t] = G[(1 + s) * 16 + 1 + t];
-    }
-    // A = -H = Tt Tt^T + diag(prec) (SPD); rhs = g = -(Tt dt) - (x0 - loc) prec; dx = A^-1 g
-    double C[NS][NS], inv[NS], dx[NS];
-    bool ok = true;
-    // log det = log of the product of the pivots: mantissas and exponents apart (the product of NS <= 8 mantissas in [1/2, 1) cannot underflow), ONE logarithm
-    double mant_all = 1.;
-    int exp_all = 0;
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        double d = H[j][j] + mg.prec[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d -= C[j][k] * C[j][k];
-        if (!(d > 0.) || d == inf) { ok = false; d = 1.; }
-        mant_all *= __builtin_amdgcn_frexp_mant(d); exp_all += __builtin_amdgcn_frexp_exp(d);
-        inv[j] = dl_rsqrt_pos(d);
-        C[j][j] = d * inv[j];
-#pragma unroll
-        for (int i = j + 1; i < NS; ++i) {
-            double sum = H[i][j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) sum -= C[i][k] * C[j][k];
-            C[i][j] = sum * inv[j];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {   // forward, backward substitution
-        double sum = -gd[i] - (mg.x0[i] - mg.loc[i]) * mg.prec[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) sum -= C[i][k] * dx[k];
-        dx[i] = sum * inv[i];
-    }
-#pragma unroll
-    for (int i = NS - 1; i >= 0; --i) {
-        double sum = dx[i];
-#pragma unroll
-        for (int k = i + 1; k < NS; ++k) sum -= C[k][i] * dx[k];
-        dx[i] = sum * inv[i];
-    }
-    // 1/2 dx H_L dx + g_L dx  (likelihoods/base.py:385-386), H_L = -Tt Tt^T, g_L = -Tt dt
-    double quad = 0., lin = 0., lps = 0.;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        double rowsum = 0.;
-#pragma unroll
-        for (int t = 0; t < NS; ++t) rowsum += (s >= t ? H[s][t] : H[t][s]) * dx[t];
-        quad += dx[s] * rowsum;
-        lin += gd[s] * dx[s];
-        const double xs = mg.x0[s] + dx[s];
-        lps += -0.5 * (xs - mg.loc[s]) * (xs - mg.loc[s]) * mg.prec[s];   // 363-364 with parameter.py:2007 (0 for flat priors: prec = 0)
-        if (active && solved) solved[(size_t)b * NS + s] = xs;
-        if (active && hessian) {
-#pragma unroll
-            for (int t = 0; t < NS; ++t) hessian[((size_t)b * NS + s) * NS + t] = -(s >= t ? H[s][t] : H[t][s]);
-        }
-    }
-    double ll = -0.5 * g00 - 0.5 * quad - lin;
-    // -1/2 logdet(-H[marg, marg]) (394-404); all-marg: the factorisation above
-    if (mg.n_marg == NS) ll -= 0.5 * (log(mant_all) + (double)exp_all * 0.693147180559945309417);
-    else if (mg.n_marg > 0) {
-        double S[NS][NS], mant2 = 1.;
-        int exp2 = 0;
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            const bool mj = mg.is_marg[j] != 0;
-            double d = mj ? H[j][j] + mg.prec[j] : 1.;
-#pragma unroll
-            for (int k = 0; k < j; ++k) d -= S[j][k] * S[j][k];
-            if (!(d > 0.) || d == inf) { ok = false; d = 1.; }
-            mant2 *= __builtin_amdgcn_frexp_mant(d); exp2 += __builtin_amdgcn_frexp_exp(d);
-            const double invj = dl_rsqrt_pos(d);
-#pragma unroll
-            for (int i = j + 1; i < NS; ++i) {
-                double sum = (mj && mg.is_marg[i] != 0) ? H[i][j] : 0.;
-#pragma unroll
-                for (int k = 0; k < j; ++k) sum -= S[i][k] * S[j][k];
-                S[i][j] = sum * invj;
-            }
-        }
-        ll -= 0.5 * (log(mant2) + (double)exp2 * 0.693147180559945309417);
-    }
+    const double* G = gram + (size_t)b * 256;
+    double lps;
+    bool ok;
+    const double ll = dl_marg_solve_lane<NS>([&](int i, int j) { return G[i * 16 + j]; }, mg, (active && solved) ? solved + (size_t)b * NS : nullptr,
+                                             (active && hessian) ? hessian + (size_t)b * NS * NS : nullptr, lps, ok);
     __syncthreads();   // the priors of the other wave
-    const double lp = lp_lds[lane];
-    const bool nan_in = nan_lds[lane] != 0;
-    if (active) {
-        const double lptot = lp + lps;
-        int st = DL_ST_OK;
-        if (nan_in) st = DL_ST_NAN_INPUT;
-        else if (lp == -inf) st = DL_ST_OUT_OF_PRIOR;
-        else if (!ok || !(ll == ll) || ll == inf || ll == -inf) st = DL_ST_NONFINITE;
-        if (loglike) loglike[b] = post_mode ? (st == DL_ST_OK ? ll + lptot : -inf) : ll;
-        if (logprior) logprior[b] = lptot;
-        if (status) status[b] = st;
-    }
+    if (active) dl_marg_store_lane(ll, lps, ok, lp_lds[lane], nan_lds[lane] != 0, post_mode, b, loglike, logprior, status);
 }
 
 void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_per_point, int n_slabs, int64_t slab_stride, const double* bias, const DlMargDev& mg,

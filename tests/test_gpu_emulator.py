@@ -175,8 +175,8 @@ def test_taylor_emulator_fitted_on_the_gpu_theory():
 
 
 def test_gram_finalize_one_lane_per_point():
-    """The finalize of the fused emulator path (`dl_finalize_marg_gram_kernel`: one lane per point on the Gram matrix the feature GEMM leaves) against the 16-lanes-per-point
-    kernel of the same library (DL_FM_NO_LANE_SOLVE=1) and against the oracle: all solved parameters marginalised, a mix of '.best' and '.marg' (the marginalised
+    """The finalize of the fused emulator path (one lane per point on the Gram matrix of the feature GEMM: in the tail of the same kernel, or as
+    `dl_finalize_marg_gram_kernel` with DL_NO_FUSED_SOLVE=1) against the 16-lanes-per-point kernel of the same library (DL_FM_NO_LANE_SOLVE=1) and against the oracle: all solved parameters marginalised, a mix of '.best' and '.marg' (the marginalised
     sub-block's determinant), a single '.best'; ragged batch."""
     import os
     cases = [None,
@@ -192,12 +192,18 @@ def test_gram_finalize_one_lane_per_point():
         theta[5, 0] = np.nan                                   # status codes travel through the same kernel
         theta[6, 1] = like.varied_params[names[1]].prior.limits[1] + 1.
         ctx = like._get_context()
-        fast = ctx.eval_batch_host(theta, return_solved=True)
-        os.environ['DL_FM_NO_LANE_SOLVE'] = '1'
+        fast = ctx.eval_batch_host(theta, return_solved=True)          # solve in the tail of the fused kernel
+        os.environ['DL_NO_FUSED_SOLVE'] = '1'
         try:
-            wide = ctx.eval_batch_host(theta, return_solved=True)
+            separate = ctx.eval_batch_host(theta, return_solved=True)  # Gram matrix through memory, one lane per point in its own launch
+            os.environ['DL_FM_NO_LANE_SOLVE'] = '1'
+            wide = ctx.eval_batch_host(theta, return_solved=True)      # ... 16 lanes per point
         finally:
-            del os.environ['DL_FM_NO_LANE_SOLVE']
+            os.environ.pop('DL_NO_FUSED_SOLVE', None); os.environ.pop('DL_FM_NO_LANE_SOLVE', None)
+        assert np.array_equal(fast[2], separate[2])
+        ok = fast[2] == 0
+        assert (np.abs(fast[0][ok] - separate[0][ok]) <= 1e-13 * np.maximum(1., np.abs(separate[0][ok]))).all() and np.allclose(fast[3][ok], separate[3][ok], rtol=1e-12, atol=1e-13)
+        assert np.allclose(fast[1][ok], separate[1][ok], rtol=1e-13, atol=1e-13)
         assert np.array_equal(fast[2], wide[2]) and fast[2][5] != 0 and fast[2][6] != 0 and (np.delete(fast[2], [5, 6]) == 0).all()
         good = fast[2] == 0
         assert (np.abs(fast[0][good] - wide[0][good]) <= 1e-12 * np.maximum(1., np.abs(wide[0][good]))).all(), np.abs(fast[0][good] - wide[0][good]).max()
