@@ -212,12 +212,24 @@ def test_gram_finalize_one_lane_per_point():
         nsol = len(solved)
         scales = np.array([like.all_params[name].prior.scale for name in solved])
         mask = np.array([derived is None or derived[name] == '.marg' for name in solved])
+        # derived outputs (likelihood Hessian w.r.t. the solved parameters, likelihoods/base.py:388-390) through the same three paths
+        sub = np.ascontiguousarray(theta[7:7 + 40])
+        dfast = ctx.eval_batch_derived_host(sub)
+        os.environ['DL_NO_FUSED_SOLVE'] = '1'
+        try:
+            dsep = ctx.eval_batch_derived_host(sub)
+        finally:
+            os.environ.pop('DL_NO_FUSED_SOLVE', None)
+        assert dfast[4].shape == (40, nsol, nsol) and np.array_equal(dfast[4], dsep[4]) and np.allclose(dfast[0], fast[0][7:47], rtol=1e-13, atol=0.)
         for i in (0, 17, 500, 1006):
             f0 = oracle_flat(like, pt, theory, theta[i], names, {name: 0. for name in solved})
             T = np.array([oracle_flat(like, pt, theory, theta[i], names, {n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
             sol = orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=np.zeros(nsol), prior_scale=scales, marg_mask=mask)
             assert abs(fast[0][i] - sol['loglikelihood']) <= 1e-10 * max(1., abs(sol['loglikelihood'])), (derived, i, fast[0][i], sol['loglikelihood'])
             assert np.allclose(fast[3][i], sol['x'], rtol=1e-7, atol=1e-9)
+            if i == 17:
+                scale_h = np.abs(sol['likelihood_hessian']).max()
+                assert np.allclose(dfast[4][i - 7], sol['likelihood_hessian'], rtol=1e-9, atol=1e-11 * scale_h)
 
 
 # north star: 1e-10 on logL -- also for the analytically marginalised value
