@@ -195,7 +195,9 @@ __device__ __forceinline__ void dl_eb_forward(const DlObsDev& o, const double* _
 //      entry, one per layer, the caller's (nine before).  Same arithmetic in the same order as dl_eb_forward: results are bit-identical.
 template <int NTHR>
 __device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const double* __restrict__ theta, int n_params, int64_t B, int64_t p0, double* lds, double* rec,
-                                                    int rec_stride, unsigned long long* st = nullptr, bool th_early = false, double th_val = 0.) {
+                                                    int rec_stride, unsigned long long* st = nullptr, bool th_early = false, double th_val = 0.,
+                                                    double* keep_theta = nullptr, double* keep_pr = nullptr, double pr_val = 0., int n_keep_pr = 0) {
+    // keep_theta / keep_pr (fused finalize): copies of the parameter rows and of the prior table that outlive the workspace, stored where theta is waited for anyway
     int st_slot = 8;   // DL_EF_STAMPS diagnostics: slots 8.. of the workgroup = after the entry barrier, then after every layer's barrier (the monomials before the first of the second run)
 #define DL_EB_STAMP if (st != nullptr && threadIdx.x == 0 && st_slot < 14) st[st_slot] = __builtin_amdgcn_s_memtime(); ++st_slot;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -284,6 +286,7 @@ __device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const dou
         const bool vlive = tid < DL_EB_PTS * DL_N_VPARS;
         const DlInput vin = o.vp_in[vlive ? vc_ : 0];
         trow[tid] = th_val;
+        if (keep_theta != nullptr) { keep_theta[tid] = th_val; if (tid < n_keep_pr) keep_pr[tid] = pr_val; }
         __syncthreads();
         if (xlive) {
             const double tv = trow[pt * 32 + (xin.col >= 0 ? xin.col : 0)];
@@ -298,7 +301,7 @@ __device__ __forceinline__ void dl_eb_forward_fused(const DlObsDev& o, const dou
             vpv[vpt * 12 + vc_] = vin.col >= 0 ? tv : vin.value;
         }
     } else {
-    if (th_early) { trow[tid] = th_val; __syncthreads(); }
+    if (th_early) { trow[tid] = th_val; if (keep_theta != nullptr) { keep_theta[tid] = th_val; if (tid < n_keep_pr) keep_pr[tid] = pr_val; } __syncthreads(); }
     for (int idx = tid; idx < DL_EB_PTS * nin0; idx += NTHR) {
         const int pt = idx / nin0, i = idx - pt * nin0;
         const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
@@ -556,7 +559,8 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const dou
         const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
         th_val = theta[(size_t)b * n_params + (j < n_params ? j : 0)];
     }
-    // fused finalize: the parameter rows and the prior table stay in LDS for the tail (requested here with the rest of the entry loads, stored after the forward pass)
+    // fused finalize: the parameter rows and the prior table stay in LDS for the tail (requested here with the rest of the entry loads, stored by the forward pass
+    // where it waits for theta: a store after the forward pass let the compiler sink the table's load there -- a global round trip, 0.6 us, in front of the feature GEMM)
     const bool keep = sv.enabled && th_early;
     __shared__ double keep_theta[DL_FG_PTS * 32], keep_pr[32 * 5], prior_term[DL_FG_PTS][33], lp_lds[DL_FG_PTS];
     __shared__ int nan_lds[DL_FG_PTS];
@@ -567,8 +571,8 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const dou
     double* rec = lds;
     double* work = lds + dl_ef_gram_rec_doubles(o);
     if (ga.stamps != nullptr && threadIdx.x == 0) { ga.stamps[(size_t)blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memtime(); ga.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime(); }
-    dl_eb_forward_fused<512>(o, theta, n_params, B, p0, work, rec, stride, ga.stamps != nullptr ? ga.stamps + (size_t)blockIdx.x * 16 : nullptr, th_early, th_val);
-    if (keep) { keep_theta[threadIdx.x] = th_val; if ((int)threadIdx.x < 5 * n_params) keep_pr[threadIdx.x] = pr_val; }   // (visible after the barriers of the feature GEMM)
+    dl_eb_forward_fused<512>(o, theta, n_params, B, p0, work, rec, stride, ga.stamps != nullptr ? ga.stamps + (size_t)blockIdx.x * 16 : nullptr, th_early, th_val,
+                             keep ? keep_theta : nullptr, keep_pr, pr_val, 5 * n_params);
     DlFgGram gr;
     gr.x = work;
     gr.xr = ga.xr; gr.gram = sv.enabled ? nullptr : ga.gram; gr.stamps = ga.stamps;
@@ -589,7 +593,9 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const dou
                 gr.x[((size_t)pt * gr.xr + ga.const_row[c]) * DL_FG_XLD + col] = ga.const_ptr[c][col];
             }
     };
-    dl_fg_compute_gram(rec, stride, o.nb_pad, R, gfrag, B, p0, &gr, after_request);
+    // MLP table engine with n_basis = 8 j + 1: the constant basis function sits alone in the last k-step pair of the operand
+    const bool bias_pair = o.eng[0].type == 0 && o.n_basis == o.nb_pad - 7 && o.nb_pad >= 16;
+    dl_fg_compute_gram(rec, stride, o.nb_pad, R, gfrag, B, p0, &gr, after_request, bias_pair);
     if (sv.enabled) {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
         const int64_t b = p0 + (lane & 15);

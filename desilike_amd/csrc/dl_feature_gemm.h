@@ -260,14 +260,20 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
 // the first two k-steps of a group's operand, requested AHEAD of its main loop (during the previous group's epilogue; for the first group before the barrier that
 // follows the forward pass): a group is only nq (9) steps long, and started cold every group paid the L2 round trip with the matrix pipe idle whenever the SIMD
 // partner was not streaming (the timelines of both waves of a SIMD: a wave alone reached 57 % of the pipe's rate)
-template <int CNT> struct DlFgAhead { dl_fg_double2 b0[CNT], b1[CNT]; };
+// c0: starting value of the accumulators.  When the last basis function is the constant 1 (MLP engines: the bias row of the folded final layer) and it is the only
+// live entry of the last k-step pair (n_basis = 8 j + 1), that pair is not multiplied at all: its product is the row G[n_basis - 1][m][column] itself, the same for
+// every point -- the accumulators START from it (gbias: that pair of the operand at the lane's column, null otherwise) and the main loop is one pair (of nine: 11 % of
+// the MFMAs and of the operand stream of config 3) shorter.
+template <int CNT> struct DlFgAhead { dl_fg_double2 b0[CNT], b1[CNT]; double c0[CNT]; };
 template <int CNT>
-__device__ __forceinline__ void dl_fg_gram_request(DlFgAhead<CNT>& ah, const dl_fg_double2* __restrict__ gw, int nq, int m0) {
+__device__ __forceinline__ void dl_fg_gram_request(DlFgAhead<CNT>& ah, const dl_fg_double2* __restrict__ gw, int nq, int m0, const dl_fg_double2* __restrict__ gbias) {
     const int q1 = 1 < nq ? 1 : nq - 1;
 #pragma unroll
     for (int i = 0; i < CNT; ++i) ah.b0[i] = gw[(size_t)(m0 + i) * 64];
 #pragma unroll
     for (int i = 0; i < CNT; ++i) ah.b1[i] = gw[(size_t)(q1 * DL_FG_NM + m0 + i) * 64];
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) ah.c0[i] = gbias ? gbias[(size_t)(m0 + i) * 64].x : 0.;
 }
 // D operand buffers, D - 1 steps in flight (the first two come from the request made ahead).  Two steps are enough while both waves of a SIMD stream MFMAs (each
 // advances at half speed); the LAST group of a wave often runs with its partner already finished, and alone, two steps ahead, a wave reached 60 % of the pipe's rate
@@ -280,7 +286,7 @@ __device__ __forceinline__ void dl_fg_gram_mainloop(const double* arow, const dl
         _Pragma("unroll") for (int i = 0; i < CNT; ++i) { acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.x, bb[i].x, acc[i], 0, 0, 0); \
                                                           acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.y, bb[i].y, acc[i], 0, 0, 0); } }
 #pragma unroll
-    for (int i = 0; i < CNT; ++i) { acc[i] = (dl_fg_double4){0., 0., 0., 0.}; b[0][i] = ah.b0[i]; b[1][i] = ah.b1[i]; }
+    for (int i = 0; i < CNT; ++i) { acc[i] = (dl_fg_double4){ah.c0[i], ah.c0[i], ah.c0[i], ah.c0[i]}; b[0][i] = ah.b0[i]; b[1][i] = ah.b1[i]; }
 #pragma unroll
     for (int d = 2; d < D - 1; ++d) DL_FG_LOAD(b[d], d)
     int q = 0;
@@ -392,13 +398,16 @@ __device__ __forceinline__ void dl_fg_gram_epilogue(const dl_fg_double4 (&acc)[C
 // barrier is inside, after the first operand request
 template <class AfterRequest>
 __device__ __forceinline__ void dl_fg_compute_gram(const double* lds, int stride, int nb_pad, int R, const double* __restrict__ gfrag, int64_t B, int64_t p0, const DlFgGram* gr,
-                                                   AfterRequest&& after_request) {
+                                                   AfterRequest&& after_request, bool bias_pair = false) {
     constexpr bool GRAM = true;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the operand base of the wave and the team branch)
     const int col = lane & 15, g = lane >> 4;
     const int jb = wave;                                // 16-column block of this wave
-    const int nq = nb_pad / 8;
-    const dl_fg_double2* gw = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * nq * DL_FG_NM * 64 + lane;
+    const int nq_all = nb_pad / 8;
+    const dl_fg_double2* gw = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * nq_all * DL_FG_NM * 64 + lane;
+    // (bias_pair: see DlFgAhead -- the last pair of the operand holds the constant basis function alone; lanes 0-15 of that pair carry k = n_basis - 1)
+    const int nq = bias_pair ? nq_all - 1 : nq_all;
+    const dl_fg_double2* gbias = bias_pair ? gw - lane + col + (size_t)(nq_all - 1) * DL_FG_NM * 64 : nullptr;
     const double* arow = lds + col * stride + 2 * g;
     const int cbase = jb * 16 + col;
     double cst[6] = {0., 0., 0., 0., 0., 0.};   // constant parts of the rows (used by the last epilogue): requested before the last main loop, which hides the round trip
@@ -407,18 +416,18 @@ __device__ __forceinline__ void dl_fg_compute_gram(const double* lds, int stride
     // every group's operand are requested before the epilogue of the group before it
     if (wave < 4) {
         DlFgAhead<8> a0; DlFgAhead<6> a1; DlFgAhead<5> a2;
-        dl_fg_gram_request<8>(a0, gw, nq, 0);
+        dl_fg_gram_request<8>(a0, gw, nq, 0, gbias);
         after_request();   // (barrier: the records of the forward pass are complete)
-        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 0, acc, a0); DL_FG_STAMP(2) dl_fg_gram_request<6>(a1, gw, nq, 8); dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 0, acc, a0); DL_FG_STAMP(2) dl_fg_gram_request<6>(a1, gw, nq, 8, gbias); dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g, cst); }
         DL_FG_STAMP(3)
-        { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6>(arow, gw, nq, 8, acc, a1); dl_fg_gram_request<5>(a2, gw, nq, 14); DL_FG_CST dl_fg_gram_epilogue<6>(acc, lds, stride, nb_pad, R, 8, false, false, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6>(arow, gw, nq, 8, acc, a1); dl_fg_gram_request<5>(a2, gw, nq, 14, gbias); DL_FG_CST dl_fg_gram_epilogue<6>(acc, lds, stride, nb_pad, R, 8, false, false, gr, cbase, g, cst); }
         { dl_fg_double4 acc[5]; dl_fg_gram_mainloop<5, 5>(arow, gw, nq, 14, acc, a2); DL_FG_STAMP(4) dl_fg_gram_epilogue<5>(acc, lds, stride, nb_pad, R, 14, false, true, gr, cbase, g, cst); }
     } else {
         DlFgAhead<4> a0; DlFgAhead<8> a1; DlFgAhead<7> a2;
-        dl_fg_gram_request<4>(a0, gw, nq, 0);
+        dl_fg_gram_request<4>(a0, gw, nq, 0, gbias);
         after_request();
-        { dl_fg_double4 acc[4]; dl_fg_gram_mainloop<4>(arow, gw, nq, 0, acc, a0); dl_fg_gram_request<8>(a1, gw, nq, 4); dl_fg_gram_epilogue<4>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g, cst); }
-        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 4, acc, a1); dl_fg_gram_request<7>(a2, gw, nq, 12); DL_FG_CST dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 4, false, false, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[4]; dl_fg_gram_mainloop<4>(arow, gw, nq, 0, acc, a0); dl_fg_gram_request<8>(a1, gw, nq, 4, gbias); dl_fg_gram_epilogue<4>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 4, acc, a1); dl_fg_gram_request<7>(a2, gw, nq, 12, gbias); DL_FG_CST dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 4, false, false, gr, cbase, g, cst); }
         { dl_fg_double4 acc[7]; dl_fg_gram_mainloop<7, 4>(arow, gw, nq, 12, acc, a2); dl_fg_gram_epilogue<7>(acc, lds, stride, nb_pad, R, 12, false, true, gr, cbase, g, cst); }
     }
 #undef DL_FG_CST
