@@ -512,6 +512,7 @@ struct DlEfGramArgs {
     double* gram;
     unsigned long long* stamps;        // DL_EF_STAMPS diagnostics
     int nz[6][2];                      // support of the derivative rows (dl_velocileptors_row_support)
+    int scaled;                        // DlFgGram::scaled
 };
 // The marginalised finalize in the tail of the same kernel (n_s <= 7): the Gram blocks of the workgroup's 16 points stay in LDS, lanes 0-15 of wave 0 solve a point
 // each (dl_marg_solve.h) while lanes 0-15 of wave 1 sum the priors of the same points; the other waves have left.  Against a separate launch (4.3 us, of which a
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const dou
                              keep ? keep_theta : nullptr, keep_pr, pr_val, 5 * n_params);
     DlFgGram gr;
     gr.x = work;
-    gr.xr = ga.xr; gr.gram = sv.enabled ? nullptr : ga.gram; gr.stamps = ga.stamps;
+    gr.xr = ga.xr; gr.gram = sv.enabled ? nullptr : ga.gram; gr.stamps = ga.stamps; gr.scaled = ga.scaled;
 #pragma unroll
     for (int r = 0; r < 6; ++r) { gr.nz[r][0] = ga.nz[r][0]; gr.nz[r][1] = ga.nz[r][1]; }
 #pragma unroll

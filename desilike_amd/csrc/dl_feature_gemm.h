@@ -41,6 +41,7 @@ struct DlFgGram {
     double* gram;              // [B, 256]; null: the 8 x 8 block of point pt goes to LDS instead, x + pt xr DL_FG_XLD + 8 i + j (the solve follows in the same kernel)
     unsigned long long* stamps;   // DL_EF_STAMPS diagnostics (null in production): 16 x s_memtime per workgroup
     int nz[6][2];              // monomials the derivative row r >= 1 touches (dl_velocileptors_row_support), -1: none
+    int scaled;                // every derivative row lives on monomials 12-18: monomials 0-11 feed row 0 only, through registers (dl_fg_gram_epilogue_row0)
 };
 #define DL_FG_STAMP(slot) if (GRAM && gr->stamps != nullptr && threadIdx.x == 0) gr->stamps[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime();
 
@@ -265,23 +266,26 @@ __device__ __forceinline__ void dl_fg_compute(const double* lds, int stride, int
 // every point -- the accumulators START from it (gbias: that pair of the operand at the lane's column, null otherwise) and the main loop is one pair (of nine: 11 % of
 // the MFMAs and of the operand stream of config 3) shorter.
 template <int CNT> struct DlFgAhead { dl_fg_double2 b0[CNT], b1[CNT]; double c0[CNT]; };
+// gw: WAVE-UNIFORM base of the wave's operand (scalar registers), lane: the lane's element offset -- kept apart so that every request is a load with a scalar base,
+// a constant vector offset and an immediate: addresses formed per lane were 1 - 2 vector instructions per load, and on this chip the fp64 MFMA runs on the vector
+// unit's own fp64 lanes -- every vector instruction of the loop is added to its time, not hidden under it (docs/EXPERIMENTS.md).
 template <int CNT>
-__device__ __forceinline__ void dl_fg_gram_request(DlFgAhead<CNT>& ah, const dl_fg_double2* __restrict__ gw, int nq, int m0, const dl_fg_double2* __restrict__ gbias) {
+__device__ __forceinline__ void dl_fg_gram_request(DlFgAhead<CNT>& ah, const dl_fg_double2* __restrict__ gw, unsigned lane, int nq, int m0, const dl_fg_double2* __restrict__ gbias, unsigned col) {
     const int q1 = 1 < nq ? 1 : nq - 1;
 #pragma unroll
-    for (int i = 0; i < CNT; ++i) ah.b0[i] = gw[(size_t)(m0 + i) * 64];
+    for (int i = 0; i < CNT; ++i) ah.b0[i] = gw[(size_t)(m0 + i) * 64 + lane];
 #pragma unroll
-    for (int i = 0; i < CNT; ++i) ah.b1[i] = gw[(size_t)(q1 * DL_FG_NM + m0 + i) * 64];
+    for (int i = 0; i < CNT; ++i) ah.b1[i] = gw[(size_t)(q1 * DL_FG_NM + m0 + i) * 64 + lane];
 #pragma unroll
-    for (int i = 0; i < CNT; ++i) ah.c0[i] = gbias ? gbias[(size_t)(m0 + i) * 64].x : 0.;
+    for (int i = 0; i < CNT; ++i) ah.c0[i] = gbias ? gbias[(size_t)(m0 + i) * 64 + col].x : 0.;
 }
 // D operand buffers, D - 1 steps in flight (the first two come from the request made ahead).  Two steps are enough while both waves of a SIMD stream MFMAs (each
 // advances at half speed); the LAST group of a wave often runs with its partner already finished, and alone, two steps ahead, a wave reached 60 % of the pipe's rate
 // (timeline of both waves: 104 cycles per MFMA instead of 64): the last groups run deeper (they hold no request for a next group: the registers are there).
 template <int CNT, int D = 3>
-__device__ __forceinline__ void dl_fg_gram_mainloop(const double* arow, const dl_fg_double2* __restrict__ gw, int nq, int m0, dl_fg_double4 (&acc)[CNT], const DlFgAhead<CNT>& ah) {
+__device__ __forceinline__ void dl_fg_gram_mainloop(const double* arow, const dl_fg_double2* __restrict__ gw, unsigned lane, int nq, int m0, dl_fg_double4 (&acc)[CNT], const DlFgAhead<CNT>& ah) {
     dl_fg_double2 b[D][CNT];
-#define DL_FG_LOAD(bb, qq) { const int q_ = (qq) < nq ? (qq) : nq - 1; _Pragma("unroll") for (int i = 0; i < CNT; ++i) bb[i] = gw[(size_t)(q_ * DL_FG_NM + m0 + i) * 64]; }
+#define DL_FG_LOAD(bb, qq) { const int q_ = (qq) < nq ? (qq) : nq - 1; _Pragma("unroll") for (int i = 0; i < CNT; ++i) bb[i] = gw[(size_t)(q_ * DL_FG_NM + m0 + i) * 64 + lane]; }
 #define DL_FG_MUL(bb, qq) { const dl_fg_double2 a_ = *reinterpret_cast<const dl_fg_double2*>(arow + 8 * (qq)); \
         _Pragma("unroll") for (int i = 0; i < CNT; ++i) { acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.x, bb[i].x, acc[i], 0, 0, 0); \
                                                           acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.y, bb[i].y, acc[i], 0, 0, 0); } }
@@ -301,13 +305,37 @@ __device__ __forceinline__ void dl_fg_gram_mainloop(const double* arow, const dl
 #undef DL_FG_MUL
 }
 
+// Row 0 of the monomials NO derivative row touches (velocileptors order: 0-11 = 1, b1 .. b1 b3; the solved alpha* / sn* live on 12-18): their epilogue is four FMAs per
+// monomial and point into REGISTERS (w0: the lane's four points) -- no X row is read or written, no derivative row is looked at.  The X rows are written once, by the
+// epilogue of monomials 12-18 (first and last at once); w0 is added to row 0 at the very end.
+template <int CNT>
+__device__ __forceinline__ void dl_fg_gram_epilogue_row0(const dl_fg_double4 (&acc)[CNT], const double* lds, int stride, int nb_pad, int m0, int g, double (&w0)[4]) {
+    constexpr int NP = (CNT + 1) / 2;
+    dl_fg_double2 mm[4][NP];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const double* mono = lds + (g + 4 * rr) * stride + nb_pad + m0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) mm[rr][j] = *reinterpret_cast<const dl_fg_double2*>(mono + 2 * j);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            w0[rr] = fma(mm[rr][j].x, acc[2 * j][rr], w0[rr]);
+            if (2 * j + 1 < CNT) w0[rr] = fma(mm[rr][j].y, acc[2 * j + 1][rr], w0[rr]);
+        }
+    }
+}
+
 // rows of the lane's four points += sum over the group's monomials (m0 even); first: the partial rows start from zero; last: the constant part of every row is added.
 // Row 0 (the residual) is dense in the monomials.  The derivative rows are not: the row of a solved alpha* / sn* touches one or two monomials (gr->nz), the other
 // seventeen entries of its monomial row are exact zeros -- multiplying them was 4/5 of the epilogue's LDS reads and FMAs (7 us of the kernel; the LDS pipe of the CU
 // was the bound: 240 16-byte broadcast reads per wave).  The sums run over the same monomials in the same order: bit-identical results.
 template <int CNT>
 __device__ __forceinline__ void dl_fg_gram_epilogue(const dl_fg_double4 (&acc)[CNT], const double* lds, int stride, int nb_pad, int R, int m0, bool first, bool last,
-                                                    const DlFgGram* gr, int cbase, int g, const double (&cst)[6]) {
+                                                    const DlFgGram* gr, int cbase, int g, const double (&cst)[6], const double* row0_start = nullptr) {
+    // row0_start [4]: with `first`, row 0 of the lane's four points starts from these values (the scaled part of the sum) instead of zero
     constexpr int NP = (CNT + 1) / 2;
     double* xb0 = gr->x + (size_t)g * gr->xr * DL_FG_XLD + cbase;                    // X rows of point g (+ 4 rr: 4 xr DL_FG_XLD doubles further)
     const size_t xpt = (size_t)4 * gr->xr * DL_FG_XLD;
@@ -324,7 +352,7 @@ __device__ __forceinline__ void dl_fg_gram_epilogue(const dl_fg_double4 (&acc)[C
         const double c0 = cst[0];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            double w = first ? 0. : v[rr];
+            double w = first ? (row0_start ? row0_start[rr] : 0.) : v[rr];
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 w = fma(mm[rr][j].x, acc[2 * j][rr], w);
@@ -404,31 +432,66 @@ __device__ __forceinline__ void dl_fg_compute_gram(const double* lds, int stride
     const int col = lane & 15, g = lane >> 4;
     const int jb = wave;                                // 16-column block of this wave
     const int nq_all = nb_pad / 8;
-    const dl_fg_double2* gw = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * nq_all * DL_FG_NM * 64 + lane;
+    const dl_fg_double2* gw = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * nq_all * DL_FG_NM * 64;   // wave-uniform (jb is a scalar)
+    const unsigned ulane = (unsigned)lane, ucol = (unsigned)col;
     // (bias_pair: see DlFgAhead -- the last pair of the operand holds the constant basis function alone; lanes 0-15 of that pair carry k = n_basis - 1)
     const int nq = bias_pair ? nq_all - 1 : nq_all;
-    const dl_fg_double2* gbias = bias_pair ? gw - lane + col + (size_t)(nq_all - 1) * DL_FG_NM * 64 : nullptr;
+    const dl_fg_double2* gbias = bias_pair ? gw + (size_t)(nq_all - 1) * DL_FG_NM * 64 : nullptr;
     const double* arow = lds + col * stride + 2 * g;
     const int cbase = jb * 16 + col;
     double cst[6] = {0., 0., 0., 0., 0., 0.};   // constant parts of the rows (used by the last epilogue): requested before the last main loop, which hides the round trip
 #define DL_FG_CST _Pragma("unroll") for (int u = 0; u < 6; ++u) cst[u] = gr->cst[u < R ? u : 0][cbase];
     // monomial groups (8, 6, 5) on waves 0-3, (4, 8, 7) on their SIMD partners -- group starts are even (16-byte reads of the monomial rows); the first two steps of
     // every group's operand are requested before the epilogue of the group before it
-    if (wave < 4) {
+    if (gr->scaled) {
+        // groups L1 = monomials 0-5, L2 = 6-11 (row 0 only, into registers), T = 12-18 (the X rows, first and last at once).  Waves 0-3: T, L1, L2; their SIMD partners:
+        // L1, T, L2 -- the one long epilogue of a wave runs beside a main loop of its partner, and the last thing either does is a short one
+        double w0[4] = {0., 0., 0., 0.};
+        DlFgAhead<6> l1, l2;
+        DlFgAhead<7> t;
+        if (wave < 4) {
+            dl_fg_gram_request<7>(t, gw, ulane, nq, 12, gbias, ucol);
+            after_request();   // (barrier: the records of the forward pass are complete)
+            { dl_fg_double4 acc[7]; dl_fg_gram_mainloop<7, 3>(arow, gw, ulane, nq, 12, acc, t); DL_FG_STAMP(2) DL_FG_CST
+              dl_fg_gram_epilogue<7>(acc, lds, stride, nb_pad, R, 12, true, true, gr, cbase, g, cst); }
+            dl_fg_gram_request<6>(l1, gw, ulane, nq, 0, gbias, ucol);   // (after the long epilogue: the registers it needs are those of a request)
+            DL_FG_STAMP(3)
+            { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6, 3>(arow, gw, ulane, nq, 0, acc, l1); dl_fg_gram_request<6>(l2, gw, ulane, nq, 6, gbias, ucol);
+              dl_fg_gram_epilogue_row0<6>(acc, lds, stride, nb_pad, 0, g, w0); }
+        } else {
+            dl_fg_gram_request<6>(l1, gw, ulane, nq, 0, gbias, ucol);
+            after_request();
+            { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6, 3>(arow, gw, ulane, nq, 0, acc, l1); dl_fg_gram_request<7>(t, gw, ulane, nq, 12, gbias, ucol);
+              dl_fg_gram_epilogue_row0<6>(acc, lds, stride, nb_pad, 0, g, w0); }
+            { dl_fg_double4 acc[7]; dl_fg_gram_mainloop<7, 3>(arow, gw, ulane, nq, 12, acc, t); DL_FG_CST
+              dl_fg_gram_epilogue<7>(acc, lds, stride, nb_pad, R, 12, true, true, gr, cbase, g, cst); }
+            dl_fg_gram_request<6>(l2, gw, ulane, nq, 6, gbias, ucol);
+        }
+        { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6, 4>(arow, gw, ulane, nq, 6, acc, l2); DL_FG_STAMP(4) dl_fg_gram_epilogue_row0<6>(acc, lds, stride, nb_pad, 6, g, w0); }
+        {   // row 0 of the lane's four points: what the T epilogue wrote + the register part
+            double* xr0 = gr->x + (size_t)g * gr->xr * DL_FG_XLD + cbase + (size_t)gr->row_of[0] * DL_FG_XLD;
+            const size_t xpt = (size_t)4 * gr->xr * DL_FG_XLD;
+            double v[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) v[rr] = xr0[rr * xpt];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) xr0[rr * xpt] = v[rr] + w0[rr];
+        }
+    } else if (wave < 4) {
         DlFgAhead<8> a0; DlFgAhead<6> a1; DlFgAhead<5> a2;
-        dl_fg_gram_request<8>(a0, gw, nq, 0, gbias);
+        dl_fg_gram_request<8>(a0, gw, ulane, nq, 0, gbias, ucol);
         after_request();   // (barrier: the records of the forward pass are complete)
-        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 0, acc, a0); DL_FG_STAMP(2) dl_fg_gram_request<6>(a1, gw, nq, 8, gbias); dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, ulane, nq, 0, acc, a0); DL_FG_STAMP(2) dl_fg_gram_request<6>(a1, gw, ulane, nq, 8, gbias, ucol); dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g, cst); }
         DL_FG_STAMP(3)
-        { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6>(arow, gw, nq, 8, acc, a1); dl_fg_gram_request<5>(a2, gw, nq, 14, gbias); DL_FG_CST dl_fg_gram_epilogue<6>(acc, lds, stride, nb_pad, R, 8, false, false, gr, cbase, g, cst); }
-        { dl_fg_double4 acc[5]; dl_fg_gram_mainloop<5, 5>(arow, gw, nq, 14, acc, a2); DL_FG_STAMP(4) dl_fg_gram_epilogue<5>(acc, lds, stride, nb_pad, R, 14, false, true, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6>(arow, gw, ulane, nq, 8, acc, a1); dl_fg_gram_request<5>(a2, gw, ulane, nq, 14, gbias, ucol); DL_FG_CST dl_fg_gram_epilogue<6>(acc, lds, stride, nb_pad, R, 8, false, false, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[5]; dl_fg_gram_mainloop<5, 5>(arow, gw, ulane, nq, 14, acc, a2); DL_FG_STAMP(4) dl_fg_gram_epilogue<5>(acc, lds, stride, nb_pad, R, 14, false, true, gr, cbase, g, cst); }
     } else {
         DlFgAhead<4> a0; DlFgAhead<8> a1; DlFgAhead<7> a2;
-        dl_fg_gram_request<4>(a0, gw, nq, 0, gbias);
+        dl_fg_gram_request<4>(a0, gw, ulane, nq, 0, gbias, ucol);
         after_request();
-        { dl_fg_double4 acc[4]; dl_fg_gram_mainloop<4>(arow, gw, nq, 0, acc, a0); dl_fg_gram_request<8>(a1, gw, nq, 4, gbias); dl_fg_gram_epilogue<4>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g, cst); }
-        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, nq, 4, acc, a1); dl_fg_gram_request<7>(a2, gw, nq, 12, gbias); DL_FG_CST dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 4, false, false, gr, cbase, g, cst); }
-        { dl_fg_double4 acc[7]; dl_fg_gram_mainloop<7, 4>(arow, gw, nq, 12, acc, a2); dl_fg_gram_epilogue<7>(acc, lds, stride, nb_pad, R, 12, false, true, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[4]; dl_fg_gram_mainloop<4>(arow, gw, ulane, nq, 0, acc, a0); dl_fg_gram_request<8>(a1, gw, ulane, nq, 4, gbias, ucol); dl_fg_gram_epilogue<4>(acc, lds, stride, nb_pad, R, 0, true, false, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[8]; dl_fg_gram_mainloop<8>(arow, gw, ulane, nq, 4, acc, a1); dl_fg_gram_request<7>(a2, gw, ulane, nq, 12, gbias, ucol); DL_FG_CST dl_fg_gram_epilogue<8>(acc, lds, stride, nb_pad, R, 4, false, false, gr, cbase, g, cst); }
+        { dl_fg_double4 acc[7]; dl_fg_gram_mainloop<7, 4>(arow, gw, ulane, nq, 12, acc, a2); dl_fg_gram_epilogue<7>(acc, lds, stride, nb_pad, R, 12, false, true, gr, cbase, g, cst); }
     }
 #undef DL_FG_CST
     DL_FG_STAMP(5)

@@ -880,6 +880,11 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
         const int slot = obs.vp_slot[c];
         if (slot >= 0 && 1 + slot < 6) dl_velocileptors_row_support(obs, c, ga.nz[1 + slot]);
     }
+    // every derivative row on monomials 12-18 (the solved alpha* / sn* of the velocileptors order): monomials 0-11 feed row 0 only, through registers (DL_NO_SCALED_ROW0=1: three
+    // full epilogues per wave, the form before; read at every launch: the tests compare)
+    ga.scaled = DL_FG_NM == 19 && obs.mono_mode != 0 && !getenv("DL_NO_SCALED_ROW0");
+    for (int r = 1; r < 6; ++r)
+        for (int z = 0; z < 2; ++z) if (ga.nz[r][z] >= 0 && ga.nz[r][z] < 12) ga.scaled = 0;
     const size_t shm = dl_ef_gram_shared_doubles(obs, ga.xr) * sizeof(double);
     if (shm > 146 * 1024) return false;   // (the kernel also holds 10 KB of static LDS: parameter rows, prior table and prior terms of the fused finalize)
     static size_t shm_set = 0;
