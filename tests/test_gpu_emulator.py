@@ -200,8 +200,14 @@ def test_gram_finalize_one_lane_per_point():
             wide = ctx.eval_batch_host(theta, return_solved=True)      # ... 16 lanes per point
         finally:
             os.environ.pop('DL_NO_FUSED_SOLVE', None); os.environ.pop('DL_FM_NO_LANE_SOLVE', None)
-        assert np.array_equal(fast[2], separate[2])
+        os.environ['DL_NO_SCALED_ROW0'] = '1'                           # every monomial group with a full epilogue on the X rows (the form before the register path of row 0)
+        try:
+            plain = ctx.eval_batch_host(theta, return_solved=True)
+        finally:
+            os.environ.pop('DL_NO_SCALED_ROW0', None)
+        assert np.array_equal(fast[2], separate[2]) and np.array_equal(fast[2], plain[2])
         ok = fast[2] == 0
+        assert (np.abs(fast[0][ok] - plain[0][ok]) <= 1e-11 * np.maximum(1., np.abs(plain[0][ok]))).all() and np.allclose(fast[3][ok], plain[3][ok], rtol=1e-9, atol=1e-11)
         assert (np.abs(fast[0][ok] - separate[0][ok]) <= 1e-13 * np.maximum(1., np.abs(separate[0][ok]))).all() and np.allclose(fast[3][ok], separate[3][ok], rtol=1e-12, atol=1e-13)
         assert np.allclose(fast[1][ok], separate[1][ok], rtol=1e-13, atol=1e-13)
         assert np.array_equal(fast[2], wide[2]) and fast[2][5] != 0 and fast[2][6] != 0 and (np.delete(fast[2], [5, 6]) == 0).all()
