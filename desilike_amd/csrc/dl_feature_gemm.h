@@ -328,6 +328,32 @@ __device__ __forceinline__ void dl_fg_gram_epilogue_row0(const dl_fg_double4 (&a
     }
 }
 
+// The same main loop for nq = 8 (config 3 after the constant basis function left the loop), completely unrolled, the A operand of the eight steps in registers for the
+// whole phase (it is the same for every group: one batch of LDS reads per wave instead of one read, and one wait, per step).  Unrolled, every use of an operand
+// register waits for exactly the loads it needs; around the back-edge of the rolled loop the compiler waited for ALL outstanding loads (`s_waitcnt vmcnt(0)`) at
+// the top of every trip -- the wave streamed with one step in flight instead of D - 1, which its SIMD partner hides while it streams too, and nobody hides while the
+// partner sits in an epilogue (a wave alone: 60 % of the pipe's rate).
+template <int CNT, int D = 3>
+__device__ __forceinline__ void dl_fg_gram_mainloop_u8(const dl_fg_double2 (&areg)[8], const dl_fg_double2* __restrict__ gw, unsigned lane, int m0, dl_fg_double4 (&acc)[CNT],
+                                                       const DlFgAhead<CNT>& ah) {
+    dl_fg_double2 b[D][CNT];
+#define DL_FG_LOAD(bb, qq) { _Pragma("unroll") for (int i = 0; i < CNT; ++i) bb[i] = gw[(size_t)((qq) * DL_FG_NM + m0 + i) * 64 + lane]; }
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) { acc[i] = (dl_fg_double4){ah.c0[i], ah.c0[i], ah.c0[i], ah.c0[i]}; b[0][i] = ah.b0[i]; b[1][i] = ah.b1[i]; }
+#pragma unroll
+    for (int d = 2; d < D - 1; ++d) DL_FG_LOAD(b[d], d)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (q + D - 1 < 8) DL_FG_LOAD(b[(q + D - 1) % D], q + D - 1)
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q].x, b[q % D][i].x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q].y, b[q % D][i].y, acc[i], 0, 0, 0);
+        }
+    }
+#undef DL_FG_LOAD
+}
+
 // rows of the lane's four points += sum over the group's monomials (m0 even); first: the partial rows start from zero; last: the constant part of every row is added.
 // Row 0 (the residual) is dense in the monomials.  The derivative rows are not: the row of a solved alpha* / sn* touches one or two monomials (gr->nz), the other
 // seventeen entries of its monomial row are exact zeros -- multiplying them was 4/5 of the epilogue's LDS reads and FMAs (7 us of the kernel; the LDS pipe of the CU
@@ -447,27 +473,30 @@ __device__ __forceinline__ void dl_fg_compute_gram(const double* lds, int stride
         // groups L1 = monomials 0-5, L2 = 6-11 (row 0 only, into registers), T = 12-18 (the X rows, first and last at once).  Waves 0-3: T, L1, L2; their SIMD partners:
         // L1, T, L2 -- the one long epilogue of a wave runs beside a main loop of its partner, and the last thing either does is a short one
         double w0[4] = {0., 0., 0., 0.};
+        dl_fg_double2 areg[8];   // A operand of the eight steps: read before every main loop (not kept across the long epilogue: registers)
+#define DL_FG_AREG { _Pragma("unroll") for (int q = 0; q < 8; ++q) areg[q] = *reinterpret_cast<const dl_fg_double2*>(arow + 8 * q); }
+#define DL_FG_MAIN(CNT_, D_, M0_, ACC_, AH_) { DL_FG_AREG dl_fg_gram_mainloop_u8<CNT_, D_>(areg, gw, ulane, M0_, ACC_, AH_); }   // (nq = 8: the launcher's condition for this path)
         DlFgAhead<6> l1, l2;
         DlFgAhead<7> t;
         if (wave < 4) {
             dl_fg_gram_request<7>(t, gw, ulane, nq, 12, gbias, ucol);
             after_request();   // (barrier: the records of the forward pass are complete)
-            { dl_fg_double4 acc[7]; dl_fg_gram_mainloop<7, 3>(arow, gw, ulane, nq, 12, acc, t); DL_FG_STAMP(2) DL_FG_CST
+            { dl_fg_double4 acc[7]; DL_FG_MAIN(7, 3, 12, acc, t) DL_FG_STAMP(2) DL_FG_CST
               dl_fg_gram_epilogue<7>(acc, lds, stride, nb_pad, R, 12, true, true, gr, cbase, g, cst); }
             dl_fg_gram_request<6>(l1, gw, ulane, nq, 0, gbias, ucol);   // (after the long epilogue: the registers it needs are those of a request)
             DL_FG_STAMP(3)
-            { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6, 3>(arow, gw, ulane, nq, 0, acc, l1); dl_fg_gram_request<6>(l2, gw, ulane, nq, 6, gbias, ucol);
+            { dl_fg_double4 acc[6]; DL_FG_MAIN(6, 3, 0, acc, l1) dl_fg_gram_request<6>(l2, gw, ulane, nq, 6, gbias, ucol);
               dl_fg_gram_epilogue_row0<6>(acc, lds, stride, nb_pad, 0, g, w0); }
         } else {
             dl_fg_gram_request<6>(l1, gw, ulane, nq, 0, gbias, ucol);
             after_request();
-            { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6, 3>(arow, gw, ulane, nq, 0, acc, l1); dl_fg_gram_request<7>(t, gw, ulane, nq, 12, gbias, ucol);
+            { dl_fg_double4 acc[6]; DL_FG_MAIN(6, 3, 0, acc, l1) dl_fg_gram_request<7>(t, gw, ulane, nq, 12, gbias, ucol);
               dl_fg_gram_epilogue_row0<6>(acc, lds, stride, nb_pad, 0, g, w0); }
-            { dl_fg_double4 acc[7]; dl_fg_gram_mainloop<7, 3>(arow, gw, ulane, nq, 12, acc, t); DL_FG_CST
+            { dl_fg_double4 acc[7]; DL_FG_MAIN(7, 3, 12, acc, t) DL_FG_CST
               dl_fg_gram_epilogue<7>(acc, lds, stride, nb_pad, R, 12, true, true, gr, cbase, g, cst); }
             dl_fg_gram_request<6>(l2, gw, ulane, nq, 6, gbias, ucol);
         }
-        { dl_fg_double4 acc[6]; dl_fg_gram_mainloop<6, 4>(arow, gw, ulane, nq, 6, acc, l2); DL_FG_STAMP(4) dl_fg_gram_epilogue_row0<6>(acc, lds, stride, nb_pad, 6, g, w0); }
+        { dl_fg_double4 acc[6]; DL_FG_MAIN(6, 4, 6, acc, l2) DL_FG_STAMP(4) dl_fg_gram_epilogue_row0<6>(acc, lds, stride, nb_pad, 6, g, w0); }
         {   // row 0 of the lane's four points: what the T epilogue wrote + the register part
             double* xr0 = gr->x + (size_t)g * gr->xr * DL_FG_XLD + cbase + (size_t)gr->row_of[0] * DL_FG_XLD;
             const size_t xpt = (size_t)4 * gr->xr * DL_FG_XLD;
@@ -477,6 +506,8 @@ __device__ __forceinline__ void dl_fg_compute_gram(const double* lds, int stride
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) xr0[rr * xpt] = v[rr] + w0[rr];
         }
+#undef DL_FG_AREG
+#undef DL_FG_MAIN
     } else if (wave < 4) {
         DlFgAhead<8> a0; DlFgAhead<6> a1; DlFgAhead<5> a2;
         dl_fg_gram_request<8>(a0, gw, ulane, nq, 0, gbias, ucol);

@@ -882,7 +882,8 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
     }
     // every derivative row on monomials 12-18 (the solved alpha* / sn* of the velocileptors order): monomials 0-11 feed row 0 only, through registers (DL_NO_SCALED_ROW0=1: three
     // full epilogues per wave, the form before; read at every launch: the tests compare)
-    ga.scaled = DL_FG_NM == 19 && obs.mono_mode != 0 && !getenv("DL_NO_SCALED_ROW0");
+    // (and eight k-step pairs in the main loops -- 64 hidden units + the constant basis function that starts the accumulators: that form is completely unrolled)
+    ga.scaled = DL_FG_NM == 19 && obs.mono_mode != 0 && obs.eng[0].type == 0 && obs.n_basis == 65 && obs.nb_pad == 72 && !getenv("DL_NO_SCALED_ROW0");
     for (int r = 1; r < 6; ++r)
         for (int z = 0; z < 2; ++z) if (ga.nz[r][z] >= 0 && ga.nz[r][z] < 12) ga.scaled = 0;
     const size_t shm = dl_ef_gram_shared_doubles(obs, ga.xr) * sizeof(double);
