@@ -215,6 +215,9 @@ def test_gram_finalize_one_lane_per_point():
         assert (np.abs(fast[0][good] - wide[0][good]) <= 1e-12 * np.maximum(1., np.abs(wide[0][good]))).all(), np.abs(fast[0][good] - wide[0][good]).max()
         assert np.allclose(fast[1][good], wide[1][good], rtol=1e-12, atol=1e-12)
         assert np.allclose(fast[3][good], wide[3][good], rtol=1e-9, atol=1e-11)
+        # the samplers' entry point (log-posterior with -inf where a sampler rejects the point, samplers/base.py:185-191) through the fused tail
+        logpost, st = ctx.eval_logposterior_host(theta)
+        assert np.array_equal(st, fast[2]) and (logpost[~good] == -np.inf).all() and np.allclose(logpost[good], fast[0][good] + fast[1][good], rtol=1e-14, atol=0.)
         nsol = len(solved)
         scales = np.array([like.all_params[name].prior.scale for name in solved])
         mask = np.array([derived is None or derived[name] == '.marg' for name in solved])

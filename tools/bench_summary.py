@@ -12,7 +12,7 @@ for c in others:
     print('  {:<60s} {:.3e} evals/s  frac {:.3f}  oracle err {:.1e}'.format(c['workload'][:60], c['value'], c['roofline']['frac'], c['oracle_check']['max_rel_err_vs_oracle']))
 if 'config5_strong' in d: print('config 5: {:.2f} us per update ({:.3e} evals/s), oracle err {:.1e}'.format(d['config5_strong']['us_per_update'], d['config5_strong']['value'], d['config5_strong']['oracle_check']['max_rel_err_vs_oracle']))
 if 'chains_weak' in d: print('chains_weak: {:.3e} evals/s'.format(d['chains_weak']['value']))
-print('cpu_baseline: {:.1f} evals/s on {} core(s)'.format(d['cpu_baseline']['value'], d['cpu_baseline']['cores']))
+if d.get('cpu_baseline'): print('cpu_baseline: {:.1f} evals/s on {} core(s)'.format(d['cpu_baseline']['value'], d['cpu_baseline']['cores']))
 if d.get('mh_chains') and 'per_config' in d['mh_chains']:
     print('mh_chains: ' + ', '.join('{:d} x {:d}: {:.1f} us per try ({:.2f} M evals/s, acceptance {:.2f})'.format(e['chains'], e['vectorize'], e['us_per_try'], e['value'] / 1e6, e['mean_acceptance_rate'])
                                     for e in d['mh_chains']['per_config']))
