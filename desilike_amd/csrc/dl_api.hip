@@ -554,7 +554,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         // marginalised fits on one emulated observable: Gram-matrix epilogue in the fused kernel -- the residual rows never reach memory (DL_NO_GRAM_EPILOGUE=1: rows + Gram in the finalize)
         bool gram_done = false, finalized_in_kernel = false;
         static const bool gram_epilogue = !getenv("DL_NO_GRAM_EPILOGUE");
-        if (feat_path && emu_fused && gram_epilogue && ctx->n_obs == 1 && ctx->n_solved > 0 && ctx->N_pad == 128) {
+        // (also without solved parameters: X is the residual row alone, chi2 = G[0][0] and the finalize -- priors, status -- runs in the kernel's tail: one launch instead of two)
+        if (feat_path && emu_fused && gram_epilogue && ctx->n_obs == 1 && ctx->N_pad == 128) {
             DlGramFinalize fin = {ctx->priors_dev, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr,
                                   solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr, hessian_dev ? hessian_dev + (size_t)b0 * ctx->n_solved * ctx->n_solved : nullptr,
                                   post_mode, false};

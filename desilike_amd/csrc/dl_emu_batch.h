@@ -629,6 +629,7 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const dou
             bool ok = true;
             const double* gl = gr.x + (size_t)lane * gr.xr * DL_FG_XLD;
             switch (sv.mg.n_s) {
+                case 0: ll = -0.5 * gl[0]; break;   // no solved parameters: chi2 = |dt|^2 = G[0][0]
                 case 1: dl_ef_solve_point<1>(gl, sv, b, ll, lps, ok); break;
                 case 2: dl_ef_solve_point<2>(gl, sv, b, ll, lps, ok); break;
                 case 3: dl_ef_solve_point<3>(gl, sv, b, ll, lps, ok); break;

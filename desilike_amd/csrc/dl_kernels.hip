@@ -862,7 +862,9 @@ void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_
 bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, const double* bias, const DlMargDev& mg, int n_valid,
                                      double* gram, hipStream_t stream, DlGramFinalize* fin) {
     const int R = 1 + obs.n_var;
-    if (R > 6 || mg.n_s < 1 || mg.n_s > 15 || n_valid > 128) return false;
+    if (R > 6 || mg.n_s < 0 || mg.n_s > 15 || n_valid > 128) return false;
+    // no solved parameters: only with the finalize in the kernel's tail (there is no separate finalize on a 1 x 1 Gram matrix)
+    if (mg.n_s == 0 && (fin == nullptr || getenv("DL_NO_FUSED_SOLVE") || getenv("DL_NO_GRAM_PLAIN"))) return false;
     DlEfGramArgs ga;
     std::memset(&ga, 0, sizeof(ga));
     ga.xr = 1 + mg.n_s; ga.gram = gram;

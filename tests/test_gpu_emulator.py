@@ -241,6 +241,34 @@ def test_gram_finalize_one_lane_per_point():
                 assert np.allclose(dfast[4][i - 7], sol['likelihood_hessian'], rtol=1e-9, atol=1e-11 * scale_h)
 
 
+def test_unmarginalised_likelihood_in_one_launch():
+    """No solved parameters: the fused emulator / feature-GEMM kernel keeps the residual row in LDS, chi2 = G[0][0], priors and status in its tail (one launch) -- against the
+    two-launch form (residual rows to memory + finalize, DL_NO_GRAM_PLAIN=1) and against the oracle; ragged batch, NaN and out-of-prior rows."""
+    import os
+    g, like, pt, theory, solved = make_mlp_likelihood(marg=False)
+    names = like.varied_params.names()
+    rng = np.random.RandomState(5)
+    theta = np.column_stack([np.clip(param.ref.sample(size=2000 + 3, random_state=rng), *param.prior.limits) for param in like.varied_params])
+    theta[11, 2] = np.nan
+    theta[12, 0] = like.varied_params[names[0]].prior.limits[0] - 1.
+    ctx = like._get_context()
+    one = ctx.eval_batch_host(theta)
+    post, st = ctx.eval_logposterior_host(theta)
+    os.environ['DL_NO_GRAM_PLAIN'] = '1'
+    try:
+        two = ctx.eval_batch_host(theta)
+    finally:
+        del os.environ['DL_NO_GRAM_PLAIN']
+    assert np.array_equal(one[2], two[2]) and np.array_equal(st, one[2]) and one[2][11] != 0 and one[2][12] != 0 and (np.delete(one[2], [11, 12]) == 0).all()
+    good = one[2] == 0
+    assert (np.abs(one[0][good] - two[0][good]) <= 1e-11 * np.maximum(1., np.abs(two[0][good]))).all(), np.abs(one[0][good] - two[0][good]).max()
+    assert np.allclose(one[1][good], two[1][good], rtol=1e-13, atol=1e-13) and (post[~good] == -np.inf).all() and np.allclose(post[good], one[0][good] + one[1][good], rtol=1e-14, atol=0.)
+    for i in (0, 999, 2002):
+        ref = oracle_flat(like, pt, theory, theta[i], names, {})
+        logl = orc.gaussian_loglikelihood(ref, like.flatdata, like.precision)[0]
+        assert abs(one[0][i] - logl) <= 1e-10 * max(1., abs(logl))
+
+
 # north star: 1e-10 on logL -- also for the analytically marginalised value
 MARG_TOL = 1e-10
 
