@@ -513,6 +513,7 @@ struct DlEfGramArgs {
     unsigned long long* stamps;        // DL_EF_STAMPS diagnostics
     int nz[6][2];                      // support of the derivative rows (dl_velocileptors_row_support)
     int scaled;                        // DlFgGram::scaled
+    int no_early;                      // DL_EF_NO_EARLY_THETA=1 (tests): the path of more than 32 sampled parameters -- theta rows and prior table read from memory where they are used
 };
 // The marginalised finalize in the tail of the same kernel (n_s <= 7): the Gram blocks of the workgroup's 16 points stay in LDS, lanes 0-15 of wave 0 solve a point
 // each (dl_marg_solve.h) while lanes 0-15 of wave 1 sum the priors of the same points; the other waves have left.  Against a separate launch (4.3 us, of which a
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(512) void dl_emulated_feature_gram_kernel(const dou
         asm volatile("; kernel arguments touched: %0" :: "s"(touched));
     }
     const int64_t p0 = (int64_t)blockIdx.x * DL_EB_PTS;
-    const bool th_early = n_params <= 32;
+    const bool th_early = n_params <= 32 && !ga.no_early;
     double th_val = 0.;
     if (th_early) {
         const int pt = threadIdx.x >> 5, j = threadIdx.x & 31;

@@ -888,6 +888,7 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
     ga.scaled = DL_FG_NM == 19 && obs.mono_mode != 0 && obs.eng[0].type == 0 && obs.n_basis == 65 && obs.nb_pad == 72 && !getenv("DL_NO_SCALED_ROW0");
     for (int r = 1; r < 6; ++r)
         for (int z = 0; z < 2; ++z) if (ga.nz[r][z] >= 0 && ga.nz[r][z] < 12) ga.scaled = 0;
+    ga.no_early = getenv("DL_EF_NO_EARLY_THETA") != nullptr;
     const size_t shm = dl_ef_gram_shared_doubles(obs, ga.xr) * sizeof(double);
     if (shm > 146 * 1024) return false;   // (the kernel also holds 10 KB of static LDS: parameter rows, prior table and prior terms of the fused finalize)
     static size_t shm_set = 0;

@@ -205,6 +205,12 @@ def test_gram_finalize_one_lane_per_point():
             plain = ctx.eval_batch_host(theta, return_solved=True)
         finally:
             os.environ.pop('DL_NO_SCALED_ROW0', None)
+        os.environ['DL_EF_NO_EARLY_THETA'] = '1'                        # the code path of more than 32 sampled parameters (theta / priors from memory where they are used)
+        try:
+            late = ctx.eval_batch_host(theta, return_solved=True)
+        finally:
+            os.environ.pop('DL_EF_NO_EARLY_THETA', None)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(fast, late))
         assert np.array_equal(fast[2], separate[2]) and np.array_equal(fast[2], plain[2])
         ok = fast[2] == 0
         assert (np.abs(fast[0][ok] - plain[0][ok]) <= 1e-11 * np.maximum(1., np.abs(plain[0][ok]))).all() and np.allclose(fast[3][ok], plain[3][ok], rtol=1e-9, atol=1e-11)
