@@ -360,8 +360,7 @@ __device__ __forceinline__ void dl_fg_gram_mainloop_u8(const dl_fg_double2 (&are
 // was the bound: 240 16-byte broadcast reads per wave).  The sums run over the same monomials in the same order: bit-identical results.
 template <int CNT>
 __device__ __forceinline__ void dl_fg_gram_epilogue(const dl_fg_double4 (&acc)[CNT], const double* lds, int stride, int nb_pad, int R, int m0, bool first, bool last,
-                                                    const DlFgGram* gr, int cbase, int g, const double (&cst)[6], const double* row0_start = nullptr) {
-    // row0_start [4]: with `first`, row 0 of the lane's four points starts from these values (the scaled part of the sum) instead of zero
+                                                    const DlFgGram* gr, int cbase, int g, const double (&cst)[6]) {
     constexpr int NP = (CNT + 1) / 2;
     double* xb0 = gr->x + (size_t)g * gr->xr * DL_FG_XLD + cbase;                    // X rows of point g (+ 4 rr: 4 xr DL_FG_XLD doubles further)
     const size_t xpt = (size_t)4 * gr->xr * DL_FG_XLD;
@@ -378,7 +377,7 @@ __device__ __forceinline__ void dl_fg_gram_epilogue(const dl_fg_double4 (&acc)[C
         const double c0 = cst[0];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            double w = first ? (row0_start ? row0_start[rr] : 0.) : v[rr];
+            double w = first ? 0. : v[rr];
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 w = fma(mm[rr][j].x, acc[2 * j][rr], w);
