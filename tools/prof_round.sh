@@ -10,7 +10,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 timeout 300 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_steps20.json 2>> $OUT/${TAG}_bench.err     # the driver's command
-B="$R/bench.py --no-cpu-baseline --config5-iterations 0 --no-other-configs --no-streams --chains-iterations 0 --sustained-seconds 0"
+# --no-host-call: the host-array leg launches ~2000 short (1 / 16 / 256-point) instances of the same kernels; with it the trace and every PMC average are diluted (round-4 verdict)
+B="$R/bench.py --no-cpu-baseline --config5-iterations 0 --no-other-configs --no-streams --no-host-call --chains-iterations 0 --sustained-seconds 0"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python3 $B --steps 200 --warmup 20 > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $TAG -- python3 $B --no-events --steps 20 --warmup 5 --prewarm-ms 20 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $TAG -- python3 $B --no-events --steps 20 --warmup 5 --prewarm-ms 20 > /dev/null 2>&1
