@@ -48,6 +48,8 @@ struct dl_ctx {
     bool feat_ok = false;
     int64_t feat_ld = 0;             // doubles per point record (all observables)
     std::vector<double*> gfrag_dev;  // per observable: whitened folded operator in MFMA fragment order
+    std::vector<int> stk_steps;      // per observable: operand steps per column block of a stacked table engine (dl_emu_stacked.h), 0: not stacked
+    bool any_stacked = false;
     double* feat_ws = nullptr;       // [cap, feat_ld]
     // workspaces (grown on demand, never inside dl_eval_* once large enough)
     int64_t cap = 0;
@@ -301,11 +303,39 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     for (int i = 0; i < ctx->n_obs && ctx->feat_ok; ++i) {
         const DlObsDev& d = ctx->obs[i].dev;
         if (d.theory != 3 || d.n_mono != DL_N_MONO || d.n_pass != 0) ctx->feat_ok = false;
+        else if (d.eng[0].type == 2 && !dl_emulated_stacked_ok(d)) ctx->feat_ok = false;   // (a stack that does not fit the LDS of the batched kernel: the general path)
     }
     if (ctx->feat_ok) {
         int64_t off = 0;
         for (int i = 0; i < ctx->n_obs; ++i) {
             DlObsDev& d = ctx->obs[i].dev;
+            ctx->stk_steps.push_back(0);
+            if (d.eng[0].type == 2) {
+                // stacked table engine: per column block, group by group: [k / 8][monomial][lane = col + 16 g][e], k = 8 q + 2 g + e < K_g, column of the theory vector col_g + k nm + mo + i
+                ctx->any_stacked = true;
+                const int njb = ctx->N_pad / 16, H = d.eng[0].widths[d.eng[0].n_layers];
+                const double* table = arena.data.data() + ctx->obs[i].off_stk[0];
+                int steps = 0;
+                for (int gi = 0; gi < d.stk.n_groups; ++gi) steps += (((int)table[gi * DL_STK_REC + 1] - (int)table[gi * DL_STK_REC]) * H + 1 + 7) / 8 * ((int)table[gi * DL_STK_REC + 3] - (int)table[gi * DL_STK_REC + 2]);
+                std::vector<double> gf((size_t)njb * steps * 64 * 2, 0.);
+                for (int jb = 0; jb < njb; ++jb)
+                    for (int gi = 0; gi < d.stk.n_groups; ++gi) {
+                        const double* rec = table + (size_t)gi * DL_STK_REC;
+                        const int K = ((int)rec[1] - (int)rec[0]) * H + 1, cnt = (int)rec[3] - (int)rec[2], col = (int)rec[4], nm = (int)rec[5], mo = (int)rec[6], kq = (int)rec[7];
+                        for (int q = 0; q < (K + 7) / 8; ++q)
+                            for (int m = 0; m < cnt; ++m)
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int e = 0; e < 2; ++e) {
+                                        const int j = jb * 16 + (lane & 15), h = 8 * q + 2 * (lane >> 4) + e;
+                                        if (h < K) gf[(((size_t)jb * steps + kq + (size_t)q * cnt + m) * 64 + lane) * 2 + e] = wt_white[(size_t)j * ctx->K_pad + d.col_offset + col + (size_t)h * nm + mo + m];
+                                    }
+                    }
+                ctx->stk_steps.back() = steps;
+                d.nb_pad = 8; d.feat_off = off;
+                off += 8;
+                gfrag_host.push_back(std::move(gf));
+                continue;
+            }
             d.nb_pad = round_up(d.n_basis, 8);
             d.feat_off = off;
             off += d.nb_pad + (int64_t)17 * DL_FG_MONO_LD;   // records sized for the largest number of rows (1 + DL_MAX_SOLVED); n_var is fixed below
@@ -524,7 +554,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         bool need_flat = ctx->any_transform || flattheory_dev != nullptr;
         // emulated (separable) theories: the theory kernel writes only the factors (basis, monomial rows), the feature GEMM turns them into residual rows
         const bool feat_path = ctx->feat_ok && !need_flat;
-        static const bool emu_fused = !getenv("DL_NO_EMU_FUSED");   // DL_NO_EMU_FUSED=1: theory kernel -> point records in HBM -> feature GEMM (two launches)
+        static const bool emu_fused_env = !getenv("DL_NO_EMU_FUSED");   // DL_NO_EMU_FUSED=1: theory kernel -> point records in HBM -> feature GEMM (two launches)
+        const bool emu_fused = emu_fused_env || ctx->any_stacked;         // (a stacked table engine has the one-launch form only)
         static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 2048;   // above: split-K slabs + finalize win (measured: 4096 rows 40 vs 49 us; 1024 rows 18 vs 13 us)
         const bool chi2_path = !feat_path && !ctx->any_transform && ctx->n_solved == 0 && nb <= chi2_max_rows;
         // the chi2 GEMM consumes row block mb (32 points; the LDS-DMA GEMM: 64) on XCD mb % 8: have the theory kernel produce it there (power then waits in that XCD's L2:
@@ -565,7 +596,8 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         }
         if (feat_path && !gram_done) {
             for (int i = 0; i < ctx->n_obs; ++i) {
-                if (emu_fused) dl_launch_emulated_feature(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, stream);
+                if (ctx->stk_steps[i]) dl_launch_emulated_stacked(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, ctx->stk_steps[i], stream);
+                else if (emu_fused) dl_launch_emulated_feature(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, stream);
                 else dl_launch_feature_gemm(ctx->feat_ws, ctx->feat_ld, ctx->obs_kernarg[i].feat_off, ctx->obs_kernarg[i].nb_pad, R, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad,
                                             ctx->N_pad, nb, i > 0, stream);
             }
@@ -667,12 +699,14 @@ int dl_eval_fisher(dl_ctx* ctx, const double* centers_dev, const double* steps_d
         int n_slabs = 1, cps = 0;
         int64_t slab_stride = 0;
         const double* bias = nullptr;
-        static const bool emu_fused = !getenv("DL_NO_EMU_FUSED");
+        static const bool emu_fused_env = !getenv("DL_NO_EMU_FUSED");
+        const bool emu_fused = emu_fused_env || ctx->any_stacked;
         if (ctx->feat_ok) {
             // emulated (separable) theories: residual rows straight from the feature GEMM
             if (!emu_fused) dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, ctx->feat_ws, ctx->feat_ld, 0);
             for (int i = 0; i < ctx->n_obs; ++i) {
-                if (emu_fused) dl_launch_emulated_feature(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, stream);
+                if (ctx->stk_steps[i]) dl_launch_emulated_stacked(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, ctx->stk_steps[i], stream);
+                else if (emu_fused) dl_launch_emulated_feature(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, stream);
                 else dl_launch_feature_gemm(ctx->feat_ws, ctx->feat_ld, ctx->obs_kernarg[i].feat_off, ctx->obs_kernarg[i].nb_pad, 1, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad,
                                             ctx->N_pad, nb, i > 0, stream);
             }

@@ -51,6 +51,9 @@
 #define DL_MAX_WIDTH 256   // hidden units per layer (one thread each)
 #define DL_N_VPARS 11      // velocileptors 'pars': b1 b2 bs b3 alpha0 alpha2 alpha4 alpha6 sn0 sn2 sn4 (full_shape.py:1184)
 #define DL_N_MONO 19       // bias monomials (full_shape.py:1185)
+#define DL_STK_REC 8       // doubles per group record of the stacked table engine (DlObsDev::Stack)
+#define DL_STK_MAX_GROUPS 8
+#define DL_STK_MAX_MONO 10  // monomials per device group (accumulator tiles of the feature GEMM)
 #define DL_MAX_ML 40       // multiplicative wiggle terms of the flexible BAO model (bao.py:310-322: up to 12 nodes per multipole)
 #define DL_PNG_MAX_MU 48   // mu nodes of the PNG kernel (its tracer-velocity variant integrates 81 trapezoid nodes on [-1, 1]: 41 after folding)
 #define DL_MAX_BAND 16     // bands of the velocity-divergence template
@@ -140,6 +143,15 @@ struct DlObsDev {
         const double *weights;                 // MLP: per layer kernel [in, out] then bias [out], packed
         const double *center, *powers, *coef;  // Taylor: center [n_x], powers [n_terms, n_x], coef [n_terms] (scalar engines)
     } eng[3];
+    // stacked table engine (eng[0].type == 2; the layout the reference ships, emulators/conversion.py:44-98): SEVERAL networks with the same hidden layers
+    // (eng[0].widths = n_x, hidden...; eng[0].weights + t * trunk_doubles: network t), in groups: group g = networks [tb, te) whose folded final layers feed the
+    // bias monomials [m0, m1) (the engines '11' / 'loop' / 'ct' / 'st' x (z, ell) stacks), times an amplitude that is log-linear in the inputs (conversion.py:88-92)
+    struct Stack {
+        int32_t n_groups, n_trunks, trunk_doubles, max_k;   // max_k: largest number of basis functions of a group, (te - tb) * H + 1
+        const double* table;   // [n_groups][DL_STK_REC] as doubles: tb, te, m0, m1, col (first column of the group's block in the theory vector), nm (monomials per basis
+                               //   function in that block: the column stride), mo (m0 - first monomial of the block), kq (first operand step of the group in a column block)
+        const double* scale;   // [n_groups][n_x + 1]: log amplitude = scale[g][n_x] + sum_j scale[g][j] x_j
+    } stk;
     const double *coef_w, *coef_n;         // [n_t, 4] interval polynomials of the wiggle P_dd - P_now and of P_now (fixed BAO template)
     const double *pknow_k;                 // [n_kin] P_now at the fiducial k (bao.py:137)
     const double *kin, *lkin, *mu, *wmu;          // [n_kin], log10(kin) [n_kin], [n_mu], [n_ell * n_mu]
@@ -1152,6 +1164,9 @@ DL_HD void dl_store_with_pass(int tid, int nthr, const DlObsDev& o, const double
 // ------------------------------------------------------------------------------------------------------------------------
 enum { DL_EM_X = 0, DL_EM_BUF0 = DL_MAX_X, DL_EM_BUF1 = DL_EM_BUF0 + DL_MAX_WIDTH + 8, DL_EM_SCAL = DL_EM_BUF1 + DL_MAX_WIDTH + 8, DL_EM_MONO = DL_EM_SCAL + 4 };
 DL_HD size_t dl_emu_shared_doubles(int n_var) { return DL_EM_MONO + (size_t)(1 + n_var) * DL_N_MONO; }
+DL_HD size_t dl_emu_shared_doubles_obs(const DlObsDev& o) {   // (stacked table engine: + the basis of one group + the scaled inputs)
+    return dl_emu_shared_doubles(o.n_var) + (o.eng[0].type == 2 ? (size_t)o.stk.max_k + 8 + DL_MAX_X : 0);
+}
 
 DL_HD double dl_activation(int act, double v) {
     if (act == 0) return v / (1. + exp(-v));      // silu, conversion.py:29
@@ -1333,6 +1348,70 @@ DL_HD double* dl_emu_engine(const DlObsDev& o, int ie, double* lds) {
     return nxt;
 }
 
+// Stacked table engine (emulators/conversion.py:44-98), one point, generic path (the theory vector itself; the batched MFMA form is dl_emu_stacked.h): group by group,
+// the networks of the group one after the other (a thread per unit), then columns col + h nm + (m - mfirst) = amplitude_g basis_h mono_m.  Called after the scalar
+// engines (lds[DL_EM_SCAL + 1, 2]) and the inputs (lds[DL_EM_X ..]) are in place.
+DL_HD void dl_emu_point_stacked(const DlObsDev& o, const double* th, double* lds, double* row0, int64_t ld) {
+    const DlObsDev::Engine& e = o.eng[0];
+    double* x = lds + DL_EM_X;
+    double* mono = lds + DL_EM_MONO;
+    double* basis = mono + (size_t)(1 + o.n_var) * DL_N_MONO;        // [max_k + 8]
+    double* xs = basis + o.stk.max_k + 8;                            // [DL_MAX_X] scaled inputs (conversion.py:75-77), the same for every network
+    const int H = e.widths[e.n_layers];
+    DL_PAR_BEGIN
+        if (tid < o.n_x) xs[tid] = (x[tid] - e.xlo[tid]) * e.xinv[tid];
+        if (tid == 0) {
+            const double sigma8 = o.eng[1].type >= 0 ? lds[DL_EM_SCAL + 1] : o.eng[1].cst, fsigma8 = o.eng[2].type >= 0 ? lds[DL_EM_SCAL + 2] : o.eng[2].cst;
+            if (o.mono_mode == 0) mono[0] = 1.;
+            else dl_velocileptors_monomials(o, th, sigma8, fsigma8, mono);
+        }
+    DL_PAR_END
+    int tb_prev = -1, te_prev = -1;
+    for (int gi = 0; gi < o.stk.n_groups; ++gi) {
+        const double* rec = o.stk.table + (size_t)gi * DL_STK_REC;
+        const int tb = (int)rec[0], te = (int)rec[1], m0 = (int)rec[2], m1 = (int)rec[3], col = (int)rec[4], nm = (int)rec[5], mo = (int)rec[6];
+        const int K = (te - tb) * H + 1;
+        if (tb != tb_prev || te != te_prev) {
+            for (int t = tb; t < te; ++t) {
+                double* cur = lds + DL_EM_BUF0;
+                double* nxt = lds + DL_EM_BUF1;
+                const double* w = e.weights + (size_t)t * o.stk.trunk_doubles;
+                for (int layer = 0; layer < e.n_layers; ++layer) {
+                    const double* in = layer == 0 ? xs : cur;
+                    DL_PAR_BEGIN
+                        dl_emu_layer(tid, e, layer, w, in, nxt, true);
+                    DL_PAR_END
+                    w += (size_t)e.widths[layer] * e.widths[layer + 1] + e.widths[layer + 1];
+                    double* sw = cur; cur = nxt; nxt = sw;
+                }
+                DL_PAR_BEGIN
+                    if (tid < H) basis[(size_t)(t - tb) * H + tid] = cur[tid];
+                DL_PAR_END
+            }
+            DL_PAR_BEGIN
+                if (tid == 0) basis[K - 1] = 1.;     // the constant parts of the folded final layers of the group, summed on the host
+            DL_PAR_END
+            tb_prev = tb; te_prev = te;
+        }
+        double la = o.stk.scale[(size_t)gi * (o.n_x + 1) + o.n_x];
+        for (int j = 0; j < o.n_x; ++j) la = fma(o.stk.scale[(size_t)gi * (o.n_x + 1) + j], x[j], la);
+        const double amp = la == 0. ? 1. : exp(la);
+        DL_PAR_BEGIN
+            const int cnt = m1 - m0;
+            for (int idx = tid; idx < K * cnt; idx += DL_FS_THREADS) {
+                const int h = idx / cnt, mi = idx - h * cnt;
+                const double bh = amp * basis[h];
+                const size_t c = (size_t)col + (size_t)h * nm + mo + mi;
+                row0[c] = bh * mono[m0 + mi];
+                for (int v = 0; v < o.n_var; ++v) row0[(size_t)(1 + v) * ld + c] = bh * mono[(size_t)(1 + v) * DL_N_MONO + m0 + mi];
+            }
+        DL_PAR_END
+    }
+    DL_PAR_BEGIN
+        for (int c = tid; c < o.n_pass; c += DL_FS_THREADS) { const int col = (int)o.pass_tab[2 * c]; row0[o.n_in + c] = col >= 0 ? th[col] : o.pass_tab[2 * c + 1]; }
+    DL_PAR_END
+}
+
 // features of one point: row0[(h, m)] = basis_h mono_m, derivative rows (1 + slot)[(h, m)] = basis_h dmono_slot,m, pass-through columns.
 // feat_rec != nullptr (feature path, dl_feature_gemm.h): only the factors are written, basis [nb_pad] then the monomial rows [(1 + n_var)][20].
 DL_HD void dl_emu_point(const DlObsDev& o, const double* th, double* lds, double* row0, int64_t ld, double* feat_rec = nullptr) {
@@ -1347,6 +1426,7 @@ DL_HD void dl_emu_point(const DlObsDev& o, const double* th, double* lds, double
             if (tid == 0) lds[DL_EM_SCAL + ie] = out[0];
         DL_PAR_END
     }
+    if (o.eng[0].type == 2) { dl_emu_point_stacked(o, th, lds, row0, ld); return; }
     double* basis = dl_emu_engine(o, 0, lds);
     double* mono = lds + DL_EM_MONO;
     DL_PAR_BEGIN

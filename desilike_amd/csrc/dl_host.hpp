@@ -65,6 +65,7 @@ struct DlObsHost {
     size_t off_kin, off_lkin, off_mu, off_wmu, off_xt, off_pk, off_th, off_lg, off_ih, off_dlt, off_A, off_nC, off_inv, off_gf, off_gb, off_coef, off_ct, off_sn;
     size_t off_cw, off_cn, off_pknowk, off_ml, off_pass, off_png = 0, off_band = 0;
     size_t off_eng[3][6];   // xlo, xinv, weights, center, powers, coef of each emulator engine
+    size_t off_stk[2] = {0, 0};   // group table, amplitude table of the stacked table engine
     int marg_vp[DL_N_VPARS];
     int marg_pass[DL_MAX_PASS];
     int n_cols() const { return dev.n_in + dev.n_pass; }   // columns of this observable in the theory vector / window matrix
@@ -80,6 +81,7 @@ struct DlObsHost {
             dev.eng[e].xlo = base + off_eng[e][0]; dev.eng[e].xinv = base + off_eng[e][1]; dev.eng[e].weights = base + off_eng[e][2];
             dev.eng[e].center = base + off_eng[e][3]; dev.eng[e].powers = base + off_eng[e][4]; dev.eng[e].coef = base + off_eng[e][5];
         }
+        dev.stk.table = base + off_stk[0]; dev.stk.scale = base + off_stk[1];
     }
 };
 
@@ -283,6 +285,56 @@ inline bool dl_build_emulated_obs(const dl_config& cfg, const std::string& p, in
                 if (widths[en.n_layers] != 1 || yl.size() != 2) { err = q + "scalar engines need one output and ylimits"; return false; }
                 en.ylo = yl[0]; en.yscale = yl[1] - yl[0];
             } else d.n_basis = widths[en.n_layers] + 1;    // last hidden layer + the bias row of the folded final layer
+        } else if (en.type == 2) {
+            // stacked table engine (include/desilike_amd.h; emulators/conversion.py:44-98): networks with the same hidden layers, in groups that feed ranges of bias monomials
+            if (e != 0) { err = q + "only the table engine can be a stack of networks"; return false; }
+            const auto& xl = cfg.F(q + "xlimits");
+            const auto& widths = cfg.I(q + "widths");
+            const auto& w = cfg.F(q + "weights");
+            const auto& groups = cfg.I(q + "groups");
+            const auto& scale = cfg.F(q + "scale");
+            en.act = cfg.i(q + "act", 0);
+            en.n_layers = (int)widths.size() - 1;
+            if ((int)xl.size() != 2 * d.n_x || en.n_layers < 1 || en.n_layers > DL_MAX_LAYERS || widths[0] != d.n_x) { err = q + "inconsistent description of the stacked networks"; return false; }
+            size_t per = 0;
+            for (int l = 0; l <= en.n_layers; ++l) {
+                en.widths[l] = widths[l];
+                if (widths[l] < 1 || widths[l] > 128) { err = q + "stacked networks: layer widths must be in [1, 128]"; return false; }
+                if (l) per += (size_t)widths[l - 1] * widths[l] + widths[l];
+            }
+            const int H = widths[en.n_layers], ng = (int)(groups.size() / 4);
+            if (d.mono_mode == 0) { err = q + "stacked networks feed the velocileptors bias monomials (mono_mode 1 .. 4)"; return false; }
+            if (ng < 1 || groups.size() != (size_t)ng * 4 || scale.size() != (size_t)ng * (d.n_x + 1)) { err = q + "groups i32[n_groups * 4] and scale f64[n_groups * (n_x + 1)] are required"; return false; }
+            int n_trunks = 0;
+            for (int gi = 0; gi < ng; ++gi) n_trunks = std::max(n_trunks, groups[4 * gi + 1]);
+            if (per == 0 || w.size() != per * (size_t)n_trunks) { err = q + "weights size does not match widths x number of networks"; return false; }
+            std::vector<double> table;
+            std::vector<double> amp;
+            int col = 0, kq = 0, max_k = 1, covered[DL_N_MONO] = {0};
+            for (int gi = 0; gi < ng; ++gi) {
+                const int tb = groups[4 * gi], te = groups[4 * gi + 1], m0 = groups[4 * gi + 2], m1 = groups[4 * gi + 3];
+                if (tb < 0 || te < tb || te > n_trunks || m0 < 0 || m1 <= m0 || m1 > DL_N_MONO) { err = q + "groups: (first network, one past the last, first monomial, one past the last) out of range"; return false; }
+                for (int m = m0; m < m1; ++m) { if (covered[m]++) { err = q + "groups: a bias monomial belongs to one group"; return false; } }
+                const int K = (te - tb) * H + 1, nm = m1 - m0;
+                max_k = std::max(max_k, K);
+                // device groups of at most DL_STK_MAX_MONO monomials (the accumulator tiles of the feature GEMM), the same networks
+                for (int ma = m0; ma < m1; ma += DL_STK_MAX_MONO) {
+                    const int mb = std::min(m1, ma + DL_STK_MAX_MONO);
+                    const double rec[DL_STK_REC] = {(double)tb, (double)te, (double)ma, (double)mb, (double)col, (double)nm, (double)(ma - m0), (double)kq};
+                    table.insert(table.end(), rec, rec + DL_STK_REC);
+                    amp.insert(amp.end(), scale.begin() + (size_t)gi * (d.n_x + 1), scale.begin() + (size_t)(gi + 1) * (d.n_x + 1));
+                    kq += (K + 7) / 8 * (mb - ma);
+                }
+                col += K * nm;
+            }
+            d.stk.n_groups = (int)(table.size() / DL_STK_REC);
+            if (d.stk.n_groups > DL_STK_MAX_GROUPS) { err = q + "at most 8 groups of networks"; return false; }
+            d.stk.n_trunks = n_trunks; d.stk.trunk_doubles = (int32_t)per; d.stk.max_k = max_k;
+            d.n_basis = col;    // (columns of the theory vector: n_kin below)
+            xlo.assign(d.n_x, 0.); xinv.assign(d.n_x, 0.);
+            for (int c = 0; c < d.n_x; ++c) { xlo[c] = xl[2 * c]; xinv[c] = 1. / (xl[2 * c + 1] - xl[2 * c]); }
+            weights = w;
+            oh.off_stk[0] = arena.push(table); oh.off_stk[1] = arena.push(amp);
         } else if (en.type == 1) {
             const auto& ce = cfg.F(q + "center");
             const auto& po = cfg.I(q + "powers");
@@ -299,7 +351,7 @@ inline bool dl_build_emulated_obs(const dl_config& cfg, const std::string& p, in
         oh.off_eng[e][0] = arena.push(xlo); oh.off_eng[e][1] = arena.push(xinv); oh.off_eng[e][2] = arena.push(weights);
         oh.off_eng[e][3] = arena.push(center); oh.off_eng[e][4] = arena.push(powers); oh.off_eng[e][5] = arena.push(coef);
     }
-    d.n_ell = 1; d.n_kin = d.n_basis * d.n_mono; d.n_in = d.n_kin; d.ell0 = -1;
+    d.n_ell = 1; d.n_kin = d.eng[0].type == 2 ? d.n_basis : d.n_basis * d.n_mono; d.n_in = d.n_kin; d.ell0 = -1;
     d.n_mu = 0; d.n_t = 0;
     const auto& pin = cfg.F(p + "in.pass");
     d.n_pass = (int)(pin.size() / 2);

@@ -17,6 +17,7 @@
 #include "dl_kernels.h"
 #include "dl_tns.h"
 #include "dl_emu_batch.h"
+#include "dl_emu_stacked.h"
 #include "dl_finalize_part.h"
 #include "dl_marg_solve.h"
 #include "dl_scalar_prefetch.h"
@@ -536,7 +537,7 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
             continue;
         }
         if (obs_host[i].theory == 3) {   // DL_THEORY_EMULATED
-            size_t shm = dl_emu_shared_doubles(obs_host[i].n_var) * sizeof(double);
+            size_t shm = dl_emu_shared_doubles_obs(obs_host[i]) * sizeof(double);
             DL_LAUNCH(dl_emulated_kernel, dim3((unsigned)B), dim3(DL_FS_THREADS), shm, stream, obs_host[i], theta, n_params, power, ld_power, feat, feat_ld);
             continue;
         }
@@ -859,9 +860,20 @@ void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_
                        out, ldo, accumulate);
 }
 
+// stacked table engine (dl_emu_stacked.h): networks of every group + feature GEMM, theta -> residual rows of one observable in one launch
+bool dl_emulated_stacked_ok(const DlObsDev& obs) { return dl_stk_feature_ok(obs); }
+void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
+                                int steps_per_block, hipStream_t stream) {
+    const size_t shm = dl_stk_shared_doubles(obs) * sizeof(double);
+    (void)hipFuncSetAttribute((const void*)dl_emulated_stacked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    DL_LAUNCH(dl_emulated_stacked_kernel, dim3((unsigned)((B + DL_STK_PTS - 1) / DL_STK_PTS), (unsigned)(N_pad / 128)), dim3(512), shm, stream, theta, n_params, B, gfrag, obs,
+                       out, ldo, accumulate, steps_per_block);
+}
+
 bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, const double* bias, const DlMargDev& mg, int n_valid,
                                      double* gram, hipStream_t stream, DlGramFinalize* fin) {
     const int R = 1 + obs.n_var;
+    if (obs.eng[0].type == 2) return false;   // (stacked table engine: rows through dl_launch_emulated_stacked, then the general finalize kernels)
     if (R > 6 || mg.n_s < 0 || mg.n_s > 15 || n_valid > 128) return false;
     // no solved parameters: only with the finalize in the kernel's tail (there is no separate finalize on a 1 x 1 Gram matrix)
     if (mg.n_s == 0 && (fin == nullptr || getenv("DL_NO_FUSED_SOLVE") || getenv("DL_NO_GRAM_PLAIN"))) return false;

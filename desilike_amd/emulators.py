@@ -15,9 +15,12 @@ velocileptors bias monomials, the k-interpolation, the window matrix and the Cho
 they are multiplied together ONCE on the host (:meth:`EmulatedCalculator.fold`); per point the GPU evaluates only the small trunk
 (hidden layers / Taylor monomials), forms the features ``phi[(h, m)] = basis_h * mono_m`` and the fp64 MFMA GEMM applies the folded matrix.
 """
+import re
+
 import numpy as np
 
 ACTIVATIONS = {'silu': 0, 'relu': 1, 'tanh': 2}
+STACKED_COMPONENTS = (('11', 3), ('loop', 9), ('ct', 4), ('st', 3))     # engines of the jaxeffort layout and their bias monomials: jnp.split(pktable, [3, 12, 16], axis=2), emulators/conversion.py:50
 
 
 class TaylorEmulatorEngine(object):
@@ -132,6 +135,39 @@ class MLPEmulatorEngine(object):
         return spec
 
 
+class StackedMLPEmulatorEngine(object):
+    """One engine of the layout the reference ships for its emulated perturbation-theory tables (emulators/conversion.py:44-98, the conversion of the jaxeffort
+    emulators): ONE NETWORK PER (z, ell), all with the same hidden layers, stacked along leading axes (``merge_operations``, conversion.py:58-66).
+
+    Parameters
+    ----------
+    xlimits : [P, 2] -- the engine's one min-max scaler of the inputs (conversion.py:72-75).
+    layers : list of (kernel [n_z, n_ell, in, out], bias [n_z, n_ell, out]).
+    activation : 'silu' | 'relu' | 'tanh' (conversion.py:27-34).
+    ylimits : [n_z, n_ell, n_m, n_k, 2] -- inverse min-max scaler of the outputs (conversion.py:76-79).
+    amplitude : (input name, factor, power) or None -- the outputs are multiplied by ``(exp(X[name]) * factor)**power`` (conversion.py:88-92: ``v * exp(logA) * 1e-10``
+        for '11' and 'ct', its square for 'loop', nothing for 'st').
+    """
+
+    def __init__(self, xlimits, layers, activation, ylimits, amplitude=None):
+        self.xlimits = np.asarray(xlimits, dtype='f8').reshape(-1, 2)
+        self.layers = [(np.asarray(kernel, dtype='f8'), np.asarray(bias, dtype='f8')) for kernel, bias in layers]
+        if activation not in ACTIVATIONS: raise ValueError('activation must be one of {}'.format(list(ACTIVATIONS)))
+        self.activation = activation
+        self.ylimits = np.asarray(ylimits, dtype='f8')
+        if self.ylimits.ndim != 5 or self.ylimits.shape[-1] != 2: raise ValueError('ylimits must have shape [n_z, n_ell, n_m, n_k, 2]')
+        self.yshape = self.ylimits.shape[:-1]
+        stack = self.yshape[:2]
+        for kernel, bias in self.layers:
+            if kernel.shape[:2] != stack or bias.shape[:2] != stack or kernel.shape[-1] != bias.shape[-1]: raise ValueError('every layer must be stacked [n_z, n_ell, ...]')
+        if len(self.layers) < 2: raise ValueError('the networks need at least one hidden layer')
+        if self.layers[-1][0].shape[-1] != self.yshape[2] * self.yshape[3]: raise ValueError('the output layer does not match ylimits')
+        if self.layers[0][0].shape[-2] != self.xlimits.shape[0]: raise ValueError('the input layer does not match xlimits')
+        self.amplitude = None if amplitude is None or not amplitude[2] else (str(amplitude[0]), float(amplitude[1]), int(amplitude[2]))
+
+    hidden = property(lambda self: [kernel.shape[-1] for kernel, bias in self.layers[:-1]])
+
+
 def fit_mlp(x, y, hidden=(64, 64, 64), activation='silu', nsteps=3000, batch=None, lr=2e-3, lr_decay=0.2, seed=0, device=0, yshape=None, return_loss=False):
     """Train an :class:`MLPEmulatorEngine` on samples ``x [S, P]`` -> ``y [S, ...]`` on the GPU (what the reference's ``Emulator(..., engine=MLPEmulatorEngine(...)).fit()`` does
     through the third-party engine, emulators/__init__.py:510-533).  Min-max scalers of inputs and outputs as emulators/conversion.py:75-79 (constant outputs get a zero
@@ -194,14 +230,60 @@ class EmulatedCalculator(object):
         self.ells = tuple(ells)
         self.z = z
         self.param_specs = dict(param_specs or {})
+        self.stacked = all(name in self.engines for name, nm in STACKED_COMPONENTS)      # the layout of emulators/conversion.py:44-98
+        if self.stacked:
+            self.table_name = 'stacked'
+            self.z = np.atleast_1d(np.asarray(z, dtype='f8'))
+            for name, nm in STACKED_COMPONENTS:
+                expected = (self.z.size, len(self.ells), nm, self.k.size)
+                if tuple(self.engines[name].yshape) != expected: raise ValueError('engine {} has output shape {}, expected {}'.format(name, self.engines[name].yshape, expected))
+            first = self.engines[STACKED_COMPONENTS[0][0]]
+            for name, nm in STACKED_COMPONENTS:
+                engine = self.engines[name]
+                if engine.hidden != first.hidden or engine.activation != first.activation or not np.array_equal(engine.xlimits, first.xlimits):
+                    raise ValueError('the engines of a stacked emulator share hidden layers, activation and input scaler')
+            return
         self.table_name = 'pktable' if 'pktable' in self.engines else 'power'
         yshape = self.engines[self.table_name].yshape
         expected = (len(self.ells), self.k.size) + ((19,) if self.table_name == 'pktable' else ())
         if tuple(yshape) != expected:
             raise ValueError('{} engine has output shape {}, expected {}'.format(self.table_name, yshape, expected))
 
+    @classmethod
+    def from_state(cls, state, param_specs=None):
+        """From the state dictionary ``convert_jaxeffort_to_desilike`` assembles and ``Emulator.save`` writes (emulators/conversion.py:44-98; ``np.load(fn, allow_pickle=True)[()]``):
+        ``state['engines'][component]`` = dict(name='mlp', params, yshape, xoperations, yoperations, model_operations) with every operation as dict(direct, inverse, locals);
+        ``state['fixed']``: ells, k, z.  The operations are recognised by their ``locals`` (``kernel`` / ``bias``: a dense layer; ``limits``: a min-max scaler) and, for the
+        activations and the amplitude rescale, by the expression strings the converter writes (conversion.py:27-34, 88-92)."""
+        expressions = {'v / (1 + jnp.exp(-v))': 'silu', 'jnp.maximum(v, 0.)': 'relu', 'jnp.tanh(v)': 'tanh'}
+        engines, params = {}, None
+        for name, engine in state['engines'].items():
+            if engine.get('name', 'mlp') != 'mlp': raise NotImplementedError('engine {}: kind {}'.format(name, engine.get('name')))
+            layers, activations = [], []
+            for operation in engine['model_operations']:
+                local = operation['locals']
+                if 'kernel' in local: layers.append((local['kernel'], local['bias']))
+                elif operation['direct'] in expressions: activations.append(expressions[operation['direct']])
+                else: raise NotImplementedError('model operation {}'.format(operation['direct']))
+            if len(set(activations)) != 1: raise NotImplementedError('one activation for all hidden layers')
+            (xoperation,) = engine['xoperations']
+            amplitude, ylimits = None, None
+            for operation in engine['yoperations']:
+                if 'limits' in operation['locals']: ylimits = operation['locals']['limits']
+                elif "X['" in operation['inverse']:                                   # "v * jnp.exp(X['logA']) * 1e-10" / "v * (jnp.exp(X['logA']) * 1e-10)**2"
+                    inverse = operation['inverse']
+                    input_name = inverse.split("X['")[1].split("']")[0]
+                    power = 2 if inverse.rstrip().endswith('**2') else 1
+                    factor = float(re.search(r"\]\)\s*\*\s*([0-9.eE+\-]+)", inverse).group(1))
+                    amplitude = (input_name, factor, power)
+                else: raise NotImplementedError('y-operation {}'.format(operation['inverse']))
+            engines[name] = StackedMLPEmulatorEngine(xoperation['locals']['limits'], layers, activations[0], ylimits, amplitude=amplitude)
+            if params is None: params = [str(n) for n in engine['params']]
+        fixed = state['fixed']
+        return cls(params, engines, k=fixed['k'], ells=tuple(fixed['ells']), z=fixed['z'], param_specs=param_specs)
+
     def engine_specs(self):
-        specs = {'emu0': self.engines[self.table_name].spec(scalar=False)}
+        specs = {} if self.stacked else {'emu0': self.engines[self.table_name].spec(scalar=False)}
         for ie, name in [(1, 'sigma8'), (2, 'fsigma8')]:
             engine = self.engines.get(name, None)
             if engine is None: continue

@@ -554,6 +554,23 @@ class _BaseVelocileptorsTracer(BaseCalculator):
         k = init.get('k', None)
         self.k = self.pt.k.copy() if k is None else np.array(k, dtype='f8')
         self.z = self.pt.z
+        if getattr(self.pt, 'stacked', False):
+            # the emulated node holds several redshifts (emulators/conversion.py:44-98); the REPT tracer names its own (full_shape.py:1556-1560), the node keeps the two
+            # emulated redshifts that bracket it and blends them (full_shape.py:1416-1443): weights per emulated redshift, zero for all but two
+            z = init.get('z', None)
+            zgrid = np.atleast_1d(np.asarray(self.pt.z, dtype='f8'))
+            if z is None:
+                if zgrid.size != 1: raise ValueError('the emulated node holds redshifts {}: provide z'.format(zgrid))
+                z = zgrid[0]
+            self.z = float(z)
+            if self.z < zgrid[0] or self.z > zgrid[-1]:
+                raise ValueError('input z = {} is outside of the range of emulated z: {} - {}'.format(self.z, zgrid[0], zgrid[-1]))
+            iz = int(np.searchsorted(zgrid, self.z, side='right')) - 1
+            self._zweights = np.zeros(zgrid.size)
+            if iz + 1 < zgrid.size:
+                wz = self.z - zgrid[iz]         # (as the reference writes it, full_shape.py:1436: a difference of redshifts, not a fraction of the interval)
+                self._zweights[iz], self._zweights[iz + 1] = 1. - wz, wz
+            else: self._zweights[iz] = 1.     # the last emulated redshift itself (the reference's blend indexes one past the end there)
         shotnoise = float(init.get('shotnoise', 1e4))
         self.nd = 1e-4                                               # full_shape.py:1154
         self.fsat = self.snd = self.sigv = 1.
@@ -577,8 +594,46 @@ class _BaseVelocileptorsTracer(BaseCalculator):
         self._initialized = True
         return self
 
+    def _stacked_groups(self):
+        """The stacked layout (emulators/conversion.py:44-98) as the device takes it (include/desilike_amd.h, ``emu0.type = 2``): per engine ('11', 'loop', 'ct', 'st': one group
+        of bias monomials each) the networks (z, ell) that reach this tracer -- nonzero redshift weight, a multipole it uses -- their hidden layers, and the constant operator
+        ``[n_ell * n_k, K_g * n_m]`` (final layers x y-scalers x redshift blend x k-interpolation), K_g = n_networks * H + 1."""
+        from ...emulators import STACKED_COMPONENTS
+        pt, nk = self.pt, self.pt.k.size
+        groups, scale, weights, blocks = [], [], [], []
+        ntrunk, m0 = 0, 0
+        for name, nm in STACKED_COMPONENTS:
+            engine = pt.engines[name]
+            kl, bl = engine.layers[-1]                                                  # [n_z, n_ell, H, n_m * n_k], [n_z, n_ell, n_m * n_k]
+            lo, rng = engine.ylimits[..., 0], engine.ylimits[..., 1] - engine.ylimits[..., 0]    # [n_z, n_ell, n_m, n_k]
+            factor = 1. if engine.amplitude is None else engine.amplitude[1]**engine.amplitude[2]
+            H = kl.shape[-2]
+            basis, used = [], []
+            const = np.zeros((len(self.ells), nk, nm))
+            for iz, wz in enumerate(self._zweights):
+                if wz == 0.: continue
+                for ill, ipt in enumerate(self._ell_index):
+                    const[ill] += (wz * factor * (lo[iz, ipt] + rng[iz, ipt] * bl[iz, ipt].reshape(nm, nk))).T
+                    jac = wz * factor * rng[iz, ipt][None] * kl[iz, ipt].reshape(H, nm, nk)       # d table[ell, m, k] / d (amplitude x hidden unit h)
+                    if not np.any(jac != 0.): continue
+                    table = np.zeros((H, len(self.ells), nk, nm))
+                    table[:, ill] = jac.transpose(0, 2, 1)
+                    basis.append(table); used.append((iz, ipt))
+            basis = np.concatenate(basis + [const[None]], axis=0)                       # [K_g, ell, kpt, m]
+            blocks.append(np.einsum('kq,hlqm->lkhm', self._interp, basis).reshape(len(self.ells) * self.k.size, -1))
+            groups.append([ntrunk, ntrunk + len(used), m0, m0 + nm])
+            row = np.zeros(len(pt.param_names) + 1)
+            if engine.amplitude is not None: row[pt.param_names.index(engine.amplitude[0])] = engine.amplitude[2]
+            scale.append(row)
+            for iz, ipt in used:
+                weights.append(np.concatenate([np.concatenate([kernel[iz, ipt].ravel(), bias[iz, ipt].ravel()]) for kernel, bias in engine.layers[:-1]]))
+            ntrunk += len(used); m0 += nm
+        return groups, scale, weights, blocks
+
     def _fold(self):
         """Theory vector P_ell(k) [n_ell * n_k] = fold . phi, phi[(h, m)] = basis_h mono_m."""
+        if getattr(self.pt, 'stacked', False):
+            return np.hstack(self._stacked_groups()[3])
         engine = self.pt.engines[self.pt.table_name]
         nb = engine.n_basis
         nellpt, nkpt = len(self.pt.ells), self.pt.k.size
@@ -591,18 +646,24 @@ class _BaseVelocileptorsTracer(BaseCalculator):
 
     def _theory_spec(self):
         self.initialize()
-        if self.pt.table_name == 'pktable':
+        if self.pt.table_name in ('pktable', 'stacked'):
             mode = {(True, False): 1, (True, True): 2, (False, False): 3, (False, True): 4}[(self.is_physical_prior, self._rept)]
         else:
             mode = 0
         spec = dict(theory=np.array([self._kind], dtype='i4'), mono_mode=np.array([mode], dtype='i4'), vconst=[self.snd, self.fsat, self.sigv, self.nd])
         spec.update(self.pt.engine_specs())
+        if getattr(self.pt, 'stacked', False):
+            from ...emulators import ACTIVATIONS, STACKED_COMPONENTS
+            first = self.pt.engines[STACKED_COMPONENTS[0][0]]
+            groups, scale, weights, blocks = self._stacked_groups()
+            spec['emu0'] = dict(type=np.array([2], dtype='i4'), widths=np.array([first.xlimits.shape[0]] + first.hidden, dtype='i4'), act=np.array([ACTIVATIONS[first.activation]], dtype='i4'),
+                                xlimits=first.xlimits, weights=np.concatenate(weights) if weights else np.zeros(1), groups=np.array(groups, dtype='i4'), scale=np.array(scale, dtype='f8'))
         return spec
 
     def _input_map(self):
         suffix = 'p' if self.is_physical_prior else ''
         toret = {'x': list(self.pt.param_names)}
-        if self.pt.table_name == 'pktable':
+        if self.pt.table_name in ('pktable', 'stacked'):
             toret['vp'] = [name + suffix for name in self._names]
         return toret
 

@@ -115,8 +115,17 @@ typedef struct dl_ctx dl_ctx;         /* opaque; owns all persistent device cons
  *                     odd multipoles in ells_in, mu / wmu_ell on the nodes mu >= 0 with the weights of the mirror nodes added (<= 48 nodes)
  *   emulated theory (theory = 3): obs<i>.in.x f64[n_x*2] emulator inputs, obs<i>.in.vp f64[11*2] velocileptors 'pars' (b1 b2 bs b3 alpha0 alpha2 alpha4 alpha6
  *                     sn0 sn2 sn4), obs<i>.mono_mode i32[1] (0 none, 1 LPT physical basis, 2 REPT physical, 3 LPT direct, 4 REPT direct), obs<i>.vconst f64[3] (snd fsat sigv),
- *                     obs<i>.emu<e>.{type i32[1] (-1 constant, 0 MLP, 1 Taylor), xlimits, widths, act, weights, ylimits, center, powers, coef, const}
+ *                     obs<i>.emu<e>.{type i32[1] (-1 constant, 0 MLP, 1 Taylor, 2 stacked MLPs: below), xlimits, widths, act, weights, ylimits, center, powers, coef, const}
  *                     for e = 0 (table basis), 1 (sigma8), 2 (fsigma8); obs<i>.marg.vp i32[11], obs<i>.marg.pass i32[n_pass]
+ *   stacked table engine (obs<i>.emu0.type = 2): the layout the reference ships (emulators/conversion.py:44-98: engines '11' / 'loop' / 'ct' / 'st', each one network per
+ *                     (z, ell) with kernels stacked [n_z, n_ell, in, out], outputs rescaled by the input logA; redshift selection / blend of full_shape.py:1416-1443):
+ *                     obs<i>.emu0.widths i32[L + 1] (n_x, hidden widths <= 128: the same for every network; the final linear layers, y-scalers, the assembly of pktable, the
+ *                     redshift blend, the k-interpolation and the window are folded into obs<i>.wmatrix), .act i32[1], .xlimits f64[n_x*2] (one min-max scaler),
+ *                     .weights f64[n_networks * per_network] (per network, layer by layer: kernel [in, out] row-major then bias [out]),
+ *                     .groups i32[n_groups*4]: (first network, one past the last, first bias monomial, one past the last) of each group of networks (a monomial belongs to
+ *                     one group; a group may have no network: constant tables), .scale f64[n_groups*(n_x + 1)]: amplitude of a group's tables,
+ *                     log amp = scale[g][n_x] + sum_j scale[g][j] x_j (conversion.py:88-92: v * exp(logA) * 1e-10, squared for 'loop');
+ *                     obs<i>.wmatrix columns, group by group: [basis function h = (network, hidden unit) ..., then the constant 1][monomial of the group]
  *   marg.kind       i32[n_s]    analytically solved linear parameters (likelihoods/base.py:314-413): 1 = marginalised ('.marg'), 0 = best fit ('.best')
  *   marg.prior      f64[n_s*2]  (loc, 1 / scale^2) of their Gaussian priors (0 precision = flat prior)
  *   marg.x0         f64[n_s]    values at which the theory is evaluated (the parameters' default values, likelihoods/base.py:355)

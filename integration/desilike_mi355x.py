@@ -8,7 +8,9 @@ This module imports ``desilike`` (the reference), never ``desilike_amd``'s Pytho
   damped-BAO tracer power spectrum and correlation function multipoles ('standard' wiggle model, 'power' broadband terms); any window handled by
   ``WindowedPowerSpectrumMultipoles``; one or several observables, tracer namespaces; parameters solved analytically ('.marg' / '.best' / '.auto': shot-noise like
   terms, counter / stochastic terms, broadband terms); **emulated perturbation-theory nodes** -- the LPT / REPT velocileptors tracer power spectrum multipoles whose
-  ``pt`` is an ``EmulatedCalculator`` (emulators/__init__.py:394-418) with Taylor or MLP engines (BASELINE configs[2]): :func:`_extract_emulated`.  For correlation functions ``get_corr`` (FFTLog) is linear in P_ell: the binding applies THE REFERENCE'S OWN
+  ``pt`` is an ``EmulatedCalculator`` (emulators/__init__.py:394-418) with Taylor or MLP engines (BASELINE configs[2]): :func:`_extract_emulated` -- one network per array,
+  or the layout the reference ships (emulators/conversion.py:44-98: engines '11' / 'loop' / 'ct' / 'st', one network per (z, ell) stacked in each, amplitude rescale by the input
+  ``logA``, redshift selection / blend of full_shape.py:1416-1443): :func:`_extract_stacked`.  For correlation functions ``get_corr`` (FFTLog) is linear in P_ell: the binding applies THE REFERENCE'S OWN
   ``theory.get_corr`` -- cosmoprimo's transform in a real installation -- to the unit vectors of the theory's k grid once, and hands the resulting operator to the
   device folded into the window matrix (desilike/theories/galaxy_clustering/base.py:127-136);
 * :class:`MI355XGaussianLikelihood` -- a ``BaseGaussianLikelihood`` whose ``calculate`` is ONE ``dl_eval_batch_host`` call; ``evaluate(values [B, P])`` is the
@@ -103,7 +105,7 @@ def _engine_description(engine):
     for operation in engine.model_operations:
         if 'kernel' in operation._locals:
             kernel, bias = np.asarray(operation._locals['kernel'], dtype='f8'), np.asarray(operation._locals['bias'], dtype='f8')
-            if kernel.ndim != 2: raise NotImplementedError('stacked MLP kernels (several networks in one engine: emulators/conversion.py:58-66)')
+            if kernel.ndim != 2: raise NotImplementedError('stacked MLP kernels in a scalar engine')
             layers.append((kernel, bias.reshape(kernel.shape[1])))
         else:
             out = np.asarray(operation(probe), dtype='f8')
@@ -146,6 +148,261 @@ def _engine_keys(description, scalar):
     return keys
 
 
+def _call(operation, v, X, inverse=False):
+    """An emulator operation on ``v`` with the inputs ``X`` at hand (operations may use them by name: emulators/conversion.py:88-92)."""
+    return (operation.inverse if inverse else operation)(v, X=X)
+
+
+def _stacked_engine(engine, X0, what):
+    """One MLP engine whose kernels may be stacked over leading axes (emulators/conversion.py:58-66): ``kernel [*S, in, out]``, ``bias [*S, out]``; the network output
+    ``[*S, out]`` is reshaped to ``yshape`` (a flat reinterpretation).  Everything else is PROBED, not parsed: the x-scaler is an elementwise affine map; the y-operations are
+    ``y = s(X) (y0 + yslope v)`` elementwise in ``v`` with ONE amplitude ``s`` per engine that is log-linear in the inputs, ``log s = sum_j a_j x_j + b`` (conversion.py:88-92:
+    ``v * exp(logA) * 1e-10`` and its square are of this form); anything else raises.  Returns dict(stack, layers [(kernel [T, in, out], bias [T, out])], act, x0, xslope,
+    y0, yslope [n_out_total] (flat ``yshape`` order, at s = 1), loga [n_x + 1])."""
+    yshape = tuple(engine.yshape)
+    ntot = int(np.prod(yshape, dtype='i8'))
+    layers, acts = [], []
+    probe = np.array([-1.3, -0.2, 0., 0.7, 2.1])
+    for operation in engine.model_operations:
+        if 'kernel' in operation._locals:
+            kernel, bias = np.asarray(operation._locals['kernel'], dtype='f8'), np.asarray(operation._locals['bias'], dtype='f8')
+            stack = kernel.shape[:-2]
+            if layers and stack != layers[0][0].shape[:-2]: raise NotImplementedError('{}: layers stacked differently'.format(what))
+            layers.append((kernel, bias.reshape(stack + (kernel.shape[-1],))))
+        else:
+            out = np.asarray(operation(probe), dtype='f8')
+            match = [code for name, code, function in _ACTIVATIONS if np.allclose(out, function(probe), rtol=1e-14, atol=1e-15)]
+            if not match: raise NotImplementedError('activation not one of silu / relu / tanh')
+            acts.append(match[0])
+    if len(layers) < 2 or len(acts) != len(layers) - 1 or len(set(acts)) != 1:
+        raise NotImplementedError('MLP engines: >= 1 hidden layer, one activation for all of them')
+    stack = layers[0][0].shape[:-2]
+    T = int(np.prod(stack, dtype='i8'))
+    nin, nout = layers[0][0].shape[-2], layers[-1][0].shape[-1]
+    if T * nout != ntot: raise NotImplementedError('{}: network outputs do not fill yshape'.format(what))
+    names = [str(n) for n in engine.params]
+
+    def xscale(v):
+        for operation in getattr(engine, 'xoperations', []): v = _call(operation, v, X0)
+        return v
+
+    def yunscale(v, X):
+        for operation in list(getattr(engine, 'yoperations', []))[::-1]: v = _call(operation, v, X, inverse=True)
+        return np.asarray(v, dtype='f8')
+
+    x0, xslope = _affine(xscale, (nin,), what + ' xoperations')
+
+    def affine_y(X):
+        v0, v1, v2 = (yunscale(np.full(yshape, value, dtype='f8'), X).reshape(ntot) for value in (0., 1., 2.))
+        if not np.allclose(v2 - v1, v1 - v0, rtol=1e-12, atol=1e-300): raise NotImplementedError('{} yoperations: not elementwise affine'.format(what))
+        return v0, v1 - v0
+
+    y0, yslope = affine_y(X0)
+    ref = np.concatenate([y0, yslope])
+    live = ref != 0.
+    loga = np.zeros(nin + 1)
+    for j, name in enumerate(names):
+        step = 0.01 * max(abs(X0[name]), 1.)
+        ratios = []
+        for mult in (1., 2.):
+            X = dict(X0); X[name] = X0[name] + mult * step
+            cur = np.concatenate(affine_y(X))
+            if np.any(cur[~live] != 0.): raise NotImplementedError('{} yoperations: offsets that depend on the inputs'.format(what))
+            ratio = cur[live] / ref[live]
+            if ratio.size and not np.allclose(ratio, ratio[0], rtol=1e-12, atol=0.): raise NotImplementedError('{} yoperations: more than one amplitude per engine'.format(what))
+            ratios.append(ratio[0] if ratio.size else 1.)
+        if ratios[0] <= 0. or abs(np.log(ratios[1]) - 2. * np.log(ratios[0])) > 1e-10 * max(1., abs(np.log(ratios[1]))):
+            raise NotImplementedError('{} yoperations: amplitude not log-linear in {}'.format(what, name))
+        loga[j] = np.log(ratios[1]) / (2. * step)
+        if abs(loga[j]) < 1e-13: loga[j] = 0.
+    # y0, yslope above hold the amplitude at X0: divide it out (s(X0) = exp(loga . x0 + b) with b chosen such that what is stored is at s = 1)
+    s0 = np.exp(sum(loga[j] * X0[name] for j, name in enumerate(names)))
+    if np.any(loga[:nin] != 0.): y0, yslope = y0 / s0, yslope / s0
+    return dict(stack=stack, T=T, nin=nin, nout=nout, yshape=yshape, act=acts[0], x0=x0, xslope=xslope, y0=y0, yslope=yslope, loga=loga,
+                layers=[(kernel.reshape((T,) + kernel.shape[-2:]), bias.reshape(T, -1)) for kernel, bias in layers])
+
+
+def _table_operator(emulator, shapes, X0, select):
+    """The constant linear map from the engines' outputs to the table the tracer combines, PROBED through the emulator's own operations (the split / concatenate /
+    moveaxis pair of emulators/conversion.py:50-51, the redshift blend of full_shape.py:1443, the tracer's own selection -- ``select(state)``): every element of the final
+    table is a weighted sum of at most one element per slab (index along the first axis) of every engine output.  Per engine and slab: (weights, flat source index or -1).
+    Verified on random outputs before it is trusted."""
+    def push(outputs):
+        state = {name: np.array(value) for name, value in outputs.items()}
+        state.update(emulator.fixed)
+        for operation in list(emulator.yoperations)[::-1]: state = _call(operation, state, X0, inverse=True)
+        return np.asarray(select(state), dtype='f8')
+
+    zeros = {name: np.zeros(shape) for name, shape in shapes.items()}
+    base = push(zeros)
+    if np.any(base != 0.): raise NotImplementedError('emulator-level operations with a constant term')
+    table = {}
+    for name, shape in shapes.items():
+        slab = int(np.prod(shape[1:], dtype='i8'))
+        table[name] = []
+        for index in range(shape[0]):
+            ones, codes = dict(zeros), dict(zeros)
+            ones[name] = np.zeros(shape); ones[name][index] = 1.
+            codes[name] = np.zeros(shape); codes[name][index] = np.arange(1., slab + 1.).reshape(shape[1:])
+            weight, value = push(ones), push(codes)
+            live = weight != 0.
+            source = np.full(weight.shape, -1, dtype='i8')
+            code = value[live] / weight[live]
+            if not np.allclose(code, np.round(code), rtol=0., atol=1e-6): raise NotImplementedError('emulator-level operations that mix elements of one slab')
+            source[live] = np.round(code).astype('i8') - 1 + index * slab
+            table[name].append((weight, source))
+    rng = np.random.RandomState(0)
+    outputs = {name: rng.standard_normal(shape) for name, shape in shapes.items()}
+    expected, mine = push(outputs), np.zeros_like(base)
+    for name in shapes:
+        flat = outputs[name].ravel()
+        for weight, source in table[name]: mine += np.where(source >= 0, weight * flat[np.maximum(source, 0)], 0.)
+    if not np.allclose(mine, expected, rtol=1e-12, atol=1e-12 * np.abs(expected).max()): raise NotImplementedError('emulator-level operations are not the sparse linear map they were probed as')
+    return table
+
+
+def _extract_stacked(cfg, p, obs, theory, pt, column, value_of, sindex, solved):
+    """The emulator layout the reference ships (emulators/conversion.py:44-98) under its velocileptors tracers: SEVERAL table engines ('11', 'loop', 'ct', 'st': one per group
+    of bias monomials), each holding one network per (z, ell); outputs rescaled by an amplitude that depends on the inputs (conversion.py:88-92); emulator-level operations that
+    assemble ``pktable [n_ell, n_k, 19, n_z]`` (50-51) and select / blend redshifts (full_shape.py:1416-1443, inserted by the emulated REPT node).  Everything after the
+    networks' last hidden layers is linear with constant coefficients times ONE scalar per engine: the final layers, the y-scalers, the assembly, the blend, the tracer's
+    redshift selection (full_shape.py:1486), the k-interpolation (1598) and the window are multiplied together here; networks that end up with a zero operator (redshifts
+    not bracketing the tracer's, multipoles it does not use) are dropped.  Device keys: ``obs<i>.emu0.type = 2`` (include/desilike_amd.h)."""
+    from desilike.jax import interp1d
+    wm = obs.wmatrix
+    emulator = pt.emulator
+    name = type(theory).__name__
+    rept = name.startswith('REPT')
+    if not (rept or name.startswith('LPT')) or 'Tracer' not in name or hasattr(theory, 'get_corr'):
+        raise NotImplementedError('emulated node under {}: the LPT / REPT velocileptors tracer power spectrum multipoles are covered'.format(name))
+    physical = bool(theory.is_physical_prior)
+    tnames = [n for n in emulator.engines if n not in ('sigma8', 'fsigma8')]
+    xnames = [str(n) for n in emulator.engines[tnames[0]].params]
+    ptnames = {param.basename: param.name for param in pt.all_params}
+    X0 = {n: float(pt.all_params[ptnames.get(n, n)].value) for n in xnames}
+    engines = {}
+    for n in tnames:
+        if [str(q) for q in emulator.engines[n].params] != xnames: raise NotImplementedError('engines with different inputs')
+        if not hasattr(emulator.engines[n], 'model_operations'): raise NotImplementedError('engine {}: several table engines must be MLPs'.format(n))
+        engines[n] = _stacked_engine(emulator.engines[n], X0, 'engine ' + n)
+    first = engines[tnames[0]]
+    widths = [first['nin']] + [kernel.shape[-1] for kernel, bias in first['layers'][:-1]]
+    for n in tnames:
+        e = engines[n]
+        if [e['nin']] + [kernel.shape[-1] for kernel, bias in e['layers'][:-1]] != widths or e['act'] != first['act']:
+            raise NotImplementedError('stacked engines: every network must have the same hidden layers and activation')
+        if not (np.array_equal(e['x0'], first['x0']) and np.array_equal(e['xslope'], first['xslope'])):
+            # another min-max scaler of the inputs: expressed through the first engine's, in the first layer u = x0 + xslope x -> scaled_e = c + r u
+            r = e['xslope'] / first['xslope']
+            c = e['x0'] - r * first['x0']
+            kernel, bias = e['layers'][0]
+            e['layers'][0] = (kernel * r[None, :, None], bias + np.einsum('j,tjo->to', c, kernel))
+    H = widths[-1]
+
+    ptells = list(pt.ells)
+    index = [ptells.index(ell) for ell in theory.ells]
+
+    def select(state):   # what the tracer combines: REPTVelocileptorsPowerSpectrumMultipoles.combine_bias_terms_poles picks its redshift (full_shape.py:1486), then its multipoles (1597)
+        table = np.asarray(state['pktable'])
+        zz = np.asarray(state.get('z', pt.z))
+        if rept and zz.ndim: table = table[..., [float(v) for v in zz].index(float(theory.z))]
+        if table.ndim != 3 or table.shape[-1] != 19: raise NotImplementedError('pktable of shape {}'.format(table.shape))
+        return table[index]
+
+    operator = _table_operator(emulator, {n: engines[n]['yshape'] for n in tnames}, X0, select)
+    kpt, k = np.asarray(pt.k, dtype='f8'), np.asarray(theory.k, dtype='f8')
+    nell, nkpt = len(index), kpt.size
+    interp = np.asarray(interp1d(k, kpt, np.eye(kpt.size)), dtype='f8')                     # the reference's own interpolation (desilike/jax.py:211-265)
+    window = None if wm.matrix_full is None else np.asarray(wm.matrix_full, dtype='f8')
+    groups, scale, weights, blocks, folds = [], [], [], [], []
+    ntrunk = 0
+    for n in tnames:
+        e = engines[n]
+        kl, bl = e['layers'][-1]                                                            # [T, H, nout], [T, nout]
+        jac = np.zeros((e['T'], H, nell * nkpt * 19))                                       # d table / d (amplitude x last hidden layer of network t)
+        const = np.zeros(nell * nkpt * 19)
+        for weight, source in operator[n]:
+            weight, source = weight.ravel(), source.ravel()
+            live = np.flatnonzero(source >= 0)
+            f = source[live]
+            t, o = f // e['nout'], f % e['nout']
+            const[live] += weight[live] * (e['y0'][f] + e['yslope'][f] * bl[t, o])
+            jac[t, :, live] += (weight[live] * e['yslope'][f])[:, None] * kl[t, :, o]
+        used = np.flatnonzero(np.any(jac.reshape(e['T'], -1) != 0., axis=1))               # networks that reach the tracer's table at all
+        monos = np.flatnonzero(np.any(jac.reshape(-1, nell * nkpt, 19) != 0., axis=(0, 1)) | np.any(const.reshape(nell * nkpt, 19) != 0., axis=0))
+        if monos.size == 0: continue
+        m0, m1 = int(monos[0]), int(monos[-1]) + 1
+        basis = np.concatenate([jac[used].reshape(used.size * H, nell, nkpt, 19), const.reshape(1, nell, nkpt, 19)], axis=0)[..., m0:m1]     # [K_g, ell, kpt, m]
+        fold = np.einsum('kq,hlqm->lkhm', interp, basis).reshape(nell * k.size, -1)        # columns (h, m): group by group
+        folds.append(fold)
+        blocks.append(fold if window is None else window.dot(fold))
+        groups.append([ntrunk, ntrunk + used.size, m0, m1])
+        scale.append(np.concatenate([e['loga'][:e['nin']], [0.]]))
+        for t in used: weights.append(np.concatenate([np.concatenate([kernel[t].ravel(), bias[t].ravel()]) for kernel, bias in e['layers'][:-1]]))
+        ntrunk += used.size
+    cfg[p + 'theory'] = np.array([DL_THEORY_EMULATED], dtype='i4')
+    cfg[p + 'transform'] = np.array([1 if getattr(obs, 'transform', None) == 'cubic' else 0], dtype='i4')
+    cfg[p + 'mono_mode'] = np.array([{(True, False): 1, (True, True): 2, (False, False): 3, (False, True): 4}[(physical, rept)]], dtype='i4')
+    cfg[p + 'vconst'] = np.array([theory.snd, theory.fsat, theory.options['sigv'] if physical else 1., theory.nd], dtype='f8')
+    cfg[p + 'in.x'] = np.array([column(ptnames.get(n, n), value_of(ptnames.get(n, n), 0.)) for n in xnames], dtype='f8')
+    names = {param.basename: param.name for param in theory.all_params}
+    vp = [names.get(n + ('p' if physical else ''), n + ('p' if physical else '')) for n in _VP_NAMES]
+    defaults = dict(theory.required_bias_params)
+    cfg[p + 'in.vp'] = np.array([column(n, value_of(n, defaults.get(b + ('p' if physical else ''), 0.))) for n, b in zip(vp, _VP_NAMES)], dtype='f8')
+    lo = -first['x0'] / first['xslope']
+    cfg[p + 'emu0.type'] = np.array([2], dtype='i4')
+    cfg[p + 'emu0.widths'], cfg[p + 'emu0.act'] = np.array(widths, dtype='i4'), np.array([first['act']], dtype='i4')
+    cfg[p + 'emu0.xlimits'] = np.column_stack([lo, lo + 1. / first['xslope']])
+    cfg[p + 'emu0.weights'] = np.concatenate(weights)
+    cfg[p + 'emu0.groups'], cfg[p + 'emu0.scale'] = np.array(groups, dtype='i4'), np.array(scale, dtype='f8')
+    for ie, ename in [(1, 'sigma8'), (2, 'fsigma8')]:
+        if ename in emulator.engines:
+            if emulator.yoperations or tuple(emulator.engines[ename].yshape) not in ((), (1,)): raise NotImplementedError('scalar engines under emulator-level operations')
+            if [str(q) for q in emulator.engines[ename].params] != xnames: raise NotImplementedError('engines with different inputs')
+            keys = _engine_keys(_engine_description(emulator.engines[ename]), scalar=True)
+        elif physical: keys = {'const': np.array([float(getattr(pt, ename))], dtype='f8')}
+        else: keys = {'const': np.array([1.], dtype='f8')}                                 # not used by the direct basis (full_shape.py:1593-1594)
+        for key, value in keys.items(): cfg[p + 'emu{:d}.{}'.format(ie, key)] = value
+    offset = None if getattr(wm, 'offset', None) is None else np.asarray(wm.offset, dtype='f8')
+    shotnoisein = np.asarray(wm.shotnoisein, dtype='f8')
+    if np.any(shotnoisein != 0.):
+        vector = np.repeat(shotnoisein, len(wm.kin))
+        extra = vector if window is None else window.dot(vector)
+        offset = extra if offset is None else offset + extra
+    cfg[p + 'wmatrix'] = np.hstack(blocks)
+    if offset is not None: cfg[p + 'offset'] = offset
+    if getattr(wm, 'kmask', None) is not None: cfg[p + 'kmask'] = np.asarray(wm.kmask, dtype='i4')
+    cfg[p + 'shotnoise_out'] = np.asarray(wm.shotnoiseout, dtype='f8')
+    cfg[p + 'flatdata'] = np.asarray(obs.flatdata, dtype='f8')
+    if solved: cfg[p + 'marg.vp'] = np.array([sindex(n) for n in vp], dtype='i4')
+    # the description against the emulator itself, at points other than the one it was probed at: pktable as the tracer sees it
+    rng = np.random.RandomState(1)
+    limits = cfg[p + 'emu0.xlimits']
+    for trial in range(3):
+        x = limits[:, 0] + rng.uniform(0.2, 0.8, len(xnames)) * (limits[:, 1] - limits[:, 0])
+        params = {param.basename: float(param.value) for param in pt.all_params}
+        params.update(dict(zip(xnames, x)))
+        expected = select({**emulator.fixed, **emulator.predict(params)})
+        mine = np.zeros((nell * k.size, 19))
+        u = first['x0'] + first['xslope'] * x
+        activation = [function for name_, code, function in _ACTIVATIONS if code == first['act']][0]
+        for (t0, t1, m0, m1), loga, block in zip(groups, scale, folds):
+            basis = []
+            for t in range(t0, t1):
+                v, pos = u, 0
+                w = weights[t]
+                for nin_, nout_ in zip(widths[:-1], widths[1:]):
+                    v = v.dot(w[pos:pos + nin_ * nout_].reshape(nin_, nout_)) + w[pos + nin_ * nout_:pos + nin_ * nout_ + nout_]
+                    pos += nin_ * nout_ + nout_
+                    v = activation(v)
+                basis.append(v)
+            basis = np.concatenate(basis + [[1.]])
+            mine[:, m0:m1] += np.exp(loga[:-1].dot(x) + loga[-1]) * block.reshape(nell * k.size, basis.size, m1 - m0).transpose(0, 2, 1).dot(basis)
+        expected = np.einsum('kq,lqm->lkm', interp, expected).reshape(nell * k.size, 19)
+        if not np.allclose(mine, expected, rtol=1e-11, atol=1e-12 * np.abs(expected).max()):
+            raise NotImplementedError('stacked emulator: the folded description does not reproduce emulator.predict (max deviation {:.3e})'.format(np.abs(mine - expected).max()))
+
+
 def _extract_emulated(cfg, p, obs, theory, pt, column, value_of, sindex, solved):
     """Velocileptors-type tracer theory whose ``pt`` is an ``EmulatedCalculator`` (emulators/__init__.py:394-418): ``pktable [n_ell, n_kpt, 19]``, ``sigma8``, ``fsigma8``
     come from ``pt.emulator.engines``; the tracer combines the 19 bias monomials (full_shape.py:1182-1186) and interpolates to its own k (full_shape.py:1312, 1598).
@@ -154,11 +411,12 @@ def _extract_emulated(cfg, p, obs, theory, pt, column, value_of, sindex, solved)
     from desilike.jax import interp1d
     wm = obs.wmatrix
     emulator = pt.emulator
-    if getattr(emulator, 'xoperations', None) or getattr(emulator, 'yoperations', None):
-        raise NotImplementedError('emulator-level operations (redshift interpolation of the jaxeffort emulators, full_shape.py:1443) are not covered')
+    if getattr(emulator, 'xoperations', None):
+        raise NotImplementedError('emulator-level operations on the inputs are not covered')
     engines = emulator.engines
-    if 'pktable' not in engines:
-        raise NotImplementedError("emulated node without a 'pktable' engine")
+    stacked = any(np.ndim(operation._locals.get('kernel', 0.)) > 2 for engine in engines.values() for operation in getattr(engine, 'model_operations', []))
+    if getattr(emulator, 'yoperations', None) or 'pktable' not in engines or stacked:     # the layout of emulators/conversion.py:44-98
+        return _extract_stacked(cfg, p, obs, theory, pt, column, value_of, sindex, solved)
     name = type(theory).__name__
     rept = name.startswith('REPT')
     if not (rept or name.startswith('LPT')) or 'Tracer' not in name or hasattr(theory, 'get_corr'):

@@ -825,6 +825,48 @@ def mlp_predict(x, xlimits, layers, activation, ylimits=None):
     return v
 
 
+def stacked_mlp_predict(X, params, xlimits, layers, activation, ylimits, amplitude_power=0):
+    """One engine of the jaxeffort layout (emulators/conversion.py:52-98): every ``kernel [n_z, n_ell, in, out]`` / ``bias [n_z, n_ell, out]`` holds one network per
+    (z, ell) (``merge_operations``, 58-66); the layer expression ``(v[..., None, :] @ kernel)[..., 0, :] + bias`` (25) runs them all by broadcasting.
+    ``X``: dict of the inputs; ``xlimits [P, 2]``: the one min-max scaler of the engine (75); ``ylimits [n_z, n_ell, n_m, n_k, 2]``: inverse min-max scaler (79);
+    ``amplitude_power`` 1 ('11', 'ct') / 2 ('loop') / 0 ('st'): the inverse of conversion.py:88-92, ``v * (exp(logA) * 1e-10)**power``, applied last.
+    Returns ``[n_z, n_ell, n_m, n_k]``."""
+    v = (np.array([X[name] for name in params], dtype='f8') - xlimits[..., 0]) / (xlimits[..., 1] - xlimits[..., 0])
+    for ilayer, (kernel, bias) in enumerate(layers):
+        v = np.matmul(v[..., None, :], kernel)[..., 0, :] + bias
+        if ilayer < len(layers) - 1:
+            if activation == 'silu': v = v / (1. + np.exp(-v))
+            elif activation == 'relu': v = np.maximum(v, 0.)
+            elif activation == 'tanh': v = np.tanh(v)
+            else: raise ValueError(activation)
+    v = v.reshape(ylimits.shape[:-1])
+    v = v * (ylimits[..., 1] - ylimits[..., 0]) + ylimits[..., 0]
+    if amplitude_power == 1: v = v * np.exp(X['logA']) * 1e-10
+    elif amplitude_power == 2: v = v * (np.exp(X['logA']) * 1e-10)**2
+    return v
+
+
+def jaxeffort_pktable(components, zgrid=None, z=None):
+    """``pktable`` of the emulated REPT node from the outputs ``[n_z, n_ell, n_m, n_k]`` of the engines '11', 'loop', 'ct', 'st' (in this order):
+    concatenation along the monomial axis and ``moveaxis(..., [0, -1], [-1, 1])`` -> ``[n_ell, n_k, 19, n_z]`` (conversion.py:50-51), then -- ``z`` given and not the emulated grid
+    itself -- the selection / blend ``_emulator_initialize`` inserts (full_shape.py:1416-1443): ``iz = searchsorted(zgrid, z, 'right') - 1``, the two bracketing redshifts kept,
+    ``pktable[..., iz] (1 - wz) + pktable[..., iz + 1] wz`` with ``wz = z - zgrid[iz]`` exactly as the reference writes it (a difference of redshifts, not a fraction of the
+    interval).  Returns ``[n_ell, n_k, 19, len(z)]`` (``[n_ell, n_k, 19, n_z]`` without ``z``)."""
+    pktable = np.moveaxis(np.concatenate(list(components), axis=-2), [0, -1], [-1, 1])
+    if z is None: return pktable
+    z, zgrid = np.atleast_1d(np.asarray(z, dtype='f8')), np.asarray(zgrid, dtype='f8')
+    if z.shape == zgrid.shape and np.allclose(z, zgrid): return pktable
+    if np.any((z < zgrid[0]) | (z > zgrid[-1])): raise ValueError('z outside of the emulated range')
+    iz = np.searchsorted(zgrid, z, side='right') - 1
+    izp1 = np.minimum(iz + 1, len(zgrid) - 1)
+    keepiz = np.unique(np.concatenate([iz, izp1], axis=0))
+    kept = zgrid[keepiz]
+    pktable = pktable[..., keepiz]           # (the reference slices the stacked weights instead: full_shape.py:1439-1442 -- the same numbers)
+    iz = np.searchsorted(keepiz, iz, side='right') - 1
+    wz = z - kept[iz]
+    return pktable[..., iz] * (1 - wz) + pktable[..., iz + 1] * wz
+
+
 # ----------------------------------------------------------------------------------------------
 # a13: Fisher algebra                         fisher.py:731-750 (Gaussian finalize), 216-257 (LikelihoodFisher), 50-53 (FisherGaussianLikelihood)
 # The reference's driver (Differentiation + mpi scatter) needs mpi4py: not runnable here.  The algebra below is a line-by-line restatement;

@@ -61,7 +61,7 @@ static void run_point_tns(const DlObsDev& o, const double* th, double* prow) {
 static void run_point(const DlObsDev& o, const double* th, double* prow, double* trow) {
     if (o.theory == 4) { run_point_tns(o, th, prow); return; }
     if (o.theory == 3) {   // emulated theory
-        std::vector<double> lds(dl_emu_shared_doubles(o.n_var));
+        std::vector<double> lds(dl_emu_shared_doubles_obs(o));
         dl_emu_point(o, th, lds.data(), prow, o.n_in + o.n_pass);
         return;
     }

@@ -54,3 +54,48 @@ def cfg3_full_engines(seed=1):
     engines['sigma8'] = dict(xlimits=CFG3_XLIMITS, layers=mlp(1, [16]), ylimits=np.array([[0.7, 0.9]]), yshape=(1,))
     engines['fsigma8'] = dict(xlimits=CFG3_XLIMITS, layers=mlp(1, [16]), ylimits=np.array([[0.4, 0.5]]), yshape=(1,))
     return engines
+
+
+# ---- the jaxeffort layout (emulators/conversion.py:44-98): engines '11' / 'loop' / 'ct' / 'st', one network per (z, ell) stacked in each, amplitude rescale by the input logA ----------
+STK_PARAMS = ['logA', 'n_s', 'h', 'omega_b', 'omega_cdm']                                     # conversion.py:15
+STK_COMPONENTS = (('11', 3), ('loop', 9), ('ct', 4), ('st', 3))                               # monomial groups: jnp.split(pktable, [3, 12, 16], axis=2), conversion.py:50
+STK_LIMITS = np.array([[2.5, 3.5], [0.9, 1.02], [55., 80.], [0.020, 0.024], [0.09, 0.15]])    # in_MinMax; the 'h' row in km / s / Mpc (conversion.py:73-74 divides it by 100)
+STK_SPECS = {'logA': dict(value=3.04, prior=dict(limits=[2.5, 3.5]), ref=dict(limits=[3.02, 3.06])), 'n_s': dict(value=0.965, prior=dict(limits=[0.9, 1.02]), ref=dict(limits=[0.96, 0.97])),
+             'h': dict(value=0.674, prior=dict(limits=[0.55, 0.8]), ref=dict(limits=[0.67, 0.68])), 'omega_b': dict(value=0.0224, prior=dict(dist='norm', loc=0.0224, scale=0.0004, limits=[0.020, 0.024]), ref=dict(limits=[0.0222, 0.0226])),
+             'omega_cdm': dict(value=0.12, prior=dict(limits=[0.09, 0.15]), ref=dict(limits=[0.118, 0.122]))}
+
+
+def stacked_kgrid(nk=30):
+    """``emu.k_grid`` of the component emulators (conversion.py:69): wide enough for the tracer's cubic interpolation to its own wavenumbers (full_shape.py:1598)."""
+    return np.concatenate([[0.0005], np.geomspace(0.0015, 0.025, nk // 3), np.linspace(0.03, 0.32, nk - nk // 3 - 1)])
+
+
+def stacked_networks(z, ells=(0, 2, 4), nk=30, hidden=(32, 32), activation='tanh', seed=3):
+    """What ``jaxeffort.load_component_emulator`` hands to conversion.py:68-79 for every (component, iz, ell), as synthetic DATA (nothing physical is trained here):
+    ``networks[component][iz][ill] = dict(k_grid, layers [(kernel [in, out], bias [out])], activations, in_MinMax [5, 2], out_MinMax [n_m * n_k, 2])``.
+    The output ranges carry the amplitudes conversion.py:88-92 divides out: '11' and 'ct' by ``exp(logA) 1e-10``, 'loop' by its square."""
+    rng = np.random.RandomState(seed)
+    k = stacked_kgrid(nk)
+    base = 2e4 * (k / 0.05)**0.96 / (1. + (k / 0.02)**2.5)
+    a1 = np.exp(3.04) * 1e-10
+    amplitude = {'11': 1. / a1, 'loop': 0.2 / a1**2, 'ct': 0.05 / a1, 'st': 1.}
+    networks = {}
+    for component, nm in STK_COMPONENTS:
+        networks[component] = []
+        for iz, zz in enumerate(z):
+            growth = 1. / (1. + 0.4 * zz)
+            row = []
+            for ill, ell in enumerate(ells):
+                layers, last = [], len(STK_PARAMS)
+                for width in list(hidden) + [nm * nk]:
+                    layers.append((rng.standard_normal((last, width)) / last**0.5, 0.1 * rng.standard_normal(width)))
+                    last = width
+                if component == 'st':   # stochastic tables: 1, k^2, k^4 on the monomial sn_{2 i} / nd, the same for every cosmology (zero output range, conversion.py:79: v * 0 + lo)
+                    lo = np.array([[(0.3 + 0.1 * ill) * (k / 0.1)**(2 * i) * (1. if i >= ill else 0.) for i in range(nm)]]).reshape(nm, nk)
+                    out = np.stack([lo, lo], axis=-1)
+                else:
+                    shape = base[None, :] * (1. + 0.3 * np.arange(nm)[:, None] / nm) * (k[None, :] / 0.1)**(0.5 * ill) * growth**2 * amplitude[component] * (0.5 if ell else 1.)
+                    out = np.stack([-shape, 1.3 * shape], axis=-1)
+                row.append(dict(k_grid=k, layers=layers, activations=[activation] * len(hidden), in_MinMax=STK_LIMITS.copy(), out_MinMax=out.reshape(nm * nk, 2)))
+            networks[component].append(row)
+    return networks

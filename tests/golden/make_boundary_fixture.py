@@ -82,7 +82,7 @@ def exact_quadratic(logpost, x0):
 SELECTED = set(sys.argv[1:])     # fixture names to (re)generate; none: all of them
 
 
-def dump(name, likelihood, size=48, seed=42, unsolved=None):
+def dump(name, likelihood, size=48, seed=42, unsolved=None, extras=None):
     """``likelihood`` / ``unsolved``: likelihoods, or callables that build them (so that only the selected fixtures cost anything).
     ``unsolved``: for likelihoods with analytically solved parameters (the reference's ``_solve`` needs jax: not runnable here) the same pipeline WITHOUT the
     '.marg' / '.best' flags -- the reference evaluates that one on a stencil of the solved parameters, which gives the exact quadratic form (value, gradient, Hessian)
@@ -114,6 +114,8 @@ def dump(name, likelihood, size=48, seed=42, unsolved=None):
     else:
         (logpost, derived), errors = vmap(likelihood, backend=None, errors='return', return_derived=True)({n: theta[:, i] for i, n in enumerate(names)})
         out.update(loglikelihood=np.asarray(derived[likelihood._param_loglikelihood]), logprior=np.asarray(derived[likelihood._param_logprior]), logposterior=np.asarray(logpost))
+    if extras is not None:      # what an oracle needs to follow the reference step by step (keys 'ref/...'): e.g. the window matrix, the theory vectors of the first rows
+        out.update({'ref/' + key: value for key, value in extras(unsolved if solved else likelihood, names, theta).items()})
     fn = os.path.join(here, 'boundary_{}.npz'.format(name))
     np.savez_compressed(fn, **out)
     print('saved', fn, '{:.1f} kB'.format(os.path.getsize(fn) / 1e3), 'keys', len(cfg) - 1, 'errors', len(errors))
@@ -160,6 +162,106 @@ def emulated_pt(cls, engines, params, specs, k, ells=(0, 2, 4), z=0.8):
     emulator.yaml_data = BaseConfig({'class': cls.__name__, 'info': {}, 'params': {}})
     emulator.all_params = ParameterCollection([Parameter(name, **spec) for name, spec in specs.items()])
     return emulator.to_calculator()
+
+
+def jaxeffort_layout_pt(cls, networks, z, params, specs, ells=(0, 2, 4), drop_z=False):
+    """A REAL ``EmulatedCalculator`` of the reference from a state dictionary with the layout ``convert_jaxeffort_to_desilike`` writes (emulators/conversion.py:44-98), through
+    the reference's own ``Emulator.from_state`` / ``__setstate__`` (emulators/__init__.py:218-238) and ``to_calculator`` (150-208).  ``networks``: what jaxeffort's
+    component emulators hold (tests/emulator_utils.py::stacked_networks: synthetic weights).  Layout, field by field:
+
+    * four engines '11', 'loop', 'ct', 'st' of kind 'mlp', ``yshape = (n_z, n_ell, n_m, n_k)``; ``model_operations``: the dense-layer / activation expressions of conversion.py:25-34
+      with every ``kernel`` / ``bias`` stacked ``[n_z, n_ell, ...]`` (``merge_operations``, 58-66); ``xoperations``: ONE min-max scaler, the 'h' row divided by 100 (73-75);
+      ``yoperations``: the min-max scaler with limits ``[n_z, n_ell, n_m, n_k, 2]`` (76-79) and, in front of it, the amplitude operation (88-92);
+    * emulator-level ``yoperations``: the split / concatenate pair of conversion.py:50-51 (``pktable [n_ell, n_k, 19, n_z]``); ``fixed``: ells, k, z; ``in_calculator_state = ['pktable']``.
+
+    ``drop_z``: the single-redshift variant an LPT node needs (its ``combine_bias_terms_poles`` takes ``pktable [n_ell, n_k, 19]``, full_shape.py:1207-1208): the emulator-level
+    inverse additionally selects ``[..., 0]`` -- NOT something conversion.py writes, an adaptation of its layout, stated as such in DESIGN.md."""
+    from desilike.emulators import Emulator, Operation
+    from desilike.parameter import ParameterCollection, Parameter
+    from desilike.utils import serialize_class
+    activation_expressions = {'silu': 'v / (1 + jnp.exp(-v))', 'relu': 'jnp.maximum(v, 0.)', 'tanh': 'jnp.tanh(v)'}                  # conversion.py:27-34
+    concat = "v['pktable'] = jnp.moveaxis(jnp.concatenate([v.pop('11'), v.pop('loop'), v.pop('ct'), v.pop('st')], axis=-2), [0, -1], [-1, 1])"
+    if drop_z: concat += "[..., 0]"
+    state = {'engines': {}, 'xoperations': [], 'defaults': {}, 'fixed': {},
+             'yoperations': [Operation("v['11'], v['loop'], v['ct'], v['st'] = jnp.split(v.pop('pktable'), [3, 12, 16], axis=2); v", concat + "; v").__getstate__()],
+             'varied_params': list(params), 'in_calculator_state': ['pktable'], 'calculator__class__': serialize_class(cls), 'is_calculator_sequence': False,
+             'yaml_data': {'class': cls.__name__, 'info': {}, 'params': {}},
+             'all_params': ParameterCollection([Parameter(name, **spec) for name, spec in specs.items()]).__getstate__()}
+
+    def stack(function):
+        return np.array([[function(networks_iz_ell) for networks_iz_ell in row] for row in component_networks])
+
+    for component, component_networks in networks.items():
+        first = component_networks[0][0]
+        k, nlayers = first['k_grid'], len(first['layers'])
+        model_operations = []
+        for ilayer in range(nlayers):
+            model_operations.append(Operation('(v[..., None, :] @ kernel)[..., 0, :] + bias', locals={'kernel': stack(lambda n: n['layers'][ilayer][0]), 'bias': stack(lambda n: n['layers'][ilayer][1])}))
+            if ilayer < nlayers - 1: model_operations.append(Operation(activation_expressions[first['activations'][ilayer]], locals={}))
+        limits = np.array(component_networks[-1][-1]['in_MinMax'], dtype='f8')                       # the scaler of the last network read (conversion.py:72-75)
+        if 'h' in params: limits[list(params).index('h')] /= 100.
+        xoperations = [Operation('(v - limits[..., 0]) / (limits[..., 1] - limits[..., 0])', locals={'limits': limits})]
+        yoperations = [Operation('((v - limits[..., 0]) / (limits[..., 1] - limits[..., 0]))', inverse='v * (limits[..., 1] - limits[..., 0]) + limits[..., 0]',
+                                 locals={'limits': stack(lambda n: np.asarray(n['out_MinMax']).reshape(-1, len(k), 2))})]
+        if 'logA' in params:
+            if component in ['11', 'ct']: yoperations.insert(0, Operation("v / (jnp.exp(X['logA']) * 1e-10)", inverse="v * jnp.exp(X['logA']) * 1e-10"))
+            if component in ['loop']: yoperations.insert(0, Operation("v / (jnp.exp(X['logA']) * 1e-10)**2", inverse="v * (jnp.exp(X['logA']) * 1e-10)**2"))
+        yshape = (len(z), len(ells), model_operations[-1]._locals['bias'].size // (len(z) * len(ells) * len(k)), len(k))
+        state['engines'][component] = {'name': 'mlp', 'params': list(params), 'xshape': (len(params),), 'yshape': yshape, 'xoperations': [operation.__getstate__() for operation in xoperations],
+                                       'yoperations': [operation.__getstate__() for operation in yoperations], 'model_operations': [operation.__getstate__() for operation in model_operations],
+                                       'model_yoperations': []}
+    state['fixed'].update(ells=list(ells), k=k, z=np.array(z))
+    return Emulator.from_state(state).to_calculator()
+
+
+def stacked_fixtures():
+    """SURVEY 8 row a12 as the reference ships it: the jaxeffort layout (four engines x (z, ell) stacks, amplitude rescale by logA), the redshift selection / blend the REPT node
+    inserts (full_shape.py:1416-1443), under the reference's REPT tracer (``z`` between two emulated redshifts, on one of them) and -- single redshift -- its LPT tracer."""
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    from desilike.theories.galaxy_clustering.full_shape import (LPTVelocileptorsPowerSpectrumMultipoles, LPTVelocileptorsTracerPowerSpectrumMultipoles,
+                                                                REPTVelocileptorsPowerSpectrumMultipoles, REPTVelocileptorsTracerPowerSpectrumMultipoles)
+    from emulator_utils import STK_PARAMS, STK_SPECS, stacked_networks
+    from make_golden import spd_covariance
+    zgrid = np.array([0.3, 0.51, 0.71, 0.92])
+
+    def rept(z, marg, hidden=(32, 32), activation='tanh', seed=3, nk=12):
+        pt = jaxeffort_layout_pt(REPTVelocileptorsPowerSpectrumMultipoles, stacked_networks(zgrid, hidden=hidden, activation=activation, seed=seed), zgrid, STK_PARAMS, STK_SPECS)
+        theory = REPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, z=z, prior_basis=None)                     # (as conversion.py:130 uses it)
+        for name in ['b3', 'alpha6', 'sn4']: theory.init.params[name].update(fixed=True)
+        for name in ['alpha0', 'alpha2', 'alpha4']: theory.init.params[name].update(prior=dict(dist='norm', loc=0., scale=20.))
+        for name in ['sn0', 'sn2']: theory.init.params[name].update(prior=dict(dist='norm', loc=0., scale=2.))
+        if marg:
+            for name in ['alpha0', 'alpha2', 'alpha4', 'sn0', 'sn2']: theory.init.params[name].update(derived='.marg')
+        obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 1.7, 'b2': 0.4, 'alpha0': 3.}, kedges=np.linspace(0.02, 0.2, nk + 1), ells=(0, 2, 4), wmatrix={'resolution': 2}, theory=theory,
+                                                      shotnoise=8e3)
+        return ObservablesGaussianLikelihood(observables=[obs], covariance=spd_covariance(3 * nk, seed=11, diag=4e4, amp=40.))
+
+    def extras(likelihood, names, theta):
+        obs = likelihood.observables[0]
+        wm, theory = obs.wmatrix, obs.wmatrix.theory
+        flat, power, pktable = [], [], []
+        for row in theta[:6]:
+            if not np.isfinite(likelihood(**dict(zip(names, row)))): flat.append(np.full(obs.flatdata.size, np.nan)); power.append(np.full(theory.power.shape, np.nan)); pktable.append(np.full(theory.pt.pktable.shape, np.nan)); continue
+            flat.append(np.array(obs.flattheory)); power.append(np.array(theory.power)); pktable.append(np.array(theory.pt.pktable))
+        return dict(window=np.asarray(wm.matrix_full), k=np.asarray(theory.k), kpt=np.asarray(theory.pt.k), shotnoiseout=np.asarray(wm.shotnoiseout), shotnoisein=np.asarray(wm.shotnoisein),
+                    flattheory=np.array(flat), power=np.array(power), pktable=np.array(pktable), covariance=np.linalg.inv(likelihood.precision))
+
+    dump('cfg3_stacked', lambda: rept(0.6, False), size=24, seed=31, extras=extras)
+    dump('cfg3_stacked_marg', lambda: rept(0.6, True), size=24, seed=31, unsolved=lambda: rept(0.6, False))
+    dump('cfg3_stacked_ongrid', lambda: rept(0.51, False, hidden=(16, 24, 16), activation='silu', seed=5, nk=10), size=24, seed=33)
+
+    def lpt(marg):
+        pt = jaxeffort_layout_pt(LPTVelocileptorsPowerSpectrumMultipoles, stacked_networks(zgrid[:1], hidden=(16, 16), activation='silu', seed=7), zgrid[:1], STK_PARAMS, STK_SPECS, drop_z=True)
+        theory = LPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, prior_basis='standard')
+        for name in ['b3', 'alpha6', 'sn4']: theory.init.params[name].update(fixed=True)
+        for name in ['alpha0', 'alpha2', 'sn0']: theory.init.params[name].update(prior=dict(dist='norm', loc=0., scale=20.))
+        if marg:
+            for name in ['alpha0', 'alpha2', 'sn0']: theory.init.params[name].update(derived='.marg')
+        obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 0.7, 'b2': 0.4, 'alpha0': 3.}, kedges=np.linspace(0.02, 0.2, 11), ells=(0, 2), wmatrix={'resolution': 2}, theory=theory,
+                                                      shotnoise=8e3)
+        return ObservablesGaussianLikelihood(observables=[obs], covariance=spd_covariance(20, seed=13, diag=4e4, amp=40.))
+
+    dump('cfg3_stacked_lpt_marg', lambda: lpt(True), size=24, seed=35, unsolved=lambda: lpt(False))
 
 
 def emulated_fixtures():
@@ -287,6 +389,8 @@ def main():
     dump('two_tracers_mixed', two_tracers_mixed, size=24, seed=24, unsolved=lambda: two_tracers(False))
     # (8) BASELINE configs[2]: emulated perturbation-theory node
     emulated_fixtures()
+    # (9) the emulator layout the reference ships (jaxeffort conversion)
+    stacked_fixtures()
 
 
 if __name__ == '__main__':

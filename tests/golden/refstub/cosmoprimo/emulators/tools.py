@@ -8,7 +8,11 @@ attribute surface that is restated here, nothing more:
   (emulators/conversion.py:20-35), ``xoperations`` / ``yoperations`` = min-max scalers with ``_locals['limits']`` (conversion.py:75-79; ``operation._locals`` /
   ``operation.update(locals=...)``: full_shape.py:1440-1441);
 * emulator: ``engines``, ``xoperations``, ``yoperations``, ``defaults``, ``fixed``, ``varied_params``, ``in_calculator_state``, ``predict(params) -> state``,
-  ``deepcopy`` (emulators/__init__.py:150-208, 386-409; full_shape.py:1416-1443).
+  ``deepcopy`` (emulators/__init__.py:150-208, 386-409; full_shape.py:1416-1443);
+* ``Emulator.from_state(state)`` on the state dictionary emulators/conversion.py:44-98 assembles (the jaxeffort layout): ``engines[name]`` = dict(name='mlp', params, xshape,
+  yshape, xoperations, yoperations, model_operations, model_yoperations) with every operation in its ``__getstate__`` form; operations whose expressions use the inputs
+  by name (``X['logA']``, conversion.py:88-92): ``X`` is the dictionary of the engine's input parameters; kernels stacked over leading axes (conversion.py:58-66) go
+  through the reference's own layer expression by broadcasting.
 
 With it ``Emulator.to_calculator()`` -- the reference's own code -- builds a real ``EmulatedCalculator`` that the reference's velocileptors tracer classes accept as ``pt``.
 The forward pass below is plain NumPy evaluation of the operations' own expression strings; the engine is third-party: parity of the engine itself stays unpinned.
@@ -61,6 +65,12 @@ class Operation(object):
     def __setstate__(self, state):
         self._direct, self._inverse, self._locals = state['direct'], state['inverse'], dict(state['locals'])
 
+    @classmethod
+    def from_state(cls, state):
+        new = cls.__new__(cls)
+        new.__setstate__(state)
+        return new
+
 
 class PCAOperation(Operation):
     pass
@@ -74,11 +84,29 @@ class BaseEmulatorEngine(object):
         self.xoperations, self.yoperations = list(xoperations or []), list(yoperations or [])
 
     def predict(self, X):
-        v = np.asarray(X, dtype='f8')
+        """``X``: the inputs as an array in the order of ``params``, or a dictionary name -> value (operations may then address them by name, conversion.py:88-92)."""
+        if isinstance(X, dict):
+            X = {name: X[name] for name in self.params}
+            v = np.array([X[name] for name in self.params], dtype='f8')
+        else:
+            v = np.asarray(X, dtype='f8')
         for operation in self.xoperations: v = operation(v, X=X)
         v = self._predict_no_operation(v)
         for operation in self.yoperations[::-1]: v = operation.inverse(v, X=X)
         return v
+
+    @classmethod
+    def from_state(cls, state):
+        """The engine dictionary of emulators/conversion.py:94-96."""
+        new = cls.__new__(cls)
+        state = dict(state)
+        state.pop('name', None)
+        for name in ['xoperations', 'yoperations', 'model_operations', 'model_yoperations']:
+            if name in state: state[name] = [operation if isinstance(operation, Operation) else Operation.from_state(operation) for operation in state[name]]
+        for name in ['xshape', 'yshape']:
+            if name in state: state[name] = tuple(state[name])
+        new.__dict__.update(state)
+        return new
 
 
 class PointEmulatorEngine(BaseEmulatorEngine):
@@ -103,11 +131,16 @@ class MLPEmulatorEngine(BaseEmulatorEngine):
         return np.asarray(v).reshape(self.yshape)
 
 
+def get_engine(name):
+    return {'point': PointEmulatorEngine, 'taylor': TaylorEmulatorEngine, 'mlp': MLPEmulatorEngine}[name]
+
+
 class Emulator(object):
 
     def predict(self, params):
         X = np.array([params[name] for name in self.varied_params], dtype='f8')
-        state = {name: engine.predict(X) for name, engine in self.engines.items()}
+        # (an engine built by ``from_state`` names its inputs: it takes the dictionary; the fitted engines of the other fixtures keep the array path -- same arithmetic)
+        state = {name: engine.predict({n: params[n] for n in engine.params} if getattr(engine, '_by_name', False) else X) for name, engine in self.engines.items()}
         state.update(self.fixed)
         for operation in self.yoperations[::-1]: state = operation.inverse(state, X=params)
         return state
@@ -119,4 +152,20 @@ class Emulator(object):
         return dict(self.__dict__)
 
     def __setstate__(self, state):
+        state = dict(state)
+        engines = {}
+        for name, engine in state.get('engines', {}).items():
+            if isinstance(engine, dict):
+                engine = get_engine(engine['name']).from_state(engine)
+                engine._by_name = True
+            engines[name] = engine
+        state['engines'] = engines
+        for name in ['xoperations', 'yoperations']:
+            state[name] = [operation if isinstance(operation, Operation) else Operation.from_state(operation) for operation in state.get(name, [])]
         self.__dict__.update(state)
+
+    @classmethod
+    def from_state(cls, state):
+        new = cls.__new__(cls)
+        new.__setstate__(state)
+        return new
