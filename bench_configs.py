@@ -77,6 +77,92 @@ def cfg3_oracle_solution(like, pt, theory, solved, row):
     return orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=np.zeros(nsol), prior_scale=scales, marg_mask=np.ones(nsol, dtype='?'))
 
 
+# ---- BASELINE configs[2] with the emulator layout the reference ships (emulators/conversion.py:44-98) ---------------------------------------------------------
+STACKED_ZGRID = np.array([0.295, 0.510, 0.706, 0.919, 0.955, 1.317, 1.491])     # seven emulated redshifts (conversion.py:109 holds seven)
+
+
+def stacked_state(networks, z, params, ells=(0, 2, 4)):
+    """The state dictionary of ``convert_jaxeffort_to_desilike`` (emulators/conversion.py:44-98) as plain data, from component networks (tests/emulator_utils.py)."""
+    expressions = {'silu': 'v / (1 + jnp.exp(-v))', 'relu': 'jnp.maximum(v, 0.)', 'tanh': 'jnp.tanh(v)'}
+    state = {'engines': {}, 'fixed': {}}
+    for component, rows in networks.items():
+        first = rows[0][0]
+        k, nlayers = first['k_grid'], len(first['layers'])
+
+        def stack(function):
+            return np.array([[function(n) for n in row] for row in rows])
+
+        operations = []
+        for i in range(nlayers):
+            operations.append(dict(direct='(v[..., None, :] @ kernel)[..., 0, :] + bias', inverse=None, locals={'kernel': stack(lambda n: n['layers'][i][0]), 'bias': stack(lambda n: n['layers'][i][1])}))
+            if i < nlayers - 1: operations.append(dict(direct=expressions[first['activations'][i]], inverse=None, locals={}))
+        limits = np.array(rows[-1][-1]['in_MinMax'], dtype='f8')
+        limits[list(params).index('h')] /= 100.
+        yoperations = [dict(direct='((v - limits[..., 0]) / (limits[..., 1] - limits[..., 0]))', inverse='v * (limits[..., 1] - limits[..., 0]) + limits[..., 0]',
+                            locals={'limits': stack(lambda n: np.asarray(n['out_MinMax']).reshape(-1, len(k), 2))})]
+        if component in ['11', 'ct']: yoperations.insert(0, dict(direct="v / (jnp.exp(X['logA']) * 1e-10)", inverse="v * jnp.exp(X['logA']) * 1e-10", locals={}))
+        if component == 'loop': yoperations.insert(0, dict(direct="v / (jnp.exp(X['logA']) * 1e-10)**2", inverse="v * (jnp.exp(X['logA']) * 1e-10)**2", locals={}))
+        state['engines'][component] = dict(name='mlp', params=list(params), xshape=(len(params),), yshape=yoperations[-1]['locals']['limits'].shape[:-1],
+                                           xoperations=[dict(direct='(v - limits[..., 0]) / (limits[..., 1] - limits[..., 0])', inverse=None, locals={'limits': limits})],
+                                           yoperations=yoperations, model_operations=operations, model_yoperations=[])
+    state['fixed'].update(ells=list(ells), k=k, z=np.array(z))
+    return state
+
+
+def make_cfg3_stacked(marg=True, z=0.8, hidden=(64, 64, 64, 64, 64), activation='tanh', nk=60, seed=11):
+    """BASELINE configs[2] on the jaxeffort layout: 4 engines x 7 redshifts x 3 multipoles = 84 networks 5 -> 5 x 64 tanh -> n_m * 60 outputs, amplitude rescale by logA, the
+    REPT tracer at a redshift between two emulated ones (12 networks survive the blend, + 12 of its neighbour: 24 on the device), 19-monomial combination, cubic interpolation
+    to n_kin = 400, binning window 120 x 1200; solved: alpha0, alpha2, alpha4, sn0, sn2 (n_s = 5, Gaussian priors).  Synthetic weights."""
+    from desilike_amd.emulators import EmulatedCalculator
+    from desilike_amd.theories.galaxy_clustering import REPTVelocileptorsTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    from emulator_utils import STK_PARAMS, STK_SPECS, stacked_networks
+    networks = stacked_networks(STACKED_ZGRID, hidden=hidden, activation=activation, seed=seed, nk=nk)
+    pt = EmulatedCalculator.from_state(stacked_state(networks, STACKED_ZGRID, STK_PARAMS), param_specs=STK_SPECS)
+    theory = REPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, z=z, prior_basis='standard')
+    for name in ['b3', 'alpha6', 'sn4']: theory.init.params[name].update(fixed=True)
+    for name in ['alpha0', 'alpha2', 'alpha4']: theory.init.params[name].update(prior=dict(dist='norm', loc=0., scale=20.))
+    for name in ['sn0', 'sn2']: theory.init.params[name].update(prior=dict(dist='norm', loc=0., scale=2.))
+    solved = ['alpha0', 'alpha2', 'alpha4', 'sn0', 'sn2'] if marg else []
+    for name in solved: theory.init.params[name].update(derived='.marg')
+    rng = np.random.RandomState(5)
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 1.7, 'b2': 0.4, 'alpha0': 3.}, kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=8e3)
+    A = rng.standard_normal((120, 120)) * 40.
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + 4e4 * np.eye(120))
+    return like, pt, theory, solved, networks
+
+
+def cfg3_stacked_oracle_solution(like, pt, theory, solved, row):
+    """The NumPy oracle at one point of the stacked configuration: every network of every engine by the stacked layer expression (``stacked_mlp_predict``), assembly and
+    redshift blend (``jaxeffort_pktable``), REPT co-evolution + 19-monomial combination, cubic interpolation, window -- the chain tests/test_stacked.py pins on the
+    reference -- then ``solve_marginalized``."""
+    orc = _orc()
+    names = like.varied_params.names()
+    nsol = len(solved)
+    wm = like.observables[0].wmatrix
+    zgrid = np.atleast_1d(pt.z)
+    powers = {'11': 1, 'loop': 2, 'ct': 1, 'st': 0}
+
+    def flat(x):
+        p = dict(zip(names, row)); p.update(x)
+        X = {name: p[name] for name in pt.param_names}
+        components = [orc.stacked_mlp_predict(X, pt.param_names, pt.engines[name].xlimits, pt.engines[name].layers, pt.engines[name].activation, pt.engines[name].ylimits, amplitude_power=powers[name])
+                      for name in ['11', 'loop', 'ct', 'st']]
+        pktable = orc.jaxeffort_pktable(components, zgrid=zgrid, z=[theory.z])[..., 0]
+        params = {name: p.get(name, like.all_params[name].value) for name in ['b1', 'b2', 'bs', 'b3', 'alpha0', 'alpha2', 'alpha4', 'alpha6', 'sn0', 'sn2', 'sn4']}
+        pars = orc.velocileptors_pars(params, 1., 1., basis='standard', model='rept')
+        power = orc.interp1d(theory.k, pt.k, orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=theory.nd).T).T
+        return orc.window_apply(power, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout)
+
+    f0 = flat({name: 0. for name in solved})
+    if not nsol:
+        return {'loglikelihood': orc.gaussian_loglikelihood(f0, like.flatdata, like.precision)[0]}
+    scales = np.array([like.all_params[name].prior.scale for name in solved])
+    T = np.array([flat({n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
+    return orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=np.zeros(nsol), prior_scale=scales, marg_mask=np.ones(nsol, dtype='?'))
+
+
 def make_cfg2(dense=False, data=None):
     from desilike_amd.theories.galaxy_clustering import ShapeFitPowerSpectrumTemplate, KaiserTracerPowerSpectrumMultipoles
     from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable

@@ -49,94 +49,95 @@ static inline bool dl_stk_feature_ok(const DlObsDev& o) {
 }
 
 #if defined(__HIPCC__)
-// One network on one wave: 16 points from `in0` (row stride ld0; layer 0) through `n_layers` dense layers; hidden activations in the wave's buffer `buf` (row stride tld),
-// the last layer's output to dst[point * dst_ld + unit] (`last_act`: activated -- a table network stops after its last HIDDEN layer -- or `v * yscale + ylo`: a scalar engine).
-__device__ __forceinline__ void dl_stk_network(const int32_t* widths, int n_layers, int act, const double* __restrict__ w, const double* in0, int ld0, double* buf, int tld,
-                                               double* dst, int dst_ld, bool last_act, double yscale, double ylo, int lane) {
+// One network on one wave: 16 points from `in0` (row stride ld0; layer 0; columns beyond the inputs zero up to a multiple of 4) through `n_layers` dense layers, every one
+// activated (a table network stops after its last HIDDEN layer); hidden activations in the wave's buffer `buf` (row stride tld), the last layer's output to
+// dst[point * dst_ld + unit].  `wf`: the network's weights in fragment order (DlObsDev::Stack::wfrag): a B-operand load is base + lane + immediate, no predicates.
+template <int TMAX>
+__device__ __forceinline__ void dl_stk_network(const int32_t* widths, int n_layers, int act, const double* __restrict__ wf, const double* in0, int ld0, double* buf, int tld,
+                                               double* dst, int dst_ld, int lane) {
     const int col = lane & 15, g = lane >> 4;
+    wf += lane;
     for (int layer = 0; layer < n_layers; ++layer) {
         const int nin = widths[layer], nout = widths[layer + 1];
         const int ksteps = (nin + 3) / 4, tiles = (nout + 15) / 16;
         const bool last = layer == n_layers - 1;
-        const double* src = layer == 0 ? in0 : buf;
-        const int lds_ld = layer == 0 ? ld0 : tld;
-        dl_stk_double4 res[DL_STK_TMAX];
-        double bw[16], bwn[16];
-        auto request = [&](double (&dstw)[16], int t, int ks0) {
-            const int oc = 16 * t + col;
+        const double* ap = (layer == 0 ? in0 + col * ld0 : buf + col * tld) + g;
+        dl_stk_double4 res[TMAX];
+        if (ksteps == 16) {
+            // a 64-input layer (the hidden layers): sixteen k-steps per output tile, the weights of the NEXT tile requested before the MFMAs of the current one
+            double bw[16], bwn[16], av[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int k = 4 * (ks0 + u) + g;
-                const bool ok = ks0 + u < ksteps && k < nin && oc < nout;
-                const double v = w[ok ? (unsigned)(k * nout + oc) : 0u];
-                dstw[u] = ok ? v : 0.;
-            }
-        };
-        request(bw, 0, 0);
+            for (int u = 0; u < 16; ++u) bw[u] = wf[u * 64];
 #pragma unroll
-        for (int t = 0; t < DL_STK_TMAX; ++t) {
-            if (t >= tiles) break;
-            dl_stk_double4 acc = {0., 0., 0., 0.}, acc2 = {0., 0., 0., 0.};
-            for (int ks0 = 0; ks0 < ksteps; ks0 += 16) {
-                // the weights of the next sixteen k-steps (of this tile, or the first sixteen of the next tile) go out before the MFMAs of these
-                const bool more = ks0 + 16 < ksteps;
-                if (more) request(bwn, t, ks0 + 16);
-                else if (t + 1 < tiles) request(bwn, t + 1, 0);
-                double av[16];
+            for (int u = 0; u < 16; ++u) av[u] = ap[4 * u];              // the A operand is the same for every output tile
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int k = 4 * (ks0 + u) + g;
-                    const double a = src[col * lds_ld + (k < nin ? k : 0)];
-                    av[u] = (ks0 + u < ksteps && k < nin) ? a : 0.;
+            for (int t = 0; t < TMAX; ++t) {
+                if (t >= tiles) break;
+                if (t + 1 < tiles) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) bwn[u] = wf[((t + 1) * 16 + u) * 64];
                 }
+                dl_stk_double4 acc = {0., 0., 0., 0.}, acc2 = {0., 0., 0., 0.};   // two chains: a dependent MFMA waits for its predecessor
 #pragma unroll
                 for (int u = 0; u < 16; u += 2) {
-                    if (ks0 + u < ksteps) {     // (wave-uniform: an input layer of five parameters is two k-steps, not sixteen)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bw[u], acc, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], bw[u + 1], acc2, 0, 0, 0);
-                    }
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bw[u], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], bw[u + 1], acc2, 0, 0, 0);
                 }
+                res[t] = acc + acc2;
 #pragma unroll
                 for (int u = 0; u < 16; ++u) bw[u] = bwn[u];
             }
-            res[t] = acc + acc2;
-        }
-        const double* bias = w + (size_t)nin * nout;
+        } else {
 #pragma unroll
-        for (int t = 0; t < DL_STK_TMAX; ++t) {
+            for (int t = 0; t < TMAX; ++t) {
+                if (t >= tiles) break;
+                dl_stk_double4 acc = {0., 0., 0., 0.}, acc2 = {0., 0., 0., 0.};
+                const double* wt = wf + (size_t)t * ksteps * 64;
+                for (int u = 0; u < ksteps; u += 2) {
+                    const bool two = u + 1 < ksteps;
+                    const double b0 = wt[u * 64], b1 = wt[(two ? u + 1 : u) * 64];
+                    const double a0 = ap[4 * u], a1 = ap[4 * (two ? u + 1 : u)];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+                    if (two) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc2, 0, 0, 0);
+                }
+                res[t] = acc + acc2;
+            }
+        }
+        const double* bias = wf + (size_t)tiles * ksteps * 64 - lane + col;      // [tile][16]
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
             if (t >= tiles) break;
             const int oc = 16 * t + col;
-            const double b = bias[oc < nout ? oc : 0];
+            const double b = bias[16 * t];
             double vv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) vv[r] = res[t][r] + b;          // accumulator register r = out[point g + 4 r][oc]
-            if (!last || last_act) {
-                if (act == 0) {
+            if (act == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[r] = vv[r] / (1. + exp(-vv[r]));      // silu, conversion.py:29
-                } else if (act == 1) {
+                for (int r = 0; r < 4; ++r) vv[r] = vv[r] / (1. + exp(-vv[r]));      // silu, conversion.py:29
+            } else if (act == 1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[r] = vv[r] > 0. ? vv[r] : 0.;
-                } else {
+                for (int r = 0; r < 4; ++r) vv[r] = vv[r] > 0. ? vv[r] : 0.;
+            } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[r] = tanh(vv[r]);
-                }
+                for (int r = 0; r < 4; ++r) vv[r] = tanh(vv[r]);
             }
-            if (oc < nout) {
+            // hidden layers: in place -- every read of this layer precedes (one wave: LDS operations complete in order); units beyond the layer (zero weights and bias) are
+            // written too when they pad the next layer's k-steps: act(0) of silu / relu / tanh is 0
+            const int nout4 = (nout + 3) & ~3;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (!last) buf[(g + 4 * r) * tld + oc] = vv[r];      // in place: every read of this layer precedes (one wave: LDS operations complete in order)
-                    else dst[(g + 4 * r) * dst_ld + oc] = last_act ? vv[r] : vv[r] * yscale + ylo;
-                }
+            for (int r = 0; r < 4; ++r) {
+                if (!last) { if (oc < nout4) buf[(g + 4 * r) * tld + oc] = vv[r]; }
+                else if (oc < nout) dst[(g + 4 * r) * dst_ld + oc] = vv[r];
             }
         }
-        w += (size_t)nin * nout + nout;
+        wf += (size_t)tiles * ksteps * 64 + 16 * tiles;
     }
 }
 
 // feature GEMM of one group: CNT monomials, nq operand steps of 8 basis functions; then the contraction with the (amplitude-scaled) monomial rows into the carried rows
-template <int CNT>
-__device__ __forceinline__ void dl_stk_group_gemm(const double* arow, const dl_fg_double2* __restrict__ gw, int nq, const double* mono, int R, int g, double (&outv)[4][DL_STK_ROWS]) {
+template <int CNT, int RMAX>
+__device__ __forceinline__ void dl_stk_group_gemm(const double* arow, const dl_fg_double2* __restrict__ gw, int nq, const double* mono, int R, int g, double (&outv)[4][RMAX]) {
     dl_fg_double4 acc[CNT];
 #pragma unroll
     for (int i = 0; i < CNT; ++i) acc[i] = (dl_fg_double4){0., 0., 0., 0.};
@@ -150,10 +151,9 @@ __device__ __forceinline__ void dl_stk_group_gemm(const double* arow, const dl_f
         for (int i = 0; i < CNT; ++i) b2[i] = gw[(size_t)(qn * CNT + i) * 64];
         const dl_fg_double2 a = *reinterpret_cast<const dl_fg_double2*>(arow + 8 * q);
 #pragma unroll
-        for (int i = 0; i < CNT; ++i) {
-            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0[i].x, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b0[i].y, acc[i], 0, 0, 0);
-        }
+        for (int i = 0; i < CNT; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0[i].x, acc[i], 0, 0, 0);      // (the two MFMAs of an accumulator CNT instructions apart)
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b0[i].y, acc[i], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < CNT; ++i) { b0[i] = b1[i]; b1[i] = b2[i]; }
     }
@@ -162,7 +162,7 @@ __device__ __forceinline__ void dl_stk_group_gemm(const double* arow, const dl_f
     for (int rr = 0; rr < 4; ++rr) {
         const double* mp = mono + (size_t)(g + 4 * rr) * DL_STK_ROWS * DL_FG_MONO_LD;
 #pragma unroll
-        for (int u = 0; u < DL_STK_ROWS; ++u) {
+        for (int u = 0; u < RMAX; ++u) {
             if (u < R) {
                 double v = outv[rr][u];
 #pragma unroll
@@ -174,6 +174,8 @@ __device__ __forceinline__ void dl_stk_group_gemm(const double* arow, const dl_f
 }
 
 // theta -> residual rows out[B * R, ldo] (+= if accumulate) of one observable; gfrag: [N_pad / 16][sum_g nq_g cnt_g][64][2]; blockIdx.y = group of 8 column blocks
+// TMAX: output tiles per layer (4: widths <= 64, 8: <= 128); RMAX: rows carried per point in registers (>= 1 + n_var)
+template <int TMAX, int RMAX>
 __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ gfrag, const DlObsDev o,
                                                                   double* __restrict__ out, int64_t ldo, int accumulate, int steps_per_block) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -211,18 +213,40 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
         vpv[pt * 12 + c] = dl_get(o.vp_in[c], theta + (size_t)b * n_params);
     }
     __syncthreads();
-    // ---- scalar engines (sigma8, fsigma8: the physical prior basis), one wave each; the amplitudes of the groups meanwhile ----
-    if (wave >= 1 && wave <= 2 && o.eng[wave].type == 0) {
-        const DlObsDev::Engine& en = o.eng[wave];
-        dl_stk_network(en.widths, en.n_layers, en.act, en.weights, xs + (size_t)wave * DL_STK_PTS * XLD, XLD, wbuf, tld, scal + wave, 4, false, en.yscale, en.ylo, lane);
-    } else if (wave == 3) {
-        for (int idx = lane; idx < DL_STK_PTS * o.stk.n_groups; idx += 64) {
-            const int pt = idx / o.stk.n_groups, gi = idx - pt * o.stk.n_groups;
-            const double* sc = o.stk.scale + (size_t)gi * (o.n_x + 1);
-            double la = sc[o.n_x];
-            for (int j = 0; j < o.n_x; ++j) la = fma(sc[j], x[pt * DL_MAX_X + j], la);
-            amp[pt * DL_STK_MAX_GROUPS + gi] = la == 0. ? 1. : exp(la);
+    // ---- scalar engines (sigma8, fsigma8: the physical prior basis; small networks): a thread per (point, unit), layer by layer, in the still unused basis record;
+    //      the amplitudes of the groups ----
+    for (int ie = 1; ie < 3; ++ie) {
+        const DlObsDev::Engine& en = o.eng[ie];
+        if (en.type != 0) continue;
+        double* cur = basis;
+        double* nxt = basis + DL_STK_PTS * tld;
+        const double* w = en.weights;
+        for (int layer = 0; layer < en.n_layers; ++layer) {
+            const int nin = en.widths[layer], nout = en.widths[layer + 1];
+            const bool last = layer == en.n_layers - 1;
+            const double* src = layer == 0 ? xs + (size_t)ie * DL_STK_PTS * XLD : cur;
+            const int sld = layer == 0 ? XLD : tld;
+            for (int idx = tid; idx < DL_STK_PTS * nout; idx += 512) {
+                const int pt = idx / nout, j = idx - pt * nout;
+                double acc0 = w[(size_t)nin * nout + j], acc1 = 0.;       // (the summation order of dl_emu_layer)
+                int i = 0;
+                for (; i + 2 <= nin; i += 2) { acc0 = fma(src[pt * sld + i], w[(size_t)i * nout + j], acc0); acc1 = fma(src[pt * sld + i + 1], w[(size_t)(i + 1) * nout + j], acc1); }
+                if (i < nin) acc0 = fma(src[pt * sld + i], w[(size_t)i * nout + j], acc0);
+                const double v = acc0 + acc1;
+                if (last) { if (j == 0) scal[pt * 4 + ie] = v * en.yscale + en.ylo; }      // inverse scaler, conversion.py:79
+                else nxt[pt * tld + j] = dl_activation(en.act, v);
+            }
+            __syncthreads();
+            w += (size_t)nin * nout + nout;
+            double* sw = cur; cur = nxt; nxt = sw;
         }
+    }
+    for (int idx = tid; idx < DL_STK_PTS * o.stk.n_groups; idx += 512) {
+        const int pt = idx / o.stk.n_groups, gi = idx - pt * o.stk.n_groups;
+        const double* sc = o.stk.scale + (size_t)gi * (o.n_x + 1);
+        double la = sc[o.n_x];
+        for (int j = 0; j < o.n_x; ++j) la = fma(sc[j], x[pt * DL_MAX_X + j], la);
+        amp[pt * DL_STK_MAX_GROUPS + gi] = la == 0. ? 1. : exp(la);
     }
     __syncthreads();
     // ---- monomial rows: one lane per (point, row), then scaled group by group (a monomial belongs to one group; monomials of no group feed nothing) ----
@@ -241,11 +265,11 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
         }
     }
     // ---- group by group: networks, then the feature GEMM ----
-    double outv[4][DL_STK_ROWS];
+    double outv[4][RMAX];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-        for (int u = 0; u < DL_STK_ROWS; ++u) outv[rr][u] = 0.;
+        for (int u = 0; u < RMAX; ++u) outv[rr][u] = 0.;
     const int jb = blockIdx.y * 8 + wave;
     const dl_fg_double2* gcol = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * steps_per_block * 64 + lane;
     int tb_prev = -1, te_prev = -1;
@@ -256,8 +280,8 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
         if (tb != tb_prev || te != te_prev) {
             __syncthreads();    // the basis record is free (the previous group's GEMM is done); first group: the monomial rows are complete
             for (int t = tb + wave; t < te; t += 8)
-                dl_stk_network(o.eng[0].widths, o.eng[0].n_layers, o.eng[0].act, o.eng[0].weights + (size_t)t * o.stk.trunk_doubles, xs, XLD, wbuf, tld,
-                               basis + (size_t)(t - tb) * H, bld, true, 1., 0., lane);
+                dl_stk_network<TMAX>(o.eng[0].widths, o.eng[0].n_layers, o.eng[0].act, o.stk.wfrag + (size_t)t * o.stk.frag_doubles, xs, XLD, wbuf, tld,
+                               basis + (size_t)(t - tb) * H, bld, lane);
             for (int idx = tid; idx < DL_STK_PTS * (8 * nq - (K - 1)); idx += 512) {      // the constant basis function and the zero padding of the last step
                 const int pt = idx / (8 * nq - (K - 1)), c = K - 1 + (idx - pt * (8 * nq - (K - 1)));
                 basis[(size_t)pt * bld + c] = c == K - 1 ? 1. : 0.;
@@ -269,16 +293,11 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
         const dl_fg_double2* gw = gcol + (size_t)kq * 64;
         const double* mp = mono + m0;
         switch (m1 - m0) {
-            case 1: dl_stk_group_gemm<1>(arow, gw, nq, mp, R, g, outv); break;
-            case 2: dl_stk_group_gemm<2>(arow, gw, nq, mp, R, g, outv); break;
-            case 3: dl_stk_group_gemm<3>(arow, gw, nq, mp, R, g, outv); break;
-            case 4: dl_stk_group_gemm<4>(arow, gw, nq, mp, R, g, outv); break;
-            case 5: dl_stk_group_gemm<5>(arow, gw, nq, mp, R, g, outv); break;
-            case 6: dl_stk_group_gemm<6>(arow, gw, nq, mp, R, g, outv); break;
-            case 7: dl_stk_group_gemm<7>(arow, gw, nq, mp, R, g, outv); break;
-            case 8: dl_stk_group_gemm<8>(arow, gw, nq, mp, R, g, outv); break;
-            case 9: dl_stk_group_gemm<9>(arow, gw, nq, mp, R, g, outv); break;
-            default: dl_stk_group_gemm<10>(arow, gw, nq, mp, R, g, outv); break;
+            case 1: dl_stk_group_gemm<1, RMAX>(arow, gw, nq, mp, R, g, outv); break;
+            case 2: dl_stk_group_gemm<2, RMAX>(arow, gw, nq, mp, R, g, outv); break;
+            case 3: dl_stk_group_gemm<3, RMAX>(arow, gw, nq, mp, R, g, outv); break;
+            case 4: dl_stk_group_gemm<4, RMAX>(arow, gw, nq, mp, R, g, outv); break;
+            default: dl_stk_group_gemm<5, RMAX>(arow, gw, nq, mp, R, g, outv); break;
         }
     }
 #pragma unroll
@@ -286,7 +305,7 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
         const int pt = g + 4 * rr;
         if (p0 + pt < B) {
 #pragma unroll
-            for (int u = 0; u < DL_STK_ROWS; ++u) {
+            for (int u = 0; u < RMAX; ++u) {
                 if (u < R) {
                     double* dst = out + ((size_t)(p0 + pt) * R + u) * ldo + jb * 16 + col;
                     *dst = accumulate ? *dst + outv[rr][u] : outv[rr][u];

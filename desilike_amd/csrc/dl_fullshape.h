@@ -52,8 +52,8 @@
 #define DL_N_VPARS 11      // velocileptors 'pars': b1 b2 bs b3 alpha0 alpha2 alpha4 alpha6 sn0 sn2 sn4 (full_shape.py:1184)
 #define DL_N_MONO 19       // bias monomials (full_shape.py:1185)
 #define DL_STK_REC 8       // doubles per group record of the stacked table engine (DlObsDev::Stack)
-#define DL_STK_MAX_GROUPS 8
-#define DL_STK_MAX_MONO 10  // monomials per device group (accumulator tiles of the feature GEMM)
+#define DL_STK_MAX_GROUPS 8   // device groups (a group of more than DL_STK_MAX_MONO monomials is split; the networks are shared)
+#define DL_STK_MAX_MONO 5   // monomials per device group (accumulator tiles of the feature GEMM: with the three operand buffers, 20 registers per monomial)
 #define DL_MAX_ML 40       // multiplicative wiggle terms of the flexible BAO model (bao.py:310-322: up to 12 nodes per multipole)
 #define DL_PNG_MAX_MU 48   // mu nodes of the PNG kernel (its tracer-velocity variant integrates 81 trapezoid nodes on [-1, 1]: 41 after folding)
 #define DL_MAX_BAND 16     // bands of the velocity-divergence template
@@ -148,6 +148,9 @@ struct DlObsDev {
     // bias monomials [m0, m1) (the engines '11' / 'loop' / 'ct' / 'st' x (z, ell) stacks), times an amplitude that is log-linear in the inputs (conversion.py:88-92)
     struct Stack {
         int32_t n_groups, n_trunks, trunk_doubles, max_k;   // max_k: largest number of basis functions of a group, (te - tb) * H + 1
+        int32_t frag_doubles, pad_frag;                     // doubles of one network in `wfrag`
+        const double* wfrag;   // the networks' weights in MFMA fragment order (dl_emu_stacked.h): per network, per layer [output tile][k-step][lane = col + 16 g] = K[4 step + g][16 tile + col]
+                               //   (zero beyond the layer), then the biases [output tile][16]
         const double* table;   // [n_groups][DL_STK_REC] as doubles: tb, te, m0, m1, col (first column of the group's block in the theory vector), nm (monomials per basis
                                //   function in that block: the column stride), mo (m0 - first monomial of the block), kq (first operand step of the group in a column block)
         const double* scale;   // [n_groups][n_x + 1]: log amplitude = scale[g][n_x] + sum_j scale[g][j] x_j

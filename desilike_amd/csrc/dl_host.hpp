@@ -65,7 +65,7 @@ struct DlObsHost {
     size_t off_kin, off_lkin, off_mu, off_wmu, off_xt, off_pk, off_th, off_lg, off_ih, off_dlt, off_A, off_nC, off_inv, off_gf, off_gb, off_coef, off_ct, off_sn;
     size_t off_cw, off_cn, off_pknowk, off_ml, off_pass, off_png = 0, off_band = 0;
     size_t off_eng[3][6];   // xlo, xinv, weights, center, powers, coef of each emulator engine
-    size_t off_stk[2] = {0, 0};   // group table, amplitude table of the stacked table engine
+    size_t off_stk[3] = {0, 0, 0};   // group table, amplitude table, fragment-ordered weights of the stacked table engine
     int marg_vp[DL_N_VPARS];
     int marg_pass[DL_MAX_PASS];
     int n_cols() const { return dev.n_in + dev.n_pass; }   // columns of this observable in the theory vector / window matrix
@@ -81,7 +81,7 @@ struct DlObsHost {
             dev.eng[e].xlo = base + off_eng[e][0]; dev.eng[e].xinv = base + off_eng[e][1]; dev.eng[e].weights = base + off_eng[e][2];
             dev.eng[e].center = base + off_eng[e][3]; dev.eng[e].powers = base + off_eng[e][4]; dev.eng[e].coef = base + off_eng[e][5];
         }
-        dev.stk.table = base + off_stk[0]; dev.stk.scale = base + off_stk[1];
+        dev.stk.table = base + off_stk[0]; dev.stk.scale = base + off_stk[1]; dev.stk.wfrag = base + off_stk[2];
     }
 };
 
@@ -334,7 +334,25 @@ inline bool dl_build_emulated_obs(const dl_config& cfg, const std::string& p, in
             xlo.assign(d.n_x, 0.); xinv.assign(d.n_x, 0.);
             for (int c = 0; c < d.n_x; ++c) { xlo[c] = xl[2 * c]; xinv[c] = 1. / (xl[2 * c + 1] - xl[2 * c]); }
             weights = w;
-            oh.off_stk[0] = arena.push(table); oh.off_stk[1] = arena.push(amp);
+            // the same weights in MFMA fragment order for the batched kernel (dl_emu_stacked.h): a B-operand load is then base + lane + immediate, zero padding instead of predicates
+            std::vector<double> wfrag;
+            for (int t = 0; t < n_trunks; ++t) {
+                const double* wl = w.data() + (size_t)t * per;
+                for (int l = 0; l < en.n_layers; ++l) {
+                    const int nin = widths[l], nout = widths[l + 1], ksteps = (nin + 3) / 4, tiles = (nout + 15) / 16;
+                    for (int tile = 0; tile < tiles; ++tile)
+                        for (int u = 0; u < ksteps; ++u)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int k = 4 * u + (lane >> 4), oc = 16 * tile + (lane & 15);
+                                wfrag.push_back(k < nin && oc < nout ? wl[(size_t)k * nout + oc] : 0.);
+                            }
+                    for (int oc = 0; oc < 16 * tiles; ++oc) wfrag.push_back(oc < nout ? wl[(size_t)nin * nout + oc] : 0.);
+                    wl += (size_t)nin * nout + nout;
+                }
+                if (t == 0) d.stk.frag_doubles = (int32_t)wfrag.size();
+            }
+            if (wfrag.empty()) wfrag.assign(2, 0.);
+            oh.off_stk[0] = arena.push(table); oh.off_stk[1] = arena.push(amp); oh.off_stk[2] = arena.push(wfrag);
         } else if (en.type == 1) {
             const auto& ce = cfg.F(q + "center");
             const auto& po = cfg.I(q + "powers");

@@ -865,9 +865,15 @@ bool dl_emulated_stacked_ok(const DlObsDev& obs) { return dl_stk_feature_ok(obs)
 void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
                                 int steps_per_block, hipStream_t stream) {
     const size_t shm = dl_stk_shared_doubles(obs) * sizeof(double);
-    (void)hipFuncSetAttribute((const void*)dl_emulated_stacked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    DL_LAUNCH(dl_emulated_stacked_kernel, dim3((unsigned)((B + DL_STK_PTS - 1) / DL_STK_PTS), (unsigned)(N_pad / 128)), dim3(512), shm, stream, theta, n_params, B, gfrag, obs,
-                       out, ldo, accumulate, steps_per_block);
+    const int R = 1 + obs.n_var;
+    auto launch = [&](auto kernel) {
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        DL_LAUNCH(kernel, dim3((unsigned)((B + DL_STK_PTS - 1) / DL_STK_PTS), (unsigned)(N_pad / 128)), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, out, ldo, accumulate,
+                  steps_per_block);
+    };
+    const bool wide = dl_stk_tld(obs) > 66;   // a layer wider than 64 units: eight output tiles per layer
+    if (wide) { if (R <= 1) launch(dl_emulated_stacked_kernel<8, 1>); else if (R <= 4) launch(dl_emulated_stacked_kernel<8, 4>); else if (R <= 6) launch(dl_emulated_stacked_kernel<8, 6>); else launch(dl_emulated_stacked_kernel<8, 8>); }
+    else { if (R <= 1) launch(dl_emulated_stacked_kernel<4, 1>); else if (R <= 4) launch(dl_emulated_stacked_kernel<4, 4>); else if (R <= 6) launch(dl_emulated_stacked_kernel<4, 6>); else launch(dl_emulated_stacked_kernel<4, 8>); }
 }
 
 bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, const double* bias, const DlMargDev& mg, int n_valid,

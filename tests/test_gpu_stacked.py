@@ -1,0 +1,118 @@
+"""GPU (-m gpu): SURVEY 8 row a12 with the emulator layout the reference ships (emulators/conversion.py:44-98) -- engines '11' / 'loop' / 'ct' / 'st' stacked over (z, ell),
+amplitude rescale by logA, redshift blend -- at the size of BASELINE configs[2] (4096 batched evaluations, 5 analytically marginalised parameters), through the MFMA kernel
+``dl_emulated_stacked_kernel`` and through the general per-point path, against the oracle chain that tests/test_stacked.py pins on the reference's own outputs."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as orc
+from bench_configs import make_cfg3_stacked, cfg3_stacked_oracle_solution, stacked_state, STACKED_ZGRID   # noqa: E402
+from emulator_utils import STK_PARAMS, STK_SPECS, stacked_networks
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def sample(like, size, seed):
+    rng = np.random.RandomState(seed)
+    return np.column_stack([np.clip(param.ref.sample(size=size, random_state=rng), *param.prior.limits) for param in like.varied_params])
+
+
+def test_stacked_full_size_marginalised_4096():
+    like, pt, theory, solved, networks = make_cfg3_stacked(marg=True)
+    like.initialize()
+    assert like.solved_params.names() == solved
+    spec = like._spec({}, like._flatdata_list(), like.precision)['observables'][0]
+    groups = np.asarray(spec['emu0']['groups'])
+    assert groups.tolist() == [[0, 6, 0, 3], [6, 12, 3, 12], [12, 18, 12, 16], [18, 18, 16, 19]]          # two redshifts x three multipoles per engine; 'st' holds constant tables
+    assert spec['wmatrix'].shape == (120, (6 * 64 + 1) * 16 + 3)
+    theta = sample(like, 4096, 3)
+    ctx = like._get_context()
+    loglike, logprior, status, xsolved = ctx.eval_batch_host(theta, return_solved=True)
+    assert (status == 0).all() and np.isfinite(loglike).all()
+    worst = 0.
+    for i in range(0, 4096, 64):
+        i += (i // 64) % 16
+        sol = cfg3_stacked_oracle_solution(like, pt, theory, solved, theta[i])
+        err = abs(loglike[i] - sol['loglikelihood']) / max(1., abs(sol['loglikelihood']))
+        worst = max(worst, err)
+        assert err <= TOL, (i, loglike[i], sol['loglikelihood'], err)
+        assert np.allclose(xsolved[i], sol['x'], rtol=1e-7, atol=1e-9)
+    print('stacked emulator, marginalised, 64 of 4096 points: max relative error on logL {:.2e}'.format(worst))
+    # ragged batches: the same rows whatever the batch they sit in
+    for size in (1, 17, 100):
+        part = ctx.eval_batch_host(theta[:size])[0]
+        assert np.array_equal(part, loglike[:size]), size
+
+
+def test_stacked_unmarginalised_and_general_path():
+    """No solved parameters; the theory vector itself through the general per-point path (``return_flattheory``: power -> window GEMM), against the oracle; both paths agree."""
+    like, pt, theory, solved, networks = make_cfg3_stacked(marg=False, z=0.955, hidden=(48, 80), activation='silu', nk=40, seed=2)   # on an emulated redshift: one stack per engine survives
+    like.initialize()
+    spec = like._spec({}, like._flatdata_list(), like.precision)['observables'][0]
+    assert np.asarray(spec['emu0']['groups'])[:, :2].tolist() == [[0, 3], [3, 6], [6, 9], [9, 9]]
+    theta = sample(like, 300, 5)
+    names = like.varied_params.names()
+    ctx = like._get_context()
+    loglike, logprior, status = ctx.eval_batch_host(theta)
+    assert (status == 0).all()
+    for i in range(0, 300, 23):
+        sol = cfg3_stacked_oracle_solution(like, pt, theory, [], theta[i])
+        assert abs(loglike[i] - sol['loglikelihood']) <= TOL * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
+    like._evaluate_dict({name: theta[:5, j] for j, name in enumerate(names)}, (5,), errors='return', return_flattheory=True)
+    flat = np.array(like.flattheory)
+    for i in range(5):
+        ll = orc.gaussian_loglikelihood(flat[i], like.flatdata, like.precision)[0]
+        assert abs(ll - loglike[i]) <= TOL * max(1., abs(loglike[i]))
+
+
+def test_stacked_with_scalar_engines_physical_basis():
+    """The physical prior basis (full_shape.py:1577-1592) on a stacked node that also emulates sigma8 / fsigma8 (scalar MLP engines run beside the table networks)."""
+    from desilike_amd.emulators import EmulatedCalculator, MLPEmulatorEngine
+    from desilike_amd.theories.galaxy_clustering import REPTVelocileptorsTracerPowerSpectrumMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    zgrid = STACKED_ZGRID[:3]
+    networks = stacked_networks(zgrid, hidden=(32, 32), activation='tanh', seed=8, nk=30)
+    pt = EmulatedCalculator.from_state(stacked_state(networks, zgrid, STK_PARAMS), param_specs=STK_SPECS)
+    rng = np.random.RandomState(4)
+    xlimits = pt.engines['11'].xlimits
+
+    def scalar(lo, hi):
+        layers, last = [], len(STK_PARAMS)
+        for width in [16, 1]:
+            layers.append((rng.standard_normal((last, width)) / last**0.5, 0.1 * rng.standard_normal(width)))
+            last = width
+        return MLPEmulatorEngine(xlimits=xlimits, layers=layers, activation='tanh', ylimits=[[lo, hi]])
+
+    pt = EmulatedCalculator(STK_PARAMS, {**pt.engines, 'sigma8': scalar(0.7, 0.9), 'fsigma8': scalar(0.4, 0.5)}, k=pt.k, ells=pt.ells, z=zgrid, param_specs=STK_SPECS)
+    theory = REPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, z=0.4, tracer='LRG')
+    for name in ['alpha0p', 'sn0p']: theory.init.params[name].update(derived='.marg')
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1p': 1.4, 'b2p': 0.3}, kedges=np.linspace(0.02, 0.2, 19), ells=(0, 2), wmatrix={'resolution': 3}, theory=theory, shotnoise=8e3)
+    A = rng.standard_normal((36, 36)) * 40.
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + 4e4 * np.eye(36))
+    like.initialize()
+    names, solved = like.varied_params.names(), like.solved_params.names()
+    theta = sample(like, 64, 9)
+    loglike, logprior, status, xsolved = like._get_context().eval_batch_host(theta, return_solved=True)
+    assert (status == 0).all()
+    wm = like.observables[0].wmatrix
+    index = [list(pt.ells).index(ell) for ell in theory.ells]
+    for i in range(0, 64, 7):
+        def flat(x):
+            p = dict(zip(names, theta[i])); p.update(x)
+            X = {name: p[name] for name in STK_PARAMS}
+            components = [orc.stacked_mlp_predict(X, STK_PARAMS, pt.engines[n].xlimits, pt.engines[n].layers, 'tanh', pt.engines[n].ylimits, amplitude_power=pw) for n, pw in [('11', 1), ('loop', 2), ('ct', 1), ('st', 0)]]
+            pktable = orc.jaxeffort_pktable(components, zgrid=zgrid, z=[0.4])[..., 0][index]
+            xin = np.array([X[name] for name in STK_PARAMS])
+            sigma8 = orc.mlp_predict(xin, xlimits, pt.engines['sigma8'].layers, 'tanh', pt.engines['sigma8'].ylimits)[0]
+            fsigma8 = orc.mlp_predict(xin, xlimits, pt.engines['fsigma8'].layers, 'tanh', pt.engines['fsigma8'].ylimits)[0]
+            params = {name: p.get(name, like.all_params[name].value) for name in ['b1p', 'b2p', 'bsp', 'b3p', 'alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p', 'sn4p']}
+            pars = orc.velocileptors_pars(params, sigma8, fsigma8 / sigma8, basis='physical', model='rept', snd=theory.snd, fsat=theory.fsat, sigv=theory.sigv)
+            power = orc.interp1d(theory.k, pt.k, orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=theory.nd).T).T
+            return orc.window_apply(power, matrix_full=wm.matrix_full, shotnoisein=wm.shotnoisein, shotnoiseout=wm.shotnoiseout)
+        f0 = flat({name: 0. for name in solved})
+        T = np.array([flat({n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
+        scales = np.array([like.all_params[name].prior.scale for name in solved])
+        sol = orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(len(solved)), prior_loc=np.zeros(len(solved)), prior_scale=scales, marg_mask=np.ones(len(solved), dtype='?'))
+        assert abs(loglike[i] - sol['loglikelihood']) <= TOL * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
+        assert np.allclose(xsolved[i], sol['x'], rtol=1e-7, atol=1e-9)

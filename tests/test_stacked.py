@@ -123,30 +123,13 @@ def test_device_arithmetic_on_the_cpu_against_the_reference(name):
         for j, i in enumerate(rows): assert np.allclose(flat[j], g['ref/flattheory'][i], rtol=1e-11, atol=1e-11 * np.abs(g['ref/flattheory'][i]).max())
 
 
+from bench_configs import stacked_state as _stacked_state   # noqa: E402  (shared with bench.py)
+
+
 def state_like_the_converter(networks, z, params=STK_PARAMS, ells=(0, 2, 4)):
     """The state dictionary of emulators/conversion.py:44-98 as plain data (what ``np.load('emulator.npy', allow_pickle=True)[()]`` returns), from the synthetic networks --
     the same layout tests/golden/make_boundary_fixture.py::jaxeffort_layout_pt hands to the reference's ``Emulator.from_state``."""
-    expressions = {'silu': 'v / (1 + jnp.exp(-v))', 'relu': 'jnp.maximum(v, 0.)', 'tanh': 'jnp.tanh(v)'}
-    state = {'engines': {}, 'fixed': {}}
-    for component, rows in networks.items():
-        first = rows[0][0]
-        k, nlayers = first['k_grid'], len(first['layers'])
-        stack = lambda function: np.array([[function(n) for n in row] for row in rows])   # noqa: E731
-        operations = []
-        for i in range(nlayers):
-            operations.append(dict(direct='(v[..., None, :] @ kernel)[..., 0, :] + bias', inverse=None, locals={'kernel': stack(lambda n: n['layers'][i][0]), 'bias': stack(lambda n: n['layers'][i][1])}))
-            if i < nlayers - 1: operations.append(dict(direct=expressions[first['activations'][i]], inverse=None, locals={}))
-        limits = np.array(rows[-1][-1]['in_MinMax'], dtype='f8')
-        limits[list(params).index('h')] /= 100.
-        yoperations = [dict(direct='((v - limits[..., 0]) / (limits[..., 1] - limits[..., 0]))', inverse='v * (limits[..., 1] - limits[..., 0]) + limits[..., 0]',
-                            locals={'limits': stack(lambda n: np.asarray(n['out_MinMax']).reshape(-1, len(k), 2))})]
-        if component in ['11', 'ct']: yoperations.insert(0, dict(direct="v / (jnp.exp(X['logA']) * 1e-10)", inverse="v * jnp.exp(X['logA']) * 1e-10", locals={}))
-        if component == 'loop': yoperations.insert(0, dict(direct="v / (jnp.exp(X['logA']) * 1e-10)**2", inverse="v * (jnp.exp(X['logA']) * 1e-10)**2", locals={}))
-        state['engines'][component] = dict(name='mlp', params=list(params), xshape=(len(params),), yshape=yoperations[-1]['locals']['limits'].shape[:-1],
-                                           xoperations=[dict(direct='(v - limits[..., 0]) / (limits[..., 1] - limits[..., 0])', inverse=None, locals={'limits': limits})],
-                                           yoperations=yoperations, model_operations=operations, model_yoperations=[])
-    state['fixed'].update(ells=list(ells), k=k, z=np.array(z))
-    return state
+    return _stacked_state(networks, z, params, ells=ells)
 
 
 def mirror_likelihood(z=0.6, marg=False, hidden=(32, 32), activation='tanh', seed=3, nk=12, flatdata=None, covariance=None, zgrid=ZGRID, networks_nk=30):
