@@ -424,6 +424,15 @@ def other_configs(device, steps=40, warmup=5, ncheck=8):
     del ctx, like, pt, theory
     gc.collect()
 
+    # ---- configs[2] on the emulator layout the reference ships (emulators/conversion.py:44-98): stacked engines, amplitude rescale, redshift blend ----
+    try:
+        out.append(_stacked_config(device, steps, warmup, ncheck, sample))
+    except Exception as exc:   # (reported, not fatal)
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        out.append({'workload': 'BASELINE configs[2], jaxeffort emulator layout', 'error': repr(exc)})
+    gc.collect()
+
     # ---- configs[3] ----
     g, like = make_cfg4('xi')
     B = 8192
@@ -468,6 +477,40 @@ def other_configs(device, steps=40, warmup=5, ncheck=8):
         traceback.print_exc(file=sys.stderr)
         out.append({'workload': 'TNS one-loop theory', 'error': repr(exc)})
     return out
+
+
+def _stacked_config(device, steps, warmup, ncheck, sample):
+    import torch
+    from bench_configs import make_cfg3_stacked, cfg3_stacked_oracle_solution
+    like, pt, theory, solved, networks = make_cfg3_stacked(marg=True)
+    B = 4096
+    ctx = like._get_context()
+    theta_host = sample(like, B, 3)
+    theta = torch.as_tensor(theta_host, dtype=torch.float64, device=device).contiguous()
+    post, status = torch.empty(B, dtype=torch.float64, device=device), torch.zeros(B, dtype=torch.int32, device=device)
+    elapsed, kernel_ms = _timed_context(ctx, theta, steps, warmup, post, status, device)
+    assert int((status != 0).sum().item()) == 0
+    loglike = ctx.eval_batch_host(theta_host[:ncheck])[0]
+    err = max(abs(loglike[i] - cfg3_stacked_oracle_solution(like, pt, theory, solved, theta_host[i])['loglikelihood']) / max(1., abs(loglike[i])) for i in range(ncheck))
+    assert err <= 1e-10, 'GPU / oracle mismatch on configs[2] (stacked layout): {:.3e}'.format(err)
+    spec = like._spec({}, like._flatdata_list(), like.precision)['observables'][0]
+    groups, widths = np.asarray(spec['emu0']['groups']), [int(w) for w in np.ravel(spec['emu0']['widths'])]
+    n, H = like.flatdata.size, widths[-1]
+    per_network = sum(2 * a * b + 25 * b for a, b in zip(widths[:-1], widths[1:]))                       # MACs + one activation (~25) per unit
+    flops = {'networks': int(groups[:, 1].max()) * per_network, 'folded_operator': int(sum(2 * n * ((te - tb) * H + 1) * (m1 - m0) for tb, te, m0, m1 in groups)),
+             'monomial_rows': 2 * n * (19 + 2 * len(solved))}
+    fused = sum(flops.values())
+    slot = max(['theory', 'window_gemm'], key=lambda name: kernel_ms[name])
+    achieved = fused * B / (kernel_ms[slot] * 1e-3) / 1e12
+    return {'workload': "BASELINE configs[2] on the emulator layout the reference ships (emulators/conversion.py:44-98): engines '11' / 'loop' / 'ct' / 'st' x 7 redshifts x 3 multipoles = 84 networks "
+                        '(5 -> 5 x 64 tanh -> n_m x 60), amplitude rescale by logA, REPT tracer between two emulated redshifts ({:d} networks reach the device), 19-monomial combination + cubic interpolation '
+                        'to n_kin = 400 + window 120 x 1200 + 5 analytically marginalised parameters, {:d} batched points'.format(int(groups[:, 1].max()), B),
+            'value': B / elapsed, 'unit': 'evals/s', 'ms_per_step': 1e3 * elapsed, 'steps': steps, 'dtype': 'f64', 'batch': B,
+            'roofline': {'bound': 'mfma', 'kernel': 'dl_emulated_stacked_kernel (every network by MFMA, one wave each; folded-operator product per monomial group)', 'flop_per_eval': flops,
+                         'flop_per_launch': fused * B, 'avg_launch_ms': kernel_ms[slot], 'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS,
+                         'flop_count': "the build's own algorithm: final layers x y-scalers x assembly x redshift blend x interpolation x window x L^T folded at create"},
+            'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize']},
+            'oracle_check': {'points': ncheck, 'max_rel_err_vs_oracle': float(err), 'tolerance': 1e-10}}
 
 
 def _tns_config(device, steps, ncheck, orc):

@@ -8,11 +8,11 @@
 //       row_r[j] = sum_g amp_g(x) sum_{m in g} mono_r[m] sum_{h < K_g} G_g[(m, j)][h] basis_g[h],     basis_g = (last hidden layers of the group's networks ..., 1)
 //   -- the separable form of dl_feature_gemm.h with one A operand (K_g = n_networks_g H + 1 basis functions) and one monomial range per group.
 //
-//   Workgroup = 16 points x 128 output columns, 512 threads.  Per group: (i) NETWORKS: wave w runs networks tb + w, tb + w + 8, ... of the group from the scaled inputs
-//   to the last hidden layer ALONE -- every dense layer is [16 points x n_in] . [n_in x n_out] by v_mfma_f64_16x16x4_f64, activations of the wave in its own LDS
-//   buffer, updated in place (all output tiles of a layer sit in registers before the first is written), so no barrier separates the layers of a network and the
-//   networks of a group run side by side on the four SIMDs; weights stream from L2 in their stored [in, out] layout (a request = the sixteen k-steps of the NEXT
-//   output tile, issued before the MFMAs of the current one); the last hidden layer lands in the group's basis record.  (ii) FEATURE GEMM: wave w = column block w;
+//   Workgroup = 16 points x 128 output columns, 512 threads.  Per group: (i) NETWORKS, layer by layer: every dense layer of every network of the group is
+//   [16 points x n_in] . [n_in x n_out] by v_mfma_f64_16x16x4_f64, in tasks of one output tile (16 units) dealt evenly to the eight waves; activations in LDS, updated
+//   in place (a wave keeps the outputs of its tasks in registers across the barrier that ends the layer's reads); weights stream from L2 in fragment order (a request =
+//   the sixteen k-steps of the NEXT task, issued before the MFMAs of the current one; the next layer's first task before the activations); one exponential and one
+//   reciprocal per activation; the last hidden layer lands in the group's basis record.  (ii) FEATURE GEMM: wave w = column block w;
 //   the operand streams from L2 in fragment order [column block][group][k / 8][m][lane][2], two steps in flight; the epilogue contracts the accumulators with the
 //   amplitude-scaled monomial rows of the lane's four points into the carried output rows (registers; at most 8 rows: residual + the seven alpha* / sn* that can be solved).
 #pragma once
@@ -49,33 +49,93 @@ static inline bool dl_stk_feature_ok(const DlObsDev& o) {
 }
 
 #if defined(__HIPCC__)
-// One network on one wave: 16 points from `in0` (row stride ld0; layer 0; columns beyond the inputs zero up to a multiple of 4) through `n_layers` dense layers, every one
-// activated (a table network stops after its last HIDDEN layer); hidden activations in the wave's buffer `buf` (row stride tld), the last layer's output to
-// dst[point * dst_ld + unit].  `wf`: the network's weights in fragment order (DlObsDev::Stack::wfrag): a B-operand load is base + lane + immediate, no predicates.
+// Activations of the batched networks: one exponential and one reciprocal (v_rcp_f64 + two Newton steps) each -- silu v / (1 + e^-v), tanh 1 - 2 / (1 + e^2v) (absolute error
+// ~1e-16; the library's tanh is 165 vector instructions, this is ~50, and on this chip every fp64 vector instruction beside the MFMAs is added to their time)
+__device__ __forceinline__ double dl_stk_rcp(double v) {
+    double r = __builtin_amdgcn_rcp(v);
+    r = fma(fma(-v, r, 1.), r, r);
+    return fma(fma(-v, r, 1.), r, r);
+}
+// e^x, ~2 ulp, 21 vector instructions (the library's: 42): x = n ln 2 + r, |r| <= ln 2 / 2 (two-term Cody-Waite), Taylor polynomial of degree 13 (first neglected term
+// r^14 / 14! < 5e-18), v_ldexp_f64; the argument is clamped to the range of finite results (the activations only need 1 / (1 + e^x))
+__device__ __forceinline__ double dl_stk_exp(double x) {
+    x = fmin(fmax(x, -708.), 709.);
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1. / 6227020800.;
+    p = fma(p, r, 1. / 479001600.); p = fma(p, r, 1. / 39916800.); p = fma(p, r, 1. / 3628800.); p = fma(p, r, 1. / 362880.); p = fma(p, r, 1. / 40320.);
+    p = fma(p, r, 1. / 5040.); p = fma(p, r, 1. / 720.); p = fma(p, r, 1. / 120.); p = fma(p, r, 1. / 24.); p = fma(p, r, 1. / 6.); p = fma(p, r, 0.5);
+    p = fma(p, r, 1.); p = fma(p, r, 1.);
+    return ldexp(p, (int)n);
+}
+__device__ __forceinline__ double dl_stk_act(int act, double v) {
+    if (act == 0) return v * dl_stk_rcp(1. + dl_stk_exp(-v));       // conversion.py:29
+    if (act == 1) return v > 0. ? v : 0.;                           // conversion.py:31
+    return 1. - 2. * dl_stk_rcp(1. + dl_stk_exp(2. * v));           // conversion.py:33 (large |v|: +-1)
+}
+
+// The networks of one group, LAYER BY LAYER on all eight waves: a task = one output tile (16 units) of one network; the n_net * tiles tasks of a layer are dealt to the waves
+// in contiguous runs (a wave's tasks mostly share a network, i.e. an A operand), so the four SIMDs carry the same load whatever the number of networks (one network per wave:
+// six networks on eight waves left two SIMDs with twice the work of the others, and the phase took their time).  Activations of network j live in bufs + j * 16 * tld
+// (row stride tld), updated in place: every wave keeps the outputs of its tasks in registers across the barrier that ends the reads of the layer.  `wf`: the weights in
+// fragment order (DlObsDev::Stack::wfrag, network `first` + j at wf + j * frag_doubles): a B-operand load is base + lane + immediate, no predicates; the weights of the next
+// task (of the next layer's first task) are requested before the MFMAs (the activations) of the current one.  The last hidden layer goes to the basis record:
+// dst[point * dst_ld + j * H + unit].
 template <int TMAX>
-__device__ __forceinline__ void dl_stk_network(const int32_t* widths, int n_layers, int act, const double* __restrict__ wf, const double* in0, int ld0, double* buf, int tld,
-                                               double* dst, int dst_ld, int lane) {
+__device__ __forceinline__ void dl_stk_networks(const int32_t* widths, int n_layers, int act, const double* __restrict__ wf, int frag_doubles, int n_net, const double* in0, int ld0,
+                                                double* bufs, int tld, double* dst, int dst_ld, int wave, int lane, unsigned long long* lst = nullptr) {
     const int col = lane & 15, g = lane >> 4;
     wf += lane;
+    double bw[16];
+    int lslot = 0;   // diagnostics (DL_STK_STAMPS): wave 0 stamps layers 1-3 of the first group: start, MFMAs issued, reads done (barrier), activations written, barrier
+#define DL_STK_LSTAMP if (lst != nullptr && layer >= 1 && layer <= 3 && threadIdx.x == 0 && lslot < 15) lst[lslot] = __builtin_amdgcn_s_memtime(); if (layer >= 1 && layer <= 3) ++lslot;
+    bool have = false;                      // bw holds the weights of this wave's first task of the coming layer
+    size_t loff = 0;                        // offset of the layer in a network's fragment-ordered weights
     for (int layer = 0; layer < n_layers; ++layer) {
         const int nin = widths[layer], nout = widths[layer + 1];
         const int ksteps = (nin + 3) / 4, tiles = (nout + 15) / 16;
         const bool last = layer == n_layers - 1;
-        const double* ap = (layer == 0 ? in0 + col * ld0 : buf + col * tld) + g;
+        const int total = n_net * tiles, per = (total + 7) / 8;
+        const int t_begin = wave * per < total ? wave * per : total, t_end = t_begin + per < total ? t_begin + per : total;
+        const size_t lnext = loff + (size_t)tiles * ksteps * 64 + 16 * tiles;
+        // this wave's first task of the next layer (the same split: tiles may differ)
+        const int ntiles = last ? 1 : (widths[layer + 2] + 15) / 16, ntotal = n_net * ntiles, nper = (ntotal + 7) / 8;
+        const int nt_begin = wave * nper < ntotal ? wave * nper : ntotal;
+        const bool next16 = !last && (nout + 3) / 4 == 16 && nt_begin < ntotal;
+ DL_STK_LSTAMP
         dl_stk_double4 res[TMAX];
+        double bb[TMAX];                    // biases of this wave's tasks: requested up front (after the barrier below they would be a round trip to L2 per layer)
+#pragma unroll
+        for (int i = 0; i < TMAX; ++i) {
+            const int task = t_begin + i < t_end ? t_begin + i : (t_end > 0 ? t_end - 1 : 0);
+            const int jn = task / tiles, t = task - jn * tiles;
+            bb[i] = (wf - lane)[(size_t)jn * frag_doubles + loff + (size_t)tiles * ksteps * 64 + 16 * t + col];
+        }
         if (ksteps == 16) {
-            // a 64-input layer (the hidden layers): sixteen k-steps per output tile, the weights of the NEXT tile requested before the MFMAs of the current one
-            double bw[16], bwn[16], av[16];
+            double bwn[16];
+            if (!have && t_begin < t_end) {
+                const double* wt = wf + (size_t)(t_begin / tiles) * frag_doubles + loff + (size_t)(t_begin % tiles) * 1024;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) bw[u] = wf[u * 64];
+                for (int u = 0; u < 16; ++u) bw[u] = wt[u * 64];
+            }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) av[u] = ap[4 * u];              // the A operand is the same for every output tile
+            for (int i = 0; i < TMAX; ++i) {
+                const int task = t_begin + i;
+                if (task >= t_end) break;
+                const int jn = task / tiles;
+                const double* ap = (layer == 0 ? in0 + col * ld0 : bufs + (size_t)jn * DL_STK_PTS * tld + col * tld) + g;
+                double av[16];
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) {
-                if (t >= tiles) break;
-                if (t + 1 < tiles) {
+                for (int u = 0; u < 16; ++u) av[u] = ap[4 * u];
+                if (task + 1 < t_end) {
+                    const double* wt = wf + (size_t)((task + 1) / tiles) * frag_doubles + loff + (size_t)((task + 1) % tiles) * 1024;
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) bwn[u] = wf[((t + 1) * 16 + u) * 64];
+                    for (int u = 0; u < 16; ++u) bwn[u] = wt[u * 64];
+                } else if (next16) {
+                    const double* wt = wf + (size_t)(nt_begin / ntiles) * frag_doubles + lnext + (size_t)(nt_begin % ntiles) * 1024;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) bwn[u] = wt[u * 64];
                 }
                 dl_stk_double4 acc = {0., 0., 0., 0.}, acc2 = {0., 0., 0., 0.};   // two chains: a dependent MFMA waits for its predecessor
 #pragma unroll
@@ -83,16 +143,19 @@ __device__ __forceinline__ void dl_stk_network(const int32_t* widths, int n_laye
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bw[u], acc, 0, 0, 0);
                     acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], bw[u + 1], acc2, 0, 0, 0);
                 }
-                res[t] = acc + acc2;
+                res[i] = acc + acc2;
 #pragma unroll
                 for (int u = 0; u < 16; ++u) bw[u] = bwn[u];
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) {
-                if (t >= tiles) break;
+            for (int i = 0; i < TMAX; ++i) {
+                const int task = t_begin + i;
+                if (task >= t_end) break;
+                const int jn = task / tiles, t = task - jn * tiles;
+                const double* ap = (layer == 0 ? in0 + col * ld0 : bufs + (size_t)jn * DL_STK_PTS * tld + col * tld) + g;
+                const double* wt = wf + (size_t)jn * frag_doubles + loff + (size_t)t * ksteps * 64;
                 dl_stk_double4 acc = {0., 0., 0., 0.}, acc2 = {0., 0., 0., 0.};
-                const double* wt = wf + (size_t)t * ksteps * 64;
                 for (int u = 0; u < ksteps; u += 2) {
                     const bool two = u + 1 < ksteps;
                     const double b0 = wt[u * 64], b1 = wt[(two ? u + 1 : u) * 64];
@@ -100,63 +163,80 @@ __device__ __forceinline__ void dl_stk_network(const int32_t* widths, int n_laye
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
                     if (two) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc2, 0, 0, 0);
                 }
-                res[t] = acc + acc2;
+                res[i] = acc + acc2;
+            }
+            if (next16) {
+                const double* wt = wf + (size_t)(nt_begin / ntiles) * frag_doubles + lnext + (size_t)(nt_begin % ntiles) * 1024;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) bw[u] = wt[u * 64];
             }
         }
-        const double* bias = wf + (size_t)tiles * ksteps * 64 - lane + col;      // [tile][16]
+        have = next16;
+        DL_STK_LSTAMP
+        // every wave has read what it needs of this layer's inputs (LDS reads of this wave are complete: lgkmcnt; the weight requests of the next layer stay in flight)
+        if (layer > 0) asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");
+        else asm volatile("" ::: "memory");
+        DL_STK_LSTAMP
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            if (t >= tiles) break;
+        for (int i = 0; i < TMAX; ++i) {
+            const int task = t_begin + i;
+            if (task >= t_end) break;
+            const int jn = task / tiles, t = task - jn * tiles;
             const int oc = 16 * t + col;
-            const double b = bias[16 * t];
+            const double b = bb[i];
             double vv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vv[r] = res[t][r] + b;          // accumulator register r = out[point g + 4 r][oc]
+            for (int r = 0; r < 4; ++r) vv[r] = res[i][r] + b;          // accumulator register r = out[point g + 4 r][oc]
             if (act == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) vv[r] = vv[r] / (1. + exp(-vv[r]));      // silu, conversion.py:29
+                for (int r = 0; r < 4; ++r) vv[r] = dl_stk_act(0, vv[r]);
             } else if (act == 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) vv[r] = vv[r] > 0. ? vv[r] : 0.;
+                for (int r = 0; r < 4; ++r) vv[r] = dl_stk_act(1, vv[r]);
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) vv[r] = tanh(vv[r]);
+                for (int r = 0; r < 4; ++r) vv[r] = dl_stk_act(2, vv[r]);
             }
-            // hidden layers: in place -- every read of this layer precedes (one wave: LDS operations complete in order); units beyond the layer (zero weights and bias) are
-            // written too when they pad the next layer's k-steps: act(0) of silu / relu / tanh is 0
+            // units beyond the layer (zero weights and bias) are written too when they pad the next layer's k-steps: act(0) of silu / relu / tanh is 0
             const int nout4 = (nout + 3) & ~3;
+            double* hb = bufs + (size_t)jn * DL_STK_PTS * tld;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (!last) { if (oc < nout4) buf[(g + 4 * r) * tld + oc] = vv[r]; }
-                else if (oc < nout) dst[(g + 4 * r) * dst_ld + oc] = vv[r];
+                if (!last) { if (oc < nout4) hb[(g + 4 * r) * tld + oc] = vv[r]; }
+                else if (oc < nout) dst[(g + 4 * r) * dst_ld + (size_t)jn * nout + oc] = vv[r];
             }
         }
-        wf += (size_t)tiles * ksteps * 64 + 16 * tiles;
+        DL_STK_LSTAMP
+        if (!last) asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");    // the layer's outputs are in place
+        DL_STK_LSTAMP
+        loff = lnext;
     }
 }
 
-// feature GEMM of one group: CNT monomials, nq operand steps of 8 basis functions; then the contraction with the (amplitude-scaled) monomial rows into the carried rows
-template <int CNT, int RMAX>
+// feature GEMM of one group: CNT monomials, nq operand steps of 8 basis functions, D operand buffers (D - 1 steps in flight: a step is only 2 CNT MFMAs long, and the
+// operand comes from L2); then the contraction with the (amplitude-scaled) monomial rows into the carried rows
+template <int CNT, int RMAX, int D>
 __device__ __forceinline__ void dl_stk_group_gemm(const double* arow, const dl_fg_double2* __restrict__ gw, int nq, const double* mono, int R, int g, double (&outv)[4][RMAX]) {
     dl_fg_double4 acc[CNT];
 #pragma unroll
     for (int i = 0; i < CNT; ++i) acc[i] = (dl_fg_double4){0., 0., 0., 0.};
-    dl_fg_double2 b0[CNT], b1[CNT], b2[CNT];
-    const int q1 = 1 < nq ? 1 : nq - 1;
+    dl_fg_double2 b[D][CNT];
+#define DL_STK_LOAD(bb, qq) { const int q_ = (qq) < nq ? (qq) : nq - 1; _Pragma("unroll") for (int i = 0; i < CNT; ++i) bb[i] = gw[(size_t)(q_ * CNT + i) * 64]; }
+#define DL_STK_MUL(bb, qq) { const dl_fg_double2 a_ = *reinterpret_cast<const dl_fg_double2*>(arow + 8 * (qq)); \
+        _Pragma("unroll") for (int i = 0; i < CNT; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.x, bb[i].x, acc[i], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < CNT; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_.y, bb[i].y, acc[i], 0, 0, 0); }
 #pragma unroll
-    for (int i = 0; i < CNT; ++i) { b0[i] = gw[(size_t)i * 64]; b1[i] = gw[(size_t)(q1 * CNT + i) * 64]; }
-    for (int q = 0; q < nq; ++q) {
-        const int qn = q + 2 < nq ? q + 2 : nq - 1;
+    for (int d = 0; d < D - 1; ++d) DL_STK_LOAD(b[d], d)
+    int q = 0;
+    for (; q + D <= nq; q += D) {
 #pragma unroll
-        for (int i = 0; i < CNT; ++i) b2[i] = gw[(size_t)(qn * CNT + i) * 64];
-        const dl_fg_double2 a = *reinterpret_cast<const dl_fg_double2*>(arow + 8 * q);
-#pragma unroll
-        for (int i = 0; i < CNT; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0[i].x, acc[i], 0, 0, 0);      // (the two MFMAs of an accumulator CNT instructions apart)
-#pragma unroll
-        for (int i = 0; i < CNT; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b0[i].y, acc[i], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < CNT; ++i) { b0[i] = b1[i]; b1[i] = b2[i]; }
+        for (int d = 0; d < D; ++d) { DL_STK_LOAD(b[(d + D - 1) % D], q + d + D - 1) DL_STK_MUL(b[d], q + d) }
     }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (q + d < nq) { DL_STK_MUL(b[d], q + d) }
+#undef DL_STK_LOAD
+#undef DL_STK_MUL
     // accumulator register rr of lane (col, g) = U[point g + 4 rr][m][column]; rows of that point += sum_m mono_row[m] U[m]
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -177,7 +257,7 @@ __device__ __forceinline__ void dl_stk_group_gemm(const double* arow, const dl_f
 // TMAX: output tiles per layer (4: widths <= 64, 8: <= 128); RMAX: rows carried per point in registers (>= 1 + n_var)
 template <int TMAX, int RMAX>
 __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ gfrag, const DlObsDev o,
-                                                                  double* __restrict__ out, int64_t ldo, int accumulate, int steps_per_block) {
+                                                                  double* __restrict__ out, int64_t ldo, int accumulate, int steps_per_block, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -185,6 +265,11 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
     const int64_t p0 = (int64_t)blockIdx.x * DL_STK_PTS;
     const int R = 1 + o.n_var;
     const int tld = dl_stk_tld(o), bld = dl_stk_bld(o);
+    // DL_STK_STAMPS diagnostics (null in production): s_memtime of wave 0 at the phase boundaries, 32 slots per workgroup: 0 entry, 1 inputs, 2 monomial rows, then per device
+    // group 3 + 2 gi: networks done (after the barrier), 4 + 2 gi: feature GEMM + epilogue done; 30: rows stored; 31: s_memrealtime at exit (100 MHz)
+    unsigned long long* st = stamps != nullptr && blockIdx.y == 0 ? stamps + (size_t)blockIdx.x * 32 : nullptr;
+#define DL_STK_STAMP(slot) if (st != nullptr && tid == 0) st[slot] = __builtin_amdgcn_s_memtime();
+    DL_STK_STAMP(0)
     constexpr int XLD = DL_MAX_X + 2;
     double* x = lds;                                           // [16][DL_MAX_X] the emulator inputs
     double* xs = x + DL_STK_PTS * DL_MAX_X;                    // [3][16][XLD] scaled inputs of the table networks (0) and of the scalar engines (1, 2), zero-padded
@@ -193,7 +278,7 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
     double* vpv = scal + DL_STK_PTS * 4;                       // [16][12] velocileptors 'pars' inputs
     double* mono = vpv + DL_STK_PTS * 12;                      // [16][DL_STK_ROWS][20] monomial rows, scaled by the amplitude of their group
     double* basis = mono + DL_STK_PTS * DL_STK_ROWS * DL_FG_MONO_LD;   // [16][bld] basis record of the current group
-    double* wbuf = basis + (size_t)DL_STK_PTS * bld + (size_t)wave * DL_STK_PTS * tld;   // this wave's activation buffer
+    double* nbufs = basis + (size_t)DL_STK_PTS * bld;           // [8][16][tld] activation buffers of eight networks
     const int H = o.eng[0].widths[o.eng[0].n_layers];
     // ---- inputs ----
     for (int idx = tid; idx < DL_STK_PTS * XLD; idx += 512) {
@@ -213,6 +298,7 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
         vpv[pt * 12 + c] = dl_get(o.vp_in[c], theta + (size_t)b * n_params);
     }
     __syncthreads();
+    DL_STK_STAMP(1)
     // ---- scalar engines (sigma8, fsigma8: the physical prior basis; small networks): a thread per (point, unit), layer by layer, in the still unused basis record;
     //      the amplitudes of the groups ----
     for (int ie = 1; ie < 3; ++ie) {
@@ -264,6 +350,7 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
             }
         }
     }
+    DL_STK_STAMP(2)
     // ---- group by group: networks, then the feature GEMM ----
     double outv[4][RMAX];
 #pragma unroll
@@ -279,9 +366,12 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
         const int K = (te - tb) * H + 1, nq = (K + 7) / 8;
         if (tb != tb_prev || te != te_prev) {
             __syncthreads();    // the basis record is free (the previous group's GEMM is done); first group: the monomial rows are complete
-            for (int t = tb + wave; t < te; t += 8)
-                dl_stk_network<TMAX>(o.eng[0].widths, o.eng[0].n_layers, o.eng[0].act, o.stk.wfrag + (size_t)t * o.stk.frag_doubles, xs, XLD, wbuf, tld,
-                               basis + (size_t)(t - tb) * H, bld, lane);
+            for (int t = tb; t < te; t += 8) {     // eight networks at a time (their activation buffers)
+                const int n_net = te - t < 8 ? te - t : 8;
+                dl_stk_networks<TMAX>(o.eng[0].widths, o.eng[0].n_layers, o.eng[0].act, o.stk.wfrag + (size_t)t * o.stk.frag_doubles, o.stk.frag_doubles, n_net, xs, XLD, nbufs, tld,
+                                      basis + (size_t)(t - tb) * H, bld, wave, lane, gi == 0 && st != nullptr ? st + 15 : nullptr);
+                if (t + 8 < te) __syncthreads();
+            }
             for (int idx = tid; idx < DL_STK_PTS * (8 * nq - (K - 1)); idx += 512) {      // the constant basis function and the zero padding of the last step
                 const int pt = idx / (8 * nq - (K - 1)), c = K - 1 + (idx - pt * (8 * nq - (K - 1)));
                 basis[(size_t)pt * bld + c] = c == K - 1 ? 1. : 0.;
@@ -289,16 +379,18 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
             tb_prev = tb; te_prev = te;
             __syncthreads();
         }
+        DL_STK_STAMP(3 + 2 * gi)
         const double* arow = basis + (size_t)col * bld + 2 * g;
         const dl_fg_double2* gw = gcol + (size_t)kq * 64;
         const double* mp = mono + m0;
         switch (m1 - m0) {
-            case 1: dl_stk_group_gemm<1, RMAX>(arow, gw, nq, mp, R, g, outv); break;
-            case 2: dl_stk_group_gemm<2, RMAX>(arow, gw, nq, mp, R, g, outv); break;
-            case 3: dl_stk_group_gemm<3, RMAX>(arow, gw, nq, mp, R, g, outv); break;
-            case 4: dl_stk_group_gemm<4, RMAX>(arow, gw, nq, mp, R, g, outv); break;
-            default: dl_stk_group_gemm<5, RMAX>(arow, gw, nq, mp, R, g, outv); break;
+            case 1: dl_stk_group_gemm<1, RMAX, 8>(arow, gw, nq, mp, R, g, outv); break;
+            case 2: dl_stk_group_gemm<2, RMAX, 8>(arow, gw, nq, mp, R, g, outv); break;
+            case 3: dl_stk_group_gemm<3, RMAX, 6>(arow, gw, nq, mp, R, g, outv); break;
+            case 4: dl_stk_group_gemm<4, RMAX, 5>(arow, gw, nq, mp, R, g, outv); break;
+            default: dl_stk_group_gemm<5, RMAX, 4>(arow, gw, nq, mp, R, g, outv); break;
         }
+        DL_STK_STAMP(4 + 2 * gi)
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -313,5 +405,8 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
             }
         }
     }
+    DL_STK_STAMP(30)
+    if (st != nullptr && tid == 0) st[31] = __builtin_amdgcn_s_memrealtime();
+#undef DL_STK_STAMP
 }
 #endif

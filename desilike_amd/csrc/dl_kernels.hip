@@ -866,14 +866,31 @@ void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_
                                 int steps_per_block, hipStream_t stream) {
     const size_t shm = dl_stk_shared_doubles(obs) * sizeof(double);
     const int R = 1 + obs.n_var;
+    const unsigned grid = (unsigned)((B + DL_STK_PTS - 1) / DL_STK_PTS);
+    static const char* stamp_file = getenv("DL_STK_STAMPS");   // diagnostics: s_memtime at the phase boundaries of launches 30..33 appended to the file (synchronises)
+    static unsigned long long* stamps_dev = nullptr;
+    static int stamp_launches = 0;
+    if (stamp_file && !stamps_dev) (void)hipMalloc((void**)&stamps_dev, (size_t)8192 * 32 * sizeof(unsigned long long));
+    unsigned long long* stamps = (stamp_file && grid <= 8192 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
+    if (stamp_file) stamp_launches++;
+    if (stamps) (void)hipMemsetAsync(stamps, 0, (size_t)grid * 32 * sizeof(unsigned long long), stream);
     auto launch = [&](auto kernel) {
         (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        DL_LAUNCH(kernel, dim3((unsigned)((B + DL_STK_PTS - 1) / DL_STK_PTS), (unsigned)(N_pad / 128)), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, out, ldo, accumulate,
-                  steps_per_block);
+        DL_LAUNCH(kernel, dim3(grid, (unsigned)(N_pad / 128)), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, out, ldo, accumulate, steps_per_block, stamps);
     };
     const bool wide = dl_stk_tld(obs) > 66;   // a layer wider than 64 units: eight output tiles per layer
     if (wide) { if (R <= 1) launch(dl_emulated_stacked_kernel<8, 1>); else if (R <= 4) launch(dl_emulated_stacked_kernel<8, 4>); else if (R <= 6) launch(dl_emulated_stacked_kernel<8, 6>); else launch(dl_emulated_stacked_kernel<8, 8>); }
     else { if (R <= 1) launch(dl_emulated_stacked_kernel<4, 1>); else if (R <= 4) launch(dl_emulated_stacked_kernel<4, 4>); else if (R <= 6) launch(dl_emulated_stacked_kernel<4, 6>); else launch(dl_emulated_stacked_kernel<4, 8>); }
+    if (stamps) {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h((size_t)grid * 32);
+        (void)hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(stamp_file, "a")) {
+            for (unsigned w = 0; w < grid; ++w) { for (int q = 0; q < 32; ++q) fprintf(f, "%llu ", h[(size_t)w * 32 + q]); fprintf(f, "\n"); }
+            fprintf(f, "#\n");
+            fclose(f);
+        }
+    }
 }
 
 bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, const double* bias, const DlMargDev& mg, int n_valid,
