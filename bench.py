@@ -207,6 +207,23 @@ def hbm_traffic(kernel_name):
     return None, None
 
 
+def trace_average(kernel_name):
+    """Average duration (ms) of ``kernel_name`` in the latest committed ``rocprofv3 --kernel-trace --stats`` summary of this same command (profiles/*_kernel_stats.csv, written by
+    tools/prof_round.sh WITHOUT the host-array leg: every launch in it is a 1024-point launch of the timed step), with the file it came from; (None, None) if absent.  The variant
+    with the most calls is taken when a kernel template has several instantiations in the file."""
+    import csv
+    import glob
+    for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9][a-z]_kernel_stats.csv')), reverse=True):
+        best = None
+        with open(fn) as f:
+            for row in csv.DictReader(f):
+                if kernel_name in row.get('Name', ''):
+                    calls = int(row['Calls'])
+                    if best is None or calls > best[0]: best = (calls, float(row['AverageNs']) * 1e-6)
+        if best is not None: return best[1], os.path.relpath(fn, ROOT)
+    return None, None
+
+
 def free_port():
     import socket
     with socket.socket() as s:
@@ -488,7 +505,7 @@ def _stacked_config(device, steps, warmup, ncheck, sample):
     theta_host = sample(like, B, 3)
     theta = torch.as_tensor(theta_host, dtype=torch.float64, device=device).contiguous()
     post, status = torch.empty(B, dtype=torch.float64, device=device), torch.zeros(B, dtype=torch.int32, device=device)
-    elapsed, kernel_ms = _timed_context(ctx, theta, steps, warmup, post, status, device)
+    elapsed, kernel_ms = _timed_context(ctx, theta, steps, max(warmup, 200), post, status, device)   # (the first ~200 calls of a fresh context run 1.5x slower: tools/time_gap_stacked.py)
     assert int((status != 0).sum().item()) == 0
     loglike = ctx.eval_batch_host(theta_host[:ncheck])[0]
     err = max(abs(loglike[i] - cfg3_stacked_oracle_solution(like, pt, theory, solved, theta_host[i])['loglikelihood']) / max(1., abs(loglike[i])) for i in range(ncheck))
@@ -877,6 +894,12 @@ def main():
         dominant = 'theory' if short else max(['theory', 'window_gemm', 'finalize'], key=lambda name: kernel_ms[name])
         kernel_name = {'theory': 'dl_fullshape_kernel', 'window_gemm': 'dl_chi2_gemm_kernel', 'finalize': 'dl_finalize_part_kernel'}[dominant]
         traffic, traffic_source = hbm_traffic(kernel_name) if B == BATCH else (None, None)
+        # the whole step against its algorithmic bytes (fused: theta in, the whitened operand once, three outputs per point): PMC bytes of the step's three kernels
+        step_kernels = ['dl_fullshape_kernel', 'dl_chi2_gemm_kernel<true, true, 32', 'dl_finalize_part_kernel']
+        step_traffic = [hbm_traffic(name)[0] for name in step_kernels] if B == BATCH else [None]
+        traffic_step = float(sum(step_traffic)) if all(t is not None for t in step_traffic) else None
+        algorithmic_bytes = float(B * 6 * 8 + 128 * 1280 * 8 + B * (8 + 8 + 4))
+        trace_ms, trace_source = trace_average(kernel_name) if B == BATCH else (None, None)
         per_launch = min(B, 32768)   # batches above 32768 points are evaluated in internal passes of 32768: the kernel intervals are per pass
         achieved = flops[dominant] * per_launch / (kernel_ms[dominant] * 1e-3) / 1e12
         # which unit bounds the dominant kernel: the theory kernel issues no MFMA (fp64 VALU: transcendentals, spline evaluation, projection -- its 78.6 TFLOP/s peak
@@ -892,7 +915,12 @@ def main():
                   'roofline': {'bound': bound, 'bound_detail': {'theory': 'fp64 VALU (no MFMA in this kernel: transcendentals, spline evaluation, projection); peak = 78.6 TFLOP/s fp64 vector',
                                                                  'window_gemm': 'fp64 MFMA (v_mfma_f64_16x16x4_f64), peak = 78.6 TFLOP/s fp64 matrix', 'finalize': 'launch latency'}[dominant],
                                'kernel': kernel_name, 'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS, 'traffic': traffic,
-                               'traffic_source': traffic_source, 'flop_per_launch': flops[dominant] * per_launch, 'avg_launch_ms': kernel_ms[dominant],
+                               'traffic_source': traffic_source, 'traffic_step': traffic_step, 'algorithmic_bytes': algorithmic_bytes,
+                               'traffic_step_over_algorithmic': (traffic_step / algorithmic_bytes) if traffic_step is not None else None,
+                               'traffic_step_kernels': dict(zip(['theory', 'window_gemm', 'finalize'], step_traffic)) if traffic_step is not None else None,
+                               'flop_per_launch': flops[dominant] * per_launch, 'avg_launch_ms': kernel_ms[dominant],
+                               'trace_avg_launch_ms': trace_ms, 'trace_source': trace_source,
+                               'trace_frac': (flops[dominant] * per_launch / (trace_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS) if trace_ms else None,
                                'event_samples': int(kernel_ms.get('samples_per_kernel', {}).get(dominant, kernel_ms.get('samples', 0))),
                                'event_mode': 'the dominant kernel only, every {:d} steps (short run)'.format(every) if short else 'all kernels of a sampled step, every {:d} steps'.format(every)},
                   'kernel_ms': {name: (kernel_ms[name] if kernel_ms[name] > 0. else None) for name in ['theory', 'window_gemm', 'finalize']},
