@@ -35,6 +35,7 @@ struct dl_ctx {
     DlObsDev* obs_array_dev = nullptr; // the same structs in device memory (one theory launch for several observables)
     double* priors_dev = nullptr;    // [P, 5]
     int32_t* gemm_counters = nullptr;// [<= 2048 / 32 + 8] arrival counters of the fused chi2 GEMM finalize (zero between launches)
+    int32_t* step_ready = nullptr;   // [32 + 8] arrival counters of the row blocks' producers in dl_step_kernel (zero between launches); behind gemm_counters in one allocation
     double* wt_white_dev = nullptr;  // [N_pad, K_pad]  L^T . blockdiag(W_obs)          (chi2 path)
     std::vector<uint8_t> panel_ranges;   // [N_pad / 16][2]: 128-wide K panels of wt_white with non-zero entries per 16-row column block (chi2 GEMM skips the others)
     double* bias_white_dev = nullptr;// [N_pad]         L^T . (bias - flatdata)
@@ -438,8 +439,9 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     for (int i = 0; i < ctx->n_obs; ++i) { ctx->obs[i].rebase(ctx->arena_dev); ctx->obs_kernarg[i] = ctx->obs[i].dev; }
     if (dl_upload(ctx, &ctx->obs_array_dev, ctx->obs_kernarg)) { dl_destroy(ctx); return 1; }
     {   // arrival counters of the fused chi2-GEMM finalize: one per 32-row block of the largest pass that takes that path (self-resetting)
-        size_t nbytes = (16384 / 32 + 8) * sizeof(int32_t);
+        size_t nbytes = (16384 / 32 + 8 + 64) * sizeof(int32_t);
         if (hipMalloc((void**)&ctx->gemm_counters, nbytes) != hipSuccess || hipMemset(ctx->gemm_counters, 0, nbytes) != hipSuccess) { dl_fail(ctx, "dl_create: counter allocation failed"); dl_destroy(ctx); return 1; }
+        ctx->step_ready = ctx->gemm_counters + (16384 / 32 + 8);
     }
     if (dl_upload(ctx, &ctx->priors_dev, priors) || dl_upload(ctx, &ctx->wt_white_dev, wt_white) ||
         dl_upload(ctx, &ctx->bias_white_dev, bias_white) || dl_upload(ctx, &ctx->wt_full_dev, wt_full) || dl_upload(ctx, &ctx->bias_full_dev, bias_full) ||
@@ -564,6 +566,21 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         static const bool chi2_fused_env_early = getenv("DL_CHI2_FUSED") != nullptr && atoi(getenv("DL_CHI2_FUSED")) != 0;
         const bool chi2_fused_early = chi2_fused_env_early && !ctx->priors_general;
         const int xcd_block = !xcd_local ? 0 : chi2_path ? (chi2_fused_early ? 32 : dl_chi2_gemm_row_tile(nb, ctx->N_pad)) : (xcd_local > 1 && !feat_path && !ctx->any_transform && ctx->n_solved == 0 && ctx->N_pad == 128) ? 64 : 0;
+        // the whole step in one launch (dl_step_kernel): plain likelihood of one Kaiser-type observable in its fast instantiation, <= 1024 points in whole groups of 256
+        // OFF by default (DL_STEP_KERNEL=1 selects it): measured 31.1 us per 1024-point step against 24.4 us for the three launches -- in-kernel stamps (profiles/r05c_step_stamps.txt):
+        // theory of four points under ONE workgroup barrier 14.4 us (four independent workgroups per CU: ~8.5), publish 1.1, wait for the row block 2.0 - 2.5, GEMM + finalize 11.1;
+        // even with the theory phase at its stand-alone time the sum is what the three launches take: the step is bound by the lives of its workgroups, not by its launch boundaries
+        static const bool step_kernel_allowed = getenv("DL_STEP_KERNEL") != nullptr && atoi(getenv("DL_STEP_KERNEL")) != 0;
+        if (step_kernel_allowed && chi2_path && !need_flat && ctx->n_obs == 1 && !ctx->priors_general && ctx->K_pad % 128 == 0 &&
+            dl_step_lds_bytes(ctx->obs_kernarg[0], nb, ctx->N_pad) != 0) {
+            prof_phase(0);
+            dl_launch_step(ctx->obs_kernarg[0], th, P, nb, ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, ctx->K_pad, ctx->K_live,
+                           ctx->gemm_counters, ctx->step_ready, 8, ctx->priors_dev, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr,
+                           status_dev ? status_dev + b0 : nullptr, post_mode, stream, ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data());
+            prof_phase(-1);
+            if (prof) ctx->prof_calls++;
+            continue;
+        }
         prof_phase(0);
         if (!(feat_path && emu_fused))
             dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, feat_path ? ctx->feat_ws : nullptr, ctx->feat_ld,

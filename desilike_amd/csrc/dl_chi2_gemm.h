@@ -43,6 +43,7 @@ struct DlChi2Fin {
     int32_t* status;         // may be null
     int32_t n_params, post_mode;
     unsigned long long* stamps;   // DL_CG_STAMPS diagnostics (nullptr in production): 8 slots per workgroup, see dl_fullshape_kernel
+    int32_t* ready;          // dl_step_kernel: arrival counters of the row blocks' producers, reset by the last column block of a row block (nullptr otherwise)
 };
 
 // Panels of K that hold non-zero entries of the 16 Wt rows of each column block (by value in the kernarg segment: scalar registers).  With a block-diagonal
@@ -56,18 +57,15 @@ struct DlChi2Panels {
 // MT: rows per workgroup, 32 or 16 (16: batches whose 32-row blocks would leave CUs without a workgroup -- 256 walkers x 16 column blocks = 128 workgroups of 32 rows,
 // 256 of 16 rows, each moving 32 instead of 48 KB per panel; the partial sums of a row do not depend on the tile height)
 // RESID: the residual itself is ALSO written, resid [M, ldr] (the analytic gradient needs d~ as well as chi2: dl_eval_logposterior_grad)
-template <bool DO_LOAD, bool DO_MMA, int MT = DL_CG_M, bool RESID = false>
-__global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
-                                                           const double* __restrict__ bias, double* __restrict__ part, int M, int K_pad, int n_tiles, DlChi2Fin fin,
-                                                           DlChi2Panels panels, int k_live, double* __restrict__ resid, int64_t ldr) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    dl_kernarg_prefetch<256>();   // pointers, sizes, finalize block, panel ranges: four lines, one round trip
+// The tile (row block mb, column block nt) by one workgroup of DL_CG_WAVES waves; `lds`: DL_CG_LDS_BYTES of workspace.  WAIT (dl_step_kernel: the rows of A are produced
+// by other workgroups of the SAME launch): the operand rows of Wt of the first two panels are requested, then `wait()` returns once the producers have published row block mb,
+// then the rows of A follow.
+template <bool DO_LOAD, bool DO_MMA, int MT, bool RESID, class Wait>
+__device__ __forceinline__ void dl_chi2_gemm_tile(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw, const double* __restrict__ bias,
+                                                  double* __restrict__ part, int M, int K_pad, int n_tiles, const DlChi2Fin& fin, const DlChi2Panels& panels, int k_live,
+                                                  double* __restrict__ resid, int64_t ldr, double* lds, int mb, int nt, Wait&& wait) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    // XCD-aware decode of the linear workgroup id L = xcd + 8 (nt + n_tiles q): row block = xcd + 8 q
-    const int L = blockIdx.x;
-    const int xcd = L & 7, rest = L >> 3;
-    const int nt = rest % n_tiles, mb = xcd + 8 * (rest / n_tiles);
     constexpr int ROWS = MT + DL_CG_N, VPT = ROWS / DL_CG_WAVES, MTILES = MT / 16;
     const int m0 = mb * MT, n0 = nt * DL_CG_N;
     if (m0 >= M) return;
@@ -99,6 +97,7 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     dl_cg_double4 acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
     const double* la = lds + r16 * DL_CG_LD + g;
     // prologue: panels 0 and 1 requested; panel 0 landed (counted wait: the pieces of panel 1 may still fly) and visible (barrier)
+    wait();
     if (DO_LOAD) { DL_CG_DMA(0) if (n_panels > 1) { DL_CG_DMA(1) } }
     // fused finalize: the priors depend on theta only -- lanes 0-31 of wave 0 evaluate them for the 32 points of the row block now, while the first panels
     // are in flight (whichever column block arrives last will need them; two registers are carried through the main loop)
@@ -198,6 +197,7 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
     done = __builtin_amdgcn_readfirstlane(done);
     if (done != n_tiles - 1) return;
     if (lane == 0) __hip_atomic_store(fin.counters + mb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream-ordered)
+    if (lane == 0 && fin.ready != nullptr) __hip_atomic_store(fin.ready + mb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (every consumer of the row block is past its wait)
     const int row = m0 + lane;
     if (lane < MT && row < M) {
         double chi2 = 0.;
@@ -212,4 +212,17 @@ __global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const do
         if (fin.logprior) fin.logprior[row] = lp;
         if (fin.status) fin.status[row] = st;
     }
+}
+
+template <bool DO_LOAD, bool DO_MMA, int MT = DL_CG_M, bool RESID = false>
+__global__ __launch_bounds__(64 * DL_CG_WAVES) void dl_chi2_gemm_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ Wt, int64_t ldw,
+                                                           const double* __restrict__ bias, double* __restrict__ part, int M, int K_pad, int n_tiles, DlChi2Fin fin,
+                                                           DlChi2Panels panels, int k_live, double* __restrict__ resid, int64_t ldr) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    dl_kernarg_prefetch<256>();   // pointers, sizes, finalize block, panel ranges: four lines, one round trip
+    // XCD-aware decode of the linear workgroup id L = xcd + 8 (nt + n_tiles q): row block = xcd + 8 q
+    const int L = blockIdx.x;
+    const int xcd = L & 7, rest = L >> 3;
+    const int nt = rest % n_tiles, mb = xcd + 8 * (rest / n_tiles);
+    dl_chi2_gemm_tile<DO_LOAD, DO_MMA, MT, RESID>(A, lda, Wt, ldw, bias, part, M, K_pad, n_tiles, fin, panels, k_live, resid, ldr, lds, mb, nt, []() {});
 }

@@ -73,6 +73,12 @@ void dl_launch_window_gemm_dma_chi2(const double* A, int64_t lda, const double* 
 // emulated theories, fused: emulator forward pass (MFMA) and feature GEMM of one observable in one launch (dl_emu_batch.h)
 void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
                                 hipStream_t stream);
+// the whole step in ONE launch (dl_step_kernel: theory of four points per workgroup, hand-over of row blocks inside the launch, chi2 GEMM, fused finalize): BASELINE configs[1]-type
+// contexts at <= 1024 points; dl_step_lds_bytes returns 0 when the configuration is not eligible.  `ready`: [>= B / 32] arrival counters that count up (target = 8 x launch number)
+size_t dl_step_lds_bytes(const DlObsDev& obs, int64_t B, int N_pad);
+void dl_launch_step(const DlObsDev& obs, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, const double* Wt, int64_t ldw, const double* bias,
+                    double* part, int K_pad, int k_live, int32_t* counters, int32_t* ready, int32_t target, const double* priors, double* loglike, double* logprior, int32_t* status,
+                    int post_mode, hipStream_t stream, const uint8_t* panel_ranges);
 // stacked table engine (obs.eng[0].type == 2: the jaxeffort layout of emulators/conversion.py:44-98; dl_emu_stacked.h): every network of every group by MFMA and the feature
 // GEMM in one launch; gfrag: [N_pad / 16][steps_per_block][64][2] (group by group, k / 8 by k / 8, monomial by monomial)
 bool dl_emulated_stacked_ok(const DlObsDev& obs);

@@ -47,16 +47,20 @@ __device__ __forceinline__ void dl_obs_prefetch(const void* p) {
 // Workgroups are dealt round-robin to the 8 XCDs; with xblk > 0 workgroup w = xcd + 8 r handles point xblk (xcd + 8 (r / xblk)) + r % xblk (see dl_fullshape_body)
 __device__ __forceinline__ int dl_fs_point_of_wg(int wg, int xblk) { return xblk ? xblk * ((wg & 7) + 8 * ((wg >> 3) / xblk)) + ((wg >> 3) % xblk) : wg; }
 
-template <bool FAST, int NL, bool EFT, bool DENSE, bool TH_ROW = false>
+// SUB: the point is evaluated by a 256-thread SUB-GROUP of a larger workgroup (dl_step_kernel: four points per 1024-thread workgroup): `lds_sub`, `tid_sub`, `b_sub` name its
+// share of LDS, the thread's index in the sub-group and the point; every sub-group runs the same sequence of barriers (the branches between them are uniform in the observable).
+template <bool FAST, int NL, bool EFT, bool DENSE, bool TH_ROW = false, bool SUB = false>
 __device__ __forceinline__ void dl_fullshape_body(const DlObsDev& o, const double* __restrict__ theta, int n_params, double* __restrict__ power,
                                                   int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after, unsigned long long* __restrict__ stamps,
-                                                  const double* th_row = nullptr) {   // th_row: the point's parameters already in LDS (dl_fullshape_ens_kernel)
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+                                                  const double* th_row = nullptr,     // th_row: the point's parameters already in LDS (dl_fullshape_ens_kernel)
+                                                  double* lds_sub = nullptr, int tid_sub = 0, int b_sub = 0) {
+    extern __shared__ __attribute__((aligned(16))) double lds_wg[];
+    double* lds = SUB ? lds_sub : lds_wg;
     // Workgroups are dealt round-robin to the 8 XCDs; the GEMM that follows runs row block mb (xblk = 32 or 64 points) on XCD mb % 8.  With xblk > 0 the points are dealt
     // so that a row block is PRODUCED on the XCD that consumes it (B a multiple of 8 xblk): workgroup w = xcd + 8 r handles point xblk (xcd + 8 (r / xblk)) + r % xblk.
-    const int xblk = (stop_after >> 8) & 0xff;
-    stop_after = xblk ? 0 : stop_after;
-    const int b = dl_fs_point_of_wg(blockIdx.x, xblk);
+    const int xblk = SUB ? 0 : (stop_after >> 8) & 0xff;
+    stop_after = (SUB || xblk) ? 0 : stop_after;
+    const int b = SUB ? b_sub : dl_fs_point_of_wg(blockIdx.x, xblk);
     // DL_FS_STAMPS diagnostics: s_memtime (shader clock) of thread 0 at entry, after each barrier and at exit, 8 slots per workgroup
 #define DL_STAMP(slot) if (stamps != nullptr && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();
     DL_STAMP(0)
@@ -65,7 +69,7 @@ __device__ __forceinline__ void dl_fullshape_body(const DlObsDev& o, const doubl
     const bool toep = !o.fixed_spline && (FAST || o.toeplitz);
     const DlFsShared s = dl_fs_shared_carve(lds, o.n_t, o.n_in, dl_fs_n_dd0(o), toep);
     const double* th = TH_ROW ? th_row : theta + (size_t)b * n_params;
-    const int tid = threadIdx.x, nthr = DL_FS_THREADS;
+    const int tid = SUB ? tid_sub : (int)threadIdx.x, nthr = DL_FS_THREADS;
     if (stop_after == -1) return;  // stop_after != 0: timing diagnostics only (DL_FS_STOP), outputs are then incomplete
     // constants of the later phases are requested now: their round trip hides behind phase 0/1
     double lk_pref[DL_P3_PREF];
@@ -986,7 +990,7 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
     }
     DlChi2Fin fin;
     fin.counters = counters; fin.theta = theta; fin.priors = priors; fin.loglike = loglike; fin.logprior = logprior; fin.status = status;
-    fin.n_params = n_params; fin.post_mode = post_mode;
+    fin.n_params = n_params; fin.post_mode = post_mode; fin.ready = nullptr;
     static const char* stamp_file = getenv("DL_CG_STAMPS");   // diagnostics: in-kernel timestamps of launches 30..33 appended to the file (synchronises)
     static unsigned long long* stamps_dev = nullptr;
     static int stamp_launches = 0;
@@ -1003,6 +1007,96 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
         else DL_LAUNCH((dl_chi2_gemm_kernel<true, true, DL_CG_M, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad, resid, ldr);
     } else if (mt == 16) DL_LAUNCH((dl_chi2_gemm_kernel<true, true, 16>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_NBUF * (16 + DL_CG_N) * DL_CG_LD * 8, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad, no_resid, (int64_t)0);
     else DL_LAUNCH((dl_chi2_gemm_kernel<true, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad, no_resid, (int64_t)0);
+    if (fin.stamps) {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h((size_t)grid * 8);
+        (void)hipMemcpy(h.data(), fin.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(stamp_file, "a")) {
+            for (unsigned w = 0; w < grid; ++w) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", h[(size_t)w * 8 + q]); fprintf(f, "\n"); }
+            fprintf(f, "#\n");
+            fclose(f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ONE LAUNCH PER STEP (BASELINE configs[1]: one Kaiser-type observable in its fast instantiation, plain likelihood, N_pad = 128): theory, chi2 GEMM and finalize of a batch
+// of up to 1024 points by one grid of 1024-thread workgroups, one per CU.  The three launches of the step each pay a ramp, a cold L2 and a drain (about 7 of 25 us);
+// here the producers of a row block hand it to its consumers inside the launch:
+//   workgroup L = xcd + 8 (8 q + c) (workgroups are dealt round-robin to the 8 XCDs) first evaluates the FOUR points 32 mb + 4 c .. + 3 of row block mb = xcd + 8 q
+//   (four 256-thread sub-groups running dl_fullshape_body side by side: what four workgroups per CU do in dl_fullshape_kernel), publishes them (the rows are written by
+//   agent-scope write-through stores: performed once vmcnt has drained; then ONE memory-side atomic increment of ready[mb]), then becomes the chi2-GEMM workgroup of tile
+//   (row block mb, column block c): it waits until the eight producers of mb have arrived (they are the eight workgroups with the same (xcd, q): the same XCD, whose L2
+//   then holds the rows), runs dl_chi2_gemm_tile, and the last column block of a row block to arrive sums the partials and writes the outputs (the fused finalize of
+//   dl_chi2_gemm.h).  Correctness does not rest on the XCD mapping (every hand-over is an agent-scope access; a launch starts with clean caches), only the traffic does.
+//   No deadlock: a workgroup waits only for workgroups of its own aligned group of 64, all of which are dispatched before or with it (in-order dispatch, 256 CUs);
+//   the wait is bounded all the same (it gives up after ~0.1 s and poisons its outputs with NaN rather than hang the device).  `ready` counts up: launch number `epoch`
+//   of a context waits for 8 epoch.
+// ------------------------------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(1024) void dl_step_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power, int64_t ld_power,
+                                                       const double* __restrict__ Wt, int64_t ldw, const double* __restrict__ bias, double* __restrict__ part, int M, int K_pad,
+                                                       DlChi2Fin fin, DlChi2Panels panels, int k_live, int32_t* __restrict__ ready, int32_t target, int lds_per_point) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int q = j >> 3, c = j & 7, mb = xcd + 8 * q;
+    const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    unsigned long long* st = fin.stamps != nullptr ? fin.stamps + (size_t)blockIdx.x * 8 : nullptr;   // DL_STEP_STAMPS: 0 entry, 1 theory done, 2 published, 3 rows ready, 4 GEMM + finalize done
+    if (st != nullptr && threadIdx.x == 0) { st[0] = __builtin_amdgcn_s_memtime(); st[6] = __builtin_amdgcn_s_memrealtime(); }
+    dl_fullshape_body<true, NL, false, false, false, true>(o, theta, n_params, power, ld_power, nullptr, 0, 0, nullptr, nullptr, lds + (size_t)sub * lds_per_point, tid, 32 * mb + 4 * c + sub);
+    if (st != nullptr && threadIdx.x == 0) st[1] = __builtin_amdgcn_s_memtime();
+    // the rows of this workgroup's four points are performed at agent scope once every wave's stores have drained; then they are published
+    __asm__ volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ready + mb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st != nullptr && threadIdx.x == 0) st[2] = __builtin_amdgcn_s_memtime();
+    DlChi2Fin f2 = fin;
+    f2.stamps = nullptr;
+    dl_chi2_gemm_tile<true, true, DL_CG_M, false>(power, ld_power, Wt, ldw, bias, part, M, K_pad, 8, f2, panels, k_live, nullptr, 0, lds, mb, c, [&]() {
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(ready + mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        __asm__ volatile("" : : : "memory");
+        if (st != nullptr && threadIdx.x == 0) st[3] = __builtin_amdgcn_s_memtime();
+    });
+    if (st != nullptr && threadIdx.x == 0) { st[4] = __builtin_amdgcn_s_memtime(); st[7] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+// eligibility of the one-launch step (dl_api.hip asks before every call): returns the dynamic LDS size, or 0
+size_t dl_step_lds_bytes(const DlObsDev& oh, int64_t B, int N_pad) {
+    const bool generic = !oh.uniform_knots || !(oh.toeplitz || oh.fixed_spline);
+    if (oh.theory >= 2 || generic || oh.n_ct > 0 || oh.n_sn > 0 || oh.n_ell > 3 || oh.n_pass != 0 || oh.n_var != 0 || N_pad != 128) return 0;
+    if (B <= 0 || B > 1024 || B % 256 != 0) return 0;     // whole groups of 8 row blocks: 64 workgroups
+    const size_t per_point = (dl_fs_shared_doubles_obs(oh, true) + 1) / 2 * 2;
+    const size_t bytes = std::max<size_t>(4 * per_point * sizeof(double), DL_CG_LDS_BYTES);
+    return bytes <= 160 * 1024 ? bytes : 0;
+}
+
+void dl_launch_step(const DlObsDev& oh, const double* theta, int n_params, int64_t B, double* power, int64_t ld_power, const double* Wt, int64_t ldw, const double* bias,
+                    double* part, int K_pad, int k_live, int32_t* counters, int32_t* ready, int32_t target, const double* priors, double* loglike, double* logprior, int32_t* status,
+                    int post_mode, hipStream_t stream, const uint8_t* panel_ranges) {
+    DlChi2Panels panels;
+    std::memset(&panels, 0, sizeof(panels));
+    if (panel_ranges != nullptr) for (int t = 0; t < 8; ++t) panels.range[t] = (uint32_t)panel_ranges[2 * t] | ((uint32_t)panel_ranges[2 * t + 1] << 8);
+    const size_t per_point = (dl_fs_shared_doubles_obs(oh, true) + 1) / 2 * 2;
+    const size_t shm = dl_step_lds_bytes(oh, B, 128);
+    static bool optin = false;
+    if (!optin) { (void)hipFuncSetAttribute((const void*)dl_step_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); optin = true; }
+    DlChi2Fin fin;
+    fin.counters = counters; fin.theta = theta; fin.priors = priors; fin.loglike = loglike; fin.logprior = logprior; fin.status = status;
+    fin.n_params = n_params; fin.post_mode = post_mode; fin.ready = ready;
+    const unsigned grid = (unsigned)(B / 4);
+    static const char* stamp_file = getenv("DL_STEP_STAMPS");   // diagnostics: in-kernel timestamps of launches 30..33 appended to the file (synchronises)
+    static unsigned long long* stamps_dev = nullptr;
+    static int stamp_launches = 0;
+    if (stamp_file && !stamps_dev) (void)hipMalloc((void**)&stamps_dev, (size_t)256 * 8 * sizeof(unsigned long long));
+    fin.stamps = (stamp_file && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
+    if (stamp_file) stamp_launches++;
+    if (fin.stamps) (void)hipMemsetAsync(fin.stamps, 0, (size_t)256 * 8 * sizeof(unsigned long long), stream);
+    DL_LAUNCH(dl_step_kernel<3>, dim3(grid), dim3(1024), shm, stream, oh, theta, n_params, power, ld_power, Wt, ldw, bias, part, (int)B, K_pad, fin, panels, k_live > 0 ? k_live : K_pad,
+              ready, target, (int)per_point);
     if (fin.stamps) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h((size_t)grid * 8);

@@ -35,7 +35,7 @@ def section_fs():
         p = dict(zip(names, row)); p['b1'] = (p['b1'], p['b1'])
         ref.append(orc.gaussian_loglikelihood(orc.fullshape_observable(c, p)['flattheory'], c['flatdata'], g['precision'])[0])
     close(loglike[rows], np.array(ref), 'cfg2 dense 2537 rows vs oracle')
-    for B in [1, 33, 1024]:
+    for B in [1, 33, 256, 512, 1024]:
         close(ctx.eval_batch_host(theta[:B])[0], loglike[:B], 'batch {:d} vs the 2537-row pass'.format(B))
 
 
