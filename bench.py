@@ -640,19 +640,23 @@ def chains_weak(group, local_rank, rank, world, chains_per_gpu=(1, 2, 4), iterat
     out = []
     for K in chains_per_gpu:
         sampler = EmceeSampler(likelihood, nwalkers=512, chains=K * world, seed=42, sharding=WalkerSharding(group=group if group is not None else False), device_resident=True)
-        sampler.run(niterations=iterations)     # (warm-up of the same length: the staging buffers of the timed run exist)
+        # three untimed batches: the staging buffers exist, and the host-side sample store of every chain (amortised doubling, desilike_amd/samplers.py::_ChainStore) has
+        # grown twice -- a growth is a fresh allocation whose pages are touched for the first time (6 ms per 12 MB chain, tools/chains_run_probe.py), and round 4 timed exactly
+        # the one batch that pays it for every chain (K = 2 looked slower in aggregate than K = 1).  Timed: `nbatch` batches, the growth of the fifth among them (amortised).
+        for _ in range(3): sampler.run(niterations=iterations)
         torch.cuda.synchronize(device)
         if group is not None: group.barrier()
+        nbatch = 4
         t0 = time.perf_counter()
-        sampler.run(niterations=iterations)          # enqueue K ensembles on K streams, drain, all-gather the chains
+        for _ in range(nbatch): sampler.run(niterations=iterations)      # each: enqueue K ensembles on K streams, drain, all-gather the chains
         torch.cuda.synchronize(device)
         if group is not None: group.barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed = (time.perf_counter() - t0) / nbatch
         if group is not None: elapsed = group.max(elapsed)
         logp = np.array([chain['logposterior'][-1] for chain in sampler.chains])
         assert np.isfinite(logp).all() and len(sampler.chains) == K * world
         entry = {'chains_per_gpu': K, 'chains': K * world, 'value': K * world * 512 * iterations / elapsed, 'unit': 'evals/s', 'us_per_update_per_chain': 1e6 * elapsed / iterations,
-                 'includes': 'enqueue, device run, drain of the chains to the host, all-gather of the chains across ranks'}
+                 'batches_timed': nbatch, 'includes': 'enqueue, device run, drain of the chains to the host, append to the host-side sample store, all-gather of the chains across ranks'}
         if rank == 0 and K == chains_per_gpu[-1]:
             # every chain's final ensemble against the oracle (16 walkers each)
             names = likelihood.varied_params.names()
@@ -870,6 +874,27 @@ def main():
         elapsed = group.max(elapsed)
 
     assert all(int((st != 0).sum().item()) == 0 for st in statuses), 'non-OK status in the benchmark batch'
+    gathered_check = None
+    if distributed:
+        # the exchange, checked end to end (outside the timed region): every rank's log-posteriors of its first batch are all-gathered through the group; every rank must hold
+        # the SAME gathered array (a checksum of it is all-gathered and compared), and rank 0 checks a few points of EVERY rank's slice against the oracle (it can draw any
+        # rank's batch: the seeds are 42 + rank)
+        post = torch.empty(B, dtype=torch.float64, device=device)
+        ctx.eval_logposterior(thetas[0], post, status=statuses[0], stream=stream.cuda_stream)
+        torch.cuda.synchronize(device)
+        everyone = np.asarray(group.allgather(post.cpu().numpy())).reshape(world, B)
+        assert np.array_equal(everyone[rank], post.cpu().numpy()), 'the gathered array does not hold this rank\'s own log-posteriors in its slice'
+        digest = float(np.frombuffer(everyone.tobytes(), dtype=np.uint32).astype(np.uint64).sum() % (1 << 52))
+        digests = np.asarray(group.allgather(np.array([digest]))).reshape(world)
+        assert (digests == digest).all(), 'ranks hold different gathered log-posteriors: {}'.format(digests)
+        if rank == 0:
+            worst, npts = 0., 4
+            for r in range(world):
+                rows = sample_theta(likelihood, B, seed=42 + r)[:npts]
+                ref = oracle_logposterior(likelihood, rows)
+                worst = max(worst, float((np.abs(everyone[r, :npts] - ref) / np.maximum(1., np.abs(ref))).max()))
+            assert worst <= 1e-10, 'gathered log-posteriors / oracle mismatch: {:.3e}'.format(worst)
+            gathered_check = {'ranks': world, 'identical_on_every_rank': True, 'oracle_points_per_rank': npts, 'max_rel_err_vs_oracle': worst, 'tolerance': 1e-10}
     sustained = sustained_leg(step, barrier, args.sustained_seconds, B, world, elapsed / args.steps, group=group) if args.sustained_seconds > 0. else None
     def guarded(name, leg):
         # secondary, single-rank legs (no collective inside): a failure there is REPORTED in the line ({'error': ...}), it does not take the headline measurement with it
@@ -925,6 +950,7 @@ def main():
                                'event_mode': 'the dominant kernel only, every {:d} steps (short run)'.format(every) if short else 'all kernels of a sampled step, every {:d} steps'.format(every)},
                   'kernel_ms': {name: (kernel_ms[name] if kernel_ms[name] > 0. else None) for name in ['theory', 'window_gemm', 'finalize']},
                   'kernel_frac_of_fp64_peak': {name: flops[name] * per_launch / (kernel_ms[name] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS for name in ['theory', 'window_gemm'] if kernel_ms[name] > 0.}}
+        if gathered_check is not None: result['gathered_check'] = gathered_check
         if sustained is not None:
             sustained['agrees_with_value_within'] = abs(sustained['value'] / value - 1.)
             result['sustained'] = sustained

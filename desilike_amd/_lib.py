@@ -20,6 +20,7 @@ SYMBOLS = {
     'dl_config_set_f64': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_double_p, ctypes.c_int64]),
     'dl_config_set_i32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_int32_p, ctypes.c_int64]),
     'dl_config_free': (None, [ctypes.c_void_p]),
+    'dl_options_refresh': (None, []),
     'dl_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
     'dl_destroy': (None, [ctypes.c_void_p]),
     'dl_last_error': (ctypes.c_char_p, [ctypes.c_void_p]),
@@ -105,6 +106,11 @@ def load():
             func.restype, func.argtypes = restype, argtypes
         _lib = lib
     return _lib
+
+
+def refresh_options():
+    """Re-read the library's diagnostic switches (environment variables ``DL_*``, include/desilike_amd.h) -- they are read once per process; the tests flip them in place."""
+    load().dl_options_refresh()
 
 
 def rccl_library_path():

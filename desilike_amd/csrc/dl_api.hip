@@ -1,5 +1,7 @@
 // dl_api.hip -- C ABI (include/desilike_amd.h) over the gfx950 kernels.
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <thread>
 
 #include <algorithm>
 #include <cstdio>
@@ -869,10 +871,7 @@ __global__ void dl_host_flag_kernel(uint64_t* flag, uint64_t seq) {
 // DL_HOST_MODE: 0 staged copies + stream synchronisation (the first version), 1 mapped buffers + stream synchronisation, 2 mapped + event polling,
 // 3 (default) mapped + completion flag (+ a stream query at the start of one call in eight), 4 the flag alone.  Tried and dropped (profiles/r04a_host_call_modes.txt):
 // a stream synchronisation after the flag (46 us median: the runtime's own wait path), polling hipStreamQuery (41 us, long tail)
-static int dl_host_mode() {
-    const char* env = std::getenv("DL_HOST_MODE");
-    return env ? std::atoi(env) : 3;
-}
+static int dl_host_mode() { return dl_options().host_mode >= 0 ? dl_options().host_mode : 3; }   // (read once: dl_options_refresh re-reads DL_HOST_MODE)
 
 // Host-pointer evaluation (what the reference-side binding and any unmodified desilike sampler call: samplers/base.py:144-200, samplers/emcee.py:69).
 // Default (mode 3): theta is copied into a pinned, device-mapped buffer which the kernels read in place; the finalize kernel writes loglike | logprior | status
@@ -937,10 +936,17 @@ static int dl_eval_host_impl(dl_ctx* ctx, const double* theta, int64_t B, double
             dl_host_flag_kernel<<<1, 1, 0, stream>>>(ctx->host_flag_dev, seq);
             e = hipGetLastError();
             volatile uint64_t* flag = ctx->host_flag;
+            // spin on the flag for a bounded time (small batches finish within tens of microseconds: the spin is what makes the call 34 us instead of 46), then hand the
+            // wait to the runtime -- a large batch must not burn a host core that the sampler's own threads (or another rank) could use
+            const auto spin_start = std::chrono::steady_clock::now();
             for (uint64_t spins = 0; e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
-                if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(stream) != hipErrorNotReady) {   // a failed kernel never writes the flag: ask the runtime now and then
-                    e = hipStreamSynchronize(stream);
+#else
+                std::this_thread::yield();
+#endif
+                if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - spin_start > std::chrono::microseconds(200)) {
+                    e = hipStreamSynchronize(stream);    // (also the way out when a failed kernel never writes the flag)
                     if (e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) e = hipErrorUnknown;
                     break;
                 }

@@ -279,7 +279,7 @@ void dl_ens_launch(const DlEnsArgs& s_in, hipStream_t stream) {
     DlEnsArgs s = s_in;
     s.stage_parts = n_tiles > 0 && n_tiles % 8 == 0 && dl_ens_shared_bytes(s.nw, s.P, n_tiles) <= 144 * 1024;   // (the staged rows are walked in groups of four 16-byte chunks)
     const size_t shm = dl_ens_shared_bytes(s.nw, s.P, s.stage_parts ? n_tiles : 0);
-    const bool force_global = getenv("DL_ENS_GLOBAL") != nullptr;   // (tests: the global-memory variant on a small ensemble)
+    const bool force_global = dl_options().ens_global;   // (tests: the global-memory variant on a small ensemble)
     if (shm <= 144 * 1024 && !force_global) {
         // up to 512 walkers: 512 threads (one slot per thread in either phase); beyond: 1024 threads
         if (s.nw <= 512) {
@@ -404,7 +404,7 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
     DlEnsArgs s;
     std::memset(&s, 0, sizeof(s));
     static unsigned long long* stamps_dev = nullptr;   // DL_ENS_STAMPS=1: per-phase times of the step kernel, printed at the end of the run (synchronises)
-    const bool stamps_on = getenv("DL_ENS_STAMPS") != nullptr;
+    const bool stamps_on = dl_options().ens_stamps;
     if (stamps_on && !stamps_dev) DL_ENS_HIP(hipMalloc((void**)&stamps_dev, 8 * sizeof(unsigned long long)));
     if (stamps_on) DL_ENS_HIP(hipMemsetAsync(stamps_dev, 0, 8 * sizeof(unsigned long long), stream));
     s.stamps = stamps_on ? stamps_dev : nullptr;
@@ -427,8 +427,8 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
     // three-launch sequence (comparison, tests)
     if (ens->fold < 0) {
         ens->fold = 0;
-        const bool comm_on = ens->comm && (ens->world > 1 || getenv("DL_ENS_FORCE_COMM"));
-        if (ens->deferred && !comm_on && !getenv("DL_ENS_NO_DEFER") && !getenv("DL_ENS_NO_FOLD") && !getenv("DL_ENS_GLOBAL") &&
+        const bool comm_on = ens->comm && (ens->world > 1 || dl_options().ens_force_comm);
+        if (ens->deferred && !comm_on && !dl_options().ens_no_defer && !dl_options().ens_no_fold && !dl_options().ens_global &&
             dl_internal_fold_info(ens->ctx, half, &ens->fold_tiles, &ens->fold_priors) == 0) {
             const size_t half_pad = (size_t)ens->count * ens->world;
             if (hipMalloc((void**)&ens->prop1, half_pad * P * sizeof(double)) == hipSuccess && hipMalloc((void**)&ens->factors1, half_pad * sizeof(double)) == hipSuccess &&
@@ -442,7 +442,7 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
     DlEnsFold f;
     std::memset(&f, 0, sizeof(f));
     static unsigned long long* fold_stamps_dev = nullptr;   // DL_ENS_FOLD_STAMPS=1: phase times of the theory kernel's proposal prologue, printed at the end of the run (synchronises)
-    const bool fold_stamps = folded && getenv("DL_ENS_FOLD_STAMPS") != nullptr;
+    const bool fold_stamps = folded && dl_options().ens_fold_stamps;
     if (fold_stamps && !fold_stamps_dev) DL_ENS_HIP(hipMalloc((void**)&fold_stamps_dev, (size_t)8192 * 8 * sizeof(unsigned long long)));
     if (fold_stamps) f.stamps = fold_stamps_dev;
     if (folded) {
@@ -477,7 +477,7 @@ int dl_ensemble_run(dl_ensemble* ens, int64_t niterations, int32_t thin_by, doub
             set_record();
             dl_ens_launch(s, stream);
             s.part = nullptr;
-            if (ens->deferred && !(ens->comm && (ens->world > 1 || getenv("DL_ENS_FORCE_COMM"))) && !getenv("DL_ENS_NO_DEFER")) {
+            if (ens->deferred && !(ens->comm && (ens->world > 1 || dl_options().ens_force_comm)) && !dl_options().ens_no_defer) {
                 int rc = dl_internal_eval_partials(ens->ctx, ens->prop, half, &s.part, &s.n_tiles, &s.priors, stream);
                 if (rc == 1) return 1;
                 if (rc == 2) { ens->deferred = false; s.part = nullptr; }

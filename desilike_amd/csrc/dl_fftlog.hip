@@ -315,7 +315,7 @@ __global__ __launch_bounds__(DL_FF_THREADS) __attribute__((amdgpu_waves_per_eu(2
 void dl_fftlog4096_kernel(const double* __restrict__ fun, const double* __restrict__ pre, const dl_ff_c* __restrict__ u, const dl_ff_c* __restrict__ u1,
                           const dl_ff_c* __restrict__ u2, const double* __restrict__ post, const dl_ff_c* __restrict__ tw, double* __restrict__ out, int n_ell, int total) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    constexpr int N2 = DL_FF4_N2, n = 2048, pad = 1024;
+    constexpr int N2 = DL_FF4_N2, n = 2048;    // (zero padding: 1024 on either side of the 2048 samples)
     const int tid = threadIdx.x;
     dl_ff_c* x = reinterpret_cast<dl_ff_c*>(lds_raw);
     dl_ff_c* twB = x + (N2 + (N2 >> 4) + 1);             // [q][j]: W_128^(j q)

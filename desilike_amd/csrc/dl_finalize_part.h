@@ -44,7 +44,6 @@ __device__ __forceinline__ void dl_finalize_from_chi2(double chi2, const double 
                                                       double& ll, double& lp, int& st) {
     lp = 0.;
     bool nan_in = false;
-    const double inf = __builtin_huge_val();
     for (int p0 = 0; p0 < n_params; p0 += 8) {
         double x[8];
         if (p0 == 0) {

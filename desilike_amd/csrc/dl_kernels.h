@@ -17,6 +17,16 @@ extern thread_local DlProfEvents dl_prof_events;
         else hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);                                                                \
     } while (0)
 
+// Diagnostic switches of the library (environment variables DL_*: alternative kernels kept for comparison, forced variants -- include/desilike_amd.h lists them): read ONCE,
+// at first use, into this table; nothing on the per-call path calls getenv.  dl_options_refresh() (C ABI; the tests flip switches inside one process) re-reads the environment.
+struct DlOptions {
+    bool no_merged_theory, no_emu_batch, no_fused_solve, no_gram_plain, no_scaled_row0, ef_no_early_theta, fm_no_lane_solve;
+    bool ens_global, ens_force_comm, ens_no_defer, ens_no_fold, ens_stamps, ens_fold_stamps;
+    int cg_mt;        // DL_CG_MT: forced row tile of the chi2 GEMM (0: chosen per batch)
+    int host_mode;    // DL_HOST_MODE: see dl_eval_batch_host (-1: default)
+};
+const DlOptions& dl_options();
+
 #define DL_ST_OK 0
 #define DL_ST_OUT_OF_PRIOR 1
 #define DL_ST_NONFINITE 2

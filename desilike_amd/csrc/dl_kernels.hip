@@ -44,6 +44,26 @@ __device__ __forceinline__ void dl_obs_prefetch(const void* p) {
     dl_scalar_prefetch<0, (offsetof(DlObsDev, ct_in) + 63) / 64 * 64, offsetof(DlObsDev, coef_w) / 64 * 64, (sizeof(DlObsDev) + 63) / 64 * 64>(p);
 }
 
+// ---- the table of diagnostic switches (dl_kernels.h) ----
+static DlOptions g_options;
+static bool g_options_read = false;
+static void dl_options_read() {
+    auto on = [](const char* name) { return std::getenv(name) != nullptr; };
+    DlOptions& o = g_options;
+    o.no_merged_theory = on("DL_NO_MERGED_THEORY"); o.no_emu_batch = on("DL_NO_EMU_BATCH"); o.no_fused_solve = on("DL_NO_FUSED_SOLVE"); o.no_gram_plain = on("DL_NO_GRAM_PLAIN");
+    o.no_scaled_row0 = on("DL_NO_SCALED_ROW0"); o.ef_no_early_theta = on("DL_EF_NO_EARLY_THETA"); o.fm_no_lane_solve = on("DL_FM_NO_LANE_SOLVE");
+    o.ens_global = on("DL_ENS_GLOBAL"); o.ens_force_comm = on("DL_ENS_FORCE_COMM"); o.ens_no_defer = on("DL_ENS_NO_DEFER"); o.ens_no_fold = on("DL_ENS_NO_FOLD");
+    o.ens_stamps = on("DL_ENS_STAMPS"); o.ens_fold_stamps = on("DL_ENS_FOLD_STAMPS");
+    o.cg_mt = std::getenv("DL_CG_MT") ? atoi(std::getenv("DL_CG_MT")) : 0;
+    o.host_mode = std::getenv("DL_HOST_MODE") ? atoi(std::getenv("DL_HOST_MODE")) : -1;
+    g_options_read = true;
+}
+const DlOptions& dl_options() {
+    if (!g_options_read) dl_options_read();
+    return g_options;
+}
+extern "C" void dl_options_refresh(void) { dl_options_read(); }
+
 // Workgroups are dealt round-robin to the 8 XCDs; with xblk > 0 workgroup w = xcd + 8 r handles point xblk (xcd + 8 (r / xblk)) + r % xblk (see dl_fullshape_body)
 __device__ __forceinline__ int dl_fs_point_of_wg(int wg, int xblk) { return xblk ? xblk * ((wg & 7) + 8 * ((wg >> 3) / xblk)) + ((wg >> 3) % xblk) : wg; }
 
@@ -501,7 +521,7 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
     unsigned long long* stamps = (stamp_file && B >= 256 && B <= 65536 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
     if (stamp_file && B >= 256) stamp_launches++;
     // all observables in one launch when they share a fast instantiation (same multipole count class, no counter terms, no separate tables, same LDS footprint class)
-    const bool merge = !getenv("DL_NO_MERGED_THEORY");   // (read at every launch: the tests compare both paths in one process)
+    const bool merge = !dl_options().no_merged_theory;   // (the tests compare both paths in one process: dl_options_refresh)
     if (merge && obs_dev != nullptr && n_obs > 1 && n_obs <= 8 && tables == nullptr && feat == nullptr && stop_after == 0 && !stamp_file) {
         bool same = true, eft0 = obs_host[0].n_ct > 0 || obs_host[0].n_sn > 0, nl3 = obs_host[0].n_ell <= 3;
         size_t shmem = 0;
@@ -534,7 +554,7 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
             dl_launch_tns(obs_host[i], theta, n_params, B, power, ld_power, stream);
             continue;
         }
-        if (obs_host[i].theory == 3 && feat != nullptr && !getenv("DL_NO_EMU_BATCH")) {   // feature path: 16 points per workgroup, MLP layers by MFMA
+        if (obs_host[i].theory == 3 && feat != nullptr && !dl_options().no_emu_batch) {   // feature path: 16 points per workgroup, MLP layers by MFMA
             size_t shm = dl_eb_shared_doubles(obs_host[i]) * sizeof(double);
             if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)dl_emulated_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
             DL_LAUNCH(dl_emulated_batch_kernel, dim3((unsigned)((B + DL_EB_PTS - 1) / DL_EB_PTS)), dim3(256), shm, stream, obs_host[i], theta, n_params, B, feat, feat_ld);
@@ -903,7 +923,7 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
     if (obs.eng[0].type == 2) return false;   // (stacked table engine: rows through dl_launch_emulated_stacked, then the general finalize kernels)
     if (R > 6 || mg.n_s < 0 || mg.n_s > 15 || n_valid > 128) return false;
     // no solved parameters: only with the finalize in the kernel's tail (there is no separate finalize on a 1 x 1 Gram matrix)
-    if (mg.n_s == 0 && (fin == nullptr || getenv("DL_NO_FUSED_SOLVE") || getenv("DL_NO_GRAM_PLAIN"))) return false;
+    if (mg.n_s == 0 && (fin == nullptr || dl_options().no_fused_solve || dl_options().no_gram_plain)) return false;
     DlEfGramArgs ga;
     std::memset(&ga, 0, sizeof(ga));
     ga.xr = 1 + mg.n_s; ga.gram = gram;
@@ -924,14 +944,14 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
     // every derivative row on monomials 12-18 (the solved alpha* / sn* of the velocileptors order): monomials 0-11 feed row 0 only, through registers (DL_NO_SCALED_ROW0=1: three
     // full epilogues per wave, the form before; read at every launch: the tests compare)
     // (and eight k-step pairs in the main loops -- 64 hidden units + the constant basis function that starts the accumulators: that form is completely unrolled)
-    ga.scaled = DL_FG_NM == 19 && obs.mono_mode != 0 && obs.eng[0].type == 0 && obs.n_basis == 65 && obs.nb_pad == 72 && !getenv("DL_NO_SCALED_ROW0");
+    ga.scaled = DL_FG_NM == 19 && obs.mono_mode != 0 && obs.eng[0].type == 0 && obs.n_basis == 65 && obs.nb_pad == 72 && !dl_options().no_scaled_row0;
     for (int r = 1; r < 6; ++r)
         for (int z = 0; z < 2; ++z) if (ga.nz[r][z] >= 0 && ga.nz[r][z] < 12) ga.scaled = 0;
-    ga.no_early = getenv("DL_EF_NO_EARLY_THETA") != nullptr;
+    ga.no_early = dl_options().ef_no_early_theta;
     const size_t shm = dl_ef_gram_shared_doubles(obs, ga.xr) * sizeof(double);
     if (shm > 146 * 1024) return false;   // (the kernel also holds 10 KB of static LDS: parameter rows, prior table and prior terms of the fused finalize)
-    static size_t shm_set = 0;
-    if (shm > shm_set) { (void)hipFuncSetAttribute((const void*)dl_emulated_feature_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); shm_set = shm; }
+    // (per device: a second device of the process needs the raised limit too -- the attribute is set at every launch, as the other launchers do; it is a host-side table write)
+    (void)hipFuncSetAttribute((const void*)dl_emulated_feature_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     static const char* stamp_file = getenv("DL_EF_STAMPS");   // diagnostics: s_memtime at the phase boundaries of launches 30..33 appended to the file (synchronises)
     static unsigned long long* stamps_dev = nullptr;
     static int stamp_launches = 0;
@@ -942,7 +962,7 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
     if (ga.stamps) (void)hipMemsetAsync(ga.stamps, 0, (size_t)grid * 16 * sizeof(unsigned long long), stream);
     DlEfSolve sv;
     std::memset(&sv, 0, sizeof(sv));
-    if (fin != nullptr && ga.xr <= 8 && !getenv("DL_NO_FUSED_SOLVE")) {   // (DL_NO_FUSED_SOLVE=1: Gram matrix to memory + dl_finalize_marg_gram_kernel; read at every launch: the tests compare)
+    if (fin != nullptr && ga.xr <= 8 && !dl_options().no_fused_solve) {   // (DL_NO_FUSED_SOLVE=1: Gram matrix to memory + dl_finalize_marg_gram_kernel)
         sv.enabled = 1; sv.post_mode = fin->post_mode & 0xff; sv.priors = fin->priors; sv.loglike = fin->loglike; sv.logprior = fin->logprior; sv.status = fin->status;
         sv.solved = fin->solved; sv.hessian = fin->hessian; sv.mg = mg;
         fin->done = true;
@@ -967,8 +987,7 @@ bool dl_launch_emulated_feature_gram(const DlObsDev& obs, const double* theta, i
 // ------------------------------------------------------------------------------------------------
 // rows per workgroup of the chi2 GEMM for a batch of M points: 16 when 32-row blocks would occupy at most half of the 256 CUs (DL_CG_MT=32 / 16 overrides: diagnostics)
 int dl_chi2_gemm_row_tile(int64_t M, int N_pad) {
-    const char* env = getenv("DL_CG_MT");   // (read at every launch: the tests compare both tiles in one process)
-    const int forced = env ? atoi(env) : 0;
+    const int forced = dl_options().cg_mt;   // (the tests compare both tiles in one process: dl_options_refresh)
     if (forced == 16 || forced == 32) return forced;
     return ((M + DL_CG_M - 1) / DL_CG_M) * (N_pad / DL_CG_N) <= 128 ? 16 : DL_CG_M;
 }
@@ -1263,7 +1282,6 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
     __shared__ long long pk_b[4];
     __shared__ int pk_flags[4];
     double* Gw = gram_lds[wave];
-    double* Cw = nullptr;
     if (LANES) {
         // Gram matrix of X = [dt; Tt_1 .. Tt_ns] (1 + ns <= 16 rows, n columns) with v_mfma_f64_16x16x4_f64: the A operand of lane l is X[l & 15][4 k + (l >> 4)]
         // and the B operand X^T[4 k + (l >> 4)][l & 15] -- the same register.  chi2 = G[0][0], Tt dt = G[0][1 + s], Tt Tt^T = G[1 + s][1 + t].
@@ -1291,7 +1309,7 @@ __global__ __launch_bounds__(256, 4) void dl_finalize_marg_kernel(const double* 
             const int rows = 1 + ns, n4 = 4 * n_ks, stride = n4 + 4;
             const int region = rows * stride > 512 ? rows * stride : 512;   // doubles per wave: the staged rows, then G [16][16] | Cholesky rows [16][16] in the same place
             double* X = dl_fm_dyn + (size_t)wave * region;
-            Gw = X; Cw = X + 256;
+            Gw = X;
             for (int c0 = 2 * lane; c0 < n4; c0 += 128) {
 #pragma unroll 4
                 for (int r = 0; r < rows; ++r) {
@@ -1639,7 +1657,7 @@ void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_p
     static const bool allow_staged = !getenv("DL_FM_NO_STAGE");   // DL_FM_NO_STAGE=1: operands of the Gram product straight from global memory (comparison)
     const size_t region = std::max<size_t>((size_t)(1 + mg.n_s) * (((n + 3) & ~3) + 4), 512);
     const size_t shm = 4 * region * sizeof(double);   // staged rows of the four waves (reused for G and the Cholesky rows)
-    const bool lane_solve = !getenv("DL_FM_NO_LANE_SOLVE");   // DL_FM_NO_LANE_SOLVE=1: the 16-lanes-per-point kernel also with a ready Gram matrix (read at every launch: the tests compare both in one process)
+    const bool lane_solve = !dl_options().fm_no_lane_solve;   // DL_FM_NO_LANE_SOLVE=1: the 16-lanes-per-point kernel also with a ready Gram matrix (read at every launch: the tests compare both in one process)
     if (gram != nullptr && lane_solve && mg.n_s >= 1 && mg.n_s <= 8) {
         const unsigned grid64 = (unsigned)((B + 63) / 64);
         const int mode = (xcd_local && xcd_tile16 && B % 512 == 0) ? ((post_mode & 0xff) | 0x100) : (post_mode & 0xff);

@@ -193,8 +193,8 @@ __global__ __launch_bounds__(64 * DL_TNS_WAVES) void dl_tns_loop_kernel(DlTnsDev
         // the parity tests); built from the integer, the address goes into the ds_read as it is (through `lds + offset` the compiler adds the segment's base, 0, with
         // a vector instruction per read).
         typedef const __attribute__((address_space(3))) double* lds_cptr;
-        lds_cptr ra = (lds_cptr)(uint32_t)r.j[u].x;
-        lds_cptr rq = (lds_cptr)(uint32_t)r.j[u].y;
+        lds_cptr ra = (lds_cptr)(uintptr_t)(uint32_t)r.j[u].x;     // (through uintptr_t: no -Wint-to-pointer-cast; LDS pointers are 32 bits wide, the upper half is dropped again)
+        lds_cptr rq = (lds_cptr)(uintptr_t)(uint32_t)r.j[u].y;
 #pragma unroll
         for (int m = 0; m < 2; ++m) { o.pq[u][m] = rq[16 * m]; o.pa[u][m] = ra[16 * m]; o.pb[u][m] = ra[DL_TNS_PTS + 16 * m]; }
     };
@@ -315,7 +315,6 @@ __global__ __launch_bounds__(256) void dl_tns_assemble_kernel(DlObsDev o, DlTnsD
         double qpar, qper;
         dl_ap_qparqper(o, th, qpar, qper);
         const double f = o.f_fid * dl_get(o.df, th);
-        const double jac = 1. / (qpar * qper * qper);
         if (tid < 6 * 32) cvec[tid] = dl_tns_combine_coef(tid >> 5, tid & 31, f, dl_get(o.b1X, th), dl_get(o.b2, th), dl_get(o.bs, th), dl_get(o.b3, th));
         if (tid >= 192 && tid < 192 + o.n_mu) dl_tns_mu_record(o, qpar, qper, tid - 192, murec);
         if (tid == 255) {

@@ -215,6 +215,8 @@ class HMCSampler(BasePosteriorSampler):
                 weights = packed[:, 0] / packed[:, 0].sum()
                 mean = (weights[:, None] * packed[:, 1:]).sum(axis=0)
                 self.step_size, self.inverse_mass_matrix = float(mean[0]), mean[1:].reshape(shape)
+                # the hyper-parameters the run uses, on every rank (also one without chains): what save() writes into the chain attributes
+                self.hyp = {'step_size': self.step_size, 'inverse_mass_matrix': np.asarray(self.inverse_mass_matrix).copy()}
                 self._adapted = True
         minv, chol = self._mass(device)
         nrec = niterations // thin_by

@@ -73,16 +73,29 @@ def _rows_of(tree, ells, list_x, coord='k'):
     return np.concatenate(index)
 
 
-def read_window(wmatrix, ells, list_x, ellsin=None, coord='k'):
+def read_window(wmatrix, ells, list_x, ellsin=None, coord='k', kin=None):
     """-> (matrix [n_out, n_ellin * n_kin], kin, ellsin): rows matched to the output bins (``list_x`` per multipole of ``ells``), columns of the input multipoles
-    ``ellsin`` (default: all of ``wmatrix.theory``), which must share one wavenumber grid (window.py:337-352)."""
+    ``ellsin`` (default: all of ``wmatrix.theory``).  Without ``kin`` the input multipoles must share one wavenumber grid, which is returned (window.py:350-351); with
+    ``kin`` every multipole is rebinned from ITS OWN grid, ``matrix . blockdiag(matrix_lininterp(kin, k_pole))^T`` (window.py:347-349)."""
     value = np.asarray(wmatrix.value(), dtype='f8')
     theory, observable = wmatrix.theory, wmatrix.observable
     ellsin = [int(ell) for ell in (ellsin if ellsin is not None else theory.ells)]
     rows = _rows_of(observable, ells, list_x, coord=coord)
-    kin = np.asarray(theory.get(ells=ellsin[0]).coords('k'), dtype='f8')
-    cols = _rows_of(theory, ellsin, [kin] * len(ellsin), coord='k')     # (raises if a multipole lives on another grid: window.py:351)
-    return value[np.ix_(rows, cols)], kin, tuple(ellsin)
+    grids = [np.asarray(theory.get(ells=ell).coords('k'), dtype='f8') for ell in ellsin]
+    if kin is None:
+        if not all(grid.shape == grids[0].shape and np.allclose(grid, grids[0]) for grid in grids):
+            raise ValueError('input coordinates of "wmatrix" are not the same for all multipoles; pass a k-coordinate array to "kin"')
+        cols = _rows_of(theory, ellsin, grids, coord='k')
+        return value[np.ix_(rows, cols)], grids[0], tuple(ellsin)
+    from ... import utils
+    kin = np.ravel(np.asarray(kin, dtype='f8'))
+    cols = _rows_of(theory, ellsin, grids, coord='k')
+    matrix = value[np.ix_(rows, cols)]
+    blocks, start = [], 0
+    for grid in grids:
+        blocks.append(matrix[:, start:start + grid.size].dot(utils.matrix_lininterp(kin, grid).T))
+        start += grid.size
+    return np.hstack(blocks), kin, tuple(ellsin)
 
 
 def read_covariance(covariance, observables):

@@ -33,7 +33,14 @@ class TracerPowerSpectrumMultipolesObservable(BaseCalculator):
         data, covariance = init.pop('data', None), init.pop('covariance', None)
         wmatrix, transform = init.pop('wmatrix', None), init.pop('transform', None)
         self.name = init.pop('name', self.name)
-        self.covariance = None if covariance is None else np.asarray(covariance, dtype='f8')
+        # ``covariance`` (power_spectrum.py:64-75): a 2-D array, a covariance-matrix container (matched to the observable at the likelihood level), or a LIST OF MOCK
+        # MEASUREMENTS whose sample covariance is taken (read below, once the binning is known); mocks passed as ``data`` only give the data vector (their mean)
+        self.covariance, self.mocks, self._covariance_container = None, None, None
+        cov_items = list(covariance) if isinstance(covariance, (list, tuple)) else None
+        cov_mocks = cov_items if cov_items and all(_containers.is_measurement(item) for item in cov_items) else None
+        if cov_mocks is None and covariance is not None:
+            if _containers.is_matrix_container(covariance): self._covariance_container = covariance
+            else: self.covariance = np.asarray(covariance, dtype='f8')
         self.nobs = init.pop('nobs', None)
         if isinstance(wmatrix, WindowedPowerSpectrumMultipoles):
             self.wmatrix = wmatrix
@@ -44,7 +51,6 @@ class TracerPowerSpectrumMultipolesObservable(BaseCalculator):
         self._require(self.wmatrix)
         # measurements given as (lsstypes-like, duck-typed) containers: one object or a list of mocks (power_spectrum.py:123-233) -> flat data vector = their mean;
         # binning and shot noise default to the containers' own
-        mocks = None
         items = list(data) if isinstance(data, (list, tuple)) else [data]
         if items and all(_containers.is_measurement(item) for item in items):
             klim = init.get('klim', None)
@@ -59,15 +65,34 @@ class TracerPowerSpectrumMultipolesObservable(BaseCalculator):
                 else: init['k'] = list_k
                 init.pop('klim', None)
             if init.get('shotnoise', None) is None and read[0][4] is not None: init['shotnoise'] = float(np.mean([r[4] for r in read]))
-            mocks = np.array([np.concatenate(r[3]) for r in read])
-            data = mocks.mean(axis=0)
-            if len(read) > 1 and self.covariance is None:   # covariance from the mocks (power_spectrum.py:97-104)
-                self.covariance, self.nobs = np.cov(mocks, rowvar=False, ddof=1), len(read)
+            data = np.array([np.concatenate(r[3]) for r in read]).mean(axis=0)      # power_spectrum.py:218-227: the mean of the measurements
+        if cov_mocks is not None:   # power_spectrum.py:69-75: mocks -> sample covariance (ddof = 1); the likelihood takes the number of observations from them (likelihoods/base.py:541-544)
+            klim = init.get('klim', None)
+            read = [_containers.read_measurement(item, lim=klim if isinstance(klim, dict) else None, coord='k') for item in cov_mocks]
+            for other in read[1:]:
+                if other[0] != read[0][0] or not all(np.allclose(a, b, rtol=1e-3, atol=0.) for a, b in zip(other[1], read[0][1])):
+                    raise ValueError('the mocks do not share the multipoles / k-bins of the first one')
+            if init.get('k', None) is None and init.get('kedges', None) is None and init.get('ells', None) is None:     # binning from the mocks when nothing else gives it
+                init['ells'] = read[0][0]
+                if all(edges is not None for edges in read[0][2]): init['kedges'] = read[0][2]
+                else: init['k'] = read[0][1]
+                init.pop('klim', None)
+            if init.get('shotnoise', None) is None and read[0][4] is not None: init['shotnoise'] = float(np.mean([r[4] for r in read]))     # power_spectrum.py:228-232
+            self.mocks = np.array([np.concatenate(r[3]) for r in read])
+            self.covariance = np.cov(self.mocks, rowvar=False, ddof=1)
+            if self.nobs is None: self.nobs = len(read)
         self.wmatrix.init.update(init)
         self.wmatrix.initialize()
         for name in ['k', 'ells', 'kedges']:
             setattr(self, name, getattr(self.wmatrix, name))
         self.shotnoise = self.wmatrix.shotnoise
+        if self._covariance_container is not None:      # power_spectrum.py:115-117: the rows / columns of this observable's bins out of a covariance-matrix container
+            container = self._covariance_container
+            if getattr(container.observable, 'observables', None): self.covariance = _containers.read_covariance(container, [self])
+            else:
+                index = _containers._rows_of(container.observable, self.ells, self.k, coord='k')
+                self.covariance = np.asarray(container.value(), dtype='f8')[np.ix_(index, index)]
+            if self.nobs is None: self.nobs = getattr(container, 'nobs', None)
         self.transform = transform
         if self.transform not in [None, 'cubic']:
             raise ValueError('transform must be one of {}'.format([None, 'cubic']))

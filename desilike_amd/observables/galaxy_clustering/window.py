@@ -176,15 +176,8 @@ class WindowedPowerSpectrumMultipoles(BaseCalculator):
             blocks = matrix_full.reshape(matrix_full.shape[0], len(self.ellsin), kin_given.size)
             self.matrix_full = np.einsum('oli,ki->olk', blocks, rebin).reshape(matrix_full.shape[0], -1)
         elif _containers.is_matrix_container(wmatrix):   # window.py:337-352: an lsstypes-like WindowMatrix (duck-typed: .value(), .theory, .observable)
-            matrix_full, kin_given, self.ellsin = _containers.read_window(wmatrix, self.ells, self.k, ellsin=ellsin)
-            if kin is not None:   # rebinned along the input axis (window.py:347-349)
-                self.kin = np.ravel(np.asarray(kin, dtype='f8'))
-                rebin = utils.matrix_lininterp(self.kin, kin_given)
-                blocks = matrix_full.reshape(matrix_full.shape[0], len(self.ellsin), kin_given.size)
-                matrix_full = np.einsum('oli,ki->olk', blocks, rebin).reshape(matrix_full.shape[0], -1)
-            else:
-                self.kin = kin_given
-            self.matrix_full = matrix_full
+            # with ``kin`` every input multipole is rebinned from its own grid (window.py:347-349); without, they must share one (350-351)
+            self.matrix_full, self.kin, self.ellsin = _containers.read_window(wmatrix, self.ells, self.k, ellsin=ellsin, kin=kin)
         else:
             raise NotImplementedError('window matrix of type {}: pass a 2D array with kin and ellsin, a file written by desilike_amd.io.save_window, or an object with '
                                       '.value(), .theory, .observable (desilike_amd/observables/galaxy_clustering/_containers.py)'.format(type(wmatrix).__name__))

@@ -213,6 +213,20 @@ int  dl_eval_logposterior_host(dl_ctx* ctx, const double* theta, int64_t B, doub
 int  dl_profile_enable(dl_ctx* ctx, int enable);
 int  dl_profile_read(dl_ctx* ctx, double* ms, int32_t n);
 
+/* ---- diagnostic switches ----------------------------------------------------------------------
+ * Environment variables DL_* select alternative kernels kept for comparison, force variants or switch diagnostics on; NONE of them is needed in production.  They are read
+ * ONCE per process (most at the first call that meets them, the ones of the table below at the first call of dl_options / dl_create) -- nothing on the per-call path calls
+ * getenv.  dl_options_refresh() re-reads the table from the environment (the tests flip switches inside one process).
+ *   kernel selection (results identical to the default path: tests/test_gpu_switches.py runs the parity checks under every one of them):
+ *     DL_NO_MERGED_THEORY, DL_NO_EMU_BATCH, DL_NO_EMU_FUSED, DL_NO_GRAM_EPILOGUE, DL_NO_FUSED_SOLVE, DL_NO_GRAM_PLAIN, DL_NO_SCALED_ROW0, DL_EF_NO_EARLY_THETA, DL_FM_NO_LANE_SOLVE,
+ *     DL_FM_NO_STAGE, DL_NO_FEATURE_PATH, DL_NO_TOEPLITZ, DL_NO_PANEL_SKIP, DL_NO_ROW_ALIGN, DL_NO_CHI2_BIG, DL_CHI2_FUSED, DL_STEP_KERNEL, DL_CHI2_GEMM_MAX, DL_CG_MT, DL_XCD_LOCAL,
+ *     DL_FS_DENSE_MIN, DL_GEMM_DMA, DL_GEMM_WGS, DL_BAO_THREADS, DL_FFTLOG_GENERIC, DL_TNS_W, DL_TNS_WAVEK, DL_ENS_GLOBAL, DL_ENS_NO_DEFER, DL_ENS_NO_FOLD, DL_ENS_FORCE_COMM,
+ *     DL_MH_NO_DEFER, DL_HOST_MODE (0 - 4: how the *_host entry points wait, see dl_eval_batch_host)
+ *   diagnostics (in-kernel time stamps written to the named file, per-phase early exits; they synchronise: never set in production):
+ *     DL_FS_STAMPS, DL_FS_STOP, DL_CG_STAMPS, DL_EF_STAMPS, DL_FM_STAMPS, DL_STK_STAMPS, DL_STEP_STAMPS, DL_ENS_STAMPS, DL_ENS_FOLD_STAMPS
+ *   environment of the collectives: DL_RCCL_PATH, DL_COMM_TIMEOUT (desilike_amd/parallel.py, bench.py) */
+void dl_options_refresh(void);
+
 /* ---- FFTLog Hankel transform (row a11) --------------------------------------------------------
  * Batched device version of the reference's third-party ``cosmoprimo.PowerToCorrelation(k, ell, q=0, lowring=True)`` (call sites
  * theories/galaxy_clustering/base.py:76-77, 135; used by get_corr 127-136): for every (point, multipole)

@@ -110,9 +110,42 @@ def test_mocks_give_data_and_covariance():
     draws = c['flatdata'] + rng.standard_normal((200, c['flatdata'].size)) * 50.
     mocks = [measurement(kedges, ells, draw, shotnoise=1e4, pad=0) for draw in draws]
     theory = KaiserTracerPowerSpectrumMultipoles(template=ShapeFitPowerSpectrumTemplate(z=0.5))
+    # the reference's call form (power_spectrum.py:64-75): mocks as ``covariance`` give the sample covariance, mocks as ``data`` only their mean
     obs = TracerPowerSpectrumMultipolesObservable(data=mocks, wmatrix=c['matrix_full'], kin=c['kin'], ellsin=ells, theory=theory)
     obs.initialize()
-    assert np.allclose(obs.flatdata, draws.mean(axis=0)) and obs.nobs == 200
+    assert np.allclose(obs.flatdata, draws.mean(axis=0)) and obs.covariance is None and obs.nobs is None
+    obs = TracerPowerSpectrumMultipolesObservable(data=mocks[:3], covariance=mocks, wmatrix=c['matrix_full'], kin=c['kin'], ellsin=ells, theory=theory)
+    obs.initialize()
+    assert np.allclose(obs.flatdata, draws[:3].mean(axis=0)) and obs.nobs == 200 and obs.mocks.shape == draws.shape
     assert np.allclose(obs.covariance, np.cov(draws, rowvar=False, ddof=1))
+    # a covariance-matrix container at the observable level (power_spectrum.py:115-117): the block of this observable's bins
+    obs = TracerPowerSpectrumMultipolesObservable(data=mocks[0], covariance=Matrix(g['covariance'], observable=mocks[0]), wmatrix=c['matrix_full'], kin=c['kin'], ellsin=ells, theory=theory)
+    obs.initialize()
+    assert np.allclose(obs.covariance, g['covariance'])
+    obs = TracerPowerSpectrumMultipolesObservable(data=c['flatdata'], covariance=mocks, wmatrix=c['matrix_full'], kin=c['kin'], ellsin=ells, theory=theory)   # binning from the mocks
+    obs.initialize()
+    assert obs.nobs == 200 and tuple(obs.ells) == ells and np.allclose(obs.covariance, np.cov(draws, rowvar=False, ddof=1))
     with pytest.raises(NotImplementedError):
         TracerPowerSpectrumMultipolesObservable(data=mocks[0], klim={0: (0., 0.2, 0.01)}, wmatrix=c['matrix_full'], kin=c['kin'], ellsin=ells, theory=theory).initialize()
+
+
+def test_window_with_input_multipoles_on_different_grids():
+    """A window container whose input multipoles live on DIFFERENT wavenumber grids: accepted with ``kin`` -- every multipole rebinned from its own grid, as the reference
+    does (window.py:347-349) --, refused without (350-351)."""
+    from desilike_amd import utils
+    from desilike_amd.observables.galaxy_clustering import _containers
+    rng = np.random.RandomState(3)
+    kedges, ells = np.linspace(0., 0.2, 11), (0, 2)
+    grids = {0: np.linspace(0.005, 0.25, 30), 2: np.linspace(0.01, 0.24, 24)}
+    value = rng.standard_normal((20, 54))
+    theory = Tree(poles={ell: Pole(grid, np.column_stack([grid, grid]), np.zeros(grid.size)) for ell, grid in grids.items()})
+    observable = measurement(kedges, ells, np.zeros(20), pad=0)
+    wmatrix = Matrix(value, observable=observable, theory=theory)
+    mid = [0.5 * (kedges[:-1] + kedges[1:])] * 2
+    with pytest.raises(ValueError, match='not the same for all multipoles'):
+        _containers.read_window(wmatrix, ells, mid)
+    kin = np.linspace(0.01, 0.2, 40)
+    matrix, kout, ellsin = _containers.read_window(wmatrix, ells, mid, kin=kin)
+    assert matrix.shape == (20, 80) and np.array_equal(kout, kin) and ellsin == (0, 2)
+    expected = np.hstack([value[:, :30].dot(utils.matrix_lininterp(kin, grids[0]).T), value[:, 30:].dot(utils.matrix_lininterp(kin, grids[2]).T)])
+    assert np.allclose(matrix, expected, rtol=1e-14, atol=0.)

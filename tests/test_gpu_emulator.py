@@ -9,6 +9,7 @@ from test_host_api import make_cfg3
 from test_oracle_emulator import table_point
 from emulator_utils import taylor_state, EMU_PARAMS
 from bench_configs import make_cfg3_full, cfg3_oracle_solution   # noqa: E402,F401  (shared with bench.py / tools)
+from desilike_amd._lib import refresh_options as _refresh_options   # the library reads its DL_* switches once per process
 
 pytestmark = pytest.mark.gpu
 
@@ -123,14 +124,14 @@ def test_feature_path_matches_dense_path_and_is_repeatable():
         theta = np.column_stack([np.clip(param.ref.sample(size=1000 + 7, random_state=rng), *param.prior.limits) for param in like.varied_params])
         ctx = like._get_context()
         fast = ctx.eval_batch_host(theta, return_solved=marg)
-        os.environ['DL_NO_FEATURE_PATH'] = '1'
+        os.environ['DL_NO_FEATURE_PATH'] = '1'; _refresh_options()
         try:
             from desilike_amd._lib import Context
             dense_ctx = Context(like._spec({}, like._flatdata_list(), like.precision), device=0)
             dense = dense_ctx.eval_batch_host(theta, return_solved=marg)
             dense_ctx.close()
         finally:
-            del os.environ['DL_NO_FEATURE_PATH']
+            del os.environ['DL_NO_FEATURE_PATH']; _refresh_options()
         assert np.array_equal(fast[2], dense[2]) and (fast[2] == 0).all()
         assert (np.abs(fast[0] - dense[0]) <= 1e-10 * np.maximum(1., np.abs(dense[0]))).all(), np.abs(fast[0] - dense[0]).max()
         assert np.allclose(fast[1], dense[1], rtol=1e-12, atol=1e-12)
@@ -193,23 +194,23 @@ def test_gram_finalize_one_lane_per_point():
         theta[6, 1] = like.varied_params[names[1]].prior.limits[1] + 1.
         ctx = like._get_context()
         fast = ctx.eval_batch_host(theta, return_solved=True)          # solve in the tail of the fused kernel
-        os.environ['DL_NO_FUSED_SOLVE'] = '1'
+        os.environ['DL_NO_FUSED_SOLVE'] = '1'; _refresh_options()
         try:
             separate = ctx.eval_batch_host(theta, return_solved=True)  # Gram matrix through memory, one lane per point in its own launch
-            os.environ['DL_FM_NO_LANE_SOLVE'] = '1'
+            os.environ['DL_FM_NO_LANE_SOLVE'] = '1'; _refresh_options()
             wide = ctx.eval_batch_host(theta, return_solved=True)      # ... 16 lanes per point
         finally:
-            os.environ.pop('DL_NO_FUSED_SOLVE', None); os.environ.pop('DL_FM_NO_LANE_SOLVE', None)
-        os.environ['DL_NO_SCALED_ROW0'] = '1'                           # every monomial group with a full epilogue on the X rows (the form before the register path of row 0)
+            os.environ.pop('DL_NO_FUSED_SOLVE', None); os.environ.pop('DL_FM_NO_LANE_SOLVE', None); _refresh_options()
+        os.environ['DL_NO_SCALED_ROW0'] = '1'; _refresh_options()  # every monomial group with a full epilogue on the X rows (the form before the register path of row 0)
         try:
             plain = ctx.eval_batch_host(theta, return_solved=True)
         finally:
-            os.environ.pop('DL_NO_SCALED_ROW0', None)
-        os.environ['DL_EF_NO_EARLY_THETA'] = '1'                        # the code path of more than 32 sampled parameters (theta / priors from memory where they are used)
+            os.environ.pop('DL_NO_SCALED_ROW0', None); _refresh_options()
+        os.environ['DL_EF_NO_EARLY_THETA'] = '1'; _refresh_options()  # the code path of more than 32 sampled parameters (theta / priors from memory where they are used)
         try:
             late = ctx.eval_batch_host(theta, return_solved=True)
         finally:
-            os.environ.pop('DL_EF_NO_EARLY_THETA', None)
+            os.environ.pop('DL_EF_NO_EARLY_THETA', None); _refresh_options()
         assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(fast, late))
         assert np.array_equal(fast[2], separate[2]) and np.array_equal(fast[2], plain[2])
         ok = fast[2] == 0
@@ -230,11 +231,11 @@ def test_gram_finalize_one_lane_per_point():
         # derived outputs (likelihood Hessian w.r.t. the solved parameters, likelihoods/base.py:388-390) through the same three paths
         sub = np.ascontiguousarray(theta[7:7 + 40])
         dfast = ctx.eval_batch_derived_host(sub)
-        os.environ['DL_NO_FUSED_SOLVE'] = '1'
+        os.environ['DL_NO_FUSED_SOLVE'] = '1'; _refresh_options()
         try:
             dsep = ctx.eval_batch_derived_host(sub)
         finally:
-            os.environ.pop('DL_NO_FUSED_SOLVE', None)
+            os.environ.pop('DL_NO_FUSED_SOLVE', None); _refresh_options()
         assert dfast[4].shape == (40, nsol, nsol) and np.array_equal(dfast[4], dsep[4]) and np.allclose(dfast[0], fast[0][7:47], rtol=1e-13, atol=0.)
         for i in (0, 17, 500, 1006):
             f0 = oracle_flat(like, pt, theory, theta[i], names, {name: 0. for name in solved})
@@ -260,11 +261,11 @@ def test_unmarginalised_likelihood_in_one_launch():
     ctx = like._get_context()
     one = ctx.eval_batch_host(theta)
     post, st = ctx.eval_logposterior_host(theta)
-    os.environ['DL_NO_GRAM_PLAIN'] = '1'
+    os.environ['DL_NO_GRAM_PLAIN'] = '1'; _refresh_options()
     try:
         two = ctx.eval_batch_host(theta)
     finally:
-        del os.environ['DL_NO_GRAM_PLAIN']
+        del os.environ['DL_NO_GRAM_PLAIN']; _refresh_options()
     assert np.array_equal(one[2], two[2]) and np.array_equal(st, one[2]) and one[2][11] != 0 and one[2][12] != 0 and (np.delete(one[2], [11, 12]) == 0).all()
     good = one[2] == 0
     assert (np.abs(one[0][good] - two[0][good]) <= 1e-11 * np.maximum(1., np.abs(two[0][good]))).all(), np.abs(one[0][good] - two[0][good]).max()

@@ -6,6 +6,7 @@ import pytest
 
 from golden_utils import load_golden
 from test_host_api import make_cfg5
+from desilike_amd._lib import refresh_options as _refresh_options   # the library reads its DL_* switches once per process
 
 pytestmark = pytest.mark.gpu
 
@@ -112,13 +113,13 @@ def test_device_ensemble_global_memory_variant():
     ref = EmceeSampler(like, nwalkers=nwalkers, seed=7)
     start, _ = ref._get_start(nwalkers)
     chain_ref = ref.run(niterations=niterations, start=start)
-    os.environ['DL_ENS_GLOBAL'] = '1'
+    os.environ['DL_ENS_GLOBAL'] = '1'; _refresh_options()
     try:
         other = EmceeSampler(like, nwalkers=nwalkers, seed=7)
         other._get_start(nwalkers)                                                 # (the device key is the generator's next draw: same history, same key)
         chain = other.run(niterations=niterations, start=start)
     finally:
-        del os.environ['DL_ENS_GLOBAL']
+        del os.environ['DL_ENS_GLOBAL']; _refresh_options()
     for name in chain_ref.keys() if hasattr(chain_ref, 'keys') else ['logposterior']:
         assert np.array_equal(np.asarray(chain[name]), np.asarray(chain_ref[name])), name
     assert np.array_equal(other.acceptance_fraction, ref.acceptance_fraction)
@@ -150,13 +151,13 @@ def test_device_ensemble_separate_finalize_path():
         ref = EmceeSampler(like, nwalkers=nwalkers, seed=9)
         start, _ = ref._get_start(nwalkers)
         chain_ref = ref.run(niterations=niterations, start=start)
-        os.environ['DL_ENS_NO_DEFER'] = '1'
+        os.environ['DL_ENS_NO_DEFER'] = '1'; _refresh_options()
         try:
             other = EmceeSampler(like, nwalkers=nwalkers, seed=9)
             other._get_start(nwalkers)
             chain = other.run(niterations=niterations, start=start)
         finally:
-            del os.environ['DL_ENS_NO_DEFER']
+            del os.environ['DL_ENS_NO_DEFER']; _refresh_options()
         for param in like.varied_params:
             assert np.array_equal(chain[param.name], chain_ref[param.name]), (nwalkers, param.name)
         assert np.array_equal(chain['logposterior'], chain_ref['logposterior'])
@@ -239,14 +240,14 @@ def test_rccl_group_single_rank():
     ref = EmceeSampler(like, nwalkers=64, seed=13)
     start, _ = ref._get_start(64)
     chain_ref = ref.run(niterations=6, start=start)
-    os.environ['DL_ENS_FORCE_COMM'] = '1'
+    os.environ['DL_ENS_FORCE_COMM'] = '1'; _refresh_options()
     try:
         sharded = EmceeSampler(like, nwalkers=64, seed=13, sharding=WalkerSharding(group=group, min_shard_rows=0), device_resident=True)
         sharded._get_start(64)
         chain = sharded.run(niterations=6, start=start)
         assert sharded._get_ensemble().info('rows_per_rank') == 32
     finally:
-        del os.environ['DL_ENS_FORCE_COMM']
+        del os.environ['DL_ENS_FORCE_COMM']; _refresh_options()
     assert np.array_equal(chain['logposterior'], chain_ref['logposterior'])
     for param in like.varied_params: assert np.array_equal(chain[param.name], chain_ref[param.name])
     group.close()
@@ -264,6 +265,8 @@ def test_bench_two_ranks_on_one_gpu():
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['config']['ranks'] == 2 and line['value'] > 0.
+    # the exchange checked end to end inside the run: every rank holds the same gathered log-posteriors, each rank's slice agrees with the oracle (bench.py::gathered_check)
+    assert line['gathered_check']['ranks'] == 2 and line['gathered_check']['identical_on_every_rank'] and line['gathered_check']['max_rel_err_vs_oracle'] <= 1e-10
     assert line['config5_strong']['n_gpus'] == 2
     assert line['chains_weak']['n_gpus'] == 2 and [entry['chains'] for entry in line['chains_weak']['per_k']] == [2, 4, 8]      # chain-parallel sampler: K chains per rank
     assert line['sustained']['steps'] >= 256
@@ -297,7 +300,7 @@ def test_config5_as_stated_device_vs_host_driver():
     ctx.eval_logposterior(theta, ref)
     torch.cuda.synchronize()
     for flag in ['DL_NO_MERGED_THEORY', 'DL_NO_PANEL_SKIP', 'DL_NO_ROW_ALIGN']:
-        os.environ[flag] = '1'
+        os.environ[flag] = '1'; _refresh_options()
     try:
         from desilike_amd._lib import Context
         plain = Context(like._spec({}, like._flatdata_list(), like.precision), device=0)
@@ -307,7 +310,7 @@ def test_config5_as_stated_device_vs_host_driver():
         plain.close()
     finally:
         for flag in ['DL_NO_MERGED_THEORY', 'DL_NO_PANEL_SKIP', 'DL_NO_ROW_ALIGN']:
-            del os.environ[flag]
+            del os.environ[flag]; _refresh_options()
     assert torch.allclose(out, ref, rtol=1e-13, atol=1e-10)
     # the chi2 GEMM's two row tiles (16 rows per workgroup below 129 workgroups of 32 rows: the 256-point half-steps; 32 otherwise): the partial sums of a row do
     # not depend on the tile, so the results are the same bit for bit
@@ -315,12 +318,12 @@ def test_config5_as_stated_device_vs_host_driver():
     out16, out32 = torch.empty(256, dtype=torch.float64, device='cuda:0'), torch.empty(256, dtype=torch.float64, device='cuda:0')
     ctx.eval_logposterior(half, out16)
     torch.cuda.synchronize()
-    os.environ['DL_CG_MT'] = '32'
+    os.environ['DL_CG_MT'] = '32'; _refresh_options()
     try:
         ctx.eval_logposterior(half, out32)
         torch.cuda.synchronize()
     finally:
-        del os.environ['DL_CG_MT']
+        del os.environ['DL_CG_MT']; _refresh_options()
     assert torch.equal(out16, out32) and torch.equal(out16, ref[:256])
 
 

@@ -79,17 +79,20 @@ def test_hmc_on_the_device_with_the_analytic_gradient():
     assert float(((ga - gf) * scale).abs().max()) < 2e-2 * max(1., float((ga * scale).abs().max()))      # (the differences use the parameters' coarse `delta` steps)
 
 
-def _worker(rank, world, port, results):
+def _worker(rank, world, port, results, nchains=6):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from desilike_amd.samplers import HMCSampler
     from desilike_amd.parallel import WalkerSharding
     like = ToyGaussianLikelihood()
-    sampler = HMCSampler(like, chains=6, seed=4, step_size=0.05, num_integration_steps=6, adaptation={'niterations': 60}, sharding=WalkerSharding(min_shard_rows=0))
-    assert sampler.chain_world == world and sampler.local_chains() == [c for c in range(6) if c % world == rank]
+    sampler = HMCSampler(like, chains=nchains, seed=4, step_size=0.05, num_integration_steps=6, adaptation={'niterations': 60}, sharding=WalkerSharding(min_shard_rows=0))
+    assert sampler.chain_world == world and sampler.local_chains() == [c for c in range(nchains) if c % world == rank]
     chains = sampler.run(check_every=80, max_iterations=160)
-    results[rank] = (np.array([chain['a'] for chain in chains]), sampler.step_size, np.asarray(sampler.inverse_mass_matrix).copy(), sampler.acceptance_rate.copy())
+    chains = chains if isinstance(chains, list) else [chains]
+    hyp = sampler.hyp
+    results[rank] = (np.array([chain['a'] for chain in chains]), sampler.step_size, np.asarray(sampler.inverse_mass_matrix).copy(), sampler.acceptance_rate.copy(),
+                     None if hyp is None else (hyp['step_size'], np.asarray(hyp['inverse_mass_matrix']).copy()))
     dist.destroy_process_group()
 
 
@@ -104,3 +107,18 @@ def test_hmc_chains_over_two_ranks():
     assert a[0].shape == (6, 160) and np.array_equal(a[0], b[0])
     assert a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
     assert 0.5 < a[3].mean() <= 1. and abs(a[0][:, 40:].mean() - 0.5) < 0.1
+
+
+def test_hmc_fewer_chains_than_ranks():
+    """One chain on two ranks: the rank without a chain adapts nothing, yet every rank ends with the chain and with the hyper-parameters the run USED (step size
+    and mass matrix averaged over the ranks that have chains) -- also in ``hyp``, which ``save()`` writes into the chain attributes."""
+    import torch.multiprocessing as mp
+    manager = mp.Manager()
+    results = manager.dict()
+    port = 39500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, results, 1), nprocs=2, join=True)
+    a, b = results[0], results[1]
+    assert a[0].shape == (1, 160) and np.array_equal(a[0], b[0])
+    assert a[1] == b[1] and np.array_equal(a[2], b[2])
+    for r in (a, b):
+        assert r[4] is not None and r[4][0] == r[1] and np.array_equal(r[4][1], r[2])

@@ -5,13 +5,14 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401
 from bench import make_likelihood, sample_theta
+from desilike_amd._lib import refresh_options as _refresh_options   # the library reads its DL_* switches once per process
 like = make_likelihood(0)
 ctx = like._get_posterior_context()[0]
 for B in (1024, 2048, 4096, 8192, 32768):
     theta = np.ascontiguousarray(sample_theta(like, B, 42))
     ref = None
     for mode in ('0', '3', '0', '3'):
-        os.environ['DL_HOST_MODE'] = mode
+        os.environ['DL_HOST_MODE'] = mode; _refresh_options()
         for _ in range(20): out = ctx.eval_logposterior_host(theta)[0]
         t = []
         for _ in range(100):

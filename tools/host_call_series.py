@@ -5,6 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401
 from bench import make_likelihood_config5, sample_theta
+from desilike_amd._lib import refresh_options as _refresh_options   # the library reads its DL_* switches once per process
 
 like = make_likelihood_config5(0)
 ctx = like._get_posterior_context()[0]
@@ -12,7 +13,7 @@ theta = np.ascontiguousarray(sample_theta(like, 256, 42))
 n = 4000
 gc.disable()
 for mode in sys.argv[1:] or ['1', '3']:
-    os.environ['DL_HOST_MODE'] = mode
+    os.environ['DL_HOST_MODE'] = mode; _refresh_options()
     for _ in range(100): ctx.eval_logposterior_host(theta)
     t = np.empty(n)
     for i in range(n):

@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401
 from bench import make_likelihood, make_likelihood_config5, sample_theta
+from desilike_amd._lib import refresh_options as _refresh_options   # the library reads its DL_* switches once per process
 
 ncalls = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 out = {}
@@ -18,7 +19,7 @@ for label, like in [('configs[1]', make_likelihood(0)), ('configs[4]', make_like
         theta = np.ascontiguousarray(theta_all[:B])
         ref = None
         for mode in (0, 1, 2, 3):
-            os.environ['DL_HOST_MODE'] = str(mode)
+            os.environ['DL_HOST_MODE'] = str(mode); _refresh_options()
             for _ in range(50): ctx.eval_logposterior_host(theta)
             t = np.empty(ncalls)
             for i in range(ncalls):
@@ -31,7 +32,7 @@ for label, like in [('configs[1]', make_likelihood(0)), ('configs[4]', make_like
             out['{} B={} mode={}'.format(label, B, mode)] = dict(median_us=float(np.median(t)), p99_us=float(np.percentile(t, 99)), mean_us=float(t.mean()), min_us=float(t.min()), identical_to_mode0=same)
             print('%-11s B=%5d mode %d: median %7.1f us  p99 %7.1f  mean %7.1f  min %7.1f  identical %s' % (label, B, mode, np.median(t), np.percentile(t, 99), t.mean(), t.min(), same), flush=True)
 # the loglikelihood / logprior / status variant (dl_eval_batch_host), default mode
-os.environ.pop('DL_HOST_MODE', None)
+os.environ.pop('DL_HOST_MODE', None); _refresh_options()
 like = make_likelihood(0)
 ctx = like._get_context()
 theta = np.ascontiguousarray(sample_theta(like, 256, 42))
