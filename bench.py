@@ -343,15 +343,23 @@ def config5_strong(group, device, local_rank, rank, world, iterations, warmup=30
 
 def _timed_context(ctx, theta, steps, warmup, posterior_out, status, device):
     """Seconds per call of ``ctx.eval_logposterior`` on the resident batch ``theta`` + the library's dispatch-attached kernel intervals (median, ms) of sampled calls."""
+    import gc
     import torch
+    # whatever the earlier legs left behind (contexts of other streams, replicas of the host-array leg) is destroyed NOW: a collector pass inside the timed loop that frees
+    # device resources synchronises the device (hipFree / hipEventDestroy: ~70 ms, seen as 2 M instead of 80 M evals/s on whichever leg it hit)
+    gc.collect()
     for _ in range(warmup): ctx.eval_logposterior(theta, posterior_out, status=status)
     torch.cuda.synchronize(device)
     every = max(1, steps // 8)
     ctx.profile_enable(every)
-    t0 = time.perf_counter()
-    for _ in range(steps): ctx.eval_logposterior(theta, posterior_out, status=status)
-    torch.cuda.synchronize(device)
-    elapsed = (time.perf_counter() - t0) / steps
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for _ in range(steps): ctx.eval_logposterior(theta, posterior_out, status=status)
+        torch.cuda.synchronize(device)
+        elapsed = (time.perf_counter() - t0) / steps
+    finally:
+        gc.enable()
     kernel_ms = ctx.profile_read()
     ctx.profile_enable(0)
     return elapsed, kernel_ms
