@@ -65,17 +65,17 @@ STK_SPECS = {'logA': dict(value=3.04, prior=dict(limits=[2.5, 3.5]), ref=dict(li
              'omega_cdm': dict(value=0.12, prior=dict(limits=[0.09, 0.15]), ref=dict(limits=[0.118, 0.122]))}
 
 
-def stacked_kgrid(nk=30):
+def stacked_kgrid(nk=30, kmax=0.32):
     """``emu.k_grid`` of the component emulators (conversion.py:69): wide enough for the tracer's cubic interpolation to its own wavenumbers (full_shape.py:1598)."""
-    return np.concatenate([[0.0005], np.geomspace(0.0015, 0.025, nk // 3), np.linspace(0.03, 0.32, nk - nk // 3 - 1)])
+    return np.concatenate([[0.0005], np.geomspace(0.0015, 0.025, nk // 3), np.linspace(0.03, kmax, nk - nk // 3 - 1)])
 
 
-def stacked_networks(z, ells=(0, 2, 4), nk=30, hidden=(32, 32), activation='tanh', seed=3):
+def stacked_networks(z, ells=(0, 2, 4), nk=30, hidden=(32, 32), activation='tanh', seed=3, kmax=0.32):
     """What ``jaxeffort.load_component_emulator`` hands to conversion.py:68-79 for every (component, iz, ell), as synthetic DATA (nothing physical is trained here):
     ``networks[component][iz][ill] = dict(k_grid, layers [(kernel [in, out], bias [out])], activations, in_MinMax [5, 2], out_MinMax [n_m * n_k, 2])``.
     The output ranges carry the amplitudes conversion.py:88-92 divides out: '11' and 'ct' by ``exp(logA) 1e-10``, 'loop' by its square."""
     rng = np.random.RandomState(seed)
-    k = stacked_kgrid(nk)
+    k = stacked_kgrid(nk, kmax=kmax)
     base = 2e4 * (k / 0.05)**0.96 / (1. + (k / 0.02)**2.5)
     a1 = np.exp(3.04) * 1e-10
     amplitude = {'11': 1. / a1, 'loop': 0.2 / a1**2, 'ct': 0.05 / a1, 'st': 1.}

@@ -116,3 +116,44 @@ def test_stacked_with_scalar_engines_physical_basis():
         sol = orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(len(solved)), prior_loc=np.zeros(len(solved)), prior_scale=scales, marg_mask=np.ones(len(solved), dtype='?'))
         assert abs(loglike[i] - sol['loglikelihood']) <= TOL * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
         assert np.allclose(xsolved[i], sol['x'], rtol=1e-7, atol=1e-9)
+
+
+def test_stacked_correlation_function_multipoles():
+    """xi_ell from the stacked emulated node (full_shape.py:1603-1629: the table combination on the log grid, then get_corr): the Hankel operator folds into the same
+    per-group operators; counter terms marginalised; against the oracle's get_corr on the oracle's P_ell."""
+    from desilike_amd.emulators import EmulatedCalculator
+    from desilike_amd.theories.galaxy_clustering import REPTVelocileptorsTracerCorrelationFunctionMultipoles
+    from desilike_amd.observables.galaxy_clustering import TracerCorrelationFunctionMultipolesObservable
+    from desilike_amd.likelihoods import ObservablesGaussianLikelihood
+    zgrid = STACKED_ZGRID[:4]
+    networks = stacked_networks(zgrid, hidden=(64, 64), activation='silu', seed=12, nk=48, kmax=0.62)     # (the tables cover the 300-point log grid of the transform: no cubic extrapolation at high k)
+    pt = EmulatedCalculator.from_state(stacked_state(networks, zgrid, STK_PARAMS), param_specs=STK_SPECS)
+    theory = REPTVelocileptorsTracerCorrelationFunctionMultipoles(pt=pt, z=0.6, prior_basis='standard')
+    for name in ['b3', 'alpha6']: theory.init.params[name].update(fixed=True)
+    for name in ['alpha0', 'alpha2', 'alpha4']: theory.init.params[name].update(prior=dict(dist='norm', loc=0., scale=20.), derived='.marg')
+    s = np.linspace(22.5, 167.5, 30)
+    rng = np.random.RandomState(6)
+    A = rng.standard_normal((90, 90)) * 3e-4
+    obs = TracerCorrelationFunctionMultipolesObservable(data={'b1': 1.7, 'b2': 0.4, 'alpha0': 3.}, s=s, ells=(0, 2, 4), theory=theory)
+    like = ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + (3e-3)**2 * np.eye(90))
+    like.initialize()
+    names, solved = like.varied_params.names(), like.solved_params.names()
+    assert solved == ['alpha0', 'alpha2', 'alpha4']
+    theta = sample(like, 128, 10)
+    loglike, logprior, status, xsolved = like._get_context().eval_batch_host(theta, return_solved=True)
+    assert (status == 0).all()
+    for i in range(0, 128, 17):
+        def flat(x):
+            p = dict(zip(names, theta[i])); p.update(x)
+            X = {name: p[name] for name in STK_PARAMS}
+            components = [orc.stacked_mlp_predict(X, STK_PARAMS, pt.engines[n].xlimits, pt.engines[n].layers, 'silu', pt.engines[n].ylimits, amplitude_power=pw) for n, pw in [('11', 1), ('loop', 2), ('ct', 1), ('st', 0)]]
+            pktable = orc.jaxeffort_pktable(components, zgrid=zgrid, z=[0.6])[..., 0]
+            params = {name: p.get(name, like.all_params[name].value if name in like.all_params else 0.) for name in ['b1', 'b2', 'bs', 'b3', 'alpha0', 'alpha2', 'alpha4', 'alpha6', 'sn0', 'sn2', 'sn4']}
+            pars = orc.velocileptors_pars(params, 1., 1., basis='standard', model='rept')
+            power = orc.interp1d(theory.k, pt.k, orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=theory.nd).T).T
+            return np.ravel(orc.get_corr(power, theory.k, s, (0, 2, 4)))
+        f0 = flat({name: 0. for name in solved})
+        T = np.array([flat({n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
+        sol = orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(3), prior_loc=np.zeros(3), prior_scale=np.full(3, 20.), marg_mask=np.ones(3, dtype='?'))
+        assert abs(loglike[i] - sol['loglikelihood']) <= TOL * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
+        assert np.allclose(xsolved[i], sol['x'], rtol=1e-7, atol=1e-9)
