@@ -27,6 +27,23 @@ DL_BENCH_FORCE_DIST=1 DL_ENS_FORCE_COMM=1 timeout 600 python3 $R/bench.py --no-c
 timeout 900 python3 $R/tools/time_configs.py > $OUT/${TAG}_time_configs.txt 2>/dev/null
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg -o $TAG -- python3 $R/tools/time_configs.py > /dev/null 2>&1
 python3 $R/tools/kernel_stats.py $OUT/trace_cfg > $OUT/${TAG}_cfg3_cfg4_kernel_stats.txt 2>&1
+# BASELINE configs[2] on the emulator layout the reference ships (dl_emulated_stacked_kernel): timing, kernel trace, SQ counters (two passes), in-kernel stamps
+timeout 300 python3 $R/tools/time_stacked.py 4096 1 200 > $OUT/${TAG}_stacked_time.txt 2>/dev/null
+timeout 300 python3 $R/tools/time_stacked.py 4096 0 200 >> $OUT/${TAG}_stacked_time.txt 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_stk -o $TAG -- python3 $R/tools/time_stacked.py 4096 1 200 > /dev/null 2>&1
+cp $(find $OUT/trace_stk -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_stacked_kernel_stats.csv 2>/dev/null
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_LDS --output-format csv -d $OUT/stk_sq1 -o $TAG -- python3 $R/tools/time_stacked.py 4096 1 60 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/stk_sq3 -o $TAG -- python3 $R/tools/time_stacked.py 4096 1 60 > /dev/null 2>&1
+python3 $R/tools/sq_summary.py $OUT/stk_sq1 $OUT/stk_sq3 --stats $OUT/${TAG}_stacked_kernel_stats.csv > $OUT/${TAG}_stacked_sq_counters.txt 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/stk_fetch -o $TAG -- python3 $R/tools/time_stacked.py 4096 1 60 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/stk_write -o $TAG -- python3 $R/tools/time_stacked.py 4096 1 60 > /dev/null 2>&1
+python3 $R/tools/pmc_summary.py $OUT/stk_fetch $OUT/stk_write > $OUT/${TAG}_stacked_hbm_traffic.txt 2>&1
+rm -f $OUT/stk_stamps_raw.txt
+DL_STK_STAMPS=$OUT/stk_stamps_raw.txt timeout 300 python3 $R/tools/time_stacked.py 4096 1 40 > /dev/null 2>&1
+python3 $R/tools/stk_stamps.py $OUT/stk_stamps_raw.txt > $OUT/${TAG}_stacked_stamps.txt 2>&1
+rm -rf $OUT/trace_stk $OUT/stk_sq1 $OUT/stk_sq3 $OUT/stk_fetch $OUT/stk_write $OUT/stk_stamps_raw.txt
+# BASELINE configs[2], single network (dl_emulated_feature_gram_kernel): SQ counters
+(cd $R && bash tools/prof_cfg3.sh $TAG > /dev/null 2>&1; mv gpurun_out/${TAG}_cfg3_* $OUT/ 2>/dev/null)
 # analytic gradient: cost against one evaluation and against the finite-difference stencil; kernels of the gradient path
 timeout 600 python3 $R/tools/time_grad.py > $OUT/${TAG}_time_grad.txt 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_grad -o $TAG -- python3 $R/tools/time_grad.py > /dev/null 2>&1

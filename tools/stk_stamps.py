@@ -1,4 +1,5 @@
-"""Summary of DL_STK_STAMPS output (dl_emulated_stacked_kernel): median over workgroups of the time between consecutive stamps, in us at the s_memtime clock (100 MHz)."""
+"""Summary of DL_STK_STAMPS output (dl_emulated_stacked_kernel): median over workgroups of the s_memtime difference between consecutive stamps, in units of 100 shader-clock
+cycles (the shader clock runs at ~2.2 GHz under this load: 100 units = 4.5 us)."""
 import sys
 import numpy as np
 
@@ -15,9 +16,9 @@ for il, a in enumerate(launches):
         d = np.median(np.diff(a[:, 15:30], axis=1), axis=0)
         print('   first group, layers 1-3 (cycles): ' + ' | '.join('MFMA %d, barrier %d, act %d, barrier %d' % tuple(d[5 * l:5 * l + 4]) + (', next %d' % d[5 * l + 4] if 5 * l + 4 < len(d) else '') for l in range(3)))
     t0 = a[:, live[0]]
-    print('launch %d: %d workgroups; per-workgroup medians (us, s_memtime at 100 MHz):' % (il, len(a)))
+    print('launch %d: %d workgroups; per-workgroup medians (units of 100 shader cycles):' % (il, len(a)))
     prev = live[0]
     for q in live[1:]:
         print('   %-16s +%8.2f   (at %8.2f)' % (names[q], np.median(a[:, q] - a[:, prev]) / 100., np.median(a[:, q] - t0) / 100.))
         prev = q
-    print('   kernel span (first entry -> last store): %.2f us' % ((a[:, live[-1]].max() - t0.min()) / 100.))
+    print('   (values: shader-clock cycles / 100; s_memtime counters differ between XCDs: only differences within a workgroup mean something)')
