@@ -404,7 +404,25 @@ def host_call_leg(likelihood, sizes=(1, 16, 256, 1024), ncalls=500):
             t[i] = 1e-3 * (time.perf_counter_ns() - t0)
         out[str(B)] = {'median_us': float(np.median(t)), 'p99_us': float(np.percentile(t, 99)), 'mean_us': float(t.mean()), 'evals_per_s': float(B / (1e-6 * t.mean()))}
     return {'entry_point': 'dl_eval_logposterior_host (host pointers in / out; pinned, device-mapped staging read and written by the kernels themselves; completion flag)',
-            'calls_per_size': ncalls, 'includes': 'ctypes call, staging copy, PCIe reads / writes of the kernels, completion wait', 'per_batch_size': out}
+            'calls_per_size': ncalls, 'includes': 'ctypes call, staging copy, PCIe reads / writes of the kernels, completion wait', 'per_batch_size': out,
+            'host_driven_ensemble': host_driven_ensemble()}
+
+
+def host_driven_ensemble(iterations=200):
+    """What an UNMODIFIED host-driven ensemble sampler pays end to end (emcee's loop in the reference, samplers/emcee.py:69: proposals in NumPy on the host, the log-posteriors of
+    each half of the walkers through ONE host-array call): BASELINE configs[4]'s 512 walkers x two tracers with ``EmceeSampler(device_resident=False)`` -- two
+    ``dl_eval_logposterior_host`` calls of 256 points plus the NumPy stretch move per update.  The device-resident ensemble of the same likelihood is the `config5_strong` leg."""
+    from desilike_amd.samplers import EmceeSampler
+    from desilike_amd.parallel import WalkerSharding
+    like = make_likelihood_config5(0)
+    sampler = EmceeSampler(like, nwalkers=512, seed=42, sharding=WalkerSharding(group=False), device_resident=False, use_emcee=False)
+    sampler.run(niterations=20)
+    t0 = time.perf_counter()
+    chain = sampler.run(niterations=iterations)
+    elapsed = time.perf_counter() - t0
+    assert np.isfinite(chain['logposterior'][-1]).all()
+    return {'workload': 'EmceeSampler(device_resident=False): host-side stretch move, two 256-point host-array calls per update, 512 walkers x two config-2 tracers', 'iterations': iterations,
+            'us_per_update': 1e6 * elapsed / iterations, 'value': 512 * iterations / elapsed, 'unit': 'evals/s'}
 
 
 def other_configs(device, steps=40, warmup=5, ncheck=8):

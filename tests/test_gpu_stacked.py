@@ -157,3 +157,22 @@ def test_stacked_correlation_function_multipoles():
         sol = orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(3), prior_loc=np.zeros(3), prior_scale=np.full(3, 20.), marg_mask=np.ones(3, dtype='?'))
         assert abs(loglike[i] - sol['loglikelihood']) <= TOL * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
         assert np.allclose(xsolved[i], sol['x'], rtol=1e-7, atol=1e-9)
+
+
+def test_ensemble_sampler_on_the_stacked_likelihood():
+    """The device-resident ensemble (dl_ensemble_*) on a likelihood whose theory is the stacked emulator: the same chain, bit for bit, as the host-driven stretch move
+    with the same counter-based generator (both evaluate through the MFMA kernel; the proposals are the same arithmetic on either side)."""
+    from desilike_amd.samplers import EmceeSampler, EnsembleStretchMove, CounterRNG
+    like, pt, theory, solved, networks = make_cfg3_stacked(marg=True, hidden=(32, 32), nk=30, seed=4)
+    like.initialize()
+    ndim = len(like.varied_params)
+    sampler = EmceeSampler(like, nwalkers=64, seed=11)
+    start, logp0 = sampler._get_start(64)
+    chain = sampler.run(niterations=8, start=start)
+    host = EnsembleStretchMove(64, ndim, sampler.logposterior, rng=CounterRNG(sampler.counter_seed))
+    coords, logp = start.copy(), sampler.logposterior(start)
+    for it in range(8):
+        coords, logp = host.step(coords, logp)
+        assert np.array_equal(np.column_stack([chain[param.name][it] for param in like.varied_params]), coords), it
+        assert np.array_equal(chain['logposterior'][it], logp), it
+    assert np.isfinite(logp).all()

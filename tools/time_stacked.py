@@ -19,7 +19,7 @@ def main():
     th = torch.as_tensor(theta, dtype=torch.float64, device='cuda').contiguous()
     out = torch.empty(B, dtype=torch.float64, device='cuda')
     st = torch.empty(B, dtype=torch.int32, device='cuda')
-    for _ in range(5): ctx.eval_logposterior(th, out, status=st)
+    for _ in range(250): ctx.eval_logposterior(th, out, status=st)     # (the first ~200 calls of a fresh process are slower: tools/time_gap_stacked.py)
     torch.cuda.synchronize()
     ctx.profile_enable(2)
     t0 = time.perf_counter()
