@@ -602,19 +602,25 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         }
         // plain likelihood: chi2 is additive over the columns of the whitened residual -> column-split GEMM that emits partial chi2 only
         // marginalised fits on one emulated observable: Gram-matrix epilogue in the fused kernel -- the residual rows never reach memory (DL_NO_GRAM_EPILOGUE=1: rows + Gram in the finalize)
-        bool gram_done = false, finalized_in_kernel = false;
+        bool gram_done = false, finalized_in_kernel = false, stacked_rows_done = false;
         static const bool gram_epilogue = !getenv("DL_NO_GRAM_EPILOGUE");
         // (also without solved parameters: X is the residual row alone, chi2 = G[0][0] and the finalize -- priors, status -- runs in the kernel's tail: one launch instead of two)
         if (feat_path && emu_fused && gram_epilogue && ctx->n_obs == 1 && ctx->N_pad == 128) {
             DlGramFinalize fin = {ctx->priors_dev, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr,
                                   solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr, hessian_dev ? hessian_dev + (size_t)b0 * ctx->n_solved * ctx->n_solved : nullptr,
                                   post_mode, false};
-            gram_done = dl_launch_emulated_feature_gram(ctx->obs_kernarg[0], th, P, nb, ctx->gfrag_dev[0], ctx->bias_white_dev, ctx->marg, ctx->n_white, ctx->delta_ws, stream, &fin);
+            if (ctx->stk_steps[0]) {   // stacked table engine: the same finalize in the tail of dl_emulated_stacked_kernel when the rows of X fit its LDS
+                dl_launch_emulated_stacked(ctx->obs_kernarg[0], th, P, nb, ctx->gfrag_dev[0], ctx->delta_ws, ctx->N_pad, ctx->N_pad, 0, ctx->stk_steps[0], stream, &fin, ctx->bias_white_dev,
+                                           &ctx->marg, ctx->n_white);
+                gram_done = fin.done;          // (launched either way: with fin.done the outputs are written ...
+                stacked_rows_done = !fin.done; //  ... without it the residual rows of the observable are in delta_ws: the general finalize follows)
+            } else gram_done = dl_launch_emulated_feature_gram(ctx->obs_kernarg[0], th, P, nb, ctx->gfrag_dev[0], ctx->bias_white_dev, ctx->marg, ctx->n_white, ctx->delta_ws, stream, &fin);
             if (gram_done) fin_bias = ctx->bias_white_dev;
             finalized_in_kernel = gram_done && fin.done;
         }
         if (feat_path && !gram_done) {
             for (int i = 0; i < ctx->n_obs; ++i) {
+                if (i == 0 && stacked_rows_done) continue;
                 if (ctx->stk_steps[i]) dl_launch_emulated_stacked(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, ctx->stk_steps[i], stream);
                 else if (emu_fused) dl_launch_emulated_feature(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, stream);
                 else dl_launch_feature_gemm(ctx->feat_ws, ctx->feat_ld, ctx->obs_kernarg[i].feat_off, ctx->obs_kernarg[i].nb_pad, R, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad,

@@ -18,6 +18,7 @@
 #pragma once
 #include "dl_fullshape.h"
 #include "dl_feature_gemm.h"
+#include "dl_marg_solve.h"
 
 typedef double dl_stk_double4 __attribute__((ext_vector_type(4)));
 
@@ -46,6 +47,27 @@ static inline bool dl_stk_feature_ok(const DlObsDev& o) {
         if (o.eng[ie].type == 0) for (int l = 0; l <= o.eng[ie].n_layers; ++l) if (o.eng[ie].widths[l] > 128) return false;
     }
     return dl_stk_shared_doubles(o) * sizeof(double) <= 160 * 1024;
+}
+
+// The finalize in the kernel's tail (one observable, N_pad = 128, 1 + n_s <= 8 rows of X that fit the LDS the networks and the basis record no longer need): the rows
+// X = [residual + bias; derivative rows + tconst_s] of the workgroup's 16 points go from the carried registers to LDS, each wave forms G = X X^T of two points by MFMA
+// (dl_fg_gram_phase), lanes 0-15 of wave 0 solve a point each (dl_marg_solve.h) while wave 1 sums the priors -- as in the tail of dl_emulated_feature_gram_kernel.  Against
+// rows through memory + dl_finalize_marg_kernel: 25 MB written and read back per 4096 points and a 20 us launch less.
+struct DlStkTail {
+    int enabled, xr, n_const;          // xr: rows of X (1 + n_s)
+    int row_of[DL_STK_ROWS];           // X row of device row r
+    const double* cst[DL_STK_ROWS];    // constant part of device row r: bias, or tconst of its solved parameter ([128] each)
+    int const_row[DL_MAX_SOLVED];      // X rows that are constants only ...
+    const double* const_ptr[DL_MAX_SOLVED];
+    int post_mode, pad;
+    const double* priors;
+    double *loglike, *logprior;
+    int32_t* status;
+    double *solved, *hessian;
+    DlMargDev mg;
+};
+static inline __host__ __device__ bool dl_stk_tail_fits(const DlObsDev& o, int xr) {
+    return xr <= 8 && (size_t)DL_STK_PTS * xr * DL_FG_XLD <= (size_t)DL_STK_PTS * dl_stk_bld(o) + (size_t)8 * DL_STK_PTS * dl_stk_tld(o);
 }
 
 #if defined(__HIPCC__)
@@ -105,13 +127,6 @@ __device__ __forceinline__ void dl_stk_networks(const int32_t* widths, int n_lay
         const bool next16 = !last && (nout + 3) / 4 == 16 && nt_begin < ntotal;
  DL_STK_LSTAMP
         dl_stk_double4 res[TMAX];
-        double bb[TMAX];                    // biases of this wave's tasks: requested up front (after the barrier below they would be a round trip to L2 per layer)
-#pragma unroll
-        for (int i = 0; i < TMAX; ++i) {
-            const int task = t_begin + i < t_end ? t_begin + i : (t_end > 0 ? t_end - 1 : 0);
-            const int jn = task / tiles, t = task - jn * tiles;
-            bb[i] = (wf - lane)[(size_t)jn * frag_doubles + loff + (size_t)tiles * ksteps * 64 + 16 * t + col];
-        }
         if (ksteps == 16) {
             double bwn[16];
             if (!have && t_begin < t_end) {
@@ -183,7 +198,7 @@ __device__ __forceinline__ void dl_stk_networks(const int32_t* widths, int n_lay
             if (task >= t_end) break;
             const int jn = task / tiles, t = task - jn * tiles;
             const int oc = 16 * t + col;
-            const double b = bb[i];
+            const double b = (wf - lane)[(size_t)jn * frag_doubles + loff + (size_t)tiles * ksteps * 64 + oc];
             double vv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) vv[r] = res[i][r] + b;          // accumulator register r = out[point g + 4 r][oc]
@@ -253,12 +268,40 @@ __device__ __forceinline__ void dl_stk_group_gemm(const double* arow, const dl_f
     }
 }
 
+// G = X X^T of the workgroup's 16 points from their rows in LDS (xr <= 8 rows per point): the two-points-per-tile form of dl_fg_gram_phase (rows 0-7 of the 16-row MFMA tile:
+// point 2 wave, rows 8-15: point 2 wave + 1; the 32 operand values of a lane requested together); the 8 x 8 block of a point lands over its own X rows, at x + pt xr DL_FG_XLD + 8 i + j
+__device__ __forceinline__ void dl_stk_gram_phase(double* x, int xr, int wave, int lane, int g) {
+    const int j = lane & 15, pp = j >> 3, row = j & 7;
+    const bool live = row < xr;
+    const double* xp = x + ((size_t)(2 * wave + pp) * xr + (live ? row : 0)) * DL_FG_XLD + g;
+    double xv[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) xv[k] = xp[4 * k];
+    dl_fg_double4 acc0 = {0., 0., 0., 0.};
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { const double x0 = live ? xv[k] : 0.; acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc0, 0, 0, 0); }
+    double* gl = x + (size_t)(2 * wave + pp) * xr * DL_FG_XLD;     // (every operand read of this wave precedes these writes; no other wave reads these rows)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = g + 4 * r;
+        if ((i >> 3) == pp) gl[(i & 7) * 8 + row] = acc0[r];
+    }
+}
+
+template <int NS>
+__device__ __forceinline__ void dl_stk_solve_point(const double* gl, const DlStkTail& tl, int64_t b, double& ll, double& lps, bool& ok) {
+    ll = dl_marg_solve_lane<NS>([&](int i, int j) { return gl[i * 8 + j]; }, tl.mg, tl.solved ? tl.solved + (size_t)b * NS : nullptr,
+                                tl.hessian ? tl.hessian + (size_t)b * NS * NS : nullptr, lps, ok);
+}
+
 // theta -> residual rows out[B * R, ldo] (+= if accumulate) of one observable; gfrag: [N_pad / 16][sum_g nq_g cnt_g][64][2]; blockIdx.y = group of 8 column blocks
 // TMAX: output tiles per layer (4: widths <= 64, 8: <= 128); RMAX: rows carried per point in registers (>= 1 + n_var)
 template <int TMAX, int RMAX>
 __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ gfrag, const DlObsDev o,
-                                                                  double* __restrict__ out, int64_t ldo, int accumulate, int steps_per_block, unsigned long long* stamps) {
+                                                                  double* __restrict__ out, int64_t ldo, int accumulate, int steps_per_block, unsigned long long* stamps, const DlStkTail tl) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double lp_lds[DL_STK_PTS];      // (tail: log-priors and NaN flags of the 16 points)
+    __shared__ int nan_lds[DL_STK_PTS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g = lane >> 4;
@@ -392,6 +435,7 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
         }
         DL_STK_STAMP(4 + 2 * gi)
     }
+    if (!tl.enabled) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int pt = g + 4 * rr;
@@ -404,6 +448,55 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
                 }
             }
         }
+    }
+    
+        DL_STK_STAMP(30)
+        if (st != nullptr && tid == 0) st[31] = __builtin_amdgcn_s_memrealtime();
+        return;
+    }
+    // ---- finalize in the tail: rows -> LDS (over the basis record and the activation buffers: every wave is past them after the barrier), Gram matrices, solve ----
+    __syncthreads();
+    double* X = basis;                                   // [16 points][xr][DL_FG_XLD]
+    const int cbase = wave * 16 + col;                   // (N_pad = 128: one workgroup column group, wave = column block)
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        if (u < R) {
+            const double c = tl.cst[u][cbase];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) X[((size_t)(g + 4 * rr) * tl.xr + tl.row_of[u]) * DL_FG_XLD + cbase] = outv[rr][u] + c;
+        }
+    }
+    for (int c = 0; c < tl.n_const; ++c)
+        for (int idx = tid; idx < DL_STK_PTS * 128; idx += 512) {
+            const int pt = idx >> 7, cc = idx & 127;
+            X[((size_t)pt * tl.xr + tl.const_row[c]) * DL_FG_XLD + cc] = tl.const_ptr[c][cc];
+        }
+    __syncthreads();
+    dl_stk_gram_phase(X, tl.xr, wave, lane, g);            // the 8 x 8 block of point pt at X + pt xr DL_FG_XLD + 8 i + j
+    if (wave == 1 && lane < DL_STK_PTS) {
+        const int64_t b = p0 + lane;
+        double lp;
+        int nan_in;
+        dl_marg_priors_lane(theta + (size_t)(b < B ? b : B - 1) * n_params, n_params, tl.priors, lp, nan_in);
+        lp_lds[lane] = lp; nan_lds[lane] = nan_in;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < DL_STK_PTS && p0 + lane < B) {
+        const int64_t b = p0 + lane;
+        const double* gl = X + (size_t)lane * tl.xr * DL_FG_XLD;
+        double ll = 0., lps = 0.;
+        bool ok = true;
+        switch (tl.mg.n_s) {
+            case 0: ll = -0.5 * gl[0]; break;   // no solved parameters: chi2 = |dt|^2 = G[0][0]
+            case 1: dl_stk_solve_point<1>(gl, tl, b, ll, lps, ok); break;
+            case 2: dl_stk_solve_point<2>(gl, tl, b, ll, lps, ok); break;
+            case 3: dl_stk_solve_point<3>(gl, tl, b, ll, lps, ok); break;
+            case 4: dl_stk_solve_point<4>(gl, tl, b, ll, lps, ok); break;
+            case 5: dl_stk_solve_point<5>(gl, tl, b, ll, lps, ok); break;
+            case 6: dl_stk_solve_point<6>(gl, tl, b, ll, lps, ok); break;
+            default: dl_stk_solve_point<7>(gl, tl, b, ll, lps, ok); break;
+        }
+        dl_marg_store_lane(ll, lps, ok, lp_lds[lane], nan_lds[lane] != 0, tl.post_mode, b, tl.loglike, tl.logprior, tl.status);
     }
     DL_STK_STAMP(30)
     if (st != nullptr && tid == 0) st[31] = __builtin_amdgcn_s_memrealtime();

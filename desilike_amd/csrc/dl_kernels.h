@@ -92,8 +92,10 @@ void dl_launch_step(const DlObsDev& obs, const double* theta, int n_params, int6
 // stacked table engine (obs.eng[0].type == 2: the jaxeffort layout of emulators/conversion.py:44-98; dl_emu_stacked.h): every network of every group by MFMA and the feature
 // GEMM in one launch; gfrag: [N_pad / 16][steps_per_block][64][2] (group by group, k / 8 by k / 8, monomial by monomial)
 bool dl_emulated_stacked_ok(const DlObsDev& obs);
+struct DlGramFinalize;
 void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
-                                int steps_per_block, hipStream_t stream);
+                                int steps_per_block, hipStream_t stream, DlGramFinalize* fin = nullptr, const double* bias = nullptr, const DlMargDev* mg = nullptr, int n_valid = 0);
+// (fin, bias, mg: the marginalised finalize in the kernel's tail -- one observable, N_pad = 128 --, see dl_kernels.hip; fin->done tells whether it was taken)
 // ... with the Gram-matrix epilogue: gram [B, 16, 16] = Gram matrix of [residual + bias; derivative rows + tconst] per point instead of the rows themselves (one observable,
 // N_pad = 128).  Returns false (nothing launched) when the rows of 16 points do not fit the LDS next to the forward pass.
 // fin != nullptr and n_s <= 7: the marginalised finalize runs in the tail of the same kernel (outputs of DlGramFinalize; *fin->done = true), nothing is written to `gram`.

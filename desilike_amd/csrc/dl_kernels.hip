@@ -886,11 +886,33 @@ void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_
 
 // stacked table engine (dl_emu_stacked.h): networks of every group + feature GEMM, theta -> residual rows of one observable in one launch
 bool dl_emulated_stacked_ok(const DlObsDev& obs) { return dl_stk_feature_ok(obs); }
+// fin != nullptr (one observable, N_pad = 128, every solved parameter on a device row or constant, X fits the LDS): the marginalised finalize runs in the kernel's tail
+// (outputs of DlGramFinalize; fin->done = true) and no row is written; otherwise the residual rows go to `out`
 void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
-                                int steps_per_block, hipStream_t stream) {
+                                int steps_per_block, hipStream_t stream, DlGramFinalize* fin, const double* bias, const DlMargDev* mg, int n_valid) {
     const size_t shm = dl_stk_shared_doubles(obs) * sizeof(double);
     const int R = 1 + obs.n_var;
     const unsigned grid = (unsigned)((B + DL_STK_PTS - 1) / DL_STK_PTS);
+    DlStkTail tl;
+    std::memset(&tl, 0, sizeof(tl));
+    if (fin != nullptr && mg != nullptr && N_pad == 128 && n_valid <= 128 && !accumulate && mg->n_s >= 0 && dl_stk_tail_fits(obs, 1 + mg->n_s)) {
+        bool ok = true;
+        tl.xr = 1 + mg->n_s;
+        tl.row_of[0] = 0; tl.cst[0] = bias;
+        for (int s = 0; s < mg->n_s && ok; ++s) {
+            const int slot = mg->var_slot[s];
+            if (slot >= 0) {
+                if (1 + slot >= R || 1 + slot >= DL_STK_ROWS) ok = false;
+                else { tl.row_of[1 + slot] = 1 + s; tl.cst[1 + slot] = mg->tconst + (size_t)s * 128; }
+            } else { tl.const_row[tl.n_const] = 1 + s; tl.const_ptr[tl.n_const] = mg->tconst + (size_t)s * 128; tl.n_const++; }
+        }
+        for (int r = 1; r < R && ok; ++r) if (tl.cst[r] == nullptr) ok = false;   // a device row that feeds no solved parameter
+        if (ok) {
+            tl.enabled = 1; tl.post_mode = fin->post_mode & 0xff; tl.priors = fin->priors; tl.loglike = fin->loglike; tl.logprior = fin->logprior; tl.status = fin->status;
+            tl.solved = fin->solved; tl.hessian = fin->hessian; tl.mg = *mg;
+            fin->done = true;
+        }
+    }
     static const char* stamp_file = getenv("DL_STK_STAMPS");   // diagnostics: s_memtime at the phase boundaries of launches 30..33 appended to the file (synchronises)
     static unsigned long long* stamps_dev = nullptr;
     static int stamp_launches = 0;
@@ -900,7 +922,7 @@ void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_
     if (stamps) (void)hipMemsetAsync(stamps, 0, (size_t)grid * 32 * sizeof(unsigned long long), stream);
     auto launch = [&](auto kernel) {
         (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        DL_LAUNCH(kernel, dim3(grid, (unsigned)(N_pad / 128)), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, out, ldo, accumulate, steps_per_block, stamps);
+        DL_LAUNCH(kernel, dim3(grid, (unsigned)(N_pad / 128)), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, out, ldo, accumulate, steps_per_block, stamps, tl);
     };
     const bool wide = dl_stk_tld(obs) > 66;   // a layer wider than 64 units: eight output tiles per layer
     if (wide) { if (R <= 1) launch(dl_emulated_stacked_kernel<8, 1>); else if (R <= 4) launch(dl_emulated_stacked_kernel<8, 4>); else if (R <= 6) launch(dl_emulated_stacked_kernel<8, 6>); else launch(dl_emulated_stacked_kernel<8, 8>); }

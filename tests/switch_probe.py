@@ -144,6 +144,33 @@ def section_png():
         close(ctx.eval_batch_host(g['theta'])[0], g['loglikelihood'], name + ' vs reference')
 
 
+def section_stk():
+    """the stacked emulator layout (emulators/conversion.py:44-98): the binding's key sets against the reference's own numbers (plain and marginalised), and a reduced
+    copy of BASELINE configs[2] on that layout against the oracle (marginalised: finalize in the kernel's tail, or rows + the general finalize under DL_NO_GRAM_EPILOGUE)"""
+    import ctypes
+    from desilike_amd._lib import load
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'integration'))
+    from desilike_mi355x import Library
+    library = Library(os.path.join(os.path.dirname(HERE), 'desilike_amd', 'lib', 'libdesilike_amd.so'))
+    g = np.load(os.path.join(HERE, 'golden', 'boundary_cfg3_stacked.npz'))
+    ctx = library.create({key[4:]: g[key] for key in g.files if key.startswith('cfg/')}, device=0)
+    loglike, logprior, status = library.eval_batch(ctx, g['theta'])
+    inside = np.isfinite(g['logprior'])
+    close(loglike[inside], g['loglikelihood'][inside], 'stacked emulator vs reference')
+    library.lib.dl_destroy(ctx)
+    from bench_configs import make_cfg3_stacked, cfg3_stacked_oracle_solution
+    for marg in (True, False):
+        like, pt, theory, solved, networks = make_cfg3_stacked(marg=marg, hidden=(32, 32), nk=30, seed=4)
+        like.initialize()
+        rng = np.random.RandomState(2)
+        theta = np.column_stack([np.clip(param.ref.sample(size=70, random_state=rng), *param.prior.limits) for param in like.varied_params])
+        out = like._get_context().eval_batch_host(theta, return_solved=marg)
+        for i in range(0, 70, 9):
+            sol = cfg3_stacked_oracle_solution(like, pt, theory, solved, theta[i])
+            close(np.array([out[0][i]]), np.array([sol['loglikelihood']]), 'stacked emulator (marg = {}) vs oracle'.format(marg))
+            if marg: assert np.allclose(out[3][i], sol['x'], rtol=1e-7, atol=1e-9)
+
+
 if __name__ == '__main__':
     for name in sys.argv[1:]:
         globals()['section_' + name]()

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 # (environment, sections of tests/switch_probe.py the switch can affect)
-SWITCHES = [({}, 'fs two ens emu bao tns png mh'),
+SWITCHES = [({}, 'fs two ens emu bao tns png mh stk'),
             ({'DL_TNS_WAVEK': '0'}, 'tns'), ({'DL_TNS_WAVEK': '1'}, 'tns'), ({'DL_TNS_W': '2'}, 'tns'), ({'DL_TNS_W': '4'}, 'tns'),                 # TNS loop kernel: split-K / one wavenumber per wave, whatever the batch
             ({'DL_NO_TOEPLITZ': '1'}, 'fs two png'),                                        # general-knot spline solve (segmented Thomas) instead of the FIR form
             ({'DL_XCD_LOCAL': '0'}, 'fs emu'), ({'DL_XCD_LOCAL': '2', 'DL_CHI2_GEMM_MAX': '512'}, 'fs'),
@@ -27,7 +27,7 @@ SWITCHES = [({}, 'fs two ens emu bao tns png mh'),
             ({'DL_FS_DENSE_MIN': '256'}, 'fs two'), ({'DL_FS_DENSE_MIN': '1000000'}, 'fs'),
             ({'DL_NO_MERGED_THEORY': '1'}, 'two ens'), ({'DL_NO_PANEL_SKIP': '1'}, 'two'), ({'DL_NO_ROW_ALIGN': '1'}, 'two ens'),
             ({'DL_ENS_GLOBAL': '1'}, 'ens'), ({'DL_ENS_NO_DEFER': '1'}, 'ens'), ({'DL_ENS_NO_FOLD': '1'}, 'ens'), ({'DL_MH_NO_DEFER': '1'}, 'mh'),
-            ({'DL_NO_EMU_FUSED': '1'}, 'emu'), ({'DL_NO_GRAM_EPILOGUE': '1'}, 'emu'), ({'DL_NO_EMU_BATCH': '1'}, 'emu'), ({'DL_NO_FEATURE_PATH': '1'}, 'emu'),
+            ({'DL_NO_EMU_FUSED': '1'}, 'emu stk'), ({'DL_NO_GRAM_EPILOGUE': '1'}, 'emu stk'), ({'DL_NO_EMU_BATCH': '1'}, 'emu'), ({'DL_NO_FEATURE_PATH': '1'}, 'emu stk'),
             ({'DL_FM_NO_STAGE': '1'}, 'emu bao'),
             ({'DL_BAO_THREADS': '64'}, 'bao'), ({'DL_BAO_THREADS': '128'}, 'bao'), ({'DL_BAO_THREADS': '256'}, 'bao'),
             ({'DL_FFTLOG_GENERIC': '1'}, 'bao')]
