@@ -541,7 +541,7 @@ def _stacked_config(device, steps, warmup, ncheck, sample):
     n, H = like.flatdata.size, widths[-1]
     per_network = sum(2 * a * b + 25 * b for a, b in zip(widths[:-1], widths[1:]))                       # MACs + one activation (~25) per unit
     flops = {'networks': int(groups[:, 1].max()) * per_network, 'folded_operator': int(sum(2 * n * ((te - tb) * H + 1) * (m1 - m0) for tb, te, m0, m1 in groups)),
-             'monomial_rows': 2 * n * (19 + 2 * len(solved))}
+             'monomial_rows': 2 * n * (19 + 2 * len(solved)), 'gram': (1 + len(solved)) * (2 + len(solved)) * n}
     fused = sum(flops.values())
     slot = max(['theory', 'window_gemm'], key=lambda name: kernel_ms[name])
     achieved = fused * B / (kernel_ms[slot] * 1e-3) / 1e12
@@ -549,7 +549,7 @@ def _stacked_config(device, steps, warmup, ncheck, sample):
                         '(5 -> 5 x 64 tanh -> n_m x 60), amplitude rescale by logA, REPT tracer between two emulated redshifts ({:d} networks reach the device), 19-monomial combination + cubic interpolation '
                         'to n_kin = 400 + window 120 x 1200 + 5 analytically marginalised parameters, {:d} batched points'.format(int(groups[:, 1].max()), B),
             'value': B / elapsed, 'unit': 'evals/s', 'ms_per_step': 1e3 * elapsed, 'steps': steps, 'dtype': 'f64', 'batch': B,
-            'roofline': {'bound': 'mfma', 'kernel': 'dl_emulated_stacked_kernel (every network by MFMA, one wave each; folded-operator product per monomial group)', 'flop_per_eval': flops,
+            'roofline': {'bound': 'mfma', 'kernel': 'dl_emulated_stacked_kernel (every network by MFMA, layer by layer in tile tasks; folded-operator product per monomial group; Gram matrices and the marginalised solve in its tail: one launch per step)', 'flop_per_eval': flops,
                          'flop_per_launch': fused * B, 'avg_launch_ms': kernel_ms[slot], 'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS,
                          'flop_count': "the build's own algorithm: final layers x y-scalers x assembly x redshift blend x interpolation x window x L^T folded at create"},
             'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize']},
