@@ -261,6 +261,7 @@ def stacked_fixtures():
                                                       shotnoise=8e3)
         return ObservablesGaussianLikelihood(observables=[obs], covariance=spd_covariance(20, seed=13, diag=4e4, amp=40.))
 
+    dump('cfg3_stacked_lpt', lambda: lpt(False), size=24, seed=35)
     dump('cfg3_stacked_lpt_marg', lambda: lpt(True), size=24, seed=35, unsolved=lambda: lpt(False))
 
 

@@ -110,7 +110,7 @@ class FlatEmulation(object):
         return loglike, flat
 
 
-@pytest.mark.parametrize('name', ['cfg3_stacked', 'cfg3_stacked_ongrid'])
+@pytest.mark.parametrize('name', ['cfg3_stacked', 'cfg3_stacked_ongrid', 'cfg3_stacked_lpt'])
 def test_device_arithmetic_on_the_cpu_against_the_reference(name):
     g, cfg = load_fixture(name)
     inside = np.isfinite(g['logprior'])
