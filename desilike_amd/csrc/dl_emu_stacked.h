@@ -13,8 +13,10 @@
 //   in place (a wave keeps the outputs of its tasks in registers across the barrier that ends the layer's reads); weights stream from L2 in fragment order (a request =
 //   the sixteen k-steps of the NEXT task, issued before the MFMAs of the current one; the next layer's first task before the activations); one exponential and one
 //   reciprocal per activation; the last hidden layer lands in the group's basis record.  (ii) FEATURE GEMM: wave w = column block w;
-//   the operand streams from L2 in fragment order [column block][group][k / 8][m][lane][2], two steps in flight; the epilogue contracts the accumulators with the
-//   amplitude-scaled monomial rows of the lane's four points into the carried output rows (registers; at most 8 rows: residual + the seven alpha* / sn* that can be solved).
+//   the operand streams from L2 in fragment order [column block][group][k / 8][m][lane][2], three to seven steps in flight (at most five monomials per pass: a step
+//   is only 2 x 5 MFMAs long); the epilogue contracts the accumulators with the amplitude-scaled monomial rows of the lane's four points into the carried output rows
+//   (registers; at most 8 rows: residual + the seven alpha* / sn* that can be solved).  (iii) FINALIZE IN THE TAIL (DlStkTail; one observable, N_pad = 128): the carried
+//   rows go to LDS, Gram matrices by MFMA, one lane per point solves -- one launch per step; otherwise the residual rows are written for the general finalize kernels.
 #pragma once
 #include "dl_fullshape.h"
 #include "dl_feature_gemm.h"
@@ -51,7 +53,7 @@ static inline bool dl_stk_feature_ok(const DlObsDev& o) {
 
 // The finalize in the kernel's tail (one observable, N_pad = 128, 1 + n_s <= 8 rows of X that fit the LDS the networks and the basis record no longer need): the rows
 // X = [residual + bias; derivative rows + tconst_s] of the workgroup's 16 points go from the carried registers to LDS, each wave forms G = X X^T of two points by MFMA
-// (dl_fg_gram_phase), lanes 0-15 of wave 0 solve a point each (dl_marg_solve.h) while wave 1 sums the priors -- as in the tail of dl_emulated_feature_gram_kernel.  Against
+// (dl_stk_gram_phase), lanes 0-15 of wave 0 solve a point each (dl_marg_solve.h) while wave 1 sums the priors -- as in the tail of dl_emulated_feature_gram_kernel.  Against
 // rows through memory + dl_finalize_marg_kernel: 25 MB written and read back per 4096 points and a 20 us launch less.
 struct DlStkTail {
     int enabled, xr, n_const;          // xr: rows of X (1 + n_s)
