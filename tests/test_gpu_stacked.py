@@ -176,3 +176,21 @@ def test_ensemble_sampler_on_the_stacked_likelihood():
         assert np.array_equal(np.column_stack([chain[param.name][it] for param in like.varied_params]), coords), it
         assert np.array_equal(chain['logposterior'][it], logp), it
     assert np.isfinite(logp).all()
+
+
+def test_stacked_batches_beyond_one_pass():
+    """40 000 points (the context's workspaces hold 32 768 per pass: two passes, the second ragged): every row equals, bit for bit, the row a 4096-point batch gives it,
+    and rows of the second pass agree with the oracle."""
+    like, pt, theory, solved, networks = make_cfg3_stacked(marg=True)
+    like.initialize()
+    base = sample(like, 4096, 13)
+    reps = 40000 // 4096 + 1
+    theta = np.tile(base, (reps, 1))[:40000]
+    ctx = like._get_context()
+    small = ctx.eval_batch_host(base)[0]
+    loglike, logprior, status = ctx.eval_batch_host(theta)
+    assert (status == 0).all()
+    assert np.array_equal(loglike, np.tile(small, reps)[:40000])
+    for i in (32768, 36001, 39999):
+        sol = cfg3_stacked_oracle_solution(like, pt, theory, solved, theta[i])
+        assert abs(loglike[i] - sol['loglikelihood']) <= TOL * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
