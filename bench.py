@@ -29,7 +29,10 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
 
 BATCH = 1024
-GATHER_EVERY = 8   # N > 1: steps per bucketed all-gather of log-posteriors
+# N > 1: steps per bucketed all-gather of log-posteriors.  One collective costs the evaluation stream 10 - 20 us whatever it carries (the event pair that orders the side stream
+# against it; tools/gather_cost_probe.py, tools/gather_every_sweep.sh: 8 / 16 / 32 / 64 steps per bucket = +2.9 / +1.6 / +0.9 / +0.5 us per 24.3 us step on a single-rank communicator):
+# fewer, larger collectives -- 32 steps = 256 KB per rank, 0.8 ms of evaluation between two of them
+GATHER_EVERY = int(os.environ.get('DL_BENCH_GATHER_EVERY', '32'))
 # Algorithmic FLOP per evaluation (DESIGN.md "Measurement"), fp64 add/mul = 1, transcendental = 20
 FLOP_THEORY = 23e3 + 5e3 + 288e3 + 57.6e3 + 7e3    # template factor, spline coefficients, AP + spline eval, GL projection, tracer combine
 FLOP_GEMM = 288e3 + 29e3                            # window GEMM 2 n n_in + chi2 2 n^2 + 2 n (precision folded into the window matrix)
