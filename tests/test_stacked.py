@@ -174,3 +174,30 @@ def test_from_state_reads_the_converter_layout():
     assert pt.engines['loop'].yshape == (4, 3, 9, 30) and pt.engines['ct'].activation == 'tanh' and pt.engines['11'].hidden == [32, 32]
     with pytest.raises(ValueError, match='outside of the range'):
         mirror_likelihood(z=1.2, flatdata=np.zeros(36), covariance=np.eye(36))[0].initialize()
+
+
+@pytest.mark.parametrize('case', ['monomial twice', 'scale size', 'width', 'weights size', 'group range', 'scalar stack'])
+def test_malformed_descriptions_are_refused_with_a_message(case):
+    """The host-side parser of ``emu0.type = 2`` (csrc/dl_host.hpp::dl_build_emulated_obs, the code ``dl_create`` runs) names what is wrong instead of evaluating garbage."""
+    g, cfg = load_fixture('cfg3_stacked')
+    cfg = {key: np.array(value) for key, value in cfg.items()}
+    groups = cfg['obs0.emu0.groups'].reshape(-1, 4)
+    expect = None
+    if case == 'monomial twice':
+        groups[1, 2] = groups[0, 2]; expect = 'belongs to one group'
+    elif case == 'scale size':
+        cfg['obs0.emu0.scale'] = cfg['obs0.emu0.scale'][:-1]; expect = 'scale f64'
+    elif case == 'width':
+        cfg['obs0.emu0.widths'][1] = 200; expect = 'layer widths'
+    elif case == 'weights size':
+        cfg['obs0.emu0.weights'] = cfg['obs0.emu0.weights'][:-3]; expect = 'weights size'
+    elif case == 'group range':
+        groups[0, 1] = 10000; expect = 'weights size'     # (one past the last network sets the number of networks the weights must hold)
+    elif case == 'scalar stack':
+        for key in list(cfg):
+            if key.startswith('obs0.emu0.'): cfg[key.replace('emu0', 'emu1')] = cfg[key]
+        expect = 'only the table engine'
+    cfg['obs0.emu0.groups'] = groups.ravel()
+    theta = g['theta'][np.isfinite(g['logprior'])][:2]
+    with pytest.raises(RuntimeError) as info: FlatEmulation(cfg).eval_batch(theta)
+    assert expect in str(info.value), str(info.value)
