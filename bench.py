@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
 
 BATCH = 1024
+PREWARM_LEG_MS = 300.   # untimed fixed-duration run before the timed calls of the other_configs legs (the headline's own: --prewarm-ms)
 # N > 1: steps per bucketed all-gather of log-posteriors.  One collective costs the evaluation stream 10 - 20 us whatever it carries (the event pair that orders the side stream
 # against it; tools/gather_cost_probe.py, tools/gather_every_sweep.sh: 8 / 16 / 32 / 64 steps per bucket = +2.9 / +1.6 / +0.9 / +0.5 us per 24.3 us step on a single-rank communicator):
 # fewer, larger collectives -- 32 steps = 256 KB per rank, 0.8 ms of evaluation between two of them
@@ -351,8 +352,14 @@ def _timed_context(ctx, theta, steps, warmup, posterior_out, status, device):
     # whatever the earlier legs left behind (contexts of other streams, replicas of the host-array leg) is destroyed NOW: a collector pass inside the timed loop that frees
     # device resources synchronises the device (hipFree / hipEventDestroy: ~70 ms, seen as 2 M instead of 80 M evals/s on whichever leg it hit)
     gc.collect()
+    # warm-up like the headline's: a fixed duration (PREWARM_LEG_MS) on top of `warmup` calls -- the first few hundred calls of a fresh context and the first tens of
+    # milliseconds after an idle period (the oracle checks between the legs run on the CPU) are 1.1 - 1.5 x slower than the steady state the figures are meant to describe
     for _ in range(warmup): ctx.eval_logposterior(theta, posterior_out, status=status)
     torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    while 1e3 * (time.perf_counter() - t0) < PREWARM_LEG_MS:
+        for _ in range(16): ctx.eval_logposterior(theta, posterior_out, status=status)
+        torch.cuda.synchronize(device)
     every = max(1, steps // 8)
     ctx.profile_enable(every)
     gc.disable()

@@ -19,6 +19,11 @@ def time_likelihood(label, like, B, steps=40, posterior=False):
     gc.collect()   # contexts of the previous likelihood are destroyed NOW (hipFree / hipEventDestroy synchronise the device: 70 ms if the collector runs inside the timed loop)
     for _ in range(5): ctx.eval_logposterior(th, out, status=st)
     torch.cuda.synchronize()
+    # steady state, like bench.py's legs: the first few hundred calls of a fresh context / the first tens of milliseconds after an idle period run 1.1 - 1.5 x slower
+    t0 = time.perf_counter()
+    while 1e3 * (time.perf_counter() - t0) < float(os.environ.get('PREWARM_MS', 300.)):
+        for _ in range(16): ctx.eval_logposterior(th, out, status=st)
+        torch.cuda.synchronize()
     ctx.profile_enable(2)
     t0 = time.perf_counter()
     for _ in range(steps): ctx.eval_logposterior(th, out, status=st)
