@@ -23,23 +23,32 @@ def build(seed):
     tracers = [None, ('LRG', 'ELG')][int(rng.rand() < 0.35)]
     template = ShapeFitPowerSpectrumTemplate(z=float(rng.uniform(0.3, 1.4)), fiducial='synthetic')
     observables = []
+    dense = bool(rng.rand() < 0.4)    # a dense survey-like window on its own theory grid, more theory multipoles than data multipoles (window.py:428-438 / 459-473)
     for tracer in ([None] if tracers is None else tracers):
         kwargs = {} if tracer is None else dict(tracers=tracer)
         theory = KaiserTracerPowerSpectrumMultipoles(template=template, **kwargs)
         prefix = '' if tracer is None else tracer + '.'
         data = {prefix + 'b1': float(rng.uniform(1.2, 2.4)), 'dm': 0.01}
-        observables.append(TracerPowerSpectrumMultipolesObservable(data=data, kedges=np.linspace(kmin, kmax, nk + 1), ells=ells, wmatrix={'resolution': resolution}, theory=theory,
-                                                                   shotnoise=float(rng.uniform(2e3, 2e4))))
+        kedges = np.linspace(kmin, kmax, nk + 1)
+        if dense:
+            import bench
+            ellsin = (0, 2, 4)
+            kin, full = bench.dense_window(kedges, ellsin, resolution=resolution, seed=int(rng.randint(1000)))    # [3 nk, 3 n_kin]: rows of the multipoles that are observed
+            rows = np.concatenate([np.arange(nk) + nk * ellsin.index(ell) for ell in ells])
+            wmatrix = dict(wmatrix=full[rows], kin=kin, ellsin=ellsin)
+        else:
+            wmatrix = dict(wmatrix={'resolution': resolution})
+        observables.append(TracerPowerSpectrumMultipolesObservable(data=data, kedges=kedges, ells=ells, theory=theory, shotnoise=float(rng.uniform(2e3, 2e4)), **wmatrix))
     n = len(ells) * nk * len(observables)
     A = rng.standard_normal((n, n)) * 30.
     like = ObservablesGaussianLikelihood(observables=observables, covariance=A.dot(A.T) + 1e4 * np.eye(n))
     fixed = [name for name in ['dm', 'df', 'qpar'] if rng.rand() < 0.25]
     for name in fixed: like.all_params[name].update(fixed=True)
     like.initialize()
-    return like, dict(ells=ells, nk=nk, resolution=resolution, tracers=tracers, n=n, fixed=fixed)
+    return like, dict(ells=ells, nk=nk, resolution=resolution, dense=dense, tracers=tracers, n=n, fixed=fixed)
 
 
-@pytest.mark.parametrize('seed', range(14))
+@pytest.mark.parametrize('seed', range(20))
 def test_shape_against_the_oracle(seed):
     import bench
     like, info = build(seed)
