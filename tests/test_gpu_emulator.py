@@ -25,7 +25,7 @@ def test_taylor_emulated_velocileptors_vs_reference():
     assert np.allclose(like.flattheory, g['flattheory'][:3], rtol=1e-11, atol=1e-8)
 
 
-def make_mlp_likelihood(marg=True, seed=1, derived=None):
+def make_mlp_likelihood(marg=True, seed=1, derived=None, hidden=(64, 64, 64), activation='silu'):
     from desilike_amd.emulators import EmulatedCalculator, MLPEmulatorEngine
     from desilike_amd.theories.galaxy_clustering import LPTVelocileptorsTracerPowerSpectrumMultipoles
     from desilike_amd.observables.galaxy_clustering import TracerPowerSpectrumMultipolesObservable
@@ -33,7 +33,7 @@ def make_mlp_likelihood(marg=True, seed=1, derived=None):
     g = load_golden('cfg3_velocileptors_table')
     rng = np.random.RandomState(seed)
     kpt = np.concatenate([[0.0005], np.geomspace(0.0015, 0.025, 20), np.arange(0.03, 0.51, 0.01)])
-    nk, nin, hidden = kpt.size, 3, [64, 64, 64]
+    nk, nin, hidden = kpt.size, 3, list(hidden)
     base = 2e4 * (kpt / 0.05)**0.96 / (1. + (kpt / 0.02)**2.5)
 
     def mlp(nout, ylimits, widths):
@@ -41,7 +41,7 @@ def make_mlp_likelihood(marg=True, seed=1, derived=None):
         for width in widths + [nout]:
             layers.append((rng.standard_normal((last, width)) / last**0.5, 0.1 * rng.standard_normal(width)))
             last = width
-        return MLPEmulatorEngine(xlimits=[[0.9, 1.1], [0.9, 1.1], [-0.1, 0.1]], layers=layers, activation='silu', ylimits=ylimits)
+        return MLPEmulatorEngine(xlimits=[[0.9, 1.1], [0.9, 1.1], [-0.1, 0.1]], layers=layers, activation=activation, ylimits=ylimits)
 
     amp = np.concatenate([[1.], 0.2 * np.ones(11), 0.05 * np.ones(4), [0., 0., 0.]])
     ylim = np.stack([-(base[None, :, None] * amp) * np.ones((3, 1, 1)), (base[None, :, None] * amp) * np.ones((3, 1, 1))], axis=-1).reshape(-1, 2)
@@ -70,9 +70,10 @@ def oracle_flat(like, pt, theory, row, names, x):
     p = dict(zip(names, row)); p.update(x)
     xin = np.array([p[name] for name in EMU_PARAMS])
     eng = pt.engines
-    pktable = orc.mlp_predict(xin, eng['pktable'].xlimits, eng['pktable'].layers, 'silu', eng['pktable'].ylimits).reshape(3, -1, 19)
-    sigma8 = orc.mlp_predict(xin, eng['sigma8'].xlimits, eng['sigma8'].layers, 'silu', eng['sigma8'].ylimits)[0]
-    fsigma8 = orc.mlp_predict(xin, eng['fsigma8'].xlimits, eng['fsigma8'].layers, 'silu', eng['fsigma8'].ylimits)[0]
+    act = eng['pktable'].activation
+    pktable = orc.mlp_predict(xin, eng['pktable'].xlimits, eng['pktable'].layers, act, eng['pktable'].ylimits).reshape(3, -1, 19)
+    sigma8 = orc.mlp_predict(xin, eng['sigma8'].xlimits, eng['sigma8'].layers, act, eng['sigma8'].ylimits)[0]
+    fsigma8 = orc.mlp_predict(xin, eng['fsigma8'].xlimits, eng['fsigma8'].layers, act, eng['fsigma8'].ylimits)[0]
     params = {name: p.get(name, like.all_params[name].value) for name in ['b1p', 'b2p', 'bsp', 'b3p', 'alpha0p', 'alpha2p', 'alpha4p', 'sn0p', 'sn2p', 'sn4p']}
     pars = orc.velocileptors_pars(params, sigma8, fsigma8 / sigma8, basis='physical', model='lpt', snd=theory.snd, fsat=theory.fsat, sigv=theory.sigv)
     power = orc.interp1d(theory.k, pt.k, orc.tablevel_combine_bias_terms_poles(pktable, pars, nd=theory.nd).T).T
@@ -111,6 +112,29 @@ def test_mlp_emulated_not_marginalised():
         assert np.allclose(flat[i], ref, rtol=1e-11, atol=1e-12 * np.abs(ref).max())
         logl = orc.gaussian_loglikelihood(ref, like.flatdata, like.precision)[0]
         assert abs(loglike[i] - logl) <= 1e-10 * max(1., abs(logl))
+
+
+@pytest.mark.parametrize('hidden,activation,marg', [((8,), 'silu', True), ((24, 40), 'tanh', True), ((100,), 'relu', False), ((128, 128, 128, 128, 128), 'silu', True),
+                                                    ((16, 16, 16, 16, 16, 16, 16), 'tanh', False), ((64, 32), 'relu', True), ((5, 7, 3), 'silu', False)])
+def test_mlp_architectures(hidden, activation, marg):
+    """Widths that are not multiples of the 16 x 16 x 4 MFMA tile, one to seven hidden layers, the three activations of emulators/conversion.py:27-34, with and without
+    solved parameters: 257 points (a ragged last tile of 16) against the oracle."""
+    g, like, pt, theory, solved = make_mlp_likelihood(marg=marg, seed=5, hidden=hidden, activation=activation)
+    names = like.varied_params.names()
+    rng = np.random.RandomState(6)
+    theta = np.column_stack([np.clip(param.ref.sample(size=257, random_state=rng), *param.prior.limits) for param in like.varied_params])
+    loglike, logprior, status = like._get_context().eval_batch_host(theta)
+    assert (status == 0).all()
+    nsol = len(solved)
+    scales = np.array([like.all_params[name].prior.scale for name in solved])
+    for i in (0, 15, 16, 100, 255, 256):
+        f0 = oracle_flat(like, pt, theory, theta[i], names, {name: 0. for name in solved})
+        if nsol:
+            T = np.array([oracle_flat(like, pt, theory, theta[i], names, {n2: float(n2 == name) for n2 in solved}) - f0 for name in solved])
+            ref = orc.solve_marginalized(f0 - like.flatdata, T, like.precision, x0=np.zeros(nsol), prior_loc=np.zeros(nsol), prior_scale=scales, marg_mask=np.ones(nsol, dtype='?'))['loglikelihood']
+        else:
+            ref = orc.gaussian_loglikelihood(f0, like.flatdata, like.precision)[0]
+        assert abs(loglike[i] - ref) <= 1e-10 * max(1., abs(ref)), (hidden, activation, i, loglike[i], ref)
 
 
 def test_feature_path_matches_dense_path_and_is_repeatable():
