@@ -194,3 +194,16 @@ def test_stacked_batches_beyond_one_pass():
     for i in (32768, 36001, 39999):
         sol = cfg3_stacked_oracle_solution(like, pt, theory, solved, theta[i])
         assert abs(loglike[i] - sol['loglikelihood']) <= TOL * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
+
+
+@pytest.mark.parametrize('hidden,activation,marg,z', [((20, 36, 12), 'relu', True, 0.8), ((128,), 'silu', False, 0.62), ((8, 8, 8, 8, 8, 8), 'tanh', True, 0.955), ((100, 28), 'silu', True, 0.3)])
+def test_stacked_architectures(hidden, activation, marg, z):
+    """Widths off the 16 x 16 x 4 tile, one to six hidden layers, the three activations, between / on emulated redshifts: 273 points (ragged last tile) against the oracle."""
+    like, pt, theory, solved, networks = make_cfg3_stacked(marg=marg, z=z, hidden=hidden, activation=activation, nk=24, seed=21)
+    like.initialize()
+    theta = sample(like, 273, 17)
+    loglike, logprior, status = like._get_context().eval_batch_host(theta)
+    assert (status == 0).all()
+    for i in (0, 15, 16, 150, 271, 272):
+        sol = cfg3_stacked_oracle_solution(like, pt, theory, solved, theta[i])
+        assert abs(loglike[i] - sol['loglikelihood']) <= TOL * max(1., abs(sol['loglikelihood'])), (hidden, activation, i, loglike[i], sol['loglikelihood'])
