@@ -558,21 +558,21 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         bool need_flat = ctx->any_transform || flattheory_dev != nullptr;
         // emulated (separable) theories: the theory kernel writes only the factors (basis, monomial rows), the feature GEMM turns them into residual rows
         const bool feat_path = ctx->feat_ok && !need_flat;
-        static const bool emu_fused_env = !getenv("DL_NO_EMU_FUSED");   // DL_NO_EMU_FUSED=1: theory kernel -> point records in HBM -> feature GEMM (two launches)
+        const bool emu_fused_env = !dl_options().no_emu_fused;   // DL_NO_EMU_FUSED=1: theory kernel -> point records in HBM -> feature GEMM (two launches)
         const bool emu_fused = emu_fused_env || ctx->any_stacked;         // (a stacked table engine has the one-launch form only)
-        static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 2048;   // above: split-K slabs + finalize win (measured: 4096 rows 40 vs 49 us; 1024 rows 18 vs 13 us)
+        const int64_t chi2_max_rows = dl_options().chi2_max_rows;   // above: split-K slabs + finalize win (measured: 4096 rows 40 vs 49 us; 1024 rows 18 vs 13 us)
         const bool chi2_path = !feat_path && !ctx->any_transform && ctx->n_solved == 0 && nb <= chi2_max_rows;
         // the chi2 GEMM consumes row block mb (32 points; the LDS-DMA GEMM: 64) on XCD mb % 8: have the theory kernel produce it there (power then waits in that XCD's L2:
         // -0.5 us per 1024 points)
-        static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;   // 0: off, 1: chi2 GEMM path, 2: also the large-batch GEMM
-        static const bool chi2_fused_env_early = getenv("DL_CHI2_FUSED") != nullptr && atoi(getenv("DL_CHI2_FUSED")) != 0;
+        const int xcd_local = dl_options().xcd_local;   // 0: off, 1: chi2 GEMM path, 2: also the large-batch GEMM
+        const bool chi2_fused_env_early = dl_options().chi2_fused;
         const bool chi2_fused_early = chi2_fused_env_early && !ctx->priors_general;
         const int xcd_block = !xcd_local ? 0 : chi2_path ? (chi2_fused_early ? 32 : dl_chi2_gemm_row_tile(nb, ctx->N_pad)) : (xcd_local > 1 && !feat_path && !ctx->any_transform && ctx->n_solved == 0 && ctx->N_pad == 128) ? 64 : 0;
         // the whole step in one launch (dl_step_kernel): plain likelihood of one Kaiser-type observable in its fast instantiation, <= 1024 points in whole groups of 256
         // OFF by default (DL_STEP_KERNEL=1 selects it): measured 31.1 us per 1024-point step against 24.4 us for the three launches -- in-kernel stamps (profiles/r05c_step_stamps.txt):
         // theory of four points under ONE workgroup barrier 14.4 us (four independent workgroups per CU: ~8.5), publish 1.1, wait for the row block 2.0 - 2.5, GEMM + finalize 11.1;
         // even with the theory phase at its stand-alone time the sum is what the three launches take: the step is bound by the lives of its workgroups, not by its launch boundaries
-        static const bool step_kernel_allowed = getenv("DL_STEP_KERNEL") != nullptr && atoi(getenv("DL_STEP_KERNEL")) != 0;
+        const bool step_kernel_allowed = dl_options().step_kernel;
         if (step_kernel_allowed && chi2_path && !need_flat && ctx->n_obs == 1 && !ctx->priors_general && ctx->K_pad % 128 == 0 &&
             dl_step_lds_bytes(ctx->obs_kernarg[0], nb, ctx->N_pad) != 0) {
             prof_phase(0);
@@ -603,7 +603,7 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         // plain likelihood: chi2 is additive over the columns of the whitened residual -> column-split GEMM that emits partial chi2 only
         // marginalised fits on one emulated observable: Gram-matrix epilogue in the fused kernel -- the residual rows never reach memory (DL_NO_GRAM_EPILOGUE=1: rows + Gram in the finalize)
         bool gram_done = false, finalized_in_kernel = false, stacked_rows_done = false;
-        static const bool gram_epilogue = !getenv("DL_NO_GRAM_EPILOGUE");
+        const bool gram_epilogue = !dl_options().no_gram_epilogue;
         // (also without solved parameters: X is the residual row alone, chi2 = G[0][0] and the finalize -- priors, status -- runs in the kernel's tail: one launch instead of two)
         if (feat_path && emu_fused && gram_epilogue && ctx->n_obs == 1 && ctx->N_pad == 128) {
             DlGramFinalize fin = {ctx->priors_dev, loglike_dev ? loglike_dev + b0 : nullptr, logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr,
@@ -630,13 +630,13 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         }
         // larger plain batches: the LDS-DMA split-K GEMM with the same partial-chi2 epilogue (no residual slab is written or read)
         int cps_probe = 0;
-        static const bool chi2_big_allowed = !getenv("DL_NO_CHI2_BIG");
+        const bool chi2_big_allowed = !dl_options().no_chi2_big;
         const bool chi2_big = !feat_path && !ctx->any_transform && ctx->n_solved == 0 && !chi2_path && ctx->K_pad % 32 == 0 && chi2_big_allowed &&
                               dl_gemm_tiled_splits(nb, ctx->N_pad, ctx->K_pad, &cps_probe) == 1;   // enough row tiles to fill the chip without splitting K
         int part_tiles = ctx->N_pad / 16;
         // DL_CHI2_FUSED=1: finalize inside the GEMM's last-arriving workgroups.  Off by default: measured 19.1 us (GEMM 17.1) against 17.5 us for GEMM + the
         // separate 1024-thread finalize launch -- the device-scope counter round trip and the dependent tail cost more than the launch they save.
-        static const bool chi2_fused_env = getenv("DL_CHI2_FUSED") && atoi(getenv("DL_CHI2_FUSED")) != 0;
+        const bool chi2_fused_env = dl_options().chi2_fused;
         const bool chi2_fused = chi2_fused_env && !ctx->priors_general;   // (the experimental fused finalize of the GEMM knows uniform / norm priors only)
         if (chi2_path) {
             if (nb > 16384) { prof_phase(-1); return dl_fail(ctx, "dl_eval_batch: DL_CHI2_GEMM_MAX above 16384 rows"); }
@@ -724,7 +724,7 @@ int dl_eval_fisher(dl_ctx* ctx, const double* centers_dev, const double* steps_d
         int n_slabs = 1, cps = 0;
         int64_t slab_stride = 0;
         const double* bias = nullptr;
-        static const bool emu_fused_env = !getenv("DL_NO_EMU_FUSED");
+        const bool emu_fused_env = !dl_options().no_emu_fused;
         const bool emu_fused = emu_fused_env || ctx->any_stacked;
         if (ctx->feat_ok) {
             // emulated (separable) theories: residual rows straight from the feature GEMM
@@ -795,7 +795,7 @@ int dl_eval_logposterior_grad(dl_ctx* ctx, const double* theta_dev, int64_t B, d
         DL_HIP_CHECK(ctx, hipDeviceSynchronize());
         ctx->grad_cap = cap;
     }
-    static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;
+    const int xcd_local = dl_options().xcd_local;
     for (int64_t b0 = 0; b0 < B; b0 += per_pass) {
         const int64_t nb = std::min<int64_t>(per_pass, B - b0);
         const double* th = theta_dev + (size_t)b0 * P;
@@ -1072,7 +1072,7 @@ int dl_profile_read(dl_ctx* ctx, double* ms, int32_t n) {
 }  // extern "C"
 
 static bool dl_fold_applicable(const dl_ctx* ctx, int64_t B) {
-    static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 2048;
+    const int64_t chi2_max_rows = dl_options().chi2_max_rows;
     if (ctx->feat_ok || ctx->any_transform || ctx->n_solved != 0 || B > chi2_max_rows || B > DL_CHUNK || ctx->n_params > 32) return false;
     for (auto& ob : ctx->obs) {
         const DlObsDev& oh = ob.dev;
@@ -1097,7 +1097,7 @@ int dl_internal_eval_fold(dl_ctx* ctx, const DlEnsFold& fold, int64_t B, double*
     DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (dl_order_streams(ctx, stream)) return 1;
     if (dl_reserve(ctx, B)) return 1;
-    static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;
+    const int xcd_local = dl_options().xcd_local;
     if (!dl_launch_fullshape_ens(ctx->obs_kernarg.data(), ctx->n_obs, ctx->obs_array_dev, fold, B, ctx->power_ws, ctx->K_pad, xcd_local ? dl_chi2_gemm_row_tile(B, ctx->N_pad) : 0, stream)) return 2;
     dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, part_out, B, ctx->N_pad, ctx->K_pad, nullptr, nullptr, ctx->n_params,
                         ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream, ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live);
@@ -1107,14 +1107,14 @@ int dl_internal_eval_fold(dl_ctx* ctx, const DlEnsFold& fold, int64_t B, double*
 
 int dl_internal_eval_partials(dl_ctx* ctx, const double* theta_dev, int64_t B, const double** part, int* n_tiles, const double** priors, hipStream_t stream) {
     if (!ctx || !theta_dev || !part || !n_tiles || !priors || B <= 0) return 1;
-    static const int64_t chi2_max_rows = getenv("DL_CHI2_GEMM_MAX") ? atoll(getenv("DL_CHI2_GEMM_MAX")) : 2048;
+    const int64_t chi2_max_rows = dl_options().chi2_max_rows;
     if (ctx->feat_ok || ctx->any_transform || ctx->n_solved != 0 || B > chi2_max_rows || B > DL_CHUNK) return 2;
     for (auto& ob : ctx->obs) if (ob.dev.theory == 3) return 2;
     dl_prof_events.start = dl_prof_events.stop = nullptr;
     DL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (dl_order_streams(ctx, stream)) return 1;
     if (dl_reserve(ctx, B)) return 1;
-    static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;
+    const int xcd_local = dl_options().xcd_local;
     dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, theta_dev, ctx->n_params, B, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, nullptr, 0, xcd_local ? dl_chi2_gemm_row_tile(B, ctx->N_pad) : 0, ctx->obs_array_dev);
     dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, B, ctx->N_pad, ctx->K_pad, nullptr, theta_dev, ctx->n_params,
                         ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream, ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live);

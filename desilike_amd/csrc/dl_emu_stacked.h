@@ -27,6 +27,7 @@ typedef double dl_stk_double4 __attribute__((ext_vector_type(4)));
 #define DL_STK_PTS 16
 #define DL_STK_ROWS 8        // rows carried per point: 1 + the solvable alpha0 alpha2 alpha4 alpha6 sn0 sn2 sn4 (full_shape.py:1226)
 #define DL_STK_TMAX 8        // output tiles of a layer (widths <= 128)
+#define DL_STK_STATIC_LDS 256   // bytes of static LDS the kernels declare beside the dynamic block (lp_lds, nan_lds, counters)
 
 static inline __host__ __device__ int dl_stk_tld(const DlObsDev& o) {          // row stride of a wave's activation buffer: widest layer, multiple of 4, + 2
     int w = 4;
@@ -48,7 +49,7 @@ static inline bool dl_stk_feature_ok(const DlObsDev& o) {
         if (o.eng[ie].type == 1) return false;
         if (o.eng[ie].type == 0) for (int l = 0; l <= o.eng[ie].n_layers; ++l) if (o.eng[ie].widths[l] > 128) return false;
     }
-    return dl_stk_shared_doubles(o) * sizeof(double) <= 160 * 1024;
+    return dl_stk_shared_doubles(o) * sizeof(double) + DL_STK_STATIC_LDS <= 160 * 1024;
 }
 
 // The finalize in the kernel's tail (one observable, N_pad = 128, 1 + n_s <= 8 rows of X that fit the LDS the networks and the basis record no longer need): the rows
@@ -96,7 +97,8 @@ __device__ __forceinline__ double dl_stk_exp(double x) {
 __device__ __forceinline__ double dl_stk_act(int act, double v) {
     if (act == 0) return v * dl_stk_rcp(1. + dl_stk_exp(-v));       // conversion.py:29
     if (act == 1) return v > 0. ? v : 0.;                           // conversion.py:31
-    return 1. - 2. * dl_stk_rcp(1. + dl_stk_exp(2. * v));           // conversion.py:33 (large |v|: +-1)
+    const double t = 1. - 2. * dl_stk_rcp(1. + dl_stk_exp(2. * v)); // conversion.py:33 (large |v|: +-1)
+    return v != v ? v : t;                                          // (the clamp inside dl_stk_exp drops a NaN: hand it on as dl_activation does)
 }
 
 // The networks of one group, LAYER BY LAYER on all eight waves: a task = one output tile (16 units) of one network; the n_net * tiles tasks of a layer are dealt to the waves
@@ -163,6 +165,11 @@ __device__ __forceinline__ void dl_stk_networks(const int32_t* widths, int n_lay
                 res[i] = acc + acc2;
 #pragma unroll
                 for (int u = 0; u < 16; ++u) bw[u] = bwn[u];
+            }
+            if (t_begin >= t_end && next16) {     // a wave without a task in this layer that has one in the next: nothing above requested its weights
+                const double* wt = wf + (size_t)(nt_begin / ntiles) * frag_doubles + lnext + (size_t)(nt_begin % ntiles) * 1024;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) bw[u] = wt[u * 64];
             }
         } else {
 #pragma unroll
@@ -296,35 +303,28 @@ __device__ __forceinline__ void dl_stk_solve_point(const double* gl, const DlStk
                                 tl.hessian ? tl.hessian + (size_t)b * NS * NS : nullptr, lps, ok);
 }
 
-// theta -> residual rows out[B * R, ldo] (+= if accumulate) of one observable; gfrag: [N_pad / 16][sum_g nq_g cnt_g][64][2]; blockIdx.y = group of 8 column blocks
-// TMAX: output tiles per layer (4: widths <= 64, 8: <= 128); RMAX: rows carried per point in registers (>= 1 + n_var)
-template <int TMAX, int RMAX>
-__global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ gfrag, const DlObsDev o,
-                                                                  double* __restrict__ out, int64_t ldo, int accumulate, int steps_per_block, unsigned long long* stamps, const DlStkTail tl) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ double lp_lds[DL_STK_PTS];      // (tail: log-priors and NaN flags of the 16 points)
-    __shared__ int nan_lds[DL_STK_PTS];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 15, g = lane >> 4;
-    const int64_t p0 = (int64_t)blockIdx.x * DL_STK_PTS;
-    const int R = 1 + o.n_var;
-    const int tld = dl_stk_tld(o), bld = dl_stk_bld(o);
-    // DL_STK_STAMPS diagnostics (null in production): s_memtime of wave 0 at the phase boundaries, 32 slots per workgroup: 0 entry, 1 inputs, 2 monomial rows, then per device
-    // group 3 + 2 gi: networks done (after the barrier), 4 + 2 gi: feature GEMM + epilogue done; 30: rows stored; 31: s_memrealtime at exit (100 MHz)
-    unsigned long long* st = stamps != nullptr && blockIdx.y == 0 ? stamps + (size_t)blockIdx.x * 32 : nullptr;
-#define DL_STK_STAMP(slot) if (st != nullptr && tid == 0) st[slot] = __builtin_amdgcn_s_memtime();
-    DL_STK_STAMP(0)
-    constexpr int XLD = DL_MAX_X + 2;
-    double* x = lds;                                           // [16][DL_MAX_X] the emulator inputs
-    double* xs = x + DL_STK_PTS * DL_MAX_X;                    // [3][16][XLD] scaled inputs of the table networks (0) and of the scalar engines (1, 2), zero-padded
-    double* amp = xs + 3 * DL_STK_PTS * XLD;                   // [16][8] amplitude of every group
-    double* scal = amp + DL_STK_PTS * DL_STK_MAX_GROUPS;       // [16][4]: sigma8 (1), fsigma8 (2)
-    double* vpv = scal + DL_STK_PTS * 4;                       // [16][12] velocileptors 'pars' inputs
-    double* mono = vpv + DL_STK_PTS * 12;                      // [16][DL_STK_ROWS][20] monomial rows, scaled by the amplitude of their group
-    double* basis = mono + DL_STK_PTS * DL_STK_ROWS * DL_FG_MONO_LD;   // [16][bld] basis record of the current group
-    double* nbufs = basis + (size_t)DL_STK_PTS * bld;           // [8][16][tld] activation buffers of eight networks
-    const int H = o.eng[0].widths[o.eng[0].n_layers];
+// LDS of a workgroup: x [16][16] | xs [3 engines][16][18] | amp [16][8] | scal [16][4] | vpv [16][12] | mono [16][8][20] | work (basis records, activation buffers, X of the tail)
+struct DlStkLds { double *x, *xs, *amp, *scal, *vpv, *mono, *work; };
+#define DL_STK_XLD (DL_MAX_X + 2)
+__device__ __forceinline__ DlStkLds dl_stk_carve(double* lds) {
+    DlStkLds s;
+    s.x = lds;                                                   // [16][DL_MAX_X] the emulator inputs
+    s.xs = s.x + DL_STK_PTS * DL_MAX_X;                          // [3][16][XLD] scaled inputs of the table networks (0) and of the scalar engines (1, 2), zero-padded
+    s.amp = s.xs + 3 * DL_STK_PTS * DL_STK_XLD;                  // [16][8] amplitude of every group
+    s.scal = s.amp + DL_STK_PTS * DL_STK_MAX_GROUPS;             // [16][4]: sigma8 (1), fsigma8 (2)
+    s.vpv = s.scal + DL_STK_PTS * 4;                             // [16][12] velocileptors 'pars' inputs
+    s.mono = s.vpv + DL_STK_PTS * 12;                            // [16][DL_STK_ROWS][20] monomial rows, scaled by the amplitude of their group
+    s.work = s.mono + DL_STK_PTS * DL_STK_ROWS * DL_FG_MONO_LD;
+    return s;
+}
+
+// Inputs, scalar engines, amplitudes and the amplitude-scaled monomial rows of the workgroup's 16 points (512 threads; `scratch`: 2 x 16 x tld doubles; the monomial rows are
+// NOT yet published by a barrier on return).  st: DL_STK_STAMPS slots 1 (inputs) and 2 (monomial rows) of this workgroup, or null
+__device__ __forceinline__ void dl_stk_prologue(const DlObsDev& o, const double* __restrict__ theta, int n_params, int64_t B, int64_t p0, int tid, double* lds_base, double* scratch,
+                                                int tld, int R, unsigned long long* st) {
+    constexpr int XLD = DL_STK_XLD;
+    const DlStkLds s = dl_stk_carve(lds_base);
+    double *x = s.x, *xs = s.xs, *amp = s.amp, *scal = s.scal, *vpv = s.vpv, *mono = s.mono;
     // ---- inputs ----
     for (int idx = tid; idx < DL_STK_PTS * XLD; idx += 512) {
         const int pt = idx / XLD, i = idx - pt * XLD;
@@ -343,14 +343,14 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
         vpv[pt * 12 + c] = dl_get(o.vp_in[c], theta + (size_t)b * n_params);
     }
     __syncthreads();
-    DL_STK_STAMP(1)
-    // ---- scalar engines (sigma8, fsigma8: the physical prior basis; small networks): a thread per (point, unit), layer by layer, in the still unused basis record;
+    if (st != nullptr && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
+    // ---- scalar engines (sigma8, fsigma8: the physical prior basis; small networks): a thread per (point, unit), layer by layer, in the still unused work area;
     //      the amplitudes of the groups ----
     for (int ie = 1; ie < 3; ++ie) {
         const DlObsDev::Engine& en = o.eng[ie];
         if (en.type != 0) continue;
-        double* cur = basis;
-        double* nxt = basis + DL_STK_PTS * tld;
+        double* cur = scratch;
+        double* nxt = scratch + DL_STK_PTS * tld;
         const double* w = en.weights;
         for (int layer = 0; layer < en.n_layers; ++layer) {
             const int nin = en.widths[layer], nout = en.widths[layer + 1];
@@ -395,49 +395,24 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
             }
         }
     }
-    DL_STK_STAMP(2)
-    // ---- group by group: networks, then the feature GEMM ----
-    double outv[4][RMAX];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-        for (int u = 0; u < RMAX; ++u) outv[rr][u] = 0.;
-    const int jb = blockIdx.y * 8 + wave;
-    const dl_fg_double2* gcol = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * steps_per_block * 64 + lane;
-    int tb_prev = -1, te_prev = -1;
-    for (int gi = 0; gi < o.stk.n_groups; ++gi) {
-        const double* rec = o.stk.table + (size_t)gi * DL_STK_REC;
-        const int tb = (int)rec[0], te = (int)rec[1], m0 = (int)rec[2], m1 = (int)rec[3], kq = (int)rec[7];
-        const int K = (te - tb) * H + 1, nq = (K + 7) / 8;
-        if (tb != tb_prev || te != te_prev) {
-            __syncthreads();    // the basis record is free (the previous group's GEMM is done); first group: the monomial rows are complete
-            for (int t = tb; t < te; t += 8) {     // eight networks at a time (their activation buffers)
-                const int n_net = te - t < 8 ? te - t : 8;
-                dl_stk_networks<TMAX>(o.eng[0].widths, o.eng[0].n_layers, o.eng[0].act, o.stk.wfrag + (size_t)t * o.stk.frag_doubles, o.stk.frag_doubles, n_net, xs, XLD, nbufs, tld,
-                                      basis + (size_t)(t - tb) * H, bld, wave, lane, gi == 0 && st != nullptr ? st + 15 : nullptr);
-                if (t + 8 < te) __syncthreads();
-            }
-            for (int idx = tid; idx < DL_STK_PTS * (8 * nq - (K - 1)); idx += 512) {      // the constant basis function and the zero padding of the last step
-                const int pt = idx / (8 * nq - (K - 1)), c = K - 1 + (idx - pt * (8 * nq - (K - 1)));
-                basis[(size_t)pt * bld + c] = c == K - 1 ? 1. : 0.;
-            }
-            tb_prev = tb; te_prev = te;
-            __syncthreads();
-        }
-        DL_STK_STAMP(3 + 2 * gi)
-        const double* arow = basis + (size_t)col * bld + 2 * g;
-        const dl_fg_double2* gw = gcol + (size_t)kq * 64;
-        const double* mp = mono + m0;
-        switch (m1 - m0) {
-            case 1: dl_stk_group_gemm<1, RMAX, 8>(arow, gw, nq, mp, R, g, outv); break;
-            case 2: dl_stk_group_gemm<2, RMAX, 8>(arow, gw, nq, mp, R, g, outv); break;
-            case 3: dl_stk_group_gemm<3, RMAX, 6>(arow, gw, nq, mp, R, g, outv); break;
-            case 4: dl_stk_group_gemm<4, RMAX, 5>(arow, gw, nq, mp, R, g, outv); break;
-            default: dl_stk_group_gemm<5, RMAX, 4>(arow, gw, nq, mp, R, g, outv); break;
-        }
-        DL_STK_STAMP(4 + 2 * gi)
+    if (st != nullptr && tid == 0) st[2] = __builtin_amdgcn_s_memtime();
+}
+
+// the feature GEMM of one device group (cnt = 1 .. 5 monomials) from the basis record `arow` points into
+template <int RMAX>
+__device__ __forceinline__ void dl_stk_group(int cnt, const double* arow, const dl_fg_double2* gw, int nq, const double* mp, int R, int g, double (&outv)[4][RMAX]) {
+    switch (cnt) {
+        case 1: dl_stk_group_gemm<1, RMAX, 8>(arow, gw, nq, mp, R, g, outv); break;
+        case 2: dl_stk_group_gemm<2, RMAX, 8>(arow, gw, nq, mp, R, g, outv); break;
+        case 3: dl_stk_group_gemm<3, RMAX, 6>(arow, gw, nq, mp, R, g, outv); break;
+        case 4: dl_stk_group_gemm<4, RMAX, 5>(arow, gw, nq, mp, R, g, outv); break;
+        default: dl_stk_group_gemm<5, RMAX, 4>(arow, gw, nq, mp, R, g, outv); break;
     }
-    if (!tl.enabled) {
+}
+
+// the carried rows to memory (no finalize in the tail): out[(p0 + pt) * R + u][jb * 16 + col]
+template <int RMAX>
+__device__ __forceinline__ void dl_stk_store_rows(const double (&outv)[4][RMAX], int R, double* __restrict__ out, int64_t ldo, int accumulate, int64_t B, int64_t p0, int jb, int col, int g) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int pt = g + 4 * rr;
@@ -451,14 +426,15 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
             }
         }
     }
-    
-        DL_STK_STAMP(30)
-        if (st != nullptr && tid == 0) st[31] = __builtin_amdgcn_s_memrealtime();
-        return;
-    }
-    // ---- finalize in the tail: rows -> LDS (over the basis record and the activation buffers: every wave is past them after the barrier), Gram matrices, solve ----
+}
+
+// the finalize in the tail: rows -> LDS (X [16 points][xr][DL_FG_XLD], over the work area: every wave is past it after the barrier), Gram matrices, solve
+template <int RMAX>
+__device__ __forceinline__ void dl_stk_finalize_tail(const DlStkTail& tl, const double (&outv)[4][RMAX], int R, double* X, const double* __restrict__ theta,
+                                                     int n_params, int64_t B, int64_t p0, int tid, int wave, int lane, int col, int g) {
+    __shared__ double lp_lds[DL_STK_PTS];      // log-priors and NaN flags of the 16 points
+    __shared__ int nan_lds[DL_STK_PTS];
     __syncthreads();
-    double* X = basis;                                   // [16 points][xr][DL_FG_XLD]
     const int cbase = wave * 16 + col;                   // (N_pad = 128: one workgroup column group, wave = column block)
 #pragma unroll
     for (int u = 0; u < RMAX; ++u) {
@@ -500,6 +476,67 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
         }
         dl_marg_store_lane(ll, lps, ok, lp_lds[lane], nan_lds[lane] != 0, tl.post_mode, b, tl.loglike, tl.logprior, tl.status);
     }
+}
+
+// theta -> residual rows out[B * R, ldo] (+= if accumulate) of one observable; gfrag: [N_pad / 16][sum_g nq_g cnt_g][64][2]; blockIdx.y = group of 8 column blocks
+// TMAX: output tiles per layer (4: widths <= 64, 8: <= 128); RMAX: rows carried per point in registers (>= 1 + n_var)
+// (the form of round 5: networks of a group, barrier, feature GEMM of the group -- every shape; dl_emu_stacked_ov.h overlaps the two where the shape allows)
+template <int TMAX, int RMAX>
+__global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* __restrict__ theta, int n_params, int64_t B, const double* __restrict__ gfrag, const DlObsDev o,
+                                                                  double* __restrict__ out, int64_t ldo, int accumulate, int steps_per_block, unsigned long long* stamps, const DlStkTail tl) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g = lane >> 4;
+    const int64_t p0 = (int64_t)blockIdx.x * DL_STK_PTS;
+    const int R = 1 + o.n_var;
+    const int tld = dl_stk_tld(o), bld = dl_stk_bld(o);
+    // DL_STK_STAMPS diagnostics (null in production): s_memtime of wave 0 at the phase boundaries, 32 slots per workgroup: 0 entry, 1 inputs, 2 monomial rows, then per device
+    // group 3 + 2 gi: networks done (after the barrier), 4 + 2 gi: feature GEMM + epilogue done; 30: rows stored; 31: s_memrealtime at exit (100 MHz)
+    unsigned long long* st = stamps != nullptr && blockIdx.y == 0 ? stamps + (size_t)blockIdx.x * 32 : nullptr;
+#define DL_STK_STAMP(slot) if (st != nullptr && tid == 0) st[slot] = __builtin_amdgcn_s_memtime();
+    DL_STK_STAMP(0)
+    constexpr int XLD = DL_STK_XLD;
+    const DlStkLds s = dl_stk_carve(lds);
+    double* basis = s.work;                                       // [16][bld] basis record of the current group
+    double* nbufs = basis + (size_t)DL_STK_PTS * bld;             // [8][16][tld] activation buffers of eight networks
+    const int H = o.eng[0].widths[o.eng[0].n_layers];
+    dl_stk_prologue(o, theta, n_params, B, p0, tid, lds, basis, tld, R, st);
+    // ---- group by group: networks, then the feature GEMM ----
+    double outv[4][RMAX];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) outv[rr][u] = 0.;
+    const int jb = blockIdx.y * 8 + wave;
+    const dl_fg_double2* gcol = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * steps_per_block * 64 + lane;
+    int tb_prev = -1, te_prev = -1;
+    for (int gi = 0; gi < o.stk.n_groups; ++gi) {
+        const double* rec = o.stk.table + (size_t)gi * DL_STK_REC;
+        const int tb = (int)rec[0], te = (int)rec[1], m0 = (int)rec[2], m1 = (int)rec[3], kq = (int)rec[7];
+        const int K = (te - tb) * H + 1, nq = (K + 7) / 8;
+        if (tb != tb_prev || te != te_prev) {
+            __syncthreads();    // the basis record is free (the previous group's GEMM is done); first group: the monomial rows are complete
+            for (int t = tb; t < te; t += 8) {     // eight networks at a time (their activation buffers)
+                const int n_net = te - t < 8 ? te - t : 8;
+                dl_stk_networks<TMAX>(o.eng[0].widths, o.eng[0].n_layers, o.eng[0].act, o.stk.wfrag + (size_t)t * o.stk.frag_doubles, o.stk.frag_doubles, n_net, s.xs, XLD, nbufs, tld,
+                                      basis + (size_t)(t - tb) * H, bld, wave, lane, gi == 0 && st != nullptr ? st + 15 : nullptr);
+                if (t + 8 < te) __syncthreads();
+            }
+            for (int idx = tid; idx < DL_STK_PTS * (8 * nq - (K - 1)); idx += 512) {      // the constant basis function and the zero padding of the last step
+                const int pt = idx / (8 * nq - (K - 1)), c = K - 1 + (idx - pt * (8 * nq - (K - 1)));
+                basis[(size_t)pt * bld + c] = c == K - 1 ? 1. : 0.;
+            }
+            tb_prev = tb; te_prev = te;
+            __syncthreads();
+        }
+        DL_STK_STAMP(3 + 2 * gi)
+        dl_stk_group<RMAX>(m1 - m0, basis + (size_t)col * bld + 2 * g, gcol + (size_t)kq * 64, nq, s.mono + m0, R, g, outv);
+        DL_STK_STAMP(4 + 2 * gi)
+    }
+    if (!tl.enabled) dl_stk_store_rows<RMAX>(outv, R, out, ldo, accumulate, B, p0, jb, col, g);
+    else dl_stk_finalize_tail<RMAX>(tl, outv, R, basis, theta, n_params, B, p0, tid, wave, lane, col, g);
+
     DL_STK_STAMP(30)
     if (st != nullptr && tid == 0) st[31] = __builtin_amdgcn_s_memrealtime();
 #undef DL_STK_STAMP

@@ -148,7 +148,7 @@ struct DlObsDev {
     // bias monomials [m0, m1) (the engines '11' / 'loop' / 'ct' / 'st' x (z, ell) stacks), times an amplitude that is log-linear in the inputs (conversion.py:88-92)
     struct Stack {
         int32_t n_groups, n_trunks, trunk_doubles, max_k;   // max_k: largest number of basis functions of a group, (te - tb) * H + 1
-        int32_t frag_doubles, pad_frag;                     // doubles of one network in `wfrag`
+        int32_t frag_doubles, max_net;                      // doubles of one network in `wfrag`; largest number of networks of a group (te - tb)
         const double* wfrag;   // the networks' weights in MFMA fragment order (dl_emu_stacked.h): per network, per layer [output tile][k-step][lane = col + 16 g] = K[4 step + g][16 tile + col]
                                //   (zero beyond the layer), then the biases [output tile][16]
         const double* table;   // [n_groups][DL_STK_REC] as doubles: tb, te, m0, m1, col (first column of the group's block in the theory vector), nm (monomials per basis

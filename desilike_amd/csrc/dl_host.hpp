@@ -330,6 +330,7 @@ inline bool dl_build_emulated_obs(const dl_config& cfg, const std::string& p, in
             d.stk.n_groups = (int)(table.size() / DL_STK_REC);
             if (d.stk.n_groups > DL_STK_MAX_GROUPS) { err = q + "at most 8 groups of networks"; return false; }
             d.stk.n_trunks = n_trunks; d.stk.trunk_doubles = (int32_t)per; d.stk.max_k = max_k;
+            d.stk.max_net = (max_k - 1) / H;
             d.n_basis = col;    // (columns of the theory vector: n_kin below)
             xlo.assign(d.n_x, 0.); xinv.assign(d.n_x, 0.);
             for (int c = 0; c < d.n_x; ++c) { xlo[c] = xl[2 * c]; xinv[c] = 1. / (xl[2 * c + 1] - xl[2 * c]); }

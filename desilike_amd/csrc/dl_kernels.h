@@ -21,7 +21,12 @@ extern thread_local DlProfEvents dl_prof_events;
 // at first use, into this table; nothing on the per-call path calls getenv.  dl_options_refresh() (C ABI; the tests flip switches inside one process) re-reads the environment.
 struct DlOptions {
     bool no_merged_theory, no_emu_batch, no_fused_solve, no_gram_plain, no_scaled_row0, ef_no_early_theta, fm_no_lane_solve;
+    int stk_overlap;                    // DL_STK_OVERLAP: the stacked engine on dl_emulated_stacked_ov_kernel where the shape allows (round-6 experiment, slower: docs/EXPERIMENTS.md):
+                                        // 1 networks of the next batch under the feature GEMM (+2: without raised priority), 4 the two halves of the workgroup on half of the networks each
     bool ens_global, ens_force_comm, ens_no_defer, ens_no_fold, ens_stamps, ens_fold_stamps;
+    bool no_emu_fused, no_gram_epilogue, step_kernel, chi2_fused, no_chi2_big;   // DL_NO_EMU_FUSED, DL_NO_GRAM_EPILOGUE, DL_STEP_KERNEL, DL_CHI2_FUSED, DL_NO_CHI2_BIG (dl_api.hip)
+    int xcd_local;    // DL_XCD_LOCAL: 0 off, 1 chi2 GEMM path (default), 2 also the theory kernel's point order
+    long long chi2_max_rows;   // DL_CHI2_GEMM_MAX (default 2048): above, the split-K / LDS-DMA GEMM paths
     int cg_mt;        // DL_CG_MT: forced row tile of the chi2 GEMM (0: chosen per batch)
     int host_mode;    // DL_HOST_MODE: see dl_eval_batch_host (-1: default)
 };

@@ -14,10 +14,12 @@
 #include <vector>
 
 #include "dl_fullshape.h"
+#include <mutex>
 #include "dl_kernels.h"
 #include "dl_tns.h"
 #include "dl_emu_batch.h"
 #include "dl_emu_stacked.h"
+#include "dl_emu_stacked_ov.h"
 #include "dl_finalize_part.h"
 #include "dl_marg_solve.h"
 #include "dl_scalar_prefetch.h"
@@ -46,23 +48,28 @@ __device__ __forceinline__ void dl_obs_prefetch(const void* p) {
 
 // ---- the table of diagnostic switches (dl_kernels.h) ----
 static DlOptions g_options;
-static bool g_options_read = false;
+static std::once_flag g_options_once;     // (several host threads -- one per chain -- may make the first call)
 static void dl_options_read() {
     auto on = [](const char* name) { return std::getenv(name) != nullptr; };
     DlOptions& o = g_options;
     o.no_merged_theory = on("DL_NO_MERGED_THEORY"); o.no_emu_batch = on("DL_NO_EMU_BATCH"); o.no_fused_solve = on("DL_NO_FUSED_SOLVE"); o.no_gram_plain = on("DL_NO_GRAM_PLAIN");
     o.no_scaled_row0 = on("DL_NO_SCALED_ROW0"); o.ef_no_early_theta = on("DL_EF_NO_EARLY_THETA"); o.fm_no_lane_solve = on("DL_FM_NO_LANE_SOLVE");
+    o.stk_overlap = std::getenv("DL_STK_OVERLAP") ? atoi(std::getenv("DL_STK_OVERLAP")) : 0;
     o.ens_global = on("DL_ENS_GLOBAL"); o.ens_force_comm = on("DL_ENS_FORCE_COMM"); o.ens_no_defer = on("DL_ENS_NO_DEFER"); o.ens_no_fold = on("DL_ENS_NO_FOLD");
     o.ens_stamps = on("DL_ENS_STAMPS"); o.ens_fold_stamps = on("DL_ENS_FOLD_STAMPS");
     o.cg_mt = std::getenv("DL_CG_MT") ? atoi(std::getenv("DL_CG_MT")) : 0;
     o.host_mode = std::getenv("DL_HOST_MODE") ? atoi(std::getenv("DL_HOST_MODE")) : -1;
-    g_options_read = true;
+    auto flag = [](const char* name) { const char* v = std::getenv(name); return v != nullptr && atoi(v) != 0; };
+    o.no_emu_fused = on("DL_NO_EMU_FUSED"); o.no_gram_epilogue = on("DL_NO_GRAM_EPILOGUE"); o.no_chi2_big = on("DL_NO_CHI2_BIG");
+    o.step_kernel = flag("DL_STEP_KERNEL"); o.chi2_fused = flag("DL_CHI2_FUSED");
+    o.xcd_local = std::getenv("DL_XCD_LOCAL") ? atoi(std::getenv("DL_XCD_LOCAL")) : 1;
+    o.chi2_max_rows = std::getenv("DL_CHI2_GEMM_MAX") ? atoll(std::getenv("DL_CHI2_GEMM_MAX")) : 2048;
 }
 const DlOptions& dl_options() {
-    if (!g_options_read) dl_options_read();
+    std::call_once(g_options_once, dl_options_read);
     return g_options;
 }
-extern "C" void dl_options_refresh(void) { dl_options_read(); }
+extern "C" void dl_options_refresh(void) { (void)dl_options(); dl_options_read(); }
 
 // Workgroups are dealt round-robin to the 8 XCDs; with xblk > 0 workgroup w = xcd + 8 r handles point xblk (xcd + 8 (r / xblk)) + r % xblk (see dl_fullshape_body)
 __device__ __forceinline__ int dl_fs_point_of_wg(int wg, int xblk) { return xblk ? xblk * ((wg & 7) + 8 * ((wg >> 3) / xblk)) + ((wg >> 3) % xblk) : wg; }
@@ -890,12 +897,21 @@ bool dl_emulated_stacked_ok(const DlObsDev& obs) { return dl_stk_feature_ok(obs)
 // (outputs of DlGramFinalize; fin->done = true) and no row is written; otherwise the residual rows go to `out`
 void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
                                 int steps_per_block, hipStream_t stream, DlGramFinalize* fin, const double* bias, const DlMargDev* mg, int n_valid) {
-    const size_t shm = dl_stk_shared_doubles(obs) * sizeof(double);
+    // the overlapped form (dl_emu_stacked_ov.h) where the shape allows: networks of the next batch under the feature GEMM of the current group
+    const bool overlap = dl_options().stk_overlap != 0 && dl_stko_ok(obs);   // (off by default: measured slower than the plain form, docs/EXPERIMENTS.md round 6)
+    size_t shm = overlap ? (dl_stko_fixed_doubles() + dl_stko_work_doubles(obs)) * sizeof(double) : dl_stk_shared_doubles(obs) * sizeof(double);
     const int R = 1 + obs.n_var;
     const unsigned grid = (unsigned)((B + DL_STK_PTS - 1) / DL_STK_PTS);
     DlStkTail tl;
     std::memset(&tl, 0, sizeof(tl));
-    if (fin != nullptr && mg != nullptr && N_pad == 128 && n_valid <= 128 && !accumulate && mg->n_s >= 0 && dl_stk_tail_fits(obs, 1 + mg->n_s)) {
+    bool tail_fits = false;
+    if (mg != nullptr && mg->n_s >= 0 && 1 + mg->n_s <= 8) {
+        if (overlap) {   // X [16][xr][DL_FG_XLD] over the work area, which grows to hold it when the LDS allows
+            const size_t need = (dl_stko_fixed_doubles() + (size_t)DL_STK_PTS * (1 + mg->n_s) * DL_FG_XLD) * sizeof(double);
+            if (need + DL_STK_STATIC_LDS <= 160 * 1024) { tail_fits = true; if (need > shm) shm = need; }
+        } else tail_fits = dl_stk_tail_fits(obs, 1 + mg->n_s);
+    }
+    if (fin != nullptr && mg != nullptr && N_pad == 128 && n_valid <= 128 && !accumulate && tail_fits && !dl_options().no_fused_solve) {
         bool ok = true;
         tl.xr = 1 + mg->n_s;
         tl.row_of[0] = 0; tl.cst[0] = bias;
@@ -916,23 +932,30 @@ void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_
     static const char* stamp_file = getenv("DL_STK_STAMPS");   // diagnostics: s_memtime at the phase boundaries of launches 30..33 appended to the file (synchronises)
     static unsigned long long* stamps_dev = nullptr;
     static int stamp_launches = 0;
-    if (stamp_file && !stamps_dev) (void)hipMalloc((void**)&stamps_dev, (size_t)8192 * 32 * sizeof(unsigned long long));
+    const int slots = overlap ? 128 : 32;                      // per workgroup (the overlapped kernel stamps waves 0 and 4, 64 slots each)
+    if (stamp_file && !stamps_dev) (void)hipMalloc((void**)&stamps_dev, (size_t)8192 * 128 * sizeof(unsigned long long));
     unsigned long long* stamps = (stamp_file && grid <= 8192 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
     if (stamp_file) stamp_launches++;
-    if (stamps) (void)hipMemsetAsync(stamps, 0, (size_t)grid * 32 * sizeof(unsigned long long), stream);
+    if (stamps) (void)hipMemsetAsync(stamps, 0, (size_t)grid * slots * sizeof(unsigned long long), stream);
     auto launch = [&](auto kernel) {
         (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         DL_LAUNCH(kernel, dim3(grid, (unsigned)(N_pad / 128)), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, out, ldo, accumulate, steps_per_block, stamps, tl);
     };
+    auto launch_ov = [&](auto kernel) {
+        const int sel = dl_options().stk_overlap, mode = (sel & 4) ? 4 : ((sel & 2) ? 0 : 1);       // kernel's mode bits: 1 raised priority of the network waves, 4 split halves
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        DL_LAUNCH(kernel, dim3(grid, (unsigned)(N_pad / 128)), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, out, ldo, accumulate, steps_per_block, stamps, tl, mode);
+    };
     const bool wide = dl_stk_tld(obs) > 66;   // a layer wider than 64 units: eight output tiles per layer
-    if (wide) { if (R <= 1) launch(dl_emulated_stacked_kernel<8, 1>); else if (R <= 4) launch(dl_emulated_stacked_kernel<8, 4>); else if (R <= 6) launch(dl_emulated_stacked_kernel<8, 6>); else launch(dl_emulated_stacked_kernel<8, 8>); }
+    if (overlap) { if (R <= 1) launch_ov(dl_emulated_stacked_ov_kernel<1, DL_STKO_TMAX>); else if (R <= 4) launch_ov(dl_emulated_stacked_ov_kernel<4, DL_STKO_TMAX>); else if (R <= 6) launch_ov(dl_emulated_stacked_ov_kernel<6, DL_STKO_TMAX>); else launch_ov(dl_emulated_stacked_ov_kernel<8, DL_STKO_TMAX>); }
+    else if (wide) { if (R <= 1) launch(dl_emulated_stacked_kernel<8, 1>); else if (R <= 4) launch(dl_emulated_stacked_kernel<8, 4>); else if (R <= 6) launch(dl_emulated_stacked_kernel<8, 6>); else launch(dl_emulated_stacked_kernel<8, 8>); }
     else { if (R <= 1) launch(dl_emulated_stacked_kernel<4, 1>); else if (R <= 4) launch(dl_emulated_stacked_kernel<4, 4>); else if (R <= 6) launch(dl_emulated_stacked_kernel<4, 6>); else launch(dl_emulated_stacked_kernel<4, 8>); }
     if (stamps) {
         (void)hipStreamSynchronize(stream);
-        std::vector<unsigned long long> h((size_t)grid * 32);
+        std::vector<unsigned long long> h((size_t)grid * slots);
         (void)hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         if (FILE* f = fopen(stamp_file, "a")) {
-            for (unsigned w = 0; w < grid; ++w) { for (int q = 0; q < 32; ++q) fprintf(f, "%llu ", h[(size_t)w * 32 + q]); fprintf(f, "\n"); }
+            for (unsigned w = 0; w < grid; ++w) { for (int q = 0; q < slots; ++q) fprintf(f, "%llu ", h[(size_t)w * slots + q]); fprintf(f, "\n"); }
             fprintf(f, "#\n");
             fclose(f);
         }
@@ -1674,7 +1697,7 @@ void dl_launch_finalize_marg(const double* dtilde, int64_t ld, int n, int rows_p
     if (stamp_file && !stamps_dev) (void)hipMalloc((void**)&stamps_dev, (size_t)65536 * 8 * sizeof(unsigned long long));
     unsigned long long* stamps = (stamp_file && grid <= 65536 && B >= 256 && stamp_launches >= 10 && stamp_launches < 12) ? stamps_dev : nullptr;
     if (stamp_file && B >= 256) stamp_launches++;
-    static const int xcd_local = getenv("DL_XCD_LOCAL") ? atoi(getenv("DL_XCD_LOCAL")) : 1;
+    const int xcd_local = dl_options().xcd_local;
     if (xcd_local && xcd_tile16 && B % 128 == 0) post_mode |= 0x100;
     static const bool allow_staged = !getenv("DL_FM_NO_STAGE");   // DL_FM_NO_STAGE=1: operands of the Gram product straight from global memory (comparison)
     const size_t region = std::max<size_t>((size_t)(1 + mg.n_s) * (((n + 3) & ~3) + 4), 512);

@@ -196,7 +196,8 @@ def test_stacked_batches_beyond_one_pass():
         assert abs(loglike[i] - sol['loglikelihood']) <= TOL * max(1., abs(sol['loglikelihood'])), (i, loglike[i], sol['loglikelihood'])
 
 
-@pytest.mark.parametrize('hidden,activation,marg,z', [((20, 36, 12), 'relu', True, 0.8), ((128,), 'silu', False, 0.62), ((8, 8, 8, 8, 8, 8), 'tanh', True, 0.955), ((100, 28), 'silu', True, 0.3)])
+@pytest.mark.parametrize('hidden,activation,marg,z', [((20, 36, 12), 'relu', True, 0.8), ((128,), 'silu', False, 0.62), ((8, 8, 8, 8, 8, 8), 'tanh', True, 0.955), ((100, 28), 'silu', True, 0.3),
+                                                     ((64, 64, 128), 'tanh', True, 0.955), ((64, 64, 80), 'silu', True, 0.8), ((64, 64, 128), 'silu', False, 0.8)])   # (two 16-step layers, then another tile count -- waves without a task in one layer and with one in the next)
 def test_stacked_architectures(hidden, activation, marg, z):
     """Widths off the 16 x 16 x 4 tile, one to six hidden layers, the three activations, between / on emulated redshifts: 273 points (ragged last tile) against the oracle."""
     like, pt, theory, solved, networks = make_cfg3_stacked(marg=marg, z=z, hidden=hidden, activation=activation, nk=24, seed=21)
@@ -207,3 +208,30 @@ def test_stacked_architectures(hidden, activation, marg, z):
     for i in (0, 15, 16, 150, 271, 272):
         sol = cfg3_stacked_oracle_solution(like, pt, theory, solved, theta[i])
         assert abs(loglike[i] - sol['loglikelihood']) <= TOL * max(1., abs(sol['loglikelihood'])), (hidden, activation, i, loglike[i], sol['loglikelihood'])
+
+
+def test_stacked_overlapped_experiment_kernel():
+    """``dl_emulated_stacked_ov_kernel`` (round 6: the networks of the next batch under the feature GEMM of the current group, or the two halves of the workgroup on half of the
+    networks each; measured slower than the plain form and off by default, docs/EXPERIMENTS.md) at the size of BASELINE configs[2]: the same log-posteriors as the default
+    kernel (another summation order inside the networks: 1e-12) and the oracle's at 1e-10, marginalised and plain."""
+    import os
+    from desilike_amd import _lib
+    lib = _lib.load()
+    try:
+        for marg in (True, False):
+            like, pt, theory, solved, networks = make_cfg3_stacked(marg=marg)
+            like.initialize()
+            theta = sample(like, 1000, 23)       # (ragged last tile)
+            ctx = like._get_context()
+            os.environ.pop('DL_STK_OVERLAP', None); lib.dl_options_refresh()
+            base = ctx.eval_batch_host(theta)[0]
+            for mode in ('1', '3', '4'):
+                os.environ['DL_STK_OVERLAP'] = mode; lib.dl_options_refresh()
+                loglike, logprior, status = ctx.eval_batch_host(theta)
+                assert (status == 0).all()
+                assert np.allclose(loglike, base, rtol=1e-12, atol=1e-12), (marg, mode, np.abs(loglike - base).max())
+                for i in (0, 15, 16, 999):
+                    sol = cfg3_stacked_oracle_solution(like, pt, theory, solved, theta[i])
+                    assert abs(loglike[i] - sol['loglikelihood']) <= TOL * max(1., abs(sol['loglikelihood'])), (marg, mode, i)
+    finally:
+        os.environ.pop('DL_STK_OVERLAP', None); lib.dl_options_refresh()
