@@ -551,6 +551,20 @@ def _stacked_config(device, steps, warmup, ncheck, sample):
     loglike = ctx.eval_batch_host(theta_host[:ncheck])[0]
     err = max(abs(loglike[i] - cfg3_stacked_oracle_solution(like, pt, theory, solved, theta_host[i])['loglikelihood']) / max(1., abs(loglike[i])) for i in range(ncheck))
     assert err <= 1e-10, 'GPU / oracle mismatch on configs[2] (stacked layout): {:.3e}'.format(err)
+    # ... and against the REFERENCE ITSELF at this shape (tests/golden/boundary_cfg3_stacked_bench.npz: the exact quadratic of the reference's own log-posterior in the solved
+    # parameters at 12 points, through its Emulator.from_state + REPT tracer on the same synthetic weights; tests/golden/make_boundary_fixture.py): the context the timed loop ran on
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'boundary_cfg3_stacked_bench.npz'))
+    names = like.varied_params.names()
+    assert sorted(names) == sorted(str(n) for n in g['names'])
+    rows = g['theta'][:len(g['marg_c'])][:, [[str(n) for n in g['names']].index(name) for name in names]]
+    ll, lp, st = ctx.eval_batch_host(rows)[:3]
+    marg = np.asarray(g['cfg/marg.kind']).astype(bool)
+    ref_err = 0.
+    for i in np.flatnonzero(st == 0):
+        c, grad, H = g['marg_c'][i], g['marg_g'][i], g['marg_H'][i]
+        ref = c - 0.5 * grad.dot(np.linalg.solve(H, grad)) - 0.5 * np.linalg.slogdet(-H[np.ix_(marg, marg)])[1]
+        ref_err = max(ref_err, abs(ll[i] + lp[i] - ref) / max(1., abs(ref)))
+    assert (st == 0).sum() >= len(rows) - 1 and ref_err <= 1e-10, 'GPU / reference mismatch on configs[2] (stacked layout): {:.3e}'.format(ref_err)
     spec = like._spec({}, like._flatdata_list(), like.precision)['observables'][0]
     groups, widths = np.asarray(spec['emu0']['groups']), [int(w) for w in np.ravel(spec['emu0']['widths'])]
     n, H = like.flatdata.size, widths[-1]
@@ -568,7 +582,8 @@ def _stacked_config(device, steps, warmup, ncheck, sample):
                          'flop_per_launch': fused * B, 'avg_launch_ms': kernel_ms[slot], 'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS,
                          'flop_count': "the build's own algorithm: final layers x y-scalers x assembly x redshift blend x interpolation x window x L^T folded at create"},
             'kernel_ms': {name: kernel_ms[name] for name in ['theory', 'window_gemm', 'finalize']},
-            'oracle_check': {'points': ncheck, 'max_rel_err_vs_oracle': float(err), 'tolerance': 1e-10}}
+            'oracle_check': {'points': ncheck, 'max_rel_err_vs_oracle': float(err), 'tolerance': 1e-10},
+            'reference_check': {'fixture': 'tests/golden/boundary_cfg3_stacked_bench.npz', 'points': int((st == 0).sum()), 'max_rel_err_vs_reference': float(ref_err), 'tolerance': 1e-10}}
 
 
 def _tns_config(device, steps, ncheck, orc):

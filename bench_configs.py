@@ -109,7 +109,7 @@ def stacked_state(networks, z, params, ells=(0, 2, 4)):
     return state
 
 
-def make_cfg3_stacked(marg=True, z=0.8, hidden=(64, 64, 64, 64, 64), activation='tanh', nk=60, seed=11):
+def make_cfg3_stacked(marg=True, z=0.8, hidden=(64, 64, 64, 64, 64), activation='tanh', nk=60, seed=11, data=None):
     """BASELINE configs[2] on the jaxeffort layout: 4 engines x 7 redshifts x 3 multipoles = 84 networks 5 -> 5 x 64 tanh -> n_m * 60 outputs, amplitude rescale by logA, the
     REPT tracer at a redshift between two emulated ones (12 networks survive the blend, + 12 of its neighbour: 24 on the device), 19-monomial combination, cubic interpolation
     to n_kin = 400, binning window 120 x 1200; solved: alpha0, alpha2, alpha4, sn0, sn2 (n_s = 5, Gaussian priors).  Synthetic weights."""
@@ -127,7 +127,8 @@ def make_cfg3_stacked(marg=True, z=0.8, hidden=(64, 64, 64, 64, 64), activation=
     solved = ['alpha0', 'alpha2', 'alpha4', 'sn0', 'sn2'] if marg else []
     for name in solved: theory.init.params[name].update(derived='.marg')
     rng = np.random.RandomState(5)
-    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 1.7, 'b2': 0.4, 'alpha0': 3.}, kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=8e3)
+    # (data: a ready-made data vector instead of the theory at these parameters, which the device evaluates at initialisation -- the CPU tests hand over the reference's)
+    obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 1.7, 'b2': 0.4, 'alpha0': 3.} if data is None else data, kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=8e3)
     A = rng.standard_normal((120, 120)) * 40.
     like = ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + 4e4 * np.eye(120))
     return like, pt, theory, solved, networks

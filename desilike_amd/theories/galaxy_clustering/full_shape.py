@@ -516,9 +516,17 @@ class _BaseVelocileptorsTracer(BaseCalculator):
             for name in ['sn0p', 'sn2p', 'sn4p']:
                 params[name] = dict(prior=dict(dist='norm', loc=0., scale=2. if name == 'sn0p' else 5.), ref=dict(dist='norm', loc=0., scale=1.))
         else:
-            params['b1'] = dict(value=1. if cls._rept else 0., prior=dict(limits=[-1., 5.]), ref=dict(dist='norm', loc=1., scale=0.1))
-            for name in cls._names[1:]:
-                params[name] = dict(value=0., prior=dict(dist='norm', loc=0., scale=100.), ref=dict(dist='norm', loc=0., scale=1.))
+            # the reference's own defaults (full_shape.yaml: LPT / REPT tracer, power spectrum / correlation function; no ``value``: the centre of ``ref``, parameter.py:811-819)
+            norm = lambda scale, ref: dict(prior=dict(dist='norm', loc=0., scale=scale), ref=dict(dist='norm', loc=0., scale=ref))   # noqa: E731
+            xi = getattr(cls, '_standalone_space', 'pk') == 'xi'
+            params['b1'] = dict(prior=dict(limits=[0., 4.]), ref=dict(limits=[1.4, 1.6])) if cls._rept else dict(prior=dict(limits=[-1., 10.]), ref=dict(limits=[0.4, 0.6]))
+            params['b2'] = norm(10., 0.5)
+            params['bs'] = norm(10. if xi else 5., 0.5)
+            params['b3'] = dict(fixed=True, **norm(10. if xi else 5., 0.5))
+            params['alpha0'] = norm(30., 1.)
+            params['alpha2'], params['alpha4'] = norm(50., 1.), norm(50., 1.)
+            params['alpha6'] = dict(fixed=True, **norm(50., 1.))
+            params['sn0'], params['sn2'], params['sn4'] = norm(4., 0.1), norm(100., 0.1), norm(500., 0.1)
         # ``freedom`` presets (full_shape.py:1100-1117): applied before the physical-basis priors, which then only keep the list of fixed parameters
         freedom = kwargs.get('freedom', None)
         suffix = 'p' if prior_basis == 'physical' else ''

@@ -250,6 +250,24 @@ def stacked_fixtures():
     dump('cfg3_stacked_marg', lambda: rept(0.6, True), size=24, seed=31, unsolved=lambda: rept(0.6, False))
     dump('cfg3_stacked_ongrid', lambda: rept(0.51, False, hidden=(16, 24, 16), activation='silu', seed=5, nk=10), size=24, seed=33)
 
+    # THE BENCHMARKED SHAPE: bench_configs.py::make_cfg3_stacked as bench.py and tests/test_gpu_stacked.py run it -- seven emulated redshifts, 5 x 64 tanh, 60
+    # wavenumbers per table, tracer at z = 0.8 between two of them, standard prior basis, 40 bins x 3 multipoles, binning window at resolution 10 (120 x 1200), five solved parameters;
+    # the same synthetic weights (stacked_networks(seed = 11)) and the same covariance, through the reference's own Emulator.from_state + REPT tracer
+    def bench(marg):
+        from bench_configs import STACKED_ZGRID
+        pt = jaxeffort_layout_pt(REPTVelocileptorsPowerSpectrumMultipoles, stacked_networks(STACKED_ZGRID, hidden=(64, 64, 64, 64, 64), activation='tanh', seed=11, nk=60), STACKED_ZGRID, STK_PARAMS, STK_SPECS)
+        theory = REPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, z=0.8, prior_basis='standard')
+        for name in ['b3', 'alpha6', 'sn4']: theory.init.params[name].update(fixed=True)
+        for name in ['alpha0', 'alpha2', 'alpha4']: theory.init.params[name].update(prior=dict(dist='norm', loc=0., scale=20.))
+        for name in ['sn0', 'sn2']: theory.init.params[name].update(prior=dict(dist='norm', loc=0., scale=2.))
+        if marg:
+            for name in ['alpha0', 'alpha2', 'alpha4', 'sn0', 'sn2']: theory.init.params[name].update(derived='.marg')
+        obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 1.7, 'b2': 0.4, 'alpha0': 3.}, kedges=np.linspace(0., 0.2, 41), ells=(0, 2, 4), wmatrix={'resolution': 10}, theory=theory, shotnoise=8e3)
+        A = np.random.RandomState(5).standard_normal((120, 120)) * 40.
+        return ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + 4e4 * np.eye(120))
+
+    dump('cfg3_stacked_bench', lambda: bench(True), size=24, seed=37, unsolved=lambda: bench(False))
+
     def lpt(marg):
         pt = jaxeffort_layout_pt(LPTVelocileptorsPowerSpectrumMultipoles, stacked_networks(zgrid[:1], hidden=(16, 16), activation='silu', seed=7), zgrid[:1], STK_PARAMS, STK_SPECS, drop_z=True)
         theory = LPTVelocileptorsTracerPowerSpectrumMultipoles(pt=pt, prior_basis='standard')

@@ -201,3 +201,38 @@ def test_malformed_descriptions_are_refused_with_a_message(case):
     theta = g['theta'][np.isfinite(g['logprior'])][:2]
     with pytest.raises(RuntimeError) as info: FlatEmulation(cfg).eval_batch(theta)
     assert expect in str(info.value), str(info.value)
+
+
+def test_benchmarked_shape_against_the_reference():
+    """the stacked configuration bench.py and tests/test_gpu_stacked.py run (``bench_configs.make_cfg3_stacked``: 7 redshifts, 5 x 64 tanh, 60 wavenumbers,
+    window 120 x 1200, 5 solved parameters) against ``boundary_cfg3_stacked_bench.npz`` -- the key set the binding read off the REFERENCE's pipeline on the same synthetic
+    weights (its ``Emulator.from_state`` + REPT tracer) and the exact quadratic of the reference's own log-posterior at 12 points: (i) the host mirror compiles those keys
+    (window, grids, precision, data vector and folded operator are the reference's, not only the mirror's own), (ii) the oracle chain reproduces the reference's marginalised
+    log-posterior to 1e-10."""
+    from desilike_amd._lib import fill_config
+    from bench_configs import make_cfg3_stacked, cfg3_stacked_oracle_solution
+    g, cfg = load_fixture('cfg3_stacked_bench')
+    like, pt, theory, solved, networks = make_cfg3_stacked(marg=True, data=cfg['obs0.flatdata'])    # (the data vector: the reference's -- the mirror evaluates its own on the device: tests/test_gpu_stacked.py)
+    like.initialize()
+    mirror = {}
+    fill_config(like._spec({}, like._flatdata_list(), like.precision), lambda key, a: mirror.__setitem__(key, a), lambda key, a: mirror.__setitem__(key, a))
+    names = like.varied_params.names()
+    assert names == [str(n) for n in g['names']] and solved == [str(n) for n in g['solved']]
+    # (the binding also hands over sigma8 / fsigma8 constants, which the standard prior basis never reads)
+    assert int(np.ravel(cfg['obs0.mono_mode'])[0]) >= 3 and set(cfg) - set(mirror) <= {'obs0.emu1.const', 'obs0.emu2.const'} and not set(mirror) - set(cfg), set(mirror) ^ set(cfg)
+    for key in mirror:
+        a, b = np.asarray(mirror[key], dtype='f8').reshape(np.asarray(cfg[key]).shape), np.asarray(cfg[key], dtype='f8')
+        if key.startswith('obs0.in.'):     # input maps (column of theta, constant): the constant counts where there is no column
+            assert np.array_equal(a[:, 0], b[:, 0]) and np.array_equal(a[a[:, 0] < 0, 1], b[b[:, 0] < 0, 1]), key
+            continue
+        scale = np.abs(b[np.isfinite(b)]).max() if b.size else 1.
+        assert np.allclose(a, b, rtol=1e-11, atol=1e-12 * scale), (key, np.abs(a - b).max(), scale)
+    marg = np.asarray(cfg['marg.kind']).astype(bool)
+    for i in (0, 5, 11):
+        c, grad, H = g['marg_c'][i], g['marg_g'][i], g['marg_H'][i]
+        ref = c - 0.5 * grad.dot(np.linalg.solve(H, grad)) - 0.5 * np.linalg.slogdet(-H[np.ix_(marg, marg)])[1]
+        sol = cfg3_stacked_oracle_solution(like, pt, theory, solved, g['theta'][i])
+        prior = sum(like.all_params[name].prior(value) for name, value in zip(names, g['theta'][i]))
+        got = sol['loglikelihood'] + sol['logprior_solved'] + prior      # (likelihoods/base.py:385-404: the best-fit prior term of the solved parameters sits in the log-prior)
+        assert abs(got - ref) <= 1e-10 * max(1., abs(ref)), (i, got, ref)
+        assert np.allclose(sol['x'], g['marg_x0'] - np.linalg.solve(H, grad), rtol=1e-7, atol=1e-9)
