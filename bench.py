@@ -197,6 +197,24 @@ def cpu_baseline(likelihood, theta, budget=10.):
     return base, check
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources of the tree (desilike_amd/csrc/*.h *.hpp *.hip, sorted by name): ``tools/prof_round.sh`` writes it next to the
+    summaries it takes (profiles/<tag>_source_hash.txt), and figures copied from a committed profile enter the bench line only when that hash is the running tree's."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, 'desilike_amd', 'csrc', '*.h')) + glob.glob(os.path.join(ROOT, 'desilike_amd', 'csrc', '*.hpp')) + glob.glob(os.path.join(ROOT, 'desilike_amd', 'csrc', '*.hip'))):
+        h.update(os.path.basename(fn).encode()); h.update(open(fn, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def profile_is_current(fn):
+    """True when the committed profile ``fn`` (profiles/<tag>_...) was taken on the kernel sources of this tree (profiles/<tag>_source_hash.txt)."""
+    tag = os.path.basename(fn).split('_')[0]
+    hfn = os.path.join(ROOT, 'profiles', tag + '_source_hash.txt')
+    return os.path.isfile(hfn) and open(hfn).read().split()[0] == source_hash()
+
+
 def hbm_traffic(kernel_name):
     """HBM bytes per launch of ``kernel_name`` from the latest committed PMC summary (profiles/*_pmc_hbm_traffic.txt: separate ``rocprofv3 --pmc FETCH_SIZE`` and
     ``--pmc WRITE_SIZE`` passes of this same command, gfx950 read-side correction applied, see tools/prof_round.sh / tools/pmc_summary.py); None if absent."""
@@ -226,6 +244,63 @@ def trace_average(kernel_name):
                     if best is None or calls > best[0]: best = (calls, float(row['AverageNs']) * 1e-6)
         if best is not None: return best[1], os.path.relpath(fn, ROOT)
     return None, None
+
+
+def compact_line(result):
+    """The bench line reduced to what a reader checks: the contract's headline fields, `roofline` and `cpu_baseline` of the headline, and per leg
+    {id, value, ms_per_step, frac of the fp64 peak, kernel microseconds, error against the oracle / the reference}."""
+    def num(x, digits=4):
+        return None if x is None else float('{:.{}g}'.format(float(x), digits))
+
+    out = {key: result[key] for key in ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'] if key in result}
+    out['value'], out['ms_per_step'] = num(out['value'], 6), num(out['ms_per_step'], 6)
+    cfg = result.get('config', {})
+    out['config'] = {'workload': 'BASELINE configs[1]: ShapeFit+Kaiser P_ell (0,2,4) x 40 k-bins, dense window 120x1200, {:d} batched points per GPU per step'.format(cfg.get('batch_per_gpu', 0)),
+                     'batch_per_gpu': cfg.get('batch_per_gpu'), 'parallelism': cfg.get('parallelism'), 'collective': cfg.get('collective'), 'ranks': cfg.get('ranks')}
+    r = result.get('roofline', {})
+    out['roofline'] = {'bound': r.get('bound'), 'kernel': r.get('kernel'), 'achieved': num(r.get('achieved')), 'peak': r.get('peak'), 'unit': r.get('unit'), 'frac': num(r.get('frac')),
+                       'traffic': r.get('traffic'), 'traffic_from_committed_profile': r.get('traffic_source'), 'avg_launch_us': num(1e3 * r['avg_launch_ms']) if r.get('avg_launch_ms') else None,
+                       'event_samples': r.get('event_samples'), 'trace_avg_launch_us': num(1e3 * r['trace_avg_launch_ms']) if r.get('trace_avg_launch_ms') else None, 'trace_frac': num(r.get('trace_frac')),
+                       'traffic_step_over_algorithmic': num(r.get('traffic_step_over_algorithmic'))}
+    out['kernel_us'] = {name: num(1e3 * v) for name, v in (result.get('kernel_ms') or {}).items() if v}
+    if result.get('cpu_baseline'):
+        b = result['cpu_baseline']
+        out['cpu_baseline'] = {key: b.get(key) for key in ['value', 'unit', 'cores', 'kind', 'sample']}
+        out['cpu_baseline']['value'] = num(b.get('value'))
+        if isinstance(b.get('multi'), dict) and 'value' in b['multi']: out['cpu_baseline']['all_threads'] = {'value': num(b['multi']['value']), 'cores': b['multi'].get('cores')}
+    if result.get('sustained'): out['sustained'] = {'value': num(result['sustained'].get('value'), 5), 'seconds': num(result['sustained'].get('seconds', result['sustained'].get('elapsed_s')), 3)}
+    if isinstance(result.get('streams'), dict): out['streams'] = {key: (num(v.get('value'), 5) if isinstance(v, dict) else num(v, 5) if isinstance(v, (int, float)) else v) for key, v in result['streams'].items() if key != 'workload'}
+    if isinstance(result.get('streams'), list): out['streams'] = [{'streams': leg.get('streams'), 'value': num(leg.get('value'), 5)} for leg in result['streams'] if isinstance(leg, dict)]
+    hc = result.get('host_call')
+    if isinstance(hc, dict):
+        if 'error' in hc: out['host_call'] = {'error': hc['error']}
+        else:
+            out['host_call'] = {'256': {k: num(v) for k, v in (hc.get('per_batch_size', {}).get('256') or {}).items()}}
+            hd = hc.get('host_driven_ensemble')
+            if isinstance(hd, dict): out['host_call']['host_driven_ensemble'] = {k: num(v) for k, v in hd.items() if isinstance(v, (int, float)) and k in ('us_per_update', 'value')}
+    legs = []
+    for i, leg in enumerate(result.get('other_configs') or []):
+        if not isinstance(leg, dict): continue
+        rr = leg.get('roofline', {}) if isinstance(leg.get('roofline'), dict) else {}
+        w = str(leg.get('workload', ''))
+        ident = ('configs[2]-stacked-layout' if 'layout the reference ships' in w else 'configs[2]-single-network' if 'configs[2]' in w else 'configs[3]-bao-xi' if 'configs[3]' in w else
+                 'tns-one-loop' if 'TNS' in w else 'other_configs[{:d}]'.format(i))
+        item = {'id': ident, 'value': num(leg.get('value'), 5), 'unit': leg.get('unit'), 'ms_per_step': num(leg.get('ms_per_step'), 5), 'batch': leg.get('batch'),
+                'frac': num(rr.get('frac')), 'kernel_us': num(1e3 * rr['avg_launch_ms']) if rr.get('avg_launch_ms') else None,
+                'oracle_err': num((leg.get('oracle_check') or {}).get('max_rel_err_vs_oracle'), 3)}
+        if leg.get('reference_check'): item['reference_err'] = num(leg['reference_check'].get('max_rel_err_vs_reference'), 3)
+        if 'error' in leg: item['error'] = leg['error']
+        legs.append(item)
+    if legs: out['other_configs'] = legs
+    cw = result.get('chains_weak')
+    if isinstance(cw, dict): out['chains_weak'] = {'error': cw['error']} if 'error' in cw else {'value': num(cw.get('value'), 5), 'unit': cw.get('unit'), 'per_k': [{'chains_per_gpu': c.get('chains_per_gpu'), 'value': num(c.get('value'), 5), 'us_per_update_per_chain': num(c.get('us_per_update_per_chain'))} for c in cw.get('per_k', []) if isinstance(c, dict)]}
+    mh = result.get('mh_chains')
+    if isinstance(mh, dict): out['mh_chains'] = {'value': num(mh.get('value'), 5), 'unit': mh.get('unit')} if 'error' not in mh else {'error': mh['error']}
+    st = result.get('config5_strong')
+    if isinstance(st, dict): out['config5_strong'] = {key: (num(st[key], 5) if isinstance(st.get(key), float) else st.get(key)) for key in ['value', 'unit', 'us_per_update', 'n_gpus', 'sharded'] if key in st}
+    if result.get('gathered_check') is not None: out['gathered_check'] = result['gathered_check']
+    out['record'] = 'compact (the complete record is the line before this one)'
+    return out
 
 
 def free_port():
@@ -975,12 +1050,14 @@ def main():
         dominant = 'theory' if short else max(['theory', 'window_gemm', 'finalize'], key=lambda name: kernel_ms[name])
         kernel_name = {'theory': 'dl_fullshape_kernel', 'window_gemm': 'dl_chi2_gemm_kernel', 'finalize': 'dl_finalize_part_kernel'}[dominant]
         traffic, traffic_source = hbm_traffic(kernel_name) if B == BATCH else (None, None)
+        if traffic_source is not None and not profile_is_current(traffic_source): traffic, traffic_source = None, None      # (a profile of another source tree says nothing about this one: ADVICE r5)
         # the whole step against its algorithmic bytes (fused: theta in, the whitened operand once, three outputs per point): PMC bytes of the step's three kernels
         step_kernels = ['dl_fullshape_kernel', 'dl_chi2_gemm_kernel<true, true, 32', 'dl_finalize_part_kernel']
-        step_traffic = [hbm_traffic(name)[0] for name in step_kernels] if B == BATCH else [None]
+        step_traffic = [hbm_traffic(name)[0] for name in step_kernels] if (B == BATCH and traffic_source is not None) else [None]
         traffic_step = float(sum(step_traffic)) if all(t is not None for t in step_traffic) else None
         algorithmic_bytes = float(B * 6 * 8 + 128 * 1280 * 8 + B * (8 + 8 + 4))
         trace_ms, trace_source = trace_average(kernel_name) if B == BATCH else (None, None)
+        if trace_source is not None and not profile_is_current(trace_source): trace_ms, trace_source = None, None
         per_launch = min(B, 32768)   # batches above 32768 points are evaluated in internal passes of 32768: the kernel intervals are per pass
         achieved = flops[dominant] * per_launch / (kernel_ms[dominant] * 1e-3) / 1e12
         # which unit bounds the dominant kernel: the theory kernel issues no MFMA (fp64 VALU: transcendentals, spline evaluation, projection -- its 78.6 TFLOP/s peak
@@ -996,7 +1073,7 @@ def main():
                   'roofline': {'bound': bound, 'bound_detail': {'theory': 'fp64 VALU (no MFMA in this kernel: transcendentals, spline evaluation, projection); peak = 78.6 TFLOP/s fp64 vector',
                                                                  'window_gemm': 'fp64 MFMA (v_mfma_f64_16x16x4_f64), peak = 78.6 TFLOP/s fp64 matrix', 'finalize': 'launch latency'}[dominant],
                                'kernel': kernel_name, 'achieved': achieved, 'peak': PEAK_FP64_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP64_TFLOPS, 'traffic': traffic,
-                               'traffic_source': traffic_source, 'traffic_step': traffic_step, 'algorithmic_bytes': algorithmic_bytes,
+                               'traffic_source': traffic_source, 'from_committed_profile': traffic_source is not None, 'source_hash': source_hash(), 'traffic_step': traffic_step, 'algorithmic_bytes': algorithmic_bytes,
                                'traffic_step_over_algorithmic': (traffic_step / algorithmic_bytes) if traffic_step is not None else None,
                                'traffic_step_kernels': dict(zip(['theory', 'window_gemm', 'finalize'], step_traffic)) if traffic_step is not None else None,
                                'flop_per_launch': flops[dominant] * per_launch, 'avg_launch_ms': kernel_ms[dominant],
@@ -1035,7 +1112,10 @@ def main():
     if distributed:
         group.barrier()
     if result is not None:
-        print(json.dumps(result), flush=True)
+        # two lines: the complete record (every leg with its workload description, FLOP accounts, latencies), then -- LAST, the line the driver parses and keeps -- the
+        # same headline with every leg reduced to its numbers (< 4 KB: the driver stores a bounded tail of the output)
+        print(json.dumps(dict(result, record='complete')), flush=True)
+        print(json.dumps(compact_line(result)), flush=True)
     if distributed:
         group.barrier()
         group.close()

@@ -13,11 +13,11 @@ the FFTLog grid, linear-in-log high-k tail with Gaussian damping, FFTLog, linear
 P_\ell(k_in), the whole map is one constant matrix per multipole (``hankel_operator``) which the GPU path folds into the window matrix:
 the FFT never runs in the hot loop.
 
-Two engines share the grid constants computed here (Mellin coefficients, low-ringing offset, pre / post factors):
-``engine='hip'`` runs the batched LDS-resident transform of the C ABI (``dl_fftlog_*``, csrc/dl_fftlog.hip: one workgroup per (point, multipole)) --
-this is what the theory classes use to build their operator (all unit vectors of the input grid in ONE batch) and what transforms batches of
-P_ell already resident on the GPU; ``engine='numpy'`` (``numpy.fft``) is the host restatement of the same algorithm kept for the CPU checks
-(tests/test_oracle_bao.py) -- it is never a fallback: ``engine='hip'`` raises without the library or a GPU.
+The transform itself runs on the device: the batched LDS-resident FFTLog of the C ABI (``dl_fftlog_*``, csrc/dl_fftlog.hip: one workgroup per (point, multipole)) --
+what the theory classes use to build their operator (all unit vectors of the input grid in ONE batch) and what transforms batches of P_ell already resident on the
+GPU.  This module holds the grid constants (Mellin coefficients, low-ringing offset, pre / post factors) and the call surface; there is NO host engine here: without the
+library or a GPU every call raises.  The ``numpy.fft`` restatement of the same algorithm that the CPU checks use lives with the oracle (``oracle/np_fftlog.py``, test
+infrastructure: tests/test_oracle_bao.py, tests/test_gpu_fftlog.py).
 """
 import numpy as np
 from scipy import special
@@ -50,9 +50,9 @@ class PowerToCorrelation(object):
     ``k`` must be log-spaced; the input is zero-padded to ``minfolds * N`` points (half on each side) before the transform.
     """
 
-    def __init__(self, k, ell=0, q=0, lowring=True, minfolds=2, engine='numpy', device=None):
-        if engine not in ('numpy', 'hip'):
-            raise ValueError('engine must be "numpy" or "hip"')
+    def __init__(self, k, ell=0, q=0, lowring=True, minfolds=2, engine='hip', device=None):
+        if engine != 'hip':
+            raise ValueError('engine must be "hip": the transform runs on the device (the NumPy restatement is test infrastructure: oracle/np_fftlog.py)')
         self.engine, self.device, self._plan = engine, device, None
         self.k = np.asarray(k, dtype='f8')
         self.ells = np.atleast_1d(ell)
@@ -99,25 +99,14 @@ class PowerToCorrelation(object):
         return self._get_plan().apply(fun, out=out, stream=stream)
 
     def __call__(self, fun):
-        if self.engine == 'hip':
-            import torch
-            plan = self._get_plan()
-            fun = np.asarray(fun, dtype='f8')
-            shape = fun.shape
-            fun = fun.reshape((-1,) + (len(self.ells), self.k.size))
-            xi = plan.apply(torch.as_tensor(fun, dtype=torch.float64, device=torch.device('cuda', plan.device)).contiguous()).cpu().numpy()
-            sl = slice(self.pad, self.pad + self.k.size)
-            return np.array([s[sl] for s in self.s]), xi.reshape(shape)
-        fun = np.atleast_2d(np.asarray(fun, dtype='f8'))
-        s, xi = [], []
-        for ill in range(len(self.ells)):
-            a = np.zeros(self.npad, dtype='f8')
-            a[self.pad:self.pad + self.k.size] = fun[ill] * self.k**1.5
-            A = np.fft.irfft(np.fft.rfft(a) * self.u[ill], self.npad)[::-1]
-            sl = slice(self.pad, self.pad + self.k.size)
-            s.append(self.s[ill][sl])
-            xi.append(self.prefactor[ill] * A[sl] * self.s[ill][sl]**(-1.5))
-        return np.array(s), np.array(xi)
+        import torch
+        plan = self._get_plan()
+        fun = np.asarray(fun, dtype='f8')
+        shape = fun.shape
+        fun = fun.reshape((-1,) + (len(self.ells), self.k.size))
+        xi = plan.apply(torch.as_tensor(fun, dtype=torch.float64, device=torch.device('cuda', plan.device)).contiguous()).cpu().numpy()
+        sl = slice(self.pad, self.pad + self.k.size)
+        return np.array([s[sl] for s in self.s]), xi.reshape(shape)
 
 
 def _interp_to_grid(logk, logkin, pk, interp_order=1):
@@ -129,23 +118,11 @@ def _interp_to_grid(logk, logkin, pk, interp_order=1):
     return interpolate.interp1d(logkin, pk, kind='cubic', fill_value='extrapolate', axis=0)(logk)
 
 
-def correlation_from_power(power, kin, k, logk_high, damp_high, kmask_mid, fftlog, s, interp_order=1):
-    """``get_corr`` of the reference (theories/galaxy_clustering/base.py:127-136)."""
-    tmp = []
-    logkin = np.log10(kin)
-    for pk in power:
-        slope_high = (pk[-1] - pk[-2]) / np.log10(kin[-1] / kin[-2])
-        interp = _interp_to_grid(np.log10(k[kmask_mid]), logkin, pk, interp_order=interp_order)
-        tmp.append(np.concatenate([interp, (pk[-1] + slope_high * logk_high) * damp_high], axis=-1))
-    ss, corr = fftlog(np.vstack(tmp))
-    return np.array([np.interp(s, sss, cc) for sss, cc in zip(ss, corr)])
-
-
-def hankel_operator(kin, s, ells, k=None, engine='numpy', device=None, interp_order=1):
+def hankel_operator(kin, s, ells, k=None, engine='hip', device=None, interp_order=1):
     r"""Matrices H_\ell [len(s), len(kin)] with \xi_\ell(s) = H_\ell P_\ell(k_in), reproducing the reference's ``get_corr`` grids
     (theories/galaxy_clustering/base.py:62-77: k = logspace(-4, 3, 2048), tail beyond kin[-1]).
 
-    ``engine='hip'``: the transforms of all len(kin) unit vectors run as ONE batch of the device FFTLog (``dl_fftlog_apply``).
+    The transforms of all len(kin) unit vectors run as ONE batch of the device FFTLog (``dl_fftlog_apply``; ``engine`` must be 'hip').
     ``interp_order``: 1 (linear) or 3 (cubic) interpolation of P_ell to the FFTLog grid (tgc/base.py:54-57, 132) -- either is linear in P_ell, so it folds
     into the operator."""
     kin = np.asarray(kin, dtype='f8')
@@ -155,27 +132,19 @@ def hankel_operator(kin, s, ells, k=None, engine='numpy', device=None, interp_or
     damp_high = np.exp(-(k[mask] / kin[-1] - 1.)**2 / (2. * (10.)**2))
     fftlog = PowerToCorrelation(k, ell=ells, q=0, lowring=True, engine=engine, device=device)
     nell = len(ells)
-    if engine == 'hip':
-        # interpolation + tail of every unit vector (the same for all multipoles), then one batched transform, then the interpolation to s
-        logkin, logk_mid = np.log10(kin), np.log10(k[~mask])
-        unit = np.zeros(kin.size, dtype='f8')
-        tmp = np.empty((kin.size, k.size), dtype='f8')
-        for i in range(kin.size):
-            unit[i] = 1.
-            slope_high = (unit[-1] - unit[-2]) / np.log10(kin[-1] / kin[-2])
-            tmp[i] = np.concatenate([_interp_to_grid(logk_mid, logkin, unit, interp_order=interp_order), (unit[-1] + slope_high * logk_high) * damp_high])
-            unit[i] = 0.
-        ss, corr = fftlog(np.repeat(tmp[:, None, :], nell, axis=1))     # corr [n_kin, n_ell, N]
-        fftlog.close()   # free the device plan now (a hipFree deferred to the garbage collector would synchronise the device at an arbitrary later time)
-        H = np.empty((nell, len(s), kin.size), dtype='f8')
-        for ill in range(nell):
-            for i in range(kin.size):
-                H[ill, :, i] = np.interp(s, ss[ill], corr[i, ill])
-        return H
-    H = np.zeros((nell, len(s), kin.size), dtype='f8')
-    basis = np.zeros((nell, kin.size), dtype='f8')
+    # interpolation + tail of every unit vector (the same for all multipoles), then one batched transform, then the interpolation to s
+    logkin, logk_mid = np.log10(kin), np.log10(k[~mask])
+    unit = np.zeros(kin.size, dtype='f8')
+    tmp = np.empty((kin.size, k.size), dtype='f8')
     for i in range(kin.size):
-        basis[:, i] = 1.
-        H[:, :, i] = correlation_from_power(basis, kin, k, logk_high, damp_high, ~mask, fftlog, s, interp_order=interp_order)
-        basis[:, i] = 0.
+        unit[i] = 1.
+        slope_high = (unit[-1] - unit[-2]) / np.log10(kin[-1] / kin[-2])
+        tmp[i] = np.concatenate([_interp_to_grid(logk_mid, logkin, unit, interp_order=interp_order), (unit[-1] + slope_high * logk_high) * damp_high])
+        unit[i] = 0.
+    ss, corr = fftlog(np.repeat(tmp[:, None, :], nell, axis=1))     # corr [n_kin, n_ell, N]
+    fftlog.close()   # free the device plan now (a hipFree deferred to the garbage collector would synchronise the device at an arbitrary later time)
+    H = np.empty((nell, len(s), kin.size), dtype='f8')
+    for ill in range(nell):
+        for i in range(kin.size):
+            H[ill, :, i] = np.interp(s, ss[ill], corr[i, ill])
     return H

@@ -72,7 +72,7 @@ def spec_from_golden(g):
 
 def spec_from_golden_bao(g):
     """Spec of a BAO fixture (cfg4_bao_xi / cfg4_bao_pk): wiggle model on the device, Hankel operator and broadband folded into the window."""
-    from desilike_amd.fftlog import hankel_operator
+    from oracle.np_fftlog import hankel_operator      # (the host construction: these specs also feed the CPU tests; the product builds the operator on the device)
     from scipy import linalg
     names = [str(n) for n in g['names']]
     c = g['obs0']

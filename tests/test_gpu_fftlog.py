@@ -1,5 +1,5 @@
 """GPU (-m gpu): the batched device FFTLog (dl_fftlog_*, csrc/dl_fftlog.hip) through the C ABI, against
- (i) the host restatement of the same algorithm with numpy.fft (desilike_amd/fftlog.py, engine='numpy'),
+ (i) the host restatement of the same algorithm with numpy.fft (oracle/np_fftlog.py),
  (ii) the oracle's independent implementation through scipy.fft.fht (oracle/np_oracle.py FFTLogPowerToCorrelation),
  (iii) the Hankel operator the BAO xi_ell path folds into the window, built by one device batch vs built on the host.
 The reference's transform is third-party (cosmoprimo, unpinned): "parity unpinned" for row a11, see oracle/np_oracle.py.
@@ -25,7 +25,8 @@ def test_device_fftlog_vs_host_restatement(n):
     rng = np.random.RandomState(n)
     B = 5
     fun = rng.standard_normal((B, len(ells), n)) * (k / 0.1)**-1.2 * np.exp(-(np.log(k / 0.05) / 3.)**2)
-    host, dev = PowerToCorrelation(k, ell=ells), PowerToCorrelation(k, ell=ells, engine='hip', device=0)
+    from oracle.np_fftlog import PowerToCorrelation as HostPowerToCorrelation
+    host, dev = HostPowerToCorrelation(k, ell=ells), PowerToCorrelation(k, ell=ells, device=0)
     s, xi = dev(fun)
     assert xi.shape == fun.shape
     for b in range(B):
@@ -71,7 +72,8 @@ def test_hankel_operator_device_vs_host():
     from desilike_amd.fftlog import hankel_operator
     g = load_golden('cfg4_bao_xi')
     c = g['obs0']
-    Hd, Hh = hankel_operator(c['kin'], c['s'], (0, 2), engine='hip', device=0), hankel_operator(c['kin'], c['s'], (0, 2))
+    from oracle.np_fftlog import hankel_operator as host_hankel_operator
+    Hd, Hh = hankel_operator(c['kin'], c['s'], (0, 2), device=0), host_hankel_operator(c['kin'], c['s'], (0, 2))
     # entries far below the largest one carry the FFT's rounding noise (relative to the transform's maximum, in either implementation)
     assert np.allclose(Hd, Hh, rtol=1e-9, atol=1e-13 * np.abs(Hh).max())
     ref = orc.get_corr(g['wiggle_power'][0], c['kin'], c['s'], (0, 2))

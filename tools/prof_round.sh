@@ -7,6 +7,8 @@ R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 [ -f "$R/bench.py" ] || { echo "prof_round.sh: $R is not the repository root" >&2; exit 1; }
 OUT="$R/gpurun_out/$TAG"
 mkdir -p "$OUT"
+# the kernel sources these summaries belong to (bench.py::source_hash: figures copied from a committed profile enter the bench line only when this matches the running tree)
+python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.source_hash())" > $OUT/${TAG}_source_hash.txt
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 timeout 300 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_steps20.json 2>> $OUT/${TAG}_bench.err     # the driver's command
