@@ -39,6 +39,7 @@ struct dl_ctx {
     int32_t* gemm_counters = nullptr;// [<= 2048 / 32 + 8] arrival counters of the fused chi2 GEMM finalize (zero between launches)
     int32_t* step_ready = nullptr;   // [32 + 8] arrival counters of the row blocks' producers in dl_step_kernel (zero between launches); behind gemm_counters in one allocation
     double* wt_white_dev = nullptr;  // [N_pad, K_pad]  L^T . blockdiag(W_obs)          (chi2 path)
+    double* wt_frag_dev = nullptr;   // the same in MFMA fragment order [N_pad / 16][K_pad / 4][64]: k-step ks of column block nt, lane l = W~[16 nt + (l & 15)][4 ks + (l >> 4)] (dl_chi2_gemm_tile_bf)
     std::vector<uint8_t> panel_ranges;   // [N_pad / 16][2]: 128-wide K panels of wt_white with non-zero entries per 16-row column block (chi2 GEMM skips the others)
     double* bias_white_dev = nullptr;// [N_pad]         L^T . (bias - flatdata)
     double* wt_full_dev = nullptr;   // [N_pad, K_pad]  blockdiag(W_obs)                 (flattheory path)
@@ -445,6 +446,15 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
         if (hipMalloc((void**)&ctx->gemm_counters, nbytes) != hipSuccess || hipMemset(ctx->gemm_counters, 0, nbytes) != hipSuccess) { dl_fail(ctx, "dl_create: counter allocation failed"); dl_destroy(ctx); return 1; }
         ctx->step_ready = ctx->gemm_counters + (16384 / 32 + 8);
     }
+    {   // W~ in MFMA fragment order for the chi2 GEMM (window.py:459-473 + likelihoods/base.py:13-17 folded: the constant operand streams straight into registers)
+        std::vector<double> frag((size_t)ctx->N_pad * ctx->K_pad);
+        const int nks = ctx->K_pad / 4;
+        for (int nt = 0; nt < ctx->N_pad / 16; ++nt)
+            for (int ks = 0; ks < nks; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    frag[((size_t)nt * nks + ks) * 64 + lane] = wt_white[(size_t)(16 * nt + (lane & 15)) * ctx->K_pad + 4 * ks + (lane >> 4)];
+        if (dl_upload(ctx, &ctx->wt_frag_dev, frag)) { dl_destroy(ctx); return 1; }
+    }
     if (dl_upload(ctx, &ctx->priors_dev, priors) || dl_upload(ctx, &ctx->wt_white_dev, wt_white) ||
         dl_upload(ctx, &ctx->bias_white_dev, bias_white) || dl_upload(ctx, &ctx->wt_full_dev, wt_full) || dl_upload(ctx, &ctx->bias_full_dev, bias_full) ||
         dl_upload(ctx, &ctx->wh_dev, wh) || dl_upload(ctx, &ctx->bias_wh_dev, bias_wh) || dl_upload(ctx, &ctx->flatdata_dev, flatdata) ||
@@ -462,7 +472,7 @@ void dl_destroy(dl_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (double* p : {ctx->grad_wtT, ctx->grad_zero, ctx->grad_delta, ctx->grad_y, ctx->grad_phys}) if (p) (void)hipFree(p);
     if (ctx->grad_status) (void)hipFree(ctx->grad_status);
-    void* ptrs[] = {ctx->arena_dev, ctx->priors_dev, ctx->wt_white_dev, ctx->bias_white_dev, ctx->wt_full_dev, ctx->bias_full_dev, ctx->wh_dev,
+    void* ptrs[] = {ctx->arena_dev, ctx->priors_dev, ctx->wt_white_dev, ctx->wt_frag_dev, ctx->bias_white_dev, ctx->wt_full_dev, ctx->bias_full_dev, ctx->wh_dev,
                     ctx->bias_wh_dev, ctx->flatdata_dev, ctx->transform_dev, ctx->tconst_dev, ctx->power_ws, ctx->delta_ws, ctx->flat_ws, ctx->stencil_ws, ctx->theta_stage, ctx->out_stage,
                     ctx->status_stage, ctx->gemm_counters, ctx->obs_array_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -643,7 +653,7 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
             dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad,
                                 chi2_fused ? ctx->gemm_counters : nullptr, th, P, ctx->priors_dev, loglike_dev ? loglike_dev + b0 : nullptr,
                                 logprior_dev ? logprior_dev + b0 : nullptr, status_dev ? status_dev + b0 : nullptr, post_mode, stream,
-                                ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live);
+                                ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live, nullptr, 0, ctx->wt_frag_dev);
         } else if (chi2_big) {
             dl_launch_window_gemm_dma_chi2(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, nb, ctx->N_pad, ctx->K_pad, stream, ctx->n_white);
             part_tiles = dl_gemm_dma_chi2_parts(ctx->N_pad);
@@ -802,7 +812,7 @@ int dl_eval_logposterior_grad(dl_ctx* ctx, const double* theta_dev, int64_t B, d
         int32_t* st = status_dev ? status_dev + b0 : ctx->grad_status;      // (the gradient's finalize needs the status whether the caller wants it or not)
         dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, nullptr, 0, xcd_local ? dl_chi2_gemm_row_tile(nb, Np) : 0, ctx->obs_array_dev);
         dl_launch_chi2_gemm(ctx->power_ws, Kp, ctx->wt_white_dev, Kp, ctx->bias_white_dev, ctx->delta_ws, nb, Np, Kp, nullptr, th, P, ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream,
-                            ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live, ctx->grad_delta, Np);
+                            ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live, ctx->grad_delta, Np, ctx->wt_frag_dev);
         dl_launch_finalize_part(ctx->delta_ws, Np / 16, th, P, ctx->priors_dev, nb, logposterior_dev + b0, nullptr, st, 1, stream);
         // Y = -d~ W~: [nb, N_pad] x [N_pad, K_pad] through the LDS-DMA tiled GEMM, one split (K = N_pad: 4 panels), no bias
         dl_launch_window_gemm_tiled(ctx->grad_delta, Np, ctx->grad_wtT, Np, ctx->grad_y, 0, Kp, nb, Kp, Np, 1, Np / 16, stream, 0);
@@ -1100,7 +1110,7 @@ int dl_internal_eval_fold(dl_ctx* ctx, const DlEnsFold& fold, int64_t B, double*
     const int xcd_local = dl_options().xcd_local;
     if (!dl_launch_fullshape_ens(ctx->obs_kernarg.data(), ctx->n_obs, ctx->obs_array_dev, fold, B, ctx->power_ws, ctx->K_pad, xcd_local ? dl_chi2_gemm_row_tile(B, ctx->N_pad) : 0, stream)) return 2;
     dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, part_out, B, ctx->N_pad, ctx->K_pad, nullptr, nullptr, ctx->n_params,
-                        ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream, ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live);
+                        ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream, ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live, nullptr, 0, ctx->wt_frag_dev);
     DL_HIP_CHECK(ctx, hipGetLastError());
     return 0;
 }
@@ -1117,7 +1127,7 @@ int dl_internal_eval_partials(dl_ctx* ctx, const double* theta_dev, int64_t B, c
     const int xcd_local = dl_options().xcd_local;
     dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, theta_dev, ctx->n_params, B, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, nullptr, 0, xcd_local ? dl_chi2_gemm_row_tile(B, ctx->N_pad) : 0, ctx->obs_array_dev);
     dl_launch_chi2_gemm(ctx->power_ws, ctx->K_pad, ctx->wt_white_dev, ctx->K_pad, ctx->bias_white_dev, ctx->delta_ws, B, ctx->N_pad, ctx->K_pad, nullptr, theta_dev, ctx->n_params,
-                        ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream, ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live);
+                        ctx->priors_dev, nullptr, nullptr, nullptr, 1, stream, ctx->panel_ranges.empty() ? nullptr : ctx->panel_ranges.data(), ctx->K_live, nullptr, 0, ctx->wt_frag_dev);
     *part = ctx->delta_ws;
     *n_tiles = ctx->N_pad / 16;
     *priors = ctx->priors_dev;

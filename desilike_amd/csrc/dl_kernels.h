@@ -21,6 +21,7 @@ extern thread_local DlProfEvents dl_prof_events;
 // at first use, into this table; nothing on the per-call path calls getenv.  dl_options_refresh() (C ABI; the tests flip switches inside one process) re-reads the environment.
 struct DlOptions {
     bool no_merged_theory, no_emu_batch, no_fused_solve, no_gram_plain, no_scaled_row0, ef_no_early_theta, fm_no_lane_solve;
+    bool chi2_bfrag;                    // DL_CHI2_BFRAG=1: the chi2 GEMM with its B operand in registers (dl_chi2_gemm_tile_bf: round-6 experiment, measured slower; docs/EXPERIMENTS.md)
     int stk_overlap;                    // DL_STK_OVERLAP: the stacked engine on dl_emulated_stacked_ov_kernel where the shape allows (round-6 experiment, slower: docs/EXPERIMENTS.md):
                                         // 1 networks of the next batch under the feature GEMM (+2: without raised priority), 4 the two halves of the workgroup on half of the networks each
     bool ens_global, ens_force_comm, ens_no_defer, ens_no_fold, ens_stamps, ens_fold_stamps;
@@ -71,7 +72,7 @@ void dl_launch_finalize(const double* dtilde, int64_t ld, int n, int n_slabs, in
 int dl_chi2_gemm_row_tile(int64_t M, int N_pad);   // 32 or 16: rows per workgroup the chi2 GEMM will use for a batch of M points (the theory kernel deals the points to the XCDs accordingly)
 void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, int32_t* counters,
                          const double* theta, int n_params, const double* priors, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream,
-                         const uint8_t* panel_ranges = nullptr, int k_live = 0, double* resid = nullptr, int64_t ldr = 0);   // resid [M, ldr]: the residual rows themselves, also written (may be null); panel_ranges [N_pad / 16][2]: 128-wide K panels [lo, hi) with non-zero Wt entries per column block (host array), or null
+                         const uint8_t* panel_ranges = nullptr, int k_live = 0, double* resid = nullptr, int64_t ldr = 0, const double* wfrag = nullptr);   // wfrag: Wt in MFMA fragment order [N_pad / 16][K_pad / 4][64] (dl_chi2_gemm_tile_bf, taken under DL_CHI2_BFRAG=1 only: the B operand in registers -- measured slower than both operands through LDS); resid [M, ldr]: the residual rows themselves, also written (may be null); panel_ranges [N_pad / 16][2]: 128-wide K panels [lo, hi) with non-zero Wt entries per column block (host array), or null
 void dl_launch_finalize_part(const double* part, int n_tiles, const double* theta, int n_params, const double* priors, int64_t B, double* loglike, double* logprior,
                              int32_t* status, int post_mode, hipStream_t stream);
 #ifndef DL_FG_NM

@@ -61,7 +61,7 @@ static void dl_options_read() {
     o.host_mode = std::getenv("DL_HOST_MODE") ? atoi(std::getenv("DL_HOST_MODE")) : -1;
     auto flag = [](const char* name) { const char* v = std::getenv(name); return v != nullptr && atoi(v) != 0; };
     o.no_emu_fused = on("DL_NO_EMU_FUSED"); o.no_gram_epilogue = on("DL_NO_GRAM_EPILOGUE"); o.no_chi2_big = on("DL_NO_CHI2_BIG");
-    o.step_kernel = flag("DL_STEP_KERNEL"); o.chi2_fused = flag("DL_CHI2_FUSED");
+    o.step_kernel = flag("DL_STEP_KERNEL"); o.chi2_fused = flag("DL_CHI2_FUSED"); o.chi2_bfrag = flag("DL_CHI2_BFRAG");
     o.xcd_local = std::getenv("DL_XCD_LOCAL") ? atoi(std::getenv("DL_XCD_LOCAL")) : 1;
     o.chi2_max_rows = std::getenv("DL_CHI2_GEMM_MAX") ? atoll(std::getenv("DL_CHI2_GEMM_MAX")) : 2048;
 }
@@ -1039,7 +1039,7 @@ int dl_chi2_gemm_row_tile(int64_t M, int N_pad) {
 
 void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t ldw, const double* bias, double* part, int64_t M, int N_pad, int K_pad, int32_t* counters,
                          const double* theta, int n_params, const double* priors, double* loglike, double* logprior, int32_t* status, int post_mode, hipStream_t stream,
-                         const uint8_t* panel_ranges, int k_live, double* resid, int64_t ldr) {
+                         const uint8_t* panel_ranges, int k_live, double* resid, int64_t ldr, const double* wfrag) {
     const int n_tiles = N_pad / DL_CG_N;
     const int mt = counters == nullptr ? dl_chi2_gemm_row_tile(M, N_pad) : DL_CG_M;   // (the experimental fused finalize counts 32-row blocks)
     const int64_t mblocks = (M + mt - 1) / mt;
@@ -1066,7 +1066,23 @@ void dl_launch_chi2_gemm(const double* A, int64_t lda, const double* Wt, int64_t
     if (panel_ranges != nullptr && n_tiles <= DL_CG_MAX_TILES)
         for (int t = 0; t < n_tiles; ++t) panels.range[t] = (uint32_t)panel_ranges[2 * t] | ((uint32_t)panel_ranges[2 * t + 1] << 8);
     double* const no_resid = nullptr;
-    if (resid != nullptr) {
+    int max_live = K_pad / DL_CG_KP;      // live panels of the widest column block
+    if (panel_ranges != nullptr && n_tiles <= DL_CG_MAX_TILES) {
+        max_live = 0;
+        for (int t = 0; t < n_tiles; ++t) max_live = std::max(max_live, panel_ranges[2 * t + 1] != 0 ? (int)panel_ranges[2 * t + 1] - (int)panel_ranges[2 * t] : K_pad / DL_CG_KP);
+    }
+    if (wfrag != nullptr && dl_options().chi2_bfrag && max_live <= DL_CG_PMAX) {
+        // the B operand in fragment order straight into registers: LDS holds the rows of A only (dl_chi2_gemm_tile_bf)
+        const int kl = k_live > 0 ? k_live : K_pad;
+        // (three panel buffers of mt rows; at least the reduction area of the tile's end: [waves][2][4][64] doubles)
+        const size_t shm = std::max((size_t)DL_CG_NBUF * mt * DL_CG_LD * 8, (size_t)DL_CG_WAVES * 2 * 4 * 64 * 8);
+        auto go = [&](auto kernel, double* rs, int64_t lr) {
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            DL_LAUNCH(kernel, dim3(grid), dim3(64 * DL_CG_WAVES), shm, stream, A, lda, wfrag, bias, part, (int)M, K_pad, n_tiles, fin, panels, kl, rs, lr);
+        };
+        if (resid != nullptr) { if (mt == 16) go(dl_chi2_gemm_bf_kernel<true, true, 16, true>, resid, ldr); else go(dl_chi2_gemm_bf_kernel<true, true, DL_CG_M, true>, resid, ldr); }
+        else { if (mt == 16) go(dl_chi2_gemm_bf_kernel<true, true, 16, false>, no_resid, (int64_t)0); else go(dl_chi2_gemm_bf_kernel<true, true, DL_CG_M, false>, no_resid, (int64_t)0); }
+    } else if (resid != nullptr) {
         if (mt == 16) DL_LAUNCH((dl_chi2_gemm_kernel<true, true, 16, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_NBUF * (16 + DL_CG_N) * DL_CG_LD * 8, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad, resid, ldr);
         else DL_LAUNCH((dl_chi2_gemm_kernel<true, true, DL_CG_M, true>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_LDS_BYTES, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad, resid, ldr);
     } else if (mt == 16) DL_LAUNCH((dl_chi2_gemm_kernel<true, true, 16>), dim3(grid), dim3(64 * DL_CG_WAVES), DL_CG_NBUF * (16 + DL_CG_N) * DL_CG_LD * 8, stream, A, lda, Wt, ldw, bias, part, (int)M, K_pad, n_tiles, fin, panels, k_live > 0 ? k_live : K_pad, no_resid, (int64_t)0);

@@ -22,6 +22,7 @@ SWITCHES = [({}, 'fs two ens emu bao tns png mh stk'),
             ({'DL_CHI2_GEMM_MAX': '512', 'DL_NO_CHI2_BIG': '1', 'DL_GEMM_WGS': '96'}, 'fs'),
             ({'DL_CHI2_GEMM_MAX': '4096'}, 'fs'),                                        # 2537 rows through the chi2 GEMM
             ({'DL_CG_MT': '16'}, 'fs two'), ({'DL_CG_MT': '32'}, 'fs two'),
+            ({'DL_CHI2_BFRAG': '1'}, 'fs two ens mh'), ({'DL_CHI2_BFRAG': '1', 'DL_CG_MT': '16'}, 'fs two'),      # the chi2 GEMM with its B operand in registers (dl_chi2_gemm_tile_bf: round-6 experiment, measured slower, kept for the record)
             ({'DL_CHI2_FUSED': '1'}, 'fs'),
             ({'DL_STEP_KERNEL': '1'}, 'fs'),                                              # theory + chi2 GEMM + finalize of <= 1024 points in ONE launch (dl_step_kernel: measured slower, kept for the record)
             ({'DL_FS_DENSE_MIN': '256'}, 'fs two'), ({'DL_FS_DENSE_MIN': '1000000'}, 'fs'),
