@@ -567,12 +567,36 @@ def extract_config(likelihood):
         names.update({param.basename: param.name for param in pt.all_params})
         # pass-through columns appended to the theory vector: broadband terms of the BAO classes (bao.py:495-534, 881-905), in the order of the multipoles
         pass_names, pass_matrix = [], None
+        resummed = flexible = False
         if bao:
-            if pt.model != 'standard':
-                raise NotImplementedError('wiggle model {}: this binding covers the standard one (the library has them all: desilike_amd/theories/galaxy_clustering/bao.py)'.format(pt.model))
+            # wiggle model (include/desilike_amd.h, obs<i>.bao_mode bits 4-8): 'standard' (bao.py:123-136); 8 | fix-damping 1 | move-all 2 | fog-damping 4 (137-150);
+            # 16 | move-all | fog-damping: resummed wiggles (165-266); 32 | move-all: flexible wiggles (269-391)
+            clsname, model = type(pt).__name__, str(getattr(pt, 'model', 'standard'))
+            resummed, flexible = clsname.startswith('ResummedBAO'), clsname.startswith('FlexibleBAO')
+            bits = 0
+            if flexible: bits = 32 | (2 if 'move-all' in model else 0)
+            elif resummed: bits = 16 | (2 if 'move-all' in model else 0) | (4 if 'fog-damping' in model else 0)
+            elif model != 'standard':
+                if any(word not in ('fix-damping', 'move-all', 'fog-damping') for word in model.replace('_', ' ').split()):
+                    raise NotImplementedError('wiggle model {}: standard, fix-damping, move-all, fog-damping and their combinations are covered'.format(model))
+                bits = 8 | (1 if 'fix-damping' in model else 0) | (2 if 'move-all' in model else 0) | (4 if 'fog-damping' in model else 0)
             cfg[p + 'pknow_dd_fid'] = np.asarray(template.pknow_dd_fid, dtype='f8')
-            cfg[p + 'bao_mode'] = np.array([1 if pt.mode == 'reciso' else 0], dtype='i4')
+            cfg[p + 'bao_mode'] = np.array([(1 if pt.mode == 'reciso' else 0) | (bits << 4)], dtype='i4')
             cfg[p + 'smoothing_radius'] = np.array([pt.smoothing_radius], dtype='f8')
+            if resummed:      # damping scales of the resummed wiggles: constants of the (fixed) BAO template, set by ResummedPowerSpectrumWiggles.calculate (bao.py:186-199)
+                wig = pt.wiggles
+                if not _has(wig, 'sigma_dd2'): wig()      # (reading parameter collections above re-initialises calculators: their cached state is gone until the next calculation)
+                cfg[p + 'resummed'] = np.array([wig.sigma_dd2, wig.sigma_nl2, getattr(wig, 'sigma_x2', 0.), wig.shotnoise * wig.sigma_sn2], dtype='f8')
+            if flexible:      # multiplicative terms ml{ell}_{i}: kernels K_i(k), the multipole each multiplies, L_ell(mu) (bao.py:337-367)
+                from scipy import special
+                ml_names, ml_rows, ml_ell = [], [], []
+                for ill, ell in enumerate(pt.ells):
+                    for name, row in zip(pt.wiggles_orders[ell], np.asarray(pt.wiggles_matrix[ell], dtype='f8').reshape(len(pt.wiggles_orders[ell]), -1)):
+                        ml_names.append(names.get(name, name)); ml_rows.append(row); ml_ell.append(ill)
+                cfg[p + 'ml_matrix'] = np.array(ml_rows, dtype='f8').reshape(len(ml_names), len(pt.k))
+                cfg[p + 'ml_ell'] = np.array(ml_ell, dtype='i4')
+                cfg[p + 'legendre'] = np.array([special.legendre(ell)(np.asarray(pt.mu, dtype='f8')) for ell in pt.ells], dtype='f8')
+                cfg[p + 'in.ml'] = np.array([column(name, value_of(name, 0.)) for name in ml_names], dtype='f8')
             pass_names = [name for ell in theory.ells for name in theory.broadband_orders[ell]]
             nx = len(theory.s) if xi else len(theory.k)
             pass_matrix = np.zeros((len(theory.ells), nx, len(pass_names)), dtype='f8')
@@ -580,11 +604,28 @@ def extract_config(likelihood):
                 for name, row in zip(theory.broadband_orders[ell], np.asarray(theory.broadband_matrix[ell])):
                     pass_matrix[ill, :, pass_names.index(name)] = row
             pass_matrix = pass_matrix.reshape(-1, len(pass_names))
+            if xi and ptheory is not theory and _has(ptheory, 'broadband_orders'):
+                # kernel broadbands of a correlation function (bao.py:859-861, 'pcs2' ...): the power spectrum class under the Hankel transform carries the Fourier-space kernels
+                # al*, the correlation function class adds the powers of s bl* -- the kernels' columns are their Hankel transforms
+                hankel = hankel_operator(theory)
+                knames = [name for ell in ptheory.ells for name in ptheory.broadband_orders[ell]]
+                kmat = np.zeros((len(theory.ells), nx, len(knames)), dtype='f8')
+                for ill, ell in enumerate(ptheory.ells):
+                    for name, row in zip(ptheory.broadband_orders[ell], np.asarray(ptheory.broadband_matrix[ell], dtype='f8')):
+                        kmat[ill, :, knames.index(name)] = hankel[ill].dot(row)
+                pass_names, pass_matrix = knames + pass_names, np.hstack([kmat.reshape(-1, len(knames)), pass_matrix])
             pass_names = [names.get(name, name) for name in pass_names]
+        xi_apply = None
         if xi:
-            if getattr(wm, 'matrix_full', None) is not None or getattr(wm, 'smask', None) is not None:
-                raise NotImplementedError('binned / masked correlation function windows: fold wm.matrix_full into the operator like the power spectrum branch does')
             window = _block_diag(list(hankel_operator(theory)))
+            if any(getattr(wm, name, None) is not None for name in ['matrix_full', 'matrix_diag', 'smask', 'offset']):
+                # binned / masked / fiber-collided correlation function windows (window.py:717-733): ``_apply`` is affine in the theory multipoles [n_ellin, n_sin] -- its
+                # linear part, column by column, folds into the operator; its constant part is the offset
+                nin = (len(theory.ells), len(theory.s))
+                zero = np.asarray(wm._apply(np.zeros(nin, dtype='f8')), dtype='f8')
+                xi_apply = lambda flat: np.asarray(wm._apply(np.asarray(flat, dtype='f8').reshape(nin)), dtype='f8') - zero      # noqa: E731
+                window = np.column_stack([xi_apply(window[:, j]) for j in range(window.shape[1])])
+                if np.any(zero != 0.): cfg[p + 'offset'] = zero
         else:
             window = None if wm.matrix_full is None else np.asarray(wm.matrix_full, dtype='f8')
             if getattr(wm, 'kmask', None) is not None: cfg[p + 'kmask'] = np.asarray(wm.kmask, dtype='i4')
@@ -592,6 +633,7 @@ def extract_config(likelihood):
             cfg[p + 'shotnoise_in'], cfg[p + 'shotnoise_out'] = np.asarray(wm.shotnoisein, dtype='f8'), np.asarray(wm.shotnoiseout, dtype='f8')
         if pass_names:
             if window is None: window = np.eye(pass_matrix.shape[0])
+            if xi and xi_apply is not None: pass_matrix = np.column_stack([xi_apply(pass_matrix[:, j]) for j in range(pass_matrix.shape[1])])   # (the broadband terms go through the window too)
             window = np.hstack([window, window.dot(pass_matrix) if not xi else pass_matrix])
             cfg[p + 'in.pass'] = np.array([column(name, value_of(name, 0.)) for name in pass_names], dtype='f8')
         if window is not None: cfg[p + 'wmatrix'] = window
@@ -610,6 +652,7 @@ def extract_config(likelihood):
             cfg[p + 'in.band'] = np.array([column(name, value_of(name, 1.)) for name in band_names], dtype='f8')
         if bao: defaults.update(dbeta=1., sigmas=0.)
         else: defaults.update(sn0=0.)
+        if resummed: names.setdefault('dres', names.get('d', 'd')); defaults.update(dres=1.)      # (growth rescaling `d` of the resummed wiggles, bao.py:201: the key's name is dres)
         if xi and not bao: defaults.pop('sn0')                             # no stochastic parameter for correlation functions (full_shape.py:336-364)
         for key, default in defaults.items():
             pname = names.get(key, key)

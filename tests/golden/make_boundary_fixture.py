@@ -375,6 +375,67 @@ def main():
         A = rng.standard_normal((n, n)) * scale
         return ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + (10. * scale)**2 * np.eye(n))
 
+    # (4b) VERDICT r5 item 6: the wiggle models beyond 'standard' and the binned correlation-function window through the binding
+    def bao_models(kind):
+        from desilike.theories.galaxy_clustering import (ResummedBAOWigglesTracerPowerSpectrumMultipoles, ResummedBAOWigglesTracerCorrelationFunctionMultipoles,
+                                                         FlexibleBAOWigglesTracerPowerSpectrumMultipoles, FlexibleBAOWigglesTracerCorrelationFunctionMultipoles)
+        template = BAOPowerSpectrumTemplate(z=0.5)
+        pk = dict(kedges=np.linspace(0.02, 0.3, 57), ells=(0, 2), wmatrix={'resolution': 3})
+        if kind == 'resummed':       # bao.py:165-266: reciso reconstruction, shot-noise damping, growth rescaling d varied
+            theory = ResummedBAOWigglesTracerPowerSpectrumMultipoles(template=template, mode='reciso', model='standard')
+            theory.init.params['d'].update(fixed=False)
+            obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, theory=theory, shotnoise=3e3, **pk)
+            n, scale = 112, 30.
+        elif kind == 'resummed_xi':  # bao.py:1051-1096: recsym, Beutler-like smooth part, every scale moved; binned separations (window.py:536-733)
+            theory = ResummedBAOWigglesTracerCorrelationFunctionMultipoles(template=template, mode='recsym', model='fog-damping_move-all')
+            obs = TracerCorrelationFunctionMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, sedges=np.linspace(20., 170., 31), wmatrix={'resolution': 2}, ells=(0, 2), theory=theory)
+            n, scale = 60, 3e-4
+        elif kind == 'flexible':     # bao.py:269-391: 'pcs' nodes multiplying the wiggles
+            theory = FlexibleBAOWigglesTracerPowerSpectrumMultipoles(template=template, mode='reciso', model='standard', wiggles='pcs')
+            obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2.}, theory=theory, **pk)
+            n, scale = 112, 30.
+        elif kind == 'models':       # bao.py:137-150: Beutler 2016 with every scale moved
+            theory = DampedBAOWigglesTracerPowerSpectrumMultipoles(template=template, mode='recsym', model='fog-damping_move-all')
+            obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, theory=theory, **pk)
+            for name in ['sigmapar', 'sigmaper']: theory.init.params[name].update(fixed=False, ref=dict(dist='norm', loc=8., scale=0.5))
+            n, scale = 112, 30.
+        for param in theory.init.params.select(basename='al*'):
+            if kind != 'resummed_xi': param.update(fixed=True)
+        for param in theory.init.params.select(basename='ml*'):
+            param.update(ref=dict(limits=[-0.3, 0.3]))
+        rng = np.random.RandomState(4)
+        A = rng.standard_normal((n, n)) * scale
+        return ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + (10. * scale)**2 * np.eye(n))
+
+    def bao_kernels(space):      # kernel broadbands (bao.py:468-523, 833-905): 'pcs' nodes for P_ell; for xi_ell the same kernels Hankel-transformed + powers of s ('pcs2')
+        template = BAOPowerSpectrumTemplate(z=0.5)
+        if space == 'xi':
+            theory = DampedBAOWigglesTracerCorrelationFunctionMultipoles(template=template, mode='recsym', broadband='pcs2')
+            obs = TracerCorrelationFunctionMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, s=np.linspace(22.5, 167.5, 30), ells=(0, 2), theory=theory)
+            n, scale = 60, 3e-4
+        else:
+            theory = DampedBAOWigglesTracerPowerSpectrumMultipoles(template=template, broadband='pcs')
+            obs = TracerPowerSpectrumMultipolesObservable(data={'b1': 2., 'sigmas': 2.}, kedges=np.linspace(0.02, 0.3, 57), ells=(0, 2), wmatrix={'resolution': 3}, theory=theory)
+            n, scale = 112, 30.
+        rng = np.random.RandomState(4)
+        A = rng.standard_normal((n, n)) * scale
+        return ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + (10. * scale)**2 * np.eye(n))
+
+    dump('cfg4_pk_pcs', lambda: bao_kernels('pk'), size=24, seed=71)
+    dump('cfg4_xi_pcs2', lambda: bao_kernels('xi'), size=24, seed=73)
+    dump('cfg4_resummed', lambda: bao_models('resummed'), size=24, seed=61)
+    dump('cfg4_resummed_xi_binned', lambda: bao_models('resummed_xi'), size=24, seed=63)
+    dump('cfg4_flexible', lambda: bao_models('flexible'), size=24, seed=65)
+    dump('cfg4_models', lambda: bao_models('models'), size=24, seed=67)
+    def xi_binned():   # Kaiser xi_ell through the bin-integration window (window.py:536-733) with scale cuts that differ per multipole
+        theory = KaiserTracerCorrelationFunctionMultipoles(template=ShapeFitPowerSpectrumTemplate(z=0.5))
+        obs = TracerCorrelationFunctionMultipolesObservable(data={'b1': 2.}, slim={0: (25., 165., 5.), 2: (40., 150., 5.)}, wmatrix={'resolution': 2}, theory=theory)
+        n = 28 + 22
+        rng = np.random.RandomState(24)
+        A = rng.standard_normal((n, n)) * 3e-4
+        return ObservablesGaussianLikelihood(observables=[obs], covariance=A.dot(A.T) + (3e-3)**2 * np.eye(n))
+
+    dump('xi_binned', xi_binned, size=24, seed=69)
     dump('cfg4_xi', lambda: bao_likelihood('xi'), size=24, seed=9)
     dump('cfg4_pk', lambda: bao_likelihood('pk'), size=24, seed=9)
     # (5) the DESI-style BAO fit: every broadband term solved analytically

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(ROOT, 'integration'))
 
-FIXTURES = ['cfg2_dense', 'two_tracers', 'eft_qisoqap', 'cfg4_xi', 'cfg4_pk', 'kaiser_xi', 'tns', 'tns_eft', 'png', 'turnover', 'bands', 'png_velocity', 'cfg3', 'cfg3_taylor', 'cfg3_taylor_standard', 'cfg3_stacked', 'cfg3_stacked_ongrid', 'cfg3_stacked_lpt']     # cfg3_stacked*: the emulator layout the reference ships (emulators/conversion.py:44-98) under its REPT tracer; cfg4_*: BASELINE configs[3] (damped BAO); *_xi: the reference's own get_corr as a folded operator; tns*: the reference's one-loop TNS theory (tests/golden/make_tns_fixture.py)
+FIXTURES = ['cfg2_dense', 'two_tracers', 'eft_qisoqap', 'cfg4_xi', 'cfg4_pk', 'cfg4_resummed', 'cfg4_resummed_xi_binned', 'cfg4_flexible', 'cfg4_models', 'xi_binned', 'cfg4_pk_pcs', 'cfg4_xi_pcs2', 'kaiser_xi', 'tns', 'tns_eft', 'png', 'turnover', 'bands', 'png_velocity', 'cfg3', 'cfg3_taylor', 'cfg3_taylor_standard', 'cfg3_stacked', 'cfg3_stacked_ongrid', 'cfg3_stacked_lpt']     # cfg3_stacked*: the emulator layout the reference ships (emulators/conversion.py:44-98) under its REPT tracer; cfg4_*: BASELINE configs[3] (damped BAO); *_xi: the reference's own get_corr as a folded operator; tns*: the reference's one-loop TNS theory (tests/golden/make_tns_fixture.py)
 MARG_FIXTURES = ['cfg4_xi_marg', 'two_tracers_marg', 'cfg3_marg', 'two_tracers_mixed', 'cfg3_taylor_marg', 'cfg3_stacked_marg', 'cfg3_stacked_lpt_marg', 'cfg3_stacked_bench']                                     # analytically solved parameters ('.marg'); cfg3*: BASELINE configs[2], the reference's
 # velocileptors tracer on a real EmulatedCalculator node (MLP 6 -> 4 x 64 -> 7296 / Taylor engines) built by the reference's own Emulator.to_calculator
 
