@@ -76,7 +76,8 @@ __device__ __forceinline__ int dl_fs_point_of_wg(int wg, int xblk) { return xblk
 
 // SUB: the point is evaluated by a 256-thread SUB-GROUP of a larger workgroup (dl_step_kernel: four points per 1024-thread workgroup): `lds_sub`, `tid_sub`, `b_sub` name its
 // share of LDS, the thread's index in the sub-group and the point; every sub-group runs the same sequence of barriers (the branches between them are uniform in the observable).
-template <bool FAST, int NL, bool EFT, bool DENSE, bool TH_ROW = false, bool SUB = false>
+// NT: threads of the point's workgroup (DL_FS_THREADS; the wide form of small batches, dl_fullshape_wide_kernel, runs a point on 512: every phase strides by the thread count)
+template <bool FAST, int NL, bool EFT, bool DENSE, bool TH_ROW = false, bool SUB = false, int NT = DL_FS_THREADS>
 __device__ __forceinline__ void dl_fullshape_body(const DlObsDev& o, const double* __restrict__ theta, int n_params, double* __restrict__ power,
                                                   int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after, unsigned long long* __restrict__ stamps,
                                                   const double* th_row = nullptr,     // th_row: the point's parameters already in LDS (dl_fullshape_ens_kernel)
@@ -96,7 +97,7 @@ __device__ __forceinline__ void dl_fullshape_body(const DlObsDev& o, const doubl
     const bool toep = !o.fixed_spline && (FAST || o.toeplitz);
     const DlFsShared s = dl_fs_shared_carve(lds, o.n_t, o.n_in, dl_fs_n_dd0(o), toep);
     const double* th = TH_ROW ? th_row : theta + (size_t)b * n_params;
-    const int tid = SUB ? tid_sub : (int)threadIdx.x, nthr = DL_FS_THREADS;
+    const int tid = SUB ? tid_sub : (int)threadIdx.x, nthr = NT;
     if (stop_after == -1) return;  // stop_after != 0: timing diagnostics only (DL_FS_STOP), outputs are then incomplete
     // constants of the later phases are requested now: their round trip hides behind phase 0/1
     double lk_pref[DL_P3_PREF];
@@ -105,7 +106,7 @@ __device__ __forceinline__ void dl_fullshape_body(const DlObsDev& o, const doubl
     if (FAST) {
         // Waves 0-2 (DL_FS_KT threads) build the spline: knots -> convolution -> interval polynomials.  Wave 3 runs the per-mu chain beside them, one part
         // per phase (its results are first read in phase 3), lane 63 of it keeps the per-point scalars.
-        constexpr int KT = DL_FS_KT;
+        constexpr int KT = NT - 64;       // (DL_FS_KT at 256 threads)
         const bool mu_wave = tid >= KT;
         const int m = tid - KT;                                  // mu node of this lane of the mu wave
         const bool mu_lane = mu_wave && m < o.n_mu, scalar_lane = (tid == nthr - 1);
@@ -187,6 +188,16 @@ __global__ __launch_bounds__(DL_FS_THREADS, DENSE ? 5 : 4) void dl_fullshape_ker
                                                                      int64_t ld_power, double* __restrict__ tables, int64_t ld_tables, int stop_after, unsigned long long* __restrict__ stamps) {
     dl_obs_prefetch((const void*)__builtin_amdgcn_kernarg_segment_ptr());
     dl_fullshape_body<FAST, NL, EFT, DENSE>(o, theta, n_params, power, ld_power, tables, ld_tables, stop_after, stamps);
+}
+
+// Small batches (B x observables <= 256: at most one 256-thread workgroup per CU, a chain of latencies on a quarter of the CU's wave slots): the same body on 512 threads per point --
+// seven waves build the spline (knots and interval polynomials stride by the thread count), the evaluation phase holds ONE wavenumber per thread instead of two.  Measured (round 6,
+// profiles/r06d_wide_theory.txt): 64 - 256 points 18.0 - 18.2 -> 17.3 - 17.6 us per step; 512 points 19.05 -> 19.2, 1024 points 23.6 -> 28.6 us (four 512-thread workgroups do not fit a CU).
+template <int NL>
+__global__ __launch_bounds__(512, 2) void dl_fullshape_wide_kernel(const DlObsDev o, const double* __restrict__ theta, int n_params, double* __restrict__ power,
+                                                                 int64_t ld_power, int stop_after, unsigned long long* __restrict__ stamps) {
+    dl_obs_prefetch((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+    dl_fullshape_body<true, NL, false, false, false, false, 512>(o, theta, n_params, power, ld_power, nullptr, 0, stop_after, stamps);
 }
 
 // ---- scale-dependent bias from local primordial non-Gaussianity (theory kind 5; primordial_non_gaussianity.py:75-112) ---------------------------------------------
@@ -605,6 +616,15 @@ void dl_launch_fullshape(const DlObsDev* obs_host, int n_obs, const double* thet
         };
         static const int64_t dense_min = getenv("DL_FS_DENSE_MIN") ? atoll(getenv("DL_FS_DENSE_MIN")) : 4096;   // batches above: the 5-workgroups-per-CU variant
         bool nl3 = oh.n_ell <= 3, eft = oh.n_ct > 0 || oh.n_sn > 0;
+        static const int wide_env = getenv("DL_FS_WIDE") ? atoi(getenv("DL_FS_WIDE")) : -1;      // 1 / 0: force / forbid the 512-thread form (default: batches of at most 256 workgroups)
+        const bool wide = !generic && !eft && tables == nullptr && (wide_env == 1 || (wide_env != 0 && B * n_obs <= 256));
+        if (wide) {
+            if (shmem > 48 * 1024) { (void)hipFuncSetAttribute((const void*)dl_fullshape_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); (void)hipFuncSetAttribute((const void*)dl_fullshape_wide_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); }
+            const int flags = (xcd_block > 0 && stop_after == 0 && B % (8 * xcd_block) == 0) ? (xcd_block << 8) : stop_after;
+            if (nl3) DL_LAUNCH(dl_fullshape_wide_kernel<3>, dim3((unsigned)B), dim3(512), shmem, stream, obs_host[i], theta, n_params, power, ld_power, flags, stamps);
+            else DL_LAUNCH(dl_fullshape_wide_kernel<5>, dim3((unsigned)B), dim3(512), shmem, stream, obs_host[i], theta, n_params, power, ld_power, flags, stamps);
+            continue;
+        }
         if (generic) launch(dl_fullshape_kernel<false, 5, true>);   // generic: run-time decisions
         else if (nl3 && !eft) { if (B > dense_min) launch(dl_fullshape_kernel<true, 3, false, true>); else launch(dl_fullshape_kernel<true, 3, false>); }
         else if (nl3) launch(dl_fullshape_kernel<true, 3, true>);

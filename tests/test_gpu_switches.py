@@ -25,6 +25,7 @@ SWITCHES = [({}, 'fs two ens emu bao tns png mh stk'),
             ({'DL_CHI2_BFRAG': '1'}, 'fs two ens mh'), ({'DL_CHI2_BFRAG': '1', 'DL_CG_MT': '16'}, 'fs two'),      # the chi2 GEMM with its B operand in registers (dl_chi2_gemm_tile_bf: round-6 experiment, measured slower, kept for the record)
             ({'DL_CHI2_FUSED': '1'}, 'fs'),
             ({'DL_STEP_KERNEL': '1'}, 'fs'),                                              # theory + chi2 GEMM + finalize of <= 1024 points in ONE launch (dl_step_kernel: measured slower, kept for the record)
+            ({'DL_FS_WIDE': '0'}, 'fs'), ({'DL_FS_WIDE': '1'}, 'fs'),                     # the 512-thread theory kernel of small batches: never / whatever the batch
             ({'DL_FS_DENSE_MIN': '256'}, 'fs two'), ({'DL_FS_DENSE_MIN': '1000000'}, 'fs'),
             ({'DL_NO_MERGED_THEORY': '1'}, 'two ens'), ({'DL_NO_PANEL_SKIP': '1'}, 'two'), ({'DL_NO_ROW_ALIGN': '1'}, 'two ens'),
             ({'DL_ENS_GLOBAL': '1'}, 'ens'), ({'DL_ENS_NO_DEFER': '1'}, 'ens'), ({'DL_ENS_NO_FOLD': '1'}, 'ens'), ({'DL_MH_NO_DEFER': '1'}, 'mh'),
