@@ -293,7 +293,7 @@ def compact_line(result):
         legs.append(item)
     if legs: out['other_configs'] = legs
     cw = result.get('chains_weak')
-    if isinstance(cw, dict): out['chains_weak'] = {'error': cw['error']} if 'error' in cw else {'value': num(cw.get('value'), 5), 'unit': cw.get('unit'), 'per_k': [{'chains_per_gpu': c.get('chains_per_gpu'), 'value': num(c.get('value'), 5), 'us_per_update_per_chain': num(c.get('us_per_update_per_chain'))} for c in cw.get('per_k', []) if isinstance(c, dict)]}
+    if isinstance(cw, dict): out['chains_weak'] = {'error': cw['error']} if 'error' in cw else {'value': num(cw.get('value'), 5), 'unit': cw.get('unit'), 'n_gpus': cw.get('n_gpus'), 'scaling': cw.get('scaling'), 'per_k': [{'chains_per_gpu': c.get('chains_per_gpu'), 'chains': c.get('chains'), 'value': num(c.get('value'), 5), 'us_per_update_per_chain': num(c.get('us_per_update_per_chain'))} for c in cw.get('per_k', []) if isinstance(c, dict)]}
     mh = result.get('mh_chains')
     if isinstance(mh, dict): out['mh_chains'] = {'value': num(mh.get('value'), 5), 'unit': mh.get('unit')} if 'error' not in mh else {'error': mh['error']}
     st = result.get('config5_strong')

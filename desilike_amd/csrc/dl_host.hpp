@@ -307,7 +307,8 @@ inline bool dl_build_emulated_obs(const dl_config& cfg, const std::string& p, in
             if (ng < 1 || groups.size() != (size_t)ng * 4 || scale.size() != (size_t)ng * (d.n_x + 1)) { err = q + "groups i32[n_groups * 4] and scale f64[n_groups * (n_x + 1)] are required"; return false; }
             int n_trunks = 0;
             for (int gi = 0; gi < ng; ++gi) n_trunks = std::max(n_trunks, groups[4 * gi + 1]);
-            if (per == 0 || w.size() != per * (size_t)n_trunks) { err = q + "weights size does not match widths x number of networks"; return false; }
+            // (no network survives -- every table a constant, e.g. a tracer of the 'st' tables alone: the weights array is then a placeholder of any size: ADVICE r5)
+            if (per == 0 || (n_trunks > 0 && w.size() != per * (size_t)n_trunks)) { err = q + "weights size does not match widths x number of networks"; return false; }
             std::vector<double> table;
             std::vector<double> amp;
             int col = 0, kq = 0, max_k = 1, covered[DL_N_MONO] = {0};

@@ -263,13 +263,15 @@ def test_bench_two_ranks_on_one_gpu():
                           '--sustained-seconds', '0.2', '--no-other-configs', '--no-cpu-baseline'],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
-    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    lines = out.stdout.decode().strip().splitlines()
+    line, complete = json.loads(lines[-1]), json.loads(lines[-2])     # the compact line the driver keeps (< 4 KB), and the complete record before it
+    assert complete['record'] == 'complete' and complete['value'] == pytest.approx(line['value'], rel=1e-5) and len(lines[-1]) < 4096
     assert line['n_gpus'] == 2 and line['config']['ranks'] == 2 and line['value'] > 0.
     # the exchange checked end to end inside the run: every rank holds the same gathered log-posteriors, each rank's slice agrees with the oracle (bench.py::gathered_check)
     assert line['gathered_check']['ranks'] == 2 and line['gathered_check']['identical_on_every_rank'] and line['gathered_check']['max_rel_err_vs_oracle'] <= 1e-10
     assert line['config5_strong']['n_gpus'] == 2
     assert line['chains_weak']['n_gpus'] == 2 and [entry['chains'] for entry in line['chains_weak']['per_k']] == [2, 4, 8]      # chain-parallel sampler: K chains per rank
-    assert line['sustained']['steps'] >= 256
+    assert complete['sustained']['steps'] >= 256
 
 
 def test_config5_as_stated_device_vs_host_driver():
