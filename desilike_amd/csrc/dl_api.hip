@@ -467,6 +467,15 @@ int dl_create(dl_ctx** out, int device, const dl_config* cfg) {
     return 0;
 }
 
+// workspace of the two-launch stacked engine (dl_emu_stacked_split.h): the last hidden layers of observable i's networks, [points, n_networks x H] -- the theory-vector
+// workspace, which the feature path does not write (rows of (1 + n_var) K_pad doubles per point: large enough when n_networks x H fits a row)
+static double* dl_stk_basis_ws(dl_ctx* ctx, int i) {
+    const DlObsDev& d = ctx->obs_kernarg[i];
+    if (d.eng[0].type != 2 || ctx->power_ws == nullptr) return nullptr;
+    const int64_t ldk = (int64_t)d.stk.n_trunks * d.eng[0].widths[d.eng[0].n_layers];
+    return ldk <= (int64_t)(1 + ctx->n_var) * ctx->K_pad ? ctx->power_ws : nullptr;
+}
+
 void dl_destroy(dl_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -621,7 +630,7 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
                                   post_mode, false};
             if (ctx->stk_steps[0]) {   // stacked table engine: the same finalize in the tail of dl_emulated_stacked_kernel when the rows of X fit its LDS
                 dl_launch_emulated_stacked(ctx->obs_kernarg[0], th, P, nb, ctx->gfrag_dev[0], ctx->delta_ws, ctx->N_pad, ctx->N_pad, 0, ctx->stk_steps[0], stream, &fin, ctx->bias_white_dev,
-                                           &ctx->marg, ctx->n_white);
+                                           &ctx->marg, ctx->n_white, dl_stk_basis_ws(ctx, 0));
                 gram_done = fin.done;          // (launched either way: with fin.done the outputs are written ...
                 stacked_rows_done = !fin.done; //  ... without it the residual rows of the observable are in delta_ws: the general finalize follows)
             } else gram_done = dl_launch_emulated_feature_gram(ctx->obs_kernarg[0], th, P, nb, ctx->gfrag_dev[0], ctx->bias_white_dev, ctx->marg, ctx->n_white, ctx->delta_ws, stream, &fin);
@@ -631,7 +640,7 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
         if (feat_path && !gram_done) {
             for (int i = 0; i < ctx->n_obs; ++i) {
                 if (i == 0 && stacked_rows_done) continue;
-                if (ctx->stk_steps[i]) dl_launch_emulated_stacked(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, ctx->stk_steps[i], stream);
+                if (ctx->stk_steps[i]) dl_launch_emulated_stacked(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, ctx->stk_steps[i], stream, nullptr, nullptr, nullptr, 0, dl_stk_basis_ws(ctx, i));
                 else if (emu_fused) dl_launch_emulated_feature(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, stream);
                 else dl_launch_feature_gemm(ctx->feat_ws, ctx->feat_ld, ctx->obs_kernarg[i].feat_off, ctx->obs_kernarg[i].nb_pad, R, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad,
                                             ctx->N_pad, nb, i > 0, stream);
@@ -740,7 +749,7 @@ int dl_eval_fisher(dl_ctx* ctx, const double* centers_dev, const double* steps_d
             // emulated (separable) theories: residual rows straight from the feature GEMM
             if (!emu_fused) dl_launch_fullshape(ctx->obs_kernarg.data(), ctx->n_obs, th, P, nb, ctx->power_ws, ctx->K_pad, nullptr, 0, stream, ctx->feat_ws, ctx->feat_ld, 0);
             for (int i = 0; i < ctx->n_obs; ++i) {
-                if (ctx->stk_steps[i]) dl_launch_emulated_stacked(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, ctx->stk_steps[i], stream);
+                if (ctx->stk_steps[i]) dl_launch_emulated_stacked(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, ctx->stk_steps[i], stream, nullptr, nullptr, nullptr, 0, dl_stk_basis_ws(ctx, i));
                 else if (emu_fused) dl_launch_emulated_feature(ctx->obs_kernarg[i], th, P, nb, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad, ctx->N_pad, i > 0, stream);
                 else dl_launch_feature_gemm(ctx->feat_ws, ctx->feat_ld, ctx->obs_kernarg[i].feat_off, ctx->obs_kernarg[i].nb_pad, 1, ctx->gfrag_dev[i], ctx->delta_ws, ctx->N_pad,
                                             ctx->N_pad, nb, i > 0, stream);

@@ -45,12 +45,17 @@ template <int NV>
 __device__ __forceinline__ void dl_stk_act_rows(int act, double (&v)[NV]) {
 #define DL_STK_ROW(body) { _Pragma("unroll") for (int r = 0; r < NV; ++r) { body; } __builtin_amdgcn_sched_barrier(0); }
     if (act == 1) { DL_STK_ROW(v[r] = v[r] > 0. ? v[r] : 0.) return; }                        // conversion.py:31
+    // e^x with full-rate instructions only (round 6: v_rndne_f64, v_cvt_i32_f64 and v_ldexp_f64 issue at a quarter of the rate of an FMA): n = rint(x log2 e) by the
+    // 1.5 x 2^52 constant (the integer sits in the low dword of the sum), Cody-Waite reduction, degree-13 Taylor polynomial, 2^n by an integer addition to the exponent field
+    // (x clamped to [-708, 709]: the result stays a normal number); then one v_rcp_f64 + two Newton steps
     double x[NV], n[NV], p[NV];
+    int ni[NV];
     if (act == 0) DL_STK_ROW(x[r] = fmax(-v[r], -708.))                                        // silu v / (1 + e^-v), conversion.py:29
     else { DL_STK_ROW(x[r] = v[r] + v[r]) DL_STK_ROW(x[r] = fmax(x[r], -708.)) }               // tanh 1 - 2 / (1 + e^2v), conversion.py:33
     DL_STK_ROW(x[r] = fmin(x[r], 709.))
-    DL_STK_ROW(n[r] = x[r] * 1.4426950408889634074)
-    DL_STK_ROW(n[r] = rint(n[r]))
+    DL_STK_ROW(n[r] = fma(x[r], 1.4426950408889634074, 6755399441055744.))
+    DL_STK_ROW(ni[r] = __double2loint(n[r]))
+    DL_STK_ROW(n[r] = n[r] - 6755399441055744.)
     DL_STK_ROW(x[r] = fma(n[r], -6.93147180369123816490e-01, x[r]))
     DL_STK_ROW(x[r] = fma(n[r], -1.90821492927058770002e-10, x[r]))
     DL_STK_ROW(p[r] = fma(1. / 6227020800., x[r], 1. / 479001600.))
@@ -66,7 +71,7 @@ __device__ __forceinline__ void dl_stk_act_rows(int act, double (&v)[NV]) {
     DL_STK_ROW(p[r] = fma(p[r], x[r], 0.5))
     DL_STK_ROW(p[r] = fma(p[r], x[r], 1.))
     DL_STK_ROW(p[r] = fma(p[r], x[r], 1.))
-    DL_STK_ROW(p[r] = ldexp(p[r], (int)n[r]))
+    DL_STK_ROW(p[r] = __hiloint2double(__double2hiint(p[r]) + (ni[r] << 20), __double2loint(p[r])))
     DL_STK_ROW(p[r] = p[r] + 1.)
     DL_STK_ROW(x[r] = __builtin_amdgcn_rcp(p[r]))
     DL_STK_ROW(n[r] = fma(-p[r], x[r], 1.))
@@ -74,7 +79,7 @@ __device__ __forceinline__ void dl_stk_act_rows(int act, double (&v)[NV]) {
     DL_STK_ROW(n[r] = fma(-p[r], x[r], 1.))
     DL_STK_ROW(x[r] = fma(n[r], x[r], x[r]))
     if (act == 0) DL_STK_ROW(v[r] = v[r] * x[r])
-    else { DL_STK_ROW(x[r] = fma(x[r], -2., 1.)) DL_STK_ROW(v[r] = v[r] != v[r] ? v[r] : x[r]) }   // (the clamp drops a NaN: hand it on as dl_activation does)
+    else { DL_STK_ROW(x[r] = fma(x[r], -2., 1.)) DL_STK_ROW(v[r] = fma(0., v[r], x[r])) }      // (+ 0 v: the clamp drops a NaN input, this hands it on -- as dl_activation does)
 #undef DL_STK_ROW
 }
 

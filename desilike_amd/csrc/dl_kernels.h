@@ -22,6 +22,7 @@ extern thread_local DlProfEvents dl_prof_events;
 struct DlOptions {
     bool no_merged_theory, no_emu_batch, no_fused_solve, no_gram_plain, no_scaled_row0, ef_no_early_theta, fm_no_lane_solve;
     bool chi2_bfrag;                    // DL_CHI2_BFRAG=1: the chi2 GEMM with its B operand in registers (dl_chi2_gemm_tile_bf: round-6 experiment, measured slower; docs/EXPERIMENTS.md)
+    bool no_stk_split;                  // DL_NO_STK_SPLIT: the stacked engine in ONE launch (dl_emulated_stacked_kernel: networks and feature GEMMs group by group) instead of dl_stk_chain_kernel + dl_emulated_stacked_gemm_kernel
     int stk_overlap;                    // DL_STK_OVERLAP: the stacked engine on dl_emulated_stacked_ov_kernel where the shape allows (round-6 experiment, slower: docs/EXPERIMENTS.md):
                                         // 1 networks of the next batch under the feature GEMM (+2: without raised priority), 4 the two halves of the workgroup on half of the networks each
     bool ens_global, ens_force_comm, ens_no_defer, ens_no_fold, ens_stamps, ens_fold_stamps;
@@ -100,7 +101,8 @@ void dl_launch_step(const DlObsDev& obs, const double* theta, int n_params, int6
 bool dl_emulated_stacked_ok(const DlObsDev& obs);
 struct DlGramFinalize;
 void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
-                                int steps_per_block, hipStream_t stream, DlGramFinalize* fin = nullptr, const double* bias = nullptr, const DlMargDev* mg = nullptr, int n_valid = 0);
+                                int steps_per_block, hipStream_t stream, DlGramFinalize* fin = nullptr, const double* bias = nullptr, const DlMargDev* mg = nullptr, int n_valid = 0,
+                                double* basis_ws = nullptr);   // basis_ws [B, n_networks x H]: workspace of the two-launch form (dl_emu_stacked_split.h); null: one launch
 // (fin, bias, mg: the marginalised finalize in the kernel's tail -- one observable, N_pad = 128 --, see dl_kernels.hip; fin->done tells whether it was taken)
 // ... with the Gram-matrix epilogue: gram [B, 16, 16] = Gram matrix of [residual + bias; derivative rows + tconst] per point instead of the rows themselves (one observable,
 // N_pad = 128).  Returns false (nothing launched) when the rows of 16 points do not fit the LDS next to the forward pass.

@@ -20,6 +20,7 @@
 #include "dl_emu_batch.h"
 #include "dl_emu_stacked.h"
 #include "dl_emu_stacked_ov.h"
+#include "dl_emu_stacked_split.h"
 #include "dl_finalize_part.h"
 #include "dl_marg_solve.h"
 #include "dl_scalar_prefetch.h"
@@ -54,6 +55,7 @@ static void dl_options_read() {
     DlOptions& o = g_options;
     o.no_merged_theory = on("DL_NO_MERGED_THEORY"); o.no_emu_batch = on("DL_NO_EMU_BATCH"); o.no_fused_solve = on("DL_NO_FUSED_SOLVE"); o.no_gram_plain = on("DL_NO_GRAM_PLAIN");
     o.no_scaled_row0 = on("DL_NO_SCALED_ROW0"); o.ef_no_early_theta = on("DL_EF_NO_EARLY_THETA"); o.fm_no_lane_solve = on("DL_FM_NO_LANE_SOLVE");
+    o.no_stk_split = on("DL_NO_STK_SPLIT");
     o.stk_overlap = std::getenv("DL_STK_OVERLAP") ? atoi(std::getenv("DL_STK_OVERLAP")) : 0;
     o.ens_global = on("DL_ENS_GLOBAL"); o.ens_force_comm = on("DL_ENS_FORCE_COMM"); o.ens_no_defer = on("DL_ENS_NO_DEFER"); o.ens_no_fold = on("DL_ENS_NO_FOLD");
     o.ens_stamps = on("DL_ENS_STAMPS"); o.ens_fold_stamps = on("DL_ENS_FOLD_STAMPS");
@@ -916,17 +918,19 @@ bool dl_emulated_stacked_ok(const DlObsDev& obs) { return dl_stk_feature_ok(obs)
 // fin != nullptr (one observable, N_pad = 128, every solved parameter on a device row or constant, X fits the LDS): the marginalised finalize runs in the kernel's tail
 // (outputs of DlGramFinalize; fin->done = true) and no row is written; otherwise the residual rows go to `out`
 void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
-                                int steps_per_block, hipStream_t stream, DlGramFinalize* fin, const double* bias, const DlMargDev* mg, int n_valid) {
+                                int steps_per_block, hipStream_t stream, DlGramFinalize* fin, const double* bias, const DlMargDev* mg, int n_valid, double* basis_ws) {
     // the overlapped form (dl_emu_stacked_ov.h) where the shape allows: networks of the next batch under the feature GEMM of the current group
     const bool overlap = dl_options().stk_overlap != 0 && dl_stko_ok(obs);   // (off by default: measured slower than the plain form, docs/EXPERIMENTS.md round 6)
-    size_t shm = overlap ? (dl_stko_fixed_doubles() + dl_stko_work_doubles(obs)) * sizeof(double) : dl_stk_shared_doubles(obs) * sizeof(double);
+    // the two-launch form (dl_emu_stacked_split.h): every network a wave-private chain, then the feature GEMMs with the basis records through memory
+    const bool split = !overlap && basis_ws != nullptr && !dl_options().no_stk_split && dl_stks_ok(obs);
+    size_t shm = (overlap || split) ? (dl_stko_fixed_doubles() + dl_stko_work_doubles(obs)) * sizeof(double) : dl_stk_shared_doubles(obs) * sizeof(double);
     const int R = 1 + obs.n_var;
     const unsigned grid = (unsigned)((B + DL_STK_PTS - 1) / DL_STK_PTS);
     DlStkTail tl;
     std::memset(&tl, 0, sizeof(tl));
     bool tail_fits = false;
     if (mg != nullptr && mg->n_s >= 0 && 1 + mg->n_s <= 8) {
-        if (overlap) {   // X [16][xr][DL_FG_XLD] over the work area, which grows to hold it when the LDS allows
+        if (overlap || split) {   // X [16][xr][DL_FG_XLD] over the work area, which grows to hold it when the LDS allows
             const size_t need = (dl_stko_fixed_doubles() + (size_t)DL_STK_PTS * (1 + mg->n_s) * DL_FG_XLD) * sizeof(double);
             if (need + DL_STK_STATIC_LDS <= 160 * 1024) { tail_fits = true; if (need > shm) shm = need; }
         } else tail_fits = dl_stk_tail_fits(obs, 1 + mg->n_s);
@@ -967,7 +971,21 @@ void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_
         DL_LAUNCH(kernel, dim3(grid, (unsigned)(N_pad / 128)), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, out, ldo, accumulate, steps_per_block, stamps, tl, mode);
     };
     const bool wide = dl_stk_tld(obs) > 66;   // a layer wider than 64 units: eight output tiles per layer
-    if (overlap) { if (R <= 1) launch_ov(dl_emulated_stacked_ov_kernel<1, DL_STKO_TMAX>); else if (R <= 4) launch_ov(dl_emulated_stacked_ov_kernel<4, DL_STKO_TMAX>); else if (R <= 6) launch_ov(dl_emulated_stacked_ov_kernel<6, DL_STKO_TMAX>); else launch_ov(dl_emulated_stacked_ov_kernel<8, DL_STKO_TMAX>); }
+    if (split) {
+        const int Hs = obs.eng[0].widths[obs.eng[0].n_layers];
+        const int64_t ldk = (int64_t)obs.stk.n_trunks * Hs;
+        const int n_pt_tiles = (int)grid;
+        const int64_t chains = (int64_t)obs.stk.n_trunks * n_pt_tiles;
+        if (chains > 0) {
+            const size_t shm_a = (size_t)4 * DL_STK_PTS * DL_STKS_LD * sizeof(double);
+            DL_LAUNCH(dl_stk_chain_kernel, dim3((unsigned)((chains + 3) / 4)), dim3(256), shm_a, stream, theta, n_params, B, obs, basis_ws, ldk, n_pt_tiles);
+        }
+        auto launch_b = [&](auto kernel) {
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            DL_LAUNCH(kernel, dim3(grid, (unsigned)(N_pad / 128)), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, out, ldo, accumulate, steps_per_block, stamps, tl, (const double*)basis_ws, ldk);
+        };
+        if (R <= 1) launch_b(dl_emulated_stacked_gemm_kernel<1>); else if (R <= 4) launch_b(dl_emulated_stacked_gemm_kernel<4>); else if (R <= 6) launch_b(dl_emulated_stacked_gemm_kernel<6>); else launch_b(dl_emulated_stacked_gemm_kernel<8>);
+    } else if (overlap) { if (R <= 1) launch_ov(dl_emulated_stacked_ov_kernel<1, DL_STKO_TMAX>); else if (R <= 4) launch_ov(dl_emulated_stacked_ov_kernel<4, DL_STKO_TMAX>); else if (R <= 6) launch_ov(dl_emulated_stacked_ov_kernel<6, DL_STKO_TMAX>); else launch_ov(dl_emulated_stacked_ov_kernel<8, DL_STKO_TMAX>); }
     else if (wide) { if (R <= 1) launch(dl_emulated_stacked_kernel<8, 1>); else if (R <= 4) launch(dl_emulated_stacked_kernel<8, 4>); else if (R <= 6) launch(dl_emulated_stacked_kernel<8, 6>); else launch(dl_emulated_stacked_kernel<8, 8>); }
     else { if (R <= 1) launch(dl_emulated_stacked_kernel<4, 1>); else if (R <= 4) launch(dl_emulated_stacked_kernel<4, 4>); else if (R <= 6) launch(dl_emulated_stacked_kernel<4, 6>); else launch(dl_emulated_stacked_kernel<4, 8>); }
     if (stamps) {

@@ -31,6 +31,7 @@ SWITCHES = [({}, 'fs two ens emu bao tns png mh stk'),
             ({'DL_ENS_GLOBAL': '1'}, 'ens'), ({'DL_ENS_NO_DEFER': '1'}, 'ens'), ({'DL_ENS_NO_FOLD': '1'}, 'ens'), ({'DL_MH_NO_DEFER': '1'}, 'mh'),
             ({'DL_NO_EMU_FUSED': '1'}, 'emu stk'), ({'DL_NO_GRAM_EPILOGUE': '1'}, 'emu stk'), ({'DL_NO_EMU_BATCH': '1'}, 'emu'), ({'DL_NO_FEATURE_PATH': '1'}, 'emu stk'),
             ({'DL_NO_FUSED_SOLVE': '1'}, 'emu stk'),
+            ({'DL_NO_STK_SPLIT': '1'}, 'stk'),                                             # the stacked engine in one launch (dl_emulated_stacked_kernel: the round-5 form) instead of chains + feature GEMMs
             ({'DL_STK_OVERLAP': '1'}, 'stk'), ({'DL_STK_OVERLAP': '3'}, 'stk'), ({'DL_STK_OVERLAP': '4'}, 'stk'),   # dl_emulated_stacked_ov_kernel (round-6 experiment, measured slower, kept for the record): networks under the feature GEMM (3: no raised priority), split halves
             ({'DL_FM_NO_STAGE': '1'}, 'emu bao'),
             ({'DL_BAO_THREADS': '64'}, 'bao'), ({'DL_BAO_THREADS': '128'}, 'bao'), ({'DL_BAO_THREADS': '256'}, 'bao'),
