@@ -170,8 +170,10 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
     const int R = 1 + o.n_var;
     const int tld = dl_stk_tld(o), bld = dl_stk_bld(o);
     // DL_STK_STAMPS (null in production): the slots of dl_emulated_stacked_kernel -- 0 entry, 1 inputs, 2 monomial rows, 3 + 2 gi: the group's record in place, 4 + 2 gi: its feature GEMM done, 30: tail done
-    unsigned long long* st = stamps != nullptr && blockIdx.y == 0 ? stamps + (size_t)blockIdx.x * 32 : nullptr;
+    // (128 slots per workgroup: 32 + 12 w + gi / + 6 + gi: wave w at the start / the end of the feature GEMM of group gi < 6 -- the skew between the eight column blocks)
+    unsigned long long* st = stamps != nullptr && blockIdx.y == 0 ? stamps + (size_t)blockIdx.x * 128 : nullptr;
 #define DL_STKS_STAMP(slot) if (st != nullptr && tid == 0) st[slot] = __builtin_amdgcn_s_memtime();
+#define DL_STKS_WSTAMP(off) if (st != nullptr && lane == 0 && gi < 6) st[32 + 12 * wave + (off) + gi] = __builtin_amdgcn_s_memtime();
     DL_STKS_STAMP(0)
     const DlStkLds s = dl_stk_carve(lds);
     double* recs = s.work;                                        // [2][16][bld] basis records: batch b in record b & 1
@@ -208,10 +210,10 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
             dl_stko_fill(recs + (size_t)(ibatch & 1) * DL_STK_PTS * bld, bld, K, tid, 512);
             DL_STK_WGBAR;                                                   // ... and everybody's
         }
-        DL_STKS_STAMP(3 + 2 * gi)
+        DL_STKS_STAMP(3 + 2 * gi) DL_STKS_WSTAMP(0)
         const double* rc = recs + (size_t)(ibatch & 1) * DL_STK_PTS * bld;
         dl_stk_group<RMAX>(m1 - m0, rc + (size_t)col * bld + 2 * g, gcol + (size_t)kq * 64, nq, s.mono + m0, R, g, outv);
-        DL_STKS_STAMP(4 + 2 * gi)
+        DL_STKS_STAMP(4 + 2 * gi) DL_STKS_WSTAMP(6)
         // the last group of its batch: the record is free for the batch after the next one
         bool last_of_batch = gi + 1 == o.stk.n_groups;
         int tbn = -1, ten = -1, seen = 0;                                   // the (ibatch + 2)-th batch, if any
@@ -236,5 +238,6 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
     DL_STKS_STAMP(30)
     if (st != nullptr && tid == 0) st[31] = __builtin_amdgcn_s_memrealtime();
 #undef DL_STKS_STAMP
+#undef DL_STKS_WSTAMP
 }
 #endif

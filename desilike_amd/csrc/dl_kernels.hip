@@ -956,7 +956,7 @@ void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_
     static const char* stamp_file = getenv("DL_STK_STAMPS");   // diagnostics: s_memtime at the phase boundaries of launches 30..33 appended to the file (synchronises)
     static unsigned long long* stamps_dev = nullptr;
     static int stamp_launches = 0;
-    const int slots = overlap ? 128 : 32;                      // per workgroup (the overlapped kernel stamps waves 0 and 4, 64 slots each)
+    const int slots = (overlap || split) ? 128 : 32;                      // per workgroup (the overlapped kernel stamps waves 0 and 4, 64 slots each)
     if (stamp_file && !stamps_dev) (void)hipMalloc((void**)&stamps_dev, (size_t)8192 * 128 * sizeof(unsigned long long));
     unsigned long long* stamps = (stamp_file && grid <= 8192 && stamp_launches >= 30 && stamp_launches < 34) ? stamps_dev : nullptr;
     if (stamp_file) stamp_launches++;

@@ -52,5 +52,24 @@ def overlapped(launches):
         print('   SIMD of wave 0 / wave 4 (HW_ID bits 5:4), first 8 workgroups: ' + ' '.join('%d/%d' % (simd(a[w, 63]), simd(a[w, 127])) for w in range(min(8, len(a)))))
 
 
+def split_form(launches):
+    """dl_emulated_stacked_gemm_kernel: slots 0-31 as dl_emulated_stacked_kernel (wave 0), slots 32 + 12 w + gi / + 6 + gi: wave w at the start / end of the feature GEMM of group gi."""
+    for il, a in enumerate(launches):
+        a = a.astype('f8')
+        names = ['entry', 'inputs', 'monomials'] + [n for gi in range(13) for n in ('g%d record in place' % gi, 'g%d gemm' % gi)] + ['', 'tail done', 'realtime']
+        live = [q for q in range(15) if np.all(a[:, q] > 0)] + [30]
+        print('launch %d: %d workgroups; per-workgroup medians (units of 100 shader cycles):' % (il, len(a)))
+        prev = live[0]
+        for q in live[1:]:
+            print('   %-22s +%8.2f   (at %8.2f)' % (names[q], np.median(a[:, q] - a[:, prev]) / 100., np.median(a[:, q] - a[:, live[0]]) / 100.))
+            prev = q
+        w = a[:, 32:128].reshape(len(a), 8, 12)
+        for gi in range(6):
+            if not np.all(w[:, :, gi] > 0): continue
+            start, end = w[:, :, gi] - a[:, [0]], w[:, :, 6 + gi] - a[:, [0]]
+            print('   g%d gemm per wave (column block): start %s | duration %s | end spread (max - min) %.1f' % (
+                gi, ' '.join('%.0f' % v for v in np.median(start, axis=0) / 100.), ' '.join('%.0f' % v for v in np.median(end - start, axis=0) / 100.), np.median(end.max(axis=1) - end.min(axis=1)) / 100.))
+
+
 if __name__ == '__main__' and launches and launches[0].shape[1] == 128:
-    overlapped(launches[:2])
+    (overlapped if np.all(launches[0].astype('u8')[:, 3] >> 56) else split_form)(launches[:2])
