@@ -629,8 +629,11 @@ static int dl_eval_impl(dl_ctx* ctx, const double* theta_dev, int64_t B, double*
                                   solved_dev ? solved_dev + (size_t)b0 * ctx->n_solved : nullptr, hessian_dev ? hessian_dev + (size_t)b0 * ctx->n_solved * ctx->n_solved : nullptr,
                                   post_mode, false};
             if (ctx->stk_steps[0]) {   // stacked table engine: the same finalize in the tail of dl_emulated_stacked_kernel when the rows of X fit its LDS
+                prof_phase(0);      // (the chains of the two-launch form carry the events of the theory phase, the feature GEMMs those of the GEMM phase)
+                const bool chains_done = dl_launch_stk_chains(ctx->obs_kernarg[0], th, P, nb, dl_stk_basis_ws(ctx, 0), stream);
+                prof_phase(1);
                 dl_launch_emulated_stacked(ctx->obs_kernarg[0], th, P, nb, ctx->gfrag_dev[0], ctx->delta_ws, ctx->N_pad, ctx->N_pad, 0, ctx->stk_steps[0], stream, &fin, ctx->bias_white_dev,
-                                           &ctx->marg, ctx->n_white, dl_stk_basis_ws(ctx, 0));
+                                           &ctx->marg, ctx->n_white, dl_stk_basis_ws(ctx, 0), chains_done);
                 gram_done = fin.done;          // (launched either way: with fin.done the outputs are written ...
                 stacked_rows_done = !fin.done; //  ... without it the residual rows of the observable are in delta_ws: the general finalize follows)
             } else gram_done = dl_launch_emulated_feature_gram(ctx->obs_kernarg[0], th, P, nb, ctx->gfrag_dev[0], ctx->bias_white_dev, ctx->marg, ctx->n_white, ctx->delta_ws, stream, &fin);

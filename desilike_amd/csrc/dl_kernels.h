@@ -102,7 +102,10 @@ bool dl_emulated_stacked_ok(const DlObsDev& obs);
 struct DlGramFinalize;
 void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
                                 int steps_per_block, hipStream_t stream, DlGramFinalize* fin = nullptr, const double* bias = nullptr, const DlMargDev* mg = nullptr, int n_valid = 0,
-                                double* basis_ws = nullptr);   // basis_ws [B, n_networks x H]: workspace of the two-launch form (dl_emu_stacked_split.h); null: one launch
+                                double* basis_ws = nullptr, bool chains_done = false);   // basis_ws [B, n_networks x H]: workspace of the two-launch form (dl_emu_stacked_split.h); null: one launch
+// the first launch of the two-launch form on its own (so that it carries the events of the theory phase): true if the shape takes that form and the chains were launched --
+// dl_launch_emulated_stacked(..., basis_ws, true) then launches the feature GEMMs only
+bool dl_launch_stk_chains(const DlObsDev& obs, const double* theta, int n_params, int64_t B, double* basis_ws, hipStream_t stream);
 // (fin, bias, mg: the marginalised finalize in the kernel's tail -- one observable, N_pad = 128 --, see dl_kernels.hip; fin->done tells whether it was taken)
 // ... with the Gram-matrix epilogue: gram [B, 16, 16] = Gram matrix of [residual + bias; derivative rows + tconst] per point instead of the rows themselves (one observable,
 // N_pad = 128).  Returns false (nothing launched) when the rows of 16 points do not fit the LDS next to the forward pass.

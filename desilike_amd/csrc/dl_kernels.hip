@@ -917,8 +917,19 @@ void dl_launch_emulated_feature(const DlObsDev& obs, const double* theta, int n_
 bool dl_emulated_stacked_ok(const DlObsDev& obs) { return dl_stk_feature_ok(obs); }
 // fin != nullptr (one observable, N_pad = 128, every solved parameter on a device row or constant, X fits the LDS): the marginalised finalize runs in the kernel's tail
 // (outputs of DlGramFinalize; fin->done = true) and no row is written; otherwise the residual rows go to `out`
+bool dl_launch_stk_chains(const DlObsDev& obs, const double* theta, int n_params, int64_t B, double* basis_ws, hipStream_t stream) {
+    if (basis_ws == nullptr || dl_options().no_stk_split || (dl_options().stk_overlap != 0 && dl_stko_ok(obs)) || !dl_stks_ok(obs)) return false;
+    const int n_pt_tiles = (int)((B + DL_STK_PTS - 1) / DL_STK_PTS);
+    const int64_t chains = (int64_t)obs.stk.n_trunks * n_pt_tiles, ldk = (int64_t)obs.stk.n_trunks * obs.eng[0].widths[obs.eng[0].n_layers];
+    if (chains > 0) {
+        const size_t shm_a = (size_t)4 * DL_STK_PTS * DL_STKS_LD * sizeof(double);
+        DL_LAUNCH(dl_stk_chain_kernel, dim3((unsigned)((chains + 3) / 4)), dim3(256), shm_a, stream, theta, n_params, B, obs, basis_ws, ldk, n_pt_tiles);
+    }
+    return true;
+}
+
 void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_params, int64_t B, const double* gfrag, double* out, int64_t ldo, int N_pad, int accumulate,
-                                int steps_per_block, hipStream_t stream, DlGramFinalize* fin, const double* bias, const DlMargDev* mg, int n_valid, double* basis_ws) {
+                                int steps_per_block, hipStream_t stream, DlGramFinalize* fin, const double* bias, const DlMargDev* mg, int n_valid, double* basis_ws, bool chains_done) {
     // the overlapped form (dl_emu_stacked_ov.h) where the shape allows: networks of the next batch under the feature GEMM of the current group
     const bool overlap = dl_options().stk_overlap != 0 && dl_stko_ok(obs);   // (off by default: measured slower than the plain form, docs/EXPERIMENTS.md round 6)
     // the two-launch form (dl_emu_stacked_split.h): every network a wave-private chain, then the feature GEMMs with the basis records through memory
@@ -974,12 +985,7 @@ void dl_launch_emulated_stacked(const DlObsDev& obs, const double* theta, int n_
     if (split) {
         const int Hs = obs.eng[0].widths[obs.eng[0].n_layers];
         const int64_t ldk = (int64_t)obs.stk.n_trunks * Hs;
-        const int n_pt_tiles = (int)grid;
-        const int64_t chains = (int64_t)obs.stk.n_trunks * n_pt_tiles;
-        if (chains > 0) {
-            const size_t shm_a = (size_t)4 * DL_STK_PTS * DL_STKS_LD * sizeof(double);
-            DL_LAUNCH(dl_stk_chain_kernel, dim3((unsigned)((chains + 3) / 4)), dim3(256), shm_a, stream, theta, n_params, B, obs, basis_ws, ldk, n_pt_tiles);
-        }
+        if (!chains_done) (void)dl_launch_stk_chains(obs, theta, n_params, B, basis_ws, stream);
         auto launch_b = [&](auto kernel) {
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
             DL_LAUNCH(kernel, dim3(grid, (unsigned)(N_pad / 128)), dim3(512), shm, stream, theta, n_params, B, gfrag, obs, out, ldo, accumulate, steps_per_block, stamps, tl, (const double*)basis_ws, ldk);

@@ -332,45 +332,69 @@ class _DeviceChain(object):
 
 class _ChainStore(object):
     """Samples of one chain, growing by batches: coords [n, nwalkers, ndim], logposterior [n, nwalkers] in arrays with amortised doubling -- appending a batch is ONE
-    copy of the batch (straight out of the pinned staging buffer of the device chain), whatever the length of the chain so far."""
+    copy of the batch (straight out of the pinned staging buffer of the device chain), whatever the length of the chain so far.
+
+    A doubling is as much fresh memory as the whole chain so far, and fresh memory costs its first touch (0.5 ms per MB here: 39 ms for the 78 MB of 2400 updates of 512
+    walkers -- three batches' worth of sampling; round 6: the K = 1 figure of the bench moved between 7.8 and 12.2 M evaluations / s depending on whether a doubling fell
+    among its four timed batches).  So the next buffer is prepared IN THE BACKGROUND as soon as the current one is half full: a thread allocates it, touches its pages and
+    copies the rows that exist by then (rows never change once appended); the swap copies the few rows appended since."""
 
     def __init__(self):
         self.size = 0
         self._coords = self._logp = None
+        self._prep = None          # (thread, coords, logp, rows copied by the thread) of the buffer being prepared
 
     def __bool__(self):
         return self._coords is not None
 
-    def reserve(self, n, shapes=None):
-        """Room for ``n`` more samples, its pages touched: called while the device runs the batch (the host has nothing else to do then), so that the append that follows is
-        one copy into memory that is already there (a growth inside the append cost 6 ms per 12 MB chain -- first touch of every page -- in front of the next batch)."""
-        if self._coords is None:
-            if shapes is None: return
-            cap = 4 * max(n, 1)
-            self._coords, self._logp = np.zeros((cap,) + tuple(shapes[0]), dtype='f8'), np.zeros((cap,) + tuple(shapes[1]), dtype='f8')
-            self._coords.fill(0.); self._logp.fill(0.)
-        elif self.size + n > self._coords.shape[0]:
-            cap = max(2 * self._coords.shape[0], self.size + n)
+    def _prepare(self, cap):
+        import threading
+        old_c, old_l, copied = self._coords, self._logp, self.size
+        new_c, new_l = np.empty((cap,) + old_c.shape[1:], dtype='f8'), np.empty((cap,) + old_l.shape[1:], dtype='f8')
+
+        def work():
+            new_c[:copied], new_l[:copied] = old_c[:copied], old_l[:copied]
+            step = max(1, (1 << 21) // max(1, new_c[0].size))      # ~16 MB at a time (NumPy releases the interpreter lock inside the assignment)
+            for i in range(copied, cap, step):
+                new_c[i:i + step] = 0.
+                new_l[i:i + step] = 0.
+
+        thread = threading.Thread(target=work, daemon=True)
+        thread.start()
+        self._prep = (thread, new_c, new_l, copied)
+
+    def _grow(self, need):
+        if self._prep is not None and self._prep[1].shape[0] >= need:
+            thread, new_c, new_l, copied = self._prep
+            thread.join()
+            new_c[copied:self.size], new_l[copied:self.size] = self._coords[copied:self.size], self._logp[copied:self.size]
+            self._coords, self._logp = new_c, new_l
+        else:                      # (a batch larger than the chain so far: grow at once)
+            if self._prep is not None: self._prep[0].join()
+            cap = max(2 * self._coords.shape[0], need)
             for name in ['_coords', '_logp']:
                 old = getattr(self, name)
                 new = np.empty((cap,) + old.shape[1:], dtype='f8')
                 new[:self.size] = old[:self.size]
                 new[self.size:] = 0.
                 setattr(self, name, new)
+        self._prep = None
+
+    def reserve(self, n, shapes=None):
+        """Room for ``n`` more samples in memory that has been touched: called while the device runs the batch, so that the append that follows is one copy."""
+        if self._coords is None:
+            if shapes is None: return
+            cap = 4 * max(n, 1)
+            self._coords, self._logp = np.zeros((cap,) + tuple(shapes[0]), dtype='f8'), np.zeros((cap,) + tuple(shapes[1]), dtype='f8')
+            self._coords.fill(0.); self._logp.fill(0.)
+        cap = self._coords.shape[0]
+        if self.size + n > cap: self._grow(self.size + n)
+        cap = self._coords.shape[0]
+        if self._prep is None and 2 * (self.size + n) > cap: self._prepare(2 * cap)
 
     def append(self, coords, logp):
         n = coords.shape[0]
-        if self._coords is None:
-            cap = 4 * max(n, 1)          # (room for the next batches; zero-filled: the pages are touched now, not inside a later, possibly timed, append)
-            self._coords, self._logp = np.zeros((cap,) + coords.shape[1:], dtype='f8'), np.zeros((cap,) + logp.shape[1:], dtype='f8')
-            self._coords.fill(0.); self._logp.fill(0.)
-        elif self.size + n > self._coords.shape[0]:
-            cap = max(2 * self._coords.shape[0], self.size + n)
-            for name in ['_coords', '_logp']:
-                old = getattr(self, name)
-                new = np.empty((cap,) + old.shape[1:], dtype='f8')
-                new[:self.size] = old[:self.size]
-                setattr(self, name, new)
+        self.reserve(n, shapes=(coords.shape[1:], logp.shape[1:]))
         self._coords[self.size:self.size + n], self._logp[self.size:self.size + n] = coords, logp
         self.size += n
 

@@ -29,7 +29,7 @@ DL_BENCH_FORCE_DIST=1 DL_ENS_FORCE_COMM=1 timeout 600 python3 $R/bench.py --no-c
 timeout 900 python3 $R/tools/time_configs.py > $OUT/${TAG}_time_configs.txt 2>/dev/null
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg -o $TAG -- python3 $R/tools/time_configs.py > /dev/null 2>&1
 python3 $R/tools/kernel_stats.py $OUT/trace_cfg > $OUT/${TAG}_cfg3_cfg4_kernel_stats.txt 2>&1
-# BASELINE configs[2] on the emulator layout the reference ships (dl_emulated_stacked_kernel): timing, kernel trace, SQ counters (two passes), in-kernel stamps
+# BASELINE configs[2] on the emulator layout the reference ships (dl_stk_chain_kernel + dl_emulated_stacked_gemm_kernel): timing, kernel trace, SQ counters (two passes), in-kernel stamps
 timeout 300 python3 $R/tools/time_stacked.py 4096 1 200 > $OUT/${TAG}_stacked_time.txt 2>/dev/null
 timeout 300 python3 $R/tools/time_stacked.py 4096 0 200 >> $OUT/${TAG}_stacked_time.txt 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_stk -o $TAG -- python3 $R/tools/time_stacked.py 4096 1 200 > /dev/null 2>&1

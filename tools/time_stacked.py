@@ -1,4 +1,5 @@
-"""Timing of BASELINE configs[2] on the emulator layout the reference ships (stacked engines, emulators/conversion.py:44-98): dl_emulated_stacked_kernel + the finalize.
+"""Timing of BASELINE configs[2] on the emulator layout the reference ships (stacked engines, emulators/conversion.py:44-98): dl_stk_chain_kernel + dl_emulated_stacked_gemm_kernel
+(DL_NO_STK_SPLIT=1: dl_emulated_stacked_kernel, one launch).
   python tools/time_stacked.py [B] [marg 0|1] [steps]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,7 +28,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     ms = ctx.profile_read(); ctx.profile_enable(0)
-    print('stacked cfg3 marg=%d B=%5d  %8.1f us/step  %7.2f M evals/s  kernels (us): theory %.1f gemm-slot %.1f finalize %.1f  [%d ok]' % (
+    print('stacked cfg3 marg=%d B=%5d  %8.1f us/step  %7.2f M evals/s  kernels (us): network chains %.1f feature GEMMs %.1f finalize %.1f  [%d ok]' % (
         marg, B, 1e6 * dt, B / dt / 1e6, *(1e3 * ms[k] for k in ['theory', 'window_gemm', 'finalize']), int((st == 0).sum().item())))
 
 
