@@ -178,18 +178,11 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
     const DlStkLds s = dl_stk_carve(lds);
     double* recs = s.work;                                        // [2][16][bld] basis records: batch b in record b & 1
     const int H = o.eng[0].widths[o.eng[0].n_layers];
-    dl_stk_prologue(o, theta, n_params, B, p0, tid, lds, recs, tld, R, st);
-    double outv[4][RMAX];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-        for (int u = 0; u < RMAX; ++u) outv[rr][u] = 0.;
-    const int jb = blockIdx.y * 8 + wave;
-    const dl_fg_double2* gcol = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * steps_per_block * 64 + lane;
-    // the batches (runs of groups on the same networks), in order; the records of the first two are requested now (the prologue's scratch in the work area is done with)
-    DL_STK_WGBAR;
-    int ibatch = -1, tb_cur = -1, te_cur = -1, requested = 0;     // requested: batches whose record has been asked for
-    {
+    // the records of the first two batches are requested before anything else when the work area is free (no scalar engine uses it as scratch: the standard prior basis):
+    // their round trip runs under the prologue
+    const bool early = o.eng[1].type != 0 && o.eng[2].type != 0;
+    int requested = 0;                                            // batches whose record has been asked for
+    auto request_first_two = [&]() {
         int tb_p = -1, te_p = -1;
         for (int gj = 0; gj < o.stk.n_groups && requested < 2; ++gj) {
             const double* rj = o.stk.table + (size_t)gj * DL_STK_REC;
@@ -199,7 +192,20 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
                 ++requested;
             }
         }
-    }
+    };
+    if (early) request_first_two();
+    dl_stk_prologue(o, theta, n_params, B, p0, tid, lds, recs, tld, R, st);
+    double outv[4][RMAX];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) outv[rr][u] = 0.;
+    const int jb = blockIdx.y * 8 + wave;
+    const dl_fg_double2* gcol = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * steps_per_block * 64 + lane;
+    // the batches (runs of groups on the same networks), in order; record of batch b: b & 1
+    DL_STK_WGBAR;
+    int ibatch = -1, tb_cur = -1, te_cur = -1;
+    if (!early) request_first_two();                              // (the prologue's scratch in the work area is done with)
     for (int gi = 0; gi < o.stk.n_groups; ++gi) {
         const double* rec = o.stk.table + (size_t)gi * DL_STK_REC;
         const int tb = (int)rec[0], te = (int)rec[1], m0 = (int)rec[2], m1 = (int)rec[3], kq = (int)rec[7];
