@@ -320,12 +320,54 @@ __device__ __forceinline__ DlStkLds dl_stk_carve(double* lds) {
 
 // Inputs, scalar engines, amplitudes and the amplitude-scaled monomial rows of the workgroup's 16 points (512 threads; `scratch`: 2 x 16 x tld doubles; the monomial rows are
 // NOT yet published by a barrier on return).  st: DL_STK_STAMPS slots 1 (inputs) and 2 (monomial rows) of this workgroup, or null
+// th_early / th_val (dl_emulated_stacked_gemm_kernel, n_params <= 32): thread t has ALREADY requested theta[point t / 32][column t % 32] -- before its first access to the descriptor
+// `o`, which is a round trip to the kernel-argument segment of its own: the rows go through LDS (the area of the monomial rows, written later) and the inputs are read from there,
+// one global round trip at entry instead of two in a row (the entry of dl_emulated_feature_gram_kernel)
+// beside(): work of the six waves that form no monomial rows, run beside them (dl_emulated_stacked_gemm_kernel: the requests of the first basis records)
+struct DlStkNoop { __device__ __forceinline__ void operator()() const {} };
+template <class F = DlStkNoop>
 __device__ __forceinline__ void dl_stk_prologue(const DlObsDev& o, const double* __restrict__ theta, int n_params, int64_t B, int64_t p0, int tid, double* lds_base, double* scratch,
-                                                int tld, int R, unsigned long long* st) {
+                                                int tld, int R, unsigned long long* st, bool th_early = false, double th_val = 0., F&& beside = F()) {
     constexpr int XLD = DL_STK_XLD;
     const DlStkLds s = dl_stk_carve(lds_base);
     double *x = s.x, *xs = s.xs, *amp = s.amp, *scal = s.scal, *vpv = s.vpv, *mono = s.mono;
     // ---- inputs ----
+    if (th_early) {
+        // descriptors first (lane-dependent fields of `o`: vector loads from the kernel-argument segment), then the theta rows into LDS, a barrier, the inputs from there
+        const int pt = tid / XLD, i = tid - pt * XLD;
+        const bool xlive = tid < DL_STK_PTS * XLD, xreal = xlive && i < o.n_x;
+        const DlInput xin = o.x_in[xreal ? i : 0];
+        double xlo[3], xinv[3];
+#pragma unroll
+        for (int ie = 0; ie < 3; ++ie) {
+            const DlObsDev::Engine& en = o.eng[ie];
+            const bool mlp = en.type == 0 || en.type == 2;
+            xlo[ie] = mlp ? en.xlo[xreal ? i : 0] : 0.;
+            xinv[ie] = mlp ? en.xinv[xreal ? i : 0] : 0.;
+        }
+        const int vpt = tid / DL_N_VPARS, vc = tid - vpt * DL_N_VPARS;
+        const bool vlive = tid < DL_STK_PTS * DL_N_VPARS;
+        const DlInput vin = o.vp_in[vlive ? vc : 0];
+        double* trow = mono;                        // [16][32] (the monomial rows are written after the barrier below)
+        if (st != nullptr && tid == 0) st[22] = __builtin_amdgcn_s_memtime();      // (slots 20 - 23: inside the entry of dl_emulated_stacked_gemm_kernel)
+        trow[tid] = th_val;
+        __syncthreads();
+        if (st != nullptr && tid == 0) st[23] = __builtin_amdgcn_s_memtime();
+        if (xlive) {
+            const double tv = trow[pt * 32 + (xin.col >= 0 ? xin.col : 0)];
+            const double v = xreal ? (xin.col >= 0 ? tv : xin.value) : 0.;
+            if (xreal) x[pt * DL_MAX_X + i] = v;
+#pragma unroll
+            for (int ie = 0; ie < 3; ++ie) {
+                const DlObsDev::Engine& en = o.eng[ie];
+                if (en.type == 0 || en.type == 2) xs[(ie * DL_STK_PTS + pt) * XLD + i] = xreal ? (v - xlo[ie]) * xinv[ie] : 0.;   // conversion.py:75-77
+            }
+        }
+        if (vlive) {
+            const double tv = trow[vpt * 32 + (vin.col >= 0 ? vin.col : 0)];
+            vpv[vpt * 12 + vc] = vin.col >= 0 ? tv : vin.value;
+        }
+    } else {
     for (int idx = tid; idx < DL_STK_PTS * XLD; idx += 512) {
         const int pt = idx / XLD, i = idx - pt * XLD;
         const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
@@ -341,6 +383,7 @@ __device__ __forceinline__ void dl_stk_prologue(const DlObsDev& o, const double*
         const int pt = idx / DL_N_VPARS, c = idx - pt * DL_N_VPARS;
         const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
         vpv[pt * 12 + c] = dl_get(o.vp_in[c], theta + (size_t)b * n_params);
+    }
     }
     __syncthreads();
     if (st != nullptr && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
@@ -381,7 +424,8 @@ __device__ __forceinline__ void dl_stk_prologue(const DlObsDev& o, const double*
     }
     __syncthreads();
     // ---- monomial rows: one lane per (point, row), then scaled group by group (a monomial belongs to one group; monomials of no group feed nothing) ----
-    if (tid < DL_STK_PTS * DL_STK_ROWS) {
+    if (tid >= DL_STK_PTS * DL_STK_ROWS) beside();
+    else {
         const int pt = tid & 15, r = tid >> 4;
         if (r < R) {
             const double sigma8 = o.eng[1].type >= 0 ? scal[pt * 4 + 1] : o.eng[1].cst;

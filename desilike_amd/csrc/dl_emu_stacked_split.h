@@ -134,13 +134,14 @@ __global__ __launch_bounds__(256, 3) void dl_stk_chain_kernel(const double* __re
 }
 
 // a batch's basis records basis [B][ldk] (columns [tb H, te H)) -> record `rec` [16][bld] in LDS, by LDS-DMA where a row is whole 1 KB pieces (wave w takes pieces w, w + 8, ...),
-// else by loads and ds_writes; asynchronous in the first case: the caller waits (vmcnt) before the barrier that publishes the record
-__device__ __forceinline__ void dl_stks_fetch(const double* __restrict__ basis_in, int64_t ldk, int64_t B, int64_t p0, int tb, int te, int H, double* rec, int bld, int tid, int wave, int lane) {
+// else by loads and ds_writes; asynchronous in the first case: the caller waits (vmcnt) before the barrier that publishes the record.  w0 > 0: waves w0 .. 7 share the work
+// (the others form the monomial rows meanwhile)
+__device__ __forceinline__ void dl_stks_fetch(const double* __restrict__ basis_in, int64_t ldk, int64_t B, int64_t p0, int tb, int te, int H, double* rec, int bld, int tid, int wave, int lane, int w0 = 0) {
     const int row_doubles = (te - tb) * H;
     if (row_doubles <= 0) return;
     if (row_doubles % 128 == 0) {
         const int segs = row_doubles / 128;
-        for (int q = wave; q < DL_STK_PTS * segs; q += 8) {
+        for (int q = wave - w0; q < DL_STK_PTS * segs; q += 8 - w0) {
             const int r = q / segs, sg = q - r * segs;
             const int64_t b = p0 + r < B ? p0 + r : B - 1;
             const double* src = basis_in + (size_t)b * ldk + (size_t)tb * H + (size_t)sg * 128 + 2 * lane;
@@ -149,7 +150,7 @@ __device__ __forceinline__ void dl_stks_fetch(const double* __restrict__ basis_i
         }
     } else {
         const int c2n = row_doubles / 2;      // (H even: dl_stks_ok)
-        for (int idx = tid; idx < DL_STK_PTS * c2n; idx += 512) {
+        for (int idx = tid - 64 * w0; idx < DL_STK_PTS * c2n; idx += 512 - 64 * w0) {
             const int r = idx / c2n, c2 = idx - r * c2n;
             const int64_t b = p0 + r < B ? p0 + r : B - 1;
             *reinterpret_cast<dl_fg_double2*>(rec + (size_t)r * bld + 2 * c2) = *reinterpret_cast<const dl_fg_double2*>(basis_in + (size_t)b * ldk + (size_t)tb * H + 2 * c2);
@@ -164,9 +165,27 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
                                                                        const double* __restrict__ basis_in, int64_t ldk) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t p0 = (int64_t)blockIdx.x * DL_STK_PTS;
+    // theta, n_params, B arrive in SGPRs with the wave (kernel-argument preload): the theta rows of the 16 points are requested before the first access to the descriptor `o`
+    // (thread t: point t / 32, column t % 32; dl_stk_prologue), and every 64-byte line of the kernel-argument segment is touched by one batch of scalar loads -- the fields
+    // are read where they are first needed, and each first touch of a line was a miss of the scalar cache inside a dependent chain (as in dl_emulated_feature_gram_kernel)
+    const bool th_early = n_params <= 32;
+    double th_val = 0.;
+    if (th_early) {
+        const int pt = tid >> 5, j = tid & 31;
+        const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
+        th_val = theta[(size_t)b * n_params + (j < n_params ? j : 0)];
+    }
+    {
+        constexpr int n_lines = (int)((32 + sizeof(DlObsDev) + 32 + sizeof(DlStkTail) + 16) / 64);      // (whole lines inside the segment)
+        const __attribute__((address_space(4))) int* kargs = (const __attribute__((address_space(4))) int*)__builtin_amdgcn_kernarg_segment_ptr();
+        int touched = 0;
+#pragma unroll
+        for (int l = 0; l < n_lines; ++l) touched |= kargs[16 * l];
+        asm volatile("; kernel arguments touched: %0" :: "s"(touched));
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g = lane >> 4;
-    const int64_t p0 = (int64_t)blockIdx.x * DL_STK_PTS;
     const int R = 1 + o.n_var;
     const int tld = dl_stk_tld(o), bld = dl_stk_bld(o);
     // DL_STK_STAMPS (null in production): the slots of dl_emulated_stacked_kernel -- 0 entry, 1 inputs, 2 monomial rows, 3 + 2 gi: the group's record in place, 4 + 2 gi: its feature GEMM done, 30: tail done
@@ -178,23 +197,25 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
     const DlStkLds s = dl_stk_carve(lds);
     double* recs = s.work;                                        // [2][16][bld] basis records: batch b in record b & 1
     const int H = o.eng[0].widths[o.eng[0].n_layers];
-    // the records of the first two batches are requested before anything else when the work area is free (no scalar engine uses it as scratch: the standard prior basis):
-    // their round trip runs under the prologue
+    // the records of the first two batches are requested by the six waves that form no monomial rows, beside them, when the work area is free (no scalar engine uses it as
+    // scratch: the standard prior basis): the group table behind the request is a cold global round trip of its own -- asked for before the prologue it sat in front of the
+    // inputs, on the path to the first feature GEMM (stamps: 60 of the entry's 206 hundred cycles)
     const bool early = o.eng[1].type != 0 && o.eng[2].type != 0;
     int requested = 0;                                            // batches whose record has been asked for
-    auto request_first_two = [&]() {
+    auto request_first_two = [&](int w0) {
         int tb_p = -1, te_p = -1;
         for (int gj = 0; gj < o.stk.n_groups && requested < 2; ++gj) {
             const double* rj = o.stk.table + (size_t)gj * DL_STK_REC;
             if ((int)rj[0] != tb_p || (int)rj[1] != te_p) {
                 tb_p = (int)rj[0]; te_p = (int)rj[1];
-                dl_stks_fetch(basis_in, ldk, B, p0, tb_p, te_p, H, recs + (size_t)(requested & 1) * DL_STK_PTS * bld, bld, tid, wave, lane);
+                dl_stks_fetch(basis_in, ldk, B, p0, tb_p, te_p, H, recs + (size_t)(requested & 1) * DL_STK_PTS * bld, bld, tid, wave, lane, w0);
                 ++requested;
             }
         }
     };
-    if (early) request_first_two();
-    dl_stk_prologue(o, theta, n_params, B, p0, tid, lds, recs, tld, R, st);
+    constexpr int mono_waves = DL_STK_PTS * DL_STK_ROWS / 64;     // (waves of the monomial rows: dl_stk_prologue)
+    if (early) dl_stk_prologue(o, theta, n_params, B, p0, tid, lds, recs, tld, R, st, th_early, th_val, [&]() { request_first_two(mono_waves); });
+    else dl_stk_prologue(o, theta, n_params, B, p0, tid, lds, recs, tld, R, st, th_early, th_val);
     double outv[4][RMAX];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
     // the batches (runs of groups on the same networks), in order; record of batch b: b & 1
     DL_STK_WGBAR;
     int ibatch = -1, tb_cur = -1, te_cur = -1;
-    if (!early) request_first_two();                              // (the prologue's scratch in the work area is done with)
+    if (!early) request_first_two(0);                             // (the prologue's scratch in the work area is done with)
     for (int gi = 0; gi < o.stk.n_groups; ++gi) {
         const double* rec = o.stk.table + (size_t)gi * DL_STK_REC;
         const int tb = (int)rec[0], te = (int)rec[1], m0 = (int)rec[2], m1 = (int)rec[3], kq = (int)rec[7];

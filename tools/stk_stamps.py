@@ -63,6 +63,8 @@ def split_form(launches):
         for q in live[1:]:
             print('   %-22s +%8.2f   (at %8.2f)' % (names[q], np.median(a[:, q] - a[:, prev]) / 100., np.median(a[:, q] - a[:, live[0]]) / 100.))
             prev = q
+        if np.all(a[:, 22:24] > 0):   # inside the entry (early theta rows): descriptors of the inputs loaded, theta rows in LDS
+            print('   entry: ' + '  '.join('%s %.1f' % (n, v) for n, v in zip(['-> input descriptors', '-> theta rows in LDS (barrier)'], np.median(a[:, 22:24] - a[:, [0]], axis=0) / 100.)))
         w = a[:, 32:128].reshape(len(a), 8, 12)
         for gi in range(6):
             if not np.all(w[:, :, gi] > 0): continue
