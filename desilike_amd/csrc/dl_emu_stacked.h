@@ -473,17 +473,56 @@ __device__ __forceinline__ void dl_stk_store_rows(const double (&outv)[4][RMAX],
 }
 
 // the finalize in the tail: rows -> LDS (X [16 points][xr][DL_FG_XLD], over the work area: every wave is past it after the barrier), Gram matrices, solve
+// log-priors and NaN flags of the workgroup's 16 points by lanes 0 - 15 of ONE wave (the caller picks it) into lp_lds / nan_lds [16]
+__device__ __forceinline__ void dl_stk_priors(const DlStkTail& tl, const double* __restrict__ theta, int n_params, int64_t B, int64_t p0, int lane, double* lp_lds, int* nan_lds) {
+    if (n_params <= 32) {
+        // four lanes per point, lane (point, q) the terms of the parameters p = q mod 4: every load of the wave goes out at once (a lane per point walking its parameters
+        // waited for the prior table four parameters at a time); then the terms are summed IN PARAMETER ORDER (shuffles) -- the sum of dl_marg_priors_lane bit for bit
+        const int pt = lane & 15, pq = lane >> 4;
+        const int64_t b = p0 + pt < B ? p0 + pt : B - 1;
+        const double* th = theta + (size_t)b * n_params;
+        double xv[8], term[8];
+        int nan_in = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xv[q] = 4 * q + pq < n_params ? th[4 * q + pq] : 0.;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = 4 * q + pq;
+            term[q] = p < n_params ? dl_prior_logpdf(tl.priors + 5 * p, xv[q]) : 0.;
+            if (p < n_params && xv[q] != xv[q]) nan_in = 1;
+        }
+        double lp = 0.;
+#pragma unroll
+        for (int p = 0; p < 32; ++p) {
+            const double t = __shfl(term[p >> 2], pt + 16 * (p & 3), 64);
+            if (p < n_params) lp += t;
+        }
+        nan_in |= __shfl_xor(nan_in, 16, 64);
+        nan_in |= __shfl_xor(nan_in, 32, 64);
+        if (lane < DL_STK_PTS) { lp_lds[lane] = lp; nan_lds[lane] = nan_in; }
+        return;
+    }
+    if (lane < DL_STK_PTS) {
+        const int64_t b = p0 + lane;
+        double lp;
+        int nan_in;
+        dl_marg_priors_lane(theta + (size_t)(b < B ? b : B - 1) * n_params, n_params, tl.priors, lp, nan_in);
+        lp_lds[lane] = lp; nan_lds[lane] = nan_in;
+    }
+}
+
+// cpre (or null): the constant parts tl.cst[u][column of this lane] of the rows, requested by the caller ahead of the tail (they are cold: a global round trip at the head
+// of the tail otherwise); priors_done: lp_lds / nan_lds were filled by the caller (dl_stk_priors beside the monomial rows) -- else wave 1 fills them here
 template <int RMAX>
 __device__ __forceinline__ void dl_stk_finalize_tail(const DlStkTail& tl, const double (&outv)[4][RMAX], int R, double* X, const double* __restrict__ theta,
-                                                     int n_params, int64_t B, int64_t p0, int tid, int wave, int lane, int col, int g) {
-    __shared__ double lp_lds[DL_STK_PTS];      // log-priors and NaN flags of the 16 points
-    __shared__ int nan_lds[DL_STK_PTS];
+                                                     int n_params, int64_t B, int64_t p0, int tid, int wave, int lane, int col, int g, double* lp_lds, int* nan_lds,
+                                                     const double* cpre = nullptr, bool priors_done = false) {
     __syncthreads();
     const int cbase = wave * 16 + col;                   // (N_pad = 128: one workgroup column group, wave = column block)
 #pragma unroll
     for (int u = 0; u < RMAX; ++u) {
         if (u < R) {
-            const double c = tl.cst[u][cbase];
+            const double c = cpre != nullptr ? cpre[u] : tl.cst[u][cbase];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) X[((size_t)(g + 4 * rr) * tl.xr + tl.row_of[u]) * DL_FG_XLD + cbase] = outv[rr][u] + c;
         }
@@ -495,13 +534,7 @@ __device__ __forceinline__ void dl_stk_finalize_tail(const DlStkTail& tl, const 
         }
     __syncthreads();
     dl_stk_gram_phase(X, tl.xr, wave, lane, g);            // the 8 x 8 block of point pt at X + pt xr DL_FG_XLD + 8 i + j
-    if (wave == 1 && lane < DL_STK_PTS) {
-        const int64_t b = p0 + lane;
-        double lp;
-        int nan_in;
-        dl_marg_priors_lane(theta + (size_t)(b < B ? b : B - 1) * n_params, n_params, tl.priors, lp, nan_in);
-        lp_lds[lane] = lp; nan_lds[lane] = nan_in;
-    }
+    if (!priors_done && wave == 1) dl_stk_priors(tl, theta, n_params, B, p0, lane, lp_lds, nan_lds);
     __syncthreads();
     if (wave == 0 && lane < DL_STK_PTS && p0 + lane < B) {
         const int64_t b = p0 + lane;
@@ -579,7 +612,11 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_kernel(const double* 
         DL_STK_STAMP(4 + 2 * gi)
     }
     if (!tl.enabled) dl_stk_store_rows<RMAX>(outv, R, out, ldo, accumulate, B, p0, jb, col, g);
-    else dl_stk_finalize_tail<RMAX>(tl, outv, R, basis, theta, n_params, B, p0, tid, wave, lane, col, g);
+    else {
+        __shared__ double lp_lds[DL_STK_PTS];      // log-priors and NaN flags of the 16 points
+        __shared__ int nan_lds[DL_STK_PTS];
+        dl_stk_finalize_tail<RMAX>(tl, outv, R, basis, theta, n_params, B, p0, tid, wave, lane, col, g, lp_lds, nan_lds);
+    }
 
     DL_STK_STAMP(30)
     if (st != nullptr && tid == 0) st[31] = __builtin_amdgcn_s_memrealtime();

@@ -412,7 +412,11 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_ov_kernel(const doubl
         }
     }
     if (!tl.enabled) dl_stk_store_rows<RMAX>(outv, R, out, ldo, accumulate, B, p0, jb, col, g);
-    else dl_stk_finalize_tail<RMAX>(tl, outv, R, recs, theta, n_params, B, p0, tid, wave, lane, col, g);
+    else {
+        __shared__ double lp_lds[DL_STK_PTS];
+        __shared__ int nan_lds[DL_STK_PTS];
+        dl_stk_finalize_tail<RMAX>(tl, outv, R, recs, theta, n_params, B, p0, tid, wave, lane, col, g, lp_lds, nan_lds);
+    }
     DL_STKO_STAMP(0x70)
     if (st != nullptr) st[63] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
 #undef DL_STKO_STAMP

@@ -214,13 +214,22 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
         }
     };
     constexpr int mono_waves = DL_STK_PTS * DL_STK_ROWS / 64;     // (waves of the monomial rows: dl_stk_prologue)
-    if (early) dl_stk_prologue(o, theta, n_params, B, p0, tid, lds, recs, tld, R, st, th_early, th_val, [&]() { request_first_two(mono_waves); });
-    else dl_stk_prologue(o, theta, n_params, B, p0, tid, lds, recs, tld, R, st, th_early, th_val);
-    double outv[4][RMAX];
+    // the log-priors of the 16 points (the finalize in the tail needs them; they depend on theta only) by the last wave, also beside the monomial rows: in the tail they were two
+    // cold round trips (prior table, theta rows) of one wave between the Gram phase and the barrier in front of the solve
+    __shared__ double lp_lds[DL_STK_PTS];
+    __shared__ int nan_lds[DL_STK_PTS];
+    auto beside = [&]() {
+        if (tl.enabled && wave == 7) dl_stk_priors(tl, theta, n_params, B, p0, lane, lp_lds, nan_lds);      // (first: its cold loads beside the others' wait for the group table)
+        if (early) request_first_two(mono_waves);
+    };
+    dl_stk_prologue(o, theta, n_params, B, p0, tid, lds, recs, tld, R, st, th_early, th_val, beside);
+    double outv[4][RMAX], cpre[RMAX];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
         for (int u = 0; u < RMAX; ++u) outv[rr][u] = 0.;
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) cpre[u] = 0.;
     const int jb = blockIdx.y * 8 + wave;
     const dl_fg_double2* gcol = reinterpret_cast<const dl_fg_double2*>(gfrag) + (size_t)jb * steps_per_block * 64 + lane;
     // the batches (runs of groups on the same networks), in order; record of batch b: b & 1
@@ -238,6 +247,10 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
             DL_STK_WGBAR;                                                   // ... and everybody's
         }
         DL_STKS_STAMP(3 + 2 * gi) DL_STKS_WSTAMP(0)
+        if (RMAX <= 6 && tl.enabled && gi + 1 == o.stk.n_groups) {      // the constant parts of the rows (cold) travel under the last feature GEMM (eight rows: no registers left for them)
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u) cpre[u] = u < R ? tl.cst[u][wave * 16 + col] : 0.;
+        }
         const double* rc = recs + (size_t)(ibatch & 1) * DL_STK_PTS * bld;
         dl_stk_group<RMAX>(m1 - m0, rc + (size_t)col * bld + 2 * g, gcol + (size_t)kq * 64, nq, s.mono + m0, R, g, outv);
         DL_STKS_STAMP(4 + 2 * gi) DL_STKS_WSTAMP(6)
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
         }
     }
     if (!tl.enabled) dl_stk_store_rows<RMAX>(outv, R, out, ldo, accumulate, B, p0, jb, col, g);
-    else dl_stk_finalize_tail<RMAX>(tl, outv, R, recs, theta, n_params, B, p0, tid, wave, lane, col, g);
+    else dl_stk_finalize_tail<RMAX>(tl, outv, R, recs, theta, n_params, B, p0, tid, wave, lane, col, g, lp_lds, nan_lds, RMAX <= 6 ? cpre : nullptr, true);
     DL_STKS_STAMP(30)
     if (st != nullptr && tid == 0) st[31] = __builtin_amdgcn_s_memrealtime();
 #undef DL_STKS_STAMP
