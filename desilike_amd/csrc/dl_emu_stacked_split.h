@@ -134,14 +134,14 @@ __global__ __launch_bounds__(256, 3) void dl_stk_chain_kernel(const double* __re
 }
 
 // a batch's basis records basis [B][ldk] (columns [tb H, te H)) -> record `rec` [16][bld] in LDS, by LDS-DMA where a row is whole 1 KB pieces (wave w takes pieces w, w + 8, ...),
-// else by loads and ds_writes; asynchronous in the first case: the caller waits (vmcnt) before the barrier that publishes the record.  w0 > 0: waves w0 .. 7 share the work
-// (the others form the monomial rows meanwhile)
-__device__ __forceinline__ void dl_stks_fetch(const double* __restrict__ basis_in, int64_t ldk, int64_t B, int64_t p0, int tb, int te, int H, double* rec, int bld, int tid, int wave, int lane, int w0 = 0) {
+// else by loads and ds_writes; asynchronous in the first case: the caller waits (vmcnt) before the barrier that publishes the record.  Waves w0 .. w0 + nw - 1 share the work
+// (the others form the monomial rows / the log-priors meanwhile)
+__device__ __forceinline__ void dl_stks_fetch(const double* __restrict__ basis_in, int64_t ldk, int64_t B, int64_t p0, int tb, int te, int H, double* rec, int bld, int tid, int wave, int lane, int w0 = 0, int nw = 8) {
     const int row_doubles = (te - tb) * H;
-    if (row_doubles <= 0) return;
+    if (row_doubles <= 0 || wave < w0 || wave >= w0 + nw) return;
     if (row_doubles % 128 == 0) {
         const int segs = row_doubles / 128;
-        for (int q = wave - w0; q < DL_STK_PTS * segs; q += 8 - w0) {
+        for (int q = wave - w0; q < DL_STK_PTS * segs; q += nw) {
             const int r = q / segs, sg = q - r * segs;
             const int64_t b = p0 + r < B ? p0 + r : B - 1;
             const double* src = basis_in + (size_t)b * ldk + (size_t)tb * H + (size_t)sg * 128 + 2 * lane;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void dl_stks_fetch(const double* __restrict__ basis_i
         }
     } else {
         const int c2n = row_doubles / 2;      // (H even: dl_stks_ok)
-        for (int idx = tid - 64 * w0; idx < DL_STK_PTS * c2n; idx += 512 - 64 * w0) {
+        for (int idx = tid - 64 * w0; idx < DL_STK_PTS * c2n; idx += 64 * nw) {
             const int r = idx / c2n, c2 = idx - r * c2n;
             const int64_t b = p0 + r < B ? p0 + r : B - 1;
             *reinterpret_cast<dl_fg_double2*>(rec + (size_t)r * bld + 2 * c2) = *reinterpret_cast<const dl_fg_double2*>(basis_in + (size_t)b * ldk + (size_t)tb * H + 2 * c2);
@@ -202,13 +202,13 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
     // inputs, on the path to the first feature GEMM (stamps: 60 of the entry's 206 hundred cycles)
     const bool early = o.eng[1].type != 0 && o.eng[2].type != 0;
     int requested = 0;                                            // batches whose record has been asked for
-    auto request_first_two = [&](int w0) {
+    auto request_first_two = [&](int w0, int nw) {
         int tb_p = -1, te_p = -1;
         for (int gj = 0; gj < o.stk.n_groups && requested < 2; ++gj) {
             const double* rj = o.stk.table + (size_t)gj * DL_STK_REC;
             if ((int)rj[0] != tb_p || (int)rj[1] != te_p) {
                 tb_p = (int)rj[0]; te_p = (int)rj[1];
-                dl_stks_fetch(basis_in, ldk, B, p0, tb_p, te_p, H, recs + (size_t)(requested & 1) * DL_STK_PTS * bld, bld, tid, wave, lane, w0);
+                dl_stks_fetch(basis_in, ldk, B, p0, tb_p, te_p, H, recs + (size_t)(requested & 1) * DL_STK_PTS * bld, bld, tid, wave, lane, w0, nw);
                 ++requested;
             }
         }
@@ -219,8 +219,11 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
     __shared__ double lp_lds[DL_STK_PTS];
     __shared__ int nan_lds[DL_STK_PTS];
     auto beside = [&]() {
+        if (st != nullptr && tid == 448) st[24] = __builtin_amdgcn_s_memtime();      // (slots 24 - 26: wave 7 beside the monomial rows)
         if (tl.enabled && wave == 7) dl_stk_priors(tl, theta, n_params, B, p0, lane, lp_lds, nan_lds);      // (first: its cold loads beside the others' wait for the group table)
-        if (early) request_first_two(mono_waves);
+        if (st != nullptr && tid == 448) st[25] = __builtin_amdgcn_s_memtime();
+        if (early) request_first_two(mono_waves, tl.enabled ? 7 - mono_waves : 8 - mono_waves);      // (wave 7 keeps to the log-priors: with a share of the requests behind them it was the last to arrive, 50 hundred cycles after the monomial rows)
+        if (st != nullptr && tid == 448) st[26] = __builtin_amdgcn_s_memtime();
     };
     dl_stk_prologue(o, theta, n_params, B, p0, tid, lds, recs, tld, R, st, th_early, th_val, beside);
     double outv[4][RMAX], cpre[RMAX];
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(512) void dl_emulated_stacked_gemm_kernel(const dou
     // the batches (runs of groups on the same networks), in order; record of batch b: b & 1
     DL_STK_WGBAR;
     int ibatch = -1, tb_cur = -1, te_cur = -1;
-    if (!early) request_first_two(0);                             // (the prologue's scratch in the work area is done with)
+    if (!early) request_first_two(0, 8);                             // (the prologue's scratch in the work area is done with)
     for (int gi = 0; gi < o.stk.n_groups; ++gi) {
         const double* rec = o.stk.table + (size_t)gi * DL_STK_REC;
         const int tb = (int)rec[0], te = (int)rec[1], m0 = (int)rec[2], m1 = (int)rec[3], kq = (int)rec[7];

@@ -65,6 +65,8 @@ def split_form(launches):
             prev = q
         if np.all(a[:, 22:24] > 0):   # inside the entry (early theta rows): descriptors of the inputs loaded, theta rows in LDS
             print('   entry: ' + '  '.join('%s %.1f' % (n, v) for n, v in zip(['-> input descriptors', '-> theta rows in LDS (barrier)'], np.median(a[:, 22:24] - a[:, [0]], axis=0) / 100.)))
+        if np.all(a[:, 24:27] > 0):   # wave 7 beside the monomial rows: start, log-priors done, first two records requested
+            print('   wave 7 beside the monomial rows: ' + '  '.join('%s %.1f' % (n, v) for n, v in zip(['start', '-> log-priors', '-> records requested'], np.median(a[:, 24:27] - a[:, [0]], axis=0) / 100.)))
         w = a[:, 32:128].reshape(len(a), 8, 12)
         for gi in range(6):
             if not np.all(w[:, :, gi] > 0): continue
