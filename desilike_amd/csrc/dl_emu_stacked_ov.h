@@ -41,18 +41,25 @@ static inline bool dl_stko_ok(const DlObsDev& o) {
 // The activations of NV values side by side, one instruction per value and step: a value alone is a chain of ~32 DEPENDENT fp64 instructions, and a dependent fp64
 // instruction issues ~16 cycles after its predecessor -- written value by value (what the compiler emits from dl_stk_act under register pressure) the activations of a task
 // took 2 k cycles for 130 instructions; four chains in step issue back to back (4 cycles per instruction).  The scheduling barriers pin the order.
+// v_max_f64 / v_min_f64 as single instructions: fmax / fmin compile to the instruction PLUS a canonicalisation of every operand that is not known to be quiet (v_max_f64 x, x, x:
+// two extra instructions per value in front of the clamps below).  In the IEEE mode of compute kernels the instruction itself returns the other operand for a NaN, as fmax / fmin do.
+__device__ __forceinline__ double dl_vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b)); return r; }
+__device__ __forceinline__ double dl_vmax_neg(double a, double b) { double r; asm("v_max_f64 %0, -%1, %2" : "=v"(r) : "v"(a), "s"(b)); return r; }
+__device__ __forceinline__ double dl_vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b)); return r; }
+__device__ __forceinline__ double dl_vmax0(double a) { double r; asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(a)); return r; }
+
 template <int NV>
 __device__ __forceinline__ void dl_stk_act_rows(int act, double (&v)[NV]) {
 #define DL_STK_ROW(body) { _Pragma("unroll") for (int r = 0; r < NV; ++r) { body; } __builtin_amdgcn_sched_barrier(0); }
-    if (act == 1) { DL_STK_ROW(v[r] = v[r] > 0. ? v[r] : 0.) return; }                        // conversion.py:31
+    if (act == 1) { DL_STK_ROW(v[r] = dl_vmax0(v[r])) return; }                                // conversion.py:31 (a NaN gives 0, as v > 0 ? v : 0 does)
     // e^x with full-rate instructions only (round 6: v_rndne_f64, v_cvt_i32_f64 and v_ldexp_f64 issue at a quarter of the rate of an FMA): n = rint(x log2 e) by the
     // 1.5 x 2^52 constant (the integer sits in the low dword of the sum), Cody-Waite reduction, degree-13 Taylor polynomial, 2^n by an integer addition to the exponent field
     // (x clamped to [-708, 709]: the result stays a normal number); then one v_rcp_f64 + two Newton steps
     double x[NV], n[NV], p[NV];
     int ni[NV];
-    if (act == 0) DL_STK_ROW(x[r] = fmax(-v[r], -708.))                                        // silu v / (1 + e^-v), conversion.py:29
-    else { DL_STK_ROW(x[r] = v[r] + v[r]) DL_STK_ROW(x[r] = fmax(x[r], -708.)) }               // tanh 1 - 2 / (1 + e^2v), conversion.py:33
-    DL_STK_ROW(x[r] = fmin(x[r], 709.))
+    if (act == 0) DL_STK_ROW(x[r] = dl_vmax_neg(v[r], -708.))                                  // silu v / (1 + e^-v), conversion.py:29
+    else { DL_STK_ROW(x[r] = v[r] + v[r]) DL_STK_ROW(x[r] = dl_vmax(x[r], -708.)) }            // tanh 1 - 2 / (1 + e^2v), conversion.py:33
+    DL_STK_ROW(x[r] = dl_vmin(x[r], 709.))
     DL_STK_ROW(n[r] = fma(x[r], 1.4426950408889634074, 6755399441055744.))
     DL_STK_ROW(ni[r] = __double2loint(n[r]))
     DL_STK_ROW(n[r] = n[r] - 6755399441055744.)

@@ -33,6 +33,7 @@ static inline bool dl_stks_ok(const DlObsDev& o) {
 
 #if defined(__HIPCC__)
 // (A) one wave = one (network, 16-point tile) chain.  basis_out [B][ldk]: the last hidden layer of network t of the observable's stack at columns [t H, (t + 1) H).
+template <int ACT>      // the activation of the hidden layers (0 silu, 1 relu, 2 tanh) at compile time: at run time a tile carried three copies of the activation rows behind scalar branches
 __global__ __launch_bounds__(256, 3) void dl_stk_chain_kernel(const double* __restrict__ theta, int n_params, int64_t B, const DlObsDev o, double* __restrict__ basis_out, int64_t ldk,
                                                             int n_pt_tiles) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -43,7 +44,8 @@ __global__ __launch_bounds__(256, 3) void dl_stk_chain_kernel(const double* __re
     const int net = chain / n_pt_tiles, tile = chain - net * n_pt_tiles;   // network-major: the waves of a workgroup share their weights
     const int col = lane & 15, g = lane >> 4;
     const DlObsDev::Engine& e = o.eng[0];
-    const int n_layers = e.n_layers, act = e.act, H = e.widths[n_layers];
+    const int n_layers = e.n_layers, H = e.widths[n_layers];
+    constexpr int act = ACT;
     const double* __restrict__ wf = o.stk.wfrag + (size_t)net * o.stk.frag_doubles + lane;
     double* hb = lds + (size_t)wave * DL_STK_PTS * DL_STKS_LD;
     const int64_t p0 = (int64_t)tile * DL_STK_PTS;
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(256, 3) void dl_stk_chain_kernel(const double* __re
         for (int t = 0; t < DL_STKS_TILES; ++t) {
             if (t < tiles) {
                 const double bias = bl[16 * t];
-                dl_stk_double4 c0 = {bias, bias, bias, bias}, c1 = {0., 0., 0., 0.};      // (the first chain accumulates onto the bias)
+                dl_stk_double4 c0 = {bias, bias, bias, bias};      // ONE accumulator chain, started from the bias: a dependent v_mfma_f64_16x16x4 issues as fast as an independent one
+                                                                    // (64 cycles either way, profiles/mfma_f64_probe.txt) -- a second chain was four zeros and four additions per tile
                 if (ksteps == 16) {
                     double (&wc)[16] = (t & 1) ? wb : wa;
                     double (&wn)[16] = (t & 1) ? wa : wb;
@@ -88,10 +91,7 @@ __global__ __launch_bounds__(256, 3) void dl_stk_chain_kernel(const double* __re
                         for (int u = 0; u < 16; ++u) wn[u] = wl[(size_t)(t + 1) * 1024 + u * 64];
                     }
 #pragma unroll
-                    for (int u = 0; u < 16; u += 2) {
-                        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], wc[u], c0, 0, 0, 0);
-                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u + 1], wc[u + 1], c1, 0, 0, 0);
-                    }
+                    for (int u = 0; u < 16; ++u) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], wc[u], c0, 0, 0, 0);
                 } else if (ksteps <= 4) {      // short layers (the first one: n_x inputs)
                     double w4[4];
 #pragma unroll
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 3) void dl_stk_chain_kernel(const double* __re
                 }
                 double vv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) vv[r] = c0[r] + c1[r];
+                for (int r = 0; r < 4; ++r) vv[r] = c0[r];
                 dl_stk_act_rows<4>(act, vv);
                 const int oc = 16 * t + col;
                 if (!last) {

@@ -923,7 +923,8 @@ bool dl_launch_stk_chains(const DlObsDev& obs, const double* theta, int n_params
     const int64_t chains = (int64_t)obs.stk.n_trunks * n_pt_tiles, ldk = (int64_t)obs.stk.n_trunks * obs.eng[0].widths[obs.eng[0].n_layers];
     if (chains > 0) {
         const size_t shm_a = (size_t)4 * DL_STK_PTS * DL_STKS_LD * sizeof(double);
-        DL_LAUNCH(dl_stk_chain_kernel, dim3((unsigned)((chains + 3) / 4)), dim3(256), shm_a, stream, theta, n_params, B, obs, basis_ws, ldk, n_pt_tiles);
+        auto launch = [&](auto kernel) { DL_LAUNCH(kernel, dim3((unsigned)((chains + 3) / 4)), dim3(256), shm_a, stream, theta, n_params, B, obs, basis_ws, ldk, n_pt_tiles); };
+        if (obs.eng[0].act == 0) launch(dl_stk_chain_kernel<0>); else if (obs.eng[0].act == 1) launch(dl_stk_chain_kernel<1>); else launch(dl_stk_chain_kernel<2>);
     }
     return true;
 }
