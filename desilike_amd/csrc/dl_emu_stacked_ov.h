@@ -53,31 +53,33 @@ __device__ __forceinline__ void dl_stk_act_rows(int act, double (&v)[NV]) {
 #define DL_STK_ROW(body) { _Pragma("unroll") for (int r = 0; r < NV; ++r) { body; } __builtin_amdgcn_sched_barrier(0); }
     if (act == 1) { DL_STK_ROW(v[r] = dl_vmax0(v[r])) return; }                                // conversion.py:31 (a NaN gives 0, as v > 0 ? v : 0 does)
     // e^x with full-rate instructions only (round 6: v_rndne_f64, v_cvt_i32_f64 and v_ldexp_f64 issue at a quarter of the rate of an FMA): n = rint(x log2 e) by the
-    // 1.5 x 2^52 constant (the integer sits in the low dword of the sum), Cody-Waite reduction, degree-13 Taylor polynomial, 2^n by an integer addition to the exponent field
+    // 1.5 x 2^52 constant (the integer sits in the low dword of the sum), Cody-Waite reduction, degree-11 polynomial, 2^n by an integer addition to the exponent field
     // (x clamped to [-708, 709]: the result stays a normal number); then one v_rcp_f64 + two Newton steps
     double x[NV], n[NV], p[NV];
     int ni[NV];
-    if (act == 0) DL_STK_ROW(x[r] = dl_vmax_neg(v[r], -708.))                                  // silu v / (1 + e^-v), conversion.py:29
-    else { DL_STK_ROW(x[r] = v[r] + v[r]) DL_STK_ROW(x[r] = dl_vmax(x[r], -708.)) }            // tanh 1 - 2 / (1 + e^2v), conversion.py:33
-    DL_STK_ROW(x[r] = dl_vmin(x[r], 709.))
-    DL_STK_ROW(n[r] = fma(x[r], 1.4426950408889634074, 6755399441055744.))
+    // silu v / (1 + e^-v) (conversion.py:29): the exponent is x = -v.  tanh 1 - 2 / (1 + e^2v) (conversion.py:33): the exponent is 2 v -- the factor two sits in the constants (log2 e doubled,
+    // ln 2 halved, coefficient k times 2^k: exact scalings), not in a row of its own: x below is HALF the exponent on that path
+    if (act == 0) DL_STK_ROW(x[r] = dl_vmax_neg(v[r], -708.))
+    else DL_STK_ROW(x[r] = dl_vmax(v[r], -354.))
+    DL_STK_ROW(x[r] = dl_vmin(x[r], act == 0 ? 709. : 354.5))
+    DL_STK_ROW(n[r] = fma(x[r], act == 0 ? 1.4426950408889634074 : 2.8853900817779268148, 6755399441055744.))
     DL_STK_ROW(ni[r] = __double2loint(n[r]))
     DL_STK_ROW(n[r] = n[r] - 6755399441055744.)
-    DL_STK_ROW(x[r] = fma(n[r], -6.93147180369123816490e-01, x[r]))
-    DL_STK_ROW(x[r] = fma(n[r], -1.90821492927058770002e-10, x[r]))
-    DL_STK_ROW(p[r] = fma(1. / 6227020800., x[r], 1. / 479001600.))
-    DL_STK_ROW(p[r] = fma(p[r], x[r], 1. / 39916800.))
-    DL_STK_ROW(p[r] = fma(p[r], x[r], 1. / 3628800.))
-    DL_STK_ROW(p[r] = fma(p[r], x[r], 1. / 362880.))
-    DL_STK_ROW(p[r] = fma(p[r], x[r], 1. / 40320.))
-    DL_STK_ROW(p[r] = fma(p[r], x[r], 1. / 5040.))
-    DL_STK_ROW(p[r] = fma(p[r], x[r], 1. / 720.))
-    DL_STK_ROW(p[r] = fma(p[r], x[r], 1. / 120.))
-    DL_STK_ROW(p[r] = fma(p[r], x[r], 1. / 24.))
-    DL_STK_ROW(p[r] = fma(p[r], x[r], 1. / 6.))
-    DL_STK_ROW(p[r] = fma(p[r], x[r], 0.5))
-    DL_STK_ROW(p[r] = fma(p[r], x[r], 1.))
-    DL_STK_ROW(p[r] = fma(p[r], x[r], 1.))
+    DL_STK_ROW(x[r] = fma(n[r], act == 0 ? -6.93147180369123816490e-01 : -3.46573590184561908245e-01, x[r]))
+    DL_STK_ROW(x[r] = fma(n[r], act == 0 ? -1.90821492927058770002e-10 : -9.54107464635293850010e-11, x[r]))
+    // (degree 11, interpolated at the Chebyshev nodes of |x| <= 1.0001 ln 2 / 2 in 60-digit arithmetic: 4.2e-18 off e^x before rounding -- two steps fewer than the
+    //  Taylor polynomial of degree 13 for the same 2.1e-16 after it)
+    DL_STK_ROW(p[r] = fma((act == 0 ? 2.5110049204818658e-08 : 5.142538077146861e-05), x[r], (act == 0 ? 2.763265472252779e-07 : 0.00028295838435868457)))
+    DL_STK_ROW(p[r] = fma(p[r], x[r], (act == 0 ? 2.755724088722987e-06 : 0.0014109307334261693)))
+    DL_STK_ROW(p[r] = fma(p[r], x[r], (act == 0 ? 2.4801485441561313e-05 : 0.006349180273039696)))
+    DL_STK_ROW(p[r] = fma(p[r], x[r], (act == 0 ? 0.00019841269890076403 : 0.025396825459297796)))
+    DL_STK_ROW(p[r] = fma(p[r], x[r], (act == 0 ? 0.0013888888952352863 : 0.08888888929505832)))
+    DL_STK_ROW(p[r] = fma(p[r], x[r], (act == 0 ? 0.008333333333319589 : 0.26666666666622685)))
+    DL_STK_ROW(p[r] = fma(p[r], x[r], (act == 0 ? 0.04166666666648795 : 0.6666666666638073)))
+    DL_STK_ROW(p[r] = fma(p[r], x[r], (act == 0 ? 0.1666666666666668 : 1.3333333333333344)))
+    DL_STK_ROW(p[r] = fma(p[r], x[r], (act == 0 ? 0.5000000000000019 : 2.0000000000000075)))
+    DL_STK_ROW(p[r] = fma(p[r], x[r], (act == 0 ? 1.0 : 2.0)))
+    DL_STK_ROW(p[r] = fma(p[r], x[r], (act == 0 ? 1.0 : 1.0)))
     DL_STK_ROW(p[r] = __hiloint2double(__double2hiint(p[r]) + (ni[r] << 20), __double2loint(p[r])))
     DL_STK_ROW(p[r] = p[r] + 1.)
     DL_STK_ROW(x[r] = __builtin_amdgcn_rcp(p[r]))
