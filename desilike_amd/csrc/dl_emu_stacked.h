@@ -472,7 +472,6 @@ __device__ __forceinline__ void dl_stk_store_rows(const double (&outv)[4][RMAX],
     }
 }
 
-// the finalize in the tail: rows -> LDS (X [16 points][xr][DL_FG_XLD], over the work area: every wave is past it after the barrier), Gram matrices, solve
 // log-priors and NaN flags of the workgroup's 16 points by lanes 0 - 15 of ONE wave (the caller picks it) into lp_lds / nan_lds [16]
 __device__ __forceinline__ void dl_stk_priors(const DlStkTail& tl, const double* __restrict__ theta, int n_params, int64_t B, int64_t p0, int lane, double* lp_lds, int* nan_lds) {
     if (n_params <= 32) {
@@ -511,6 +510,7 @@ __device__ __forceinline__ void dl_stk_priors(const DlStkTail& tl, const double*
     }
 }
 
+// the finalize in the tail: rows -> LDS (X [16 points][xr][DL_FG_XLD], over the work area: every wave is past it after the barrier), Gram matrices, solve.
 // cpre (or null): the constant parts tl.cst[u][column of this lane] of the rows, requested by the caller ahead of the tail (they are cold: a global round trip at the head
 // of the tail otherwise); priors_done: lp_lds / nan_lds were filled by the caller (dl_stk_priors beside the monomial rows) -- else wave 1 fills them here
 template <int RMAX>
