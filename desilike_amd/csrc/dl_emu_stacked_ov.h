@@ -54,7 +54,7 @@ __device__ __forceinline__ void dl_stk_act_rows(int act, double (&v)[NV]) {
     if (act == 1) { DL_STK_ROW(v[r] = dl_vmax0(v[r])) return; }                                // conversion.py:31 (a NaN gives 0, as v > 0 ? v : 0 does)
     // e^x with full-rate instructions only (round 6: v_rndne_f64, v_cvt_i32_f64 and v_ldexp_f64 issue at a quarter of the rate of an FMA): n = rint(x log2 e) by the
     // 1.5 x 2^52 constant (the integer sits in the low dword of the sum), Cody-Waite reduction, degree-11 polynomial, 2^n by an integer addition to the exponent field
-    // (x clamped to [-708, 709]: the result stays a normal number); then one v_rcp_f64 + two Newton steps
+    // (x clamped to [-708, 709]: the result stays a normal number); then one v_rcp_f64 + one cubic step
     double x[NV], n[NV], p[NV];
     int ni[NV];
     // silu v / (1 + e^-v) (conversion.py:29): the exponent is x = -v.  tanh 1 - 2 / (1 + e^2v) (conversion.py:33): the exponent is 2 v -- the factor two sits in the constants (log2 e doubled,
@@ -82,11 +82,12 @@ __device__ __forceinline__ void dl_stk_act_rows(int act, double (&v)[NV]) {
     DL_STK_ROW(p[r] = fma(p[r], x[r], (act == 0 ? 1.0 : 1.0)))
     DL_STK_ROW(p[r] = __hiloint2double(__double2hiint(p[r]) + (ni[r] << 20), __double2loint(p[r])))
     DL_STK_ROW(p[r] = p[r] + 1.)
+    // 1 / p: v_rcp_f64 is good to 2^-24.4; ONE cubic step y (1 + e + e^2), e = 1 - p y, takes it to 2^-53 -- what two Newton steps do with one instruction more
+    // (tools/probes/rcp_probe.hip, profiles/r06p_rcp_probe.txt)
     DL_STK_ROW(x[r] = __builtin_amdgcn_rcp(p[r]))
     DL_STK_ROW(n[r] = fma(-p[r], x[r], 1.))
-    DL_STK_ROW(x[r] = fma(n[r], x[r], x[r]))
-    DL_STK_ROW(n[r] = fma(-p[r], x[r], 1.))
-    DL_STK_ROW(x[r] = fma(n[r], x[r], x[r]))
+    DL_STK_ROW(n[r] = fma(n[r], n[r], n[r]))
+    DL_STK_ROW(x[r] = fma(x[r], n[r], x[r]))
     if (act == 0) DL_STK_ROW(v[r] = v[r] * x[r])
     else { DL_STK_ROW(x[r] = fma(x[r], -2., 1.)) DL_STK_ROW(v[r] = fma(0., v[r], x[r])) }      // (+ 0 v: the clamp drops a NaN input, this hands it on -- as dl_activation does)
 #undef DL_STK_ROW
