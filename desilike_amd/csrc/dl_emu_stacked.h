@@ -27,7 +27,7 @@ typedef double dl_stk_double4 __attribute__((ext_vector_type(4)));
 #define DL_STK_PTS 16
 #define DL_STK_ROWS 8        // rows carried per point: 1 + the solvable alpha0 alpha2 alpha4 alpha6 sn0 sn2 sn4 (full_shape.py:1226)
 #define DL_STK_TMAX 8        // output tiles of a layer (widths <= 128)
-#define DL_STK_STATIC_LDS 256   // bytes of static LDS the kernels declare beside the dynamic block (lp_lds, nan_lds, counters)
+#define DL_STK_STATIC_LDS 512   // bytes of static LDS the kernels declare beside the dynamic block (lp_lds, nan_lds, counters)
 
 static inline __host__ __device__ int dl_stk_tld(const DlObsDev& o) {          // row stride of a wave's activation buffer: widest layer, multiple of 4, + 2
     int w = 4;
@@ -422,6 +422,18 @@ __device__ __forceinline__ void dl_stk_prologue(const DlObsDev& o, const double*
         for (int j = 0; j < o.n_x; ++j) la = fma(sc[j], x[pt * DL_MAX_X + j], la);
         amp[pt * DL_STK_MAX_GROUPS + gi] = la == 0. ? 1. : exp(la);
     }
+    // the group of every monomial (-1: none), by the last threads beside the amplitudes: the rows below are then scaled by twenty independent multiplications per lane -- walking
+    // the group table inside every lane (its records one after the other, a read-multiply-write chain through LDS per monomial) took 45 of the 140 hundred cycles of this phase
+    __shared__ int group_of[DL_FG_MONO_LD];
+    if (tid >= 512 - DL_FG_MONO_LD) {
+        const int m = tid - (512 - DL_FG_MONO_LD);
+        int gm = -1;
+        for (int gi = 0; gi < o.stk.n_groups; ++gi) {
+            const double* rec = o.stk.table + (size_t)gi * DL_STK_REC;
+            if (m >= (int)rec[2] && m < (int)rec[3]) gm = gi;
+        }
+        group_of[m] = gm;
+    }
     __syncthreads();
     // ---- monomial rows: one lane per (point, row), then scaled group by group (a monomial belongs to one group; monomials of no group feed nothing) ----
     if (tid >= DL_STK_PTS * DL_STK_ROWS) beside();
@@ -432,10 +444,11 @@ __device__ __forceinline__ void dl_stk_prologue(const DlObsDev& o, const double*
             const double fsigma8 = o.eng[2].type >= 0 ? scal[pt * 4 + 2] : o.eng[2].cst;
             double* row = mono + ((size_t)pt * DL_STK_ROWS + r) * DL_FG_MONO_LD;
             dl_velocileptors_monomials(o, nullptr, sigma8, fsigma8, mono + (size_t)pt * DL_STK_ROWS * DL_FG_MONO_LD, DL_FG_MONO_LD, vpv + pt * 12, r);
-            for (int gi = 0; gi < o.stk.n_groups; ++gi) {
-                const double* rec = o.stk.table + (size_t)gi * DL_STK_REC;
-                const double a = amp[pt * DL_STK_MAX_GROUPS + gi];
-                for (int m = (int)rec[2]; m < (int)rec[3]; ++m) row[m] *= a;
+#pragma unroll
+            for (int m = 0; m < DL_FG_MONO_LD; ++m) {
+                const int gm = group_of[m];
+                const double a = amp[pt * DL_STK_MAX_GROUPS + (gm >= 0 ? gm : 0)];
+                if (gm >= 0) row[m] *= a;
             }
         }
     }
